@@ -1,0 +1,15 @@
+"""coslam_amd -- MI355X-native implementation of CoSLAM's per-frame hot path.
+
+Only what the path needs: csrc/ (hand-written HIP for gfx950 + the C-ABI of include/coslam_hip.h),
+the ctypes mirror of the reference's tracker / pose / BA interface, and the synthetic multi-camera
+sequence generator used by tests and bench.  There is no CPU fallback in this package.
+"""
+from ._lib import CoslamHipError, lib  # noqa: F401
+from .klt import (  # noqa: F401
+    KLT_SequenceTracker,
+    KLT_SequenceTrackerConfig,
+    KLT_TrackedFeature,
+    coslam_config,
+)
+
+__version__ = "0.1.0"

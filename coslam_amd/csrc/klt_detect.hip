@@ -1,0 +1,426 @@
+// klt_detect.hip -- min-eigenvalue corner detector, non-max suppression, compaction, top-K and slot
+// filling, gfx950.
+//
+// Replaces KLT_Detector::detectCorners / extractCorners (src/tracking/CGKLT/v3d_gpuklt.cpp:423-588 and
+// Shaders/klt_detector_{pass1,pass2,nonmax,discriminator,build_histpyr,traverse_histpyr}.cg) and the CPU
+// selection / slot-fill loops of KLT_SequenceTracker::{detect,redetect} (v3d_gpuklt.cpp:650-805).
+//
+// Design: the reference needs 5 full-screen passes, a log2(512)-level HistoPyramid, two synchronous
+// glReadPixels and a CPU nth_element per frame.  Here
+//   k_cornerness      one LDS-tiled kernel for the separable 7x7 structure tensor + min eigenvalue,
+//   k_post_track      per slot: status + tracked count + the "present feature" -1e30 scatter,
+//   k_nonmax_compact  both separable non-max passes out of one LDS tile, survivors appended to a
+//                     candidate list with one wave-aggregated atomic (replaces the HistoPyramid),
+//   k_rank_morton / k_select   rank sort of the (<= a few thousand) candidates: HistoPyramid order is
+//                     Morton order of the pixel, top-K is by cornerness; both are O(n^2/256) per lane,
+//   k_fill            one workgroup scans the dead slots and writes dest[] and the next feature list.
+// Nothing is read back mid-frame; the counts the reference reads with glReadPixels stay in HBM and
+// kernels that depend on them early-exit on the device value.
+#include "klt_internal.h"
+
+#pragma clang fp contract(off)
+
+
+namespace {
+
+// ------------------------------------------------------------------ cornerness
+constexpr int CTW = 64, CTH = 8, CR = 3;
+
+__global__ __launch_bounds__(256) void k_cornerness(const cs_texel* __restrict__ lvl0, int W, int H,
+                                                    float minCornerness, float lox, float loy, float hix, float hiy,
+                                                    float* __restrict__ out) {
+    __shared__ float2 g[CTH + 2 * CR][CTW + 2 * CR];
+    __shared__ float conv[3][CTH][CTW + 2 * CR];
+    const int x0 = blockIdx.x * CTW, y0 = blockIdx.y * CTH, tid = threadIdx.x;
+    for (int i = tid; i < (CTH + 2 * CR) * (CTW + 2 * CR); i += 256) {
+        int ly = i / (CTW + 2 * CR), lx = i - ly * (CTW + 2 * CR);
+        int gx = cs_clampi(x0 + lx - CR, 0, W - 1), gy = cs_clampi(y0 + ly - CR, 0, H - 1);
+        float I, Ix, Iy;
+        cs_unpack_texel(lvl0[(size_t)gy * W + gx], I, Ix, Iy);
+        g[ly][lx] = make_float2(Ix, Iy);
+    }
+    __syncthreads();
+    // klt_detector_pass1.cg: vertical taps -3..+3 accumulated in that order
+    for (int i = tid; i < CTH * (CTW + 2 * CR); i += 256) {
+        int ly = i / (CTW + 2 * CR), lx = i - ly * (CTW + 2 * CR);
+        float r0 = 0, r1 = 0, r2 = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * CR + 1; ++k) {
+            float2 v = g[ly + k][lx];
+            r0 += v.x * v.x;
+            r1 += v.x * v.y;
+            r2 += v.y * v.y;
+        }
+        conv[0][ly][lx] = r0;
+        conv[1][ly][lx] = r1;
+        conv[2][ly][lx] = r2;
+    }
+    __syncthreads();
+    // klt_detector_pass2.cg:12-33
+    const int lx = tid & (CTW - 1), x = x0 + lx;
+    for (int ly = tid / CTW; ly < CTH; ly += 256 / CTW) {
+        int y = y0 + ly;
+        if (x >= W || y >= H) continue;
+        float a = 0, b = 0, c = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * CR + 1; ++k) {
+            a += conv[0][ly][lx + k];
+            b += conv[1][ly][lx + k];
+            c += conv[2][ly][lx + k];
+        }
+        float amc = a - c;
+        float cn = 0.5f * ((a + c) - sqrtf(amc * amc + 4.0f * (b * b)));
+        cn = fmaxf(cn - minCornerness, 0.0f);
+        float stx = ((float)x + 0.5f) / (float)W, sty = ((float)y + 0.5f) / (float)H;
+        bool inside = (stx >= lox && sty >= loy) && (stx <= hix && sty <= hiy);
+        out[(size_t)y * W + x] = inside ? cn : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------ present-feature scatter
+__device__ __forceinline__ void suppress_at(float* corner, int W, int H, float s, float t) {
+    if (!(s >= 0.0f && t >= 0.0f)) return;
+    float fx = floorf(s * (float)W), fy = floorf(t * (float)H);
+    if (fx >= (float)W || fy >= (float)H) return;
+    corner[(size_t)(int)fy * W + (int)fx] = -1e30f;  // v3d_gpuklt.cpp:444-447
+}
+
+__global__ void k_suppress_list(float* corner, int W, int H, int n, const float* __restrict__ list3) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) suppress_at(corner, W, H, list3[3 * k], list3[3 * k + 1]);
+}
+
+// v3d_gpuklt.cpp:872-888 (status loop of track()) fused with :744-752 + :475-500 (present list scatter)
+__global__ void k_post_track(const float* __restrict__ feat, int N, cs_klt_feature* __restrict__ dest, int* ctr,
+                             float* corner, int W, int H, int doSuppress) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float X = feat[3 * i], Y = feat[3 * i + 1], gain = feat[3 * i + 2];
+    if (X >= 0) {
+        dest[i].status = 0;
+        dest[i].pos[0] = X;
+        dest[i].pos[1] = Y;
+        dest[i].gain = gain;
+        dest[i].fed = -1;
+        atomicAdd(&ctr[1], 1);
+        if (doSuppress) suppress_at(corner, W, H, X, Y);
+    } else {
+        dest[i].status = -1;
+        dest[i].fed = -1;
+    }
+}
+
+__global__ void k_clear_dest(cs_klt_feature* dest, int N) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) {
+        dest[i].status = -1;
+        dest[i].fed = -1;
+    }
+}
+
+// ------------------------------------------------------------------ non-max + compaction
+constexpr int NTW = 64, NTH = 16;
+
+__device__ __forceinline__ unsigned part1by1(unsigned v) {
+    v &= 0xffffu;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_nonmax_compact(const float* __restrict__ in, int W, int H, int d,
+                                                        float* __restrict__ out, CsCand* __restrict__ cand,
+                                                        int maxCand, int* ctr) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int RW = NTW + 2 * d, RH = NTH + 2 * d;
+    float* raw = smem;              // [RH][RW]
+    float* rowres = smem + RH * RW;  // [RH][NTW]
+    const int x0 = blockIdx.x * NTW, y0 = blockIdx.y * NTH, tid = threadIdx.x;
+    for (int i = tid; i < RH * RW; i += 256) {
+        int ly = i / RW, lx = i - ly * RW;
+        int gx = cs_clampi(x0 + lx - d, 0, W - 1), gy = cs_clampi(y0 + ly - d, 0, H - 1);
+        raw[i] = in[(size_t)gy * W + gx];
+    }
+    __syncthreads();
+    // klt_detector_nonmax.cg:12-26 with ds = (1/W, 0)
+    for (int i = tid; i < RH * NTW; i += 256) {
+        int ly = i / NTW, lx = i - ly * NTW;
+        const float* r = raw + ly * RW + lx + d;
+        float m = r[0];
+        for (int k = -d; k < 0; ++k) {
+            float cn = fabsf(r[k]);
+            m = (cn >= fabsf(m)) ? (-cn) : m;
+        }
+        for (int k = 1; k <= d; ++k) {
+            float cn = fabsf(r[k]);
+            m = (cn >= fabsf(m)) ? (-cn) : m;
+        }
+        rowres[i] = m;
+    }
+    __syncthreads();
+    // ... then ds = (0, 1/H), discriminator (value > 0) and append
+    const int lx = tid & (NTW - 1), x = x0 + lx;
+    for (int ly = tid / NTW; ly < NTH; ly += 256 / NTW) {
+        int y = y0 + ly;
+        if (x >= W || y >= H) continue;
+        const float* r = rowres + (ly + d) * NTW + lx;
+        float m = r[0];
+        for (int k = -d; k < 0; ++k) {
+            float cn = fabsf(r[k * NTW]);
+            m = (cn >= fabsf(m)) ? (-cn) : m;
+        }
+        for (int k = 1; k <= d; ++k) {
+            float cn = fabsf(r[k * NTW]);
+            m = (cn >= fabsf(m)) ? (-cn) : m;
+        }
+        out[(size_t)y * W + x] = m;
+        if (m > 0.0f) {
+            int slot = atomicAdd(&ctr[0], 1);
+            if (slot < maxCand) {
+                CsCand cd;
+                cd.key = part1by1((unsigned)x) | (part1by1((unsigned)y) << 1);
+                cd.x = ((float)x + 0.5f) / (float)W;  // klt_detector_traverse_histpyr.cg:85-86
+                cd.y = ((float)y + 0.5f) / (float)H;
+                cd.c = m;
+                cand[slot] = cd;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ ordering and selection
+__global__ __launch_bounds__(256) void k_rank_morton(const CsCand* __restrict__ cand, int maxCand, const int* ctr,
+                                                     int* __restrict__ rankM) {
+    __shared__ unsigned keys[256];
+    const int n = min(ctr[0], maxCand);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= n) return;
+    const unsigned ki = (i < n) ? cand[i].key : 0u;
+    int r = 0;
+    for (int base = 0; base < n; base += 256) {
+        int j = base + threadIdx.x;
+        keys[threadIdx.x] = (j < n) ? cand[j].key : 0xffffffffu;
+        __syncthreads();
+        int m = min(256, n - base);
+        for (int q = 0; q < m; ++q) r += (keys[q] < ki) ? 1 : 0;
+        __syncthreads();
+    }
+    if (i < n) rankM[i] = r;
+}
+
+// maxKeepFixed >= 0: use it; else maxKeep = N - ctr[1] (free slots after tracking)
+__global__ __launch_bounds__(256) void k_select(const CsCand* __restrict__ cand, int maxCand, int cap, int N,
+                                                int maxKeepFixed, int* ctr, const int* __restrict__ rankM,
+                                                CsCand* __restrict__ sel) {
+    __shared__ float cs[256];
+    __shared__ unsigned ks[256];
+    __shared__ int rs[256];
+    const int n = min(ctr[0], maxCand);
+    const int nK = min(n, cap);  // v3d_gpuklt.cpp:659,701,756: point list holds at most plw*plh
+    int maxKeep = (maxKeepFixed >= 0) ? maxKeepFixed : (N - ctr[1]);
+    if (maxKeep < 0) maxKeep = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr[2] = min(nK, maxKeep);
+    if (blockIdx.x * 256 >= n) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    CsCand me;
+    me.key = 0;
+    me.x = me.y = me.c = 0;
+    int myRank = 0x7fffffff;
+    if (i < n) {
+        me = cand[i];
+        myRank = rankM[i];
+    }
+    if (nK <= maxKeep) {  // everything that fits the point list is used, in HistoPyramid order
+        if (i < n && myRank < nK) sel[myRank] = me;
+        return;
+    }
+    // more corners than free slots: the most distinctive ones, cornerness descending (std::sort branch,
+    // v3d_gpuklt.cpp:704-708,763-767), ties in HistoPyramid order
+    int r = 0;
+    for (int base = 0; base < n; base += 256) {
+        int j = base + threadIdx.x;
+        bool ok = (j < n);
+        cs[threadIdx.x] = ok ? cand[j].c : 0.0f;
+        ks[threadIdx.x] = ok ? cand[j].key : 0u;
+        rs[threadIdx.x] = ok ? rankM[j] : 0x7fffffff;
+        __syncthreads();
+        int m = min(256, n - base);
+        for (int q = 0; q < m; ++q) {
+            bool in = rs[q] < nK;
+            bool before = (cs[q] > me.c) || (cs[q] == me.c && ks[q] < me.key);
+            r += (in && before) ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    if (i < n && myRank < nK && r < maxKeep) sel[r] = me;
+}
+
+
+__global__ __launch_bounds__(1024) void k_fill(CsFillArgs A) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int N = A.N;
+    const int nSel = A.ctr[2];
+    const int chunk = (N + 1023) / 1024;
+    const int lo = min(tid * chunk, N), hi = min(lo + chunk, N);
+    int nDead = 0;
+    for (int i = lo; i < hi; ++i) nDead += (A.mode == 2) ? (A.dest[i].status < 0 ? 1 : 0) : 1;
+    part[tid] = nDead;
+    __syncthreads();
+    for (int s = 1; s < 1024; s <<= 1) {  // inclusive Hillis-Steele scan
+        int v = (tid >= s) ? part[tid - s] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int r = part[tid] - nDead;  // exclusive prefix = rank of my first free slot
+    for (int i = lo; i < hi; ++i) {
+        bool dead = (A.mode == 2) ? (A.dest[i].status < 0) : true;
+        float lx, ly, lz;
+        if (dead) {
+            if (r < nSel) {
+                CsCand c = A.sel[r];
+                cs_klt_feature f;
+                f.status = 1;
+                f.pos[0] = c.x;
+                f.pos[1] = c.y;
+                // redetect reports the cornerness (:782); detect reports data[2] after the gain reset (:716-727)
+                f.gain = (A.mode == 2) ? c.c : (A.withGain ? 1.0f : c.c);
+                f.fed = -1;
+                A.dest[i] = f;
+                lx = c.x;
+                ly = c.y;
+                lz = (A.mode == 2 || A.withGain) ? 1.0f : c.c;
+            } else if (A.mode == 1 && r < nSel + A.nPresentGiven) {
+                int q = r - nSel;
+                cs_klt_feature f;
+                f.status = 1;
+                f.pos[0] = A.present3[3 * q];
+                f.pos[1] = A.present3[3 * q + 1];
+                f.gain = A.withGain ? 1.0f : 0.0f;
+                f.fed = q;
+                A.dest[i] = f;
+                lx = f.pos[0];
+                ly = f.pos[1];
+                lz = f.gain;
+            } else {
+                A.dest[i].status = -1;
+                if (A.mode != 1) A.dest[i].fed = -1;
+                lx = ly = -1.0f;
+                lz = (A.mode == 2 || A.withGain) ? 1.0f : -1.0f;
+            }
+            ++r;
+        } else {
+            lx = A.dest[i].pos[0];
+            ly = A.dest[i].pos[1];
+            lz = 1.0f;
+        }
+        A.list_a[3 * i] = lx;
+        A.list_a[3 * i + 1] = ly;
+        A.list_a[3 * i + 2] = lz;
+        if (A.list_b) {
+            A.list_b[3 * i] = lx;
+            A.list_b[3 * i + 1] = ly;
+            A.list_b[3 * i + 2] = lz;
+        }
+    }
+    if (tid == 0) {
+        int nPres = (A.mode == 2) ? A.ctr[1] : (A.mode == 1 ? min(A.nPresentGiven, max(N - nSel, 0)) : 0);
+        A.counts[0] = nSel + nPres;
+        A.counts[1] = (A.mode == 2) ? A.ctr[1] : 0;
+        A.counts[2] = A.ctr[0];
+        A.counts[3] = nSel;
+    }
+}
+
+// track() only: counts from ctr
+__global__ void k_counts_track(const int* ctr, int* counts) {
+    counts[0] = ctr[1];
+    counts[1] = ctr[1];
+    counts[2] = 0;
+    counts[3] = 0;
+}
+
+}  // namespace
+
+int cs_launch_cornerness(const cs_texel* lvl0, int W, int H, float minCornerness, float margin, float* out,
+                         hipStream_t stream) {
+    const float lox = margin / (float)W, loy = margin / (float)H;
+    const float hix = 1.0f - margin / (float)W, hiy = 1.0f - margin / (float)H;
+    dim3 grid((W + CTW - 1) / CTW, (H + CTH - 1) / CTH);
+    hipLaunchKernelGGL(k_cornerness, grid, dim3(256), 0, stream, lvl0, W, H, minCornerness, lox, loy, hix, hiy, out);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int cs_launch_suppress_list(float* corner, int W, int H, int n, const float* d_list3, hipStream_t stream) {
+    if (n <= 0) return CS_OK;
+    hipLaunchKernelGGL(k_suppress_list, dim3((n + 255) / 256), dim3(256), 0, stream, corner, W, H, n, d_list3);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int cs_launch_post_track(const float* feat, int N, cs_klt_feature* dest, int* ctr, float* corner, int W, int H,
+                         int doSuppress, hipStream_t stream) {
+    hipLaunchKernelGGL(k_post_track, dim3((N + 255) / 256), dim3(256), 0, stream, feat, N, dest, ctr, corner, W, H,
+                       doSuppress);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int cs_launch_clear_dest(cs_klt_feature* dest, int N, hipStream_t stream) {
+    hipLaunchKernelGGL(k_clear_dest, dim3((N + 255) / 256), dim3(256), 0, stream, dest, N);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+size_t cs_nonmax_lds_bytes(int d) { return sizeof(float) * ((size_t)(NTH + 2 * d) * (NTW + 2 * d) + (size_t)(NTH + 2 * d) * NTW); }
+
+int cs_launch_nonmax_compact(const float* in, int W, int H, int d, float* out, CsCand* cand, int maxCand, int* ctr,
+                             hipStream_t stream) {
+    size_t lds = cs_nonmax_lds_bytes(d);
+    if (lds > 160 * 1024) {
+        cs_set_error("minDistance %d needs %zu B of LDS (> 160 KiB)", d, lds);
+        return CS_ERR_INVALID;
+    }
+    dim3 grid((W + NTW - 1) / NTW, (H + NTH - 1) / NTH);
+    hipLaunchKernelGGL(k_nonmax_compact, grid, dim3(256), lds, stream, in, W, H, d, out, cand, maxCand, ctr);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int cs_nonmax_prepare(int d) {
+    size_t lds = cs_nonmax_lds_bytes(d);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_nonmax_compact, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) {
+            cs_set_error("hipFuncSetAttribute(maxDynamicShared=%zu) failed: %s", lds, hipGetErrorString(e));
+            return CS_ERR_HIP;
+        }
+    }
+    return CS_OK;
+}
+
+int cs_launch_select(const CsCand* cand, int maxCand, int cap, int N, int maxKeepFixed, int* ctr, int* rankM,
+                     CsCand* sel, hipStream_t stream) {
+    dim3 grid((maxCand + 255) / 256);
+    hipLaunchKernelGGL(k_rank_morton, grid, dim3(256), 0, stream, cand, maxCand, ctr, rankM);
+    hipLaunchKernelGGL(k_select, grid, dim3(256), 0, stream, cand, maxCand, cap, N, maxKeepFixed, ctr, rankM, sel);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int cs_launch_fill(const CsFillArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fill, dim3(1), dim3(1024), 0, stream, a);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int cs_launch_counts_track(const int* ctr, int* counts, hipStream_t stream) {
+    hipLaunchKernelGGL(k_counts_track, dim3(1), dim3(1), 0, stream, ctr, counts);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}

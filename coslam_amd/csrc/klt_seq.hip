@@ -1,0 +1,568 @@
+// klt_seq.hip -- C-ABI of the KLT sequence tracker (include/coslam_hip.h) and its frame schedule.
+//
+// Replaces V3D_GPU::KLT_SequenceTracker (src/tracking/CGKLT/v3d_gpuklt.h:202-294,
+// v3d_gpuklt.cpp:592-889).  The feature-buffer and pyramid "pointer swaps" of the reference
+// (_featuresBuffer0/1/2, _pyrCreator0/1) are modelled one to one, so every call sequence -- including
+// the odd ones (track without redetect, feed + advance) -- evolves the same state as the reference.
+#include <mutex>
+#include <new>
+
+#include "klt_internal.h"
+
+// ---- error string ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void cs_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int cs_version(void) { return 100; }
+const char* cs_last_error(void) { return g_err; }
+
+int cs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void cs_klt_config_default(cs_klt_config* c) {  // v3d_gpuklt.h:181-191
+    c->nIterations = 12;
+    c->nLevels = 3;
+    c->levelSkip = 2;
+    c->windowWidth = 5;
+    c->trackBorderMargin = 4.0f;
+    c->convergenceThreshold = 0.1f;
+    c->SSD_Threshold = 5000.0f;
+    c->trackWithGain = 0;
+    c->minDistance = 8;
+    c->minCornerness = 1000.0f;
+    c->detectBorderMargin = 4.0f;
+}
+
+}  // extern "C"
+
+struct cs_klt {
+    cs_klt_config cfg;
+    int device, tap_mode;
+    bool allocated;
+    int W, H, L, fw, fh, plw, plh, N;
+    float margin, convThr, ssdThr, detMargin;
+    CsPyrLayout lay;
+    hipStream_t own_stream, stream;
+    uint8_t* d_img;
+    cs_texel* d_pyr[2];
+    int p0, p1;
+    float* d_fb[3];
+    int b0, b1, b2;
+    float *d_corner_raw, *d_corner;
+    CsCand *d_cand, *d_sel;
+    int maxCand;
+    int* d_rank;
+    int* d_ctr;
+    cs_klt_feature* d_dest;
+    int* d_counts;
+    float* d_present;
+    int presentCap;
+    cs_klt_feature* h_dest;  // pinned
+    int* h_counts;           // pinned
+    float* h_feat;           // pinned
+};
+
+#define CS_REQUIRE(cond, msg)      \
+    do {                           \
+        if (!(cond)) {             \
+            cs_set_error(msg);     \
+            return CS_ERR_INVALID; \
+        }                          \
+    } while (0)
+
+static int bind_device(cs_klt* k) {
+    CS_HIP(hipSetDevice(k->device));
+    return CS_OK;
+}
+
+static float* read_buffer(cs_klt* k) {  // readFeatures / readFeaturesAndGain, v3d_gpuklt.cpp:94-97,199-203
+    return k->cfg.trackWithGain ? k->d_fb[k->b2] : k->d_fb[k->b1];
+}
+
+// ---- frame schedules (all asynchronous on k->stream) -------------------------------------------
+
+static int enqueue_tracker(cs_klt* k) {
+    const cs_klt_config& c = k->cfg;
+    const int hw = c.windowWidth / 2;
+    const cs_texel *P0 = k->d_pyr[k->p0], *P1 = k->d_pyr[k->p1];
+    if (!c.trackWithGain) {
+        // the host passes -DNITERATIONS but the shader reads N_ITERATIONS: always 5
+        // (v3d_gpuklt.cpp:108 vs klt_tracker.cg:16-18)
+        return cs_launch_track_nogain(P0, P1, k->lay, c.levelSkip, hw, 5, k->margin, k->convThr, k->ssdThr, k->N,
+                                      k->d_fb[k->b0], k->d_fb[k->b1], k->stream);
+    }
+    int rc = cs_launch_reset_beta(k->d_fb[k->b0], k->N, k->stream);  // v3d_gpuklt.cpp:223-227
+    if (rc) return rc;
+    CsGainPassArgs a;
+    memset(&a, 0, sizeof(a));
+    a.whx = (float)k->W;
+    a.why = (float)k->H;
+    a.fw = k->fw;
+    a.fh = k->fh;
+    a.N = k->N;
+    a.hw = hw;
+    a.lambda = 1.0f;  // :250
+    {
+        // st0 +- ds0.x / ds0.y are scalar broadcasts (klt_tracker_with_gain.cg:64-67)
+        const double rxy = (double)k->fh / (double)k->fw, ryx = (double)k->fw / (double)k->fh;
+        a.n1x[0] = 1;
+        a.n1x[1] = -1;
+        a.n1x[2] = (int)floor(0.5 + ryx);
+        a.n1x[3] = (int)floor(0.5 - ryx);
+        a.n1y[0] = (int)floor(0.5 + rxy);
+        a.n1y[1] = (int)floor(0.5 - rxy);
+        a.n1y[2] = 1;
+        a.n1y[3] = -1;
+    }
+    float delta = 200.0f;
+    const float tau = 1.0f;
+    int levelSkip = c.levelSkip > 0 ? c.levelSkip : (c.nLevels - 1);  // v3d_gpuklt.h:14
+    if (levelSkip <= 0) levelSkip = 1;
+    a.sqrConvThr = 1000000.0f;
+    a.ssdThr = 1000000.0f;
+    a.vr[0] = a.vr[1] = -1.0f;
+    a.vr[2] = a.vr[3] = 2.0f;
+    for (int level = k->L - 1; level >= 0; level -= levelSkip) {  // :254
+        a.lvl0 = P0 + k->lay.off[level];
+        a.lvl1 = P1 + k->lay.off[level];
+        a.Wl = k->lay.w[level];
+        a.Hl = k->lay.h[level];
+        for (int iter = 1; iter <= c.nIterations; ++iter) {  // :268
+            a.delta = delta;
+            delta *= tau;
+            if (iter == 1) {  // :271-279
+                a.sqrConvThr = 1000000.0f;
+                a.ssdThr = 1000000.0f;
+                a.vr[0] = a.vr[1] = -1.0f;
+                a.vr[2] = a.vr[3] = 2.0f;
+            } else if (iter == c.nIterations) {
+                a.sqrConvThr = k->convThr * k->convThr;
+                a.ssdThr = k->ssdThr;
+                a.vr[0] = k->margin / (float)k->W;
+                a.vr[1] = k->margin / (float)k->H;
+                a.vr[2] = 1.0f - k->margin / (float)k->W;
+                a.vr[3] = 1.0f - k->margin / (float)k->H;
+            }
+            a.feat0 = k->d_fb[k->b2];
+            a.featIn = k->d_fb[k->b0];
+            a.featOut = k->d_fb[k->b1];
+            rc = cs_launch_track_gain_pass(a, k->stream);
+            if (rc) return rc;
+            std::swap(k->b0, k->b1);  // :285
+        }
+    }
+    std::swap(k->b0, k->b2);  // :304
+    return CS_OK;
+}
+
+static int enqueue_detect_tail(cs_klt* k, int mode, int nPresentGiven, int maxKeepFixed, cs_klt_feature* d_dest,
+                               int* d_counts) {
+    int rc = cs_launch_nonmax_compact(k->d_corner_raw, k->W, k->H, k->cfg.minDistance, k->d_corner, k->d_cand,
+                                      k->maxCand, k->d_ctr, k->stream);
+    if (rc) return rc;
+    rc = cs_launch_select(k->d_cand, k->maxCand, k->plw * k->plh, k->N, maxKeepFixed, k->d_ctr, k->d_rank, k->d_sel,
+                          k->stream);
+    if (rc) return rc;
+    CsFillArgs f;
+    f.mode = mode;
+    f.N = k->N;
+    f.withGain = k->cfg.trackWithGain;
+    f.nPresentGiven = nPresentGiven;
+    f.present3 = k->d_present;
+    f.sel = k->d_sel;
+    f.ctr = k->d_ctr;
+    f.dest = d_dest;
+    // provideFeatures / provideFeaturesAndGain, v3d_gpuklt.cpp:86-92,188-197
+    f.list_a = k->d_fb[k->b1];
+    f.list_b = k->cfg.trackWithGain ? k->d_fb[k->b2] : nullptr;
+    f.counts = d_counts;
+    return cs_launch_fill(f, k->stream);
+}
+
+static int enqueue_track(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest, int* d_counts, bool forRedetect) {
+    CS_HIP(hipMemsetAsync(k->d_ctr, 0, 8 * sizeof(int), k->stream));
+    int rc = cs_launch_pyramid(d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, k->stream);  // :858
+    if (rc) return rc;
+    if (forRedetect) {
+        rc = cs_launch_cornerness(k->d_pyr[k->p1] + k->lay.off[0], k->W, k->H, k->cfg.minCornerness, k->detMargin,
+                                  k->d_corner_raw, k->stream);
+        if (rc) return rc;
+    }
+    rc = enqueue_tracker(k);
+    if (rc) return rc;
+    rc = cs_launch_post_track(read_buffer(k), k->N, d_dest, k->d_ctr, k->d_corner_raw, k->W, k->H, forRedetect ? 1 : 0,
+                              k->stream);
+    if (rc) return rc;
+    if (!forRedetect) rc = cs_launch_counts_track(k->d_ctr, d_counts, k->stream);
+    return rc;
+}
+
+static int enqueue_redetect(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest, int* d_counts) {
+    int rc = enqueue_track(k, d_img, d_dest, d_counts, true);
+    if (rc) return rc;
+    return enqueue_detect_tail(k, 2, 0, -1, d_dest, d_counts);
+}
+
+static int enqueue_detect(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest, int* d_counts, int nPresent) {
+    CS_HIP(hipMemsetAsync(k->d_ctr, 0, 8 * sizeof(int), k->stream));
+    int rc = cs_launch_pyramid(d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, k->stream);
+    if (rc) return rc;
+    rc = cs_launch_cornerness(k->d_pyr[k->p1] + k->lay.off[0], k->W, k->H, k->cfg.minCornerness, k->detMargin,
+                              k->d_corner_raw, k->stream);
+    if (rc) return rc;
+    if (nPresent > 0) {
+        rc = cs_launch_suppress_list(k->d_corner_raw, k->W, k->H, nPresent, k->d_present, k->stream);
+        if (rc) return rc;
+    }
+    rc = cs_launch_clear_dest(d_dest, k->N, k->stream);
+    if (rc) return rc;
+    int maxKeep = k->N - nPresent;
+    if (maxKeep < 0) maxKeep = 0;
+    return enqueue_detect_tail(k, nPresent > 0 ? 1 : 0, nPresent, maxKeep, d_dest, d_counts);
+}
+
+static int fetch_results(cs_klt* k, int* count, cs_klt_feature* dest) {
+    CS_HIP(hipMemcpyAsync(k->h_dest, k->d_dest, sizeof(cs_klt_feature) * k->N, hipMemcpyDeviceToHost, k->stream));
+    CS_HIP(hipMemcpyAsync(k->h_counts, k->d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, k->stream));
+    CS_HIP(hipStreamSynchronize(k->stream));
+    memcpy(dest, k->h_dest, sizeof(cs_klt_feature) * k->N);
+    *count = k->h_counts[0];
+    return CS_OK;
+}
+
+static int upload_image(cs_klt* k, const uint8_t* image) {
+    CS_HIP(hipMemcpyAsync(k->d_img, image, (size_t)k->W * k->H, hipMemcpyHostToDevice, k->stream));
+    return CS_OK;
+}
+
+extern "C" {
+
+cs_klt* cs_klt_create(const cs_klt_config* cfg, int device, int tap_mode) {
+    if (!cfg) {
+        cs_set_error("cs_klt_create: null config");
+        return nullptr;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0 || device < 0 || device >= n) {
+        cs_set_error("cs_klt_create: no usable HIP device %d (count %d, %s); there is no CPU fallback", device, n,
+                     e == hipSuccess ? "ok" : hipGetErrorString(e));
+        return nullptr;
+    }
+    cs_klt* k = new (std::nothrow) cs_klt();
+    if (!k) return nullptr;
+    memset(k, 0, sizeof(*k));
+    k->cfg = *cfg;
+    k->device = device;
+    k->tap_mode = tap_mode;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&k->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        cs_set_error("cs_klt_create: cannot create a stream on device %d", device);
+        delete k;
+        return nullptr;
+    }
+    k->stream = k->own_stream;
+    return k;
+}
+
+int cs_klt_deallocate(cs_klt* k) {
+    CS_REQUIRE(k, "null handle");
+    if (!k->allocated) return CS_OK;
+    int rc = bind_device(k);
+    if (rc) return rc;
+    hipStreamSynchronize(k->stream);
+    hipFree(k->d_img);
+    hipFree(k->d_pyr[0]);
+    hipFree(k->d_pyr[1]);
+    for (int i = 0; i < 3; ++i) hipFree(k->d_fb[i]);
+    hipFree(k->d_corner_raw);
+    hipFree(k->d_corner);
+    hipFree(k->d_cand);
+    hipFree(k->d_sel);
+    hipFree(k->d_rank);
+    hipFree(k->d_ctr);
+    hipFree(k->d_dest);
+    hipFree(k->d_counts);
+    hipFree(k->d_present);
+    hipHostFree(k->h_dest);
+    hipHostFree(k->h_counts);
+    hipHostFree(k->h_feat);
+    k->allocated = false;
+    return CS_OK;
+}
+
+void cs_klt_destroy(cs_klt* k) {
+    if (!k) return;
+    cs_klt_deallocate(k);
+    hipSetDevice(k->device);
+    hipStreamDestroy(k->own_stream);
+    delete k;
+}
+
+int cs_klt_allocate(cs_klt* k, int W, int H, int nLevels, int fw, int fh, int plw, int plh) {
+    CS_REQUIRE(k, "null handle");
+    CS_REQUIRE(!k->allocated, "cs_klt_allocate: already allocated (the reference warns on double allocate)");
+    CS_REQUIRE(W >= 16 && H >= 16 && nLevels >= 1 && nLevels <= CS_MAX_LEVELS, "cs_klt_allocate: bad image size / level count");
+    CS_REQUIRE((W >> (nLevels - 1)) >= 2 && (H >> (nLevels - 1)) >= 2, "cs_klt_allocate: too many levels for this size");
+    CS_REQUIRE(fw >= 1 && fh >= 1, "cs_klt_allocate: bad feature grid");
+    CS_REQUIRE(k->cfg.minDistance >= 0 && k->cfg.windowWidth >= 1, "cs_klt_allocate: bad minDistance/windowWidth");
+    if (plw <= 0 || plh <= 0) {  // v3d_gpuklt.h:213-215
+        plw = 2 * fw;
+        plh = 2 * fh;
+    }
+    int rc = bind_device(k);
+    if (rc) return rc;
+    k->W = W;
+    k->H = H;
+    k->L = nLevels;
+    k->fw = fw;
+    k->fh = fh;
+    k->plw = plw;
+    k->plh = plh;
+    k->N = fw * fh;
+    // v3d_gpuklt.cpp:603-619; the detector margin stays at its constructor value 10 (v3d_gpuklt.h:114)
+    k->margin = k->cfg.trackBorderMargin;
+    k->convThr = k->cfg.convergenceThreshold;
+    k->ssdThr = k->cfg.SSD_Threshold;
+    k->detMargin = 10.0f;
+    k->lay = cs_make_layout(W, H, nLevels);
+    k->p0 = 0;
+    k->p1 = 1;
+    k->b0 = 0;
+    k->b1 = 1;
+    k->b2 = 2;
+    const int d = k->cfg.minDistance;
+    k->maxCand = ((W + d) / (d + 1)) * ((H + d) / (d + 1));  // one strict maximum per (d+1)^2 block at most
+    if (k->maxCand < 256) k->maxCand = 256;
+    k->presentCap = k->N > 4096 ? k->N : 4096;
+    rc = cs_nonmax_prepare(d);
+    if (rc) return rc;
+
+    CS_HIP(hipMalloc((void**)&k->d_img, (size_t)W * H));
+    for (int i = 0; i < 2; ++i) {
+        CS_HIP(hipMalloc((void**)&k->d_pyr[i], k->lay.texels * sizeof(cs_texel)));
+        CS_HIP(hipMemsetAsync(k->d_pyr[i], 0, k->lay.texels * sizeof(cs_texel), k->stream));
+    }
+    for (int i = 0; i < 3; ++i) {
+        CS_HIP(hipMalloc((void**)&k->d_fb[i], sizeof(float) * 3 * k->N));
+    }
+    CS_HIP(hipMalloc((void**)&k->d_corner_raw, sizeof(float) * (size_t)W * H));
+    CS_HIP(hipMalloc((void**)&k->d_corner, sizeof(float) * (size_t)W * H));
+    CS_HIP(hipMemsetAsync(k->d_corner, 0, sizeof(float) * (size_t)W * H, k->stream));
+    CS_HIP(hipMalloc((void**)&k->d_cand, sizeof(CsCand) * k->maxCand));
+    CS_HIP(hipMalloc((void**)&k->d_sel, sizeof(CsCand) * k->maxCand));
+    CS_HIP(hipMalloc((void**)&k->d_rank, sizeof(int) * k->maxCand));
+    CS_HIP(hipMalloc((void**)&k->d_ctr, sizeof(int) * 8));
+    CS_HIP(hipMalloc((void**)&k->d_dest, sizeof(cs_klt_feature) * k->N));
+    CS_HIP(hipMalloc((void**)&k->d_counts, sizeof(int) * 4));
+    CS_HIP(hipMalloc((void**)&k->d_present, sizeof(float) * 3 * k->presentCap));
+    CS_HIP(hipHostMalloc((void**)&k->h_dest, sizeof(cs_klt_feature) * k->N, hipHostMallocDefault));
+    CS_HIP(hipHostMalloc((void**)&k->h_counts, sizeof(int) * 4, hipHostMallocDefault));
+    CS_HIP(hipHostMalloc((void**)&k->h_feat, sizeof(float) * 3 * k->presentCap, hipHostMallocDefault));
+    // RTT buffers start undefined in the reference; we define every slot dead
+    for (int i = 0; i < 3 * k->N; ++i) k->h_feat[i] = -1.0f;
+    for (int i = 0; i < 3; ++i) {
+        CS_HIP(hipMemcpyAsync(k->d_fb[i], k->h_feat, sizeof(float) * 3 * k->N, hipMemcpyHostToDevice, k->stream));
+    }
+    CS_HIP(hipMemsetAsync(k->d_dest, 0xff, sizeof(cs_klt_feature) * k->N, k->stream));  // status = fed = -1
+    CS_HIP(hipMemsetAsync(k->d_counts, 0, sizeof(int) * 4, k->stream));
+    CS_HIP(hipStreamSynchronize(k->stream));
+    k->allocated = true;
+    return CS_OK;
+}
+
+int cs_klt_set_border_margin(cs_klt* k, float m) {  // v3d_gpuklt.h:219-226
+    CS_REQUIRE(k, "null handle");
+    k->margin = m;
+    k->detMargin = m;
+    return CS_OK;
+}
+int cs_klt_set_convergence_threshold(cs_klt* k, float t) {
+    CS_REQUIRE(k, "null handle");
+    k->convThr = t;
+    return CS_OK;
+}
+int cs_klt_set_ssd_threshold(cs_klt* k, float t) {
+    CS_REQUIRE(k, "null handle");
+    k->ssdThr = t;
+    return CS_OK;
+}
+
+int cs_klt_set_stream(cs_klt* k, void* s) {
+    CS_REQUIRE(k, "null handle");
+    k->stream = s ? (hipStream_t)s : k->own_stream;
+    return CS_OK;
+}
+
+int cs_klt_synchronize(cs_klt* k) {
+    CS_REQUIRE(k && k->allocated, "not allocated");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    CS_HIP(hipStreamSynchronize(k->stream));
+    return CS_OK;
+}
+
+int cs_klt_advance(cs_klt* k) {  // v3d_gpuklt.h:252-259
+    CS_REQUIRE(k && k->allocated, "not allocated");
+    std::swap(k->b0, k->b1);
+    std::swap(k->p0, k->p1);
+    return CS_OK;
+}
+
+// ---- device-resident entry points ----------------------------------------------------------------
+int cs_klt_detect_dev(cs_klt* k, const void* d_image, void* d_dest, void* d_counts) {
+    CS_REQUIRE(k && k->allocated && d_image && d_dest && d_counts, "cs_klt_detect_dev: bad arguments");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    return enqueue_detect(k, (const uint8_t*)d_image, (cs_klt_feature*)d_dest, (int*)d_counts, 0);
+}
+int cs_klt_redetect_dev(cs_klt* k, const void* d_image, void* d_dest, void* d_counts) {
+    CS_REQUIRE(k && k->allocated && d_image && d_dest && d_counts, "cs_klt_redetect_dev: bad arguments");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    return enqueue_redetect(k, (const uint8_t*)d_image, (cs_klt_feature*)d_dest, (int*)d_counts);
+}
+int cs_klt_track_dev(cs_klt* k, const void* d_image, void* d_dest, void* d_counts) {
+    CS_REQUIRE(k && k->allocated && d_image && d_dest && d_counts, "cs_klt_track_dev: bad arguments");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    return enqueue_track(k, (const uint8_t*)d_image, (cs_klt_feature*)d_dest, (int*)d_counts, false);
+}
+
+// ---- reference-shaped host entry points ---------------------------------------------------------
+int cs_klt_detect(cs_klt* k, const uint8_t* image, int* nDetected, cs_klt_feature* dest) {
+    CS_REQUIRE(k && k->allocated && image && nDetected && dest, "cs_klt_detect: bad arguments");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    if ((rc = upload_image(k, image))) return rc;
+    if ((rc = enqueue_detect(k, k->d_img, k->d_dest, k->d_counts, 0))) return rc;
+    return fetch_results(k, nDetected, dest);
+}
+
+int cs_klt_detect_present(cs_klt* k, const uint8_t* image, int* nDetected, cs_klt_feature* dest, int nPresent,
+                          const float* present) {
+    CS_REQUIRE(k && k->allocated && image && nDetected && dest, "cs_klt_detect_present: bad arguments");
+    CS_REQUIRE(nPresent >= 0 && nPresent <= k->presentCap && (nPresent == 0 || present), "cs_klt_detect_present: bad present list");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    if ((rc = upload_image(k, image))) return rc;
+    if (nPresent > 0) {
+        memcpy(k->h_feat, present, sizeof(float) * 3 * nPresent);
+        CS_HIP(hipMemcpyAsync(k->d_present, k->h_feat, sizeof(float) * 3 * nPresent, hipMemcpyHostToDevice, k->stream));
+    }
+    if ((rc = enqueue_detect(k, k->d_img, k->d_dest, k->d_counts, nPresent))) return rc;
+    return fetch_results(k, nDetected, dest);
+}
+
+int cs_klt_redetect(cs_klt* k, const uint8_t* image, int* nNew, cs_klt_feature* dest) {
+    CS_REQUIRE(k && k->allocated && image && nNew && dest, "cs_klt_redetect: bad arguments");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    if ((rc = upload_image(k, image))) return rc;
+    if ((rc = enqueue_redetect(k, k->d_img, k->d_dest, k->d_counts))) return rc;
+    return fetch_results(k, nNew, dest);
+}
+
+int cs_klt_track(cs_klt* k, const uint8_t* image, int* nPresent, cs_klt_feature* dest) {
+    CS_REQUIRE(k && k->allocated && image && nPresent && dest, "cs_klt_track: bad arguments");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    if ((rc = upload_image(k, image))) return rc;
+    if ((rc = enqueue_track(k, k->d_img, k->d_dest, k->d_counts, false))) return rc;
+    return fetch_results(k, nPresent, dest);
+}
+
+int cs_klt_feed(cs_klt* k, int npts, const float* featPts, int* trackIds, int* nFed) {  // v3d_gpuklt.cpp:808-855
+    CS_REQUIRE(k && k->allocated && nFed && npts >= 0 && (npts == 0 || (featPts && trackIds)), "cs_klt_feed: bad arguments");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    float* c = k->h_feat;
+    CS_HIP(hipMemcpyAsync(c, read_buffer(k), sizeof(float) * 3 * k->N, hipMemcpyDeviceToHost, k->stream));
+    CS_HIP(hipStreamSynchronize(k->stream));
+    const double radius2 = 1e-4;
+    for (int q = 0; q < npts; ++q) {
+        for (int i = 0; i < k->N; ++i) {
+            if (c[3 * i] < 0) continue;
+            // stride-2 read of the stride-3 list: reproduces v3d_gpuklt.cpp:826-827 as shipped
+            double dx = (double)(featPts[2 * q] - c[3 * i]);
+            double dy = (double)(featPts[2 * q + 1] - c[3 * i + 1]);
+            if (dx * dx + dy * dy < radius2) c[3 * i] = -1.0f;
+        }
+    }
+    int q = 0;
+    for (int i = 0; i < k->N && q < npts; ++i) {
+        if (c[3 * i] < 0) {
+            c[3 * i] = featPts[3 * q];
+            c[3 * i + 1] = featPts[3 * q + 1];
+            c[3 * i + 2] = 1.0f;
+            trackIds[q] = i;
+            ++q;
+        }
+    }
+    *nFed = q;
+    CS_HIP(hipMemcpyAsync(k->d_fb[k->b1], c, sizeof(float) * 3 * k->N, hipMemcpyHostToDevice, k->stream));
+    if (k->cfg.trackWithGain) {
+        CS_HIP(hipMemcpyAsync(k->d_fb[k->b2], c, sizeof(float) * 3 * k->N, hipMemcpyHostToDevice, k->stream));
+    }
+    CS_HIP(hipStreamSynchronize(k->stream));
+    return CS_OK;
+}
+
+// ---- introspection ------------------------------------------------------------------------------
+size_t cs_klt_pyramid_texels(const cs_klt* k) { return (k && k->allocated) ? k->lay.texels : 0; }
+
+int cs_klt_pyramid_level_offset(const cs_klt* k, int level, int64_t* off, int* w, int* h) {
+    CS_REQUIRE(k && k->allocated && level >= 0 && level < k->L, "bad level");
+    if (off) *off = k->lay.off[level];
+    if (w) *w = k->lay.w[level];
+    if (h) *h = k->lay.h[level];
+    return CS_OK;
+}
+
+int cs_klt_read_pyramid(cs_klt* k, int which, uint16_t* out) {
+    CS_REQUIRE(k && k->allocated && out && (which == 0 || which == 1), "cs_klt_read_pyramid: bad arguments");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    CS_HIP(hipStreamSynchronize(k->stream));
+    CS_HIP(hipMemcpy(out, k->d_pyr[which ? k->p1 : k->p0], k->lay.texels * sizeof(cs_texel), hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
+int cs_klt_read_cornerness(cs_klt* k, float* out) {
+    CS_REQUIRE(k && k->allocated && out, "cs_klt_read_cornerness: bad arguments");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    CS_HIP(hipStreamSynchronize(k->stream));
+    CS_HIP(hipMemcpy(out, k->d_corner, sizeof(float) * (size_t)k->W * k->H, hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
+int cs_klt_read_features(cs_klt* k, float* out) {
+    CS_REQUIRE(k && k->allocated && out, "cs_klt_read_features: bad arguments");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    CS_HIP(hipStreamSynchronize(k->stream));
+    CS_HIP(hipMemcpy(out, read_buffer(k), sizeof(float) * 3 * k->N, hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
+int cs_klt_build_pyramid(cs_klt* k, const uint8_t* image) {
+    CS_REQUIRE(k && k->allocated && image, "cs_klt_build_pyramid: bad arguments");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    if ((rc = upload_image(k, image))) return rc;
+    if ((rc = cs_launch_pyramid(k->d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, k->stream))) return rc;
+    CS_HIP(hipStreamSynchronize(k->stream));
+    return CS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,208 @@
+"""Host-side mirror of the reference's tracker interface over the C-ABI (include/coslam_hip.h).
+
+Names, argument meaning and error behaviour follow V3D_GPU::KLT_SequenceTracker
+(reference src/tracking/CGKLT/v3d_gpuklt.h:166-263).  This is plumbing for tests / bench; the C++
+drop-in header is include/v3d_gpuklt_hip.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import CoslamHipError, check, lib
+
+# == KLT_TrackedFeature, v3d_gpuklt.h:166-176
+KLT_TrackedFeature = np.dtype([("status", "<i4"), ("pos", "<f4", (2,)), ("gain", "<f4"), ("fed", "<i4")])
+assert KLT_TrackedFeature.itemsize == 20
+
+
+class KLT_SequenceTrackerConfig(C.Structure):
+    """== KLT_SequenceTrackerConfig, v3d_gpuklt.h:180-199 (defaults identical)."""
+
+    _fields_ = [
+        ("nIterations", C.c_int),
+        ("nLevels", C.c_int),
+        ("levelSkip", C.c_int),
+        ("windowWidth", C.c_int),
+        ("trackBorderMargin", C.c_float),
+        ("convergenceThreshold", C.c_float),
+        ("SSD_Threshold", C.c_float),
+        ("trackWithGain", C.c_int),
+        ("minDistance", C.c_int),
+        ("minCornerness", C.c_float),
+        ("detectBorderMargin", C.c_float),
+    ]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.nIterations = 12
+        self.nLevels = 3
+        self.levelSkip = 2
+        self.windowWidth = 5
+        self.trackBorderMargin = 4.0
+        self.convergenceThreshold = 0.1
+        self.SSD_Threshold = 5000.0
+        self.trackWithGain = 0
+        self.minDistance = 8
+        self.minCornerness = 1000.0
+        self.detectBorderMargin = 4.0
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError(k)
+            setattr(self, k, v)
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def coslam_config(**kw):
+    """The parameter set CoSLAM itself runs with (src/app/SL_SingleSLAM.cpp:291-298,
+    src/app/SL_GlobParam.cpp:28-34, src/gui/MyApp.cpp:210-211)."""
+    base = dict(minDistance=8, minCornerness=3000.0, nLevels=6, windowWidth=6, convergenceThreshold=1.0,
+                SSD_Threshold=20000.0, trackWithGain=1)
+    base.update(kw)
+    return KLT_SequenceTrackerConfig(**base)
+
+
+def _u8(img, W, H):
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    if a.size != W * H:
+        raise ValueError(f"image has {a.size} bytes, expected {W}x{H}")
+    return a
+
+
+class KLT_SequenceTracker:
+    """== V3D_GPU::KLT_SequenceTracker (v3d_gpuklt.h:202-294) on one MI355X."""
+
+    def __init__(self, config, device=0, tap_mode=0):
+        self._L = lib()
+        self._L.cs_klt_create.restype = C.c_void_p
+        self._L.cs_klt_create.argtypes = [C.POINTER(KLT_SequenceTrackerConfig), C.c_int, C.c_int]
+        self.config = config
+        self._h = self._L.cs_klt_create(C.byref(config), int(device), int(tap_mode))
+        if not self._h:
+            raise CoslamHipError("cs_klt_create: " + self._L.cs_last_error().decode())
+        self._h = C.c_void_p(self._h)
+        self.N = 0
+
+    # -- lifetime
+    def allocate(self, width, height, nLevels, featuresWidth, featuresHeight, pointListWidth=0, pointListHeight=0):
+        check(self._L.cs_klt_allocate(self._h, width, height, nLevels, featuresWidth, featuresHeight,
+                                      pointListWidth, pointListHeight), "cs_klt_allocate")
+        self.W, self.H, self.L = width, height, nLevels
+        self.fw, self.fh = featuresWidth, featuresHeight
+        self.N = featuresWidth * featuresHeight
+
+    def deallocate(self):
+        check(self._L.cs_klt_deallocate(self._h), "cs_klt_deallocate")
+
+    def close(self):
+        if self._h:
+            self._L.cs_klt_destroy.argtypes = [C.c_void_p]
+            self._L.cs_klt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- setters, v3d_gpuklt.h:219-240
+    def setBorderMargin(self, m):
+        check(self._L.cs_klt_set_border_margin(self._h, C.c_float(m)))
+
+    def setConvergenceThreshold(self, t):
+        check(self._L.cs_klt_set_convergence_threshold(self._h, C.c_float(t)))
+
+    def setSSD_Threshold(self, t):
+        check(self._L.cs_klt_set_ssd_threshold(self._h, C.c_float(t)))
+
+    # -- reference-shaped host calls: return (count, dest[N])
+    def _dest(self):
+        return np.zeros(self.N, dtype=KLT_TrackedFeature)
+
+    def detect(self, image, present=None):
+        img = _u8(image, self.W, self.H)
+        dest, n = self._dest(), C.c_int(0)
+        if present is None:
+            check(self._L.cs_klt_detect(self._h, img.ctypes.data_as(C.c_void_p), C.byref(n),
+                                        dest.ctypes.data_as(C.c_void_p)), "cs_klt_detect")
+        else:
+            p = np.ascontiguousarray(present, dtype=np.float32).reshape(-1, 3)
+            check(self._L.cs_klt_detect_present(self._h, img.ctypes.data_as(C.c_void_p), C.byref(n),
+                                                dest.ctypes.data_as(C.c_void_p), p.shape[0],
+                                                p.ctypes.data_as(C.c_void_p)), "cs_klt_detect_present")
+        return n.value, dest
+
+    def redetect(self, image):
+        img = _u8(image, self.W, self.H)
+        dest, n = self._dest(), C.c_int(0)
+        check(self._L.cs_klt_redetect(self._h, img.ctypes.data_as(C.c_void_p), C.byref(n),
+                                      dest.ctypes.data_as(C.c_void_p)), "cs_klt_redetect")
+        return n.value, dest
+
+    def track(self, image):
+        img = _u8(image, self.W, self.H)
+        dest, n = self._dest(), C.c_int(0)
+        check(self._L.cs_klt_track(self._h, img.ctypes.data_as(C.c_void_p), C.byref(n),
+                                   dest.ctypes.data_as(C.c_void_p)), "cs_klt_track")
+        return n.value, dest
+
+    def feedExternFeaturePoints(self, featPts):
+        p = np.ascontiguousarray(featPts, dtype=np.float32).reshape(-1, 3)
+        ids = np.full(max(p.shape[0], 1), -1, dtype=np.int32)
+        n = C.c_int(0)
+        check(self._L.cs_klt_feed(self._h, p.shape[0], p.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
+                                  C.byref(n)), "cs_klt_feed")
+        return n.value, ids[: n.value].copy()
+
+    def advanceFrame(self):
+        check(self._L.cs_klt_advance(self._h), "cs_klt_advance")
+
+    # -- device-resident calls (pointers are ints: torch tensor .data_ptr())
+    def set_stream(self, stream_ptr):
+        check(self._L.cs_klt_set_stream(self._h, C.c_void_p(stream_ptr)), "cs_klt_set_stream")
+
+    def detect_dev(self, d_image, d_dest, d_counts):
+        check(self._L.cs_klt_detect_dev(self._h, C.c_void_p(d_image), C.c_void_p(d_dest), C.c_void_p(d_counts)),
+              "cs_klt_detect_dev")
+
+    def redetect_dev(self, d_image, d_dest, d_counts):
+        check(self._L.cs_klt_redetect_dev(self._h, C.c_void_p(d_image), C.c_void_p(d_dest), C.c_void_p(d_counts)),
+              "cs_klt_redetect_dev")
+
+    def track_dev(self, d_image, d_dest, d_counts):
+        check(self._L.cs_klt_track_dev(self._h, C.c_void_p(d_image), C.c_void_p(d_dest), C.c_void_p(d_counts)),
+              "cs_klt_track_dev")
+
+    def synchronize(self):
+        check(self._L.cs_klt_synchronize(self._h), "cs_klt_synchronize")
+
+    # -- introspection for parity tests
+    def pyramid_texels(self):
+        self._L.cs_klt_pyramid_texels.restype = C.c_size_t
+        return int(self._L.cs_klt_pyramid_texels(self._h))
+
+    def level_view(self, pyr, level):
+        off, w, h = C.c_int64(0), C.c_int(0), C.c_int(0)
+        check(self._L.cs_klt_pyramid_level_offset(self._h, level, C.byref(off), C.byref(w), C.byref(h)))
+        return pyr.reshape(-1, 4)[off.value: off.value + w.value * h.value].reshape(h.value, w.value, 4)
+
+    def read_pyramid(self, which=1):
+        out = np.zeros(self.pyramid_texels() * 4, dtype=np.uint16)
+        check(self._L.cs_klt_read_pyramid(self._h, which, out.ctypes.data_as(C.c_void_p)), "cs_klt_read_pyramid")
+        return out
+
+    def read_cornerness(self):
+        out = np.zeros((self.H, self.W), dtype=np.float32)
+        check(self._L.cs_klt_read_cornerness(self._h, out.ctypes.data_as(C.c_void_p)), "cs_klt_read_cornerness")
+        return out
+
+    def read_features(self):
+        out = np.zeros((self.N, 3), dtype=np.float32)
+        check(self._L.cs_klt_read_features(self._h, out.ctypes.data_as(C.c_void_p)), "cs_klt_read_features")
+        return out
+
+    def build_pyramid(self, image):
+        img = _u8(image, self.W, self.H)
+        check(self._L.cs_klt_build_pyramid(self._h, img.ctypes.data_as(C.c_void_p)), "cs_klt_build_pyramid")

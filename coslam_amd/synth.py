@@ -1,0 +1,173 @@
+"""Deterministic synthetic multi-camera sequence.
+
+The reference ships no data, fixtures or tests; every parity test and the bench run on this generator.
+World: P static points uniform in the box [-5,5]x[-3,3]x[6,14], drawn as Gaussian blobs over a faint
+band-limited background; C cameras on a 1 m-radius arc looking at the box centre, each advancing
+1.5 cm/frame with 0.1 deg/frame yaw.  K = [[0.82W,0,W/2],[0,0.82W,H/2],[0,0,1]], no distortion.
+Image coordinates put pixel centres at half-integers (feature pos * W, src/tracking/GPUKLT.cpp:43-44).
+Ground-truth poses, points and projections are available next to the images.
+"""
+import math
+
+import numpy as np
+
+
+def _rot_y(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype=np.float64)
+
+
+def _rot_x(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]], dtype=np.float64)
+
+
+def look_at(cam_pos, target):
+    """World->camera rotation with +z towards target, +y down (image convention)."""
+    z = target - cam_pos
+    z = z / np.linalg.norm(z)
+    up = np.array([0.0, -1.0, 0.0])
+    x = np.cross(-up, z)  # right
+    x = x / np.linalg.norm(x)
+    y = np.cross(z, x)
+    return np.stack([x, y, z], axis=0)
+
+
+class Scene:
+    def __init__(self, n_cams=1, W=640, H=480, n_points=3000, seed=0xC051A, sigma=1.2, bg_amp=5.0):
+        self.C, self.W, self.H, self.P = n_cams, W, H, n_points
+        self.rng = np.random.Generator(np.random.MT19937(seed))
+        rng = self.rng
+        self.points = np.stack(
+            [rng.uniform(-5, 5, n_points), rng.uniform(-3, 3, n_points), rng.uniform(6, 14, n_points)], axis=1
+        )
+        self.amp = rng.uniform(60, 160, n_points) * rng.choice([-1.0, 1.0], n_points)
+        self.sigma = sigma
+        f = 0.82 * W
+        self.K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1.0]], dtype=np.float64)
+        self.target = np.array([0.0, 0.0, 10.0])
+        # faint static background (band-limited noise): below any sensible minCornerness
+        bg = rng.standard_normal((H, W))
+        k = np.array([1, 4, 6, 4, 1], dtype=np.float64) / 16.0
+        for _ in range(3):
+            bg = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 1, bg)
+            bg = np.apply_along_axis(lambda r: np.convolve(r, k, mode="same"), 0, bg)
+        bg = bg / (np.abs(bg).max() + 1e-12)
+        self.background = 128.0 + bg_amp * bg
+
+    # ---- geometry ----
+    def pose(self, cam, frame):
+        """(R, t) with x_cam = R x_world + t."""
+        a0 = (cam - (self.C - 1) / 2.0) * math.radians(12.0)  # cameras spread on the arc
+        yaw = math.radians(0.1) * frame
+        pos = np.array([math.sin(a0) * 1.0 + 0.015 * frame, 0.05 * math.sin(0.7 * cam), -math.cos(a0) * 1.0 + 1.0])
+        R = _rot_y(yaw).T @ look_at(pos, self.target)
+        t = -R @ pos
+        return R, t
+
+    def project(self, cam, frame, points=None):
+        R, t = self.pose(cam, frame)
+        X = (self.points if points is None else points) @ R.T + t
+        z = X[:, 2]
+        uv = (X @ self.K.T)[:, :2] / z[:, None]
+        vis = (z > 0.1) & (uv[:, 0] >= 0) & (uv[:, 0] < self.W) & (uv[:, 1] >= 0) & (uv[:, 1] < self.H)
+        return uv, vis
+
+    # ---- rendering ----
+    def render(self, cam, frame):
+        uv, vis = self.project(cam, frame)
+        img = self.background.copy()
+        r = int(math.ceil(4 * self.sigma))
+        idx = np.nonzero(vis)[0]
+        u, v, a = uv[idx, 0], uv[idx, 1], self.amp[idx]
+        # pixel (i,j) has its centre at (i+0.5, j+0.5)
+        ci = np.floor(u).astype(np.int64)
+        cj = np.floor(v).astype(np.int64)
+        inv2s2 = 1.0 / (2.0 * self.sigma * self.sigma)
+        for dj in range(-r, r + 1):
+            jj = cj + dj
+            okj = (jj >= 0) & (jj < self.H)
+            dy2 = (jj + 0.5 - v) ** 2
+            for di in range(-r, r + 1):
+                ii = ci + di
+                ok = okj & (ii >= 0) & (ii < self.W)
+                w = a * np.exp(-((ii + 0.5 - u) ** 2 + dy2) * inv2s2)
+                np.add.at(img, (jj[ok], ii[ok]), w[ok])
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def shift_image(img, dx, dy):
+    """Sub-pixel shift by bilinear resampling (known-answer flow tests): out(x,y) = img(x-dx, y-dy)."""
+    H, W = img.shape
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    sx, sy = xs - dx, ys - dy
+    x0 = np.clip(np.floor(sx).astype(int), 0, W - 1)
+    y0 = np.clip(np.floor(sy).astype(int), 0, H - 1)
+    x1 = np.clip(x0 + 1, 0, W - 1)
+    y1 = np.clip(y0 + 1, 0, H - 1)
+    fx = np.clip(sx - np.floor(sx), 0, 1)
+    fy = np.clip(sy - np.floor(sy), 0, 1)
+    f = img.astype(np.float64)
+    out = (f[y0, x0] * (1 - fx) + f[y0, x1] * fx) * (1 - fy) + (f[y1, x0] * (1 - fx) + f[y1, x1] * fx) * fy
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def blob_image(W, H, centers, sigma=2.0, amp=120.0, base=100.0):
+    """Isolated Gaussian blobs at continuous positions (pixel centres at half-integers)."""
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    img = np.full((H, W), base)
+    for (u, v) in centers:
+        img += amp * np.exp(-(((xs + 0.5 - u) ** 2) + ((ys + 0.5 - v) ** 2)) / (2 * sigma * sigma))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+# ---- bundle-adjustment problem generator (cfg1: 10 key frames x 500 points) ----
+def rodrigues(w):
+    th = np.linalg.norm(w)
+    if th == 0:
+        return np.eye(3)
+    k = w / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + math.sin(th) * Kx + (1 - math.cos(th)) * (Kx @ Kx)
+
+
+def make_ba_problem(n_cams=10, n_pts=500, W=640, H=480, noise=0.5, rot_pert=0.01, trans_pert=0.03, pt_pert=0.05,
+                    outlier_frac=0.05, outlier_mag=20.0, seed=0xC051A + 1, visibility=1.0):
+    """Synthetic local-BA problem in the flat layout of cs_ba_robust.
+    Returns dict with ground truth and perturbed initial values."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    f = 0.82 * W
+    K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1.0]])
+    pts = np.stack([rng.uniform(-5, 5, n_pts), rng.uniform(-3, 3, n_pts), rng.uniform(6, 14, n_pts)], axis=1)
+    target = np.array([0.0, 0.0, 10.0])
+    Rs, ts = [], []
+    for c in range(n_cams):
+        a = (c - (n_cams - 1) / 2.0) * math.radians(4.0)
+        pos = np.array([math.sin(a) * 2.0, 0.1 * math.sin(1.3 * c), -math.cos(a) * 2.0 + 2.0])
+        R = look_at(pos, target)
+        Rs.append(R)
+        ts.append(-R @ pos)
+    Rs, ts = np.array(Rs), np.array(ts)
+    obs_cam, obs_pt, obs_xy = [], [], []
+    for i in range(n_pts):
+        for c in range(n_cams):
+            if visibility < 1.0 and rng.uniform() > visibility:
+                continue
+            X = Rs[c] @ pts[i] + ts[c]
+            uv = (K @ X)[:2] / X[2]
+            obs_cam.append(c)
+            obs_pt.append(i)
+            obs_xy.append(uv)
+    obs_cam = np.array(obs_cam, dtype=np.int32)
+    obs_pt = np.array(obs_pt, dtype=np.int32)
+    obs_xy = np.array(obs_xy, dtype=np.float64)
+    n_obs = len(obs_cam)
+    obs_xy_noisy = obs_xy + noise * rng.standard_normal(obs_xy.shape)
+    is_out = rng.uniform(size=n_obs) < outlier_frac
+    sign = rng.choice([-1.0, 1.0], size=(n_obs, 2))
+    obs_xy_noisy[is_out] += outlier_mag * sign[is_out]
+    Rs0 = np.array([Rs[c] @ rodrigues(rot_pert * rng.standard_normal(3)) for c in range(n_cams)])
+    ts0 = ts + trans_pert * rng.standard_normal(ts.shape)
+    pts0 = pts + pt_pert * rng.standard_normal(pts.shape)
+    return dict(K=K, Ks=np.repeat(K[None], n_cams, 0), Rs_gt=Rs, ts_gt=ts, pts_gt=pts, Rs0=Rs0, ts0=ts0, pts0=pts0,
+                obs_cam=obs_cam, obs_pt=obs_pt, obs_xy=obs_xy_noisy, obs_xy_clean=obs_xy, is_outlier=is_out)

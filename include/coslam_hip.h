@@ -1,0 +1,125 @@
+/*
+ * coslam_hip.h -- C-ABI of libcoslam_hip.so: the MI355X (gfx950) implementation of CoSLAM's
+ * per-frame hot path (pyramidal KLT tracker, intra-camera pose, robust multi-camera BA).
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * danping/CoSLAM root).  Plain C types only: pointers, sizes, ints, floats.  Functions return
+ * CS_OK (0) or a negative CS_ERR_* code; cs_last_error() gives the message for the calling thread.
+ *
+ * Threading: one cs_klt handle is bound to one device and one HIP stream and must be driven by a
+ * single caller thread at a time -- the same rule the reference has for its GL context
+ * (src/gui/CoSLAMThread.cpp:48-54).  Different handles are independent.
+ *
+ * Host-pointer entry points mirror the reference exactly (caller-owned host image and dest[]).
+ * The *_dev entry points take device pointers (image already in HBM, results left in HBM) and only
+ * enqueue work on the handle's stream; they are what a multi-camera / multi-GPU driver uses.
+ */
+#ifndef COSLAM_HIP_H
+#define COSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CS_OK 0
+#define CS_ERR_INVALID (-1)   /* bad argument / wrong state */
+#define CS_ERR_NO_DEVICE (-2) /* no usable HIP device: there is NO CPU fallback */
+#define CS_ERR_HIP (-3)       /* a HIP runtime call failed */
+#define CS_ERR_ALLOC (-4)
+#define CS_ERR_NUMERIC (-5) /* solver failure (LM diverged, Cholesky broke down) */
+
+int cs_version(void);
+const char* cs_last_error(void);
+int cs_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * KLT sequence tracker
+ * ------------------------------------------------------------------------------------------ */
+
+/* == V3D_GPU::KLT_TrackedFeature, src/tracking/CGKLT/v3d_gpuklt.h:166-176 (same layout, 20 bytes) */
+typedef struct cs_klt_feature {
+    int status; /* 0 tracked from previous frame, 1 newly created, -1 invalidated */
+    float pos[2]; /* normalized [0,1] image coordinates, pixel centres at (i+0.5)/W */
+    float gain;
+    int fed; /* >=0: index of the externally fed point */
+} cs_klt_feature;
+
+/* == V3D_GPU::KLT_SequenceTrackerConfig, v3d_gpuklt.h:180-199 (same field order; bool -> int) */
+typedef struct cs_klt_config {
+    int nIterations, nLevels, levelSkip, windowWidth;
+    float trackBorderMargin, convergenceThreshold, SSD_Threshold;
+    int trackWithGain;
+    int minDistance;
+    float minCornerness, detectBorderMargin;
+} cs_klt_config;
+
+/* fills the defaults of v3d_gpuklt.h:181-191 */
+void cs_klt_config_default(cs_klt_config* cfg);
+
+typedef struct cs_klt cs_klt;
+
+/* KLT_SequenceTracker::KLT_SequenceTracker(config), v3d_gpuklt.h:203-208.
+ * device: HIP device ordinal.  tap_mode: 0 = GL-spec floor for the on-boundary decimation taps
+ * (v3d_gpupyramid.cpp:407-418), 1 = geometrically centred taps (DESIGN.md "pyramid taps"). */
+cs_klt* cs_klt_create(const cs_klt_config* cfg, int device, int tap_mode);
+void cs_klt_destroy(cs_klt* k);
+
+/* KLT_SequenceTracker::allocate(w,h,nLevels,fw,fh,plw,plh), v3d_gpuklt.h:213-216, v3d_gpuklt.cpp:592-624.
+ * Pass plw = plh = 0 for the 5-argument overload (2*fw, 2*fh). */
+int cs_klt_allocate(cs_klt* k, int width, int height, int nLevels, int featuresWidth, int featuresHeight,
+                    int pointListWidth, int pointListHeight);
+/* KLT_SequenceTracker::deallocate(), v3d_gpuklt.cpp:626-647 */
+int cs_klt_deallocate(cs_klt* k);
+
+/* v3d_gpuklt.h:219-240 */
+int cs_klt_set_border_margin(cs_klt* k, float margin);
+int cs_klt_set_convergence_threshold(cs_klt* k, float thr);
+int cs_klt_set_ssd_threshold(cs_klt* k, float thr);
+
+/* KLT_SequenceTracker::detect(image,nDetected,dest), v3d_gpuklt.cpp:692-735.  image: W*H bytes host. dest: fw*fh. */
+int cs_klt_detect(cs_klt* k, const uint8_t* image, int* nDetectedFeatures, cs_klt_feature* dest);
+/* KLT_SequenceTracker::detect(image,nDetected,dest,nPresent,present), v3d_gpuklt.cpp:650-691. present: nPresent*3 floats */
+int cs_klt_detect_present(cs_klt* k, const uint8_t* image, int* nDetectedFeatures, cs_klt_feature* dest, int nPresent,
+                          const float* present);
+/* KLT_SequenceTracker::redetect(image,nNew,dest), v3d_gpuklt.cpp:737-805 */
+int cs_klt_redetect(cs_klt* k, const uint8_t* image, int* nNewFeatures, cs_klt_feature* dest);
+/* KLT_SequenceTracker::track(image,nPresent,dest), v3d_gpuklt.cpp:857-889 */
+int cs_klt_track(cs_klt* k, const uint8_t* image, int* nPresentFeatures, cs_klt_feature* dest);
+/* KLT_SequenceTracker::feedExternFeaturePoints(npts,featPts,trackIds,nFed), v3d_gpuklt.cpp:808-855.
+ * featPts: npts*3 floats (stride 3 as GPUKLT.cpp:165-171 passes it); trackIds: npts ints. */
+int cs_klt_feed(cs_klt* k, int npts, const float* featPts, int* trackIds, int* nFed);
+/* KLT_SequenceTracker::advanceFrame(), v3d_gpuklt.h:252-259 */
+int cs_klt_advance(cs_klt* k);
+
+/* ---- device-resident variants: enqueue on the handle's stream, no host synchronisation ----
+ * d_image: W*H bytes in HBM.  d_dest: fw*fh cs_klt_feature in HBM (caller-owned).
+ * d_counts: 4 ints in HBM: [0] = the count the host variant returns, [1] = tracked (status 0),
+ * [2] = detector survivors before selection, [3] = reserved. */
+int cs_klt_set_stream(cs_klt* k, void* hip_stream); /* NULL = the handle's own stream */
+int cs_klt_detect_dev(cs_klt* k, const void* d_image, void* d_dest, void* d_counts);
+int cs_klt_redetect_dev(cs_klt* k, const void* d_image, void* d_dest, void* d_counts);
+int cs_klt_track_dev(cs_klt* k, const void* d_image, void* d_dest, void* d_counts);
+int cs_klt_synchronize(cs_klt* k);
+
+/* ---- introspection used by the parity tests (host copies; synchronise the stream) ----
+ * which: 0 = _pyrCreator0 (previous frame), 1 = _pyrCreator1 (frame most recently built). */
+size_t cs_klt_pyramid_texels(const cs_klt* k); /* texels of 4 halfs, all levels */
+int cs_klt_pyramid_level_offset(const cs_klt* k, int level, int64_t* off_texels, int* w, int* h);
+int cs_klt_read_pyramid(cs_klt* k, int which, uint16_t* host_out);
+int cs_klt_read_cornerness(cs_klt* k, float* host_out); /* W*H floats after non-max suppression */
+int cs_klt_read_features(cs_klt* k, float* host_out3);  /* what readFeatures() returns, fw*fh*3 */
+/* standalone kernels, for unit parity */
+int cs_klt_build_pyramid(cs_klt* k, const uint8_t* image); /* builds into _pyrCreator1 */
+
+/* ------------------------------------------------------------------------------------------
+ * Intra-camera pose (src/slam/SL_IntraCamPose.h:92-95) and robust BA are declared in
+ * coslam_pose.h / coslam_ba.h.
+ * ------------------------------------------------------------------------------------------ */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COSLAM_HIP_H */

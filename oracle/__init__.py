@@ -1,0 +1,208 @@
+"""ctypes bindings of oracle/liboracle.so (and oracle/_ref/libintracam_ref.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Nothing under coslam_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+REF_PATH = os.path.join(_HERE, "_ref", "libintracam_ref.so")
+
+TrackedFeature = np.dtype([("status", "<i4"), ("pos", "<f4", (2,)), ("gain", "<f4"), ("fed", "<i4")])
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("nIterations", C.c_int), ("nLevels", C.c_int), ("levelSkip", C.c_int), ("windowWidth", C.c_int),
+        ("trackBorderMargin", C.c_float), ("convergenceThreshold", C.c_float), ("SSD_Threshold", C.c_float),
+        ("trackWithGain", C.c_int), ("minDistance", C.c_int), ("minCornerness", C.c_float),
+        ("detectBorderMargin", C.c_float),
+    ]
+
+    @classmethod
+    def from_any(cls, cfg):
+        c = cls()
+        for n, _ in cls._fields_:
+            setattr(c, n, getattr(cfg, n))
+        return c
+
+
+def build(force=False):
+    """make -C oracle (liboracle.so, and _ref/ when /root/reference exists)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "all"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB_PATH)
+        L = _lib
+        L.okl_pyr_layout.restype = C.c_size_t
+        L.okl_pyr_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.okl_seq_create.restype = C.c_void_p
+        L.okl_seq_create.argtypes = [C.POINTER(Config), C.c_int]
+        L.okl_seq_cur_pyramid.restype = C.c_void_p
+        L.okl_seq_cornerness.restype = C.c_void_p
+        L.okl_f32_to_f16.restype = C.c_uint16
+        L.okl_f32_to_f16.argtypes = [C.c_float]
+        L.okl_f16_to_f32.restype = C.c_float
+        L.okl_f16_to_f32.argtypes = [C.c_uint16]
+        L.okl_extract.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def pyr_layout(W, H, L):
+    off = np.zeros(L, dtype=np.int64)
+    total = lib().okl_pyr_layout(W, H, L, _p(off))
+    return int(total), off
+
+
+def pyramid_build(img, W, H, L, centered=0):
+    total, off = pyr_layout(W, H, L)
+    out = np.zeros(total * 4, dtype=np.uint16)
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    lib().okl_pyramid_build(_p(img), W, H, L, centered, _p(out))
+    return out
+
+
+def level_view(pyr, W, H, L, level):
+    _, off = pyr_layout(W, H, L)
+    w, h = W >> level, H >> level
+    return pyr.reshape(-1, 4)[off[level]: off[level] + w * h].reshape(h, w, 4)
+
+
+def half_to_float(u16):
+    return np.asarray(u16, dtype=np.uint16).view(np.float16).astype(np.float32)
+
+
+def cornerness(lvl0, W, H, minCornerness, margin):
+    out = np.zeros((H, W), dtype=np.float32)
+    lvl0 = np.ascontiguousarray(lvl0, dtype=np.uint16)
+    lib().okl_cornerness(_p(lvl0), W, H, C.c_float(minCornerness), C.c_float(margin), _p(out))
+    return out
+
+
+def nonmax(corner, d):
+    c = np.ascontiguousarray(corner, dtype=np.float32).copy()
+    H, W = c.shape
+    lib().okl_nonmax(_p(c), W, H, d)
+    return c
+
+
+def suppress_present(corner, present3):
+    c = np.ascontiguousarray(corner, dtype=np.float32).copy()
+    H, W = c.shape
+    p = np.ascontiguousarray(present3, dtype=np.float32).reshape(-1, 3)
+    lib().okl_suppress_present(_p(c), W, H, p.shape[0], _p(p))
+    return c
+
+
+def extract(corner, maxOut):
+    c = np.ascontiguousarray(corner, dtype=np.float32)
+    H, W = c.shape
+    out = np.zeros((maxOut, 3), dtype=np.float32)
+    n = lib().okl_extract(_p(c), W, H, maxOut, _p(out))
+    return n, out[: min(n, maxOut)]
+
+
+def sample(lvl, Wl, Hl, s, t):
+    out = np.zeros(3, dtype=np.float32)
+    lvl = np.ascontiguousarray(lvl, dtype=np.uint16)
+    lib().okl_sample(_p(lvl), Wl, Hl, C.c_float(s), C.c_float(t), _p(out))
+    return out
+
+
+class SequenceTracker:
+    """okl_seq: CPU restatement of V3D_GPU::KLT_SequenceTracker."""
+
+    def __init__(self, config, centered=0):
+        self._L = lib()
+        self.cfg = Config.from_any(config)
+        self._h = C.c_void_p(self._L.okl_seq_create(C.byref(self.cfg), centered))
+
+    def allocate(self, W, H, L, fw, fh, plw=0, plh=0):
+        if plw <= 0 or plh <= 0:
+            plw, plh = 2 * fw, 2 * fh
+        self._L.okl_seq_allocate(self._h, W, H, L, fw, fh, plw, plh)
+        self.W, self.H, self.L, self.fw, self.fh, self.N = W, H, L, fw, fh, fw * fh
+
+    def close(self):
+        if self._h:
+            self._L.okl_seq_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def setBorderMargin(self, m):
+        self._L.okl_seq_set_border_margin(self._h, C.c_float(m))
+
+    def setConvergenceThreshold(self, t):
+        self._L.okl_seq_set_convergence_threshold(self._h, C.c_float(t))
+
+    def setSSD_Threshold(self, t):
+        self._L.okl_seq_set_ssd_threshold(self._h, C.c_float(t))
+
+    def _call(self, fn, image, *extra):
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        assert img.size == self.W * self.H
+        dest = np.zeros(self.N, dtype=TrackedFeature)
+        dest["status"] = -1
+        dest["fed"] = -1
+        n = C.c_int(0)
+        fn(self._h, _p(img), C.byref(n), _p(dest), *extra)
+        return n.value, dest
+
+    def detect(self, image, present=None):
+        if present is None:
+            return self._call(self._L.okl_seq_detect, image)
+        p = np.ascontiguousarray(present, dtype=np.float32).reshape(-1, 3)
+        return self._call(self._L.okl_seq_detect_present, image, p.shape[0], _p(p))
+
+    def redetect(self, image):
+        return self._call(self._L.okl_seq_redetect, image)
+
+    def track(self, image):
+        return self._call(self._L.okl_seq_track, image)
+
+    def feedExternFeaturePoints(self, featPts):
+        p = np.ascontiguousarray(featPts, dtype=np.float32).reshape(-1, 3)
+        ids = np.full(max(p.shape[0], 1), -1, dtype=np.int32)
+        n = C.c_int(0)
+        self._L.okl_seq_feed(self._h, p.shape[0], _p(p), _p(ids), C.byref(n))
+        return n.value, ids[: n.value].copy()
+
+    def advanceFrame(self):
+        self._L.okl_seq_advance(self._h)
+
+    def read_pyramid(self):
+        total, _ = pyr_layout(self.W, self.H, self.L)
+        ptr = self._L.okl_seq_cur_pyramid(self._h)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint16)), shape=(total * 4,)).copy()
+
+    def read_cornerness(self):
+        ptr = self._L.okl_seq_cornerness(self._h)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(self.H, self.W)).copy()
+
+    def read_features(self):
+        out = np.zeros((self.N, 3), dtype=np.float32)
+        self._L.okl_seq_read_features(self._h, _p(out))
+        return out

@@ -1,0 +1,117 @@
+/*
+ * oracle/klt_oracle.h -- CPU restatement of CoSLAM's GPU-KLT hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under coslam_amd/ may include, link or
+ * call this.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / the reported baseline.
+ *
+ * PARITY UNPINNED for the KLT part: the reference (danping/CoSLAM) runs this
+ * path as Nvidia Cg fragment shaders through OpenGL FBOs and ships no tests,
+ * golden vectors or fixtures.  It cannot run in this
+ * image (no Cg, no GL context).  This file restates, line by line, what the
+ * shaders and their host scheduling compute; each function cites the
+ * reference file:line it follows (paths relative to the reference root).
+ * The known-answer tests in tests/ (analytic shifts, ramps, isolated corner)
+ * are ours, not the reference's.
+ *
+ * Numeric model (the places where OpenGL leaves bits to the hardware and we
+ * had to pick; all are stated in DESIGN.md):
+ *   - pyramid texels are IEEE binary16, round-to-nearest-even, subnormals kept;
+ *   - all shader arithmetic is IEEE binary32, no FMA contraction, evaluated in
+ *     the order written in the .cg source;
+ *   - NEAREST taps that land exactly on a texel boundary (the 2x decimation,
+ *     v3d_gpupyramid.cpp:407-418) resolve with floor() as the GL spec says
+ *     ("centered" = 0); centered = 1 selects the geometrically centred taps;
+ *   - bilinear weights are full binary32 (real texture units quantise them to
+ *     8 fractional bits; not modelled).
+ */
+#ifndef COSLAM_KLT_ORACLE_H
+#define COSLAM_KLT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OKL_MAX_LEVELS 12
+
+/* v3d_gpuklt.h:166-176 */
+typedef struct okl_tracked_feature {
+    int status; /* 0 tracked, 1 new, -1 dead */
+    float pos[2];
+    float gain;
+    int fed;
+} okl_tracked_feature;
+
+/* v3d_gpuklt.h:180-199 (same field order, same defaults via okl_config_default) */
+typedef struct okl_config {
+    int nIterations, nLevels, levelSkip, windowWidth;
+    float trackBorderMargin, convergenceThreshold, SSD_Threshold;
+    int trackWithGain;
+    int minDistance;
+    float minCornerness, detectBorderMargin;
+} okl_config;
+
+void okl_config_default(okl_config* c);
+
+/* ---- pyramid layout: level l is (W>>l) x (H>>l) texels of 4 halfs (I,Ix,Iy,0),
+ *      level starts aligned to 64 texels.  Returns the total texel count. */
+size_t okl_pyr_layout(int W, int H, int nLevels, int64_t* off_texels);
+
+uint16_t okl_f32_to_f16(float f);
+float okl_f16_to_f32(uint16_t h);
+
+/* v3d_gpupyramid.cpp:376-429 + pyramid_with_derivative_pass1v/1h/pass2.cg */
+void okl_pyramid_build(const uint8_t* img, int W, int H, int nLevels, int centered, uint16_t* pyr);
+
+/* bilinear fetch of (I,Ix,Iy) at normalized (s,t) on one level (GL_LINEAR, CLAMP_TO_EDGE) */
+void okl_sample(const uint16_t* lvl, int Wl, int Hl, float s, float t, float out[3]);
+
+/* klt_tracker.cg:24-132 scheduled by v3d_gpuklt.cpp:99-161; N features, in/out N x 3 floats */
+void okl_track_nogain(const uint16_t* pyr0, const uint16_t* pyr1, int W, int H, int nLevels, int levelSkip,
+                      int halfWidth, int nIterShader, float margin, float convThr, float ssdThr, int N,
+                      const float* featIn, float* featOut);
+
+/* one launch of klt_tracker_with_gain.cg:42-148 on level `level` */
+void okl_track_gain_pass(const uint16_t* pyr0, const uint16_t* pyr1, int W, int H, int nLevels, int level, int fw,
+                         int fh, int halfWidth, const float* feat0, const float* featIn, float* featOut,
+                         float sqrConvThr, float ssdThr, const float validRegion[4], float lambda, float delta);
+
+/* 7x7 structure tensor -> min eigenvalue: klt_detector_pass1.cg, klt_detector_pass2.cg,
+ * scheduled by v3d_gpuklt.cpp:457-473 */
+void okl_cornerness(const uint16_t* lvl0, int W, int H, float minCornerness, float margin, float* out);
+/* v3d_gpuklt.cpp:475-500 */
+void okl_suppress_present(float* corner, int W, int H, int nPresent, const float* present3);
+/* klt_detector_nonmax.cg x2, v3d_gpuklt.cpp:502-512 */
+void okl_nonmax(float* corner, int W, int H, int minDist);
+/* discriminator + histopyramid + traversal (v3d_gpuklt.cpp:514-588): survivors (value>0) in
+ * HistoPyramid order (= Morton order of (x,y), x minor), at most maxOut; returns the TOTAL count */
+int okl_extract(const float* corner, int W, int H, int maxOut, float* list3);
+
+/* ---- KLT_SequenceTracker restated (v3d_gpuklt.cpp:592-889, v3d_gpuklt.h:202-263) ---- */
+typedef struct okl_seq okl_seq;
+okl_seq* okl_seq_create(const okl_config* cfg, int centered);
+void okl_seq_destroy(okl_seq* s);
+void okl_seq_allocate(okl_seq* s, int W, int H, int nLevels, int fw, int fh, int plw, int plh);
+void okl_seq_detect(okl_seq* s, const uint8_t* img, int* nDetected, okl_tracked_feature* dest);
+void okl_seq_detect_present(okl_seq* s, const uint8_t* img, int* nDetected, okl_tracked_feature* dest, int nPresent,
+                            const float* present3);
+void okl_seq_redetect(okl_seq* s, const uint8_t* img, int* nNew, okl_tracked_feature* dest);
+void okl_seq_track(okl_seq* s, const uint8_t* img, int* nPresent, okl_tracked_feature* dest);
+void okl_seq_feed(okl_seq* s, int npts, const float* featPts, int* trackIds, int* nFed);
+void okl_seq_advance(okl_seq* s);
+void okl_seq_set_border_margin(okl_seq* s, float m);
+void okl_seq_set_convergence_threshold(okl_seq* s, float t);
+void okl_seq_set_ssd_threshold(okl_seq* s, float t);
+/* test access: pyramid of the frame most recently built (pyrCreator1) and the cornerness map */
+const uint16_t* okl_seq_cur_pyramid(const okl_seq* s);
+const float* okl_seq_cornerness(const okl_seq* s);
+/* copy of the feature buffer that readFeatures() would return (N x 3) */
+void okl_seq_read_features(const okl_seq* s, float* out3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,253 @@
+"""GPU parity tests of the KLT path: libcoslam_hip.so (through the C-ABI) vs the oracle on the same
+seeded synthetic inputs.  Bit-exact for the pyramid, the cornerness map, the detection set and the
+slot tables (binary16/32 with a fixed evaluation order); <= 0.02 px for tracked positions, where the
+wave-wide summation order differs from the oracle's serial order (tolerance from SURVEY.md 8d)."""
+import numpy as np
+import pytest
+
+import coslam_amd
+import oracle
+from coslam_amd.synth import Scene, blob_image, shift_image
+
+pytestmark = pytest.mark.gpu
+
+TOL_PX = 0.02
+
+
+def make_pair(cfg, W, H, L, fw, fh, tap_mode=0):
+    trk = coslam_amd.KLT_SequenceTracker(cfg, device=0, tap_mode=tap_mode)
+    trk.allocate(W, H, L, fw, fh)
+    ora = oracle.SequenceTracker(cfg, centered=tap_mode)
+    ora.allocate(W, H, L, fw, fh)
+    return trk, ora
+
+
+def cfg2(**kw):
+    base = dict(nIterations=10, nLevels=4, levelSkip=1, windowWidth=7, trackWithGain=1, minCornerness=3000.0,
+                convergenceThreshold=1.0, SSD_Threshold=20000.0, minDistance=5)
+    base.update(kw)
+    return coslam_amd.KLT_SequenceTrackerConfig(**base)
+
+
+def compare_dest(d_g, d_o, W, H, min_same=1.0, tol=TOL_PX):
+    same = d_g["status"] == d_o["status"]
+    assert same.mean() >= min_same, f"status agreement {same.mean():.4f} < {min_same}"
+    live = same & (d_o["status"] >= 0)
+    err = np.abs(d_g["pos"][live] - d_o["pos"][live]) * np.array([W, H], dtype=np.float32)
+    return same, live, (err.max() if err.size else 0.0)
+
+
+@pytest.mark.parametrize("W,H,L,tap", [(640, 480, 4, 0), (640, 480, 4, 1), (322, 250, 3, 0), (1920, 1080, 4, 0),
+                                       (96, 64, 1, 0), (640, 480, 6, 0)])
+def test_pyramid_bitexact(hip, W, H, L, tap):
+    rng = np.random.default_rng(W * 7 + H + L)
+    img = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+    trk = coslam_amd.KLT_SequenceTracker(cfg2(nLevels=L), 0, tap)
+    trk.allocate(W, H, L, 8, 8)
+    trk.build_pyramid(img)
+    got = trk.read_pyramid(1)
+    want = oracle.pyramid_build(img, W, H, L, centered=tap)
+    for l in range(L):
+        g = trk.level_view(got, l)
+        w = oracle.level_view(want, W, H, L, l)
+        assert np.array_equal(g, w), f"level {l}: {np.sum(g != w)} halfs differ"
+    trk.close()
+
+
+def test_pyramid_edge_images(hip):
+    W, H, L = 128, 96, 3
+    trk = coslam_amd.KLT_SequenceTracker(cfg2(nLevels=L), 0, 0)
+    trk.allocate(W, H, L, 8, 8)
+    for img in (np.zeros((H, W), np.uint8), np.full((H, W), 255, np.uint8),
+                (np.indices((H, W)).sum(0) % 2 * 255).astype(np.uint8)):
+        trk.build_pyramid(img)
+        assert np.array_equal(trk.read_pyramid(1), oracle.pyramid_build(img, W, H, L))
+    trk.close()
+
+
+@pytest.mark.parametrize("W,H,N,gain", [(640, 480, (50, 40), 1), (640, 480, (32, 32), 0), (322, 250, (16, 16), 1)])
+def test_detect_bitexact(hip, W, H, N, gain):
+    sc = Scene(1, W, H, 4000 if W >= 640 else 1200, seed=11)
+    img = sc.render(0, 0)
+    cfg = cfg2(trackWithGain=gain, nLevels=3)
+    trk, ora = make_pair(cfg, W, H, 3, *N)
+    n_g, d_g = trk.detect(img)
+    n_o, d_o = ora.detect(img)
+    assert np.array_equal(trk.read_cornerness(), ora.read_cornerness()), "non-max cornerness map differs"
+    assert n_g == n_o and n_g > 100
+    assert np.array_equal(d_g["status"], d_o["status"])
+    live = d_o["status"] >= 0
+    for f in ("pos", "gain", "fed"):
+        assert np.array_equal(d_g[f][live], d_o[f][live]), f
+    assert np.array_equal(trk.read_features(), ora.read_features())
+    trk.close()
+
+
+def test_detect_topk_when_more_corners_than_slots(hip):
+    W, H = 640, 480
+    sc = Scene(1, W, H, 5000, seed=5)
+    img = sc.render(0, 0)
+    cfg = cfg2(minDistance=3, minCornerness=500.0, nLevels=2)
+    trk, ora = make_pair(cfg, W, H, 2, 16, 16)  # 256 slots, thousands of corners
+    n_g, d_g = trk.detect(img)
+    n_o, d_o = ora.detect(img)
+    assert n_g == n_o == 256
+    assert np.array_equal(d_g["pos"], d_o["pos"]) and np.array_equal(d_g["gain"], d_o["gain"])
+    trk.close()
+
+
+def test_detect_with_present_points(hip):
+    W, H = 320, 240
+    sc = Scene(1, W, H, 900, seed=3)
+    img = sc.render(0, 0)
+    rng = np.random.default_rng(0)
+    present = np.zeros((40, 3), np.float32)
+    present[:, :2] = rng.uniform(0.1, 0.9, (40, 2))
+    cfg = cfg2(nLevels=2, minCornerness=1000.0)
+    trk, ora = make_pair(cfg, W, H, 2, 20, 20)
+    n_g, d_g = trk.detect(img, present)
+    n_o, d_o = ora.detect(img, present)
+    assert n_g == n_o
+    assert np.array_equal(d_g["status"], d_o["status"])
+    live = d_o["status"] >= 0
+    for f in ("pos", "gain", "fed"):
+        assert np.array_equal(d_g[f][live], d_o[f][live]), f
+    assert (d_g["fed"][live] >= 0).sum() == 40
+    assert np.array_equal(trk.read_features(), ora.read_features())
+    trk.close()
+
+
+def test_empty_image_detects_nothing(hip):
+    W, H = 128, 96
+    cfg = cfg2(nLevels=2)
+    trk, ora = make_pair(cfg, W, H, 2, 8, 8)
+    img = np.full((H, W), 77, np.uint8)
+    n_g, d_g = trk.detect(img)
+    assert n_g == 0 and np.all(d_g["status"] == -1)
+    trk.advanceFrame()
+    n_g, d_g = trk.redetect(img)
+    assert n_g == 0 and np.all(d_g["status"] == -1)
+    trk.close()
+
+
+@pytest.mark.parametrize("gain,levels,skip,win", [(1, 4, 1, 7), (0, 4, 1, 7), (1, 6, 2, 6), (0, 3, 2, 5), (0, 4, 1, 11),
+                                                  (1, 4, 1, 13)])
+def test_track_parity(hip, gain, levels, skip, win):
+    W, H, fw, fh = 640, 480, 50, 40
+    sc = Scene(1, W, H, 4000, seed=21)
+    im0, im1 = sc.render(0, 0), sc.render(0, 1)
+    cfg = cfg2(trackWithGain=gain, nLevels=levels, levelSkip=skip, windowWidth=win)
+    trk, ora = make_pair(cfg, W, H, levels, fw, fh)
+    n_g, _ = trk.detect(im0)
+    n_o, _ = ora.detect(im0)
+    assert n_g == n_o
+    trk.advanceFrame()
+    ora.advanceFrame()
+    n_g, d_g = trk.track(im1)
+    n_o, d_o = ora.track(im1)
+    same, live, emax = compare_dest(d_g, d_o, W, H, min_same=0.995)
+    assert live.sum() > 200
+    assert emax <= TOL_PX, emax
+    if gain:
+        assert np.max(np.abs(d_g["gain"][live] - d_o["gain"][live])) < 1e-3
+    assert abs(n_g - n_o) <= (~same).sum()
+    trk.close()
+
+
+@pytest.mark.parametrize("gain", [1, 0])
+def test_redetect_sequence(hip, gain):
+    """The reference's per-frame call: redetect + advanceFrame (GPUKLT::next, GPUKLT.cpp:144-161)."""
+    W, H, fw, fh = 640, 480, 50, 40
+    sc = Scene(1, W, H, 4000, seed=33)
+    cfg = cfg2(trackWithGain=gain)
+    trk, ora = make_pair(cfg, W, H, 4, fw, fh)
+    img = sc.render(0, 0)
+    assert trk.detect(img)[0] == ora.detect(img)[0]
+    trk.advanceFrame()
+    ora.advanceFrame()
+    for f in range(1, 6):
+        img = sc.render(0, f)
+        n_g, d_g = trk.redetect(img)
+        n_o, d_o = ora.redetect(img)
+        same, live, emax = compare_dest(d_g, d_o, W, H, min_same=0.99)
+        assert emax <= TOL_PX * f, (f, emax)  # per-frame tolerance; states are not re-synchronised
+        assert abs(n_g - n_o) <= 2 * (~same).sum() + 2
+        trk.advanceFrame()
+        ora.advanceFrame()
+    assert (d_o["status"] == 0).sum() > 300
+    trk.close()
+
+
+def test_known_shift_is_recovered(hip):
+    """Known-answer: a pure translation of the image must come back as the flow of every tracked feature."""
+    W, H = 320, 240
+    sc = Scene(1, W, H, 700, seed=8, sigma=1.6)
+    im0 = sc.render(0, 0)
+    dx, dy = 1.3, -0.7
+    im1 = shift_image(im0, dx, dy)
+    cfg = cfg2(nLevels=3, trackWithGain=0, minCornerness=1500.0)
+    trk = coslam_amd.KLT_SequenceTracker(cfg, 0)
+    trk.allocate(W, H, 3, 20, 20)
+    n0, d0 = trk.detect(im0)
+    trk.advanceFrame()
+    n1, d1 = trk.track(im1)
+    ok = d1["status"] == 0
+    assert ok.sum() > 0.8 * n0
+    flow = (d1["pos"][ok] - d0["pos"][ok]) * np.array([W, H], np.float32)
+    assert np.median(np.abs(flow[:, 0] - dx)) < 0.05 and np.median(np.abs(flow[:, 1] - dy)) < 0.05
+    trk.close()
+
+
+def test_feed_extern_points_matches_oracle(hip):
+    W, H = 320, 240
+    sc = Scene(1, W, H, 600, seed=4)
+    img = sc.render(0, 0)
+    cfg = cfg2(nLevels=2, minCornerness=1500.0)
+    trk, ora = make_pair(cfg, W, H, 2, 16, 16)
+    trk.detect(img)
+    ora.detect(img)
+    trk.advanceFrame()
+    ora.advanceFrame()
+    pts = np.zeros((12, 3), np.float32)
+    pts[:, :2] = np.random.default_rng(2).uniform(0.2, 0.8, (12, 2))
+    n_g, ids_g = trk.feedExternFeaturePoints(pts)
+    n_o, ids_o = ora.feedExternFeaturePoints(pts)
+    assert n_g == n_o and np.array_equal(ids_g, ids_o)
+    assert np.array_equal(trk.read_features(), ora.read_features())
+    trk.close()
+
+
+def test_device_resident_entry_points(hip):
+    """*_dev variants: image and results stay in HBM; same answer as the host-pointer variants."""
+    import torch
+
+    W, H, fw, fh = 640, 480, 50, 40
+    sc = Scene(1, W, H, 4000, seed=33)
+    cfg = cfg2()
+    a = coslam_amd.KLT_SequenceTracker(cfg, 0)
+    a.allocate(W, H, 4, fw, fh)
+    b = coslam_amd.KLT_SequenceTracker(cfg, 0)
+    b.allocate(W, H, 4, fw, fh)
+    dev = torch.device("cuda:0")
+    d_dest = torch.zeros(fw * fh * 5, dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(4, dtype=torch.int32, device=dev)
+    b.set_stream(torch.cuda.current_stream().cuda_stream)
+    for f in range(3):
+        img = sc.render(0, f)
+        d_img = torch.from_numpy(img).to(dev)
+        if f == 0:
+            n_a, dest_a = a.detect(img)
+            b.detect_dev(d_img.data_ptr(), d_dest.data_ptr(), d_counts.data_ptr())
+        else:
+            n_a, dest_a = a.redetect(img)
+            b.redetect_dev(d_img.data_ptr(), d_dest.data_ptr(), d_counts.data_ptr())
+        torch.cuda.synchronize()
+        dest_b = d_dest.cpu().numpy().view(coslam_amd.KLT_TrackedFeature)
+        assert int(d_counts[0]) == n_a
+        assert np.array_equal(dest_b["status"], dest_a["status"])
+        live = dest_a["status"] >= 0
+        assert np.array_equal(dest_b["pos"][live], dest_a["pos"][live])
+        a.advanceFrame()
+        b.advanceFrame()
+    a.close()
+    b.close()
