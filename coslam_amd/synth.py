@@ -132,7 +132,7 @@ def rodrigues(w):
 
 
 def make_ba_problem(n_cams=10, n_pts=500, W=640, H=480, noise=0.5, rot_pert=0.01, trans_pert=0.03, pt_pert=0.05,
-                    outlier_frac=0.05, outlier_mag=20.0, seed=0xC051A + 1, visibility=1.0):
+                    outlier_frac=0.05, outlier_mag=20.0, seed=0xC051A + 1, visibility=1.0, n_cams_con=2, n_pts_con=2):
     """Synthetic local-BA problem in the flat layout of cs_ba_robust.
     Returns dict with ground truth and perturbed initial values."""
     rng = np.random.Generator(np.random.MT19937(seed))
@@ -169,5 +169,9 @@ def make_ba_problem(n_cams=10, n_pts=500, W=640, H=480, noise=0.5, rot_pert=0.01
     Rs0 = np.array([Rs[c] @ rodrigues(rot_pert * rng.standard_normal(3)) for c in range(n_cams)])
     ts0 = ts + trans_pert * rng.standard_normal(ts.shape)
     pts0 = pts + pt_pert * rng.standard_normal(pts.shape)
+    # the held-fixed cameras / points define the gauge: they keep their true values
+    Rs0[:n_cams_con] = Rs[:n_cams_con]
+    ts0[:n_cams_con] = ts[:n_cams_con]
+    pts0[:n_pts_con] = pts[:n_pts_con]
     return dict(K=K, Ks=np.repeat(K[None], n_cams, 0), Rs_gt=Rs, ts_gt=ts, pts_gt=pts, Rs0=Rs0, ts0=ts0, pts0=pts0,
                 obs_cam=obs_cam, obs_pt=obs_pt, obs_xy=obs_xy_noisy, obs_xy_clean=obs_xy, is_outlier=is_out)
