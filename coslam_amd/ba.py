@@ -1,0 +1,107 @@
+"""bundleAdjustRobust over the C-ABI (call contract: reference src/app/SL_CoSLAMRobustBA.cpp:170-180,
+SL_InterCamPoseEstimator.cpp:92-95).  The reference passes vector<Mat_d> Ks,Rs,Ts, vector<Point3d> pts and
+vector<vector<Meas2D>> meas; here meas is either that nested list [(viewId, x, y), ...] per point or the
+flat CSR arrays the C-ABI takes."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import CoslamHipError, check, lib
+
+
+class BAStats(C.Structure):
+    _fields_ = [("cost0", C.c_double), ("cost", C.c_double), ("nIterTotal", C.c_int), ("nOuter", C.c_int),
+                ("nOutliers", C.c_int), ("pad", C.c_int)]
+
+
+def flatten_meas(meas2Ds):
+    """vector<vector<Meas2D>> -> (obs_ptr, obs_cam, obs_xy)"""
+    ptr = np.zeros(len(meas2Ds) + 1, dtype=np.int32)
+    cams, xy = [], []
+    for i, ms in enumerate(meas2Ds):
+        for (v, x, y) in ms:
+            cams.append(v)
+            xy.append((x, y))
+        ptr[i + 1] = len(cams)
+    return ptr, np.asarray(cams, dtype=np.int32), np.asarray(xy, dtype=np.float64).reshape(-1, 2)
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def bundleAdjustRobust(nCamsCon, Ks, Rs, Ts, nPtsCon, pt3Ds, meas, maxErr, maxIter, innerMaxIter, device=0):
+    """In-place on Rs (C,3,3), Ts (C,3), pt3Ds (P,3) like the reference; returns (outlier[nObs], stats).
+    meas: nested list per point of (viewId, x, y) or a tuple (obs_ptr, obs_cam, obs_xy)."""
+    L = lib()
+    if isinstance(meas, tuple):
+        obs_ptr, obs_cam, obs_xy = meas
+    else:
+        obs_ptr, obs_cam, obs_xy = flatten_meas(meas)
+    Cn, P = len(Rs), len(pt3Ds)
+    Ksf = _d(Ks).reshape(Cn, 9)
+    Rsf = _d(Rs).reshape(Cn, 9).copy()
+    Tsf = _d(Ts).reshape(Cn, 3).copy()
+    ptsf = _d(pt3Ds).reshape(P, 3).copy()
+    obs_ptr = np.ascontiguousarray(obs_ptr, dtype=np.int32)
+    obs_cam = np.ascontiguousarray(obs_cam, dtype=np.int32)
+    obs_xy = _d(obs_xy).reshape(-1, 2)
+    n = len(obs_cam)
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    st = BAStats()
+    check(L.cs_ba_robust(Cn, P, n, _vp(Ksf), _vp(Rsf), _vp(Tsf), _vp(ptsf), _vp(obs_ptr), _vp(obs_cam), _vp(obs_xy),
+                         int(nCamsCon), int(nPtsCon), C.c_double(maxErr), int(maxIter), int(innerMaxIter), _vp(out),
+                         C.byref(st), int(device)), "cs_ba_robust")
+    np.asarray(Rs).reshape(Cn, 9)[:] = Rsf
+    np.asarray(Ts).reshape(Cn, 3)[:] = Tsf
+    np.asarray(pt3Ds).reshape(P, 3)[:] = ptsf
+    return out[:n], st
+
+
+class BAWorkspace:
+    """Device-resident BA: upload once, re-solve on a stream from device-resident initial estimates."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        self._L.cs_ba_create.restype = C.c_void_p
+        h = self._L.cs_ba_create(int(device))
+        if not h:
+            raise CoslamHipError("cs_ba_create: " + self._L.cs_last_error().decode())
+        self._h = C.c_void_p(h)
+
+    def upload(self, Ks, Rs, Ts, pts, obs_ptr, obs_cam, obs_xy):
+        self.C, self.P, self.nObs = len(Rs), len(pts), len(obs_cam)
+        a = [_d(Ks).reshape(-1), _d(Rs).reshape(-1), _d(Ts).reshape(-1), _d(pts).reshape(-1),
+             np.ascontiguousarray(obs_ptr, dtype=np.int32), np.ascontiguousarray(obs_cam, dtype=np.int32),
+             _d(obs_xy).reshape(-1)]
+        check(self._L.cs_ba_upload(self._h, self.C, self.P, self.nObs, *[_vp(x) for x in a]), "cs_ba_upload")
+
+    def solve_dev(self, stream_ptr, d_Rs0, d_Ts0, d_pts0, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter):
+        vp = C.c_void_p
+        check(self._L.cs_ba_solve_dev(self._h, vp(stream_ptr), self.C, self.P, self.nObs, vp(d_Rs0), vp(d_Ts0),
+                                      vp(d_pts0), int(nCamsCon), int(nPtsCon), C.c_double(maxErr), int(maxIter),
+                                      int(innerMaxIter)), "cs_ba_solve_dev")
+
+    def download(self):
+        Rs, Ts, pts = np.zeros((self.C, 9)), np.zeros((self.C, 3)), np.zeros((max(self.P, 1), 3))
+        out = np.zeros(max(self.nObs, 1), dtype=np.int32)
+        st = BAStats()
+        check(self._L.cs_ba_download(self._h, self.C, self.P, self.nObs, _vp(Rs), _vp(Ts), _vp(pts), _vp(out),
+                                     C.byref(st)), "cs_ba_download")
+        return Rs.reshape(self.C, 3, 3), Ts, pts[: self.P], out[: self.nObs], st
+
+    def close(self):
+        if self._h:
+            self._L.cs_ba_destroy.argtypes = [C.c_void_p]
+            self._L.cs_ba_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -18,6 +18,8 @@ HIP_SOURCES = [
     "klt_track.hip",
     "klt_detect.hip",
     "klt_seq.hip",
+    "pose.hip",
+    "ba.hip",
 ]
 
 HIPCC_FLAGS = [

@@ -1,0 +1,946 @@
+// ba.hip -- robust multi-camera bundle adjustment on gfx950 (binary64): the bundleAdjustRobust contract.
+//
+// Replaces the external LibVisualSLAM call bundleAdjustRobust(nCamsCon,Ks,Rs,Ts,nPtsCon,pts,meas,maxErr,
+// maxIter,innerMaxIter) reached from src/app/SL_CoSLAMRobustBA.cpp:170-180 (local BA),
+// SL_InterCamPoseEstimator.cpp:92-95 (inter-camera pose) and SL_MergeCameraGroup.cpp:646-647.  The
+// algorithm is the one defined in oracle/ba_oracle.c (the library is not vendored: parity unpinned).
+//
+// Design: measurements live in HBM grouped by point (CSR), with a second index by camera and a dense
+// (point, camera) -> measurement table.  One LM step is a short chain of kernels and the LM / outlier
+// control flow stays on the device (a state word every kernel checks on entry), so the host enqueues the
+// whole maxIter x innerMaxIter schedule without a single synchronisation:
+//   k_linearize   one wave per point: residual + analytic Jacobians per measurement (lane = measurement),
+//                 W_ij = Jc^T Jp to HBM, V_i and g_i folded across the wave with butterflies, V_i^-1 stored;
+//   k_cam_reduce  one wave per free camera: U_j = sum Jc^T Jc (+ lambda I), g_j, again by wave butterflies;
+//   k_schur       one workgroup per camera pair (j,k): S_jk -= sum_i W_ij V_i^-1 W_ik^T through the dense
+//                 table (deterministic order, no atomics); rhs_j -= sum_i W_ij V_i^-1 g_i on the diagonal;
+//   k_solve       one workgroup: Cholesky of the reduced camera system in LDS + the two triangular solves;
+//   k_update      tentative step: cameras R exp(w), t + dt; points by back-substitution (wave per point);
+//   k_cost        squared inlier residuals at the tentative (or current) estimate, per-block partials;
+//   k_control     one workgroup: fixed-order sum of the partials, accept/reject, lambda, commit, stop flags;
+//   k_flag        outlier flags (residual > maxErr) and the "flags changed" bit for the outer loop.
+// MFMA is deliberately absent: at the sizes of the reference's calls (<= 13 cameras x 5 key frames) the
+// reduced system is <= 390 x 390 and the Schur products are 6x3 blocks -- wave-shuffle territory.
+#include "cs_common.h"
+
+#pragma clang fp contract(off)
+
+struct cs_ba_stats_dev {
+    double cost0, cost;
+    int nIterTotal, nOuter, nOutliers, pad;
+};
+
+namespace {
+
+struct BaState {
+    double lambda, cost, cost_new, step2, cost0;
+    int inner_it, inner_done, all_done, chol_ok, changed, nIterTotal, nOuter, nOutliers, first_cost;
+};
+
+struct BaDev {
+    int C, P, nObs, nCamsCon, nPtsCon, nc, n;
+    const double* Ks;
+    double *Rs, *Ts, *pts;  // current
+    double *Rn, *Tn, *Mn;   // tentative
+    const int *obs_ptr, *obs_cam, *obs_pt, *cam_ptr, *cam_obs, *obs_of;
+    const double* obs_xy;
+    int* outlier;
+    double *Jc, *e, *W, *Vinv, *gp, *S, *rhs, *costPart, *stepPart;
+    BaState* st;
+    int nCostBlocks;
+    double maxErr;
+    int innerMaxIter;
+};
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__device__ __forceinline__ void so3_exp(const double w[3], double R[9]) {
+    double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    if (th == 0) {
+        R[0] = 1, R[1] = 0, R[2] = 0, R[3] = 0, R[4] = 1, R[5] = 0, R[6] = 0, R[7] = 0, R[8] = 1;
+        return;
+    }
+    double h0 = w[0] / th, h1 = w[1] / th, h2 = w[2] / th;
+    double st = sin(th), ct = 1 - cos(th);
+    R[0] = -ct * h1 * h1 - ct * h2 * h2 + 1;
+    R[1] = ct * h0 * h1 - st * h2;
+    R[2] = st * h1 + ct * h0 * h2;
+    R[3] = st * h2 + ct * h0 * h1;
+    R[4] = -ct * h0 * h0 - ct * h2 * h2 + 1;
+    R[5] = ct * h1 * h2 - st * h0;
+    R[6] = ct * h0 * h2 - st * h1;
+    R[7] = st * h0 + ct * h1 * h2;
+    R[8] = -ct * h0 * h0 - ct * h1 * h1 + 1;
+}
+
+__device__ __forceinline__ void mat33AB(const double* A, const double* B, double* C) {
+    double T[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) T[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) C[i] = T[i];
+}
+
+// same arithmetic as oracle oba_residual()
+template <bool JAC>
+__device__ __forceinline__ bool residual(const double* K, const double* R, const double* t, const double* M,
+                                         const double* m, double* e, double* Jc, double* Jp) {
+    double X[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) X[r] = R[3 * r] * M[0] + R[3 * r + 1] * M[1] + R[3 * r + 2] * M[2] + t[r];
+    double u = K[0] * X[0] + K[1] * X[1] + K[2] * X[2];
+    double v = K[3] * X[0] + K[4] * X[1] + K[5] * X[2];
+    double w = K[6] * X[0] + K[7] * X[1] + K[8] * X[2];
+    if (!(w > 1e-12)) {
+        e[0] = e[1] = 1e150;
+        if (JAC) {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) Jc[q] = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) Jp[q] = 0;
+        }
+        return false;
+    }
+    double mx = u / w, my = v / w;
+    e[0] = m[0] - mx;
+    e[1] = m[1] - my;
+    if (JAC) {
+        double A[6];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            A[c] = (K[c] - mx * K[6 + c]) / w;
+            A[3 + c] = (K[3 + c] - my * K[6 + c]) / w;
+        }
+        double Mx[9] = {0, -M[2], M[1], M[2], 0, -M[0], -M[1], M[0], 0};
+        double RMx[9];
+        mat33AB(R, Mx, RMx);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Jc[6 * r + c] = -(A[3 * r] * RMx[c] + A[3 * r + 1] * RMx[3 + c] + A[3 * r + 2] * RMx[6 + c]);
+                Jc[6 * r + 3 + c] = A[3 * r + c];
+                Jp[3 * r + c] = A[3 * r] * R[c] + A[3 * r + 1] * R[3 + c] + A[3 * r + 2] * R[6 + c];
+            }
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool inv33(const double* V, double* Vi) {
+    double a = V[0], b = V[1], c = V[2], d = V[3], e = V[4], f = V[5], g = V[6], h = V[7], i = V[8];
+    double A = e * i - f * h, B = -(d * i - f * g), Cc = d * h - e * g;
+    double det = a * A + b * B + c * Cc;
+    if (!(fabs(det) > 0)) return false;
+    double r = 1.0 / det;
+    Vi[0] = A * r;
+    Vi[1] = -(b * i - c * h) * r;
+    Vi[2] = (b * f - c * e) * r;
+    Vi[3] = B * r;
+    Vi[4] = (a * i - c * g) * r;
+    Vi[5] = -(a * f - c * d) * r;
+    Vi[6] = Cc * r;
+    Vi[7] = -(a * h - b * g) * r;
+    Vi[8] = (a * e - b * d) * r;
+    return true;
+}
+
+#define BA_ACTIVE(D) (!((D).st->all_done) && !((D).st->inner_done))
+
+// ---- one wave per point --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_linearize(BaDev D) {
+    if (!BA_ACTIVE(D)) return;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= D.P) return;
+    const int o0 = D.obs_ptr[i], o1 = D.obs_ptr[i + 1];
+    const bool freeP = (i >= D.nPtsCon);
+    const double lambda = D.st->lambda;
+    const double M[3] = {D.pts[3 * i], D.pts[3 * i + 1], D.pts[3 * i + 2]};
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // V upper (6) + g (3)
+    for (int o = o0 + lane; o < o1; o += 64) {
+        double* Wo = D.W + 18 * (size_t)o;
+        double* Jo = D.Jc + 12 * (size_t)o;
+        double e[2], Jc[12], Jp[6];
+        const int j = D.obs_cam[o];
+        const bool in = !D.outlier[o];
+        if (in) {
+            residual<true>(D.Ks + 9 * j, D.Rs + 9 * j, D.Ts + 3 * j, M, D.obs_xy + 2 * (size_t)o, e, Jc, Jp);
+        } else {
+            e[0] = e[1] = 0;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) Jc[q] = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) Jp[q] = 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 12; ++q) Jo[q] = Jc[q];
+        D.e[2 * (size_t)o] = e[0];
+        D.e[2 * (size_t)o + 1] = e[1];
+        const bool freeC = (j >= D.nCamsCon);
+        if (in && freeP) {
+            acc[0] += Jp[0] * Jp[0] + Jp[3] * Jp[3];
+            acc[1] += Jp[0] * Jp[1] + Jp[3] * Jp[4];
+            acc[2] += Jp[0] * Jp[2] + Jp[3] * Jp[5];
+            acc[3] += Jp[1] * Jp[1] + Jp[4] * Jp[4];
+            acc[4] += Jp[1] * Jp[2] + Jp[4] * Jp[5];
+            acc[5] += Jp[2] * Jp[2] + Jp[5] * Jp[5];
+            acc[6] += Jp[0] * e[0] + Jp[3] * e[1];
+            acc[7] += Jp[1] * e[0] + Jp[4] * e[1];
+            acc[8] += Jp[2] * e[0] + Jp[5] * e[1];
+        }
+        const bool w = in && freeP && freeC;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Wo[3 * r + c] = w ? (Jc[r] * Jp[c] + Jc[6 + r] * Jp[3 + c]) : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc[q] = wsum(acc[q]);
+    if (lane == 0) {
+        double Vi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (freeP) {
+            double V[9] = {acc[0] + lambda, acc[1], acc[2], acc[1], acc[3] + lambda, acc[4], acc[2], acc[4], acc[5] + lambda};
+            if (!inv33(V, Vi)) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) Vi[q] = 0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) D.Vinv[9 * (size_t)i + q] = Vi[q];
+        D.gp[3 * (size_t)i] = acc[6];
+        D.gp[3 * (size_t)i + 1] = acc[7];
+        D.gp[3 * (size_t)i + 2] = acc[8];
+    }
+}
+
+// ---- one wave per free camera: diagonal block of S and the camera gradient -----------------------
+__global__ __launch_bounds__(256) void k_cam_reduce(BaDev D) {
+    if (!BA_ACTIVE(D)) return;
+    const int lane = threadIdx.x & 63;
+    const int jf = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (jf >= D.nc) return;
+    const int j = jf + D.nCamsCon;
+    double acc[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) acc[q] = 0;
+    for (int s = D.cam_ptr[j] + lane; s < D.cam_ptr[j + 1]; s += 64) {
+        const int o = D.cam_obs[s];
+        if (D.outlier[o]) continue;
+        const double* J = D.Jc + 12 * (size_t)o;
+        const double e0 = D.e[2 * (size_t)o], e1 = D.e[2 * (size_t)o + 1];
+        int q = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) acc[q++] += J[r] * J[c] + J[6 + r] * J[6 + c];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[21 + r] += J[r] * e0 + J[6 + r] * e1;
+    }
+#pragma unroll
+    for (int q = 0; q < 27; ++q) acc[q] = wsum(acc[q]);
+    if (lane == 0) {
+        const double lambda = D.st->lambda;
+        const int n = D.n;
+        int q = 0;
+        for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c) {
+                double v = acc[q++] + ((r == c) ? lambda : 0.0);
+                D.S[(size_t)(6 * jf + r) * n + 6 * jf + c] = v;
+                D.S[(size_t)(6 * jf + c) * n + 6 * jf + r] = v;
+            }
+        for (int r = 0; r < 6; ++r) D.rhs[6 * jf + r] = acc[21 + r];
+    }
+}
+
+// ---- one workgroup per camera pair (ja <= jb) ----------------------------------------------------
+__global__ __launch_bounds__(256) void k_schur(BaDev D) {
+    if (!BA_ACTIVE(D)) return;
+    __shared__ double red[4][42];
+    // decode the pair from the linear block index over the upper triangle
+    int pair = blockIdx.x, ja = 0;
+    while (pair >= D.nc - ja) {
+        pair -= D.nc - ja;
+        ++ja;
+    }
+    const int jb = ja + pair;
+    const int ca = ja + D.nCamsCon, cb = jb + D.nCamsCon;
+    double acc[42];
+#pragma unroll
+    for (int q = 0; q < 42; ++q) acc[q] = 0;
+    for (int i = D.nPtsCon + threadIdx.x; i < D.P; i += 256) {
+        const int oa = D.obs_of[(size_t)i * D.C + ca];
+        if (oa < 0 || D.outlier[oa]) continue;
+        const int ob = (ja == jb) ? oa : D.obs_of[(size_t)i * D.C + cb];
+        if (ob < 0 || D.outlier[ob]) continue;
+        const double* Wa = D.W + 18 * (size_t)oa;
+        const double* Wb = D.W + 18 * (size_t)ob;
+        const double* Vi = D.Vinv + 9 * (size_t)i;
+        double Y[18];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Y[3 * r + c] = Wa[3 * r] * Vi[c] + Wa[3 * r + 1] * Vi[3 + c] + Wa[3 * r + 2] * Vi[6 + c];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                acc[6 * r + c] += Y[3 * r] * Wb[3 * c] + Y[3 * r + 1] * Wb[3 * c + 1] + Y[3 * r + 2] * Wb[3 * c + 2];
+        if (ja == jb) {
+            const double* g = D.gp + 3 * (size_t)i;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[36 + r] += Y[3 * r] * g[0] + Y[3 * r + 1] * g[1] + Y[3 * r + 2] * g[2];
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 42; ++q) {
+        double s = wsum(acc[q]);
+        if (lane == 0) red[wv][q] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 42) {
+        const int q = threadIdx.x;
+        double s = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
+        const int n = D.n;
+        if (q < 36) {
+            const int r = q / 6, c = q - 6 * r;
+            if (ja == jb) {
+                D.S[(size_t)(6 * ja + r) * n + 6 * ja + c] -= s;
+            } else {
+                D.S[(size_t)(6 * ja + r) * n + 6 * jb + c] = -s;
+                D.S[(size_t)(6 * jb + c) * n + 6 * ja + r] = -s;
+            }
+        } else if (ja == jb) {
+            D.rhs[6 * ja + (q - 36)] -= s;
+        }
+    }
+}
+
+// ---- one workgroup: Cholesky + solve of the reduced camera system --------------------------------
+__global__ __launch_bounds__(256) void k_solve(BaDev D, int useLds) {
+    if (!BA_ACTIVE(D)) return;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int okFlag;
+    const int n = D.n, tid = threadIdx.x;
+    if (n == 0) {
+        if (tid == 0) D.st->chol_ok = 1;
+        return;
+    }
+    double* A = useLds ? sm : D.S;
+    double* b = useLds ? (sm + (size_t)n * n) : D.rhs;
+    if (useLds) {
+        for (int q = tid; q < n * n; q += 256) A[q] = D.S[q];
+        for (int q = tid; q < n; q += 256) b[q] = D.rhs[q];
+    }
+    if (tid == 0) okFlag = 1;
+    __syncthreads();
+    // right-looking Cholesky on the lower triangle
+    for (int j = 0; j < n; ++j) {
+        if (tid == 0) {
+            double d = A[(size_t)j * n + j];
+            if (!(d > 0)) {
+                okFlag = 0;
+                d = 1.0;
+            }
+            A[(size_t)j * n + j] = sqrt(d);
+        }
+        __syncthreads();
+        const double djj = A[(size_t)j * n + j];
+        for (int i = j + 1 + tid; i < n; i += 256) A[(size_t)i * n + j] /= djj;
+        __syncthreads();
+        // trailing update: A[i][k] -= A[i][j] * A[k][j] for j < k <= i
+        const int m = n - j - 1;
+        for (int q = tid; q < m * m; q += 256) {
+            const int i = j + 1 + q / m, k = j + 1 + q % m;
+            if (k <= i) A[(size_t)i * n + k] -= A[(size_t)i * n + j] * A[(size_t)k * n + j];
+        }
+        __syncthreads();
+    }
+    // forward substitution L y = b (column oriented)
+    for (int j = 0; j < n; ++j) {
+        if (tid == 0) b[j] /= A[(size_t)j * n + j];
+        __syncthreads();
+        const double yj = b[j];
+        for (int i = j + 1 + tid; i < n; i += 256) b[i] -= A[(size_t)i * n + j] * yj;
+        __syncthreads();
+    }
+    // back substitution L^T x = y
+    for (int j = n - 1; j >= 0; --j) {
+        if (tid == 0) b[j] /= A[(size_t)j * n + j];
+        __syncthreads();
+        const double xj = b[j];
+        for (int i = tid; i < j; i += 256) b[i] -= A[(size_t)j * n + i] * xj;
+        __syncthreads();
+    }
+    if (useLds)
+        for (int q = tid; q < n; q += 256) D.rhs[q] = b[q];
+    if (tid == 0) D.st->chol_ok = okFlag;
+}
+
+// ---- tentative step -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_update(BaDev D) {
+    if (!BA_ACTIVE(D)) return;
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // waves [0, P): points; the cameras are handled by the first lanes of block 0 afterwards
+    if (gw < D.P) {
+        const int i = gw;
+        double b[3] = {0, 0, 0};
+        if (i >= D.nPtsCon) {
+            for (int o = D.obs_ptr[i] + lane; o < D.obs_ptr[i + 1]; o += 64) {
+                const int j = D.obs_cam[o] - D.nCamsCon;
+                if (j < 0 || D.outlier[o]) continue;
+                const double* Wo = D.W + 18 * (size_t)o;
+                const double* dc = D.rhs + 6 * j;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) b[c] -= Wo[3 * r + c] * dc[r];
+            }
+        }
+        b[0] = wsum(b[0]);
+        b[1] = wsum(b[1]);
+        b[2] = wsum(b[2]);
+        if (lane == 0) {
+            double d[3] = {0, 0, 0};
+            if (i >= D.nPtsCon) {
+                const double* Vi = D.Vinv + 9 * (size_t)i;
+                const double g0 = D.gp[3 * (size_t)i] + b[0], g1 = D.gp[3 * (size_t)i + 1] + b[1],
+                             g2 = D.gp[3 * (size_t)i + 2] + b[2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) d[r] = Vi[3 * r] * g0 + Vi[3 * r + 1] * g1 + Vi[3 * r + 2] * g2;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) D.Mn[3 * (size_t)i + r] = D.pts[3 * (size_t)i + r] + d[r];
+            D.stepPart[i] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        }
+    }
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < D.C) {
+        const int j = t;
+        double s2 = 0;
+        if (j >= D.nCamsCon) {
+            const double* dc = D.rhs + 6 * (j - D.nCamsCon);
+            double w[3] = {dc[0], dc[1], dc[2]}, dR[9], Rn[9];
+            so3_exp(w, dR);
+            mat33AB(D.Rs + 9 * j, dR, Rn);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) D.Rn[9 * j + q] = Rn[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) D.Tn[3 * j + q] = D.Ts[3 * j + q] + dc[3 + q];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) s2 += dc[q] * dc[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) D.Rn[9 * j + q] = D.Rs[9 * j + q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) D.Tn[3 * j + q] = D.Ts[3 * j + q];
+        }
+        D.stepPart[D.P + j] = s2;
+    }
+}
+
+// ---- cost at the tentative (which=1) or current (which=0) estimate ------------------------------------
+__global__ __launch_bounds__(256) void k_cost(BaDev D, int which) {
+    if (D.st->all_done) return;
+    if (which == 1 && D.st->inner_done) return;
+    __shared__ double red[4];
+    const double* Rs = which ? D.Rn : D.Rs;
+    const double* Ts = which ? D.Tn : D.Ts;
+    const double* pts = which ? D.Mn : D.pts;
+    double c = 0;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < D.nObs; o += gridDim.x * 256) {
+        if (D.outlier[o]) continue;
+        const int j = D.obs_cam[o], i = D.obs_pt[o];
+        double e[2];
+        residual<false>(D.Ks + 9 * j, Rs + 9 * j, Ts + 3 * j, pts + 3 * (size_t)i, D.obs_xy + 2 * (size_t)o, e, nullptr,
+                        nullptr);
+        c += e[0] * e[0] + e[1] * e[1];
+    }
+    c = wsum(c);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) D.costPart[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// ---- LM control: one workgroup -----------------------------------------------------------------------
+// phase 0: start of an LM run (cost of the current estimate over the current inliers)
+// phase 1: after a tentative step (accept / reject, commit, stop tests)
+__global__ __launch_bounds__(256) void k_control(BaDev D, int phase) {
+    __shared__ double red[4];
+    __shared__ int accept;
+    BaState* st = D.st;
+    if (st->all_done) return;
+    if (phase == 1 && st->inner_done) return;
+    const int tid = threadIdx.x;
+    // fixed-order sums
+    double c = 0;
+    for (int q = tid; q < D.nCostBlocks; q += 256) c += D.costPart[q];
+    c = wsum(c);
+    if ((tid & 63) == 0) red[tid >> 6] = c;
+    __syncthreads();
+    const double cost_sum = ((red[0] + red[1]) + red[2]) + red[3];
+    __syncthreads();
+    if (phase == 0) {
+        if (tid == 0) {
+            st->cost = cost_sum;
+            st->lambda = 1e-3;
+            st->inner_it = 0;
+            st->inner_done = (D.innerMaxIter <= 0) ? 1 : 0;
+            if (st->first_cost) {
+                st->cost0 = cost_sum;
+                st->first_cost = 0;
+            }
+        }
+        return;
+    }
+    double s2 = 0;
+    for (int q = tid; q < D.P + D.C; q += 256) s2 += D.stepPart[q];
+    s2 = wsum(s2);
+    if ((tid & 63) == 0) red[tid >> 6] = s2;
+    __syncthreads();
+    const double step2 = ((red[0] + red[1]) + red[2]) + red[3];
+    if (tid == 0) {
+        const double cost_new = st->chol_ok ? cost_sum : 1e300;
+        int acc = (st->chol_ok && cost_new <= st->cost) ? 1 : 0;
+        int done = 0;
+        st->nIterTotal += 1;
+        st->inner_it += 1;
+        if (acc) {
+            const double dec = st->cost - cost_new;
+            st->cost = cost_new;
+            st->lambda /= 10;
+            if (dec < 1e-9 * cost_new + 1e-15 || step2 < 1e-20) done = 1;
+        } else {
+            st->lambda *= 10;
+            if (st->lambda > 1e12) done = 1;
+        }
+        if (st->inner_it >= D.innerMaxIter) done = 1;
+        st->inner_done = done;
+        accept = acc;
+    }
+    __syncthreads();
+    if (accept) {
+        for (int q = tid; q < 9 * D.C; q += 256) D.Rs[q] = D.Rn[q];
+        for (int q = tid; q < 3 * D.C; q += 256) D.Ts[q] = D.Tn[q];
+        for (int q = tid; q < 3 * D.P; q += 256) D.pts[q] = D.Mn[q];
+    }
+}
+
+// ---- outer loop: outlier flags ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flag(BaDev D) {
+    BaState* st = D.st;
+    if (st->all_done) return;
+    const double thr2 = D.maxErr * D.maxErr;
+    int changed = 0, nout = 0;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < D.nObs; o += gridDim.x * 256) {
+        const int j = D.obs_cam[o], i = D.obs_pt[o];
+        double e[2];
+        residual<false>(D.Ks + 9 * j, D.Rs + 9 * j, D.Ts + 3 * j, D.pts + 3 * (size_t)i, D.obs_xy + 2 * (size_t)o, e,
+                        nullptr, nullptr);
+        const int out = (e[0] * e[0] + e[1] * e[1] > thr2) ? 1 : 0;
+        if (out != D.outlier[o]) changed = 1;
+        D.outlier[o] = out;
+        nout += out;
+    }
+    if (changed) atomicOr(&st->changed, 1);
+    if (nout) atomicAdd(&st->nOutliers, nout);
+}
+
+__global__ void k_init_state(BaState* st) {
+    BaState z;
+    z.lambda = 1e-3;
+    z.cost = z.cost_new = z.step2 = z.cost0 = 0;
+    z.inner_it = z.inner_done = z.all_done = z.chol_ok = z.changed = z.nIterTotal = z.nOuter = z.nOutliers = 0;
+    z.first_cost = 1;
+    *st = z;
+}
+
+__global__ void k_outer_begin(BaDev D) {
+    BaState* st = D.st;
+    if (st->all_done) return;
+    st->changed = 0;
+    st->nOutliers = 0;
+}
+
+__global__ void k_outer_end(BaDev D) {
+    BaState* st = D.st;
+    if (st->all_done) return;
+    st->nOuter += 1;
+    st->inner_done = 0;
+    if (!st->changed) st->all_done = 1;
+}
+
+__global__ void k_finish(BaDev D, cs_ba_stats_dev* out) {
+    // final cost over the final inlier set was computed by k_cost(0) + costPart
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    double c = 0;
+    for (int q = tid; q < D.nCostBlocks; q += 256) c += D.costPart[q];
+    c = wsum(c);
+    if ((tid & 63) == 0) red[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) {
+        out->cost0 = D.st->cost0;
+        out->cost = ((red[0] + red[1]) + red[2]) + red[3];
+        out->nIterTotal = D.st->nIterTotal;
+        out->nOuter = D.st->nOuter;
+        out->nOutliers = D.st->nOutliers;
+        out->pad = 0;
+    }
+}
+
+__global__ void k_cost_force(BaDev D) {  // k_cost(0) ignoring the stop flags (final report)
+    __shared__ double red[4];
+    double c = 0;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < D.nObs; o += gridDim.x * 256) {
+        if (D.outlier[o]) continue;
+        const int j = D.obs_cam[o], i = D.obs_pt[o];
+        double e[2];
+        residual<false>(D.Ks + 9 * j, D.Rs + 9 * j, D.Ts + 3 * j, D.pts + 3 * (size_t)i, D.obs_xy + 2 * (size_t)o, e,
+                        nullptr, nullptr);
+        c += e[0] * e[0] + e[1] * e[1];
+    }
+    c = wsum(c);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) D.costPart[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// ---- index building on the device -----------------------------------------------------------------
+__global__ void k_build_obs_pt(int P, const int* obs_ptr, int* obs_pt) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= P) return;
+    for (int o = obs_ptr[i] + lane; o < obs_ptr[i + 1]; o += 64) obs_pt[o] = i;
+}
+
+__global__ void k_build_obs_of(int nObs, int C, const int* obs_pt, const int* obs_cam, int* obs_of) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < nObs) obs_of[(size_t)obs_pt[o] * C + obs_cam[o]] = o;  // duplicates: last writer wins (host rejects them)
+}
+
+}  // namespace
+
+// =====================================================================================================
+struct cs_ba {
+    int device;
+    int capC, capP, capObs;
+    hipStream_t own_stream;
+    // device buffers
+    double *Ks, *Rs, *Ts, *pts, *Rn, *Tn, *Mn, *obs_xy, *Jc, *e, *W, *Vinv, *gp, *S, *rhs, *costPart, *stepPart;
+    int *obs_ptr, *obs_cam, *obs_pt, *cam_ptr, *cam_obs, *obs_of, *outlier;
+    BaState* st;
+    cs_ba_stats_dev* stats;
+    // pinned staging for the host-pointer entry
+    int *h_cam_ptr, *h_cam_obs;
+    int nCostBlocks;
+};
+
+static int ba_free(cs_ba* b) {
+    double** dp[] = {&b->Ks, &b->Rs, &b->Ts, &b->pts, &b->Rn, &b->Tn, &b->Mn, &b->obs_xy, &b->Jc, &b->e, &b->W,
+                     &b->Vinv, &b->gp, &b->S, &b->rhs, &b->costPart, &b->stepPart};
+    for (auto p : dp) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    int** ip[] = {&b->obs_ptr, &b->obs_cam, &b->obs_pt, &b->cam_ptr, &b->cam_obs, &b->obs_of, &b->outlier};
+    for (auto p : ip) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    if (b->st) (void)hipFree(b->st);
+    if (b->stats) (void)hipFree(b->stats);
+    if (b->h_cam_ptr) (void)hipHostFree(b->h_cam_ptr);
+    if (b->h_cam_obs) (void)hipHostFree(b->h_cam_obs);
+    b->st = nullptr;
+    b->stats = nullptr;
+    b->h_cam_ptr = b->h_cam_obs = nullptr;
+    return CS_OK;
+}
+
+static int ba_reserve(cs_ba* b, int C, int P, int nObs) {
+    if (C <= b->capC && P <= b->capP && nObs <= b->capObs) return CS_OK;
+    ba_free(b);
+    const size_t cC = (size_t)(C > b->capC ? C : b->capC), cP = (size_t)(P > b->capP ? P : b->capP),
+                 cO = (size_t)(nObs > b->capObs ? nObs : b->capObs);
+    const size_t n = 6 * cC;
+#define BA_ALLOC(ptr, count, type) CS_HIP(hipMalloc((void**)&(ptr), ((count) > 0 ? (count) : 1) * sizeof(type)))
+    BA_ALLOC(b->Ks, 9 * cC, double);
+    BA_ALLOC(b->Rs, 9 * cC, double);
+    BA_ALLOC(b->Ts, 3 * cC, double);
+    BA_ALLOC(b->pts, 3 * cP, double);
+    BA_ALLOC(b->Rn, 9 * cC, double);
+    BA_ALLOC(b->Tn, 3 * cC, double);
+    BA_ALLOC(b->Mn, 3 * cP, double);
+    BA_ALLOC(b->obs_xy, 2 * cO, double);
+    BA_ALLOC(b->Jc, 12 * cO, double);
+    BA_ALLOC(b->e, 2 * cO, double);
+    BA_ALLOC(b->W, 18 * cO, double);
+    BA_ALLOC(b->Vinv, 9 * cP, double);
+    BA_ALLOC(b->gp, 3 * cP, double);
+    BA_ALLOC(b->S, n * n, double);
+    BA_ALLOC(b->rhs, n, double);
+    BA_ALLOC(b->costPart, 1024, double);
+    BA_ALLOC(b->stepPart, cP + cC, double);
+    BA_ALLOC(b->obs_ptr, cP + 1, int);
+    BA_ALLOC(b->obs_cam, cO, int);
+    BA_ALLOC(b->obs_pt, cO, int);
+    BA_ALLOC(b->cam_ptr, cC + 1, int);
+    BA_ALLOC(b->cam_obs, cO, int);
+    BA_ALLOC(b->obs_of, cP * cC, int);
+    BA_ALLOC(b->outlier, cO, int);
+    BA_ALLOC(b->st, 1, BaState);
+    BA_ALLOC(b->stats, 1, cs_ba_stats_dev);
+#undef BA_ALLOC
+    CS_HIP(hipHostMalloc((void**)&b->h_cam_ptr, (cC + 1) * sizeof(int), hipHostMallocDefault));
+    CS_HIP(hipHostMalloc((void**)&b->h_cam_obs, (cO > 0 ? cO : 1) * sizeof(int), hipHostMallocDefault));
+    b->capC = (int)cC;
+    b->capP = (int)cP;
+    b->capObs = (int)cO;
+    return CS_OK;
+}
+
+// enqueue the whole solve on `stream`; every array already resident in b's device buffers
+static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int nCamsCon, int nPtsCon, double maxErr,
+                      int maxIter, int innerMaxIter) {
+    BaDev D;
+    memset(&D, 0, sizeof(D));
+    D.C = C;
+    D.P = P;
+    D.nObs = nObs;
+    D.nCamsCon = nCamsCon > C ? C : nCamsCon;
+    D.nPtsCon = nPtsCon > P ? P : nPtsCon;
+    D.nc = C - D.nCamsCon;
+    D.n = 6 * D.nc;
+    D.Ks = b->Ks;
+    D.Rs = b->Rs;
+    D.Ts = b->Ts;
+    D.pts = b->pts;
+    D.Rn = b->Rn;
+    D.Tn = b->Tn;
+    D.Mn = b->Mn;
+    D.obs_ptr = b->obs_ptr;
+    D.obs_cam = b->obs_cam;
+    D.obs_pt = b->obs_pt;
+    D.cam_ptr = b->cam_ptr;
+    D.cam_obs = b->cam_obs;
+    D.obs_of = b->obs_of;
+    D.obs_xy = b->obs_xy;
+    D.outlier = b->outlier;
+    D.Jc = b->Jc;
+    D.e = b->e;
+    D.W = b->W;
+    D.Vinv = b->Vinv;
+    D.gp = b->gp;
+    D.S = b->S;
+    D.rhs = b->rhs;
+    D.costPart = b->costPart;
+    D.stepPart = b->stepPart;
+    D.st = b->st;
+    D.maxErr = maxErr;
+    D.innerMaxIter = innerMaxIter;
+    int cb = (nObs + 255) / 256;
+    if (cb < 1) cb = 1;
+    if (cb > 1024) cb = 1024;
+    D.nCostBlocks = cb;
+    b->nCostBlocks = cb;
+
+    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, stream, b->st);
+    CS_HIP(hipMemsetAsync(b->outlier, 0, sizeof(int) * (nObs > 0 ? nObs : 1), stream));
+    CS_HIP(hipMemsetAsync(b->obs_of, 0xff, sizeof(int) * (size_t)P * C, stream));
+    if (P > 0) hipLaunchKernelGGL(k_build_obs_pt, dim3((P + 3) / 4), dim3(256), 0, stream, P, b->obs_ptr, b->obs_pt);
+    if (nObs > 0)
+        hipLaunchKernelGGL(k_build_obs_of, dim3((nObs + 255) / 256), dim3(256), 0, stream, nObs, C, b->obs_pt, b->obs_cam,
+                           b->obs_of);
+
+    const int nPairs = D.nc * (D.nc + 1) / 2;
+    const size_t ldsSolve = sizeof(double) * ((size_t)D.n * D.n + D.n);
+    const int useLds = (ldsSolve <= 150 * 1024) ? 1 : 0;
+    if (useLds && ldsSolve > 64 * 1024) {
+        CS_HIP(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
+    }
+    const dim3 gPts((P + 3) / 4 > 0 ? (P + 3) / 4 : 1), gCam((D.nc + 3) / 4 > 0 ? (D.nc + 3) / 4 : 1), blk(256);
+    int gUpd = (P + 3) / 4;
+    if (gUpd * 256 < C) gUpd = (C + 255) / 256;
+    if (gUpd < 1) gUpd = 1;
+
+    for (int outer = 0; outer < maxIter; ++outer) {
+        hipLaunchKernelGGL(k_cost, dim3(cb), blk, 0, stream, D, 0);
+        hipLaunchKernelGGL(k_control, dim3(1), blk, 0, stream, D, 0);
+        for (int it = 0; it < innerMaxIter; ++it) {
+            hipLaunchKernelGGL(k_linearize, gPts, blk, 0, stream, D);
+            if (D.nc > 0) {
+                hipLaunchKernelGGL(k_cam_reduce, gCam, blk, 0, stream, D);
+                hipLaunchKernelGGL(k_schur, dim3(nPairs), blk, 0, stream, D);
+            }
+            hipLaunchKernelGGL(k_solve, dim3(1), blk, useLds ? ldsSolve : 0, stream, D, useLds);
+            hipLaunchKernelGGL(k_update, dim3(gUpd), blk, 0, stream, D);
+            hipLaunchKernelGGL(k_cost, dim3(cb), blk, 0, stream, D, 1);
+            hipLaunchKernelGGL(k_control, dim3(1), blk, 0, stream, D, 1);
+        }
+        hipLaunchKernelGGL(k_outer_begin, dim3(1), dim3(1), 0, stream, D);
+        hipLaunchKernelGGL(k_flag, dim3(cb), blk, 0, stream, D);
+        hipLaunchKernelGGL(k_outer_end, dim3(1), dim3(1), 0, stream, D);
+    }
+    hipLaunchKernelGGL(k_cost_force, dim3(cb), blk, 0, stream, D);
+    hipLaunchKernelGGL(k_finish, dim3(1), blk, 0, stream, D, b->stats);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+extern "C" {
+
+cs_ba* cs_ba_create(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+        cs_set_error("cs_ba_create: no usable HIP device %d; there is no CPU fallback", device);
+        return nullptr;
+    }
+    cs_ba* b = new cs_ba();
+    memset(b, 0, sizeof(*b));
+    b->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        cs_set_error("cs_ba_create: cannot create a stream");
+        delete b;
+        return nullptr;
+    }
+    return b;
+}
+
+void cs_ba_destroy(cs_ba* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(b->own_stream);
+    ba_free(b);
+    (void)hipStreamDestroy(b->own_stream);
+    delete b;
+}
+
+int cs_ba_robust_h(cs_ba* b, int C, int P, int nObs, const double* Ks, double* Rs, double* Ts, double* pts,
+                   const int* obs_ptr, const int* obs_cam, const double* obs_xy, int nCamsCon, int nPtsCon,
+                   double maxErr, int maxIter, int innerMaxIter, int* out_outlier, cs_ba_stats* stats) {
+    if (!b || C <= 0 || P < 0 || nObs < 0 || !Ks || !Rs || !Ts || (P > 0 && (!pts || !obs_ptr)) ||
+        (nObs > 0 && (!obs_cam || !obs_xy)) || maxIter < 0 || innerMaxIter < 0) {
+        cs_set_error("cs_ba_robust: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (P > 0 && (obs_ptr[0] != 0 || obs_ptr[P] != nObs)) {
+        cs_set_error("cs_ba_robust: obs_ptr must start at 0 and end at nObs");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(b->device));
+    int rc = ba_reserve(b, C, P, nObs);
+    if (rc) return rc;
+    // index by camera (counting sort; also validates the view ids)
+    for (int j = 0; j <= C; ++j) b->h_cam_ptr[j] = 0;
+    for (int o = 0; o < nObs; ++o) {
+        if (obs_cam[o] < 0 || obs_cam[o] >= C) {
+            cs_set_error("cs_ba_robust: measurement %d has viewId %d outside [0,%d)", o, obs_cam[o], C);
+            return CS_ERR_INVALID;
+        }
+        b->h_cam_ptr[obs_cam[o] + 1]++;
+    }
+    for (int j = 0; j < C; ++j) b->h_cam_ptr[j + 1] += b->h_cam_ptr[j];
+    {
+        int* fill = new int[C > 0 ? C : 1];
+        for (int j = 0; j < C; ++j) fill[j] = b->h_cam_ptr[j];
+        for (int o = 0; o < nObs; ++o) b->h_cam_obs[fill[obs_cam[o]]++] = o;
+        delete[] fill;
+    }
+    hipStream_t s = b->own_stream;
+    CS_HIP(hipMemcpyAsync(b->Ks, Ks, sizeof(double) * 9 * C, hipMemcpyHostToDevice, s));
+    CS_HIP(hipMemcpyAsync(b->Rs, Rs, sizeof(double) * 9 * C, hipMemcpyHostToDevice, s));
+    CS_HIP(hipMemcpyAsync(b->Ts, Ts, sizeof(double) * 3 * C, hipMemcpyHostToDevice, s));
+    if (P > 0) {
+        CS_HIP(hipMemcpyAsync(b->pts, pts, sizeof(double) * 3 * P, hipMemcpyHostToDevice, s));
+        CS_HIP(hipMemcpyAsync(b->obs_ptr, obs_ptr, sizeof(int) * (P + 1), hipMemcpyHostToDevice, s));
+    }
+    if (nObs > 0) {
+        CS_HIP(hipMemcpyAsync(b->obs_cam, obs_cam, sizeof(int) * nObs, hipMemcpyHostToDevice, s));
+        CS_HIP(hipMemcpyAsync(b->obs_xy, obs_xy, sizeof(double) * 2 * nObs, hipMemcpyHostToDevice, s));
+        CS_HIP(hipMemcpyAsync(b->cam_obs, b->h_cam_obs, sizeof(int) * nObs, hipMemcpyHostToDevice, s));
+    }
+    CS_HIP(hipMemcpyAsync(b->cam_ptr, b->h_cam_ptr, sizeof(int) * (C + 1), hipMemcpyHostToDevice, s));
+    rc = ba_enqueue(b, s, C, P, nObs, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter);
+    if (rc) return rc;
+    CS_HIP(hipMemcpyAsync(Rs, b->Rs, sizeof(double) * 9 * C, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipMemcpyAsync(Ts, b->Ts, sizeof(double) * 3 * C, hipMemcpyDeviceToHost, s));
+    if (P > 0) CS_HIP(hipMemcpyAsync(pts, b->pts, sizeof(double) * 3 * P, hipMemcpyDeviceToHost, s));
+    if (nObs > 0 && out_outlier)
+        CS_HIP(hipMemcpyAsync(out_outlier, b->outlier, sizeof(int) * nObs, hipMemcpyDeviceToHost, s));
+    cs_ba_stats_dev hs;
+    CS_HIP(hipMemcpyAsync(&hs, b->stats, sizeof(hs), hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    if (stats) memcpy(stats, &hs, sizeof(hs));
+    return CS_OK;
+}
+
+// one-shot convenience with a per-thread cached workspace
+int cs_ba_robust(int C, int P, int nObs, const double* Ks, double* Rs, double* Ts, double* pts, const int* obs_ptr,
+                 const int* obs_cam, const double* obs_xy, int nCamsCon, int nPtsCon, double maxErr, int maxIter,
+                 int innerMaxIter, int* out_outlier, cs_ba_stats* stats, int device) {
+    static thread_local cs_ba* cached = nullptr;
+    if (cached && cached->device != device) {
+        cs_ba_destroy(cached);
+        cached = nullptr;
+    }
+    if (!cached) cached = cs_ba_create(device);
+    if (!cached) return CS_ERR_NO_DEVICE;
+    return cs_ba_robust_h(cached, C, P, nObs, Ks, Rs, Ts, pts, obs_ptr, obs_cam, obs_xy, nCamsCon, nPtsCon, maxErr,
+                          maxIter, innerMaxIter, out_outlier, stats);
+}
+
+// device-resident: upload once (cs_ba_upload), then re-solve from the stored initial state on any stream
+int cs_ba_upload(cs_ba* b, int C, int P, int nObs, const double* Ks, const double* Rs, const double* Ts,
+                 const double* pts, const int* obs_ptr, const int* obs_cam, const double* obs_xy) {
+    double* R2 = new double[9 * (size_t)C];
+    double* T2 = new double[3 * (size_t)C];
+    double* M2 = new double[3 * (size_t)(P > 0 ? P : 1)];
+    memcpy(R2, Rs, sizeof(double) * 9 * C);
+    memcpy(T2, Ts, sizeof(double) * 3 * C);
+    if (P > 0) memcpy(M2, pts, sizeof(double) * 3 * P);
+    // maxIter = 0: uploads everything and runs no iteration
+    int rc = cs_ba_robust_h(b, C, P, nObs, Ks, R2, T2, M2, obs_ptr, obs_cam, obs_xy, 0, 0, 1.0, 0, 0, nullptr, nullptr);
+    delete[] R2;
+    delete[] T2;
+    delete[] M2;
+    return rc;
+}
+
+/* d_Rs0/d_Ts0/d_pts0: device pointers to the initial estimate (copied into the workspace on the stream);
+ * results are left in the workspace and can be fetched with cs_ba_download. */
+int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const double* d_Rs0, const double* d_Ts0,
+                    const double* d_pts0, int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter) {
+    if (!b || C > b->capC || P > b->capP || nObs > b->capObs) {
+        cs_set_error("cs_ba_solve_dev: workspace not uploaded for this size");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(b->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
+    CS_HIP(hipMemcpyAsync(b->Rs, d_Rs0, sizeof(double) * 9 * C, hipMemcpyDeviceToDevice, s));
+    CS_HIP(hipMemcpyAsync(b->Ts, d_Ts0, sizeof(double) * 3 * C, hipMemcpyDeviceToDevice, s));
+    if (P > 0) CS_HIP(hipMemcpyAsync(b->pts, d_pts0, sizeof(double) * 3 * P, hipMemcpyDeviceToDevice, s));
+    return ba_enqueue(b, s, C, P, nObs, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter);
+}
+
+int cs_ba_download(cs_ba* b, int C, int P, int nObs, double* Rs, double* Ts, double* pts, int* out_outlier,
+                   cs_ba_stats* stats) {
+    if (!b) return CS_ERR_INVALID;
+    CS_HIP(hipSetDevice(b->device));
+    CS_HIP(hipDeviceSynchronize());
+    if (Rs) CS_HIP(hipMemcpy(Rs, b->Rs, sizeof(double) * 9 * C, hipMemcpyDeviceToHost));
+    if (Ts) CS_HIP(hipMemcpy(Ts, b->Ts, sizeof(double) * 3 * C, hipMemcpyDeviceToHost));
+    if (pts && P > 0) CS_HIP(hipMemcpy(pts, b->pts, sizeof(double) * 3 * P, hipMemcpyDeviceToHost));
+    if (out_outlier && nObs > 0) CS_HIP(hipMemcpy(out_outlier, b->outlier, sizeof(int) * nObs, hipMemcpyDeviceToHost));
+    if (stats) CS_HIP(hipMemcpy(stats, b->stats, sizeof(cs_ba_stats), hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
+}  // extern "C"

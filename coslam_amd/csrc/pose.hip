@@ -1,0 +1,480 @@
+// pose.hip -- intraCamEstimate on gfx950: Tukey-IRLS around Levenberg-Marquardt, binary64.
+//
+// Replaces bool intraCamEstimate(...) (src/slam/SL_IntraCamPose.h:92-95, SL_IntraCamPose.cpp:626-709) and
+// the functions under it: intraCamWeightedLMProc (:475-549), intraCamWeightedLMStep (:259-303), the
+// forward-difference Jacobians (:43-117, eps = 1e-8), getSO3ExpMap (:10-39), intraCamUpdatePose (:367-380).
+//
+// Design: the whole estimate -- up to 5 re-weighting rounds x up to 100 LM steps -- is ONE launch of ONE
+// workgroup per camera (a batch of cameras = a grid of workgroups).  The reference is a serial loop
+// over <= 192 points with 7 projections each; here lane i owns point i, the 21+6 entries of the
+// weighted normal equations are folded with 64-lane butterflies and a 4-entry LDS exchange between the
+// waves, and every lane then runs the 6x6 Gauss-Jordan and the LM accept/reject logic redundantly on
+// identical inputs, so the control flow stays uniform with no host round trip per iteration.
+// The arithmetic per point is the reference's, operation for operation (numeric Jacobians included):
+// only the order of the sum over points differs from the serial CPU loop.
+#include "cs_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int PB = 256;  // threads per pose problem
+constexpr int NW = PB / 64;
+
+__device__ __forceinline__ void so3_exp(const double w[3], double R[9]) {  // SL_IntraCamPose.cpp:10-39
+    double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    if (theta == 0) {
+        R[0] = 1, R[1] = 0, R[2] = 0, R[3] = 0, R[4] = 1, R[5] = 0, R[6] = 0, R[7] = 0, R[8] = 1;
+        return;
+    }
+    double hw0 = w[0] / theta, hw1 = w[1] / theta, hw2 = w[2] / theta;
+    double st = sin(theta);
+    double ct = 1 - cos(theta);
+    double hw0hw0 = hw0 * hw0, hw0hw1 = hw0 * hw1, hw0hw2 = hw0 * hw2;
+    double hw1hw1 = hw1 * hw1, hw1hw2 = hw1 * hw2, hw2hw2 = hw2 * hw2;
+    R[0] = -ct * hw1hw1 - ct * hw2hw2 + 1;
+    R[1] = ct * hw0hw1 - st * hw2;
+    R[2] = st * hw1 + ct * hw0hw2;
+    R[3] = st * hw2 + ct * hw0hw1;
+    R[4] = -ct * hw0hw0 - ct * hw2hw2 + 1;
+    R[5] = ct * hw1hw2 - st * hw0;
+    R[6] = ct * hw0hw2 - st * hw1;
+    R[7] = st * hw0 + ct * hw1hw2;
+    R[8] = -ct * hw0hw0 - ct * hw1hw1 + 1;
+}
+
+__device__ __forceinline__ void mat33AB(const double* A, const double* B, double* C) {
+    double T[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) T[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) C[i] = T[i];
+}
+
+__device__ __forceinline__ void project(const double* K, const double* R, const double* t, const double* M, double* m) {
+    double X = R[0] * M[0] + R[1] * M[1] + R[2] * M[2] + t[0];
+    double Y = R[3] * M[0] + R[4] * M[1] + R[5] * M[2] + t[1];
+    double Z = R[6] * M[0] + R[7] * M[1] + R[8] * M[2] + t[2];
+    double u = K[0] * X + K[1] * Y + K[2] * Z;
+    double v = K[3] * X + K[4] * Y + K[5] * Z;
+    double w = K[6] * X + K[7] * Y + K[8] * Z;
+    m[0] = u / w;
+    m[1] = v / w;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// sum NV per-thread values over the workgroup; result identical in every thread
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* lds /* [NW][NV] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double s = wave_sum_d(v[q]);
+        if (lane == 0) lds[wv * NV + q] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        double s = lds[q];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += lds[w * NV + q];
+        v[q] = s;
+    }
+    __syncthreads();
+}
+
+// 6x6 inverse times vector by Gauss-Jordan with partial pivoting on [A | I] (the reference's matInv is LAPACK)
+__device__ void solve66(const double* sA, const double* sB, double* param) {
+    double M[6][12];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            M[i][j] = sA[6 * i + j];
+            M[i][6 + j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < 6; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 6; ++r)
+            if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+        if (piv != c)
+            for (int j = 0; j < 12; ++j) {
+                double tmp = M[c][j];
+                M[c][j] = M[piv][j];
+                M[piv][j] = tmp;
+            }
+        double d = M[c][c];
+        for (int j = 0; j < 12; ++j) M[c][j] /= d;
+        for (int r = 0; r < 6; ++r) {
+            if (r == c) continue;
+            double f = M[r][c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < 12; ++j) M[r][j] -= f * M[c][j];
+        }
+    }
+    for (int r = 0; r < 6; ++r) {
+        double s = 0;
+        for (int c = 0; c < 6; ++c) s += M[r][6 + c] * sB[c];
+        param[r] = s;
+    }
+}
+
+__device__ __forceinline__ double tukey(double e, double tau) {  // :646-653
+    if (e >= tau) return 0;
+    e /= tau;
+    e = 1 - e * e;
+    return e * e;
+}
+
+struct PoseCtx {
+    const double* K;
+    const double* Ms;
+    const double* ms;
+    double* Ws;  // LDS or global scratch, npts
+    int npts;
+    double* red;  // LDS [NW][27]
+};
+
+__device__ double reproj_err2_weighted(const PoseCtx& c, const double* R, const double* t) {  // :439-456
+    double e[1] = {0};
+    for (int i = threadIdx.x; i < c.npts; i += PB) {
+        double rm[2];
+        project(c.K, R, t, c.Ms + 3 * i, rm);
+        double dx = c.ms[2 * i] - rm[0], dy = c.ms[2 * i + 1] - rm[1];
+        e[0] += (dx * dx + dy * dy) * c.Ws[i];
+    }
+    block_sum<1>(e, c.red);
+    return e[0];
+}
+
+__device__ void weighted_lm_step(const PoseCtx& c, const double* R, const double* t, double* param, double lambda) {
+    const double eps = 1e-8;
+    // the perturbed rotations R * exp(eps e_k) do not depend on the point (:57-59)
+    double R1[3][9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double w[3] = {0, 0, 0}, dR[9];
+        w[a] = eps;
+        so3_exp(w, dR);
+        mat33AB(R, dR, R1[a]);
+    }
+    double acc[27];  // upper triangle of sA (21) + sB (6)
+#pragma unroll
+    for (int q = 0; q < 27; ++q) acc[q] = 0;
+    for (int i = threadIdx.x; i < c.npts; i += PB) {
+        const double* pM = c.Ms + 3 * i;
+        double rm0[2], rm[2], J[12];
+        project(c.K, R, t, pM, rm0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            project(c.K, R1[a], t, pM, rm);
+            J[a] = (rm[0] - rm0[0]) / eps;
+            J[6 + a] = (rm[1] - rm0[1]) / eps;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            double t1[3] = {t[0], t[1], t[2]};
+            t1[a] = t[a] + eps;
+            project(c.K, R, t1, pM, rm);
+            J[3 + a] = (rm[0] - rm0[0]) / eps;
+            J[9 + a] = (rm[1] - rm0[1]) / eps;
+        }
+        const double w = c.Ws[i];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) J[q] = w * J[q];
+        const double r0 = (-rm0[0] + c.ms[2 * i]) * w, r1 = (-rm0[1] + c.ms[2 * i + 1]) * w;
+        int q = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int cc = r; cc < 6; ++cc) acc[q++] += J[r] * J[cc] + J[6 + r] * J[6 + cc];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[21 + r] += J[r] * r0 + J[6 + r] * r1;
+    }
+    block_sum<27>(acc, c.red);
+    double sA[36], sB[6];
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int cc = r; cc < 6; ++cc) {
+            sA[6 * r + cc] = acc[q];
+            sA[6 * cc + r] = acc[q];
+            ++q;
+        }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        sB[r] = acc[21 + r];
+        sA[7 * r] += lambda;
+    }
+    solve66(sA, sB, param);
+}
+
+__device__ __forceinline__ void update_pose(const double* R, const double* t, const double* p, double* Rn, double* tn) {
+    double dR[9];
+    so3_exp(p, dR);
+    mat33AB(R, dR, Rn);
+    tn[0] = t[0] + p[3];
+    tn[1] = t[1] + p[4];
+    tn[2] = t[2] + p[5];
+}
+
+__device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0, double* R_opt, double* t_opt,
+                            cs_pose_option& opt) {  // :475-549
+    double param[6];
+    opt.npts = c.npts;
+    opt.lambda = opt.lambda0;
+    opt.err0 = reproj_err2_weighted(c, R0, t0);
+    opt.err = opt.err0;
+    double R[9], t[3], R_tmp[9], t_tmp[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = R_tmp[i] = R0[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = t_tmp[i] = t0[i];
+    opt.retTypeLM = 1;
+    int i = 0;
+    double err = opt.err0;
+    for (; i < opt.maxIterLM; ++i) {
+        weighted_lm_step(c, R, t, param, opt.lambda);
+        update_pose(R, t, param, R_opt, t_opt);
+        double p2 = param[0] * param[0] + param[1] * param[1] + param[2] * param[2] + param[3] * param[3] +
+                    param[4] * param[4] + param[5] * param[5];
+        if (p2 < opt.epsParamChangeLM) {
+            opt.retTypeLM = 0;
+            break;
+        }
+        err = reproj_err2_weighted(c, R_opt, t_opt);
+        if (fabs(err - opt.err) < opt.epsErrorChangeLM) {
+            opt.retTypeLM = 0;
+            break;
+        }
+        if (err <= opt.err) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) R[q] = R_tmp[q] = R_opt[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) t[q] = t_tmp[q] = t_opt[q];
+            opt.err = err;
+            opt.lambda /= 10;
+        } else {
+            opt.lambda *= 10;
+            if (opt.lambda > 1e+18) {
+                opt.retTypeLM = -1;
+                break;
+            }
+        }
+    }
+    if (opt.retTypeLM == -1) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) R_opt[q] = R_tmp[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) t_opt[q] = t_tmp[q];
+    }
+    opt.err = err;
+    opt.nIterLM = i;
+    return opt.retTypeLM >= 0;
+}
+
+__global__ __launch_bounds__(PB) void k_intracam(int ptsStride, const double* __restrict__ Kall,
+                                                 const double* __restrict__ R0all, const double* __restrict__ t0all,
+                                                 const int* __restrict__ nptsAll, const double* __restrict__ prevErrs,
+                                                 const double* __restrict__ MsAll, const double* __restrict__ msAll,
+                                                 double tau, double* __restrict__ RoptAll, double* __restrict__ toptAll,
+                                                 cs_pose_option* __restrict__ optAll, int* __restrict__ okAll,
+                                                 double* __restrict__ wsScratch) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int pb = blockIdx.x;
+    double* red = smem;            // [NW][27]
+    double* sK = smem + NW * 27;   // 9 (+3 pad)
+    double* WsL = sK + 12;         // npts (when it fits)
+    const int npts = nptsAll[pb];
+    if (threadIdx.x < 9) sK[threadIdx.x] = Kall[9 * pb + threadIdx.x];
+    PoseCtx c;
+    c.K = sK;
+    c.Ms = MsAll + (size_t)3 * ptsStride * pb;
+    c.ms = msAll + (size_t)2 * ptsStride * pb;
+    c.npts = npts;
+    c.red = red;
+    c.Ws = wsScratch ? (wsScratch + (size_t)ptsStride * pb) : WsL;
+    for (int i = threadIdx.x; i < npts; i += PB)
+        c.Ws[i] = prevErrs ? tukey(fabs(prevErrs[(size_t)ptsStride * pb + i]), tau) : 1.0;  // :641-655
+    __syncthreads();
+
+    cs_pose_option opt = optAll[pb];
+    double R[9], t[3], R_opt[9], t_opt[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = R_opt[i] = R0all[9 * pb + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = t_opt[i] = t0all[3 * pb + i];
+    bool ret = true;
+    int k = 0;
+    opt.errRW = -1;
+    for (; k < opt.maxIterRW; ++k) {  // :664
+        if (!weighted_lm(c, R, t, R_opt, t_opt, opt)) {
+            ret = false;
+            break;
+        }
+        opt.lambda0 = opt.lambda;
+        if (opt.errRW < 0) {
+            opt.errRW = opt.err;
+        } else {
+            if (fabs(opt.err - opt.errRW) < opt.epsErrorChangeRW) {
+                ret = true;
+                break;
+            }
+            opt.errRW = opt.err;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = R_opt[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = t_opt[i];
+        for (int i = threadIdx.x; i < npts; i += PB) {  // :687-701
+            double rm[2];
+            project(c.K, R, t, c.Ms + 3 * i, rm);
+            double dx = rm[0] - c.ms[2 * i], dy = rm[1] - c.ms[2 * i + 1];
+            c.Ws[i] = tukey(sqrt(dx * dx + dy * dy), tau);
+        }
+        __syncthreads();
+    }
+    opt.nIterRW = k;
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 9; ++i) RoptAll[9 * pb + i] = R_opt[i];
+        for (int i = 0; i < 3; ++i) toptAll[3 * pb + i] = t_opt[i];
+        optAll[pb] = opt;
+        okAll[pb] = ret ? 1 : 0;
+    }
+}
+
+constexpr int WS_LDS_MAX = 4096;  // points whose IRLS weights fit in LDS next to the reduction scratch
+
+struct PoseScratch {
+    int device = -1;
+    size_t cap = 0;  // points
+    double *d_K = nullptr, *d_R0 = nullptr, *d_t0 = nullptr, *d_Ms = nullptr, *d_ms = nullptr, *d_prev = nullptr,
+           *d_Ropt = nullptr, *d_topt = nullptr, *d_ws = nullptr;
+    int *d_npts = nullptr, *d_ok = nullptr;
+    cs_pose_option* d_opt = nullptr;
+    hipStream_t stream = nullptr;
+};
+thread_local PoseScratch g_ps;
+
+int ensure_scratch(int device, size_t npts) {
+    CS_HIP(hipSetDevice(device));
+    PoseScratch& s = g_ps;
+    if (s.device != device) {
+        s = PoseScratch();
+        s.device = device;
+        CS_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        CS_HIP(hipMalloc((void**)&s.d_K, 9 * 8));
+        CS_HIP(hipMalloc((void**)&s.d_R0, 9 * 8));
+        CS_HIP(hipMalloc((void**)&s.d_t0, 3 * 8));
+        CS_HIP(hipMalloc((void**)&s.d_Ropt, 9 * 8));
+        CS_HIP(hipMalloc((void**)&s.d_topt, 3 * 8));
+        CS_HIP(hipMalloc((void**)&s.d_npts, 4));
+        CS_HIP(hipMalloc((void**)&s.d_ok, 4));
+        CS_HIP(hipMalloc((void**)&s.d_opt, sizeof(cs_pose_option)));
+    }
+    if (npts > s.cap) {
+        size_t cap = npts < 1024 ? 1024 : npts;
+        if (s.d_Ms) {
+            (void)hipFree(s.d_Ms);
+            (void)hipFree(s.d_ms);
+            (void)hipFree(s.d_prev);
+            (void)hipFree(s.d_ws);
+        }
+        CS_HIP(hipMalloc((void**)&s.d_Ms, cap * 24));
+        CS_HIP(hipMalloc((void**)&s.d_ms, cap * 16));
+        CS_HIP(hipMalloc((void**)&s.d_prev, cap * 8));
+        CS_HIP(hipMalloc((void**)&s.d_ws, cap * 8));
+        s.cap = cap;
+    }
+    return CS_OK;
+}
+
+int launch_intracam(hipStream_t stream, int nProb, int ptsStride, const double* K, const double* R0, const double* t0,
+                    const int* npts, const double* prevErrs, const double* Ms, const double* ms, double tau,
+                    double* R_opt, double* t_opt, cs_pose_option* opt, int* ok, double* wsScratch) {
+    size_t lds = sizeof(double) * (NW * 27 + 12 + (wsScratch ? 0 : ptsStride));
+    hipLaunchKernelGGL(k_intracam, dim3(nProb), dim3(PB), lds, stream, ptsStride, K, R0, t0, npts, prevErrs, Ms, ms, tau,
+                       R_opt, t_opt, opt, ok, wsScratch);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void cs_pose_option_default(cs_pose_option* o) {  // SL_IntraCamPose.h:42-46
+    memset(o, 0, sizeof(*o));
+    o->maxIterLM = 100;
+    o->maxIterRW = 5;
+    o->epsErrorChangeLM = 1e-7;
+    o->epsParamChangeLM = 1e-6;
+    o->epsErrorChangeRW = 1e-6;
+    o->lambda0 = 1e-3;
+}
+
+int cs_pose_intracam(const double K[9], const double R0[9], const double t0[3], int npts, const double* prevErrs,
+                     const double* Ms, const double* ms, double tau, double R_opt[9], double t_opt[3],
+                     cs_pose_option* opt, int device) {
+    if (!K || !R0 || !t0 || npts < 0 || (npts > 0 && (!Ms || !ms)) || !R_opt || !t_opt || !opt) {
+        cs_set_error("cs_pose_intracam: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+        cs_set_error("cs_pose_intracam: no usable HIP device %d; there is no CPU fallback", device);
+        return CS_ERR_NO_DEVICE;
+    }
+    int rc = ensure_scratch(device, (size_t)npts);
+    if (rc) return rc;
+    PoseScratch& s = g_ps;
+    CS_HIP(hipMemcpyAsync(s.d_K, K, 72, hipMemcpyHostToDevice, s.stream));
+    CS_HIP(hipMemcpyAsync(s.d_R0, R0, 72, hipMemcpyHostToDevice, s.stream));
+    CS_HIP(hipMemcpyAsync(s.d_t0, t0, 24, hipMemcpyHostToDevice, s.stream));
+    CS_HIP(hipMemcpyAsync(s.d_npts, &npts, 4, hipMemcpyHostToDevice, s.stream));
+    CS_HIP(hipMemcpyAsync(s.d_opt, opt, sizeof(*opt), hipMemcpyHostToDevice, s.stream));
+    if (npts > 0) {
+        CS_HIP(hipMemcpyAsync(s.d_Ms, Ms, (size_t)npts * 24, hipMemcpyHostToDevice, s.stream));
+        CS_HIP(hipMemcpyAsync(s.d_ms, ms, (size_t)npts * 16, hipMemcpyHostToDevice, s.stream));
+        if (prevErrs) CS_HIP(hipMemcpyAsync(s.d_prev, prevErrs, (size_t)npts * 8, hipMemcpyHostToDevice, s.stream));
+    }
+    const int stride = npts > 0 ? npts : 1;
+    rc = launch_intracam(s.stream, 1, stride, s.d_K, s.d_R0, s.d_t0, s.d_npts, prevErrs ? s.d_prev : nullptr, s.d_Ms,
+                         s.d_ms, tau, s.d_Ropt, s.d_topt, s.d_opt, s.d_ok, stride > WS_LDS_MAX ? s.d_ws : nullptr);
+    if (rc) return rc;
+    int ok = 0;
+    CS_HIP(hipMemcpyAsync(R_opt, s.d_Ropt, 72, hipMemcpyDeviceToHost, s.stream));
+    CS_HIP(hipMemcpyAsync(t_opt, s.d_topt, 24, hipMemcpyDeviceToHost, s.stream));
+    CS_HIP(hipMemcpyAsync(opt, s.d_opt, sizeof(*opt), hipMemcpyDeviceToHost, s.stream));
+    CS_HIP(hipMemcpyAsync(&ok, s.d_ok, 4, hipMemcpyDeviceToHost, s.stream));
+    CS_HIP(hipStreamSynchronize(s.stream));
+    return ok;
+}
+
+int cs_pose_intracam_batch_dev(int device, void* hip_stream, int nProb, int ptsStride, const double* K,
+                               const double* R0, const double* t0, const int* npts, const double* prevErrs,
+                               const double* Ms, const double* ms, double tau, double* R_opt, double* t_opt,
+                               cs_pose_option* opt, int* ok) {
+    if (nProb <= 0 || ptsStride <= 0 || !K || !R0 || !t0 || !npts || !Ms || !ms || !R_opt || !t_opt || !opt || !ok) {
+        cs_set_error("cs_pose_intracam_batch_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (ptsStride > WS_LDS_MAX) {
+        cs_set_error("cs_pose_intracam_batch_dev: ptsStride %d > %d (weights must fit LDS in the batched form)", ptsStride,
+                     WS_LDS_MAX);
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(device));
+    return launch_intracam((hipStream_t)hip_stream, nProb, ptsStride, K, R0, t0, npts, prevErrs, Ms, ms, tau, R_opt, t_opt,
+                           opt, ok, nullptr);
+}
+
+}  // extern "C"

@@ -115,9 +115,75 @@ int cs_klt_read_features(cs_klt* k, float* host_out3);  /* what readFeatures() r
 int cs_klt_build_pyramid(cs_klt* k, const uint8_t* image); /* builds into _pyrCreator1 */
 
 /* ------------------------------------------------------------------------------------------
- * Intra-camera pose (src/slam/SL_IntraCamPose.h:92-95) and robust BA are declared in
- * coslam_pose.h / coslam_ba.h.
+ * Intra-camera pose: robust 6-DoF pose of one camera from 3D-2D correspondences
  * ------------------------------------------------------------------------------------------ */
+
+/* == class IntraCamPoseOption, src/slam/SL_IntraCamPose.h:19-57 (inputs and outputs, same names) */
+typedef struct cs_pose_option {
+    int maxIterLM, maxIterRW;                                    /* 100, 5 */
+    double epsErrorChangeLM, epsParamChangeLM, epsErrorChangeRW; /* 1e-7, 1e-6, 1e-6 */
+    int verboseLM, verboseRW;                                    /* ignored */
+    double lambda0, lambda;                                      /* 1e-3 in; both updated as the reference does */
+    double err0, err, errRW;
+    int retTypeLM, npts, nIterLM, nIterRW;
+} cs_pose_option;
+
+void cs_pose_option_default(cs_pose_option* opt); /* IntraCamPoseOption(), SL_IntraCamPose.h:42-46 */
+
+/* bool intraCamEstimate(K,R0,t0,npts,prevErrs,Ms,ms,tau,R_opt,t_opt,opt), src/slam/SL_IntraCamPose.h:92-95,
+ * SL_IntraCamPose.cpp:626-709.  Host pointers, row-major doubles, prevErrs may be NULL.
+ * Returns 1 (true), 0 (false: LM failed, as the reference) or a negative CS_ERR_* code. */
+int cs_pose_intracam(const double K[9], const double R0[9], const double t0[3], int npts, const double* prevErrs,
+                     const double* Ms, const double* ms, double tau, double R_opt[9], double t_opt[3],
+                     cs_pose_option* opt, int device);
+
+/* Batched, device-resident form: nProb independent cameras in one launch (one workgroup each), enqueued on
+ * hip_stream.  All pointers are device pointers.  Problem p reads K[9p..], R0[9p..], t0[3p..], npts[p],
+ * Ms[3*ptsStride*p ..], ms[2*ptsStride*p ..], prevErrs (NULL or ptsStride*p ..) and writes R_opt[9p..],
+ * t_opt[3p..], opt[p] (opt[p] must be initialised, e.g. with cs_pose_option_default), ok[p] in {0,1}. */
+int cs_pose_intracam_batch_dev(int device, void* hip_stream, int nProb, int ptsStride, const double* K,
+                               const double* R0, const double* t0, const int* npts, const double* prevErrs,
+                               const double* Ms, const double* ms, double tau, double* R_opt, double* t_opt,
+                               cs_pose_option* opt, int* ok);
+
+/* ------------------------------------------------------------------------------------------
+ * Robust multi-camera bundle adjustment
+ * ------------------------------------------------------------------------------------------ */
+
+typedef struct cs_ba_stats {
+    double cost0, cost; /* sum of squared inlier residuals before / after */
+    int nIterTotal, nOuter, nOutliers, pad;
+} cs_ba_stats;
+
+/* bundleAdjustRobust(int nCamsCon, vector<Mat_d>& Ks, vector<Mat_d>& Rs, vector<Mat_d>& Ts, int nPtsCon,
+ *                    vector<Point3d>& pts, vector<vector<Meas2D>>& meas, double maxErr, int maxIter, int innerMaxIter)
+ * -- external LibVisualSLAM geometry/SL_BundleAdjust.h; call sites src/app/SL_CoSLAMRobustBA.cpp:174,
+ * src/app/SL_InterCamPoseEstimator.cpp:95, src/app/SL_MergeCameraGroup.cpp:646-647.
+ * Flat form: Ks/Rs (C x 9, row-major), Ts (C x 3), pts (P x 3); meas[i] = measurements obs_ptr[i]..obs_ptr[i+1]
+ * with obs_cam = Meas2D::viewId and obs_xy = (Meas2D::x, Meas2D::y).  Rs, Ts, pts are updated in place (host
+ * memory); out_outlier[nObs] receives Meas2D::outlier (may be NULL); the first nCamsCon cameras and the first
+ * nPtsCon points are held fixed.  Returns CS_OK or a negative CS_ERR_* code. */
+int cs_ba_robust(int C, int P, int nObs, const double* Ks, double* Rs, double* Ts, double* pts, const int* obs_ptr,
+                 const int* obs_cam, const double* obs_xy, int nCamsCon, int nPtsCon, double maxErr, int maxIter,
+                 int innerMaxIter, int* out_outlier, cs_ba_stats* stats, int device);
+
+/* Workspace form: buffers stay allocated between calls; *_dev leaves inputs and results in HBM. */
+typedef struct cs_ba cs_ba;
+cs_ba* cs_ba_create(int device);
+void cs_ba_destroy(cs_ba* b);
+int cs_ba_robust_h(cs_ba* b, int C, int P, int nObs, const double* Ks, double* Rs, double* Ts, double* pts,
+                   const int* obs_ptr, const int* obs_cam, const double* obs_xy, int nCamsCon, int nPtsCon,
+                   double maxErr, int maxIter, int innerMaxIter, int* out_outlier, cs_ba_stats* stats);
+/* upload the problem (host pointers) into the workspace without solving */
+int cs_ba_upload(cs_ba* b, int C, int P, int nObs, const double* Ks, const double* Rs, const double* Ts,
+                 const double* pts, const int* obs_ptr, const int* obs_cam, const double* obs_xy);
+/* enqueue one full robust BA on hip_stream (NULL = the workspace's own stream) starting from the device-resident
+ * initial estimate d_Rs0/d_Ts0/d_pts0; no host synchronisation */
+int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const double* d_Rs0, const double* d_Ts0,
+                    const double* d_pts0, int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter);
+/* synchronise and copy the workspace's current estimate back (any pointer may be NULL) */
+int cs_ba_download(cs_ba* b, int C, int P, int nObs, double* Rs, double* Ts, double* pts, int* out_outlier,
+                   cs_ba_stats* stats);
 
 #ifdef __cplusplus
 }

@@ -206,3 +206,92 @@ class SequenceTracker:
         out = np.zeros((self.N, 3), dtype=np.float32)
         self._L.okl_seq_read_features(self._h, _p(out))
         return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# intra-camera pose (pose_oracle.c) and the reference's own code (oracle/_ref/libintracam_ref.so)
+class PoseOption(C.Structure):
+    _fields_ = [
+        ("maxIterLM", C.c_int), ("maxIterRW", C.c_int),
+        ("epsErrorChangeLM", C.c_double), ("epsParamChangeLM", C.c_double), ("epsErrorChangeRW", C.c_double),
+        ("verboseLM", C.c_int), ("verboseRW", C.c_int),
+        ("lambda0", C.c_double), ("lambda_", C.c_double),
+        ("err0", C.c_double), ("err", C.c_double), ("errRW", C.c_double),
+        ("retTypeLM", C.c_int), ("npts", C.c_int), ("nIterLM", C.c_int), ("nIterRW", C.c_int),
+    ]
+
+
+def _dd(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def intracam_estimate(K, R0, t0, npts, prevErrs, Ms, ms, tau):
+    """okp_intracam_estimate -> (ok, R[3,3], t[3], opt)"""
+    L = lib()
+    K, R0, t0, Ms, ms = _dd(K).ravel(), _dd(R0).ravel(), _dd(t0).ravel(), _dd(Ms).ravel(), _dd(ms).ravel()
+    pe = None if prevErrs is None else _dd(prevErrs).ravel()
+    R, t = np.zeros(9), np.zeros(3)
+    o = PoseOption()
+    L.okp_option_default(C.byref(o))
+    ok = L.okp_intracam_estimate(_p(K), _p(R0), _p(t0), int(npts), None if pe is None else _p(pe), _p(Ms), _p(ms),
+                                 C.c_double(tau), _p(R), _p(t), C.byref(o))
+    return bool(ok), R.reshape(3, 3), t, o
+
+
+_ref = None
+
+
+def have_ref():
+    return os.path.exists(REF_PATH)
+
+
+def ref_intracam_estimate(K, R0, t0, npts, prevErrs, Ms, ms, tau):
+    """The reference's own intraCamEstimate (SL_IntraCamPose.cpp compiled in place into oracle/_ref)."""
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(REF_PATH)
+    K, R0, t0, Ms, ms = _dd(K).ravel(), _dd(R0).ravel(), _dd(t0).ravel(), _dd(Ms).ravel(), _dd(ms).ravel()
+    pe = None if prevErrs is None else _dd(prevErrs).ravel()
+    R, t, st = np.zeros(9), np.zeros(3), np.zeros(8)
+    ok = _ref.ref_intraCamEstimate(_p(K), _p(R0), _p(t0), int(npts), None if pe is None else _p(pe), _p(Ms), _p(ms),
+                                   C.c_double(tau), _p(R), _p(t), _p(st))
+    stats = dict(err=st[0], errRW=st[1], lambda_=st[2], nIterLM=int(st[3]), nIterRW=int(st[4]), retTypeLM=int(st[5]),
+                 err0=st[6], lambda0=st[7])
+    return bool(ok), R.reshape(3, 3), t, stats
+
+
+# ---------------------------------------------------------------------------------------------------
+# robust bundle adjustment (ba_oracle.c)
+class BAStats(C.Structure):
+    _fields_ = [("cost0", C.c_double), ("cost", C.c_double), ("nIterTotal", C.c_int), ("nOuter", C.c_int),
+                ("nOutliers", C.c_int), ("pad", C.c_int)]
+
+
+def csr_by_point(P, obs_pt, obs_cam, obs_xy):
+    """Group measurements by point (stable): returns obs_ptr[P+1], obs_cam, obs_xy, order."""
+    obs_pt = np.asarray(obs_pt, dtype=np.int64)
+    order = np.argsort(obs_pt, kind="stable")
+    ptr = np.zeros(P + 1, dtype=np.int32)
+    np.add.at(ptr, obs_pt + 1, 1)
+    ptr = np.cumsum(ptr).astype(np.int32)
+    return ptr, np.ascontiguousarray(np.asarray(obs_cam, dtype=np.int32)[order]), \
+        np.ascontiguousarray(np.asarray(obs_xy, dtype=np.float64)[order]), order
+
+
+def ba_robust(Ks, Rs, Ts, pts, obs_ptr, obs_cam, obs_xy, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter):
+    """oba_robust on copies -> (Rs, Ts, pts, outlier, stats)"""
+    L = lib()
+    Cn, P = len(Rs), len(pts)
+    Ks = _dd(Ks).reshape(Cn, 9)
+    Rs = _dd(Rs).reshape(Cn, 9).copy()
+    Ts = _dd(Ts).reshape(Cn, 3).copy()
+    pts = _dd(pts).reshape(P, 3).copy()
+    obs_ptr = np.ascontiguousarray(obs_ptr, dtype=np.int32)
+    obs_cam = np.ascontiguousarray(obs_cam, dtype=np.int32)
+    obs_xy = _dd(obs_xy)
+    n = len(obs_cam)
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    st = BAStats()
+    L.oba_robust(Cn, P, n, _p(Ks), _p(Rs), _p(Ts), _p(pts), _p(obs_ptr), _p(obs_cam), _p(obs_xy), int(nCamsCon),
+                 int(nPtsCon), C.c_double(maxErr), int(maxIter), int(innerMaxIter), _p(out), C.byref(st))
+    return Rs.reshape(Cn, 3, 3), Ts, pts, out[:n], st

@@ -1,0 +1,115 @@
+"""GPU parity of the pose solve and the robust BA against the oracle (binary64 on both sides).
+Tolerances: rel 1e-9 when the iteration paths coincide; 1e-6 is the hard bound, because the
+GPU folds sums in a different order than the serial CPU loop and LM stop tests can fire one step apart."""
+import numpy as np
+import pytest
+
+import coslam_amd
+import oracle
+from coslam_amd.synth import Scene, make_ba_problem, rodrigues
+
+pytestmark = pytest.mark.gpu
+
+
+def pose_problem(seed, npts=192, noise=0.5, n_out=10, frame=3):
+    rng = np.random.default_rng(seed)
+    sc = Scene(1, 640, 480, 3000, seed=100 + seed)
+    R, t = sc.pose(0, frame)
+    uv, vis = sc.project(0, frame)
+    idx = np.nonzero(vis)[0][:npts]
+    Ms = np.ascontiguousarray(sc.points[idx])
+    ms = uv[idx] + noise * rng.standard_normal((len(idx), 2))
+    ms[:n_out] += 30 * rng.standard_normal((n_out, 2))
+    R0 = R @ rodrigues(0.01 * rng.standard_normal(3))
+    t0 = t + 0.03 * rng.standard_normal(3)
+    return sc.K, R0, t0, Ms, np.ascontiguousarray(ms), R, t
+
+
+@pytest.mark.parametrize("seed,npts", [(0, 192), (1, 192), (2, 64), (3, 7), (4, 1000), (5, 5000)])
+def test_intracam_matches_oracle(hip, seed, npts):
+    K, R0, t0, Ms, ms, Rgt, tgt = pose_problem(seed, npts, n_out=min(10, npts // 4))
+    n = len(Ms)
+    ok_g, R_g, t_g, o_g = coslam_amd.intraCamEstimate(K, R0, t0, n, None, Ms, ms, 10.0)
+    ok_o, R_o, t_o, o_o = oracle.intracam_estimate(K, R0, t0, n, None, Ms, ms, 10.0)
+    assert ok_g == ok_o
+    assert np.max(np.abs(R_g - R_o)) < 1e-6 and np.max(np.abs(t_g - t_o)) < 1e-6
+    if o_g.nIterRW == o_o.nIterRW and o_g.nIterLM == o_o.nIterLM:
+        assert np.max(np.abs(R_g - R_o)) < 1e-9 and np.max(np.abs(t_g - t_o)) < 1e-8
+        assert abs(o_g.err - o_o.err) <= 1e-9 * max(1.0, abs(o_o.err))
+    assert np.allclose(R_g @ R_g.T, np.eye(3), atol=1e-9)
+
+
+def test_intracam_with_prev_errors_and_failure_modes(hip):
+    K, R0, t0, Ms, ms, _, _ = pose_problem(7, 100)
+    prev = np.abs(np.random.default_rng(1).standard_normal(100)) * 6
+    ok_g, R_g, t_g, _ = coslam_amd.intraCamEstimate(K, R0, t0, 100, prev, Ms, ms, 10.0)
+    ok_o, R_o, t_o, _ = oracle.intracam_estimate(K, R0, t0, 100, prev, Ms, ms, 10.0)
+    assert ok_g == ok_o and np.max(np.abs(R_g - R_o)) < 1e-6 and np.max(np.abs(t_g - t_o)) < 1e-6
+    # noise-free: recovers the true pose
+    K, R0, t0, Ms, ms, Rgt, tgt = pose_problem(9, 150, noise=0.0, n_out=0)
+    ok, R, t, _ = coslam_amd.intraCamEstimate(K, R0, t0, 150, None, Ms, ms, 10.0)
+    assert ok and np.max(np.abs(R - Rgt)) < 1e-6 and np.max(np.abs(t - tgt)) < 1e-5
+
+
+def ba_inputs(**kw):
+    pr = make_ba_problem(**kw)
+    P = len(pr["pts0"])
+    ptr, cam, xy, _ = oracle.csr_by_point(P, pr["obs_pt"], pr["obs_cam"], pr["obs_xy"])
+    return pr, ptr, cam, xy
+
+
+@pytest.mark.parametrize("kw,ncon,npcon,maxIter,inner", [
+    (dict(), 2, 2, 2, 10),                                  # cfg1: the queued local BA call (SL_CoSLAM.cpp:1769)
+    (dict(), 2, 2, 5, 50),                                  # the initial-map call (SL_CoSLAM.cpp:276)
+    (dict(noise=0.0, outlier_frac=0.0), 2, 2, 2, 30),       # noise-free: exact recovery
+    (dict(n_cams=3, n_pts=200, n_cams_con=0, n_pts_con=140, seed=5), 0, 140, 3, 40),  # inter-camera pose shape
+    (dict(n_cams=15, n_pts=800, visibility=0.6, seed=9), 6, 2, 2, 10),                 # 3 cams x 5 KF, ragged tracks
+])
+def test_ba_matches_oracle(hip, kw, ncon, npcon, maxIter, inner):
+    kw = dict(kw)
+    kw.setdefault("n_cams_con", ncon)
+    kw.setdefault("n_pts_con", npcon)
+    pr, ptr, cam, xy = ba_inputs(**kw)
+    Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+    out_g, st_g = coslam_amd.bundleAdjustRobust(ncon, pr["Ks"], Rs, Ts, npcon, pts, (ptr, cam, xy), 6.0, maxIter, inner)
+    R_o, T_o, M_o, out_o, st_o = oracle.ba_robust(pr["Ks"], pr["Rs0"], pr["ts0"], pr["pts0"], ptr, cam, xy, ncon,
+                                                  npcon, 6.0, maxIter, inner)
+    assert np.array_equal(out_g, out_o), f"{(out_g != out_o).sum()} outlier flags differ"
+    assert st_g.nOuter == st_o.nOuter
+    scale = max(1.0, np.abs(M_o).max())
+    assert np.max(np.abs(Rs - R_o)) < 1e-6
+    assert np.max(np.abs(Ts - T_o)) < 1e-6 * scale
+    assert np.max(np.abs(pts - M_o)) < 1e-6 * scale
+    assert abs(st_g.cost - st_o.cost) <= 1e-7 * max(1.0, st_o.cost)
+    if kw.get("noise", 0.5) == 0.0:
+        assert st_g.cost < 1e-12 and np.max(np.abs(pts - pr["pts_gt"])) < 1e-8
+
+
+def test_ba_edge_cases(hip):
+    # all cameras fixed: structure-only refinement
+    pr, ptr, cam, xy = ba_inputs(n_cams=4, n_pts=50, n_cams_con=4, n_pts_con=0, outlier_frac=0.0)
+    Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+    out, st = coslam_amd.bundleAdjustRobust(4, pr["Ks"], Rs, Ts, 0, pts, (ptr, cam, xy), 6.0, 2, 20)
+    R_o, T_o, M_o, out_o, st_o = oracle.ba_robust(pr["Ks"], pr["Rs0"], pr["ts0"], pr["pts0"], ptr, cam, xy, 4, 0, 6.0, 2, 20)
+    assert np.array_equal(Rs, pr["Rs0"]) and np.max(np.abs(pts - M_o)) < 1e-6
+    # a point with no measurement and one with a single measurement must not break anything
+    pr, ptr, cam, xy = ba_inputs(n_cams=5, n_pts=60, outlier_frac=0.0, seed=3)
+    keep = np.ones(len(cam), bool)
+    keep[ptr[10]:ptr[11]] = False
+    keep[ptr[20] + 1:ptr[21]] = False
+    obs_pt = np.repeat(np.arange(60), np.diff(ptr))[keep]
+    ptr2, cam2, xy2, _ = oracle.csr_by_point(60, obs_pt, cam[keep], xy[keep])
+    Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+    out, st = coslam_amd.bundleAdjustRobust(2, pr["Ks"], Rs, Ts, 2, pts, (ptr2, cam2, xy2), 6.0, 2, 10)
+    R_o, T_o, M_o, out_o, _ = oracle.ba_robust(pr["Ks"], pr["Rs0"], pr["ts0"], pr["pts0"], ptr2, cam2, xy2, 2, 2, 6.0, 2, 10)
+    assert np.all(np.isfinite(pts)) and np.max(np.abs(pts - M_o)) < 1e-6 and np.array_equal(out, out_o)
+    # nested-list (vector<vector<Meas2D>>) form gives the same answer as the flat form
+    meas = [[(int(cam2[o]), float(xy2[o, 0]), float(xy2[o, 1])) for o in range(ptr2[i], ptr2[i + 1])] for i in range(60)]
+    Rs2, Ts2, pts2 = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+    coslam_amd.bundleAdjustRobust(2, pr["Ks"], Rs2, Ts2, 2, pts2, meas, 6.0, 2, 10)
+    assert np.array_equal(pts2, pts)
+    # bad view id -> error, not a crash
+    bad = cam2.copy()
+    bad[0] = 99
+    with pytest.raises(coslam_amd.CoslamHipError):
+        coslam_amd.bundleAdjustRobust(2, pr["Ks"], Rs2, Ts2, 2, pts2, (ptr2, bad, xy2), 6.0, 1, 1)
