@@ -159,7 +159,12 @@ __global__ __launch_bounds__(256) void k_linearize(BaDev D) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= D.P) return;
     const int o0 = D.obs_ptr[i], o1 = D.obs_ptr[i + 1];
-    const bool freeP = (i >= D.nPtsCon);
+    int nIn = 0;
+    for (int o = o0 + lane; o < o1; o += 64) nIn += D.outlier[o] ? 0 : 1;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) nIn += __shfl_xor(nIn, m, 64);
+    // a point seen by fewer than two inlier measurements has no depth constraint: hold it (oracle/ba_oracle.c)
+    const bool freeP = (i >= D.nPtsCon) && (nIn >= 2);
     const double lambda = D.st->lambda;
     const double M[3] = {D.pts[3 * i], D.pts[3 * i + 1], D.pts[3 * i + 2]};
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // V upper (6) + g (3)

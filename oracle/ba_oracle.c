@@ -14,6 +14,7 @@
  *   src/slam/SL_IntraCamPose.cpp:367-380) and points i >= nPtsCon (M_i <- M_i + dM), K fixed;
  *   outer loop (<= maxIter): Levenberg-Marquardt with the point blocks eliminated by Schur complement
  *   (<= innerMaxIter steps, lambda0 = 1e-3, x10 on reject / /10 on accept, additive damping lambda*I),
+ *   (a free point with fewer than two inlier measurements is held for that run: its depth is unconstrained),
  *   then every measurement with reprojection error > maxErr is flagged outlier (Meas2D::outlier = 1,
  *   consumed at SL_CoSLAMRobustBA.cpp:298-306) and leaves the next round; stop when the flags no longer
  *   change.  Jacobians are analytic; everything is binary64.
@@ -184,7 +185,10 @@ static int lm_run(const prob_t* p, double* Rs, double* Ts, double* pts, const in
         /* linearise: U_j, V_i, W_ij, gradients */
         for (int i = 0; i < P; ++i) {
             double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-            int freeP = (i >= p->nPtsCon);
+            int nIn = 0;
+            for (int o = p->obs_ptr[i]; o < p->obs_ptr[i + 1]; ++o) nIn += outlier[o] ? 0 : 1;
+            /* a point seen by fewer than two inlier measurements has no depth constraint: hold it */
+            int freeP = (i >= p->nPtsCon) && (nIn >= 2);
             for (int o = p->obs_ptr[i]; o < p->obs_ptr[i + 1]; ++o) {
                 memset(W + 18 * o, 0, sizeof(double) * 18);
                 if (outlier[o]) continue;
