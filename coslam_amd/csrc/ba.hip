@@ -52,11 +52,7 @@ struct BaDev {
     int innerMaxIter;
 };
 
-__device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
+__device__ __forceinline__ double wsum(double v) { return cs_wave_sum_d(v); }
 
 __device__ __forceinline__ void so3_exp(const double w[3], double R[9]) {
     double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
@@ -161,8 +157,7 @@ __global__ __launch_bounds__(256) void k_linearize(BaDev D) {
     const int o0 = D.obs_ptr[i], o1 = D.obs_ptr[i + 1];
     int nIn = 0;
     for (int o = o0 + lane; o < o1; o += 64) nIn += D.outlier[o] ? 0 : 1;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) nIn += __shfl_xor(nIn, m, 64);
+    nIn = cs_wave_sum_i(nIn);
     // a point seen by fewer than two inlier measurements has no depth constraint: hold it (oracle/ba_oracle.c)
     const bool freeP = (i >= D.nPtsCon) && (nIn >= 2);
     const double lambda = D.st->lambda;

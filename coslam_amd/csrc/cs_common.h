@@ -86,11 +86,56 @@ __device__ __forceinline__ void cs_unpack_texel(cs_texel t, float& I, float& Ix,
     Iy = cs_h2f((unsigned short)(t.y & 0xffffu));
 }
 
-// butterfly all-reduce over the 64 lanes of a wave
+// ---- wave64 reductions on the DPP data path (no LDS crossbar, no ds_bpermute) -----------------------
+// quad_perm xor1, quad_perm xor2, row_half_mirror, row_mirror fold each 16-lane row; row_bcast15 / row_bcast31
+// (gfx9 DPP controls 0x142 / 0x143) carry the row totals forward so that lane 63 holds the wave total, which
+// v_readlane then broadcasts through an SGPR: the result is wave-uniform and the order of additions is fixed.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int cs_dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float cs_dpp_f(float v) {
+    return __int_as_float(cs_dpp_i<CTRL, ROW_MASK>(__float_as_int(v)));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double cs_dpp_d(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = cs_dpp_i<CTRL, ROW_MASK>(lo);
+    hi = cs_dpp_i<CTRL, ROW_MASK>(hi);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ float cs_wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v += cs_dpp_f<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += cs_dpp_f<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += cs_dpp_f<0x141, 0xf>(v);  // row_half_mirror
+    v += cs_dpp_f<0x140, 0xf>(v);  // row_mirror
+    v += cs_dpp_f<0x142, 0xa>(v);  // row_bcast15 -> rows 1,3
+    v += cs_dpp_f<0x143, 0xc>(v);  // row_bcast31 -> rows 2,3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ double cs_wave_sum_d(double v) {
+    v += cs_dpp_d<0xB1, 0xf>(v);
+    v += cs_dpp_d<0x4E, 0xf>(v);
+    v += cs_dpp_d<0x141, 0xf>(v);
+    v += cs_dpp_d<0x140, 0xf>(v);
+    v += cs_dpp_d<0x142, 0xa>(v);
+    v += cs_dpp_d<0x143, 0xc>(v);
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int cs_wave_sum_i(int v) {
+    v += cs_dpp_i<0xB1, 0xf>(v);
+    v += cs_dpp_i<0x4E, 0xf>(v);
+    v += cs_dpp_i<0x141, 0xf>(v);
+    v += cs_dpp_i<0x140, 0xf>(v);
+    v += cs_dpp_i<0x142, 0xa>(v);
+    v += cs_dpp_i<0x143, 0xc>(v);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 #endif  // __HIPCC__

@@ -4,8 +4,8 @@
 // v3d_gpuklt.cpp:592-889).  The feature-buffer and pyramid "pointer swaps" of the reference
 // (_featuresBuffer0/1/2, _pyrCreator0/1) are modelled one to one, so every call sequence -- including
 // the odd ones (track without redetect, feed + advance) -- evolves the same state as the reference.
-#include <mutex>
 #include <new>
+#include <vector>
 
 #include "klt_internal.h"
 
@@ -70,6 +70,16 @@ struct cs_klt {
     cs_klt_feature* h_dest;  // pinned
     int* h_counts;           // pinned
     float* h_feat;           // pinned
+    // hipGraph cache for the *_dev entry points: one executable graph per (call, buffer rotation state)
+    bool use_graphs;
+    struct GraphEntry {
+        int mode, b0, b1, b2, p0, p1;
+        const void* img;
+        void *dest, *counts;
+        int post_b0, post_b1, post_b2, post_p0, post_p1;
+        hipGraphExec_t exec;
+    };
+    std::vector<GraphEntry>* graphs;
 };
 
 #define CS_REQUIRE(cond, msg)      \
@@ -83,6 +93,12 @@ struct cs_klt {
 static int bind_device(cs_klt* k) {
     CS_HIP(hipSetDevice(k->device));
     return CS_OK;
+}
+
+static void drop_graphs(cs_klt* k) {
+    if (!k->graphs) return;
+    for (auto& g : *k->graphs) (void)hipGraphExecDestroy(g.exec);
+    k->graphs->clear();
 }
 
 static float* read_buffer(cs_klt* k) {  // readFeatures / readFeaturesAndGain, v3d_gpuklt.cpp:94-97,199-203
@@ -271,6 +287,7 @@ cs_klt* cs_klt_create(const cs_klt_config* cfg, int device, int tap_mode) {
         return nullptr;
     }
     k->stream = k->own_stream;
+    k->graphs = new std::vector<cs_klt::GraphEntry>();
     return k;
 }
 
@@ -280,6 +297,7 @@ int cs_klt_deallocate(cs_klt* k) {
     int rc = bind_device(k);
     if (rc) return rc;
     hipStreamSynchronize(k->stream);
+    drop_graphs(k);
     hipFree(k->d_img);
     hipFree(k->d_pyr[0]);
     hipFree(k->d_pyr[1]);
@@ -303,6 +321,8 @@ int cs_klt_deallocate(cs_klt* k) {
 void cs_klt_destroy(cs_klt* k) {
     if (!k) return;
     cs_klt_deallocate(k);
+    delete k->graphs;
+    k->graphs = nullptr;
     hipSetDevice(k->device);
     hipStreamDestroy(k->own_stream);
     delete k;
@@ -419,23 +439,96 @@ int cs_klt_advance(cs_klt* k) {  // v3d_gpuklt.h:252-259
 }
 
 // ---- device-resident entry points ----------------------------------------------------------------
+// The frame schedule is ~60 short kernels; replayed from a hipGraph the host cost per frame is one launch.
+// The three feature buffers and two pyramids rotate from call to call (period <= 6), so the cache is keyed by
+// the rotation state; the graph reads the image from the handle's own staging buffer.
+static int run_dev(cs_klt* k, int mode, const void* d_image, void* d_dest, void* d_counts) {
+    auto enqueue = [&](const uint8_t* img) -> int {
+        if (mode == 0) return enqueue_detect(k, img, (cs_klt_feature*)d_dest, (int*)d_counts, 0);
+        if (mode == 1) return enqueue_redetect(k, img, (cs_klt_feature*)d_dest, (int*)d_counts);
+        return enqueue_track(k, img, (cs_klt_feature*)d_dest, (int*)d_counts, false);
+    };
+    if (!k->use_graphs) return enqueue((const uint8_t*)d_image);
+    CS_HIP(hipMemcpyAsync(k->d_img, d_image, (size_t)k->W * k->H, hipMemcpyDeviceToDevice, k->stream));
+    for (auto& g : *k->graphs) {
+        if (g.mode == mode && g.b0 == k->b0 && g.b1 == k->b1 && g.b2 == k->b2 && g.p0 == k->p0 && g.p1 == k->p1 &&
+            g.dest == d_dest && g.counts == d_counts) {
+            CS_HIP(hipGraphLaunch(g.exec, k->stream));
+            k->b0 = g.post_b0;
+            k->b1 = g.post_b1;
+            k->b2 = g.post_b2;
+            k->p0 = g.post_p0;
+            k->p1 = g.post_p1;
+            return CS_OK;
+        }
+    }
+    cs_klt::GraphEntry g;
+    g.mode = mode;
+    g.b0 = k->b0;
+    g.b1 = k->b1;
+    g.b2 = k->b2;
+    g.p0 = k->p0;
+    g.p1 = k->p1;
+    g.img = k->d_img;
+    g.dest = d_dest;
+    g.counts = d_counts;
+    CS_HIP(hipStreamBeginCapture(k->stream, hipStreamCaptureModeRelaxed));
+    int rc = enqueue(k->d_img);
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(k->stream, &graph);
+    if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    if (e != hipSuccess) {
+        cs_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        return CS_ERR_HIP;
+    }
+    e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        cs_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        return CS_ERR_HIP;
+    }
+    g.post_b0 = k->b0;
+    g.post_b1 = k->b1;
+    g.post_b2 = k->b2;
+    g.post_p0 = k->p0;
+    g.post_p1 = k->p1;
+    k->graphs->push_back(g);
+    CS_HIP(hipGraphLaunch(g.exec, k->stream));
+    return CS_OK;
+}
+
+int cs_klt_enable_graphs(cs_klt* k, int on) {
+    CS_REQUIRE(k, "null handle");
+    k->use_graphs = on != 0;
+    if (!on && k->allocated) {
+        int rc = bind_device(k);
+        if (rc) return rc;
+        CS_HIP(hipStreamSynchronize(k->stream));
+        drop_graphs(k);
+    }
+    return CS_OK;
+}
+
 int cs_klt_detect_dev(cs_klt* k, const void* d_image, void* d_dest, void* d_counts) {
     CS_REQUIRE(k && k->allocated && d_image && d_dest && d_counts, "cs_klt_detect_dev: bad arguments");
     int rc = bind_device(k);
     if (rc) return rc;
-    return enqueue_detect(k, (const uint8_t*)d_image, (cs_klt_feature*)d_dest, (int*)d_counts, 0);
+    return run_dev(k, 0, d_image, d_dest, d_counts);
 }
 int cs_klt_redetect_dev(cs_klt* k, const void* d_image, void* d_dest, void* d_counts) {
     CS_REQUIRE(k && k->allocated && d_image && d_dest && d_counts, "cs_klt_redetect_dev: bad arguments");
     int rc = bind_device(k);
     if (rc) return rc;
-    return enqueue_redetect(k, (const uint8_t*)d_image, (cs_klt_feature*)d_dest, (int*)d_counts);
+    return run_dev(k, 1, d_image, d_dest, d_counts);
 }
 int cs_klt_track_dev(cs_klt* k, const void* d_image, void* d_dest, void* d_counts) {
     CS_REQUIRE(k && k->allocated && d_image && d_dest && d_counts, "cs_klt_track_dev: bad arguments");
     int rc = bind_device(k);
     if (rc) return rc;
-    return enqueue_track(k, (const uint8_t*)d_image, (cs_klt_feature*)d_dest, (int*)d_counts, false);
+    return run_dev(k, 2, d_image, d_dest, d_counts);
 }
 
 // ---- reference-shaped host entry points ---------------------------------------------------------

@@ -18,8 +18,8 @@
 
 namespace {
 
-constexpr int PB = 256;  // threads per pose problem
-constexpr int NW = PB / 64;
+constexpr int WS_LDS_MAX = 4096;  // points whose IRLS weights fit in LDS next to the reduction scratch
+constexpr int SMALL_NPTS = 256;   // up to here ONE wave owns the problem: no LDS exchange, no barrier
 
 __device__ __forceinline__ void so3_exp(const double w[3], double R[9]) {  // SL_IntraCamPose.cpp:10-39
     double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
@@ -64,20 +64,17 @@ __device__ __forceinline__ void project(const double* K, const double* R, const 
     m[1] = v / w;
 }
 
-__device__ __forceinline__ double wave_sum_d(double v) {
+// sum NV per-thread values over the workgroup (PB threads); result identical in every thread
+template <int PB, int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* lds /* [PB/64][NV] */) {
+    constexpr int NW = PB / 64;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
-
-// sum NV per-thread values over the workgroup; result identical in every thread
-template <int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double* lds /* [NW][NV] */) {
+    for (int q = 0; q < NV; ++q) v[q] = cs_wave_sum_d(v[q]);
+    if (NW == 1) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
 #pragma unroll
-    for (int q = 0; q < NV; ++q) {
-        double s = wave_sum_d(v[q]);
-        if (lane == 0) lds[wv * NV + q] = s;
+        for (int q = 0; q < NV; ++q) lds[wv * NV + q] = v[q];
     }
     __syncthreads();
 #pragma unroll
@@ -90,40 +87,42 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* lds /* [NW][N
     __syncthreads();
 }
 
-// 6x6 inverse times vector by Gauss-Jordan with partial pivoting on [A | I] (the reference's matInv is LAPACK)
-__device__ void solve66(const double* sA, const double* sB, double* param) {
-    double M[6][12];
+// (A + lambda I) p = B by Gauss-Jordan elimination with partial pivoting on [A | B], fully unrolled so that the
+// 42 entries stay in registers (the reference forms the LAPACK inverse and multiplies: same solution, and the
+// pivot row at every step is the same row -- the largest remaining entry of the column).
+__device__ __forceinline__ void solve66(const double* sA, const double* sB, double* param) {
+    double M[6][7];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 6; ++i) {
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            M[i][j] = sA[6 * i + j];
-            M[i][6 + j] = (i == j) ? 1.0 : 0.0;
-        }
+        for (int j = 0; j < 6; ++j) M[i][j] = sA[6 * i + j];
+        M[i][6] = sB[i];
+    }
+#pragma unroll
     for (int c = 0; c < 6; ++c) {
-        int piv = c;
-        for (int r = c + 1; r < 6; ++r)
-            if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
-        if (piv != c)
-            for (int j = 0; j < 12; ++j) {
-                double tmp = M[c][j];
-                M[c][j] = M[piv][j];
-                M[piv][j] = tmp;
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) {
+            const bool sw = fabs(M[r][c]) > fabs(M[c][c]);
+#pragma unroll
+            for (int j = c; j < 7; ++j) {
+                const double x = M[c][j], y = M[r][j];
+                M[c][j] = sw ? y : x;
+                M[r][j] = sw ? x : y;
             }
-        double d = M[c][c];
-        for (int j = 0; j < 12; ++j) M[c][j] /= d;
+        }
+        const double d = M[c][c];
+#pragma unroll
+        for (int j = c + 1; j < 7; ++j) M[c][j] /= d;
+#pragma unroll
         for (int r = 0; r < 6; ++r) {
             if (r == c) continue;
-            double f = M[r][c];
-            if (f == 0.0) continue;
-            for (int j = 0; j < 12; ++j) M[r][j] -= f * M[c][j];
+            const double f = M[r][c];
+#pragma unroll
+            for (int j = c + 1; j < 7; ++j) M[r][j] -= f * M[c][j];
         }
     }
-    for (int r = 0; r < 6; ++r) {
-        double s = 0;
-        for (int c = 0; c < 6; ++c) s += M[r][6 + c] * sB[c];
-        param[r] = s;
-    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) param[r] = M[r][6];
 }
 
 __device__ __forceinline__ double tukey(double e, double tau) {  // :646-653
@@ -139,9 +138,11 @@ struct PoseCtx {
     const double* ms;
     double* Ws;  // LDS or global scratch, npts
     int npts;
-    double* red;  // LDS [NW][27]
+    double* red;          // LDS [PB/64][27]
+    double dR[3][9];      // exp(eps e_k): independent of the iterate (SL_IntraCamPose.cpp:57-58)
 };
 
+template <int PB>
 __device__ double reproj_err2_weighted(const PoseCtx& c, const double* R, const double* t) {  // :439-456
     double e[1] = {0};
     for (int i = threadIdx.x; i < c.npts; i += PB) {
@@ -150,21 +151,17 @@ __device__ double reproj_err2_weighted(const PoseCtx& c, const double* R, const 
         double dx = c.ms[2 * i] - rm[0], dy = c.ms[2 * i + 1] - rm[1];
         e[0] += (dx * dx + dy * dy) * c.Ws[i];
     }
-    block_sum<1>(e, c.red);
+    block_sum<PB, 1>(e, c.red);
     return e[0];
 }
 
+template <int PB>
 __device__ void weighted_lm_step(const PoseCtx& c, const double* R, const double* t, double* param, double lambda) {
     const double eps = 1e-8;
     // the perturbed rotations R * exp(eps e_k) do not depend on the point (:57-59)
     double R1[3][9];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        double w[3] = {0, 0, 0}, dR[9];
-        w[a] = eps;
-        so3_exp(w, dR);
-        mat33AB(R, dR, R1[a]);
-    }
+    for (int a = 0; a < 3; ++a) mat33AB(R, c.dR[a], R1[a]);
     double acc[27];  // upper triangle of sA (21) + sB (6)
 #pragma unroll
     for (int q = 0; q < 27; ++q) acc[q] = 0;
@@ -198,7 +195,7 @@ __device__ void weighted_lm_step(const PoseCtx& c, const double* R, const double
 #pragma unroll
         for (int r = 0; r < 6; ++r) acc[21 + r] += J[r] * r0 + J[6 + r] * r1;
     }
-    block_sum<27>(acc, c.red);
+    block_sum<PB, 27>(acc, c.red);
     double sA[36], sB[6];
     int q = 0;
 #pragma unroll
@@ -226,12 +223,13 @@ __device__ __forceinline__ void update_pose(const double* R, const double* t, co
     tn[2] = t[2] + p[5];
 }
 
+template <int PB>
 __device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0, double* R_opt, double* t_opt,
                             cs_pose_option& opt) {  // :475-549
     double param[6];
     opt.npts = c.npts;
     opt.lambda = opt.lambda0;
-    opt.err0 = reproj_err2_weighted(c, R0, t0);
+    opt.err0 = reproj_err2_weighted<PB>(c, R0, t0);
     opt.err = opt.err0;
     double R[9], t[3], R_tmp[9], t_tmp[3];
 #pragma unroll
@@ -242,7 +240,7 @@ __device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0
     int i = 0;
     double err = opt.err0;
     for (; i < opt.maxIterLM; ++i) {
-        weighted_lm_step(c, R, t, param, opt.lambda);
+        weighted_lm_step<PB>(c, R, t, param, opt.lambda);
         update_pose(R, t, param, R_opt, t_opt);
         double p2 = param[0] * param[0] + param[1] * param[1] + param[2] * param[2] + param[3] * param[3] +
                     param[4] * param[4] + param[5] * param[5];
@@ -250,7 +248,7 @@ __device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0
             opt.retTypeLM = 0;
             break;
         }
-        err = reproj_err2_weighted(c, R_opt, t_opt);
+        err = reproj_err2_weighted<PB>(c, R_opt, t_opt);
         if (fabs(err - opt.err) < opt.epsErrorChangeLM) {
             opt.retTypeLM = 0;
             break;
@@ -281,6 +279,7 @@ __device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0
     return opt.retTypeLM >= 0;
 }
 
+template <int PB>
 __global__ __launch_bounds__(PB) void k_intracam(int ptsStride, const double* __restrict__ Kall,
                                                  const double* __restrict__ R0all, const double* __restrict__ t0all,
                                                  const int* __restrict__ nptsAll, const double* __restrict__ prevErrs,
@@ -290,6 +289,7 @@ __global__ __launch_bounds__(PB) void k_intracam(int ptsStride, const double* __
                                                  double* __restrict__ wsScratch) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int pb = blockIdx.x;
+    constexpr int NW = PB / 64;
     double* red = smem;            // [NW][27]
     double* sK = smem + NW * 27;   // 9 (+3 pad)
     double* WsL = sK + 12;         // npts (when it fits)
@@ -302,6 +302,12 @@ __global__ __launch_bounds__(PB) void k_intracam(int ptsStride, const double* __
     c.npts = npts;
     c.red = red;
     c.Ws = wsScratch ? (wsScratch + (size_t)ptsStride * pb) : WsL;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double w[3] = {0, 0, 0};
+        w[a] = 1e-8;
+        so3_exp(w, c.dR[a]);
+    }
     for (int i = threadIdx.x; i < npts; i += PB)
         c.Ws[i] = prevErrs ? tukey(fabs(prevErrs[(size_t)ptsStride * pb + i]), tau) : 1.0;  // :641-655
     __syncthreads();
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(PB) void k_intracam(int ptsStride, const double* __
     int k = 0;
     opt.errRW = -1;
     for (; k < opt.maxIterRW; ++k) {  // :664
-        if (!weighted_lm(c, R, t, R_opt, t_opt, opt)) {
+        if (!weighted_lm<PB>(c, R, t, R_opt, t_opt, opt)) {
             ret = false;
             break;
         }
@@ -350,8 +356,6 @@ __global__ __launch_bounds__(PB) void k_intracam(int ptsStride, const double* __
         okAll[pb] = ret ? 1 : 0;
     }
 }
-
-constexpr int WS_LDS_MAX = 4096;  // points whose IRLS weights fit in LDS next to the reduction scratch
 
 struct PoseScratch {
     int device = -1;
@@ -400,9 +404,15 @@ int ensure_scratch(int device, size_t npts) {
 int launch_intracam(hipStream_t stream, int nProb, int ptsStride, const double* K, const double* R0, const double* t0,
                     const int* npts, const double* prevErrs, const double* Ms, const double* ms, double tau,
                     double* R_opt, double* t_opt, cs_pose_option* opt, int* ok, double* wsScratch) {
-    size_t lds = sizeof(double) * (NW * 27 + 12 + (wsScratch ? 0 : ptsStride));
-    hipLaunchKernelGGL(k_intracam, dim3(nProb), dim3(PB), lds, stream, ptsStride, K, R0, t0, npts, prevErrs, Ms, ms, tau,
-                       R_opt, t_opt, opt, ok, wsScratch);
+    if (ptsStride <= SMALL_NPTS) {
+        size_t lds = sizeof(double) * (1 * 27 + 12 + (wsScratch ? 0 : ptsStride));
+        hipLaunchKernelGGL(k_intracam<64>, dim3(nProb), dim3(64), lds, stream, ptsStride, K, R0, t0, npts, prevErrs, Ms,
+                           ms, tau, R_opt, t_opt, opt, ok, wsScratch);
+    } else {
+        size_t lds = sizeof(double) * (4 * 27 + 12 + (wsScratch ? 0 : ptsStride));
+        hipLaunchKernelGGL(k_intracam<256>, dim3(nProb), dim3(256), lds, stream, ptsStride, K, R0, t0, npts, prevErrs,
+                           Ms, ms, tau, R_opt, t_opt, opt, ok, wsScratch);
+    }
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

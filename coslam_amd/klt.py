@@ -175,6 +175,9 @@ class KLT_SequenceTracker:
         check(self._L.cs_klt_track_dev(self._h, C.c_void_p(d_image), C.c_void_p(d_dest), C.c_void_p(d_counts)),
               "cs_klt_track_dev")
 
+    def enable_graphs(self, on=True):
+        check(self._L.cs_klt_enable_graphs(self._h, 1 if on else 0), "cs_klt_enable_graphs")
+
     def synchronize(self):
         check(self._L.cs_klt_synchronize(self._h), "cs_klt_synchronize")
 

@@ -103,6 +103,9 @@ int cs_klt_detect_dev(cs_klt* k, const void* d_image, void* d_dest, void* d_coun
 int cs_klt_redetect_dev(cs_klt* k, const void* d_image, void* d_dest, void* d_counts);
 int cs_klt_track_dev(cs_klt* k, const void* d_image, void* d_dest, void* d_counts);
 int cs_klt_synchronize(cs_klt* k);
+/* Replay the *_dev frame schedules from cached hipGraphs (one host launch per frame instead of ~60).  The image is
+ * first copied into the handle's staging buffer (device-to-device) so that one graph serves every frame. */
+int cs_klt_enable_graphs(cs_klt* k, int on);
 
 /* ---- introspection used by the parity tests (host copies; synchronise the stream) ----
  * which: 0 = _pyrCreator0 (previous frame), 1 = _pyrCreator1 (frame most recently built). */

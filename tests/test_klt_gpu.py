@@ -251,3 +251,39 @@ def test_device_resident_entry_points(hip):
         b.advanceFrame()
     a.close()
     b.close()
+
+
+def test_graph_replay_matches_eager(hip):
+    """hipGraph replay of the frame schedule (all buffer-rotation states) gives the eager results bit for bit."""
+    import torch
+
+    W, H, fw, fh = 640, 480, 50, 40
+    sc = Scene(1, W, H, 4000, seed=44)
+    cfg = cfg2()
+    dev = torch.device("cuda:0")
+    res = []
+    for graphs in (False, True):
+        t = coslam_amd.KLT_SequenceTracker(cfg, 0)
+        t.allocate(W, H, 4, fw, fh)
+        t.set_stream(torch.cuda.current_stream().cuda_stream)
+        t.enable_graphs(graphs)
+        d_dest = torch.zeros(fw * fh * 5, dtype=torch.int32, device=dev)
+        d_counts = torch.zeros(4, dtype=torch.int32, device=dev)
+        out = []
+        for f in range(14):  # > 2 full rotation periods (6)
+            d_img = torch.from_numpy(sc.render(0, f % 7)).to(dev)
+            if f == 0:
+                t.detect_dev(d_img.data_ptr(), d_dest.data_ptr(), d_counts.data_ptr())
+            else:
+                t.redetect_dev(d_img.data_ptr(), d_dest.data_ptr(), d_counts.data_ptr())
+            t.advanceFrame()
+            torch.cuda.synchronize()
+            out.append((d_dest.cpu().numpy().copy(), d_counts.cpu().numpy().copy()))
+        res.append(out)
+        t.close()
+    for (da, ca), (db, cb) in zip(*res):
+        assert np.array_equal(ca, cb)
+        fa, fb = da.view(coslam_amd.KLT_TrackedFeature), db.view(coslam_amd.KLT_TrackedFeature)
+        assert np.array_equal(fa["status"], fb["status"])
+        live = fa["status"] >= 0
+        assert np.array_equal(fa["pos"][live], fb["pos"][live])
