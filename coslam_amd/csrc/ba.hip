@@ -219,17 +219,16 @@ __global__ __launch_bounds__(256) void k_linearize(BaDev D) {
     }
 }
 
-// ---- one wave per free camera: diagonal block of S and the camera gradient -----------------------
+// ---- one workgroup per free camera: diagonal block of S and the camera gradient -----------------------
 __global__ __launch_bounds__(256) void k_cam_reduce(BaDev D) {
     if (!BA_ACTIVE(D)) return;
-    const int lane = threadIdx.x & 63;
-    const int jf = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (jf >= D.nc) return;
+    __shared__ double red[4][27];
+    const int jf = blockIdx.x;
     const int j = jf + D.nCamsCon;
     double acc[27];
 #pragma unroll
     for (int q = 0; q < 27; ++q) acc[q] = 0;
-    for (int s = D.cam_ptr[j] + lane; s < D.cam_ptr[j + 1]; s += 64) {
+    for (int s = D.cam_ptr[j] + threadIdx.x; s < D.cam_ptr[j + 1]; s += 256) {
         const int o = D.cam_obs[s];
         if (D.outlier[o]) continue;
         const double* J = D.Jc + 12 * (size_t)o;
@@ -242,19 +241,31 @@ __global__ __launch_bounds__(256) void k_cam_reduce(BaDev D) {
 #pragma unroll
         for (int r = 0; r < 6; ++r) acc[21 + r] += J[r] * e0 + J[6 + r] * e1;
     }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int q = 0; q < 27; ++q) acc[q] = wsum(acc[q]);
-    if (lane == 0) {
-        const double lambda = D.st->lambda;
+    for (int q = 0; q < 27; ++q) {
+        double v = wsum(acc[q]);
+        if (lane == 0) red[wv][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        const int q = threadIdx.x;
+        const double v = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
         const int n = D.n;
-        int q = 0;
-        for (int r = 0; r < 6; ++r)
-            for (int c = r; c < 6; ++c) {
-                double v = acc[q++] + ((r == c) ? lambda : 0.0);
-                D.S[(size_t)(6 * jf + r) * n + 6 * jf + c] = v;
-                D.S[(size_t)(6 * jf + c) * n + 6 * jf + r] = v;
+        if (q < 21) {
+            // unrank the upper-triangular index
+            int r = 0, base = 0;
+            while (q >= base + (6 - r)) {
+                base += 6 - r;
+                ++r;
             }
-        for (int r = 0; r < 6; ++r) D.rhs[6 * jf + r] = acc[21 + r];
+            const int c = r + (q - base);
+            const double vv = v + ((r == c) ? D.st->lambda : 0.0);
+            D.S[(size_t)(6 * jf + r) * n + 6 * jf + c] = vv;
+            D.S[(size_t)(6 * jf + c) * n + 6 * jf + r] = vv;
+        } else {
+            D.rhs[6 * jf + (q - 21)] = v;
+        }
     }
 }
 
@@ -323,7 +334,8 @@ __global__ __launch_bounds__(256) void k_schur(BaDev D) {
 }
 
 // ---- one workgroup: Cholesky + solve of the reduced camera system --------------------------------
-__global__ __launch_bounds__(256) void k_solve(BaDev D, int useLds) {
+template <int NT>
+__global__ __launch_bounds__(NT) void k_solve(BaDev D, int useLds) {
     if (!BA_ACTIVE(D)) return;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ int okFlag;
@@ -335,8 +347,8 @@ __global__ __launch_bounds__(256) void k_solve(BaDev D, int useLds) {
     double* A = useLds ? sm : D.S;
     double* b = useLds ? (sm + (size_t)n * n) : D.rhs;
     if (useLds) {
-        for (int q = tid; q < n * n; q += 256) A[q] = D.S[q];
-        for (int q = tid; q < n; q += 256) b[q] = D.rhs[q];
+        for (int q = tid; q < n * n; q += NT) A[q] = D.S[q];
+        for (int q = tid; q < n; q += NT) b[q] = D.rhs[q];
     }
     if (tid == 0) okFlag = 1;
     __syncthreads();
@@ -352,11 +364,11 @@ __global__ __launch_bounds__(256) void k_solve(BaDev D, int useLds) {
         }
         __syncthreads();
         const double djj = A[(size_t)j * n + j];
-        for (int i = j + 1 + tid; i < n; i += 256) A[(size_t)i * n + j] /= djj;
+        for (int i = j + 1 + tid; i < n; i += NT) A[(size_t)i * n + j] /= djj;
         __syncthreads();
         // trailing update: A[i][k] -= A[i][j] * A[k][j] for j < k <= i
         const int m = n - j - 1;
-        for (int q = tid; q < m * m; q += 256) {
+        for (int q = tid; q < m * m; q += NT) {
             const int i = j + 1 + q / m, k = j + 1 + q % m;
             if (k <= i) A[(size_t)i * n + k] -= A[(size_t)i * n + j] * A[(size_t)k * n + j];
         }
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(256) void k_solve(BaDev D, int useLds) {
         if (tid == 0) b[j] /= A[(size_t)j * n + j];
         __syncthreads();
         const double yj = b[j];
-        for (int i = j + 1 + tid; i < n; i += 256) b[i] -= A[(size_t)i * n + j] * yj;
+        for (int i = j + 1 + tid; i < n; i += NT) b[i] -= A[(size_t)i * n + j] * yj;
         __syncthreads();
     }
     // back substitution L^T x = y
@@ -375,11 +387,11 @@ __global__ __launch_bounds__(256) void k_solve(BaDev D, int useLds) {
         if (tid == 0) b[j] /= A[(size_t)j * n + j];
         __syncthreads();
         const double xj = b[j];
-        for (int i = tid; i < j; i += 256) b[i] -= A[(size_t)j * n + i] * xj;
+        for (int i = tid; i < j; i += NT) b[i] -= A[(size_t)j * n + i] * xj;
         __syncthreads();
     }
     if (useLds)
-        for (int q = tid; q < n; q += 256) D.rhs[q] = b[q];
+        for (int q = tid; q < n; q += NT) D.rhs[q] = b[q];
     if (tid == 0) D.st->chol_ok = okFlag;
 }
 
@@ -764,7 +776,7 @@ static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int 
     const size_t ldsSolve = sizeof(double) * ((size_t)D.n * D.n + D.n);
     const int useLds = (ldsSolve <= 150 * 1024) ? 1 : 0;
     if (useLds && ldsSolve > 64 * 1024) {
-        CS_HIP(hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
+        CS_HIP(hipFuncSetAttribute((const void*)k_solve<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
     }
     const dim3 gPts((P + 3) / 4 > 0 ? (P + 3) / 4 : 1), gCam((D.nc + 3) / 4 > 0 ? (D.nc + 3) / 4 : 1), blk(256);
     int gUpd = (P + 3) / 4;
@@ -777,10 +789,15 @@ static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int 
         for (int it = 0; it < innerMaxIter; ++it) {
             hipLaunchKernelGGL(k_linearize, gPts, blk, 0, stream, D);
             if (D.nc > 0) {
-                hipLaunchKernelGGL(k_cam_reduce, gCam, blk, 0, stream, D);
+                hipLaunchKernelGGL(k_cam_reduce, dim3(D.nc), blk, 0, stream, D);
                 hipLaunchKernelGGL(k_schur, dim3(nPairs), blk, 0, stream, D);
             }
-            hipLaunchKernelGGL(k_solve, dim3(1), blk, useLds ? ldsSolve : 0, stream, D, useLds);
+            if (D.n <= 64) {
+                // one wave: the barriers between elimination steps cost nothing
+                hipLaunchKernelGGL(k_solve<64>, dim3(1), dim3(64), useLds ? ldsSolve : 0, stream, D, useLds);
+            } else {
+                hipLaunchKernelGGL(k_solve<256>, dim3(1), blk, useLds ? ldsSolve : 0, stream, D, useLds);
+            }
             hipLaunchKernelGGL(k_update, dim3(gUpd), blk, 0, stream, D);
             hipLaunchKernelGGL(k_cost, dim3(cb), blk, 0, stream, D, 1);
             hipLaunchKernelGGL(k_control, dim3(1), blk, 0, stream, D, 1);

@@ -28,6 +28,23 @@ struct CsGainPassArgs {
     int n1x[4], n1y[4];  // the four "betaN1" neighbour offsets in slot texels
 };
 
+struct CsGainFusedArgs {
+    const cs_texel* pyr0;
+    const cs_texel* pyr1;
+    CsTrackLevels lv;
+    int W, H, fw, fh, N, hw, nIter, levelSkip;
+    const float* feat0;      // X0 list (features0_tex)
+    const float* featStart;  // iterate at entry (x, y; gain restarts at 1)
+    float* outLast;          // result of the last pass
+    float* outPrev;          // result of the pass before it (what the ping-pong schedule leaves behind)
+    unsigned long long* gran;  // [2][N] {tag, beta} granules, zeroed before every launch
+    float sqrConvThr, ssdThr;
+    float vr[4];
+    float lambda, delta;
+    int n1x[4], n1y[4];
+    int* err;
+};
+
 // mode 0: detect (all slots free, v3d_gpuklt.cpp:716-734)
 // mode 1: detect with present points appended after the detected ones (:667-690)
 // mode 2: redetect (free slots in ascending index, :775-797)
@@ -48,6 +65,7 @@ int cs_launch_track_nogain(const cs_texel* pyr0, const cs_texel* pyr1, const CsP
                            float* featOut, hipStream_t stream);
 int cs_launch_track_gain_pass(const CsGainPassArgs& a, hipStream_t stream);
 int cs_launch_reset_beta(float* feat, int N, hipStream_t stream);
+int cs_launch_track_gain_fused(const CsGainFusedArgs& a, hipStream_t stream);
 int cs_launch_cornerness(const cs_texel* lvl0, int W, int H, float minCornerness, float margin, float* out,
                          hipStream_t stream);
 int cs_launch_suppress_list(float* corner, int W, int H, int n, const float* d_list3, hipStream_t stream);

@@ -4,6 +4,8 @@
 // v3d_gpuklt.cpp:592-889).  The feature-buffer and pyramid "pointer swaps" of the reference
 // (_featuresBuffer0/1/2, _pyrCreator0/1) are modelled one to one, so every call sequence -- including
 // the odd ones (track without redetect, feed + advance) -- evolves the same state as the reference.
+#include <cstdlib>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -70,6 +72,10 @@ struct cs_klt {
     cs_klt_feature* h_dest;  // pinned
     int* h_counts;           // pinned
     float* h_feat;           // pinned
+    // persistent (single-launch) gain tracker
+    bool use_fused;
+    unsigned long long* d_gran;
+    int* d_err;
     // hipGraph cache for the *_dev entry points: one executable graph per (call, buffer rotation state)
     bool use_graphs;
     struct GraphEntry {
@@ -81,6 +87,12 @@ struct cs_klt {
     };
     std::vector<GraphEntry>* graphs;
 };
+
+// live handles per device: the persistent tracker needs every one of its waves co-resident, so the budget of
+// resident workgroups (8 x 256-thread blocks on each of the 256 CUs, minus a margin) is shared between handles
+static std::mutex g_reg_mutex;
+static int g_live_handles[64];
+constexpr int CS_RESIDENT_BLOCK_BUDGET = 1536;
 
 #define CS_REQUIRE(cond, msg)      \
     do {                           \
@@ -116,6 +128,69 @@ static int enqueue_tracker(cs_klt* k) {
         // (v3d_gpuklt.cpp:108 vs klt_tracker.cg:16-18)
         return cs_launch_track_nogain(P0, P1, k->lay, c.levelSkip, hw, 5, k->margin, k->convThr, k->ssdThr, k->N,
                                       k->d_fb[k->b0], k->d_fb[k->b1], k->stream);
+    }
+    int levelSkipF = c.levelSkip > 0 ? c.levelSkip : (c.nLevels - 1);
+    if (levelSkipF <= 0) levelSkipF = 1;
+    int nLevelsVisited = 0;
+    for (int level = k->L - 1; level >= 0; level -= levelSkipF) ++nLevelsVisited;
+    const int T = nLevelsVisited * c.nIterations;
+    int live = 1;
+    {
+        std::lock_guard<std::mutex> g(g_reg_mutex);
+        live = g_live_handles[k->device & 63] > 0 ? g_live_handles[k->device & 63] : 1;
+    }
+    const int blocks = (k->N + 3) / 4;
+    if (k->use_fused && T >= 1 && blocks * live <= CS_RESIDENT_BLOCK_BUDGET && (2 * hw + 1) * (2 * hw + 1) <= 256) {
+        CsGainFusedArgs f;
+        memset(&f, 0, sizeof(f));
+        f.pyr0 = P0;
+        f.pyr1 = P1;
+        f.lv.L = k->L;
+        for (int l = 0; l < k->L; ++l) {
+            f.lv.w[l] = k->lay.w[l];
+            f.lv.h[l] = k->lay.h[l];
+            f.lv.off[l] = k->lay.off[l];
+        }
+        f.W = k->W;
+        f.H = k->H;
+        f.fw = k->fw;
+        f.fh = k->fh;
+        f.N = k->N;
+        f.hw = hw;
+        f.nIter = c.nIterations;
+        f.levelSkip = levelSkipF;
+        f.feat0 = k->d_fb[k->b2];
+        f.featStart = k->d_fb[k->b0];
+        // where the ping-pong schedule of the reference leaves its last two results (v3d_gpuklt.cpp:281-285)
+        f.outLast = k->d_fb[(T & 1) ? k->b1 : k->b0];
+        f.outPrev = k->d_fb[(T & 1) ? k->b0 : k->b1];
+        f.gran = k->d_gran;
+        f.sqrConvThr = k->convThr * k->convThr;
+        f.ssdThr = k->ssdThr;
+        f.vr[0] = k->margin / (float)k->W;
+        f.vr[1] = k->margin / (float)k->H;
+        f.vr[2] = 1.0f - k->margin / (float)k->W;
+        f.vr[3] = 1.0f - k->margin / (float)k->H;
+        f.lambda = 1.0f;
+        f.delta = 200.0f;
+        {
+            const double rxy = (double)k->fh / (double)k->fw, ryx = (double)k->fw / (double)k->fh;
+            f.n1x[0] = 1;
+            f.n1x[1] = -1;
+            f.n1x[2] = (int)floor(0.5 + ryx);
+            f.n1x[3] = (int)floor(0.5 - ryx);
+            f.n1y[0] = (int)floor(0.5 + rxy);
+            f.n1y[1] = (int)floor(0.5 - rxy);
+            f.n1y[2] = 1;
+            f.n1y[3] = -1;
+        }
+        f.err = k->d_err;
+        CS_HIP(hipMemsetAsync(k->d_gran, 0, sizeof(unsigned long long) * 2 * k->N, k->stream));
+        int rcf = cs_launch_track_gain_fused(f, k->stream);
+        if (rcf) return rcf;
+        if (T & 1) std::swap(k->b0, k->b1);  // T swaps of (buffer0, buffer1)
+        std::swap(k->b0, k->b2);             // v3d_gpuklt.cpp:304
+        return CS_OK;
     }
     int rc = cs_launch_reset_beta(k->d_fb[k->b0], k->N, k->stream);  // v3d_gpuklt.cpp:223-227
     if (rc) return rc;
@@ -247,13 +322,26 @@ static int enqueue_detect(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_des
     return enqueue_detect_tail(k, nPresent > 0 ? 1 : 0, nPresent, maxKeep, d_dest, d_counts);
 }
 
+// the persistent tracker raises *d_err when a bounded spin ran out (waves not co-resident): results are invalid
+static int check_device_error(cs_klt* k) {
+    int e = 0;
+    CS_HIP(hipMemcpy(&e, k->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) {
+        (void)hipMemset(k->d_err, 0, sizeof(int));
+        cs_set_error("persistent KLT tracker timed out waiting for a neighbour (grid not co-resident); "
+                     "call cs_klt_set_fused(k, 0) to use the one-launch-per-pass schedule");
+        return CS_ERR_HIP;
+    }
+    return CS_OK;
+}
+
 static int fetch_results(cs_klt* k, int* count, cs_klt_feature* dest) {
     CS_HIP(hipMemcpyAsync(k->h_dest, k->d_dest, sizeof(cs_klt_feature) * k->N, hipMemcpyDeviceToHost, k->stream));
     CS_HIP(hipMemcpyAsync(k->h_counts, k->d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, k->stream));
     CS_HIP(hipStreamSynchronize(k->stream));
     memcpy(dest, k->h_dest, sizeof(cs_klt_feature) * k->N);
     *count = k->h_counts[0];
-    return CS_OK;
+    return check_device_error(k);
 }
 
 static int upload_image(cs_klt* k, const uint8_t* image) {
@@ -288,6 +376,8 @@ cs_klt* cs_klt_create(const cs_klt_config* cfg, int device, int tap_mode) {
     }
     k->stream = k->own_stream;
     k->graphs = new std::vector<cs_klt::GraphEntry>();
+    const char* env = getenv("COSLAM_KLT_FUSED");
+    k->use_fused = !(env && env[0] == '0');
     return k;
 }
 
@@ -311,6 +401,12 @@ int cs_klt_deallocate(cs_klt* k) {
     hipFree(k->d_dest);
     hipFree(k->d_counts);
     hipFree(k->d_present);
+    hipFree(k->d_gran);
+    hipFree(k->d_err);
+    {
+        std::lock_guard<std::mutex> g(g_reg_mutex);
+        g_live_handles[k->device & 63]--;
+    }
     hipHostFree(k->h_dest);
     hipHostFree(k->h_counts);
     hipHostFree(k->h_feat);
@@ -385,6 +481,9 @@ int cs_klt_allocate(cs_klt* k, int W, int H, int nLevels, int fw, int fh, int pl
     CS_HIP(hipMalloc((void**)&k->d_dest, sizeof(cs_klt_feature) * k->N));
     CS_HIP(hipMalloc((void**)&k->d_counts, sizeof(int) * 4));
     CS_HIP(hipMalloc((void**)&k->d_present, sizeof(float) * 3 * k->presentCap));
+    CS_HIP(hipMalloc((void**)&k->d_gran, sizeof(unsigned long long) * 2 * k->N));
+    CS_HIP(hipMalloc((void**)&k->d_err, sizeof(int)));
+    CS_HIP(hipMemsetAsync(k->d_err, 0, sizeof(int), k->stream));
     CS_HIP(hipHostMalloc((void**)&k->h_dest, sizeof(cs_klt_feature) * k->N, hipHostMallocDefault));
     CS_HIP(hipHostMalloc((void**)&k->h_counts, sizeof(int) * 4, hipHostMallocDefault));
     CS_HIP(hipHostMalloc((void**)&k->h_feat, sizeof(float) * 3 * k->presentCap, hipHostMallocDefault));
@@ -397,6 +496,10 @@ int cs_klt_allocate(cs_klt* k, int W, int H, int nLevels, int fw, int fh, int pl
     CS_HIP(hipMemsetAsync(k->d_counts, 0, sizeof(int) * 4, k->stream));
     CS_HIP(hipStreamSynchronize(k->stream));
     k->allocated = true;
+    {
+        std::lock_guard<std::mutex> g(g_reg_mutex);
+        g_live_handles[k->device & 63]++;
+    }
     return CS_OK;
 }
 
@@ -428,6 +531,18 @@ int cs_klt_synchronize(cs_klt* k) {
     int rc = bind_device(k);
     if (rc) return rc;
     CS_HIP(hipStreamSynchronize(k->stream));
+    return check_device_error(k);
+}
+
+int cs_klt_set_fused(cs_klt* k, int on) {
+    CS_REQUIRE(k, "null handle");
+    if (k->allocated) {
+        int rc = bind_device(k);
+        if (rc) return rc;
+        CS_HIP(hipStreamSynchronize(k->stream));
+        drop_graphs(k);
+    }
+    k->use_fused = on != 0;
     return CS_OK;
 }
 

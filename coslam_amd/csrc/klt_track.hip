@@ -236,6 +236,206 @@ __global__ __launch_bounds__(256) void k_track_gain_pass(CsGainPassArgs A) {
     }
 }
 
+// ---- with gain, ALL passes in one persistent launch ------------------------------------------------
+// The Jacobi coupling between features is only through the gains of <= 6 neighbouring slots, so instead of a
+// kernel boundary per pass (40 boundaries per frame, ~5 us each measured) every feature's wave stays resident for
+// the whole schedule and neighbours hand their gain over through memory: after pass p a wave publishes one
+// naturally aligned 8-byte granule {tag = p+1, beta} with a write-through (sc1) store into gran[p & 1][slot];
+// before pass p it sweeps its neighbours' granules in gran[(p-1) & 1] with L1-bypassing loads until every tag
+// is >= p (MI355X guide, Guideline 16 recipe R2: the data is the flag, no fences).  Two parities suffice: a wave
+// can only overwrite beta_{p-1} after it has read its neighbours' beta_p, i.e. after they finished pass p.
+// Dead features keep sweeping and publishing beta = -1 so the protocol never waits on them.  Every wave of
+// the grid must be co-resident (the launcher checks the grid against the device); every spin is bounded and a
+// timeout raises *err instead of hanging the GPU.  Frame-0 samples are fetched once per level and kept in
+// registers.  Arithmetic per pass is identical to k_track_gain_pass (bit-identical results).
+typedef unsigned long long cs_granule;
+typedef __attribute__((address_space(1))) cs_granule gu64;
+
+__device__ __forceinline__ cs_granule gran_load(const cs_granule* p) {
+    return __hip_atomic_load((const gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gran_store(cs_granule* p, unsigned tag, float beta) {
+    __hip_atomic_store((gu64*)p, ((cs_granule)tag << 32) | (cs_granule)__float_as_uint(beta), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NPL>
+__global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= A.N) return;
+    const float X0x = A.feat0[3 * k], X0y = A.feat0[3 * k + 1];
+    float X1x = A.featStart[3 * k], X1y = A.featStart[3 * k + 1];
+    float beta = 1.0f;  // v3d_gpuklt.cpp:223-227
+    bool dead = (X1x < 0) || (X0x < 0);
+    // previous-pass state (what the multi-launch schedule leaves in the other ping-pong buffer)
+    float pX = X1x, pY = X1y, pB = 1.0f;
+
+    cs_granule* gran0 = A.gran;
+    cs_granule* gran1 = A.gran + A.N;
+    if (lane == 0) gran_store(gran0 + k, 1u, 1.0f);  // beta_0 = 1 for every slot, dead or alive
+
+    // neighbour slots: lanes 0..3 = betaN1, lanes 4..7 = betaN2 (klt_tracker_with_gain.cg:64-72)
+    const int si = k % A.fw, sj = k / A.fw;
+    int nbSlot = k;
+    if (lane < 8) {
+        const int q = lane & 3;
+        int dx, dy;
+        if (lane < 4) {
+            dx = A.n1x[q];
+            dy = A.n1y[q];
+        } else {
+            dx = (q == 0) ? 1 : (q == 1 ? -1 : 0);
+            dy = (q == 2) ? 1 : (q == 3 ? -1 : 0);
+        }
+        nbSlot = cs_clampi(sj + dy, 0, A.fh - 1) * A.fw + cs_clampi(si + dx, 0, A.fw - 1);
+    }
+
+    const int hw = A.hw, fwid = 2 * hw + 1, nPix = fwid * fwid;
+    const float whx = (float)A.W, why = (float)A.H;
+    unsigned pass = 0;
+    for (int level = A.lv.L - 1; level >= 0; level -= A.levelSkip) {
+        const cs_texel* L0 = A.pyr0 + A.lv.off[level];
+        const cs_texel* L1 = A.pyr1 + A.lv.off[level];
+        const int Wl = A.lv.w[level], Hl = A.lv.h[level];
+        const float dsx = 1.0f / (float)Wl, dsy = 1.0f / (float)Hl;
+        float ox[NPL], oy[NPL], I0[NPL], I0x[NPL], I0y[NPL];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            int p = lane + 64 * q;
+            int py = p / fwid, px = p - py * fwid;
+            ox[q] = (float)(px - hw) * dsx;
+            oy[q] = (float)(py - hw) * dsy;
+            I0[q] = I0x[q] = I0y[q] = 0.0f;
+            if (!dead && p < nPix) sample(L0, Wl, Hl, X0x + ox[q], X0y + oy[q], I0[q], I0x[q], I0y[q]);
+        }
+        for (int iter = 1; iter <= A.nIter; ++iter) {
+            ++pass;
+            // ---- sweep the neighbours' granules of the previous pass --------------------------------------
+            float nbBeta = beta;
+            {
+                const cs_granule* src = ((pass - 1) & 1u) ? gran1 : gran0;
+                bool ok = true;
+                unsigned spins = 0;
+                do {
+                    ok = true;
+                    if (lane < 8 && nbSlot != k) {
+                        cs_granule g = gran_load(src + nbSlot);
+                        ok = (unsigned)(g >> 32) >= pass;
+                        nbBeta = __uint_as_float((unsigned)g);
+                    }
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 20)) {
+                        if (lane == 0) atomicExch(A.err, 1);
+                        break;
+                    }
+                } while (true);
+            }
+            float newX = -1.0f, newY = -1.0f, newB = -1.0f;
+            if (!dead) {
+                float bsum;
+                {
+                    float t4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nbBeta), q));
+                        float b2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nbBeta), 4 + q));
+                        if (b1 < 0) b1 = beta;
+                        if (b2 < 0) b2 = beta;
+                        t4[q] = (b1 + b2) - 2.0f * beta;
+                    }
+                    bsum = ((t4[0] + t4[1]) + t4[2]) + t4[3];
+                }
+                // thresholds: v3d_gpuklt.cpp:271-279
+                const bool real = (iter == A.nIter) && (iter != 1);
+                const float sqrConvThr = real ? A.sqrConvThr : 1000000.0f;
+                const float ssdThr = real ? A.ssdThr : 1000000.0f;
+                const float vr0 = real ? A.vr[0] : -1.0f, vr1 = real ? A.vr[1] : -1.0f;
+                const float vr2 = real ? A.vr[2] : 2.0f, vr3 = real ? A.vr[3] : 2.0f;
+                float a = 0, b = 0, c = 0, d = 0, e_ = 0, f = 0, r0 = 0, r1 = 0, r2 = 0, ssd = 0;
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) {
+                    if (lane + 64 * q < nPix) {
+                        float I1, I1x, I1y;
+                        sample(L1, Wl, Hl, X1x + ox[q], X1y + oy[q], I1, I1x, I1y);
+                        float ex = beta * I0[q] - I1;
+                        float gx = (beta * I0x[q] + I1x) * whx / 2.0f;
+                        float gy = (beta * I0y[q] + I1y) * why / 2.0f;
+                        float m0 = sqrtf(I0x[q] * I0x[q] + I0y[q] * I0y[q]);
+                        float m1 = sqrtf(I1x * I1x + I1y * I1y);
+                        a += gx * gx;
+                        b += gx * gy;
+                        c += gx * (-I0[q]);
+                        d += gy * gy;
+                        e_ += gy * (-I0[q]);
+                        f += (I0[q] * I0[q] + A.lambda * m0 * m0) + A.delta * 8.0f;
+                        r0 += ex * gx;
+                        r1 += ex * gy;
+                        r2 += (-ex * I0[q] + A.lambda * m0 * (m1 - beta * m0)) + A.delta * bsum;
+                        ssd += ex * ex;
+                    }
+                }
+                a = cs_wave_sum(a);
+                b = cs_wave_sum(b);
+                c = cs_wave_sum(c);
+                d = cs_wave_sum(d);
+                e_ = cs_wave_sum(e_);
+                f = cs_wave_sum(f);
+                r0 = cs_wave_sum(r0);
+                r1 = cs_wave_sum(r1);
+                r2 = cs_wave_sum(r2);
+                const float SSD = cs_wave_sum(ssd);
+                float det = a * d * f + 2.0f * b * c * e_;
+                det -= (a * e_ * e_ + b * b * f) + c * c * d;
+                const float rcp = 1.0f / det;
+                const float A_ = d * f - e_ * e_, B_ = c * e_ - b * f, C_ = b * e_ - c * d;
+                const float D_ = a * f - c * c, E_ = b * c - a * e_, F_ = a * d - b * b;
+                float dX = (A_ * r0 + B_ * r1) + C_ * r2;
+                float dY = (B_ * r0 + D_ * r1) + E_ * r2;
+                float dZ = (C_ * r0 + E_ * r1) + F_ * r2;
+                dX *= rcp;
+                dY *= rcp;
+                dZ *= rcp;
+                const float nX = X1x + dX, nY = X1y + dY;
+                const float ux = dX * whx, uy = dY * why;
+                const float sqrLen = ux * ux + uy * uy;
+                bool invalid = (det < 0.00001f);
+                invalid = invalid || (SSD > ssdThr);
+                invalid = invalid || (sqrLen > sqrConvThr);
+                invalid = invalid || (nX < vr0 || nY < vr1) || (nX > vr2 || nY > vr3);
+                const float nB = beta + dZ;
+                if (!(invalid || !(nX == nX) || !(nY == nY) || !(nB == nB))) {
+                    newX = nX;
+                    newY = nY;
+                    newB = nB;
+                }
+            }
+            pX = dead ? -1.0f : X1x;
+            pY = dead ? -1.0f : X1y;
+            pB = dead ? -1.0f : beta;
+            if (pass == 1) {  // the buffer the first pass read from holds (x, y, 1) for every slot
+                pX = X1x;
+                pY = X1y;
+                pB = 1.0f;
+            }
+            X1x = newX;
+            X1y = newY;
+            beta = newB;
+            dead = dead || (newX < 0);
+            if (lane == 0) gran_store(((pass & 1u) ? gran1 : gran0) + k, pass + 1u, beta);
+        }
+    }
+    if (lane == 0) {
+        A.outLast[3 * k] = X1x;
+        A.outLast[3 * k + 1] = X1y;
+        A.outLast[3 * k + 2] = beta;
+        A.outPrev[3 * k] = pX;
+        A.outPrev[3 * k + 1] = pY;
+        A.outPrev[3 * k + 2] = pB;
+    }
+}
+
 // glClear of the blue channel to 1, v3d_gpuklt.cpp:223-227
 __global__ void k_reset_beta(float* feat, int N) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -291,6 +491,24 @@ int cs_launch_track_gain_pass(const CsGainPassArgs& a, hipStream_t stream) {
 
 int cs_launch_reset_beta(float* feat, int N, hipStream_t stream) {
     hipLaunchKernelGGL(k_reset_beta, dim3((N + 255) / 256), dim3(256), 0, stream, feat, N);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int cs_launch_track_gain_fused(const CsGainFusedArgs& a, hipStream_t stream) {
+    const int nPix = (2 * a.hw + 1) * (2 * a.hw + 1);
+    const int npl = (nPix + 63) / 64;
+    dim3 grid((a.N + 3) / 4), block(256);
+    if (npl <= 1) {
+        hipLaunchKernelGGL(k_track_gain_fused<1>, grid, block, 0, stream, a);
+    } else if (npl <= 2) {
+        hipLaunchKernelGGL(k_track_gain_fused<2>, grid, block, 0, stream, a);
+    } else if (npl <= 4) {
+        hipLaunchKernelGGL(k_track_gain_fused<4>, grid, block, 0, stream, a);
+    } else {
+        cs_set_error("fused gain tracker: windowWidth %d too large", 2 * a.hw + 1);
+        return CS_ERR_INVALID;
+    }
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

@@ -178,6 +178,9 @@ class KLT_SequenceTracker:
     def enable_graphs(self, on=True):
         check(self._L.cs_klt_enable_graphs(self._h, 1 if on else 0), "cs_klt_enable_graphs")
 
+    def set_fused(self, on=True):
+        check(self._L.cs_klt_set_fused(self._h, 1 if on else 0), "cs_klt_set_fused")
+
     def synchronize(self):
         check(self._L.cs_klt_synchronize(self._h), "cs_klt_synchronize")
 

@@ -106,6 +106,10 @@ int cs_klt_synchronize(cs_klt* k);
 /* Replay the *_dev frame schedules from cached hipGraphs (one host launch per frame instead of ~60).  The image is
  * first copied into the handle's staging buffer (device-to-device) so that one graph serves every frame. */
 int cs_klt_enable_graphs(cs_klt* k, int on);
+/* Gain tracker schedule: 1 (default) = one persistent launch for all levels x iterations, neighbours exchange gains
+ * through 8-byte {tag, beta} granules; 0 = one launch per Gauss-Newton pass as the reference schedules its shader
+ * (v3d_gpuklt.cpp:254-287).  Both give bit-identical results.  Env COSLAM_KLT_FUSED=0 sets the default to 0. */
+int cs_klt_set_fused(cs_klt* k, int on);
 
 /* ---- introspection used by the parity tests (host copies; synchronise the stream) ----
  * which: 0 = _pyrCreator0 (previous frame), 1 = _pyrCreator1 (frame most recently built). */

@@ -287,3 +287,32 @@ def test_graph_replay_matches_eager(hip):
         assert np.array_equal(fa["status"], fb["status"])
         live = fa["status"] >= 0
         assert np.array_equal(fa["pos"][live], fb["pos"][live])
+
+
+@pytest.mark.parametrize("levels,skip,iters,win,grid", [(4, 1, 10, 7, (50, 40)), (6, 2, 12, 6, (32, 32)), (3, 1, 1, 7, (20, 15)),
+                                                       (3, 1, 3, 11, (20, 20)), (2, 1, 5, 7, (7, 5))])
+def test_persistent_gain_tracker_is_bit_identical_to_per_pass_launches(hip, levels, skip, iters, win, grid):
+    """One persistent launch with granule hand-offs == the reference's one-launch-per-pass Jacobi schedule."""
+    W, H = 640, 480
+    sc = Scene(1, W, H, 4000, seed=51)
+    cfg = cfg2(nLevels=levels, levelSkip=skip, nIterations=iters, windowWidth=win)
+    out = []
+    for fused in (0, 1):
+        t = coslam_amd.KLT_SequenceTracker(cfg, 0)
+        t.allocate(W, H, levels, *grid)
+        t.set_fused(fused)
+        t.detect(sc.render(0, 0))
+        t.advanceFrame()
+        frames = []
+        for f in range(1, 5):
+            n, d = (t.redetect if f % 2 else t.track)(sc.render(0, f))  # track-only frames exercise the stale buffer
+            frames.append((n, d.copy(), t.read_features().copy()))
+            t.advanceFrame()
+        out.append(frames)
+        t.close()
+    for (n0, d0, f0), (n1, d1, f1) in zip(*out):
+        assert n0 == n1
+        assert np.array_equal(d0["status"], d1["status"])
+        live = d0["status"] >= 0
+        assert np.array_equal(d0["pos"][live], d1["pos"][live]) and np.array_equal(d0["gain"][live], d1["gain"][live])
+        assert np.array_equal(f0, f1)
