@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--sync-ba", action="store_true", help="run the local BA on the tracking stream instead of its own")
+    ap.add_argument("--ba-every", type=int, default=BA_EVERY, help="diagnostic: 0 disables the BA leg (result not a valid bench line)")
     args = ap.parse_args()
 
     import torch
@@ -146,6 +148,10 @@ def main():
     d_counts = torch.zeros(4, dtype=torch.int32, device=dev)
 
     stream = torch.cuda.current_stream().cuda_stream
+    # the reference runs local BA on a worker thread next to tracking (src/app/SL_CoSLAM.cpp:1702-1730, one request in
+    # flight at a time); here that is a second HIP stream
+    ba_torch_stream = torch.cuda.current_stream() if args.sync_ba else torch.cuda.Stream(device=dev)
+    ba_stream = ba_torch_stream.cuda_stream
     trk = coslam_amd.KLT_SequenceTracker(klt_config(), device=local_rank)
     trk.allocate(W, H, LEVELS, FW, FH)
     trk.set_stream(stream)
@@ -179,8 +185,8 @@ def main():
                                    d_npts.data_ptr(), 0, d_Ms[f].data_ptr(), d_ms[f].data_ptr(), 10.0,
                                    d_Ropt.data_ptr(), d_topt.data_ptr(), d_opt.data_ptr(), d_ok.data_ptr(),
                                    device=local_rank)
-        if (i + 1) % BA_EVERY == 0:
-            ba_ws.solve_dev(stream, d_baR.data_ptr(), d_baT.data_ptr(), d_baM.data_ptr(), 2, 2, 6.0, 2, 10)
+        if args.ba_every > 0 and (i + 1) % args.ba_every == 0:
+            ba_ws.solve_dev(ba_stream, d_baR.data_ptr(), d_baT.data_ptr(), d_baM.data_ptr(), 2, 2, 6.0, 2, 10)
         if world > 1:
             d_send[: N_FEAT * 5].copy_(d_dest, non_blocking=True)
             d_send[N_FEAT * 5: N_FEAT * 5 + 18].copy_(d_Ropt.view(torch.int32), non_blocking=True)
@@ -241,7 +247,9 @@ def main():
                                    f"frame; local robust BA (5 KF x 500 pts, maxIter 2 / inner 10) every {BA_EVERY}th "
                                    "frame; all-gather of features+pose when N>1",
                        "cameras": n_gpus, "live_features_last_frame": n_live, "pose_ok": pose_ok,
-                       "hip_graphs": bool(not args.no_graphs and hasattr(trk, "enable_graphs"))},
+                       "hip_graphs": bool(not args.no_graphs and hasattr(trk, "enable_graphs")),
+                       "local_ba": "own HIP stream, like the reference's BA worker thread" if not args.sync_ba
+                       else "on the tracking stream"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

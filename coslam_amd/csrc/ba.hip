@@ -11,9 +11,8 @@
 // whole maxIter x innerMaxIter schedule without a single synchronisation:
 //   k_linearize   one wave per point: residual + analytic Jacobians per measurement (lane = measurement),
 //                 W_ij = Jc^T Jp to HBM, V_i and g_i folded across the wave with butterflies, V_i^-1 stored;
-//   k_cam_reduce  one wave per free camera: U_j = sum Jc^T Jc (+ lambda I), g_j, again by wave butterflies;
-//   k_schur       one workgroup per camera pair (j,k): S_jk -= sum_i W_ij V_i^-1 W_ik^T through the dense
-//                 table (deterministic order, no atomics); rhs_j -= sum_i W_ij V_i^-1 g_i on the diagonal;
+//   k_schur       one workgroup per camera pair (j,k): S_jk = [j==k](U_j + lambda I) - sum_i W_ij V_i^-1 W_ik^T through
+//                 the dense table (deterministic order, no atomics); rhs_j = g_j - sum_i W_ij V_i^-1 g_i;
 //   k_solve       one workgroup: Cholesky of the reduced camera system in LDS + the two triangular solves;
 //   k_update      tentative step: cameras R exp(w), t + dt; points by back-substitution (wave per point);
 //   k_cost        squared inlier residuals at the tentative (or current) estimate, per-block partials;
@@ -21,6 +20,8 @@
 //   k_flag        outlier flags (residual > maxErr) and the "flags changed" bit for the outer loop.
 // MFMA is deliberately absent: at the sizes of the reference's calls (<= 13 cameras x 5 key frames) the
 // reduced system is <= 390 x 390 and the Schur products are 6x3 blocks -- wave-shuffle territory.
+#include <cstdlib>
+
 #include "cs_common.h"
 
 #pragma clang fp contract(off)
@@ -219,60 +220,13 @@ __global__ __launch_bounds__(256) void k_linearize(BaDev D) {
     }
 }
 
-// ---- one workgroup per free camera: diagonal block of S and the camera gradient -----------------------
-__global__ __launch_bounds__(256) void k_cam_reduce(BaDev D) {
-    if (!BA_ACTIVE(D)) return;
-    __shared__ double red[4][27];
-    const int jf = blockIdx.x;
-    const int j = jf + D.nCamsCon;
-    double acc[27];
-#pragma unroll
-    for (int q = 0; q < 27; ++q) acc[q] = 0;
-    for (int s = D.cam_ptr[j] + threadIdx.x; s < D.cam_ptr[j + 1]; s += 256) {
-        const int o = D.cam_obs[s];
-        if (D.outlier[o]) continue;
-        const double* J = D.Jc + 12 * (size_t)o;
-        const double e0 = D.e[2 * (size_t)o], e1 = D.e[2 * (size_t)o + 1];
-        int q = 0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = r; c < 6; ++c) acc[q++] += J[r] * J[c] + J[6 + r] * J[6 + c];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) acc[21 + r] += J[r] * e0 + J[6 + r] * e1;
-    }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int q = 0; q < 27; ++q) {
-        double v = wsum(acc[q]);
-        if (lane == 0) red[wv][q] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 27) {
-        const int q = threadIdx.x;
-        const double v = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
-        const int n = D.n;
-        if (q < 21) {
-            // unrank the upper-triangular index
-            int r = 0, base = 0;
-            while (q >= base + (6 - r)) {
-                base += 6 - r;
-                ++r;
-            }
-            const int c = r + (q - base);
-            const double vv = v + ((r == c) ? D.st->lambda : 0.0);
-            D.S[(size_t)(6 * jf + r) * n + 6 * jf + c] = vv;
-            D.S[(size_t)(6 * jf + c) * n + 6 * jf + r] = vv;
-        } else {
-            D.rhs[6 * jf + (q - 21)] = v;
-        }
-    }
-}
-
 // ---- one workgroup per camera pair (ja <= jb) ----------------------------------------------------
+// Diagonal pairs also form U_j = sum Jc^T Jc + lambda I and g_j = sum Jc^T e over the camera's own measurement
+// list, so the whole reduced system S, rhs is written by this one launch (no read-modify-write between kernels).
 __global__ __launch_bounds__(256) void k_schur(BaDev D) {
     if (!BA_ACTIVE(D)) return;
     __shared__ double red[4][42];
+    __shared__ double redU[4][27];
     // decode the pair from the linear block index over the upper triangle
     int pair = blockIdx.x, ja = 0;
     while (pair >= D.nc - ja) {
@@ -281,6 +235,30 @@ __global__ __launch_bounds__(256) void k_schur(BaDev D) {
     }
     const int jb = ja + pair;
     const int ca = ja + D.nCamsCon, cb = jb + D.nCamsCon;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (ja == jb) {
+        double u[27];
+#pragma unroll
+        for (int q = 0; q < 27; ++q) u[q] = 0;
+        for (int s = D.cam_ptr[ca] + threadIdx.x; s < D.cam_ptr[ca + 1]; s += 256) {
+            const int o = D.cam_obs[s];
+            if (D.outlier[o]) continue;
+            const double* J = D.Jc + 12 * (size_t)o;
+            const double e0 = D.e[2 * (size_t)o], e1 = D.e[2 * (size_t)o + 1];
+            int q = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = r; c < 6; ++c) u[q++] += J[r] * J[c] + J[6 + r] * J[6 + c];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) u[21 + r] += J[r] * e0 + J[6 + r] * e1;
+        }
+#pragma unroll
+        for (int q = 0; q < 27; ++q) {
+            double v = wsum(u[q]);
+            if (lane == 0) redU[wv][q] = v;
+        }
+    }
     double acc[42];
 #pragma unroll
     for (int q = 0; q < 42; ++q) acc[q] = 0;
@@ -308,7 +286,6 @@ __global__ __launch_bounds__(256) void k_schur(BaDev D) {
             for (int r = 0; r < 6; ++r) acc[36 + r] += Y[3 * r] * g[0] + Y[3 * r + 1] * g[1] + Y[3 * r + 2] * g[2];
         }
     }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int q = 0; q < 42; ++q) {
         double s = wsum(acc[q]);
@@ -317,18 +294,24 @@ __global__ __launch_bounds__(256) void k_schur(BaDev D) {
     __syncthreads();
     if (threadIdx.x < 42) {
         const int q = threadIdx.x;
-        double s = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
+        const double s = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
         const int n = D.n;
         if (q < 36) {
             const int r = q / 6, c = q - 6 * r;
             if (ja == jb) {
-                D.S[(size_t)(6 * ja + r) * n + 6 * ja + c] -= s;
+                // U_j entry (upper-triangular rank of (min,max)) + lambda on the diagonal - Schur sum
+                const int rr = r < c ? r : c, cc = r < c ? c : r;
+                const int uq = rr * 6 - (rr * (rr - 1)) / 2 + (cc - rr);
+                const double uv = ((redU[0][uq] + redU[1][uq]) + redU[2][uq]) + redU[3][uq];
+                D.S[(size_t)(6 * ja + r) * n + 6 * ja + c] = (uv + ((r == c) ? D.st->lambda : 0.0)) - s;
             } else {
                 D.S[(size_t)(6 * ja + r) * n + 6 * jb + c] = -s;
                 D.S[(size_t)(6 * jb + c) * n + 6 * ja + r] = -s;
             }
         } else if (ja == jb) {
-            D.rhs[6 * ja + (q - 36)] -= s;
+            const int r = q - 36;
+            const double gv = ((redU[0][21 + r] + redU[1][21 + r]) + redU[2][21 + r]) + redU[3][21 + r];
+            D.rhs[6 * ja + r] = gv - s;
         }
     }
 }
@@ -393,6 +376,106 @@ __global__ __launch_bounds__(NT) void k_solve(BaDev D, int useLds) {
     if (useLds)
         for (int q = tid; q < n; q += NT) D.rhs[q] = b[q];
     if (tid == 0) D.st->chol_ok = okFlag;
+}
+
+// ---- one WAVE: reduced camera system of order n <= 64 -------------------------------------------------
+// Lane i owns row i of S (in LDS) and entry i of the right-hand side (in a register).  Column j of the Cholesky
+// factor is formed from one LDS read per lane plus v_readlane broadcasts of the pivot and of l_kj, the trailing
+// update touches only the lane's own row (no cross-lane hazard, so no barrier anywhere), the forward substitution
+// rides along with the factorisation, and the back substitution is a column sweep over the rows of L.
+__device__ __forceinline__ double rdlane_d(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void k_solve_wave(BaDev D) {
+    if (!BA_ACTIVE(D)) return;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int n = D.n, i = threadIdx.x;
+    if (n == 0) {
+        if (i == 0) D.st->chol_ok = 1;
+        return;
+    }
+    const int ld = n | 1;  // odd leading dimension: a column read hits distinct banks
+    for (int q = i; q < n * n; q += 64) sm[(q / n) * ld + (q % n)] = D.S[q];
+    double b = (i < n) ? D.rhs[i] : 0.0;
+    double diag = 1.0;  // L[i][i]
+    bool ok = true;
+    __syncthreads();
+    double* row = sm + (size_t)(i < n ? i : 0) * ld;
+    for (int j = 0; j < n; ++j) {
+        const double cj = (i < n) ? row[j] : 0.0;
+        double d = rdlane_d(cj, j);
+        if (!(d > 0)) {
+            ok = false;
+            d = 1.0;
+        }
+        d = sqrt(d);
+        const double lij = (i > j && i < n) ? cj / d : 0.0;
+        if (i == j) diag = d;
+        if (i > j && i < n) row[j] = lij;
+        // forward substitution step
+        const double yj = rdlane_d(b, j) / d;
+        if (i == j) b = yj;
+        if (i > j) b -= lij * yj;
+        // trailing update of my own row: A[i][k] -= l_ij * l_kj, j < k <= i
+        for (int k = j + 1; k < n; ++k) {
+            const double lkj = rdlane_d(lij, k);
+            if (k <= i && i < n) row[k] -= lij * lkj;
+        }
+    }
+    __syncthreads();
+    // back substitution L^T x = y as a column sweep over the rows of L
+    for (int j = n - 1; j >= 0; --j) {
+        const double xj = rdlane_d(b, j) / rdlane_d(diag, j);
+        if (i == j) b = xj;
+        if (i < j) b -= sm[(size_t)j * ld + i] * xj;
+    }
+    if (i < n) D.rhs[i] = b;
+    if (i == 0) D.st->chol_ok = ok ? 1 : 0;
+}
+
+// ---- one WAVE, rows in REGISTERS: reduced camera systems of order n <= NMAX <= 36 -----------------------
+// Lane i keeps row i of S in NMAX registers; both loops are fully unrolled, so every index is static and every
+// cross-lane read is a v_readlane of a constant lane: no LDS, no barrier, one reciprocal square root per column.
+// Rows/columns n..NMAX-1 are identity padding.
+template <int NMAX>
+__global__ __launch_bounds__(64) void k_solve_reg(BaDev D) {
+    if (!BA_ACTIVE(D)) return;
+    const int n = D.n, i = threadIdx.x;
+    double a[NMAX];
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) a[k] = (i < n && k < n) ? D.S[(size_t)i * n + k] : ((i == k) ? 1.0 : 0.0);
+    double b = (i < n) ? D.rhs[i] : 0.0;
+    double rdiag[NMAX];  // 1 / L[j][j] (wave-uniform)
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        const double cj = a[j];
+        double d = rdlane_d(cj, j);
+        if (!(d > 0)) {
+            ok = false;
+            d = 1.0;
+        }
+        const double rd = 1.0 / sqrt(d);
+        rdiag[j] = rd;
+        const double lij = (i > j) ? cj * rd : 0.0;
+        a[j] = lij;
+        const double yj = rdlane_d(b, j) * rd;
+        b = (i == j) ? yj : (b - lij * yj);
+#pragma unroll
+        for (int k = j + 1; k < NMAX; ++k) a[k] -= lij * rdlane_d(lij, k);
+    }
+    // L^T x = y: x_j = (y_j - sum_{i>j} L[i][j] x_i) / L[j][j]
+#pragma unroll
+    for (int j = NMAX - 1; j >= 0; --j) {
+        const double s = cs_wave_sum_d((i > j) ? a[j] * b : 0.0);
+        const double xj = (rdlane_d(b, j) - s) * rdiag[j];
+        if (i == j) b = xj;
+    }
+    if (i < n) D.rhs[i] = b;
+    if (i == 0) D.st->chol_ok = ok ? 1 : 0;
 }
 
 // ---- tentative step -------------------------------------------------------------------------------
@@ -653,9 +736,22 @@ struct cs_ba {
     // pinned staging for the host-pointer entry
     int *h_cam_ptr, *h_cam_obs;
     int nCostBlocks;
+    // cached executable graph of one full solve (cs_ba_solve_dev): ~150 launches become one
+    struct GraphKey {
+        int C, P, nObs, nCamsCon, nPtsCon, maxIter, innerMaxIter;
+        double maxErr;
+        const void *R0, *T0, *M0;
+    } gkey;
+    hipGraphExec_t gexec;
 };
 
+static void ba_drop_graph(cs_ba* b) {
+    if (b->gexec) (void)hipGraphExecDestroy(b->gexec);
+    b->gexec = nullptr;
+}
+
 static int ba_free(cs_ba* b) {
+    ba_drop_graph(b);
     double** dp[] = {&b->Ks, &b->Rs, &b->Ts, &b->pts, &b->Rn, &b->Tn, &b->Mn, &b->obs_xy, &b->Jc, &b->e, &b->W,
                      &b->Vinv, &b->gp, &b->S, &b->rhs, &b->costPart, &b->stepPart};
     for (auto p : dp) {
@@ -789,12 +885,16 @@ static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int 
         for (int it = 0; it < innerMaxIter; ++it) {
             hipLaunchKernelGGL(k_linearize, gPts, blk, 0, stream, D);
             if (D.nc > 0) {
-                hipLaunchKernelGGL(k_cam_reduce, dim3(D.nc), blk, 0, stream, D);
                 hipLaunchKernelGGL(k_schur, dim3(nPairs), blk, 0, stream, D);
             }
-            if (D.n <= 64) {
-                // one wave: the barriers between elimination steps cost nothing
-                hipLaunchKernelGGL(k_solve<64>, dim3(1), dim3(64), useLds ? ldsSolve : 0, stream, D, useLds);
+            if (D.n <= 12) {
+                hipLaunchKernelGGL(k_solve_reg<12>, dim3(1), dim3(64), 0, stream, D);
+            } else if (D.n <= 24) {
+                hipLaunchKernelGGL(k_solve_reg<24>, dim3(1), dim3(64), 0, stream, D);
+            } else if (D.n <= 36) {
+                hipLaunchKernelGGL(k_solve_reg<36>, dim3(1), dim3(64), 0, stream, D);
+            } else if (D.n <= 64) {
+                hipLaunchKernelGGL(k_solve_wave, dim3(1), dim3(64), sizeof(double) * (size_t)D.n * (D.n | 1), stream, D);
             } else {
                 hipLaunchKernelGGL(k_solve<256>, dim3(1), blk, useLds ? ldsSolve : 0, stream, D, useLds);
             }
@@ -941,10 +1041,47 @@ int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const do
     }
     CS_HIP(hipSetDevice(b->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
-    CS_HIP(hipMemcpyAsync(b->Rs, d_Rs0, sizeof(double) * 9 * C, hipMemcpyDeviceToDevice, s));
-    CS_HIP(hipMemcpyAsync(b->Ts, d_Ts0, sizeof(double) * 3 * C, hipMemcpyDeviceToDevice, s));
-    if (P > 0) CS_HIP(hipMemcpyAsync(b->pts, d_pts0, sizeof(double) * 3 * P, hipMemcpyDeviceToDevice, s));
-    return ba_enqueue(b, s, C, P, nObs, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter);
+    const char* env = getenv("COSLAM_BA_GRAPHS");
+    const bool useGraph = !(env && env[0] == '0');
+    cs_ba::GraphKey key = {C, P, nObs, nCamsCon, nPtsCon, maxIter, innerMaxIter, maxErr, d_Rs0, d_Ts0, d_pts0};
+    if (useGraph && b->gexec && memcmp(&key, &b->gkey, sizeof(key)) == 0) {
+        CS_HIP(hipGraphLaunch(b->gexec, s));
+        return CS_OK;
+    }
+    if (useGraph) {
+        ba_drop_graph(b);
+        CS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    }
+    int rc = CS_OK;
+    {
+        hipError_t e1 = hipMemcpyAsync(b->Rs, d_Rs0, sizeof(double) * 9 * C, hipMemcpyDeviceToDevice, s);
+        hipError_t e2 = hipMemcpyAsync(b->Ts, d_Ts0, sizeof(double) * 3 * C, hipMemcpyDeviceToDevice, s);
+        hipError_t e3 = (P > 0) ? hipMemcpyAsync(b->pts, d_pts0, sizeof(double) * 3 * P, hipMemcpyDeviceToDevice, s) : hipSuccess;
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+            cs_set_error("cs_ba_solve_dev: device copy of the initial estimate failed");
+            rc = CS_ERR_HIP;
+        }
+    }
+    if (!rc) rc = ba_enqueue(b, s, C, P, nObs, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter);
+    if (!useGraph) return rc;
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc || e != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!rc) cs_set_error("cs_ba_solve_dev: hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        return rc ? rc : CS_ERR_HIP;
+    }
+    e = hipGraphInstantiate(&b->gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        b->gexec = nullptr;
+        cs_set_error("cs_ba_solve_dev: hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        return CS_ERR_HIP;
+    }
+    memset(&b->gkey, 0, sizeof(b->gkey));
+    b->gkey = key;
+    CS_HIP(hipGraphLaunch(b->gexec, s));
+    return CS_OK;
 }
 
 int cs_ba_download(cs_ba* b, int C, int P, int nObs, double* Rs, double* Ts, double* pts, int* out_outlier,

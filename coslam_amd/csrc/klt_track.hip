@@ -311,6 +311,14 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
         }
         for (int iter = 1; iter <= A.nIter; ++iter) {
             ++pass;
+            // the frame-1 footprints do not depend on the neighbours: put their loads in flight first so that the
+            // L2 round trip overlaps the hand-off wait
+            float J1[NPL], J1x[NPL], J1y[NPL];
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                J1[q] = J1x[q] = J1y[q] = 0.0f;
+                if (!dead && lane + 64 * q < nPix) sample(L1, Wl, Hl, X1x + ox[q], X1y + oy[q], J1[q], J1x[q], J1y[q]);
+            }
             // ---- sweep the neighbours' granules of the previous pass --------------------------------------
             float nbBeta = beta;
             {
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
                         nbBeta = __uint_as_float((unsigned)g);
                     }
                     if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(2);
                     if (++spins > (1u << 20)) {
                         if (lane == 0) atomicExch(A.err, 1);
                         break;
@@ -357,8 +365,7 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) {
                     if (lane + 64 * q < nPix) {
-                        float I1, I1x, I1y;
-                        sample(L1, Wl, Hl, X1x + ox[q], X1y + oy[q], I1, I1x, I1y);
+                        const float I1 = J1[q], I1x = J1x[q], I1y = J1y[q];
                         float ex = beta * I0[q] - I1;
                         float gx = (beta * I0x[q] + I1x) * whx / 2.0f;
                         float gy = (beta * I0y[q] + I1y) * why / 2.0f;
