@@ -218,17 +218,31 @@ def main():
     n_live = int((d_dest.cpu().numpy().view(coslam_amd.KLT_TrackedFeature)["status"] >= 0).sum())
     pose_ok = int(d_ok.item())
 
-    # ---- roofline of the dominant data-parallel kernel: one Gauss-Newton pass of the gain tracker ----
+    # ---- roofline of the dominant kernel: the KLT gain tracker (all levels x iterations in one persistent launch).
+    # Timed with HIP events on the stream it is launched on, over a replay of the same frames right after the
+    # timed region (event pairs cannot sit inside the hipGraph the timed region replays).
     roof = None
-    if rank == 0 and hasattr(trk, "profile_track_pass"):
-        prof = trk.profile_track_pass(200)
+    if rank == 0:
+        trk.set_profiling(True)
+        n_prof = min(args.steps, 100)
+        for i in range(n_prof):
+            f = order[(args.warmup + args.steps + i + 1) % len(order)]
+            trk.redetect_dev(d_frames[f].data_ptr(), d_dest.data_ptr(), d_counts.data_ptr())
+            trk.advanceFrame()
+        prof = trk.get_profile()
+        trk.set_profiling(False)
         hw = 7 // 2
-        per_feature = 2 * (2 * hw + 2) ** 2 * 6 + 2 * 12  # two 8x8 footprints of 6-B texels + feature I/O
+        levels_visited = LEVELS  # levelSkip = 1
+        # per feature per visited level two (2hw+2)^2 footprints of 6-byte texels, + 2 x 12 B feature I/O
+        per_feature = levels_visited * 2 * (2 * hw + 2) ** 2 * 6 + 2 * 12
         alg_bytes = per_feature * N_FEAT
-        ach = alg_bytes / (prof["avg_us"] * 1e-6) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_track_gain_pass", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
-                "avg_launch_us": prof["avg_us"], "launches_per_frame": prof["launches_per_frame"]}
+        launches = max(prof["launches_per_frame"], 1)
+        avg_us = prof["tracker_us_total"] / max(prof["frames"], 1) / launches
+        ach = (alg_bytes / launches) / (avg_us * 1e-6) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_track_gain_fused" if launches == 1 else "k_track_gain_pass",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_us": avg_us,
+                "launches_per_frame": launches, "frames_timed": prof["frames"]}
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

@@ -72,6 +72,10 @@ struct cs_klt {
     cs_klt_feature* h_dest;  // pinned
     int* h_counts;           // pinned
     float* h_feat;           // pinned
+    // HIP-event timing of the tracker stage (bench.py roofline leg): eager launches only
+    bool profiling;
+    hipEvent_t ev0, ev1;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev_pairs;
     // persistent (single-launch) gain tracker
     bool use_fused;
     unsigned long long* d_gran;
@@ -289,8 +293,18 @@ static int enqueue_track(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest
                                   k->d_corner_raw, k->stream);
         if (rc) return rc;
     }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (k->profiling) {
+        CS_HIP(hipEventCreate(&e0));
+        CS_HIP(hipEventCreate(&e1));
+        CS_HIP(hipEventRecord(e0, k->stream));
+    }
     rc = enqueue_tracker(k);
     if (rc) return rc;
+    if (k->profiling) {
+        CS_HIP(hipEventRecord(e1, k->stream));
+        k->ev_pairs->push_back(std::make_pair(e0, e1));
+    }
     rc = cs_launch_post_track(read_buffer(k), k->N, d_dest, k->d_ctr, k->d_corner_raw, k->W, k->H, forRedetect ? 1 : 0,
                               k->stream);
     if (rc) return rc;
@@ -376,6 +390,7 @@ cs_klt* cs_klt_create(const cs_klt_config* cfg, int device, int tap_mode) {
     }
     k->stream = k->own_stream;
     k->graphs = new std::vector<cs_klt::GraphEntry>();
+    k->ev_pairs = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
     const char* env = getenv("COSLAM_KLT_FUSED");
     k->use_fused = !(env && env[0] == '0');
     return k;
@@ -419,6 +434,12 @@ void cs_klt_destroy(cs_klt* k) {
     cs_klt_deallocate(k);
     delete k->graphs;
     k->graphs = nullptr;
+    for (auto& p : *k->ev_pairs) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    delete k->ev_pairs;
+    k->ev_pairs = nullptr;
     hipSetDevice(k->device);
     hipStreamDestroy(k->own_stream);
     delete k;
@@ -534,6 +555,42 @@ int cs_klt_synchronize(cs_klt* k) {
     return check_device_error(k);
 }
 
+// HIP-event timing of the tracker stage on the handle's stream.  While on, the *_dev calls run eagerly (no graph
+// replay) and every track/redetect brackets the tracker launch(es) with an event pair.
+int cs_klt_set_profiling(cs_klt* k, int on) {
+    CS_REQUIRE(k, "null handle");
+    k->profiling = on != 0;
+    return CS_OK;
+}
+
+// sum of the bracketed tracker times (microseconds), number of frames and kernel launches per frame; clears the log
+int cs_klt_get_profile(cs_klt* k, double* tracker_us, int* n_frames, int* launches_per_frame) {
+    CS_REQUIRE(k && k->allocated && tracker_us && n_frames, "cs_klt_get_profile: bad arguments");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    CS_HIP(hipStreamSynchronize(k->stream));
+    double total = 0;
+    for (auto& p : *k->ev_pairs) {
+        float ms = 0;
+        CS_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+        total += (double)ms * 1e3;
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    *tracker_us = total;
+    *n_frames = (int)k->ev_pairs->size();
+    k->ev_pairs->clear();
+    if (launches_per_frame) {
+        const cs_klt_config& c = k->cfg;
+        int skip = c.levelSkip > 0 ? c.levelSkip : (c.nLevels - 1);
+        if (skip <= 0) skip = 1;
+        int lv = 0;
+        for (int level = k->L - 1; level >= 0; level -= skip) ++lv;
+        *launches_per_frame = !c.trackWithGain ? 1 : (k->use_fused ? 1 : lv * c.nIterations + 1);
+    }
+    return CS_OK;
+}
+
 int cs_klt_set_fused(cs_klt* k, int on) {
     CS_REQUIRE(k, "null handle");
     if (k->allocated) {
@@ -563,7 +620,7 @@ static int run_dev(cs_klt* k, int mode, const void* d_image, void* d_dest, void*
         if (mode == 1) return enqueue_redetect(k, img, (cs_klt_feature*)d_dest, (int*)d_counts);
         return enqueue_track(k, img, (cs_klt_feature*)d_dest, (int*)d_counts, false);
     };
-    if (!k->use_graphs) return enqueue((const uint8_t*)d_image);
+    if (!k->use_graphs || k->profiling) return enqueue((const uint8_t*)d_image);
     CS_HIP(hipMemcpyAsync(k->d_img, d_image, (size_t)k->W * k->H, hipMemcpyDeviceToDevice, k->stream));
     for (auto& g : *k->graphs) {
         if (g.mode == mode && g.b0 == k->b0 && g.b1 == k->b1 && g.b2 == k->b2 && g.p0 == k->p0 && g.p1 == k->p1 &&

@@ -178,6 +178,14 @@ class KLT_SequenceTracker:
     def enable_graphs(self, on=True):
         check(self._L.cs_klt_enable_graphs(self._h, 1 if on else 0), "cs_klt_enable_graphs")
 
+    def set_profiling(self, on=True):
+        check(self._L.cs_klt_set_profiling(self._h, 1 if on else 0), "cs_klt_set_profiling")
+
+    def get_profile(self):
+        us, n, lpf = C.c_double(0), C.c_int(0), C.c_int(0)
+        check(self._L.cs_klt_get_profile(self._h, C.byref(us), C.byref(n), C.byref(lpf)), "cs_klt_get_profile")
+        return {"tracker_us_total": us.value, "frames": n.value, "launches_per_frame": lpf.value}
+
     def set_fused(self, on=True):
         check(self._L.cs_klt_set_fused(self._h, 1 if on else 0), "cs_klt_set_fused")
 
