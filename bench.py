@@ -171,10 +171,9 @@ def main():
     d_baT = torch.from_numpy(ba["ts0"].reshape(-1).copy()).to(dev)
     d_baM = torch.from_numpy(ba["pts0"].reshape(-1).copy()).to(dev)
 
-    # all-gather payload at the merge step: features (N x 20 B) + pose (12 doubles = 96 B) as int32 words
-    words = N_FEAT * 5 + 24
-    d_send = torch.zeros(words, dtype=torch.int32, device=dev)
-    d_recv = torch.zeros(words * world, dtype=torch.int32, device=dev) if world > 1 else None
+    # all-gather payload at the merge step: features (N x 20 B) + pose (12 doubles = 96 B)
+    from coslam_amd.multicam import CameraExchange
+    xchg = CameraExchange(N_FEAT, dev) if world > 1 else None
 
     def step(i):
         f = order[i % len(order)]
@@ -188,10 +187,8 @@ def main():
         if args.ba_every > 0 and (i + 1) % args.ba_every == 0:
             ba_ws.solve_dev(ba_stream, d_baR.data_ptr(), d_baT.data_ptr(), d_baM.data_ptr(), 2, 2, 6.0, 2, 10)
         if world > 1:
-            d_send[: N_FEAT * 5].copy_(d_dest, non_blocking=True)
-            d_send[N_FEAT * 5: N_FEAT * 5 + 18].copy_(d_Ropt.view(torch.int32), non_blocking=True)
-            d_send[N_FEAT * 5 + 18:].copy_(d_topt.view(torch.int32), non_blocking=True)
-            dist.all_gather_into_tensor(d_recv, d_send)
+            xchg.pack(d_dest, d_Ropt, d_topt)
+            xchg.all_gather()
 
     def barrier():
         torch.cuda.synchronize()

@@ -3,7 +3,7 @@
 // Replaces the external LibVisualSLAM call bundleAdjustRobust(nCamsCon,Ks,Rs,Ts,nPtsCon,pts,meas,maxErr,
 // maxIter,innerMaxIter) reached from src/app/SL_CoSLAMRobustBA.cpp:170-180 (local BA),
 // SL_InterCamPoseEstimator.cpp:92-95 (inter-camera pose) and SL_MergeCameraGroup.cpp:646-647.  The
-// algorithm is the one defined in oracle/ba_oracle.c (the library is not vendored: parity unpinned).
+// algorithm is the one defined in DESIGN.md "Robust BA" (the library is not vendored: parity unpinned).
 //
 // Design: measurements live in HBM grouped by point (CSR), with a second index by camera and a dense
 // (point, camera) -> measurement table.  One LM step is a short chain of kernels and the LM / outlier
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_linearize(BaDev D) {
     int nIn = 0;
     for (int o = o0 + lane; o < o1; o += 64) nIn += D.outlier[o] ? 0 : 1;
     nIn = cs_wave_sum_i(nIn);
-    // a point seen by fewer than two inlier measurements has no depth constraint: hold it (oracle/ba_oracle.c)
+    // a point seen by fewer than two inlier measurements has no depth constraint: hold it (DESIGN.md "Robust BA")
     const bool freeP = (i >= D.nPtsCon) && (nIn >= 2);
     const double lambda = D.st->lambda;
     const double M[3] = {D.pts[3 * i], D.pts[3 * i + 1], D.pts[3 * i + 2]};

@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.npz.
+
+pose_golden.npz  -- inputs and outputs of the REFERENCE's own intraCamEstimate (src/slam/SL_IntraCamPose.cpp compiled in
+                    place into oracle/_ref/libintracam_ref.so by oracle/Makefile).  Needs /root/reference; run in the build
+                    container only.  These vectors pin oracle/pose_oracle.c and the HIP pose kernel to the reference.
+klt_golden.npz   -- small KLT cases (pyramid texels, detection list, two tracked frames) produced by oracle/klt_oracle.c.
+                    The reference's KLT cannot run here (Cg/OpenGL), so these pin our restatement against regressions;
+                    they are NOT reference outputs (parity unpinned, see oracle/klt_oracle.h).
+ba_golden.npz    -- cfg1-shaped BA problem solved by oracle/ba_oracle.c (our definition; parity unpinned).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import oracle  # noqa: E402
+from coslam_amd.klt import KLT_SequenceTrackerConfig  # noqa: E402
+from coslam_amd.synth import Scene, make_ba_problem, rodrigues  # noqa: E402
+
+
+def pose_cases():
+    out = {}
+    sc = Scene(1, 640, 480, 3000, seed=77)
+    rng = np.random.default_rng(5)
+    n_cases = 6
+    for c in range(n_cases):
+        npts = [192, 192, 64, 12, 300, 192][c]
+        R, t = sc.pose(0, 2 * c)
+        uv, vis = sc.project(0, 2 * c)
+        idx = np.nonzero(vis)[0][:npts]
+        Ms = sc.points[idx]
+        ms = uv[idx] + 0.5 * rng.standard_normal((len(idx), 2))
+        ms[: max(1, npts // 20)] += 30 * rng.standard_normal((max(1, npts // 20), 2))
+        R0 = R @ rodrigues(0.01 * rng.standard_normal(3))
+        t0 = t + 0.03 * rng.standard_normal(3)
+        prev = None if c % 2 == 0 else np.abs(rng.standard_normal(len(idx))) * 5
+        ok, Rr, tr, st = oracle.ref_intracam_estimate(sc.K, R0, t0, len(idx), prev, Ms, ms, 10.0)
+        out[f"K{c}"], out[f"R0{c}"], out[f"t0{c}"], out[f"Ms{c}"], out[f"ms{c}"] = sc.K, R0, t0, Ms, ms
+        out[f"prev{c}"] = np.zeros(0) if prev is None else prev
+        out[f"ok{c}"], out[f"R{c}"], out[f"t{c}"] = np.array([ok]), Rr, tr
+        out[f"stats{c}"] = np.array([st["err"], st["errRW"], st["lambda_"], st["nIterLM"], st["nIterRW"], st["retTypeLM"]])
+    out["n"] = np.array([n_cases])
+    return out
+
+
+def klt_cases():
+    W, H, L, fw, fh = 160, 120, 3, 10, 8
+    sc = Scene(1, W, H, 260, seed=9, sigma=1.4)
+    imgs = np.stack([sc.render(0, f) for f in range(3)])
+    out = {"images": imgs, "dims": np.array([W, H, L, fw, fh])}
+    for gain in (0, 1):
+        cfg = KLT_SequenceTrackerConfig(nIterations=6, nLevels=L, levelSkip=1, windowWidth=7, trackWithGain=gain,
+                                        minCornerness=800.0, convergenceThreshold=1.0, SSD_Threshold=20000.0, minDistance=5)
+        o = oracle.SequenceTracker(cfg)
+        o.allocate(W, H, L, fw, fh)
+        n0, d0 = o.detect(imgs[0])
+        out[f"pyr{gain}"] = o.read_pyramid()
+        out[f"corner{gain}"] = o.read_cornerness()
+        o.advanceFrame()
+        n1, d1 = o.redetect(imgs[1])
+        o.advanceFrame()
+        n2, d2 = o.track(imgs[2])
+        out[f"n{gain}"] = np.array([n0, n1, n2])
+        for k, d in enumerate((d0, d1, d2)):
+            out[f"status{gain}_{k}"], out[f"pos{gain}_{k}"], out[f"gain{gain}_{k}"] = d["status"], d["pos"], d["gain"]
+    return out
+
+
+def ba_case():
+    pr = make_ba_problem()
+    P = len(pr["pts0"])
+    ptr, cam, xy, _ = oracle.csr_by_point(P, pr["obs_pt"], pr["obs_cam"], pr["obs_xy"])
+    R, T, M, outl, st = oracle.ba_robust(pr["Ks"], pr["Rs0"], pr["ts0"], pr["pts0"], ptr, cam, xy, 2, 2, 6.0, 2, 10)
+    return dict(Ks=pr["Ks"], Rs0=pr["Rs0"], ts0=pr["ts0"], pts0=pr["pts0"], ptr=ptr, cam=cam, xy=xy, R=R, T=T, M=M,
+                outlier=outl, stats=np.array([st.cost0, st.cost, st.nIterTotal, st.nOuter, st.nOutliers]))
+
+
+if __name__ == "__main__":
+    if not oracle.have_ref():
+        raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
+    np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
+    np.savez_compressed(os.path.join(HERE, "klt_golden.npz"), **klt_cases())
+    np.savez_compressed(os.path.join(HERE, "ba_golden.npz"), **ba_case())
+    print("golden fixtures written")
