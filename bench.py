@@ -236,8 +236,14 @@ def main():
         launches = max(prof["launches_per_frame"], 1)
         avg_us = prof["tracker_us_total"] / max(prof["frames"], 1) / launches
         ach = (alg_bytes / launches) / (avg_us * 1e-6) / 1e9
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_tracker_pmc.json")
+        if launches == 1 and os.path.exists(pmc_file):  # HBM bytes per launch from the committed rocprofv3 --pmc passes
+            pj = json.load(open(pmc_file))
+            traffic, traffic_src = pj["traffic_bytes_per_launch"], "profiles/r01_tracker_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
         roof = {"bound": "hbm", "kernel": "k_track_gain_fused" if launches == 1 else "k_track_gain_pass",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_us": avg_us,
                 "launches_per_frame": launches, "frames_timed": prof["frames"]}
 

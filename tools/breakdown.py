@@ -59,3 +59,11 @@ def bafn(i):
     ws.solve_dev(stream, d_baR.data_ptr(), d_baT.data_ptr(), d_baM.data_ptr(), 2, 2, 6.0, 2, 10)
 print("BA (2,10): %.1f us/call (host %.1f us)" % timeit(bafn, 50, 5))
 print(ws.download()[4].nIterTotal, "LM iterations")
+
+# PCIe-inclusive: the reference-shaped host entry point (image upload + dest read-back + sync every frame)
+trk = coslam_amd.KLT_SequenceTracker(bench.klt_config(), 0)
+trk.allocate(640, 480, 4, 50, 40)
+trk.detect(frames[0]); trk.advanceFrame()
+def host(i):
+    trk.redetect(frames[order[(i + 1) % len(order)]]); trk.advanceFrame()
+print("KLT redetect through the host-pointer API (H2D image + D2H dest + sync): %.1f us/frame (host %.1f)" % timeit(host, 200, 20))
