@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--sync-ba", action="store_true", help="run the local BA on the tracking stream instead of its own")
+    ap.add_argument("--no-pose", action="store_true", help="diagnostic: skip the pose leg (result not a valid bench line)")
+    ap.add_argument("--serial", action="store_true", help="diagnostic: tracker, pose and BA on ONE stream (no overlap)")
     ap.add_argument("--ba-every", type=int, default=BA_EVERY, help="diagnostic: 0 disables the BA leg (result not a valid bench line)")
     args = ap.parse_args()
 
@@ -147,11 +149,23 @@ def main():
     d_dest = torch.zeros(N_FEAT * 5, dtype=torch.int32, device=dev)
     d_counts = torch.zeros(4, dtype=torch.int32, device=dev)
 
-    stream = torch.cuda.current_stream().cuda_stream
-    # the reference runs local BA on a worker thread next to tracking (src/app/SL_CoSLAM.cpp:1702-1730, one request in
-    # flight at a time); here that is a second HIP stream
-    ba_torch_stream = torch.cuda.current_stream() if args.sync_ba else torch.cuda.Stream(device=dev)
+    # Three HIP streams, mirroring the reference's thread structure and data dependences:
+    #   klt_stream   the per-frame tracker (GPUKLT::next) -- frame f+1 only needs the tracker state of frame f;
+    #   pose_stream  intraCamEstimate of frame f: waits (event) for the tracker of frame f, runs next to the tracker
+    #                of frame f+1; the all-gather of features||pose at the merge step (N > 1) follows it on this stream;
+    #   ba_stream    local BA: the reference runs it on a worker thread next to tracking
+    #                (src/app/SL_CoSLAM.cpp:1702-1730, one request in flight at a time).
+    # --serial puts everything back on one stream (diagnostic).
+    klt_torch_stream = torch.cuda.Stream(device=dev)
+    pose_torch_stream = klt_torch_stream if args.serial else torch.cuda.Stream(device=dev)
+    ba_torch_stream = klt_torch_stream if (args.sync_ba or args.serial) else torch.cuda.Stream(device=dev)
+    stream = klt_torch_stream.cuda_stream
+    pose_stream = pose_torch_stream.cuda_stream
     ba_stream = ba_torch_stream.cuda_stream
+    # dest[] is double-buffered: the pose / exchange stage of frame f reads it while the tracker of frame f+1 writes
+    d_dests = [d_dest, torch.zeros_like(d_dest)]
+    klt_done = [torch.cuda.Event(), torch.cuda.Event()]
+    dest_free = [torch.cuda.Event(), torch.cuda.Event()]
     trk = coslam_amd.KLT_SequenceTracker(klt_config(), device=local_rank)
     trk.allocate(W, H, LEVELS, FW, FH)
     trk.set_stream(stream)
@@ -177,18 +191,28 @@ def main():
 
     def step(i):
         f = order[i % len(order)]
-        trk.redetect_dev(d_frames[f].data_ptr(), d_dest.data_ptr(), d_counts.data_ptr())
+        b = i & 1
+        if i >= 2:
+            klt_torch_stream.wait_event(dest_free[b])      # the consumer of this dest buffer two frames ago is done
+        trk.redetect_dev(d_frames[f].data_ptr(), d_dests[b].data_ptr(), d_counts.data_ptr())
         trk.advanceFrame()
-        d_opt.copy_(d_opt0, non_blocking=True)
-        intraCamEstimate_batch_dev(stream, 1, N_POSE_PTS, d_K.data_ptr(), d_R0[f].data_ptr(), d_t0[f].data_ptr(),
-                                   d_npts.data_ptr(), 0, d_Ms[f].data_ptr(), d_ms[f].data_ptr(), 10.0,
-                                   d_Ropt.data_ptr(), d_topt.data_ptr(), d_opt.data_ptr(), d_ok.data_ptr(),
-                                   device=local_rank)
+        klt_done[b].record(klt_torch_stream)
+        pose_torch_stream.wait_event(klt_done[b])          # pose(f) consumes what the tracker produced for frame f
+        with torch.cuda.stream(pose_torch_stream):
+            if args.no_pose:
+                pass
+            else:
+              d_opt.copy_(d_opt0, non_blocking=True)
+              intraCamEstimate_batch_dev(pose_stream, 1, N_POSE_PTS, d_K.data_ptr(), d_R0[f].data_ptr(),
+                                         d_t0[f].data_ptr(), d_npts.data_ptr(), 0, d_Ms[f].data_ptr(), d_ms[f].data_ptr(),
+                                         10.0, d_Ropt.data_ptr(), d_topt.data_ptr(), d_opt.data_ptr(), d_ok.data_ptr(),
+                                         device=local_rank)
+            if world > 1:
+                xchg.pack(d_dests[b], d_Ropt, d_topt)
+                xchg.all_gather()
+            dest_free[b].record(pose_torch_stream)
         if args.ba_every > 0 and (i + 1) % args.ba_every == 0:
             ba_ws.solve_dev(ba_stream, d_baR.data_ptr(), d_baT.data_ptr(), d_baM.data_ptr(), 2, 2, 6.0, 2, 10)
-        if world > 1:
-            xchg.pack(d_dest, d_Ropt, d_topt)
-            xchg.all_gather()
 
     def barrier():
         torch.cuda.synchronize()
@@ -197,7 +221,7 @@ def main():
             torch.cuda.synchronize()
 
     # first frame: detect (GPUKLT::first, reference src/tracking/GPUKLT.cpp:133-142)
-    trk.detect_dev(d_frames[order[0]].data_ptr(), d_dest.data_ptr(), d_counts.data_ptr())
+    trk.detect_dev(d_frames[order[0]].data_ptr(), d_dests[0].data_ptr(), d_counts.data_ptr())
     trk.advanceFrame()
     for i in range(args.warmup):
         step(i + 1)
@@ -205,6 +229,7 @@ def main():
     t_begin = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i + 1)
+    t_host = time.perf_counter() - t_begin
     barrier()
     dt = time.perf_counter() - t_begin
     if world > 1:
@@ -212,7 +237,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    n_live = int((d_dest.cpu().numpy().view(coslam_amd.KLT_TrackedFeature)["status"] >= 0).sum())
+    last = (args.warmup + args.steps) & 1
+    n_live = int((d_dests[last].cpu().numpy().view(coslam_amd.KLT_TrackedFeature)["status"] >= 0).sum())
     pose_ok = int(d_ok.item())
 
     # ---- roofline of the dominant kernel: the KLT gain tracker (all levels x iterations in one persistent launch).
@@ -265,8 +291,10 @@ def main():
                                    "frame; all-gather of features+pose when N>1",
                        "cameras": n_gpus, "live_features_last_frame": n_live, "pose_ok": pose_ok,
                        "hip_graphs": bool(not args.no_graphs and hasattr(trk, "enable_graphs")),
-                       "local_ba": "own HIP stream, like the reference's BA worker thread" if not args.sync_ba
-                       else "on the tracking stream"},
+                       "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
+                       "streams": "one stream (--serial)" if args.serial else
+                       "tracker | pose (event-ordered behind the tracker of the same frame) | local BA "
+                       "(own stream, like the reference's BA worker thread)"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

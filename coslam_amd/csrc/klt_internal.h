@@ -43,6 +43,8 @@ struct CsGainFusedArgs {
     float lambda, delta;
     int n1x[4], n1y[4];
     int* err;
+    int variant, pollDepth, pollGap;  // hand-off tuning (klt_track.hip)
+    unsigned long long* probe;        // diagnostic per-wave cycle counters (8 per slot) or null
 };
 
 // mode 0: detect (all slots free, v3d_gpuklt.cpp:716-734)

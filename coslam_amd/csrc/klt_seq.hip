@@ -80,6 +80,7 @@ struct cs_klt {
     bool use_fused;
     unsigned long long* d_gran;
     int* d_err;
+    unsigned long long* d_probe;  // diagnostic cycle counters of the persistent tracker (cs_klt_debug_probe)
     // hipGraph cache for the *_dev entry points: one executable graph per (call, buffer rotation state)
     bool use_graphs;
     struct GraphEntry {
@@ -189,6 +190,15 @@ static int enqueue_tracker(cs_klt* k) {
             f.n1y[3] = -1;
         }
         f.err = k->d_err;
+        f.probe = k->d_probe;
+        {
+            const char* ev = getenv("COSLAM_TRACK_VARIANT");
+            f.variant = ev ? atoi(ev) : 2;
+            const char* ed = getenv("COSLAM_TRACK_POLLDEPTH");
+            f.pollDepth = ed ? atoi(ed) : 3;
+            const char* eg = getenv("COSLAM_TRACK_POLLGAP");
+            f.pollGap = eg ? atoi(eg) : 0;
+        }
         CS_HIP(hipMemsetAsync(k->d_gran, 0, sizeof(unsigned long long) * 2 * k->N, k->stream));
         int rcf = cs_launch_track_gain_fused(f, k->stream);
         if (rcf) return rcf;
@@ -418,6 +428,8 @@ int cs_klt_deallocate(cs_klt* k) {
     hipFree(k->d_present);
     hipFree(k->d_gran);
     hipFree(k->d_err);
+    if (k->d_probe) hipFree(k->d_probe);
+    k->d_probe = nullptr;
     {
         std::lock_guard<std::mutex> g(g_reg_mutex);
         g_live_handles[k->device & 63]--;
@@ -600,6 +612,26 @@ int cs_klt_set_fused(cs_klt* k, int on) {
         drop_graphs(k);
     }
     k->use_fused = on != 0;
+    return CS_OK;
+}
+
+// diagnostic: per-slot cycle counters of the persistent gain tracker {texel wait, arithmetic, hand-off wait, solve +
+// publish, polls, total, start, XCC id}; eager launches only (drops the graph cache)
+int cs_klt_debug_probe(cs_klt* k, int on, unsigned long long* host_out8) {
+    CS_REQUIRE(k && k->allocated, "not allocated");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    CS_HIP(hipStreamSynchronize(k->stream));
+    drop_graphs(k);
+    if (host_out8 && k->d_probe)
+        CS_HIP(hipMemcpy(host_out8, k->d_probe, sizeof(unsigned long long) * 8 * k->N, hipMemcpyDeviceToHost));
+    if (on && !k->d_probe) {
+        CS_HIP(hipMalloc((void**)&k->d_probe, sizeof(unsigned long long) * 8 * k->N));
+        CS_HIP(hipMemset(k->d_probe, 0, sizeof(unsigned long long) * 8 * k->N));
+    } else if (!on && k->d_probe) {
+        CS_HIP(hipFree(k->d_probe));
+        k->d_probe = nullptr;
+    }
     return CS_OK;
 }
 

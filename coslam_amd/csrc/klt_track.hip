@@ -136,6 +136,53 @@ __global__ __launch_bounds__(256) void k_track_nogain(const cs_texel* __restrict
     }
 }
 
+// ---- with gain: the 3x3 Gauss-Newton solve, split where the neighbours' gains enter ---------------------------
+// klt_tracker_with_gain.cg:111-134.  The shader adds delta * bsum to the third right-hand side once per window
+// pixel; here the per-pixel part is wave-summed on its own and delta * bsum enters as nPix * (delta * bsum), so
+// that (in the persistent kernel) nothing but one multiply-add per Cramer row waits for the hand-off.  Both gain
+// kernels go through these three functions: their results are bit-identical to each other.
+struct CsGainSolve {
+    float det, rcp, pX, pY, pZ, C_, E_, F_;
+};
+
+__device__ __forceinline__ CsGainSolve cs_gain_solve_prepare(float a, float b, float c, float d, float e_, float f,
+                                                             float r0, float r1) {
+    CsGainSolve S;
+    float det = a * d * f + 2.0f * b * c * e_;
+    det -= (a * e_ * e_ + b * b * f) + c * c * d;
+    S.det = det;
+    S.rcp = 1.0f / det;
+    const float A_ = d * f - e_ * e_, B_ = c * e_ - b * f, D_ = a * f - c * c;
+    S.C_ = b * e_ - c * d;
+    S.E_ = b * c - a * e_;
+    S.F_ = a * d - b * b;
+    S.pX = A_ * r0 + B_ * r1;
+    S.pY = B_ * r0 + D_ * r1;
+    S.pZ = S.C_ * r0 + S.E_ * r1;
+    return S;
+}
+
+__device__ __forceinline__ void cs_gain_solve_finish(const CsGainSolve& S, float r2s, float nPixF, float delta,
+                                                     float bsum, float& dX, float& dY, float& dZ) {
+    const float r2 = r2s + nPixF * (delta * bsum);
+    dX = (S.pX + S.C_ * r2) * S.rcp;
+    dY = (S.pY + S.E_ * r2) * S.rcp;
+    dZ = (S.pZ + S.F_ * r2) * S.rcp;
+}
+
+// nb: lanes 0..3 hold betaN1, lanes 4..7 betaN2 (negative = dead neighbour -> own gain); dot(1, N1 + N2 - 2 beta).
+// The substitution and the pair sums run in the lanes (one row_shl:4 DPP add), four v_readlane and three adds finish.
+__device__ __forceinline__ float cs_gain_bsum(float nb, float beta) {
+    const float v = (nb < 0) ? beta : nb;
+    const float pair = v + cs_dpp_f<0x104, 0xf>(v);  // lane q: N1[q] + N2[q]   (row_shl:4: lane i reads lane i + 4)
+    const float t = pair - 2.0f * beta;
+    const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 0));
+    const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 1));
+    const float t2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 2));
+    const float t3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 3));
+    return ((t0 + t1) + t2) + t3;
+}
+
 // ---- with gain: one launch of klt_tracker_with_gain.cg:42-148 --------------------------------
 __device__ __forceinline__ float slot_beta(const float* __restrict__ feat, int fw, int fh, int i, int j) {
     i = cs_clampi(i, 0, fw - 1);
@@ -171,7 +218,7 @@ __global__ __launch_bounds__(256) void k_track_gain_pass(CsGainPassArgs A) {
     }
     const int hw = A.hw, fwid = 2 * hw + 1, nPix = fwid * fwid;
     const float dsx = 1.0f / (float)A.Wl, dsy = 1.0f / (float)A.Hl;
-    float a = 0, b = 0, c = 0, d = 0, e_ = 0, f = 0, r0 = 0, r1 = 0, r2 = 0, ssd = 0;
+    float a = 0, b = 0, c = 0, d = 0, e_ = 0, f = 0, r0 = 0, r1 = 0, r2s = 0, ssd = 0;
     for (int p = lane; p < nPix; p += 64) {
         int py = p / fwid, px = p - py * fwid;
         float ox = (float)(px - hw) * dsx, oy = (float)(py - hw) * dsy;
@@ -191,7 +238,7 @@ __global__ __launch_bounds__(256) void k_track_gain_pass(CsGainPassArgs A) {
         f += (I0 * I0 + A.lambda * m0 * m0) + A.delta * 8.0f;
         r0 += ex * gx;
         r1 += ex * gy;
-        r2 += (-ex * I0 + A.lambda * m0 * (m1 - beta * m0)) + A.delta * bsum;
+        r2s += -ex * I0 + A.lambda * m0 * (m1 - beta * m0);
         ssd += ex * ex;
     }
     a = cs_wave_sum(a);
@@ -202,20 +249,13 @@ __global__ __launch_bounds__(256) void k_track_gain_pass(CsGainPassArgs A) {
     f = cs_wave_sum(f);
     r0 = cs_wave_sum(r0);
     r1 = cs_wave_sum(r1);
-    r2 = cs_wave_sum(r2);
+    r2s = cs_wave_sum(r2s);
     const float SSD = cs_wave_sum(ssd);
 
-    float det = a * d * f + 2.0f * b * c * e_;
-    det -= (a * e_ * e_ + b * b * f) + c * c * d;
-    const float rcp = 1.0f / det;
-    const float A_ = d * f - e_ * e_, B_ = c * e_ - b * f, C_ = b * e_ - c * d;
-    const float D_ = a * f - c * c, E_ = b * c - a * e_, F_ = a * d - b * b;
-    float dX = (A_ * r0 + B_ * r1) + C_ * r2;
-    float dY = (B_ * r0 + D_ * r1) + E_ * r2;
-    float dZ = (C_ * r0 + E_ * r1) + F_ * r2;
-    dX *= rcp;
-    dY *= rcp;
-    dZ *= rcp;
+    const CsGainSolve S = cs_gain_solve_prepare(a, b, c, d, e_, f, r0, r1);
+    const float det = S.det;
+    float dX, dY, dZ;
+    cs_gain_solve_finish(S, r2s, (float)nPix, A.delta, bsum, dX, dY, dZ);
     X1x += dX;
     X1y += dY;
     const float ux = dX * A.whx, uy = dY * A.why;
@@ -248,6 +288,12 @@ __global__ __launch_bounds__(256) void k_track_gain_pass(CsGainPassArgs A) {
 // the grid must be co-resident (the launcher checks the grid against the device); every spin is bounded and a
 // timeout raises *err instead of hanging the GPU.  Frame-0 samples are fetched once per level and kept in
 // registers.  Arithmetic per pass is identical to k_track_gain_pass (bit-identical results).
+//
+// Critical path of a pass (cycle counters, tools/track_sweep.py): a hand-off costs ~1.5 us from publish to the
+// neighbour's successful poll, so everything that does not need the neighbours' gains is finished BEFORE the
+// sweep -- all ten window sums and their wave folds, the adjugate, 1/det and the two-thirds of each Cramer row
+// that multiply r0, r1 -- and only `bsum`, one multiply-add per row, the validity tests and the publish remain
+// behind it.
 typedef unsigned long long cs_granule;
 typedef __attribute__((address_space(1))) cs_granule gu64;
 
@@ -259,8 +305,10 @@ __device__ __forceinline__ void gran_store(cs_granule* p, unsigned tag, float be
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int NPL>
+template <int NPL, bool PROBE = false>
 __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
+    unsigned long long tTex = 0, tMath = 0, tPoll = 0, tPost = 0, nPoll = 0, tStart = 0, tm0 = 0, tm1 = 0;
+    if (PROBE) tStart = __builtin_amdgcn_s_memtime();
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= A.N) return;
@@ -268,14 +316,15 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
     float X1x = A.featStart[3 * k], X1y = A.featStart[3 * k + 1];
     float beta = 1.0f;  // v3d_gpuklt.cpp:223-227
     bool dead = (X1x < 0) || (X0x < 0);
-    // previous-pass state (what the multi-launch schedule leaves in the other ping-pong buffer)
     float pX = X1x, pY = X1y, pB = 1.0f;
 
     cs_granule* gran0 = A.gran;
     cs_granule* gran1 = A.gran + A.N;
     if (lane == 0) gran_store(gran0 + k, 1u, 1.0f);  // beta_0 = 1 for every slot, dead or alive
 
-    // neighbour slots: lanes 0..3 = betaN1, lanes 4..7 = betaN2 (klt_tracker_with_gain.cg:64-72)
+    // neighbour slots: lanes 0..3 = betaN1, lanes 4..7 = betaN2 (klt_tracker_with_gain.cg:64-72); every other
+    // lane (and a neighbour that clamps onto the slot itself) points at the wave's own granule, whose line the
+    // row neighbours share, so the sweep is one unconditional load per lane
     const int si = k % A.fw, sj = k / A.fw;
     int nbSlot = k;
     if (lane < 8) {
@@ -290,6 +339,7 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
         }
         nbSlot = cs_clampi(sj + dy, 0, A.fh - 1) * A.fw + cs_clampi(si + dx, 0, A.fw - 1);
     }
+    const bool polls = (nbSlot != k);
 
     const int hw = A.hw, fwid = 2 * hw + 1, nPix = fwid * fwid;
     const float whx = (float)A.W, why = (float)A.H;
@@ -311,104 +361,106 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
         }
         for (int iter = 1; iter <= A.nIter; ++iter) {
             ++pass;
-            // the frame-1 footprints do not depend on the neighbours: put their loads in flight first so that the
-            // L2 round trip overlaps the hand-off wait
+            const cs_granule* src = (((pass - 1) & 1u) ? gran1 : gran0) + nbSlot;
+            if (PROBE) tm0 = __builtin_amdgcn_s_memtime();
             float J1[NPL], J1x[NPL], J1y[NPL];
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
                 J1[q] = J1x[q] = J1y[q] = 0.0f;
                 if (!dead && lane + 64 * q < nPix) sample(L1, Wl, Hl, X1x + ox[q], X1y + oy[q], J1[q], J1x[q], J1y[q]);
             }
-            // ---- sweep the neighbours' granules of the previous pass --------------------------------------
+            if (PROBE) {
+                asm volatile("" : "+v"(J1[0]));
+                tm1 = __builtin_amdgcn_s_memtime();
+                tTex += tm1 - tm0;
+                tm0 = tm1;
+            }
+            // ---- everything that does not need the neighbours ------------------------------------------
+            float a = 0, b = 0, c = 0, d = 0, e_ = 0, f = 0, r0 = 0, r1 = 0, r2s = 0, ssd = 0;
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                if (lane + 64 * q < nPix) {
+                    const float I1 = J1[q], I1x = J1x[q], I1y = J1y[q];
+                    float ex = beta * I0[q] - I1;
+                    float gx = (beta * I0x[q] + I1x) * whx / 2.0f;
+                    float gy = (beta * I0y[q] + I1y) * why / 2.0f;
+                    float m0 = sqrtf(I0x[q] * I0x[q] + I0y[q] * I0y[q]);
+                    float m1 = sqrtf(I1x * I1x + I1y * I1y);
+                    a += gx * gx;
+                    b += gx * gy;
+                    c += gx * (-I0[q]);
+                    d += gy * gy;
+                    e_ += gy * (-I0[q]);
+                    f += (I0[q] * I0[q] + A.lambda * m0 * m0) + A.delta * 8.0f;
+                    r0 += ex * gx;
+                    r1 += ex * gy;
+                    r2s += -ex * I0[q] + A.lambda * m0 * (m1 - beta * m0);
+                    ssd += ex * ex;
+                }
+            }
+            // The first poll goes out here: a poll is a ~0.4 us fabric round trip and every pass needs at least one, so it
+            // flies under the ten wave folds and the adjugate and has landed when they are done.
+            cs_granule got = gran_load(src);
+            if (PROBE) ++nPoll;
+            a = cs_wave_sum(a);
+            b = cs_wave_sum(b);
+            c = cs_wave_sum(c);
+            d = cs_wave_sum(d);
+            e_ = cs_wave_sum(e_);
+            f = cs_wave_sum(f);
+            r0 = cs_wave_sum(r0);
+            r1 = cs_wave_sum(r1);
+            r2s = cs_wave_sum(r2s);
+            const float SSD = cs_wave_sum(ssd);
+            const CsGainSolve S = cs_gain_solve_prepare(a, b, c, d, e_, f, r0, r1);
+            // thresholds: v3d_gpuklt.cpp:271-279
+            const bool real = (iter == A.nIter) && (iter != 1);
+            const float sqrConvThr = real ? A.sqrConvThr : 1000000.0f;
+            const float ssdThr = real ? A.ssdThr : 1000000.0f;
+            const float vr0 = real ? A.vr[0] : -1.0f, vr1 = real ? A.vr[1] : -1.0f;
+            const float vr2 = real ? A.vr[2] : 2.0f, vr3 = real ? A.vr[3] : 2.0f;
+            float invalidEarly = ((S.det < 0.00001f) || (SSD > ssdThr)) ? 1.0f : 0.0f;
+            CsGainSolve Sp = S;
+            // pin the prepared solve in registers here: without this the compiler sinks the whole adjugate and the
+            // IEEE division below the sweep, back onto the hand-off's critical path
+            asm volatile("; solve prepared" : "+v"(Sp.rcp), "+v"(Sp.pX), "+v"(Sp.pY), "+v"(Sp.pZ), "+v"(Sp.C_), "+v"(Sp.E_),
+                         "+v"(Sp.F_), "+v"(invalidEarly), "+v"(r2s));
+            if (PROBE) {
+                tm1 = __builtin_amdgcn_s_memtime();
+                tMath += tm1 - tm0;
+                tm0 = tm1;
+            }
+            // ---- sweep the neighbours' granules of the previous pass ----------------------------------------
             float nbBeta = beta;
             {
-                const cs_granule* src = ((pass - 1) & 1u) ? gran1 : gran0;
-                bool ok = true;
                 unsigned spins = 0;
-                do {
-                    ok = true;
-                    if (lane < 8 && nbSlot != k) {
-                        cs_granule g = gran_load(src + nbSlot);
-                        ok = (unsigned)(g >> 32) >= pass;
-                        nbBeta = __uint_as_float((unsigned)g);
-                    }
-                    if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(2);
+#pragma nounroll
+                while (!__all(!polls || ((unsigned)(got >> 32) >= pass))) {
+                    for (int z = 0; z < A.pollGap; ++z) __builtin_amdgcn_s_sleep(1);
+                    got = gran_load(src);
+                    if (PROBE) ++nPoll;
                     if (++spins > (1u << 20)) {
                         if (lane == 0) atomicExch(A.err, 1);
                         break;
                     }
-                } while (true);
+                }
+                if (polls) nbBeta = __uint_as_float((unsigned)got);
+                if (PROBE) {
+                    asm volatile("" : "+v"(nbBeta));
+                    tm1 = __builtin_amdgcn_s_memtime();
+                    tPoll += tm1 - tm0;
+                    tm0 = tm1;
+                }
             }
             float newX = -1.0f, newY = -1.0f, newB = -1.0f;
             if (!dead) {
-                float bsum;
-                {
-                    float t4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nbBeta), q));
-                        float b2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nbBeta), 4 + q));
-                        if (b1 < 0) b1 = beta;
-                        if (b2 < 0) b2 = beta;
-                        t4[q] = (b1 + b2) - 2.0f * beta;
-                    }
-                    bsum = ((t4[0] + t4[1]) + t4[2]) + t4[3];
-                }
-                // thresholds: v3d_gpuklt.cpp:271-279
-                const bool real = (iter == A.nIter) && (iter != 1);
-                const float sqrConvThr = real ? A.sqrConvThr : 1000000.0f;
-                const float ssdThr = real ? A.ssdThr : 1000000.0f;
-                const float vr0 = real ? A.vr[0] : -1.0f, vr1 = real ? A.vr[1] : -1.0f;
-                const float vr2 = real ? A.vr[2] : 2.0f, vr3 = real ? A.vr[3] : 2.0f;
-                float a = 0, b = 0, c = 0, d = 0, e_ = 0, f = 0, r0 = 0, r1 = 0, r2 = 0, ssd = 0;
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) {
-                    if (lane + 64 * q < nPix) {
-                        const float I1 = J1[q], I1x = J1x[q], I1y = J1y[q];
-                        float ex = beta * I0[q] - I1;
-                        float gx = (beta * I0x[q] + I1x) * whx / 2.0f;
-                        float gy = (beta * I0y[q] + I1y) * why / 2.0f;
-                        float m0 = sqrtf(I0x[q] * I0x[q] + I0y[q] * I0y[q]);
-                        float m1 = sqrtf(I1x * I1x + I1y * I1y);
-                        a += gx * gx;
-                        b += gx * gy;
-                        c += gx * (-I0[q]);
-                        d += gy * gy;
-                        e_ += gy * (-I0[q]);
-                        f += (I0[q] * I0[q] + A.lambda * m0 * m0) + A.delta * 8.0f;
-                        r0 += ex * gx;
-                        r1 += ex * gy;
-                        r2 += (-ex * I0[q] + A.lambda * m0 * (m1 - beta * m0)) + A.delta * bsum;
-                        ssd += ex * ex;
-                    }
-                }
-                a = cs_wave_sum(a);
-                b = cs_wave_sum(b);
-                c = cs_wave_sum(c);
-                d = cs_wave_sum(d);
-                e_ = cs_wave_sum(e_);
-                f = cs_wave_sum(f);
-                r0 = cs_wave_sum(r0);
-                r1 = cs_wave_sum(r1);
-                r2 = cs_wave_sum(r2);
-                const float SSD = cs_wave_sum(ssd);
-                float det = a * d * f + 2.0f * b * c * e_;
-                det -= (a * e_ * e_ + b * b * f) + c * c * d;
-                const float rcp = 1.0f / det;
-                const float A_ = d * f - e_ * e_, B_ = c * e_ - b * f, C_ = b * e_ - c * d;
-                const float D_ = a * f - c * c, E_ = b * c - a * e_, F_ = a * d - b * b;
-                float dX = (A_ * r0 + B_ * r1) + C_ * r2;
-                float dY = (B_ * r0 + D_ * r1) + E_ * r2;
-                float dZ = (C_ * r0 + E_ * r1) + F_ * r2;
-                dX *= rcp;
-                dY *= rcp;
-                dZ *= rcp;
+                const float bsum = cs_gain_bsum(nbBeta, beta);
+                float dX, dY, dZ;
+                cs_gain_solve_finish(Sp, r2s, (float)nPix, A.delta, bsum, dX, dY, dZ);
                 const float nX = X1x + dX, nY = X1y + dY;
                 const float ux = dX * whx, uy = dY * why;
                 const float sqrLen = ux * ux + uy * uy;
-                bool invalid = (det < 0.00001f);
-                invalid = invalid || (SSD > ssdThr);
+                bool invalid = (invalidEarly != 0.0f);
                 invalid = invalid || (sqrLen > sqrConvThr);
                 invalid = invalid || (nX < vr0 || nY < vr1) || (nX > vr2 || nY > vr3);
                 const float nB = beta + dZ;
@@ -431,6 +483,10 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
             beta = newB;
             dead = dead || (newX < 0);
             if (lane == 0) gran_store(((pass & 1u) ? gran1 : gran0) + k, pass + 1u, beta);
+            if (PROBE) {
+                tm1 = __builtin_amdgcn_s_memtime();
+                tPost += tm1 - tm0;
+            }
         }
     }
     if (lane == 0) {
@@ -440,6 +496,17 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
         A.outPrev[3 * k] = pX;
         A.outPrev[3 * k + 1] = pY;
         A.outPrev[3 * k + 2] = pB;
+        if (PROBE && A.probe) {
+            unsigned long long* o = A.probe + 8 * (size_t)k;
+            o[0] = tTex;
+            o[1] = tMath;
+            o[2] = tPoll;
+            o[3] = tPost;
+            o[4] = nPoll;
+            o[5] = __builtin_amdgcn_s_memtime() - tStart;
+            o[6] = tStart;
+            o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);
+        }
     }
 }
 
@@ -506,6 +573,11 @@ int cs_launch_track_gain_fused(const CsGainFusedArgs& a, hipStream_t stream) {
     const int nPix = (2 * a.hw + 1) * (2 * a.hw + 1);
     const int npl = (nPix + 63) / 64;
     dim3 grid((a.N + 3) / 4), block(256);
+    if (npl <= 1 && a.probe) {
+        hipLaunchKernelGGL((k_track_gain_fused<1, true>), grid, block, 0, stream, a);
+        CS_CHECK_LAUNCH();
+        return CS_OK;
+    }
     if (npl <= 1) {
         hipLaunchKernelGGL(k_track_gain_fused<1>, grid, block, 0, stream, a);
     } else if (npl <= 2) {

@@ -189,6 +189,13 @@ class KLT_SequenceTracker:
     def set_fused(self, on=True):
         check(self._L.cs_klt_set_fused(self._h, 1 if on else 0), "cs_klt_set_fused")
 
+    def debug_probe(self, on=True, read=False):
+        """diagnostic: per-slot cycle counters of the persistent gain tracker (uint64[N, 8])"""
+        out = np.zeros((self.N, 8), dtype=np.uint64) if read else None
+        check(self._L.cs_klt_debug_probe(self._h, 1 if on else 0, out.ctypes.data_as(C.c_void_p) if read else None),
+              "cs_klt_debug_probe")
+        return out
+
     def synchronize(self):
         check(self._L.cs_klt_synchronize(self._h), "cs_klt_synchronize")
 
