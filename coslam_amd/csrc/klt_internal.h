@@ -43,7 +43,8 @@ struct CsGainFusedArgs {
     float lambda, delta;
     int n1x[4], n1y[4];
     int* err;
-    int variant, pollDepth, pollGap;  // hand-off tuning (klt_track.hip)
+    int pollGap;                      // s_sleep units between re-polls of the hand-off sweep
+    int patchR;                       // side of the wave-private LDS patch in texels (set by the launcher)
     unsigned long long* probe;        // diagnostic per-wave cycle counters (8 per slot) or null
 };
 

@@ -191,14 +191,7 @@ static int enqueue_tracker(cs_klt* k) {
         }
         f.err = k->d_err;
         f.probe = k->d_probe;
-        {
-            const char* ev = getenv("COSLAM_TRACK_VARIANT");
-            f.variant = ev ? atoi(ev) : 2;
-            const char* ed = getenv("COSLAM_TRACK_POLLDEPTH");
-            f.pollDepth = ed ? atoi(ed) : 3;
-            const char* eg = getenv("COSLAM_TRACK_POLLGAP");
-            f.pollGap = eg ? atoi(eg) : 0;
-        }
+        f.pollGap = 0;
         CS_HIP(hipMemsetAsync(k->d_gran, 0, sizeof(unsigned long long) * 2 * k->N, k->stream));
         int rcf = cs_launch_track_gain_fused(f, k->stream);
         if (rcf) return rcf;

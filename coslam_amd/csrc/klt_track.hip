@@ -47,6 +47,37 @@ __device__ __forceinline__ void sample(const cs_texel* __restrict__ lvl, int Wl,
     Iy = ((w00 * Y00 + w10 * Y10) + w01 * Y01) + w11 * Y11;
 }
 
+// The same fetch out of a wave-private LDS patch: cell (lx, ly) of `patch` (row pitch R) holds the texel at
+// (clamp(rx0 + lx), clamp(ry0 + ly)) of the level, so unclamped footprint indices minus the patch origin address it
+// and CLAMP_TO_EDGE is already folded in.  Arithmetic identical to sample().
+__device__ __forceinline__ void sample_patch(const cs_texel* patch, int R, int rx0, int ry0, int Wl, int Hl, float s,
+                                             float t, float& I, float& Ix, float& Iy) {
+    float u = s * (float)Wl - 0.5f;
+    float v = t * (float)Hl - 0.5f;
+    u = fminf(fmaxf(u, -2.0f), (float)Wl + 1.0f);
+    v = fminf(fmaxf(v, -2.0f), (float)Hl + 1.0f);
+    float fu = floorf(u), fv = floorf(v);
+    float a = u - fu, b = v - fv;
+    const cs_texel* c = patch + ((int)fv - ry0) * R + ((int)fu - rx0);
+    cs_texel t00 = c[0], t10 = c[1], t01 = c[R], t11 = c[R + 1];
+    float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    float I00, X00, Y00, I10, X10, Y10, I01, X01, Y01, I11, X11, Y11;
+    cs_unpack_texel(t00, I00, X00, Y00);
+    cs_unpack_texel(t10, I10, X10, Y10);
+    cs_unpack_texel(t01, I01, X01, Y01);
+    cs_unpack_texel(t11, I11, X11, Y11);
+    I = ((w00 * I00 + w10 * I10) + w01 * I01) + w11 * I11;
+    Ix = ((w00 * X00 + w10 * X10) + w01 * X01) + w11 * X11;
+    Iy = ((w00 * Y00 + w10 * Y10) + w01 * Y01) + w11 * Y11;
+}
+
+// floor of the (clamped) texel coordinate sample() would compute for normalised coordinate s on a level of width Wl
+__device__ __forceinline__ int footprint_floor(float s, int Wl) {
+    float u = s * (float)Wl - 0.5f;
+    u = fminf(fmaxf(u, -2.0f), (float)Wl + 1.0f);
+    return (int)floorf(u);
+}
+
 // ---- no gain: klt_tracker.cg:24-132 -----------------------------------------------------------
 template <int NPL>  // window pixels per lane = ceil((2hw+1)^2 / 64)
 __global__ __launch_bounds__(256) void k_track_nogain(const cs_texel* __restrict__ pyr0,
@@ -294,6 +325,7 @@ __global__ __launch_bounds__(256) void k_track_gain_pass(CsGainPassArgs A) {
 // sweep -- all ten window sums and their wave folds, the adjugate, 1/det and the two-thirds of each Cramer row
 // that multiply r0, r1 -- and only `bsum`, one multiply-add per row, the validity tests and the publish remain
 // behind it.
+constexpr int CS_PATCH_MARGIN = 2;
 typedef unsigned long long cs_granule;
 typedef __attribute__((address_space(1))) cs_granule gu64;
 
@@ -307,7 +339,7 @@ __device__ __forceinline__ void gran_store(cs_granule* p, unsigned tag, float be
 
 template <int NPL, bool PROBE = false>
 __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
-    unsigned long long tTex = 0, tMath = 0, tPoll = 0, tPost = 0, nPoll = 0, tStart = 0, tm0 = 0, tm1 = 0;
+    unsigned long long tTex = 0, tMath = 0, tPoll = 0, tPost = 0, nPoll = 0, nReload = 0, tStart = 0, tm0 = 0, tm1 = 0;
     if (PROBE) tStart = __builtin_amdgcn_s_memtime();
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -343,12 +375,20 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
 
     const int hw = A.hw, fwid = 2 * hw + 1, nPix = fwid * fwid;
     const float whx = (float)A.W, why = (float)A.H;
+    // wave-private LDS patch of the frame-1 level around the iterate (the window's bilinear footprint plus a margin
+    // of CS_PATCH_MARGIN texels on every side): filled once, every pass samples it; it is re-centred only when the
+    // iterate drifts out of the margin.  Keeps the per-pass texel traffic out of the CU's memory queue, where the
+    // hand-off polls wait.
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_track_smem[];
+    const int R = A.patchR;
+    cs_texel* patch = (cs_texel*)cs_track_smem + (size_t)(threadIdx.x >> 6) * R * R;
     unsigned pass = 0;
     for (int level = A.lv.L - 1; level >= 0; level -= A.levelSkip) {
         const cs_texel* L0 = A.pyr0 + A.lv.off[level];
         const cs_texel* L1 = A.pyr1 + A.lv.off[level];
         const int Wl = A.lv.w[level], Hl = A.lv.h[level];
         const float dsx = 1.0f / (float)Wl, dsy = 1.0f / (float)Hl;
+        const float oxLo = (float)(-hw) * dsx, oxHi = (float)hw * dsx, oyLo = (float)(-hw) * dsy, oyHi = (float)hw * dsy;
         float ox[NPL], oy[NPL], I0[NPL], I0x[NPL], I0y[NPL];
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
@@ -359,15 +399,47 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
             I0[q] = I0x[q] = I0y[q] = 0.0f;
             if (!dead && p < nPix) sample(L0, Wl, Hl, X0x + ox[q], X0y + oy[q], I0[q], I0x[q], I0y[q]);
         }
+        // the (I0^2 + lambda |grad I0|^2 + 8 delta) window sum does not change within a level
+        float fLevel = 0;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            if (lane + 64 * q < nPix) {
+                float m0 = sqrtf(I0x[q] * I0x[q] + I0y[q] * I0y[q]);
+                fLevel += (I0[q] * I0[q] + A.lambda * m0 * m0) + A.delta * 8.0f;
+            }
+        }
+        fLevel = cs_wave_sum(fLevel);
+        int rx0 = 0, ry0 = 0;
+        bool patchValid = false;
         for (int iter = 1; iter <= A.nIter; ++iter) {
             ++pass;
             const cs_granule* src = (((pass - 1) & 1u) ? gran1 : gran0) + nbSlot;
             if (PROBE) tm0 = __builtin_amdgcn_s_memtime();
             float J1[NPL], J1x[NPL], J1y[NPL];
+            if (!dead) {
+                // footprint extent of the whole window (the coordinate map is monotone in the window offset)
+                const int iLo = footprint_floor(X1x + oxLo, Wl), iHi = footprint_floor(X1x + oxHi, Wl) + 1;
+                const int jLo = footprint_floor(X1y + oyLo, Hl), jHi = footprint_floor(X1y + oyHi, Hl) + 1;
+                if (!patchValid || iLo < rx0 || jLo < ry0 || iHi >= rx0 + R || jHi >= ry0 + R) {
+                    rx0 = iLo - CS_PATCH_MARGIN;
+                    ry0 = jLo - CS_PATCH_MARGIN;
+                    for (int idx = lane; idx < R * R; idx += 64) {
+                        const int ly = idx / R, lx = idx - ly * R;
+                        const int gx = cs_clampi(rx0 + lx, 0, Wl - 1), gy = cs_clampi(ry0 + ly, 0, Hl - 1);
+                        patch[idx] = L1[(size_t)gy * Wl + gx];
+                    }
+                    patchValid = true;
+                    if (PROBE) ++nReload;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
                 J1[q] = J1x[q] = J1y[q] = 0.0f;
-                if (!dead && lane + 64 * q < nPix) sample(L1, Wl, Hl, X1x + ox[q], X1y + oy[q], J1[q], J1x[q], J1y[q]);
+                if (!dead && lane + 64 * q < nPix)
+                    sample_patch(patch, R, rx0, ry0, Wl, Hl, X1x + ox[q], X1y + oy[q], J1[q], J1x[q], J1y[q]);
             }
             if (PROBE) {
                 asm volatile("" : "+v"(J1[0]));
@@ -376,7 +448,8 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
                 tm0 = tm1;
             }
             // ---- everything that does not need the neighbours ------------------------------------------
-            float a = 0, b = 0, c = 0, d = 0, e_ = 0, f = 0, r0 = 0, r1 = 0, r2s = 0, ssd = 0;
+            float a = 0, b = 0, c = 0, d = 0, e_ = 0, r0 = 0, r1 = 0, r2s = 0, ssd = 0;
+            const float f = fLevel;
 #pragma unroll
             for (int q = 0; q < NPL; ++q) {
                 if (lane + 64 * q < nPix) {
@@ -391,7 +464,6 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
                     c += gx * (-I0[q]);
                     d += gy * gy;
                     e_ += gy * (-I0[q]);
-                    f += (I0[q] * I0[q] + A.lambda * m0 * m0) + A.delta * 8.0f;
                     r0 += ex * gx;
                     r1 += ex * gy;
                     r2s += -ex * I0[q] + A.lambda * m0 * (m1 - beta * m0);
@@ -407,7 +479,6 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
             c = cs_wave_sum(c);
             d = cs_wave_sum(d);
             e_ = cs_wave_sum(e_);
-            f = cs_wave_sum(f);
             r0 = cs_wave_sum(r0);
             r1 = cs_wave_sum(r1);
             r2s = cs_wave_sum(r2s);
@@ -505,7 +576,7 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
             o[4] = nPoll;
             o[5] = __builtin_amdgcn_s_memtime() - tStart;
             o[6] = tStart;
-            o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);
+            o[7] = nReload;
         }
     }
 }
@@ -569,21 +640,23 @@ int cs_launch_reset_beta(float* feat, int N, hipStream_t stream) {
     return CS_OK;
 }
 
-int cs_launch_track_gain_fused(const CsGainFusedArgs& a, hipStream_t stream) {
+int cs_track_patch_r(int hw) { return 2 * hw + 2 + 2 * CS_PATCH_MARGIN; }
+
+int cs_launch_track_gain_fused(const CsGainFusedArgs& a0, hipStream_t stream) {
+    CsGainFusedArgs a = a0;
     const int nPix = (2 * a.hw + 1) * (2 * a.hw + 1);
     const int npl = (nPix + 63) / 64;
+    a.patchR = cs_track_patch_r(a.hw);
+    const size_t lds = (size_t)4 * a.patchR * a.patchR * sizeof(cs_texel);
     dim3 grid((a.N + 3) / 4), block(256);
     if (npl <= 1 && a.probe) {
-        hipLaunchKernelGGL((k_track_gain_fused<1, true>), grid, block, 0, stream, a);
-        CS_CHECK_LAUNCH();
-        return CS_OK;
-    }
-    if (npl <= 1) {
-        hipLaunchKernelGGL(k_track_gain_fused<1>, grid, block, 0, stream, a);
+        hipLaunchKernelGGL((k_track_gain_fused<1, true>), grid, block, lds, stream, a);
+    } else if (npl <= 1) {
+        hipLaunchKernelGGL((k_track_gain_fused<1>), grid, block, lds, stream, a);
     } else if (npl <= 2) {
-        hipLaunchKernelGGL(k_track_gain_fused<2>, grid, block, 0, stream, a);
+        hipLaunchKernelGGL((k_track_gain_fused<2>), grid, block, lds, stream, a);
     } else if (npl <= 4) {
-        hipLaunchKernelGGL(k_track_gain_fused<4>, grid, block, 0, stream, a);
+        hipLaunchKernelGGL((k_track_gain_fused<4>), grid, block, lds, stream, a);
     } else {
         cs_set_error("fused gain tracker: windowWidth %d too large", 2 * a.hw + 1);
         return CS_ERR_INVALID;

@@ -20,10 +20,7 @@ def canon(dest_words):
     a["pos"][dead] = 0; a["gain"][dead] = 0
     return a.tobytes()
 
-def run(variant, depth, gap, fused=1, n=60, probe=False):
-    os.environ["COSLAM_TRACK_VARIANT"] = str(variant)
-    os.environ["COSLAM_TRACK_POLLDEPTH"] = str(depth)
-    os.environ["COSLAM_TRACK_POLLGAP"] = str(gap)
+def run(fused=1, n=60, probe=False):
     trk = coslam_amd.KLT_SequenceTracker(bench.klt_config(), 0)
     trk.allocate(640, 480, 4, 50, 40); trk.set_stream(stream); trk.set_fused(fused)
     trk.detect_dev(d_frames[0].data_ptr(), d_dest.data_ptr(), d_counts.data_ptr()); trk.advanceFrame()
@@ -42,18 +39,15 @@ def run(variant, depth, gap, fused=1, n=60, probe=False):
     trk.close()
     return prof["tracker_us_total"] / prof["frames"], h.hexdigest()[:12], pr
 
-cases = [(2, 1, 0, 1), (2, 1, 0, 1), (2, 1, 0, 0), (2, 1, 2, 1)]
-for c in cases:
-    us, hh, _ = run(*c)
-    print(f"variant={c[0]} depth={c[1]} gap={c[2]} fused={c[3]}: tracker {us:7.1f} us/frame  dest-hash {hh}", flush=True)
-us, hh, pr = run(2, 1, 0, 1, probe=True)
+for fused in (1, 1, 0):
+    us, hh, _ = run(fused)
+    print(f"fused={fused}: tracker {us:7.1f} us/frame  dest-hash {hh}", flush=True)
+us, hh, pr = run(1, probe=True)
 print(f"probe run: tracker {us:.1f} us/frame  hash {hh}")
 pr = pr.astype(np.float64)
 tot = pr[:, 5]
 print("per-wave cycles (last frame), mean / p10 / p90 over 2000 waves; 40 passes")
-for i, nm in enumerate(["texel wait", "arithmetic", "hand-off wait", "solve+publish", "polls", "total"]):
+pr[:, 6] = pr[:, 7]
+for i, nm in enumerate(["texel wait", "arithmetic", "hand-off wait", "solve+publish", "polls", "total", "patch loads"]):
     v = pr[:, i]
     print(f"  {nm:14s} {v.mean():10.0f} {np.percentile(v,10):10.0f} {np.percentile(v,90):10.0f}")
-t0 = pr[:, 6]
-print("start skew (cycles): max-min", t0.max() - t0.min(), " xcc ids:", np.unique(pr[:, 7].astype(np.int64) & 0xf, return_counts=True))
-print("kernel span (cycles):", (t0 + tot).max() - t0.min())
