@@ -11,9 +11,8 @@
 //   k_post_track      per slot: status + tracked count + the "present feature" -1e30 scatter,
 //   k_nonmax_compact  both separable non-max passes out of one LDS tile, survivors appended to a
 //                     candidate list with one wave-aggregated atomic (replaces the HistoPyramid),
-//   k_rank_morton / k_select   rank sort of the (<= a few thousand) candidates: HistoPyramid order is
-//                     Morton order of the pixel, top-K is by cornerness; both are O(n^2/256) per lane,
-//   k_fill            one workgroup scans the dead slots and writes dest[] and the next feature list.
+//   k_select_fill     one workgroup: rank sorts of the candidates (HistoPyramid order is Morton order of the pixel,
+//                     top-K is by cornerness), then a scan over the dead slots writes dest[] and the next feature list.
 // Nothing is read back mid-frame; the counts the reference reads with glReadPixels stay in HBM and
 // kernels that depend on them early-exit on the device value.
 #include "klt_internal.h"
@@ -102,7 +101,6 @@ __global__ void k_post_track(const float* __restrict__ feat, int N, cs_klt_featu
         dest[i].pos[1] = Y;
         dest[i].gain = gain;
         dest[i].fed = -1;
-        atomicAdd(&ctr[1], 1);
         if (doSuppress) suppress_at(corner, W, H, X, Y);
     } else {
         dest[i].status = -1;
@@ -190,79 +188,98 @@ __global__ __launch_bounds__(256) void k_nonmax_compact(const float* __restrict_
     }
 }
 
-// ------------------------------------------------------------------ ordering and selection
-__global__ __launch_bounds__(256) void k_rank_morton(const CsCand* __restrict__ cand, int maxCand, const int* ctr,
-                                                     int* __restrict__ rankM) {
-    __shared__ unsigned keys[256];
-    const int n = min(ctr[0], maxCand);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 >= n) return;
-    const unsigned ki = (i < n) ? cand[i].key : 0u;
-    int r = 0;
-    for (int base = 0; base < n; base += 256) {
-        int j = base + threadIdx.x;
-        keys[threadIdx.x] = (j < n) ? cand[j].key : 0xffffffffu;
-        __syncthreads();
-        int m = min(256, n - base);
-        for (int q = 0; q < m; ++q) r += (keys[q] < ki) ? 1 : 0;
-        __syncthreads();
-    }
-    if (i < n) rankM[i] = r;
-}
+// ------------------------------------------------------------------ ordering, selection and slot fill
+// One workgroup does what the reference does on the CPU after its read-backs (v3d_gpuklt.cpp:650-805): order the
+// candidates (HistoPyramid order == Morton order of the pixel), keep the most distinctive ones when there are more
+// than free slots (std::sort branch, :704-708,763-767: cornerness descending, ties in HistoPyramid order), and write
+// them into the dead slots in ascending slot index together with the next frame's feature list.  Rank sorts are
+// O(n^2 / 1024) per thread over the (normally <= a few hundred) candidates; one launch instead of three.
+struct CsSelectArgs {
+    const CsCand* cand;
+    int maxCand, cap, maxKeepFixed;  // maxKeepFixed >= 0: use it; else maxKeep = N - ctr[1] (free slots after tracking)
+    int* rankM;
+    CsCand* sel;
+};
 
-// maxKeepFixed >= 0: use it; else maxKeep = N - ctr[1] (free slots after tracking)
-__global__ __launch_bounds__(256) void k_select(const CsCand* __restrict__ cand, int maxCand, int cap, int N,
-                                                int maxKeepFixed, int* ctr, const int* __restrict__ rankM,
-                                                CsCand* __restrict__ sel) {
-    __shared__ float cs[256];
-    __shared__ unsigned ks[256];
-    __shared__ int rs[256];
-    const int n = min(ctr[0], maxCand);
-    const int nK = min(n, cap);  // v3d_gpuklt.cpp:659,701,756: point list holds at most plw*plh
-    int maxKeep = (maxKeepFixed >= 0) ? maxKeepFixed : (N - ctr[1]);
-    if (maxKeep < 0) maxKeep = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctr[2] = min(nK, maxKeep);
-    if (blockIdx.x * 256 >= n) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    CsCand me;
-    me.key = 0;
-    me.x = me.y = me.c = 0;
-    int myRank = 0x7fffffff;
-    if (i < n) {
-        me = cand[i];
-        myRank = rankM[i];
-    }
-    if (nK <= maxKeep) {  // everything that fits the point list is used, in HistoPyramid order
-        if (i < n && myRank < nK) sel[myRank] = me;
-        return;
-    }
-    // more corners than free slots: the most distinctive ones, cornerness descending (std::sort branch,
-    // v3d_gpuklt.cpp:704-708,763-767), ties in HistoPyramid order
-    int r = 0;
-    for (int base = 0; base < n; base += 256) {
-        int j = base + threadIdx.x;
-        bool ok = (j < n);
-        cs[threadIdx.x] = ok ? cand[j].c : 0.0f;
-        ks[threadIdx.x] = ok ? cand[j].key : 0u;
-        rs[threadIdx.x] = ok ? rankM[j] : 0x7fffffff;
-        __syncthreads();
-        int m = min(256, n - base);
-        for (int q = 0; q < m; ++q) {
-            bool in = rs[q] < nK;
-            bool before = (cs[q] > me.c) || (cs[q] == me.c && ks[q] < me.key);
-            r += (in && before) ? 1 : 0;
-        }
-        __syncthreads();
-    }
-    if (i < n && myRank < nK && r < maxKeep) sel[r] = me;
-}
-
-
-__global__ __launch_bounds__(1024) void k_fill(CsFillArgs A) {
+__global__ __launch_bounds__(1024) void k_select_fill(CsSelectArgs Q, CsFillArgs A) {
+    __shared__ float cs[1024];
+    __shared__ unsigned ks[1024];
+    __shared__ int rs[1024];
     __shared__ int part[1024];
     const int tid = threadIdx.x;
     const int N = A.N;
-    const int nSel = A.ctr[2];
+    // tracked features (redetect): status >= 0 in dest[], counted here in a fixed order
+    __shared__ int nTrackedSh;
+    {
+        int c = 0;
+        if (A.mode == 2)
+            for (int i = tid; i < N; i += 1024) c += (A.dest[i].status >= 0) ? 1 : 0;
+        part[tid] = c;
+        __syncthreads();
+        for (int s = 512; s > 0; s >>= 1) {
+            if (tid < s) part[tid] += part[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) nTrackedSh = part[0];
+        __syncthreads();
+    }
+    const int nTracked = nTrackedSh;
+    const int n = min(A.ctr[0], Q.maxCand);
+    const int nK = min(n, Q.cap);  // v3d_gpuklt.cpp:659,701,756: point list holds at most plw*plh
+    int maxKeep = (Q.maxKeepFixed >= 0) ? Q.maxKeepFixed : (N - nTracked);
+    if (maxKeep < 0) maxKeep = 0;
+    const int nSel = min(nK, maxKeep);
+    // ---- Morton rank ------------------------------------------------------------------------------------
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        const unsigned ki = (i < n) ? Q.cand[i].key : 0u;
+        int r = 0;
+        for (int base = 0; base < n; base += 1024) {
+            const int j = base + tid;
+            ks[tid] = (j < n) ? Q.cand[j].key : 0xffffffffu;
+            __syncthreads();
+            const int m = min(1024, n - base);
+            for (int q = 0; q < m; ++q) r += (ks[q] < ki) ? 1 : 0;
+            __syncthreads();
+        }
+        if (i < n) Q.rankM[i] = r;
+    }
+    __syncthreads();
+    // ---- selection ----------------------------------------------------------------------------------------
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        CsCand me;
+        me.key = 0;
+        me.x = me.y = me.c = 0;
+        int myRank = 0x7fffffff;
+        if (i < n) {
+            me = Q.cand[i];
+            myRank = Q.rankM[i];
+        }
+        if (nK <= maxKeep) {  // everything that fits the point list is used, in HistoPyramid order
+            if (i < n && myRank < nK) Q.sel[myRank] = me;
+            continue;
+        }
+        int r = 0;
+        for (int base = 0; base < n; base += 1024) {
+            const int j = base + tid;
+            const bool ok = (j < n);
+            cs[tid] = ok ? Q.cand[j].c : 0.0f;
+            ks[tid] = ok ? Q.cand[j].key : 0u;
+            rs[tid] = ok ? Q.rankM[j] : 0x7fffffff;
+            __syncthreads();
+            const int m = min(1024, n - base);
+            for (int q = 0; q < m; ++q) {
+                const bool in = rs[q] < nK;
+                const bool before = (cs[q] > me.c) || (cs[q] == me.c && ks[q] < me.key);
+                r += (in && before) ? 1 : 0;
+            }
+            __syncthreads();
+        }
+        if (i < n && myRank < nK && r < maxKeep) Q.sel[r] = me;
+    }
+    __syncthreads();
+    // ---- slot fill (provideFeatures / provideFeaturesAndGain, :86-92,188-197) ---------------------------------
     const int chunk = (N + 1023) / 1024;
     const int lo = min(tid * chunk, N), hi = min(lo + chunk, N);
     int nDead = 0;
@@ -281,7 +298,7 @@ __global__ __launch_bounds__(1024) void k_fill(CsFillArgs A) {
         float lx, ly, lz;
         if (dead) {
             if (r < nSel) {
-                CsCand c = A.sel[r];
+                CsCand c = Q.sel[r];
                 cs_klt_feature f;
                 f.status = 1;
                 f.pos[0] = c.x;
@@ -327,20 +344,34 @@ __global__ __launch_bounds__(1024) void k_fill(CsFillArgs A) {
         }
     }
     if (tid == 0) {
-        int nPres = (A.mode == 2) ? A.ctr[1] : (A.mode == 1 ? min(A.nPresentGiven, max(N - nSel, 0)) : 0);
+        int nPres = (A.mode == 2) ? nTracked : (A.mode == 1 ? min(A.nPresentGiven, max(N - nSel, 0)) : 0);
+        A.ctr[1] = nTracked;
+        A.ctr[2] = nSel;
         A.counts[0] = nSel + nPres;
-        A.counts[1] = (A.mode == 2) ? A.ctr[1] : 0;
+        A.counts[1] = (A.mode == 2) ? nTracked : 0;
         A.counts[2] = A.ctr[0];
         A.counts[3] = nSel;
     }
 }
 
-// track() only: counts from ctr
-__global__ void k_counts_track(const int* ctr, int* counts) {
-    counts[0] = ctr[1];
-    counts[1] = ctr[1];
-    counts[2] = 0;
-    counts[3] = 0;
+// track() only: the tracked count (status >= 0 in dest[]), one workgroup
+__global__ __launch_bounds__(1024) void k_counts_track(const cs_klt_feature* __restrict__ dest, int N, int* counts) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    int c = 0;
+    for (int i = tid; i < N; i += 1024) c += (dest[i].status >= 0) ? 1 : 0;
+    part[tid] = c;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) part[tid] += part[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        counts[0] = part[0];
+        counts[1] = part[0];
+        counts[2] = 0;
+        counts[3] = 0;
+    }
 }
 
 }  // namespace
@@ -404,23 +435,22 @@ int cs_nonmax_prepare(int d) {
     return CS_OK;
 }
 
-int cs_launch_select(const CsCand* cand, int maxCand, int cap, int N, int maxKeepFixed, int* ctr, int* rankM,
-                     CsCand* sel, hipStream_t stream) {
-    dim3 grid((maxCand + 255) / 256);
-    hipLaunchKernelGGL(k_rank_morton, grid, dim3(256), 0, stream, cand, maxCand, ctr, rankM);
-    hipLaunchKernelGGL(k_select, grid, dim3(256), 0, stream, cand, maxCand, cap, N, maxKeepFixed, ctr, rankM, sel);
+int cs_launch_select_fill(const CsCand* cand, int maxCand, int cap, int maxKeepFixed, int* rankM, CsCand* sel,
+                          const CsFillArgs& a, hipStream_t stream) {
+    CsSelectArgs q;
+    q.cand = cand;
+    q.maxCand = maxCand;
+    q.cap = cap;
+    q.maxKeepFixed = maxKeepFixed;
+    q.rankM = rankM;
+    q.sel = sel;
+    hipLaunchKernelGGL(k_select_fill, dim3(1), dim3(1024), 0, stream, q, a);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }
 
-int cs_launch_fill(const CsFillArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(k_fill, dim3(1), dim3(1024), 0, stream, a);
-    CS_CHECK_LAUNCH();
-    return CS_OK;
-}
-
-int cs_launch_counts_track(const int* ctr, int* counts, hipStream_t stream) {
-    hipLaunchKernelGGL(k_counts_track, dim3(1), dim3(1), 0, stream, ctr, counts);
+int cs_launch_counts_track(const cs_klt_feature* dest, int N, int* counts, hipStream_t stream) {
+    hipLaunchKernelGGL(k_counts_track, dim3(1), dim3(1024), 0, stream, dest, N, counts);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

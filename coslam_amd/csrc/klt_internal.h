@@ -45,6 +45,11 @@ struct CsGainFusedArgs {
     int* err;
     int pollGap;                      // s_sleep units between re-polls of the hand-off sweep
     int patchR;                       // side of the wave-private LDS patch in texels (set by the launcher)
+    // fused k_post_track (v3d_gpuklt.cpp:872-888 status loop + :744-752 present scatter); dest == null: not fused
+    cs_klt_feature* dest;
+    int* ctr;
+    float* corner;
+    int doSuppress;
     unsigned long long* probe;        // diagnostic per-wave cycle counters (8 per slot) or null
 };
 
@@ -63,6 +68,9 @@ struct CsFillArgs {
 };
 
 int cs_launch_pyramid(const uint8_t* d_img, const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mode, hipStream_t stream);
+int cs_launch_frame_front(const uint8_t* d_img, const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mode, float* corner_out,
+                          float minCornerness, float margin, int* ctr, unsigned long long* gran, int nGran,
+                          hipStream_t stream);
 int cs_launch_track_nogain(const cs_texel* pyr0, const cs_texel* pyr1, const CsPyrLayout& lay, int levelSkip, int hw,
                            int nIterShader, float margin, float convThr, float ssdThr, int N, const float* featIn,
                            float* featOut, hipStream_t stream);
@@ -78,7 +86,6 @@ int cs_launch_clear_dest(cs_klt_feature* dest, int N, hipStream_t stream);
 int cs_nonmax_prepare(int d);
 int cs_launch_nonmax_compact(const float* in, int W, int H, int d, float* out, CsCand* cand, int maxCand, int* ctr,
                              hipStream_t stream);
-int cs_launch_select(const CsCand* cand, int maxCand, int cap, int N, int maxKeepFixed, int* ctr, int* rankM,
-                     CsCand* sel, hipStream_t stream);
-int cs_launch_fill(const CsFillArgs& a, hipStream_t stream);
-int cs_launch_counts_track(const int* ctr, int* counts, hipStream_t stream);
+int cs_launch_select_fill(const CsCand* cand, int maxCand, int cap, int maxKeepFixed, int* rankM, CsCand* sel,
+                          const CsFillArgs& a, hipStream_t stream);
+int cs_launch_counts_track(const cs_klt_feature* dest, int N, int* counts, hipStream_t stream);

@@ -124,7 +124,9 @@ static float* read_buffer(cs_klt* k) {  // readFeatures / readFeaturesAndGain, v
 
 // ---- frame schedules (all asynchronous on k->stream) -------------------------------------------
 
-static int enqueue_tracker(cs_klt* k) {
+// postDest != null: the persistent tracker may fold k_post_track into its epilogue; *postFused says whether it did
+static int enqueue_tracker(cs_klt* k, cs_klt_feature* postDest, int doSuppress, bool* postFused) {
+    if (postFused) *postFused = false;
     const cs_klt_config& c = k->cfg;
     const int hw = c.windowWidth / 2;
     const cs_texel *P0 = k->d_pyr[k->p0], *P1 = k->d_pyr[k->p1];
@@ -191,8 +193,12 @@ static int enqueue_tracker(cs_klt* k) {
         }
         f.err = k->d_err;
         f.probe = k->d_probe;
+        f.dest = postDest;
+        f.ctr = k->d_ctr;
+        f.corner = k->d_corner_raw;
+        f.doSuppress = doSuppress;
+        if (postFused) *postFused = (postDest != nullptr);
         f.pollGap = 0;
-        CS_HIP(hipMemsetAsync(k->d_gran, 0, sizeof(unsigned long long) * 2 * k->N, k->stream));
         int rcf = cs_launch_track_gain_fused(f, k->stream);
         if (rcf) return rcf;
         if (T & 1) std::swap(k->b0, k->b1);  // T swaps of (buffer0, buffer1)
@@ -268,9 +274,6 @@ static int enqueue_detect_tail(cs_klt* k, int mode, int nPresentGiven, int maxKe
     int rc = cs_launch_nonmax_compact(k->d_corner_raw, k->W, k->H, k->cfg.minDistance, k->d_corner, k->d_cand,
                                       k->maxCand, k->d_ctr, k->stream);
     if (rc) return rc;
-    rc = cs_launch_select(k->d_cand, k->maxCand, k->plw * k->plh, k->N, maxKeepFixed, k->d_ctr, k->d_rank, k->d_sel,
-                          k->stream);
-    if (rc) return rc;
     CsFillArgs f;
     f.mode = mode;
     f.N = k->N;
@@ -284,34 +287,34 @@ static int enqueue_detect_tail(cs_klt* k, int mode, int nPresentGiven, int maxKe
     f.list_a = k->d_fb[k->b1];
     f.list_b = k->cfg.trackWithGain ? k->d_fb[k->b2] : nullptr;
     f.counts = d_counts;
-    return cs_launch_fill(f, k->stream);
+    return cs_launch_select_fill(k->d_cand, k->maxCand, k->plw * k->plh, maxKeepFixed, k->d_rank, k->d_sel, f, k->stream);
 }
 
 static int enqueue_track(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest, int* d_counts, bool forRedetect) {
-    CS_HIP(hipMemsetAsync(k->d_ctr, 0, 8 * sizeof(int), k->stream));
-    int rc = cs_launch_pyramid(d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, k->stream);  // :858
+    // pyramid (:858), the cornerness map the detector will need, and the zeroing of this frame's counters and
+    // hand-off granules: two launches (klt_pyramid.hip)
+    int rc = cs_launch_frame_front(d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, forRedetect ? k->d_corner_raw : nullptr,
+                                   k->cfg.minCornerness, k->detMargin, k->d_ctr, k->d_gran, 2 * k->N, k->stream);
     if (rc) return rc;
-    if (forRedetect) {
-        rc = cs_launch_cornerness(k->d_pyr[k->p1] + k->lay.off[0], k->W, k->H, k->cfg.minCornerness, k->detMargin,
-                                  k->d_corner_raw, k->stream);
-        if (rc) return rc;
-    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (k->profiling) {
         CS_HIP(hipEventCreate(&e0));
         CS_HIP(hipEventCreate(&e1));
         CS_HIP(hipEventRecord(e0, k->stream));
     }
-    rc = enqueue_tracker(k);
+    bool postFused = false;
+    rc = enqueue_tracker(k, d_dest, forRedetect ? 1 : 0, &postFused);
     if (rc) return rc;
     if (k->profiling) {
         CS_HIP(hipEventRecord(e1, k->stream));
         k->ev_pairs->push_back(std::make_pair(e0, e1));
     }
-    rc = cs_launch_post_track(read_buffer(k), k->N, d_dest, k->d_ctr, k->d_corner_raw, k->W, k->H, forRedetect ? 1 : 0,
-                              k->stream);
-    if (rc) return rc;
-    if (!forRedetect) rc = cs_launch_counts_track(k->d_ctr, d_counts, k->stream);
+    if (!postFused) {
+        rc = cs_launch_post_track(read_buffer(k), k->N, d_dest, k->d_ctr, k->d_corner_raw, k->W, k->H,
+                                  forRedetect ? 1 : 0, k->stream);
+        if (rc) return rc;
+    }
+    if (!forRedetect) rc = cs_launch_counts_track(d_dest, k->N, d_counts, k->stream);
     return rc;
 }
 
@@ -322,11 +325,8 @@ static int enqueue_redetect(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_d
 }
 
 static int enqueue_detect(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest, int* d_counts, int nPresent) {
-    CS_HIP(hipMemsetAsync(k->d_ctr, 0, 8 * sizeof(int), k->stream));
-    int rc = cs_launch_pyramid(d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, k->stream);
-    if (rc) return rc;
-    rc = cs_launch_cornerness(k->d_pyr[k->p1] + k->lay.off[0], k->W, k->H, k->cfg.minCornerness, k->detMargin,
-                              k->d_corner_raw, k->stream);
+    int rc = cs_launch_frame_front(d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, k->d_corner_raw, k->cfg.minCornerness,
+                                   k->detMargin, k->d_ctr, nullptr, 0, k->stream);
     if (rc) return rc;
     if (nPresent > 0) {
         rc = cs_launch_suppress_list(k->d_corner_raw, k->W, k->H, nPresent, k->d_present, k->stream);
@@ -850,7 +850,9 @@ int cs_klt_build_pyramid(cs_klt* k, const uint8_t* image) {
     int rc = bind_device(k);
     if (rc) return rc;
     if ((rc = upload_image(k, image))) return rc;
-    if ((rc = cs_launch_pyramid(k->d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, k->stream))) return rc;
+    if ((rc = cs_launch_frame_front(k->d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, nullptr, 0.0f, 0.0f, nullptr, nullptr, 0,
+                                    k->stream)))
+        return rc;
     CS_HIP(hipStreamSynchronize(k->stream));
     return CS_OK;
 }

@@ -567,6 +567,24 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
         A.outPrev[3 * k] = pX;
         A.outPrev[3 * k + 1] = pY;
         A.outPrev[3 * k + 2] = pB;
+        if (A.dest) {  // what k_post_track would do in its own launch
+            cs_klt_feature* dst = A.dest + k;
+            if (X1x >= 0) {
+                dst->status = 0;
+                dst->pos[0] = X1x;
+                dst->pos[1] = X1y;
+                dst->gain = beta;
+                dst->fed = -1;  // the tracked count is taken by the consumer of dest[] (one hot atomic word would
+                                // serialise the 2000 waves that finish together: ~88 atomics/us)
+                if (A.doSuppress && X1y >= 0.0f) {  // v3d_gpuklt.cpp:444-447
+                    const float fx = floorf(X1x * (float)A.W), fy = floorf(X1y * (float)A.H);
+                    if (fx < (float)A.W && fy < (float)A.H) A.corner[(size_t)(int)fy * A.W + (int)fx] = -1e30f;
+                }
+            } else {
+                dst->status = -1;
+                dst->fed = -1;
+            }
+        }
         if (PROBE && A.probe) {
             unsigned long long* o = A.probe + 8 * (size_t)k;
             o[0] = tTex;
