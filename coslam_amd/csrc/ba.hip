@@ -48,7 +48,8 @@ struct BaDev {
     int* outlier;
     double *Jc, *e, *W, *Vinv, *gp, *S, *rhs, *costPart, *stepPart;
     BaState* st;
-    int nCostBlocks;
+    int nCostBlocks, nUpdBlocks, nSlices;
+    double* schurPart;  // [nPairs][nSlices][72] partial Schur blocks (orders <= 36)
     double maxErr;
     int innerMaxIter;
 };
@@ -316,6 +317,89 @@ __global__ __launch_bounds__(256) void k_schur(BaDev D) {
     }
 }
 
+// ---- small reduced systems (order <= 36): one WAVE per (camera pair, point slice) -------------------------------
+// The pair-per-workgroup kernel above walks all points with 256 threads and then folds 42 sums over four waves; at
+// the reference's local-BA sizes (3..6 free cameras) that is 6..21 workgroups and two rounds of dependent loads.
+// Here the points are cut into D.nSlices contiguous slices and every (pair, slice) is one wave (lane = point); the
+// wave totals go to schurPart[pair][slice][72] and the register Cholesky adds the slices in slice order while it
+// loads its rows -- deterministic, no atomics, no extra launch.
+__global__ __launch_bounds__(64) void k_schur_part(BaDev D) {
+    if (!BA_ACTIVE(D)) return;
+    const int lane = threadIdx.x;
+    const int pairIdx = blockIdx.x / D.nSlices, slice = blockIdx.x - pairIdx * D.nSlices;
+    int ja = 0, pr = pairIdx;
+    while (pr >= D.nc - ja) {
+        pr -= D.nc - ja;
+        ++ja;
+    }
+    const int jb = ja + pr;
+    const int ca = ja + D.nCamsCon, cb = jb + D.nCamsCon;
+    double* out = D.schurPart + (size_t)blockIdx.x * 72;
+    double acc[42];
+#pragma unroll
+    for (int q = 0; q < 42; ++q) acc[q] = 0;
+    {
+        const int nFree = D.P - D.nPtsCon;
+        const int per = (nFree + D.nSlices - 1) / D.nSlices;
+        const int lo = D.nPtsCon + slice * per, hi = min(lo + per, D.P);
+        for (int i = lo + lane; i < hi; i += 64) {
+            const int oa = D.obs_of[(size_t)i * D.C + ca];
+            if (oa < 0 || D.outlier[oa]) continue;
+            const int ob = (ja == jb) ? oa : D.obs_of[(size_t)i * D.C + cb];
+            if (ob < 0 || D.outlier[ob]) continue;
+            const double* Wa = D.W + 18 * (size_t)oa;
+            const double* Wb = D.W + 18 * (size_t)ob;
+            const double* Vi = D.Vinv + 9 * (size_t)i;
+            double Y[18];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Y[3 * r + c] = Wa[3 * r] * Vi[c] + Wa[3 * r + 1] * Vi[3 + c] + Wa[3 * r + 2] * Vi[6 + c];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    acc[6 * r + c] += Y[3 * r] * Wb[3 * c] + Y[3 * r + 1] * Wb[3 * c + 1] + Y[3 * r + 2] * Wb[3 * c + 2];
+            if (ja == jb) {
+                const double* g = D.gp + 3 * (size_t)i;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) acc[36 + r] += Y[3 * r] * g[0] + Y[3 * r + 1] * g[1] + Y[3 * r + 2] * g[2];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 42; ++q) {
+        const double v = wsum(acc[q]);
+        if (lane == 0) out[q] = v;
+    }
+    if (ja == jb) {  // U_j = sum Jc^T Jc and g_j = sum Jc^T e over this slice of the camera's own measurement list
+        double u[27];
+#pragma unroll
+        for (int q = 0; q < 27; ++q) u[q] = 0;
+        const int c0 = D.cam_ptr[ca], c1 = D.cam_ptr[ca + 1];
+        const int per = (c1 - c0 + D.nSlices - 1) / D.nSlices;
+        const int lo = c0 + slice * per, hi = min(lo + per, c1);
+        for (int sI = lo + lane; sI < hi; sI += 64) {
+            const int o = D.cam_obs[sI];
+            if (D.outlier[o]) continue;
+            const double* J = D.Jc + 12 * (size_t)o;
+            const double e0 = D.e[2 * (size_t)o], e1 = D.e[2 * (size_t)o + 1];
+            int q = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = r; c < 6; ++c) u[q++] += J[r] * J[c] + J[6 + r] * J[6 + c];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) u[21 + r] += J[r] * e0 + J[6 + r] * e1;
+        }
+#pragma unroll
+        for (int q = 0; q < 27; ++q) {
+            const double v = wsum(u[q]);
+            if (lane == 0) out[42 + q] = v;
+        }
+    }
+}
+
 // ---- one workgroup: Cholesky + solve of the reduced camera system --------------------------------
 template <int NT>
 __global__ __launch_bounds__(NT) void k_solve(BaDev D, int useLds) {
@@ -440,14 +524,59 @@ __global__ __launch_bounds__(64) void k_solve_wave(BaDev D) {
 // Lane i keeps row i of S in NMAX registers; both loops are fully unrolled, so every index is static and every
 // cross-lane read is a v_readlane of a constant lane: no LDS, no barrier, one reciprocal square root per column.
 // Rows/columns n..NMAX-1 are identity padding.
+// Called by all 256 threads of a workgroup; on return Ssm[NMAX * NMAX + r] holds the solved camera step and
+// *okSh the Cholesky status (both in LDS, visible to the whole workgroup).
 template <int NMAX>
-__global__ __launch_bounds__(64) void k_solve_reg(BaDev D) {
-    if (!BA_ACTIVE(D)) return;
-    const int n = D.n, i = threadIdx.x;
+__device__ __forceinline__ void solve_reg_block(const BaDev& D, double* Ssm, int* okSh) {
+    // all four waves add the slice partials of k_schur_part (slice order) into the reduced system in LDS ...
+    const int n = D.n;
+    {
+        const double lambda = D.st->lambda;
+        const int nPairs = D.nc * (D.nc + 1) / 2;
+        for (int w = threadIdx.x; w < nPairs * 42; w += 256) {
+            const int pi = w / 42, q = w - 42 * pi;
+            int a = 0, pr = pi;
+            while (pr >= D.nc - a) {
+                pr -= D.nc - a;
+                ++a;
+            }
+            const int b = a + pr;
+            const double* p = D.schurPart + (size_t)pi * D.nSlices * 72;
+            int uq = -1;
+            if (a == b) {
+                if (q < 36) {
+                    const int r = q / 6, c = q - 6 * r, rr = r < c ? r : c, cc = r < c ? c : r;
+                    uq = rr * 6 - (rr * (rr - 1)) / 2 + (cc - rr);
+                } else {
+                    uq = 21 + (q - 36);
+                }
+            }
+            double sSum = 0, uSum = 0;
+            for (int sl = 0; sl < D.nSlices; ++sl) {
+                sSum += p[sl * 72 + q];
+                if (uq >= 0) uSum += p[sl * 72 + 42 + uq];
+            }
+            if (q < 36) {
+                const int r = q / 6, c = q - 6 * r;
+                if (a == b) {
+                    Ssm[(6 * a + r) * NMAX + 6 * a + c] = (uSum + ((r == c) ? lambda : 0.0)) - sSum;
+                } else {
+                    Ssm[(6 * a + r) * NMAX + 6 * b + c] = -sSum;
+                    Ssm[(6 * b + c) * NMAX + 6 * a + r] = -sSum;
+                }
+            } else if (a == b) {
+                Ssm[NMAX * NMAX + 6 * a + (q - 36)] = uSum - sSum;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+    // ... and wave 0 factorises it out of registers
+    const int i = threadIdx.x;
     double a[NMAX];
 #pragma unroll
-    for (int k = 0; k < NMAX; ++k) a[k] = (i < n && k < n) ? D.S[(size_t)i * n + k] : ((i == k) ? 1.0 : 0.0);
-    double b = (i < n) ? D.rhs[i] : 0.0;
+    for (int k = 0; k < NMAX; ++k) a[k] = (i < n && k < n) ? Ssm[i * NMAX + k] : ((i == k) ? 1.0 : 0.0);
+    double b = (i < n) ? Ssm[NMAX * NMAX + i] : 0.0;
     double rdiag[NMAX];  // 1 / L[j][j] (wave-uniform)
     bool ok = true;
 #pragma unroll
@@ -474,25 +603,46 @@ __global__ __launch_bounds__(64) void k_solve_reg(BaDev D) {
         const double xj = (rdlane_d(b, j) - s) * rdiag[j];
         if (i == j) b = xj;
     }
-    if (i < n) D.rhs[i] = b;
-    if (i == 0) D.st->chol_ok = ok ? 1 : 0;
+    if (i < n) Ssm[NMAX * NMAX + i] = b;
+    if (i == 0) *okSh = ok ? 1 : 0;
+    }
+    __syncthreads();
 }
 
-// ---- tentative step -------------------------------------------------------------------------------
+// ---- tentative step + its cost ----------------------------------------------------------------------
+// Wave per point: back-substituted point step, then (lane = measurement) the squared inlier residuals of that point
+// at the tentative estimate.  The tentative pose of a measurement's camera is re-derived in the lane from the
+// solved camera step (R exp(w), t + dt -- the same operations block 0 performs when it writes Rn / Tn for the
+// commit), so the cost needs no second launch behind a grid-wide dependency.  Per-block partial costs go to
+// costPart[blockIdx.x] (D.nUpdBlocks of them), summed in a fixed order by k_control.
+template <int NMAX>  // > 0: the reduced system is combined and solved here, redundantly per workgroup (no solve launch)
 __global__ __launch_bounds__(256) void k_update(BaDev D) {
     if (!BA_ACTIVE(D)) return;
+    __shared__ double red[4];
+    __shared__ double Ssm[NMAX > 0 ? NMAX * NMAX + NMAX : 1];
+    __shared__ int okSh;
+    const double* rhs = D.rhs;
+    if (NMAX > 0) {
+        solve_reg_block<(NMAX > 0 ? NMAX : 1)>(D, Ssm, &okSh);
+        rhs = Ssm + NMAX * NMAX;
+        if (blockIdx.x == 0) {
+            if (threadIdx.x < D.n) D.rhs[threadIdx.x] = rhs[threadIdx.x];
+            if (threadIdx.x == 0) D.st->chol_ok = okSh;
+        }
+    }
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    // waves [0, P): points; the cameras are handled by the first lanes of block 0 afterwards
+    double cost = 0;
     if (gw < D.P) {
         const int i = gw;
+        const int o0 = D.obs_ptr[i], o1 = D.obs_ptr[i + 1];
         double b[3] = {0, 0, 0};
         if (i >= D.nPtsCon) {
-            for (int o = D.obs_ptr[i] + lane; o < D.obs_ptr[i + 1]; o += 64) {
+            for (int o = o0 + lane; o < o1; o += 64) {
                 const int j = D.obs_cam[o] - D.nCamsCon;
                 if (j < 0 || D.outlier[o]) continue;
                 const double* Wo = D.W + 18 * (size_t)o;
-                const double* dc = D.rhs + 6 * j;
+                const double* dc = rhs + 6 * j;
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -502,26 +652,54 @@ __global__ __launch_bounds__(256) void k_update(BaDev D) {
         b[0] = wsum(b[0]);
         b[1] = wsum(b[1]);
         b[2] = wsum(b[2]);
+        double d[3] = {0, 0, 0};
+        if (i >= D.nPtsCon) {
+            const double* Vi = D.Vinv + 9 * (size_t)i;
+            const double g0 = D.gp[3 * (size_t)i] + b[0], g1 = D.gp[3 * (size_t)i + 1] + b[1],
+                         g2 = D.gp[3 * (size_t)i + 2] + b[2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) d[r] = Vi[3 * r] * g0 + Vi[3 * r + 1] * g1 + Vi[3 * r + 2] * g2;
+        }
+        double Mn[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Mn[r] = D.pts[3 * (size_t)i + r] + d[r];
         if (lane == 0) {
-            double d[3] = {0, 0, 0};
-            if (i >= D.nPtsCon) {
-                const double* Vi = D.Vinv + 9 * (size_t)i;
-                const double g0 = D.gp[3 * (size_t)i] + b[0], g1 = D.gp[3 * (size_t)i + 1] + b[1],
-                             g2 = D.gp[3 * (size_t)i + 2] + b[2];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) d[r] = Vi[3 * r] * g0 + Vi[3 * r + 1] * g1 + Vi[3 * r + 2] * g2;
-            }
-#pragma unroll
-            for (int r = 0; r < 3; ++r) D.Mn[3 * (size_t)i + r] = D.pts[3 * (size_t)i + r] + d[r];
+            for (int r = 0; r < 3; ++r) D.Mn[3 * (size_t)i + r] = Mn[r];
             D.stepPart[i] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
         }
+        for (int o = o0 + lane; o < o1; o += 64) {
+            if (D.outlier[o]) continue;
+            const int j = D.obs_cam[o];
+            double Rn[9], Tn[3];
+            if (j >= D.nCamsCon) {
+                const double* dc = rhs + 6 * (j - D.nCamsCon);
+                double w[3] = {dc[0], dc[1], dc[2]}, dR[9];
+                so3_exp(w, dR);
+                mat33AB(D.Rs + 9 * j, dR, Rn);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) Tn[q] = D.Ts[3 * j + q] + dc[3 + q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) Rn[q] = D.Rs[9 * j + q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) Tn[q] = D.Ts[3 * j + q];
+            }
+            double e[2];
+            residual<false>(D.Ks + 9 * j, Rn, Tn, Mn, D.obs_xy + 2 * (size_t)o, e, nullptr, nullptr);
+            cost += e[0] * e[0] + e[1] * e[1];
+        }
     }
+    cost = wsum(cost);
+    if (lane == 0) red[threadIdx.x >> 6] = cost;
+    __syncthreads();
+    if (threadIdx.x == 0) D.costPart[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < D.C) {
         const int j = t;
         double s2 = 0;
         if (j >= D.nCamsCon) {
-            const double* dc = D.rhs + 6 * (j - D.nCamsCon);
+            const double* dc = rhs + 6 * (j - D.nCamsCon);
             double w[3] = {dc[0], dc[1], dc[2]}, dR[9], Rn[9];
             so3_exp(w, dR);
             mat33AB(D.Rs + 9 * j, dR, Rn);
@@ -576,7 +754,8 @@ __global__ __launch_bounds__(256) void k_control(BaDev D, int phase) {
     const int tid = threadIdx.x;
     // fixed-order sums
     double c = 0;
-    for (int q = tid; q < D.nCostBlocks; q += 256) c += D.costPart[q];
+    const int nPart = (phase == 1) ? D.nUpdBlocks : D.nCostBlocks;  // phase 1: k_update's per-block tentative costs
+    for (int q = tid; q < nPart; q += 256) c += D.costPart[q];
     c = wsum(c);
     if ((tid & 63) == 0) red[tid >> 6] = c;
     __syncthreads();
@@ -729,7 +908,7 @@ struct cs_ba {
     int capC, capP, capObs;
     hipStream_t own_stream;
     // device buffers
-    double *Ks, *Rs, *Ts, *pts, *Rn, *Tn, *Mn, *obs_xy, *Jc, *e, *W, *Vinv, *gp, *S, *rhs, *costPart, *stepPart;
+    double *Ks, *Rs, *Ts, *pts, *Rn, *Tn, *Mn, *obs_xy, *Jc, *e, *W, *Vinv, *gp, *S, *rhs, *costPart, *stepPart, *schurPart;
     int *obs_ptr, *obs_cam, *obs_pt, *cam_ptr, *cam_obs, *obs_of, *outlier;
     BaState* st;
     cs_ba_stats_dev* stats;
@@ -753,7 +932,7 @@ static void ba_drop_graph(cs_ba* b) {
 static int ba_free(cs_ba* b) {
     ba_drop_graph(b);
     double** dp[] = {&b->Ks, &b->Rs, &b->Ts, &b->pts, &b->Rn, &b->Tn, &b->Mn, &b->obs_xy, &b->Jc, &b->e, &b->W,
-                     &b->Vinv, &b->gp, &b->S, &b->rhs, &b->costPart, &b->stepPart};
+                     &b->Vinv, &b->gp, &b->S, &b->rhs, &b->costPart, &b->stepPart, &b->schurPart};
     for (auto p : dp) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -795,7 +974,8 @@ static int ba_reserve(cs_ba* b, int C, int P, int nObs) {
     BA_ALLOC(b->gp, 3 * cP, double);
     BA_ALLOC(b->S, n * n, double);
     BA_ALLOC(b->rhs, n, double);
-    BA_ALLOC(b->costPart, 1024, double);
+    BA_ALLOC(b->costPart, 1024 + cP / 4 + cC / 256 + 2, double);
+    BA_ALLOC(b->schurPart, (size_t)21 * 16 * 72, double);  // <= 6 free cameras (21 pairs) x 16 slices
     BA_ALLOC(b->stepPart, cP + cC, double);
     BA_ALLOC(b->obs_ptr, cP + 1, int);
     BA_ALLOC(b->obs_cam, cO, int);
@@ -851,6 +1031,7 @@ static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int 
     D.rhs = b->rhs;
     D.costPart = b->costPart;
     D.stepPart = b->stepPart;
+    D.schurPart = b->schurPart;
     D.st = b->st;
     D.maxErr = maxErr;
     D.innerMaxIter = innerMaxIter;
@@ -878,6 +1059,18 @@ static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int 
     int gUpd = (P + 3) / 4;
     if (gUpd * 256 < C) gUpd = (C + 255) / 256;
     if (gUpd < 1) gUpd = 1;
+    D.nUpdBlocks = gUpd;
+    // orders <= 36: sliced Schur partials, combined by the register Cholesky
+    const bool sliced = (D.n > 0 && D.n <= 36);
+    D.nSlices = 1;
+    if (sliced) {
+        int sl = 96 / (nPairs > 0 ? nPairs : 1);
+        if (sl > 16) sl = 16;
+        if (sl < 1) sl = 1;
+        const int nFree = P - D.nPtsCon;
+        while (sl > 1 && (nFree + sl - 1) / sl < 32) sl /= 2;  // at least half a wave of points per slice
+        D.nSlices = sl;
+    }
 
     for (int outer = 0; outer < maxIter; ++outer) {
         hipLaunchKernelGGL(k_cost, dim3(cb), blk, 0, stream, D, 0);
@@ -885,21 +1078,25 @@ static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int 
         for (int it = 0; it < innerMaxIter; ++it) {
             hipLaunchKernelGGL(k_linearize, gPts, blk, 0, stream, D);
             if (D.nc > 0) {
-                hipLaunchKernelGGL(k_schur, dim3(nPairs), blk, 0, stream, D);
+                if (sliced)
+                    hipLaunchKernelGGL(k_schur_part, dim3(nPairs * D.nSlices), dim3(64), 0, stream, D);
+                else
+                    hipLaunchKernelGGL(k_schur, dim3(nPairs), blk, 0, stream, D);
             }
-            if (D.n <= 12) {
-                hipLaunchKernelGGL(k_solve_reg<12>, dim3(1), dim3(64), 0, stream, D);
-            } else if (D.n <= 24) {
-                hipLaunchKernelGGL(k_solve_reg<24>, dim3(1), dim3(64), 0, stream, D);
-            } else if (D.n <= 36) {
-                hipLaunchKernelGGL(k_solve_reg<36>, dim3(1), dim3(64), 0, stream, D);
-            } else if (D.n <= 64) {
-                hipLaunchKernelGGL(k_solve_wave, dim3(1), dim3(64), sizeof(double) * (size_t)D.n * (D.n | 1), stream, D);
+            if (D.n > 0 && D.n <= 12) {
+                hipLaunchKernelGGL(k_update<12>, dim3(gUpd), blk, 0, stream, D);  // + solve + tentative cost
+            } else if (D.n > 0 && D.n <= 24) {
+                hipLaunchKernelGGL(k_update<24>, dim3(gUpd), blk, 0, stream, D);
+            } else if (D.n > 0 && D.n <= 36) {
+                hipLaunchKernelGGL(k_update<36>, dim3(gUpd), blk, 0, stream, D);
             } else {
-                hipLaunchKernelGGL(k_solve<256>, dim3(1), blk, useLds ? ldsSolve : 0, stream, D, useLds);
+                if (D.n <= 64) {
+                    hipLaunchKernelGGL(k_solve_wave, dim3(1), dim3(64), sizeof(double) * (size_t)D.n * (D.n | 1), stream, D);
+                } else {
+                    hipLaunchKernelGGL(k_solve<256>, dim3(1), blk, useLds ? ldsSolve : 0, stream, D, useLds);
+                }
+                hipLaunchKernelGGL(k_update<0>, dim3(gUpd), blk, 0, stream, D);  // + the tentative cost
             }
-            hipLaunchKernelGGL(k_update, dim3(gUpd), blk, 0, stream, D);
-            hipLaunchKernelGGL(k_cost, dim3(cb), blk, 0, stream, D, 1);
             hipLaunchKernelGGL(k_control, dim3(1), blk, 0, stream, D, 1);
         }
         hipLaunchKernelGGL(k_outer_begin, dim3(1), dim3(1), 0, stream, D);
