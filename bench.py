@@ -159,6 +159,8 @@ def main():
     klt_torch_stream = torch.cuda.Stream(device=dev)
     pose_torch_stream = klt_torch_stream if args.serial else torch.cuda.Stream(device=dev)
     ba_torch_stream = klt_torch_stream if (args.sync_ba or args.serial) else torch.cuda.Stream(device=dev)
+    if os.environ.get("BENCH_BA_ON_POSE"):
+        ba_torch_stream = pose_torch_stream
     stream = klt_torch_stream.cuda_stream
     pose_stream = pose_torch_stream.cuda_stream
     ba_stream = ba_torch_stream.cuda_stream
@@ -189,14 +191,20 @@ def main():
     from coslam_amd.multicam import CameraExchange
     xchg = CameraExchange(N_FEAT, dev) if world > 1 else None
 
+    trace = [] if os.environ.get("BENCH_TRACE") else None
+
     def step(i):
         f = order[i % len(order)]
         b = i & 1
-        if i >= 2:
+        if trace is not None:
+            trace.append((i, "start", time.perf_counter()))
+        if i >= 2 and not os.environ.get("BENCH_NO_DESTFREE"):
             klt_torch_stream.wait_event(dest_free[b])      # the consumer of this dest buffer two frames ago is done
         trk.redetect_dev(d_frames[f].data_ptr(), d_dests[b].data_ptr(), d_counts.data_ptr())
         trk.advanceFrame()
         klt_done[b].record(klt_torch_stream)
+        if trace is not None:
+            trace.append((i, "klt", time.perf_counter()))
         pose_torch_stream.wait_event(klt_done[b])          # pose(f) consumes what the tracker produced for frame f
         with torch.cuda.stream(pose_torch_stream):
             if args.no_pose:
@@ -211,8 +219,12 @@ def main():
                 xchg.pack(d_dests[b], d_Ropt, d_topt)
                 xchg.all_gather()
             dest_free[b].record(pose_torch_stream)
+        if trace is not None:
+            trace.append((i, "pose", time.perf_counter()))
         if args.ba_every > 0 and (i + 1) % args.ba_every == 0:
             ba_ws.solve_dev(ba_stream, d_baR.data_ptr(), d_baT.data_ptr(), d_baM.data_ptr(), 2, 2, 6.0, 2, 10)
+            if trace is not None:
+                trace.append((i, "ba", time.perf_counter()))
 
     def barrier():
         torch.cuda.synchronize()
@@ -238,6 +250,10 @@ def main():
         dt = float(tmax.item())
 
     last = (args.warmup + args.steps) & 1
+    if trace is not None and rank == 0:
+        t00 = trace[0][2]
+        for (i, what, t) in trace[-60:]:
+            print(f"# step {i} {what} {1e6 * (t - t00):.1f} us", file=sys.stderr)
     n_live = int((d_dests[last].cpu().numpy().view(coslam_amd.KLT_TrackedFeature)["status"] >= 0).sum())
     pose_ok = int(d_ok.item())
 
