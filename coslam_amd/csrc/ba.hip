@@ -462,6 +462,204 @@ __global__ __launch_bounds__(NT) void k_solve(BaDev D, int useLds) {
     if (tid == 0) D.st->chol_ok = okFlag;
 }
 
+// ---- large reduced systems (order > 138: the LDS single-workgroup Cholesky no longer fits) -----------------
+// Right-looking blocked Cholesky on S in HBM, block CB = 32, lower triangle, two launches per block column:
+//   k_chol_panel   every workgroup re-factors the 32x32 diagonal block in LDS (cheap, saves a launch and a grid-wide
+//                  dependency) and solves 64 rows of the panel below it against L_kk^T (thread per row);
+//   k_chol_trail   C -= A_i A_j^T on the 64x64 tiles of the trailing lower triangle, both 64x32 panels staged in LDS,
+//                  4x4 outputs per thread in registers;
+//   k_chol_trsv    one workgroup: blocked forward and backward substitution of the right-hand side.
+// binary64 VALU throughout: on MI355X the f64 MFMA peak equals the f64 vector peak (78.6 TFLOP/s), so the matrix
+// cores buy nothing for this contraction; what matters is LDS tiling and enough workgroups (cfg5: C = 120, order 720,
+// 58 trailing tiles in the first step).
+constexpr int CB = 32;   // block column width
+constexpr int CT = 64;   // tile edge of panel / trailing kernels
+
+__global__ __launch_bounds__(256) void k_chol_panel(BaDev D, int k0) {
+    if (!BA_ACTIVE(D)) return;
+    __shared__ double Lkk[CB][CB + 1];
+    __shared__ int okSh;
+    const int n = D.n, tid = threadIdx.x;
+    const int kb = min(CB, n - k0);
+    double* S = D.S;
+    for (int q = tid; q < CB * CB; q += 256) {
+        const int r = q / CB, c = q - CB * r;
+        Lkk[r][c] = (r < kb && c < kb) ? S[(size_t)(k0 + r) * n + k0 + c] : ((r == c) ? 1.0 : 0.0);
+    }
+    if (tid == 0) okSh = 1;
+    __syncthreads();
+    // factor the diagonal block: column by column, one wave (rows = lanes), LDS resident
+    if (tid < 64) {
+        const int i = tid;
+        for (int j = 0; j < kb; ++j) {
+            double d = Lkk[j][j];
+            if (!(d > 0)) {
+                if (i == 0) okSh = 0;
+                d = 1.0;
+            }
+            d = sqrt(d);
+            const double lij = (i > j && i < kb) ? Lkk[i][j] / d : 0.0;
+            __builtin_amdgcn_wave_barrier();
+            if (i == j) Lkk[j][j] = d;
+            if (i > j && i < kb) Lkk[i][j] = lij;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (i > j && i < kb)
+                for (int c = j + 1; c <= i; ++c) Lkk[i][c] -= lij * Lkk[c][j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int q = tid; q < kb * kb; q += 256) {
+            const int r = q / kb, c = q - kb * r;
+            if (c <= r) S[(size_t)(k0 + r) * n + k0 + c] = Lkk[r][c];
+        }
+        if (tid == 0 && !okSh) D.st->chol_ok = 0;
+    }
+    // panel rows below the diagonal block: X L^T = B, thread per row
+    const int row = k0 + kb + blockIdx.x * 256 + tid;
+    if (row < n) {
+        double x[CB];
+        double* src = S + (size_t)row * n + k0;
+#pragma unroll
+        for (int c = 0; c < CB; ++c) x[c] = (c < kb) ? src[c] : 0.0;
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            if (j < kb) {
+                double v = x[j];
+#pragma unroll
+                for (int m = 0; m < CB; ++m)
+                    if (m < j) v -= x[m] * Lkk[j][m];
+                x[j] = v / Lkk[j][j];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+            if (c < kb) src[c] = x[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chol_trail(BaDev D, int k0) {
+    if (!BA_ACTIVE(D)) return;
+    __shared__ double Ai[CT][CB + 1];
+    __shared__ double Aj[CT][CB + 1];
+    const int n = D.n, tid = threadIdx.x;
+    const int kb = min(CB, n - k0), t0 = k0 + kb;
+    // decode the lower-triangular tile (ti >= tj) from the linear block index
+    int tj = 0, rem = blockIdx.x;
+    const int nt = (n - t0 + CT - 1) / CT;
+    while (rem >= nt - tj) {
+        rem -= nt - tj;
+        ++tj;
+    }
+    const int ti = tj + rem;
+    const int i0 = t0 + ti * CT, j0 = t0 + tj * CT;
+    double* S = D.S;
+    for (int q = tid; q < CT * CB; q += 256) {
+        const int r = q / CB, c = q - CB * r;
+        Ai[r][c] = (i0 + r < n && c < kb) ? S[(size_t)(i0 + r) * n + k0 + c] : 0.0;
+        Aj[r][c] = (j0 + r < n && c < kb) ? S[(size_t)(j0 + r) * n + k0 + c] : 0.0;
+    }
+    __syncthreads();
+    const int tr = (tid >> 4) * 4, tc = (tid & 15) * 4;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0;
+#pragma unroll 8
+    for (int c = 0; c < CB; ++c) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            av[a] = Ai[tr + a][c];
+            bv[a] = Aj[tc + a][c];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] += av[a] * bv[b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int r = i0 + tr + a, c = j0 + tc + b;
+            if (r < n && c < n && c <= r) S[(size_t)r * n + c] -= acc[a][b];
+        }
+}
+
+// L y = b, then L^T x = y, blocked by CB: the diagonal block is solved by thread 0..kb-1 cooperatively through LDS,
+// the remaining right-hand side is updated by all threads (one row / column entry each)
+__global__ __launch_bounds__(1024) void k_chol_trsv(BaDev D) {
+    if (!BA_ACTIVE(D)) return;
+    extern __shared__ __attribute__((aligned(16))) double bsh[];  // [n]
+    __shared__ double xk[CB];
+    const int n = D.n, tid = threadIdx.x;
+    const double* L = D.S;
+    for (int q = tid; q < n; q += 1024) bsh[q] = D.rhs[q];
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += CB) {
+        const int kb = min(CB, n - k0);
+        if (tid < 64) {  // forward solve of the diagonal block by one wave (serial over its columns)
+            for (int j = 0; j < kb; ++j) {
+                const double yj = bsh[k0 + j] / L[(size_t)(k0 + j) * n + k0 + j];
+                __builtin_amdgcn_wave_barrier();
+                if (tid == j) {
+                    bsh[k0 + j] = yj;
+                    xk[j] = yj;
+                }
+                if (tid > j && tid < kb) bsh[k0 + tid] -= L[(size_t)(k0 + tid) * n + k0 + j] * yj;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        __syncthreads();
+        for (int r = k0 + kb + tid; r < n; r += 1024) {
+            double v = bsh[r];
+            const double* Lr = L + (size_t)r * n + k0;
+            for (int c = 0; c < kb; ++c) v -= Lr[c] * xk[c];
+            bsh[r] = v;
+        }
+        __syncthreads();
+    }
+    for (int k0 = ((n - 1) / CB) * CB; k0 >= 0; k0 -= CB) {
+        const int kb = min(CB, n - k0);
+        if (tid < 64) {
+            for (int j = kb - 1; j >= 0; --j) {
+                const double xj = bsh[k0 + j] / L[(size_t)(k0 + j) * n + k0 + j];
+                __builtin_amdgcn_wave_barrier();
+                if (tid == j) {
+                    bsh[k0 + j] = xj;
+                    xk[j] = xj;
+                }
+                if (tid < j) bsh[k0 + tid] -= L[(size_t)(k0 + j) * n + k0 + tid] * xj;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < k0; r += 1024) {  // x_r -= sum_c L[k0 + c][r] x_{k0 + c}
+            double v = bsh[r];
+            for (int c = 0; c < kb; ++c) v -= L[(size_t)(k0 + c) * n + r] * xk[c];
+            bsh[r] = v;
+        }
+        __syncthreads();
+    }
+    for (int q = tid; q < n; q += 1024) D.rhs[q] = bsh[q];
+}
+
+__global__ void k_chol_begin(BaDev D) {
+    if (!BA_ACTIVE(D)) return;
+    D.st->chol_ok = 1;
+}
+
 // ---- one WAVE: reduced camera system of order n <= 64 -------------------------------------------------
 // Lane i owns row i of S (in LDS) and entry i of the right-hand side (in a register).  Column j of the Cholesky
 // factor is formed from one LDS read per lane plus v_readlane broadcasts of the pivot and of l_kj, the trailing
@@ -1092,8 +1290,22 @@ static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int 
             } else {
                 if (D.n <= 64) {
                     hipLaunchKernelGGL(k_solve_wave, dim3(1), dim3(64), sizeof(double) * (size_t)D.n * (D.n | 1), stream, D);
-                } else {
-                    hipLaunchKernelGGL(k_solve<256>, dim3(1), blk, useLds ? ldsSolve : 0, stream, D, useLds);
+                } else if (useLds) {
+                    hipLaunchKernelGGL(k_solve<256>, dim3(1), blk, ldsSolve, stream, D, 1);
+                } else {  // blocked Cholesky in HBM
+                    hipLaunchKernelGGL(k_chol_begin, dim3(1), dim3(1), 0, stream, D);
+                    for (int k0 = 0; k0 < D.n; k0 += CB) {
+                        const int kb = (D.n - k0 < CB) ? D.n - k0 : CB;
+                        const int below = D.n - k0 - kb;
+                        int gp = (below + 255) / 256;
+                        if (gp < 1) gp = 1;
+                        hipLaunchKernelGGL(k_chol_panel, dim3(gp), blk, 0, stream, D, k0);
+                        if (below > 0) {
+                            const int nt = (below + CT - 1) / CT;
+                            hipLaunchKernelGGL(k_chol_trail, dim3(nt * (nt + 1) / 2), blk, 0, stream, D, k0);
+                        }
+                    }
+                    hipLaunchKernelGGL(k_chol_trsv, dim3(1), dim3(1024), sizeof(double) * (size_t)D.n, stream, D);
                 }
                 hipLaunchKernelGGL(k_update<0>, dim3(gUpd), blk, 0, stream, D);  // + the tentative cost
             }

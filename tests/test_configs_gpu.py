@@ -1,0 +1,147 @@
+"""BASELINE.json configs at their full sizes (cfg3: 3 cameras on one GPU + inter-camera BA; cfg5: 1920x1080 x 5000
+feature slots, 4 x 30 key frames x 5000 points).  Where the oracle finishes in seconds the comparison is against it;
+at sizes where it does not, the checks are size-independent properties (noise-free recovery, monotone cost,
+device-resident == host path, concurrent handles == sequential handles)."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+import coslam_amd
+import oracle
+from coslam_amd.synth import Scene, make_ba_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def cfg2(**kw):
+    base = dict(nIterations=10, nLevels=4, levelSkip=1, windowWidth=7, trackWithGain=1, minCornerness=3000.0,
+                convergenceThreshold=1.0, SSD_Threshold=20000.0, minDistance=5)
+    base.update(kw)
+    return coslam_amd.KLT_SequenceTrackerConfig(**base)
+
+
+def test_cfg5_klt_1080p_5000_slots_matches_oracle(hip):
+    W, H, L, fw, fh = 1920, 1080, 4, 100, 50
+    sc = Scene(1, W, H, 9000, seed=0xC051A + 5)
+    im0, im1 = sc.render(0, 0), sc.render(0, 1)
+    cfg = cfg2(minDistance=8)
+    trk = coslam_amd.KLT_SequenceTracker(cfg, 0)
+    trk.allocate(W, H, L, fw, fh)
+    ora = oracle.SequenceTracker(cfg)
+    ora.allocate(W, H, L, fw, fh)
+    n_g, d_g = trk.detect(im0)
+    n_o, d_o = ora.detect(im0)
+    assert n_g == n_o and n_g > 2000
+    assert np.array_equal(trk.read_pyramid(1), ora.read_pyramid())
+    assert np.array_equal(d_g["status"], d_o["status"])
+    live = d_o["status"] >= 0
+    assert np.array_equal(d_g["pos"][live], d_o["pos"][live])
+    trk.advanceFrame()
+    ora.advanceFrame()
+    n_g, d_g = trk.redetect(im1)
+    n_o, d_o = ora.redetect(im1)
+    same = d_g["status"] == d_o["status"]
+    assert same.mean() > 0.995
+    both = same & (d_o["status"] == 0)
+    err = np.abs(d_g["pos"][both] - d_o["pos"][both]) * np.array([W, H], dtype=np.float32)
+    assert both.sum() > 1500 and err.max() < 0.02
+    trk.close()
+
+
+def test_cfg3_three_cameras_on_one_gpu_concurrent_equals_sequential(hip):
+    """Three tracker handles on three streams, frames interleaved without host synchronisation, must produce what each
+    handle produces on its own (the persistent trackers of all three are co-resident)."""
+    import torch
+
+    W, H, L, fw, fh = 640, 480, 4, 50, 40
+    sc = Scene(3, W, H, 7000, seed=0xC051A + 3)
+    n_frames = 6
+    frames = [[sc.render(c, f) for f in range(n_frames)] for c in range(3)]
+    dev = torch.device("cuda:0")
+
+    def run(concurrent):
+        trks, streams, dests, counts, imgs = [], [], [], [], []
+        for c in range(3):
+            t = coslam_amd.KLT_SequenceTracker(cfg2(), 0)
+            t.allocate(W, H, L, fw, fh)
+            s = torch.cuda.Stream(device=dev) if concurrent else torch.cuda.current_stream()
+            t.set_stream(s.cuda_stream)
+            trks.append(t)
+            streams.append(s)
+            dests.append(torch.zeros(fw * fh * 5, dtype=torch.int32, device=dev))
+            counts.append(torch.zeros(4, dtype=torch.int32, device=dev))
+            imgs.append(torch.from_numpy(np.stack(frames[c])).to(dev))
+        torch.cuda.synchronize()
+        out = []
+        for f in range(n_frames):
+            for c in range(3):
+                fn = trks[c].detect_dev if f == 0 else trks[c].redetect_dev
+                fn(imgs[c][f].data_ptr(), dests[c].data_ptr(), counts[c].data_ptr())
+                trks[c].advanceFrame()
+            if not concurrent:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        for c in range(3):
+            trks[c].synchronize()
+            a = dests[c].cpu().numpy().view(coslam_amd.KLT_TrackedFeature).copy()
+            dead = a["status"] < 0
+            a["pos"][dead] = 0
+            a["gain"][dead] = 0
+            out.append((a, trks[c].read_features().copy(), counts[c].cpu().numpy().copy()))
+            trks[c].close()
+        return out
+
+    seq, con = run(False), run(True)
+    for c in range(3):
+        assert np.array_equal(seq[c][2], con[c][2])
+        assert seq[c][0].tobytes() == con[c][0].tobytes()
+        assert np.array_equal(seq[c][1], con[c][1])
+        assert (seq[c][0]["status"] >= 0).sum() > 800
+
+
+def test_cfg3_inter_camera_pose_solve_matches_oracle(hip):
+    """SL_InterCamPoseEstimator.cpp:92-95: nCamsCon = 0, every static point fixed, 60 free dynamic points."""
+    pr = make_ba_problem(n_cams=3, n_pts=2060, n_cams_con=0, n_pts_con=2000, visibility=0.8, seed=33)
+    P = len(pr["pts0"])
+    ptr, cam, xy, _ = oracle.csr_by_point(P, pr["obs_pt"], pr["obs_cam"], pr["obs_xy"])
+    Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+    out_g, st_g = coslam_amd.bundleAdjustRobust(0, pr["Ks"], Rs, Ts, 2000, pts, (ptr, cam, xy), 6.0, 3, 40)
+    R_o, T_o, M_o, out_o, st_o = oracle.ba_robust(pr["Ks"], pr["Rs0"], pr["ts0"], pr["pts0"], ptr, cam, xy, 0, 2000, 6.0, 3, 40)
+    assert np.array_equal(out_g, out_o)
+    assert np.array_equal(pts[:2000], pr["pts0"][:2000])  # fixed points untouched
+    sane = np.linalg.norm(M_o, axis=1) < 1e3
+    assert np.max(np.abs(Rs - R_o)) < 1e-6 and np.max(np.abs(Ts - T_o)) < 1e-5
+    assert np.max(np.abs(pts[sane] - M_o[sane])) < 1e-5
+    assert np.max(np.abs(Rs - pr["Rs_gt"])) < 5e-3  # the solve lands near the truth
+
+
+def test_cfg5_sliding_window_ba_full_size(hip):
+    """4 cameras x 30 key frames = 120 poses, 5000 points, every point seen in every key frame (600 k measurements).
+    The oracle needs ~15 GFLOP per LM step here, so: noise-free data must be recovered, and on noisy data the cost
+    must not increase and the flagged outliers must be the planted ones."""
+    pr = make_ba_problem(n_cams=120, n_pts=5000, W=1920, H=1080, noise=0.0, outlier_frac=0.0, n_cams_con=8,
+                         n_pts_con=2, seed=55)
+    P = len(pr["pts0"])
+    ptr, cam, xy, _ = oracle.csr_by_point(P, pr["obs_pt"], pr["obs_cam"], pr["obs_xy"])
+    assert len(cam) == 600000
+    Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+    t0 = time.perf_counter()
+    out, st = coslam_amd.bundleAdjustRobust(8, pr["Ks"], Rs, Ts, 2, pts, (ptr, cam, xy), 6.0, 2, 12)
+    dt = time.perf_counter() - t0
+    assert st.cost <= st.cost0 and st.cost < 1e-10 * max(1.0, st.cost0), (st.cost0, st.cost)
+    assert np.max(np.abs(Rs - pr["Rs_gt"])) < 1e-7 and np.max(np.abs(pts - pr["pts_gt"])) < 1e-6
+    assert out.sum() == 0
+    print(f"cfg5 BA (C=120, P=5000, 600k obs): {st.nIterTotal} LM steps in {dt*1e3:.1f} ms")
+    # noisy + planted outliers: flags == planted set (20 px against a 6 px gate), cost goes down
+    pr = make_ba_problem(n_cams=120, n_pts=2000, W=1920, H=1080, noise=0.3, outlier_frac=0.02, outlier_mag=40.0,
+                         n_cams_con=8, n_pts_con=2, seed=56)
+    P = len(pr["pts0"])
+    ptr, cam, xy, order = oracle.csr_by_point(P, pr["obs_pt"], pr["obs_cam"], pr["obs_xy"])
+    Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+    out, st = coslam_amd.bundleAdjustRobust(8, pr["Ks"], Rs, Ts, 2, pts, (ptr, cam, xy), 6.0, 3, 10)
+    planted = pr["is_outlier"][order]
+    assert st.cost < st.cost0
+    assert (out.astype(bool) == planted).mean() > 0.999
+    assert np.max(np.abs(Rs - pr["Rs_gt"])) < 2e-3

@@ -66,6 +66,9 @@ def ba_inputs(**kw):
     (dict(noise=0.0, outlier_frac=0.0), 2, 2, 2, 30),       # noise-free: exact recovery
     (dict(n_cams=3, n_pts=200, n_cams_con=0, n_pts_con=140, seed=5), 0, 140, 3, 40),  # inter-camera pose shape
     (dict(n_cams=15, n_pts=800, visibility=0.6, seed=9), 6, 2, 2, 10),                 # 3 cams x 5 KF, ragged tracks
+    (dict(n_cams=22, n_pts=500, visibility=0.5, seed=10), 2, 2, 2, 8),                 # order 120: LDS workgroup Cholesky
+    (dict(n_cams=40, n_pts=400, visibility=0.5, seed=11), 2, 2, 2, 8),                 # order 228: blocked Cholesky in HBM
+    (dict(n_cams=120, n_pts=300, visibility=0.25, seed=12, W=1920, H=1080), 8, 2, 1, 6),  # cfg5 camera count (4 x 30 KF), order 672
 ])
 def test_ba_matches_oracle(hip, kw, ncon, npcon, maxIter, inner):
     kw = dict(kw)
