@@ -156,11 +156,22 @@ def main():
     #   ba_stream    local BA: the reference runs it on a worker thread next to tracking
     #                (src/app/SL_CoSLAM.cpp:1702-1730, one request in flight at a time).
     # --serial puts everything back on one stream (diagnostic).
-    klt_torch_stream = torch.cuda.Stream(device=dev)
-    pose_torch_stream = klt_torch_stream if args.serial else torch.cuda.Stream(device=dev)
-    ba_torch_stream = klt_torch_stream if (args.sync_ba or args.serial) else torch.cuda.Stream(device=dev)
-    if os.environ.get("BENCH_BA_ON_POSE"):
-        ba_torch_stream = pose_torch_stream
+    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    side_cus = int(os.environ.get("BENCH_SIDE_CUS", "0"))  # CUs reserved for the pose / BA streams (0 = no CU masks)
+
+    def make_stream(first, count):
+        if side_cus <= 0 or args.serial:
+            return torch.cuda.Stream(device=dev)
+        L = coslam_amd.lib()
+        L.cs_stream_create_cu_range.restype = C.c_void_p
+        h = L.cs_stream_create_cu_range(local_rank, first, count)
+        if not h:
+            raise SystemExit("CU-masked stream: " + L.cs_last_error().decode())
+        return torch.cuda.ExternalStream(h, device=dev)
+
+    klt_torch_stream = make_stream(0, n_cus - side_cus)
+    pose_torch_stream = klt_torch_stream if args.serial else make_stream(n_cus - side_cus, side_cus)
+    ba_torch_stream = klt_torch_stream if (args.sync_ba or args.serial) else make_stream(n_cus - side_cus, side_cus)
     stream = klt_torch_stream.cuda_stream
     pose_stream = pose_torch_stream.cuda_stream
     ba_stream = ba_torch_stream.cuda_stream

@@ -31,6 +31,37 @@ int cs_device_count(void) {
     return n;
 }
 
+// A HIP stream restricted to the compute units [first_cu, first_cu + n_cus) of `device` (hipExtStreamCreateWithCUMask).
+// The persistent tracker runs every wave in lock-step with its neighbours, so one foreign wave on one of its SIMDs
+// slows the whole mesh; pose / BA streams confined to a few CUs, and the tracker stream to the others, keeps them
+// apart.  Returns the stream handle (a hipStream_t) or null.
+void* cs_stream_create_cu_range(int device, int first_cu, int n_cus) {
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        cs_set_error("cs_stream_create_cu_range: bad device %d", device);
+        return nullptr;
+    }
+    const int total = prop.multiProcessorCount;
+    if (first_cu < 0 || n_cus <= 0 || first_cu + n_cus > total) {
+        cs_set_error("cs_stream_create_cu_range: range [%d, %d) outside the %d CUs", first_cu, first_cu + n_cus, total);
+        return nullptr;
+    }
+    std::vector<uint32_t> mask((total + 31) / 32, 0u);
+    for (int c = first_cu; c < first_cu + n_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
+    hipStream_t s = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data());
+    if (e != hipSuccess) {
+        cs_set_error("hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    return (void*)s;
+}
+
+int cs_stream_destroy(void* stream) {
+    if (stream) CS_HIP(hipStreamDestroy((hipStream_t)stream));
+    return CS_OK;
+}
+
 void cs_klt_config_default(cs_klt_config* c) {  // v3d_gpuklt.h:181-191
     c->nIterations = 12;
     c->nLevels = 3;

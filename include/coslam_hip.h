@@ -110,6 +110,10 @@ int cs_klt_enable_graphs(cs_klt* k, int on);
  * through 8-byte {tag, beta} granules; 0 = one launch per Gauss-Newton pass as the reference schedules its shader
  * (v3d_gpuklt.cpp:254-287).  Both give bit-identical results.  Env COSLAM_KLT_FUSED=0 sets the default to 0. */
 int cs_klt_set_fused(cs_klt* k, int on);
+/* a stream confined to the compute units [first_cu, first_cu + n_cus): keeps pose / BA kernels off the SIMDs of the
+ * lock-stepped persistent tracker; returns a hipStream_t (null on error) */
+void* cs_stream_create_cu_range(int device, int first_cu, int n_cus);
+int cs_stream_destroy(void* stream);
 /* diagnostic only: per-slot cycle counters (8 x uint64) of the persistent gain tracker; see klt_seq.hip */
 int cs_klt_debug_probe(cs_klt* k, int on, unsigned long long* host_out8);
 /* HIP-event timing of the tracker stage on the handle's stream (used by bench.py's roofline leg).  While on, the
