@@ -56,6 +56,51 @@ struct BaDev {
 
 __device__ __forceinline__ double wsum(double v) { return cs_wave_sum_d(v); }
 
+// ---- many sums at once: transposed butterfly ----------------------------------------------------------------------
+// Folding N per-lane values with N independent 64-lane butterflies costs 6 N exchange steps; here every exchange step
+// halves the number of values a lane still carries (the lower lane of a pair keeps the first half of the list, the
+// upper lane the second half), so N values need N/2 + N/4 + ... ~ N exchanges in total and each total ends up in ONE
+// lane: value q in lane wave_reduce_owner(q).  Fixed tree, deterministic.
+__device__ __forceinline__ double shfl_xor_d(double v, int d) {
+    int lo = __shfl_xor(__double2loint(v), d, 64), hi = __shfl_xor(__double2hiint(v), d, 64);
+    return __hiloint2double(hi, lo);
+}
+template <int M, int DIST>
+__device__ __forceinline__ void wave_reduce_step(double* v, int lane) {
+    if constexpr (DIST >= 1) {
+        constexpr int H = (M + 1) / 2;
+        const bool up = (lane & DIST) != 0;
+#pragma unroll
+        for (int t = 0; t < H; ++t) {
+            const double lo = v[t];
+            const double hi = (H + t < M) ? v[H + t] : 0.0;
+            const double recv = shfl_xor_d(up ? lo : hi, DIST);
+            v[t] = (up ? hi : lo) + recv;
+        }
+        wave_reduce_step<H, DIST / 2>(v, lane);
+    }
+}
+// after the call v[0] of lane l holds the total of value wave_reduce_index<N>(l) (or -1: the lane holds nothing)
+template <int N>
+__device__ __forceinline__ void wave_reduce_many(double* v, int lane) {
+    wave_reduce_step<N, 32>(v, lane);
+}
+template <int N>
+__device__ __forceinline__ int wave_reduce_index(int lane) {
+    int lo = 0, end = N, m = N;  // the lane's slot list covers [lo, lo + m); indices >= end are zero padding
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int h = (m + 1) / 2;
+        if (lane & d) {
+            lo += h;
+        } else {
+            end = min(end, lo + h);
+        }
+        m = h;
+    }
+    return lo < end ? lo : -1;
+}
+
 __device__ __forceinline__ void so3_exp(const double w[3], double R[9]) {
     double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
     if (th == 0) {
@@ -367,10 +412,10 @@ __global__ __launch_bounds__(64) void k_schur_part(BaDev D) {
             }
         }
     }
-#pragma unroll
-    for (int q = 0; q < 42; ++q) {
-        const double v = wsum(acc[q]);
-        if (lane == 0) out[q] = v;
+    wave_reduce_many<42>(acc, lane);
+    {
+        const int q = wave_reduce_index<42>(lane);
+        if (q >= 0) out[q] = acc[0];
     }
     if (ja == jb) {  // U_j = sum Jc^T Jc and g_j = sum Jc^T e over this slice of the camera's own measurement list
         double u[27];
@@ -392,11 +437,9 @@ __global__ __launch_bounds__(64) void k_schur_part(BaDev D) {
 #pragma unroll
             for (int r = 0; r < 6; ++r) u[21 + r] += J[r] * e0 + J[6 + r] * e1;
         }
-#pragma unroll
-        for (int q = 0; q < 27; ++q) {
-            const double v = wsum(u[q]);
-            if (lane == 0) out[42 + q] = v;
-        }
+        wave_reduce_many<27>(u, lane);
+        const int q = wave_reduce_index<27>(lane);
+        if (q >= 0) out[42 + q] = u[0];
     }
 }
 
@@ -794,12 +837,19 @@ __device__ __forceinline__ void solve_reg_block(const BaDev& D, double* Ssm, int
 #pragma unroll
         for (int k = j + 1; k < NMAX; ++k) a[k] -= lij * rdlane_d(lij, k);
     }
-    // L^T x = y: x_j = (y_j - sum_{i>j} L[i][j] x_i) / L[j][j]
+    // L^T x = y as a column sweep over the rows of L, which go back to LDS (row i by lane i) for the transposed reads
+    if (i < NMAX) {
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) Ssm[i * NMAX + k] = a[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int j = NMAX - 1; j >= 0; --j) {
-        const double s = cs_wave_sum_d((i > j) ? a[j] * b : 0.0);
-        const double xj = (rdlane_d(b, j) - s) * rdiag[j];
+        const double xj = rdlane_d(b, j) * rdiag[j];
         if (i == j) b = xj;
+        if (i < j) b -= Ssm[j * NMAX + i] * xj;
     }
     if (i < n) Ssm[NMAX * NMAX + i] = b;
     if (i == 0) *okSh = ok ? 1 : 0;
@@ -1281,11 +1331,17 @@ static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int 
                 else
                     hipLaunchKernelGGL(k_schur, dim3(nPairs), blk, 0, stream, D);
             }
-            if (D.n > 0 && D.n <= 12) {
-                hipLaunchKernelGGL(k_update<12>, dim3(gUpd), blk, 0, stream, D);  // + solve + tentative cost
-            } else if (D.n > 0 && D.n <= 24) {
+            if (D.n == 6) {
+                hipLaunchKernelGGL(k_update<6>, dim3(gUpd), blk, 0, stream, D);  // + solve + tentative cost
+            } else if (D.n == 12) {
+                hipLaunchKernelGGL(k_update<12>, dim3(gUpd), blk, 0, stream, D);
+            } else if (D.n == 18) {
+                hipLaunchKernelGGL(k_update<18>, dim3(gUpd), blk, 0, stream, D);
+            } else if (D.n == 24) {
                 hipLaunchKernelGGL(k_update<24>, dim3(gUpd), blk, 0, stream, D);
-            } else if (D.n > 0 && D.n <= 36) {
+            } else if (D.n == 30) {
+                hipLaunchKernelGGL(k_update<30>, dim3(gUpd), blk, 0, stream, D);
+            } else if (D.n == 36) {
                 hipLaunchKernelGGL(k_update<36>, dim3(gUpd), blk, 0, stream, D);
             } else {
                 if (D.n <= 64) {
