@@ -49,6 +49,8 @@ struct BaDev {
     double *Jc, *e, *W, *Vinv, *gp, *S, *rhs, *costPart, *stepPart;
     BaState* st;
     int nCostBlocks, nUpdBlocks, nSlices;
+    int pLo, pHi, addLambda;  // point slice owned by this rank ([0, P) and 1 in the single-process solve)
+    double* scal;             // [4] cost / point-step / flags-changed / outlier-count partials (distributed solve)
     double* schurPart;  // [nPairs][nSlices][72] partial Schur blocks (orders <= 36)
     double maxErr;
     int innerMaxIter;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256) void k_linearize(BaDev D) {
     if (!BA_ACTIVE(D)) return;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= D.P) return;
+    if (i >= D.P || i < D.pLo || i >= D.pHi) return;
     const int o0 = D.obs_ptr[i], o1 = D.obs_ptr[i + 1];
     int nIn = 0;
     for (int o = o0 + lane; o < o1; o += 64) nIn += D.outlier[o] ? 0 : 1;
@@ -289,6 +291,8 @@ __global__ __launch_bounds__(256) void k_schur(BaDev D) {
         for (int s = D.cam_ptr[ca] + threadIdx.x; s < D.cam_ptr[ca + 1]; s += 256) {
             const int o = D.cam_obs[s];
             if (D.outlier[o]) continue;
+            const int ip = D.obs_pt[o];
+            if (ip < D.pLo || ip >= D.pHi) continue;  // another rank's point
             const double* J = D.Jc + 12 * (size_t)o;
             const double e0 = D.e[2 * (size_t)o], e1 = D.e[2 * (size_t)o + 1];
             int q = 0;
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(256) void k_schur(BaDev D) {
     double acc[42];
 #pragma unroll
     for (int q = 0; q < 42; ++q) acc[q] = 0;
-    for (int i = D.nPtsCon + threadIdx.x; i < D.P; i += 256) {
+    for (int i = (D.nPtsCon > D.pLo ? D.nPtsCon : D.pLo) + threadIdx.x; i < D.pHi; i += 256) {
         const int oa = D.obs_of[(size_t)i * D.C + ca];
         if (oa < 0 || D.outlier[oa]) continue;
         const int ob = (ja == jb) ? oa : D.obs_of[(size_t)i * D.C + cb];
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(256) void k_schur(BaDev D) {
                 const int rr = r < c ? r : c, cc = r < c ? c : r;
                 const int uq = rr * 6 - (rr * (rr - 1)) / 2 + (cc - rr);
                 const double uv = ((redU[0][uq] + redU[1][uq]) + redU[2][uq]) + redU[3][uq];
-                D.S[(size_t)(6 * ja + r) * n + 6 * ja + c] = (uv + ((r == c) ? D.st->lambda : 0.0)) - s;
+                D.S[(size_t)(6 * ja + r) * n + 6 * ja + c] = (uv + ((r == c && D.addLambda) ? D.st->lambda : 0.0)) - s;
             } else {
                 D.S[(size_t)(6 * ja + r) * n + 6 * jb + c] = -s;
                 D.S[(size_t)(6 * jb + c) * n + 6 * ja + r] = -s;
@@ -881,7 +885,9 @@ __global__ __launch_bounds__(256) void k_update(BaDev D) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     double cost = 0;
-    if (gw < D.P) {
+    if (gw < D.P && (gw < D.pLo || gw >= D.pHi)) {
+        if (lane == 0) D.stepPart[gw] = 0;  // another rank's point
+    } else if (gw < D.P) {
         const int i = gw;
         const int o0 = D.obs_ptr[i], o1 = D.obs_ptr[i + 1];
         double b[3] = {0, 0, 0};
@@ -979,6 +985,7 @@ __global__ __launch_bounds__(256) void k_cost(BaDev D, int which) {
     for (int o = blockIdx.x * 256 + threadIdx.x; o < D.nObs; o += gridDim.x * 256) {
         if (D.outlier[o]) continue;
         const int j = D.obs_cam[o], i = D.obs_pt[o];
+        if (i < D.pLo || i >= D.pHi) continue;
         double e[2];
         residual<false>(D.Ks + 9 * j, Rs + 9 * j, Ts + 3 * j, pts + 3 * (size_t)i, D.obs_xy + 2 * (size_t)o, e, nullptr,
                         nullptr);
@@ -1063,6 +1070,7 @@ __global__ __launch_bounds__(256) void k_flag(BaDev D) {
     int changed = 0, nout = 0;
     for (int o = blockIdx.x * 256 + threadIdx.x; o < D.nObs; o += gridDim.x * 256) {
         const int j = D.obs_cam[o], i = D.obs_pt[o];
+        if (i < D.pLo || i >= D.pHi) continue;
         double e[2];
         residual<false>(D.Ks + 9 * j, D.Rs + 9 * j, D.Ts + 3 * j, D.pts + 3 * (size_t)i, D.obs_xy + 2 * (size_t)o, e,
                         nullptr, nullptr);
@@ -1124,6 +1132,7 @@ __global__ void k_cost_force(BaDev D) {  // k_cost(0) ignoring the stop flags (f
     for (int o = blockIdx.x * 256 + threadIdx.x; o < D.nObs; o += gridDim.x * 256) {
         if (D.outlier[o]) continue;
         const int j = D.obs_cam[o], i = D.obs_pt[o];
+        if (i < D.pLo || i >= D.pHi) continue;
         double e[2];
         residual<false>(D.Ks + 9 * j, D.Rs + 9 * j, D.Ts + 3 * j, D.pts + 3 * (size_t)i, D.obs_xy + 2 * (size_t)o, e,
                         nullptr, nullptr);
@@ -1148,18 +1157,140 @@ __global__ void k_build_obs_of(int nObs, int C, const int* obs_pt, const int* ob
     if (o < nObs) obs_of[(size_t)obs_pt[o] * C + obs_cam[o]] = o;  // duplicates: last writer wins (host rejects them)
 }
 
+
+// ---- distributed solve (collective 2): points sliced by rank -------------------------------------
+// Every rank holds the whole problem (the per-frame all-gather replicated measurements and poses) and owns the points
+// [pLo, pHi).  Per LM step a rank linearises its points, forms ITS part of the reduced camera system (the dense
+// S || rhs, lambda added by rank 0 only), the host all-reduces S || rhs (RCCL over xGMI), every rank solves the same
+// system, steps its own points and all cameras, and the partial tentative costs are all-reduced as four scalars.
+// The LM / outlier control flow stays on the device exactly as in the single-process solve (every rank takes the
+// same decisions from the same all-reduced numbers), so the host still never synchronises: it only interleaves the
+// phase launches below with collectives on the same stream.
+// scal[0] cost partial, scal[1] squared point step partial, scal[2] flags changed, scal[3] outlier count
+__global__ __launch_bounds__(256) void k_dist_pack(BaDev D, int what) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    if (what == 2) {  // after k_flag
+        if (tid == 0) {
+            D.scal[2] = (double)D.st->changed;
+            D.scal[3] = (double)D.st->nOutliers;
+        }
+        return;
+    }
+    double c = 0;
+    const int nPart = (what == 1) ? D.nUpdBlocks : D.nCostBlocks;
+    for (int q = tid; q < nPart; q += 256) c += D.costPart[q];
+    c = wsum(c);
+    if ((tid & 63) == 0) red[tid >> 6] = c;
+    __syncthreads();
+    const double cost_sum = ((red[0] + red[1]) + red[2]) + red[3];
+    __syncthreads();
+    double s2 = 0;
+    if (what == 1)
+        for (int q = D.pLo + tid; q < D.pHi; q += 256) s2 += D.stepPart[q];
+    s2 = wsum(s2);
+    if ((tid & 63) == 0) red[tid >> 6] = s2;
+    __syncthreads();
+    if (tid == 0) {
+        D.scal[0] = cost_sum;
+        D.scal[1] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
+}
+
+// k_control with the all-reduced scalars; commits all cameras and this rank's points
+__global__ __launch_bounds__(256) void k_dist_control(BaDev D, int phase) {
+    __shared__ int accept;
+    BaState* st = D.st;
+    if (st->all_done) return;
+    if (phase == 1 && st->inner_done) return;
+    const int tid = threadIdx.x;
+    const double cost_sum = D.scal[0];
+    if (phase == 0) {
+        if (tid == 0) {
+            st->cost = cost_sum;
+            st->lambda = 1e-3;
+            st->inner_it = 0;
+            st->inner_done = (D.innerMaxIter <= 0) ? 1 : 0;
+            if (st->first_cost) {
+                st->cost0 = cost_sum;
+                st->first_cost = 0;
+            }
+        }
+        return;
+    }
+    if (tid == 0) {
+        double step2 = D.scal[1];
+        for (int j = 0; j < D.C; ++j) step2 += D.stepPart[D.P + j];  // camera steps: identical on every rank
+        const double cost_new = st->chol_ok ? cost_sum : 1e300;
+        int acc = (st->chol_ok && cost_new <= st->cost) ? 1 : 0;
+        int done = 0;
+        st->nIterTotal += 1;
+        st->inner_it += 1;
+        if (acc) {
+            const double dec = st->cost - cost_new;
+            st->cost = cost_new;
+            st->lambda /= 10;
+            if (dec < 1e-9 * cost_new + 1e-15 || step2 < 1e-20) done = 1;
+        } else {
+            st->lambda *= 10;
+            if (st->lambda > 1e12) done = 1;
+        }
+        if (st->inner_it >= D.innerMaxIter) done = 1;
+        st->inner_done = done;
+        accept = acc;
+    }
+    __syncthreads();
+    if (accept) {
+        for (int q = tid; q < 9 * D.C; q += 256) D.Rs[q] = D.Rn[q];
+        for (int q = tid; q < 3 * D.C; q += 256) D.Ts[q] = D.Tn[q];
+        for (int q = 3 * D.pLo + tid; q < 3 * D.pHi; q += 256) D.pts[q] = D.Mn[q];
+    }
+}
+
+__global__ void k_dist_outer_end(BaDev D) {
+    BaState* st = D.st;
+    if (st->all_done) return;
+    st->changed = (D.scal[2] > 0.0) ? 1 : 0;
+    st->nOutliers = (int)(D.scal[3] + 0.5);
+    st->nOuter += 1;
+    st->inner_done = 0;
+    if (!st->changed) st->all_done = 1;
+}
+
+// before the final all-reduce (sum) of points and flags: entries owned by other ranks contribute zero
+__global__ void k_dist_zero_foreign(BaDev D) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 3 * D.P) {
+        const int i = t / 3;
+        if (i < D.pLo || i >= D.pHi) D.pts[t] = 0.0;
+    }
+    if (t < D.nObs) {
+        const int i = D.obs_pt[t];
+        if (i < D.pLo || i >= D.pHi) D.outlier[t] = 0;
+    }
+}
+
 }  // namespace
 
 // =====================================================================================================
+// launch geometry of one solve (host side)
+struct BaPlan {
+    BaDev D;
+    int cb, gPts, gUpd, nPairs, useLds;
+    size_t ldsSolve;
+    bool sliced;
+};
+
 struct cs_ba {
     int device;
     int capC, capP, capObs;
     hipStream_t own_stream;
     // device buffers
-    double *Ks, *Rs, *Ts, *pts, *Rn, *Tn, *Mn, *obs_xy, *Jc, *e, *W, *Vinv, *gp, *S, *rhs, *costPart, *stepPart, *schurPart;
+    double *Ks, *Rs, *Ts, *pts, *Rn, *Tn, *Mn, *obs_xy, *Jc, *e, *W, *Vinv, *gp, *S, *rhs, *costPart, *stepPart, *schurPart, *scal;
     int *obs_ptr, *obs_cam, *obs_pt, *cam_ptr, *cam_obs, *obs_of, *outlier;
     BaState* st;
     cs_ba_stats_dev* stats;
+    BaPlan* dist;  // plan of the distributed solve in progress (cs_ba_dist_begin)
     // pinned staging for the host-pointer entry
     int *h_cam_ptr, *h_cam_obs;
     int nCostBlocks;
@@ -1179,8 +1310,10 @@ static void ba_drop_graph(cs_ba* b) {
 
 static int ba_free(cs_ba* b) {
     ba_drop_graph(b);
+    delete b->dist;
+    b->dist = nullptr;
     double** dp[] = {&b->Ks, &b->Rs, &b->Ts, &b->pts, &b->Rn, &b->Tn, &b->Mn, &b->obs_xy, &b->Jc, &b->e, &b->W,
-                     &b->Vinv, &b->gp, &b->S, &b->rhs, &b->costPart, &b->stepPart, &b->schurPart};
+                     &b->Vinv, &b->gp, &b->S, &b->costPart, &b->stepPart, &b->schurPart, &b->scal};
     for (auto p : dp) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -1220,8 +1353,9 @@ static int ba_reserve(cs_ba* b, int C, int P, int nObs) {
     BA_ALLOC(b->W, 18 * cO, double);
     BA_ALLOC(b->Vinv, 9 * cP, double);
     BA_ALLOC(b->gp, 3 * cP, double);
-    BA_ALLOC(b->S, n * n, double);
-    BA_ALLOC(b->rhs, n, double);
+    BA_ALLOC(b->S, n * n + n + 8, double);  // S || rhs contiguous: one all-reduce in the distributed solve
+    b->rhs = nullptr;                        // set per solve: S + n^2 of the actual order
+    BA_ALLOC(b->scal, 8, double);
     BA_ALLOC(b->costPart, 1024 + cP / 4 + cC / 256 + 2, double);
     BA_ALLOC(b->schurPart, (size_t)21 * 16 * 72, double);  // <= 6 free cameras (21 pairs) x 16 slices
     BA_ALLOC(b->stepPart, cP + cC, double);
@@ -1243,10 +1377,10 @@ static int ba_reserve(cs_ba* b, int C, int P, int nObs) {
     return CS_OK;
 }
 
-// enqueue the whole solve on `stream`; every array already resident in b's device buffers
-static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int nCamsCon, int nPtsCon, double maxErr,
-                      int maxIter, int innerMaxIter) {
-    BaDev D;
+static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPtsCon, double maxErr, int innerMaxIter,
+                        bool distributed, BaPlan* out) {
+    BaPlan& L = *out;
+    BaDev& D = L.D;
     memset(&D, 0, sizeof(D));
     D.C = C;
     D.P = P;
@@ -1276,95 +1410,133 @@ static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int 
     D.Vinv = b->Vinv;
     D.gp = b->gp;
     D.S = b->S;
+    b->rhs = b->S + (size_t)D.n * D.n;  // S || rhs contiguous
     D.rhs = b->rhs;
     D.costPart = b->costPart;
     D.stepPart = b->stepPart;
     D.schurPart = b->schurPart;
+    D.scal = b->scal;
     D.st = b->st;
     D.maxErr = maxErr;
     D.innerMaxIter = innerMaxIter;
+    D.pLo = 0;
+    D.pHi = P;
+    D.addLambda = 1;
     int cb = (nObs + 255) / 256;
     if (cb < 1) cb = 1;
     if (cb > 1024) cb = 1024;
     D.nCostBlocks = cb;
     b->nCostBlocks = cb;
-
-    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, stream, b->st);
-    CS_HIP(hipMemsetAsync(b->outlier, 0, sizeof(int) * (nObs > 0 ? nObs : 1), stream));
-    CS_HIP(hipMemsetAsync(b->obs_of, 0xff, sizeof(int) * (size_t)P * C, stream));
-    if (P > 0) hipLaunchKernelGGL(k_build_obs_pt, dim3((P + 3) / 4), dim3(256), 0, stream, P, b->obs_ptr, b->obs_pt);
-    if (nObs > 0)
-        hipLaunchKernelGGL(k_build_obs_of, dim3((nObs + 255) / 256), dim3(256), 0, stream, nObs, C, b->obs_pt, b->obs_cam,
-                           b->obs_of);
-
-    const int nPairs = D.nc * (D.nc + 1) / 2;
-    const size_t ldsSolve = sizeof(double) * ((size_t)D.n * D.n + D.n);
-    const int useLds = (ldsSolve <= 150 * 1024) ? 1 : 0;
-    if (useLds && ldsSolve > 64 * 1024) {
-        CS_HIP(hipFuncSetAttribute((const void*)k_solve<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsSolve));
+    L.cb = cb;
+    L.nPairs = D.nc * (D.nc + 1) / 2;
+    L.ldsSolve = sizeof(double) * ((size_t)D.n * D.n + D.n);
+    L.useLds = (L.ldsSolve <= 150 * 1024) ? 1 : 0;
+    if (L.useLds && L.ldsSolve > 64 * 1024) {
+        CS_HIP(hipFuncSetAttribute((const void*)k_solve<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.ldsSolve));
     }
-    const dim3 gPts((P + 3) / 4 > 0 ? (P + 3) / 4 : 1), gCam((D.nc + 3) / 4 > 0 ? (D.nc + 3) / 4 : 1), blk(256);
+    L.gPts = (P + 3) / 4 > 0 ? (P + 3) / 4 : 1;
     int gUpd = (P + 3) / 4;
     if (gUpd * 256 < C) gUpd = (C + 255) / 256;
     if (gUpd < 1) gUpd = 1;
     D.nUpdBlocks = gUpd;
-    // orders <= 36: sliced Schur partials, combined by the register Cholesky
-    const bool sliced = (D.n > 0 && D.n <= 36);
+    L.gUpd = gUpd;
+    // orders <= 36: sliced Schur partials, combined by the register Cholesky (single-process solve only: the
+    // distributed solve needs the dense S || rhs for its all-reduce)
+    L.sliced = (!distributed && D.n > 0 && D.n <= 36);
     D.nSlices = 1;
-    if (sliced) {
-        int sl = 96 / (nPairs > 0 ? nPairs : 1);
+    if (L.sliced) {
+        int sl = 96 / (L.nPairs > 0 ? L.nPairs : 1);
         if (sl > 16) sl = 16;
         if (sl < 1) sl = 1;
         const int nFree = P - D.nPtsCon;
         while (sl > 1 && (nFree + sl - 1) / sl < 32) sl /= 2;  // at least half a wave of points per slice
         D.nSlices = sl;
     }
+    return CS_OK;
+}
+
+static void ba_enqueue_init(cs_ba* b, hipStream_t stream, const BaPlan& L) {
+    const BaDev& D = L.D;
+    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, stream, b->st);
+    (void)hipMemsetAsync(b->outlier, 0, sizeof(int) * (D.nObs > 0 ? D.nObs : 1), stream);
+    (void)hipMemsetAsync(b->obs_of, 0xff, sizeof(int) * (size_t)D.P * D.C, stream);
+    if (D.P > 0) hipLaunchKernelGGL(k_build_obs_pt, dim3((D.P + 3) / 4), dim3(256), 0, stream, D.P, b->obs_ptr, b->obs_pt);
+    if (D.nObs > 0)
+        hipLaunchKernelGGL(k_build_obs_of, dim3((D.nObs + 255) / 256), dim3(256), 0, stream, D.nObs, D.C, b->obs_pt,
+                           b->obs_cam, b->obs_of);
+}
+
+// linearisation + reduced system of one LM step (this rank's point slice)
+static void ba_enqueue_lin_schur(hipStream_t stream, const BaPlan& L) {
+    const BaDev& D = L.D;
+    const dim3 blk(256);
+    hipLaunchKernelGGL(k_linearize, dim3(L.gPts), blk, 0, stream, D);
+    if (D.nc > 0) {
+        if (L.sliced)
+            hipLaunchKernelGGL(k_schur_part, dim3(L.nPairs * D.nSlices), dim3(64), 0, stream, D);
+        else
+            hipLaunchKernelGGL(k_schur, dim3(L.nPairs), blk, 0, stream, D);
+    }
+}
+
+// solve of the reduced system + tentative step + its cost
+static void ba_enqueue_solve_update(hipStream_t stream, const BaPlan& L) {
+    const BaDev& D = L.D;
+    const dim3 blk(256);
+    const int gUpd = L.gUpd;
+    if (L.sliced && D.n == 6) {
+        hipLaunchKernelGGL(k_update<6>, dim3(gUpd), blk, 0, stream, D);  // + solve + tentative cost
+    } else if (L.sliced && D.n == 12) {
+        hipLaunchKernelGGL(k_update<12>, dim3(gUpd), blk, 0, stream, D);
+    } else if (L.sliced && D.n == 18) {
+        hipLaunchKernelGGL(k_update<18>, dim3(gUpd), blk, 0, stream, D);
+    } else if (L.sliced && D.n == 24) {
+        hipLaunchKernelGGL(k_update<24>, dim3(gUpd), blk, 0, stream, D);
+    } else if (L.sliced && D.n == 30) {
+        hipLaunchKernelGGL(k_update<30>, dim3(gUpd), blk, 0, stream, D);
+    } else if (L.sliced && D.n == 36) {
+        hipLaunchKernelGGL(k_update<36>, dim3(gUpd), blk, 0, stream, D);
+    } else {
+        if (D.n <= 64) {
+            hipLaunchKernelGGL(k_solve_wave, dim3(1), dim3(64), sizeof(double) * (size_t)D.n * (D.n | 1), stream, D);
+        } else if (L.useLds) {
+            hipLaunchKernelGGL(k_solve<256>, dim3(1), blk, L.ldsSolve, stream, D, 1);
+        } else {  // blocked Cholesky in HBM
+            hipLaunchKernelGGL(k_chol_begin, dim3(1), dim3(1), 0, stream, D);
+            for (int k0 = 0; k0 < D.n; k0 += CB) {
+                const int kb = (D.n - k0 < CB) ? D.n - k0 : CB;
+                const int below = D.n - k0 - kb;
+                int gp = (below + 255) / 256;
+                if (gp < 1) gp = 1;
+                hipLaunchKernelGGL(k_chol_panel, dim3(gp), blk, 0, stream, D, k0);
+                if (below > 0) {
+                    const int nt = (below + CT - 1) / CT;
+                    hipLaunchKernelGGL(k_chol_trail, dim3(nt * (nt + 1) / 2), blk, 0, stream, D, k0);
+                }
+            }
+            hipLaunchKernelGGL(k_chol_trsv, dim3(1), dim3(1024), sizeof(double) * (size_t)D.n, stream, D);
+        }
+        hipLaunchKernelGGL(k_update<0>, dim3(gUpd), blk, 0, stream, D);  // + the tentative cost
+    }
+}
+
+// enqueue the whole solve on `stream`; every array already resident in b's device buffers
+static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int nCamsCon, int nPtsCon, double maxErr,
+                      int maxIter, int innerMaxIter) {
+    BaPlan L;
+    int rc = ba_make_plan(b, C, P, nObs, nCamsCon, nPtsCon, maxErr, innerMaxIter, false, &L);
+    if (rc) return rc;
+    const BaDev& D = L.D;
+    const int cb = L.cb;
+    const dim3 blk(256);
+    ba_enqueue_init(b, stream, L);
 
     for (int outer = 0; outer < maxIter; ++outer) {
         hipLaunchKernelGGL(k_cost, dim3(cb), blk, 0, stream, D, 0);
         hipLaunchKernelGGL(k_control, dim3(1), blk, 0, stream, D, 0);
         for (int it = 0; it < innerMaxIter; ++it) {
-            hipLaunchKernelGGL(k_linearize, gPts, blk, 0, stream, D);
-            if (D.nc > 0) {
-                if (sliced)
-                    hipLaunchKernelGGL(k_schur_part, dim3(nPairs * D.nSlices), dim3(64), 0, stream, D);
-                else
-                    hipLaunchKernelGGL(k_schur, dim3(nPairs), blk, 0, stream, D);
-            }
-            if (D.n == 6) {
-                hipLaunchKernelGGL(k_update<6>, dim3(gUpd), blk, 0, stream, D);  // + solve + tentative cost
-            } else if (D.n == 12) {
-                hipLaunchKernelGGL(k_update<12>, dim3(gUpd), blk, 0, stream, D);
-            } else if (D.n == 18) {
-                hipLaunchKernelGGL(k_update<18>, dim3(gUpd), blk, 0, stream, D);
-            } else if (D.n == 24) {
-                hipLaunchKernelGGL(k_update<24>, dim3(gUpd), blk, 0, stream, D);
-            } else if (D.n == 30) {
-                hipLaunchKernelGGL(k_update<30>, dim3(gUpd), blk, 0, stream, D);
-            } else if (D.n == 36) {
-                hipLaunchKernelGGL(k_update<36>, dim3(gUpd), blk, 0, stream, D);
-            } else {
-                if (D.n <= 64) {
-                    hipLaunchKernelGGL(k_solve_wave, dim3(1), dim3(64), sizeof(double) * (size_t)D.n * (D.n | 1), stream, D);
-                } else if (useLds) {
-                    hipLaunchKernelGGL(k_solve<256>, dim3(1), blk, ldsSolve, stream, D, 1);
-                } else {  // blocked Cholesky in HBM
-                    hipLaunchKernelGGL(k_chol_begin, dim3(1), dim3(1), 0, stream, D);
-                    for (int k0 = 0; k0 < D.n; k0 += CB) {
-                        const int kb = (D.n - k0 < CB) ? D.n - k0 : CB;
-                        const int below = D.n - k0 - kb;
-                        int gp = (below + 255) / 256;
-                        if (gp < 1) gp = 1;
-                        hipLaunchKernelGGL(k_chol_panel, dim3(gp), blk, 0, stream, D, k0);
-                        if (below > 0) {
-                            const int nt = (below + CT - 1) / CT;
-                            hipLaunchKernelGGL(k_chol_trail, dim3(nt * (nt + 1) / 2), blk, 0, stream, D, k0);
-                        }
-                    }
-                    hipLaunchKernelGGL(k_chol_trsv, dim3(1), dim3(1024), sizeof(double) * (size_t)D.n, stream, D);
-                }
-                hipLaunchKernelGGL(k_update<0>, dim3(gUpd), blk, 0, stream, D);  // + the tentative cost
-            }
+            ba_enqueue_lin_schur(stream, L);
+            ba_enqueue_solve_update(stream, L);
             hipLaunchKernelGGL(k_control, dim3(1), blk, 0, stream, D, 1);
         }
         hipLaunchKernelGGL(k_outer_begin, dim3(1), dim3(1), 0, stream, D);
@@ -1546,6 +1718,112 @@ int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const do
     memset(&b->gkey, 0, sizeof(b->gkey));
     b->gkey = key;
     CS_HIP(hipGraphLaunch(b->gexec, s));
+    return CS_OK;
+}
+
+// ---- distributed solve: phase API (see k_dist_pack above) --------------------------------------------------------
+// The caller (coslam_amd/multicam.py) uploads the replicated problem with cs_ba_upload, calls cs_ba_dist_begin with
+// its point slice, then per outer round
+//     phase COST0 | all-reduce scal | phase CONTROL0
+//     innerMaxIter x ( phase LIN_SCHUR | all-reduce S||rhs | phase SOLVE_UPDATE | all-reduce scal | phase CONTROL1 )
+//     phase FLAG | all-reduce scal | phase OUTER_END
+// and finally phase FINAL_PREP | all-reduce pts, outlier | phase FINISH.  Everything is enqueued on `stream`.
+int cs_ba_dist_begin(cs_ba* b, void* hip_stream, int C, int P, int nObs, const double* d_Rs0, const double* d_Ts0,
+                     const double* d_pts0, int nCamsCon, int nPtsCon, double maxErr, int innerMaxIter, int pLo, int pHi,
+                     int addLambda) {
+    if (!b || C > b->capC || P > b->capP || nObs > b->capObs || pLo < 0 || pHi > P || pLo > pHi) {
+        cs_set_error("cs_ba_dist_begin: workspace not uploaded for this size, or bad slice");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(b->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
+    if (!b->dist) b->dist = new BaPlan();
+    int rc = ba_make_plan(b, C, P, nObs, nCamsCon, nPtsCon, maxErr, innerMaxIter, true, b->dist);
+    if (rc) return rc;
+    b->dist->D.pLo = pLo;
+    b->dist->D.pHi = pHi;
+    b->dist->D.addLambda = addLambda ? 1 : 0;
+    if (d_Rs0) CS_HIP(hipMemcpyAsync(b->Rs, d_Rs0, sizeof(double) * 9 * C, hipMemcpyDeviceToDevice, s));
+    if (d_Ts0) CS_HIP(hipMemcpyAsync(b->Ts, d_Ts0, sizeof(double) * 3 * C, hipMemcpyDeviceToDevice, s));
+    if (d_pts0 && P > 0) CS_HIP(hipMemcpyAsync(b->pts, d_pts0, sizeof(double) * 3 * P, hipMemcpyDeviceToDevice, s));
+    CS_HIP(hipMemsetAsync(b->scal, 0, sizeof(double) * 8, s));
+    ba_enqueue_init(b, s, *b->dist);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+int cs_ba_dist_phase(cs_ba* b, void* hip_stream, int phase) {
+    if (!b || !b->dist) {
+        cs_set_error("cs_ba_dist_phase: cs_ba_dist_begin has not been called");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(b->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
+    const BaPlan& L = *b->dist;
+    const BaDev& D = L.D;
+    const dim3 blk(256);
+    switch (phase) {
+        case CS_BA_PH_COST0:
+            hipLaunchKernelGGL(k_cost, dim3(L.cb), blk, 0, s, D, 0);
+            hipLaunchKernelGGL(k_dist_pack, dim3(1), blk, 0, s, D, 0);
+            break;
+        case CS_BA_PH_CONTROL0:
+            hipLaunchKernelGGL(k_dist_control, dim3(1), blk, 0, s, D, 0);
+            break;
+        case CS_BA_PH_LIN_SCHUR:
+            if (D.n > 0) (void)hipMemsetAsync(b->S, 0, sizeof(double) * ((size_t)D.n * D.n + D.n), s);
+            ba_enqueue_lin_schur(s, L);
+            break;
+        case CS_BA_PH_SOLVE_UPDATE:
+            ba_enqueue_solve_update(s, L);
+            hipLaunchKernelGGL(k_dist_pack, dim3(1), blk, 0, s, D, 1);
+            break;
+        case CS_BA_PH_CONTROL1:
+            hipLaunchKernelGGL(k_dist_control, dim3(1), blk, 0, s, D, 1);
+            break;
+        case CS_BA_PH_FLAG:
+            hipLaunchKernelGGL(k_outer_begin, dim3(1), dim3(1), 0, s, D);
+            hipLaunchKernelGGL(k_flag, dim3(L.cb), blk, 0, s, D);
+            hipLaunchKernelGGL(k_dist_pack, dim3(1), blk, 0, s, D, 2);
+            break;
+        case CS_BA_PH_OUTER_END:
+            hipLaunchKernelGGL(k_dist_outer_end, dim3(1), dim3(1), 0, s, D);
+            break;
+        case CS_BA_PH_FINAL_PREP: {
+            int nn = 3 * D.P > D.nObs ? 3 * D.P : D.nObs;
+            if (nn < 1) nn = 1;
+            hipLaunchKernelGGL(k_dist_zero_foreign, dim3((nn + 255) / 256), blk, 0, s, D);
+            break;
+        }
+        case CS_BA_PH_FINISH: {  // pts / outlier are complete on every rank now: report the full cost
+            BaDev F = D;
+            F.pLo = 0;
+            F.pHi = D.P;
+            hipLaunchKernelGGL(k_cost_force, dim3(L.cb), blk, 0, s, F);
+            hipLaunchKernelGGL(k_finish, dim3(1), blk, 0, s, F, b->stats);
+            break;
+        }
+        default:
+            cs_set_error("cs_ba_dist_phase: unknown phase %d", phase);
+            return CS_ERR_INVALID;
+    }
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+/* device pointers of the buffers the collectives run on: S || rhs (n_red doubles), scal (4 doubles), pts (3 P doubles),
+ * outlier (nObs int32) */
+int cs_ba_dist_buffers(cs_ba* b, void** d_S_rhs, int* n_red, void** d_scal, void** d_pts, void** d_outlier) {
+    if (!b || !b->dist) {
+        cs_set_error("cs_ba_dist_buffers: cs_ba_dist_begin has not been called");
+        return CS_ERR_INVALID;
+    }
+    const BaDev& D = b->dist->D;
+    if (d_S_rhs) *d_S_rhs = b->S;
+    if (n_red) *n_red = D.n * D.n + D.n;
+    if (d_scal) *d_scal = b->scal;
+    if (d_pts) *d_pts = b->pts;
+    if (d_outlier) *d_outlier = b->outlier;
     return CS_OK;
 }
 

@@ -59,3 +59,109 @@ def features_from_words(words):
 
     a = words.cpu().numpy() if hasattr(words, "cpu") else np.asarray(words)
     return np.ascontiguousarray(a, dtype=np.int32).reshape(-1).view(KLT_TrackedFeature)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Collective 2: joint bundle adjustment with the points sliced by rank.
+#
+# After the per-frame all-gather every rank holds all measurements and poses, i.e. the whole bundleAdjustRobust
+# problem of src/app/SL_CoSLAMRobustBA.cpp:170-180 / SL_InterCamPoseEstimator.cpp:92-95.  Rank r owns the points
+# [pLo, pHi): it linearises them and forms ITS part of the reduced camera system; ONE all-reduce of S || rhs
+# ((6C')^2 + 6C' doubles: 29 KB for 8 cameras x 1 key frame, 4.1 MB for cfg5) per LM step makes it whole; every rank
+# then solves the same system, steps its own points and all cameras, and four scalars (cost, point step, flag change,
+# outlier count) are all-reduced so that every rank takes the same LM / outlier decisions.  Points and outlier flags
+# are exchanged once at the end.  The phases are device launches on one stream (coslam_amd/csrc/ba.hip,
+# cs_ba_dist_*); with backend "nccl" (RCCL over xGMI) the collectives are stream-ordered too, so the host never
+# synchronises.
+PH_COST0, PH_CONTROL0, PH_LIN_SCHUR, PH_SOLVE_UPDATE, PH_CONTROL1, PH_FLAG, PH_OUTER_END, PH_FINAL_PREP, PH_FINISH = range(9)
+
+
+def point_slice(rank, world, n_points):
+    """Contiguous slice of the point list owned by `rank`."""
+    per = (n_points + world - 1) // world
+    lo = min(rank * per, n_points)
+    return lo, min(lo + per, n_points)
+
+
+def run_sliced_ba(backends, reduce_fn, max_iter, inner_max_iter):
+    """The phase / collective schedule of the sliced BA.
+
+    backends: the rank-local phase engines (ONE in a real job: HipSlicedBA; several only when ranks are emulated in one
+    process).  Each exposes phase(ph) and the buffers S_rhs, scal, pts, outlier.  reduce_fn(name) sums buffer `name`
+    over all ranks in place (dist.all_reduce in a real job)."""
+    def ph(p):
+        for b in backends:
+            b.phase(p)
+
+    for _ in range(max_iter):
+        ph(PH_COST0)
+        reduce_fn("scal")
+        ph(PH_CONTROL0)
+        for _ in range(inner_max_iter):
+            ph(PH_LIN_SCHUR)
+            reduce_fn("S_rhs")
+            ph(PH_SOLVE_UPDATE)
+            reduce_fn("scal")
+            ph(PH_CONTROL1)
+        ph(PH_FLAG)
+        reduce_fn("scal")
+        ph(PH_OUTER_END)
+    ph(PH_FINAL_PREP)
+    reduce_fn("pts")
+    reduce_fn("outlier")
+    ph(PH_FINISH)
+
+
+class _DevArray:
+    """Zero-copy view of library-owned device memory for torch (CUDA array interface, also honoured by ROCm builds)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class HipSlicedBA:
+    """Rank-local engine of the sliced BA on one MI355X: the phases of cs_ba_dist_phase and torch views of the buffers
+    the collectives run on.  `ws` is a BAWorkspace holding the (replicated) problem."""
+
+    def __init__(self, ws, stream, d_Rs0, d_Ts0, d_pts0, nCamsCon, nPtsCon, maxErr, innerMaxIter, pLo, pHi, add_lambda,
+                 device):
+        import ctypes as C
+
+        from ._lib import check
+
+        self.ws, self.stream, self._check, self._C = ws, stream, check, C
+        L = ws._L
+        vp = C.c_void_p
+        check(L.cs_ba_dist_begin(ws._h, vp(stream.cuda_stream), ws.C, ws.P, ws.nObs, vp(d_Rs0), vp(d_Ts0), vp(d_pts0),
+                                 int(nCamsCon), int(nPtsCon), C.c_double(maxErr), int(innerMaxIter), int(pLo), int(pHi),
+                                 1 if add_lambda else 0), "cs_ba_dist_begin")
+        pS, pscal, ppts, pout, nred = vp(), vp(), vp(), vp(), C.c_int(0)
+        check(L.cs_ba_dist_buffers(ws._h, C.byref(pS), C.byref(nred), C.byref(pscal), C.byref(ppts), C.byref(pout)),
+              "cs_ba_dist_buffers")
+        dev = torch.device("cuda", device)
+        self.S_rhs = torch.as_tensor(_DevArray(pS.value, max(nred.value, 1), "<f8"), device=dev)
+        self.scal = torch.as_tensor(_DevArray(pscal.value, 4, "<f8"), device=dev)
+        self.pts = torch.as_tensor(_DevArray(ppts.value, max(3 * ws.P, 1), "<f8"), device=dev)
+        self.outlier = torch.as_tensor(_DevArray(pout.value, max(ws.nObs, 1), "<i4"), device=dev)
+
+    def phase(self, ph):
+        self._check(self.ws._L.cs_ba_dist_phase(self.ws._h, self._C.c_void_p(self.stream.cuda_stream), int(ph)),
+                    "cs_ba_dist_phase")
+
+
+def bundle_adjust_sliced(ws, stream, d_Rs0, d_Ts0, d_pts0, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter, device,
+                         group=None):
+    """bundleAdjustRobust over all ranks of `group` (one process per GPU).  Every rank passes the same replicated
+    problem (already in `ws`) and receives the same result (ws.download())."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = point_slice(rank, world, ws.P)
+    eng = HipSlicedBA(ws, stream, d_Rs0, d_Ts0, d_pts0, nCamsCon, nPtsCon, maxErr, innerMaxIter, lo, hi, rank == 0, device)
+
+    def reduce_fn(name):
+        if world > 1:
+            with torch.cuda.stream(stream):
+                dist.all_reduce(getattr(eng, name), group=group)
+
+    run_sliced_ba([eng], reduce_fn, maxIter, innerMaxIter)
+    return eng

@@ -199,6 +199,25 @@ int cs_ba_upload(cs_ba* b, int C, int P, int nObs, const double* Ks, const doubl
 int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const double* d_Rs0, const double* d_Ts0,
                     const double* d_pts0, int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter);
 /* synchronise and copy the workspace's current estimate back (any pointer may be NULL) */
+/* Distributed solve (one process per GPU, points sliced by rank; SURVEY.md 8e collective 2): the reduced camera system
+ * S || rhs is all-reduced once per LM step by the caller between the phases below; every launch is asynchronous on
+ * `hip_stream`, the LM / outlier control flow stays on the device.  Schedule: see coslam_amd/multicam.py. */
+enum {
+    CS_BA_PH_COST0 = 0,        /* partial cost of the current estimate          -> all-reduce scal   */
+    CS_BA_PH_CONTROL0 = 1,     /* start of an LM run                                                   */
+    CS_BA_PH_LIN_SCHUR = 2,    /* linearise own points, partial S || rhs        -> all-reduce S||rhs  */
+    CS_BA_PH_SOLVE_UPDATE = 3, /* solve, tentative step, partial tentative cost -> all-reduce scal   */
+    CS_BA_PH_CONTROL1 = 4,     /* accept / reject, commit                                              */
+    CS_BA_PH_FLAG = 5,         /* outlier flags of own measurements             -> all-reduce scal   */
+    CS_BA_PH_OUTER_END = 6,
+    CS_BA_PH_FINAL_PREP = 7,   /* zero foreign points / flags                   -> all-reduce pts, outlier */
+    CS_BA_PH_FINISH = 8        /* final cost and statistics                                            */
+};
+int cs_ba_dist_begin(cs_ba* b, void* hip_stream, int C, int P, int nObs, const double* d_Rs0, const double* d_Ts0,
+                     const double* d_pts0, int nCamsCon, int nPtsCon, double maxErr, int innerMaxIter, int pLo, int pHi,
+                     int addLambda);
+int cs_ba_dist_phase(cs_ba* b, void* hip_stream, int phase);
+int cs_ba_dist_buffers(cs_ba* b, void** d_S_rhs, int* n_red, void** d_scal, void** d_pts, void** d_outlier);
 int cs_ba_download(cs_ba* b, int C, int P, int nObs, double* Rs, double* Ts, double* pts, int* out_outlier,
                    cs_ba_stats* stats);
 

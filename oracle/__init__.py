@@ -295,3 +295,15 @@ def ba_robust(Ks, Rs, Ts, pts, obs_ptr, obs_cam, obs_xy, nCamsCon, nPtsCon, maxE
     L.oba_robust(Cn, P, n, _p(Ks), _p(Rs), _p(Ts), _p(pts), _p(obs_ptr), _p(obs_cam), _p(obs_xy), int(nCamsCon),
                  int(nPtsCon), C.c_double(maxErr), int(maxIter), int(innerMaxIter), _p(out), C.byref(st))
     return Rs.reshape(Cn, 3, 3), Ts, pts, out[:n], st
+
+
+def ba_residual(K, R, t, M, m, jac=True):
+    """oba_residual (oracle/ba_oracle.c): e = m - pi(K(RM+t)) and, optionally, Jc (2x6) and Jp (2x3)."""
+    L = lib()
+    K, R, t, M, m = (_dd(a).reshape(-1) for a in (K, R, t, M, m))
+    e, Jc, Jp = np.zeros(2), np.zeros(12), np.zeros(6)
+    vp = C.c_void_p
+    ok = L.oba_residual(K.ctypes.data_as(vp), R.ctypes.data_as(vp), t.ctypes.data_as(vp), M.ctypes.data_as(vp),
+                        m.ctypes.data_as(vp), e.ctypes.data_as(vp), Jc.ctypes.data_as(vp) if jac else None,
+                        Jp.ctypes.data_as(vp) if jac else None)
+    return bool(ok), e, Jc.reshape(2, 6), Jp.reshape(2, 3)
