@@ -156,22 +156,36 @@ def main():
     #   ba_stream    local BA: the reference runs it on a worker thread next to tracking
     #                (src/app/SL_CoSLAM.cpp:1702-1730, one request in flight at a time).
     # --serial puts everything back on one stream (diagnostic).
+    # The persistent tracker runs its 2000 waves in lock-step (neighbour hand-offs every pass), so a foreign wave on one
+    # of its SIMDs slows the whole mesh: measured 89 -> 100-120 us per launch when pose / BA kernels share the chip.
+    # The chip is therefore partitioned with CU-masked streams (hipExtStreamCreateWithCUMask): the tracker stream gets
+    # all but SIDE_CUS compute units, the pose and BA streams the rest.  BENCH_SIDE_CUS=0 turns the partition off.
     n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    side_cus = int(os.environ.get("BENCH_SIDE_CUS", "0"))  # CUs reserved for the pose / BA streams (0 = no CU masks)
+    side_cus = int(os.environ.get("BENCH_SIDE_CUS", "64"))
+    if args.serial or side_cus >= n_cus:
+        side_cus = 0
+    masked = {"ok": side_cus > 0}
 
     def make_stream(first, count):
-        if side_cus <= 0 or args.serial:
-            return torch.cuda.Stream(device=dev)
-        L = coslam_amd.lib()
-        L.cs_stream_create_cu_range.restype = C.c_void_p
-        h = L.cs_stream_create_cu_range(local_rank, first, count)
-        if not h:
-            raise SystemExit("CU-masked stream: " + L.cs_last_error().decode())
-        return torch.cuda.ExternalStream(h, device=dev)
+        if masked["ok"]:
+            try:
+                L = coslam_amd.lib()
+                L.cs_stream_create_cu_range.restype = C.c_void_p
+                h = L.cs_stream_create_cu_range(local_rank, first, count)
+                if h:
+                    return torch.cuda.ExternalStream(h, device=dev)
+                print("bench: CU-masked stream unavailable (" + L.cs_last_error().decode() + "); plain streams",
+                      file=sys.stderr)
+            except Exception as ex:  # noqa: BLE001 -- never let the partition break the benchmark
+                print(f"bench: CU-masked stream unavailable ({ex}); plain streams", file=sys.stderr)
+            masked["ok"] = False
+        return torch.cuda.Stream(device=dev)
 
     klt_torch_stream = make_stream(0, n_cus - side_cus)
     pose_torch_stream = klt_torch_stream if args.serial else make_stream(n_cus - side_cus, side_cus)
     ba_torch_stream = klt_torch_stream if (args.sync_ba or args.serial) else make_stream(n_cus - side_cus, side_cus)
+    if not masked["ok"]:
+        side_cus = 0
     stream = klt_torch_stream.cuda_stream
     pose_stream = pose_torch_stream.cuda_stream
     ba_stream = ba_torch_stream.cuda_stream
@@ -182,6 +196,8 @@ def main():
     trk = coslam_amd.KLT_SequenceTracker(klt_config(), device=local_rank)
     trk.allocate(W, H, LEVELS, FW, FH)
     trk.set_stream(stream)
+    if side_cus > 0:
+        trk.set_cu_count(n_cus - side_cus)
     if not args.no_graphs and hasattr(trk, "enable_graphs"):
         trk.enable_graphs(True)
 
@@ -319,6 +335,8 @@ def main():
                        "cameras": n_gpus, "live_features_last_frame": n_live, "pose_ok": pose_ok,
                        "hip_graphs": bool(not args.no_graphs and hasattr(trk, "enable_graphs")),
                        "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
+                       "cu_partition": (f"tracker stream on {n_cus - side_cus} CUs, pose / BA streams on {side_cus} CUs"
+                                        if side_cus > 0 else "none"),
                        "streams": "one stream (--serial)" if args.serial else
                        "tracker | pose (event-ordered behind the tracker of the same frame) | local BA "
                        "(own stream, like the reference's BA worker thread)"},

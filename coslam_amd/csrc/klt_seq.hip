@@ -111,6 +111,7 @@ struct cs_klt {
     bool use_fused;
     unsigned long long* d_gran;
     int* d_err;
+    int cu_count;                 // compute units the handle's stream may use (cs_klt_set_cu_count; default: all)
     unsigned long long* d_probe;  // diagnostic cycle counters of the persistent tracker (cs_klt_debug_probe)
     // hipGraph cache for the *_dev entry points: one executable graph per (call, buffer rotation state)
     bool use_graphs;
@@ -128,7 +129,7 @@ struct cs_klt {
 // resident workgroups (8 x 256-thread blocks on each of the 256 CUs, minus a margin) is shared between handles
 static std::mutex g_reg_mutex;
 static int g_live_handles[64];
-constexpr int CS_RESIDENT_BLOCK_BUDGET = 1536;
+constexpr int CS_RESIDENT_BLOCKS_PER_CU = 6;  // of the 8 x 256-thread blocks a CU admits, minus a margin
 
 #define CS_REQUIRE(cond, msg)      \
     do {                           \
@@ -178,7 +179,7 @@ static int enqueue_tracker(cs_klt* k, cs_klt_feature* postDest, int doSuppress, 
         live = g_live_handles[k->device & 63] > 0 ? g_live_handles[k->device & 63] : 1;
     }
     const int blocks = (k->N + 3) / 4;
-    if (k->use_fused && T >= 1 && blocks * live <= CS_RESIDENT_BLOCK_BUDGET && (2 * hw + 1) * (2 * hw + 1) <= 256) {
+    if (k->use_fused && T >= 1 && blocks * live <= CS_RESIDENT_BLOCKS_PER_CU * k->cu_count && (2 * hw + 1) * (2 * hw + 1) <= 256) {
         CsGainFusedArgs f;
         memset(&f, 0, sizeof(f));
         f.pyr0 = P0;
@@ -423,6 +424,10 @@ cs_klt* cs_klt_create(const cs_klt_config* cfg, int device, int tap_mode) {
         return nullptr;
     }
     k->stream = k->own_stream;
+    {
+        hipDeviceProp_t prop;
+        k->cu_count = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
     k->graphs = new std::vector<cs_klt::GraphEntry>();
     k->ev_pairs = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
     const char* env = getenv("COSLAM_KLT_FUSED");
@@ -580,6 +585,20 @@ int cs_klt_set_ssd_threshold(cs_klt* k, float t) {
 int cs_klt_set_stream(cs_klt* k, void* s) {
     CS_REQUIRE(k, "null handle");
     k->stream = s ? (hipStream_t)s : k->own_stream;
+    return CS_OK;
+}
+
+// The persistent tracker needs every wave co-resident: tell the handle how many compute units its stream may use
+// when that stream carries a CU mask (cs_stream_create_cu_range); the default is the whole device.
+int cs_klt_set_cu_count(cs_klt* k, int n_cus) {
+    CS_REQUIRE(k && n_cus > 0, "cs_klt_set_cu_count: bad arguments");
+    k->cu_count = n_cus;
+    if (k->allocated) {
+        int rc = bind_device(k);
+        if (rc) return rc;
+        CS_HIP(hipStreamSynchronize(k->stream));
+        drop_graphs(k);
+    }
     return CS_OK;
 }
 

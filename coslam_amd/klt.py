@@ -196,6 +196,9 @@ class KLT_SequenceTracker:
               "cs_klt_debug_probe")
         return out
 
+    def set_cu_count(self, n_cus):
+        check(self._L.cs_klt_set_cu_count(self._h, int(n_cus)), "cs_klt_set_cu_count")
+
     def synchronize(self):
         check(self._L.cs_klt_synchronize(self._h), "cs_klt_synchronize")
 

@@ -110,6 +110,8 @@ int cs_klt_enable_graphs(cs_klt* k, int on);
  * through 8-byte {tag, beta} granules; 0 = one launch per Gauss-Newton pass as the reference schedules its shader
  * (v3d_gpuklt.cpp:254-287).  Both give bit-identical results.  Env COSLAM_KLT_FUSED=0 sets the default to 0. */
 int cs_klt_set_fused(cs_klt* k, int on);
+/* compute units available to the handle's stream when it carries a CU mask (co-residency budget of the persistent tracker) */
+int cs_klt_set_cu_count(cs_klt* k, int n_cus);
 /* a stream confined to the compute units [first_cu, first_cu + n_cus): keeps pose / BA kernels off the SIMDs of the
  * lock-stepped persistent tracker; returns a hipStream_t (null on error) */
 void* cs_stream_create_cu_range(int device, int first_cu, int n_cus);
