@@ -8,18 +8,24 @@
 // Design: measurements live in HBM grouped by point (CSR), with a second index by camera and a dense
 // (point, camera) -> measurement table.  One LM step is a short chain of kernels and the LM / outlier
 // control flow stays on the device (a state word every kernel checks on entry), so the host enqueues the
-// whole maxIter x innerMaxIter schedule without a single synchronisation:
+// whole maxIter x innerMaxIter schedule without a single synchronisation (four launches per LM step):
 //   k_linearize   one wave per point: residual + analytic Jacobians per measurement (lane = measurement),
 //                 W_ij = Jc^T Jp to HBM, V_i and g_i folded across the wave with butterflies, V_i^-1 stored;
-//   k_schur       one workgroup per camera pair (j,k): S_jk = [j==k](U_j + lambda I) - sum_i W_ij V_i^-1 W_ik^T through
-//                 the dense table (deterministic order, no atomics); rhs_j = g_j - sum_i W_ij V_i^-1 g_i;
-//   k_solve       one workgroup: Cholesky of the reduced camera system in LDS + the two triangular solves;
-//   k_update      tentative step: cameras R exp(w), t + dt; points by back-substitution (wave per point);
-//   k_cost        squared inlier residuals at the tentative (or current) estimate, per-block partials;
+//   k_schur_part  (orders <= 36) one WAVE per (camera pair, point slice): partial S_jk, rhs_j, U_j, g_j, the 69 sums
+//                 folded with a transposed butterfly; k_schur (larger systems): one workgroup per camera pair writes
+//                 S_jk = [j==k](U_j + lambda I) - sum_i W_ij V_i^-1 W_ik^T through the dense table;
+//   k_update<N>   N > 0: every workgroup adds the slice partials in LDS and factorises the reduced system out of the
+//                 registers of one wave; then the tentative step (cameras R exp(w), t + dt; points by
+//                 back-substitution, wave per point) and the tentative cost of the wave's own measurements;
+//                 N = 0: the system was solved by k_solve_wave / k_solve<256> (LDS) or the blocked Cholesky
+//                 k_chol_panel / k_chol_trail / k_chol_trsv (HBM, order > 138);
 //   k_control     one workgroup: fixed-order sum of the partials, accept/reject, lambda, commit, stop flags;
-//   k_flag        outlier flags (residual > maxErr) and the "flags changed" bit for the outer loop.
-// MFMA is deliberately absent: at the sizes of the reference's calls (<= 13 cameras x 5 key frames) the
-// reduced system is <= 390 x 390 and the Schur products are 6x3 blocks -- wave-shuffle territory.
+//   k_cost / k_flag  start-of-round cost; outlier flags (residual > maxErr) and the "flags changed" bit.
+// Every sum has a fixed order (no atomics): results are run-to-run identical.
+// MFMA is deliberately absent: the f64 matrix peak of MI355X equals its f64 vector peak, and the Schur products
+// are 6x3 blocks -- wave-shuffle territory; the large-order Cholesky tiles through LDS with 4x4 register blocks.
+// The distributed solve (points sliced by rank, all-reduce of S || rhs per LM step) reuses these kernels through
+// the cs_ba_dist_* phase API at the end of this file.
 #include <cstdlib>
 
 #include "cs_common.h"

@@ -7,8 +7,10 @@
 //
 // Design: the reference needs 5 full-screen passes, a log2(512)-level HistoPyramid, two synchronous
 // glReadPixels and a CPU nth_element per frame.  Here
-//   k_cornerness      one LDS-tiled kernel for the separable 7x7 structure tensor + min eigenvalue,
-//   k_post_track      per slot: status + tracked count + the "present feature" -1e30 scatter,
+//   (cornerness)      the separable 7x7 structure tensor + min eigenvalue is computed by the level-0 pyramid kernel
+//                     out of the tile it has just produced (klt_pyramid.hip, k_pyr_level0_corner),
+//   k_post_track      per slot: status + the "present feature" -1e30 scatter (only behind the per-pass / no-gain
+//                     trackers: the persistent gain tracker does this in its epilogue),
 //   k_nonmax_compact  both separable non-max passes out of one LDS tile, survivors appended to a
 //                     candidate list with one wave-aggregated atomic (replaces the HistoPyramid),
 //   k_select_fill     one workgroup: rank sorts of the candidates (HistoPyramid order is Morton order of the pixel,
@@ -21,60 +23,6 @@
 
 
 namespace {
-
-// ------------------------------------------------------------------ cornerness
-constexpr int CTW = 64, CTH = 8, CR = 3;
-
-__global__ __launch_bounds__(256) void k_cornerness(const cs_texel* __restrict__ lvl0, int W, int H,
-                                                    float minCornerness, float lox, float loy, float hix, float hiy,
-                                                    float* __restrict__ out) {
-    __shared__ float2 g[CTH + 2 * CR][CTW + 2 * CR];
-    __shared__ float conv[3][CTH][CTW + 2 * CR];
-    const int x0 = blockIdx.x * CTW, y0 = blockIdx.y * CTH, tid = threadIdx.x;
-    for (int i = tid; i < (CTH + 2 * CR) * (CTW + 2 * CR); i += 256) {
-        int ly = i / (CTW + 2 * CR), lx = i - ly * (CTW + 2 * CR);
-        int gx = cs_clampi(x0 + lx - CR, 0, W - 1), gy = cs_clampi(y0 + ly - CR, 0, H - 1);
-        float I, Ix, Iy;
-        cs_unpack_texel(lvl0[(size_t)gy * W + gx], I, Ix, Iy);
-        g[ly][lx] = make_float2(Ix, Iy);
-    }
-    __syncthreads();
-    // klt_detector_pass1.cg: vertical taps -3..+3 accumulated in that order
-    for (int i = tid; i < CTH * (CTW + 2 * CR); i += 256) {
-        int ly = i / (CTW + 2 * CR), lx = i - ly * (CTW + 2 * CR);
-        float r0 = 0, r1 = 0, r2 = 0;
-#pragma unroll
-        for (int k = 0; k < 2 * CR + 1; ++k) {
-            float2 v = g[ly + k][lx];
-            r0 += v.x * v.x;
-            r1 += v.x * v.y;
-            r2 += v.y * v.y;
-        }
-        conv[0][ly][lx] = r0;
-        conv[1][ly][lx] = r1;
-        conv[2][ly][lx] = r2;
-    }
-    __syncthreads();
-    // klt_detector_pass2.cg:12-33
-    const int lx = tid & (CTW - 1), x = x0 + lx;
-    for (int ly = tid / CTW; ly < CTH; ly += 256 / CTW) {
-        int y = y0 + ly;
-        if (x >= W || y >= H) continue;
-        float a = 0, b = 0, c = 0;
-#pragma unroll
-        for (int k = 0; k < 2 * CR + 1; ++k) {
-            a += conv[0][ly][lx + k];
-            b += conv[1][ly][lx + k];
-            c += conv[2][ly][lx + k];
-        }
-        float amc = a - c;
-        float cn = 0.5f * ((a + c) - sqrtf(amc * amc + 4.0f * (b * b)));
-        cn = fmaxf(cn - minCornerness, 0.0f);
-        float stx = ((float)x + 0.5f) / (float)W, sty = ((float)y + 0.5f) / (float)H;
-        bool inside = (stx >= lox && sty >= loy) && (stx <= hix && sty <= hiy);
-        out[(size_t)y * W + x] = inside ? cn : 0.0f;
-    }
-}
 
 // ------------------------------------------------------------------ present-feature scatter
 __device__ __forceinline__ void suppress_at(float* corner, int W, int H, float s, float t) {
@@ -375,16 +323,6 @@ __global__ __launch_bounds__(1024) void k_counts_track(const cs_klt_feature* __r
 }
 
 }  // namespace
-
-int cs_launch_cornerness(const cs_texel* lvl0, int W, int H, float minCornerness, float margin, float* out,
-                         hipStream_t stream) {
-    const float lox = margin / (float)W, loy = margin / (float)H;
-    const float hix = 1.0f - margin / (float)W, hiy = 1.0f - margin / (float)H;
-    dim3 grid((W + CTW - 1) / CTW, (H + CTH - 1) / CTH);
-    hipLaunchKernelGGL(k_cornerness, grid, dim3(256), 0, stream, lvl0, W, H, minCornerness, lox, loy, hix, hiy, out);
-    CS_CHECK_LAUNCH();
-    return CS_OK;
-}
 
 int cs_launch_suppress_list(float* corner, int W, int H, int n, const float* d_list3, hipStream_t stream) {
     if (n <= 0) return CS_OK;

@@ -67,7 +67,6 @@ struct CsFillArgs {
     int* counts;    // user-visible counts[4]
 };
 
-int cs_launch_pyramid(const uint8_t* d_img, const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mode, hipStream_t stream);
 int cs_launch_frame_front(const uint8_t* d_img, const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mode, float* corner_out,
                           float minCornerness, float margin, int* ctr, unsigned long long* gran, int nGran,
                           hipStream_t stream);
@@ -77,8 +76,6 @@ int cs_launch_track_nogain(const cs_texel* pyr0, const cs_texel* pyr1, const CsP
 int cs_launch_track_gain_pass(const CsGainPassArgs& a, hipStream_t stream);
 int cs_launch_reset_beta(float* feat, int N, hipStream_t stream);
 int cs_launch_track_gain_fused(const CsGainFusedArgs& a, hipStream_t stream);
-int cs_launch_cornerness(const cs_texel* lvl0, int W, int H, float minCornerness, float margin, float* out,
-                         hipStream_t stream);
 int cs_launch_suppress_list(float* corner, int W, int H, int n, const float* d_list3, hipStream_t stream);
 int cs_launch_post_track(const float* feat, int N, cs_klt_feature* dest, int* ctr, float* corner, int W, int H,
                          int doSuppress, hipStream_t stream);

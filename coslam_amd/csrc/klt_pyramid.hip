@@ -4,64 +4,20 @@
 // (src/tracking/CGKLT/v3d_gpupyramid.cpp:366-429) and the three Cg passes it schedules
 // (Shaders/pyramid_with_derivative_pass1v.cg:63-83, pass1h.cg:96-128, pass2.cg:6-12).
 //
-// Design: the reference makes 2 + 2(L-1) full-screen passes through an RGBA16F intermediate
-// (8 B/px written and re-read).  Here level 0 is ONE kernel: a u8 tile with a 2-px halo is staged in
-// LDS, the vertical and horizontal 5-tap filters run out of LDS, and each lane stores one 8-byte texel
-// (I,Ix,Iy,0 as binary16) so a wave writes 512 contiguous bytes.  Each coarser level is ONE kernel that
-// applies the vertical and the horizontal [1 3 3 1]/8 with the intermediate binary16 rounding the
-// reference's RGB16F temporary imposes, without ever materialising that temporary in HBM.
-// HBM traffic per frame = W*H bytes in + 8 B per texel out (+ the 4x4 gather of the level above,
-// L1/L2-resident).
+// Design: the reference makes 2 + 2(L-1) full-screen passes through an RGBA16F intermediate (8 B/px written and
+// re-read) and the detector another two for its cornerness map.  Here the frame front end is TWO launches (see the
+// block comment above k_pyr_level0_corner): level 0 together with the cornerness map out of one LDS tile, and levels
+// 1..3 together out of a recomputed dependency cone in LDS; each lane stores one 8-byte texel (I, Ix, Iy, 0 as
+// binary16).  The vertical and horizontal [1 3 3 1]/8 keep the intermediate binary16 rounding the reference's RGB16F
+// temporary imposes, without ever materialising that temporary in HBM.  Levels >= 4 (rare: nLevels 6) take one
+// gather kernel each (k_pyr_down).
 #include "klt_internal.h"
 
 #pragma clang fp contract(off)
 
 namespace {
 
-constexpr int TW = 64;  // tile width  (one wave = one output row segment)
-constexpr int TH = 8;   // tile height
-constexpr int HALO = 2;
-
-__global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ img, int W, int H,
-                                                    cs_texel* __restrict__ out) {
-    __shared__ float g[TH + 2 * HALO][TW + 2 * HALO];  // luminance * 255 (exact integers)
-    __shared__ float v[TH][TW + 2 * HALO];             // vertical [1 2 1]/4
-    __shared__ float dv[TH][TW + 2 * HALO];            // vertical [-1 -2 0 2 1]/8
-
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const int tid = threadIdx.x;
-
-    for (int i = tid; i < (TH + 2 * HALO) * (TW + 2 * HALO); i += 256) {
-        int ly = i / (TW + 2 * HALO), lx = i - ly * (TW + 2 * HALO);
-        int gx = cs_clampi(x0 + lx - HALO, 0, W - 1);  // CLAMP_TO_EDGE, v3d_gpubase.cpp:220-223
-        int gy = cs_clampi(y0 + ly - HALO, 0, H - 1);
-        // LUMINANCE8 -> [0,1] -> *255 as pass1v.cg:79-80 does; exact for every byte value
-        g[ly][lx] = ((float)img[(size_t)gy * W + gx] / 255.0f) * 255.0f;
-    }
-    __syncthreads();
-
-    for (int i = tid; i < TH * (TW + 2 * HALO); i += 256) {
-        int ly = i / (TW + 2 * HALO), lx = i - ly * (TW + 2 * HALO);
-        float g0 = g[ly][lx], g1 = g[ly + 1][lx], g2 = g[ly + 2][lx], g3 = g[ly + 3][lx], g4 = g[ly + 4][lx];
-        v[ly][lx] = ((0.0f * g0 + 0.25f * g1) + 0.5f * g2) + 0.25f * g3;
-        dv[ly][lx] = (((-0.125f * g0 + -0.25f * g1) + 0.0f * g2) + 0.25f * g3) + 0.125f * g4;
-    }
-    __syncthreads();
-
-    const int lx = tid & (TW - 1);
-    const int x = x0 + lx;
-    for (int ly = tid / TW; ly < TH; ly += 256 / TW) {
-        int y = y0 + ly;
-        if (x < W && y < H) {
-            const float* vr = &v[ly][lx];  // vr[2] is the centre
-            const float* dr = &dv[ly][lx];
-            float I = ((0.0f * vr[0] + 0.25f * vr[1]) + 0.5f * vr[2]) + 0.25f * vr[3];
-            float Ix = (((-0.125f * vr[0] + -0.25f * vr[1]) + 0.0f * vr[2]) + 0.25f * vr[3]) + 0.125f * vr[4];
-            float Iy = ((0.0f * dr[0] + 0.25f * dr[1]) + 0.5f * dr[2]) + 0.25f * dr[3];
-            out[(size_t)y * W + x] = cs_pack_texel(I, Ix, Iy);
-        }
-    }
-}
+constexpr int HALO = 2;  // level-0 filters are 5 taps wide
 
 __device__ __forceinline__ int tap_base(int o, int n_dst, int n_src) {
     return (int)(((long long)(2 * o + 1) * n_src) / (2 * (long long)n_dst));
@@ -339,20 +295,6 @@ __global__ __launch_bounds__(256) void k_pyr_down_fused(cs_texel* __restrict__ p
 }
 
 }  // namespace
-
-int cs_launch_pyramid(const uint8_t* d_img, const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mode,
-                      hipStream_t stream) {
-    dim3 g0((lay.W + TW - 1) / TW, (lay.H + TH - 1) / TH);
-    hipLaunchKernelGGL(k_pyr_level0, g0, dim3(256), 0, stream, d_img, lay.W, lay.H, d_pyr + lay.off[0]);
-    for (int l = 1; l < lay.L; ++l) {
-        dim3 g((lay.w[l] + 63) / 64, (lay.h[l] + 3) / 4);
-        hipLaunchKernelGGL(k_pyr_down, g, dim3(256), 0, stream, d_pyr + lay.off[l - 1], lay.w[l - 1], lay.h[l - 1],
-                           d_pyr + lay.off[l], lay.w[l], lay.h[l], tap_mode ? -1 : 0);
-    }
-    CS_CHECK_LAUNCH();
-    return CS_OK;
-}
-
 
 // pyramid (+ cornerness map, + zeroing of the frame's counters and hand-off granules) in two launches
 int cs_launch_frame_front(const uint8_t* d_img, const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mode, float* corner_out,

@@ -686,7 +686,8 @@ int cs_klt_advance(cs_klt* k) {  // v3d_gpuklt.h:252-259
 }
 
 // ---- device-resident entry points ----------------------------------------------------------------
-// The frame schedule is ~60 short kernels; replayed from a hipGraph the host cost per frame is one launch.
+// The frame schedule is five launches (klt_pyramid.hip x2, klt_track.hip, klt_detect.hip x2); it can be issued
+// eagerly (default) or replayed from a hipGraph (cs_klt_enable_graphs; one host launch per frame).
 // The three feature buffers and two pyramids rotate from call to call (period <= 6), so the cache is keyed by
 // the rotation state; the graph reads the image from the handle's own staging buffer.
 static int run_dev(cs_klt* k, int mode, const void* d_image, void* d_dest, void* d_counts) {

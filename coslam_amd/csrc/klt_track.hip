@@ -11,10 +11,12 @@
 // same sums and redundantly solves the 2x2 / 3x3 system, so no LDS round trip and no divergence.
 //   - no gain: all levels and all iterations run inside one launch; the frame-0 samples (which do not
 //     depend on the iterate) are fetched once per level and kept in registers.
-//   - with gain: one Gauss-Newton step per launch, exactly the reference's Jacobi schedule, because
-//     every step reads the neighbours' gains of the previous step (klt_tracker_with_gain.cg:64-75).
-//     A dependent kernel boundary (~1.5 us) is cheaper on MI355X than an in-kernel grid barrier
-//     (~4 us, MI355X_MICROARCH "barrier-xcd"), so the steps stay separate launches.
+//   - with gain: every Gauss-Newton step reads the neighbours' gains of the previous step
+//     (klt_tracker_with_gain.cg:64-75), which the reference honours with one launch per step.  The default here is
+//     ONE persistent launch (k_track_gain_fused): every feature's wave stays resident, neighbours hand their gain
+//     over through 8-byte tagged granules, the frame-1 footprint lives in a wave-private LDS patch; the
+//     launch-per-step schedule (k_track_gain_pass) is kept as the fallback when the grid cannot be co-resident and
+//     as the reference the persistent kernel must match bit for bit.
 #include "klt_internal.h"
 
 #pragma clang fp contract(off)
