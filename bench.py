@@ -167,12 +167,21 @@ def main():
         side_cus = 0
     masked = {"ok": side_cus > 0}
 
-    def make_stream(first, count):
+    # BENCH_SIDE_MODE=range (default): the last `side_cus` CUs (whole XCDs) go to the side streams -- measured 5330
+    # frames/s; =interleaved: every (n_cus/side_cus)-th CU (the tracker alone stays at 91 us, the loop drops to 4810)
+    side_mode = os.environ.get("BENCH_SIDE_MODE", "range")
+
+    def make_stream(side):
         if masked["ok"]:
             try:
                 L = coslam_amd.lib()
-                L.cs_stream_create_cu_range.restype = C.c_void_p
-                h = L.cs_stream_create_cu_range(local_rank, first, count)
+                if side_mode == "interleaved":
+                    L.cs_stream_create_cu_interleaved.restype = C.c_void_p
+                    h = L.cs_stream_create_cu_interleaved(local_rank, n_cus // side_cus, 1, 0 if side else 1)
+                else:
+                    L.cs_stream_create_cu_range.restype = C.c_void_p
+                    h = (L.cs_stream_create_cu_range(local_rank, n_cus - side_cus, side_cus) if side
+                         else L.cs_stream_create_cu_range(local_rank, 0, n_cus - side_cus))
                 if h:
                     return torch.cuda.ExternalStream(h, device=dev)
                 print("bench: CU-masked stream unavailable (" + L.cs_last_error().decode() + "); plain streams",
@@ -182,9 +191,9 @@ def main():
             masked["ok"] = False
         return torch.cuda.Stream(device=dev)
 
-    klt_torch_stream = make_stream(0, n_cus - side_cus)
-    pose_torch_stream = klt_torch_stream if args.serial else make_stream(n_cus - side_cus, side_cus)
-    ba_torch_stream = klt_torch_stream if (args.sync_ba or args.serial) else make_stream(n_cus - side_cus, side_cus)
+    klt_torch_stream = make_stream(False)
+    pose_torch_stream = klt_torch_stream if args.serial else make_stream(True)
+    ba_torch_stream = klt_torch_stream if (args.sync_ba or args.serial) else make_stream(True)
     if not masked["ok"]:
         side_cus = 0
     stream = klt_torch_stream.cuda_stream
@@ -336,8 +345,8 @@ def main():
                        "cameras": n_gpus, "live_features_last_frame": n_live, "pose_ok": pose_ok,
                        "hip_graphs": bool(args.graphs and not args.no_graphs),
                        "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
-                       "cu_partition": (f"tracker stream on {n_cus - side_cus} CUs, pose / BA streams on {side_cus} CUs"
-                                        if side_cus > 0 else "none"),
+                       "cu_partition": (f"tracker stream on {n_cus - side_cus} CUs, pose / BA streams on {side_cus} CUs "
+                                        f"({side_mode})" if side_cus > 0 else "none"),
                        "streams": "one stream (--serial)" if args.serial else
                        "tracker | pose (event-ordered behind the tracker of the same frame) | local BA "
                        "(own stream, like the reference's BA worker thread)"},

@@ -57,6 +57,39 @@ void* cs_stream_create_cu_range(int device, int first_cu, int n_cus) {
     return (void*)s;
 }
 
+// Interleaved partition: the CUs whose index modulo `period` is (complement == 0) / is not (complement != 0) in
+// [0, take).  Consecutive CU indices sit in the same shader engine / XCD, so an interleaved side partition leaves every
+// XCD a few CUs short instead of removing whole XCDs: measured, the local BA runs as fast on 16 interleaved CUs as on
+// the whole chip (760 vs 742 us) but 938 us on 32 contiguous ones.
+void* cs_stream_create_cu_interleaved(int device, int period, int take, int complement) {
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        cs_set_error("cs_stream_create_cu_interleaved: bad device %d", device);
+        return nullptr;
+    }
+    const int total = prop.multiProcessorCount;
+    if (period <= 1 || take <= 0 || take >= period) {
+        cs_set_error("cs_stream_create_cu_interleaved: need 0 < take < period");
+        return nullptr;
+    }
+    std::vector<uint32_t> mask((total + 31) / 32, 0u);
+    int n = 0;
+    for (int c = 0; c < total; ++c) {
+        const bool in = (c % period) < take;
+        if (in != (complement != 0)) {
+            mask[c >> 5] |= 1u << (c & 31);
+            ++n;
+        }
+    }
+    hipStream_t s = nullptr;
+    hipError_t e = (n > 0) ? hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) : hipErrorInvalidValue;
+    if (e != hipSuccess) {
+        cs_set_error("hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    return (void*)s;
+}
+
 int cs_stream_destroy(void* stream) {
     if (stream) CS_HIP(hipStreamDestroy((hipStream_t)stream));
     return CS_OK;

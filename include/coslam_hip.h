@@ -115,6 +115,8 @@ int cs_klt_set_cu_count(cs_klt* k, int n_cus);
 /* a stream confined to the compute units [first_cu, first_cu + n_cus): keeps pose / BA kernels off the SIMDs of the
  * lock-stepped persistent tracker; returns a hipStream_t (null on error) */
 void* cs_stream_create_cu_range(int device, int first_cu, int n_cus);
+/* interleaved partition: CUs with (index % period) < take, or (complement != 0) all the others */
+void* cs_stream_create_cu_interleaved(int device, int period, int take, int complement);
 int cs_stream_destroy(void* stream);
 /* diagnostic only: per-slot cycle counters (8 x uint64) of the persistent gain tracker; see klt_seq.hip */
 int cs_klt_debug_probe(cs_klt* k, int on, unsigned long long* host_out8);
