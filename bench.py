@@ -121,6 +121,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks for exercising the N > 1 code path on a box with ONE GPU: BENCH_FORCE_DEVICE pins every rank to that
+    # device, BENCH_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU).  Never set by the driver.
+    if os.environ.get("BENCH_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["BENCH_FORCE_DEVICE"])
+    dist_backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -130,7 +135,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(dist_backend, rank=rank, world_size=world)
 
     sc, frames, Ms, ms, R0, t0, ba = build_inputs(rank, n_gpus, seed=0xC051A + 2)
     order = frame_order(N_FRAMES)
