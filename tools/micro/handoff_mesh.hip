@@ -197,13 +197,92 @@ static void run2(const char* name, int work, int stride, int fw = 50, int fh = 4
     hipFree(sink);
 }
 
-int main() {
-    // calibrate the filler: one wave-pass of pure work
-    for (int work : {0, 50, 100, 150, 200, 250}) {
-        for (int stride : {1, 64}) run2<0>("pull", work, stride, 50, 40, 40, 60);
-        for (int stride : {1, 8}) run2<1>("push", work, stride, 50, 40, 40, 60);
+// hierarchical pull: a workgroup = 4 waves = 4 consecutive slots of a row; ONE wave polls the 14 external neighbours of
+// the strip (3 rows x 6 columns minus the strip) and hands them to its mates through LDS; mates' own values go through
+// LDS too.  Chip-wide pollers: N/4 instead of N.
+__global__ __launch_bounds__(256) void k_mesh_hier(u64* gran, int fw, int fh, int N, int passes, int work, int* err,
+                                                  float* sink, int post) {
+    __shared__ volatile unsigned extTag;            // pass number whose external neighbours are complete in LDS
+    __shared__ volatile unsigned ownTag[2][4];      // [parity][wave]: tag of the mates' published value
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int k = blockIdx.x * 4 + wv;
+    const bool live = k < N;
+    u64* g0 = gran;
+    u64* g1 = gran + N;
+    if (threadIdx.x == 0) extTag = 0;
+    if (lane == 0) { ownTag[0][wv] = 1; ownTag[1][wv] = 0; }
+    if (live && lane == 0) publish<PUB_SC1>(g0 + k, 1u, 1u);
+    __syncthreads();
+    // external neighbour list of the strip (wave 0 polls): rows sj-1..sj+1, cols si0-1..si0+4, outside the strip, inside the grid
+    const int k0 = blockIdx.x * 4, si0 = k0 % fw, sj = k0 / fw;
+    int nb = -1;
+    if (wv == 0 && lane < 18) {
+        const int r = lane / 6, c = lane % 6;
+        const int x = si0 - 1 + c, y = sj - 1 + r;
+        const bool inStrip = (r == 1 && c >= 1 && c <= 4);
+        if (!inStrip && x >= 0 && x < fw && y >= 0 && y < fh && (y * fw + x) < N) nb = y * fw + x;
     }
-    run2<0>("pull 2x1 (filler cost)", 250, 1, 2, 1, 40, 60);
-    run2<0>("pull 2x1 (filler cost)", 0, 1, 2, 1, 40, 0);
+    float acc = (float)k;
+    for (unsigned pass = 1; pass <= (unsigned)passes; ++pass) {
+        for (int w = 0; w < work; ++w) acc = acc * 1.0001f + 0.5f;
+        const u64* src = ((pass - 1) & 1u) ? g1 : g0;
+        unsigned spins = 0;
+        if (wv == 0) {
+            for (;;) {
+                u64 got = (nb >= 0) ? poll<POLL_SC1>(src + nb) : ((u64)pass << 32);
+                if (__all((unsigned)(got >> 32) >= pass)) break;
+                if (++spins > (1u << 18)) { if (lane == 0) atomicExch(err, 1); break; }
+            }
+            if (lane == 0) extTag = pass;
+        } else {
+            while (extTag < pass) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 20)) { if (lane == 0) atomicExch(err, 2); break; }
+            }
+        }
+        // mates' values of the previous pass (LDS)
+        for (int m = 0; m < 4; ++m) {
+            while (ownTag[(pass - 1) & 1u][m] < pass) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 20)) { if (lane == 0) atomicExch(err, 3); break; }
+            }
+        }
+        for (int w = 0; w < post; ++w) acc = acc * 1.0001f + 0.5f;
+        if (lane == 0) {
+            if (live) publish<PUB_SC1>(((pass & 1u) ? g1 : g0) + k, pass + 1u, (unsigned)pass);
+            ownTag[pass & 1u][wv] = pass + 1u;
+        }
+    }
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
+static void run_hier(int work, int post, int fw = 50, int fh = 40, int passes = 40) {
+    const int N = fw * fh;
+    u64* gran; int* err; float* sink;
+    hipMalloc(&gran, sizeof(u64) * 2 * N); hipMalloc(&err, 4); hipMalloc(&sink, 4); hipMemset(err, 0, 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9, sum = 0; const int reps = 20;
+    for (int r = 0; r < reps + 3; ++r) {
+        hipMemsetAsync(gran, 0, sizeof(u64) * 2 * N, 0);
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_mesh_hier, dim3((N + 3) / 4), dim3(256), 0, 0, gran, fw, fh, N, passes, work, err, sink, post);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (r >= 3) { sum += ms; best = ms < best ? ms : best; }
+    }
+    int herr = 0; hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost);
+    printf("post=%d hierarchical (1 poller / 4 waves)   work=%4d grid=%dx%d: avg %.2f us/pass (best %.2f)%s\n", post, work, fw, fh,
+           sum / reps * 1e3 / passes, best * 1e3 / passes, herr ? "  TIMEOUT/ERR" : "");
+    hipFree(gran); hipFree(err); hipFree(sink);
+}
+
+int main() {
+    for (int work : {0, 50, 75}) {
+        const int post = work ? 20 : 0;
+        run2<0>("pull", work, 1, 50, 40, 40, post);
+        run_hier(work, post);
+    }
+    run2<0>("pull 16x16", 0, 1, 16, 16, 40, 0);
+    run_hier(0, 0, 16, 16);
     return 0;
 }
