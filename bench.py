@@ -200,7 +200,15 @@ def main():
         return torch.cuda.Stream(device=dev)
 
     klt_torch_stream = make_stream(False)
-    pose_torch_stream = klt_torch_stream if args.serial else make_stream(True)
+    # pose: one wave, 80 us.  On the tracker's partition it costs the loop less than next to the BA's launch chain
+    # (5670 vs 5375 frames/s measured); BENCH_POSE_PART=side|klt|all
+    pose_part = os.environ.get("BENCH_POSE_PART", "klt")
+    if args.serial:
+        pose_torch_stream = klt_torch_stream
+    elif pose_part == "all":
+        pose_torch_stream = torch.cuda.Stream(device=dev)
+    else:
+        pose_torch_stream = make_stream(pose_part == "side")
     ba_torch_stream = klt_torch_stream if (args.sync_ba or args.serial) else make_stream(True)
     if not masked["ok"]:
         side_cus = 0
@@ -353,8 +361,8 @@ def main():
                        "cameras": n_gpus, "live_features_last_frame": n_live, "pose_ok": pose_ok,
                        "hip_graphs": bool(args.graphs and not args.no_graphs),
                        "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
-                       "cu_partition": (f"tracker stream on {n_cus - side_cus} CUs, pose / BA streams on {side_cus} CUs "
-                                        f"({side_mode})" if side_cus > 0 else "none"),
+                       "cu_partition": (f"tracker stream on {n_cus - side_cus} CUs, BA stream on {side_cus} CUs ({side_mode}), "
+                                        f"pose stream: {pose_part}" if side_cus > 0 else "none"),
                        "streams": "one stream (--serial)" if args.serial else
                        "tracker | pose (event-ordered behind the tracker of the same frame) | local BA "
                        "(own stream, like the reference's BA worker thread)"},
