@@ -316,3 +316,55 @@ def test_persistent_gain_tracker_is_bit_identical_to_per_pass_launches(hip, leve
         live = d0["status"] >= 0
         assert np.array_equal(d0["pos"][live], d1["pos"][live]) and np.array_equal(d0["gain"][live], d1["gain"][live])
         assert np.array_equal(f0, f1)
+
+
+def test_persistent_gain_tracker_under_uneven_foreign_load(hip):
+    """The granule hand-off must not depend on timing or placement: with other streams hammering the chip (large
+    GEMMs, copies, many tiny launches: uneven load, L1-warm consumers) every frame of the persistent tracker must still
+    be bit-identical to the per-pass schedule run on a quiet chip."""
+    import torch
+
+    W, H, L, grid = 640, 480, 4, (50, 40)
+    sc = Scene(1, W, H, 6000, seed=77)
+    cfg = cfg2()
+    frames = [sc.render(0, f) for f in range(9)]
+
+    def run(fused, load):
+        t = coslam_amd.KLT_SequenceTracker(cfg, 0)
+        t.allocate(W, H, L, *grid)
+        t.set_fused(fused)
+        t.detect(frames[0])
+        t.advanceFrame()
+        dev = torch.device("cuda:0")
+        bg = [torch.cuda.Stream(device=dev) for _ in range(3)] if load else []
+        A = torch.randn(2048, 2048, device=dev) if load else None
+        x = torch.zeros(1 << 22, device=dev) if load else None
+        y = torch.zeros(4096, device=dev) if load else None
+        out = []
+        for f in range(1, 9):
+            if load:  # keep the background queues full while the tracker frame runs
+                with torch.cuda.stream(bg[0]):
+                    for _ in range(6):
+                        A @ A
+                with torch.cuda.stream(bg[1]):
+                    for _ in range(8):
+                        x.add_(1.0)
+                with torch.cuda.stream(bg[2]):
+                    for _ in range(200):
+                        y.mul_(1.0)
+            n, d = t.redetect(frames[f])
+            out.append((n, d.copy(), t.read_features().copy()))
+            t.advanceFrame()
+        if load:
+            torch.cuda.synchronize()
+        t.close()
+        return out
+
+    quiet = run(0, False)
+    loaded = run(1, True)
+    for (n0, d0, f0), (n1, d1, f1) in zip(quiet, loaded):
+        assert n0 == n1
+        assert np.array_equal(d0["status"], d1["status"])
+        live = d0["status"] >= 0
+        assert np.array_equal(d0["pos"][live], d1["pos"][live]) and np.array_equal(d0["gain"][live], d1["gain"][live])
+        assert np.array_equal(f0, f1)
