@@ -64,51 +64,6 @@ struct BaDev {
 
 __device__ __forceinline__ double wsum(double v) { return cs_wave_sum_d(v); }
 
-// ---- many sums at once: transposed butterfly ----------------------------------------------------------------------
-// Folding N per-lane values with N independent 64-lane butterflies costs 6 N exchange steps; here every exchange step
-// halves the number of values a lane still carries (the lower lane of a pair keeps the first half of the list, the
-// upper lane the second half), so N values need N/2 + N/4 + ... ~ N exchanges in total and each total ends up in ONE
-// lane: value q in lane wave_reduce_owner(q).  Fixed tree, deterministic.
-__device__ __forceinline__ double shfl_xor_d(double v, int d) {
-    int lo = __shfl_xor(__double2loint(v), d, 64), hi = __shfl_xor(__double2hiint(v), d, 64);
-    return __hiloint2double(hi, lo);
-}
-template <int M, int DIST>
-__device__ __forceinline__ void wave_reduce_step(double* v, int lane) {
-    if constexpr (DIST >= 1) {
-        constexpr int H = (M + 1) / 2;
-        const bool up = (lane & DIST) != 0;
-#pragma unroll
-        for (int t = 0; t < H; ++t) {
-            const double lo = v[t];
-            const double hi = (H + t < M) ? v[H + t] : 0.0;
-            const double recv = shfl_xor_d(up ? lo : hi, DIST);
-            v[t] = (up ? hi : lo) + recv;
-        }
-        wave_reduce_step<H, DIST / 2>(v, lane);
-    }
-}
-// after the call v[0] of lane l holds the total of value wave_reduce_index<N>(l) (or -1: the lane holds nothing)
-template <int N>
-__device__ __forceinline__ void wave_reduce_many(double* v, int lane) {
-    wave_reduce_step<N, 32>(v, lane);
-}
-template <int N>
-__device__ __forceinline__ int wave_reduce_index(int lane) {
-    int lo = 0, end = N, m = N;  // the lane's slot list covers [lo, lo + m); indices >= end are zero padding
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int h = (m + 1) / 2;
-        if (lane & d) {
-            lo += h;
-        } else {
-            end = min(end, lo + h);
-        }
-        m = h;
-    }
-    return lo < end ? lo : -1;
-}
-
 __device__ __forceinline__ void so3_exp(const double w[3], double R[9]) {
     double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
     if (th == 0) {
@@ -255,8 +210,7 @@ __global__ __launch_bounds__(256) void k_linearize(BaDev D) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) Wo[3 * r + c] = w ? (Jc[r] * Jp[c] + Jc[6 + r] * Jp[3 + c]) : 0.0;
     }
-#pragma unroll
-    for (int q = 0; q < 9; ++q) acc[q] = wsum(acc[q]);
+    cs_wave_sum_many_d<9>(acc);
     if (lane == 0) {
         double Vi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (freeP) {
@@ -422,9 +376,9 @@ __global__ __launch_bounds__(64) void k_schur_part(BaDev D) {
             }
         }
     }
-    wave_reduce_many<42>(acc, lane);
+    cs_reduce_many<42>(acc, lane);
     {
-        const int q = wave_reduce_index<42>(lane);
+        const int q = cs_reduce_index<42>(lane);
         if (q >= 0) out[q] = acc[0];
     }
     if (ja == jb) {  // U_j = sum Jc^T Jc and g_j = sum Jc^T e over this slice of the camera's own measurement list
@@ -447,8 +401,8 @@ __global__ __launch_bounds__(64) void k_schur_part(BaDev D) {
 #pragma unroll
             for (int r = 0; r < 6; ++r) u[21 + r] += J[r] * e0 + J[6 + r] * e1;
         }
-        wave_reduce_many<27>(u, lane);
-        const int q = wave_reduce_index<27>(lane);
+        cs_reduce_many<27>(u, lane);
+        const int q = cs_reduce_index<27>(lane);
         if (q >= 0) out[42 + q] = u[0];
     }
 }

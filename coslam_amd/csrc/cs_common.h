@@ -138,4 +138,82 @@ __device__ __forceinline__ int cs_wave_sum_i(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// ---- many sums at once: transposed butterfly ----------------------------------------------------------------------
+// Folding N per-lane values with N independent 64-lane butterflies costs 6 N exchange steps; here every exchange step
+// halves the number of values a lane still carries (the lower lane of a pair keeps the first half of the list, the
+// upper lane the second half), so N values need N/2 + N/4 + ... ~ N exchanges in total and each total ends up in ONE
+// lane: value q in lane cs_reduce_owner<N>(q).  Fixed tree, deterministic.
+__device__ __forceinline__ double cs_shfl_xor_d(double v, int d) {
+    int lo = __shfl_xor(__double2loint(v), d, 64), hi = __shfl_xor(__double2hiint(v), d, 64);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double cs_readlane_d(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+template <int M, int DIST>
+__device__ __forceinline__ void cs_reduce_step(double* v, int lane) {
+    if constexpr (DIST >= 1) {
+        constexpr int H = (M + 1) / 2;
+        const bool up = (lane & DIST) != 0;
+#pragma unroll
+        for (int t = 0; t < H; ++t) {
+            const double lo = v[t];
+            const double hi = (H + t < M) ? v[H + t] : 0.0;
+            const double recv = cs_shfl_xor_d(up ? lo : hi, DIST);
+            v[t] = (up ? hi : lo) + recv;
+        }
+        cs_reduce_step<H, DIST / 2>(v, lane);
+    }
+}
+// after the call v[0] of lane l holds the total of value cs_reduce_index<N>(l) (or -1: the lane holds nothing)
+template <int N>
+__device__ __forceinline__ void cs_reduce_many(double* v, int lane) {
+    cs_reduce_step<N, 32>(v, lane);
+}
+template <int N>
+__host__ __device__ constexpr int cs_reduce_index(int lane) {
+    int lo = 0, end = N, m = N;  // the lane's slot list covers [lo, lo + m); indices >= end are zero padding
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int h = (m + 1) / 2;
+        if (lane & d) {
+            lo += h;
+        } else {
+            end = end < lo + h ? end : lo + h;
+        }
+        m = h;
+    }
+    return lo < end ? lo : -1;
+}
+template <int N>
+__host__ __device__ constexpr int cs_reduce_owner(int q) {  // the lane that ends up with the total of value q
+    for (int l = 0; l < 64; ++l)
+        if (cs_reduce_index<N>(l) == q) return l;
+    return 0;
+}
+// all N totals in every lane: transposed butterfly, then one v_readlane pair per value from its (constant) owner lane
+template <int N>
+struct CsOwnerTable {
+    int lane[N];
+    constexpr CsOwnerTable() : lane{} {
+        for (int q = 0; q < N; ++q) lane[q] = cs_reduce_owner<N>(q);
+    }
+};
+template <int N, int Q>
+__device__ __forceinline__ void cs_bcast_totals(double tot, double (&v)[N]) {
+    if constexpr (Q < N) {
+        constexpr CsOwnerTable<N> T{};
+        v[Q] = cs_readlane_d(tot, T.lane[Q]);  // compile-time lane: a plain v_readlane pair
+        cs_bcast_totals<N, Q + 1>(tot, v);
+    }
+}
+template <int N>
+__device__ __forceinline__ void cs_wave_sum_many_d(double (&v)[N]) {
+    const int lane = threadIdx.x & 63;
+    cs_reduce_many<N>(v, lane);
+    const double tot = v[0];
+    cs_bcast_totals<N, 0>(tot, v);
+}
+
 #endif  // __HIPCC__
