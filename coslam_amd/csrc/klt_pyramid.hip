@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(const cs_texel* __restrict__ s
 //                         recomputes the (one-sided, 2-texel) dependency cone below it in LDS.
 // Arithmetic, operation order and the fp16 roundings are those of k_pyr_level0 / k_pyr_down / k_cornerness:
 // results are bit-identical to the separate kernels.
-constexpr int FTW = 64, FTH = 16;
+constexpr int FTW = 64, FTH = 8;
 
 template <bool CORNER>
 __global__ __launch_bounds__(256) void k_pyr_level0_corner(const uint8_t* __restrict__ img, int W, int H,
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_pyr_level0_corner(const uint8_t* __rest
 }
 
 // ---- levels 1..NL (NL <= 3) in one launch -----------------------------------------------------------------
-constexpr int DTW = 8, DTH = 4;  // tile of the coarsest fused level owned by a block
+constexpr int DTW = 4, DTH = 4;  // tile of the coarsest fused level owned by a block
 
 struct CsDownFused {
     int NL;            // destination levels 1..NL
