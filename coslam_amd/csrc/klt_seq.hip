@@ -136,6 +136,7 @@ struct cs_klt {
     cs_klt_feature* h_dest;  // pinned
     int* h_counts;           // pinned
     float* h_feat;           // pinned
+    uint8_t* h_img;          // pinned staging for the host-pointer entry points (a pageable source is staged by the runtime, ~3x slower)
     // HIP-event timing of the tracker stage (bench.py roofline leg): eager launches only
     bool profiling;
     hipEvent_t ev0, ev1;
@@ -418,16 +419,20 @@ static int check_device_error(cs_klt* k) {
 }
 
 static int fetch_results(cs_klt* k, int* count, cs_klt_feature* dest) {
-    CS_HIP(hipMemcpyAsync(k->h_dest, k->d_dest, sizeof(cs_klt_feature) * k->N, hipMemcpyDeviceToHost, k->stream));
-    CS_HIP(hipMemcpyAsync(k->h_counts, k->d_counts, 4 * sizeof(int), hipMemcpyDeviceToHost, k->stream));
+    // dest[], the counts and the persistent tracker's error word come back in ONE copy behind one synchronisation
+    CS_HIP(hipMemcpyAsync(k->h_dest, k->d_dest, sizeof(cs_klt_feature) * k->N + 8 * sizeof(int), hipMemcpyDeviceToHost,
+                          k->stream));
     CS_HIP(hipStreamSynchronize(k->stream));
     memcpy(dest, k->h_dest, sizeof(cs_klt_feature) * k->N);
-    *count = k->h_counts[0];
-    return check_device_error(k);
+    const int* tail = (const int*)(k->h_dest + k->N);
+    *count = tail[0];
+    if (tail[4]) return check_device_error(k);
+    return CS_OK;
 }
 
 static int upload_image(cs_klt* k, const uint8_t* image) {
-    CS_HIP(hipMemcpyAsync(k->d_img, image, (size_t)k->W * k->H, hipMemcpyHostToDevice, k->stream));
+    memcpy(k->h_img, image, (size_t)k->W * k->H);
+    CS_HIP(hipMemcpyAsync(k->d_img, k->h_img, (size_t)k->W * k->H, hipMemcpyHostToDevice, k->stream));
     return CS_OK;
 }
 
@@ -486,10 +491,8 @@ int cs_klt_deallocate(cs_klt* k) {
     hipFree(k->d_rank);
     hipFree(k->d_ctr);
     hipFree(k->d_dest);
-    hipFree(k->d_counts);
     hipFree(k->d_present);
     hipFree(k->d_gran);
-    hipFree(k->d_err);
     if (k->d_probe) hipFree(k->d_probe);
     k->d_probe = nullptr;
     {
@@ -499,6 +502,7 @@ int cs_klt_deallocate(cs_klt* k) {
     hipHostFree(k->h_dest);
     hipHostFree(k->h_counts);
     hipHostFree(k->h_feat);
+    hipHostFree(k->h_img);
     k->allocated = false;
     return CS_OK;
 }
@@ -573,15 +577,17 @@ int cs_klt_allocate(cs_klt* k, int W, int H, int nLevels, int fw, int fh, int pl
     CS_HIP(hipMalloc((void**)&k->d_sel, sizeof(CsCand) * k->maxCand));
     CS_HIP(hipMalloc((void**)&k->d_rank, sizeof(int) * k->maxCand));
     CS_HIP(hipMalloc((void**)&k->d_ctr, sizeof(int) * 8));
-    CS_HIP(hipMalloc((void**)&k->d_dest, sizeof(cs_klt_feature) * k->N));
-    CS_HIP(hipMalloc((void**)&k->d_counts, sizeof(int) * 4));
+    // dest[] || counts[4] || error word in ONE allocation: the host-pointer entry points read all of it back with one copy
+    CS_HIP(hipMalloc((void**)&k->d_dest, sizeof(cs_klt_feature) * k->N + 8 * sizeof(int)));
+    k->d_counts = (int*)(k->d_dest + k->N);
+    k->d_err = k->d_counts + 4;
     CS_HIP(hipMalloc((void**)&k->d_present, sizeof(float) * 3 * k->presentCap));
     CS_HIP(hipMalloc((void**)&k->d_gran, sizeof(unsigned long long) * 2 * k->N));
-    CS_HIP(hipMalloc((void**)&k->d_err, sizeof(int)));
     CS_HIP(hipMemsetAsync(k->d_err, 0, sizeof(int), k->stream));
-    CS_HIP(hipHostMalloc((void**)&k->h_dest, sizeof(cs_klt_feature) * k->N, hipHostMallocDefault));
-    CS_HIP(hipHostMalloc((void**)&k->h_counts, sizeof(int) * 4, hipHostMallocDefault));
+    CS_HIP(hipHostMalloc((void**)&k->h_dest, sizeof(cs_klt_feature) * k->N + 8 * sizeof(int), hipHostMallocDefault));
+    CS_HIP(hipHostMalloc((void**)&k->h_counts, sizeof(int) * 8, hipHostMallocDefault));
     CS_HIP(hipHostMalloc((void**)&k->h_feat, sizeof(float) * 3 * k->presentCap, hipHostMallocDefault));
+    CS_HIP(hipHostMalloc((void**)&k->h_img, (size_t)W * H, hipHostMallocDefault));
     // RTT buffers start undefined in the reference; we define every slot dead
     for (int i = 0; i < 3 * k->N; ++i) k->h_feat[i] = -1.0f;
     for (int i = 0; i < 3; ++i) {
