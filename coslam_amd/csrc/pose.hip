@@ -361,15 +361,19 @@ __global__ __launch_bounds__(PB) void k_intracam(int ptsStride, const double* __
     }
 }
 
+// Host-pointer entry point: every input in ONE pinned staging block / one device block / one H2D copy, every output
+// in one block and one D2H copy behind a single synchronisation (a dozen small pageable copies cost more than the
+// solve itself).  Layout in doubles: in  = K 9 | R0 9 | t0 3 | opt 12 | npts (as int) 1 | Ms 3n | ms 2n | prev n
+//                                    out = Ropt 9 | topt 3 | opt 12 | ok (as int) 1
 struct PoseScratch {
     int device = -1;
     size_t cap = 0;  // points
-    double *d_K = nullptr, *d_R0 = nullptr, *d_t0 = nullptr, *d_Ms = nullptr, *d_ms = nullptr, *d_prev = nullptr,
-           *d_Ropt = nullptr, *d_topt = nullptr, *d_ws = nullptr;
-    int *d_npts = nullptr, *d_ok = nullptr;
-    cs_pose_option* d_opt = nullptr;
+    double *d_in = nullptr, *d_out = nullptr, *d_ws = nullptr;
+    double *h_in = nullptr, *h_out = nullptr;  // pinned
     hipStream_t stream = nullptr;
 };
+constexpr size_t PS_IN_HEAD = 9 + 9 + 3 + 12 + 1, PS_OUT = 9 + 3 + 12 + 1;
+static_assert(sizeof(cs_pose_option) == 96, "cs_pose_option is 12 doubles");
 thread_local PoseScratch g_ps;
 
 int ensure_scratch(int device, size_t npts) {
@@ -379,27 +383,19 @@ int ensure_scratch(int device, size_t npts) {
         s = PoseScratch();
         s.device = device;
         CS_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        CS_HIP(hipMalloc((void**)&s.d_K, 9 * 8));
-        CS_HIP(hipMalloc((void**)&s.d_R0, 9 * 8));
-        CS_HIP(hipMalloc((void**)&s.d_t0, 3 * 8));
-        CS_HIP(hipMalloc((void**)&s.d_Ropt, 9 * 8));
-        CS_HIP(hipMalloc((void**)&s.d_topt, 3 * 8));
-        CS_HIP(hipMalloc((void**)&s.d_npts, 4));
-        CS_HIP(hipMalloc((void**)&s.d_ok, 4));
-        CS_HIP(hipMalloc((void**)&s.d_opt, sizeof(cs_pose_option)));
+        CS_HIP(hipMalloc((void**)&s.d_out, PS_OUT * 8));
+        CS_HIP(hipHostMalloc((void**)&s.h_out, PS_OUT * 8, hipHostMallocDefault));
     }
-    if (npts > s.cap) {
+    if (npts > s.cap || !s.d_in) {
         size_t cap = npts < 1024 ? 1024 : npts;
-        if (s.d_Ms) {
-            (void)hipFree(s.d_Ms);
-            (void)hipFree(s.d_ms);
-            (void)hipFree(s.d_prev);
+        if (s.d_in) {
+            (void)hipFree(s.d_in);
             (void)hipFree(s.d_ws);
+            (void)hipHostFree(s.h_in);
         }
-        CS_HIP(hipMalloc((void**)&s.d_Ms, cap * 24));
-        CS_HIP(hipMalloc((void**)&s.d_ms, cap * 16));
-        CS_HIP(hipMalloc((void**)&s.d_prev, cap * 8));
+        CS_HIP(hipMalloc((void**)&s.d_in, (PS_IN_HEAD + 6 * cap) * 8));
         CS_HIP(hipMalloc((void**)&s.d_ws, cap * 8));
+        CS_HIP(hipHostMalloc((void**)&s.h_in, (PS_IN_HEAD + 6 * cap) * 8, hipHostMallocDefault));
         s.cap = cap;
     }
     return CS_OK;
@@ -450,26 +446,34 @@ int cs_pose_intracam(const double K[9], const double R0[9], const double t0[3], 
     int rc = ensure_scratch(device, (size_t)npts);
     if (rc) return rc;
     PoseScratch& s = g_ps;
-    CS_HIP(hipMemcpyAsync(s.d_K, K, 72, hipMemcpyHostToDevice, s.stream));
-    CS_HIP(hipMemcpyAsync(s.d_R0, R0, 72, hipMemcpyHostToDevice, s.stream));
-    CS_HIP(hipMemcpyAsync(s.d_t0, t0, 24, hipMemcpyHostToDevice, s.stream));
-    CS_HIP(hipMemcpyAsync(s.d_npts, &npts, 4, hipMemcpyHostToDevice, s.stream));
-    CS_HIP(hipMemcpyAsync(s.d_opt, opt, sizeof(*opt), hipMemcpyHostToDevice, s.stream));
+    const size_t np = (size_t)npts;
+    double* h = s.h_in;
+    memcpy(h, K, 72);
+    memcpy(h + 9, R0, 72);
+    memcpy(h + 18, t0, 24);
+    memcpy(h + 21, opt, sizeof(*opt));
+    memcpy(h + 33, &npts, sizeof(int));
     if (npts > 0) {
-        CS_HIP(hipMemcpyAsync(s.d_Ms, Ms, (size_t)npts * 24, hipMemcpyHostToDevice, s.stream));
-        CS_HIP(hipMemcpyAsync(s.d_ms, ms, (size_t)npts * 16, hipMemcpyHostToDevice, s.stream));
-        if (prevErrs) CS_HIP(hipMemcpyAsync(s.d_prev, prevErrs, (size_t)npts * 8, hipMemcpyHostToDevice, s.stream));
+        memcpy(h + PS_IN_HEAD, Ms, np * 24);
+        memcpy(h + PS_IN_HEAD + 3 * np, ms, np * 16);
+        if (prevErrs) memcpy(h + PS_IN_HEAD + 5 * np, prevErrs, np * 8);
     }
+    const size_t inDoubles = PS_IN_HEAD + (prevErrs ? 6 : 5) * np;
+    CS_HIP(hipMemcpyAsync(s.d_in, h, inDoubles * 8, hipMemcpyHostToDevice, s.stream));
+    CS_HIP(hipMemcpyAsync(s.d_out + 12, s.d_in + 21, sizeof(*opt), hipMemcpyDeviceToDevice, s.stream));  // opt is in/out
     const int stride = npts > 0 ? npts : 1;
-    rc = launch_intracam(s.stream, 1, stride, s.d_K, s.d_R0, s.d_t0, s.d_npts, prevErrs ? s.d_prev : nullptr, s.d_Ms,
-                         s.d_ms, tau, s.d_Ropt, s.d_topt, s.d_opt, s.d_ok, stride > WS_LDS_MAX ? s.d_ws : nullptr);
+    double* d = s.d_in;
+    rc = launch_intracam(s.stream, 1, stride, d, d + 9, d + 18, (const int*)(d + 33), prevErrs ? d + PS_IN_HEAD + 5 * np : nullptr,
+                         d + PS_IN_HEAD, d + PS_IN_HEAD + 3 * np, tau, s.d_out, s.d_out + 9, (cs_pose_option*)(s.d_out + 12),
+                         (int*)(s.d_out + 24), stride > WS_LDS_MAX ? s.d_ws : nullptr);
     if (rc) return rc;
-    int ok = 0;
-    CS_HIP(hipMemcpyAsync(R_opt, s.d_Ropt, 72, hipMemcpyDeviceToHost, s.stream));
-    CS_HIP(hipMemcpyAsync(t_opt, s.d_topt, 24, hipMemcpyDeviceToHost, s.stream));
-    CS_HIP(hipMemcpyAsync(opt, s.d_opt, sizeof(*opt), hipMemcpyDeviceToHost, s.stream));
-    CS_HIP(hipMemcpyAsync(&ok, s.d_ok, 4, hipMemcpyDeviceToHost, s.stream));
+    CS_HIP(hipMemcpyAsync(s.h_out, s.d_out, PS_OUT * 8, hipMemcpyDeviceToHost, s.stream));
     CS_HIP(hipStreamSynchronize(s.stream));
+    memcpy(R_opt, s.h_out, 72);
+    memcpy(t_opt, s.h_out + 9, 24);
+    memcpy(opt, s.h_out + 12, sizeof(*opt));
+    int ok = 0;
+    memcpy(&ok, s.h_out + 24, sizeof(int));
     return ok;
 }
 

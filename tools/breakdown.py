@@ -67,3 +67,10 @@ trk.detect(frames[0]); trk.advanceFrame()
 def host(i):
     trk.redetect(frames[order[(i + 1) % len(order)]]); trk.advanceFrame()
 print("KLT redetect through the host-pointer API (H2D image + D2H dest + sync): %.1f us/frame (host %.1f)" % timeit(host, 200, 20))
+
+# the reference-shaped host entry points of the pose solve and the BA (host arrays in, host arrays out, synchronous)
+from coslam_amd.pose import intraCamEstimate
+def pose_host(i):
+    f = order[i % len(order)]
+    intraCamEstimate(sc.K, R0[f].reshape(3, 3), t0[f], 192, None, Ms[f], ms[f], 10.0)
+print("intraCamEstimate through the host-pointer API: %.1f us/call (host %.1f)" % timeit(pose_host, 200, 20))
