@@ -1251,8 +1251,11 @@ struct cs_ba {
     BaState* st;
     cs_ba_stats_dev* stats;
     BaPlan* dist;  // plan of the distributed solve in progress (cs_ba_dist_begin)
-    // pinned staging for the host-pointer entry
-    int *h_cam_ptr, *h_cam_obs;
+    // host-pointer entry: every input lives in ONE device block (io) mirrored by one pinned block (h_io), so a solve
+    // is one H2D copy; Rs | Ts | pts sit next to each other in it (one D2H); statistics | outlier flags form the
+    // second block (ob / h_ob, one D2H)
+    unsigned char *io, *h_io, *ob, *h_ob;
+    size_t ioBytes, obBytes;
     int nCostBlocks;
     // cached executable graph of one full solve (cs_ba_solve_dev): ~150 launches become one
     struct GraphKey {
@@ -1272,25 +1275,68 @@ static int ba_free(cs_ba* b) {
     ba_drop_graph(b);
     delete b->dist;
     b->dist = nullptr;
-    double** dp[] = {&b->Ks, &b->Rs, &b->Ts, &b->pts, &b->Rn, &b->Tn, &b->Mn, &b->obs_xy, &b->Jc, &b->e, &b->W,
-                     &b->Vinv, &b->gp, &b->S, &b->costPart, &b->stepPart, &b->schurPart, &b->scal};
+    double** dp[] = {&b->Rn, &b->Tn, &b->Mn, &b->Jc, &b->e, &b->W, &b->Vinv, &b->gp, &b->S, &b->costPart, &b->stepPart,
+                     &b->schurPart, &b->scal};
     for (auto p : dp) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
-    int** ip[] = {&b->obs_ptr, &b->obs_cam, &b->obs_pt, &b->cam_ptr, &b->cam_obs, &b->obs_of, &b->outlier};
+    int** ip[] = {&b->obs_pt, &b->obs_of};
     for (auto p : ip) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
     if (b->st) (void)hipFree(b->st);
-    if (b->stats) (void)hipFree(b->stats);
-    if (b->h_cam_ptr) (void)hipHostFree(b->h_cam_ptr);
-    if (b->h_cam_obs) (void)hipHostFree(b->h_cam_obs);
+    if (b->io) (void)hipFree(b->io);
+    if (b->ob) (void)hipFree(b->ob);
+    if (b->h_io) (void)hipHostFree(b->h_io);
+    if (b->h_ob) (void)hipHostFree(b->h_ob);
     b->st = nullptr;
+    b->io = b->ob = b->h_io = b->h_ob = nullptr;
+    b->Ks = b->Rs = b->Ts = b->pts = b->obs_xy = nullptr;
+    b->obs_ptr = b->obs_cam = b->cam_ptr = b->cam_obs = b->outlier = nullptr;
     b->stats = nullptr;
-    b->h_cam_ptr = b->h_cam_obs = nullptr;
     return CS_OK;
+}
+
+// section offsets (bytes) of the I/O block for a problem of C cameras, P points, nObs measurements
+struct BaIoLayout {
+    size_t Ks, Rs, Ts, pts, xy, optr, ocam, cptr, cobs, total;
+};
+static BaIoLayout ba_io_layout(size_t C, size_t P, size_t O) {
+    BaIoLayout L;
+    size_t o = 0;
+    auto take = [&o](size_t bytes) {
+        const size_t at = o;
+        o += (bytes + 7) & ~(size_t)7;
+        return at;
+    };
+    L.Ks = take(72 * C);
+    L.Rs = take(72 * C);
+    L.Ts = take(24 * C);
+    L.pts = take(24 * P);
+    L.xy = take(16 * O);
+    L.optr = take(4 * (P + 1));
+    L.ocam = take(4 * O);
+    L.cptr = take(4 * (C + 1));
+    L.cobs = take(4 * O);
+    L.total = o;
+    return L;
+}
+// point the workspace's input / output arrays into the blocks for this problem size
+static void ba_bind_io(cs_ba* b, int C, int P, int nObs) {
+    const BaIoLayout L = ba_io_layout((size_t)C, (size_t)P, (size_t)nObs);
+    b->Ks = (double*)(b->io + L.Ks);
+    b->Rs = (double*)(b->io + L.Rs);
+    b->Ts = (double*)(b->io + L.Ts);
+    b->pts = (double*)(b->io + L.pts);
+    b->obs_xy = (double*)(b->io + L.xy);
+    b->obs_ptr = (int*)(b->io + L.optr);
+    b->obs_cam = (int*)(b->io + L.ocam);
+    b->cam_ptr = (int*)(b->io + L.cptr);
+    b->cam_obs = (int*)(b->io + L.cobs);
+    b->stats = (cs_ba_stats_dev*)b->ob;
+    b->outlier = (int*)(b->ob + 64);
 }
 
 static int ba_reserve(cs_ba* b, int C, int P, int nObs) {
@@ -1300,14 +1346,9 @@ static int ba_reserve(cs_ba* b, int C, int P, int nObs) {
                  cO = (size_t)(nObs > b->capObs ? nObs : b->capObs);
     const size_t n = 6 * cC;
 #define BA_ALLOC(ptr, count, type) CS_HIP(hipMalloc((void**)&(ptr), ((count) > 0 ? (count) : 1) * sizeof(type)))
-    BA_ALLOC(b->Ks, 9 * cC, double);
-    BA_ALLOC(b->Rs, 9 * cC, double);
-    BA_ALLOC(b->Ts, 3 * cC, double);
-    BA_ALLOC(b->pts, 3 * cP, double);
     BA_ALLOC(b->Rn, 9 * cC, double);
     BA_ALLOC(b->Tn, 3 * cC, double);
     BA_ALLOC(b->Mn, 3 * cP, double);
-    BA_ALLOC(b->obs_xy, 2 * cO, double);
     BA_ALLOC(b->Jc, 12 * cO, double);
     BA_ALLOC(b->e, 2 * cO, double);
     BA_ALLOC(b->W, 18 * cO, double);
@@ -1319,18 +1360,16 @@ static int ba_reserve(cs_ba* b, int C, int P, int nObs) {
     BA_ALLOC(b->costPart, 1024 + cP / 4 + cC / 256 + 2, double);
     BA_ALLOC(b->schurPart, (size_t)21 * 16 * 72, double);  // <= 6 free cameras (21 pairs) x 16 slices
     BA_ALLOC(b->stepPart, cP + cC, double);
-    BA_ALLOC(b->obs_ptr, cP + 1, int);
-    BA_ALLOC(b->obs_cam, cO, int);
     BA_ALLOC(b->obs_pt, cO, int);
-    BA_ALLOC(b->cam_ptr, cC + 1, int);
-    BA_ALLOC(b->cam_obs, cO, int);
     BA_ALLOC(b->obs_of, cP * cC, int);
-    BA_ALLOC(b->outlier, cO, int);
     BA_ALLOC(b->st, 1, BaState);
-    BA_ALLOC(b->stats, 1, cs_ba_stats_dev);
 #undef BA_ALLOC
-    CS_HIP(hipHostMalloc((void**)&b->h_cam_ptr, (cC + 1) * sizeof(int), hipHostMallocDefault));
-    CS_HIP(hipHostMalloc((void**)&b->h_cam_obs, (cO > 0 ? cO : 1) * sizeof(int), hipHostMallocDefault));
+    b->ioBytes = ba_io_layout(cC, cP, cO).total + 64;
+    b->obBytes = 64 + 4 * (cO > 0 ? cO : 1);
+    CS_HIP(hipMalloc((void**)&b->io, b->ioBytes));
+    CS_HIP(hipMalloc((void**)&b->ob, b->obBytes));
+    CS_HIP(hipHostMalloc((void**)&b->h_io, b->ioBytes, hipHostMallocDefault));
+    CS_HIP(hipHostMalloc((void**)&b->h_ob, b->obBytes, hipHostMallocDefault));
     b->capC = (int)cC;
     b->capP = (int)cP;
     b->capObs = (int)cO;
@@ -1552,47 +1591,51 @@ int cs_ba_robust_h(cs_ba* b, int C, int P, int nObs, const double* Ks, double* R
     CS_HIP(hipSetDevice(b->device));
     int rc = ba_reserve(b, C, P, nObs);
     if (rc) return rc;
-    // index by camera (counting sort; also validates the view ids)
-    for (int j = 0; j <= C; ++j) b->h_cam_ptr[j] = 0;
+    ba_bind_io(b, C, P, nObs);
+    const BaIoLayout L = ba_io_layout((size_t)C, (size_t)P, (size_t)nObs);
+    // index by camera (counting sort; also validates the view ids), straight into the pinned block
+    int* h_cam_ptr = (int*)(b->h_io + L.cptr);
+    int* h_cam_obs = (int*)(b->h_io + L.cobs);
+    for (int j = 0; j <= C; ++j) h_cam_ptr[j] = 0;
     for (int o = 0; o < nObs; ++o) {
         if (obs_cam[o] < 0 || obs_cam[o] >= C) {
             cs_set_error("cs_ba_robust: measurement %d has viewId %d outside [0,%d)", o, obs_cam[o], C);
             return CS_ERR_INVALID;
         }
-        b->h_cam_ptr[obs_cam[o] + 1]++;
+        h_cam_ptr[obs_cam[o] + 1]++;
     }
-    for (int j = 0; j < C; ++j) b->h_cam_ptr[j + 1] += b->h_cam_ptr[j];
+    for (int j = 0; j < C; ++j) h_cam_ptr[j + 1] += h_cam_ptr[j];
     {
         int* fill = new int[C > 0 ? C : 1];
-        for (int j = 0; j < C; ++j) fill[j] = b->h_cam_ptr[j];
-        for (int o = 0; o < nObs; ++o) b->h_cam_obs[fill[obs_cam[o]]++] = o;
+        for (int j = 0; j < C; ++j) fill[j] = h_cam_ptr[j];
+        for (int o = 0; o < nObs; ++o) h_cam_obs[fill[obs_cam[o]]++] = o;
         delete[] fill;
     }
-    hipStream_t s = b->own_stream;
-    CS_HIP(hipMemcpyAsync(b->Ks, Ks, sizeof(double) * 9 * C, hipMemcpyHostToDevice, s));
-    CS_HIP(hipMemcpyAsync(b->Rs, Rs, sizeof(double) * 9 * C, hipMemcpyHostToDevice, s));
-    CS_HIP(hipMemcpyAsync(b->Ts, Ts, sizeof(double) * 3 * C, hipMemcpyHostToDevice, s));
+    memcpy(b->h_io + L.Ks, Ks, sizeof(double) * 9 * C);
+    memcpy(b->h_io + L.Rs, Rs, sizeof(double) * 9 * C);
+    memcpy(b->h_io + L.Ts, Ts, sizeof(double) * 3 * C);
     if (P > 0) {
-        CS_HIP(hipMemcpyAsync(b->pts, pts, sizeof(double) * 3 * P, hipMemcpyHostToDevice, s));
-        CS_HIP(hipMemcpyAsync(b->obs_ptr, obs_ptr, sizeof(int) * (P + 1), hipMemcpyHostToDevice, s));
+        memcpy(b->h_io + L.pts, pts, sizeof(double) * 3 * P);
+        memcpy(b->h_io + L.optr, obs_ptr, sizeof(int) * (P + 1));
     }
     if (nObs > 0) {
-        CS_HIP(hipMemcpyAsync(b->obs_cam, obs_cam, sizeof(int) * nObs, hipMemcpyHostToDevice, s));
-        CS_HIP(hipMemcpyAsync(b->obs_xy, obs_xy, sizeof(double) * 2 * nObs, hipMemcpyHostToDevice, s));
-        CS_HIP(hipMemcpyAsync(b->cam_obs, b->h_cam_obs, sizeof(int) * nObs, hipMemcpyHostToDevice, s));
+        memcpy(b->h_io + L.xy, obs_xy, sizeof(double) * 2 * nObs);
+        memcpy(b->h_io + L.ocam, obs_cam, sizeof(int) * nObs);
     }
-    CS_HIP(hipMemcpyAsync(b->cam_ptr, b->h_cam_ptr, sizeof(int) * (C + 1), hipMemcpyHostToDevice, s));
+    hipStream_t s = b->own_stream;
+    CS_HIP(hipMemcpyAsync(b->io, b->h_io, L.total, hipMemcpyHostToDevice, s));  // the whole problem in one copy
     rc = ba_enqueue(b, s, C, P, nObs, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter);
     if (rc) return rc;
-    CS_HIP(hipMemcpyAsync(Rs, b->Rs, sizeof(double) * 9 * C, hipMemcpyDeviceToHost, s));
-    CS_HIP(hipMemcpyAsync(Ts, b->Ts, sizeof(double) * 3 * C, hipMemcpyDeviceToHost, s));
-    if (P > 0) CS_HIP(hipMemcpyAsync(pts, b->pts, sizeof(double) * 3 * P, hipMemcpyDeviceToHost, s));
-    if (nObs > 0 && out_outlier)
-        CS_HIP(hipMemcpyAsync(out_outlier, b->outlier, sizeof(int) * nObs, hipMemcpyDeviceToHost, s));
-    cs_ba_stats_dev hs;
-    CS_HIP(hipMemcpyAsync(&hs, b->stats, sizeof(hs), hipMemcpyDeviceToHost, s));
+    // Rs | Ts | pts are adjacent: one copy; statistics | outlier flags: one copy
+    const size_t outBytes = (L.pts + sizeof(double) * 3 * (size_t)P) - L.Rs;
+    CS_HIP(hipMemcpyAsync(b->h_io + L.Rs, b->io + L.Rs, outBytes, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipMemcpyAsync(b->h_ob, b->ob, 64 + sizeof(int) * (size_t)(nObs > 0 ? nObs : 0), hipMemcpyDeviceToHost, s));
     CS_HIP(hipStreamSynchronize(s));
-    if (stats) memcpy(stats, &hs, sizeof(hs));
+    memcpy(Rs, b->h_io + L.Rs, sizeof(double) * 9 * C);
+    memcpy(Ts, b->h_io + L.Ts, sizeof(double) * 3 * C);
+    if (P > 0) memcpy(pts, b->h_io + L.pts, sizeof(double) * 3 * P);
+    if (nObs > 0 && out_outlier) memcpy(out_outlier, b->h_ob + 64, sizeof(int) * nObs);
+    if (stats) memcpy(stats, b->h_ob, sizeof(cs_ba_stats_dev));
     return CS_OK;
 }
 
