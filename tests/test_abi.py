@@ -85,3 +85,15 @@ def test_cxx_shim_compiles_and_links():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "shim ok" in out.stdout
+
+
+def test_cxx_dropin_bench_compiles():
+    """tools/cxx/dropin_bench.cpp (latency of the reference-shaped synchronous calls) builds against the shims."""
+    src = os.path.join(ROOT, "tools", "cxx", "dropin_bench.cpp")
+    exe = os.path.join(ROOT, "tools", "cxx", "dropin_bench.bin")
+    libdir = os.path.join(ROOT, "coslam_amd", "lib")
+    cmd = ["g++", "-O2", "-std=c++11", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "include", "shim"),
+           src, "-L", libdir, "-lcoslam_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib",
+           "-o", exe]
+    subprocess.check_call(cmd)
+    assert os.path.exists(exe)

@@ -1,0 +1,163 @@
+// dropin_bench.cpp -- what a CoSLAM maintainer sees after swapping the headers: latency of the reference-shaped,
+// synchronous C++ calls (host arrays in, host arrays out) through include/shim over libcoslam_hip.so.
+//   g++ -O2 -std=c++11 -Iinclude -Iinclude/shim tools/cxx/dropin_bench.cpp -Lcoslam_amd/lib -lcoslam_hip \
+//       -Wl,-rpath,$PWD/coslam_amd/lib -Wl,-rpath,/opt/rocm/lib -L/opt/rocm/lib -o tools/cxx/dropin_bench.bin
+// Synthetic inputs: a band-limited noise image that shifts by a pixel per frame (640x480, 50x40 slots, CoSLAM's KLT
+// parameters with 4 levels), 192 exact 3D-2D correspondences with noise, a 5 key frame x 500 point local BA.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "CGKLT/v3d_gpuklt.h"
+#include "geometry/SL_BundleAdjust.h"
+#include "slam/SL_IntraCamPose.h"
+
+struct Mat_d {
+    int rows, cols;
+    std::vector<double> store;
+    double* data;
+    Mat_d(int r, int c, const double* d) : rows(r), cols(c), store(d, d + r * c), data(0) { data = store.data(); }
+    Mat_d(const Mat_d& o) : rows(o.rows), cols(o.cols), store(o.store), data(0) { data = store.data(); }
+};
+struct Point3d {
+    double M[3];
+    Point3d(double x, double y, double z) { M[0] = x, M[1] = y, M[2] = z; }
+};
+struct Meas2D {
+    int viewId;
+    double x, y;
+    int outlier;
+    Meas2D(int v, double x_, double y_) : viewId(v), x(x_), y(y_), outlier(0) {}
+};
+
+static double now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static unsigned rng_state = 12345;
+static double urand() {
+    rng_state = rng_state * 1664525u + 1013904223u;
+    return (rng_state >> 8) / 16777216.0;
+}
+static double nrand() { return std::sqrt(-2.0 * std::log(urand() + 1e-12)) * std::cos(6.283185307179586 * urand()); }
+
+int main() {
+    if (cs_device_count() < 1) {
+        printf("no HIP device: nothing to measure (there is no CPU fallback)\n");
+        return 0;
+    }
+    const int W = 640, H = 480, L = 4, fw = 50, fh = 40;
+    // texture: white noise, three 5-tap binomial passes, stretched
+    std::vector<float> tex((W + 64) * H);
+    for (auto& v : tex) v = (float)urand();
+    for (int pass = 0; pass < 3; ++pass) {
+        std::vector<float> t2(tex);
+        const int TW = W + 64;
+        for (int y = 2; y < H - 2; ++y)
+            for (int x = 2; x < TW - 2; ++x) {
+                float s = 0;
+                for (int dy = -2; dy <= 2; ++dy)
+                    for (int dx = -2; dx <= 2; ++dx) {
+                        static const float k[5] = {1, 4, 6, 4, 1};
+                        s += k[dy + 2] * k[dx + 2] * tex[(y + dy) * TW + x + dx];
+                    }
+                t2[y * TW + x] = s / 256.0f;
+            }
+        tex.swap(t2);
+    }
+    float lo = 1e9f, hi = -1e9f;
+    for (float v : tex) lo = v < lo ? v : lo, hi = v > hi ? v : hi;
+    for (auto& v : tex) v = 0.25f + 0.3f * (v - lo) / (hi - lo);
+    {  // Gaussian blobs (sigma 1.2 px): the corners the detector is after
+        const int TW = W + 64;
+        for (int b = 0; b < 9000; ++b) {
+            const double cx = 4 + (TW - 8) * urand(), cy = 4 + (H - 8) * urand(), amp = 0.25 + 0.35 * urand();
+            for (int y = (int)cy - 4; y <= (int)cy + 4; ++y)
+                for (int x = (int)cx - 4; x <= (int)cx + 4; ++x) {
+                    const double d2 = (x - cx) * (x - cx) + (y - cy) * (y - cy);
+                    tex[y * TW + x] += (float)(amp * std::exp(-d2 / (2 * 1.2 * 1.2)));
+                }
+        }
+    }
+    lo = 1e9f, hi = -1e9f;
+    for (float v : tex) lo = v < lo ? v : lo, hi = v > hi ? v : hi;
+    std::vector<std::vector<unsigned char> > frames(32, std::vector<unsigned char>(W * H));
+    for (int f = 0; f < 32; ++f)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x)
+                frames[f][y * W + x] = (unsigned char)(24 + 208 * (tex[y * (W + 64) + x + f] - lo) / (hi - lo));
+
+    V3D_GPU::KLT_SequenceTrackerConfig cfg;
+    cfg.nIterations = 10, cfg.nLevels = L, cfg.levelSkip = 1, cfg.windowWidth = 7, cfg.trackWithGain = true;
+    cfg.minCornerness = 3000.0f, cfg.convergenceThreshold = 1.0f, cfg.SSD_Threshold = 20000.0f, cfg.minDistance = 4;
+    std::vector<V3D_GPU::KLT_TrackedFeature> feats(fw * fh);
+    V3D_GPU::KLT_SequenceTracker trk(cfg);
+    trk.allocate(W, H, L, fw, fh);
+    int n = 0;
+    trk.detect(frames[0].data(), n, feats.data());
+    trk.advanceFrame();
+    for (int i = 1; i < 20; ++i) {  // warm-up
+        trk.redetect(frames[i % 32].data(), n, feats.data());
+        trk.advanceFrame();
+    }
+    const int NF = 300;
+    double t = now_us();
+    for (int i = 0; i < NF; ++i) {
+        trk.redetect(frames[(20 + i) % 32].data(), n, feats.data());
+        trk.advanceFrame();
+    }
+    printf("KLT_SequenceTracker::redetect + advanceFrame (640x480, 2000 slots, host image in / dest[] out): %.1f us/frame, %d live\n",
+           (now_us() - t) / NF, n);
+
+    // intraCamEstimate
+    double K[9] = {524.8, 0, 320, 0, 524.8, 240, 0, 0, 1}, R0[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t0[3] = {0.02, -0.01, 0.03};
+    const int NP = 192;
+    std::vector<double> Ms(3 * NP), ms(2 * NP);
+    for (int i = 0; i < NP; ++i) {
+        Ms[3 * i] = -5 + 10 * urand(), Ms[3 * i + 1] = -3 + 6 * urand(), Ms[3 * i + 2] = 6 + 8 * urand();
+        ms[2 * i] = K[0] * Ms[3 * i] / Ms[3 * i + 2] + K[2] + 0.5 * nrand();
+        ms[2 * i + 1] = K[4] * Ms[3 * i + 1] / Ms[3 * i + 2] + K[5] + 0.5 * nrand();
+    }
+    double Ro[9], to[3];
+    IntraCamPoseOption opt;
+    for (int i = 0; i < 10; ++i) intraCamEstimate(K, R0, t0, NP, 0, Ms.data(), ms.data(), 10.0, Ro, to, &opt);
+    t = now_us();
+    for (int i = 0; i < 200; ++i) intraCamEstimate(K, R0, t0, NP, 0, Ms.data(), ms.data(), 10.0, Ro, to, &opt);
+    printf("intraCamEstimate (192 points): %.1f us/call\n", (now_us() - t) / 200);
+
+    // bundleAdjustRobust: 5 key frames x 500 points, all visible, the call queued at SL_CoSLAM.cpp:1345 (2 fixed, 2/10)
+    const int C = 5, P = 500;
+    std::vector<Mat_d> Ks, Rs, Ts;
+    std::vector<Point3d> pts;
+    std::vector<std::vector<Meas2D> > meas(P);
+    std::vector<double> camx(C);
+    for (int c = 0; c < C; ++c) {
+        double tc[3] = {-0.3 * c, 0.0, 0.0};
+        camx[c] = tc[0];
+        Ks.push_back(Mat_d(3, 3, K));
+        Rs.push_back(Mat_d(3, 3, R0));
+        Ts.push_back(Mat_d(3, 1, tc));
+    }
+    for (int i = 0; i < P; ++i) {
+        double X = -5 + 10 * urand(), Y = -3 + 6 * urand(), Z = 6 + 8 * urand();
+        pts.push_back(Point3d(X + 0.05 * nrand(), Y + 0.05 * nrand(), Z + 0.05 * nrand()));
+        for (int c = 0; c < C; ++c)
+            meas[i].push_back(Meas2D(c, K[0] * (X + camx[c]) / Z + K[2] + 0.5 * nrand(), K[4] * Y / Z + K[5] + 0.5 * nrand()));
+    }
+    std::vector<Mat_d> Rs0(Rs), Ts0(Ts);
+    std::vector<Point3d> pts0(pts);
+    for (int i = 0; i < 5; ++i) {
+        Rs = Rs0, Ts = Ts0, pts = pts0;
+        bundleAdjustRobust(2, Ks, Rs, Ts, 2, pts, meas, 6.0, 2, 10);
+    }
+    t = now_us();
+    for (int i = 0; i < 50; ++i) {
+        Rs = Rs0, Ts = Ts0, pts = pts0;
+        bundleAdjustRobust(2, Ks, Rs, Ts, 2, pts, meas, 6.0, 2, 10);
+    }
+    printf("bundleAdjustRobust (5 key frames x 500 points x 2500 measurements, maxIter 2 / inner 10): %.1f us/call\n",
+           (now_us() - t) / 50);
+    trk.deallocate();
+    return 0;
+}
