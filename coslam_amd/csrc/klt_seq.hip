@@ -146,6 +146,7 @@ struct cs_klt {
     unsigned long long* d_gran;
     int* d_err;
     int cu_count;                 // compute units the handle's stream may use (cs_klt_set_cu_count; default: all)
+    int concurrent;               // handles whose persistent kernels may overlap (cs_klt_set_concurrent_handles; 0: all live ones)
     unsigned long long* d_probe;  // diagnostic cycle counters of the persistent tracker (cs_klt_debug_probe)
     // hipGraph cache for the *_dev entry points: one executable graph per (call, buffer rotation state)
     bool use_graphs;
@@ -212,6 +213,7 @@ static int enqueue_tracker(cs_klt* k, cs_klt_feature* postDest, int doSuppress, 
         std::lock_guard<std::mutex> g(g_reg_mutex);
         live = g_live_handles[k->device & 63] > 0 ? g_live_handles[k->device & 63] : 1;
     }
+    if (k->concurrent > 0 && k->concurrent < live) live = k->concurrent;
     const int blocks = (k->N + 3) / 4;
     if (k->use_fused && T >= 1 && blocks * live <= CS_RESIDENT_BLOCKS_PER_CU * k->cu_count && (2 * hw + 1) * (2 * hw + 1) <= 256) {
         CsGainFusedArgs f;
@@ -632,6 +634,21 @@ int cs_klt_set_stream(cs_klt* k, void* s) {
 int cs_klt_set_cu_count(cs_klt* k, int n_cus) {
     CS_REQUIRE(k && n_cus > 0, "cs_klt_set_cu_count: bad arguments");
     k->cu_count = n_cus;
+    if (k->allocated) {
+        int rc = bind_device(k);
+        if (rc) return rc;
+        CS_HIP(hipStreamSynchronize(k->stream));
+        drop_graphs(k);
+    }
+    return CS_OK;
+}
+
+// Many cameras on one GPU: the co-residency budget of the persistent tracker is shared between the handles whose
+// launches can overlap.  By default that is every live handle of the device; a caller that serialises cameras (e.g.
+// eight cameras on three streams) states the real concurrency here.
+int cs_klt_set_concurrent_handles(cs_klt* k, int n) {
+    CS_REQUIRE(k && n >= 0, "cs_klt_set_concurrent_handles: bad arguments");
+    k->concurrent = n;
     if (k->allocated) {
         int rc = bind_device(k);
         if (rc) return rc;

@@ -112,6 +112,8 @@ int cs_klt_enable_graphs(cs_klt* k, int on);
 int cs_klt_set_fused(cs_klt* k, int on);
 /* compute units available to the handle's stream when it carries a CU mask (co-residency budget of the persistent tracker) */
 int cs_klt_set_cu_count(cs_klt* k, int n_cus);
+/* how many handles of this device may have their persistent tracker in flight at the same time (0 = every live handle) */
+int cs_klt_set_concurrent_handles(cs_klt* k, int n);
 /* a stream confined to the compute units [first_cu, first_cu + n_cus): keeps pose / BA kernels off the SIMDs of the
  * lock-stepped persistent tracker; returns a hipStream_t (null on error) */
 void* cs_stream_create_cu_range(int device, int first_cu, int n_cus);
