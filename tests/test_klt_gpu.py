@@ -38,7 +38,10 @@ def compare_dest(d_g, d_o, W, H, min_same=1.0, tol=TOL_PX):
 
 
 @pytest.mark.parametrize("W,H,L,tap", [(640, 480, 4, 0), (640, 480, 4, 1), (322, 250, 3, 0), (1920, 1080, 4, 0),
-                                       (96, 64, 1, 0), (640, 480, 6, 0)])
+                                       (96, 64, 1, 0), (640, 480, 6, 0),
+                                       # odd sizes at every level, ragged last tiles of the fused kernels, 2 / 5 / 6 levels
+                                       (333, 241, 5, 0), (333, 241, 5, 1), (101, 67, 4, 0), (101, 67, 4, 1), (64, 48, 2, 0),
+                                       (1000, 562, 6, 0), (1279, 719, 4, 1), (130, 33, 3, 0)])
 def test_pyramid_bitexact(hip, W, H, L, tap):
     rng = np.random.default_rng(W * 7 + H + L)
     img = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
@@ -368,3 +371,65 @@ def test_persistent_gain_tracker_under_uneven_foreign_load(hip):
         live = d0["status"] >= 0
         assert np.array_equal(d0["pos"][live], d1["pos"][live]) and np.array_equal(d0["gain"][live], d1["gain"][live])
         assert np.array_equal(f0, f1)
+
+
+@pytest.mark.parametrize("W,H", [(333, 241), (101, 67), (640, 480)])
+def test_cornerness_of_fused_front_end_is_bitexact_on_ragged_sizes(hip, W, H):
+    """The detector's cornerness map comes out of the level-0 pyramid kernel's LDS tile (halo recomputed, CLAMP_TO_EDGE
+    folded in): it must equal the oracle's two-pass result bit for bit, image borders and ragged tiles included."""
+    rng = np.random.default_rng(W + H)
+    img = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+    cfg = cfg2(nLevels=3, minCornerness=50.0, minDistance=3)
+    trk, ora = make_pair(cfg, W, H, 3, 16, 12)
+    n_g, d_g = trk.detect(img)
+    n_o, d_o = ora.detect(img)
+    assert np.array_equal(trk.read_cornerness(), ora.read_cornerness())
+    assert n_g == n_o
+    assert np.array_equal(d_g["status"], d_o["status"])
+    live = d_o["status"] >= 0
+    assert np.array_equal(d_g["pos"][live], d_o["pos"][live])
+    trk.close()
+
+
+def test_cu_masked_stream_and_budget(hip):
+    """cs_stream_create_cu_range + cs_klt_set_cu_count: the tracker on a CU-masked stream gives the same result, and a
+    budget too small for the grid falls back to the launch-per-pass schedule instead of hanging."""
+    import ctypes as C
+
+    import torch
+
+    W, H, L, grid = 640, 480, 4, (50, 40)
+    sc = Scene(1, W, H, 5000, seed=88)
+    frames = [sc.render(0, f) for f in range(4)]
+    lib = coslam_amd.lib()
+    lib.cs_stream_create_cu_range.restype = C.c_void_p
+    n_cus = torch.cuda.get_device_properties(0).multi_processor_count
+
+    def run(stream_ptr, cu_count):
+        t = coslam_amd.KLT_SequenceTracker(cfg2(), 0)
+        t.allocate(W, H, L, *grid)
+        if stream_ptr:
+            t.set_stream(stream_ptr)
+        if cu_count:
+            t.set_cu_count(cu_count)
+        t.detect(frames[0])
+        t.advanceFrame()
+        out = []
+        for f in range(1, 4):
+            n, d = t.redetect(frames[f])
+            out.append((n, d.copy()))
+            t.advanceFrame()
+        t.close()
+        return out
+
+    ref = run(None, 0)
+    h = lib.cs_stream_create_cu_range(0, 0, n_cus - 64)
+    assert h, lib.cs_last_error()
+    masked = run(h, n_cus - 64)
+    tiny = run(None, 8)  # 8 CUs x 6 blocks < 500 blocks: must take the per-pass schedule, same numbers
+    for other in (masked, tiny):
+        for (n0, d0), (n1, d1) in zip(ref, other):
+            assert n0 == n1 and np.array_equal(d0["status"], d1["status"])
+            live = d0["status"] >= 0
+            assert np.array_equal(d0["pos"][live], d1["pos"][live])
+    lib.cs_stream_destroy(C.c_void_p(h))
