@@ -792,7 +792,11 @@ __device__ __forceinline__ void solve_reg_block(const BaDev& D, double* Ssm, int
             ok = false;
             d = 1.0;
         }
-        const double rd = 1.0 / sqrt(d);
+        // 1/sqrt(d): the hardware estimate + two Newton steps (full binary64 accuracy) is a ~12-instruction dependent
+        // chain; IEEE sqrt followed by an IEEE division is ~50, and this chain is the critical path of every column
+        double rd = __builtin_amdgcn_rsq(d);
+        rd = rd * (1.5 - (0.5 * d) * rd * rd);
+        rd = rd * (1.5 - (0.5 * d) * rd * rd);
         rdiag[j] = rd;
         const double lij = (i > j) ? cj * rd : 0.0;
         a[j] = lij;
