@@ -837,6 +837,40 @@ __global__ __launch_bounds__(256) void k_update(BaDev D) {
     __shared__ double red[4];
     __shared__ double Ssm[NMAX > 0 ? NMAX * NMAX + NMAX : 1];
     __shared__ int okSh;
+    // Everything the point step and the tentative residuals read that does NOT depend on the solve is loaded first: the
+    // loads then fly under the combine + Cholesky below instead of starting a fresh miss chain behind it.
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool mine = gw < D.P && gw >= D.pLo && gw < D.pHi;
+    int o0 = 0, o1 = 0, pj = -1, pout = 1;
+    double pW[18], pR[9], pT[3], pK[9], pxy[2], pVi[9], pg[3], pM[3];
+    if (mine) {
+        o0 = D.obs_ptr[gw];
+        o1 = D.obs_ptr[gw + 1];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) pVi[q] = D.Vinv[9 * (size_t)gw + q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            pg[q] = D.gp[3 * (size_t)gw + q];
+            pM[q] = D.pts[3 * (size_t)gw + q];
+        }
+        const int o = o0 + lane;
+        if (o < o1) {
+            pj = D.obs_cam[o];
+            pout = D.outlier[o];
+#pragma unroll
+            for (int q = 0; q < 18; ++q) pW[q] = D.W[18 * (size_t)o + q];
+            pxy[0] = D.obs_xy[2 * (size_t)o];
+            pxy[1] = D.obs_xy[2 * (size_t)o + 1];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                pR[q] = D.Rs[9 * pj + q];
+                pK[q] = D.Ks[9 * pj + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) pT[q] = D.Ts[3 * pj + q];
+        }
+    }
     const double* rhs = D.rhs;
     if (NMAX > 0) {
         solve_reg_block<(NMAX > 0 ? NMAX : 1)>(D, Ssm, &okSh);
@@ -846,25 +880,30 @@ __global__ __launch_bounds__(256) void k_update(BaDev D) {
             if (threadIdx.x == 0) D.st->chol_ok = okSh;
         }
     }
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     double cost = 0;
-    if (gw < D.P && (gw < D.pLo || gw >= D.pHi)) {
+    if (gw < D.P && !mine) {
         if (lane == 0) D.stepPart[gw] = 0;  // another rank's point
-    } else if (gw < D.P) {
+    } else if (mine) {
         const int i = gw;
-        const int o0 = D.obs_ptr[i], o1 = D.obs_ptr[i + 1];
         double b[3] = {0, 0, 0};
         if (i >= D.nPtsCon) {
             for (int o = o0 + lane; o < o1; o += 64) {
-                const int j = D.obs_cam[o] - D.nCamsCon;
-                if (j < 0 || D.outlier[o]) continue;
-                const double* Wo = D.W + 18 * (size_t)o;
+                const bool first = (o == o0 + lane);
+                const int j = (first ? pj : D.obs_cam[o]) - D.nCamsCon;
+                if (j < 0 || (first ? pout : D.outlier[o])) continue;
                 const double* dc = rhs + 6 * j;
+                if (first) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
+                    for (int c = 0; c < 3; ++c)
 #pragma unroll
-                    for (int r = 0; r < 6; ++r) b[c] -= Wo[3 * r + c] * dc[r];
+                        for (int r = 0; r < 6; ++r) b[c] -= pW[3 * r + c] * dc[r];
+                } else {
+                    const double* Wo = D.W + 18 * (size_t)o;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) b[c] -= Wo[3 * r + c] * dc[r];
+                }
             }
         }
         b[0] = wsum(b[0]);
@@ -872,39 +911,60 @@ __global__ __launch_bounds__(256) void k_update(BaDev D) {
         b[2] = wsum(b[2]);
         double d[3] = {0, 0, 0};
         if (i >= D.nPtsCon) {
-            const double* Vi = D.Vinv + 9 * (size_t)i;
-            const double g0 = D.gp[3 * (size_t)i] + b[0], g1 = D.gp[3 * (size_t)i + 1] + b[1],
-                         g2 = D.gp[3 * (size_t)i + 2] + b[2];
+            const double g0 = pg[0] + b[0], g1 = pg[1] + b[1], g2 = pg[2] + b[2];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) d[r] = Vi[3 * r] * g0 + Vi[3 * r + 1] * g1 + Vi[3 * r + 2] * g2;
+            for (int r = 0; r < 3; ++r) d[r] = pVi[3 * r] * g0 + pVi[3 * r + 1] * g1 + pVi[3 * r + 2] * g2;
         }
         double Mn[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) Mn[r] = D.pts[3 * (size_t)i + r] + d[r];
+        for (int r = 0; r < 3; ++r) Mn[r] = pM[r] + d[r];
         if (lane == 0) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) D.Mn[3 * (size_t)i + r] = Mn[r];
             D.stepPart[i] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
         }
         for (int o = o0 + lane; o < o1; o += 64) {
-            if (D.outlier[o]) continue;
-            const int j = D.obs_cam[o];
+            const bool first = (o == o0 + lane);
+            if (first ? pout : D.outlier[o]) continue;
+            const int j = first ? pj : D.obs_cam[o];
+            double Rc[9], Tc[3], Kc[9], xy[2];
+            if (first) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    Rc[q] = pR[q];
+                    Kc[q] = pK[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) Tc[q] = pT[q];
+                xy[0] = pxy[0];
+                xy[1] = pxy[1];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    Rc[q] = D.Rs[9 * j + q];
+                    Kc[q] = D.Ks[9 * j + q];
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) Tc[q] = D.Ts[3 * j + q];
+                xy[0] = D.obs_xy[2 * (size_t)o];
+                xy[1] = D.obs_xy[2 * (size_t)o + 1];
+            }
             double Rn[9], Tn[3];
             if (j >= D.nCamsCon) {
                 const double* dc = rhs + 6 * (j - D.nCamsCon);
                 double w[3] = {dc[0], dc[1], dc[2]}, dR[9];
                 so3_exp(w, dR);
-                mat33AB(D.Rs + 9 * j, dR, Rn);
+                mat33AB(Rc, dR, Rn);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) Tn[q] = D.Ts[3 * j + q] + dc[3 + q];
+                for (int q = 0; q < 3; ++q) Tn[q] = Tc[q] + dc[3 + q];
             } else {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) Rn[q] = D.Rs[9 * j + q];
+                for (int q = 0; q < 9; ++q) Rn[q] = Rc[q];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) Tn[q] = D.Ts[3 * j + q];
+                for (int q = 0; q < 3; ++q) Tn[q] = Tc[q];
             }
             double e[2];
-            residual<false>(D.Ks + 9 * j, Rn, Tn, Mn, D.obs_xy + 2 * (size_t)o, e, nullptr, nullptr);
+            residual<false>(Kc, Rn, Tn, Mn, xy, e, nullptr, nullptr);
             cost += e[0] * e[0] + e[1] * e[1];
         }
     }
