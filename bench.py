@@ -188,8 +188,12 @@ def main():
                     h = L.cs_stream_create_cu_interleaved(local_rank, n_cus // side_cus, 1, 0 if side else 1)
                 else:
                     L.cs_stream_create_cu_range.restype = C.c_void_p
-                    h = (L.cs_stream_create_cu_range(local_rank, n_cus - side_cus, side_cus) if side
-                         else L.cs_stream_create_cu_range(local_rank, 0, n_cus - side_cus))
+                    if side == "pose":
+                        h = L.cs_stream_create_cu_range(local_rank, pose_first, pose_cus)
+                    elif side:
+                        h = L.cs_stream_create_cu_range(local_rank, n_cus - side_cus, side_cus - pose_from_side)
+                    else:
+                        h = L.cs_stream_create_cu_range(local_rank, 0, n_cus - side_cus - pose_from_klt)
                 if h:
                     return torch.cuda.ExternalStream(h, device=dev)
                 print("bench: CU-masked stream unavailable (" + L.cs_last_error().decode() + "); plain streams",
@@ -199,14 +203,24 @@ def main():
             masked["ok"] = False
         return torch.cuda.Stream(device=dev)
 
-    klt_torch_stream = make_stream(False)
-    # pose: one wave, 80 us.  On the tracker's partition it costs the loop less than next to the BA's launch chain
-    # (5670 vs 5375 frames/s measured); BENCH_POSE_PART=side|klt|all
     pose_part = os.environ.get("BENCH_POSE_PART", "klt")
+    pose_cus = int(os.environ.get("BENCH_POSE_CUS", "1"))
+    pose_from_klt = pose_cus if pose_part == "own" else 0        # own: pose_cus CUs carved off the tracker's range
+    pose_from_side = pose_cus if pose_part == "ownside" else 0   # ownside: carved off the BA's range
+    pose_first = (n_cus - side_cus - pose_cus) if pose_part == "own" else (n_cus - pose_cus)
+    klt_part = os.environ.get("BENCH_KLT_PART", "own")   # own: the complement of the side range; all: every CU
+    klt_torch_stream = torch.cuda.Stream(device=dev) if klt_part == "all" else make_stream(False)
+    # pose: one wave, 75 us.  It shares the tracker's partition: the tracker raises its wave priority (s_setprio), so
+    # the pose wave only gets the issue slots the mesh leaves free and costs the loop nothing (6266 vs 6284 frames/s
+    # without the BA leg).  BENCH_POSE_PART=klt|side|all|own|ownside (own*: BENCH_POSE_CUS CUs carved off the tracker's /
+    # the BA's range -- measured slower: an uneven CU count per shader engine unbalances the tracker's mesh, and the
+    # BA falls off a cliff below 64 CUs, tools/ba_partition.py)
     if args.serial:
         pose_torch_stream = klt_torch_stream
     elif pose_part == "all":
         pose_torch_stream = torch.cuda.Stream(device=dev)
+    elif pose_part in ("own", "ownside") and masked["ok"]:
+        pose_torch_stream = make_stream("pose")
     else:
         pose_torch_stream = make_stream(pose_part == "side")
     ba_torch_stream = klt_torch_stream if (args.sync_ba or args.serial) else make_stream(True)
@@ -223,7 +237,7 @@ def main():
     trk.allocate(W, H, LEVELS, FW, FH)
     trk.set_stream(stream)
     if side_cus > 0:
-        trk.set_cu_count(n_cus - side_cus)
+        trk.set_cu_count(n_cus if klt_part == "all" else n_cus - side_cus - pose_from_klt)
     if args.graphs and not args.no_graphs:
         trk.enable_graphs(True)
 

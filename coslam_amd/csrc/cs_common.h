@@ -116,6 +116,36 @@ __device__ __forceinline__ float cs_wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Four wave sums at once.  The 16-lane rows fold as above; the two cross-row steps use the gfx950 lane-swap
+// instructions on PAIRS of values (v_permlane16_swap exchanges the odd rows of one register with the even rows of
+// the other, v_permlane32_swap the upper half of one with the lower half of the other), so each step is one swap
+// and one add for two values instead of a masked move, an add and a re-zero for each.  The addition tree is the
+// same as cs_wave_sum's -- (r0 + r1) + (r2 + r3) -- hence the same bits.
+__device__ __forceinline__ float cs_row_sum(float v) {
+    v += cs_dpp_f<0xB1, 0xf>(v);
+    v += cs_dpp_f<0x4E, 0xf>(v);
+    v += cs_dpp_f<0x141, 0xf>(v);
+    v += cs_dpp_f<0x140, 0xf>(v);
+    return v;
+}
+__device__ __forceinline__ float cs_swap16_add(float x, float y) {  // rows: [x01, y01, x23, y23]
+    const auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(p[0]) + __uint_as_float(p[1]);
+}
+__device__ __forceinline__ float cs_swap32_add(float x, float y) {  // rows: [x0 + x2, x1 + x3, y0 + y2, y1 + y3]
+    const auto p = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(p[0]) + __uint_as_float(p[1]);
+}
+__device__ __forceinline__ void cs_wave_sum4(float& a, float& b, float& c, float& d) {
+    const float ab = cs_swap16_add(cs_row_sum(a), cs_row_sum(b));
+    const float cd = cs_swap16_add(cs_row_sum(c), cs_row_sum(d));
+    const int t = __float_as_int(cs_swap32_add(ab, cd));  // rows 0..3 hold the totals of a, b, c, d
+    a = __int_as_float(__builtin_amdgcn_readlane(t, 0));
+    b = __int_as_float(__builtin_amdgcn_readlane(t, 16));
+    c = __int_as_float(__builtin_amdgcn_readlane(t, 32));
+    d = __int_as_float(__builtin_amdgcn_readlane(t, 48));
+}
+
 __device__ __forceinline__ double cs_wave_sum_d(double v) {
     v += cs_dpp_d<0xB1, 0xf>(v);
     v += cs_dpp_d<0x4E, 0xf>(v);

@@ -274,15 +274,9 @@ __global__ __launch_bounds__(256) void k_track_gain_pass(CsGainPassArgs A) {
         r2s += -ex * I0 + A.lambda * m0 * (m1 - beta * m0);
         ssd += ex * ex;
     }
-    a = cs_wave_sum(a);
-    b = cs_wave_sum(b);
-    c = cs_wave_sum(c);
-    d = cs_wave_sum(d);
-    e_ = cs_wave_sum(e_);
+    cs_wave_sum4(a, b, c, d);
+    cs_wave_sum4(e_, r0, r1, r2s);
     f = cs_wave_sum(f);
-    r0 = cs_wave_sum(r0);
-    r1 = cs_wave_sum(r1);
-    r2s = cs_wave_sum(r2s);
     const float SSD = cs_wave_sum(ssd);
 
     const CsGainSolve S = cs_gain_solve_prepare(a, b, c, d, e_, f, r0, r1);
@@ -343,6 +337,9 @@ template <int NPL, bool PROBE = false>
 __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
     unsigned long long tTex = 0, tMath = 0, tPoll = 0, tPost = 0, nPoll = 0, nReload = 0, tStart = 0, tm0 = 0, tm1 = 0;
     if (PROBE) tStart = __builtin_amdgcn_s_memtime();
+    // the mesh advances at the pace of its slowest wave: win issue arbitration against any foreign wave (pose, BA)
+    // that lands on one of these SIMDs
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= A.N) return;
@@ -476,14 +473,8 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
             // flies under the ten wave folds and the adjugate and has landed when they are done.
             cs_granule got = gran_load(src);
             if (PROBE) ++nPoll;
-            a = cs_wave_sum(a);
-            b = cs_wave_sum(b);
-            c = cs_wave_sum(c);
-            d = cs_wave_sum(d);
-            e_ = cs_wave_sum(e_);
-            r0 = cs_wave_sum(r0);
-            r1 = cs_wave_sum(r1);
-            r2s = cs_wave_sum(r2s);
+            cs_wave_sum4(a, b, c, d);
+            cs_wave_sum4(e_, r0, r1, r2s);
             const float SSD = cs_wave_sum(ssd);
             const CsGainSolve S = cs_gain_solve_prepare(a, b, c, d, e_, f, r0, r1);
             // thresholds: v3d_gpuklt.cpp:271-279
