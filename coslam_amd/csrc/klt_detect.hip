@@ -299,11 +299,15 @@ __global__ __launch_bounds__(1024) void k_select_fill(CsSelectArgs Q, CsFillArgs
         A.counts[1] = (A.mode == 2) ? nTracked : 0;
         A.counts[2] = A.ctr[0];
         A.counts[3] = nSel;
+        A.ctr[0] = 0;  // every read of the candidate count is behind the barriers above
     }
+    if (A.zgran)
+        for (int i = tid; i < A.nGran; i += 1024) A.zgran[i] = 0ull;
 }
 
 // track() only: the tracked count (status >= 0 in dest[]), one workgroup
-__global__ __launch_bounds__(1024) void k_counts_track(const cs_klt_feature* __restrict__ dest, int N, int* counts) {
+__global__ __launch_bounds__(1024) void k_counts_track(const cs_klt_feature* __restrict__ dest, int N, int* counts, int* ctr,
+                                                       unsigned long long* zgran, int nGran) {
     __shared__ int part[1024];
     const int tid = threadIdx.x;
     int c = 0;
@@ -319,7 +323,10 @@ __global__ __launch_bounds__(1024) void k_counts_track(const cs_klt_feature* __r
         counts[1] = part[0];
         counts[2] = 0;
         counts[3] = 0;
+        if (ctr) ctr[0] = 0;
     }
+    if (zgran)
+        for (int i = tid; i < nGran; i += 1024) zgran[i] = 0ull;
 }
 
 }  // namespace
@@ -387,8 +394,9 @@ int cs_launch_select_fill(const CsCand* cand, int maxCand, int cap, int maxKeepF
     return CS_OK;
 }
 
-int cs_launch_counts_track(const cs_klt_feature* dest, int N, int* counts, hipStream_t stream) {
-    hipLaunchKernelGGL(k_counts_track, dim3(1), dim3(1024), 0, stream, dest, N, counts);
+int cs_launch_counts_track(const cs_klt_feature* dest, int N, int* counts, int* ctr, unsigned long long* zgran, int nGran,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(k_counts_track, dim3(1), dim3(1024), 0, stream, dest, N, counts, ctr, zgran, nGran);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

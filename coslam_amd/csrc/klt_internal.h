@@ -65,6 +65,10 @@ struct CsFillArgs {
     float* list_a;  // provide target 1 (buffer1)
     float* list_b;  // provide target 2 (buffer2, with gain only; may be null)
     int* counts;    // user-visible counts[4]
+    // the frame's last kernel leaves the hand-off granules and the candidate counter zeroed for the next frame, so a
+    // frame whose pyramid was prefetched (cs_klt_prefetch_dev) needs no zeroing launch of its own
+    unsigned long long* zgran;
+    int nGran;
 };
 
 int cs_launch_frame_front(const uint8_t* d_img, const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mode, float* corner_out,
@@ -85,4 +89,5 @@ int cs_launch_nonmax_compact(const float* in, int W, int H, int d, float* out, C
                              hipStream_t stream);
 int cs_launch_select_fill(const CsCand* cand, int maxCand, int cap, int maxKeepFixed, int* rankM, CsCand* sel,
                           const CsFillArgs& a, hipStream_t stream);
-int cs_launch_counts_track(const cs_klt_feature* dest, int N, int* counts, hipStream_t stream);
+int cs_launch_counts_track(const cs_klt_feature* dest, int N, int* counts, int* ctr, unsigned long long* zgran, int nGran,
+                           hipStream_t stream);

@@ -120,11 +120,18 @@ struct cs_klt {
     CsPyrLayout lay;
     hipStream_t own_stream, stream;
     uint8_t* d_img;
-    cs_texel* d_pyr[2];
-    int p0, p1;
+    cs_texel* d_pyr[3];  // [2]: target of cs_klt_prefetch_dev, allocated on first use
+    int p0, p1, p2;
     float* d_fb[3];
     int b0, b1, b2;
     float *d_corner_raw, *d_corner;
+    float* d_corner_raw_spare;  // prefetch target, swapped with d_corner_raw when the prefetched frame is consumed
+    // frame-front prefetch (cs_klt_prefetch_dev): the next frame's pyramid + cornerness map are built on front_stream
+    // beside this frame's detector tail
+    hipStream_t front_stream, own_front_stream;
+    hipEvent_t ev_front_done, ev_trk_done;
+    bool pf_ready, pf_valid;
+    const void* pf_img;
     CsCand *d_cand, *d_sel;
     int maxCand;
     int* d_rank;
@@ -355,15 +362,27 @@ static int enqueue_detect_tail(cs_klt* k, int mode, int nPresentGiven, int maxKe
     f.list_a = k->d_fb[k->b1];
     f.list_b = k->cfg.trackWithGain ? k->d_fb[k->b2] : nullptr;
     f.counts = d_counts;
+    f.zgran = k->d_gran;
+    f.nGran = 2 * k->N;
     return cs_launch_select_fill(k->d_cand, k->maxCand, k->plw * k->plh, maxKeepFixed, k->d_rank, k->d_sel, f, k->stream);
 }
 
 static int enqueue_track(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest, int* d_counts, bool forRedetect) {
     // pyramid (:858), the cornerness map the detector will need, and the zeroing of this frame's counters and
     // hand-off granules: two launches (klt_pyramid.hip)
-    int rc = cs_launch_frame_front(d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, forRedetect ? k->d_corner_raw : nullptr,
+    int rc = CS_OK;
+    if (k->pf_valid && k->pf_img == (const void*)d_img) {
+        // prefetched: the spare pyramid / cornerness buffers become this frame's, the ones they replace (last read two
+        // frames ago) become the next prefetch's targets.  Counters and granules were zeroed by the previous frame's tail.
+        std::swap(k->p1, k->p2);
+        std::swap(k->d_corner_raw, k->d_corner_raw_spare);
+        CS_HIP(hipStreamWaitEvent(k->stream, k->ev_front_done, 0));
+    } else {
+        rc = cs_launch_frame_front(d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, forRedetect ? k->d_corner_raw : nullptr,
                                    k->cfg.minCornerness, k->detMargin, k->d_ctr, k->d_gran, 2 * k->N, k->stream);
-    if (rc) return rc;
+        if (rc) return rc;
+    }
+    k->pf_valid = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (k->profiling) {
         CS_HIP(hipEventCreate(&e0));
@@ -377,12 +396,19 @@ static int enqueue_track(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest
         CS_HIP(hipEventRecord(e1, k->stream));
         k->ev_pairs->push_back(std::make_pair(e0, e1));
     }
+    if (k->pf_ready) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(k->stream, &cap);
+        if (cap == hipStreamCaptureStatusNone) CS_HIP(hipEventRecord(k->ev_trk_done, k->stream));
+    }
     if (!postFused) {
         rc = cs_launch_post_track(read_buffer(k), k->N, d_dest, k->d_ctr, k->d_corner_raw, k->W, k->H,
                                   forRedetect ? 1 : 0, k->stream);
         if (rc) return rc;
     }
-    if (!forRedetect) rc = cs_launch_counts_track(d_dest, k->N, d_counts, k->stream);
+    if (!forRedetect) {
+        rc = cs_launch_counts_track(d_dest, k->N, d_counts, k->d_ctr, k->d_gran, 2 * k->N, k->stream);
+    }
     return rc;
 }
 
@@ -393,6 +419,7 @@ static int enqueue_redetect(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_d
 }
 
 static int enqueue_detect(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest, int* d_counts, int nPresent) {
+    k->pf_valid = false;
     int rc = cs_launch_frame_front(d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, k->d_corner_raw, k->cfg.minCornerness,
                                    k->detMargin, k->d_ctr, nullptr, 0, k->stream);
     if (rc) return rc;
@@ -485,6 +512,21 @@ int cs_klt_deallocate(cs_klt* k) {
     hipFree(k->d_img);
     hipFree(k->d_pyr[0]);
     hipFree(k->d_pyr[1]);
+    if (k->pf_ready) {
+        (void)hipStreamSynchronize(k->front_stream);
+        (void)hipEventDestroy(k->ev_front_done);
+        (void)hipEventDestroy(k->ev_trk_done);
+        if (k->own_front_stream) {
+            if (k->front_stream == k->own_front_stream) k->front_stream = nullptr;
+            (void)hipStreamDestroy(k->own_front_stream);
+        }
+        k->own_front_stream = nullptr;
+        k->pf_ready = k->pf_valid = false;
+    }
+    if (k->d_pyr[2]) hipFree(k->d_pyr[2]);
+    k->d_pyr[2] = nullptr;
+    if (k->d_corner_raw_spare) hipFree(k->d_corner_raw_spare);
+    k->d_corner_raw_spare = nullptr;
     for (int i = 0; i < 3; ++i) hipFree(k->d_fb[i]);
     hipFree(k->d_corner_raw);
     hipFree(k->d_corner);
@@ -554,6 +596,11 @@ int cs_klt_allocate(cs_klt* k, int W, int H, int nLevels, int fw, int fh, int pl
     k->lay = cs_make_layout(W, H, nLevels);
     k->p0 = 0;
     k->p1 = 1;
+    k->p2 = 2;
+    k->d_pyr[2] = nullptr;
+    k->d_corner_raw_spare = nullptr;
+    k->pf_ready = k->pf_valid = false;
+    k->pf_img = nullptr;
     k->b0 = 0;
     k->b1 = 1;
     k->b2 = 2;
@@ -813,6 +860,48 @@ int cs_klt_enable_graphs(cs_klt* k, int on) {
         CS_HIP(hipStreamSynchronize(k->stream));
         drop_graphs(k);
     }
+    return CS_OK;
+}
+
+// Frame-front prefetch.  The pyramid and cornerness map of the NEXT frame depend only on its image, so they can be built
+// (on a second stream, into a third pyramid buffer and a second cornerness map) beside the current frame's detector
+// tail; the next cs_klt_redetect_dev / cs_klt_track_dev called with the same image pointer then starts at the tracker.
+// Results are identical with and without the call; a prefetch that is never consumed is harmless.
+int cs_klt_set_prefetch_stream(cs_klt* k, void* s) {
+    CS_REQUIRE(k, "null handle");
+    k->front_stream = (hipStream_t)s;
+    return CS_OK;
+}
+
+int cs_klt_prefetch_dev(cs_klt* k, const void* d_image) {
+    CS_REQUIRE(k && k->allocated && d_image, "cs_klt_prefetch_dev: bad arguments");
+    if (k->use_graphs) return CS_OK;  // the captured schedule has its front inside
+    int rc = bind_device(k);
+    if (rc) return rc;
+    if (!k->pf_ready) {
+        CS_HIP(hipMalloc((void**)&k->d_pyr[2], k->lay.texels * sizeof(cs_texel)));
+        CS_HIP(hipMalloc((void**)&k->d_corner_raw_spare, sizeof(float) * (size_t)k->W * k->H));
+        if (!k->front_stream) {
+            CS_HIP(hipStreamCreateWithFlags(&k->own_front_stream, hipStreamNonBlocking));
+            k->front_stream = k->own_front_stream;
+        }
+        CS_HIP(hipEventCreateWithFlags(&k->ev_front_done, hipEventDisableTiming));
+        CS_HIP(hipEventCreateWithFlags(&k->ev_trk_done, hipEventDisableTiming));
+        CS_HIP(hipMemsetAsync(k->d_pyr[2], 0, k->lay.texels * sizeof(cs_texel), k->front_stream));
+        k->pf_ready = true;
+    }
+    // Start behind the latest tracker, next to that frame's detector tail.  The tail is two small launches (non-max
+    // compaction, then ONE workgroup of selection + slot fill) that leave the chip idle, so the front fits beside them;
+    // beside the persistent tracker it does not -- measured: tracker 109 -> 160 us and the front kernels 4-6x slower
+    // when they truly share the CUs.  The spare buffers' last readers (the tracker / non-max of the frame before) are
+    // older than that tracker.
+    CS_HIP(hipStreamWaitEvent(k->front_stream, k->ev_trk_done, 0));
+    rc = cs_launch_frame_front((const uint8_t*)d_image, k->lay, k->d_pyr[k->p2], k->tap_mode, k->d_corner_raw_spare,
+                               k->cfg.minCornerness, k->detMargin, nullptr, nullptr, 0, k->front_stream);
+    if (rc) return rc;
+    CS_HIP(hipEventRecord(k->ev_front_done, k->front_stream));
+    k->pf_img = d_image;
+    k->pf_valid = true;
     return CS_OK;
 }
 

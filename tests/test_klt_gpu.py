@@ -292,6 +292,47 @@ def test_graph_replay_matches_eager(hip):
         assert np.array_equal(fa["pos"][live], fb["pos"][live])
 
 
+@pytest.mark.parametrize("levels", [4, 6])
+def test_frame_front_prefetch_matches_unprefetched(hip, levels):
+    """cs_klt_prefetch_dev (next frame's pyramid + cornerness built under this frame's tracker, third pyramid buffer,
+    second cornerness map) gives the unprefetched results bit for bit -- also when a prefetch goes unused, when
+    track-only frames and a feed sit in between, and with no host synchronisation between frames."""
+    import torch
+
+    W, H, fw, fh = 640, 480, 50, 40
+    sc = Scene(1, W, H, 4000, seed=52)
+    cfg = cfg2(nLevels=levels)
+    dev = torch.device("cuda:0")
+    frames = [torch.from_numpy(sc.render(0, f % 9)).to(dev) for f in range(9)]
+    n_steps = 16
+    plan = ["detect"] + ["redetect"] * 6 + ["track", "track"] + ["redetect"] * 7
+    res = []
+    for prefetch in (False, True):
+        t = coslam_amd.KLT_SequenceTracker(cfg, 0)
+        t.allocate(W, H, levels, fw, fh)
+        t.set_stream(torch.cuda.current_stream().cuda_stream)
+        d_dests = [torch.zeros(fw * fh * 5, dtype=torch.int32, device=dev) for _ in range(n_steps)]
+        d_counts = [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(n_steps)]
+        for f in range(n_steps):
+            img = frames[f % 9]
+            fn = {"detect": t.detect_dev, "redetect": t.redetect_dev, "track": t.track_dev}[plan[f]]
+            fn(img.data_ptr(), d_dests[f].data_ptr(), d_counts[f].data_ptr())
+            t.advanceFrame()
+            if prefetch and f + 1 < n_steps:
+                # f == 4: prefetch the WRONG image -- must be ignored by the next call
+                t.prefetch_dev(frames[(f + 1 + (3 if f == 4 else 0)) % 9].data_ptr())
+        torch.cuda.synchronize()
+        res.append([(d.cpu().numpy().copy(), c.cpu().numpy().copy()) for d, c in zip(d_dests, d_counts)])
+        t.close()
+    for f, ((da, ca), (db, cb)) in enumerate(zip(*res)):
+        assert np.array_equal(ca, cb), f
+        fa, fb = da.view(coslam_amd.KLT_TrackedFeature), db.view(coslam_amd.KLT_TrackedFeature)
+        assert np.array_equal(fa["status"], fb["status"]), f
+        live = fa["status"] >= 0
+        assert np.array_equal(fa["pos"][live], fb["pos"][live]), f
+        assert np.array_equal(fa["gain"][live], fb["gain"][live]), f
+
+
 @pytest.mark.parametrize("levels,skip,iters,win,grid", [(4, 1, 10, 7, (50, 40)), (6, 2, 12, 6, (32, 32)), (3, 1, 1, 7, (20, 15)),
                                                        (3, 1, 3, 11, (20, 20)), (2, 1, 5, 7, (7, 5))])
 def test_persistent_gain_tracker_is_bit_identical_to_per_pass_launches(hip, levels, skip, iters, win, grid):
