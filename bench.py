@@ -210,8 +210,6 @@ def main():
     pose_first = (n_cus - side_cus - pose_cus) if pose_part == "own" else (n_cus - pose_cus)
     klt_part = os.environ.get("BENCH_KLT_PART", "own")   # own: the complement of the side range; all: every CU
     klt_torch_stream = torch.cuda.Stream(device=dev) if klt_part == "all" else make_stream(False)
-    # created right behind the tracker's stream: the LAST-created CU-masked stream is serviced worst (see below)
-    early_front = make_stream(False) if os.environ.get("BENCH_PREFETCH", "0") == "1" and klt_part != "all" else None
     # pose: one wave, 75 us.  It shares the tracker's partition: the tracker raises its wave priority (s_setprio), so
     # the pose wave only gets the issue slots the mesh leaves free and costs the loop nothing (6266 vs 6284 frames/s
     # without the BA leg).  BENCH_POSE_PART=klt|side|all|own|ownside (own*: BENCH_POSE_CUS CUs carved off the tracker's /
@@ -242,25 +240,11 @@ def main():
         trk.set_cu_count(n_cus if klt_part == "all" else n_cus - side_cus - pose_from_klt)
     if args.graphs and not args.no_graphs:
         trk.enable_graphs(True)
-    # Frame-front prefetch (cs_klt_prefetch_dev: the next frame's pyramid + cornerness map built beside this frame's
-    # detector tail) is OFF by default.  Measured on the partitioned loop (us/frame, BENCH_PREFETCH=1): tracker only
-    # 159.6 -> 155.6, with pose 155.7, but with the BA stream as well 167.9 -> 178-185: a fourth concurrently active
-    # CU-masked queue is serviced badly (whichever stream was created last: its kernels run 3-6x longer, and when it is
-    # the prefetch stream the tracker itself goes 109 -> 180 us).  Without the partition (plain streams) it gains
-    # 141.5 -> 135.6 us/frame, but that configuration loses more to the BA sharing the tracker's CUs.
-    prefetch = os.environ.get("BENCH_PREFETCH", "0") == "1" and not args.graphs and not args.serial
-    front_torch_stream = None
-    if prefetch:
-        front_part = os.environ.get("BENCH_FRONT_PART", "klt")
-        if front_part == "all" or klt_part == "all":
-            front_torch_stream = torch.cuda.Stream(device=dev)
-        elif front_part == "pose":
-            front_torch_stream = pose_torch_stream
-        elif early_front is not None:
-            front_torch_stream = early_front
-        else:
-            front_torch_stream = make_stream(front_part == "side")
-        trk.set_prefetch_stream(front_torch_stream.cuda_stream)
+    # Frame-front prefetch (cs_klt_prefetch_dev): this frame's detector tail -- two small launches that leave the chip
+    # mostly idle -- also builds the next frame's pyramid + cornerness map (horizontal fusion in the same launches).
+    # (A second stream for the front was tried first: a fourth concurrently active CU-masked queue is serviced badly --
+    # whichever masked stream was created last runs its kernels 3-6x longer -- 167.9 -> 178-185 us/frame.)
+    prefetch = os.environ.get("BENCH_PREFETCH", "1") != "0" and not args.graphs
 
     P = len(ba["pts0"])
     import numpy as _np
@@ -288,10 +272,10 @@ def main():
             trace.append((i, "start", time.perf_counter()))
         if i >= 2 and not os.environ.get("BENCH_NO_DESTFREE"):
             klt_torch_stream.wait_event(dest_free[b])      # the consumer of this dest buffer two frames ago is done
+        if prefetch:   # this frame's detector tail also builds the next frame's pyramid + cornerness map
+            trk.prefetch_dev(d_frames[order[(i + 1) % len(order)]].data_ptr())
         trk.redetect_dev(d_frames[f].data_ptr(), d_dests[b].data_ptr(), d_counts.data_ptr())
         trk.advanceFrame()
-        if prefetch:   # the next frame's pyramid + cornerness map are built under this frame's tracker
-            trk.prefetch_dev(d_frames[order[(i + 1) % len(order)]].data_ptr())
         klt_done[b].record(klt_torch_stream)
         if trace is not None:
             trace.append((i, "klt", time.perf_counter()))
@@ -356,10 +340,10 @@ def main():
         n_prof = min(args.steps, 100)
         for i in range(n_prof):
             f = order[(args.warmup + args.steps + i + 1) % len(order)]
+            if prefetch:
+                trk.prefetch_dev(d_frames[order[(args.warmup + args.steps + i + 2) % len(order)]].data_ptr())
             trk.redetect_dev(d_frames[f].data_ptr(), d_dest.data_ptr(), d_counts.data_ptr())
             trk.advanceFrame()
-            if prefetch:  # same overlap as in the timed loop: the tracker is timed WITH the next frame's front beside it
-                trk.prefetch_dev(d_frames[order[(args.warmup + args.steps + i + 2) % len(order)]].data_ptr())
         prof = trk.get_profile()
         trk.set_profiling(False)
         hw = 7 // 2

@@ -17,7 +17,7 @@
 //                     top-K is by cornerness), then a scan over the dead slots writes dest[] and the next feature list.
 // Nothing is read back mid-frame; the counts the reference reads with glReadPixels stay in HBM and
 // kernels that depend on them early-exit on the device value.
-#include "klt_internal.h"
+#include "klt_front_dev.h"
 
 #pragma clang fp contract(off)
 
@@ -76,14 +76,26 @@ __device__ __forceinline__ unsigned part1by1(unsigned v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_nonmax_compact(const float* __restrict__ in, int W, int H, int d,
-                                                        float* __restrict__ out, CsCand* __restrict__ cand,
-                                                        int maxCand, int* ctr) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+struct CsNonmaxArgs {
+    const float* in;
+    int W, H, d;
+    float* out;
+    CsCand* cand;
+    int maxCand;
+    int* ctr;
+};
+
+// one workgroup (256 threads) of the non-max + compaction stage: tile (bx, by)
+__device__ __forceinline__ void nonmax_body(const CsNonmaxArgs& Z, int bx, int by, int tid, float* smem) {
+    const float* __restrict__ in = Z.in;
+    float* __restrict__ out = Z.out;
+    CsCand* __restrict__ cand = Z.cand;
+    int* ctr = Z.ctr;
+    const int W = Z.W, H = Z.H, d = Z.d, maxCand = Z.maxCand;
     const int RW = NTW + 2 * d, RH = NTH + 2 * d;
     float* raw = smem;              // [RH][RW]
     float* rowres = smem + RH * RW;  // [RH][NTW]
-    const int x0 = blockIdx.x * NTW, y0 = blockIdx.y * NTH, tid = threadIdx.x;
+    const int x0 = bx * NTW, y0 = by * NTH;
     for (int i = tid; i < RH * RW; i += 256) {
         int ly = i / RW, lx = i - ly * RW;
         int gx = cs_clampi(x0 + lx - d, 0, W - 1), gy = cs_clampi(y0 + ly - d, 0, H - 1);
@@ -136,6 +148,11 @@ __global__ __launch_bounds__(256) void k_nonmax_compact(const float* __restrict_
     }
 }
 
+__global__ __launch_bounds__(256) void k_nonmax_compact(CsNonmaxArgs Z) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    nonmax_body(Z, blockIdx.x, blockIdx.y, threadIdx.x, smem);
+}
+
 // ------------------------------------------------------------------ ordering, selection and slot fill
 // One workgroup does what the reference does on the CPU after its read-backs (v3d_gpuklt.cpp:650-805): order the
 // candidates (HistoPyramid order == Morton order of the pixel), keep the most distinctive ones when there are more
@@ -149,7 +166,8 @@ struct CsSelectArgs {
     CsCand* sel;
 };
 
-__global__ __launch_bounds__(1024) void k_select_fill(CsSelectArgs Q, CsFillArgs A) {
+// one workgroup of 1024 threads
+__device__ __forceinline__ void select_fill_body(const CsSelectArgs& Q, const CsFillArgs& A) {
     __shared__ float cs[1024];
     __shared__ unsigned ks[1024];
     __shared__ int rs[1024];
@@ -305,6 +323,51 @@ __global__ __launch_bounds__(1024) void k_select_fill(CsSelectArgs Q, CsFillArgs
         for (int i = tid; i < A.nGran; i += 1024) A.zgran[i] = 0ull;
 }
 
+__global__ __launch_bounds__(1024) void k_select_fill(CsSelectArgs Q, CsFillArgs A) { select_fill_body(Q, A); }
+
+// ---- detector tail fused with the NEXT frame's front (cs_klt_prefetch_dev) ---------------------------------------
+// The tail is two small dependent launches that leave most of the chip idle (non-max: 300 workgroups; selection + slot
+// fill: ONE workgroup), and the next frame's pyramid depends only on its image.  Horizontal fusion puts the two
+// independent jobs into the same launches -- no second stream, no events:
+//   k_tail_nonmax_level0   workgroups [0, nA): non-max + compaction of THIS frame; [nA, nA + nB): level 0 + cornerness
+//                          map of the NEXT image (into the spare pyramid / cornerness buffers);
+//   k_tail_select_down     workgroup 0: selection + slot fill of THIS frame; every other workgroup: four 256-thread
+//                          groups, each one tile of the fused levels 1..3 of the NEXT pyramid.
+struct CsLevel0Args {
+    const uint8_t* img;
+    int W, H;
+    cs_texel* out;
+    float* corner;
+    float minCornerness, lox, loy, hix, hiy;
+    int nbx, nby;
+};
+
+__global__ __launch_bounds__(256) void k_tail_nonmax_level0(CsNonmaxArgs Z, int nax, int nA, CsLevel0Args Y) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    if (b < nA) {
+        nonmax_body(Z, b % nax, b / nax, threadIdx.x, smem);
+    } else {
+        const int q = b - nA;
+        cs_level0_body<true>(Y.img, Y.W, Y.H, Y.out, Y.corner, Y.minCornerness, Y.lox, Y.loy, Y.hix, Y.hiy, nullptr, nullptr,
+                             0, q % Y.nbx, q / Y.nbx, Y.nbx, Y.nby, threadIdx.x, *(CsLevel0Lds<true>*)smem);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_tail_select_down(CsSelectArgs Q, CsFillArgs A, cs_texel* pyr, CsDownFused F,
+                                                           int ntx, int nty) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char down_smem[];
+    if (blockIdx.x == 0) {
+        select_fill_body(Q, A);
+        return;
+    }
+    const int grp = threadIdx.x >> 8;
+    const int t = (blockIdx.x - 1) * 4 + grp;
+    const bool valid = t < ntx * nty;
+    cs_texel* reg = (cs_texel*)down_smem + (size_t)grp * (F.cap1 + F.cap2);
+    cs_down_body(pyr, F, valid ? t % ntx : 0, valid ? t / ntx : 0, threadIdx.x & 255, reg, valid);
+}
+
 // track() only: the tracked count (status >= 0 in dest[]), one workgroup
 __global__ __launch_bounds__(1024) void k_counts_track(const cs_klt_feature* __restrict__ dest, int N, int* counts, int* ctr,
                                                        unsigned long long* zgran, int nGran) {
@@ -362,7 +425,8 @@ int cs_launch_nonmax_compact(const float* in, int W, int H, int d, float* out, C
         return CS_ERR_INVALID;
     }
     dim3 grid((W + NTW - 1) / NTW, (H + NTH - 1) / NTH);
-    hipLaunchKernelGGL(k_nonmax_compact, grid, dim3(256), lds, stream, in, W, H, d, out, cand, maxCand, ctr);
+    CsNonmaxArgs Z = {in, W, H, d, out, cand, maxCand, ctr};
+    hipLaunchKernelGGL(k_nonmax_compact, grid, dim3(256), lds, stream, Z);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }
@@ -397,6 +461,58 @@ int cs_launch_select_fill(const CsCand* cand, int maxCand, int cap, int maxKeepF
 int cs_launch_counts_track(const cs_klt_feature* dest, int N, int* counts, int* ctr, unsigned long long* zgran, int nGran,
                            hipStream_t stream) {
     hipLaunchKernelGGL(k_counts_track, dim3(1), dim3(1024), 0, stream, dest, N, counts, ctr, zgran, nGran);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+// detector tail of THIS frame + frame front of the NEXT image in two launches (see k_tail_* above)
+int cs_launch_tail_with_next_front(const float* in, int W, int H, int d, float* out, const CsCand* candc, int maxCand,
+                                   int cap, int maxKeepFixed, int* rankM, CsCand* sel, const CsFillArgs& a,
+                                   const uint8_t* d_img_next, const CsPyrLayout& lay, cs_texel* d_pyr_next, int tap_mode,
+                                   float* corner_next, float minCornerness, float margin, hipStream_t stream) {
+    CsCand* cand = const_cast<CsCand*>(candc);
+    size_t ldsA = cs_nonmax_lds_bytes(d);
+    if (ldsA < sizeof(CsLevel0Lds<true>)) ldsA = sizeof(CsLevel0Lds<true>);
+    if (ldsA > 64 * 1024) {
+        cs_set_error("fused detector tail: minDistance %d needs %zu B of LDS", d, ldsA);
+        return CS_ERR_INVALID;
+    }
+    CsNonmaxArgs Z = {in, W, H, d, out, cand, maxCand, a.ctr};
+    const int nax = (W + NTW - 1) / NTW, nay = (H + NTH - 1) / NTH;
+    CsLevel0Args Y;
+    Y.img = d_img_next;
+    Y.W = W;
+    Y.H = H;
+    Y.out = d_pyr_next + lay.off[0];
+    Y.corner = corner_next;
+    Y.minCornerness = minCornerness;
+    Y.lox = margin / (float)W;
+    Y.loy = margin / (float)H;
+    Y.hix = 1.0f - margin / (float)W;
+    Y.hiy = 1.0f - margin / (float)H;
+    Y.nbx = (W + FTW - 1) / FTW;
+    Y.nby = (H + FTH - 1) / FTH;
+    hipLaunchKernelGGL(k_tail_nonmax_level0, dim3(nax * nay + Y.nbx * Y.nby), dim3(256), ldsA, stream, Z, nax, nax * nay, Y);
+    CsSelectArgs q;
+    q.cand = cand;
+    q.maxCand = maxCand;
+    q.cap = cap;
+    q.maxKeepFixed = maxKeepFixed;
+    q.rankM = rankM;
+    q.sel = sel;
+    if (lay.L >= 2) {
+        CsDownFused F;
+        int ntx, nty;
+        size_t lds;
+        int rc = cs_down_fused_plan(lay, tap_mode, &F, &ntx, &nty, &lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_tail_select_down, dim3(1 + (ntx * nty + 3) / 4), dim3(1024), 4 * lds, stream, q, a, d_pyr_next, F,
+                           ntx, nty);
+        rc = cs_launch_pyr_down_from(lay, d_pyr_next, tap_mode, F.NL + 1, stream);
+        if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(k_select_fill, dim3(1), dim3(1024), 0, stream, q, a);
+    }
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

@@ -74,6 +74,12 @@ struct CsFillArgs {
 int cs_launch_frame_front(const uint8_t* d_img, const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mode, float* corner_out,
                           float minCornerness, float margin, int* ctr, unsigned long long* gran, int nGran,
                           hipStream_t stream);
+size_t cs_nonmax_lds_bytes(int d);
+int cs_launch_pyr_down_from(const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mode, int first, hipStream_t stream);
+int cs_launch_tail_with_next_front(const float* in, int W, int H, int d, float* out, const CsCand* cand, int maxCand, int cap,
+                                   int maxKeepFixed, int* rankM, CsCand* sel, const CsFillArgs& a, const uint8_t* d_img_next,
+                                   const CsPyrLayout& lay, cs_texel* d_pyr_next, int tap_mode, float* corner_next,
+                                   float minCornerness, float margin, hipStream_t stream);
 int cs_launch_track_nogain(const cs_texel* pyr0, const cs_texel* pyr1, const CsPyrLayout& lay, int levelSkip, int hw,
                            int nIterShader, float margin, float convThr, float ssdThr, int N, const float* featIn,
                            float* featOut, hipStream_t stream);

@@ -126,12 +126,11 @@ struct cs_klt {
     int b0, b1, b2;
     float *d_corner_raw, *d_corner;
     float* d_corner_raw_spare;  // prefetch target, swapped with d_corner_raw when the prefetched frame is consumed
-    // frame-front prefetch (cs_klt_prefetch_dev): the next frame's pyramid + cornerness map are built on front_stream
-    // beside this frame's detector tail
-    hipStream_t front_stream, own_front_stream;
-    hipEvent_t ev_front_done, ev_trk_done;
-    bool pf_ready, pf_valid;
-    const void* pf_img;
+    // frame-front prefetch (cs_klt_prefetch_dev): the next frame's pyramid + cornerness map are built by the SAME two
+    // launches as this frame's detector tail (horizontal fusion, klt_detect.hip)
+    const void* pf_next_img;  // request: image the next redetect's tail should build the front of
+    const void* pf_img;       // image whose front sits in d_pyr[p2] / d_corner_raw_spare
+    bool pf_valid;
     CsCand *d_cand, *d_sel;
     int maxCand;
     int* d_rank;
@@ -346,9 +345,20 @@ static int enqueue_tracker(cs_klt* k, cs_klt_feature* postDest, int doSuppress, 
 
 static int enqueue_detect_tail(cs_klt* k, int mode, int nPresentGiven, int maxKeepFixed, cs_klt_feature* d_dest,
                                int* d_counts) {
-    int rc = cs_launch_nonmax_compact(k->d_corner_raw, k->W, k->H, k->cfg.minDistance, k->d_corner, k->d_cand,
-                                      k->maxCand, k->d_ctr, k->stream);
-    if (rc) return rc;
+    // a pending cs_klt_prefetch_dev request rides in the tail's two launches; inside a graph capture it is dropped
+    const uint8_t* next = (const uint8_t*)k->pf_next_img;
+    k->pf_next_img = nullptr;
+    if (next) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(k->stream, &cap);
+        if (cap != hipStreamCaptureStatusNone || cs_nonmax_lds_bytes(k->cfg.minDistance) > 64 * 1024) next = nullptr;
+    }
+    int rc = CS_OK;
+    if (!next) {
+        rc = cs_launch_nonmax_compact(k->d_corner_raw, k->W, k->H, k->cfg.minDistance, k->d_corner, k->d_cand, k->maxCand,
+                                      k->d_ctr, k->stream);
+        if (rc) return rc;
+    }
     CsFillArgs f;
     f.mode = mode;
     f.N = k->N;
@@ -364,6 +374,18 @@ static int enqueue_detect_tail(cs_klt* k, int mode, int nPresentGiven, int maxKe
     f.counts = d_counts;
     f.zgran = k->d_gran;
     f.nGran = 2 * k->N;
+    if (next) {
+        // spare buffers: last read by the tracker / non-max of the frame BEFORE this one -- older than this point of
+        // the stream
+        rc = cs_launch_tail_with_next_front(k->d_corner_raw, k->W, k->H, k->cfg.minDistance, k->d_corner, k->d_cand,
+                                            k->maxCand, k->plw * k->plh, maxKeepFixed, k->d_rank, k->d_sel, f, next, k->lay,
+                                            k->d_pyr[k->p2], k->tap_mode, k->d_corner_raw_spare, k->cfg.minCornerness,
+                                            k->detMargin, k->stream);
+        if (rc) return rc;
+        k->pf_img = next;
+        k->pf_valid = true;
+        return CS_OK;
+    }
     return cs_launch_select_fill(k->d_cand, k->maxCand, k->plw * k->plh, maxKeepFixed, k->d_rank, k->d_sel, f, k->stream);
 }
 
@@ -376,7 +398,6 @@ static int enqueue_track(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest
         // frames ago) become the next prefetch's targets.  Counters and granules were zeroed by the previous frame's tail.
         std::swap(k->p1, k->p2);
         std::swap(k->d_corner_raw, k->d_corner_raw_spare);
-        CS_HIP(hipStreamWaitEvent(k->stream, k->ev_front_done, 0));
     } else {
         rc = cs_launch_frame_front(d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, forRedetect ? k->d_corner_raw : nullptr,
                                    k->cfg.minCornerness, k->detMargin, k->d_ctr, k->d_gran, 2 * k->N, k->stream);
@@ -396,17 +417,13 @@ static int enqueue_track(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest
         CS_HIP(hipEventRecord(e1, k->stream));
         k->ev_pairs->push_back(std::make_pair(e0, e1));
     }
-    if (k->pf_ready) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(k->stream, &cap);
-        if (cap == hipStreamCaptureStatusNone) CS_HIP(hipEventRecord(k->ev_trk_done, k->stream));
-    }
     if (!postFused) {
         rc = cs_launch_post_track(read_buffer(k), k->N, d_dest, k->d_ctr, k->d_corner_raw, k->W, k->H,
                                   forRedetect ? 1 : 0, k->stream);
         if (rc) return rc;
     }
     if (!forRedetect) {
+        k->pf_next_img = nullptr;  // no detector tail to carry the next front: the request lapses
         rc = cs_launch_counts_track(d_dest, k->N, d_counts, k->d_ctr, k->d_gran, 2 * k->N, k->stream);
     }
     return rc;
@@ -512,17 +529,6 @@ int cs_klt_deallocate(cs_klt* k) {
     hipFree(k->d_img);
     hipFree(k->d_pyr[0]);
     hipFree(k->d_pyr[1]);
-    if (k->pf_ready) {
-        (void)hipStreamSynchronize(k->front_stream);
-        (void)hipEventDestroy(k->ev_front_done);
-        (void)hipEventDestroy(k->ev_trk_done);
-        if (k->own_front_stream) {
-            if (k->front_stream == k->own_front_stream) k->front_stream = nullptr;
-            (void)hipStreamDestroy(k->own_front_stream);
-        }
-        k->own_front_stream = nullptr;
-        k->pf_ready = k->pf_valid = false;
-    }
     if (k->d_pyr[2]) hipFree(k->d_pyr[2]);
     k->d_pyr[2] = nullptr;
     if (k->d_corner_raw_spare) hipFree(k->d_corner_raw_spare);
@@ -599,8 +605,8 @@ int cs_klt_allocate(cs_klt* k, int W, int H, int nLevels, int fw, int fh, int pl
     k->p2 = 2;
     k->d_pyr[2] = nullptr;
     k->d_corner_raw_spare = nullptr;
-    k->pf_ready = k->pf_valid = false;
-    k->pf_img = nullptr;
+    k->pf_valid = false;
+    k->pf_img = k->pf_next_img = nullptr;
     k->b0 = 0;
     k->b1 = 1;
     k->b2 = 2;
@@ -863,45 +869,26 @@ int cs_klt_enable_graphs(cs_klt* k, int on) {
     return CS_OK;
 }
 
-// Frame-front prefetch.  The pyramid and cornerness map of the NEXT frame depend only on its image, so they can be built
-// (on a second stream, into a third pyramid buffer and a second cornerness map) beside the current frame's detector
-// tail; the next cs_klt_redetect_dev / cs_klt_track_dev called with the same image pointer then starts at the tracker.
-// Results are identical with and without the call; a prefetch that is never consumed is harmless.
-int cs_klt_set_prefetch_stream(cs_klt* k, void* s) {
-    CS_REQUIRE(k, "null handle");
-    k->front_stream = (hipStream_t)s;
-    return CS_OK;
-}
-
-int cs_klt_prefetch_dev(cs_klt* k, const void* d_image) {
-    CS_REQUIRE(k && k->allocated && d_image, "cs_klt_prefetch_dev: bad arguments");
-    if (k->use_graphs) return CS_OK;  // the captured schedule has its front inside
+// Frame-front prefetch.  The pyramid and cornerness map of the NEXT frame depend only on its image, so the detector
+// tail of the CURRENT frame (two small launches that leave the chip mostly idle) can build them on the side: call
+// cs_klt_prefetch_dev(next image) BEFORE the cs_klt_redetect_dev / cs_klt_detect_dev of the current frame; that call's
+// tail then carries the next front in the same two launches (third pyramid buffer, second cornerness map), and the
+// cs_klt_redetect_dev / cs_klt_track_dev that follows with the same image pointer starts at the tracker.
+// Results are identical with and without; an unconsumed or mismatched prefetch is ignored.
+int cs_klt_prefetch_dev(cs_klt* k, const void* d_image_next) {
+    CS_REQUIRE(k && k->allocated, "cs_klt_prefetch_dev: not allocated");
+    if (k->use_graphs || !d_image_next) {  // the captured schedule has its front inside
+        k->pf_next_img = nullptr;
+        return CS_OK;
+    }
     int rc = bind_device(k);
     if (rc) return rc;
-    if (!k->pf_ready) {
+    if (!k->d_pyr[2]) {
         CS_HIP(hipMalloc((void**)&k->d_pyr[2], k->lay.texels * sizeof(cs_texel)));
         CS_HIP(hipMalloc((void**)&k->d_corner_raw_spare, sizeof(float) * (size_t)k->W * k->H));
-        if (!k->front_stream) {
-            CS_HIP(hipStreamCreateWithFlags(&k->own_front_stream, hipStreamNonBlocking));
-            k->front_stream = k->own_front_stream;
-        }
-        CS_HIP(hipEventCreateWithFlags(&k->ev_front_done, hipEventDisableTiming));
-        CS_HIP(hipEventCreateWithFlags(&k->ev_trk_done, hipEventDisableTiming));
-        CS_HIP(hipMemsetAsync(k->d_pyr[2], 0, k->lay.texels * sizeof(cs_texel), k->front_stream));
-        k->pf_ready = true;
+        CS_HIP(hipMemsetAsync(k->d_pyr[2], 0, k->lay.texels * sizeof(cs_texel), k->stream));
     }
-    // Start behind the latest tracker, next to that frame's detector tail.  The tail is two small launches (non-max
-    // compaction, then ONE workgroup of selection + slot fill) that leave the chip idle, so the front fits beside them;
-    // beside the persistent tracker it does not -- measured: tracker 109 -> 160 us and the front kernels 4-6x slower
-    // when they truly share the CUs.  The spare buffers' last readers (the tracker / non-max of the frame before) are
-    // older than that tracker.
-    CS_HIP(hipStreamWaitEvent(k->front_stream, k->ev_trk_done, 0));
-    rc = cs_launch_frame_front((const uint8_t*)d_image, k->lay, k->d_pyr[k->p2], k->tap_mode, k->d_corner_raw_spare,
-                               k->cfg.minCornerness, k->detMargin, nullptr, nullptr, 0, k->front_stream);
-    if (rc) return rc;
-    CS_HIP(hipEventRecord(k->ev_front_done, k->front_stream));
-    k->pf_img = d_image;
-    k->pf_valid = true;
+    k->pf_next_img = d_image_next;
     return CS_OK;
 }
 

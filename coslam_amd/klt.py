@@ -176,11 +176,9 @@ class KLT_SequenceTracker:
               "cs_klt_track_dev")
 
     def prefetch_dev(self, d_image_next):
-        """Build the next frame's pyramid + cornerness map under this frame's tracker (cs_klt_prefetch_dev)."""
+        """Call BEFORE this frame's redetect_dev/detect_dev: its detector tail also builds the next frame's pyramid +
+        cornerness map (cs_klt_prefetch_dev)."""
         check(self._L.cs_klt_prefetch_dev(self._h, C.c_void_p(d_image_next)), "cs_klt_prefetch_dev")
-
-    def set_prefetch_stream(self, stream):
-        check(self._L.cs_klt_set_prefetch_stream(self._h, C.c_void_p(stream)), "cs_klt_set_prefetch_stream")
 
     def enable_graphs(self, on=True):
         check(self._L.cs_klt_enable_graphs(self._h, 1 if on else 0), "cs_klt_enable_graphs")

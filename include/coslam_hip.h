@@ -102,14 +102,14 @@ int cs_klt_set_stream(cs_klt* k, void* hip_stream); /* NULL = the handle's own s
 int cs_klt_detect_dev(cs_klt* k, const void* d_image, void* d_dest, void* d_counts);
 int cs_klt_redetect_dev(cs_klt* k, const void* d_image, void* d_dest, void* d_counts);
 int cs_klt_track_dev(cs_klt* k, const void* d_image, void* d_dest, void* d_counts);
-/* Frame-front prefetch: build the pyramid and cornerness map of the NEXT frame's image (device pointer) on a second
- * stream, beside the current frame's detector tail (after its tracker).  The next cs_klt_redetect_dev / cs_klt_track_dev called with the
- * same pointer starts at the tracker; any other call ignores the prefetch.  Results are identical with and without.
- * A no-op while hipGraph replay is enabled.  cs_klt_set_prefetch_stream: the stream the prefetch runs on (NULL = one
- * the handle creates); pass a CU-masked stream when the handle's own stream carries a CU mask.
- * (The reference builds the pyramid inside track()/redetect(), v3d_gpuklt.cpp:737-745,856-860.) */
+/* Frame-front prefetch: call BEFORE the cs_klt_redetect_dev / cs_klt_detect_dev of the current frame with the NEXT
+ * frame's image (device pointer, must stay valid and unchanged until consumed).  The current frame's detector tail
+ * then builds the next pyramid + cornerness map in the same two launches (horizontal fusion: the tail leaves the chip
+ * mostly idle), and the following cs_klt_redetect_dev / cs_klt_track_dev called with that pointer starts at the
+ * tracker.  Results are identical with and without; a request is dropped by a track-only frame, by hipGraph replay
+ * and by any call with a different image.  (The reference builds the pyramid inside track()/redetect(),
+ * v3d_gpuklt.cpp:737-745,856-860.) */
 int cs_klt_prefetch_dev(cs_klt* k, const void* d_image_next);
-int cs_klt_set_prefetch_stream(cs_klt* k, void* hip_stream);
 int cs_klt_synchronize(cs_klt* k);
 /* Replay the *_dev frame schedules from cached hipGraphs (one host launch per frame instead of ~60).  The image is
  * first copied into the handle's staging buffer (device-to-device) so that one graph serves every frame. */

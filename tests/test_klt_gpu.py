@@ -294,9 +294,9 @@ def test_graph_replay_matches_eager(hip):
 
 @pytest.mark.parametrize("levels", [4, 6])
 def test_frame_front_prefetch_matches_unprefetched(hip, levels):
-    """cs_klt_prefetch_dev (next frame's pyramid + cornerness built under this frame's tracker, third pyramid buffer,
-    second cornerness map) gives the unprefetched results bit for bit -- also when a prefetch goes unused, when
-    track-only frames and a feed sit in between, and with no host synchronisation between frames."""
+    """cs_klt_prefetch_dev (next frame's pyramid + cornerness built by this frame's detector-tail launches, third pyramid
+    buffer, second cornerness map) gives the unprefetched results bit for bit -- also when a prefetch names the wrong
+    image, when track-only frames sit in between, and with no host synchronisation between frames."""
     import torch
 
     W, H, fw, fh = 640, 480, 50, 40
@@ -316,11 +316,11 @@ def test_frame_front_prefetch_matches_unprefetched(hip, levels):
         for f in range(n_steps):
             img = frames[f % 9]
             fn = {"detect": t.detect_dev, "redetect": t.redetect_dev, "track": t.track_dev}[plan[f]]
-            fn(img.data_ptr(), d_dests[f].data_ptr(), d_counts[f].data_ptr())
-            t.advanceFrame()
             if prefetch and f + 1 < n_steps:
                 # f == 4: prefetch the WRONG image -- must be ignored by the next call
                 t.prefetch_dev(frames[(f + 1 + (3 if f == 4 else 0)) % 9].data_ptr())
+            fn(img.data_ptr(), d_dests[f].data_ptr(), d_counts[f].data_ptr())
+            t.advanceFrame()
         torch.cuda.synchronize()
         res.append([(d.cpu().numpy().copy(), c.cpu().numpy().copy()) for d, c in zip(d_dests, d_counts)])
         t.close()
