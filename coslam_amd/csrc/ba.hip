@@ -1046,6 +1046,8 @@ __global__ __launch_bounds__(256) void k_control(BaDev D, int phase) {
             st->lambda = 1e-3;
             st->inner_it = 0;
             st->inner_done = (D.innerMaxIter <= 0) ? 1 : 0;
+            st->changed = 0;  // k_outer_begin's job, for the k_flag at the end of this round
+            st->nOutliers = 0;
             if (st->first_cost) {
                 st->cost0 = cost_sum;
                 st->first_cost = 0;
@@ -1107,7 +1109,10 @@ __global__ __launch_bounds__(256) void k_flag(BaDev D) {
     if (nout) atomicAdd(&st->nOutliers, nout);
 }
 
-__global__ void k_init_state(BaState* st) {
+// start of a solve: LM state + every measurement an inlier
+__global__ __launch_bounds__(256) void k_init_state(BaState* st, int* outlier, int nObs) {
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < nObs; o += gridDim.x * 256) outlier[o] = 0;
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
     BaState z;
     z.lambda = 1e-3;
     z.cost = z.cost_new = z.step2 = z.cost0 = 0;
@@ -1235,6 +1240,8 @@ __global__ __launch_bounds__(256) void k_dist_control(BaDev D, int phase) {
             st->lambda = 1e-3;
             st->inner_it = 0;
             st->inner_done = (D.innerMaxIter <= 0) ? 1 : 0;
+            st->changed = 0;  // k_outer_begin's job, for the k_flag at the end of this round
+            st->nOutliers = 0;
             if (st->first_cost) {
                 st->cost0 = cost_sum;
                 st->first_cost = 0;
@@ -1518,10 +1525,14 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
     return CS_OK;
 }
 
-static void ba_enqueue_init(cs_ba* b, hipStream_t stream, const BaPlan& L) {
+// rebuildTopology = false: the measurement tables (obs_pt, obs_of) of the uploaded problem are already built
+static void ba_enqueue_init(cs_ba* b, hipStream_t stream, const BaPlan& L, bool rebuildTopology = true) {
     const BaDev& D = L.D;
-    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, stream, b->st);
-    (void)hipMemsetAsync(b->outlier, 0, sizeof(int) * (D.nObs > 0 ? D.nObs : 1), stream);
+    int gi = (D.nObs + 255) / 256;
+    if (gi < 1) gi = 1;
+    if (gi > 64) gi = 64;
+    hipLaunchKernelGGL(k_init_state, dim3(gi), dim3(256), 0, stream, b->st, b->outlier, D.nObs);
+    if (!rebuildTopology) return;
     (void)hipMemsetAsync(b->obs_of, 0xff, sizeof(int) * (size_t)D.P * D.C, stream);
     if (D.P > 0) hipLaunchKernelGGL(k_build_obs_pt, dim3((D.P + 3) / 4), dim3(256), 0, stream, D.P, b->obs_ptr, b->obs_pt);
     if (D.nObs > 0)
@@ -1585,14 +1596,14 @@ static void ba_enqueue_solve_update(hipStream_t stream, const BaPlan& L) {
 
 // enqueue the whole solve on `stream`; every array already resident in b's device buffers
 static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int nCamsCon, int nPtsCon, double maxErr,
-                      int maxIter, int innerMaxIter) {
+                      int maxIter, int innerMaxIter, bool rebuildTopology = true) {
     BaPlan L;
     int rc = ba_make_plan(b, C, P, nObs, nCamsCon, nPtsCon, maxErr, innerMaxIter, false, &L);
     if (rc) return rc;
     const BaDev& D = L.D;
     const int cb = L.cb;
     const dim3 blk(256);
-    ba_enqueue_init(b, stream, L);
+    ba_enqueue_init(b, stream, L, rebuildTopology);
 
     for (int outer = 0; outer < maxIter; ++outer) {
         hipLaunchKernelGGL(k_cost, dim3(cb), blk, 0, stream, D, 0);
@@ -1602,8 +1613,7 @@ static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int 
             ba_enqueue_solve_update(stream, L);
             hipLaunchKernelGGL(k_control, dim3(1), blk, 0, stream, D, 1);
         }
-        hipLaunchKernelGGL(k_outer_begin, dim3(1), dim3(1), 0, stream, D);
-        hipLaunchKernelGGL(k_flag, dim3(cb), blk, 0, stream, D);
+        hipLaunchKernelGGL(k_flag, dim3(cb), blk, 0, stream, D);  // (its counters were zeroed by k_control phase 0)
         hipLaunchKernelGGL(k_outer_end, dim3(1), dim3(1), 0, stream, D);
     }
     hipLaunchKernelGGL(k_cost_force, dim3(cb), blk, 0, stream, D);
@@ -1766,7 +1776,8 @@ int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const do
             rc = CS_ERR_HIP;
         }
     }
-    if (!rc) rc = ba_enqueue(b, s, C, P, nObs, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter);
+    // the measurement tables were built when the problem was uploaded (cs_ba_upload -> cs_ba_robust_h)
+    if (!rc) rc = ba_enqueue(b, s, C, P, nObs, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter, false);
     if (!useGraph) return rc;
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamEndCapture(s, &graph);
