@@ -1024,67 +1024,95 @@ __global__ __launch_bounds__(256) void k_cost(BaDev D, int which) {
 // ---- LM control: one workgroup -----------------------------------------------------------------------
 // phase 0: start of an LM run (cost of the current estimate over the current inliers)
 // phase 1: after a tentative step (accept / reject, commit, stop tests)
-__global__ __launch_bounds__(256) void k_control(BaDev D, int phase) {
+__global__ __launch_bounds__(256) void k_control(BaDev D) {  // phase 0
     __shared__ double red[4];
-    __shared__ int accept;
     BaState* st = D.st;
     if (st->all_done) return;
-    if (phase == 1 && st->inner_done) return;
     const int tid = threadIdx.x;
-    // fixed-order sums
+    // fixed-order sum of k_cost's partials
     double c = 0;
-    const int nPart = (phase == 1) ? D.nUpdBlocks : D.nCostBlocks;  // phase 1: k_update's per-block tentative costs
-    for (int q = tid; q < nPart; q += 256) c += D.costPart[q];
+    for (int q = tid; q < D.nCostBlocks; q += 256) c += D.costPart[q];
     c = wsum(c);
     if ((tid & 63) == 0) red[tid >> 6] = c;
     __syncthreads();
     const double cost_sum = ((red[0] + red[1]) + red[2]) + red[3];
-    __syncthreads();
-    if (phase == 0) {
-        if (tid == 0) {
-            st->cost = cost_sum;
-            st->lambda = 1e-3;
-            st->inner_it = 0;
-            st->inner_done = (D.innerMaxIter <= 0) ? 1 : 0;
-            st->changed = 0;  // k_outer_begin's job, for the k_flag at the end of this round
-            st->nOutliers = 0;
-            if (st->first_cost) {
-                st->cost0 = cost_sum;
-                st->first_cost = 0;
-            }
-        }
-        return;
-    }
-    double s2 = 0;
-    for (int q = tid; q < D.P + D.C; q += 256) s2 += D.stepPart[q];
-    s2 = wsum(s2);
-    if ((tid & 63) == 0) red[tid >> 6] = s2;
-    __syncthreads();
-    const double step2 = ((red[0] + red[1]) + red[2]) + red[3];
     if (tid == 0) {
-        const double cost_new = st->chol_ok ? cost_sum : 1e300;
-        int acc = (st->chol_ok && cost_new <= st->cost) ? 1 : 0;
+        st->cost = cost_sum;
+        st->lambda = 1e-3;
+        st->inner_it = 0;
+        st->inner_done = (D.innerMaxIter <= 0) ? 1 : 0;
+        st->changed = 0;  // k_outer_begin's job, for the k_flag at the end of this round
+        st->nOutliers = 0;
+        if (st->first_cost) {
+            st->cost0 = cost_sum;
+            st->first_cost = 0;
+        }
+    }
+}
+
+// phase 1: after a tentative step (accept / reject, commit, stop tests).  Everything the launch reads -- the state word,
+// both partial lists and the tentative values each thread would commit -- is requested up front, so the launch is one
+// round trip to memory, the decision, and the stores; the sums keep k_control's order.
+__global__ __launch_bounds__(256) void k_control_step(BaDev D) {
+    __shared__ double red[8];
+    __shared__ int accept;
+    BaState* st = D.st;
+    const int tid = threadIdx.x;
+    const int all_done = st->all_done, inner_done = st->inner_done, chol_ok = st->chol_ok, inner_it = st->inner_it;
+    const double cost_old = st->cost, lambda = st->lambda;
+    double c = 0, s2 = 0;
+    for (int q = tid; q < D.nUpdBlocks; q += 256) c += D.costPart[q];
+    for (int q = tid; q < D.P + D.C; q += 256) s2 += D.stepPart[q];
+    constexpr int PRE = 8;
+    const int nR = 9 * D.C, nT = 3 * D.C, total = nR + nT + 3 * D.P;
+    double pre[PRE];
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+        const int q = tid + 256 * k;
+        pre[k] = (q < nR) ? D.Rn[q] : (q < nR + nT) ? D.Tn[q - nR] : (q < total) ? D.Mn[q - nR - nT] : 0.0;
+    }
+    if (all_done || inner_done) return;
+    c = wsum(c);
+    s2 = wsum(s2);
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = c;
+        red[4 + (tid >> 6)] = s2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double cost_sum = ((red[0] + red[1]) + red[2]) + red[3];
+        const double step2 = ((red[4] + red[5]) + red[6]) + red[7];
+        const double cost_new = chol_ok ? cost_sum : 1e300;
+        int acc = (chol_ok && cost_new <= cost_old) ? 1 : 0;
         int done = 0;
         st->nIterTotal += 1;
-        st->inner_it += 1;
+        st->inner_it = inner_it + 1;
         if (acc) {
-            const double dec = st->cost - cost_new;
+            const double dec = cost_old - cost_new;
             st->cost = cost_new;
-            st->lambda /= 10;
+            st->lambda = lambda / 10;
             if (dec < 1e-9 * cost_new + 1e-15 || step2 < 1e-20) done = 1;
         } else {
-            st->lambda *= 10;
-            if (st->lambda > 1e12) done = 1;
+            st->lambda = lambda * 10;
+            if (lambda * 10 > 1e12) done = 1;
         }
-        if (st->inner_it >= D.innerMaxIter) done = 1;
+        if (inner_it + 1 >= D.innerMaxIter) done = 1;
         st->inner_done = done;
         accept = acc;
     }
     __syncthreads();
     if (accept) {
-        for (int q = tid; q < 9 * D.C; q += 256) D.Rs[q] = D.Rn[q];
-        for (int q = tid; q < 3 * D.C; q += 256) D.Ts[q] = D.Tn[q];
-        for (int q = tid; q < 3 * D.P; q += 256) D.pts[q] = D.Mn[q];
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+            const int q = tid + 256 * k;
+            if (q < nR)
+                D.Rs[q] = pre[k];
+            else if (q < nR + nT)
+                D.Ts[q - nR] = pre[k];
+            else if (q < total)
+                D.pts[q - nR - nT] = pre[k];
+        }
+        for (int q = tid + 256 * PRE; q < total; q += 256) D.pts[q - nR - nT] = D.Mn[q - nR - nT];
     }
 }
 
@@ -1607,11 +1635,11 @@ static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int 
 
     for (int outer = 0; outer < maxIter; ++outer) {
         hipLaunchKernelGGL(k_cost, dim3(cb), blk, 0, stream, D, 0);
-        hipLaunchKernelGGL(k_control, dim3(1), blk, 0, stream, D, 0);
+        hipLaunchKernelGGL(k_control, dim3(1), blk, 0, stream, D);
         for (int it = 0; it < innerMaxIter; ++it) {
             ba_enqueue_lin_schur(stream, L);
             ba_enqueue_solve_update(stream, L);
-            hipLaunchKernelGGL(k_control, dim3(1), blk, 0, stream, D, 1);
+            hipLaunchKernelGGL(k_control_step, dim3(1), blk, 0, stream, D);
         }
         hipLaunchKernelGGL(k_flag, dim3(cb), blk, 0, stream, D);  // (its counters were zeroed by k_control phase 0)
         hipLaunchKernelGGL(k_outer_end, dim3(1), dim3(1), 0, stream, D);
