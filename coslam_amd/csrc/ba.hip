@@ -333,7 +333,8 @@ __global__ __launch_bounds__(256) void k_schur(BaDev D) {
 // wave totals go to schurPart[pair][slice][72] and the register Cholesky adds the slices in slice order while it
 // loads its rows -- deterministic, no atomics, no extra launch.
 __global__ __launch_bounds__(64) void k_schur_part(BaDev D) {
-    if (!BA_ACTIVE(D)) return;
+    // The launch is a chain of dependent loads (state -> measurement index -> outlier flag -> blocks), a few waves
+    // wide: every load whose address is known is issued before the first value is looked at.
     const int lane = threadIdx.x;
     const int pairIdx = blockIdx.x / D.nSlices, slice = blockIdx.x - pairIdx * D.nSlices;
     int ja = 0, pr = pairIdx;
@@ -343,56 +344,131 @@ __global__ __launch_bounds__(64) void k_schur_part(BaDev D) {
     }
     const int jb = ja + pr;
     const int ca = ja + D.nCamsCon, cb = jb + D.nCamsCon;
+    const bool diag = (ja == jb);
+    const int nFree = D.P - D.nPtsCon;
+    const int per = (nFree + D.nSlices - 1) / D.nSlices;
+    const int lo = D.nPtsCon + slice * per, hi = min(lo + per, D.P);
+    // round trip 1: the state word, this lane's first point and (diagonal pairs) the camera's measurement list bounds
+    const int all_done = D.st->all_done, inner_done = D.st->inner_done;
+    const int i0 = lo + lane;
+    const bool has0 = i0 < hi;
+    int oa0 = -1, ob0 = -1;
+    double Vi0[9], g0[3];
+    if (has0) {
+        oa0 = D.obs_of[(size_t)i0 * D.C + ca];
+        ob0 = diag ? oa0 : D.obs_of[(size_t)i0 * D.C + cb];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Vi0[q] = D.Vinv[9 * (size_t)i0 + q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) g0[q] = diag ? D.gp[3 * (size_t)i0 + q] : 0.0;
+    }
+    int c0 = 0, c1 = 0;
+    if (diag) {
+        c0 = D.cam_ptr[ca];
+        c1 = D.cam_ptr[ca + 1];
+    }
+    if (all_done || inner_done) return;
+    // round trip 2: flags and W blocks of the first point (indices clamped: a missing measurement loads slot 0 and is
+    // masked below), and the first entry of the camera's list
+    const int perU = (c1 - c0 + D.nSlices - 1) / D.nSlices;
+    const int loU = c0 + slice * perU, hiU = min(loU + perU, c1);
+    const int sI0 = loU + lane;
+    const int oU0 = (diag && sI0 < hiU) ? D.cam_obs[sI0] : -1;
+    int outA0 = 1, outB0 = 1;
+    double Wa0[18], Wb0[18];
+    if (has0) {
+        const int qa = oa0 < 0 ? 0 : oa0, qb = ob0 < 0 ? 0 : ob0;
+        outA0 = D.outlier[qa];
+        outB0 = D.outlier[qb];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) Wa0[q] = D.W[18 * (size_t)qa + q];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) Wb0[q] = diag ? Wa0[q] : D.W[18 * (size_t)qb + q];
+    }
     double* out = D.schurPart + (size_t)blockIdx.x * 72;
     double acc[42];
 #pragma unroll
     for (int q = 0; q < 42; ++q) acc[q] = 0;
-    {
-        const int nFree = D.P - D.nPtsCon;
-        const int per = (nFree + D.nSlices - 1) / D.nSlices;
-        const int lo = D.nPtsCon + slice * per, hi = min(lo + per, D.P);
-        for (int i = lo + lane; i < hi; i += 64) {
-            const int oa = D.obs_of[(size_t)i * D.C + ca];
-            if (oa < 0 || D.outlier[oa]) continue;
-            const int ob = (ja == jb) ? oa : D.obs_of[(size_t)i * D.C + cb];
-            if (ob < 0 || D.outlier[ob]) continue;
-            const double* Wa = D.W + 18 * (size_t)oa;
-            const double* Wb = D.W + 18 * (size_t)ob;
-            const double* Vi = D.Vinv + 9 * (size_t)i;
-            double Y[18];
+    for (int i = i0; i < hi; i += 64) {
+        const bool first = (i == i0);
+        int oa, ob;
+        double Wa[18], Wb[18], Vi[9], g[3];
+        if (first) {
+            if (oa0 < 0 || outA0 || ob0 < 0 || outB0) continue;
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Y[3 * r + c] = Wa[3 * r] * Vi[c] + Wa[3 * r + 1] * Vi[3 + c] + Wa[3 * r + 2] * Vi[6 + c];
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int c = 0; c < 6; ++c)
-                    acc[6 * r + c] += Y[3 * r] * Wb[3 * c] + Y[3 * r + 1] * Wb[3 * c + 1] + Y[3 * r + 2] * Wb[3 * c + 2];
-            if (ja == jb) {
-                const double* g = D.gp + 3 * (size_t)i;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) acc[36 + r] += Y[3 * r] * g[0] + Y[3 * r + 1] * g[1] + Y[3 * r + 2] * g[2];
+            for (int q = 0; q < 18; ++q) {
+                Wa[q] = Wa0[q];
+                Wb[q] = Wb0[q];
             }
+#pragma unroll
+            for (int q = 0; q < 9; ++q) Vi[q] = Vi0[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) g[q] = g0[q];
+        } else {
+            oa = D.obs_of[(size_t)i * D.C + ca];
+            if (oa < 0 || D.outlier[oa]) continue;
+            ob = diag ? oa : D.obs_of[(size_t)i * D.C + cb];
+            if (ob < 0 || D.outlier[ob]) continue;
+#pragma unroll
+            for (int q = 0; q < 18; ++q) {
+                Wa[q] = D.W[18 * (size_t)oa + q];
+                Wb[q] = D.W[18 * (size_t)ob + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 9; ++q) Vi[q] = D.Vinv[9 * (size_t)i + q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) g[q] = diag ? D.gp[3 * (size_t)i + q] : 0.0;
         }
+        double Y[18];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Y[3 * r + c] = Wa[3 * r] * Vi[c] + Wa[3 * r + 1] * Vi[3 + c] + Wa[3 * r + 2] * Vi[6 + c];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                acc[6 * r + c] += Y[3 * r] * Wb[3 * c] + Y[3 * r + 1] * Wb[3 * c + 1] + Y[3 * r + 2] * Wb[3 * c + 2];
+        if (diag) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[36 + r] += Y[3 * r] * g[0] + Y[3 * r + 1] * g[1] + Y[3 * r + 2] * g[2];
+        }
+    }
+    // round trip 3 (diagonal pairs; independent of the loop above, so it is in flight under it): Jc, e of the list entry
+    int outU0 = 1;
+    double J0[12], e00 = 0, e01 = 0;
+    if (oU0 >= 0) {
+        outU0 = D.outlier[oU0];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) J0[q] = D.Jc[12 * (size_t)oU0 + q];
+        e00 = D.e[2 * (size_t)oU0];
+        e01 = D.e[2 * (size_t)oU0 + 1];
     }
     cs_reduce_many<42>(acc, lane);
     {
         const int q = cs_reduce_index<42>(lane);
         if (q >= 0) out[q] = acc[0];
     }
-    if (ja == jb) {  // U_j = sum Jc^T Jc and g_j = sum Jc^T e over this slice of the camera's own measurement list
+    if (diag) {  // U_j = sum Jc^T Jc and g_j = sum Jc^T e over this slice of the camera's own measurement list
         double u[27];
 #pragma unroll
         for (int q = 0; q < 27; ++q) u[q] = 0;
-        const int c0 = D.cam_ptr[ca], c1 = D.cam_ptr[ca + 1];
-        const int per = (c1 - c0 + D.nSlices - 1) / D.nSlices;
-        const int lo = c0 + slice * per, hi = min(lo + per, c1);
-        for (int sI = lo + lane; sI < hi; sI += 64) {
-            const int o = D.cam_obs[sI];
-            if (D.outlier[o]) continue;
-            const double* J = D.Jc + 12 * (size_t)o;
-            const double e0 = D.e[2 * (size_t)o], e1 = D.e[2 * (size_t)o + 1];
+        for (int sI = sI0; sI < hiU; sI += 64) {
+            double J[12], e0, e1;
+            if (sI == sI0) {
+                if (outU0) continue;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) J[q] = J0[q];
+                e0 = e00;
+                e1 = e01;
+            } else {
+                const int o = D.cam_obs[sI];
+                if (D.outlier[o]) continue;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) J[q] = D.Jc[12 * (size_t)o + q];
+                e0 = D.e[2 * (size_t)o];
+                e1 = D.e[2 * (size_t)o + 1];
+            }
             int q = 0;
 #pragma unroll
             for (int r = 0; r < 6; ++r)
