@@ -331,8 +331,8 @@ __global__ __launch_bounds__(1024) void k_select_fill(CsSelectArgs Q, CsFillArgs
 // independent jobs into the same launches -- no second stream, no events:
 //   k_tail_nonmax_level0   workgroups [0, nA): non-max + compaction of THIS frame; [nA, nA + nB): level 0 + cornerness
 //                          map of the NEXT image (into the spare pyramid / cornerness buffers);
-//   k_tail_select_down     workgroup 0: selection + slot fill of THIS frame; every other workgroup: four 256-thread
-//                          groups, each one tile of the fused levels 1..3 of the NEXT pyramid.
+//   k_tail_select_down     workgroup 0: selection + slot fill of THIS frame; every other workgroup: one tile of the
+//                          fused levels 1..3 of the NEXT pyramid (first four waves; the rest retire immediately).
 struct CsLevel0Args {
     const uint8_t* img;
     int W, H;
@@ -361,11 +361,11 @@ __global__ __launch_bounds__(1024) void k_tail_select_down(CsSelectArgs Q, CsFil
         select_fill_body(Q, A);
         return;
     }
-    const int grp = threadIdx.x >> 8;
-    const int t = (blockIdx.x - 1) * 4 + grp;
-    const bool valid = t < ntx * nty;
-    cs_texel* reg = (cs_texel*)down_smem + (size_t)grp * (F.cap1 + F.cap2);
-    cs_down_body(pyr, F, valid ? t % ntx : 0, valid ? t / ntx : 0, threadIdx.x & 255, reg, valid);
+    // one tile per workgroup, worked by its first four waves (the other twelve retire at once and leave the barriers):
+    // the tiles spread over the CUs exactly as in the stand-alone launch
+    if (threadIdx.x >= 256) return;
+    const int t = blockIdx.x - 1;
+    cs_down_body(pyr, F, t % ntx, t / ntx, threadIdx.x, (cs_texel*)down_smem, true);
 }
 
 // track() only: the tracked count (status >= 0 in dest[]), one workgroup
@@ -506,8 +506,7 @@ int cs_launch_tail_with_next_front(const float* in, int W, int H, int d, float* 
         size_t lds;
         int rc = cs_down_fused_plan(lay, tap_mode, &F, &ntx, &nty, &lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_tail_select_down, dim3(1 + (ntx * nty + 3) / 4), dim3(1024), 4 * lds, stream, q, a, d_pyr_next, F,
-                           ntx, nty);
+        hipLaunchKernelGGL(k_tail_select_down, dim3(1 + ntx * nty), dim3(1024), lds, stream, q, a, d_pyr_next, F, ntx, nty);
         rc = cs_launch_pyr_down_from(lay, d_pyr_next, tap_mode, F.NL + 1, stream);
         if (rc) return rc;
     } else {
