@@ -1214,8 +1214,19 @@ __global__ __launch_bounds__(256) void k_flag(BaDev D) {
 }
 
 // start of a solve: LM state + every measurement an inlier
-__global__ __launch_bounds__(256) void k_init_state(BaState* st, int* outlier, int nObs) {
-    for (int o = blockIdx.x * 256 + threadIdx.x; o < nObs; o += gridDim.x * 256) outlier[o] = 0;
+struct BaInitCopy {  // initial estimate to copy into the workspace (cs_ba_solve_dev); src null = already in place
+    const double *R0, *T0, *M0;
+    double *R, *T, *M;
+    int nR, nT, nM;
+};
+__global__ __launch_bounds__(256) void k_init_state(BaState* st, int* outlier, int nObs, BaInitCopy I) {
+    const int t0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    for (int o = t0; o < nObs; o += stride) outlier[o] = 0;
+    if (I.R0) {
+        for (int q = t0; q < I.nR; q += stride) I.R[q] = I.R0[q];
+        for (int q = t0; q < I.nT; q += stride) I.T[q] = I.T0[q];
+        for (int q = t0; q < I.nM; q += stride) I.M[q] = I.M0[q];
+    }
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     BaState z;
     z.lambda = 1e-3;
@@ -1630,12 +1641,14 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
 }
 
 // rebuildTopology = false: the measurement tables (obs_pt, obs_of) of the uploaded problem are already built
-static void ba_enqueue_init(cs_ba* b, hipStream_t stream, const BaPlan& L, bool rebuildTopology = true) {
+static void ba_enqueue_init(cs_ba* b, hipStream_t stream, const BaPlan& L, bool rebuildTopology = true,
+                            const double* d_Rs0 = nullptr, const double* d_Ts0 = nullptr, const double* d_pts0 = nullptr) {
     const BaDev& D = L.D;
-    int gi = (D.nObs + 255) / 256;
+    int gi = ((D.nObs > 3 * D.P ? D.nObs : 3 * D.P) + 255) / 256;
     if (gi < 1) gi = 1;
     if (gi > 64) gi = 64;
-    hipLaunchKernelGGL(k_init_state, dim3(gi), dim3(256), 0, stream, b->st, b->outlier, D.nObs);
+    BaInitCopy I = {d_Rs0, d_Ts0, d_pts0, b->Rs, b->Ts, b->pts, 9 * D.C, 3 * D.C, 3 * D.P};
+    hipLaunchKernelGGL(k_init_state, dim3(gi), dim3(256), 0, stream, b->st, b->outlier, D.nObs, I);
     if (!rebuildTopology) return;
     (void)hipMemsetAsync(b->obs_of, 0xff, sizeof(int) * (size_t)D.P * D.C, stream);
     if (D.P > 0) hipLaunchKernelGGL(k_build_obs_pt, dim3((D.P + 3) / 4), dim3(256), 0, stream, D.P, b->obs_ptr, b->obs_pt);
@@ -1700,14 +1713,15 @@ static void ba_enqueue_solve_update(hipStream_t stream, const BaPlan& L) {
 
 // enqueue the whole solve on `stream`; every array already resident in b's device buffers
 static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int nCamsCon, int nPtsCon, double maxErr,
-                      int maxIter, int innerMaxIter, bool rebuildTopology = true) {
+                      int maxIter, int innerMaxIter, bool rebuildTopology = true, const double* d_Rs0 = nullptr,
+                      const double* d_Ts0 = nullptr, const double* d_pts0 = nullptr) {
     BaPlan L;
     int rc = ba_make_plan(b, C, P, nObs, nCamsCon, nPtsCon, maxErr, innerMaxIter, false, &L);
     if (rc) return rc;
     const BaDev& D = L.D;
     const int cb = L.cb;
     const dim3 blk(256);
-    ba_enqueue_init(b, stream, L, rebuildTopology);
+    ba_enqueue_init(b, stream, L, rebuildTopology, d_Rs0, d_Ts0, d_pts0);
 
     for (int outer = 0; outer < maxIter; ++outer) {
         hipLaunchKernelGGL(k_cost, dim3(cb), blk, 0, stream, D, 0);
@@ -1870,18 +1884,9 @@ int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const do
         ba_drop_graph(b);
         CS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     }
-    int rc = CS_OK;
-    {
-        hipError_t e1 = hipMemcpyAsync(b->Rs, d_Rs0, sizeof(double) * 9 * C, hipMemcpyDeviceToDevice, s);
-        hipError_t e2 = hipMemcpyAsync(b->Ts, d_Ts0, sizeof(double) * 3 * C, hipMemcpyDeviceToDevice, s);
-        hipError_t e3 = (P > 0) ? hipMemcpyAsync(b->pts, d_pts0, sizeof(double) * 3 * P, hipMemcpyDeviceToDevice, s) : hipSuccess;
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-            cs_set_error("cs_ba_solve_dev: device copy of the initial estimate failed");
-            rc = CS_ERR_HIP;
-        }
-    }
-    // the measurement tables were built when the problem was uploaded (cs_ba_upload -> cs_ba_robust_h)
-    if (!rc) rc = ba_enqueue(b, s, C, P, nObs, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter, false);
+    // the measurement tables were built when the problem was uploaded (cs_ba_upload -> cs_ba_robust_h); the initial
+    // estimate is copied into the workspace by the solve's first kernel
+    int rc = ba_enqueue(b, s, C, P, nObs, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter, false, d_Rs0, d_Ts0, d_pts0);
     if (!useGraph) return rc;
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamEndCapture(s, &graph);
