@@ -1442,6 +1442,7 @@ struct cs_ba {
     // second block (ob / h_ob, one D2H)
     unsigned char *io, *h_io, *ob, *h_ob;
     size_t ioBytes, obBytes;
+    unsigned char* slab;  // ONE device allocation behind every workspace array (few TLB entries for the whole solve)
     int nCostBlocks;
     // cached executable graph of one full solve (cs_ba_solve_dev): ~150 launches become one
     struct GraphKey {
@@ -1461,22 +1462,13 @@ static int ba_free(cs_ba* b) {
     ba_drop_graph(b);
     delete b->dist;
     b->dist = nullptr;
-    double** dp[] = {&b->Rn, &b->Tn, &b->Mn, &b->Jc, &b->e, &b->W, &b->Vinv, &b->gp, &b->S, &b->costPart, &b->stepPart,
-                     &b->schurPart, &b->scal};
-    for (auto p : dp) {
-        if (*p) (void)hipFree(*p);
-        *p = nullptr;
-    }
-    int** ip[] = {&b->obs_pt, &b->obs_of};
-    for (auto p : ip) {
-        if (*p) (void)hipFree(*p);
-        *p = nullptr;
-    }
-    if (b->st) (void)hipFree(b->st);
-    if (b->io) (void)hipFree(b->io);
-    if (b->ob) (void)hipFree(b->ob);
+    if (b->slab) (void)hipFree(b->slab);
     if (b->h_io) (void)hipHostFree(b->h_io);
     if (b->h_ob) (void)hipHostFree(b->h_ob);
+    b->slab = nullptr;
+    b->Rn = b->Tn = b->Mn = b->Jc = b->e = b->W = b->Vinv = b->gp = b->S = b->costPart = b->stepPart = b->schurPart = b->scal =
+        nullptr;
+    b->obs_pt = b->obs_of = nullptr;
     b->st = nullptr;
     b->io = b->ob = b->h_io = b->h_ob = nullptr;
     b->Ks = b->Rs = b->Ts = b->pts = b->obs_xy = nullptr;
@@ -1485,7 +1477,6 @@ static int ba_free(cs_ba* b) {
     return CS_OK;
 }
 
-// section offsets (bytes) of the I/O block for a problem of C cameras, P points, nObs measurements
 struct BaIoLayout {
     size_t Ks, Rs, Ts, pts, xy, optr, ocam, cptr, cobs, total;
 };
@@ -1531,29 +1522,45 @@ static int ba_reserve(cs_ba* b, int C, int P, int nObs) {
     const size_t cC = (size_t)(C > b->capC ? C : b->capC), cP = (size_t)(P > b->capP ? P : b->capP),
                  cO = (size_t)(nObs > b->capObs ? nObs : b->capObs);
     const size_t n = 6 * cC;
-#define BA_ALLOC(ptr, count, type) CS_HIP(hipMalloc((void**)&(ptr), ((count) > 0 ? (count) : 1) * sizeof(type)))
-    BA_ALLOC(b->Rn, 9 * cC, double);
-    BA_ALLOC(b->Tn, 3 * cC, double);
-    BA_ALLOC(b->Mn, 3 * cP, double);
-    BA_ALLOC(b->Jc, 12 * cO, double);
-    BA_ALLOC(b->e, 2 * cO, double);
-    BA_ALLOC(b->W, 18 * cO, double);
-    BA_ALLOC(b->Vinv, 9 * cP, double);
-    BA_ALLOC(b->gp, 3 * cP, double);
-    BA_ALLOC(b->S, n * n + n + 8, double);  // S || rhs contiguous: one all-reduce in the distributed solve
-    b->rhs = nullptr;                        // set per solve: S + n^2 of the actual order
-    BA_ALLOC(b->scal, 8, double);
-    BA_ALLOC(b->costPart, 1024 + cP / 4 + cC / 256 + 2, double);
-    BA_ALLOC(b->schurPart, (size_t)21 * 16 * 72, double);  // <= 6 free cameras (21 pairs) x 16 slices
-    BA_ALLOC(b->stepPart, cP + cC, double);
-    BA_ALLOC(b->obs_pt, cO, int);
-    BA_ALLOC(b->obs_of, cP * cC, int);
-    BA_ALLOC(b->st, 1, BaState);
-#undef BA_ALLOC
+    // every array of the workspace is carved out of ONE allocation (256-byte aligned pieces): the solve is a chain of
+    // small dependent kernels, and two dozen separate allocations would mean two dozen translations to warm per kernel
     b->ioBytes = ba_io_layout(cC, cP, cO).total + 64;
     b->obBytes = 64 + 4 * (cO > 0 ? cO : 1);
-    CS_HIP(hipMalloc((void**)&b->io, b->ioBytes));
-    CS_HIP(hipMalloc((void**)&b->ob, b->obBytes));
+    struct Piece {
+        void** ptr;
+        size_t bytes;
+    };
+    const Piece pieces[] = {
+        {(void**)&b->st, sizeof(BaState)},
+        {(void**)&b->scal, 8 * sizeof(double)},
+        {(void**)&b->costPart, (1024 + cP / 4 + cC / 256 + 2) * sizeof(double)},
+        {(void**)&b->stepPart, (cP + cC + 1) * sizeof(double)},
+        {(void**)&b->schurPart, (size_t)21 * 16 * 72 * sizeof(double)},  // <= 6 free cameras (21 pairs) x 16 slices
+        {(void**)&b->S, (n * n + n + 8) * sizeof(double)},  // S || rhs contiguous: one all-reduce in the distributed solve
+        {(void**)&b->Rn, (9 * cC + 1) * sizeof(double)},
+        {(void**)&b->Tn, (3 * cC + 1) * sizeof(double)},
+        {(void**)&b->Mn, (3 * cP + 1) * sizeof(double)},
+        {(void**)&b->Vinv, (9 * cP + 1) * sizeof(double)},
+        {(void**)&b->gp, (3 * cP + 1) * sizeof(double)},
+        {(void**)&b->ob, b->obBytes},
+        {(void**)&b->io, b->ioBytes},
+        {(void**)&b->e, (2 * cO + 1) * sizeof(double)},
+        {(void**)&b->Jc, (12 * cO + 1) * sizeof(double)},
+        {(void**)&b->W, (18 * cO + 1) * sizeof(double)},
+        {(void**)&b->obs_pt, (cO + 1) * sizeof(int)},
+        {(void**)&b->obs_of, (cP * cC + 1) * sizeof(int)},
+    };
+    size_t total = 0;
+    for (const Piece& q : pieces) total += (q.bytes + 255) & ~(size_t)255;
+    CS_HIP(hipMalloc((void**)&b->slab, total));
+    {
+        size_t off = 0;
+        for (const Piece& q : pieces) {
+            *q.ptr = b->slab + off;
+            off += (q.bytes + 255) & ~(size_t)255;
+        }
+    }
+    b->rhs = nullptr;  // set per solve: S + n^2 of the actual order
     CS_HIP(hipHostMalloc((void**)&b->h_io, b->ioBytes, hipHostMallocDefault));
     CS_HIP(hipHostMalloc((void**)&b->h_ob, b->obBytes, hipHostMallocDefault));
     b->capC = (int)cC;
