@@ -201,6 +201,36 @@ def test_known_shift_is_recovered(hip):
     trk.close()
 
 
+@pytest.mark.parametrize("gain", [0, 1])
+def test_affine_warp_flow_is_recovered(hip, gain):
+    """Known-answer: the analytic flow of an affine warp (1 % zoom, 0.35 degrees, a shift), HIP path."""
+    from scipy.ndimage import affine_transform
+
+    W, H = 320, 240
+    sc = Scene(1, W, H, 700, seed=11, sigma=1.6)
+    im0 = sc.render(0, 0)
+    th, zoom, t = np.deg2rad(0.35), 1.01, np.array([0.6, -0.4])
+    A = zoom * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    c0 = np.array([(W - 1) / 2.0, (H - 1) / 2.0])
+    Ai = np.linalg.inv(A)
+    off_xy = c0 - Ai @ (c0 + t)
+    im1 = affine_transform(im0.astype(np.float64), Ai[::-1, ::-1], offset=off_xy[::-1], order=3, mode="nearest")
+    im1 = np.clip(np.rint(im1), 0, 255).astype(np.uint8)
+    trk = coslam_amd.KLT_SequenceTracker(cfg2(nLevels=3, trackWithGain=gain, minCornerness=1500.0), 0)
+    trk.allocate(W, H, 3, 20, 20)
+    n0, d0 = trk.detect(im0)
+    trk.advanceFrame()
+    n1, d1 = trk.track(im1)
+    ok = d1["status"] == 0
+    assert ok.sum() > 0.8 * n0
+    q0 = d0["pos"][ok].astype(np.float64) * [W, H] - 0.5
+    flow = (d1["pos"][ok].astype(np.float64) - d0["pos"][ok]) * [W, H]
+    want = (q0 - c0) @ A.T + c0 + t - q0
+    err = np.linalg.norm(flow - want, axis=1)
+    assert np.median(err) < 0.1 and np.percentile(err, 90) < 0.25
+    trk.close()
+
+
 def test_feed_extern_points_matches_oracle(hip):
     W, H = 320, 240
     sc = Scene(1, W, H, 600, seed=4)
