@@ -31,7 +31,8 @@ int cs_device_count(void) {
     return n;
 }
 
-// A HIP stream restricted to the compute units [first_cu, first_cu + n_cus) of `device` (hipExtStreamCreateWithCUMask).
+// A HIP stream restricted to the CU-mask bits [first_cu, first_cu + n_cus) of `device` (hipExtStreamCreateWithCUMask;
+// bit i = XCC i % 8, shader engine (i / 8) % 4, CU (i / 8) / 4: a range is the same few CUs of every XCD).
 // The persistent tracker runs every wave in lock-step with its neighbours, so one foreign wave on one of its SIMDs
 // slows the whole mesh; pose / BA streams confined to a few CUs, and the tracker stream to the others, keeps them
 // apart.  Returns the stream handle (a hipStream_t) or null.
@@ -57,10 +58,10 @@ void* cs_stream_create_cu_range(int device, int first_cu, int n_cus) {
     return (void*)s;
 }
 
-// Interleaved partition: the CUs whose index modulo `period` is (complement == 0) / is not (complement != 0) in
-// [0, take).  Consecutive CU indices sit in the same shader engine / XCD, so an interleaved side partition leaves every
-// XCD a few CUs short instead of removing whole XCDs: measured, the local BA runs as fast on 16 interleaved CUs as on
-// the whole chip (760 vs 742 us) but 938 us on 32 contiguous ones.
+// Mask bits whose index modulo `period` is (complement == 0) / is not (complement != 0) in [0, take).  Mask bit i is a CU
+// of XCC (i % 8) (tools/micro/cu_map.hip), and an XCC whose share of the mask is empty gets ALL its CUs: with period 8, 4
+// or 2 this is therefore no partition at all (what an earlier round took for "an interleaved partition that keeps the
+// tracker at 91 us" was the whole chip).  Kept for experiments with other periods.
 void* cs_stream_create_cu_interleaved(int device, int period, int take, int complement) {
     hipDeviceProp_t prop;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {

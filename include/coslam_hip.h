@@ -122,10 +122,13 @@ int cs_klt_set_fused(cs_klt* k, int on);
 int cs_klt_set_cu_count(cs_klt* k, int n_cus);
 /* how many handles of this device may have their persistent tracker in flight at the same time (0 = every live handle) */
 int cs_klt_set_concurrent_handles(cs_klt* k, int n);
-/* a stream confined to the compute units [first_cu, first_cu + n_cus): keeps pose / BA kernels off the SIMDs of the
- * lock-stepped persistent tracker; returns a hipStream_t (null on error) */
+/* a stream confined to the CU-mask bits [first_cu, first_cu + n_cus) (hipExtStreamCreateWithCUMask): keeps BA kernels
+ * off the SIMDs of the lock-stepped persistent tracker; returns a hipStream_t (null on error).  On MI355X mask bit i is
+ * a CU of XCC (i % 8) -- shader engine (i / 8) % 4, CU (i / 8) / 4 -- so a range is "the same few CUs of every XCD";
+ * use sizes that are multiples of 32 (one CU per shader engine per XCD each). */
 void* cs_stream_create_cu_range(int device, int first_cu, int n_cus);
-/* interleaved partition: CUs with (index % period) < take, or (complement != 0) all the others */
+/* mask bits with (index % period) < take, or (complement != 0) all the others.  NOTE: an XCC whose share of the mask
+ * is empty gets all its CUs, so period = 8 (or 4, 2) masks do not partition the chip at all; kept for experiments. */
 void* cs_stream_create_cu_interleaved(int device, int period, int take, int complement);
 int cs_stream_destroy(void* stream);
 /* diagnostic only: per-slot cycle counters (8 x uint64) of the persistent gain tracker; see klt_seq.hip */
