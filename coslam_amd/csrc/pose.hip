@@ -19,7 +19,10 @@
 namespace {
 
 constexpr int WS_LDS_MAX = 4096;  // points whose IRLS weights fit in LDS next to the reduction scratch
-constexpr int SMALL_NPTS = 256;   // up to here ONE wave owns the problem: no LDS exchange, no barrier
+constexpr int SMALL_NPTS = 64;    // up to here ONE wave owns the problem (no LDS exchange, no barrier).  Beyond, four waves
+                                  // with one point per lane win although they meet in LDS every LM step: an LM step is
+                                  // seven projections per point, and three points per lane made it 73.6 vs 64.1 us at 192
+                                  // points
 
 __device__ __forceinline__ void so3_exp(const double w[3], double R[9]) {  // SL_IntraCamPose.cpp:10-39
     double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
