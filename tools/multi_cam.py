@@ -8,7 +8,7 @@ import numpy as np, torch
 import bench, coslam_amd
 dev = torch.device("cuda:0")
 order = bench.frame_order(bench.N_FRAMES)
-def run(n_cams, n_streams, frames_per_cam=60):
+def run(n_cams, n_streams, frames_per_cam=60, prefetch=False):
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
     cams = []
     for c in range(n_cams):
@@ -23,6 +23,7 @@ def run(n_cams, n_streams, frames_per_cam=60):
         cams.append((t, d_frames, dest, cnt))
     def frame(i):
         for (t, d_frames, dest, cnt) in cams:
+            if prefetch: t.prefetch_dev(d_frames[order[(i + 2) % len(order)]].data_ptr())
             t.redetect_dev(d_frames[order[(i + 1) % len(order)]].data_ptr(), dest.data_ptr(), cnt.data_ptr()); t.advanceFrame()
     for i in range(10): frame(i)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -30,6 +31,8 @@ def run(n_cams, n_streams, frames_per_cam=60):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     live = [int((c[2].cpu().numpy().view(coslam_amd.KLT_TrackedFeature)["status"] >= 0).sum()) for c in cams]
     for c in cams: c[0].synchronize(); c[0].close()
-    print(f"{n_cams} cameras on {n_streams} stream(s): {n_cams * frames_per_cam / dt:8.0f} camera-frames/s ({1e6 * dt / frames_per_cam:7.1f} us per frame set), live {min(live)}..{max(live)}", flush=True)
+    print(f"{n_cams} cameras on {n_streams} stream(s){' + prefetch' if prefetch else ''}: {n_cams * frames_per_cam / dt:8.0f} camera-frames/s ({1e6 * dt / frames_per_cam:7.1f} us per frame set), live {min(live)}..{max(live)}", flush=True)
 for n_cams, n_streams in ((1, 1), (2, 2), (3, 3), (4, 2), (6, 3), (8, 2), (8, 3), (8, 4), (8, 8)):
     run(n_cams, n_streams)
+for n_cams, n_streams in ((1, 1), (2, 2), (3, 3), (8, 2), (8, 3)):
+    run(n_cams, n_streams, prefetch=True)
