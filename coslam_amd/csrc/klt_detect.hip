@@ -319,8 +319,7 @@ __device__ __forceinline__ void select_fill_body(const CsSelectArgs& Q, const Cs
         A.counts[3] = nSel;
         A.ctr[0] = 0;  // every read of the candidate count is behind the barriers above
     }
-    if (A.zgran)
-        for (int i = tid; i < A.nGran; i += 1024) A.zgran[i] = 0ull;
+    if (A.tagWord && tid == 0) *A.tagWord += 1u;
 }
 
 __global__ __launch_bounds__(1024) void k_select_fill(CsSelectArgs Q, CsFillArgs A) { select_fill_body(Q, A); }
@@ -370,7 +369,7 @@ __global__ __launch_bounds__(1024) void k_tail_select_down(CsSelectArgs Q, CsFil
 
 // track() only: the tracked count (status >= 0 in dest[]), one workgroup
 __global__ __launch_bounds__(1024) void k_counts_track(const cs_klt_feature* __restrict__ dest, int N, int* counts, int* ctr,
-                                                       unsigned long long* zgran, int nGran) {
+                                                       unsigned* tagWord) {
     __shared__ int part[1024];
     const int tid = threadIdx.x;
     int c = 0;
@@ -388,8 +387,7 @@ __global__ __launch_bounds__(1024) void k_counts_track(const cs_klt_feature* __r
         counts[3] = 0;
         if (ctr) ctr[0] = 0;
     }
-    if (zgran)
-        for (int i = tid; i < nGran; i += 1024) zgran[i] = 0ull;
+    if (tagWord && tid == 0) *tagWord += 1u;
 }
 
 }  // namespace
@@ -458,9 +456,8 @@ int cs_launch_select_fill(const CsCand* cand, int maxCand, int cap, int maxKeepF
     return CS_OK;
 }
 
-int cs_launch_counts_track(const cs_klt_feature* dest, int N, int* counts, int* ctr, unsigned long long* zgran, int nGran,
-                           hipStream_t stream) {
-    hipLaunchKernelGGL(k_counts_track, dim3(1), dim3(1024), 0, stream, dest, N, counts, ctr, zgran, nGran);
+int cs_launch_counts_track(const cs_klt_feature* dest, int N, int* counts, int* ctr, unsigned* tagWord, hipStream_t stream) {
+    hipLaunchKernelGGL(k_counts_track, dim3(1), dim3(1024), 0, stream, dest, N, counts, ctr, tagWord);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

@@ -37,7 +37,8 @@ struct CsGainFusedArgs {
     const float* featStart;  // iterate at entry (x, y; gain restarts at 1)
     float* outLast;          // result of the last pass
     float* outPrev;          // result of the pass before it (what the ping-pong schedule leaves behind)
-    unsigned long long* gran;  // [2][N] {tag, beta} granules, zeroed before every launch
+    unsigned long long* gran;  // [passes + 1][N] {tag, beta} granules: one row per pass, never overwritten within a frame
+    const unsigned* tagWord;   // frame-unique tag base (device word, bumped by the frame's last kernel)
     float sqrConvThr, ssdThr;
     float vr[4];
     float lambda, delta;
@@ -65,10 +66,8 @@ struct CsFillArgs {
     float* list_a;  // provide target 1 (buffer1)
     float* list_b;  // provide target 2 (buffer2, with gain only; may be null)
     int* counts;    // user-visible counts[4]
-    // the frame's last kernel leaves the hand-off granules and the candidate counter zeroed for the next frame, so a
-    // frame whose pyramid was prefetched (cs_klt_prefetch_dev) needs no zeroing launch of its own
-    unsigned long long* zgran;
-    int nGran;
+    // the frame's last kernel leaves the candidate counter zeroed and bumps the tracker's frame tag for the next frame
+    unsigned* tagWord;
 };
 
 int cs_launch_frame_front(const uint8_t* d_img, const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mode, float* corner_out,
@@ -95,5 +94,4 @@ int cs_launch_nonmax_compact(const float* in, int W, int H, int d, float* out, C
                              hipStream_t stream);
 int cs_launch_select_fill(const CsCand* cand, int maxCand, int cap, int maxKeepFixed, int* rankM, CsCand* sel,
                           const CsFillArgs& a, hipStream_t stream);
-int cs_launch_counts_track(const cs_klt_feature* dest, int N, int* counts, int* ctr, unsigned long long* zgran, int nGran,
-                           hipStream_t stream);
+int cs_launch_counts_track(const cs_klt_feature* dest, int N, int* counts, int* ctr, unsigned* tagWord, hipStream_t stream);

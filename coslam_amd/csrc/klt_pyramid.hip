@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_pyr_down(const cs_texel* __restrict__ s
 //   k_pyr_level0_corner   level 0 AND the detector's cornerness map (klt_detector_pass1/pass2.cg) out of one LDS
 //                         tile: the (Ix, Iy) the 7x7 structure tensor needs are the fp16-rounded texels this block
 //                         has just produced (own tile + 3-px halo, recomputed, never re-read from HBM); the same
-//                         launch zeroes the frame's counters and the tracker's hand-off granules;
+//                         launch zeroes the frame's counters;
 //   k_pyr_down_fused      levels 1..3 in one launch: every block owns an 8x4 tile of the coarsest of them and
 //                         recomputes the (one-sided, 2-texel) dependency cone below it in LDS.
 // Arithmetic, operation order and the fp16 roundings are those of k_pyr_level0 / k_pyr_down / k_cornerness:
@@ -92,7 +92,7 @@ int cs_launch_pyr_down_from(const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mod
     return CS_OK;
 }
 
-// pyramid (+ cornerness map, + zeroing of the frame's counters and hand-off granules) in two launches
+// pyramid (+ cornerness map, + zeroing of the frame's counters) in two launches
 int cs_launch_frame_front(const uint8_t* d_img, const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mode, float* corner_out,
                           float minCornerness, float margin, int* ctr, unsigned long long* gran, int nGran,
                           hipStream_t stream) {

@@ -150,7 +150,8 @@ struct cs_klt {
     std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev_pairs;
     // persistent (single-launch) gain tracker
     bool use_fused;
-    unsigned long long* d_gran;
+    unsigned long long* d_gran;  // [granRows][N] hand-off granules of the persistent tracker (one row per pass + 1)
+    int granRows;
     int* d_err;
     int cu_count;                 // compute units the handle's stream may use (cs_klt_set_cu_count; default: all)
     int concurrent;               // handles whose persistent kernels may overlap (cs_klt_set_concurrent_handles; 0: all live ones)
@@ -222,7 +223,8 @@ static int enqueue_tracker(cs_klt* k, cs_klt_feature* postDest, int doSuppress, 
     }
     if (k->concurrent > 0 && k->concurrent < live) live = k->concurrent;
     const int blocks = (k->N + 3) / 4;
-    if (k->use_fused && T >= 1 && blocks * live <= CS_RESIDENT_BLOCKS_PER_CU * k->cu_count && (2 * hw + 1) * (2 * hw + 1) <= 256) {
+    if (k->use_fused && T >= 1 && T + 1 <= k->granRows && blocks * live <= CS_RESIDENT_BLOCKS_PER_CU * k->cu_count &&
+        (2 * hw + 1) * (2 * hw + 1) <= 256) {
         CsGainFusedArgs f;
         memset(&f, 0, sizeof(f));
         f.pyr0 = P0;
@@ -247,6 +249,7 @@ static int enqueue_tracker(cs_klt* k, cs_klt_feature* postDest, int doSuppress, 
         f.outLast = k->d_fb[(T & 1) ? k->b1 : k->b0];
         f.outPrev = k->d_fb[(T & 1) ? k->b0 : k->b1];
         f.gran = k->d_gran;
+        f.tagWord = (const unsigned*)(k->d_counts + 5);
         f.sqrConvThr = k->convThr * k->convThr;
         f.ssdThr = k->ssdThr;
         f.vr[0] = k->margin / (float)k->W;
@@ -373,8 +376,7 @@ static int enqueue_detect_tail(cs_klt* k, int mode, int nPresentGiven, int maxKe
     f.list_a = k->d_fb[k->b1];
     f.list_b = k->cfg.trackWithGain ? k->d_fb[k->b2] : nullptr;
     f.counts = d_counts;
-    f.zgran = k->d_gran;
-    f.nGran = 2 * k->N;
+    f.tagWord = (unsigned*)(k->d_counts + 5);
     if (next) {
         // spare buffers: last read by the tracker / non-max of the frame BEFORE this one -- older than this point of
         // the stream
@@ -396,12 +398,12 @@ static int enqueue_track(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest
     int rc = CS_OK;
     if (k->pf_valid && k->pf_img == (const void*)d_img) {
         // prefetched: the spare pyramid / cornerness buffers become this frame's, the ones they replace (last read two
-        // frames ago) become the next prefetch's targets.  Counters and granules were zeroed by the previous frame's tail.
+        // frames ago) become the next prefetch's targets.  The candidate counter was zeroed by the previous frame's tail.
         std::swap(k->p1, k->p2);
         std::swap(k->d_corner_raw, k->d_corner_raw_spare);
     } else {
         rc = cs_launch_frame_front(d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, forRedetect ? k->d_corner_raw : nullptr,
-                                   k->cfg.minCornerness, k->detMargin, k->d_ctr, k->d_gran, 2 * k->N, k->stream);
+                                   k->cfg.minCornerness, k->detMargin, k->d_ctr, nullptr, 0, k->stream);
         if (rc) return rc;
     }
     k->pf_valid = false;
@@ -425,7 +427,7 @@ static int enqueue_track(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest
     }
     if (!forRedetect) {
         k->pf_next_img = nullptr;  // no detector tail to carry the next front: the request lapses
-        rc = cs_launch_counts_track(d_dest, k->N, d_counts, k->d_ctr, k->d_gran, 2 * k->N, k->stream);
+        rc = cs_launch_counts_track(d_dest, k->N, d_counts, k->d_ctr, (unsigned*)(k->d_counts + 5), k->stream);
     }
     return rc;
 }
@@ -638,8 +640,17 @@ int cs_klt_allocate(cs_klt* k, int W, int H, int nLevels, int fw, int fh, int pl
     k->d_counts = (int*)(k->d_dest + k->N);
     k->d_err = k->d_counts + 4;
     CS_HIP(hipMalloc((void**)&k->d_present, sizeof(float) * 3 * k->presentCap));
-    CS_HIP(hipMalloc((void**)&k->d_gran, sizeof(unsigned long long) * 2 * k->N));
-    CS_HIP(hipMemsetAsync(k->d_err, 0, sizeof(int), k->stream));
+    {
+        // one granule row per Gauss-Newton pass of the with-gain schedule (+ the initial row): levels visited x iterations
+        int visited = 0;
+        int skip = k->cfg.levelSkip > 0 ? k->cfg.levelSkip : (k->cfg.nLevels - 1);  // as enqueue_tracker
+        if (skip <= 0) skip = 1;
+        for (int l = nLevels - 1; l >= 0; l -= skip) ++visited;
+        k->granRows = visited * (k->cfg.nIterations > 0 ? k->cfg.nIterations : 0) + 1;
+        CS_HIP(hipMalloc((void**)&k->d_gran, sizeof(unsigned long long) * (size_t)k->granRows * k->N));
+        CS_HIP(hipMemsetAsync(k->d_gran, 0, sizeof(unsigned long long) * (size_t)k->granRows * k->N, k->stream));
+    }
+    CS_HIP(hipMemsetAsync(k->d_err, 0, 4 * sizeof(int), k->stream));  // error word, frame tag of the hand-off granules, spare
     CS_HIP(hipHostMalloc((void**)&k->h_dest, sizeof(cs_klt_feature) * k->N + 8 * sizeof(int), hipHostMallocDefault));
     CS_HIP(hipHostMalloc((void**)&k->h_counts, sizeof(int) * 8, hipHostMallocDefault));
     CS_HIP(hipHostMalloc((void**)&k->h_feat, sizeof(float) * 3 * k->presentCap, hipHostMallocDefault));

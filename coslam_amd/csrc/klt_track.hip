@@ -307,10 +307,15 @@ __global__ __launch_bounds__(256) void k_track_gain_pass(CsGainPassArgs A) {
 // The Jacobi coupling between features is only through the gains of <= 6 neighbouring slots, so instead of a
 // kernel boundary per pass (40 boundaries per frame, ~5 us each measured) every feature's wave stays resident for
 // the whole schedule and neighbours hand their gain over through memory: after pass p a wave publishes one
-// naturally aligned 8-byte granule {tag = p+1, beta} with a write-through (sc1) store into gran[p & 1][slot];
-// before pass p it sweeps its neighbours' granules in gran[(p-1) & 1] with L1-bypassing loads until every tag
-// is >= p (MI355X guide, Guideline 16 recipe R2: the data is the flag, no fences).  Two parities suffice: a wave
-// can only overwrite beta_{p-1} after it has read its neighbours' beta_p, i.e. after they finished pass p.
+// naturally aligned 8-byte granule {tag, beta} with a write-through (sc1) store into row p + 1 of gran[passes + 1][N];
+// before pass p it sweeps its neighbours' granules in row p with L1-bypassing loads until every tag equals the one
+// pass p - 1 publishes (MI355X guide, Guideline 16 recipe R2: the data is the flag, no fences).  One row per pass and
+// tags offset by a per-frame base (a device word the frame's last kernel bumps): a granule is written once per frame
+// and what a row still holds from the previous frame can never match, so nothing is zeroed and nothing is ever
+// overwritten under a reader.  (Two rows alternating by parity were the first design; they are only safe when the
+// neighbour relation is symmetric, and the reference's betaN1 offsets are not for every slot grid -- 100 x 50 has
+// (1,1) without (-1,-1) -- so a wave two passes ahead of a reader it does not itself read could overwrite the gain the
+// reader was about to fetch: a handful of gains differing in the 6th digit from run to run.)
 // Dead features keep sweeping and publishing beta = -1 so the protocol never waits on them.  Every wave of
 // the grid must be co-resident (the launcher checks the grid against the device); every spin is bounded and a
 // timeout raises *err instead of hanging the GPU.  Frame-0 samples are fetched once per level and kept in
@@ -349,9 +354,8 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
     bool dead = (X1x < 0) || (X0x < 0);
     float pX = X1x, pY = X1y, pB = 1.0f;
 
-    cs_granule* gran0 = A.gran;
-    cs_granule* gran1 = A.gran + A.N;
-    if (lane == 0) gran_store(gran0 + k, 1u, 1.0f);  // beta_0 = 1 for every slot, dead or alive
+    const unsigned tagBase = *A.tagWord;  // frame-unique: what the rows hold from the previous frame can never match
+    if (lane == 0) gran_store(A.gran + k, tagBase + 1u, 1.0f);  // row 0: beta_0 = 1 for every slot, dead or alive
 
     // neighbour slots: lanes 0..3 = betaN1, lanes 4..7 = betaN2 (klt_tracker_with_gain.cg:64-72); every other
     // lane (and a neighbour that clamps onto the slot itself) points at the wave's own granule, whose line the
@@ -412,7 +416,8 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
         bool patchValid = false;
         for (int iter = 1; iter <= A.nIter; ++iter) {
             ++pass;
-            const cs_granule* src = (((pass - 1) & 1u) ? gran1 : gran0) + nbSlot;
+            const cs_granule* src = A.gran + (size_t)(pass - 1) * A.N + nbSlot;
+            const unsigned want = tagBase + pass;
             if (PROBE) tm0 = __builtin_amdgcn_s_memtime();
             float J1[NPL], J1x[NPL], J1y[NPL];
             if (!dead) {
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
             {
                 unsigned spins = 0;
 #pragma nounroll
-                while (!__all(!polls || ((unsigned)(got >> 32) >= pass))) {
+                while (!__all(!polls || ((unsigned)(got >> 32) == want))) {
                     for (int z = 0; z < A.pollGap; ++z) __builtin_amdgcn_s_sleep(1);
                     got = gran_load(src);
                     if (PROBE) ++nPoll;
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
             X1y = newY;
             beta = newB;
             dead = dead || (newX < 0);
-            if (lane == 0) gran_store(((pass & 1u) ? gran1 : gran0) + k, pass + 1u, beta);
+            if (lane == 0) gran_store(A.gran + (size_t)pass * A.N + k, want + 1u, beta);
             if (PROBE) {
                 tm1 = __builtin_amdgcn_s_memtime();
                 tPost += tm1 - tm0;

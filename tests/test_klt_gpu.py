@@ -322,18 +322,19 @@ def test_graph_replay_matches_eager(hip):
         assert np.array_equal(fa["pos"][live], fb["pos"][live])
 
 
-@pytest.mark.parametrize("levels", [4, 6])
-def test_frame_front_prefetch_matches_unprefetched(hip, levels):
+@pytest.mark.parametrize("W,H,levels,fw,fh", [(640, 480, 4, 50, 40), (640, 480, 6, 50, 40), (333, 241, 3, 20, 15),
+                                              (1920, 1080, 4, 100, 50)])
+def test_frame_front_prefetch_matches_unprefetched(hip, W, H, levels, fw, fh):
     """cs_klt_prefetch_dev (next frame's pyramid + cornerness built by this frame's detector-tail launches, third pyramid
     buffer, second cornerness map) gives the unprefetched results bit for bit -- also when a prefetch names the wrong
     image, when track-only frames sit in between, and with no host synchronisation between frames."""
     import torch
 
-    W, H, fw, fh = 640, 480, 50, 40
-    sc = Scene(1, W, H, 4000, seed=52)
+    nf = 9 if W <= 640 else 4   # distinct frames (rendering 1080p scenes on the host is the slow part)
+    sc = Scene(1, W, H, 4000 if W <= 640 else 12000, seed=52)
     cfg = cfg2(nLevels=levels)
     dev = torch.device("cuda:0")
-    frames = [torch.from_numpy(sc.render(0, f % 9)).to(dev) for f in range(9)]
+    frames = [torch.from_numpy(sc.render(0, f)).to(dev) for f in range(nf)]
     n_steps = 16
     plan = ["detect"] + ["redetect"] * 6 + ["track", "track"] + ["redetect"] * 7
     res = []
@@ -344,11 +345,11 @@ def test_frame_front_prefetch_matches_unprefetched(hip, levels):
         d_dests = [torch.zeros(fw * fh * 5, dtype=torch.int32, device=dev) for _ in range(n_steps)]
         d_counts = [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(n_steps)]
         for f in range(n_steps):
-            img = frames[f % 9]
+            img = frames[f % nf]
             fn = {"detect": t.detect_dev, "redetect": t.redetect_dev, "track": t.track_dev}[plan[f]]
             if prefetch and f + 1 < n_steps:
                 # f == 4: prefetch the WRONG image -- must be ignored by the next call
-                t.prefetch_dev(frames[(f + 1 + (3 if f == 4 else 0)) % 9].data_ptr())
+                t.prefetch_dev(frames[(f + 1 + (2 if f == 4 else 0)) % nf].data_ptr())
             fn(img.data_ptr(), d_dests[f].data_ptr(), d_counts[f].data_ptr())
             t.advanceFrame()
         torch.cuda.synchronize()
@@ -390,6 +391,40 @@ def test_persistent_gain_tracker_is_bit_identical_to_per_pass_launches(hip, leve
         live = d0["status"] >= 0
         assert np.array_equal(d0["pos"][live], d1["pos"][live]) and np.array_equal(d0["gain"][live], d1["gain"][live])
         assert np.array_equal(f0, f1)
+
+
+def test_persistent_gain_tracker_with_asymmetric_neighbour_offsets(hip):
+    """A 100 x 50 slot grid makes the reference's betaN1 offsets asymmetric ((1,1) without (-1,-1)): a wave may run
+    passes ahead of a slot that reads it.  Every granule row is written once per frame under a frame-unique tag, so the
+    result must still be the per-pass schedule's, bit for bit, frame after frame (1080p, 5000 slots, 20 frames)."""
+    import torch
+
+    W, H, fw, fh = 1920, 1080, 100, 50
+    sc = Scene(1, W, H, 12000, seed=52)
+    cfg = cfg2()
+    dev = torch.device("cuda:0")
+    frames = [torch.from_numpy(sc.render(0, f)).to(dev) for f in range(4)]
+    res = []
+    for fused in (0, 1, 1):
+        t = coslam_amd.KLT_SequenceTracker(cfg, 0)
+        t.allocate(W, H, 4, fw, fh)
+        t.set_stream(torch.cuda.current_stream().cuda_stream)
+        t.set_fused(fused)
+        n = 21
+        d_dests = [torch.zeros(fw * fh * 5, dtype=torch.int32, device=dev) for _ in range(n)]
+        d_counts = torch.zeros(4, dtype=torch.int32, device=dev)
+        for f in range(n):
+            (t.detect_dev if f == 0 else t.redetect_dev)(frames[f % 4].data_ptr(), d_dests[f].data_ptr(), d_counts.data_ptr())
+            t.advanceFrame()
+        torch.cuda.synchronize()
+        res.append([d.cpu().numpy().view(coslam_amd.KLT_TrackedFeature).copy() for d in d_dests])
+        t.close()
+    for other in (1, 2):
+        for f, (a, b) in enumerate(zip(res[0], res[other])):
+            assert np.array_equal(a["status"], b["status"]), f
+            live = a["status"] >= 0
+            assert np.array_equal(a["pos"][live], b["pos"][live]), f
+            assert np.array_equal(a["gain"][live], b["gain"][live]), f
 
 
 def test_persistent_gain_tracker_under_uneven_foreign_load(hip):
