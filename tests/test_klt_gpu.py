@@ -365,7 +365,9 @@ def test_frame_front_prefetch_matches_unprefetched(hip, W, H, levels, fw, fh):
 
 
 @pytest.mark.parametrize("levels,skip,iters,win,grid", [(4, 1, 10, 7, (50, 40)), (6, 2, 12, 6, (32, 32)), (3, 1, 1, 7, (20, 15)),
-                                                       (3, 1, 3, 11, (20, 20)), (2, 1, 5, 7, (7, 5))])
+                                                       (3, 1, 3, 11, (20, 20)), (2, 1, 5, 7, (7, 5)),
+                                                       (4, 1, 10, 7, (64, 17)), (4, 1, 10, 7, (37, 53)),
+                                                       (4, 1, 10, 7, (100, 50)), (4, 1, 10, 7, (90, 30))])
 def test_persistent_gain_tracker_is_bit_identical_to_per_pass_launches(hip, levels, skip, iters, win, grid):
     """One persistent launch with granule hand-offs == the reference's one-launch-per-pass Jacobi schedule."""
     W, H = 640, 480
