@@ -322,9 +322,9 @@ def test_graph_replay_matches_eager(hip):
         assert np.array_equal(fa["pos"][live], fb["pos"][live])
 
 
-@pytest.mark.parametrize("W,H,levels,fw,fh", [(640, 480, 4, 50, 40), (640, 480, 6, 50, 40), (333, 241, 3, 20, 15),
-                                              (1920, 1080, 4, 100, 50)])
-def test_frame_front_prefetch_matches_unprefetched(hip, W, H, levels, fw, fh):
+@pytest.mark.parametrize("W,H,levels,fw,fh,mind", [(640, 480, 4, 50, 40, 5), (640, 480, 6, 50, 40, 5), (333, 241, 3, 20, 15, 5),
+                                                   (1920, 1080, 4, 100, 50, 5), (640, 480, 4, 20, 15, 40)])
+def test_frame_front_prefetch_matches_unprefetched(hip, W, H, levels, fw, fh, mind):
     """cs_klt_prefetch_dev (next frame's pyramid + cornerness built by this frame's detector-tail launches, third pyramid
     buffer, second cornerness map) gives the unprefetched results bit for bit -- also when a prefetch names the wrong
     image, when track-only frames sit in between, and with no host synchronisation between frames."""
@@ -332,7 +332,7 @@ def test_frame_front_prefetch_matches_unprefetched(hip, W, H, levels, fw, fh):
 
     nf = 9 if W <= 640 else 4   # distinct frames (rendering 1080p scenes on the host is the slow part)
     sc = Scene(1, W, H, 4000 if W <= 640 else 12000, seed=52)
-    cfg = cfg2(nLevels=levels)
+    cfg = cfg2(nLevels=levels, minDistance=mind)  # minDistance 40: the non-max tile outgrows the fused tail's LDS
     dev = torch.device("cuda:0")
     frames = [torch.from_numpy(sc.render(0, f)).to(dev) for f in range(nf)]
     n_steps = 16
