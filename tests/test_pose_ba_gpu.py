@@ -98,6 +98,34 @@ def test_ba_matches_oracle(hip, kw, ncon, npcon, maxIter, inner):
         assert st_g.cost < 1e-12 and np.max(np.abs(pts - pr["pts_gt"])) < 1e-8
 
 
+@pytest.mark.parametrize("case", range(14))
+def test_ba_random_shapes(hip, case):
+    """Seeded random problem shapes (camera / point counts, ragged visibility, gauge sizes, outlier rates, iteration
+    budgets): flags and iteration counts equal to the oracle's, parameters to 1e-6."""
+    rng = np.random.default_rng(1000 + case)
+    n_cams = int(rng.integers(2, 9))
+    n_pts = int(rng.integers(12, 320))
+    ncon = int(rng.integers(0, min(3, n_cams)))
+    npcon = int(rng.integers(0, n_pts // 2))
+    if ncon == 0 and npcon < 4:
+        npcon = 4                       # some gauge must be held
+    kw = dict(n_cams=n_cams, n_pts=n_pts, n_cams_con=ncon, n_pts_con=npcon, visibility=float(rng.uniform(0.45, 1.0)),
+              outlier_frac=float(rng.choice([0.0, 0.03, 0.1])), noise=float(rng.choice([0.0, 0.3, 1.0])), seed=2000 + case)
+    maxIter, inner = int(rng.integers(1, 4)), int(rng.integers(1, 16))
+    pr, ptr, cam, xy = ba_inputs(**kw)
+    Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+    out_g, st_g = coslam_amd.bundleAdjustRobust(ncon, pr["Ks"], Rs, Ts, npcon, pts, (ptr, cam, xy), 6.0, maxIter, inner)
+    R_o, T_o, M_o, out_o, st_o = oracle.ba_robust(pr["Ks"], pr["Rs0"], pr["ts0"], pr["pts0"], ptr, cam, xy, ncon, npcon,
+                                                  6.0, maxIter, inner)
+    assert np.array_equal(out_g, out_o), (kw, (out_g != out_o).sum())
+    assert st_g.nOuter == st_o.nOuter and st_g.nIterTotal == st_o.nIterTotal, kw
+    sane = np.linalg.norm(M_o, axis=1) < 1e3
+    scale = max(1.0, np.abs(M_o[sane]).max())
+    assert np.max(np.abs(Rs - R_o)) < 1e-6 and np.max(np.abs(Ts - T_o)) < 1e-6 * scale, kw
+    assert np.max(np.abs(pts[sane] - M_o[sane])) < 1e-6 * scale, kw
+    assert abs(st_g.cost - st_o.cost) <= 1e-7 * max(1.0, st_o.cost), kw
+
+
 def test_ba_edge_cases(hip):
     # all cameras fixed: structure-only refinement
     pr, ptr, cam, xy = ba_inputs(n_cams=4, n_pts=50, n_cams_con=4, n_pts_con=0, outlier_frac=0.0)
