@@ -2,6 +2,8 @@
 seeded synthetic inputs.  Bit-exact for the pyramid, the cornerness map, the detection set and the
 slot tables (binary16/32 with a fixed evaluation order); <= 0.02 px for tracked positions, where the
 wave-wide summation order differs from the oracle's serial order (tolerance from SURVEY.md 8d)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -154,6 +156,41 @@ def test_track_parity(hip, gain, levels, skip, win):
     if gain:
         assert np.max(np.abs(d_g["gain"][live] - d_o["gain"][live])) < 1e-3
     assert abs(n_g - n_o) <= (~same).sum()
+    trk.close()
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("COSLAM_TEST_CASES", "10"))))
+def test_random_configurations_match_the_oracle(hip, case):
+    """Seeded random tracker configurations (image size, levels, skip, window, iterations, slot grid, thresholds, gain on /
+    off): detect + redetect + track against the oracle, same tolerances as the fixed-configuration tests."""
+    rng = np.random.default_rng(500 + case)
+    W, H = int(rng.integers(180, 420)), int(rng.integers(140, 320))
+    levels = int(rng.integers(2, 5))
+    while (min(W, H) >> (levels - 1)) < 12:
+        levels -= 1
+    cfg = cfg2(trackWithGain=int(rng.integers(0, 2)), nLevels=levels, levelSkip=int(rng.integers(1, 3)),
+               windowWidth=int(rng.choice([5, 6, 7, 9, 11])), nIterations=int(rng.integers(1, 13)),
+               minDistance=int(rng.integers(3, 10)), minCornerness=float(rng.choice([800.0, 1500.0, 3000.0])),
+               convergenceThreshold=float(rng.choice([0.5, 1.0, 2.0])), SSD_Threshold=float(rng.choice([5000.0, 20000.0])))
+    fw, fh = int(rng.integers(6, 26)), int(rng.integers(5, 22))
+    sc = Scene(1, W, H, 1500, seed=700 + case, sigma=1.4)
+    trk, ora = make_pair(cfg, W, H, levels, fw, fh)
+    img = sc.render(0, 0)
+    n_g, d_g = trk.detect(img)
+    n_o, d_o = ora.detect(img)
+    assert n_g == n_o and np.array_equal(d_g["status"], d_o["status"])
+    assert np.array_equal(d_g["pos"][d_o["status"] >= 0], d_o["pos"][d_o["status"] >= 0])
+    trk.advanceFrame()
+    ora.advanceFrame()
+    for f, call in ((1, "redetect"), (2, "track"), (3, "redetect")):
+        img = sc.render(0, f)
+        n_g, d_g = getattr(trk, call)(img)
+        n_o, d_o = getattr(ora, call)(img)
+        same, live, emax = compare_dest(d_g, d_o, W, H, min_same=0.98)
+        assert emax <= TOL_PX * f, (case, f, call, emax)
+        assert abs(n_g - n_o) <= 2 * (~same).sum() + 2, (case, f, call)
+        trk.advanceFrame()
+        ora.advanceFrame()
     trk.close()
 
 
