@@ -805,12 +805,12 @@ __global__ __launch_bounds__(64) void k_solve_wave(BaDev D) {
 // Lane i keeps row i of S in NMAX registers; both loops are fully unrolled, so every index is static and every
 // cross-lane read is a v_readlane of a constant lane: no LDS, no barrier, one reciprocal square root per column.
 // Rows/columns n..NMAX-1 are identity padding.
-// Called by all 256 threads of a workgroup; on return Ssm[NMAX * NMAX + r] holds the solved camera step and
-// *okSh the Cholesky status (both in LDS, visible to the whole workgroup).
+// solve_reg_combine then solve_reg_factor, both called by all 256 threads of a workgroup; on return
+// Ssm[NMAX * NMAX + r] holds the solved camera step and *okSh the Cholesky status (both in LDS, visible to the whole
+// workgroup).
 template <int NMAX>
-__device__ __forceinline__ void solve_reg_block(const BaDev& D, double* Ssm, int* okSh) {
+__device__ __forceinline__ void solve_reg_combine(const BaDev& D, double* Ssm) {
     // all four waves add the slice partials of k_schur_part (slice order) into the reduced system in LDS ...
-    const int n = D.n;
     {
         const double lambda = D.st->lambda;
         const int nPairs = D.nc * (D.nc + 1) / 2;
@@ -832,10 +832,20 @@ __device__ __forceinline__ void solve_reg_block(const BaDev& D, double* Ssm, int
                     uq = 21 + (q - 36);
                 }
             }
+            // all slice loads of this entry are issued before the first is consumed (a loop with a run-time trip count
+            // is not unrolled, and eight dependent round trips were 6.4 us of this 17 us kernel, s_memtime); the slices
+            // are still added in slice order, the padding adds exact zeros
+            double sv[16], uv[16];
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl) {
+                sv[sl] = (sl < D.nSlices) ? p[sl * 72 + q] : 0.0;
+                uv[sl] = (sl < D.nSlices && uq >= 0) ? p[sl * 72 + 42 + uq] : 0.0;
+            }
             double sSum = 0, uSum = 0;
-            for (int sl = 0; sl < D.nSlices; ++sl) {
-                sSum += p[sl * 72 + q];
-                if (uq >= 0) uSum += p[sl * 72 + 42 + uq];
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl) {
+                sSum += sv[sl];
+                uSum += uv[sl];
             }
             if (q < 36) {
                 const int r = q / 6, c = q - 6 * r;
@@ -851,6 +861,11 @@ __device__ __forceinline__ void solve_reg_block(const BaDev& D, double* Ssm, int
         }
     }
     __syncthreads();
+}
+
+template <int NMAX>
+__device__ __forceinline__ void solve_reg_factor(const BaDev& D, double* Ssm, int* okSh) {
+    const int n = D.n;
     if (threadIdx.x < 64) {
     // ... and wave 0 factorises it out of registers
     const int i = threadIdx.x;
@@ -913,8 +928,11 @@ __global__ __launch_bounds__(256) void k_update(BaDev D) {
     __shared__ double red[4];
     __shared__ double Ssm[NMAX > 0 ? NMAX * NMAX + NMAX : 1];
     __shared__ int okSh;
-    // Everything the point step and the tentative residuals read that does NOT depend on the solve is loaded first: the
-    // loads then fly under the combine + Cholesky below instead of starting a fresh miss chain behind it.
+    // The partials of the reduced system are the first thing on the critical path (combine -> factorisation) and the
+    // last thing the previous launch wrote: their loads go out first, alone.
+    if (NMAX > 0) solve_reg_combine<(NMAX > 0 ? NMAX : 1)>(D, Ssm);
+    // Everything the point step and the tentative residuals read that does NOT depend on the solve is loaded now: the
+    // loads fly under the factorisation below instead of starting a fresh miss chain behind it.
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const bool mine = gw < D.P && gw >= D.pLo && gw < D.pHi;
@@ -949,7 +967,7 @@ __global__ __launch_bounds__(256) void k_update(BaDev D) {
     }
     const double* rhs = D.rhs;
     if (NMAX > 0) {
-        solve_reg_block<(NMAX > 0 ? NMAX : 1)>(D, Ssm, &okSh);
+        solve_reg_factor<(NMAX > 0 ? NMAX : 1)>(D, Ssm, &okSh);
         rhs = Ssm + NMAX * NMAX;
         if (blockIdx.x == 0) {
             if (threadIdx.x < D.n) D.rhs[threadIdx.x] = rhs[threadIdx.x];
