@@ -427,10 +427,22 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
                 if (!patchValid || iLo < rx0 || jLo < ry0 || iHi >= rx0 + R || jHi >= ry0 + R) {
                     rx0 = iLo - CS_PATCH_MARGIN;
                     ry0 = jLo - CS_PATCH_MARGIN;
-                    for (int idx = lane; idx < R * R; idx += 64) {
-                        const int ly = idx / R, lx = idx - ly * R;
-                        const int gx = cs_clampi(rx0 + lx, 0, Wl - 1), gy = cs_clampi(ry0 + ly, 0, Hl - 1);
-                        patch[idx] = L1[(size_t)gy * Wl + gx];
+                    // four texels per lane per batch, every load issued before the first LDS store: a loop with a
+                    // run-time trip count is not unrolled and would make the 144-texel fill three dependent round trips
+                    for (int base = lane; base < R * R; base += 256) {
+                        cs_texel tv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int idx = base + 64 * u;
+                            const int ly = idx / R, lx = idx - ly * R;
+                            const int gx = cs_clampi(rx0 + lx, 0, Wl - 1), gy = cs_clampi(ry0 + ly, 0, Hl - 1);
+                            tv[u] = L1[(size_t)gy * Wl + gx];  // (clamped: in range even when idx >= R * R)
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int idx = base + 64 * u;
+                            if (idx < R * R) patch[idx] = tv[u];
+                        }
                     }
                     patchValid = true;
                     if (PROBE) ++nReload;
