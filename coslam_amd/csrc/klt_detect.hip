@@ -96,10 +96,22 @@ __device__ __forceinline__ void nonmax_body(const CsNonmaxArgs& Z, int bx, int b
     float* raw = smem;              // [RH][RW]
     float* rowres = smem + RH * RW;  // [RH][NTW]
     const int x0 = bx * NTW, y0 = by * NTH;
-    for (int i = tid; i < RH * RW; i += 256) {
-        int ly = i / RW, lx = i - ly * RW;
-        int gx = cs_clampi(x0 + lx - d, 0, W - 1), gy = cs_clampi(y0 + ly - d, 0, H - 1);
-        raw[i] = in[(size_t)gy * W + gx];
+    // the tile's loads go out in batches of eight per thread before any LDS store: RW and RH are run-time values, the loop
+    // is not unrolled, and one load per trip would be (RH * RW / 256) dependent round trips
+    for (int base = tid; base < RH * RW; base += 8 * 256) {
+        float tv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + 256 * u;
+            const int ly = i / RW, lx = i - ly * RW;
+            const int gx = cs_clampi(x0 + lx - d, 0, W - 1), gy = cs_clampi(y0 + ly - d, 0, H - 1);
+            tv[u] = in[(size_t)gy * W + gx];  // (clamped: in range even when i >= RH * RW)
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + 256 * u;
+            if (i < RH * RW) raw[i] = tv[u];
+        }
     }
     __syncthreads();
     // klt_detector_nonmax.cg:12-26 with ds = (1/W, 0)

@@ -50,11 +50,25 @@ __device__ __forceinline__ void cs_level0_body(const uint8_t* __restrict__ img, 
     }
     const int x0 = bx * FTW, y0 = by * FTH;
     const int rx0 = x0 - CR, ry0 = y0 - CR;
-    for (int i = tid; i < (RH + 2 * HALO) * (RW + 2 * HALO); i += 256) {
-        int ly = i / (RW + 2 * HALO), lx = i - ly * (RW + 2 * HALO);
-        int gx = cs_clampi(rx0 + lx - HALO, 0, W - 1);
-        int gy = cs_clampi(ry0 + ly - HALO, 0, H - 1);
-        g[ly][lx] = ((float)img[(size_t)gy * W + gx] / 255.0f) * 255.0f;
+    {  // the tile's pixel loads in one batch per thread, ahead of the LDS stores
+        constexpr int NG = (RH + 2 * HALO) * (RW + 2 * HALO), NB = (NG + 255) / 256;
+        uint8_t pv[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int i = tid + 256 * u;
+            const int ly = i / (RW + 2 * HALO), lx = i - ly * (RW + 2 * HALO);
+            const int gx = cs_clampi(rx0 + lx - HALO, 0, W - 1);
+            const int gy = cs_clampi(ry0 + ly - HALO, 0, H - 1);
+            pv[u] = img[(size_t)gy * W + gx];  // (clamped: in range even when i >= NG)
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int i = tid + 256 * u;
+            if (i < NG) {
+                const int ly = i / (RW + 2 * HALO), lx = i - ly * (RW + 2 * HALO);
+                g[ly][lx] = ((float)pv[u] / 255.0f) * 255.0f;
+            }
+        }
     }
     __syncthreads();
     for (int i = tid; i < RH * (RW + 2 * HALO); i += 256) {
