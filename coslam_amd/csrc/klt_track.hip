@@ -393,6 +393,23 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
         const float dsx = 1.0f / (float)Wl, dsy = 1.0f / (float)Hl;
         const float oxLo = (float)(-hw) * dsx, oxHi = (float)hw * dsx, oyLo = (float)(-hw) * dsy, oyHi = (float)hw * dsy;
         float ox[NPL], oy[NPL], I0[NPL], I0x[NPL], I0y[NPL];
+        // The level's first patch fill is known here (the iterate does not move between levels), so its loads go out
+        // TOGETHER with the frame-0 samples below: one round trip to the freshly written pyramid instead of two.
+        int rx0 = 0, ry0 = 0;
+        bool patchValid = false;
+        cs_texel tvL[4];
+        const bool preFill = !dead && R * R <= 256;
+        if (preFill) {
+            rx0 = footprint_floor(X1x + oxLo, Wl) - CS_PATCH_MARGIN;
+            ry0 = footprint_floor(X1y + oyLo, Hl) - CS_PATCH_MARGIN;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = lane + 64 * u;
+                const int ly = idx / R, lx = idx - ly * R;
+                const int gx = cs_clampi(rx0 + lx, 0, Wl - 1), gy = cs_clampi(ry0 + ly, 0, Hl - 1);
+                tvL[u] = L1[(size_t)gy * Wl + gx];  // (clamped: in range even when idx >= R * R)
+            }
+        }
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
             int p = lane + 64 * q;
@@ -412,8 +429,18 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
             }
         }
         fLevel = cs_wave_sum(fLevel);
-        int rx0 = 0, ry0 = 0;
-        bool patchValid = false;
+        if (preFill) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = lane + 64 * u;
+                if (idx < R * R) patch[idx] = tvL[u];
+            }
+            patchValid = true;
+            if (PROBE) ++nReload;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         for (int iter = 1; iter <= A.nIter; ++iter) {
             ++pass;
             const cs_granule* src = A.gran + (size_t)(pass - 1) * A.N + nbSlot;
