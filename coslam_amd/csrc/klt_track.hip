@@ -538,6 +538,9 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
                 tMath += tm1 - tm0;
                 tm0 = tm1;
             }
+            // From here to the publish the wave is on the mesh's critical path (its neighbours wait for the granule):
+            // it outranks the co-resident waves that are still in their pre-sweep arithmetic.
+            __builtin_amdgcn_s_setprio(3);
             // ---- sweep the neighbours' granules of the previous pass ----------------------------------------
             float nbBeta = beta;
             {
@@ -591,6 +594,7 @@ __global__ __launch_bounds__(256) void k_track_gain_fused(CsGainFusedArgs A) {
             beta = newB;
             dead = dead || (newX < 0);
             if (lane == 0) gran_store(A.gran + (size_t)pass * A.N + k, want + 1u, beta);
+            __builtin_amdgcn_s_setprio(2);  // still above any foreign wave (pose, BA: priority 0)
             if (PROBE) {
                 tm1 = __builtin_amdgcn_s_memtime();
                 tPost += tm1 - tm0;
