@@ -1154,9 +1154,19 @@ __global__ __launch_bounds__(256) void k_control_step(BaDev D) {
     const int tid = threadIdx.x;
     const int all_done = st->all_done, inner_done = st->inner_done, chol_ok = st->chol_ok, inner_it = st->inner_it;
     const double cost_old = st->cost, lambda = st->lambda;
-    double c = 0, s2 = 0;
-    for (int q = tid; q < D.nUpdBlocks; q += 256) c += D.costPart[q];
-    for (int q = tid; q < D.P + D.C; q += 256) s2 += D.stepPart[q];
+    // both partial lists in one batch of loads per thread (a loop with a run-time trip count would make the second
+    // trip wait for the first); same order of additions as before
+    double cv[2], sv[8];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int q = tid + 256 * k;
+        cv[k] = (q < D.nUpdBlocks) ? D.costPart[q] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int q = tid + 256 * k;
+        sv[k] = (q < D.P + D.C) ? D.stepPart[q] : 0.0;
+    }
     constexpr int PRE = 8;
     const int nR = 9 * D.C, nT = 3 * D.C, total = nR + nT + 3 * D.P;
     double pre[PRE];
@@ -1166,6 +1176,13 @@ __global__ __launch_bounds__(256) void k_control_step(BaDev D) {
         pre[k] = (q < nR) ? D.Rn[q] : (q < nR + nT) ? D.Tn[q - nR] : (q < total) ? D.Mn[q - nR - nT] : 0.0;
     }
     if (all_done || inner_done) return;
+    double c = 0, s2 = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) c += cv[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s2 += sv[k];
+    for (int q = tid + 512; q < D.nUpdBlocks; q += 256) c += D.costPart[q];
+    for (int q = tid + 2048; q < D.P + D.C; q += 256) s2 += D.stepPart[q];
     c = wsum(c);
     s2 = wsum(s2);
     if ((tid & 63) == 0) {
