@@ -886,15 +886,19 @@ __device__ __forceinline__ void solve_reg_factor(const BaDev& D, double* Ssm, in
         // 1/sqrt(d): the hardware estimate + two Newton steps (full binary64 accuracy) is a ~12-instruction dependent
         // chain; IEEE sqrt followed by an IEEE division is ~50, and this chain is the critical path of every column
         double rd = __builtin_amdgcn_rsq(d);
-        rd = rd * (1.5 - (0.5 * d) * rd * rd);
-        rd = rd * (1.5 - (0.5 * d) * rd * rd);
+        const double hd = 0.5 * d;
+        rd = __builtin_fma(rd, __builtin_fma(-(hd * rd), rd, 0.5), rd);  // y += y (1/2 - (d/2) y^2)
+        rd = __builtin_fma(rd, __builtin_fma(-(hd * rd), rd, 0.5), rd);
         rdiag[j] = rd;
         const double lij = (i > j) ? cj * rd : 0.0;
         a[j] = lij;
         const double yj = rdlane_d(b, j) * rd;
-        b = (i == j) ? yj : (b - lij * yj);
+        b = (i == j) ? yj : __builtin_fma(-lij, yj, b);
+        // (fused multiply-adds here and in the back substitution: this solve already differs from the oracle's in the
+        // last bits -- reciprocal square roots instead of sqrt + division -- and the chain below is the longest
+        // dependent instruction sequence of the LM step)
 #pragma unroll
-        for (int k = j + 1; k < NMAX; ++k) a[k] -= lij * rdlane_d(lij, k);
+        for (int k = j + 1; k < NMAX; ++k) a[k] = __builtin_fma(-lij, rdlane_d(lij, k), a[k]);
     }
     // L^T x = y as a column sweep over the rows of L, which go back to LDS (row i by lane i) for the transposed reads
     if (i < NMAX) {
@@ -908,7 +912,7 @@ __device__ __forceinline__ void solve_reg_factor(const BaDev& D, double* Ssm, in
     for (int j = NMAX - 1; j >= 0; --j) {
         const double xj = rdlane_d(b, j) * rdiag[j];
         if (i == j) b = xj;
-        if (i < j) b -= Ssm[j * NMAX + i] * xj;
+        if (i < j) b = __builtin_fma(-Ssm[j * NMAX + i], xj, b);
     }
     if (i < n) Ssm[NMAX * NMAX + i] = b;
     if (i == 0) *okSh = ok ? 1 : 0;
