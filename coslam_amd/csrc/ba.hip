@@ -56,6 +56,7 @@ struct BaDev {
     BaState* st;
     int nCostBlocks, nUpdBlocks, nSlices;
     int pLo, pHi, addLambda;  // point slice owned by this rank ([0, P) and 1 in the single-process solve)
+    int maxObsPerPoint;       // largest measurement count of a point (computed at upload)
     double* scal;             // [4] cost / point-step / flags-changed / outlier-count partials (distributed solve)
     double* schurPart;  // [nPairs][nSlices][72] partial Schur blocks (orders <= 36)
     double maxErr;
@@ -212,6 +213,91 @@ __global__ __launch_bounds__(256) void k_linearize(BaDev D) {
     }
     cs_wave_sum_many_d<9>(acc);
     if (lane == 0) {
+        double Vi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (freeP) {
+            double V[9] = {acc[0] + lambda, acc[1], acc[2], acc[1], acc[3] + lambda, acc[4], acc[2], acc[4], acc[5] + lambda};
+            if (!inv33(V, Vi)) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) Vi[q] = 0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) D.Vinv[9 * (size_t)i + q] = Vi[q];
+        D.gp[3 * (size_t)i] = acc[6];
+        D.gp[3 * (size_t)i + 1] = acc[7];
+        D.gp[3 * (size_t)i + 2] = acc[8];
+    }
+}
+
+// ---- eight lanes per point ---------------------------------------------------------------------------------------
+// A local-BA point has a handful of measurements (one per key frame that sees it), so a wave per point leaves 59 of 64
+// lanes idle through ~400 f64 instructions per measurement -- and with two such workgroups per CU (the 64-CU partition)
+// the launch is bound by exactly that: 3.4 us of arithmetic on the whole chip, 5.4 us on the partition (s_memtime).
+// When no point has more than 8 measurements (maxObsPerPoint, known at upload) eight points share a wave: lane = (point,
+// measurement), the per-point sums are three DPP steps inside the 8-lane segment, one lane per segment inverts V.
+__device__ __forceinline__ double seg8_sum(double v) {
+    v += cs_dpp_d<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v += cs_dpp_d<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v += cs_dpp_d<0x141, 0xf>(v);  // row_half_mirror: the other quad of the segment
+    return v;
+}
+__global__ __launch_bounds__(256) void k_linearize_seg8(BaDev D) {
+    if (!BA_ACTIVE(D)) return;
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 3), k = threadIdx.x & 7;
+    const bool hasP = !(i >= D.P || i < D.pLo || i >= D.pHi);
+    const double lambda = D.st->lambda;
+    int o = -1;
+    double M[3] = {0, 0, 0};
+    if (hasP) {
+        const int o0 = D.obs_ptr[i], o1 = D.obs_ptr[i + 1];
+        if (o0 + k < o1) o = o0 + k;
+        M[0] = D.pts[3 * (size_t)i];
+        M[1] = D.pts[3 * (size_t)i + 1];
+        M[2] = D.pts[3 * (size_t)i + 2];
+    }
+    int j = 0;
+    bool in = false;
+    if (o >= 0) {
+        j = D.obs_cam[o];
+        in = !D.outlier[o];
+    }
+    const int nIn = (int)seg8_sum(in ? 1.0 : 0.0);
+    // a point seen by fewer than two inlier measurements has no depth constraint: hold it (DESIGN.md "Robust BA")
+    const bool freeP = hasP && (i >= D.nPtsCon) && (nIn >= 2);
+    double e[2] = {0, 0}, Jc[12], Jp[6];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) Jc[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) Jp[q] = 0;
+    if (in) residual<true>(D.Ks + 9 * j, D.Rs + 9 * j, D.Ts + 3 * j, M, D.obs_xy + 2 * (size_t)o, e, Jc, Jp);
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // V upper (6) + g (3)
+    if (in && freeP) {
+        acc[0] = Jp[0] * Jp[0] + Jp[3] * Jp[3];
+        acc[1] = Jp[0] * Jp[1] + Jp[3] * Jp[4];
+        acc[2] = Jp[0] * Jp[2] + Jp[3] * Jp[5];
+        acc[3] = Jp[1] * Jp[1] + Jp[4] * Jp[4];
+        acc[4] = Jp[1] * Jp[2] + Jp[4] * Jp[5];
+        acc[5] = Jp[2] * Jp[2] + Jp[5] * Jp[5];
+        acc[6] = Jp[0] * e[0] + Jp[3] * e[1];
+        acc[7] = Jp[1] * e[0] + Jp[4] * e[1];
+        acc[8] = Jp[2] * e[0] + Jp[5] * e[1];
+    }
+    if (o >= 0) {
+        double* Wo = D.W + 18 * (size_t)o;
+        double* Jo = D.Jc + 12 * (size_t)o;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) Jo[q] = Jc[q];
+        D.e[2 * (size_t)o] = e[0];
+        D.e[2 * (size_t)o + 1] = e[1];
+        const bool w = in && freeP && (j >= D.nCamsCon);
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Wo[3 * r + c] = w ? (Jc[r] * Jp[c] + Jc[6 + r] * Jp[3 + c]) : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc[q] = seg8_sum(acc[q]);
+    if (hasP && k == 0) {
         double Vi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (freeP) {
             double V[9] = {acc[0] + lambda, acc[1], acc[2], acc[1], acc[3] + lambda, acc[4], acc[2], acc[4], acc[5] + lambda};
@@ -1483,6 +1569,7 @@ struct cs_ba {
     size_t ioBytes, obBytes;
     unsigned char* slab;  // ONE device allocation behind every workspace array (few TLB entries for the whole solve)
     int nCostBlocks;
+    int maxObs;  // largest measurement count of a point of the uploaded problem
     // cached executable graph of one full solve (cs_ba_solve_dev): ~150 launches become one
     struct GraphKey {
         int C, P, nObs, nCamsCon, nPtsCon, maxIter, innerMaxIter;
@@ -1653,6 +1740,7 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
     D.pLo = 0;
     D.pHi = P;
     D.addLambda = 1;
+    D.maxObsPerPoint = b->maxObs;
     int cb = (nObs + 255) / 256;
     if (cb < 1) cb = 1;
     if (cb > 1024) cb = 1024;
@@ -1707,7 +1795,13 @@ static void ba_enqueue_init(cs_ba* b, hipStream_t stream, const BaPlan& L, bool 
 static void ba_enqueue_lin_schur(hipStream_t stream, const BaPlan& L) {
     const BaDev& D = L.D;
     const dim3 blk(256);
-    hipLaunchKernelGGL(k_linearize, dim3(L.gPts), blk, 0, stream, D);
+    {
+        static const bool noSeg = getenv("COSLAM_BA_SEG8") && getenv("COSLAM_BA_SEG8")[0] == '0';
+        if (D.maxObsPerPoint <= 8 && !noSeg)
+            hipLaunchKernelGGL(k_linearize_seg8, dim3((D.P + 31) / 32 > 0 ? (D.P + 31) / 32 : 1), blk, 0, stream, D);
+        else
+            hipLaunchKernelGGL(k_linearize, dim3(L.gPts), blk, 0, stream, D);
+    }
     if (D.nc > 0) {
         if (L.sliced)
             hipLaunchKernelGGL(k_schur_part, dim3(L.nPairs * D.nSlices), dim3(64), 0, stream, D);
@@ -1856,6 +1950,9 @@ int cs_ba_robust_h(cs_ba* b, int C, int P, int nObs, const double* Ks, double* R
         memcpy(b->h_io + L.pts, pts, sizeof(double) * 3 * P);
         memcpy(b->h_io + L.optr, obs_ptr, sizeof(int) * (P + 1));
     }
+    b->maxObs = 0;
+    for (int i = 0; i < P; ++i)
+        if (obs_ptr[i + 1] - obs_ptr[i] > b->maxObs) b->maxObs = obs_ptr[i + 1] - obs_ptr[i];
     if (nObs > 0) {
         memcpy(b->h_io + L.xy, obs_xy, sizeof(double) * 2 * nObs);
         memcpy(b->h_io + L.ocam, obs_cam, sizeof(int) * nObs);
