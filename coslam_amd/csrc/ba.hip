@@ -1181,6 +1181,139 @@ __global__ __launch_bounds__(256) void k_update(BaDev D) {
     }
 }
 
+// ---- tentative step + its cost, eight lanes per point (see k_linearize_seg8): 32 points per workgroup, so the redundant
+// combine + factorisation runs in 16 workgroups instead of 125 for the 500-point local BA, and the ~300 f64 instructions of
+// a measurement's tentative residual run with 40 of 64 lanes busy instead of 5.
+template <int NMAX>
+__global__ __launch_bounds__(256) void k_update_seg8(BaDev D) {
+    if (!BA_ACTIVE(D)) return;
+    __shared__ double red[4];
+    __shared__ double Ssm[NMAX * NMAX + NMAX];
+    __shared__ int okSh;
+    solve_reg_combine<NMAX>(D, Ssm);
+    const int lane = threadIdx.x & 63, k = threadIdx.x & 7;
+    const int gw = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool mine = gw < D.P && gw >= D.pLo && gw < D.pHi;
+    int o = -1, pj = 0, pout = 1;
+    double pW[18], pR[9], pT[3], pK[9], pxy[2] = {0, 0}, pVi[9], pg[3], pM[3];
+#pragma unroll
+    for (int q = 0; q < 18; ++q) pW[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) pR[q] = pK[q] = pVi[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) pT[q] = pg[q] = pM[q] = 0;
+    if (mine) {
+        const int o0 = D.obs_ptr[gw], o1 = D.obs_ptr[gw + 1];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) pVi[q] = D.Vinv[9 * (size_t)gw + q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            pg[q] = D.gp[3 * (size_t)gw + q];
+            pM[q] = D.pts[3 * (size_t)gw + q];
+        }
+        if (o0 + k < o1) {
+            o = o0 + k;
+            pj = D.obs_cam[o];
+            pout = D.outlier[o];
+#pragma unroll
+            for (int q = 0; q < 18; ++q) pW[q] = D.W[18 * (size_t)o + q];
+            pxy[0] = D.obs_xy[2 * (size_t)o];
+            pxy[1] = D.obs_xy[2 * (size_t)o + 1];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                pR[q] = D.Rs[9 * pj + q];
+                pK[q] = D.Ks[9 * pj + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) pT[q] = D.Ts[3 * pj + q];
+        }
+    }
+    solve_reg_factor<NMAX>(D, Ssm, &okSh);
+    const double* rhs = Ssm + NMAX * NMAX;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < D.n) D.rhs[threadIdx.x] = rhs[threadIdx.x];
+        if (threadIdx.x == 0) D.st->chol_ok = okSh;
+    }
+    double cost = 0;
+    if (gw < D.P && !mine) {
+        if (k == 0) D.stepPart[gw] = 0;  // another rank's point
+    } else if (mine) {
+        const int i = gw;
+        const bool inl = (o >= 0) && !pout;
+        double b[3] = {0, 0, 0};
+        if (i >= D.nPtsCon && inl && pj >= D.nCamsCon) {
+            const double* dc = rhs + 6 * (pj - D.nCamsCon);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int r = 0; r < 6; ++r) b[c] -= pW[3 * r + c] * dc[r];
+        }
+        b[0] = seg8_sum(b[0]);
+        b[1] = seg8_sum(b[1]);
+        b[2] = seg8_sum(b[2]);
+        double d[3] = {0, 0, 0};
+        if (i >= D.nPtsCon) {
+            const double g0 = pg[0] + b[0], g1 = pg[1] + b[1], g2 = pg[2] + b[2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) d[r] = pVi[3 * r] * g0 + pVi[3 * r + 1] * g1 + pVi[3 * r + 2] * g2;
+        }
+        double Mn[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Mn[r] = pM[r] + d[r];
+        if (k == 0) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) D.Mn[3 * (size_t)i + r] = Mn[r];
+            D.stepPart[i] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        }
+        if (inl) {
+            double Rn[9], Tn[3];
+            if (pj >= D.nCamsCon) {
+                const double* dc = rhs + 6 * (pj - D.nCamsCon);
+                double w[3] = {dc[0], dc[1], dc[2]}, dR[9];
+                so3_exp(w, dR);
+                mat33AB(pR, dR, Rn);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) Tn[q] = pT[q] + dc[3 + q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) Rn[q] = pR[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) Tn[q] = pT[q];
+            }
+            double e[2];
+            residual<false>(pK, Rn, Tn, Mn, pxy, e, nullptr, nullptr);
+            cost = e[0] * e[0] + e[1] * e[1];
+        }
+    }
+    cost = wsum(cost);
+    if (lane == 0) red[threadIdx.x >> 6] = cost;
+    __syncthreads();
+    if (threadIdx.x == 0) D.costPart[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < D.C) {
+        const int j = t;
+        double s2 = 0;
+        if (j >= D.nCamsCon) {
+            const double* dc = rhs + 6 * (j - D.nCamsCon);
+            double w[3] = {dc[0], dc[1], dc[2]}, dR[9], Rn[9];
+            so3_exp(w, dR);
+            mat33AB(D.Rs + 9 * j, dR, Rn);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) D.Rn[9 * j + q] = Rn[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) D.Tn[3 * j + q] = D.Ts[3 * j + q] + dc[3 + q];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) s2 += dc[q] * dc[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) D.Rn[9 * j + q] = D.Rs[9 * j + q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) D.Tn[3 * j + q] = D.Ts[3 * j + q];
+        }
+        D.stepPart[D.P + j] = s2;
+    }
+}
+
 // ---- cost at the tentative (which=1) or current (which=0) estimate ------------------------------------
 __global__ __launch_bounds__(256) void k_cost(BaDev D, int which) {
     if (D.st->all_done) return;
@@ -1546,6 +1679,7 @@ __global__ void k_dist_zero_foreign(BaDev D) {
 // =====================================================================================================
 // launch geometry of one solve (host side)
 struct BaPlan {
+    bool seg8;  // eight lanes per point in the linearisation and the update (no point has more than 8 measurements)
     BaDev D;
     int cb, gPts, gUpd, nPairs, useLds;
     size_t ldsSolve;
@@ -1762,6 +1896,17 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
     // orders <= 36: sliced Schur partials, combined by the register Cholesky (single-process solve only: the
     // distributed solve needs the dense S || rhs for its all-reduce)
     L.sliced = (!distributed && D.n > 0 && D.n <= 36);
+    {
+        static const bool noSeg = getenv("COSLAM_BA_SEG8") && getenv("COSLAM_BA_SEG8")[0] == '0';
+        L.seg8 = L.sliced && b->maxObs <= 8 && !noSeg;
+        if (L.seg8) {
+            gUpd = (P + 31) / 32;
+            if (gUpd * 256 < C) gUpd = (C + 255) / 256;
+            if (gUpd < 1) gUpd = 1;
+            D.nUpdBlocks = gUpd;
+            L.gUpd = gUpd;
+        }
+    }
     D.nSlices = 1;
     if (L.sliced) {
         int sl = 96 / (L.nPairs > 0 ? L.nPairs : 1);
@@ -1815,7 +1960,16 @@ static void ba_enqueue_solve_update(hipStream_t stream, const BaPlan& L) {
     const BaDev& D = L.D;
     const dim3 blk(256);
     const int gUpd = L.gUpd;
-    if (L.sliced && D.n == 6) {
+    if (L.seg8) {
+        switch (D.n) {
+            case 6: hipLaunchKernelGGL(k_update_seg8<6>, dim3(gUpd), blk, 0, stream, D); break;
+            case 12: hipLaunchKernelGGL(k_update_seg8<12>, dim3(gUpd), blk, 0, stream, D); break;
+            case 18: hipLaunchKernelGGL(k_update_seg8<18>, dim3(gUpd), blk, 0, stream, D); break;
+            case 24: hipLaunchKernelGGL(k_update_seg8<24>, dim3(gUpd), blk, 0, stream, D); break;
+            case 30: hipLaunchKernelGGL(k_update_seg8<30>, dim3(gUpd), blk, 0, stream, D); break;
+            default: hipLaunchKernelGGL(k_update_seg8<36>, dim3(gUpd), blk, 0, stream, D); break;
+        }
+    } else if (L.sliced && D.n == 6) {
         hipLaunchKernelGGL(k_update<6>, dim3(gUpd), blk, 0, stream, D);  // + solve + tentative cost
     } else if (L.sliced && D.n == 12) {
         hipLaunchKernelGGL(k_update<12>, dim3(gUpd), blk, 0, stream, D);
