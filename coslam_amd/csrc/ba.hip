@@ -11,6 +11,9 @@
 // whole maxIter x innerMaxIter schedule without a single synchronisation (four launches per LM step):
 //   k_linearize   one wave per point: residual + analytic Jacobians per measurement (lane = measurement),
 //                 W_ij = Jc^T Jp to HBM, V_i and g_i folded across the wave with butterflies, V_i^-1 stored;
+//                 k_linearize_seg8 / k_update_seg8: EIGHT lanes per point (eight points per wave) when no point has more
+//                 than 8 measurements -- the local-BA case, where a wave per point leaves 59 lanes idle
+//                 (COSLAM_BA_SEG8=0 forces the wave-per-point kernels, for A/B runs);
 //   k_schur_part  (orders <= 36) one WAVE per (camera pair, point slice): partial S_jk, rhs_j, U_j, g_j, the 69 sums
 //                 folded with a transposed butterfly; k_schur (larger systems): one workgroup per camera pair writes
 //                 S_jk = [j==k](U_j + lambda I) - sum_i W_ij V_i^-1 W_ik^T through the dense table;
@@ -19,7 +22,8 @@
 //                 back-substitution, wave per point) and the tentative cost of the wave's own measurements;
 //                 N = 0: the system was solved by k_solve_wave / k_solve<256> (LDS) or the blocked Cholesky
 //                 k_chol_panel / k_chol_trail / k_chol_trsv (HBM, order > 138);
-//   k_control     one workgroup: fixed-order sum of the partials, accept/reject, lambda, commit, stop flags;
+//   k_control_step  one workgroup: fixed-order sum of the partials, accept/reject, lambda, commit, stop flags
+//                 (k_control: the same at the start of an outer round);
 //   k_cost / k_flag  start-of-round cost; outlier flags (residual > maxErr) and the "flags changed" bit.
 // Every sum has a fixed order (no atomics): results are run-to-run identical.
 // MFMA is deliberately absent: the f64 matrix peak of MI355X equals its f64 vector peak, and the Schur products
