@@ -9,6 +9,7 @@ from .klt import (  # noqa: F401
     KLT_SequenceTracker,
     KLT_SequenceTrackerConfig,
     KLT_TrackedFeature,
+    KLT_TrackerGroup,
     coslam_config,
 )
 

@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcoslam_hip.so")
+# COSLAM_HIP_LIB: another build of the same library (A/B runs of two kernel variants on one GPU box)
+LIB_PATH = os.environ.get("COSLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libcoslam_hip.so")
 
 _lib = None
 

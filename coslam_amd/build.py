@@ -16,6 +16,7 @@ LIB = os.path.join(LIBDIR, "libcoslam_hip.so")
 HIP_SOURCES = [
     "klt_pyramid.hip",
     "klt_track.hip",
+    "klt_track_rows.hip",
     "klt_detect.hip",
     "klt_seq.hip",
     "pose.hip",
@@ -48,6 +49,17 @@ def _stale(target, sources):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_variant(name, defines, verbose=True):
+    """an A/B build with extra -D flags into coslam_amd/lib/libcoslam_hip_<name>.so (select with COSLAM_HIP_LIB)"""
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    out = os.path.join(LIBDIR, f"libcoslam_hip_{name}.so")
+    cmd = [_hipcc()] + HIPCC_FLAGS + [f"-D{d}" for d in defines] + srcs + ["-o", out]
+    if verbose:
+        print("[coslam_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
 
 
 def build_hip(force=False, verbose=True):

@@ -160,9 +160,18 @@ __device__ __forceinline__ void nonmax_body(const CsNonmaxArgs& Z, int bx, int b
     }
 }
 
-__global__ __launch_bounds__(256) void k_nonmax_compact(CsNonmaxArgs Z) {
+struct CsNonmaxBatch {
+    int W, H, d, maxCand;
+    CsNonmaxCam cam[CS_MAX_CAMS];
+};
+__device__ __forceinline__ CsNonmaxArgs nonmax_args(const CsNonmaxBatch& B, int c) {
+    CsNonmaxArgs Z = {B.cam[c].in, B.W, B.H, B.d, B.cam[c].out, B.cam[c].cand, B.maxCand, B.cam[c].ctr};
+    return Z;
+}
+
+__global__ __launch_bounds__(256) void k_nonmax_compact(CsNonmaxBatch B) {  // blockIdx.z = camera
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    nonmax_body(Z, blockIdx.x, blockIdx.y, threadIdx.x, smem);
+    nonmax_body(nonmax_args(B, blockIdx.z), blockIdx.x, blockIdx.y, threadIdx.x, smem);
 }
 
 // ------------------------------------------------------------------ ordering, selection and slot fill
@@ -334,7 +343,18 @@ __device__ __forceinline__ void select_fill_body(const CsSelectArgs& Q, const Cs
     if (A.tagWord && tid == 0) *A.tagWord += 1u;
 }
 
-__global__ __launch_bounds__(1024) void k_select_fill(CsSelectArgs Q, CsFillArgs A) { select_fill_body(Q, A); }
+struct CsSelectBatch {
+    int maxCand, cap;
+    CsSelectCam cam[CS_MAX_CAMS];
+};
+__device__ __forceinline__ CsSelectArgs select_args(const CsSelectBatch& B, int c) {
+    CsSelectArgs Q = {B.cam[c].cand, B.maxCand, B.cap, B.cam[c].maxKeepFixed, B.cam[c].rankM, B.cam[c].sel};
+    return Q;
+}
+
+__global__ __launch_bounds__(1024) void k_select_fill(CsSelectBatch B) {  // one workgroup per camera
+    select_fill_body(select_args(B, blockIdx.x), B.cam[blockIdx.x].fill);
+}
 
 // ---- detector tail fused with the NEXT frame's front (cs_klt_prefetch_dev) ---------------------------------------
 // The tail is two small dependent launches that leave most of the chip idle (non-max: 300 workgroups; selection + slot
@@ -344,39 +364,41 @@ __global__ __launch_bounds__(1024) void k_select_fill(CsSelectArgs Q, CsFillArgs
 //                          map of the NEXT image (into the spare pyramid / cornerness buffers);
 //   k_tail_select_down     workgroup 0: selection + slot fill of THIS frame; every other workgroup: one tile of the
 //                          fused levels 1..3 of the NEXT pyramid (first four waves; the rest retire immediately).
-struct CsLevel0Args {
-    const uint8_t* img;
+struct CsLevel0Batch {
     int W, H;
-    cs_texel* out;
-    float* corner;
     float minCornerness, lox, loy, hix, hiy;
     int nbx, nby;
+    CsFrontCam cam[CS_MAX_CAMS];
 };
 
-__global__ __launch_bounds__(256) void k_tail_nonmax_level0(CsNonmaxArgs Z, int nax, int nA, CsLevel0Args Y) {
+__global__ __launch_bounds__(256) void k_tail_nonmax_level0(CsNonmaxBatch Z, int nax, int nA, CsLevel0Batch Y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, c = blockIdx.y;
     if (b < nA) {
-        nonmax_body(Z, b % nax, b / nax, threadIdx.x, smem);
+        nonmax_body(nonmax_args(Z, c), b % nax, b / nax, threadIdx.x, smem);
     } else {
         const int q = b - nA;
-        cs_level0_body<true>(Y.img, Y.W, Y.H, Y.out, Y.corner, Y.minCornerness, Y.lox, Y.loy, Y.hix, Y.hiy, nullptr, nullptr,
-                             0, q % Y.nbx, q / Y.nbx, Y.nbx, Y.nby, threadIdx.x, *(CsLevel0Lds<true>*)smem);
+        const CsFrontCam& F = Y.cam[c];
+        cs_level0_body<true>(F.img, Y.W, Y.H, F.pyr, F.corner, Y.minCornerness, Y.lox, Y.loy, Y.hix, Y.hiy, nullptr, q % Y.nbx,
+                             q / Y.nbx, Y.nbx, Y.nby, threadIdx.x, *(CsLevel0Lds<true>*)smem);
     }
 }
 
-__global__ __launch_bounds__(1024) void k_tail_select_down(CsSelectArgs Q, CsFillArgs A, cs_texel* pyr, CsDownFused F,
-                                                           int ntx, int nty) {
+struct CsTailPyr {
+    cs_texel* pyr[CS_MAX_CAMS];
+};
+__global__ __launch_bounds__(1024) void k_tail_select_down(CsSelectBatch B, CsTailPyr P, CsDownFused F, int ntx, int nty) {
     extern __shared__ __attribute__((aligned(16))) unsigned char down_smem[];
+    const int c = blockIdx.y;
     if (blockIdx.x == 0) {
-        select_fill_body(Q, A);
+        select_fill_body(select_args(B, c), B.cam[c].fill);
         return;
     }
     // one tile per workgroup, worked by its first four waves (the other twelve retire at once and leave the barriers):
     // the tiles spread over the CUs exactly as in the stand-alone launch
     if (threadIdx.x >= 256) return;
     const int t = blockIdx.x - 1;
-    cs_down_body(pyr, F, t % ntx, t / ntx, threadIdx.x, (cs_texel*)down_smem, true);
+    cs_down_body(P.pyr[c], F, t % ntx, t / ntx, threadIdx.x, (cs_texel*)down_smem, true);
 }
 
 // track() only: the tracked count (status >= 0 in dest[]), one workgroup
@@ -427,16 +449,37 @@ int cs_launch_clear_dest(cs_klt_feature* dest, int N, hipStream_t stream) {
 
 size_t cs_nonmax_lds_bytes(int d) { return sizeof(float) * ((size_t)(NTH + 2 * d) * (NTW + 2 * d) + (size_t)(NTH + 2 * d) * NTW); }
 
-int cs_launch_nonmax_compact(const float* in, int W, int H, int d, float* out, CsCand* cand, int maxCand, int* ctr,
-                             hipStream_t stream) {
+static int fill_nonmax_batch(CsNonmaxBatch& B, const CsNonmaxCam* cams, int n, int W, int H, int d, int maxCand) {
+    if (n < 1 || n > CS_MAX_CAMS) {
+        cs_set_error("detector: %d cameras (1..%d)", n, CS_MAX_CAMS);
+        return CS_ERR_INVALID;
+    }
+    memset(&B, 0, sizeof(B));
+    B.W = W;
+    B.H = H;
+    B.d = d;
+    B.maxCand = maxCand;
+    for (int c = 0; c < n; ++c) B.cam[c] = cams[c];
+    return CS_OK;
+}
+static void fill_select_batch(CsSelectBatch& B, const CsSelectCam* cams, int n, int maxCand, int cap) {
+    memset(&B, 0, sizeof(B));
+    B.maxCand = maxCand;
+    B.cap = cap;
+    for (int c = 0; c < n; ++c) B.cam[c] = cams[c];
+}
+
+int cs_launch_nonmax_compact(const CsNonmaxCam* cams, int n, int W, int H, int d, int maxCand, hipStream_t stream) {
     size_t lds = cs_nonmax_lds_bytes(d);
     if (lds > 160 * 1024) {
         cs_set_error("minDistance %d needs %zu B of LDS (> 160 KiB)", d, lds);
         return CS_ERR_INVALID;
     }
-    dim3 grid((W + NTW - 1) / NTW, (H + NTH - 1) / NTH);
-    CsNonmaxArgs Z = {in, W, H, d, out, cand, maxCand, ctr};
-    hipLaunchKernelGGL(k_nonmax_compact, grid, dim3(256), lds, stream, Z);
+    CsNonmaxBatch B;
+    int rc = fill_nonmax_batch(B, cams, n, W, H, d, maxCand);
+    if (rc) return rc;
+    dim3 grid((W + NTW - 1) / NTW, (H + NTH - 1) / NTH, n);
+    hipLaunchKernelGGL(k_nonmax_compact, grid, dim3(256), lds, stream, B);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }
@@ -454,16 +497,14 @@ int cs_nonmax_prepare(int d) {
     return CS_OK;
 }
 
-int cs_launch_select_fill(const CsCand* cand, int maxCand, int cap, int maxKeepFixed, int* rankM, CsCand* sel,
-                          const CsFillArgs& a, hipStream_t stream) {
-    CsSelectArgs q;
-    q.cand = cand;
-    q.maxCand = maxCand;
-    q.cap = cap;
-    q.maxKeepFixed = maxKeepFixed;
-    q.rankM = rankM;
-    q.sel = sel;
-    hipLaunchKernelGGL(k_select_fill, dim3(1), dim3(1024), 0, stream, q, a);
+int cs_launch_select_fill(const CsSelectCam* cams, int n, int maxCand, int cap, hipStream_t stream) {
+    if (n < 1 || n > CS_MAX_CAMS) {
+        cs_set_error("selection: %d cameras (1..%d)", n, CS_MAX_CAMS);
+        return CS_ERR_INVALID;
+    }
+    CsSelectBatch B;
+    fill_select_batch(B, cams, n, maxCand, cap);
+    hipLaunchKernelGGL(k_select_fill, dim3(n), dim3(1024), 0, stream, B);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }
@@ -474,26 +515,24 @@ int cs_launch_counts_track(const cs_klt_feature* dest, int N, int* counts, int* 
     return CS_OK;
 }
 
-// detector tail of THIS frame + frame front of the NEXT image in two launches (see k_tail_* above)
-int cs_launch_tail_with_next_front(const float* in, int W, int H, int d, float* out, const CsCand* candc, int maxCand,
-                                   int cap, int maxKeepFixed, int* rankM, CsCand* sel, const CsFillArgs& a,
-                                   const uint8_t* d_img_next, const CsPyrLayout& lay, cs_texel* d_pyr_next, int tap_mode,
-                                   float* corner_next, float minCornerness, float margin, hipStream_t stream) {
-    CsCand* cand = const_cast<CsCand*>(candc);
+// detector tail of THIS frame + frame front of the NEXT image in two launches (see k_tail_* above), n cameras
+int cs_launch_tail_with_next_front(const CsNonmaxCam* nm, const CsSelectCam* sel, const CsFrontCam* next, int n, int W, int H,
+                                   int d, int maxCand, int cap, const CsPyrLayout& lay, int tap_mode, float minCornerness,
+                                   float margin, hipStream_t stream) {
     size_t ldsA = cs_nonmax_lds_bytes(d);
     if (ldsA < sizeof(CsLevel0Lds<true>)) ldsA = sizeof(CsLevel0Lds<true>);
     if (ldsA > 64 * 1024) {
         cs_set_error("fused detector tail: minDistance %d needs %zu B of LDS", d, ldsA);
         return CS_ERR_INVALID;
     }
-    CsNonmaxArgs Z = {in, W, H, d, out, cand, maxCand, a.ctr};
+    CsNonmaxBatch Z;
+    int rc = fill_nonmax_batch(Z, nm, n, W, H, d, maxCand);
+    if (rc) return rc;
     const int nax = (W + NTW - 1) / NTW, nay = (H + NTH - 1) / NTH;
-    CsLevel0Args Y;
-    Y.img = d_img_next;
+    CsLevel0Batch Y;
+    memset(&Y, 0, sizeof(Y));
     Y.W = W;
     Y.H = H;
-    Y.out = d_pyr_next + lay.off[0];
-    Y.corner = corner_next;
     Y.minCornerness = minCornerness;
     Y.lox = margin / (float)W;
     Y.loy = margin / (float)H;
@@ -501,25 +540,26 @@ int cs_launch_tail_with_next_front(const float* in, int W, int H, int d, float* 
     Y.hiy = 1.0f - margin / (float)H;
     Y.nbx = (W + FTW - 1) / FTW;
     Y.nby = (H + FTH - 1) / FTH;
-    hipLaunchKernelGGL(k_tail_nonmax_level0, dim3(nax * nay + Y.nbx * Y.nby), dim3(256), ldsA, stream, Z, nax, nax * nay, Y);
-    CsSelectArgs q;
-    q.cand = cand;
-    q.maxCand = maxCand;
-    q.cap = cap;
-    q.maxKeepFixed = maxKeepFixed;
-    q.rankM = rankM;
-    q.sel = sel;
+    CsTailPyr P;
+    memset(&P, 0, sizeof(P));
+    for (int c = 0; c < n; ++c) {
+        Y.cam[c] = next[c];
+        P.pyr[c] = next[c].pyr;
+    }
+    hipLaunchKernelGGL(k_tail_nonmax_level0, dim3(nax * nay + Y.nbx * Y.nby, n), dim3(256), ldsA, stream, Z, nax, nax * nay, Y);
+    CsSelectBatch B;
+    fill_select_batch(B, sel, n, maxCand, cap);
     if (lay.L >= 2) {
         CsDownFused F;
         int ntx, nty;
         size_t lds;
-        int rc = cs_down_fused_plan(lay, tap_mode, &F, &ntx, &nty, &lds);
+        rc = cs_down_fused_plan(lay, tap_mode, &F, &ntx, &nty, &lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_tail_select_down, dim3(1 + ntx * nty), dim3(1024), lds, stream, q, a, d_pyr_next, F, ntx, nty);
-        rc = cs_launch_pyr_down_from(lay, d_pyr_next, tap_mode, F.NL + 1, stream);
+        hipLaunchKernelGGL(k_tail_select_down, dim3(1 + ntx * nty, n), dim3(1024), lds, stream, B, P, F, ntx, nty);
+        rc = cs_launch_pyr_down_tail(P.pyr, n, lay, tap_mode, F.NL + 1, stream);
         if (rc) return rc;
     } else {
-        hipLaunchKernelGGL(k_select_fill, dim3(1), dim3(1024), 0, stream, q, a);
+        hipLaunchKernelGGL(k_select_fill, dim3(n), dim3(1024), 0, stream, B);
     }
     CS_CHECK_LAUNCH();
     return CS_OK;

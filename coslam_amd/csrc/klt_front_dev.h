@@ -33,8 +33,8 @@ struct CsLevel0Lds {
 template <bool CORNER>
 __device__ __forceinline__ void cs_level0_body(const uint8_t* __restrict__ img, int W, int H, cs_texel* __restrict__ out,
                                                float* __restrict__ corner, float minCornerness, float lox, float loy,
-                                               float hix, float hiy, int* ctr, unsigned long long* gran, int nGran,
-                                               int bx, int by, int nbx, int nby, int tid, CsLevel0Lds<CORNER>& S) {
+                                               float hix, float hiy, int* ctr, int bx, int by, int nbx, int nby, int tid,
+                                               CsLevel0Lds<CORNER>& S) {
     constexpr int CR = CORNER ? 3 : 0;
     constexpr int RW = FTW + 2 * CR, RH = FTH + 2 * CR;
     auto& g = S.g;
@@ -45,8 +45,6 @@ __device__ __forceinline__ void cs_level0_body(const uint8_t* __restrict__ img, 
     {
         const int gid = (by * nbx + bx) * 256 + tid;
         if (ctr && gid < 8) ctr[gid] = 0;
-        if (gran)
-            for (int q = gid; q < nGran; q += nbx * nby * 256) gran[q] = 0ull;
     }
     const int x0 = bx * FTW, y0 = by * FTH;
     const int rx0 = x0 - CR, ry0 = y0 - CR;

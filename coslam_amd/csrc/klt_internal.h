@@ -28,31 +28,43 @@ struct CsGainPassArgs {
     int n1x[4], n1y[4];  // the four "betaN1" neighbour offsets in slot texels
 };
 
-struct CsGainFusedArgs {
+// ---- rows tracker (klt_track_rows.hip): several features per wave, several cameras per launch ------------------------
+constexpr int CS_MAX_CAMS = 16;  // SLAM_MAX_NUM is 13 (src/slam/SL_Define.h:11)
+
+struct CsRowsCam {
     const cs_texel* pyr0;
     const cs_texel* pyr1;
-    CsTrackLevels lv;
-    int W, H, fw, fh, N, hw, nIter, levelSkip;
     const float* feat0;      // X0 list (features0_tex)
-    const float* featStart;  // iterate at entry (x, y; gain restarts at 1)
-    float* outLast;          // result of the last pass
-    float* outPrev;          // result of the pass before it (what the ping-pong schedule leaves behind)
-    unsigned long long* gran;  // [passes + 1][N] {tag, beta} granules: one row per pass, never overwritten within a frame
-    const unsigned* tagWord;   // frame-unique tag base (device word, bumped by the frame's last kernel)
+    const float* featStart;  // iterate at entry (persistent) / features_tex (per pass)
+    float* outLast;          // result of the last pass (persistent) / featOut (per pass)
+    float* outPrev;          // result of the pass before it (persistent only)
+    unsigned long long* gran;  // [passes + 1][N] {tag, beta} hand-off granules (persistent only)
+    const unsigned* tagWord;   // frame-unique tag base
+    int* err;
+    cs_klt_feature* dest;  // fused k_post_track; null: not fused
+    float* corner;
+    unsigned long long* probe;  // diagnostic cycle counters (8 per wave) or null
+};
+
+struct CsRowsArgs {
+    CsTrackLevels lv;
+    int W, H, fw, fh, N, nIter, levelSkip, doSuppress;
     float sqrConvThr, ssdThr;
     float vr[4];
     float lambda, delta;
     int n1x[4], n1y[4];
-    int* err;
-    int pollGap;                      // s_sleep units between re-polls of the hand-off sweep
-    int patchR;                       // side of the wave-private LDS patch in texels (set by the launcher)
-    // fused k_post_track (v3d_gpuklt.cpp:872-888 status loop + :744-752 present scatter); dest == null: not fused
-    cs_klt_feature* dest;
-    int* ctr;
-    float* corner;
-    int doSuppress;
-    unsigned long long* probe;        // diagnostic per-wave cycle counters (8 per slot) or null
+    int level;  // per-pass kernel only: the level this launch works on
+    int nCams;
+    CsRowsCam cam[CS_MAX_CAMS];
 };
+
+// window widths the rows tracker covers (2 * hw + 1 <= 15); wider windows use the wave-per-feature kernels
+bool cs_rows_supported(int hw);
+size_t cs_rows_lds_bytes(int hw);
+int cs_rows_waves(int hw, int N);  // waves (= 64-thread workgroups) one camera needs
+int cs_rows_max_resident_blocks(int hw, int device, int* blocksPerCu);
+int cs_launch_track_rows_fused(const CsRowsArgs& a, int hw, hipStream_t stream);
+int cs_launch_track_rows_pass(const CsRowsArgs& a, int hw, hipStream_t stream);
 
 // mode 0: detect (all slots free, v3d_gpuklt.cpp:716-734)
 // mode 1: detect with present points appended after the detected ones (:667-690)
@@ -70,28 +82,45 @@ struct CsFillArgs {
     unsigned* tagWord;
 };
 
-int cs_launch_frame_front(const uint8_t* d_img, const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mode, float* corner_out,
-                          float minCornerness, float margin, int* ctr, unsigned long long* gran, int nGran,
-                          hipStream_t stream);
+// ---- camera batches: every frame-schedule kernel takes the cameras of a group as one more grid dimension ------------
+// (the reference runs its cameras one after the other through one GL context, src/app/SL_CoSLAM.cpp:299-305)
+struct CsFrontCam {
+    const uint8_t* img;
+    cs_texel* pyr;   // pyramid base (level 0 at offset 0)
+    float* corner;   // raw cornerness map or null
+    int* ctr;        // frame counters to zero or null
+};
+struct CsNonmaxCam {
+    const float* in;
+    float* out;
+    CsCand* cand;
+    int* ctr;
+};
+struct CsSelectCam {  // selection + slot fill of one camera
+    const CsCand* cand;
+    int* rankM;
+    CsCand* sel;
+    int maxKeepFixed;  // >= 0: use it; else N - tracked
+    CsFillArgs fill;
+};
+
+int cs_launch_frame_front(const CsFrontCam* cams, int n, const CsPyrLayout& lay, int tap_mode, bool withCorner,
+                          float minCornerness, float margin, hipStream_t stream);
+int cs_launch_pyr_down_tail(cs_texel* const* pyrs, int n, const CsPyrLayout& lay, int tap_mode, int first, hipStream_t stream);
 size_t cs_nonmax_lds_bytes(int d);
-int cs_launch_pyr_down_from(const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mode, int first, hipStream_t stream);
-int cs_launch_tail_with_next_front(const float* in, int W, int H, int d, float* out, const CsCand* cand, int maxCand, int cap,
-                                   int maxKeepFixed, int* rankM, CsCand* sel, const CsFillArgs& a, const uint8_t* d_img_next,
-                                   const CsPyrLayout& lay, cs_texel* d_pyr_next, int tap_mode, float* corner_next,
-                                   float minCornerness, float margin, hipStream_t stream);
+int cs_launch_tail_with_next_front(const CsNonmaxCam* nm, const CsSelectCam* sel, const CsFrontCam* next, int n, int W, int H,
+                                   int d, int maxCand, int cap, const CsPyrLayout& lay, int tap_mode, float minCornerness,
+                                   float margin, hipStream_t stream);
 int cs_launch_track_nogain(const cs_texel* pyr0, const cs_texel* pyr1, const CsPyrLayout& lay, int levelSkip, int hw,
                            int nIterShader, float margin, float convThr, float ssdThr, int N, const float* featIn,
                            float* featOut, hipStream_t stream);
 int cs_launch_track_gain_pass(const CsGainPassArgs& a, hipStream_t stream);
 int cs_launch_reset_beta(float* feat, int N, hipStream_t stream);
-int cs_launch_track_gain_fused(const CsGainFusedArgs& a, hipStream_t stream);
 int cs_launch_suppress_list(float* corner, int W, int H, int n, const float* d_list3, hipStream_t stream);
 int cs_launch_post_track(const float* feat, int N, cs_klt_feature* dest, int* ctr, float* corner, int W, int H,
                          int doSuppress, hipStream_t stream);
 int cs_launch_clear_dest(cs_klt_feature* dest, int N, hipStream_t stream);
 int cs_nonmax_prepare(int d);
-int cs_launch_nonmax_compact(const float* in, int W, int H, int d, float* out, CsCand* cand, int maxCand, int* ctr,
-                             hipStream_t stream);
-int cs_launch_select_fill(const CsCand* cand, int maxCand, int cap, int maxKeepFixed, int* rankM, CsCand* sel,
-                          const CsFillArgs& a, hipStream_t stream);
+int cs_launch_nonmax_compact(const CsNonmaxCam* cams, int n, int W, int H, int d, int maxCand, hipStream_t stream);
+int cs_launch_select_fill(const CsSelectCam* cams, int n, int maxCand, int cap, hipStream_t stream);
 int cs_launch_counts_track(const cs_klt_feature* dest, int N, int* counts, int* ctr, unsigned* tagWord, hipStream_t stream);

@@ -21,9 +21,14 @@ __device__ __forceinline__ int tap_base(int o, int n_dst, int n_src) {
     return (int)(((long long)(2 * o + 1) * n_src) / (2 * (long long)n_dst));
 }
 
-// one output texel per lane: 4x4 gather from the level above
-__global__ __launch_bounds__(256) void k_pyr_down(const cs_texel* __restrict__ src, int Ws, int Hs,
-                                                  cs_texel* __restrict__ dst, int Wd, int Hd, int shift) {
+// one output texel per lane: 4x4 gather from the level above; blockIdx.z = camera
+struct CsPyrPtrs {
+    cs_texel* pyr[CS_MAX_CAMS];
+};
+__global__ __launch_bounds__(256) void k_pyr_down(CsPyrPtrs P, long long offSrc, int Ws, int Hs, long long offDst, int Wd,
+                                                  int Hd, int shift) {
+    const cs_texel* __restrict__ src = P.pyr[blockIdx.z] + offSrc;
+    cs_texel* __restrict__ dst = P.pyr[blockIdx.z] + offDst;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= Wd || y >= Hd) return;
@@ -64,48 +69,74 @@ __global__ __launch_bounds__(256) void k_pyr_down(const cs_texel* __restrict__ s
 // Arithmetic, operation order and the fp16 roundings are those of k_pyr_level0 / k_pyr_down / k_cornerness:
 // results are bit-identical to the separate kernels.
 // (The bodies live in klt_front_dev.h: the detector tail re-uses them for the next frame's front.)
+struct CsFrontBatch {
+    int W, H;
+    float minCornerness, lox, loy, hix, hiy;
+    CsFrontCam cam[CS_MAX_CAMS];
+};
+
 template <bool CORNER>
-__global__ __launch_bounds__(256) void k_pyr_level0_corner(const uint8_t* __restrict__ img, int W, int H,
-                                                           cs_texel* __restrict__ out, float* __restrict__ corner,
-                                                           float minCornerness, float lox, float loy, float hix,
-                                                           float hiy, int* ctr, unsigned long long* gran, int nGran) {
+__global__ __launch_bounds__(256) void k_pyr_level0_corner(CsFrontBatch B) {
     __shared__ CsLevel0Lds<CORNER> S;
-    cs_level0_body<CORNER>(img, W, H, out, corner, minCornerness, lox, loy, hix, hiy, ctr, gran, nGran, blockIdx.x,
+    const CsFrontCam& C = B.cam[blockIdx.z];
+    cs_level0_body<CORNER>(C.img, B.W, B.H, C.pyr, C.corner, B.minCornerness, B.lox, B.loy, B.hix, B.hiy, C.ctr, blockIdx.x,
                            blockIdx.y, gridDim.x, gridDim.y, threadIdx.x, S);
 }
 
-__global__ __launch_bounds__(256) void k_pyr_down_fused(cs_texel* __restrict__ pyr, CsDownFused F) {
+__global__ __launch_bounds__(256) void k_pyr_down_fused(CsPyrPtrs P, CsDownFused F) {
     extern __shared__ __attribute__((aligned(16))) unsigned char down_smem[];
-    cs_down_body(pyr, F, blockIdx.x, blockIdx.y, threadIdx.x, (cs_texel*)down_smem, true);
+    cs_down_body(P.pyr[blockIdx.z], F, blockIdx.x, blockIdx.y, threadIdx.x, (cs_texel*)down_smem, true);
 }
 
 }  // namespace
 
-// levels >= first (those the fused decimation does not cover): one gather launch each
-int cs_launch_pyr_down_from(const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mode, int first, hipStream_t stream) {
+// levels >= first (those the fused decimation does not cover): one gather launch each, all cameras
+static int launch_pyr_down_from(const CsPyrPtrs& P, int n, const CsPyrLayout& lay, int tap_mode, int first,
+                                hipStream_t stream) {
     for (int l = first; l < lay.L; ++l) {
-        dim3 g((lay.w[l] + 63) / 64, (lay.h[l] + 3) / 4);
-        hipLaunchKernelGGL(k_pyr_down, g, dim3(256), 0, stream, d_pyr + lay.off[l - 1], lay.w[l - 1], lay.h[l - 1],
-                           d_pyr + lay.off[l], lay.w[l], lay.h[l], tap_mode ? -1 : 0);
+        dim3 g((lay.w[l] + 63) / 64, (lay.h[l] + 3) / 4, n);
+        hipLaunchKernelGGL(k_pyr_down, g, dim3(256), 0, stream, P, (long long)lay.off[l - 1], lay.w[l - 1], lay.h[l - 1],
+                           (long long)lay.off[l], lay.w[l], lay.h[l], tap_mode ? -1 : 0);
     }
     CS_CHECK_LAUNCH();
     return CS_OK;
 }
 
-// pyramid (+ cornerness map, + zeroing of the frame's counters) in two launches
-int cs_launch_frame_front(const uint8_t* d_img, const CsPyrLayout& lay, cs_texel* d_pyr, int tap_mode, float* corner_out,
-                          float minCornerness, float margin, int* ctr, unsigned long long* gran, int nGran,
-                          hipStream_t stream) {
+int cs_launch_pyr_down_tail(cs_texel* const* pyrs, int n, const CsPyrLayout& lay, int tap_mode, int first, hipStream_t stream) {
+    CsPyrPtrs P;
+    memset(&P, 0, sizeof(P));
+    for (int c = 0; c < n; ++c) P.pyr[c] = pyrs[c];
+    return launch_pyr_down_from(P, n, lay, tap_mode, first, stream);
+}
+
+// pyramid (+ cornerness map, + zeroing of the frame's counters) of n cameras in two launches
+int cs_launch_frame_front(const CsFrontCam* cams, int n, const CsPyrLayout& lay, int tap_mode, bool withCorner,
+                          float minCornerness, float margin, hipStream_t stream) {
+    if (n < 1 || n > CS_MAX_CAMS) {
+        cs_set_error("frame front: %d cameras (1..%d)", n, CS_MAX_CAMS);
+        return CS_ERR_INVALID;
+    }
     const int W = lay.W, H = lay.H;
-    dim3 g0((W + FTW - 1) / FTW, (H + FTH - 1) / FTH);
-    if (corner_out) {
-        const float lox = margin / (float)W, loy = margin / (float)H;
-        const float hix = 1.0f - margin / (float)W, hiy = 1.0f - margin / (float)H;
-        hipLaunchKernelGGL(k_pyr_level0_corner<true>, g0, dim3(256), 0, stream, d_img, W, H, d_pyr + lay.off[0], corner_out,
-                           minCornerness, lox, loy, hix, hiy, ctr, gran, nGran);
+    CsFrontBatch B;
+    memset(&B, 0, sizeof(B));
+    B.W = W;
+    B.H = H;
+    CsPyrPtrs P;
+    memset(&P, 0, sizeof(P));
+    for (int c = 0; c < n; ++c) {
+        B.cam[c] = cams[c];
+        P.pyr[c] = cams[c].pyr;
+    }
+    dim3 g0((W + FTW - 1) / FTW, (H + FTH - 1) / FTH, n);
+    if (withCorner) {
+        B.minCornerness = minCornerness;
+        B.lox = margin / (float)W;
+        B.loy = margin / (float)H;
+        B.hix = 1.0f - margin / (float)W;
+        B.hiy = 1.0f - margin / (float)H;
+        hipLaunchKernelGGL(k_pyr_level0_corner<true>, g0, dim3(256), 0, stream, B);
     } else {
-        hipLaunchKernelGGL(k_pyr_level0_corner<false>, g0, dim3(256), 0, stream, d_img, W, H, d_pyr + lay.off[0],
-                           (float*)nullptr, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, ctr, gran, nGran);
+        hipLaunchKernelGGL(k_pyr_level0_corner<false>, g0, dim3(256), 0, stream, B);
     }
     if (lay.L >= 2) {
         CsDownFused F;
@@ -113,8 +144,8 @@ int cs_launch_frame_front(const uint8_t* d_img, const CsPyrLayout& lay, cs_texel
         size_t lds;
         int rc = cs_down_fused_plan(lay, tap_mode, &F, &ntx, &nty, &lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_pyr_down_fused, dim3(ntx, nty), dim3(256), lds, stream, d_pyr, F);
-        rc = cs_launch_pyr_down_from(lay, d_pyr, tap_mode, F.NL + 1, stream);
+        hipLaunchKernelGGL(k_pyr_down_fused, dim3(ntx, nty, n), dim3(256), lds, stream, P, F);
+        rc = launch_pyr_down_from(P, n, lay, tap_mode, F.NL + 1, stream);
         if (rc) return rc;
     }
     CS_CHECK_LAUNCH();

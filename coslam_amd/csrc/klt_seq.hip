@@ -160,6 +160,7 @@ struct cs_klt {
     bool use_graphs;
     struct GraphEntry {
         int mode, b0, b1, b2, p0, p1;
+        int live_gen;  // generation of the device's live-handle count the residency decision was captured under
         const void* img;
         void *dest, *counts;
         int post_b0, post_b1, post_b2, post_p0, post_p1;
@@ -172,7 +173,14 @@ struct cs_klt {
 // resident workgroups (8 x 256-thread blocks on each of the 256 CUs, minus a margin) is shared between handles
 static std::mutex g_reg_mutex;
 static int g_live_handles[64];
-constexpr int CS_RESIDENT_BLOCKS_PER_CU = 6;  // of the 8 x 256-thread blocks a CU admits, minus a margin
+static int g_live_gen[64];  // bumped whenever g_live_handles changes: cached graphs captured under another count are stale
+
+// cameras whose frame schedule is issued together (one more grid dimension of every kernel)
+struct Span {
+    cs_klt* const* k;
+    int n;
+    hipStream_t stream;
+};
 
 #define CS_REQUIRE(cond, msg)      \
     do {                           \
@@ -197,261 +205,387 @@ static float* read_buffer(cs_klt* k) {  // readFeatures / readFeaturesAndGain, v
     return k->cfg.trackWithGain ? k->d_fb[k->b2] : k->d_fb[k->b1];
 }
 
-// ---- frame schedules (all asynchronous on k->stream) -------------------------------------------
+// ---- frame schedules (all asynchronous on the span's stream) ------------------------------------
 
-// postDest != null: the persistent tracker may fold k_post_track into its epilogue; *postFused says whether it did
-static int enqueue_tracker(cs_klt* k, cs_klt_feature* postDest, int doSuppress, bool* postFused) {
-    if (postFused) *postFused = false;
-    const cs_klt_config& c = k->cfg;
-    const int hw = c.windowWidth / 2;
-    const cs_texel *P0 = k->d_pyr[k->p0], *P1 = k->d_pyr[k->p1];
-    if (!c.trackWithGain) {
-        // the host passes -DNITERATIONS but the shader reads N_ITERATIONS: always 5
-        // (v3d_gpuklt.cpp:108 vs klt_tracker.cg:16-18)
-        return cs_launch_track_nogain(P0, P1, k->lay, c.levelSkip, hw, 5, k->margin, k->convThr, k->ssdThr, k->N,
-                                      k->d_fb[k->b0], k->d_fb[k->b1], k->stream);
-    }
-    int levelSkipF = c.levelSkip > 0 ? c.levelSkip : (c.nLevels - 1);
-    if (levelSkipF <= 0) levelSkipF = 1;
-    int nLevelsVisited = 0;
-    for (int level = k->L - 1; level >= 0; level -= levelSkipF) ++nLevelsVisited;
-    const int T = nLevelsVisited * c.nIterations;
+static void gain_neighbour_offsets(int fw, int fh, int* n1x, int* n1y) {
+    // st0 +- ds0.x / ds0.y are scalar broadcasts (klt_tracker_with_gain.cg:64-67)
+    const double rxy = (double)fh / (double)fw, ryx = (double)fw / (double)fh;
+    n1x[0] = 1;
+    n1x[1] = -1;
+    n1x[2] = (int)floor(0.5 + ryx);
+    n1x[3] = (int)floor(0.5 - ryx);
+    n1y[0] = (int)floor(0.5 + rxy);
+    n1y[1] = (int)floor(0.5 - rxy);
+    n1y[2] = 1;
+    n1y[3] = -1;
+}
+
+// How many cameras of this span may share ONE persistent launch of the rows tracker (0: none -- use the per-pass
+// schedule)?  Every wave of a launch must be co-resident: the budget is the occupancy the runtime reports for the
+// instantiation actually launched (with its dynamic LDS size), scaled to the CUs the stream may use, shared between the
+// independent launches that may overlap on the device.  A span with more cameras than fit is issued as several
+// persistent launches one after the other on its stream.  (Every spin in the kernel is bounded: a grid that is not
+// resident after all raises the handle's error word instead of hanging.)
+static int rows_cams_per_persistent_launch(const Span& S, int hw, int T) {
+    cs_klt* k0 = S.k[0];
+    if (!k0->use_fused || T < 1 || T + 1 > k0->granRows) return 0;
+    int perCu = 0;  // resident waves per CU the runtime reports for this instantiation (VGPR- or LDS-bound here)
+    if (cs_rows_max_resident_blocks(hw, k0->device, &perCu) <= 0) return 0;
+    const long capacity = (long)perCu * k0->cu_count - k0->cu_count / 8;  // a little slack below the reported occupancy
     int live = 1;
     {
         std::lock_guard<std::mutex> g(g_reg_mutex);
-        live = g_live_handles[k->device & 63] > 0 ? g_live_handles[k->device & 63] : 1;
+        live = g_live_handles[k0->device & 63] > 0 ? g_live_handles[k0->device & 63] : 1;
     }
-    if (k->concurrent > 0 && k->concurrent < live) live = k->concurrent;
-    const int blocks = (k->N + 3) / 4;
-    if (k->use_fused && T >= 1 && T + 1 <= k->granRows && blocks * live <= CS_RESIDENT_BLOCKS_PER_CU * k->cu_count &&
-        (2 * hw + 1) * (2 * hw + 1) <= 256) {
-        CsGainFusedArgs f;
-        memset(&f, 0, sizeof(f));
-        f.pyr0 = P0;
-        f.pyr1 = P1;
-        f.lv.L = k->L;
-        for (int l = 0; l < k->L; ++l) {
-            f.lv.w[l] = k->lay.w[l];
-            f.lv.h[l] = k->lay.h[l];
-            f.lv.off[l] = k->lay.off[l];
+    if (k0->concurrent > 0 && k0->concurrent < live) live = k0->concurrent;
+    int launches = live - S.n + 1;  // the span's cameras share ONE stream; every other live handle may overlap with it
+    if (launches < 1) launches = 1;
+    const long perCam = (long)cs_rows_waves(hw, k0->N) * launches;
+    long m = capacity / (perCam > 0 ? perCam : 1);
+    if (m > S.n) m = S.n;
+    return (int)m;
+}
+
+// postDest != null: the persistent tracker folds k_post_track into its epilogue; *postFused says whether it did
+static int enqueue_tracker(const Span& S, cs_klt_feature* const* postDest, int doSuppress, bool* postFused) {
+    if (postFused) *postFused = false;
+    cs_klt* k0 = S.k[0];
+    const cs_klt_config& c = k0->cfg;
+    const int hw = c.windowWidth / 2;
+    if (!c.trackWithGain) {
+        // the host passes -DNITERATIONS but the shader reads N_ITERATIONS: always 5
+        // (v3d_gpuklt.cpp:108 vs klt_tracker.cg:16-18)
+        for (int i = 0; i < S.n; ++i) {
+            cs_klt* k = S.k[i];
+            int rc = cs_launch_track_nogain(k->d_pyr[k->p0], k->d_pyr[k->p1], k->lay, c.levelSkip, hw, 5, k->margin,
+                                            k->convThr, k->ssdThr, k->N, k->d_fb[k->b0], k->d_fb[k->b1], S.stream);
+            if (rc) return rc;
         }
-        f.W = k->W;
-        f.H = k->H;
-        f.fw = k->fw;
-        f.fh = k->fh;
-        f.N = k->N;
-        f.hw = hw;
-        f.nIter = c.nIterations;
-        f.levelSkip = levelSkipF;
-        f.feat0 = k->d_fb[k->b2];
-        f.featStart = k->d_fb[k->b0];
-        // where the ping-pong schedule of the reference leaves its last two results (v3d_gpuklt.cpp:281-285)
-        f.outLast = k->d_fb[(T & 1) ? k->b1 : k->b0];
-        f.outPrev = k->d_fb[(T & 1) ? k->b0 : k->b1];
-        f.gran = k->d_gran;
-        f.tagWord = (const unsigned*)(k->d_counts + 5);
-        f.sqrConvThr = k->convThr * k->convThr;
-        f.ssdThr = k->ssdThr;
-        f.vr[0] = k->margin / (float)k->W;
-        f.vr[1] = k->margin / (float)k->H;
-        f.vr[2] = 1.0f - k->margin / (float)k->W;
-        f.vr[3] = 1.0f - k->margin / (float)k->H;
-        f.lambda = 1.0f;
-        f.delta = 200.0f;
-        {
-            const double rxy = (double)k->fh / (double)k->fw, ryx = (double)k->fw / (double)k->fh;
-            f.n1x[0] = 1;
-            f.n1x[1] = -1;
-            f.n1x[2] = (int)floor(0.5 + ryx);
-            f.n1x[3] = (int)floor(0.5 - ryx);
-            f.n1y[0] = (int)floor(0.5 + rxy);
-            f.n1y[1] = (int)floor(0.5 - rxy);
-            f.n1y[2] = 1;
-            f.n1y[3] = -1;
-        }
-        f.err = k->d_err;
-        f.probe = k->d_probe;
-        f.dest = postDest;
-        f.ctr = k->d_ctr;
-        f.corner = k->d_corner_raw;
-        f.doSuppress = doSuppress;
-        if (postFused) *postFused = (postDest != nullptr);
-        f.pollGap = 0;
-        int rcf = cs_launch_track_gain_fused(f, k->stream);
-        if (rcf) return rcf;
-        if (T & 1) std::swap(k->b0, k->b1);  // T swaps of (buffer0, buffer1)
-        std::swap(k->b0, k->b2);             // v3d_gpuklt.cpp:304
         return CS_OK;
     }
-    int rc = cs_launch_reset_beta(k->d_fb[k->b0], k->N, k->stream);  // v3d_gpuklt.cpp:223-227
-    if (rc) return rc;
-    CsGainPassArgs a;
-    memset(&a, 0, sizeof(a));
-    a.whx = (float)k->W;
-    a.why = (float)k->H;
-    a.fw = k->fw;
-    a.fh = k->fh;
-    a.N = k->N;
-    a.hw = hw;
-    a.lambda = 1.0f;  // :250
-    {
-        // st0 +- ds0.x / ds0.y are scalar broadcasts (klt_tracker_with_gain.cg:64-67)
-        const double rxy = (double)k->fh / (double)k->fw, ryx = (double)k->fw / (double)k->fh;
-        a.n1x[0] = 1;
-        a.n1x[1] = -1;
-        a.n1x[2] = (int)floor(0.5 + ryx);
-        a.n1x[3] = (int)floor(0.5 - ryx);
-        a.n1y[0] = (int)floor(0.5 + rxy);
-        a.n1y[1] = (int)floor(0.5 - rxy);
-        a.n1y[2] = 1;
-        a.n1y[3] = -1;
-    }
-    float delta = 200.0f;
-    const float tau = 1.0f;
     int levelSkip = c.levelSkip > 0 ? c.levelSkip : (c.nLevels - 1);  // v3d_gpuklt.h:14
     if (levelSkip <= 0) levelSkip = 1;
-    a.sqrConvThr = 1000000.0f;
-    a.ssdThr = 1000000.0f;
-    a.vr[0] = a.vr[1] = -1.0f;
-    a.vr[2] = a.vr[3] = 2.0f;
-    for (int level = k->L - 1; level >= 0; level -= levelSkip) {  // :254
-        a.lvl0 = P0 + k->lay.off[level];
-        a.lvl1 = P1 + k->lay.off[level];
-        a.Wl = k->lay.w[level];
-        a.Hl = k->lay.h[level];
-        for (int iter = 1; iter <= c.nIterations; ++iter) {  // :268
-            a.delta = delta;
-            delta *= tau;
-            if (iter == 1) {  // :271-279
-                a.sqrConvThr = 1000000.0f;
-                a.ssdThr = 1000000.0f;
-                a.vr[0] = a.vr[1] = -1.0f;
-                a.vr[2] = a.vr[3] = 2.0f;
-            } else if (iter == c.nIterations) {
-                a.sqrConvThr = k->convThr * k->convThr;
-                a.ssdThr = k->ssdThr;
-                a.vr[0] = k->margin / (float)k->W;
-                a.vr[1] = k->margin / (float)k->H;
-                a.vr[2] = 1.0f - k->margin / (float)k->W;
-                a.vr[3] = 1.0f - k->margin / (float)k->H;
-            }
-            a.feat0 = k->d_fb[k->b2];
-            a.featIn = k->d_fb[k->b0];
-            a.featOut = k->d_fb[k->b1];
-            rc = cs_launch_track_gain_pass(a, k->stream);
-            if (rc) return rc;
-            std::swap(k->b0, k->b1);  // :285
+    int nLevelsVisited = 0;
+    for (int level = k0->L - 1; level >= 0; level -= levelSkip) ++nLevelsVisited;
+    const int T = nLevelsVisited * c.nIterations;
+    const float delta = 200.0f, lambda = 1.0f;  // v3d_gpuklt.cpp:243-250 (tau = 1: delta stays)
+
+    if (cs_rows_supported(hw)) {
+        CsRowsArgs A;
+        memset(&A, 0, sizeof(A));
+        A.lv.L = k0->L;
+        for (int l = 0; l < k0->L; ++l) {
+            A.lv.w[l] = k0->lay.w[l];
+            A.lv.h[l] = k0->lay.h[l];
+            A.lv.off[l] = k0->lay.off[l];
         }
+        A.W = k0->W;
+        A.H = k0->H;
+        A.fw = k0->fw;
+        A.fh = k0->fh;
+        A.N = k0->N;
+        A.nIter = c.nIterations;
+        A.levelSkip = levelSkip;
+        A.doSuppress = doSuppress;
+        A.lambda = lambda;
+        A.delta = delta;
+        gain_neighbour_offsets(k0->fw, k0->fh, A.n1x, A.n1y);
+        A.nCams = S.n;
+        const float realConv = k0->convThr * k0->convThr, realSsd = k0->ssdThr;
+        const float realVr[4] = {k0->margin / (float)k0->W, k0->margin / (float)k0->H, 1.0f - k0->margin / (float)k0->W,
+                                 1.0f - k0->margin / (float)k0->H};
+        const int perLaunch = rows_cams_per_persistent_launch(S, hw, T);
+        if (perLaunch >= 1) {
+            A.sqrConvThr = realConv;
+            A.ssdThr = realSsd;
+            for (int q = 0; q < 4; ++q) A.vr[q] = realVr[q];
+            for (int first = 0; first < S.n; first += perLaunch) {
+                const int m = (S.n - first < perLaunch) ? S.n - first : perLaunch;
+                A.nCams = m;
+                for (int i = 0; i < m; ++i) {
+                    cs_klt* k = S.k[first + i];
+                    CsRowsCam& C = A.cam[i];
+                    C.pyr0 = k->d_pyr[k->p0];
+                    C.pyr1 = k->d_pyr[k->p1];
+                    C.feat0 = k->d_fb[k->b2];
+                    C.featStart = k->d_fb[k->b0];
+                    // where the ping-pong schedule of the reference leaves its last two results (v3d_gpuklt.cpp:281-285)
+                    C.outLast = k->d_fb[(T & 1) ? k->b1 : k->b0];
+                    C.outPrev = k->d_fb[(T & 1) ? k->b0 : k->b1];
+                    C.gran = k->d_gran;
+                    C.tagWord = (const unsigned*)(k->d_counts + 5);
+                    C.err = k->d_err;
+                    C.dest = postDest ? postDest[first + i] : nullptr;
+                    C.corner = k->d_corner_raw;
+                    C.probe = k->d_probe;
+                }
+                int rc = cs_launch_track_rows_fused(A, hw, S.stream);
+                if (rc) return rc;
+            }
+            if (postFused) *postFused = (postDest != nullptr);
+            for (int i = 0; i < S.n; ++i) {
+                cs_klt* k = S.k[i];
+                if (T & 1) std::swap(k->b0, k->b1);  // T swaps of (buffer0, buffer1)
+                std::swap(k->b0, k->b2);             // v3d_gpuklt.cpp:304
+            }
+            return CS_OK;
+        }
+        A.nCams = S.n;
+        // one launch per Gauss-Newton pass (v3d_gpuklt.cpp:254-287), all cameras per launch
+        for (int i = 0; i < S.n; ++i) {
+            int rc = cs_launch_reset_beta(S.k[i]->d_fb[S.k[i]->b0], S.k[i]->N, S.stream);  // v3d_gpuklt.cpp:223-227
+            if (rc) return rc;
+        }
+        for (int level = k0->L - 1; level >= 0; level -= levelSkip) {  // :254
+            A.level = level;
+            for (int iter = 1; iter <= c.nIterations; ++iter) {  // :268
+                if (iter == 1) {  // :271-279
+                    A.sqrConvThr = 1000000.0f;
+                    A.ssdThr = 1000000.0f;
+                    A.vr[0] = A.vr[1] = -1.0f;
+                    A.vr[2] = A.vr[3] = 2.0f;
+                } else if (iter == c.nIterations) {
+                    A.sqrConvThr = realConv;
+                    A.ssdThr = realSsd;
+                    for (int q = 0; q < 4; ++q) A.vr[q] = realVr[q];
+                }
+                for (int i = 0; i < S.n; ++i) {
+                    cs_klt* k = S.k[i];
+                    CsRowsCam& C = A.cam[i];
+                    C.pyr0 = k->d_pyr[k->p0];
+                    C.pyr1 = k->d_pyr[k->p1];
+                    C.feat0 = k->d_fb[k->b2];
+                    C.featStart = k->d_fb[k->b0];
+                    C.outLast = k->d_fb[k->b1];
+                }
+                int rc = cs_launch_track_rows_pass(A, hw, S.stream);
+                if (rc) return rc;
+                for (int i = 0; i < S.n; ++i) std::swap(S.k[i]->b0, S.k[i]->b1);  // :285
+            }
+        }
+        for (int i = 0; i < S.n; ++i) std::swap(S.k[i]->b0, S.k[i]->b2);  // :304
+        return CS_OK;
     }
-    std::swap(k->b0, k->b2);  // :304
+
+    // window sizes the rows design does not cover: one wave per feature, one launch per pass, camera by camera
+    for (int i = 0; i < S.n; ++i) {
+        cs_klt* k = S.k[i];
+        const cs_texel *P0 = k->d_pyr[k->p0], *P1 = k->d_pyr[k->p1];
+        int rc = cs_launch_reset_beta(k->d_fb[k->b0], k->N, S.stream);  // v3d_gpuklt.cpp:223-227
+        if (rc) return rc;
+        CsGainPassArgs a;
+        memset(&a, 0, sizeof(a));
+        a.whx = (float)k->W;
+        a.why = (float)k->H;
+        a.fw = k->fw;
+        a.fh = k->fh;
+        a.N = k->N;
+        a.hw = hw;
+        a.lambda = lambda;  // :250
+        a.delta = delta;
+        gain_neighbour_offsets(k->fw, k->fh, a.n1x, a.n1y);
+        a.sqrConvThr = 1000000.0f;
+        a.ssdThr = 1000000.0f;
+        a.vr[0] = a.vr[1] = -1.0f;
+        a.vr[2] = a.vr[3] = 2.0f;
+        for (int level = k->L - 1; level >= 0; level -= levelSkip) {  // :254
+            a.lvl0 = P0 + k->lay.off[level];
+            a.lvl1 = P1 + k->lay.off[level];
+            a.Wl = k->lay.w[level];
+            a.Hl = k->lay.h[level];
+            for (int iter = 1; iter <= c.nIterations; ++iter) {  // :268
+                if (iter == 1) {  // :271-279
+                    a.sqrConvThr = 1000000.0f;
+                    a.ssdThr = 1000000.0f;
+                    a.vr[0] = a.vr[1] = -1.0f;
+                    a.vr[2] = a.vr[3] = 2.0f;
+                } else if (iter == c.nIterations) {
+                    a.sqrConvThr = k->convThr * k->convThr;
+                    a.ssdThr = k->ssdThr;
+                    a.vr[0] = k->margin / (float)k->W;
+                    a.vr[1] = k->margin / (float)k->H;
+                    a.vr[2] = 1.0f - k->margin / (float)k->W;
+                    a.vr[3] = 1.0f - k->margin / (float)k->H;
+                }
+                a.feat0 = k->d_fb[k->b2];
+                a.featIn = k->d_fb[k->b0];
+                a.featOut = k->d_fb[k->b1];
+                rc = cs_launch_track_gain_pass(a, S.stream);
+                if (rc) return rc;
+                std::swap(k->b0, k->b1);  // :285
+            }
+        }
+        std::swap(k->b0, k->b2);  // :304
+    }
     return CS_OK;
 }
 
-static int enqueue_detect_tail(cs_klt* k, int mode, int nPresentGiven, int maxKeepFixed, cs_klt_feature* d_dest,
-                               int* d_counts) {
-    // a pending cs_klt_prefetch_dev request rides in the tail's two launches; inside a graph capture it is dropped
-    const uint8_t* next = (const uint8_t*)k->pf_next_img;
-    k->pf_next_img = nullptr;
-    if (next) {
+static int enqueue_detect_tail(const Span& S, int mode, const int* nPresentGiven, const int* maxKeepFixed,
+                               cs_klt_feature* const* d_dest, int* const* d_counts) {
+    cs_klt* k0 = S.k[0];
+    // pending cs_klt_prefetch_dev requests ride in the tail's two launches (all cameras or none); inside a graph
+    // capture they are dropped
+    bool withNext = true;
+    for (int i = 0; i < S.n; ++i) withNext = withNext && (S.k[i]->pf_next_img != nullptr);
+    if (withNext) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(k->stream, &cap);
-        if (cap != hipStreamCaptureStatusNone || cs_nonmax_lds_bytes(k->cfg.minDistance) > 64 * 1024) next = nullptr;
+        (void)hipStreamIsCapturing(S.stream, &cap);
+        if (cap != hipStreamCaptureStatusNone || cs_nonmax_lds_bytes(k0->cfg.minDistance) > 64 * 1024) withNext = false;
     }
-    int rc = CS_OK;
-    if (!next) {
-        rc = cs_launch_nonmax_compact(k->d_corner_raw, k->W, k->H, k->cfg.minDistance, k->d_corner, k->d_cand, k->maxCand,
-                                      k->d_ctr, k->stream);
-        if (rc) return rc;
-    }
-    CsFillArgs f;
-    f.mode = mode;
-    f.N = k->N;
-    f.withGain = k->cfg.trackWithGain;
-    f.nPresentGiven = nPresentGiven;
-    f.present3 = k->d_present;
-    f.sel = k->d_sel;
-    f.ctr = k->d_ctr;
-    f.dest = d_dest;
-    // provideFeatures / provideFeaturesAndGain, v3d_gpuklt.cpp:86-92,188-197
-    f.list_a = k->d_fb[k->b1];
-    f.list_b = k->cfg.trackWithGain ? k->d_fb[k->b2] : nullptr;
-    f.counts = d_counts;
-    f.tagWord = (unsigned*)(k->d_counts + 5);
-    if (next) {
+    CsNonmaxCam nm[CS_MAX_CAMS];
+    CsSelectCam sel[CS_MAX_CAMS];
+    CsFrontCam nxt[CS_MAX_CAMS];
+    for (int i = 0; i < S.n; ++i) {
+        cs_klt* k = S.k[i];
+        nm[i].in = k->d_corner_raw;
+        nm[i].out = k->d_corner;
+        nm[i].cand = k->d_cand;
+        nm[i].ctr = k->d_ctr;
+        sel[i].cand = k->d_cand;
+        sel[i].rankM = k->d_rank;
+        sel[i].sel = k->d_sel;
+        sel[i].maxKeepFixed = maxKeepFixed ? maxKeepFixed[i] : -1;
+        CsFillArgs& f = sel[i].fill;
+        f.mode = mode;
+        f.N = k->N;
+        f.withGain = k->cfg.trackWithGain;
+        f.nPresentGiven = nPresentGiven ? nPresentGiven[i] : 0;
+        f.present3 = k->d_present;
+        f.sel = k->d_sel;
+        f.ctr = k->d_ctr;
+        f.dest = d_dest[i];
+        // provideFeatures / provideFeaturesAndGain, v3d_gpuklt.cpp:86-92,188-197
+        f.list_a = k->d_fb[k->b1];
+        f.list_b = k->cfg.trackWithGain ? k->d_fb[k->b2] : nullptr;
+        f.counts = d_counts[i];
+        f.tagWord = (unsigned*)(k->d_counts + 5);
         // spare buffers: last read by the tracker / non-max of the frame BEFORE this one -- older than this point of
         // the stream
-        rc = cs_launch_tail_with_next_front(k->d_corner_raw, k->W, k->H, k->cfg.minDistance, k->d_corner, k->d_cand,
-                                            k->maxCand, k->plw * k->plh, maxKeepFixed, k->d_rank, k->d_sel, f, next, k->lay,
-                                            k->d_pyr[k->p2], k->tap_mode, k->d_corner_raw_spare, k->cfg.minCornerness,
-                                            k->detMargin, k->stream);
+        nxt[i].img = (const uint8_t*)k->pf_next_img;
+        nxt[i].pyr = k->d_pyr[k->p2];
+        nxt[i].corner = k->d_corner_raw_spare;
+        nxt[i].ctr = nullptr;
+        k->pf_next_img = nullptr;
+    }
+    if (withNext) {
+        int rc = cs_launch_tail_with_next_front(nm, sel, nxt, S.n, k0->W, k0->H, k0->cfg.minDistance, k0->maxCand,
+                                                k0->plw * k0->plh, k0->lay, k0->tap_mode, k0->cfg.minCornerness,
+                                                k0->detMargin, S.stream);
         if (rc) return rc;
-        k->pf_img = next;
-        k->pf_valid = true;
+        for (int i = 0; i < S.n; ++i) {
+            S.k[i]->pf_img = nxt[i].img;
+            S.k[i]->pf_valid = true;
+        }
         return CS_OK;
     }
-    return cs_launch_select_fill(k->d_cand, k->maxCand, k->plw * k->plh, maxKeepFixed, k->d_rank, k->d_sel, f, k->stream);
+    int rc = cs_launch_nonmax_compact(nm, S.n, k0->W, k0->H, k0->cfg.minDistance, k0->maxCand, S.stream);
+    if (rc) return rc;
+    return cs_launch_select_fill(sel, S.n, k0->maxCand, k0->plw * k0->plh, S.stream);
 }
 
-static int enqueue_track(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest, int* d_counts, bool forRedetect) {
-    // pyramid (:858), the cornerness map the detector will need, and the zeroing of this frame's counters and
-    // hand-off granules: two launches (klt_pyramid.hip)
+static int enqueue_front(const Span& S, const uint8_t* const* d_img, bool withCorner) {
+    cs_klt* k0 = S.k[0];
+    CsFrontCam fc[CS_MAX_CAMS];
+    for (int i = 0; i < S.n; ++i) {
+        cs_klt* k = S.k[i];
+        fc[i].img = d_img[i];
+        fc[i].pyr = k->d_pyr[k->p1];
+        fc[i].corner = withCorner ? k->d_corner_raw : nullptr;
+        fc[i].ctr = k->d_ctr;
+    }
+    return cs_launch_frame_front(fc, S.n, k0->lay, k0->tap_mode, withCorner, k0->cfg.minCornerness, k0->detMargin, S.stream);
+}
+
+static int enqueue_track(const Span& S, const uint8_t* const* d_img, cs_klt_feature* const* d_dest, int* const* d_counts,
+                         bool forRedetect) {
+    cs_klt* k0 = S.k[0];
+    // pyramid (:858), the cornerness map the detector will need, and the zeroing of this frame's counters: two launches
+    // (klt_pyramid.hip) -- unless the previous frame's detector tail has already built them (cs_klt_prefetch_dev)
     int rc = CS_OK;
-    if (k->pf_valid && k->pf_img == (const void*)d_img) {
-        // prefetched: the spare pyramid / cornerness buffers become this frame's, the ones they replace (last read two
-        // frames ago) become the next prefetch's targets.  The candidate counter was zeroed by the previous frame's tail.
-        std::swap(k->p1, k->p2);
-        std::swap(k->d_corner_raw, k->d_corner_raw_spare);
+    bool prefetched = true;
+    for (int i = 0; i < S.n; ++i) prefetched = prefetched && S.k[i]->pf_valid && S.k[i]->pf_img == (const void*)d_img[i];
+    if (prefetched) {
+        // the spare pyramid / cornerness buffers become this frame's, the ones they replace (last read two frames ago)
+        // become the next prefetch's targets.  The candidate counter was zeroed by the previous frame's tail.
+        for (int i = 0; i < S.n; ++i) {
+            std::swap(S.k[i]->p1, S.k[i]->p2);
+            std::swap(S.k[i]->d_corner_raw, S.k[i]->d_corner_raw_spare);
+        }
     } else {
-        rc = cs_launch_frame_front(d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, forRedetect ? k->d_corner_raw : nullptr,
-                                   k->cfg.minCornerness, k->detMargin, k->d_ctr, nullptr, 0, k->stream);
+        rc = enqueue_front(S, d_img, forRedetect);
         if (rc) return rc;
     }
-    k->pf_valid = false;
+    for (int i = 0; i < S.n; ++i) S.k[i]->pf_valid = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (k->profiling) {
+    if (k0->profiling) {
         CS_HIP(hipEventCreate(&e0));
         CS_HIP(hipEventCreate(&e1));
-        CS_HIP(hipEventRecord(e0, k->stream));
+        CS_HIP(hipEventRecord(e0, S.stream));
     }
     bool postFused = false;
-    rc = enqueue_tracker(k, d_dest, forRedetect ? 1 : 0, &postFused);
+    rc = enqueue_tracker(S, d_dest, forRedetect ? 1 : 0, &postFused);
     if (rc) return rc;
-    if (k->profiling) {
-        CS_HIP(hipEventRecord(e1, k->stream));
-        k->ev_pairs->push_back(std::make_pair(e0, e1));
+    if (k0->profiling) {
+        CS_HIP(hipEventRecord(e1, S.stream));
+        k0->ev_pairs->push_back(std::make_pair(e0, e1));
     }
-    if (!postFused) {
-        rc = cs_launch_post_track(read_buffer(k), k->N, d_dest, k->d_ctr, k->d_corner_raw, k->W, k->H,
-                                  forRedetect ? 1 : 0, k->stream);
-        if (rc) return rc;
-    }
-    if (!forRedetect) {
-        k->pf_next_img = nullptr;  // no detector tail to carry the next front: the request lapses
-        rc = cs_launch_counts_track(d_dest, k->N, d_counts, k->d_ctr, (unsigned*)(k->d_counts + 5), k->stream);
+    for (int i = 0; i < S.n; ++i) {
+        cs_klt* k = S.k[i];
+        if (!postFused) {
+            rc = cs_launch_post_track(k->cfg.trackWithGain ? k->d_fb[k->b2] : k->d_fb[k->b1], k->N, d_dest[i], k->d_ctr,
+                                      k->d_corner_raw, k->W, k->H, forRedetect ? 1 : 0, S.stream);
+            if (rc) return rc;
+        }
+        if (!forRedetect) {
+            k->pf_next_img = nullptr;  // no detector tail to carry the next front: the request lapses
+            rc = cs_launch_counts_track(d_dest[i], k->N, d_counts[i], k->d_ctr, (unsigned*)(k->d_counts + 5), S.stream);
+            if (rc) return rc;
+        }
     }
     return rc;
 }
 
-static int enqueue_redetect(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest, int* d_counts) {
-    int rc = enqueue_track(k, d_img, d_dest, d_counts, true);
+static int enqueue_redetect(const Span& S, const uint8_t* const* d_img, cs_klt_feature* const* d_dest, int* const* d_counts) {
+    int rc = enqueue_track(S, d_img, d_dest, d_counts, true);
     if (rc) return rc;
-    return enqueue_detect_tail(k, 2, 0, -1, d_dest, d_counts);
+    return enqueue_detect_tail(S, 2, nullptr, nullptr, d_dest, d_counts);
 }
 
-static int enqueue_detect(cs_klt* k, const uint8_t* d_img, cs_klt_feature* d_dest, int* d_counts, int nPresent) {
-    k->pf_valid = false;
-    int rc = cs_launch_frame_front(d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, k->d_corner_raw, k->cfg.minCornerness,
-                                   k->detMargin, k->d_ctr, nullptr, 0, k->stream);
+static int enqueue_detect(const Span& S, const uint8_t* const* d_img, cs_klt_feature* const* d_dest, int* const* d_counts,
+                          const int* nPresent) {
+    for (int i = 0; i < S.n; ++i) S.k[i]->pf_valid = false;
+    int rc = enqueue_front(S, d_img, true);
     if (rc) return rc;
-    if (nPresent > 0) {
-        rc = cs_launch_suppress_list(k->d_corner_raw, k->W, k->H, nPresent, k->d_present, k->stream);
+    int maxKeep[CS_MAX_CAMS], nPres[CS_MAX_CAMS];
+    bool anyPresent = false;
+    for (int i = 0; i < S.n; ++i) {
+        cs_klt* k = S.k[i];
+        nPres[i] = nPresent ? nPresent[i] : 0;
+        anyPresent = anyPresent || nPres[i] > 0;
+        if (nPres[i] > 0) {
+            rc = cs_launch_suppress_list(k->d_corner_raw, k->W, k->H, nPres[i], k->d_present, S.stream);
+            if (rc) return rc;
+        }
+        rc = cs_launch_clear_dest(d_dest[i], k->N, S.stream);
         if (rc) return rc;
+        maxKeep[i] = k->N - nPres[i];
+        if (maxKeep[i] < 0) maxKeep[i] = 0;
     }
-    rc = cs_launch_clear_dest(d_dest, k->N, k->stream);
-    if (rc) return rc;
-    int maxKeep = k->N - nPresent;
-    if (maxKeep < 0) maxKeep = 0;
-    return enqueue_detect_tail(k, nPresent > 0 ? 1 : 0, nPresent, maxKeep, d_dest, d_counts);
+    return enqueue_detect_tail(S, anyPresent ? 1 : 0, nPres, maxKeep, d_dest, d_counts);
+}
+
+// single-camera forms used by the per-handle entry points
+static int enqueue_detect1(cs_klt* k, const uint8_t* img, cs_klt_feature* dest, int* counts, int nPresent) {
+    Span S = {&k, 1, k->stream};
+    return enqueue_detect(S, &img, &dest, &counts, &nPresent);
+}
+static int enqueue_redetect1(cs_klt* k, const uint8_t* img, cs_klt_feature* dest, int* counts) {
+    Span S = {&k, 1, k->stream};
+    return enqueue_redetect(S, &img, &dest, &counts);
+}
+static int enqueue_track1(cs_klt* k, const uint8_t* img, cs_klt_feature* dest, int* counts) {
+    Span S = {&k, 1, k->stream};
+    return enqueue_track(S, &img, &dest, &counts, false);
 }
 
 // the persistent tracker raises *d_err when a bounded spin ran out (waves not co-resident): results are invalid
@@ -551,6 +685,7 @@ int cs_klt_deallocate(cs_klt* k) {
     {
         std::lock_guard<std::mutex> g(g_reg_mutex);
         g_live_handles[k->device & 63]--;
+        g_live_gen[k->device & 63]++;
     }
     hipHostFree(k->h_dest);
     hipHostFree(k->h_counts);
@@ -667,23 +802,36 @@ int cs_klt_allocate(cs_klt* k, int W, int H, int nLevels, int fw, int fh, int pl
     {
         std::lock_guard<std::mutex> g(g_reg_mutex);
         g_live_handles[k->device & 63]++;
+        g_live_gen[k->device & 63]++;
     }
     return CS_OK;
 }
 
 int cs_klt_set_border_margin(cs_klt* k, float m) {  // v3d_gpuklt.h:219-226
     CS_REQUIRE(k, "null handle");
+    if (k->allocated && k->graphs && !k->graphs->empty()) {  // the thresholds are baked into captured kernel arguments
+        if (bind_device(k) == CS_OK) (void)hipStreamSynchronize(k->stream);
+        drop_graphs(k);
+    }
     k->margin = m;
     k->detMargin = m;
     return CS_OK;
 }
 int cs_klt_set_convergence_threshold(cs_klt* k, float t) {
     CS_REQUIRE(k, "null handle");
+    if (k->allocated && k->graphs && !k->graphs->empty()) {  // the thresholds are baked into captured kernel arguments
+        if (bind_device(k) == CS_OK) (void)hipStreamSynchronize(k->stream);
+        drop_graphs(k);
+    }
     k->convThr = t;
     return CS_OK;
 }
 int cs_klt_set_ssd_threshold(cs_klt* k, float t) {
     CS_REQUIRE(k, "null handle");
+    if (k->allocated && k->graphs && !k->graphs->empty()) {  // the thresholds are baked into captured kernel arguments
+        if (bind_device(k) == CS_OK) (void)hipStreamSynchronize(k->stream);
+        drop_graphs(k);
+    }
     k->ssdThr = t;
     return CS_OK;
 }
@@ -813,13 +961,19 @@ int cs_klt_advance(cs_klt* k) {  // v3d_gpuklt.h:252-259
 // the rotation state; the graph reads the image from the handle's own staging buffer.
 static int run_dev(cs_klt* k, int mode, const void* d_image, void* d_dest, void* d_counts) {
     auto enqueue = [&](const uint8_t* img) -> int {
-        if (mode == 0) return enqueue_detect(k, img, (cs_klt_feature*)d_dest, (int*)d_counts, 0);
-        if (mode == 1) return enqueue_redetect(k, img, (cs_klt_feature*)d_dest, (int*)d_counts);
-        return enqueue_track(k, img, (cs_klt_feature*)d_dest, (int*)d_counts, false);
+        if (mode == 0) return enqueue_detect1(k, img, (cs_klt_feature*)d_dest, (int*)d_counts, 0);
+        if (mode == 1) return enqueue_redetect1(k, img, (cs_klt_feature*)d_dest, (int*)d_counts);
+        return enqueue_track1(k, img, (cs_klt_feature*)d_dest, (int*)d_counts);
     };
     if (!k->use_graphs || k->profiling) return enqueue((const uint8_t*)d_image);
     CS_HIP(hipMemcpyAsync(k->d_img, d_image, (size_t)k->W * k->H, hipMemcpyDeviceToDevice, k->stream));
+    int liveGen = 0;
+    {
+        std::lock_guard<std::mutex> lg(g_reg_mutex);
+        liveGen = g_live_gen[k->device & 63];
+    }
     for (auto& g : *k->graphs) {
+        if (g.live_gen != liveGen) continue;  // captured under another live-handle count: its residency decision is stale
         if (g.mode == mode && g.b0 == k->b0 && g.b1 == k->b1 && g.b2 == k->b2 && g.p0 == k->p0 && g.p1 == k->p1 &&
             g.dest == d_dest && g.counts == d_counts) {
             CS_HIP(hipGraphLaunch(g.exec, k->stream));
@@ -838,6 +992,7 @@ static int run_dev(cs_klt* k, int mode, const void* d_image, void* d_dest, void*
     g.b2 = k->b2;
     g.p0 = k->p0;
     g.p1 = k->p1;
+    g.live_gen = liveGen;
     g.img = k->d_img;
     g.dest = d_dest;
     g.counts = d_counts;
@@ -929,7 +1084,7 @@ int cs_klt_detect(cs_klt* k, const uint8_t* image, int* nDetected, cs_klt_featur
     int rc = bind_device(k);
     if (rc) return rc;
     if ((rc = upload_image(k, image))) return rc;
-    if ((rc = enqueue_detect(k, k->d_img, k->d_dest, k->d_counts, 0))) return rc;
+    if ((rc = enqueue_detect1(k, k->d_img, k->d_dest, k->d_counts, 0))) return rc;
     return fetch_results(k, nDetected, dest);
 }
 
@@ -944,7 +1099,7 @@ int cs_klt_detect_present(cs_klt* k, const uint8_t* image, int* nDetected, cs_kl
         memcpy(k->h_feat, present, sizeof(float) * 3 * nPresent);
         CS_HIP(hipMemcpyAsync(k->d_present, k->h_feat, sizeof(float) * 3 * nPresent, hipMemcpyHostToDevice, k->stream));
     }
-    if ((rc = enqueue_detect(k, k->d_img, k->d_dest, k->d_counts, nPresent))) return rc;
+    if ((rc = enqueue_detect1(k, k->d_img, k->d_dest, k->d_counts, nPresent))) return rc;
     return fetch_results(k, nDetected, dest);
 }
 
@@ -953,7 +1108,7 @@ int cs_klt_redetect(cs_klt* k, const uint8_t* image, int* nNew, cs_klt_feature* 
     int rc = bind_device(k);
     if (rc) return rc;
     if ((rc = upload_image(k, image))) return rc;
-    if ((rc = enqueue_redetect(k, k->d_img, k->d_dest, k->d_counts))) return rc;
+    if ((rc = enqueue_redetect1(k, k->d_img, k->d_dest, k->d_counts))) return rc;
     return fetch_results(k, nNew, dest);
 }
 
@@ -962,7 +1117,7 @@ int cs_klt_track(cs_klt* k, const uint8_t* image, int* nPresent, cs_klt_feature*
     int rc = bind_device(k);
     if (rc) return rc;
     if ((rc = upload_image(k, image))) return rc;
-    if ((rc = enqueue_track(k, k->d_img, k->d_dest, k->d_counts, false))) return rc;
+    if ((rc = enqueue_track1(k, k->d_img, k->d_dest, k->d_counts))) return rc;
     return fetch_results(k, nPresent, dest);
 }
 
@@ -1045,10 +1200,141 @@ int cs_klt_build_pyramid(cs_klt* k, const uint8_t* image) {
     int rc = bind_device(k);
     if (rc) return rc;
     if ((rc = upload_image(k, image))) return rc;
-    if ((rc = cs_launch_frame_front(k->d_img, k->lay, k->d_pyr[k->p1], k->tap_mode, nullptr, 0.0f, 0.0f, nullptr, nullptr, 0,
-                                    k->stream)))
-        return rc;
+    CsFrontCam fc = {k->d_img, k->d_pyr[k->p1], nullptr, nullptr};
+    if ((rc = cs_launch_frame_front(&fc, 1, k->lay, k->tap_mode, false, 0.0f, 0.0f, k->stream))) return rc;
     CS_HIP(hipStreamSynchronize(k->stream));
+    return CS_OK;
+}
+
+// ---- camera groups: the frame schedule of several cameras in one set of launches -----------------------------------
+// CoSLAM::featureTracking() (src/app/SL_CoSLAM.cpp:299-305) calls GPUKLT::next camera by camera; a group issues the
+// same per-camera work with the camera as one more grid dimension of every kernel: 3-5 launches per frame for ALL
+// cameras, and one persistent tracker launch whose waves (8 features each) are all co-resident.
+struct cs_klt_group {
+    std::vector<cs_klt*> ks;
+    hipStream_t stream;
+};
+
+static bool same_setup(const cs_klt* a, const cs_klt* b) {
+    return a->device == b->device && a->tap_mode == b->tap_mode && a->W == b->W && a->H == b->H && a->L == b->L &&
+           a->fw == b->fw && a->fh == b->fh && a->plw == b->plw && a->plh == b->plh && a->margin == b->margin &&
+           a->convThr == b->convThr && a->ssdThr == b->ssdThr && a->detMargin == b->detMargin &&
+           memcmp(&a->cfg, &b->cfg, sizeof(cs_klt_config)) == 0;
+}
+
+cs_klt_group* cs_klt_group_create(cs_klt* const* handles, int n) {
+    if (!handles || n < 1 || n > CS_MAX_CAMS) {
+        cs_set_error("cs_klt_group_create: need 1..%d handles", CS_MAX_CAMS);
+        return nullptr;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!handles[i] || !handles[i]->allocated) {
+            cs_set_error("cs_klt_group_create: handle %d is null or not allocated", i);
+            return nullptr;
+        }
+        for (int j = 0; j < i; ++j)
+            if (handles[j] == handles[i]) {
+                cs_set_error("cs_klt_group_create: handle %d appears twice", i);
+                return nullptr;
+            }
+        if (!same_setup(handles[0], handles[i])) {
+            cs_set_error("cs_klt_group_create: handle %d differs from handle 0 in device, size or configuration", i);
+            return nullptr;
+        }
+    }
+    cs_klt_group* g = new (std::nothrow) cs_klt_group();
+    if (!g) return nullptr;
+    g->ks.assign(handles, handles + n);
+    g->stream = handles[0]->stream;
+    return g;
+}
+
+void cs_klt_group_destroy(cs_klt_group* g) { delete g; }
+
+int cs_klt_group_size(const cs_klt_group* g) { return g ? (int)g->ks.size() : 0; }
+
+int cs_klt_group_set_stream(cs_klt_group* g, void* hip_stream) {
+    CS_REQUIRE(g, "null group");
+    g->stream = hip_stream ? (hipStream_t)hip_stream : g->ks[0]->own_stream;
+    for (cs_klt* k : g->ks) k->stream = g->stream;
+    return CS_OK;
+}
+
+static int group_check(cs_klt_group* g, const void* const* a, void* const* b, void* const* c, const char* what) {
+    if (!g || !a || !b || !c) {
+        cs_set_error("%s: bad arguments", what);
+        return CS_ERR_INVALID;
+    }
+    const int n = (int)g->ks.size();
+    for (int i = 0; i < n; ++i) {
+        if (!a[i] || !b[i] || !c[i] || !g->ks[i]->allocated) {
+            cs_set_error("%s: null pointer or deallocated handle for camera %d", what, i);
+            return CS_ERR_INVALID;
+        }
+        if (!same_setup(g->ks[0], g->ks[i])) {
+            cs_set_error("%s: camera %d no longer matches camera 0 (thresholds changed on one handle only?)", what, i);
+            return CS_ERR_INVALID;
+        }
+    }
+    return bind_device(g->ks[0]);
+}
+
+static int group_run(cs_klt_group* g, int mode, const void* const* d_images, void* const* d_dests, void* const* d_counts,
+                     const char* what) {
+    int rc = group_check(g, d_images, d_dests, d_counts, what);
+    if (rc) return rc;
+    const int n = (int)g->ks.size();
+    Span S = {g->ks.data(), n, g->stream};
+    const uint8_t* img[CS_MAX_CAMS];
+    cs_klt_feature* dest[CS_MAX_CAMS];
+    int* counts[CS_MAX_CAMS];
+    for (int i = 0; i < n; ++i) {
+        img[i] = (const uint8_t*)d_images[i];
+        dest[i] = (cs_klt_feature*)d_dests[i];
+        counts[i] = (int*)d_counts[i];
+    }
+    if (mode == 0) return enqueue_detect(S, img, dest, counts, nullptr);
+    if (mode == 1) return enqueue_redetect(S, img, dest, counts);
+    return enqueue_track(S, img, dest, counts, false);
+}
+
+int cs_klt_group_detect_dev(cs_klt_group* g, const void* const* d_images, void* const* d_dests, void* const* d_counts) {
+    return group_run(g, 0, d_images, d_dests, d_counts, "cs_klt_group_detect_dev");
+}
+int cs_klt_group_redetect_dev(cs_klt_group* g, const void* const* d_images, void* const* d_dests, void* const* d_counts) {
+    return group_run(g, 1, d_images, d_dests, d_counts, "cs_klt_group_redetect_dev");
+}
+int cs_klt_group_track_dev(cs_klt_group* g, const void* const* d_images, void* const* d_dests, void* const* d_counts) {
+    return group_run(g, 2, d_images, d_dests, d_counts, "cs_klt_group_track_dev");
+}
+
+int cs_klt_group_prefetch_dev(cs_klt_group* g, const void* const* d_images_next) {
+    CS_REQUIRE(g && d_images_next, "cs_klt_group_prefetch_dev: bad arguments");
+    for (size_t i = 0; i < g->ks.size(); ++i) {
+        int rc = cs_klt_prefetch_dev(g->ks[i], d_images_next[i]);
+        if (rc) return rc;
+    }
+    return CS_OK;
+}
+
+int cs_klt_group_advance(cs_klt_group* g) {
+    CS_REQUIRE(g, "null group");
+    for (cs_klt* k : g->ks) {
+        int rc = cs_klt_advance(k);
+        if (rc) return rc;
+    }
+    return CS_OK;
+}
+
+int cs_klt_group_synchronize(cs_klt_group* g) {
+    CS_REQUIRE(g, "null group");
+    int rc = bind_device(g->ks[0]);
+    if (rc) return rc;
+    CS_HIP(hipStreamSynchronize(g->stream));
+    for (cs_klt* k : g->ks) {
+        rc = check_device_error(k);
+        if (rc) return rc;
+    }
     return CS_OK;
 }
 

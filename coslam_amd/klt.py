@@ -238,3 +238,63 @@ class KLT_SequenceTracker:
     def build_pyramid(self, image):
         img = _u8(image, self.W, self.H)
         check(self._L.cs_klt_build_pyramid(self._h, img.ctypes.data_as(C.c_void_p)), "cs_klt_build_pyramid")
+
+
+class KLT_TrackerGroup:
+    """Several KLT_SequenceTracker objects (same device, size and configuration) driven together: the per-frame loop of
+    CoSLAM::featureTracking() (reference src/app/SL_CoSLAM.cpp:299-305) as ONE set of launches, the camera being one more
+    grid dimension of every kernel (cs_klt_group_*).  Results are bit-identical to driving the trackers one by one."""
+
+    def __init__(self, trackers):
+        self._L = lib()
+        self.trackers = list(trackers)
+        n = len(self.trackers)
+        arr = (C.c_void_p * n)(*[t._h for t in self.trackers])
+        self._L.cs_klt_group_create.restype = C.c_void_p
+        self._L.cs_klt_group_create.argtypes = [C.c_void_p, C.c_int]
+        h = self._L.cs_klt_group_create(arr, n)
+        if not h:
+            raise CoslamHipError("cs_klt_group_create: " + self._L.cs_last_error().decode())
+        self._h = C.c_void_p(h)
+        self.n = n
+
+    def close(self):
+        if self._h:
+            self._L.cs_klt_group_destroy.argtypes = [C.c_void_p]
+            self._L.cs_klt_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ptrs(self, ptrs):
+        if len(ptrs) != self.n:
+            raise ValueError(f"expected {self.n} pointers, got {len(ptrs)}")
+        return (C.c_void_p * self.n)(*[int(p) for p in ptrs])
+
+    def set_stream(self, stream_ptr):
+        check(self._L.cs_klt_group_set_stream(self._h, C.c_void_p(stream_ptr)), "cs_klt_group_set_stream")
+
+    def detect_dev(self, d_images, d_dests, d_counts):
+        check(self._L.cs_klt_group_detect_dev(self._h, self._ptrs(d_images), self._ptrs(d_dests), self._ptrs(d_counts)),
+              "cs_klt_group_detect_dev")
+
+    def redetect_dev(self, d_images, d_dests, d_counts):
+        check(self._L.cs_klt_group_redetect_dev(self._h, self._ptrs(d_images), self._ptrs(d_dests), self._ptrs(d_counts)),
+              "cs_klt_group_redetect_dev")
+
+    def track_dev(self, d_images, d_dests, d_counts):
+        check(self._L.cs_klt_group_track_dev(self._h, self._ptrs(d_images), self._ptrs(d_dests), self._ptrs(d_counts)),
+              "cs_klt_group_track_dev")
+
+    def prefetch_dev(self, d_images_next):
+        check(self._L.cs_klt_group_prefetch_dev(self._h, self._ptrs(d_images_next)), "cs_klt_group_prefetch_dev")
+
+    def advanceFrame(self):
+        check(self._L.cs_klt_group_advance(self._h), "cs_klt_group_advance")
+
+    def synchronize(self):
+        check(self._L.cs_klt_group_synchronize(self._h), "cs_klt_group_synchronize")

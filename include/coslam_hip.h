@@ -114,9 +114,11 @@ int cs_klt_synchronize(cs_klt* k);
 /* Replay the *_dev frame schedules from cached hipGraphs (one host launch per frame instead of ~60).  The image is
  * first copied into the handle's staging buffer (device-to-device) so that one graph serves every frame. */
 int cs_klt_enable_graphs(cs_klt* k, int on);
-/* Gain tracker schedule: 1 (default) = one persistent launch for all levels x iterations, neighbours exchange gains
- * through 8-byte {tag, beta} granules; 0 = one launch per Gauss-Newton pass as the reference schedules its shader
- * (v3d_gpuklt.cpp:254-287).  Both give bit-identical results.  Env COSLAM_KLT_FUSED=0 sets the default to 0. */
+/* Gain tracker schedule: 1 (default) = one persistent launch for all levels x iterations (and all cameras of a group),
+ * neighbours exchange gains through 8-byte {tag, beta} granules; 0 = one launch per Gauss-Newton pass as the reference
+ * schedules its shader (v3d_gpuklt.cpp:254-287).  Both give bit-identical results.  The persistent schedule needs every
+ * wave co-resident (checked against the occupancy the runtime reports); otherwise the per-pass schedule runs.
+ * Env COSLAM_KLT_FUSED=0 sets the default to 0. */
 int cs_klt_set_fused(cs_klt* k, int on);
 /* compute units available to the handle's stream when it carries a CU mask (co-residency budget of the persistent tracker) */
 int cs_klt_set_cu_count(cs_klt* k, int n_cus);
@@ -131,12 +133,32 @@ void* cs_stream_create_cu_range(int device, int first_cu, int n_cus);
  * is empty gets all its CUs, so period = 8 (or 4, 2) masks do not partition the chip at all; kept for experiments. */
 void* cs_stream_create_cu_interleaved(int device, int period, int take, int complement);
 int cs_stream_destroy(void* stream);
-/* diagnostic only: per-slot cycle counters (8 x uint64) of the persistent gain tracker; see klt_seq.hip */
+/* diagnostic only: per-wave cycle counters (8 x uint64 per wave of 8 slots; host_out8 holds 8 * N) of the persistent gain
+ * tracker; see klt_seq.hip */
 int cs_klt_debug_probe(cs_klt* k, int on, unsigned long long* host_out8);
 /* HIP-event timing of the tracker stage on the handle's stream (used by bench.py's roofline leg).  While on, the
  * *_dev calls launch eagerly and bracket the tracker kernel(s) of every frame with an event pair. */
 int cs_klt_set_profiling(cs_klt* k, int on);
 int cs_klt_get_profile(cs_klt* k, double* tracker_us_total, int* n_frames, int* launches_per_frame);
+
+/* ---- camera groups: the per-frame call of SEVERAL cameras in one set of launches ----
+ * CoSLAM::featureTracking() (src/app/SL_CoSLAM.cpp:299-305) calls GPUKLT::next -> KLT_SequenceTracker::redetect
+ * camera by camera.  A group issues the same per-camera work with the camera as one more grid dimension of every
+ * kernel: 3-5 launches per frame for all cameras together, the gain tracker of all cameras in ONE persistent launch.
+ * Results are bit-identical to driving the handles one by one.  The handles must live on one device and share image
+ * size, slot grid and configuration (cs_klt_group_create returns NULL otherwise); they stay owned by the caller, and
+ * every array argument has one entry per handle, in the order given at creation. */
+typedef struct cs_klt_group cs_klt_group;
+cs_klt_group* cs_klt_group_create(cs_klt* const* handles, int n); /* n <= 16 */
+void cs_klt_group_destroy(cs_klt_group* g);                        /* the handles are NOT destroyed */
+int cs_klt_group_size(const cs_klt_group* g);
+int cs_klt_group_set_stream(cs_klt_group* g, void* hip_stream); /* also rebinds every member handle */
+int cs_klt_group_detect_dev(cs_klt_group* g, const void* const* d_images, void* const* d_dests, void* const* d_counts);
+int cs_klt_group_redetect_dev(cs_klt_group* g, const void* const* d_images, void* const* d_dests, void* const* d_counts);
+int cs_klt_group_track_dev(cs_klt_group* g, const void* const* d_images, void* const* d_dests, void* const* d_counts);
+int cs_klt_group_prefetch_dev(cs_klt_group* g, const void* const* d_images_next);
+int cs_klt_group_advance(cs_klt_group* g);     /* advanceFrame() on every handle */
+int cs_klt_group_synchronize(cs_klt_group* g); /* + the persistent tracker's error words */
 
 /* ---- introspection used by the parity tests (host copies; synchronise the stream) ----
  * which: 0 = _pyrCreator0 (previous frame), 1 = _pyrCreator1 (frame most recently built). */

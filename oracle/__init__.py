@@ -127,19 +127,38 @@ def sample(lvl, Wl, Hl, s, t):
     return out
 
 
+def set_threshold_margin_buffer(buf):
+    """buf: float32[N] preset to a large value (kept alive by the caller), or None to switch the diagnostic off."""
+    lib().okl_set_threshold_margin_buffer(_p(buf) if buf is not None else None)
+
+
 class SequenceTracker:
     """okl_seq: CPU restatement of V3D_GPU::KLT_SequenceTracker."""
 
-    def __init__(self, config, centered=0):
+    def __init__(self, config, centered=0, sum_mode=0):
+        """sum_mode 0: window sums serially, as the shader writes them; 1 ("tree"): in the HIP tracker's fixed order
+        (okl_track_gain_pass_tree) -- tracking must then agree with the HIP path bit for bit."""
         self._L = lib()
         self.cfg = Config.from_any(config)
         self._h = C.c_void_p(self._L.okl_seq_create(C.byref(self.cfg), centered))
+        self._L.okl_seq_set_sum_mode(self._h, int(sum_mode))
 
     def allocate(self, W, H, L, fw, fh, plw=0, plh=0):
         if plw <= 0 or plh <= 0:
             plw, plh = 2 * fw, 2 * fh
         self._L.okl_seq_allocate(self._h, W, H, L, fw, fh, plw, plh)
         self.W, self.H, self.L, self.fw, self.fh, self.N = W, H, L, fw, fh, fw * fh
+
+    def clone(self, sum_mode=None):
+        """deep copy of the whole tracker state (optionally switched to another summation mode)"""
+        c = object.__new__(SequenceTracker)
+        c._L, c.cfg = self._L, self.cfg
+        self._L.okl_seq_clone.restype = C.c_void_p
+        c._h = C.c_void_p(self._L.okl_seq_clone(self._h))
+        c.W, c.H, c.L, c.fw, c.fh, c.N = self.W, self.H, self.L, self.fw, self.fh, self.N
+        if sum_mode is not None:
+            self._L.okl_seq_set_sum_mode(c._h, int(sum_mode))
+        return c
 
     def close(self):
         if self._h:

@@ -310,6 +310,31 @@ void okl_track_nogain(const uint16_t* pyr0, const uint16_t* pyr1, int W, int H, 
 
 /* ------------------------------------------------------------------ tracker with gain */
 
+/* Test diagnostic: when set, every gain pass records per slot the smallest RELATIVE distance of a tested quantity to the
+ * threshold it is tested against -- |det - 1e-5| / 1e-5, |SSD - thr| / thr, |dX|^2 vs thr^2 likewise, and the distance
+ * of the new position to the valid-region border relative to the border margin.  A slot whose status differs between
+ * two summation orders must sit within ~1 % of one of them. */
+static float* g_thr_margin = NULL;
+void okl_set_threshold_margin_buffer(float* perSlot) { g_thr_margin = perSlot; }
+
+static void note_margin(size_t k, float det, float SSD, float ssdThr, float sqrLen, float sqrConvThr, float X1x, float X1y,
+                        const float vr[4]) {
+    if (!g_thr_margin) return;
+    float m = fabsf(det - 0.00001f) / 0.00001f;
+    float t = fabsf(SSD - ssdThr) / ssdThr;
+    if (t < m) m = t;
+    t = fabsf(sqrLen - sqrConvThr) / sqrConvThr;
+    if (t < m) m = t;
+    if (vr[0] > 0.0f) { /* real valid region (the relaxed one is (-1,-1,2,2)) */
+        const float bx = vr[0], by = vr[1];
+        t = fminf(fabsf(X1x - vr[0]), fabsf(X1x - vr[2])) / bx;
+        if (t < m) m = t;
+        t = fminf(fabsf(X1y - vr[1]), fabsf(X1y - vr[3])) / by;
+        if (t < m) m = t;
+    }
+    if (!(m >= g_thr_margin[k])) g_thr_margin[k] = m; /* NaN counts as "at a threshold" */
+}
+
 static inline float slot_beta(const float* feat, int fw, int fh, int i, int j) {
     i = clampi(i, 0, fw - 1); /* NEAREST + clamp, features textures */
     j = clampi(j, 0, fh - 1);
@@ -402,6 +427,7 @@ void okl_track_gain_pass(const uint16_t* pyr0, const uint16_t* pyr1, int W, int 
             invalid = invalid || (SSD > ssdThr);                                                   /* :143 */
             invalid = invalid || (sqrLen > sqrConvThr);                                            /* :144 */
             invalid = invalid || (X1x < vr[0] || X1y < vr[1]) || (X1x > vr[2] || X1y > vr[3]);     /* :145 */
+            note_margin(k, det, SSD, ssdThr, sqrLen, sqrConvThr, X1x, X1y, vr);
             float nb = beta + dZ;
             if (invalid || !(X1x == X1x) || !(X1y == X1y) || !(nb == nb)) {
                 featOut[3 * k] = featOut[3 * k + 1] = featOut[3 * k + 2] = -1.0f;
@@ -409,6 +435,120 @@ void okl_track_gain_pass(const uint16_t* pyr0, const uint16_t* pyr1, int W, int 
                 featOut[3 * k] = X1x;
                 featOut[3 * k + 1] = X1y;
                 featOut[3 * k + 2] = nb; /* :147 */
+            }
+        }
+    }
+}
+
+/* ---- the same pass with the window sums taken in the GPU's fixed order ("tree" mode) -----------------------
+ * The shader accumulates its ten window sums serially over all (2hw+1)^2 pixels; the HIP tracker
+ * (coslam_amd/csrc/klt_track_rows.hip) gives every window ROW to one lane -- which sums its pixels serially, left to
+ * right, starting from 0.0f, exactly like the shader's inner loop -- and folds the rows of a feature in a fixed tree:
+ * ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), rows beyond the window contributing 0.0f (windows wider than 7:
+ * that tree over rows 0..7 plus the same tree over rows 8..15), and adds the neighbour term of the third right-hand
+ * side once, as nPix * (delta * bsum), instead of delta * bsum per pixel (klt_tracker_with_gain.cg:111).  Same
+ * mathematics, different binary32 rounding: in this mode the oracle and the HIP path must agree BIT FOR BIT, which turns
+ * every statistical status/position comparison of the tracking tests into an exact one.  hw must be 1..7. */
+static float fold8(const float* v) { return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); }
+static float fold_rows(const float* v, int lpf) { return lpf == 8 ? fold8(v) : fold8(v) + fold8(v + 8); }
+
+void okl_track_gain_pass_tree(const uint16_t* pyr0, const uint16_t* pyr1, int W, int H, int nLevels, int level, int fw,
+                              int fh, int hw, const float* feat0, const float* featIn, float* featOut, float sqrConvThr,
+                              float ssdThr, const float vr[4], float lambda, float delta) {
+    int64_t off[OKL_MAX_LEVELS];
+    okl_pyr_layout(W, H, nLevels, off);
+    const uint16_t* L0 = pyr0 + 4 * off[level];
+    const uint16_t* L1 = pyr1 + 4 * off[level];
+    const int Wl = W >> level, Hl = H >> level;
+    const float dsx = 1.0f / (float)Wl, dsy = 1.0f / (float)Hl;
+    const float whx = (float)W, why = (float)H;
+    const double rxy = (double)fh / (double)fw, ryx = (double)fw / (double)fh;
+    const int n1x[4] = {1, -1, (int)floor(0.5 + ryx), (int)floor(0.5 - ryx)};
+    const int n1y[4] = {(int)floor(0.5 + rxy), (int)floor(0.5 - rxy), 1, -1};
+    const int n2x[4] = {1, -1, 0, 0};
+    const int n2y[4] = {0, 0, 1, -1};
+    const int lpf = (hw <= 3) ? 8 : 16;
+    const int nPix = (2 * hw + 1) * (2 * hw + 1);
+
+    for (int j = 0; j < fh; ++j) {
+        for (int i = 0; i < fw; ++i) {
+            size_t k = (size_t)j * fw + i;
+            float X0x = feat0[3 * k], X0y = feat0[3 * k + 1];
+            float X1x = featIn[3 * k], X1y = featIn[3 * k + 1], beta = featIn[3 * k + 2];
+            if ((X1x < 0) || (X0x < 0)) {
+                featOut[3 * k] = featOut[3 * k + 1] = featOut[3 * k + 2] = -1.0f;
+                continue;
+            }
+            float bsum;
+            {
+                float t4[4];
+                for (int q = 0; q < 4; ++q) {
+                    float b1 = slot_beta(featIn, fw, fh, i + n1x[q], j + n1y[q]);
+                    float b2 = slot_beta(featIn, fw, fh, i + n2x[q], j + n2y[q]);
+                    if (b1 < 0) b1 = beta;
+                    if (b2 < 0) b2 = beta;
+                    t4[q] = (b1 + b2) - 2.0f * beta;
+                }
+                bsum = ((t4[0] + t4[1]) + t4[2]) + t4[3];
+            }
+            float ra[16] = {0}, rb[16] = {0}, rc[16] = {0}, rd[16] = {0}, re[16] = {0}, rf[16] = {0};
+            float rr0[16] = {0}, rr1[16] = {0}, rr2[16] = {0}, rss[16] = {0};
+            for (int y = -hw; y <= hw; ++y) {
+                const int row = y + hw;
+                float st_y = X0y + (float)y * dsy, st_w = X1y + (float)y * dsy;
+                float a = 0, b = 0, c = 0, d = 0, e_ = 0, f = 0, r0 = 0, r1 = 0, r2s = 0, ssd = 0;
+                for (int x = -hw; x <= hw; ++x) {
+                    float st_x = X0x + (float)x * dsx, st_z = X1x + (float)x * dsx;
+                    float I0[3], I1[3];
+                    okl_sample(L0, Wl, Hl, st_x, st_y, I0);
+                    okl_sample(L1, Wl, Hl, st_z, st_w, I1);
+                    float ex = beta * I0[0] - I1[0];
+                    float gx = (beta * I0[1] + I1[1]) * whx / 2.0f;
+                    float gy = (beta * I0[2] + I1[2]) * why / 2.0f;
+                    float m0 = sqrtf(I0[1] * I0[1] + I0[2] * I0[2]);
+                    float m1 = sqrtf(I1[1] * I1[1] + I1[2] * I1[2]);
+                    a += gx * gx;
+                    b += gx * gy;
+                    c += gx * (-I0[0]);
+                    d += gy * gy;
+                    e_ += gy * (-I0[0]);
+                    f += (I0[0] * I0[0] + lambda * m0 * m0) + delta * 8.0f;
+                    r0 += ex * gx;
+                    r1 += ex * gy;
+                    r2s += -ex * I0[0] + lambda * m0 * (m1 - beta * m0);
+                    ssd += ex * ex;
+                }
+                ra[row] = a, rb[row] = b, rc[row] = c, rd[row] = d, re[row] = e_, rf[row] = f;
+                rr0[row] = r0, rr1[row] = r1, rr2[row] = r2s, rss[row] = ssd;
+            }
+            const float a = fold_rows(ra, lpf), b = fold_rows(rb, lpf), c = fold_rows(rc, lpf), d = fold_rows(rd, lpf);
+            const float e_ = fold_rows(re, lpf), f = fold_rows(rf, lpf), r0 = fold_rows(rr0, lpf), r1 = fold_rows(rr1, lpf);
+            const float r2s = fold_rows(rr2, lpf), SSD = fold_rows(rss, lpf);
+            const float r2 = r2s + (float)nPix * (delta * bsum);
+            float det = a * d * f + 2.0f * b * c * e_;
+            det -= (a * e_ * e_ + b * b * f) + c * c * d;
+            float rcp = 1.0f / det;
+            float A_ = d * f - e_ * e_, B_ = c * e_ - b * f, C_ = b * e_ - c * d;
+            float D_ = a * f - c * c, E_ = b * c - a * e_, F_ = a * d - b * b;
+            float dX = ((A_ * r0 + B_ * r1) + C_ * r2) * rcp;
+            float dY = ((B_ * r0 + D_ * r1) + E_ * r2) * rcp;
+            float dZ = ((C_ * r0 + E_ * r1) + F_ * r2) * rcp;
+            X1x += dX;
+            X1y += dY;
+            float ux = dX * whx, uy = dY * why;
+            float sqrLen = ux * ux + uy * uy;
+            int invalid = (det < 0.00001f);
+            invalid = invalid || (SSD > ssdThr);
+            invalid = invalid || (sqrLen > sqrConvThr);
+            invalid = invalid || (X1x < vr[0] || X1y < vr[1]) || (X1x > vr[2] || X1y > vr[3]);
+            note_margin(k, det, SSD, ssdThr, sqrLen, sqrConvThr, X1x, X1y, vr);
+            float nb = beta + dZ;
+            if (invalid || !(X1x == X1x) || !(X1y == X1y) || !(nb == nb)) {
+                featOut[3 * k] = featOut[3 * k + 1] = featOut[3 * k + 2] = -1.0f;
+            } else {
+                featOut[3 * k] = X1x;
+                featOut[3 * k + 1] = X1y;
+                featOut[3 * k + 2] = nb;
             }
         }
     }
@@ -587,12 +727,34 @@ struct okl_seq {
     int b0, b1, b2; /* _featuresBuffer0/1/2 */
     float* corner;
     cand_t* corners; /* host _corners, plw*plh */
+    int sum_mode;    /* 0: the shader's serial window sums; 1: the HIP tracker's fixed tree (okl_track_gain_pass_tree) */
 };
 
 okl_seq* okl_seq_create(const okl_config* cfg, int centered) {
     okl_seq* s = (okl_seq*)calloc(1, sizeof(okl_seq));
     s->cfg = *cfg;
     s->centered = centered;
+    return s;
+}
+
+/* deep copy (test support: two summation orders from IDENTICAL state, frame after frame) */
+okl_seq* okl_seq_clone(const okl_seq* src) {
+    okl_seq* s = (okl_seq*)malloc(sizeof(okl_seq));
+    *s = *src;
+    size_t tex = okl_pyr_layout(src->W, src->H, src->L, NULL);
+    for (int i = 0; i < 2; ++i) {
+        s->pyr[i] = (uint16_t*)malloc(tex * 4 * sizeof(uint16_t));
+        memcpy(s->pyr[i], src->pyr[i], tex * 4 * sizeof(uint16_t));
+    }
+    for (int i = 0; i < 3; ++i) {
+        s->fb[i] = (float*)malloc(sizeof(float) * 3 * src->N);
+        memcpy(s->fb[i], src->fb[i], sizeof(float) * 3 * src->N);
+    }
+    s->corner = (float*)malloc((size_t)src->W * src->H * sizeof(float));
+    memcpy(s->corner, src->corner, (size_t)src->W * src->H * sizeof(float));
+    size_t nc = (size_t)src->plw * src->plh + src->N;
+    s->corners = (cand_t*)malloc(nc * sizeof(cand_t));
+    memcpy(s->corners, src->corners, nc * sizeof(cand_t));
     return s;
 }
 
@@ -639,6 +801,7 @@ void okl_seq_set_border_margin(okl_seq* s, float m) { /* v3d_gpuklt.h:219-226 */
     s->margin = m;
     s->detMargin = m;
 }
+void okl_seq_set_sum_mode(okl_seq* s, int mode) { s->sum_mode = mode; }
 void okl_seq_set_convergence_threshold(okl_seq* s, float t) { s->convThr = t; }
 void okl_seq_set_ssd_threshold(okl_seq* s, float t) { s->ssdThr = t; }
 const uint16_t* okl_seq_cur_pyramid(const okl_seq* s) { return s->pyr[s->p1]; }
@@ -701,8 +864,12 @@ static void run_tracker(okl_seq* s) {
                 vr[2] = 1.0f - s->margin / (float)s->W;
                 vr[3] = 1.0f - s->margin / (float)s->H;
             }
-            okl_track_gain_pass(P0, P1, s->W, s->H, s->L, level, s->fw, s->fh, hw, s->fb[s->b2], s->fb[s->b0],
-                                s->fb[s->b1], sqrConv, ssd, vr, 1.0f, dcur);
+            if (s->sum_mode == 1 && hw >= 1 && hw <= 7)
+                okl_track_gain_pass_tree(P0, P1, s->W, s->H, s->L, level, s->fw, s->fh, hw, s->fb[s->b2], s->fb[s->b0],
+                                         s->fb[s->b1], sqrConv, ssd, vr, 1.0f, dcur);
+            else
+                okl_track_gain_pass(P0, P1, s->W, s->H, s->L, level, s->fw, s->fh, hw, s->fb[s->b2], s->fb[s->b0],
+                                    s->fb[s->b1], sqrConv, ssd, vr, 1.0f, dcur);
             int t = s->b0;
             s->b0 = s->b1;
             s->b1 = t; /* :285 */

@@ -79,6 +79,16 @@ void okl_track_gain_pass(const uint16_t* pyr0, const uint16_t* pyr1, int W, int 
                          int fh, int halfWidth, const float* feat0, const float* featIn, float* featOut,
                          float sqrConvThr, float ssdThr, const float validRegion[4], float lambda, float delta);
 
+/* the same pass with the window sums in the HIP tracker's fixed order (rows serially, rows folded in a fixed tree, the
+ * neighbour term added once): bit-for-bit what coslam_amd/csrc/klt_track_rows.hip computes.  hw in 1..7. */
+void okl_track_gain_pass_tree(const uint16_t* pyr0, const uint16_t* pyr1, int W, int H, int nLevels, int level, int fw,
+                              int fh, int halfWidth, const float* feat0, const float* featIn, float* featOut,
+                              float sqrConvThr, float ssdThr, const float validRegion[4], float lambda, float delta);
+
+/* test diagnostic: per-slot minimum relative distance to a validity threshold over the gain passes that follow
+ * (caller-owned N floats, preset to a large value; NULL turns it off) */
+void okl_set_threshold_margin_buffer(float* perSlot);
+
 /* 7x7 structure tensor -> min eigenvalue: klt_detector_pass1.cg, klt_detector_pass2.cg,
  * scheduled by v3d_gpuklt.cpp:457-473 */
 void okl_cornerness(const uint16_t* lvl0, int W, int H, float minCornerness, float margin, float* out);
@@ -94,6 +104,7 @@ int okl_extract(const float* corner, int W, int H, int maxOut, float* list3);
 typedef struct okl_seq okl_seq;
 okl_seq* okl_seq_create(const okl_config* cfg, int centered);
 void okl_seq_destroy(okl_seq* s);
+okl_seq* okl_seq_clone(const okl_seq* s); /* deep copy of the whole tracker state */
 void okl_seq_allocate(okl_seq* s, int W, int H, int nLevels, int fw, int fh, int plw, int plh);
 void okl_seq_detect(okl_seq* s, const uint8_t* img, int* nDetected, okl_tracked_feature* dest);
 void okl_seq_detect_present(okl_seq* s, const uint8_t* img, int* nDetected, okl_tracked_feature* dest, int nPresent,
@@ -105,6 +116,8 @@ void okl_seq_advance(okl_seq* s);
 void okl_seq_set_border_margin(okl_seq* s, float m);
 void okl_seq_set_convergence_threshold(okl_seq* s, float t);
 void okl_seq_set_ssd_threshold(okl_seq* s, float t);
+/* 0 (default): window sums serially as the shader writes them; 1: okl_track_gain_pass_tree for the gain tracker */
+void okl_seq_set_sum_mode(okl_seq* s, int mode);
 /* test access: pyramid of the frame most recently built (pyrCreator1) and the cornerness map */
 const uint16_t* okl_seq_cur_pyramid(const okl_seq* s);
 const float* okl_seq_cornerness(const okl_seq* s);

@@ -4,7 +4,8 @@
 pose_golden.npz  -- inputs and outputs of the REFERENCE's own intraCamEstimate (src/slam/SL_IntraCamPose.cpp compiled in
                     place into oracle/_ref/libintracam_ref.so by oracle/Makefile).  Needs /root/reference; run in the build
                     container only.  These vectors pin oracle/pose_oracle.c and the HIP pose kernel to the reference.
-klt_golden.npz   -- small KLT cases (pyramid texels, detection list, two tracked frames) produced by oracle/klt_oracle.c.
+klt_golden.npz   -- small KLT cases (pyramid texels, detection list, two tracked frames) produced by oracle/klt_oracle.c
+                    (the with-gain case in the oracle's "tree" summation mode, which the HIP tracker matches bit for bit).
                     The reference's KLT cannot run here (Cg/OpenGL), so these pin our restatement against regressions;
                     they are NOT reference outputs (parity unpinned, see oracle/klt_oracle.h).
 ba_golden.npz    -- cfg1-shaped BA problem solved by oracle/ba_oracle.c (our definition; parity unpinned).
@@ -56,7 +57,8 @@ def klt_cases():
     for gain in (0, 1):
         cfg = KLT_SequenceTrackerConfig(nIterations=6, nLevels=L, levelSkip=1, windowWidth=7, trackWithGain=gain,
                                         minCornerness=800.0, convergenceThreshold=1.0, SSD_Threshold=20000.0, minDistance=5)
-        o = oracle.SequenceTracker(cfg)
+        # gain tracker: window sums in the HIP tracker's fixed order ("tree" mode) -> the GPU test is bit-exact
+        o = oracle.SequenceTracker(cfg, sum_mode=1 if gain else 0)
         o.allocate(W, H, L, fw, fh)
         n0, d0 = o.detect(imgs[0])
         out[f"pyr{gain}"] = o.read_pyramid()
@@ -83,7 +85,11 @@ def ba_case():
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
-    np.savez_compressed(os.path.join(HERE, "klt_golden.npz"), **klt_cases())
-    np.savez_compressed(os.path.join(HERE, "ba_golden.npz"), **ba_case())
+    which = sys.argv[1:] or ["pose", "klt", "ba"]
+    if "pose" in which:
+        np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
+    if "klt" in which:
+        np.savez_compressed(os.path.join(HERE, "klt_golden.npz"), **klt_cases())
+    if "ba" in which:
+        np.savez_compressed(os.path.join(HERE, "ba_golden.npz"), **ba_case())
     print("golden fixtures written")
