@@ -1,20 +1,29 @@
 #!/usr/bin/env python
 """bench.py -- frames/sec of the track + pose + local-BA loop on MI355X (BASELINE.json metric).
 
-One "step" = one camera frame through the hot path on each rank:
-    redetect (pyramid -> KLT track -> corner detect -> top-K -> slot fill) -> advanceFrame
-    -> intraCamEstimate on 192 3D-2D correspondences
-    -> every BA_EVERY-th frame: local robust BA (5 key frames x 500 points, maxIter 2 / inner 10, the call the
-       reference queues at src/app/SL_CoSLAM.cpp:1769)
-    -> (N > 1) RCCL all-gather of {features, pose} at the inter-camera merge step.
-Inputs (images, correspondences, BA problem) are resident in HBM before the timed region starts.
-One camera per GPU (weak scaling).  Prints ONE JSON line on rank 0.
+Workload (BASELINE.json `metric`): 8 synchronised cameras 640x480, 2000 KLT feature slots each.  One "step" = ONE FRAME of
+the whole rig, i.e. every camera's image consumed and poses updated:
+    all cameras   redetect (pyramid -> KLT track with gain -> corner detect -> top-K -> slot fill) + advanceFrame
+                  [CoSLAM::featureTracking, reference src/app/SL_CoSLAM.cpp:299-305 -> GPUKLT::next]
+    all cameras   hand-back on the device (undistort, track bookkeeping, one static mapped track per 40x40 block, Ms/ms
+                  packing) [GPUKLT::addToFeaturePoints, SingleSLAM::chooseStaticFeatPts / poseUpdate3D] feeding
+                  intraCamEstimate of every camera, started from the previous frame's result [SL_CoSLAM.cpp:366-417]
+    key frames    (every KEY_EVERY-th frame)
+                  joint local BA: last 5 key frames of all 8 cameras = 40 cameras, the 16 oldest fixed, maxIter 2 / inner
+                  10 [requestForBA(5, 2, 2, 30) -> RobustBundleRTS, SL_CoSLAM.cpp:1345,1731-1784], on its own stream like
+                  the reference's BA worker thread;
+                  inter-camera pose solve: the 8 current cameras free, 8 x 192 static points fixed, 60 dynamic points free,
+                  sigma 6, 3 x 40 [InterCamPoseEstimator, SL_InterCamPoseEstimator.cpp:18-95].
+    N > 1         the cameras are sharded over the ranks (8 / N each); per frame one all-gather of {features, pose} of
+                  every camera; the joint BA is sliced by points over the ranks with one all-reduce of S || rhs per LM step.
+Inputs (images, map points, BA problems) are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -22,13 +31,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+N_CAMS = 8
 W, H, LEVELS, FW, FH = 640, 480, 4, 50, 40
 N_FEAT = FW * FH
 N_FRAMES = 24
-N_POSE_PTS = 192
-BA_EVERY = 5
-BA_KF, BA_PTS = 5, 500
+PTS_STRIDE = 192          # 12 x 16 blocks (reference src/app/SL_SingleSLAM.h:36-37)
+N_COL_BLK, N_ROW_BLK = 16, 12
+KEY_EVERY = 5
 HBM_PEAK_GBS = 8000.0
+SEED = 0xC051A + 2
 
 
 def klt_config():
@@ -46,55 +57,106 @@ def frame_order(n):
     return fwd + fwd[-2:0:-1]
 
 
-def build_inputs(cam, n_cams, seed):
-    from coslam_amd.synth import Scene, make_ba_problem
+def build_scene():
+    from coslam_amd.synth import Scene
 
-    sc = Scene(n_cams, W, H, 7000, seed=seed, sigma=1.0)
-    frames = np.stack([sc.render(cam, f) for f in range(N_FRAMES)])
-    rng = np.random.default_rng(seed + 17 * cam)
-    Ms = np.zeros((N_FRAMES, N_POSE_PTS, 3))
-    ms = np.zeros((N_FRAMES, N_POSE_PTS, 2))
-    R0 = np.zeros((N_FRAMES, 9))
-    t0 = np.zeros((N_FRAMES, 3))
-    for f in range(N_FRAMES):
-        uv, vis = sc.project(cam, f)
-        idx = np.nonzero(vis)[0][:N_POSE_PTS]
-        Ms[f] = sc.points[idx]
-        ms[f] = uv[idx] + 0.5 * rng.standard_normal((N_POSE_PTS, 2))
-        ms[f, :8] += 25.0 * rng.standard_normal((8, 2))  # gross outliers for the Tukey re-weighting
-        Rp, tp = sc.pose(cam, max(f - 1, 0))              # initial guess = previous frame's pose
-        R0[f], t0[f] = Rp.ravel(), tp
-    ba = make_ba_problem(n_cams=BA_KF, n_pts=BA_PTS, seed=seed + 99 + cam)
-    return sc, frames, Ms, ms, R0, t0, ba
+    return Scene(N_CAMS, W, H, 7000, seed=SEED, sigma=1.0)
 
 
-def cpu_baseline(frames, Ms, ms, R0, t0, K, ba, budget_s=20.0):
-    """The oracle (our C restatement of the reference's path: 'port') on ONE host core."""
+def build_ba_problems(sc):
+    from coslam_amd.synth import make_intercam_problem, make_joint_ba_problem
+
+    return make_joint_ba_problem(sc, seed=SEED + 7), make_intercam_problem(sc, seed=SEED + 11)
+
+
+def csr(pr):
+    P = len(pr["pts0"])
+    obs_pt = np.asarray(pr["obs_pt"])
+    order = np.argsort(obs_pt, kind="stable")
+    ptr = np.zeros(P + 1, dtype=np.int32)
+    np.add.at(ptr, obs_pt + 1, 1)
+    return np.cumsum(ptr).astype(np.int32), pr["obs_cam"][order], pr["obs_xy"][order]
+
+
+def associate(sc, cam, frame, dest):
+    """slot -> scene point: the map point a freshly detected feature belongs to (nearest projected point within 1 px).
+    Stands in for CoSLAM's map initialisation (out of scope); computed once, before the clock starts."""
+    from scipy.spatial import cKDTree
+
+    uv, vis = sc.project(cam, frame)
+    idx = np.nonzero(vis)[0]
+    s2m = np.full(len(dest), -1, dtype=np.int32)
+    live = np.nonzero(dest["status"] >= 0)[0]
+    if len(live) == 0 or len(idx) == 0:
+        return s2m
+    p = dest["pos"][live].astype(np.float64) * [W, H]
+    d, j = cKDTree(uv[idx]).query(p, distance_upper_bound=1.0)
+    ok = np.isfinite(d)
+    s2m[live[ok]] = idx[j[ok]]
+    return s2m
+
+
+def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s):
+    """The oracle (C restatement of the reference's path: kind "port") on `n_threads` host cores: the cameras of a frame
+    in parallel (the ctypes calls release the GIL), the key-frame solves on the calling thread."""
     import oracle
 
-    cfg = klt_config()
-    o = oracle.SequenceTracker(cfg)
-    o.allocate(W, H, LEVELS, FW, FH)
-    P = len(ba["pts0"])
-    ptr, cam, xy, _ = oracle.csr_by_point(P, ba["obs_pt"], ba["obs_cam"], ba["obs_xy"])
     order = frame_order(N_FRAMES)
-    o.detect(frames[order[0]])
-    o.advanceFrame()
+    cfg = klt_config()
+    trk, s2m, tl, xy, Rc, tc = [], [], [], [], [], []
+    for c in range(N_CAMS):
+        o = oracle.SequenceTracker(cfg)
+        o.allocate(W, H, LEVELS, FW, FH)
+        _, d = o.detect(frames[c][order[0]])
+        o.advanceFrame()
+        trk.append(o)
+        s2m.append(associate(sc, c, order[0], d))
+        tl.append(np.zeros(N_FEAT, dtype=np.int32))
+        xy.append(np.zeros(2 * N_FEAT))
+        oracle.handback(d, W, H, sc.K, np.zeros(7), sc.points, s2m[c], tl[c], xy[c])
+        s2m[c][:] = associate(sc, c, order[0], d)   # (the first hand-back resets new tracks: restore the map)
+        R, t = sc.pose(c, order[0])
+        Rc.append(R.copy())
+        tc.append(t.copy())
+    jptr, jcam, jxy = csr(joint)
+    iptr, icam, ixy = csr(ic)
+    kud = np.zeros(7)
+
+    def cam_step(c, f):
+        _, d = trk[c].redetect(frames[c][f])
+        trk[c].advanceFrame()
+        hb = oracle.handback(d, W, H, sc.K, kud, sc.points, s2m[c], tl[c], xy[c])
+        if hb["npts"] >= 6:
+            ok, R, t, _ = oracle.intracam_estimate(sc.K, Rc[c], tc[c], hb["npts"], None, hb["Ms"], hb["ms"], 10.0)
+            if ok:
+                Rc[c], tc[c] = R, t
+
+    def run_cams(cams, f):
+        for c in cams:
+            cam_step(c, f)
+
     t_start = time.perf_counter()
     n = 0
     while True:
         f = order[(n + 1) % len(order)]
-        o.redetect(frames[f])
-        o.advanceFrame()
-        oracle.intracam_estimate(K, R0[f], t0[f], N_POSE_PTS, None, Ms[f], ms[f], 10.0)
-        if (n + 1) % BA_EVERY == 0:
-            oracle.ba_robust(ba["Ks"], ba["Rs0"], ba["ts0"], ba["pts0"], ptr, cam, xy, 2, 2, 6.0, 2, 10)
+        if n_threads <= 1:
+            run_cams(range(N_CAMS), f)
+        else:
+            parts = [list(range(N_CAMS))[q::n_threads] for q in range(n_threads)]
+            th = [threading.Thread(target=run_cams, args=(p, f)) for p in parts if p]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+        if (n + 1) % KEY_EVERY == 0:
+            oracle.ba_robust(joint["Ks"], joint["Rs0"], joint["ts0"], joint["pts0"], jptr, jcam, jxy,
+                             joint["n_cams_con"], joint["n_pts_con"], 6.0, 2, 10)
+            oracle.ba_robust(ic["Ks"], ic["Rs0"], ic["ts0"], ic["pts0"], iptr, icam, ixy, 0, ic["n_static"], 6.0, 3, 40)
         n += 1
         if time.perf_counter() - t_start > budget_s or n >= 200:
             break
     dt = time.perf_counter() - t_start
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n} frames of the same workload (oracle/: C restatement, gcc -O2, 1 thread), {dt:.1f} s"}
+    return n / dt, n, dt
 
 
 def main():
@@ -103,12 +165,10 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graphs", action="store_true", help="replay the KLT frame schedule from a hipGraph (default: the five launches are issued eagerly, which measures ~10 us/frame faster)")
-    ap.add_argument("--no-graphs", action="store_true", help="(default behaviour; kept for older command lines)")
-    ap.add_argument("--sync-ba", action="store_true", help="run the local BA on the tracking stream instead of its own")
-    ap.add_argument("--no-pose", action="store_true", help="diagnostic: skip the pose leg (result not a valid bench line)")
-    ap.add_argument("--serial", action="store_true", help="diagnostic: tracker, pose and BA on ONE stream (no overlap)")
-    ap.add_argument("--ba-every", type=int, default=BA_EVERY, help="diagnostic: 0 disables the BA leg (result not a valid bench line)")
+    ap.add_argument("--serial", action="store_true", help="diagnostic: every leg on ONE stream (no overlap)")
+    ap.add_argument("--key-every", type=int, default=KEY_EVERY, help="diagnostic: 0 disables the key-frame solves (not a valid bench line)")
+    ap.add_argument("--no-pose", action="store_true", help="diagnostic: skip hand-back + pose (not a valid bench line)")
+    ap.add_argument("--native-comm", type=int, default=1, help="N > 1: collectives issued by libcoslam_hip (RCCL behind the C-ABI) instead of torch.distributed")
     args = ap.parse_args()
 
     import torch
@@ -116,7 +176,8 @@ def main():
 
     import coslam_amd
     from coslam_amd.ba import BAWorkspace
-    from coslam_amd.pose import IntraCamPoseOption, intraCamEstimate_batch_dev
+    from coslam_amd.handback import handback_dev
+    from coslam_amd.pose import intraCamEstimate_batch_dev
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,6 +191,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
     n_gpus = max(world, 1)
+    if N_CAMS % n_gpus != 0:
+        raise SystemExit(f"bench.py: {N_CAMS} cameras do not shard over {n_gpus} GPUs (use 1, 2, 4 or 8)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -140,175 +203,166 @@ def main():
         else:
             dist.init_process_group(dist_backend, rank=rank, world_size=world)
 
-    sc, frames, Ms, ms, R0, t0, ba = build_inputs(rank, n_gpus, seed=0xC051A + 2)
+    cams_here = N_CAMS // n_gpus
+    my_cams = list(range(rank * cams_here, (rank + 1) * cams_here))
+    sc = build_scene()
     order = frame_order(N_FRAMES)
+    frames = {c: np.stack([sc.render(c, f) for f in range(N_FRAMES)]) for c in (range(N_CAMS) if (rank == 0 and n_gpus == 1) else my_cams)}
+    joint, ic = build_ba_problems(sc)
 
     # ---- everything resident in HBM before the clock starts -------------------------------------
-    d_frames = torch.from_numpy(frames).to(dev)
-    d_K = torch.from_numpy(sc.K.ravel().copy()).to(dev)
-    d_Ms, d_ms = torch.from_numpy(Ms).to(dev), torch.from_numpy(ms).to(dev)
-    d_R0, d_t0 = torch.from_numpy(R0).to(dev), torch.from_numpy(t0).to(dev)
-    d_npts = torch.full((1,), N_POSE_PTS, dtype=torch.int32, device=dev)
-    d_Ropt = torch.zeros(9, dtype=torch.float64, device=dev)
-    d_topt = torch.zeros(3, dtype=torch.float64, device=dev)
-    opt0 = IntraCamPoseOption()
-    d_opt0 = torch.from_numpy(np.frombuffer(bytes(opt0), dtype=np.uint8).copy()).to(dev)
-    d_opt = torch.zeros_like(d_opt0)
-    d_ok = torch.zeros(1, dtype=torch.int32, device=dev)
-    d_dest = torch.zeros(N_FEAT * 5, dtype=torch.int32, device=dev)
-    d_counts = torch.zeros(4, dtype=torch.int32, device=dev)
+    d_frames = [torch.from_numpy(frames[c]).to(dev) for c in my_cams]
+    nc = cams_here
+    d_K = torch.from_numpy(np.tile(sc.K.ravel(), nc)).to(dev)
+    d_K1 = torch.from_numpy(sc.K.ravel().copy()).to(dev)
+    d_kud = torch.zeros(7, dtype=torch.float64, device=dev)
+    d_map = torch.from_numpy(sc.points.copy()).to(dev)
+    d_slot2map = torch.full((nc, N_FEAT), -1, dtype=torch.int32, device=dev)
+    d_tracklen = torch.zeros((nc, N_FEAT), dtype=torch.int32, device=dev)
+    d_xy = torch.zeros((nc, 2 * N_FEAT), dtype=torch.float64, device=dev)
+    d_state = torch.zeros((nc, N_FEAT), dtype=torch.int32, device=dev)
+    d_Ms = torch.zeros((nc, PTS_STRIDE, 3), dtype=torch.float64, device=dev)
+    d_ms = torch.zeros((nc, PTS_STRIDE, 2), dtype=torch.float64, device=dev)
+    d_sel = torch.zeros((nc, PTS_STRIDE), dtype=torch.int32, device=dev)
+    d_npts = torch.zeros(nc, dtype=torch.int32, device=dev)
+    d_opt = torch.zeros((nc, 96), dtype=torch.uint8, device=dev)
+    d_ok = torch.zeros(nc, dtype=torch.int32, device=dev)
+    R0 = np.stack([sc.pose(c, order[0])[0].ravel() for c in my_cams])
+    t0 = np.stack([sc.pose(c, order[0])[1] for c in my_cams])
+    d_R = [torch.from_numpy(R0.copy()).to(dev), torch.from_numpy(R0.copy()).to(dev)]   # pose ping-pong: frame f reads [f&1^1]
+    d_t = [torch.from_numpy(t0.copy()).to(dev), torch.from_numpy(t0.copy()).to(dev)]
+    d_dests = [[torch.zeros(N_FEAT * 5, dtype=torch.int32, device=dev) for _ in range(nc)] for _ in range(2)]
+    d_counts = [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(nc)]
 
-    # Three HIP streams, mirroring the reference's thread structure and data dependences:
-    #   klt_stream   the per-frame tracker (GPUKLT::next) -- frame f+1 only needs the tracker state of frame f;
-    #   pose_stream  intraCamEstimate of frame f: waits (event) for the tracker of frame f, runs next to the tracker
-    #                of frame f+1; the all-gather of features||pose at the merge step (N > 1) follows it on this stream;
-    #   ba_stream    local BA: the reference runs it on a worker thread next to tracking
-    #                (src/app/SL_CoSLAM.cpp:1702-1730, one request in flight at a time).
-    # --serial puts everything back on one stream (diagnostic).
-    # The persistent tracker runs its 2000 waves in lock-step (neighbour hand-offs every pass), so a foreign wave on one
-    # of its SIMDs slows the whole mesh: measured 89 -> 100-120 us per launch when pose / BA kernels share the chip.
-    # The chip is therefore partitioned with CU-masked streams (hipExtStreamCreateWithCUMask): the tracker stream gets
-    # all but SIDE_CUS compute units, the pose and BA streams the rest.  BENCH_SIDE_CUS=0 turns the partition off.
-    n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    side_cus = int(os.environ.get("BENCH_SIDE_CUS", "64"))
-    if args.serial or side_cus >= n_cus:
-        side_cus = 0
-    masked = {"ok": side_cus > 0}
+    # Streams and threads mirror the reference's threads and data dependences:
+    #   klt     the tracker of all cameras (one camera group): frame f+1 only needs the tracker state of frame f;
+    #   pose    hand-back + intraCamEstimate of frame f (event-ordered behind the tracker of frame f), then the all-gather
+    #           of features||pose at the merge step (N > 1);
+    #   key-frame solves (inter-camera pose, joint local BA): each on its workspace's own worker thread + stream
+    #           (cs_ba_solve_async), started behind that frame's pose -- the reference's BA worker thread
+    #           (src/app/SL_CoSLAM.cpp:1702-1784); the thread enqueues LM steps in chunks and stops at convergence.
+    klt_s = torch.cuda.Stream(device=dev)
+    pose_s = klt_s if args.serial else torch.cuda.Stream(device=dev)
+    ba_s = klt_s if args.serial else torch.cuda.Stream(device=dev)   # N > 1: the sliced joint BA and its collectives
 
-    # BENCH_SIDE_MODE=range (default): the last `side_cus` CUs (whole XCDs) go to the side streams -- measured 5330
-    # frames/s; =interleaved: every (n_cus/side_cus)-th CU (the tracker alone stays at 91 us, the loop drops to 4810)
-    side_mode = os.environ.get("BENCH_SIDE_MODE", "range")
+    trks = []
+    for _ in my_cams:
+        t = coslam_amd.KLT_SequenceTracker(klt_config(), device=local_rank)
+        t.allocate(W, H, LEVELS, FW, FH)
+        trks.append(t)
+    grp = coslam_amd.KLT_TrackerGroup(trks)
+    grp.set_stream(klt_s.cuda_stream)
+    prefetch = os.environ.get("BENCH_PREFETCH", "1") != "0"
 
-    def make_stream(side):
-        if masked["ok"]:
+    jptr, jcam, jxy = csr(joint)
+    ba_ws = BAWorkspace(local_rank)
+    ba_ws.upload(joint["Ks"], joint["Rs0"], joint["ts0"], joint["pts0"], jptr, jcam, jxy)
+    d_jR = torch.from_numpy(joint["Rs0"].reshape(-1).copy()).to(dev)
+    d_jT = torch.from_numpy(joint["ts0"].reshape(-1).copy()).to(dev)
+    d_jM = torch.from_numpy(joint["pts0"].reshape(-1).copy()).to(dev)
+    iptr, icam, ixy = csr(ic)
+    ic_ws = BAWorkspace(local_rank)
+    ic_ws.upload(ic["Ks"], ic["Rs0"], ic["ts0"], ic["pts0"], iptr, icam, ixy)
+    d_iR = torch.from_numpy(ic["Rs0"].reshape(-1).copy()).to(dev)
+    d_iT = torch.from_numpy(ic["ts0"].reshape(-1).copy()).to(dev)
+    d_iM = torch.from_numpy(ic["pts0"].reshape(-1).copy()).to(dev)
+
+    # merge step at N > 1: one all-gather of every camera's {features, R, t}; the joint BA sliced by points
+    xchg = None
+    native = None
+    if world > 1:
+        from coslam_amd import multicam
+
+        if args.native_comm and dist_backend == "nccl":
             try:
-                L = coslam_amd.lib()
-                if side_mode == "interleaved":
-                    L.cs_stream_create_cu_interleaved.restype = C.c_void_p
-                    h = L.cs_stream_create_cu_interleaved(local_rank, n_cus // side_cus, 1, 0 if side else 1)
-                else:
-                    L.cs_stream_create_cu_range.restype = C.c_void_p
-                    if side == "pose":
-                        h = L.cs_stream_create_cu_range(local_rank, pose_first, pose_cus)
-                    elif side:
-                        h = L.cs_stream_create_cu_range(local_rank, n_cus - side_cus, side_cus - pose_from_side)
-                    else:
-                        h = L.cs_stream_create_cu_range(local_rank, 0, n_cus - side_cus - pose_from_klt)
-                if h:
-                    return torch.cuda.ExternalStream(h, device=dev)
-                print("bench: CU-masked stream unavailable (" + L.cs_last_error().decode() + "); plain streams",
-                      file=sys.stderr)
-            except Exception as ex:  # noqa: BLE001 -- never let the partition break the benchmark
-                print(f"bench: CU-masked stream unavailable ({ex}); plain streams", file=sys.stderr)
-            masked["ok"] = False
-        return torch.cuda.Stream(device=dev)
+                native = multicam.NativeComm(world, rank, local_rank)
+            except Exception as ex:  # noqa: BLE001 -- fall back to torch.distributed collectives, never break the bench
+                print(f"bench: native RCCL communicator unavailable ({ex}); using torch.distributed", file=sys.stderr)
+                native = None
+        xchg = multicam.CameraExchange(N_FEAT * nc, dev, native=native)
 
-    pose_part = os.environ.get("BENCH_POSE_PART", "klt")
-    pose_cus = int(os.environ.get("BENCH_POSE_CUS", "1"))
-    pose_from_klt = pose_cus if pose_part == "own" else 0        # own: pose_cus CUs carved off the tracker's range
-    pose_from_side = pose_cus if pose_part == "ownside" else 0   # ownside: carved off the BA's range
-    pose_first = (n_cus - side_cus - pose_cus) if pose_part == "own" else (n_cus - pose_cus)
-    klt_part = os.environ.get("BENCH_KLT_PART", "own")   # own: the complement of the side range; all: every CU
-    klt_torch_stream = torch.cuda.Stream(device=dev) if klt_part == "all" else make_stream(False)
-    # pose: one wave, 75 us.  It shares the tracker's partition: the tracker raises its wave priority (s_setprio), so
-    # the pose wave only gets the issue slots the mesh leaves free and costs the loop nothing (6266 vs 6284 frames/s
-    # without the BA leg).  BENCH_POSE_PART=klt|side|all|own|ownside (own*: BENCH_POSE_CUS CUs carved off the tracker's /
-    # the BA's range -- measured slower: an uneven CU count per shader engine unbalances the tracker's mesh, and the
-    # BA falls off a cliff below 64 CUs, tools/ba_partition.py)
-    if args.serial:
-        pose_torch_stream = klt_torch_stream
-    elif pose_part == "all":
-        pose_torch_stream = torch.cuda.Stream(device=dev)
-    elif pose_part in ("own", "ownside") and masked["ok"]:
-        pose_torch_stream = make_stream("pose")
-    else:
-        pose_torch_stream = make_stream(pose_part == "side")
-    ba_torch_stream = klt_torch_stream if (args.sync_ba or args.serial) else make_stream(True)
-    if not masked["ok"]:
-        side_cus = 0
-    stream = klt_torch_stream.cuda_stream
-    pose_stream = pose_torch_stream.cuda_stream
-    ba_stream = ba_torch_stream.cuda_stream
-    # dest[] is double-buffered: the pose / exchange stage of frame f reads it while the tracker of frame f+1 writes
-    d_dests = [d_dest, torch.zeros_like(d_dest)]
     klt_done = [torch.cuda.Event(), torch.cuda.Event()]
     dest_free = [torch.cuda.Event(), torch.cuda.Event()]
-    trk = coslam_amd.KLT_SequenceTracker(klt_config(), device=local_rank)
-    trk.allocate(W, H, LEVELS, FW, FH)
-    trk.set_stream(stream)
-    if side_cus > 0:
-        trk.set_cu_count(n_cus if klt_part == "all" else n_cus - side_cus - pose_from_klt)
-    if args.graphs and not args.no_graphs:
-        trk.enable_graphs(True)
-    # Frame-front prefetch (cs_klt_prefetch_dev): this frame's detector tail -- two small launches that leave the chip
-    # mostly idle -- also builds the next frame's pyramid + cornerness map (horizontal fusion in the same launches).
-    # (A second stream for the front was tried first: a fourth concurrently active CU-masked queue is serviced badly --
-    # whichever masked stream was created last runs its kernels 3-6x longer -- 167.9 -> 178-185 us/frame.)
-    prefetch = os.environ.get("BENCH_PREFETCH", "1") != "0" and not args.graphs
+    pose_done = torch.cuda.Event()
 
-    P = len(ba["pts0"])
-    import numpy as _np
-    obs_pt = _np.asarray(ba["obs_pt"])
-    o_order = _np.argsort(obs_pt, kind="stable")
-    ptr = _np.zeros(P + 1, dtype=_np.int32)
-    _np.add.at(ptr, obs_pt + 1, 1)
-    ptr = _np.cumsum(ptr).astype(_np.int32)
-    ba_ws = BAWorkspace(local_rank)
-    ba_ws.upload(ba["Ks"], ba["Rs0"], ba["ts0"], ba["pts0"], ptr, ba["obs_cam"][o_order], ba["obs_xy"][o_order])
-    d_baR = torch.from_numpy(ba["Rs0"].reshape(-1).copy()).to(dev)
-    d_baT = torch.from_numpy(ba["ts0"].reshape(-1).copy()).to(dev)
-    d_baM = torch.from_numpy(ba["pts0"].reshape(-1).copy()).to(dev)
+    def hb_cams(b):
+        return [dict(dest=d_dests[b][i].data_ptr(), K=d_K1.data_ptr(), kud=d_kud.data_ptr(), mapPts=d_map.data_ptr(),
+                     slot2map=d_slot2map[i].data_ptr(), trackLen=d_tracklen[i].data_ptr(), xy=d_xy[i].data_ptr(),
+                     state=d_state[i].data_ptr(), Ms=d_Ms[i].data_ptr(), ms=d_ms[i].data_ptr(), sel=d_sel[i].data_ptr(),
+                     npts=d_npts[i:i + 1].data_ptr(), opt=d_opt[i].data_ptr()) for i in range(nc)]
 
-    # all-gather payload at the merge step: features (N x 20 B) + pose (12 doubles = 96 B)
-    from coslam_amd.multicam import CameraExchange
-    xchg = CameraExchange(N_FEAT, dev) if world > 1 else None
+    hb_args = [hb_cams(0), hb_cams(1)]
+    dest_ptrs = [[d.data_ptr() for d in d_dests[b]] for b in range(2)]
+    cnt_ptrs = [c.data_ptr() for c in d_counts]
+    img_ptrs = [[d_frames[i][f].data_ptr() for i in range(nc)] for f in range(N_FRAMES)]
 
-    trace = [] if os.environ.get("BENCH_TRACE") else None
+    def pose_leg(b, i):
+        handback_dev(pose_s.cuda_stream, hb_args[b], N_FEAT, W, H, N_COL_BLK, N_ROW_BLK, PTS_STRIDE, device=local_rank)
+        src, dst = (i + 1) & 1, i & 1
+        intraCamEstimate_batch_dev(pose_s.cuda_stream, nc, PTS_STRIDE, d_K.data_ptr(), d_R[src].data_ptr(),
+                                   d_t[src].data_ptr(), d_npts.data_ptr(), 0, d_Ms.data_ptr(), d_ms.data_ptr(), 10.0,
+                                   d_R[dst].data_ptr(), d_t[dst].data_ptr(), d_opt.data_ptr(), d_ok.data_ptr(),
+                                   device=local_rank)
 
     def step(i):
-        f = order[i % len(order)]
+        f, fn = order[i % len(order)], order[(i + 1) % len(order)]
         b = i & 1
-        if trace is not None:
-            trace.append((i, "start", time.perf_counter()))
-        if i >= 2 and not os.environ.get("BENCH_NO_DESTFREE"):
-            klt_torch_stream.wait_event(dest_free[b])      # the consumer of this dest buffer two frames ago is done
-        if prefetch:   # this frame's detector tail also builds the next frame's pyramid + cornerness map
-            trk.prefetch_dev(d_frames[order[(i + 1) % len(order)]].data_ptr())
-        trk.redetect_dev(d_frames[f].data_ptr(), d_dests[b].data_ptr(), d_counts.data_ptr())
-        trk.advanceFrame()
-        klt_done[b].record(klt_torch_stream)
-        if trace is not None:
-            trace.append((i, "klt", time.perf_counter()))
-        pose_torch_stream.wait_event(klt_done[b])          # pose(f) consumes what the tracker produced for frame f
-        with torch.cuda.stream(pose_torch_stream):
-            if args.no_pose:
-                pass
+        if i >= 2:
+            klt_s.wait_event(dest_free[b])      # the consumer of this dest buffer two frames ago is done
+        if prefetch:   # this frame's detector tail also builds the next frame's pyramids + cornerness maps
+            grp.prefetch_dev(img_ptrs[fn])
+        grp.redetect_dev(img_ptrs[f], dest_ptrs[b], cnt_ptrs)
+        grp.advanceFrame()
+        klt_done[b].record(klt_s)
+        pose_s.wait_event(klt_done[b])          # pose(f) consumes what the tracker produced for frame f
+        if not args.no_pose:
+            pose_leg(b, i)
+        if world > 1:
+            with torch.cuda.stream(pose_s):
+                xchg.pack_group(d_dests[b], d_R[i & 1], d_t[i & 1], pose_s)
+                xchg.all_gather(pose_s)
+        dest_free[b].record(pose_s)
+        if args.key_every > 0 and (i + 1) % args.key_every == 0:
+            if args.serial:
+                ic_ws.solve_dev(klt_s.cuda_stream, d_iR.data_ptr(), d_iT.data_ptr(), d_iM.data_ptr(), 0, ic["n_static"], 6.0, 3, 40)
             else:
-              d_opt.copy_(d_opt0, non_blocking=True)
-              intraCamEstimate_batch_dev(pose_stream, 1, N_POSE_PTS, d_K.data_ptr(), d_R0[f].data_ptr(),
-                                         d_t0[f].data_ptr(), d_npts.data_ptr(), 0, d_Ms[f].data_ptr(), d_ms[f].data_ptr(),
-                                         10.0, d_Ropt.data_ptr(), d_topt.data_ptr(), d_opt.data_ptr(), d_ok.data_ptr(),
-                                         device=local_rank)
+                ic_ws.solve_async(pose_s.cuda_stream, d_iR.data_ptr(), d_iT.data_ptr(), d_iM.data_ptr(), 0, ic["n_static"], 6.0, 3, 40)
             if world > 1:
-                xchg.pack(d_dests[b], d_Ropt, d_topt)
-                xchg.all_gather()
-            dest_free[b].record(pose_torch_stream)
-        if trace is not None:
-            trace.append((i, "pose", time.perf_counter()))
-        if args.ba_every > 0 and (i + 1) % args.ba_every == 0:
-            ba_ws.solve_dev(ba_stream, d_baR.data_ptr(), d_baT.data_ptr(), d_baM.data_ptr(), 2, 2, 6.0, 2, 10)
-            if trace is not None:
-                trace.append((i, "ba", time.perf_counter()))
+                pose_done.record(pose_s)
+                ba_s.wait_event(pose_done)
+                multicam.bundle_adjust_sliced(ba_ws, ba_s, d_jR.data_ptr(), d_jT.data_ptr(), d_jM.data_ptr(),
+                                              joint["n_cams_con"], joint["n_pts_con"], 6.0, 2, 10, local_rank, native=native)
+            elif args.serial:
+                ba_ws.solve_dev(klt_s.cuda_stream, d_jR.data_ptr(), d_jT.data_ptr(), d_jM.data_ptr(), joint["n_cams_con"],
+                                joint["n_pts_con"], 6.0, 2, 10)
+            else:
+                ba_ws.solve_async(pose_s.cuda_stream, d_jR.data_ptr(), d_jT.data_ptr(), d_jM.data_ptr(), joint["n_cams_con"],
+                                  joint["n_pts_con"], 6.0, 2, 10)
 
     def barrier():
+        ic_ws.wait()      # the worker threads' queues are part of the timed work
+        ba_ws.wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    # first frame: detect (GPUKLT::first, reference src/tracking/GPUKLT.cpp:133-142)
-    trk.detect_dev(d_frames[order[0]].data_ptr(), d_dests[0].data_ptr(), d_counts.data_ptr())
-    trk.advanceFrame()
+    # first frame: detect (GPUKLT::first, reference src/tracking/GPUKLT.cpp:133-142), map association, first hand-back
+    grp.detect_dev(img_ptrs[order[0]], dest_ptrs[0], cnt_ptrs)
+    grp.advanceFrame()
+    grp.synchronize()
+    for i, c in enumerate(my_cams):
+        d = d_dests[0][i].cpu().numpy().view(coslam_amd.KLT_TrackedFeature)
+        s2m = associate(sc, c, order[0], d)
+        d_slot2map[i].copy_(torch.from_numpy(s2m))
+    with torch.cuda.stream(pose_s):
+        handback_dev(pose_s.cuda_stream, hb_args[0], N_FEAT, W, H, N_COL_BLK, N_ROW_BLK, PTS_STRIDE, device=local_rank)
+    torch.cuda.synchronize()
+    for i, c in enumerate(my_cams):   # the first hand-back starts every track as new (unmapped): put the map back
+        d = d_dests[0][i].cpu().numpy().view(coslam_amd.KLT_TrackedFeature)
+        d_slot2map[i].copy_(torch.from_numpy(associate(sc, c, order[0], d)))
+    torch.cuda.synchronize()
+
     for i in range(args.warmup):
         step(i + 1)
     barrier()
@@ -323,73 +377,90 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    grp.synchronize()
     last = (args.warmup + args.steps) & 1
-    if trace is not None and rank == 0:
-        t00 = trace[0][2]
-        for (i, what, t) in trace[-60:]:
-            print(f"# step {i} {what} {1e6 * (t - t00):.1f} us", file=sys.stderr)
-    n_live = int((d_dests[last].cpu().numpy().view(coslam_amd.KLT_TrackedFeature)["status"] >= 0).sum())
-    pose_ok = int(d_ok.item())
+    n_live = [int((d.cpu().numpy().view(coslam_amd.KLT_TrackedFeature)["status"] >= 0).sum()) for d in d_dests[last]]
+    pose_ok = d_ok.cpu().numpy().tolist()
+    pose_npts = d_npts.cpu().numpy().tolist()
+    # how far the device-resident poses are from the synthetic ground truth of the last frame (data-coupled pose leg)
+    f_last = order[(args.warmup + args.steps) % len(order)]
+    Rl, tl_ = d_R[last].cpu().numpy(), d_t[last].cpu().numpy()
+    pose_err = max(float(np.abs(tl_[i] - sc.pose(c, f_last)[1]).max()) for i, c in enumerate(my_cams))
+    _, _, _, _, st_j = ba_ws.download() if world == 1 else (None, None, None, None, None)
+    _, _, _, _, st_i = ic_ws.download()
 
-    # ---- roofline of the dominant kernel: the KLT gain tracker (all levels x iterations in one persistent launch).
-    # Timed with HIP events on the stream it is launched on, over a replay of the same frames right after the
-    # timed region (event pairs cannot sit inside the hipGraph the timed region replays).
+    # ---- roofline of the dominant kernel: the persistent gain tracker of all cameras of this rank (one launch per frame).
+    # Timed with HIP events on the stream it is launched on, over a replay of the same frames after the timed region.
     roof = None
     if rank == 0:
-        trk.set_profiling(True)
+        trks[0].set_profiling(True)
         n_prof = min(args.steps, 100)
+        base = args.warmup + args.steps
         for i in range(n_prof):
-            f = order[(args.warmup + args.steps + i + 1) % len(order)]
+            f, fn = order[(base + i + 1) % len(order)], order[(base + i + 2) % len(order)]
             if prefetch:
-                trk.prefetch_dev(d_frames[order[(args.warmup + args.steps + i + 2) % len(order)]].data_ptr())
-            trk.redetect_dev(d_frames[f].data_ptr(), d_dest.data_ptr(), d_counts.data_ptr())
-            trk.advanceFrame()
-        prof = trk.get_profile()
-        trk.set_profiling(False)
+                grp.prefetch_dev(img_ptrs[fn])
+            grp.redetect_dev(img_ptrs[f], dest_ptrs[0], cnt_ptrs)
+            grp.advanceFrame()
+        prof = trks[0].get_profile()
+        trks[0].set_profiling(False)
         hw = 7 // 2
-        levels_visited = LEVELS  # levelSkip = 1
         # per feature per visited level two (2hw+2)^2 footprints of 6-byte texels, + 2 x 12 B feature I/O
-        per_feature = levels_visited * 2 * (2 * hw + 2) ** 2 * 6 + 2 * 12
-        alg_bytes = per_feature * N_FEAT
+        per_feature = LEVELS * 2 * (2 * hw + 2) ** 2 * 6 + 2 * 12
+        alg_bytes = per_feature * N_FEAT * nc
         launches = max(prof["launches_per_frame"], 1)
         avg_us = prof["tracker_us_total"] / max(prof["frames"], 1) / launches
         ach = (alg_bytes / launches) / (avg_us * 1e-6) / 1e9
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_tracker_pmc.json")
-        if launches == 1 and os.path.exists(pmc_file):  # HBM bytes per launch from the committed rocprofv3 --pmc passes
+        pmc_file = os.path.join(ROOT, "profiles", "r02_tracker_pmc.json")
+        if launches == 1 and nc == N_CAMS and os.path.exists(pmc_file):  # HBM bytes per launch from the committed --pmc passes
             pj = json.load(open(pmc_file))
-            traffic, traffic_src = pj["traffic_bytes_per_launch"], "profiles/r01_tracker_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
-        roof = {"bound": "hbm", "kernel": "k_track_gain_fused" if launches == 1 else "k_track_gain_pass",
+            traffic, traffic_src = pj["traffic_bytes_per_launch"], "profiles/r02_tracker_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
+        roof = {"bound": "hbm", "kernel": "k_track_rows_fused" if launches == 1 else "k_track_rows_pass",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": alg_bytes / launches, "avg_launch_us": avg_us,
-                "launches_per_frame": launches, "frames_timed": prof["frames"]}
+                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes / launches,
+                "avg_launch_us": avg_us, "launches_per_frame": launches, "frames_timed": prof["frames"],
+                "cameras_per_launch": nc}
 
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(frames, Ms, ms, R0, t0, sc.K, ba)
+        cores = os.cpu_count() or 1
+        nt = min(cores, N_CAMS)
+        v1, n1, dt1 = cpu_baseline(sc, frames, joint, ic, 1, 12.0)
+        vN, nN, dtN = cpu_baseline(sc, frames, joint, ic, nt, 12.0) if nt > 1 else (v1, n1, dt1)
+        cpu = {"value": vN, "unit": "frames/s", "cores": nt, "kind": "port",
+               "sample": f"{nN} frames of the same 8-camera workload on {nt} threads (cameras in parallel) in {dtN:.1f} s; "
+                         f"{n1} frames on 1 thread in {dt1:.1f} s (oracle/: C restatement, gcc -O2); host has {cores} cores",
+               "value_1_thread": v1, "host_cores": cores}
 
     if rank == 0:
-        total_frames = args.steps * n_gpus
         out = {
-            "metric": "frames/sec for track+local-BA loop (camera-frames, 640x480 x 2000 feature slots)",
-            "value": total_frames / dt, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps,
+            "metric": "frames/sec for track+local-BA loop, 8 cams 640x480 x 2000 feats (one frame = all 8 cameras)",
+            "value": args.steps / dt, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (KLT, f16 pyramid storage) + f64 (pose, BA)",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32 (KLT, f16 pyramid storage) + f64 (pose, BA)",
             "data": "synthetic",
-            "config": {"workload": "cfg2: 1 camera/GPU 640x480, 50x40=2000 KLT slots, 4-level pyramid, 7x7 window, "
-                                   "10 it/level with gain, redetect every frame; intraCamEstimate on 192 pts every "
-                                   f"frame; local robust BA (5 KF x 500 pts, maxIter 2 / inner 10) every {BA_EVERY}th "
-                                   "frame; all-gather of features+pose when N>1",
-                       "cameras": n_gpus, "live_features_last_frame": n_live, "pose_ok": pose_ok,
-                       "hip_graphs": bool(args.graphs and not args.no_graphs),
+            "config": {"workload": "8 cams 640x480 x 2000 KLT slots (50x40), 4-level pyramid, 7x7 window, 10 it/level with "
+                                   "gain, redetect every frame; on-device hand-back + intraCamEstimate of all 8 cameras "
+                                   f"every frame (fed by the tracker's output); every {KEY_EVERY}th frame: joint local BA "
+                                   f"C=40 (16 fixed) x {len(joint['pts0'])} pts x {len(joint['obs_cam'])} meas, maxIter 2 / inner 10, and "
+                                   f"inter-camera solve C=8 free, {ic['n_static']} static pts fixed + {ic['n_dynamic']} dynamic, "
+                                   "sigma 6, 3 x 40; N>1: cameras sharded 8/N per GPU, all-gather of features+pose per "
+                                   "frame, joint BA sliced by points with an all-reduce per LM step",
+                       "cameras": N_CAMS, "cameras_per_gpu": nc, "camera_frames_per_s": N_CAMS * args.steps / dt,
+                       "live_features_last_frame": n_live, "pose_ok": pose_ok, "pose_correspondences": pose_npts,
+                       "pose_translation_error_vs_truth": pose_err,
+                       "joint_ba_last": None if st_j is None else {"lm_steps": st_j.nIterTotal, "outliers": st_j.nOutliers,
+                                                                  "cost0": st_j.cost0, "cost": st_j.cost},
+                       "intercam_last": {"lm_steps": st_i.nIterTotal, "outliers": st_i.nOutliers, "cost0": st_i.cost0,
+                                         "cost": st_i.cost},
                        "frame_front_prefetch": bool(prefetch),
                        "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
-                       "cu_partition": (f"tracker stream on {n_cus - side_cus} CUs, BA stream on {side_cus} CUs ({side_mode}), "
-                                        f"pose stream: {pose_part}" if side_cus > 0 else "none"),
+                       "collectives": None if world == 1 else ("libcoslam_hip RCCL (C-ABI)" if native else "torch.distributed " + dist_backend),
                        "streams": "one stream (--serial)" if args.serial else
-                       "tracker | pose (event-ordered behind the tracker of the same frame) | local BA "
-                       "(own stream, like the reference's BA worker thread)"},
+                       "tracker group | hand-back + pose (event-ordered behind the tracker of the same frame) | "
+                       "inter-camera solve and joint local BA each on its workspace's worker thread + stream "
+                       "(cs_ba_solve_async, like the reference's BA worker thread)"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

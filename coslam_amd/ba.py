@@ -86,6 +86,17 @@ class BAWorkspace:
                                       vp(d_pts0), int(nCamsCon), int(nPtsCon), C.c_double(maxErr), int(maxIter),
                                       int(innerMaxIter)), "cs_ba_solve_dev")
 
+    def solve_async(self, after_stream_ptr, d_Rs0, d_Ts0, d_pts0, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter):
+        """cs_ba_solve_async: the solve on the workspace's worker thread (the reference's BA thread), started once the work
+        enqueued on `after_stream_ptr` so far has finished; returns at once."""
+        vp = C.c_void_p
+        check(self._L.cs_ba_solve_async(self._h, vp(after_stream_ptr), self.C, self.P, self.nObs, vp(d_Rs0), vp(d_Ts0),
+                                        vp(d_pts0), int(nCamsCon), int(nPtsCon), C.c_double(maxErr), int(maxIter),
+                                        int(innerMaxIter)), "cs_ba_solve_async")
+
+    def wait(self):
+        check(self._L.cs_ba_wait(self._h), "cs_ba_wait")
+
     def download(self):
         Rs, Ts, pts = np.zeros((self.C, 9)), np.zeros((self.C, 3)), np.zeros((max(self.P, 1), 3))
         out = np.zeros(max(self.nObs, 1), dtype=np.int32)

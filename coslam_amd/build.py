@@ -20,6 +20,7 @@ HIP_SOURCES = [
     "klt_detect.hip",
     "klt_seq.hip",
     "pose.hip",
+    "handback.hip",
     "ba.hip",
 ]
 

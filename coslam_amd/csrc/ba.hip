@@ -30,7 +30,12 @@
 // are 6x3 blocks -- wave-shuffle territory; the large-order Cholesky tiles through LDS with 4x4 register blocks.
 // The distributed solve (points sliced by rank, all-reduce of S || rhs per LM step) reuses these kernels through
 // the cs_ba_dist_* phase API at the end of this file.
+#include <condition_variable>
 #include <cstdlib>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 #include "cs_common.h"
 
@@ -334,62 +339,80 @@ __global__ __launch_bounds__(256) void k_schur(BaDev D) {
     const int jb = ja + pair;
     const int ca = ja + D.nCamsCon, cb = jb + D.nCamsCon;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (ja == jb) {
-        double u[27];
+    const bool diag = (ja == jb);
+    // The points both cameras measure are found by walking camera a's OWN measurement list (ascending point index) and
+    // looking camera b up in the dense (point, camera) table: one dependent lookup per entry of a list a few hundred
+    // long, where walking all P points cost two lookups each, most of them misses.  The diagonal pair takes U_j and
+    // g_j from the same entries.
+    double u[27], acc[42];
 #pragma unroll
-        for (int q = 0; q < 27; ++q) u[q] = 0;
-        for (int s = D.cam_ptr[ca] + threadIdx.x; s < D.cam_ptr[ca + 1]; s += 256) {
-            const int o = D.cam_obs[s];
-            if (D.outlier[o]) continue;
-            const int ip = D.obs_pt[o];
-            if (ip < D.pLo || ip >= D.pHi) continue;  // another rank's point
-            const double* J = D.Jc + 12 * (size_t)o;
-            const double e0 = D.e[2 * (size_t)o], e1 = D.e[2 * (size_t)o + 1];
-            int q = 0;
+    for (int q = 0; q < 27; ++q) u[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 42; ++q) acc[q] = 0;
+    const int sBeg = D.cam_ptr[ca], sEnd = D.cam_ptr[ca + 1];
+    for (int s0 = sBeg; s0 < sEnd; s0 += 4 * 256) {
+        // the index chain of four entries per thread goes out as one batch (entry -> point -> partner measurement)
+        int oa[4], ip[4], ob[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int s = s0 + threadIdx.x + 256 * t;
+            oa[t] = (s < sEnd) ? D.cam_obs[s] : -1;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ip[t] = -1;
+            if (oa[t] >= 0 && !D.outlier[oa[t]]) ip[t] = D.obs_pt[oa[t]];
+            if (ip[t] < D.pLo || ip[t] >= D.pHi) ip[t] = -1;  // another rank's point
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ob[t] = -1;
+            if (ip[t] >= D.nPtsCon) ob[t] = diag ? oa[t] : D.obs_of[(size_t)ip[t] * D.C + cb];
+            if (ob[t] >= 0 && D.outlier[ob[t]]) ob[t] = -1;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (diag && ip[t] >= 0) {  // U_j, g_j: every inlier measurement of the camera, fixed points included
+                const double* J = D.Jc + 12 * (size_t)oa[t];
+                const double e0 = D.e[2 * (size_t)oa[t]], e1 = D.e[2 * (size_t)oa[t] + 1];
+                int q = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = r; c < 6; ++c) u[q++] += J[r] * J[c] + J[6 + r] * J[6 + c];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) u[21 + r] += J[r] * e0 + J[6 + r] * e1;
+            }
+            if (ob[t] < 0) continue;
+            const double* Wa = D.W + 18 * (size_t)oa[t];
+            const double* Wb = D.W + 18 * (size_t)ob[t];
+            const double* Vi = D.Vinv + 9 * (size_t)ip[t];
+            double Y[18];
 #pragma unroll
             for (int r = 0; r < 6; ++r)
 #pragma unroll
-                for (int c = r; c < 6; ++c) u[q++] += J[r] * J[c] + J[6 + r] * J[6 + c];
+                for (int c = 0; c < 3; ++c) Y[3 * r + c] = Wa[3 * r] * Vi[c] + Wa[3 * r + 1] * Vi[3 + c] + Wa[3 * r + 2] * Vi[6 + c];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) u[21 + r] += J[r] * e0 + J[6 + r] * e1;
-        }
+            for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int q = 0; q < 27; ++q) {
-            double v = wsum(u[q]);
-            if (lane == 0) redU[wv][q] = v;
-        }
-    }
-    double acc[42];
+                for (int c = 0; c < 6; ++c)
+                    acc[6 * r + c] += Y[3 * r] * Wb[3 * c] + Y[3 * r + 1] * Wb[3 * c + 1] + Y[3 * r + 2] * Wb[3 * c + 2];
+            if (diag) {
+                const double* g = D.gp + 3 * (size_t)ip[t];
 #pragma unroll
-    for (int q = 0; q < 42; ++q) acc[q] = 0;
-    for (int i = (D.nPtsCon > D.pLo ? D.nPtsCon : D.pLo) + threadIdx.x; i < D.pHi; i += 256) {
-        const int oa = D.obs_of[(size_t)i * D.C + ca];
-        if (oa < 0 || D.outlier[oa]) continue;
-        const int ob = (ja == jb) ? oa : D.obs_of[(size_t)i * D.C + cb];
-        if (ob < 0 || D.outlier[ob]) continue;
-        const double* Wa = D.W + 18 * (size_t)oa;
-        const double* Wb = D.W + 18 * (size_t)ob;
-        const double* Vi = D.Vinv + 9 * (size_t)i;
-        double Y[18];
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) Y[3 * r + c] = Wa[3 * r] * Vi[c] + Wa[3 * r + 1] * Vi[3 + c] + Wa[3 * r + 2] * Vi[6 + c];
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c < 6; ++c)
-                acc[6 * r + c] += Y[3 * r] * Wb[3 * c] + Y[3 * r + 1] * Wb[3 * c + 1] + Y[3 * r + 2] * Wb[3 * c + 2];
-        if (ja == jb) {
-            const double* g = D.gp + 3 * (size_t)i;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) acc[36 + r] += Y[3 * r] * g[0] + Y[3 * r + 1] * g[1] + Y[3 * r + 2] * g[2];
+                for (int r = 0; r < 6; ++r) acc[36 + r] += Y[3 * r] * g[0] + Y[3 * r + 1] * g[1] + Y[3 * r + 2] * g[2];
+            }
         }
     }
-#pragma unroll
-    for (int q = 0; q < 42; ++q) {
-        double s = wsum(acc[q]);
-        if (lane == 0) red[wv][q] = s;
+    if (diag) {
+        cs_reduce_many<27>(u, lane);  // transposed butterfly: total q ends up in lane cs_reduce_owner<27>(q)
+        const int q = cs_reduce_index<27>(lane);
+        if (q >= 0) redU[wv][q] = u[0];
+    }
+    {
+        cs_reduce_many<42>(acc, lane);
+        const int q = cs_reduce_index<42>(lane);
+        if (q >= 0) red[wv][q] = acc[0];
     }
     __syncthreads();
     if (threadIdx.x < 42) {
@@ -398,7 +421,7 @@ __global__ __launch_bounds__(256) void k_schur(BaDev D) {
         const int n = D.n;
         if (q < 36) {
             const int r = q / 6, c = q - 6 * r;
-            if (ja == jb) {
+            if (diag) {
                 // U_j entry (upper-triangular rank of (min,max)) + lambda on the diagonal - Schur sum
                 const int rr = r < c ? r : c, cc = r < c ? c : r;
                 const int uq = rr * 6 - (rr * (rr - 1)) / 2 + (cc - rr);
@@ -408,7 +431,7 @@ __global__ __launch_bounds__(256) void k_schur(BaDev D) {
                 D.S[(size_t)(6 * ja + r) * n + 6 * jb + c] = -s;
                 D.S[(size_t)(6 * jb + c) * n + 6 * ja + r] = -s;
             }
-        } else if (ja == jb) {
+        } else if (diag) {
             const int r = q - 36;
             const double gv = ((redU[0][21 + r] + redU[1][21 + r]) + redU[2][21 + r]) + redU[3][21 + r];
             D.rhs[6 * ja + r] = gv - s;
@@ -831,6 +854,259 @@ __global__ __launch_bounds__(1024) void k_chol_trsv(BaDev D) {
 __global__ void k_chol_begin(BaDev D) {
     if (!BA_ACTIVE(D)) return;
     D.st->chol_ok = 1;
+}
+
+// ---- one workgroup, blocked, LDS-resident: reduced camera systems of order 36 < n <= 176 ---------------------------
+// The joint local BA of the 8-camera rig (24 free key-frame cameras, order 144) and the inter-camera solve (order 48)
+// land here.  The unblocked kernels pay three workgroup barriers per COLUMN (k_solve<256>) or run on one wave
+// (k_solve_wave); the HBM-blocked Cholesky was built for order 720 and costs ~350 us at order 144.  Here the lower
+// triangle of S lives in LDS as packed 16 x 16 blocks (order 144: 45 blocks = 90 KB; order 192: 156 KB) and one
+// 1024-thread workgroup runs a right-looking blocked factorisation with two barriers per BLOCK column:
+//   1. wave 0 factors the diagonal block out of REGISTERS (lane i = row i, sixteen unrolled column steps, every
+//      cross-lane read a v_readlane of a constant lane) and leaves L_kk and 1 / diag(L_kk) in LDS -- with look-ahead:
+//      the block of step k + 1 is updated first and factored while the other fifteen waves do step k's trailing update;
+//   2. panel  A[I][k] <- A[I][k] L_kk^-T by substitution, one row per thread;
+//   3. trailing update A[I][J] -= P_I P_J^T, one 4 x 4 register tile per thread.
+// The right-hand side rides along as one more row of the matrix (an augmented factorisation), so the forward
+// substitution costs no extra phase; the back substitution is a wave-level sweep per diagonal block plus one update
+// phase.  Rows n..16*NB-1 are identity padding.
+constexpr int SB = 16;
+// Row pitch of a block in LDS: 18 doubles = 36 banks, so the sixteen rows of a block start in sixteen different
+// bank groups (pitch 16 put every other row on the same banks: 8- and 16-way conflicts in every phase -- 90 us per
+// order-144 solve instead of the ~40 below).  Order limit: 66 blocks x 2304 B = 152 KB at NB = 11.
+constexpr int SP = 18, SBLK = SB * SP;
+constexpr int SB_MAX_ORDER = 176;
+__device__ __forceinline__ int sb_off(int I, int J) { return (I * (I + 1) / 2 + J) * SBLK; }
+
+__host__ __device__ constexpr size_t sb_lds_bytes(int n) {
+    const int NB = (n + SB - 1) / SB;
+    return sizeof(double) * ((size_t)(NB * (NB + 1) / 2) * SBLK + (size_t)2 * NB * SB) + 16;
+}
+
+__device__ __forceinline__ double sb_rdlane(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// wave 0: Cholesky of one diagonal block out of registers (lane i < 16 holds row i); leaves L_kk and 1 / diag in LDS.
+// (The cross-lane reads are v_readlane pairs of a constant lane; a DPP row_newbcast per value measured slower:
+// 11.5k instead of 6.6k cycles per block.)
+__device__ __forceinline__ bool sb_factor_diag(double* Dk, double* rdiag, int lane) {
+    const int row = lane & 15;
+    double a[SB];
+#pragma unroll
+    for (int k = 0; k < SB; ++k) a[k] = Dk[row * SP + k];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < SB; ++j) {
+        double d = sb_rdlane(a[j], j);
+        if (!(d > 0)) {
+            ok = false;
+            d = 1.0;
+        }
+        const double r = rsqrt(d);  // one reciprocal square root per column: no f64 sqrt + divide on the serial path
+        const double lij = (lane == j) ? d * r : a[j] * r;  // sqrt(d) on the diagonal, a_ij / sqrt(d) below
+        a[j] = lij;
+        if (lane == j) rdiag[j] = r;
+#pragma unroll
+        for (int k = j + 1; k < SB; ++k) {
+            const double lkj = sb_rdlane(lij, k);
+            a[k] -= lij * lkj;  // meaningful for k <= lane (the lower triangle); the rest is never read
+        }
+    }
+    if (lane < SB) {
+#pragma unroll
+        for (int k = 0; k < SB; ++k) Dk[lane * SP + k] = a[k];
+    }
+    return ok;
+}
+
+// one 4 x 4 tile of  A[I][J] -= P_I P_J^T  (tile (tr, tc) of the 16 x 16 block)
+__device__ __forceinline__ void sb_tile_update(double* A, int I, int J, int kb, int tr, int tc) {
+    const double* PI = A + sb_off(I, kb) + (4 * tr) * SP;
+    const double* PJ = A + sb_off(J, kb) + (4 * tc) * SP;
+    double acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+#pragma unroll
+    for (int k = 0; k < SB; k += 2) {
+        double2 pa[4], pb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pa[r] = *(const double2*)(PI + r * SP + k);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pb[c] = *(const double2*)(PJ + c * SP + k);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] += pa[r].x * pb[c].x + pa[r].y * pb[c].y;
+    }
+    double* T = A + sb_off(I, J) + (4 * tr) * SP + 4 * tc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) T[r * SP + c] -= acc[r][c];
+}
+
+__global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
+    const int stAllDone = D.st->all_done, stInnerDone = D.st->inner_done;  // (consumed after the matrix loads are in flight)
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int okFlag;
+    const int n = D.n, tid = threadIdx.x, NT = 1024;
+    if (n == 0) {
+        if (tid == 0) D.st->chol_ok = 1;
+        return;
+    }
+    const int NB = (n + SB - 1) / SB, NBT = NB * (NB + 1) / 2;
+#ifdef CS_SOLVE_PROBE
+    unsigned long long pT0 = __builtin_amdgcn_s_memtime(), pLoad = 0, pDiag = 0, pPanel = 0, pTrail = 0, pBack = 0, pT = 0;
+#define CS_PROBE(acc)                                      \
+    do {                                                   \
+        unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+        acc += _t - pT;                                    \
+        pT = _t;                                           \
+    } while (0)
+#else
+#define CS_PROBE(acc) ((void)0)
+#endif
+    double* A = sm;
+    double* b = sm + (size_t)NBT * SBLK;  // the right-hand side: one more row of the matrix
+    double* rdiag = b + (size_t)NB * SB;  // 1 / L_jj
+    // ---- load the lower triangle (identity padding beyond n): up to 16 loads in flight per thread (order 176: all of it)
+    for (int e0 = 0; e0 < NBT * SB * SB; e0 += 16 * NT) {
+        double v[16];
+        int dst[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = e0 + tid + u * NT;
+            const int blk = e >> 8, r = (e >> 4) & 15, c = e & 15;
+            int I = 0;
+            while ((I + 1) * (I + 2) / 2 <= blk) ++I;
+            const int J = blk - I * (I + 1) / 2;
+            const int gi = I * SB + r, gj = J * SB + c;
+            dst[u] = (e < NBT * SB * SB) ? blk * SBLK + r * SP + c : -1;
+            v[u] = 0.0;
+            if (dst[u] >= 0) {
+                if (gi < n && gj < n)
+                    v[u] = D.S[(size_t)gi * n + gj];
+                else if (gi == gj)
+                    v[u] = 1.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (dst[u] >= 0) A[dst[u]] = v[u];
+        if (stAllDone || stInnerDone) return;  // !BA_ACTIVE (uniform); tested here so that it is not one more dependent trip
+    }
+    for (int q = tid; q < NB * SB; q += NT) b[q] = (q < n) ? D.rhs[q] : 0.0;
+    if (tid == 0) okFlag = 1;
+    __syncthreads();
+#ifdef CS_SOLVE_PROBE
+    pT = __builtin_amdgcn_s_memtime();
+    pLoad = pT - pT0;
+#endif
+    // the first diagonal block; every later one is factored by wave 0 NEXT TO the trailing update of the step before
+    // (look-ahead), so the serial column chain -- the longest phase -- is off the critical path
+    if (tid < 64) {
+        if (!sb_factor_diag(A + sb_off(0, 0), rdiag, tid) && tid == 0) okFlag = 0;
+    }
+    __syncthreads();
+    CS_PROBE(pDiag);
+
+    for (int kb = 0; kb < NB; ++kb) {
+        const double* Dk = A + sb_off(kb, kb);
+        // ---- panel by substitution: x L_kk^T = a, one row per thread (the last row is the right-hand side's block kb)
+        const int m = NB - kb - 1;
+        for (int rr = tid; rr < m * SB + 1; rr += NT) {
+            double* row = (rr < m * SB) ? A + sb_off(kb + 1 + rr / SB, kb) + (rr % SB) * SP : b + kb * SB;
+            double a[SB];
+#pragma unroll
+            for (int k = 0; k < SB; ++k) a[k] = row[k];
+#pragma unroll
+            for (int c = 0; c < SB; ++c) {
+                const double x = a[c] * rdiag[kb * SB + c];
+                a[c] = x;
+#pragma unroll
+                for (int k = c + 1; k < SB; ++k) a[k] -= x * Dk[k * SP + c];
+            }
+#pragma unroll
+            for (int k = 0; k < SB; ++k) row[k] = a[k];
+        }
+        __syncthreads();
+        CS_PROBE(pPanel);
+        if (m == 0) break;
+        // ---- trailing update A[I][J] -= P_I P_J^T for kb < J <= I (4 x 4 tile per thread) and b_J -= b_kb P_J^T.
+        // Wave 0 takes the next diagonal block's sixteen tiles and then factors it; waves 1..15 take everything else.
+        if (tid < 64) {
+            if (tid < 16) sb_tile_update(A, kb + 1, kb + 1, kb, tid >> 2, tid & 3);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (!sb_factor_diag(A + sb_off(kb + 1, kb + 1), rdiag + (kb + 1) * SB, tid) && tid == 0) okFlag = 0;
+        } else {
+            const int nTiles = m * (m + 1) / 2 * 16;
+            for (int t = 16 + (tid - 64); t < nTiles + m * SB; t += NT - 64) {
+                if (t >= nTiles) {  // one entry of the right-hand side row
+                    const int q = t - nTiles, J = kb + 1 + q / SB, c = q % SB;
+                    const double* PJ = A + sb_off(J, kb) + c * SP;
+                    const double* y = b + kb * SB;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < SB; ++k) acc += y[k] * PJ[k];
+                    b[J * SB + c] -= acc;
+                    continue;
+                }
+                const int blk = t >> 4;
+                int bi = 0;
+                while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
+                const int bj = blk - bi * (bi + 1) / 2;
+                sb_tile_update(A, kb + 1 + bi, kb + 1 + bj, kb, (t >> 2) & 3, t & 3);
+            }
+        }
+        __syncthreads();
+        CS_PROBE(pTrail);
+    }
+    // b now holds y = L^-1 rhs.  Back substitution L^T x = y, block by block from the bottom.
+    for (int kb = NB - 1; kb >= 0; --kb) {
+        const double* Lk = A + sb_off(kb, kb);
+        if (tid < 64) {  // x_kb = L_kk^-T y_kb: lane i holds y_i and column i of L_kk (= row i of L_kk^T)
+            const int lane = tid, i = lane & 15;
+            double y = b[kb * SB + i];
+            double col[SB];
+#pragma unroll
+            for (int c = 0; c < SB; ++c) col[c] = Lk[c * SP + i];  // L_ci
+            const double rd = rdiag[kb * SB + i];
+#pragma unroll
+            for (int c = SB - 1; c >= 0; --c) {
+                const double xc = sb_rdlane(y, c) * sb_rdlane(rd, c);
+                if (i == c) y = xc;
+                if (i < c) y -= col[c] * xc;
+            }
+            if (lane < SB) b[kb * SB + lane] = y;
+        }
+        __syncthreads();
+        // b_J -= L_{kb,J}^T x_kb for every block column J < kb: one entry per thread
+        for (int cc = tid; cc < kb * SB; cc += NT) {
+            const int J = cc / SB, c = cc % SB;
+            const double* blk = A + sb_off(kb, J);
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < SB; ++k) acc += blk[k * SP + c] * b[kb * SB + k];
+            b[J * SB + c] -= acc;
+        }
+        __syncthreads();
+    }
+    for (int q = tid; q < n; q += NT) D.rhs[q] = b[q];
+    if (tid == 0) D.st->chol_ok = okFlag;
+#ifdef CS_SOLVE_PROBE
+    CS_PROBE(pBack);
+    if (tid == 0 && D.st->nIterTotal == 3)
+        printf("k_solve_blocked n=%d NB=%d cycles: load %llu diag %llu panel %llu trail %llu back %llu total %llu\n", n, NB, pLoad,
+               pDiag, pPanel, pTrail, pBack, __builtin_amdgcn_s_memtime() - pT0);
+#endif
+#undef CS_PROBE
 }
 
 // ---- one WAVE: reduced camera system of order n <= 64 -------------------------------------------------
@@ -1688,6 +1964,7 @@ struct BaPlan {
     int cb, gPts, gUpd, nPairs, useLds;
     size_t ldsSolve;
     bool sliced;
+    bool legacySolve;  // COSLAM_BA_LEGACY_SOLVE=1: k_solve_wave / k_solve<256> / HBM-blocked Cholesky (A/B runs)
 };
 
 struct cs_ba {
@@ -1715,11 +1992,14 @@ struct cs_ba {
         const void *R0, *T0, *M0;
     } gkey;
     hipGraphExec_t gexec;
+    struct BaWorker* worker;  // cs_ba_solve_async: the workspace's solver thread (the reference's BA thread)
 };
 
+static void ba_worker_drop_graphs(cs_ba* b);
 static void ba_drop_graph(cs_ba* b) {
     if (b->gexec) (void)hipGraphExecDestroy(b->gexec);
     b->gexec = nullptr;
+    ba_worker_drop_graphs(b);
 }
 
 static int ba_free(cs_ba* b) {
@@ -1891,6 +2171,14 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
     if (L.useLds && L.ldsSolve > 64 * 1024) {
         CS_HIP(hipFuncSetAttribute((const void*)k_solve<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.ldsSolve));
     }
+    {
+        static const bool legacy = getenv("COSLAM_BA_LEGACY_SOLVE") && getenv("COSLAM_BA_LEGACY_SOLVE")[0] == '1';
+        L.legacySolve = legacy;
+        if (!legacy && D.n > 36 && D.n <= SB_MAX_ORDER && sb_lds_bytes(D.n) > 64 * 1024) {
+            CS_HIP(hipFuncSetAttribute((const void*)k_solve_blocked, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sb_lds_bytes(D.n)));
+        }
+    }
     L.gPts = (P + 3) / 4 > 0 ? (P + 3) / 4 : 1;
     int gUpd = (P + 3) / 4;
     if (gUpd * 256 < C) gUpd = (C + 255) / 256;
@@ -1986,7 +2274,9 @@ static void ba_enqueue_solve_update(hipStream_t stream, const BaPlan& L) {
     } else if (L.sliced && D.n == 36) {
         hipLaunchKernelGGL(k_update<36>, dim3(gUpd), blk, 0, stream, D);
     } else {
-        if (D.n <= 64) {
+        if (D.n <= SB_MAX_ORDER && !L.legacySolve) {
+            hipLaunchKernelGGL(k_solve_blocked, dim3(1), dim3(1024), sb_lds_bytes(D.n), stream, D);
+        } else if (D.n <= 64) {
             hipLaunchKernelGGL(k_solve_wave, dim3(1), dim3(64), sizeof(double) * (size_t)D.n * (D.n | 1), stream, D);
         } else if (L.useLds) {
             hipLaunchKernelGGL(k_solve<256>, dim3(1), blk, L.ldsSolve, stream, D, 1);
@@ -2038,6 +2328,175 @@ static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int 
     return CS_OK;
 }
 
+// ---- cs_ba_solve_async: the solve on the workspace's own thread, enqueued in chunks -----------------------------------
+// cs_ba_solve_dev enqueues the whole maxIter x innerMaxIter schedule up front; a run that converges early leaves the rest
+// behind as no-op launches (~2 us each: the inter-camera solve -- 3 x 40 steps scheduled, ~13 taken -- spent more time in
+// them than in its LM steps).  The reference runs bundle adjustment on a worker thread next to tracking
+// (src/app/SL_CoSLAM.cpp:1702-1784); so does this entry: a thread per workspace replays captured graphs of CHUNK LM
+// steps on the workspace's stream and reads the 8-byte {inner_done, all_done} word back between chunks, so at most one
+// chunk of no-ops is ever issued.  The caller's thread only records an event and queues the request.
+struct BaAsyncJob {
+    int C, P, nObs, nCamsCon, nPtsCon, maxIter, innerMaxIter;
+    double maxErr;
+    const double *R0, *T0, *M0;
+    hipEvent_t ready;
+};
+
+struct BaWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv, cvDone;
+    std::deque<BaAsyncJob> q;
+    bool stop = false;
+    int inflight = 0;
+    int lastRc = CS_OK;
+    char err[256] = "";
+    // captured pieces of the solve, keyed like the whole-solve graph
+    cs_ba::GraphKey key;
+    bool haveGraphs = false;
+    int chunk = 0;
+    hipGraphExec_t gHead = nullptr, gChunk = nullptr, gTail = nullptr, gRound = nullptr, gFinish = nullptr;
+    int* h_state = nullptr;  // pinned {inner_done, all_done}
+};
+
+static void ba_worker_drop_graphs(cs_ba* b) {
+    BaWorker* w = b->worker;
+    if (!w) return;
+    for (hipGraphExec_t* g : {&w->gHead, &w->gChunk, &w->gTail, &w->gRound, &w->gFinish}) {
+        if (*g) (void)hipGraphExecDestroy(*g);
+        *g = nullptr;
+    }
+    w->haveGraphs = false;
+}
+
+template <class F>
+static int ba_capture(hipStream_t s, hipGraphExec_t* out, F&& body) {
+    CS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    body();
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (e != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        cs_set_error("cs_ba_solve_async: hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        return CS_ERR_HIP;
+    }
+    e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        cs_set_error("cs_ba_solve_async: hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        return CS_ERR_HIP;
+    }
+    return CS_OK;
+}
+
+static int ba_worker_run(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
+    CS_HIP(hipSetDevice(b->device));
+    hipStream_t s = b->own_stream;
+    CS_HIP(hipStreamWaitEvent(s, J.ready, 0));
+    cs_ba::GraphKey key = {J.C, J.P, J.nObs, J.nCamsCon, J.nPtsCon, J.maxIter, J.innerMaxIter, J.maxErr, J.R0, J.T0, J.M0};
+    BaPlan L;
+    int rc = ba_make_plan(b, J.C, J.P, J.nObs, J.nCamsCon, J.nPtsCon, J.maxErr, J.innerMaxIter, false, &L);
+    if (rc) return rc;
+    const BaDev& D = L.D;
+    const dim3 blk(256);
+    if (!w->haveGraphs || memcmp(&key, &w->key, sizeof(key)) != 0) {
+        ba_worker_drop_graphs(b);
+        static const int envChunk = getenv("COSLAM_BA_CHUNK") ? atoi(getenv("COSLAM_BA_CHUNK")) : 0;
+        w->chunk = envChunk > 0 ? envChunk : 5;
+        if (w->chunk > J.innerMaxIter && J.innerMaxIter > 0) w->chunk = J.innerMaxIter;
+        // head: initial estimate into the workspace, cost and LM state of the first round
+        rc = ba_capture(s, &w->gHead, [&] {
+            ba_enqueue_init(b, s, L, false, J.R0, J.T0, J.M0);
+            hipLaunchKernelGGL(k_cost, dim3(L.cb), blk, 0, s, D, 0);
+            hipLaunchKernelGGL(k_control, dim3(1), blk, 0, s, D);
+        });
+        if (rc) return rc;
+        rc = ba_capture(s, &w->gChunk, [&] {
+            for (int it = 0; it < w->chunk; ++it) {
+                ba_enqueue_lin_schur(s, L);
+                ba_enqueue_solve_update(s, L);
+                hipLaunchKernelGGL(k_control_step, dim3(1), blk, 0, s, D);
+            }
+            (void)hipMemcpyAsync(w->h_state, &b->st->inner_done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+        });
+        if (rc) return rc;
+        // tail of a round: outlier flags, round bookkeeping; start of the next round: cost + LM state
+        rc = ba_capture(s, &w->gTail, [&] {
+            hipLaunchKernelGGL(k_flag, dim3(L.cb), blk, 0, s, D);
+            hipLaunchKernelGGL(k_outer_end, dim3(1), dim3(1), 0, s, D);
+            (void)hipMemcpyAsync(w->h_state, &b->st->inner_done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+        });
+        if (rc) return rc;
+        rc = ba_capture(s, &w->gRound, [&] {
+            hipLaunchKernelGGL(k_cost, dim3(L.cb), blk, 0, s, D, 0);
+            hipLaunchKernelGGL(k_control, dim3(1), blk, 0, s, D);
+        });
+        if (rc) return rc;
+        rc = ba_capture(s, &w->gFinish, [&] {
+            hipLaunchKernelGGL(k_cost_force, dim3(L.cb), blk, 0, s, D);
+            hipLaunchKernelGGL(k_finish, dim3(1), blk, 0, s, D, b->stats);
+        });
+        if (rc) return rc;
+        w->key = key;
+        w->haveGraphs = true;
+    }
+    CS_HIP(hipGraphLaunch(w->gHead, s));
+    for (int outer = 0; outer < J.maxIter; ++outer) {
+        if (outer > 0) CS_HIP(hipGraphLaunch(w->gRound, s));
+        for (int done = 0; done < J.innerMaxIter; done += w->chunk) {
+            CS_HIP(hipGraphLaunch(w->gChunk, s));
+            CS_HIP(hipStreamSynchronize(s));
+            if (w->h_state[0] || w->h_state[1]) break;  // inner_done / all_done
+        }
+        CS_HIP(hipGraphLaunch(w->gTail, s));
+        CS_HIP(hipStreamSynchronize(s));
+        if (w->h_state[1]) break;
+    }
+    CS_HIP(hipGraphLaunch(w->gFinish, s));
+    CS_HIP(hipStreamSynchronize(s));
+    return CS_OK;
+}
+
+static void ba_worker_main(cs_ba* b, BaWorker* w) {
+    for (;;) {
+        BaAsyncJob J;
+        {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return w->stop || !w->q.empty(); });
+            if (w->q.empty()) return;  // stop requested and nothing left
+            J = w->q.front();
+            w->q.pop_front();
+        }
+        const int rc = ba_worker_run(b, w, J);
+        (void)hipEventDestroy(J.ready);
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            if (rc != CS_OK) {
+                w->lastRc = rc;
+                snprintf(w->err, sizeof(w->err), "%s", cs_last_error());
+            }
+            w->inflight -= 1;
+        }
+        w->cvDone.notify_all();
+    }
+}
+
+static void ba_worker_stop(cs_ba* b) {
+    BaWorker* w = b->worker;
+    if (!w) return;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->stop = true;
+    }
+    w->cv.notify_all();
+    if (w->th.joinable()) w->th.join();
+    ba_worker_drop_graphs(b);
+    if (w->h_state) (void)hipHostFree(w->h_state);
+    delete w;
+    b->worker = nullptr;
+}
+
 extern "C" {
 
 cs_ba* cs_ba_create(int device) {
@@ -2060,6 +2519,7 @@ cs_ba* cs_ba_create(int device) {
 void cs_ba_destroy(cs_ba* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
+    ba_worker_stop(b);
     (void)hipStreamSynchronize(b->own_stream);
     ba_free(b);
     (void)hipStreamDestroy(b->own_stream);
@@ -2078,7 +2538,32 @@ int cs_ba_robust_h(cs_ba* b, int C, int P, int nObs, const double* Ks, double* R
         cs_set_error("cs_ba_robust: obs_ptr must start at 0 and end at nObs");
         return CS_ERR_INVALID;
     }
+    if (nCamsCon < 0 || nPtsCon < 0) {
+        cs_set_error("cs_ba_robust: nCamsCon / nPtsCon must not be negative");
+        return CS_ERR_INVALID;
+    }
+    {
+        // obs_ptr monotone; a point must not carry two measurements of the same view (the (point, view) table keeps one
+        // entry per pair: U_j would count both while the Schur terms count one -- an inconsistent reduced system)
+        std::vector<int> seen((size_t)C, 0);
+        for (int i = 0; i < P; ++i) {
+            if (obs_ptr[i + 1] < obs_ptr[i]) {
+                cs_set_error("cs_ba_robust: obs_ptr is not monotone at point %d", i);
+                return CS_ERR_INVALID;
+            }
+            for (int o = obs_ptr[i]; o < obs_ptr[i + 1]; ++o) {
+                const int v = obs_cam[o];
+                if (v < 0 || v >= C) continue;  // reported below
+                if (seen[v] == i + 1) {
+                    cs_set_error("cs_ba_robust: point %d has two measurements with viewId %d", i, v);
+                    return CS_ERR_INVALID;
+                }
+                seen[v] = i + 1;
+            }
+        }
+    }
     CS_HIP(hipSetDevice(b->device));
+    ba_drop_graph(b);  // cached graphs bake in the plan derived from the uploaded topology (e.g. the seg8 kernels)
     int rc = ba_reserve(b, C, P, nObs);
     if (rc) return rc;
     ba_bind_io(b, C, P, nObs);
@@ -2318,6 +2803,10 @@ int cs_ba_dist_buffers(cs_ba* b, void** d_S_rhs, int* n_red, void** d_scal, void
 int cs_ba_download(cs_ba* b, int C, int P, int nObs, double* Rs, double* Ts, double* pts, int* out_outlier,
                    cs_ba_stats* stats) {
     if (!b) return CS_ERR_INVALID;
+    {
+        const int wrc = cs_ba_wait(b);
+        if (wrc) return wrc;
+    }
     CS_HIP(hipSetDevice(b->device));
     CS_HIP(hipDeviceSynchronize());
     if (Rs) CS_HIP(hipMemcpy(Rs, b->Rs, sizeof(double) * 9 * C, hipMemcpyDeviceToHost));
@@ -2327,5 +2816,58 @@ int cs_ba_download(cs_ba* b, int C, int P, int nObs, double* Rs, double* Ts, dou
     if (stats) CS_HIP(hipMemcpy(stats, b->stats, sizeof(cs_ba_stats), hipMemcpyDeviceToHost));
     return CS_OK;
 }
+
+// bundleAdjustRobust as the reference runs it: on a worker thread next to tracking (src/app/SL_CoSLAM.cpp:1702-1784).
+// The call records an event on `after_stream` (the solve starts once everything enqueued there so far -- e.g. the
+// kernels producing d_Rs0 / d_Ts0 / d_pts0 -- has finished), queues the request for the workspace's thread and returns.
+// Requests of one workspace run in order.  cs_ba_wait blocks until all of them are done; cs_ba_download then reads
+// the result.  Same arithmetic and results as cs_ba_solve_dev; only the schedule differs (chunks of LM steps with an
+// early exit between them instead of the whole schedule up front).
+int cs_ba_solve_async(cs_ba* b, void* after_stream, int C, int P, int nObs, const double* d_Rs0, const double* d_Ts0,
+                      const double* d_pts0, int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter) {
+    if (!b || C > b->capC || P > b->capP || nObs > b->capObs) {
+        cs_set_error("cs_ba_solve_async: workspace not uploaded for this size");
+        return CS_ERR_INVALID;
+    }
+    if (nCamsCon < 0 || nPtsCon < 0 || maxIter < 0 || innerMaxIter < 0) {
+        cs_set_error("cs_ba_solve_async: negative count");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(b->device));
+    if (!b->worker) {
+        BaWorker* w = new BaWorker();
+        if (hipHostMalloc((void**)&w->h_state, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+            delete w;
+            cs_set_error("cs_ba_solve_async: cannot allocate the pinned state word");
+            return CS_ERR_ALLOC;
+        }
+        w->h_state[0] = w->h_state[1] = 0;
+        b->worker = w;
+        w->th = std::thread(ba_worker_main, b, w);
+    }
+    BaAsyncJob J = {C, P, nObs, nCamsCon, nPtsCon, maxIter, innerMaxIter, maxErr, d_Rs0, d_Ts0, d_pts0, nullptr};
+    CS_HIP(hipEventCreateWithFlags(&J.ready, hipEventDisableTiming));
+    CS_HIP(hipEventRecord(J.ready, (hipStream_t)after_stream));
+    {
+        std::lock_guard<std::mutex> lk(b->worker->mu);
+        b->worker->q.push_back(J);
+        b->worker->inflight += 1;
+    }
+    b->worker->cv.notify_one();
+    return CS_OK;
+}
+
+int cs_ba_wait(cs_ba* b) {
+    if (!b) return CS_ERR_INVALID;
+    BaWorker* w = b->worker;
+    if (!w) return CS_OK;
+    std::unique_lock<std::mutex> lk(w->mu);
+    w->cvDone.wait(lk, [&] { return w->inflight == 0; });
+    const int rc = w->lastRc;
+    if (rc != CS_OK) cs_set_error("cs_ba_solve_async: %s", w->err);
+    w->lastRc = CS_OK;
+    return rc;
+}
+
 
 }  // extern "C"

@@ -1,0 +1,25 @@
+"""On-device hand-back of the tracker's dest[] to the pose stage (cs_klt_handback_dev): what GPUKLT::addToFeaturePoints
+(reference src/tracking/GPUKLT.cpp:36-60), SingleSLAM::chooseStaticFeatPts (src/app/SL_SingleSLAM.cpp:345-397) and the
+Ms / ms packing of SingleSLAM::poseUpdate3D (:620-640) do on the host with pointer lists, for all cameras in one launch."""
+import ctypes as C
+
+from ._lib import check, lib
+from .pose import IntraCamPoseOption  # noqa: F401  (layout of the `opt` record)
+
+
+class HandbackCam(C.Structure):
+    """== cs_handback_cam (include/coslam_hip.h): device pointers of one camera."""
+
+    _fields_ = [(n, C.c_void_p) for n in ("dest", "K", "kud", "mapPts", "isStatic", "slot2map", "trackLen", "xy", "state",
+                                          "selBlk", "Ms", "ms", "sel", "npts", "opt")]
+
+
+def handback_dev(stream_ptr, cams, N, W, H, nColBlk=16, nRowBlk=12, ptsStride=192, device=0):
+    """cams: list of dicts of device pointers (ints; missing / None = NULL) with the field names of cs_handback_cam."""
+    arr = (HandbackCam * len(cams))()
+    for a, c in zip(arr, cams):
+        for n, _ in HandbackCam._fields_:
+            v = c.get(n)
+            setattr(a, n, int(v) if v else None)
+    check(lib().cs_klt_handback_dev(int(device), C.c_void_p(stream_ptr), len(cams), arr, int(N), int(W), int(H),
+                                    int(nColBlk), int(nRowBlk), int(ptsStride)), "cs_klt_handback_dev")

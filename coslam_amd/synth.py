@@ -175,3 +175,121 @@ def make_ba_problem(n_cams=10, n_pts=500, W=640, H=480, noise=0.5, rot_pert=0.01
     pts0[:n_pts_con] = pts[:n_pts_con]
     return dict(K=K, Ks=np.repeat(K[None], n_cams, 0), Rs_gt=Rs, ts_gt=ts, pts_gt=pts, Rs0=Rs0, ts0=ts0, pts0=pts0,
                 obs_cam=obs_cam, obs_pt=obs_pt, obs_xy=obs_xy_noisy, obs_xy_clean=obs_xy, is_outlier=is_out)
+
+
+# ---- the headline workload's BA problems (8 synchronised cameras) ------------------------------------------------
+def make_joint_ba_problem(scene, n_kf=5, kf_step=5, pts_per_cam=500, pool=1500, noise=0.5, rot_pert=0.005,
+                          trans_pert=0.02, pt_pert=0.05, outlier_frac=0.03, outlier_mag=20.0, n_old_kf=2, n_pts_con=2,
+                          seed=0xC051A + 7):
+    """The joint local BA CoSLAM queues at a key frame (reference src/app/SL_CoSLAM.cpp:1345,1731-1784 ->
+    RobustBundleRTS, src/app/SL_CoSLAMRobustBA.cpp:37-78,109-165): the last `n_kf` key frames of ALL cameras are the
+    cameras of ONE problem, ordered key frame by key frame (addKeyFrames), the first numCams * n_old_kf of them held
+    fixed; the points are the static map points seen in those key frames, each measured in every (key frame, camera) it
+    was tracked in; points with a single measurement are dropped (parseInputs: nfpts > 1).
+    Same dict layout as make_ba_problem, plus n_cams_con / n_pts_con."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    nc = scene.C
+    C = n_kf * nc
+    K = scene.K
+    Rs, ts = [], []
+    for kf in range(n_kf):
+        for c in range(nc):
+            R, t = scene.pose(c, kf * kf_step)
+            Rs.append(R)
+            ts.append(t)
+    Rs, ts = np.array(Rs), np.array(ts)
+    # a pool of map points; every camera tracks `pts_per_cam` of those it sees in all its key frames
+    vis_all = []
+    for c in range(nc):
+        v = np.ones(scene.P, dtype=bool)
+        for kf in range(n_kf):
+            _, vk = scene.project(c, kf * kf_step)
+            v &= vk
+        vis_all.append(v)
+    seen = np.nonzero(np.any(vis_all, axis=0))[0]
+    pool_idx = rng.choice(seen, size=min(pool, len(seen)), replace=False)
+    tracked = np.zeros((nc, len(pool_idx)), dtype=bool)
+    for c in range(nc):
+        cand = np.nonzero(vis_all[c][pool_idx])[0]
+        pick = rng.choice(cand, size=min(pts_per_cam, len(cand)), replace=False)
+        tracked[c, pick] = True
+    keep = np.nonzero(tracked.sum(0) * n_kf > 1)[0]
+    pts = scene.points[pool_idx[keep]]
+    tracked = tracked[:, keep]
+    obs_cam, obs_pt, obs_xy = [], [], []
+    for i in range(len(pts)):
+        for kf in range(n_kf):
+            for c in range(nc):
+                if not tracked[c, i]:
+                    continue
+                j = kf * nc + c
+                X = Rs[j] @ pts[i] + ts[j]
+                obs_cam.append(j)
+                obs_pt.append(i)
+                obs_xy.append((K @ X)[:2] / X[2])
+    obs_cam = np.array(obs_cam, dtype=np.int32)
+    obs_pt = np.array(obs_pt, dtype=np.int32)
+    obs_xy = np.array(obs_xy, dtype=np.float64)
+    n_obs = len(obs_cam)
+    noisy = obs_xy + noise * rng.standard_normal(obs_xy.shape)
+    is_out = rng.uniform(size=n_obs) < outlier_frac
+    noisy[is_out] += outlier_mag * rng.choice([-1.0, 1.0], size=(n_obs, 2))[is_out]
+    n_con = nc * n_old_kf
+    Rs0 = np.array([Rs[j] @ rodrigues(rot_pert * rng.standard_normal(3)) for j in range(C)])
+    ts0 = ts + trans_pert * rng.standard_normal(ts.shape)
+    pts0 = pts + pt_pert * rng.standard_normal(pts.shape)
+    Rs0[:n_con], ts0[:n_con] = Rs[:n_con], ts[:n_con]
+    pts0[:n_pts_con] = pts[:n_pts_con]
+    return dict(K=K, Ks=np.repeat(K[None], C, 0), Rs_gt=Rs, ts_gt=ts, pts_gt=pts, Rs0=Rs0, ts0=ts0, pts0=pts0,
+                obs_cam=obs_cam, obs_pt=obs_pt, obs_xy=noisy, obs_xy_clean=obs_xy, is_outlier=is_out,
+                n_cams_con=n_con, n_pts_con=n_pts_con)
+
+
+def make_intercam_problem(scene, frame=10, n_static=192, n_dyn=60, noise=0.5, rot_pert=0.004, trans_pert=0.015,
+                          dyn_pert=0.05, outlier_frac=0.02, outlier_mag=20.0, seed=0xC051A + 11):
+    """The inter-camera pose solve (reference src/app/SL_InterCamPoseEstimator.cpp:18-95): cameras = the current pose
+    of every camera, all free (nCamsCon 0); points = per camera the static feature points chosen for pose estimation
+    (<= 192, ONE measurement each, held fixed: nPtsCon = numStatic) followed by <= 61 dynamic points measured in every
+    camera that sees them (free).  bundleAdjustRobust(0, ..., numStatic, ..., sigma 6, maxIter 3, 40 inner)."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    nc = scene.C
+    K = scene.K
+    Rs, ts = zip(*[scene.pose(c, frame) for c in range(nc)])
+    Rs, ts = np.array(Rs), np.array(ts)
+    uv, vis = zip(*[scene.project(c, frame) for c in range(nc)])
+    pts, obs_cam, obs_pt, obs_xy = [], [], [], []
+    used = np.zeros(scene.P, dtype=bool)
+    for c in range(nc):
+        cand = np.nonzero(vis[c])[0]
+        pick = rng.choice(cand, size=min(n_static, len(cand)), replace=False)
+        used[pick] = True
+        for p in pick:
+            obs_cam.append(c)
+            obs_pt.append(len(pts))
+            obs_xy.append(uv[c][p])
+            pts.append(scene.points[p])
+    n_stat = len(pts)
+    nvis = np.sum(vis, axis=0)
+    cand = np.nonzero((nvis >= 2) & ~used)[0]
+    for p in rng.choice(cand, size=min(n_dyn, len(cand)), replace=False):
+        for c in range(nc):
+            if vis[c][p]:
+                obs_cam.append(c)
+                obs_pt.append(len(pts))
+                obs_xy.append(uv[c][p])
+        pts.append(scene.points[p])
+    pts = np.array(pts)
+    obs_cam = np.array(obs_cam, dtype=np.int32)
+    obs_pt = np.array(obs_pt, dtype=np.int32)
+    obs_xy = np.array(obs_xy, dtype=np.float64)
+    n_obs = len(obs_cam)
+    noisy = obs_xy + noise * rng.standard_normal(obs_xy.shape)
+    is_out = rng.uniform(size=n_obs) < outlier_frac
+    noisy[is_out] += outlier_mag * rng.choice([-1.0, 1.0], size=(n_obs, 2))[is_out]
+    Rs0 = np.array([Rs[c] @ rodrigues(rot_pert * rng.standard_normal(3)) for c in range(nc)])
+    ts0 = ts + trans_pert * rng.standard_normal(ts.shape)
+    pts0 = pts.copy()
+    pts0[n_stat:] += dyn_pert * rng.standard_normal((len(pts) - n_stat, 3))
+    return dict(K=K, Ks=np.repeat(K[None], nc, 0), Rs_gt=Rs, ts_gt=ts, pts_gt=pts, Rs0=Rs0, ts0=ts0, pts0=pts0,
+                obs_cam=obs_cam, obs_pt=obs_pt, obs_xy=noisy, obs_xy_clean=obs_xy, is_outlier=is_out,
+                n_cams_con=0, n_pts_con=n_stat, n_static=n_stat, n_dynamic=len(pts) - n_stat)

@@ -203,6 +203,39 @@ int cs_pose_intracam_batch_dev(int device, void* hip_stream, int nProb, int ptsS
                                cs_pose_option* opt, int* ok);
 
 /* ------------------------------------------------------------------------------------------
+ * Hand-back of the tracker's output to the pose stage, on the device (every camera of a group in one launch)
+ * ------------------------------------------------------------------------------------------
+ * Replaces GPUKLT::addToFeaturePoints (src/tracking/GPUKLT.cpp:36-60: x W,H -> undistorPoint -> drop when out >= W | H
+ * -> FeaturePoints::add + Track2D add / clear), SingleSLAM::chooseStaticFeatPts (src/app/SL_SingleSLAM.cpp:345-397: one
+ * track per (W / nColBlk) x (H / nRowBlk) block, a mapped one first, else the longest) and the Ms / ms packing of
+ * SingleSLAM::poseUpdate3D (:620-640).  The reference allocates one FeaturePoint per feature per frame on the host
+ * (src/slam/SL_FeaturePoints.cpp:81-87); here dest[] stays in HBM and the outputs are structure-of-arrays records
+ * plus the packed correspondences cs_pose_intracam_batch_dev consumes.  All pointers are DEVICE pointers.
+ * undistorPoint itself is external (LibVisualSLAM); our definition: normalise with K, scale by
+ * 1 + sum_i k_ud[i] r^(2(i+1)), i = 0..6, map back with K (k_ud = 0: identity). */
+typedef struct cs_handback_cam {
+    const cs_klt_feature* dest; /* N: what cs_klt_*_dev wrote for this frame */
+    const double* K;            /* 9, row-major */
+    const double* kud;          /* 7 (GPUKLT::m_kud, src/tracking/GPUKLT.h:44-47) */
+    const double* mapPts;       /* P x 3: MapPoint::M of the point a slot is associated with */
+    const unsigned char* isStatic; /* N or NULL: slots classified static without a map point (FeaturePoint::type) */
+    int* slot2map;              /* N in/out: map point index of the slot's track or -1; new / dead slots are reset to -1 */
+    int* trackLen;              /* N in/out: Track2D length (0 = empty) */
+    double* xy;                 /* 2N in/out: undistorted pixel, x[N] then y[N]; kept for a slot dropped by the >= W|H rule */
+    int* state;                 /* N out: 0 tracked, 1 new, -1 dead, -2 dropped by the out >= W | H rule */
+    int* selBlk;                /* nColBlk * nRowBlk out or NULL: chosen slot of every block (-1: none), featPts order */
+    double* Ms;                 /* ptsStride x 3 out */
+    double* ms;                 /* ptsStride x 2 out */
+    int* sel;                   /* ptsStride out: slot of every packed correspondence */
+    int* npts;                  /* 1 out */
+    cs_pose_option* opt;        /* 1 out or NULL: reset to IntraCamPoseOption() for the pose solve that follows */
+} cs_handback_cam;
+/* cams: HOST array of nCams (<= 16) records of device pointers.  nColBlk x nRowBlk = 16 x 12 in CoSLAM
+ * (src/app/SL_SingleSLAM.h:36-37); ptsStride >= the most correspondences wanted per camera (192). */
+int cs_klt_handback_dev(int device, void* hip_stream, int nCams, const cs_handback_cam* cams, int N, int W, int H,
+                        int nColBlk, int nRowBlk, int ptsStride);
+
+/* ------------------------------------------------------------------------------------------
  * Robust multi-camera bundle adjustment
  * ------------------------------------------------------------------------------------------ */
 
@@ -237,6 +270,14 @@ int cs_ba_upload(cs_ba* b, int C, int P, int nObs, const double* Ks, const doubl
  * initial estimate d_Rs0/d_Ts0/d_pts0; no host synchronisation */
 int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const double* d_Rs0, const double* d_Ts0,
                     const double* d_pts0, int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter);
+/* The same solve the way the reference runs it -- on a worker thread next to tracking (src/app/SL_CoSLAM.cpp:1702-1784):
+ * records an event on after_stream (the solve starts once the work enqueued there so far has finished), queues the
+ * request for the workspace's own thread and returns.  That thread enqueues the schedule in chunks of LM steps and
+ * stops at convergence, where cs_ba_solve_dev issues all maxIter x innerMaxIter steps up front.  Requests of one
+ * workspace run in order; cs_ba_wait blocks until they are all done (cs_ba_download waits too). */
+int cs_ba_solve_async(cs_ba* b, void* after_stream, int C, int P, int nObs, const double* d_Rs0, const double* d_Ts0,
+                      const double* d_pts0, int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter);
+int cs_ba_wait(cs_ba* b);
 /* synchronise and copy the workspace's current estimate back (any pointer may be NULL) */
 /* Distributed solve (one process per GPU, points sliced by rank; SURVEY.md 8e collective 2): the reduced camera system
  * S || rhs is all-reduced once per LM step by the caller between the phases below; every launch is asynchronous on

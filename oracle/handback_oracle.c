@@ -1,0 +1,107 @@
+/*
+ * oracle/handback_oracle.c -- CPU restatement of the host glue between the tracker and the pose solve.
+ *
+ * TEST INFRASTRUCTURE ONLY (see klt_oracle.h).  Follows, statement by statement:
+ *   GPUKLT::addToFeaturePoints        /root/reference/src/tracking/GPUKLT.cpp:36-60
+ *   SingleSLAM::chooseStaticFeatPts   /root/reference/src/app/SL_SingleSLAM.cpp:345-397
+ *   SingleSLAM::poseUpdate3D          /root/reference/src/app/SL_SingleSLAM.cpp:620-640 (the Ms / ms packing)
+ * with the pointer lists (FeaturePoints, Track2D) reduced to what those statements read: per slot the track length, the
+ * tail point's undistorted pixel and its map point.
+ *
+ * PARITY UNPINNED for undistorPoint: it lives in un-vendored LibVisualSLAM (only the call, GPUKLT.cpp:45, and the
+ * 7-vector k_ud, GPUKLT.h:44-47, are in the reference).  Definition used here and in coslam_amd/csrc/handback.hip:
+ * normalise with K, scale by 1 + sum_{i=0..6} k_ud[i] r^(2(i+1)), map back with K; k_ud = 0 is the identity.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "klt_oracle.h"
+
+void ohb_undistort_point(const double K[9], const double kud[7], const double in[2], double out[2]) {
+    const double yn = (in[1] - K[5]) / K[4];
+    const double xn = ((in[0] - K[2]) - K[1] * yn) / K[0];
+    const double r2 = xn * xn + yn * yn;
+    double f = kud[6];
+    for (int i = 5; i >= 0; --i) f = f * r2 + kud[i];
+    f = 1.0 + f * r2;
+    const double xu = xn * f, yu = yn * f;
+    out[0] = (K[0] * xu + K[1] * yu) + K[2];
+    out[1] = K[4] * yu + K[5];
+}
+
+/* One frame of one camera.  In/out per slot: slot2map (FeaturePoint::mpt of the track's tail, -1 = none), trackLen
+ * (Track2D::length(), 0 = empty), xy (tail point, x[N] then y[N]).  Out: state[N] (0 tracked, 1 new, -1 dead, -2 dropped),
+ * selBlk[nColBlk * nRowBlk] (featPts of chooseStaticFeatPts in block order, -1 = none), and the packed 3D-2D
+ * correspondences (at most ptsStride).  Returns the number of correspondences. */
+int ohb_handback(int N, int W, int H, const okl_tracked_feature* features, const double K[9], const double kud[7],
+                 const double* mapPts, const unsigned char* isStatic, int* slot2map, int* trackLen, double* xy, int* state,
+                 int nColBlk, int nRowBlk, int* selBlk, int ptsStride, double* Ms, double* ms, int* sel) {
+    /* ---- GPUKLT::addToFeaturePoints, GPUKLT.cpp:36-60 */
+    for (int i = 0; i < N; i++) {
+        if (features[i].status >= 0) {
+            double in[2], out[2];
+            in[0] = features[i].pos[0] * W; /* float * int -> float, then widened (:43-44) */
+            in[1] = features[i].pos[1] * H;
+            ohb_undistort_point(K, kud, in, out); /* :45 */
+            if (out[0] >= W || out[1] >= H) {     /* :46-47 continue: neither added nor cleared */
+                state[i] = -2;
+                continue;
+            }
+            xy[i] = out[0]; /* ips.add(m_frame, m_camId, out[0], out[1]) */
+            xy[N + i] = out[1];
+            if (features[i].status == 0) {
+                trackLen[i] += 1; /* m_tks[i].add(p) */
+            } else {
+                trackLen[i] = 1; /* m_tks[i].clear(); m_tks[i].add(p): a new, unmapped feature point */
+                slot2map[i] = -1;
+            }
+            state[i] = features[i].status;
+        } else {
+            trackLen[i] = 0; /* m_tks[i].clear() */
+            slot2map[i] = -1;
+            state[i] = -1;
+        }
+    }
+    /* ---- SingleSLAM::chooseStaticFeatPts, SL_SingleSLAM.cpp:345-397 */
+    const int blkW = W / nColBlk, blkH = H / nRowBlk; /* :270-271 */
+    const int len = nRowBlk * nColBlk;
+    int* tracks = (int*)malloc(sizeof(int) * (size_t)len);
+    for (int b = 0; b < len; b++) tracks[b] = -1;
+    for (int i = 0; i < N; i++) {
+        if (trackLen[i] == 0) continue; /* tk->empty() */
+        const int mapped = slot2map[i] >= 0;
+        if (mapped || (isStatic && isStatic[i])) { /* fp->type == STATIC || (fp->mpt && fp->mpt->isCertainStatic()) */
+            int bx = (int)(xy[i] / blkW);
+            int by = (int)(xy[N + i] / blkH);
+            if (bx >= nColBlk || by >= nRowBlk) continue;
+            if (bx < 0 || by < 0) continue; /* (the reference indexes out of bounds here; never happens for tracked points) */
+            int bi = by * nColBlk + bx;
+            int old = tracks[bi];
+            if (old < 0) {
+                tracks[bi] = i;
+            } else if (!(slot2map[old] >= 0)) { /* !fpOld->mpt */
+                if (mapped) {
+                    tracks[bi] = i;
+                } else if (trackLen[old] < trackLen[i]) {
+                    tracks[bi] = i;
+                }
+            }
+        }
+    }
+    /* ---- poseUpdate3D, :620-640: the mapped ones, in featPts order */
+    int n = 0;
+    for (int b = 0; b < len; b++) {
+        if (selBlk) selBlk[b] = tracks[b];
+        int i = tracks[b];
+        if (i < 0 || slot2map[i] < 0) continue;
+        if (n < ptsStride) {
+            sel[n] = i;
+            ms[2 * n] = xy[i];
+            ms[2 * n + 1] = xy[N + i];
+            memcpy(Ms + 3 * n, mapPts + 3 * (size_t)slot2map[i], sizeof(double) * 3);
+        }
+        n++;
+    }
+    free(tracks);
+    return n < ptsStride ? n : ptsStride;
+}

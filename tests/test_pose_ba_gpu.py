@@ -156,3 +156,120 @@ def test_ba_edge_cases(hip):
     bad[0] = 99
     with pytest.raises(coslam_amd.CoslamHipError):
         coslam_amd.bundleAdjustRobust(2, pr["Ks"], Rs2, Ts2, 2, pts2, (ptr2, bad, xy2), 6.0, 1, 1)
+
+
+# ---- the headline workload's two bundleAdjustRobust calls, and the solver / schedule they run through ---------------
+def _headline_problems():
+    from coslam_amd.synth import make_intercam_problem, make_joint_ba_problem
+
+    sc = Scene(8, 640, 480, 7000, seed=0xC051A + 2, sigma=1.0)
+    return make_joint_ba_problem(sc, seed=0xC051A + 9), make_intercam_problem(sc, seed=0xC051A + 13)
+
+
+def _csr(pr):
+    return oracle.csr_by_point(len(pr["pts0"]), pr["obs_pt"], pr["obs_cam"], pr["obs_xy"])[:3]
+
+
+def _check_vs_oracle(pr, ptr, cam, xy, ncon, npcon, maxErr, maxIter, inner, Rs, Ts, pts, out_g, st_g):
+    R_o, T_o, M_o, out_o, st_o = oracle.ba_robust(pr["Ks"], pr["Rs0"], pr["ts0"], pr["pts0"], ptr, cam, xy, ncon, npcon,
+                                                  maxErr, maxIter, inner)
+    assert np.array_equal(out_g, out_o), f"{(out_g != out_o).sum()} outlier flags differ"
+    assert st_g.nOuter == st_o.nOuter and st_g.nIterTotal == st_o.nIterTotal
+    sane = np.linalg.norm(M_o, axis=1) < 1e3
+    scale = max(1.0, np.abs(M_o[sane]).max())
+    assert np.max(np.abs(Rs - R_o)) < 1e-6 and np.max(np.abs(Ts - T_o)) < 1e-6 * scale
+    assert np.max(np.abs(pts[sane] - M_o[sane])) < 1e-6 * scale
+    assert abs(st_g.cost - st_o.cost) <= 1e-7 * max(1.0, st_o.cost)
+
+
+def test_joint_local_ba_of_the_eight_camera_rig_matches_oracle(hip):
+    """RobustBundleRTS at a key frame (src/app/SL_CoSLAMRobustBA.cpp:109-180 via SL_CoSLAM.cpp:1731-1784): 5 key frames x 8
+    cameras = 40 cameras, the 16 oldest fixed, 2 points fixed, maxIter 2 / inner 10: order-144 reduced system."""
+    joint, _ = _headline_problems()
+    ptr, cam, xy = _csr(joint)
+    Rs, Ts, pts = joint["Rs0"].copy(), joint["ts0"].copy(), joint["pts0"].copy()
+    out, st = coslam_amd.bundleAdjustRobust(joint["n_cams_con"], joint["Ks"], Rs, Ts, joint["n_pts_con"], pts, (ptr, cam, xy),
+                                            6.0, 2, 10)
+    _check_vs_oracle(joint, ptr, cam, xy, joint["n_cams_con"], joint["n_pts_con"], 6.0, 2, 10, Rs, Ts, pts, out, st)
+    assert np.max(np.abs(Ts - joint["ts_gt"])) < 0.02  # and it actually solves the problem
+
+
+def test_inter_camera_pose_solve_of_the_eight_camera_rig_matches_oracle(hip):
+    """InterCamPoseEstimator::apply (src/app/SL_InterCamPoseEstimator.cpp:92-95): 8 cameras free, 1536 single-view static
+    points fixed, 60 dynamic points free, sigma 6, maxIter 3, 40 inner steps: order-48 reduced system."""
+    _, ic = _headline_problems()
+    ptr, cam, xy = _csr(ic)
+    Rs, Ts, pts = ic["Rs0"].copy(), ic["ts0"].copy(), ic["pts0"].copy()
+    out, st = coslam_amd.bundleAdjustRobust(0, ic["Ks"], Rs, Ts, ic["n_static"], pts, (ptr, cam, xy), 6.0, 3, 40)
+    _check_vs_oracle(ic, ptr, cam, xy, 0, ic["n_static"], 6.0, 3, 40, Rs, Ts, pts, out, st)
+    assert np.array_equal(pts[: ic["n_static"]], ic["pts0"][: ic["n_static"]])  # the static points are held
+
+
+@pytest.mark.parametrize("n_cams,ncon", [(9, 2), (10, 2), (13, 2), (18, 2), (26, 2), (34, 2), (31, 2), (24, 0), (34, 2)])
+def test_ba_orders_of_the_lds_blocked_cholesky(hip, n_cams, ncon):
+    """Reduced systems of order 42 ... 176 run through k_solve_blocked (packed 16 x 16 blocks in LDS; order 192 takes the
+    HBM-blocked path): every block count
+    3 <= NB <= 11 incl. orders that are not multiples of 16 (identity padding)."""
+    kw = dict(n_cams=n_cams, n_pts=260, visibility=0.55, seed=40 + n_cams, n_cams_con=ncon, n_pts_con=3 if ncon else 40)
+    pr, ptr, cam, xy = ba_inputs(**kw)
+    Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+    out, st = coslam_amd.bundleAdjustRobust(ncon, pr["Ks"], Rs, Ts, kw["n_pts_con"], pts, (ptr, cam, xy), 6.0, 2, 8)
+    _check_vs_oracle(pr, ptr, cam, xy, ncon, kw["n_pts_con"], 6.0, 2, 8, Rs, Ts, pts, out, st)
+
+
+def test_async_worker_schedule_gives_the_up_front_schedule_bit_for_bit(hip):
+    """cs_ba_solve_async (the workspace's own thread enqueues chunks of LM steps and stops at convergence -- the reference's
+    BA worker thread, src/app/SL_CoSLAM.cpp:1702-1784) == cs_ba_solve_dev (whole schedule up front): identical bits, also
+    when several requests are queued back to back and when the run converges long before the budget."""
+    import torch
+
+    joint, ic = _headline_problems()
+    dev = torch.device("cuda:0")
+    for pr, ncon, npcon, maxIter, inner in ((joint, joint["n_cams_con"], joint["n_pts_con"], 2, 10),
+                                            (ic, 0, ic["n_static"], 3, 40)):
+        ptr, cam, xy = _csr(pr)
+        d_R = torch.from_numpy(pr["Rs0"].reshape(-1).copy()).to(dev)
+        d_T = torch.from_numpy(pr["ts0"].reshape(-1).copy()).to(dev)
+        d_M = torch.from_numpy(pr["pts0"].reshape(-1).copy()).to(dev)
+        res = []
+        for mode in ("dev", "async", "async3"):
+            ws = coslam_amd.BAWorkspace(0)
+            ws.upload(pr["Ks"], pr["Rs0"], pr["ts0"], pr["pts0"], ptr, cam, xy)
+            s = torch.cuda.current_stream().cuda_stream
+            if mode == "dev":
+                ws.solve_dev(s, d_R.data_ptr(), d_T.data_ptr(), d_M.data_ptr(), ncon, npcon, 6.0, maxIter, inner)
+            else:
+                for _ in range(3 if mode == "async3" else 1):   # queued requests run in order, each from the same start
+                    ws.solve_async(s, d_R.data_ptr(), d_T.data_ptr(), d_M.data_ptr(), ncon, npcon, 6.0, maxIter, inner)
+                ws.wait()
+            R, T, M, out, st = ws.download()
+            res.append((R.copy(), T.copy(), M.copy(), out.copy(), (st.cost0, st.cost, st.nIterTotal, st.nOuter, st.nOutliers)))
+            ws.close()
+        for other in res[1:]:
+            for a, b in zip(res[0][:4], other[:4]):
+                assert np.array_equal(a, b)
+            assert res[0][4] == other[4]
+        assert res[0][4][2] <= maxIter * inner
+
+
+def test_ba_rejects_malformed_problems(hip):
+    """Negative fixed counts, a non-monotone obs_ptr and a point with two measurements of one view are errors, not
+    out-of-bounds writes or silently inconsistent systems."""
+    pr, ptr, cam, xy = ba_inputs(n_cams=4, n_pts=30, outlier_frac=0.0, seed=8)
+
+    def call(ncon=2, npcon=2, ptr_=ptr, cam_=cam):
+        Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+        return coslam_amd.bundleAdjustRobust(ncon, pr["Ks"], Rs, Ts, npcon, pts, (ptr_, cam_, xy), 6.0, 1, 2)
+
+    call()
+    for kw in (dict(ncon=-1), dict(npcon=-3)):
+        with pytest.raises(coslam_amd.CoslamHipError):
+            call(**kw)
+    bad_ptr = ptr.copy()
+    bad_ptr[5], bad_ptr[6] = ptr[6], ptr[5]
+    with pytest.raises(coslam_amd.CoslamHipError):
+        call(ptr_=bad_ptr)
+    dup = cam.copy()
+    dup[ptr[3] + 1] = dup[ptr[3]]
+    with pytest.raises(coslam_amd.CoslamHipError):
+        call(cam_=dup)
