@@ -111,9 +111,9 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s):
         o.advanceFrame()
         trk.append(o)
         s2m.append(associate(sc, c, order[0], d))
-        tl.append(np.zeros(N_FEAT, dtype=np.int32))
+        tl.append(np.full(2 * N_FEAT, -1, dtype=np.int32))
         xy.append(np.zeros(2 * N_FEAT))
-        oracle.handback(d, W, H, sc.K, np.zeros(7), sc.points, s2m[c], tl[c], xy[c])
+        oracle.handback(d, W, H, sc.K, np.zeros(7), sc.points, s2m[c], tl[c], xy[c], 0)
         s2m[c][:] = associate(sc, c, order[0], d)   # (the first hand-back resets new tracks: restore the map)
         R, t = sc.pose(c, order[0])
         Rc.append(R.copy())
@@ -122,28 +122,28 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s):
     iptr, icam, ixy = csr(ic)
     kud = np.zeros(7)
 
-    def cam_step(c, f):
+    def cam_step(c, f, frame_no):
         _, d = trk[c].redetect(frames[c][f])
         trk[c].advanceFrame()
-        hb = oracle.handback(d, W, H, sc.K, kud, sc.points, s2m[c], tl[c], xy[c])
+        hb = oracle.handback(d, W, H, sc.K, kud, sc.points, s2m[c], tl[c], xy[c], frame_no)
         if hb["npts"] >= 6:
             ok, R, t, _ = oracle.intracam_estimate(sc.K, Rc[c], tc[c], hb["npts"], None, hb["Ms"], hb["ms"], 10.0)
             if ok:
                 Rc[c], tc[c] = R, t
 
-    def run_cams(cams, f):
+    def run_cams(cams, f, frame_no):
         for c in cams:
-            cam_step(c, f)
+            cam_step(c, f, frame_no)
 
     t_start = time.perf_counter()
     n = 0
     while True:
         f = order[(n + 1) % len(order)]
         if n_threads <= 1:
-            run_cams(range(N_CAMS), f)
+            run_cams(range(N_CAMS), f, n + 1)
         else:
             parts = [list(range(N_CAMS))[q::n_threads] for q in range(n_threads)]
-            th = [threading.Thread(target=run_cams, args=(p, f)) for p in parts if p]
+            th = [threading.Thread(target=run_cams, args=(p, f, n + 1)) for p in parts if p]
             for x in th:
                 x.start()
             for x in th:
@@ -218,7 +218,7 @@ def main():
     d_kud = torch.zeros(7, dtype=torch.float64, device=dev)
     d_map = torch.from_numpy(sc.points.copy()).to(dev)
     d_slot2map = torch.full((nc, N_FEAT), -1, dtype=torch.int32, device=dev)
-    d_tracklen = torch.zeros((nc, N_FEAT), dtype=torch.int32, device=dev)
+    d_trackspan = torch.full((nc, 2 * N_FEAT), -1, dtype=torch.int32, device=dev)
     d_xy = torch.zeros((nc, 2 * N_FEAT), dtype=torch.float64, device=dev)
     d_state = torch.zeros((nc, N_FEAT), dtype=torch.int32, device=dev)
     d_Ms = torch.zeros((nc, PTS_STRIDE, 3), dtype=torch.float64, device=dev)
@@ -279,7 +279,7 @@ def main():
             except Exception as ex:  # noqa: BLE001 -- fall back to torch.distributed collectives, never break the bench
                 print(f"bench: native RCCL communicator unavailable ({ex}); using torch.distributed", file=sys.stderr)
                 native = None
-        xchg = multicam.CameraExchange(N_FEAT * nc, dev, native=native)
+        xchg = multicam.CameraExchange(N_FEAT * nc, dev, native=native, cams_per_rank=nc)
 
     klt_done = [torch.cuda.Event(), torch.cuda.Event()]
     dest_free = [torch.cuda.Event(), torch.cuda.Event()]
@@ -287,7 +287,7 @@ def main():
 
     def hb_cams(b):
         return [dict(dest=d_dests[b][i].data_ptr(), K=d_K1.data_ptr(), kud=d_kud.data_ptr(), mapPts=d_map.data_ptr(),
-                     slot2map=d_slot2map[i].data_ptr(), trackLen=d_tracklen[i].data_ptr(), xy=d_xy[i].data_ptr(),
+                     slot2map=d_slot2map[i].data_ptr(), trackSpan=d_trackspan[i].data_ptr(), xy=d_xy[i].data_ptr(),
                      state=d_state[i].data_ptr(), Ms=d_Ms[i].data_ptr(), ms=d_ms[i].data_ptr(), sel=d_sel[i].data_ptr(),
                      npts=d_npts[i:i + 1].data_ptr(), opt=d_opt[i].data_ptr()) for i in range(nc)]
 
@@ -297,7 +297,8 @@ def main():
     img_ptrs = [[d_frames[i][f].data_ptr() for i in range(nc)] for f in range(N_FRAMES)]
 
     def pose_leg(b, i):
-        handback_dev(pose_s.cuda_stream, hb_args[b], N_FEAT, W, H, N_COL_BLK, N_ROW_BLK, PTS_STRIDE, device=local_rank)
+        handback_dev(pose_s.cuda_stream, hb_args[b], N_FEAT, W, H, N_COL_BLK, N_ROW_BLK, PTS_STRIDE, device=local_rank,
+                     frame=i)
         src, dst = (i + 1) & 1, i & 1
         intraCamEstimate_batch_dev(pose_s.cuda_stream, nc, PTS_STRIDE, d_K.data_ptr(), d_R[src].data_ptr(),
                                    d_t[src].data_ptr(), d_npts.data_ptr(), 0, d_Ms.data_ptr(), d_ms.data_ptr(), 10.0,
@@ -356,7 +357,8 @@ def main():
         s2m = associate(sc, c, order[0], d)
         d_slot2map[i].copy_(torch.from_numpy(s2m))
     with torch.cuda.stream(pose_s):
-        handback_dev(pose_s.cuda_stream, hb_args[0], N_FEAT, W, H, N_COL_BLK, N_ROW_BLK, PTS_STRIDE, device=local_rank)
+        handback_dev(pose_s.cuda_stream, hb_args[0], N_FEAT, W, H, N_COL_BLK, N_ROW_BLK, PTS_STRIDE, device=local_rank,
+                     frame=0)
     torch.cuda.synchronize()
     for i, c in enumerate(my_cams):   # the first hand-back starts every track as new (unmapped): put the map back
         d = d_dests[0][i].cpu().numpy().view(coslam_amd.KLT_TrackedFeature)

@@ -22,6 +22,7 @@ HIP_SOURCES = [
     "pose.hip",
     "handback.hip",
     "ba.hip",
+    "comm.hip",
 ]
 
 HIPCC_FLAGS = [
@@ -35,6 +36,7 @@ HIPCC_FLAGS = [
     "-Wall",
     "-Wno-unused-value",
     "-Wno-unused-result",
+    "-ldl",
 ]
 
 

@@ -1,0 +1,290 @@
+// comm.hip -- the multi-GPU merge step behind the C-ABI: RCCL collectives over xGMI issued by the library itself.
+//
+// The reference is one process that tracks its cameras serially and reads every camera's features and pose directly
+// (src/app/SL_CoSLAM.cpp:299-305, src/app/SL_InterCamPoseEstimator.cpp:24-37); there is no collective to mirror.  With
+// the cameras sharded over the GPUs of a node (one process per GPU) the same information travels in
+//   collective 1  (every frame)   ONE all-gather of a fixed-size record per camera: N x KLT_TrackedFeature || R || t,
+//                                 packed by ONE kernel for all of the rank's cameras (cs_exchange_allgather_dev);
+//   collective 2  (per LM step)   the joint bundle adjustment sliced by points: ONE all-reduce of S || rhs per LM step,
+//                                 four scalars for the LM / outlier decisions, points and flags once at the end
+//                                 (cs_ba_dist_solve: the whole schedule of coslam_amd/csrc/ba.hip's phase API, enqueued
+//                                 from C++ with no host synchronisation).
+// RCCL is loaded at run time (dlopen): the library keeps loading on a box without it, and a process that already
+// carries PyTorch's copy shares it.  Payloads are small (40 KB per camera; 166 KB of S at order 144): latency-bound on
+// xGMI, so each is ONE collective, never chunked.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <new>
+
+#include "cs_common.h"
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+    decltype(&ncclCommInitRank) commInitRank = nullptr;
+    decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclAllGather) allGather = nullptr;
+    decltype(&ncclAllReduce) allReduce = nullptr;
+    decltype(&ncclGetErrorString) getErrorString = nullptr;
+};
+
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.handle ? &api : nullptr;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+        api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (api.handle) break;
+    }
+    if (!api.handle) {
+        cs_set_error("RCCL not found (dlopen librccl.so.1): %s", dlerror());
+        return nullptr;
+    }
+    api.getUniqueId = (decltype(api.getUniqueId))dlsym(api.handle, "ncclGetUniqueId");
+    api.commInitRank = (decltype(api.commInitRank))dlsym(api.handle, "ncclCommInitRank");
+    api.commDestroy = (decltype(api.commDestroy))dlsym(api.handle, "ncclCommDestroy");
+    api.allGather = (decltype(api.allGather))dlsym(api.handle, "ncclAllGather");
+    api.allReduce = (decltype(api.allReduce))dlsym(api.handle, "ncclAllReduce");
+    api.getErrorString = (decltype(api.getErrorString))dlsym(api.handle, "ncclGetErrorString");
+    if (!api.getUniqueId || !api.commInitRank || !api.commDestroy || !api.allGather || !api.allReduce || !api.getErrorString) {
+        cs_set_error("RCCL library lacks a required symbol");
+        dlclose(api.handle);
+        api.handle = nullptr;
+        return nullptr;
+    }
+    return &api;
+}
+
+#define CS_NCCL(call)                                                                                     \
+    do {                                                                                                  \
+        ncclResult_t _r = (call);                                                                         \
+        if (_r != ncclSuccess) {                                                                          \
+            cs_set_error("%s failed: %s (%s:%d)", #call, rccl_api()->getErrorString(_r), __FILE__, __LINE__); \
+            return CS_ERR_HIP;                                                                            \
+        }                                                                                                 \
+    } while (0)
+
+}  // namespace
+
+struct cs_comm {
+    ncclComm_t comm;
+    int world, rank, device;
+};
+
+constexpr int CS_EX_MAX_CAMS = 16;
+struct cs_exchange {
+    cs_comm* c;
+    int nCams, nFeat;
+    size_t recWords;  // int32 words of one camera's record
+    int* send;
+    int* recv;
+};
+
+namespace {
+
+struct PackArgs {
+    int nFeatWords;  // N * 5
+    int recWords;
+    int* send;
+    const double* R;
+    const double* t;
+    const int* dest[CS_EX_MAX_CAMS];
+};
+
+// one launch packs every local camera's record: grid.y = camera
+__global__ __launch_bounds__(256) void k_exchange_pack(PackArgs A) {
+    const int cam = blockIdx.y;
+    int* out = A.send + (size_t)cam * A.recWords;
+    const int* src = A.dest[cam];
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < A.recWords; q += gridDim.x * 256) {
+        int v;
+        if (q < A.nFeatWords) {
+            v = src[q];
+        } else {
+            const int w = q - A.nFeatWords;  // 18 words of R, 6 of t
+            const int* p = (w < 18) ? (const int*)(A.R + 9 * (size_t)cam) + w : (const int*)(A.t + 3 * (size_t)cam) + (w - 18);
+            v = *p;
+        }
+        out[q] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cs_comm_unique_id(unsigned char id[128]) {
+    RcclApi* api = rccl_api();
+    if (!api || !id) return CS_ERR_INVALID;
+    ncclUniqueId u;
+    CS_NCCL(api->getUniqueId(&u));
+    memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+    return CS_OK;
+}
+
+cs_comm* cs_comm_create(const unsigned char id[128], int world, int rank, int device) {
+    RcclApi* api = rccl_api();
+    if (!api) return nullptr;
+    if (!id || world < 1 || rank < 0 || rank >= world) {
+        cs_set_error("cs_comm_create: bad arguments");
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        cs_set_error("cs_comm_create: cannot select device %d", device);
+        return nullptr;
+    }
+    ncclUniqueId u;
+    memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = api->commInitRank(&comm, world, u, rank);
+    if (r != ncclSuccess) {
+        cs_set_error("ncclCommInitRank failed: %s", api->getErrorString(r));
+        return nullptr;
+    }
+    cs_comm* c = new (std::nothrow) cs_comm();
+    if (!c) return nullptr;
+    c->comm = comm;
+    c->world = world;
+    c->rank = rank;
+    c->device = device;
+    return c;
+}
+
+void cs_comm_destroy(cs_comm* c) {
+    if (!c) return;
+    RcclApi* api = rccl_api();
+    if (api && c->comm) (void)api->commDestroy(c->comm);
+    delete c;
+}
+
+int cs_comm_world(const cs_comm* c) { return c ? c->world : 0; }
+int cs_comm_rank(const cs_comm* c) { return c ? c->rank : -1; }
+
+// ---- collective 1: features || pose of every camera to every rank ---------------------------------------------------
+cs_exchange* cs_exchange_create(cs_comm* c, int nCamsLocal, int nFeatures) {
+    if (!c || nCamsLocal < 1 || nCamsLocal > CS_EX_MAX_CAMS || nFeatures < 1) {
+        cs_set_error("cs_exchange_create: bad arguments (1..%d local cameras)", CS_EX_MAX_CAMS);
+        return nullptr;
+    }
+    cs_exchange* x = new (std::nothrow) cs_exchange();
+    if (!x) return nullptr;
+    x->c = c;
+    x->nCams = nCamsLocal;
+    x->nFeat = nFeatures;
+    x->recWords = (size_t)nFeatures * 5 + 24;
+    x->send = x->recv = nullptr;
+    const size_t sendBytes = sizeof(int) * x->recWords * nCamsLocal;
+    if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void**)&x->send, sendBytes) != hipSuccess ||
+        hipMalloc((void**)&x->recv, sendBytes * c->world) != hipSuccess) {
+        cs_set_error("cs_exchange_create: allocation failed");
+        if (x->send) (void)hipFree(x->send);
+        delete x;
+        return nullptr;
+    }
+    return x;
+}
+
+void cs_exchange_destroy(cs_exchange* x) {
+    if (!x) return;
+    (void)hipFree(x->send);
+    (void)hipFree(x->recv);
+    delete x;
+}
+
+int cs_exchange_allgather_dev(cs_exchange* x, void* hip_stream, const void* const* d_dests, const double* d_R,
+                              const double* d_t) {
+    RcclApi* api = rccl_api();
+    if (!api || !x || !d_dests || !d_R || !d_t) {
+        cs_set_error("cs_exchange_allgather_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(x->c->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    PackArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nFeatWords = x->nFeat * 5;
+    A.recWords = (int)x->recWords;
+    A.send = x->send;
+    A.R = d_R;
+    A.t = d_t;
+    for (int i = 0; i < x->nCams; ++i) {
+        if (!d_dests[i]) {
+            cs_set_error("cs_exchange_allgather_dev: null dest[] of camera %d", i);
+            return CS_ERR_INVALID;
+        }
+        A.dest[i] = (const int*)d_dests[i];
+    }
+    int gx = (int)((x->recWords + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_exchange_pack, dim3(gx, x->nCams), dim3(256), 0, s, A);
+    CS_CHECK_LAUNCH();
+    const size_t sendBytes = sizeof(int) * x->recWords * x->nCams;
+    CS_NCCL(api->allGather(x->send, x->recv, sendBytes, ncclInt8, x->c->comm, s));
+    return CS_OK;
+}
+
+// gathered records: global camera g (rank g / nCamsLocal, local index g % nCamsLocal) at d_recv + g * record_bytes:
+// N x cs_klt_feature, then R (9 doubles), then t (3 doubles)
+int cs_exchange_buffers(cs_exchange* x, void** d_recv, size_t* record_bytes) {
+    if (!x) return CS_ERR_INVALID;
+    if (d_recv) *d_recv = x->recv;
+    if (record_bytes) *record_bytes = sizeof(int) * x->recWords;
+    return CS_OK;
+}
+
+// ---- collective 2: bundleAdjustRobust over all ranks, points sliced by rank ------------------------------------------
+// Every rank passes the same replicated problem (cs_ba_upload) and ends with the same result (cs_ba_download).
+// Everything -- phases and collectives -- is enqueued on hip_stream; the host never synchronises.
+int cs_ba_dist_solve(cs_ba* b, cs_comm* c, void* hip_stream, int C, int P, int nObs, const double* d_Rs0, const double* d_Ts0,
+                     const double* d_pts0, int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter) {
+    RcclApi* api = rccl_api();
+    if (!api || !b || !c) {
+        cs_set_error("cs_ba_dist_solve: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int per = (P + c->world - 1) / c->world;
+    int lo = c->rank * per;
+    if (lo > P) lo = P;
+    int hi = lo + per;
+    if (hi > P) hi = P;
+    int rc = cs_ba_dist_begin(b, hip_stream, C, P, nObs, d_Rs0, d_Ts0, d_pts0, nCamsCon, nPtsCon, maxErr, innerMaxIter, lo, hi,
+                              c->rank == 0 ? 1 : 0);
+    if (rc) return rc;
+    void *dS = nullptr, *dScal = nullptr, *dPts = nullptr, *dOut = nullptr;
+    int nRed = 0;
+    rc = cs_ba_dist_buffers(b, &dS, &nRed, &dScal, &dPts, &dOut);
+    if (rc) return rc;
+    auto phase = [&](int ph) { return cs_ba_dist_phase(b, hip_stream, ph); };
+    auto sum_d = [&](void* buf, size_t n) -> int {
+        if (c->world == 1 || n == 0) return CS_OK;
+        CS_NCCL(api->allReduce(buf, buf, n, ncclFloat64, ncclSum, c->comm, s));
+        return CS_OK;
+    };
+    for (int outer = 0; outer < maxIter; ++outer) {
+        if ((rc = phase(CS_BA_PH_COST0))) return rc;
+        if ((rc = sum_d(dScal, 4))) return rc;
+        if ((rc = phase(CS_BA_PH_CONTROL0))) return rc;
+        for (int it = 0; it < innerMaxIter; ++it) {
+            if ((rc = phase(CS_BA_PH_LIN_SCHUR))) return rc;
+            if ((rc = sum_d(dS, (size_t)nRed))) return rc;
+            if ((rc = phase(CS_BA_PH_SOLVE_UPDATE))) return rc;
+            if ((rc = sum_d(dScal, 4))) return rc;
+            if ((rc = phase(CS_BA_PH_CONTROL1))) return rc;
+        }
+        if ((rc = phase(CS_BA_PH_FLAG))) return rc;
+        if ((rc = sum_d(dScal, 4))) return rc;
+        if ((rc = phase(CS_BA_PH_OUTER_END))) return rc;
+    }
+    if ((rc = phase(CS_BA_PH_FINAL_PREP))) return rc;
+    if ((rc = sum_d(dPts, (size_t)3 * P))) return rc;
+    if (c->world > 1 && nObs > 0) CS_NCCL(api->allReduce(dOut, dOut, (size_t)nObs, ncclInt32, ncclSum, c->comm, s));
+    return phase(CS_BA_PH_FINISH);
+}
+
+}  // extern "C"

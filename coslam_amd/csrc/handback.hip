@@ -24,7 +24,7 @@ constexpr int HB_MAX_CAMS = 16;
 constexpr int HB_MAX_BLOCKS = 1024;
 
 struct HbArgs {
-    int N, W, H, nColBlk, nRowBlk, blkW, blkH, ptsStride, nCams;
+    int N, W, H, nColBlk, nRowBlk, blkW, blkH, ptsStride, nCams, frame;
     cs_handback_cam cam[HB_MAX_CAMS];
 };
 
@@ -53,7 +53,8 @@ __global__ __launch_bounds__(1024) void k_handback(HbArgs A) {
     // ---- GPUKLT.cpp:36-60 per slot, then the block vote of SL_SingleSLAM.cpp:353-384 ------------------------------
     for (int i = tid; i < N; i += 1024) {
         const cs_klt_feature f = C.dest[i];
-        int st = f.status, len = C.trackLen[i], mp = C.slot2map[i];
+        // Track2D keeps the frame span [f1, f2] of the slot's track; its length() is f2 - f1 + 1 (src/tracking/SL_Track2D.h:63-65)
+        int st = f.status, f1 = C.trackSpan[i], f2 = C.trackSpan[N + i], mp = C.slot2map[i];
         double x = C.xy[i], y = C.xy[N + i];
         if (st >= 0) {
             const double inx = (double)(f.pos[0] * (float)A.W), iny = (double)(f.pos[1] * (float)A.H);  // :43-44
@@ -64,21 +65,23 @@ __global__ __launch_bounds__(1024) void k_handback(HbArgs A) {
             } else {
                 x = ox;
                 y = oy;
-                if (st == 0) {
-                    len += 1;  // :50-52
+                if (st == 0 && f1 >= 0) {
+                    f2 = A.frame;  // :50-52 m_tks[i].add(p): the span grows to this frame
                 } else {
-                    len = 1;  // :53-57 newly detected: the track restarts, unmapped
-                    mp = -1;
+                    f1 = f2 = A.frame;  // :53-57 newly detected (or first point of an empty track): the track restarts
+                    if (st != 0) mp = -1;
                 }
             }
         } else {
-            len = 0;  // :59 m_tks[i].clear()
+            f1 = f2 = -1;  // :59 m_tks[i].clear()
             mp = -1;
         }
+        const int len = (f1 >= 0) ? f2 - f1 + 1 : 0;
         C.xy[i] = x;
         C.xy[N + i] = y;
         C.state[i] = st;
-        C.trackLen[i] = len;
+        C.trackSpan[i] = f1;
+        C.trackSpan[N + i] = f2;
         C.slot2map[i] = mp;
         if (len > 0) {  // !tk->empty(); candidates are the static ones: here every mapped slot and, when the caller
                         // supplies the classification, every slot it marks static
@@ -141,8 +144,8 @@ __global__ __launch_bounds__(1024) void k_handback(HbArgs A) {
 }  // namespace
 
 extern "C" int cs_klt_handback_dev(int device, void* hip_stream, int nCams, const cs_handback_cam* cams, int N, int W, int H,
-                                   int nColBlk, int nRowBlk, int ptsStride) {
-    if (nCams < 1 || nCams > HB_MAX_CAMS || !cams || N < 1 || N >= (1 << 24) || W < 1 || H < 1 || nColBlk < 1 || nRowBlk < 1 ||
+                                   int nColBlk, int nRowBlk, int ptsStride, int frame) {
+    if (nCams < 1 || nCams > HB_MAX_CAMS || !cams || N < 1 || N >= (1 << 24) || W < 1 || H < 1 || frame < 0 || nColBlk < 1 || nRowBlk < 1 ||
         nColBlk * nRowBlk > HB_MAX_BLOCKS || ptsStride < 1 || W / nColBlk < 1 || H / nRowBlk < 1) {
         cs_set_error("cs_klt_handback_dev: bad arguments (1..%d cameras, <= %d blocks)", HB_MAX_CAMS, HB_MAX_BLOCKS);
         return CS_ERR_INVALID;
@@ -158,9 +161,10 @@ extern "C" int cs_klt_handback_dev(int device, void* hip_stream, int nCams, cons
     A.blkH = H / nRowBlk;
     A.ptsStride = ptsStride;
     A.nCams = nCams;
+    A.frame = frame;
     for (int c = 0; c < nCams; ++c) {
         const cs_handback_cam& q = cams[c];
-        if (!q.dest || !q.K || !q.kud || !q.mapPts || !q.slot2map || !q.trackLen || !q.xy || !q.state || !q.Ms || !q.ms ||
+        if (!q.dest || !q.K || !q.kud || !q.mapPts || !q.slot2map || !q.trackSpan || !q.xy || !q.state || !q.Ms || !q.ms ||
             !q.sel || !q.npts) {
             cs_set_error("cs_klt_handback_dev: null pointer in camera %d", c);
             return CS_ERR_INVALID;

@@ -10,16 +10,17 @@ from .pose import IntraCamPoseOption  # noqa: F401  (layout of the `opt` record)
 class HandbackCam(C.Structure):
     """== cs_handback_cam (include/coslam_hip.h): device pointers of one camera."""
 
-    _fields_ = [(n, C.c_void_p) for n in ("dest", "K", "kud", "mapPts", "isStatic", "slot2map", "trackLen", "xy", "state",
+    _fields_ = [(n, C.c_void_p) for n in ("dest", "K", "kud", "mapPts", "isStatic", "slot2map", "trackSpan", "xy", "state",
                                           "selBlk", "Ms", "ms", "sel", "npts", "opt")]
 
 
-def handback_dev(stream_ptr, cams, N, W, H, nColBlk=16, nRowBlk=12, ptsStride=192, device=0):
-    """cams: list of dicts of device pointers (ints; missing / None = NULL) with the field names of cs_handback_cam."""
+def handback_dev(stream_ptr, cams, N, W, H, nColBlk=16, nRowBlk=12, ptsStride=192, device=0, frame=0):
+    """cams: list of dicts of device pointers (ints; missing / None = NULL) with the field names of cs_handback_cam;
+    frame: GPUKLT::m_frame of this call (the tracks' frame spans are kept in trackSpan)."""
     arr = (HandbackCam * len(cams))()
     for a, c in zip(arr, cams):
         for n, _ in HandbackCam._fields_:
             v = c.get(n)
             setattr(a, n, int(v) if v else None)
     check(lib().cs_klt_handback_dev(int(device), C.c_void_p(stream_ptr), len(cams), arr, int(N), int(W), int(H),
-                                    int(nColBlk), int(nRowBlk), int(ptsStride)), "cs_klt_handback_dev")
+                                    int(nColBlk), int(nRowBlk), int(ptsStride), int(frame)), "cs_klt_handback_dev")

@@ -19,17 +19,89 @@ def record_words(n_features):
     return n_features * FEATURE_WORDS + POSE_WORDS
 
 
-class CameraExchange:
-    """Preallocated send/recv buffers + the per-frame all-gather."""
+class NativeComm:
+    """RCCL communicators owned by libcoslam_hip (cs_comm_*): the collectives of the merge step are then issued from C++
+    (one fused pack kernel + ncclAllGather per frame; the whole sliced-BA schedule with its ncclAllReduce calls enqueued
+    natively).  Rank 0 creates the unique ids and ships them through torch.distributed; two communicators, because the
+    per-frame exchange and the BA's all-reduces run on different streams."""
 
-    def __init__(self, n_features, device, group=None):
+    def __init__(self, world, rank, device, group=None):
+        import ctypes as C
+
+        from ._lib import CoslamHipError, check, lib
+
+        self._L, self._C = lib(), C
+        self.world, self.rank, self.device = world, rank, device
+        L = self._L
+        L.cs_comm_create.restype = C.c_void_p
+        L.cs_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        self.comms = []
+        for _ in range(2):
+            ident = (C.c_ubyte * 128)()
+            if rank == 0:
+                check(L.cs_comm_unique_id(ident), "cs_comm_unique_id")
+            if world > 1:
+                backend = dist.get_backend(group)
+                dev = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
+                t = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
+                dist.broadcast(t, src=0, group=group)
+                ident = (C.c_ubyte * 128)(*t.cpu().tolist())
+            h = L.cs_comm_create(ident, world, rank, device)
+            if not h:
+                raise CoslamHipError("cs_comm_create: " + L.cs_last_error().decode())
+            self.comms.append(C.c_void_p(h))
+        self.exchange_comm, self.ba_comm = self.comms
+
+    def close(self):
+        self._L.cs_comm_destroy.argtypes = [self._C.c_void_p]
+        for c in self.comms:
+            self._L.cs_comm_destroy(c)
+        self.comms = []
+
+
+class CameraExchange:
+    """Preallocated send/recv buffers + the per-frame all-gather.  n_features counts the feature slots of ALL cameras of
+    this rank (cameras_per_rank x N); the record of a rank is its cameras' dest[] arrays back to back, then R, t of each.
+    With `native` (a NativeComm) packing and the collective are one C-ABI call (cs_exchange_allgather_dev)."""
+
+    def __init__(self, n_features, device, group=None, native=None, cams_per_rank=1):
         self.n = n_features
         self.group = group
+        self.native = native
+        self.cams = cams_per_rank
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        w = record_words(n_features)
+        self._x = None
+        if native is not None:
+            import ctypes as C
+
+            from ._lib import CoslamHipError
+
+            L = native._L
+            L.cs_exchange_create.restype = C.c_void_p
+            L.cs_exchange_create.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            h = L.cs_exchange_create(native.exchange_comm, cams_per_rank, n_features // cams_per_rank)
+            if not h:
+                raise CoslamHipError("cs_exchange_create: " + L.cs_last_error().decode())
+            self._x = C.c_void_p(h)
+            self.world = native.world
+            return
+        w = n_features * FEATURE_WORDS + POSE_WORDS * cams_per_rank
         self.send = torch.zeros(w, dtype=torch.int32, device=device)
         self.recv = torch.zeros(w * self.world, dtype=torch.int32, device=device)
+
+    def pack_group(self, dest_words_list, R, t, stream=None):
+        """dest_words_list: one int32[N*5] tensor per local camera; R: f64[cams, 9]; t: f64[cams, 3] (same device).
+        torch path: the copies go out on the current stream.  Native path: nothing here, all_gather() packs."""
+        self._pending = (dest_words_list, R, t)
+        if self._x is not None:
+            return
+        n1 = (self.n // self.cams) * FEATURE_WORDS
+        for i, d in enumerate(dest_words_list):
+            self.send[i * n1: (i + 1) * n1].copy_(d, non_blocking=True)
+        base = self.cams * n1
+        self.send[base: base + 18 * self.cams].copy_(R.reshape(-1).view(torch.int32), non_blocking=True)
+        self.send[base + 18 * self.cams:].copy_(t.reshape(-1).view(torch.int32), non_blocking=True)
 
     def pack(self, dest_words, R, t):
         """dest_words: int32[N*5] view of the KLT_TrackedFeature array; R: f64[9]; t: f64[3] (same device)."""
@@ -38,12 +110,38 @@ class CameraExchange:
         self.send[nf: nf + 18].copy_(R.view(torch.int32), non_blocking=True)
         self.send[nf + 18:].copy_(t.view(torch.int32), non_blocking=True)
 
-    def all_gather(self):
+    def all_gather(self, stream=None):
+        if self._x is not None:
+            import ctypes as C
+
+            from ._lib import check
+
+            dests, R, t = self._pending
+            arr = (C.c_void_p * len(dests))(*[d.data_ptr() for d in dests])
+            s = stream.cuda_stream if stream is not None else torch.cuda.current_stream().cuda_stream
+            check(self.native._L.cs_exchange_allgather_dev(self._x, C.c_void_p(s), arr, C.c_void_p(R.data_ptr()),
+                                                           C.c_void_p(t.data_ptr())), "cs_exchange_allgather_dev")
+            return None
         if self.world == 1:
             self.recv.copy_(self.send, non_blocking=True)
         else:
             dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
         return self.recv
+
+    def native_records(self, device):
+        """(torch uint8 view of the gathered records, record_bytes) of the native path: global camera g at g * record_bytes"""
+        import ctypes as C
+
+        p, nb = C.c_void_p(), C.c_size_t(0)
+        self.native._L.cs_exchange_buffers(self._x, C.byref(p), C.byref(nb))
+        total = nb.value * self.cams * self.world
+        return torch.as_tensor(_DevArray(p.value, total, "|u1"), device=torch.device("cuda", device)), nb.value
+
+    def close(self):
+        if self._x is not None:
+            self.native._L.cs_exchange_destroy.argtypes = [self.native._C.c_void_p]
+            self.native._L.cs_exchange_destroy(self._x)
+            self._x = None
 
     def unpack(self, cam):
         """-> (features int32[N,5] view, R f64[9], t f64[3]) of camera `cam` from the last all_gather."""
@@ -150,9 +248,20 @@ class HipSlicedBA:
 
 
 def bundle_adjust_sliced(ws, stream, d_Rs0, d_Ts0, d_pts0, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter, device,
-                         group=None):
+                         group=None, native=None):
     """bundleAdjustRobust over all ranks of `group` (one process per GPU).  Every rank passes the same replicated
-    problem (already in `ws`) and receives the same result (ws.download())."""
+    problem (already in `ws`) and receives the same result (ws.download()).  With `native` (a NativeComm) the whole
+    schedule -- phases and RCCL all-reduces -- is enqueued by ONE C-ABI call (cs_ba_dist_solve)."""
+    if native is not None:
+        import ctypes as C
+
+        from ._lib import check
+
+        vp = C.c_void_p
+        check(ws._L.cs_ba_dist_solve(ws._h, native.ba_comm, vp(stream.cuda_stream), ws.C, ws.P, ws.nObs, vp(d_Rs0), vp(d_Ts0),
+                                     vp(d_pts0), int(nCamsCon), int(nPtsCon), C.c_double(maxErr), int(maxIter),
+                                     int(innerMaxIter)), "cs_ba_dist_solve")
+        return None
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lo, hi = point_slice(rank, world, ws.P)

@@ -220,7 +220,8 @@ typedef struct cs_handback_cam {
     const double* mapPts;       /* P x 3: MapPoint::M of the point a slot is associated with */
     const unsigned char* isStatic; /* N or NULL: slots classified static without a map point (FeaturePoint::type) */
     int* slot2map;              /* N in/out: map point index of the slot's track or -1; new / dead slots are reset to -1 */
-    int* trackLen;              /* N in/out: Track2D length (0 = empty) */
+    int* trackSpan;             /* 2N in/out: first[N] then last[N] frame of the slot's Track2D (-1 = empty); its length()
+                                   is last - first + 1 (src/tracking/SL_Track2D.h:63-65) */
     double* xy;                 /* 2N in/out: undistorted pixel, x[N] then y[N]; kept for a slot dropped by the >= W|H rule */
     int* state;                 /* N out: 0 tracked, 1 new, -1 dead, -2 dropped by the out >= W | H rule */
     int* selBlk;                /* nColBlk * nRowBlk out or NULL: chosen slot of every block (-1: none), featPts order */
@@ -233,7 +234,7 @@ typedef struct cs_handback_cam {
 /* cams: HOST array of nCams (<= 16) records of device pointers.  nColBlk x nRowBlk = 16 x 12 in CoSLAM
  * (src/app/SL_SingleSLAM.h:36-37); ptsStride >= the most correspondences wanted per camera (192). */
 int cs_klt_handback_dev(int device, void* hip_stream, int nCams, const cs_handback_cam* cams, int N, int W, int H,
-                        int nColBlk, int nRowBlk, int ptsStride);
+                        int nColBlk, int nRowBlk, int ptsStride, int frame /* GPUKLT::m_frame of this call, >= 0 */);
 
 /* ------------------------------------------------------------------------------------------
  * Robust multi-camera bundle adjustment
@@ -300,6 +301,39 @@ int cs_ba_dist_phase(cs_ba* b, void* hip_stream, int phase);
 int cs_ba_dist_buffers(cs_ba* b, void** d_S_rhs, int* n_red, void** d_scal, void** d_pts, void** d_outlier);
 int cs_ba_download(cs_ba* b, int C, int P, int nObs, double* Rs, double* Ts, double* pts, int* out_outlier,
                    cs_ba_stats* stats);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU merge step: RCCL collectives over xGMI issued by the library (one process per GPU)
+ * ------------------------------------------------------------------------------------------
+ * The reference is one process; it reads every camera's features and pose directly (src/app/SL_CoSLAM.cpp:299-305,
+ * src/app/SL_InterCamPoseEstimator.cpp:24-37).  With the cameras sharded over the GPUs these entry points carry the
+ * same information: one all-gather per frame, and the joint bundleAdjustRobust sliced by points with one all-reduce of
+ * S || rhs per LM step.  RCCL is loaded at run time (dlopen); without it the cs_comm_* calls fail and nothing else is
+ * affected. */
+typedef struct cs_comm cs_comm;
+int cs_comm_unique_id(unsigned char id[128]); /* rank 0 creates it; the caller ships it to the other ranks */
+cs_comm* cs_comm_create(const unsigned char id[128], int world, int rank, int device); /* ncclCommInitRank */
+void cs_comm_destroy(cs_comm* c);
+int cs_comm_world(const cs_comm* c);
+int cs_comm_rank(const cs_comm* c);
+
+/* collective 1: every camera's {N x cs_klt_feature, R[9], t[3]} to every rank.  nCamsLocal cameras per rank (<= 16),
+ * the same on every rank.  One kernel packs the rank's records, one ncclAllGather ships them; both on hip_stream. */
+typedef struct cs_exchange cs_exchange;
+cs_exchange* cs_exchange_create(cs_comm* c, int nCamsLocal, int nFeatures);
+void cs_exchange_destroy(cs_exchange* x);
+/* d_dests: HOST array of nCamsLocal device pointers to dest[]; d_R / d_t: device arrays 9 / 3 doubles per local camera */
+int cs_exchange_allgather_dev(cs_exchange* x, void* hip_stream, const void* const* d_dests, const double* d_R,
+                              const double* d_t);
+/* gathered records: global camera g = rank * nCamsLocal + local index at d_recv + g * record_bytes */
+int cs_exchange_buffers(cs_exchange* x, void** d_recv, size_t* record_bytes);
+
+/* collective 2: bundleAdjustRobust over all ranks of c.  Every rank uploads the same problem (cs_ba_upload) and calls
+ * this with the same arguments; rank r linearises its contiguous slice of the points, S || rhs is all-reduced once per
+ * LM step, every rank takes the same LM / outlier decisions on the device, points and flags are summed at the end.
+ * Everything is enqueued on hip_stream (no host synchronisation); cs_ba_download reads the (replicated) result. */
+int cs_ba_dist_solve(cs_ba* b, cs_comm* c, void* hip_stream, int C, int P, int nObs, const double* d_Rs0, const double* d_Ts0,
+                     const double* d_pts0, int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter);
 
 #ifdef __cplusplus
 }

@@ -127,8 +127,10 @@ def sample(lvl, Wl, Hl, s, t):
     return out
 
 
-def handback(features, W, H, K, kud, mapPts, slot2map, trackLen, xy, isStatic=None, nColBlk=16, nRowBlk=12, ptsStride=192):
-    """ohb_handback: one frame of one camera.  slot2map, trackLen (int32[N]) and xy (float64[2N]) are updated in place.
+def handback(features, W, H, K, kud, mapPts, slot2map, trackSpan, xy, frame, isStatic=None, nColBlk=16, nRowBlk=12,
+             ptsStride=192):
+    """ohb_handback: frame number `frame` of one camera.  slot2map (int32[N]), trackSpan (int32[2N]: first / last frame
+    of every slot's track, -1 = empty) and xy (float64[2N]) are updated in place.
     Returns dict(state, selBlk, npts, Ms, ms, sel)."""
     L = lib()
     L.ohb_handback.restype = C.c_int
@@ -137,14 +139,16 @@ def handback(features, W, H, K, kud, mapPts, slot2map, trackLen, xy, isStatic=No
     K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
     kud = np.ascontiguousarray(kud, dtype=np.float64).reshape(7)
     mp = np.ascontiguousarray(mapPts, dtype=np.float64).reshape(-1, 3)
-    assert slot2map.dtype == np.int32 and trackLen.dtype == np.int32 and xy.dtype == np.float64 and xy.size == 2 * N
+    assert slot2map.dtype == np.int32 and trackSpan.dtype == np.int32 and trackSpan.size == 2 * N
+    assert xy.dtype == np.float64 and xy.size == 2 * N
     st = np.zeros(N, dtype=np.int32)
     selBlk = np.zeros(nColBlk * nRowBlk, dtype=np.int32)
     Ms, ms = np.zeros((ptsStride, 3)), np.zeros((ptsStride, 2))
     sel = np.full(ptsStride, -1, dtype=np.int32)
     stat = None if isStatic is None else np.ascontiguousarray(isStatic, dtype=np.uint8)
-    n = L.ohb_handback(N, W, H, _p(f), _p(K), _p(kud), _p(mp), _p(stat) if stat is not None else None, _p(slot2map),
-                       _p(trackLen), _p(xy), _p(st), nColBlk, nRowBlk, _p(selBlk), ptsStride, _p(Ms), _p(ms), _p(sel))
+    n = L.ohb_handback(N, W, H, int(frame), _p(f), _p(K), _p(kud), _p(mp), _p(stat) if stat is not None else None,
+                       _p(slot2map), _p(trackSpan), _p(xy), _p(st), nColBlk, nRowBlk, _p(selBlk), ptsStride, _p(Ms), _p(ms),
+                       _p(sel))
     return dict(state=st, selBlk=selBlk, npts=n, Ms=Ms[:n], ms=ms[:n], sel=sel[:n])
 
 

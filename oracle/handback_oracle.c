@@ -29,13 +29,16 @@ void ohb_undistort_point(const double K[9], const double kud[7], const double in
     out[1] = K[4] * yu + K[5];
 }
 
-/* One frame of one camera.  In/out per slot: slot2map (FeaturePoint::mpt of the track's tail, -1 = none), trackLen
- * (Track2D::length(), 0 = empty), xy (tail point, x[N] then y[N]).  Out: state[N] (0 tracked, 1 new, -1 dead, -2 dropped),
+/* One frame (number `frame`) of one camera.  In/out per slot: slot2map (FeaturePoint::mpt of the track's tail, -1 = none),
+ * trackSpan (Track2D::f1 / f2: first[N] then last[N] frame, -1 = empty; length() = f2 - f1 + 1, SL_Track2D.h:63-65),
+ * xy (tail point, x[N] then y[N]).  Out: state[N] (0 tracked, 1 new, -1 dead, -2 dropped),
  * selBlk[nColBlk * nRowBlk] (featPts of chooseStaticFeatPts in block order, -1 = none), and the packed 3D-2D
  * correspondences (at most ptsStride).  Returns the number of correspondences. */
-int ohb_handback(int N, int W, int H, const okl_tracked_feature* features, const double K[9], const double kud[7],
-                 const double* mapPts, const unsigned char* isStatic, int* slot2map, int* trackLen, double* xy, int* state,
+int ohb_handback(int N, int W, int H, int frame, const okl_tracked_feature* features, const double K[9], const double kud[7],
+                 const double* mapPts, const unsigned char* isStatic, int* slot2map, int* trackSpan, double* xy, int* state,
                  int nColBlk, int nRowBlk, int* selBlk, int ptsStride, double* Ms, double* ms, int* sel) {
+    int* tf1 = trackSpan;
+    int* tf2 = trackSpan + N;
     /* ---- GPUKLT::addToFeaturePoints, GPUKLT.cpp:36-60 */
     for (int i = 0; i < N; i++) {
         if (features[i].status >= 0) {
@@ -49,15 +52,16 @@ int ohb_handback(int N, int W, int H, const okl_tracked_feature* features, const
             }
             xy[i] = out[0]; /* ips.add(m_frame, m_camId, out[0], out[1]) */
             xy[N + i] = out[1];
-            if (features[i].status == 0) {
-                trackLen[i] += 1; /* m_tks[i].add(p) */
-            } else {
-                trackLen[i] = 1; /* m_tks[i].clear(); m_tks[i].add(p): a new, unmapped feature point */
+            if (features[i].status != 0) { /* m_tks[i].clear(): a new, unmapped feature point starts the track */
+                tf1[i] = tf2[i] = -1;
                 slot2map[i] = -1;
             }
+            /* m_tks[i].add(p), SL_Track2D.h:78-104: the frame span grows to this frame */
+            if (frame < tf1[i] || tf1[i] < 0) tf1[i] = frame;
+            if (frame > tf2[i] || tf2[i] < 0) tf2[i] = frame;
             state[i] = features[i].status;
         } else {
-            trackLen[i] = 0; /* m_tks[i].clear() */
+            tf1[i] = tf2[i] = -1; /* m_tks[i].clear() */
             slot2map[i] = -1;
             state[i] = -1;
         }
@@ -68,7 +72,7 @@ int ohb_handback(int N, int W, int H, const okl_tracked_feature* features, const
     int* tracks = (int*)malloc(sizeof(int) * (size_t)len);
     for (int b = 0; b < len; b++) tracks[b] = -1;
     for (int i = 0; i < N; i++) {
-        if (trackLen[i] == 0) continue; /* tk->empty() */
+        if (tf1[i] < 0) continue; /* tk->empty() */
         const int mapped = slot2map[i] >= 0;
         if (mapped || (isStatic && isStatic[i])) { /* fp->type == STATIC || (fp->mpt && fp->mpt->isCertainStatic()) */
             int bx = (int)(xy[i] / blkW);
@@ -82,7 +86,7 @@ int ohb_handback(int N, int W, int H, const okl_tracked_feature* features, const
             } else if (!(slot2map[old] >= 0)) { /* !fpOld->mpt */
                 if (mapped) {
                     tracks[bi] = i;
-                } else if (trackLen[old] < trackLen[i]) {
+                } else if (tf2[old] - tf1[old] + 1 < tf2[i] - tf1[i] + 1) { /* tkOld->length() < tk->length() */
                     tracks[bi] = i;
                 }
             }

@@ -127,8 +127,8 @@ void okl_seq_read_features(const okl_seq* s, float* out3);
 /* ---- host glue between tracker and pose solve restated (handback_oracle.c): GPUKLT::addToFeaturePoints,
  * SingleSLAM::chooseStaticFeatPts and the Ms / ms packing of SingleSLAM::poseUpdate3D ---- */
 void ohb_undistort_point(const double K[9], const double kud[7], const double in[2], double out[2]);
-int ohb_handback(int N, int W, int H, const okl_tracked_feature* features, const double K[9], const double kud[7],
-                 const double* mapPts, const unsigned char* isStatic, int* slot2map, int* trackLen, double* xy, int* state,
+int ohb_handback(int N, int W, int H, int frame, const okl_tracked_feature* features, const double K[9], const double kud[7],
+                 const double* mapPts, const unsigned char* isStatic, int* slot2map, int* trackSpan, double* xy, int* state,
                  int nColBlk, int nRowBlk, int* selBlk, int ptsStride, double* Ms, double* ms, int* sel);
 
 #ifdef __cplusplus

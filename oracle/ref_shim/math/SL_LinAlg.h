@@ -7,6 +7,7 @@
 #define REF_SHIM_SL_LINALG_H
 #include <cstring>
 #include <cmath>
+#include "ref_not_on_path.h"
 
 /* dst[off*n .. off*n+n) = src[0..n)  (always called with off == 0 in SL_IntraCamPose.cpp) */
 void doubleArrCopy(double* dst, int off, const double* src, int n);
@@ -20,4 +21,7 @@ void matAB(int m, int n, int p, int q, const double* A, const double* B, double*
 void matInv(int n, const double* A, double* invA);
 void mat22Inv(const double* A, double* invA);
 void mat33Inv(const double* A, double* invA);
+void mat33Trans(const double* A, double* At);
+/* Euclidean distance of two 2-vectors (src/app/SL_SingleSLAM.cpp:658: dist2(m, fp->m)) */
+double dist2(const double* a, const double* b);
 #endif

@@ -1,0 +1,34 @@
+/* ref_shim/ref_not_on_path.h -- declarations only, NO definitions: external (LibVisualSLAM / OpenCV) helpers that the
+ * reference's translation units name in functions which are NOT on the tracker / pose / BA call path (new-map-point
+ * triangulation, image scaling, the epipolar pose variant ...).  They let src/app/SL_SingleSLAM.cpp compile in place;
+ * the objects are built with -ffunction-sections and linked with --gc-sections, so the functions that would need them
+ * are discarded and nothing here is ever resolved.  TEST INFRASTRUCTURE (see math/SL_Matrix.h). */
+#ifndef REF_SHIM_NOT_ON_PATH_H
+#define REF_SHIM_NOT_ON_PATH_H
+template <class... A> void scaleDownAvg(const A&...);
+template <class... A> void normPoint(const A&...);
+template <class... A> bool isAtCameraBack(const A&...);
+template <class... A> void getCameraCenter(const A&...);
+template <class... A> void triangulateMultiView(const A&...);
+template <class... A> int searchNearestPoint(const A&...);
+template <class... A> double reprojErrorSingle(const A&...);
+template <class... A> void matScale(const A&...);
+template <class... A> bool intraCamEstimateEpi(const A&...);
+template <class... A> void getTriangulateCovMat(const A&...);
+template <class... A> void getInvK(const A&...);
+template <class... A> double getCameraDistance(const A&...);
+template <class... A> void getBinTriangulateCovMat(const A&...);
+template <class... A> double getAbsRadiansBetween(const A&...);
+template <class... A> double dist3(const A&...);
+template <class... A> void binTriangulate(const A&...);
+#define CV_8UC1 0
+namespace cv {
+struct Size {
+    Size(int, int);
+};
+struct Mat {
+    Mat(int, int, int, void*);
+};
+void resize(Mat&, Mat&, Size);
+}  // namespace cv
+#endif

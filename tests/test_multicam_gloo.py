@@ -81,3 +81,50 @@ def test_single_rank_exchange_is_identity():
     w, R, t = x.unpack(0)
     assert torch.equal(w.reshape(-1), d) and R[8] == 8 and t[2] == 2
     assert record_words(10) == 74
+
+
+def _group_worker(rank, world, port, n_feat, cams, out_dir):
+    sys.path.insert(0, ROOT)
+    from coslam_amd.klt import KLT_TrackedFeature
+    from coslam_amd.multicam import FEATURE_WORDS, CameraExchange
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def camera(g):
+        rng = np.random.default_rng(200 + g)
+        f = np.zeros(n_feat, dtype=KLT_TrackedFeature)
+        f["status"] = rng.integers(-1, 2, n_feat)
+        f["pos"] = rng.random((n_feat, 2)).astype(np.float32)
+        f["fed"] = -1
+        return f, rng.standard_normal(9), rng.standard_normal(3)
+
+    mine = [camera(rank * cams + i) for i in range(cams)]
+    x = CameraExchange(n_feat * cams, torch.device("cpu"), cams_per_rank=cams)
+    x.pack_group([torch.from_numpy(f.view(np.int32).copy()) for f, _, _ in mine], torch.from_numpy(np.stack([r for _, r, _ in mine])),
+                 torch.from_numpy(np.stack([t for _, _, t in mine])))
+    recv = x.all_gather().numpy()
+    w = n_feat * cams * FEATURE_WORDS + 24 * cams
+    ok = True
+    for r in range(world):
+        rec = recv[r * w: (r + 1) * w]
+        for i in range(cams):
+            f, R, t = camera(r * cams + i)
+            n1 = n_feat * FEATURE_WORDS
+            ok &= bool(np.array_equal(rec[i * n1: (i + 1) * n1], f.view(np.int32)))
+            base = cams * n1
+            ok &= bool(np.array_equal(rec[base + 18 * i: base + 18 * (i + 1)].view(np.float64), R))
+            ok &= bool(np.array_equal(rec[base + 18 * cams + 6 * i: base + 18 * cams + 6 * (i + 1)].view(np.float64), t))
+    np.save(os.path.join(out_dir, f"gok{rank}.npy"), np.array([ok]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_ranks_with_four_cameras_each(tmp_path):
+    """the bench's N = 2 layout: the rank's cameras travel in one record, one all-gather per frame"""
+    world, port = 2, _free_port()
+    mp.spawn(_group_worker, args=(world, port, 120, 4, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert bool(np.load(tmp_path / f"gok{r}.npy")[0]), f"rank {r} saw a wrong record"
