@@ -148,7 +148,11 @@ __device__ __forceinline__ void cs_level0_body(const uint8_t* __restrict__ img, 
 }
 
 // ---- levels 1..NL (NL <= 3) in one launch -----------------------------------------------------------------
-constexpr int DTW = 4, DTH = 4;  // tile of the coarsest fused level owned by a block
+// Tile of the coarsest fused level owned by a block: 16 x 2 texels.  Sixteen texels are 128 bytes -- one full cache line
+// per stored row at EVERY level (level 3: 16, level 2: 32, level 1: 64 texels wide).  The first version owned 4 x 4
+// tiles: 32- and 64-byte row pieces written by different workgroups (on different XCDs) into the same lines, and the
+// counters showed 7.99 MB written per dispatch for 0.81 MB of pyramid (profiles/r01_j_pmc_WRITE_SIZE_session3.md).
+constexpr int DTW = 16, DTH = 2;
 
 struct CsDownFused {
     int NL;            // destination levels 1..NL
@@ -215,57 +219,64 @@ __device__ __forceinline__ void cs_down_body(cs_texel* __restrict__ pyr, const C
                                              cs_texel* reg1, bool valid) {
     cs_texel* reg2 = reg1 + F.cap1;
     const int NL = F.NL;
-    const int ntx = (F.w[NL] + DTW - 1) / DTW, nty = (F.h[NL] + DTH - 1) / DTH;
-    CsRange ownx[4], owny[4], needx[4], needy[4];
-    for (int l = NL; l >= 1; --l) {
-        ownx[l] = cs_own(tx, ntx, DTW, F.w[l], NL - l);
-        owny[l] = cs_own(ty, nty, DTH, F.h[l], NL - l);
-        if (l == NL) {
-            needx[l] = ownx[l];
-            needy[l] = owny[l];
-        } else {
-            needx[l] = cs_union(ownx[l], cs_tap_range(needx[l + 1], F.w[l + 1], F.w[l], F.shift));
-            needy[l] = cs_union(owny[l], cs_tap_range(needy[l + 1], F.h[l + 1], F.h[l], F.shift));
-        }
+    // Ranges per level, statically indexed: a loop over a run-time NL put these arrays (and a copy of F) in scratch --
+    // 144 B per lane whose spills the write counters billed to this kernel (4.4 MB per camera for 0.81 MB of pyramid).
+    const int w0 = F.w[0], h0 = F.h[0], w1 = F.w[1], h1 = F.h[1], w2 = F.w[2], h2 = F.h[2], w3 = F.w[3], h3 = F.h[3];
+    const int wN = NL == 3 ? w3 : (NL == 2 ? w2 : w1), hN = NL == 3 ? h3 : (NL == 2 ? h2 : h1);
+    const int ntx = (wN + DTW - 1) / DTW, nty = (hN + DTH - 1) / DTH;
+    const CsRange none = {0, 0};
+    CsRange ownx3 = none, owny3 = none, ownx2 = none, owny2 = none, needx2 = none, needy2 = none;
+    if (NL == 3) {
+        ownx3 = cs_own(tx, ntx, DTW, w3, 0);
+        owny3 = cs_own(ty, nty, DTH, h3, 0);
     }
+    if (NL >= 2) {
+        ownx2 = cs_own(tx, ntx, DTW, w2, NL - 2);
+        owny2 = cs_own(ty, nty, DTH, h2, NL - 2);
+        needx2 = NL == 2 ? ownx2 : cs_union(ownx2, cs_tap_range(ownx3, w3, w2, F.shift));
+        needy2 = NL == 2 ? owny2 : cs_union(owny2, cs_tap_range(owny3, h3, h2, F.shift));
+    }
+    const CsRange ownx1 = cs_own(tx, ntx, DTW, w1, NL - 1), owny1 = cs_own(ty, nty, DTH, h1, NL - 1);
+    const CsRange needx1 = NL == 1 ? ownx1 : cs_union(ownx1, cs_tap_range(needx2, w2, w1, F.shift));
+    const CsRange needy1 = NL == 1 ? owny1 : cs_union(owny1, cs_tap_range(needy2, h2, h1, F.shift));
     // level 1 from level 0 in HBM
     {
         const cs_texel* src = pyr + F.off[0];
         cs_texel* dst = pyr + F.off[1];
-        const int nw = needx[1].hi - needx[1].lo, nh = needy[1].hi - needy[1].lo;
+        const int nw = needx1.hi - needx1.lo, nh = needy1.hi - needy1.lo;
         for (int i = valid ? tid : nw * nh; i < nw * nh; i += 256) {
             const int ly = i / nw, lx = i - ly * nw;
-            const int x = needx[1].lo + lx, y = needy[1].lo + ly;
-            const cs_texel t = down_one(src, F.w[0], 0, 0, F.w[0], F.h[0], F.w[1], F.h[1], x, y, F.shift);
+            const int x = needx1.lo + lx, y = needy1.lo + ly;
+            const cs_texel t = down_one(src, w0, 0, 0, w0, h0, w1, h1, x, y, F.shift);
             if (NL > 1) reg1[i] = t;
-            if (x >= ownx[1].lo && x < ownx[1].hi && y >= owny[1].lo && y < owny[1].hi) dst[(size_t)y * F.w[1] + x] = t;
+            if (x >= ownx1.lo && x < ownx1.hi && y >= owny1.lo && y < owny1.hi) dst[(size_t)y * w1 + x] = t;
         }
     }
     if (NL < 2) return;
     __syncthreads();
     {
         cs_texel* dst = pyr + F.off[2];
-        const int sw = needx[1].hi - needx[1].lo;
-        const int nw = needx[2].hi - needx[2].lo, nh = needy[2].hi - needy[2].lo;
+        const int sw = needx1.hi - needx1.lo;
+        const int nw = needx2.hi - needx2.lo, nh = needy2.hi - needy2.lo;
         for (int i = valid ? tid : nw * nh; i < nw * nh; i += 256) {
             const int ly = i / nw, lx = i - ly * nw;
-            const int x = needx[2].lo + lx, y = needy[2].lo + ly;
-            const cs_texel t = down_one(reg1, sw, needx[1].lo, needy[1].lo, F.w[1], F.h[1], F.w[2], F.h[2], x, y, F.shift);
+            const int x = needx2.lo + lx, y = needy2.lo + ly;
+            const cs_texel t = down_one(reg1, sw, needx1.lo, needy1.lo, w1, h1, w2, h2, x, y, F.shift);
             if (NL > 2) reg2[i] = t;
-            if (x >= ownx[2].lo && x < ownx[2].hi && y >= owny[2].lo && y < owny[2].hi) dst[(size_t)y * F.w[2] + x] = t;
+            if (x >= ownx2.lo && x < ownx2.hi && y >= owny2.lo && y < owny2.hi) dst[(size_t)y * w2 + x] = t;
         }
     }
     if (NL < 3) return;
     __syncthreads();
     {
         cs_texel* dst = pyr + F.off[3];
-        const int sw = needx[2].hi - needx[2].lo;
-        const int nw = ownx[3].hi - ownx[3].lo, nh = owny[3].hi - owny[3].lo;
+        const int sw = needx2.hi - needx2.lo;
+        const int nw = ownx3.hi - ownx3.lo, nh = owny3.hi - owny3.lo;
         for (int i = valid ? tid : nw * nh; i < nw * nh; i += 256) {
             const int ly = i / nw, lx = i - ly * nw;
-            const int x = ownx[3].lo + lx, y = owny[3].lo + ly;
-            dst[(size_t)y * F.w[3] + x] =
-                down_one(reg2, sw, needx[2].lo, needy[2].lo, F.w[2], F.h[2], F.w[3], F.h[3], x, y, F.shift);
+            const int x = ownx3.lo + lx, y = owny3.lo + ly;
+            dst[(size_t)y * w3 + x] =
+                down_one(reg2, sw, needx2.lo, needy2.lo, w2, h2, w3, h3, x, y, F.shift);
         }
     }
 }
