@@ -17,3 +17,4 @@ __version__ = "0.1.0"
 from .pose import IntraCamPoseOption, intraCamEstimate  # noqa: F401,E402
 from .ba import BAStats, BAWorkspace, bundleAdjustRobust  # noqa: F401,E402
 from .handback import HandbackCam, handback_dev  # noqa: F401,E402
+from .register import RegisterCam, register_search, register_search_dev  # noqa: F401,E402

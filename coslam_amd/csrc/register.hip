@@ -1,0 +1,323 @@
+// register.hip -- the search step of CoSLAM's map-point registration for all points x all cameras in one launch, gfx950
+// (SURVEY.md 8f-2).
+//
+// Replaces, inside the three registration loops of the reference
+//   CoSLAM::curStaticPointRegInGroup        src/app/SL_CoSLAM.cpp:731-757
+//   CoSLAM::curDynamicPointRegInGroup       src/app/SL_CoSLAM.cpp:955-980
+//   CoSLAM::activeMapPointRegisterInGroup   src/app/SL_CoSLAM.cpp:1118-1145
+// the per (map point, camera) statements that are the same in all three -- isAtCameraBack, project, the image test,
+// getProjectionCovMat, searchMahaNearestFeatPt (src/app/SL_SingleSLAM.cpp:1141-1164: a serial walk over the camera's
+// feature list of the current frame) -- plus the candidate's own term of staticCheckMergability (SL_CoSLAM.cpp:714-729).
+// The reference runs them point by point, camera by camera, under the BA mutex: P x C x N distance evaluations on one
+// host core per frame (1500 x 8 x 2000 = 24 M).  What the loops do with a candidate afterwards (NCC comparison, the walk
+// over the candidate's earlier frames, pointer updates, refineMapPoint, checkUnify) stays with the caller.
+//
+// Layout: one WAVE per (point, camera) pair.  The 64 lanes stride the camera's slots (the hand-back's SoA records: x[N],
+// y[N], state[N] -- coalesced 512-byte rows, 40 KB per camera, L2-resident), every lane keeps its first minimum, and the
+// wave takes the lexicographic minimum of (distance, slot): exactly the serial loop's "strict <, first wins".  A pair that
+// the reference skips (feature of this frame already attached, behind the camera, outside the image) retires after the
+// projection -- the test is wave-uniform.  12000 waves for the headline's rig: the chip is full, the kernel is bound by the
+// 2000 / 64 dependent f64 distance evaluations per lane.
+//
+// searchMahaNearestFeatPt scales the inverse covariance by 1 / maxDist and never compares the distance with a threshold:
+// the nearest feature in that metric wins however far it is.  Reproduced as is; the scaled distance is returned so the
+// caller can gate.  isAtCameraBack / project / getProjectionCovMat / mat22Inv / mahaDist2 are un-vendored LibVisualSLAM:
+// definitions in DESIGN.md, same arithmetic order as the test oracle, no FMA contraction.
+#include "cs_common.h"
+
+#include <cfloat>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int RG_MAX_CAMS = 16;
+
+struct RgArgs {
+    int nCams, N, W, H, P;
+    double sigmaSearch, maxDist, sigmaMerge;
+    const double* M;
+    const double* cov;
+    const int* pointFeat;
+    int* slot;
+    double* m;
+    double* var;
+    double* dist;
+    int* flags;
+    cs_register_cam cam[RG_MAX_CAMS];
+};
+
+struct Proj {
+    double u, v, w;
+    double KR[9];
+};
+
+__device__ __forceinline__ void projection_cov(const Proj& q, const double* __restrict__ cov, double sigma, double var[4]) {
+    const double ww = q.w * q.w;
+    double J[6], JC[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        J[j] = (q.KR[j] * q.w - q.u * q.KR[6 + j]) / ww;
+        J[3 + j] = (q.KR[3 + j] * q.w - q.v * q.KR[6 + j]) / ww;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) JC[3 * i + j] = (J[3 * i] * cov[j] + J[3 * i + 1] * cov[3 + j]) + J[3 * i + 2] * cov[6 + j];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double s = (JC[3 * i] * J[3 * j] + JC[3 * i + 1] * J[3 * j + 1]) + JC[3 * i + 2] * J[3 * j + 2];
+            var[2 * i + j] = (i == j) ? s + sigma * sigma : s;
+        }
+}
+
+__device__ __forceinline__ void mat22_inv(const double A[4], double iA[4]) {
+    const double det = A[0] * A[3] - A[1] * A[2];
+    iA[0] = A[3] / det;
+    iA[1] = -A[1] / det;
+    iA[2] = -A[2] / det;
+    iA[3] = A[0] / det;
+}
+
+__device__ __forceinline__ double maha_dist2(double mx, double my, double bx, double by, const double ivar[4]) {
+    const double dx = mx - bx, dy = my - by;
+    return dx * (ivar[0] * dx + ivar[1] * dy) + dy * (ivar[2] * dx + ivar[3] * dy);
+}
+
+__global__ __launch_bounds__(256) void k_register_search(RgArgs A) {
+    const int lane = threadIdx.x & 63;
+    const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= (long)A.P * A.nCams) return;
+    const int p = (int)(pair / A.nCams), c = (int)(pair - (long)p * A.nCams);
+    const cs_register_cam& C = A.cam[c];
+    const size_t o = (size_t)pair;
+    int outSlot = -1, outFlags = 0;
+    double m0 = 0, m1 = 0, var[4] = {0, 0, 0, 0}, outDist = 0;
+    bool search = false;
+    Proj q;
+    if (A.pointFeat[o] < 0) {  // SL_CoSLAM.cpp:737-738: no feature of this frame attached in this camera yet
+        const double *K = C.K, *R = C.R, *t = C.t, *M = A.M + 3 * (size_t)p;
+        const double X = ((R[0] * M[0] + R[1] * M[1]) + R[2] * M[2]) + t[0];
+        const double Y = ((R[3] * M[0] + R[4] * M[1]) + R[5] * M[2]) + t[1];
+        const double Z = ((R[6] * M[0] + R[7] * M[1]) + R[8] * M[2]) + t[2];
+        if (Z < 0.0) {  // :740-742 isAtCameraBack
+            outSlot = -2;
+        } else {
+            q.u = (K[0] * X + K[1] * Y) + K[2] * Z;
+            q.v = (K[3] * X + K[4] * Y) + K[5] * Z;
+            q.w = (K[6] * X + K[7] * Y) + K[8] * Z;
+            m0 = q.u / q.w;  // :744-745 project
+            m1 = q.v / q.w;
+            if (m0 < 0 || m0 >= (double)A.W || m1 < 0 || m1 >= (double)A.H) {  // :746-748
+                outSlot = -3;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) q.KR[3 * i + j] = (K[3 * i] * R[j] + K[3 * i + 1] * R[3 + j]) + K[3 * i + 2] * R[6 + j];
+                projection_cov(q, A.cov + 9 * (size_t)p, A.sigmaSearch, var);  // :750-753
+                search = true;
+            }
+        }
+    }
+    if (search) {  // wave-uniform
+        // ---- searchMahaNearestFeatPt, SL_SingleSLAM.cpp:1141-1164 ----
+        double ivar[4];
+        mat22_inv(var, ivar);
+        const double sc = 1 / A.maxDist;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ivar[k] = ivar[k] * sc;
+        const int N = A.N;
+        const double* __restrict__ xs = C.xy;
+        const double* __restrict__ ys = C.xy + N;
+        const int* __restrict__ st = C.state;
+        double dMin = DBL_MAX;
+        int iMin = 0x7fffffff;
+        for (int i = lane; i < N; i += 64) {
+            const int s = st[i];
+            const double d = maha_dist2(m0, m1, xs[i], ys[i], ivar);
+            if ((s == 0 || s == 1) && d < dMin) {
+                dMin = d;
+                iMin = i;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double d2 = __shfl_xor(dMin, off, 64);
+            const int i2 = __shfl_xor(iMin, off, 64);
+            if (d2 < dMin || (d2 == dMin && i2 < iMin)) {
+                dMin = d2;
+                iMin = i2;
+            }
+        }
+        if (iMin == 0x7fffffff) {
+            outSlot = -4;
+        } else {
+            outSlot = iMin;
+            outDist = dMin;
+            if (C.slot2map[iMin] < 0) outFlags |= 1;               // :759 pFeat->mpt == 0
+            if (C.isDynamic && C.isDynamic[iMin]) outFlags |= 2;  // :758 pFeat->type
+            double v2[4], iv[4];                                   // staticCheckMergability, the candidate itself (:716-725)
+            projection_cov(q, A.cov + 9 * (size_t)p, A.sigmaMerge, v2);
+            mat22_inv(v2, iv);
+            if (!(maha_dist2(m0, m1, xs[iMin], ys[iMin], iv) > 1.0)) outFlags |= 4;
+        }
+    }
+    if (lane == 0) {
+        A.slot[o] = outSlot;
+        A.flags[o] = outFlags;
+        A.dist[o] = outDist;
+        A.m[2 * o] = m0;
+        A.m[2 * o + 1] = m1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) A.var[4 * o + k] = var[k];
+    }
+}
+
+int check_args(const char* who, int nCams, const cs_register_cam* cams, int N, int W, int H, int P, double sigmaSearch,
+               double maxDist, double sigmaMerge) {
+    if (nCams < 1 || nCams > RG_MAX_CAMS || !cams || N < 1 || W < 1 || H < 1 || P < 0 || !(maxDist > 0) || !(sigmaSearch >= 0) ||
+        !(sigmaMerge >= 0)) {
+        cs_set_error("%s: bad arguments (1..%d cameras, N >= 1, maxDist > 0)", who, RG_MAX_CAMS);
+        return CS_ERR_INVALID;
+    }
+    return CS_OK;
+}
+
+}  // namespace
+
+extern "C" int cs_register_search_dev(int device, void* hip_stream, int nCams, const cs_register_cam* cams, int N, int W, int H,
+                                      int P, const double* d_M, const double* d_cov, const int* d_pointFeat, double sigmaSearch,
+                                      double maxDist, double sigmaMerge, int* d_slot, double* d_m, double* d_var, double* d_dist,
+                                      int* d_flags) {
+    int rc = check_args("cs_register_search_dev", nCams, cams, N, W, H, P, sigmaSearch, maxDist, sigmaMerge);
+    if (rc != CS_OK) return rc;
+    if (P == 0) return CS_OK;
+    if (!d_M || !d_cov || !d_pointFeat || !d_slot || !d_m || !d_var || !d_dist || !d_flags) {
+        cs_set_error("cs_register_search_dev: null pointer");
+        return CS_ERR_INVALID;
+    }
+    RgArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = nCams;
+    A.N = N;
+    A.W = W;
+    A.H = H;
+    A.P = P;
+    A.sigmaSearch = sigmaSearch;
+    A.maxDist = maxDist;
+    A.sigmaMerge = sigmaMerge;
+    A.M = d_M;
+    A.cov = d_cov;
+    A.pointFeat = d_pointFeat;
+    A.slot = d_slot;
+    A.m = d_m;
+    A.var = d_var;
+    A.dist = d_dist;
+    A.flags = d_flags;
+    for (int c = 0; c < nCams; ++c) {
+        const cs_register_cam& q = cams[c];
+        if (!q.K || !q.R || !q.t || !q.xy || !q.state || !q.slot2map) {
+            cs_set_error("cs_register_search_dev: null pointer in camera %d", c);
+            return CS_ERR_INVALID;
+        }
+        A.cam[c] = q;
+    }
+    CS_HIP(hipSetDevice(device));
+    const long pairs = (long)P * nCams;
+    hipLaunchKernelGGL(k_register_search, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream, A);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+// Host-pointer form for the reference's loops: one upload, one launch, one read-back.  cams[c] holds HOST pointers.
+extern "C" int cs_register_search(int device, int nCams, const cs_register_cam* cams, int N, int W, int H, int P, const double* M,
+                                  const double* cov, const int* pointFeat, double sigmaSearch, double maxDist, double sigmaMerge,
+                                  int* slot, double* m, double* var, double* dist, int* flags) {
+    int rc = check_args("cs_register_search", nCams, cams, N, W, H, P, sigmaSearch, maxDist, sigmaMerge);
+    if (rc != CS_OK) return rc;
+    if (P == 0) return CS_OK;
+    if (!M || !cov || !pointFeat || !slot || !m || !var || !dist || !flags) {
+        cs_set_error("cs_register_search: null pointer");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(device));
+    const size_t pairs = (size_t)P * nCams;
+    // one staging block: per camera K R t | xy | state | slot2map | isDynamic, then M | cov | pointFeat, then the outputs
+    const size_t camBytes = (21 + 2 * (size_t)N) * 8 + 2 * (size_t)N * 4 + (((size_t)N + 7) & ~(size_t)7);
+    const size_t inBytes = camBytes * nCams + (size_t)P * 12 * 8 + ((pairs * 4 + 7) & ~(size_t)7);
+    const size_t outBytes = pairs * (2 + 4 + 1) * 8 + 2 * ((pairs * 4 + 7) & ~(size_t)7);
+    char *h = nullptr, *d = nullptr;
+    CS_HIP(hipHostMalloc((void**)&h, inBytes + outBytes, hipHostMallocDefault));
+    if (hipMalloc((void**)&d, inBytes + outBytes) != hipSuccess) {
+        (void)hipHostFree(h);
+        cs_set_error("cs_register_search: out of device memory");
+        return CS_ERR_HIP;
+    }
+    cs_register_cam dc[RG_MAX_CAMS];
+    size_t off = 0;
+    for (int c = 0; c < nCams; ++c) {
+        const cs_register_cam& q = cams[c];
+        if (!q.K || !q.R || !q.t || !q.xy || !q.state || !q.slot2map) {
+            (void)hipHostFree(h);
+            (void)hipFree(d);
+            cs_set_error("cs_register_search: null pointer in camera %d", c);
+            return CS_ERR_INVALID;
+        }
+        memcpy(h + off, q.K, 72);
+        dc[c].K = (const double*)(d + off);
+        memcpy(h + off + 72, q.R, 72);
+        dc[c].R = (const double*)(d + off + 72);
+        memcpy(h + off + 144, q.t, 24);
+        dc[c].t = (const double*)(d + off + 144);
+        size_t o2 = off + 168;
+        memcpy(h + o2, q.xy, 2 * (size_t)N * 8);
+        dc[c].xy = (const double*)(d + o2);
+        o2 += 2 * (size_t)N * 8;
+        memcpy(h + o2, q.state, (size_t)N * 4);
+        dc[c].state = (const int*)(d + o2);
+        o2 += (size_t)N * 4;
+        memcpy(h + o2, q.slot2map, (size_t)N * 4);
+        dc[c].slot2map = (const int*)(d + o2);
+        o2 += (size_t)N * 4;
+        if (q.isDynamic) {
+            memcpy(h + o2, q.isDynamic, (size_t)N);
+            dc[c].isDynamic = (const unsigned char*)(d + o2);
+        } else {
+            dc[c].isDynamic = nullptr;
+        }
+        off += camBytes;
+    }
+    const size_t oM = off, oC = oM + (size_t)P * 24, oF = oC + (size_t)P * 72;
+    memcpy(h + oM, M, (size_t)P * 24);
+    memcpy(h + oC, cov, (size_t)P * 72);
+    memcpy(h + oF, pointFeat, pairs * 4);
+    const size_t pad4 = (pairs * 4 + 7) & ~(size_t)7;
+    const size_t om = inBytes, ov = om + pairs * 16, od = ov + pairs * 32, os = od + pairs * 8, ofl = os + pad4;
+    hipStream_t s = nullptr;
+    hipError_t e = hipMemcpyAsync(d, h, inBytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        rc = cs_register_search_dev(device, s, nCams, dc, N, W, H, P, (const double*)(d + oM), (const double*)(d + oC),
+                                    (const int*)(d + oF), sigmaSearch, maxDist, sigmaMerge, (int*)(d + os), (double*)(d + om),
+                                    (double*)(d + ov), (double*)(d + od), (int*)(d + ofl));
+        if (rc == CS_OK) e = hipMemcpyAsync(h + inBytes, d + inBytes, outBytes, hipMemcpyDeviceToHost, s);
+        if (rc == CS_OK && e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    if (rc == CS_OK && e == hipSuccess) {
+        memcpy(m, h + om, pairs * 16);
+        memcpy(var, h + ov, pairs * 32);
+        memcpy(dist, h + od, pairs * 8);
+        memcpy(slot, h + os, pairs * 4);
+        memcpy(flags, h + ofl, pairs * 4);
+    }
+    (void)hipHostFree(h);
+    (void)hipFree(d);
+    if (rc != CS_OK) return rc;
+    if (e != hipSuccess) {
+        cs_set_error("cs_register_search: %s", hipGetErrorString(e));
+        return CS_ERR_HIP;
+    }
+    return CS_OK;
+}

@@ -1,0 +1,75 @@
+"""Search step of CoSLAM's map-point registration (cs_register_search*): for every (map point, camera) pair what
+CoSLAM::curStaticPointRegInGroup / curDynamicPointRegInGroup / activeMapPointRegisterInGroup (reference
+src/app/SL_CoSLAM.cpp:731-757, 955-980, 1118-1145) compute before they decide -- projection, projected covariance, the
+Mahalanobis-nearest feature of the camera's current frame (searchMahaNearestFeatPt, src/app/SL_SingleSLAM.cpp:1141-1164) --
+for all points and cameras in one launch."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+SKIP_HAS_FEATURE, SKIP_BEHIND, SKIP_OUTSIDE, SKIP_NO_FEATURES = -1, -2, -3, -4
+FLAG_UNMAPPED, FLAG_DYNAMIC, FLAG_MERGEABLE = 1, 2, 4
+
+
+class RegisterCam(C.Structure):
+    """== cs_register_cam (include/coslam_hip.h)."""
+
+    _fields_ = [(n, C.c_void_p) for n in ("K", "R", "t", "xy", "state", "slot2map", "isDynamic")]
+
+
+def _cams(cams):
+    arr = (RegisterCam * len(cams))()
+    for a, c in zip(arr, cams):
+        for n, _ in RegisterCam._fields_:
+            v = c.get(n)
+            setattr(a, n, int(v) if v else None)
+    return arr
+
+
+def register_search_dev(stream_ptr, cams, N, W, H, P, d_M, d_cov, d_pointFeat, sigmaSearch, maxDist, sigmaMerge, d_slot, d_m,
+                        d_var, d_dist, d_flags, device=0):
+    """cams: list of dicts of DEVICE pointers (ints) with the field names of cs_register_cam; outputs P x nCams tables."""
+    vp = C.c_void_p
+    check(lib().cs_register_search_dev(int(device), vp(stream_ptr), len(cams), _cams(cams), int(N), int(W), int(H), int(P),
+                                       vp(d_M), vp(d_cov), vp(d_pointFeat), C.c_double(sigmaSearch), C.c_double(maxDist),
+                                       C.c_double(sigmaMerge), vp(d_slot), vp(d_m), vp(d_var), vp(d_dist), vp(d_flags)),
+          "cs_register_search_dev")
+
+
+def register_search(W, H, Ks, Rs, ts, xy, state, slot2map, isDynamic, Ms, covs, pointFeat, sigmaSearch, maxDist, sigmaMerge,
+                    device=0):
+    """Host arrays in and out (cs_register_search).  xy / state / slot2map / isDynamic: one array per camera (isDynamic
+    entries may be None).  Returns dict(slot, m, var, dist, flags), P x nCams each."""
+    nC = len(xy)
+    N = len(state[0])
+    Ks = np.ascontiguousarray(Ks, dtype=np.float64).reshape(nC, 9)
+    Rs = np.ascontiguousarray(Rs, dtype=np.float64).reshape(nC, 9)
+    ts = np.ascontiguousarray(ts, dtype=np.float64).reshape(nC, 3)
+    Ms = np.ascontiguousarray(Ms, dtype=np.float64).reshape(-1, 3)
+    P = len(Ms)
+    covs = np.ascontiguousarray(covs, dtype=np.float64).reshape(P, 9)
+    pf = np.ascontiguousarray(pointFeat, dtype=np.int32).reshape(P, nC)
+    keep = []
+    cams = []
+    for c in range(nC):
+        x = np.ascontiguousarray(xy[c], dtype=np.float64)
+        s = np.ascontiguousarray(state[c], dtype=np.int32)
+        m2 = np.ascontiguousarray(slot2map[c], dtype=np.int32)
+        dy = None if isDynamic is None or isDynamic[c] is None else np.ascontiguousarray(isDynamic[c], dtype=np.uint8)
+        assert x.size == 2 * N and s.size == N and m2.size == N
+        keep += [x, s, m2, dy]
+        cams.append(dict(K=Ks[c].ctypes.data, R=Rs[c].ctypes.data, t=ts[c].ctypes.data, xy=x.ctypes.data, state=s.ctypes.data,
+                         slot2map=m2.ctypes.data, isDynamic=None if dy is None else dy.ctypes.data))
+    slot = np.zeros((P, nC), dtype=np.int32)
+    m = np.zeros((P, nC, 2))
+    var = np.zeros((P, nC, 4))
+    dist = np.zeros((P, nC))
+    flags = np.zeros((P, nC), dtype=np.int32)
+    vp = C.c_void_p
+    check(lib().cs_register_search(int(device), nC, _cams(cams), int(N), int(W), int(H), int(P), vp(Ms.ctypes.data),
+                                   vp(covs.ctypes.data), vp(pf.ctypes.data), C.c_double(sigmaSearch), C.c_double(maxDist),
+                                   C.c_double(sigmaMerge), vp(slot.ctypes.data), vp(m.ctypes.data), vp(var.ctypes.data),
+                                   vp(dist.ctypes.data), vp(flags.ctypes.data)), "cs_register_search")
+    return dict(slot=slot, m=m, var=var, dist=dist, flags=flags)

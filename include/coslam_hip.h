@@ -237,6 +237,44 @@ int cs_klt_handback_dev(int device, void* hip_stream, int nCams, const cs_handba
                         int nColBlk, int nRowBlk, int ptsStride, int frame /* GPUKLT::m_frame of this call, >= 0 */);
 
 /* ------------------------------------------------------------------------------------------
+ * Map-point registration: the search step for all map points x all cameras in one launch
+ * ------------------------------------------------------------------------------------------
+ * Replaces, inside CoSLAM::curStaticPointRegInGroup (src/app/SL_CoSLAM.cpp:731-757), curDynamicPointRegInGroup (:955-980)
+ * and activeMapPointRegisterInGroup (:1118-1145), the statements they share per (map point, camera): isAtCameraBack,
+ * project, the image test, getProjectionCovMat, searchMahaNearestFeatPt (src/app/SL_SingleSLAM.cpp:1141-1164), plus the
+ * candidate's own term of staticCheckMergability (:714-729).  A caller runs it once per frame before its loop over the
+ * points and reads the candidates from the tables; what happens to a candidate afterwards stays in the caller.
+ * The three loops differ only in the scalars:   sigmaSearch  maxDist          sigmaMerge
+ *     current static points                     pixelErrVar  3 pixelErrVar    pixelErrVar
+ *     current dynamic points                    pixelErrVar  4 pixelErrVar    pixelErrVar
+ *     active points                             2.5 pixelErrVar  3 pixelErrVar  pixelErrVar
+ * Features of a camera = the hand-back records of this frame (cs_klt_handback_dev): slots with state 0 or 1, in slot
+ * order (the order GPUKLT::addToFeaturePoints appends them to FeaturePoints). */
+typedef struct cs_register_cam {
+    const double* K;                /* 9: slam[iCam].K */
+    const double* R;                /* 9: m_camPos.current()->R */
+    const double* t;                /* 3 */
+    const double* xy;               /* 2N: undistorted pixel, x[N] then y[N] (FeaturePoint::m) */
+    const int* state;               /* N: 0 tracked, 1 new; anything else = not in this frame's list */
+    const int* slot2map;            /* N: FeaturePoint::mpt as an index, < 0 = none */
+    const unsigned char* isDynamic; /* N or NULL: FeaturePoint::type == TYPE_FEATPOINT_DYNAMIC */
+} cs_register_cam;
+/* Outputs are P x nCams tables (point-major).  slot: >= 0 the nearest feature's slot; -1 pointFeat says the point already
+ * has a feature of this frame in the camera; -2 behind the camera; -3 projects outside [0,W) x [0,H); -4 the camera has
+ * no feature this frame.  m (x2): the projection; var (x4): its covariance; dist: the winner's Mahalanobis distance
+ * scaled by 1 / maxDist (the reference applies NO threshold to it); flags: bit 0 the candidate has no map point, bit 1
+ * it is dynamic, bit 2 it passes the candidate's own mergability term (distance under var(sigmaMerge) <= 1).
+ * pointFeat (P x nCams): slot of p->pFeatures[iCam] when that feature belongs to the current frame, else -1.
+ * cams: HOST array of nCams (<= 16) records; in the _dev form their members and every d_* argument are DEVICE pointers,
+ * in the host form everything is host memory (one upload, one launch, one read-back). */
+int cs_register_search_dev(int device, void* hip_stream, int nCams, const cs_register_cam* cams, int N, int W, int H, int P,
+                           const double* d_M, const double* d_cov, const int* d_pointFeat, double sigmaSearch, double maxDist,
+                           double sigmaMerge, int* d_slot, double* d_m, double* d_var, double* d_dist, int* d_flags);
+int cs_register_search(int device, int nCams, const cs_register_cam* cams, int N, int W, int H, int P, const double* M,
+                       const double* cov, const int* pointFeat, double sigmaSearch, double maxDist, double sigmaMerge, int* slot,
+                       double* m, double* var, double* dist, int* flags);
+
+/* ------------------------------------------------------------------------------------------
  * Robust multi-camera bundle adjustment
  * ------------------------------------------------------------------------------------------ */
 

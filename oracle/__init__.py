@@ -152,6 +152,52 @@ def handback(features, W, H, K, kud, mapPts, slot2map, trackSpan, xy, frame, isS
     return dict(state=st, selBlk=selBlk, npts=n, Ms=Ms[:n], ms=ms[:n], sel=sel[:n])
 
 
+def search_maha_nearest(xy, state, m, var, maxDist):
+    """org_search_maha_nearest (searchMahaNearestFeatPt): xy float64[2N] (x then y), state int32[N].  Returns (slot, dmin)."""
+    L = lib()
+    L.org_search_maha_nearest.restype = C.c_int
+    xy = np.ascontiguousarray(xy, dtype=np.float64)
+    st = np.ascontiguousarray(state, dtype=np.int32)
+    m = np.ascontiguousarray(m, dtype=np.float64)
+    var = np.ascontiguousarray(var, dtype=np.float64).reshape(4)
+    d = C.c_double(0)
+    s = L.org_search_maha_nearest(len(st), _p(xy), _p(st), _p(m), _p(var), C.c_double(maxDist), C.byref(d))
+    return s, d.value
+
+
+def register_search(W, H, Ks, Rs, ts, xy, state, slot2map, isDynamic, Ms, covs, pointFeat, sigmaSearch, maxDist, sigmaMerge):
+    """org_register_search: per-camera lists xy (float64[2N]), state / slot2map (int32[N]), isDynamic (uint8[N] or None);
+    Ms (P x 3), covs (P x 9), pointFeat (P x nCams int32).  Returns dict(slot, m, var, dist, flags), P x nCams each."""
+    L = lib()
+    nC = len(xy)
+    N = len(state[0])
+    Ks = np.ascontiguousarray(Ks, dtype=np.float64).reshape(nC, 9)
+    Rs = np.ascontiguousarray(Rs, dtype=np.float64).reshape(nC, 9)
+    ts = np.ascontiguousarray(ts, dtype=np.float64).reshape(nC, 3)
+    Ms = np.ascontiguousarray(Ms, dtype=np.float64).reshape(-1, 3)
+    P = len(Ms)
+    covs = np.ascontiguousarray(covs, dtype=np.float64).reshape(P, 9)
+    pf = np.ascontiguousarray(pointFeat, dtype=np.int32).reshape(P, nC)
+    xs = [np.ascontiguousarray(a, dtype=np.float64) for a in xy]
+    ss = [np.ascontiguousarray(a, dtype=np.int32) for a in state]
+    s2 = [np.ascontiguousarray(a, dtype=np.int32) for a in slot2map]
+    dy = [None if a is None else np.ascontiguousarray(a, dtype=np.uint8) for a in isDynamic]
+    vp = C.c_void_p * nC
+    a_xy = vp(*[a.ctypes.data for a in xs])
+    a_st = vp(*[a.ctypes.data for a in ss])
+    a_s2 = vp(*[a.ctypes.data for a in s2])
+    a_dy = vp(*[None if a is None else a.ctypes.data for a in dy])
+    slot = np.zeros((P, nC), dtype=np.int32)
+    m = np.zeros((P, nC, 2))
+    var = np.zeros((P, nC, 4))
+    dist = np.zeros((P, nC))
+    flags = np.zeros((P, nC), dtype=np.int32)
+    L.org_register_search(nC, N, int(W), int(H), _p(Ks), _p(Rs), _p(ts), a_xy, a_st, a_s2, a_dy, P, _p(Ms), _p(covs), _p(pf),
+                          C.c_double(sigmaSearch), C.c_double(maxDist), C.c_double(sigmaMerge), _p(slot), _p(m), _p(var),
+                          _p(dist), _p(flags))
+    return dict(slot=slot, m=m, var=var, dist=dist, flags=flags)
+
+
 def set_threshold_margin_buffer(buf):
     """buf: float32[N] preset to a large value (kept alive by the caller), or None to switch the diagnostic off."""
     lib().okl_set_threshold_margin_buffer(_p(buf) if buf is not None else None)

@@ -131,6 +131,20 @@ int ohb_handback(int N, int W, int H, int frame, const okl_tracked_feature* feat
                  const double* mapPts, const unsigned char* isStatic, int* slot2map, int* trackSpan, double* xy, int* state,
                  int nColBlk, int nRowBlk, int* selBlk, int ptsStride, double* Ms, double* ms, int* sel);
 
+/* ---- search step of CoSLAM's map-point registration restated (register_oracle.c): projection, projected covariance,
+ * searchMahaNearestFeatPt, the candidate's own mergability term ---- */
+int org_is_at_camera_back(const double R[9], const double t[3], const double M[3]);
+void org_project(const double K[9], const double R[9], const double t[3], const double M[3], double m[2]);
+void org_projection_cov(const double K[9], const double R[9], const double t[3], const double M[3], const double cov[9],
+                        double var[4], double sigma);
+int org_search_maha_nearest(int N, const double* xy, const int* state, const double m[2], const double var[4], double maxDist,
+                            double* dmin);
+void org_register_search(int nCams, int N, int W, int H, const double* Ks, const double* Rs, const double* ts,
+                         const double* const* xy, const int* const* state, const int* const* slot2map,
+                         const unsigned char* const* isDynamic, int P, const double* Ms, const double* covs,
+                         const int* pointFeat, double sigmaSearch, double maxDist, double sigmaMerge, int* slot, double* m_out,
+                         double* var_out, double* dist, int* flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,10 @@ void matATB(int m, int n, int p, int q, const double* A, const double* B, double
 void matAB(int m, int n, int p, int q, const double* A, const double* B, double* C);
 /* invA = A^-1, n x n (LibVisualSLAM: LAPACK dgetrf/dgetri; here LU with partial pivoting) */
 void matInv(int n, const double* A, double* invA);
+/* adjugate / determinant (the closed form; searchMahaNearestFeatPt, src/app/SL_SingleSLAM.cpp:1148) */
 void mat22Inv(const double* A, double* invA);
+/* B(m x n) = s A(m x n) (src/app/SL_SingleSLAM.cpp:1149: matScale(2, 2, ivar, 1 / maxDist, ivar)) */
+void matScale(int m, int n, const double* A, double s, double* B);
 void mat33Inv(const double* A, double* invA);
 void mat33Trans(const double* A, double* At);
 /* Euclidean distance of two 2-vectors (src/app/SL_SingleSLAM.cpp:658: dist2(m, fp->m)) */

@@ -12,7 +12,6 @@ template <class... A> void getCameraCenter(const A&...);
 template <class... A> void triangulateMultiView(const A&...);
 template <class... A> int searchNearestPoint(const A&...);
 template <class... A> double reprojErrorSingle(const A&...);
-template <class... A> void matScale(const A&...);
 template <class... A> bool intraCamEstimateEpi(const A&...);
 template <class... A> void getTriangulateCovMat(const A&...);
 template <class... A> void getInvK(const A&...);

@@ -60,7 +60,17 @@ void matInv(int n, const double* A, double* invA) {
         for (int j = 0; j < n; ++j) invA[i * n + j] = M[(size_t)i * 2 * n + n + j];
 }
 
-void mat22Inv(const double* A, double* invA) { matInv(2, A, invA); }
+void mat22Inv(const double* A, double* invA) {
+    const double det = A[0] * A[3] - A[1] * A[2];
+    const double a = A[0], b = A[1], c = A[2], d = A[3];
+    invA[0] = d / det;
+    invA[1] = -b / det;
+    invA[2] = -c / det;
+    invA[3] = a / det;
+}
+void matScale(int m, int n, const double* A, double s, double* B) {
+    for (int i = 0; i < m * n; ++i) B[i] = A[i] * s;
+}
 void mat33Inv(const double* A, double* invA) { matInv(3, A, invA); }
 
 void project(const double* K, const double* R, const double* t, const double* M, double* m) {

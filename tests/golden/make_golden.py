@@ -9,6 +9,10 @@ klt_golden.npz   -- small KLT cases (pyramid texels, detection list, two tracked
                     The reference's KLT cannot run here (Cg/OpenGL), so these pin our restatement against regressions;
                     they are NOT reference outputs (parity unpinned, see oracle/klt_oracle.h).
 ba_golden.npz    -- cfg1-shaped BA problem solved by oracle/ba_oracle.c (our definition; parity unpinned).
+register_golden.npz -- a feature list, 400 (m, var, maxDist) queries and the answers of the REFERENCE's own
+                    searchMahaNearestFeatPt (src/app/SL_SingleSLAM.cpp:1141-1164 compiled in place into
+                    oracle/_ref/ref_register_test, `golden` mode, CPU).  Pins oracle/register_oracle.c's search and,
+                    on the GPU box, the registration kernel.
 """
 import os
 import sys
@@ -82,14 +86,40 @@ def ba_case():
                 outlier=outl, stats=np.array([st.cost0, st.cost, st.nIterTotal, st.nOuter, st.nOutliers]))
 
 
+def register_case():
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_register_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_register_test missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "reg.bin")
+        subprocess.run([exe, "golden", path], check=True)
+        raw = open(path, "rb").read()
+    N, Q, none, _ = np.frombuffer(raw, dtype=np.int32, count=4)
+    o = 16
+    xy = np.frombuffer(raw, dtype=np.float64, count=2 * N, offset=o)
+    o += 16 * N
+    state = np.frombuffer(raw, dtype=np.int32, count=N, offset=o)
+    o += 4 * N
+    q = np.frombuffer(raw, dtype=np.float64, count=7 * Q, offset=o).reshape(Q, 7)
+    o += 56 * Q
+    ans = np.frombuffer(raw, dtype=np.int32, count=Q, offset=o)
+    return dict(xy=xy.copy(), state=state.copy(), m=q[:, 0:2].copy(), var=q[:, 2:6].copy(), maxDist=q[:, 6].copy(),
+                slot=ans.copy(), empty_frame_returns_null=np.int32(1 - none))
+
+
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
         np.savez_compressed(os.path.join(HERE, "klt_golden.npz"), **klt_cases())
     if "ba" in which:
         np.savez_compressed(os.path.join(HERE, "ba_golden.npz"), **ba_case())
+    if "register" in which:
+        np.savez_compressed(os.path.join(HERE, "register_golden.npz"), **register_case())
     print("golden fixtures written")

@@ -7,7 +7,9 @@
 * oracle/_ref/ref_ba_dropin_test       the REFERENCE'S OWN src/app/SL_CoSLAMRobustBA.cpp (parseInputs / run),
                                        SL_InterCamPoseEstimator.cpp (addMapPoints / apply) and SL_SingleSLAM.cpp
                                        (chooseStaticFeatPts ...) compiled in place over the shims.
-The two oracle/_ref binaries are built by oracle/Makefile where the reference tree exists (__graft_entry__.build()) and
+* oracle/_ref/ref_register_test        the REFERENCE'S OWN searchMahaNearestFeatPt (src/app/SL_SingleSLAM.cpp:1141-1164) over
+                                       FeaturePoints lists built with the reference's classes, against cs_register_search.
+The oracle/_ref binaries are built by oracle/Makefile where the reference tree exists (__graft_entry__.build()) and
 travel with the repo snapshot; the reference sources themselves are never copied."""
 import os
 import subprocess
@@ -34,6 +36,11 @@ def test_reference_gpuklt_source_runs_over_the_shim_and_matches_the_device_handb
 def test_reference_ba_callers_run_over_the_shim(hip):
     out = _run(os.path.join(ROOT, "oracle", "_ref", "ref_ba_dropin_test"), "ref BA callers drop-in ok")
     assert "RobustBundleRTS drop-in ok" in out and "InterCamPoseEstimator drop-in ok" in out
+    print(out)
+
+
+def test_reference_search_function_agrees_with_the_registration_kernel(hip):
+    out = _run(os.path.join(ROOT, "oracle", "_ref", "ref_register_test"), "candidates agree with the reference's searchMahaNearestFeatPt")
     print(out)
 
 

@@ -1,0 +1,190 @@
+"""cs_register_search* (the search step of CoSLAM's map-point registration, reference src/app/SL_CoSLAM.cpp:731-757,
+955-980, 1118-1145 + searchMahaNearestFeatPt, src/app/SL_SingleSLAM.cpp:1141-1164) against
+  * the answers of the reference's own searchMahaNearestFeatPt (tests/golden/register_golden.npz), and
+  * the oracle's restatement of the loops: every output table bit for bit (integers and binary64, same operation order),
+at the headline's size (8 cameras x 2000 slots x 1500 points), on ragged / empty / duplicated inputs, and chained behind
+the tracker's on-device hand-back."""
+import os
+
+import numpy as np
+import pytest
+
+import coslam_amd
+import oracle
+from coslam_amd.synth import Scene
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+W, H = 640, 480
+PIXEL_ERR_VAR = 10.0            # Const::PIXEL_ERR_VAR, reference src/app/SL_GlobParam.cpp:37
+MODES = {"static": (PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR),       # SL_CoSLAM.cpp:750-756
+         "dynamic": (PIXEL_ERR_VAR, 4 * PIXEL_ERR_VAR, PIXEL_ERR_VAR),      # :975-979
+         "active": (2.5 * PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)}  # :1131-1143
+
+
+def assert_tables_equal(g, o, what=""):
+    assert np.array_equal(g["slot"], o["slot"]), f"{what}: {(g['slot'] != o['slot']).sum()} candidates differ"
+    assert np.array_equal(g["flags"], o["flags"]), what
+    for k in ("m", "var", "dist"):
+        assert np.array_equal(g[k], o[k]), f"{what}: {k} differs by {np.abs(g[k] - o[k]).max()}"
+
+
+def test_register_search_returns_what_the_reference_returns(hip):
+    """Golden queries (m, var, maxDist) with the reference's answers.  K = R = I, t = 0, M = (m, 1) and a covariance whose
+    third row / column is zero make the kernel's projection and projected covariance EXACTLY the query's (sigma 0)."""
+    g = np.load(os.path.join(GOLD, "register_golden.npz"))
+    N = len(g["state"])
+    I3 = np.eye(3)
+    for md in np.unique(g["maxDist"]):
+        q = np.nonzero(g["maxDist"] == md)[0]
+        Ms = np.concatenate([g["m"][q], np.ones((len(q), 1))], axis=1)
+        covs = np.zeros((len(q), 3, 3))
+        covs[:, :2, :2] = g["var"][q].reshape(-1, 2, 2)
+        r = coslam_amd.register_search(W, H, I3, I3, np.zeros(3), [g["xy"]], [g["state"]], [np.full(N, -1, np.int32)], [None],
+                                       Ms, covs, np.full((len(q), 1), -1, np.int32), 0.0, float(md), 1.0)
+        assert np.array_equal(r["m"][:, 0], g["m"][q]) and np.array_equal(r["var"][:, 0], g["var"][q])
+        assert np.array_equal(r["slot"][:, 0], g["slot"][q])
+
+
+def _rig(n_cams, N, P, seed, frame=3):
+    """cameras of the synthetic rig, random feature records around the projections of the scene's points"""
+    rng = np.random.default_rng(seed)
+    sc = Scene(n_cams, W, H, P, seed=seed)
+    Ks = np.stack([sc.K for _ in range(n_cams)])
+    Rs = np.stack([sc.pose(c, frame)[0] for c in range(n_cams)])
+    ts = np.stack([sc.pose(c, frame)[1] for c in range(n_cams)])
+    Ms = sc.points[:P].copy()
+    Ms[::37] *= -1.0                                    # some behind the cameras
+    A = rng.normal(size=(P, 3, 3)) * 0.02
+    covs = A @ A.transpose(0, 2, 1) + 1e-6 * np.eye(3)
+    xy, state, s2m, dyn = [], [], [], []
+    for c in range(n_cams):
+        uv, vis = sc.project(c, frame)
+        x = rng.uniform(0, W, N)
+        y = rng.uniform(0, H, N)
+        k = np.nonzero(vis[:P])[0][: N // 2]            # half of the slots sit near a point's projection
+        x[: len(k)] = uv[k, 0] + rng.normal(0, 2.0, len(k))
+        y[: len(k)] = uv[k, 1] + rng.normal(0, 2.0, len(k))
+        x[5::101] = x[4::101][: len(x[5::101])]         # exact duplicates: first must win
+        y[5::101] = y[4::101][: len(y[5::101])]
+        r = rng.uniform(size=N)
+        state.append(np.where(r < 0.06, -1, np.where(r < 0.08, -2, np.where(r < 0.3, 1, 0))).astype(np.int32))
+        xy.append(np.concatenate([x, y]))
+        s2m.append(np.where(rng.uniform(size=N) < 0.4, rng.integers(0, P, N), -1).astype(np.int32))
+        dyn.append((rng.uniform(size=N) < 0.1).astype(np.uint8))
+    pf = np.where(rng.uniform(size=(P, n_cams)) < 0.25, rng.integers(0, N, (P, n_cams)), -1).astype(np.int32)
+    return Ks, Rs, ts, xy, state, s2m, dyn, Ms, covs, pf
+
+
+@pytest.mark.parametrize("mode", ["static", "dynamic", "active"])
+@pytest.mark.parametrize("n_cams,N,P", [(8, 2000, 1500), (3, 777, 211), (1, 65, 9), (2, 1, 40)])
+def test_register_search_matches_oracle(hip, mode, n_cams, N, P):
+    Ks, Rs, ts, xy, state, s2m, dyn, Ms, covs, pf = _rig(n_cams, N, P, seed=100 + N)
+    sS, mD, sM = MODES[mode]
+    o = oracle.register_search(W, H, Ks, Rs, ts, xy, state, s2m, dyn, Ms, covs, pf, sS, mD, sM)
+    g = coslam_amd.register_search(W, H, Ks, Rs, ts, xy, state, s2m, dyn, Ms, covs, pf, sS, mD, sM)
+    assert_tables_equal(g, o, f"{mode} {n_cams}x{N}x{P}")
+    if P >= 200:   # every branch was taken
+        s = o["slot"]
+        assert (s >= 0).sum() > P // 4 and (s == -1).any() and (s == -2).any() and (s == -3).any()
+        assert (o["flags"][s >= 0] & 4).any() and not (o["flags"][s >= 0] & 4).all()
+
+
+def test_register_search_edge_cases(hip):
+    Ks, Rs, ts, xy, state, s2m, dyn, Ms, covs, pf = _rig(2, 300, 50, seed=9)
+    sS, mD, sM = MODES["static"]
+    # a camera whose frame has no feature at all; isDynamic absent
+    state[1][:] = -1
+    o = oracle.register_search(W, H, Ks, Rs, ts, xy, state, s2m, [None, None], Ms, covs, pf, sS, mD, sM)
+    g = coslam_amd.register_search(W, H, Ks, Rs, ts, xy, state, s2m, [None, None], Ms, covs, pf, sS, mD, sM)
+    assert_tables_equal(g, o, "empty camera")
+    assert (o["slot"][:, 1] == -4).any() and not (o["slot"][:, 1] >= 0).any()
+    # every point already attached everywhere
+    full = np.zeros_like(pf)
+    g = coslam_amd.register_search(W, H, Ks, Rs, ts, xy, state, s2m, dyn, Ms, covs, full, sS, mD, sM)
+    assert (g["slot"] == -1).all() and not g["dist"].any()
+    # no points: nothing to do
+    g = coslam_amd.register_search(W, H, Ks, Rs, ts, xy, state, s2m, dyn, Ms[:0], covs[:0], pf[:0], sS, mD, sM)
+    assert g["slot"].shape == (0, 2)
+    with pytest.raises(coslam_amd.CoslamHipError):
+        coslam_amd.register_search(W, H, Ks, Rs, ts, xy, state, s2m, dyn, Ms, covs, pf, sS, 0.0, sM)     # maxDist must be > 0
+    with pytest.raises(coslam_amd.CoslamHipError):
+        coslam_amd.register_search_dev(0, [], 10, W, H, 1, 1, 1, 1, sS, mD, sM, 1, 1, 1, 1, 1)             # no cameras
+
+
+def test_register_search_behind_the_tracker_and_the_hand_back(hip):
+    """Data-coupled: detect on rendered frames of 3 cameras -> cs_klt_handback_dev -> cs_register_search_dev reading the
+    hand-back's device records in place; the oracle runs the same chain on the host."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    n_cams, fw, fh, P = 3, 50, 40, 1200
+    N = fw * fh
+    sc = Scene(n_cams, W, H, 4000, seed=31)
+    cfg = coslam_amd.KLT_SequenceTrackerConfig(nIterations=10, nLevels=4, levelSkip=1, windowWidth=7, trackWithGain=1,
+                                               minCornerness=3000.0, convergenceThreshold=1.0, SSD_Threshold=20000.0, minDistance=5)
+    K = sc.K
+    kud = np.zeros(7)
+    rng = np.random.default_rng(3)
+    Ms = sc.points[:P].copy()
+    A = rng.normal(size=(P, 3, 3)) * 0.01
+    covs = A @ A.transpose(0, 2, 1) + 1e-6 * np.eye(3)
+    d_K, d_kud, d_map = (torch.from_numpy(a.copy()).to(dev) for a in (K.ravel(), kud, Ms))
+    d_cov = torch.from_numpy(covs.reshape(-1).copy()).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    hb, o_xy, o_state, o_s2m, Rs, ts, keep = [], [], [], [], [], [], []
+    for c in range(n_cams):
+        trk = coslam_amd.KLT_SequenceTracker(cfg, device=0)
+        trk.allocate(W, H, 4, fw, fh)
+        _, dest = trk.detect(sc.render(c, 0))
+        trk.close()
+        s2m = np.full(N, -1, np.int32)
+        span, xyo = np.full(2 * N, -1, np.int32), np.zeros(2 * N)
+        r = oracle.handback(dest, W, H, K, kud, Ms, s2m.copy(), span, xyo, 0)
+        o_xy.append(xyo)
+        o_state.append(r["state"])
+        s2m[::3] = rng.integers(0, P, len(s2m[::3]))     # "map initialisation" after the first hand-back, on both sides
+        o_s2m.append(s2m)
+        t = dict(dest=torch.from_numpy(dest.view(np.int32).copy()).to(dev), s2m=torch.full((N,), -1, dtype=torch.int32, device=dev),
+                 tl=torch.full((2 * N,), -1, dtype=torch.int32, device=dev), xy=torch.zeros(2 * N, dtype=torch.float64, device=dev),
+                 state=torch.zeros(N, dtype=torch.int32, device=dev), Ms=torch.zeros(192 * 3, dtype=torch.float64, device=dev),
+                 ms=torch.zeros(192 * 2, dtype=torch.float64, device=dev), sel=torch.zeros(192, dtype=torch.int32, device=dev),
+                 npts=torch.zeros(1, dtype=torch.int32, device=dev))
+        keep.append(t)
+        hb.append(dict(dest=t["dest"].data_ptr(), K=d_K.data_ptr(), kud=d_kud.data_ptr(), mapPts=d_map.data_ptr(),
+                       slot2map=t["s2m"].data_ptr(), trackSpan=t["tl"].data_ptr(), xy=t["xy"].data_ptr(), state=t["state"].data_ptr(),
+                       Ms=t["Ms"].data_ptr(), ms=t["ms"].data_ptr(), sel=t["sel"].data_ptr(), npts=t["npts"].data_ptr()))
+        R, tt = sc.pose(c, 0)
+        Rs.append(R)
+        ts.append(tt)
+    coslam_amd.handback_dev(stream, hb, N, W, H, 16, 12, 192, frame=0)
+    for c in range(n_cams):
+        keep[c]["s2m"].copy_(torch.from_numpy(o_s2m[c]))
+    d_R = torch.from_numpy(np.stack(Rs).reshape(-1).copy()).to(dev)
+    d_t = torch.from_numpy(np.stack(ts).reshape(-1).copy()).to(dev)
+    pf = np.full((P, n_cams), -1, np.int32)
+    d_pf = torch.from_numpy(pf).to(dev)
+    out = dict(slot=torch.zeros(P * n_cams, dtype=torch.int32, device=dev), m=torch.zeros(P * n_cams * 2, dtype=torch.float64, device=dev),
+               var=torch.zeros(P * n_cams * 4, dtype=torch.float64, device=dev), dist=torch.zeros(P * n_cams, dtype=torch.float64, device=dev),
+               flags=torch.zeros(P * n_cams, dtype=torch.int32, device=dev))
+    cams = [dict(K=d_K.data_ptr(), R=d_R.data_ptr() + 72 * c, t=d_t.data_ptr() + 24 * c, xy=keep[c]["xy"].data_ptr(),
+                 state=keep[c]["state"].data_ptr(), slot2map=keep[c]["s2m"].data_ptr()) for c in range(n_cams)]
+    sS, mD, sM = MODES["active"]
+    coslam_amd.register_search_dev(stream, cams, N, W, H, P, d_map.data_ptr(), d_cov.data_ptr(), d_pf.data_ptr(), sS, mD, sM,
+                                   out["slot"].data_ptr(), out["m"].data_ptr(), out["var"].data_ptr(), out["dist"].data_ptr(),
+                                   out["flags"].data_ptr())
+    torch.cuda.synchronize()
+    for c in range(n_cams):
+        assert np.array_equal(keep[c]["xy"].cpu().numpy(), o_xy[c]) and np.array_equal(keep[c]["s2m"].cpu().numpy(), o_s2m[c])
+    o = oracle.register_search(W, H, np.stack([K] * n_cams), np.stack(Rs), np.stack(ts), o_xy, o_state, o_s2m, [None] * n_cams,
+                               Ms, covs, pf, sS, mD, sM)
+    g = dict(slot=out["slot"].cpu().numpy().reshape(P, n_cams), flags=out["flags"].cpu().numpy().reshape(P, n_cams),
+             m=out["m"].cpu().numpy().reshape(P, n_cams, 2), var=out["var"].cpu().numpy().reshape(P, n_cams, 4),
+             dist=out["dist"].cpu().numpy().reshape(P, n_cams))
+    assert_tables_equal(g, o, "chained")
+    assert (o["slot"] >= 0).sum() > 500
+    # points that project onto a detected corner find it: within ~4 px (scaled distance r^2 / (sigma^2 maxDist) < 1e-3), and
+    # such a candidate passes the mergability term (r^2 / pixelErrVar^2 <= 1)
+    near = (o["slot"] >= 0) & (o["dist"] < 1e-3)
+    assert near.sum() > 30 and (o["flags"][near] & 4).all()
