@@ -8,6 +8,11 @@ the whole rig, i.e. every camera's image consumed and poses updated:
     all cameras   hand-back on the device (undistort, track bookkeeping, one static mapped track per 40x40 block, Ms/ms
                   packing) [GPUKLT::addToFeaturePoints, SingleSLAM::chooseStaticFeatPts / poseUpdate3D] feeding
                   intraCamEstimate of every camera, started from the previous frame's result [SL_CoSLAM.cpp:366-417]
+    all cameras   map-point registration, search step, twice per frame as the reference does [CoSLAMThread.cpp:108-118]:
+                  activeMapPointsRegister (1536 active points: covariance sigma 2.5 x, SL_CoSLAM.cpp:1118-1145) and
+                  currentMapPointsRegister (1536 current static points, skipping cameras where the point already has a
+                  feature of this frame, :731-757): projection with the poses just solved + Mahalanobis-nearest feature
+                  over the hand-back's records of every camera
     key frames    (every KEY_EVERY-th frame)
                   joint local BA: last 5 key frames of all 8 cameras = 40 cameras, the 16 oldest fixed, maxIter 2 / inner
                   10 [requestForBA(5, 2, 2, 30) -> RobustBundleRTS, SL_CoSLAM.cpp:1345,1731-1784], on its own stream like
@@ -38,6 +43,8 @@ N_FRAMES = 24
 PTS_STRIDE = 192          # 12 x 16 blocks (reference src/app/SL_SingleSLAM.h:36-37)
 N_COL_BLK, N_ROW_BLK = 16, 12
 KEY_EVERY = 5
+P_REG = 1536             # map points per registration pass (the size of the inter-camera solve's static set)
+PIXEL_ERR_VAR = 10.0      # Const::PIXEL_ERR_VAR, reference src/app/SL_GlobParam.cpp:37
 HBM_PEAK_GBS = 8000.0
 SEED = 0xC051A + 2
 
@@ -96,14 +103,21 @@ def associate(sc, cam, frame, dest):
     return s2m
 
 
-def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s):
+def reg_covariances():
+    """MapPoint::cov of the 2 x P_REG registered points: synthetic SPD 3 x 3, a few cm"""
+    rng = np.random.default_rng(SEED + 23)
+    A = rng.normal(size=(2 * P_REG, 3, 3)) * 0.02
+    return A @ A.transpose(0, 2, 1) + 1e-6 * np.eye(3)
+
+
+def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True):
     """The oracle (C restatement of the reference's path: kind "port") on `n_threads` host cores: the cameras of a frame
     in parallel (the ctypes calls release the GIL), the key-frame solves on the calling thread."""
     import oracle
 
     order = frame_order(N_FRAMES)
     cfg = klt_config()
-    trk, s2m, tl, xy, Rc, tc = [], [], [], [], [], []
+    trk, s2m, tl, xy, Rc, tc, st = [], [], [], [], [], [], []
     for c in range(N_CAMS):
         o = oracle.SequenceTracker(cfg)
         o.allocate(W, H, LEVELS, FW, FH)
@@ -113,7 +127,7 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s):
         s2m.append(associate(sc, c, order[0], d))
         tl.append(np.full(2 * N_FEAT, -1, dtype=np.int32))
         xy.append(np.zeros(2 * N_FEAT))
-        oracle.handback(d, W, H, sc.K, np.zeros(7), sc.points, s2m[c], tl[c], xy[c], 0)
+        st.append(oracle.handback(d, W, H, sc.K, np.zeros(7), sc.points, s2m[c], tl[c], xy[c], 0)["state"])
         s2m[c][:] = associate(sc, c, order[0], d)   # (the first hand-back resets new tracks: restore the map)
         R, t = sc.pose(c, order[0])
         Rc.append(R.copy())
@@ -126,14 +140,30 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s):
         _, d = trk[c].redetect(frames[c][f])
         trk[c].advanceFrame()
         hb = oracle.handback(d, W, H, sc.K, kud, sc.points, s2m[c], tl[c], xy[c], frame_no)
+        st[c] = hb["state"]
         if hb["npts"] >= 6:
             ok, R, t, _ = oracle.intracam_estimate(sc.K, Rc[c], tc[c], hb["npts"], None, hb["Ms"], hb["ms"], 10.0)
             if ok:
                 Rc[c], tc[c] = R, t
 
+    cov = reg_covariances()
+    no_feat = np.full((P_REG, 1), -1, dtype=np.int32)
+    Kc = sc.K
+
+    def reg_step(c):
+        # activeMapPointsRegister + currentMapPointsRegister, search step, this camera's column of the tables
+        one = lambda a: [a]  # noqa: E731
+        oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), sc.points[P_REG:2 * P_REG],
+                               cov[P_REG:], no_feat, 2.5 * PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)
+        pf = oracle.point_features(st[c], s2m[c], P_REG).reshape(P_REG, 1)
+        oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), sc.points[:P_REG],
+                               cov[:P_REG], pf, PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)
+
     def run_cams(cams, f, frame_no):
         for c in cams:
             cam_step(c, f, frame_no)
+            if with_register:
+                reg_step(c)
 
     t_start = time.perf_counter()
     n = 0
@@ -168,6 +198,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="diagnostic: every leg on ONE stream (no overlap)")
     ap.add_argument("--key-every", type=int, default=KEY_EVERY, help="diagnostic: 0 disables the key-frame solves (not a valid bench line)")
     ap.add_argument("--no-pose", action="store_true", help="diagnostic: skip hand-back + pose (not a valid bench line)")
+    ap.add_argument("--no-register", action="store_true", help="diagnostic: skip the map-point registration search (not a valid bench line)")
     ap.add_argument("--native-comm", type=int, default=1, help="N > 1: collectives issued by libcoslam_hip (RCCL behind the C-ABI) instead of torch.distributed")
     args = ap.parse_args()
 
@@ -178,6 +209,7 @@ def main():
     from coslam_amd.ba import BAWorkspace
     from coslam_amd.handback import handback_dev
     from coslam_amd.pose import intraCamEstimate_batch_dev
+    from coslam_amd.register import register_search_dev
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -227,6 +259,13 @@ def main():
     d_npts = torch.zeros(nc, dtype=torch.int32, device=dev)
     d_opt = torch.zeros((nc, 96), dtype=torch.uint8, device=dev)
     d_ok = torch.zeros(nc, dtype=torch.int32, device=dev)
+    # map-point registration: P x nCams tables (this rank's cameras are its columns), covariances of the 2 x P_REG points
+    d_cov = torch.from_numpy(reg_covariances().reshape(-1).copy()).to(dev)
+    d_pf = torch.full((P_REG, nc), -1, dtype=torch.int32, device=dev)           # written by the hand-back every frame
+    d_pf_none = torch.full((P_REG, nc), -1, dtype=torch.int32, device=dev)      # active points: no feature of this frame
+    reg_out = [dict(slot=torch.zeros((P_REG, nc), dtype=torch.int32, device=dev), m=torch.zeros((P_REG, nc, 2), dtype=torch.float64, device=dev),
+                    var=torch.zeros((P_REG, nc, 4), dtype=torch.float64, device=dev), dist=torch.zeros((P_REG, nc), dtype=torch.float64, device=dev),
+                    flags=torch.zeros((P_REG, nc), dtype=torch.int32, device=dev)) for _ in range(2)]
     R0 = np.stack([sc.pose(c, order[0])[0].ravel() for c in my_cams])
     t0 = np.stack([sc.pose(c, order[0])[1] for c in my_cams])
     d_R = [torch.from_numpy(R0.copy()).to(dev), torch.from_numpy(R0.copy()).to(dev)]   # pose ping-pong: frame f reads [f&1^1]
@@ -289,7 +328,8 @@ def main():
         return [dict(dest=d_dests[b][i].data_ptr(), K=d_K1.data_ptr(), kud=d_kud.data_ptr(), mapPts=d_map.data_ptr(),
                      slot2map=d_slot2map[i].data_ptr(), trackSpan=d_trackspan[i].data_ptr(), xy=d_xy[i].data_ptr(),
                      state=d_state[i].data_ptr(), Ms=d_Ms[i].data_ptr(), ms=d_ms[i].data_ptr(), sel=d_sel[i].data_ptr(),
-                     npts=d_npts[i:i + 1].data_ptr(), opt=d_opt[i].data_ptr()) for i in range(nc)]
+                     npts=d_npts[i:i + 1].data_ptr(), opt=d_opt[i].data_ptr(), pointFeat=d_pf.data_ptr() + 4 * i,
+                     pointFeatStride=nc, nPointFeat=P_REG) for i in range(nc)]
 
     hb_args = [hb_cams(0), hb_cams(1)]
     dest_ptrs = [[d.data_ptr() for d in d_dests[b]] for b in range(2)]
@@ -304,6 +344,23 @@ def main():
                                    d_t[src].data_ptr(), d_npts.data_ptr(), 0, d_Ms.data_ptr(), d_ms.data_ptr(), 10.0,
                                    d_R[dst].data_ptr(), d_t[dst].data_ptr(), d_opt.data_ptr(), d_ok.data_ptr(),
                                    device=local_rank)
+        if not args.no_register:
+            register_leg(dst)
+
+    def reg_cams(dst):
+        return [dict(K=d_K1.data_ptr(), R=d_R[dst].data_ptr() + 72 * i, t=d_t[dst].data_ptr() + 24 * i, xy=d_xy[i].data_ptr(),
+                     state=d_state[i].data_ptr(), slot2map=d_slot2map[i].data_ptr()) for i in range(nc)]
+
+    reg_args = [reg_cams(0), reg_cams(1)]
+
+    def register_leg(dst):
+        # CoSLAMThread.cpp:108 activeMapPointsRegister, then :117 currentMapPointsRegister (static points), search step
+        for k, (pts_off, pf, sS) in enumerate(((P_REG, d_pf_none, 2.5 * PIXEL_ERR_VAR), (0, d_pf, PIXEL_ERR_VAR))):
+            o = reg_out[k]
+            register_search_dev(pose_s.cuda_stream, reg_args[dst], N_FEAT, W, H, P_REG, d_map.data_ptr() + 24 * pts_off,
+                                d_cov.data_ptr() + 72 * pts_off, pf.data_ptr(), sS, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR,
+                                o["slot"].data_ptr(), o["m"].data_ptr(), o["var"].data_ptr(), o["dist"].data_ptr(),
+                                o["flags"].data_ptr(), device=local_rank)
 
     def step(i):
         f, fn = order[i % len(order)], order[(i + 1) % len(order)]
@@ -466,8 +523,8 @@ def main():
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
         nt = min(cores, N_CAMS)
-        v1, n1, dt1 = cpu_baseline(sc, frames, joint, ic, 1, 12.0)
-        vN, nN, dtN = cpu_baseline(sc, frames, joint, ic, nt, 12.0) if nt > 1 else (v1, n1, dt1)
+        v1, n1, dt1 = cpu_baseline(sc, frames, joint, ic, 1, 12.0, not args.no_register)
+        vN, nN, dtN = cpu_baseline(sc, frames, joint, ic, nt, 12.0, not args.no_register) if nt > 1 else (v1, n1, dt1)
         cpu = {"value": vN, "unit": "frames/s", "cores": nt, "kind": "port",
                "sample": f"{nN} frames of the same 8-camera workload on {nt} threads (cameras in parallel) in {dtN:.1f} s; "
                          f"{n1} frames on 1 thread in {dt1:.1f} s (oracle/: C restatement, gcc -O2); host has {cores} cores",
@@ -482,7 +539,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "8 cams 640x480 x 2000 KLT slots (50x40), 4-level pyramid, 7x7 window, 10 it/level with "
                                    "gain, redetect every frame; on-device hand-back + intraCamEstimate of all 8 cameras "
-                                   f"every frame (fed by the tracker's output); every {KEY_EVERY}th frame: joint local BA "
+                                   "every frame (fed by the tracker's output); map-point registration search every frame "
+                                   f"(active + current static, {P_REG} points each x 8 cams x 2000 slots); "
+                                   f"every {KEY_EVERY}th frame: joint local BA "
                                    f"C=40 (16 fixed) x {len(joint['pts0'])} pts x {len(joint['obs_cam'])} meas, maxIter 2 / inner 10, and "
                                    f"inter-camera solve C=8 free, {ic['n_static']} static pts fixed + {ic['n_dynamic']} dynamic, "
                                    "sigma 6, 3 x 40; N>1: cameras sharded 8/N per GPU, all-gather of features+pose per "
@@ -495,6 +554,9 @@ def main():
                        "intercam_last": {"lm_steps": st_i.nIterTotal, "outliers": st_i.nOutliers, "cost0": st_i.cost0,
                                          "cost": st_i.cost},
                        "frame_front_prefetch": bool(prefetch), "secondary_cfg2": cfg2,
+                       "register_candidates_last_frame": None if args.no_register else
+                       {"active": int((reg_out[0]["slot"] >= 0).sum().item()), "current_static": int((reg_out[1]["slot"] >= 0).sum().item()),
+                        "already_attached": int((reg_out[1]["slot"] == -1).sum().item())},
                        "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
                        "collectives": None if world == 1 else ("libcoslam_hip RCCL (C-ABI)" if native else "torch.distributed " + dist_backend),
                        "streams": "one stream (--serial)" if args.serial else

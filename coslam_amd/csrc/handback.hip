@@ -49,6 +49,8 @@ __global__ __launch_bounds__(1024) void k_handback(HbArgs A) {
     const int tid = threadIdx.x, N = A.N;
     const int nBlk = A.nColBlk * A.nRowBlk;
     for (int b = tid; b < nBlk; b += 1024) key[b] = 0ull;
+    if (C.pointFeat)
+        for (int q = tid; q < C.nPointFeat; q += 1024) C.pointFeat[(size_t)q * C.pointFeatStride] = -1;
     __syncthreads();
     // ---- GPUKLT.cpp:36-60 per slot, then the block vote of SL_SingleSLAM.cpp:353-384 ------------------------------
     for (int i = tid; i < N; i += 1024) {
@@ -83,6 +85,8 @@ __global__ __launch_bounds__(1024) void k_handback(HbArgs A) {
         C.trackSpan[i] = f1;
         C.trackSpan[N + i] = f2;
         C.slot2map[i] = mp;
+        // MapPoint::pFeatures[iCam] of the current frame: the (highest) slot in this frame's list that carries the point
+        if (C.pointFeat && mp >= 0 && mp < C.nPointFeat && (st == 0 || st == 1)) atomicMax(&C.pointFeat[(size_t)mp * C.pointFeatStride], i);
         if (len > 0) {  // !tk->empty(); candidates are the static ones: here every mapped slot and, when the caller
                         // supplies the classification, every slot it marks static
             const bool isStatic = (mp >= 0) || (C.isStatic && C.isStatic[i]);
@@ -167,6 +171,10 @@ extern "C" int cs_klt_handback_dev(int device, void* hip_stream, int nCams, cons
         if (!q.dest || !q.K || !q.kud || !q.mapPts || !q.slot2map || !q.trackSpan || !q.xy || !q.state || !q.Ms || !q.ms ||
             !q.sel || !q.npts) {
             cs_set_error("cs_klt_handback_dev: null pointer in camera %d", c);
+            return CS_ERR_INVALID;
+        }
+        if (q.pointFeat && (q.pointFeatStride < 1 || q.nPointFeat < 0)) {
+            cs_set_error("cs_klt_handback_dev: bad pointFeat stride / count in camera %d", c);
             return CS_ERR_INVALID;
         }
         A.cam[c] = q;

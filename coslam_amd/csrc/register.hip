@@ -12,12 +12,12 @@
 // host core per frame (1500 x 8 x 2000 = 24 M).  What the loops do with a candidate afterwards (NCC comparison, the walk
 // over the candidate's earlier frames, pointer updates, refineMapPoint, checkUnify) stays with the caller.
 //
-// Layout: one WAVE per (point, camera) pair.  The 64 lanes stride the camera's slots (the hand-back's SoA records: x[N],
-// y[N], state[N] -- coalesced 512-byte rows, 40 KB per camera, L2-resident), every lane keeps its first minimum, and the
-// wave takes the lexicographic minimum of (distance, slot): exactly the serial loop's "strict <, first wins".  A pair that
-// the reference skips (feature of this frame already attached, behind the camera, outside the image) retires after the
-// projection -- the test is wave-uniform.  12000 waves for the headline's rig: the chip is full, the kernel is bound by the
-// 2000 / 64 dependent f64 distance evaluations per lane.
+// Layout: one workgroup per (tile of 64 map points, camera); lane = point, the camera's feature list (the hand-back's SoA
+// records x[N], y[N], state[N]) staged in LDS once and walked with broadcast reads by 16 waves, 1/16 of the list each; the
+// waves' minima are merged on (distance, slot) -- exactly the serial loop's "strict <, first wins".  The first version ran
+// one wave per pair with the lanes striding the list out of L2: 12000 waves x 2000 x 20 B = 480 MB of L1 fills per launch,
+// 59 us in the benchmark loop; staging cuts that to 15 MB.  A pair the reference skips (feature of this frame already
+// attached, behind the camera, outside the image) only idles its lane.
 //
 // searchMahaNearestFeatPt scales the inverse covariance by 1 / maxDist and never compares the distance with a threshold:
 // the nearest feature in that metric wins however far it is.  Reproduced as is; the scaled distance is returned so the
@@ -86,18 +86,33 @@ __device__ __forceinline__ double maha_dist2(double mx, double my, double bx, do
     return dx * (ivar[0] * dx + ivar[1] * dy) + dy * (ivar[2] * dx + ivar[3] * dy);
 }
 
-__global__ __launch_bounds__(256) void k_register_search(RgArgs A) {
-    const int lane = threadIdx.x & 63;
-    const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pair >= (long)A.P * A.nCams) return;
-    const int p = (int)(pair / A.nCams), c = (int)(pair - (long)p * A.nCams);
+constexpr int RG_WAVES = 16;      // waves per workgroup: each scans 1 / 16 of the staged features for the block's 64 points
+constexpr int RG_CHUNK = 4096;    // features staged in LDS at a time (64 KB); longer lists are scanned chunk by chunk
+
+// One workgroup = 64 map points x one camera.  Lane = point: its projection and scaled inverse covariance live in
+// registers.  The camera's feature list is staged in LDS once per workgroup (x, y as doubles; a slot that is not in this
+// frame's list is staged as NaN, so its distance compares false and it can never win -- no state test in the loop), and
+// every wave walks its share of it with BROADCAST reads: one LDS read serves 64 points.  Per wave the walk is in slot
+// order with a strict <, the waves' minima are merged lexicographically on (distance, slot): the serial loop's answer.
+__global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y;
+    const int p = blockIdx.x * 64 + lane;
     const cs_register_cam& C = A.cam[c];
-    const size_t o = (size_t)pair;
+    const int N = A.N;
+    const int CH = N < RG_CHUNK ? N : RG_CHUNK;
+    double* sx = lds;
+    double* sy = lds + CH;
+    double* cd = lds + 2 * CH;                        // [RG_WAVES][64]
+    int* ci = (int*)(cd + RG_WAVES * 64);             // [RG_WAVES][64]
+    const size_t o = (size_t)p * A.nCams + c;
     int outSlot = -1, outFlags = 0;
     double m0 = 0, m1 = 0, var[4] = {0, 0, 0, 0}, outDist = 0;
+    double ivar[4] = {0, 0, 0, 0};
     bool search = false;
     Proj q;
-    if (A.pointFeat[o] < 0) {  // SL_CoSLAM.cpp:737-738: no feature of this frame attached in this camera yet
+    if (wave == 0 && p < A.P && A.pointFeat[o] < 0) {  // SL_CoSLAM.cpp:737-738: no feature of this frame attached in this camera yet
         const double *K = C.K, *R = C.R, *t = C.t, *M = A.M + 3 * (size_t)p;
         const double X = ((R[0] * M[0] + R[1] * M[1]) + R[2] * M[2]) + t[0];
         const double Y = ((R[3] * M[0] + R[4] * M[1]) + R[5] * M[2]) + t[1];
@@ -118,54 +133,84 @@ __global__ __launch_bounds__(256) void k_register_search(RgArgs A) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j) q.KR[3 * i + j] = (K[3 * i] * R[j] + K[3 * i + 1] * R[3 + j]) + K[3 * i + 2] * R[6 + j];
                 projection_cov(q, A.cov + 9 * (size_t)p, A.sigmaSearch, var);  // :750-753
+                mat22_inv(var, ivar);                                          // SL_SingleSLAM.cpp:1148-1149
+                const double sc = 1 / A.maxDist;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ivar[k] = ivar[k] * sc;
                 search = true;
             }
         }
     }
-    if (search) {  // wave-uniform
-        // ---- searchMahaNearestFeatPt, SL_SingleSLAM.cpp:1141-1164 ----
-        double ivar[4];
-        mat22_inv(var, ivar);
-        const double sc = 1 / A.maxDist;
+    if (__syncthreads_or(search)) {
+        // the projection and the scaled inverse covariance were worked out by wave 0 only: hand them to the other waves
+        double* sq = cd;  // [6][64], overwritten by the minima after the scan
+        if (wave == 0) {
+            sq[lane] = m0;
+            sq[64 + lane] = m1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ivar[k] = ivar[k] * sc;
-        const int N = A.N;
+            for (int k = 0; k < 4; ++k) sq[(2 + k) * 64 + lane] = ivar[k];
+        }
+        __syncthreads();
+        if (wave != 0) {
+            m0 = sq[lane];
+            m1 = sq[64 + lane];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ivar[k] = sq[(2 + k) * 64 + lane];
+        }
+        // ---- searchMahaNearestFeatPt, SL_SingleSLAM.cpp:1141-1164 ----
         const double* __restrict__ xs = C.xy;
         const double* __restrict__ ys = C.xy + N;
         const int* __restrict__ st = C.state;
         double dMin = DBL_MAX;
         int iMin = 0x7fffffff;
-        for (int i = lane; i < N; i += 64) {
-            const int s = st[i];
-            const double d = maha_dist2(m0, m1, xs[i], ys[i], ivar);
-            if ((s == 0 || s == 1) && d < dMin) {
-                dMin = d;
-                iMin = i;
+        for (int base = 0; base < N; base += CH) {
+            const int n = (N - base) < CH ? (N - base) : CH;
+            if (base) __syncthreads();
+            for (int i = threadIdx.x; i < n; i += 64 * RG_WAVES) {
+                const int s = st[base + i];
+                const bool in = (s == 0 || s == 1);
+                sx[i] = in ? xs[base + i] : __builtin_nan("");
+                sy[i] = in ? ys[base + i] : __builtin_nan("");
+            }
+            __syncthreads();
+            const int per = (n + RG_WAVES - 1) / RG_WAVES;
+            const int lo = wave * per, hi = (lo + per) < n ? (lo + per) : n;
+            for (int i = lo; i < hi; ++i) {
+                const double d = maha_dist2(m0, m1, sx[i], sy[i], ivar);
+                if (d < dMin) {
+                    dMin = d;
+                    iMin = base + i;
+                }
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double d2 = __shfl_xor(dMin, off, 64);
-            const int i2 = __shfl_xor(iMin, off, 64);
-            if (d2 < dMin || (d2 == dMin && i2 < iMin)) {
-                dMin = d2;
-                iMin = i2;
+        cd[wave * 64 + lane] = dMin;  // (every wave read its copy of sq before the staging barrier above)
+        ci[wave * 64 + lane] = iMin;
+        __syncthreads();
+        if (wave == 0 && search) {
+#pragma unroll 4
+            for (int w = 1; w < RG_WAVES; ++w) {
+                const double d2 = cd[w * 64 + lane];
+                const int i2 = ci[w * 64 + lane];
+                if (d2 < dMin || (d2 == dMin && i2 < iMin)) {
+                    dMin = d2;
+                    iMin = i2;
+                }
             }
-        }
-        if (iMin == 0x7fffffff) {
-            outSlot = -4;
-        } else {
-            outSlot = iMin;
-            outDist = dMin;
-            if (C.slot2map[iMin] < 0) outFlags |= 1;               // :759 pFeat->mpt == 0
-            if (C.isDynamic && C.isDynamic[iMin]) outFlags |= 2;  // :758 pFeat->type
-            double v2[4], iv[4];                                   // staticCheckMergability, the candidate itself (:716-725)
-            projection_cov(q, A.cov + 9 * (size_t)p, A.sigmaMerge, v2);
-            mat22_inv(v2, iv);
-            if (!(maha_dist2(m0, m1, xs[iMin], ys[iMin], iv) > 1.0)) outFlags |= 4;
+            if (iMin == 0x7fffffff) {
+                outSlot = -4;
+            } else {
+                outSlot = iMin;
+                outDist = dMin;
+                if (C.slot2map[iMin] < 0) outFlags |= 1;               // :759 pFeat->mpt == 0
+                if (C.isDynamic && C.isDynamic[iMin]) outFlags |= 2;  // :758 pFeat->type
+                double v2[4], iv[4];                                   // staticCheckMergability, the candidate itself (:716-725)
+                projection_cov(q, A.cov + 9 * (size_t)p, A.sigmaMerge, v2);
+                mat22_inv(v2, iv);
+                if (!(maha_dist2(m0, m1, xs[iMin], ys[iMin], iv) > 1.0)) outFlags |= 4;
+            }
         }
     }
-    if (lane == 0) {
+    if (wave == 0 && p < A.P) {
         A.slot[o] = outSlot;
         A.flags[o] = outFlags;
         A.dist[o] = outDist;
@@ -226,8 +271,17 @@ extern "C" int cs_register_search_dev(int device, void* hip_stream, int nCams, c
         A.cam[c] = q;
     }
     CS_HIP(hipSetDevice(device));
-    const long pairs = (long)P * nCams;
-    hipLaunchKernelGGL(k_register_search, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream, A);
+    const int CH = N < RG_CHUNK ? N : RG_CHUNK;
+    const size_t ldsBytes = (size_t)2 * CH * sizeof(double) + (size_t)RG_WAVES * 64 * (sizeof(double) + sizeof(int));
+    if (ldsBytes > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            CS_HIP(hipFuncSetAttribute((const void*)k_register_search, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(k_register_search, dim3((unsigned)((P + 63) / 64), (unsigned)nCams), dim3(64 * RG_WAVES), ldsBytes,
+                       (hipStream_t)hip_stream, A);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

@@ -11,7 +11,8 @@ class HandbackCam(C.Structure):
     """== cs_handback_cam (include/coslam_hip.h): device pointers of one camera."""
 
     _fields_ = [(n, C.c_void_p) for n in ("dest", "K", "kud", "mapPts", "isStatic", "slot2map", "trackSpan", "xy", "state",
-                                          "selBlk", "Ms", "ms", "sel", "npts", "opt")]
+                                          "selBlk", "Ms", "ms", "sel", "npts", "opt", "pointFeat")] + \
+               [("pointFeatStride", C.c_int), ("nPointFeat", C.c_int)]
 
 
 def handback_dev(stream_ptr, cams, N, W, H, nColBlk=16, nRowBlk=12, ptsStride=192, device=0, frame=0):
@@ -19,8 +20,8 @@ def handback_dev(stream_ptr, cams, N, W, H, nColBlk=16, nRowBlk=12, ptsStride=19
     frame: GPUKLT::m_frame of this call (the tracks' frame spans are kept in trackSpan)."""
     arr = (HandbackCam * len(cams))()
     for a, c in zip(arr, cams):
-        for n, _ in HandbackCam._fields_:
+        for n, ty in HandbackCam._fields_:
             v = c.get(n)
-            setattr(a, n, int(v) if v else None)
+            setattr(a, n, int(v or 0) if ty is C.c_int else (int(v) if v else None))
     check(lib().cs_klt_handback_dev(int(device), C.c_void_p(stream_ptr), len(cams), arr, int(N), int(W), int(H),
                                     int(nColBlk), int(nRowBlk), int(ptsStride), int(frame)), "cs_klt_handback_dev")

@@ -230,6 +230,11 @@ typedef struct cs_handback_cam {
     int* sel;                   /* ptsStride out: slot of every packed correspondence */
     int* npts;                  /* 1 out */
     cs_pose_option* opt;        /* 1 out or NULL: reset to IntraCamPoseOption() for the pose solve that follows */
+    int* pointFeat;             /* out or NULL: for map points 0 .. nPointFeat-1 the slot of this camera's feature of THIS
+                                   frame attached to the point (MapPoint::pFeatures[iCam] with ->f == curFrame), else -1;
+                                   entry p is pointFeat[p * pointFeatStride] -- a column of the P x nCams table
+                                   cs_register_search_dev reads */
+    int pointFeatStride, nPointFeat;
 } cs_handback_cam;
 /* cams: HOST array of nCams (<= 16) records of device pointers.  nColBlk x nRowBlk = 16 x 12 in CoSLAM
  * (src/app/SL_SingleSLAM.h:36-37); ptsStride >= the most correspondences wanted per camera (192). */

@@ -152,6 +152,15 @@ def handback(features, W, H, K, kud, mapPts, slot2map, trackSpan, xy, frame, isS
     return dict(state=st, selBlk=selBlk, npts=n, Ms=Ms[:n], ms=ms[:n], sel=sel[:n])
 
 
+def point_features(state, slot2map, P):
+    """ohb_point_features: int32[P], the slot of the camera's feature of this frame attached to every map point, or -1."""
+    st = np.ascontiguousarray(state, dtype=np.int32)
+    s2 = np.ascontiguousarray(slot2map, dtype=np.int32)
+    out = np.zeros(P, dtype=np.int32)
+    lib().ohb_point_features(len(st), _p(st), _p(s2), int(P), 1, _p(out))
+    return out
+
+
 def search_maha_nearest(xy, state, m, var, maxDist):
     """org_search_maha_nearest (searchMahaNearestFeatPt): xy float64[2N] (x then y), state int32[N].  Returns (slot, dmin)."""
     L = lib()

@@ -109,3 +109,15 @@ int ohb_handback(int N, int W, int H, int frame, const okl_tracked_feature* feat
     free(tracks);
     return n < ptsStride ? n : ptsStride;
 }
+
+/* MapPoint::pFeatures[iCam] restricted to the current frame, as a table column: for map points 0..P-1 the slot of this
+ * camera's feature of THIS frame (state 0 or 1) whose FeaturePoint::mpt is the point, else -1 -- what the registration
+ * loops test with `p->pFeatures[iCam] && p->pFeatures[iCam]->f == curFrame` (SL_CoSLAM.cpp:737-738).  When two slots
+ * carry the same point (the reference's pointer can only hold one) the higher slot is reported. */
+void ohb_point_features(int N, const int* state, const int* slot2map, int P, int stride, int* pointFeat) {
+    for (int p = 0; p < P; p++) pointFeat[(size_t)p * stride] = -1;
+    for (int i = 0; i < N; i++) {
+        const int mp = slot2map[i];
+        if (mp >= 0 && mp < P && (state[i] == 0 || state[i] == 1)) pointFeat[(size_t)mp * stride] = i;
+    }
+}

@@ -131,6 +131,8 @@ int ohb_handback(int N, int W, int H, int frame, const okl_tracked_feature* feat
                  const double* mapPts, const unsigned char* isStatic, int* slot2map, int* trackSpan, double* xy, int* state,
                  int nColBlk, int nRowBlk, int* selBlk, int ptsStride, double* Ms, double* ms, int* sel);
 
+void ohb_point_features(int N, const int* state, const int* slot2map, int P, int stride, int* pointFeat);
+
 /* ---- search step of CoSLAM's map-point registration restated (register_oracle.c): projection, projected covariance,
  * searchMahaNearestFeatPt, the candidate's own mergability term ---- */
 int org_is_at_camera_back(const double R[9], const double t[3], const double M[3]);

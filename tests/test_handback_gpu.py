@@ -45,6 +45,7 @@ def test_handback_matches_oracle_over_a_sequence(hip, distort, n_cams):
               sel=torch.zeros(192, dtype=torch.int32, device=dev), npts=torch.zeros(1, dtype=torch.int32, device=dev),
               opt=torch.zeros(96, dtype=torch.uint8, device=dev), stat=torch.from_numpy(st_o[c]["stat"]).to(dev))
          for c in range(n_cams)]
+    d_pf = torch.full((P, n_cams), -7, dtype=torch.int32, device=dev)   # P x nCams table, one column per camera
     stream = torch.cuda.current_stream().cuda_stream
     total_dropped = 0
     for frame in range(6):
@@ -61,8 +62,9 @@ def test_handback_matches_oracle_over_a_sequence(hip, distort, n_cams):
         cams = [dict(dest=x["dest"].data_ptr(), K=d_K.data_ptr(), kud=d_kud.data_ptr(), mapPts=d_map.data_ptr(),
                      isStatic=x["stat"].data_ptr(), slot2map=x["s2m"].data_ptr(), trackSpan=x["tl"].data_ptr(),
                      xy=x["xy"].data_ptr(), state=x["state"].data_ptr(), selBlk=x["selBlk"].data_ptr(), Ms=x["Ms"].data_ptr(),
-                     ms=x["ms"].data_ptr(), sel=x["sel"].data_ptr(), npts=x["npts"].data_ptr(), opt=x["opt"].data_ptr())
-                for x in d]
+                     ms=x["ms"].data_ptr(), sel=x["sel"].data_ptr(), npts=x["npts"].data_ptr(), opt=x["opt"].data_ptr(),
+                     pointFeat=d_pf.data_ptr() + 4 * c, pointFeatStride=n_cams, nPointFeat=P)
+                for c, x in enumerate(d)]
         coslam_amd.handback_dev(stream, cams, N, W, H, 16, 12, 192, frame=10 + frame)
         torch.cuda.synchronize()
         for c in range(n_cams):
@@ -74,6 +76,7 @@ def test_handback_matches_oracle_over_a_sequence(hip, distort, n_cams):
             assert np.array_equal(g["tl"].cpu().numpy(), o["tl"]) and np.array_equal(g["s2m"].cpu().numpy(), o["s2m"])
             assert np.array_equal(g["xy"].cpu().numpy(), o["xy"]), (frame, c)
             assert np.array_equal(g["selBlk"].cpu().numpy(), r["selBlk"]), (frame, c)
+            assert np.array_equal(d_pf[:, c].cpu().numpy(), oracle.point_features(r["state"], o["s2m"], P)), (frame, c)
             n = int(g["npts"].item())
             assert n == r["npts"]
             assert np.array_equal(g["sel"].cpu().numpy()[:n], r["sel"])

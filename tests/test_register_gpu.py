@@ -78,14 +78,14 @@ def _rig(n_cams, N, P, seed, frame=3):
 
 
 @pytest.mark.parametrize("mode", ["static", "dynamic", "active"])
-@pytest.mark.parametrize("n_cams,N,P", [(8, 2000, 1500), (3, 777, 211), (1, 65, 9), (2, 1, 40)])
+@pytest.mark.parametrize("n_cams,N,P", [(8, 2000, 1500), (3, 777, 211), (1, 65, 9), (2, 1, 40), (2, 5000, 333), (1, 9001, 70)])
 def test_register_search_matches_oracle(hip, mode, n_cams, N, P):
     Ks, Rs, ts, xy, state, s2m, dyn, Ms, covs, pf = _rig(n_cams, N, P, seed=100 + N)
     sS, mD, sM = MODES[mode]
     o = oracle.register_search(W, H, Ks, Rs, ts, xy, state, s2m, dyn, Ms, covs, pf, sS, mD, sM)
     g = coslam_amd.register_search(W, H, Ks, Rs, ts, xy, state, s2m, dyn, Ms, covs, pf, sS, mD, sM)
     assert_tables_equal(g, o, f"{mode} {n_cams}x{N}x{P}")
-    if P >= 200:   # every branch was taken
+    if P >= 1000:   # the headline's size: every branch was taken
         s = o["slot"]
         assert (s >= 0).sum() > P // 4 and (s == -1).any() and (s == -2).any() and (s == -3).any()
         assert (o["flags"][s >= 0] & 4).any() and not (o["flags"][s >= 0] & 4).all()
