@@ -889,37 +889,76 @@ __device__ __forceinline__ double sb_rdlane(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
-// wave 0: Cholesky of one diagonal block out of registers (lane i < 16 holds row i); leaves L_kk and 1 / diag in LDS.
-// (The cross-lane reads are v_readlane pairs of a constant lane; a DPP row_newbcast per value measured slower:
-// 11.5k instead of 6.6k cycles per block.)
+// f64 DPP (gfx90a+ "DP ALU DPP": VOP1 / VOP2 f64 ops take row_newbcast:k -- every lane of a 16-lane row reads lane k of
+// its row).  v_fmac_f64_dpp folds the broadcast into the multiply-add: ONE instruction where v_readlane needs two scalar
+// reads, their hazards and the fma.  The leading s_nop 1 covers the VALU-write -> DPP-read hazard (2 wait states); the
+// compiler's hazard recogniser does not look inside inline assembly.
+template <int K>
+__device__ __forceinline__ double sb_bcast(double v) {  // lane K of the row, to every lane of the row
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+    return r;
+}
+template <int K, bool NOP>
+__device__ __forceinline__ void sb_fmac_bcast(double& acc, double bsrc, double own) {  // acc += bcast_K(bsrc) * own
+    if (NOP)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(own), "n"(K));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bsrc), "v"(own), "n"(K));
+}
+
+template <int J, int K>
+struct SbRank1 {  // a[k] -= l_ij l_kj for k = K .. 15
+    static __device__ __forceinline__ void run(double (&a)[16], double lij, double nl) {
+        sb_fmac_bcast<K, K == J + 1>(a[K], lij, nl);
+        SbRank1<J, K + 1>::run(a, lij, nl);
+    }
+};
+template <int J>
+struct SbRank1<J, 16> {
+    static __device__ __forceinline__ void run(double (&)[16], double, double) {}
+};
+
+template <int J>
+struct SbColumn {
+    static __device__ __forceinline__ void run(double (&a)[16], double& myr, bool& bad, int row) {
+        const double d = sb_bcast<J>(a[J]);
+        bad |= !(d > 0);  // (the same in every lane of a row; off the dependency chain: a bad pivot poisons the block with
+                          // NaNs, chol_ok = 0 makes the LM control reject the step without reading the result)
+        // 1 / sqrt(d): v_rsq_f64 (~2^-26) + one Newton step r0 (1.5 - (d / 2) r0^2): three dependent operations instead of
+        // the library's eight (range checks + a third-order step); the pivots of a damped normal matrix are normal numbers
+        const double r0 = __builtin_amdgcn_rsq(d);
+        const double r = r0 * fma(-0.5 * d, r0 * r0, 1.5);
+        const double lij = a[J] * r;  // lane J holds d itself: sqrt(d) on the diagonal, a_ij / sqrt(d) below
+        a[J] = lij;
+        myr = (row == J) ? r : myr;
+        SbRank1<J, J + 1>::run(a, lij, -lij);  // meaningful for k <= row (the lower triangle); the rest is never read
+        SbColumn<J + 1>::run(a, myr, bad, row);
+    }
+};
+template <>
+struct SbColumn<16> {
+    static __device__ __forceinline__ void run(double (&)[16], double&, bool&, int) {}
+};
+
+// wave 0: Cholesky of one diagonal block out of registers (lane i holds row i & 15: the four 16-lane rows of the wave
+// carry the same block); leaves L_kk and 1 / diag in LDS.  Sixteen unrolled column steps; the pivot broadcast and the
+// rank-1 updates are f64 DPP instructions (v_readlane pairs + fma: 4.6 k cycles per block; a 32-bit DPP mov pair per
+// value, the first attempt: 11.5 k).
 __device__ __forceinline__ bool sb_factor_diag(double* Dk, double* rdiag, int lane) {
     const int row = lane & 15;
     double a[SB];
 #pragma unroll
     for (int k = 0; k < SB; ++k) a[k] = Dk[row * SP + k];
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < SB; ++j) {
-        double d = sb_rdlane(a[j], j);
-        if (!(d > 0)) {
-            ok = false;
-            d = 1.0;
-        }
-        const double r = rsqrt(d);  // one reciprocal square root per column: no f64 sqrt + divide on the serial path
-        const double lij = (lane == j) ? d * r : a[j] * r;  // sqrt(d) on the diagonal, a_ij / sqrt(d) below
-        a[j] = lij;
-        if (lane == j) rdiag[j] = r;
-#pragma unroll
-        for (int k = j + 1; k < SB; ++k) {
-            const double lkj = sb_rdlane(lij, k);
-            a[k] -= lij * lkj;  // meaningful for k <= lane (the lower triangle); the rest is never read
-        }
-    }
+    bool bad = false;
+    double myr = 1.0;  // 1 / L_jj of this lane's own column, picked up branch-free as the columns go by
+    SbColumn<0>::run(a, myr, bad, row);
     if (lane < SB) {
+        rdiag[lane] = myr;
 #pragma unroll
         for (int k = 0; k < SB; ++k) Dk[lane * SP + k] = a[k];
     }
-    return ok;
+    return !bad;
 }
 
 // one 4 x 4 tile of  A[I][J] -= P_I P_J^T  (tile (tr, tc) of the 16 x 16 block)
@@ -941,7 +980,7 @@ __device__ __forceinline__ void sb_tile_update(double* A, int I, int J, int kb, 
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] += pa[r].x * pb[c].x + pa[r].y * pb[c].y;
+            for (int c = 0; c < 4; ++c) acc[r][c] = fma(pa[r].y, pb[c].y, fma(pa[r].x, pb[c].x, acc[r][c]));
     }
     double* T = A + sb_off(I, J) + (4 * tr) * SP + 4 * tc;
 #pragma unroll
@@ -974,31 +1013,39 @@ __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
     double* A = sm;
     double* b = sm + (size_t)NBT * SBLK;  // the right-hand side: one more row of the matrix
     double* rdiag = b + (size_t)NB * SB;  // 1 / L_jj
-    // ---- load the lower triangle (identity padding beyond n): up to 16 loads in flight per thread (order 176: all of it)
-    for (int e0 = 0; e0 < NBT * SB * SB; e0 += 16 * NT) {
-        double v[16];
-        int dst[16];
+    // ---- load the lower triangle (identity padding beyond n).  One wave per 16 x 16 block, four entries per lane (a lane
+    // reads 32-byte row pieces, a wave 16 full rows of 128 bytes); the block -> (I, J) arithmetic is wave-uniform and runs
+    // on the scalar unit, every load of a wave's blocks (up to 5 at order 176) is issued before the first LDS store.
+    // (The first version derived (I, J) per element with a per-lane search loop: ~2 k instructions in front of the loads.)
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+        const int r = ln >> 2, c0 = (ln & 3) * 4;
+        constexpr int MAXB = 5;  // ceil(66 blocks / 16 waves)
+        double v[MAXB][4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int e = e0 + tid + u * NT;
-            const int blk = e >> 8, r = (e >> 4) & 15, c = e & 15;
-            int I = 0;
-            while ((I + 1) * (I + 2) / 2 <= blk) ++I;
-            const int J = blk - I * (I + 1) / 2;
-            const int gi = I * SB + r, gj = J * SB + c;
-            dst[u] = (e < NBT * SB * SB) ? blk * SBLK + r * SP + c : -1;
-            v[u] = 0.0;
-            if (dst[u] >= 0) {
-                if (gi < n && gj < n)
-                    v[u] = D.S[(size_t)gi * n + gj];
-                else if (gi == gj)
-                    v[u] = 1.0;
+        for (int q = 0; q < MAXB; ++q) {
+            const int blk = wv + q * 16;
+            if (blk < NBT) {
+                int I = 0;
+                while ((I + 1) * (I + 2) / 2 <= blk) ++I;
+                const int J = blk - I * (I + 1) / 2;
+                const int gi = I * SB + r, gj = J * SB + c0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[q][u] = (gi == gj + u) ? 1.0 : 0.0;
+                    if (gi < n && gj + u < n) v[q][u] = D.S[(size_t)gi * n + gj + u];
+                }
             }
         }
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-            if (dst[u] >= 0) A[dst[u]] = v[u];
         if (stAllDone || stInnerDone) return;  // !BA_ACTIVE (uniform); tested here so that it is not one more dependent trip
+#pragma unroll
+        for (int q = 0; q < MAXB; ++q) {
+            const int blk = wv + q * 16;
+            if (blk < NBT) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) A[blk * SBLK + r * SP + c0 + u] = v[q][u];
+            }
+        }
     }
     for (int q = tid; q < NB * SB; q += NT) b[q] = (q < n) ? D.rhs[q] : 0.0;
     if (tid == 0) okFlag = 1;
@@ -1029,7 +1076,7 @@ __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
                 const double x = a[c] * rdiag[kb * SB + c];
                 a[c] = x;
 #pragma unroll
-                for (int k = c + 1; k < SB; ++k) a[k] -= x * Dk[k * SP + c];
+                for (int k = c + 1; k < SB; ++k) a[k] = fma(-x, Dk[k * SP + c], a[k]);
             }
 #pragma unroll
             for (int k = 0; k < SB; ++k) row[k] = a[k];
@@ -1054,7 +1101,7 @@ __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
                     const double* y = b + kb * SB;
                     double acc = 0.0;
 #pragma unroll
-                    for (int k = 0; k < SB; ++k) acc += y[k] * PJ[k];
+                    for (int k = 0; k < SB; ++k) acc = fma(y[k], PJ[k], acc);
                     b[J * SB + c] -= acc;
                     continue;
                 }
@@ -1082,7 +1129,7 @@ __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
             for (int c = SB - 1; c >= 0; --c) {
                 const double xc = sb_rdlane(y, c) * sb_rdlane(rd, c);
                 if (i == c) y = xc;
-                if (i < c) y -= col[c] * xc;
+                if (i < c) y = fma(-col[c], xc, y);
             }
             if (lane < SB) b[kb * SB + lane] = y;
         }
@@ -1093,7 +1140,7 @@ __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
             const double* blk = A + sb_off(kb, J);
             double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < SB; ++k) acc += blk[k * SP + c] * b[kb * SB + k];
+            for (int k = 0; k < SB; ++k) acc = fma(blk[k * SP + c], b[kb * SB + k], acc);
             b[J * SB + c] -= acc;
         }
         __syncthreads();
