@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--serial", action="store_true", help="diagnostic: every leg on ONE stream (no overlap)")
     ap.add_argument("--key-every", type=int, default=KEY_EVERY, help="diagnostic: 0 disables the key-frame solves (not a valid bench line)")
     ap.add_argument("--no-pose", action="store_true", help="diagnostic: skip hand-back + pose (not a valid bench line)")
+    ap.add_argument("--klt-cus", type=int, default=int(os.environ.get("BENCH_KLT_CUS", "0")),
+                    help="tracker stream confined to the first N compute units (0 = whole chip): leaves CUs the persistent tracker "
+                         "never occupies, where the BA's 1024-thread solver workgroup can start while the tracker runs")
     ap.add_argument("--no-register", action="store_true", help="diagnostic: skip the map-point registration search (not a valid bench line)")
     ap.add_argument("--native-comm", type=int, default=1, help="N > 1: collectives issued by libcoslam_hip (RCCL behind the C-ABI) instead of torch.distributed")
     args = ap.parse_args()
@@ -280,7 +283,14 @@ def main():
     #   key-frame solves (inter-camera pose, joint local BA): each on its workspace's own worker thread + stream
     #           (cs_ba_solve_async), started behind that frame's pose -- the reference's BA worker thread
     #           (src/app/SL_CoSLAM.cpp:1702-1784); the thread enqueues LM steps in chunks and stops at convergence.
-    klt_s = torch.cuda.Stream(device=dev)
+    if args.klt_cus > 0:
+        coslam_amd.lib().cs_stream_create_cu_range.restype = C.c_void_p
+        ptr = coslam_amd.lib().cs_stream_create_cu_range(local_rank, 0, args.klt_cus)
+        if not ptr:
+            raise SystemExit("bench.py: cs_stream_create_cu_range failed")
+        klt_s = torch.cuda.ExternalStream(ptr, device=dev)
+    else:
+        klt_s = torch.cuda.Stream(device=dev)
     pose_s = klt_s if args.serial else torch.cuda.Stream(device=dev)
     ba_s = klt_s if args.serial else torch.cuda.Stream(device=dev)   # N > 1: the sliced joint BA and its collectives
 
@@ -291,6 +301,9 @@ def main():
         trks.append(t)
     grp = coslam_amd.KLT_TrackerGroup(trks)
     grp.set_stream(klt_s.cuda_stream)
+    if args.klt_cus > 0:
+        for t in trks:
+            t.set_cu_count(args.klt_cus)
     prefetch = os.environ.get("BENCH_PREFETCH", "1") != "0"
 
     jptr, jcam, jxy = csr(joint)
@@ -557,7 +570,7 @@ def main():
                        "register_candidates_last_frame": None if args.no_register else
                        {"active": int((reg_out[0]["slot"] >= 0).sum().item()), "current_static": int((reg_out[1]["slot"] >= 0).sum().item()),
                         "already_attached": int((reg_out[1]["slot"] == -1).sum().item())},
-                       "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
+                       "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "tracker_stream_cus": args.klt_cus or "all",
                        "collectives": None if world == 1 else ("libcoslam_hip RCCL (C-ABI)" if native else "torch.distributed " + dist_backend),
                        "streams": "one stream (--serial)" if args.serial else
                        "tracker group | hand-back + pose (event-ordered behind the tracker of the same frame) | "

@@ -39,6 +39,10 @@ namespace {
 // dispatcher piles up to ten of them on a CU while others idle: 218 vs 164 us for the eight-camera tracker stage.
 #define CS_ROWS_WPB 4
 #endif
+#ifndef CS_ROWS_PRIO_BASE
+#define CS_ROWS_PRIO_BASE 1  // s_setprio while a wave samples its patch
+#define CS_ROWS_PRIO_HOT 3   // ... from the first poll to the publish
+#endif
 #ifndef CS_ROWS_LDS_PAD
 #define CS_ROWS_LDS_PAD 0  // extra dynamic LDS per wave (bytes): caps the workgroups a CU admits
 #endif
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(64 * CS_ROWS_WPB, (LPF == 8 ? 3 : 2)) void k_track_
     constexpr int NPIX = FW * FW;
     unsigned long long tTex = 0, tMath = 0, tPoll = 0, tPost = 0, nPoll = 0, nReload = 0, tStart = 0, tm0 = 0, tm1 = 0;
     if (PROBE) tStart = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(CS_ROWS_PRIO_BASE);
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int waveId = blockIdx.x * CS_ROWS_WPB + wib;
     const int g = lane / LPF, r = lane - g * LPF;
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(64 * CS_ROWS_WPB, (LPF == 8 ? 3 : 2)) void k_track_
             // The first poll goes out here and flies under the folds and the adjugate.  From here to the publish the
             // wave runs at raised priority: the closer a wave is to publishing the granule its neighbours wait for, the
             // earlier it gets the SIMD's issue slots over a co-resident wave that is still sampling.
-            __builtin_amdgcn_s_setprio(3);
+            __builtin_amdgcn_s_setprio(CS_ROWS_PRIO_HOT);
             cs_granule got = gran_load(src);
             if (PROBE) ++nPoll;
             const float a = rows_fold<LPF>(s.a), b = rows_fold<LPF>(s.b), c = rows_fold<LPF>(s.c), d = rows_fold<LPF>(s.d);
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(64 * CS_ROWS_WPB, (LPF == 8 ? 3 : 2)) void k_track_
             beta = newB;
             dead = dead || (newX < 0);
             if (valid && r == 0) gran_store(gran + (size_t)pass * N + k, want + 1u, beta);
-            __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(CS_ROWS_PRIO_BASE);
             if (PROBE) {
                 tm1 = __builtin_amdgcn_s_memtime();
                 tPost += tm1 - tm0;
