@@ -39,6 +39,10 @@
 
 #include "cs_common.h"
 
+#ifndef CS_BA_PRIO
+#define CS_BA_PRIO 0  // s_setprio of the LM-step kernels' waves (A/B: the persistent tracker runs at 1..3)
+#endif
+#define CS_BA_SETPRIO() do { if (CS_BA_PRIO) __builtin_amdgcn_s_setprio(CS_BA_PRIO); } while (0)
 #pragma clang fp contract(off)
 
 struct cs_ba_stats_dev {
@@ -170,6 +174,7 @@ __device__ __forceinline__ bool inv33(const double* V, double* Vi) {
 
 // ---- one wave per point --------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_linearize(BaDev D) {
+    CS_BA_SETPRIO();
     if (!BA_ACTIVE(D)) return;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -251,6 +256,7 @@ __device__ __forceinline__ double seg8_sum(double v) {
     return v;
 }
 __global__ __launch_bounds__(256) void k_linearize_seg8(BaDev D) {
+    CS_BA_SETPRIO();
     if (!BA_ACTIVE(D)) return;
     const int i = blockIdx.x * 32 + (threadIdx.x >> 3), k = threadIdx.x & 7;
     const bool hasP = !(i >= D.P || i < D.pLo || i >= D.pHi);
@@ -327,6 +333,7 @@ __global__ __launch_bounds__(256) void k_linearize_seg8(BaDev D) {
 // Diagonal pairs also form U_j = sum Jc^T Jc + lambda I and g_j = sum Jc^T e over the camera's own measurement
 // list, so the whole reduced system S, rhs is written by this one launch (no read-modify-write between kernels).
 __global__ __launch_bounds__(256) void k_schur(BaDev D) {
+    CS_BA_SETPRIO();
     if (!BA_ACTIVE(D)) return;
     __shared__ double red[4][42];
     __shared__ double redU[4][27];
@@ -993,6 +1000,7 @@ __device__ __forceinline__ void sb_tile_update(double* A, int I, int J, int kb, 
 }
 
 __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
+    CS_BA_SETPRIO();
     const int stAllDone = D.st->all_done, stInnerDone = D.st->inner_done;  // (consumed after the matrix loads are in flight)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ int okFlag;
@@ -1358,6 +1366,7 @@ __device__ __forceinline__ void solve_reg_factor(const BaDev& D, double* Ssm, in
 // costPart[blockIdx.x] (D.nUpdBlocks of them), summed in a fixed order by k_control.
 template <int NMAX>  // > 0: the reduced system is combined and solved here, redundantly per workgroup (no solve launch)
 __global__ __launch_bounds__(256) void k_update(BaDev D) {
+    CS_BA_SETPRIO();
     if (!BA_ACTIVE(D)) return;
     __shared__ double red[4];
     __shared__ double Ssm[NMAX > 0 ? NMAX * NMAX + NMAX : 1];
@@ -1530,6 +1539,7 @@ __global__ __launch_bounds__(256) void k_update(BaDev D) {
 // a measurement's tentative residual run with 40 of 64 lanes busy instead of 5.
 template <int NMAX>
 __global__ __launch_bounds__(256) void k_update_seg8(BaDev D) {
+    CS_BA_SETPRIO();
     if (!BA_ACTIVE(D)) return;
     __shared__ double red[4];
     __shared__ double Ssm[NMAX * NMAX + NMAX];
@@ -1715,6 +1725,7 @@ __global__ __launch_bounds__(256) void k_control(BaDev D) {  // phase 0
 // both partial lists and the tentative values each thread would commit -- is requested up front, so the launch is one
 // round trip to memory, the decision, and the stores; the sums keep k_control's order.
 __global__ __launch_bounds__(256) void k_control_step(BaDev D) {
+    CS_BA_SETPRIO();
     __shared__ double red[8];
     __shared__ int accept;
     BaState* st = D.st;
@@ -2572,7 +2583,16 @@ cs_ba* cs_ba_create(int device) {
     cs_ba* b = new cs_ba();
     memset(b, 0, sizeof(*b));
     b->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    // COSLAM_BA_STREAM_PRIO=1 (A/B): the workspace's stream (the async worker's) at the highest stream priority, so that its
+    // short kernels are dispatched ahead of the per-frame streams' workgroups
+    static const bool hiPrio = getenv("COSLAM_BA_STREAM_PRIO") && getenv("COSLAM_BA_STREAM_PRIO")[0] == '1';
+    int prLo = 0, prHi = 0;
+    hipError_t se = hipSetDevice(device);
+    if (se == hipSuccess && hiPrio) (void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);
+    if (se == hipSuccess)
+        se = hiPrio ? hipStreamCreateWithPriority(&b->own_stream, hipStreamNonBlocking, prHi)
+                    : hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
         cs_set_error("cs_ba_create: cannot create a stream");
         delete b;
         return nullptr;

@@ -31,13 +31,16 @@
 namespace {
 
 #ifndef CS_ROWS_UNROLL
-#define CS_ROWS_UNROLL 1
+#define CS_ROWS_UNROLL 7
 #endif
 #ifndef CS_ROWS_WPB
 // Waves per workgroup.  4: a workgroup's waves go to the CU's four SIMDs and its 64 KB of LDS admit two workgroups per
 // CU, so eight cameras (2000 waves) land as exactly two waves on every SIMD.  With single-wave workgroups the
 // dispatcher piles up to ten of them on a CU while others idle: 218 vs 164 us for the eight-camera tracker stage.
 #define CS_ROWS_WPB 4
+#endif
+#ifndef CS_ROWS_MINBLOCKS
+#define CS_ROWS_MINBLOCKS 3  // resident workgroups per CU the 8-lanes-per-feature instantiations are compiled for
 #endif
 #ifndef CS_ROWS_PRIO_BASE
 #define CS_ROWS_PRIO_BASE 1  // s_setprio while a wave samples its patch
@@ -129,6 +132,56 @@ __device__ __forceinline__ void sample_p(const cs_texel* patch, int rx0, int ry0
     Iy = ((w00 * Y00 + w10 * Y10) + w01 * Y01) + w11 * Y11;
 }
 
+// Packed FP32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE binary32 operations per instruction, same rounding as the scalar
+// forms): the two gradient channels travel as one register pair through the bilinear blend and the window sums, the four
+// bilinear weights as two pairs.  Operation for operation the arithmetic of sample_p / the shader's inner loop --
+// bit-identical results, ~20 % fewer vector instructions per window pixel.
+typedef float cs_f2 __attribute__((ext_vector_type(2)));
+
+template <int R>
+__device__ __forceinline__ void sample_p2(const cs_texel* patch, int rx0, int ry0, int Wl, int Hl, float s, float t, float& I,
+                                          cs_f2& G) {
+    float u = s * (float)Wl - 0.5f;
+    float v = t * (float)Hl - 0.5f;
+    u = fminf(fmaxf(u, -2.0f), (float)Wl + 1.0f);
+    v = fminf(fmaxf(v, -2.0f), (float)Hl + 1.0f);
+    float fu = floorf(u), fv = floorf(v);
+    float a = u - fu, b = v - fv;
+    const cs_texel* c = patch + ((int)fv - ry0) * R + ((int)fu - rx0);
+    cs_texel t00 = c[0], t10 = c[1], t01 = c[R], t11 = c[R + 1];
+    const cs_f2 wa = {1.0f - a, a};
+    const cs_f2 w0 = wa * (1.0f - b), w1 = wa * b;  // (w00, w10), (w01, w11)
+    float I00, X00, Y00, I10, X10, Y10, I01, X01, Y01, I11, X11, Y11;
+    cs_unpack_texel(t00, I00, X00, Y00);
+    cs_unpack_texel(t10, I10, X10, Y10);
+    cs_unpack_texel(t01, I01, X01, Y01);
+    cs_unpack_texel(t11, I11, X11, Y11);
+    const cs_f2 p0 = w0 * (cs_f2){I00, I10}, p1 = w1 * (cs_f2){I01, I11};
+    I = ((p0.x + p0.y) + p1.x) + p1.y;
+    G = ((w0.x * (cs_f2){X00, Y00} + w0.y * (cs_f2){X10, Y10}) + w1.x * (cs_f2){X01, Y01}) + w1.y * (cs_f2){X11, Y11};
+}
+
+// one Gauss-Newton pass worth of window sums for this lane's row (all zero for an inactive lane)
+struct RowSums {
+    cs_f2 ab, ce, r01;  // (a, b), (c, e'), (r0, r1) of klt_tracker_with_gain.cg:106-110
+    float d, r2s, ssd;
+};
+
+// klt_tracker_with_gain.cg:99-121 for one window pixel: frame-0 sample (I0, G0, m0), frame-1 sample (I1, G1)
+__device__ __forceinline__ void rows_accumulate(RowSums& s, float beta, float I0, cs_f2 G0, float m0, float I1, cs_f2 G1, cs_f2 wh,
+                                                float lambda) {
+    const float ex = beta * I0 - I1;             // :99
+    const cs_f2 g = (beta * G0 + G1) * wh / 2.0f;  // :100
+    const cs_f2 q = G1 * G1;
+    const float m1 = sqrtf(q.x + q.y);           // :103
+    s.ab += g.x * g;                             // :106  a += gx gx, b += gx gy
+    s.ce += g * (-I0);                           //       c += gx (-I0) ... :107 e' += gy (-I0)
+    s.d += g.y * g.y;                            // :107
+    s.r01 += ex * g;                             // :110
+    s.r2s += -ex * I0 + lambda * m0 * (m1 - beta * m0);  // :111 without the neighbour term
+    s.ssd += ex * ex;                            // :121
+}
+
 // group-cooperative patch fill, split so that every load is issued before the first LDS store
 template <int LPF, int R, int NT>
 __device__ __forceinline__ void patch_load(const cs_texel* __restrict__ L, int Wl, int Hl, int rx0, int ry0, int r,
@@ -218,14 +271,10 @@ __host__ __device__ constexpr size_t rows_lds_bytes(int fpw, int R, int R0, int 
     return (size_t)fpw * R * R * sizeof(cs_texel) + (b0 > b1 ? b0 : b1);
 }
 
-// one Gauss-Newton pass worth of window sums for this lane's row (all zero for an inactive lane)
-struct RowSums {
-    float a, b, c, d, e_, r0, r1, r2s, ssd;
-};
 
 // ---- ALL passes of ALL cameras in one persistent launch ----------------------------------------------------------
 template <int LPF, int FW, bool PROBE>
-__global__ __launch_bounds__(64 * CS_ROWS_WPB, (LPF == 8 ? 3 : 2)) void k_track_rows_fused(CsRowsArgs A) {
+__global__ __launch_bounds__(64 * CS_ROWS_WPB, (LPF == 8 ? CS_ROWS_MINBLOCKS : 2)) void k_track_rows_fused(CsRowsArgs A) {
     constexpr int HW = FW / 2, R = FW + 1 + 2 * RW_MARGIN, FPW = 64 / LPF, NT = (R * R + LPF - 1) / LPF;
     constexpr int R0 = FW + 2, NT0 = (R0 * R0 + LPF - 1) / LPF;  // frame-0 footprint: fixed position, no slack needed
     constexpr int NPIX = FW * FW;
@@ -349,32 +398,21 @@ __global__ __launch_bounds__(64 * CS_ROWS_WPB, (LPF == 8 ? 3 : 2)) void k_track_
                 wave_lds_sync();
             }
             // ---- this lane's window row: klt_tracker_with_gain.cg:86-122 ------------------------------------
-            RowSums s = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            RowSums s = {{0, 0}, {0, 0}, {0, 0}, 0, 0, 0};
             if (!dead && rowOn) {
                 const float t1 = X1y + oy;
+                const cs_f2 wh = {whx, why};
 #pragma unroll CS_ROWS_UNROLL
                 for (int px = 0; px < FW; ++px) {
                     const float4 q0 = rec[px * 64];
-                    const float I0 = q0.x, I0x = q0.y, I0y = q0.z, m0 = q0.w;
-                    float I1, I1x, I1y;
-                    sample_p<R>(patch, rx0, ry0, Wl, Hl, X1x + (float)(px - HW) * dsx, t1, I1, I1x, I1y);
-                    const float ex = beta * I0 - I1;                      // :99
-                    const float gx = (beta * I0x + I1x) * whx / 2.0f;    // :100
-                    const float gy = (beta * I0y + I1y) * why / 2.0f;
-                    const float m1 = sqrtf(I1x * I1x + I1y * I1y);        // :103
-                    s.a += gx * gx;                                       // :106
-                    s.b += gx * gy;
-                    s.c += gx * (-I0);
-                    s.d += gy * gy;                                       // :107
-                    s.e_ += gy * (-I0);
-                    s.r0 += ex * gx;                                      // :110
-                    s.r1 += ex * gy;
-                    s.r2s += -ex * I0 + A.lambda * m0 * (m1 - beta * m0);  // :111 without the neighbour term
-                    s.ssd += ex * ex;                                     // :121
+                    float I1;
+                    cs_f2 G1;
+                    sample_p2<R>(patch, rx0, ry0, Wl, Hl, X1x + (float)(px - HW) * dsx, t1, I1, G1);
+                    rows_accumulate(s, beta, q0.x, (cs_f2){q0.y, q0.z}, q0.w, I1, G1, wh, A.lambda);
                 }
             }
             if (PROBE) {
-                asm volatile("" : "+v"(s.a));
+                asm volatile("" : "+v"(s.d));
                 tm1 = __builtin_amdgcn_s_memtime();
                 tTex += tm1 - tm0;
                 tm0 = tm1;
@@ -385,8 +423,8 @@ __global__ __launch_bounds__(64 * CS_ROWS_WPB, (LPF == 8 ? 3 : 2)) void k_track_
             __builtin_amdgcn_s_setprio(CS_ROWS_PRIO_HOT);
             cs_granule got = gran_load(src);
             if (PROBE) ++nPoll;
-            const float a = rows_fold<LPF>(s.a), b = rows_fold<LPF>(s.b), c = rows_fold<LPF>(s.c), d = rows_fold<LPF>(s.d);
-            const float e_ = rows_fold<LPF>(s.e_), r0 = rows_fold<LPF>(s.r0), r1 = rows_fold<LPF>(s.r1);
+            const float a = rows_fold<LPF>(s.ab.x), b = rows_fold<LPF>(s.ab.y), c = rows_fold<LPF>(s.ce.x), d = rows_fold<LPF>(s.d);
+            const float e_ = rows_fold<LPF>(s.ce.y), r0 = rows_fold<LPF>(s.r01.x), r1 = rows_fold<LPF>(s.r01.y);
             float r2s = rows_fold<LPF>(s.r2s);
             const float SSD = rows_fold<LPF>(s.ssd);
             const RowsSolve S = solve_prepare(a, b, c, d, e_, fLevel, r0, r1);
@@ -536,10 +574,11 @@ __global__ __launch_bounds__(64) void k_track_rows_pass(CsRowsArgs A) {
     const float dsx = 1.0f / (float)Wl, dsy = 1.0f / (float)Hl;
     const float whx = (float)A.W, why = (float)A.H;
     const float oy = (float)(r - HW) * dsy;
-    RowSums s = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    RowSums s = {{0, 0}, {0, 0}, {0, 0}, 0, 0, 0};
     float fRow = 0.0f;
     if (!dead && r < FW) {
         const float t0 = X0y + oy, t1 = X1y + oy;
+        const cs_f2 wh = {whx, why};
 #pragma unroll
         for (int px = 0; px < FW; ++px) {
             const float ox = (float)(px - HW) * dsx;
@@ -548,24 +587,12 @@ __global__ __launch_bounds__(64) void k_track_rows_pass(CsRowsArgs A) {
             sample_g(L1, Wl, Hl, X1x + ox, t1, I1, I1x, I1y);
             const float m0 = sqrtf(I0x * I0x + I0y * I0y);
             fRow += (I0 * I0 + A.lambda * m0 * m0) + A.delta * 8.0f;
-            const float ex = beta * I0 - I1;
-            const float gx = (beta * I0x + I1x) * whx / 2.0f;
-            const float gy = (beta * I0y + I1y) * why / 2.0f;
-            const float m1 = sqrtf(I1x * I1x + I1y * I1y);
-            s.a += gx * gx;
-            s.b += gx * gy;
-            s.c += gx * (-I0);
-            s.d += gy * gy;
-            s.e_ += gy * (-I0);
-            s.r0 += ex * gx;
-            s.r1 += ex * gy;
-            s.r2s += -ex * I0 + A.lambda * m0 * (m1 - beta * m0);
-            s.ssd += ex * ex;
+            rows_accumulate(s, beta, I0, (cs_f2){I0x, I0y}, m0, I1, (cs_f2){I1x, I1y}, wh, A.lambda);
         }
     }
     const float f = rows_fold<LPF>(fRow);
-    const float a = rows_fold<LPF>(s.a), b = rows_fold<LPF>(s.b), c = rows_fold<LPF>(s.c), d = rows_fold<LPF>(s.d);
-    const float e_ = rows_fold<LPF>(s.e_), r0 = rows_fold<LPF>(s.r0), r1 = rows_fold<LPF>(s.r1);
+    const float a = rows_fold<LPF>(s.ab.x), b = rows_fold<LPF>(s.ab.y), c = rows_fold<LPF>(s.ce.x), d = rows_fold<LPF>(s.d);
+    const float e_ = rows_fold<LPF>(s.ce.y), r0 = rows_fold<LPF>(s.r01.x), r1 = rows_fold<LPF>(s.r01.y);
     const float r2s = rows_fold<LPF>(s.r2s);
     const float SSD = rows_fold<LPF>(s.ssd);
     const RowsSolve S = solve_prepare(a, b, c, d, e_, f, r0, r1);
