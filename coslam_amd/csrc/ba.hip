@@ -2432,6 +2432,7 @@ struct BaWorker {
     int chunk = 0;
     hipGraphExec_t gHead = nullptr, gChunk = nullptr, gTail = nullptr, gRound = nullptr, gFinish = nullptr;
     int* h_state = nullptr;  // pinned {inner_done, all_done}
+    hipEvent_t ev[2] = {nullptr, nullptr};
 };
 
 static void ba_worker_drop_graphs(cs_ba* b) {
@@ -2516,19 +2517,72 @@ static int ba_worker_run(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
         w->key = key;
         w->haveGraphs = true;
     }
-    CS_HIP(hipGraphLaunch(w->gHead, s));
+    // The schedule as a list of graph segments -- head, then per round [round start,] chunks, tail, then finish -- replayed
+    // with ONE segment of look-ahead: segment i + 1 is on the stream before the host waits for segment i's state word, so
+    // the stream never idles for a host round trip (~40 us per chunk next to a busy tracker).  What the state word says
+    // only prunes segments that are not launched yet; a speculative segment behind a converged one runs as no-ops (every
+    // kernel tests the state first).
+    struct Seg {
+        hipGraphExec_t g;
+        char kind;  // 'H'ead, 'R'ound start, 'C'hunk, 'T'ail, 'F'inish
+        int outer;
+    };
+    std::vector<Seg> seg;
+    seg.push_back({w->gHead, 'H', 0});
     for (int outer = 0; outer < J.maxIter; ++outer) {
-        if (outer > 0) CS_HIP(hipGraphLaunch(w->gRound, s));
-        for (int done = 0; done < J.innerMaxIter; done += w->chunk) {
-            CS_HIP(hipGraphLaunch(w->gChunk, s));
-            CS_HIP(hipStreamSynchronize(s));
-            if (w->h_state[0] || w->h_state[1]) break;  // inner_done / all_done
-        }
-        CS_HIP(hipGraphLaunch(w->gTail, s));
-        CS_HIP(hipStreamSynchronize(s));
-        if (w->h_state[1]) break;
+        if (outer > 0) seg.push_back({w->gRound, 'R', outer});
+        for (int done = 0; done < J.innerMaxIter; done += w->chunk) seg.push_back({w->gChunk, 'C', outer});
+        seg.push_back({w->gTail, 'T', outer});
     }
-    CS_HIP(hipGraphLaunch(w->gFinish, s));
+    seg.push_back({w->gFinish, 'F', J.maxIter});
+    static const bool noSpec = getenv("COSLAM_BA_SPECULATE") && getenv("COSLAM_BA_SPECULATE")[0] == '0';  // A/B
+    if (!w->ev[0]) {
+        CS_HIP(hipEventCreateWithFlags(&w->ev[0], hipEventDisableTiming));
+        CS_HIP(hipEventCreateWithFlags(&w->ev[1], hipEventDisableTiming));
+    }
+    int skipChunksOfOuter = -1;  // chunks of this round that are not launched yet are dropped
+    bool allDone = false;        // ... and everything up to the finish segment
+    auto next_of = [&](size_t i) {
+        size_t n = i + 1;
+        while (n < seg.size()) {
+            const Seg& q = seg[n];
+            if (q.kind != 'F' && allDone) {
+                ++n;
+                continue;
+            }
+            if (q.kind == 'C' && q.outer == skipChunksOfOuter) {
+                ++n;
+                continue;
+            }
+            break;
+        }
+        return n;
+    };
+    size_t i = 0;
+    CS_HIP(hipGraphLaunch(seg[0].g, s));
+    CS_HIP(hipEventRecord(w->ev[0], s));
+    int slot = 0;
+    while (i < seg.size()) {
+        const size_t n = next_of(i);
+        if (n < seg.size() && !noSpec) {
+            CS_HIP(hipGraphLaunch(seg[n].g, s));
+            CS_HIP(hipEventRecord(w->ev[slot ^ 1], s));
+        }
+        CS_HIP(hipEventSynchronize(w->ev[slot]));
+        if (seg[i].kind == 'C' && (w->h_state[0] || w->h_state[1])) skipChunksOfOuter = seg[i].outer;  // inner_done / all_done
+        if (seg[i].kind == 'T' && w->h_state[1]) allDone = true;
+        if (noSpec) {
+            const size_t m = next_of(i);
+            if (m < seg.size()) {
+                CS_HIP(hipGraphLaunch(seg[m].g, s));
+                CS_HIP(hipEventRecord(w->ev[slot ^ 1], s));
+            }
+            i = m;
+        } else {
+            i = n;
+        }
+        slot ^= 1;
+    }
     CS_HIP(hipStreamSynchronize(s));
     return CS_OK;
 }
@@ -2568,6 +2622,8 @@ static void ba_worker_stop(cs_ba* b) {
     if (w->th.joinable()) w->th.join();
     ba_worker_drop_graphs(b);
     if (w->h_state) (void)hipHostFree(w->h_state);
+    for (hipEvent_t e : w->ev)
+        if (e) (void)hipEventDestroy(e);
     delete w;
     b->worker = nullptr;
 }
