@@ -22,6 +22,7 @@ HIP_SOURCES = [
     "pose.hip",
     "handback.hip",
     "register.hip",
+    "ncc.hip",
     "ba.hip",
     "comm.hip",
 ]

@@ -1,0 +1,296 @@
+// ncc.hip -- NCC blocks and the epipolar / NCC matrices of CoSLAM's inter-camera matching, gfx950.
+//
+// Replaces
+//   NCCBlock::compute / computeScaled   src/slam/SL_NCCBlock.cpp:15-54    one 11 x 11 block per feature + its A, B, C
+//   matchNCCBlock                       src/slam/SL_NCCBlock.cpp:258-264  121 byte products per PAIR of features
+//   getEpiNccMat                        src/slam/SL_FeatureMatching.cpp:3-46   M x N epipolar errors and NCC scores --
+// what NewMapPtsNCC::matchBetween (src/app/SL_NewMapPointsInterCam.cpp:273-317, every <= 4 frames per camera pair,
+// SL_CoSLAM.cpp:1368-1371) computes on one host core before its greedy matcher: 2000 x 2000 pairs x 121 products.
+//
+// The pair scores are a matrix product of byte rows -- this one IS GEMM-shaped, so it runs on the matrix cores:
+// v_mfma_i32_16x16x32_i8.  The blocks are unsigned bytes and the instruction multiplies signed ones, so the rows are fed
+// as (I - 128) (one XOR with 0x80 per byte on the way in; rows are padded to 128 bytes with 0x80 = 0 after the shift) and
+// the exact integer sum  sum I1 I2 = sum (I1 - 128)(I2 - 128) + 128 (A1 - 121 * 128) + 128 (A2 - 121 * 128) + 121 * 128^2
+// is rebuilt from the blocks' own sums A.  Everything up to here is integer arithmetic: exact.  The score itself,
+// ((121 d - A1 A2) C1) C2, and the epipolar error are binary64 in the reference's operation order: the matrices are
+// bit-identical to the reference's (tests: the reference's own SL_NCCBlock.cpp / SL_FeatureMatching.cpp compiled in place).
+// A workgroup = a 64 x 64 tile of pairs (four waves, 16 rows each, 16 MFMAs per wave); the output -- two M x N binary64
+// matrices, what the reference's matcher reads -- is the traffic that bounds it (16 bytes per pair).
+//
+// epipolarError is un-vendored LibVisualSLAM: definition in DESIGN.md (distance of the first point from the line F (second
+// point, 1)).  How matchBetween cuts its blocks (cv::getRectSubPix on a cv::resize'd image) is OpenCV; the in-tree
+// NCCBlock::compute (truncated position on the small image) is what cs_ncc_blocks* implements.
+#include "cs_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int NC_HW = 5, NC_BW = 11, NC_LEN = 121, NC_PITCH = 128;
+
+// ---- NCCBlock::computeScaled for n features: one wave per feature ---------------------------------------------------
+__global__ __launch_bounds__(256) void k_ncc_blocks(const unsigned char* __restrict__ img, int W, int H, int n,
+                                                    const double* __restrict__ xs, const double* __restrict__ ys, double scale,
+                                                    unsigned char* __restrict__ blocks, double* __restrict__ abc,
+                                                    int* __restrict__ valid) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const double x = xs[i] * scale, y = ys[i] * scale;  // SL_NCCBlock.cpp:51-54
+    const int x0 = (int)x, y0 = (int)y;                  // :20-21
+    const bool ok = !(x0 - NC_HW < 0 || x0 + NC_HW >= W || y0 - NC_HW < 0 || y0 + NC_HW >= H);  // :24-26
+    unsigned v0 = 0x80, v1 = 0x80;  // bytes lane and lane + 64 of the padded row
+    if (ok) {
+        const int j0 = lane, j1 = lane + 64;
+        const int yy0 = j0 / NC_BW, xx0 = j0 - yy0 * NC_BW;
+        v0 = img[(size_t)(y0 + yy0 - NC_HW) * W + (x0 + xx0 - NC_HW)];
+        if (j1 < NC_LEN) {
+            const int yy1 = j1 / NC_BW, xx1 = j1 - yy1 * NC_BW;
+            v1 = img[(size_t)(y0 + yy1 - NC_HW) * W + (x0 + xx1 - NC_HW)];
+        }
+    }
+    blocks[(size_t)i * NC_PITCH + lane] = (unsigned char)v0;
+    blocks[(size_t)i * NC_PITCH + 64 + lane] = (unsigned char)v1;
+    // A = sum I, B = sum I^2: integers (< 2^23), so any summation order gives the reference's binary64 values exactly
+    // (select the BYTES, then square: `v0 * v0 + (in ? v1 * v1 : 0)` is turned into v_dot4_u32_u8 with the predicate as
+    // the accumulator by this compiler -- v0^2 + v1^2 + in -- which the golden test caught)
+    const unsigned w0 = ok ? v0 : 0u, w1 = (ok && lane + 64 < NC_LEN) ? v1 : 0u;
+    unsigned a = w0 + w1;
+    unsigned b = w0 * w0 + w1 * w1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+    }
+    if (lane == 0) {
+        valid[i] = ok ? 1 : 0;
+        const double A = (double)a, B = (double)b;
+        abc[4 * (size_t)i] = ok ? A : 0.0;
+        abc[4 * (size_t)i + 1] = ok ? B : 0.0;
+        abc[4 * (size_t)i + 2] = ok ? 1 / sqrt((double)NC_LEN * B - A * A) : 0.0;  // :49
+        abc[4 * (size_t)i + 3] = ok ? A / (double)NC_LEN : 0.0;                     // :40 (the byte sum is exact)
+    }
+}
+
+// ---- getEpiNccMat: 64 x 64 pairs per workgroup ------------------------------------------------------------------------
+struct NcSide {
+    const double* x;
+    const double* y;
+    const unsigned char* blocks;
+    const double* abc;
+    const int* valid;
+    int n;
+};
+struct NcArgs {
+    double F[9];
+    NcSide s1, s2;
+    double epiMax, nccMin, wNone;
+    double* epiMat;
+    double* nccMat;
+};
+
+typedef int nc_i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ long nc_row_chunk(const unsigned char* blocks, int row, int n, int byteOff) {
+    // eight bytes of a padded row, shifted to signed (x ^ 0x80 == x - 128 in two's complement); rows beyond n are zeros
+    if (row >= n) return 0;
+    const unsigned long long u = *(const unsigned long long*)(blocks + (size_t)row * NC_PITCH + byteOff);
+    return (long)(u ^ 0x8080808080808080ull);
+}
+
+__global__ __launch_bounds__(256) void k_ncc_epi_mat(NcArgs A) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int M = A.s1.n, N = A.s2.n;
+    const int i0 = blockIdx.y * 64 + 16 * wv;  // this wave's 16 rows (features of camera 1)
+    const int j0 = blockIdx.x * 64;            // the tile's 64 columns (features of camera 2)
+    if (i0 >= M) return;
+    const int lr = lane & 15, lk = lane >> 4;  // MFMA operand layout: row / column lr, k-chunk lk (8 bytes)
+    nc_i32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (nc_i32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int off = 32 * ks + 8 * lk;
+        const long a = nc_row_chunk(A.s1.blocks, i0 + lr, M, off);
+        long b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = nc_row_chunk(A.s2.blocks, j0 + 16 * t + lr, N, off);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b[t], acc[t], 0, 0, 0);
+    }
+    // ---- epilogue: lane holds rows 4 lk .. 4 lk + 3 of column lr of every 16 x 16 tile ----
+    double x1[4], y1[4], A1[4], C1[4];
+    int v1[4], s1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 4 * lk + r;
+        const bool in = i < M;
+        x1[r] = in ? A.s1.x[i] : 0.0;
+        y1[r] = in ? A.s1.y[i] : 0.0;
+        A1[r] = in ? A.s1.abc[4 * (size_t)i] : 0.0;
+        C1[r] = in ? A.s1.abc[4 * (size_t)i + 2] : 0.0;
+        v1[r] = in ? A.s1.valid[i] : 0;
+        s1[r] = (int)A1[r] - NC_LEN * 128;  // sum (I1 - 128)
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = j0 + 16 * t + lr;
+        if (j >= N) continue;
+        const double bx = A.s2.x[j], by = A.s2.y[j];
+        const double A2 = A.s2.abc[4 * (size_t)j], C2 = A.s2.abc[4 * (size_t)j + 2];
+        const int v2 = A.s2.valid[j];
+        const int s2 = (int)A2 - NC_LEN * 128;
+        // epipolarError(F, p1, p2): the line of p2
+        const double l0 = (A.F[0] * bx + A.F[1] * by) + A.F[2];
+        const double l1 = (A.F[3] * bx + A.F[4] * by) + A.F[5];
+        const double l2 = (A.F[6] * bx + A.F[7] * by) + A.F[8];
+        const double nn = sqrt(l0 * l0 + l1 * l1);
+        const double den = nn > 0 ? nn : 1.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 4 * lk + r;
+            if (i >= M) continue;
+            const double epiErr = fabs((l0 * x1[r] + l1 * y1[r]) + l2) / den;  // SL_FeatureMatching.cpp:24-25
+            double e = A.wNone, c = A.wNone;
+            if (epiErr <= A.epiMax && v1[r] && v2) {                           // :26
+                const int d = acc[t][r] + 128 * s1[r] + 128 * s2 + NC_LEN * 128 * 128;  // sum I1 I2, exact
+                const double ncc = (((double)NC_LEN * (double)d - A1[r] * A2) * C1[r]) * C2;  // SL_NCCBlock.cpp:263
+                if (ncc >= A.nccMin) {                                          // :29-31
+                    e = epiErr;
+                    c = ncc;
+                }
+            }
+            A.epiMat[(size_t)i * N + j] = e;
+            A.nccMat[(size_t)i * N + j] = c;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cs_ncc_blocks_dev(int device, void* hip_stream, const unsigned char* d_img, int W, int H, int n, const double* d_x,
+                                 const double* d_y, double scale, unsigned char* d_blocks, double* d_abc, int* d_valid) {
+    if (W < NC_BW || H < NC_BW || n < 0 || !(scale > 0)) {
+        cs_set_error("cs_ncc_blocks_dev: bad arguments (image at least 11 x 11, scale > 0)");
+        return CS_ERR_INVALID;
+    }
+    if (n == 0) return CS_OK;
+    if (!d_img || !d_x || !d_y || !d_blocks || !d_abc || !d_valid) {
+        cs_set_error("cs_ncc_blocks_dev: null pointer");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_ncc_blocks, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)hip_stream, d_img, W, H, n, d_x, d_y,
+                       scale, d_blocks, d_abc, d_valid);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+extern "C" int cs_ncc_epi_mat_dev(int device, void* hip_stream, const double F[9], int M, const double* d_x1, const double* d_y1,
+                                  const unsigned char* d_blocks1, const double* d_abc1, const int* d_valid1, int N,
+                                  const double* d_x2, const double* d_y2, const unsigned char* d_blocks2, const double* d_abc2,
+                                  const int* d_valid2, double epiMax, double nccMin, double wNone, double* d_epiMat,
+                                  double* d_nccMat) {
+    if (!F || M < 0 || N < 0) {
+        cs_set_error("cs_ncc_epi_mat_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (M == 0 || N == 0) return CS_OK;
+    if (!d_x1 || !d_y1 || !d_blocks1 || !d_abc1 || !d_valid1 || !d_x2 || !d_y2 || !d_blocks2 || !d_abc2 || !d_valid2 || !d_epiMat ||
+        !d_nccMat) {
+        cs_set_error("cs_ncc_epi_mat_dev: null pointer");
+        return CS_ERR_INVALID;
+    }
+    NcArgs A;
+    memcpy(A.F, F, sizeof(A.F));
+    A.s1 = {d_x1, d_y1, d_blocks1, d_abc1, d_valid1, M};
+    A.s2 = {d_x2, d_y2, d_blocks2, d_abc2, d_valid2, N};
+    A.epiMax = epiMax;
+    A.nccMin = nccMin;
+    A.wNone = wNone;
+    A.epiMat = d_epiMat;
+    A.nccMat = d_nccMat;
+    CS_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_ncc_epi_mat, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0,
+                       (hipStream_t)hip_stream, A);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+// Host-pointer form of the whole stage for one camera pair, as NewMapPtsNCC::matchBetween calls it: blocks of both
+// cameras from their small images, then the two matrices.  One upload, three launches, one read-back.
+extern "C" int cs_ncc_match_between(int device, const unsigned char* img1, int W1, int H1, int M, const double* x1, const double* y1,
+                                    const unsigned char* img2, int W2, int H2, int N, const double* x2, const double* y2,
+                                    double scale, const double F[9], double epiMax, double nccMin, double wNone, double* epiMat,
+                                    double* nccMat, unsigned char* blocks1, double* abc1, int* valid1, unsigned char* blocks2,
+                                    double* abc2, int* valid2) {
+    if (!img1 || !img2 || !F || M < 0 || N < 0 || (M && (!x1 || !y1)) || (N && (!x2 || !y2)) || (M && N && (!epiMat || !nccMat))) {
+        cs_set_error("cs_ncc_match_between: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (M == 0 || N == 0) return CS_OK;
+    CS_HIP(hipSetDevice(device));
+    const size_t i1 = (size_t)W1 * H1, i2 = (size_t)W2 * H2;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    const size_t oI1 = off; off += al(i1);
+    const size_t oI2 = off; off += al(i2);
+    const size_t oX1 = off; off += al(8 * (size_t)M);
+    const size_t oY1 = off; off += al(8 * (size_t)M);
+    const size_t oX2 = off; off += al(8 * (size_t)N);
+    const size_t oY2 = off; off += al(8 * (size_t)N);
+    const size_t inBytes = off;
+    const size_t oB1 = off; off += al(128 * (size_t)M);
+    const size_t oB2 = off; off += al(128 * (size_t)N);
+    const size_t oC1 = off; off += al(32 * (size_t)M);
+    const size_t oC2 = off; off += al(32 * (size_t)N);
+    const size_t oV1 = off; off += al(4 * (size_t)M);
+    const size_t oV2 = off; off += al(4 * (size_t)N);
+    const size_t oE = off; off += al(8 * (size_t)M * N);
+    const size_t oN = off; off += al(8 * (size_t)M * N);
+    char* d = nullptr;
+    if (hipMalloc((void**)&d, off) != hipSuccess) {
+        cs_set_error("cs_ncc_match_between: out of device memory (%zu bytes)", off);
+        return CS_ERR_HIP;
+    }
+    hipStream_t s = nullptr;
+    int rc = CS_OK;
+    hipError_t e = hipMemcpyAsync(d + oI1, img1, i1, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + oI2, img2, i2, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + oX1, x1, 8 * (size_t)M, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + oY1, y1, 8 * (size_t)M, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + oX2, x2, 8 * (size_t)N, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + oY2, y2, 8 * (size_t)N, hipMemcpyHostToDevice, s);
+    (void)inBytes;
+    if (e == hipSuccess) {
+        rc = cs_ncc_blocks_dev(device, s, (const unsigned char*)(d + oI1), W1, H1, M, (const double*)(d + oX1), (const double*)(d + oY1),
+                               scale, (unsigned char*)(d + oB1), (double*)(d + oC1), (int*)(d + oV1));
+        if (rc == CS_OK)
+            rc = cs_ncc_blocks_dev(device, s, (const unsigned char*)(d + oI2), W2, H2, N, (const double*)(d + oX2),
+                                   (const double*)(d + oY2), scale, (unsigned char*)(d + oB2), (double*)(d + oC2), (int*)(d + oV2));
+        if (rc == CS_OK)
+            rc = cs_ncc_epi_mat_dev(device, s, F, M, (const double*)(d + oX1), (const double*)(d + oY1), (const unsigned char*)(d + oB1),
+                                    (const double*)(d + oC1), (const int*)(d + oV1), N, (const double*)(d + oX2),
+                                    (const double*)(d + oY2), (const unsigned char*)(d + oB2), (const double*)(d + oC2),
+                                    (const int*)(d + oV2), epiMax, nccMin, wNone, (double*)(d + oE), (double*)(d + oN));
+    }
+    if (rc == CS_OK && e == hipSuccess) e = hipMemcpyAsync(epiMat, d + oE, 8 * (size_t)M * N, hipMemcpyDeviceToHost, s);
+    if (rc == CS_OK && e == hipSuccess) e = hipMemcpyAsync(nccMat, d + oN, 8 * (size_t)M * N, hipMemcpyDeviceToHost, s);
+    auto back = [&](void* dst, size_t o, size_t bytes) {
+        if (dst && rc == CS_OK && e == hipSuccess) e = hipMemcpyAsync(dst, d + o, bytes, hipMemcpyDeviceToHost, s);
+    };
+    back(blocks1, oB1, 128 * (size_t)M);
+    back(blocks2, oB2, 128 * (size_t)N);
+    back(abc1, oC1, 32 * (size_t)M);
+    back(abc2, oC2, 32 * (size_t)N);
+    back(valid1, oV1, 4 * (size_t)M);
+    back(valid2, oV2, 4 * (size_t)N);
+    if (rc == CS_OK && e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (rc != CS_OK) return rc;
+    if (e != hipSuccess) {
+        cs_set_error("cs_ncc_match_between: %s", hipGetErrorString(e));
+        return CS_ERR_HIP;
+    }
+    return CS_OK;
+}

@@ -1,0 +1,44 @@
+"""NCC blocks and the epipolar / NCC matrices of CoSLAM's inter-camera matching (cs_ncc_*): NCCBlock::compute,
+matchNCCBlock (reference src/slam/SL_NCCBlock.cpp:15-54, 258-264) and getEpiNccMat (src/slam/SL_FeatureMatching.cpp:3-46) --
+what NewMapPtsNCC::matchBetween (src/app/SL_NewMapPointsInterCam.cpp:273-317) computes before its greedy matcher."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+
+def ncc_blocks_dev(stream_ptr, d_img, W, H, n, d_x, d_y, scale, d_blocks, d_abc, d_valid, device=0):
+    vp = C.c_void_p
+    check(lib().cs_ncc_blocks_dev(int(device), vp(stream_ptr), vp(d_img), int(W), int(H), int(n), vp(d_x), vp(d_y),
+                                  C.c_double(scale), vp(d_blocks), vp(d_abc), vp(d_valid)), "cs_ncc_blocks_dev")
+
+
+def ncc_epi_mat_dev(stream_ptr, F, M, d_x1, d_y1, d_blocks1, d_abc1, d_valid1, N, d_x2, d_y2, d_blocks2, d_abc2, d_valid2, epiMax,
+                    nccMin, wNone, d_epiMat, d_nccMat, device=0):
+    vp = C.c_void_p
+    F = np.ascontiguousarray(F, dtype=np.float64).reshape(9)
+    check(lib().cs_ncc_epi_mat_dev(int(device), vp(stream_ptr), vp(F.ctypes.data), int(M), vp(d_x1), vp(d_y1), vp(d_blocks1),
+                                   vp(d_abc1), vp(d_valid1), int(N), vp(d_x2), vp(d_y2), vp(d_blocks2), vp(d_abc2), vp(d_valid2),
+                                   C.c_double(epiMax), C.c_double(nccMin), C.c_double(wNone), vp(d_epiMat), vp(d_nccMat)),
+          "cs_ncc_epi_mat_dev")
+
+
+def ncc_match_between(img1, x1, y1, img2, x2, y2, scale, F, epiMax, nccMin, wNone=-1.0, device=0):
+    """Host arrays in and out (cs_ncc_match_between).  Returns dict(epi, ncc (M x N), blocks1/2 (n x 128 uint8), abc1/2
+    (n x 4), valid1/2)."""
+    img1 = np.ascontiguousarray(img1, dtype=np.uint8)
+    img2 = np.ascontiguousarray(img2, dtype=np.uint8)
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (x1, y1, x2, y2)]
+    M, N = len(a[0]), len(a[2])
+    F = np.ascontiguousarray(F, dtype=np.float64).reshape(9)
+    epi, ncc = np.zeros((M, N)), np.zeros((M, N))
+    b1, b2 = np.zeros((M, 128), np.uint8), np.zeros((N, 128), np.uint8)
+    c1, c2 = np.zeros((M, 4)), np.zeros((N, 4))
+    v1, v2 = np.zeros(M, np.int32), np.zeros(N, np.int32)
+    p = lambda v: C.c_void_p(v.ctypes.data)  # noqa: E731
+    check(lib().cs_ncc_match_between(int(device), p(img1), img1.shape[1], img1.shape[0], M, p(a[0]), p(a[1]), p(img2),
+                                     img2.shape[1], img2.shape[0], N, p(a[2]), p(a[3]), C.c_double(scale), p(F),
+                                     C.c_double(epiMax), C.c_double(nccMin), C.c_double(wNone), p(epi), p(ncc), p(b1), p(c1),
+                                     p(v1), p(b2), p(c2), p(v2)), "cs_ncc_match_between")
+    return dict(epi=epi, ncc=ncc, blocks1=b1, abc1=c1, valid1=v1, blocks2=b2, abc2=c2, valid2=v2)

@@ -280,6 +280,32 @@ int cs_register_search(int device, int nCams, const cs_register_cam* cams, int N
                        double* m, double* var, double* dist, int* flags);
 
 /* ------------------------------------------------------------------------------------------
+ * Inter-camera NCC matching: blocks and the epipolar / NCC matrices of one camera pair
+ * ------------------------------------------------------------------------------------------
+ * Replaces NCCBlock::compute / computeScaled (src/slam/SL_NCCBlock.cpp:15-54), matchNCCBlock (:258-264) and getEpiNccMat
+ * (src/slam/SL_FeatureMatching.cpp:3-46) -- the matrices NewMapPtsNCC::matchBetween
+ * (src/app/SL_NewMapPointsInterCam.cpp:273-317) hands to its greedy matcher.
+ * Block record: 128 bytes per feature, the 121 bytes of NCCBlock::I row by row, then 7 bytes of 0x80; abc: 4 doubles per
+ * feature (NCCBlock::A, B, C, avgI); valid: compute()'s return value (0: the block would leave the image; its record is
+ * 0x80 / zeros).  Feature positions are x[] and y[] in pixels of the FULL image; the block is cut at (int)(x * scale),
+ * (int)(y * scale) of the small image (SingleSLAM::m_smallImg, m_smallScale = 0.3).
+ * Matrices: M x N doubles, row = feature of camera 1.  Entry (i, j): e = epipolarError(F, p1_i, p2_j) (distance of p1_i
+ * from the line F (p2_j, 1)); if e <= epiMax and matchNCCBlock >= nccMin: epiMat = e, nccMat = the score; else both
+ * wNone (-1 in the reference).  A pair with a missing block is wNone. */
+int cs_ncc_blocks_dev(int device, void* hip_stream, const unsigned char* d_img, int W, int H, int n, const double* d_x,
+                      const double* d_y, double scale, unsigned char* d_blocks, double* d_abc, int* d_valid);
+int cs_ncc_epi_mat_dev(int device, void* hip_stream, const double F[9] /* host */, int M, const double* d_x1, const double* d_y1,
+                       const unsigned char* d_blocks1, const double* d_abc1, const int* d_valid1, int N, const double* d_x2,
+                       const double* d_y2, const unsigned char* d_blocks2, const double* d_abc2, const int* d_valid2,
+                       double epiMax, double nccMin, double wNone, double* d_epiMat, double* d_nccMat);
+/* Host memory in and out, the whole stage for one camera pair (blocks of both cameras, then the matrices); the block
+ * outputs (blocks / abc / valid) may be NULL. */
+int cs_ncc_match_between(int device, const unsigned char* img1, int W1, int H1, int M, const double* x1, const double* y1,
+                         const unsigned char* img2, int W2, int H2, int N, const double* x2, const double* y2, double scale,
+                         const double F[9], double epiMax, double nccMin, double wNone, double* epiMat, double* nccMat,
+                         unsigned char* blocks1, double* abc1, int* valid1, unsigned char* blocks2, double* abc2, int* valid2);
+
+/* ------------------------------------------------------------------------------------------
  * Robust multi-camera bundle adjustment
  * ------------------------------------------------------------------------------------------ */
 

@@ -207,6 +207,41 @@ def register_search(W, H, Ks, Rs, ts, xy, state, slot2map, isDynamic, Ms, covs, 
     return dict(slot=slot, m=m, var=var, dist=dist, flags=flags)
 
 
+def ncc_blocks(img, x, y, scale):
+    """onc_block_compute for n points: returns (blocks uint8[n,128] (121 used, pad 0x80), abc float64[n,4], valid int32[n])."""
+    L = lib()
+    L.onc_block_compute.restype = C.c_int
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W = img.shape
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    n = len(x)
+    blocks = np.full((n, 128), 0x80, dtype=np.uint8)
+    abc = np.zeros((n, 4))
+    valid = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        valid[i] = L.onc_block_compute(_p(img), W, H, C.c_double(x[i]), C.c_double(y[i]), C.c_double(scale),
+                                       blocks[i].ctypes.data_as(C.c_void_p), abc[i].ctypes.data_as(C.c_void_p))
+        if not valid[i]:
+            blocks[i] = 0x80
+            abc[i] = 0
+    return blocks, abc, valid
+
+
+def ncc_epi_mat(F, x1, y1, blk1, abc1, valid1, x2, y2, blk2, abc2, valid2, epiMax, nccMin, wNone=-1.0):
+    """onc_epi_ncc_mat: returns (epiMat, nccMat), M x N float64."""
+    F = np.ascontiguousarray(F, dtype=np.float64).reshape(9)
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (x1, y1, x2, y2)]
+    M, N = len(a[0]), len(a[2])
+    b1, b2 = np.ascontiguousarray(blk1, dtype=np.uint8), np.ascontiguousarray(blk2, dtype=np.uint8)
+    c1, c2 = np.ascontiguousarray(abc1, dtype=np.float64), np.ascontiguousarray(abc2, dtype=np.float64)
+    v1, v2 = np.ascontiguousarray(valid1, dtype=np.int32), np.ascontiguousarray(valid2, dtype=np.int32)
+    epi, ncc = np.zeros((M, N)), np.zeros((M, N))
+    lib().onc_epi_ncc_mat(_p(F), M, _p(a[0]), _p(a[1]), _p(b1), _p(c1), _p(v1), N, _p(a[2]), _p(a[3]), _p(b2), _p(c2), _p(v2),
+                          C.c_double(epiMax), C.c_double(nccMin), C.c_double(wNone), _p(epi), _p(ncc))
+    return epi, ncc
+
+
 def set_threshold_margin_buffer(buf):
     """buf: float32[N] preset to a large value (kept alive by the caller), or None to switch the diagnostic off."""
     lib().okl_set_threshold_margin_buffer(_p(buf) if buf is not None else None)

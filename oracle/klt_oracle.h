@@ -147,6 +147,13 @@ void org_register_search(int nCams, int N, int W, int H, const double* Ks, const
                          const int* pointFeat, double sigmaSearch, double maxDist, double sigmaMerge, int* slot, double* m_out,
                          double* var_out, double* dist, int* flags);
 
+/* ---- NCC blocks and the epipolar / NCC matrices of the inter-camera matching restated (ncc_oracle.c) ---- */
+int onc_block_compute(const unsigned char* img, int W, int H, double x, double y, double scale, unsigned char* I, double* abc);
+double onc_match(const unsigned char* I1, const double* abc1, const unsigned char* I2, const double* abc2);
+void onc_epi_ncc_mat(const double* F, int M, const double* x1, const double* y1, const unsigned char* blk1, const double* abc1,
+                     const int* valid1, int N, const double* x2, const double* y2, const unsigned char* blk2, const double* abc2,
+                     const int* valid2, double epiMax, double nccMin, double wNone, double* epiMat, double* nccMat);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,11 +23,19 @@ template <class... A> void binTriangulate(const A&...);
 #define CV_8UC1 0
 namespace cv {
 struct Size {
+    Size();
     Size(int, int);
 };
+struct Point2d {
+    Point2d(double, double);
+};
 struct Mat {
+    unsigned char* data;
+    Mat();
     Mat(int, int, int, void*);
 };
 void resize(Mat&, Mat&, Size);
+void resize(Mat&, Mat&, Size, double, double);
+void getRectSubPix(Mat&, Size, Point2d, Mat&);
 }  // namespace cv
 #endif

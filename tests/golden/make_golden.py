@@ -13,6 +13,9 @@ register_golden.npz -- a feature list, 400 (m, var, maxDist) queries and the ans
                     searchMahaNearestFeatPt (src/app/SL_SingleSLAM.cpp:1141-1164 compiled in place into
                     oracle/_ref/ref_register_test, `golden` mode, CPU).  Pins oracle/register_oracle.c's search and,
                     on the GPU box, the registration kernel.
+ncc_golden.npz   -- two small images, feature positions, F and the REFERENCE's own NCC blocks (NCCBlock::computeScaled,
+                    src/slam/SL_NCCBlock.cpp:15-54) and epipolar / NCC matrices (getEpiNccMat,
+                    src/slam/SL_FeatureMatching.cpp:3-46; matchNCCBlock) from oracle/_ref/ref_ncc_test `golden` (CPU).
 """
 import os
 import sys
@@ -110,10 +113,48 @@ def register_case():
                 slot=ans.copy(), empty_frame_returns_null=np.int32(1 - none))
 
 
+def ncc_case():
+    """the reference's own NCCBlock::computeScaled / getEpiNccMat (oracle/_ref/ref_ncc_test golden, CPU)"""
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_ncc_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_ncc_test missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "ncc.bin")
+        subprocess.run([exe, "golden", path], check=True)
+        raw = open(path, "rb").read()
+    W, H, M, N = np.frombuffer(raw, dtype=np.int32, count=4)
+    o = 16
+    F = np.frombuffer(raw, dtype=np.float64, count=9, offset=o)
+    o += 72
+    scale, epiMax, nccMin = np.frombuffer(raw, dtype=np.float64, count=3, offset=o)
+    o += 24
+    out = dict(F=F.copy(), scale=scale, epiMax=epiMax, nccMin=nccMin)
+    for tag, n in (("1", M), ("2", N)):
+        out["img" + tag] = np.frombuffer(raw, dtype=np.uint8, count=W * H, offset=o).reshape(H, W).copy()
+        o += W * H
+        out["x" + tag] = np.frombuffer(raw, dtype=np.float64, count=n, offset=o).copy()
+        o += 8 * n
+        out["y" + tag] = np.frombuffer(raw, dtype=np.float64, count=n, offset=o).copy()
+        o += 8 * n
+        out["blocks" + tag] = np.frombuffer(raw, dtype=np.uint8, count=128 * n, offset=o).reshape(n, 128).copy()
+        o += 128 * n
+        out["abc" + tag] = np.frombuffer(raw, dtype=np.float64, count=4 * n, offset=o).reshape(n, 4).copy()
+        o += 32 * n
+        out["valid" + tag] = np.frombuffer(raw, dtype=np.int32, count=n, offset=o).copy()
+        o += 4 * n
+    out["epi"] = np.frombuffer(raw, dtype=np.float64, count=M * N, offset=o).reshape(M, N).copy()
+    o += 8 * M * N
+    out["ncc"] = np.frombuffer(raw, dtype=np.float64, count=M * N, offset=o).reshape(M, N).copy()
+    return out
+
+
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -122,4 +163,6 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "ba_golden.npz"), **ba_case())
     if "register" in which:
         np.savez_compressed(os.path.join(HERE, "register_golden.npz"), **register_case())
+    if "ncc" in which:
+        np.savez_compressed(os.path.join(HERE, "ncc_golden.npz"), **ncc_case())
     print("golden fixtures written")

@@ -9,6 +9,8 @@
                                        (chooseStaticFeatPts ...) compiled in place over the shims.
 * oracle/_ref/ref_register_test        the REFERENCE'S OWN searchMahaNearestFeatPt (src/app/SL_SingleSLAM.cpp:1141-1164) over
                                        FeaturePoints lists built with the reference's classes, against cs_register_search.
+* oracle/_ref/ref_ncc_test             the REFERENCE'S OWN NCCBlock::computeScaled, matchNCCBlock (src/slam/SL_NCCBlock.cpp) and
+                                       getEpiNccMat (src/slam/SL_FeatureMatching.cpp) against cs_ncc_match_between.
 The oracle/_ref binaries are built by oracle/Makefile where the reference tree exists (__graft_entry__.build()) and
 travel with the repo snapshot; the reference sources themselves are never copied."""
 import os
@@ -41,6 +43,11 @@ def test_reference_ba_callers_run_over_the_shim(hip):
 
 def test_reference_search_function_agrees_with_the_registration_kernel(hip):
     out = _run(os.path.join(ROOT, "oracle", "_ref", "ref_register_test"), "candidates agree with the reference's searchMahaNearestFeatPt")
+    print(out)
+
+
+def test_reference_ncc_code_agrees_with_the_ncc_kernels(hip):
+    out = _run(os.path.join(ROOT, "oracle", "_ref", "ref_ncc_test"), "equal the reference's bit for bit")
     print(out)
 
 

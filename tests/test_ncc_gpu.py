@@ -1,0 +1,104 @@
+"""cs_ncc_* (NCC blocks + the epipolar / NCC matrices of the inter-camera matching; reference src/slam/SL_NCCBlock.cpp:15-54,
+258-264, src/slam/SL_FeatureMatching.cpp:3-46) against the reference's own outputs (tests/golden/ncc_golden.npz) and the
+oracle's restatement: bytes and binary64 values bit for bit -- the pair scores come out of v_mfma_i32_16x16x32_i8 as exact
+integers -- at the headline's size (2000 x 2000 features), on ragged sizes and on degenerate blocks."""
+import os
+
+import numpy as np
+import pytest
+
+import coslam_amd
+import oracle
+from coslam_amd.synth import Scene
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _check(g, img1, x1, y1, img2, x2, y2, scale, F, epiMax, nccMin, what=""):
+    o1 = oracle.ncc_blocks(img1, x1, y1, scale)
+    o2 = oracle.ncc_blocks(img2, x2, y2, scale)
+    for t, o in (("1", o1), ("2", o2)):
+        assert np.array_equal(g["valid" + t], o[2]), what
+        assert np.array_equal(g["blocks" + t], o[0]), what
+        assert np.array_equal(g["abc" + t], o[1]), what
+    epi, ncc = oracle.ncc_epi_mat(F, x1, y1, *o1, x2, y2, *o2, epiMax, nccMin)
+    assert np.array_equal(g["ncc"], ncc), f"{what}: {(g['ncc'] != ncc).sum()} scores differ"
+    assert np.array_equal(g["epi"], epi), what
+    return epi, ncc
+
+
+def test_ncc_matches_the_reference_golden(hip):
+    g = np.load(os.path.join(GOLD, "ncc_golden.npz"))
+    r = coslam_amd.ncc_match_between(g["img1"], g["x1"], g["y1"], g["img2"], g["x2"], g["y2"], float(g["scale"]), g["F"],
+                                     float(g["epiMax"]), float(g["nccMin"]))
+    for t in ("1", "2"):
+        assert np.array_equal(r["valid" + t], g["valid" + t])
+        assert np.array_equal(r["blocks" + t], g["blocks" + t])
+        assert np.array_equal(r["abc" + t], g["abc" + t])
+    assert np.array_equal(r["epi"], g["epi"]) and np.array_equal(r["ncc"], g["ncc"])
+
+
+def _fundamental(sc, c1, c2, f=0):
+    """F with x1^T F x2 = 0 for the scene's cameras c1, c2 (pixels of the full image)"""
+    R1, t1 = sc.pose(c1, f)
+    R2, t2 = sc.pose(c2, f)
+    R = R1 @ R2.T
+    t = t1 - R @ t2
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Ki = np.linalg.inv(sc.K)
+    return Ki.T @ tx @ R @ Ki
+
+
+@pytest.mark.parametrize("M,N", [(2000, 2000), (777, 1301), (1, 65), (64, 1)])
+def test_ncc_matches_oracle_on_rendered_cameras(hip, M, N):
+    """two cameras of the synthetic rig, small images = 0.3 x decimations of the rendered frames, features at the projections
+    of the scene's points (so true matches exist) plus random ones"""
+    W, H, scale = 640, 480, 0.3
+    sc = Scene(2, W, H, 3000, seed=77)
+    rng = np.random.default_rng(M + N)
+    small = []
+    for c in range(2):
+        im = sc.render(c, 0).astype(np.float64)
+        ys = (np.arange(int(H * scale)) / scale).astype(int)
+        xs = (np.arange(int(W * scale)) / scale).astype(int)
+        small.append(np.ascontiguousarray(im[np.ix_(ys, xs)]).astype(np.uint8))
+    pts = []
+    for c, n in ((0, M), (1, N)):
+        uv, vis = sc.project(c, 0)
+        k = np.nonzero(vis)[0][: n // 2]
+        x = np.concatenate([uv[k, 0], rng.uniform(-20, W + 20, n - len(k))])
+        y = np.concatenate([uv[k, 1], rng.uniform(-20, H + 20, n - len(k))])
+        pts.append((x, y))
+    F = _fundamental(sc, 0, 1)
+    # NewMapPtsNCCParam's defaults (epipolar 50 px, NCC 0.8), then a looser score gate so that many pairs are kept
+    r = coslam_amd.ncc_match_between(small[0], *pts[0], small[1], *pts[1], scale, F, 50.0, 0.8)
+    _check(r, small[0], *pts[0], small[1], *pts[1], scale, F, 50.0, 0.8, f"{M}x{N}")
+    r = coslam_amd.ncc_match_between(small[0], *pts[0], small[1], *pts[1], scale, F, 50.0, 0.3)
+    epi, ncc = _check(r, small[0], *pts[0], small[1], *pts[1], scale, F, 50.0, 0.3, f"{M}x{N} loose")
+    if M >= 700:
+        kept = ncc != -1
+        assert kept.sum() > 100 and (r["valid1"] == 0).any()
+        # true correspondences (the same scene point seen by both cameras) sit on their epipolar lines
+        n_true = min(M, N) // 2
+        d = np.abs(np.diag(oracle.ncc_epi_mat(F, *pts[0], r["blocks1"], r["abc1"], r["valid1"], *pts[1], r["blocks2"], r["abc2"],
+                                              r["valid2"], 1e9, -2.0)[0])[:n_true // 4])
+        assert np.median(d) < 1.0
+
+
+def test_ncc_degenerate_blocks_and_arguments(hip):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+    img[:, 32:] = 255                                           # saturated half: flat blocks (C = inf), largest byte products
+    flat = np.full((48, 64), 255, np.uint8)
+    x = rng.uniform(0, 64 / 0.3, 130)
+    y = rng.uniform(0, 48 / 0.3, 130)
+    F = rng.normal(size=(3, 3))
+    for a, b in ((img, img), (img, flat), (flat, flat)):
+        r = coslam_amd.ncc_match_between(a, x, y, b, x[:97], y[:97], 0.3, F, 1e9, -2.0)   # every pair with both blocks is scored
+        _check(r, a, x, y, b, x[:97], y[:97], 0.3, F, 1e9, -2.0)
+    r = coslam_amd.ncc_match_between(img, x[:0], y[:0], img, x, y, 0.3, F, 50.0, 0.8)          # no features on one side
+    assert r["ncc"].shape == (0, 130)
+    with pytest.raises(coslam_amd.CoslamHipError):
+        coslam_amd.ncc_blocks_dev(0, 1, 5, 5, 3, 1, 1, 0.3, 1, 1, 1)                           # image smaller than a block
