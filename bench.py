@@ -435,14 +435,23 @@ def main():
         d_slot2map[i].copy_(torch.from_numpy(associate(sc, c, order[0], d)))
     torch.cuda.synchronize()
 
+    # set-up, not warm-up: one key-frame interval so that everything that happens once per process is behind us -- the BA
+    # workers capture and instantiate their graphs on first use, the runtime loads each kernel's code object at its first
+    # launch -- whatever W the caller asks for
+    for i in range(max(args.key_every, 1) + 1):
+        step(i + 1, args.key_every > 0 and i == 0)
+    barrier()
     for i in range(args.warmup):
         step(i + 1, args.key_every > 0 and i % args.key_every == 0)
     barrier()
     t_begin = time.perf_counter()
+    t_step_max, t_prev = 0.0, t_begin
     for i in range(args.steps):
         # key frames: the first frame of the timed region and every KEY_EVERY-th after it (K / KEY_EVERY solves of each
         # kind in K frames, all completed before the clock stops)
         step(args.warmup + i + 1, args.key_every > 0 and i % args.key_every == 0)
+        t_now = time.perf_counter()
+        t_step_max, t_prev = max(t_step_max, t_now - t_prev), t_now
     t_host = time.perf_counter() - t_begin
     barrier()
     dt = time.perf_counter() - t_begin
@@ -572,7 +581,7 @@ def main():
                        "register_candidates_last_frame": None if args.no_register else
                        {"active": int((reg_out[0]["slot"] >= 0).sum().item()), "current_static": int((reg_out[1]["slot"] >= 0).sum().item()),
                         "already_attached": int((reg_out[1]["slot"] == -1).sum().item())},
-                       "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "tracker_stream_cus": args.klt_cus or "all",
+                       "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "host_enqueue_ms_max_step": t_step_max * 1e3, "tracker_stream_cus": args.klt_cus or "all",
                        "collectives": None if world == 1 else ("libcoslam_hip RCCL (C-ABI)" if native else "torch.distributed " + dist_backend),
                        "streams": "one stream (--serial)" if args.serial else
                        "tracker group | hand-back + pose (event-ordered behind the tracker of the same frame) | "
