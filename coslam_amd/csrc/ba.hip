@@ -887,7 +887,7 @@ __device__ __forceinline__ int sb_off(int I, int J) { return (I * (I + 1) / 2 + 
 
 __host__ __device__ constexpr size_t sb_lds_bytes(int n) {
     const int NB = (n + SB - 1) / SB;
-    return sizeof(double) * ((size_t)(NB * (NB + 1) / 2) * SBLK + (size_t)2 * NB * SB + SB * SB) + 16;
+    return sizeof(double) * ((size_t)(NB * (NB + 1) / 2) * SBLK + (size_t)NB * SB) + 16;
 }
 
 __device__ __forceinline__ double sb_rdlane(double v, int l) {
@@ -948,26 +948,49 @@ struct SbColumn<16> {
     static __device__ __forceinline__ void run(double (&)[16], double&, bool&, int) {}
 };
 
+template <int K>
+struct SbInvStep {  // row K of X = L^-1 is final: X[i][c] -= (L_iK / L_ii) X[K][c] for the rows i > K (this lane's four columns)
+    static __device__ __forceinline__ void run(double (&x)[4], const double (&nlp)[16]) {
+        sb_fmac_bcast<K, true>(x[0], x[0], nlp[K]);
+        sb_fmac_bcast<K, false>(x[1], x[1], nlp[K]);
+        sb_fmac_bcast<K, false>(x[2], x[2], nlp[K]);
+        sb_fmac_bcast<K, false>(x[3], x[3], nlp[K]);
+        SbInvStep<K + 1>::run(x, nlp);
+    }
+};
+template <>
+struct SbInvStep<15> {
+    static __device__ __forceinline__ void run(double (&)[4], const double (&)[16]) {}
+};
+
 // wave 0: Cholesky of one diagonal block out of registers (lane i holds row i & 15: the four 16-lane rows of the wave
-// carry the same block); leaves L_kk and 1 / diag in LDS.  Sixteen unrolled column steps; the pivot broadcast and the
-// rank-1 updates are f64 DPP instructions (v_readlane pairs + fma: 4.6 k cycles per block; a 32-bit DPP mov pair per
-// value, the first attempt: 11.5 k).
-__device__ __forceinline__ bool sb_factor_diag(double* Dk, double* rdiag, double* LTs, int lane) {
-    const int row = lane & 15;
+// carry the same block), then its INVERSE, which replaces the block in LDS: with L_kk^-1 at hand the panel A L_kk^-T and
+// both substitutions with L_kk are products (matrix cores / independent dot products) instead of sixteen-step recurrences
+// in every panel row.  Factor: sixteen unrolled column steps; the pivot broadcast and the rank-1 updates are f64 DPP
+// instructions (v_readlane pairs + fma: 4.6 k cycles per block; a 32-bit DPP mov pair per value, the first attempt: 11.5 k).
+// Inverse: forward substitution on the identity, rows = lanes; each of the wave's four 16-lane rows takes four columns, so a
+// step is four v_fmac_f64_dpp and the whole inverse ~100 instructions.
+__device__ __forceinline__ bool sb_factor_diag(double* Dk, int lane) {
+    const int row = lane & 15, g = lane >> 4;
     double a[SB];
 #pragma unroll
     for (int k = 0; k < SB; ++k) a[k] = Dk[row * SP + k];
     bool bad = false;
     double myr = 1.0;  // 1 / L_jj of this lane's own column, picked up branch-free as the columns go by
     SbColumn<0>::run(a, myr, bad, row);
-    if (lane < SB) {
-        rdiag[lane] = myr;
+    // X = L^-1:  X[i][c] = delta_ic / L_ii - sum_{k < i} (L_ik / L_ii) X[k][c]; this lane holds X[row][4 g .. 4 g + 3]
+    double nlp[SB];
 #pragma unroll
-        for (int k = 0; k < SB; ++k) Dk[lane * SP + k] = a[k];
-        // for the panel: LTs[c][k] = L_kc / L_kk, row c = column c of L_kk scaled by the reciprocal pivots of its rows
+    for (int k = 0; k < SB; ++k) nlp[k] = (k < row) ? -(a[k] * myr) : 0.0;
+    double x[4];
 #pragma unroll
-        for (int c = 0; c < SB; ++c) LTs[c * SB + lane] = a[c] * myr;
-    }
+    for (int j = 0; j < 4; ++j) x[j] = (row == 4 * g + j) ? myr : 0.0;
+    SbInvStep<0>::run(x, nlp);
+    // (the block is read by nobody else until the workgroup barrier that follows)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Dk[row * SP + 4 * g + j] = x[j];
     return !bad;
 }
 
@@ -999,6 +1022,51 @@ __device__ __forceinline__ void sb_tile_update(double* A, int I, int J, int kb, 
         for (int c = 0; c < 4; ++c) T[r * SP + c] -= acc[r][c];
 }
 
+// One whole 16 x 16 block  A[I][J] -= P_I P_J^T  by ONE wave on the matrix cores: four v_mfma_f64_16x16x4f64.  The f64 matrix
+// peak equals the f64 vector peak on this chip, so this buys no throughput -- it buys instructions: 4 MFMAs + 16 LDS accesses
+// per lane instead of 16 lanes x (64 fma + 64 LDS reads) for the same block, and the factorisation is a latency chain.
+// Operand layout (tools/micro/mfma_f64_layout.hip): A: lane l supplies A[l % 16][l / 16]; B: lane l supplies B[l / 16][l % 16];
+// D: lane l, register q holds D[l / 16 + 4 q][l % 16].
+typedef double sb_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sb_block_update_mfma(double* A, int I, int J, int kb, int lane) {
+    const double* PI = A + sb_off(I, kb);
+    const double* PJ = A + sb_off(J, kb);
+    double* T = A + sb_off(I, J);
+    const int lr = lane & 15, lg = lane >> 4;
+    sb_d4 c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = T[(lg + 4 * q) * SP + lr];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const double a = -PI[lr * SP + 4 * s + lg];
+        const double bb = PJ[lr * SP + 4 * s + lg];
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T[(lg + 4 * q) * SP + lr] = c[q];
+}
+
+// panel block  A[I][kb] <- A[I][kb] L_kk^-T = A[I][kb] Linv^T  (Linv = the inverted diagonal block, in place of A[kb][kb])
+__device__ __forceinline__ void sb_panel_mfma(double* A, int I, int kb, int lane) {
+    double* P = A + sb_off(I, kb);
+    const double* Li = A + sb_off(kb, kb);
+    const int lr = lane & 15, lg = lane >> 4;
+    double pa[4], pb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        pa[s] = P[lr * SP + 4 * s + lg];    // A operand: A[i = lr][c = 4 s + lg]
+        pb[s] = Li[lr * SP + 4 * s + lg];   // B operand: B[c][j = lr] = Linv[j][c]
+    }
+    sb_d4 c = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[s], pb[s], c, 0, 0, 0);
+    // (every lane has read its operands of this block before anyone overwrites it: one wave owns the block)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) P[(lg + 4 * q) * SP + lr] = c[q];
+}
+
 __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
     CS_BA_SETPRIO();
     const int stAllDone = D.st->all_done, stInnerDone = D.st->inner_done;  // (consumed after the matrix loads are in flight)
@@ -1023,8 +1091,6 @@ __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
 #endif
     double* A = sm;
     double* b = sm + (size_t)NBT * SBLK;  // the right-hand side: one more row of the matrix
-    double* rdiag = b + (size_t)NB * SB;  // 1 / L_jj
-    double* LTs = rdiag + (size_t)NB * SB;  // 16 x 16: the current diagonal block, transposed and row-scaled (see the panel)
     // ---- load the lower triangle (identity padding beyond n).  One wave per 16 x 16 block, four entries per lane (a lane
     // reads 32-byte row pieces, a wave 16 full rows of 128 bytes); the block -> (I, J) arithmetic is wave-uniform and runs
     // on the scalar unit, every load of a wave's blocks (up to 5 at order 176) is issued before the first LDS store.
@@ -1069,94 +1135,69 @@ __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
     // the first diagonal block; every later one is factored by wave 0 NEXT TO the trailing update of the step before
     // (look-ahead), so the serial column chain -- the longest phase -- is off the critical path
     if (tid < 64) {
-        if (!sb_factor_diag(A + sb_off(0, 0), rdiag, LTs, tid) && tid == 0) okFlag = 0;
+        if (!sb_factor_diag(A + sb_off(0, 0), tid) && tid == 0) okFlag = 0;
     }
     __syncthreads();
     CS_PROBE(pDiag);
 
     for (int kb = 0; kb < NB; ++kb) {
-        // ---- panel by substitution: x L_kk^T = a, one row per thread (the last row is the right-hand side's block kb).
-        // With a' = a / diag(L) and L' = diag(L)^-1 L (rows scaled, kept transposed in LTs by the factorisation) the
-        // recurrence is x_c = a'_c - sum_{k<c} x_k L'_ck: ONE fma on the dependent chain per column, the other updates of a
-        // column are independent and fill the issue slots.  Written right-looking with a scheduling barrier per column:
-        // left to itself the compiler turns it into sixteen serial dot products (2.4 k cycles per step instead of ~1 k).
+        // ---- panel: A[I][kb] <- A[I][kb] Linv^T, one block per wave on the matrix cores; the right-hand side's block kb
+        // (one more row of the matrix) is sixteen dot products with the rows of Linv: y_c = sum_{j <= c} b_j Linv[c][j].
         const int m = NB - kb - 1;
-        for (int rr = tid; rr < m * SB + 1; rr += NT) {
-            double* row = (rr < m * SB) ? A + sb_off(kb + 1 + rr / SB, kb) + (rr % SB) * SP : b + kb * SB;
-            double a[SB];
+        {
+            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+            for (int I = kb + 1 + wv; I < NB; I += 16) sb_panel_mfma(A, I, kb, ln);
+            if (wv == 15 && ln < SB) {
+                const double* Li = A + sb_off(kb, kb) + ln * SP;
+                double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < SB; ++k) a[k] = row[k] * rdiag[kb * SB + k];
-            double2 lc[SB / 2], ln[SB / 2];
-#pragma unroll
-            for (int q = 0; q < SB / 2; ++q) lc[q] = *(const double2*)(LTs + 2 * q);  // row 0 of LTs
-#pragma unroll
-            for (int c = 0; c < SB - 1; ++c) {
-                const double nx = -a[c];
-                if (c + 1 < SB - 1) {  // the next column's row of LTs, requested before this column's updates
-#pragma unroll
-                    for (int q = (c + 2) / 2; q < SB / 2; ++q) ln[q] = *(const double2*)(LTs + (c + 1) * SB + 2 * q);
-                }
-                a[c + 1] = fma(nx, ((c + 1) & 1) ? lc[(c + 1) / 2].y : lc[(c + 1) / 2].x, a[c + 1]);  // the chain first
-#pragma unroll
-                for (int k = c + 2; k < SB; ++k) a[k] = fma(nx, (k & 1) ? lc[k / 2].y : lc[k / 2].x, a[k]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < SB / 2; ++q) lc[q] = ln[q];
+                for (int j = 0; j < SB; ++j) acc = fma(b[kb * SB + j], Li[j], acc);  // Linv[c][j] = 0 for j > c
+                b[kb * SB + ln] = acc;  // (in place: the sixteen lanes' reads are all issued before this store)
             }
-#pragma unroll
-            for (int k = 0; k < SB; ++k) row[k] = a[k];
         }
         __syncthreads();
         CS_PROBE(pPanel);
         if (m == 0) break;
-        // ---- trailing update A[I][J] -= P_I P_J^T for kb < J <= I (4 x 4 tile per thread) and b_J -= b_kb P_J^T.
-        // Wave 0 takes the next diagonal block's sixteen tiles and then factors it; waves 1..15 take everything else.
+        // ---- trailing update A[I][J] -= P_I P_J^T for kb < J <= I (one block per wave and turn, on the matrix cores) and
+        // b_J -= b_kb P_J^T.  Wave 0 takes the next diagonal block and then factors it; waves 1..15 take everything else.
         if (tid < 64) {
-            if (tid < 16) sb_tile_update(A, kb + 1, kb + 1, kb, tid >> 2, tid & 3);
+            sb_block_update_mfma(A, kb + 1, kb + 1, kb, tid);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (!sb_factor_diag(A + sb_off(kb + 1, kb + 1), rdiag + (kb + 1) * SB, LTs, tid) && tid == 0) okFlag = 0;
+            if (!sb_factor_diag(A + sb_off(kb + 1, kb + 1), tid) && tid == 0) okFlag = 0;
         } else {
-            const int nTiles = m * (m + 1) / 2 * 16;
-            for (int t = 16 + (tid - 64); t < nTiles + m * SB; t += NT - 64) {
-                if (t >= nTiles) {  // one entry of the right-hand side row
-                    const int q = t - nTiles, J = kb + 1 + q / SB, c = q % SB;
-                    const double* PJ = A + sb_off(J, kb) + c * SP;
-                    const double* y = b + kb * SB;
-                    double acc = 0.0;
-#pragma unroll
-                    for (int k = 0; k < SB; ++k) acc = fma(y[k], PJ[k], acc);
-                    b[J * SB + c] -= acc;
-                    continue;
-                }
-                const int blk = t >> 4;
+            const int wv = __builtin_amdgcn_readfirstlane((tid >> 6) - 1), ln = tid & 63;  // 0..14
+            const int nBlk = m * (m + 1) / 2;
+            for (int blk = 1 + wv; blk < nBlk; blk += 15) {  // block 0 of the list is wave 0's (kb + 1, kb + 1)
                 int bi = 0;
                 while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
                 const int bj = blk - bi * (bi + 1) / 2;
-                sb_tile_update(A, kb + 1 + bi, kb + 1 + bj, kb, (t >> 2) & 3, t & 3);
+                sb_block_update_mfma(A, kb + 1 + bi, kb + 1 + bj, kb, ln);
+            }
+            // the right-hand side row: one entry per thread of the waves that are done first
+            for (int q = (tid - 64); q < m * SB; q += NT - 64) {
+                const int J = kb + 1 + q / SB, c = q % SB;
+                const double* PJ = A + sb_off(J, kb) + c * SP;
+                const double* y = b + kb * SB;
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < SB; ++k) acc = fma(y[k], PJ[k], acc);
+                b[J * SB + c] -= acc;
             }
         }
         __syncthreads();
         CS_PROBE(pTrail);
     }
-    // b now holds y = L^-1 rhs.  Back substitution L^T x = y, block by block from the bottom.
+    // b now holds y = L^-1 rhs.  Back substitution L^T x = y, block by block from the bottom; the diagonal blocks hold
+    // their inverses, so x_kb = Linv^T y_kb is sixteen independent dot products: x_c = sum_{j >= c} Linv[j][c] y_j.
     for (int kb = NB - 1; kb >= 0; --kb) {
-        const double* Lk = A + sb_off(kb, kb);
-        if (tid < 64) {  // x_kb = L_kk^-T y_kb: lane i holds y_i and column i of L_kk (= row i of L_kk^T)
-            const int lane = tid, i = lane & 15;
-            double y = b[kb * SB + i];
-            double col[SB];
+        if (tid < SB) {
+            const double* Li = A + sb_off(kb, kb);
+            double acc = 0.0;
 #pragma unroll
-            for (int c = 0; c < SB; ++c) col[c] = Lk[c * SP + i];  // L_ci
-            const double rd = rdiag[kb * SB + i];
-#pragma unroll
-            for (int c = SB - 1; c >= 0; --c) {
-                const double xc = sb_rdlane(y, c) * sb_rdlane(rd, c);
-                if (i == c) y = xc;
-                if (i < c) y = fma(-col[c], xc, y);
-            }
-            if (lane < SB) b[kb * SB + lane] = y;
+            for (int j = 0; j < SB; ++j) acc = fma(Li[j * SP + tid], b[kb * SB + j], acc);  // Linv[j][c] = 0 for j < c
+            b[kb * SB + tid] = acc;  // (in place: see the panel)
         }
         __syncthreads();
         // b_J -= L_{kb,J}^T x_kb for every block column J < kb: one entry per thread
