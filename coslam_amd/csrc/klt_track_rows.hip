@@ -138,6 +138,20 @@ __device__ __forceinline__ void sample_p(const cs_texel* patch, int rx0, int ry0
 // bit-identical results, ~20 % fewer vector instructions per window pixel.
 typedef float cs_f2 __attribute__((ext_vector_type(2)));
 
+// w * (binary16 half of a packed texel word) in ONE instruction: v_fma_mix_f32 reads the half directly (op_sel_hi marks the
+// source as f16, op_sel picks the upper half) and the addend neg(0) = -0.0 leaves the correctly rounded product, sign of zero
+// included -- the same bits as v_cvt_f32_f16 + v_mul_f32, one instruction instead of two.
+__device__ __forceinline__ float mixmul_lo(float w, unsigned packed) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, neg(0) op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(packed));
+    return r;
+}
+__device__ __forceinline__ float mixmul_hi(float w, unsigned packed) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, neg(0) op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(w), "v"(packed));
+    return r;
+}
+
 template <int R>
 __device__ __forceinline__ void sample_p2(const cs_texel* patch, int rx0, int ry0, int Wl, int Hl, float s, float t, float& I,
                                           cs_f2& G) {
@@ -151,14 +165,11 @@ __device__ __forceinline__ void sample_p2(const cs_texel* patch, int rx0, int ry
     cs_texel t00 = c[0], t10 = c[1], t01 = c[R], t11 = c[R + 1];
     const cs_f2 wa = {1.0f - a, a};
     const cs_f2 w0 = wa * (1.0f - b), w1 = wa * b;  // (w00, w10), (w01, w11)
-    float I00, X00, Y00, I10, X10, Y10, I01, X01, Y01, I11, X11, Y11;
-    cs_unpack_texel(t00, I00, X00, Y00);
-    cs_unpack_texel(t10, I10, X10, Y10);
-    cs_unpack_texel(t01, I01, X01, Y01);
-    cs_unpack_texel(t11, I11, X11, Y11);
-    const cs_f2 p0 = w0 * (cs_f2){I00, I10}, p1 = w1 * (cs_f2){I01, I11};
-    I = ((p0.x + p0.y) + p1.x) + p1.y;
-    G = ((w0.x * (cs_f2){X00, Y00} + w0.y * (cs_f2){X10, Y10}) + w1.x * (cs_f2){X01, Y01}) + w1.y * (cs_f2){X11, Y11};
+    // texel word x = I | Ix << 16, word y = Iy: the twelve weight x channel products straight off the packed halves
+    I = ((mixmul_lo(w0.x, t00.x) + mixmul_lo(w0.y, t10.x)) + mixmul_lo(w1.x, t01.x)) + mixmul_lo(w1.y, t11.x);
+    const cs_f2 g00 = {mixmul_hi(w0.x, t00.x), mixmul_lo(w0.x, t00.y)}, g10 = {mixmul_hi(w0.y, t10.x), mixmul_lo(w0.y, t10.y)};
+    const cs_f2 g01 = {mixmul_hi(w1.x, t01.x), mixmul_lo(w1.x, t01.y)}, g11 = {mixmul_hi(w1.y, t11.x), mixmul_lo(w1.y, t11.y)};
+    G = ((g00 + g10) + g01) + g11;
 }
 
 // one Gauss-Newton pass worth of window sums for this lane's row (all zero for an inactive lane)
