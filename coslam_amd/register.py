@@ -19,7 +19,10 @@ class RegisterCam(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("K", "R", "t", "xy", "state", "slot2map", "isDynamic")]
 
 
-def _cams(cams):
+def register_cams(cams):
+    """list of dicts of pointers (ints) with the field names of cs_register_cam -> the ctypes array (build once)"""
+    if isinstance(cams, C.Array):
+        return cams
     arr = (RegisterCam * len(cams))()
     for a, c in zip(arr, cams):
         for n, _ in RegisterCam._fields_:
@@ -32,7 +35,7 @@ def register_search_dev(stream_ptr, cams, N, W, H, P, d_M, d_cov, d_pointFeat, s
                         d_var, d_dist, d_flags, device=0):
     """cams: list of dicts of DEVICE pointers (ints) with the field names of cs_register_cam; outputs P x nCams tables."""
     vp = C.c_void_p
-    check(lib().cs_register_search_dev(int(device), vp(stream_ptr), len(cams), _cams(cams), int(N), int(W), int(H), int(P),
+    check(lib().cs_register_search_dev(int(device), vp(stream_ptr), len(cams), register_cams(cams), int(N), int(W), int(H), int(P),
                                        vp(d_M), vp(d_cov), vp(d_pointFeat), C.c_double(sigmaSearch), C.c_double(maxDist),
                                        C.c_double(sigmaMerge), vp(d_slot), vp(d_m), vp(d_var), vp(d_dist), vp(d_flags)),
           "cs_register_search_dev")
@@ -68,7 +71,7 @@ def register_search(W, H, Ks, Rs, ts, xy, state, slot2map, isDynamic, Ms, covs, 
     dist = np.zeros((P, nC))
     flags = np.zeros((P, nC), dtype=np.int32)
     vp = C.c_void_p
-    check(lib().cs_register_search(int(device), nC, _cams(cams), int(N), int(W), int(H), int(P), vp(Ms.ctypes.data),
+    check(lib().cs_register_search(int(device), nC, register_cams(cams), int(N), int(W), int(H), int(P), vp(Ms.ctypes.data),
                                    vp(covs.ctypes.data), vp(pf.ctypes.data), C.c_double(sigmaSearch), C.c_double(maxDist),
                                    C.c_double(sigmaMerge), vp(slot.ctypes.data), vp(m.ctypes.data), vp(var.ctypes.data),
                                    vp(dist.ctypes.data), vp(flags.ctypes.data)), "cs_register_search")
