@@ -72,6 +72,11 @@ struct BaDev {
     int maxObsPerPoint;       // largest measurement count of a point (computed at upload)
     double* scal;             // [4] cost / point-step / flags-changed / outlier-count partials (distributed solve)
     double* schurPart;  // [nPairs][nSlices][72] partial Schur blocks (orders <= 36)
+    // camera-pair lists (built at upload when they are small enough, else null): for cameras ca <= cb the measurements
+    // {oa, ob, point} of the points both see (ca == cb: every measurement of the camera), pair index
+    // ca C - ca (ca - 1) / 2 + (cb - ca)
+    const int* pairPtr;
+    const int4* pairEnt;
     double maxErr;
     int innerMaxIter;
 };
@@ -430,6 +435,100 @@ __global__ __launch_bounds__(256) void k_schur(BaDev D) {
             const int r = q / 6, c = q - 6 * r;
             if (diag) {
                 // U_j entry (upper-triangular rank of (min,max)) + lambda on the diagonal - Schur sum
+                const int rr = r < c ? r : c, cc = r < c ? c : r;
+                const int uq = rr * 6 - (rr * (rr - 1)) / 2 + (cc - rr);
+                const double uv = ((redU[0][uq] + redU[1][uq]) + redU[2][uq]) + redU[3][uq];
+                D.S[(size_t)(6 * ja + r) * n + 6 * ja + c] = (uv + ((r == c && D.addLambda) ? D.st->lambda : 0.0)) - s;
+            } else {
+                D.S[(size_t)(6 * ja + r) * n + 6 * jb + c] = -s;
+                D.S[(size_t)(6 * jb + c) * n + 6 * ja + r] = -s;
+            }
+        } else if (diag) {
+            const int r = q - 36;
+            const double gv = ((redU[0][21 + r] + redU[1][21 + r]) + redU[2][21 + r]) + redU[3][21 + r];
+            D.rhs[6 * ja + r] = gv - s;
+        }
+    }
+}
+
+// ---- the same reduced system from the camera-pair lists built at upload ------------------------------------------------
+// One workgroup per pair of free cameras; a thread takes entries {oa, ob, point} of the pair's list -- ONE load instead of
+// k_schur's chain of three, and every entry is a hit.  Nothing else has to be tested: k_linearize leaves W = 0 for a
+// measurement that is an outlier, belongs to a fixed camera or to a point that is held, Jc = e = 0 for an outlier and
+// V^-1 = 0 for a held point, so those entries add zeros; only another rank's points (not linearised here: stale) are skipped.
+__global__ __launch_bounds__(256) void k_schur_pairs(BaDev D) {
+    CS_BA_SETPRIO();
+    if (!BA_ACTIVE(D)) return;
+    __shared__ double red[4][42];
+    __shared__ double redU[4][27];
+    int pair = blockIdx.x, ja = 0;
+    while (pair >= D.nc - ja) {
+        pair -= D.nc - ja;
+        ++ja;
+    }
+    const int jb = ja + pair;
+    const int ca = ja + D.nCamsCon, cb = jb + D.nCamsCon;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool diag = (ja == jb);
+    const size_t pid = (size_t)ca * D.C - (size_t)ca * (ca - 1) / 2 + (size_t)(cb - ca);
+    const int eBeg = D.pairPtr[pid], eEnd = D.pairPtr[pid + 1];
+    double u[27], acc[42];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) u[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 42; ++q) acc[q] = 0;
+    for (int en = eBeg + (int)threadIdx.x; en < eEnd; en += 256) {
+        const int4 E = D.pairEnt[en];
+        const int oa = E.x, ob = E.y, ip = E.z;
+        if (ip < D.pLo || ip >= D.pHi) continue;  // another rank's point
+        if (diag) {  // U_j, g_j: every measurement of the camera (outliers carry Jc = e = 0), fixed points included
+            const double* J = D.Jc + 12 * (size_t)oa;
+            const double e0 = D.e[2 * (size_t)oa], e1 = D.e[2 * (size_t)oa + 1];
+            int q = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = r; c < 6; ++c) u[q++] += J[r] * J[c] + J[6 + r] * J[6 + c];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) u[21 + r] += J[r] * e0 + J[6 + r] * e1;
+        }
+        const double* Wa = D.W + 18 * (size_t)oa;
+        const double* Wb = D.W + 18 * (size_t)ob;
+        const double* Vi = D.Vinv + 9 * (size_t)ip;
+        double Y[18];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Y[3 * r + c] = Wa[3 * r] * Vi[c] + Wa[3 * r + 1] * Vi[3 + c] + Wa[3 * r + 2] * Vi[6 + c];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                acc[6 * r + c] += Y[3 * r] * Wb[3 * c] + Y[3 * r + 1] * Wb[3 * c + 1] + Y[3 * r + 2] * Wb[3 * c + 2];
+        if (diag) {
+            const double* g = D.gp + 3 * (size_t)ip;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[36 + r] += Y[3 * r] * g[0] + Y[3 * r + 1] * g[1] + Y[3 * r + 2] * g[2];
+        }
+    }
+    if (diag) {
+        cs_reduce_many<27>(u, lane);
+        const int q = cs_reduce_index<27>(lane);
+        if (q >= 0) redU[wv][q] = u[0];
+    }
+    {
+        cs_reduce_many<42>(acc, lane);
+        const int q = cs_reduce_index<42>(lane);
+        if (q >= 0) red[wv][q] = acc[0];
+    }
+    __syncthreads();
+    if (threadIdx.x < 42) {
+        const int q = threadIdx.x;
+        const double s = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
+        const int n = D.n;
+        if (q < 36) {
+            const int r = q / 6, c = q - 6 * r;
+            if (diag) {
                 const int rr = r < c ? r : c, cc = r < c ? c : r;
                 const int uq = rr * 6 - (rr * (rr - 1)) / 2 + (cc - rr);
                 const double uv = ((redU[0][uq] + redU[1][uq]) + redU[2][uq]) + redU[3][uq];
@@ -2101,6 +2200,10 @@ struct cs_ba {
     unsigned char* slab;  // ONE device allocation behind every workspace array (few TLB entries for the whole solve)
     int nCostBlocks;
     int maxObs;  // largest measurement count of a point of the uploaded problem
+    int* pairPtr;     // camera-pair lists of the uploaded problem (own allocations: sized by the topology, not by C / P / nObs)
+    int4* pairEnt;
+    size_t pairPtrCap, pairEntCap;
+    bool havePairs;
     // cached executable graph of one full solve (cs_ba_solve_dev): ~150 launches become one
     struct GraphKey {
         int C, P, nObs, nCamsCon, nPtsCon, maxIter, innerMaxIter;
@@ -2122,6 +2225,12 @@ static int ba_free(cs_ba* b) {
     ba_drop_graph(b);
     delete b->dist;
     b->dist = nullptr;
+    if (b->pairPtr) (void)hipFree(b->pairPtr);
+    if (b->pairEnt) (void)hipFree(b->pairEnt);
+    b->pairPtr = nullptr;
+    b->pairEnt = nullptr;
+    b->pairPtrCap = b->pairEntCap = 0;
+    b->havePairs = false;
     if (b->slab) (void)hipFree(b->slab);
     if (b->h_io) (void)hipHostFree(b->h_io);
     if (b->h_ob) (void)hipHostFree(b->h_ob);
@@ -2254,6 +2363,8 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
     D.cam_ptr = b->cam_ptr;
     D.cam_obs = b->cam_obs;
     D.obs_of = b->obs_of;
+    D.pairPtr = b->havePairs ? b->pairPtr : nullptr;
+    D.pairEnt = b->havePairs ? b->pairEnt : nullptr;
     D.obs_xy = b->obs_xy;
     D.outlier = b->outlier;
     D.Jc = b->Jc;
@@ -2359,7 +2470,10 @@ static void ba_enqueue_lin_schur(hipStream_t stream, const BaPlan& L) {
         if (L.sliced)
             hipLaunchKernelGGL(k_schur_part, dim3(L.nPairs * D.nSlices), dim3(64), 0, stream, D);
         else
-            hipLaunchKernelGGL(k_schur, dim3(L.nPairs), blk, 0, stream, D);
+            if (D.pairPtr)
+                hipLaunchKernelGGL(k_schur_pairs, dim3(L.nPairs), blk, 0, stream, D);
+            else
+                hipLaunchKernelGGL(k_schur, dim3(L.nPairs), blk, 0, stream, D);
     }
 }
 
@@ -2782,6 +2896,54 @@ int cs_ba_robust_h(cs_ba* b, int C, int P, int nObs, const double* Ks, double* R
         memcpy(b->h_io + L.ocam, obs_cam, sizeof(int) * nObs);
     }
     hipStream_t s = b->own_stream;
+    // Camera-pair lists for k_schur_pairs: which measurements meet in which block of the reduced system is fixed by the
+    // topology, so the kernel's index chain (camera list -> point -> partner measurement, three dependent loads per entry,
+    // four in five of them misses) is walked once here instead of once per LM step.  sum_i k_i (k_i + 1) / 2 entries: 152 k
+    // for the 8-camera rig's joint local BA; not built beyond 4 M entries (cfg5: 36 M), where k_schur's walk is used.
+    b->havePairs = false;
+    {
+        size_t total = 0;
+        for (int i = 0; i < P; ++i) {
+            const size_t k = (size_t)(obs_ptr[i + 1] - obs_ptr[i]);
+            total += k * (k + 1) / 2;
+        }
+        static const bool noPairs = getenv("COSLAM_BA_PAIR_LISTS") && getenv("COSLAM_BA_PAIR_LISTS")[0] == '0';  // A/B
+        // Only on the upload path (cs_ba_upload: maxIter == 0), i.e. for callers that solve the same topology repeatedly
+        // from device memory; a one-shot host call would pay ~1 ms of list building to save ~0.25 ms of LM steps.
+        if (!noPairs && maxIter == 0 && total > 0 && total <= ((size_t)4 << 20) && C <= 1024) {
+            const size_t nPairsAll = (size_t)C * (C + 1) / 2;
+            auto pid = [C](int ca, int cb) { return (size_t)ca * C - (size_t)ca * (ca - 1) / 2 + (size_t)(cb - ca); };
+            std::vector<int> ptr(nPairsAll + 1, 0);
+            for (int i = 0; i < P; ++i)
+                for (int o1 = obs_ptr[i]; o1 < obs_ptr[i + 1]; ++o1)
+                    for (int o2 = obs_ptr[i]; o2 < obs_ptr[i + 1]; ++o2)
+                        if (obs_cam[o1] <= obs_cam[o2] && (obs_cam[o1] != obs_cam[o2] || o1 == o2)) ptr[pid(obs_cam[o1], obs_cam[o2]) + 1]++;
+            for (size_t q = 0; q < nPairsAll; ++q) ptr[q + 1] += ptr[q];
+            std::vector<int4> ent((size_t)ptr[nPairsAll]);
+            std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+            for (int i = 0; i < P; ++i)  // ascending point index inside every list, like the walk it replaces
+                for (int o1 = obs_ptr[i]; o1 < obs_ptr[i + 1]; ++o1)
+                    for (int o2 = obs_ptr[i]; o2 < obs_ptr[i + 1]; ++o2)
+                        if (obs_cam[o1] <= obs_cam[o2] && (obs_cam[o1] != obs_cam[o2] || o1 == o2))
+                            ent[(size_t)fill[pid(obs_cam[o1], obs_cam[o2])]++] = make_int4(o1, o2, i, 0);
+            if (ptr.size() > b->pairPtrCap) {
+                if (b->pairPtr) (void)hipFree(b->pairPtr);
+                b->pairPtr = nullptr;
+                CS_HIP(hipMalloc((void**)&b->pairPtr, sizeof(int) * ptr.size()));
+                b->pairPtrCap = ptr.size();
+            }
+            if (ent.size() > b->pairEntCap) {
+                if (b->pairEnt) (void)hipFree(b->pairEnt);
+                b->pairEnt = nullptr;
+                CS_HIP(hipMalloc((void**)&b->pairEnt, sizeof(int4) * ent.size()));
+                b->pairEntCap = ent.size();
+            }
+            CS_HIP(hipMemcpyAsync(b->pairPtr, ptr.data(), sizeof(int) * ptr.size(), hipMemcpyHostToDevice, s));
+            CS_HIP(hipMemcpyAsync(b->pairEnt, ent.data(), sizeof(int4) * ent.size(), hipMemcpyHostToDevice, s));
+            CS_HIP(hipStreamSynchronize(s));  // (the vectors go out of scope)
+            b->havePairs = true;
+        }
+    }
     CS_HIP(hipMemcpyAsync(b->io, b->h_io, L.total, hipMemcpyHostToDevice, s));  // the whole problem in one copy
     rc = ba_enqueue(b, s, C, P, nObs, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter);
     if (rc) return rc;
