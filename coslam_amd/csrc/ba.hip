@@ -458,6 +458,9 @@ __global__ __launch_bounds__(256) void k_schur(BaDev D) {
 // V^-1 = 0 for a held point, so those entries add zeros; only another rank's points (not linearised here: stale) are skipped.
 __global__ __launch_bounds__(256) void k_schur_pairs(BaDev D) {
     CS_BA_SETPRIO();
+#ifdef CS_SCHUR_PROBE
+    const unsigned long long p0 = __builtin_amdgcn_s_memtime();
+#endif
     if (!BA_ACTIVE(D)) return;
     __shared__ double red[4][42];
     __shared__ double redU[4][27];
@@ -511,6 +514,10 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BaDev D) {
             for (int r = 0; r < 6; ++r) acc[36 + r] += Y[3 * r] * g[0] + Y[3 * r + 1] * g[1] + Y[3 * r + 2] * g[2];
         }
     }
+#ifdef CS_SCHUR_PROBE
+    asm volatile("" : "+v"(acc[0]));
+    const unsigned long long p1 = __builtin_amdgcn_s_memtime();
+#endif
     if (diag) {
         cs_reduce_many<27>(u, lane);
         const int q = cs_reduce_index<27>(lane);
@@ -521,7 +528,14 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BaDev D) {
         const int q = cs_reduce_index<42>(lane);
         if (q >= 0) red[wv][q] = acc[0];
     }
+#ifdef CS_SCHUR_PROBE
+    const unsigned long long p2 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
+#ifdef CS_SCHUR_PROBE
+    if (threadIdx.x == 0 && (diag ? ja < 3 : blockIdx.x == 7) && D.st->nIterTotal == 3)
+        printf("k_schur_pairs block %d diag %d (%d entries): state+loop %llu reduce %llu\n", (int)blockIdx.x, (int)diag, eEnd - eBeg, p1 - p0, p2 - p1);
+#endif
     if (threadIdx.x < 42) {
         const int q = threadIdx.x;
         const double s = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
