@@ -477,6 +477,9 @@ def main():
     last = (args.warmup + args.steps) & 1
     n_live = [int((d.cpu().numpy().view(coslam_amd.KLT_TrackedFeature)["status"] >= 0).sum()) for d in d_dests[last]]
     pose_ok = d_ok.cpu().numpy().tolist()
+    from coslam_amd.pose import IntraCamPoseOption
+    _opts = [IntraCamPoseOption.from_buffer_copy(d_opt[i].cpu().numpy().tobytes()) for i in range(nc)]
+    pose_iters = [[o.nIterRW, o.nIterLM] for o in _opts]     # re-weighting rounds, LM steps of the last round (last frame)
     pose_npts = d_npts.cpu().numpy().tolist()
     # how far the device-resident poses are from the synthetic ground truth of the last frame (data-coupled pose leg)
     f_last = order[(args.warmup + args.steps) % len(order)]
@@ -585,7 +588,7 @@ def main():
                                    "sigma 6, 3 x 40; N>1: cameras sharded 8/N per GPU, all-gather of features+pose per "
                                    "frame, joint BA sliced by points with an all-reduce per LM step",
                        "cameras": N_CAMS, "cameras_per_gpu": nc, "camera_frames_per_s": N_CAMS * args.steps / dt,
-                       "live_features_last_frame": n_live, "pose_ok": pose_ok, "pose_correspondences": pose_npts,
+                       "live_features_last_frame": n_live, "pose_ok": pose_ok, "pose_correspondences": pose_npts, "pose_rounds_and_last_lm_steps": pose_iters,
                        "pose_translation_error_vs_truth": pose_err,
                        "joint_ba_last": None if st_j is None else {"lm_steps": st_j.nIterTotal, "outliers": st_j.nOutliers,
                                                                   "cost0": st_j.cost0, "cost": st_j.cost},
