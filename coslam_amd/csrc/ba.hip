@@ -1003,12 +1003,6 @@ __host__ __device__ constexpr size_t sb_lds_bytes(int n) {
     return sizeof(double) * ((size_t)(NB * (NB + 1) / 2) * SBLK + (size_t)NB * SB) + 16;
 }
 
-__device__ __forceinline__ double sb_rdlane(double v, int l) {
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
 // f64 DPP (gfx90a+ "DP ALU DPP": VOP1 / VOP2 f64 ops take row_newbcast:k -- every lane of a 16-lane row reads lane k of
 // its row).  v_fmac_f64_dpp folds the broadcast into the multiply-add: ONE instruction where v_readlane needs two scalar
 // reads, their hazards and the fma.  The leading s_nop 1 covers the VALU-write -> DPP-read hazard (2 wait states); the
@@ -1105,34 +1099,6 @@ __device__ __forceinline__ bool sb_factor_diag(double* Dk, int lane) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) Dk[row * SP + 4 * g + j] = x[j];
     return !bad;
-}
-
-// one 4 x 4 tile of  A[I][J] -= P_I P_J^T  (tile (tr, tc) of the 16 x 16 block)
-__device__ __forceinline__ void sb_tile_update(double* A, int I, int J, int kb, int tr, int tc) {
-    const double* PI = A + sb_off(I, kb) + (4 * tr) * SP;
-    const double* PJ = A + sb_off(J, kb) + (4 * tc) * SP;
-    double acc[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
-#pragma unroll
-    for (int k = 0; k < SB; k += 2) {
-        double2 pa[4], pb[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pa[r] = *(const double2*)(PI + r * SP + k);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) pb[c] = *(const double2*)(PJ + c * SP + k);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] = fma(pa[r].y, pb[c].y, fma(pa[r].x, pb[c].x, acc[r][c]));
-    }
-    double* T = A + sb_off(I, J) + (4 * tr) * SP + 4 * tc;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) T[r * SP + c] -= acc[r][c];
 }
 
 // One whole 16 x 16 block  A[I][J] -= P_I P_J^T  by ONE wave on the matrix cores: four v_mfma_f64_16x16x4f64.  The f64 matrix
