@@ -25,7 +25,7 @@ _frames = {}
 def frames_of(cam):
     if cam not in _frames:
         sc = Scene(8, W, H, 7000, seed=0xC051A + 4, sigma=1.0)
-        _frames[cam] = torch.from_numpy(np.stack([sc.render(cam, f) for f in range(NF)])).to(dev)
+        _frames[cam] = torch.from_numpy(np.stack([sc.render(cam % 8, f) for f in range(NF)])).to(dev)   # (cameras >= 8 reuse views)
     return _frames[cam]
 
 
@@ -102,7 +102,7 @@ def probe_report(n):
 
 if __name__ == "__main__":
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
-    for n in ((1, 8) if quick else (1, 2, 4, 8)):
+    for n in ((1, 8) if quick else (1, 2, 4, 8, 12, 16)):   # beyond the co-residency capacity the span is tracked in two launches
         run(n)
     if not quick:
         run(8, prefetch=False)
