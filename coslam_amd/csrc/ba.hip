@@ -343,12 +343,19 @@ __global__ __launch_bounds__(256) void k_schur(BaDev D) {
     __shared__ double red[4][42];
     __shared__ double redU[4][27];
     // decode the pair from the linear block index over the upper triangle
-    int pair = blockIdx.x, ja = 0;
-    while (pair >= D.nc - ja) {
-        pair -= D.nc - ja;
-        ++ja;
+    // the diagonal pairs first: they carry the longest lists (+ U_j, g_j), so they must not be the launch's last workgroups
+    int ja, jb;
+    if ((int)blockIdx.x < D.nc) {
+        ja = jb = blockIdx.x;
+    } else {
+        int pair = blockIdx.x - D.nc;
+        ja = 0;
+        while (pair >= D.nc - 1 - ja) {
+            pair -= D.nc - 1 - ja;
+            ++ja;
+        }
+        jb = ja + 1 + pair;
     }
-    const int jb = ja + pair;
     const int ca = ja + D.nCamsCon, cb = jb + D.nCamsCon;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool diag = (ja == jb);
@@ -464,12 +471,19 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BaDev D) {
     if (!BA_ACTIVE(D)) return;
     __shared__ double red[4][42];
     __shared__ double redU[4][27];
-    int pair = blockIdx.x, ja = 0;
-    while (pair >= D.nc - ja) {
-        pair -= D.nc - ja;
-        ++ja;
+    // the diagonal pairs first: they carry the longest lists (+ U_j, g_j), so they must not be the launch's last workgroups
+    int ja, jb;
+    if ((int)blockIdx.x < D.nc) {
+        ja = jb = blockIdx.x;
+    } else {
+        int pair = blockIdx.x - D.nc;
+        ja = 0;
+        while (pair >= D.nc - 1 - ja) {
+            pair -= D.nc - 1 - ja;
+            ++ja;
+        }
+        jb = ja + 1 + pair;
     }
-    const int jb = ja + pair;
     const int ca = ja + D.nCamsCon, cb = jb + D.nCamsCon;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const bool diag = (ja == jb);
