@@ -23,6 +23,7 @@ HIP_SOURCES = [
     "handback.hip",
     "register.hip",
     "ncc.hip",
+    "posegraph.hip",
     "ba.hip",
     "comm.hip",
 ]

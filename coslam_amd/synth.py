@@ -293,3 +293,63 @@ def make_intercam_problem(scene, frame=10, n_static=192, n_dyn=60, noise=0.5, ro
     return dict(K=K, Ks=np.repeat(K[None], nc, 0), Rs_gt=Rs, ts_gt=ts, pts_gt=pts, Rs0=Rs0, ts0=ts0, pts0=pts0,
                 obs_cam=obs_cam, obs_pt=obs_pt, obs_xy=noisy, obs_xy_clean=obs_xy, is_outlier=is_out,
                 n_cams_con=0, n_pts_con=n_stat, n_static=n_stat, n_dynamic=len(pts) - n_stat)
+
+
+def make_pose_graphs(n_cams=8, n_frames=21, key_every=5, rot_adj=0.01, trans_adj=0.05, seed=0, loop_edges=0, loop_noise=0.01,
+                     free_tail=0):
+    """Camera pose graphs the way RobustBundleRTS::constructCameraGraphs / output() build them (reference
+    src/app/SL_CoSLAMRobustBA.cpp:182-229, 283-294): per camera a chain of n_frames poses, every key_every-th one a key frame
+    (fixed), edges = relative transform of consecutive poses BEFORE the adjustment, key poses then moved by a small rigid
+    correction (what a BA does).  loop_edges extra (i -> j) edges per camera with noisy relative transforms; free_tail frames
+    after the last key frame.  Returns dict(graphs=[(fixed, id1, id2)], nodeR0, nodeT0 (before), nodeR, nodeT (fixed nodes
+    adjusted), ge1, ge2 (edges' ends as flat node indices), node_ptr, edge_ptr)."""
+    rng = np.random.default_rng(seed)
+    graphs, R0, T0, R1, T1 = [], [], [], [], []
+    for _c in range(n_cams):
+        n = n_frames + free_tail
+        w = rng.uniform(-0.3, 0.3, 3)
+        p = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), 4 + rng.uniform(-1, 1)])
+        dw, dp = rng.uniform(-0.02, 0.02, 3), rng.uniform(-0.05, 0.05, 3)
+        fixed = np.zeros(n, dtype=np.uint8)
+        fixed[0:n_frames:key_every] = 1
+        for i in range(n):
+            R = rodrigues(w)
+            R0.append(R.reshape(9)), T0.append(p.copy())
+            if fixed[i]:
+                R1.append((rodrigues(rng.uniform(-rot_adj, rot_adj, 3)) @ R).reshape(9))
+                T1.append(p + rng.uniform(-trans_adj, trans_adj, 3))
+            else:
+                R1.append(R.reshape(9)), T1.append(p.copy())
+            dw += rng.uniform(-0.004, 0.004, 3)
+            dp += rng.uniform(-0.01, 0.01, 3)
+            w = w + dw
+            p = p + dp
+        id1 = list(range(n - 1))
+        id2 = list(range(1, n))
+        for _k in range(loop_edges):
+            a, b = rng.choice(n, 2, replace=False)
+            if abs(int(a) - int(b)) > 6:
+                b = int(a) + int(np.sign(int(b) - int(a))) * int(rng.integers(2, 6))
+            id1.append(int(a)), id2.append(int(b))
+        graphs.append((fixed, np.array(id1, np.int32), np.array(id2, np.int32)))
+    node_ptr = np.concatenate([[0], np.cumsum([len(g[0]) for g in graphs])]).astype(np.int32)
+    edge_ptr = np.concatenate([[0], np.cumsum([len(g[1]) for g in graphs])]).astype(np.int32)
+    base = np.repeat(node_ptr[:-1], np.diff(edge_ptr))
+    ge1 = np.concatenate([g[1] for g in graphs]) + base
+    ge2 = np.concatenate([g[2] for g in graphs]) + base
+    out = dict(graphs=graphs, nodeR0=np.array(R0), nodeT0=np.array(T0), nodeR=np.array(R1), nodeT=np.array(T1), ge1=ge1, ge2=ge2,
+               node_ptr=node_ptr, edge_ptr=edge_ptr)
+    # relative transforms of the chain edges follow from the poses; the loop edges get a measurement error on top
+    nchain = [n_frames + free_tail - 1] * n_cams
+    eR, eT = [], []
+    for e in range(len(ge1)):
+        Ra, Rb = out["nodeR0"][ge1[e]].reshape(3, 3), out["nodeR0"][ge2[e]].reshape(3, 3)
+        R = Rb @ Ra.T
+        t = out["nodeT0"][ge2[e]] - R @ out["nodeT0"][ge1[e]]
+        g = int(np.searchsorted(edge_ptr, e, side="right") - 1)
+        if e - edge_ptr[g] >= nchain[g]:
+            R = rodrigues(rng.uniform(-loop_noise, loop_noise, 3)) @ R
+            t = t + rng.uniform(-loop_noise, loop_noise, 3)
+        eR.append(R.reshape(9)), eT.append(t)
+    out["edgeR"], out["edgeT"] = np.array(eR), np.array(eT)
+    return out

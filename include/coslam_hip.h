@@ -280,6 +280,44 @@ int cs_register_search(int device, int nCams, const cs_register_cam* cams, int N
                        double* m, double* var, double* dist, int* flags);
 
 /* ------------------------------------------------------------------------------------------
+ * Pose-graph relaxation of the non-key frames after a bundle adjustment, all camera graphs in one launch
+ * ------------------------------------------------------------------------------------------
+ * Replaces GlobalPoseGraph::computeNewCameraRotations + computeNewCameraTranslations
+ * (src/slam/SL_GlobalPoseEstimation.cpp:52-219, 220-359) as RobustBundleRTS::updateNonKeyCameraPoses runs them per camera
+ * after every BA (src/app/SL_CoSLAMRobustBA.cpp:230-247): each edge (id1 -> id2, R, t) with a free end asks for
+ * R_2 = R R_1 and t_2 = R t_1 + t; the free nodes' poses are the least-squares solution with the fixed nodes (the key
+ * frames the BA just moved) held, rotations projected to the nearest orthogonal matrix.  include/shim/slam/
+ * coslam_posegraph.h carries the two member functions over this interface.
+ * Topology is given once (create): nGraphs graphs, graph g owns nodes [nodePtr[g], nodePtr[g+1]) and edges
+ * [edgePtr[g], edgePtr[g+1]) of the flat arrays; id1 / id2 are node indices LOCAL to the edge's graph (CamPoseEdge::id1,
+ * id2); fixed[i] != 0 is CamPoseNode::fixed.  Any topology is accepted (band width follows the node order; CoSLAM's
+ * chains give the minimum).  Edges with CamPoseEdge::uncertainScale are not supported (the shim refuses them).
+ * Values per call, row-major: nodeR [N][9], nodeT [N][3] (CamPoseNode::R, t), edgeR [E][9], edgeT [E][3] (CamPoseEdge::R, t)
+ * -> newR [N][9], newT [N][3] (CamPoseNode::newR, newt; fixed nodes are copied).  new* must not alias node*.
+ * A free node that no edge constrains makes its graph fail: cs_posegraph_status / the host form return CS_ERR_NUMERIC. */
+typedef struct cs_posegraph cs_posegraph;
+int cs_posegraph_create(int device, int nGraphs, const int* nodePtr, const int* edgePtr, const unsigned char* fixed,
+                        const int* id1, const int* id2, cs_posegraph** out);
+void cs_posegraph_destroy(cs_posegraph* g);
+int cs_posegraph_counts(const cs_posegraph* g, int* nNodes, int* nEdges, int* nComponents, int* maxHalfBandwidth);
+/* device pointers, asynchronous on hip_stream */
+int cs_posegraph_relax_dev(cs_posegraph* g, void* hip_stream, const double* d_nodeR, const double* d_nodeT,
+                           const double* d_edgeR, const double* d_edgeT, double* d_newR, double* d_newT);
+/* synchronises hip_stream and reads the last launch's verdict: CS_OK, or CS_ERR_NUMERIC with the failed graph */
+int cs_posegraph_status(cs_posegraph* g, void* hip_stream, int* nFailed, int* firstFailedGraph);
+/* host pointers: upload, one launch, read-back, status */
+int cs_posegraph_relax(cs_posegraph* g, const double* nodeR, const double* nodeT, const double* edgeR, const double* edgeT,
+                       double* newR, double* newT);
+/* the data movement around the solve, on the device: every edge's relative transform from the poses of its ends
+ * (constructCameraGraphs, src/app/SL_CoSLAMRobustBA.cpp:216-227: getRigidTransFromTo = R2 R1^T, t2 - R t1) -- run BEFORE
+ * the adjusted key poses are written -- and the scatter of n poses (d_R [n][9], d_t [n][3]) into nodes d_nodeIdx[n]
+ * (output(), :283-294: the BA's key poses into the fixed nodes; index < 0 = skip). */
+int cs_posegraph_edges_dev(cs_posegraph* g, void* hip_stream, const double* d_nodeR, const double* d_nodeT, double* d_edgeR,
+                           double* d_edgeT);
+int cs_posegraph_set_poses_dev(int device, void* hip_stream, int n, const int* d_nodeIdx, const double* d_R, const double* d_t,
+                               double* d_nodeR, double* d_nodeT);
+
+/* ------------------------------------------------------------------------------------------
  * Inter-camera NCC matching: blocks and the epipolar / NCC matrices of one camera pair
  * ------------------------------------------------------------------------------------------
  * Replaces NCCBlock::compute / computeScaled (src/slam/SL_NCCBlock.cpp:15-54), matchNCCBlock (:258-264) and getEpiNccMat

@@ -242,6 +242,45 @@ def ncc_epi_mat(F, x1, y1, blk1, abc1, valid1, x2, y2, blk2, abc2, valid2, epiMa
     return epi, ncc
 
 
+def posegraph_edges(nodeR, nodeT, id1, id2):
+    """opg_rigid_from_to for every edge (getRigidTransFromTo of the two ends' poses): returns (edgeR [E,9], edgeT [E,3])."""
+    L = lib()
+    nodeR = np.ascontiguousarray(nodeR, dtype=np.float64).reshape(-1, 9)
+    nodeT = np.ascontiguousarray(nodeT, dtype=np.float64).reshape(-1, 3)
+    E = len(id1)
+    eR, eT = np.zeros((E, 9)), np.zeros((E, 3))
+    for e in range(E):
+        i, j = int(id1[e]), int(id2[e])
+        L.opg_rigid_from_to(_p(nodeR[i]), _p(nodeT[i]), _p(nodeR[j]), _p(nodeT[j]), eR[e].ctypes.data_as(C.c_void_p),
+                            eT[e].ctypes.data_as(C.c_void_p))
+    return eR, eT
+
+
+def posegraph_relax(fixed, nodeR, nodeT, id1, id2, edgeR, edgeT):
+    """opg_relax on ONE graph: returns (rc, newR [N,9], newT [N,3])."""
+    L = lib()
+    L.opg_relax.restype = C.c_int
+    fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+    nodeR = np.ascontiguousarray(nodeR, dtype=np.float64).reshape(-1, 9)
+    nodeT = np.ascontiguousarray(nodeT, dtype=np.float64).reshape(-1, 3)
+    id1 = np.ascontiguousarray(id1, dtype=np.int32)
+    id2 = np.ascontiguousarray(id2, dtype=np.int32)
+    edgeR = np.ascontiguousarray(edgeR, dtype=np.float64).reshape(-1, 9)
+    edgeT = np.ascontiguousarray(edgeT, dtype=np.float64).reshape(-1, 3)
+    N, E = len(fixed), len(id1)
+    newR, newT = np.zeros((N, 9)), np.zeros((N, 3))
+    rc = L.opg_relax(N, E, _p(fixed), _p(nodeR), _p(nodeT), _p(id1), _p(id2), _p(edgeR), _p(edgeT), _p(newR), _p(newT))
+    return rc, newR, newT
+
+
+def approx_rotation(M):
+    """opg_approx_rotation: U V^T of the 3x3 M."""
+    M = np.ascontiguousarray(M, dtype=np.float64).reshape(9)
+    out = np.zeros(9)
+    lib().opg_approx_rotation(_p(M), _p(out))
+    return out.reshape(3, 3)
+
+
 def set_threshold_margin_buffer(buf):
     """buf: float32[N] preset to a large value (kept alive by the caller), or None to switch the diagnostic off."""
     lib().okl_set_threshold_margin_buffer(_p(buf) if buf is not None else None)

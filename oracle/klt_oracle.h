@@ -154,6 +154,12 @@ void onc_epi_ncc_mat(const double* F, int M, const double* x1, const double* y1,
                      const int* valid1, int N, const double* x2, const double* y2, const unsigned char* blk2, const double* abc2,
                      const int* valid2, double epiMax, double nccMin, double wNone, double* epiMat, double* nccMat);
 
+/* ---- pose-graph relaxation of the non-key frames after a BA restated (posegraph_oracle.c) ---- */
+void opg_rigid_from_to(const double R1[9], const double t1[3], const double R2[9], const double t2[3], double R[9], double t[3]);
+void opg_approx_rotation(const double R[9], double Rnew[9]);
+int opg_relax(int nNodes, int nEdges, const unsigned char* fixed, const double* nodeR, const double* nodeT, const int* id1,
+              const int* id2, const double* edgeR, const double* edgeT, double* newR, double* newT);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,4 +15,12 @@ public:
 void repErr(const char* fmt, ...);
 void warn(const char* fmt, ...);
 void logInfo(const char* fmt, ...);
+/* printf-style path formatting of the write / read helpers (src/slam/SL_GlobalPoseEstimation.cpp:1365) */
+#define GET_FMT_STR(fmtstr, buf) \
+    {                            \
+        va_list args;            \
+        va_start(args, fmtstr);  \
+        vsprintf(buf, fmtstr, args); \
+        va_end(args);            \
+    }
 #endif

@@ -1,6 +1,6 @@
 // ref_shim/ref_posegraph_standin.cpp -- GlobalPoseGraph (pose-graph relaxation of the non-key frames after a BA,
-// src/slam/SL_GlobalPoseEstimation.cpp:52-337) is SURVEY.md 8f-4: not built, and its source needs LibVisualSLAM's sparse
-// solver.  RobustBundleRTS holds GlobalPoseGraph members (src/app/SL_CoSLAMRobustBA.h:62), so creating one needs the
+// src/slam/SL_GlobalPoseEstimation.cpp:52-337) is SURVEY.md 8f-4; the drop-in drivers below do not need its solve
+// methods (ref_posegraph_test compiles the real source instead).  RobustBundleRTS holds GlobalPoseGraph members (src/app/SL_CoSLAMRobustBA.h:62), so creating one needs the
 // constructor / destructor; the solve methods are only reached from RobustBundleRTS::output(), which the drop-in test
 // does not drive -- they abort loudly if they ever are.  TEST INFRASTRUCTURE (see math/SL_Matrix.h).
 #include <cstdio>
@@ -25,9 +25,11 @@ void GlobalPoseGraph::reserve(int n, int e) {
     nMaxNodes = n;
     nMaxEdges = e;
 }
+#ifndef POSEGRAPH_METHODS_ELSEWHERE  // ref_posegraph_methods_test takes the two solve methods from include/shim/slam/coslam_posegraph.h
 static void not_built(const char* what) {
     fprintf(stderr, "GlobalPoseGraph::%s: pose-graph relaxation (SURVEY 8f-4) is not built\n", what);
     abort();
 }
 void GlobalPoseGraph::computeNewCameraRotations() { not_built("computeNewCameraRotations"); }
 void GlobalPoseGraph::computeNewCameraTranslations() { not_built("computeNewCameraTranslations"); }
+#endif

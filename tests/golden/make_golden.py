@@ -151,10 +151,49 @@ def ncc_case():
     return out
 
 
+def posegraph_case():
+    """the reference's own GlobalPoseGraph::computeNewCameraRotations / computeNewCameraTranslations on 9 graphs
+    (oracle/_ref/ref_posegraph_test golden, CPU).  Flat arrays: graph g owns nodes [node_ptr[g], node_ptr[g+1]) and edges
+    [edge_ptr[g], edge_ptr[g+1]); id1 / id2 are local to the graph."""
+    import struct
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_posegraph_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_posegraph_test missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "pg.bin")
+        subprocess.run([exe, "golden", path], check=True)
+        raw = open(path, "rb").read()
+    ng, _ = struct.unpack_from("ii", raw, 0)
+    o = 8
+    node_ptr, edge_ptr = [0], [0]
+    fixed, R, t, nR, nt, id1, id2, eR, eT = [], [], [], [], [], [], [], [], []
+    for _g in range(ng):
+        n, e = struct.unpack_from("ii", raw, o)
+        o += 8
+        for _i in range(n):
+            fixed.append(struct.unpack_from("i", raw, o)[0])
+            v = np.frombuffer(raw, np.float64, 24, o + 4)
+            o += 4 + 192
+            R.append(v[:9]), t.append(v[9:12]), nR.append(v[12:21]), nt.append(v[21:24])
+        for _k in range(e):
+            a, b = struct.unpack_from("ii", raw, o)
+            v = np.frombuffer(raw, np.float64, 12, o + 8)
+            o += 8 + 96
+            id1.append(a), id2.append(b), eR.append(v[:9]), eT.append(v[9:])
+        node_ptr.append(node_ptr[-1] + n), edge_ptr.append(edge_ptr[-1] + e)
+    assert o == len(raw)
+    return dict(node_ptr=np.array(node_ptr, np.int32), edge_ptr=np.array(edge_ptr, np.int32), fixed=np.array(fixed, np.uint8),
+                nodeR=np.array(R), nodeT=np.array(t), newR=np.array(nR), newT=np.array(nt), id1=np.array(id1, np.int32),
+                id2=np.array(id2, np.int32), edgeR=np.array(eR), edgeT=np.array(eT))
+
+
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -165,4 +204,6 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "register_golden.npz"), **register_case())
     if "ncc" in which:
         np.savez_compressed(os.path.join(HERE, "ncc_golden.npz"), **ncc_case())
+    if "posegraph" in which:
+        np.savez_compressed(os.path.join(HERE, "posegraph_golden.npz"), **posegraph_case())
     print("golden fixtures written")

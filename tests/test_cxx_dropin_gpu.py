@@ -11,6 +11,11 @@
                                        FeaturePoints lists built with the reference's classes, against cs_register_search.
 * oracle/_ref/ref_ncc_test             the REFERENCE'S OWN NCCBlock::computeScaled, matchNCCBlock (src/slam/SL_NCCBlock.cpp) and
                                        getEpiNccMat (src/slam/SL_FeatureMatching.cpp) against cs_ncc_match_between.
+* oracle/_ref/ref_posegraph_test       the REFERENCE'S OWN GlobalPoseGraph::computeNewCameraRotations / computeNewCameraTranslations
+                                       (src/slam/SL_GlobalPoseEstimation.cpp) against relaxPoseGraphs / cs_posegraph_* on graphs
+                                       built with the reference's classes; ref_posegraph_methods_test: the two member functions
+                                       taken from include/shim/slam/coslam_posegraph.h instead, checked against the golden file
+                                       the first binary writes on the CPU.
 The oracle/_ref binaries are built by oracle/Makefile where the reference tree exists (__graft_entry__.build()) and
 travel with the repo snapshot; the reference sources themselves are never copied."""
 import os
@@ -49,6 +54,18 @@ def test_reference_search_function_agrees_with_the_registration_kernel(hip):
 def test_reference_ncc_code_agrees_with_the_ncc_kernels(hip):
     out = _run(os.path.join(ROOT, "oracle", "_ref", "ref_ncc_test"), "equal the reference's bit for bit")
     print(out)
+
+
+def test_reference_posegraph_code_agrees_with_the_relaxation_kernel(hip, tmp_path):
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_posegraph_test")
+    out = _run(exe, "vs the reference's own methods")
+    print(out)
+    gold = str(tmp_path / "pg.bin")
+    subprocess.run([exe, "golden", gold], check=True, timeout=600)        # CPU: the reference's methods
+    m = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_posegraph_methods_test"), gold], capture_output=True, text=True,
+                       timeout=600)
+    assert m.returncode == 0 and "ref_posegraph_methods_test: OK" in m.stdout, m.stdout + m.stderr
+    print(m.stdout)
 
 
 def test_cxx_shims_link_and_run(hip):
