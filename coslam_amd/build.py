@@ -24,6 +24,7 @@ HIP_SOURCES = [
     "register.hip",
     "ncc.hip",
     "posegraph.hip",
+    "results.cpp",
     "ba.hip",
     "comm.hip",
 ]

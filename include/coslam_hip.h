@@ -318,6 +318,34 @@ int cs_posegraph_set_poses_dev(int device, void* hip_stream, int n, const int* d
                                double* d_nodeR, double* d_nodeT);
 
 /* ------------------------------------------------------------------------------------------
+ * Result text files of a run (host code, no device work)
+ * ------------------------------------------------------------------------------------------
+ * Replaces the body of CoSLAM::exportResultsVer1 (src/app/SL_CoSLAM.cpp:1914-2028) for a caller that holds its results as
+ * arrays: writes input_videos.txt, mappts.txt, <c>_campose.txt and <c>_featpts.txt into dirPath (created if missing), byte
+ * for byte what the reference's `ofstream <<` statements write.  The reference puts them in $HOME/slam_results/<time>/;
+ * the directory is the caller's choice here. */
+typedef struct cs_export_cam {
+    const char* videoFilePath;    /* SingleSLAM::videoFilePath */
+    const double* K;              /* 9 */
+    const double* kc;             /* 5: SingleSLAM::k_c */
+    int W, H;
+    int startFrameInVideo;        /* frames are written as startFrameInVideo + f + 1 (CoSLAM::getFrameInVideo) */
+    int nPoses;                   /* m_camPos.size(), >= 1 */
+    const int* poseFrame;         /* [nPoses] CamPoseItem::f, list order; poseFrame[0] = m_camPos.first()->f */
+    const double* poseR;          /* [nPoses][9] */
+    const double* poseT;          /* [nPoses][3] */
+    const int* featPtr;           /* [curFrame - poseFrame[0] + 2]: row r = frame poseFrame[0] + r owns entries
+                                     [featPtr[r], featPtr[r+1]) of the two arrays below */
+    const long long* featPointId; /* id of the (certain static) map point each feature point carries */
+    const double* featXY;         /* [n][2] FeaturePoint::x, y */
+} cs_export_cam;
+/* nPts static map points in the order they are to be listed (the reference: address order of the objects, the address
+ * being the id, :1862): ptId [nPts], ptM [nPts][3], ptCov [nPts][9].  covAsReference != 0: the 9 numbers of every point are
+ * ptCov[k][k], k = 0..8 -- what the reference's shadowed loop variable makes it write (:1965-1966); 0: each point's own 9. */
+int cs_export_results_v1(const char* dirPath, int nCams, const cs_export_cam* cams, int curFrame, int nPts, const long long* ptId,
+                         const double* ptM, const double* ptCov, int covAsReference);
+
+/* ------------------------------------------------------------------------------------------
  * Inter-camera NCC matching: blocks and the epipolar / NCC matrices of one camera pair
  * ------------------------------------------------------------------------------------------
  * Replaces NCCBlock::compute / computeScaled (src/slam/SL_NCCBlock.cpp:15-54), matchNCCBlock (:258-264) and getEpiNccMat

@@ -8,6 +8,7 @@ public:
     VideoReader() : _w(0), _h(0) {}
     virtual ~VideoReader() {}
     virtual void open(const char*) {}
+    virtual void open() {}
     virtual void grabFrame() {}
     virtual void readCurFrame(unsigned char*, unsigned char*) {}
     virtual void getCurGrayImage(unsigned char*) {}

@@ -3,4 +3,10 @@
 #define REF_SHIM_CVHELPER_H
 #include "matching/SL_Matching.h"
 #include "SL_error.h"
+#include <vector>
+/* the OpenCV key-point / match lists SL_InitMap.h holds as members (src/app/SL_InitMap.h:42,125-128): never touched */
+struct RefShimKeyPoint {};
+struct RefShimDMatch {};
+typedef std::vector<RefShimKeyPoint> KpVec;
+typedef std::vector<RefShimDMatch> DMatchVec;
 #endif

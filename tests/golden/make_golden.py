@@ -190,10 +190,52 @@ def posegraph_case():
                 id2=np.array(id2, np.int32), edgeR=np.array(eR), edgeT=np.array(eT))
 
 
+def export_case():
+    """the reference's own CoSLAM::exportResults (oracle/_ref/ref_export_test golden, CPU): the six files it writes and the
+    arrays cs_export_results_v1 needs to write them again.  Map point ids are the addresses of that run's objects."""
+    import struct
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_export_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_export_test missing: run `make -C oracle` where /root/reference exists")
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        subprocess.run([exe, "golden", td], check=True, stdout=subprocess.DEVNULL)
+        raw = open(os.path.join(td, "inputs.bin"), "rb").read()
+        for n in ("input_videos.txt", "mappts.txt", "0_campose.txt", "1_campose.txt", "0_featpts.txt", "1_featpts.txt"):
+            out["file_" + n] = np.frombuffer(open(os.path.join(td, "slam_results", "ref", n), "rb").read(), dtype=np.uint8).copy()
+    nC, cur, nP, _ = struct.unpack_from("iiii", raw, 0)
+    o = 16
+
+    def take(dt, n):
+        nonlocal o
+        v = np.frombuffer(raw, dtype=dt, count=n, offset=o).copy()
+        o += v.nbytes
+        return v
+
+    out.update(nCams=np.int32(nC), curFrame=np.int32(cur), ptId=take(np.int64, nP), ptM=take(np.float64, 3 * nP).reshape(nP, 3),
+               ptCov=take(np.float64, 9 * nP).reshape(nP, 9))
+    for c in range(nC):
+        pl = int(take(np.int32, 1)[0])
+        out[f"c{c}_path"] = take(np.uint8, pl)
+        W, H, start, nposes = take(np.int32, 4)
+        out[f"c{c}_whs"] = np.array([W, H, start], np.int32)
+        out[f"c{c}_K"], out[f"c{c}_kc"] = take(np.float64, 9), take(np.float64, 5)
+        out[f"c{c}_poseFrame"] = take(np.int32, nposes)
+        out[f"c{c}_poseR"], out[f"c{c}_poseT"] = take(np.float64, 9 * nposes).reshape(-1, 9), take(np.float64, 3 * nposes).reshape(-1, 3)
+        out[f"c{c}_featPtr"] = take(np.int32, int(take(np.int32, 1)[0]))
+        nf = int(take(np.int32, 1)[0])
+        out[f"c{c}_featId"], out[f"c{c}_featXY"] = take(np.int64, nf), take(np.float64, 2 * nf).reshape(-1, 2)
+    assert o == len(raw)
+    return out
+
+
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -206,4 +248,6 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "ncc_golden.npz"), **ncc_case())
     if "posegraph" in which:
         np.savez_compressed(os.path.join(HERE, "posegraph_golden.npz"), **posegraph_case())
+    if "export" in which:
+        np.savez_compressed(os.path.join(HERE, "export_golden.npz"), **export_case())
     print("golden fixtures written")

@@ -16,6 +16,8 @@
                                        built with the reference's classes; ref_posegraph_methods_test: the two member functions
                                        taken from include/shim/slam/coslam_posegraph.h instead, checked against the golden file
                                        the first binary writes on the CPU.
+* oracle/_ref/ref_export_test          the REFERENCE'S OWN CoSLAM::exportResultsVer1 (src/app/SL_CoSLAM.cpp) against
+                                       cs_export_results_v1: six text files, byte for byte.
 The oracle/_ref binaries are built by oracle/Makefile where the reference tree exists (__graft_entry__.build()) and
 travel with the repo snapshot; the reference sources themselves are never copied."""
 import os
@@ -66,6 +68,14 @@ def test_reference_posegraph_code_agrees_with_the_relaxation_kernel(hip, tmp_pat
                        timeout=600)
     assert m.returncode == 0 and "ref_posegraph_methods_test: OK" in m.stdout, m.stdout + m.stderr
     print(m.stdout)
+
+
+def test_reference_export_code_agrees_with_the_result_writer(hip, tmp_path):
+    """the reference's own CoSLAM::exportResults (src/app/SL_CoSLAM.cpp compiled in place) against cs_export_results_v1; host
+    code, also run by the CPU suite (tests/test_results_cpu.py)"""
+    out = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_export_test"), str(tmp_path)], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0 and "ref_export_test: OK" in out.stdout, out.stdout + out.stderr
 
 
 def test_cxx_shims_link_and_run(hip):
