@@ -109,6 +109,29 @@ def associate(sc, cam, frame, dest):
     return s2m
 
 
+def build_pose_graphs(sc, joint, cams, n_kf=5, kf_step=5):
+    """The camera graphs RobustBundleRTS::constructCameraGraphs builds for the joint BA's window (reference
+    src/app/SL_CoSLAMRobustBA.cpp:182-229): per camera the chain of frames from the first key frame of the window to the last,
+    key frames fixed.  Poses before the adjustment: the BA's initial estimate at the key frames, the tracked poses in
+    between.  Returns (graphs, nodeR, nodeT, camNode): camNode[j] = node of BA camera j (j = kf * numCams + c) or -1."""
+    n = (n_kf - 1) * kf_step + 1
+    graphs, R, T = [], [], []
+    camNode = np.full(len(joint["Rs0"]), -1, dtype=np.int32)
+    for gi, c in enumerate(cams):
+        fixed = np.zeros(n, dtype=np.uint8)
+        fixed[::kf_step] = 1
+        for f in range(n):
+            if f % kf_step == 0:
+                j = (f // kf_step) * sc.C + c
+                camNode[j] = gi * n + f
+                R.append(joint["Rs0"][j].reshape(9)), T.append(joint["ts0"][j])
+            else:
+                Rf, tf = sc.pose(c, f)
+                R.append(Rf.reshape(9)), T.append(tf)
+        graphs.append((fixed, np.arange(n - 1, dtype=np.int32), np.arange(1, n, dtype=np.int32)))
+    return graphs, np.array(R), np.array(T), camNode
+
+
 def reg_covariances():
     """MapPoint::cov of the 2 x P_REG registered points: synthetic SPD 3 x 3, a few cm"""
     rng = np.random.default_rng(SEED + 23)
@@ -116,7 +139,7 @@ def reg_covariances():
     return A @ A.transpose(0, 2, 1) + 1e-6 * np.eye(3)
 
 
-def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True):
+def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True, with_posegraph=True):
     """The oracle (C restatement of the reference's path: kind "port") on `n_threads` host cores: the cameras of a frame
     in parallel (the ctypes calls release the GIL), the key-frame solves on the calling thread."""
     import oracle
@@ -141,6 +164,10 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True)
     jptr, jcam, jxy = csr(joint)
     iptr, icam, ixy = csr(ic)
     kud = np.zeros(7)
+    pg_graphs, pg_R, pg_T, pg_cam = build_pose_graphs(sc, joint, range(N_CAMS))
+    npc = len(pg_graphs[0][0])
+    ends = np.concatenate([np.arange(npc - 1) + g * npc for g in range(len(pg_graphs))])
+    pg_eR, pg_eT = oracle.posegraph_edges(pg_R, pg_T, ends, ends + 1)
 
     def cam_step(c, f, frame_no):
         _, d = trk[c].redetect(frames[c][f])
@@ -185,8 +212,15 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True)
             for x in th:
                 x.join()
         if n % KEY_EVERY == 0:
-            oracle.ba_robust(joint["Ks"], joint["Rs0"], joint["ts0"], joint["pts0"], jptr, jcam, jxy,
-                             joint["n_cams_con"], joint["n_pts_con"], 6.0, 2, 10)
+            jR, jT = oracle.ba_robust(joint["Ks"], joint["Rs0"], joint["ts0"], joint["pts0"], jptr, jcam, jxy,
+                                      joint["n_cams_con"], joint["n_pts_con"], 6.0, 2, 10)[:2]
+            if with_posegraph:   # RobustBundleRTS::output(): the non-key frames follow the adjusted key frames
+                nR, nT = pg_R.copy(), pg_T.copy()
+                nR[pg_cam[pg_cam >= 0]], nT[pg_cam[pg_cam >= 0]] = jR.reshape(-1, 9)[pg_cam >= 0], jT[pg_cam >= 0]
+                npc = len(pg_graphs[0][0])
+                for g, (fx, a, b) in enumerate(pg_graphs):
+                    ns, es = slice(g * npc, (g + 1) * npc), slice(g * (npc - 1), (g + 1) * (npc - 1))
+                    oracle.posegraph_relax(fx, nR[ns], nT[ns], a, b, pg_eR[es], pg_eT[es])
             oracle.ba_robust(ic["Ks"], ic["Rs0"], ic["ts0"], ic["pts0"], iptr, icam, ixy, 0, ic["n_static"], 6.0, 3, 40)
         n += 1
         if time.perf_counter() - t_start > budget_s or n >= 200:
@@ -207,6 +241,7 @@ def main():
     ap.add_argument("--klt-cus", type=int, default=int(os.environ.get("BENCH_KLT_CUS", "0")),
                     help="tracker stream confined to the first N compute units (0 = whole chip): leaves CUs the persistent tracker "
                          "never occupies, where the BA's 1024-thread solver workgroup can start while the tracker runs")
+    ap.add_argument("--no-posegraph", action="store_true", help="diagnostic: skip the pose-graph relaxation behind the joint BA (not a valid bench line)")
     ap.add_argument("--no-register", action="store_true", help="diagnostic: skip the map-point registration search (not a valid bench line)")
     ap.add_argument("--native-comm", type=int, default=1, help="N > 1: collectives issued by libcoslam_hip (RCCL behind the C-ABI) instead of torch.distributed")
     args = ap.parse_args()
@@ -318,6 +353,28 @@ def main():
     d_jR = torch.from_numpy(joint["Rs0"].reshape(-1).copy()).to(dev)
     d_jT = torch.from_numpy(joint["ts0"].reshape(-1).copy()).to(dev)
     d_jM = torch.from_numpy(joint["pts0"].reshape(-1).copy()).to(dev)
+    # RobustBundleRTS::output() behind every joint BA: adjusted key poses into the fixed nodes of this rank's camera graphs,
+    # relaxation of the non-key frames -- installed as the workspace's follow-up (N = 1: the worker thread enqueues it behind
+    # the solve's last kernel) or enqueued behind the sliced solve (N > 1)
+    pg = None
+    if not args.no_posegraph:
+        from coslam_amd.posegraph import PoseGraphs, after_ba_function, after_ba_record, posegraph_set_poses_dev
+
+        pg_graphs, pg_R, pg_T, pg_cam = build_pose_graphs(sc, joint, my_cams)
+        pg = PoseGraphs(pg_graphs, device=local_rank)
+        d_pgR, d_pgT = torch.from_numpy(pg_R).to(dev), torch.from_numpy(pg_T).to(dev)
+        d_pgER = torch.zeros(pg.n_edges, 9, dtype=torch.float64, device=dev)
+        d_pgET = torch.zeros(pg.n_edges, 3, dtype=torch.float64, device=dev)
+        d_pgNR, d_pgNT = torch.zeros_like(d_pgR), torch.zeros_like(d_pgT)
+        d_pgCam = torch.from_numpy(pg_cam).to(dev)
+        s0 = torch.cuda.current_stream().cuda_stream
+        pg.edges_dev(s0, d_pgR.data_ptr(), d_pgT.data_ptr(), d_pgER.data_ptr(), d_pgET.data_ptr())   # constructCameraGraphs
+        torch.cuda.synchronize()
+        bR, bT, _ = ba_ws.result_buffers()
+        pg_rec = after_ba_record(pg, len(pg_cam), d_pgCam.data_ptr(), bR, bT, d_pgR.data_ptr(), d_pgT.data_ptr(), d_pgER.data_ptr(),
+                                 d_pgET.data_ptr(), d_pgNR.data_ptr(), d_pgNT.data_ptr(), device=local_rank)
+        if world == 1:
+            ba_ws.set_followup(after_ba_function(), C.addressof(pg_rec))
     iptr, icam, ixy = csr(ic)
     ic_ws = BAWorkspace(local_rank)
     ic_ws.upload(ic["Ks"], ic["Rs0"], ic["ts0"], ic["pts0"], iptr, icam, ixy)
@@ -409,6 +466,11 @@ def main():
                 ba_s.wait_event(pose_done)
                 multicam.bundle_adjust_sliced(ba_ws, ba_s, d_jR.data_ptr(), d_jT.data_ptr(), d_jM.data_ptr(),
                                               joint["n_cams_con"], joint["n_pts_con"], 6.0, 2, 10, local_rank, native=native)
+                if pg is not None:
+                    posegraph_set_poses_dev(ba_s.cuda_stream, len(pg_cam), d_pgCam.data_ptr(), bR, bT, d_pgR.data_ptr(),
+                                            d_pgT.data_ptr(), device=local_rank)
+                    pg.relax_dev(ba_s.cuda_stream, d_pgR.data_ptr(), d_pgT.data_ptr(), d_pgER.data_ptr(), d_pgET.data_ptr(),
+                                 d_pgNR.data_ptr(), d_pgNT.data_ptr())
             elif args.serial:
                 ba_ws.solve_dev(klt_s.cuda_stream, d_jR.data_ptr(), d_jT.data_ptr(), d_jM.data_ptr(), joint["n_cams_con"],
                                 joint["n_pts_con"], 6.0, 2, 10)
@@ -468,6 +530,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t_begin
     gc.enable()
+    pg_info = None
+    if pg is not None:
+        pg.status(ba_s.cuda_stream)      # raises if a graph failed
+        moved = (d_pgNT - d_pgT).abs().max().item()
+        pg_info = dict(pg.counts(), max_non_key_translation_change=moved)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -564,8 +631,8 @@ def main():
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
         nt = min(cores, N_CAMS)
-        v1, n1, dt1 = cpu_baseline(sc, frames, joint, ic, 1, 12.0, not args.no_register)
-        vN, nN, dtN = cpu_baseline(sc, frames, joint, ic, nt, 12.0, not args.no_register) if nt > 1 else (v1, n1, dt1)
+        v1, n1, dt1 = cpu_baseline(sc, frames, joint, ic, 1, 12.0, not args.no_register, not args.no_posegraph)
+        vN, nN, dtN = cpu_baseline(sc, frames, joint, ic, nt, 12.0, not args.no_register, not args.no_posegraph) if nt > 1 else (v1, n1, dt1)
         cpu = {"value": vN, "unit": "frames/s", "cores": nt, "kind": "port",
                "sample": f"{nN} frames of the same 8-camera workload on {nt} threads (cameras in parallel) in {dtN:.1f} s; "
                          f"{n1} frames on 1 thread in {dt1:.1f} s (oracle/: C restatement, gcc -O2); host has {cores} cores",
@@ -583,7 +650,9 @@ def main():
                                    "every frame (fed by the tracker's output); map-point registration search every frame "
                                    f"(active + current static, {P_REG} points each x 8 cams x 2000 slots); "
                                    f"every {KEY_EVERY}th frame: joint local BA "
-                                   f"C=40 (16 fixed) x {len(joint['pts0'])} pts x {len(joint['obs_cam'])} meas, maxIter 2 / inner 10, and "
+                                   f"C=40 (16 fixed) x {len(joint['pts0'])} pts x {len(joint['obs_cam'])} meas, maxIter 2 / inner 10"
+                                   + ("" if args.no_posegraph else ", followed on its stream by the pose-graph relaxation of the "
+                                      "window's non-key frames (21-frame chain per camera, 5 key frames fixed)") + ", and "
                                    f"inter-camera solve C=8 free, {ic['n_static']} static pts fixed + {ic['n_dynamic']} dynamic, "
                                    "sigma 6, 3 x 40; N>1: cameras sharded 8/N per GPU, all-gather of features+pose per "
                                    "frame, joint BA sliced by points with an all-reduce per LM step",
@@ -595,6 +664,7 @@ def main():
                        "intercam_last": {"lm_steps": st_i.nIterTotal, "outliers": st_i.nOutliers, "cost0": st_i.cost0,
                                          "cost": st_i.cost},
                        "frame_front_prefetch": bool(prefetch), "secondary_cfg2": cfg2,
+                       "posegraph_last": pg_info,
                        "register_candidates_last_frame": None if args.no_register else
                        {"active": int((reg_out[0]["slot"] >= 0).sum().item()), "current_static": int((reg_out[1]["slot"] >= 0).sum().item()),
                         "already_attached": int((reg_out[1]["slot"] == -1).sum().item())},

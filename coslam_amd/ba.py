@@ -97,6 +97,17 @@ class BAWorkspace:
     def wait(self):
         check(self._L.cs_ba_wait(self._h), "cs_ba_wait")
 
+    def result_buffers(self):
+        """device addresses (ints) of the workspace's current estimate: (Rs [C,9], Ts [C,3], pts [P,3])"""
+        r, t, m = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(self._L.cs_ba_result_buffers(self._h, C.byref(r), C.byref(t), C.byref(m)), "cs_ba_result_buffers")
+        return r.value, t.value, m.value
+
+    def set_followup(self, fn_ptr, user_ptr):
+        """cs_ba_set_followup: a NATIVE function (address, e.g. coslam_amd.posegraph.after_ba_function()) and its record's
+        address; enqueued behind every solve on the solve's stream.  The caller keeps the record alive.  (0, 0) removes it."""
+        check(self._L.cs_ba_set_followup(self._h, C.c_void_p(fn_ptr), C.c_void_p(user_ptr)), "cs_ba_set_followup")
+
     def download(self):
         Rs, Ts, pts = np.zeros((self.C, 9)), np.zeros((self.C, 3)), np.zeros((max(self.P, 1), 3))
         out = np.zeros(max(self.nObs, 1), dtype=np.int32)

@@ -2206,7 +2206,16 @@ struct cs_ba {
     } gkey;
     hipGraphExec_t gexec;
     struct BaWorker* worker;  // cs_ba_solve_async: the workspace's solver thread (the reference's BA thread)
+    cs_ba_followup_fn followup;  // cs_ba_set_followup: enqueued on the solve's stream right behind every solve
+    void* followupUser;
 };
+
+static int ba_run_followup(cs_ba* b, hipStream_t s) {
+    if (!b->followup) return CS_OK;
+    const int rc = b->followup((void*)s, b->followupUser);
+    if (rc != CS_OK) cs_set_error("cs_ba: the follow-up of the solve failed (%d): %s", rc, cs_last_error());
+    return rc;
+}
 
 static void ba_worker_drop_graphs(cs_ba* b);
 static void ba_drop_graph(cs_ba* b) {
@@ -2732,8 +2741,9 @@ static int ba_worker_run(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
         }
         slot ^= 1;
     }
+    rc = ba_run_followup(b, s);  // the finish segment is on the stream: RobustBundleRTS::output()'s non-key-frame update goes here
     CS_HIP(hipStreamSynchronize(s));
-    return CS_OK;
+    return rc;
 }
 
 static void ba_worker_main(cs_ba* b, BaWorker* w) {
@@ -3001,7 +3011,7 @@ int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const do
     cs_ba::GraphKey key = {C, P, nObs, nCamsCon, nPtsCon, maxIter, innerMaxIter, maxErr, d_Rs0, d_Ts0, d_pts0};
     if (useGraph && b->gexec && memcmp(&key, &b->gkey, sizeof(key)) == 0) {
         CS_HIP(hipGraphLaunch(b->gexec, s));
-        return CS_OK;
+        return ba_run_followup(b, s);
     }
     if (useGraph) {
         ba_drop_graph(b);
@@ -3010,7 +3020,7 @@ int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const do
     // the measurement tables were built when the problem was uploaded (cs_ba_upload -> cs_ba_robust_h); the initial
     // estimate is copied into the workspace by the solve's first kernel
     int rc = ba_enqueue(b, s, C, P, nObs, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter, false, d_Rs0, d_Ts0, d_pts0);
-    if (!useGraph) return rc;
+    if (!useGraph) return rc ? rc : ba_run_followup(b, s);
     hipGraph_t graph = nullptr;
     hipError_t e = hipStreamEndCapture(s, &graph);
     if (rc || e != hipSuccess) {
@@ -3028,6 +3038,28 @@ int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const do
     memset(&b->gkey, 0, sizeof(b->gkey));
     b->gkey = key;
     CS_HIP(hipGraphLaunch(b->gexec, s));
+    return ba_run_followup(b, s);
+}
+
+int cs_ba_set_followup(cs_ba* b, cs_ba_followup_fn fn, void* user) {
+    if (!b) {
+        cs_set_error("cs_ba_set_followup: null workspace");
+        return CS_ERR_INVALID;
+    }
+    const int rc = cs_ba_wait(b);  // no solve of the worker may be between its finish segment and the call
+    b->followup = fn;
+    b->followupUser = user;
+    return rc;
+}
+
+int cs_ba_result_buffers(cs_ba* b, double** d_Rs, double** d_Ts, double** d_pts) {
+    if (!b || !b->Rs) {
+        cs_set_error("cs_ba_result_buffers: workspace not uploaded");
+        return CS_ERR_INVALID;
+    }
+    if (d_Rs) *d_Rs = b->Rs;
+    if (d_Ts) *d_Ts = b->Ts;
+    if (d_pts) *d_pts = b->pts;
     return CS_OK;
 }
 

@@ -664,3 +664,14 @@ extern "C" int cs_posegraph_relax(cs_posegraph* g, const double* nodeR, const do
     memcpy(newT, h + inD + 9 * N, 3 * N * 8);
     return rc;
 }
+
+extern "C" int cs_posegraph_after_ba(void* hip_stream, void* rec) {
+    const cs_posegraph_after_ba_rec* r = (const cs_posegraph_after_ba_rec*)rec;
+    if (!r || !r->g) {
+        cs_set_error("cs_posegraph_after_ba: null record");
+        return CS_ERR_INVALID;
+    }
+    int rc = cs_posegraph_set_poses_dev(r->device, hip_stream, r->nCams, r->d_camNode, r->d_Rs, r->d_Ts, r->d_nodeR, r->d_nodeT);
+    if (rc == CS_OK) rc = cs_posegraph_relax_dev(r->g, hip_stream, r->d_nodeR, r->d_nodeT, r->d_edgeR, r->d_edgeT, r->d_newR, r->d_newT);
+    return rc;
+}

@@ -82,3 +82,21 @@ def posegraph_set_poses_dev(stream_ptr, n, d_nodeIdx, d_R, d_t, d_nodeR, d_nodeT
     vp = C.c_void_p
     check(lib().cs_posegraph_set_poses_dev(int(device), vp(stream_ptr), int(n), vp(d_nodeIdx), vp(d_R), vp(d_t), vp(d_nodeR),
                                            vp(d_nodeT)), "cs_posegraph_set_poses_dev")
+
+
+class AfterBARec(C.Structure):
+    """== cs_posegraph_after_ba_rec (include/coslam_hip.h)."""
+
+    _fields_ = [("g", C.c_void_p), ("device", C.c_int), ("nCams", C.c_int), ("d_camNode", C.c_void_p), ("d_Rs", C.c_void_p),
+                ("d_Ts", C.c_void_p), ("d_nodeR", C.c_void_p), ("d_nodeT", C.c_void_p), ("d_edgeR", C.c_void_p),
+                ("d_edgeT", C.c_void_p), ("d_newR", C.c_void_p), ("d_newT", C.c_void_p)]
+
+
+def after_ba_function():
+    """address of the native cs_posegraph_after_ba (for BAWorkspace.set_followup)"""
+    return C.cast(lib().cs_posegraph_after_ba, C.c_void_p).value
+
+
+def after_ba_record(graphs, n_cams, d_camNode, d_Rs, d_Ts, d_nodeR, d_nodeT, d_edgeR, d_edgeT, d_newR, d_newT, device=0):
+    """the record cs_posegraph_after_ba reads; keep it (and `graphs`) alive while it is installed"""
+    return AfterBARec(graphs._h, int(device), int(n_cams), d_camNode, d_Rs, d_Ts, d_nodeR, d_nodeT, d_edgeR, d_edgeT, d_newR, d_newT)

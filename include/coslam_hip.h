@@ -316,6 +316,26 @@ int cs_posegraph_edges_dev(cs_posegraph* g, void* hip_stream, const double* d_no
                            double* d_edgeT);
 int cs_posegraph_set_poses_dev(int device, void* hip_stream, int n, const int* d_nodeIdx, const double* d_R, const double* d_t,
                                double* d_nodeR, double* d_nodeT);
+/* The non-key-frame update of RobustBundleRTS::output() as a follow-up of the BA (cs_ba_set_followup(b,
+ * cs_posegraph_after_ba, &rec)): scatter the adjusted key poses d_Rs / d_Ts (cs_ba_result_buffers) into the nodes d_camNode
+ * names (one entry per BA camera, < 0 = not a node), then relax all graphs -- two launches behind the solve's last kernel.
+ * The record must stay alive and unchanged while it is installed; d_edgeR / d_edgeT were computed (cs_posegraph_edges_dev)
+ * from the poses before the adjustment. */
+typedef struct cs_posegraph_after_ba_rec {
+    cs_posegraph* g;
+    int device;
+    int nCams;              /* entries of d_camNode = cameras of the BA problem */
+    const int* d_camNode;
+    const double* d_Rs;
+    const double* d_Ts;
+    double* d_nodeR;
+    double* d_nodeT;
+    const double* d_edgeR;
+    const double* d_edgeT;
+    double* d_newR;
+    double* d_newT;
+} cs_posegraph_after_ba_rec;
+int cs_posegraph_after_ba(void* hip_stream, void* rec /* cs_posegraph_after_ba_rec* */);
 
 /* ------------------------------------------------------------------------------------------
  * Result text files of a run (host code, no device work)
@@ -414,6 +434,16 @@ int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const do
 int cs_ba_solve_async(cs_ba* b, void* after_stream, int C, int P, int nObs, const double* d_Rs0, const double* d_Ts0,
                       const double* d_pts0, int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter);
 int cs_ba_wait(cs_ba* b);
+/* Work that belongs right behind every solve of this workspace, on the solve's own stream and without a host round trip:
+ * `fn(stream, user)` is called (from cs_ba_solve_dev's caller thread, or from the workspace's worker thread for
+ * cs_ba_solve_async) once the solve's last kernel is enqueued; it enqueues more work on `stream` and returns CS_OK.  This is
+ * where RobustBundleRTS::output()'s update of the non-key frames goes (src/app/SL_CoSLAMRobustBA.cpp:311-315): see
+ * cs_posegraph_after_ba.  NULL removes it.  Waits for queued asynchronous solves first. */
+typedef int (*cs_ba_followup_fn)(void* hip_stream, void* user);
+int cs_ba_set_followup(cs_ba* b, cs_ba_followup_fn fn, void* user);
+/* device addresses of the workspace's current estimate: Rs [C][9], Ts [C][3], pts [P][3] (valid until the next upload of a
+ * larger problem) */
+int cs_ba_result_buffers(cs_ba* b, double** d_Rs, double** d_Ts, double** d_pts);
 /* synchronise and copy the workspace's current estimate back (any pointer may be NULL) */
 /* Distributed solve (one process per GPU, points sliced by rank; SURVEY.md 8e collective 2): the reduced camera system
  * S || rhs is all-reduced once per LM step by the caller between the phases below; every launch is asynchronous on

@@ -29,6 +29,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys(hip):
     assert cfg["cameras"] == 8 and all(cfg["pose_ok"]) and min(cfg["pose_correspondences"]) > 50
     assert min(cfg["live_features_last_frame"]) > 1500
     assert cfg["joint_ba_last"]["lm_steps"] > 0 and cfg["joint_ba_last"]["cost"] < cfg["joint_ba_last"]["cost0"]
+    assert cfg["posegraph_last"]["nodes"] == 8 * 21 and cfg["posegraph_last"]["components"] == 32
+    assert cfg["posegraph_last"]["max_non_key_translation_change"] > 1e-4 and "pose-graph relaxation" in cfg["workload"]
     assert cfg["intercam_last"]["lm_steps"] > 0 and cfg["register_candidates_last_frame"]["current_static"] > 1000
     r = j["roofline"]
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):

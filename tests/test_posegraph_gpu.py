@@ -155,3 +155,59 @@ def test_posegraph_failure_and_argument_errors(hip):
     h1 = coslam_amd.PoseGraphs([(np.array([1, 1, 1], np.uint8), [0, 1], [1, 2])])
     R, T = h1.relax(pg["nodeR"][:3], pg["nodeT"][:3], pg["edgeR"][:2], pg["edgeT"][:2])
     assert np.array_equal(R, pg["nodeR"][:3]) and np.array_equal(T, pg["nodeT"][:3])
+
+
+@pytest.mark.parametrize("mode", ["dev", "async"])
+def test_posegraph_runs_as_the_follow_up_of_a_bundle_adjustment(hip, mode):
+    """RobustBundleRTS::output() (reference src/app/SL_CoSLAMRobustBA.cpp:273-316) on the device: the adjusted key poses go
+    from the BA workspace into the fixed nodes and the non-key frames are relaxed, enqueued by the library right behind the
+    solve's last kernel (cs_ba_set_followup + cs_posegraph_after_ba) -- for the up-front schedule and for the worker thread.
+    Expected: the oracle's relaxation with the fixed nodes at the BA's result."""
+    from coslam_amd.synth import make_ba_problem
+
+    n_cam, n_kf, key_every = 2, 5, 5
+    pr = make_ba_problem(n_cams=n_cam * n_kf, n_pts=300, noise=0.3, outlier_frac=0.02, seed=21, n_cams_con=2)
+    ptr, cam, xy = oracle.csr_by_point(len(pr["pts0"]), pr["obs_pt"], pr["obs_cam"], pr["obs_xy"])[:3]
+    pg = make_pose_graphs(n_cams=n_cam, n_frames=(n_kf - 1) * key_every + 1, key_every=key_every, seed=22)
+    h = coslam_amd.PoseGraphs(pg["graphs"])
+    key_nodes = np.nonzero(h.fixed)[0].astype(np.int32)              # BA camera j <-> j-th key node (camera-major)
+    assert len(key_nodes) == n_cam * n_kf
+    before_R, before_T = pg["nodeR0"].copy(), pg["nodeT0"].copy()
+    before_R[key_nodes], before_T[key_nodes] = pr["Rs0"].reshape(-1, 9), pr["ts0"]      # the key frames' poses before the BA
+    dev = torch.device("cuda:0")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    d_nodeR, d_nodeT = T(before_R), T(before_T)
+    d_eR = torch.zeros(h.n_edges, 9, dtype=torch.float64, device=dev)
+    d_eT = torch.zeros(h.n_edges, 3, dtype=torch.float64, device=dev)
+    d_newR, d_newT = torch.zeros_like(d_nodeR), torch.zeros_like(d_nodeT)
+    d_camNode = T(key_nodes)
+    s = torch.cuda.current_stream().cuda_stream
+    h.edges_dev(s, d_nodeR.data_ptr(), d_nodeT.data_ptr(), d_eR.data_ptr(), d_eT.data_ptr())     # constructCameraGraphs
+    ws = coslam_amd.BAWorkspace(0)
+    ws.upload(pr["Ks"], pr["Rs0"], pr["ts0"], pr["pts0"], ptr, cam, xy)
+    d_R0, d_T0, d_M0 = T(pr["Rs0"].reshape(-1)), T(pr["ts0"].reshape(-1)), T(pr["pts0"].reshape(-1))
+    bR, bT, _ = ws.result_buffers()
+    rec = coslam_amd.after_ba_record(h, len(key_nodes), d_camNode.data_ptr(), bR, bT, d_nodeR.data_ptr(), d_nodeT.data_ptr(),
+                                     d_eR.data_ptr(), d_eT.data_ptr(), d_newR.data_ptr(), d_newT.data_ptr())
+    import ctypes
+    ws.set_followup(coslam_amd.after_ba_function(), ctypes.addressof(rec))
+    if mode == "dev":
+        ws.solve_dev(s, d_R0.data_ptr(), d_T0.data_ptr(), d_M0.data_ptr(), 2, 0, 6.0, 2, 10)
+    else:
+        ws.solve_async(s, d_R0.data_ptr(), d_T0.data_ptr(), d_M0.data_ptr(), 2, 0, 6.0, 2, 10)
+        ws.wait()
+    torch.cuda.synchronize()
+    h.status(s)
+    Rs, Ts, _, _, st = ws.download()
+    assert st.nIterTotal > 0 and np.abs(Ts - pr["ts0"]).max() > 1e-3          # the BA moved the key frames
+    after_R, after_T = before_R.copy(), before_T.copy()
+    after_R[key_nodes], after_T[key_nodes] = Rs.reshape(-1, 9), Ts
+    assert np.array_equal(d_nodeR.cpu().numpy(), after_R) and np.array_equal(d_nodeT.cpu().numpy(), after_T)
+    oeR, oeT = oracle.posegraph_edges(before_R, before_T, pg["ge1"], pg["ge2"])
+    oR, oT = _oracle_all(dict(pg, nodeR=after_R, nodeT=after_T, edgeR=oeR, edgeT=oeT))
+    newR, newT = d_newR.cpu().numpy(), d_newT.cpu().numpy()
+    assert np.abs(newR - oR).max() < TOL_R and np.abs(newT - oT).max() < TOL_T
+    free = h.fixed == 0
+    assert np.abs(newT[free] - before_T[free]).max() > 1e-4                  # and the non-key frames followed
+    ws.set_followup(0, 0)
+    ws.close()
