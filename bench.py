@@ -237,6 +237,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="diagnostic: every leg on ONE stream (no overlap)")
     ap.add_argument("--key-every", type=int, default=KEY_EVERY, help="diagnostic: 0 disables the key-frame solves (not a valid bench line)")
+    ap.add_argument("--only-solve", choices=["both", "joint", "intercam"], default="both",
+                    help="diagnostic: run only one of the two key-frame solves (not a valid bench line)")
     ap.add_argument("--no-pose", action="store_true", help="diagnostic: skip hand-back + pose (not a valid bench line)")
     ap.add_argument("--klt-cus", type=int, default=int(os.environ.get("BENCH_KLT_CUS", "0")),
                     help="tracker stream confined to the first N compute units (0 = whole chip): leaves CUs the persistent tracker "
@@ -457,11 +459,15 @@ def main():
                 xchg.all_gather(pose_s)
         dest_free[b].record(pose_s)
         if key_frame:
-            if args.serial:
+            if args.only_solve == "joint":
+                pass
+            elif args.serial:
                 ic_ws.solve_dev(klt_s.cuda_stream, d_iR.data_ptr(), d_iT.data_ptr(), d_iM.data_ptr(), 0, ic["n_static"], 6.0, 3, 40)
             else:
                 ic_ws.solve_async(pose_s.cuda_stream, d_iR.data_ptr(), d_iT.data_ptr(), d_iM.data_ptr(), 0, ic["n_static"], 6.0, 3, 40)
-            if world > 1:
+            if args.only_solve == "intercam":
+                pass
+            elif world > 1:
                 pose_done.record(pose_s)
                 ba_s.wait_event(pose_done)
                 multicam.bundle_adjust_sliced(ba_ws, ba_s, d_jR.data_ptr(), d_jT.data_ptr(), d_jM.data_ptr(),

@@ -5,6 +5,8 @@ python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -2
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; echo "bench(driver cmd) rc=$?"
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench(default) rc=$?"
+python tools/pg_time.py > $O/posegraph_time.txt 2>&1; tail -2 $O/posegraph_time.txt
+for m in joint intercam; do python3 bench.py --no-cpu-baseline --only-solve $m 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('only-solve $m:', round(j['value'],1), 'frames/s')"; done | tee $O/only_solve.txt
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c; timeout 300 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o klt -- python $GRAFT_REPO_ROOT/tools/pmc_klt.py > /tmp/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
