@@ -40,7 +40,7 @@
 #include "cs_common.h"
 
 #ifndef CS_BA_PRIO
-#define CS_BA_PRIO 0  // s_setprio of the LM-step kernels' waves (A/B: the persistent tracker runs at 1..3)
+#define CS_BA_PRIO 1  // s_setprio of the LM-step kernels' waves: the persistent tracker's base level (it runs at 1..3); 0 costs 2 % of the loop, 3 is erratic
 #endif
 #define CS_BA_SETPRIO() do { if (CS_BA_PRIO) __builtin_amdgcn_s_setprio(CS_BA_PRIO); } while (0)
 #pragma clang fp contract(off)
@@ -1160,8 +1160,11 @@ __device__ __forceinline__ void sb_panel_mfma(double* A, int I, int kb, int lane
     for (int q = 0; q < 4; ++q) P[(lg + 4 * q) * SP + lr] = c[q];
 }
 
+#ifndef CS_SOLVE_PRIO
+#define CS_SOLVE_PRIO CS_BA_PRIO  // A/B: the solver is ONE workgroup on the LM step's critical path
+#endif
 __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
-    CS_BA_SETPRIO();
+    if (CS_SOLVE_PRIO) __builtin_amdgcn_s_setprio(CS_SOLVE_PRIO);
     const int stAllDone = D.st->all_done, stInnerDone = D.st->inner_done;  // (consumed after the matrix loads are in flight)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ int okFlag;
