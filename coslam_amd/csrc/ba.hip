@@ -573,6 +573,8 @@ __global__ __launch_bounds__(256) void k_schur_pairs(BaDev D) {
     }
 }
 
+#include "ba_syrk_dev.h"
+
 // ---- small reduced systems (order <= 36): one WAVE per (camera pair, point slice) -------------------------------
 // The pair-per-workgroup kernel above walks all points with 256 threads and then folds 42 sums over four waves; at
 // the reference's local-BA sizes (3..6 free cameras) that is 6..21 workgroups and two rounds of dependent loads.
@@ -2177,6 +2179,9 @@ struct BaPlan {
     size_t ldsSolve;
     bool sliced;
     bool legacySolve;  // COSLAM_BA_LEGACY_SOLVE=1: k_solve_wave / k_solve<256> / HBM-blocked Cholesky (A/B runs)
+    bool syrk;         // large orders without pair lists: the Schur sum as Z Z^T on the f64 matrix cores (ba_syrk_dev.h)
+    SyrkDev Y;
+    size_t syrkZtBytes;
 };
 
 struct cs_ba {
@@ -2209,6 +2214,8 @@ struct cs_ba {
     } gkey;
     hipGraphExec_t gexec;
     struct BaWorker* worker;  // cs_ba_solve_async: the workspace's solver thread (the reference's BA thread)
+    unsigned char* syrkBuf;  // Zt | Tobs | Cpart | Udiag of the SYRK path (own allocation, grown on demand)
+    size_t syrkCap;
     cs_ba_followup_fn followup;  // cs_ba_set_followup: enqueued on the solve's stream right behind every solve
     void* followupUser;
 };
@@ -2238,6 +2245,9 @@ static int ba_free(cs_ba* b) {
     b->pairPtrCap = b->pairEntCap = 0;
     b->havePairs = false;
     if (b->slab) (void)hipFree(b->slab);
+    if (b->syrkBuf) (void)hipFree(b->syrkBuf);
+    b->syrkBuf = nullptr;
+    b->syrkCap = 0;
     if (b->h_io) (void)hipHostFree(b->h_io);
     if (b->h_ob) (void)hipHostFree(b->h_ob);
     b->slab = nullptr;
@@ -2441,6 +2451,52 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
         while (sl > 1 && (nFree + sl - 1) / sl < 32) sl /= 2;  // at least half a wave of points per slice
         D.nSlices = sl;
     }
+    // orders beyond the LDS solver whose pair lists were too large to build: Z Z^T on the matrix cores
+    L.syrk = false;
+    {
+        // COSLAM_BA_SYRK=0: never (k_schur); =2: always, also where the pair lists or the LDS solver would apply (tests)
+        const char* env = getenv("COSLAM_BA_SYRK");
+        const bool noSyrk = env && env[0] == '0', force = env && env[0] == '2';
+        if (force && D.n > 0) D.pairPtr = nullptr, D.pairEnt = nullptr;
+        if (!distributed && !noSyrk && !D.pairPtr && (D.n > SB_MAX_ORDER || (force && D.n > 0)) && P > 0 && nObs > 0) {
+            SyrkDev& Y = L.Y;
+            Y.nT = (D.n + SY_TB - 1) / SY_TB;
+            Y.nTiles = Y.nT * (Y.nT + 1) / 2;
+            Y.ldz = Y.nT * SY_TB;
+            int sl = 384 / Y.nTiles;
+            if (sl > 16) sl = 16;
+            if (sl < 1) sl = 1;
+            const int K = 3 * P;
+            int ks = (K + sl - 1) / sl;
+            ks = (ks + SY_KC - 1) / SY_KC * SY_KC;
+            Y.nSlices = sl;
+            Y.Kslice = ks;
+            Y.Kpad = ks * sl;
+            auto pad = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            const size_t bZt = pad(sizeof(double) * (size_t)Y.Kpad * Y.ldz), bT = pad(sizeof(double) * 6 * (size_t)nObs),
+                         bC = pad(sizeof(double) * (size_t)sl * Y.nTiles * SY_TB * SY_TB), bU = pad(sizeof(double) * 33 * (size_t)D.nc);
+            const size_t need = bZt + bT + bC + bU;
+            if (need > b->syrkCap) {
+                if (b->syrkBuf) (void)hipFree(b->syrkBuf);
+                b->syrkBuf = nullptr;
+                b->syrkCap = 0;
+                if (hipMalloc((void**)&b->syrkBuf, need) != hipSuccess) {
+                    cs_set_error("cs_ba: cannot allocate %zu MB for the Schur contraction", need >> 20);
+                    return CS_ERR_ALLOC;
+                }
+                b->syrkCap = need;
+                ba_drop_graph(b);  // captured graphs hold the old addresses
+            }
+            Y.Zt = (double*)b->syrkBuf;
+            Y.Tobs = (double*)(b->syrkBuf + bZt);
+            Y.Cpart = (double*)(b->syrkBuf + bZt + bT);
+            Y.Udiag = (double*)(b->syrkBuf + bZt + bT + bC);
+            L.syrkZtBytes = bZt;
+            CS_HIP(hipFuncSetAttribute((const void*)k_syrk_mfma, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(double) * 4 * SY_KC * SY_LDP)));
+            L.syrk = true;
+        }
+    }
     return CS_OK;
 }
 
@@ -2453,6 +2509,9 @@ static void ba_enqueue_init(cs_ba* b, hipStream_t stream, const BaPlan& L, bool 
     if (gi > 64) gi = 64;
     BaInitCopy I = {d_Rs0, d_Ts0, d_pts0, b->Rs, b->Ts, b->pts, 9 * D.C, 3 * D.C, 3 * D.P};
     hipLaunchKernelGGL(k_init_state, dim3(gi), dim3(256), 0, stream, b->st, b->outlier, D.nObs, I);
+    // Z's entries of (point, camera) pairs without a measurement are never written: cleared once per solve (every present
+    // entry is rewritten by every step)
+    if (L.syrk) (void)hipMemsetAsync(L.Y.Zt, 0, L.syrkZtBytes, stream);
     if (!rebuildTopology) return;
     (void)hipMemsetAsync(b->obs_of, 0xff, sizeof(int) * (size_t)D.P * D.C, stream);
     if (D.P > 0) hipLaunchKernelGGL(k_build_obs_pt, dim3((D.P + 3) / 4), dim3(256), 0, stream, D.P, b->obs_ptr, b->obs_pt);
@@ -2476,10 +2535,17 @@ static void ba_enqueue_lin_schur(hipStream_t stream, const BaPlan& L) {
         if (L.sliced)
             hipLaunchKernelGGL(k_schur_part, dim3(L.nPairs * D.nSlices), dim3(64), 0, stream, D);
         else
-            if (D.pairPtr)
+            if (D.pairPtr) {
                 hipLaunchKernelGGL(k_schur_pairs, dim3(L.nPairs), blk, 0, stream, D);
-            else
+            } else if (L.syrk) {
+                const SyrkDev& Y = L.Y;
+                hipLaunchKernelGGL(k_syrk_pack, dim3(L.gPts), blk, 0, stream, D, Y);
+                hipLaunchKernelGGL(k_syrk_mfma, dim3(Y.nTiles * Y.nSlices), blk, sizeof(double) * 4 * SY_KC * SY_LDP, stream, D, Y);
+                hipLaunchKernelGGL(k_schur_diag_u, dim3(D.nc), blk, 0, stream, D, Y);
+                hipLaunchKernelGGL(k_syrk_reduce, dim3((unsigned)(((size_t)D.n * D.n + 255) / 256)), blk, 0, stream, D, Y);
+            } else {
                 hipLaunchKernelGGL(k_schur, dim3(L.nPairs), blk, 0, stream, D);
+            }
     }
 }
 

@@ -227,6 +227,39 @@ def test_ba_orders_of_the_lds_blocked_cholesky(hip, n_cams, ncon):
     _check_vs_oracle(pr, ptr, cam, xy, ncon, kw["n_pts_con"], 6.0, 2, 8, Rs, Ts, pts, out, st)
 
 
+@pytest.mark.parametrize("kw,ncon,npcon", [
+    (dict(n_cams=10, n_pts=260, visibility=0.55, seed=61), 2, 3),                       # order 48: one tile, LDS solver behind it
+    (dict(n_cams=26, n_pts=500, visibility=0.7, seed=62), 2, 3),                        # order 144: 2 x 2 tiles, ragged K slices
+    (dict(n_cams=40, n_pts=400, visibility=0.5, seed=11), 2, 2),                        # order 228: HBM Cholesky behind it
+    (dict(n_cams=60, n_pts=700, visibility=0.9, seed=63, outlier_frac=0.05), 4, 20),    # order 336: 3 x 3 tiles, dense visibility
+    (dict(n_cams=24, n_pts=300, visibility=0.4, seed=64, n_cams_con=0), 0, 200),        # no fixed camera, most points held
+])
+def test_schur_complement_on_the_matrix_cores_matches_oracle(hip, kw, ncon, npcon):
+    """The reduced camera system as Z Z^T on v_mfma_f64_16x16x4f64 (ba_syrk_dev.h; the path large problems without pair lists
+    take, BASELINE cfg5) forced onto problems small enough for the oracle (COSLAM_BA_SYRK=2): same flags, same iteration
+    counts, same minimum as the oracle -- the summation order differs (K slices of 16-row panels instead of camera pairs),
+    the tolerance is the BA's 1e-6."""
+    kw = dict(kw)
+    kw.setdefault("n_cams_con", ncon)
+    kw["n_pts_con"] = npcon
+    pr, ptr, cam, xy = ba_inputs(**kw)
+    res = {}
+    for mode in ("2", "0"):
+        os.environ["COSLAM_BA_SYRK"] = mode
+        try:
+            Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+            out, st = coslam_amd.bundleAdjustRobust(ncon, pr["Ks"], Rs, Ts, npcon, pts, (ptr, cam, xy), 6.0, 2, 8)
+        finally:
+            del os.environ["COSLAM_BA_SYRK"]
+        res[mode] = (Rs, Ts, pts, out, st)
+    Rs, Ts, pts, out, st = res["2"]
+    _check_vs_oracle(pr, ptr, cam, xy, ncon, npcon, 6.0, 2, 8, Rs, Ts, pts, out, st)
+    # and against the pair-per-workgroup kernels on the same device: the two orders of summation agree far below the tolerance
+    R0, T0, M0, out0, st0 = res["0"]
+    assert np.array_equal(out, out0) and st.nIterTotal == st0.nIterTotal
+    assert np.max(np.abs(Rs - R0)) < 1e-9 and np.max(np.abs(Ts - T0)) < 1e-8
+
+
 def test_async_worker_schedule_gives_the_up_front_schedule_bit_for_bit(hip):
     """cs_ba_solve_async (the workspace's own thread enqueues chunks of LM steps and stops at convergence -- the reference's
     BA worker thread, src/app/SL_CoSLAM.cpp:1702-1784) == cs_ba_solve_dev (whole schedule up front): identical bits, also
