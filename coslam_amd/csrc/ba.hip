@@ -1165,6 +1165,8 @@ __device__ __forceinline__ void sb_panel_mfma(double* A, int I, int kb, int lane
 #ifndef CS_SOLVE_PRIO
 #define CS_SOLVE_PRIO CS_BA_PRIO  // A/B: the solver is ONE workgroup on the LM step's critical path
 #endif
+#include "ba_cholflow_dev.h"
+
 __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
     if (CS_SOLVE_PRIO) __builtin_amdgcn_s_setprio(CS_SOLVE_PRIO);
     const int stAllDone = D.st->all_done, stInnerDone = D.st->inner_done;  // (consumed after the matrix loads are in flight)
@@ -2179,6 +2181,8 @@ struct BaPlan {
     size_t ldsSolve;
     bool sliced;
     bool legacySolve;  // COSLAM_BA_LEGACY_SOLVE=1: k_solve_wave / k_solve<256> / HBM-blocked Cholesky (A/B runs)
+    bool cholFlow;     // orders beyond the LDS solver: the one-launch dataflow Cholesky (ba_cholflow_dev.h)
+    CholFlow F;
     bool syrk;         // large orders without pair lists: the Schur sum as Z Z^T on the f64 matrix cores (ba_syrk_dev.h)
     SyrkDev Y;
     size_t syrkZtBytes;
@@ -2214,6 +2218,8 @@ struct cs_ba {
     } gkey;
     hipGraphExec_t gexec;
     struct BaWorker* worker;  // cs_ba_solve_async: the workspace's solver thread (the reference's BA thread)
+    unsigned char* cholBuf;  // published columns | x | flags of the dataflow Cholesky (own allocation, grown on demand)
+    size_t cholCap;
     unsigned char* syrkBuf;  // Zt | Tobs | Cpart | Udiag of the SYRK path (own allocation, grown on demand)
     size_t syrkCap;
     cs_ba_followup_fn followup;  // cs_ba_set_followup: enqueued on the solve's stream right behind every solve
@@ -2248,6 +2254,9 @@ static int ba_free(cs_ba* b) {
     if (b->syrkBuf) (void)hipFree(b->syrkBuf);
     b->syrkBuf = nullptr;
     b->syrkCap = 0;
+    if (b->cholBuf) (void)hipFree(b->cholBuf);
+    b->cholBuf = nullptr;
+    b->cholCap = 0;
     if (b->h_io) (void)hipHostFree(b->h_io);
     if (b->h_ob) (void)hipHostFree(b->h_ob);
     b->slab = nullptr;
@@ -2451,6 +2460,37 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
         while (sl > 1 && (nFree + sl - 1) / sl < 32) sl /= 2;  // at least half a wave of points per slice
         D.nSlices = sl;
     }
+    // orders beyond the LDS solver: block columns owned by workgroups, one launch (COSLAM_BA_CHOLFLOW=0: the launch-per-block
+    // kernels)
+    L.cholFlow = false;
+    {
+        const char* env = getenv("COSLAM_BA_CHOLFLOW");
+        const int NB = (D.n + SB - 1) / SB;
+        if (!(env && env[0] == '0') && !L.legacySolve && D.n > SB_MAX_ORDER && NB + 1 <= CF_MAX_BLOCKS) {
+            auto pad = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            const size_t bPub = pad(sizeof(double) * (size_t)NB * (NB + 1) * 256), bX = pad(sizeof(double) * 16 * (size_t)NB),
+                         bF = pad(sizeof(int) * 2 * (size_t)NB);
+            const size_t need = bPub + bX + bF;
+            if (need > b->cholCap) {
+                if (b->cholBuf) (void)hipFree(b->cholBuf);
+                b->cholBuf = nullptr;
+                b->cholCap = 0;
+                if (hipMalloc((void**)&b->cholBuf, need) != hipSuccess) {
+                    cs_set_error("cs_ba: cannot allocate %zu KB for the Cholesky columns", need >> 10);
+                    return CS_ERR_ALLOC;
+                }
+                b->cholCap = need;
+                ba_drop_graph(b);
+            }
+            L.F.pub = (double*)b->cholBuf;
+            L.F.xpub = (double*)(b->cholBuf + bPub);
+            L.F.flagL = (int*)(b->cholBuf + bPub + bX);
+            L.F.flagX = L.F.flagL + NB;
+            L.F.NB = NB;
+            CS_HIP(hipFuncSetAttribute((const void*)k_cholflow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cf_lds_bytes(NB + 1)));
+            L.cholFlow = true;
+        }
+    }
     // orders beyond the LDS solver whose pair lists were too large to build: Z Z^T on the matrix cores
     L.syrk = false;
     {
@@ -2582,6 +2622,9 @@ static void ba_enqueue_solve_update(hipStream_t stream, const BaPlan& L) {
             hipLaunchKernelGGL(k_solve_wave, dim3(1), dim3(64), sizeof(double) * (size_t)D.n * (D.n | 1), stream, D);
         } else if (L.useLds) {
             hipLaunchKernelGGL(k_solve<256>, dim3(1), blk, L.ldsSolve, stream, D, 1);
+        } else if (L.cholFlow) {  // one launch: workgroup per block column, flags in HBM
+            hipLaunchKernelGGL(k_cholflow_begin, dim3(1), dim3(128), 0, stream, D, L.F);
+            hipLaunchKernelGGL(k_cholflow, dim3(L.F.NB), dim3(CF_NT), cf_lds_bytes(L.F.NB + 1), stream, D, L.F);
         } else {  // blocked Cholesky in HBM
             hipLaunchKernelGGL(k_chol_begin, dim3(1), dim3(1), 0, stream, D);
             for (int k0 = 0; k0 < D.n; k0 += CB) {
