@@ -2503,8 +2503,9 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
             Y.nT = (D.n + SY_TB - 1) / SY_TB;
             Y.nTiles = Y.nT * (Y.nT + 1) / 2;
             Y.ldz = Y.nT * SY_TB;
-            int sl = 384 / Y.nTiles;
-            if (sl > 16) sl = 16;
+            int sl = 512 / Y.nTiles;  // two workgroups per CU: 189 us at cfg5 (one per CU: 204, 1.3 per CU: 259)
+            if (sl > 32) sl = 32;
+            if (const char* e = getenv("COSLAM_SYRK_SLICES")) sl = atoi(e);  // (A/B)
             if (sl < 1) sl = 1;
             const int K = 3 * P;
             int ks = (K + sl - 1) / sl;
@@ -2514,7 +2515,7 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
             Y.Kpad = ks * sl;
             auto pad = [](size_t v) { return (v + 255) & ~(size_t)255; };
             const size_t bZt = pad(sizeof(double) * (size_t)Y.Kpad * Y.ldz), bT = pad(sizeof(double) * 6 * (size_t)nObs),
-                         bC = pad(sizeof(double) * (size_t)sl * Y.nTiles * SY_TB * SY_TB), bU = pad(sizeof(double) * 33 * (size_t)D.nc);
+                         bC = pad(sizeof(double) * (size_t)sl * Y.nTiles * SY_TB * SY_TB), bU = pad(sizeof(double) * 33 * SY_US * (size_t)D.nc);
             const size_t need = bZt + bT + bC + bU;
             if (need > b->syrkCap) {
                 if (b->syrkBuf) (void)hipFree(b->syrkBuf);
@@ -2581,7 +2582,7 @@ static void ba_enqueue_lin_schur(hipStream_t stream, const BaPlan& L) {
                 const SyrkDev& Y = L.Y;
                 hipLaunchKernelGGL(k_syrk_pack, dim3(L.gPts), blk, 0, stream, D, Y);
                 hipLaunchKernelGGL(k_syrk_mfma, dim3(Y.nTiles * Y.nSlices), blk, sizeof(double) * 4 * SY_KC * SY_LDP, stream, D, Y);
-                hipLaunchKernelGGL(k_schur_diag_u, dim3(D.nc), blk, 0, stream, D, Y);
+                hipLaunchKernelGGL(k_schur_diag_u, dim3(D.nc * SY_US), blk, 0, stream, D, Y);
                 hipLaunchKernelGGL(k_syrk_reduce, dim3((unsigned)(((size_t)D.n * D.n + 255) / 256)), blk, 0, stream, D, Y);
             } else {
                 hipLaunchKernelGGL(k_schur, dim3(L.nPairs), blk, 0, stream, D);

@@ -20,6 +20,7 @@
 
 constexpr int SY_TB = 128;    // output tile
 constexpr int SY_KC = 16;     // K rows per LDS panel
+constexpr int SY_US = 8;      // slices of a camera's measurement list in k_schur_diag_u
 constexpr int SY_LDP = 144;   // panel row stride in doubles: = 16 mod 32 -> conflict-free ds_read_b64 for the MFMA operands
 
 typedef double sy_v4 __attribute__((ext_vector_type(4)));
@@ -28,7 +29,7 @@ struct SyrkDev {
     double* Zt;      // [Kpad][ldz]
     double* Tobs;    // [nObs][6]
     double* Cpart;   // [nSlices][nTiles][128 * 128]
-    double* Udiag;   // [nc][33]: U upper (21), g (6), sum t (6)
+    double* Udiag;   // [nc][SY_US][33]: U upper (21), g (6), sum t (6), in SY_US slices of the camera's measurement list
     int ldz, Kpad, Kslice, nSlices, nT, nTiles;
 };
 
@@ -186,12 +187,13 @@ __global__ __launch_bounds__(256) void k_schur_diag_u(BaDev D, SyrkDev Y) {
     CS_BA_SETPRIO();
     if (!BA_ACTIVE(D)) return;
     __shared__ double red[4][33];
-    const int ja = blockIdx.x, ca = ja + D.nCamsCon;
+    const int ja = blockIdx.x / SY_US, sl = blockIdx.x % SY_US, ca = ja + D.nCamsCon;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double u[33];
 #pragma unroll
     for (int q = 0; q < 33; ++q) u[q] = 0;
-    const int sBeg = D.cam_ptr[ca], sEnd = D.cam_ptr[ca + 1];
+    const int s0 = D.cam_ptr[ca], s1 = D.cam_ptr[ca + 1], len = (s1 - s0 + SY_US - 1) / SY_US;
+    const int sBeg = s0 + sl * len, sEnd = min(s1, sBeg + len);
     for (int s = sBeg + (int)threadIdx.x; s < sEnd; s += 256) {
         const int oa = D.cam_obs[s];
         const int ip = D.obs_pt[oa];
@@ -214,7 +216,16 @@ __global__ __launch_bounds__(256) void k_schur_diag_u(BaDev D, SyrkDev Y) {
     const int q = cs_reduce_index<33>(lane);
     if (q >= 0) red[wv][q] = u[0];
     __syncthreads();
-    if (threadIdx.x < 33) Y.Udiag[33 * (size_t)ja + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    if (threadIdx.x < 33)
+        Y.Udiag[33 * ((size_t)ja * SY_US + sl) + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__device__ __forceinline__ double sy_udiag(const SyrkDev& Y, int ja, int q) {  // slices added in slice order
+    const double* p = Y.Udiag + 33 * (size_t)ja * SY_US + q;
+    double v = 0;
+#pragma unroll
+    for (int k = 0; k < SY_US; ++k) v += p[33 * k];
+    return v;
 }
 
 // S = U + lambda I - sum over the K slices (slice order), both triangles; rhs = g - sum t
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(256) void k_syrk_reduce(BaDev D, SyrkDev Y) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx < (size_t)n) {
         const int ja = (int)idx / 6, r = (int)idx % 6;
-        D.rhs[idx] = Y.Udiag[33 * (size_t)ja + 21 + r] - Y.Udiag[33 * (size_t)ja + 27 + r];
+        D.rhs[idx] = sy_udiag(Y, ja, 21 + r) - sy_udiag(Y, ja, 27 + r);
     }
     if (idx >= (size_t)n * n) return;
     const int r = (int)(idx / n), c = (int)(idx % n);
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(256) void k_syrk_reduce(BaDev D, SyrkDev Y) {
     if (r / 6 == c / 6) {
         const int ja = r / 6, rr = c % 6, cc = r % 6;  // rr <= cc inside the block (c <= r)
         const int uq = rr * 6 - (rr * (rr - 1)) / 2 + (cc - rr);
-        v = (Y.Udiag[33 * (size_t)ja + uq] + ((r == c && D.addLambda) ? D.st->lambda : 0.0)) - s;
+        v = (sy_udiag(Y, ja, uq) + ((r == c && D.addLambda) ? D.st->lambda : 0.0)) - s;
     }
     D.S[(size_t)r * n + c] = v;
     D.S[(size_t)c * n + r] = v;
