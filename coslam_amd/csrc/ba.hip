@@ -1942,7 +1942,14 @@ __global__ __launch_bounds__(256) void k_control_step(BaDev D) {
             else if (q < total)
                 D.pts[q - nR - nT] = pre[k];
         }
-        for (int q = tid + 256 * PRE; q < total; q += 256) D.pts[q - nR - nT] = D.Mn[q - nR - nT];
+        for (int q = tid + 256 * PRE; q < total; q += 256) {  // (more than 170 cameras: the tail still holds R / t entries)
+            if (q < nR)
+                D.Rs[q] = D.Rn[q];
+            else if (q < nR + nT)
+                D.Ts[q - nR] = D.Tn[q - nR];
+            else
+                D.pts[q - nR - nT] = D.Mn[q - nR - nT];
+        }
     }
 }
 

@@ -227,6 +227,17 @@ def test_ba_orders_of_the_lds_blocked_cholesky(hip, n_cams, ncon):
     _check_vs_oracle(pr, ptr, cam, xy, ncon, kw["n_pts_con"], 6.0, 2, 8, Rs, Ts, pts, out, st)
 
 
+@pytest.mark.parametrize("n_cams,ncon,vis", [(33, 2, 0.5), (36, 2, 0.45), (50, 3, 0.35), (90, 2, 0.3), (176, 2, 0.2)])
+def test_ba_orders_of_the_dataflow_cholesky(hip, n_cams, ncon, vis):
+    """Reduced systems of order 186 ... 1044: k_cholflow (one launch, a workgroup per 16-column block column: 12 ... 55 columns,
+    orders that are not multiples of 16 -> identity padding in the last block) and, beyond 1040, the launch-per-block kernels."""
+    kw = dict(n_cams=n_cams, n_pts=240, visibility=vis, seed=70 + n_cams, n_cams_con=ncon, n_pts_con=3)
+    pr, ptr, cam, xy = ba_inputs(**kw)
+    Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+    out, st = coslam_amd.bundleAdjustRobust(ncon, pr["Ks"], Rs, Ts, 3, pts, (ptr, cam, xy), 6.0, 2, 6)
+    _check_vs_oracle(pr, ptr, cam, xy, ncon, 3, 6.0, 2, 6, Rs, Ts, pts, out, st)
+
+
 @pytest.mark.parametrize("kw,ncon,npcon", [
     (dict(n_cams=10, n_pts=260, visibility=0.55, seed=61), 2, 3),                       # order 48: one tile, LDS solver behind it
     (dict(n_cams=26, n_pts=500, visibility=0.7, seed=62), 2, 3),                        # order 144: 2 x 2 tiles, ragged K slices
