@@ -243,6 +243,7 @@ def main():
     ap.add_argument("--klt-cus", type=int, default=int(os.environ.get("BENCH_KLT_CUS", "0")),
                     help="tracker stream confined to the first N compute units (0 = whole chip): leaves CUs the persistent tracker "
                          "never occupies, where the BA's 1024-thread solver workgroup can start while the tracker runs")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cfg5 BA leg (3 s of problem generation)")
     ap.add_argument("--no-posegraph", action="store_true", help="diagnostic: skip the pose-graph relaxation behind the joint BA (not a valid bench line)")
     ap.add_argument("--no-register", action="store_true", help="diagnostic: skip the map-point registration search (not a valid bench line)")
     ap.add_argument("--native-comm", type=int, default=1, help="N > 1: collectives issued by libcoslam_hip (RCCL behind the C-ABI) instead of torch.distributed")
@@ -633,6 +634,31 @@ def main():
         cfg2 = {"workload": "cfg2: 1 camera 640x480 x 2000 slots, KLT (redetect, prefetch) + hand-back + intraCamEstimate "
                             "per frame, no key-frame solves", "camera_frames_per_s": n2 / dt2, "frames": n2}
 
+    # ---- secondary key: the sliding-window BA of cfg5 (BASELINE.json configs[4]: 4 cameras x 30 key frames = 120 poses of which 8
+    # fixed, 5000 points, every point in every key frame: 600 k measurements, reduced system of order 672), one full robust solve
+    cfg5 = None
+    if rank == 0 and n_gpus == 1 and not args.no_secondary:
+        from coslam_amd.synth import make_ba_problem
+
+        pr5 = make_ba_problem(n_cams=120, n_pts=5000, W=1920, H=1080, noise=0.3, outlier_frac=0.01, outlier_mag=40.0, n_cams_con=8,
+                              n_pts_con=2, seed=55)
+        p5, c5, x5 = csr(pr5)
+        ws5 = BAWorkspace(local_rank)
+        ws5.upload(pr5["Ks"], pr5["Rs0"], pr5["ts0"], pr5["pts0"], p5, c5, x5)
+        d5 = [torch.from_numpy(pr5[k].reshape(-1).copy()).to(dev) for k in ("Rs0", "ts0", "pts0")]
+        s5 = torch.cuda.current_stream().cuda_stream
+        for rep in range(3):   # the first solve allocates the workspace of the large-problem kernels and captures the graph
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            ws5.solve_dev(s5, d5[0].data_ptr(), d5[1].data_ptr(), d5[2].data_ptr(), 8, 2, 6.0, 2, 5)
+            torch.cuda.synchronize()
+            dt5 = time.perf_counter() - t5
+        st5 = ws5.download()[4]
+        cfg5 = {"workload": "cfg5 BA: C=120 (8 fixed) x 5000 pts x 600 k meas, order 672, maxIter 2 / inner 5", "ms_per_solve": dt5 * 1e3,
+                "lm_steps": st5.nIterTotal, "us_per_lm_step": dt5 * 1e6 / max(st5.nIterTotal, 1), "cost0": st5.cost0, "cost": st5.cost,
+                "outliers": st5.nOutliers}
+        ws5.close()
+
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
@@ -669,7 +695,7 @@ def main():
                                                                   "cost0": st_j.cost0, "cost": st_j.cost},
                        "intercam_last": {"lm_steps": st_i.nIterTotal, "outliers": st_i.nOutliers, "cost0": st_i.cost0,
                                          "cost": st_i.cost},
-                       "frame_front_prefetch": bool(prefetch), "secondary_cfg2": cfg2,
+                       "frame_front_prefetch": bool(prefetch), "secondary_cfg2": cfg2, "secondary_cfg5_ba": cfg5,
                        "posegraph_last": pg_info,
                        "register_candidates_last_frame": None if args.no_register else
                        {"active": int((reg_out[0]["slot"] >= 0).sum().item()), "current_static": int((reg_out[1]["slot"] >= 0).sum().item()),
