@@ -360,9 +360,7 @@ struct cs_posegraph {
     char* dev = nullptr;  // one allocation: plan arrays | status | workspace
     PgPlan plan{};
     std::vector<int> compGraph;  // component -> graph (error messages)
-    // staging of the host form
-    double* dIn = nullptr;
-    double* hIn = nullptr;
+    double* dIn = nullptr;  // staging of the host form (inside `dev`)
 };
 
 extern "C" int cs_posegraph_create(int device, int nGraphs, const int* nodePtr, const int* edgePtr, const unsigned char* fixed,
@@ -490,7 +488,8 @@ extern "C" int cs_posegraph_create(int device, int nGraphs, const int* nodePtr, 
                  oCompOff = oCompW + pad(4 * (size_t)nComp), oAdjPtr = oCompOff + pad(8 * (size_t)nComp),
                  oAdjEnt = oAdjPtr + pad(4 * (size_t)(nFree + 1)), oNodeSlot = oAdjEnt + pad(16 * adjEnt.size()),
                  oGe1 = oNodeSlot + pad(4 * (size_t)N), oGe2 = oGe1 + pad(4 * (size_t)E), oStatus = oGe2 + pad(4 * (size_t)E),
-                 oScratch = oStatus + pad(4 * (size_t)std::max(nComp, 1)), planBytes = oScratch, total = oScratch + pad(8 * scratchDoubles);
+                 oScratch = oStatus + pad(4 * (size_t)std::max(nComp, 1)), planBytes = oScratch,
+                 oStage = oScratch + pad(8 * scratchDoubles), total = oStage + pad(8 * (24 * (size_t)N + 12 * (size_t)E));
     std::vector<char> h(planBytes, 0);
     auto put = [&](size_t off, const void* src, size_t bytes) {
         if (bytes) memcpy(h.data() + off, src, bytes);
@@ -526,6 +525,7 @@ extern "C" int cs_posegraph_create(int device, int nGraphs, const int* nodePtr, 
     p.ge2 = (const int*)(G->dev + oGe2);
     p.status = (int*)(G->dev + oStatus);
     p.scratch = (double*)(G->dev + oScratch);
+    G->dIn = (double*)(G->dev + oStage);  // staging of the host form: nodeR | nodeT | edgeR | edgeT | newR | newT
     *out = G;
     return CS_OK;
 }
@@ -534,8 +534,6 @@ extern "C" void cs_posegraph_destroy(cs_posegraph* g) {
     if (!g) return;
     (void)hipSetDevice(g->device);
     if (g->dev) (void)hipFree(g->dev);
-    if (g->dIn) (void)hipFree(g->dIn);
-    if (g->hIn) (void)hipHostFree(g->hIn);
     delete g;
 }
 
@@ -641,27 +639,21 @@ extern "C" int cs_posegraph_relax(cs_posegraph* g, const double* nodeR, const do
     }
     if (g->nNodes == 0) return CS_OK;
     CS_HIP(hipSetDevice(g->device));
-    const size_t N = g->nNodes, E = g->nEdges, inD = 12 * N + 12 * E, allD = inD + 12 * N;
-    if (!g->dIn) {
-        CS_HIP(hipMalloc((void**)&g->dIn, allD * sizeof(double)));
-        CS_HIP(hipHostMalloc((void**)&g->hIn, allD * sizeof(double), hipHostMallocDefault));
-    }
-    double* h = g->hIn;
-    memcpy(h, nodeR, 9 * N * 8);
-    memcpy(h + 9 * N, nodeT, 3 * N * 8);
-    if (E) {
-        memcpy(h + 12 * N, edgeR, 9 * E * 8);
-        memcpy(h + 12 * N + 9 * E, edgeT, 3 * E * 8);
-    }
+    const size_t N = g->nNodes, E = g->nEdges, inD = 12 * N + 12 * E;
     double* d = g->dIn;
     hipStream_t s = nullptr;
-    CS_HIP(hipMemcpyAsync(d, h, inD * 8, hipMemcpyHostToDevice, s));
+    // (pageable copies: a few KB each; a pinned staging block would cost more to allocate than these copies take)
+    CS_HIP(hipMemcpyAsync(d, nodeR, 9 * N * 8, hipMemcpyHostToDevice, s));
+    CS_HIP(hipMemcpyAsync(d + 9 * N, nodeT, 3 * N * 8, hipMemcpyHostToDevice, s));
+    if (E) {
+        CS_HIP(hipMemcpyAsync(d + 12 * N, edgeR, 9 * E * 8, hipMemcpyHostToDevice, s));
+        CS_HIP(hipMemcpyAsync(d + 12 * N + 9 * E, edgeT, 3 * E * 8, hipMemcpyHostToDevice, s));
+    }
     int rc = cs_posegraph_relax_dev(g, s, d, d + 9 * N, d + 12 * N, d + 12 * N + 9 * E, d + inD, d + inD + 9 * N);
     if (rc != CS_OK) return rc;
-    CS_HIP(hipMemcpyAsync(h + inD, d + inD, 12 * N * 8, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipMemcpyAsync(newR, d + inD, 9 * N * 8, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipMemcpyAsync(newT, d + inD + 9 * N, 3 * N * 8, hipMemcpyDeviceToHost, s));
     rc = cs_posegraph_status(g, s, nullptr, nullptr);  // synchronises the stream
-    memcpy(newR, h + inD, 9 * N * 8);
-    memcpy(newT, h + inD + 9 * N, 3 * N * 8);
     return rc;
 }
 

@@ -13,6 +13,7 @@
 #include "CGKLT/v3d_gpuklt.h"
 #include "geometry/SL_BundleAdjust.h"
 #include "slam/SL_IntraCamPose.h"
+#include "slam/coslam_posegraph.h"
 
 struct Mat_d {
     int rows, cols;
@@ -30,6 +31,22 @@ struct Meas2D {
     double x, y;
     int outlier;
     Meas2D(int v, double x_, double y_) : viewId(v), x(x_), y(y_), outlier(0) {}
+};
+
+// the members of GlobalPoseGraph / CamPoseNode / CamPoseEdge that relaxPoseGraphs binds to (src/slam/SL_GlobalPoseEstimation.h)
+struct PgNode {
+    bool fixed;
+    double R[9], t[3], newR[9], newt[3];
+};
+struct PgEdge {
+    int id1, id2;
+    bool uncertainScale;
+    double R[9], t[3];
+};
+struct PgGraph {
+    int nNodes, nEdges;
+    PgNode* poseNodes;
+    PgEdge* poseEdges;
 };
 
 static double now_us() {
@@ -158,6 +175,38 @@ int main() {
     }
     printf("bundleAdjustRobust (5 key frames x 500 points x 2500 measurements, maxIter 2 / inner 10): %.1f us/call\n",
            (now_us() - t) / 50);
+    // the non-key frames behind a BA: 8 camera chains of 21 frames, key frame every 5th (RobustBundleRTS::updateNonKeyCameraPoses)
+    {
+        const int NC = 8, NN = 21;
+        std::vector<std::vector<PgNode> > nodes(NC, std::vector<PgNode>(NN));
+        std::vector<std::vector<PgEdge> > edges(NC, std::vector<PgEdge>(NN - 1));
+        std::vector<PgGraph> graphs(NC);
+        for (int c = 0; c < NC; ++c) {
+            for (int i = 0; i < NN; ++i) {
+                PgNode& nd = nodes[c][i];
+                nd.fixed = (i % 5 == 0);
+                const double a = 0.01 * i + 0.1 * c, ca = std::cos(a), sa = std::sin(a);
+                const double R[9] = {ca, 0, sa, 0, 1, 0, -sa, 0, ca};
+                for (int q = 0; q < 9; ++q) nd.R[q] = R[q];
+                nd.t[0] = 0.05 * i, nd.t[1] = 0.01 * c, nd.t[2] = 4 + 0.02 * i;
+            }
+            for (int i = 0; i + 1 < NN; ++i) {  // getRigidTransFromTo(node i, node i + 1)
+                PgEdge& e = edges[c][i];
+                const PgNode &n1 = nodes[c][i], &n2 = nodes[c][i + 1];
+                e.id1 = i, e.id2 = i + 1, e.uncertainScale = false;
+                for (int r = 0; r < 3; ++r)
+                    for (int q = 0; q < 3; ++q) e.R[3 * r + q] = n2.R[3 * r] * n1.R[3 * q] + n2.R[3 * r + 1] * n1.R[3 * q + 1] + n2.R[3 * r + 2] * n1.R[3 * q + 2];
+                for (int r = 0; r < 3; ++r) e.t[r] = n2.t[r] - (e.R[3 * r] * n1.t[0] + e.R[3 * r + 1] * n1.t[1] + e.R[3 * r + 2] * n1.t[2]);
+            }
+            for (int i = 0; i < NN; i += 5) nodes[c][i].t[0] += 0.03;  // what the BA did to the key frames
+            graphs[c].nNodes = NN, graphs[c].nEdges = NN - 1, graphs[c].poseNodes = nodes[c].data(), graphs[c].poseEdges = edges[c].data();
+        }
+        for (int i = 0; i < 10; ++i) relaxPoseGraphs(graphs.data(), NC);
+        t = now_us();
+        for (int i = 0; i < 200; ++i) relaxPoseGraphs(graphs.data(), NC);
+        printf("relaxPoseGraphs (8 camera chains x 21 frames, key frame every 5th; topology + values up, poses back): %.1f us/call, "
+               "node 3 of camera 0 moved by %.4f\n", (now_us() - t) / 200, nodes[0][3].newt[0] - nodes[0][3].t[0]);
+    }
     trk.deallocate();
     return 0;
 }
