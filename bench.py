@@ -246,6 +246,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cfg5 BA leg (3 s of problem generation)")
     ap.add_argument("--no-posegraph", action="store_true", help="diagnostic: skip the pose-graph relaxation behind the joint BA (not a valid bench line)")
     ap.add_argument("--no-register", action="store_true", help="diagnostic: skip the map-point registration search (not a valid bench line)")
+    ap.add_argument("--ba-sliced", choices=["auto", "0", "1"], default="auto",
+                    help="N > 1: joint BA sliced by points with an all-reduce per LM step (1), solved redundantly by every rank "
+                         "without any collective (0), or chosen by size (auto: sliced from 200 k measurements)")
     ap.add_argument("--native-comm", type=int, default=1, help="N > 1: collectives issued by libcoslam_hip (RCCL behind the C-ABI) instead of torch.distributed")
     args = ap.parse_args()
 
@@ -359,6 +362,11 @@ def main():
     # RobustBundleRTS::output() behind every joint BA: adjusted key poses into the fixed nodes of this rank's camera graphs,
     # relaxation of the non-key frames -- installed as the workspace's follow-up (N = 1: the worker thread enqueues it behind
     # the solve's last kernel) or enqueued behind the sliced solve (N > 1)
+    # N > 1: the joint BA of the headline (20 k measurements, LM step ~100 us of dependent launches) is latency-bound -- slicing
+    # it by points shortens no link of that chain and adds two all-reduces per LM step, so every rank solves it redundantly from
+    # the all-gathered measurements (bit-identical results, no collective).  Throughput-bound problems (cfg5: 600 k measurements)
+    # are sliced.  --ba-sliced 1 forces the sliced solve (SURVEY 8e collective 2).
+    ba_sliced = world > 1 and (args.ba_sliced == "1" or (args.ba_sliced == "auto" and len(joint["obs_cam"]) >= 200000))
     pg = None
     if not args.no_posegraph:
         from coslam_amd.posegraph import PoseGraphs, after_ba_function, after_ba_record, posegraph_set_poses_dev
@@ -376,7 +384,7 @@ def main():
         bR, bT, _ = ba_ws.result_buffers()
         pg_rec = after_ba_record(pg, len(pg_cam), d_pgCam.data_ptr(), bR, bT, d_pgR.data_ptr(), d_pgT.data_ptr(), d_pgER.data_ptr(),
                                  d_pgET.data_ptr(), d_pgNR.data_ptr(), d_pgNT.data_ptr(), device=local_rank)
-        if world == 1:
+        if world == 1 or not ba_sliced:
             ba_ws.set_followup(after_ba_function(), C.addressof(pg_rec))
     iptr, icam, ixy = csr(ic)
     ic_ws = BAWorkspace(local_rank)
@@ -468,7 +476,7 @@ def main():
                 ic_ws.solve_async(pose_s.cuda_stream, d_iR.data_ptr(), d_iT.data_ptr(), d_iM.data_ptr(), 0, ic["n_static"], 6.0, 3, 40)
             if args.only_solve == "intercam":
                 pass
-            elif world > 1:
+            elif world > 1 and ba_sliced:
                 pose_done.record(pose_s)
                 ba_s.wait_event(pose_done)
                 multicam.bundle_adjust_sliced(ba_ws, ba_s, d_jR.data_ptr(), d_jT.data_ptr(), d_jM.data_ptr(),
@@ -559,7 +567,7 @@ def main():
     f_last = order[(args.warmup + args.steps) % len(order)]
     Rl, tl_ = d_R[last].cpu().numpy(), d_t[last].cpu().numpy()
     pose_err = max(float(np.abs(tl_[i] - sc.pose(c, f_last)[1]).max()) for i, c in enumerate(my_cams))
-    _, _, _, _, st_j = ba_ws.download() if world == 1 else (None, None, None, None, None)
+    _, _, _, _, st_j = ba_ws.download() if (world == 1 or not ba_sliced) else (None, None, None, None, None)
     _, _, _, _, st_i = ic_ws.download()
 
     # ---- roofline of the dominant kernel: the persistent gain tracker of all cameras of this rank (one launch per frame).
@@ -686,8 +694,9 @@ def main():
                                    + ("" if args.no_posegraph else ", followed on its stream by the pose-graph relaxation of the "
                                       "window's non-key frames (21-frame chain per camera, 5 key frames fixed)") + ", and "
                                    f"inter-camera solve C=8 free, {ic['n_static']} static pts fixed + {ic['n_dynamic']} dynamic, "
-                                   "sigma 6, 3 x 40; N>1: cameras sharded 8/N per GPU, all-gather of features+pose per "
-                                   "frame, joint BA sliced by points with an all-reduce per LM step",
+                                   "sigma 6, 3 x 40; N>1: cameras sharded 8/N per GPU, all-gather of features+pose per frame, "
+                                   + ("joint BA sliced by points with an all-reduce per LM step" if ba_sliced else
+                                      "joint BA solved by every rank from the gathered measurements (latency-bound: no collective; --ba-sliced 1 slices it)"),
                        "cameras": N_CAMS, "cameras_per_gpu": nc, "camera_frames_per_s": N_CAMS * args.steps / dt,
                        "live_features_last_frame": n_live, "pose_ok": pose_ok, "pose_correspondences": pose_npts, "pose_rounds_and_last_lm_steps": pose_iters,
                        "pose_translation_error_vs_truth": pose_err,
