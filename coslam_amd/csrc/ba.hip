@@ -20,14 +20,17 @@
 //   k_update<N>   N > 0: every workgroup adds the slice partials in LDS and factorises the reduced system out of the
 //                 registers of one wave; then the tentative step (cameras R exp(w), t + dt; points by
 //                 back-substitution, wave per point) and the tentative cost of the wave's own measurements;
-//                 N = 0: the system was solved by k_solve_wave / k_solve<256> (LDS) or the blocked Cholesky
-//                 k_chol_panel / k_chol_trail / k_chol_trsv (HBM, order > 138);
+//                 N = 0: the system was solved by k_solve_blocked (one workgroup, LDS, orders 37..176), k_cholflow (one
+//                 dataflow launch, a workgroup per block column, orders 177..1040: ba_cholflow_dev.h) or, beyond that and
+//                 for A/B runs, k_chol_panel / k_chol_trail / k_chol_trsv (HBM, two launches per block);
 //   k_control_step  one workgroup: fixed-order sum of the partials, accept/reject, lambda, commit, stop flags
 //                 (k_control: the same at the start of an outer round);
 //   k_cost / k_flag  start-of-round cost; outlier flags (residual > maxErr) and the "flags changed" bit.
 // Every sum has a fixed order (no atomics): results are run-to-run identical.
-// MFMA is deliberately absent: the f64 matrix peak of MI355X equals its f64 vector peak, and the Schur products
-// are 6x3 blocks -- wave-shuffle territory; the large-order Cholesky tiles through LDS with 4x4 register blocks.
+// MFMA: the f64 matrix peak of MI355X equals its f64 vector peak, and the Schur products of the local BA are 6x3 blocks --
+// wave-shuffle territory.  The matrix cores are used where they save instructions on a latency chain (the block updates and
+// panels of k_solve_blocked / k_cholflow) and where the contraction is large and dense (ba_syrk_dev.h: the Schur sum of a
+// sliding-window BA as Z Z^T, 0.72 of the f64 matrix peak at cfg5).
 // The distributed solve (points sliced by rank, all-reduce of S || rhs per LM step) reuses these kernels through
 // the cs_ba_dist_* phase API at the end of this file.
 #include <condition_variable>

@@ -69,7 +69,7 @@ def ba_inputs(**kw):
     (dict(n_cams=3, n_pts=200, n_cams_con=0, n_pts_con=140, seed=5), 0, 140, 3, 40),  # inter-camera pose shape
     (dict(n_cams=15, n_pts=800, visibility=0.6, seed=9), 6, 2, 2, 10),                 # 3 cams x 5 KF, ragged tracks
     (dict(n_cams=22, n_pts=500, visibility=0.5, seed=10), 2, 2, 2, 8),                 # order 120: LDS workgroup Cholesky
-    (dict(n_cams=40, n_pts=400, visibility=0.5, seed=11), 2, 2, 2, 8),                 # order 228: blocked Cholesky in HBM
+    (dict(n_cams=40, n_pts=400, visibility=0.5, seed=11), 2, 2, 2, 8),                 # order 228: the dataflow Cholesky (k_cholflow)
     (dict(n_cams=120, n_pts=300, visibility=0.25, seed=12, W=1920, H=1080), 8, 2, 1, 6),  # cfg5 camera count (4 x 30 KF), order 672
 ])
 def test_ba_matches_oracle(hip, kw, ncon, npcon, maxIter, inner):
@@ -217,8 +217,8 @@ def test_inter_camera_pose_solve_of_the_eight_camera_rig_matches_oracle(hip):
 
 @pytest.mark.parametrize("n_cams,ncon", [(9, 2), (10, 2), (13, 2), (18, 2), (26, 2), (34, 2), (31, 2), (24, 0), (34, 2)])
 def test_ba_orders_of_the_lds_blocked_cholesky(hip, n_cams, ncon):
-    """Reduced systems of order 42 ... 176 run through k_solve_blocked (packed 16 x 16 blocks in LDS; order 192 takes the
-    HBM-blocked path): every block count
+    """Reduced systems of order 42 ... 176 run through k_solve_blocked (packed 16 x 16 blocks in LDS; order 192 takes
+    k_cholflow): every block count
     3 <= NB <= 11 incl. orders that are not multiples of 16 (identity padding)."""
     kw = dict(n_cams=n_cams, n_pts=260, visibility=0.55, seed=40 + n_cams, n_cams_con=ncon, n_pts_con=3 if ncon else 40)
     pr, ptr, cam, xy = ba_inputs(**kw)
