@@ -138,6 +138,40 @@ def test_ba_random_shapes(hip, case):
     assert abs(st_g.cost - st_o.cost) <= ctol * max(1.0, st_o.cost), kw
 
 
+@pytest.mark.parametrize("case", range(int(os.environ.get("COSLAM_TEST_CASES_LARGE", "6"))))
+def test_ba_random_large_shapes(hip, case):
+    """Seeded random LARGE shapes (30 ... 130 cameras: reduced systems of order 150 ... 780, sparse to dense visibility): the
+    kernels a sliding-window BA gets -- pair lists or the matrix-core Schur sum (every other case forces it), k_solve_blocked or
+    the dataflow Cholesky -- against the oracle."""
+    rng = np.random.default_rng(5000 + case)
+    n_cams = int(rng.integers(30, 131))
+    n_pts = int(rng.integers(120, 420))
+    ncon = int(rng.integers(0, 9))
+    npcon = int(rng.integers(0, n_pts // 3)) if ncon else int(rng.integers(8, n_pts // 2))
+    kw = dict(n_cams=n_cams, n_pts=n_pts, n_cams_con=ncon, n_pts_con=npcon, visibility=float(rng.uniform(0.15, 0.95)),
+              outlier_frac=float(rng.choice([0.0, 0.02, 0.08])), noise=float(rng.choice([0.2, 0.5, 1.0])), seed=6000 + case,
+              W=1920, H=1080)
+    maxIter, inner = int(rng.integers(1, 3)), int(rng.integers(2, 8))
+    pr, ptr, cam, xy = ba_inputs(**kw)
+    if case % 2:
+        os.environ["COSLAM_BA_SYRK"] = "2"
+    try:
+        Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+        out, st = coslam_amd.bundleAdjustRobust(ncon, pr["Ks"], Rs, Ts, npcon, pts, (ptr, cam, xy), 6.0, maxIter, inner)
+    finally:
+        os.environ.pop("COSLAM_BA_SYRK", None)
+    R_o, T_o, M_o, out_o, st_o = oracle.ba_robust(pr["Ks"], pr["Rs0"], pr["ts0"], pr["pts0"], ptr, cam, xy, ncon, npcon, 6.0,
+                                                  maxIter, inner)
+    assert np.array_equal(out, out_o), (kw, (out != out_o).sum())
+    assert st.nOuter == st_o.nOuter and abs(st.nIterTotal - st_o.nIterTotal) <= 2, kw
+    tol = 1e-6 if st.nIterTotal == st_o.nIterTotal else 1e-5
+    sane = np.linalg.norm(M_o, axis=1) < 1e3
+    scale = max(1.0, np.abs(M_o[sane]).max())
+    assert np.max(np.abs(Rs - R_o)) < tol and np.max(np.abs(Ts - T_o)) < tol * scale, kw
+    assert np.max(np.abs(pts[sane] - M_o[sane])) < tol * scale, kw
+    assert abs(st.cost - st_o.cost) <= 10 * tol * max(1.0, st_o.cost), kw
+
+
 def test_ba_edge_cases(hip):
     # all cameras fixed: structure-only refinement
     pr, ptr, cam, xy = ba_inputs(n_cams=4, n_pts=50, n_cams_con=4, n_pts_con=0, outlier_frac=0.0)
