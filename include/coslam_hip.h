@@ -361,7 +361,8 @@ typedef struct cs_export_cam {
 } cs_export_cam;
 /* nPts static map points in the order they are to be listed (the reference: address order of the objects, the address
  * being the id, :1862): ptId [nPts], ptM [nPts][3], ptCov [nPts][9].  covAsReference != 0: the 9 numbers of every point are
- * ptCov[k][k], k = 0..8 -- what the reference's shadowed loop variable makes it write (:1965-1966); 0: each point's own 9. */
+ * ptCov[k][k], k = 0..8 -- what the reference's shadowed loop variable makes it write (:1965-1966); 0: each point's own 9,
+ * the "<3x3 covariance>" the reference's README.md:152-158 documents. */
 int cs_export_results_v1(const char* dirPath, int nCams, const cs_export_cam* cams, int curFrame, int nPts, const long long* ptId,
                          const double* ptM, const double* ptCov, int covAsReference);
 
