@@ -575,7 +575,7 @@ def main():
     roof = None
     if rank == 0:
         trks[0].set_profiling(True)
-        n_prof = min(args.steps, 100)
+        n_prof = 100   # (also for a short --steps run: the first frames after the switch to profiling are slower)
         base = args.warmup + args.steps
         for i in range(n_prof):
             f, fn = order[(base + i + 1) % len(order)], order[(base + i + 2) % len(order)]
