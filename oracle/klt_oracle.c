@@ -232,6 +232,26 @@ void okl_sample(const uint16_t* lvl, int Wl, int Hl, float s, float t, float out
 
 /* ------------------------------------------------------------------ tracker, no gain */
 
+/* The HIP kernel's order of the window sums (k_track_nogain, coslam_amd/csrc/klt_track.hip): pixel p = 64 q + lane goes to
+ * lane p % 64, a lane adds its pixels in the order of q, and the 64 lane values are folded by cs_wave_sum -- a balanced binary
+ * tree inside each row of 16 lanes (commutative at every level, so every lane of the row holds the same bits), then
+ * (row3 + row2) + (row1 + row0).  Same per-pixel arithmetic as the serial order below. */
+static float nogain_tree_sum(const float lanes[64]) {
+    float R[4];
+    for (int r = 0; r < 4; ++r) {
+        float q[4];
+        for (int k = 0; k < 4; ++k) {
+            const float* a = lanes + 16 * r + 4 * k;
+            q[k] = (a[0] + a[1]) + (a[2] + a[3]);
+        }
+        R[r] = (q[0] + q[1]) + (q[2] + q[3]);
+    }
+    return (R[3] + R[2]) + (R[1] + R[0]);
+}
+
+static int g_nogain_sum_mode = 0; /* 0 serial (the shader's loop order), 1 the HIP kernel's tree */
+void okl_set_nogain_sum_mode(int mode) { g_nogain_sum_mode = mode; }
+
 void okl_track_nogain(const uint16_t* pyr0, const uint16_t* pyr1, int W, int H, int nLevels, int levelSkip,
                       int hw, int nIterShader, float margin, float convThr, float ssdThr, int N, const float* featIn,
                       float* featOut) {
@@ -264,9 +284,12 @@ void okl_track_nogain(const uint16_t* pyr0, const uint16_t* pyr1, int W, int H, 
             for (int iter = 0; iter < nIterShader; ++iter) {
                 float a = 0, b = 0, c = 0, rx = 0, ry = 0;
                 SSD = 0;
+                float la[6][64];
+                if (g_nogain_sum_mode == 1) memset(la, 0, sizeof(la));
+                int p = 0;
                 for (int y = -hw; y <= hw; ++y) {
                     float st_y = X0y + (float)y * dsy, st_w = X1y + (float)y * dsy; /* :81-82 */
-                    for (int x = -hw; x <= hw; ++x) {
+                    for (int x = -hw; x <= hw; ++x, ++p) {
                         float st_x = X0x + (float)x * dsx, st_z = X1x + (float)x * dsx;
                         float I0[3], I1[3];
                         okl_sample(L0, Wl, Hl, st_x, st_y, I0);
@@ -274,6 +297,12 @@ void okl_track_nogain(const uint16_t* pyr0, const uint16_t* pyr1, int W, int H, 
                         float e = I0[0] - I1[0];                   /* :93 */
                         float gx = (I0[1] + I1[1]) * whx / 2.0f; /* :94 */
                         float gy = (I0[2] + I1[2]) * why / 2.0f;
+                        if (g_nogain_sum_mode == 1) {
+                            const int ln = p & 63;
+                            la[0][ln] += gx * gx, la[1][ln] += gx * gy, la[2][ln] += gy * gy;
+                            la[3][ln] += e * gx, la[4][ln] += e * gy, la[5][ln] += e * e;
+                            continue;
+                        }
                         a += gx * gx; /* :105 abc += IJ.yyz*IJ.yzz */
                         b += gx * gy;
                         c += gy * gy;
@@ -281,6 +310,10 @@ void okl_track_nogain(const uint16_t* pyr0, const uint16_t* pyr1, int W, int H, 
                         ry += e * gy;
                         SSD += e * e; /* :107 */
                     }
+                }
+                if (g_nogain_sum_mode == 1) {
+                    a = nogain_tree_sum(la[0]), b = nogain_tree_sum(la[1]), c = nogain_tree_sum(la[2]);
+                    rx = nogain_tree_sum(la[3]), ry = nogain_tree_sum(la[4]), SSD = nogain_tree_sum(la[5]);
                 }
                 float det = a * c - b * b;               /* :111 */
                 invalid = invalid || (det < 0.00001f);   /* :113 */
@@ -835,6 +868,7 @@ static void run_tracker(okl_seq* s) {
     const uint16_t *P0 = s->pyr[s->p0], *P1 = s->pyr[s->p1];
     if (!c->trackWithGain) {
         /* host passes -DNITERATIONS, the shader reads N_ITERATIONS => always 5 (v3d_gpuklt.cpp:108, klt_tracker.cg:16-18) */
+        okl_set_nogain_sum_mode(s->sum_mode == 1);
         okl_track_nogain(P0, P1, s->W, s->H, s->L, c->levelSkip, hw, 5, s->margin, s->convThr, s->ssdThr, s->N,
                          s->fb[s->b0], s->fb[s->b1]);
         return;

@@ -70,6 +70,7 @@ void okl_pyramid_build(const uint8_t* img, int W, int H, int nLevels, int center
 void okl_sample(const uint16_t* lvl, int Wl, int Hl, float s, float t, float out[3]);
 
 /* klt_tracker.cg:24-132 scheduled by v3d_gpuklt.cpp:99-161; N features, in/out N x 3 floats */
+void okl_set_nogain_sum_mode(int mode); /* 0: the shader's serial window sums; 1: the HIP kernel's lane / tree order */
 void okl_track_nogain(const uint16_t* pyr0, const uint16_t* pyr1, int W, int H, int nLevels, int levelSkip,
                       int halfWidth, int nIterShader, float margin, float convThr, float ssdThr, int N,
                       const float* featIn, float* featOut);

@@ -64,8 +64,8 @@ def klt_cases():
     for gain in (0, 1):
         cfg = KLT_SequenceTrackerConfig(nIterations=6, nLevels=L, levelSkip=1, windowWidth=7, trackWithGain=gain,
                                         minCornerness=800.0, convergenceThreshold=1.0, SSD_Threshold=20000.0, minDistance=5)
-        # gain tracker: window sums in the HIP tracker's fixed order ("tree" mode) -> the GPU test is bit-exact
-        o = oracle.SequenceTracker(cfg, sum_mode=1 if gain else 0)
+        # window sums in the HIP trackers' fixed order ("tree" mode), with and without gain -> the GPU test is bit-exact
+        o = oracle.SequenceTracker(cfg, sum_mode=1)
         o.allocate(W, H, L, fw, fh)
         n0, d0 = o.detect(imgs[0])
         out[f"pyr{gain}"] = o.read_pyramid()

@@ -21,8 +21,9 @@ TOL_PX = 0.02
 
 
 def exact_mode(cfg):
-    """the gain tracker with a window the rows kernel covers: the oracle's tree mode must match bit for bit"""
-    return bool(cfg.trackWithGain) and 1 <= cfg.windowWidth // 2 <= 7
+    """the gain tracker with a window the rows kernel covers, and the no-gain tracker: the oracle's tree mode (window sums in
+    the HIP kernels' fixed order) must match bit for bit"""
+    return (not cfg.trackWithGain) or 1 <= cfg.windowWidth // 2 <= 7
 
 
 def make_pair(cfg, W, H, L, fw, fh, tap_mode=0, sum_mode=None):
