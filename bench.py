@@ -243,6 +243,13 @@ def main():
     ap.add_argument("--klt-cus", type=int, default=int(os.environ.get("BENCH_KLT_CUS", "0")),
                     help="tracker stream confined to the first N compute units (0 = whole chip): leaves CUs the persistent tracker "
                          "never occupies, where the BA's 1024-thread solver workgroup can start while the tracker runs")
+    ap.add_argument("--klt-cams-per-launch", type=int, default=int(os.environ.get("BENCH_KLT_CAMS_PER_LAUNCH", "0")),
+                    help="cameras per persistent tracker launch (0 = as many as are co-resident: all 8 at two waves per SIMD). 4 = two "
+                         "launches of four cameras back to back at ONE wave per SIMD: every SIMD keeps a free wave slot (and every CU "
+                         "96 KB of LDS) for the key-frame solves' kernels")
+    ap.add_argument("--ba-cus", default=os.environ.get("BENCH_BA_CUS", ""), help="FIRST:COUNT -- the joint BA's stream confined to these CU-mask bits")
+    ap.add_argument("--ic-cus", default=os.environ.get("BENCH_IC_CUS", ""), help="FIRST:COUNT -- the inter-camera solve's stream confined to these CU-mask bits")
+    ap.add_argument("--pose-cus", default=os.environ.get("BENCH_POSE_CUS", ""), help="FIRST:COUNT -- the pose stream (hand-back, pose, registration) confined to these CU-mask bits")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cfg5 BA leg (3 s of problem generation)")
     ap.add_argument("--no-posegraph", action="store_true", help="diagnostic: skip the pose-graph relaxation behind the joint BA (not a valid bench line)")
     ap.add_argument("--no-register", action="store_true", help="diagnostic: skip the map-point registration search (not a valid bench line)")
@@ -338,7 +345,16 @@ def main():
         klt_s = torch.cuda.ExternalStream(ptr, device=dev)
     else:
         klt_s = torch.cuda.Stream(device=dev)
-    pose_s = klt_s if args.serial else torch.cuda.Stream(device=dev)
+    def masked_stream(spec):
+        first, count = (int(v) for v in spec.split(":"))
+        coslam_amd.lib().cs_stream_create_cu_range.restype = C.c_void_p
+        p = coslam_amd.lib().cs_stream_create_cu_range(local_rank, first, count)
+        if not p:
+            raise SystemExit("bench.py: cs_stream_create_cu_range failed: " + coslam_amd.lib().cs_last_error().decode())
+        return p
+
+    pose_s = klt_s if args.serial else (torch.cuda.ExternalStream(masked_stream(args.pose_cus), device=dev) if args.pose_cus
+                                        else torch.cuda.Stream(device=dev))
     ba_s = klt_s if args.serial else torch.cuda.Stream(device=dev)   # N > 1: the sliced joint BA and its collectives
 
     trks = []
@@ -351,10 +367,18 @@ def main():
     if args.klt_cus > 0:
         for t in trks:
             t.set_cu_count(args.klt_cus)
+    if args.klt_cams_per_launch > 0 and not args.klt_cus:
+        # the co-residency budget of the persistent tracker is what decides how many cameras share a launch: hand it the
+        # budget of cams_per_launch cameras (250 waves each, 8 resident waves per CU) -- no CU mask, the launches still spread
+        # over the whole chip
+        for t in trks:
+            t.set_cu_count(min(256, (250 * args.klt_cams_per_launch + 60) // 8 + 5))
     prefetch = os.environ.get("BENCH_PREFETCH", "1") != "0"
 
     jptr, jcam, jxy = csr(joint)
     ba_ws = BAWorkspace(local_rank)
+    if args.ba_cus:
+        ba_ws.set_stream(masked_stream(args.ba_cus))
     ba_ws.upload(joint["Ks"], joint["Rs0"], joint["ts0"], joint["pts0"], jptr, jcam, jxy)
     d_jR = torch.from_numpy(joint["Rs0"].reshape(-1).copy()).to(dev)
     d_jT = torch.from_numpy(joint["ts0"].reshape(-1).copy()).to(dev)
@@ -388,6 +412,8 @@ def main():
             ba_ws.set_followup(after_ba_function(), C.addressof(pg_rec))
     iptr, icam, ixy = csr(ic)
     ic_ws = BAWorkspace(local_rank)
+    if args.ic_cus:
+        ic_ws.set_stream(masked_stream(args.ic_cus))
     ic_ws.upload(ic["Ks"], ic["Rs0"], ic["ts0"], ic["pts0"], iptr, icam, ixy)
     d_iR = torch.from_numpy(ic["Rs0"].reshape(-1).copy()).to(dev)
     d_iT = torch.from_numpy(ic["ts0"].reshape(-1).copy()).to(dev)

@@ -11,7 +11,7 @@ from ._lib import CoslamHipError, check, lib
 
 class BAStats(C.Structure):
     _fields_ = [("cost0", C.c_double), ("cost", C.c_double), ("nIterTotal", C.c_int), ("nOuter", C.c_int),
-                ("nOutliers", C.c_int), ("pad", C.c_int)]
+                ("nOutliers", C.c_int), ("flags", C.c_int)]   # flags: CS_BA_FLAG_CHOL_FAILED 1 | NO_PROGRESS 2 | SOLVER_TIMEOUT 4
 
 
 def flatten_meas(meas2Ds):
@@ -93,6 +93,15 @@ class BAWorkspace:
         check(self._L.cs_ba_solve_async(self._h, vp(after_stream_ptr), self.C, self.P, self.nObs, vp(d_Rs0), vp(d_Ts0),
                                         vp(d_pts0), int(nCamsCon), int(nPtsCon), C.c_double(maxErr), int(maxIter),
                                         int(innerMaxIter)), "cs_ba_solve_async")
+
+    def set_stream(self, stream_ptr):
+        """cs_ba_set_stream: the workspace (and its asynchronous worker) enqueue on the caller's stream -- e.g. one confined
+        to a CU range; 0 restores the workspace's own.  The caller keeps the stream alive."""
+        check(self._L.cs_ba_set_stream(self._h, C.c_void_p(stream_ptr)), "cs_ba_set_stream")
+
+    def stream(self):
+        self._L.cs_ba_stream.restype = C.c_void_p
+        return self._L.cs_ba_stream(self._h)
 
     def wait(self):
         check(self._L.cs_ba_wait(self._h), "cs_ba_wait")

@@ -29,19 +29,20 @@ HIP_SOURCES = [
     "comm.hip",
 ]
 
-HIPCC_FLAGS = [
+COMPILE_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",
     "-std=c++17",
     "-fPIC",
-    "-shared",
     # the pyramid / detector kernels are bit-exact against the oracle: no FMA contraction
     "-ffp-contract=off",
     "-Wall",
     "-Wno-unused-value",
     "-Wno-unused-result",
-    "-ldl",
 ]
+LINK_FLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-ldl"]
+HIPCC_FLAGS = COMPILE_FLAGS + ["-shared", "-ldl"]   # one-command form (build_variant)
+OBJDIR = os.path.join(LIBDIR, "obj")
 
 
 def _hipcc():
@@ -70,13 +71,34 @@ def build_variant(name, defines, verbose=True):
 
 
 def build_hip(force=False, verbose=True):
+    """every source to its own object (in parallel, only the stale ones: a header change rebuilds all), then one link"""
+    from concurrent.futures import ThreadPoolExecutor
+
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    deps += [os.path.join(ROOT, "..", "include", f) for f in os.listdir(os.path.join(ROOT, "..", "include"))]
-    os.makedirs(LIBDIR, exist_ok=True)
-    if not force and not _stale(LIB, deps):
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs += [os.path.join(ROOT, "..", "include", f) for f in os.listdir(os.path.join(ROOT, "..", "include"))
+             if os.path.isfile(os.path.join(ROOT, "..", "include", f))]
+    os.makedirs(OBJDIR, exist_ok=True)
+    if not force and not _stale(LIB, srcs + hdrs):
         return LIB
-    cmd = [_hipcc()] + HIPCC_FLAGS + srcs + ["-o", LIB]
+    hipcc = _hipcc()
+    jobs = []
+    for src in srcs:
+        obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            # .cpp host sources go through hipcc as well (same flags, HIP headers available)
+            jobs.append(([hipcc] + COMPILE_FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj], src))
+
+    def run(job):
+        cmd, src = job
+        if verbose:
+            print("[coslam_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4) or 1) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(OBJDIR, os.path.basename(src) + ".o") for src in srcs]
+    cmd = [hipcc] + LINK_FLAGS + objs + ["-o", LIB]
     if verbose:
         print("[coslam_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

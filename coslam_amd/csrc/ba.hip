@@ -50,7 +50,7 @@
 
 struct cs_ba_stats_dev {
     double cost0, cost;
-    int nIterTotal, nOuter, nOutliers, pad;
+    int nIterTotal, nOuter, nOutliers, flags;  // flags: CS_BA_FLAG_* (coslam_hip.h)
 };
 
 namespace {
@@ -58,6 +58,9 @@ namespace {
 struct BaState {
     double lambda, cost, cost_new, step2, cost0;
     int inner_it, inner_done, all_done, chol_ok, changed, nIterTotal, nOuter, nOutliers, first_cost;
+    int nCholFail;      // LM steps whose reduced system could not be factorised (not positive definite, NaN, time-out)
+    int nAccepted;      // LM steps that were accepted
+    int solverTimeout;  // the dataflow Cholesky gave up waiting for a block column (scheduling stall, not arithmetic)
 };
 
 struct BaDev {
@@ -1920,6 +1923,8 @@ __global__ __launch_bounds__(256) void k_control_step(BaDev D) {
         int done = 0;
         st->nIterTotal += 1;
         st->inner_it = inner_it + 1;
+        if (!chol_ok) st->nCholFail += 1;
+        if (acc) st->nAccepted += 1;
         if (acc) {
             const double dec = cost_old - cost_new;
             st->cost = cost_new;
@@ -1996,6 +2001,7 @@ __global__ __launch_bounds__(256) void k_init_state(BaState* st, int* outlier, i
     z.lambda = 1e-3;
     z.cost = z.cost_new = z.step2 = z.cost0 = 0;
     z.inner_it = z.inner_done = z.all_done = z.chol_ok = z.changed = z.nIterTotal = z.nOuter = z.nOutliers = 0;
+    z.nCholFail = z.nAccepted = z.solverTimeout = 0;
     z.first_cost = 1;
     *st = z;
 }
@@ -2030,7 +2036,11 @@ __global__ void k_finish(BaDev D, cs_ba_stats_dev* out) {
         out->nIterTotal = D.st->nIterTotal;
         out->nOuter = D.st->nOuter;
         out->nOutliers = D.st->nOutliers;
-        out->pad = 0;
+        int fl = 0;
+        if (D.st->nCholFail > 0) fl |= 1;                               // CS_BA_FLAG_CHOL_FAILED
+        if (D.st->nCholFail > 0 && D.st->nAccepted == 0) fl |= 2;       // CS_BA_FLAG_NO_PROGRESS
+        if (D.st->solverTimeout) fl |= 4;                               // CS_BA_FLAG_SOLVER_TIMEOUT
+        out->flags = fl;
     }
 }
 
@@ -2136,6 +2146,8 @@ __global__ __launch_bounds__(256) void k_dist_control(BaDev D, int phase) {
         int done = 0;
         st->nIterTotal += 1;
         st->inner_it += 1;
+        if (!st->chol_ok) st->nCholFail += 1;
+        if (acc) st->nAccepted += 1;
         if (acc) {
             const double dec = st->cost - cost_new;
             st->cost = cost_new;
@@ -2202,6 +2214,7 @@ struct cs_ba {
     int device;
     int capC, capP, capObs;
     hipStream_t own_stream;
+    bool ownStreamIsOurs;  // false after cs_ba_set_stream: the caller's stream, not destroyed with the workspace
     // device buffers
     double *Ks, *Rs, *Ts, *pts, *Rn, *Tn, *Mn, *obs_xy, *Jc, *e, *W, *Vinv, *gp, *S, *rhs, *costPart, *stepPart, *schurPart, *scal;
     int *obs_ptr, *obs_cam, *obs_pt, *cam_ptr, *cam_obs, *obs_of, *outlier;
@@ -2236,6 +2249,22 @@ struct cs_ba {
     void* followupUser;
 };
 
+// solver breakdown is an error, not a silently unchanged estimate (the reference's callers catch what bundleAdjustRobust
+// throws: src/app/SL_CoSLAMRobustBA.cpp:173-179)
+static int ba_check_flags(int flags, const char* who) {
+    if (flags & 4) {
+        cs_set_error("%s: the dataflow Cholesky timed out waiting for a block column (a scheduling stall: another persistent kernel "
+                     "holds the CUs its workgroups need); the step was rejected -- results are not to be trusted", who);
+        return CS_ERR_NUMERIC;
+    }
+    if (flags & 2) {
+        cs_set_error("%s: the reduced camera system could not be factorised in any LM step (not positive definite or not finite) "
+                     "and no step was accepted: the estimate is unchanged", who);
+        return CS_ERR_NUMERIC;
+    }
+    return CS_OK;
+}
+
 static int ba_run_followup(cs_ba* b, hipStream_t s) {
     if (!b->followup) return CS_OK;
     const int rc = b->followup((void*)s, b->followupUser);
@@ -2245,6 +2274,9 @@ static int ba_run_followup(cs_ba* b, hipStream_t s) {
 
 static void ba_worker_drop_graphs(cs_ba* b);
 static void ba_drop_graph(cs_ba* b) {
+    // (callers on the API thread have drained the worker's queue -- cs_ba_wait -- before they get here; the worker itself gets
+    // here only from ba_make_plan when a scratch allocation grew, with the API thread blocked out of the workspace by the same
+    // rule: a queued job means every mutating entry point waits)
     if (b->gexec) (void)hipGraphExecDestroy(b->gexec);
     b->gexec = nullptr;
     ba_worker_drop_graphs(b);
@@ -2714,16 +2746,29 @@ struct BaWorker {
     hipGraphExec_t gHead = nullptr, gChunk = nullptr, gTail = nullptr, gRound = nullptr, gFinish = nullptr;
     int* h_state = nullptr;  // pinned {inner_done, all_done}
     hipEvent_t ev[2] = {nullptr, nullptr};
+    std::thread::id tid;     // the worker thread: the only one that destroys the graph handles above
+    bool stale = false;      // (under mu) another thread invalidated what the graphs bake in: re-capture before the next job
 };
 
-static void ba_worker_drop_graphs(cs_ba* b) {
-    BaWorker* w = b->worker;
-    if (!w) return;
+// The worker's graph handles are worker-private: any other thread only marks them stale (under the mutex) and the worker
+// destroys and re-captures them before its next job; every entry point that rewrites what they bake in (upload, solve_dev,
+// dist_begin, set_stream) waits for the queue to drain first (cs_ba_wait), so no job can be replaying them meanwhile.
+static void ba_worker_destroy_graphs(BaWorker* w) {
     for (hipGraphExec_t* g : {&w->gHead, &w->gChunk, &w->gTail, &w->gRound, &w->gFinish}) {
         if (*g) (void)hipGraphExecDestroy(*g);
         *g = nullptr;
     }
     w->haveGraphs = false;
+}
+static void ba_worker_drop_graphs(cs_ba* b) {
+    BaWorker* w = b->worker;
+    if (!w) return;
+    if (!w->th.joinable() || std::this_thread::get_id() == w->tid) {
+        ba_worker_destroy_graphs(w);
+        return;
+    }
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->stale = true;
 }
 
 template <class F>
@@ -2752,13 +2797,20 @@ static int ba_worker_run(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
     hipStream_t s = b->own_stream;
     CS_HIP(hipStreamWaitEvent(s, J.ready, 0));
     cs_ba::GraphKey key = {J.C, J.P, J.nObs, J.nCamsCon, J.nPtsCon, J.maxIter, J.innerMaxIter, J.maxErr, J.R0, J.T0, J.M0};
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        if (w->stale) {
+            ba_worker_destroy_graphs(w);
+            w->stale = false;
+        }
+    }
     BaPlan L;
     int rc = ba_make_plan(b, J.C, J.P, J.nObs, J.nCamsCon, J.nPtsCon, J.maxErr, J.innerMaxIter, false, &L);
     if (rc) return rc;
     const BaDev& D = L.D;
     const dim3 blk(256);
     if (!w->haveGraphs || memcmp(&key, &w->key, sizeof(key)) != 0) {
-        ba_worker_drop_graphs(b);
+        ba_worker_destroy_graphs(w);
         static const int envChunk = getenv("COSLAM_BA_CHUNK") ? atoi(getenv("COSLAM_BA_CHUNK")) : 0;
         w->chunk = envChunk > 0 ? envChunk : 5;
         if (w->chunk > J.innerMaxIter && J.innerMaxIter > 0) w->chunk = J.innerMaxIter;
@@ -2870,6 +2922,10 @@ static int ba_worker_run(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
 }
 
 static void ba_worker_main(cs_ba* b, BaWorker* w) {
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->tid = std::this_thread::get_id();
+    }
     for (;;) {
         BaAsyncJob J;
         {
@@ -2902,7 +2958,7 @@ static void ba_worker_stop(cs_ba* b) {
     }
     w->cv.notify_all();
     if (w->th.joinable()) w->th.join();
-    ba_worker_drop_graphs(b);
+    ba_worker_destroy_graphs(w);
     if (w->h_state) (void)hipHostFree(w->h_state);
     for (hipEvent_t e : w->ev)
         if (e) (void)hipEventDestroy(e);
@@ -2935,6 +2991,7 @@ cs_ba* cs_ba_create(int device) {
         delete b;
         return nullptr;
     }
+    b->ownStreamIsOurs = true;
     return b;
 }
 
@@ -2944,8 +3001,36 @@ void cs_ba_destroy(cs_ba* b) {
     ba_worker_stop(b);
     (void)hipStreamSynchronize(b->own_stream);
     ba_free(b);
-    (void)hipStreamDestroy(b->own_stream);
+    if (b->ownStreamIsOurs) (void)hipStreamDestroy(b->own_stream);
     delete b;
+}
+
+// The workspace's own stream: where the host-pointer entry points, cs_ba_solve_dev(NULL stream) and the asynchronous worker
+// enqueue.
+void* cs_ba_stream(cs_ba* b) { return b ? (void*)b->own_stream : nullptr; }
+
+// Replace it by the caller's stream -- e.g. one confined to a CU range (cs_stream_create_cu_range), so that the solve's short
+// dependent kernels never queue behind the per-frame streams' workgroups.  The caller keeps ownership of `hip_stream` (it must
+// outlive the workspace or the next cs_ba_set_stream); NULL restores a plain stream of the workspace's own.
+int cs_ba_set_stream(cs_ba* b, void* hip_stream) {
+    if (!b) {
+        cs_set_error("cs_ba_set_stream: null workspace");
+        return CS_ERR_INVALID;
+    }
+    const int wrc = cs_ba_wait(b);
+    if (wrc) return wrc;
+    CS_HIP(hipSetDevice(b->device));
+    CS_HIP(hipStreamSynchronize(b->own_stream));
+    ba_drop_graph(b);  // (graphs replay on whatever stream they are launched on, but the worker's were captured on the old one)
+    if (b->ownStreamIsOurs) (void)hipStreamDestroy(b->own_stream);
+    if (hip_stream) {
+        b->own_stream = (hipStream_t)hip_stream;
+        b->ownStreamIsOurs = false;
+    } else {
+        CS_HIP(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
+        b->ownStreamIsOurs = true;
+    }
+    return CS_OK;
 }
 
 int cs_ba_robust_h(cs_ba* b, int C, int P, int nObs, const double* Ks, double* Rs, double* Ts, double* pts,
@@ -2963,6 +3048,10 @@ int cs_ba_robust_h(cs_ba* b, int C, int P, int nObs, const double* Ks, double* R
     if (nCamsCon < 0 || nPtsCon < 0) {
         cs_set_error("cs_ba_robust: nCamsCon / nPtsCon must not be negative");
         return CS_ERR_INVALID;
+    }
+    {   // an asynchronous solve of this workspace may still be queued or running: it reads what this call rewrites
+        const int wrc = cs_ba_wait(b);
+        if (wrc) return wrc;
     }
     {
         // obs_ptr monotone; a point must not carry two measurements of the same view (the (point, view) table keeps one
@@ -3084,6 +3173,7 @@ int cs_ba_robust_h(cs_ba* b, int C, int P, int nObs, const double* Ks, double* R
     if (P > 0) memcpy(pts, b->h_io + L.pts, sizeof(double) * 3 * P);
     if (nObs > 0 && out_outlier) memcpy(out_outlier, b->h_ob + 64, sizeof(int) * nObs);
     if (stats) memcpy(stats, b->h_ob, sizeof(cs_ba_stats_dev));
+    if (maxIter > 0) return ba_check_flags(((const cs_ba_stats_dev*)b->h_ob)->flags, "cs_ba_robust");
     return CS_OK;
 }
 
@@ -3126,6 +3216,10 @@ int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const do
     if (!b || C > b->capC || P > b->capP || nObs > b->capObs) {
         cs_set_error("cs_ba_solve_dev: workspace not uploaded for this size");
         return CS_ERR_INVALID;
+    }
+    {   // queued asynchronous solves of this workspace use the same buffers and graph handles
+        const int wrc = cs_ba_wait(b);
+        if (wrc) return wrc;
     }
     CS_HIP(hipSetDevice(b->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
@@ -3199,6 +3293,10 @@ int cs_ba_dist_begin(cs_ba* b, void* hip_stream, int C, int P, int nObs, const d
     if (!b || C > b->capC || P > b->capP || nObs > b->capObs || pLo < 0 || pHi > P || pLo > pHi) {
         cs_set_error("cs_ba_dist_begin: workspace not uploaded for this size, or bad slice");
         return CS_ERR_INVALID;
+    }
+    {
+        const int wrc = cs_ba_wait(b);
+        if (wrc) return wrc;
     }
     CS_HIP(hipSetDevice(b->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
@@ -3305,8 +3403,10 @@ int cs_ba_download(cs_ba* b, int C, int P, int nObs, double* Rs, double* Ts, dou
     if (Ts) CS_HIP(hipMemcpy(Ts, b->Ts, sizeof(double) * 3 * C, hipMemcpyDeviceToHost));
     if (pts && P > 0) CS_HIP(hipMemcpy(pts, b->pts, sizeof(double) * 3 * P, hipMemcpyDeviceToHost));
     if (out_outlier && nObs > 0) CS_HIP(hipMemcpy(out_outlier, b->outlier, sizeof(int) * nObs, hipMemcpyDeviceToHost));
-    if (stats) CS_HIP(hipMemcpy(stats, b->stats, sizeof(cs_ba_stats), hipMemcpyDeviceToHost));
-    return CS_OK;
+    cs_ba_stats_dev sd;
+    CS_HIP(hipMemcpy(&sd, b->stats, sizeof(sd), hipMemcpyDeviceToHost));
+    if (stats) memcpy(stats, &sd, sizeof(cs_ba_stats));
+    return ba_check_flags(sd.flags, "cs_ba_download");
 }
 
 // bundleAdjustRobust as the reference runs it: on a worker thread next to tracking (src/app/SL_CoSLAM.cpp:1702-1784).

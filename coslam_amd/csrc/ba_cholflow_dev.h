@@ -178,6 +178,7 @@ __global__ __launch_bounds__(CF_NT) void k_cholflow(BaDev D, CholFlow F) {
     __syncthreads();
     if (tid == 0) {
         if (!okSh) D.st->chol_ok = 0;
+        if (!alive) D.st->solverTimeout = 1;  // a scheduling stall, not a non-positive-definite system: reported as such
         __hip_atomic_store(F.flagL + j, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef CF_PROBE
         if ((j == NB - 1 || j == NB / 2 || j == 1) && D.st->nIterTotal == 2) printf("cholflow column %d published at %llu (x 10 ns)\n", j, wall_clock64() - cfT0);
@@ -221,7 +222,10 @@ __global__ __launch_bounds__(CF_NT) void k_cholflow(BaDev D, CholFlow F) {
         cf_stores_done();
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
-            if (!alive) D.st->chol_ok = 0;
+            if (!alive) {
+                D.st->chol_ok = 0;
+                D.st->solverTimeout = 1;
+            }
             __hip_atomic_store(F.flagX + j, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef CF_PROBE
             if ((j == NB - 1 || j == NB / 2 || j == 0) && D.st->nIterTotal == 2) printf("cholflow x_%d published at %llu (x 10 ns)\n", j, wall_clock64() - cfT0);

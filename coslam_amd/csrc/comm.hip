@@ -247,6 +247,9 @@ int cs_ba_dist_solve(cs_ba* b, cs_comm* c, void* hip_stream, int C, int P, int n
         cs_set_error("cs_ba_dist_solve: bad arguments");
         return CS_ERR_INVALID;
     }
+    // ONE stream for the phases and the collectives: a NULL argument means the workspace's own stream for both (the phases
+    // would pick it on their own while the all-reduces went to the legacy null stream, unordered against them)
+    if (!hip_stream) hip_stream = cs_ba_stream(b);
     hipStream_t s = (hipStream_t)hip_stream;
     const int per = (P + c->world - 1) / c->world;
     int lo = c->rank * per;

@@ -396,9 +396,12 @@ int cs_ncc_match_between(int device, const unsigned char* img1, int W1, int H1, 
  * Robust multi-camera bundle adjustment
  * ------------------------------------------------------------------------------------------ */
 
+#define CS_BA_FLAG_CHOL_FAILED 1    /* at least one LM step's reduced system could not be factorised (the step was rejected) */
+#define CS_BA_FLAG_NO_PROGRESS 2    /* ... and NO step of the whole solve was accepted: the call returns CS_ERR_NUMERIC */
+#define CS_BA_FLAG_SOLVER_TIMEOUT 4 /* the dataflow Cholesky gave up waiting for a block column: CS_ERR_NUMERIC */
 typedef struct cs_ba_stats {
     double cost0, cost; /* sum of squared inlier residuals before / after */
-    int nIterTotal, nOuter, nOutliers, pad;
+    int nIterTotal, nOuter, nOutliers, flags; /* flags: CS_BA_FLAG_* */
 } cs_ba_stats;
 
 /* bundleAdjustRobust(int nCamsCon, vector<Mat_d>& Ks, vector<Mat_d>& Rs, vector<Mat_d>& Ts, int nPtsCon,
@@ -408,7 +411,10 @@ typedef struct cs_ba_stats {
  * Flat form: Ks/Rs (C x 9, row-major), Ts (C x 3), pts (P x 3); meas[i] = measurements obs_ptr[i]..obs_ptr[i+1]
  * with obs_cam = Meas2D::viewId and obs_xy = (Meas2D::x, Meas2D::y).  Rs, Ts, pts are updated in place (host
  * memory); out_outlier[nObs] receives Meas2D::outlier (may be NULL); the first nCamsCon cameras and the first
- * nPtsCon points are held fixed.  Returns CS_OK or a negative CS_ERR_* code. */
+ * nPtsCon points are held fixed.  Returns CS_OK or a negative CS_ERR_* code; CS_ERR_NUMERIC when the solver broke down
+ * (stats->flags has CS_BA_FLAG_NO_PROGRESS or CS_BA_FLAG_SOLVER_TIMEOUT; the arrays are still written back -- unchanged in the
+ * first case).  The C++ shim turns any error into an exception, which the reference's callers catch
+ * (src/app/SL_CoSLAMRobustBA.cpp:173-179). */
 int cs_ba_robust(int C, int P, int nObs, const double* Ks, double* Rs, double* Ts, double* pts, const int* obs_ptr,
                  const int* obs_cam, const double* obs_xy, int nCamsCon, int nPtsCon, double maxErr, int maxIter,
                  int innerMaxIter, int* out_outlier, cs_ba_stats* stats, int device);
@@ -417,6 +423,12 @@ int cs_ba_robust(int C, int P, int nObs, const double* Ks, double* Rs, double* T
 typedef struct cs_ba cs_ba;
 cs_ba* cs_ba_create(int device);
 void cs_ba_destroy(cs_ba* b);
+/* the stream the host-pointer entry points, cs_ba_solve_dev(NULL stream) and the asynchronous worker enqueue on; and a way to
+ * replace it by the caller's -- e.g. one confined to a CU range (cs_stream_create_cu_range) so that the solve's short
+ * dependent kernels never wait behind the per-frame streams' workgroups.  The caller keeps ownership; NULL restores the
+ * workspace's own.  Waits for queued asynchronous solves. */
+void* cs_ba_stream(cs_ba* b);
+int cs_ba_set_stream(cs_ba* b, void* hip_stream);
 int cs_ba_robust_h(cs_ba* b, int C, int P, int nObs, const double* Ks, double* Rs, double* Ts, double* pts,
                    const int* obs_ptr, const int* obs_cam, const double* obs_xy, int nCamsCon, int nPtsCon,
                    double maxErr, int maxIter, int innerMaxIter, int* out_outlier, cs_ba_stats* stats);

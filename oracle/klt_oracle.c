@@ -249,6 +249,11 @@ static float nogain_tree_sum(const float lanes[64]) {
     return (R[3] + R[2]) + (R[1] + R[0]);
 }
 
+/* threshold-margin diagnostic (defined with the gain tracker below): smallest relative distance of a tested quantity to its
+ * threshold, per slot */
+static void note_margin_rel(size_t k, float value, float thr);
+static void note_margin_region(size_t k, float X1x, float X1y, const float vr[4]);
+
 static int g_nogain_sum_mode = 0; /* 0 serial (the shader's loop order), 1 the HIP kernel's tree */
 void okl_set_nogain_sum_mode(int mode) { g_nogain_sum_mode = mode; }
 
@@ -316,6 +321,7 @@ void okl_track_nogain(const uint16_t* pyr0, const uint16_t* pyr1, int W, int H, 
                     rx = nogain_tree_sum(la[3]), ry = nogain_tree_sum(la[4]), SSD = nogain_tree_sum(la[5]);
                 }
                 float det = a * c - b * b;               /* :111 */
+                note_margin_rel((size_t)k, det, 0.00001f);
                 invalid = invalid || (det < 0.00001f);   /* :113 */
                 float rdet = 1.0f / det;                 /* :115 */
                 float dXx = rdet * (c * rx - b * ry);
@@ -326,9 +332,15 @@ void okl_track_nogain(const uint16_t* pyr0, const uint16_t* pyr1, int W, int H, 
                 dXy *= why;
                 sqrLen = dXx * dXx + dXy * dXy; /* :120 */
             }
+            note_margin_rel((size_t)k, sqrLen, sqrConv);
+            note_margin_rel((size_t)k, SSD, ssdThr);
             invalid = invalid || (sqrLen > sqrConv); /* :123 */
             invalid = invalid || (SSD > ssdThr);     /* :124 */
             mult /= (float)(1 << levelSkip);         /* :126 */
+        }
+        {
+            const float vr[4] = {vr0, vr1, vr2, vr3};
+            note_margin_region((size_t)k, X1x, X1y, vr);
         }
         invalid = invalid || (X1x < vr0 || X1y < vr1) || (X1x > vr2 || X1y > vr3); /* :129 */
         if (invalid || !(X1x == X1x) || !(X1y == X1y)) {
@@ -349,6 +361,19 @@ void okl_track_nogain(const uint16_t* pyr0, const uint16_t* pyr1, int W, int H, 
  * two summation orders must sit within ~1 % of one of them. */
 static float* g_thr_margin = NULL;
 void okl_set_threshold_margin_buffer(float* perSlot) { g_thr_margin = perSlot; }
+
+static void note_margin_rel(size_t k, float value, float thr) {
+    if (!g_thr_margin) return;
+    const float m = fabsf(value - thr) / thr;
+    if (!(m >= g_thr_margin[k])) g_thr_margin[k] = m;
+}
+static void note_margin_region(size_t k, float X1x, float X1y, const float vr[4]) {
+    if (!g_thr_margin || !(vr[0] > 0.0f)) return;
+    float m = fminf(fabsf(X1x - vr[0]), fabsf(X1x - vr[2])) / vr[0];
+    const float t = fminf(fabsf(X1y - vr[1]), fabsf(X1y - vr[3])) / vr[1];
+    if (t < m) m = t;
+    if (!(m >= g_thr_margin[k])) g_thr_margin[k] = m;
+}
 
 static void note_margin(size_t k, float det, float SSD, float ssdThr, float sqrLen, float sqrConvThr, float X1x, float X1y,
                         const float vr[4]) {

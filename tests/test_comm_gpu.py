@@ -74,6 +74,15 @@ def test_single_rank_communicator_exchange_and_sliced_ba(hip):
     sane = np.linalg.norm(M_o, axis=1) < 1e3   # (a two-view point with a gross outlier runs off along its ray on both sides)
     assert np.max(np.abs(Rg - R_o)) < 1e-6 and np.max(np.abs(Tg - T_o)) < 1e-6 and np.max(np.abs(Mg[sane] - M_o[sane])) < 1e-5
     assert abs(st_g.cost - st_o.cost) <= 1e-7 * max(1.0, st_o.cost)
+    # the same through torch's DEFAULT stream (cuda_stream == 0 -> NULL at the C-ABI): phases and all-reduces must land on
+    # one and the same stream (the workspace's own), not the phases there and the collectives on the legacy null stream
+    d1 = [torch.from_numpy(pr[k].reshape(-1).copy()).to(dev) for k in ("Rs0", "ts0", "pts0")]
+    torch.cuda.synchronize()
+    multicam.bundle_adjust_sliced(ws, torch.cuda.default_stream(dev), d1[0].data_ptr(), d1[1].data_ptr(), d1[2].data_ptr(),
+                                  pr["n_cams_con"], pr["n_pts_con"], 6.0, 2, 10, 0, native=comm)
+    R1, T1, M1, out1, st1 = ws.download()
+    assert np.array_equal(out1, out_g) and st1.nIterTotal == st_g.nIterTotal
+    assert np.array_equal(R1, Rg) and np.array_equal(T1, Tg) and np.array_equal(M1, Mg)
     ws.close()
     comm.close()
 

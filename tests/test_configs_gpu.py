@@ -29,7 +29,7 @@ def test_cfg5_klt_1080p_5000_slots_matches_oracle(hip):
     cfg = cfg2(minDistance=8)
     trk = coslam_amd.KLT_SequenceTracker(cfg, 0)
     trk.allocate(W, H, L, fw, fh)
-    ora = oracle.SequenceTracker(cfg)
+    ora = oracle.SequenceTracker(cfg, sum_mode=1)   # the HIP tracker's summation tree: bit for bit
     ora.allocate(W, H, L, fw, fh)
     n_g, d_g = trk.detect(im0)
     n_o, d_o = ora.detect(im0)
@@ -42,11 +42,24 @@ def test_cfg5_klt_1080p_5000_slots_matches_oracle(hip):
     ora.advanceFrame()
     n_g, d_g = trk.redetect(im1)
     n_o, d_o = ora.redetect(im1)
-    same = d_g["status"] == d_o["status"]
-    assert same.mean() > 0.995
-    both = same & (d_o["status"] == 0)
-    err = np.abs(d_g["pos"][both] - d_o["pos"][both]) * np.array([W, H], dtype=np.float32)
-    assert both.sum() > 1500 and err.max() < 0.02
+    assert n_g == n_o
+    assert np.array_equal(d_g["status"], d_o["status"])
+    live = d_o["status"] >= 0
+    assert (d_o["status"] == 0).sum() > 1500
+    assert np.array_equal(d_g["pos"][live], d_o["pos"][live]) and np.array_equal(d_g["gain"][live], d_o["gain"][live])
+    assert np.array_equal(trk.read_features(), ora.read_features())
+    trk.close()
+    # the same frame pair against the SHADER's serial summation order, from identical state (track, so that a status
+    # difference cannot move the detector's slot fill): <= 0.02 px, every status difference within 1 % of a threshold
+    from tests.test_klt_gpu import assert_serial_order_differs_only_at_thresholds, serial_track_with_margins
+
+    trk = coslam_amd.KLT_SequenceTracker(cfg, 0)
+    trk.allocate(W, H, L, fw, fh)
+    trk.detect(im0)
+    trk.advanceFrame()
+    _, d_t = trk.track(im1)
+    d_s, margin = serial_track_with_margins(cfg, W, H, L, fw, fh, im0, im1)
+    assert_serial_order_differs_only_at_thresholds(d_t, d_s, margin, W, H, "cfg5 1080p")
     trk.close()
 
 

@@ -202,10 +202,52 @@ def test_ba_edge_cases(hip):
         coslam_amd.bundleAdjustRobust(2, pr["Ks"], Rs2, Ts2, 2, pts2, (ptr2, bad, xy2), 6.0, 1, 1)
 
 
+def test_solver_breakdown_is_an_error_not_an_unchanged_estimate(hip):
+    """A reduced system that cannot be factorised in ANY LM step (here: an infinite depth offset in a free camera's
+    translation -- projections inf / inf, Jacobians and therefore pivots not-a-number) used to return CS_OK with the input
+    untouched.  Now: stats.flags carries CS_BA_FLAG_CHOL_FAILED |
+    CS_BA_FLAG_NO_PROGRESS and the call returns CS_ERR_NUMERIC -- which the C++ shim throws and the reference's callers
+    catch (src/app/SL_CoSLAMRobustBA.cpp:173-179).  A healthy problem reports flags == 0."""
+    import ctypes as C
+
+    pr, ptr, cam, xy = ba_inputs(n_cams=6, n_pts=80, n_cams_con=2, n_pts_con=2, outlier_frac=0.0, seed=5)
+    Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+    out, st = coslam_amd.bundleAdjustRobust(2, pr["Ks"], Rs, Ts, 2, pts, (ptr, cam, xy), 6.0, 2, 10)
+    assert st.flags == 0 and st.nIterTotal > 0
+    for n_cams, n_pts in ((6, 80), (12, 200)):       # register solver (order 24) and k_solve_blocked (order 60)
+        pr, ptr, cam, xy = ba_inputs(n_cams=n_cams, n_pts=n_pts, n_cams_con=2, n_pts_con=2, outlier_frac=0.0, seed=5)
+        Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+        Ts[3, 2] = np.inf
+        with pytest.raises(coslam_amd.CoslamHipError, match="code -5"):
+            coslam_amd.bundleAdjustRobust(2, pr["Ks"], Rs, Ts, 2, pts, (ptr, cam, xy), 6.0, 2, 10)
+        # the device-resident form: the solve runs, download reports it
+        ws = coslam_amd.BAWorkspace(0)
+        bad = pr["ts0"].copy()
+        bad[3, 2] = np.inf
+        ws.upload(pr["Ks"], pr["Rs0"], bad, pr["pts0"], ptr, cam, xy)
+        import torch
+
+        d0 = [torch.from_numpy(a.reshape(-1).copy()).cuda() for a in (pr["Rs0"], bad, pr["pts0"])]
+        ws.solve_dev(0, d0[0].data_ptr(), d0[1].data_ptr(), d0[2].data_ptr(), 2, 2, 6.0, 2, 10)
+        with pytest.raises(coslam_amd.CoslamHipError, match="code -5"):
+            ws.download()
+        st = coslam_amd.BAStats()
+        lib = coslam_amd.lib()
+        rc = lib.cs_ba_download(ws._h, ws.C, ws.P, ws.nObs, None, None, None, None, C.byref(st))
+        assert rc == -5 and (st.flags & 3) == 3 and st.nIterTotal > 0
+        ws.close()
+
+
 # ---- the headline workload's two bundleAdjustRobust calls, and the solver / schedule they run through ---------------
-def _headline_problems():
+def _headline_problems(which="test"):
+    """which = "bench": exactly the two problems bench.py solves at every key frame (its own builders and seeds);
+    "test": the same generators with other seeds"""
     from coslam_amd.synth import make_intercam_problem, make_joint_ba_problem
 
+    if which == "bench":
+        import bench
+
+        return bench.build_ba_problems(bench.build_scene())
     sc = Scene(8, 640, 480, 7000, seed=0xC051A + 2, sigma=1.0)
     return make_joint_ba_problem(sc, seed=0xC051A + 9), make_intercam_problem(sc, seed=0xC051A + 13)
 
@@ -226,10 +268,11 @@ def _check_vs_oracle(pr, ptr, cam, xy, ncon, npcon, maxErr, maxIter, inner, Rs, 
     assert abs(st_g.cost - st_o.cost) <= 1e-7 * max(1.0, st_o.cost)
 
 
-def test_joint_local_ba_of_the_eight_camera_rig_matches_oracle(hip):
+@pytest.mark.parametrize("which", ["test", "bench"])
+def test_joint_local_ba_of_the_eight_camera_rig_matches_oracle(hip, which):
     """RobustBundleRTS at a key frame (src/app/SL_CoSLAMRobustBA.cpp:109-180 via SL_CoSLAM.cpp:1731-1784): 5 key frames x 8
     cameras = 40 cameras, the 16 oldest fixed, 2 points fixed, maxIter 2 / inner 10: order-144 reduced system."""
-    joint, _ = _headline_problems()
+    joint, _ = _headline_problems(which)
     ptr, cam, xy = _csr(joint)
     Rs, Ts, pts = joint["Rs0"].copy(), joint["ts0"].copy(), joint["pts0"].copy()
     out, st = coslam_amd.bundleAdjustRobust(joint["n_cams_con"], joint["Ks"], Rs, Ts, joint["n_pts_con"], pts, (ptr, cam, xy),
@@ -238,10 +281,11 @@ def test_joint_local_ba_of_the_eight_camera_rig_matches_oracle(hip):
     assert np.max(np.abs(Ts - joint["ts_gt"])) < 0.02  # and it actually solves the problem
 
 
-def test_inter_camera_pose_solve_of_the_eight_camera_rig_matches_oracle(hip):
+@pytest.mark.parametrize("which", ["test", "bench"])
+def test_inter_camera_pose_solve_of_the_eight_camera_rig_matches_oracle(hip, which):
     """InterCamPoseEstimator::apply (src/app/SL_InterCamPoseEstimator.cpp:92-95): 8 cameras free, 1536 single-view static
     points fixed, 60 dynamic points free, sigma 6, maxIter 3, 40 inner steps: order-48 reduced system."""
-    _, ic = _headline_problems()
+    _, ic = _headline_problems(which)
     ptr, cam, xy = _csr(ic)
     Rs, Ts, pts = ic["Rs0"].copy(), ic["ts0"].copy(), ic["pts0"].copy()
     out, st = coslam_amd.bundleAdjustRobust(0, ic["Ks"], Rs, Ts, ic["n_static"], pts, (ptr, cam, xy), 6.0, 3, 40)
