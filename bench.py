@@ -247,6 +247,14 @@ def main():
                     help="cameras per persistent tracker launch (0 = as many as are co-resident: all 8 at two waves per SIMD). 4 = two "
                          "launches of four cameras back to back at ONE wave per SIMD: every SIMD keeps a free wave slot (and every CU "
                          "96 KB of LDS) for the key-frame solves' kernels")
+    ap.add_argument("--reg-stream", type=int, default=int(os.environ.get("BENCH_REG_STREAM", "1")),
+                    help="1: the two registration passes of frame f on their own stream behind pose(f) -- they are consumers of the "
+                         "frame's poses and features, nothing of frame f+1's tracking or pose depends on them, so they overlap the next "
+                         "frame's tracker (hand-back(f+1) waits for them: it rewrites the records they read); 0: on the pose stream")
+    ap.add_argument("--ba-persist", default=os.environ.get("BENCH_BA_PERSIST", ""),
+                    help="GJ:GI -- the LM loops of the joint BA / the inter-camera solve as ONE cooperative launch of at most GJ / GI "
+                         "workgroups each (cs_ba_set_persistent: a compute unit per workgroup, kept for the whole run); the tracker is "
+                         "budgeted for the other 256 - GJ - GI compute units")
     ap.add_argument("--ba-cus", default=os.environ.get("BENCH_BA_CUS", ""), help="FIRST:COUNT -- the joint BA's stream confined to these CU-mask bits")
     ap.add_argument("--ic-cus", default=os.environ.get("BENCH_IC_CUS", ""), help="FIRST:COUNT -- the inter-camera solve's stream confined to these CU-mask bits")
     ap.add_argument("--pose-cus", default=os.environ.get("BENCH_POSE_CUS", ""), help="FIRST:COUNT -- the pose stream (hand-back, pose, registration) confined to these CU-mask bits")
@@ -356,6 +364,7 @@ def main():
     pose_s = klt_s if args.serial else (torch.cuda.ExternalStream(masked_stream(args.pose_cus), device=dev) if args.pose_cus
                                         else torch.cuda.Stream(device=dev))
     ba_s = klt_s if args.serial else torch.cuda.Stream(device=dev)   # N > 1: the sliced joint BA and its collectives
+    reg_s = torch.cuda.Stream(device=dev) if (args.reg_stream and not args.serial) else pose_s
 
     trks = []
     for _ in my_cams:
@@ -367,6 +376,12 @@ def main():
     if args.klt_cus > 0:
         for t in trks:
             t.set_cu_count(args.klt_cus)
+    persist_j = persist_i = 0
+    if args.ba_persist:
+        persist_j, persist_i = (int(v) for v in args.ba_persist.split(":"))
+        if not args.klt_cus and args.klt_cams_per_launch <= 0:
+            for t in trks:
+                t.set_cu_count(256 - persist_j - persist_i)
     if args.klt_cams_per_launch > 0 and not args.klt_cus:
         # the co-residency budget of the persistent tracker is what decides how many cameras share a launch: hand it the
         # budget of cams_per_launch cameras (250 waves each, 8 resident waves per CU) -- no CU mask, the launches still spread
@@ -380,6 +395,8 @@ def main():
     if args.ba_cus:
         ba_ws.set_stream(masked_stream(args.ba_cus))
     ba_ws.upload(joint["Ks"], joint["Rs0"], joint["ts0"], joint["pts0"], jptr, jcam, jxy)
+    if persist_j:
+        ba_ws.set_persistent(persist_j)
     d_jR = torch.from_numpy(joint["Rs0"].reshape(-1).copy()).to(dev)
     d_jT = torch.from_numpy(joint["ts0"].reshape(-1).copy()).to(dev)
     d_jM = torch.from_numpy(joint["pts0"].reshape(-1).copy()).to(dev)
@@ -415,6 +432,8 @@ def main():
     if args.ic_cus:
         ic_ws.set_stream(masked_stream(args.ic_cus))
     ic_ws.upload(ic["Ks"], ic["Rs0"], ic["ts0"], ic["pts0"], iptr, icam, ixy)
+    if persist_i:
+        ic_ws.set_persistent(persist_i)
     d_iR = torch.from_numpy(ic["Rs0"].reshape(-1).copy()).to(dev)
     d_iT = torch.from_numpy(ic["ts0"].reshape(-1).copy()).to(dev)
     d_iM = torch.from_numpy(ic["pts0"].reshape(-1).copy()).to(dev)
@@ -436,6 +455,7 @@ def main():
     klt_done = [torch.cuda.Event(), torch.cuda.Event()]
     dest_free = [torch.cuda.Event(), torch.cuda.Event()]
     pose_done = torch.cuda.Event()
+    pose_ready, reg_done = torch.cuda.Event(), torch.cuda.Event()
 
     def hb_cams(b):
         return [dict(dest=d_dests[b][i].data_ptr(), K=d_K1.data_ptr(), kud=d_kud.data_ptr(), mapPts=d_map.data_ptr(),
@@ -450,6 +470,8 @@ def main():
     img_ptrs = [[d_frames[i][f].data_ptr() for i in range(nc)] for f in range(N_FRAMES)]
 
     def pose_leg(b, i):
+        if reg_s is not pose_s and i >= 2 and not args.no_register:
+            pose_s.wait_event(reg_done)     # the registration of the previous frame reads the records this hand-back rewrites
         handback_dev(pose_s.cuda_stream, hb_args[b], N_FEAT, W, H, N_COL_BLK, N_ROW_BLK, PTS_STRIDE, device=local_rank,
                      frame=i)
         src, dst = (i + 1) & 1, i & 1
@@ -458,7 +480,12 @@ def main():
                                    d_R[dst].data_ptr(), d_t[dst].data_ptr(), d_opt.data_ptr(), d_ok.data_ptr(),
                                    device=local_rank)
         if not args.no_register:
+            if reg_s is not pose_s:
+                pose_ready.record(pose_s)
+                reg_s.wait_event(pose_ready)
             register_leg(dst)
+            if reg_s is not pose_s:
+                reg_done.record(reg_s)
 
     def reg_cams(dst):
         return [dict(K=d_K1.data_ptr(), R=d_R[dst].data_ptr() + 72 * i, t=d_t[dst].data_ptr() + 24 * i, xy=d_xy[i].data_ptr(),
@@ -470,7 +497,7 @@ def main():
         # CoSLAMThread.cpp:108 activeMapPointsRegister, then :117 currentMapPointsRegister (static points), search step
         for k, (pts_off, pf, sS) in enumerate(((P_REG, d_pf_none, 2.5 * PIXEL_ERR_VAR), (0, d_pf, PIXEL_ERR_VAR))):
             o = reg_out[k]
-            register_search_dev(pose_s.cuda_stream, reg_args[dst], N_FEAT, W, H, P_REG, d_map.data_ptr() + 24 * pts_off,
+            register_search_dev(reg_s.cuda_stream, reg_args[dst], N_FEAT, W, H, P_REG, d_map.data_ptr() + 24 * pts_off,
                                 d_cov.data_ptr() + 72 * pts_off, pf.data_ptr(), sS, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR,
                                 o["slot"].data_ptr(), o["m"].data_ptr(), o["var"].data_ptr(), o["dist"].data_ptr(),
                                 o["flags"].data_ptr(), device=local_rank)

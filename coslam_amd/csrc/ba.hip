@@ -58,6 +58,8 @@ namespace {
 struct BaState {
     double lambda, cost, cost_new, step2, cost0;
     int inner_it, inner_done, all_done, chol_ok, changed, nIterTotal, nOuter, nOutliers, first_cost;
+    int pending;        // packed path: a tentative step awaits its accept / reject (decided by the next k_lin_packed)
+    int cur;            // packed path: which estimate is current: 0 = Rs / Ts / pts, 1 = Rn / Tn / Mn
     int nCholFail;      // LM steps whose reduced system could not be factorised (not positive definite, NaN, time-out)
     int nAccepted;      // LM steps that were accepted
     int solverTimeout;  // the dataflow Cholesky gave up waiting for a block column (scheduling stall, not arithmetic)
@@ -85,6 +87,11 @@ struct BaDev {
     const int4* pairEnt;
     double maxErr;
     int innerMaxIter;
+    // packed path (ba_packed_dev.h): whole points back to back in the lanes of a wave
+    const int* waveStart;  // [nPackWaves + 1] first measurement of every wave
+    int nPackWaves;
+    double* Y;             // [nObs][18]  W V^-1
+    BaState* stn;          // the state the launch writes (see ba_packed_dev.h)
 };
 
 __device__ __forceinline__ double wsum(double v) { return cs_wave_sum_d(v); }
@@ -1173,16 +1180,29 @@ __device__ __forceinline__ void sb_panel_mfma(double* A, int I, int kb, int lane
 #endif
 #include "ba_cholflow_dev.h"
 
-__global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
-    if (CS_SOLVE_PRIO) __builtin_amdgcn_s_setprio(CS_SOLVE_PRIO);
-    const int stAllDone = D.st->all_done, stInnerDone = D.st->inner_done;  // (consumed after the matrix loads are in flight)
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ int okFlag;
-    const int n = D.n, tid = threadIdx.x, NT = 1024;
-    if (n == 0) {
-        if (tid == 0) D.st->chol_ok = 1;
-        return;
-    }
+// memory flavour of the solver's (and the packed LM-step functions') traffic: plain when a kernel boundary separates producer
+// and consumer, relaxed agent-scope atomics (sc1: never served from a stale L1 / non-coherent L2 line) when both run inside
+// ONE launch (ba_persist_dev.h)
+template <bool COH>
+__device__ __forceinline__ double ldm(const double* p) {
+    if (COH) return cf_ld(p);
+    return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void stm(double* p, double v) {
+    if (COH)
+        cf_st(p, v);
+    else
+        *p = v;
+}
+
+// NW waves (16: k_solve_blocked's own workgroup; 8: inside the persistent LM kernel); n > 0; `skip` = the LM state says there
+// is nothing to do (evaluated by the caller, consumed behind the matrix loads); *okFlagP (shared) = 1 iff every pivot was
+// positive.  Which wave takes which block does not enter the arithmetic: the result is the same for every NW.
+template <int NW, bool COH>
+__device__ __forceinline__ void sb_solve_body(const BaDev& D, double* sm, int* okFlagP, const bool skip) {
+    const int n = D.n, tid = threadIdx.x;
+    constexpr int NT = NW * 64;
     const int NB = (n + SB - 1) / SB, NBT = NB * (NB + 1) / 2;
 #ifdef CS_SOLVE_PROBE
     unsigned long long pT0 = __builtin_amdgcn_s_memtime(), pLoad = 0, pDiag = 0, pPanel = 0, pTrail = 0, pBack = 0, pT = 0;
@@ -1204,11 +1224,11 @@ __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
     {
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
         const int r = ln >> 2, c0 = (ln & 3) * 4;
-        constexpr int MAXB = 5;  // ceil(66 blocks / 16 waves)
+        constexpr int MAXB = (66 + NW - 1) / NW;  // 66 blocks at order 176
         double v[MAXB][4];
 #pragma unroll
         for (int q = 0; q < MAXB; ++q) {
-            const int blk = wv + q * 16;
+            const int blk = wv + q * NW;
             if (blk < NBT) {
                 int I = 0;
                 while ((I + 1) * (I + 2) / 2 <= blk) ++I;
@@ -1217,22 +1237,22 @@ __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     v[q][u] = (gi == gj + u) ? 1.0 : 0.0;
-                    if (gi < n && gj + u < n) v[q][u] = D.S[(size_t)gi * n + gj + u];
+                    if (gi < n && gj + u < n) v[q][u] = ldm<COH>(&D.S[(size_t)gi * n + gj + u]);
                 }
             }
         }
-        if (stAllDone || stInnerDone) return;  // !BA_ACTIVE (uniform); tested here so that it is not one more dependent trip
+        if (skip) return;  // !BA_ACTIVE (uniform); tested here so that it is not one more dependent trip
 #pragma unroll
         for (int q = 0; q < MAXB; ++q) {
-            const int blk = wv + q * 16;
+            const int blk = wv + q * NW;
             if (blk < NBT) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) A[blk * SBLK + r * SP + c0 + u] = v[q][u];
             }
         }
     }
-    for (int q = tid; q < NB * SB; q += NT) b[q] = (q < n) ? D.rhs[q] : 0.0;
-    if (tid == 0) okFlag = 1;
+    for (int q = tid; q < NB * SB; q += NT) b[q] = (q < n) ? ldm<COH>(&D.rhs[q]) : 0.0;
+    if (tid == 0) *okFlagP = 1;
     __syncthreads();
 #ifdef CS_SOLVE_PROBE
     pT = __builtin_amdgcn_s_memtime();
@@ -1241,7 +1261,7 @@ __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
     // the first diagonal block; every later one is factored by wave 0 NEXT TO the trailing update of the step before
     // (look-ahead), so the serial column chain -- the longest phase -- is off the critical path
     if (tid < 64) {
-        if (!sb_factor_diag(A + sb_off(0, 0), tid) && tid == 0) okFlag = 0;
+        if (!sb_factor_diag(A + sb_off(0, 0), tid) && tid == 0) *okFlagP = 0;
     }
     __syncthreads();
     CS_PROBE(pDiag);
@@ -1252,8 +1272,8 @@ __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
         const int m = NB - kb - 1;
         {
             const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
-            for (int I = kb + 1 + wv; I < NB; I += 16) sb_panel_mfma(A, I, kb, ln);
-            if (wv == 15 && ln < SB) {
+            for (int I = kb + 1 + wv; I < NB; I += NW) sb_panel_mfma(A, I, kb, ln);
+            if (wv == NW - 1 && ln < SB) {
                 const double* Li = A + sb_off(kb, kb) + ln * SP;
                 double acc = 0.0;
 #pragma unroll
@@ -1271,11 +1291,11 @@ __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (!sb_factor_diag(A + sb_off(kb + 1, kb + 1), tid) && tid == 0) okFlag = 0;
+            if (!sb_factor_diag(A + sb_off(kb + 1, kb + 1), tid) && tid == 0) *okFlagP = 0;
         } else {
-            const int wv = __builtin_amdgcn_readfirstlane((tid >> 6) - 1), ln = tid & 63;  // 0..14
+            const int wv = __builtin_amdgcn_readfirstlane((tid >> 6) - 1), ln = tid & 63;  // 0..NW-2
             const int nBlk = m * (m + 1) / 2;
-            for (int blk = 1 + wv; blk < nBlk; blk += 15) {  // block 0 of the list is wave 0's (kb + 1, kb + 1)
+            for (int blk = 1 + wv; blk < nBlk; blk += NW - 1) {  // block 0 of the list is wave 0's (kb + 1, kb + 1)
                 int bi = 0;
                 while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
                 const int bj = blk - bi * (bi + 1) / 2;
@@ -1317,8 +1337,7 @@ __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
         }
         __syncthreads();
     }
-    for (int q = tid; q < n; q += NT) D.rhs[q] = b[q];
-    if (tid == 0) D.st->chol_ok = okFlag;
+    for (int q = tid; q < n; q += NT) stm<COH>(&D.rhs[q], b[q]);
 #ifdef CS_SOLVE_PROBE
     CS_PROBE(pBack);
     if (tid == 0 && D.st->nIterTotal == 3)
@@ -1326,6 +1345,20 @@ __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
                pDiag, pPanel, pTrail, pBack, __builtin_amdgcn_s_memtime() - pT0);
 #endif
 #undef CS_PROBE
+}
+
+__global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
+    if (CS_SOLVE_PRIO) __builtin_amdgcn_s_setprio(CS_SOLVE_PRIO);
+    const int stAllDone = D.st->all_done, stInnerDone = D.st->inner_done;  // (consumed after the matrix loads are in flight)
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int okFlag;
+    if (D.n == 0) {
+        if (threadIdx.x == 0) D.st->chol_ok = 1;
+        return;
+    }
+    sb_solve_body<16, false>(D, sm, &okFlag, stAllDone || stInnerDone);
+    if (stAllDone || stInnerDone) return;
+    if (threadIdx.x == 0) D.st->chol_ok = okFlag;  // (behind the body's last workgroup barrier)
 }
 
 // ---- one WAVE: reduced camera system of order n <= 64 -------------------------------------------------
@@ -1861,6 +1894,8 @@ __global__ __launch_bounds__(256) void k_control(BaDev D) {  // phase 0
         st->inner_done = (D.innerMaxIter <= 0) ? 1 : 0;
         st->changed = 0;  // k_outer_begin's job, for the k_flag at the end of this round
         st->nOutliers = 0;
+        st->pending = 0;
+        st->cur = 0;
         if (st->first_cost) {
             st->cost0 = cost_sum;
             st->first_cost = 0;
@@ -1961,6 +1996,9 @@ __global__ __launch_bounds__(256) void k_control_step(BaDev D) {
     }
 }
 
+#include "ba_packed_dev.h"
+#include "ba_persist_dev.h"
+
 // ---- outer loop: outlier flags ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_flag(BaDev D) {
     BaState* st = D.st;
@@ -2002,6 +2040,7 @@ __global__ __launch_bounds__(256) void k_init_state(BaState* st, int* outlier, i
     z.cost = z.cost_new = z.step2 = z.cost0 = 0;
     z.inner_it = z.inner_done = z.all_done = z.chol_ok = z.changed = z.nIterTotal = z.nOuter = z.nOutliers = 0;
     z.nCholFail = z.nAccepted = z.solverTimeout = 0;
+    z.pending = z.cur = 0;
     z.first_cost = 1;
     *st = z;
 }
@@ -2205,6 +2244,13 @@ struct BaPlan {
     bool legacySolve;  // COSLAM_BA_LEGACY_SOLVE=1: k_solve_wave / k_solve<256> / HBM-blocked Cholesky (A/B runs)
     bool cholFlow;     // orders beyond the LDS solver: the one-launch dataflow Cholesky (ba_cholflow_dev.h)
     CholFlow F;
+    bool packed;       // orders 37..176 with pair lists, no point with more than 64 measurements: ba_packed_dev.h
+    int gPack;
+    bool persist;      // ... and a run of LM steps as ONE cooperative launch of persistG workgroups (ba_persist_dev.h)
+    int persistG;
+    size_t persistLds;
+    int* persistBar;
+    BaDev DB;          // packed path: the same launch arguments with the two LM state words swapped
     bool syrk;         // large orders without pair lists: the Schur sum as Z Z^T on the f64 matrix cores (ba_syrk_dev.h)
     SyrkDev Y;
     size_t syrkZtBytes;
@@ -2216,7 +2262,8 @@ struct cs_ba {
     hipStream_t own_stream;
     bool ownStreamIsOurs;  // false after cs_ba_set_stream: the caller's stream, not destroyed with the workspace
     // device buffers
-    double *Ks, *Rs, *Ts, *pts, *Rn, *Tn, *Mn, *obs_xy, *Jc, *e, *W, *Vinv, *gp, *S, *rhs, *costPart, *stepPart, *schurPart, *scal;
+    double *Ks, *Rs, *Ts, *pts, *Rn, *Tn, *Mn, *obs_xy, *Jc, *e, *W, *Vinv, *gp, *S, *rhs, *costPart, *stepPart, *schurPart, *scal, *Y;
+    BaState* st2;
     int *obs_ptr, *obs_cam, *obs_pt, *cam_ptr, *cam_obs, *obs_of, *outlier;
     BaState* st;
     cs_ba_stats_dev* stats;
@@ -2233,6 +2280,11 @@ struct cs_ba {
     int4* pairEnt;
     size_t pairPtrCap, pairEntCap;
     bool havePairs;
+    int persistWGs;  // cs_ba_set_persistent: compute units the LM loop may keep for itself (0: one launch per phase)
+    int* persistBar; // [16] barrier counter | chol_ok | time-out flag of the cooperative launch
+    int* waveStart;  // packed lane plan of the uploaded problem (own allocation), nPackWaves waves; 0 = none
+    size_t waveStartCap;
+    int nPackWaves;
     // cached executable graph of one full solve (cs_ba_solve_dev): ~150 launches become one
     struct GraphKey {
         int C, P, nObs, nCamsCon, nPtsCon, maxIter, innerMaxIter;
@@ -2288,6 +2340,12 @@ static int ba_free(cs_ba* b) {
     b->dist = nullptr;
     if (b->pairPtr) (void)hipFree(b->pairPtr);
     if (b->pairEnt) (void)hipFree(b->pairEnt);
+    if (b->persistBar) (void)hipFree(b->persistBar);
+    b->persistBar = nullptr;
+    if (b->waveStart) (void)hipFree(b->waveStart);
+    b->waveStart = nullptr;
+    b->waveStartCap = 0;
+    b->nPackWaves = 0;
     b->pairPtr = nullptr;
     b->pairEnt = nullptr;
     b->pairPtrCap = b->pairEntCap = 0;
@@ -2303,7 +2361,8 @@ static int ba_free(cs_ba* b) {
     if (b->h_ob) (void)hipHostFree(b->h_ob);
     b->slab = nullptr;
     b->Rn = b->Tn = b->Mn = b->Jc = b->e = b->W = b->Vinv = b->gp = b->S = b->costPart = b->stepPart = b->schurPart = b->scal =
-        nullptr;
+        b->Y = nullptr;
+    b->st2 = nullptr;
     b->obs_pt = b->obs_of = nullptr;
     b->st = nullptr;
     b->io = b->ob = b->h_io = b->h_ob = nullptr;
@@ -2368,6 +2427,7 @@ static int ba_reserve(cs_ba* b, int C, int P, int nObs) {
     };
     const Piece pieces[] = {
         {(void**)&b->st, sizeof(BaState)},
+        {(void**)&b->st2, sizeof(BaState)},
         {(void**)&b->scal, 8 * sizeof(double)},
         {(void**)&b->costPart, (1024 + cP / 4 + cC / 256 + 2) * sizeof(double)},
         {(void**)&b->stepPart, (cP + cC + 1) * sizeof(double)},
@@ -2383,6 +2443,7 @@ static int ba_reserve(cs_ba* b, int C, int P, int nObs) {
         {(void**)&b->e, (2 * cO + 1) * sizeof(double)},
         {(void**)&b->Jc, (12 * cO + 1) * sizeof(double)},
         {(void**)&b->W, (18 * cO + 1) * sizeof(double)},
+        {(void**)&b->Y, (18 * cO + 1) * sizeof(double)},
         {(void**)&b->obs_pt, (cO + 1) * sizeof(int)},
         {(void**)&b->obs_of, (cP * cC + 1) * sizeof(int)},
     };
@@ -2453,6 +2514,10 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
     D.pHi = P;
     D.addLambda = 1;
     D.maxObsPerPoint = b->maxObs;
+    D.Y = b->Y;
+    D.stn = b->st2;
+    D.waveStart = b->waveStart;
+    D.nPackWaves = b->nPackWaves;
     int cb = (nObs + 255) / 256;
     if (cb < 1) cb = 1;
     if (cb > 1024) cb = 1024;
@@ -2580,6 +2645,55 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
             L.syrk = true;
         }
     }
+    // orders 37..176 with pair lists and a lane plan: the kernels that fit a few compute units (COSLAM_BA_PACKED=0: the
+    // wave-per-point / workgroup-per-pair kernels, for A/B runs)
+    {
+        const bool noPacked = getenv("COSLAM_BA_PACKED") && getenv("COSLAM_BA_PACKED")[0] == '0';
+        L.packed = !noPacked && !distributed && !L.sliced && !L.legacySolve && !L.syrk && D.pairPtr && b->nPackWaves > 0 &&
+                   D.n > 36 && D.n <= SB_MAX_ORDER && P > 0 && nObs > 0;
+        L.gPack = 0;
+        if (L.packed) {
+            int g = (b->nPackWaves + 3) / 4;
+            if (g * 256 < C) g = (C + 255) / 256;
+            L.gPack = g;
+            D.nUpdBlocks = g;
+            L.DB = D;
+            L.DB.st = b->st2;
+            L.DB.stn = b->st;
+        }
+        const bool noPersist = getenv("COSLAM_BA_PERSIST") && getenv("COSLAM_BA_PERSIST")[0] == '0';
+        L.persist = L.packed && !noPersist && b->persistWGs > 0;
+        L.persistG = 0;
+        L.persistLds = 0;
+        L.persistBar = b->persistBar;
+        if (L.persist) {
+            if (!b->persistBar) {
+                if (hipMalloc((void**)&b->persistBar, 16 * sizeof(int)) != hipSuccess) {
+                    cs_set_error("cs_ba: cannot allocate the barrier words");
+                    return CS_ERR_ALLOC;
+                }
+                L.persistBar = b->persistBar;
+            }
+            const int needL = (b->nPackWaves + LP_NW - 1) / LP_NW, needS = (L.nPairs * CS_SCHUR_WPP + LP_NW - 1) / LP_NW;
+            int g = needL > needS ? needL : needS;
+            if (g > b->persistWGs) g = b->persistWGs;
+            if (g < 1) g = 1;
+            L.persistG = g;
+            D.nUpdBlocks = g;
+            // LDS: the solver's blocks or the phases' scratch, whichever is larger -- and never less than what keeps a CU to
+            // this workgroup alone next to the persistent tracker (64 KB per tracker workgroup, 160 KB per CU):
+            // COSLAM_BA_PERSIST_LDS_KB (default 100)
+            size_t lds = sb_lds_bytes(D.n);
+            const size_t scratch = sizeof(double) * LP_NW * 10 * 64;
+            if (lds < scratch) lds = scratch;
+            const char* e = getenv("COSLAM_BA_PERSIST_LDS_KB");
+            const size_t floorB = (size_t)(e ? atoi(e) : 100) * 1024;
+            if (lds < floorB) lds = floorB;
+            if (lds > 160 * 1024 - 256) lds = 160 * 1024 - 256;
+            L.persistLds = lds;
+            CS_HIP(hipFuncSetAttribute((const void*)k_lm_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+    }
     return CS_OK;
 }
 
@@ -2595,6 +2709,7 @@ static void ba_enqueue_init(cs_ba* b, hipStream_t stream, const BaPlan& L, bool 
     // Z's entries of (point, camera) pairs without a measurement are never written: cleared once per solve (every present
     // entry is rewritten by every step)
     if (L.syrk) (void)hipMemsetAsync(L.Y.Zt, 0, L.syrkZtBytes, stream);
+    if (L.packed) hipLaunchKernelGGL(k_mirror_estimate, dim3(gi > 16 ? 16 : gi), dim3(256), 0, stream, D);
     if (!rebuildTopology) return;
     (void)hipMemsetAsync(b->obs_of, 0xff, sizeof(int) * (size_t)D.P * D.C, stream);
     if (D.P > 0) hipLaunchKernelGGL(k_build_obs_pt, dim3((D.P + 3) / 4), dim3(256), 0, stream, D.P, b->obs_ptr, b->obs_pt);
@@ -2607,6 +2722,11 @@ static void ba_enqueue_init(cs_ba* b, hipStream_t stream, const BaPlan& L, bool 
 static void ba_enqueue_lin_schur(hipStream_t stream, const BaPlan& L) {
     const BaDev& D = L.D;
     const dim3 blk(256);
+    if (L.packed) {  // (+ the LM control of the previous step in the head of the linearisation)
+        hipLaunchKernelGGL(k_lin_packed, dim3(L.gPack), blk, 0, stream, D);
+        if (D.nc > 0) hipLaunchKernelGGL(k_schur_wave, dim3((L.nPairs * CS_SCHUR_WPP + 3) / 4), blk, 0, stream, L.DB);
+        return;
+    }
     {
         static const bool noSeg = getenv("COSLAM_BA_SEG8") && getenv("COSLAM_BA_SEG8")[0] == '0';
         if (D.maxObsPerPoint <= 8 && !noSeg)
@@ -2637,6 +2757,11 @@ static void ba_enqueue_solve_update(hipStream_t stream, const BaPlan& L) {
     const BaDev& D = L.D;
     const dim3 blk(256);
     const int gUpd = L.gUpd;
+    if (L.packed) {
+        hipLaunchKernelGGL(k_solve_blocked, dim3(1), dim3(1024), sb_lds_bytes(D.n), stream, L.DB);
+        hipLaunchKernelGGL(k_update_packed, dim3(L.gPack), blk, 0, stream, L.DB);
+        return;
+    }
     if (L.seg8) {
         switch (D.n) {
             case 6: hipLaunchKernelGGL(k_update_seg8<6>, dim3(gUpd), blk, 0, stream, D); break;
@@ -2687,6 +2812,31 @@ static void ba_enqueue_solve_update(hipStream_t stream, const BaPlan& L) {
     }
 }
 
+// LM control behind a tentative step: its own launch, or (packed path) nothing -- the next linearisation decides
+static void ba_enqueue_control_step(hipStream_t stream, const BaPlan& L) {
+    if (!L.packed) hipLaunchKernelGGL(k_control_step, dim3(1), dim3(256), 0, stream, L.D);
+}
+// ... and at the end of a run of LM steps (packed path): the pending decision, the estimate back in Rs / Ts / pts
+static void ba_enqueue_control_final(hipStream_t stream, const BaPlan& L) {
+    if (L.packed) hipLaunchKernelGGL(k_control_final, dim3(1), dim3(256), 0, stream, L.D);
+}
+
+// a run of up to `steps` LM steps (the state word says where it stops)
+static void ba_enqueue_lm_run(hipStream_t stream, const BaPlan& L, int steps) {
+    if (L.persist) {
+        (void)hipMemsetAsync(L.persistBar, 0, 16 * sizeof(int), stream);
+        LmPersist Q = {L.persistBar, steps};
+        hipLaunchKernelGGL(k_lm_persist, dim3(L.persistG), dim3(LP_NT), L.persistLds, stream, L.D, Q);
+        return;
+    }
+    for (int it = 0; it < steps; ++it) {
+        ba_enqueue_lin_schur(stream, L);
+        ba_enqueue_solve_update(stream, L);
+        ba_enqueue_control_step(stream, L);
+    }
+    ba_enqueue_control_final(stream, L);
+}
+
 // enqueue the whole solve on `stream`; every array already resident in b's device buffers
 static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int nCamsCon, int nPtsCon, double maxErr,
                       int maxIter, int innerMaxIter, bool rebuildTopology = true, const double* d_Rs0 = nullptr,
@@ -2702,11 +2852,7 @@ static int ba_enqueue(cs_ba* b, hipStream_t stream, int C, int P, int nObs, int 
     for (int outer = 0; outer < maxIter; ++outer) {
         hipLaunchKernelGGL(k_cost, dim3(cb), blk, 0, stream, D, 0);
         hipLaunchKernelGGL(k_control, dim3(1), blk, 0, stream, D);
-        for (int it = 0; it < innerMaxIter; ++it) {
-            ba_enqueue_lin_schur(stream, L);
-            ba_enqueue_solve_update(stream, L);
-            hipLaunchKernelGGL(k_control_step, dim3(1), blk, 0, stream, D);
-        }
+        ba_enqueue_lm_run(stream, L, innerMaxIter);
         hipLaunchKernelGGL(k_flag, dim3(cb), blk, 0, stream, D);  // (its counters were zeroed by k_control phase 0)
         hipLaunchKernelGGL(k_outer_end, dim3(1), dim3(1), 0, stream, D);
     }
@@ -2814,6 +2960,7 @@ static int ba_worker_run(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
         static const int envChunk = getenv("COSLAM_BA_CHUNK") ? atoi(getenv("COSLAM_BA_CHUNK")) : 0;
         w->chunk = envChunk > 0 ? envChunk : 5;
         if (w->chunk > J.innerMaxIter && J.innerMaxIter > 0) w->chunk = J.innerMaxIter;
+        if (L.persist && J.innerMaxIter > 0) w->chunk = J.innerMaxIter;  // the whole run is one launch: it stops itself
         // head: initial estimate into the workspace, cost and LM state of the first round
         rc = ba_capture(s, &w->gHead, [&] {
             ba_enqueue_init(b, s, L, false, J.R0, J.T0, J.M0);
@@ -2822,11 +2969,7 @@ static int ba_worker_run(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
         });
         if (rc) return rc;
         rc = ba_capture(s, &w->gChunk, [&] {
-            for (int it = 0; it < w->chunk; ++it) {
-                ba_enqueue_lin_schur(s, L);
-                ba_enqueue_solve_update(s, L);
-                hipLaunchKernelGGL(k_control_step, dim3(1), blk, 0, s, D);
-            }
+            ba_enqueue_lm_run(s, L, w->chunk);  // (the state word read back below is exact at every chunk boundary)
             (void)hipMemcpyAsync(w->h_state, &b->st->inner_done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
         });
         if (rc) return rc;
@@ -3009,6 +3152,25 @@ void cs_ba_destroy(cs_ba* b) {
 // enqueue.
 void* cs_ba_stream(cs_ba* b) { return b ? (void*)b->own_stream : nullptr; }
 
+// The LM loop of the solves this workspace runs from device memory (cs_ba_solve_dev / cs_ba_solve_async; reduced systems of order
+// 37..176 with pair lists) as ONE cooperative launch of at most n_workgroups workgroups that stay resident for the whole run
+// and keep a compute unit each (ba_persist_dev.h) -- instead of four short dependent kernels per LM step that queue behind
+// whatever else fills the chip.  The caller's side of the bargain: n_workgroups compute units must be obtainable, i.e. other
+// persistent kernels are budgeted for the rest of the chip (cs_klt_set_cu_count(total - n_workgroups) on the trackers).  0
+// switches back to one launch per phase.
+int cs_ba_set_persistent(cs_ba* b, int n_workgroups) {
+    if (!b || n_workgroups < 0) {
+        cs_set_error("cs_ba_set_persistent: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    const int wrc = cs_ba_wait(b);
+    if (wrc) return wrc;
+    CS_HIP(hipSetDevice(b->device));
+    ba_drop_graph(b);
+    b->persistWGs = n_workgroups;
+    return CS_OK;
+}
+
 // Replace it by the caller's stream -- e.g. one confined to a CU range (cs_stream_create_cu_range), so that the solve's short
 // dependent kernels never queue behind the per-frame streams' workgroups.  The caller keeps ownership of `hip_stream` (it must
 // outlive the workspace or the next cs_ba_set_stream); NULL restores a plain stream of the workspace's own.
@@ -3112,6 +3274,34 @@ int cs_ba_robust_h(cs_ba* b, int C, int P, int nObs, const double* Ks, double* R
         memcpy(b->h_io + L.ocam, obs_cam, sizeof(int) * nObs);
     }
     hipStream_t s = b->own_stream;
+    // Lane plan of the packed kernels (ba_packed_dev.h): whole points back to back, at most 64 measurements per wave, in point
+    // order -- a wave is then a contiguous range of the measurement arrays.  Not for a point with more than 64 measurements.
+    b->nPackWaves = 0;
+    if (maxIter == 0 && nObs > 0 && b->maxObs <= 64) {
+        std::vector<int> ws;
+        ws.push_back(0);
+        int fill = 0;
+        for (int i = 0; i < P; ++i) {
+            const int k = obs_ptr[i + 1] - obs_ptr[i];
+            if (k == 0) continue;
+            if (fill + k > 64) {
+                ws.push_back(obs_ptr[i]);
+                fill = 0;
+            }
+            fill += k;
+        }
+        ws.push_back(nObs);
+        if (ws.size() > b->waveStartCap) {
+            if (b->waveStart) (void)hipFree(b->waveStart);
+            b->waveStart = nullptr;
+            b->waveStartCap = 0;
+            CS_HIP(hipMalloc((void**)&b->waveStart, sizeof(int) * ws.size()));
+            b->waveStartCap = ws.size();
+        }
+        CS_HIP(hipMemcpyAsync(b->waveStart, ws.data(), sizeof(int) * ws.size(), hipMemcpyHostToDevice, s));
+        CS_HIP(hipStreamSynchronize(s));  // (the vector goes out of scope)
+        b->nPackWaves = (int)ws.size() - 1;
+    }
     // Camera-pair lists for k_schur_pairs: which measurements meet in which block of the reduced system is fixed by the
     // topology, so the kernel's index chain (camera list -> point -> partner measurement, three dependent loads per entry,
     // four in five of them misses) is walked once here instead of once per LM step.  sum_i k_i (k_i + 1) / 2 entries: 152 k

@@ -429,6 +429,12 @@ void cs_ba_destroy(cs_ba* b);
  * workspace's own.  Waits for queued asynchronous solves. */
 void* cs_ba_stream(cs_ba* b);
 int cs_ba_set_stream(cs_ba* b, void* hip_stream);
+/* The LM loop of the device-resident solves of this workspace (orders 37..176, pair lists: the frame loop's joint local BA and
+ * inter-camera solve) as ONE cooperative launch of at most n_workgroups workgroups that keep a compute unit each for the whole
+ * run, instead of four short dependent kernels per LM step that queue behind whatever else fills the chip.  The caller
+ * guarantees that n_workgroups compute units can be had: other persistent kernels are budgeted for the rest of the chip
+ * (cs_klt_set_cu_count(total - n_workgroups)).  0 = one launch per phase (the default). */
+int cs_ba_set_persistent(cs_ba* b, int n_workgroups);
 int cs_ba_robust_h(cs_ba* b, int C, int P, int nObs, const double* Ks, double* Rs, double* Ts, double* pts,
                    const int* obs_ptr, const int* obs_cam, const double* obs_xy, int nCamsCon, int nPtsCon,
                    double maxErr, int maxIter, int innerMaxIter, int* out_outlier, cs_ba_stats* stats);

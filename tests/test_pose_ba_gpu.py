@@ -349,6 +349,69 @@ def test_schur_complement_on_the_matrix_cores_matches_oracle(hip, kw, ncon, npco
     assert np.max(np.abs(Rs - R0)) < 1e-9 and np.max(np.abs(Ts - T0)) < 1e-8
 
 
+def _solve_in_workspace(pr, ptr, cam, xy, ncon, npcon, maxIter, inner, packed=True, persist=0, use_async=False):
+    """upload + cs_ba_solve_dev: the device-resident form the frame loop uses (pair lists, lane plan -> the packed LM-step
+    kernels of ba_packed_dev.h unless COSLAM_BA_PACKED=0)"""
+    import torch
+
+    if not packed:
+        os.environ["COSLAM_BA_PACKED"] = "0"
+    try:
+        ws = coslam_amd.BAWorkspace(0)
+        ws.upload(pr["Ks"], pr["Rs0"], pr["ts0"], pr["pts0"], ptr, cam, xy)
+        if persist:
+            ws.set_persistent(persist)
+        d0 = [torch.from_numpy(pr[k].reshape(-1).copy()).cuda() for k in ("Rs0", "ts0", "pts0")]
+        fn = ws.solve_async if use_async else ws.solve_dev
+        fn(torch.cuda.current_stream().cuda_stream, d0[0].data_ptr(), d0[1].data_ptr(), d0[2].data_ptr(), ncon, npcon, 6.0, maxIter,
+           inner)
+        R, T, M, out, st = ws.download()
+        ws.close()
+    finally:
+        os.environ.pop("COSLAM_BA_PACKED", None)
+    return R, T, M, out, st
+
+
+@pytest.mark.parametrize("case", ["joint", "intercam", "bench_joint", "bench_intercam", 9, 10, 13, 18, 26, 31, 24])
+def test_packed_lm_step_kernels_match_oracle(hip, case):
+    """The LM step that fits a few compute units (ba_packed_dev.h: whole points back to back in a wave, one wave per camera
+    pair, the LM control folded into the next linearisation, current / tentative estimates as two buffers and an index) -- what
+    the frame loop's two key-frame solves run -- against the oracle (flags, iteration counts, 1e-6) and against the
+    wave-per-point / workgroup-per-pair kernels on the same device (COSLAM_BA_PACKED=0)."""
+    if isinstance(case, str):
+        joint, ic = _headline_problems("bench" if case.startswith("bench") else "test")
+        if case.endswith("joint"):
+            pr, ncon, npcon, maxIter, inner = joint, joint["n_cams_con"], joint["n_pts_con"], 2, 10
+        else:
+            pr, ncon, npcon, maxIter, inner = ic, 0, ic["n_static"], 3, 40
+        ptr, cam, xy = _csr(pr)
+    else:   # reduced systems of order 42 ... 174, ragged visibility; a point without measurements, one with a single one
+        ncon = 0 if case == 24 else 2
+        npcon = 40 if ncon == 0 else 3
+        pr, ptr, cam, xy = ba_inputs(n_cams=case, n_pts=260, visibility=0.55, seed=140 + case, n_cams_con=ncon, n_pts_con=npcon)
+        keep = np.ones(len(cam), bool)
+        keep[ptr[50]:ptr[51]] = False
+        keep[ptr[70] + 1:ptr[71]] = False
+        obs_pt = np.repeat(np.arange(260), np.diff(ptr))[keep]
+        ptr, cam, xy, _ = oracle.csr_by_point(260, obs_pt, cam[keep], xy[keep])
+        maxIter, inner = 2, 8
+    R, T, M, out, st = _solve_in_workspace(pr, ptr, cam, xy, ncon, npcon, maxIter, inner)
+    Rs, Ts = R.reshape(-1, 3, 3), T
+    _check_vs_oracle(pr, ptr, cam, xy, ncon, npcon, 6.0, maxIter, inner, Rs, Ts, M, out, st)
+    R0, T0, M0, out0, st0 = _solve_in_workspace(pr, ptr, cam, xy, ncon, npcon, maxIter, inner, packed=False)
+    assert np.array_equal(out, out0) and st.nIterTotal == st0.nIterTotal and st.nOuter == st0.nOuter
+    sane = np.linalg.norm(M0, axis=1) < 1e3
+    assert np.max(np.abs(R - R0)) < 1e-8 and np.max(np.abs(T - T0)) < 1e-7 and np.max(np.abs(M[sane] - M0[sane])) < 1e-6
+    assert st.flags == 0
+    # the whole LM loop as ONE cooperative launch (ba_persist_dev.h): a few workgroups that loop over the waves / pairs, and
+    # enough of them that nobody loops; through the up-front schedule and through the worker thread
+    for g, use_async in ((3, False), (64, False), (7, True)):
+        Rp, Tp, Mp, outp, stp = _solve_in_workspace(pr, ptr, cam, xy, ncon, npcon, maxIter, inner, persist=g, use_async=use_async)
+        assert np.array_equal(outp, out) and stp.nIterTotal == st.nIterTotal and stp.nOuter == st.nOuter and stp.flags == 0, (g, use_async)
+        assert np.max(np.abs(Rp - R)) < 1e-8 and np.max(np.abs(Tp - T)) < 1e-7 and np.max(np.abs(Mp[sane] - M[sane])) < 1e-6
+        assert abs(stp.cost - st.cost) <= 1e-9 * max(1.0, st.cost)
+
+
 def test_async_worker_schedule_gives_the_up_front_schedule_bit_for_bit(hip):
     """cs_ba_solve_async (the workspace's own thread enqueues chunks of LM steps and stops at convergence -- the reference's
     BA worker thread, src/app/SL_CoSLAM.cpp:1702-1784) == cs_ba_solve_dev (whole schedule up front): identical bits, also

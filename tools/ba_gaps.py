@@ -14,7 +14,8 @@ for q, lst in byq.items():
     names = collections.Counter(n for n, *_ in lst)
     if "k_solve_blocked" not in names:
         continue
-    kind = "joint (order 144)" if any(n == "k_linearize" for n, *_ in lst) else "inter-camera (order 48)"
+    sb = [(e - s) / 1000 for n, s, e, *_ in lst if n == "k_solve_blocked" and (e - s) > 3000]   # (skip the no-op launches)
+    kind = "joint (order 144)" if sb and sorted(sb)[len(sb) // 2] > 17 else "inter-camera (order 48)"
     dur, gap, cnt = collections.Counter(), collections.Counter(), collections.Counter()
     prev_end = None
     for n, s, e, gx, lds in lst:
