@@ -243,11 +243,13 @@ def main():
     ap.add_argument("--klt-cus", type=int, default=int(os.environ.get("BENCH_KLT_CUS", "0")),
                     help="tracker stream confined to the first N compute units (0 = whole chip): leaves CUs the persistent tracker "
                          "never occupies, where the BA's 1024-thread solver workgroup can start while the tracker runs")
-    ap.add_argument("--klt-cams-per-launch", type=int, default=int(os.environ.get("BENCH_KLT_CAMS_PER_LAUNCH", "0")),
-                    help="cameras per persistent tracker launch (0 = as many as are co-resident: all 8 at two waves per SIMD). 4 = two "
-                         "launches of four cameras back to back at ONE wave per SIMD: every SIMD keeps a free wave slot (and every CU "
-                         "96 KB of LDS) for the key-frame solves' kernels")
-    ap.add_argument("--reg-stream", type=int, default=int(os.environ.get("BENCH_REG_STREAM", "1")),
+    ap.add_argument("--klt-cams-per-launch", type=int, default=int(os.environ.get("BENCH_KLT_CAMS_PER_LAUNCH", "-1")),
+                    help="cameras per persistent tracker launch.  0 = as many as are co-resident (all 8 at two waves per SIMD: the "
+                         "fastest tracker, 146 us per frame).  3 or 4 = launches of <= 3 / 4 cameras back to back at ONE wave per SIMD "
+                         "(tracker 203 us per frame with 4): every SIMD keeps a free wave slot and every CU 96 KB of LDS for the "
+                         "key-frame solves' kernels, whose latency chain -- not the tracker -- bounds the loop: measured +6 % (4) / "
+                         "+8 % (3) frames/s (profiles/r03_tracker_split.txt).  -1 (default) = 3 when all 8 cameras are on this GPU, else 0")
+    ap.add_argument("--reg-stream", type=int, default=int(os.environ.get("BENCH_REG_STREAM", "0")),
                     help="1: the two registration passes of frame f on their own stream behind pose(f) -- they are consumers of the "
                          "frame's poses and features, nothing of frame f+1's tracking or pose depends on them, so they overlap the next "
                          "frame's tracker (hand-back(f+1) waits for them: it rewrites the records they read); 0: on the pose stream")
@@ -258,6 +260,7 @@ def main():
     ap.add_argument("--ba-cus", default=os.environ.get("BENCH_BA_CUS", ""), help="FIRST:COUNT -- the joint BA's stream confined to these CU-mask bits")
     ap.add_argument("--ic-cus", default=os.environ.get("BENCH_IC_CUS", ""), help="FIRST:COUNT -- the inter-camera solve's stream confined to these CU-mask bits")
     ap.add_argument("--pose-cus", default=os.environ.get("BENCH_POSE_CUS", ""), help="FIRST:COUNT -- the pose stream (hand-back, pose, registration) confined to these CU-mask bits")
+    ap.add_argument("--no-upload-leg", action="store_true", help="skip the upload-inclusive repetition of the loop (config.with_upload)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cfg5 BA leg (3 s of problem generation)")
     ap.add_argument("--no-posegraph", action="store_true", help="diagnostic: skip the pose-graph relaxation behind the joint BA (not a valid bench line)")
     ap.add_argument("--no-register", action="store_true", help="diagnostic: skip the map-point registration search (not a valid bench line)")
@@ -382,6 +385,8 @@ def main():
         if not args.klt_cus and args.klt_cams_per_launch <= 0:
             for t in trks:
                 t.set_cu_count(256 - persist_j - persist_i)
+    if args.klt_cams_per_launch < 0:
+        args.klt_cams_per_launch = 3 if (nc == N_CAMS and not args.serial) else 0
     if args.klt_cams_per_launch > 0 and not args.klt_cus:
         # the co-residency budget of the persistent tracker is what decides how many cameras share a launch: hand it the
         # budget of cams_per_launch cameras (250 waves each, 8 resident waves per CU) -- no CU mask, the launches still spread
@@ -447,11 +452,14 @@ def main():
         if args.native_comm and dist_backend == "nccl":
             try:
                 native = multicam.NativeComm(world, rank, local_rank)
-            except Exception as ex:  # noqa: BLE001 -- fall back to torch.distributed collectives, never break the bench
-                print(f"bench: native RCCL communicator unavailable ({ex}); using torch.distributed", file=sys.stderr)
-                native = None
+            except Exception as ex:  # noqa: BLE001
+                # no silent change of what is measured: the library's RCCL path is the product; torch.distributed collectives
+                # are available, but only when asked for
+                raise SystemExit(f"bench.py: libcoslam_hip's RCCL communicator could not be created ({ex}); "
+                                 "run with --native-comm 0 to measure with torch.distributed collectives instead")
         xchg = multicam.CameraExchange(N_FEAT * nc, dev, native=native, cams_per_rank=nc)
 
+    ic_start_snap = torch.zeros(12 * N_CAMS, dtype=torch.float64, device=dev)
     klt_done = [torch.cuda.Event(), torch.cuda.Event()]
     dest_free = [torch.cuda.Event(), torch.cuda.Event()]
     pose_done = torch.cuda.Event()
@@ -502,14 +510,29 @@ def main():
                                 o["slot"].data_ptr(), o["m"].data_ptr(), o["var"].data_ptr(), o["dist"].data_ptr(),
                                 o["flags"].data_ptr(), device=local_rank)
 
-    def step(i, key_frame):
+    # upload-inclusive variant (config.with_upload): the frames arrive in PINNED HOST memory (the capture threads' buffers,
+    # reference src/app/SL_CoSLAM.cpp:119-133) and every frame's 8 x 300 KB go host -> device inside the loop: frame i + 2 is
+    # staged (cs_klt_group_stage_h: copy stream, ring of 3 slots) while frame i is tracked and frame i + 1 is prefetched
+    h_frames = None
+    stage_slot = {}
+
+    def stage(i):
+        f = order[i % len(order)]
+        stage_slot[i] = grp.stage_h([h_frames[c][f].data_ptr() for c in range(nc)])
+
+    def step(i, key_frame, upload=False):
         f, fn = order[i % len(order)], order[(i + 1) % len(order)]
         b = i & 1
         if i >= 2:
             klt_s.wait_event(dest_free[b])      # the consumer of this dest buffer two frames ago is done
+        if upload:
+            stage(i + 2)
+            cur, nxt = grp.staged(stage_slot.pop(i)), grp.staged(stage_slot[i + 1])
+        else:
+            cur, nxt = img_ptrs[f], img_ptrs[fn]
         if prefetch:   # this frame's detector tail also builds the next frame's pyramids + cornerness maps
-            grp.prefetch_dev(img_ptrs[fn])
-        grp.redetect_dev(img_ptrs[f], dest_ptrs[b], cnt_ptrs)
+            grp.prefetch_dev(nxt)
+        grp.redetect_dev(cur, dest_ptrs[b], cnt_ptrs)
         grp.advanceFrame()
         klt_done[b].record(klt_s)
         pose_s.wait_event(klt_done[b])          # pose(f) consumes what the tracker produced for frame f
@@ -520,6 +543,17 @@ def main():
                 xchg.pack_group(d_dests[b], d_R[i & 1], d_t[i & 1], pose_s)
                 xchg.all_gather(pose_s)
         dest_free[b].record(pose_s)
+        if key_frame and world > 1:
+            # InterCamPoseEstimator::addMapPoints (reference src/app/SL_InterCamPoseEstimator.cpp:24-37) starts the solve from
+            # every camera's CURRENT pose: at N > 1 those are the poses this frame's all-gather just delivered (records of all 8
+            # cameras: local ones included), not anything rank-local
+            with torch.cuda.stream(pose_s):
+                for g in range(N_CAMS):
+                    _, Rg, tg = xchg.unpack(g, device=local_rank)
+                    d_iR[9 * g: 9 * g + 9].copy_(Rg, non_blocking=True)
+                    d_iT[3 * g: 3 * g + 3].copy_(tg, non_blocking=True)
+                    ic_start_snap[12 * g: 12 * g + 9].copy_(Rg, non_blocking=True)
+                    ic_start_snap[12 * g + 9: 12 * g + 12].copy_(tg, non_blocking=True)
         if key_frame:
             if args.only_solve == "joint":
                 pass
@@ -597,19 +631,68 @@ def main():
     t_host = time.perf_counter() - t_begin
     barrier()
     dt = time.perf_counter() - t_begin
+    with_upload = None
+    if not args.no_upload_leg and not args.serial:
+        # the same loop once more, the images coming from pinned host memory every frame (same key-frame cadence, same drain)
+        h_frames = [torch.from_numpy(frames[c]).pin_memory() for c in my_cams]
+        i0 = args.warmup + args.steps + 1
+        stage(i0)
+        stage(i0 + 1)
+        for i in range(args.warmup):
+            step(i0 + i, args.key_every > 0 and i % args.key_every == 0, upload=True)
+        barrier()
+        tu = time.perf_counter()
+        for i in range(args.steps):
+            step(i0 + args.warmup + i, args.key_every > 0 and i % args.key_every == 0, upload=True)
+        barrier()
+        dtu = time.perf_counter() - tu
+        if world > 1:
+            tmu = torch.tensor([dtu], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmu, op=dist.ReduceOp.MAX)
+            dtu = float(tmu.item())
+        with_upload = {"frames_per_s": args.steps / dtu, "ms_per_step": dtu / args.steps * 1e3,
+                       "ratio_to_value": (args.steps / dtu) / (args.steps / dt),
+                       "what": f"the same loop with every frame's {nc} x {W * H} B images copied from pinned host memory inside the "
+                               "loop (cs_klt_group_stage_h: copy stream + ring of 3 device slots, two frames ahead of the tracker)"}
+        replay_base = i0 + args.warmup + args.steps - 1
+    else:
+        replay_base = args.warmup + args.steps
     gc.enable()
     pg_info = None
     if pg is not None:
         pg.status(ba_s.cuda_stream)      # raises if a graph failed
         moved = (d_pgNT - d_pgT).abs().max().item()
         pg_info = dict(pg.counts(), max_non_key_translation_change=moved)
+    gathered_info = None
     if world > 1:
+        # what the last frame's all-gather delivered, checked against its owners: every rank sums the words of the records of its
+        # OWN cameras as it packed them; the sums travel through torch.distributed; every rank compares all 8 gathered records
+        last_b = replay_base & 1
+        w1 = multicam.record_words(N_FEAT)
+        own = []
+        for i in range(nc):
+            ws_ = d_dests[last_b][i].to(torch.int64).sum() + d_R[last_b][i].view(torch.int32).to(torch.int64).sum() + \
+                d_t[last_b][i].view(torch.int32).to(torch.int64).sum()
+            own.append(ws_)
+        own_t = torch.stack(own).to("cpu" if dist_backend != "nccl" else dev)
+        all_t = [torch.zeros_like(own_t) for _ in range(world)]
+        dist.all_gather(all_t, own_t)
+        sums = torch.cat(all_t).cpu().tolist()
+        ok = True
+        for g in range(N_CAMS):
+            fw, Rg, tg = xchg.unpack(g, device=local_rank)
+            got = int(fw.to(torch.int64).sum().item() + Rg.view(torch.int32).to(torch.int64).sum().item() + tg.view(torch.int32).to(torch.int64).sum().item())
+            ok = ok and got == int(sums[g])
+        snapR = torch.cat([ic_start_snap[12 * g: 12 * g + 9] for g in range(N_CAMS)])
+        gathered_info = {"cameras_checked": N_CAMS, "records_match_owner": bool(ok), "record_bytes": 4 * w1,
+                         "intercam_start_is_gathered_pose": bool(torch.equal(d_iR, snapR)),
+                         "intercam_start_differs_from_prebaked": bool((d_iR.cpu().numpy() != ic["Rs0"].reshape(-1)).any())}
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     grp.synchronize()
-    last = (args.warmup + args.steps) & 1
+    last = replay_base & 1
     n_live = [int((d.cpu().numpy().view(coslam_amd.KLT_TrackedFeature)["status"] >= 0).sum()) for d in d_dests[last]]
     pose_ok = d_ok.cpu().numpy().tolist()
     from coslam_amd.pose import IntraCamPoseOption
@@ -617,7 +700,7 @@ def main():
     pose_iters = [[o.nIterRW, o.nIterLM] for o in _opts]     # re-weighting rounds, LM steps of the last round (last frame)
     pose_npts = d_npts.cpu().numpy().tolist()
     # how far the device-resident poses are from the synthetic ground truth of the last frame (data-coupled pose leg)
-    f_last = order[(args.warmup + args.steps) % len(order)]
+    f_last = order[replay_base % len(order)]
     Rl, tl_ = d_R[last].cpu().numpy(), d_t[last].cpu().numpy()
     pose_err = max(float(np.abs(tl_[i] - sc.pose(c, f_last)[1]).max()) for i, c in enumerate(my_cams))
     _, _, _, _, st_j = ba_ws.download() if (world == 1 or not ba_sliced) else (None, None, None, None, None)
@@ -626,10 +709,11 @@ def main():
     # ---- roofline of the dominant kernel: the persistent gain tracker of all cameras of this rank (one launch per frame).
     # Timed with HIP events on the stream it is launched on, over a replay of the same frames after the timed region.
     roof = None
+    replayed = 100
     if rank == 0:
         trks[0].set_profiling(True)
         n_prof = 100   # (also for a short --steps run: the first frames after the switch to profiling are slower)
-        base = args.warmup + args.steps
+        base = replay_base
         for i in range(n_prof):
             f, fn = order[(base + i + 1) % len(order)], order[(base + i + 2) % len(order)]
             if prefetch:
@@ -645,23 +729,63 @@ def main():
         launches = max(prof["launches_per_frame"], 1)
         avg_us = prof["tracker_us_total"] / max(prof["frames"], 1) / launches
         ach = (alg_bytes / launches) / (avg_us * 1e-6) / 1e9
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r02_tracker_pmc.json")
-        if launches == 1 and nc == N_CAMS and os.path.exists(pmc_file):  # HBM bytes per launch from the committed --pmc passes
-            pj = json.load(open(pmc_file))
-            traffic, traffic_src = pj["traffic_bytes_per_launch"], "profiles/r02_tracker_pmc.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
-        roof = {"bound": "hbm", "kernel": "k_track_rows_fused" if launches == 1 else "k_track_rows_pass",
+        traffic, traffic_src, valu = None, None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r03_tracker_pmc.json")
+        if not os.path.exists(pmc_file):
+            pmc_file = os.path.join(ROOT, "profiles", "r02_tracker_pmc.json")
+        pj = json.load(open(pmc_file)) if (nc == N_CAMS and os.path.exists(pmc_file)) else None
+        if pj is not None:   # HBM bytes per frame's worth of launches from the committed --pmc passes (8 cameras per launch there)
+            traffic = pj["traffic_bytes_per_launch"] / launches
+            traffic_src = os.path.relpath(pmc_file, ROOT) + " (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE: bytes of all 8 cameras / launches per frame)"
+            if "valu_wave_insts_per_launch" in pj:
+                # the second roofline: the kernel is bound by VALU issue, not by HBM.  A wave64 VALU
+                # instruction holds its SIMD's issue port for 4 cycles; 1024 SIMDs.
+                insts = pj["valu_wave_insts_per_launch"] / launches
+                floor_us = insts * 4.0 / (1024 * pj.get("sclk_ghz", 2.4) * 1e3)
+                valu = {"insts": insts, "floor_us": floor_us, "frac": floor_us / avg_us, "unit": "wave64 VALU instructions per launch",
+                        "source": os.path.relpath(pmc_file, ROOT) + " (SQ_INSTS_VALU, separate --pmc pass)"}
+        fused_kernel = prof["launches_per_frame"] <= N_CAMS
+        roof = {"bound": "hbm", "kernel": "k_track_rows_fused" if fused_kernel else "k_track_rows_pass",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes / launches,
                 "avg_launch_us": avg_us, "launches_per_frame": launches, "frames_timed": prof["frames"],
-                "cameras_per_launch": nc}
+                "cameras_per_launch": nc / launches, "valu": valu}
+        if launches > 1 and fused_kernel:
+            # the same kernel with every camera in ONE launch (two waves per SIMD: its own best configuration, slower for the loop)
+            for t in trks:
+                t.set_cu_count(256)
+            for i in range(20):   # (the frame sequence continues where the replay above stopped: base + 100)
+                f, fn = order[(base + 100 + i + 1) % len(order)], order[(base + 100 + i + 2) % len(order)]
+                if prefetch:
+                    grp.prefetch_dev(img_ptrs[fn])
+                grp.redetect_dev(img_ptrs[f], dest_ptrs[0], cnt_ptrs)
+                grp.advanceFrame()
+            trks[0].set_profiling(True)
+            for i in range(n_prof):
+                f, fn = order[(base + 120 + i + 1) % len(order)], order[(base + 120 + i + 2) % len(order)]
+                if prefetch:
+                    grp.prefetch_dev(img_ptrs[fn])
+                grp.redetect_dev(img_ptrs[f], dest_ptrs[0], cnt_ptrs)
+                grp.advanceFrame()
+            p1 = trks[0].get_profile()
+            trks[0].set_profiling(False)
+            replayed = 100 + 20 + n_prof
+            if p1["launches_per_frame"] == 1:
+                us1 = p1["tracker_us_total"] / max(p1["frames"], 1)
+                a1 = alg_bytes / (us1 * 1e-6) / 1e9
+                roof["all_cameras_in_one_launch"] = {"avg_launch_us": us1, "achieved": a1, "frac": a1 / HBM_PEAK_GBS,
+                                                     "algorithmic_bytes_per_launch": alg_bytes,
+                                                     "valu_frac": None if valu is None else valu["floor_us"] * launches / us1}
 
     # ---- secondary key: cfg2 (BASELINE.json configs[1]) = ONE camera on the GPU, KLT + hand-back + pose per frame, no
     # key-frame solves; same kernels through the single-handle entry points.  Not the headline; kept for continuity.
     cfg2 = None
     if rank == 0 and n_gpus == 1 and not args.serial and not args.no_pose:
+        if not args.klt_cus:
+            for t in trks:
+                t.set_cu_count(256)   # (the headline loop may have budgeted the tracker for fewer cameras per launch)
         n2 = min(args.steps, 200)
-        base = args.warmup + args.steps + 100
+        base = replay_base + replayed   # (continues the frame sequence of the replays above)
         k0 = trks[0]
         hb1 = [handback_cams(hb_cams(0)[:1]), handback_cams(hb_cams(1)[:1])]
 
@@ -763,6 +887,7 @@ def main():
                        {"active": int((reg_out[0]["slot"] >= 0).sum().item()), "current_static": int((reg_out[1]["slot"] >= 0).sum().item()),
                         "already_attached": int((reg_out[1]["slot"] == -1).sum().item())},
                        "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "host_enqueue_ms_max_step": t_step_max * 1e3, "host_enqueue_max_at_step": i_step_max, "tracker_stream_cus": args.klt_cus or "all",
+                       "gathered_records": gathered_info, "with_upload": with_upload,
                        "collectives": None if world == 1 else ("libcoslam_hip RCCL (C-ABI)" if native else "torch.distributed " + dist_backend),
                        "streams": "one stream (--serial)" if args.serial else
                        "tracker group | hand-back + pose (event-ordered behind the tracker of the same frame) | "

@@ -58,6 +58,7 @@ namespace {
 struct BaState {
     double lambda, cost, cost_new, step2, cost0;
     int inner_it, inner_done, all_done, chol_ok, changed, nIterTotal, nOuter, nOutliers, first_cost;
+    int seq;            // packed path: LM steps started so far (the flow schedule's sequence number)
     int pending;        // packed path: a tentative step awaits its accept / reject (decided by the next k_lin_packed)
     int cur;            // packed path: which estimate is current: 0 = Rs / Ts / pts, 1 = Rn / Tn / Mn
     int nCholFail;      // LM steps whose reduced system could not be factorised (not positive definite, NaN, time-out)
@@ -2040,7 +2041,7 @@ __global__ __launch_bounds__(256) void k_init_state(BaState* st, int* outlier, i
     z.cost = z.cost_new = z.step2 = z.cost0 = 0;
     z.inner_it = z.inner_done = z.all_done = z.chol_ok = z.changed = z.nIterTotal = z.nOuter = z.nOutliers = 0;
     z.nCholFail = z.nAccepted = z.solverTimeout = 0;
-    z.pending = z.cur = 0;
+    z.pending = z.cur = z.seq = 0;
     z.first_cost = 1;
     *st = z;
 }
@@ -2340,8 +2341,7 @@ static int ba_free(cs_ba* b) {
     b->dist = nullptr;
     if (b->pairPtr) (void)hipFree(b->pairPtr);
     if (b->pairEnt) (void)hipFree(b->pairEnt);
-    if (b->persistBar) (void)hipFree(b->persistBar);
-    b->persistBar = nullptr;
+    b->persistBar = nullptr;  // (a piece of the slab)
     if (b->waveStart) (void)hipFree(b->waveStart);
     b->waveStart = nullptr;
     b->waveStartCap = 0;
@@ -2428,6 +2428,7 @@ static int ba_reserve(cs_ba* b, int C, int P, int nObs) {
     const Piece pieces[] = {
         {(void**)&b->st, sizeof(BaState)},
         {(void**)&b->st2, sizeof(BaState)},
+        {(void**)&b->persistBar, 32 * sizeof(int)},
         {(void**)&b->scal, 8 * sizeof(double)},
         {(void**)&b->costPart, (1024 + cP / 4 + cC / 256 + 2) * sizeof(double)},
         {(void**)&b->stepPart, (cP + cC + 1) * sizeof(double)},
@@ -2667,13 +2668,6 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
         L.persistLds = 0;
         L.persistBar = b->persistBar;
         if (L.persist) {
-            if (!b->persistBar) {
-                if (hipMalloc((void**)&b->persistBar, 16 * sizeof(int)) != hipSuccess) {
-                    cs_set_error("cs_ba: cannot allocate the barrier words");
-                    return CS_ERR_ALLOC;
-                }
-                L.persistBar = b->persistBar;
-            }
             const int needL = (b->nPackWaves + LP_NW - 1) / LP_NW, needS = (L.nPairs * CS_SCHUR_WPP + LP_NW - 1) / LP_NW;
             int g = needL > needS ? needL : needS;
             if (g > b->persistWGs) g = b->persistWGs;

@@ -24,6 +24,9 @@
 // COH (template flag of every function here): plain loads / stores when a kernel boundary separates producer and consumer,
 // relaxed agent-scope atomics when both run inside one launch.
 
+__device__ __forceinline__ int lp_ld_i(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lp_st_i(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 struct LmView {
     int active, cur;
     double lambda;
@@ -57,7 +60,8 @@ __device__ __forceinline__ LmRule lm_rule(int chol_ok, double cost_old, double l
 
 // LM control of the previous step, by every thread of a 256-thread workgroup (all arrive at the same answer); workgroup 0 records
 // it in *D.stn.
-__device__ __forceinline__ LmView lm_head(const BaDev& D, double* red /* shared, 8 doubles */) {
+// takesStep: the caller goes on to take an LM step when the answer is "active" (k_lin_packed: yes; k_control_final: no)
+__device__ __forceinline__ LmView lm_head(const BaDev& D, double* red /* shared, 8 doubles */, const bool takesStep) {
     const int tid = threadIdx.x;
     const BaState* st = D.st;
     const int all_done = st->all_done, inner_done = st->inner_done, pending = st->pending, chol_ok = st->chol_ok,
@@ -71,6 +75,7 @@ __device__ __forceinline__ LmView lm_head(const BaDev& D, double* red /* shared,
     if (!pending) {  // first step of an LM run: nothing to decide
         if (blockIdx.x == 0 && tid == 0) {
             BaState s = *st;
+            if (takesStep) s.seq += 1;  // (one more LM step is being taken)
             *D.stn = s;
         }
         v.active = 1;
@@ -102,6 +107,7 @@ __device__ __forceinline__ LmView lm_head(const BaDev& D, double* red /* shared,
         s.inner_done = r.done;
         s.pending = 0;
         s.cur = r.acc ? (cur ^ 1) : cur;
+        if (!r.done && takesStep) s.seq += 1;
         *D.stn = s;
     }
     v.active = r.done ? 0 : 1;
@@ -348,7 +354,7 @@ __device__ __forceinline__ void schur_finish(const BaDev& D, int pi, int lane, c
 
 // tentative step of the points of wave w and the tentative cost of its measurements (per lane, to be summed by the caller);
 // rhs = the solved camera step; wl: 3 x 64 doubles of LDS
-template <bool COH>
+template <bool COH, bool COH_RHS = COH>
 __device__ __forceinline__ void update_wave(const BaDev& D, int w, int lane, int cur, double* wl, double& cost, double& step) {
     const double* Rc = cur ? D.Rn : D.Rs;
     const double* Tc = cur ? D.Tn : D.Ts;
@@ -361,7 +367,7 @@ __device__ __forceinline__ void update_wave(const BaDev& D, int w, int lane, int
     const int jf = L.j - D.nCamsCon;
     if (L.has && jf >= 0) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) dc[q] = ldm<COH>(rhs + 6 * jf + q);
+        for (int q = 0; q < 6; ++q) dc[q] = ldm<COH_RHS>(rhs + 6 * jf + q);
     }
     if (L.has && L.in && jf >= 0 && L.i >= D.nPtsCon) {
         const double* Wo = D.W + 18 * (size_t)L.o;
@@ -419,7 +425,7 @@ __device__ __forceinline__ void update_wave(const BaDev& D, int w, int lane, int
 }
 
 // tentative pose of camera j and its squared step
-template <bool COH>
+template <bool COH, bool COH_RHS = COH>
 __device__ __forceinline__ void update_cam(const BaDev& D, int j, int cur, double& step) {
     const double* Rc = cur ? D.Rn : D.Rs;
     const double* Tc = cur ? D.Tn : D.Ts;
@@ -432,7 +438,7 @@ __device__ __forceinline__ void update_cam(const BaDev& D, int j, int cur, doubl
         const double* dcj = D.rhs + 6 * (j - D.nCamsCon);
         double dc[6];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) dc[q] = ldm<COH>(dcj + q);
+        for (int q = 0; q < 6; ++q) dc[q] = ldm<COH_RHS>(dcj + q);
         double wv3[3] = {dc[0], dc[1], dc[2]}, dR[9], Rn[9];
         so3_exp(wv3, dR);
         mat33AB(Rcur, dR, Rn);
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(256) void k_lin_packed(BaDev D) {
     CS_BA_SETPRIO();
     __shared__ double red[8];
     __shared__ double segl[4][10 * 64];
-    const LmView V = lm_head(D, red);
+    const LmView V = lm_head(D, red, true);
     if (!V.active) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, w = blockIdx.x * 4 + wv;
     if (w >= D.nPackWaves) return;
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(256) void k_lin_packed(BaDev D) {
 }
 
 #ifndef CS_SCHUR_WPP
-#define CS_SCHUR_WPP 2  // waves per camera pair
+#define CS_SCHUR_WPP 4  // waves per camera pair (measured in the frame loop: 1 -> 1920, 2 -> 2150, 4 -> 2200 frames/s)
 #endif
 __global__ __launch_bounds__(256) void k_schur_wave(BaDev D) {
     CS_BA_SETPRIO();
@@ -520,7 +526,7 @@ __global__ __launch_bounds__(256) void k_control_final(BaDev D) {
     if (D.st->all_done) return;
     BaDev D2 = D;
     D2.stn = D.st;  // in place: one workgroup, every thread has read the state before thread 0 rewrites it (barrier inside)
-    const LmView V = lm_head(D2, red);
+    const LmView V = lm_head(D2, red, false);
     __syncthreads();
     const int tid = threadIdx.x;
     if (V.cur == 1) {

@@ -30,8 +30,6 @@ struct LmPersist {
     int maxSteps;
 };
 
-__device__ __forceinline__ int lp_ld_i(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void lp_st_i(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // all threads of the workgroup call; false: timed out (the grid is not resident / a workgroup died)
 __device__ __forceinline__ bool lp_barrier(int* bar, int G, int& epoch, int* aliveSh) {

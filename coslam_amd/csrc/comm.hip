@@ -103,10 +103,13 @@ __global__ __launch_bounds__(256) void k_exchange_pack(PackArgs A) {
     const int* src = A.dest[cam];
     for (int q = blockIdx.x * 256 + threadIdx.x; q < A.recWords; q += gridDim.x * 256) {
         int v;
+        const int fp = (A.nFeatWords + 1) & ~1;
         if (q < A.nFeatWords) {
             v = src[q];
+        } else if (q < fp) {
+            v = 0;  // (padding word of an odd feature count)
         } else {
-            const int w = q - A.nFeatWords;  // 18 words of R, 6 of t
+            const int w = q - fp;  // 18 words of R, 6 of t
             const int* p = (w < 18) ? (const int*)(A.R + 9 * (size_t)cam) + w : (const int*)(A.t + 3 * (size_t)cam) + (w - 18);
             v = *p;
         }
@@ -176,7 +179,7 @@ cs_exchange* cs_exchange_create(cs_comm* c, int nCamsLocal, int nFeatures) {
     x->c = c;
     x->nCams = nCamsLocal;
     x->nFeat = nFeatures;
-    x->recWords = (size_t)nFeatures * 5 + 24;
+    x->recWords = (((size_t)nFeatures * 5 + 1) & ~(size_t)1) + 24;  // features padded to 8 bytes: R | t behind them stay aligned
     x->send = x->recv = nullptr;
     const size_t sendBytes = sizeof(int) * x->recWords * nCamsLocal;
     if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void**)&x->send, sendBytes) != hipSuccess ||

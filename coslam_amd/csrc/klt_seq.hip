@@ -146,6 +146,9 @@ struct cs_klt {
     uint8_t* h_img;          // pinned staging for the host-pointer entry points (a pageable source is staged by the runtime, ~3x slower)
     // HIP-event timing of the tracker stage (bench.py roofline leg): eager launches only
     bool profiling;
+    bool async_pending;           // cs_klt_redetect_async_h enqueued a frame that cs_klt_fetch has not collected yet
+    hipEvent_t async_ev;
+    int last_tracker_launches;    // persistent launches the last frame's tracker took (a span that is not co-resident is split)
     hipEvent_t ev0, ev1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev_pairs;
     // persistent (single-launch) gain tracker
@@ -299,6 +302,7 @@ static int enqueue_tracker(const Span& S, cs_klt_feature* const* postDest, int d
             A.sqrConvThr = realConv;
             A.ssdThr = realSsd;
             for (int q = 0; q < 4; ++q) A.vr[q] = realVr[q];
+            k0->last_tracker_launches = (S.n + perLaunch - 1) / perLaunch;
             for (int first = 0; first < S.n; first += perLaunch) {
                 const int m = (S.n - first < perLaunch) ? S.n - first : perLaunch;
                 A.nCams = m;
@@ -910,7 +914,8 @@ int cs_klt_get_profile(cs_klt* k, double* tracker_us, int* n_frames, int* launch
         if (skip <= 0) skip = 1;
         int lv = 0;
         for (int level = k->L - 1; level >= 0; level -= skip) ++lv;
-        *launches_per_frame = !c.trackWithGain ? 1 : (k->use_fused ? 1 : lv * c.nIterations + 1);
+        *launches_per_frame = !c.trackWithGain ? 1 : (k->use_fused ? (k->last_tracker_launches > 0 ? k->last_tracker_launches : 1)
+                                                                     : lv * c.nIterations + 1);
     }
     return CS_OK;
 }
@@ -1112,6 +1117,38 @@ int cs_klt_redetect(cs_klt* k, const uint8_t* image, int* nNew, cs_klt_feature* 
     return fetch_results(k, nNew, dest);
 }
 
+// GPUKLT::next in two halves: everything of the frame -- upload, redetect, the copy of dest[] back -- is enqueued and the call
+// returns; cs_klt_fetch blocks until that frame's results are on the host.  Several cameras' frames are then in flight
+// together (one handle each), where the synchronous form serialises upload -> kernels -> read-back per camera (155-178 us per
+// camera-frame, profiles/r02_dropin_cxx_latency.txt).  One frame per handle may be outstanding.
+int cs_klt_redetect_async_h(cs_klt* k, const uint8_t* image) {
+    CS_REQUIRE(k && k->allocated && image, "cs_klt_redetect_async_h: bad arguments");
+    CS_REQUIRE(!k->async_pending, "cs_klt_redetect_async_h: the previous frame has not been fetched (cs_klt_fetch)");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    if ((rc = upload_image(k, image))) return rc;
+    if ((rc = enqueue_redetect1(k, k->d_img, k->d_dest, k->d_counts))) return rc;
+    CS_HIP(hipMemcpyAsync(k->h_dest, k->d_dest, sizeof(cs_klt_feature) * k->N + 8 * sizeof(int), hipMemcpyDeviceToHost, k->stream));
+    if (!k->async_ev) CS_HIP(hipEventCreateWithFlags(&k->async_ev, hipEventDisableTiming));
+    CS_HIP(hipEventRecord(k->async_ev, k->stream));
+    k->async_pending = true;
+    return CS_OK;
+}
+
+int cs_klt_fetch(cs_klt* k, int* nNew, cs_klt_feature* dest) {
+    CS_REQUIRE(k && k->allocated && nNew && dest, "cs_klt_fetch: bad arguments");
+    CS_REQUIRE(k->async_pending, "cs_klt_fetch: no frame outstanding (cs_klt_redetect_async_h)");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    CS_HIP(hipEventSynchronize(k->async_ev));
+    k->async_pending = false;
+    memcpy(dest, k->h_dest, sizeof(cs_klt_feature) * k->N);
+    const int* tail = (const int*)(k->h_dest + k->N);
+    *nNew = tail[0];
+    if (tail[4]) return check_device_error(k);
+    return CS_OK;
+}
+
 int cs_klt_track(cs_klt* k, const uint8_t* image, int* nPresent, cs_klt_feature* dest) {
     CS_REQUIRE(k && k->allocated && image && nPresent && dest, "cs_klt_track: bad arguments");
     int rc = bind_device(k);
@@ -1210,9 +1247,17 @@ int cs_klt_build_pyramid(cs_klt* k, const uint8_t* image) {
 // CoSLAM::featureTracking() (src/app/SL_CoSLAM.cpp:299-305) calls GPUKLT::next camera by camera; a group issues the
 // same per-camera work with the camera as one more grid dimension of every kernel: 3-5 launches per frame for ALL
 // cameras, and one persistent tracker launch whose waves (8 features each) are all co-resident.
+constexpr int CS_STAGE_SLOTS = 3;
 struct cs_klt_group {
     std::vector<cs_klt*> ks;
     hipStream_t stream;
+    // host images into the device off the frame's critical path (cs_klt_group_stage_h): a ring of CS_STAGE_SLOTS x n images,
+    // a copy stream, per slot "copied" (recorded on the copy stream) and "free again" (recorded on the group's stream) events
+    uint8_t* d_stage = nullptr;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copied[CS_STAGE_SLOTS] = {nullptr, nullptr, nullptr};
+    hipEvent_t freed[CS_STAGE_SLOTS] = {nullptr, nullptr, nullptr};
+    int next_slot = 0;
 };
 
 static bool same_setup(const cs_klt* a, const cs_klt* b) {
@@ -1249,7 +1294,81 @@ cs_klt_group* cs_klt_group_create(cs_klt* const* handles, int n) {
     return g;
 }
 
-void cs_klt_group_destroy(cs_klt_group* g) { delete g; }
+void cs_klt_group_destroy(cs_klt_group* g) {
+    if (!g) return;
+    if (g->copy_stream) {
+        (void)hipSetDevice(g->ks[0]->device);
+        (void)hipStreamSynchronize(g->copy_stream);
+        (void)hipStreamDestroy(g->copy_stream);
+        for (int q = 0; q < CS_STAGE_SLOTS; ++q) {
+            (void)hipEventDestroy(g->copied[q]);
+            (void)hipEventDestroy(g->freed[q]);
+        }
+        (void)hipFree(g->d_stage);
+    }
+    delete g;
+}
+
+// ---- host images into the device, asynchronously -----------------------------------------------------------------------
+// GPUKLT::next(const unsigned char*) (reference src/tracking/GPUKLT.cpp:144-161) uploads the frame and then tracks it: the
+// copy sits on the frame's critical path.  Here the n host images of a FUTURE frame go into the next slot of a small ring on
+// the group's copy stream while the current frame is tracked; the slot's device pointers are then handed to
+// cs_klt_group_prefetch_dev / _redetect_dev like any device image.  Pinned host memory (cs_pinned_alloc) makes the copies
+// truly asynchronous; pageable memory works, the runtime then stages it (and blocks the caller for the duration).
+int cs_klt_group_stage_h(cs_klt_group* g, const unsigned char* const* h_images, int* slot) {
+    CS_REQUIRE(g && h_images && slot, "cs_klt_group_stage_h: bad arguments");
+    cs_klt* k0 = g->ks[0];
+    int rc = bind_device(k0);
+    if (rc) return rc;
+    const size_t bytes = (size_t)k0->W * k0->H, n = g->ks.size();
+    if (!g->copy_stream) {
+        CS_HIP(hipMalloc((void**)&g->d_stage, bytes * n * CS_STAGE_SLOTS));
+        CS_HIP(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
+        for (int q = 0; q < CS_STAGE_SLOTS; ++q) {
+            CS_HIP(hipEventCreateWithFlags(&g->copied[q], hipEventDisableTiming));
+            CS_HIP(hipEventCreateWithFlags(&g->freed[q], hipEventDisableTiming));
+        }
+    }
+    const int q = g->next_slot;
+    g->next_slot = (q + 1) % CS_STAGE_SLOTS;
+    // whatever read this slot's previous images was enqueued on the group's stream before this call
+    CS_HIP(hipEventRecord(g->freed[q], g->stream));
+    CS_HIP(hipStreamWaitEvent(g->copy_stream, g->freed[q], 0));
+    for (size_t i = 0; i < n; ++i) {
+        if (!h_images[i]) {
+            cs_set_error("cs_klt_group_stage_h: null image of camera %d", (int)i);
+            return CS_ERR_INVALID;
+        }
+        CS_HIP(hipMemcpyAsync(g->d_stage + ((size_t)q * n + i) * bytes, h_images[i], bytes, hipMemcpyHostToDevice, g->copy_stream));
+    }
+    CS_HIP(hipEventRecord(g->copied[q], g->copy_stream));
+    *slot = q;
+    return CS_OK;
+}
+
+// the device images of a staged slot; the group's stream waits for the slot's copy (on the device: the host does not block)
+int cs_klt_group_staged(cs_klt_group* g, int slot, const void** d_images) {
+    CS_REQUIRE(g && d_images && slot >= 0 && slot < CS_STAGE_SLOTS && g->copy_stream, "cs_klt_group_staged: bad arguments (stage first)");
+    cs_klt* k0 = g->ks[0];
+    int rc = bind_device(k0);
+    if (rc) return rc;
+    CS_HIP(hipStreamWaitEvent(g->stream, g->copied[slot], 0));
+    const size_t bytes = (size_t)k0->W * k0->H, n = g->ks.size();
+    for (size_t i = 0; i < n; ++i) d_images[i] = g->d_stage + ((size_t)slot * n + i) * bytes;
+    return CS_OK;
+}
+
+void* cs_pinned_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        cs_set_error("cs_pinned_alloc: hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+void cs_pinned_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
 
 int cs_klt_group_size(const cs_klt_group* g) { return g ? (int)g->ks.size() : 0; }
 

@@ -201,6 +201,17 @@ class KLT_SequenceTracker:
               "cs_klt_debug_probe")
         return out
 
+    def redetect_async(self, image):
+        """cs_klt_redetect_async_h: upload + redetect + read-back enqueued, returns at once (GPUKLT::next, first half)"""
+        img = _u8(image, self.W, self.H)
+        check(self._L.cs_klt_redetect_async_h(self._h, img.ctypes.data_as(C.c_void_p)), "cs_klt_redetect_async_h")
+
+    def fetch(self):
+        """cs_klt_fetch: blocks until the outstanding frame's results are on the host -> (count, dest[])"""
+        dest, n = self._dest(), C.c_int(0)
+        check(self._L.cs_klt_fetch(self._h, C.byref(n), dest.ctypes.data_as(C.c_void_p)), "cs_klt_fetch")
+        return n.value, dest
+
     def set_cu_count(self, n_cus):
         check(self._L.cs_klt_set_cu_count(self._h, int(n_cus)), "cs_klt_set_cu_count")
 
@@ -298,3 +309,16 @@ class KLT_TrackerGroup:
 
     def synchronize(self):
         check(self._L.cs_klt_group_synchronize(self._h), "cs_klt_group_synchronize")
+
+    def stage_h(self, h_images):
+        """cs_klt_group_stage_h: the n HOST images (addresses; pinned memory for a truly asynchronous copy) of a future frame
+        into the next slot of the group's staging ring, on the group's copy stream.  Returns the slot."""
+        slot = C.c_int(-1)
+        check(self._L.cs_klt_group_stage_h(self._h, self._ptrs(h_images), C.byref(slot)), "cs_klt_group_stage_h")
+        return slot.value
+
+    def staged(self, slot):
+        """cs_klt_group_staged: the slot's device images (ints); the group's stream waits for the slot's copy"""
+        out = (C.c_void_p * self.n)()
+        check(self._L.cs_klt_group_staged(self._h, int(slot), out), "cs_klt_group_staged")
+        return [int(p) for p in out]

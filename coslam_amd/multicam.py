@@ -15,8 +15,15 @@ FEATURE_WORDS = 5   # sizeof(KLT_TrackedFeature) / 4
 POSE_WORDS = 24     # 12 doubles
 
 
+def feature_words_padded(n_features):
+    """int32 words of one camera's feature part: N x 5, padded to an even count so that R | t behind it are 8-byte aligned"""
+    return (n_features * FEATURE_WORDS + 1) & ~1
+
+
 def record_words(n_features):
-    return n_features * FEATURE_WORDS + POSE_WORDS
+    """int32 words of ONE camera's record: its N features (padded to 8 bytes), R (9 doubles), t (3 doubles) -- the layout of
+    both the torch path below and the native path (csrc/comm.hip)"""
+    return feature_words_padded(n_features) + POSE_WORDS
 
 
 class NativeComm:
@@ -86,7 +93,7 @@ class CameraExchange:
             self._x = C.c_void_p(h)
             self.world = native.world
             return
-        w = n_features * FEATURE_WORDS + POSE_WORDS * cams_per_rank
+        w = record_words(n_features // cams_per_rank) * cams_per_rank   # per-camera records back to back
         self.send = torch.zeros(w, dtype=torch.int32, device=device)
         self.recv = torch.zeros(w * self.world, dtype=torch.int32, device=device)
 
@@ -96,19 +103,21 @@ class CameraExchange:
         self._pending = (dest_words_list, R, t)
         if self._x is not None:
             return
-        n1 = (self.n // self.cams) * FEATURE_WORDS
+        n1 = self.n // self.cams
+        nf, fp, rw = n1 * FEATURE_WORDS, feature_words_padded(n1), record_words(n1)
+        Rw, tw = R.reshape(self.cams, 9).view(torch.int32), t.reshape(self.cams, 3).view(torch.int32)
         for i, d in enumerate(dest_words_list):
-            self.send[i * n1: (i + 1) * n1].copy_(d, non_blocking=True)
-        base = self.cams * n1
-        self.send[base: base + 18 * self.cams].copy_(R.reshape(-1).view(torch.int32), non_blocking=True)
-        self.send[base + 18 * self.cams:].copy_(t.reshape(-1).view(torch.int32), non_blocking=True)
+            self.send[i * rw: i * rw + nf].copy_(d, non_blocking=True)
+            self.send[i * rw + fp: i * rw + fp + 18].copy_(Rw[i], non_blocking=True)
+            self.send[i * rw + fp + 18: (i + 1) * rw].copy_(tw[i], non_blocking=True)
 
     def pack(self, dest_words, R, t):
         """dest_words: int32[N*5] view of the KLT_TrackedFeature array; R: f64[9]; t: f64[3] (same device)."""
-        nf = self.n * FEATURE_WORDS
+        assert self.cams == 1, "pack() is the one-camera-per-rank form; use pack_group()"
+        nf, fp = self.n * FEATURE_WORDS, feature_words_padded(self.n)
         self.send[:nf].copy_(dest_words, non_blocking=True)
-        self.send[nf: nf + 18].copy_(R.view(torch.int32), non_blocking=True)
-        self.send[nf + 18:].copy_(t.view(torch.int32), non_blocking=True)
+        self.send[fp: fp + 18].copy_(R.view(torch.int32), non_blocking=True)
+        self.send[fp + 18:].copy_(t.view(torch.int32), non_blocking=True)
 
     def all_gather(self, stream=None):
         if self._x is not None:
@@ -143,12 +152,19 @@ class CameraExchange:
             self.native._L.cs_exchange_destroy(self._x)
             self._x = None
 
-    def unpack(self, cam):
-        """-> (features int32[N,5] view, R f64[9], t f64[3]) of camera `cam` from the last all_gather."""
-        w = record_words(self.n)
-        rec = self.recv[cam * w: (cam + 1) * w]
-        nf = self.n * FEATURE_WORDS
-        return rec[:nf].view(self.n, FEATURE_WORDS), rec[nf: nf + 18].view(torch.float64), rec[nf + 18:].view(torch.float64)
+    def unpack(self, cam, device=None):
+        """-> (features int32[N,5] view, R f64[9], t f64[3]) of GLOBAL camera `cam` (rank cam // cams_per_rank, local index
+        cam % cams_per_rank) from the last all_gather; N = the slots of one camera.  Both paths (torch buffers / the native
+        exchange's library-owned buffer: pass `device`) use the same per-camera record."""
+        n1 = self.n // self.cams
+        nf, fp, w = n1 * FEATURE_WORDS, feature_words_padded(n1), record_words(n1)
+        if self._x is not None:
+            rec8, nb = self.native_records(device if device is not None else self.native.device)
+            assert nb == 4 * w
+            rec = rec8.view(torch.int32)[cam * w: (cam + 1) * w]
+        else:
+            rec = self.recv[cam * w: (cam + 1) * w]
+        return rec[:nf].view(n1, FEATURE_WORDS), rec[fp: fp + 18].view(torch.float64), rec[fp + 18:].view(torch.float64)
 
 
 def features_from_words(words):

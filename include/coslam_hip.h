@@ -88,6 +88,11 @@ int cs_klt_detect_present(cs_klt* k, const uint8_t* image, int* nDetectedFeature
 int cs_klt_redetect(cs_klt* k, const uint8_t* image, int* nNewFeatures, cs_klt_feature* dest);
 /* KLT_SequenceTracker::track(image,nPresent,dest), v3d_gpuklt.cpp:857-889 */
 int cs_klt_track(cs_klt* k, const uint8_t* image, int* nPresentFeatures, cs_klt_feature* dest);
+/* GPUKLT::next in two halves (asynchronous host form): cs_klt_redetect_async_h enqueues the upload, the redetect and the copy
+ * of dest[] back and returns; cs_klt_fetch blocks until that frame's results are on the host.  With one handle per camera all
+ * cameras' frames are in flight together.  One frame per handle may be outstanding. */
+int cs_klt_redetect_async_h(cs_klt* k, const unsigned char* image);
+int cs_klt_fetch(cs_klt* k, int* nNew, cs_klt_feature* dest);
 /* KLT_SequenceTracker::feedExternFeaturePoints(npts,featPts,trackIds,nFed), v3d_gpuklt.cpp:808-855.
  * featPts: npts*3 floats (stride 3 as GPUKLT.cpp:165-171 passes it); trackIds: npts ints. */
 int cs_klt_feed(cs_klt* k, int npts, const float* featPts, int* trackIds, int* nFed);
@@ -157,6 +162,16 @@ int cs_klt_group_detect_dev(cs_klt_group* g, const void* const* d_images, void* 
 int cs_klt_group_redetect_dev(cs_klt_group* g, const void* const* d_images, void* const* d_dests, void* const* d_counts);
 int cs_klt_group_track_dev(cs_klt_group* g, const void* const* d_images, void* const* d_dests, void* const* d_counts);
 int cs_klt_group_prefetch_dev(cs_klt_group* g, const void* const* d_images_next);
+/* Host images into the device OFF the frame's critical path (GPUKLT::next uploads, then tracks: reference
+ * src/tracking/GPUKLT.cpp:144-161).  cs_klt_group_stage_h copies the n host images of a FUTURE frame (W*H bytes each; pinned
+ * memory -- cs_pinned_alloc -- makes the copies truly asynchronous) into the next slot of a ring of 3 on the group's copy
+ * stream and returns the slot; cs_klt_group_staged makes the group's stream wait for that copy (a stream-side wait, the host
+ * does not block) and returns the slot's device images, which then go to cs_klt_group_prefetch_dev / _redetect_dev like any
+ * device image.  Stage frame f+2 while f is tracked and f+1 is prefetched: the copy never shows up in the frame time. */
+int cs_klt_group_stage_h(cs_klt_group* g, const unsigned char* const* h_images, int* slot);
+int cs_klt_group_staged(cs_klt_group* g, int slot, const void** d_images);
+void* cs_pinned_alloc(size_t bytes);
+void cs_pinned_free(void* p);
 int cs_klt_group_advance(cs_klt_group* g);     /* advanceFrame() on every handle */
 int cs_klt_group_synchronize(cs_klt_group* g); /* + the persistent tracker's error words */
 

@@ -38,3 +38,32 @@ def test_bench_prints_one_json_line_with_the_contract_keys(hip):
     assert r["bound"] == "hbm" and r["kernel"] == "k_track_rows_fused" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.01 < r["frac"] < 1.0
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
+
+
+def test_bench_two_ranks_on_one_gpu_feed_the_solve_from_the_gathered_records(hip):
+    """The N > 1 code path on a box with ONE GPU: two ranks pinned to the same device (BENCH_FORCE_DEVICE), gloo instead of RCCL
+    (which refuses two ranks on one device).  4 cameras per rank; every frame's all-gather delivers all 8 cameras' features
+    and poses to both ranks, and the inter-camera solve of a key frame starts from exactly those gathered poses
+    (InterCamPoseEstimator::addMapPoints, reference src/app/SL_InterCamPoseEstimator.cpp:24-37)."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BENCH_FORCE_DEVICE="0", BENCH_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    cfg = j["config"]
+    assert j["n_gpus"] == 2 and cfg["cameras_per_gpu"] == 4 and "gloo" in cfg["collectives"]
+    g = cfg["gathered_records"]
+    # every rank saw every camera's record of the last frame, bit for bit what the owning rank packed
+    assert g["cameras_checked"] == 8 and g["records_match_owner"] is True
+    # ... and the inter-camera solve's initial estimate was the gathered poses (all 8), not the pre-baked ones
+    assert g["intercam_start_is_gathered_pose"] is True and g["intercam_start_differs_from_prebaked"] is True
+    assert cfg["intercam_last"]["lm_steps"] > 0 and cfg["intercam_last"]["cost"] < cfg["intercam_last"]["cost0"]

@@ -725,3 +725,85 @@ def test_camera_group_rejects_mismatched_handles(hip):
     g.close()
     for t in (a, b, c):
         t.close()
+
+
+def test_staged_host_images_and_async_host_form_match_the_device_path(hip):
+    """cs_klt_group_stage_h / cs_klt_group_staged (host images into a device ring on a copy stream, two frames ahead) and
+    cs_klt_redetect_async_h / cs_klt_fetch (GPUKLT::next in two halves) give bit for bit what the device-resident and the
+    synchronous host entry points give."""
+    import torch
+
+    W, H, L, fw, fh, n_cams, n_frames = 320, 240, 3, 20, 15, 3, 7
+    sc = Scene(n_cams, W, H, 900, seed=77)
+    frames = [[sc.render(c, f) for f in range(n_frames)] for c in range(n_cams)]
+    cfg = cfg2(nLevels=L, minCornerness=1500.0)
+    dev = torch.device("cuda:0")
+
+    def make():
+        ts = []
+        for _ in range(n_cams):
+            t = coslam_amd.KLT_SequenceTracker(cfg, 0)
+            t.allocate(W, H, L, fw, fh)
+            ts.append(t)
+        return ts, coslam_amd.KLT_TrackerGroup(ts)
+
+    def run(staged):
+        ts, grp = make()
+        s = torch.cuda.Stream(device=dev)
+        grp.set_stream(s.cuda_stream)
+        d_img = [torch.from_numpy(np.stack(frames[c])).to(dev) for c in range(n_cams)]
+        h_img = [torch.from_numpy(np.stack(frames[c])).pin_memory() for c in range(n_cams)]
+        dests = [torch.zeros(fw * fh * 5, dtype=torch.int32, device=dev) for _ in range(n_cams)]
+        cnts = [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(n_cams)]
+        dp, cp = [d.data_ptr() for d in dests], [c.data_ptr() for c in cnts]
+        slots, out = {}, []
+        if staged:
+            for f in (0, 1):
+                slots[f] = grp.stage_h([h_img[c][f].data_ptr() for c in range(n_cams)])
+        for f in range(n_frames):
+            if staged:
+                if f + 2 < n_frames:
+                    slots[f + 2] = grp.stage_h([h_img[c][f + 2].data_ptr() for c in range(n_cams)])
+                cur = grp.staged(slots[f])
+                nxt = grp.staged(slots[f + 1]) if f + 1 < n_frames else None
+            else:
+                cur = [d_img[c][f].data_ptr() for c in range(n_cams)]
+                nxt = [d_img[c][f + 1].data_ptr() for c in range(n_cams)] if f + 1 < n_frames else None
+            if nxt is not None:
+                grp.prefetch_dev(nxt)
+            (grp.detect_dev if f == 0 else grp.redetect_dev)(cur, dp, cp)
+            grp.advanceFrame()
+            grp.synchronize()
+            out.append([d.cpu().numpy().copy() for d in dests])
+        grp.close()
+        for t in ts:
+            t.close()
+        return out
+
+    a, b = run(False), run(True)
+    for f in range(n_frames):
+        for c in range(n_cams):
+            assert np.array_equal(a[f][c], b[f][c]), (f, c)
+    # the asynchronous host form: all cameras' frames in flight together == the synchronous calls
+    ts_sync, _g1 = make()
+    ts_async, _g2 = make()
+    for c in range(n_cams):
+        ts_sync[c].detect(frames[c][0])
+        ts_async[c].detect(frames[c][0])
+        ts_sync[c].advanceFrame()
+        ts_async[c].advanceFrame()
+    for f in range(1, n_frames):
+        for c in range(n_cams):
+            ts_async[c].redetect_async(frames[c][f])
+        for c in range(n_cams):
+            n_s, d_s = ts_sync[c].redetect(frames[c][f])
+            n_a, d_a = ts_async[c].fetch()
+            assert n_s == n_a and np.array_equal(d_s, d_a), (f, c)
+            ts_sync[c].advanceFrame()
+            ts_async[c].advanceFrame()
+    with pytest.raises(coslam_amd.CoslamHipError):
+        ts_async[0].fetch()           # nothing outstanding
+    _g1.close()
+    _g2.close()
+    for t in ts_sync + ts_async:
+        t.close()
