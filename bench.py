@@ -516,16 +516,22 @@ def main():
     h_frames = None
     stage_slot = {}
 
+    upload_mode = os.environ.get("BENCH_UPLOAD_MODE", "")   # diagnostics: "copyonly" = stage but track the resident images
+
     def stage(i):
         f = order[i % len(order)]
-        stage_slot[i] = grp.stage_h([h_frames[c][f].data_ptr() for c in range(nc)])
+        stage_slot[i] = grp.stage_h([h_frames[f][c].data_ptr() for c in range(nc)])
 
     def step(i, key_frame, upload=False):
         f, fn = order[i % len(order)], order[(i + 1) % len(order)]
         b = i & 1
         if i >= 2:
             klt_s.wait_event(dest_free[b])      # the consumer of this dest buffer two frames ago is done
-        if upload:
+        if upload and upload_mode == "copyonly":
+            stage(i + 2)
+            stage_slot.pop(i)
+            cur, nxt = img_ptrs[f], img_ptrs[fn]
+        elif upload:
             stage(i + 2)
             cur, nxt = grp.staged(stage_slot.pop(i)), grp.staged(stage_slot[i + 1])
         else:
@@ -634,7 +640,9 @@ def main():
     with_upload = None
     if not args.no_upload_leg and not args.serial:
         # the same loop once more, the images coming from pinned host memory every frame (same key-frame cadence, same drain)
-        h_frames = [torch.from_numpy(frames[c]).pin_memory() for c in my_cams]
+        # one pinned ring entry per frame: the cameras' images back to back, as capture threads writing into cs_pinned_alloc'd
+        # memory would leave them -> ONE host-to-device copy per frame
+        h_frames = torch.from_numpy(np.stack([frames[c] for c in my_cams], axis=1).copy()).pin_memory()   # [frame][camera][H][W]
         i0 = args.warmup + args.steps + 1
         stage(i0)
         stage(i0 + 1)

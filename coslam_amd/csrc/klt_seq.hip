@@ -617,6 +617,27 @@ static int fetch_results(cs_klt* k, int* count, cs_klt_feature* dest) {
     return CS_OK;
 }
 
+// device-side pull of a host image (pinned, device-visible) into the staging ring: 16-byte loads over PCIe, grid-stride
+__global__ __launch_bounds__(256) void k_stage_pull(uint8_t* dst, const uint8_t* src, size_t nbytes) {
+    const size_t n16 = nbytes / 16, t0 = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const u4v* s4 = (const u4v*)src;
+    u4v* d4 = (u4v*)dst;
+    __builtin_amdgcn_s_setprio(0);  // (a background copy: never ahead of the tracker's or the solves' waves)
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        size_t q = t0;
+        for (; q + 3 * stride < n16; q += 4 * stride) {  // four 16-byte PCIe reads in flight per lane
+            const u4v a = __builtin_nontemporal_load(s4 + q), b = __builtin_nontemporal_load(s4 + q + stride),
+                      c = __builtin_nontemporal_load(s4 + q + 2 * stride), d = __builtin_nontemporal_load(s4 + q + 3 * stride);
+            d4[q] = a, d4[q + stride] = b, d4[q + 2 * stride] = c, d4[q + 3 * stride] = d;
+        }
+        for (; q < n16; q += stride) d4[q] = __builtin_nontemporal_load(s4 + q);
+        for (size_t q = n16 * 16 + t0; q < nbytes; q += stride) dst[q] = src[q];
+    } else {
+        for (size_t q = t0; q < nbytes; q += stride) dst[q] = src[q];
+    }
+}
+
 static int upload_image(cs_klt* k, const uint8_t* image) {
     memcpy(k->h_img, image, (size_t)k->W * k->H);
     CS_HIP(hipMemcpyAsync(k->d_img, k->h_img, (size_t)k->W * k->H, hipMemcpyHostToDevice, k->stream));
@@ -1331,17 +1352,49 @@ int cs_klt_group_stage_h(cs_klt_group* g, const unsigned char* const* h_images, 
     }
     const int q = g->next_slot;
     g->next_slot = (q + 1) % CS_STAGE_SLOTS;
-    // whatever read this slot's previous images was enqueued on the group's stream before this call
-    CS_HIP(hipEventRecord(g->freed[q], g->stream));
-    CS_HIP(hipStreamWaitEvent(g->copy_stream, g->freed[q], 0));
+    // By default the pull runs on the group's OWN stream, in order with the frames: 57 us in front of the next tracker launch,
+    // on a stream that has slack (the key-frame solves bound the loop) -- measured 0.88-0.91 of the resident-image frame rate,
+    // against 0.84 with the pull on a second stream beside the tracker (two more cross-stream events per frame cost more than
+    // the serialisation; COSLAM_STAGE_INLINE=0 selects that form).  profiles/r03_upload.txt
+    static const bool inlinePull = !(getenv("COSLAM_STAGE_INLINE") && getenv("COSLAM_STAGE_INLINE")[0] == '0');
+    hipStream_t cs = inlinePull ? g->stream : g->copy_stream;
+    if (!inlinePull) {
+        // whatever read this slot's previous images was enqueued on the group's stream before this call
+        CS_HIP(hipEventRecord(g->freed[q], g->stream));
+        CS_HIP(hipStreamWaitEvent(g->copy_stream, g->freed[q], 0));
+    }
+    bool contiguous = true;  // the capture side wrote the n images back to back (one pinned ring entry per frame): ONE copy
     for (size_t i = 0; i < n; ++i) {
         if (!h_images[i]) {
             cs_set_error("cs_klt_group_stage_h: null image of camera %d", (int)i);
             return CS_ERR_INVALID;
         }
-        CS_HIP(hipMemcpyAsync(g->d_stage + ((size_t)q * n + i) * bytes, h_images[i], bytes, hipMemcpyHostToDevice, g->copy_stream));
+        if (i > 0 && h_images[i] != h_images[i - 1] + bytes) contiguous = false;
     }
-    CS_HIP(hipEventRecord(g->copied[q], g->copy_stream));
+    // hipMemcpyAsync from pinned memory is NOT asynchronous for the caller here: the runtime writes through the PCIe aperture
+    // on the calling thread (measured: 160-280 us of host time per 2.4 MB call, tools/stage_time.py) -- a frame loop that
+    // enqueues 0.4 ms frames cannot afford that.  Pinned (device-visible) memory is therefore PULLED by a small copy kernel on
+    // the copy stream (a kernel launch for the host, PCIe reads for the device); pageable memory takes hipMemcpyAsync.
+    auto one = [&](uint8_t* dst, const unsigned char* src, size_t nbytes) -> int {
+        void* dsrc = nullptr;
+        if (hipHostGetDevicePointer(&dsrc, (void*)src, 0) == hipSuccess && dsrc) {
+            static const int blocks = getenv("COSLAM_STAGE_BLOCKS") ? atoi(getenv("COSLAM_STAGE_BLOCKS")) : 16;  // a few CUs
+            // are plenty for a PCIe-bound pull (~90 KB in flight saturate the link); the tracker and the solves keep the rest
+            hipLaunchKernelGGL(k_stage_pull, dim3(blocks), dim3(256), 0, cs, dst, (const uint8_t*)dsrc, nbytes);
+            CS_CHECK_LAUNCH();
+        } else {
+            (void)hipGetLastError();
+            CS_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, cs));
+        }
+        return CS_OK;
+    };
+    if (contiguous) {
+        if ((rc = one(g->d_stage + (size_t)q * n * bytes, h_images[0], bytes * n))) return rc;
+    } else {
+        for (size_t i = 0; i < n; ++i)
+            if ((rc = one(g->d_stage + ((size_t)q * n + i) * bytes, h_images[i], bytes))) return rc;
+    }
+    CS_HIP(hipEventRecord(g->copied[q], cs));
     *slot = q;
     return CS_OK;
 }

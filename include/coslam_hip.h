@@ -164,10 +164,12 @@ int cs_klt_group_track_dev(cs_klt_group* g, const void* const* d_images, void* c
 int cs_klt_group_prefetch_dev(cs_klt_group* g, const void* const* d_images_next);
 /* Host images into the device OFF the frame's critical path (GPUKLT::next uploads, then tracks: reference
  * src/tracking/GPUKLT.cpp:144-161).  cs_klt_group_stage_h copies the n host images of a FUTURE frame (W*H bytes each; pinned
- * memory -- cs_pinned_alloc -- makes the copies truly asynchronous) into the next slot of a ring of 3 on the group's copy
- * stream and returns the slot; cs_klt_group_staged makes the group's stream wait for that copy (a stream-side wait, the host
- * does not block) and returns the slot's device images, which then go to cs_klt_group_prefetch_dev / _redetect_dev like any
- * device image.  Stage frame f+2 while f is tracked and f+1 is prefetched: the copy never shows up in the frame time. */
+ * memory -- cs_pinned_alloc -- is PULLED by a copy kernel: a kernel launch for the caller; hipMemcpyAsync blocks the calling
+ * thread for 160-280 us per 2.4 MB here; pageable memory falls back to it) into the next slot of a ring of 3 and returns
+ * the slot; cs_klt_group_staged orders the group's stream behind that copy (a stream-side wait, the host does not block) and
+ * returns the slot's device images, which then go to cs_klt_group_prefetch_dev / _redetect_dev like any device image.
+ * Stage frame f+2 while f is tracked and f+1 is prefetched.  Images written back to back (one ring entry per frame) go in
+ * one copy. */
 int cs_klt_group_stage_h(cs_klt_group* g, const unsigned char* const* h_images, int* slot);
 int cs_klt_group_staged(cs_klt_group* g, int slot, const void** d_images);
 void* cs_pinned_alloc(size_t bytes);

@@ -798,7 +798,7 @@ def test_staged_host_images_and_async_host_form_match_the_device_path(hip):
         for c in range(n_cams):
             n_s, d_s = ts_sync[c].redetect(frames[c][f])
             n_a, d_a = ts_async[c].fetch()
-            assert n_s == n_a and np.array_equal(d_s, d_a), (f, c)
+            assert n_s == n_a and np.array_equal(d_s.view(np.uint8), d_a.view(np.uint8)), (f, c)   # (bitwise: dead slots hold NaN)
             ts_sync[c].advanceFrame()
             ts_async[c].advanceFrame()
     with pytest.raises(coslam_amd.CoslamHipError):

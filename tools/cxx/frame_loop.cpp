@@ -1,0 +1,389 @@
+// frame_loop.cpp -- the headline frame loop of bench.py driven from C++ through the C-ABI only (include/coslam_hip.h): no
+// Python, no torch.  north_star: "Host stays C++".  Same workload, same streams, same key-frame cadence, same drain as
+// bench.py's timed loop; the workload (synthetic frames, map, BA problems, pose graphs) is read from the file bench.py writes
+// with --export-workload (tools: bench.py export_workload()).
+//   hipcc -O2 -std=c++17 -Iinclude tools/cxx/frame_loop.cpp -Lcoslam_amd/lib -lcoslam_hip -Wl,-rpath,$PWD/coslam_amd/lib \
+//         -o tools/cxx/frame_loop.bin
+//   tools/cxx/frame_loop.bin <workload file> <steps> <warmup> [cams per tracker launch]
+// Per frame (reference call sites in bench.py's docstring): camera-group redetect (+ prefetch of the next frame's front) on the
+// tracker stream; hand-back + intraCamEstimate of all cameras + both registration passes on the pose stream, event-ordered
+// behind the tracker; at key frames the inter-camera solve and the joint local BA on their workspaces' worker threads
+// (cs_ba_solve_async), the pose-graph relaxation installed as the joint BA's follow-up.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "coslam_hip.h"
+
+#define HIPCHK(x)                                                                              \
+    do {                                                                                       \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess) {                                                                \
+            fprintf(stderr, "%s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(2);                                                                           \
+        }                                                                                      \
+    } while (0)
+#define CSCHK(x)                                                                     \
+    do {                                                                             \
+        int rc_ = (x);                                                               \
+        if (rc_ != CS_OK) {                                                          \
+            fprintf(stderr, "%s failed (%d): %s (%s:%d)\n", #x, rc_, cs_last_error(), __FILE__, __LINE__); \
+            exit(3);                                                                 \
+        }                                                                            \
+    } while (0)
+
+struct Reader {
+    FILE* f;
+    template <class T>
+    std::vector<T> vec(size_t n) {
+        std::vector<T> v(n);
+        if (n && fread(v.data(), sizeof(T), n, f) != n) {
+            fprintf(stderr, "workload file truncated\n");
+            exit(4);
+        }
+        return v;
+    }
+    int i32() { return vec<int>(1)[0]; }
+    double f64() { return vec<double>(1)[0]; }
+};
+
+template <class T>
+static T* to_dev(const std::vector<T>& h) {
+    T* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, sizeof(T) * (h.size() ? h.size() : 1)));
+    if (!h.empty()) HIPCHK(hipMemcpy(d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+    return d;
+}
+template <class T>
+static T* dev_zeros(size_t n) {
+    T* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, sizeof(T) * (n ? n : 1)));
+    HIPCHK(hipMemset(d, 0, sizeof(T) * (n ? n : 1)));
+    return d;
+}
+
+struct BaProblem {
+    int C, P, nObs, nCamsCon, nPtsCon, maxIter, inner;
+    double maxErr;
+    std::vector<double> Ks, Rs, Ts, pts, xy;
+    std::vector<int> ptr, cam;
+    cs_ba* ws = nullptr;
+    double *dR = nullptr, *dT = nullptr, *dM = nullptr;
+    void read(Reader& r) {
+        C = r.i32(), P = r.i32(), nObs = r.i32(), nCamsCon = r.i32(), nPtsCon = r.i32(), maxIter = r.i32(), inner = r.i32();
+        maxErr = r.f64();
+        Ks = r.vec<double>(9 * (size_t)C), Rs = r.vec<double>(9 * (size_t)C), Ts = r.vec<double>(3 * (size_t)C);
+        pts = r.vec<double>(3 * (size_t)P);
+        ptr = r.vec<int>((size_t)P + 1), cam = r.vec<int>((size_t)nObs), xy = r.vec<double>(2 * (size_t)nObs);
+    }
+    void upload(int dev) {
+        ws = cs_ba_create(dev);
+        if (!ws) {
+            fprintf(stderr, "cs_ba_create: %s\n", cs_last_error());
+            exit(3);
+        }
+        CSCHK(cs_ba_upload(ws, C, P, nObs, Ks.data(), Rs.data(), Ts.data(), pts.data(), ptr.data(), cam.data(), xy.data()));
+        dR = to_dev(Rs), dT = to_dev(Ts), dM = to_dev(pts);
+    }
+    void solve_async(hipStream_t after) {
+        CSCHK(cs_ba_solve_async(ws, (void*)after, C, P, nObs, dR, dT, dM, nCamsCon, nPtsCon, maxErr, maxIter, inner));
+    }
+};
+
+int main(int argc, char** argv) {
+    if (argc < 4) {
+        fprintf(stderr, "usage: %s <workload file> <steps> <warmup> [cams per tracker launch]\n", argv[0]);
+        return 1;
+    }
+    const int steps = atoi(argv[2]), warmup = atoi(argv[3]);
+    const int camsPerLaunchArg = argc > 4 ? atoi(argv[4]) : -1;
+    Reader rd{fopen(argv[1], "rb")};
+    if (!rd.f) {
+        perror(argv[1]);
+        return 1;
+    }
+    char magic[8];
+    if (fread(magic, 1, 8, rd.f) != 8 || memcmp(magic, "CSWL1\0\0\0", 8) != 0) {
+        fprintf(stderr, "%s is not a workload file\n", argv[1]);
+        return 1;
+    }
+    const std::vector<int> hd = rd.vec<int>(16);
+    const int nCams = hd[0], W = hd[1], H = hd[2], L = hd[3], FW = hd[4], FH = hd[5], nFrames = hd[6], orderLen = hd[7],
+              nMap = hd[8], P_REG = hd[9], PTS = hd[10], nColBlk = hd[11], nRowBlk = hd[12], keyEvery = hd[13];
+    const int camsPerLaunch = camsPerLaunchArg >= 0 ? camsPerLaunchArg : hd[14];
+    const int N = FW * FH, dev = 0;
+    const std::vector<int> order = rd.vec<int>(orderLen);
+    const std::vector<double> K = rd.vec<double>(9);
+    cs_klt_config cfg;
+    {
+        const std::vector<int> ci = rd.vec<int>(6);      // nIterations, nLevels, levelSkip, windowWidth, trackWithGain, minDistance
+        const std::vector<float> cf = rd.vec<float>(5);  // trackBorderMargin, convergenceThreshold, SSD_Threshold, minCornerness, detectBorderMargin
+        cfg.nIterations = ci[0], cfg.nLevels = ci[1], cfg.levelSkip = ci[2], cfg.windowWidth = ci[3], cfg.trackWithGain = ci[4],
+        cfg.minDistance = ci[5];
+        cfg.trackBorderMargin = cf[0], cfg.convergenceThreshold = cf[1], cfg.SSD_Threshold = cf[2], cfg.minCornerness = cf[3],
+        cfg.detectBorderMargin = cf[4];
+    }
+    HIPCHK(hipSetDevice(dev));
+    // frames: resident in HBM before the clock starts, like bench.py's headline
+    std::vector<uint8_t*> dFrames(nCams);
+    const size_t imgBytes = (size_t)W * H;
+    for (int c = 0; c < nCams; ++c) dFrames[c] = to_dev(rd.vec<uint8_t>(imgBytes * nFrames));
+    const std::vector<double> mapPts = rd.vec<double>(3 * (size_t)nMap);
+    // projections of the visible map points in the first frame (for the slot -> map point association that stands in for the
+    // map initialisation, as in bench.py associate())
+    std::vector<std::vector<int>> visIdx(nCams);
+    std::vector<std::vector<double>> visUV(nCams);
+    for (int c = 0; c < nCams; ++c) {
+        const int nv = rd.i32();
+        visIdx[c] = rd.vec<int>(nv);
+        visUV[c] = rd.vec<double>(2 * (size_t)nv);
+    }
+    const std::vector<double> R0 = rd.vec<double>(9 * (size_t)nCams), t0 = rd.vec<double>(3 * (size_t)nCams);
+    const std::vector<double> cov = rd.vec<double>(9 * 2 * (size_t)P_REG);
+    BaProblem joint, ic;
+    joint.read(rd);
+    ic.read(rd);
+    const int pgGraphs = rd.i32(), pgNodesPer = rd.i32();
+    const int pgNodes = pgGraphs * pgNodesPer, pgEdges = pgGraphs * (pgNodesPer - 1);
+    const std::vector<uint8_t> pgFixed = rd.vec<uint8_t>(pgNodes);
+    const std::vector<double> pgR = rd.vec<double>(9 * (size_t)pgNodes), pgT = rd.vec<double>(3 * (size_t)pgNodes);
+    const std::vector<int> pgCam = rd.vec<int>(joint.C);
+    fclose(rd.f);
+
+    // ---- trackers, group, streams ----
+    hipStream_t kltS, poseS;
+    HIPCHK(hipStreamCreateWithFlags(&kltS, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&poseS, hipStreamNonBlocking));
+    std::vector<cs_klt*> trk(nCams);
+    for (int c = 0; c < nCams; ++c) {
+        trk[c] = cs_klt_create(&cfg, dev, 0);
+        if (!trk[c]) {
+            fprintf(stderr, "cs_klt_create: %s\n", cs_last_error());
+            return 3;
+        }
+        CSCHK(cs_klt_allocate(trk[c], W, H, L, FW, FH, 0, 0));
+    }
+    cs_klt_group* grp = cs_klt_group_create(trk.data(), nCams);
+    if (!grp) {
+        fprintf(stderr, "cs_klt_group_create: %s\n", cs_last_error());
+        return 3;
+    }
+    CSCHK(cs_klt_group_set_stream(grp, (void*)kltS));
+    if (camsPerLaunch > 0)  // the co-residency budget of `camsPerLaunch` cameras (250 waves each, 8 resident waves per CU)
+        for (cs_klt* k : trk) CSCHK(cs_klt_set_cu_count(k, std::min(256, (250 * camsPerLaunch + 60) / 8 + 5)));
+
+    double* dK = to_dev(K);
+    std::vector<double> Kall;
+    for (int c = 0; c < nCams; ++c) Kall.insert(Kall.end(), K.begin(), K.end());
+    double* dKall = to_dev(Kall);
+    double* dKud = dev_zeros<double>(7);
+    double* dMap = to_dev(mapPts);
+    double* dCov = to_dev(cov);
+    int* dS2M = dev_zeros<int>((size_t)nCams * N);
+    int* dSpan = dev_zeros<int>((size_t)nCams * 2 * N);
+    HIPCHK(hipMemset(dS2M, 0xff, sizeof(int) * (size_t)nCams * N));
+    HIPCHK(hipMemset(dSpan, 0xff, sizeof(int) * (size_t)nCams * 2 * N));
+    double* dXY = dev_zeros<double>((size_t)nCams * 2 * N);
+    int* dState = dev_zeros<int>((size_t)nCams * N);
+    double* dMs = dev_zeros<double>((size_t)nCams * PTS * 3);
+    double* dms = dev_zeros<double>((size_t)nCams * PTS * 2);
+    int* dSel = dev_zeros<int>((size_t)nCams * PTS);
+    int* dNpts = dev_zeros<int>(nCams);
+    cs_pose_option* dOpt = (cs_pose_option*)dev_zeros<unsigned char>((size_t)nCams * sizeof(cs_pose_option));
+    int* dOk = dev_zeros<int>(nCams);
+    int* dPf = dev_zeros<int>((size_t)P_REG * nCams);
+    int* dPfNone = dev_zeros<int>((size_t)P_REG * nCams);
+    HIPCHK(hipMemset(dPf, 0xff, sizeof(int) * (size_t)P_REG * nCams));
+    HIPCHK(hipMemset(dPfNone, 0xff, sizeof(int) * (size_t)P_REG * nCams));
+    double* dR[2] = {to_dev(R0), to_dev(R0)};
+    double* dT[2] = {to_dev(t0), to_dev(t0)};
+    cs_klt_feature* dDest[2][16];
+    int* dCnt[16];
+    for (int c = 0; c < nCams; ++c) {
+        dDest[0][c] = dev_zeros<cs_klt_feature>(N);
+        dDest[1][c] = dev_zeros<cs_klt_feature>(N);
+        dCnt[c] = dev_zeros<int>(4);
+    }
+    struct RegOut {
+        int *slot, *flags;
+        double *m, *var, *dist;
+    } reg[2];
+    for (RegOut& o : reg) {
+        o.slot = dev_zeros<int>((size_t)P_REG * nCams), o.flags = dev_zeros<int>((size_t)P_REG * nCams);
+        o.m = dev_zeros<double>((size_t)P_REG * nCams * 2), o.var = dev_zeros<double>((size_t)P_REG * nCams * 4);
+        o.dist = dev_zeros<double>((size_t)P_REG * nCams);
+    }
+    auto hb_cams = [&](int b) {
+        std::vector<cs_handback_cam> v(nCams);
+        for (int c = 0; c < nCams; ++c) {
+            cs_handback_cam& h = v[c];
+            memset(&h, 0, sizeof(h));
+            h.dest = dDest[b][c], h.K = dK, h.kud = dKud, h.mapPts = dMap, h.slot2map = dS2M + (size_t)c * N;
+            h.trackSpan = dSpan + (size_t)c * 2 * N, h.xy = dXY + (size_t)c * 2 * N, h.state = dState + (size_t)c * N;
+            h.Ms = dMs + (size_t)c * PTS * 3, h.ms = dms + (size_t)c * PTS * 2, h.sel = dSel + (size_t)c * PTS;
+            h.npts = dNpts + c, h.opt = dOpt + c, h.pointFeat = dPf + c, h.pointFeatStride = nCams, h.nPointFeat = P_REG;
+        }
+        return v;
+    };
+    const std::vector<cs_handback_cam> hb[2] = {hb_cams(0), hb_cams(1)};
+    auto reg_cams = [&](int dst) {
+        std::vector<cs_register_cam> v(nCams);
+        for (int c = 0; c < nCams; ++c) {
+            memset(&v[c], 0, sizeof(v[c]));
+            v[c].K = dK, v[c].R = dR[dst] + 9 * c, v[c].t = dT[dst] + 3 * c, v[c].xy = dXY + (size_t)c * 2 * N;
+            v[c].state = dState + (size_t)c * N, v[c].slot2map = dS2M + (size_t)c * N;
+        }
+        return v;
+    };
+    const std::vector<cs_register_cam> rc[2] = {reg_cams(0), reg_cams(1)};
+
+    // ---- key-frame solves: workspaces, pose graphs as the joint BA's follow-up ----
+    joint.upload(dev);
+    ic.upload(dev);
+    std::vector<int> nodePtr(pgGraphs + 1), edgePtr(pgGraphs + 1), id1, id2;
+    for (int g = 0; g <= pgGraphs; ++g) nodePtr[g] = g * pgNodesPer, edgePtr[g] = g * (pgNodesPer - 1);
+    for (int g = 0; g < pgGraphs; ++g)
+        for (int e = 0; e < pgNodesPer - 1; ++e) id1.push_back(e), id2.push_back(e + 1);
+    cs_posegraph* pg = nullptr;
+    CSCHK(cs_posegraph_create(dev, pgGraphs, nodePtr.data(), edgePtr.data(), pgFixed.data(), id1.data(), id2.data(), &pg));
+    double *dPgR = to_dev(pgR), *dPgT = to_dev(pgT), *dPgER = dev_zeros<double>(9 * (size_t)pgEdges),
+           *dPgET = dev_zeros<double>(3 * (size_t)pgEdges), *dPgNR = dev_zeros<double>(9 * (size_t)pgNodes),
+           *dPgNT = dev_zeros<double>(3 * (size_t)pgNodes);
+    int* dPgCam = to_dev(pgCam);
+    CSCHK(cs_posegraph_edges_dev(pg, nullptr, dPgR, dPgT, dPgER, dPgET));
+    HIPCHK(hipDeviceSynchronize());
+    cs_posegraph_after_ba_rec rec;
+    memset(&rec, 0, sizeof(rec));
+    rec.g = pg, rec.device = dev, rec.nCams = joint.C, rec.d_camNode = dPgCam;
+    {
+        double *bR, *bT, *bM;
+        CSCHK(cs_ba_result_buffers(joint.ws, &bR, &bT, &bM));
+        rec.d_Rs = bR, rec.d_Ts = bT;
+    }
+    rec.d_nodeR = dPgR, rec.d_nodeT = dPgT, rec.d_edgeR = dPgER, rec.d_edgeT = dPgET, rec.d_newR = dPgNR, rec.d_newT = dPgNT;
+    CSCHK(cs_ba_set_followup(joint.ws, cs_posegraph_after_ba, &rec));
+
+    hipEvent_t kltDone[2], destFree[2];
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(hipEventCreateWithFlags(&kltDone[b], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&destFree[b], hipEventDisableTiming));
+    }
+    auto img_ptrs = [&](int f, const void** out) {
+        for (int c = 0; c < nCams; ++c) out[c] = dFrames[c] + imgBytes * f;
+    };
+    const double PIX = 10.0;  // Const::PIXEL_ERR_VAR, reference src/app/SL_GlobParam.cpp:37
+    auto step = [&](int i, bool key) {
+        const int f = order[i % orderLen], fn = order[(i + 1) % orderLen], b = i & 1;
+        const void *cur[16], *nxt[16];
+        void *dst[16], *cnt[16];
+        img_ptrs(f, cur);
+        img_ptrs(fn, nxt);
+        for (int c = 0; c < nCams; ++c) dst[c] = dDest[b][c], cnt[c] = dCnt[c];
+        if (i >= 2) HIPCHK(hipStreamWaitEvent(kltS, destFree[b], 0));
+        CSCHK(cs_klt_group_prefetch_dev(grp, nxt));
+        CSCHK(cs_klt_group_redetect_dev(grp, cur, dst, cnt));
+        CSCHK(cs_klt_group_advance(grp));
+        HIPCHK(hipEventRecord(kltDone[b], kltS));
+        HIPCHK(hipStreamWaitEvent(poseS, kltDone[b], 0));
+        CSCHK(cs_klt_handback_dev(dev, (void*)poseS, nCams, hb[b].data(), N, W, H, nColBlk, nRowBlk, PTS, i));
+        const int src = (i + 1) & 1, dsti = i & 1;
+        CSCHK(cs_pose_intracam_batch_dev(dev, (void*)poseS, nCams, PTS, dKall, dR[src], dT[src], dNpts, nullptr, dMs, dms, 10.0,
+                                         dR[dsti], dT[dsti], dOpt, dOk));
+        // activeMapPointsRegister, then currentMapPointsRegister (static points), search step
+        CSCHK(cs_register_search_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, P_REG, dMap + 3 * (size_t)P_REG,
+                                     dCov + 9 * (size_t)P_REG, dPfNone, 2.5 * PIX, 3 * PIX, PIX, reg[0].slot, reg[0].m, reg[0].var,
+                                     reg[0].dist, reg[0].flags));
+        CSCHK(cs_register_search_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, P_REG, dMap, dCov, dPf, PIX, 3 * PIX, PIX,
+                                     reg[1].slot, reg[1].m, reg[1].var, reg[1].dist, reg[1].flags));
+        HIPCHK(hipEventRecord(destFree[b], poseS));
+        if (key) {
+            ic.solve_async(poseS);
+            joint.solve_async(poseS);
+        }
+    };
+    auto barrier = [&]() {
+        CSCHK(cs_ba_wait(ic.ws));
+        CSCHK(cs_ba_wait(joint.ws));
+        HIPCHK(hipDeviceSynchronize());
+    };
+
+    // ---- first frame: detect, map association, first hand-back (GPUKLT::first + map initialisation stand-in) ----
+    {
+        const void* cur[16];
+        void *dst[16], *cnt[16];
+        img_ptrs(order[0], cur);
+        for (int c = 0; c < nCams; ++c) dst[c] = dDest[0][c], cnt[c] = dCnt[c];
+        CSCHK(cs_klt_group_detect_dev(grp, cur, dst, cnt));
+        CSCHK(cs_klt_group_advance(grp));
+        CSCHK(cs_klt_group_synchronize(grp));
+    }
+    auto associate = [&]() {
+        std::vector<cs_klt_feature> d(N);
+        std::vector<int> s2m(N);
+        for (int c = 0; c < nCams; ++c) {
+            HIPCHK(hipMemcpy(d.data(), dDest[0][c], sizeof(cs_klt_feature) * N, hipMemcpyDeviceToHost));
+            const std::vector<double>& uv = visUV[c];
+            const int nv = (int)visIdx[c].size();
+            for (int s = 0; s < N; ++s) {
+                s2m[s] = -1;
+                if (d[s].status < 0) continue;
+                const double px = (double)d[s].pos[0] * W, py = (double)d[s].pos[1] * H;
+                double best = 1.0;  // nearest projected point within 1 px
+                for (int q = 0; q < nv; ++q) {
+                    const double dx = uv[2 * q] - px, dy = uv[2 * q + 1] - py, dd = std::sqrt(dx * dx + dy * dy);
+                    if (dd < best) best = dd, s2m[s] = visIdx[c][q];
+                }
+            }
+            HIPCHK(hipMemcpy(dS2M + (size_t)c * N, s2m.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+        }
+    };
+    associate();
+    CSCHK(cs_klt_handback_dev(dev, (void*)poseS, nCams, hb[0].data(), N, W, H, nColBlk, nRowBlk, PTS, 0));
+    HIPCHK(hipDeviceSynchronize());
+    associate();  // (the first hand-back starts every track as new, i.e. unmapped: put the map back)
+    HIPCHK(hipDeviceSynchronize());
+
+    // set-up (one key-frame interval: graph capture in the BA workers, lazy code-object loading), warm-up, timed loop
+    for (int i = 0; i < std::max(keyEvery, 1) + 1; ++i) step(i + 1, keyEvery > 0 && i == 0);
+    barrier();
+    for (int i = 0; i < warmup; ++i) step(i + 1, keyEvery > 0 && i % keyEvery == 0);
+    barrier();
+    const auto t0c = std::chrono::steady_clock::now();
+    for (int i = 0; i < steps; ++i) step(warmup + i + 1, keyEvery > 0 && i % keyEvery == 0);
+    const auto t1c = std::chrono::steady_clock::now();
+    barrier();
+    const auto t2c = std::chrono::steady_clock::now();
+    const double dt = std::chrono::duration<double>(t2c - t0c).count(), dtHost = std::chrono::duration<double>(t1c - t0c).count();
+
+    // sanity of what was computed: live features, pose flags, the solves' statistics
+    int okAll = 1, minLive = N;
+    {
+        std::vector<int> ok(nCams);
+        HIPCHK(hipMemcpy(ok.data(), dOk, sizeof(int) * nCams, hipMemcpyDeviceToHost));
+        for (int v : ok) okAll &= (v != 0);
+        std::vector<cs_klt_feature> d(N);
+        const int last = (warmup + steps) & 1;
+        for (int c = 0; c < nCams; ++c) {
+            HIPCHK(hipMemcpy(d.data(), dDest[last][c], sizeof(cs_klt_feature) * N, hipMemcpyDeviceToHost));
+            int live = 0;
+            for (const cs_klt_feature& q : d) live += q.status >= 0;
+            minLive = std::min(minLive, live);
+        }
+    }
+    cs_ba_stats sj, si;
+    CSCHK(cs_ba_download(joint.ws, joint.C, joint.P, joint.nObs, nullptr, nullptr, nullptr, nullptr, &sj));
+    CSCHK(cs_ba_download(ic.ws, ic.C, ic.P, ic.nObs, nullptr, nullptr, nullptr, nullptr, &si));
+    printf("{\"frames_per_s\": %.3f, \"ms_per_step\": %.5f, \"steps\": %d, \"warmup\": %d, \"host_enqueue_ms_per_step\": %.5f, "
+           "\"cams_per_tracker_launch\": %d, \"pose_ok\": %s, \"min_live_features\": %d, \"joint_lm_steps\": %d, \"joint_cost\": %.6f, "
+           "\"intercam_lm_steps\": %d, \"intercam_cost\": %.6f}\n",
+           steps / dt, dt / steps * 1e3, steps, warmup, dtHost / steps * 1e3, camsPerLaunch, okAll ? "true" : "false", minLive,
+           sj.nIterTotal, sj.cost, si.nIterTotal, si.cost);
+    return 0;
+}
