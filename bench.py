@@ -139,6 +139,55 @@ def reg_covariances():
     return A @ A.transpose(0, 2, 1) + 1e-6 * np.eye(3)
 
 
+def export_workload(path, sc, frames, joint, ic, cams_per_launch):
+    """The headline workload as one binary file for tools/cxx/frame_loop.cpp (the same loop driven from C++ through the C-ABI):
+    magic, int32 header[16], frame order, K, the KLT configuration, the frames, the map, the projections of the visible points in
+    the first frame (for the slot -> map association), the initial poses, the registration covariances, both BA problems, the
+    pose graphs of the joint BA's window."""
+    import struct
+
+    order = frame_order(N_FRAMES)
+    cfg = klt_config()
+    pg_graphs, pg_R, pg_T, pg_cam = build_pose_graphs(sc, joint, range(N_CAMS))
+    with open(path, "wb") as f:
+        f.write(b"CSWL1\0\0\0")
+        hd = [N_CAMS, W, H, LEVELS, FW, FH, N_FRAMES, len(order), len(sc.points), P_REG, PTS_STRIDE, N_COL_BLK, N_ROW_BLK, KEY_EVERY,
+              cams_per_launch, 0]
+        f.write(np.asarray(hd, np.int32).tobytes())
+        f.write(np.asarray(order, np.int32).tobytes())
+        f.write(np.ascontiguousarray(sc.K, np.float64).tobytes())
+        f.write(np.asarray([cfg.nIterations, cfg.nLevels, cfg.levelSkip, cfg.windowWidth, cfg.trackWithGain, cfg.minDistance], np.int32).tobytes())
+        f.write(np.asarray([cfg.trackBorderMargin, cfg.convergenceThreshold, cfg.SSD_Threshold, cfg.minCornerness, cfg.detectBorderMargin],
+                           np.float32).tobytes())
+        for c in range(N_CAMS):
+            f.write(np.ascontiguousarray(frames[c], np.uint8).tobytes())
+        f.write(np.ascontiguousarray(sc.points, np.float64).tobytes())
+        for c in range(N_CAMS):
+            uv, vis = sc.project(c, order[0])
+            idx = np.nonzero(vis)[0].astype(np.int32)
+            f.write(struct.pack("i", len(idx)))
+            f.write(idx.tobytes())
+            f.write(np.ascontiguousarray(uv[idx], np.float64).tobytes())
+        f.write(np.stack([sc.pose(c, order[0])[0].ravel() for c in range(N_CAMS)]).astype(np.float64).tobytes())
+        f.write(np.stack([sc.pose(c, order[0])[1] for c in range(N_CAMS)]).astype(np.float64).tobytes())
+        f.write(np.ascontiguousarray(reg_covariances(), np.float64).tobytes())
+        for pr, ncon, npcon, mi, inner in ((joint, joint["n_cams_con"], joint["n_pts_con"], 2, 10), (ic, 0, ic["n_static"], 3, 40)):
+            ptr, cam, xy = csr(pr)
+            f.write(np.asarray([len(pr["Rs0"]), len(pr["pts0"]), len(cam), ncon, npcon, mi, inner], np.int32).tobytes())
+            f.write(struct.pack("d", 6.0))
+            for a in (pr["Ks"], pr["Rs0"], pr["ts0"], pr["pts0"]):
+                f.write(np.ascontiguousarray(a, np.float64).tobytes())
+            f.write(np.ascontiguousarray(ptr, np.int32).tobytes())
+            f.write(np.ascontiguousarray(cam, np.int32).tobytes())
+            f.write(np.ascontiguousarray(xy, np.float64).tobytes())
+        npc = len(pg_graphs[0][0])
+        f.write(np.asarray([len(pg_graphs), npc], np.int32).tobytes())
+        f.write(np.concatenate([g[0] for g in pg_graphs]).astype(np.uint8).tobytes())
+        f.write(np.ascontiguousarray(pg_R, np.float64).tobytes())
+        f.write(np.ascontiguousarray(pg_T, np.float64).tobytes())
+        f.write(np.ascontiguousarray(pg_cam, np.int32).tobytes())
+
+
 def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True, with_posegraph=True):
     """The oracle (C restatement of the reference's path: kind "port") on `n_threads` host cores: the cameras of a frame
     in parallel (the ctypes calls release the GIL), the key-frame solves on the calling thread."""
@@ -260,6 +309,7 @@ def main():
     ap.add_argument("--ba-cus", default=os.environ.get("BENCH_BA_CUS", ""), help="FIRST:COUNT -- the joint BA's stream confined to these CU-mask bits")
     ap.add_argument("--ic-cus", default=os.environ.get("BENCH_IC_CUS", ""), help="FIRST:COUNT -- the inter-camera solve's stream confined to these CU-mask bits")
     ap.add_argument("--pose-cus", default=os.environ.get("BENCH_POSE_CUS", ""), help="FIRST:COUNT -- the pose stream (hand-back, pose, registration) confined to these CU-mask bits")
+    ap.add_argument("--no-cxx-loop", action="store_true", help="skip the C++ frame loop (tools/cxx/frame_loop.bin, config.cxx_frame_loop)")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the upload-inclusive repetition of the loop (config.with_upload)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cfg5 BA leg (3 s of problem generation)")
     ap.add_argument("--no-posegraph", action="store_true", help="diagnostic: skip the pose-graph relaxation behind the joint BA (not a valid bench line)")
@@ -863,6 +913,29 @@ def main():
                          f"{n1} frames on 1 thread in {dt1:.1f} s (oracle/: C restatement, gcc -O2); host has {cores} cores",
                "value_1_thread": v1, "host_cores": cores}
 
+    # ---- the same loop driven from C++ through the C-ABI only (north_star: "Host stays C++"): tools/cxx/frame_loop.cpp, its
+    # own process, the workload handed over as a file; same steps / warm-up / key-frame cadence / drain
+    cxx = None
+    if rank == 0 and n_gpus == 1 and not args.no_cxx_loop and not args.serial and args.key_every == KEY_EVERY:
+        import subprocess
+        import tempfile
+
+        exe = os.path.join(ROOT, "tools", "cxx", "frame_loop.bin")
+        if os.path.exists(exe):
+            torch.cuda.synchronize()
+            with tempfile.TemporaryDirectory() as td:
+                wl = os.path.join(td, "workload.bin")
+                export_workload(wl, sc, frames, joint, ic, args.klt_cams_per_launch)
+                pr = subprocess.run([exe, wl, str(args.steps), str(args.warmup)], capture_output=True, text=True, timeout=600)
+            if pr.returncode == 0 and pr.stdout.strip().startswith("{"):
+                cxx = json.loads(pr.stdout.strip().splitlines()[-1])
+                cxx["what"] = ("tools/cxx/frame_loop.cpp: the headline loop from C++ through include/coslam_hip.h only (no Python, no "
+                               "torch), own process, images resident in HBM")
+            else:
+                cxx = {"error": (pr.stderr or pr.stdout)[-400:]}
+        else:
+            cxx = {"error": "tools/cxx/frame_loop.bin not built (python -c 'import __graft_entry__ as g; g.build()')"}
+
     if rank == 0:
         out = {
             "metric": "frames/sec for track+local-BA loop, 8 cams 640x480 x 2000 feats (one frame = all 8 cameras)",
@@ -895,7 +968,7 @@ def main():
                        {"active": int((reg_out[0]["slot"] >= 0).sum().item()), "current_static": int((reg_out[1]["slot"] >= 0).sum().item()),
                         "already_attached": int((reg_out[1]["slot"] == -1).sum().item())},
                        "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "host_enqueue_ms_max_step": t_step_max * 1e3, "host_enqueue_max_at_step": i_step_max, "tracker_stream_cus": args.klt_cus or "all",
-                       "gathered_records": gathered_info, "with_upload": with_upload,
+                       "gathered_records": gathered_info, "with_upload": with_upload, "cxx_frame_loop": cxx,
                        "collectives": None if world == 1 else ("libcoslam_hip RCCL (C-ABI)" if native else "torch.distributed " + dist_backend),
                        "streams": "one stream (--serial)" if args.serial else
                        "tracker group | hand-back + pose (event-ordered behind the tracker of the same frame) | "

@@ -32,11 +32,21 @@ def test_bench_prints_one_json_line_with_the_contract_keys(hip):
     assert cfg["posegraph_last"]["nodes"] == 8 * 21 and cfg["posegraph_last"]["components"] == 32
     assert cfg["posegraph_last"]["max_non_key_translation_change"] > 1e-4 and "pose-graph relaxation" in cfg["workload"]
     assert cfg["intercam_last"]["lm_steps"] > 0 and cfg["register_candidates_last_frame"]["current_static"] > 1000
+    # the same loop from C++ through the C-ABI only (tools/cxx/frame_loop.cpp): same solves, same results, a comparable rate
+    cx = cfg["cxx_frame_loop"]
+    assert "error" not in cx, cx
+    assert cx["pose_ok"] is True and cx["min_live_features"] > 1500 and cx["steps"] == 10
+    assert cx["joint_lm_steps"] == cfg["joint_ba_last"]["lm_steps"] and abs(cx["joint_cost"] - cfg["joint_ba_last"]["cost"]) < 1e-6
+    assert cx["intercam_lm_steps"] == cfg["intercam_last"]["lm_steps"] and 0.5 < cx["frames_per_s"] / j["value"] < 2.0
+    # ... and with every frame's images coming from pinned host memory inside the loop
+    up = cfg["with_upload"]
+    assert up["frames_per_s"] > 0 and 0.5 < up["ratio_to_value"] < 1.2
     r = j["roofline"]
+    assert r["valu"] is not None and 0.05 < r["valu"]["frac"] < 1.0 and r["launches_per_frame"] >= 1
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["kernel"] == "k_track_rows_fused" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.01 < r["frac"] < 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.005 < r["frac"] < 1.0
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
 
 
