@@ -186,6 +186,17 @@ def export_workload(path, sc, frames, joint, ic, cams_per_launch):
         f.write(np.ascontiguousarray(pg_R, np.float64).tobytes())
         f.write(np.ascontiguousarray(pg_T, np.float64).tobytes())
         f.write(np.ascontiguousarray(pg_cam, np.int32).tobytes())
+        # fundamental matrices of the consecutive camera pairs at every frame (the NCC matching leg): [frame][pair][9]
+        Kinv = np.linalg.inv(sc.K)
+        Fs = np.zeros((N_FRAMES, N_CAMS - 1, 9))
+        for fr in range(N_FRAMES):
+            for c in range(N_CAMS - 1):
+                (R1, t1), (R2, t2) = sc.pose(c, fr), sc.pose(c + 1, fr)
+                R = R1 @ R2.T
+                t = t1 - R @ t2
+                E = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
+                Fs[fr, c] = (Kinv.T @ E @ Kinv).reshape(9)
+        f.write(Fs.tobytes())
 
 
 def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True, with_posegraph=True):
@@ -309,6 +320,7 @@ def main():
     ap.add_argument("--ba-cus", default=os.environ.get("BENCH_BA_CUS", ""), help="FIRST:COUNT -- the joint BA's stream confined to these CU-mask bits")
     ap.add_argument("--ic-cus", default=os.environ.get("BENCH_IC_CUS", ""), help="FIRST:COUNT -- the inter-camera solve's stream confined to these CU-mask bits")
     ap.add_argument("--pose-cus", default=os.environ.get("BENCH_POSE_CUS", ""), help="FIRST:COUNT -- the pose stream (hand-back, pose, registration) confined to these CU-mask bits")
+    ap.add_argument("--no-ncc", action="store_true", help="diagnostic: skip the inter-camera NCC matching leg (not a valid bench line)")
     ap.add_argument("--no-cxx-loop", action="store_true", help="skip the C++ frame loop (tools/cxx/frame_loop.bin, config.cxx_frame_loop)")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the upload-inclusive repetition of the loop (config.with_upload)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cfg5 BA leg (3 s of problem generation)")
@@ -572,6 +584,50 @@ def main():
         f = order[i % len(order)]
         stage_slot[i] = grp.stage_h([h_frames[f][c].data_ptr() for c in range(nc)])
 
+    # Inter-camera NCC matching for new map points, every NCC_EVERY-th frame (CoSLAM::genNewMapPoints: "curFrame -
+    # m_lastFrmInterMapping > 3", reference src/app/SL_CoSLAM.cpp:1368-1371 -> NewMapPtsNCC::run: matchBetween(i, i + 1) for the
+    # consecutive cameras of the group, src/app/SL_NewMapPointsInterCam.cpp:150-158,273-290): per camera getNCCBlocks on the FULL
+    # frame (cv::resize by 0.3 + cv::getRectSubPix per feature), per pair the epipolar-error and NCC matrices over all slots
+    # (slots that are not unmapped features of this frame are masked out); F from the frame's poses; the greedy matcher that
+    # consumes the matrices stays with the caller.
+    NCC_EVERY = 4
+    ncc = None
+    if not args.no_ncc and nc >= 2:
+        from coslam_amd._lib import check
+        from coslam_amd.ncc import ncc_epi_mat_dev, ncc_get_blocks_dev, ncc_scaled_dims
+
+        ws_, hs_ = ncc_scaled_dims(W, H, 0.3)
+        Kinv = np.linalg.inv(sc.K)
+
+        def f_matrix(c1, c2, f):
+            (R1, t1), (R2, t2) = sc.pose(c1, f), sc.pose(c2, f)
+            R = R1 @ R2.T
+            t = t1 - R @ t2
+            E = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
+            return Kinv.T @ E @ Kinv
+
+        ncc = dict(small=torch.zeros((nc, ws_ * hs_), dtype=torch.uint8, device=dev), blk=torch.zeros((nc, N_FEAT, 128), dtype=torch.uint8, device=dev),
+                   abc=torch.zeros((nc, N_FEAT, 4), dtype=torch.float64, device=dev), valid=torch.zeros((nc, N_FEAT), dtype=torch.int32, device=dev),
+                   epi=torch.zeros((N_FEAT, N_FEAT), dtype=torch.float64, device=dev), score=torch.zeros((N_FEAT, N_FEAT), dtype=torch.float64, device=dev),
+                   F={(my_cams[i], f): f_matrix(my_cams[i], my_cams[i + 1], f) for i in range(nc - 1) for f in range(N_FRAMES)}, runs=0)
+
+    def ncc_leg(f):
+        s_ = pose_s.cuda_stream
+        # unmapped features of this frame: state 0 / 1 and no map point (hand-back records of all cameras, back to back)
+        check(coslam_amd.lib().cs_ncc_unmapped_mask_dev(local_rank, C.c_void_p(s_), nc * N_FEAT, C.c_void_p(d_state.data_ptr()),
+                                                        C.c_void_p(d_slot2map.data_ptr()), C.c_void_p(ncc["valid"].data_ptr())),
+              "cs_ncc_unmapped_mask_dev")
+        for i in range(nc):
+            ncc_get_blocks_dev(s_, img_ptrs[f][i], W, H, N_FEAT, d_xy[i].data_ptr(), d_xy[i].data_ptr() + 8 * N_FEAT, 0.3,
+                               ncc["small"][i].data_ptr(), ncc["blk"][i].data_ptr(), ncc["abc"][i].data_ptr(), 0, device=local_rank)
+        for i in range(nc - 1):
+            ncc_epi_mat_dev(s_, ncc["F"][(my_cams[i], f)], N_FEAT, d_xy[i].data_ptr(), d_xy[i].data_ptr() + 8 * N_FEAT, ncc["blk"][i].data_ptr(),
+                            ncc["abc"][i].data_ptr(), ncc["valid"][i].data_ptr(), N_FEAT, d_xy[i + 1].data_ptr(),
+                            d_xy[i + 1].data_ptr() + 8 * N_FEAT, ncc["blk"][i + 1].data_ptr(), ncc["abc"][i + 1].data_ptr(),
+                            ncc["valid"][i + 1].data_ptr(), 50.0, 0.80, -1.0, ncc["epi"].data_ptr(), ncc["score"].data_ptr(),
+                            device=local_rank)   # maxEpiErr 50, minNcc 0.80: src/app/SL_NewMapPointsInterCam.h:71-72
+        ncc["runs"] += 1
+
     def step(i, key_frame, upload=False):
         f, fn = order[i % len(order)], order[(i + 1) % len(order)]
         b = i & 1
@@ -598,6 +654,8 @@ def main():
             with torch.cuda.stream(pose_s):
                 xchg.pack_group(d_dests[b], d_R[i & 1], d_t[i & 1], pose_s)
                 xchg.all_gather(pose_s)
+        if ncc is not None and i % NCC_EVERY == 0:
+            ncc_leg(f)
         dest_free[b].record(pose_s)
         if key_frame and world > 1:
             # InterCamPoseEstimator::addMapPoints (reference src/app/SL_InterCamPoseEstimator.cpp:24-37) starts the solve from
@@ -968,6 +1026,10 @@ def main():
                        {"active": int((reg_out[0]["slot"] >= 0).sum().item()), "current_static": int((reg_out[1]["slot"] >= 0).sum().item()),
                         "already_attached": int((reg_out[1]["slot"] == -1).sum().item())},
                        "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "host_enqueue_ms_max_step": t_step_max * 1e3, "host_enqueue_max_at_step": i_step_max, "tracker_stream_cus": args.klt_cus or "all",
+                       "ncc_matching": None if ncc is None else {
+                           "every_frames": NCC_EVERY, "camera_pairs_per_run": nc - 1, "runs": ncc["runs"],
+                           "pairs_kept_last_matrix": int((ncc["score"] != -1.0).sum().item()),
+                           "unmapped_features_last_run": [int(v) for v in ncc["valid"].sum(dim=1).cpu().tolist()]},
                        "gathered_records": gathered_info, "with_upload": with_upload, "cxx_frame_loop": cxx,
                        "collectives": None if world == 1 else ("libcoslam_hip RCCL (C-ABI)" if native else "torch.distributed " + dist_backend),
                        "streams": "one stream (--serial)" if args.serial else

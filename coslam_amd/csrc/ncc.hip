@@ -72,6 +72,152 @@ __global__ __launch_bounds__(256) void k_ncc_blocks(const unsigned char* __restr
     }
 }
 
+// ---- getNCCBlocks: how matchBetween really cuts its blocks (SL_NCCBlock.cpp:79-155) -----------------------------------
+// cv::resize(img, small, Size(), scale, scale) [INTER_LINEAR, 8-bit] once per image, then per point
+// cv::getRectSubPix(small, 11 x 11, (x scale, y scale)) [8u -> 8u] and A, B, C.  OpenCV is not in this image: both functions
+// are the published generic C++ paths restated (imgproc/src/resize.cpp: 11-bit coefficients, the (b (S >> 4)) >> 16 vertical
+// pass; imgproc/src/samplers.cpp getRectSubPix_Cn_ + adjustRect: 16-bit fixed-point bilinear weights, replicated border) --
+// integer arithmetic behind float weights, so the kernels are bit-exact against oracle/ncc_oracle.c (parity unpinned there).
+__device__ __forceinline__ int nc_floorf(float v) {
+    const int i = (int)v;
+    return i - (i > v);
+}
+__device__ __forceinline__ int nc_clip(int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; }
+__device__ __forceinline__ int nc_sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+// one thread per destination pixel; (dx, dy) -> the two source columns / rows and their 11-bit weights exactly as
+// cv::resize's tables hold them
+__global__ __launch_bounds__(256) void k_resize_linear_u8(const unsigned char* __restrict__ src, int W, int H, double scale_x,
+                                                          double scale_y, unsigned char* __restrict__ dst, int Wd, int Hd) {
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= Wd || dy >= Hd) return;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = nc_floorf(fx);
+    fx -= sx;
+    if (sx < 0) fx = 0, sx = 0;
+    bool edge = false;  // dx >= xmax: xmax is the first dx with sx + 1 >= W, and sx is monotone in dx
+    if (sx + 1 >= W) {
+        edge = true;
+        if (sx >= W - 1) fx = 0, sx = W - 1;
+    }
+    const int a0 = nc_sat_short(__float2int_rn((1.f - fx) * 2048.f)), a1 = nc_sat_short(__float2int_rn(fx * 2048.f));
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    const int sy = nc_floorf(fy);
+    fy -= sy;
+    const int b0 = nc_sat_short(__float2int_rn((1.f - fy) * 2048.f)), b1 = nc_sat_short(__float2int_rn(fy * 2048.f));
+    const unsigned char* S0 = src + (size_t)nc_clip(sy, 0, H) * W;
+    const unsigned char* S1 = src + (size_t)nc_clip(sy + 1, 0, H) * W;
+    int r0, r1;
+    if (!edge) {
+        r0 = S0[sx] * a0 + S0[sx + 1] * a1;
+        r1 = S1[sx] * a0 + S1[sx + 1] * a1;
+    } else {
+        r0 = S0[sx] * 2048;
+        r1 = S1[sx] * 2048;
+    }
+    dst[(size_t)dy * Wd + dx] = (unsigned char)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+}
+
+// one wave per point: lanes 0..120 = the pixels of the 11 x 11 patch (two per lane); cv::getRectSubPix 8u -> 8u.
+// The border path of the original walks the rows with a pointer that stops advancing outside the image; in closed form the
+// top source row of window row i is row0 + max(0, min(i, rh) - ry), the bottom one the next row unless i < ry or i >= rh.
+__global__ __launch_bounds__(256) void k_ncc_blocks_subpix(const unsigned char* __restrict__ img, int W, int H, int n,
+                                                           const double* __restrict__ xs, const double* __restrict__ ys,
+                                                           double scale, int scaled, unsigned char* __restrict__ blocks,
+                                                           double* __restrict__ abc, int* __restrict__ valid) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n) return;
+    const int win = NC_BW;
+    const double px = scaled ? xs[p] * scale : xs[p], py = scaled ? ys[p] * scale : ys[p];  // SL_NCCBlock.cpp:131-132 / :99-100
+    float fxc = (float)px, fyc = (float)py;
+    fxc -= (win - 1) * 0.5f;
+    fyc -= (win - 1) * 0.5f;
+    const int ipx = nc_floorf(fxc), ipy = nc_floorf(fyc);
+    const float a = fxc - ipx, b = fyc - ipy;
+    const int a11 = __float2int_rn((1.f - a) * (1.f - b) * 65536.f), a12 = __float2int_rn(a * (1.f - b) * 65536.f),
+              a21 = __float2int_rn((1.f - a) * b * 65536.f), a22 = __float2int_rn(a * b * 65536.f);
+    const int b1 = __float2int_rn((1.f - b) * 65536.f), b2 = __float2int_rn(b * 65536.f);
+    const bool inside = 0 <= ipx && ipx < W - win && 0 <= ipy && ipy < H - win;
+    int rx = 0, rw = win, ry = 0, rh = win, col0 = ipx, row0 = ipy;
+    if (!inside) {  // adjustRect
+        if (ipx >= 0) {
+            col0 = ipx, rx = 0;
+        } else {
+            col0 = 0, rx = -ipx;
+            if (rx > win) rx = win;
+        }
+        if (ipx < W - win) {
+            rw = win;
+        } else {
+            rw = W - ipx - 1;
+            if (rw < 0) col0 += rw, rw = 0;
+        }
+        if (ipy >= 0) {
+            row0 = ipy, ry = 0;
+        } else {
+            row0 = 0, ry = -ipy;
+        }
+        if (ipy < H - win) {
+            rh = win;
+        } else {
+            rh = H - ipy - 1;
+            if (rh < 0) row0 += rh, rh = 0;
+        }
+    }
+    unsigned v[2] = {0x80u, 0x80u};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int q = lane + 64 * h;
+        if (q >= NC_LEN) continue;
+        const int i = q / win, j = q - i * win;
+        int t;
+        if (inside) {
+            const unsigned char* s = img + (size_t)(ipy + i) * W + ipx;
+            t = s[j] * a11 + s[j + 1] * a12 + s[j + W] * a21 + s[j + W + 1] * a22;
+        } else {
+            const int adv = (i < rh ? i : rh) - ry;
+            const int rt = row0 + (adv > 0 ? adv : 0);
+            const int rb = rt + ((i < ry || i >= rh) ? 0 : 1);
+            const unsigned char* s = img + (size_t)rt * W + (col0 - rx);
+            const unsigned char* s2 = img + (size_t)rb * W + (col0 - rx);
+            if (j < rx)
+                t = s[rx] * b1 + s2[rx] * b2;
+            else if (j >= rw)
+                t = s[rw] * b1 + s2[rw] * b2;
+            else
+                t = s[j] * a11 + s[j + 1] * a12 + s2[j] * a21 + s2[j + 1] * a22;
+        }
+        v[h] = (unsigned)((t + (1 << 15)) >> 16) & 0xffu;
+    }
+    blocks[(size_t)p * NC_PITCH + lane] = (unsigned char)v[0];
+    blocks[(size_t)p * NC_PITCH + 64 + lane] = (unsigned char)v[1];
+    const unsigned w0 = v[0], w1 = (lane + 64 < NC_LEN) ? v[1] : 0u;   // (select the bytes, then square: see k_ncc_blocks)
+    unsigned sa = w0 + w1;
+    unsigned sb = w0 * w0 + w1 * w1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        sa += __shfl_xor(sa, off, 64);
+        sb += __shfl_xor(sb, off, 64);
+    }
+    if (lane == 0) {
+        const double A = (double)sa, B = (double)sb;
+        abc[4 * (size_t)p] = A;
+        abc[4 * (size_t)p + 1] = B;
+        abc[4 * (size_t)p + 2] = 1 / sqrt((double)NC_LEN * B - A * A);
+        abc[4 * (size_t)p + 3] = A / (double)NC_LEN;
+        if (valid) valid[p] = 1;
+    }
+}
+
+// which slots are features matchBetween would be given: in this frame's list (hand-back state 0 / 1) and without a map point
+// (NewMapPtsNCC::addSlam collects the unmapped feature points of the current frame)
+__global__ __launch_bounds__(256) void k_ncc_unmapped_mask(int n, const int* __restrict__ state, const int* __restrict__ slot2map,
+                                                           int* __restrict__ valid) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) valid[i] = (state[i] >= 0 && slot2map[i] < 0) ? 1 : 0;
+}
+
 // ---- getEpiNccMat: 64 x 64 pairs per workgroup ------------------------------------------------------------------------
 struct NcSide {
     const double* x;
@@ -186,6 +332,62 @@ extern "C" int cs_ncc_blocks_dev(int device, void* hip_stream, const unsigned ch
     return CS_OK;
 }
 
+extern "C" int cs_ncc_unmapped_mask_dev(int device, void* hip_stream, int n, const int* d_state, const int* d_slot2map, int* d_valid) {
+    if (n < 0 || (n && (!d_state || !d_slot2map || !d_valid))) {
+        cs_set_error("cs_ncc_unmapped_mask_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (n == 0) return CS_OK;
+    CS_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_ncc_unmapped_mask, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, n, d_state, d_slot2map, d_valid);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+// cv::Size of the resized image: saturate_cast<int>(W * scale) (round half to even)
+extern "C" int cs_ncc_scaled_dims(int W, int H, double scale, int* Ws, int* Hs) {
+    if (!Ws || !Hs || W <= 0 || H <= 0 || !(scale > 0)) {
+        cs_set_error("cs_ncc_scaled_dims: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    *Ws = (int)lrint(W * scale);
+    *Hs = (int)lrint(H * scale);
+    return CS_OK;
+}
+
+// getNCCBlocks(img, pts, blocks, scale) for n points, asynchronous on hip_stream; d_scaled: the caller's scratch for the resized
+// image (cs_ncc_scaled_dims bytes; ignored when scale == 1.0).  Every point gets a block (the border is replicated), so there is
+// no `valid` output -- d_valid, when given, is set to 1 for cs_ncc_epi_mat_dev.
+extern "C" int cs_ncc_get_blocks_dev(int device, void* hip_stream, const unsigned char* d_img, int W, int H, int n, const double* d_x,
+                                     const double* d_y, double scale, unsigned char* d_scaled, unsigned char* d_blocks, double* d_abc,
+                                     int* d_valid) {
+    if (!d_img || W <= 0 || H <= 0 || n < 0 || (n && (!d_x || !d_y || !d_blocks || !d_abc)) || !(scale > 0) ||
+        (scale != 1.0 && !d_scaled)) {
+        cs_set_error("cs_ncc_get_blocks_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    const unsigned char* im = d_img;
+    int Ws = W, Hs = H;
+    if (scale != 1.0) {
+        Ws = (int)lrint(W * scale), Hs = (int)lrint(H * scale);
+        if (Ws < 1 || Hs < 1) {
+            cs_set_error("cs_ncc_get_blocks_dev: the scaled image is empty");
+            return CS_ERR_INVALID;
+        }
+        hipLaunchKernelGGL(k_resize_linear_u8, dim3((Ws + 63) / 64, (Hs + 3) / 4), dim3(256), 0, s, d_img, W, H, 1. / scale, 1. / scale,
+                           d_scaled, Ws, Hs);
+        im = d_scaled;
+    }
+    if (n > 0) {
+        hipLaunchKernelGGL(k_ncc_blocks_subpix, dim3((n + 3) / 4), dim3(256), 0, s, im, Ws, Hs, n, d_x, d_y, scale, scale != 1.0 ? 1 : 0,
+                           d_blocks, d_abc, d_valid);
+    }
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
 extern "C" int cs_ncc_epi_mat_dev(int device, void* hip_stream, const double F[9], int M, const double* d_x1, const double* d_y1,
                                   const unsigned char* d_blocks1, const double* d_abc1, const int* d_valid1, int N,
                                   const double* d_x2, const double* d_y2, const unsigned char* d_blocks2, const double* d_abc2,
@@ -219,11 +421,13 @@ extern "C" int cs_ncc_epi_mat_dev(int device, void* hip_stream, const double F[9
 
 // Host-pointer form of the whole stage for one camera pair, as NewMapPtsNCC::matchBetween calls it: blocks of both
 // cameras from their small images, then the two matrices.  One upload, three launches, one read-back.
-extern "C" int cs_ncc_match_between(int device, const unsigned char* img1, int W1, int H1, int M, const double* x1, const double* y1,
-                                    const unsigned char* img2, int W2, int H2, int N, const double* x2, const double* y2,
-                                    double scale, const double F[9], double epiMax, double nccMin, double wNone, double* epiMat,
-                                    double* nccMat, unsigned char* blocks1, double* abc1, int* valid1, unsigned char* blocks2,
-                                    double* abc2, int* valid2) {
+// cutter 0: NCCBlock::computeScaled on the SMALL image passed in (SL_NCCBlock.cpp:15-54); 1: getNCCBlocks on the FULL image
+// passed in (resize by `scale`, sub-pixel patch: SL_NCCBlock.cpp:79-155 -- what matchBetween itself calls)
+static int ncc_match_between_impl(int cutter, int device, const unsigned char* img1, int W1, int H1, int M, const double* x1,
+                                  const double* y1, const unsigned char* img2, int W2, int H2, int N, const double* x2, const double* y2,
+                                  double scale, const double F[9], double epiMax, double nccMin, double wNone, double* epiMat,
+                                  double* nccMat, unsigned char* blocks1, double* abc1, int* valid1, unsigned char* blocks2,
+                                  double* abc2, int* valid2) {
     if (!img1 || !img2 || !F || M < 0 || N < 0 || (M && (!x1 || !y1)) || (N && (!x2 || !y2)) || (M && N && (!epiMat || !nccMat))) {
         cs_set_error("cs_ncc_match_between: bad arguments");
         return CS_ERR_INVALID;
@@ -248,6 +452,8 @@ extern "C" int cs_ncc_match_between(int device, const unsigned char* img1, int W
     const size_t oV2 = off; off += al(4 * (size_t)N);
     const size_t oE = off; off += al(8 * (size_t)M * N);
     const size_t oN = off; off += al(8 * (size_t)M * N);
+    const size_t oS1 = off; off += al(cutter ? i1 : 0);   // (scratch of the resized images: never larger than the originals
+    const size_t oS2 = off; off += al(cutter ? i2 : 0);   //  for scale <= 1; larger scales are refused below)
     char* d = nullptr;
     if (hipMalloc((void**)&d, off) != hipSuccess) {
         cs_set_error("cs_ncc_match_between: out of device memory (%zu bytes)", off);
@@ -262,7 +468,24 @@ extern "C" int cs_ncc_match_between(int device, const unsigned char* img1, int W
     if (e == hipSuccess) e = hipMemcpyAsync(d + oX2, x2, 8 * (size_t)N, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d + oY2, y2, 8 * (size_t)N, hipMemcpyHostToDevice, s);
     (void)inBytes;
-    if (e == hipSuccess) {
+    if (cutter && scale > 1.0) {
+        (void)hipFree(d);
+        cs_set_error("cs_ncc_match_between_full: scale > 1 is not supported");
+        return CS_ERR_INVALID;
+    }
+    if (e == hipSuccess && cutter) {
+        rc = cs_ncc_get_blocks_dev(device, s, (const unsigned char*)(d + oI1), W1, H1, M, (const double*)(d + oX1), (const double*)(d + oY1),
+                                   scale, (unsigned char*)(d + oS1), (unsigned char*)(d + oB1), (double*)(d + oC1), (int*)(d + oV1));
+        if (rc == CS_OK)
+            rc = cs_ncc_get_blocks_dev(device, s, (const unsigned char*)(d + oI2), W2, H2, N, (const double*)(d + oX2),
+                                       (const double*)(d + oY2), scale, (unsigned char*)(d + oS2), (unsigned char*)(d + oB2),
+                                       (double*)(d + oC2), (int*)(d + oV2));
+        if (rc == CS_OK)
+            rc = cs_ncc_epi_mat_dev(device, s, F, M, (const double*)(d + oX1), (const double*)(d + oY1), (const unsigned char*)(d + oB1),
+                                    (const double*)(d + oC1), (const int*)(d + oV1), N, (const double*)(d + oX2),
+                                    (const double*)(d + oY2), (const unsigned char*)(d + oB2), (const double*)(d + oC2),
+                                    (const int*)(d + oV2), epiMax, nccMin, wNone, (double*)(d + oE), (double*)(d + oN));
+    } else if (e == hipSuccess) {
         rc = cs_ncc_blocks_dev(device, s, (const unsigned char*)(d + oI1), W1, H1, M, (const double*)(d + oX1), (const double*)(d + oY1),
                                scale, (unsigned char*)(d + oB1), (double*)(d + oC1), (int*)(d + oV1));
         if (rc == CS_OK)
@@ -293,4 +516,23 @@ extern "C" int cs_ncc_match_between(int device, const unsigned char* img1, int W
         return CS_ERR_HIP;
     }
     return CS_OK;
+}
+
+extern "C" int cs_ncc_match_between(int device, const unsigned char* img1, int W1, int H1, int M, const double* x1, const double* y1,
+                                    const unsigned char* img2, int W2, int H2, int N, const double* x2, const double* y2,
+                                    double scale, const double F[9], double epiMax, double nccMin, double wNone, double* epiMat,
+                                    double* nccMat, unsigned char* blocks1, double* abc1, int* valid1, unsigned char* blocks2,
+                                    double* abc2, int* valid2) {
+    return ncc_match_between_impl(0, device, img1, W1, H1, M, x1, y1, img2, W2, H2, N, x2, y2, scale, F, epiMax, nccMin, wNone, epiMat,
+                                  nccMat, blocks1, abc1, valid1, blocks2, abc2, valid2);
+}
+
+// NewMapPtsNCC::matchBetween's own data path (src/app/SL_NewMapPointsInterCam.cpp:273-290): the FULL images, getNCCBlocks with
+// blockScale, then the two matrices.
+extern "C" int cs_ncc_match_between_full(int device, const unsigned char* img1, int W1, int H1, int M, const double* x1, const double* y1,
+                                         const unsigned char* img2, int W2, int H2, int N, const double* x2, const double* y2,
+                                         double scale, const double F[9], double epiMax, double nccMin, double wNone, double* epiMat,
+                                         double* nccMat, unsigned char* blocks1, double* abc1, unsigned char* blocks2, double* abc2) {
+    return ncc_match_between_impl(1, device, img1, W1, H1, M, x1, y1, img2, W2, H2, N, x2, y2, scale, F, epiMax, nccMin, wNone, epiMat,
+                                  nccMat, blocks1, abc1, nullptr, blocks2, abc2, nullptr);
 }

@@ -42,3 +42,35 @@ def ncc_match_between(img1, x1, y1, img2, x2, y2, scale, F, epiMax, nccMin, wNon
                                      C.c_double(epiMax), C.c_double(nccMin), C.c_double(wNone), p(epi), p(ncc), p(b1), p(c1),
                                      p(v1), p(b2), p(c2), p(v2)), "cs_ncc_match_between")
     return dict(epi=epi, ncc=ncc, blocks1=b1, abc1=c1, valid1=v1, blocks2=b2, abc2=c2, valid2=v2)
+
+
+def ncc_get_blocks_dev(stream_ptr, d_img, W, H, n, d_x, d_y, scale, d_scaled, d_blocks, d_abc, d_valid=0, device=0):
+    """cs_ncc_get_blocks_dev: getNCCBlocks (reference src/slam/SL_NCCBlock.cpp:79-155) for n points, device pointers"""
+    vp = C.c_void_p
+    check(lib().cs_ncc_get_blocks_dev(int(device), vp(stream_ptr), vp(d_img), int(W), int(H), int(n), vp(d_x), vp(d_y),
+                                      C.c_double(scale), vp(d_scaled), vp(d_blocks), vp(d_abc), vp(d_valid)), "cs_ncc_get_blocks_dev")
+
+
+def ncc_scaled_dims(W, H, scale):
+    ws, hs = C.c_int(0), C.c_int(0)
+    check(lib().cs_ncc_scaled_dims(int(W), int(H), C.c_double(scale), C.byref(ws), C.byref(hs)), "cs_ncc_scaled_dims")
+    return ws.value, hs.value
+
+
+def ncc_match_between_full(img1, x1, y1, img2, x2, y2, scale, F, epiMax, nccMin, wNone=-1.0, device=0):
+    """NewMapPtsNCC::matchBetween's own data path (cs_ncc_match_between_full): FULL images, getNCCBlocks with blockScale, the
+    two matrices.  Returns dict(epi, ncc (M x N), blocks1/2 (n x 128), abc1/2 (n x 4))."""
+    img1 = np.ascontiguousarray(img1, dtype=np.uint8)
+    img2 = np.ascontiguousarray(img2, dtype=np.uint8)
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (x1, y1, x2, y2)]
+    M, N = len(a[0]), len(a[2])
+    F = np.ascontiguousarray(F, dtype=np.float64).reshape(9)
+    epi, ncc = np.zeros((M, N)), np.zeros((M, N))
+    b1, b2 = np.zeros((M, 128), np.uint8), np.zeros((N, 128), np.uint8)
+    c1, c2 = np.zeros((M, 4)), np.zeros((N, 4))
+    p = lambda v: C.c_void_p(v.ctypes.data)  # noqa: E731
+    check(lib().cs_ncc_match_between_full(int(device), p(img1), img1.shape[1], img1.shape[0], M, p(a[0]), p(a[1]), p(img2),
+                                          img2.shape[1], img2.shape[0], N, p(a[2]), p(a[3]), C.c_double(scale), p(F),
+                                          C.c_double(epiMax), C.c_double(nccMin), C.c_double(wNone), p(epi), p(ncc), p(b1), p(c1),
+                                          p(b2), p(c2)), "cs_ncc_match_between_full")
+    return dict(epi=epi, ncc=ncc, blocks1=b1, abc1=c1, blocks2=b2, abc2=c2)

@@ -402,8 +402,25 @@ int cs_ncc_epi_mat_dev(int device, void* hip_stream, const double F[9] /* host *
                        const unsigned char* d_blocks1, const double* d_abc1, const int* d_valid1, int N, const double* d_x2,
                        const double* d_y2, const unsigned char* d_blocks2, const double* d_abc2, const int* d_valid2,
                        double epiMax, double nccMin, double wNone, double* d_epiMat, double* d_nccMat);
+/* How NewMapPtsNCC::matchBetween itself cuts its blocks: getNCCBlocks (src/slam/SL_NCCBlock.cpp:79-155, called at
+ * src/app/SL_NewMapPointsInterCam.cpp:280-282 with the FULL image and blockScale 0.3) = cv::resize(img, Size(), scale, scale)
+ * [INTER_LINEAR, 8-bit] once per image, then per point cv::getRectSubPix(small, 11 x 11, (x scale, y scale)) [8u -> 8u,
+ * replicated border] and A, B, C.  OpenCV (un-vendored, version unpinned) is restated from its published generic C++ paths
+ * (oracle/ncc_oracle.c says which); every point gets a block.  d_scaled: scratch for the resized image, cs_ncc_scaled_dims
+ * bytes (unused for scale == 1.0, where the patches are cut from the image itself, :93-121); d_valid (may be NULL) is set to 1. */
+/* valid[i] = slot i is an unmapped feature of this frame (hand-back: state 0 / 1, slot2map < 0) -- the features
+ * NewMapPtsNCC::addSlam hands to matchBetween; n may span several cameras' records laid out back to back */
+int cs_ncc_unmapped_mask_dev(int device, void* hip_stream, int n, const int* d_state, const int* d_slot2map, int* d_valid);
+int cs_ncc_scaled_dims(int W, int H, double scale, int* Ws, int* Hs);
+int cs_ncc_get_blocks_dev(int device, void* hip_stream, const unsigned char* d_img, int W, int H, int n, const double* d_x,
+                          const double* d_y, double scale, unsigned char* d_scaled, unsigned char* d_blocks, double* d_abc, int* d_valid);
 /* Host memory in and out, the whole stage for one camera pair (blocks of both cameras, then the matrices); the block
- * outputs (blocks / abc / valid) may be NULL. */
+ * outputs (blocks / abc / valid) may be NULL.  cs_ncc_match_between cuts the blocks with NCCBlock::computeScaled from the SMALL
+ * images it is given; cs_ncc_match_between_full is matchBetween's own path: FULL images, getNCCBlocks (scale <= 1). */
+int cs_ncc_match_between_full(int device, const unsigned char* img1, int W1, int H1, int M, const double* x1, const double* y1,
+                              const unsigned char* img2, int W2, int H2, int N, const double* x2, const double* y2, double scale,
+                              const double F[9], double epiMax, double nccMin, double wNone, double* epiMat, double* nccMat,
+                              unsigned char* blocks1, double* abc1, unsigned char* blocks2, double* abc2);
 int cs_ncc_match_between(int device, const unsigned char* img1, int W1, int H1, int M, const double* x1, const double* y1,
                          const unsigned char* img2, int W2, int H2, int N, const double* x2, const double* y2, double scale,
                          const double F[9], double epiMax, double nccMin, double wNone, double* epiMat, double* nccMat,

@@ -228,6 +228,40 @@ def ncc_blocks(img, x, y, scale):
     return blocks, abc, valid
 
 
+def resize_linear_u8(img, fx, fy):
+    """onc_resize_linear_u8: cv::resize(img, Size(), fx, fy) with INTER_LINEAR on 8-bit (restated)"""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W = img.shape
+    wd, hd = C.c_int(0), C.c_int(0)
+    lib().onc_resize_dims(W, H, C.c_double(fx), C.c_double(fy), C.byref(wd), C.byref(hd))
+    out = np.zeros((hd.value, wd.value), np.uint8)
+    lib().onc_resize_linear_u8(_p(img), W, H, C.c_double(fx), C.c_double(fy), _p(out))
+    return out
+
+
+def get_rect_sub_pix_u8(img, cx, cy, win=11):
+    """onc_get_rect_sub_pix_u8: cv::getRectSubPix(img, Size(win, win), (cx, cy)) 8u -> 8u (restated)"""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W = img.shape
+    out = np.zeros((win, win), np.uint8)
+    lib().onc_get_rect_sub_pix_u8(_p(img), W, H, C.c_double(cx), C.c_double(cy), int(win), _p(out))
+    return out
+
+
+def get_ncc_blocks(img, x, y, scale):
+    """onc_get_ncc_blocks: getNCCBlocks (reference src/slam/SL_NCCBlock.cpp:79-155) -> (blocks uint8[n,128], abc float64[n,4])"""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W = img.shape
+    x, y = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(y, dtype=np.float64)
+    n = len(x)
+    wd, hd = C.c_int(W), C.c_int(H)
+    lib().onc_resize_dims(W, H, C.c_double(scale), C.c_double(scale), C.byref(wd), C.byref(hd))
+    small = np.zeros(max(wd.value * hd.value, 1), np.uint8)
+    blocks, abc = np.zeros((n, 128), np.uint8), np.zeros((n, 4))
+    lib().onc_get_ncc_blocks(_p(img), W, H, n, _p(x), _p(y), C.c_double(scale), _p(small), _p(blocks), _p(abc))
+    return blocks, abc
+
+
 def ncc_epi_mat(F, x1, y1, blk1, abc1, valid1, x2, y2, blk2, abc2, valid2, epiMax, nccMin, wNone=-1.0):
     """onc_epi_ncc_mat: returns (epiMat, nccMat), M x N float64."""
     F = np.ascontiguousarray(F, dtype=np.float64).reshape(9)

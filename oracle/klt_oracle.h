@@ -151,6 +151,12 @@ void org_register_search(int nCams, int N, int W, int H, const double* Ks, const
 /* ---- NCC blocks and the epipolar / NCC matrices of the inter-camera matching restated (ncc_oracle.c) ---- */
 int onc_block_compute(const unsigned char* img, int W, int H, double x, double y, double scale, unsigned char* I, double* abc);
 double onc_match(const unsigned char* I1, const double* abc1, const unsigned char* I2, const double* abc2);
+/* getNCCBlocks' block cutter (SL_NCCBlock.cpp:79-155): OpenCV's resize (INTER_LINEAR, 8-bit) and getRectSubPix (8u -> 8u) restated */
+void onc_resize_dims(int W, int H, double fx, double fy, int* Wd, int* Hd);
+void onc_resize_linear_u8(const unsigned char* src, int W, int H, double fx, double fy, unsigned char* dst);
+void onc_get_rect_sub_pix_u8(const unsigned char* img, int W, int H, double cx, double cy, int win, unsigned char* patch);
+void onc_get_ncc_blocks(const unsigned char* img, int W, int H, int n, const double* x, const double* y, double scale,
+                        unsigned char* small, unsigned char* blocks, double* abc);
 void onc_epi_ncc_mat(const double* F, int M, const double* x1, const double* y1, const unsigned char* blk1, const double* abc1,
                      const int* valid1, int N, const double* x2, const double* y2, const unsigned char* blk2, const double* abc2,
                      const int* valid2, double epiMax, double nccMin, double wNone, double* epiMat, double* nccMat);

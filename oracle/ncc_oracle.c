@@ -85,3 +85,196 @@ void onc_epi_ncc_mat(const double* F, int M, const double* x1, const double* y1,
             }
         }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * How NewMapPtsNCC::matchBetween really cuts its blocks: getNCCBlocks (SL_NCCBlock.cpp:79-180, called at
+ * src/app/SL_NewMapPointsInterCam.cpp:280-282 with the camera's FULL image and blockScale = 0.3) =
+ *     cv::resize(img, small, cv::Size(), scale, scale)        [default interpolation INTER_LINEAR, CV_8UC1]       (:125-127)
+ *     per point: cv::getRectSubPix(small, 11 x 11, cv::Point2d(x * scale, y * scale), patch)                       (:131-134)
+ *     A = sum I, B = sum I^2, C = 1 / sqrt(121 B - A^2), avgI                                                      (:137-151)
+ * (scale == 1.0: getRectSubPix on the image itself, :93-121).
+ *
+ * THIRD-PARTY, ABSENT FROM THIS IMAGE, VERSION UNPINNED (CMakeLists.txt: find_package(OpenCV REQUIRED), no version): OpenCV.
+ * PARITY UNPINNED for the two functions below.  They restate the published generic (non-IPP, non-OpenCL, non-SIMD) C++ paths:
+ *   cv::resize INTER_LINEAR on 8-bit: modules/imgproc/src/resize.cpp -- cv::resize's table set-up, HResizeLinear<uchar, int,
+ *       short, INTER_RESIZE_COEF_SCALE = 2048>, VResizeLinear<uchar, int, short, FixedPtCast<int, uchar, 22>> (the same
+ *       arithmetic from OpenCV 2.4 to 4.x);
+ *   cv::getRectSubPix 8u -> 8u: modules/imgproc/src/samplers.cpp getRectSubPix_Cn_<uchar, uchar, int, scale_fixpt, cast_8u> +
+ *       adjustRect (OpenCV 3.x / 4.x: 16-bit fixed-point weights, replicated border; 2.4's C path used float weights and
+ *       cvRound and can differ by one grey level).
+ * Known-answer tests in tests/test_oracle_cpu.py (integer centres copy pixels, half-pixel centres average four with the
+ * fixed-point rounding, centres outside replicate the border, constant and ramp images under resize).
+ * ------------------------------------------------------------------------------------------------------------------------ */
+#include <stdint.h>
+#include <stdlib.h>
+
+static int onc_cv_round(double v) { return (int)lrint(v); }    /* cvRound: round half to even */
+static int onc_cv_roundf(float v) { return (int)lrintf(v); }
+static int onc_cv_floorf(float v) {                              /* cvFloor */
+    int i = (int)v;
+    return i - (i > v);
+}
+static int onc_clip(int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; } /* resize.cpp clip() */
+static short onc_sat_short(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+/* Size dsize(saturate_cast<int>(ssize.width * inv_scale_x), saturate_cast<int>(ssize.height * inv_scale_y)) */
+void onc_resize_dims(int W, int H, double fx, double fy, int* Wd, int* Hd) {
+    *Wd = onc_cv_round(W * fx);
+    *Hd = onc_cv_round(H * fy);
+}
+
+void onc_resize_linear_u8(const unsigned char* src, int W, int H, double fx, double fy, unsigned char* dst) {
+    int Wd, Hd;
+    onc_resize_dims(W, H, fx, fy, &Wd, &Hd);
+    const double scale_x = 1. / fx, scale_y = 1. / fy;
+    int* xofs = (int*)malloc(sizeof(int) * Wd);
+    short* ialpha = (short*)malloc(sizeof(short) * 2 * Wd);
+    int xmax = Wd;
+    for (int dx = 0; dx < Wd; dx++) {
+        float f = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = onc_cv_floorf(f);
+        f -= sx;
+        if (sx < 0) f = 0, sx = 0; /* ksize2 - 1 = 0 */
+        if (sx + 1 >= W) {
+            xmax = xmax < dx ? xmax : dx;
+            if (sx >= W - 1) f = 0, sx = W - 1;
+        }
+        xofs[dx] = sx;
+        ialpha[2 * dx] = onc_sat_short(onc_cv_roundf((1.f - f) * 2048.f));
+        ialpha[2 * dx + 1] = onc_sat_short(onc_cv_roundf(f * 2048.f));
+    }
+    int* row0 = (int*)malloc(sizeof(int) * Wd);
+    int* row1 = (int*)malloc(sizeof(int) * Wd);
+    for (int dy = 0; dy < Hd; dy++) {
+        float f = (float)((dy + 0.5) * scale_y - 0.5);
+        const int sy = onc_cv_floorf(f);
+        f -= sy;
+        const short b0 = onc_sat_short(onc_cv_roundf((1.f - f) * 2048.f)), b1 = onc_sat_short(onc_cv_roundf(f * 2048.f));
+        const unsigned char* S0 = src + (size_t)onc_clip(sy, 0, H) * W;
+        const unsigned char* S1 = src + (size_t)onc_clip(sy + 1, 0, H) * W;
+        for (int dx = 0; dx < Wd; dx++) { /* HResizeLinear */
+            const int sx = xofs[dx];
+            if (dx < xmax) {
+                row0[dx] = S0[sx] * ialpha[2 * dx] + S0[sx + 1] * ialpha[2 * dx + 1];
+                row1[dx] = S1[sx] * ialpha[2 * dx] + S1[sx + 1] * ialpha[2 * dx + 1];
+            } else {
+                row0[dx] = S0[sx] * 2048;
+                row1[dx] = S1[sx] * 2048;
+            }
+        }
+        unsigned char* D = dst + (size_t)dy * Wd;
+        for (int x = 0; x < Wd; x++) /* VResizeLinear, uchar */
+            D[x] = (unsigned char)((((b0 * (row0[x] >> 4)) >> 16) + ((b1 * (row1[x] >> 4)) >> 16) + 2) >> 2);
+    }
+    free(xofs);
+    free(ialpha);
+    free(row0);
+    free(row1);
+}
+
+/* cv::getRectSubPix(img (W x H, 8UC1), Size(win, win), Point2f((float)cx, (float)cy), patch 8UC1), row-major win x win out.
+ * Pointer arithmetic of the original kept as (row, column) indices. */
+void onc_get_rect_sub_pix_u8(const unsigned char* img, int W, int H, double cx, double cy, int win, unsigned char* patch) {
+    float fxc = (float)cx, fyc = (float)cy; /* Point2d -> Point2f */
+    fxc -= (win - 1) * 0.5f;
+    fyc -= (win - 1) * 0.5f;
+    const int ipx = onc_cv_floorf(fxc), ipy = onc_cv_floorf(fyc);
+    const float a = fxc - ipx, b = fyc - ipy;
+#define ONC_FIX(v) onc_cv_roundf((v) * 65536.f)               /* scale_fixpt */
+#define ONC_CAST(t) ((unsigned char)(((t) + (1 << 15)) >> 16)) /* cast_8u */
+    const int a11 = ONC_FIX((1.f - a) * (1.f - b)), a12 = ONC_FIX(a * (1.f - b)), a21 = ONC_FIX((1.f - a) * b), a22 = ONC_FIX(a * b);
+    const int b1 = ONC_FIX(1.f - b), b2 = ONC_FIX(b);
+    if (0 <= ipx && ipx < W - win && 0 <= ipy && ipy < H - win) { /* totally inside */
+        for (int i = 0; i < win; i++) {
+            const unsigned char* s = img + (size_t)(ipy + i) * W + ipx;
+            for (int j = 0; j < win; j++) {
+                const int t = s[j] * a11 + s[j + 1] * a12 + s[j + W] * a21 + s[j + W + 1] * a22;
+                patch[i * win + j] = ONC_CAST(t);
+            }
+        }
+        return;
+    }
+    /* adjustRect */
+    int rx, rw, ry, rh;
+    int col0; /* image column that src[rect.x] refers to: the returned pointer is src - rect.x */
+    int row = 0;
+    if (ipx >= 0) {
+        col0 = ipx;
+        rx = 0;
+    } else {
+        col0 = 0;
+        rx = -ipx;
+        if (rx > win) rx = win;
+    }
+    if (ipx < W - win) {
+        rw = win;
+    } else {
+        rw = W - ipx - 1;
+        if (rw < 0) {
+            col0 += rw;
+            rw = 0;
+        }
+    }
+    if (ipy >= 0) {
+        row = ipy;
+        ry = 0;
+    } else {
+        ry = -ipy;
+    }
+    if (ipy < H - win) {
+        rh = win;
+    } else {
+        rh = H - ipy - 1;
+        if (rh < 0) {
+            row += rh;
+            rh = 0;
+        }
+    }
+    /* src[j] (j in window columns) = img[row][col0 + j - rx] */
+    for (int i = 0; i < win; i++) {
+        int row2 = row + 1;
+        if (i < ry || i >= rh) row2 -= 1;
+        const unsigned char* s = img + (size_t)row * W + (col0 - rx);
+        const unsigned char* s2 = img + (size_t)row2 * W + (col0 - rx);
+        int t = s[rx] * b1 + s2[rx] * b2;
+        for (int j = 0; j < rx; j++) patch[i * win + j] = ONC_CAST(t);
+        t = s[rw] * b1 + s2[rw] * b2;
+        for (int j = rw; j < win; j++) patch[i * win + j] = ONC_CAST(t);
+        for (int j = rx; j < rw; j++) {
+            const int u = s[j] * a11 + s[j + 1] * a12 + s2[j] * a21 + s2[j + 1] * a22;
+            patch[i * win + j] = ONC_CAST(u);
+        }
+        if (i < rh) row = row2;
+    }
+#undef ONC_FIX
+#undef ONC_CAST
+}
+
+/* getNCCBlocks(img, pts, blocks, scale), SL_NCCBlock.cpp:79-155: blocks n x 128 (121 used, padding 0x80), abc n x 4
+ * (A, B, C, avgI).  small: caller's scratch of onc_resize_dims bytes (unused when scale == 1.0). */
+void onc_get_ncc_blocks(const unsigned char* img, int W, int H, int n, const double* x, const double* y, double scale,
+                        unsigned char* small, unsigned char* blocks, double* abc) {
+    const unsigned char* im = img;
+    int Ws = W, Hs = H;
+    if (scale != 1.0) { /* :123-127 */
+        onc_resize_dims(W, H, scale, scale, &Ws, &Hs);
+        onc_resize_linear_u8(img, W, H, scale, scale, small);
+        im = small;
+    }
+    for (int i = 0; i < n; i++) {
+        unsigned char* I = blocks + 128 * (size_t)i;
+        memset(I, 0x80, 128);
+        const double px = (scale != 1.0) ? x[i] * scale : x[i], py = (scale != 1.0) ? y[i] * scale : y[i]; /* :131-132 / :99-100 */
+        onc_get_rect_sub_pix_u8(im, Ws, Hs, px, py, 2 * ONC_HW + 1, I);
+        double a = 0, b = 0, avg = 0;
+        for (int j = 0; j < ONC_LEN; ++j) { /* :142-150 */
+            a += I[j];
+            b += (double)I[j] * I[j];
+            avg += I[j];
+        }
+        abc[4 * i] = a;
+        abc[4 * i + 1] = b;
+        abc[4 * i + 2] = 1 / sqrt(ONC_LEN * b - a * a);
+        abc[4 * i + 3] = avg / ONC_LEN;
+    }
+}

@@ -102,3 +102,56 @@ def test_ncc_degenerate_blocks_and_arguments(hip):
     assert r["ncc"].shape == (0, 130)
     with pytest.raises(coslam_amd.CoslamHipError):
         coslam_amd.ncc_blocks_dev(0, 1, 5, 5, 3, 1, 1, 0.3, 1, 1, 1)                           # image smaller than a block
+
+
+@pytest.mark.parametrize("W,H,scale", [(640, 480, 0.3), (322, 250, 0.3), (200, 150, 1.0), (640, 480, 0.5), (101, 67, 0.3)])
+def test_get_ncc_blocks_matches_the_restated_opencv_path(hip, W, H, scale):
+    """cs_ncc_get_blocks_dev = getNCCBlocks (reference src/slam/SL_NCCBlock.cpp:79-155, what matchBetween calls): the resized
+    image, every block and A / B / C / avgI bit for bit against oracle/ncc_oracle.c's restatement of cv::resize + cv::getRectSubPix;
+    points inside, on the border, outside the image, with fractional positions."""
+    import torch
+
+    rng = np.random.default_rng(W + H)
+    img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    img[H // 3: H // 3 + 20, W // 4: W // 4 + 30] = 200          # a flat patch: C = inf there
+    n = 700
+    x = rng.uniform(-25, W + 25, n)
+    y = rng.uniform(-25, H + 25, n)
+    x[:50], y[:50] = np.floor(x[:50]), np.floor(y[:50])             # integer positions too
+    dev = torch.device("cuda:0")
+    d_img, d_x, d_y = torch.from_numpy(img).to(dev), torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    ws, hs = coslam_amd.ncc_scaled_dims(W, H, scale)
+    d_small = torch.zeros(max(ws * hs, 1), dtype=torch.uint8, device=dev)
+    d_blk = torch.zeros((n, 128), dtype=torch.uint8, device=dev)
+    d_abc = torch.zeros((n, 4), dtype=torch.float64, device=dev)
+    d_val = torch.zeros(n, dtype=torch.int32, device=dev)
+    coslam_amd.ncc_get_blocks_dev(torch.cuda.current_stream().cuda_stream, d_img.data_ptr(), W, H, n, d_x.data_ptr(), d_y.data_ptr(),
+                                  scale, d_small.data_ptr(), d_blk.data_ptr(), d_abc.data_ptr(), d_val.data_ptr())
+    torch.cuda.synchronize()
+    if scale != 1.0:
+        small_o = oracle.resize_linear_u8(img, scale, scale)
+        assert small_o.shape == (hs, ws)
+        assert np.array_equal(d_small.cpu().numpy().reshape(hs, ws), small_o), "resized image differs"
+    blk_o, abc_o = oracle.get_ncc_blocks(img, x, y, scale)
+    assert np.array_equal(d_blk.cpu().numpy(), blk_o), "blocks differ"
+    assert np.array_equal(d_abc.cpu().numpy(), abc_o), "A / B / C / avgI differ"     # (inf == inf for the flat blocks)
+    assert np.all(d_val.cpu().numpy() == 1)
+
+
+def test_match_between_full_is_get_ncc_blocks_plus_the_matrices(hip):
+    """cs_ncc_match_between_full = matchBetween's own data path (src/app/SL_NewMapPointsInterCam.cpp:273-290): FULL images ->
+    getNCCBlocks(0.3) -> getEpiNccMat; both matrices bit for bit against the oracle."""
+    W, H = 640, 480
+    sc = Scene(2, W, H, 3000, seed=5)
+    im1, im2 = sc.render(0, 0), sc.render(1, 0)
+    rng = np.random.default_rng(9)
+    M, N = 300, 280
+    x1, y1, x2, y2 = rng.uniform(0, W, M), rng.uniform(0, H, M), rng.uniform(0, W, N), rng.uniform(0, H, N)
+    F = rng.normal(size=(3, 3))
+    g = coslam_amd.ncc_match_between_full(im1, x1, y1, im2, x2, y2, 0.3, F, 1e9, 0.3)
+    b1, c1 = oracle.get_ncc_blocks(im1, x1, y1, 0.3)
+    b2, c2 = oracle.get_ncc_blocks(im2, x2, y2, 0.3)
+    assert np.array_equal(g["blocks1"], b1) and np.array_equal(g["blocks2"], b2) and np.array_equal(g["abc1"], c1)
+    ones1, ones2 = np.ones(M, np.int32), np.ones(N, np.int32)
+    e_o, n_o = oracle.ncc_epi_mat(F, x1, y1, b1, c1, ones1, x2, y2, b2, c2, ones2, 1e9, 0.3)
+    assert np.array_equal(g["epi"], e_o) and np.array_equal(g["ncc"], n_o) and (n_o != -1).sum() > 50

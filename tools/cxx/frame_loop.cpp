@@ -155,6 +155,7 @@ int main(int argc, char** argv) {
     const std::vector<uint8_t> pgFixed = rd.vec<uint8_t>(pgNodes);
     const std::vector<double> pgR = rd.vec<double>(9 * (size_t)pgNodes), pgT = rd.vec<double>(3 * (size_t)pgNodes);
     const std::vector<int> pgCam = rd.vec<int>(joint.C);
+    const std::vector<double> Fs = rd.vec<double>((size_t)nFrames * (nCams - 1) * 9);  // [frame][pair (c, c + 1)][9]
     fclose(rd.f);
 
     // ---- trackers, group, streams ----
@@ -270,6 +271,18 @@ int main(int argc, char** argv) {
     rec.d_nodeR = dPgR, rec.d_nodeT = dPgT, rec.d_edgeR = dPgER, rec.d_edgeT = dPgET, rec.d_newR = dPgNR, rec.d_newT = dPgNT;
     CSCHK(cs_ba_set_followup(joint.ws, cs_posegraph_after_ba, &rec));
 
+    // inter-camera NCC matching every 4th frame: getNCCBlocks per camera on the full frame, the matrices per consecutive pair
+    const int NCC_EVERY = 4;
+    int wsS = 0, hsS = 0;
+    CSCHK(cs_ncc_scaled_dims(W, H, 0.3, &wsS, &hsS));
+    unsigned char* dSmall = dev_zeros<unsigned char>((size_t)nCams * wsS * hsS);
+    unsigned char* dBlk = dev_zeros<unsigned char>((size_t)nCams * N * 128);
+    double* dAbc = dev_zeros<double>((size_t)nCams * N * 4);
+    int* dValid = dev_zeros<int>((size_t)nCams * N);
+    double* dEpi = dev_zeros<double>((size_t)N * N);
+    double* dScore = dev_zeros<double>((size_t)N * N);
+    int nccRuns = 0;
+
     hipEvent_t kltDone[2], destFree[2];
     for (int b = 0; b < 2; ++b) {
         HIPCHK(hipEventCreateWithFlags(&kltDone[b], hipEventDisableTiming));
@@ -302,6 +315,22 @@ int main(int argc, char** argv) {
                                      reg[0].dist, reg[0].flags));
         CSCHK(cs_register_search_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, P_REG, dMap, dCov, dPf, PIX, 3 * PIX, PIX,
                                      reg[1].slot, reg[1].m, reg[1].var, reg[1].dist, reg[1].flags));
+        if (nCams >= 2 && i % NCC_EVERY == 0) {
+            CSCHK(cs_ncc_unmapped_mask_dev(dev, (void*)poseS, nCams * N, dState, dS2M, dValid));
+            for (int c = 0; c < nCams; ++c)
+                CSCHK(cs_ncc_get_blocks_dev(dev, (void*)poseS, dFrames[c] + imgBytes * f, W, H, N, dXY + (size_t)c * 2 * N,
+                                            dXY + (size_t)c * 2 * N + N, 0.3, dSmall + (size_t)c * wsS * hsS, dBlk + (size_t)c * N * 128,
+                                            dAbc + (size_t)c * N * 4, nullptr));
+            for (int c = 0; c + 1 < nCams; ++c) {
+                const double* xa = dXY + (size_t)c * 2 * N;
+                const double* xb = dXY + (size_t)(c + 1) * 2 * N;
+                CSCHK(cs_ncc_epi_mat_dev(dev, (void*)poseS, Fs.data() + ((size_t)f * (nCams - 1) + c) * 9, N, xa, xa + N,
+                                         dBlk + (size_t)c * N * 128, dAbc + (size_t)c * N * 4, dValid + (size_t)c * N, N, xb, xb + N,
+                                         dBlk + (size_t)(c + 1) * N * 128, dAbc + (size_t)(c + 1) * N * 4, dValid + (size_t)(c + 1) * N, 50.0,
+                                         0.80, -1.0, dEpi, dScore));
+            }
+            ++nccRuns;
+        }
         HIPCHK(hipEventRecord(destFree[b], poseS));
         if (key) {
             ic.solve_async(poseS);
@@ -382,8 +411,8 @@ int main(int argc, char** argv) {
     CSCHK(cs_ba_download(ic.ws, ic.C, ic.P, ic.nObs, nullptr, nullptr, nullptr, nullptr, &si));
     printf("{\"frames_per_s\": %.3f, \"ms_per_step\": %.5f, \"steps\": %d, \"warmup\": %d, \"host_enqueue_ms_per_step\": %.5f, "
            "\"cams_per_tracker_launch\": %d, \"pose_ok\": %s, \"min_live_features\": %d, \"joint_lm_steps\": %d, \"joint_cost\": %.6f, "
-           "\"intercam_lm_steps\": %d, \"intercam_cost\": %.6f}\n",
+           "\"intercam_lm_steps\": %d, \"intercam_cost\": %.6f, \"ncc_runs\": %d}\n",
            steps / dt, dt / steps * 1e3, steps, warmup, dtHost / steps * 1e3, camsPerLaunch, okAll ? "true" : "false", minLive,
-           sj.nIterTotal, sj.cost, si.nIterTotal, si.cost);
+           sj.nIterTotal, sj.cost, si.nIterTotal, si.cost, nccRuns);
     return 0;
 }
