@@ -654,8 +654,6 @@ def main():
             with torch.cuda.stream(pose_s):
                 xchg.pack_group(d_dests[b], d_R[i & 1], d_t[i & 1], pose_s)
                 xchg.all_gather(pose_s)
-        if ncc is not None and i % NCC_EVERY == 0:
-            ncc_leg(f)
         dest_free[b].record(pose_s)
         if key_frame and world > 1:
             # InterCamPoseEstimator::addMapPoints (reference src/app/SL_InterCamPoseEstimator.cpp:24-37) starts the solve from
@@ -693,6 +691,15 @@ def main():
             else:
                 ba_ws.solve_async(pose_s.cuda_stream, d_jR.data_ptr(), d_jT.data_ptr(), d_jM.data_ptr(), joint["n_cams_con"],
                                   joint["n_pts_con"], 6.0, 2, 10)
+
+    _step_core = step
+
+    def step(i, key_frame, upload=False):   # noqa: F811
+        # the NCC matching leg goes LAST on the pose stream: behind the event that frees the tracker's dest buffer and behind
+        # the events the key-frame solves wait for (it consumes the frame's records; nothing of this frame waits for it)
+        _step_core(i, key_frame, upload)
+        if ncc is not None and i % NCC_EVERY == 0:
+            ncc_leg(order[i % len(order)])
 
     def barrier():
         ic_ws.wait()      # the worker threads' queues are part of the timed work
@@ -960,6 +967,61 @@ def main():
                 "outliers": st5.nOutliers}
         ws5.close()
 
+    # ---- secondary key: the KLT stage of cfg5 (BASELINE.json configs[4]: 4 cameras 1920 x 1080 x 5000 slots (100 x 50), here all
+    # four on ONE GPU as a camera group): redetect + prefetch per frame, HIP-event time of the tracker stage
+    cfg5_klt = None
+    if rank == 0 and n_gpus == 1 and not args.no_secondary:
+        from coslam_amd.synth import Scene as _Scene
+
+        W5, H5, L5, FW5, FH5, C5, NF5 = 1920, 1080, 4, 100, 50, 4, 4
+        sc5 = _Scene(C5, W5, H5, 12000, seed=0xC051A + 5)
+        fr5 = [torch.from_numpy(np.stack([sc5.render(c, f) for f in range(NF5)])).to(dev) for c in range(C5)]
+        ord5 = list(range(NF5)) + list(range(NF5 - 2, 0, -1))
+        t5s = []
+        for _ in range(C5):
+            t = coslam_amd.KLT_SequenceTracker(coslam_amd.KLT_SequenceTrackerConfig(
+                nIterations=10, nLevels=L5, levelSkip=1, windowWidth=7, trackWithGain=1, minCornerness=3000.0, convergenceThreshold=1.0,
+                SSD_Threshold=20000.0, minDistance=8), device=local_rank)
+            t.allocate(W5, H5, L5, FW5, FH5)
+            t5s.append(t)
+        g5 = coslam_amd.KLT_TrackerGroup(t5s)
+        g5.set_stream(klt_s.cuda_stream)
+        dd5 = [torch.zeros(FW5 * FH5 * 5, dtype=torch.int32, device=dev) for _ in range(C5)]
+        cc5 = [torch.zeros(4, dtype=torch.int32, device=dev) for _ in range(C5)]
+        dp5, cp5 = [d.data_ptr() for d in dd5], [c.data_ptr() for c in cc5]
+        g5.detect_dev([f[0].data_ptr() for f in fr5], dp5, cp5)
+        g5.advanceFrame()
+
+        def frame5(i):
+            a, b = ord5[(i + 1) % len(ord5)], ord5[(i + 2) % len(ord5)]
+            g5.prefetch_dev([f[b].data_ptr() for f in fr5])
+            g5.redetect_dev([f[a].data_ptr() for f in fr5], dp5, cp5)
+            g5.advanceFrame()
+
+        for i in range(8):
+            frame5(i)
+        g5.synchronize()
+        t5s[0].set_profiling(True)
+        n5 = 40
+        tk = time.perf_counter()
+        for i in range(n5):
+            frame5(8 + i)
+        g5.synchronize()
+        dtk = time.perf_counter() - tk
+        p5 = t5s[0].get_profile()
+        t5s[0].set_profiling(False)
+        live5 = [int((d.cpu().numpy().view(coslam_amd.KLT_TrackedFeature)["status"] >= 0).sum()) for d in dd5]
+        per_feat5 = L5 * 2 * (2 * 3 + 2) ** 2 * 6 + 2 * 12
+        trk_us5 = p5["tracker_us_total"] / max(p5["frames"], 1)
+        cfg5_klt = {"workload": "cfg5 KLT: 4 cameras 1920x1080 x 5000 slots (100x50) as one camera group on one GPU, 4 levels, 7x7, 10 it/level "
+                                "with gain, redetect + prefetch per frame", "frames_per_s": n5 / dtk, "camera_frames_per_s": C5 * n5 / dtk,
+                    "us_per_frame": dtk / n5 * 1e6, "tracker_stage_us": trk_us5, "tracker_launches_per_frame": p5["launches_per_frame"],
+                    "tracker_algorithmic_GBps": per_feat5 * FW5 * FH5 * C5 / (trk_us5 * 1e-6) / 1e9, "live_features": live5}
+        g5.close()
+        for t in t5s:
+            t.close()
+        del fr5
+
     cpu = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         cores = os.cpu_count() or 1
@@ -1020,7 +1082,7 @@ def main():
                                                                   "cost0": st_j.cost0, "cost": st_j.cost},
                        "intercam_last": {"lm_steps": st_i.nIterTotal, "outliers": st_i.nOutliers, "cost0": st_i.cost0,
                                          "cost": st_i.cost},
-                       "frame_front_prefetch": bool(prefetch), "secondary_cfg2": cfg2, "secondary_cfg5_ba": cfg5,
+                       "frame_front_prefetch": bool(prefetch), "secondary_cfg2": cfg2, "secondary_cfg5_ba": cfg5, "secondary_cfg5_klt": cfg5_klt,
                        "posegraph_last": pg_info,
                        "register_candidates_last_frame": None if args.no_register else
                        {"active": int((reg_out[0]["slot"] >= 0).sum().item()), "current_static": int((reg_out[1]["slot"] >= 0).sum().item()),

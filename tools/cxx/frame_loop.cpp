@@ -315,6 +315,12 @@ int main(int argc, char** argv) {
                                      reg[0].dist, reg[0].flags));
         CSCHK(cs_register_search_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, P_REG, dMap, dCov, dPf, PIX, 3 * PIX, PIX,
                                      reg[1].slot, reg[1].m, reg[1].var, reg[1].dist, reg[1].flags));
+        HIPCHK(hipEventRecord(destFree[b], poseS));
+        if (key) {
+            ic.solve_async(poseS);
+            joint.solve_async(poseS);
+        }
+        // (last on the pose stream: nothing of this frame waits for the matching leg)
         if (nCams >= 2 && i % NCC_EVERY == 0) {
             CSCHK(cs_ncc_unmapped_mask_dev(dev, (void*)poseS, nCams * N, dState, dS2M, dValid));
             for (int c = 0; c < nCams; ++c)
@@ -330,11 +336,6 @@ int main(int argc, char** argv) {
                                          0.80, -1.0, dEpi, dScore));
             }
             ++nccRuns;
-        }
-        HIPCHK(hipEventRecord(destFree[b], poseS));
-        if (key) {
-            ic.solve_async(poseS);
-            joint.solve_async(poseS);
         }
     };
     auto barrier = [&]() {

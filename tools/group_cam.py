@@ -11,12 +11,15 @@ from coslam_amd.synth import Scene
 dev = torch.device("cuda:0")
 W, H, L, FW, FH = 640, 480, 4, 50, 40
 NF = 12
+CFG5 = os.environ.get("GROUP_CAM_CFG5") == "1"   # BASELINE.json configs[4]'s KLT stage: 4 cameras 1920 x 1080 x 5000 slots
+if CFG5:
+    W, H, L, FW, FH, NF = 1920, 1080, 4, 100, 50, 4
 
 
 def cfg():
     return coslam_amd.KLT_SequenceTrackerConfig(nIterations=10, nLevels=L, levelSkip=1, windowWidth=7, trackWithGain=1,
                                                 minCornerness=3000.0, convergenceThreshold=1.0, SSD_Threshold=20000.0,
-                                                minDistance=4)
+                                                minDistance=8 if CFG5 else 4)
 
 
 _frames = {}
@@ -24,7 +27,7 @@ _frames = {}
 
 def frames_of(cam):
     if cam not in _frames:
-        sc = Scene(8, W, H, 7000, seed=0xC051A + 4, sigma=1.0)
+        sc = Scene(8, W, H, 12000 if CFG5 else 7000, seed=0xC051A + (5 if CFG5 else 4), sigma=1.0)
         _frames[cam] = torch.from_numpy(np.stack([sc.render(cam % 8, f) for f in range(NF)])).to(dev)   # (cameras >= 8 reuse views)
     return _frames[cam]
 
@@ -102,6 +105,11 @@ def probe_report(n):
 
 if __name__ == "__main__":
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+    if CFG5:
+        for n in (1, 2, 4):
+            run(n, n_frames=40)
+        run(4, n_frames=10, fused=0)
+        sys.exit(0)
     for n in ((1, 8) if quick else (1, 2, 4, 8, 12, 16)):   # beyond the co-residency capacity the span is tracked in two launches
         run(n)
     if not quick:
