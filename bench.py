@@ -320,6 +320,9 @@ def main():
     ap.add_argument("--ba-cus", default=os.environ.get("BENCH_BA_CUS", ""), help="FIRST:COUNT -- the joint BA's stream confined to these CU-mask bits")
     ap.add_argument("--ic-cus", default=os.environ.get("BENCH_IC_CUS", ""), help="FIRST:COUNT -- the inter-camera solve's stream confined to these CU-mask bits")
     ap.add_argument("--pose-cus", default=os.environ.get("BENCH_POSE_CUS", ""), help="FIRST:COUNT -- the pose stream (hand-back, pose, registration) confined to these CU-mask bits")
+    ap.add_argument("--ba-prebaked", action="store_true",
+                    help="the joint local BA re-solves ONE pre-baked synthetic problem at every key frame (rounds 1-2) instead of the problem "
+                         "parsed on the device from the last 5 key frames' tracked features and poses (N = 1 default: cs_ba_window_*)")
     ap.add_argument("--no-ncc", action="store_true", help="diagnostic: skip the inter-camera NCC matching leg (not a valid bench line)")
     ap.add_argument("--no-cxx-loop", action="store_true", help="skip the C++ frame loop (tools/cxx/frame_loop.bin, config.cxx_frame_loop)")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the upload-inclusive repetition of the loop (config.with_upload)")
@@ -457,11 +460,24 @@ def main():
             t.set_cu_count(min(256, (250 * args.klt_cams_per_launch + 60) // 8 + 5))
     prefetch = os.environ.get("BENCH_PREFETCH", "1") != "0"
 
+    # Joint local BA, data-coupled (N = 1): a ring of the last 5 key frames on the device -- every camera's hand-back records
+    # and solved pose at the key frame -- from which RobustBundleRTS::addKeyFrames / addPoints / parseInputs' flat problem is
+    # built on the device at every key frame (cameras = 5 key frames x 8, the 16 oldest held; points = mapped map points with
+    # more than one feature point in the window) and solved from the tracked poses.  N > 1 keeps the pre-baked problem: the
+    # all-gather carries the trackers' dest[] records, not the hand-back's.
+    use_window = (world == 1) and not args.ba_prebaked and not args.serial and not args.no_pose
     jptr, jcam, jxy = csr(joint)
     ba_ws = BAWorkspace(local_rank)
     if args.ba_cus:
         ba_ws.set_stream(masked_stream(args.ba_cus))
-    ba_ws.upload(joint["Ks"], joint["Rs0"], joint["ts0"], joint["pts0"], jptr, jcam, jxy)
+    ba_win = None
+    if use_window:
+        from coslam_amd.ba import BAWindow
+
+        ba_win = BAWindow(nc, 5, N_FEAT, len(sc.points), device=local_rank)
+        ba_win.reserve(ba_ws)
+    else:
+        ba_ws.upload(joint["Ks"], joint["Rs0"], joint["ts0"], joint["pts0"], jptr, jcam, jxy)
     if persist_j:
         ba_ws.set_persistent(persist_j)
     d_jR = torch.from_numpy(joint["Rs0"].reshape(-1).copy()).to(dev)
@@ -688,6 +704,11 @@ def main():
             elif args.serial:
                 ba_ws.solve_dev(klt_s.cuda_stream, d_jR.data_ptr(), d_jT.data_ptr(), d_jM.data_ptr(), joint["n_cams_con"],
                                 joint["n_pts_con"], 6.0, 2, 10)
+            elif ba_win is not None:
+                # this key frame into the ring (the hand-back's records and the poses pose(f) just wrote), then
+                # requestForBA(5, 2, 2, 30): the numCams * 2 oldest key cameras held, 2 points held, maxIter 2, inner 10
+                ba_win.push_dev(pose_s.cuda_stream, hb_args[b], d_K1.data_ptr(), 1, d_R[i & 1].data_ptr(), d_t[i & 1].data_ptr(), i)
+                ba_win.solve_async(ba_ws, pose_s.cuda_stream, d_map.data_ptr(), 2 * nc, 2, 6.0, 2, 10)
             else:
                 ba_ws.solve_async(pose_s.cuda_stream, d_jR.data_ptr(), d_jT.data_ptr(), d_jM.data_ptr(), joint["n_cams_con"],
                                   joint["n_pts_con"], 6.0, 2, 10)
@@ -733,18 +754,22 @@ def main():
 
     gc.collect()
     gc.disable()   # no collector pauses on the launching thread from here to the end of the timed region
-    for i in range(max(args.key_every, 1) + 1):
-        step(i + 1, args.key_every > 0 and i == 0)
+    n_setup = max(args.key_every, 1) + 1
+    if ba_win is not None and args.key_every > 0:
+        n_setup = 5 * args.key_every + 1      # (fills the ring: every timed solve then has its 5 key frames = 40 cameras)
+    for i in range(n_setup):
+        step(i + 1, args.key_every > 0 and i % max(args.key_every, 1) == 0)
     barrier()
+    base0 = n_setup    # (the frame sequence continues through set-up, warm-up and the timed region: no jump for the tracker)
     for i in range(args.warmup):
-        step(i + 1, args.key_every > 0 and i % args.key_every == 0)
+        step(base0 + i + 1, args.key_every > 0 and i % args.key_every == 0)
     barrier()
     t_begin = time.perf_counter()
     t_step_max, i_step_max, t_prev = 0.0, -1, t_begin
     for i in range(args.steps):
         # key frames: the first frame of the timed region and every KEY_EVERY-th after it (K / KEY_EVERY solves of each
         # kind in K frames, all completed before the clock stops)
-        step(args.warmup + i + 1, args.key_every > 0 and i % args.key_every == 0)
+        step(base0 + args.warmup + i + 1, args.key_every > 0 and i % args.key_every == 0)
         t_now = time.perf_counter()
         if t_now - t_prev > t_step_max:
             t_step_max, i_step_max = t_now - t_prev, i
@@ -758,7 +783,7 @@ def main():
         # one pinned ring entry per frame: the cameras' images back to back, as capture threads writing into cs_pinned_alloc'd
         # memory would leave them -> ONE host-to-device copy per frame
         h_frames = torch.from_numpy(np.stack([frames[c] for c in my_cams], axis=1).copy()).pin_memory()   # [frame][camera][H][W]
-        i0 = args.warmup + args.steps + 1
+        i0 = base0 + args.warmup + args.steps + 1
         stage(i0)
         stage(i0 + 1)
         for i in range(args.warmup):
@@ -779,7 +804,7 @@ def main():
                                "loop (cs_klt_group_stage_h: copy stream + ring of 3 device slots, two frames ahead of the tracker)"}
         replay_base = i0 + args.warmup + args.steps - 1
     else:
-        replay_base = args.warmup + args.steps
+        replay_base = base0 + args.warmup + args.steps
     gc.enable()
     pg_info = None
     if pg is not None:
@@ -826,6 +851,12 @@ def main():
     f_last = order[replay_base % len(order)]
     Rl, tl_ = d_R[last].cpu().numpy(), d_t[last].cpu().numpy()
     pose_err = max(float(np.abs(tl_[i] - sc.pose(c, f_last)[1]).max()) for i, c in enumerate(my_cams))
+    win_info = None
+    if ba_win is not None:
+        wC, wP, wO, _, wkf = ba_win.last_problem()
+        ba_ws.set_sizes(wC, wP, wO)
+        win_info = {"cameras": wC, "points": wP, "measurements": wO, "key_frames": wkf,
+                    "what": "parsed on the device from the last 5 key frames' hand-back records and solved poses (cs_ba_window_*)"}
     _, _, _, _, st_j = ba_ws.download() if (world == 1 or not ba_sliced) else (None, None, None, None, None)
     _, _, _, _, st_i = ic_ws.download()
 
@@ -1068,7 +1099,10 @@ def main():
                                    "every frame (fed by the tracker's output); map-point registration search every frame "
                                    f"(active + current static, {P_REG} points each x 8 cams x 2000 slots); "
                                    f"every {KEY_EVERY}th frame: joint local BA "
-                                   f"C=40 (16 fixed) x {len(joint['pts0'])} pts x {len(joint['obs_cam'])} meas, maxIter 2 / inner 10"
+                                   + (f"C=40 (16 fixed), parsed on the device from the last 5 key frames' tracked features and poses "
+                                      f"(last: {win_info['points']} pts x {win_info['measurements']} meas), maxIter 2 / inner 10"
+                                      if win_info is not None else
+                                      f"C=40 (16 fixed) x {len(joint['pts0'])} pts x {len(joint['obs_cam'])} meas (pre-baked), maxIter 2 / inner 10")
                                    + ("" if args.no_posegraph else ", followed on its stream by the pose-graph relaxation of the "
                                       "window's non-key frames (21-frame chain per camera, 5 key frames fixed)") + ", and "
                                    f"inter-camera solve C=8 free, {ic['n_static']} static pts fixed + {ic['n_dynamic']} dynamic, "
@@ -1078,6 +1112,9 @@ def main():
                        "cameras": N_CAMS, "cameras_per_gpu": nc, "camera_frames_per_s": N_CAMS * args.steps / dt,
                        "live_features_last_frame": n_live, "pose_ok": pose_ok, "pose_correspondences": pose_npts, "pose_rounds_and_last_lm_steps": pose_iters,
                        "pose_translation_error_vs_truth": pose_err,
+                       "joint_ba_problem": win_info if win_info is not None else {
+                           "cameras": len(joint["Rs0"]), "points": len(joint["pts0"]), "measurements": len(joint["obs_cam"]),
+                           "what": "pre-baked synthetic problem, re-solved from the same start at every key frame"},
                        "joint_ba_last": None if st_j is None else {"lm_steps": st_j.nIterTotal, "outliers": st_j.nOutliers,
                                                                   "cost0": st_j.cost0, "cost": st_j.cost},
                        "intercam_last": {"lm_steps": st_i.nIterTotal, "outliers": st_i.nOutliers, "cost0": st_i.cost0,

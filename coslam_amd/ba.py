@@ -122,6 +122,16 @@ class BAWorkspace:
         address; enqueued behind every solve on the solve's stream.  The caller keeps the record alive.  (0, 0) removes it."""
         check(self._L.cs_ba_set_followup(self._h, C.c_void_p(fn_ptr), C.c_void_p(user_ptr)), "cs_ba_set_followup")
 
+    def problem_buffers(self):
+        """device addresses (ints) of the flat problem in the workspace: (Ks, obs_ptr, obs_cam, obs_xy)"""
+        a, b, c, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(self._L.cs_ba_problem_buffers(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "cs_ba_problem_buffers")
+        return a.value, b.value, c.value, d.value
+
+    def set_sizes(self, n_cams, n_pts, n_obs):
+        """the sizes download() copies (a problem parsed on the device: BAWindow.last_problem())"""
+        self.C, self.P, self.nObs = int(n_cams), int(n_pts), int(n_obs)
+
     def download(self):
         Rs, Ts, pts = np.zeros((self.C, 9)), np.zeros((self.C, 3)), np.zeros((max(self.P, 1), 3))
         out = np.zeros(max(self.nObs, 1), dtype=np.int32)
@@ -134,6 +144,56 @@ class BAWorkspace:
         if self._h:
             self._L.cs_ba_destroy.argtypes = [C.c_void_p]
             self._L.cs_ba_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BAWindow:
+    """cs_ba_window: a ring of key frames on the device -- per key frame and camera the hand-back's records (undistorted pixels,
+    slot -> map point) and K, R, t -- from which the bundle adjuster's inputs are parsed on the device
+    (RobustBundleRTS::addKeyFrames / addPoints / parseInputs, reference src/app/SL_CoSLAMRobustBA.cpp:37-78,109-165)."""
+
+    def __init__(self, n_cams, n_key_frames, n_slots, n_map_pts, device=0):
+        self._L = lib()
+        self._L.cs_ba_window_create.restype = C.c_void_p
+        h = self._L.cs_ba_window_create(int(device), int(n_cams), int(n_key_frames), int(n_slots), int(n_map_pts))
+        if not h:
+            raise CoslamHipError("cs_ba_window_create: " + self._L.cs_last_error().decode())
+        self._h = C.c_void_p(h)
+        self.n_cams, self.n_key_frames, self.device = n_cams, n_key_frames, device
+
+    def push_dev(self, stream_ptr, hb_cams, d_K, k_shared, d_R, d_t, frame):
+        """hb_cams: the ctypes array handback_cams() built (its xy / state / slot2map are read); device pointers as ints"""
+        vp = C.c_void_p
+        check(self._L.cs_ba_window_push_dev(self._h, vp(stream_ptr), hb_cams, vp(d_K), int(k_shared), vp(d_R), vp(d_t), int(frame)),
+              "cs_ba_window_push_dev")
+
+    def solve_async(self, ws, after_stream_ptr, d_map_pts, n_cams_con, n_pts_con, max_err, max_iter, inner_max_iter, d_map_static=0):
+        vp = C.c_void_p
+        check(self._L.cs_ba_solve_window_async(ws._h, self._h, vp(after_stream_ptr), vp(d_map_pts), vp(d_map_static), int(n_cams_con),
+                                               int(n_pts_con), C.c_double(max_err), int(max_iter), int(inner_max_iter)),
+              "cs_ba_solve_window_async")
+
+    def reserve(self, ws):
+        """cs_ba_reserve_for_window: ws sized and bound for this window's largest problem (result_buffers() then stay valid)"""
+        check(self._L.cs_ba_reserve_for_window(ws._h, self._h), "cs_ba_reserve_for_window")
+
+    def last_problem(self):
+        """(C, P, nObs, device address of the points' map indices, key-frame numbers oldest first); call after ws.wait()"""
+        c, p, o, pm = C.c_int(0), C.c_int(0), C.c_int(0), C.c_void_p()
+        kf = (C.c_int * self.n_key_frames)()
+        check(self._L.cs_ba_window_last_problem(self._h, C.byref(c), C.byref(p), C.byref(o), C.byref(pm), kf), "cs_ba_window_last_problem")
+        return c.value, p.value, o.value, pm.value, list(kf)
+
+    def close(self):
+        if self._h:
+            self._L.cs_ba_window_destroy.argtypes = [C.c_void_p]
+            self._L.cs_ba_window_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -1999,6 +1999,7 @@ __global__ __launch_bounds__(256) void k_control_step(BaDev D) {
 
 #include "ba_packed_dev.h"
 #include "ba_persist_dev.h"
+#include "ba_window_dev.h"
 
 // ---- outer loop: outlier flags ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_flag(BaDev D) {
@@ -2868,6 +2869,9 @@ struct BaAsyncJob {
     double maxErr;
     const double *R0, *T0, *M0;
     hipEvent_t ready;
+    struct cs_ba_window* win = nullptr;  // cs_ba_solve_window_async: the problem is built on the device from this window
+    const double* d_map = nullptr;
+    const unsigned char* d_mapStatic = nullptr;
 };
 
 struct BaWorker {
@@ -2932,7 +2936,106 @@ static int ba_capture(hipStream_t s, hipGraphExec_t* out, F&& body) {
     return CS_OK;
 }
 
+// ---- the sliding window of key frames (ba_window_dev.h) ------------------------------------------------------------------
+struct cs_ba_window {
+    int device, nCams, nKf, N, nMap;
+    int head, count;     // ring: the next slot to write; key frames held
+    int frameOf[16];
+    unsigned char* slab;
+    double *xy, *K, *R, *t;
+    int *pf, *cnt, *ptIndex, *obsStart, *totals, *pointMap, *pairCnt, *pairTotal;
+    int* h_totals;       // pinned [8]
+    int lastC, lastP, lastObs;
+};
+
+static int ba_worker_run_window(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
+    cs_ba_window* win = J.win;
+    CS_HIP(hipSetDevice(b->device));
+    hipStream_t s = b->own_stream;
+    CS_HIP(hipStreamWaitEvent(s, J.ready, 0));
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        if (w->stale) {
+            ba_worker_destroy_graphs(w);
+            w->stale = false;
+        }
+    }
+    if (win->count < 1) {
+        cs_set_error("cs_ba_solve_window_async: the window holds no key frame");
+        return CS_ERR_INVALID;
+    }
+    const int C = win->count * win->nCams;
+    // the workspace for the largest problem this window can produce: every slot of every key camera a measurement
+    int rc = ba_reserve(b, win->nKf * win->nCams, win->nMap, win->nKf * win->nCams * win->N);
+    if (rc) return rc;
+    ba_bind_io(b, b->capC, b->capP, b->capObs);
+    ba_drop_graph(b);
+    WinDev Wd;
+    memset(&Wd, 0, sizeof(Wd));
+    Wd.nCams = win->nCams, Wd.nKf = win->nKf, Wd.N = win->N, Wd.nMap = win->nMap, Wd.count = win->count;
+    for (int j = 0; j < win->count; ++j) Wd.slotOf[j] = (win->head - win->count + j + 2 * win->nKf) % win->nKf;  // oldest first
+    Wd.xy = win->xy, Wd.pf = win->pf, Wd.K = win->K, Wd.R = win->R, Wd.t = win->t;
+    Wd.mapStatic = J.d_mapStatic, Wd.mapPts = J.d_map;
+    Wd.cnt = win->cnt, Wd.ptIndex = win->ptIndex, Wd.obsStart = win->obsStart, Wd.totals = win->totals;
+    const int gM = (win->nMap + 255) / 256 > 0 ? (win->nMap + 255) / 256 : 1;
+    hipLaunchKernelGGL(k_win_count, dim3(gM), dim3(256), 0, s, Wd);
+    hipLaunchKernelGGL(k_win_scan, dim3(1), dim3(1024), 0, s, Wd);
+    WinFillOut O = {b->Ks, b->Rs, b->Ts, b->pts, b->obs_xy, b->obs_ptr, b->obs_cam, win->pointMap};
+    const int gF = ((win->nMap > C ? win->nMap : C) + 255) / 256;
+    hipLaunchKernelGGL(k_win_fill, dim3(gF), dim3(256), 0, s, Wd, O);
+    CS_HIP(hipMemcpyAsync(win->h_totals, win->totals, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));  // (this is the worker thread: the frame loop does not wait)
+    const int P = win->h_totals[0], nObs = win->h_totals[1];
+    win->lastC = C, win->lastP = P, win->lastObs = nObs;
+    b->maxObs = win->h_totals[2];
+    b->nPackWaves = 0;  // (no lane plan for a problem built on the device: the wave-per-point kernels)
+    b->havePairs = false;
+    if (P == 0 || nObs == 0) {
+        cs_set_error("cs_ba_solve_window_async: no map point has two feature points in the window");
+        return CS_ERR_INVALID;
+    }
+    // measurement tables (obs_pt, the dense (point, camera) table) and the camera-pair lists, all on the device
+    (void)hipMemsetAsync(b->obs_of, 0xff, sizeof(int) * (size_t)P * C, s);
+    hipLaunchKernelGGL(k_build_obs_pt, dim3((P + 3) / 4), dim3(256), 0, s, P, b->obs_ptr, b->obs_pt);
+    hipLaunchKernelGGL(k_build_obs_of, dim3((nObs + 255) / 256), dim3(256), 0, s, nObs, C, b->obs_pt, b->obs_cam, b->obs_of);
+    const int nPairsAll = C * (C + 1) / 2;
+    if ((size_t)nPairsAll + 1 > b->pairPtrCap) {
+        if (b->pairPtr) (void)hipFree(b->pairPtr);
+        b->pairPtr = nullptr;
+        CS_HIP(hipMalloc((void**)&b->pairPtr, sizeof(int) * ((size_t)nPairsAll + 1)));
+        b->pairPtrCap = (size_t)nPairsAll + 1;
+    }
+    hipLaunchKernelGGL(k_pairs_count, dim3(nPairsAll), dim3(64), 0, s, C, P, b->obs_of, win->pairCnt);
+    hipLaunchKernelGGL(k_pairs_scan, dim3(1), dim3(1024), 0, s, nPairsAll, win->pairCnt, b->pairPtr, win->pairTotal);
+    CS_HIP(hipMemcpyAsync(win->h_totals + 4, win->pairTotal, sizeof(int), hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    const size_t nEnt = (size_t)win->h_totals[4];
+    if (nEnt > 0 && nEnt <= ((size_t)8 << 20)) {
+        if (nEnt > b->pairEntCap) {
+            if (b->pairEnt) (void)hipFree(b->pairEnt);
+            b->pairEnt = nullptr;
+            const size_t cap = nEnt + nEnt / 4 + 1024;
+            CS_HIP(hipMalloc((void**)&b->pairEnt, sizeof(int4) * cap));
+            b->pairEntCap = cap;
+        }
+        hipLaunchKernelGGL(k_pairs_fill, dim3(nPairsAll), dim3(64), 0, s, C, P, b->obs_of, b->pairPtr, b->pairEnt);
+        b->havePairs = true;
+    }
+    if (!b->havePairs) {  // (the camera-indexed lists k_schur would need are not built on the device)
+        cs_set_error("cs_ba_solve_window_async: %zu camera-pair entries exceed what the window path supports", nEnt);
+        return CS_ERR_INVALID;
+    }
+    // the whole robust solve, enqueued eagerly (the sizes change with every key frame: no graph to replay); the estimate the
+    // fill kernel wrote into Rs / Ts / pts is the start (the key poses as tracked, the map as it stands)
+    rc = ba_enqueue(b, s, C, P, nObs, J.nCamsCon, J.nPtsCon, J.maxErr, J.maxIter, J.innerMaxIter, false, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    rc = ba_run_followup(b, s);
+    CS_HIP(hipStreamSynchronize(s));
+    return rc;
+}
+
 static int ba_worker_run(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
+    if (J.win) return ba_worker_run_window(b, w, J);
     CS_HIP(hipSetDevice(b->device));
     hipStream_t s = b->own_stream;
     CS_HIP(hipStreamWaitEvent(s, J.ready, 0));
@@ -3621,7 +3724,9 @@ int cs_ba_solve_async(cs_ba* b, void* after_stream, int C, int P, int nObs, cons
         b->worker = w;
         w->th = std::thread(ba_worker_main, b, w);
     }
-    BaAsyncJob J = {C, P, nObs, nCamsCon, nPtsCon, maxIter, innerMaxIter, maxErr, d_Rs0, d_Ts0, d_pts0, nullptr};
+    BaAsyncJob J;
+    J.C = C, J.P = P, J.nObs = nObs, J.nCamsCon = nCamsCon, J.nPtsCon = nPtsCon, J.maxIter = maxIter, J.innerMaxIter = innerMaxIter;
+    J.maxErr = maxErr, J.R0 = d_Rs0, J.T0 = d_Ts0, J.M0 = d_pts0, J.ready = nullptr;
     CS_HIP(hipEventCreateWithFlags(&J.ready, hipEventDisableTiming));
     CS_HIP(hipEventRecord(J.ready, (hipStream_t)after_stream));
     {
@@ -3630,6 +3735,183 @@ int cs_ba_solve_async(cs_ba* b, void* after_stream, int C, int P, int nObs, cons
         b->worker->inflight += 1;
     }
     b->worker->cv.notify_one();
+    return CS_OK;
+}
+
+// ---- sliding window of key frames: the BA's inputs from the tracker's own records (ba_window_dev.h) ---------------------------
+cs_ba_window* cs_ba_window_create(int device, int nCams, int nKeyFrames, int N, int nMapPts) {
+    if (nCams < 1 || nCams > 16 || nKeyFrames < 1 || nKeyFrames > 16 || N < 1 || nMapPts < 1) {
+        cs_set_error("cs_ba_window_create: need 1..16 cameras, 1..16 key frames, N >= 1, nMapPts >= 1");
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        cs_set_error("cs_ba_window_create: no usable HIP device %d", device);
+        return nullptr;
+    }
+    cs_ba_window* w = new cs_ba_window();
+    memset(w, 0, sizeof(*w));
+    w->device = device, w->nCams = nCams, w->nKf = nKeyFrames, w->N = N, w->nMap = nMapPts;
+    const size_t KC = (size_t)nKeyFrames * nCams, nPairs = KC * (KC + 1) / 2;
+    struct Piece {
+        void** ptr;
+        size_t bytes;
+    };
+    const Piece pieces[] = {
+        {(void**)&w->xy, sizeof(double) * KC * 2 * N}, {(void**)&w->K, sizeof(double) * KC * 9},
+        {(void**)&w->R, sizeof(double) * KC * 9},      {(void**)&w->t, sizeof(double) * KC * 3},
+        {(void**)&w->pf, sizeof(int) * KC * nMapPts},  {(void**)&w->cnt, sizeof(int) * nMapPts},
+        {(void**)&w->ptIndex, sizeof(int) * nMapPts},  {(void**)&w->obsStart, sizeof(int) * nMapPts},
+        {(void**)&w->totals, sizeof(int) * 8},         {(void**)&w->pointMap, sizeof(int) * nMapPts},
+        {(void**)&w->pairCnt, sizeof(int) * (nPairs + 1)}, {(void**)&w->pairTotal, sizeof(int) * 8},
+    };
+    size_t total = 0;
+    for (const Piece& q : pieces) total += (q.bytes + 255) & ~(size_t)255;
+    if (hipMalloc((void**)&w->slab, total) != hipSuccess || hipHostMalloc((void**)&w->h_totals, 8 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        cs_set_error("cs_ba_window_create: cannot allocate %zu MB", total >> 20);
+        if (w->slab) (void)hipFree(w->slab);
+        delete w;
+        return nullptr;
+    }
+    size_t off = 0;
+    for (const Piece& q : pieces) {
+        *q.ptr = w->slab + off;
+        off += (q.bytes + 255) & ~(size_t)255;
+    }
+    return w;
+}
+
+void cs_ba_window_destroy(cs_ba_window* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(w->slab);
+    (void)hipHostFree(w->h_totals);
+    delete w;
+}
+
+// A key frame into the ring (asynchronous on hip_stream): of every camera the hand-back's records of THIS frame -- xy, state,
+// slot2map of cams[c] (the cs_handback_cam the hand-back was called with) -- and K, R, t (d_K: nCams x 9 or ONE 9 shared,
+// d_R: nCams x 9, d_t: nCams x 3: the poses just solved).  The oldest key frame is overwritten when the ring is full.
+int cs_ba_window_push_dev(cs_ba_window* w, void* hip_stream, const cs_handback_cam* cams, const double* d_K, int kShared,
+                          const double* d_R, const double* d_t, int frame) {
+    if (!w || !cams || !d_K || !d_R || !d_t) {
+        cs_set_error("cs_ba_window_push_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(w->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int slot = w->head;
+    const size_t base = (size_t)slot * w->nCams;
+    WinSnapArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = w->nCams, A.N = w->N, A.nMap = w->nMap;
+    for (int c = 0; c < w->nCams; ++c) {
+        if (!cams[c].xy || !cams[c].state || !cams[c].slot2map) {
+            cs_set_error("cs_ba_window_push_dev: camera %d has no hand-back records", c);
+            return CS_ERR_INVALID;
+        }
+        A.xy[c] = cams[c].xy, A.state[c] = cams[c].state, A.slot2map[c] = cams[c].slot2map;
+    }
+    A.xyOut = w->xy + base * 2 * w->N;
+    A.pfOut = w->pf + base * w->nMap;
+    CS_HIP(hipMemsetAsync(A.pfOut, 0xff, sizeof(int) * (size_t)w->nCams * w->nMap, s));
+    hipLaunchKernelGGL(k_win_snapshot, dim3((w->N + 255) / 256, w->nCams), dim3(256), 0, s, A);
+    CS_CHECK_LAUNCH();
+    if (kShared) {
+        for (int c = 0; c < w->nCams; ++c)
+            CS_HIP(hipMemcpyAsync(w->K + (base + c) * 9, d_K, 72, hipMemcpyDeviceToDevice, s));
+    } else {
+        CS_HIP(hipMemcpyAsync(w->K + base * 9, d_K, 72 * (size_t)w->nCams, hipMemcpyDeviceToDevice, s));
+    }
+    CS_HIP(hipMemcpyAsync(w->R + base * 9, d_R, 72 * (size_t)w->nCams, hipMemcpyDeviceToDevice, s));
+    CS_HIP(hipMemcpyAsync(w->t + base * 3, d_t, 24 * (size_t)w->nCams, hipMemcpyDeviceToDevice, s));
+    w->frameOf[slot] = frame;
+    w->head = (slot + 1) % w->nKf;
+    if (w->count < w->nKf) w->count += 1;
+    return CS_OK;
+}
+
+// bundleAdjustRobust on the window the way RobustBundleRTS::run does it (reference src/app/SL_CoSLAMRobustBA.cpp:170-180): the
+// flat problem is parsed on the device from the ring and the map (d_mapPts: nMapPts x 3; d_mapStatic: nMapPts flags or NULL =
+// every mapped point is static), then solved in workspace b on its worker thread, started when the work enqueued on
+// after_stream so far (the push of the newest key frame) is done.  The result stays in the workspace (cs_ba_result_buffers /
+// cs_ba_download with cs_ba_window_last_problem's sizes); cs_ba_wait / cs_ba_download report errors.
+int cs_ba_solve_window_async(cs_ba* b, cs_ba_window* w, void* after_stream, const double* d_mapPts, const unsigned char* d_mapStatic,
+                             int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter) {
+    if (!b || !w || !d_mapPts || nCamsCon < 0 || nPtsCon < 0 || maxIter < 0 || innerMaxIter < 0 || b->device != w->device) {
+        cs_set_error("cs_ba_solve_window_async: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(b->device));
+    if (!b->worker) {
+        BaWorker* wk = new BaWorker();
+        if (hipHostMalloc((void**)&wk->h_state, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+            delete wk;
+            cs_set_error("cs_ba_solve_window_async: cannot allocate the pinned state word");
+            return CS_ERR_ALLOC;
+        }
+        wk->h_state[0] = wk->h_state[1] = 0;
+        b->worker = wk;
+        wk->th = std::thread(ba_worker_main, b, wk);
+    }
+    BaAsyncJob J;
+    J.C = J.P = J.nObs = 0;
+    J.nCamsCon = nCamsCon, J.nPtsCon = nPtsCon, J.maxIter = maxIter, J.innerMaxIter = innerMaxIter, J.maxErr = maxErr;
+    J.R0 = J.T0 = J.M0 = nullptr;
+    J.win = w, J.d_map = d_mapPts, J.d_mapStatic = d_mapStatic;
+    CS_HIP(hipEventCreateWithFlags(&J.ready, hipEventDisableTiming));
+    CS_HIP(hipEventRecord(J.ready, (hipStream_t)after_stream));
+    {
+        std::lock_guard<std::mutex> lk(b->worker->mu);
+        b->worker->q.push_back(J);
+        b->worker->inflight += 1;
+    }
+    b->worker->cv.notify_one();
+    return CS_OK;
+}
+
+// Size and bind the workspace for the largest problem the window can produce NOW (cs_ba_solve_window_async does it on first
+// use): afterwards cs_ba_result_buffers' addresses stay valid across the window's solves -- what a follow-up record
+// (cs_posegraph_after_ba_rec) needs before the first solve has run.
+int cs_ba_reserve_for_window(cs_ba* b, cs_ba_window* w) {
+    if (!b || !w || b->device != w->device) {
+        cs_set_error("cs_ba_reserve_for_window: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    const int wrc = cs_ba_wait(b);
+    if (wrc) return wrc;
+    CS_HIP(hipSetDevice(b->device));
+    ba_drop_graph(b);
+    const int rc = ba_reserve(b, w->nKf * w->nCams, w->nMap, w->nKf * w->nCams * w->N);
+    if (rc) return rc;
+    ba_bind_io(b, b->capC, b->capP, b->capObs);
+    return CS_OK;
+}
+
+// sizes of the problem the last cs_ba_solve_window_async of this window built, the map index of every point (device, P ints:
+// RobustBundleRTS::int2MapPt) and the frame number of every key frame (host, oldest first).  Call after cs_ba_wait.
+int cs_ba_window_last_problem(cs_ba_window* w, int* C, int* P, int* nObs, const int** d_pointMap, int* keyFrames /* [nKeyFrames] or NULL */) {
+    if (!w) return CS_ERR_INVALID;
+    if (C) *C = w->lastC;
+    if (P) *P = w->lastP;
+    if (nObs) *nObs = w->lastObs;
+    if (d_pointMap) *d_pointMap = w->pointMap;
+    if (keyFrames)
+        for (int j = 0; j < w->count; ++j) keyFrames[j] = w->frameOf[(w->head - w->count + j + 2 * w->nKf) % w->nKf];
+    return CS_OK;
+}
+
+// device addresses of the flat problem in the workspace (what parseInputs produced / cs_ba_upload stored): Ks [C][9],
+// obs_ptr [P + 1], obs_cam [nObs], obs_xy [nObs][2]
+int cs_ba_problem_buffers(cs_ba* b, const double** d_Ks, const int** d_obs_ptr, const int** d_obs_cam, const double** d_obs_xy) {
+    if (!b || !b->Ks) {
+        cs_set_error("cs_ba_problem_buffers: workspace holds no problem");
+        return CS_ERR_INVALID;
+    }
+    if (d_Ks) *d_Ks = b->Ks;
+    if (d_obs_ptr) *d_obs_ptr = b->obs_ptr;
+    if (d_obs_cam) *d_obs_cam = b->obs_cam;
+    if (d_obs_xy) *d_obs_xy = b->obs_xy;
     return CS_OK;
 }
 

@@ -487,6 +487,28 @@ int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const do
 int cs_ba_solve_async(cs_ba* b, void* after_stream, int C, int P, int nObs, const double* d_Rs0, const double* d_Ts0,
                       const double* d_pts0, int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter);
 int cs_ba_wait(cs_ba* b);
+/* The bundle adjuster's inputs built ON THE DEVICE from the tracker's own records: RobustBundleRTS::addKeyFrames / addPoints /
+ * parseInputs (src/app/SL_CoSLAMRobustBA.cpp:37-78,109-165) fed by CoSLAM::requestForBA's walk over the last key frames
+ * (src/app/SL_CoSLAM.cpp:1731-1784).  A window is a ring of nKeyFrames key frames x nCams cameras: per key frame and camera the
+ * hand-back's records of that frame (undistorted pixels, which slot carries which map point) and K, R, t.  Cameras of the
+ * problem: key frame (oldest first) x nCams + camera; points: every (static) map point with more than one feature point in the
+ * window, in map-index order; measurements of a point in camera order -- the flattening parseInputs produces (pinned against
+ * the reference's own parseInputs in tests/cxx/ref_ba_dropin_test.cpp).  The solve runs on the workspace's worker thread like
+ * cs_ba_solve_async; the estimate it starts from is the key poses as pushed and the map as it stands. */
+typedef struct cs_ba_window cs_ba_window;
+cs_ba_window* cs_ba_window_create(int device, int nCams, int nKeyFrames, int N, int nMapPts);
+void cs_ba_window_destroy(cs_ba_window* w);
+/* cams: HOST array of nCams records whose xy / state / slot2map (device) are the hand-back's output of this frame;
+ * d_K: nCams x 9, or one 9 shared by all cameras (kShared != 0); d_R nCams x 9, d_t nCams x 3.  Asynchronous on hip_stream. */
+int cs_ba_window_push_dev(cs_ba_window* w, void* hip_stream, const cs_handback_cam* cams, const double* d_K, int kShared,
+                          const double* d_R, const double* d_t, int frame);
+int cs_ba_solve_window_async(cs_ba* b, cs_ba_window* w, void* after_stream, const double* d_mapPts, const unsigned char* d_mapStatic,
+                             int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter);
+/* size and bind workspace b for the largest problem w can produce (cs_ba_solve_window_async does it on first use); afterwards
+ * cs_ba_result_buffers' addresses stay put across the window's solves -- a follow-up record can be built before the first */
+int cs_ba_reserve_for_window(cs_ba* b, cs_ba_window* w);
+int cs_ba_window_last_problem(cs_ba_window* w, int* C, int* P, int* nObs, const int** d_pointMap, int* keyFrames);
+int cs_ba_problem_buffers(cs_ba* b, const double** d_Ks, const int** d_obs_ptr, const int** d_obs_cam, const double** d_obs_xy);
 /* Work that belongs right behind every solve of this workspace, on the solve's own stream and without a host round trip:
  * `fn(stream, user)` is called (from cs_ba_solve_dev's caller thread, or from the workspace's worker thread for
  * cs_ba_solve_async) once the solve's last kernel is enqueued; it enqueues more work on `stream` and returns CS_OK.  This is

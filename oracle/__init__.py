@@ -514,3 +514,44 @@ def ba_residual(K, R, t, M, m, jac=True):
                         m.ctypes.data_as(vp), e.ctypes.data_as(vp), Jc.ctypes.data_as(vp) if jac else None,
                         Jp.ctypes.data_as(vp) if jac else None)
     return bool(ok), e, Jc.reshape(2, 6), Jp.reshape(2, 3)
+
+
+def parse_inputs_window(key_frames, map_pts, map_static=None):
+    """RobustBundleRTS::addKeyFrames + addPoints + parseInputs (reference src/app/SL_CoSLAMRobustBA.cpp:37-78,109-165) restated
+    over structure-of-arrays key-frame records (numpy; test infrastructure).  key_frames: oldest first, each a list over the
+    cameras of dicts(xy float64[2N] (x[N] then y[N]), state int[N], slot2map int[N], K[9], R[9], t[3]).  A feature point is a
+    slot with state 0 / 1 whose slot2map names a (static) map point; FeaturePoints lists are in slot order
+    (GPUKLT::addToFeaturePoints), so for one (key frame, camera) a later slot of the same map point replaces an earlier one
+    (vecFeatPts[camId] = fpt, :141) -- but BOTH count towards `nfpts > 1` (:120-121: the size of the point's list)...
+    except that CoSLAM never maps two features of one frame and camera to one map point (MapPoint::pFeatures[camId] is one
+    pointer); the device path counts a (key frame, camera) once, and so does this restatement.
+    Returns dict(Ks, Rs, Ts, pts, obs_ptr, obs_cam, obs_xy, point_map)."""
+    n_cams = len(key_frames[0])
+    n_map = len(map_pts)
+    cams = [(j, c) for j in range(len(key_frames)) for c in range(n_cams)]          # addKeyFrames: key frame x camera
+    feat = np.full((len(cams), n_map), -1, dtype=np.int64)                          # (camera index, map point) -> slot
+    for ci, (j, c) in enumerate(cams):
+        rec = key_frames[j][c]
+        for s_ in range(len(rec["state"])):                                         # list order = slot order: the last one stays
+            m = int(rec["slot2map"][s_])
+            if rec["state"][s_] in (0, 1) and 0 <= m < n_map and (map_static is None or map_static[m]):
+                feat[ci, m] = s_
+    Ks = np.stack([np.asarray(key_frames[j][c]["K"], float).reshape(9) for j, c in cams])
+    Rs = np.stack([np.asarray(key_frames[j][c]["R"], float).reshape(9) for j, c in cams])
+    Ts = np.stack([np.asarray(key_frames[j][c]["t"], float).reshape(3) for j, c in cams])
+    pts, ptr, ocam, oxy, pmap = [], [0], [], [], []
+    for m in range(n_map):                                                          # std::map<MapPoint*, ...>: address = index order
+        seen = np.nonzero(feat[:, m] >= 0)[0]
+        if len(seen) <= 1:                                                          # nfpts > 1 (:120-121)
+            continue
+        pts.append(map_pts[m])
+        pmap.append(m)
+        for ci in seen:                                                             # camera order (:146-151)
+            j, c = cams[ci]
+            rec, s_ = key_frames[j][c], int(feat[ci, m])
+            n = len(rec["state"])
+            ocam.append(ci)
+            oxy.append((rec["xy"][s_], rec["xy"][n + s_]))
+        ptr.append(len(ocam))
+    return dict(Ks=Ks, Rs=Rs, Ts=Ts, pts=np.asarray(pts, float).reshape(-1, 3), obs_ptr=np.asarray(ptr, np.int32),
+                obs_cam=np.asarray(ocam, np.int32), obs_xy=np.asarray(oxy, float).reshape(-1, 2), point_map=np.asarray(pmap, np.int32))

@@ -468,3 +468,88 @@ def test_ba_rejects_malformed_problems(hip):
     dup[ptr[3] + 1] = dup[ptr[3]]
     with pytest.raises(coslam_amd.CoslamHipError):
         call(cam_=dup)
+
+
+def test_ba_window_parses_the_problem_on_the_device_and_solves_it(hip):
+    """cs_ba_window_* + cs_ba_solve_window_async: RobustBundleRTS::addKeyFrames / addPoints / parseInputs (reference
+    src/app/SL_CoSLAMRobustBA.cpp:37-78,109-165) on the device.  Seven key frames pushed into a ring of five (the two oldest
+    drop out), records with unmapped, dead, dropped and doubled slots; the flat problem the device builds must equal the
+    numpy restatement array for array (cameras, kept points in map order, measurements in camera order, the map indices), and
+    its robust solve the oracle's on that flat problem (flags, iteration counts, 1e-6)."""
+    import torch
+
+    from coslam_amd.handback import handback_cams
+    from coslam_amd.multicam import _DevArray
+
+    rng = np.random.default_rng(77)
+    n_cams, n_kf, n_push, N, n_map = 3, 5, 7, 320, 400
+    C_all = n_push * n_cams
+    pr = make_ba_problem(n_cams=C_all, n_pts=n_map, visibility=0.5, noise=0.4, outlier_frac=0.03, n_cams_con=2 * n_cams, n_pts_con=2, seed=21)
+    dev = torch.device("cuda:0")
+    obs_by_cam = [[] for _ in range(C_all)]
+    for o in range(len(pr["obs_cam"])):
+        obs_by_cam[int(pr["obs_cam"][o])].append(o)
+    key_frames, keep = [], []
+    for j in range(n_push):
+        recs = []
+        for c in range(n_cams):
+            ci = j * n_cams + c
+            xy, state, s2m = np.zeros(2 * N), np.full(N, -1, np.int32), np.full(N, -1, np.int32)
+            slots = rng.permutation(N)
+            k = 0
+            for o in obs_by_cam[ci][: N - 60]:
+                m = int(pr["obs_pt"][o])
+                s_ = int(slots[k]); k += 1
+                state[s_], s2m[s_] = int(rng.integers(0, 2)), m
+                xy[s_], xy[N + s_] = pr["obs_xy"][o]
+            for q in range(20):                 # unmapped features, dead slots that still name a map point, dropped ones
+                s_ = int(slots[k]); k += 1
+                state[s_], s2m[s_] = [(0, -1), (-1, int(rng.integers(0, n_map))), (-2, int(rng.integers(0, n_map)))][q % 3]
+                xy[s_], xy[N + s_] = rng.uniform(0, 640), rng.uniform(0, 480)
+            # a doubled map point: an EARLIER slot of the same point with a wrong pixel must lose against the later one
+            mapped = np.nonzero((state >= 0) & (s2m >= 0))[0]
+            for s_late in mapped[mapped > 40][:3]:
+                free = [q for q in range(int(s_late)) if state[q] == -1 and s2m[q] == -1]
+                if free:
+                    state[free[0]], s2m[free[0]] = 0, s2m[s_late]
+                    xy[free[0]], xy[N + free[0]] = 1.0, 2.0
+            recs.append(dict(xy=xy, state=state, slot2map=s2m, K=pr["Ks"][ci].reshape(9), R=pr["Rs0"][ci].reshape(9), t=pr["ts0"][ci]))
+        key_frames.append(recs)
+    win = coslam_amd.BAWindow(n_cams, n_kf, N, n_map)
+    ws = coslam_amd.BAWorkspace(0)
+    d_map = torch.from_numpy(pr["pts0"].copy()).to(dev)
+    s = torch.cuda.Stream(device=dev)
+    for j in range(n_push):
+        t_xy = [torch.from_numpy(r["xy"]).to(dev) for r in key_frames[j]]
+        t_st = [torch.from_numpy(r["state"]).to(dev) for r in key_frames[j]]
+        t_sm = [torch.from_numpy(r["slot2map"]).to(dev) for r in key_frames[j]]
+        hb = handback_cams([dict(xy=t_xy[c].data_ptr(), state=t_st[c].data_ptr(), slot2map=t_sm[c].data_ptr()) for c in range(n_cams)])
+        d_K = torch.from_numpy(np.stack([r["K"] for r in key_frames[j]])).to(dev)
+        d_R = torch.from_numpy(np.stack([r["R"] for r in key_frames[j]])).to(dev)
+        d_t = torch.from_numpy(np.stack([r["t"] for r in key_frames[j]])).to(dev)
+        win.push_dev(s.cuda_stream, hb, d_K.data_ptr(), 0, d_R.data_ptr(), d_t.data_ptr(), 5 * j)
+        s.synchronize()
+        keep.append((t_xy, t_st, t_sm, d_K, d_R, d_t))
+    ref = oracle.parse_inputs_window(key_frames[n_push - n_kf:], pr["pts0"])
+    ncon, npcon = 2 * n_cams, 2
+    win.solve_async(ws, s.cuda_stream, d_map.data_ptr(), ncon, npcon, 6.0, 2, 10)
+    ws.wait()
+    Cw, Pw, Ow, pm_ptr, kfs = win.last_problem()
+    assert (Cw, Pw, Ow) == (n_kf * n_cams, len(ref["pts"]), len(ref["obs_cam"])) and Pw > 150 and kfs == [5 * j for j in range(2, 7)]
+    view = lambda ptr, n, ty: torch.as_tensor(_DevArray(ptr, n, ty), device=dev).cpu().numpy()   # noqa: E731
+    pK, pptr, pcam, pxy = ws.problem_buffers()
+    assert np.array_equal(view(pptr, Pw + 1, "<i4"), ref["obs_ptr"])
+    assert np.array_equal(view(pcam, Ow, "<i4"), ref["obs_cam"])
+    assert np.array_equal(view(pxy, 2 * Ow, "<f8").reshape(-1, 2), ref["obs_xy"])
+    assert np.array_equal(view(pK, 9 * Cw, "<f8").reshape(-1, 9), ref["Ks"])
+    assert np.array_equal(view(pm_ptr, Pw, "<i4"), ref["point_map"])
+    ws.set_sizes(Cw, Pw, Ow)
+    R, T, M, out, st = ws.download()
+    R_o, T_o, M_o, out_o, st_o = oracle.ba_robust(ref["Ks"].reshape(-1, 3, 3), ref["Rs"].reshape(-1, 3, 3), ref["Ts"], ref["pts"], ref["obs_ptr"],
+                                                  ref["obs_cam"], ref["obs_xy"], ncon, npcon, 6.0, 2, 10)
+    assert np.array_equal(out, out_o) and st.nIterTotal == st_o.nIterTotal and st.nOuter == st_o.nOuter and st.flags == 0
+    sane = np.linalg.norm(M_o, axis=1) < 1e3
+    assert np.max(np.abs(R - R_o)) < 1e-6 and np.max(np.abs(T - T_o)) < 1e-6 and np.max(np.abs(M[sane] - M_o[sane])) < 1e-6
+    assert abs(st.cost - st_o.cost) <= 1e-7 * max(1.0, st_o.cost) and st.cost < 0.2 * st.cost0
+    win.close()
+    ws.close()
