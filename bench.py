@@ -1077,7 +1077,8 @@ def main():
             with tempfile.TemporaryDirectory() as td:
                 wl = os.path.join(td, "workload.bin")
                 export_workload(wl, sc, frames, joint, ic, args.klt_cams_per_launch)
-                pr = subprocess.run([exe, wl, str(args.steps), str(args.warmup)], capture_output=True, text=True, timeout=600)
+                pr = subprocess.run([exe, wl, str(args.steps), str(args.warmup), str(args.klt_cams_per_launch),
+                                     "1" if ba_win is not None else "0"], capture_output=True, text=True, timeout=600)
             if pr.returncode == 0 and pr.stdout.strip().startswith("{"):
                 cxx = json.loads(pr.stdout.strip().splitlines()[-1])
                 cxx["what"] = ("tools/cxx/frame_loop.cpp: the headline loop from C++ through include/coslam_hip.h only (no Python, no "

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_ncc_blocks(const unsigned char* __restr
 // cv::getRectSubPix(small, 11 x 11, (x scale, y scale)) [8u -> 8u] and A, B, C.  OpenCV is not in this image: both functions
 // are the published generic C++ paths restated (imgproc/src/resize.cpp: 11-bit coefficients, the (b (S >> 4)) >> 16 vertical
 // pass; imgproc/src/samplers.cpp getRectSubPix_Cn_ + adjustRect: 16-bit fixed-point bilinear weights, replicated border) --
-// integer arithmetic behind float weights, so the kernels are bit-exact against oracle/ncc_oracle.c (parity unpinned there).
+// integer arithmetic behind float weights, so the kernels are bit-exact against the CPU restatement the tests hold (which is itself unpinned: no OpenCV here).
 __device__ __forceinline__ int nc_floorf(float v) {
     const int i = (int)v;
     return i - (i > v);

@@ -124,6 +124,9 @@ static int test_robust_bundle_rts() {
     RobustBundleRTS ba;
     for (int j = 0; j < C; ++j) ba.addKeyCamera(K, &cams[j]);
     std::vector<FeaturePoint*> fps;
+    std::vector<int> fpMap;   // map-point index of every feature point
+    std::vector<double> R0all(9 * (size_t)C), t0all(3 * (size_t)C);   // the poses the key cameras start from
+    for (int j = 0; j < C; ++j) memcpy(&R0all[9 * j], cams[j].R, 72), memcpy(&t0all[3 * j], cams[j].t, 24);
     std::vector<int> nMeas(P, 0);
     for (int i = 0; i < P; ++i)
         for (int j = 0; j < C; ++j) {
@@ -135,6 +138,7 @@ static int test_robust_bundle_rts() {
             FeaturePoint* fp = new FeaturePoint(cams[j].f, cams[j].camId, m[0], m[1]);
             fp->camId = cams[j].camId;
             fps.push_back(fp);
+            fpMap.push_back(i);
             ba.addCorrespondingPoint(&mpts[i], fp);
             nMeas[i]++;
         }
@@ -187,6 +191,98 @@ static int test_robust_bundle_rts() {
     CHECK(dR == 0 && dM == 0);   // the reference's caller over the shim == the direct C-ABI call, bit for bit
     CHECK(nOut > 20 && st.nOutliers == nOut);
     CHECK(eT < 0.02);            // and the poses are recovered
+    // ---- (1b) the same key frames through the DEVICE-side parseInputs (cs_ba_window_*): every feature point becomes a slot of
+    // its (key frame, camera) record -- slot order = the order the feature points were created in, i.e. FeaturePoints list order
+    // -- with slot2map = the map point's index; the flat problem the device builds must be the one the reference's parseInputs
+    // built (ba.pt3Ds / ba.meas2Ds above: same points in the same order, same Meas2D lists), and the solve behind it must land
+    // where the reference's caller landed.
+    {
+        const int Nslots = 512;
+        cs_ba_window* win = cs_ba_window_create(0, nc, nkf, Nslots, P);
+        CHECK(win != nullptr);
+        std::vector<double> hMap(3 * (size_t)P);
+        for (int i = 0; i < P; ++i) hMap[3 * i] = mpts[i].x, hMap[3 * i + 1] = mpts[i].y, hMap[3 * i + 2] = mpts[i].z;
+        // (mpts still hold the INITIAL estimate: RobustBundleRTS::run does not write back, output() would)
+        double* dMap = nullptr;
+        hipMalloc((void**)&dMap, sizeof(double) * 3 * P);
+        hipMemcpy(dMap, hMap.data(), sizeof(double) * 3 * P, hipMemcpyHostToDevice);
+        std::vector<void*> keep;
+        for (int kf = 0; kf < nkf; ++kf) {
+            std::vector<cs_handback_cam> hb(nc);
+            std::vector<double> Kc, Rc, tc;
+            for (int c = 0; c < nc; ++c) {
+                const int j = kf * nc + c;
+                std::vector<double> xy(2 * Nslots, 0.0);
+                std::vector<int> state(Nslots, -1), s2m(Nslots, -1);
+                int slot = 0;
+                for (size_t q = 0; q < fps.size(); ++q) {   // creation order == the order addCorrespondingPoint saw them
+                    if (fps[q]->f != cams[j].f || fps[q]->camId != cams[j].camId) continue;
+                    CHECK(slot < Nslots);
+                    xy[slot] = fps[q]->x, xy[Nslots + slot] = fps[q]->y;
+                    state[slot] = 0;
+                    s2m[slot] = fpMap[q];
+                    ++slot;
+                }
+                double* dxy; int *dst, *dsm;
+                hipMalloc((void**)&dxy, sizeof(double) * 2 * Nslots), hipMalloc((void**)&dst, sizeof(int) * Nslots), hipMalloc((void**)&dsm, sizeof(int) * Nslots);
+                hipMemcpy(dxy, xy.data(), sizeof(double) * 2 * Nslots, hipMemcpyHostToDevice);
+                hipMemcpy(dst, state.data(), sizeof(int) * Nslots, hipMemcpyHostToDevice);
+                hipMemcpy(dsm, s2m.data(), sizeof(int) * Nslots, hipMemcpyHostToDevice);
+                keep.push_back(dxy), keep.push_back(dst), keep.push_back(dsm);
+                memset(&hb[c], 0, sizeof(hb[c]));
+                hb[c].xy = dxy, hb[c].state = dst, hb[c].slot2map = dsm;
+                Kc.insert(Kc.end(), K, K + 9);
+                Rc.insert(Rc.end(), &Rs[9 * j], &Rs[9 * j] + 9);   // (Rs / Ts above: the poses ba was given, untouched by cs_ba_robust? no:
+                tc.insert(tc.end(), &Ts[3 * j], &Ts[3 * j] + 3);   //  cs_ba_robust updated them in place -- take the initial ones below)
+            }
+            for (int c = 0; c < nc; ++c)
+                for (int q = 0; q < 9; ++q) Rc[9 * c + q] = R0all[9 * (kf * nc + c) + q];
+            for (int c = 0; c < nc; ++c)
+                for (int q = 0; q < 3; ++q) tc[3 * c + q] = t0all[3 * (kf * nc + c) + q];
+            double *dK, *dR, *dT;
+            hipMalloc((void**)&dK, 72 * nc), hipMalloc((void**)&dR, 72 * nc), hipMalloc((void**)&dT, 24 * nc);
+            hipMemcpy(dK, Kc.data(), 72 * nc, hipMemcpyHostToDevice);
+            hipMemcpy(dR, Rc.data(), 72 * nc, hipMemcpyHostToDevice);
+            hipMemcpy(dT, tc.data(), 24 * nc, hipMemcpyHostToDevice);
+            keep.push_back(dK), keep.push_back(dR), keep.push_back(dT);
+            CHECK(cs_ba_window_push_dev(win, nullptr, hb.data(), dK, 0, dR, dT, cams[kf * nc].f) == CS_OK);
+            hipDeviceSynchronize();
+        }
+        cs_ba* wb = cs_ba_create(0);
+        CHECK(wb != nullptr);
+        CHECK(cs_ba_solve_window_async(wb, win, nullptr, dMap, nullptr, nc * 2, 2, 6.0, 2, 10) == CS_OK);
+        CHECK(cs_ba_wait(wb) == CS_OK);
+        int wC = 0, wP = 0, wO = 0;
+        const int* dPm = nullptr;
+        CHECK(cs_ba_window_last_problem(win, &wC, &wP, &wO, &dPm, nullptr) == CS_OK);
+        CHECK(wC == C && wP == Pk && wO == nObs);   // the reference's parseInputs kept the same points and measurements
+        const double* dKs; const int *dPtr, *dCam; const double* dXy;
+        CHECK(cs_ba_problem_buffers(wb, &dKs, &dPtr, &dCam, &dXy) == CS_OK);
+        std::vector<int> gPtr(wP + 1), gCam(wO), gPm(wP);
+        std::vector<double> gXy(2 * (size_t)wO);
+        hipMemcpy(gPtr.data(), dPtr, sizeof(int) * (wP + 1), hipMemcpyDeviceToHost);
+        hipMemcpy(gCam.data(), dCam, sizeof(int) * wO, hipMemcpyDeviceToHost);
+        hipMemcpy(gXy.data(), dXy, sizeof(double) * 2 * wO, hipMemcpyDeviceToHost);
+        hipMemcpy(gPm.data(), dPm, sizeof(int) * wP, hipMemcpyDeviceToHost);
+        CHECK(gPtr == ptr && gCam == cam && gXy == xy);                                   // meas2Ds, list for list
+        for (int i = 0; i < wP; ++i) CHECK(ba.mapPoints[i] == &mpts[gPm[i]]);            // int2MapPt
+        std::vector<double> wR(9 * (size_t)C), wT(3 * (size_t)C), wM(3 * (size_t)wP);
+        std::vector<int> wOut(wO);
+        cs_ba_stats wst;
+        CHECK(cs_ba_download(wb, C, wP, wO, wR.data(), wT.data(), wM.data(), wOut.data(), &wst) == CS_OK);
+        double dd = 0;
+        for (int q = 0; q < 9 * C; ++q) dd = fmax(dd, fabs(wR[q] - Rs[q]));
+        for (int q = 0; q < 3 * C; ++q) dd = fmax(dd, fabs(wT[q] - Ts[q]));
+        for (int q = 0; q < 3 * wP; ++q) dd = fmax(dd, fabs(wM[q] - pts[q]));
+        CHECK(wOut == outl);
+        CHECK(dd < 1e-8);   // (same problem, same estimate; the device-built lane plan may order the sums differently)
+        printf("device-side parseInputs ok: %d cameras, %d points, %d measurements identical to the reference's parseInputs; "
+               "solve |d| = %.2e vs the reference's caller\n", wC, wP, wO, dd);
+        cs_ba_destroy(wb);
+        cs_ba_window_destroy(win);
+        for (void* q : keep) hipFree(q);
+        hipFree(dMap);
+    }
     for (size_t i = 0; i < fps.size(); ++i) delete fps[i];
     printf("RobustBundleRTS drop-in ok: C=%d (%d fixed), %d of %d points kept by parseInputs, %d measurements, %d outliers, "
            "|t - truth| <= %.4f\n", C, nc * 2, Pk, P, nObs, nOut, eT);

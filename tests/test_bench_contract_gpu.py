@@ -36,7 +36,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys(hip):
     cx = cfg["cxx_frame_loop"]
     assert "error" not in cx, cx
     assert cx["pose_ok"] is True and cx["min_live_features"] > 1500 and cx["steps"] == 10
-    assert cx["joint_lm_steps"] == cfg["joint_ba_last"]["lm_steps"] and abs(cx["joint_cost"] - cfg["joint_ba_last"]["cost"]) < 1e-6
+    # the joint BA is data-coupled (parsed on the device from the window's key frames): the C++ loop's last solve is the one of
+    # its last timed key frame, bench.py's the one behind its replays -- the same kind of problem, not the same frames
+    assert cx["joint_ba_from_window"] is True and cx["joint_cameras"] == cfg["joint_ba_problem"]["cameras"] == 40
+    assert 0.9 < cx["joint_measurements"] / cfg["joint_ba_problem"]["measurements"] < 1.1
+    assert cx["joint_lm_steps"] > 0 and 0.8 < cx["joint_cost"] / cfg["joint_ba_last"]["cost"] < 1.25
     assert cx["intercam_lm_steps"] == cfg["intercam_last"]["lm_steps"] and 0.5 < cx["frames_per_s"] / j["value"] < 2.0
     # ... and with every frame's images coming from pinned host memory inside the loop
     up = cfg["with_upload"]

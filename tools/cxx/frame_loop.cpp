@@ -99,11 +99,12 @@ struct BaProblem {
 
 int main(int argc, char** argv) {
     if (argc < 4) {
-        fprintf(stderr, "usage: %s <workload file> <steps> <warmup> [cams per tracker launch]\n", argv[0]);
+        fprintf(stderr, "usage: %s <workload file> <steps> <warmup> [cams per tracker launch] [joint BA from the window: 1 | 0]\n", argv[0]);
         return 1;
     }
     const int steps = atoi(argv[2]), warmup = atoi(argv[3]);
     const int camsPerLaunchArg = argc > 4 ? atoi(argv[4]) : -1;
+    const bool useWindow = argc > 5 ? atoi(argv[5]) != 0 : true;
     Reader rd{fopen(argv[1], "rb")};
     if (!rd.f) {
         perror(argv[1]);
@@ -246,7 +247,21 @@ int main(int argc, char** argv) {
     const std::vector<cs_register_cam> rc[2] = {reg_cams(0), reg_cams(1)};
 
     // ---- key-frame solves: workspaces, pose graphs as the joint BA's follow-up ----
-    joint.upload(dev);
+    // joint local BA: parsed on the device from the ring of the last 5 key frames (cs_ba_window_*: the hand-back's records and
+    // the poses of every camera at the key frame), like bench.py's N = 1 default; `0` as the 5th argument keeps the pre-baked one
+    const int WIN_KF = 5;
+    cs_ba_window* win = nullptr;
+    if (useWindow) {
+        joint.ws = cs_ba_create(dev);
+        win = cs_ba_window_create(dev, nCams, WIN_KF, N, nMap);
+        if (!joint.ws || !win) {
+            fprintf(stderr, "cs_ba_window_create: %s\n", cs_last_error());
+            return 3;
+        }
+        CSCHK(cs_ba_reserve_for_window(joint.ws, win));  // (the result buffers' addresses are final from here on)
+    } else {
+        joint.upload(dev);
+    }
     ic.upload(dev);
     std::vector<int> nodePtr(pgGraphs + 1), edgePtr(pgGraphs + 1), id1, id2;
     for (int g = 0; g <= pgGraphs; ++g) nodePtr[g] = g * pgNodesPer, edgePtr[g] = g * (pgNodesPer - 1);
@@ -318,7 +333,12 @@ int main(int argc, char** argv) {
         HIPCHK(hipEventRecord(destFree[b], poseS));
         if (key) {
             ic.solve_async(poseS);
-            joint.solve_async(poseS);
+            if (win) {  // requestForBA(5, 2, 2, 30): the numCams * 2 oldest key cameras and 2 points held, maxIter 2, inner 10
+                CSCHK(cs_ba_window_push_dev(win, (void*)poseS, hb[b].data(), dK, 1, dR[dsti], dT[dsti], i));
+                CSCHK(cs_ba_solve_window_async(joint.ws, win, (void*)poseS, dMap, nullptr, 2 * nCams, 2, 6.0, 2, 10));
+            } else {
+                joint.solve_async(poseS);
+            }
         }
         // (last on the pose stream: nothing of this frame waits for the matching leg)
         if (nCams >= 2 && i % NCC_EVERY == 0) {
@@ -381,12 +401,15 @@ int main(int argc, char** argv) {
     HIPCHK(hipDeviceSynchronize());
 
     // set-up (one key-frame interval: graph capture in the BA workers, lazy code-object loading), warm-up, timed loop
-    for (int i = 0; i < std::max(keyEvery, 1) + 1; ++i) step(i + 1, keyEvery > 0 && i == 0);
+    // (with the window: 5 key-frame intervals, so that every timed solve has its 5 key frames = 5 x nCams cameras); the frame
+    // sequence runs on through set-up, warm-up and the timed region
+    const int nSetup = (win && keyEvery > 0) ? WIN_KF * keyEvery + 1 : std::max(keyEvery, 1) + 1;
+    for (int i = 0; i < nSetup; ++i) step(i + 1, keyEvery > 0 && i % std::max(keyEvery, 1) == 0);
     barrier();
-    for (int i = 0; i < warmup; ++i) step(i + 1, keyEvery > 0 && i % keyEvery == 0);
+    for (int i = 0; i < warmup; ++i) step(nSetup + i + 1, keyEvery > 0 && i % keyEvery == 0);
     barrier();
     const auto t0c = std::chrono::steady_clock::now();
-    for (int i = 0; i < steps; ++i) step(warmup + i + 1, keyEvery > 0 && i % keyEvery == 0);
+    for (int i = 0; i < steps; ++i) step(nSetup + warmup + i + 1, keyEvery > 0 && i % keyEvery == 0);
     const auto t1c = std::chrono::steady_clock::now();
     barrier();
     const auto t2c = std::chrono::steady_clock::now();
@@ -399,7 +422,7 @@ int main(int argc, char** argv) {
         HIPCHK(hipMemcpy(ok.data(), dOk, sizeof(int) * nCams, hipMemcpyDeviceToHost));
         for (int v : ok) okAll &= (v != 0);
         std::vector<cs_klt_feature> d(N);
-        const int last = (warmup + steps) & 1;
+        const int last = (nSetup + warmup + steps) & 1;
         for (int c = 0; c < nCams; ++c) {
             HIPCHK(hipMemcpy(d.data(), dDest[last][c], sizeof(cs_klt_feature) * N, hipMemcpyDeviceToHost));
             int live = 0;
@@ -408,12 +431,15 @@ int main(int argc, char** argv) {
         }
     }
     cs_ba_stats sj, si;
-    CSCHK(cs_ba_download(joint.ws, joint.C, joint.P, joint.nObs, nullptr, nullptr, nullptr, nullptr, &sj));
+    int jC = joint.C, jP = joint.P, jO = joint.nObs;
+    if (win) CSCHK(cs_ba_window_last_problem(win, &jC, &jP, &jO, nullptr, nullptr));
+    CSCHK(cs_ba_download(joint.ws, jC, jP, jO, nullptr, nullptr, nullptr, nullptr, &sj));
     CSCHK(cs_ba_download(ic.ws, ic.C, ic.P, ic.nObs, nullptr, nullptr, nullptr, nullptr, &si));
     printf("{\"frames_per_s\": %.3f, \"ms_per_step\": %.5f, \"steps\": %d, \"warmup\": %d, \"host_enqueue_ms_per_step\": %.5f, "
            "\"cams_per_tracker_launch\": %d, \"pose_ok\": %s, \"min_live_features\": %d, \"joint_lm_steps\": %d, \"joint_cost\": %.6f, "
-           "\"intercam_lm_steps\": %d, \"intercam_cost\": %.6f, \"ncc_runs\": %d}\n",
+           "\"intercam_lm_steps\": %d, \"intercam_cost\": %.6f, \"ncc_runs\": %d, \"joint_ba_from_window\": %s, \"joint_cameras\": %d, "
+           "\"joint_points\": %d, \"joint_measurements\": %d}\n",
            steps / dt, dt / steps * 1e3, steps, warmup, dtHost / steps * 1e3, camsPerLaunch, okAll ? "true" : "false", minLive,
-           sj.nIterTotal, sj.cost, si.nIterTotal, si.cost, nccRuns);
+           sj.nIterTotal, sj.cost, si.nIterTotal, si.cost, nccRuns, win ? "true" : "false", jC, jP, jO);
     return 0;
 }
