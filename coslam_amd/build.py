@@ -22,6 +22,7 @@ HIP_SOURCES = [
     "pose.hip",
     "handback.hip",
     "register.hip",
+    "poseupdate.hip",
     "ncc.hip",
     "posegraph.hip",
     "results.cpp",

@@ -89,7 +89,9 @@ __global__ __launch_bounds__(1024) void k_handback(HbArgs A) {
         if (C.pointFeat && mp >= 0 && mp < C.nPointFeat && (st == 0 || st == 1)) atomicMax(&C.pointFeat[(size_t)mp * C.pointFeatStride], i);
         if (len > 0) {  // !tk->empty(); candidates are the static ones: here every mapped slot and, when the caller
                         // supplies the classification, every slot it marks static
-            const bool isStatic = (mp >= 0) || (C.isStatic && C.isStatic[i]);
+            // (a track born in this frame has no predecessor to take a type from -- propagateFeatureStates, SL_SingleSLAM.cpp:40-42 --
+            // and keeps the constructor's TYPE_FEATPOINT_STATIC, whatever the slot's previous track left in isStatic[])
+            const bool isStatic = (mp >= 0) || (C.isStatic && (C.isStatic[i] || f1 == A.frame));
             if (isStatic) {
                 const int bx = (int)(x / (double)A.blkW), by = (int)(y / (double)A.blkH);
                 if (bx < A.nColBlk && by < A.nRowBlk && bx >= 0 && by >= 0) {

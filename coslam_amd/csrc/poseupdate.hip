@@ -1,0 +1,467 @@
+// poseupdate.hip -- what a frame does with the cameras' new poses, on the device (second half), gfx950.
+//
+// Replaces, for every camera of a group in ONE launch behind the batched intraCamEstimate:
+//   SingleSLAM::poseUpdate3D, second half   src/app/SL_SingleSLAM.cpp:672-708  per static mapped track node: project,
+//       getProjectionCovMat, mat22Inv, mahaDist2 against 2.0 (6.0 with largeErr); inlier: FeaturePoint::reprojErr = that
+//       distance and seqTriangulate updates the map point and its covariance in place; outlier: reprojErr = the pixel
+//       distance, MapPoint::setUncertain()
+//   SingleSLAM::getStaticMappedTrackNodes   :60-75
+//   SingleSLAM::detectDynamicFeaturePoints  :784-824   per track of length >= minLen whose tail feature is unmapped or on a
+//       certain-dynamic map point: walk the track backwards, count the past positions whose epipolar error against the current
+//       one (F from the two frames' poses) is >= maxEpiErr; more than minOutNum -> TYPE_FEATPOINT_DYNAMIC, else an unmapped
+//       feature -> TYPE_FEATPOINT_STATIC
+//   SingleSLAM::getUnMappedAndDynamicTrackNodes :91-105
+//   the type / reprojErr hand-down of propagateFeatureStates (:40-42, :54) = the persistence of the two per-slot arrays.
+// The reference walks pointer lists (Track2DNode -> FeaturePoint -> MapPoint / CamPoseItem, FeaturePoint::preFrame) per camera
+// on one host core.  Here:
+//   gate role      one LANE PER MAP POINT walks the point's features over the cameras IN CAMERA ORDER (the hand-back's
+//                  pointFeat table: MapPoint::pFeatures[iCam] of this frame): CoSLAM::parallelPoseUpdate runs the cameras one
+//                  after the other (src/app/SL_CoSLAM.cpp:398-410), so a point seen by several cameras is updated in camera
+//                  order and a point one camera made uncertain is no node of the next -- the lane reproduces exactly that,
+//                  with the point and its covariance in registers between the cameras.  (One feature per camera and point, as
+//                  MapPoint::pFeatures[iCam] holds one; of two slots carrying the same point the higher one counts.)
+//   dynamic role   one lane per (camera, slot).  The track's past positions come from a ring of the last H frames' hand-back
+//                  pixels (cs_track_history), the fundamental matrices from the ring of the camera's poses: F_j of "j frames
+//                  back" is computed once per workgroup into LDS (formEMat + getFMat), the walk then costs two coalesced loads
+//                  and ~25 flops a step.  NOTE src/app/SL_SingleSLAM.cpp:799: the reference's loop counter `f` is never
+//                  advanced, so its `f < maxLen` never ends the walk (it runs to the head of the track or until the count
+//                  exceeds minOutNum); maxLen is accepted here and, as there, has no effect -- the walk is bounded by the ring
+//                  depth H instead (choose H >= the longest track that matters; H x nCams x 16 N bytes of HBM).
+// Both roles are workgroups of the same launch (the gate only ever marks STATIC points uncertain, the dynamic role only reads
+// the certain-DYNAMIC bit pattern: no ordering between them is needed).
+// What is NOT identical to the serial reference when all cameras' poses come from ONE batched intraCamEstimate launch: camera c
+// > 0 estimated its pose from the map as it stood before cameras < c refined it (the reference's own _parallelPoseUpdate,
+// SL_CoSLAM.cpp:390-397, has the same property).  cam0 / nCamsRun let a caller run camera by camera for the serial order.
+//
+// project, getProjectionCovMat, mat22Inv, mahaDist2, dist2, seqTriangulate, formEMat, getFMat, epipolarError are un-vendored
+// LibVisualSLAM (only their calls are in the reference): definitions in DESIGN.md, the same as register.hip / ncc.hip use;
+// seqTriangulate = one Kalman update of (M, cov) from the measurement with noise sigma^2 I.
+#include "cs_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int PU_MAX_CAMS = 16;
+constexpr int PU_MAX_HIST = 512;
+
+struct PuArgs {
+    int nCams, N, nMap, cam0, nCamsRun;
+    int gateBlocks, dynBlocksPerCam;
+    // gate
+    const int* pointFeat;  // [nMap][nCams]
+    const double* R;       // [nCams][9] the new poses
+    const double* t;       // [nCams][3]
+    double* mapPts;
+    double* mapCov;
+    unsigned char* mapFlags;
+    double errThres, sigma;
+    int* numNodes;  // [nCams] or null (zeroed by the caller)
+    int* numOut;
+    // dynamic
+    int H, head, nHist;  // ring depth, ring slot of this frame, frames held (this one included)
+    double* histXY;      // [nCams][H][2N]
+    double* histR;       // [nCams][H][9]
+    double* histT;       // [nCams][H][3]
+    int minLen, minOutNum;
+    double maxEpiErr;
+    int* numDyn;  // [nCams] or null
+    cs_poseupdate_cam cam[PU_MAX_CAMS];
+};
+
+__device__ __forceinline__ void pu_mat22_inv(const double A[4], double iA[4]) {
+    const double det = A[0] * A[3] - A[1] * A[2];
+    iA[0] = A[3] / det;
+    iA[1] = -A[1] / det;
+    iA[2] = -A[2] / det;
+    iA[3] = A[0] / det;
+}
+
+// everything one (camera, point) pair needs of the projection: u, v, w and J = d project / dM
+struct PuProj {
+    double u, v, w, J[6];
+};
+__device__ __forceinline__ PuProj pu_project(const double* __restrict__ K, const double* __restrict__ R, const double* __restrict__ t,
+                                             const double M[3]) {
+    PuProj q;
+    const double X = ((R[0] * M[0] + R[1] * M[1]) + R[2] * M[2]) + t[0];
+    const double Y = ((R[3] * M[0] + R[4] * M[1]) + R[5] * M[2]) + t[1];
+    const double Z = ((R[6] * M[0] + R[7] * M[1]) + R[8] * M[2]) + t[2];
+    double KR[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) KR[3 * i + j] = (K[3 * i] * R[j] + K[3 * i + 1] * R[3 + j]) + K[3 * i + 2] * R[6 + j];
+    q.u = (K[0] * X + K[1] * Y) + K[2] * Z;
+    q.v = (K[3] * X + K[4] * Y) + K[5] * Z;
+    q.w = (K[6] * X + K[7] * Y) + K[8] * Z;
+    const double ww = q.w * q.w;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        q.J[j] = (KR[j] * q.w - q.u * KR[6 + j]) / ww;
+        q.J[3 + j] = (KR[3 + j] * q.w - q.v * KR[6 + j]) / ww;
+    }
+    return q;
+}
+
+__device__ __forceinline__ void pu_gate_point(const PuArgs& A, int m) {
+    unsigned char fl = A.mapFlags[m];
+    if (fl & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) return;  // !isCertainStatic()
+    double M[3], cov[9];
+    bool loaded = false, dirty = false;
+    for (int c = A.cam0; c < A.cam0 + A.nCamsRun; ++c) {
+        const int s = A.pointFeat[(size_t)m * A.nCams + c];
+        if (s < 0) continue;
+        const cs_poseupdate_cam& C = A.cam[c];
+        if (!loaded) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) M[q] = A.mapPts[3 * (size_t)m + q];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) cov[q] = A.mapCov[9 * (size_t)m + q];
+            loaded = true;
+        }
+        const double* K = C.K;
+        const double* R = A.R + 9 * c;
+        const double* t = A.t + 3 * c;
+        const double mx = C.xy[s], my = C.xy[A.N + s];
+        const PuProj q = pu_project(K, R, t, M);
+        const double rm0 = q.u / q.w, rm1 = q.v / q.w;  // project (:678)
+        // getProjectionCovMat (:679): var = J cov J^T + sigma^2 I
+        double JC[6], var[4], ivar[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) JC[3 * i + j] = (q.J[3 * i] * cov[j] + q.J[3 * i + 1] * cov[3 + j]) + q.J[3 * i + 2] * cov[6 + j];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const double sv = (JC[3 * i] * q.J[3 * j] + JC[3 * i + 1] * q.J[3 * j + 1]) + JC[3 * i + 2] * q.J[3 * j + 2];
+                var[2 * i + j] = (i == j) ? sv + A.sigma * A.sigma : sv;
+            }
+        pu_mat22_inv(var, ivar);
+        const double dx = rm0 - mx, dy = rm1 - my;
+        const double err = dx * (ivar[0] * dx + ivar[1] * dy) + dy * (ivar[2] * dx + ivar[3] * dy);  // mahaDist2 (:681)
+        if (A.numNodes) atomicAdd(A.numNodes + c, 1);
+        if (err < A.errThres) {
+            C.reprojErr[s] = err;  // :683
+            // seqTriangulate (:684-685): S = J (cov J^T) + sigma^2 I, G = (cov J^T) S^-1, M += G (m - rm), cov -= G (cov J^T)^T
+            double PJt[6], S[4], iS[4], G[6];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) PJt[2 * r + k] = (cov[3 * r] * q.J[3 * k] + cov[3 * r + 1] * q.J[3 * k + 1]) + cov[3 * r + 2] * q.J[3 * k + 2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const double sv = (q.J[3 * r] * PJt[k] + q.J[3 * r + 1] * PJt[2 + k]) + q.J[3 * r + 2] * PJt[4 + k];
+                    S[2 * r + k] = (r == k) ? sv + A.sigma * A.sigma : sv;
+                }
+            pu_mat22_inv(S, iS);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) G[2 * r + k] = PJt[2 * r] * iS[k] + PJt[2 * r + 1] * iS[2 + k];
+            const double e0 = mx - rm0, e1 = my - rm1;
+            double nc[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) nc[3 * r + k] = cov[3 * r + k] - (G[2 * r] * PJt[2 * k] + G[2 * r + 1] * PJt[2 * k + 1]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) M[r] = M[r] + (G[2 * r] * e0 + G[2 * r + 1] * e1);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) cov[r] = nc[r];
+            dirty = true;
+        } else {
+            if (A.numOut) atomicAdd(A.numOut + c, 1);
+            C.reprojErr[s] = sqrt(dx * dx + dy * dy);  // :701-702 dist2
+            fl |= CS_MAP_UNCERTAIN;                      // :704: no node of the cameras that follow
+            A.mapFlags[m] = fl;
+            break;
+        }
+    }
+    if (dirty) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) A.mapPts[3 * (size_t)m + q] = M[q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) A.mapCov[9 * (size_t)m + q] = cov[q];
+    }
+}
+
+__device__ __forceinline__ void pu_mat33_ab(const double* A, const double* B, double* C) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+// F of (the frame j steps back, this frame): formEMat(R1, t1, R0, t0, E), getFMat(iK, iK, E, F)   (:806-807)
+__device__ __forceinline__ void pu_fmat(const double* __restrict__ iK, const double* __restrict__ R1, const double* __restrict__ t1,
+                                        const double* __restrict__ R0, const double* __restrict__ t0, double* F) {
+    const double R1t[9] = {R1[0], R1[3], R1[6], R1[1], R1[4], R1[7], R1[2], R1[5], R1[8]};
+    double R[9], t[3], E[9], T[9];
+    pu_mat33_ab(R0, R1t, R);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = t0[i] - (R[3 * i] * t1[0] + R[3 * i + 1] * t1[1] + R[3 * i + 2] * t1[2]);
+    const double Tx[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+    pu_mat33_ab(Tx, R, E);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s += iK[3 * k + i] * E[3 * k + j];
+            T[3 * i + j] = s;
+        }
+    pu_mat33_ab(T, iK, F);
+}
+
+__global__ __launch_bounds__(256) void k_pose_update(PuArgs A) {
+    extern __shared__ double Fs[];  // dynamic role: [nHist][9]
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < A.gateBlocks) {
+        const int m = blockIdx.x * 256 + tid;
+        if (m < A.nMap) pu_gate_point(A, m);
+        return;
+    }
+    const int b = blockIdx.x - A.gateBlocks;
+    const int c = A.cam0 + b / A.dynBlocksPerCam, blk = b % A.dynBlocksPerCam;
+    const cs_poseupdate_cam& C = A.cam[c];
+    const int N = A.N, H = A.H;
+    double* hR = A.histR + (size_t)c * H * 9;
+    double* hT = A.histT + (size_t)c * H * 3;
+    double* hXY = A.histXY + (size_t)c * H * 2 * N;
+    const double* R0 = A.R + 9 * c;
+    const double* t0 = A.t + 3 * c;
+    // this frame's pose into the ring (FeaturePoint::cam of this frame's features, updateCamParamForFeatPts :333-344)
+    if (blk == 0 && tid < 12) {
+        if (tid < 9)
+            hR[(size_t)A.head * 9 + tid] = R0[tid];
+        else
+            hT[(size_t)A.head * 3 + (tid - 9)] = t0[tid - 9];
+    }
+    for (int j = tid; j < A.nHist; j += 256) {
+        const int rs = (A.head - j + H) % H;
+        const double* R1 = j ? hR + (size_t)rs * 9 : R0;  // (j = 0: this frame itself, possibly not in the ring yet)
+        const double* t1 = j ? hT + (size_t)rs * 3 : t0;
+        pu_fmat(C.iK, R1, t1, R0, t0, Fs + 9 * j);
+    }
+    __syncthreads();
+    const int i = blk * 256 + tid;
+    if (i >= N) return;
+    const int st = C.state[i];
+    const double m0x = C.xy[i], m0y = C.xy[N + i];
+    hXY[(size_t)A.head * 2 * N + i] = m0x;  // (every slot: a dead slot's entry is never read, its track is empty)
+    hXY[(size_t)A.head * 2 * N + N + i] = m0y;
+    if (!(st == 0 || st == 1)) return;
+    unsigned char type = C.isStatic[i];
+    if (st == 1) type = 1;  // a new FeaturePoint: type(0) = TYPE_FEATPOINT_STATIC (src/slam/SL_FeaturePoint.cpp:23)
+    const int f1 = C.trackSpan[i], f2 = C.trackSpan[N + i];
+    const int len = f1 >= 0 ? f2 - f1 + 1 : 0;
+    const int mp = C.slot2map[i];
+    const bool mapped = mp >= 0 && mp < A.nMap;
+    bool examine = len >= A.minLen;  // :96
+    if (examine && mapped) {
+        const unsigned char fl = A.mapFlags[mp];
+        examine = (fl & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) == CS_MAP_DYNAMIC;  // isCertainDynamic() (:99)
+    }
+    if (examine) {
+        int nOut = 0;
+        const int depth = len < A.nHist ? len : A.nHist;
+        for (int j = 0; j < depth && nOut <= A.minOutNum; ++j) {  // :799 (`f` never advances: maxLen does not bound the walk)
+            double bx = m0x, by = m0y;
+            if (j) {
+                const int rs = (A.head - j + H) % H;
+                bx = hXY[(size_t)rs * 2 * N + i];
+                by = hXY[(size_t)rs * 2 * N + N + i];
+            }
+            const double* F = Fs + 9 * j;
+            // epipolarError(F, m0, m1): distance of m0 from the line F (m1, 1)   (:809)
+            const double l0 = F[0] * bx + F[1] * by + F[2], l1 = F[3] * bx + F[4] * by + F[5], l2 = F[6] * bx + F[7] * by + F[8];
+            const double n = sqrt(l0 * l0 + l1 * l1);
+            const double err = fabs(l0 * m0x + l1 * m0y + l2) / (n > 0 ? n : 1.0);
+            if (err >= A.maxEpiErr) ++nOut;
+        }
+        if (nOut > A.minOutNum) {
+            type = 0;  // TYPE_FEATPOINT_DYNAMIC (:814-816)
+            if (A.numDyn) atomicAdd(A.numDyn + c, 1);
+        } else if (!mapped) {
+            type = 1;  // :817-818
+        }
+    }
+    C.isStatic[i] = type;
+}
+
+}  // namespace
+
+struct cs_track_history {
+    int device, nCams, N, H;
+    int head, count, lastFrame;
+    double *xy, *R, *t;
+};
+
+extern "C" cs_track_history* cs_track_history_create(int device, int nCams, int N, int histLen) {
+    if (nCams < 1 || nCams > PU_MAX_CAMS || N < 1 || histLen < 1 || histLen > PU_MAX_HIST) {
+        cs_set_error("cs_track_history_create: nCams in 1..%d, N >= 1, histLen in 1..%d", PU_MAX_CAMS, PU_MAX_HIST);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        cs_set_error("cs_track_history_create: no usable HIP device %d (there is no CPU fallback)", device);
+        return nullptr;
+    }
+    cs_track_history* h = new cs_track_history();
+    h->device = device, h->nCams = nCams, h->N = N, h->H = histLen;
+    h->head = -1, h->count = 0, h->lastFrame = -0x7fffffff;
+    const size_t nXY = (size_t)nCams * histLen * 2 * N, nR = (size_t)nCams * histLen * 9, nT = (size_t)nCams * histLen * 3;
+    if (hipMalloc((void**)&h->xy, sizeof(double) * nXY) != hipSuccess || hipMalloc((void**)&h->R, sizeof(double) * nR) != hipSuccess ||
+        hipMalloc((void**)&h->t, sizeof(double) * nT) != hipSuccess) {
+        cs_set_error("cs_track_history_create: hipMalloc failed");
+        (void)hipFree(h->xy), (void)hipFree(h->R), (void)hipFree(h->t);
+        delete h;
+        return nullptr;
+    }
+    (void)hipMemset(h->xy, 0, sizeof(double) * nXY);
+    (void)hipMemset(h->R, 0, sizeof(double) * nR);
+    (void)hipMemset(h->t, 0, sizeof(double) * nT);
+    return h;
+}
+
+extern "C" void cs_track_history_destroy(cs_track_history* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->xy), (void)hipFree(h->R), (void)hipFree(h->t);
+    delete h;
+}
+
+extern "C" int cs_track_history_frames(const cs_track_history* h) { return h ? h->count : 0; }
+
+namespace {
+
+int pu_launch(const char* who, int device, void* hip_stream, PuArgs& A, const cs_poseupdate_cam* cams, bool gate, bool dyn) {
+    for (int c = 0; c < A.nCams; ++c) {
+        const cs_poseupdate_cam& q = cams[c];
+        const bool run = c >= A.cam0 && c < A.cam0 + A.nCamsRun;
+        if (run && (!q.K || !q.xy || !q.state || !q.slot2map || (gate && !q.reprojErr) || (dyn && (!q.iK || !q.trackSpan || !q.isStatic)))) {
+            cs_set_error("%s: null pointer in camera %d", who, c);
+            return CS_ERR_INVALID;
+        }
+        A.cam[c] = q;
+    }
+    CS_HIP(hipSetDevice(device));
+    A.gateBlocks = gate ? (A.nMap + 255) / 256 : 0;
+    A.dynBlocksPerCam = (A.N + 255) / 256;
+    const int dynBlocks = dyn ? A.dynBlocksPerCam * A.nCamsRun : 0;
+    if (A.gateBlocks + dynBlocks == 0) return CS_OK;
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (gate && A.numNodes) CS_HIP(hipMemsetAsync(A.numNodes + A.cam0, 0, sizeof(int) * A.nCamsRun, s));
+    if (gate && A.numOut) CS_HIP(hipMemsetAsync(A.numOut + A.cam0, 0, sizeof(int) * A.nCamsRun, s));
+    if (dyn && A.numDyn) CS_HIP(hipMemsetAsync(A.numDyn + A.cam0, 0, sizeof(int) * A.nCamsRun, s));
+    const size_t lds = dyn ? sizeof(double) * 9 * (size_t)(A.nHist > 0 ? A.nHist : 1) : 0;
+    hipLaunchKernelGGL(k_pose_update, dim3(A.gateBlocks + dynBlocks), dim3(256), lds, s, A);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int pu_check_common(const char* who, int nCams, int cam0, int nCamsRun, const cs_poseupdate_cam* cams, int N, const double* d_R,
+                    const double* d_t) {
+    if (nCams < 1 || nCams > PU_MAX_CAMS || cam0 < 0 || nCamsRun < 0 || cam0 + nCamsRun > nCams || !cams || N < 1 || !d_R || !d_t) {
+        cs_set_error("%s: nCams in 1..%d, 0 <= cam0, cam0 + nCamsRun <= nCams, N >= 1, non-null cams / d_R / d_t", who, PU_MAX_CAMS);
+        return CS_ERR_INVALID;
+    }
+    return CS_OK;
+}
+
+void pu_fill_gate(PuArgs& A, const int* d_pointFeat, int nMap, double* d_mapPts, double* d_mapCov, unsigned char* d_mapFlags,
+                  int largeErr, double pixelErrVar, int* d_numNodes, int* d_numOut) {
+    A.pointFeat = d_pointFeat;
+    A.nMap = nMap;
+    A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.mapFlags = d_mapFlags;
+    A.errThres = largeErr ? 6.0 : 2.0;  // :673
+    A.sigma = pixelErrVar;
+    A.numNodes = d_numNodes, A.numOut = d_numOut;
+}
+
+// advance the ring to `frame` (host bookkeeping only; the launch writes the entry)
+void pu_advance(cs_track_history* h, int frame) {
+    if (frame == h->lastFrame) return;  // the same frame again (camera-by-camera calls): the entry is rewritten
+    if (frame != h->lastFrame + 1) h->count = 0;  // Track2D's length() counts frames: a gap in the numbering loses the history
+    h->head = (h->head + 1) % h->H;
+    h->count = h->count < h->H ? h->count + 1 : h->H;
+    h->lastFrame = frame;
+}
+
+void pu_fill_dyn(PuArgs& A, cs_track_history* h, int minLen, int minOutNum, double maxEpiErr, int* d_numDyn) {
+    A.H = h->H, A.head = h->head, A.nHist = h->count;
+    A.histXY = h->xy, A.histR = h->R, A.histT = h->t;
+    A.minLen = minLen, A.minOutNum = minOutNum, A.maxEpiErr = maxEpiErr;
+    A.numDyn = d_numDyn;
+}
+
+}  // namespace
+
+extern "C" int cs_pose_update3d_dev(int device, void* hip_stream, int nCams, int cam0, int nCamsRun, const cs_poseupdate_cam* cams,
+                                    int N, const int* d_pointFeat, int nMap, const double* d_R, const double* d_t, double* d_mapPts,
+                                    double* d_mapCov, unsigned char* d_mapFlags, int largeErr, double pixelErrVar, int* d_numNodes,
+                                    int* d_numOut) {
+    int rc = pu_check_common("cs_pose_update3d_dev", nCams, cam0, nCamsRun, cams, N, d_R, d_t);
+    if (rc != CS_OK) return rc;
+    if (nMap < 0 || (nMap > 0 && (!d_pointFeat || !d_mapPts || !d_mapCov || !d_mapFlags))) {
+        cs_set_error("cs_pose_update3d_dev: null map pointer");
+        return CS_ERR_INVALID;
+    }
+    PuArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = nCams, A.N = N, A.cam0 = cam0, A.nCamsRun = nCamsRun, A.R = d_R, A.t = d_t;
+    pu_fill_gate(A, d_pointFeat, nMap, d_mapPts, d_mapCov, d_mapFlags, largeErr, pixelErrVar, d_numNodes, d_numOut);
+    return pu_launch("cs_pose_update3d_dev", device, hip_stream, A, cams, true, false);
+}
+
+extern "C" int cs_detect_dynamic_dev(cs_track_history* h, void* hip_stream, int cam0, int nCamsRun, const cs_poseupdate_cam* cams,
+                                     const double* d_R, const double* d_t, int nMap, const unsigned char* d_mapFlags, int frame,
+                                     int maxLen, int minLen, int minOutNum, double maxEpiErr, int* d_numDyn) {
+    if (!h) {
+        cs_set_error("cs_detect_dynamic_dev: null history");
+        return CS_ERR_INVALID;
+    }
+    (void)maxLen;  // SL_SingleSLAM.cpp:799: the reference never advances the counter it compares with maxLen
+    int rc = pu_check_common("cs_detect_dynamic_dev", h->nCams, cam0, nCamsRun, cams, h->N, d_R, d_t);
+    if (rc != CS_OK) return rc;
+    if (nMap > 0 && !d_mapFlags) {
+        cs_set_error("cs_detect_dynamic_dev: null map flags");
+        return CS_ERR_INVALID;
+    }
+    PuArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = h->nCams, A.N = h->N, A.cam0 = cam0, A.nCamsRun = nCamsRun, A.R = d_R, A.t = d_t;
+    A.nMap = nMap, A.mapFlags = (unsigned char*)d_mapFlags;
+    pu_advance(h, frame);
+    pu_fill_dyn(A, h, minLen, minOutNum, maxEpiErr, d_numDyn);
+    return pu_launch("cs_detect_dynamic_dev", h->device, hip_stream, A, cams, false, true);
+}
+
+extern "C" int cs_pose_update_frame_dev(cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const int* d_pointFeat,
+                                        int nMap, const double* d_R, const double* d_t, double* d_mapPts, double* d_mapCov,
+                                        unsigned char* d_mapFlags, int largeErr, double pixelErrVar, int frame, int maxLen, int minLen,
+                                        int minOutNum, double maxEpiErr, int* d_numNodes, int* d_numOut, int* d_numDyn) {
+    if (!h) {
+        cs_set_error("cs_pose_update_frame_dev: null history");
+        return CS_ERR_INVALID;
+    }
+    (void)maxLen;
+    int rc = pu_check_common("cs_pose_update_frame_dev", h->nCams, 0, h->nCams, cams, h->N, d_R, d_t);
+    if (rc != CS_OK) return rc;
+    if (nMap < 0 || (nMap > 0 && (!d_pointFeat || !d_mapPts || !d_mapCov || !d_mapFlags))) {
+        cs_set_error("cs_pose_update_frame_dev: null map pointer");
+        return CS_ERR_INVALID;
+    }
+    PuArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = h->nCams, A.N = h->N, A.cam0 = 0, A.nCamsRun = h->nCams, A.R = d_R, A.t = d_t;
+    pu_fill_gate(A, d_pointFeat, nMap, d_mapPts, d_mapCov, d_mapFlags, largeErr, pixelErrVar, d_numNodes, d_numOut);
+    pu_advance(h, frame);
+    pu_fill_dyn(A, h, minLen, minOutNum, maxEpiErr, d_numDyn);
+    return pu_launch("cs_pose_update_frame_dev", h->device, hip_stream, A, cams, true, true);
+}

@@ -1,0 +1,87 @@
+"""What a frame does with the cameras' new poses (cs_pose_update3d_dev / cs_detect_dynamic_dev / cs_pose_update_frame_dev): the
+gate + seqTriangulate loop of SingleSLAM::poseUpdate3D (reference src/app/SL_SingleSLAM.cpp:672-708) and
+SingleSLAM::detectDynamicFeaturePoints (:784-824) for every camera of a group, on the device."""
+import ctypes as C
+
+from ._lib import check, lib
+
+MAP_DYNAMIC, MAP_FALSE, MAP_UNCERTAIN = 1, 2, 4
+
+
+class PoseUpdateCam(C.Structure):
+    """== cs_poseupdate_cam (include/coslam_hip.h)."""
+
+    _fields_ = [(n, C.c_void_p) for n in ("K", "iK", "xy", "state", "slot2map", "trackSpan", "reprojErr", "isStatic")]
+
+
+def poseupdate_cams(cams):
+    """list of dicts of DEVICE pointers (ints) with the field names of cs_poseupdate_cam -> the ctypes array (build once)"""
+    if isinstance(cams, C.Array):
+        return cams
+    arr = (PoseUpdateCam * len(cams))()
+    for a, c in zip(arr, cams):
+        for n, _ in PoseUpdateCam._fields_:
+            v = c.get(n)
+            setattr(a, n, int(v) if v else None)
+    return arr
+
+
+def pose_update3d_dev(stream_ptr, cams, N, d_pointFeat, nMap, d_R, d_t, d_mapPts, d_mapCov, d_mapFlags, largeErr, pixelErrVar,
+                      d_numNodes=None, d_numOut=None, cam0=0, nCamsRun=None, device=0):
+    """The gate loop for cameras cam0 .. cam0 + nCamsRun - 1 (default: all), in camera order per map point."""
+    vp = C.c_void_p
+    arr = poseupdate_cams(cams)
+    n = len(arr)
+    check(lib().cs_pose_update3d_dev(int(device), vp(stream_ptr), n, int(cam0), int(n - cam0 if nCamsRun is None else nCamsRun), arr,
+                                     int(N), vp(d_pointFeat), int(nMap), vp(d_R), vp(d_t), vp(d_mapPts), vp(d_mapCov),
+                                     vp(d_mapFlags), int(largeErr), C.c_double(pixelErrVar), vp(d_numNodes), vp(d_numOut)),
+          "cs_pose_update3d_dev")
+
+
+class TrackHistory:
+    """cs_track_history: the ring of the last histLen frames' hand-back pixels and poses the dynamic test walks."""
+
+    def __init__(self, nCams, N, histLen, device=0):
+        L = lib()
+        L.cs_track_history_create.restype = C.c_void_p
+        self._L = L
+        self.nCams, self.N, self.histLen = int(nCams), int(N), int(histLen)
+        self._h = L.cs_track_history_create(int(device), self.nCams, self.N, self.histLen)
+        if not self._h:
+            check(-1, "cs_track_history_create")
+
+    def close(self):
+        if self._h:
+            self._L.cs_track_history_destroy(C.c_void_p(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def frames(self):
+        return self._L.cs_track_history_frames(C.c_void_p(self._h))
+
+    def detect_dynamic_dev(self, stream_ptr, cams, d_R, d_t, nMap, d_mapFlags, frame, maxLen=20, minLen=5, minOutNum=3,
+                           maxEpiErr=6.0, d_numDyn=None, cam0=0, nCamsRun=None):
+        """detectDynamicFeaturePoints(20, 5, 3, Const::MAX_EPI_ERR) (reference src/app/SL_CoSLAM.cpp:361, 404-405)."""
+        vp = C.c_void_p
+        arr = poseupdate_cams(cams)
+        check(self._L.cs_detect_dynamic_dev(vp(self._h), vp(stream_ptr), int(cam0),
+                                            int(self.nCams - cam0 if nCamsRun is None else nCamsRun), arr, vp(d_R), vp(d_t), int(nMap),
+                                            vp(d_mapFlags), int(frame), int(maxLen), int(minLen), int(minOutNum),
+                                            C.c_double(maxEpiErr), vp(d_numDyn)), "cs_detect_dynamic_dev")
+
+    def pose_update_frame_dev(self, stream_ptr, cams, d_pointFeat, nMap, d_R, d_t, d_mapPts, d_mapCov, d_mapFlags, largeErr,
+                              pixelErrVar, frame, maxLen=20, minLen=5, minOutNum=3, maxEpiErr=6.0, d_numNodes=None, d_numOut=None,
+                              d_numDyn=None):
+        """Gate + dynamic test of all cameras in one launch."""
+        vp = C.c_void_p
+        arr = poseupdate_cams(cams)
+        check(self._L.cs_pose_update_frame_dev(vp(self._h), vp(stream_ptr), arr, vp(d_pointFeat), int(nMap), vp(d_R), vp(d_t),
+                                               vp(d_mapPts), vp(d_mapCov), vp(d_mapFlags), int(largeErr), C.c_double(pixelErrVar),
+                                               int(frame), int(maxLen), int(minLen), int(minOutNum), C.c_double(maxEpiErr),
+                                               vp(d_numNodes), vp(d_numOut), vp(d_numDyn)), "cs_pose_update_frame_dev")

@@ -297,6 +297,60 @@ int cs_register_search(int device, int nCams, const cs_register_cam* cams, int N
                        double* m, double* var, double* dist, int* flags);
 
 /* ------------------------------------------------------------------------------------------
+ * What a frame does with the cameras' new poses: the gate + seqTriangulate loop of poseUpdate3D and the dynamic-point test
+ * ------------------------------------------------------------------------------------------
+ * Replaces the second half of SingleSLAM::poseUpdate3D (src/app/SL_SingleSLAM.cpp:672-708, nodes of getStaticMappedTrackNodes
+ * :60-75) and SingleSLAM::detectDynamicFeaturePoints (:784-824, nodes of getUnMappedAndDynamicTrackNodes :91-105) for every
+ * camera of a group, behind cs_pose_intracam_batch_dev.  All pointers are DEVICE pointers unless noted.
+ *  gate: per map point that isCertainStatic() and per camera IN CAMERA ORDER (CoSLAM::parallelPoseUpdate runs the cameras one
+ *        after the other, src/app/SL_CoSLAM.cpp:398-410) the feature of this frame attached to it (d_pointFeat: the hand-back's
+ *        nMap x nCams table): Mahalanobis distance of the projection under the new pose against 2.0 (6.0 with largeErr);
+ *        inlier: reprojErr[slot] = the distance, the point and its covariance updated in place by seqTriangulate; outlier:
+ *        reprojErr[slot] = the pixel distance, the point's CS_MAP_UNCERTAIN bit set (MapPoint::setUncertain) -- it is no node
+ *        of the cameras that follow.
+ *  dynamic test: per slot with a track of >= minLen frames whose feature is unmapped or on a certain-dynamic point: the
+ *        epipolar error of the current position against the track's past positions (ring of the last histLen frames' pixels
+ *        and poses, cs_track_history), counted against maxEpiErr; more than minOutNum: isStatic[slot] = 0
+ *        (TYPE_FEATPOINT_DYNAMIC), else an unmapped slot's isStatic = 1.  maxLen has no effect, as in the reference (:799: its
+ *        loop never advances the counter it compares with maxLen); the walk is bounded by histLen.
+ * reprojErr[] and isStatic[] persist per slot between frames: that is propagateFeatureStates' hand-down along a track
+ * (:40-42, :54); isStatic[] is what the next frame's cs_klt_handback_dev takes as cs_handback_cam.isStatic.
+ * project / getProjectionCovMat / mat22Inv / mahaDist2 / dist2 / seqTriangulate / formEMat / getFMat / epipolarError are
+ * un-vendored LibVisualSLAM: definitions in DESIGN.md. */
+#define CS_MAP_DYNAMIC 1   /* MapPoint::iLocalType == TYPE_MAP_DYNAMIC (src/slam/SL_MapPoint.h:22-24) */
+#define CS_MAP_FALSE 2     /*                      == TYPE_MAP_FALSE; neither bit: TYPE_MAP_STATIC */
+#define CS_MAP_UNCERTAIN 4 /* MapPoint::bUncertain */
+typedef struct cs_poseupdate_cam {
+    const double* K;         /* 9 */
+    const double* iK;        /* 9: SingleSLAM::iK (dynamic test) */
+    const double* xy;        /* 2N: the hand-back's undistorted pixels of this frame */
+    const int* state;        /* N: the hand-back's state (0 tracked, 1 new: the slot has a feature in this frame) */
+    const int* slot2map;     /* N */
+    const int* trackSpan;    /* 2N (dynamic test) */
+    double* reprojErr;       /* N in/out: FeaturePoint::reprojErr (gate) */
+    unsigned char* isStatic; /* N in/out: FeaturePoint::type == TYPE_FEATPOINT_STATIC (dynamic test) */
+} cs_poseupdate_cam;
+typedef struct cs_track_history cs_track_history;
+cs_track_history* cs_track_history_create(int device, int nCams, int N, int histLen /* <= 512 */);
+void cs_track_history_destroy(cs_track_history* h);
+int cs_track_history_frames(const cs_track_history* h); /* consecutive frames held (<= histLen) */
+/* cams: HOST array of nCams records; cameras cam0 .. cam0 + nCamsRun - 1 are processed (all: 0, nCams).  d_R nCams x 9, d_t
+ * nCams x 3: the new poses.  d_numNodes / d_numOut / d_numDyn: nCams counters or NULL (poseUpdate3D's `num`, `numOut`,
+ * detectDynamicFeaturePoints' return value). */
+int cs_pose_update3d_dev(int device, void* hip_stream, int nCams, int cam0, int nCamsRun, const cs_poseupdate_cam* cams, int N,
+                         const int* d_pointFeat, int nMap, const double* d_R, const double* d_t, double* d_mapPts, double* d_mapCov,
+                         unsigned char* d_mapFlags, int largeErr, double pixelErrVar, int* d_numNodes, int* d_numOut);
+/* `frame`: this frame's number; the history is kept while the numbers are consecutive (Track2D::length() counts frames) */
+int cs_detect_dynamic_dev(cs_track_history* h, void* hip_stream, int cam0, int nCamsRun, const cs_poseupdate_cam* cams,
+                          const double* d_R, const double* d_t, int nMap, const unsigned char* d_mapFlags, int frame, int maxLen,
+                          int minLen, int minOutNum, double maxEpiErr, int* d_numDyn);
+/* both, all cameras, ONE launch (what a frame loop calls behind cs_pose_intracam_batch_dev) */
+int cs_pose_update_frame_dev(cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap,
+                             const double* d_R, const double* d_t, double* d_mapPts, double* d_mapCov, unsigned char* d_mapFlags,
+                             int largeErr, double pixelErrVar, int frame, int maxLen, int minLen, int minOutNum, double maxEpiErr,
+                             int* d_numNodes, int* d_numOut, int* d_numDyn);
+
+/* ------------------------------------------------------------------------------------------
  * Pose-graph relaxation of the non-key frames after a bundle adjustment, all camera graphs in one launch
  * ------------------------------------------------------------------------------------------
  * Replaces GlobalPoseGraph::computeNewCameraRotations + computeNewCameraTranslations

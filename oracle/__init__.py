@@ -207,6 +207,60 @@ def register_search(W, H, Ks, Rs, ts, xy, state, slot2map, isDynamic, Ms, covs, 
     return dict(slot=slot, m=m, var=var, dist=dist, flags=flags)
 
 
+def seq_triangulate(K, R, t, m, M, cov, sigma):
+    """opu_seq_triangulate: returns the updated (M, cov)."""
+    L = lib()
+    K, R, t, m = (np.ascontiguousarray(a, dtype=np.float64).reshape(-1) for a in (K, R, t, m))
+    M = np.array(M, dtype=np.float64).reshape(3).copy()
+    cov = np.array(cov, dtype=np.float64).reshape(9).copy()
+    L.opu_seq_triangulate(_p(K), _p(R), _p(t), _p(m), _p(M), _p(cov), C.c_double(sigma))
+    return M, cov.reshape(3, 3)
+
+
+def pose_update_gate(Ks, Rs, ts, xy, state, slot2map, mapPts, mapCov, mapFlags, largeErr, sigma, reprojErr, cams=None):
+    """poseUpdate3D's second half for the cameras `cams` (default: all) ONE AFTER THE OTHER (opu_gate_camera per camera, the map
+    updated in place between them).  Per-camera lists xy (float64[2N]), state / slot2map (int32[N]), reprojErr (float64[N], in /
+    out); mapPts (P x 3), mapCov (P x 9), mapFlags (uint8[P]) are updated IN PLACE.  Returns (num nodes, numOut) per camera."""
+    L = lib()
+    L.opu_gate_camera.restype = C.c_int
+    nC = len(xy)
+    Ks = np.ascontiguousarray(Ks, dtype=np.float64).reshape(nC, 9)
+    Rs = np.ascontiguousarray(Rs, dtype=np.float64).reshape(nC, 9)
+    ts = np.ascontiguousarray(ts, dtype=np.float64).reshape(nC, 3)
+    assert mapPts.dtype == np.float64 and mapCov.dtype == np.float64 and mapFlags.dtype == np.uint8
+    assert mapPts.flags.c_contiguous and mapCov.flags.c_contiguous and mapFlags.flags.c_contiguous
+    out = []
+    for c in (range(nC) if cams is None else cams):
+        x = np.ascontiguousarray(xy[c], dtype=np.float64)
+        st = np.ascontiguousarray(state[c], dtype=np.int32)
+        s2 = np.ascontiguousarray(slot2map[c], dtype=np.int32)
+        assert reprojErr[c].dtype == np.float64 and reprojErr[c].flags.c_contiguous
+        no = C.c_int(0)
+        num = L.opu_gate_camera(_p(Ks[c]), _p(Rs[c]), _p(ts[c]), len(st), _p(x), _p(st), _p(s2), len(mapFlags), _p(mapPts),
+                                _p(mapCov), _p(mapFlags), int(largeErr), C.c_double(sigma), _p(reprojErr[c]), C.byref(no))
+        out.append((num, no.value))
+    return out
+
+
+def detect_dynamic(iK, histR, histT, histXY, state, slot2map, trackSpan, mapFlags, maxLen, minLen, minOutNum, maxEpiErr, isStatic):
+    """opu_detect_dynamic_camera for one camera: histR (nHist x 9), histT (nHist x 3), histXY (nHist x 2N), entry 0 = this frame;
+    isStatic uint8[N] is updated in place.  Returns the number of features made dynamic."""
+    L = lib()
+    L.opu_detect_dynamic_camera.restype = C.c_int
+    iK = np.ascontiguousarray(iK, dtype=np.float64).reshape(9)
+    histR = np.ascontiguousarray(histR, dtype=np.float64)
+    histT = np.ascontiguousarray(histT, dtype=np.float64)
+    histXY = np.ascontiguousarray(histXY, dtype=np.float64)
+    nH = len(histR)
+    st = np.ascontiguousarray(state, dtype=np.int32)
+    s2 = np.ascontiguousarray(slot2map, dtype=np.int32)
+    sp = np.ascontiguousarray(trackSpan, dtype=np.int32)
+    fl = np.ascontiguousarray(mapFlags, dtype=np.uint8)
+    assert isStatic.dtype == np.uint8 and isStatic.flags.c_contiguous and histXY.shape == (nH, 2 * len(st))
+    return L.opu_detect_dynamic_camera(_p(iK), len(st), nH, nH, _p(histR), _p(histT), _p(histXY), _p(st), _p(s2), _p(sp), len(fl),
+                                       _p(fl), int(maxLen), int(minLen), int(minOutNum), C.c_double(maxEpiErr), _p(isStatic))
+
+
 def ncc_blocks(img, x, y, scale):
     """onc_block_compute for n points: returns (blocks uint8[n,128] (121 used, pad 0x80), abc float64[n,4], valid int32[n])."""
     L = lib()

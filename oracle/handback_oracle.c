@@ -74,7 +74,10 @@ int ohb_handback(int N, int W, int H, int frame, const okl_tracked_feature* feat
     for (int i = 0; i < N; i++) {
         if (tf1[i] < 0) continue; /* tk->empty() */
         const int mapped = slot2map[i] >= 0;
-        if (mapped || (isStatic && isStatic[i])) { /* fp->type == STATIC || (fp->mpt && fp->mpt->isCertainStatic()) */
+        /* fp->type == STATIC || (fp->mpt && fp->mpt->isCertainStatic()); a track born in this frame has no predecessor to take a
+         * type from (propagateFeatureStates, :40-42) and keeps the constructor's type(0) = STATIC (SL_FeaturePoint.cpp:23),
+         * whatever the slot's previous track left in isStatic[] */
+        if (mapped || (isStatic && (isStatic[i] || tf1[i] == frame))) {
             int bx = (int)(xy[i] / blkW);
             int by = (int)(xy[N + i] / blkH);
             if (bx >= nColBlk || by >= nRowBlk) continue;

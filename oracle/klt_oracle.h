@@ -148,6 +148,21 @@ void org_register_search(int nCams, int N, int W, int H, const double* Ks, const
                          const int* pointFeat, double sigmaSearch, double maxDist, double sigmaMerge, int* slot, double* m_out,
                          double* var_out, double* dist, int* flags);
 
+/* ---- what a frame does with a camera's new pose: poseUpdate3D's gate + seqTriangulate loop, detectDynamicFeaturePoints
+ * (poseupdate_oracle.c) ---- */
+void opu_seq_triangulate(const double K[9], const double R[9], const double t[3], const double m[2], double M[3], double cov[9],
+                         double sigma);
+int opu_gate_camera(const double K[9], const double R[9], const double t[3], int N, const double* xy, const int* state,
+                    const int* slot2map, int nMap, double* mapPts, double* mapCov, unsigned char* mapFlags, int largeErr,
+                    double sigma, double* reprojErr, int* numOut);
+void opu_form_emat(const double* R1, const double* t1, const double* R2, const double* t2, double* E);
+void opu_get_fmat(const double* iK1, const double* iK2, const double* E, double* F);
+double opu_epipolar_error(const double* F, double ax, double ay, double bx, double by);
+int opu_detect_dynamic_camera(const double iK[9], int N, int H, int nHist, const double* histR, const double* histT,
+                              const double* histXY, const int* state, const int* slot2map, const int* trackSpan, int nMap,
+                              const unsigned char* mapFlags, int maxLen, int minLen, int minOutNum, double maxEpiErr,
+                              unsigned char* isStatic);
+
 /* ---- NCC blocks and the epipolar / NCC matrices of the inter-camera matching restated (ncc_oracle.c) ---- */
 int onc_block_compute(const unsigned char* img, int W, int H, double x, double y, double scale, unsigned char* I, double* abc);
 double onc_match(const unsigned char* I1, const double* abc1, const unsigned char* I2, const double* abc2);

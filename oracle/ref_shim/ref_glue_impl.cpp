@@ -59,33 +59,35 @@ void getRigidTransFromTo(const double* R1, const double* t1, const double* R2, c
     mat33AB(R2, R1t, R);
     for (int r = 0; r < 3; ++r) t[r] = t2[r] - (R[3 * r] * t1[0] + R[3 * r + 1] * t1[1] + R[3 * r + 2] * t1[2]);
 }
-// One Kalman / Gauss-Newton update of a map point and its covariance from a new measurement (our definition of the
-// external helper; used by the Mahalanobis post-pass of InterCamPoseEstimator::apply, off the product's path).
+// One Kalman update of a map point and its covariance from a new measurement with noise sigma^2 I (our definition of the
+// external helper; the operation order is the one coslam_amd/csrc/poseupdate.hip and oracle/poseupdate_oracle.c use,
+// with J as getProjectionCovMat forms it):
+//   S = J (cov J^T) + sigma^2 I, G = (cov J^T) S^-1, M += G (m - project(M)), cov -= G (cov J^T)^T
 void seqTriangulate(const double* K, const double* R, const double* t, const double* m, double* M, double* cov, double sigma) {
-    double X[3], rm[2];
-    for (int r = 0; r < 3; ++r) X[r] = R[3 * r] * M[0] + R[3 * r + 1] * M[1] + R[3 * r + 2] * M[2] + t[r];
-    project(K, R, t, M, rm);
-    const double w = K[6] * X[0] + K[7] * X[1] + K[8] * X[2];
-    double J[6];  // d project / d M (2 x 3)
-    for (int c = 0; c < 3; ++c) {
-        const double du = K[0] * R[c] + K[1] * R[3 + c] + K[2] * R[6 + c], dv = K[3] * R[c] + K[4] * R[3 + c] + K[5] * R[6 + c];
-        const double dw = K[6] * R[c] + K[7] * R[3 + c] + K[8] * R[6 + c];
-        J[c] = (du - rm[0] * dw) / w;
-        J[3 + c] = (dv - rm[1] * dw) / w;
+    const double X = R[0] * M[0] + R[1] * M[1] + R[2] * M[2] + t[0];
+    const double Y = R[3] * M[0] + R[4] * M[1] + R[5] * M[2] + t[1];
+    const double Z = R[6] * M[0] + R[7] * M[1] + R[8] * M[2] + t[2];
+    double KR[9];
+    mat33AB(K, R, KR);
+    const double u = K[0] * X + K[1] * Y + K[2] * Z, v = K[3] * X + K[4] * Y + K[5] * Z, w = K[6] * X + K[7] * Y + K[8] * Z;
+    double J[6], PJt[6], S[4], iS[4], G[6], nc[9];
+    for (int j = 0; j < 3; ++j) {
+        J[j] = (KR[j] * w - u * KR[6 + j]) / (w * w);
+        J[3 + j] = (KR[3 + j] * w - v * KR[6 + j]) / (w * w);
     }
-    double PJt[6], S[4], iS[4];  // cov J^T (3 x 2), S = J cov J^T + sigma^2 I
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 2; ++c) PJt[2 * r + c] = cov[3 * r] * J[3 * c] + cov[3 * r + 1] * J[3 * c + 1] + cov[3 * r + 2] * J[3 * c + 2];
     for (int r = 0; r < 2; ++r)
-        for (int c = 0; c < 2; ++c) S[2 * r + c] = J[3 * r] * PJt[c] + J[3 * r + 1] * PJt[2 + c] + J[3 * r + 2] * PJt[4 + c] + (r == c ? sigma * sigma : 0);
+        for (int c = 0; c < 2; ++c) {
+            const double sv = J[3 * r] * PJt[c] + J[3 * r + 1] * PJt[2 + c] + J[3 * r + 2] * PJt[4 + c];
+            S[2 * r + c] = (r == c) ? sv + sigma * sigma : sv;
+        }
     mat22Inv(S, iS);
-    double Kg[6];
     for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 2; ++c) Kg[2 * r + c] = PJt[2 * r] * iS[c] + PJt[2 * r + 1] * iS[2 + c];
-    const double e[2] = {m[0] - rm[0], m[1] - rm[1]};
-    for (int r = 0; r < 3; ++r) M[r] += Kg[2 * r] * e[0] + Kg[2 * r + 1] * e[1];
-    double nc[9];
+        for (int c = 0; c < 2; ++c) G[2 * r + c] = PJt[2 * r] * iS[c] + PJt[2 * r + 1] * iS[2 + c];
+    const double e0 = m[0] - u / w, e1 = m[1] - v / w;
     for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) nc[3 * r + c] = cov[3 * r + c] - (Kg[2 * r] * PJt[2 * c] + Kg[2 * r + 1] * PJt[2 * c + 1]);
+        for (int c = 0; c < 3; ++c) nc[3 * r + c] = cov[3 * r + c] - (G[2 * r] * PJt[2 * c] + G[2 * r + 1] * PJt[2 * c + 1]);
+    for (int r = 0; r < 3; ++r) M[r] = M[r] + (G[2 * r] * e0 + G[2 * r + 1] * e1);
     for (int i = 0; i < 9; ++i) cov[i] = nc[i];
 }

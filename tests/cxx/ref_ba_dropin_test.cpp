@@ -14,6 +14,10 @@
 //       on a CoSLAM whose cameras carry tracks, feature points and map points.  Checked: static / dynamic counts, the
 //       poses the solve writes back through CamPoseList::add, and -- pinning SURVEY 8f-1 to the reference -- that the
 //       on-device hand-back (cs_klt_handback_dev) picks exactly the feature points chooseStaticFeatPts picks.
+//   (3) SingleSLAM::poseUpdate3D + detectDynamicFeaturePoints (src/app/SL_SingleSLAM.cpp:600-708, 784-824), camera after
+//       camera, on cameras with 13 frames of tracks, poses and map points of every kind.  Checked: the device's one launch for
+//       all cameras (cs_pose_update_frame_dev) leaves the same map points, covariances, uncertain flags, reprojErr, feature
+//       types and counts, bit for bit.
 // TEST INFRASTRUCTURE; built into oracle/_ref/ where the reference tree exists, run by tests/test_cxx_dropin_gpu.py.
 #include <hip/hip_runtime.h>
 
@@ -343,9 +347,11 @@ static int test_inter_cam_pose_estimator() {
             if (!proj(K, &Rgt[9 * c], &tgt[3 * c], Mobs, m, W, H)) continue;
             if (!dyn && (i % nc) != c) continue;  // static points: one camera each
             Track2D& tk = s->m_tracker.m_tks[slot++];
-            if (urand() < 0.5) tk.add(s->m_featPts.add(frame - 1, c, m[0] - 1, m[1] + 0.5));
+            const bool hasPrev = urand() < 0.5;
+            if (hasPrev) tk.add(s->m_featPts.add(frame - 1, c, m[0] - 1, m[1] + 0.5));
             FeaturePoint* fp = s->m_featPts.add(frame, c, m[0] + 0.4 * nrand(), m[1] + 0.4 * nrand());
-            fp->type = dyn ? TYPE_FEATPOINT_DYNAMIC : TYPE_FEATPOINT_STATIC;
+            // (a feature without a predecessor is STATIC by construction, src/slam/SL_FeaturePoint.cpp:23: nothing hands it a type)
+            fp->type = (dyn && hasPrev) ? TYPE_FEATPOINT_DYNAMIC : TYPE_FEATPOINT_STATIC;
             fp->mpt = mpts[i];
             mpts[i]->pFeatures[c] = fp;
             tk.add(fp);
@@ -445,9 +451,260 @@ static int test_inter_cam_pose_estimator() {
     return 0;
 }
 
+// ---- (3) SingleSLAM::poseUpdate3D + detectDynamicFeaturePoints, camera after camera as CoSLAM::parallelPoseUpdate runs them
+// (src/app/SL_CoSLAM.cpp:398-410), against the device's ONE launch for all cameras (cs_pose_update_frame_dev) fed the poses the
+// reference's own intraCamEstimate call produced.  The loops, their node selection, the thresholds, the camera order through
+// the shared map points and the never-advanced `f` of :799 are the reference's own code; the helpers they call are the
+// stand-ins of oracle/ref_shim/ (un-vendored LibVisualSLAM), the same definitions the device uses.
+static int test_pose_update3d_and_dynamic_points() {
+    const int W = 640, H = 480, nc = 3, Fcur = 12, NMAP = 500, NFREE = 300, NALL = NMAP + NFREE;
+    const double K[9] = {0.82 * W, 0, W / 2.0, 0, 0.82 * W, H / 2.0, 0, 0, 1};
+    const double iK[9] = {1 / K[0], 0, -K[2] / K[0], 0, 1 / K[4], -K[5] / K[4], 0, 0, 1};
+    const double kud[7] = {0, 0, 0, 0, 0, 0, 0};
+    CoSLAM* co = (CoSLAM*)calloc(1, sizeof(CoSLAM));
+    co->numCams = nc;
+    co->curFrame = Fcur;
+    // scene points: the first NMAP are map points (some moving), the rest never mapped (some moving)
+    std::vector<double> P0(3 * NALL), vel(3 * NALL, 0.0);
+    std::vector<MapPoint*> mpts;
+    for (int i = 0; i < NALL; ++i) {
+        P0[3 * i] = -5 + 10 * urand(), P0[3 * i + 1] = -3 + 6 * urand(), P0[3 * i + 2] = 6 + 8 * urand();
+        const bool moving = urand() < 0.25;
+        if (moving)
+            for (int q = 0; q < 3; ++q) vel[3 * i + q] = 0.06 * nrand();
+        if (i >= NMAP) continue;
+        MapPoint* mp = new MapPoint(P0[3 * i] + 0.03 * nrand(), P0[3 * i + 1] + 0.03 * nrand(), P0[3 * i + 2] + 0.03 * nrand(), 0);
+        double A[9];
+        for (int q = 0; q < 9; ++q) A[q] = 0.03 * nrand();
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                mp->cov[3 * r + c] = A[3 * r] * A[3 * c] + A[3 * r + 1] * A[3 * c + 1] + A[3 * r + 2] * A[3 * c + 2] + (r == c ? 1e-4 : 0);
+        if (moving && urand() < 0.8)
+            mp->setLocalDynamic();
+        else
+            mp->setLocalStatic();
+        if (urand() < 0.03) mp->setUncertain();
+        if (urand() < 0.02) mp->setFalse();
+        mp->bNewPt = false;
+        mpts.push_back(mp);
+    }
+    V3D_GPU::KLT_SequenceTrackerConfig cfg;
+    cfg.nLevels = 3;
+    const int N = 1024;   // slots used per camera (of m_nMaxCorners)
+    struct CamData {
+        std::vector<int> slotPt, birth;
+        std::vector<std::vector<double> > xy, R, t;   // per frame
+    };
+    std::vector<CamData> cd(nc);
+    for (int c = 0; c < nc; ++c) {
+        SingleSLAM* s = new (&co->slam[c]) SingleSLAM();
+        s->camId = c;
+        s->W = W, s->H = H;
+        s->blkW = W / s->nColBlk, s->blkH = H / s->nRowBlk;
+        s->K.cloneFrom(K, 3, 3);
+        s->iK.cloneFrom(iK, 3, 3);
+        s->k_ud.cloneFrom(kud, 7, 1);
+        s->m_tracker.init(c, W, H, &cfg);
+        s->m_tracker.setIntrinsicParam(K, iK, kud);
+        s->m_tracker.m_frame = Fcur;
+        CHECK(s->m_tracker.m_nMaxCorners >= N);
+        CamData& D = cd[c];
+        D.slotPt.assign(N, -1), D.birth.assign(N, 0);
+        std::vector<char> used(NALL, 0);
+        for (int i = 0; i < N; ++i) {
+            const int p = (int)(urand() * NALL) % NALL;
+            if (used[p]) continue;   // one slot per (camera, point): MapPoint::pFeatures[iCam] holds one feature
+            used[p] = 1;
+            bool inside = true;      // tracked points stay in the image (chooseStaticFeatPts indexes its block table unchecked)
+            for (int f = 0; f <= Fcur && inside; ++f) {
+                double Rg[9], tg[3], M[3], m[2];
+                scene_pose(c, nc, f, Rg, tg);
+                for (int q = 0; q < 3; ++q) M[q] = P0[3 * p + q] + vel[3 * p + q] * f;
+                inside = proj(K, Rg, tg, M, m, W, H) && m[0] > 40 && m[1] > 40 && m[0] < W - 40 && m[1] < H - 40;
+            }
+            if (!inside) continue;
+            D.slotPt[i] = p;
+            D.birth[i] = urand() < 0.5 ? 0 : (int)(urand() * (Fcur + 1)) % (Fcur + 1);
+        }
+        D.xy.resize(Fcur + 1), D.R.resize(Fcur + 1), D.t.resize(Fcur + 1);
+        for (int f = 0; f <= Fcur; ++f) {
+            double Rg[9], tg[3];
+            scene_pose(c, nc, f, Rg, tg);
+            CamPoseItem* cam = nullptr;
+            if (f < Fcur) {   // past frames: the pose as solved then (truth + a little noise); Fcur's comes out of poseUpdate3D
+                double w[3] = {2e-4 * nrand(), 2e-4 * nrand(), 2e-4 * nrand()}, dRm[9], Re[9], te[3];
+                rodrigues(w, dRm);
+                mul33(Rg, dRm, Re);
+                for (int q = 0; q < 3; ++q) te[q] = tg[q] + 1e-3 * nrand();
+                cam = s->m_camPos.add(f, c, Re, te);
+                D.R[f].assign(Re, Re + 9), D.t[f].assign(te, te + 3);
+            }
+            D.xy[f].assign(2 * N, 0.0);
+            for (int i = 0; i < N; ++i) {
+                const int p = D.slotPt[i];
+                if (p < 0 || f < D.birth[i]) continue;
+                double M[3], m[2];
+                for (int q = 0; q < 3; ++q) M[q] = P0[3 * p + q] + vel[3 * p + q] * f;
+                double X[3];
+                for (int r = 0; r < 3; ++r) X[r] = Rg[3 * r] * M[0] + Rg[3 * r + 1] * M[1] + Rg[3 * r + 2] * M[2] + tg[r];
+                m[0] = (K[0] * X[0] + K[2] * X[2]) / X[2] + 0.5 * nrand() + (urand() < 0.02 ? 25 : 0);
+                m[1] = (K[4] * X[1] + K[5] * X[2]) / X[2] + 0.5 * nrand();
+                D.xy[f][i] = m[0], D.xy[f][N + i] = m[1];
+                FeaturePoint* fp = s->m_featPts.add(f, c, m[0], m[1]);
+                if (f < Fcur) fp->setIntrinsic(K), fp->setCameraPose(cam);
+                if (p < NMAP && f > D.birth[i]) {   // (a track's first feature carries no map point; the later ones do)
+                    fp->mpt = mpts[p];
+                    mpts[p]->pFeatures[c] = fp;
+                }
+                s->m_tracker.m_tks[i].add(fp);
+            }
+        }
+    }
+    // ---- what the device is given: the state BEFORE this frame's pose update ----
+    std::vector<double> hMap(3 * NMAP), hCov(9 * NMAP);
+    std::vector<unsigned char> hFlags(NMAP);
+    for (int i = 0; i < NMAP; ++i) {
+        memcpy(&hMap[3 * i], mpts[i]->M, 24);
+        memcpy(&hCov[9 * i], mpts[i]->cov, 72);
+        hFlags[i] = (mpts[i]->isLocalDynamic() ? CS_MAP_DYNAMIC : 0) | (mpts[i]->isFalse() ? CS_MAP_FALSE : 0) |
+                    (mpts[i]->isUncertain() ? CS_MAP_UNCERTAIN : 0);
+    }
+    std::vector<std::vector<int> > hState(nc), hS2M(nc), hSpan(nc);
+    std::vector<int> hPf((size_t)NMAP * nc, -1);
+    for (int c = 0; c < nc; ++c) {
+        hState[c].assign(N, -1), hS2M[c].assign(N, -1), hSpan[c].assign(2 * N, -1);
+        for (int i = 0; i < N; ++i) {
+            const int p = cd[c].slotPt[i];
+            if (p < 0) continue;
+            hState[c][i] = cd[c].birth[i] == Fcur ? 1 : 0;
+            hSpan[c][i] = cd[c].birth[i], hSpan[c][N + i] = Fcur;
+            if (p < NMAP && Fcur > cd[c].birth[i] && !mpts[p]->isFalse()) {   // (propagateFeatureStates :48: not onto a false point)
+                hS2M[c][i] = p;
+                hPf[(size_t)p * nc + c] = i;
+            }
+        }
+    }
+    // a false map point's feature loses the point in propagateFeatureStates only because the harness attached it above; detach
+    // it on the reference's side too so that both sides start from the same association
+    for (int c = 0; c < nc; ++c)
+        for (int i = 0; i < N; ++i) {
+            Track2D& tk = co->slam[c].m_tracker.m_tks[i];
+            if (!tk.empty() && tk.tail->pt->mpt && tk.tail->pt->mpt->isFalse()) tk.tail->pt->mpt = nullptr;
+        }
+
+    // ---- the reference: camera after camera ----
+    std::vector<int> refNum(nc), refDyn(nc);
+    std::vector<double> Rnew(9 * nc), tnew(3 * nc);
+    for (int c = 0; c < nc; ++c) {
+        refNum[c] = co->slam[c].poseUpdate3D(false);
+        CHECK(refNum[c] > 50);
+        refDyn[c] = co->slam[c].detectDynamicFeaturePoints(20, 5, 3, Const::MAX_EPI_ERR);
+        CamPoseItem* cur = co->slam[c].m_camPos.current();
+        CHECK(cur && cur->f == Fcur);
+        memcpy(&Rnew[9 * c], cur->R, 72), memcpy(&tnew[3 * c], cur->t, 24);
+    }
+
+    // ---- the device: the history ring filled frame by frame, then ONE launch for the frame ----
+    cs_track_history* hist = cs_track_history_create(0, nc, N, 32);
+    CHECK(hist != nullptr);
+    double *dK, *diK, *dR, *dT, *dMap, *dCov;
+    unsigned char* dFlags;
+    int *dPf, *dCnt;
+    hipMalloc((void**)&dK, 72), hipMalloc((void**)&diK, 72), hipMalloc((void**)&dR, 72 * nc), hipMalloc((void**)&dT, 24 * nc);
+    hipMalloc((void**)&dMap, 24 * NMAP), hipMalloc((void**)&dCov, 72 * NMAP), hipMalloc((void**)&dFlags, NMAP);
+    hipMalloc((void**)&dPf, 4 * NMAP * nc), hipMalloc((void**)&dCnt, 4 * 3 * nc);
+    hipMemcpy(dK, K, 72, hipMemcpyHostToDevice), hipMemcpy(diK, iK, 72, hipMemcpyHostToDevice);
+    hipMemcpy(dMap, hMap.data(), 24 * NMAP, hipMemcpyHostToDevice), hipMemcpy(dCov, hCov.data(), 72 * NMAP, hipMemcpyHostToDevice);
+    hipMemcpy(dFlags, hFlags.data(), NMAP, hipMemcpyHostToDevice), hipMemcpy(dPf, hPf.data(), 4 * NMAP * nc, hipMemcpyHostToDevice);
+    std::vector<cs_poseupdate_cam> pc(nc);
+    std::vector<double*> dXY(nc), dErr(nc);
+    std::vector<int*> dState(nc), dS2M(nc), dSpan(nc), dDead(nc);
+    std::vector<unsigned char*> dStat(nc);
+    std::vector<int> dead(N, -1);
+    for (int c = 0; c < nc; ++c) {
+        hipMalloc((void**)&dXY[c], 16 * N), hipMalloc((void**)&dErr[c], 8 * N), hipMalloc((void**)&dState[c], 4 * N);
+        hipMalloc((void**)&dS2M[c], 4 * N), hipMalloc((void**)&dSpan[c], 8 * N), hipMalloc((void**)&dStat[c], N);
+        hipMalloc((void**)&dDead[c], 4 * N);
+        hipMemset(dErr[c], 0, 8 * N);
+        hipMemset(dStat[c], 1, N);   // every earlier feature was TYPE_FEATPOINT_STATIC
+        hipMemcpy(dDead[c], dead.data(), 4 * N, hipMemcpyHostToDevice);
+        hipMemcpy(dS2M[c], hS2M[c].data(), 4 * N, hipMemcpyHostToDevice);
+        hipMemcpy(dSpan[c], hSpan[c].data(), 8 * N, hipMemcpyHostToDevice);
+        memset(&pc[c], 0, sizeof(pc[c]));
+        pc[c].K = dK, pc[c].iK = diK, pc[c].xy = dXY[c], pc[c].state = dDead[c], pc[c].slot2map = dS2M[c], pc[c].trackSpan = dSpan[c];
+        pc[c].reprojErr = dErr[c], pc[c].isStatic = dStat[c];
+    }
+    for (int f = 0; f < Fcur; ++f) {   // past frames: only the ring is written (no slot is live in `state`)
+        for (int c = 0; c < nc; ++c) {
+            hipMemcpy(dXY[c], cd[c].xy[f].data(), 16 * N, hipMemcpyHostToDevice);
+            hipMemcpy(dR + 9 * c, cd[c].R[f].data(), 72, hipMemcpyHostToDevice);
+            hipMemcpy(dT + 3 * c, cd[c].t[f].data(), 24, hipMemcpyHostToDevice);
+        }
+        CHECK(cs_detect_dynamic_dev(hist, nullptr, 0, nc, pc.data(), dR, dT, NMAP, dFlags, f, 20, 5, 3, Const::MAX_EPI_ERR, nullptr) == CS_OK);
+        CHECK(hipDeviceSynchronize() == hipSuccess);
+    }
+    for (int c = 0; c < nc; ++c) {
+        hipMemcpy(dXY[c], cd[c].xy[Fcur].data(), 16 * N, hipMemcpyHostToDevice);
+        hipMemcpy(dState[c], hState[c].data(), 4 * N, hipMemcpyHostToDevice);
+        pc[c].state = dState[c];
+    }
+    hipMemcpy(dR, Rnew.data(), 72 * nc, hipMemcpyHostToDevice), hipMemcpy(dT, tnew.data(), 24 * nc, hipMemcpyHostToDevice);
+    CHECK(cs_pose_update_frame_dev(hist, nullptr, pc.data(), dPf, NMAP, dR, dT, dMap, dCov, dFlags, 0, Const::PIXEL_ERR_VAR, Fcur, 20, 5, 3,
+                                   Const::MAX_EPI_ERR, dCnt, dCnt + nc, dCnt + 2 * nc) == CS_OK);
+    CHECK(hipDeviceSynchronize() == hipSuccess);
+    CHECK(cs_track_history_frames(hist) == Fcur + 1);
+
+    // ---- compare ----
+    std::vector<double> gMap(3 * NMAP), gCov(9 * NMAP);
+    std::vector<unsigned char> gFlags(NMAP);
+    std::vector<int> gCnt(3 * nc);
+    hipMemcpy(gMap.data(), dMap, 24 * NMAP, hipMemcpyDeviceToHost), hipMemcpy(gCov.data(), dCov, 72 * NMAP, hipMemcpyDeviceToHost);
+    hipMemcpy(gFlags.data(), dFlags, NMAP, hipMemcpyDeviceToHost), hipMemcpy(gCnt.data(), dCnt, 12 * nc, hipMemcpyDeviceToHost);
+    double dM = 0, dC = 0, dE = 0;
+    int nRefined = 0, nUncertainNew = 0, nDynFeat = 0, nOutAll = 0;
+    for (int i = 0; i < NMAP; ++i) {
+        for (int q = 0; q < 3; ++q) dM = fmax(dM, fabs(gMap[3 * i + q] - mpts[i]->M[q]));
+        for (int q = 0; q < 9; ++q) dC = fmax(dC, fabs(gCov[9 * i + q] - mpts[i]->cov[q]));
+        nRefined += memcmp(&hMap[3 * i], mpts[i]->M, 24) != 0;
+        const unsigned char want = (mpts[i]->isLocalDynamic() ? CS_MAP_DYNAMIC : 0) | (mpts[i]->isFalse() ? CS_MAP_FALSE : 0) |
+                                   (mpts[i]->isUncertain() ? CS_MAP_UNCERTAIN : 0);
+        CHECK(gFlags[i] == want);
+        nUncertainNew += (want & CS_MAP_UNCERTAIN) && !(hFlags[i] & CS_MAP_UNCERTAIN);
+    }
+    for (int c = 0; c < nc; ++c) {
+        std::vector<double> gErr(N);
+        std::vector<unsigned char> gStat(N);
+        hipMemcpy(gErr.data(), dErr[c], 8 * N, hipMemcpyDeviceToHost), hipMemcpy(gStat.data(), dStat[c], N, hipMemcpyDeviceToHost);
+        for (int i = 0; i < N; ++i) {
+            const Track2D& tk = co->slam[c].m_tracker.m_tks[i];
+            if (tk.empty()) continue;
+            const FeaturePoint* fp = tk.tail->pt;
+            CHECK(fp->f == Fcur);
+            dE = fmax(dE, fabs(gErr[i] - fp->reprojErr));
+            CHECK((gStat[i] != 0) == (fp->type == TYPE_FEATPOINT_STATIC));
+            nDynFeat += fp->type == TYPE_FEATPOINT_DYNAMIC;
+        }
+        CHECK(gCnt[c] == refNum[c]);            // poseUpdate3D's return value: the number of nodes
+        CHECK(gCnt[2 * nc + c] == refDyn[c]);   // detectDynamicFeaturePoints' return value
+        nOutAll += gCnt[nc + c];
+    }
+    CHECK(nOutAll == nUncertainNew);            // every outlier made its (distinct) point uncertain
+    CHECK(dM == 0 && dC == 0 && dE == 0);       // same arithmetic in the same order: bit for bit
+    CHECK(nRefined > 150 && nUncertainNew > 3 && nDynFeat > 30);
+    printf("poseUpdate3D + detectDynamicFeaturePoints drop-in ok: %d cameras one after the other vs one launch: nodes %d / %d / %d, "
+           "%d map points refined by seqTriangulate, %d made uncertain, %d features dynamic (%d / %d / %d found this frame); points, "
+           "covariances, reprojErr identical\n", nc, refNum[0], refNum[1], refNum[2], nRefined, nUncertainNew, nDynFeat, refDyn[0],
+           refDyn[1], refDyn[2]);
+    cs_track_history_destroy(hist);
+    return 0;
+}
+
 int main() {
-    if (test_robust_bundle_rts()) return 1;
-    if (test_inter_cam_pose_estimator()) return 1;
+    setvbuf(stdout, nullptr, _IOLBF, 0);
+    const char* only = getenv("DROPIN_PART");   // (debugging aid: run one part)
+    if ((!only || atoi(only) == 1) && test_robust_bundle_rts()) return 1;
+    if ((!only || atoi(only) == 2) && test_inter_cam_pose_estimator()) return 1;
+    if ((!only || atoi(only) == 3) && test_pose_update3d_and_dynamic_points()) return 1;
     printf("ref BA callers drop-in ok\n");
     return 0;
 }

@@ -1,0 +1,153 @@
+"""poseUpdate3D's gate + seqTriangulate loop and detectDynamicFeaturePoints on the device (cs_pose_update3d_dev,
+cs_detect_dynamic_dev, cs_pose_update_frame_dev) against the oracle's restatement of the reference's loops
+(src/app/SL_SingleSLAM.cpp:672-708, 784-824), frame after frame with the state carried along on both sides."""
+import numpy as np
+import pytest
+
+from tests.poseupdate_scene import Scene
+
+pytestmark = pytest.mark.gpu
+
+SIGMA = 10.0   # Const::PIXEL_ERR_VAR (src/app/SL_GlobParam.cpp:37)
+MAX_EPI = 6.0  # Const::MAX_EPI_ERR (:36)
+
+
+def _run(mode, largeErr=0, H=32, T=14):
+    import torch
+
+    import oracle
+    from coslam_amd.poseupdate import TrackHistory, pose_update3d_dev
+
+    sc = Scene(T=T)
+    nC, N, nMap = sc.nC, sc.N, sc.nMap
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    # oracle state
+    o_map, o_cov, o_fl = sc.map0.copy(), sc.cov0.copy(), sc.flags0.copy()
+    o_err = [np.zeros(N) for _ in range(nC)]
+    o_stat = [np.ones(N, dtype=np.uint8) for _ in range(nC)]
+    hist = [dict(R=[], t=[], xy=[]) for _ in range(nC)]
+    # device state
+    d_map = torch.from_numpy(sc.map0.copy()).to(dev)
+    d_cov = torch.from_numpy(sc.cov0.copy()).to(dev)
+    d_fl = torch.from_numpy(sc.flags0.copy()).to(dev)
+    d_err = [torch.zeros(N, dtype=torch.float64, device=dev) for _ in range(nC)]
+    d_stat = [torch.ones(N, dtype=torch.uint8, device=dev) for _ in range(nC)]
+    d_K = torch.from_numpy(sc.K.reshape(9).copy()).to(dev)
+    d_iK = torch.from_numpy(sc.iK.reshape(9).copy()).to(dev)
+    d_cnt = torch.zeros(3, nC, dtype=torch.int32, device=dev)
+    th = TrackHistory(nC, N, H)
+    exact = True
+    n_dyn_total = n_out_total = n_in_total = 0
+    for f in range(sc.T):
+        recs = sc.frame(f)
+        pf = Scene.point_feat(recs, nMap)
+        Rs = np.stack([sc.Re[f][c].reshape(9) for c in range(nC)])
+        ts = np.stack([sc.te[f][c] for c in range(nC)])
+        # ---- oracle: the cameras one after the other, gate then dynamic test (CoSLAM::parallelPoseUpdate) ----
+        res = oracle.pose_update_gate([sc.K] * nC, Rs, ts, [r["xy"] for r in recs], [r["state"] for r in recs],
+                                      [r["slot2map"] for r in recs], o_map, o_cov, o_fl, largeErr, SIGMA, o_err)
+        o_dyn = []
+        for c in range(nC):
+            h = hist[c]
+            h["R"].insert(0, Rs[c]), h["t"].insert(0, ts[c]), h["xy"].insert(0, recs[c]["xy"].copy())
+            del h["R"][H:], h["t"][H:], h["xy"][H:]
+            o_dyn.append(oracle.detect_dynamic(sc.iK, np.stack(h["R"]), np.stack(h["t"]), np.stack(h["xy"]), recs[c]["state"],
+                                               recs[c]["slot2map"], recs[c]["trackSpan"], o_fl, 20, 5, 3, MAX_EPI, o_stat[c]))
+        # ---- device ----
+        keep, cams = [], []
+        for c, r in enumerate(recs):
+            t_ = {k: torch.from_numpy(v).to(dev) for k, v in r.items()}
+            keep.append(t_)
+            cams.append(dict(K=d_K.data_ptr(), iK=d_iK.data_ptr(), xy=t_["xy"].data_ptr(), state=t_["state"].data_ptr(),
+                             slot2map=t_["slot2map"].data_ptr(), trackSpan=t_["trackSpan"].data_ptr(),
+                             reprojErr=d_err[c].data_ptr(), isStatic=d_stat[c].data_ptr()))
+        d_pf = torch.from_numpy(pf).to(dev)
+        d_R, d_t = torch.from_numpy(Rs).to(dev), torch.from_numpy(ts).to(dev)
+        if mode == "fused":
+            th.pose_update_frame_dev(s, cams, d_pf.data_ptr(), nMap, d_R.data_ptr(), d_t.data_ptr(), d_map.data_ptr(),
+                                     d_cov.data_ptr(), d_fl.data_ptr(), largeErr, SIGMA, f, maxEpiErr=MAX_EPI,
+                                     d_numNodes=d_cnt[0].data_ptr(), d_numOut=d_cnt[1].data_ptr(), d_numDyn=d_cnt[2].data_ptr())
+        else:   # camera by camera (the serial caller) through the two separate entry points
+            for c in range(nC):
+                pose_update3d_dev(s, cams, N, d_pf.data_ptr(), nMap, d_R.data_ptr(), d_t.data_ptr(), d_map.data_ptr(),
+                                  d_cov.data_ptr(), d_fl.data_ptr(), largeErr, SIGMA, d_cnt[0].data_ptr(), d_cnt[1].data_ptr(),
+                                  cam0=c, nCamsRun=1)
+                th.detect_dynamic_dev(s, cams, d_R.data_ptr(), d_t.data_ptr(), nMap, d_fl.data_ptr(), f, maxEpiErr=MAX_EPI,
+                                      d_numDyn=d_cnt[2].data_ptr(), cam0=c, nCamsRun=1)
+        torch.cuda.synchronize()
+        assert th.frames == min(f + 1, H)
+        cnt = d_cnt.cpu().numpy()
+        assert cnt[0].tolist() == [r[0] for r in res], f"nodes, frame {f}"
+        assert cnt[1].tolist() == [r[1] for r in res], f"numOut, frame {f}"
+        assert cnt[2].tolist() == o_dyn, f"numDyn, frame {f}"
+        assert np.array_equal(d_fl.cpu().numpy(), o_fl), f"map flags, frame {f}"
+        for c in range(nC):
+            assert np.array_equal(d_stat[c].cpu().numpy(), o_stat[c]), f"feature types, frame {f} camera {c}"
+            g = d_err[c].cpu().numpy()
+            np.testing.assert_allclose(g, o_err[c], rtol=1e-11, atol=1e-13)
+            exact &= np.array_equal(g, o_err[c])
+        gm, gc = d_map.cpu().numpy(), d_cov.cpu().numpy()
+        np.testing.assert_allclose(gm, o_map, rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(gc, o_cov, rtol=1e-9, atol=1e-16)
+        exact &= np.array_equal(gm, o_map) and np.array_equal(gc, o_cov)
+        n_dyn_total += sum(o_dyn)
+        n_out_total += sum(r[1] for r in res)
+        n_in_total += sum(r[0] - r[1] for r in res)
+    # the scene exercises every branch
+    assert n_dyn_total > 20 and n_out_total > 5 and n_in_total > 500
+    assert (o_fl & 4).sum() > (sc.flags0 & 4).sum()          # points were made uncertain
+    assert not np.array_equal(o_map, sc.map0)                 # and points were refined
+    assert all((st == 0).sum() > 3 for st in o_stat)          # dynamic features in every camera
+    th.close()
+    return exact
+
+
+@pytest.mark.parametrize("mode", ["fused", "serial"])
+def test_pose_update_gate_and_dynamic_test_match_the_oracle_frame_after_frame(mode):
+    exact = _run(mode)
+    assert exact, "floating-point outputs agree within tolerance but not bit for bit"
+
+
+def test_large_err_gate_and_a_short_history_ring():
+    # largeErr: the 6.0 gate (SL_SingleSLAM.cpp:673); a ring shorter than the tracks bounds the walk on both sides alike
+    _run("fused", largeErr=1, H=6)
+
+
+def test_history_is_dropped_when_the_frame_numbers_jump():
+    import torch
+
+    from coslam_amd.poseupdate import TrackHistory
+
+    sc = Scene(T=3)
+    dev = torch.device("cuda:0")
+    th = TrackHistory(sc.nC, sc.N, 8)
+    d_K = torch.from_numpy(sc.K.reshape(9).copy()).to(dev)
+    d_iK = torch.from_numpy(sc.iK.reshape(9).copy()).to(dev)
+    d_fl = torch.from_numpy(sc.flags0.copy()).to(dev)
+    keep = []
+    for frame in (0, 1, 2, 7, 8):
+        recs = sc.frame(min(frame, 2))
+        cams = []
+        for r in recs:
+            t_ = {k: torch.from_numpy(v).to(dev) for k, v in r.items()}
+            st = torch.ones(sc.N, dtype=torch.uint8, device=dev)
+            keep += [t_, st]
+            cams.append(dict(K=d_K.data_ptr(), iK=d_iK.data_ptr(), xy=t_["xy"].data_ptr(), state=t_["state"].data_ptr(),
+                             slot2map=t_["slot2map"].data_ptr(), trackSpan=t_["trackSpan"].data_ptr(), isStatic=st.data_ptr()))
+        Rs = torch.from_numpy(np.stack([sc.Re[0][c].reshape(9) for c in range(sc.nC)])).to(dev)
+        ts = torch.from_numpy(np.stack([sc.te[0][c] for c in range(sc.nC)])).to(dev)
+        th.detect_dynamic_dev(torch.cuda.current_stream().cuda_stream, cams, Rs.data_ptr(), ts.data_ptr(), sc.nMap, d_fl.data_ptr(), frame)
+        torch.cuda.synchronize()
+        assert th.frames == {0: 1, 1: 2, 2: 3, 7: 1, 8: 2}[frame]
+    th.close()
+
+
+def test_bad_arguments_are_refused():
+    from coslam_amd._lib import CoslamHipError
+    from coslam_amd.poseupdate import TrackHistory, pose_update3d_dev
+
+    with pytest.raises(CoslamHipError):
+        TrackHistory(3, 100, 100000)
+    with pytest.raises(CoslamHipError):
+        pose_update3d_dev(0, [dict()], 10, 0, 5, 0, 0, 0, 0, 0, 0, SIGMA)
