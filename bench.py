@@ -51,6 +51,7 @@ N_COL_BLK, N_ROW_BLK = 16, 12
 KEY_EVERY = 5
 P_REG = 1536             # map points per registration pass (the size of the inter-camera solve's static set)
 PIXEL_ERR_VAR = 10.0      # Const::PIXEL_ERR_VAR, reference src/app/SL_GlobParam.cpp:37
+MAX_EPI_ERR = 6.0         # Const::MAX_EPI_ERR, :36
 HBM_PEAK_GBS = 8000.0
 SEED = 0xC051A + 2
 
@@ -132,10 +133,10 @@ def build_pose_graphs(sc, joint, cams, n_kf=5, kf_step=5):
     return graphs, np.array(R), np.array(T), camNode
 
 
-def reg_covariances():
-    """MapPoint::cov of the 2 x P_REG registered points: synthetic SPD 3 x 3, a few cm"""
+def reg_covariances(n=None):
+    """MapPoint::cov of the first n map points (default: the 2 x P_REG registered ones): synthetic SPD 3 x 3, a few cm"""
     rng = np.random.default_rng(SEED + 23)
-    A = rng.normal(size=(2 * P_REG, 3, 3)) * 0.02
+    A = rng.normal(size=(2 * P_REG if n is None else max(n, 2 * P_REG), 3, 3)) * 0.02
     return A @ A.transpose(0, 2, 1) + 1e-6 * np.eye(3)
 
 
@@ -170,7 +171,7 @@ def export_workload(path, sc, frames, joint, ic, cams_per_launch):
             f.write(np.ascontiguousarray(uv[idx], np.float64).tobytes())
         f.write(np.stack([sc.pose(c, order[0])[0].ravel() for c in range(N_CAMS)]).astype(np.float64).tobytes())
         f.write(np.stack([sc.pose(c, order[0])[1] for c in range(N_CAMS)]).astype(np.float64).tobytes())
-        f.write(np.ascontiguousarray(reg_covariances(), np.float64).tobytes())
+        f.write(np.ascontiguousarray(reg_covariances(len(sc.points)), np.float64).tobytes())   # MapPoint::cov of every map point
         for pr, ncon, npcon, mi, inner in ((joint, joint["n_cams_con"], joint["n_pts_con"], 2, 10), (ic, 0, ic["n_static"], 3, 40)):
             ptr, cam, xy = csr(pr)
             f.write(np.asarray([len(pr["Rs0"]), len(pr["pts0"]), len(cam), ncon, npcon, mi, inner], np.int32).tobytes())
@@ -232,24 +233,42 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
     def cam_step(c, f, frame_no):
         _, d = trk[c].redetect(frames[c][f])
         trk[c].advanceFrame()
-        hb = oracle.handback(d, W, H, sc.K, kud, sc.points, s2m[c], tl[c], xy[c], frame_no)
+        hb = oracle.handback(d, W, H, sc.K, kud, map_pts, s2m[c], tl[c], xy[c], frame_no, isStatic=is_static[c])
         st[c] = hb["state"]
         if hb["npts"] >= 6:
             ok, R, t, _ = oracle.intracam_estimate(sc.K, Rc[c], tc[c], hb["npts"], None, hb["Ms"], hb["ms"], 10.0)
             if ok:
                 Rc[c], tc[c] = R, t
 
-    cov = reg_covariances()
+    cov = reg_covariances(len(sc.points))
     no_feat = np.full((P_REG, 1), -1, dtype=np.int32)
+    # poseUpdate3D's gate + seqTriangulate and the dynamic-point test: camera after camera on the calling thread (they share the map)
+    map_pts, map_cov = sc.points.copy(), np.ascontiguousarray(cov[:len(sc.points)].reshape(-1, 9))
+    map_flags = np.zeros(len(sc.points), dtype=np.uint8)
+    reproj = [np.zeros(N_FEAT) for _ in range(N_CAMS)]
+    is_static = [np.ones(N_FEAT, dtype=np.uint8) for _ in range(N_CAMS)]
+    hist = [dict(R=[], t=[], xy=[]) for _ in range(N_CAMS)]
+    iK = np.linalg.inv(sc.K)
+
+    def pose_update_all(frame_no):
+        for c in range(N_CAMS):
+            oracle.pose_update_gate([Kc] * N_CAMS, np.stack([r.reshape(9) for r in Rc]), np.stack(tc), xy, st, s2m, map_pts, map_cov,
+                                    map_flags, 0, PIXEL_ERR_VAR, reproj, cams=[c])
+            h = hist[c]
+            h["R"].insert(0, Rc[c].reshape(9).copy()), h["t"].insert(0, tc[c].copy()), h["xy"].insert(0, xy[c].copy())
+            del h["R"][64:], h["t"][64:], h["xy"][64:]
+            oracle.detect_dynamic(iK, np.stack(h["R"]), np.stack(h["t"]), np.stack(h["xy"]), st[c], s2m[c], tl[c], map_flags, 20, 5, 3,
+                                  MAX_EPI_ERR, is_static[c])
+
     Kc = sc.K
 
     def reg_step(c):
         # activeMapPointsRegister + currentMapPointsRegister, search step, this camera's column of the tables
         one = lambda a: [a]  # noqa: E731
-        oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), sc.points[P_REG:2 * P_REG],
-                               cov[P_REG:], no_feat, 2.5 * PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)
+        oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), map_pts[P_REG:2 * P_REG],
+                               cov[P_REG:2 * P_REG], no_feat, 2.5 * PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)
         pf = oracle.point_features(st[c], s2m[c], P_REG).reshape(P_REG, 1)
-        oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), sc.points[:P_REG],
+        oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), map_pts[:P_REG],
                                cov[:P_REG], pf, PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)
 
     def run_cams(cams, f, frame_no):
@@ -271,6 +290,7 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
                 x.start()
             for x in th:
                 x.join()
+        pose_update_all(n + 1)
         if n % KEY_EVERY == 0:
             jR, jT = oracle.ba_robust(joint["Ks"], joint["Rs0"], joint["ts0"], joint["pts0"], jptr, jcam, jxy,
                                       joint["n_cams_con"], joint["n_pts_con"], 6.0, 2, 10)[:2]
@@ -308,7 +328,7 @@ def main():
                          "fastest tracker, 146 us per frame).  3 or 4 = launches of <= 3 / 4 cameras back to back at ONE wave per SIMD "
                          "(tracker 203 us per frame with 4): every SIMD keeps a free wave slot and every CU 96 KB of LDS for the "
                          "key-frame solves' kernels, whose latency chain -- not the tracker -- bounds the loop: measured +6 % (4) / "
-                         "+8 % (3) frames/s (profiles/r03_tracker_split.txt).  -1 (default) = 3 when all 8 cameras are on this GPU, else 0")
+                         "+8 % (3) frames/s (profiles/r03_tracker_split.txt).  -1 (default) = 4 when all 8 cameras are on this GPU, else 0")
     ap.add_argument("--reg-stream", type=int, default=int(os.environ.get("BENCH_REG_STREAM", "0")),
                     help="1: the two registration passes of frame f on their own stream behind pose(f) -- they are consumers of the "
                          "frame's poses and features, nothing of frame f+1's tracking or pose depends on them, so they overlap the next "
@@ -323,6 +343,8 @@ def main():
     ap.add_argument("--ba-prebaked", action="store_true",
                     help="the joint local BA re-solves ONE pre-baked synthetic problem at every key frame (rounds 1-2) instead of the problem "
                          "parsed on the device from the last 5 key frames' tracked features and poses (N = 1 default: cs_ba_window_*)")
+    ap.add_argument("--no-pose-update", action="store_true",
+                    help="skip poseUpdate3D's gate + seqTriangulate loop and the dynamic-point test behind the pose solve")
     ap.add_argument("--no-ncc", action="store_true", help="diagnostic: skip the inter-camera NCC matching leg (not a valid bench line)")
     ap.add_argument("--no-cxx-loop", action="store_true", help="skip the C++ frame loop (tools/cxx/frame_loop.bin, config.cxx_frame_loop)")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the upload-inclusive repetition of the loop (config.with_upload)")
@@ -393,8 +415,9 @@ def main():
     d_opt = torch.zeros((nc, 96), dtype=torch.uint8, device=dev)
     d_ok = torch.zeros(nc, dtype=torch.int32, device=dev)
     # map-point registration: P x nCams tables (this rank's cameras are its columns), covariances of the 2 x P_REG points
-    d_cov = torch.from_numpy(reg_covariances().reshape(-1).copy()).to(dev)
-    d_pf = torch.full((P_REG, nc), -1, dtype=torch.int32, device=dev)           # written by the hand-back every frame
+    n_map = len(sc.points)
+    d_cov = torch.from_numpy(reg_covariances(n_map).reshape(-1).copy()).to(dev)  # MapPoint::cov of every map point
+    d_pf = torch.full((n_map, nc), -1, dtype=torch.int32, device=dev)           # MapPoint::pFeatures of this frame: written by the hand-back
     d_pf_none = torch.full((P_REG, nc), -1, dtype=torch.int32, device=dev)      # active points: no feature of this frame
     reg_out = [dict(slot=torch.zeros((P_REG, nc), dtype=torch.int32, device=dev), m=torch.zeros((P_REG, nc, 2), dtype=torch.float64, device=dev),
                     var=torch.zeros((P_REG, nc, 4), dtype=torch.float64, device=dev), dist=torch.zeros((P_REG, nc), dtype=torch.float64, device=dev),
@@ -451,7 +474,7 @@ def main():
             for t in trks:
                 t.set_cu_count(256 - persist_j - persist_i)
     if args.klt_cams_per_launch < 0:
-        args.klt_cams_per_launch = 3 if (nc == N_CAMS and not args.serial) else 0
+        args.klt_cams_per_launch = 4 if (nc == N_CAMS and not args.serial) else 0
     if args.klt_cams_per_launch > 0 and not args.klt_cus:
         # the co-residency budget of the persistent tracker is what decides how many cameras share a launch: hand it the
         # budget of cams_per_launch cameras (250 waves each, 8 resident waves per CU) -- no CU mask, the launches still spread
@@ -543,12 +566,32 @@ def main():
     pose_done = torch.cuda.Event()
     pose_ready, reg_done = torch.cuda.Event(), torch.cuda.Event()
 
+    # poseUpdate3D's second half + detectDynamicFeaturePoints (reference src/app/SL_SingleSLAM.cpp:672-708, 784-824), every frame
+    # behind the pose solve, one launch for all cameras: the Mahalanobis gate and seqTriangulate refine the map points and their
+    # covariances IN PLACE (what the next frame's hand-back, the registration and the BA window then read), the dynamic test
+    # walks a ring of the last 64 frames' pixels and poses and sets the feature types the next hand-back's block vote takes.
+    # N > 1: this rank's cameras only (the map is a per-rank replica there).
+    pose_upd = None
+    if not args.no_pose and not args.no_pose_update:
+        from coslam_amd.poseupdate import TrackHistory, poseupdate_cams
+
+        PU_HIST = 64
+        d_isstatic = torch.ones((nc, N_FEAT), dtype=torch.uint8, device=dev)
+        d_reproj = torch.zeros((nc, N_FEAT), dtype=torch.float64, device=dev)
+        d_mapflags = torch.zeros(n_map, dtype=torch.uint8, device=dev)
+        d_iK1 = torch.from_numpy(np.linalg.inv(sc.K).ravel().copy()).to(dev)
+        pose_upd = TrackHistory(nc, N_FEAT, PU_HIST, device=local_rank)
+        pu_args = poseupdate_cams([dict(K=d_K1.data_ptr(), iK=d_iK1.data_ptr(), xy=d_xy[i].data_ptr(), state=d_state[i].data_ptr(),
+                                        slot2map=d_slot2map[i].data_ptr(), trackSpan=d_trackspan[i].data_ptr(),
+                                        reprojErr=d_reproj[i].data_ptr(), isStatic=d_isstatic[i].data_ptr()) for i in range(nc)])
+
     def hb_cams(b):
         return [dict(dest=d_dests[b][i].data_ptr(), K=d_K1.data_ptr(), kud=d_kud.data_ptr(), mapPts=d_map.data_ptr(),
                      slot2map=d_slot2map[i].data_ptr(), trackSpan=d_trackspan[i].data_ptr(), xy=d_xy[i].data_ptr(),
                      state=d_state[i].data_ptr(), Ms=d_Ms[i].data_ptr(), ms=d_ms[i].data_ptr(), sel=d_sel[i].data_ptr(),
                      npts=d_npts[i:i + 1].data_ptr(), opt=d_opt[i].data_ptr(), pointFeat=d_pf.data_ptr() + 4 * i,
-                     pointFeatStride=nc, nPointFeat=P_REG) for i in range(nc)]
+                     pointFeatStride=nc, nPointFeat=n_map, isStatic=(d_isstatic[i].data_ptr() if pose_upd is not None else 0))
+                for i in range(nc)]
 
     hb_args = [handback_cams(hb_cams(0)), handback_cams(hb_cams(1))]   # ctypes arrays, built once
     dest_ptrs = [[d.data_ptr() for d in d_dests[b]] for b in range(2)]
@@ -565,6 +608,11 @@ def main():
                                    d_t[src].data_ptr(), d_npts.data_ptr(), 0, d_Ms.data_ptr(), d_ms.data_ptr(), 10.0,
                                    d_R[dst].data_ptr(), d_t[dst].data_ptr(), d_opt.data_ptr(), d_ok.data_ptr(),
                                    device=local_rank)
+        if pose_upd is not None:
+            # parallelPoseUpdate(false): gate 2.0, sigma = PIXEL_ERR_VAR; detectDynamicFeaturePoints(20, 5, 3, MAX_EPI_ERR)
+            pose_upd.pose_update_frame_dev(pose_s.cuda_stream, pu_args, d_pf.data_ptr(), n_map, d_R[dst].data_ptr(),
+                                           d_t[dst].data_ptr(), d_map.data_ptr(), d_cov.data_ptr(), d_mapflags.data_ptr(), 0,
+                                           PIXEL_ERR_VAR, i, 20, 5, 3, MAX_EPI_ERR)
         if not args.no_register:
             if reg_s is not pose_s:
                 pose_ready.record(pose_s)
@@ -1097,7 +1145,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "8 cams 640x480 x 2000 KLT slots (50x40), 4-level pyramid, 7x7 window, 10 it/level with "
                                    "gain, redetect every frame; on-device hand-back + intraCamEstimate of all 8 cameras "
-                                   "every frame (fed by the tracker's output); map-point registration search every frame "
+                                   "every frame (fed by the tracker's output)"
+                                   + ("" if pose_upd is None else ", then poseUpdate3D's Mahalanobis gate + seqTriangulate refinement of the "
+                                      "map points and the dynamic-point test (64-frame history)") + "; map-point registration search every frame "
                                    f"(active + current static, {P_REG} points each x 8 cams x 2000 slots); "
                                    f"every {KEY_EVERY}th frame: joint local BA "
                                    + (f"C=40 (16 fixed), parsed on the device from the last 5 key frames' tracked features and poses "
@@ -1125,6 +1175,13 @@ def main():
                        "register_candidates_last_frame": None if args.no_register else
                        {"active": int((reg_out[0]["slot"] >= 0).sum().item()), "current_static": int((reg_out[1]["slot"] >= 0).sum().item()),
                         "already_attached": int((reg_out[1]["slot"] == -1).sum().item())},
+                       "pose_update": None if pose_upd is None else {
+                           "what": "poseUpdate3D's gate + seqTriangulate over all static mapped features and detectDynamicFeaturePoints over "
+                                   "all unmapped / dynamic tracks, every frame, one launch for the rank's cameras (cs_pose_update_frame_dev)",
+                           "history_frames": pose_upd.frames, "map_points_uncertain": int((d_mapflags & 4).ne(0).sum().item()),
+                           "map_points_refined": int((d_map - torch.from_numpy(sc.points).to(dev)).abs().amax(dim=1).gt(0).sum().item()),
+                           "features_dynamic_last_frame": [int(v) for v in ((d_isstatic == 0) & (d_state >= 0)).sum(dim=1).cpu().tolist()],
+                           "static_mapped_features_last_frame": [int(v) for v in ((d_state >= 0) & (d_slot2map >= 0)).sum(dim=1).cpu().tolist()]},
                        "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "host_enqueue_ms_max_step": t_step_max * 1e3, "host_enqueue_max_at_step": i_step_max, "tracker_stream_cus": args.klt_cus or "all",
                        "ncc_matching": None if ncc is None else {
                            "every_frames": NCC_EVERY, "camera_pairs_per_run": nc - 1, "runs": ncc["runs"],

@@ -188,7 +188,7 @@ class BAWindow:
         c, p, o, pm = C.c_int(0), C.c_int(0), C.c_int(0), C.c_void_p()
         kf = (C.c_int * self.n_key_frames)()
         check(self._L.cs_ba_window_last_problem(self._h, C.byref(c), C.byref(p), C.byref(o), C.byref(pm), kf), "cs_ba_window_last_problem")
-        return c.value, p.value, o.value, pm.value, list(kf)
+        return c.value, p.value, o.value, pm.value, [f for f in kf if f >= 0]
 
     def close(self):
         if self._h:

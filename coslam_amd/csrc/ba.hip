@@ -2872,6 +2872,7 @@ struct BaAsyncJob {
     struct cs_ba_window* win = nullptr;  // cs_ba_solve_window_async: the problem is built on the device from this window
     const double* d_map = nullptr;
     const unsigned char* d_mapStatic = nullptr;
+    int winCount = 0, winSlotOf[16], winFrames[16];  // the window as it stood when the solve was requested (oldest first)
 };
 
 struct BaWorker {
@@ -2937,14 +2938,99 @@ static int ba_capture(hipStream_t s, hipGraphExec_t* out, F&& body) {
 }
 
 // ---- the sliding window of key frames (ba_window_dev.h) ------------------------------------------------------------------
+// The schedule of a robust solve as a list of segments -- head, then per round [round start,] chunks of w->chunk LM steps, tail,
+// then finish -- issued with ONE segment of look-ahead: segment i + 1 is on the stream before the host waits for segment i's
+// state word, so the stream never idles for a host round trip (~40 us per chunk next to a busy tracker).  What the state word
+// says only prunes segments that are not launched yet; a speculative segment behind a converged one runs as no-ops (every
+// kernel tests the state first).  `launch(kind)` puts one segment on the stream: a captured graph (cs_ba_solve_async, sizes
+// fixed) or the kernels themselves (cs_ba_solve_window_async, sizes new with every key frame); chunk and tail segments end
+// with the copy of {inner_done, all_done} into w->h_state.
+template <class F>
+static int ba_run_segments(BaWorker* w, hipStream_t s, int maxIter, int innerMaxIter, F&& launch) {
+    struct Seg {
+        char kind;  // 'H'ead, 'R'ound start, 'C'hunk, 'T'ail, 'F'inish
+        int outer;
+    };
+    std::vector<Seg> seg;
+    seg.push_back({'H', 0});
+    for (int outer = 0; outer < maxIter; ++outer) {
+        if (outer > 0) seg.push_back({'R', outer});
+        for (int done = 0; done < innerMaxIter; done += w->chunk) seg.push_back({'C', outer});
+        seg.push_back({'T', outer});
+    }
+    seg.push_back({'F', maxIter});
+    static const bool noSpec = getenv("COSLAM_BA_SPECULATE") && getenv("COSLAM_BA_SPECULATE")[0] == '0';  // A/B
+    if (!w->ev[0]) {
+        CS_HIP(hipEventCreateWithFlags(&w->ev[0], hipEventDisableTiming));
+        CS_HIP(hipEventCreateWithFlags(&w->ev[1], hipEventDisableTiming));
+    }
+    int skipChunksOfOuter = -1;  // chunks of this round that are not launched yet are dropped
+    bool allDone = false;        // ... and everything up to the finish segment
+    auto next_of = [&](size_t i) {
+        size_t n = i + 1;
+        while (n < seg.size()) {
+            const Seg& q = seg[n];
+            if (q.kind != 'F' && allDone) {
+                ++n;
+                continue;
+            }
+            if (q.kind == 'C' && q.outer == skipChunksOfOuter) {
+                ++n;
+                continue;
+            }
+            break;
+        }
+        return n;
+    };
+    size_t i = 0;
+    CS_HIP(launch(seg[0].kind));
+    CS_HIP(hipEventRecord(w->ev[0], s));
+    int slot = 0;
+    while (i < seg.size()) {
+        const size_t n = next_of(i);
+        if (n < seg.size() && !noSpec) {
+            CS_HIP(launch(seg[n].kind));
+            CS_HIP(hipEventRecord(w->ev[slot ^ 1], s));
+        }
+        CS_HIP(hipEventSynchronize(w->ev[slot]));
+        if (seg[i].kind == 'C' && (w->h_state[0] || w->h_state[1])) skipChunksOfOuter = seg[i].outer;  // inner_done / all_done
+        if (seg[i].kind == 'T' && w->h_state[1]) allDone = true;
+        if (noSpec) {
+            const size_t m = next_of(i);
+            if (m < seg.size()) {
+                CS_HIP(launch(seg[m].kind));
+                CS_HIP(hipEventRecord(w->ev[slot ^ 1], s));
+            }
+            i = m;
+        } else {
+            i = n;
+        }
+        slot ^= 1;
+    }
+    return CS_OK;
+}
+
+// The ring holds WIN_SLACK key frames more than a window: a request's window (its slots are fixed when the solve is REQUESTED)
+// stays intact while up to WIN_SLACK newer key frames are pushed -- the frame loop's thread may run that far ahead of the
+// worker's parse; one further push waits (on the host) for the oldest outstanding parse.
+constexpr int WIN_SLACK = 2, WIN_MAX_RING = 16 + WIN_SLACK;
 struct cs_ba_window {
     int device, nCams, nKf, N, nMap;
-    int head, count;     // ring: the next slot to write; key frames held
-    int frameOf[16];
+    int ring;            // slots in the ring: nKf + WIN_SLACK
+    int head, count;     // ring: the next slot to write; key frames held (<= nKf)
+    int frameOf[WIN_MAX_RING];
+    std::mutex mu;       // parsesPending / lastFrames: the requesting thread and the worker
+    std::condition_variable cv;
+    int parsesPending;   // solves requested whose parse has not read the ring yet
+    int lastFrames[16], lastCount;
     unsigned char* slab;
     double *xy, *K, *R, *t;
     int *pf, *cnt, *ptIndex, *obsStart, *totals, *pointMap, *pairCnt, *pairTotal;
-    int* h_totals;       // pinned [8]
+    double* mapSnap[WIN_SLACK + 1];   // the map as it stood when a solve was requested: one per request that can be outstanding
+    unsigned char* staticSnap[WIN_SLACK + 1];
+    int snapNext;
+    int* h_plan;         // pinned [nMap + 2]: the lane plan on its way to the device
+    int* h_totals;       // pinned [8], followed by nMap + 1 ints: obs_ptr of the parsed problem (for the lane plan)
     int lastC, lastP, lastObs;
 };
 
@@ -2960,11 +3046,25 @@ static int ba_worker_run_window(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
             w->stale = false;
         }
     }
-    if (win->count < 1) {
+    struct ParseDone {   // whatever way this function is left: the ring is free for the pushes that wait for this parse
+        cs_ba_window* w;
+        bool done = false;
+        void release() {
+            if (done) return;
+            done = true;
+            {
+                std::lock_guard<std::mutex> lk(w->mu);
+                w->parsesPending -= 1;
+            }
+            w->cv.notify_all();
+        }
+        ~ParseDone() { release(); }
+    } parseDone{win};
+    if (J.winCount < 1) {
         cs_set_error("cs_ba_solve_window_async: the window holds no key frame");
         return CS_ERR_INVALID;
     }
-    const int C = win->count * win->nCams;
+    const int C = J.winCount * win->nCams;
     // the workspace for the largest problem this window can produce: every slot of every key camera a measurement
     int rc = ba_reserve(b, win->nKf * win->nCams, win->nMap, win->nKf * win->nCams * win->N);
     if (rc) return rc;
@@ -2972,32 +3072,18 @@ static int ba_worker_run_window(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
     ba_drop_graph(b);
     WinDev Wd;
     memset(&Wd, 0, sizeof(Wd));
-    Wd.nCams = win->nCams, Wd.nKf = win->nKf, Wd.N = win->N, Wd.nMap = win->nMap, Wd.count = win->count;
-    for (int j = 0; j < win->count; ++j) Wd.slotOf[j] = (win->head - win->count + j + 2 * win->nKf) % win->nKf;  // oldest first
+    Wd.nCams = win->nCams, Wd.nKf = win->nKf, Wd.N = win->N, Wd.nMap = win->nMap, Wd.count = J.winCount;
+    for (int j = 0; j < J.winCount; ++j) Wd.slotOf[j] = J.winSlotOf[j];  // oldest first
     Wd.xy = win->xy, Wd.pf = win->pf, Wd.K = win->K, Wd.R = win->R, Wd.t = win->t;
     Wd.mapStatic = J.d_mapStatic, Wd.mapPts = J.d_map;
     Wd.cnt = win->cnt, Wd.ptIndex = win->ptIndex, Wd.obsStart = win->obsStart, Wd.totals = win->totals;
     const int gM = (win->nMap + 255) / 256 > 0 ? (win->nMap + 255) / 256 : 1;
     hipLaunchKernelGGL(k_win_count, dim3(gM), dim3(256), 0, s, Wd);
     hipLaunchKernelGGL(k_win_scan, dim3(1), dim3(1024), 0, s, Wd);
-    WinFillOut O = {b->Ks, b->Rs, b->Ts, b->pts, b->obs_xy, b->obs_ptr, b->obs_cam, win->pointMap};
+    WinFillOut O = {b->Ks, b->Rs, b->Ts, b->pts, b->obs_xy, b->obs_ptr, b->obs_cam, win->pointMap, b->obs_pt, b->obs_of};
     const int gF = ((win->nMap > C ? win->nMap : C) + 255) / 256;
     hipLaunchKernelGGL(k_win_fill, dim3(gF), dim3(256), 0, s, Wd, O);
-    CS_HIP(hipMemcpyAsync(win->h_totals, win->totals, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-    CS_HIP(hipStreamSynchronize(s));  // (this is the worker thread: the frame loop does not wait)
-    const int P = win->h_totals[0], nObs = win->h_totals[1];
-    win->lastC = C, win->lastP = P, win->lastObs = nObs;
-    b->maxObs = win->h_totals[2];
-    b->nPackWaves = 0;  // (no lane plan for a problem built on the device: the wave-per-point kernels)
-    b->havePairs = false;
-    if (P == 0 || nObs == 0) {
-        cs_set_error("cs_ba_solve_window_async: no map point has two feature points in the window");
-        return CS_ERR_INVALID;
-    }
-    // measurement tables (obs_pt, the dense (point, camera) table) and the camera-pair lists, all on the device
-    (void)hipMemsetAsync(b->obs_of, 0xff, sizeof(int) * (size_t)P * C, s);
-    hipLaunchKernelGGL(k_build_obs_pt, dim3((P + 3) / 4), dim3(256), 0, s, P, b->obs_ptr, b->obs_pt);
-    hipLaunchKernelGGL(k_build_obs_of, dim3((nObs + 255) / 256), dim3(256), 0, s, nObs, C, b->obs_pt, b->obs_cam, b->obs_of);
+    // the camera-pair lists' sizes, still without the host knowing P (one wave per pair; P read on the device)
     const int nPairsAll = C * (C + 1) / 2;
     if ((size_t)nPairsAll + 1 > b->pairPtrCap) {
         if (b->pairPtr) (void)hipFree(b->pairPtr);
@@ -3005,10 +3091,54 @@ static int ba_worker_run_window(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
         CS_HIP(hipMalloc((void**)&b->pairPtr, sizeof(int) * ((size_t)nPairsAll + 1)));
         b->pairPtrCap = (size_t)nPairsAll + 1;
     }
-    hipLaunchKernelGGL(k_pairs_count, dim3(nPairsAll), dim3(64), 0, s, C, P, b->obs_of, win->pairCnt);
+    hipLaunchKernelGGL(k_pairs_count, dim3(nPairsAll), dim3(64), 0, s, C, win->totals, b->obs_of, win->pairCnt);
     hipLaunchKernelGGL(k_pairs_scan, dim3(1), dim3(1024), 0, s, nPairsAll, win->pairCnt, b->pairPtr, win->pairTotal);
+    // ONE round trip: the sizes (launch dimensions of everything that follows), the pair total, obs_ptr for the lane plan
+    CS_HIP(hipMemcpyAsync(win->h_totals, win->totals, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     CS_HIP(hipMemcpyAsync(win->h_totals + 4, win->pairTotal, sizeof(int), hipMemcpyDeviceToHost, s));
-    CS_HIP(hipStreamSynchronize(s));
+    int* h_optr = win->h_totals + 8;
+    CS_HIP(hipMemcpyAsync(h_optr, b->obs_ptr, sizeof(int) * ((size_t)win->nMap + 1), hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));  // (this is the worker thread: the frame loop does not wait)
+    parseDone.release();              // the ring has been read
+    const int P = win->h_totals[0], nObs = win->h_totals[1];
+    {
+        std::lock_guard<std::mutex> lk(win->mu);
+        win->lastC = C, win->lastP = P, win->lastObs = nObs;
+        win->lastCount = J.winCount;
+        for (int j = 0; j < J.winCount; ++j) win->lastFrames[j] = J.winFrames[j];
+    }
+    b->maxObs = win->h_totals[2];
+    b->havePairs = false;
+    if (P == 0 || nObs == 0) {
+        cs_set_error("cs_ba_solve_window_async: no map point has two feature points in the window");
+        return CS_ERR_INVALID;
+    }
+    // lane plan of the packed kernels (as cs_ba_upload builds it): whole points back to back, at most 64 measurements per wave
+    b->nPackWaves = 0;
+    if (b->maxObs <= 64) {
+        if ((size_t)win->nMap + 2 > b->waveStartCap) {
+            if (b->waveStart) (void)hipFree(b->waveStart);
+            b->waveStart = nullptr;
+            b->waveStartCap = 0;
+            CS_HIP(hipMalloc((void**)&b->waveStart, sizeof(int) * ((size_t)win->nMap + 2)));
+            b->waveStartCap = (size_t)win->nMap + 2;
+        }
+        int* ws = win->h_plan;
+        int nw = 0, fill = 0;
+        ws[nw++] = 0;
+        for (int i = 0; i < P; ++i) {
+            const int k = h_optr[i + 1] - h_optr[i];
+            if (k == 0) continue;
+            if (fill + k > 64) {
+                ws[nw++] = h_optr[i];
+                fill = 0;
+            }
+            fill += k;
+        }
+        ws[nw++] = nObs;
+        CS_HIP(hipMemcpyAsync(b->waveStart, ws, sizeof(int) * nw, hipMemcpyHostToDevice, s));  // (h_plan is pinned and outlives the copy)
+        b->nPackWaves = nw - 1;
+    }
     const size_t nEnt = (size_t)win->h_totals[4];
     if (nEnt > 0 && nEnt <= ((size_t)8 << 20)) {
         if (nEnt > b->pairEntCap) {
@@ -3025,9 +3155,47 @@ static int ba_worker_run_window(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
         cs_set_error("cs_ba_solve_window_async: %zu camera-pair entries exceed what the window path supports", nEnt);
         return CS_ERR_INVALID;
     }
-    // the whole robust solve, enqueued eagerly (the sizes change with every key frame: no graph to replay); the estimate the
-    // fill kernel wrote into Rs / Ts / pts is the start (the key poses as tracked, the map as it stands)
-    rc = ba_enqueue(b, s, C, P, nObs, J.nCamsCon, J.nPtsCon, J.maxErr, J.maxIter, J.innerMaxIter, false, nullptr, nullptr, nullptr);
+    // the robust solve in the same segments as cs_ba_solve_async's, the kernels enqueued directly (the sizes change with every
+    // key frame: no graph to replay); the estimate the fill kernel wrote into Rs / Ts / pts is the start (the key poses as
+    // tracked, the map as it stands)
+    BaPlan L;
+    rc = ba_make_plan(b, C, P, nObs, J.nCamsCon, J.nPtsCon, J.maxErr, J.innerMaxIter, false, &L);
+    if (rc) return rc;
+    {
+        static const int envChunk = getenv("COSLAM_BA_WINDOW_CHUNK") ? atoi(getenv("COSLAM_BA_WINDOW_CHUNK")) : 0;
+        w->chunk = envChunk > 0 ? envChunk : 3;
+        if (w->chunk > J.innerMaxIter && J.innerMaxIter > 0) w->chunk = J.innerMaxIter;
+        if (w->chunk < 1) w->chunk = 1;
+    }
+    const BaDev& D = L.D;
+    const dim3 blk(256);
+    rc = ba_run_segments(w, s, J.maxIter, J.innerMaxIter, [&](char kind) {
+        switch (kind) {
+            case 'H':
+                ba_enqueue_init(b, s, L, false, nullptr, nullptr, nullptr);
+                hipLaunchKernelGGL(k_cost, dim3(L.cb), blk, 0, s, D, 0);
+                hipLaunchKernelGGL(k_control, dim3(1), blk, 0, s, D);
+                break;
+            case 'R':
+                hipLaunchKernelGGL(k_cost, dim3(L.cb), blk, 0, s, D, 0);
+                hipLaunchKernelGGL(k_control, dim3(1), blk, 0, s, D);
+                break;
+            case 'C':
+                ba_enqueue_lm_run(s, L, w->chunk);
+                (void)hipMemcpyAsync(w->h_state, &b->st->inner_done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+                break;
+            case 'T':
+                hipLaunchKernelGGL(k_flag, dim3(L.cb), blk, 0, s, D);
+                hipLaunchKernelGGL(k_outer_end, dim3(1), dim3(1), 0, s, D);
+                (void)hipMemcpyAsync(w->h_state, &b->st->inner_done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+                break;
+            default:
+                hipLaunchKernelGGL(k_cost_force, dim3(L.cb), blk, 0, s, D);
+                hipLaunchKernelGGL(k_finish, dim3(1), blk, 0, s, D, b->stats);
+                break;
+        }
+        return hipGetLastError();
+    });
     if (rc) return rc;
     rc = ba_run_followup(b, s);
     CS_HIP(hipStreamSynchronize(s));
@@ -3090,72 +3258,11 @@ static int ba_worker_run(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
         w->key = key;
         w->haveGraphs = true;
     }
-    // The schedule as a list of graph segments -- head, then per round [round start,] chunks, tail, then finish -- replayed
-    // with ONE segment of look-ahead: segment i + 1 is on the stream before the host waits for segment i's state word, so
-    // the stream never idles for a host round trip (~40 us per chunk next to a busy tracker).  What the state word says
-    // only prunes segments that are not launched yet; a speculative segment behind a converged one runs as no-ops (every
-    // kernel tests the state first).
-    struct Seg {
-        hipGraphExec_t g;
-        char kind;  // 'H'ead, 'R'ound start, 'C'hunk, 'T'ail, 'F'inish
-        int outer;
-    };
-    std::vector<Seg> seg;
-    seg.push_back({w->gHead, 'H', 0});
-    for (int outer = 0; outer < J.maxIter; ++outer) {
-        if (outer > 0) seg.push_back({w->gRound, 'R', outer});
-        for (int done = 0; done < J.innerMaxIter; done += w->chunk) seg.push_back({w->gChunk, 'C', outer});
-        seg.push_back({w->gTail, 'T', outer});
-    }
-    seg.push_back({w->gFinish, 'F', J.maxIter});
-    static const bool noSpec = getenv("COSLAM_BA_SPECULATE") && getenv("COSLAM_BA_SPECULATE")[0] == '0';  // A/B
-    if (!w->ev[0]) {
-        CS_HIP(hipEventCreateWithFlags(&w->ev[0], hipEventDisableTiming));
-        CS_HIP(hipEventCreateWithFlags(&w->ev[1], hipEventDisableTiming));
-    }
-    int skipChunksOfOuter = -1;  // chunks of this round that are not launched yet are dropped
-    bool allDone = false;        // ... and everything up to the finish segment
-    auto next_of = [&](size_t i) {
-        size_t n = i + 1;
-        while (n < seg.size()) {
-            const Seg& q = seg[n];
-            if (q.kind != 'F' && allDone) {
-                ++n;
-                continue;
-            }
-            if (q.kind == 'C' && q.outer == skipChunksOfOuter) {
-                ++n;
-                continue;
-            }
-            break;
-        }
-        return n;
-    };
-    size_t i = 0;
-    CS_HIP(hipGraphLaunch(seg[0].g, s));
-    CS_HIP(hipEventRecord(w->ev[0], s));
-    int slot = 0;
-    while (i < seg.size()) {
-        const size_t n = next_of(i);
-        if (n < seg.size() && !noSpec) {
-            CS_HIP(hipGraphLaunch(seg[n].g, s));
-            CS_HIP(hipEventRecord(w->ev[slot ^ 1], s));
-        }
-        CS_HIP(hipEventSynchronize(w->ev[slot]));
-        if (seg[i].kind == 'C' && (w->h_state[0] || w->h_state[1])) skipChunksOfOuter = seg[i].outer;  // inner_done / all_done
-        if (seg[i].kind == 'T' && w->h_state[1]) allDone = true;
-        if (noSpec) {
-            const size_t m = next_of(i);
-            if (m < seg.size()) {
-                CS_HIP(hipGraphLaunch(seg[m].g, s));
-                CS_HIP(hipEventRecord(w->ev[slot ^ 1], s));
-            }
-            i = m;
-        } else {
-            i = n;
-        }
-        slot ^= 1;
-    }
+    rc = ba_run_segments(w, s, J.maxIter, J.innerMaxIter, [&](char kind) {
+        hipGraphExec_t g = kind == 'H' ? w->gHead : kind == 'R' ? w->gRound : kind == 'C' ? w->gChunk : kind == 'T' ? w->gTail : w->gFinish;
+        return hipGraphLaunch(g, s);
+    });
+    if (rc) return rc;
     rc = ba_run_followup(b, s);  // the finish segment is on the stream: RobustBundleRTS::output()'s non-key-frame update goes here
     CS_HIP(hipStreamSynchronize(s));
     return rc;
@@ -3749,9 +3856,12 @@ cs_ba_window* cs_ba_window_create(int device, int nCams, int nKeyFrames, int N, 
         return nullptr;
     }
     cs_ba_window* w = new cs_ba_window();
-    memset(w, 0, sizeof(*w));
     w->device = device, w->nCams = nCams, w->nKf = nKeyFrames, w->N = N, w->nMap = nMapPts;
-    const size_t KC = (size_t)nKeyFrames * nCams, nPairs = KC * (KC + 1) / 2;
+    w->ring = nKeyFrames + WIN_SLACK;
+    w->head = w->count = w->parsesPending = w->lastCount = w->snapNext = 0;
+    w->lastC = w->lastP = w->lastObs = 0;
+    w->slab = nullptr, w->h_totals = w->h_plan = nullptr;
+    const size_t KC = (size_t)w->ring * nCams, KW = (size_t)nKeyFrames * nCams, nPairs = KW * (KW + 1) / 2;
     struct Piece {
         void** ptr;
         size_t bytes;
@@ -3763,10 +3873,14 @@ cs_ba_window* cs_ba_window_create(int device, int nCams, int nKeyFrames, int N, 
         {(void**)&w->ptIndex, sizeof(int) * nMapPts},  {(void**)&w->obsStart, sizeof(int) * nMapPts},
         {(void**)&w->totals, sizeof(int) * 8},         {(void**)&w->pointMap, sizeof(int) * nMapPts},
         {(void**)&w->pairCnt, sizeof(int) * (nPairs + 1)}, {(void**)&w->pairTotal, sizeof(int) * 8},
+        {(void**)&w->mapSnap[0], sizeof(double) * 3 * nMapPts}, {(void**)&w->mapSnap[1], sizeof(double) * 3 * nMapPts},
+        {(void**)&w->mapSnap[2], sizeof(double) * 3 * nMapPts}, {(void**)&w->staticSnap[0], (size_t)nMapPts},
+        {(void**)&w->staticSnap[1], (size_t)nMapPts},           {(void**)&w->staticSnap[2], (size_t)nMapPts},
     };
     size_t total = 0;
     for (const Piece& q : pieces) total += (q.bytes + 255) & ~(size_t)255;
-    if (hipMalloc((void**)&w->slab, total) != hipSuccess || hipHostMalloc((void**)&w->h_totals, 8 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+    if (hipMalloc((void**)&w->slab, total) != hipSuccess || hipHostMalloc((void**)&w->h_totals, (8 + (size_t)nMapPts + 1) * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&w->h_plan, ((size_t)nMapPts + 2) * sizeof(int), hipHostMallocDefault) != hipSuccess) {
         cs_set_error("cs_ba_window_create: cannot allocate %zu MB", total >> 20);
         if (w->slab) (void)hipFree(w->slab);
         delete w;
@@ -3786,6 +3900,7 @@ void cs_ba_window_destroy(cs_ba_window* w) {
     (void)hipDeviceSynchronize();
     (void)hipFree(w->slab);
     (void)hipHostFree(w->h_totals);
+    (void)hipHostFree(w->h_plan);
     delete w;
 }
 
@@ -3801,6 +3916,11 @@ int cs_ba_window_push_dev(cs_ba_window* w, void* hip_stream, const cs_handback_c
     CS_HIP(hipSetDevice(w->device));
     hipStream_t s = (hipStream_t)hip_stream;
     const int slot = w->head;
+    {   // the slot about to be rewritten belongs to the window of the request WIN_SLACK + 1 pushes back: wait for its parse
+        std::unique_lock<std::mutex> lk(w->mu);
+        static const bool noWait = getenv("COSLAM_WIN_NOWAIT") != nullptr;   // (diagnostic only: unsafe)
+        if (!noWait) w->cv.wait(lk, [&] { return w->parsesPending <= WIN_SLACK; });
+    }
     const size_t base = (size_t)slot * w->nCams;
     WinSnapArgs A;
     memset(&A, 0, sizeof(A));
@@ -3826,7 +3946,7 @@ int cs_ba_window_push_dev(cs_ba_window* w, void* hip_stream, const cs_handback_c
     CS_HIP(hipMemcpyAsync(w->R + base * 9, d_R, 72 * (size_t)w->nCams, hipMemcpyDeviceToDevice, s));
     CS_HIP(hipMemcpyAsync(w->t + base * 3, d_t, 24 * (size_t)w->nCams, hipMemcpyDeviceToDevice, s));
     w->frameOf[slot] = frame;
-    w->head = (slot + 1) % w->nKf;
+    w->head = (slot + 1) % w->ring;
     if (w->count < w->nKf) w->count += 1;
     return CS_OK;
 }
@@ -3858,7 +3978,24 @@ int cs_ba_solve_window_async(cs_ba* b, cs_ba_window* w, void* after_stream, cons
     J.C = J.P = J.nObs = 0;
     J.nCamsCon = nCamsCon, J.nPtsCon = nPtsCon, J.maxIter = maxIter, J.innerMaxIter = innerMaxIter, J.maxErr = maxErr;
     J.R0 = J.T0 = J.M0 = nullptr;
-    J.win = w, J.d_map = d_mapPts, J.d_mapStatic = d_mapStatic;
+    // the map as it stands NOW, in after_stream's order (RobustBundleRTS::addPoints copies the points when the BA is requested,
+    // under the BA mutex: src/app/SL_CoSLAMRobustBA.cpp:56-78, SL_CoSLAM.cpp:1731-1784): the frame loop goes on refining the map
+    // (cs_pose_update_frame_dev) while the worker parses
+    const int sn = w->snapNext;
+    w->snapNext = (sn + 1) % (WIN_SLACK + 1);
+    CS_HIP(hipMemcpyAsync(w->mapSnap[sn], d_mapPts, sizeof(double) * 3 * (size_t)w->nMap, hipMemcpyDeviceToDevice, (hipStream_t)after_stream));
+    if (d_mapStatic)
+        CS_HIP(hipMemcpyAsync(w->staticSnap[sn], d_mapStatic, (size_t)w->nMap, hipMemcpyDeviceToDevice, (hipStream_t)after_stream));
+    J.win = w, J.d_map = w->mapSnap[sn], J.d_mapStatic = d_mapStatic ? w->staticSnap[sn] : nullptr;
+    J.winCount = w->count;
+    for (int j = 0; j < w->count; ++j) {
+        J.winSlotOf[j] = (w->head - w->count + j + 2 * w->ring) % w->ring;
+        J.winFrames[j] = w->frameOf[J.winSlotOf[j]];
+    }
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->parsesPending += 1;
+    }
     CS_HIP(hipEventCreateWithFlags(&J.ready, hipEventDisableTiming));
     CS_HIP(hipEventRecord(J.ready, (hipStream_t)after_stream));
     {
@@ -3892,12 +4029,13 @@ int cs_ba_reserve_for_window(cs_ba* b, cs_ba_window* w) {
 // RobustBundleRTS::int2MapPt) and the frame number of every key frame (host, oldest first).  Call after cs_ba_wait.
 int cs_ba_window_last_problem(cs_ba_window* w, int* C, int* P, int* nObs, const int** d_pointMap, int* keyFrames /* [nKeyFrames] or NULL */) {
     if (!w) return CS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(w->mu);
     if (C) *C = w->lastC;
     if (P) *P = w->lastP;
     if (nObs) *nObs = w->lastObs;
     if (d_pointMap) *d_pointMap = w->pointMap;
     if (keyFrames)
-        for (int j = 0; j < w->count; ++j) keyFrames[j] = w->frameOf[(w->head - w->count + j + 2 * w->nKf) % w->nKf];
+        for (int j = 0; j < w->nKf; ++j) keyFrames[j] = j < w->lastCount ? w->lastFrames[j] : -1;
     return CS_OK;
 }
 

@@ -14,7 +14,8 @@
 //                    = slot order, GPUKLT::addToFeaturePoints) whose feature of this frame carries map point m
 //   k_win_count      per map point: feature points over the window's key cameras
 //   k_win_scan       one workgroup: which points stay (> 1 feature point), their index, their first measurement
-//   k_win_fill       per kept point: pt3Ds entry, obs_ptr, the Meas2D list in camera order; per camera K, R, t
+//   k_win_fill       per kept point: pt3Ds entry, obs_ptr, the Meas2D list in camera order (+ the measurement -> point and the
+//                    dense (point, camera) -> measurement tables of the solver); per camera K, R, t
 // and the camera-pair lists of the Schur kernel (built on the host for uploaded problems) on the device too:
 //   k_pairs_count / k_pairs_fill   one wave per camera pair, ballot-compaction over the points in index order.
 
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(1024) void k_win_scan(WinDev Wd) {
 struct WinFillOut {
     double *Ks, *Rs, *Ts, *pts, *obs_xy;
     int *obs_ptr, *obs_cam, *pointMap;
+    int *obs_pt, *obs_of;   // the measurement's point; the dense (point, camera) -> measurement table (-1: none)
 };
 __global__ __launch_bounds__(256) void k_win_fill(WinDev Wd, WinFillOut O) {
     const int m = blockIdx.x * 256 + threadIdx.x;
@@ -136,7 +138,9 @@ __global__ __launch_bounds__(256) void k_win_fill(WinDev Wd, WinFillOut O) {
         for (int c = 0; c < Wd.nCams; ++c) {  // camera order (:146-151)
             const size_t src = (size_t)Wd.slotOf[j] * Wd.nCams + c;
             const int s = Wd.pf[src * Wd.nMap + m];
+            O.obs_of[(size_t)i * C + j * Wd.nCams + c] = s < 0 ? -1 : o;
             if (s < 0) continue;
+            O.obs_pt[o] = i;
             O.obs_cam[o] = j * Wd.nCams + c;
             O.obs_xy[2 * (size_t)o] = Wd.xy[src * 2 * Wd.N + s];
             O.obs_xy[2 * (size_t)o + 1] = Wd.xy[src * 2 * Wd.N + Wd.N + s];
@@ -148,8 +152,8 @@ __global__ __launch_bounds__(256) void k_win_fill(WinDev Wd, WinFillOut O) {
 // pair (ca <= cb), id = ca C - ca (ca - 1) / 2 + (cb - ca): the measurements {oa, ob, point} of the points both cameras see,
 // ascending point index (ca == cb: every measurement of the camera) -- what cs_ba_upload builds on the host.  One wave per
 // pair walks the points 64 at a time through the dense (point, camera) table.
-__global__ __launch_bounds__(64) void k_pairs_count(int C, int P, const int* obs_of, int* pairCnt) {
-    const int pid = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(64) void k_pairs_count(int C, const int* totals, const int* obs_of, int* pairCnt) {
+    const int pid = blockIdx.x, lane = threadIdx.x, P = totals[0];  // (the number of kept points is still on its way to the host)
     int ca = 0, rest = pid;
     while (rest >= C - ca) {
         rest -= C - ca;

@@ -553,3 +553,75 @@ def test_ba_window_parses_the_problem_on_the_device_and_solves_it(hip):
     assert abs(st.cost - st_o.cost) <= 1e-7 * max(1.0, st_o.cost) and st.cost < 0.2 * st.cost0
     win.close()
     ws.close()
+
+
+def test_ba_window_requests_queue_up_behind_a_frame_loop_that_runs_ahead(hip):
+    """The frame loop's thread never waits for the bundle adjuster: it pushes key frames and requests solves far ahead of the
+    worker.  Every request must solve the window and the map AS THEY STOOD when it was made (the reference copies both under the
+    BA mutex when the BA is requested: src/app/SL_CoSLAM.cpp:1757-1775, SL_CoSLAMRobustBA.cpp:56-78): 12 key frames pushed with a
+    solve requested behind every one from the 5th on, nothing waited for, the map overwritten right behind the last request."""
+    import torch
+
+    from coslam_amd.handback import handback_cams
+
+    rng = np.random.default_rng(78)
+    n_cams, n_kf, n_push, N, n_map = 3, 5, 12, 320, 400
+    C_all = n_push * n_cams
+    pr = make_ba_problem(n_cams=C_all, n_pts=n_map, visibility=0.5, noise=0.4, outlier_frac=0.03, n_cams_con=2 * n_cams, n_pts_con=2, seed=22)
+    dev = torch.device("cuda:0")
+    obs_by_cam = [[] for _ in range(C_all)]
+    for o in range(len(pr["obs_cam"])):
+        obs_by_cam[int(pr["obs_cam"][o])].append(o)
+    key_frames = []
+    for j in range(n_push):
+        recs = []
+        for c in range(n_cams):
+            ci = j * n_cams + c
+            xy, state, s2m = np.zeros(2 * N), np.full(N, -1, np.int32), np.full(N, -1, np.int32)
+            slots = rng.permutation(N)
+            for k, o in enumerate(obs_by_cam[ci][: N - 20]):
+                s_ = int(slots[k])
+                state[s_], s2m[s_] = 0, int(pr["obs_pt"][o])
+                xy[s_], xy[N + s_] = pr["obs_xy"][o]
+            recs.append(dict(xy=xy, state=state, slot2map=s2m, K=pr["Ks"][ci].reshape(9), R=pr["Rs0"][ci].reshape(9), t=pr["ts0"][ci]))
+        key_frames.append(recs)
+    win = coslam_amd.BAWindow(n_cams, n_kf, N, n_map)
+    ws = coslam_amd.BAWorkspace(0)
+    s = torch.cuda.Stream(device=dev)
+    # everything the pushes read, resident before the loop starts (nothing below synchronises)
+    dev_recs = []
+    for j in range(n_push):
+        t_xy = [torch.from_numpy(r["xy"]).to(dev) for r in key_frames[j]]
+        t_st = [torch.from_numpy(r["state"]).to(dev) for r in key_frames[j]]
+        t_sm = [torch.from_numpy(r["slot2map"]).to(dev) for r in key_frames[j]]
+        hb = handback_cams([dict(xy=t_xy[c].data_ptr(), state=t_st[c].data_ptr(), slot2map=t_sm[c].data_ptr()) for c in range(n_cams)])
+        d_K = torch.from_numpy(np.stack([r["K"] for r in key_frames[j]])).to(dev)
+        d_R = torch.from_numpy(np.stack([r["R"] for r in key_frames[j]])).to(dev)
+        d_t = torch.from_numpy(np.stack([r["t"] for r in key_frames[j]])).to(dev)
+        dev_recs.append((t_xy, t_st, t_sm, hb, d_K, d_R, d_t))
+    maps = [pr["pts0"] + 0.002 * j for j in range(n_push)]      # the map moves a little between the requests
+    d_maps = [torch.from_numpy(m.copy()).to(dev) for m in maps]
+    d_map = torch.zeros_like(d_maps[0])
+    torch.cuda.synchronize()
+    ncon, npcon = 2 * n_cams, 2
+    with torch.cuda.stream(s):
+        for j in range(n_push):
+            _, _, _, hb, d_K, d_R, d_t = dev_recs[j]
+            d_map.copy_(d_maps[j], non_blocking=True)
+            win.push_dev(s.cuda_stream, hb, d_K.data_ptr(), 0, d_R.data_ptr(), d_t.data_ptr(), 5 * j)
+            if j >= n_kf - 1:
+                win.solve_async(ws, s.cuda_stream, d_map.data_ptr(), ncon, npcon, 6.0, 2, 10)
+        d_map.fill_(1e6)   # the frame loop goes on changing the map: the last request must not see this
+    ws.wait()
+    Cw, Pw, Ow, _, kfs = win.last_problem()
+    ref = oracle.parse_inputs_window(key_frames[n_push - n_kf:], maps[-1])
+    assert (Cw, Pw, Ow) == (n_kf * n_cams, len(ref["pts"]), len(ref["obs_cam"])) and kfs == [5 * j for j in range(n_push - n_kf, n_push)]
+    ws.set_sizes(Cw, Pw, Ow)
+    R, T, M, out, st = ws.download()
+    R_o, T_o, M_o, out_o, st_o = oracle.ba_robust(ref["Ks"].reshape(-1, 3, 3), ref["Rs"].reshape(-1, 3, 3), ref["Ts"], ref["pts"], ref["obs_ptr"],
+                                                  ref["obs_cam"], ref["obs_xy"], ncon, npcon, 6.0, 2, 10)
+    assert np.array_equal(out, out_o) and st.nIterTotal == st_o.nIterTotal and st.flags == 0
+    sane = np.linalg.norm(M_o, axis=1) < 1e3
+    assert np.max(np.abs(R - R_o)) < 1e-6 and np.max(np.abs(T - T_o)) < 1e-6 and np.max(np.abs(M[sane] - M_o[sane])) < 1e-6
+    win.close()
+    ws.close()

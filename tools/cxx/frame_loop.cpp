@@ -147,7 +147,7 @@ int main(int argc, char** argv) {
         visUV[c] = rd.vec<double>(2 * (size_t)nv);
     }
     const std::vector<double> R0 = rd.vec<double>(9 * (size_t)nCams), t0 = rd.vec<double>(3 * (size_t)nCams);
-    const std::vector<double> cov = rd.vec<double>(9 * 2 * (size_t)P_REG);
+    const std::vector<double> cov = rd.vec<double>(9 * (size_t)std::max(nMap, 2 * P_REG));  // MapPoint::cov of every map point
     BaProblem joint, ic;
     joint.read(rd);
     ic.read(rd);
@@ -200,9 +200,21 @@ int main(int argc, char** argv) {
     int* dNpts = dev_zeros<int>(nCams);
     cs_pose_option* dOpt = (cs_pose_option*)dev_zeros<unsigned char>((size_t)nCams * sizeof(cs_pose_option));
     int* dOk = dev_zeros<int>(nCams);
-    int* dPf = dev_zeros<int>((size_t)P_REG * nCams);
+    int* dPf = dev_zeros<int>((size_t)nMap * nCams);  // MapPoint::pFeatures of this frame, nMap x nCams (the hand-back writes it)
     int* dPfNone = dev_zeros<int>((size_t)P_REG * nCams);
-    HIPCHK(hipMemset(dPf, 0xff, sizeof(int) * (size_t)P_REG * nCams));
+    HIPCHK(hipMemset(dPf, 0xff, sizeof(int) * (size_t)nMap * nCams));
+    // poseUpdate3D's second half + detectDynamicFeaturePoints behind the pose solve (cs_pose_update_frame_dev)
+    const std::vector<double> iKh = {1 / K[0], -K[1] / (K[0] * K[4]), (K[1] * K[5] - K[2] * K[4]) / (K[0] * K[4]), 0, 1 / K[4], -K[5] / K[4], 0, 0, 1};
+    double* diK = to_dev(iKh);
+    unsigned char* dIsStatic = dev_zeros<unsigned char>((size_t)nCams * N);
+    HIPCHK(hipMemset(dIsStatic, 1, (size_t)nCams * N));
+    double* dReproj = dev_zeros<double>((size_t)nCams * N);
+    unsigned char* dMapFlags = dev_zeros<unsigned char>(nMap);
+    cs_track_history* hist = cs_track_history_create(dev, nCams, N, 64);
+    if (!hist) {
+        fprintf(stderr, "cs_track_history_create: %s\n", cs_last_error());
+        return 3;
+    }
     HIPCHK(hipMemset(dPfNone, 0xff, sizeof(int) * (size_t)P_REG * nCams));
     double* dR[2] = {to_dev(R0), to_dev(R0)};
     double* dT[2] = {to_dev(t0), to_dev(t0)};
@@ -230,7 +242,8 @@ int main(int argc, char** argv) {
             h.dest = dDest[b][c], h.K = dK, h.kud = dKud, h.mapPts = dMap, h.slot2map = dS2M + (size_t)c * N;
             h.trackSpan = dSpan + (size_t)c * 2 * N, h.xy = dXY + (size_t)c * 2 * N, h.state = dState + (size_t)c * N;
             h.Ms = dMs + (size_t)c * PTS * 3, h.ms = dms + (size_t)c * PTS * 2, h.sel = dSel + (size_t)c * PTS;
-            h.npts = dNpts + c, h.opt = dOpt + c, h.pointFeat = dPf + c, h.pointFeatStride = nCams, h.nPointFeat = P_REG;
+            h.npts = dNpts + c, h.opt = dOpt + c, h.pointFeat = dPf + c, h.pointFeatStride = nCams, h.nPointFeat = nMap;
+            h.isStatic = dIsStatic + (size_t)c * N;
         }
         return v;
     };
@@ -245,6 +258,13 @@ int main(int argc, char** argv) {
         return v;
     };
     const std::vector<cs_register_cam> rc[2] = {reg_cams(0), reg_cams(1)};
+    std::vector<cs_poseupdate_cam> pu(nCams);
+    for (int c = 0; c < nCams; ++c) {
+        memset(&pu[c], 0, sizeof(pu[c]));
+        pu[c].K = dK, pu[c].iK = diK, pu[c].xy = dXY + (size_t)c * 2 * N, pu[c].state = dState + (size_t)c * N;
+        pu[c].slot2map = dS2M + (size_t)c * N, pu[c].trackSpan = dSpan + (size_t)c * 2 * N;
+        pu[c].reprojErr = dReproj + (size_t)c * N, pu[c].isStatic = dIsStatic + (size_t)c * N;
+    }
 
     // ---- key-frame solves: workspaces, pose graphs as the joint BA's follow-up ----
     // joint local BA: parsed on the device from the ring of the last 5 key frames (cs_ba_window_*: the hand-back's records and
@@ -324,6 +344,9 @@ int main(int argc, char** argv) {
         const int src = (i + 1) & 1, dsti = i & 1;
         CSCHK(cs_pose_intracam_batch_dev(dev, (void*)poseS, nCams, PTS, dKall, dR[src], dT[src], dNpts, nullptr, dMs, dms, 10.0,
                                          dR[dsti], dT[dsti], dOpt, dOk));
+        // parallelPoseUpdate(false): the gate + seqTriangulate loop of poseUpdate3D, detectDynamicFeaturePoints(20, 5, 3, MAX_EPI_ERR)
+        CSCHK(cs_pose_update_frame_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dR[dsti], dT[dsti], dMap, dCov, dMapFlags, 0, PIX, i, 20, 5,
+                                       3, 6.0, nullptr, nullptr, nullptr));
         // activeMapPointsRegister, then currentMapPointsRegister (static points), search step
         CSCHK(cs_register_search_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, P_REG, dMap + 3 * (size_t)P_REG,
                                      dCov + 9 * (size_t)P_REG, dPfNone, 2.5 * PIX, 3 * PIX, PIX, reg[0].slot, reg[0].m, reg[0].var,

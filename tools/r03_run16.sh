@@ -1,13 +1,16 @@
-cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03_s16; mkdir -p $O
-for a in "--steps 20 --warmup 5" "" "--steps 20 --warmup 5" ""; do
-timeout 600 python3 bench.py --no-cpu-baseline --no-secondary $a > $O/b.json 2> $O/b.err; echo rc=$?
-python - $O/b.json <<'PY'
-import json,sys
+#!/bin/bash
+mkdir -p gpurun_out/r03_16
+timeout 900 python -m pytest tests/test_pose_ba_gpu.py tests/test_cxx_dropin_gpu.py tests/test_bench_contract_gpu.py -x -q > gpurun_out/r03_16/pytest.txt 2>&1; tail -5 gpurun_out/r03_16/pytest.txt
+for rep in 1 2 3; do
+for cams in 4 0; do
+timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --no-upload-leg --klt-cams-per-launch $cams > gpurun_out/r03_16/b_${rep}_$cams.json 2> gpurun_out/r03_16/b_${rep}_$cams.err
+python - <<PY
+import json
 try:
-    j=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c=j['config']
-    print("value", round(j['value'],1), "upload", round(c['with_upload']['frames_per_s'],1), "cxx", c['cxx_frame_loop']['frames_per_s'])
+    d=json.loads(open('gpurun_out/r03_16/b_${rep}_$cams.json').read().strip().splitlines()[-1]); c=d['config']
+    print('rep', $rep, 'cams', $cams, round(d['value'],1), 'cxx', c['cxx_frame_loop'].get('frames_per_s') or c['cxx_frame_loop'], c['joint_ba_last'])
 except Exception as e:
-    print('FAILED',e); print(open(sys.argv[1].replace('.json','.err')).read()[-1500:])
+    print('FAILED', e); print(open('gpurun_out/r03_16/b_${rep}_$cams.err').read()[-800:])
 PY
+done
 done

@@ -1,12 +1,16 @@
-cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-O=gpurun_out/r03_s17; mkdir -p $O
-timeout 600 python3 bench.py --no-cpu-baseline --no-cxx-loop --no-upload-leg --steps 20 --warmup 5 > $O/b.json 2> $O/b.err; echo rc=$?
-python - $O/b.json <<'PY'
-import json,sys
+#!/bin/bash
+mkdir -p gpurun_out/r03_17
+for rep in 1 2; do
+for nw in 0 1; do
+if [ $nw = 1 ]; then export COSLAM_WIN_NOWAIT=1; else unset COSLAM_WIN_NOWAIT; fi
+timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --no-upload-leg --no-cxx-loop > gpurun_out/r03_17/b_${rep}_$nw.json 2> gpurun_out/r03_17/b_${rep}_$nw.err
+python - <<PY
+import json
 try:
-    j=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); c=j['config']
-    print("value", round(j['value'],1)); print(c['secondary_cfg5_klt']); print(c['secondary_cfg5_ba'])
+    d=json.loads(open('gpurun_out/r03_17/b_${rep}_$nw.json').read().strip().splitlines()[-1]); c=d['config']
+    print('rep', $rep, 'nowait', $nw, round(d['value'],1), 'host ms/step', round(c['host_enqueue_ms_per_step'],3), 'max', round(c['host_enqueue_ms_max_step'],3))
 except Exception as e:
-    print('FAILED',e); print(open(sys.argv[1].replace('.json','.err')).read()[-1500:])
+    print('FAILED', e); print(open('gpurun_out/r03_17/b_${rep}_$nw.err').read()[-800:])
 PY
+done
+done
