@@ -812,6 +812,7 @@ def main():
     for i in range(args.warmup):
         step(base0 + i + 1, args.key_every > 0 and i % args.key_every == 0)
     barrier()
+    ba_ws.worker_stats(), ic_ws.worker_stats()   # (reset: the sums below cover the timed region only)
     t_begin = time.perf_counter()
     t_step_max, i_step_max, t_prev = 0.0, -1, t_begin
     for i in range(args.steps):
@@ -825,6 +826,11 @@ def main():
     t_host = time.perf_counter() - t_begin
     barrier()
     dt = time.perf_counter() - t_begin
+    wj, wi = ba_ws.worker_stats(), ic_ws.worker_stats()
+    solve_duty = {"what": "time the key-frame solves held their workspaces' streams inside the timed region (GPU clock, from the moment the "
+                          "frame they wait for was done), against the region's length: which chain bounds the loop",
+                  "joint_ba": {"solves": wj[0], "ms_total": wj[1], "ms_max": wj[3], "ms_parse_total": wj[4], "share_of_timed_region": wj[1] / (dt * 1e3)},
+                  "inter_camera": {"solves": wi[0], "ms_total": wi[1], "ms_max": wi[3], "share_of_timed_region": wi[1] / (dt * 1e3)}}
     with_upload = None
     if not args.no_upload_leg and not args.serial:
         # the same loop once more, the images coming from pinned host memory every frame (same key-frame cadence, same drain)
@@ -1182,6 +1188,7 @@ def main():
                            "map_points_refined": int((d_map - torch.from_numpy(sc.points).to(dev)).abs().amax(dim=1).gt(0).sum().item()),
                            "features_dynamic_last_frame": [int(v) for v in ((d_isstatic == 0) & (d_state >= 0)).sum(dim=1).cpu().tolist()],
                            "static_mapped_features_last_frame": [int(v) for v in ((d_state >= 0) & (d_slot2map >= 0)).sum(dim=1).cpu().tolist()]},
+                       "key_frame_solves_duty": solve_duty,
                        "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "host_enqueue_ms_max_step": t_step_max * 1e3, "host_enqueue_max_at_step": i_step_max, "tracker_stream_cus": args.klt_cus or "all",
                        "ncc_matching": None if ncc is None else {
                            "every_frames": NCC_EVERY, "camera_pairs_per_run": nc - 1, "runs": ncc["runs"],

@@ -108,6 +108,13 @@ class BAWorkspace:
         self._L.cs_ba_stream.restype = C.c_void_p
         return self._L.cs_ba_stream(self._h)
 
+    def worker_stats(self):
+        """(solves completed by the worker since the last call, GPU ms they held the stream in total, the last one, the longest, the
+        window parses' part of the total)"""
+        j, t, l, m, p = C.c_int(0), C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        check(self._L.cs_ba_worker_stats(self._h, C.byref(j), C.byref(t), C.byref(l), C.byref(m), C.byref(p)), "cs_ba_worker_stats")
+        return j.value, t.value, l.value, m.value, p.value
+
     def wait(self):
         check(self._L.cs_ba_wait(self._h), "cs_ba_wait")
 

@@ -1348,7 +1348,12 @@ __device__ __forceinline__ void sb_solve_body(const BaDev& D, double* sm, int* o
 #undef CS_PROBE
 }
 
-__global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
+// NW waves.  16 (1024 threads, 4 waves of 112 VGPRs per SIMD) is the fastest solve on an idle chip and needs a compute unit with
+// NOTHING else on it -- next to the persistent tracker it waited 35-45 us per LM step for one to drain
+// (profiles/r03_key_frame_interval_per_queue.txt); 8 (2 waves per SIMD) starts on any compute unit whose tracker workgroup
+// leaves half the register file, 4 on nearly any.  Same arithmetic and bits for every NW (sb_solve_body).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_solve_blocked(BaDev D) {
     if (CS_SOLVE_PRIO) __builtin_amdgcn_s_setprio(CS_SOLVE_PRIO);
     const int stAllDone = D.st->all_done, stInnerDone = D.st->inner_done;  // (consumed after the matrix loads are in flight)
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -1357,9 +1362,22 @@ __global__ __launch_bounds__(1024) void k_solve_blocked(BaDev D) {
         if (threadIdx.x == 0) D.st->chol_ok = 1;
         return;
     }
-    sb_solve_body<16, false>(D, sm, &okFlag, stAllDone || stInnerDone);
+    sb_solve_body<NW, false>(D, sm, &okFlag, stAllDone || stInnerDone);
     if (stAllDone || stInnerDone) return;
     if (threadIdx.x == 0) D.st->chol_ok = okFlag;  // (behind the body's last workgroup barrier)
+}
+static int sb_solve_waves(int n) {  // COSLAM_BA_SOLVE_WAVES = 4 | 8 | 16 overrides (A/B runs)
+    static const int env = getenv("COSLAM_BA_SOLVE_WAVES") ? atoi(getenv("COSLAM_BA_SOLVE_WAVES")) : 0;
+    if (env == 4 || env == 8 || env == 16) return env;
+    return n <= 64 ? 4 : 8;
+}
+static void sb_launch_solve(hipStream_t stream, const BaDev& D) {
+    const size_t lds = sb_lds_bytes(D.n);
+    switch (sb_solve_waves(D.n)) {
+        case 4: hipLaunchKernelGGL(k_solve_blocked<4>, dim3(1), dim3(256), lds, stream, D); break;
+        case 8: hipLaunchKernelGGL(k_solve_blocked<8>, dim3(1), dim3(512), lds, stream, D); break;
+        default: hipLaunchKernelGGL(k_solve_blocked<16>, dim3(1), dim3(1024), lds, stream, D); break;
+    }
 }
 
 // ---- one WAVE: reduced camera system of order n <= 64 -------------------------------------------------
@@ -2536,8 +2554,9 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
         static const bool legacy = getenv("COSLAM_BA_LEGACY_SOLVE") && getenv("COSLAM_BA_LEGACY_SOLVE")[0] == '1';
         L.legacySolve = legacy;
         if (!legacy && D.n > 36 && D.n <= SB_MAX_ORDER && sb_lds_bytes(D.n) > 64 * 1024) {
-            CS_HIP(hipFuncSetAttribute((const void*)k_solve_blocked, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)sb_lds_bytes(D.n)));
+            CS_HIP(hipFuncSetAttribute((const void*)k_solve_blocked<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb_lds_bytes(D.n)));
+            CS_HIP(hipFuncSetAttribute((const void*)k_solve_blocked<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb_lds_bytes(D.n)));
+            CS_HIP(hipFuncSetAttribute((const void*)k_solve_blocked<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb_lds_bytes(D.n)));
         }
     }
     L.gPts = (P + 3) / 4 > 0 ? (P + 3) / 4 : 1;
@@ -2753,7 +2772,7 @@ static void ba_enqueue_solve_update(hipStream_t stream, const BaPlan& L) {
     const dim3 blk(256);
     const int gUpd = L.gUpd;
     if (L.packed) {
-        hipLaunchKernelGGL(k_solve_blocked, dim3(1), dim3(1024), sb_lds_bytes(D.n), stream, L.DB);
+        sb_launch_solve(stream, L.DB);
         hipLaunchKernelGGL(k_update_packed, dim3(L.gPack), blk, 0, stream, L.DB);
         return;
     }
@@ -2780,7 +2799,7 @@ static void ba_enqueue_solve_update(hipStream_t stream, const BaPlan& L) {
         hipLaunchKernelGGL(k_update<36>, dim3(gUpd), blk, 0, stream, D);
     } else {
         if (D.n <= SB_MAX_ORDER && !L.legacySolve) {
-            hipLaunchKernelGGL(k_solve_blocked, dim3(1), dim3(1024), sb_lds_bytes(D.n), stream, D);
+            sb_launch_solve(stream, D);
         } else if (D.n <= 64) {
             hipLaunchKernelGGL(k_solve_wave, dim3(1), dim3(64), sizeof(double) * (size_t)D.n * (D.n | 1), stream, D);
         } else if (L.useLds) {
@@ -2891,6 +2910,10 @@ struct BaWorker {
     hipGraphExec_t gHead = nullptr, gChunk = nullptr, gTail = nullptr, gRound = nullptr, gFinish = nullptr;
     int* h_state = nullptr;  // pinned {inner_done, all_done}
     hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t tmEv[3] = {nullptr, nullptr, nullptr};  // timing: the job's first and last moment on the workspace's stream, end of the window parse
+    int jobsDone = 0;
+    double gpuMsTotal = 0, gpuMsLast = 0, gpuMsMax = 0, gpuMsParse = 0;
+    bool parseStamped = false;
     std::thread::id tid;     // the worker thread: the only one that destroys the graph handles above
     bool stale = false;      // (under mu) another thread invalidated what the graphs bake in: re-capture before the next job
 };
@@ -3098,6 +3121,10 @@ static int ba_worker_run_window(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
     CS_HIP(hipMemcpyAsync(win->h_totals + 4, win->pairTotal, sizeof(int), hipMemcpyDeviceToHost, s));
     int* h_optr = win->h_totals + 8;
     CS_HIP(hipMemcpyAsync(h_optr, b->obs_ptr, sizeof(int) * ((size_t)win->nMap + 1), hipMemcpyDeviceToHost, s));
+    if (w->tmEv[2]) {
+        (void)hipEventRecord(w->tmEv[2], s);
+        w->parseStamped = true;
+    }
     CS_HIP(hipStreamSynchronize(s));  // (this is the worker thread: the frame loop does not wait)
     parseDone.release();              // the ring has been read
     const int P = win->h_totals[0], nObs = win->h_totals[1];
@@ -3163,7 +3190,7 @@ static int ba_worker_run_window(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
     if (rc) return rc;
     {
         static const int envChunk = getenv("COSLAM_BA_WINDOW_CHUNK") ? atoi(getenv("COSLAM_BA_WINDOW_CHUNK")) : 0;
-        w->chunk = envChunk > 0 ? envChunk : 3;
+        w->chunk = envChunk > 0 ? envChunk : 2;   // (measured in the frame loop: 1 -> 1.85, 2 -> 1.81, 3 -> 1.89 ms per joint solve)
         if (w->chunk > J.innerMaxIter && J.innerMaxIter > 0) w->chunk = J.innerMaxIter;
         if (w->chunk < 1) w->chunk = 1;
     }
@@ -3202,7 +3229,36 @@ static int ba_worker_run_window(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
     return rc;
 }
 
+static int ba_worker_run_inner(cs_ba* b, BaWorker* w, const BaAsyncJob& J);
+// (cs_ba_worker_stats: how long the job held the workspace's stream, from the moment the work it waits for was done)
 static int ba_worker_run(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
+    (void)hipSetDevice(b->device);
+    if (!w->tmEv[0]) {
+        (void)hipEventCreate(&w->tmEv[0]);
+        (void)hipEventCreate(&w->tmEv[1]);
+        (void)hipEventCreate(&w->tmEv[2]);
+    }
+    w->parseStamped = false;
+    (void)hipStreamWaitEvent(b->own_stream, J.ready, 0);
+    (void)hipEventRecord(w->tmEv[0], b->own_stream);
+    const int rc = ba_worker_run_inner(b, w, J);
+    (void)hipEventRecord(w->tmEv[1], b->own_stream);
+    if (hipEventSynchronize(w->tmEv[1]) == hipSuccess) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, w->tmEv[0], w->tmEv[1]) == hipSuccess) {
+            float pms = 0;
+            if (w->parseStamped && hipEventElapsedTime(&pms, w->tmEv[0], w->tmEv[2]) != hipSuccess) pms = 0;
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->gpuMsParse += pms;
+            w->jobsDone += 1;
+            w->gpuMsTotal += ms;
+            w->gpuMsLast = ms;
+            if (ms > w->gpuMsMax) w->gpuMsMax = ms;
+        }
+    }
+    return rc;
+}
+static int ba_worker_run_inner(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
     if (J.win) return ba_worker_run_window(b, w, J);
     CS_HIP(hipSetDevice(b->device));
     hipStream_t s = b->own_stream;
@@ -3296,6 +3352,27 @@ static void ba_worker_main(cs_ba* b, BaWorker* w) {
     }
 }
 
+// diagnostics: jobs completed by the workspace's worker and the time they held its stream (GPU clock, ms); resets the sums
+extern "C" int cs_ba_worker_stats(cs_ba* b, int* jobs, double* gpu_ms_total, double* gpu_ms_last, double* gpu_ms_max, double* gpu_ms_parse) {
+    if (!b) return CS_ERR_INVALID;
+    BaWorker* w = b->worker;
+    if (jobs) *jobs = 0;
+    if (gpu_ms_total) *gpu_ms_total = 0;
+    if (gpu_ms_last) *gpu_ms_last = 0;
+    if (gpu_ms_max) *gpu_ms_max = 0;
+    if (gpu_ms_parse) *gpu_ms_parse = 0;
+    if (!w) return CS_OK;
+    std::lock_guard<std::mutex> lk(w->mu);
+    if (jobs) *jobs = w->jobsDone;
+    if (gpu_ms_total) *gpu_ms_total = w->gpuMsTotal;
+    if (gpu_ms_last) *gpu_ms_last = w->gpuMsLast;
+    if (gpu_ms_max) *gpu_ms_max = w->gpuMsMax;
+    if (gpu_ms_parse) *gpu_ms_parse = w->gpuMsParse;
+    w->jobsDone = 0;
+    w->gpuMsTotal = w->gpuMsMax = w->gpuMsParse = 0;
+    return CS_OK;
+}
+
 static void ba_worker_stop(cs_ba* b) {
     BaWorker* w = b->worker;
     if (!w) return;
@@ -3308,6 +3385,8 @@ static void ba_worker_stop(cs_ba* b) {
     ba_worker_destroy_graphs(w);
     if (w->h_state) (void)hipHostFree(w->h_state);
     for (hipEvent_t e : w->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : w->tmEv)
         if (e) (void)hipEventDestroy(e);
     delete w;
     b->worker = nullptr;

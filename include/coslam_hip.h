@@ -561,6 +561,10 @@ int cs_ba_solve_window_async(cs_ba* b, cs_ba_window* w, void* after_stream, cons
 /* size and bind workspace b for the largest problem w can produce (cs_ba_solve_window_async does it on first use); afterwards
  * cs_ba_result_buffers' addresses stay put across the window's solves -- a follow-up record can be built before the first */
 int cs_ba_reserve_for_window(cs_ba* b, cs_ba_window* w);
+/* diagnostics: solves completed by the workspace's worker thread since the last call and the time they held its stream (GPU
+ * clock, milliseconds, from the moment the work the solve waits for was done); the call resets the sums */
+int cs_ba_worker_stats(cs_ba* b, int* jobs, double* gpu_ms_total, double* gpu_ms_last, double* gpu_ms_max,
+                       double* gpu_ms_parse /* of gpu_ms_total: the window parses (cs_ba_solve_window_async), up to their host round trip */);
 int cs_ba_window_last_problem(cs_ba_window* w, int* C, int* P, int* nObs, const int** d_pointMap, int* keyFrames);
 int cs_ba_problem_buffers(cs_ba* b, const double** d_Ks, const int** d_obs_ptr, const int** d_obs_cam, const double** d_obs_xy);
 /* Work that belongs right behind every solve of this workspace, on the solve's own stream and without a host round trip:
