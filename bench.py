@@ -53,6 +53,7 @@ P_REG = 1536             # map points per registration pass (the size of the int
 PIXEL_ERR_VAR = 10.0      # Const::PIXEL_ERR_VAR, reference src/app/SL_GlobParam.cpp:37
 MAX_EPI_ERR = 6.0         # Const::MAX_EPI_ERR, :36
 HBM_PEAK_GBS = 8000.0
+SETUP_SECONDS = float(os.environ.get("BENCH_SETUP_SECONDS", "0.5"))   # untimed set-up run before the warm-up (see main)
 SEED = 0xC051A + 2
 
 
@@ -324,11 +325,11 @@ def main():
                     help="tracker stream confined to the first N compute units (0 = whole chip): leaves CUs the persistent tracker "
                          "never occupies, where the BA's 1024-thread solver workgroup can start while the tracker runs")
     ap.add_argument("--klt-cams-per-launch", type=int, default=int(os.environ.get("BENCH_KLT_CAMS_PER_LAUNCH", "-1")),
-                    help="cameras per persistent tracker launch.  0 = as many as are co-resident (all 8 at two waves per SIMD: the "
-                         "fastest tracker, 146 us per frame).  3 or 4 = launches of <= 3 / 4 cameras back to back at ONE wave per SIMD "
-                         "(tracker 203 us per frame with 4): every SIMD keeps a free wave slot and every CU 96 KB of LDS for the "
-                         "key-frame solves' kernels, whose latency chain -- not the tracker -- bounds the loop: measured +6 % (4) / "
-                         "+8 % (3) frames/s (profiles/r03_tracker_split.txt).  -1 (default) = 4 when all 8 cameras are on this GPU, else 0")
+                    help="cameras per persistent tracker launch.  0 (default, also -1) = as many as are co-resident: all 8 in ONE launch at "
+                         "two waves per SIMD, the tracker's own best configuration (145 us per frame, HBM frac 0.043).  4 = two launches of 4 "
+                         "cameras back to back at ONE wave per SIMD (2 x 102 us): every SIMD keeps 352 free VGPRs and every CU 96 KB of LDS for "
+                         "the key-frame solves' kernels, whose latency chain -- not the tracker -- bounds the loop: +2.5-3 % frames/s, tracker "
+                         "HBM frac 0.030 (profiles/r03_tracker_split.txt).  3: 2374, 2: 1978 frames/s")
     ap.add_argument("--reg-stream", type=int, default=int(os.environ.get("BENCH_REG_STREAM", "0")),
                     help="1: the two registration passes of frame f on their own stream behind pose(f) -- they are consumers of the "
                          "frame's poses and features, nothing of frame f+1's tracking or pose depends on them, so they overlap the next "
@@ -474,7 +475,7 @@ def main():
             for t in trks:
                 t.set_cu_count(256 - persist_j - persist_i)
     if args.klt_cams_per_launch < 0:
-        args.klt_cams_per_launch = 4 if (nc == N_CAMS and not args.serial) else 0
+        args.klt_cams_per_launch = 0
     if args.klt_cams_per_launch > 0 and not args.klt_cus:
         # the co-residency budget of the persistent tracker is what decides how many cameras share a launch: hand it the
         # budget of cams_per_launch cameras (250 waves each, 8 resident waves per CU) -- no CU mask, the launches still spread
@@ -808,6 +809,17 @@ def main():
     for i in range(n_setup):
         step(i + 1, args.key_every > 0 and i % max(args.key_every, 1) == 0)
     barrier()
+    # ... and the device out of its idle power state: a fresh process on a fresh box measured 2177 frames/s on the driver's
+    # 20-step command where the second and third process measured 2460 / 2489 (profiles/r03_bench_lines.txt) -- the 12 ms of
+    # set-up above plus W = 5 frames are over before the clocks have ramped.  Keep the loop running (same cadence, untimed)
+    # for SETUP_SECONDS of wall time; K and W are untouched.
+    t_su = time.perf_counter()
+    ke = max(args.key_every, 1)
+    while time.perf_counter() - t_su < SETUP_SECONDS:
+        for i in range(n_setup, n_setup + 4 * ke):
+            step(i + 1, args.key_every > 0 and i % ke == 0)
+        n_setup += 4 * ke
+        barrier()
     base0 = n_setup    # (the frame sequence continues through set-up, warm-up and the timed region: no jump for the tracker)
     for i in range(args.warmup):
         step(base0 + i + 1, args.key_every > 0 and i % args.key_every == 0)
@@ -1068,6 +1080,7 @@ def main():
                 nIterations=10, nLevels=L5, levelSkip=1, windowWidth=7, trackWithGain=1, minCornerness=3000.0, convergenceThreshold=1.0,
                 SSD_Threshold=20000.0, minDistance=8), device=local_rank)
             t.allocate(W5, H5, L5, FW5, FH5)
+            t.set_concurrent_handles(C5)   # (the headline's 8 trackers are still alive but idle: only this group's launches overlap)
             t5s.append(t)
         g5 = coslam_amd.KLT_TrackerGroup(t5s)
         g5.set_stream(klt_s.cuda_stream)
@@ -1101,7 +1114,9 @@ def main():
         cfg5_klt = {"workload": "cfg5 KLT: 4 cameras 1920x1080 x 5000 slots (100x50) as one camera group on one GPU, 4 levels, 7x7, 10 it/level "
                                 "with gain, redetect + prefetch per frame", "frames_per_s": n5 / dtk, "camera_frames_per_s": C5 * n5 / dtk,
                     "us_per_frame": dtk / n5 * 1e6, "tracker_stage_us": trk_us5, "tracker_launches_per_frame": p5["launches_per_frame"],
-                    "tracker_algorithmic_GBps": per_feat5 * FW5 * FH5 * C5 / (trk_us5 * 1e-6) / 1e9, "live_features": live5}
+                    "tracker_algorithmic_GBps": per_feat5 * FW5 * FH5 * C5 / (trk_us5 * 1e-6) / 1e9, "live_features": live5,
+                    "hbm_frac_per_launch": per_feat5 * FW5 * FH5 * C5 / (trk_us5 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    "pmc": "profiles/r03_cfg5_klt_pmc.json (traffic 2.98 x the algorithmic bytes, VALU issue 0.50 of the launch)"}
         g5.close()
         for t in t5s:
             t.close()

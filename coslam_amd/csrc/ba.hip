@@ -39,6 +39,7 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <string>
 
 #include "cs_common.h"
 
@@ -3005,15 +3006,51 @@ static int ba_run_segments(BaWorker* w, hipStream_t s, int maxIter, int innerMax
         }
         return n;
     };
+    // COSLAM_BA_SEGTIME=1 (diagnostic): GPU time between the ends of consecutive segments, summed per kind, printed per solve
+    static const bool segTime = getenv("COSLAM_BA_SEGTIME") != nullptr;
+    std::vector<std::pair<char, hipEvent_t>> stamps;
+    auto stamp = [&](char kind) {
+        if (!segTime) return;
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) == hipSuccess) {
+            (void)hipEventRecord(e, s);
+            stamps.push_back({kind, e});
+        }
+    };
+    stamp('0');
     size_t i = 0;
     CS_HIP(launch(seg[0].kind));
     CS_HIP(hipEventRecord(w->ev[0], s));
+    stamp(seg[0].kind);
     int slot = 0;
+    struct StampDump {
+        std::vector<std::pair<char, hipEvent_t>>& st;
+        ~StampDump() {
+            if (st.size() < 2) return;
+            (void)hipEventSynchronize(st.back().second);
+            double sum[128] = {0};
+            int cnt[128] = {0};
+            std::string seq;
+            for (size_t k = 1; k < st.size(); ++k) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, st[k - 1].second, st[k].second);
+                sum[(int)st[k].first] += ms;
+                cnt[(int)st[k].first] += 1;
+                char buf[32];
+                snprintf(buf, sizeof(buf), " %c%.0f", st[k].first, ms * 1e3);
+                seq += buf;
+            }
+            fprintf(stderr, "[ba segtime] H %.0f us, R %.0f, C %d x %.0f, T %d x %.0f, F %.0f |%s\n", sum['H'] * 1e3, sum['R'] * 1e3, cnt['C'],
+                    cnt['C'] ? sum['C'] * 1e3 / cnt['C'] : 0.0, cnt['T'], cnt['T'] ? sum['T'] * 1e3 / cnt['T'] : 0.0, sum['F'] * 1e3, seq.c_str());
+            for (auto& q : st) (void)hipEventDestroy(q.second);
+        }
+    } stampDump{stamps};
     while (i < seg.size()) {
         const size_t n = next_of(i);
         if (n < seg.size() && !noSpec) {
             CS_HIP(launch(seg[n].kind));
             CS_HIP(hipEventRecord(w->ev[slot ^ 1], s));
+            stamp(seg[n].kind);
         }
         CS_HIP(hipEventSynchronize(w->ev[slot]));
         if (seg[i].kind == 'C' && (w->h_state[0] || w->h_state[1])) skipChunksOfOuter = seg[i].outer;  // inner_done / all_done
@@ -3023,6 +3060,7 @@ static int ba_run_segments(BaWorker* w, hipStream_t s, int maxIter, int innerMax
             if (m < seg.size()) {
                 CS_HIP(launch(seg[m].kind));
                 CS_HIP(hipEventRecord(w->ev[slot ^ 1], s));
+                stamp(seg[m].kind);
             }
             i = m;
         } else {
