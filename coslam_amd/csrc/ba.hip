@@ -59,7 +59,7 @@ namespace {
 struct BaState {
     double lambda, cost, cost_new, step2, cost0;
     int inner_it, inner_done, all_done, chol_ok, changed, nIterTotal, nOuter, nOutliers, first_cost;
-    int seq;            // packed path: LM steps started so far (the flow schedule's sequence number)
+    int seq;            // packed path: LM steps started so far in this solve (diagnostic; the persistent kernel's barrier epochs)
     int pending;        // packed path: a tentative step awaits its accept / reject (decided by the next k_lin_packed)
     int cur;            // packed path: which estimate is current: 0 = Rs / Ts / pts, 1 = Rn / Tn / Mn
     int nCholFail;      // LM steps whose reduced system could not be factorised (not positive definite, NaN, time-out)

@@ -553,7 +553,10 @@ typedef struct cs_ba_window cs_ba_window;
 cs_ba_window* cs_ba_window_create(int device, int nCams, int nKeyFrames, int N, int nMapPts);
 void cs_ba_window_destroy(cs_ba_window* w);
 /* cams: HOST array of nCams records whose xy / state / slot2map (device) are the hand-back's output of this frame;
- * d_K: nCams x 9, or one 9 shared by all cameras (kShared != 0); d_R nCams x 9, d_t nCams x 3.  Asynchronous on hip_stream. */
+ * d_K: nCams x 9, or one 9 shared by all cameras (kShared != 0); d_R nCams x 9, d_t nCams x 3.  Asynchronous on hip_stream.
+ * A solve request (cs_ba_solve_window_async) fixes the window -- its ring slots -- and a snapshot of the map when it is MADE; the
+ * ring holds two key frames more than a window, so the caller may push two key frames beyond a request whose parse has not run
+ * yet; a third push waits (on the host) for the oldest outstanding parse. */
 int cs_ba_window_push_dev(cs_ba_window* w, void* hip_stream, const cs_handback_cam* cams, const double* d_K, int kShared,
                           const double* d_R, const double* d_t, int frame);
 int cs_ba_solve_window_async(cs_ba* b, cs_ba_window* w, void* after_stream, const double* d_mapPts, const unsigned char* d_mapStatic,
