@@ -39,6 +39,7 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <chrono>
 #include <string>
 
 #include "cs_common.h"
@@ -65,6 +66,7 @@ struct BaState {
     int nCholFail;      // LM steps whose reduced system could not be factorised (not positive definite, NaN, time-out)
     int nAccepted;      // LM steps that were accepted
     int solverTimeout;  // the dataflow Cholesky gave up waiting for a block column (scheduling stall, not arithmetic)
+    int fuseEpoch;      // packed path: fused update + linearisation launches that went through their grid barrier in this solve
 };
 
 struct BaDev {
@@ -2047,7 +2049,7 @@ struct BaInitCopy {  // initial estimate to copy into the workspace (cs_ba_solve
     double *R, *T, *M;
     int nR, nT, nM;
 };
-__global__ __launch_bounds__(256) void k_init_state(BaState* st, int* outlier, int nObs, BaInitCopy I) {
+__global__ __launch_bounds__(256) void k_init_state(BaState* st, int* outlier, int nObs, BaInitCopy I, int* fuseBar) {
     const int t0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
     for (int o = t0; o < nObs; o += stride) outlier[o] = 0;
     if (I.R0) {
@@ -2061,9 +2063,10 @@ __global__ __launch_bounds__(256) void k_init_state(BaState* st, int* outlier, i
     z.cost = z.cost_new = z.step2 = z.cost0 = 0;
     z.inner_it = z.inner_done = z.all_done = z.chol_ok = z.changed = z.nIterTotal = z.nOuter = z.nOutliers = 0;
     z.nCholFail = z.nAccepted = z.solverTimeout = 0;
-    z.pending = z.cur = z.seq = 0;
+    z.pending = z.cur = z.seq = z.fuseEpoch = 0;
     z.first_cost = 1;
     *st = z;
+    if (fuseBar) *fuseBar = 0;  // the grid barrier's counter of k_update_lin_packed (monotonic within a solve)
 }
 
 __global__ void k_outer_begin(BaDev D) {
@@ -2266,6 +2269,7 @@ struct BaPlan {
     bool cholFlow;     // orders beyond the LDS solver: the one-launch dataflow Cholesky (ba_cholflow_dev.h)
     CholFlow F;
     bool packed;       // orders 37..176 with pair lists, no point with more than 64 measurements: ba_packed_dev.h
+    bool fuseUL;       // ... with update(k) + linearisation(k + 1) as one launch around a grid barrier (k_update_lin_packed)
     int gPack;
     bool persist;      // ... and a run of LM steps as ONE cooperative launch of persistG workgroups (ba_persist_dev.h)
     int persistG;
@@ -2683,6 +2687,14 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
             L.DB.st = b->st2;
             L.DB.stn = b->st;
         }
+        // COSLAM_BA_FUSE_UL=1: update(k) + linearisation(k + 1) as ONE launch around a grid barrier (k_update_lin_packed; its
+        // workgroups must all be resident together: a few dozen 256-thread workgroups are, anywhere).  Off by default: bit-identical
+        // results, one kernel boundary less per LM step, and NO gain in the frame loop (2.086 vs 2.088 ms per joint solve: the
+        // in-loop step is slowed by the co-running streams' kernels -- undisturbed solves run at the stand-alone 68 us per step
+        // with either schedule -- not by its launch boundaries).  (Read per plan so that a test can switch it.)
+        const char* fuseEnv = getenv("COSLAM_BA_FUSE_UL");
+        L.fuseUL = L.packed && fuseEnv && fuseEnv[0] == '1' && L.gPack <= 192;
+        L.persistBar = b->persistBar;
         const bool noPersist = getenv("COSLAM_BA_PERSIST") && getenv("COSLAM_BA_PERSIST")[0] == '0';
         L.persist = L.packed && !noPersist && b->persistWGs > 0;
         L.persistG = 0;
@@ -2720,7 +2732,7 @@ static void ba_enqueue_init(cs_ba* b, hipStream_t stream, const BaPlan& L, bool 
     if (gi < 1) gi = 1;
     if (gi > 64) gi = 64;
     BaInitCopy I = {d_Rs0, d_Ts0, d_pts0, b->Rs, b->Ts, b->pts, 9 * D.C, 3 * D.C, 3 * D.P};
-    hipLaunchKernelGGL(k_init_state, dim3(gi), dim3(256), 0, stream, b->st, b->outlier, D.nObs, I);
+    hipLaunchKernelGGL(k_init_state, dim3(gi), dim3(256), 0, stream, b->st, b->outlier, D.nObs, I, b->persistBar + 16);
     // Z's entries of (point, camera) pairs without a measurement are never written: cleared once per solve (every present
     // entry is rewritten by every step)
     if (L.syrk) (void)hipMemsetAsync(L.Y.Zt, 0, L.syrkZtBytes, stream);
@@ -2842,6 +2854,29 @@ static void ba_enqueue_lm_run(hipStream_t stream, const BaPlan& L, int steps) {
         (void)hipMemsetAsync(L.persistBar, 0, 16 * sizeof(int), stream);
         LmPersist Q = {L.persistBar, steps};
         hipLaunchKernelGGL(k_lm_persist, dim3(L.persistG), dim3(LP_NT), L.persistLds, stream, L.D, Q);
+        return;
+    }
+    if (L.packed && L.fuseUL && steps > 1) {
+        // lin | (schur, solve, update + lin) x (steps - 1) | schur, solve, update | final: the LM state alternates between the two
+        // state words (X reads, Xo is written by the fused launch)
+        const dim3 blk(256);
+        const int gS = (L.nPairs * CS_SCHUR_WPP + 3) / 4;
+        hipLaunchKernelGGL(k_lin_packed, dim3(L.gPack), blk, 0, stream, L.D);  // reads A, writes B
+        const BaDev* X = &L.DB;
+        const BaDev* Xo = &L.D;
+        for (int it = 0; it < steps; ++it) {
+            if (L.D.nc > 0) hipLaunchKernelGGL(k_schur_wave, dim3(gS), blk, 0, stream, *X);
+            sb_launch_solve(stream, *X);
+            if (it + 1 < steps) {
+                hipLaunchKernelGGL(k_update_lin_packed, dim3(L.gPack), blk, 0, stream, *X, L.persistBar + 16);
+                const BaDev* t = X;
+                X = Xo;
+                Xo = t;
+            } else {
+                hipLaunchKernelGGL(k_update_packed, dim3(L.gPack), blk, 0, stream, *X);  // writes Xo's word, pending
+            }
+        }
+        hipLaunchKernelGGL(k_control_final, dim3(1), blk, 0, stream, *Xo);
         return;
     }
     for (int it = 0; it < steps; ++it) {
@@ -3017,16 +3052,27 @@ static int ba_run_segments(BaWorker* w, hipStream_t s, int maxIter, int innerMax
             stamps.push_back({kind, e});
         }
     };
+    double hostUs[128] = {0};   // (diagnostic) host time spent inside launch(kind), per kind
+    auto timed_launch = [&](char kind) {
+        if (!segTime) return launch(kind);
+        const auto t0 = std::chrono::steady_clock::now();
+        const hipError_t e = launch(kind);
+        hostUs[(int)kind] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        return e;
+    };
     stamp('0');
     size_t i = 0;
-    CS_HIP(launch(seg[0].kind));
+    CS_HIP(timed_launch(seg[0].kind));
     CS_HIP(hipEventRecord(w->ev[0], s));
     stamp(seg[0].kind);
     int slot = 0;
     struct StampDump {
         std::vector<std::pair<char, hipEvent_t>>& st;
+        double* hostUs;
         ~StampDump() {
             if (st.size() < 2) return;
+            fprintf(stderr, "[ba segtime] host us inside launch(): H %.0f R %.0f C %.0f T %.0f F %.0f\n", hostUs['H'], hostUs['R'], hostUs['C'],
+                    hostUs['T'], hostUs['F']);
             (void)hipEventSynchronize(st.back().second);
             double sum[128] = {0};
             int cnt[128] = {0};
@@ -3044,11 +3090,11 @@ static int ba_run_segments(BaWorker* w, hipStream_t s, int maxIter, int innerMax
                     cnt['C'] ? sum['C'] * 1e3 / cnt['C'] : 0.0, cnt['T'], cnt['T'] ? sum['T'] * 1e3 / cnt['T'] : 0.0, sum['F'] * 1e3, seq.c_str());
             for (auto& q : st) (void)hipEventDestroy(q.second);
         }
-    } stampDump{stamps};
+    } stampDump{stamps, hostUs};
     while (i < seg.size()) {
         const size_t n = next_of(i);
         if (n < seg.size() && !noSpec) {
-            CS_HIP(launch(seg[n].kind));
+            CS_HIP(timed_launch(seg[n].kind));
             CS_HIP(hipEventRecord(w->ev[slot ^ 1], s));
             stamp(seg[n].kind);
         }

@@ -410,6 +410,16 @@ def test_packed_lm_step_kernels_match_oracle(hip, case):
         assert np.array_equal(outp, out) and stp.nIterTotal == st.nIterTotal and stp.nOuter == st.nOuter and stp.flags == 0, (g, use_async)
         assert np.max(np.abs(Rp - R)) < 1e-8 and np.max(np.abs(Tp - T)) < 1e-7 and np.max(np.abs(Mp[sane] - M[sane])) < 1e-6
         assert abs(stp.cost - st.cost) <= 1e-9 * max(1.0, st.cost)
+    # update(k) + linearisation(k + 1) as one launch around a grid barrier (k_update_lin_packed, COSLAM_BA_FUSE_UL=1): the same
+    # arithmetic in the same order -- bit for bit the separate launches' result, up front and through the worker thread
+    os.environ["COSLAM_BA_FUSE_UL"] = "1"
+    try:
+        for use_async in (False, True):
+            Rf, Tf, Mf, outf, stf = _solve_in_workspace(pr, ptr, cam, xy, ncon, npcon, maxIter, inner, use_async=use_async)
+            assert np.array_equal(outf, out) and stf.nIterTotal == st.nIterTotal and stf.nOuter == st.nOuter and stf.flags == 0
+            assert np.array_equal(Rf, R) and np.array_equal(Tf, T) and np.array_equal(Mf, M) and stf.cost == st.cost, use_async
+    finally:
+        os.environ.pop("COSLAM_BA_FUSE_UL", None)
 
 
 def test_async_worker_schedule_gives_the_up_front_schedule_bit_for_bit(hip):
