@@ -269,8 +269,12 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
         oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), map_pts[P_REG:2 * P_REG],
                                cov[P_REG:2 * P_REG], no_feat, 2.5 * PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)
         pf = oracle.point_features(st[c], s2m[c], P_REG).reshape(P_REG, 1)
-        oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), map_pts[:P_REG],
-                               cov[:P_REG], pf, PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)
+        rs = oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), map_pts[:P_REG],
+                                    cov[:P_REG], pf, PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)
+        h = hist[c]
+        if h["R"]:   # staticCheckMergability of the candidates over their whole tracks (the history as of the previous frame's pose update)
+            oracle.register_mergability_cam(Kc, np.stack(h["R"]), np.stack(h["t"]), np.stack(h["xy"]), tl[c], map_pts[:P_REG], cov[:P_REG],
+                                            rs["slot"][:, 0], PIXEL_ERR_VAR)
 
     def run_cams(cams, f, frame_no):
         for c in cams:
@@ -346,6 +350,8 @@ def main():
                          "parsed on the device from the last 5 key frames' tracked features and poses (N = 1 default: cs_ba_window_*)")
     ap.add_argument("--no-pose-update", action="store_true",
                     help="skip poseUpdate3D's gate + seqTriangulate loop and the dynamic-point test behind the pose solve")
+    ap.add_argument("--no-mergability", action="store_true",
+                    help="skip staticCheckMergability over the candidates' whole tracks behind the current-static registration pass")
     ap.add_argument("--no-ncc", action="store_true", help="diagnostic: skip the inter-camera NCC matching leg (not a valid bench line)")
     ap.add_argument("--no-cxx-loop", action="store_true", help="skip the C++ frame loop (tools/cxx/frame_loop.bin, config.cxx_frame_loop)")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the upload-inclusive repetition of the loop (config.with_upload)")
@@ -580,6 +586,7 @@ def main():
         d_isstatic = torch.ones((nc, N_FEAT), dtype=torch.uint8, device=dev)
         d_reproj = torch.zeros((nc, N_FEAT), dtype=torch.float64, device=dev)
         d_mapflags = torch.zeros(n_map, dtype=torch.uint8, device=dev)
+        d_mergeable = torch.zeros((P_REG, nc), dtype=torch.uint8, device=dev)
         d_iK1 = torch.from_numpy(np.linalg.inv(sc.K).ravel().copy()).to(dev)
         pose_upd = TrackHistory(nc, N_FEAT, PU_HIST, device=local_rank)
         pu_args = poseupdate_cams([dict(K=d_K1.data_ptr(), iK=d_iK1.data_ptr(), xy=d_xy[i].data_ptr(), state=d_state[i].data_ptr(),
@@ -636,6 +643,10 @@ def main():
                                 d_cov.data_ptr() + 72 * pts_off, pf.data_ptr(), sS, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR,
                                 o["slot"].data_ptr(), o["m"].data_ptr(), o["var"].data_ptr(), o["dist"].data_ptr(),
                                 o["flags"].data_ptr(), device=local_rank)
+        if pose_upd is not None and not args.no_mergability:
+            # staticCheckMergability of every candidate of the current-static pass over its whole track (SL_CoSLAM.cpp:714-729, :768)
+            pose_upd.register_mergability_dev(reg_s.cuda_stream, pu_args, P_REG, d_map.data_ptr(), d_cov.data_ptr(),
+                                              reg_out[1]["slot"].data_ptr(), PIXEL_ERR_VAR, d_mergeable.data_ptr())
 
     # upload-inclusive variant (config.with_upload): the frames arrive in PINNED HOST memory (the capture threads' buffers,
     # reference src/app/SL_CoSLAM.cpp:119-133) and every frame's 8 x 300 KB go host -> device inside the loop: frame i + 2 is
@@ -815,10 +826,13 @@ def main():
     # for SETUP_SECONDS of wall time; K and W are untouched.
     t_su = time.perf_counter()
     ke = max(args.key_every, 1)
-    while time.perf_counter() - t_su < SETUP_SECONDS:
+    rounds = 0
+    # (N > 1: every rank must take the same number of steps -- each carries an all-gather -- so the count is fixed there, not timed)
+    while (rounds < 12) if world > 1 else (time.perf_counter() - t_su < SETUP_SECONDS):
         for i in range(n_setup, n_setup + 4 * ke):
             step(i + 1, args.key_every > 0 and i % ke == 0)
         n_setup += 4 * ke
+        rounds += 1
         barrier()
     base0 = n_setup    # (the frame sequence continues through set-up, warm-up and the timed region: no jump for the tracker)
     for i in range(args.warmup):
@@ -1195,7 +1209,8 @@ def main():
                        "posegraph_last": pg_info,
                        "register_candidates_last_frame": None if args.no_register else
                        {"active": int((reg_out[0]["slot"] >= 0).sum().item()), "current_static": int((reg_out[1]["slot"] >= 0).sum().item()),
-                        "already_attached": int((reg_out[1]["slot"] == -1).sum().item())},
+                        "already_attached": int((reg_out[1]["slot"] == -1).sum().item()),
+                        "current_static_mergeable_over_the_whole_track": None if pose_upd is None else int((d_mergeable == 1).sum().item())},
                        "pose_update": None if pose_upd is None else {
                            "what": "poseUpdate3D's gate + seqTriangulate over all static mapped features and detectDynamicFeaturePoints over "
                                    "all unmapped / dynamic tracks, every frame, one launch for the rank's cameras (cs_pose_update_frame_dev)",

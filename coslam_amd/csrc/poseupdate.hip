@@ -295,6 +295,85 @@ __global__ __launch_bounds__(256) void k_pose_update(PuArgs A) {
     C.isStatic[i] = type;
 }
 
+// ---- CoSLAM::staticCheckMergability (src/app/SL_CoSLAM.cpp:714-729) for every candidate of a registration search --------------
+// The candidate feature and every earlier feature of its track (fp, fp->preFrame, ...) must lie within Mahalanobis distance 1 of
+// the map point's projection under the pose of its own frame (FeaturePoint::cam), covariance J cov J^T + pixelVar^2 I; the walk
+// stops at the first failure.  The reference runs it per candidate inside the registration loops on the host, following
+// pointers; here a group of lanes = one (map point, camera) candidate, blockIdx.y = camera, the camera's ring of poses in LDS,
+// the track's past pixels from the history ring (one 16-byte gather per step).
+struct MgArgs {
+    int nCams, N, P, H, head, nHist;
+    double sigma;
+    const double* M;
+    const double* cov;
+    const int* slot;
+    unsigned char* out;
+    const double* histXY;
+    const double* histR;
+    const double* histT;
+    cs_poseupdate_cam cam[PU_MAX_CAMS];
+};
+// MG_LPC lanes per candidate: lane r of the group takes the frames j = r, r + MG_LPC, ... of the walk (the verdict is the AND over
+// the frames: the order in which they are tested does not enter it), so a candidate's 64-frame walk is 8 steps deep and the
+// 12 k candidates of a pass are 1500 waves -- the whole chip -- instead of 190 waves walking 64 dependent steps each (68 us).
+constexpr int MG_LPC = 8;
+__global__ __launch_bounds__(256) void k_register_mergability(MgArgs A) {
+    extern __shared__ double mg_pose[];  // [nHist][12]
+    const int c = blockIdx.y, tid = threadIdx.x, N = A.N, H = A.H;
+    const cs_poseupdate_cam& C = A.cam[c];
+    const double* hR = A.histR + (size_t)c * H * 9;
+    const double* hT = A.histT + (size_t)c * H * 3;
+    const double* hXY = A.histXY + (size_t)c * H * 2 * N;
+    for (int q = tid; q < A.nHist * 12; q += 256) {
+        const int j = q / 12, e = q - 12 * j, rs = (A.head - j + H) % H;
+        mg_pose[q] = e < 9 ? hR[(size_t)rs * 9 + e] : hT[(size_t)rs * 3 + (e - 9)];
+    }
+    __syncthreads();
+    const int lane = tid & 63, r = lane % MG_LPC, g = lane / MG_LPC;
+    const int p = (blockIdx.x * 256 + tid) / MG_LPC;
+    const bool live = p < A.P;
+    const int s = live ? A.slot[(size_t)p * A.nCams + c] : -1;
+    bool fail = false;
+    if (s >= 0) {
+        double M[3], cov[9];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) M[q] = A.M[3 * (size_t)p + q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) cov[q] = A.cov[9 * (size_t)p + q];
+        const int f1 = C.trackSpan[s], f2 = C.trackSpan[N + s];
+        const int len = f1 >= 0 ? f2 - f1 + 1 : 0;
+        const int depth = len < A.nHist ? len : A.nHist;
+        for (int j = r; j < depth && !fail; j += MG_LPC) {
+            const double* R = mg_pose + 12 * j;
+            const double* t = R + 9;
+            const int rs = (A.head - j + H) % H;
+            const double mx = hXY[(size_t)rs * 2 * N + s], my = hXY[(size_t)rs * 2 * N + N + s];
+            const PuProj q = pu_project(C.K, R, t, M);
+            const double rm0 = q.u / q.w, rm1 = q.v / q.w;
+            double JC[6], var[4], ivar[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) JC[3 * i + k] = (q.J[3 * i] * cov[k] + q.J[3 * i + 1] * cov[3 + k]) + q.J[3 * i + 2] * cov[6 + k];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const double sv = (JC[3 * i] * q.J[3 * k] + JC[3 * i + 1] * q.J[3 * k + 1]) + JC[3 * i + 2] * q.J[3 * k + 2];
+                    var[2 * i + k] = (i == k) ? sv + A.sigma * A.sigma : sv;
+                }
+            pu_mat22_inv(var, ivar);
+            const double dx = rm0 - mx, dy = rm1 - my;
+            fail = dx * (ivar[0] * dx + ivar[1] * dy) + dy * (ivar[2] * dx + ivar[3] * dy) > 1.0;  // :723
+        }
+    }
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(fail);
+    if (live && r == 0) {
+        const bool anyFail = ((b >> (MG_LPC * g)) & ((1ull << MG_LPC) - 1ull)) != 0ull;
+        A.out[(size_t)p * A.nCams + c] = s < 0 ? 255 : (anyFail ? 0 : 1);
+    }
+}
+
 }  // namespace
 
 struct cs_track_history {
@@ -464,4 +543,36 @@ extern "C" int cs_pose_update_frame_dev(cs_track_history* h, void* hip_stream, c
     pu_advance(h, frame);
     pu_fill_dyn(A, h, minLen, minOutNum, maxEpiErr, d_numDyn);
     return pu_launch("cs_pose_update_frame_dev", h->device, hip_stream, A, cams, true, true);
+}
+
+extern "C" int cs_register_mergability_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int P,
+                                           const double* d_M, const double* d_cov, const int* d_slot, double pixelErrVar,
+                                           unsigned char* d_mergeable) {
+    if (!h || !cams || P < 0 || (P > 0 && (!d_M || !d_cov || !d_slot || !d_mergeable))) {
+        cs_set_error("cs_register_mergability_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (h->count < 1) {
+        cs_set_error("cs_register_mergability_dev: the history holds no frame (cs_pose_update_frame_dev / cs_detect_dynamic_dev push one per frame)");
+        return CS_ERR_INVALID;
+    }
+    if (P == 0) return CS_OK;
+    MgArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = h->nCams, A.N = h->N, A.P = P, A.H = h->H, A.head = h->head, A.nHist = h->count;
+    A.sigma = pixelErrVar;
+    A.M = d_M, A.cov = d_cov, A.slot = d_slot, A.out = d_mergeable;
+    A.histXY = h->xy, A.histR = h->R, A.histT = h->t;
+    for (int c = 0; c < h->nCams; ++c) {
+        if (!cams[c].K || !cams[c].trackSpan) {
+            cs_set_error("cs_register_mergability_dev: null pointer in camera %d", c);
+            return CS_ERR_INVALID;
+        }
+        A.cam[c] = cams[c];
+    }
+    CS_HIP(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_register_mergability, dim3((P * MG_LPC + 255) / 256, h->nCams), dim3(256), sizeof(double) * 12 * (size_t)h->count,
+                       (hipStream_t)hip_stream, A);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
 }

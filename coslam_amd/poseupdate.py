@@ -75,6 +75,12 @@ class TrackHistory:
                                             vp(d_mapFlags), int(frame), int(maxLen), int(minLen), int(minOutNum),
                                             C.c_double(maxEpiErr), vp(d_numDyn)), "cs_detect_dynamic_dev")
 
+    def register_mergability_dev(self, stream_ptr, cams, P, d_M, d_cov, d_slot, pixelErrVar, d_mergeable):
+        """CoSLAM::staticCheckMergability for every candidate of a registration search (d_slot: P x nCams), full track history."""
+        vp = C.c_void_p
+        check(self._L.cs_register_mergability_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), int(P), vp(d_M), vp(d_cov), vp(d_slot),
+                                                  C.c_double(pixelErrVar), vp(d_mergeable)), "cs_register_mergability_dev")
+
     def pose_update_frame_dev(self, stream_ptr, cams, d_pointFeat, nMap, d_R, d_t, d_mapPts, d_mapCov, d_mapFlags, largeErr,
                               pixelErrVar, frame, maxLen=20, minLen=5, minOutNum=3, maxEpiErr=6.0, d_numNodes=None, d_numOut=None,
                               d_numDyn=None):

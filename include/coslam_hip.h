@@ -350,6 +350,17 @@ int cs_pose_update_frame_dev(cs_track_history* h, void* hip_stream, const cs_pos
                              int largeErr, double pixelErrVar, int frame, int maxLen, int minLen, int minOutNum, double maxEpiErr,
                              int* d_numNodes, int* d_numOut, int* d_numDyn);
 
+/* CoSLAM::staticCheckMergability (src/app/SL_CoSLAM.cpp:714-729) for every candidate of a registration search, in one launch:
+ * the candidate feature and every earlier feature of its track must lie within Mahalanobis distance 1 of the map point's
+ * projection under the pose of its own frame (covariance J cov J^T + pixelErrVar^2 I).  d_slot: the P x nCams candidate table of
+ * cs_register_search_dev (entries < 0: no candidate); the tracks' past pixels and the frames' poses come from the history h, whose
+ * newest entry must be THIS frame (what cs_pose_update_frame_dev / cs_detect_dynamic_dev pushed); cams: K and trackSpan of every
+ * camera.  d_mergeable [P x nCams]: 1 mergeable, 0 not, 255 no candidate.  (The search's own flag bit 2 is the first term of this
+ * walk -- this frame only.)  What the registration loops do with a mergeable candidate -- pointer updates, refineMapPoint,
+ * checkUnify -- stays with the caller; compareFeaturePt, which they also call, returns true whatever its NCC score is (:546-558). */
+int cs_register_mergability_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int P, const double* d_M,
+                                const double* d_cov, const int* d_slot, double pixelErrVar, unsigned char* d_mergeable);
+
 /* ------------------------------------------------------------------------------------------
  * Pose-graph relaxation of the non-key frames after a bundle adjustment, all camera graphs in one launch
  * ------------------------------------------------------------------------------------------

@@ -261,6 +261,41 @@ def detect_dynamic(iK, histR, histT, histXY, state, slot2map, trackSpan, mapFlag
                                        _p(fl), int(maxLen), int(minLen), int(minOutNum), C.c_double(maxEpiErr), _p(isStatic))
 
 
+def static_check_mergability(K, histR, histT, histXY, slot, length, M, cov, pixelVar):
+    """org_static_check_mergability (CoSLAM::staticCheckMergability): histR (nHist x 9), histT (nHist x 3), histXY (nHist x 2N),
+    entry 0 = this frame; the track of `slot` covers the `length` newest entries.  Returns True / False."""
+    L = lib()
+    L.org_static_check_mergability.restype = C.c_int
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+    histR = np.ascontiguousarray(histR, dtype=np.float64)
+    histT = np.ascontiguousarray(histT, dtype=np.float64)
+    histXY = np.ascontiguousarray(histXY, dtype=np.float64)
+    nH = len(histR)
+    N = histXY.shape[1] // 2
+    M = np.ascontiguousarray(M, dtype=np.float64).reshape(3)
+    cov = np.ascontiguousarray(cov, dtype=np.float64).reshape(9)
+    return bool(L.org_static_check_mergability(_p(K), nH, _p(histR), _p(histT), _p(histXY), N, int(slot), int(length), _p(M), _p(cov),
+                                               C.c_double(pixelVar)))
+
+
+def register_mergability_cam(K, histR, histT, histXY, trackSpan, Ms, covs, slot, pixelVar):
+    """org_register_mergability_cam: staticCheckMergability for one camera's candidates (slot int32[P]); returns uint8[P]
+    (1 mergeable, 0 not, 255 no candidate)."""
+    L = lib()
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+    histR = np.ascontiguousarray(histR, dtype=np.float64)
+    histT = np.ascontiguousarray(histT, dtype=np.float64)
+    histXY = np.ascontiguousarray(histXY, dtype=np.float64)
+    sp = np.ascontiguousarray(trackSpan, dtype=np.int32)
+    Ms = np.ascontiguousarray(Ms, dtype=np.float64).reshape(-1, 3)
+    covs = np.ascontiguousarray(covs, dtype=np.float64).reshape(len(Ms), 9)
+    sl = np.ascontiguousarray(slot, dtype=np.int32).reshape(-1)
+    out = np.zeros(len(Ms), dtype=np.uint8)
+    L.org_register_mergability_cam(_p(K), len(histR), _p(histR), _p(histT), _p(histXY), len(sp) // 2, _p(sp), len(Ms), _p(Ms), _p(covs),
+                                   _p(sl), 1, C.c_double(pixelVar), _p(out))
+    return out
+
+
 def ncc_blocks(img, x, y, scale):
     """onc_block_compute for n points: returns (blocks uint8[n,128] (121 used, pad 0x80), abc float64[n,4], valid int32[n])."""
     L = lib()

@@ -148,6 +148,13 @@ void org_register_search(int nCams, int N, int W, int H, const double* Ks, const
                          const int* pointFeat, double sigmaSearch, double maxDist, double sigmaMerge, int* slot, double* m_out,
                          double* var_out, double* dist, int* flags);
 
+int org_static_check_mergability(const double K[9], int nHist, const double* histR, const double* histT, const double* histXY, int N,
+                                 int slot, int len, const double M[3], const double cov[9], double pixelVar);
+
+void org_register_mergability_cam(const double K[9], int nHist, const double* histR, const double* histT, const double* histXY, int N,
+                                  const int* trackSpan, int P, const double* Ms, const double* covs, const int* slot, int slotStride,
+                                  double pixelVar, unsigned char* out);
+
 /* ---- what a frame does with a camera's new pose: poseUpdate3D's gate + seqTriangulate loop, detectDynamicFeaturePoints
  * (poseupdate_oracle.c) ---- */
 void opu_seq_triangulate(const double K[9], const double R[9], const double t[3], const double m[2], double M[3], double cov[9],

@@ -171,3 +171,40 @@ void org_register_search(int nCams, int N, int W, int H, const double* Ks, const
             flags[o] = fl;
         }
 }
+
+/* CoSLAM::staticCheckMergability(mp, fp, pixelVar), SL_CoSLAM.cpp:714-729: the candidate feature AND every earlier feature of its
+ * track (fp, fp->preFrame, ...) must lie within Mahalanobis distance 1 of the map point's projection under the pose of its own
+ * frame (p->cam: the pose that frame was given), covariance J cov J^T + pixelVar^2 I; the walk stops at the first failure.
+ * History as in poseupdate_oracle.c: entry j = the frame j steps back (0: this frame): histR [nHist][9], histT [nHist][3],
+ * histXY [nHist][2N]; the track of `slot` covers the len newest entries.  Returns 1 (mergeable) or 0.
+ * (Pinned: tests/golden/mergability_golden.npz holds results of the reference's own function compiled in place.) */
+int org_static_check_mergability(const double K[9], int nHist, const double* histR, const double* histT, const double* histXY, int N,
+                                 int slot, int len, const double M[3], const double cov[9], double pixelVar) {
+    const int depth = len < nHist ? len : nHist;
+    for (int j = 0; j < depth; j++) {
+        double rm[2], var[4], ivar[4];
+        org_project(K, histR + 9 * (size_t)j, histT + 3 * (size_t)j, M, rm);
+        org_projection_cov(K, histR + 9 * (size_t)j, histT + 3 * (size_t)j, M, cov, var, pixelVar);
+        mat22_inv(var, ivar);
+        const double* h = histXY + (size_t)j * 2 * N;
+        if (maha_dist2(rm, h[slot], h[N + slot], ivar) > 1.0) return 0;
+    }
+    return 1;
+}
+
+/* ... for every candidate of one camera's column of a registration search (slot[p * slotStride]: the candidate's slot or < 0);
+ * out[p * slotStride] = 1 mergeable, 0 not, 255 no candidate */
+void org_register_mergability_cam(const double K[9], int nHist, const double* histR, const double* histT, const double* histXY, int N,
+                                  const int* trackSpan, int P, const double* Ms, const double* covs, const int* slot, int slotStride,
+                                  double pixelVar, unsigned char* out) {
+    for (int p = 0; p < P; p++) {
+        const int s = slot[(size_t)p * slotStride];
+        if (s < 0) {
+            out[(size_t)p * slotStride] = 255;
+            continue;
+        }
+        const int len = trackSpan[s] >= 0 ? trackSpan[N + s] - trackSpan[s] + 1 : 0;
+        out[(size_t)p * slotStride] =
+            (unsigned char)org_static_check_mergability(K, nHist, histR, histT, histXY, N, s, len, Ms + 3 * (size_t)p, covs + 9 * (size_t)p, pixelVar);
+    }
+}

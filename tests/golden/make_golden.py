@@ -232,10 +232,41 @@ def export_case():
     return out
 
 
+def mergability_case():
+    """the reference's own CoSLAM::staticCheckMergability (oracle/_ref/ref_mergability_test golden, CPU): 300 tracks of 1..24
+    frames, newest first, and its verdicts."""
+    import struct
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_mergability_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_mergability_test missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "m.bin")
+        subprocess.run([exe, "golden", path], check=True, stdout=subprocess.DEVNULL)
+        raw = open(path, "rb").read()
+    (n,) = struct.unpack_from("i", raw, 0)
+    o = 4
+    Ls, sig, K, M, cov, rec, verdict = [], [], [], [], [], [], []
+    for _ in range(n):
+        (L,) = struct.unpack_from("i", raw, o)
+        o += 4
+        v = np.frombuffer(raw, dtype=np.float64, count=1 + 9 + 3 + 9 + 14 * L, offset=o).copy()
+        o += v.nbytes
+        (vd,) = struct.unpack_from("i", raw, o)
+        o += 4
+        Ls.append(L), sig.append(v[0]), K.append(v[1:10]), M.append(v[10:13]), cov.append(v[13:22]), rec.append(v[22:]), verdict.append(vd)
+    assert o == len(raw)
+    return dict(L=np.array(Ls, np.int32), sigma=np.array(sig), K=np.array(K), M=np.array(M), cov=np.array(cov),
+                rec=np.concatenate(rec), rec_ptr=np.concatenate([[0], np.cumsum(14 * np.array(Ls))]).astype(np.int64),
+                verdict=np.array(verdict, np.int32))
+
+
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -250,4 +281,6 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "posegraph_golden.npz"), **posegraph_case())
     if "export" in which:
         np.savez_compressed(os.path.join(HERE, "export_golden.npz"), **export_case())
+    if "mergability" in which:
+        np.savez_compressed(os.path.join(HERE, "mergability_golden.npz"), **mergability_case())
     print("golden fixtures written")

@@ -151,3 +151,76 @@ def test_bad_arguments_are_refused():
         TrackHistory(3, 100, 100000)
     with pytest.raises(CoslamHipError):
         pose_update3d_dev(0, [dict()], 10, 0, 5, 0, 0, 0, 0, 0, 0, SIGMA)
+
+
+def test_register_mergability_walks_the_candidates_tracks_like_the_oracle():
+    """cs_register_mergability_dev: CoSLAM::staticCheckMergability (reference src/app/SL_CoSLAM.cpp:714-729) for every candidate of
+    a registration search in one launch, the tracks' past pixels and the frames' poses from the history ring, against the oracle
+    (which reproduces the reference's own function on tests/golden/mergability_golden.npz): every verdict equal."""
+    import torch
+
+    import oracle
+    from coslam_amd.poseupdate import TrackHistory
+
+    sc = Scene(T=12, seed=11)
+    nC, N, nMap, H = sc.nC, sc.N, sc.nMap, 8     # (a ring shorter than the longest tracks: the walk is bounded alike on both sides)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    th = TrackHistory(nC, N, H)
+    d_K = torch.from_numpy(sc.K.reshape(9).copy()).to(dev)
+    d_iK = torch.from_numpy(sc.iK.reshape(9).copy()).to(dev)
+    d_fl = torch.from_numpy(sc.flags0.copy()).to(dev)
+    hist = [dict(R=[], t=[], xy=[]) for _ in range(nC)]
+    keep = []
+    for f in range(sc.T):
+        recs = sc.frame(f)
+        Rs = np.stack([sc.Re[f][c].reshape(9) for c in range(nC)])
+        ts = np.stack([sc.te[f][c] for c in range(nC)])
+        cams = []
+        for c, r in enumerate(recs):
+            t_ = {k: torch.from_numpy(v).to(dev) for k, v in r.items()}
+            st = torch.ones(N, dtype=torch.uint8, device=dev)
+            keep += [t_, st]
+            cams.append(dict(K=d_K.data_ptr(), iK=d_iK.data_ptr(), xy=t_["xy"].data_ptr(), state=t_["state"].data_ptr(),
+                             slot2map=t_["slot2map"].data_ptr(), trackSpan=t_["trackSpan"].data_ptr(), isStatic=st.data_ptr()))
+            h = hist[c]
+            h["R"].insert(0, Rs[c]), h["t"].insert(0, ts[c]), h["xy"].insert(0, r["xy"].copy())
+            del h["R"][H:], h["t"][H:], h["xy"][H:]
+        d_R, d_t = torch.from_numpy(Rs).to(dev), torch.from_numpy(ts).to(dev)
+        th.detect_dynamic_dev(s, cams, d_R.data_ptr(), d_t.data_ptr(), nMap, d_fl.data_ptr(), f)   # (pushes the frame into the ring)
+        torch.cuda.synchronize()
+    # candidates: for every (map point, camera) the slot that tracks the point there, else (every third pair) some live slot
+    rng = np.random.default_rng(4)
+    slot = np.full((nMap, nC), -1, dtype=np.int32)
+    for c in range(nC):
+        live = np.nonzero(recs[c]["state"] >= 0)[0]
+        by_pt = {int(sc.slotPt[c, i]): int(i) for i in live}
+        for m in range(nMap):
+            if m in by_pt:
+                slot[m, c] = by_pt[m]
+            elif m % 3 == 0:
+                slot[m, c] = int(live[rng.integers(len(live))])
+    n_true = {}
+    for sigma in (1.2, 10.0):
+        d_slot = torch.from_numpy(slot).to(dev)
+        d_M = torch.from_numpy(sc.map0.copy()).to(dev)
+        d_cov = torch.from_numpy(sc.cov0.copy()).to(dev)
+        d_out = torch.full((nMap, nC), 77, dtype=torch.uint8, device=dev)
+        th.register_mergability_dev(s, cams, nMap, d_M.data_ptr(), d_cov.data_ptr(), d_slot.data_ptr(), sigma, d_out.data_ptr())
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        want = np.full((nMap, nC), 255, dtype=np.uint8)
+        for c in range(nC):
+            h = hist[c]
+            hR, hT, hXY = np.stack(h["R"]), np.stack(h["t"]), np.stack(h["xy"])
+            span = recs[c]["trackSpan"]
+            for m in range(nMap):
+                sl = slot[m, c]
+                if sl < 0:
+                    continue
+                ln = span[N + sl] - span[sl] + 1 if span[sl] >= 0 else 0
+                want[m, c] = 1 if oracle.static_check_mergability(sc.K, hR, hT, hXY, sl, ln, sc.map0[m], sc.cov0[m], sigma) else 0
+        assert np.array_equal(got, want), sigma
+        n_true[sigma] = (int((want == 1).sum()), int((want == 0).sum()))
+    assert n_true[1.2][0] > 50 and n_true[1.2][1] > 200 and n_true[10.0][0] > n_true[1.2][0]   # both verdicts occur, the gate matters
+    th.close()

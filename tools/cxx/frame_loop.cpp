@@ -210,6 +210,7 @@ int main(int argc, char** argv) {
     HIPCHK(hipMemset(dIsStatic, 1, (size_t)nCams * N));
     double* dReproj = dev_zeros<double>((size_t)nCams * N);
     unsigned char* dMapFlags = dev_zeros<unsigned char>(nMap);
+    unsigned char* dMergeable = dev_zeros<unsigned char>((size_t)P_REG * nCams);
     cs_track_history* hist = cs_track_history_create(dev, nCams, N, 64);
     if (!hist) {
         fprintf(stderr, "cs_track_history_create: %s\n", cs_last_error());
@@ -353,6 +354,8 @@ int main(int argc, char** argv) {
                                      reg[0].dist, reg[0].flags));
         CSCHK(cs_register_search_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, P_REG, dMap, dCov, dPf, PIX, 3 * PIX, PIX,
                                      reg[1].slot, reg[1].m, reg[1].var, reg[1].dist, reg[1].flags));
+        // staticCheckMergability of the current-static pass's candidates over their whole tracks (SL_CoSLAM.cpp:714-729, :768)
+        CSCHK(cs_register_mergability_dev(hist, (void*)poseS, pu.data(), P_REG, dMap, dCov, reg[1].slot, PIX, dMergeable));
         HIPCHK(hipEventRecord(destFree[b], poseS));
         if (key) {
             ic.solve_async(poseS);
