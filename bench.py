@@ -350,6 +350,8 @@ def main():
                          "parsed on the device from the last 5 key frames' tracked features and poses (N = 1 default: cs_ba_window_*)")
     ap.add_argument("--no-pose-update", action="store_true",
                     help="skip poseUpdate3D's gate + seqTriangulate loop and the dynamic-point test behind the pose solve")
+    ap.add_argument("--ncc-stream", type=int, default=int(os.environ.get("BENCH_NCC_STREAM", "0")),
+                    help="1: the NCC matching leg on its own stream against a snapshot of the frame's records (A/B)")
     ap.add_argument("--no-mergability", action="store_true",
                     help="skip staticCheckMergability over the candidates' whole tracks behind the current-static registration pass")
     ap.add_argument("--no-ncc", action="store_true", help="diagnostic: skip the inter-camera NCC matching leg (not a valid bench line)")
@@ -687,21 +689,38 @@ def main():
                    epi=torch.zeros((N_FEAT, N_FEAT), dtype=torch.float64, device=dev), score=torch.zeros((N_FEAT, N_FEAT), dtype=torch.float64, device=dev),
                    F={(my_cams[i], f): f_matrix(my_cams[i], my_cams[i + 1], f) for i in range(nc - 1) for f in range(N_FRAMES)}, runs=0)
 
+    # --ncc-stream 1: the matching leg on its own stream, working off a snapshot of the frame's records (the mask of unmapped
+    # features and the pixels: two small launches / copies on the pose stream), so that the next frames' hand-backs do not wait
+    # for its 270 us
+    ncc_s = torch.cuda.Stream(device=dev) if (ncc is not None and args.ncc_stream and not args.serial) else None
+    ncc_xy = torch.zeros_like(d_xy) if ncc_s is not None else d_xy
+    ncc_snap, ncc_free = torch.cuda.Event(), torch.cuda.Event()
+
     def ncc_leg(f):
         s_ = pose_s.cuda_stream
         # unmapped features of this frame: state 0 / 1 and no map point (hand-back records of all cameras, back to back)
+        if ncc_s is not None and ncc["runs"] > 0:
+            pose_s.wait_event(ncc_free)      # (the previous run has read its snapshot)
         check(coslam_amd.lib().cs_ncc_unmapped_mask_dev(local_rank, C.c_void_p(s_), nc * N_FEAT, C.c_void_p(d_state.data_ptr()),
                                                         C.c_void_p(d_slot2map.data_ptr()), C.c_void_p(ncc["valid"].data_ptr())),
               "cs_ncc_unmapped_mask_dev")
+        if ncc_s is not None:
+            with torch.cuda.stream(pose_s):
+                ncc_xy.copy_(d_xy, non_blocking=True)
+            ncc_snap.record(pose_s)
+            ncc_s.wait_event(ncc_snap)
+            s_ = ncc_s.cuda_stream
         for i in range(nc):
-            ncc_get_blocks_dev(s_, img_ptrs[f][i], W, H, N_FEAT, d_xy[i].data_ptr(), d_xy[i].data_ptr() + 8 * N_FEAT, 0.3,
+            ncc_get_blocks_dev(s_, img_ptrs[f][i], W, H, N_FEAT, ncc_xy[i].data_ptr(), ncc_xy[i].data_ptr() + 8 * N_FEAT, 0.3,
                                ncc["small"][i].data_ptr(), ncc["blk"][i].data_ptr(), ncc["abc"][i].data_ptr(), 0, device=local_rank)
         for i in range(nc - 1):
-            ncc_epi_mat_dev(s_, ncc["F"][(my_cams[i], f)], N_FEAT, d_xy[i].data_ptr(), d_xy[i].data_ptr() + 8 * N_FEAT, ncc["blk"][i].data_ptr(),
-                            ncc["abc"][i].data_ptr(), ncc["valid"][i].data_ptr(), N_FEAT, d_xy[i + 1].data_ptr(),
-                            d_xy[i + 1].data_ptr() + 8 * N_FEAT, ncc["blk"][i + 1].data_ptr(), ncc["abc"][i + 1].data_ptr(),
+            ncc_epi_mat_dev(s_, ncc["F"][(my_cams[i], f)], N_FEAT, ncc_xy[i].data_ptr(), ncc_xy[i].data_ptr() + 8 * N_FEAT, ncc["blk"][i].data_ptr(),
+                            ncc["abc"][i].data_ptr(), ncc["valid"][i].data_ptr(), N_FEAT, ncc_xy[i + 1].data_ptr(),
+                            ncc_xy[i + 1].data_ptr() + 8 * N_FEAT, ncc["blk"][i + 1].data_ptr(), ncc["abc"][i + 1].data_ptr(),
                             ncc["valid"][i + 1].data_ptr(), 50.0, 0.80, -1.0, ncc["epi"].data_ptr(), ncc["score"].data_ptr(),
                             device=local_rank)   # maxEpiErr 50, minNcc 0.80: src/app/SL_NewMapPointsInterCam.h:71-72
+        if ncc_s is not None:
+            ncc_free.record(ncc_s)
         ncc["runs"] += 1
 
     def step(i, key_frame, upload=False):

@@ -286,8 +286,15 @@ __device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0
     return opt.retTypeLM >= 0;
 }
 
+// CS_IC_WAVES_PER_EU (A/B builds): compile for that many waves per SIMD (3: 168 VGPRs + 460 bytes of scratch per lane instead of 255
+// VGPRs: a workgroup then fits a compute unit that holds two tracker waves per SIMD)
+#ifdef CS_IC_WAVES_PER_EU
+#define CS_IC_ATTR __attribute__((amdgpu_waves_per_eu(CS_IC_WAVES_PER_EU, CS_IC_WAVES_PER_EU)))
+#else
+#define CS_IC_ATTR
+#endif
 template <int PB>
-__global__ __launch_bounds__(PB) void k_intracam(int ptsStride, const double* __restrict__ Kall,
+__global__ __launch_bounds__(PB) CS_IC_ATTR void k_intracam(int ptsStride, const double* __restrict__ Kall,
                                                  const double* __restrict__ R0all, const double* __restrict__ t0all,
                                                  const int* __restrict__ nptsAll, const double* __restrict__ prevErrs,
                                                  const double* __restrict__ MsAll, const double* __restrict__ msAll,

@@ -1,0 +1,17 @@
+#!/bin/bash
+O=gpurun_out/r03_31; mkdir -p $O
+run() { n=$1; shift
+timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --no-upload-leg --no-cxx-loop "$@" > $O/$n.json 2> $O/$n.err
+python - <<PY
+import json
+try:
+    d=json.loads(open('$O/$n.json').read().strip().splitlines()[-1]); c=d['config']; k=c['key_frame_solves_duty']
+    print('$n', round(d['value'],1), 'joint ms/solve', round(k['joint_ba']['ms_total']/max(k['joint_ba']['solves'],1),3), 'duty', round(k['joint_ba']['share_of_timed_region'],3), 'pose err', round(c['pose_translation_error_vs_truth'],4))
+except Exception as e:
+    print('$n FAILED', e); print(open('$O/$n.err').read()[-600:])
+PY
+}
+for rep in 1 2 3; do
+run base_$rep
+COSLAM_HIP_LIB=$GRAFT_REPO_ROOT/coslam_amd/lib/libcoslam_hip_ic3.so run ic3_$rep
+done
