@@ -350,6 +350,9 @@ def main():
                          "parsed on the device from the last 5 key frames' tracked features and poses (N = 1 default: cs_ba_window_*)")
     ap.add_argument("--no-pose-update", action="store_true",
                     help="skip poseUpdate3D's gate + seqTriangulate loop and the dynamic-point test behind the pose solve")
+    ap.add_argument("--ncc-dense", action="store_true",
+                    help="the NCC matching leg writes getEpiNccMat's two dense 2000 x 2000 matrices per camera pair (64 MB) instead of the "
+                         "list of the pairs that pass (cs_ncc_epi_pairs_dev)")
     ap.add_argument("--ncc-stream", type=int, default=int(os.environ.get("BENCH_NCC_STREAM", "0")),
                     help="1: the NCC matching leg on its own stream against a snapshot of the frame's records (A/B)")
     ap.add_argument("--no-mergability", action="store_true",
@@ -669,10 +672,11 @@ def main():
     # (slots that are not unmapped features of this frame are masked out); F from the frame's poses; the greedy matcher that
     # consumes the matrices stays with the caller.
     NCC_EVERY = 4
+    NCC_PAIR_CAP = 1 << 16   # passing pairs kept per camera pair and run (the dense matrices hold 4 M entries, a few dozen pass)
     ncc = None
     if not args.no_ncc and nc >= 2:
         from coslam_amd._lib import check
-        from coslam_amd.ncc import ncc_epi_mat_dev, ncc_get_blocks_dev, ncc_scaled_dims
+        from coslam_amd.ncc import NCC_PAIR_DTYPE, ncc_epi_mat_dev, ncc_epi_pairs_dev, ncc_get_blocks_dev, ncc_scaled_dims
 
         ws_, hs_ = ncc_scaled_dims(W, H, 0.3)
         Kinv = np.linalg.inv(sc.K)
@@ -687,7 +691,9 @@ def main():
         ncc = dict(small=torch.zeros((nc, ws_ * hs_), dtype=torch.uint8, device=dev), blk=torch.zeros((nc, N_FEAT, 128), dtype=torch.uint8, device=dev),
                    abc=torch.zeros((nc, N_FEAT, 4), dtype=torch.float64, device=dev), valid=torch.zeros((nc, N_FEAT), dtype=torch.int32, device=dev),
                    epi=torch.zeros((N_FEAT, N_FEAT), dtype=torch.float64, device=dev), score=torch.zeros((N_FEAT, N_FEAT), dtype=torch.float64, device=dev),
-                   F={(my_cams[i], f): f_matrix(my_cams[i], my_cams[i + 1], f) for i in range(nc - 1) for f in range(N_FRAMES)}, runs=0)
+                   F={(my_cams[i], f): f_matrix(my_cams[i], my_cams[i + 1], f) for i in range(nc - 1) for f in range(N_FRAMES)}, runs=0,
+                   pairs=torch.zeros((nc - 1, NCC_PAIR_CAP * NCC_PAIR_DTYPE.itemsize), dtype=torch.uint8, device=dev),
+                   pair_count=torch.zeros(nc - 1, dtype=torch.int32, device=dev))
 
     # --ncc-stream 1: the matching leg on its own stream, working off a snapshot of the frame's records (the mask of unmapped
     # features and the pixels: two small launches / copies on the pose stream), so that the next frames' hand-backs do not wait
@@ -714,6 +720,15 @@ def main():
             ncc_get_blocks_dev(s_, img_ptrs[f][i], W, H, N_FEAT, ncc_xy[i].data_ptr(), ncc_xy[i].data_ptr() + 8 * N_FEAT, 0.3,
                                ncc["small"][i].data_ptr(), ncc["blk"][i].data_ptr(), ncc["abc"][i].data_ptr(), 0, device=local_rank)
         for i in range(nc - 1):
+            if not args.ncc_dense:
+                # the pairs that pass getEpiNccMat's two tests as a list (what the dense matrices hold besides -1): per camera pair
+                # kilobytes instead of the matrices' 64 MB
+                ncc_epi_pairs_dev(s_, ncc["F"][(my_cams[i], f)], N_FEAT, ncc_xy[i].data_ptr(), ncc_xy[i].data_ptr() + 8 * N_FEAT,
+                                  ncc["blk"][i].data_ptr(), ncc["abc"][i].data_ptr(), ncc["valid"][i].data_ptr(), N_FEAT,
+                                  ncc_xy[i + 1].data_ptr(), ncc_xy[i + 1].data_ptr() + 8 * N_FEAT, ncc["blk"][i + 1].data_ptr(),
+                                  ncc["abc"][i + 1].data_ptr(), ncc["valid"][i + 1].data_ptr(), 50.0, 0.80, ncc["pairs"][i].data_ptr(),
+                                  NCC_PAIR_CAP, ncc["pair_count"][i:i + 1].data_ptr(), device=local_rank)
+                continue
             ncc_epi_mat_dev(s_, ncc["F"][(my_cams[i], f)], N_FEAT, ncc_xy[i].data_ptr(), ncc_xy[i].data_ptr() + 8 * N_FEAT, ncc["blk"][i].data_ptr(),
                             ncc["abc"][i].data_ptr(), ncc["valid"][i].data_ptr(), N_FEAT, ncc_xy[i + 1].data_ptr(),
                             ncc_xy[i + 1].data_ptr() + 8 * N_FEAT, ncc["blk"][i + 1].data_ptr(), ncc["abc"][i + 1].data_ptr(),
@@ -1241,7 +1256,9 @@ def main():
                        "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "host_enqueue_ms_max_step": t_step_max * 1e3, "host_enqueue_max_at_step": i_step_max, "tracker_stream_cus": args.klt_cus or "all",
                        "ncc_matching": None if ncc is None else {
                            "every_frames": NCC_EVERY, "camera_pairs_per_run": nc - 1, "runs": ncc["runs"],
-                           "pairs_kept_last_matrix": int((ncc["score"] != -1.0).sum().item()),
+                           "output": "dense matrices (cs_ncc_epi_mat_dev)" if args.ncc_dense else "list of the passing pairs (cs_ncc_epi_pairs_dev)",
+                           "pairs_kept_last_run": (int((ncc["score"] != -1.0).sum().item()) if args.ncc_dense
+                                                   else [int(v) for v in ncc["pair_count"].cpu().tolist()]),
                            "unmapped_features_last_run": [int(v) for v in ncc["valid"].sum(dim=1).cpu().tolist()]},
                        "gathered_records": gathered_info, "with_upload": with_upload, "cxx_frame_loop": cxx,
                        "collectives": None if world == 1 else ("libcoslam_hip RCCL (C-ABI)" if native else "torch.distributed " + dist_backend),

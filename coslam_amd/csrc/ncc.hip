@@ -233,6 +233,9 @@ struct NcArgs {
     double epiMax, nccMin, wNone;
     double* epiMat;
     double* nccMat;
+    cs_ncc_pair* pairs;  // SPARSE: the entries that pass both tests, as records; capacity pairCap; *pairCount counts every one
+    int pairCap;
+    int* pairCount;
 };
 
 typedef int nc_i32x4 __attribute__((ext_vector_type(4)));
@@ -244,6 +247,11 @@ __device__ __forceinline__ long nc_row_chunk(const unsigned char* blocks, int ro
     return (long)(u ^ 0x8080808080808080ull);
 }
 
+// SPARSE = false: the two dense M x N matrices getEpiNccMat fills (-1 / wNone where a pair fails a test) -- 16 bytes per pair,
+// 64 MB for 2000 x 2000: what bounds the kernel.  SPARSE = true: only the pairs that pass, as {i, j, epiErr, ncc} records
+// appended through one atomic counter (the order of the list is not defined; the matrices are its scatter into wNone-filled
+// arrays): a matching run of 7 camera pairs then writes kilobytes instead of 448 MB.
+template <bool SPARSE>
 __global__ __launch_bounds__(256) void k_ncc_epi_mat(NcArgs A) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int M = A.s1.n, N = A.s2.n;
@@ -298,16 +306,29 @@ __global__ __launch_bounds__(256) void k_ncc_epi_mat(NcArgs A) {
             if (i >= M) continue;
             const double epiErr = fabs((l0 * x1[r] + l1 * y1[r]) + l2) / den;  // SL_FeatureMatching.cpp:24-25
             double e = A.wNone, c = A.wNone;
+            bool pass = false;
             if (epiErr <= A.epiMax && v1[r] && v2) {                           // :26
                 const int d = acc[t][r] + 128 * s1[r] + 128 * s2 + NC_LEN * 128 * 128;  // sum I1 I2, exact
                 const double ncc = (((double)NC_LEN * (double)d - A1[r] * A2) * C1[r]) * C2;  // SL_NCCBlock.cpp:263
                 if (ncc >= A.nccMin) {                                          // :29-31
                     e = epiErr;
                     c = ncc;
+                    pass = true;
                 }
             }
-            A.epiMat[(size_t)i * N + j] = e;
-            A.nccMat[(size_t)i * N + j] = c;
+            if (SPARSE) {
+                if (pass) {
+                    const int at = atomicAdd(A.pairCount, 1);
+                    if (at < A.pairCap) {
+                        cs_ncc_pair q;
+                        q.i = i, q.j = j, q.epi = e, q.ncc = c;
+                        A.pairs[at] = q;
+                    }
+                }
+            } else {
+                A.epiMat[(size_t)i * N + j] = e;
+                A.nccMat[(size_t)i * N + j] = c;
+            }
         }
     }
 }
@@ -413,7 +434,38 @@ extern "C" int cs_ncc_epi_mat_dev(int device, void* hip_stream, const double F[9
     A.epiMat = d_epiMat;
     A.nccMat = d_nccMat;
     CS_HIP(hipSetDevice(device));
-    hipLaunchKernelGGL(k_ncc_epi_mat, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0,
+    A.pairs = nullptr, A.pairCap = 0, A.pairCount = nullptr;
+    hipLaunchKernelGGL(k_ncc_epi_mat<false>, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0,
+                       (hipStream_t)hip_stream, A);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+extern "C" int cs_ncc_epi_pairs_dev(int device, void* hip_stream, const double F[9], int M, const double* d_x1, const double* d_y1,
+                                    const unsigned char* d_blocks1, const double* d_abc1, const int* d_valid1, int N, const double* d_x2,
+                                    const double* d_y2, const unsigned char* d_blocks2, const double* d_abc2, const int* d_valid2,
+                                    double epiMax, double nccMin, cs_ncc_pair* d_pairs, int pairCap, int* d_pairCount) {
+    if (!F || M < 0 || N < 0 || pairCap < 0 || !d_pairCount || (pairCap > 0 && !d_pairs)) {
+        cs_set_error("cs_ncc_epi_pairs_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(device));
+    CS_HIP(hipMemsetAsync(d_pairCount, 0, sizeof(int), (hipStream_t)hip_stream));
+    if (M == 0 || N == 0) return CS_OK;
+    if (!d_x1 || !d_y1 || !d_blocks1 || !d_abc1 || !d_valid1 || !d_x2 || !d_y2 || !d_blocks2 || !d_abc2 || !d_valid2) {
+        cs_set_error("cs_ncc_epi_pairs_dev: null pointer");
+        return CS_ERR_INVALID;
+    }
+    NcArgs A;
+    memcpy(A.F, F, sizeof(A.F));
+    A.s1 = {d_x1, d_y1, d_blocks1, d_abc1, d_valid1, M};
+    A.s2 = {d_x2, d_y2, d_blocks2, d_abc2, d_valid2, N};
+    A.epiMax = epiMax;
+    A.nccMin = nccMin;
+    A.wNone = -1.0;
+    A.epiMat = A.nccMat = nullptr;
+    A.pairs = d_pairs, A.pairCap = pairCap, A.pairCount = d_pairCount;
+    hipLaunchKernelGGL(k_ncc_epi_mat<true>, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0,
                        (hipStream_t)hip_stream, A);
     CS_CHECK_LAUNCH();
     return CS_OK;

@@ -24,6 +24,20 @@ def ncc_epi_mat_dev(stream_ptr, F, M, d_x1, d_y1, d_blocks1, d_abc1, d_valid1, N
           "cs_ncc_epi_mat_dev")
 
 
+NCC_PAIR_DTYPE = np.dtype([("i", "<i4"), ("j", "<i4"), ("epi", "<f8"), ("ncc", "<f8")])   # == cs_ncc_pair
+
+
+def ncc_epi_pairs_dev(stream_ptr, F, M, d_x1, d_y1, d_blocks1, d_abc1, d_valid1, N, d_x2, d_y2, d_blocks2, d_abc2, d_valid2, epiMax,
+                      nccMin, d_pairs, pairCap, d_pairCount, device=0):
+    """cs_ncc_epi_pairs_dev: only the pairs that pass both tests, as NCC_PAIR_DTYPE records (24 bytes each) + their count."""
+    vp = C.c_void_p
+    F = np.ascontiguousarray(F, dtype=np.float64).reshape(9)
+    check(lib().cs_ncc_epi_pairs_dev(int(device), vp(stream_ptr), vp(F.ctypes.data), int(M), vp(d_x1), vp(d_y1), vp(d_blocks1),
+                                     vp(d_abc1), vp(d_valid1), int(N), vp(d_x2), vp(d_y2), vp(d_blocks2), vp(d_abc2), vp(d_valid2),
+                                     C.c_double(epiMax), C.c_double(nccMin), vp(d_pairs), int(pairCap), vp(d_pairCount)),
+          "cs_ncc_epi_pairs_dev")
+
+
 def ncc_match_between(img1, x1, y1, img2, x2, y2, scale, F, epiMax, nccMin, wNone=-1.0, device=0):
     """Host arrays in and out (cs_ncc_match_between).  Returns dict(epi, ncc (M x N), blocks1/2 (n x 128 uint8), abc1/2
     (n x 4), valid1/2)."""

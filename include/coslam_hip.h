@@ -467,6 +467,19 @@ int cs_ncc_epi_mat_dev(int device, void* hip_stream, const double F[9] /* host *
                        const unsigned char* d_blocks1, const double* d_abc1, const int* d_valid1, int N, const double* d_x2,
                        const double* d_y2, const unsigned char* d_blocks2, const double* d_abc2, const int* d_valid2,
                        double epiMax, double nccMin, double wNone, double* d_epiMat, double* d_nccMat);
+/* The same test of every pair, with only the pairs that PASS it written out: {i, j, epipolar error, NCC score} records through
+ * one atomic counter (d_pairCount is zeroed by the call and counts every passing pair, also those beyond pairCap, which are
+ * dropped; the order of the list is not defined).  The dense matrices above are this list scattered into wNone-filled arrays:
+ * 64 MB of output per 2000 x 2000 camera pair, of which a matching run keeps a few dozen entries -- a device-resident caller
+ * (or one that hands the greedy matcher a candidate list) wants this form. */
+typedef struct cs_ncc_pair {
+    int i, j;        /* feature of camera 1, of camera 2 */
+    double epi, ncc; /* epiMat(i, j), nccMat(i, j) */
+} cs_ncc_pair;
+int cs_ncc_epi_pairs_dev(int device, void* hip_stream, const double F[9] /* host */, int M, const double* d_x1, const double* d_y1,
+                         const unsigned char* d_blocks1, const double* d_abc1, const int* d_valid1, int N, const double* d_x2,
+                         const double* d_y2, const unsigned char* d_blocks2, const double* d_abc2, const int* d_valid2,
+                         double epiMax, double nccMin, cs_ncc_pair* d_pairs, int pairCap, int* d_pairCount);
 /* How NewMapPtsNCC::matchBetween itself cuts its blocks: getNCCBlocks (src/slam/SL_NCCBlock.cpp:79-155, called at
  * src/app/SL_NewMapPointsInterCam.cpp:280-282 with the FULL image and blockScale 0.3) = cv::resize(img, Size(), scale, scale)
  * [INTER_LINEAR, 8-bit] once per image, then per point cv::getRectSubPix(small, 11 x 11, (x scale, y scale)) [8u -> 8u,

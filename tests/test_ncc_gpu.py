@@ -155,3 +155,60 @@ def test_match_between_full_is_get_ncc_blocks_plus_the_matrices(hip):
     ones1, ones2 = np.ones(M, np.int32), np.ones(N, np.int32)
     e_o, n_o = oracle.ncc_epi_mat(F, x1, y1, b1, c1, ones1, x2, y2, b2, c2, ones2, 1e9, 0.3)
     assert np.array_equal(g["epi"], e_o) and np.array_equal(g["ncc"], n_o) and (n_o != -1).sum() > 50
+
+
+@pytest.mark.parametrize("nccMin,cap", [(0.8, 4096), (0.3, 1 << 20), (0.3, 100)])
+def test_epi_pairs_is_the_list_of_the_matrices_kept_entries(hip, nccMin, cap):
+    """cs_ncc_epi_pairs_dev writes only the pairs that pass both tests of getEpiNccMat (reference src/slam/SL_FeatureMatching.cpp:
+    24-31): the records must be exactly the non-(-1) entries of the dense matrices of cs_ncc_epi_mat_dev -- same doubles -- in any
+    order; the counter counts every passing pair, also those a too-small list drops."""
+    import torch
+
+    from coslam_amd.ncc import NCC_PAIR_DTYPE, ncc_blocks_dev, ncc_epi_mat_dev, ncc_epi_pairs_dev
+
+    W, H, scale, M, N = 640, 480, 0.3, 900, 777
+    sc = Scene(2, W, H, 3000, seed=78)
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    side = []
+    for c, n in ((0, M), (1, N)):
+        im = sc.render(c, 0).astype(np.float64)
+        ys = (np.arange(int(H * scale)) / scale).astype(int)
+        xs = (np.arange(int(W * scale)) / scale).astype(int)
+        small = torch.from_numpy(np.ascontiguousarray(im[np.ix_(ys, xs)]).astype(np.uint8)).to(dev)
+        uv, vis = sc.project(c, 0)
+        k = np.nonzero(vis)[0][: n // 2]
+        x = torch.from_numpy(np.concatenate([uv[k, 0], rng.uniform(-20, W + 20, n - len(k))])).to(dev)
+        y = torch.from_numpy(np.concatenate([uv[k, 1], rng.uniform(-20, H + 20, n - len(k))])).to(dev)
+        blk = torch.zeros((n, 128), dtype=torch.uint8, device=dev)
+        abc = torch.zeros((n, 4), dtype=torch.float64, device=dev)
+        val = torch.zeros(n, dtype=torch.int32, device=dev)
+        ncc_blocks_dev(s, small.data_ptr(), small.shape[1], small.shape[0], n, x.data_ptr(), y.data_ptr(), scale, blk.data_ptr(),
+                       abc.data_ptr(), val.data_ptr())
+        side.append((x, y, blk, abc, val, small))
+    F = _fundamental(sc, 0, 1)
+    (x1, y1, b1, a1, v1, _), (x2, y2, b2, a2, v2, _) = side
+    epi = torch.zeros((M, N), dtype=torch.float64, device=dev)
+    ncc = torch.zeros((M, N), dtype=torch.float64, device=dev)
+    ncc_epi_mat_dev(s, F, M, x1.data_ptr(), y1.data_ptr(), b1.data_ptr(), a1.data_ptr(), v1.data_ptr(), N, x2.data_ptr(), y2.data_ptr(),
+                    b2.data_ptr(), a2.data_ptr(), v2.data_ptr(), 50.0, nccMin, -1.0, epi.data_ptr(), ncc.data_ptr())
+    pairs = torch.zeros(max(cap, 1) * NCC_PAIR_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    cnt = torch.full((1,), 12345, dtype=torch.int32, device=dev)
+    ncc_epi_pairs_dev(s, F, M, x1.data_ptr(), y1.data_ptr(), b1.data_ptr(), a1.data_ptr(), v1.data_ptr(), N, x2.data_ptr(), y2.data_ptr(),
+                      b2.data_ptr(), a2.data_ptr(), v2.data_ptr(), 50.0, nccMin, pairs.data_ptr(), cap, cnt.data_ptr())
+    torch.cuda.synchronize()
+    epi_h, ncc_h = epi.cpu().numpy(), ncc.cpu().numpy()
+    kept = np.argwhere(ncc_h != -1.0)
+    n = int(cnt.item())
+    assert n == len(kept) and n > (1 if nccMin > 0.5 else 300)
+    rec = pairs.cpu().numpy().view(NCC_PAIR_DTYPE)[: min(n, cap)]
+    if n <= cap:
+        order = np.lexsort((rec["j"], rec["i"]))
+        rec = rec[order]
+        assert np.array_equal(np.stack([rec["i"], rec["j"]], 1), kept)
+        assert np.array_equal(rec["epi"], epi_h[kept[:, 0], kept[:, 1]]) and np.array_equal(rec["ncc"], ncc_h[kept[:, 0], kept[:, 1]])
+    else:   # a list that is too small: every record it holds is a kept entry, the counter says how many there were
+        assert len(rec) == cap
+        assert np.array_equal(rec["epi"], epi_h[rec["i"], rec["j"]]) and np.array_equal(rec["ncc"], ncc_h[rec["i"], rec["j"]])
+        assert len({(int(a), int(b)) for a, b in zip(rec["i"], rec["j"])}) == cap and np.all(ncc_h[rec["i"], rec["j"]] != -1.0)

@@ -317,6 +317,10 @@ int main(int argc, char** argv) {
     int* dValid = dev_zeros<int>((size_t)nCams * N);
     double* dEpi = dev_zeros<double>((size_t)N * N);
     double* dScore = dev_zeros<double>((size_t)N * N);
+    const int NCC_PAIR_CAP = 1 << 16;   // passing pairs kept per camera pair and run (cs_ncc_epi_pairs_dev)
+    cs_ncc_pair* dPairs = (cs_ncc_pair*)dev_zeros<unsigned char>((size_t)(nCams > 1 ? nCams - 1 : 1) * NCC_PAIR_CAP * sizeof(cs_ncc_pair));
+    int* dPairCount = dev_zeros<int>(nCams);
+    const bool nccDense = getenv("FRAME_LOOP_NCC_DENSE") != nullptr;
     int nccRuns = 0;
 
     hipEvent_t kltDone[2], destFree[2];
@@ -376,6 +380,13 @@ int main(int argc, char** argv) {
             for (int c = 0; c + 1 < nCams; ++c) {
                 const double* xa = dXY + (size_t)c * 2 * N;
                 const double* xb = dXY + (size_t)(c + 1) * 2 * N;
+                if (!nccDense) {   // the pairs that pass getEpiNccMat's tests as a list, not the two dense 64 MB matrices
+                    CSCHK(cs_ncc_epi_pairs_dev(dev, (void*)poseS, Fs.data() + ((size_t)f * (nCams - 1) + c) * 9, N, xa, xa + N,
+                                               dBlk + (size_t)c * N * 128, dAbc + (size_t)c * N * 4, dValid + (size_t)c * N, N, xb, xb + N,
+                                               dBlk + (size_t)(c + 1) * N * 128, dAbc + (size_t)(c + 1) * N * 4, dValid + (size_t)(c + 1) * N,
+                                               50.0, 0.80, dPairs + (size_t)c * NCC_PAIR_CAP, NCC_PAIR_CAP, dPairCount + c));
+                    continue;
+                }
                 CSCHK(cs_ncc_epi_mat_dev(dev, (void*)poseS, Fs.data() + ((size_t)f * (nCams - 1) + c) * 9, N, xa, xa + N,
                                          dBlk + (size_t)c * N * 128, dAbc + (size_t)c * N * 4, dValid + (size_t)c * N, N, xb, xb + N,
                                          dBlk + (size_t)(c + 1) * N * 128, dAbc + (size_t)(c + 1) * N * 4, dValid + (size_t)(c + 1) * N, 50.0,
