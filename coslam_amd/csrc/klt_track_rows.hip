@@ -172,6 +172,21 @@ __device__ __forceinline__ void sample_p2(const cs_texel* patch, int rx0, int ry
     G = ((g00 + g10) + g01) + g11;
 }
 
+// Correctly rounded square root of a gradient magnitude squared (a sum of two squares of blends of binary16 texels: 0 or
+// >= 2^-48, finite).  sqrtf() compiles to v_sqrt_f32 (<= 1 ulp) followed by the two-sided correction below AND a 2^32 pre-scale /
+// 2^-16 post-scale for inputs under 2^-96 and a class test for 0 / inf -- 16 instructions, a fifth of the window pixel's work
+// (profiles/r03_*): the input's range makes the scale and the class test dead weight.  What is kept is the compiler's own
+// correction, instruction for instruction: y -= 1 ulp if x - (y - 1 ulp) y <= 0, y += 1 ulp if x - (y + 1 ulp) y > 0 (both
+// residuals in one FMA each).  x = 0: y = 0, both tests fail (NaN / -0), the result is 0.  Same bits as sqrtf on the range.
+__device__ __forceinline__ float rows_sqrt(float x) {
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float ym = __uint_as_float(__float_as_uint(y) - 1u), yp = __uint_as_float(__float_as_uint(y) + 1u);
+    const float rm = __builtin_fmaf(-ym, y, x), rp = __builtin_fmaf(-yp, y, x);
+    float r = (rm <= 0.0f) ? ym : y;
+    r = (rp > 0.0f) ? yp : r;
+    return r;
+}
+
 // one Gauss-Newton pass worth of window sums for this lane's row (all zero for an inactive lane)
 struct RowSums {
     cs_f2 ab, ce, r01;  // (a, b), (c, e'), (r0, r1) of klt_tracker_with_gain.cg:106-110
@@ -182,9 +197,10 @@ struct RowSums {
 __device__ __forceinline__ void rows_accumulate(RowSums& s, float beta, float I0, cs_f2 G0, float m0, float I1, cs_f2 G1, cs_f2 wh,
                                                 float lambda) {
     const float ex = beta * I0 - I1;             // :99
-    const cs_f2 g = (beta * G0 + G1) * wh / 2.0f;  // :100
+    // :100, (x * wh) / 2 as x * (wh / 2): halving is exact, so the two roundings coincide bit for bit (no subnormals here)
+    const cs_f2 g = (beta * G0 + G1) * wh;
     const cs_f2 q = G1 * G1;
-    const float m1 = sqrtf(q.x + q.y);           // :103
+    const float m1 = rows_sqrt(q.x + q.y);       // :103
     s.ab += g.x * g;                             // :106  a += gx gx, b += gx gy
     s.ce += g * (-I0);                           //       c += gx (-I0) ... :107 e' += gy (-I0)
     s.d += g.y * g.y;                            // :107
@@ -412,7 +428,7 @@ __global__ __launch_bounds__(64 * CS_ROWS_WPB, (LPF == 8 ? CS_ROWS_MINBLOCKS : 2
             RowSums s = {{0, 0}, {0, 0}, {0, 0}, 0, 0, 0};
             if (!dead && rowOn) {
                 const float t1 = X1y + oy;
-                const cs_f2 wh = {whx, why};
+                const cs_f2 wh = {whx * 0.5f, why * 0.5f};
 #pragma unroll CS_ROWS_UNROLL
                 for (int px = 0; px < FW; ++px) {
                     const float4 q0 = rec[px * 64];
@@ -589,7 +605,7 @@ __global__ __launch_bounds__(64) void k_track_rows_pass(CsRowsArgs A) {
     float fRow = 0.0f;
     if (!dead && r < FW) {
         const float t0 = X0y + oy, t1 = X1y + oy;
-        const cs_f2 wh = {whx, why};
+        const cs_f2 wh = {whx * 0.5f, why * 0.5f};
 #pragma unroll
         for (int px = 0; px < FW; ++px) {
             const float ox = (float)(px - HW) * dsx;
