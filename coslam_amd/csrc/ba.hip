@@ -4155,12 +4155,12 @@ int cs_ba_solve_window_async(cs_ba* b, cs_ba_window* w, void* after_stream, cons
         J.winSlotOf[j] = (w->head - w->count + j + 2 * w->ring) % w->ring;
         J.winFrames[j] = w->frameOf[J.winSlotOf[j]];
     }
-    {
+    CS_HIP(hipEventCreateWithFlags(&J.ready, hipEventDisableTiming));
+    CS_HIP(hipEventRecord(J.ready, (hipStream_t)after_stream));
+    {   // (behind everything that can fail: a request that is counted is a request the worker will release)
         std::lock_guard<std::mutex> lk(w->mu);
         w->parsesPending += 1;
     }
-    CS_HIP(hipEventCreateWithFlags(&J.ready, hipEventDisableTiming));
-    CS_HIP(hipEventRecord(J.ready, (hipStream_t)after_stream));
     {
         std::lock_guard<std::mutex> lk(b->worker->mu);
         b->worker->q.push_back(J);

@@ -575,7 +575,7 @@ int cs_ba_wait(cs_ba* b);
  * cs_ba_solve_async; the estimate it starts from is the key poses as pushed and the map as it stands. */
 typedef struct cs_ba_window cs_ba_window;
 cs_ba_window* cs_ba_window_create(int device, int nCams, int nKeyFrames, int N, int nMapPts);
-void cs_ba_window_destroy(cs_ba_window* w);
+void cs_ba_window_destroy(cs_ba_window* w); /* after cs_ba_wait() of every workspace that still has a request of this window queued */
 /* cams: HOST array of nCams records whose xy / state / slot2map (device) are the hand-back's output of this frame;
  * d_K: nCams x 9, or one 9 shared by all cameras (kShared != 0); d_R nCams x 9, d_t nCams x 3.  Asynchronous on hip_stream.
  * A solve request (cs_ba_solve_window_async) fixes the window -- its ring slots -- and a snapshot of the map when it is MADE; the
