@@ -20,7 +20,7 @@
 //                  order and a point one camera made uncertain is no node of the next -- the lane reproduces exactly that,
 //                  with the point and its covariance in registers between the cameras.  (One feature per camera and point, as
 //                  MapPoint::pFeatures[iCam] holds one; of two slots carrying the same point the higher one counts.)
-//   dynamic role   one lane per (camera, slot).  The track's past positions come from a ring of the last H frames' hand-back
+//   dynamic role   eight lanes per (camera, slot) striding the walk.  The track's past positions come from a ring of the last H frames' hand-back
 //                  pixels (cs_track_history), the fundamental matrices from the ring of the camera's poses: F_j of "j frames
 //                  back" is computed once per workgroup into LDS (formEMat + getFMat), the walk then costs two coalesced loads
 //                  and ~25 flops a step.  NOTE src/app/SL_SingleSLAM.cpp:799: the reference's loop counter `f` is never
@@ -44,6 +44,7 @@ namespace {
 
 constexpr int PU_MAX_CAMS = 16;
 constexpr int PU_MAX_HIST = 512;
+constexpr int PU_LPS = 8;  // lanes per slot in the dynamic-point test
 
 struct PuArgs {
     int nCams, N, nMap, cam0, nCamsRun;
@@ -250,12 +251,17 @@ __global__ __launch_bounds__(256) void k_pose_update(PuArgs A) {
         pu_fmat(C.iK, R1, t1, R0, t0, Fs + 9 * j);
     }
     __syncthreads();
-    const int i = blk * 256 + tid;
-    if (i >= N) return;
+    // PU_LPS lanes per slot: lane r of the group takes the frames j = r, r + PU_LPS, ... of the walk.  The reference stops
+    // walking once the count exceeds minOutNum; the verdict -- count > minOutNum -- is the same over the whole depth, so the
+    // frames can be tested in any order and in parallel: a 64-frame walk is 8 steps deep.
+    const int i = blk * (256 / PU_LPS) + tid / PU_LPS, r = tid % PU_LPS;
+    if (i >= N) return;  // (whole groups leave together: the shuffles below stay inside a group)
     const int st = C.state[i];
     const double m0x = C.xy[i], m0y = C.xy[N + i];
-    hXY[(size_t)A.head * 2 * N + i] = m0x;  // (every slot: a dead slot's entry is never read, its track is empty)
-    hXY[(size_t)A.head * 2 * N + N + i] = m0y;
+    if (r == 0) {
+        hXY[(size_t)A.head * 2 * N + i] = m0x;  // (every slot: a dead slot's entry is never read, its track is empty)
+        hXY[(size_t)A.head * 2 * N + N + i] = m0y;
+    }
     if (!(st == 0 || st == 1)) return;
     unsigned char type = C.isStatic[i];
     if (st == 1) type = 1;  // a new FeaturePoint: type(0) = TYPE_FEATPOINT_STATIC (src/slam/SL_FeaturePoint.cpp:23)
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(256) void k_pose_update(PuArgs A) {
     if (examine) {
         int nOut = 0;
         const int depth = len < A.nHist ? len : A.nHist;
-        for (int j = 0; j < depth && nOut <= A.minOutNum; ++j) {  // :799 (`f` never advances: maxLen does not bound the walk)
+        for (int j = r; j < depth; j += PU_LPS) {  // :799 (`f` never advances: maxLen does not bound the walk)
             double bx = m0x, by = m0y;
             if (j) {
                 const int rs = (A.head - j + H) % H;
@@ -285,14 +291,16 @@ __global__ __launch_bounds__(256) void k_pose_update(PuArgs A) {
             const double err = fabs(l0 * m0x + l1 * m0y + l2) / (n > 0 ? n : 1.0);
             if (err >= A.maxEpiErr) ++nOut;
         }
+#pragma unroll
+        for (int off = 1; off < PU_LPS; off <<= 1) nOut += __shfl_xor(nOut, off, 64);  // (examine is uniform over the group)
         if (nOut > A.minOutNum) {
             type = 0;  // TYPE_FEATPOINT_DYNAMIC (:814-816)
-            if (A.numDyn) atomicAdd(A.numDyn + c, 1);
+            if (A.numDyn && r == 0) atomicAdd(A.numDyn + c, 1);
         } else if (!mapped) {
             type = 1;  // :817-818
         }
     }
-    C.isStatic[i] = type;
+    if (r == 0) C.isStatic[i] = type;
 }
 
 // ---- CoSLAM::staticCheckMergability (src/app/SL_CoSLAM.cpp:714-729) for every candidate of a registration search --------------
@@ -431,7 +439,7 @@ int pu_launch(const char* who, int device, void* hip_stream, PuArgs& A, const cs
     }
     CS_HIP(hipSetDevice(device));
     A.gateBlocks = gate ? (A.nMap + 255) / 256 : 0;
-    A.dynBlocksPerCam = (A.N + 255) / 256;
+    A.dynBlocksPerCam = (A.N * PU_LPS + 255) / 256;
     const int dynBlocks = dyn ? A.dynBlocksPerCam * A.nCamsRun : 0;
     if (A.gateBlocks + dynBlocks == 0) return CS_OK;
     hipStream_t s = (hipStream_t)hip_stream;
