@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
     FILE* f = fopen(argv[2], "wb");
     if (!f) return 1;
     CoSLAM* co = new CoSLAM();
-    const int nCases = 300;
+    const int nCases = 150;
     fwrite(&nCases, 4, 1, f);
     int nTrue = 0;
     for (int cs = 0; cs < nCases; ++cs) {

@@ -233,7 +233,7 @@ def export_case():
 
 
 def mergability_case():
-    """the reference's own CoSLAM::staticCheckMergability (oracle/_ref/ref_mergability_test golden, CPU): 300 tracks of 1..24
+    """the reference's own CoSLAM::staticCheckMergability (oracle/_ref/ref_mergability_test golden, CPU): 150 tracks of 1..24
     frames, newest first, and its verdicts."""
     import struct
     import subprocess
