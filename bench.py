@@ -640,14 +640,18 @@ def main():
 
     reg_args = [register_cams(reg_cams(0)), register_cams(reg_cams(1))]
 
+    from coslam_amd.register import register_passes, register_search_passes_dev
+
+    # CoSLAMThread.cpp:108 activeMapPointsRegister, then :117 currentMapPointsRegister (static points), search step: the two
+    # passes of a frame in ONE launch (cs_register_search_passes_dev)
+    reg_passes = register_passes([dict(P=P_REG, sigmaSearch=sS, maxDist=3 * PIXEL_ERR_VAR, sigmaMerge=PIXEL_ERR_VAR,
+                                       M=d_map.data_ptr() + 24 * pts_off, cov=d_cov.data_ptr() + 72 * pts_off, pointFeat=pf.data_ptr(),
+                                       slot=reg_out[k]["slot"].data_ptr(), m=reg_out[k]["m"].data_ptr(), var=reg_out[k]["var"].data_ptr(),
+                                       dist=reg_out[k]["dist"].data_ptr(), flags=reg_out[k]["flags"].data_ptr())
+                                  for k, (pts_off, pf, sS) in enumerate(((P_REG, d_pf_none, 2.5 * PIXEL_ERR_VAR), (0, d_pf, PIXEL_ERR_VAR)))])
+
     def register_leg(dst):
-        # CoSLAMThread.cpp:108 activeMapPointsRegister, then :117 currentMapPointsRegister (static points), search step
-        for k, (pts_off, pf, sS) in enumerate(((P_REG, d_pf_none, 2.5 * PIXEL_ERR_VAR), (0, d_pf, PIXEL_ERR_VAR))):
-            o = reg_out[k]
-            register_search_dev(reg_s.cuda_stream, reg_args[dst], N_FEAT, W, H, P_REG, d_map.data_ptr() + 24 * pts_off,
-                                d_cov.data_ptr() + 72 * pts_off, pf.data_ptr(), sS, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR,
-                                o["slot"].data_ptr(), o["m"].data_ptr(), o["var"].data_ptr(), o["dist"].data_ptr(),
-                                o["flags"].data_ptr(), device=local_rank)
+        register_search_passes_dev(reg_s.cuda_stream, reg_args[dst], N_FEAT, W, H, reg_passes, device=local_rank)
         if pose_upd is not None and not args.no_mergability:
             # staticCheckMergability of every candidate of the current-static pass over its whole track (SL_CoSLAM.cpp:714-729, :768)
             pose_upd.register_mergability_dev(reg_s.cuda_stream, pu_args, P_REG, d_map.data_ptr(), d_cov.data_ptr(),

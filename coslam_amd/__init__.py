@@ -17,7 +17,8 @@ __version__ = "0.1.0"
 from .pose import IntraCamPoseOption, intraCamEstimate  # noqa: F401,E402
 from .ba import BAStats, BAWindow, BAWorkspace, bundleAdjustRobust  # noqa: F401,E402
 from .handback import HandbackCam, handback_cams, handback_dev  # noqa: F401,E402
-from .register import RegisterCam, register_cams, register_search, register_search_dev  # noqa: F401,E402
+from .register import (RegisterCam, RegisterPass, register_cams, register_passes, register_search, register_search_dev,  # noqa: F401,E402
+                       register_search_passes_dev)
 from .poseupdate import (MAP_DYNAMIC, MAP_FALSE, MAP_UNCERTAIN, PoseUpdateCam, TrackHistory, pose_update3d_dev,  # noqa: F401,E402
                          poseupdate_cams)
 from .ncc import (ncc_blocks_dev, ncc_epi_mat_dev, ncc_get_blocks_dev, ncc_match_between, ncc_match_between_full,  # noqa: F401,E402

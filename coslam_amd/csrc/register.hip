@@ -34,16 +34,8 @@ namespace {
 constexpr int RG_MAX_CAMS = 16;
 
 struct RgArgs {
-    int nCams, N, W, H, P;
-    double sigmaSearch, maxDist, sigmaMerge;
-    const double* M;
-    const double* cov;
-    const int* pointFeat;
-    int* slot;
-    double* m;
-    double* var;
-    double* dist;
-    int* flags;
+    int nCams, N, W, H, nPass;
+    cs_register_pass pass[2];  // blockIdx.z: the passes of a frame share ONE launch (cs_register_search_passes_dev)
     cs_register_cam cam[RG_MAX_CAMS];
 };
 
@@ -99,6 +91,7 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.y;
     const int p = blockIdx.x * 64 + lane;
+    const cs_register_pass& Q = A.pass[blockIdx.z];
     const cs_register_cam& C = A.cam[c];
     const int N = A.N;
     const int CH = N < RG_CHUNK ? N : RG_CHUNK;
@@ -112,8 +105,8 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
     double ivar[4] = {0, 0, 0, 0};
     bool search = false;
     Proj q;
-    if (wave == 0 && p < A.P && A.pointFeat[o] < 0) {  // SL_CoSLAM.cpp:737-738: no feature of this frame attached in this camera yet
-        const double *K = C.K, *R = C.R, *t = C.t, *M = A.M + 3 * (size_t)p;
+    if (wave == 0 && p < Q.P && Q.pointFeat[o] < 0) {  // SL_CoSLAM.cpp:737-738: no feature of this frame attached in this camera yet
+        const double *K = C.K, *R = C.R, *t = C.t, *M = Q.M + 3 * (size_t)p;
         const double X = ((R[0] * M[0] + R[1] * M[1]) + R[2] * M[2]) + t[0];
         const double Y = ((R[3] * M[0] + R[4] * M[1]) + R[5] * M[2]) + t[1];
         const double Z = ((R[6] * M[0] + R[7] * M[1]) + R[8] * M[2]) + t[2];
@@ -132,9 +125,9 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) q.KR[3 * i + j] = (K[3 * i] * R[j] + K[3 * i + 1] * R[3 + j]) + K[3 * i + 2] * R[6 + j];
-                projection_cov(q, A.cov + 9 * (size_t)p, A.sigmaSearch, var);  // :750-753
+                projection_cov(q, Q.cov + 9 * (size_t)p, Q.sigmaSearch, var);  // :750-753
                 mat22_inv(var, ivar);                                          // SL_SingleSLAM.cpp:1148-1149
-                const double sc = 1 / A.maxDist;
+                const double sc = 1 / Q.maxDist;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) ivar[k] = ivar[k] * sc;
                 search = true;
@@ -204,20 +197,20 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
                 if (C.slot2map[iMin] < 0) outFlags |= 1;               // :759 pFeat->mpt == 0
                 if (C.isDynamic && C.isDynamic[iMin]) outFlags |= 2;  // :758 pFeat->type
                 double v2[4], iv[4];                                   // staticCheckMergability, the candidate itself (:716-725)
-                projection_cov(q, A.cov + 9 * (size_t)p, A.sigmaMerge, v2);
+                projection_cov(q, Q.cov + 9 * (size_t)p, Q.sigmaMerge, v2);
                 mat22_inv(v2, iv);
                 if (!(maha_dist2(m0, m1, xs[iMin], ys[iMin], iv) > 1.0)) outFlags |= 4;
             }
         }
     }
-    if (wave == 0 && p < A.P) {
-        A.slot[o] = outSlot;
-        A.flags[o] = outFlags;
-        A.dist[o] = outDist;
-        A.m[2 * o] = m0;
-        A.m[2 * o + 1] = m1;
+    if (wave == 0 && p < Q.P) {
+        Q.slot[o] = outSlot;
+        Q.flags[o] = outFlags;
+        Q.dist[o] = outDist;
+        Q.m[2 * o] = m0;
+        Q.m[2 * o + 1] = m1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) A.var[4 * o + k] = var[k];
+        for (int k = 0; k < 4; ++k) Q.var[4 * o + k] = var[k];
     }
 }
 
@@ -233,39 +226,32 @@ int check_args(const char* who, int nCams, const cs_register_cam* cams, int N, i
 
 }  // namespace
 
-extern "C" int cs_register_search_dev(int device, void* hip_stream, int nCams, const cs_register_cam* cams, int N, int W, int H,
-                                      int P, const double* d_M, const double* d_cov, const int* d_pointFeat, double sigmaSearch,
-                                      double maxDist, double sigmaMerge, int* d_slot, double* d_m, double* d_var, double* d_dist,
-                                      int* d_flags) {
-    int rc = check_args("cs_register_search_dev", nCams, cams, N, W, H, P, sigmaSearch, maxDist, sigmaMerge);
-    if (rc != CS_OK) return rc;
-    if (P == 0) return CS_OK;
-    if (!d_M || !d_cov || !d_pointFeat || !d_slot || !d_m || !d_var || !d_dist || !d_flags) {
-        cs_set_error("cs_register_search_dev: null pointer");
+extern "C" int cs_register_search_passes_dev(int device, void* hip_stream, int nCams, const cs_register_cam* cams, int N, int W, int H,
+                                             int nPass, const cs_register_pass* passes) {
+    if (nPass < 1 || nPass > 2 || !passes) {
+        cs_set_error("cs_register_search_passes_dev: 1 or 2 passes");
         return CS_ERR_INVALID;
     }
     RgArgs A;
     memset(&A, 0, sizeof(A));
-    A.nCams = nCams;
-    A.N = N;
-    A.W = W;
-    A.H = H;
-    A.P = P;
-    A.sigmaSearch = sigmaSearch;
-    A.maxDist = maxDist;
-    A.sigmaMerge = sigmaMerge;
-    A.M = d_M;
-    A.cov = d_cov;
-    A.pointFeat = d_pointFeat;
-    A.slot = d_slot;
-    A.m = d_m;
-    A.var = d_var;
-    A.dist = d_dist;
-    A.flags = d_flags;
+    A.nCams = nCams, A.N = N, A.W = W, A.H = H, A.nPass = nPass;
+    int maxP = 0;
+    for (int k = 0; k < nPass; ++k) {
+        const cs_register_pass& q = passes[k];
+        int rc = check_args("cs_register_search_passes_dev", nCams, cams, N, W, H, q.P, q.sigmaSearch, q.maxDist, q.sigmaMerge);
+        if (rc != CS_OK) return rc;
+        if (q.P > 0 && (!q.M || !q.cov || !q.pointFeat || !q.slot || !q.m || !q.var || !q.dist || !q.flags)) {
+            cs_set_error("cs_register_search_passes_dev: null pointer in pass %d", k);
+            return CS_ERR_INVALID;
+        }
+        A.pass[k] = q;
+        if (q.P > maxP) maxP = q.P;
+    }
+    if (maxP == 0) return CS_OK;
     for (int c = 0; c < nCams; ++c) {
         const cs_register_cam& q = cams[c];
         if (!q.K || !q.R || !q.t || !q.xy || !q.state || !q.slot2map) {
-            cs_set_error("cs_register_search_dev: null pointer in camera %d", c);
+            cs_set_error("cs_register_search_passes_dev: null pointer in camera %d", c);
             return CS_ERR_INVALID;
         }
         A.cam[c] = q;
@@ -280,10 +266,28 @@ extern "C" int cs_register_search_dev(int device, void* hip_stream, int nCams, c
             raised = true;
         }
     }
-    hipLaunchKernelGGL(k_register_search, dim3((unsigned)((P + 63) / 64), (unsigned)nCams), dim3(64 * RG_WAVES), ldsBytes,
+    hipLaunchKernelGGL(k_register_search, dim3((unsigned)((maxP + 63) / 64), (unsigned)nCams, (unsigned)nPass), dim3(64 * RG_WAVES), ldsBytes,
                        (hipStream_t)hip_stream, A);
     CS_CHECK_LAUNCH();
     return CS_OK;
+}
+
+extern "C" int cs_register_search_dev(int device, void* hip_stream, int nCams, const cs_register_cam* cams, int N, int W, int H,
+                                      int P, const double* d_M, const double* d_cov, const int* d_pointFeat, double sigmaSearch,
+                                      double maxDist, double sigmaMerge, int* d_slot, double* d_m, double* d_var, double* d_dist,
+                                      int* d_flags) {
+    int rc = check_args("cs_register_search_dev", nCams, cams, N, W, H, P, sigmaSearch, maxDist, sigmaMerge);
+    if (rc != CS_OK) return rc;
+    if (P == 0) return CS_OK;
+    if (!d_M || !d_cov || !d_pointFeat || !d_slot || !d_m || !d_var || !d_dist || !d_flags) {
+        cs_set_error("cs_register_search_dev: null pointer");
+        return CS_ERR_INVALID;
+    }
+    cs_register_pass q;
+    memset(&q, 0, sizeof(q));
+    q.P = P, q.sigmaSearch = sigmaSearch, q.maxDist = maxDist, q.sigmaMerge = sigmaMerge;
+    q.M = d_M, q.cov = d_cov, q.pointFeat = d_pointFeat, q.slot = d_slot, q.m = d_m, q.var = d_var, q.dist = d_dist, q.flags = d_flags;
+    return cs_register_search_passes_dev(device, hip_stream, nCams, cams, N, W, H, 1, &q);
 }
 
 // Host-pointer form for the reference's loops: one upload, one launch, one read-back.  cams[c] holds HOST pointers.

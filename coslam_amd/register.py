@@ -41,6 +41,32 @@ def register_search_dev(stream_ptr, cams, N, W, H, P, d_M, d_cov, d_pointFeat, s
           "cs_register_search_dev")
 
 
+class RegisterPass(C.Structure):
+    """== cs_register_pass (include/coslam_hip.h)."""
+
+    _fields_ = [("P", C.c_int), ("sigmaSearch", C.c_double), ("maxDist", C.c_double), ("sigmaMerge", C.c_double)] + \
+               [(n, C.c_void_p) for n in ("M", "cov", "pointFeat", "slot", "m", "var", "dist", "flags")]
+
+
+def register_passes(passes):
+    """list of dicts with the field names of cs_register_pass (pointers as ints) -> the ctypes array (build once)"""
+    if isinstance(passes, C.Array):
+        return passes
+    arr = (RegisterPass * len(passes))()
+    for a, q in zip(arr, passes):
+        a.P, a.sigmaSearch, a.maxDist, a.sigmaMerge = int(q["P"]), float(q["sigmaSearch"]), float(q["maxDist"]), float(q["sigmaMerge"])
+        for n in ("M", "cov", "pointFeat", "slot", "m", "var", "dist", "flags"):
+            setattr(a, n, int(q[n]))
+    return arr
+
+
+def register_search_passes_dev(stream_ptr, cams, N, W, H, passes, device=0):
+    """The registration passes of a frame (1 or 2) in ONE launch; cams / passes: lists of dicts or the prebuilt ctypes arrays."""
+    arr = register_passes(passes)
+    check(lib().cs_register_search_passes_dev(int(device), C.c_void_p(stream_ptr), len(register_cams(cams)), register_cams(cams), int(N),
+                                              int(W), int(H), len(arr), arr), "cs_register_search_passes_dev")
+
+
 def register_search(W, H, Ks, Rs, ts, xy, state, slot2map, isDynamic, Ms, covs, pointFeat, sigmaSearch, maxDist, sigmaMerge,
                     device=0):
     """Host arrays in and out (cs_register_search).  xy / state / slot2map / isDynamic: one array per camera (isDynamic

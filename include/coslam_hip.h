@@ -289,6 +289,22 @@ typedef struct cs_register_cam {
  * pointFeat (P x nCams): slot of p->pFeatures[iCam] when that feature belongs to the current frame, else -1.
  * cams: HOST array of nCams (<= 16) records; in the _dev form their members and every d_* argument are DEVICE pointers,
  * in the host form everything is host memory (one upload, one launch, one read-back). */
+/* One pass = one of the registration loops' searches (its map points, its three scalars, its output tables); the passes of a
+ * frame -- active points, current static points: CoSLAMThread.cpp:108-118 -- can share ONE launch. */
+typedef struct cs_register_pass {
+    int P;
+    double sigmaSearch, maxDist, sigmaMerge;
+    const double* M;      /* P x 3 */
+    const double* cov;    /* P x 9 */
+    const int* pointFeat; /* P x nCams */
+    int* slot;            /* P x nCams out, like cs_register_search_dev's tables */
+    double* m;
+    double* var;
+    double* dist;
+    int* flags;
+} cs_register_pass;
+int cs_register_search_passes_dev(int device, void* hip_stream, int nCams, const cs_register_cam* cams, int N, int W, int H,
+                                  int nPass /* 1 or 2 */, const cs_register_pass* passes /* host array */);
 int cs_register_search_dev(int device, void* hip_stream, int nCams, const cs_register_cam* cams, int N, int W, int H, int P,
                            const double* d_M, const double* d_cov, const int* d_pointFeat, double sigmaSearch, double maxDist,
                            double sigmaMerge, int* d_slot, double* d_m, double* d_var, double* d_dist, int* d_flags);

@@ -188,3 +188,33 @@ def test_register_search_behind_the_tracker_and_the_hand_back(hip):
     # such a candidate passes the mergability term (r^2 / pixelErrVar^2 <= 1)
     near = (o["slot"] >= 0) & (o["dist"] < 1e-3)
     assert near.sum() > 30 and (o["flags"][near] & 4).all()
+    # ... and the two passes of a frame (active points: 2.5 sigma; current static points: 1 sigma, a different point set of a
+    # different size and a pointFeat table with attached points) in ONE launch give the tables of two separate launches
+    from coslam_amd.register import register_search_passes_dev
+
+    P2 = 700
+    pf2 = np.full((P2, n_cams), -1, np.int32)
+    pf2[::7, 1] = 5                                   # these points already have a feature of this frame in camera 1
+    d_pf2 = torch.from_numpy(pf2).to(dev)
+
+    def tables(n):
+        return dict(slot=torch.full((n * n_cams,), 99, dtype=torch.int32, device=dev), m=torch.zeros(n * n_cams * 2, dtype=torch.float64, device=dev),
+                    var=torch.zeros(n * n_cams * 4, dtype=torch.float64, device=dev), dist=torch.zeros(n * n_cams, dtype=torch.float64, device=dev),
+                    flags=torch.zeros(n * n_cams, dtype=torch.int32, device=dev))
+
+    sS2, mD2, sM2 = MODES["static"]
+    sep, fus = [tables(P), tables(P2)], [tables(P), tables(P2)]
+    specs = [(P, d_map.data_ptr(), d_cov.data_ptr(), d_pf.data_ptr(), sS, mD, sM),
+             (P2, d_map.data_ptr() + 24 * 100, d_cov.data_ptr() + 72 * 100, d_pf2.data_ptr(), sS2, mD2, sM2)]
+    for (n, pM, pC, pF, a, b, c_), o_ in zip(specs, sep):
+        coslam_amd.register_search_dev(stream, cams, N, W, H, n, pM, pC, pF, a, b, c_, o_["slot"].data_ptr(), o_["m"].data_ptr(),
+                                       o_["var"].data_ptr(), o_["dist"].data_ptr(), o_["flags"].data_ptr())
+    register_search_passes_dev(stream, cams, N, W, H,
+                               [dict(P=n, sigmaSearch=a, maxDist=b, sigmaMerge=c_, M=pM, cov=pC, pointFeat=pF, slot=o_["slot"].data_ptr(),
+                                     m=o_["m"].data_ptr(), var=o_["var"].data_ptr(), dist=o_["dist"].data_ptr(), flags=o_["flags"].data_ptr())
+                                for (n, pM, pC, pF, a, b, c_), o_ in zip(specs, fus)])
+    torch.cuda.synchronize()
+    for o1, o2 in zip(sep, fus):
+        for k in o1:
+            assert np.array_equal(o1[k].cpu().numpy().view(np.uint8), o2[k].cpu().numpy().view(np.uint8)), k
+    assert (fus[1]["slot"].cpu().numpy().reshape(P2, n_cams)[::7, 1] == -1).all()

@@ -353,11 +353,17 @@ int main(int argc, char** argv) {
         CSCHK(cs_pose_update_frame_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dR[dsti], dT[dsti], dMap, dCov, dMapFlags, 0, PIX, i, 20, 5,
                                        3, 6.0, nullptr, nullptr, nullptr));
         // activeMapPointsRegister, then currentMapPointsRegister (static points), search step
-        CSCHK(cs_register_search_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, P_REG, dMap + 3 * (size_t)P_REG,
-                                     dCov + 9 * (size_t)P_REG, dPfNone, 2.5 * PIX, 3 * PIX, PIX, reg[0].slot, reg[0].m, reg[0].var,
-                                     reg[0].dist, reg[0].flags));
-        CSCHK(cs_register_search_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, P_REG, dMap, dCov, dPf, PIX, 3 * PIX, PIX,
-                                     reg[1].slot, reg[1].m, reg[1].var, reg[1].dist, reg[1].flags));
+        {
+            cs_register_pass ps[2];
+            memset(ps, 0, sizeof(ps));
+            ps[0].P = P_REG, ps[0].sigmaSearch = 2.5 * PIX, ps[0].maxDist = 3 * PIX, ps[0].sigmaMerge = PIX;
+            ps[0].M = dMap + 3 * (size_t)P_REG, ps[0].cov = dCov + 9 * (size_t)P_REG, ps[0].pointFeat = dPfNone;
+            ps[0].slot = reg[0].slot, ps[0].m = reg[0].m, ps[0].var = reg[0].var, ps[0].dist = reg[0].dist, ps[0].flags = reg[0].flags;
+            ps[1].P = P_REG, ps[1].sigmaSearch = PIX, ps[1].maxDist = 3 * PIX, ps[1].sigmaMerge = PIX;
+            ps[1].M = dMap, ps[1].cov = dCov, ps[1].pointFeat = dPf;
+            ps[1].slot = reg[1].slot, ps[1].m = reg[1].m, ps[1].var = reg[1].var, ps[1].dist = reg[1].dist, ps[1].flags = reg[1].flags;
+            CSCHK(cs_register_search_passes_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, 2, ps));   // both passes, one launch
+        }
         // staticCheckMergability of the current-static pass's candidates over their whole tracks (SL_CoSLAM.cpp:714-729, :768)
         CSCHK(cs_register_mergability_dev(hist, (void*)poseS, pu.data(), P_REG, dMap, dCov, reg[1].slot, PIX, dMergeable));
         HIPCHK(hipEventRecord(destFree[b], poseS));
