@@ -680,7 +680,8 @@ def main():
     ncc = None
     if not args.no_ncc and nc >= 2:
         from coslam_amd._lib import check
-        from coslam_amd.ncc import NCC_PAIR_DTYPE, ncc_epi_mat_dev, ncc_epi_pairs_dev, ncc_get_blocks_dev, ncc_scaled_dims
+        from coslam_amd.ncc import (NCC_PAIR_DTYPE, ncc_cams, ncc_epi_mat_dev, ncc_epi_pairs_group_dev, ncc_get_blocks_dev,
+                                    ncc_get_blocks_group_dev, ncc_pair_jobs, ncc_scaled_dims)
 
         ws_, hs_ = ncc_scaled_dims(W, H, 0.3)
         Kinv = np.linalg.inv(sc.K)
@@ -705,6 +706,7 @@ def main():
     ncc_s = torch.cuda.Stream(device=dev) if (ncc is not None and args.ncc_stream and not args.serial) else None
     ncc_xy = torch.zeros_like(d_xy) if ncc_s is not None else d_xy
     ncc_snap, ncc_free = torch.cuda.Event(), torch.cuda.Event()
+    ncc_group = {}   # per frame of the sequence: the ctypes tables of the run's three launches (built once)
 
     def ncc_leg(f):
         s_ = pose_s.cuda_stream
@@ -720,19 +722,28 @@ def main():
             ncc_snap.record(pose_s)
             ncc_s.wait_event(ncc_snap)
             s_ = ncc_s.cuda_stream
+        if not args.ncc_dense:
+            # the whole run in three launches: getNCCBlocks of all cameras (resize, cutter), then every camera pair's passing pairs as
+            # a list (what getEpiNccMat's dense matrices hold besides -1: kilobytes instead of 64 MB per camera pair)
+            key = (f, id(ncc_xy))
+            if key not in ncc_group:
+                cams_ = ncc_cams([dict(img=img_ptrs[f][i], x=ncc_xy[i].data_ptr(), y=ncc_xy[i].data_ptr() + 8 * N_FEAT,
+                                       scaled=ncc["small"][i].data_ptr(), blocks=ncc["blk"][i].data_ptr(), abc=ncc["abc"][i].data_ptr(),
+                                       valid=ncc["valid"][i].data_ptr()) for i in range(nc)])
+                jobs_ = ncc_pair_jobs([dict(F=ncc["F"][(my_cams[i], f)], camA=i, camB=i + 1, pairs=ncc["pairs"][i].data_ptr(),
+                                            count=ncc["pair_count"][i:i + 1].data_ptr()) for i in range(nc - 1)])
+                ncc_group[key] = (cams_, jobs_)
+            cams_, jobs_ = ncc_group[key]
+            ncc_get_blocks_group_dev(s_, cams_, W, H, N_FEAT, 0.3, device=local_rank)
+            ncc_epi_pairs_group_dev(s_, cams_, N_FEAT, jobs_, 50.0, 0.80, NCC_PAIR_CAP, device=local_rank)
+            if ncc_s is not None:
+                ncc_free.record(ncc_s)
+            ncc["runs"] += 1
+            return
         for i in range(nc):
             ncc_get_blocks_dev(s_, img_ptrs[f][i], W, H, N_FEAT, ncc_xy[i].data_ptr(), ncc_xy[i].data_ptr() + 8 * N_FEAT, 0.3,
                                ncc["small"][i].data_ptr(), ncc["blk"][i].data_ptr(), ncc["abc"][i].data_ptr(), 0, device=local_rank)
         for i in range(nc - 1):
-            if not args.ncc_dense:
-                # the pairs that pass getEpiNccMat's two tests as a list (what the dense matrices hold besides -1): per camera pair
-                # kilobytes instead of the matrices' 64 MB
-                ncc_epi_pairs_dev(s_, ncc["F"][(my_cams[i], f)], N_FEAT, ncc_xy[i].data_ptr(), ncc_xy[i].data_ptr() + 8 * N_FEAT,
-                                  ncc["blk"][i].data_ptr(), ncc["abc"][i].data_ptr(), ncc["valid"][i].data_ptr(), N_FEAT,
-                                  ncc_xy[i + 1].data_ptr(), ncc_xy[i + 1].data_ptr() + 8 * N_FEAT, ncc["blk"][i + 1].data_ptr(),
-                                  ncc["abc"][i + 1].data_ptr(), ncc["valid"][i + 1].data_ptr(), 50.0, 0.80, ncc["pairs"][i].data_ptr(),
-                                  NCC_PAIR_CAP, ncc["pair_count"][i:i + 1].data_ptr(), device=local_rank)
-                continue
             ncc_epi_mat_dev(s_, ncc["F"][(my_cams[i], f)], N_FEAT, ncc_xy[i].data_ptr(), ncc_xy[i].data_ptr() + 8 * N_FEAT, ncc["blk"][i].data_ptr(),
                             ncc["abc"][i].data_ptr(), ncc["valid"][i].data_ptr(), N_FEAT, ncc_xy[i + 1].data_ptr(),
                             ncc_xy[i + 1].data_ptr() + 8 * N_FEAT, ncc["blk"][i + 1].data_ptr(), ncc["abc"][i + 1].data_ptr(),

@@ -85,10 +85,23 @@ __device__ __forceinline__ int nc_floorf(float v) {
 __device__ __forceinline__ int nc_clip(int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; }
 __device__ __forceinline__ int nc_sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 
+// the cameras of a group launch (blockIdx.z / blockIdx.y): cs_ncc_get_blocks_group_dev
+constexpr int NC_MAX_CAMS = 16;
+struct NcCamSet {
+    const unsigned char* img[NC_MAX_CAMS];
+    unsigned char* scaled[NC_MAX_CAMS];
+    const double* x[NC_MAX_CAMS];
+    const double* y[NC_MAX_CAMS];
+    unsigned char* blocks[NC_MAX_CAMS];
+    double* abc[NC_MAX_CAMS];
+    int* valid[NC_MAX_CAMS];
+};
+
 // one thread per destination pixel; (dx, dy) -> the two source columns / rows and their 11-bit weights exactly as
-// cv::resize's tables hold them
-__global__ __launch_bounds__(256) void k_resize_linear_u8(const unsigned char* __restrict__ src, int W, int H, double scale_x,
-                                                          double scale_y, unsigned char* __restrict__ dst, int Wd, int Hd) {
+// cv::resize's tables hold them; blockIdx.z = camera
+__global__ __launch_bounds__(256) void k_resize_linear_u8(NcCamSet S, int W, int H, double scale_x, double scale_y, int Wd, int Hd) {
+    const unsigned char* __restrict__ src = S.img[blockIdx.z];
+    unsigned char* __restrict__ dst = S.scaled[blockIdx.z];
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= Wd || dy >= Hd) return;
     float fx = (float)((dx + 0.5) * scale_x - 0.5);
@@ -121,10 +134,14 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(const unsigned char* _
 // one wave per point: lanes 0..120 = the pixels of the 11 x 11 patch (two per lane); cv::getRectSubPix 8u -> 8u.
 // The border path of the original walks the rows with a pointer that stops advancing outside the image; in closed form the
 // top source row of window row i is row0 + max(0, min(i, rh) - ry), the bottom one the next row unless i < ry or i >= rh.
-__global__ __launch_bounds__(256) void k_ncc_blocks_subpix(const unsigned char* __restrict__ img, int W, int H, int n,
-                                                           const double* __restrict__ xs, const double* __restrict__ ys,
-                                                           double scale, int scaled, unsigned char* __restrict__ blocks,
-                                                           double* __restrict__ abc, int* __restrict__ valid) {
+__global__ __launch_bounds__(256) void k_ncc_blocks_subpix(NcCamSet S, int W, int H, int n, double scale, int scaled) {
+    const int cam = blockIdx.y;  // (of a group launch)
+    const unsigned char* __restrict__ img = scaled ? S.scaled[cam] : S.img[cam];
+    const double* __restrict__ xs = S.x[cam];
+    const double* __restrict__ ys = S.y[cam];
+    unsigned char* __restrict__ blocks = S.blocks[cam];
+    double* __restrict__ abc = S.abc[cam];
+    int* __restrict__ valid = S.valid[cam];
     const int lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= n) return;
@@ -251,8 +268,13 @@ __device__ __forceinline__ long nc_row_chunk(const unsigned char* blocks, int ro
 // 64 MB for 2000 x 2000: what bounds the kernel.  SPARSE = true: only the pairs that pass, as {i, j, epiErr, ncc} records
 // appended through one atomic counter (the order of the list is not defined; the matrices are its scatter into wNone-filled
 // arrays): a matching run of 7 camera pairs then writes kilobytes instead of 448 MB.
+constexpr int NC_MAX_JOBS = 8;
+struct NcJobs {
+    NcArgs job[NC_MAX_JOBS];  // blockIdx.z = camera pair of a group launch (cs_ncc_epi_pairs_group_dev)
+};
 template <bool SPARSE>
-__global__ __launch_bounds__(256) void k_ncc_epi_mat(NcArgs A) {
+__global__ __launch_bounds__(256) void k_ncc_epi_mat(NcJobs J) {
+    const NcArgs& A = J.job[blockIdx.z];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int M = A.s1.n, N = A.s2.n;
     const int i0 = blockIdx.y * 64 + 16 * wv;  // this wave's 16 rows (features of camera 1)
@@ -376,6 +398,8 @@ extern "C" int cs_ncc_scaled_dims(int W, int H, double scale, int* Ws, int* Hs) 
     return CS_OK;
 }
 
+static int ncc_get_blocks_group_impl(int device, void* hip_stream, int nCams, const cs_ncc_cam* cams, int W, int H, int n, double scale,
+                                     bool writeValid);
 // getNCCBlocks(img, pts, blocks, scale) for n points, asynchronous on hip_stream; d_scaled: the caller's scratch for the resized
 // image (cs_ncc_scaled_dims bytes; ignored when scale == 1.0).  Every point gets a block (the border is replicated), so there is
 // no `valid` output -- d_valid, when given, is set to 1 for cs_ncc_epi_mat_dev.
@@ -387,24 +411,46 @@ extern "C" int cs_ncc_get_blocks_dev(int device, void* hip_stream, const unsigne
         cs_set_error("cs_ncc_get_blocks_dev: bad arguments");
         return CS_ERR_INVALID;
     }
+    cs_ncc_cam one;
+    memset(&one, 0, sizeof(one));
+    one.img = d_img, one.x = d_x, one.y = d_y, one.scaled = d_scaled, one.blocks = d_blocks, one.abc = d_abc, one.valid = d_valid;
+    return ncc_get_blocks_group_impl(device, hip_stream, 1, &one, W, H, n, scale, true);
+}
+
+// every camera of a group: ONE resize launch and ONE cutter launch (blockIdx.z / .y = camera).  cs_ncc_cam::valid is the caller's
+// mask for the matrices (which features take part) and is left alone.
+extern "C" int cs_ncc_get_blocks_group_dev(int device, void* hip_stream, int nCams, const cs_ncc_cam* cams, int W, int H, int n,
+                                           double scale) {
+    return ncc_get_blocks_group_impl(device, hip_stream, nCams, cams, W, H, n, scale, false);
+}
+static int ncc_get_blocks_group_impl(int device, void* hip_stream, int nCams, const cs_ncc_cam* cams, int W, int H, int n, double scale,
+                                     bool writeValid) {
+    if (nCams < 1 || nCams > NC_MAX_CAMS || !cams || W <= 0 || H <= 0 || n < 0 || !(scale > 0)) {
+        cs_set_error("cs_ncc_get_blocks_group_dev: bad arguments (1..%d cameras)", NC_MAX_CAMS);
+        return CS_ERR_INVALID;
+    }
+    NcCamSet S;
+    memset(&S, 0, sizeof(S));
+    for (int c = 0; c < nCams; ++c) {
+        const cs_ncc_cam& q = cams[c];
+        if (!q.img || (n && (!q.x || !q.y || !q.blocks || !q.abc)) || (scale != 1.0 && !q.scaled)) {
+            cs_set_error("cs_ncc_get_blocks_group_dev: null pointer in camera %d", c);
+            return CS_ERR_INVALID;
+        }
+        S.img[c] = q.img, S.scaled[c] = q.scaled, S.x[c] = q.x, S.y[c] = q.y, S.blocks[c] = q.blocks, S.abc[c] = q.abc, S.valid[c] = writeValid ? q.valid : nullptr;
+    }
     CS_HIP(hipSetDevice(device));
     hipStream_t s = (hipStream_t)hip_stream;
-    const unsigned char* im = d_img;
     int Ws = W, Hs = H;
     if (scale != 1.0) {
         Ws = (int)lrint(W * scale), Hs = (int)lrint(H * scale);
         if (Ws < 1 || Hs < 1) {
-            cs_set_error("cs_ncc_get_blocks_dev: the scaled image is empty");
+            cs_set_error("cs_ncc_get_blocks_group_dev: the scaled image is empty");
             return CS_ERR_INVALID;
         }
-        hipLaunchKernelGGL(k_resize_linear_u8, dim3((Ws + 63) / 64, (Hs + 3) / 4), dim3(256), 0, s, d_img, W, H, 1. / scale, 1. / scale,
-                           d_scaled, Ws, Hs);
-        im = d_scaled;
+        hipLaunchKernelGGL(k_resize_linear_u8, dim3((Ws + 63) / 64, (Hs + 3) / 4, nCams), dim3(256), 0, s, S, W, H, 1. / scale, 1. / scale, Ws, Hs);
     }
-    if (n > 0) {
-        hipLaunchKernelGGL(k_ncc_blocks_subpix, dim3((n + 3) / 4), dim3(256), 0, s, im, Ws, Hs, n, d_x, d_y, scale, scale != 1.0 ? 1 : 0,
-                           d_blocks, d_abc, d_valid);
-    }
+    if (n > 0) hipLaunchKernelGGL(k_ncc_blocks_subpix, dim3((n + 3) / 4, nCams), dim3(256), 0, s, S, Ws, Hs, n, scale, scale != 1.0 ? 1 : 0);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }
@@ -435,8 +481,10 @@ extern "C" int cs_ncc_epi_mat_dev(int device, void* hip_stream, const double F[9
     A.nccMat = d_nccMat;
     CS_HIP(hipSetDevice(device));
     A.pairs = nullptr, A.pairCap = 0, A.pairCount = nullptr;
+    NcJobs J;
+    J.job[0] = A;
     hipLaunchKernelGGL(k_ncc_epi_mat<false>, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0,
-                       (hipStream_t)hip_stream, A);
+                       (hipStream_t)hip_stream, J);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }
@@ -465,8 +513,49 @@ extern "C" int cs_ncc_epi_pairs_dev(int device, void* hip_stream, const double F
     A.wNone = -1.0;
     A.epiMat = A.nccMat = nullptr;
     A.pairs = d_pairs, A.pairCap = pairCap, A.pairCount = d_pairCount;
+    NcJobs J;
+    J.job[0] = A;
     hipLaunchKernelGGL(k_ncc_epi_mat<true>, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0,
-                       (hipStream_t)hip_stream, A);
+                       (hipStream_t)hip_stream, J);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+// the camera pairs of a matching run in ONE launch (blockIdx.z = pair): jobs[k] = {F, camA, camB, pairs, count}; the cameras'
+// blocks / abc / valid / positions as cs_ncc_get_blocks_group_dev left them (n features each)
+extern "C" int cs_ncc_epi_pairs_group_dev(int device, void* hip_stream, int nCams, const cs_ncc_cam* cams, int n, int nJobs,
+                                          const cs_ncc_pair_job* jobs, double epiMax, double nccMin, int pairCap) {
+    if (nCams < 1 || nCams > NC_MAX_CAMS || !cams || n < 0 || nJobs < 0 || nJobs > NC_MAX_JOBS || (nJobs && !jobs) || pairCap < 0) {
+        cs_set_error("cs_ncc_epi_pairs_group_dev: bad arguments (<= %d camera pairs per call)", NC_MAX_JOBS);
+        return CS_ERR_INVALID;
+    }
+    if (nJobs == 0) return CS_OK;
+    CS_HIP(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    NcJobs J;
+    memset(&J, 0, sizeof(J));
+    for (int k = 0; k < nJobs; ++k) {
+        const cs_ncc_pair_job& q = jobs[k];
+        if (q.camA < 0 || q.camA >= nCams || q.camB < 0 || q.camB >= nCams || !q.count || (pairCap > 0 && !q.pairs)) {
+            cs_set_error("cs_ncc_epi_pairs_group_dev: bad job %d", k);
+            return CS_ERR_INVALID;
+        }
+        const cs_ncc_cam &a = cams[q.camA], &b = cams[q.camB];
+        if (n && (!a.x || !a.y || !a.blocks || !a.abc || !a.valid || !b.x || !b.y || !b.blocks || !b.abc || !b.valid)) {
+            cs_set_error("cs_ncc_epi_pairs_group_dev: null pointer in a camera of job %d", k);
+            return CS_ERR_INVALID;
+        }
+        NcArgs& A = J.job[k];
+        memcpy(A.F, q.F, sizeof(A.F));
+        A.s1 = {a.x, a.y, a.blocks, a.abc, a.valid, n};
+        A.s2 = {b.x, b.y, b.blocks, b.abc, b.valid, n};
+        A.epiMax = epiMax, A.nccMin = nccMin, A.wNone = -1.0;
+        A.epiMat = A.nccMat = nullptr;
+        A.pairs = q.pairs, A.pairCap = pairCap, A.pairCount = q.count;
+        CS_HIP(hipMemsetAsync(q.count, 0, sizeof(int), s));
+    }
+    if (n == 0) return CS_OK;
+    hipLaunchKernelGGL(k_ncc_epi_mat<true>, dim3((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64), (unsigned)nJobs), dim3(256), 0, s, J);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

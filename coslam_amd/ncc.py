@@ -38,6 +38,54 @@ def ncc_epi_pairs_dev(stream_ptr, F, M, d_x1, d_y1, d_blocks1, d_abc1, d_valid1,
           "cs_ncc_epi_pairs_dev")
 
 
+class NccCam(C.Structure):
+    """== cs_ncc_cam (include/coslam_hip.h)."""
+
+    _fields_ = [(n, C.c_void_p) for n in ("img", "x", "y", "scaled", "blocks", "abc", "valid")]
+
+
+class NccPairJob(C.Structure):
+    """== cs_ncc_pair_job."""
+
+    _fields_ = [("F", C.c_double * 9), ("camA", C.c_int), ("camB", C.c_int), ("pairs", C.c_void_p), ("count", C.c_void_p)]
+
+
+def ncc_cams(cams):
+    """list of dicts of DEVICE pointers (ints) with the field names of cs_ncc_cam -> the ctypes array"""
+    arr = (NccCam * len(cams))()
+    for a, c in zip(arr, cams):
+        for n, _ in NccCam._fields_:
+            v = c.get(n)
+            setattr(a, n, int(v) if v else None)
+    return arr
+
+
+def ncc_pair_jobs(jobs):
+    """list of dicts(F (9 floats), camA, camB, pairs, count) -> the ctypes array"""
+    arr = (NccPairJob * len(jobs))()
+    for a, q in zip(arr, jobs):
+        F = np.ascontiguousarray(q["F"], dtype=np.float64).reshape(9)
+        for k in range(9):
+            a.F[k] = float(F[k])
+        a.camA, a.camB, a.pairs, a.count = int(q["camA"]), int(q["camB"]), int(q["pairs"]), int(q["count"])
+    return arr
+
+
+def ncc_get_blocks_group_dev(stream_ptr, cams, W, H, n, scale, device=0):
+    """getNCCBlocks of every camera of a group: one resize launch + one cutter launch (cams: ncc_cams(...) or a list of dicts)"""
+    arr = cams if isinstance(cams, C.Array) else ncc_cams(cams)
+    check(lib().cs_ncc_get_blocks_group_dev(int(device), C.c_void_p(stream_ptr), len(arr), arr, int(W), int(H), int(n), C.c_double(scale)),
+          "cs_ncc_get_blocks_group_dev")
+
+
+def ncc_epi_pairs_group_dev(stream_ptr, cams, n, jobs, epiMax, nccMin, pairCap, device=0):
+    """cs_ncc_epi_pairs_dev of every camera pair of a matching run in one launch (jobs: ncc_pair_jobs(...) or a list of dicts)"""
+    arr = cams if isinstance(cams, C.Array) else ncc_cams(cams)
+    jb = jobs if isinstance(jobs, C.Array) else ncc_pair_jobs(jobs)
+    check(lib().cs_ncc_epi_pairs_group_dev(int(device), C.c_void_p(stream_ptr), len(arr), arr, int(n), len(jb), jb, C.c_double(epiMax),
+                                           C.c_double(nccMin), int(pairCap)), "cs_ncc_epi_pairs_group_dev")
+
+
 def ncc_match_between(img1, x1, y1, img2, x2, y2, scale, F, epiMax, nccMin, wNone=-1.0, device=0):
     """Host arrays in and out (cs_ncc_match_between).  Returns dict(epi, ncc (M x N), blocks1/2 (n x 128 uint8), abc1/2
     (n x 4), valid1/2)."""

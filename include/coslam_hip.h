@@ -496,6 +496,29 @@ int cs_ncc_epi_pairs_dev(int device, void* hip_stream, const double F[9] /* host
                          const unsigned char* d_blocks1, const double* d_abc1, const int* d_valid1, int N, const double* d_x2,
                          const double* d_y2, const unsigned char* d_blocks2, const double* d_abc2, const int* d_valid2,
                          double epiMax, double nccMin, cs_ncc_pair* d_pairs, int pairCap, int* d_pairCount);
+/* A whole matching run (NewMapPtsNCC::run: matchBetween for the consecutive cameras of the group,
+ * src/app/SL_NewMapPointsInterCam.cpp:150-158) in THREE launches instead of two per camera and one per pair:
+ * cs_ncc_get_blocks_group_dev = getNCCBlocks of every camera (one resize launch, one cutter launch; `valid` is NOT written: it is
+ * the caller's mask, e.g. cs_ncc_unmapped_mask_dev's), cs_ncc_epi_pairs_group_dev = cs_ncc_epi_pairs_dev of every camera pair. */
+typedef struct cs_ncc_cam {
+    const unsigned char* img; /* the full frame, W x H */
+    const double* x;          /* n positions in full-image pixels */
+    const double* y;
+    unsigned char* scaled;    /* scratch for the resized image (cs_ncc_scaled_dims bytes) */
+    unsigned char* blocks;    /* n x 128 out */
+    double* abc;              /* n x 4 out */
+    int* valid;               /* n: which features take part in the matrices (the caller's mask: read by cs_ncc_epi_pairs_group_dev) */
+} cs_ncc_cam;
+typedef struct cs_ncc_pair_job {
+    double F[9];        /* fundamental matrix of (camA, camB) */
+    int camA, camB;
+    cs_ncc_pair* pairs; /* pairCap records out */
+    int* count;         /* 1 out: zeroed by the call */
+} cs_ncc_pair_job;
+int cs_ncc_get_blocks_group_dev(int device, void* hip_stream, int nCams, const cs_ncc_cam* cams /* host */, int W, int H, int n,
+                                double scale);
+int cs_ncc_epi_pairs_group_dev(int device, void* hip_stream, int nCams, const cs_ncc_cam* cams /* host */, int n, int nJobs,
+                               const cs_ncc_pair_job* jobs /* host, <= 8 */, double epiMax, double nccMin, int pairCap);
 /* How NewMapPtsNCC::matchBetween itself cuts its blocks: getNCCBlocks (src/slam/SL_NCCBlock.cpp:79-155, called at
  * src/app/SL_NewMapPointsInterCam.cpp:280-282 with the FULL image and blockScale 0.3) = cv::resize(img, Size(), scale, scale)
  * [INTER_LINEAR, 8-bit] once per image, then per point cv::getRectSubPix(small, 11 x 11, (x scale, y scale)) [8u -> 8u,

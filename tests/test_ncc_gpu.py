@@ -212,3 +212,58 @@ def test_epi_pairs_is_the_list_of_the_matrices_kept_entries(hip, nccMin, cap):
         assert len(rec) == cap
         assert np.array_equal(rec["epi"], epi_h[rec["i"], rec["j"]]) and np.array_equal(rec["ncc"], ncc_h[rec["i"], rec["j"]])
         assert len({(int(a), int(b)) for a, b in zip(rec["i"], rec["j"])}) == cap and np.all(ncc_h[rec["i"], rec["j"]] != -1.0)
+
+
+def test_group_launches_give_what_the_per_camera_calls_give(hip):
+    """cs_ncc_get_blocks_group_dev + cs_ncc_epi_pairs_group_dev (a whole matching run of three cameras in three launches) against
+    cs_ncc_get_blocks_dev per camera + cs_ncc_epi_pairs_dev per camera pair: the same blocks, A / B / C and pair lists."""
+    import torch
+
+    from coslam_amd.ncc import (NCC_PAIR_DTYPE, ncc_epi_pairs_dev, ncc_epi_pairs_group_dev, ncc_get_blocks_dev, ncc_get_blocks_group_dev,
+                                ncc_scaled_dims)
+
+    W, H, n, nC, scale, cap = 640, 480, 1000, 3, 0.3, 1 << 16
+    sc = Scene(nC, W, H, 3000, seed=79)
+    rng = np.random.default_rng(6)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    ws_, hs_ = ncc_scaled_dims(W, H, scale)
+    imgs, xs, ys, val = [], [], [], []
+    for c in range(nC):
+        imgs.append(torch.from_numpy(sc.render(c, 0)).to(dev))
+        uv, vis = sc.project(c, 0)
+        k = np.nonzero(vis)[0][: n // 2]
+        xs.append(torch.from_numpy(np.concatenate([uv[k, 0], rng.uniform(-20, W + 20, n - len(k))])).to(dev))
+        ys.append(torch.from_numpy(np.concatenate([uv[k, 1], rng.uniform(-20, H + 20, n - len(k))])).to(dev))
+        val.append(torch.from_numpy((rng.random(n) < 0.8).astype(np.int32)).to(dev))
+
+    def bufs():
+        return ([torch.zeros(ws_ * hs_, dtype=torch.uint8, device=dev) for _ in range(nC)], [torch.zeros((n, 128), dtype=torch.uint8, device=dev) for _ in range(nC)],
+                [torch.zeros((n, 4), dtype=torch.float64, device=dev) for _ in range(nC)], [torch.zeros(cap * 24, dtype=torch.uint8, device=dev) for _ in range(nC - 1)],
+                torch.full((nC - 1,), 7, dtype=torch.int32, device=dev))
+
+    Fm = [_fundamental(sc, c, c + 1) for c in range(nC - 1)]
+    sm1, bl1, ab1, pr1, cn1 = bufs()
+    for c in range(nC):
+        ncc_get_blocks_dev(s, imgs[c].data_ptr(), W, H, n, xs[c].data_ptr(), ys[c].data_ptr(), scale, sm1[c].data_ptr(), bl1[c].data_ptr(),
+                           ab1[c].data_ptr(), 0)
+    for c in range(nC - 1):
+        ncc_epi_pairs_dev(s, Fm[c], n, xs[c].data_ptr(), ys[c].data_ptr(), bl1[c].data_ptr(), ab1[c].data_ptr(), val[c].data_ptr(), n,
+                          xs[c + 1].data_ptr(), ys[c + 1].data_ptr(), bl1[c + 1].data_ptr(), ab1[c + 1].data_ptr(), val[c + 1].data_ptr(), 50.0, 0.5,
+                          pr1[c].data_ptr(), cap, cn1[c:c + 1].data_ptr())
+    sm2, bl2, ab2, pr2, cn2 = bufs()
+    cams = [dict(img=imgs[c].data_ptr(), x=xs[c].data_ptr(), y=ys[c].data_ptr(), scaled=sm2[c].data_ptr(), blocks=bl2[c].data_ptr(),
+                 abc=ab2[c].data_ptr(), valid=val[c].data_ptr()) for c in range(nC)]
+    ncc_get_blocks_group_dev(s, cams, W, H, n, scale)
+    ncc_epi_pairs_group_dev(s, cams, n, [dict(F=Fm[c], camA=c, camB=c + 1, pairs=pr2[c].data_ptr(), count=cn2[c:c + 1].data_ptr())
+                                         for c in range(nC - 1)], 50.0, 0.5, cap)
+    torch.cuda.synchronize()
+    for c in range(nC):
+        assert torch.equal(sm1[c], sm2[c]) and torch.equal(bl1[c], bl2[c]) and torch.equal(ab1[c].view(torch.int64), ab2[c].view(torch.int64))
+        assert int(val[c].sum()) < n   # (the mask is the caller's: the group cutter leaves it alone)
+    c1, c2 = cn1.cpu().numpy(), cn2.cpu().numpy()
+    assert np.array_equal(c1, c2) and c1.min() > 20 and c1.max() < cap
+    for c in range(nC - 1):
+        a = np.sort(pr1[c].cpu().numpy().view(NCC_PAIR_DTYPE)[: c1[c]], order=("i", "j"))
+        b = np.sort(pr2[c].cpu().numpy().view(NCC_PAIR_DTYPE)[: c2[c]], order=("i", "j"))
+        assert np.array_equal(a, b)

@@ -379,24 +379,33 @@ int main(int argc, char** argv) {
         // (last on the pose stream: nothing of this frame waits for the matching leg)
         if (nCams >= 2 && i % NCC_EVERY == 0) {
             CSCHK(cs_ncc_unmapped_mask_dev(dev, (void*)poseS, nCams * N, dState, dS2M, dValid));
-            for (int c = 0; c < nCams; ++c)
-                CSCHK(cs_ncc_get_blocks_dev(dev, (void*)poseS, dFrames[c] + imgBytes * f, W, H, N, dXY + (size_t)c * 2 * N,
-                                            dXY + (size_t)c * 2 * N + N, 0.3, dSmall + (size_t)c * wsS * hsS, dBlk + (size_t)c * N * 128,
-                                            dAbc + (size_t)c * N * 4, nullptr));
-            for (int c = 0; c + 1 < nCams; ++c) {
-                const double* xa = dXY + (size_t)c * 2 * N;
-                const double* xb = dXY + (size_t)(c + 1) * 2 * N;
-                if (!nccDense) {   // the pairs that pass getEpiNccMat's tests as a list, not the two dense 64 MB matrices
-                    CSCHK(cs_ncc_epi_pairs_dev(dev, (void*)poseS, Fs.data() + ((size_t)f * (nCams - 1) + c) * 9, N, xa, xa + N,
-                                               dBlk + (size_t)c * N * 128, dAbc + (size_t)c * N * 4, dValid + (size_t)c * N, N, xb, xb + N,
-                                               dBlk + (size_t)(c + 1) * N * 128, dAbc + (size_t)(c + 1) * N * 4, dValid + (size_t)(c + 1) * N,
-                                               50.0, 0.80, dPairs + (size_t)c * NCC_PAIR_CAP, NCC_PAIR_CAP, dPairCount + c));
-                    continue;
+            if (!nccDense) {   // the whole run in three launches: resize + cutter of all cameras, the passing pairs of all camera pairs
+                std::vector<cs_ncc_cam> nc(nCams);
+                std::vector<cs_ncc_pair_job> jb(nCams - 1);
+                for (int c = 0; c < nCams; ++c) {
+                    nc[c].img = dFrames[c] + imgBytes * f, nc[c].x = dXY + (size_t)c * 2 * N, nc[c].y = dXY + (size_t)c * 2 * N + N;
+                    nc[c].scaled = dSmall + (size_t)c * wsS * hsS, nc[c].blocks = dBlk + (size_t)c * N * 128, nc[c].abc = dAbc + (size_t)c * N * 4;
+                    nc[c].valid = dValid + (size_t)c * N;
                 }
-                CSCHK(cs_ncc_epi_mat_dev(dev, (void*)poseS, Fs.data() + ((size_t)f * (nCams - 1) + c) * 9, N, xa, xa + N,
-                                         dBlk + (size_t)c * N * 128, dAbc + (size_t)c * N * 4, dValid + (size_t)c * N, N, xb, xb + N,
-                                         dBlk + (size_t)(c + 1) * N * 128, dAbc + (size_t)(c + 1) * N * 4, dValid + (size_t)(c + 1) * N, 50.0,
-                                         0.80, -1.0, dEpi, dScore));
+                for (int c = 0; c + 1 < nCams; ++c) {
+                    memcpy(jb[c].F, Fs.data() + ((size_t)f * (nCams - 1) + c) * 9, 72);
+                    jb[c].camA = c, jb[c].camB = c + 1, jb[c].pairs = dPairs + (size_t)c * NCC_PAIR_CAP, jb[c].count = dPairCount + c;
+                }
+                CSCHK(cs_ncc_get_blocks_group_dev(dev, (void*)poseS, nCams, nc.data(), W, H, N, 0.3));
+                CSCHK(cs_ncc_epi_pairs_group_dev(dev, (void*)poseS, nCams, nc.data(), N, nCams - 1, jb.data(), 50.0, 0.80, NCC_PAIR_CAP));
+            } else {
+                for (int c = 0; c < nCams; ++c)
+                    CSCHK(cs_ncc_get_blocks_dev(dev, (void*)poseS, dFrames[c] + imgBytes * f, W, H, N, dXY + (size_t)c * 2 * N,
+                                                dXY + (size_t)c * 2 * N + N, 0.3, dSmall + (size_t)c * wsS * hsS, dBlk + (size_t)c * N * 128,
+                                                dAbc + (size_t)c * N * 4, nullptr));
+                for (int c = 0; c + 1 < nCams; ++c) {
+                    const double* xa = dXY + (size_t)c * 2 * N;
+                    const double* xb = dXY + (size_t)(c + 1) * 2 * N;
+                    CSCHK(cs_ncc_epi_mat_dev(dev, (void*)poseS, Fs.data() + ((size_t)f * (nCams - 1) + c) * 9, N, xa, xa + N,
+                                             dBlk + (size_t)c * N * 128, dAbc + (size_t)c * N * 4, dValid + (size_t)c * N, N, xb, xb + N,
+                                             dBlk + (size_t)(c + 1) * N * 128, dAbc + (size_t)(c + 1) * N * 4, dValid + (size_t)(c + 1) * N, 50.0,
+                                             0.80, -1.0, dEpi, dScore));
+                }
             }
             ++nccRuns;
         }
