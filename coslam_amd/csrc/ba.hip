@@ -2718,7 +2718,8 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
             if (lds < floorB) lds = floorB;
             if (lds > 160 * 1024 - 256) lds = 160 * 1024 - 256;
             L.persistLds = lds;
-            CS_HIP(hipFuncSetAttribute((const void*)k_lm_persist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CS_HIP(hipFuncSetAttribute((const void*)k_lm_persist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CS_HIP(hipFuncSetAttribute((const void*)k_lm_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
     }
     return CS_OK;
@@ -2853,7 +2854,10 @@ static void ba_enqueue_lm_run(hipStream_t stream, const BaPlan& L, int steps) {
     if (L.persist) {
         (void)hipMemsetAsync(L.persistBar, 0, 16 * sizeof(int), stream);
         LmPersist Q = {L.persistBar, steps};
-        hipLaunchKernelGGL(k_lm_persist, dim3(L.persistG), dim3(LP_NT), L.persistLds, stream, L.D, Q);
+        if (L.persistG == 1)
+            hipLaunchKernelGGL(k_lm_persist<false>, dim3(1), dim3(LP_NT), L.persistLds, stream, L.D, Q);
+        else
+            hipLaunchKernelGGL(k_lm_persist<true>, dim3(L.persistG), dim3(LP_NT), L.persistLds, stream, L.D, Q);
         return;
     }
     if (L.packed && L.fuseUL && steps > 1) {

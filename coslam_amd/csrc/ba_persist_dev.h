@@ -59,6 +59,10 @@ __device__ __forceinline__ bool lp_barrier(int* bar, int G, int& epoch, int* ali
     return *aliveSh != 0;
 }
 
+// COH = false: ONE workgroup (G = 1) -- nothing crosses workgroups, every access is a plain one and the "grid" barrier is the
+// workgroup's own: the whole run of LM steps of a SMALL problem (the inter-camera solve: order 48, 2 k measurements) without a
+// single launch boundary or coherent access.
+template <bool COH>
 __global__ __launch_bounds__(LP_NT) void k_lm_persist(BaDev D, LmPersist Q) {
     CS_BA_SETPRIO();
     extern __shared__ __attribute__((aligned(16))) double lp_sm[];  // the solver's blocks; the other phases' scratch aliases it
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(LP_NT) void k_lm_persist(BaDev D, LmPersist Q) {
     double* tot = lp_sm;                                           // S: [LP_NW][72]
     for (int it = 0; it < Q.maxSteps && !done; ++it) {
         // ---- L ----
-        for (int w = gw0; w < D.nPackWaves; w += nW) lin_wave<true>(D, w, lane, cur, lambda, wl);
+        for (int w = gw0; w < D.nPackWaves; w += nW) lin_wave<COH>(D, w, lane, cur, lambda, wl);
         if (!lp_barrier(Q.bar, G, epoch, &aliveSh)) {
             timedOut = 1;
             break;
@@ -87,9 +91,9 @@ __global__ __launch_bounds__(LP_NT) void k_lm_persist(BaDev D, LmPersist Q) {
         // ---- S ----
         for (int p0 = blockIdx.x * TEAMS; p0 < nPairs; p0 += G * TEAMS) {  // (workgroup-uniform trip count)
             const int team = wv / WPP, sub = wv % WPP, pi = p0 + team;
-            if (pi < nPairs) schur_pair_part<true, WPP>(D, pi, sub, lane, tot + (size_t)wv * 72);
+            if (pi < nPairs) schur_pair_part<COH, WPP>(D, pi, sub, lane, tot + (size_t)wv * 72);
             __syncthreads();
-            if (pi < nPairs && sub == 0) schur_finish<true, WPP>(D, pi, lane, tot + (size_t)team * WPP * 72, lambda);
+            if (pi < nPairs && sub == 0) schur_finish<COH, WPP>(D, pi, lane, tot + (size_t)team * WPP * 72, lambda);
             __syncthreads();
         }
         if (!lp_barrier(Q.bar, G, epoch, &aliveSh)) {
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(LP_NT) void k_lm_persist(BaDev D, LmPersist Q) {
         // ---- V ----
         if (blockIdx.x == 0) {
             if (D.n > 0) {
-                sb_solve_body<LP_NW, true>(D, lp_sm, &okFlag, false);
+                sb_solve_body<LP_NW, COH>(D, lp_sm, &okFlag, false);
             } else if (tid == 0) {
                 okFlag = 1;
             }
@@ -114,8 +118,8 @@ __global__ __launch_bounds__(LP_NT) void k_lm_persist(BaDev D, LmPersist Q) {
         const int chol_ok = lp_ld_i(Q.bar + 1);
         // ---- U ----
         double c = 0, s2 = 0;
-        for (int w = gw0; w < D.nPackWaves; w += nW) update_wave<true>(D, w, lane, cur, wl, c, s2);
-        for (int j = blockIdx.x * LP_NT + tid; j < D.C; j += G * LP_NT) update_cam<true>(D, j, cur, s2);
+        for (int w = gw0; w < D.nPackWaves; w += nW) update_wave<COH>(D, w, lane, cur, wl, c, s2);
+        for (int j = blockIdx.x * LP_NT + tid; j < D.C; j += G * LP_NT) update_cam<COH>(D, j, cur, s2);
         c = wsum(c);
         s2 = wsum(s2);
         if (lane == 0) {
@@ -130,8 +134,8 @@ __global__ __launch_bounds__(LP_NT) void k_lm_persist(BaDev D, LmPersist Q) {
                 a += red[u];
                 b += red[LP_NW + u];
             }
-            cf_st(D.costPart + blockIdx.x, a);
-            cf_st(D.stepPart + blockIdx.x, b);
+            stm<COH>(D.costPart + blockIdx.x, a);
+            stm<COH>(D.stepPart + blockIdx.x, b);
         }
         if (!lp_barrier(Q.bar, G, epoch, &aliveSh)) {
             timedOut = 1;
@@ -140,8 +144,8 @@ __global__ __launch_bounds__(LP_NT) void k_lm_persist(BaDev D, LmPersist Q) {
         // ---- D ---- (every workgroup, same partials, same order)
         double pc = 0, ps = 0;
         for (int q = tid; q < G; q += LP_NT) {
-            pc += cf_ld(D.costPart + q);
-            ps += cf_ld(D.stepPart + q);
+            pc += ldm<COH>(D.costPart + q);
+            ps += ldm<COH>(D.stepPart + q);
         }
         pc = wsum(pc);
         ps = wsum(ps);
@@ -173,9 +177,9 @@ __global__ __launch_bounds__(LP_NT) void k_lm_persist(BaDev D, LmPersist Q) {
     if (blockIdx.x != 0) return;
     if (cur == 1 && !timedOut) {
         // (the other workgroups' tentative points were drained and their barrier passed before this workgroup got here)
-        for (int q = tid; q < 9 * D.C; q += LP_NT) D.Rs[q] = cf_ld(D.Rn + q);
-        for (int q = tid; q < 3 * D.C; q += LP_NT) D.Ts[q] = cf_ld(D.Tn + q);
-        for (int q = tid; q < 3 * D.P; q += LP_NT) D.pts[q] = cf_ld(D.Mn + q);
+        for (int q = tid; q < 9 * D.C; q += LP_NT) D.Rs[q] = ldm<COH>(D.Rn + q);
+        for (int q = tid; q < 3 * D.C; q += LP_NT) D.Ts[q] = ldm<COH>(D.Tn + q);
+        for (int q = tid; q < 3 * D.P; q += LP_NT) D.pts[q] = ldm<COH>(D.Mn + q);
     }
     if (tid == 0) {
         st->nIterTotal += nSteps;

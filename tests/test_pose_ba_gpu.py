@@ -405,7 +405,7 @@ def test_packed_lm_step_kernels_match_oracle(hip, case):
     assert st.flags == 0
     # the whole LM loop as ONE cooperative launch (ba_persist_dev.h): a few workgroups that loop over the waves / pairs, and
     # enough of them that nobody loops; through the up-front schedule and through the worker thread
-    for g, use_async in ((3, False), (64, False), (7, True)):
+    for g, use_async in ((1, False), (1, True), (3, False), (64, False), (7, True)):
         Rp, Tp, Mp, outp, stp = _solve_in_workspace(pr, ptr, cam, xy, ncon, npcon, maxIter, inner, persist=g, use_async=use_async)
         assert np.array_equal(outp, out) and stp.nIterTotal == st.nIterTotal and stp.nOuter == st.nOuter and stp.flags == 0, (g, use_async)
         assert np.max(np.abs(Rp - R)) < 1e-8 and np.max(np.abs(Tp - T)) < 1e-7 and np.max(np.abs(Mp[sane] - M[sane])) < 1e-6
