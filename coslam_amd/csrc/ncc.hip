@@ -322,14 +322,24 @@ __global__ __launch_bounds__(256) void k_ncc_epi_mat(NcJobs J) {
         const double l2 = (A.F[6] * bx + A.F[7] * by) + A.F[8];
         const double nn = sqrt(l0 * l0 + l1 * l1);
         const double den = nn > 0 ? nn : 1.0;
+        // |l . p1| / den <= epiMax is decided without the division wherever it is not close: a numerator beyond epiMax den (1 + 1e-12)
+        // fails for certain (the margin is 10^4 roundings wide), and a pair that fails writes wNone whatever its quotient is.  Only
+        // the few pairs near or inside the band pay the IEEE division (~20 instructions of the ~26 this test used to cost per pair).
+        const double numMax = (A.epiMax * den) * (1.0 + 1e-12);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = i0 + 4 * lk + r;
             if (i >= M) continue;
-            const double epiErr = fabs((l0 * x1[r] + l1 * y1[r]) + l2) / den;  // SL_FeatureMatching.cpp:24-25
+            const double num = fabs((l0 * x1[r] + l1 * y1[r]) + l2);
             double e = A.wNone, c = A.wNone;
             bool pass = false;
-            if (epiErr <= A.epiMax && v1[r] && v2) {                           // :26
+            double epiErr = 0;
+            bool near = v1[r] && v2 && !(num > numMax);   // (NaN stays in: the exact test below decides as it always did)
+            if (near) {
+                epiErr = num / den;                        // SL_FeatureMatching.cpp:24-25
+                near = epiErr <= A.epiMax;                 // :26
+            }
+            if (near) {
                 const int d = acc[t][r] + 128 * s1[r] + 128 * s2 + NC_LEN * 128 * 128;  // sum I1 I2, exact
                 const double ncc = (((double)NC_LEN * (double)d - A1[r] * A2) * C1[r]) * C2;  // SL_NCCBlock.cpp:263
                 if (ncc >= A.nccMin) {                                          // :29-31
