@@ -118,6 +118,18 @@ class BAWorkspace:
     def wait(self):
         check(self._L.cs_ba_wait(self._h), "cs_ba_wait")
 
+    def pending(self):
+        """asynchronous solves still queued or running (never blocks): RobustBundleRTS::processed as CoSLAM's main loop reads it"""
+        n = self._L.cs_ba_pending(self._h)
+        if n < 0:
+            check(n, "cs_ba_pending")
+        return n
+
+    def completed(self):
+        """asynchronous solves finished since the workspace was created (never blocks)"""
+        self._L.cs_ba_completed.restype = C.c_longlong
+        return int(self._L.cs_ba_completed(self._h))
+
     def result_buffers(self):
         """device addresses (ints) of the workspace's current estimate: (Rs [C,9], Ts [C,3], pts [P,3])"""
         r, t, m = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -2952,6 +2952,7 @@ struct BaWorker {
     hipEvent_t ev[2] = {nullptr, nullptr};
     hipEvent_t tmEv[3] = {nullptr, nullptr, nullptr};  // timing: the job's first and last moment on the workspace's stream, end of the window parse
     int jobsDone = 0;
+    long long jobsCompleted = 0;  // since the workspace was created (cs_ba_completed)
     double gpuMsTotal = 0, gpuMsLast = 0, gpuMsMax = 0, gpuMsParse = 0;
     bool parseStamped = false;
     std::thread::id tid;     // the worker thread: the only one that destroys the graph handles above
@@ -3435,6 +3436,7 @@ static void ba_worker_main(cs_ba* b, BaWorker* w) {
                 snprintf(w->err, sizeof(w->err), "%s", cs_last_error());
             }
             w->inflight -= 1;
+            w->jobsCompleted += 1;
         }
         w->cvDone.notify_all();
     }
@@ -4218,6 +4220,26 @@ int cs_ba_problem_buffers(cs_ba* b, const double** d_Ks, const int** d_obs_ptr, 
     if (d_obs_cam) *d_obs_cam = b->obs_cam;
     if (d_obs_xy) *d_obs_xy = b->obs_xy;
     return CS_OK;
+}
+
+// Where the workspace's asynchronous solves stand, without blocking: cs_ba_pending = queued or running (0 = the last result is
+// final), cs_ba_completed = finished since the workspace was created (the worker has synchronised with the solve's last kernel and
+// its follow-up before it counts one).  A frame loop whose host runs ahead of the device always has the NEXT solve queued, so it
+// watches the completed count to learn that a result is there (the reference's BA thread calls output() itself, under the lock it
+// shares with the tracking thread: src/app/SL_CoSLAM.cpp:1713-1720).
+int cs_ba_pending(cs_ba* b) {
+    if (!b) return CS_ERR_INVALID;
+    BaWorker* w = b->worker;
+    if (!w) return 0;
+    std::lock_guard<std::mutex> lk(w->mu);
+    return w->inflight;
+}
+long long cs_ba_completed(cs_ba* b) {
+    if (!b) return -1;
+    BaWorker* w = b->worker;
+    if (!w) return 0;
+    std::lock_guard<std::mutex> lk(w->mu);
+    return w->jobsCompleted;
 }
 
 int cs_ba_wait(cs_ba* b) {

@@ -36,6 +36,8 @@
 // project, getProjectionCovMat, mat22Inv, mahaDist2, dist2, seqTriangulate, formEMat, getFMat, epipolarError are un-vendored
 // LibVisualSLAM (only their calls are in the reference): definitions in DESIGN.md, the same as register.hip / ncc.hip use;
 // seqTriangulate = one Kalman update of (M, cov) from the measurement with noise sigma^2 I.
+#include <cstdlib>
+
 #include "cs_common.h"
 
 #pragma clang fp contract(off)
@@ -382,6 +384,211 @@ __global__ __launch_bounds__(256) void k_register_mergability(MgArgs A) {
     }
 }
 
+
+// ---- RobustBundleRTS::updateNewPosesPoints (src/app/SL_CoSLAMRobustBA.cpp:248-271) -------------------------------------------------
+// Behind a bundle adjustment + relaxation every map point seen after the window's first key frame is triangulated again from the
+// moved poses: updateStaticPointPosition (src/slam/SL_CoSLAMHelper.cpp:338-394) takes, per camera that holds a feature of the
+// point, that feature and the feature of the same track whose camera centre subtends the largest angle with the current one at
+// the point (first of equal angles in the backward walk; an angle of 0 never), updateDynamicPointPosition (:455-484) this frame's
+// features only (at least one of them TYPE_FEATPOINT_DYNAMIC); then triangulateMultiView over the views' normalised points and
+// getTriangulateCovMat at the new point.  The reference walks FeaturePoint::preFrame lists per point on the host; here UP_LPP lanes
+// = one map point: the lanes stride the backward walk of a camera's track (poses from the history ring -- which therefore has to
+// hold the poses AS ADJUSTED: cs_track_history_set_poses_dev), compare COSINES (acos is monotone; no libm on the device or in the
+// oracle's matching mode) and fold to the walk's first minimum; the 3x3 normal equations are summed view by view in the
+// reference's order and solved by cofactors.  getCameraCenter, getAbsRadiansBetween, normPoint, triangulateMultiView,
+// getTriangulateCovMat are un-vendored LibVisualSLAM: definitions in DESIGN.md 3.9 (the oracle's, operation for operation).
+struct UpArgs {
+    int nCams, N, nMap, H, head, nHist, firstKeyFrame;
+    const int* pointFeat;            // [nMap][nCams]
+    const int* lastFrame;            // [nMap] or null
+    const unsigned char* isCurrent;  // [nMap] or null
+    const double* histXY;
+    const double* histR;
+    const double* histT;
+    double* mapPts;
+    double* mapCov;
+    const unsigned char* mapFlags;
+    double sigma;
+    int* counts;  // [2] static / dynamic points re-triangulated, or null
+    int centresInLds;  // the camera centres of all (camera, ring entry) pairs fit the workgroup's LDS
+    cs_poseupdate_cam cam[PU_MAX_CAMS];
+};
+constexpr int UP_LPP = 8;
+constexpr size_t UP_MAX_LDS = 48 * 1024;
+
+struct UpNormalEq {
+    double N[6], g[3];
+};
+__device__ __forceinline__ void up_add_view(UpNormalEq& E, const double* __restrict__ iK, const double* __restrict__ R,
+                                            const double* __restrict__ t, double mx, double my) {
+    const double w = (iK[6] * mx + iK[7] * my) + iK[8];
+    const double x = ((iK[0] * mx + iK[1] * my) + iK[2]) / w, y = ((iK[3] * mx + iK[4] * my) + iK[5]) / w;  // normPoint
+    const double a0[3] = {R[0] - x * R[6], R[1] - x * R[7], R[2] - x * R[8]}, a1[3] = {R[3] - y * R[6], R[4] - y * R[7], R[5] - y * R[8]};
+    const double b0 = x * t[2] - t[0], b1 = y * t[2] - t[1];
+    E.N[0] = E.N[0] + (a0[0] * a0[0] + a1[0] * a1[0]);
+    E.N[1] = E.N[1] + (a0[0] * a0[1] + a1[0] * a1[1]);
+    E.N[2] = E.N[2] + (a0[0] * a0[2] + a1[0] * a1[2]);
+    E.N[3] = E.N[3] + (a0[1] * a0[1] + a1[1] * a1[1]);
+    E.N[4] = E.N[4] + (a0[1] * a0[2] + a1[1] * a1[2]);
+    E.N[5] = E.N[5] + (a0[2] * a0[2] + a1[2] * a1[2]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) E.g[q] = E.g[q] + (a0[q] * b0 + a1[q] * b1);
+}
+__device__ __forceinline__ void up_add_cov(double* S, const double* __restrict__ K, const double* __restrict__ R,
+                                           const double* __restrict__ t, const double* M) {
+    const PuProj q = pu_project(K, R, t, M);
+    S[0] = S[0] + (q.J[0] * q.J[0] + q.J[3] * q.J[3]);
+    S[1] = S[1] + (q.J[0] * q.J[1] + q.J[3] * q.J[4]);
+    S[2] = S[2] + (q.J[0] * q.J[2] + q.J[3] * q.J[5]);
+    S[3] = S[3] + (q.J[1] * q.J[1] + q.J[4] * q.J[4]);
+    S[4] = S[4] + (q.J[1] * q.J[2] + q.J[4] * q.J[5]);
+    S[5] = S[5] + (q.J[2] * q.J[2] + q.J[5] * q.J[5]);
+}
+// symmetric 3x3 {n00, n01, n02, n11, n12, n22}: cofactors (same order) and the determinant
+__device__ __forceinline__ double up_sym33_cof(const double* N, double* c) {
+    c[0] = N[3] * N[5] - N[4] * N[4];
+    c[1] = N[2] * N[4] - N[1] * N[5];
+    c[2] = N[1] * N[4] - N[2] * N[3];
+    c[3] = N[0] * N[5] - N[2] * N[2];
+    c[4] = N[1] * N[2] - N[0] * N[4];
+    c[5] = N[0] * N[3] - N[1] * N[1];
+    return (N[0] * c[0] + N[1] * c[1]) + N[2] * c[2];
+}
+__device__ __forceinline__ void up_cam_center(const double* __restrict__ R, const double* __restrict__ t, double* C) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) C[i] = -((R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2]);
+}
+
+__global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
+    __shared__ int second[256 / UP_LPP][PU_MAX_CAMS];  // per point and camera: ring depth of the second view, -1 none, -2 no feature
+    extern __shared__ double up_cen[];                  // [nCams][nHist][3] camera centres by walk depth (0 = this frame)
+    const int tid = threadIdx.x, g = tid / UP_LPP, r = tid % UP_LPP;
+    const int m = blockIdx.x * (256 / UP_LPP) + g;
+    if (A.centresInLds) {
+        // the walk of every point of the workgroup needs the same nCams x nHist centres: once per workgroup instead of once per
+        // point and step (12 dependent loads each) -- the same arithmetic, so the same doubles
+        for (int q = tid; q < A.nCams * A.nHist; q += 256) {
+            const int c = q / A.nHist, j = q - c * A.nHist, rs = (A.head - j + A.H) % A.H;
+            up_cam_center(A.histR + ((size_t)c * A.H + rs) * 9, A.histT + ((size_t)c * A.H + rs) * 3, up_cen + 3 * (size_t)q);
+        }
+        __syncthreads();
+    }
+    // (every test below is uniform over a point's lanes: whole groups leave together, the shuffles stay inside a group)
+    if (m >= A.nMap) return;
+    if (A.lastFrame && A.lastFrame[m] <= A.firstKeyFrame) return;  // :250, :261
+    const unsigned char fl = A.mapFlags[m];
+    const bool locStatic = (fl & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) == 0;               // isLocalStatic()
+    const bool locDynamic = (fl & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) == CS_MAP_DYNAMIC;  // isLocalDynamic()
+    const bool cur = A.isCurrent ? A.isCurrent[m] != 0 : true;
+    if (!(locStatic || (locDynamic && cur))) return;  // (:266-269: the active list's dynamic points are never reached)
+    const int N = A.N, H = A.H;
+    double M[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) M[q] = A.mapPts[3 * (size_t)m + q];
+    UpNormalEq E;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) E.N[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) E.g[q] = 0;
+    int numView = 0, nDynamic = 0;
+    for (int c = 0; c < A.nCams; ++c) {
+        if (r == 0) second[g][c] = -2;
+        const int s = A.pointFeat[(size_t)m * A.nCams + c];
+        if (s < 0) continue;
+        const cs_poseupdate_cam& C = A.cam[c];
+        const double* hR = A.histR + (size_t)c * H * 9;
+        const double* hT = A.histT + (size_t)c * H * 3;
+        const double* hXY = A.histXY + (size_t)c * H * 2 * N;
+        const double* R0 = hR + (size_t)A.head * 9;
+        const double* t0 = hT + (size_t)A.head * 3;
+        up_add_view(E, C.iK, R0, t0, hXY[(size_t)A.head * 2 * N + s], hXY[(size_t)A.head * 2 * N + N + s]);  // :347-356 / :463-470
+        ++numView;
+        int best = -1;
+        if (locStatic) {
+            double C0[3];
+            up_cam_center(R0, t0, C0);
+            const double a0 = C0[0] - M[0], a1 = C0[1] - M[1], a2 = C0[2] - M[2];
+            const double na = (a0 * a0 + a1 * a1) + a2 * a2;
+            const int f1 = C.trackSpan[s], f2 = C.trackSpan[N + s];
+            const int len = f1 >= 0 ? f2 - f1 + 1 : 0;
+            const int depth = len < A.nHist ? len : A.nHist;
+            double bestCos = 1.0;
+            for (int j = 1 + r; j < depth; j += UP_LPP) {  // :362-373 fp = fp->preFrame
+                double Cj[3];
+                if (A.centresInLds) {
+                    const double* cj = up_cen + 3 * ((size_t)c * A.nHist + j);
+                    Cj[0] = cj[0], Cj[1] = cj[1], Cj[2] = cj[2];
+                } else {
+                    const int rs = (A.head - j + H) % H;
+                    up_cam_center(hR + (size_t)rs * 9, hT + (size_t)rs * 3, Cj);
+                }
+                const double b0 = Cj[0] - M[0], b1 = Cj[1] - M[1], b2 = Cj[2] - M[2];
+                const double d = (a0 * b0 + a1 * b1) + a2 * b2;
+                const double nb = (b0 * b0 + b1 * b1) + b2 * b2;
+                const double cv = d / sqrt(na * nb);
+                if (cv < bestCos) bestCos = cv, best = j;  // (j ascending: the first of equal cosines stays)
+            }
+#pragma unroll
+            for (int off = 1; off < UP_LPP; off <<= 1) {
+                const double oc = __shfl_xor(bestCos, off, 64);
+                const int oj = __shfl_xor(best, off, 64);
+                if (oj >= 0 && (oc < bestCos || (oc == bestCos && (best < 0 || oj < best)))) bestCos = oc, best = oj;
+            }
+            if (best >= 0) {  // :374-383
+                const int rs = (A.head - best + H) % H;
+                up_add_view(E, C.iK, hR + (size_t)rs * 9, hT + (size_t)rs * 3, hXY[(size_t)rs * 2 * N + s], hXY[(size_t)rs * 2 * N + N + s]);
+                ++numView;
+            }
+        } else if (!C.isStatic[s])
+            ++nDynamic;  // :471-472
+        if (r == 0) second[g][c] = best;
+    }
+    if (numView < 2 || (!locStatic && nDynamic < 1)) return;  // :388, :475
+    double cf[6];
+    const double det = up_sym33_cof(E.N, cf);
+    M[0] = ((cf[0] * E.g[0] + cf[1] * E.g[1]) + cf[2] * E.g[2]) / det;  // triangulateMultiView
+    M[1] = ((cf[1] * E.g[0] + cf[3] * E.g[1]) + cf[4] * E.g[2]) / det;
+    M[2] = ((cf[2] * E.g[0] + cf[4] * E.g[1]) + cf[5] * E.g[2]) / det;
+    if (r != 0) return;
+    double S[6] = {0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < A.nCams; ++c) {  // getTriangulateCovMat over the same views
+        const int sv = second[g][c];     // (written by this lane)
+        if (sv == -2) continue;
+        const double* hR = A.histR + (size_t)c * H * 9;
+        const double* hT = A.histT + (size_t)c * H * 3;
+        up_add_cov(S, A.cam[c].K, hR + (size_t)A.head * 9, hT + (size_t)A.head * 3, M);
+        if (sv >= 0) {
+            const int rs = (A.head - sv + H) % H;
+            up_add_cov(S, A.cam[c].K, hR + (size_t)rs * 9, hT + (size_t)rs * 3, M);
+        }
+    }
+    const double dS = up_sym33_cof(S, cf), s2 = A.sigma * A.sigma;
+    double* cov = A.mapCov + 9 * (size_t)m;
+    const double c01 = (cf[1] / dS) * s2, c02 = (cf[2] / dS) * s2, c12 = (cf[4] / dS) * s2;
+    cov[0] = (cf[0] / dS) * s2, cov[1] = c01, cov[2] = c02;
+    cov[3] = c01, cov[4] = (cf[3] / dS) * s2, cov[5] = c12;
+    cov[6] = c02, cov[7] = c12, cov[8] = (cf[5] / dS) * s2;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) A.mapPts[3 * (size_t)m + q] = M[q];
+    if (A.counts) atomicAdd(A.counts + (locStatic ? 0 : 1), 1);
+}
+
+// poses of (camera, frame) pairs into the ring: what RobustBundleRTS::output() writes through the CamPoseItem pointers the features
+// share (src/app/SL_CoSLAMRobustBA.cpp:283-285 key poses, :239-244 relaxed non-key poses)
+__global__ __launch_bounds__(256) void k_history_set_poses(int n, const int* __restrict__ cam, const int* __restrict__ frame,
+                                                           const double* __restrict__ R, const double* __restrict__ t, double* hR,
+                                                           double* hT, int nCams, int H, int head, int count, int lastFrame) {
+    const int q = blockIdx.x * 256 + threadIdx.x, i = q / 12, e = q - 12 * i;
+    if (i >= n) return;
+    const int c = cam[i], back = lastFrame - frame[i];
+    if (c < 0 || c >= nCams || back < 0 || back >= count) return;  // a frame the ring does not hold
+    const int rs = (head - back + H) % H;
+    if (e < 9)
+        hR[((size_t)c * H + rs) * 9 + e] = R[9 * (size_t)i + e];
+    else
+        hT[((size_t)c * H + rs) * 3 + (e - 9)] = t[3 * (size_t)i + (e - 9)];
+}
+
 }  // namespace
 
 struct cs_track_history {
@@ -581,6 +788,59 @@ extern "C" int cs_register_mergability_dev(const cs_track_history* h, void* hip_
     CS_HIP(hipSetDevice(h->device));
     hipLaunchKernelGGL(k_register_mergability, dim3((P * MG_LPC + 255) / 256, h->nCams), dim3(256), sizeof(double) * 12 * (size_t)h->count,
                        (hipStream_t)hip_stream, A);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+extern "C" int cs_track_history_set_poses_dev(cs_track_history* h, void* hip_stream, int n, const int* d_cam, const int* d_frame,
+                                              const double* d_R, const double* d_t) {
+    if (!h || n < 0 || (n > 0 && (!d_cam || !d_frame || !d_R || !d_t))) {
+        cs_set_error("cs_track_history_set_poses_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (n == 0 || h->count < 1) return CS_OK;
+    CS_HIP(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_history_set_poses, dim3((n * 12 + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, n, d_cam, d_frame, d_R, d_t,
+                       h->R, h->t, h->nCams, h->H, h->head, h->count, h->lastFrame);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+extern "C" int cs_update_new_poses_points_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams,
+                                              const int* d_pointFeat, int nMap, const int* d_lastFrame,
+                                              const unsigned char* d_isCurrent, int firstKeyFrame, double* d_mapPts, double* d_mapCov,
+                                              const unsigned char* d_mapFlags, double pixelErrVar, int* d_counts) {
+    if (!h || !cams || nMap < 0 || (nMap > 0 && (!d_pointFeat || !d_mapPts || !d_mapCov || !d_mapFlags))) {
+        cs_set_error("cs_update_new_poses_points_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (h->count < 1) {
+        cs_set_error("cs_update_new_poses_points_dev: the history holds no frame (cs_pose_update_frame_dev / cs_detect_dynamic_dev push one per frame)");
+        return CS_ERR_INVALID;
+    }
+    UpArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = h->nCams, A.N = h->N, A.nMap = nMap, A.H = h->H, A.head = h->head, A.nHist = h->count, A.firstKeyFrame = firstKeyFrame;
+    A.pointFeat = d_pointFeat, A.lastFrame = d_lastFrame, A.isCurrent = d_isCurrent;
+    A.histXY = h->xy, A.histR = h->R, A.histT = h->t;
+    A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.mapFlags = d_mapFlags;
+    A.sigma = pixelErrVar;
+    A.counts = d_counts;
+    for (int c = 0; c < h->nCams; ++c) {
+        if (!cams[c].K || !cams[c].iK || !cams[c].trackSpan || !cams[c].isStatic) {
+            cs_set_error("cs_update_new_poses_points_dev: null pointer in camera %d (K, iK, trackSpan, isStatic are read)", c);
+            return CS_ERR_INVALID;
+        }
+        A.cam[c] = cams[c];
+    }
+    CS_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (d_counts) CS_HIP(hipMemsetAsync(d_counts, 0, 2 * sizeof(int), s));
+    if (nMap == 0) return CS_OK;
+    const size_t cenBytes = sizeof(double) * 3 * (size_t)h->nCams * h->count;
+    const char* noLds = getenv("COSLAM_UPDATE_POINTS_NO_LDS");  // diagnostic / tests: the path deep rings take (read per call)
+    A.centresInLds = cenBytes <= UP_MAX_LDS && !(noLds && noLds[0] == '1');
+    hipLaunchKernelGGL(k_update_points, dim3((nMap * UP_LPP + 255) / 256), dim3(256), A.centresInLds ? cenBytes : 0, s, A);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

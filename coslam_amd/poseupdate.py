@@ -91,3 +91,20 @@ class TrackHistory:
                                                vp(d_mapPts), vp(d_mapCov), vp(d_mapFlags), int(largeErr), C.c_double(pixelErrVar),
                                                int(frame), int(maxLen), int(minLen), int(minOutNum), C.c_double(maxEpiErr),
                                                vp(d_numNodes), vp(d_numOut), vp(d_numDyn)), "cs_pose_update_frame_dev")
+
+    def set_poses_dev(self, stream_ptr, n, d_cam, d_frame, d_R, d_t):
+        """Poses of n (camera, frame) pairs into the ring (RobustBundleRTS::output(): adjusted key poses and relaxed non-key poses,
+        reference src/app/SL_CoSLAMRobustBA.cpp:283-285, 239-244); pairs the ring does not hold are skipped."""
+        vp = C.c_void_p
+        check(self._L.cs_track_history_set_poses_dev(vp(self._h), vp(stream_ptr), int(n), vp(d_cam), vp(d_frame), vp(d_R), vp(d_t)),
+              "cs_track_history_set_poses_dev")
+
+    def update_new_poses_points_dev(self, stream_ptr, cams, d_pointFeat, nMap, d_mapPts, d_mapCov, d_mapFlags, pixelErrVar,
+                                    d_lastFrame=None, d_isCurrent=None, firstKeyFrame=-1, d_counts=None):
+        """RobustBundleRTS::updateNewPosesPoints (reference src/app/SL_CoSLAMRobustBA.cpp:248-271): every map point seen after the
+        window's first key frame is triangulated again from the ring's (adjusted) poses, in place."""
+        vp = C.c_void_p
+        check(self._L.cs_update_new_poses_points_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), vp(d_pointFeat), int(nMap),
+                                                     vp(d_lastFrame), vp(d_isCurrent), int(firstKeyFrame), vp(d_mapPts), vp(d_mapCov),
+                                                     vp(d_mapFlags), C.c_double(pixelErrVar), vp(d_counts)),
+              "cs_update_new_poses_points_dev")

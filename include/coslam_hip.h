@@ -377,6 +377,29 @@ int cs_pose_update_frame_dev(cs_track_history* h, void* hip_stream, const cs_pos
 int cs_register_mergability_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int P, const double* d_M,
                                 const double* d_cov, const int* d_slot, double pixelErrVar, unsigned char* d_mergeable);
 
+/* RobustBundleRTS::updateNewPosesPoints (src/app/SL_CoSLAMRobustBA.cpp:248-271) in one launch: behind a bundle adjustment and the
+ * relaxation of the non-key frames, every map point with lastFrame > firstKeyFrame is triangulated again from the moved poses --
+ * a locally static point (flags without CS_MAP_DYNAMIC / CS_MAP_FALSE) by updateStaticPointPosition (src/slam/SL_CoSLAMHelper.cpp:
+ * 338-394: per camera holding a feature of it, that feature and the one further back on the same track with the largest parallax
+ * angle at the point), a locally dynamic point by updateDynamicPointPosition (:455-484: this frame's features, at least one of
+ * them dynamic, at least two); triangulateMultiView + getTriangulateCovMat (definitions: DESIGN.md 3.9) write d_mapPts [nMap][3]
+ * and d_mapCov [nMap][9] IN PLACE; a point with fewer than two views is left alone.
+ * The tracks' pixels AND the frames' poses come from the history h, newest entry = the frame whose hand-back produced d_pointFeat
+ * ([nMap][nCams] slot of the point's feature, < 0 none).  The reference's features share their frame's CamPoseItem, so the
+ * adjusted poses reach them by themselves; here the ring holds copies: cs_track_history_set_poses_dev scatters n poses (d_R [n][9],
+ * d_t [n][3]) into the entries of (d_cam[i], d_frame[i]) first -- the BA's key poses (output(), :283-285) and the relaxed non-key
+ * poses (updateNonKeyCameraPoses, :239-244; cs_posegraph_relax_dev's newR / newT); pairs the ring does not hold are skipped.
+ * d_lastFrame [nMap] (MapPoint::lastFrame) or NULL = every point passes the frame test; d_isCurrent [nMap] or NULL = all points are
+ * on curMapPts: a point with isCurrent == 0 is on actMapPts, whose dynamic points the reference never updates (:266-269 tests
+ * isLocalStatic() twice) -- such a point must still have its features of THIS frame in d_pointFeat to be touched at all.
+ * cams: K, iK, trackSpan, isStatic (feature types) of every camera.  d_counts [2] or NULL: static / dynamic points re-triangulated. */
+int cs_track_history_set_poses_dev(cs_track_history* h, void* hip_stream, int n, const int* d_cam, const int* d_frame, const double* d_R,
+                                   const double* d_t);
+int cs_update_new_poses_points_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const int* d_pointFeat,
+                                   int nMap, const int* d_lastFrame, const unsigned char* d_isCurrent, int firstKeyFrame,
+                                   double* d_mapPts, double* d_mapCov, const unsigned char* d_mapFlags, double pixelErrVar,
+                                   int* d_counts);
+
 /* ------------------------------------------------------------------------------------------
  * Pose-graph relaxation of the non-key frames after a bundle adjustment, all camera graphs in one launch
  * ------------------------------------------------------------------------------------------
@@ -604,6 +627,14 @@ int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const do
 int cs_ba_solve_async(cs_ba* b, void* after_stream, int C, int P, int nObs, const double* d_Rs0, const double* d_Ts0,
                       const double* d_pts0, int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter);
 int cs_ba_wait(cs_ba* b);
+/* Where the asynchronous solves of this workspace stand; neither call blocks.  cs_ba_pending: queued or running (0 = the last
+ * result and its follow-up are complete on the device).  cs_ba_completed: solves finished since the workspace was created -- a
+ * frame loop that runs ahead of the device always has the next solve queued, so it watches THIS count to learn that a result is
+ * there and enqueues what the reference's BA thread does in output() under the lock it shares with the tracking thread
+ * (src/app/SL_CoSLAM.cpp:1713-1720) on the stream that owns the map: cs_track_history_set_poses_dev,
+ * cs_update_new_poses_points_dev. */
+int cs_ba_pending(cs_ba* b);
+long long cs_ba_completed(cs_ba* b);
 /* The bundle adjuster's inputs built ON THE DEVICE from the tracker's own records: RobustBundleRTS::addKeyFrames / addPoints /
  * parseInputs (src/app/SL_CoSLAMRobustBA.cpp:37-78,109-165) fed by CoSLAM::requestForBA's walk over the last key frames
  * (src/app/SL_CoSLAM.cpp:1731-1784).  A window is a ring of nKeyFrames key frames x nCams cameras: per key frame and camera the

@@ -261,6 +261,38 @@ def detect_dynamic(iK, histR, histT, histXY, state, slot2map, trackSpan, mapFlag
                                        _p(fl), int(maxLen), int(minLen), int(minOutNum), C.c_double(maxEpiErr), _p(isStatic))
 
 
+def update_new_poses_points(Ks, iKs, histR, histT, histXY, trackSpan, featStatic, pointFeat, mapPts, mapCov, mapFlags, sigma,
+                            lastFrame=None, isCurrent=None, firstKeyFrame=-1, cmpAcos=False):
+    """opu_update_new_poses_points (RobustBundleRTS::updateNewPosesPoints): histR (nC x nHist x 9), histT (nC x nHist x 3), histXY
+    (nC x nHist x 2N), entry 0 = this frame; trackSpan (nC x 2N), featStatic (nC x N), pointFeat (nMap x nC); mapPts (nMap x 3) and
+    mapCov (nMap x 9) are updated IN PLACE.  Returns (number re-triangulated, static ones, dynamic ones, chosen second views)."""
+    L = lib()
+    L.opu_update_new_poses_points.restype = C.c_int
+    histR = np.ascontiguousarray(histR, dtype=np.float64)
+    histT = np.ascontiguousarray(histT, dtype=np.float64)
+    histXY = np.ascontiguousarray(histXY, dtype=np.float64)
+    nC, nH = histR.shape[0], histR.shape[1]
+    N = histXY.shape[2] // 2
+    Ks = np.ascontiguousarray(Ks, dtype=np.float64).reshape(nC, 9)
+    iKs = np.ascontiguousarray(iKs, dtype=np.float64).reshape(nC, 9)
+    sp = np.ascontiguousarray(trackSpan, dtype=np.int32).reshape(nC, 2 * N)
+    fs = np.ascontiguousarray(featStatic, dtype=np.uint8).reshape(nC, N)
+    pf = np.ascontiguousarray(pointFeat, dtype=np.int32)
+    nMap = pf.shape[0]
+    assert pf.shape == (nMap, nC) and histT.shape == (nC, nH, 3) and histXY.shape == (nC, nH, 2 * N)
+    assert mapPts.dtype == np.float64 and mapCov.dtype == np.float64 and mapPts.flags.c_contiguous and mapCov.flags.c_contiguous
+    fl = np.ascontiguousarray(mapFlags, dtype=np.uint8)
+    lf = None if lastFrame is None else np.ascontiguousarray(lastFrame, dtype=np.int32)
+    ic = None if isCurrent is None else np.ascontiguousarray(isCurrent, dtype=np.uint8)
+    chosen = np.full((nMap, nC), -1, dtype=np.int32)
+    ns, nd = C.c_int(0), C.c_int(0)
+    n = L.opu_update_new_poses_points(nC, N, nH, _p(Ks), _p(iKs), _p(histR), _p(histT), _p(histXY), _p(sp), _p(fs), nMap, _p(pf),
+                                      _p(lf) if lf is not None else None, _p(ic) if ic is not None else None, int(firstKeyFrame),
+                                      _p(mapPts), _p(mapCov), _p(fl), C.c_double(sigma), int(bool(cmpAcos)), _p(chosen),
+                                      C.byref(ns), C.byref(nd))
+    return n, ns.value, nd.value, chosen
+
+
 def static_check_mergability(K, histR, histT, histXY, slot, length, M, cov, pixelVar):
     """org_static_check_mergability (CoSLAM::staticCheckMergability): histR (nHist x 9), histT (nHist x 3), histXY (nHist x 2N),
     entry 0 = this frame; the track of `slot` covers the `length` newest entries.  Returns True / False."""

@@ -169,6 +169,11 @@ int opu_detect_dynamic_camera(const double iK[9], int N, int H, int nHist, const
                               const double* histXY, const int* state, const int* slot2map, const int* trackSpan, int nMap,
                               const unsigned char* mapFlags, int maxLen, int minLen, int minOutNum, double maxEpiErr,
                               unsigned char* isStatic);
+int opu_update_new_poses_points(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR,
+                                const double* histT, const double* histXY, const int* trackSpan, const unsigned char* featStatic,
+                                int nMap, const int* pointFeat, const int* lastFrame, const unsigned char* isCurrent,
+                                int firstKeyFrame, double* mapPts, double* mapCov, const unsigned char* mapFlags, double sigma,
+                                int cmpAcos, int* chosen, int* nStat, int* nDyn);
 
 /* ---- NCC blocks and the epipolar / NCC matrices of the inter-camera matching restated (ncc_oracle.c) ---- */
 int onc_block_compute(const unsigned char* img, int W, int H, double x, double y, double scale, unsigned char* I, double* abc);

@@ -188,3 +188,176 @@ int opu_detect_dynamic_camera(const double iK[9], int N, int H, int nHist, const
     }
     return k;
 }
+
+/* ---- RobustBundleRTS::updateNewPosesPoints (/root/reference/src/app/SL_CoSLAMRobustBA.cpp:248-271) --------------------------
+ * Behind every bundle adjustment + relaxation of the non-key frames, every map point seen after the window's first key frame
+ * (MapPoint::lastFrame > firstKeyFrame->f) is triangulated again from the moved poses:
+ *   updateStaticPointPosition  (src/slam/SL_CoSLAMHelper.cpp:338-394)   a locally static point: per camera that holds a feature
+ *       of it, TWO views -- that feature (pose of its frame) and the feature of the SAME track, further back, whose camera
+ *       centre subtends the largest angle with the current one at the point (getAbsRadiansBetween(M, C0, C) > maxAngle,
+ *       maxAngle from 0: the first of equal angles in the backward walk wins, an angle of 0 never does) -- then
+ *       triangulateMultiView over all views (normalised image points) and getTriangulateCovMat at the new point;
+ *   updateDynamicPointPosition (:455-484)   a locally dynamic point: this frame's features only, provided at least one of them
+ *       is TYPE_FEATPOINT_DYNAMIC and there are two;
+ *   points of the ACTIVE list are only ever updated as static ones (:266-269 tests isLocalStatic() twice).
+ * With fewer than two views the point is left alone.  The walk is bounded by the history handed in (nHist frames).
+ * PARITY: the loop is pinned against the reference's own SL_CoSLAMHelper.cpp + SL_CoSLAMRobustBA.cpp compiled in place
+ * (tests/cxx/ref_update_points_test.cpp -> tests/golden/update_points_golden.npz).  UNPINNED (un-vendored LibVisualSLAM, only
+ * their calls are in the reference) are the helpers, defined here as
+ *   getCameraCenter(R, t, C)             C = -R^T t
+ *   getAbsRadiansBetween(M, C0, C)       the angle at M between C0 - M and C - M, acos(d / sqrt(|a|^2 |b|^2)); compared through
+ *                                        its COSINE (cmpAcos = 0: what the kernel does -- no libm on either side) or as the
+ *                                        angle itself (cmpAcos = 1: the literal restatement; the two choose the same views
+ *                                        unless two cosines differ by less than acos resolves)
+ *   getInvK / normPoint(iK, m, nm)       nm = the dehomogenised iK (m, 1); iK is an input here
+ *   triangulateMultiView(n, Rs, ts, nms, M)   linear least squares of the 2n equations (r1 - x r3) M = x t3 - t1,
+ *                                        (r2 - y r3) M = y t3 - t2 through the normal equations, 3x3 symmetric inverse by cofactors
+ *   getTriangulateCovMat(n, Ks, Rs, ts, M, cov, sigma)   cov = sigma^2 (sum_i J_i^T J_i)^-1, J_i = d project_i / dM at M */
+static void cam_center(const double* R, const double* t, double* C) {
+    for (int i = 0; i < 3; i++) C[i] = -((R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2]);
+}
+static double cos_between(const double* M, const double* C0, const double* C) {
+    const double a[3] = {C0[0] - M[0], C0[1] - M[1], C0[2] - M[2]}, b[3] = {C[0] - M[0], C[1] - M[1], C[2] - M[2]};
+    const double d = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+    const double na = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2], nb = (b[0] * b[0] + b[1] * b[1]) + b[2] * b[2];
+    return d / sqrt(na * nb);
+}
+/* symmetric 3x3: N = {n00, n01, n02, n11, n12, n22}; returns the cofactors c (same order) and the determinant */
+static double sym33_cof(const double* N, double* c) {
+    c[0] = N[3] * N[5] - N[4] * N[4];
+    c[1] = N[2] * N[4] - N[1] * N[5];
+    c[2] = N[1] * N[4] - N[2] * N[3];
+    c[3] = N[0] * N[5] - N[2] * N[2];
+    c[4] = N[1] * N[2] - N[0] * N[4];
+    c[5] = N[0] * N[3] - N[1] * N[1];
+    return (N[0] * c[0] + N[1] * c[1]) + N[2] * c[2];
+}
+typedef struct {
+    double N[6], g[3];
+} opu_normal_eq;
+static void ne_add_view(opu_normal_eq* E, const double* iK, const double* R, const double* t, double mx, double my) {
+    const double w = (iK[6] * mx + iK[7] * my) + iK[8];
+    const double x = ((iK[0] * mx + iK[1] * my) + iK[2]) / w, y = ((iK[3] * mx + iK[4] * my) + iK[5]) / w; /* normPoint */
+    const double a0[3] = {R[0] - x * R[6], R[1] - x * R[7], R[2] - x * R[8]}, a1[3] = {R[3] - y * R[6], R[4] - y * R[7], R[5] - y * R[8]};
+    const double b0 = x * t[2] - t[0], b1 = y * t[2] - t[1];
+    static const int I[6] = {0, 0, 0, 1, 1, 2}, J[6] = {0, 1, 2, 1, 2, 2};
+    for (int q = 0; q < 6; q++) E->N[q] = E->N[q] + (a0[I[q]] * a0[J[q]] + a1[I[q]] * a1[J[q]]);
+    for (int q = 0; q < 3; q++) E->g[q] = E->g[q] + (a0[q] * b0 + a1[q] * b1);
+}
+static void cov_add_view(double* S, const double* K, const double* R, const double* t, const double* M) {
+    const double X = ((R[0] * M[0] + R[1] * M[1]) + R[2] * M[2]) + t[0];
+    const double Y = ((R[3] * M[0] + R[4] * M[1]) + R[5] * M[2]) + t[1];
+    const double Z = ((R[6] * M[0] + R[7] * M[1]) + R[8] * M[2]) + t[2];
+    double KR[9], Jm[6];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) KR[3 * i + j] = (K[3 * i] * R[j] + K[3 * i + 1] * R[3 + j]) + K[3 * i + 2] * R[6 + j];
+    const double u = (K[0] * X + K[1] * Y) + K[2] * Z, v = (K[3] * X + K[4] * Y) + K[5] * Z, w = (K[6] * X + K[7] * Y) + K[8] * Z;
+    const double ww = w * w;
+    for (int j = 0; j < 3; j++) {
+        Jm[j] = (KR[j] * w - u * KR[6 + j]) / ww;
+        Jm[3 + j] = (KR[3 + j] * w - v * KR[6 + j]) / ww;
+    }
+    static const int I[6] = {0, 0, 0, 1, 1, 2}, J[6] = {0, 1, 2, 1, 2, 2};
+    for (int q = 0; q < 6; q++) S[q] = S[q] + (Jm[I[q]] * Jm[J[q]] + Jm[3 + I[q]] * Jm[3 + J[q]]);
+}
+
+/* Layouts: Ks / iKs [nCams][9]; histR [nCams][nHist][9], histT [nCams][nHist][3], histXY [nCams][nHist][2N] with entry 0 = this
+ * frame (the poses as they stand AFTER the adjustment); trackSpan [nCams][2N] (first | last frame of the slot's track),
+ * featStatic [nCams][N] (1 = TYPE_FEATPOINT_STATIC); pointFeat [nMap][nCams] = the slot of the point's feature of this frame in
+ * that camera, < 0 none; lastFrame [nMap] or NULL (= every point passes :250); isCurrent [nMap] or NULL (= all on curMapPts).
+ * chosen (or NULL): [nMap][nCams] the history entry taken as the second view (-1 none), for the tests.
+ * Returns the number of points re-triangulated; *nStat / *nDyn count them by kind. */
+int opu_update_new_poses_points(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR,
+                                const double* histT, const double* histXY, const int* trackSpan, const unsigned char* featStatic,
+                                int nMap, const int* pointFeat, const int* lastFrame, const unsigned char* isCurrent,
+                                int firstKeyFrame, double* mapPts, double* mapCov, const unsigned char* mapFlags, double sigma,
+                                int cmpAcos, int* chosen, int* nStat, int* nDyn) {
+    int nUpd = 0, ns = 0, nd = 0;
+    for (int m = 0; m < nMap; m++) {
+        if (chosen)
+            for (int c = 0; c < nCams; c++) chosen[(size_t)m * nCams + c] = -1;
+        if (lastFrame && lastFrame[m] <= firstKeyFrame) continue; /* :250, :261 */
+        const unsigned char fl = mapFlags[m];
+        const int locStatic = (fl & (OPU_DYNAMIC | OPU_FALSE)) == 0, locDynamic = (fl & (OPU_DYNAMIC | OPU_FALSE)) == OPU_DYNAMIC;
+        const int cur = isCurrent ? isCurrent[m] != 0 : 1;
+        double* M = mapPts + 3 * (size_t)m;
+        opu_normal_eq E;
+        memset(&E, 0, sizeof(E));
+        int numView = 0, second[64];
+        if (locStatic) { /* updateStaticPointPosition */
+            for (int c = 0; c < nCams; c++) {
+                second[c] = -2;
+                const int s = pointFeat[(size_t)m * nCams + c];
+                if (s < 0) continue;
+                const double* hR = histR + (size_t)c * nHist * 9;
+                const double* hT = histT + (size_t)c * nHist * 3;
+                const double* hXY = histXY + (size_t)c * nHist * 2 * N;
+                const double* iK = iKs + 9 * c;
+                ne_add_view(&E, iK, hR, hT, hXY[s], hXY[N + s]); /* :347-356 */
+                numView++;
+                double C0[3];
+                cam_center(hR, hT, C0);
+                const int f1 = trackSpan[(size_t)c * 2 * N + s], f2 = trackSpan[(size_t)c * 2 * N + N + s];
+                const int len = f1 >= 0 ? f2 - f1 + 1 : 0;
+                const int depth = len < nHist ? len : nHist;
+                int best = -1;
+                double bestCos = 1.0, bestAngle = 0.0;
+                for (int j = 1; j < depth; j++) { /* :362-373 fp = fp->preFrame */
+                    double Cj[3];
+                    cam_center(hR + 9 * (size_t)j, hT + 3 * (size_t)j, Cj);
+                    const double cv = cos_between(M, C0, Cj);
+                    if (cmpAcos) {
+                        const double ang = fabs(acos(cv));
+                        if (ang > bestAngle) bestAngle = ang, best = j;
+                    } else if (cv < bestCos)
+                        bestCos = cv, best = j;
+                }
+                second[c] = best;
+                if (chosen) chosen[(size_t)m * nCams + c] = best;
+                if (best >= 0) { /* :374-383 */
+                    ne_add_view(&E, iK, hR + 9 * (size_t)best, hT + 3 * (size_t)best, hXY[(size_t)best * 2 * N + s],
+                                hXY[(size_t)best * 2 * N + N + s]);
+                    numView++;
+                }
+            }
+        } else if (locDynamic && cur) { /* updateDynamicPointPosition; :266-269 never reaches it for the active list */
+            int nDynamic = 0;
+            for (int c = 0; c < nCams; c++) {
+                second[c] = -2;
+                const int s = pointFeat[(size_t)m * nCams + c];
+                if (s < 0) continue;
+                second[c] = -1;
+                ne_add_view(&E, iKs + 9 * c, histR + (size_t)c * nHist * 9, histT + (size_t)c * nHist * 3,
+                            histXY[(size_t)c * nHist * 2 * N + s], histXY[(size_t)c * nHist * 2 * N + N + s]);
+                numView++;
+                if (!featStatic[(size_t)c * N + s]) nDynamic++;
+            }
+            if (nDynamic < 1) continue; /* :475 */
+        } else
+            continue;
+        if (numView < 2) continue; /* :388, :475 */
+        double cf[6];
+        const double det = sym33_cof(E.N, cf);
+        M[0] = ((cf[0] * E.g[0] + cf[1] * E.g[1]) + cf[2] * E.g[2]) / det;
+        M[1] = ((cf[1] * E.g[0] + cf[3] * E.g[1]) + cf[4] * E.g[2]) / det;
+        M[2] = ((cf[2] * E.g[0] + cf[4] * E.g[1]) + cf[5] * E.g[2]) / det;
+        double S[6] = {0, 0, 0, 0, 0, 0};
+        for (int c = 0; c < nCams; c++) {
+            if (second[c] == -2) continue;
+            const double* hR = histR + (size_t)c * nHist * 9;
+            const double* hT = histT + (size_t)c * nHist * 3;
+            cov_add_view(S, Ks + 9 * c, hR, hT, M);
+            if (second[c] >= 0) cov_add_view(S, Ks + 9 * c, hR + 9 * (size_t)second[c], hT + 3 * (size_t)second[c], M);
+        }
+        const double dS = sym33_cof(S, cf), s2 = sigma * sigma;
+        double* cov = mapCov + 9 * (size_t)m;
+        cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
+        cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
+        cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
+        nUpd++;
+        if (locStatic) ns++; else nd++;
+    }
+    if (nStat) *nStat = ns;
+    if (nDyn) *nDyn = nd;
+    return nUpd;
+}

@@ -6,18 +6,29 @@
 #ifndef REF_SHIM_NOT_ON_PATH_H
 #define REF_SHIM_NOT_ON_PATH_H
 template <class... A> void scaleDownAvg(const A&...);
-template <class... A> void normPoint(const A&...);
 template <class... A> bool isAtCameraBack(const A&...);
-template <class... A> void getCameraCenter(const A&...);
-template <class... A> void triangulateMultiView(const A&...);
 template <class... A> int searchNearestPoint(const A&...);
 template <class... A> double reprojErrorSingle(const A&...);
 template <class... A> bool intraCamEstimateEpi(const A&...);
-template <class... A> void getTriangulateCovMat(const A&...);
-template <class... A> void getInvK(const A&...);
 template <class... A> double getCameraDistance(const A&...);
 template <class... A> void getBinTriangulateCovMat(const A&...);
+#ifdef REF_SHIM_TRIANGULATE_ON_PATH
+/* src/slam/SL_CoSLAMHelper.cpp compiled in place for updateStaticPointPosition / updateDynamicPointPosition (:338-394, :455-484):
+ * there these helpers ARE on the path -- real prototypes, OUR definitions in ref_triangulate_impl.cpp (un-vendored LibVisualSLAM) */
+void normPoint(const double* iK, const double* m, double* nm);
+void getCameraCenter(const double* R, const double* t, double* C);
+void triangulateMultiView(int nView, const double* Rs, const double* ts, const double* nms, double* M);
+void getTriangulateCovMat(int nView, const double* Ks, const double* Rs, const double* ts, const double* M, double* cov, double sigma);
+void getInvK(const double* K, double* iK);
+double getAbsRadiansBetween(const double* M, const double* C0, const double* C);
+#else
+template <class... A> void normPoint(const A&...);
+template <class... A> void getCameraCenter(const A&...);
+template <class... A> void triangulateMultiView(const A&...);
+template <class... A> void getTriangulateCovMat(const A&...);
+template <class... A> void getInvK(const A&...);
 template <class... A> double getAbsRadiansBetween(const A&...);
+#endif
 template <class... A> double dist3(const A&...);
 template <class... A> void binTriangulate(const A&...);
 #define CV_8UC1 0

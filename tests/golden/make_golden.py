@@ -263,10 +263,85 @@ def mergability_case():
                 verdict=np.array(verdict, np.int32))
 
 
+def update_points_case():
+    """the reference's own RobustBundleRTS::updateNewPosesPoints over updateStaticPointPosition / updateDynamicPointPosition
+    (oracle/_ref/ref_update_points_test golden, CPU): 6 scenes of 60 map points, re-laid out the way the device holds them (slot =
+    point index, ring entry 0 = the current frame), and the reference's points / covariances afterwards."""
+    import struct
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_update_points_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_update_points_test missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "u.bin")
+        subprocess.run([exe, "golden", path], check=True, stdout=subprocess.DEVNULL)
+        raw = open(path, "rb").read()
+    o = 0
+
+    def ints(n):
+        nonlocal o
+        v = np.frombuffer(raw, dtype=np.int32, count=n, offset=o).copy()
+        o += 4 * n
+        return v
+
+    def dbls(n):
+        nonlocal o
+        v = np.frombuffer(raw, dtype=np.float64, count=n, offset=o).copy()
+        o += 8 * n
+        return v
+
+    out = {}
+    (nS,) = ints(1)
+    out["n_scenes"] = np.int32(nS)
+    for sc in range(nS):
+        nC, H, nP, firstKey, cur = ints(5)
+        (sigma,) = dbls(1)
+        K, iK = np.zeros((nC, 9)), np.zeros((nC, 9))
+        for c in range(nC):
+            K[c], iK[c] = dbls(9), dbls(9)
+        hR, hT = np.zeros((nC, H, 9)), np.zeros((nC, H, 3))
+        for c in range(nC):
+            for j in range(H):
+                hR[c, j], hT[c, j] = dbls(9), dbls(3)
+        N = nP
+        hXY = np.zeros((nC, H, 2 * N))
+        span = np.full((nC, 2 * N), -1, np.int32)
+        fstat = np.ones((nC, N), np.uint8)
+        pf = np.full((nP, nC), -1, np.int32)
+        M0, cov0 = np.zeros((nP, 3)), np.zeros((nP, 9))
+        flags, lastF, isCur = np.zeros(nP, np.uint8), np.zeros(nP, np.int32), np.zeros(nP, np.uint8)
+        for p in range(nP):
+            M0[p], cov0[p] = dbls(3), dbls(9)
+            ltype, unc, lastF[p], isCur[p] = ints(4)
+            flags[p] = (1 if ltype == 1 else 0) | (2 if ltype == -2 else 0) | (4 if unc else 0)
+            for c in range(nC):
+                L, dyn = ints(2)
+                m = dbls(2 * L).reshape(L, 2)
+                if L:
+                    pf[p, c] = p
+                    span[c, p], span[c, N + p] = cur - L + 1, cur
+                    fstat[c, p] = 0 if dyn else 1
+                    hXY[c, :L, p], hXY[c, :L, N + p] = m[:, 0], m[:, 1]
+        Mr, covr = dbls(3 * nP).reshape(nP, 3), np.zeros((nP, 9))
+        # (the driver writes M, cov per point interleaved)
+        o -= 8 * 3 * nP
+        for p in range(nP):
+            Mr[p], covr[p] = dbls(3), dbls(9)
+        pre = f"s{sc}_"
+        for k, v in dict(K=K, iK=iK, histR=hR, histT=hT, histXY=hXY, trackSpan=span, featStatic=fstat, pointFeat=pf, M0=M0, cov0=cov0,
+                         flags=flags, lastFrame=lastF, isCurrent=isCur, firstKey=np.int32(firstKey), curFrame=np.int32(cur),
+                         sigma=np.float64(sigma), M_ref=Mr, cov_ref=covr).items():
+            out[pre + k] = v
+    assert o == len(raw)
+    return out
+
+
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "update_points"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -283,4 +358,6 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "export_golden.npz"), **export_case())
     if "mergability" in which:
         np.savez_compressed(os.path.join(HERE, "mergability_golden.npz"), **mergability_case())
+    if "update_points" in which:
+        np.savez_compressed(os.path.join(HERE, "update_points_golden.npz"), **update_points_case())
     print("golden fixtures written")

@@ -151,6 +151,14 @@ def test_bad_arguments_are_refused():
         TrackHistory(3, 100, 100000)
     with pytest.raises(CoslamHipError):
         pose_update3d_dev(0, [dict()], 10, 0, 5, 0, 0, 0, 0, 0, 0, SIGMA)
+    th = TrackHistory(2, 16, 4)
+    with pytest.raises(CoslamHipError):   # null map pointers
+        th.update_new_poses_points_dev(0, [dict(), dict()], 0, 5, 0, 0, 0, SIGMA)
+    with pytest.raises(CoslamHipError):   # a history without a frame
+        th.update_new_poses_points_dev(0, [dict(), dict()], 0, 0, 0, 0, 0, SIGMA)
+    with pytest.raises(CoslamHipError):
+        th.set_poses_dev(0, 3, 0, 0, 0, 0)
+    th.close()
 
 
 def test_register_mergability_walks_the_candidates_tracks_like_the_oracle():
@@ -223,4 +231,173 @@ def test_register_mergability_walks_the_candidates_tracks_like_the_oracle():
         assert np.array_equal(got, want), sigma
         n_true[sigma] = (int((want == 1).sum()), int((want == 0).sum()))
     assert n_true[1.2][0] > 50 and n_true[1.2][1] > 200 and n_true[10.0][0] > n_true[1.2][0]   # both verdicts occur, the gate matters
+    th.close()
+
+
+@pytest.mark.parametrize("centres", ["lds", "global"])
+def test_update_new_poses_points_reproduces_the_reference_on_its_golden_scenes(centres, monkeypatch):
+    """cs_update_new_poses_points_dev against tests/golden/update_points_golden.npz -- what the reference's own
+    RobustBundleRTS::updateNewPosesPoints + updateStaticPointPosition / updateDynamicPointPosition (src/app/SL_CoSLAMRobustBA.cpp:
+    248-271, src/slam/SL_CoSLAMHelper.cpp:338-394, 455-484, compiled in place) made of six scenes: every point and covariance bit for
+    bit (the un-vendored triangulation helpers are our definitions on both sides; the loops are the reference's).  The ring is
+    filled frame by frame with placeholder poses and then given the scene's poses through cs_track_history_set_poses_dev, the way
+    the adjusted poses arrive after a bundle adjustment."""
+    import os
+
+    import torch
+
+    from coslam_amd.poseupdate import TrackHistory
+
+    # the camera centres of all (camera, ring entry) pairs once per workgroup in LDS, or -- rings too deep for that -- per step
+    monkeypatch.setenv("COSLAM_UPDATE_POINTS_NO_LDS", "1" if centres == "global" else "0")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "update_points_golden.npz"))
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    touched = 0
+    for sc in range(int(g["n_scenes"])):
+        G = lambda k: g[f"s{sc}_{k}"]   # noqa: E731
+        hR, hT, hXY, span = G("histR"), G("histT"), G("histXY"), G("trackSpan")
+        nC, H = hR.shape[0], hR.shape[1]
+        N = hXY.shape[2] // 2
+        cur, nMap = int(G("curFrame")), G("M0").shape[0]
+        th = TrackHistory(nC, N, H + 3)   # (a ring deeper than the history: the unused entries are never walked)
+        d_K = torch.from_numpy(G("K").copy()).to(dev)
+        d_iK = torch.from_numpy(G("iK").copy()).to(dev)
+        d_fl = torch.from_numpy(G("flags").copy()).to(dev)
+        d_span = torch.from_numpy(span.copy()).to(dev)
+        d_fstat = torch.from_numpy(G("featStatic").copy()).to(dev)
+        d_scratch = torch.ones((nC, N), dtype=torch.uint8, device=dev)
+        d_s2m = torch.full((nC, N), -1, dtype=torch.int32, device=dev)
+        eye = torch.from_numpy(np.tile(np.eye(3).reshape(9), (nC, 1))).to(dev)
+        zero = torch.zeros((nC, 3), dtype=torch.float64, device=dev)
+        keep = []
+        for j in range(H - 1, -1, -1):   # oldest first; entry j = frame cur - j
+            xy = torch.from_numpy(hXY[:, j].copy()).to(dev)
+            alive = ((span[:, :N] >= 0) & (span[:, :N] <= cur - j)).astype(np.int32) - 1   # 0 tracked / -1 dead at that frame
+            st = torch.from_numpy(alive).to(dev)
+            keep += [xy, st]
+            cams = [dict(K=d_K[c].data_ptr(), iK=d_iK[c].data_ptr(), xy=xy[c].data_ptr(), state=st[c].data_ptr(),
+                         slot2map=d_s2m[c].data_ptr(), trackSpan=d_span[c].data_ptr(), isStatic=d_scratch[c].data_ptr()) for c in range(nC)]
+            th.detect_dynamic_dev(s, cams, eye.data_ptr(), zero.data_ptr(), nMap, d_fl.data_ptr(), cur - j, minLen=1 << 30)
+        assert th.frames == H
+        # the poses: every (camera, frame) of the history plus pairs the ring does not hold (skipped)
+        cam_i = np.repeat(np.arange(nC), H).astype(np.int32)
+        frm_i = np.tile(cur - np.arange(H), nC).astype(np.int32)
+        cam_i = np.concatenate([cam_i, [0, 1, nC, -1]]).astype(np.int32)
+        frm_i = np.concatenate([frm_i, [cur - H, cur + 1, cur, cur]]).astype(np.int32)
+        Rq = np.concatenate([hR.reshape(-1, 9), np.full((4, 9), 777.0)])
+        tq = np.concatenate([hT.reshape(-1, 3), np.full((4, 3), 777.0)])
+        d_ci, d_fi = torch.from_numpy(cam_i).to(dev), torch.from_numpy(frm_i).to(dev)
+        d_Rq, d_tq = torch.from_numpy(Rq).to(dev), torch.from_numpy(tq).to(dev)
+        th.set_poses_dev(s, len(cam_i), d_ci.data_ptr(), d_fi.data_ptr(), d_Rq.data_ptr(), d_tq.data_ptr())
+        d_M = torch.from_numpy(G("M0").copy()).to(dev)
+        d_cov = torch.from_numpy(G("cov0").copy()).to(dev)
+        d_pf = torch.from_numpy(G("pointFeat").copy()).to(dev)
+        d_lf = torch.from_numpy(G("lastFrame").copy()).to(dev)
+        d_ic = torch.from_numpy(G("isCurrent").copy()).to(dev)
+        d_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+        cams = [dict(K=d_K[c].data_ptr(), iK=d_iK[c].data_ptr(), trackSpan=d_span[c].data_ptr(), isStatic=d_fstat[c].data_ptr())
+                for c in range(nC)]
+        th.update_new_poses_points_dev(s, cams, d_pf.data_ptr(), nMap, d_M.data_ptr(), d_cov.data_ptr(), d_fl.data_ptr(),
+                                       float(G("sigma")), d_lastFrame=d_lf.data_ptr(), d_isCurrent=d_ic.data_ptr(),
+                                       firstKeyFrame=int(G("firstKey")), d_counts=d_cnt.data_ptr())
+        torch.cuda.synchronize()
+        M, cov = d_M.cpu().numpy(), d_cov.cpu().numpy()
+        n_ref = int((G("M_ref") != G("M0")).any(axis=1).sum())
+        assert int(d_cnt.sum()) == n_ref, f"scene {sc}: {d_cnt.tolist()} points re-triangulated, the reference touched {n_ref}"
+        dM, dC = np.abs(M - G("M_ref")).max(), np.abs(cov - G("cov_ref")).max()
+        assert np.array_equal(M, G("M_ref")) and np.array_equal(cov, G("cov_ref")), f"scene {sc}: max |dM| {dM:.3e}, max |dcov| {dC:.3e}"
+        touched += n_ref
+        th.close()
+    assert touched > 150
+
+
+def test_update_new_poses_points_after_a_tracked_sequence_matches_the_oracle():
+    """The same launch at the end of a tracked multi-camera sequence (512 slots x 3 cameras, 600 map points, ring shorter than the
+    longest tracks), after the poses of the last frames were replaced the way a bundle adjustment + relaxation replaces them:
+    against the oracle on the same arrays, bit for bit, with the feature types the dynamic test left behind."""
+    import torch
+
+    import oracle
+    from coslam_amd.poseupdate import TrackHistory
+
+    sc = Scene(T=12, seed=23)
+    nC, N, nMap, H = sc.nC, sc.N, sc.nMap, 8
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    th = TrackHistory(nC, N, H)
+    d_K = torch.from_numpy(sc.K.reshape(9).copy()).to(dev)
+    d_iK = torch.from_numpy(sc.iK.reshape(9).copy()).to(dev)
+    d_fl = torch.from_numpy(sc.flags0.copy()).to(dev)
+    d_stat = [torch.ones(N, dtype=torch.uint8, device=dev) for _ in range(nC)]
+    o_stat = [np.ones(N, dtype=np.uint8) for _ in range(nC)]
+    hist = [dict(R=[], t=[], xy=[]) for _ in range(nC)]
+    keep = []
+    for f in range(sc.T):
+        recs = sc.frame(f)
+        Rs = np.stack([sc.Re[f][c].reshape(9) for c in range(nC)])
+        ts = np.stack([sc.te[f][c] for c in range(nC)])
+        cams = []
+        for c, r in enumerate(recs):
+            t_ = {k: torch.from_numpy(v).to(dev) for k, v in r.items()}
+            keep.append(t_)
+            cams.append(dict(K=d_K.data_ptr(), iK=d_iK.data_ptr(), xy=t_["xy"].data_ptr(), state=t_["state"].data_ptr(),
+                             slot2map=t_["slot2map"].data_ptr(), trackSpan=t_["trackSpan"].data_ptr(), isStatic=d_stat[c].data_ptr()))
+            h = hist[c]
+            h["R"].insert(0, Rs[c]), h["t"].insert(0, ts[c]), h["xy"].insert(0, r["xy"].copy())
+            del h["R"][H:], h["t"][H:], h["xy"][H:]
+            oracle.detect_dynamic(sc.iK, np.stack(h["R"]), np.stack(h["t"]), np.stack(h["xy"]), r["state"], r["slot2map"], r["trackSpan"],
+                                  sc.flags0, 20, 5, 3, MAX_EPI, o_stat[c])
+        d_R, d_t = torch.from_numpy(Rs).to(dev), torch.from_numpy(ts).to(dev)
+        th.detect_dynamic_dev(s, cams, d_R.data_ptr(), d_t.data_ptr(), nMap, d_fl.data_ptr(), f, maxEpiErr=MAX_EPI)
+        torch.cuda.synchronize()
+    for c in range(nC):
+        assert np.array_equal(d_stat[c].cpu().numpy(), o_stat[c])
+    # "the adjustment": new poses for the last 6 frames of every camera
+    rng = np.random.default_rng(9)
+    last = sc.T - 1
+    ci, fi, Rn, tn = [], [], [], []
+    from tests.poseupdate_scene import rodrigues
+    for c in range(nC):
+        for j in range(6):
+            R = rodrigues(rng.normal(0, 3e-4, 3)) @ hist[c]["R"][j].reshape(3, 3)
+            t = hist[c]["t"][j] + rng.normal(0, 2e-3, 3)
+            hist[c]["R"][j], hist[c]["t"][j] = R.reshape(9).copy(), t.copy()
+            ci.append(c), fi.append(last - j), Rn.append(R.reshape(9)), tn.append(t)
+    d_ci, d_fi = torch.from_numpy(np.array(ci, np.int32)).to(dev), torch.from_numpy(np.array(fi, np.int32)).to(dev)
+    d_Rn, d_tn = torch.from_numpy(np.array(Rn)).to(dev), torch.from_numpy(np.array(tn)).to(dev)
+    th.set_poses_dev(s, len(ci), d_ci.data_ptr(), d_fi.data_ptr(), d_Rn.data_ptr(), d_tn.data_ptr())
+    pf = Scene.point_feat(recs, nMap)
+    lastFrame = np.where(rng.random(nMap) < 0.1, last - 9, last).astype(np.int32)
+    isCur = (rng.random(nMap) < 0.8).astype(np.uint8)
+    first_key = last - 8
+    o_M, o_cov = sc.map0.copy(), sc.cov0.copy()
+    span = np.stack([r["trackSpan"] for r in recs])
+    n, ns, nd, chosen = oracle.update_new_poses_points([sc.K] * nC, [sc.iK] * nC, np.stack([np.stack(h["R"]) for h in hist]),
+                                                       np.stack([np.stack(h["t"]) for h in hist]), np.stack([np.stack(h["xy"]) for h in hist]),
+                                                       span, np.stack(o_stat), pf, o_M, o_cov, sc.flags0, SIGMA, lastFrame=lastFrame,
+                                                       isCurrent=isCur, firstKeyFrame=first_key)
+    assert ns > 150 and nd > 5 and (chosen >= 1).sum() > 150 and chosen.max() == H - 1
+    d_M, d_cov = torch.from_numpy(sc.map0.copy()).to(dev), torch.from_numpy(sc.cov0.copy()).to(dev)
+    d_pf, d_lf, d_ic = torch.from_numpy(pf).to(dev), torch.from_numpy(lastFrame).to(dev), torch.from_numpy(isCur).to(dev)
+    d_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    th.update_new_poses_points_dev(s, cams, d_pf.data_ptr(), nMap, d_M.data_ptr(), d_cov.data_ptr(), d_fl.data_ptr(), SIGMA,
+                                   d_lastFrame=d_lf.data_ptr(), d_isCurrent=d_ic.data_ptr(), firstKeyFrame=first_key,
+                                   d_counts=d_cnt.data_ptr())
+    torch.cuda.synchronize()
+    assert d_cnt.tolist() == [ns, nd]
+    M, cov = d_M.cpu().numpy(), d_cov.cpu().numpy()
+    dM, dC = np.abs(M - o_M).max(), np.abs(cov - o_cov).max()
+    assert np.array_equal(M, o_M) and np.array_equal(cov, o_cov), f"max |dM| {dM:.3e}, max |dcov| {dC:.3e}"
+    # NULL lastFrame / isCurrent: every point passes the frame test and counts as current
+    o_M2, o_cov2 = sc.map0.copy(), sc.cov0.copy()
+    n2, ns2, nd2, _ = oracle.update_new_poses_points([sc.K] * nC, [sc.iK] * nC, np.stack([np.stack(h["R"]) for h in hist]),
+                                                     np.stack([np.stack(h["t"]) for h in hist]), np.stack([np.stack(h["xy"]) for h in hist]),
+                                                     span, np.stack(o_stat), pf, o_M2, o_cov2, sc.flags0, SIGMA)
+    d_M2, d_cov2 = torch.from_numpy(sc.map0.copy()).to(dev), torch.from_numpy(sc.cov0.copy()).to(dev)
+    th.update_new_poses_points_dev(s, cams, d_pf.data_ptr(), nMap, d_M2.data_ptr(), d_cov2.data_ptr(), d_fl.data_ptr(), SIGMA,
+                                   d_counts=d_cnt.data_ptr())
+    torch.cuda.synchronize()
+    assert d_cnt.tolist() == [ns2, nd2] and ns2 >= ns and nd2 >= nd
+    assert np.array_equal(d_M2.cpu().numpy(), o_M2) and np.array_equal(d_cov2.cpu().numpy(), o_cov2)
     th.close()

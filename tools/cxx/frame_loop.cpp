@@ -211,6 +211,11 @@ int main(int argc, char** argv) {
     double* dReproj = dev_zeros<double>((size_t)nCams * N);
     unsigned char* dMapFlags = dev_zeros<unsigned char>(nMap);
     unsigned char* dMergeable = dev_zeros<unsigned char>((size_t)P_REG * nCams);
+    // RobustBundleRTS::updateNewPosesPoints behind every finished joint BA, on a copy of the map (see bench.py: the video repeats)
+    double* dMapUpd = dev_zeros<double>((size_t)nMap * 3);
+    double* dCovUpd = dev_zeros<double>((size_t)nMap * 9);
+    long long baApplied = 0;
+    int baRequested = 0, updRuns = 0, updFirstKey = 0;
     cs_track_history* hist = cs_track_history_create(dev, nCams, N, 64);
     if (!hist) {
         fprintf(stderr, "cs_track_history_create: %s\n", cs_last_error());
@@ -352,6 +357,14 @@ int main(int argc, char** argv) {
         // parallelPoseUpdate(false): the gate + seqTriangulate loop of poseUpdate3D, detectDynamicFeaturePoints(20, 5, 3, MAX_EPI_ERR)
         CSCHK(cs_pose_update_frame_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dR[dsti], dT[dsti], dMap, dCov, dMapFlags, 0, PIX, i, 20, 5,
                                        3, 6.0, nullptr, nullptr, nullptr));
+        // output() of a finished joint BA (cs_ba_completed read between frames: the host runs ahead of the device): updateNewPosesPoints, one launch
+        if (win && cs_ba_completed(joint.ws) != baApplied) {
+            baApplied = cs_ba_completed(joint.ws), ++updRuns;
+            HIPCHK(hipMemcpyAsync(dMapUpd, dMap, sizeof(double) * 3 * (size_t)nMap, hipMemcpyDeviceToDevice, poseS));
+            HIPCHK(hipMemcpyAsync(dCovUpd, dCov, sizeof(double) * 9 * (size_t)nMap, hipMemcpyDeviceToDevice, poseS));
+            CSCHK(cs_update_new_poses_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, nullptr, nullptr, updFirstKey, dMapUpd, dCovUpd,
+                                                 dMapFlags, PIX, nullptr));
+        }
         // activeMapPointsRegister, then currentMapPointsRegister (static points), search step
         {
             cs_register_pass ps[2];
@@ -372,6 +385,7 @@ int main(int argc, char** argv) {
             if (win) {  // requestForBA(5, 2, 2, 30): the numCams * 2 oldest key cameras and 2 points held, maxIter 2, inner 10
                 CSCHK(cs_ba_window_push_dev(win, (void*)poseS, hb[b].data(), dK, 1, dR[dsti], dT[dsti], i));
                 CSCHK(cs_ba_solve_window_async(joint.ws, win, (void*)poseS, dMap, nullptr, 2 * nCams, 2, 6.0, 2, 10));
+                ++baRequested, updFirstKey = i - 4 * keyEvery;
             } else {
                 joint.solve_async(poseS);
             }
@@ -490,8 +504,8 @@ int main(int argc, char** argv) {
     printf("{\"frames_per_s\": %.3f, \"ms_per_step\": %.5f, \"steps\": %d, \"warmup\": %d, \"host_enqueue_ms_per_step\": %.5f, "
            "\"cams_per_tracker_launch\": %d, \"pose_ok\": %s, \"min_live_features\": %d, \"joint_lm_steps\": %d, \"joint_cost\": %.6f, "
            "\"intercam_lm_steps\": %d, \"intercam_cost\": %.6f, \"ncc_runs\": %d, \"joint_ba_from_window\": %s, \"joint_cameras\": %d, "
-           "\"joint_points\": %d, \"joint_measurements\": %d}\n",
+           "\"joint_points\": %d, \"joint_measurements\": %d, \"update_new_poses_points_runs\": %d}\n",
            steps / dt, dt / steps * 1e3, steps, warmup, dtHost / steps * 1e3, camsPerLaunch, okAll ? "true" : "false", minLive,
-           sj.nIterTotal, sj.cost, si.nIterTotal, si.cost, nccRuns, win ? "true" : "false", jC, jP, jO);
+           sj.nIterTotal, sj.cost, si.nIterTotal, si.cost, nccRuns, win ? "true" : "false", jC, jP, jO, updRuns);
     return 0;
 }
