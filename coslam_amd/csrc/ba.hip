@@ -3189,11 +3189,11 @@ static int ba_worker_run_window(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
     Wd.xy = win->xy, Wd.pf = win->pf, Wd.K = win->K, Wd.R = win->R, Wd.t = win->t;
     Wd.mapStatic = J.d_mapStatic, Wd.mapPts = J.d_map;
     Wd.cnt = win->cnt, Wd.ptIndex = win->ptIndex, Wd.obsStart = win->obsStart, Wd.totals = win->totals;
-    const int gM = (win->nMap + 255) / 256 > 0 ? (win->nMap + 255) / 256 : 1;
+    const int gM = (win->nMap + 3) / 4 > 0 ? (win->nMap + 3) / 4 : 1;   // a wave per map point
     hipLaunchKernelGGL(k_win_count, dim3(gM), dim3(256), 0, s, Wd);
     hipLaunchKernelGGL(k_win_scan, dim3(1), dim3(1024), 0, s, Wd);
     WinFillOut O = {b->Ks, b->Rs, b->Ts, b->pts, b->obs_xy, b->obs_ptr, b->obs_cam, win->pointMap, b->obs_pt, b->obs_of};
-    const int gF = ((win->nMap > C ? win->nMap : C) + 255) / 256;
+    const int gF = (win->nMap + 3) / 4 > (C + 255) / 256 ? (win->nMap + 3) / 4 : (C + 255) / 256;   // a wave per map point; a thread per key camera
     hipLaunchKernelGGL(k_win_fill, dim3(gF), dim3(256), 0, s, Wd, O);
     // the camera-pair lists' sizes, still without the host knowing P (one wave per pair; P read on the device)
     const int nPairsAll = C * (C + 1) / 2;

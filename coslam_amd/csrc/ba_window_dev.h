@@ -53,15 +53,25 @@ __global__ __launch_bounds__(256) void k_win_snapshot(WinSnapArgs A) {
     if ((st == 0 || st == 1) && m >= 0 && m < A.nMap) atomicMax(A.pfOut + (size_t)c * A.nMap + m, s);
 }
 
+// one WAVE per map point, lane = (key frame, camera) entry of the window (64 entries at a time): the point's feature count is a
+// ballot (a lane per point walking 40 entries one load after the other: 14 us in the loop)
 __global__ __launch_bounds__(256) void k_win_count(WinDev Wd) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (m >= Wd.nMap) return;
     int n = 0;
     if (!Wd.mapStatic || Wd.mapStatic[m]) {
-        for (int j = 0; j < Wd.count; ++j)
-            for (int c = 0; c < Wd.nCams; ++c) n += Wd.pf[((size_t)Wd.slotOf[j] * Wd.nCams + c) * Wd.nMap + m] >= 0 ? 1 : 0;
+        const int C = Wd.count * Wd.nCams;
+        for (int e0 = 0; e0 < C; e0 += 64) {
+            const int e = e0 + lane;
+            bool in = false;
+            if (e < C) {
+                const int j = e / Wd.nCams, c = e - j * Wd.nCams;
+                in = Wd.pf[((size_t)Wd.slotOf[j] * Wd.nCams + c) * Wd.nMap + m] >= 0;
+            }
+            n += __popcll(__builtin_amdgcn_ballot_w64(in));
+        }
     }
-    Wd.cnt[m] = n;
+    if (lane == 0) Wd.cnt[m] = n;
 }
 
 // exclusive scans over the map points in index order (one workgroup of 1024: chunks of consecutive points per thread)
@@ -111,41 +121,55 @@ struct WinFillOut {
     int *obs_ptr, *obs_cam, *pointMap;
     int *obs_pt, *obs_of;   // the measurement's point; the dense (point, camera) -> measurement table (-1: none)
 };
+// one WAVE per map point, lane = (key frame, camera) entry: the measurements of a kept point in camera order (:146-151) are the
+// set lanes of a ballot in lane order, a lane's measurement index = the point's start + the set lanes below it
 __global__ __launch_bounds__(256) void k_win_fill(WinDev Wd, WinFillOut O) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.x * 256 + threadIdx.x;
     const int C = Wd.count * Wd.nCams;
-    if (m < C) {  // the key cameras: K, R, t as CamPoseItem holds them (addKeyCamera, :80-89)
-        const int j = m / Wd.nCams, c = m - j * Wd.nCams;
+    if (g < C) {  // the key cameras: K, R, t as CamPoseItem holds them (addKeyCamera, :80-89)
+        const int j = g / Wd.nCams, c = g - j * Wd.nCams;
         const size_t src = (size_t)Wd.slotOf[j] * Wd.nCams + c;
         for (int q = 0; q < 9; ++q) {
-            O.Ks[9 * m + q] = Wd.K[9 * src + q];
-            O.Rs[9 * m + q] = Wd.R[9 * src + q];
+            O.Ks[9 * g + q] = Wd.K[9 * src + q];
+            O.Rs[9 * g + q] = Wd.R[9 * src + q];
         }
-        for (int q = 0; q < 3; ++q) O.Ts[3 * m + q] = Wd.t[3 * src + q];
+        for (int q = 0; q < 3; ++q) O.Ts[3 * g + q] = Wd.t[3 * src + q];
     }
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (m >= Wd.nMap) return;
     const int i = Wd.ptIndex[m];
-    if (m == Wd.nMap - 1) {  // closing entry of obs_ptr
+    if (m == Wd.nMap - 1 && lane == 0) {  // closing entry of obs_ptr
         const int P = Wd.totals[0];
         O.obs_ptr[P] = Wd.totals[1];
     }
     if (i < 0) return;
-    O.pointMap[i] = m;
-    for (int q = 0; q < 3; ++q) O.pts[3 * (size_t)i + q] = Wd.mapPts[3 * (size_t)m + q];
     int o = Wd.obsStart[m];
-    O.obs_ptr[i] = o;
-    for (int j = 0; j < Wd.count; ++j)
-        for (int c = 0; c < Wd.nCams; ++c) {  // camera order (:146-151)
-            const size_t src = (size_t)Wd.slotOf[j] * Wd.nCams + c;
-            const int s = Wd.pf[src * Wd.nMap + m];
-            O.obs_of[(size_t)i * C + j * Wd.nCams + c] = s < 0 ? -1 : o;
-            if (s < 0) continue;
-            O.obs_pt[o] = i;
-            O.obs_cam[o] = j * Wd.nCams + c;
-            O.obs_xy[2 * (size_t)o] = Wd.xy[src * 2 * Wd.N + s];
-            O.obs_xy[2 * (size_t)o + 1] = Wd.xy[src * 2 * Wd.N + Wd.N + s];
-            ++o;
+    if (lane == 0) {
+        O.pointMap[i] = m;
+        for (int q = 0; q < 3; ++q) O.pts[3 * (size_t)i + q] = Wd.mapPts[3 * (size_t)m + q];
+        O.obs_ptr[i] = o;
+    }
+    for (int e0 = 0; e0 < C; e0 += 64) {
+        const int e = e0 + lane;
+        int sl = -1;
+        size_t src = 0;
+        if (e < C) {
+            const int j = e / Wd.nCams, c = e - j * Wd.nCams;
+            src = (size_t)Wd.slotOf[j] * Wd.nCams + c;
+            sl = Wd.pf[src * Wd.nMap + m];
         }
+        const bool in = sl >= 0;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
+        const int mine = o + __popcll(mask & ((1ull << lane) - 1ull));
+        if (e < C) O.obs_of[(size_t)i * C + e] = in ? mine : -1;
+        if (in) {
+            O.obs_pt[mine] = i;
+            O.obs_cam[mine] = e;
+            O.obs_xy[2 * (size_t)mine] = Wd.xy[src * 2 * Wd.N + sl];
+            O.obs_xy[2 * (size_t)mine + 1] = Wd.xy[src * 2 * Wd.N + Wd.N + sl];
+        }
+        o += __popcll(mask);
+    }
 }
 
 // ---- camera-pair lists on the device -------------------------------------------------------------------------------------
