@@ -475,7 +475,14 @@ __global__ __launch_bounds__(256) void k_lin_packed(BaDev D) {
 #ifndef CS_SCHUR_WPP
 #define CS_SCHUR_WPP 4  // waves per camera pair (measured in the frame loop: 1 -> 1920, 2 -> 2150, 4 -> 2200 frames/s)
 #endif
-__global__ __launch_bounds__(256) void k_schur_wave(BaDev D) {
+// CS_SCHUR_WAVES_PER_EU (A/B builds): compile the pair kernel for that many waves per SIMD (3: 168 VGPRs instead of 206 -- a wave
+// then fits a SIMD that holds two tracker waves of 160)
+#ifdef CS_SCHUR_WAVES_PER_EU
+#define CS_SCHUR_ATTR __attribute__((amdgpu_waves_per_eu(CS_SCHUR_WAVES_PER_EU, CS_SCHUR_WAVES_PER_EU)))
+#else
+#define CS_SCHUR_ATTR
+#endif
+__global__ __launch_bounds__(256) CS_SCHUR_ATTR void k_schur_wave(BaDev D) {
     CS_BA_SETPRIO();
     if (!BA_ACTIVE(D)) return;
     constexpr int WPP = CS_SCHUR_WPP, TEAMS = 4 / WPP;
