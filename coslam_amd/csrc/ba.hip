@@ -96,7 +96,17 @@ struct BaDev {
     int nPackWaves;
     double* Y;             // [nObs][18]  W V^-1
     BaState* stn;          // the state the launch writes (see ba_packed_dev.h)
+    int* hostState;        // worker-run solves: pinned host {inner_done, all_done}, written by the last launch of a chunk / tail
+                           // (a copy node between the chunks cost 3.6 us + ~12 us of gap on the chain); null: nobody listens
 };
+
+// the word the worker's host thread reads between segments (system scope: the store must have left the device when the event
+// behind the launch fires)
+__device__ __forceinline__ void ba_publish_state(const BaDev& D, int inner_done, int all_done) {
+    if (!D.hostState) return;
+    __hip_atomic_store(D.hostState, inner_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(D.hostState + 1, all_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ double wsum(double v) { return cs_wave_sum_d(v); }
 
@@ -2082,6 +2092,7 @@ __global__ void k_outer_end(BaDev D) {
     st->nOuter += 1;
     st->inner_done = 0;
     if (!st->changed) st->all_done = 1;
+    ba_publish_state(D, 0, st->all_done);
 }
 
 __global__ void k_finish(BaDev D, cs_ba_stats_dev* out) {
@@ -3001,6 +3012,19 @@ static int ba_capture(hipStream_t s, hipGraphExec_t* out, F&& body) {
     return CS_OK;
 }
 
+// Packed launch-per-phase schedule: the last launch of a chunk (k_control_final) and of a tail (k_outer_end) store the state word
+// straight into the worker's pinned host word -- no copy node on the chain.  Other schedules (large systems, the persistent
+// launch) keep the copy.  COSLAM_BA_STATE_COPY=1 (A/B): always the copy.
+static bool ba_state_in_kernel(BaWorker* w, BaPlan& L) {
+    static const bool forceCopy = getenv("COSLAM_BA_STATE_COPY") && getenv("COSLAM_BA_STATE_COPY")[0] == '1';
+    L.D.hostState = L.DB.hostState = nullptr;
+    if (forceCopy || !L.packed || L.persist || !w->h_state) return false;
+    int* dp = nullptr;
+    if (hipHostGetDevicePointer((void**)&dp, w->h_state, 0) != hipSuccess || !dp) return false;
+    L.D.hostState = L.DB.hostState = dp;
+    return true;
+}
+
 // ---- the sliding window of key frames (ba_window_dev.h) ------------------------------------------------------------------
 // The schedule of a robust solve as a list of segments -- head, then per round [round start,] chunks of w->chunk LM steps, tail,
 // then finish -- issued with ONE segment of look-ahead: segment i + 1 is on the stream before the host waits for segment i's
@@ -3283,6 +3307,7 @@ static int ba_worker_run_window(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
         if (w->chunk > J.innerMaxIter && J.innerMaxIter > 0) w->chunk = J.innerMaxIter;
         if (w->chunk < 1) w->chunk = 1;
     }
+    const bool stateInKernel = ba_state_in_kernel(w, L);
     const BaDev& D = L.D;
     const dim3 blk(256);
     rc = ba_run_segments(w, s, J.maxIter, J.innerMaxIter, [&](char kind) {
@@ -3298,12 +3323,12 @@ static int ba_worker_run_window(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
                 break;
             case 'C':
                 ba_enqueue_lm_run(s, L, w->chunk);
-                (void)hipMemcpyAsync(w->h_state, &b->st->inner_done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+                if (!stateInKernel) (void)hipMemcpyAsync(w->h_state, &b->st->inner_done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
                 break;
             case 'T':
                 hipLaunchKernelGGL(k_flag, dim3(L.cb), blk, 0, s, D);
                 hipLaunchKernelGGL(k_outer_end, dim3(1), dim3(1), 0, s, D);
-                (void)hipMemcpyAsync(w->h_state, &b->st->inner_done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+                if (!stateInKernel) (void)hipMemcpyAsync(w->h_state, &b->st->inner_done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
                 break;
             default:
                 hipLaunchKernelGGL(k_cost_force, dim3(L.cb), blk, 0, s, D);
@@ -3363,6 +3388,7 @@ static int ba_worker_run_inner(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
     BaPlan L;
     int rc = ba_make_plan(b, J.C, J.P, J.nObs, J.nCamsCon, J.nPtsCon, J.maxErr, J.innerMaxIter, false, &L);
     if (rc) return rc;
+    const bool stateInKernel = ba_state_in_kernel(w, L);
     const BaDev& D = L.D;
     const dim3 blk(256);
     if (!w->haveGraphs || memcmp(&key, &w->key, sizeof(key)) != 0) {
@@ -3380,14 +3406,14 @@ static int ba_worker_run_inner(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
         if (rc) return rc;
         rc = ba_capture(s, &w->gChunk, [&] {
             ba_enqueue_lm_run(s, L, w->chunk);  // (the state word read back below is exact at every chunk boundary)
-            (void)hipMemcpyAsync(w->h_state, &b->st->inner_done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+            if (!stateInKernel) (void)hipMemcpyAsync(w->h_state, &b->st->inner_done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
         });
         if (rc) return rc;
         // tail of a round: outlier flags, round bookkeeping; start of the next round: cost + LM state
         rc = ba_capture(s, &w->gTail, [&] {
             hipLaunchKernelGGL(k_flag, dim3(L.cb), blk, 0, s, D);
             hipLaunchKernelGGL(k_outer_end, dim3(1), dim3(1), 0, s, D);
-            (void)hipMemcpyAsync(w->h_state, &b->st->inner_done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+            if (!stateInKernel) (void)hipMemcpyAsync(w->h_state, &b->st->inner_done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
         });
         if (rc) return rc;
         rc = ba_capture(s, &w->gRound, [&] {

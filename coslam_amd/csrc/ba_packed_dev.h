@@ -654,6 +654,7 @@ __global__ __launch_bounds__(256) void k_control_final(BaDev D) {
         D.st->cur = 0;
         BaState s = *D.st;
         *D.stn = s;
+        ba_publish_state(D, s.inner_done, s.all_done);
     }
 }
 
