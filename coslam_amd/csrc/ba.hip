@@ -3036,15 +3036,19 @@ static bool ba_state_in_kernel(BaWorker* w, BaPlan& L) {
 template <class F>
 static int ba_run_segments(BaWorker* w, hipStream_t s, int maxIter, int innerMaxIter, F&& launch) {
     struct Seg {
-        char kind;  // 'H'ead, 'R'ound start, 'C'hunk, 'T'ail, 'F'inish
+        char kind;  // 'H'ead, 'R'ound start, 'C'hunk, 'T'ail, 'U' = tail + next round's start, 'F'inish
         int outer;
     };
     std::vector<Seg> seg;
+    // (a round's tail and the next round's start are ONE segment, 'U' = T + R: two launches each -- as separate segments the second
+    // one waited for the host thread to wake up from the first one's event, ~15 us of idle stream per round; behind a converged
+    // tail the round start runs as no-ops like any speculative segment)
+    static const bool splitTR = getenv("COSLAM_BA_SPLIT_TR") && getenv("COSLAM_BA_SPLIT_TR")[0] == '1';  // A/B
     seg.push_back({'H', 0});
     for (int outer = 0; outer < maxIter; ++outer) {
-        if (outer > 0) seg.push_back({'R', outer});
+        if (outer > 0 && splitTR) seg.push_back({'R', outer});
         for (int done = 0; done < innerMaxIter; done += w->chunk) seg.push_back({'C', outer});
-        seg.push_back({'T', outer});
+        seg.push_back({(outer + 1 < maxIter && !splitTR) ? 'U' : 'T', outer});
     }
     seg.push_back({'F', maxIter});
     static const bool noSpec = getenv("COSLAM_BA_SPECULATE") && getenv("COSLAM_BA_SPECULATE")[0] == '0';  // A/B
@@ -3082,10 +3086,15 @@ static int ba_run_segments(BaWorker* w, hipStream_t s, int maxIter, int innerMax
         }
     };
     double hostUs[128] = {0};   // (diagnostic) host time spent inside launch(kind), per kind
+    auto launch_seg = [&](char kind) {
+        if (kind != 'U') return launch(kind);
+        const hipError_t e = launch('T');
+        return e != hipSuccess ? e : launch('R');
+    };
     auto timed_launch = [&](char kind) {
-        if (!segTime) return launch(kind);
+        if (!segTime) return launch_seg(kind);
         const auto t0 = std::chrono::steady_clock::now();
-        const hipError_t e = launch(kind);
+        const hipError_t e = launch_seg(kind);
         hostUs[(int)kind] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         return e;
     };
@@ -3129,11 +3138,11 @@ static int ba_run_segments(BaWorker* w, hipStream_t s, int maxIter, int innerMax
         }
         CS_HIP(hipEventSynchronize(w->ev[slot]));
         if (seg[i].kind == 'C' && (w->h_state[0] || w->h_state[1])) skipChunksOfOuter = seg[i].outer;  // inner_done / all_done
-        if (seg[i].kind == 'T' && w->h_state[1]) allDone = true;
+        if ((seg[i].kind == 'T' || seg[i].kind == 'U') && w->h_state[1]) allDone = true;
         if (noSpec) {
             const size_t m = next_of(i);
             if (m < seg.size()) {
-                CS_HIP(launch(seg[m].kind));
+                CS_HIP(launch_seg(seg[m].kind));
                 CS_HIP(hipEventRecord(w->ev[slot ^ 1], s));
                 stamp(seg[m].kind);
             }
