@@ -391,8 +391,8 @@ __global__ __launch_bounds__(256) void k_register_mergability(MgArgs A) {
 // point, that feature and the feature of the same track whose camera centre subtends the largest angle with the current one at
 // the point (first of equal angles in the backward walk; an angle of 0 never), updateDynamicPointPosition (:455-484) this frame's
 // features only (at least one of them TYPE_FEATPOINT_DYNAMIC); then triangulateMultiView over the views' normalised points and
-// getTriangulateCovMat at the new point.  The reference walks FeaturePoint::preFrame lists per point on the host; here UP_LPP lanes
-// = one map point: the lanes stride the backward walk of a camera's track (poses from the history ring -- which therefore has to
+// getTriangulateCovMat at the new point.  The reference walks FeaturePoint::preFrame lists per point on the host; here a WAVE
+// = one map point: the lanes take the frames of the backward walk of a camera's track (poses from the history ring -- which therefore has to
 // hold the poses AS ADJUSTED: cs_track_history_set_poses_dev), compare COSINES (acos is monotone; no libm on the device or in the
 // oracle's matching mode) and fold to the walk's first minimum; the 3x3 normal equations are summed view by view in the
 // reference's order and solved by cofactors.  getCameraCenter, getAbsRadiansBetween, normPoint, triangulateMultiView,
@@ -410,11 +410,11 @@ struct UpArgs {
     const unsigned char* mapFlags;
     double sigma;
     int* counts;  // [2] static / dynamic points re-triangulated, or null
-    int centresInLds;  // the camera centres of all (camera, ring entry) pairs fit the workgroup's LDS
+    const double* cen;  // [nCams][nHist][3] camera centres by walk depth (0 = this frame): k_ring_centres, once per launch
     cs_poseupdate_cam cam[PU_MAX_CAMS];
 };
-constexpr int UP_LPP = 8;
-constexpr size_t UP_MAX_LDS = 48 * 1024;
+constexpr int UP_LPP = 64;  // a WAVE per map point
+static_assert(UP_LPP == 64 && PU_MAX_CAMS <= UP_LPP, "the covariance tail broadcasts from lane = camera of the point's own wave");
 
 struct UpNormalEq {
     double N[6], g[3];
@@ -434,15 +434,13 @@ __device__ __forceinline__ void up_add_view(UpNormalEq& E, const double* __restr
 #pragma unroll
     for (int q = 0; q < 3; ++q) E.g[q] = E.g[q] + (a0[q] * b0 + a1[q] * b1);
 }
-__device__ __forceinline__ void up_add_cov(double* S, const double* __restrict__ K, const double* __restrict__ R,
-                                           const double* __restrict__ t, const double* M) {
-    const PuProj q = pu_project(K, R, t, M);
-    S[0] = S[0] + (q.J[0] * q.J[0] + q.J[3] * q.J[3]);
-    S[1] = S[1] + (q.J[0] * q.J[1] + q.J[3] * q.J[4]);
-    S[2] = S[2] + (q.J[0] * q.J[2] + q.J[3] * q.J[5]);
-    S[3] = S[3] + (q.J[1] * q.J[1] + q.J[4] * q.J[4]);
-    S[4] = S[4] + (q.J[1] * q.J[2] + q.J[4] * q.J[5]);
-    S[5] = S[5] + (q.J[2] * q.J[2] + q.J[5] * q.J[5]);
+__device__ __forceinline__ void up_add_jtj(double* S, const double* J) {
+    S[0] = S[0] + (J[0] * J[0] + J[3] * J[3]);
+    S[1] = S[1] + (J[0] * J[1] + J[3] * J[4]);
+    S[2] = S[2] + (J[0] * J[2] + J[3] * J[5]);
+    S[3] = S[3] + (J[1] * J[1] + J[4] * J[4]);
+    S[4] = S[4] + (J[1] * J[2] + J[4] * J[5]);
+    S[5] = S[5] + (J[2] * J[2] + J[5] * J[5]);
 }
 // symmetric 3x3 {n00, n01, n02, n11, n12, n22}: cofactors (same order) and the determinant
 __device__ __forceinline__ double up_sym33_cof(const double* N, double* c) {
@@ -459,20 +457,18 @@ __device__ __forceinline__ void up_cam_center(const double* __restrict__ R, cons
     for (int i = 0; i < 3; ++i) C[i] = -((R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2]);
 }
 
+// the camera centres of all (camera, ring entry) pairs by walk depth: every point's walk reads the same nCams x nHist of them
+__global__ __launch_bounds__(256) void k_ring_centres(int nCams, int H, int head, int nHist, const double* __restrict__ hR,
+                                                      const double* __restrict__ hT, double* __restrict__ cen) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nCams * nHist) return;
+    const int c = q / nHist, j = q - c * nHist, rs = (head - j + H) % H;
+    up_cam_center(hR + ((size_t)c * H + rs) * 9, hT + ((size_t)c * H + rs) * 3, cen + 3 * (size_t)q);
+}
+
 __global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
-    __shared__ int second[256 / UP_LPP][PU_MAX_CAMS];  // per point and camera: ring depth of the second view, -1 none, -2 no feature
-    extern __shared__ double up_cen[];                  // [nCams][nHist][3] camera centres by walk depth (0 = this frame)
     const int tid = threadIdx.x, g = tid / UP_LPP, r = tid % UP_LPP;
     const int m = blockIdx.x * (256 / UP_LPP) + g;
-    if (A.centresInLds) {
-        // the walk of every point of the workgroup needs the same nCams x nHist centres: once per workgroup instead of once per
-        // point and step (12 dependent loads each) -- the same arithmetic, so the same doubles
-        for (int q = tid; q < A.nCams * A.nHist; q += 256) {
-            const int c = q / A.nHist, j = q - c * A.nHist, rs = (A.head - j + A.H) % A.H;
-            up_cam_center(A.histR + ((size_t)c * A.H + rs) * 9, A.histT + ((size_t)c * A.H + rs) * 3, up_cen + 3 * (size_t)q);
-        }
-        __syncthreads();
-    }
     // (every test below is uniform over a point's lanes: whole groups leave together, the shuffles stay inside a group)
     if (m >= A.nMap) return;
     if (A.lastFrame && A.lastFrame[m] <= A.firstKeyFrame) return;  // :250, :261
@@ -491,8 +487,8 @@ __global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) E.g[q] = 0;
     int numView = 0, nDynamic = 0;
+    int mySecond = -2;  // lane r keeps camera r's second view: ring depth, -1 none, -2 the camera holds no feature of the point
     for (int c = 0; c < A.nCams; ++c) {
-        if (r == 0) second[g][c] = -2;
         const int s = A.pointFeat[(size_t)m * A.nCams + c];
         if (s < 0) continue;
         const cs_poseupdate_cam& C = A.cam[c];
@@ -514,14 +510,7 @@ __global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
             const int depth = len < A.nHist ? len : A.nHist;
             double bestCos = 1.0;
             for (int j = 1 + r; j < depth; j += UP_LPP) {  // :362-373 fp = fp->preFrame
-                double Cj[3];
-                if (A.centresInLds) {
-                    const double* cj = up_cen + 3 * ((size_t)c * A.nHist + j);
-                    Cj[0] = cj[0], Cj[1] = cj[1], Cj[2] = cj[2];
-                } else {
-                    const int rs = (A.head - j + H) % H;
-                    up_cam_center(hR + (size_t)rs * 9, hT + (size_t)rs * 3, Cj);
-                }
+                const double* Cj = A.cen + 3 * ((size_t)c * A.nHist + j);  // (consecutive lanes, consecutive entries)
                 const double b0 = Cj[0] - M[0], b1 = Cj[1] - M[1], b2 = Cj[2] - M[2];
                 const double d = (a0 * b0 + a1 * b1) + a2 * b2;
                 const double nb = (b0 * b0 + b1 * b1) + b2 * b2;
@@ -541,7 +530,7 @@ __global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
             }
         } else if (!C.isStatic[s])
             ++nDynamic;  // :471-472
-        if (r == 0) second[g][c] = best;
+        if (r == c) mySecond = best;
     }
     if (numView < 2 || (!locStatic && nDynamic < 1)) return;  // :388, :475
     double cf[6];
@@ -549,19 +538,37 @@ __global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
     M[0] = ((cf[0] * E.g[0] + cf[1] * E.g[1]) + cf[2] * E.g[2]) / det;  // triangulateMultiView
     M[1] = ((cf[1] * E.g[0] + cf[3] * E.g[1]) + cf[4] * E.g[2]) / det;
     M[2] = ((cf[2] * E.g[0] + cf[4] * E.g[1]) + cf[5] * E.g[2]) / det;
-    if (r != 0) return;
-    double S[6] = {0, 0, 0, 0, 0, 0};
-    for (int c = 0; c < A.nCams; ++c) {  // getTriangulateCovMat over the same views
-        const int sv = second[g][c];     // (written by this lane)
-        if (sv == -2) continue;
-        const double* hR = A.histR + (size_t)c * H * 9;
-        const double* hT = A.histT + (size_t)c * H * 3;
-        up_add_cov(S, A.cam[c].K, hR + (size_t)A.head * 9, hT + (size_t)A.head * 3, M);
-        if (sv >= 0) {
-            const int rs = (A.head - sv + H) % H;
-            up_add_cov(S, A.cam[c].K, hR + (size_t)rs * 9, hT + (size_t)rs * 3, M);
+    // getTriangulateCovMat over the same views: lane c computes camera c's (up to) two Jacobians at the new point -- the divisions
+    // are the expensive part --, then every lane sums the J^T J blocks in the reference's view order from lane c's registers
+    double J1[6] = {0, 0, 0, 0, 0, 0}, J2[6] = {0, 0, 0, 0, 0, 0};
+    if (r < A.nCams && mySecond != -2) {
+        const double* hR = A.histR + (size_t)r * H * 9;
+        const double* hT = A.histT + (size_t)r * H * 3;
+        const PuProj q1 = pu_project(A.cam[r].K, hR + (size_t)A.head * 9, hT + (size_t)A.head * 3, M);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) J1[k] = q1.J[k];
+        if (mySecond >= 0) {
+            const int rs = (A.head - mySecond + H) % H;
+            const PuProj q2 = pu_project(A.cam[r].K, hR + (size_t)rs * 9, hT + (size_t)rs * 3, M);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) J2[k] = q2.J[k];
         }
     }
+    double S[6] = {0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < A.nCams; ++c) {
+        const int sv = __shfl(mySecond, c, 64);
+        if (sv == -2) continue;
+        double Jc[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Jc[k] = __shfl(J1[k], c, 64);
+        up_add_jtj(S, Jc);
+        if (sv >= 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Jc[k] = __shfl(J2[k], c, 64);
+            up_add_jtj(S, Jc);
+        }
+    }
+    if (r != 0) return;
     const double dS = up_sym33_cof(S, cf), s2 = A.sigma * A.sigma;
     double* cov = A.mapCov + 9 * (size_t)m;
     const double c01 = (cf[1] / dS) * s2, c02 = (cf[2] / dS) * s2, c12 = (cf[4] / dS) * s2;
@@ -595,6 +602,7 @@ struct cs_track_history {
     int device, nCams, N, H;
     int head, count, lastFrame;
     double *xy, *R, *t;
+    double* cen;  // [nCams][H][3] scratch of cs_update_new_poses_points_dev: the camera centres by walk depth
 };
 
 extern "C" cs_track_history* cs_track_history_create(int device, int nCams, int N, int histLen) {
@@ -611,9 +619,9 @@ extern "C" cs_track_history* cs_track_history_create(int device, int nCams, int 
     h->head = -1, h->count = 0, h->lastFrame = -0x7fffffff;
     const size_t nXY = (size_t)nCams * histLen * 2 * N, nR = (size_t)nCams * histLen * 9, nT = (size_t)nCams * histLen * 3;
     if (hipMalloc((void**)&h->xy, sizeof(double) * nXY) != hipSuccess || hipMalloc((void**)&h->R, sizeof(double) * nR) != hipSuccess ||
-        hipMalloc((void**)&h->t, sizeof(double) * nT) != hipSuccess) {
+        hipMalloc((void**)&h->t, sizeof(double) * nT) != hipSuccess || hipMalloc((void**)&h->cen, sizeof(double) * nT) != hipSuccess) {
         cs_set_error("cs_track_history_create: hipMalloc failed");
-        (void)hipFree(h->xy), (void)hipFree(h->R), (void)hipFree(h->t);
+        (void)hipFree(h->xy), (void)hipFree(h->R), (void)hipFree(h->t), (void)hipFree(h->cen);
         delete h;
         return nullptr;
     }
@@ -626,7 +634,7 @@ extern "C" cs_track_history* cs_track_history_create(int device, int nCams, int 
 extern "C" void cs_track_history_destroy(cs_track_history* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    (void)hipFree(h->xy), (void)hipFree(h->R), (void)hipFree(h->t);
+    (void)hipFree(h->xy), (void)hipFree(h->R), (void)hipFree(h->t), (void)hipFree(h->cen);
     delete h;
 }
 
@@ -837,10 +845,10 @@ extern "C" int cs_update_new_poses_points_dev(const cs_track_history* h, void* h
     hipStream_t s = (hipStream_t)hip_stream;
     if (d_counts) CS_HIP(hipMemsetAsync(d_counts, 0, 2 * sizeof(int), s));
     if (nMap == 0) return CS_OK;
-    const size_t cenBytes = sizeof(double) * 3 * (size_t)h->nCams * h->count;
-    const char* noLds = getenv("COSLAM_UPDATE_POINTS_NO_LDS");  // diagnostic / tests: the path deep rings take (read per call)
-    A.centresInLds = cenBytes <= UP_MAX_LDS && !(noLds && noLds[0] == '1');
-    hipLaunchKernelGGL(k_update_points, dim3((nMap * UP_LPP + 255) / 256), dim3(256), A.centresInLds ? cenBytes : 0, s, A);
+    A.cen = h->cen;
+    hipLaunchKernelGGL(k_ring_centres, dim3((h->nCams * h->count + 255) / 256), dim3(256), 0, s, h->nCams, h->H, h->head, h->count, h->R, h->t,
+                       h->cen);
+    hipLaunchKernelGGL(k_update_points, dim3((nMap * UP_LPP + 255) / 256), dim3(256), 0, s, A);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

@@ -234,8 +234,7 @@ def test_register_mergability_walks_the_candidates_tracks_like_the_oracle():
     th.close()
 
 
-@pytest.mark.parametrize("centres", ["lds", "global"])
-def test_update_new_poses_points_reproduces_the_reference_on_its_golden_scenes(centres, monkeypatch):
+def test_update_new_poses_points_reproduces_the_reference_on_its_golden_scenes():
     """cs_update_new_poses_points_dev against tests/golden/update_points_golden.npz -- what the reference's own
     RobustBundleRTS::updateNewPosesPoints + updateStaticPointPosition / updateDynamicPointPosition (src/app/SL_CoSLAMRobustBA.cpp:
     248-271, src/slam/SL_CoSLAMHelper.cpp:338-394, 455-484, compiled in place) made of six scenes: every point and covariance bit for
@@ -248,8 +247,6 @@ def test_update_new_poses_points_reproduces_the_reference_on_its_golden_scenes(c
 
     from coslam_amd.poseupdate import TrackHistory
 
-    # the camera centres of all (camera, ring entry) pairs once per workgroup in LDS, or -- rings too deep for that -- per step
-    monkeypatch.setenv("COSLAM_UPDATE_POINTS_NO_LDS", "1" if centres == "global" else "0")
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "update_points_golden.npz"))
     dev = torch.device("cuda:0")
     s = torch.cuda.current_stream().cuda_stream
