@@ -392,7 +392,9 @@ int cs_register_mergability_dev(const cs_track_history* h, void* hip_stream, con
  * d_lastFrame [nMap] (MapPoint::lastFrame) or NULL = every point passes the frame test; d_isCurrent [nMap] or NULL = all points are
  * on curMapPts: a point with isCurrent == 0 is on actMapPts, whose dynamic points the reference never updates (:266-269 tests
  * isLocalStatic() twice) -- such a point must still have its features of THIS frame in d_pointFeat to be touched at all.
- * cams: K, iK, trackSpan, isStatic (feature types) of every camera.  d_counts [2] or NULL: static / dynamic points re-triangulated. */
+ * cams: K, iK, trackSpan, isStatic (feature types) of every camera.  d_counts [2] or NULL: static / dynamic points re-triangulated.
+ * The launch keeps the camera centres of the ring's entries in a scratch array of h: calls that share a history must be ordered
+ * (one stream, or events), like every other call that advances or reads it. */
 int cs_track_history_set_poses_dev(cs_track_history* h, void* hip_stream, int n, const int* d_cam, const int* d_frame, const double* d_R,
                                    const double* d_t);
 int cs_update_new_poses_points_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const int* d_pointFeat,

@@ -444,9 +444,15 @@ def test_async_worker_schedule_gives_the_up_front_schedule_bit_for_bit(hip):
             if mode == "dev":
                 ws.solve_dev(s, d_R.data_ptr(), d_T.data_ptr(), d_M.data_ptr(), ncon, npcon, 6.0, maxIter, inner)
             else:
-                for _ in range(3 if mode == "async3" else 1):   # queued requests run in order, each from the same start
+                n_req = 3 if mode == "async3" else 1
+                assert ws.pending() == 0 and ws.completed() == 0
+                for _ in range(n_req):   # queued requests run in order, each from the same start
                     ws.solve_async(s, d_R.data_ptr(), d_T.data_ptr(), d_M.data_ptr(), ncon, npcon, 6.0, maxIter, inner)
+                # cs_ba_pending / cs_ba_completed never block: together they account for every request at any moment
+                p_, c_ = ws.pending(), ws.completed()
+                assert 0 <= c_ <= n_req and 0 <= p_ <= n_req
                 ws.wait()
+                assert ws.pending() == 0 and ws.completed() == n_req
             R, T, M, out, st = ws.download()
             res.append((R.copy(), T.copy(), M.copy(), out.copy(), (st.cost0, st.cost, st.nIterTotal, st.nOuter, st.nOutliers)))
             ws.close()
