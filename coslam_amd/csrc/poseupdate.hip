@@ -411,6 +411,8 @@ struct UpArgs {
     double sigma;
     int* counts;  // [2] static / dynamic points re-triangulated, or null
     const double* cen;  // [nCams][nHist][3] camera centres by walk depth (0 = this frame): k_ring_centres, once per launch
+    int refine;                   // CoSLAM::refineMapPoint: the points `select` names, whatever their type, no frame test
+    const unsigned char* select;  // [nMap] or null (= all)
     cs_poseupdate_cam cam[PU_MAX_CAMS];
 };
 constexpr int UP_LPP = 64;  // a WAVE per map point
@@ -471,8 +473,11 @@ __global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
     const int m = blockIdx.x * (256 / UP_LPP) + g;
     // (every test below is uniform over a point's lanes: whole groups leave together, the shuffles stay inside a group)
     if (m >= A.nMap) return;
-    if (A.lastFrame && A.lastFrame[m] <= A.firstKeyFrame) return;  // :250, :261
-    const unsigned char fl = A.mapFlags[m];
+    if (A.refine) {
+        if (A.select && !A.select[m]) return;
+    } else if (A.lastFrame && A.lastFrame[m] <= A.firstKeyFrame)
+        return;  // :250, :261
+    const unsigned char fl = A.refine ? 0 : A.mapFlags[m];  // (refineMapPoint asks nothing about the point's type)
     const bool locStatic = (fl & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) == 0;               // isLocalStatic()
     const bool locDynamic = (fl & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) == CS_MAP_DYNAMIC;  // isLocalDynamic()
     const bool cur = A.isCurrent ? A.isCurrent[m] != 0 : true;
@@ -814,6 +819,35 @@ extern "C" int cs_track_history_set_poses_dev(cs_track_history* h, void* hip_str
     return CS_OK;
 }
 
+namespace {
+int up_launch(const char* who, const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, UpArgs& A, int* d_counts, int nCounts) {
+    if (h->count < 1) {
+        cs_set_error("%s: the history holds no frame (cs_pose_update_frame_dev / cs_detect_dynamic_dev push one per frame)", who);
+        return CS_ERR_INVALID;
+    }
+    A.nCams = h->nCams, A.N = h->N, A.H = h->H, A.head = h->head, A.nHist = h->count;
+    A.histXY = h->xy, A.histR = h->R, A.histT = h->t;
+    A.counts = d_counts;
+    for (int c = 0; c < h->nCams; ++c) {
+        if (!cams[c].K || !cams[c].iK || !cams[c].trackSpan || (!A.refine && !cams[c].isStatic)) {
+            cs_set_error("%s: null pointer in camera %d (K, iK, trackSpan%s are read)", who, c, A.refine ? "" : ", isStatic");
+            return CS_ERR_INVALID;
+        }
+        A.cam[c] = cams[c];
+    }
+    CS_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (d_counts) CS_HIP(hipMemsetAsync(d_counts, 0, nCounts * sizeof(int), s));
+    if (A.nMap == 0) return CS_OK;
+    A.cen = h->cen;
+    hipLaunchKernelGGL(k_ring_centres, dim3((h->nCams * h->count + 255) / 256), dim3(256), 0, s, h->nCams, h->H, h->head, h->count, h->R, h->t,
+                       h->cen);
+    hipLaunchKernelGGL(k_update_points, dim3((A.nMap * UP_LPP + 255) / 256), dim3(256), 0, s, A);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+}  // namespace
+
 extern "C" int cs_update_new_poses_points_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams,
                                               const int* d_pointFeat, int nMap, const int* d_lastFrame,
                                               const unsigned char* d_isCurrent, int firstKeyFrame, double* d_mapPts, double* d_mapCov,
@@ -822,33 +856,28 @@ extern "C" int cs_update_new_poses_points_dev(const cs_track_history* h, void* h
         cs_set_error("cs_update_new_poses_points_dev: bad arguments");
         return CS_ERR_INVALID;
     }
-    if (h->count < 1) {
-        cs_set_error("cs_update_new_poses_points_dev: the history holds no frame (cs_pose_update_frame_dev / cs_detect_dynamic_dev push one per frame)");
+    UpArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nMap = nMap, A.firstKeyFrame = firstKeyFrame;
+    A.pointFeat = d_pointFeat, A.lastFrame = d_lastFrame, A.isCurrent = d_isCurrent;
+    A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.mapFlags = d_mapFlags;
+    A.sigma = pixelErrVar;
+    return up_launch("cs_update_new_poses_points_dev", h, hip_stream, cams, A, d_counts, 2);
+}
+
+extern "C" int cs_refine_map_points_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const int* d_pointFeat,
+                                        int nMap, const unsigned char* d_select, double* d_mapPts, double* d_mapCov, double pixelErrVar,
+                                        int* d_count) {
+    if (!h || !cams || nMap < 0 || (nMap > 0 && (!d_pointFeat || !d_mapPts || !d_mapCov))) {
+        cs_set_error("cs_refine_map_points_dev: bad arguments");
         return CS_ERR_INVALID;
     }
     UpArgs A;
     memset(&A, 0, sizeof(A));
-    A.nCams = h->nCams, A.N = h->N, A.nMap = nMap, A.H = h->H, A.head = h->head, A.nHist = h->count, A.firstKeyFrame = firstKeyFrame;
-    A.pointFeat = d_pointFeat, A.lastFrame = d_lastFrame, A.isCurrent = d_isCurrent;
-    A.histXY = h->xy, A.histR = h->R, A.histT = h->t;
-    A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.mapFlags = d_mapFlags;
+    A.nMap = nMap;
+    A.pointFeat = d_pointFeat;
+    A.mapPts = d_mapPts, A.mapCov = d_mapCov;
     A.sigma = pixelErrVar;
-    A.counts = d_counts;
-    for (int c = 0; c < h->nCams; ++c) {
-        if (!cams[c].K || !cams[c].iK || !cams[c].trackSpan || !cams[c].isStatic) {
-            cs_set_error("cs_update_new_poses_points_dev: null pointer in camera %d (K, iK, trackSpan, isStatic are read)", c);
-            return CS_ERR_INVALID;
-        }
-        A.cam[c] = cams[c];
-    }
-    CS_HIP(hipSetDevice(h->device));
-    hipStream_t s = (hipStream_t)hip_stream;
-    if (d_counts) CS_HIP(hipMemsetAsync(d_counts, 0, 2 * sizeof(int), s));
-    if (nMap == 0) return CS_OK;
-    A.cen = h->cen;
-    hipLaunchKernelGGL(k_ring_centres, dim3((h->nCams * h->count + 255) / 256), dim3(256), 0, s, h->nCams, h->H, h->head, h->count, h->R, h->t,
-                       h->cen);
-    hipLaunchKernelGGL(k_update_points, dim3((nMap * UP_LPP + 255) / 256), dim3(256), 0, s, A);
-    CS_HIP(hipGetLastError());
-    return CS_OK;
+    A.refine = 1, A.select = d_select;
+    return up_launch("cs_refine_map_points_dev", h, hip_stream, cams, A, d_count, 1);
 }

@@ -108,3 +108,11 @@ class TrackHistory:
                                                      vp(d_lastFrame), vp(d_isCurrent), int(firstKeyFrame), vp(d_mapPts), vp(d_mapCov),
                                                      vp(d_mapFlags), C.c_double(pixelErrVar), vp(d_counts)),
               "cs_update_new_poses_points_dev")
+
+    def refine_map_points_dev(self, stream_ptr, cams, d_pointFeat, nMap, d_mapPts, d_mapCov, pixelErrVar, d_select=None, d_count=None):
+        """CoSLAM::refineMapPoint (reference src/app/SL_CoSLAM.cpp:666-713) for the selected map points (uint8 mask; None = all), in
+        place: what the registration loops call on a point that has just gained a feature."""
+        vp = C.c_void_p
+        check(self._L.cs_refine_map_points_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), vp(d_pointFeat), int(nMap), vp(d_select),
+                                               vp(d_mapPts), vp(d_mapCov), C.c_double(pixelErrVar), vp(d_count)),
+              "cs_refine_map_points_dev")

@@ -401,6 +401,14 @@ int cs_update_new_poses_points_dev(const cs_track_history* h, void* hip_stream, 
                                    int nMap, const int* d_lastFrame, const unsigned char* d_isCurrent, int firstKeyFrame,
                                    double* d_mapPts, double* d_mapCov, const unsigned char* d_mapFlags, double pixelErrVar,
                                    int* d_counts);
+/* CoSLAM::refineMapPoint (src/app/SL_CoSLAM.cpp:666-713) for every map point d_select names (uint8 [nMap]; NULL = all) in one
+ * launch: what the registration loops call on a point that has just gained a feature (:896, :948, :1166).  The views are those of
+ * updateStaticPointPosition (per camera holding a feature of the point in d_pointFeat: that feature and the widest-parallax one
+ * further back on its track), then triangulateMultiView + getTriangulateCovMat IN PLACE -- whatever the point's type, no frame
+ * test.  The reference does not look at the number of views; here a point with fewer than two is left alone.  The same kernel,
+ * history and ordering rules as cs_update_new_poses_points_dev; cams: K, iK, trackSpan.  d_count [1] or NULL: points refined. */
+int cs_refine_map_points_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap,
+                             const unsigned char* d_select, double* d_mapPts, double* d_mapCov, double pixelErrVar, int* d_count);
 
 /* ------------------------------------------------------------------------------------------
  * Pose-graph relaxation of the non-key frames after a bundle adjustment, all camera graphs in one launch

@@ -293,6 +293,28 @@ def update_new_poses_points(Ks, iKs, histR, histT, histXY, trackSpan, featStatic
     return n, ns.value, nd.value, chosen
 
 
+def refine_map_points(Ks, iKs, histR, histT, histXY, trackSpan, pointFeat, mapPts, mapCov, sigma, select=None, cmpAcos=False):
+    """opu_refine_map_points (CoSLAM::refineMapPoint for the selected points; layouts as update_new_poses_points); mapPts / mapCov are
+    updated IN PLACE.  Returns the number of points refined."""
+    L = lib()
+    L.opu_refine_map_points.restype = C.c_int
+    histR = np.ascontiguousarray(histR, dtype=np.float64)
+    histT = np.ascontiguousarray(histT, dtype=np.float64)
+    histXY = np.ascontiguousarray(histXY, dtype=np.float64)
+    nC, nH = histR.shape[0], histR.shape[1]
+    N = histXY.shape[2] // 2
+    Ks = np.ascontiguousarray(Ks, dtype=np.float64).reshape(nC, 9)
+    iKs = np.ascontiguousarray(iKs, dtype=np.float64).reshape(nC, 9)
+    sp = np.ascontiguousarray(trackSpan, dtype=np.int32).reshape(nC, 2 * N)
+    pf = np.ascontiguousarray(pointFeat, dtype=np.int32)
+    nMap = pf.shape[0]
+    assert pf.shape == (nMap, nC) and mapPts.dtype == np.float64 and mapCov.dtype == np.float64
+    assert mapPts.flags.c_contiguous and mapCov.flags.c_contiguous
+    sel = None if select is None else np.ascontiguousarray(select, dtype=np.uint8)
+    return L.opu_refine_map_points(nC, N, nH, _p(Ks), _p(iKs), _p(histR), _p(histT), _p(histXY), _p(sp), nMap, _p(pf),
+                                   _p(sel) if sel is not None else None, _p(mapPts), _p(mapCov), C.c_double(sigma), int(bool(cmpAcos)))
+
+
 def static_check_mergability(K, histR, histT, histXY, slot, length, M, cov, pixelVar):
     """org_static_check_mergability (CoSLAM::staticCheckMergability): histR (nHist x 9), histT (nHist x 3), histXY (nHist x 2N),
     entry 0 = this frame; the track of `slot` covers the `length` newest entries.  Returns True / False."""

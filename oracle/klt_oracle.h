@@ -174,6 +174,9 @@ int opu_update_new_poses_points(int nCams, int N, int nHist, const double* Ks, c
                                 int nMap, const int* pointFeat, const int* lastFrame, const unsigned char* isCurrent,
                                 int firstKeyFrame, double* mapPts, double* mapCov, const unsigned char* mapFlags, double sigma,
                                 int cmpAcos, int* chosen, int* nStat, int* nDyn);
+int opu_refine_map_points(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
+                          const double* histXY, const int* trackSpan, int nMap, const int* pointFeat, const unsigned char* select,
+                          double* mapPts, double* mapCov, double sigma, int cmpAcos);
 
 /* ---- NCC blocks and the epipolar / NCC matrices of the inter-camera matching restated (ncc_oracle.c) ---- */
 int onc_block_compute(const unsigned char* img, int W, int H, double x, double y, double scale, unsigned char* I, double* abc);

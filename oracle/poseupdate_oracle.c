@@ -267,17 +267,18 @@ static void cov_add_view(double* S, const double* K, const double* R, const doub
  * that camera, < 0 none; lastFrame [nMap] or NULL (= every point passes :250); isCurrent [nMap] or NULL (= all on curMapPts).
  * chosen (or NULL): [nMap][nCams] the history entry taken as the second view (-1 none), for the tests.
  * Returns the number of points re-triangulated; *nStat / *nDyn count them by kind. */
-int opu_update_new_poses_points(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR,
-                                const double* histT, const double* histXY, const int* trackSpan, const unsigned char* featStatic,
-                                int nMap, const int* pointFeat, const int* lastFrame, const unsigned char* isCurrent,
-                                int firstKeyFrame, double* mapPts, double* mapCov, const unsigned char* mapFlags, double sigma,
-                                int cmpAcos, int* chosen, int* nStat, int* nDyn) {
+static int update_points_core(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR,
+                              const double* histT, const double* histXY, const int* trackSpan, const unsigned char* featStatic,
+                              int nMap, const int* pointFeat, const int* lastFrame, const unsigned char* isCurrent,
+                              int firstKeyFrame, double* mapPts, double* mapCov, const unsigned char* mapFlags, double sigma,
+                              int cmpAcos, int* chosen, int* nStat, int* nDyn, int refine, const unsigned char* select) {
     int nUpd = 0, ns = 0, nd = 0;
     for (int m = 0; m < nMap; m++) {
         if (chosen)
             for (int c = 0; c < nCams; c++) chosen[(size_t)m * nCams + c] = -1;
-        if (lastFrame && lastFrame[m] <= firstKeyFrame) continue; /* :250, :261 */
-        const unsigned char fl = mapFlags[m];
+        if (refine && select && !select[m]) continue;
+        if (!refine && lastFrame && lastFrame[m] <= firstKeyFrame) continue; /* :250, :261 */
+        const unsigned char fl = refine ? 0 : mapFlags[m]; /* refineMapPoint asks nothing about the point's type */
         const int locStatic = (fl & (OPU_DYNAMIC | OPU_FALSE)) == 0, locDynamic = (fl & (OPU_DYNAMIC | OPU_FALSE)) == OPU_DYNAMIC;
         const int cur = isCurrent ? isCurrent[m] != 0 : 1;
         double* M = mapPts + 3 * (size_t)m;
@@ -360,4 +361,27 @@ int opu_update_new_poses_points(int nCams, int N, int nHist, const double* Ks, c
     if (nStat) *nStat = ns;
     if (nDyn) *nDyn = nd;
     return nUpd;
+}
+
+int opu_update_new_poses_points(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR,
+                                const double* histT, const double* histXY, const int* trackSpan, const unsigned char* featStatic,
+                                int nMap, const int* pointFeat, const int* lastFrame, const unsigned char* isCurrent,
+                                int firstKeyFrame, double* mapPts, double* mapCov, const unsigned char* mapFlags, double sigma,
+                                int cmpAcos, int* chosen, int* nStat, int* nDyn) {
+    return update_points_core(nCams, N, nHist, Ks, iKs, histR, histT, histXY, trackSpan, featStatic, nMap, pointFeat, lastFrame, isCurrent,
+                              firstKeyFrame, mapPts, mapCov, mapFlags, sigma, cmpAcos, chosen, nStat, nDyn, 0, 0);
+}
+
+/* CoSLAM::refineMapPoint (/root/reference/src/app/SL_CoSLAM.cpp:666-713) for the points `select` names (NULL: all): what the
+ * registration loops call on a map point that has just gained a feature (:896, :948, :1166).  The views are those of
+ * updateStaticPointPosition -- per camera holding a feature, that feature and the widest-parallax one further back on its track --
+ * followed by the same triangulateMultiView + getTriangulateCovMat, whatever the point's type and without a frame test.  The
+ * reference does not look at the number of views (with one, its least-squares call is rank deficient); here a point with fewer
+ * than two views is left alone.  Pinned like the function above (tests/cxx/ref_update_points_test.cpp calls the reference's own
+ * refineMapPoint on a copy of every point that two cameras see).  Returns the number of points refined. */
+int opu_refine_map_points(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
+                          const double* histXY, const int* trackSpan, int nMap, const int* pointFeat, const unsigned char* select,
+                          double* mapPts, double* mapCov, double sigma, int cmpAcos) {
+    return update_points_core(nCams, N, nHist, Ks, iKs, histR, histT, histXY, trackSpan, 0, nMap, pointFeat, 0, 0, 0, mapPts, mapCov, 0,
+                              sigma, cmpAcos, 0, 0, 0, 1, select);
 }

@@ -12,7 +12,8 @@
 //   ref_update_points_test golden <out.bin>
 // Layout of out.bin: int32 nScenes; per scene: int32 nCams, H, nPts, firstKeyFrame, curFrame; double sigma; per camera K[9], iK[9];
 // per camera and history entry (newest first) R[9], t[3]; per point: M[3], cov[9], int32 localType, uncertain, lastFrame, isCurrent,
-// per camera int32 L, int32 featDynamic, L x m[2] (newest first); then per point the reference's M[3], cov[9].
+// per camera int32 L, int32 featDynamic, L x m[2] (newest first); then per point the reference's M[3], cov[9]; then per point int32
+// refined, and CoSLAM::refineMapPoint's M[3], cov[9] for a copy of the point as it stood before (refined = 0: not called, unchanged).
 // TEST INFRASTRUCTURE; built into oracle/_ref/ where the reference tree exists.
 #include <cmath>
 #include <cstdio>
@@ -57,7 +58,7 @@ int main(int argc, char** argv) {
     if (!f) return 1;
     const int nScenes = 6;
     puti(f, nScenes);
-    int nTouched = 0, nTotal = 0, nMoved2 = 0;
+    int nTouched = 0, nTotal = 0, nMoved2 = 0, nRefined = 0;
     for (int sc = 0; sc < nScenes; ++sc) {
         const int nCams = 2 + sc % 4, H = 6 + 5 * (sc % 3), nPts = 60, curFrame = 200 + sc, firstKey = curFrame - 12;
         // kind of motion: 0 moving rig, 1 stands still for the older half of the history, 2 rotation only
@@ -139,6 +140,26 @@ int main(int argc, char** argv) {
             pts[p] = mp;
             if (isCur) co->curMapPts.add(mp); else co->actMapPts.add(mp);
         }
+        // CoSLAM::refineMapPoint (src/app/SL_CoSLAM.cpp:666-713: what the registration loops call on a point that just gained a feature,
+        // :896, :948, :1166) on a COPY of every point that at least two cameras see -- the same views and the same two helper calls as
+        // updateStaticPointPosition, whatever the point's type, and no frame test
+        std::vector<int> refSel(nPts, 0);
+        std::vector<double> refM(3 * nPts), refCov(9 * nPts);
+        for (int c = 0; c < nCams; ++c) {
+            co->slam[c].K.resize(3, 3);
+            memcpy(co->slam[c].K.data, Ks[c].data(), 72);
+        }
+        for (int p = 0; p < nPts; ++p) {
+            int seen = 0;
+            for (int c = 0; c < nCams; ++c) seen += pts[p]->pFeatures[c] != nullptr;
+            MapPoint tmp(*pts[p]);
+            if (seen >= 2) {
+                co->refineMapPoint(&tmp);
+                refSel[p] = 1;
+                ++nRefined;
+            }
+            memcpy(&refM[3 * p], tmp.M, 24), memcpy(&refCov[9 * p], tmp.cov, 72);
+        }
         std::vector<double> before(3 * nPts);
         for (int p = 0; p < nPts; ++p) memcpy(&before[3 * p], pts[p]->M, 24);
         RobustBundleRTS ba;
@@ -153,9 +174,11 @@ int main(int argc, char** argv) {
             for (int q = 0; q < 3; ++q)
                 if (!(fabs(pts[p]->M[q]) < 1e3)) ++nMoved2;
         }
+        for (int p = 0; p < nPts; ++p) puti(f, refSel[p]), put(f, &refM[3 * p], 3), put(f, &refCov[9 * p], 9);
         co->curMapPts.clearWithoutRelease(), co->actMapPts.clearWithoutRelease();
     }
     fclose(f);
-    printf("ref_update_points_test: %d scenes, %d of %d points re-triangulated, %d wild coordinates\n", nScenes, nTouched, nTotal, nMoved2);
-    return (nTouched > nTotal / 4 && nTouched < nTotal && nMoved2 == 0) ? 0 : 1;
+    printf("ref_update_points_test: %d scenes, %d of %d points re-triangulated, %d wild coordinates; refineMapPoint on %d points\n", nScenes, nTouched,
+           nTotal, nMoved2, nRefined);
+    return (nTouched > nTotal / 4 && nTouched < nTotal && nMoved2 == 0 && nRefined > nTotal / 4) ? 0 : 1;
 }

@@ -329,10 +329,14 @@ def update_points_case():
         o -= 8 * 3 * nP
         for p in range(nP):
             Mr[p], covr[p] = dbls(3), dbls(9)
+        rsel, Mf, covf = np.zeros(nP, np.uint8), np.zeros((nP, 3)), np.zeros((nP, 9))
+        for p in range(nP):
+            (rs_,) = ints(1)
+            rsel[p], Mf[p], covf[p] = rs_, dbls(3), dbls(9)
         pre = f"s{sc}_"
         for k, v in dict(K=K, iK=iK, histR=hR, histT=hT, histXY=hXY, trackSpan=span, featStatic=fstat, pointFeat=pf, M0=M0, cov0=cov0,
                          flags=flags, lastFrame=lastF, isCurrent=isCur, firstKey=np.int32(firstKey), curFrame=np.int32(cur),
-                         sigma=np.float64(sigma), M_ref=Mr, cov_ref=covr).items():
+                         sigma=np.float64(sigma), M_ref=Mr, cov_ref=covr, refine_select=rsel, M_refine=Mf, cov_refine=covf).items():
             out[pre + k] = v
     assert o == len(raw)
     return out

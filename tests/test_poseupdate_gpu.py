@@ -305,6 +305,19 @@ def test_update_new_poses_points_reproduces_the_reference_on_its_golden_scenes()
         dM, dC = np.abs(M - G("M_ref")).max(), np.abs(cov - G("cov_ref")).max()
         assert np.array_equal(M, G("M_ref")) and np.array_equal(cov, G("cov_ref")), f"scene {sc}: max |dM| {dM:.3e}, max |dcov| {dC:.3e}"
         touched += n_ref
+        # CoSLAM::refineMapPoint on the same history: the reference's own function (src/app/SL_CoSLAM.cpp:666-713) was run on a copy
+        # of every point two cameras see; the selected points bit for bit, the others untouched
+        d_M2 = torch.from_numpy(G("M0").copy()).to(dev)
+        d_cov2 = torch.from_numpy(G("cov0").copy()).to(dev)
+        d_sel = torch.from_numpy(G("refine_select").copy()).to(dev)
+        d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+        th.refine_map_points_dev(s, cams, d_pf.data_ptr(), nMap, d_M2.data_ptr(), d_cov2.data_ptr(), float(G("sigma")),
+                                 d_select=d_sel.data_ptr(), d_count=d_n.data_ptr())
+        torch.cuda.synchronize()
+        assert int(d_n.item()) == int(G("refine_select").sum())
+        M2, cov2 = d_M2.cpu().numpy(), d_cov2.cpu().numpy()
+        assert np.array_equal(M2, G("M_refine")) and np.array_equal(cov2, G("cov_refine")), \
+            f"scene {sc} refine: max |dM| {np.abs(M2 - G('M_refine')).max():.3e}"
         th.close()
     assert touched > 150
 
