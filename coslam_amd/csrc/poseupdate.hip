@@ -585,6 +585,284 @@ __global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
     if (A.counts) atomicAdd(A.counts + (locStatic ? 0 : 1), 1);
 }
 
+// ---- CoSLAM::mapPointsClassify (src/app/SL_CoSLAM.cpp:418-520) ------------------------------------------------------------------------
+// Every frame behind the pose update (CoSLAM::poseUpdate, :381-385) the reference re-examines every map point of the current list that
+// is uncertain (what the gate above made of it) or locally dynamic: static again (isStaticPoint over the last 60 frames: the views of
+// updateStaticPointPosition inside that window, triangulation, covariance, every view within Mahalanobis distance 1), dynamic
+// (isDynamicPoint: this frame's features, in front of the first camera, a covariance small against the distance, every view within
+// the gate), static without its worst view (isStaticRemovable -> that feature is detached), or false; dynamic points that stand
+// still (isLittleMove) for more than 50 frames may return to static.  The examined points are few (what the gate rejected, the
+// moving objects' points) and each decision is a chain of small f64 solves: ONE LANE PER MAP POINT runs the reference's control
+// flow as written (src/slam/SL_CoSLAMHelper.cpp:67-330), the camera centres of the ring from k_ring_centres; nothing is shared
+// between points (a feature belongs to one point), so the in-place updates need no ordering.  Helper definitions as above, plus
+// isAtCameraBack(R, t, M) = (R M + t).z < 0 and dist3 = Euclidean distance.
+struct ClsArgs {
+    int nCams, N, nMap, H, head, nHist, curFrame;
+    int* pointFeat;        // [nMap][nCams] in / out (a detached feature becomes -1)
+    const int* featFrame;  // [nMap][nCams] or null: the frame of MapPoint::pFeatures[iCam] (null: all of this frame)
+    const int* featFirst;  // [nMap][nCams] or null: the first frame of that feature's track (null: the slot's trackSpan)
+    const double* histXY;
+    const double* histR;
+    const double* histT;
+    const double* cen;
+    double* mapPts;
+    double* mapCov;
+    unsigned char* mapFlags;
+    unsigned char* newPt;
+    int* staticFrameNum;
+    const int* firstFrame;
+    double sigma;
+    int* counts;  // [2] points examined / points that became false, or null
+    cs_poseupdate_cam cam[PU_MAX_CAMS];
+};
+struct ClsView {
+    int c, j;  // camera, walk depth (0 = this frame)
+};
+
+__device__ __forceinline__ bool cls_feature(const ClsArgs& A, int m, int c, int& s, int& j0, int& f, int& ff) {
+    s = A.pointFeat[(size_t)m * A.nCams + c];
+    if (s < 0) return false;
+    f = A.featFrame ? A.featFrame[(size_t)m * A.nCams + c] : A.curFrame;
+    j0 = A.curFrame - f;
+    if (j0 < 0 || j0 >= A.nHist) return false;  // older than the history: treated as absent
+    ff = A.featFirst ? A.featFirst[(size_t)m * A.nCams + c] : A.cam[c].trackSpan[s];
+    return true;
+}
+__device__ __forceinline__ const double* cls_R(const ClsArgs& A, int c, int j) {
+    return A.histR + ((size_t)c * A.H + (A.head - j + A.H) % A.H) * 9;
+}
+__device__ __forceinline__ const double* cls_t(const ClsArgs& A, int c, int j) {
+    return A.histT + ((size_t)c * A.H + (A.head - j + A.H) % A.H) * 3;
+}
+__device__ __forceinline__ void cls_pixel(const ClsArgs& A, int c, int j, int s, double& mx, double& my) {
+    const double* h = A.histXY + ((size_t)c * A.H + (A.head - j + A.H) % A.H) * 2 * A.N;
+    mx = h[s], my = h[A.N + s];
+}
+// mahaDist2 of a feature from the projection of (M, cov) under its own frame's pose: project, getProjectionCovMat, mat22Inv
+__device__ __noinline__ double cls_err(const ClsArgs& A, int c, int j, int s, const double* M, const double* cov) {
+    double mx, my;
+    cls_pixel(A, c, j, s, mx, my);
+    const PuProj q = pu_project(A.cam[c].K, cls_R(A, c, j), cls_t(A, c, j), M);
+    const double rm0 = q.u / q.w, rm1 = q.v / q.w;
+    double JC[6], var[4], ivar[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) JC[3 * i + k] = (q.J[3 * i] * cov[k] + q.J[3 * i + 1] * cov[3 + k]) + q.J[3 * i + 2] * cov[6 + k];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double sv = (JC[3 * i] * q.J[3 * k] + JC[3 * i + 1] * q.J[3 * k + 1]) + JC[3 * i + 2] * q.J[3 * k + 2];
+            var[2 * i + k] = (i == k) ? sv + A.sigma * A.sigma : sv;
+        }
+    pu_mat22_inv(var, ivar);
+    const double dx = rm0 - mx, dy = rm1 - my;
+    return dx * (ivar[0] * dx + ivar[1] * dy) + dy * (ivar[2] * dx + ivar[3] * dy);
+}
+// triangulateMultiView over the view list; mode 2 stops there; else getTriangulateCovMat; mode 1 adds the gate of every view (> 1 fails)
+__device__ __noinline__ bool cls_triangulate(const ClsArgs& A, const int* slotOf, const ClsView* v, int nv, double* M, double* cov, int mode) {
+    UpNormalEq E;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) E.N[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) E.g[q] = 0;
+    for (int i = 0; i < nv; ++i) {
+        double mx, my;
+        cls_pixel(A, v[i].c, v[i].j, slotOf[v[i].c], mx, my);
+        up_add_view(E, A.cam[v[i].c].iK, cls_R(A, v[i].c, v[i].j), cls_t(A, v[i].c, v[i].j), mx, my);
+    }
+    double cf[6];
+    const double det = up_sym33_cof(E.N, cf);
+    M[0] = ((cf[0] * E.g[0] + cf[1] * E.g[1]) + cf[2] * E.g[2]) / det;
+    M[1] = ((cf[1] * E.g[0] + cf[3] * E.g[1]) + cf[4] * E.g[2]) / det;
+    M[2] = ((cf[2] * E.g[0] + cf[4] * E.g[1]) + cf[5] * E.g[2]) / det;
+    if (mode == 2) return true;
+    double S[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < nv; ++i) {
+        const PuProj q = pu_project(A.cam[v[i].c].K, cls_R(A, v[i].c, v[i].j), cls_t(A, v[i].c, v[i].j), M);
+        up_add_jtj(S, q.J);
+    }
+    const double dS = up_sym33_cof(S, cf), s2 = A.sigma * A.sigma;
+    cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
+    cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
+    cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
+    if (mode == 0) return true;
+    for (int i = 0; i < nv; ++i)
+        if (cls_err(A, v[i].c, v[i].j, slotOf[v[i].c], M, cov) > 1.0) return false;
+    return true;
+}
+// isStaticPoint (exclude < 0) / isStaticPointExclude (src/slam/SL_CoSLAMHelper.cpp:117-250)
+__device__ __noinline__ bool cls_is_static(const ClsArgs& A, int m, const double* Mold, double* M, double* cov, int exclude, int numFrame) {
+    ClsView v[2 * PU_MAX_CAMS];
+    int slotOf[PU_MAX_CAMS], nv = 0;
+    const int firstFrame = A.curFrame - numFrame;
+    for (int c = 0; c < A.nCams; ++c) {
+        int s, j0, f, ff;
+        if (c == exclude || !cls_feature(A, m, c, s, j0, f, ff) || f < firstFrame) continue;
+        slotOf[c] = s;
+        v[nv].c = c, v[nv].j = j0, ++nv;
+        const double* C0 = A.cen + 3 * ((size_t)c * A.nHist + j0);
+        const double a0 = C0[0] - Mold[0], a1 = C0[1] - Mold[1], a2 = C0[2] - Mold[2];
+        const double na = (a0 * a0 + a1 * a1) + a2 * a2;
+        int best = -1;
+        double bestCos = 1.0;
+        const int lo = ff > firstFrame ? ff : firstFrame;
+        for (int fr = f - 1; fr >= lo; --fr) {  // fp = fp->preFrame while fp->f >= firstFrame
+            const int j = A.curFrame - fr;
+            if (j >= A.nHist) break;
+            const double* Cj = A.cen + 3 * ((size_t)c * A.nHist + j);
+            const double b0 = Cj[0] - Mold[0], b1 = Cj[1] - Mold[1], b2 = Cj[2] - Mold[2];
+            const double d = (a0 * b0 + a1 * b1) + a2 * b2;
+            const double nb = (b0 * b0 + b1 * b1) + b2 * b2;
+            const double cv = d / sqrt(na * nb);
+            if (cv < bestCos) bestCos = cv, best = j;
+        }
+        if (best >= 0) v[nv].c = c, v[nv].j = best, ++nv;
+    }
+    return cls_triangulate(A, slotOf, v, nv, M, cov, 1);
+}
+// isDynamicPoint (:251-312)
+__device__ __noinline__ bool cls_is_dynamic(const ClsArgs& A, int m, double* M, double* cov) {
+    ClsView v[PU_MAX_CAMS];
+    int slotOf[PU_MAX_CAMS], nv = 0;
+    for (int c = 0; c < A.nCams; ++c) {
+        int s, j0, f, ff;
+        if (!cls_feature(A, m, c, s, j0, f, ff) || f != A.curFrame) continue;
+        slotOf[c] = s;
+        v[nv].c = c, v[nv].j = 0, ++nv;
+    }
+    if (nv < 2) return false;
+    const double* org = A.cen + 3 * ((size_t)v[0].c * A.nHist);
+    cls_triangulate(A, slotOf, v, nv, M, cov, 2);
+    {
+        const double* R = cls_R(A, v[0].c, 0);
+        const double* t = cls_t(A, v[0].c, 0);
+        if (((R[6] * M[0] + R[7] * M[1]) + R[8] * M[2]) + t[2] < 0) return false;  // isAtCameraBack
+    }
+    double S[6] = {0, 0, 0, 0, 0, 0}, cf[6];
+    for (int i = 0; i < nv; ++i) {
+        const PuProj q = pu_project(A.cam[v[i].c].K, cls_R(A, v[i].c, 0), cls_t(A, v[i].c, 0), M);
+        up_add_jtj(S, q.J);
+    }
+    const double dS = up_sym33_cof(S, cf), s2 = A.sigma * A.sigma;
+    cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
+    cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
+    cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
+    const double sc = (fabs(cov[0]) + fabs(cov[4])) + fabs(cov[8]);
+    const double dx = M[0] - org[0], dy = M[1] - org[1], dz = M[2] - org[2];
+    if (sqrt((dx * dx + dy * dy) + dz * dz) * 0.2 < sqrt(sc)) return false;  // :290-293
+    for (int i = 0; i < nv; ++i)
+        if (cls_err(A, v[i].c, 0, slotOf[v[i].c], M, cov) > 1.0) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_map_points_classify(ClsArgs A) {
+    constexpr int FRAME_NUM_FOR_NEWPOINT = 30, FRAME_NUM_FOR_DONTMOVE = 50, NUM_FRAME_CHECK_STATIC = 60;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= A.nMap) return;
+    // the current list after mapStateUpdate (:1183-1197): points with a feature in this frame; numVisCam counts those features
+    int numVisCam = 0;
+    for (int c = 0; c < A.nCams; ++c) {
+        int s, j0, f, ff;
+        if (cls_feature(A, m, c, s, j0, f, ff) && f == A.curFrame) ++numVisCam;
+    }
+    if (numVisCam == 0) return;
+    const unsigned char fl0 = A.mapFlags[m];
+    unsigned char fl = fl0;
+    const bool uncertain = (fl & CS_MAP_UNCERTAIN) != 0, locDyn = (fl & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) == CS_MAP_DYNAMIC;
+    if (!(uncertain || locDyn)) return;  // :431
+    if (A.counts) atomicAdd(A.counts, 1);
+    double* pM = A.mapPts + 3 * (size_t)m;
+    double* pCov = A.mapCov + 9 * (size_t)m;
+    double Mold[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) Mold[q] = pM[q];
+    double M[3], cov[9];
+    bool write = false;   // updatePosition(M, cov)
+    int sfn = A.staticFrameNum[m];
+    if (numVisCam == 1) {  // :433-437
+        fl = (unsigned char)((fl & ~CS_MAP_DYNAMIC) | CS_MAP_FALSE);
+    } else if (uncertain) {
+        if (A.newPt[m]) {
+            if (cls_is_static(A, m, Mold, M, cov, -1, NUM_FRAME_CHECK_STATIC)) {
+                if (A.curFrame - A.firstFrame[m] > FRAME_NUM_FOR_NEWPOINT) {
+                    fl = 0, sfn = 0;
+                    A.newPt[m] = 0;
+                    write = true;
+                }
+            } else if (cls_is_dynamic(A, m, M, cov)) {
+                fl = CS_MAP_DYNAMIC, sfn = 0;
+                write = true;
+                A.newPt[m] = 0;
+            } else
+                fl = (unsigned char)((fl & ~CS_MAP_DYNAMIC) | CS_MAP_FALSE);
+        } else {
+            if (cls_is_dynamic(A, m, M, cov)) {
+                fl = CS_MAP_DYNAMIC, sfn = 0;
+                write = true;
+            } else {
+                // isStaticRemovable (:67-115): the view with the largest error (> 1) under the point as it stands; static without it?
+                double covOld[9];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) covOld[q] = pCov[q];
+                int maxI = -1, nVis = 0;
+                double maxErr = 1.0;
+                for (int c = 0; c < A.nCams; ++c) {
+                    int s, j0, f, ff;
+                    if (!cls_feature(A, m, c, s, j0, f, ff)) continue;
+                    const double err = cls_err(A, c, j0, s, Mold, covOld);
+                    if (err > maxErr) maxErr = err, maxI = c;
+                    ++nVis;
+                }
+                if (maxI >= 0 && nVis > 2 && cls_is_static(A, m, Mold, M, cov, maxI, NUM_FRAME_CHECK_STATIC)) {  // :476-482
+                    const int s = A.pointFeat[(size_t)m * A.nCams + maxI];
+                    if (A.cam[maxI].slot2map) const_cast<int*>(A.cam[maxI].slot2map)[s] = -1;
+                    A.pointFeat[(size_t)m * A.nCams + maxI] = -1;
+                    fl = 0, sfn = 0;
+                    write = true;
+                } else
+                    fl = (unsigned char)((fl & ~CS_MAP_DYNAMIC) | CS_MAP_FALSE);
+            }
+        }
+    } else {  // locally dynamic (:489-516)
+        if (cls_is_dynamic(A, m, M, cov)) {
+            bool little = true;
+            for (int c = 0; c < A.nCams && little; ++c) {  // isLittleMove: >= 1 fails
+                int s, j0, f, ff;
+                if (!cls_feature(A, m, c, s, j0, f, ff)) continue;
+                if (cls_err(A, c, j0, s, M, cov) >= 1) little = false;
+            }
+            if (little) {
+                ++sfn;
+                if (sfn > FRAME_NUM_FOR_DONTMOVE) {
+                    double M0[3], cov0[9];
+                    if (cls_is_static(A, m, Mold, M0, cov0, -1, NUM_FRAME_CHECK_STATIC)) {
+                        fl = 0, sfn = 0;
+                        for (int c = 0; c < A.nCams; ++c) {
+                            int s, j0, f, ff;
+                            if (cls_feature(A, m, c, s, j0, f, ff) && f == A.curFrame) A.cam[c].isStatic[s] = 1;
+                        }
+                    } else
+                        sfn = 0;
+                }
+            } else
+                sfn = 0;
+            write = true;  // :512: the dynamic triangulation is what stays, also for a point that went back to static
+        } else
+            fl = (unsigned char)((fl & ~CS_MAP_DYNAMIC) | CS_MAP_FALSE);
+    }
+    if (write) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pM[q] = M[q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) pCov[q] = cov[q];
+    }
+    A.staticFrameNum[m] = sfn;
+    A.mapFlags[m] = fl;
+    if (A.counts && (fl & CS_MAP_FALSE) && !(fl0 & CS_MAP_FALSE)) atomicAdd(A.counts + 1, 1);
+}
+
 // poses of (camera, frame) pairs into the ring: what RobustBundleRTS::output() writes through the CamPoseItem pointers the features
 // share (src/app/SL_CoSLAMRobustBA.cpp:283-285 key poses, :239-244 relaxed non-key poses)
 __global__ __launch_bounds__(256) void k_history_set_poses(int n, const int* __restrict__ cam, const int* __restrict__ frame,
@@ -880,4 +1158,45 @@ extern "C" int cs_refine_map_points_dev(const cs_track_history* h, void* hip_str
     A.sigma = pixelErrVar;
     A.refine = 1, A.select = d_select;
     return up_launch("cs_refine_map_points_dev", h, hip_stream, cams, A, d_count, 1);
+}
+
+extern "C" int cs_map_points_classify_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int* d_pointFeat,
+                                          int nMap, const int* d_featFrame, const int* d_featFirst, int curFrame, double* d_mapPts,
+                                          double* d_mapCov, unsigned char* d_mapFlags, unsigned char* d_newPt, int* d_staticFrameNum,
+                                          const int* d_firstFrame, double pixelVar, int* d_counts) {
+    if (!h || !cams || nMap < 0 ||
+        (nMap > 0 && (!d_pointFeat || !d_mapPts || !d_mapCov || !d_mapFlags || !d_newPt || !d_staticFrameNum || !d_firstFrame))) {
+        cs_set_error("cs_map_points_classify_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (h->count < 1 || curFrame != h->lastFrame) {
+        cs_set_error("cs_map_points_classify_dev: the history's newest entry must be frame %d (it holds %d frame(s), the newest %d)", curFrame,
+                     h->count, h->lastFrame);
+        return CS_ERR_INVALID;
+    }
+    ClsArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = h->nCams, A.N = h->N, A.nMap = nMap, A.H = h->H, A.head = h->head, A.nHist = h->count, A.curFrame = curFrame;
+    A.pointFeat = d_pointFeat, A.featFrame = d_featFrame, A.featFirst = d_featFirst;
+    A.histXY = h->xy, A.histR = h->R, A.histT = h->t, A.cen = h->cen;
+    A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.mapFlags = d_mapFlags, A.newPt = d_newPt, A.staticFrameNum = d_staticFrameNum;
+    A.firstFrame = d_firstFrame;
+    A.sigma = pixelVar;
+    A.counts = d_counts;
+    for (int c = 0; c < h->nCams; ++c) {
+        if (!cams[c].K || !cams[c].iK || !cams[c].trackSpan || !cams[c].isStatic) {
+            cs_set_error("cs_map_points_classify_dev: null pointer in camera %d (K, iK, trackSpan, isStatic; slot2map if given is written)", c);
+            return CS_ERR_INVALID;
+        }
+        A.cam[c] = cams[c];
+    }
+    CS_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (d_counts) CS_HIP(hipMemsetAsync(d_counts, 0, 2 * sizeof(int), s));
+    if (nMap == 0) return CS_OK;
+    hipLaunchKernelGGL(k_ring_centres, dim3((h->nCams * h->count + 255) / 256), dim3(256), 0, s, h->nCams, h->H, h->head, h->count, h->R, h->t,
+                       h->cen);
+    hipLaunchKernelGGL(k_map_points_classify, dim3((nMap + 255) / 256), dim3(256), 0, s, A);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
 }

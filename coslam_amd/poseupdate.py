@@ -116,3 +116,13 @@ class TrackHistory:
         check(self._L.cs_refine_map_points_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), vp(d_pointFeat), int(nMap), vp(d_select),
                                                vp(d_mapPts), vp(d_mapCov), C.c_double(pixelErrVar), vp(d_count)),
               "cs_refine_map_points_dev")
+
+    def map_points_classify_dev(self, stream_ptr, cams, d_pointFeat, nMap, curFrame, d_mapPts, d_mapCov, d_mapFlags, d_newPt,
+                                d_staticFrameNum, d_firstFrame, pixelVar=12.0, d_featFrame=None, d_featFirst=None, d_counts=None):
+        """CoSLAM::mapPointsClassify (reference src/app/SL_CoSLAM.cpp:418-520; CoSLAM::poseUpdate calls it with 12.0 every frame):
+        the uncertain and the dynamic map points of this frame decided again, in place."""
+        vp = C.c_void_p
+        check(self._L.cs_map_points_classify_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), vp(d_pointFeat), int(nMap),
+                                                 vp(d_featFrame), vp(d_featFirst), int(curFrame), vp(d_mapPts), vp(d_mapCov),
+                                                 vp(d_mapFlags), vp(d_newPt), vp(d_staticFrameNum), vp(d_firstFrame),
+                                                 C.c_double(pixelVar), vp(d_counts)), "cs_map_points_classify_dev")

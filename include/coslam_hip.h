@@ -410,6 +410,25 @@ int cs_update_new_poses_points_dev(const cs_track_history* h, void* hip_stream, 
 int cs_refine_map_points_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap,
                              const unsigned char* d_select, double* d_mapPts, double* d_mapCov, double pixelErrVar, int* d_count);
 
+/* CoSLAM::mapPointsClassify (src/app/SL_CoSLAM.cpp:418-520) in one launch: what CoSLAM::poseUpdate runs every frame behind the pose
+ * update (:381-385, pixelVar = 12.0) -- every map point with a feature in this frame that is uncertain (CS_MAP_UNCERTAIN: what the
+ * gate of cs_pose_update_frame_dev made of it) or locally dynamic is decided again: static (isStaticPoint over the last 60 frames),
+ * dynamic (isDynamicPoint), static without its worst view (isStaticRemovable: that feature is detached), or false; dynamic points
+ * that stand still for more than 50 frames (isLittleMove) may return to static (src/slam/SL_CoSLAMHelper.cpp:67-330).  In / out per
+ * point: d_mapPts, d_mapCov, d_mapFlags (setFalse keeps CS_MAP_UNCERTAIN and clears CS_MAP_DYNAMIC, setLocalDynamic / setLocalStatic
+ * clear the others), d_newPt (MapPoint::bNewPt, uint8), d_staticFrameNum; in: d_firstFrame (MapPoint::firstFrame).  A point's
+ * features are MapPoint::pFeatures[iCam]: d_pointFeat [nMap][nCams] (slot, < 0 none; a detached feature becomes -1 and its slot's
+ * entry in cams[c].slot2map -- written through the const pointer when given -- too), with, optionally, d_featFrame (the feature's
+ * frame: a camera that lost the point keeps its last feature in the reference and three of the helpers still use it; NULL = all of
+ * this frame) and d_featFirst (first frame of that feature's track; NULL = the slot's trackSpan).  cams: K, iK, trackSpan, isStatic
+ * (feature types; a point that returns to static sets its current features' types), slot2map.  Pixels and poses come from the
+ * history h, whose newest entry must be curFrame; features older than the history are treated as absent (60 frames are looked at).
+ * d_counts [2] or NULL: points examined / points that became false.  One lane per map point (the examined points are few). */
+int cs_map_points_classify_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int* d_pointFeat, int nMap,
+                               const int* d_featFrame, const int* d_featFirst, int curFrame, double* d_mapPts, double* d_mapCov,
+                               unsigned char* d_mapFlags, unsigned char* d_newPt, int* d_staticFrameNum, const int* d_firstFrame,
+                               double pixelVar, int* d_counts);
+
 /* ------------------------------------------------------------------------------------------
  * Pose-graph relaxation of the non-key frames after a bundle adjustment, all camera graphs in one launch
  * ------------------------------------------------------------------------------------------

@@ -315,6 +315,39 @@ def refine_map_points(Ks, iKs, histR, histT, histXY, trackSpan, pointFeat, mapPt
                                    _p(sel) if sel is not None else None, _p(mapPts), _p(mapCov), C.c_double(sigma), int(bool(cmpAcos)))
 
 
+def map_points_classify(Ks, iKs, histR, histT, histXY, trackSpan, featStatic, pointFeat, curFrame, mapPts, mapCov, mapFlags, newPt,
+                        staticFrameNum, firstFrame, pixelVar, featFrame=None, featFirst=None, slot2map=None):
+    """opu_map_points_classify (CoSLAM::mapPointsClassify, one frame; layouts as update_new_poses_points).  featStatic (nC x N uint8),
+    pointFeat (nMap x nC int32), mapPts, mapCov, mapFlags, newPt (uint8), staticFrameNum (int32) and slot2map (nC x N int32, optional)
+    are updated IN PLACE.  Returns (points examined, points that became false)."""
+    L = lib()
+    L.opu_map_points_classify.restype = C.c_int
+    histR = np.ascontiguousarray(histR, dtype=np.float64)
+    histT = np.ascontiguousarray(histT, dtype=np.float64)
+    histXY = np.ascontiguousarray(histXY, dtype=np.float64)
+    nC, nH = histR.shape[0], histR.shape[1]
+    N = histXY.shape[2] // 2
+    Ks = np.ascontiguousarray(Ks, dtype=np.float64).reshape(nC, 9)
+    iKs = np.ascontiguousarray(iKs, dtype=np.float64).reshape(nC, 9)
+    sp = np.ascontiguousarray(trackSpan, dtype=np.int32).reshape(nC, 2 * N)
+    nMap = pointFeat.shape[0]
+    for a, dt in ((featStatic, np.uint8), (pointFeat, np.int32), (mapPts, np.float64), (mapCov, np.float64), (mapFlags, np.uint8),
+                  (newPt, np.uint8), (staticFrameNum, np.int32)):
+        assert a.dtype == dt and a.flags.c_contiguous
+    assert pointFeat.shape == (nMap, nC) and featStatic.shape == (nC, N)
+    ff = None if featFrame is None else np.ascontiguousarray(featFrame, dtype=np.int32)
+    f1 = None if featFirst is None else np.ascontiguousarray(featFirst, dtype=np.int32)
+    fr = np.ascontiguousarray(firstFrame, dtype=np.int32)
+    if slot2map is not None:
+        assert slot2map.dtype == np.int32 and slot2map.flags.c_contiguous and slot2map.shape == (nC, N)
+    nf = C.c_int(0)
+    n = L.opu_map_points_classify(nC, N, nH, _p(Ks), _p(iKs), _p(histR), _p(histT), _p(histXY), _p(sp), _p(featStatic),
+                                  _p(slot2map) if slot2map is not None else None, nMap, _p(pointFeat),
+                                  _p(ff) if ff is not None else None, _p(f1) if f1 is not None else None, int(curFrame), _p(mapPts),
+                                  _p(mapCov), _p(mapFlags), _p(newPt), _p(staticFrameNum), _p(fr), C.c_double(pixelVar), C.byref(nf))
+    return n, nf.value
+
+
 def static_check_mergability(K, histR, histT, histXY, slot, length, M, cov, pixelVar):
     """org_static_check_mergability (CoSLAM::staticCheckMergability): histR (nHist x 9), histT (nHist x 3), histXY (nHist x 2N),
     entry 0 = this frame; the track of `slot` covers the `length` newest entries.  Returns True / False."""

@@ -174,6 +174,11 @@ int opu_update_new_poses_points(int nCams, int N, int nHist, const double* Ks, c
                                 int nMap, const int* pointFeat, const int* lastFrame, const unsigned char* isCurrent,
                                 int firstKeyFrame, double* mapPts, double* mapCov, const unsigned char* mapFlags, double sigma,
                                 int cmpAcos, int* chosen, int* nStat, int* nDyn);
+int opu_map_points_classify(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
+                            const double* histXY, const int* trackSpan, unsigned char* featStatic, int* slot2map, int nMap, int* pointFeat,
+                            const int* featFrame, const int* featFirst, int curFrame, double* mapPts, double* mapCov,
+                            unsigned char* mapFlags, unsigned char* newPt, int* staticFrameNum, const int* firstFrame, double pixelVar,
+                            int* numFalse);
 int opu_refine_map_points(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
                           const double* histXY, const int* trackSpan, int nMap, const int* pointFeat, const unsigned char* select,
                           double* mapPts, double* mapCov, double sigma, int cmpAcos);

@@ -385,3 +385,279 @@ int opu_refine_map_points(int nCams, int N, int nHist, const double* Ks, const d
     return update_points_core(nCams, N, nHist, Ks, iKs, histR, histT, histXY, trackSpan, 0, nMap, pointFeat, 0, 0, 0, mapPts, mapCov, 0,
                               sigma, cmpAcos, 0, 0, 0, 1, select);
 }
+
+/* ---- CoSLAM::mapPointsClassify (/root/reference/src/app/SL_CoSLAM.cpp:418-520) --------------------------------------------------
+ * Every frame, behind the pose update (CoSLAM::poseUpdate, :381-385: mapStateUpdate(), then mapPointsClassify(12.0)), every map point
+ * of the current list that is uncertain (what the gate of poseUpdate3D made of it) or locally dynamic is re-examined:
+ *   seen by one camera only                            -> false (:434-438)
+ *   uncertain, new (bNewPt)   isStaticPoint over the last 60 frames?  yes: older than 30 frames -> static at the new position
+ *                             (else it stays uncertain);  no: isDynamicPoint?  yes -> dynamic at the new position, no -> false
+ *   uncertain, not new        isDynamicPoint? yes -> dynamic; no: isStaticRemovable (drop the view with the largest error, static
+ *                             from the rest)?  yes -> that feature is detached, static at the new position;  no -> false
+ *   dynamic                   isDynamicPoint? no -> false;  yes: moved little (isLittleMove)?  count the frames; beyond 50 and
+ *                             isStaticPoint -> static again (its features' types too) -- but the position written last is the
+ *                             dynamic one in every branch (:512 follows the if / else)
+ * with the helpers of src/slam/SL_CoSLAMHelper.cpp: isStaticPoint (:117-181), isStaticPointExclude (:183-250), isDynamicPoint
+ * (:251-312), isLittleMove (:314-330), isStaticRemovable (:67-115).  A point's features are MapPoint::pFeatures[iCam]: the table
+ * pointFeat (slot per camera, < 0 none) with, optionally, featFrame (the feature's frame; NULL: all of this frame) and featFirst (the
+ * first frame of its track; NULL: trackSpan of the slot) -- a camera that lost the point keeps its last feature in the reference, and
+ * isStaticPoint / isLittleMove / isStaticRemovable still use it while it is young enough.  Pixels and poses of a feature's frame and
+ * of the frames before it come from the history (entry = curFrame - frame; a feature older than the history is treated as absent).
+ * PARITY: the state machine and the helpers' loops are pinned against the reference's own SL_CoSLAM.cpp + SL_CoSLAMHelper.cpp
+ * compiled in place (tests/cxx/ref_classify_test.cpp -> tests/golden/classify_golden.npz); UNPINNED are the LibVisualSLAM helpers
+ * (as above, plus isAtCameraBack(R, t, M) = (R M + t).z < 0 and dist3 = Euclidean distance). */
+typedef struct {
+    int nCams, N, nHist, curFrame;
+    const double *Ks, *iKs, *histR, *histT, *histXY;
+    const int* trackSpan;
+    const int *featFrame, *featFirst; /* [nMap][nCams] or NULL */
+} opu_cls_ctx;
+
+typedef struct {
+    int c, j; /* camera, history entry */
+} opu_view;
+
+/* the feature of point m in camera c: slot, history entry of its frame, first frame of its track; 0 if none (or older than the history) */
+static int cls_feature(const opu_cls_ctx* X, const int* pf, int m, int c, int* slot, int* j0, int* frame, int* first) {
+    const int s = pf[(size_t)m * X->nCams + c];
+    if (s < 0) return 0;
+    const int f = X->featFrame ? X->featFrame[(size_t)m * X->nCams + c] : X->curFrame;
+    const int j = X->curFrame - f;
+    if (j < 0 || j >= X->nHist) return 0;
+    *slot = s, *j0 = j, *frame = f;
+    *first = X->featFirst ? X->featFirst[(size_t)m * X->nCams + c] : X->trackSpan[(size_t)c * 2 * X->N + s];
+    return 1;
+}
+static const double* cls_R(const opu_cls_ctx* X, int c, int j) { return X->histR + ((size_t)c * X->nHist + j) * 9; }
+static const double* cls_t(const opu_cls_ctx* X, int c, int j) { return X->histT + ((size_t)c * X->nHist + j) * 3; }
+static void cls_pixel(const opu_cls_ctx* X, int c, int j, int s, double* mx, double* my) {
+    const double* h = X->histXY + ((size_t)c * X->nHist + j) * 2 * X->N;
+    *mx = h[s], *my = h[X->N + s];
+}
+/* triangulateMultiView + getTriangulateCovMat over a view list, then the reprojection gate of every view (> 1.0 fails) */
+static int cls_triangulate_and_gate(const opu_cls_ctx* X, const int* slotOf, const opu_view* v, int nv, double sigma, double* M, double* cov,
+                                    int gate) {
+    opu_normal_eq E;
+    memset(&E, 0, sizeof(E));
+    for (int i = 0; i < nv; i++) {
+        double mx, my;
+        cls_pixel(X, v[i].c, v[i].j, slotOf[v[i].c], &mx, &my);
+        ne_add_view(&E, X->iKs + 9 * v[i].c, cls_R(X, v[i].c, v[i].j), cls_t(X, v[i].c, v[i].j), mx, my);
+    }
+    double cf[6];
+    const double det = sym33_cof(E.N, cf);
+    M[0] = ((cf[0] * E.g[0] + cf[1] * E.g[1]) + cf[2] * E.g[2]) / det;
+    M[1] = ((cf[1] * E.g[0] + cf[3] * E.g[1]) + cf[4] * E.g[2]) / det;
+    M[2] = ((cf[2] * E.g[0] + cf[4] * E.g[1]) + cf[5] * E.g[2]) / det;
+    if (gate == 2) return 1; /* isDynamicPoint looks at the point before it asks for the covariance */
+    double S[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < nv; i++) cov_add_view(S, X->Ks + 9 * v[i].c, cls_R(X, v[i].c, v[i].j), cls_t(X, v[i].c, v[i].j), M);
+    const double dS = sym33_cof(S, cf), s2 = sigma * sigma;
+    cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
+    cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
+    cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
+    if (!gate) return 1;
+    for (int i = 0; i < nv; i++) {
+        double rm[2], var[4], ivar[4], mx, my;
+        cls_pixel(X, v[i].c, v[i].j, slotOf[v[i].c], &mx, &my);
+        org_project(X->Ks + 9 * v[i].c, cls_R(X, v[i].c, v[i].j), cls_t(X, v[i].c, v[i].j), M, rm);
+        org_projection_cov(X->Ks + 9 * v[i].c, cls_R(X, v[i].c, v[i].j), cls_t(X, v[i].c, v[i].j), M, cov, var, sigma);
+        mat22_inv(var, ivar);
+        if (maha_dist2(rm, mx, my, ivar) > 1.0) return 0;
+    }
+    return 1;
+}
+/* isStaticPoint (exclude < 0) / isStaticPointExclude: the views of updateStaticPointPosition inside the window of numFrame frames */
+static int cls_is_static(const opu_cls_ctx* X, const int* pf, int m, const double* Mold, double sigma, double* M, double* cov, int exclude,
+                         int numFrame) {
+    opu_view v[64];
+    int slotOf[32], nv = 0;
+    const int firstFrame = X->curFrame - numFrame; /* p->lastFrame - numFrame; lastFrame == curFrame on the current list */
+    for (int c = 0; c < X->nCams; c++) {
+        int s, j0, f, ff;
+        if (c == exclude || !cls_feature(X, pf, m, c, &s, &j0, &f, &ff) || f < firstFrame) continue;
+        slotOf[c] = s;
+        v[nv].c = c, v[nv].j = j0, nv++;
+        double C0[3];
+        cam_center(cls_R(X, c, j0), cls_t(X, c, j0), C0);
+        int best = -1;
+        double bestCos = 1.0;
+        const int lo = ff > firstFrame ? ff : firstFrame;
+        for (int fr = f - 1; fr >= lo; fr--) { /* fp = fp->preFrame while fp->f >= firstFrame */
+            const int j = X->curFrame - fr;
+            if (j >= X->nHist) break;
+            double Cj[3];
+            cam_center(cls_R(X, c, j), cls_t(X, c, j), Cj);
+            const double cv = cos_between(Mold, C0, Cj);
+            if (cv < bestCos) bestCos = cv, best = j;
+        }
+        if (best >= 0) v[nv].c = c, v[nv].j = best, nv++;
+    }
+    return cls_triangulate_and_gate(X, slotOf, v, nv, sigma, M, cov, 1);
+}
+/* isDynamicPoint: this frame's features only */
+static int cls_is_dynamic(const opu_cls_ctx* X, const int* pf, const unsigned char* featStatic, int m, double sigma, double* M, double* cov) {
+    opu_view v[32];
+    int slotOf[32], nv = 0;
+    for (int c = 0; c < X->nCams; c++) {
+        int s, j0, f, ff;
+        if (!cls_feature(X, pf, m, c, &s, &j0, &f, &ff) || f != X->curFrame) continue;
+        slotOf[c] = s;
+        v[nv].c = c, v[nv].j = 0, nv++;
+    }
+    (void)featStatic; /* (:269-270 count the dynamic features and never use the count) */
+    if (nv < 2) return 0;
+    double org[3];
+    cam_center(cls_R(X, v[0].c, 0), cls_t(X, v[0].c, 0), org);
+    cls_triangulate_and_gate(X, slotOf, v, nv, sigma, M, cov, 2);
+    {
+        const double* R = cls_R(X, v[0].c, 0);
+        const double* t = cls_t(X, v[0].c, 0);
+        if (((R[6] * M[0] + R[7] * M[1]) + R[8] * M[2]) + t[2] < 0) return 0; /* isAtCameraBack */
+    }
+    /* (the covariance and the gate: the same sums as above, recomputed -- the reference calls the helpers in this order) */
+    double S[6] = {0, 0, 0, 0, 0, 0}, cf[6];
+    for (int i = 0; i < nv; i++) cov_add_view(S, X->Ks + 9 * v[i].c, cls_R(X, v[i].c, 0), cls_t(X, v[i].c, 0), M);
+    const double dS = sym33_cof(S, cf), s2 = sigma * sigma;
+    cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
+    cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
+    cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
+    const double sc = (fabs(cov[0]) + fabs(cov[4])) + fabs(cov[8]);
+    const double dx = M[0] - org[0], dy = M[1] - org[1], dz = M[2] - org[2];
+    if (sqrt((dx * dx + dy * dy) + dz * dz) * 0.2 < sqrt(sc)) return 0; /* :290-293 */
+    for (int i = 0; i < nv; i++) {
+        double rm[2], var[4], ivar[4], mx, my;
+        cls_pixel(X, v[i].c, 0, slotOf[v[i].c], &mx, &my);
+        org_project(X->Ks + 9 * v[i].c, cls_R(X, v[i].c, 0), cls_t(X, v[i].c, 0), M, rm);
+        org_projection_cov(X->Ks + 9 * v[i].c, cls_R(X, v[i].c, 0), cls_t(X, v[i].c, 0), M, cov, var, sigma);
+        mat22_inv(var, ivar);
+        if (maha_dist2(rm, mx, my, ivar) > 1.0) return 0;
+    }
+    return 1;
+}
+/* the Mahalanobis distance of a feature (any frame of the history) from the projection of (M, cov) under its own frame's pose */
+static double cls_feature_err(const opu_cls_ctx* X, int c, int j, int s, const double* M, const double* cov, double sigma) {
+    double rm[2], var[4], ivar[4], mx, my;
+    cls_pixel(X, c, j, s, &mx, &my);
+    org_project(X->Ks + 9 * c, cls_R(X, c, j), cls_t(X, c, j), M, rm);
+    org_projection_cov(X->Ks + 9 * c, cls_R(X, c, j), cls_t(X, c, j), M, cov, var, sigma);
+    mat22_inv(var, ivar);
+    return maha_dist2(rm, mx, my, ivar);
+}
+
+/* One frame's mapPointsClassify over the points that have a feature in this frame.  In / out per point: mapPts, mapCov, mapFlags
+ * (bit 0 dynamic, bit 1 false, bit 2 uncertain), newPt (MapPoint::bNewPt), staticFrameNum; in: firstFrame (MapPoint::firstFrame).
+ * In / out tables: pointFeat (a detached feature becomes -1), slot2map [nCams][N] (or NULL; the detached feature's slot becomes
+ * -1), featStatic [nCams][N] (feature types; a point that returns to static sets its features' types to static).  Returns the number
+ * of points examined; *numFalse = those that became false. */
+int opu_map_points_classify(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
+                            const double* histXY, const int* trackSpan, unsigned char* featStatic, int* slot2map, int nMap, int* pointFeat,
+                            const int* featFrame, const int* featFirst, int curFrame, double* mapPts, double* mapCov,
+                            unsigned char* mapFlags, unsigned char* newPt, int* staticFrameNum, const int* firstFrame, double pixelVar,
+                            int* numFalse) {
+    const int FRAME_NUM_FOR_NEWPOINT = 30, FRAME_NUM_FOR_DONTMOVE = 50, NUM_FRAME_CHECK_STATIC = 60;
+    opu_cls_ctx X = {nCams, N, nHist, curFrame, Ks, iKs, histR, histT, histXY, trackSpan, featFrame, featFirst};
+    int nExamined = 0, nFalse = 0;
+    for (int m = 0; m < nMap; m++) {
+        /* the current list after mapStateUpdate (:1183-1197): points with a feature in this frame; numVisCam counts those features */
+        int numVisCam = 0;
+        for (int c = 0; c < nCams; c++) {
+            int s, j0, f, ff;
+            if (cls_feature(&X, pointFeat, m, c, &s, &j0, &f, &ff) && f == curFrame) numVisCam++;
+        }
+        if (numVisCam == 0) continue;
+        unsigned char fl = mapFlags[m];
+        const int uncertain = (fl & OPU_UNCERTAIN) != 0, locDyn = (fl & (OPU_DYNAMIC | OPU_FALSE)) == OPU_DYNAMIC;
+        if (!(uncertain || locDyn)) continue; /* :431 */
+        nExamined++;
+        double* pM = mapPts + 3 * (size_t)m;
+        double* pCov = mapCov + 9 * (size_t)m;
+#define SET_FALSE() (fl = (unsigned char)((fl & ~OPU_DYNAMIC) | OPU_FALSE))
+#define SET_DYNAMIC() (fl = OPU_DYNAMIC, staticFrameNum[m] = 0)
+#define SET_STATIC() (fl = 0, staticFrameNum[m] = 0)
+#define UPDATE_POS(Mn, Cn) (memcpy(pM, Mn, 24), memcpy(pCov, Cn, 72))
+        if (numVisCam == 1) { /* :433-437 */
+            SET_FALSE();
+            if (!(mapFlags[m] & OPU_FALSE)) nFalse++;
+            mapFlags[m] = fl;
+            continue;
+        }
+        double M[3], cov[9];
+        if (uncertain) {
+            if (newPt[m]) {
+                if (cls_is_static(&X, pointFeat, m, pM, pixelVar, M, cov, -1, NUM_FRAME_CHECK_STATIC)) {
+                    if (curFrame - firstFrame[m] > FRAME_NUM_FOR_NEWPOINT) { /* p->lastFrame - p->firstFrame */
+                        SET_STATIC();
+                        newPt[m] = 0;
+                        UPDATE_POS(M, cov);
+                    }
+                } else if (cls_is_dynamic(&X, pointFeat, featStatic, m, pixelVar, M, cov)) {
+                    SET_DYNAMIC();
+                    UPDATE_POS(M, cov);
+                    newPt[m] = 0;
+                } else
+                    SET_FALSE();
+            } else {
+                if (cls_is_dynamic(&X, pointFeat, featStatic, m, pixelVar, M, cov)) {
+                    SET_DYNAMIC();
+                    UPDATE_POS(M, cov);
+                } else {
+                    /* isStaticRemovable: the view with the largest error (> 1) under the point as it stands; static without it? */
+                    int maxI = -1, nVis = 0;
+                    double maxErr = 1.0;
+                    for (int c = 0; c < nCams; c++) {
+                        int s, j0, f, ff;
+                        if (!cls_feature(&X, pointFeat, m, c, &s, &j0, &f, &ff)) continue;
+                        const double err = cls_feature_err(&X, c, j0, s, pM, pCov, pixelVar);
+                        if (err > maxErr) maxErr = err, maxI = c;
+                        nVis++;
+                    }
+                    int out = -1;
+                    if (maxI >= 0 && nVis > 2 && cls_is_static(&X, pointFeat, m, pM, pixelVar, M, cov, maxI, NUM_FRAME_CHECK_STATIC)) out = maxI;
+                    if (out >= 0) { /* :476-482 */
+                        const int s = pointFeat[(size_t)m * nCams + out];
+                        if (slot2map) slot2map[(size_t)out * N + s] = -1;
+                        pointFeat[(size_t)m * nCams + out] = -1;
+                        SET_STATIC();
+                        UPDATE_POS(M, cov);
+                    } else
+                        SET_FALSE();
+                }
+            }
+        } else { /* locally dynamic (:489-516) */
+            if (cls_is_dynamic(&X, pointFeat, featStatic, m, pixelVar, M, cov)) {
+                int little = 1;
+                for (int c = 0; c < nCams && little; c++) { /* isLittleMove: >= 1 fails */
+                    int s, j0, f, ff;
+                    if (!cls_feature(&X, pointFeat, m, c, &s, &j0, &f, &ff)) continue;
+                    if (cls_feature_err(&X, c, j0, s, M, cov, pixelVar) >= 1) little = 0;
+                }
+                if (little) {
+                    staticFrameNum[m]++;
+                    if (staticFrameNum[m] > FRAME_NUM_FOR_DONTMOVE) {
+                        double M0[3], cov0[9];
+                        if (cls_is_static(&X, pointFeat, m, pM, pixelVar, M0, cov0, -1, NUM_FRAME_CHECK_STATIC)) {
+                            SET_STATIC();
+                            for (int c = 0; c < nCams; c++) {
+                                int s, j0, f, ff;
+                                if (cls_feature(&X, pointFeat, m, c, &s, &j0, &f, &ff) && f == curFrame) featStatic[(size_t)c * N + s] = 1;
+                            }
+                        } else
+                            staticFrameNum[m] = 0;
+                    }
+                } else
+                    staticFrameNum[m] = 0;
+                UPDATE_POS(M, cov); /* :512: the dynamic triangulation is what stays, also for a point that went back to static */
+            } else
+                SET_FALSE();
+        }
+        if ((fl & OPU_FALSE) && !(mapFlags[m] & OPU_FALSE)) nFalse++;
+        mapFlags[m] = fl;
+#undef SET_FALSE
+#undef SET_DYNAMIC
+#undef SET_STATIC
+#undef UPDATE_POS
+    }
+    if (numFalse) *numFalse = nFalse;
+    return nExamined;
+}

@@ -6,7 +6,6 @@
 #ifndef REF_SHIM_NOT_ON_PATH_H
 #define REF_SHIM_NOT_ON_PATH_H
 template <class... A> void scaleDownAvg(const A&...);
-template <class... A> bool isAtCameraBack(const A&...);
 template <class... A> int searchNearestPoint(const A&...);
 template <class... A> double reprojErrorSingle(const A&...);
 template <class... A> bool intraCamEstimateEpi(const A&...);
@@ -21,7 +20,11 @@ void triangulateMultiView(int nView, const double* Rs, const double* ts, const d
 void getTriangulateCovMat(int nView, const double* Ks, const double* Rs, const double* ts, const double* M, double* cov, double sigma);
 void getInvK(const double* K, double* iK);
 double getAbsRadiansBetween(const double* M, const double* C0, const double* C);
+bool isAtCameraBack(const double* R, const double* t, const double* M);   /* isDynamicPoint (:283) */
+double dist3(const double* a, const double* b);                           /* isDynamicPoint (:290) */
 #else
+template <class... A> bool isAtCameraBack(const A&...);
+template <class... A> double dist3(const A&...);
 template <class... A> void normPoint(const A&...);
 template <class... A> void getCameraCenter(const A&...);
 template <class... A> void triangulateMultiView(const A&...);
@@ -29,7 +32,6 @@ template <class... A> void getTriangulateCovMat(const A&...);
 template <class... A> void getInvK(const A&...);
 template <class... A> double getAbsRadiansBetween(const A&...);
 #endif
-template <class... A> double dist3(const A&...);
 template <class... A> void binTriangulate(const A&...);
 #define CV_8UC1 0
 namespace cv {

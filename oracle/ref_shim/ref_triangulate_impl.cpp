@@ -10,6 +10,7 @@
 //   triangulateMultiView  linear least squares of (r1 - x r3) M = x t3 - t1, (r2 - y r3) M = y t3 - t2 over the views, normal
 //                         equations, symmetric 3x3 inverse by cofactors
 //   getTriangulateCovMat  sigma^2 (sum_i J_i^T J_i)^-1 with J_i = d project_i / dM at M
+//   isAtCameraBack, dist3 (isDynamicPoint, :251-312)
 #include <cmath>
 #include <cstring>
 
@@ -87,4 +88,10 @@ void getTriangulateCovMat(int nView, const double* Ks, const double* Rs, const d
     cov[0] = (c[0] / dS) * s2, cov[1] = (c[1] / dS) * s2, cov[2] = (c[2] / dS) * s2;
     cov[3] = cov[1], cov[4] = (c[3] / dS) * s2, cov[5] = (c[4] / dS) * s2;
     cov[6] = cov[2], cov[7] = cov[5], cov[8] = (c[5] / dS) * s2;
+}
+// isAtCameraBack(R, t, M) = (R M + t).z < 0 (as register.hip / register_oracle.c define it); dist3 = Euclidean distance
+bool isAtCameraBack(const double* R, const double* t, const double* M) { return ((R[6] * M[0] + R[7] * M[1]) + R[8] * M[2]) + t[2] < 0; }
+double dist3(const double* a, const double* b) {
+    const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return sqrt((dx * dx + dy * dy) + dz * dz);
 }

@@ -342,10 +342,96 @@ def update_points_case():
     return out
 
 
+def classify_case():
+    """the reference's own CoSLAM::mapPointsClassify over isStaticPoint / isStaticPointExclude / isDynamicPoint / isLittleMove /
+    isStaticRemovable (oracle/_ref/ref_classify_test golden, CPU): 3 scenes of 72 map points walking every branch, re-laid out the
+    way the device holds them (slot = point index, ring entry 0 = the current frame), and the points' states afterwards."""
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_classify_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_classify_test missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "c.bin")
+        subprocess.run([exe, "golden", path], check=True, stdout=subprocess.DEVNULL)
+        raw = open(path, "rb").read()
+    o = 0
+
+    def ints(n):
+        nonlocal o
+        v = np.frombuffer(raw, dtype=np.int32, count=n, offset=o).copy()
+        o += 4 * n
+        return v
+
+    def dbls(n):
+        nonlocal o
+        v = np.frombuffer(raw, dtype=np.float64, count=n, offset=o).copy()
+        o += 8 * n
+        return v
+
+    def flags_of(ltype, unc):
+        return (1 if ltype == 1 else 0) | (2 if ltype == -2 else 0) | (4 if unc else 0)
+
+    out = {}
+    (nS,) = ints(1)
+    out["n_scenes"] = np.int32(nS)
+    for sc in range(nS):
+        nC, H, nP, cur = ints(4)
+        (pixelVar,) = dbls(1)
+        K, iK = np.zeros((nC, 9)), np.zeros((nC, 9))
+        for c in range(nC):
+            K[c], iK[c] = dbls(9), dbls(9)
+        hR, hT = np.zeros((nC, H, 9)), np.zeros((nC, H, 3))
+        for c in range(nC):
+            for j in range(H):
+                hR[c, j], hT[c, j] = dbls(9), dbls(3)
+        N = nP
+        hXY = np.zeros((nC, H, 2 * N), np.float32).astype(np.float64)
+        span = np.full((nC, 2 * N), -1, np.int32)
+        fstat = np.ones((nC, N), np.uint8)
+        pf = np.full((nP, nC), -1, np.int32)
+        fframe = np.full((nP, nC), -1, np.int32)
+        ffirst = np.full((nP, nC), -1, np.int32)
+        M0, cov0 = np.zeros((nP, 3)), np.zeros((nP, 9))
+        flags, newpt, sfn, first = np.zeros(nP, np.uint8), np.zeros(nP, np.uint8), np.zeros(nP, np.int32), np.zeros(nP, np.int32)
+        for p in range(nP):
+            M0[p], cov0[p] = dbls(3), dbls(9)
+            ltype, unc, newpt[p], sfn[p], first[p] = ints(5)
+            flags[p] = flags_of(ltype, unc)
+            for c in range(nC):
+                L, back, dyn = ints(3)
+                m = dbls(2 * L).reshape(L, 2)
+                if L:
+                    pf[p, c], fframe[p, c], ffirst[p, c] = p, cur - back, cur - back - L + 1
+                    span[c, p], span[c, N + p] = cur - back - L + 1, cur - back
+                    fstat[c, p] = 0 if dyn else 1
+                    hXY[c, back:back + L, p], hXY[c, back:back + L, N + p] = m[:, 0], m[:, 1]
+        Mr, covr = np.zeros((nP, 3)), np.zeros((nP, 9))
+        flr, newr, sfr = np.zeros(nP, np.uint8), np.zeros(nP, np.uint8), np.zeros(nP, np.int32)
+        has_r, fstat_r = np.zeros((nP, nC), np.uint8), fstat.copy()
+        for p in range(nP):
+            Mr[p], covr[p] = dbls(3), dbls(9)
+            ltype, unc, newr[p], sfr[p] = ints(4)
+            flr[p] = flags_of(ltype, unc)
+            for c in range(nC):
+                has_r[p, c], dyn = ints(2)
+                if has_r[p, c] and fframe[p, c] == cur:
+                    fstat_r[c, p] = 0 if dyn else 1
+        pre = f"s{sc}_"
+        for k, v in dict(K=K, iK=iK, histR=hR, histT=hT, histXY=hXY, trackSpan=span, featStatic=fstat, pointFeat=pf, featFrame=fframe,
+                         featFirst=ffirst, M0=M0, cov0=cov0, flags=flags, newPt=newpt, staticFrameNum=sfn, firstFrame=first,
+                         curFrame=np.int32(cur), pixelVar=np.float64(pixelVar), M_ref=Mr, cov_ref=covr, flags_ref=flr, newPt_ref=newr,
+                         staticFrameNum_ref=sfr, hasFeature_ref=has_r, featStatic_ref=fstat_r).items():
+            out[pre + k] = v
+    assert o == len(raw)
+    return out
+
+
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "update_points"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "update_points", "classify"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -364,4 +450,6 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "mergability_golden.npz"), **mergability_case())
     if "update_points" in which:
         np.savez_compressed(os.path.join(HERE, "update_points_golden.npz"), **update_points_case())
+    if "classify" in which:
+        np.savez_compressed(os.path.join(HERE, "classify_golden.npz"), **classify_case())
     print("golden fixtures written")
