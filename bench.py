@@ -250,6 +250,8 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
     is_static = [np.ones(N_FEAT, dtype=np.uint8) for _ in range(N_CAMS)]
     hist = [dict(R=[], t=[], xy=[]) for _ in range(N_CAMS)]
     iK = np.linalg.inv(sc.K)
+    cls_new, cls_sfn = np.zeros(len(sc.points), dtype=np.uint8), np.zeros(len(sc.points), dtype=np.int32)
+    cls_first = np.zeros(len(sc.points), dtype=np.int32)
 
     def pose_update_all(frame_no):
         for c in range(N_CAMS):
@@ -260,6 +262,14 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
             del h["R"][64:], h["t"][64:], h["xy"][64:]
             oracle.detect_dynamic(iK, np.stack(h["R"]), np.stack(h["t"]), np.stack(h["xy"]), st[c], s2m[c], tl[c], map_flags, 20, 5, 3,
                                   MAX_EPI_ERR, is_static[c])
+        # CoSLAM::mapPointsClassify(12.0) behind the cameras' pose updates
+        pf_all = np.ascontiguousarray(np.stack([oracle.point_features(st[c], s2m[c], len(sc.points)) for c in range(N_CAMS)], 1))
+        fs_all = np.ascontiguousarray(np.stack(is_static))
+        oracle.map_points_classify([Kc] * N_CAMS, [iK] * N_CAMS, np.stack([np.stack(h["R"]) for h in hist]),
+                                   np.stack([np.stack(h["t"]) for h in hist]), np.stack([np.stack(h["xy"]) for h in hist]), np.stack(tl),
+                                   fs_all, pf_all, frame_no, map_pts, map_cov, map_flags, cls_new, cls_sfn, cls_first, 12.0)
+        for c in range(N_CAMS):
+            is_static[c][:] = fs_all[c]
 
     Kc = sc.K
 
@@ -327,6 +337,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="diagnostic: every leg on ONE stream (no overlap)")
+    ap.add_argument("--no-classify", action="store_true",
+                    help="diagnostic: skip mapPointsClassify behind the pose update (not a valid bench line)")
     ap.add_argument("--no-update-points", action="store_true",
                     help="diagnostic: skip updateNewPosesPoints behind the finished joint BA (not a valid bench line)")
     ap.add_argument("--key-every", type=int, default=KEY_EVERY, help="diagnostic: 0 disables the key-frame solves (not a valid bench line)")
@@ -600,6 +612,12 @@ def main():
         d_reproj = torch.zeros((nc, N_FEAT), dtype=torch.float64, device=dev)
         d_mapflags = torch.zeros(n_map, dtype=torch.uint8, device=dev)
         d_mergeable = torch.zeros((P_REG, nc), dtype=torch.uint8, device=dev)
+        # CoSLAM::mapPointsClassify (reference src/app/SL_CoSLAM.cpp:381-385, 418-520): the points the gate made uncertain and the
+        # dynamic ones decided again every frame, one launch behind the pose update (MapPoint::bNewPt / staticFrameNum / firstFrame)
+        d_newpt = torch.zeros(n_map, dtype=torch.uint8, device=dev)
+        d_sfn = torch.zeros(n_map, dtype=torch.int32, device=dev)
+        d_firstfrm = torch.zeros(n_map, dtype=torch.int32, device=dev)
+        d_cls_counts = torch.zeros(2, dtype=torch.int32, device=dev)
         d_iK1 = torch.from_numpy(np.linalg.inv(sc.K).ravel().copy()).to(dev)
         pose_upd = TrackHistory(nc, N_FEAT, PU_HIST, device=local_rank)
         pu_args = poseupdate_cams([dict(K=d_K1.data_ptr(), iK=d_iK1.data_ptr(), xy=d_xy[i].data_ptr(), state=d_state[i].data_ptr(),
@@ -659,6 +677,10 @@ def main():
             pose_upd.pose_update_frame_dev(pose_s.cuda_stream, pu_args, d_pf.data_ptr(), n_map, d_R[dst].data_ptr(),
                                            d_t[dst].data_ptr(), d_map.data_ptr(), d_cov.data_ptr(), d_mapflags.data_ptr(), 0,
                                            PIXEL_ERR_VAR, i, 20, 5, 3, MAX_EPI_ERR)
+            if not args.no_classify:
+                pose_upd.map_points_classify_dev(pose_s.cuda_stream, pu_args, d_pf.data_ptr(), n_map, i, d_map.data_ptr(), d_cov.data_ptr(),
+                                                 d_mapflags.data_ptr(), d_newpt.data_ptr(), d_sfn.data_ptr(), d_firstfrm.data_ptr(), 12.0,
+                                                 d_counts=d_cls_counts.data_ptr())
         if not args.no_register:
             if reg_s is not pose_s:
                 pose_ready.record(pose_s)
@@ -1311,6 +1333,11 @@ def main():
                            "what": "poseUpdate3D's gate + seqTriangulate over all static mapped features and detectDynamicFeaturePoints over "
                                    "all unmapped / dynamic tracks, every frame, one launch for the rank's cameras (cs_pose_update_frame_dev)",
                            "history_frames": pose_upd.frames, "map_points_uncertain": int((d_mapflags & 4).ne(0).sum().item()),
+                           "map_points_classify": None if args.no_classify else {
+                               "what": "CoSLAM::mapPointsClassify(12.0) every frame behind the gate (cs_map_points_classify_dev)",
+                               "examined_last_frame": int(d_cls_counts[0].item()), "became_false_last_frame": int(d_cls_counts[1].item()),
+                               "map_points_false": int((d_mapflags & 2).ne(0).sum().item()),
+                               "map_points_dynamic": int(((d_mapflags & 3) == 1).sum().item())},
                            "map_points_refined": int((d_map - torch.from_numpy(sc.points).to(dev)).abs().amax(dim=1).gt(0).sum().item()),
                            "features_dynamic_last_frame": [int(v) for v in ((d_isstatic == 0) & (d_state >= 0)).sum(dim=1).cpu().tolist()],
                            "static_mapped_features_last_frame": [int(v) for v in ((d_state >= 0) & (d_slot2map >= 0)).sum(dim=1).cpu().tolist()]},

@@ -216,6 +216,10 @@ int main(int argc, char** argv) {
     double* dCovUpd = dev_zeros<double>((size_t)nMap * 9);
     long long baApplied = 0;
     int baRequested = 0, updRuns = 0, updFirstKey = 0;
+    // CoSLAM::mapPointsClassify behind the pose update: MapPoint::bNewPt / staticFrameNum / firstFrame of every map point
+    unsigned char* dNewPt = dev_zeros<unsigned char>(nMap);
+    int* dSfn = dev_zeros<int>(nMap);
+    int* dFirstFrm = dev_zeros<int>(nMap);
     cs_track_history* hist = cs_track_history_create(dev, nCams, N, 64);
     if (!hist) {
         fprintf(stderr, "cs_track_history_create: %s\n", cs_last_error());
@@ -357,6 +361,9 @@ int main(int argc, char** argv) {
         // parallelPoseUpdate(false): the gate + seqTriangulate loop of poseUpdate3D, detectDynamicFeaturePoints(20, 5, 3, MAX_EPI_ERR)
         CSCHK(cs_pose_update_frame_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dR[dsti], dT[dsti], dMap, dCov, dMapFlags, 0, PIX, i, 20, 5,
                                        3, 6.0, nullptr, nullptr, nullptr));
+        // mapPointsClassify(12.0) (SL_CoSLAM.cpp:385): the uncertain / dynamic points of this frame decided again
+        CSCHK(cs_map_points_classify_dev(hist, (void*)poseS, pu.data(), dPf, nMap, nullptr, nullptr, i, dMap, dCov, dMapFlags, dNewPt, dSfn,
+                                         dFirstFrm, 12.0, nullptr));
         // output() of a finished joint BA (cs_ba_completed read between frames: the host runs ahead of the device): updateNewPosesPoints, one launch
         if (win && cs_ba_completed(joint.ws) != baApplied) {
             baApplied = cs_ba_completed(joint.ws), ++updRuns;
