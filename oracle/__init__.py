@@ -348,6 +348,27 @@ def map_points_classify(Ks, iKs, histR, histT, histXY, trackSpan, featStatic, po
     return n, nf.value
 
 
+def check_unify(Ks, iKs, histR, histT, histXY, trackSpan, pf1, pf2, M1, M2, sigma, cmpAcos=False):
+    """opu_check_unify (CoSLAM::checkUnify): pf1 / pf2 int32[nC] = the two points' slots per camera (< 0 none), M1 / M2 their
+    positions.  Returns (ok, M, cov)."""
+    L = lib()
+    L.opu_check_unify.restype = C.c_int
+    histR = np.ascontiguousarray(histR, dtype=np.float64)
+    histT = np.ascontiguousarray(histT, dtype=np.float64)
+    histXY = np.ascontiguousarray(histXY, dtype=np.float64)
+    nC, nH = histR.shape[0], histR.shape[1]
+    N = histXY.shape[2] // 2
+    Ks = np.ascontiguousarray(Ks, dtype=np.float64).reshape(nC, 9)
+    iKs = np.ascontiguousarray(iKs, dtype=np.float64).reshape(nC, 9)
+    sp = np.ascontiguousarray(trackSpan, dtype=np.int32).reshape(nC, 2 * N)
+    a, b = np.ascontiguousarray(pf1, dtype=np.int32).reshape(nC), np.ascontiguousarray(pf2, dtype=np.int32).reshape(nC)
+    m1, m2 = np.ascontiguousarray(M1, dtype=np.float64).reshape(3), np.ascontiguousarray(M2, dtype=np.float64).reshape(3)
+    M, cov = np.zeros(3), np.zeros(9)
+    ok = L.opu_check_unify(nC, N, nH, _p(Ks), _p(iKs), _p(histR), _p(histT), _p(histXY), _p(sp), _p(a), _p(b), _p(m1), _p(m2),
+                           C.c_double(sigma), int(bool(cmpAcos)), _p(M), _p(cov))
+    return bool(ok), M, cov
+
+
 def static_check_mergability(K, histR, histT, histXY, slot, length, M, cov, pixelVar):
     """org_static_check_mergability (CoSLAM::staticCheckMergability): histR (nHist x 9), histT (nHist x 3), histXY (nHist x 2N),
     entry 0 = this frame; the track of `slot` covers the `length` newest entries.  Returns True / False."""

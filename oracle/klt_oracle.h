@@ -179,6 +179,9 @@ int opu_map_points_classify(int nCams, int N, int nHist, const double* Ks, const
                             const int* featFrame, const int* featFirst, int curFrame, double* mapPts, double* mapCov,
                             unsigned char* mapFlags, unsigned char* newPt, int* staticFrameNum, const int* firstFrame, double pixelVar,
                             int* numFalse);
+int opu_check_unify(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
+                    const double* histXY, const int* trackSpan, const int* pf1, const int* pf2, const double* M1, const double* M2,
+                    double sigma, int cmpAcos, double* M, double* cov);
 int opu_refine_map_points(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
                           const double* histXY, const int* trackSpan, int nMap, const int* pointFeat, const unsigned char* select,
                           double* mapPts, double* mapCov, double sigma, int cmpAcos);

@@ -661,3 +661,82 @@ int opu_map_points_classify(int nCams, int N, int nHist, const double* Ks, const
     if (numFalse) *numFalse = nFalse;
     return nExamined;
 }
+
+/* ---- CoSLAM::checkUnify (/root/reference/src/app/SL_CoSLAM.cpp:561-665) ---------------------------------------------------------
+ * What the registration loops ask when a map point's candidate feature already belongs to another map point (:795-829, every 50th
+ * frame and after a group merge): can the two points be one?  The views of BOTH points -- per camera first point 1's feature and
+ * its widest-parallax predecessor (angles at point 1's position), then point 2's likewise (angles at point 2's position) -- are
+ * triangulated together (triangulateMultiView, getTriangulateCovMat) and every view must lie within Mahalanobis distance 1 of the
+ * new point.  NOTE :657: the gate's getProjectionCovMat is handed `Rs + 3 * i` where `Rs + 9 * i` is meant, i.e. for view i >= 1 the
+ * nine doubles starting at offset 3 i of the concatenated rotations -- rows of two different views' matrices; the projection itself
+ * (:656) uses the right one.  Restated as written.  Features of this frame only (a pair's tables name the slot per camera, < 0 none);
+ * the walk runs over the whole track (no window), bounded by the history.  Returns 1 / 0; M and cov are written in either case.
+ * Pinned against the reference's own function (tests/cxx/ref_update_points_test.cpp: halves of one point's cameras, and different
+ * points); no device counterpart yet. */
+int opu_check_unify(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
+                    const double* histXY, const int* trackSpan, const int* pf1, const int* pf2, const double* M1, const double* M2,
+                    double sigma, int cmpAcos, double* M, double* cov) {
+    opu_view v[128];
+    int slotv[128], nv = 0;
+    for (int c = 0; c < nCams; c++) {
+        for (int which = 0; which < 2; which++) {
+            const int s = (which ? pf2 : pf1)[c];
+            if (s < 0) continue;
+            const double* Mold = which ? M2 : M1;
+            const double* hR = histR + (size_t)c * nHist * 9;
+            const double* hT = histT + (size_t)c * nHist * 3;
+            v[nv].c = c, v[nv].j = 0, slotv[nv] = s, nv++;
+            double C0[3];
+            cam_center(hR, hT, C0);
+            const int f1 = trackSpan[(size_t)c * 2 * N + s], f2 = trackSpan[(size_t)c * 2 * N + N + s];
+            const int len = f1 >= 0 ? f2 - f1 + 1 : 0;
+            const int depth = len < nHist ? len : nHist;
+            int best = -1;
+            double bestCos = 1.0, bestAngle = 0.0;
+            for (int j = 1; j < depth; j++) {
+                double Cj[3];
+                cam_center(hR + 9 * (size_t)j, hT + 3 * (size_t)j, Cj);
+                const double cv = cos_between(Mold, C0, Cj);
+                if (cmpAcos) {
+                    const double ang = fabs(acos(cv));
+                    if (ang > bestAngle) bestAngle = ang, best = j;
+                } else if (cv < bestCos)
+                    bestCos = cv, best = j;
+            }
+            if (best >= 0) v[nv].c = c, v[nv].j = best, slotv[nv] = s, nv++;
+        }
+    }
+    opu_normal_eq E;
+    memset(&E, 0, sizeof(E));
+    double RsFlat[128 * 9 + 9];
+    for (int i = 0; i < nv; i++) {
+        const double* R = histR + ((size_t)v[i].c * nHist + v[i].j) * 9;
+        const double* t = histT + ((size_t)v[i].c * nHist + v[i].j) * 3;
+        const double* h = histXY + ((size_t)v[i].c * nHist + v[i].j) * 2 * N;
+        memcpy(RsFlat + 9 * i, R, 72);
+        ne_add_view(&E, iKs + 9 * v[i].c, R, t, h[slotv[i]], h[N + slotv[i]]);
+    }
+    double cf[6];
+    const double det = sym33_cof(E.N, cf);
+    M[0] = ((cf[0] * E.g[0] + cf[1] * E.g[1]) + cf[2] * E.g[2]) / det;
+    M[1] = ((cf[1] * E.g[0] + cf[3] * E.g[1]) + cf[4] * E.g[2]) / det;
+    M[2] = ((cf[2] * E.g[0] + cf[4] * E.g[1]) + cf[5] * E.g[2]) / det;
+    double S[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < nv; i++)
+        cov_add_view(S, Ks + 9 * v[i].c, histR + ((size_t)v[i].c * nHist + v[i].j) * 9, histT + ((size_t)v[i].c * nHist + v[i].j) * 3, M);
+    const double dS = sym33_cof(S, cf), s2 = sigma * sigma;
+    cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
+    cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
+    cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
+    for (int i = 0; i < nv; i++) {
+        const double* R = histR + ((size_t)v[i].c * nHist + v[i].j) * 9;
+        const double* t = histT + ((size_t)v[i].c * nHist + v[i].j) * 3;
+        const double* h = histXY + ((size_t)v[i].c * nHist + v[i].j) * 2 * N;
+        double rm[2], var[4], ivar[4];
+        org_project(Ks + 9 * v[i].c, R, t, M, rm);                                  /* :656 */
+        org_projection_cov(Ks + 9 * v[i].c, RsFlat + 3 * i, t, M, cov, var, sigma); /* :657: Rs + 3 * i */
+        mat22_inv(var, ivar);
+        if (maha_dist2(rm, h[slotv[i]], h[N + slotv[i]], ivar) > 1.0) return 0;
+    }
+    return 1;
+}

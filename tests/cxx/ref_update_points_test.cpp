@@ -13,7 +13,9 @@
 // Layout of out.bin: int32 nScenes; per scene: int32 nCams, H, nPts, firstKeyFrame, curFrame; double sigma; per camera K[9], iK[9];
 // per camera and history entry (newest first) R[9], t[3]; per point: M[3], cov[9], int32 localType, uncertain, lastFrame, isCurrent,
 // per camera int32 L, int32 featDynamic, L x m[2] (newest first); then per point the reference's M[3], cov[9]; then per point int32
-// refined, and CoSLAM::refineMapPoint's M[3], cov[9] for a copy of the point as it stood before (refined = 0: not called, unchanged).
+// refined, and CoSLAM::refineMapPoint's M[3], cov[9] for a copy of the point as it stood before (refined = 0: not called, unchanged);
+// then int32 nPairs and per pair of temporary points handed to CoSLAM::checkUnify: int32 p1, p2, per camera int32 has1, has2, M1[3],
+// M2[3], int32 ok, M[3], cov[9].
 // TEST INFRASTRUCTURE; built into oracle/_ref/ where the reference tree exists.
 #include <cmath>
 #include <cstdio>
@@ -58,7 +60,7 @@ int main(int argc, char** argv) {
     if (!f) return 1;
     const int nScenes = 6;
     puti(f, nScenes);
-    int nTouched = 0, nTotal = 0, nMoved2 = 0, nRefined = 0;
+    int nTouched = 0, nTotal = 0, nMoved2 = 0, nRefined = 0, nUnify = 0, nUnifyAll = 0;
     for (int sc = 0; sc < nScenes; ++sc) {
         const int nCams = 2 + sc % 4, H = 6 + 5 * (sc % 3), nPts = 60, curFrame = 200 + sc, firstKey = curFrame - 12;
         // kind of motion: 0 moving rig, 1 stands still for the older half of the history, 2 rotation only
@@ -160,6 +162,46 @@ int main(int argc, char** argv) {
             }
             memcpy(&refM[3 * p], tmp.M, 24), memcpy(&refCov[9 * p], tmp.cov, 72);
         }
+        // CoSLAM::checkUnify (src/app/SL_CoSLAM.cpp:561-665) on pairs of temporary points: the two halves of one point's cameras (the same
+        // physical point: they should unify) and two different points (they should not); features of this frame, whole tracks
+        struct UnifyRec {
+            int p1, p2, ok;
+            int has1[SLAM_MAX_NUM], has2[SLAM_MAX_NUM];
+            double M1[3], M2[3], M[3], cov[9];
+        };
+        std::vector<UnifyRec> uni;
+        for (int p = 0; p + 1 < nPts; ++p) {
+            int seen = 0;
+            for (int c = 0; c < nCams; ++c) seen += pts[p]->pFeatures[c] != nullptr;
+            for (int mode = 0; mode < 2; ++mode) {
+                if (mode == 0 && seen < 2) continue;
+                MapPoint A(*pts[p]), B(mode == 0 ? *pts[p] : *pts[p + 1]);
+                UnifyRec r;
+                memset(&r, 0, sizeof(r));
+                r.p1 = p, r.p2 = mode == 0 ? p : p + 1;
+                if (mode == 0) {   // the cameras that see the point dealt out alternately
+                    int k = 0;
+                    for (int c = 0; c < nCams; ++c)
+                        if (pts[p]->pFeatures[c]) {
+                            if (k++ % 2) A.pFeatures[c] = nullptr; else B.pFeatures[c] = nullptr;
+                        }
+                    B.M[0] += 0.02, B.M[1] -= 0.015, B.M[2] += 0.03;
+                }
+                int nA = 0, nB = 0;
+                for (int c = 0; c < nCams; ++c) {
+                    r.has1[c] = A.pFeatures[c] != nullptr, r.has2[c] = B.pFeatures[c] != nullptr;
+                    nA += r.has1[c], nB += r.has2[c];
+                }
+                if (nA + nB < 2 || nA == 0 || nB == 0) continue;
+                memcpy(r.M1, A.M, 24), memcpy(r.M2, B.M, 24);
+                r.ok = co->checkUnify(&A, &B, r.M, r.cov, Const::PIXEL_ERR_VAR) ? 1 : 0;
+                bool fin = true;
+                for (int q = 0; q < 3; ++q) fin = fin && fabs(r.M[q]) < 1e6;
+                if (!fin) continue;   // (a degenerate union -- rotation-only rig -- is not a test vector)
+                uni.push_back(r);
+                nUnify += r.ok, ++nUnifyAll;
+            }
+        }
         std::vector<double> before(3 * nPts);
         for (int p = 0; p < nPts; ++p) memcpy(&before[3 * p], pts[p]->M, 24);
         RobustBundleRTS ba;
@@ -175,10 +217,17 @@ int main(int argc, char** argv) {
                 if (!(fabs(pts[p]->M[q]) < 1e3)) ++nMoved2;
         }
         for (int p = 0; p < nPts; ++p) puti(f, refSel[p]), put(f, &refM[3 * p], 3), put(f, &refCov[9 * p], 9);
+        puti(f, (int)uni.size());
+        for (const UnifyRec& r : uni) {
+            puti(f, r.p1), puti(f, r.p2);
+            for (int c = 0; c < nCams; ++c) puti(f, r.has1[c]), puti(f, r.has2[c]);
+            put(f, r.M1, 3), put(f, r.M2, 3);
+            puti(f, r.ok), put(f, r.M, 3), put(f, r.cov, 9);
+        }
         co->curMapPts.clearWithoutRelease(), co->actMapPts.clearWithoutRelease();
     }
     fclose(f);
-    printf("ref_update_points_test: %d scenes, %d of %d points re-triangulated, %d wild coordinates; refineMapPoint on %d points\n", nScenes, nTouched,
-           nTotal, nMoved2, nRefined);
-    return (nTouched > nTotal / 4 && nTouched < nTotal && nMoved2 == 0 && nRefined > nTotal / 4) ? 0 : 1;
+    printf("ref_update_points_test: %d scenes, %d of %d points re-triangulated, %d wild coordinates; refineMapPoint on %d points; checkUnify: %d of %d pairs unify\n",
+           nScenes, nTouched, nTotal, nMoved2, nRefined, nUnify, nUnifyAll);
+    return (nTouched > nTotal / 4 && nTouched < nTotal && nMoved2 == 0 && nRefined > nTotal / 4 && nUnify > 20 && nUnifyAll - nUnify > 20) ? 0 : 1;
 }

@@ -333,7 +333,21 @@ def update_points_case():
         for p in range(nP):
             (rs_,) = ints(1)
             rsel[p], Mf[p], covf[p] = rs_, dbls(3), dbls(9)
+        (nU,) = ints(1)
+        up = np.zeros((nU, 2), np.int32)
+        uh1, uh2 = np.zeros((nU, nC), np.uint8), np.zeros((nU, nC), np.uint8)
+        uM1, uM2, uM, ucov, uok = np.zeros((nU, 3)), np.zeros((nU, 3)), np.zeros((nU, 3)), np.zeros((nU, 9)), np.zeros(nU, np.uint8)
+        for q in range(nU):
+            up[q] = ints(2)
+            hh = ints(2 * nC).reshape(nC, 2)
+            uh1[q], uh2[q] = hh[:, 0], hh[:, 1]
+            uM1[q], uM2[q] = dbls(3), dbls(3)
+            (uok[q],) = ints(1)
+            uM[q], ucov[q] = dbls(3), dbls(9)
         pre = f"s{sc}_"
+        for k, v in dict(unify_pts=up, unify_has1=uh1, unify_has2=uh2, unify_M1=uM1, unify_M2=uM2, unify_ok=uok, unify_M=uM,
+                         unify_cov=ucov).items():
+            out[pre + k] = v
         for k, v in dict(K=K, iK=iK, histR=hR, histT=hT, histXY=hXY, trackSpan=span, featStatic=fstat, pointFeat=pf, M0=M0, cov0=cov0,
                          flags=flags, lastFrame=lastF, isCurrent=isCur, firstKey=np.int32(firstKey), curFrame=np.int32(cur),
                          sigma=np.float64(sigma), M_ref=Mr, cov_ref=covr, refine_select=rsel, M_refine=Mf, cov_refine=covf).items():
