@@ -330,6 +330,29 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
     return n / dt, n, dt
 
 
+def spawn_command(n_gpus, argv, port):
+    """the launcher line the driver itself uses for N > 1 (one rank per GPU, rendezvous on 127.0.0.1)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n_gpus, argv):
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = spawn_command(n_gpus, argv, port)
+    if os.environ.get("BENCH_SPAWN_DRYRUN"):   # (CPU test hook: what would be launched)
+        print(json.dumps({"spawn": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on these hosts
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -388,6 +411,18 @@ def main():
                          "without any collective (0), or chosen by size (auto: sliced from 200 k measurements)")
     ap.add_argument("--native-comm", type=int, default=1, help="N > 1: collectives issued by libcoslam_hip (RCCL behind the C-ABI) instead of torch.distributed")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` started bare (no launcher: WORLD_SIZE unset) spawns its own N ranks, one per GPU, through
+    # torch.distributed.run on 127.0.0.1 and a free port, and hands their exit code on.  Started BY a launcher the world size
+    # must be what --gpus says: the line never reports an n_gpus that was not asked for.
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks; refusing to report "
+                         "an n_gpus that differs from --gpus")
 
     import torch
     import torch.distributed as dist
