@@ -198,6 +198,13 @@ class BAWindow:
                                                int(n_pts_con), C.c_double(max_err), int(max_iter), int(inner_max_iter)),
               "cs_ba_solve_window_async")
 
+    def solve_flags_async(self, ws, after_stream_ptr, d_map_pts, d_map_flags, n_cams_con, n_pts_con, max_err, max_iter, inner_max_iter):
+        """cs_ba_solve_window_flags_async: only the points that are isLocalStatic() under the map's CS_MAP_* flag bytes take part"""
+        vp = C.c_void_p
+        check(self._L.cs_ba_solve_window_flags_async(ws._h, self._h, vp(after_stream_ptr), vp(d_map_pts), vp(d_map_flags), int(n_cams_con),
+                                                     int(n_pts_con), C.c_double(max_err), int(max_iter), int(inner_max_iter)),
+              "cs_ba_solve_window_flags_async")
+
     def reserve(self, ws):
         """cs_ba_reserve_for_window: ws sized and bound for this window's largest problem (result_buffers() then stay valid)"""
         check(self._L.cs_ba_reserve_for_window(ws._h, self._h), "cs_ba_reserve_for_window")
@@ -213,6 +220,88 @@ class BAWindow:
         if self._h:
             self._L.cs_ba_window_destroy.argtypes = [C.c_void_p]
             self._L.cs_ba_window_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BAOutput:
+    """cs_ba_output: RobustBundleRTS::output() (reference src/app/SL_CoSLAMRobustBA.cpp:273-316) in two halves -- the solve's worker
+    packs every window solve's result into a record of a small ring; the stream that owns the map applies a record between two
+    frames (key poses into the pose history / the window / the camera graphs, points into the map, relaxation of the non-key
+    frames, updateNewPosesPoints)."""
+
+    def __init__(self, n_cams, n_key_frames, n_map_pts, n_slots=8, device=0):
+        self._L = lib()
+        self._L.cs_ba_output_create.restype = C.c_void_p
+        h = self._L.cs_ba_output_create(int(device), int(n_cams), int(n_key_frames), int(n_map_pts), int(n_slots))
+        if not h:
+            raise CoslamHipError("cs_ba_output_create: " + self._L.cs_last_error().decode())
+        self._h = C.c_void_p(h)
+        self._L.cs_ba_output_record_bytes.restype = C.c_size_t
+        self._L.cs_ba_output_record_bytes.argtypes = [C.c_void_p]
+        self.record_bytes = int(self._L.cs_ba_output_record_bytes(self._h))
+        self._L.cs_ba_output_packed.restype = C.c_longlong
+        self._L.cs_ba_output_packed.argtypes = [C.c_void_p]
+        self._L.cs_ba_output_wait.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p]
+        self._L.cs_ba_output_slot.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p]
+        self.n_cams, self.n_key_frames, self.n_map_pts, self.device = n_cams, n_key_frames, n_map_pts, device
+
+    def attach(self, ws):
+        check(self._L.cs_ba_output_attach(self._h, ws._h), "cs_ba_output_attach")
+
+    def packed(self):
+        return int(self._L.cs_ba_output_packed(self._h))
+
+    def wait(self, seq):
+        """blocks until record `seq` is complete on the device -> its device address"""
+        p = C.c_void_p()
+        check(self._L.cs_ba_output_wait(self._h, int(seq), C.byref(p)), "cs_ba_output_wait")
+        return p.value
+
+    def wait_dev(self, seq, stream_ptr, timeout_ms=0):
+        """the wait on the device: work enqueued on the stream afterwards runs once record `seq` is complete -> its address, at once"""
+        p = C.c_void_p()
+        check(self._L.cs_ba_output_wait_dev(self._h, C.c_longlong(int(seq)), C.c_void_p(stream_ptr), int(timeout_ms), C.byref(p)),
+              "cs_ba_output_wait_dev")
+        return p.value
+
+    def wait_errors(self):
+        return int(self._L.cs_ba_output_wait_errors(self._h))
+
+    def slot(self, seq):
+        p = C.c_void_p()
+        check(self._L.cs_ba_output_slot(self._h, int(seq), C.byref(p)), "cs_ba_output_slot")
+        return p.value
+
+    def header(self, d_record, stream_ptr=0):
+        """dict(C, P, nObs, nKf, nCams, seq, ok, key_frames) of a record (synchronises the stream)"""
+        h8, kf = (C.c_int * 8)(), (C.c_int * 16)()
+        check(self._L.cs_ba_output_header(self._h, C.c_void_p(d_record), C.c_void_p(stream_ptr), h8, kf), "cs_ba_output_header")
+        return dict(C=h8[0], P=h8[1], nObs=h8[2], nKf=h8[3], nCams=h8[4], seq=h8[5], ok=h8[6], key_frames=[f for f in kf if f >= 0])
+
+    def arrays(self, d_record):
+        """device addresses (ints): Rs, Ts, pts, pointMap, ptOutlier of a record"""
+        a = [C.c_void_p() for _ in range(5)]
+        check(self._L.cs_ba_output_arrays(self._h, C.c_void_p(d_record), *[C.byref(x) for x in a]), "cs_ba_output_arrays")
+        return [x.value for x in a]
+
+    def apply_dev(self, d_record, stream_ptr, history, window, pu_cams, d_pointFeat, n_map, d_mapPts, d_mapCov, d_mapFlags, pixelErrVar,
+                  first_key_frame, key_every, d_Rcur, d_tcur, d_counts=0):
+        vp = C.c_void_p
+        check(self._L.cs_ba_output_apply_dev(self._h, vp(d_record), vp(stream_ptr), vp(history._h), window._h if window is not None else None,
+                                             pu_cams, vp(d_pointFeat), int(n_map), vp(d_mapPts), vp(d_mapCov), vp(d_mapFlags),
+                                             C.c_double(pixelErrVar), int(first_key_frame), int(key_every), vp(d_Rcur), vp(d_tcur),
+                                             vp(d_counts)), "cs_ba_output_apply_dev")
+
+    def close(self):
+        if self._h:
+            self._L.cs_ba_output_destroy.argtypes = [C.c_void_p]
+            self._L.cs_ba_output_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -2031,6 +2031,7 @@ __global__ __launch_bounds__(256) void k_control_step(BaDev D) {
 #include "ba_packed_dev.h"
 #include "ba_persist_dev.h"
 #include "ba_window_dev.h"
+#include "ba_output_dev.h"
 
 // ---- outer loop: outlier flags ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_flag(BaDev D) {
@@ -2335,6 +2336,7 @@ struct cs_ba {
     size_t syrkCap;
     cs_ba_followup_fn followup;  // cs_ba_set_followup: enqueued on the solve's stream right behind every solve
     void* followupUser;
+    struct cs_ba_output* output;  // cs_ba_output_attach: every window solve's result is packed into its next record
 };
 
 // solver breakdown is an error, not a silently unchanged estimate (the reference's callers catch what bundleAdjustRobust
@@ -2942,6 +2944,7 @@ struct BaAsyncJob {
     struct cs_ba_window* win = nullptr;  // cs_ba_solve_window_async: the problem is built on the device from this window
     const double* d_map = nullptr;
     const unsigned char* d_mapStatic = nullptr;
+    const double *winR = nullptr, *winT = nullptr;   // the ring's key poses as they stood when the solve was requested
     int winCount = 0, winSlotOf[16], winFrames[16];  // the window as it stood when the solve was requested (oldest first)
 };
 
@@ -3173,13 +3176,77 @@ struct cs_ba_window {
     int *pf, *cnt, *ptIndex, *obsStart, *totals, *pointMap, *pairCnt, *pairTotal;
     double* mapSnap[WIN_SLACK + 1];   // the map as it stood when a solve was requested: one per request that can be outstanding
     unsigned char* staticSnap[WIN_SLACK + 1];
+    double *poseSnapR[WIN_SLACK + 1], *poseSnapT[WIN_SLACK + 1];   // ... and the ring's key poses (cs_ba_output_apply_dev rewrites them)
     int snapNext;
     int* h_plan;         // pinned [nMap + 2]: the lane plan on its way to the device
     int* h_totals;       // pinned [8], followed by nMap + 1 ints: obs_ptr of the parsed problem (for the lane plan)
     int lastC, lastP, lastObs;
 };
 
+// ---- RobustBundleRTS::output() (ba_output_dev.h): a ring of result records, packed by the worker behind every window solve ----
+struct cs_ba_output {
+    int device, nCams, nKf, nMap, nSlots;
+    BoLayout L;
+    unsigned char* slab;  // nSlots records of L.bytes
+    int* d_err;           // cs_ba_output_wait_dev: waits that gave up
+    std::mutex mu;
+    std::condition_variable cv;
+    long long issued;     // records the worker has started to pack (its slot = issued % nSlots)
+    long long packed;     // records complete on the device (the worker has synchronised with the pack)
+    // the applying side's scratch (cs_ba_output_apply_dev: one caller thread): camera graphs of nCams chains of graphNodes nodes
+    cs_posegraph* graph;
+    int graphNodes, graphKeyEvery, maxNodes;
+    double *nodeR, *nodeT, *newR, *newT, *edgeR, *edgeT;
+    unsigned char* scratch;
+};
+
+static int ba_output_pack(cs_ba* b, cs_ba_window* win, const BaAsyncJob& J, hipStream_t s, int C, int P, int nObs, bool ok) {
+    cs_ba_output* o = b->output;
+    if (C > o->L.maxC || P > o->L.maxP) ok = false;   // (cannot happen for the window the record was sized for)
+    BoPackArgs A;
+    memset(&A, 0, sizeof(A));
+    A.C = ok ? C : 0, A.P = ok ? P : 0, A.nObs = ok ? nObs : 0, A.nKf = J.winCount, A.nCams = win->nCams, A.ok = ok ? 1 : 0;
+    for (int j = 0; j < 16; ++j) A.kfFrame[j] = j < J.winCount ? J.winFrames[j] : -1;
+    long long seq;
+    {
+        std::lock_guard<std::mutex> lk(o->mu);
+        seq = o->issued++;
+    }
+    A.seq = (int)seq;
+    A.Rs = b->Rs, A.Ts = b->Ts, A.pts = b->pts, A.obs_ptr = b->obs_ptr, A.outlier = b->outlier, A.pointMap = win->pointMap;
+    A.rec = o->slab + (size_t)(seq % o->nSlots) * o->L.bytes;
+    A.L = o->L;
+    int n = 9 * A.C > 3 * A.P ? 9 * A.C : 3 * A.P;
+    if (n < BO_HDR_INTS) n = BO_HDR_INTS;
+    hipLaunchKernelGGL(k_ba_output_pack, dim3((n + 255) / 256), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_ba_output_publish, dim3(1), dim3(1), 0, s, (int*)A.rec, A.seq);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+static void ba_output_publish(cs_ba_output* o) {
+    {
+        std::lock_guard<std::mutex> lk(o->mu);
+        o->packed += 1;
+    }
+    o->cv.notify_all();
+}
+
+static int ba_worker_run_window_inner(cs_ba* b, BaWorker* w, const BaAsyncJob& J, bool* packed);
 static int ba_worker_run_window(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
+    bool packed = false;
+    const int rc = ba_worker_run_window_inner(b, w, J, &packed);
+    if (b->output && !packed) {   // the solve failed before it had a result: an empty record keeps the sequence of records = requests
+        (void)hipSetDevice(b->device);
+        char keep[256];
+        snprintf(keep, sizeof(keep), "%s", cs_last_error());
+        (void)ba_output_pack(b, J.win, J, b->own_stream, 0, 0, 0, false);
+        (void)hipStreamSynchronize(b->own_stream);
+        ba_output_publish(b->output);
+        cs_set_error("%s", keep);
+    }
+    return rc;
+}
+static int ba_worker_run_window_inner(cs_ba* b, BaWorker* w, const BaAsyncJob& J, bool* packed) {
     cs_ba_window* win = J.win;
     CS_HIP(hipSetDevice(b->device));
     hipStream_t s = b->own_stream;
@@ -3219,7 +3286,7 @@ static int ba_worker_run_window(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
     memset(&Wd, 0, sizeof(Wd));
     Wd.nCams = win->nCams, Wd.nKf = win->nKf, Wd.N = win->N, Wd.nMap = win->nMap, Wd.count = J.winCount;
     for (int j = 0; j < J.winCount; ++j) Wd.slotOf[j] = J.winSlotOf[j];  // oldest first
-    Wd.xy = win->xy, Wd.pf = win->pf, Wd.K = win->K, Wd.R = win->R, Wd.t = win->t;
+    Wd.xy = win->xy, Wd.pf = win->pf, Wd.K = win->K, Wd.R = J.winR ? J.winR : win->R, Wd.t = J.winT ? J.winT : win->t;
     Wd.mapStatic = J.d_mapStatic, Wd.mapPts = J.d_map;
     Wd.cnt = win->cnt, Wd.ptIndex = win->ptIndex, Wd.obsStart = win->obsStart, Wd.totals = win->totals;
     const int gM = (win->nMap + 3) / 4 > 0 ? (win->nMap + 3) / 4 : 1;   // a wave per map point
@@ -3348,6 +3415,18 @@ static int ba_worker_run_window(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
     });
     if (rc) return rc;
     rc = ba_run_followup(b, s);
+    if (b->output) {   // RobustBundleRTS::output(), first half: the result into the next record, behind the solve's last kernel
+        const int prc = ba_output_pack(b, win, J, s, C, P, nObs, rc == CS_OK);
+        if (prc != CS_OK) return rc != CS_OK ? rc : prc;
+        *packed = true;
+        const hipError_t e = hipStreamSynchronize(s);
+        ba_output_publish(b->output);
+        if (e != hipSuccess) {
+            cs_set_error("cs_ba_solve_window_async: hipStreamSynchronize failed: %s", hipGetErrorString(e));
+            return CS_ERR_HIP;
+        }
+        return rc;
+    }
     CS_HIP(hipStreamSynchronize(s));
     return rc;
 }
@@ -4080,6 +4159,9 @@ cs_ba_window* cs_ba_window_create(int device, int nCams, int nKeyFrames, int N, 
         {(void**)&w->mapSnap[0], sizeof(double) * 3 * nMapPts}, {(void**)&w->mapSnap[1], sizeof(double) * 3 * nMapPts},
         {(void**)&w->mapSnap[2], sizeof(double) * 3 * nMapPts}, {(void**)&w->staticSnap[0], (size_t)nMapPts},
         {(void**)&w->staticSnap[1], (size_t)nMapPts},           {(void**)&w->staticSnap[2], (size_t)nMapPts},
+        {(void**)&w->poseSnapR[0], sizeof(double) * KC * 9},    {(void**)&w->poseSnapT[0], sizeof(double) * KC * 3},
+        {(void**)&w->poseSnapR[1], sizeof(double) * KC * 9},    {(void**)&w->poseSnapT[1], sizeof(double) * KC * 3},
+        {(void**)&w->poseSnapR[2], sizeof(double) * KC * 9},    {(void**)&w->poseSnapT[2], sizeof(double) * KC * 3},
     };
     size_t total = 0;
     for (const Piece& q : pieces) total += (q.bytes + 255) & ~(size_t)255;
@@ -4160,8 +4242,24 @@ int cs_ba_window_push_dev(cs_ba_window* w, void* hip_stream, const cs_handback_c
 // every mapped point is static), then solved in workspace b on its worker thread, started when the work enqueued on
 // after_stream so far (the push of the newest key frame) is done.  The result stays in the workspace (cs_ba_result_buffers /
 // cs_ba_download with cs_ba_window_last_problem's sizes); cs_ba_wait / cs_ba_download report errors.
+static int ba_solve_window_async(cs_ba* b, cs_ba_window* w, void* after_stream, const double* d_mapPts, const unsigned char* d_mapStatic,
+                                 int staticIsFlags, int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter);
 int cs_ba_solve_window_async(cs_ba* b, cs_ba_window* w, void* after_stream, const double* d_mapPts, const unsigned char* d_mapStatic,
                              int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter) {
+    return ba_solve_window_async(b, w, after_stream, d_mapPts, d_mapStatic, 0, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter);
+}
+// the same with the map's CS_MAP_* flag bytes instead of a 0 / 1 table: a point takes part when it isLocalStatic() -- neither
+// CS_MAP_DYNAMIC nor CS_MAP_FALSE (RobustBundleRTS::addPoints takes the static points only, src/app/SL_CoSLAMRobustBA.cpp:56-66)
+int cs_ba_solve_window_flags_async(cs_ba* b, cs_ba_window* w, void* after_stream, const double* d_mapPts, const unsigned char* d_mapFlags,
+                                   int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter) {
+    if (!d_mapFlags) {
+        cs_set_error("cs_ba_solve_window_flags_async: null flags");
+        return CS_ERR_INVALID;
+    }
+    return ba_solve_window_async(b, w, after_stream, d_mapPts, d_mapFlags, 1, nCamsCon, nPtsCon, maxErr, maxIter, innerMaxIter);
+}
+static int ba_solve_window_async(cs_ba* b, cs_ba_window* w, void* after_stream, const double* d_mapPts, const unsigned char* d_mapStatic,
+                                 int staticIsFlags, int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter) {
     if (!b || !w || !d_mapPts || nCamsCon < 0 || nPtsCon < 0 || maxIter < 0 || innerMaxIter < 0 || b->device != w->device) {
         cs_set_error("cs_ba_solve_window_async: bad arguments");
         return CS_ERR_INVALID;
@@ -4188,8 +4286,19 @@ int cs_ba_solve_window_async(cs_ba* b, cs_ba_window* w, void* after_stream, cons
     const int sn = w->snapNext;
     w->snapNext = (sn + 1) % (WIN_SLACK + 1);
     CS_HIP(hipMemcpyAsync(w->mapSnap[sn], d_mapPts, sizeof(double) * 3 * (size_t)w->nMap, hipMemcpyDeviceToDevice, (hipStream_t)after_stream));
-    if (d_mapStatic)
+    if (d_mapStatic) {
         CS_HIP(hipMemcpyAsync(w->staticSnap[sn], d_mapStatic, (size_t)w->nMap, hipMemcpyDeviceToDevice, (hipStream_t)after_stream));
+        if (staticIsFlags) {
+            hipLaunchKernelGGL(k_win_static_from_flags, dim3((w->nMap + 255) / 256), dim3(256), 0, (hipStream_t)after_stream, w->nMap, w->staticSnap[sn]);
+            CS_CHECK_LAUNCH();
+        }
+    }
+    // ... and the ring's key poses: cs_ba_output_apply_dev writes a finished solve's key poses back into the ring (the next
+    // window starts from them), possibly while this request is still waiting for its parse
+    const size_t KCs = (size_t)w->ring * w->nCams;
+    CS_HIP(hipMemcpyAsync(w->poseSnapR[sn], w->R, sizeof(double) * 9 * KCs, hipMemcpyDeviceToDevice, (hipStream_t)after_stream));
+    CS_HIP(hipMemcpyAsync(w->poseSnapT[sn], w->t, sizeof(double) * 3 * KCs, hipMemcpyDeviceToDevice, (hipStream_t)after_stream));
+    J.winR = w->poseSnapR[sn], J.winT = w->poseSnapT[sn];
     J.win = w, J.d_map = w->mapSnap[sn], J.d_mapStatic = d_mapStatic ? w->staticSnap[sn] : nullptr;
     J.winCount = w->count;
     for (int j = 0; j < w->count; ++j) {
@@ -4289,5 +4398,239 @@ int cs_ba_wait(cs_ba* b) {
     return rc;
 }
 
+
+
+// ---- RobustBundleRTS::output() on the device (ba_output_dev.h) ------------------------------------------------------------------------
+cs_ba_output* cs_ba_output_create(int device, int nCams, int nKeyFrames, int nMapPts, int nSlots) {
+    if (nCams < 1 || nCams > 16 || nKeyFrames < 1 || nKeyFrames > 16 || nMapPts < 1 || nSlots < 1 || nSlots > 64) {
+        cs_set_error("cs_ba_output_create: need 1..16 cameras, 1..16 key frames, nMapPts >= 1, 1..64 slots");
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        cs_set_error("cs_ba_output_create: no usable HIP device %d", device);
+        return nullptr;
+    }
+    cs_ba_output* o = new cs_ba_output();
+    o->device = device, o->nCams = nCams, o->nKf = nKeyFrames, o->nMap = nMapPts, o->nSlots = nSlots;
+    o->L = bo_layout(nCams * nKeyFrames, nMapPts);
+    o->issued = o->packed = 0;
+    o->graph = nullptr, o->graphNodes = o->graphKeyEvery = o->maxNodes = 0;
+    o->nodeR = o->nodeT = o->newR = o->newT = o->edgeR = o->edgeT = nullptr;
+    o->scratch = nullptr, o->slab = nullptr, o->d_err = nullptr;
+    if (hipMalloc((void**)&o->slab, o->L.bytes * nSlots) != hipSuccess || hipMalloc((void**)&o->d_err, sizeof(int)) != hipSuccess) {
+        cs_set_error("cs_ba_output_create: cannot allocate %zu KB", (o->L.bytes * nSlots) >> 10);
+        delete o;
+        return nullptr;
+    }
+    (void)hipMemset(o->slab, 0, o->L.bytes * nSlots);   // (hdr[6] = 0: an unwritten record applies nothing)
+    (void)hipMemset(o->d_err, 0, sizeof(int));
+    return o;
+}
+
+void cs_ba_output_destroy(cs_ba_output* o) {
+    if (!o) return;
+    (void)hipSetDevice(o->device);
+    (void)hipDeviceSynchronize();
+    if (o->graph) cs_posegraph_destroy(o->graph);
+    (void)hipFree(o->scratch);
+    (void)hipFree(o->slab);
+    (void)hipFree(o->d_err);
+    delete o;
+}
+
+// every window solve of workspace b packs its result into o's next record from now on (NULL detaches); waits for queued solves
+int cs_ba_output_attach(cs_ba_output* o, cs_ba* b) {
+    if (!b || (o && o->device != b->device)) {
+        cs_set_error("cs_ba_output_attach: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    const int rc = cs_ba_wait(b);
+    if (rc) return rc;
+    b->output = o;
+    return CS_OK;
+}
+
+size_t cs_ba_output_record_bytes(const cs_ba_output* o) { return o ? o->L.bytes : 0; }
+
+long long cs_ba_output_packed(cs_ba_output* o) {
+    if (!o) return -1;
+    std::lock_guard<std::mutex> lk(o->mu);
+    return o->packed;
+}
+
+// blocks the calling thread until record number `seq` (0-based, in request order over every workspace attached to o) is complete
+// on the device; returns its address.  A record stays valid until nSlots further solves have been packed.
+int cs_ba_output_wait(cs_ba_output* o, long long seq, void** d_record) {
+    if (!o || seq < 0) {
+        cs_set_error("cs_ba_output_wait: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    {
+        std::unique_lock<std::mutex> lk(o->mu);
+        o->cv.wait(lk, [&] { return o->packed > seq; });
+        if (o->issued - seq > o->nSlots) {
+            cs_set_error("cs_ba_output_wait: record %lld has been overwritten (%lld issued, %d slots)", seq, o->issued, o->nSlots);
+            return CS_ERR_INVALID;
+        }
+    }
+    if (d_record) *d_record = o->slab + (size_t)(seq % o->nSlots) * o->L.bytes;
+    return CS_OK;
+}
+
+// The same wait ON THE DEVICE: one polling lane is enqueued on hip_stream and the call returns the record's address at once -- work
+// enqueued on hip_stream afterwards runs when record `seq` is complete, while the caller's thread goes on enqueueing frames.  The
+// solve must be running on a DIFFERENT stream (a workspace's worker).  Gives up after timeoutMs of GPU wall-clock time
+// (cs_ba_output_wait_errors counts that; the stream then goes on with whatever the slot holds).  seq must already be REQUESTED.
+int cs_ba_output_wait_dev(cs_ba_output* o, long long seq, void* hip_stream, int timeoutMs, void** d_record) {
+    if (!o || seq < 0 || !d_record) {
+        cs_set_error("cs_ba_output_wait_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(o->device));
+    unsigned char* rec = o->slab + (size_t)(seq % o->nSlots) * o->L.bytes;
+    hipLaunchKernelGGL(k_ba_output_wait, dim3(1), dim3(1), 0, (hipStream_t)hip_stream, (const int*)rec, (int)seq,
+                       (long long)(timeoutMs > 0 ? timeoutMs : 2000) * 100000LL, o->d_err);
+    CS_CHECK_LAUNCH();
+    *d_record = rec;
+    return CS_OK;
+}
+int cs_ba_output_wait_errors(cs_ba_output* o) {   // synchronises the device
+    if (!o) return -1;
+    int v = 0;
+    if (hipSetDevice(o->device) != hipSuccess || hipMemcpy(&v, o->d_err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
+}
+
+// slot `seq` would use, without waiting (the receive buffer of a broadcast on the ranks that did not solve this window)
+int cs_ba_output_slot(cs_ba_output* o, long long seq, void** d_record) {
+    if (!o || seq < 0 || !d_record) return CS_ERR_INVALID;
+    *d_record = o->slab + (size_t)(seq % o->nSlots) * o->L.bytes;
+    return CS_OK;
+}
+
+// host copy of a record's header (synchronises hip_stream): C, P, nObs, nKf, nCams, seq, ok, and the key frames' numbers
+int cs_ba_output_header(cs_ba_output* o, const void* d_record, void* hip_stream, int hdr8[8], int keyFrames[16]) {
+    if (!o || !d_record) return CS_ERR_INVALID;
+    int h[BO_HDR_INTS];
+    CS_HIP(hipSetDevice(o->device));
+    CS_HIP(hipMemcpyAsync(h, d_record, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    CS_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+    if (hdr8) memcpy(hdr8, h, 8 * sizeof(int));
+    if (keyFrames) memcpy(keyFrames, h + 8, 16 * sizeof(int));
+    return CS_OK;
+}
+
+// device addresses of a record's arrays (tests, a caller that wants the numbers): Rs [C][9], Ts [C][3], pts [P][3], pointMap [P], ptOutlier [P]
+int cs_ba_output_arrays(cs_ba_output* o, const void* d_record, const double** d_Rs, const double** d_Ts, const double** d_pts,
+                        const int** d_pointMap, const unsigned char** d_ptOutlier) {
+    if (!o || !d_record) return CS_ERR_INVALID;
+    const unsigned char* r = (const unsigned char*)d_record;
+    if (d_Rs) *d_Rs = (const double*)(r + o->L.offRs);
+    if (d_Ts) *d_Ts = (const double*)(r + o->L.offTs);
+    if (d_pts) *d_pts = (const double*)(r + o->L.offPts);
+    if (d_pointMap) *d_pointMap = (const int*)(r + o->L.offMap);
+    if (d_ptOutlier) *d_ptOutlier = r + o->L.offOut;
+    return CS_OK;
+}
+
+static int bo_ensure_graph(cs_ba_output* o, int nNodes, int keyEvery) {
+    if (o->graph && o->graphNodes == nNodes && o->graphKeyEvery == keyEvery) return CS_OK;
+    if (o->graph) cs_posegraph_destroy(o->graph);
+    o->graph = nullptr;
+    if (nNodes > o->maxNodes) {
+        (void)hipFree(o->scratch);
+        o->scratch = nullptr;
+        const int cap = nNodes + 16;
+        const size_t nN = (size_t)o->nCams * cap;
+        const size_t bytes = sizeof(double) * nN * (9 + 3) * 3;   // node | new | edge, R and t each
+        CS_HIP(hipMalloc((void**)&o->scratch, bytes));
+        double* p = (double*)o->scratch;
+        o->nodeR = p, p += nN * 9;
+        o->nodeT = p, p += nN * 3;
+        o->newR = p, p += nN * 9;
+        o->newT = p, p += nN * 3;
+        o->edgeR = p, p += nN * 9;
+        o->edgeT = p;
+        o->maxNodes = cap;
+    }
+    // nCams chains: node i of camera c = frame firstKeyFrame + i; fixed: the window's key frames (constructCameraGraphs, :206-213)
+    std::vector<int> nodePtr(o->nCams + 1), edgePtr(o->nCams + 1), id1, id2;
+    std::vector<unsigned char> fixed((size_t)o->nCams * nNodes, 0);
+    for (int c = 0; c <= o->nCams; ++c) nodePtr[c] = c * nNodes, edgePtr[c] = c * (nNodes - 1);
+    for (int c = 0; c < o->nCams; ++c) {
+        for (int j = 0; j < o->nKf; ++j)
+            if (j * keyEvery < nNodes) fixed[(size_t)c * nNodes + j * keyEvery] = 1;
+        for (int i = 0; i + 1 < nNodes; ++i) id1.push_back(i), id2.push_back(i + 1);
+    }
+    static const int none = 0;
+    const int rc = cs_posegraph_create(o->device, o->nCams, nodePtr.data(), edgePtr.data(), fixed.data(), id1.empty() ? &none : id1.data(),
+                                       id2.empty() ? &none : id2.data(), &o->graph);
+    if (rc != CS_OK) return rc;
+    o->graphNodes = nNodes, o->graphKeyEvery = keyEvery;
+    return CS_OK;
+}
+
+// RobustBundleRTS::output(), second half, on the stream that owns the map (asynchronous on hip_stream; call it BETWEEN two frames:
+// the history's newest entry is the last frame whose pose update ran, d_pointFeat is that frame's hand-back table):
+//   constructCameraGraphs over the history's frames firstKeyFrame .. newest (edges from the poses as they stand),
+//   the record's key poses into the graphs' fixed nodes (and into window w's ring copies of those key frames, w may be NULL),
+//   the record's points into the map, points with an outlier measurement set false,
+//   updateNonKeyCameraPoses: relaxed poses back into the history, the newest frame's into d_Rcur / d_tcur (nCams x 9 / 3: the
+//   poses the next frame's pose solve starts from),
+//   updateNewPosesPoints over the live map (cs_update_new_poses_points_dev).
+// The key frames of the record must be firstKeyFrame + j * keyEvery, j < nKeyFrames (the caller knows its own schedule; the
+// record's header is not read back).  A record whose solve failed (ok = 0) moves nothing but still relaxes (a no-op up to rounding).
+// d_counts [3] or NULL: static / dynamic points re-triangulated, points that became false.
+int cs_ba_output_apply_dev(cs_ba_output* o, const void* d_record, void* hip_stream, cs_track_history* h, cs_ba_window* w,
+                           const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap, double* d_mapPts, double* d_mapCov,
+                           unsigned char* d_mapFlags, double pixelErrVar, int firstKeyFrame, int keyEvery, double* d_Rcur, double* d_tcur,
+                           int* d_counts) {
+    if (!o || !d_record || !h || !cams || !d_pointFeat || nMap != o->nMap || !d_mapPts || !d_mapCov || !d_mapFlags || keyEvery < 1 ||
+        !d_Rcur || !d_tcur || cs_track_history_cams(h) != o->nCams || (w && (w->nCams != o->nCams || w->device != o->device))) {
+        cs_set_error("cs_ba_output_apply_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    const int newest = cs_track_history_newest_frame(h), nNodes = newest - firstKeyFrame + 1;
+    if (nNodes < (o->nKf - 1) * keyEvery + 1) {
+        cs_set_error("cs_ba_output_apply_dev: the history's newest frame %d lies before the window's last key frame %d", newest,
+                     firstKeyFrame + (o->nKf - 1) * keyEvery);
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(o->device));
+    int rc = bo_ensure_graph(o, nNodes, keyEvery);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    if ((rc = cs_track_history_get_span_dev(h, hip_stream, firstKeyFrame, nNodes, o->nodeR, o->nodeT))) return rc;
+    if (nNodes > 1 && (rc = cs_posegraph_edges_dev(o->graph, hip_stream, o->nodeR, o->nodeT, o->edgeR, o->edgeT))) return rc;
+    BoPosesArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nKf = o->nKf, A.nCams = o->nCams, A.nNodes = nNodes, A.keyEvery = keyEvery;
+    A.nodeR = o->nodeR, A.nodeT = o->nodeT;
+    for (int j = 0; j < 16; ++j) A.slotOf[j] = -1;
+    if (w) {
+        A.winR = w->R, A.winT = w->t;
+        for (int j = 0; j < o->nKf; ++j)
+            for (int k = 0; k < w->count; ++k) {
+                const int slot = (w->head - 1 - k + 2 * w->ring) % w->ring;
+                if (w->frameOf[slot] == firstKeyFrame + j * keyEvery) A.slotOf[j] = slot;
+            }
+    }
+    hipLaunchKernelGGL(k_ba_output_poses, dim3((o->nKf * o->nCams * 12 + 255) / 256), dim3(256), 0, s, (const unsigned char*)d_record, o->L, A);
+    if (d_counts) CS_HIP(hipMemsetAsync(d_counts + 2, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_ba_output_points, dim3((o->L.maxP + 255) / 256), dim3(256), 0, s, (const unsigned char*)d_record, o->L, nMap, d_mapPts,
+                       d_mapFlags, d_counts ? d_counts + 2 : nullptr);
+    CS_CHECK_LAUNCH();
+    if (nNodes > 1) {
+        if ((rc = cs_posegraph_relax_dev(o->graph, hip_stream, o->nodeR, o->nodeT, o->edgeR, o->edgeT, o->newR, o->newT))) return rc;
+    } else {
+        CS_HIP(hipMemcpyAsync(o->newR, o->nodeR, sizeof(double) * 9 * o->nCams, hipMemcpyDeviceToDevice, s));
+        CS_HIP(hipMemcpyAsync(o->newT, o->nodeT, sizeof(double) * 3 * o->nCams, hipMemcpyDeviceToDevice, s));
+    }
+    if ((rc = cs_track_history_set_span_dev(h, hip_stream, firstKeyFrame, nNodes, o->newR, o->newT))) return rc;
+    hipLaunchKernelGGL(k_ba_output_tail, dim3((o->nCams * 12 + 255) / 256), dim3(256), 0, s, o->nCams, nNodes, o->newR, o->newT, d_Rcur, d_tcur);
+    CS_CHECK_LAUNCH();
+    return cs_update_new_poses_points_dev(h, hip_stream, cams, d_pointFeat, nMap, nullptr, nullptr, firstKeyFrame, d_mapPts, d_mapCov,
+                                          d_mapFlags, pixelErrVar, d_counts);
+}
 
 }  // extern "C"

@@ -28,6 +28,7 @@ struct RcclApi {
     decltype(&ncclCommDestroy) commDestroy = nullptr;
     decltype(&ncclAllGather) allGather = nullptr;
     decltype(&ncclAllReduce) allReduce = nullptr;
+    decltype(&ncclBroadcast) broadcast = nullptr;
     decltype(&ncclGetErrorString) getErrorString = nullptr;
 };
 
@@ -51,7 +52,8 @@ RcclApi* rccl_api() {
     api.allGather = (decltype(api.allGather))dlsym(api.handle, "ncclAllGather");
     api.allReduce = (decltype(api.allReduce))dlsym(api.handle, "ncclAllReduce");
     api.getErrorString = (decltype(api.getErrorString))dlsym(api.handle, "ncclGetErrorString");
-    if (!api.getUniqueId || !api.commInitRank || !api.commDestroy || !api.allGather || !api.allReduce || !api.getErrorString) {
+    api.broadcast = (decltype(api.broadcast))dlsym(api.handle, "ncclBroadcast");
+    if (!api.broadcast || !api.getUniqueId || !api.commInitRank || !api.commDestroy || !api.allGather || !api.allReduce || !api.getErrorString) {
         cs_set_error("RCCL library lacks a required symbol");
         dlclose(api.handle);
         api.handle = nullptr;
@@ -115,6 +117,19 @@ __global__ __launch_bounds__(256) void k_exchange_pack(PackArgs A) {
         }
         out[q] = v;
     }
+}
+
+// every gathered camera's pose out of the records into contiguous [nCamsAll][9] / [nCamsAll][3] arrays (the layout the pose
+// update, the registration and the window take); cameras [skip0, skip0 + nSkip) are left alone (the rank's own: already there)
+__global__ __launch_bounds__(256) void k_exchange_unpack_poses(const int* __restrict__ recv, int recWords, int nFeatWords, int nCamsAll, int skip0,
+                                                               int nSkip, double* __restrict__ R, double* __restrict__ t) {
+    const int q = blockIdx.x * 256 + threadIdx.x, g = q / 12, e = q - 12 * g;
+    if (g >= nCamsAll || (g >= skip0 && g < skip0 + nSkip)) return;
+    const double* p = (const double*)(recv + (size_t)g * recWords + ((nFeatWords + 1) & ~1));
+    if (e < 9)
+        R[9 * (size_t)g + e] = p[e];
+    else
+        t[3 * (size_t)g + (e - 9)] = p[e];
 }
 
 }  // namespace
@@ -237,6 +252,35 @@ int cs_exchange_buffers(cs_exchange* x, void** d_recv, size_t* record_bytes) {
     if (!x) return CS_ERR_INVALID;
     if (d_recv) *d_recv = x->recv;
     if (record_bytes) *record_bytes = sizeof(int) * x->recWords;
+    return CS_OK;
+}
+
+// the poses of every gathered camera into d_R [world * nCamsLocal][9], d_t [..][3]; skipOwn != 0: this rank's own cameras are not
+// written (the arrays already hold them: the pose solve wrote them in place)
+int cs_exchange_unpack_poses_dev(cs_exchange* x, void* hip_stream, double* d_R, double* d_t, int skipOwn) {
+    if (!x || !d_R || !d_t) {
+        cs_set_error("cs_exchange_unpack_poses_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(x->c->device));
+    const int nAll = x->nCams * x->c->world;
+    hipLaunchKernelGGL(k_exchange_unpack_poses, dim3((nAll * 12 + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, x->recv, (int)x->recWords,
+                       x->nFeat * 5, nAll, x->c->rank * x->nCams, skipOwn ? x->nCams : 0, d_R, d_t);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+// one buffer from rank `root` to every rank, in place, on hip_stream (ncclBroadcast): the packed result of a bundle adjustment
+// (cs_ba_output_*) from the rank that solved the window to every replica of the map
+int cs_comm_broadcast_dev(cs_comm* c, void* hip_stream, void* d_buf, size_t bytes, int root) {
+    RcclApi* api = rccl_api();
+    if (!api || !c || !d_buf || root < 0 || root >= c->world) {
+        cs_set_error("cs_comm_broadcast_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (c->world == 1 || bytes == 0) return CS_OK;
+    CS_HIP(hipSetDevice(c->device));
+    CS_NCCL(api->broadcast(d_buf, d_buf, bytes, ncclInt8, root, c->comm, (hipStream_t)hip_stream));
     return CS_OK;
 }
 

@@ -7,9 +7,13 @@
 // Design: the whole estimate -- up to 5 re-weighting rounds x up to 100 LM steps -- is ONE launch of ONE
 // workgroup per camera (a batch of cameras = a grid of workgroups).  The reference is a serial loop
 // over <= 192 points with 7 projections each; here lane i owns point i, the 21+6 entries of the
-// weighted normal equations are folded with 64-lane butterflies and a 4-entry LDS exchange between the
-// waves, and every lane then runs the 6x6 Gauss-Jordan and the LM accept/reject logic redundantly on
-// identical inputs, so the control flow stays uniform with no host round trip per iteration.
+// weighted normal equations AND the weighted error of the same pose are folded together with one
+// transposed 64-lane butterfly per wave and one LDS exchange between the waves (one barrier), and
+// every lane then runs the 6x6 Gauss-Jordan and the LM accept/reject logic redundantly on identical
+// inputs, so the control flow stays uniform with no host round trip per iteration.  An LM step is ONE
+// pass over the points: the reference projects every point at a tentative pose for its error and, once
+// it has accepted the pose, again for the next step's Jacobians -- the same numbers; here the pass at
+// the tentative pose yields both (lm_pass), and a round's Tukey weights are computed inside its first pass.
 // The arithmetic per point is the reference's, operation for operation (numeric Jacobians included):
 // only the order of the sum over points differs from the serial CPU loop.
 #include "cs_common.h"
@@ -67,33 +71,6 @@ __device__ __forceinline__ void project(const double* K, const double* R, const 
     m[1] = v / w;
 }
 
-// sum NV per-thread values over the workgroup (PB threads); result identical in every thread
-template <int PB, int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double* lds /* [PB/64][NV] */) {
-    constexpr int NW = PB / 64;
-    if (NV >= 4) {
-        cs_wave_sum_many_d<NV>(v);  // 27 sums of the normal equations: ~N exchanges instead of 6 N
-    } else {
-#pragma unroll
-        for (int q = 0; q < NV; ++q) v[q] = cs_wave_sum_d(v[q]);
-    }
-    if (NW == 1) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < NV; ++q) lds[wv * NV + q] = v[q];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-        double s = lds[q];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) s += lds[w * NV + q];
-        v[q] = s;
-    }
-    __syncthreads();
-}
-
 // (A + lambda I) p = B by Gauss-Jordan elimination with partial pivoting on [A | B], fully unrolled so that the
 // 42 entries stay in registers (the reference forms the LAPACK inverse and multiplies: same solution, and the
 // pivot row at every step is the same row -- the largest remaining entry of the column).
@@ -149,33 +126,62 @@ struct PoseCtx {
     double dR[3][9];      // exp(eps e_k): independent of the iterate (SL_IntraCamPose.cpp:57-58)
 };
 
+// The 27 sums of the weighted normal equations and the weighted squared error, over the workgroup, in every lane: the waves'
+// transposed butterflies leave each total in ONE lane, which stores it; ONE barrier; every lane adds the waves' totals in wave
+// order.  The scratch is double-buffered (`par` flips per call), so no second barrier protects it from the next call's stores.
+constexpr int NSUM = 28;
 template <int PB>
-__device__ double reproj_err2_weighted(const PoseCtx& c, const double* R, const double* t) {  // :439-456
-    double e[1] = {0};
-    for (int i = threadIdx.x; i < c.npts; i += PB) {
-        double rm[2];
-        project(c.K, R, t, c.Ms + 3 * i, rm);
-        double dx = c.ms[2 * i] - rm[0], dy = c.ms[2 * i + 1] - rm[1];
-        e[0] += (dx * dx + dy * dy) * c.Ws[i];
+__device__ __forceinline__ void block_sum28(double (&v)[NSUM], double* lds /* [2][PB/64][NSUM] */, int& par) {
+    constexpr int NW = PB / 64;
+    if (NW == 1) {
+        cs_wave_sum_many_d<NSUM>(v);
+        return;
     }
-    block_sum<PB, 1>(e, c.red);
-    return e[0];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    cs_reduce_many<NSUM>(v, lane);
+    const int mine = cs_reduce_index<NSUM>(lane);
+    double* buf = lds + par * (NW * NSUM);
+    par ^= 1;
+    if (mine >= 0) buf[wv * NSUM + mine] = v[0];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NSUM; ++q) {
+        double s = buf[q];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += buf[w * NSUM + q];
+        v[q] = s;
+    }
 }
 
+// ONE pass over the points at the pose (R, t): acc[0..20] the upper triangle of sum J^T J, acc[21..26] sum J^T r
+// (intraCamWeightedLMStep, :259-303: forward-difference Jacobians, eps = 1e-8, the weight on J and on r) and acc[27] the weighted
+// squared reprojection error (:439-456: the weight once).  The reference evaluates the error of a tentative pose and, when it
+// accepts it, the Jacobians at that same pose in its next step: the same projections twice.  Here the tentative pose gets both in
+// one pass -- accepted: the next step's normal equations are there; rejected: the previous ones are still in registers -- so an LM
+// step is ONE pass and ONE reduction.  reweight: first the Tukey weights from the residuals at (R, t) (:687-701), which is where
+// the reference computes them: at the pose the next round starts from.
 template <int PB>
-__device__ void weighted_lm_step(const PoseCtx& c, const double* R, const double* t, double* param, double lambda) {
+__device__ void lm_pass(const PoseCtx& c, const double* R, const double* t, bool reweight, double tau, double (&acc)[NSUM], int& par) {
     const double eps = 1e-8;
     // the perturbed rotations R * exp(eps e_k) do not depend on the point (:57-59)
     double R1[3][9];
 #pragma unroll
     for (int a = 0; a < 3; ++a) mat33AB(R, c.dR[a], R1[a]);
-    double acc[27];  // upper triangle of sA (21) + sB (6)
 #pragma unroll
-    for (int q = 0; q < 27; ++q) acc[q] = 0;
+    for (int q = 0; q < NSUM; ++q) acc[q] = 0;
     for (int i = threadIdx.x; i < c.npts; i += PB) {
         const double* pM = c.Ms + 3 * i;
         double rm0[2], rm[2], J[12];
         project(c.K, R, t, pM, rm0);
+        const double dx = rm0[0] - c.ms[2 * i], dy = rm0[1] - c.ms[2 * i + 1];
+        double w;
+        if (reweight) {
+            w = tukey(sqrt(dx * dx + dy * dy), tau);
+            c.Ws[i] = w;   // (a point's weight is read by the lane that wrote it: no barrier)
+        } else {
+            w = c.Ws[i];
+        }
+        acc[27] += (dx * dx + dy * dy) * w;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             project(c.K, R1[a], t, pM, rm);
@@ -190,7 +196,6 @@ __device__ void weighted_lm_step(const PoseCtx& c, const double* R, const double
             J[3 + a] = (rm[0] - rm0[0]) / eps;
             J[9 + a] = (rm[1] - rm0[1]) / eps;
         }
-        const double w = c.Ws[i];
 #pragma unroll
         for (int q = 0; q < 12; ++q) J[q] = w * J[q];
         const double r0 = (-rm0[0] + c.ms[2 * i]) * w, r1 = (-rm0[1] + c.ms[2 * i + 1]) * w;
@@ -202,7 +207,11 @@ __device__ void weighted_lm_step(const PoseCtx& c, const double* R, const double
 #pragma unroll
         for (int r = 0; r < 6; ++r) acc[21 + r] += J[r] * r0 + J[6 + r] * r1;
     }
-    block_sum<PB, 27>(acc, c.red);
+    block_sum28<PB>(acc, c.red, par);
+}
+
+// (sum J^T J + lambda I) p = sum J^T r
+__device__ __forceinline__ void lm_solve(const double (&acc)[NSUM], double lambda, double* param) {
     double sA[36], sB[6];
     int q = 0;
 #pragma unroll
@@ -232,11 +241,13 @@ __device__ __forceinline__ void update_pose(const double* R, const double* t, co
 
 template <int PB>
 __device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0, double* R_opt, double* t_opt,
-                            cs_pose_option& opt) {  // :475-549
+                            cs_pose_option& opt, bool reweight, double tau, int& par) {  // :475-549
     double param[6];
+    double ne[NSUM], cand[NSUM];   // the normal equations at the accepted pose; error + normal equations at the tentative one
     opt.npts = c.npts;
     opt.lambda = opt.lambda0;
-    opt.err0 = reproj_err2_weighted<PB>(c, R0, t0);
+    lm_pass<PB>(c, R0, t0, reweight, tau, ne, par);
+    opt.err0 = ne[27];
     opt.err = opt.err0;
     double R[9], t[3], R_tmp[9], t_tmp[3];
 #pragma unroll
@@ -247,7 +258,7 @@ __device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0
     int i = 0;
     double err = opt.err0;
     for (; i < opt.maxIterLM; ++i) {
-        weighted_lm_step<PB>(c, R, t, param, opt.lambda);
+        lm_solve(ne, opt.lambda, param);
         update_pose(R, t, param, R_opt, t_opt);
         double p2 = param[0] * param[0] + param[1] * param[1] + param[2] * param[2] + param[3] * param[3] +
                     param[4] * param[4] + param[5] * param[5];
@@ -255,7 +266,8 @@ __device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0
             opt.retTypeLM = 0;
             break;
         }
-        err = reproj_err2_weighted<PB>(c, R_opt, t_opt);
+        lm_pass<PB>(c, R_opt, t_opt, false, tau, cand, par);
+        err = cand[27];
         if (fabs(err - opt.err) < opt.epsErrorChangeLM) {
             opt.retTypeLM = 0;
             break;
@@ -265,6 +277,8 @@ __device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0
             for (int q = 0; q < 9; ++q) R[q] = R_tmp[q] = R_opt[q];
 #pragma unroll
             for (int q = 0; q < 3; ++q) t[q] = t_tmp[q] = t_opt[q];
+#pragma unroll
+            for (int q = 0; q < NSUM; ++q) ne[q] = cand[q];
             opt.err = err;
             opt.lambda /= 10;
         } else {
@@ -283,6 +297,7 @@ __device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0
     }
     opt.err = err;
     opt.nIterLM = i;
+    opt.verboseRW += i < opt.maxIterLM ? i + 1 : i;   // (diagnostic, see coslam_hip.h: LM steps taken over all rounds)
     return opt.retTypeLM >= 0;
 }
 
@@ -304,8 +319,8 @@ __global__ __launch_bounds__(PB) CS_IC_ATTR void k_intracam(int ptsStride, const
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int pb = blockIdx.x;
     constexpr int NW = PB / 64;
-    double* red = smem;            // [NW][27]
-    double* sK = smem + NW * 27;   // 9 (+3 pad)
+    double* red = smem;                  // [2][NW][NSUM]
+    double* sK = smem + 2 * NW * NSUM;   // 9 (+3 pad)
     double* WsL = sK + 12;         // npts (when it fits)
     const int npts = nptsAll[pb];
     if (threadIdx.x < 9) sK[threadIdx.x] = Kall[9 * pb + threadIdx.x];
@@ -333,10 +348,12 @@ __global__ __launch_bounds__(PB) CS_IC_ATTR void k_intracam(int ptsStride, const
 #pragma unroll
     for (int i = 0; i < 3; ++i) t[i] = t_opt[i] = t0all[3 * pb + i];
     bool ret = true;
-    int k = 0;
+    int k = 0, par = 0;
     opt.errRW = -1;
+    opt.verboseRW = 0;
     for (; k < opt.maxIterRW; ++k) {  // :664
-        if (!weighted_lm<PB>(c, R, t, R_opt, t_opt, opt)) {
+        // (round k > 0: the Tukey weights from the residuals at the pose it starts from, :687-701, inside its first pass)
+        if (!weighted_lm<PB>(c, R, t, R_opt, t_opt, opt, k > 0, tau, par)) {
             ret = false;
             break;
         }
@@ -354,13 +371,6 @@ __global__ __launch_bounds__(PB) CS_IC_ATTR void k_intracam(int ptsStride, const
         for (int i = 0; i < 9; ++i) R[i] = R_opt[i];
 #pragma unroll
         for (int i = 0; i < 3; ++i) t[i] = t_opt[i];
-        for (int i = threadIdx.x; i < npts; i += PB) {  // :687-701
-            double rm[2];
-            project(c.K, R, t, c.Ms + 3 * i, rm);
-            double dx = rm[0] - c.ms[2 * i], dy = rm[1] - c.ms[2 * i + 1];
-            c.Ws[i] = tukey(sqrt(dx * dx + dy * dy), tau);
-        }
-        __syncthreads();
     }
     opt.nIterRW = k;
     if (threadIdx.x == 0) {
@@ -415,11 +425,11 @@ int launch_intracam(hipStream_t stream, int nProb, int ptsStride, const double* 
                     const int* npts, const double* prevErrs, const double* Ms, const double* ms, double tau,
                     double* R_opt, double* t_opt, cs_pose_option* opt, int* ok, double* wsScratch) {
     if (ptsStride <= SMALL_NPTS) {
-        size_t lds = sizeof(double) * (1 * 27 + 12 + (wsScratch ? 0 : ptsStride));
+        size_t lds = sizeof(double) * (2 * 1 * NSUM + 12 + (wsScratch ? 0 : ptsStride));
         hipLaunchKernelGGL(k_intracam<64>, dim3(nProb), dim3(64), lds, stream, ptsStride, K, R0, t0, npts, prevErrs, Ms,
                            ms, tau, R_opt, t_opt, opt, ok, wsScratch);
     } else {
-        size_t lds = sizeof(double) * (4 * 27 + 12 + (wsScratch ? 0 : ptsStride));
+        size_t lds = sizeof(double) * (2 * 4 * NSUM + 12 + (wsScratch ? 0 : ptsStride));
         hipLaunchKernelGGL(k_intracam<256>, dim3(nProb), dim3(256), lds, stream, ptsStride, K, R0, t0, npts, prevErrs,
                            Ms, ms, tau, R_opt, t_opt, opt, ok, wsScratch);
     }

@@ -312,6 +312,7 @@ __global__ __launch_bounds__(256) void k_pose_update(PuArgs A) {
 // pointers; here a group of lanes = one (map point, camera) candidate, blockIdx.y = camera, the camera's ring of poses in LDS,
 // the track's past pixels from the history ring (one 16-byte gather per step).
 struct MgArgs {
+    int cam0;  // cameras cam0 .. cam0 + gridDim.y - 1
     int nCams, N, P, H, head, nHist;
     double sigma;
     const double* M;
@@ -329,7 +330,7 @@ struct MgArgs {
 constexpr int MG_LPC = 8;
 __global__ __launch_bounds__(256) void k_register_mergability(MgArgs A) {
     extern __shared__ double mg_pose[];  // [nHist][12]
-    const int c = blockIdx.y, tid = threadIdx.x, N = A.N, H = A.H;
+    const int c = A.cam0 + blockIdx.y, tid = threadIdx.x, N = A.N, H = A.H;
     const cs_poseupdate_cam& C = A.cam[c];
     const double* hR = A.histR + (size_t)c * H * 9;
     const double* hT = A.histT + (size_t)c * H * 3;
@@ -879,6 +880,23 @@ __global__ __launch_bounds__(256) void k_history_set_poses(int n, const int* __r
         hT[((size_t)c * H + rs) * 3 + (e - 9)] = t[3 * (size_t)i + (e - 9)];
 }
 
+// a run of consecutive frames [firstFrame, firstFrame + nFrames) of every camera out of / into the ring, camera-major
+// ([nCams][nFrames][9] / [3]): the nodes of the camera graphs RobustBundleRTS::constructCameraGraphs walks
+// (src/app/SL_CoSLAMRobustBA.cpp:182-227: every CamPoseItem from the window's first key frame to the newest frame) and where
+// updateNonKeyCameraPoses puts the relaxed poses back (:230-247).  set != 0: the array into the ring.
+__global__ __launch_bounds__(256) void k_history_span(int set, int nCams, int firstFrame, int nFrames, double* R, double* t, double* hR,
+                                                      double* hT, int H, int head, int lastFrame) {
+    const int q = blockIdx.x * 256 + threadIdx.x, i = q / 12, e = q - 12 * i;
+    if (i >= nCams * nFrames) return;
+    const int c = i / nFrames, f = firstFrame + (i - c * nFrames), rs = (head - (lastFrame - f) + 2 * H) % H;
+    double* a = e < 9 ? R + 9 * (size_t)i + e : t + 3 * (size_t)i + (e - 9);
+    double* b = e < 9 ? hR + ((size_t)c * H + rs) * 9 + e : hT + ((size_t)c * H + rs) * 3 + (e - 9);
+    if (set)
+        *b = *a;
+    else
+        *a = *b;
+}
+
 }  // namespace
 
 struct cs_track_history {
@@ -1054,6 +1072,16 @@ extern "C" int cs_pose_update_frame_dev(cs_track_history* h, void* hip_stream, c
 extern "C" int cs_register_mergability_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int P,
                                            const double* d_M, const double* d_cov, const int* d_slot, double pixelErrVar,
                                            unsigned char* d_mergeable) {
+    return cs_register_mergability_range_dev(h, hip_stream, 0, h ? h->nCams : 0, cams, P, d_M, d_cov, d_slot, pixelErrVar, d_mergeable);
+}
+
+extern "C" int cs_register_mergability_range_dev(const cs_track_history* h, void* hip_stream, int cam0, int nCamsRun,
+                                                 const cs_poseupdate_cam* cams, int P, const double* d_M, const double* d_cov,
+                                                 const int* d_slot, double pixelErrVar, unsigned char* d_mergeable) {
+    if (h && (cam0 < 0 || nCamsRun < 0 || cam0 + nCamsRun > h->nCams)) {
+        cs_set_error("cs_register_mergability_range_dev: camera range %d + %d of %d", cam0, nCamsRun, h->nCams);
+        return CS_ERR_INVALID;
+    }
     if (!h || !cams || P < 0 || (P > 0 && (!d_M || !d_cov || !d_slot || !d_mergeable))) {
         cs_set_error("cs_register_mergability_dev: bad arguments");
         return CS_ERR_INVALID;
@@ -1062,9 +1090,10 @@ extern "C" int cs_register_mergability_dev(const cs_track_history* h, void* hip_
         cs_set_error("cs_register_mergability_dev: the history holds no frame (cs_pose_update_frame_dev / cs_detect_dynamic_dev push one per frame)");
         return CS_ERR_INVALID;
     }
-    if (P == 0) return CS_OK;
+    if (P == 0 || nCamsRun == 0) return CS_OK;
     MgArgs A;
     memset(&A, 0, sizeof(A));
+    A.cam0 = cam0;
     A.nCams = h->nCams, A.N = h->N, A.P = P, A.H = h->H, A.head = h->head, A.nHist = h->count;
     A.sigma = pixelErrVar;
     A.M = d_M, A.cov = d_cov, A.slot = d_slot, A.out = d_mergeable;
@@ -1077,7 +1106,7 @@ extern "C" int cs_register_mergability_dev(const cs_track_history* h, void* hip_
         A.cam[c] = cams[c];
     }
     CS_HIP(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_register_mergability, dim3((P * MG_LPC + 255) / 256, h->nCams), dim3(256), sizeof(double) * 12 * (size_t)h->count,
+    hipLaunchKernelGGL(k_register_mergability, dim3((P * MG_LPC + 255) / 256, nCamsRun), dim3(256), sizeof(double) * 12 * (size_t)h->count,
                        (hipStream_t)hip_stream, A);
     CS_HIP(hipGetLastError());
     return CS_OK;
@@ -1096,6 +1125,36 @@ extern "C" int cs_track_history_set_poses_dev(cs_track_history* h, void* hip_str
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
+
+namespace {
+int hist_span(const char* who, cs_track_history* h, void* hip_stream, int set, int firstFrame, int nFrames, double* d_R, double* d_t) {
+    if (!h || nFrames < 0 || (nFrames > 0 && (!d_R || !d_t))) {
+        cs_set_error("%s: bad arguments", who);
+        return CS_ERR_INVALID;
+    }
+    if (nFrames == 0) return CS_OK;
+    if (firstFrame + nFrames - 1 > h->lastFrame || h->lastFrame - firstFrame >= h->count) {
+        cs_set_error("%s: frames %d..%d are not all in the ring (it holds %d frame(s), the newest %d)", who, firstFrame, firstFrame + nFrames - 1,
+                     h->count, h->lastFrame);
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_history_span, dim3((h->nCams * nFrames * 12 + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, set, h->nCams,
+                       firstFrame, nFrames, d_R, d_t, h->R, h->t, h->H, h->head, h->lastFrame);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+}  // namespace
+
+extern "C" int cs_track_history_get_span_dev(const cs_track_history* h, void* hip_stream, int firstFrame, int nFrames, double* d_R, double* d_t) {
+    return hist_span("cs_track_history_get_span_dev", (cs_track_history*)h, hip_stream, 0, firstFrame, nFrames, d_R, d_t);
+}
+extern "C" int cs_track_history_set_span_dev(cs_track_history* h, void* hip_stream, int firstFrame, int nFrames, const double* d_R,
+                                             const double* d_t) {
+    return hist_span("cs_track_history_set_span_dev", h, hip_stream, 1, firstFrame, nFrames, (double*)d_R, (double*)d_t);
+}
+extern "C" int cs_track_history_newest_frame(const cs_track_history* h) { return h ? h->lastFrame : -0x7fffffff; }
+extern "C" int cs_track_history_cams(const cs_track_history* h) { return h ? h->nCams : 0; }
 
 namespace {
 int up_launch(const char* who, const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, UpArgs& A, int* d_counts, int nCounts) {

@@ -34,7 +34,7 @@ namespace {
 constexpr int RG_MAX_CAMS = 16;
 
 struct RgArgs {
-    int nCams, N, W, H, nPass;
+    int nCams, N, W, H, nPass, cam0;   // cameras cam0 .. cam0 + gridDim.y - 1 of the nCams-wide tables
     cs_register_pass pass[2];  // blockIdx.z: the passes of a frame share ONE launch (cs_register_search_passes_dev)
     cs_register_cam cam[RG_MAX_CAMS];
 };
@@ -89,7 +89,7 @@ constexpr int RG_CHUNK = 4096;    // features staged in LDS at a time (64 KB); l
 __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.y;
+    const int c = A.cam0 + blockIdx.y;
     const int p = blockIdx.x * 64 + lane;
     const cs_register_pass& Q = A.pass[blockIdx.z];
     const cs_register_cam& C = A.cam[c];
@@ -228,13 +228,24 @@ int check_args(const char* who, int nCams, const cs_register_cam* cams, int N, i
 
 extern "C" int cs_register_search_passes_dev(int device, void* hip_stream, int nCams, const cs_register_cam* cams, int N, int W, int H,
                                              int nPass, const cs_register_pass* passes) {
+    return cs_register_search_passes_range_dev(device, hip_stream, nCams, 0, nCams, cams, N, W, H, nPass, passes);
+}
+
+// cameras cam0 .. cam0 + nCamsRun - 1 only: their columns of the nCams-wide tables (a rank that holds every camera's records but
+// searches only for the cameras it owns)
+extern "C" int cs_register_search_passes_range_dev(int device, void* hip_stream, int nCams, int cam0, int nCamsRun, const cs_register_cam* cams,
+                                                   int N, int W, int H, int nPass, const cs_register_pass* passes) {
+    if (cam0 < 0 || nCamsRun < 0 || cam0 + nCamsRun > nCams) {
+        cs_set_error("cs_register_search_passes_range_dev: camera range %d + %d of %d", cam0, nCamsRun, nCams);
+        return CS_ERR_INVALID;
+    }
     if (nPass < 1 || nPass > 2 || !passes) {
         cs_set_error("cs_register_search_passes_dev: 1 or 2 passes");
         return CS_ERR_INVALID;
     }
     RgArgs A;
     memset(&A, 0, sizeof(A));
-    A.nCams = nCams, A.N = N, A.W = W, A.H = H, A.nPass = nPass;
+    A.nCams = nCams, A.N = N, A.W = W, A.H = H, A.nPass = nPass, A.cam0 = cam0;
     int maxP = 0;
     for (int k = 0; k < nPass; ++k) {
         const cs_register_pass& q = passes[k];
@@ -247,8 +258,8 @@ extern "C" int cs_register_search_passes_dev(int device, void* hip_stream, int n
         A.pass[k] = q;
         if (q.P > maxP) maxP = q.P;
     }
-    if (maxP == 0) return CS_OK;
-    for (int c = 0; c < nCams; ++c) {
+    if (maxP == 0 || nCamsRun == 0) return CS_OK;
+    for (int c = cam0; c < cam0 + nCamsRun; ++c) {
         const cs_register_cam& q = cams[c];
         if (!q.K || !q.R || !q.t || !q.xy || !q.state || !q.slot2map) {
             cs_set_error("cs_register_search_passes_dev: null pointer in camera %d", c);
@@ -266,7 +277,7 @@ extern "C" int cs_register_search_passes_dev(int device, void* hip_stream, int n
             raised = true;
         }
     }
-    hipLaunchKernelGGL(k_register_search, dim3((unsigned)((maxP + 63) / 64), (unsigned)nCams, (unsigned)nPass), dim3(64 * RG_WAVES), ldsBytes,
+    hipLaunchKernelGGL(k_register_search, dim3((unsigned)((maxP + 63) / 64), (unsigned)nCamsRun, (unsigned)nPass), dim3(64 * RG_WAVES), ldsBytes,
                        (hipStream_t)hip_stream, A);
     CS_CHECK_LAUNCH();
     return CS_OK;

@@ -1,0 +1,466 @@
+"""The body of CoSLAM's main loop over device-resident state, one process per GPU.
+
+What the reference runs per frame on its tracking thread (src/gui/CoSLAMThread.cpp:95-125: grabReadFrame, featureTracking, poseUpdate,
+activeMapPointsRegister, genNewMapPoints, currentMapPointsRegister) with the bundle adjuster on a second thread
+(src/app/SL_CoSLAM.cpp:1702-1784), as streams of libcoslam_hip calls:
+
+    tracker stream   redetect of the rank's OWN cameras (one camera group)                          [featureTracking -> GPUKLT::next]
+    pose stream      BA output due this frame (cs_ba_output_apply_dev)                              [RobustBundleRTS::output]
+                     hand-back + intraCamEstimate of the own cameras                                [poseUpdate3D, first half]
+                     N > 1: ONE all-gather of every camera's {dest[], R, t}; hand-back of the OTHER ranks' cameras from the gathered
+                            dest[] -- every rank then holds every camera's records and poses, bit for bit
+                     gate + seqTriangulate + dynamic test over ALL cameras, mapPointsClassify          [poseUpdate3D second half, :381-385]
+                     registration search + staticCheckMergability for the own cameras' columns       [activeMapPointsRegister, currentMapPointsRegister]
+                     every 4th frame: NCC matching of the own consecutive camera pairs              [genNewMapPoints -> NewMapPtsNCC]
+    key frames       every rank pushes the key frame into its window ring (identical on every rank); window k is SOLVED by rank
+                     k mod N (cs_ba_solve_window_flags_async on that rank's worker thread), the inter-camera solve by rank
+                     (k + N / 2) mod N; `ba_lag` key-frame intervals later the solving rank broadcasts the packed result and EVERY rank
+                     applies it to its replica of the map, the pose history and the window ring at the same frame.
+
+Because every step that writes the map (gate, classify, BA output) runs on every rank over all cameras in the same order on the same
+inputs, the replicas never diverge: there is ONE map, held N times.  What is sharded is what is per camera and costs the time: tracking,
+the pose solve, the registration search, the NCC cutter.  What added GPUs buy on the key-frame side is TIME: a rank solves every N-th
+window and has N key-frame intervals for it, so the solve's latency chain leaves the frame's critical path.
+The apply lag makes a run reproducible (the reference applies a result whenever its BA thread gets the lock, :1713-1720).
+"""
+import ctypes as C
+
+import numpy as np
+
+PIXEL_ERR_VAR = 10.0      # Const::PIXEL_ERR_VAR, reference src/app/SL_GlobParam.cpp:37
+MAX_EPI_ERR = 6.0         # Const::MAX_EPI_ERR, :36
+
+
+class LoopConfig:
+    def __init__(self, **kw):
+        self.n_cams, self.W, self.H, self.levels, self.fw, self.fh = 8, 640, 480, 4, 50, 40
+        self.pts_stride, self.n_col_blk, self.n_row_blk = 192, 16, 12    # reference src/app/SL_SingleSLAM.h:36-37
+        self.key_every, self.n_key_frames = 5, 5                         # requestForBA(5, 2, 2, 30), SL_CoSLAM.cpp:1345
+        self.ba_lag = 0            # key-frame intervals between a window's key frame and the frame its result is applied; 0 = min(N, 4)
+        self.p_reg = 1536
+        self.hist = 64
+        self.ncc_every, self.ncc_pair_cap = 4, 1 << 16
+        self.klt_cams_per_launch = 0
+        self.klt_fused = True      # False: one launch per Gauss-Newton pass (bit-identical): for SEVERAL processes sharing one GPU, where the
+                                   # persistent tracker's co-residency budget does not hold
+        self.prefetch = True
+        self.with_pose_update = self.with_classify = self.with_register = self.with_mergability = self.with_ncc = True
+        self.with_joint = self.with_intercam = True
+        self.native_comm = True
+        self.device_wait = True    # the BA result's apply waits for the solve on the device (cs_ba_output_wait_dev), not on the host
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise TypeError(f"LoopConfig: unknown field {k}")
+            setattr(self, k, v)
+
+    @property
+    def n_feat(self):
+        return self.fw * self.fh
+
+
+class FrameLoop:
+    """Device state of ONE rank and the enqueue of one frame.  `video`: dict camera -> uint8 tensor [T, H, W] on the device for
+    the rank's own cameras; `scene`: K, points (the map), pose(cam, frame) (first frame's poses, F matrices of the NCC leg);
+    `ic`: the inter-camera problem (coslam_amd.synth.make_intercam_problem); `klt_cfg`: KLT_SequenceTrackerConfig."""
+
+    def __init__(self, cfg, scene, video, ic, klt_cfg, map_cov, rank=0, world=1, device=0, dist_backend="nccl", associate=None):
+        import torch
+
+        import coslam_amd
+        from coslam_amd.ba import BAOutput, BAWindow, BAWorkspace
+        from coslam_amd.handback import handback_cams
+        from coslam_amd.poseupdate import TrackHistory, poseupdate_cams
+        from coslam_amd.register import register_cams, register_passes
+
+        self.torch = torch
+        self.cfg, self.sc, self.ic = cfg, scene, ic
+        self.rank, self.world, self.device = rank, world, device
+        NA, N = cfg.n_cams, cfg.n_feat
+        if NA % world:
+            raise ValueError(f"{NA} cameras do not shard over {world} ranks")
+        self.nc = nc = NA // world
+        self.c0 = c0 = rank * nc
+        self.my_cams = list(range(c0, c0 + nc))
+        self.lag = cfg.ba_lag if cfg.ba_lag > 0 else min(max(world, 1), 4)
+        if (cfg.n_key_frames - 1 + self.lag) * cfg.key_every + 1 > cfg.hist:
+            raise ValueError("the pose history is shorter than a window + its apply lag")
+        dev = self.dev = torch.device("cuda", device)
+        self.T = int(next(iter(video.values())).shape[0])
+        self.video = video
+        self.associate = associate
+        n_map = self.n_map = len(scene.points)
+        f64, i32, u8 = torch.float64, torch.int32, torch.uint8
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
+        K = np.ascontiguousarray(scene.K, dtype=np.float64)
+        self.d_K = torch.from_numpy(np.tile(K.ravel(), NA)).to(dev)
+        self.d_K1 = torch.from_numpy(K.ravel().copy()).to(dev)
+        self.d_iK1 = torch.from_numpy(np.linalg.inv(K).ravel().copy()).to(dev)
+        self.d_kud = z(7, f64)
+        # ---- the ONE map (a replica per rank) and every camera's records
+        self.d_map = torch.from_numpy(np.ascontiguousarray(scene.points, dtype=np.float64).copy()).to(dev)
+        self.d_cov = torch.from_numpy(np.ascontiguousarray(map_cov, dtype=np.float64).reshape(-1).copy()).to(dev)
+        self.d_mapflags = z(n_map, u8)
+        self.d_newpt, self.d_sfn, self.d_firstfrm = z(n_map, u8), z(n_map, i32), z(n_map, i32)
+        self.d_slot2map = torch.full((NA, N), -1, dtype=i32, device=dev)
+        self.d_trackspan = torch.full((NA, 2 * N), -1, dtype=i32, device=dev)
+        self.d_xy, self.d_state = z((NA, 2 * N), f64), z((NA, N), i32)
+        self.d_Ms, self.d_ms, self.d_sel = z((NA, cfg.pts_stride, 3), f64), z((NA, cfg.pts_stride, 2), f64), z((NA, cfg.pts_stride), i32)
+        self.d_npts, self.d_opt, self.d_ok = z(NA, i32), z((NA, 96), u8), z(NA, i32)
+        self.d_isstatic, self.d_reproj = torch.ones((NA, N), dtype=u8, device=dev), z((NA, N), f64)
+        self.d_pf = torch.full((n_map, NA), -1, dtype=i32, device=dev)          # MapPoint::pFeatures of this frame (hand-back)
+        self.d_pf_none = torch.full((cfg.p_reg, NA), -1, dtype=i32, device=dev)
+        R0 = np.stack([scene.pose(c, 0)[0].ravel() for c in range(NA)])
+        t0 = np.stack([scene.pose(c, 0)[1] for c in range(NA)])
+        self.d_R = [torch.from_numpy(R0.copy()).to(dev), torch.from_numpy(R0.copy()).to(dev)]   # pose ping-pong: frame i reads [(i+1)&1]
+        self.d_t = [torch.from_numpy(t0.copy()).to(dev), torch.from_numpy(t0.copy()).to(dev)]
+        self.d_dests = [[z(N * 5, i32) for _ in range(nc)] for _ in range(2)]
+        self.d_counts = [z(4, i32) for _ in range(nc)]
+        self.d_cls_counts, self.d_apply_counts = z(2, i32), z(3, i32)
+        self.d_mergeable = z((cfg.p_reg, NA), u8)
+        self.reg_out = [dict(slot=z((cfg.p_reg, NA), i32), m=z((cfg.p_reg, NA, 2), f64), var=z((cfg.p_reg, NA, 4), f64),
+                             dist=z((cfg.p_reg, NA), f64), flags=z((cfg.p_reg, NA), i32)) for _ in range(2)]
+        # ---- streams
+        self.klt_s, self.pose_s = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.klt_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self.dest_free = [torch.cuda.Event(), torch.cuda.Event()]
+        # ---- trackers of the own cameras
+        self.trks = []
+        for _ in self.my_cams:
+            t = coslam_amd.KLT_SequenceTracker(klt_cfg, device=device)
+            t.allocate(cfg.W, cfg.H, cfg.levels, cfg.fw, cfg.fh)
+            if not cfg.klt_fused:
+                t.set_fused(False)
+            self.trks.append(t)
+        self.grp = coslam_amd.KLT_TrackerGroup(self.trks)
+        self.grp.set_stream(self.klt_s.cuda_stream)
+        if cfg.klt_cams_per_launch > 0:
+            for t in self.trks:   # co-residency budget of the persistent tracker = that many cameras per launch
+                t.set_cu_count(min(256, (250 * cfg.klt_cams_per_launch + 60) // 8 + 5))
+        # ---- multi-GPU exchange
+        self.xchg = self.native = None
+        if world > 1:
+            from coslam_amd import multicam
+
+            if cfg.native_comm and dist_backend == "nccl":
+                self.native = multicam.NativeComm(world, rank, device)
+            self.xchg = multicam.CameraExchange(N * nc, dev, native=self.native, cams_per_rank=nc)
+        # ---- per-camera argument tables (built once)
+        def hb_cam(g, dest):
+            return dict(dest=dest, K=self.d_K1.data_ptr(), kud=self.d_kud.data_ptr(), mapPts=self.d_map.data_ptr(),
+                        slot2map=self.d_slot2map[g].data_ptr(), trackSpan=self.d_trackspan[g].data_ptr(), xy=self.d_xy[g].data_ptr(),
+                        state=self.d_state[g].data_ptr(), Ms=self.d_Ms[g].data_ptr(), ms=self.d_ms[g].data_ptr(), sel=self.d_sel[g].data_ptr(),
+                        npts=self.d_npts[g:g + 1].data_ptr(), opt=self.d_opt[g].data_ptr(), pointFeat=self.d_pf.data_ptr() + 4 * g,
+                        pointFeatStride=NA, nPointFeat=n_map, isStatic=(self.d_isstatic[g].data_ptr() if cfg.with_pose_update else 0))
+
+        self.hb_own = [handback_cams([hb_cam(c0 + i, self.d_dests[b][i].data_ptr()) for i in range(nc)]) for b in range(2)]
+        self.hb_other = None
+        if world > 1:
+            others = [g for g in range(NA) if g not in self.my_cams]
+            self.hb_other = handback_cams([hb_cam(g, self.xchg.record_ptr(g, device)) for g in others])
+        # (the window's push reads xy / state / slot2map of every camera; dest is not looked at)
+        self.hb_all = handback_cams([hb_cam(g, self.d_dests[0][0].data_ptr()) for g in range(NA)])
+        self.dest_ptrs = [[d.data_ptr() for d in self.d_dests[b]] for b in range(2)]
+        self.cnt_ptrs = [c.data_ptr() for c in self.d_counts]
+        self.img_ptrs = [[self.video[c][f].data_ptr() for c in self.my_cams] for f in range(self.T)]
+        self.pose_upd = None
+        if cfg.with_pose_update:
+            self.pose_upd = TrackHistory(NA, N, cfg.hist, device=device)
+            self.pu_args = poseupdate_cams([dict(K=self.d_K1.data_ptr(), iK=self.d_iK1.data_ptr(), xy=self.d_xy[g].data_ptr(),
+                                                 state=self.d_state[g].data_ptr(), slot2map=self.d_slot2map[g].data_ptr(),
+                                                 trackSpan=self.d_trackspan[g].data_ptr(), reprojErr=self.d_reproj[g].data_ptr(),
+                                                 isStatic=self.d_isstatic[g].data_ptr()) for g in range(NA)])
+        self.reg_args = [register_cams([dict(K=self.d_K1.data_ptr(), R=self.d_R[b].data_ptr() + 72 * g, t=self.d_t[b].data_ptr() + 24 * g,
+                                             xy=self.d_xy[g].data_ptr(), state=self.d_state[g].data_ptr(),
+                                             slot2map=self.d_slot2map[g].data_ptr()) for g in range(NA)]) for b in range(2)]
+        # CoSLAMThread.cpp:108 activeMapPointsRegister, then :117 currentMapPointsRegister (static points), search step
+        self.reg_passes = register_passes([dict(P=cfg.p_reg, sigmaSearch=sS, maxDist=3 * PIXEL_ERR_VAR, sigmaMerge=PIXEL_ERR_VAR,
+                                                M=self.d_map.data_ptr() + 24 * off, cov=self.d_cov.data_ptr() + 72 * off, pointFeat=pf.data_ptr(),
+                                                slot=self.reg_out[k]["slot"].data_ptr(), m=self.reg_out[k]["m"].data_ptr(),
+                                                var=self.reg_out[k]["var"].data_ptr(), dist=self.reg_out[k]["dist"].data_ptr(),
+                                                flags=self.reg_out[k]["flags"].data_ptr())
+                                           for k, (off, pf, sS) in enumerate(((cfg.p_reg, self.d_pf_none, 2.5 * PIXEL_ERR_VAR),
+                                                                              (0, self.d_pf, PIXEL_ERR_VAR)))])
+        # ---- key-frame solves
+        self.ba_ws, self.ic_ws = BAWorkspace(device), BAWorkspace(device)
+        self.win = self.out = None
+        if cfg.with_joint and self.pose_upd is not None:
+            self.win = BAWindow(NA, cfg.n_key_frames, N, n_map, device=device)
+            self.win.reserve(self.ba_ws)
+            self.out = BAOutput(NA, cfg.n_key_frames, n_map, n_slots=8, device=device)
+            self.out.attach(self.ba_ws)
+            self.recv_rec = z((2, self.out.record_bytes), u8)     # records solved by other ranks arrive here
+        from coslam_amd.synth import csr_of_problem
+
+        iptr, icam, ixy = csr_of_problem(ic)
+        self.ic_ws.upload(ic["Ks"], ic["Rs0"], ic["ts0"], ic["pts0"], iptr, icam, ixy)
+        self.d_iR = torch.from_numpy(ic["Rs0"].reshape(-1).copy()).to(dev)
+        self.d_iT = torch.from_numpy(ic["ts0"].reshape(-1).copy()).to(dev)
+        self.d_iM = torch.from_numpy(ic["pts0"].reshape(-1).copy()).to(dev)
+        self.n_pushed = self.n_windows = self.n_key = self.n_my_solves = self.n_my_ic = 0
+        self.apply_at, self.my_seq = {}, {}
+        self.applied, self.last_apply = 0, None
+        self.stage_slot, self.h_frames = {}, None
+        import os as _os
+
+        self._timing = {} if _os.environ.get("FRAMELOOP_TIMING") else None   # (diagnostic: host seconds per section)
+        self._init_ncc()
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def _sec(self, name):
+        """diagnostic (FRAMELOOP_TIMING=1): host seconds spent inside a section of the enqueue"""
+        import contextlib
+        import time as _t
+
+        if self._timing is None:
+            return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def cm():
+            t0 = _t.perf_counter()
+            try:
+                yield
+            finally:
+                self._timing[name] = self._timing.get(name, 0.0) + _t.perf_counter() - t0
+        return cm()
+
+    def vid(self, i):
+        return i % self.T
+
+    def _init_ncc(self):
+        torch, cfg = self.torch, self.cfg
+        self.ncc = None
+        if not cfg.with_ncc or self.nc < 2:
+            return
+        from coslam_amd.ncc import NCC_PAIR_DTYPE, ncc_scaled_dims
+
+        ws_, hs_ = ncc_scaled_dims(cfg.W, cfg.H, 0.3)
+        Kinv = np.linalg.inv(self.sc.K)
+
+        def f_matrix(c1, c2, f):
+            (R1, t1), (R2, t2) = self.sc.pose(c1, f), self.sc.pose(c2, f)
+            R = R1 @ R2.T
+            t = t1 - R @ t2
+            E = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
+            return Kinv.T @ E @ Kinv
+
+        nc, N, dev = self.nc, cfg.n_feat, self.dev
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
+        self.ncc = dict(small=z((nc, ws_ * hs_), torch.uint8), blk=z((nc, N, 128), torch.uint8), abc=z((nc, N, 4), torch.float64),
+                        valid=z((nc, N), torch.int32), runs=0,
+                        F={(c, f): f_matrix(c, c + 1, f) for c in self.my_cams[:-1] for f in range(0, self.T)},
+                        pairs=z((nc - 1, cfg.ncc_pair_cap * NCC_PAIR_DTYPE.itemsize), torch.uint8), pair_count=z(nc - 1, torch.int32),
+                        group={})
+
+    def _ncc_leg(self, f):
+        import coslam_amd
+        from coslam_amd._lib import check
+        from coslam_amd.ncc import ncc_cams, ncc_epi_pairs_group_dev, ncc_get_blocks_group_dev, ncc_pair_jobs
+
+        cfg, nc, c0, N, ncc = self.cfg, self.nc, self.c0, self.cfg.n_feat, self.ncc
+        s_ = self.pose_s.cuda_stream
+        # unmapped features of this frame: state 0 / 1 and no map point (the own cameras' hand-back records, back to back)
+        check(coslam_amd.lib().cs_ncc_unmapped_mask_dev(self.device, C.c_void_p(s_), nc * N, C.c_void_p(self.d_state[c0].data_ptr()),
+                                                        C.c_void_p(self.d_slot2map[c0].data_ptr()), C.c_void_p(ncc["valid"].data_ptr())),
+              "cs_ncc_unmapped_mask_dev")
+        if f not in ncc["group"]:
+            cams_ = ncc_cams([dict(img=self.img_ptrs[f][i], x=self.d_xy[c0 + i].data_ptr(), y=self.d_xy[c0 + i].data_ptr() + 8 * N,
+                                   scaled=ncc["small"][i].data_ptr(), blocks=ncc["blk"][i].data_ptr(), abc=ncc["abc"][i].data_ptr(),
+                                   valid=ncc["valid"][i].data_ptr()) for i in range(nc)])
+            jobs_ = ncc_pair_jobs([dict(F=ncc["F"][(c0 + i, f)], camA=i, camB=i + 1, pairs=ncc["pairs"][i].data_ptr(),
+                                        count=ncc["pair_count"][i:i + 1].data_ptr()) for i in range(nc - 1)])
+            ncc["group"][f] = (cams_, jobs_)
+        cams_, jobs_ = ncc["group"][f]
+        ncc_get_blocks_group_dev(s_, cams_, cfg.W, cfg.H, N, 0.3, device=self.device)
+        ncc_epi_pairs_group_dev(s_, cams_, N, jobs_, 50.0, 0.80, cfg.ncc_pair_cap, device=self.device)   # SL_NewMapPointsInterCam.h:71-72
+        ncc["runs"] += 1
+
+    # ---------------------------------------------------------------------------------------------------------------
+    def first_frame(self):
+        """GPUKLT::first (reference src/tracking/GPUKLT.cpp:133-142) of every camera, the slot -> map-point association that stands
+        in for the map initialisation (out of scope), and the first hand-back."""
+        torch, cfg = self.torch, self.cfg
+        import coslam_amd
+        from coslam_amd.handback import handback_dev
+
+        NA, N = cfg.n_cams, cfg.n_feat
+        self.grp.detect_dev(self.img_ptrs[0], self.dest_ptrs[0], self.cnt_ptrs)
+        self.grp.advanceFrame()
+        self.grp.synchronize()
+        if self.world > 1:
+            with torch.cuda.stream(self.pose_s):
+                self.xchg.pack_group(self.d_dests[0], self.d_R[0][self.c0:self.c0 + self.nc], self.d_t[0][self.c0:self.c0 + self.nc], self.pose_s)
+                self.xchg.all_gather(self.pose_s)
+            torch.cuda.synchronize()
+        dests = []
+        for g in range(NA):
+            if g in self.my_cams:
+                w = self.d_dests[0][g - self.c0].cpu().numpy()
+            else:
+                w = self.xchg.unpack(g, device=self.device)[0].cpu().numpy().reshape(-1)
+            dests.append(np.ascontiguousarray(w, dtype=np.int32).view(coslam_amd.KLT_TrackedFeature))
+        s2m = np.stack([self.associate(self.sc, g, 0, dests[g]) for g in range(NA)])
+        self.d_slot2map.copy_(torch.from_numpy(s2m))
+        with torch.cuda.stream(self.pose_s):
+            self._handback(0, 0)
+        torch.cuda.synchronize()
+        self.d_slot2map.copy_(torch.from_numpy(s2m))   # the first hand-back starts every track as new (unmapped): put the map back
+        torch.cuda.synchronize()
+
+    def _handback(self, b, frame, which="all"):
+        from coslam_amd.handback import handback_dev
+
+        cfg = self.cfg
+        a = dict(N=cfg.n_feat, W=cfg.W, H=cfg.H, nColBlk=cfg.n_col_blk, nRowBlk=cfg.n_row_blk, ptsStride=cfg.pts_stride, device=self.device,
+                 frame=frame)
+        if which in ("all", "own"):
+            handback_dev(self.pose_s.cuda_stream, self.hb_own[b], **a)
+        if which in ("all", "other") and self.hb_other is not None:
+            handback_dev(self.pose_s.cuda_stream, self.hb_other, **a)
+
+    def _apply_due(self, i, src):
+        """RobustBundleRTS::output() of the window whose lag ends at this frame, before anything of frame i touches the map"""
+        due = self.apply_at.pop(i, None)
+        if due is None:
+            return
+        k, owner, first_key = due
+        if owner == self.rank:
+            # the pose stream waits ON THE DEVICE for this rank's worker to publish the record: the host goes on enqueueing frames
+            rec = self.out.wait_dev(self.my_seq.pop(k), self.pose_s.cuda_stream) if self.cfg.device_wait else self.out.wait(self.my_seq.pop(k))
+        else:
+            rec = self.recv_rec[k & 1].data_ptr()
+        if self.world > 1:
+            self.xchg.broadcast(rec, self.out.record_bytes, owner, self.device, self.pose_s)
+        self.out.apply_dev(rec, self.pose_s.cuda_stream, self.pose_upd, self.win, self.pu_args, self.d_pf.data_ptr(), self.n_map,
+                           self.d_map.data_ptr(), self.d_cov.data_ptr(), self.d_mapflags.data_ptr(), PIXEL_ERR_VAR, first_key,
+                           self.cfg.key_every, self.d_R[src].data_ptr(), self.d_t[src].data_ptr(), self.d_apply_counts.data_ptr())
+        self.applied += 1
+        self.last_apply = dict(window=k, solved_by_rank=owner, first_key_frame=first_key, applied_at_frame=i)
+
+    def stage(self, i):
+        f = self.vid(i)
+        self.stage_slot[i] = self.grp.stage_h([self.h_frames[f][c].data_ptr() for c in range(self.nc)])
+
+    def step(self, i, key_frame, upload=False):
+        from coslam_amd.pose import intraCamEstimate_batch_dev
+        from coslam_amd.register import register_search_passes_dev
+
+        torch, cfg = self.torch, self.cfg
+        klt_s, pose_s, c0, nc = self.klt_s, self.pose_s, self.c0, self.nc
+        f, fn = self.vid(i), self.vid(i + 1)
+        b = i & 1
+        if i >= 2:
+            klt_s.wait_event(self.dest_free[b])      # the consumer of this dest buffer two frames ago is done
+        if upload:
+            self.stage(i + 2)
+            cur, nxt = self.grp.staged(self.stage_slot.pop(i)), self.grp.staged(self.stage_slot[i + 1])
+        else:
+            cur, nxt = self.img_ptrs[f], self.img_ptrs[fn]
+        if cfg.prefetch:   # this frame's detector tail also builds the next frame's pyramids + cornerness maps
+            self.grp.prefetch_dev(nxt)
+        self.grp.redetect_dev(cur, self.dest_ptrs[b], self.cnt_ptrs)
+        self.grp.advanceFrame()
+        self.klt_done[b].record(klt_s)
+        pose_s.wait_event(self.klt_done[b])          # pose(f) consumes what the tracker produced for frame f
+        src, dst = (i + 1) & 1, i & 1
+        ps = pose_s.cuda_stream
+        if self.out is not None:
+            if self._timing is not None:
+                import time as _t
+
+                t0 = _t.perf_counter()
+                self._apply_due(i, src)
+                self._timing["apply"] = self._timing.get("apply", 0.0) + _t.perf_counter() - t0
+            else:
+                self._apply_due(i, src)
+        self._handback(b, i, "own")
+        intraCamEstimate_batch_dev(ps, nc, cfg.pts_stride, self.d_K.data_ptr(), self.d_R[src].data_ptr() + 72 * c0,
+                                   self.d_t[src].data_ptr() + 24 * c0, self.d_npts.data_ptr() + 4 * c0, 0,
+                                   self.d_Ms.data_ptr() + 24 * cfg.pts_stride * c0, self.d_ms.data_ptr() + 16 * cfg.pts_stride * c0, 10.0,
+                                   self.d_R[dst].data_ptr() + 72 * c0, self.d_t[dst].data_ptr() + 24 * c0, self.d_opt.data_ptr() + 96 * c0,
+                                   self.d_ok.data_ptr() + 4 * c0, device=self.device)
+        if self.world > 1:
+            # the merge step: every camera's {dest[], R, t} to every rank, then the other ranks' cameras through the same hand-back
+            with torch.cuda.stream(pose_s):
+                self.xchg.pack_group(self.d_dests[b], self.d_R[dst][c0:c0 + nc], self.d_t[dst][c0:c0 + nc], pose_s)
+                self.xchg.all_gather(pose_s)
+                self.xchg.unpack_poses(self.d_R[dst], self.d_t[dst], pose_s, skip_own=True)
+            self._handback(b, i, "other")
+        if self.pose_upd is not None:
+            # parallelPoseUpdate(false): gate 2.0, sigma = PIXEL_ERR_VAR; detectDynamicFeaturePoints(20, 5, 3, MAX_EPI_ERR)
+            self.pose_upd.pose_update_frame_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_R[dst].data_ptr(),
+                                                self.d_t[dst].data_ptr(), self.d_map.data_ptr(), self.d_cov.data_ptr(),
+                                                self.d_mapflags.data_ptr(), 0, PIXEL_ERR_VAR, i, 20, 5, 3, MAX_EPI_ERR)
+            if cfg.with_classify:
+                self.pose_upd.map_points_classify_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, i, self.d_map.data_ptr(),
+                                                      self.d_cov.data_ptr(), self.d_mapflags.data_ptr(), self.d_newpt.data_ptr(),
+                                                      self.d_sfn.data_ptr(), self.d_firstfrm.data_ptr(), 12.0,
+                                                      d_counts=self.d_cls_counts.data_ptr())
+        if cfg.with_register:
+            register_search_passes_dev(ps, self.reg_args[dst], cfg.n_feat, cfg.W, cfg.H, self.reg_passes, device=self.device, cam0=c0,
+                                       nCamsRun=nc)
+            if self.pose_upd is not None and cfg.with_mergability:
+                # staticCheckMergability of every candidate of the current-static pass over its whole track (SL_CoSLAM.cpp:714-729, :768)
+                self.pose_upd.register_mergability_dev(ps, self.pu_args, cfg.p_reg, self.d_map.data_ptr(), self.d_cov.data_ptr(),
+                                                       self.reg_out[1]["slot"].data_ptr(), PIXEL_ERR_VAR, self.d_mergeable.data_ptr(),
+                                                       cam0=c0, nCamsRun=nc)
+        self.dest_free[b].record(pose_s)
+        if key_frame:
+            if self._timing is not None:
+                import time as _t
+
+                t0 = _t.perf_counter()
+                self._key_frame(i, dst)
+                self._timing["key_frame"] = self._timing.get("key_frame", 0.0) + _t.perf_counter() - t0
+            else:
+                self._key_frame(i, dst)
+        if self.ncc is not None and i % cfg.ncc_every == 0:
+            self._ncc_leg(f)
+
+    def _key_frame(self, i, dst):
+        cfg, ps, NA = self.cfg, self.pose_s.cuda_stream, self.cfg.n_cams
+        k_ic = self.n_key
+        self.n_key += 1
+        if cfg.with_intercam and (k_ic + self.world // 2) % self.world == self.rank:
+            # InterCamPoseEstimator::addMapPoints (reference src/app/SL_InterCamPoseEstimator.cpp:24-37) starts the solve from every
+            # camera's CURRENT pose: all of them are here (own: just solved; others: this frame's all-gather)
+            with self.torch.cuda.stream(self.pose_s):
+                self.d_iR.copy_(self.d_R[dst].view(-1), non_blocking=True)
+                self.d_iT.copy_(self.d_t[dst].view(-1), non_blocking=True)
+            with self._sec("kf_intercam"):
+                self.ic_ws.solve_async(ps, self.d_iR.data_ptr(), self.d_iT.data_ptr(), self.d_iM.data_ptr(), 0, self.ic["n_static"], 6.0, 3, 40)
+            self.n_my_ic += 1
+        if self.win is None:
+            return
+        # this key frame into the ring (every camera's records and poses: identical on every rank), then requestForBA(5, 2, 2, 30):
+        # the numCams * 2 oldest key cameras held, 2 points held, maxIter 2, inner 10 -- solved by ONE rank
+        with self._sec("kf_push"):
+            self.win.push_dev(ps, self.hb_all, self.d_K1.data_ptr(), 1, self.d_R[dst].data_ptr(), self.d_t[dst].data_ptr(), i)
+        self.n_pushed += 1
+        if self.n_pushed < cfg.n_key_frames:
+            return
+        k = self.n_windows
+        self.n_windows += 1
+        owner = k % self.world
+        if owner == self.rank:
+            with self._sec("kf_request"):
+                self.win.solve_flags_async(self.ba_ws, ps, self.d_map.data_ptr(), self.d_mapflags.data_ptr(), 2 * NA, 2, 6.0, 2, 10)
+            self.my_seq[k] = self.n_my_solves
+            self.n_my_solves += 1
+        self.apply_at[i + self.lag * cfg.key_every] = (k, owner, i - (cfg.n_key_frames - 1) * cfg.key_every)
+
+    def drain(self):
+        """the worker threads' queues are part of the work: every requested solve completes"""
+        self.ic_ws.wait()
+        self.ba_ws.wait()
+        self.torch.cuda.synchronize()
+
+    def digest(self):
+        """sha256 over the state every rank must agree on (the map, its flags and covariances, every camera's records and poses)"""
+        import hashlib
+
+        self.torch.cuda.synchronize()
+        h = hashlib.sha256()
+        for t in (self.d_map, self.d_cov, self.d_mapflags, self.d_slot2map, self.d_trackspan, self.d_xy, self.d_state, self.d_isstatic,
+                  self.d_R[0], self.d_R[1], self.d_t[0], self.d_t[1], self.d_pf):
+            h.update(t.cpu().numpy().tobytes())
+        return h.hexdigest()

@@ -11,6 +11,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from contextlib import nullcontext as _nullcontext
+
 FEATURE_WORDS = 5   # sizeof(KLT_TrackedFeature) / 4
 POSE_WORDS = 24     # 12 doubles
 
@@ -145,6 +147,64 @@ class CameraExchange:
         self.native._L.cs_exchange_buffers(self._x, C.byref(p), C.byref(nb))
         total = nb.value * self.cams * self.world
         return torch.as_tensor(_DevArray(p.value, total, "|u1"), device=torch.device("cuda", device)), nb.value
+
+    def record_ptr(self, cam, device=None):
+        """device address of GLOBAL camera `cam`'s gathered record: its N KLT_TrackedFeature first -- what cs_klt_handback_dev takes as
+        `dest` for a camera another rank tracks"""
+        n1 = self.n // self.cams
+        w = record_words(n1)
+        if self._x is not None:
+            import ctypes as C
+
+            p, nb = C.c_void_p(), C.c_size_t(0)
+            self.native._L.cs_exchange_buffers(self._x, C.byref(p), C.byref(nb))
+            return p.value + cam * nb.value
+        return self.recv.data_ptr() + 4 * w * cam
+
+    def unpack_poses(self, d_R, d_t, stream=None, skip_own=True):
+        """every gathered camera's R | t into d_R [world * cams_per_rank, 9] / d_t [.., 3] (torch f64 tensors on this device), on
+        `stream`; skip_own: this rank's own cameras are left alone (the pose solve wrote them in place)"""
+        if self._x is not None:
+            import ctypes as C
+
+            from ._lib import check
+
+            s = stream.cuda_stream if stream is not None else torch.cuda.current_stream().cuda_stream
+            check(self.native._L.cs_exchange_unpack_poses_dev(self._x, C.c_void_p(s), C.c_void_p(d_R.data_ptr()), C.c_void_p(d_t.data_ptr()),
+                                                              1 if skip_own else 0), "cs_exchange_unpack_poses_dev")
+            return
+        n1 = self.n // self.cams
+        fp, w = feature_words_padded(n1), record_words(n1)
+        own = range(self.rank * self.cams, (self.rank + 1) * self.cams) if skip_own else ()
+        ctx = torch.cuda.stream(stream) if stream is not None else _nullcontext()
+        with ctx:
+            rec = self.recv.view(self.world * self.cams, w)
+            keep = [g for g in range(self.world * self.cams) if g not in own]
+            idx = torch.tensor(keep, device=self.recv.device)
+            d_R.view(-1, 9)[idx] = rec[idx, fp: fp + 18].contiguous().view(torch.float64).view(-1, 9)
+            d_t.view(-1, 3)[idx] = rec[idx, fp + 18: fp + 24].contiguous().view(torch.float64).view(-1, 3)
+
+    def broadcast(self, ptr, nbytes, root, device, stream=None):
+        """`nbytes` of device memory at `ptr` from rank `root` to every rank, in place (collective 3: a packed bundle-adjustment
+        result); native: ncclBroadcast on `stream` through the exchange communicator (same stream, same order on every rank as the
+        per-frame all-gather); torch path: dist.broadcast of a view of the same memory"""
+        if self.world == 1:
+            return
+        if self._x is not None:
+            import ctypes as C
+
+            from ._lib import check
+
+            s = stream.cuda_stream if stream is not None else torch.cuda.current_stream().cuda_stream
+            L = self.native._L
+            L.cs_comm_broadcast_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            check(L.cs_comm_broadcast_dev(self.native.exchange_comm, C.c_void_p(s), C.c_void_p(ptr), int(nbytes), int(root)),
+                  "cs_comm_broadcast_dev")
+            return
+        t = torch.as_tensor(_DevArray(ptr, nbytes, "|u1"), device=torch.device("cuda", device))
+        ctx = torch.cuda.stream(stream) if stream is not None else _nullcontext()
+        with ctx:
+            dist.broadcast(t, src=root, group=self.group)
 
     def close(self):
         if self._x is not None:

@@ -75,11 +75,14 @@ class TrackHistory:
                                             vp(d_mapFlags), int(frame), int(maxLen), int(minLen), int(minOutNum),
                                             C.c_double(maxEpiErr), vp(d_numDyn)), "cs_detect_dynamic_dev")
 
-    def register_mergability_dev(self, stream_ptr, cams, P, d_M, d_cov, d_slot, pixelErrVar, d_mergeable):
-        """CoSLAM::staticCheckMergability for every candidate of a registration search (d_slot: P x nCams), full track history."""
+    def register_mergability_dev(self, stream_ptr, cams, P, d_M, d_cov, d_slot, pixelErrVar, d_mergeable, cam0=0, nCamsRun=None):
+        """CoSLAM::staticCheckMergability for every candidate of a registration search (d_slot: P x nCams), full track history;
+        cam0 / nCamsRun: only these cameras' columns."""
         vp = C.c_void_p
-        check(self._L.cs_register_mergability_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), int(P), vp(d_M), vp(d_cov), vp(d_slot),
-                                                  C.c_double(pixelErrVar), vp(d_mergeable)), "cs_register_mergability_dev")
+        check(self._L.cs_register_mergability_range_dev(vp(self._h), vp(stream_ptr), int(cam0),
+                                                        int(self.nCams - cam0 if nCamsRun is None else nCamsRun), poseupdate_cams(cams),
+                                                        int(P), vp(d_M), vp(d_cov), vp(d_slot), C.c_double(pixelErrVar), vp(d_mergeable)),
+              "cs_register_mergability_range_dev")
 
     def pose_update_frame_dev(self, stream_ptr, cams, d_pointFeat, nMap, d_R, d_t, d_mapPts, d_mapCov, d_mapFlags, largeErr,
                               pixelErrVar, frame, maxLen=20, minLen=5, minOutNum=3, maxEpiErr=6.0, d_numNodes=None, d_numOut=None,
@@ -98,6 +101,21 @@ class TrackHistory:
         vp = C.c_void_p
         check(self._L.cs_track_history_set_poses_dev(vp(self._h), vp(stream_ptr), int(n), vp(d_cam), vp(d_frame), vp(d_R), vp(d_t)),
               "cs_track_history_set_poses_dev")
+
+    def get_span_dev(self, stream_ptr, first_frame, n_frames, d_R, d_t):
+        """poses of frames first_frame .. first_frame + n_frames - 1 of every camera out of the ring, [nCams][n_frames][9] / [3]"""
+        vp = C.c_void_p
+        check(self._L.cs_track_history_get_span_dev(vp(self._h), vp(stream_ptr), int(first_frame), int(n_frames), vp(d_R), vp(d_t)),
+              "cs_track_history_get_span_dev")
+
+    def set_span_dev(self, stream_ptr, first_frame, n_frames, d_R, d_t):
+        vp = C.c_void_p
+        check(self._L.cs_track_history_set_span_dev(vp(self._h), vp(stream_ptr), int(first_frame), int(n_frames), vp(d_R), vp(d_t)),
+              "cs_track_history_set_span_dev")
+
+    @property
+    def newest_frame(self):
+        return self._L.cs_track_history_newest_frame(C.c_void_p(self._h))
 
     def update_new_poses_points_dev(self, stream_ptr, cams, d_pointFeat, nMap, d_mapPts, d_mapCov, d_mapFlags, pixelErrVar,
                                     d_lastFrame=None, d_isCurrent=None, firstKeyFrame=-1, d_counts=None):

@@ -60,11 +60,14 @@ def register_passes(passes):
     return arr
 
 
-def register_search_passes_dev(stream_ptr, cams, N, W, H, passes, device=0):
-    """The registration passes of a frame (1 or 2) in ONE launch; cams / passes: lists of dicts or the prebuilt ctypes arrays."""
+def register_search_passes_dev(stream_ptr, cams, N, W, H, passes, device=0, cam0=0, nCamsRun=None):
+    """The registration passes of a frame (1 or 2) in ONE launch; cams / passes: lists of dicts or the prebuilt ctypes arrays.
+    cam0 / nCamsRun: only these cameras' columns of the len(cams)-wide tables (cs_register_search_passes_range_dev)."""
     arr = register_passes(passes)
-    check(lib().cs_register_search_passes_dev(int(device), C.c_void_p(stream_ptr), len(register_cams(cams)), register_cams(cams), int(N),
-                                              int(W), int(H), len(arr), arr), "cs_register_search_passes_dev")
+    ca = register_cams(cams)
+    check(lib().cs_register_search_passes_range_dev(int(device), C.c_void_p(stream_ptr), len(ca), int(cam0),
+                                                    int(len(ca) - cam0 if nCamsRun is None else nCamsRun), ca, int(N),
+                                                    int(W), int(H), len(arr), arr), "cs_register_search_passes_range_dev")
 
 
 def register_search(W, H, Ks, Rs, ts, xy, state, slot2map, isDynamic, Ms, covs, pointFeat, sigmaSearch, maxDist, sigmaMerge,

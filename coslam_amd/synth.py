@@ -34,7 +34,11 @@ def look_at(cam_pos, target):
 
 
 class Scene:
-    def __init__(self, n_cams=1, W=640, H=480, n_points=3000, seed=0xC051A, sigma=1.2, bg_amp=5.0):
+    def __init__(self, n_cams=1, W=640, H=480, n_points=3000, seed=0xC051A, sigma=1.2, bg_amp=5.0, loop_period=0):
+        """loop_period > 0: every camera moves on a smooth CLOSED curve with that period in frames (peak speed 1.5 cm/frame, peak
+        yaw rate 0.1 deg/frame: the figures of the straight path) -- a video of any length that never reverses and never jumps:
+        frame f and frame f + loop_period are the same image."""
+        self.loop_period = int(loop_period)
         self.C, self.W, self.H, self.P = n_cams, W, H, n_points
         self.rng = np.random.Generator(np.random.MT19937(seed))
         rng = self.rng
@@ -59,8 +63,16 @@ class Scene:
     def pose(self, cam, frame):
         """(R, t) with x_cam = R x_world + t."""
         a0 = (cam - (self.C - 1) / 2.0) * math.radians(12.0)  # cameras spread on the arc
-        yaw = math.radians(0.1) * frame
-        pos = np.array([math.sin(a0) * 1.0 + 0.015 * frame, 0.05 * math.sin(0.7 * cam), -math.cos(a0) * 1.0 + 1.0])
+        if self.loop_period > 0:
+            T = self.loop_period
+            ph = 2.0 * math.pi * (frame % T) / T
+            amp = 0.015 * T / (2.0 * math.pi)          # peak speed amp * 2 pi / T = 1.5 cm / frame
+            yaw = math.radians(0.1) * T / (2.0 * math.pi) * math.sin(ph + 0.9)
+            pos = np.array([math.sin(a0) * 1.0 + amp * math.sin(ph), 0.05 * math.sin(0.7 * cam) + 0.25 * amp * math.sin(2.0 * ph),
+                            -math.cos(a0) * 1.0 + 1.0 + 0.5 * amp * (1.0 - math.cos(ph))])
+        else:
+            yaw = math.radians(0.1) * frame
+            pos = np.array([math.sin(a0) * 1.0 + 0.015 * frame, 0.05 * math.sin(0.7 * cam), -math.cos(a0) * 1.0 + 1.0])
         R = _rot_y(yaw).T @ look_at(pos, self.target)
         t = -R @ pos
         return R, t
@@ -243,6 +255,16 @@ def make_joint_ba_problem(scene, n_kf=5, kf_step=5, pts_per_cam=500, pool=1500, 
     return dict(K=K, Ks=np.repeat(K[None], C, 0), Rs_gt=Rs, ts_gt=ts, pts_gt=pts, Rs0=Rs0, ts0=ts0, pts0=pts0,
                 obs_cam=obs_cam, obs_pt=obs_pt, obs_xy=noisy, obs_xy_clean=obs_xy, is_outlier=is_out,
                 n_cams_con=n_con, n_pts_con=n_pts_con)
+
+
+def csr_of_problem(pr):
+    """(obs_ptr, obs_cam, obs_xy) of a generated problem's measurements grouped by point (the flat layout of cs_ba_upload)"""
+    P = len(pr["pts0"])
+    obs_pt = np.asarray(pr["obs_pt"])
+    order = np.argsort(obs_pt, kind="stable")
+    ptr = np.zeros(P + 1, dtype=np.int32)
+    np.add.at(ptr, obs_pt + 1, 1)
+    return np.cumsum(ptr).astype(np.int32), pr["obs_cam"][order], pr["obs_xy"][order]
 
 
 def make_intercam_problem(scene, frame=10, n_static=192, n_dyn=60, noise=0.5, rot_pert=0.004, trans_pert=0.015,

@@ -195,7 +195,8 @@ int cs_klt_build_pyramid(cs_klt* k, const uint8_t* image); /* builds into _pyrCr
 typedef struct cs_pose_option {
     int maxIterLM, maxIterRW;                                    /* 100, 5 */
     double epsErrorChangeLM, epsParamChangeLM, epsErrorChangeRW; /* 1e-7, 1e-6, 1e-6 */
-    int verboseLM, verboseRW;                                    /* ignored */
+    int verboseLM, verboseRW;                                    /* ignored on input; on return verboseRW = LM steps taken over all
+                                                                    re-weighting rounds (a diagnostic the reference does not have) */
     double lambda0, lambda;                                      /* 1e-3 in; both updated as the reference does */
     double err0, err, errRW;
     int retTypeLM, npts, nIterLM, nIterRW;
@@ -305,6 +306,10 @@ typedef struct cs_register_pass {
 } cs_register_pass;
 int cs_register_search_passes_dev(int device, void* hip_stream, int nCams, const cs_register_cam* cams, int N, int W, int H,
                                   int nPass /* 1 or 2 */, const cs_register_pass* passes /* host array */);
+/* the same for cameras cam0 .. cam0 + nCamsRun - 1 only: their columns of the nCams-wide tables (with the cameras sharded over
+ * several GPUs every rank holds all cameras' records and searches for the cameras it owns) */
+int cs_register_search_passes_range_dev(int device, void* hip_stream, int nCams, int cam0, int nCamsRun, const cs_register_cam* cams,
+                                        int N, int W, int H, int nPass, const cs_register_pass* passes);
 int cs_register_search_dev(int device, void* hip_stream, int nCams, const cs_register_cam* cams, int N, int W, int H, int P,
                            const double* d_M, const double* d_cov, const int* d_pointFeat, double sigmaSearch, double maxDist,
                            double sigmaMerge, int* d_slot, double* d_m, double* d_var, double* d_dist, int* d_flags);
@@ -377,6 +382,10 @@ int cs_pose_update_frame_dev(cs_track_history* h, void* hip_stream, const cs_pos
 int cs_register_mergability_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int P, const double* d_M,
                                 const double* d_cov, const int* d_slot, double pixelErrVar, unsigned char* d_mergeable);
 
+int cs_register_mergability_range_dev(const cs_track_history* h, void* hip_stream, int cam0, int nCamsRun, const cs_poseupdate_cam* cams,
+                                      int P, const double* d_M, const double* d_cov, const int* d_slot, double pixelErrVar,
+                                      unsigned char* d_mergeable); /* columns cam0 .. cam0 + nCamsRun - 1 only */
+
 /* RobustBundleRTS::updateNewPosesPoints (src/app/SL_CoSLAMRobustBA.cpp:248-271) in one launch: behind a bundle adjustment and the
  * relaxation of the non-key frames, every map point with lastFrame > firstKeyFrame is triangulated again from the moved poses --
  * a locally static point (flags without CS_MAP_DYNAMIC / CS_MAP_FALSE) by updateStaticPointPosition (src/slam/SL_CoSLAMHelper.cpp:
@@ -397,6 +406,14 @@ int cs_register_mergability_dev(const cs_track_history* h, void* hip_stream, con
  * (one stream, or events), like every other call that advances or reads it. */
 int cs_track_history_set_poses_dev(cs_track_history* h, void* hip_stream, int n, const int* d_cam, const int* d_frame, const double* d_R,
                                    const double* d_t);
+/* A run of consecutive frames of every camera out of / into the history, camera-major (d_R [nCams][nFrames][9], d_t [nCams][nFrames][3]):
+ * the nodes of the camera graphs RobustBundleRTS::constructCameraGraphs builds (src/app/SL_CoSLAMRobustBA.cpp:182-227: every pose
+ * from the window's first key frame to the newest frame) and where updateNonKeyCameraPoses writes the relaxed poses (:230-247).
+ * All of firstFrame .. firstFrame + nFrames - 1 must be in the ring. */
+int cs_track_history_get_span_dev(const cs_track_history* h, void* hip_stream, int firstFrame, int nFrames, double* d_R, double* d_t);
+int cs_track_history_set_span_dev(cs_track_history* h, void* hip_stream, int firstFrame, int nFrames, const double* d_R, const double* d_t);
+int cs_track_history_newest_frame(const cs_track_history* h); /* the frame of the newest entry */
+int cs_track_history_cams(const cs_track_history* h);
 int cs_update_new_poses_points_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const int* d_pointFeat,
                                    int nMap, const int* d_lastFrame, const unsigned char* d_isCurrent, int firstKeyFrame,
                                    double* d_mapPts, double* d_mapCov, const unsigned char* d_mapFlags, double pixelErrVar,
@@ -684,6 +701,48 @@ int cs_ba_window_push_dev(cs_ba_window* w, void* hip_stream, const cs_handback_c
                           const double* d_R, const double* d_t, int frame);
 int cs_ba_solve_window_async(cs_ba* b, cs_ba_window* w, void* after_stream, const double* d_mapPts, const unsigned char* d_mapStatic,
                              int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter);
+/* The same request with the map's CS_MAP_* flag bytes (cs_pose_update_frame_dev's d_mapFlags) instead of a 0 / 1 table: a point takes
+ * part when it isLocalStatic() -- neither CS_MAP_DYNAMIC nor CS_MAP_FALSE (addPoints, src/app/SL_CoSLAMRobustBA.cpp:56-66). */
+int cs_ba_solve_window_flags_async(cs_ba* b, cs_ba_window* w, void* after_stream, const double* d_mapPts, const unsigned char* d_mapFlags,
+                                   int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter);
+/* RobustBundleRTS::output() (src/app/SL_CoSLAMRobustBA.cpp:273-316) for the window solves, in two halves.  The reference's BA thread
+ * writes a finished adjustment back under the lock it shares with tracking (src/app/SL_CoSLAM.cpp:1713-1720).  Here
+ *   (1) the solve's worker thread PACKS the result -- key poses, points, their map indices, which points have an outlier measurement
+ *       -- into the next record of a small ring, behind the solve's last kernel on the solve's stream (cs_ba_output_attach), and
+ *   (2) the stream that owns the map APPLIES a record between two frames (cs_ba_output_apply_dev): key poses into the pose
+ *       history, the window's ring and the camera graphs' fixed nodes; points into the map, outlier points set false;
+ *       constructCameraGraphs + updateNonKeyCameraPoses over the history's frames from the window's first key frame to the newest
+ *       (cs_posegraph_*); the newest relaxed pose = the camera's current pose; updateNewPosesPoints over the live map.
+ * Records are numbered in request order (0, 1, ...) over everything attached to the ring; a frame loop applies record k at a
+ * frame of its own choosing (a fixed lag behind the key frame keeps a run reproducible) after cs_ba_output_wait(k).  A record is
+ * self-contained plain memory of cs_ba_output_record_bytes bytes: with the cameras sharded over several GPUs the rank that solved
+ * window k broadcasts it (cs_comm_broadcast_dev) and every rank applies the same bytes to its replica of the map.  A solve that
+ * failed packs an empty record (header ok = 0), which applies nothing. */
+typedef struct cs_ba_output cs_ba_output;
+cs_ba_output* cs_ba_output_create(int device, int nCams, int nKeyFrames, int nMapPts, int nSlots);
+void cs_ba_output_destroy(cs_ba_output* o);
+int cs_ba_output_attach(cs_ba_output* o, cs_ba* b); /* o == NULL detaches; waits for b's queued solves */
+size_t cs_ba_output_record_bytes(const cs_ba_output* o);
+long long cs_ba_output_packed(cs_ba_output* o);      /* records complete on the device; never blocks */
+int cs_ba_output_wait(cs_ba_output* o, long long seq, void** d_record); /* blocks until record seq is complete */
+/* the same wait on the DEVICE: a polling lane enqueued on hip_stream; returns the record's address at once, what is enqueued on
+ * hip_stream afterwards runs when the record is complete (the solve must be on another stream).  timeoutMs of GPU time (0 = 2000),
+ * after which the stream goes on regardless and cs_ba_output_wait_errors (synchronises) counts it. */
+int cs_ba_output_wait_dev(cs_ba_output* o, long long seq, void* hip_stream, int timeoutMs, void** d_record);
+int cs_ba_output_wait_errors(cs_ba_output* o);
+int cs_ba_output_slot(cs_ba_output* o, long long seq, void** d_record); /* the slot record seq uses (a broadcast's receive buffer) */
+/* hdr8: C, P, nObs, nKf, nCams, seq, ok, 0; keyFrames[16]: frame of key frame j or -1.  Synchronises hip_stream. */
+int cs_ba_output_header(cs_ba_output* o, const void* d_record, void* hip_stream, int hdr8[8], int keyFrames[16]);
+int cs_ba_output_arrays(cs_ba_output* o, const void* d_record, const double** d_Rs, const double** d_Ts, const double** d_pts,
+                        const int** d_pointMap, const unsigned char** d_ptOutlier);
+/* h: the pose history (newest entry = the last frame whose pose update ran); w: the window whose ring copies of the key poses are
+ * rewritten, or NULL; cams / d_pointFeat / the map: as cs_update_new_poses_points_dev takes them; the record's key frames are
+ * firstKeyFrame + j * keyEvery, j < nKeyFrames; d_Rcur [nCams][9], d_tcur [nCams][3]: the cameras' current poses (rewritten with
+ * the newest relaxed ones); d_counts [3] or NULL: static / dynamic points re-triangulated, points set false. */
+int cs_ba_output_apply_dev(cs_ba_output* o, const void* d_record, void* hip_stream, cs_track_history* h, cs_ba_window* w,
+                           const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap, double* d_mapPts, double* d_mapCov,
+                           unsigned char* d_mapFlags, double pixelErrVar, int firstKeyFrame, int keyEvery, double* d_Rcur, double* d_tcur,
+                           int* d_counts);
 /* size and bind workspace b for the largest problem w can produce (cs_ba_solve_window_async does it on first use); afterwards
  * cs_ba_result_buffers' addresses stay put across the window's solves -- a follow-up record can be built before the first */
 int cs_ba_reserve_for_window(cs_ba* b, cs_ba_window* w);
@@ -751,6 +810,12 @@ int cs_exchange_allgather_dev(cs_exchange* x, void* hip_stream, const void* cons
                               const double* d_t);
 /* gathered records: global camera g = rank * nCamsLocal + local index at d_recv + g * record_bytes */
 int cs_exchange_buffers(cs_exchange* x, void** d_recv, size_t* record_bytes);
+
+/* every gathered camera's pose into d_R [world * nCamsLocal][9] / d_t [..][3] (skipOwn != 0: all but this rank's own cameras) */
+int cs_exchange_unpack_poses_dev(cs_exchange* x, void* hip_stream, double* d_R, double* d_t, int skipOwn);
+/* collective 3: one buffer from rank `root` to every rank, in place (ncclBroadcast on hip_stream) -- a packed bundle-adjustment
+ * result (cs_ba_output_*) from the rank that solved the window to every replica of the map.  World size 1: no-op. */
+int cs_comm_broadcast_dev(cs_comm* c, void* hip_stream, void* d_buf, size_t bytes, int root);
 
 /* collective 2: bundleAdjustRobust over all ranks of c.  Every rank uploads the same problem (cs_ba_upload) and calls
  * this with the same arguments; rank r linearises its contiguous slice of the points, S || rhs is all-reduced once per

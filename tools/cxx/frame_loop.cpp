@@ -7,8 +7,10 @@
 //   tools/cxx/frame_loop.bin <workload file> <steps> <warmup> [cams per tracker launch]
 // Per frame (reference call sites in bench.py's docstring): camera-group redetect (+ prefetch of the next frame's front) on the
 // tracker stream; hand-back + intraCamEstimate of all cameras + both registration passes on the pose stream, event-ordered
-// behind the tracker; at key frames the inter-camera solve and the joint local BA on their workspaces' worker threads
-// (cs_ba_solve_async), the pose-graph relaxation installed as the joint BA's follow-up.
+// behind the tracker; at key frames the inter-camera solve and the joint local BA (parsed on the device from the window ring) on their
+// workspaces' worker threads; `lag` key-frame intervals behind its key frame every joint BA's packed result is written back into
+// the LIVE map, the pose history and the window (cs_ba_output_apply_dev = RobustBundleRTS::output(): key poses, points, outlier
+// points false, relaxation of the non-key frames, updateNewPosesPoints) -- the pose stream waits for the record on the device.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -99,12 +101,13 @@ struct BaProblem {
 
 int main(int argc, char** argv) {
     if (argc < 4) {
-        fprintf(stderr, "usage: %s <workload file> <steps> <warmup> [cams per tracker launch] [joint BA from the window: 1 | 0]\n", argv[0]);
+        fprintf(stderr, "usage: %s <workload file> <steps> <warmup> [cams per tracker launch] [BA apply lag in key-frame intervals: 1]\n", argv[0]);
         return 1;
     }
     const int steps = atoi(argv[2]), warmup = atoi(argv[3]);
     const int camsPerLaunchArg = argc > 4 ? atoi(argv[4]) : -1;
-    const bool useWindow = argc > 5 ? atoi(argv[5]) != 0 : true;
+    const int baLag = argc > 5 && atoi(argv[5]) > 0 ? atoi(argv[5]) : 1;
+    const bool useWindow = true;
     Reader rd{fopen(argv[1], "rb")};
     if (!rd.f) {
         perror(argv[1]);
@@ -211,11 +214,6 @@ int main(int argc, char** argv) {
     double* dReproj = dev_zeros<double>((size_t)nCams * N);
     unsigned char* dMapFlags = dev_zeros<unsigned char>(nMap);
     unsigned char* dMergeable = dev_zeros<unsigned char>((size_t)P_REG * nCams);
-    // RobustBundleRTS::updateNewPosesPoints behind every finished joint BA, on a copy of the map (see bench.py: the video repeats)
-    double* dMapUpd = dev_zeros<double>((size_t)nMap * 3);
-    double* dCovUpd = dev_zeros<double>((size_t)nMap * 9);
-    long long baApplied = 0;
-    int baRequested = 0, updRuns = 0, updFirstKey = 0;
     // CoSLAM::mapPointsClassify behind the pose update: MapPoint::bNewPt / staticFrameNum / firstFrame of every map point
     unsigned char* dNewPt = dev_zeros<unsigned char>(nMap);
     int* dSfn = dev_zeros<int>(nMap);
@@ -293,28 +291,22 @@ int main(int argc, char** argv) {
         joint.upload(dev);
     }
     ic.upload(dev);
-    std::vector<int> nodePtr(pgGraphs + 1), edgePtr(pgGraphs + 1), id1, id2;
-    for (int g = 0; g <= pgGraphs; ++g) nodePtr[g] = g * pgNodesPer, edgePtr[g] = g * (pgNodesPer - 1);
-    for (int g = 0; g < pgGraphs; ++g)
-        for (int e = 0; e < pgNodesPer - 1; ++e) id1.push_back(e), id2.push_back(e + 1);
-    cs_posegraph* pg = nullptr;
-    CSCHK(cs_posegraph_create(dev, pgGraphs, nodePtr.data(), edgePtr.data(), pgFixed.data(), id1.data(), id2.data(), &pg));
-    double *dPgR = to_dev(pgR), *dPgT = to_dev(pgT), *dPgER = dev_zeros<double>(9 * (size_t)pgEdges),
-           *dPgET = dev_zeros<double>(3 * (size_t)pgEdges), *dPgNR = dev_zeros<double>(9 * (size_t)pgNodes),
-           *dPgNT = dev_zeros<double>(3 * (size_t)pgNodes);
-    int* dPgCam = to_dev(pgCam);
-    CSCHK(cs_posegraph_edges_dev(pg, nullptr, dPgR, dPgT, dPgER, dPgET));
-    HIPCHK(hipDeviceSynchronize());
-    cs_posegraph_after_ba_rec rec;
-    memset(&rec, 0, sizeof(rec));
-    rec.g = pg, rec.device = dev, rec.nCams = joint.C, rec.d_camNode = dPgCam;
-    {
-        double *bR, *bT, *bM;
-        CSCHK(cs_ba_result_buffers(joint.ws, &bR, &bT, &bM));
-        rec.d_Rs = bR, rec.d_Ts = bT;
+    // RobustBundleRTS::output(): every window solve's result packed by the worker, applied `baLag` key-frame intervals later
+    cs_ba_output* bout = cs_ba_output_create(dev, nCams, WIN_KF, nMap, 8);
+    if (!bout) {
+        fprintf(stderr, "cs_ba_output_create: %s\n", cs_last_error());
+        return 3;
     }
-    rec.d_nodeR = dPgR, rec.d_nodeT = dPgT, rec.d_edgeR = dPgER, rec.d_edgeT = dPgET, rec.d_newR = dPgNR, rec.d_newT = dPgNT;
-    CSCHK(cs_ba_set_followup(joint.ws, cs_posegraph_after_ba, &rec));
+    CSCHK(cs_ba_output_attach(bout, joint.ws));
+    (void)pgFixed, (void)pgR, (void)pgT, (void)pgCam, (void)pgEdges;   // (the file's pre-baked camera graphs: the graphs are built live now)
+    struct Due {
+        int frame, firstKey;
+        long long seq;
+    };
+    std::vector<Due> due;   // applies still to come, in frame order
+    int nPushed = 0, nApplied = 0;
+    long long nRequested = 0;
+    int* dApplyCnt = dev_zeros<int>(3);
 
     // inter-camera NCC matching every 4th frame: getNCCBlocks per camera on the full frame, the matrices per consecutive pair
     const int NCC_EVERY = 4;
@@ -354,8 +346,18 @@ int main(int argc, char** argv) {
         CSCHK(cs_klt_group_advance(grp));
         HIPCHK(hipEventRecord(kltDone[b], kltS));
         HIPCHK(hipStreamWaitEvent(poseS, kltDone[b], 0));
-        CSCHK(cs_klt_handback_dev(dev, (void*)poseS, nCams, hb[b].data(), N, W, H, nColBlk, nRowBlk, PTS, i));
         const int src = (i + 1) & 1, dsti = i & 1;
+        // output() of the window whose lag ends at this frame, before anything of frame i touches the map: the pose stream waits ON
+        // THE DEVICE for the worker to publish the record; the host goes on enqueueing
+        if (!due.empty() && due.front().frame == i) {
+            void* rec = nullptr;
+            CSCHK(cs_ba_output_wait_dev(bout, due.front().seq, (void*)poseS, 0, &rec));
+            CSCHK(cs_ba_output_apply_dev(bout, rec, (void*)poseS, hist, win, pu.data(), dPf, nMap, dMap, dCov, dMapFlags, PIX, due.front().firstKey,
+                                         keyEvery, dR[src], dT[src], dApplyCnt));
+            due.erase(due.begin());
+            ++nApplied;
+        }
+        CSCHK(cs_klt_handback_dev(dev, (void*)poseS, nCams, hb[b].data(), N, W, H, nColBlk, nRowBlk, PTS, i));
         CSCHK(cs_pose_intracam_batch_dev(dev, (void*)poseS, nCams, PTS, dKall, dR[src], dT[src], dNpts, nullptr, dMs, dms, 10.0,
                                          dR[dsti], dT[dsti], dOpt, dOk));
         // parallelPoseUpdate(false): the gate + seqTriangulate loop of poseUpdate3D, detectDynamicFeaturePoints(20, 5, 3, MAX_EPI_ERR)
@@ -364,14 +366,6 @@ int main(int argc, char** argv) {
         // mapPointsClassify(12.0) (SL_CoSLAM.cpp:385): the uncertain / dynamic points of this frame decided again
         CSCHK(cs_map_points_classify_dev(hist, (void*)poseS, pu.data(), dPf, nMap, nullptr, nullptr, i, dMap, dCov, dMapFlags, dNewPt, dSfn,
                                          dFirstFrm, 12.0, nullptr));
-        // output() of a finished joint BA (cs_ba_completed read between frames: the host runs ahead of the device): updateNewPosesPoints, one launch
-        if (win && cs_ba_completed(joint.ws) != baApplied) {
-            baApplied = cs_ba_completed(joint.ws), ++updRuns;
-            HIPCHK(hipMemcpyAsync(dMapUpd, dMap, sizeof(double) * 3 * (size_t)nMap, hipMemcpyDeviceToDevice, poseS));
-            HIPCHK(hipMemcpyAsync(dCovUpd, dCov, sizeof(double) * 9 * (size_t)nMap, hipMemcpyDeviceToDevice, poseS));
-            CSCHK(cs_update_new_poses_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, nullptr, nullptr, updFirstKey, dMapUpd, dCovUpd,
-                                                 dMapFlags, PIX, nullptr));
-        }
         // activeMapPointsRegister, then currentMapPointsRegister (static points), search step
         {
             cs_register_pass ps[2];
@@ -388,13 +382,15 @@ int main(int argc, char** argv) {
         CSCHK(cs_register_mergability_dev(hist, (void*)poseS, pu.data(), P_REG, dMap, dCov, reg[1].slot, PIX, dMergeable));
         HIPCHK(hipEventRecord(destFree[b], poseS));
         if (key) {
+            // InterCamPoseEstimator::addMapPoints starts from every camera's current pose
+            HIPCHK(hipMemcpyAsync(ic.dR, dR[dsti], sizeof(double) * 9 * nCams, hipMemcpyDeviceToDevice, poseS));
+            HIPCHK(hipMemcpyAsync(ic.dT, dT[dsti], sizeof(double) * 3 * nCams, hipMemcpyDeviceToDevice, poseS));
             ic.solve_async(poseS);
-            if (win) {  // requestForBA(5, 2, 2, 30): the numCams * 2 oldest key cameras and 2 points held, maxIter 2, inner 10
-                CSCHK(cs_ba_window_push_dev(win, (void*)poseS, hb[b].data(), dK, 1, dR[dsti], dT[dsti], i));
-                CSCHK(cs_ba_solve_window_async(joint.ws, win, (void*)poseS, dMap, nullptr, 2 * nCams, 2, 6.0, 2, 10));
-                ++baRequested, updFirstKey = i - 4 * keyEvery;
-            } else {
-                joint.solve_async(poseS);
+            // requestForBA(5, 2, 2, 30): the numCams * 2 oldest key cameras and 2 points held, maxIter 2, inner 10; static points only
+            CSCHK(cs_ba_window_push_dev(win, (void*)poseS, hb[b].data(), dK, 1, dR[dsti], dT[dsti], i));
+            if (++nPushed >= WIN_KF) {
+                CSCHK(cs_ba_solve_window_flags_async(joint.ws, win, (void*)poseS, dMap, dMapFlags, 2 * nCams, 2, 6.0, 2, 10));
+                due.push_back({i + baLag * keyEvery, i - (WIN_KF - 1) * keyEvery, nRequested++});
             }
         }
         // (last on the pose stream: nothing of this frame waits for the matching leg)
@@ -476,13 +472,20 @@ int main(int argc, char** argv) {
     // set-up (one key-frame interval: graph capture in the BA workers, lazy code-object loading), warm-up, timed loop
     // (with the window: 5 key-frame intervals, so that every timed solve has its 5 key frames = 5 x nCams cameras); the frame
     // sequence runs on through set-up, warm-up and the timed region
-    const int nSetup = (win && keyEvery > 0) ? WIN_KF * keyEvery + 1 : std::max(keyEvery, 1) + 1;
-    for (int i = 0; i < nSetup; ++i) step(i + 1, keyEvery > 0 && i % std::max(keyEvery, 1) == 0);
+    int nDone = 0;
+    auto run = [&](int n) {
+        for (int q = 0; q < n; ++q, ++nDone) step(nDone + 1, keyEvery > 0 && nDone % keyEvery == 0);
+    };
+    run(WIN_KF * std::max(keyEvery, 1) + 1);
     barrier();
-    for (int i = 0; i < warmup; ++i) step(nSetup + i + 1, keyEvery > 0 && i % keyEvery == 0);
+    run((std::max(keyEvery, 1) - nDone % std::max(keyEvery, 1)) % std::max(keyEvery, 1));
+    run(4 * std::max(keyEvery, 1));   // (one set-up round: bench.py --setup-rounds 1)
     barrier();
+    run(warmup);
+    barrier();
+    const int applied0 = nApplied;
     const auto t0c = std::chrono::steady_clock::now();
-    for (int i = 0; i < steps; ++i) step(nSetup + warmup + i + 1, keyEvery > 0 && i % keyEvery == 0);
+    run(steps);
     const auto t1c = std::chrono::steady_clock::now();
     barrier();
     const auto t2c = std::chrono::steady_clock::now();
@@ -495,7 +498,7 @@ int main(int argc, char** argv) {
         HIPCHK(hipMemcpy(ok.data(), dOk, sizeof(int) * nCams, hipMemcpyDeviceToHost));
         for (int v : ok) okAll &= (v != 0);
         std::vector<cs_klt_feature> d(N);
-        const int last = (nSetup + warmup + steps) & 1;
+        const int last = nDone & 1;
         for (int c = 0; c < nCams; ++c) {
             HIPCHK(hipMemcpy(d.data(), dDest[last][c], sizeof(cs_klt_feature) * N, hipMemcpyDeviceToHost));
             int live = 0;
@@ -511,8 +514,9 @@ int main(int argc, char** argv) {
     printf("{\"frames_per_s\": %.3f, \"ms_per_step\": %.5f, \"steps\": %d, \"warmup\": %d, \"host_enqueue_ms_per_step\": %.5f, "
            "\"cams_per_tracker_launch\": %d, \"pose_ok\": %s, \"min_live_features\": %d, \"joint_lm_steps\": %d, \"joint_cost\": %.6f, "
            "\"intercam_lm_steps\": %d, \"intercam_cost\": %.6f, \"ncc_runs\": %d, \"joint_ba_from_window\": %s, \"joint_cameras\": %d, "
-           "\"joint_points\": %d, \"joint_measurements\": %d, \"update_new_poses_points_runs\": %d}\n",
+           "\"joint_points\": %d, \"joint_measurements\": %d, \"ba_lag\": %d, \"windows_applied_in_timed_region\": %d, \"apply_wait_errors\": %d}\n",
            steps / dt, dt / steps * 1e3, steps, warmup, dtHost / steps * 1e3, camsPerLaunch, okAll ? "true" : "false", minLive,
-           sj.nIterTotal, sj.cost, si.nIterTotal, si.cost, nccRuns, win ? "true" : "false", jC, jP, jO, updRuns);
+           sj.nIterTotal, sj.cost, si.nIterTotal, si.cost, nccRuns, win ? "true" : "false", jC, jP, jO, baLag, nApplied - applied0,
+           cs_ba_output_wait_errors(bout));
     return 0;
 }
