@@ -487,7 +487,7 @@ def main():
                      native_comm=bool(args.native_comm),
                      klt_fused=os.environ.get("BENCH_FORCE_DEVICE") is None or world == 1)   # (ranks sharing ONE GPU: test hook)
     try:
-        loop = FrameLoop(cfg, sc, video, ic, klt_config(), reg_covariances(n_map), rank=rank, world=world, device=local_rank,
+        loop = FrameLoop(cfg, sc, video, None if os.environ.get("BENCH_IC_PREBAKED") is None else ic, klt_config(), reg_covariances(n_map), rank=rank, world=world, device=local_rank,
                          dist_backend=dist_backend, associate=associate)
     except coslam_amd.CoslamHipError as ex:
         # no silent change of what is measured: the library's RCCL path is the product; torch.distributed collectives are
@@ -624,7 +624,15 @@ def main():
                     "what": "parsed on the device from the last 5 key frames' hand-back records and solved poses of ALL cameras "
                             "(cs_ba_window_*), the last window this rank solved"}
         st_j = ba_ws.download()[4]
-    st_i = ic_ws.download()[4] if loop.n_my_ic > 0 else None
+    st_i = ic_info = None
+    if loop.n_my_ic > 0:
+        if loop.icam is not None:
+            iC, iP, iO, iS, _ = loop.icam.last_problem()
+            ic_ws.set_sizes(iC, iP, iO)
+            ic_info = {"cameras": iC, "static_points_fixed": iS, "dynamic_points": iP - iS, "measurements": iO,
+                       "what": "InterCamPoseEstimator::addMapPoints built on the device from the key frame's records of all cameras "
+                               "(cs_ba_solve_intercam_async)"}
+        st_i = ic_ws.download()[4]
     apply_info = None
     if loop.out is not None:
         cnt = loop.d_apply_counts.cpu().tolist()
@@ -878,8 +886,8 @@ def main():
                                    + (f" (last: {win_info['points']} pts x {win_info['measurements']} meas)" if win_info else "")
                                    + f", maxIter 2 / inner 10, its result written back into the LIVE map, pose history and window {loop.lag} "
                                    "key-frame interval(s) later (key poses, points, outlier points false, pose-graph relaxation of the non-key "
-                                   "frames, updateNewPosesPoints), and inter-camera solve C=8 free, "
-                                   f"{ic['n_static']} static pts fixed + {ic['n_dynamic']} dynamic, sigma 6, 3 x 40; N>1: cameras sharded 8/N per "
+                                   "frames, updateNewPosesPoints), and inter-camera solve C=8 free, built on the device from the "
+                                   "frame's records (the block-voted static features' map points fixed, <= 61 dynamic points), sigma 6, 3 x 40; N>1: cameras sharded 8/N per "
                                    "GPU, one all-gather of features+pose per frame, every rank replays the other cameras' hand-back and the map "
                                    "update (ONE map held N times, bit-identical), window k solved by rank k mod N and its packed result broadcast",
                        "cameras": N_CAMS, "cameras_per_gpu": nc, "camera_frames_per_s": N_CAMS * args.steps / dt,
@@ -894,7 +902,7 @@ def main():
                                                                   "cost0": st_j.cost0, "cost": st_j.cost},
                        "intercam_last": None if st_i is None else {"lm_steps": st_i.nIterTotal, "outliers": st_i.nOutliers, "cost0": st_i.cost0,
                                                                   "cost": st_i.cost},
-                       "ba_output": apply_info, "state_digest": digest, "replicas": replicas,
+                       "intercam_problem": ic_info, "ba_output": apply_info, "state_digest": digest, "replicas": replicas,
                        "frame_front_prefetch": bool(prefetch), "secondary_cfg2": cfg2, "secondary_cfg5_ba": cfg5, "secondary_cfg5_klt": cfg5_klt,
                        "secondary_reference_default_klt": ref_default,
                        "register_candidates_last_frame": None if args.no_register else

@@ -15,7 +15,7 @@ from .klt import (  # noqa: F401
 
 __version__ = "0.1.0"
 from .pose import IntraCamPoseOption, intraCamEstimate  # noqa: F401,E402
-from .ba import BAOutput, BAStats, BAWindow, BAWorkspace, bundleAdjustRobust  # noqa: F401,E402
+from .ba import BAInterCam, BAOutput, BAStats, BAWindow, BAWorkspace, bundleAdjustRobust  # noqa: F401,E402
 from .handback import HandbackCam, handback_cams, handback_dev  # noqa: F401,E402
 from .register import (RegisterCam, RegisterPass, register_cams, register_passes, register_search, register_search_dev,  # noqa: F401,E402
                        register_search_passes_dev)

@@ -309,3 +309,58 @@ class BAOutput:
             self.close()
         except Exception:
             pass
+
+
+class InterCamCam(C.Structure):
+    """== cs_intercam_cam (include/coslam_hip.h)."""
+
+    _fields_ = [(n, C.c_void_p) for n in ("K", "xy", "state", "slot2map", "trackSpan", "isStatic")]
+
+
+def intercam_cams(cams):
+    arr = (InterCamCam * len(cams))()
+    for a, c in zip(arr, cams):
+        for n, _ in InterCamCam._fields_:
+            setattr(a, n, int(c[n]))
+    return arr
+
+
+class BAInterCam:
+    """cs_ba_intercam: InterCamPoseEstimator::addMapPoints (reference src/app/SL_InterCamPoseEstimator.cpp:18-91) built on the device
+    from the frame's records when the solve is requested; the solve on a workspace's worker thread."""
+
+    def __init__(self, n_cams, n_slots, pts_stride, n_map_pts, max_dyn=60, device=0):
+        self._L = lib()
+        self._L.cs_ba_intercam_create.restype = C.c_void_p
+        h = self._L.cs_ba_intercam_create(int(device), int(n_cams), int(n_slots), int(pts_stride), int(n_map_pts), int(max_dyn))
+        if not h:
+            raise CoslamHipError("cs_ba_intercam_create: " + self._L.cs_last_error().decode())
+        self._h = C.c_void_p(h)
+        self.n_cams = n_cams
+
+    def solve_async(self, ws, after_stream_ptr, cams, W, H, n_col_blk, n_row_blk, d_R, d_t, d_mapPts, d_mapFlags, d_newPt, d_pointFeat,
+                    max_err=6.0, max_iter=3, inner_max_iter=40):
+        """cams: the array intercam_cams() built; InterCamPoseEstimator's constants: sigma 6, maxIter 3, 40 inner (SL_InterCamPoseEstimator.h)"""
+        vp = C.c_void_p
+        check(self._L.cs_ba_solve_intercam_async(ws._h, self._h, vp(after_stream_ptr), cams, int(W), int(H), int(n_col_blk), int(n_row_blk),
+                                                 vp(d_R), vp(d_t), vp(d_mapPts), vp(d_mapFlags), vp(d_newPt), vp(d_pointFeat),
+                                                 C.c_double(max_err), int(max_iter), int(inner_max_iter)), "cs_ba_solve_intercam_async")
+
+    def last_problem(self):
+        """(C, P, nObs, nStatic, device address of the points' map indices); call after ws.wait()"""
+        c, p, o, st, pm = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_void_p()
+        check(self._L.cs_ba_intercam_last_problem(self._h, C.byref(c), C.byref(p), C.byref(o), C.byref(st), C.byref(pm)),
+              "cs_ba_intercam_last_problem")
+        return c.value, p.value, o.value, st.value, pm.value
+
+    def close(self):
+        if self._h:
+            self._L.cs_ba_intercam_destroy.argtypes = [C.c_void_p]
+            self._L.cs_ba_intercam_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

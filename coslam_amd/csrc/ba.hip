@@ -2032,6 +2032,7 @@ __global__ __launch_bounds__(256) void k_control_step(BaDev D) {
 #include "ba_persist_dev.h"
 #include "ba_window_dev.h"
 #include "ba_output_dev.h"
+#include "ba_intercam_dev.h"
 
 // ---- outer loop: outlier flags ---------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_flag(BaDev D) {
@@ -2945,6 +2946,8 @@ struct BaAsyncJob {
     const double* d_map = nullptr;
     const unsigned char* d_mapStatic = nullptr;
     const double *winR = nullptr, *winT = nullptr;   // the ring's key poses as they stood when the solve was requested
+    struct cs_ba_intercam* ic = nullptr;             // cs_ba_solve_intercam_async: the problem sits in staging record icSlot
+    int icSlot = 0;
     int winCount = 0, winSlotOf[16], winFrames[16];  // the window as it stood when the solve was requested (oldest first)
 };
 
@@ -3295,6 +3298,8 @@ static int ba_worker_run_window_inner(cs_ba* b, BaWorker* w, const BaAsyncJob& J
     WinFillOut O = {b->Ks, b->Rs, b->Ts, b->pts, b->obs_xy, b->obs_ptr, b->obs_cam, win->pointMap, b->obs_pt, b->obs_of};
     const int gF = (win->nMap + 3) / 4 > (C + 255) / 256 ? (win->nMap + 3) / 4 : (C + 255) / 256;   // a wave per map point; a thread per key camera
     hipLaunchKernelGGL(k_win_fill, dim3(gF), dim3(256), 0, s, Wd, O);
+    if (6 * (C - J.nCamsCon) <= 36 && C <= 256)   // (the small-order solver's Schur kernels walk camera-indexed lists)
+        hipLaunchKernelGGL(k_cam_lists, dim3(1), dim3(1024), 0, s, C, win->totals, b->obs_cam, b->cam_ptr, b->cam_obs);
     // the camera-pair lists' sizes, still without the host knowing P (one wave per pair; P read on the device)
     const int nPairsAll = C * (C + 1) / 2;
     if ((size_t)nPairsAll + 1 > b->pairPtrCap) {
@@ -3431,6 +3436,178 @@ static int ba_worker_run_window_inner(cs_ba* b, BaWorker* w, const BaAsyncJob& J
     return rc;
 }
 
+// ---- InterCamPoseEstimator::addMapPoints built on the device (ba_intercam_dev.h) --------------------------------------------------
+constexpr int IC_STAGES = 3;
+struct cs_ba_intercam {
+    int device, nCams, N, ptsStride, nMap, maxDyn;
+    int maxP, maxObs;
+    IcStage st[IC_STAGES];
+    unsigned char* slab;
+    int *pairCnt, *pairTotal;
+    int *h_totals, *h_plan;   // pinned: [8 + maxP + 1], [maxP + 2]
+    std::mutex mu;
+    std::condition_variable cv;
+    long long issued, consumed;   // staging records handed to requests / copied into a workspace by a worker
+    int lastC, lastP, lastObs, lastStatic;
+    int* lastPointMap;            // device, maxP: the map index of every point of the last problem solved
+};
+
+static int ba_worker_run_intercam(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
+    cs_ba_intercam* ic = J.ic;
+    CS_HIP(hipSetDevice(b->device));
+    hipStream_t s = b->own_stream;
+    CS_HIP(hipStreamWaitEvent(s, J.ready, 0));
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        if (w->stale) {
+            ba_worker_destroy_graphs(w);
+            w->stale = false;
+        }
+    }
+    struct Consumed {   // whatever way this function is left: the staging record is free again
+        cs_ba_intercam* ic;
+        bool done = false;
+        void release() {
+            if (done) return;
+            done = true;
+            {
+                std::lock_guard<std::mutex> lk(ic->mu);
+                ic->consumed += 1;
+            }
+            ic->cv.notify_all();
+        }
+        ~Consumed() { release(); }
+    } consumed{ic};
+    const int C = ic->nCams;
+    int rc = ba_reserve(b, C, ic->maxP, ic->maxObs);
+    if (rc) return rc;
+    ba_bind_io(b, b->capC, b->capP, b->capObs);
+    ba_drop_graph(b);
+    const IcStage& st = ic->st[J.icSlot];
+    const size_t P1 = (size_t)ic->maxP, O1 = (size_t)ic->maxObs;
+    CS_HIP(hipMemcpyAsync(b->Ks, st.Ks, 72 * (size_t)C, hipMemcpyDeviceToDevice, s));
+    CS_HIP(hipMemcpyAsync(b->Rs, st.Rs, 72 * (size_t)C, hipMemcpyDeviceToDevice, s));
+    CS_HIP(hipMemcpyAsync(b->Ts, st.Ts, 24 * (size_t)C, hipMemcpyDeviceToDevice, s));
+    CS_HIP(hipMemcpyAsync(b->pts, st.pts, 24 * P1, hipMemcpyDeviceToDevice, s));
+    CS_HIP(hipMemcpyAsync(b->obs_xy, st.obs_xy, 16 * O1, hipMemcpyDeviceToDevice, s));
+    CS_HIP(hipMemcpyAsync(b->obs_ptr, st.obs_ptr, 4 * (P1 + 1), hipMemcpyDeviceToDevice, s));
+    CS_HIP(hipMemcpyAsync(b->obs_cam, st.obs_cam, 4 * O1, hipMemcpyDeviceToDevice, s));
+    CS_HIP(hipMemcpyAsync(b->obs_pt, st.obs_pt, 4 * O1, hipMemcpyDeviceToDevice, s));
+    CS_HIP(hipMemcpyAsync(b->obs_of, st.obs_of, 4 * P1 * C, hipMemcpyDeviceToDevice, s));
+    CS_HIP(hipMemcpyAsync(ic->lastPointMap, st.pointMap, 4 * P1, hipMemcpyDeviceToDevice, s));
+    if (6 * C <= 36)   // (the small-order solver's Schur kernels walk camera-indexed lists)
+        hipLaunchKernelGGL(k_cam_lists, dim3(1), dim3(1024), 0, s, C, st.totals, b->obs_cam, b->cam_ptr, b->cam_obs);
+    const int nPairsAll = C * (C + 1) / 2;
+    if ((size_t)nPairsAll + 1 > b->pairPtrCap) {
+        if (b->pairPtr) (void)hipFree(b->pairPtr);
+        b->pairPtr = nullptr;
+        CS_HIP(hipMalloc((void**)&b->pairPtr, sizeof(int) * ((size_t)nPairsAll + 1)));
+        b->pairPtrCap = (size_t)nPairsAll + 1;
+    }
+    hipLaunchKernelGGL(k_pairs_count, dim3(nPairsAll), dim3(64), 0, s, C, st.totals, b->obs_of, ic->pairCnt);
+    hipLaunchKernelGGL(k_pairs_scan, dim3(1), dim3(1024), 0, s, nPairsAll, ic->pairCnt, b->pairPtr, ic->pairTotal);
+    CS_HIP(hipMemcpyAsync(ic->h_totals, st.totals, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    CS_HIP(hipMemcpyAsync(ic->h_totals + 4, ic->pairTotal, sizeof(int), hipMemcpyDeviceToHost, s));
+    int* h_optr = ic->h_totals + 8;
+    CS_HIP(hipMemcpyAsync(h_optr, b->obs_ptr, sizeof(int) * (P1 + 1), hipMemcpyDeviceToHost, s));
+    if (w->tmEv[2]) {
+        (void)hipEventRecord(w->tmEv[2], s);
+        w->parseStamped = true;
+    }
+    CS_HIP(hipStreamSynchronize(s));
+    consumed.release();
+    const int P = ic->h_totals[0], nObs = ic->h_totals[1], nStatic = ic->h_totals[3];
+    {
+        std::lock_guard<std::mutex> lk(ic->mu);
+        ic->lastC = C, ic->lastP = P, ic->lastObs = nObs, ic->lastStatic = nStatic;
+    }
+    b->maxObs = ic->h_totals[2];
+    b->havePairs = false;
+    if (P == 0 || nObs == 0 || nStatic == 0) {   // (the reference asserts m_numStatic > 0, :93)
+        cs_set_error("cs_ba_solve_intercam_async: no static feature point carries a map point");
+        return CS_ERR_INVALID;
+    }
+    b->nPackWaves = 0;
+    if (b->maxObs <= 64) {
+        if ((size_t)ic->maxP + 2 > b->waveStartCap) {
+            if (b->waveStart) (void)hipFree(b->waveStart);
+            b->waveStart = nullptr;
+            b->waveStartCap = 0;
+            CS_HIP(hipMalloc((void**)&b->waveStart, sizeof(int) * ((size_t)ic->maxP + 2)));
+            b->waveStartCap = (size_t)ic->maxP + 2;
+        }
+        int* ws = ic->h_plan;
+        int nw = 0, fill = 0;
+        ws[nw++] = 0;
+        for (int i = 0; i < P; ++i) {
+            const int k = h_optr[i + 1] - h_optr[i];
+            if (k == 0) continue;
+            if (fill + k > 64) {
+                ws[nw++] = h_optr[i];
+                fill = 0;
+            }
+            fill += k;
+        }
+        ws[nw++] = nObs;
+        CS_HIP(hipMemcpyAsync(b->waveStart, ws, sizeof(int) * nw, hipMemcpyHostToDevice, s));
+        b->nPackWaves = nw - 1;
+    }
+    const size_t nEnt = (size_t)ic->h_totals[4];
+    if (nEnt == 0 || nEnt > ((size_t)8 << 20)) {
+        cs_set_error("cs_ba_solve_intercam_async: %zu camera-pair entries", nEnt);
+        return CS_ERR_INVALID;
+    }
+    if (nEnt > b->pairEntCap) {
+        if (b->pairEnt) (void)hipFree(b->pairEnt);
+        b->pairEnt = nullptr;
+        const size_t cap = nEnt + nEnt / 4 + 1024;
+        CS_HIP(hipMalloc((void**)&b->pairEnt, sizeof(int4) * cap));
+        b->pairEntCap = cap;
+    }
+    hipLaunchKernelGGL(k_pairs_fill, dim3(nPairsAll), dim3(64), 0, s, C, P, b->obs_of, b->pairPtr, b->pairEnt);
+    b->havePairs = true;
+    BaPlan L;
+    rc = ba_make_plan(b, C, P, nObs, 0, nStatic, J.maxErr, J.innerMaxIter, false, &L);   // nCamsCon 0, nPtsCon = m_numStatic (:95)
+    if (rc) return rc;
+    w->chunk = 5;
+    if (w->chunk > J.innerMaxIter && J.innerMaxIter > 0) w->chunk = J.innerMaxIter;
+    if (w->chunk < 1) w->chunk = 1;
+    const bool stateInKernel = ba_state_in_kernel(w, L);
+    const BaDev& D = L.D;
+    const dim3 blk(256);
+    rc = ba_run_segments(w, s, J.maxIter, J.innerMaxIter, [&](char kind) {
+        switch (kind) {
+            case 'H':
+                ba_enqueue_init(b, s, L, false, nullptr, nullptr, nullptr);
+                hipLaunchKernelGGL(k_cost, dim3(L.cb), blk, 0, s, D, 0);
+                hipLaunchKernelGGL(k_control, dim3(1), blk, 0, s, D);
+                break;
+            case 'R':
+                hipLaunchKernelGGL(k_cost, dim3(L.cb), blk, 0, s, D, 0);
+                hipLaunchKernelGGL(k_control, dim3(1), blk, 0, s, D);
+                break;
+            case 'C':
+                ba_enqueue_lm_run(s, L, w->chunk);
+                if (!stateInKernel) (void)hipMemcpyAsync(w->h_state, &b->st->inner_done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+                break;
+            case 'T':
+                hipLaunchKernelGGL(k_flag, dim3(L.cb), blk, 0, s, D);
+                hipLaunchKernelGGL(k_outer_end, dim3(1), dim3(1), 0, s, D);
+                if (!stateInKernel) (void)hipMemcpyAsync(w->h_state, &b->st->inner_done, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+                break;
+            default:
+                hipLaunchKernelGGL(k_cost_force, dim3(L.cb), blk, 0, s, D);
+                hipLaunchKernelGGL(k_finish, dim3(1), blk, 0, s, D, b->stats);
+                break;
+        }
+        return hipGetLastError();
+    });
+    if (rc) return rc;
+    rc = ba_run_followup(b, s);
+    CS_HIP(hipStreamSynchronize(s));
+    return rc;
+}
+
 static int ba_worker_run_inner(cs_ba* b, BaWorker* w, const BaAsyncJob& J);
 // (cs_ba_worker_stats: how long the job held the workspace's stream, from the moment the work it waits for was done)
 static int ba_worker_run(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
@@ -3462,6 +3639,7 @@ static int ba_worker_run(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
 }
 static int ba_worker_run_inner(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
     if (J.win) return ba_worker_run_window(b, w, J);
+    if (J.ic) return ba_worker_run_intercam(b, w, J);
     CS_HIP(hipSetDevice(b->device));
     hipStream_t s = b->own_stream;
     CS_HIP(hipStreamWaitEvent(s, J.ready, 0));
@@ -4631,6 +4809,154 @@ int cs_ba_output_apply_dev(cs_ba_output* o, const void* d_record, void* hip_stre
     CS_CHECK_LAUNCH();
     return cs_update_new_poses_points_dev(h, hip_stream, cams, d_pointFeat, nMap, nullptr, nullptr, firstKeyFrame, d_mapPts, d_mapCov,
                                           d_mapFlags, pixelErrVar, d_counts);
+}
+
+
+// ---- InterCamPoseEstimator::addMapPoints + apply's solve, the problem built on the device (ba_intercam_dev.h) ------------------------
+cs_ba_intercam* cs_ba_intercam_create(int device, int nCams, int N, int ptsStride, int nMapPts, int maxDyn) {
+    if (nCams < 1 || nCams > 16 || N < 1 || N >= (1 << 24) || ptsStride < 1 || nMapPts < 1 || maxDyn < 0 || maxDyn > 62) {
+        cs_set_error("cs_ba_intercam_create: need 1..16 cameras, N in 1..2^24, ptsStride >= 1, nMapPts >= 1, maxDyn in 0..62");
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        cs_set_error("cs_ba_intercam_create: no usable HIP device %d", device);
+        return nullptr;
+    }
+    cs_ba_intercam* ic = new cs_ba_intercam();
+    ic->device = device, ic->nCams = nCams, ic->N = N, ic->ptsStride = ptsStride, ic->nMap = nMapPts, ic->maxDyn = maxDyn;
+    ic->maxP = nCams * ptsStride + maxDyn + 1;
+    ic->maxObs = nCams * ptsStride + (maxDyn + 1) * nCams;
+    ic->issued = ic->consumed = 0;
+    ic->lastC = ic->lastP = ic->lastObs = ic->lastStatic = 0;
+    ic->slab = nullptr, ic->h_totals = ic->h_plan = nullptr;
+    const size_t P1 = ic->maxP, O1 = ic->maxObs, nPairs = (size_t)nCams * (nCams + 1) / 2;
+    struct Piece {
+        void** ptr;
+        size_t bytes;
+    };
+    std::vector<Piece> pieces;
+    for (int k = 0; k < IC_STAGES; ++k) {
+        IcStage& t = ic->st[k];
+        pieces.push_back({(void**)&t.Ks, 72 * (size_t)nCams}), pieces.push_back({(void**)&t.Rs, 72 * (size_t)nCams});
+        pieces.push_back({(void**)&t.Ts, 24 * (size_t)nCams}), pieces.push_back({(void**)&t.pts, 24 * P1});
+        pieces.push_back({(void**)&t.obs_xy, 16 * O1}), pieces.push_back({(void**)&t.obs_ptr, 4 * (P1 + 1)});
+        pieces.push_back({(void**)&t.obs_cam, 4 * O1}), pieces.push_back({(void**)&t.pointMap, 4 * P1});
+        pieces.push_back({(void**)&t.obs_pt, 4 * O1}), pieces.push_back({(void**)&t.obs_of, 4 * P1 * nCams});
+        pieces.push_back({(void**)&t.totals, 32}), pieces.push_back({(void**)&t.stPts, 24 * (size_t)nCams * ptsStride});
+        pieces.push_back({(void**)&t.stXY, 16 * (size_t)nCams * ptsStride}), pieces.push_back({(void**)&t.stMap, 4 * (size_t)nCams * ptsStride});
+        pieces.push_back({(void**)&t.stCount, 4 * (size_t)nCams}), pieces.push_back({(void**)&t.dynMark, (size_t)nMapPts});
+    }
+    pieces.push_back({(void**)&ic->pairCnt, 4 * (nPairs + 1)}), pieces.push_back({(void**)&ic->pairTotal, 32});
+    pieces.push_back({(void**)&ic->lastPointMap, 4 * P1});
+    size_t total = 0;
+    for (const Piece& q : pieces) total += (q.bytes + 255) & ~(size_t)255;
+    if (hipMalloc((void**)&ic->slab, total) != hipSuccess ||
+        hipHostMalloc((void**)&ic->h_totals, (8 + P1 + 1) * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&ic->h_plan, (P1 + 2) * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        cs_set_error("cs_ba_intercam_create: cannot allocate %zu KB", total >> 10);
+        if (ic->slab) (void)hipFree(ic->slab);
+        if (ic->h_totals) (void)hipHostFree(ic->h_totals);
+        delete ic;
+        return nullptr;
+    }
+    (void)hipMemset(ic->slab, 0, total);
+    size_t off = 0;
+    for (const Piece& q : pieces) {
+        *q.ptr = ic->slab + off;
+        off += (q.bytes + 255) & ~(size_t)255;
+    }
+    return ic;
+}
+
+void cs_ba_intercam_destroy(cs_ba_intercam* ic) {   // after cs_ba_wait() of every workspace that still has a request of it queued
+    if (!ic) return;
+    (void)hipSetDevice(ic->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(ic->slab);
+    (void)hipHostFree(ic->h_totals);
+    (void)hipHostFree(ic->h_plan);
+    delete ic;
+}
+
+// The problem is BUILT when the request is made, on after_stream (two launches: the frame's records as they stand in that stream's
+// order), into one of three staging records; workspace b's worker thread copies it and solves: bundleAdjustRobust(0, Ks, Rs, Ts,
+// m_numStatic, pts, meas, maxErr, maxIter, innerMaxIter) (SL_InterCamPoseEstimator.cpp:95).  A fourth request while three records
+// are still waiting for their workers blocks the caller.
+int cs_ba_solve_intercam_async(cs_ba* b, cs_ba_intercam* ic, void* after_stream, const cs_intercam_cam* cams, int W, int H, int nColBlk,
+                               int nRowBlk, const double* d_R, const double* d_t, const double* d_mapPts, const unsigned char* d_mapFlags,
+                               const unsigned char* d_newPt, const int* d_pointFeat, double maxErr, int maxIter, int innerMaxIter) {
+    if (!b || !ic || !cams || b->device != ic->device || W < 1 || H < 1 || nColBlk < 1 || nRowBlk < 1 || nColBlk * nRowBlk > IC_MAX_BLOCKS ||
+        W / nColBlk < 1 || H / nRowBlk < 1 || !d_R || !d_t || !d_mapPts || !d_mapFlags || !d_newPt || !d_pointFeat || maxIter < 0 ||
+        innerMaxIter < 0) {
+        cs_set_error("cs_ba_solve_intercam_async: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(b->device));
+    if (!b->worker) {
+        BaWorker* wk = new BaWorker();
+        if (hipHostMalloc((void**)&wk->h_state, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+            delete wk;
+            cs_set_error("cs_ba_solve_intercam_async: cannot allocate the pinned state word");
+            return CS_ERR_ALLOC;
+        }
+        wk->h_state[0] = wk->h_state[1] = 0;
+        b->worker = wk;
+        wk->th = std::thread(ba_worker_main, b, wk);
+    }
+    IcArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = ic->nCams, A.N = ic->N, A.W = W, A.H = H, A.nColBlk = nColBlk, A.nRowBlk = nRowBlk;
+    A.blkW = W / nColBlk, A.blkH = H / nRowBlk;   // src/app/SL_SingleSLAM.cpp:270-271 (integer division)
+    A.ptsStride = ic->ptsStride, A.nMap = ic->nMap, A.maxDyn = ic->maxDyn;
+    A.R = d_R, A.t = d_t, A.mapPts = d_mapPts, A.mapFlags = d_mapFlags, A.newPt = d_newPt, A.pointFeat = d_pointFeat;
+    for (int c = 0; c < ic->nCams; ++c) {
+        const cs_intercam_cam& q = cams[c];
+        if (!q.K || !q.xy || !q.state || !q.slot2map || !q.trackSpan || !q.isStatic) {
+            cs_set_error("cs_ba_solve_intercam_async: null pointer in camera %d", c);
+            return CS_ERR_INVALID;
+        }
+        A.cam.K[c] = q.K, A.cam.xy[c] = q.xy, A.cam.state[c] = q.state, A.cam.slot2map[c] = q.slot2map, A.cam.trackSpan[c] = q.trackSpan, A.cam.isStatic[c] = q.isStatic;
+    }
+    int slot;
+    {
+        std::unique_lock<std::mutex> lk(ic->mu);
+        ic->cv.wait(lk, [&] { return ic->issued - ic->consumed < IC_STAGES; });
+        slot = (int)(ic->issued % IC_STAGES);
+        ic->issued += 1;
+    }
+    A.st = ic->st[slot];
+    hipStream_t as = (hipStream_t)after_stream;
+    CS_HIP(hipMemsetAsync(A.st.dynMark, 0, (size_t)ic->nMap, as));
+    hipLaunchKernelGGL(k_ic_gather, dim3(ic->nCams), dim3(256), 0, as, A);
+    hipLaunchKernelGGL(k_ic_assemble, dim3(1), dim3(1024), 0, as, A);
+    CS_CHECK_LAUNCH();
+    BaAsyncJob J;
+    J.C = J.P = J.nObs = 0;
+    J.nCamsCon = 0, J.nPtsCon = 0, J.maxIter = maxIter, J.innerMaxIter = innerMaxIter, J.maxErr = maxErr;
+    J.R0 = J.T0 = J.M0 = nullptr;
+    J.ic = ic, J.icSlot = slot;
+    CS_HIP(hipEventCreateWithFlags(&J.ready, hipEventDisableTiming));
+    CS_HIP(hipEventRecord(J.ready, as));
+    {
+        std::lock_guard<std::mutex> lk(b->worker->mu);
+        b->worker->q.push_back(J);
+        b->worker->inflight += 1;
+    }
+    b->worker->cv.notify_one();
+    return CS_OK;
+}
+
+// sizes of the last problem a worker solved from ic (call after cs_ba_wait): cameras, points (static first), measurements, m_numStatic,
+// and the map index of every point (device, P ints)
+int cs_ba_intercam_last_problem(cs_ba_intercam* ic, int* C, int* P, int* nObs, int* nStatic, const int** d_pointMap) {
+    if (!ic) return CS_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ic->mu);
+    if (C) *C = ic->lastC;
+    if (P) *P = ic->lastP;
+    if (nObs) *nObs = ic->lastObs;
+    if (nStatic) *nStatic = ic->lastStatic;
+    if (d_pointMap) *d_pointMap = ic->lastPointMap;
+    return CS_OK;
 }
 
 }  // extern "C"

@@ -238,3 +238,41 @@ __global__ __launch_bounds__(64) void k_pairs_fill(int C, int P, const int* obs_
         base += __popcll(mask);
     }
 }
+
+// the camera-indexed measurement lists (cam_ptr [C + 1], cam_obs [nObs]: per camera its measurements in ascending order) that the
+// small-order solver's sliced Schur kernels walk -- what cs_ba_upload builds on the host.  One workgroup, a wave per camera (round
+// robin), ballot compaction over the measurements 64 at a time.  Only enqueued for reduced systems of order <= 36.
+__global__ __launch_bounds__(1024) void k_cam_lists(int C, const int* __restrict__ totals, const int* __restrict__ obs_cam, int* __restrict__ cam_ptr,
+                                                    int* __restrict__ cam_obs) {
+    __shared__ int cnt[257];
+    const int nObs = totals[1], wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = wv; c < C; c += 16) {
+        int n = 0;
+        for (int o0 = 0; o0 < nObs; o0 += 64) {
+            const int o = o0 + lane;
+            n += __popcll(__builtin_amdgcn_ballot_w64(o < nObs && obs_cam[o] == c));
+        }
+        if (lane == 0) cnt[c] = n;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = 0;
+        for (int c = 0; c < C; ++c) {
+            const int n = cnt[c];
+            cnt[c] = a, cam_ptr[c] = a;
+            a += n;
+        }
+        cam_ptr[C] = a;
+    }
+    __syncthreads();
+    for (int c = wv; c < C; c += 16) {
+        int base = cnt[c];
+        for (int o0 = 0; o0 < nObs; o0 += 64) {
+            const int o = o0 + lane;
+            const bool in = o < nObs && obs_cam[o] == c;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+            if (in) cam_obs[base + __popcll(m & ((1ull << lane) - 1ull))] = o;
+            base += __popcll(m);
+        }
+    }
+}

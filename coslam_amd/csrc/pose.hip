@@ -35,8 +35,33 @@ __device__ __forceinline__ void so3_exp(const double w[3], double R[9]) {  // SL
         return;
     }
     double hw0 = w[0] / theta, hw1 = w[1] / theta, hw2 = w[2] / theta;
-    double st = sin(theta);
-    double ct = 1 - cos(theta);
+    double st, ct;
+    if (theta < 0.5) {
+        // an LM step's rotation is a fraction of a degree: sin and cos from their Taylor series (truncation below 2^-56 of the
+        // value for theta < 0.5; the library's routines carry a range reduction for arguments this never sees)
+        const double x2 = theta * theta;
+        double ps = 1.0 / 355687428096000.0;   // 1 / 17!
+        ps = ps * x2 - 1.0 / 1307674368000.0;
+        ps = ps * x2 + 1.0 / 6227020800.0;
+        ps = ps * x2 - 1.0 / 39916800.0;
+        ps = ps * x2 + 1.0 / 362880.0;
+        ps = ps * x2 - 1.0 / 5040.0;
+        ps = ps * x2 + 1.0 / 120.0;
+        ps = ps * x2 - 1.0 / 6.0;
+        st = theta + theta * (x2 * ps);
+        double pc = 1.0 / 20922789888000.0;    // 1 / 16!
+        pc = pc * x2 - 1.0 / 87178291200.0;
+        pc = pc * x2 + 1.0 / 479001600.0;
+        pc = pc * x2 - 1.0 / 3628800.0;
+        pc = pc * x2 + 1.0 / 40320.0;
+        pc = pc * x2 - 1.0 / 720.0;
+        pc = pc * x2 + 1.0 / 24.0;
+        const double c = 1.0 - (0.5 * x2 - x2 * x2 * pc);   // cos(theta), rounded: the reference forms 1 - cos(theta) from that (:20)
+        ct = 1 - c;
+    } else {
+        st = sin(theta);
+        ct = 1 - cos(theta);
+    }
     double hw0hw0 = hw0 * hw0, hw0hw1 = hw0 * hw1, hw0hw2 = hw0 * hw2;
     double hw1hw1 = hw1 * hw1, hw1hw2 = hw1 * hw2, hw2hw2 = hw2 * hw2;
     R[0] = -ct * hw1hw1 - ct * hw2hw2 + 1;
@@ -71,42 +96,42 @@ __device__ __forceinline__ void project(const double* K, const double* R, const 
     m[1] = v / w;
 }
 
-// (A + lambda I) p = B by Gauss-Jordan elimination with partial pivoting on [A | B], fully unrolled so that the
-// 42 entries stay in registers (the reference forms the LAPACK inverse and multiplies: same solution, and the
-// pivot row at every step is the same row -- the largest remaining entry of the column).
-__device__ __forceinline__ void solve66(const double* sA, const double* sB, double* param) {
-    double M[6][7];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) M[i][j] = sA[6 * i + j];
-        M[i][6] = sB[i];
-    }
+// (A + lambda I) p = B by Gauss-Jordan elimination with partial pivoting on [A | B] (the reference forms the LAPACK inverse and
+// multiplies: same solution), ONE MATRIX ENTRY PER LANE: lane 7 r + j holds M[r][j] (r < 6, j < 7; column 6 = B).  Every lane of a
+// wave running all 42 entries' arithmetic redundantly cost ~800 wave instructions per LM step, issued at 4 cycles each -- a third of
+// the step; here a pivot step is one divide and one multiply-subtract across the lanes plus the exchanges that feed them (the pivot
+// column through v_readlane, the row swap and the two factors through ds_bpermute).  Element for element the same operations as
+// the register version: the pivot of column c is the first row >= c with the largest |M[r][c]|, the pivot row is divided by it,
+// every other row loses f times the pivot row, columns <= c are left as they are.
+__device__ __forceinline__ double cs_shfl_d(double v, int srcLane) {
+    int lo = __shfl(__double2loint(v), srcLane, 64), hi = __shfl(__double2hiint(v), srcLane, 64);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void solve66_lanes(double m, int lane, double* param) {
+    const int r = lane / 7, j = lane - 7 * r;   // lanes >= 42 (r >= 6) carry nothing
+    const bool in = r < 6;
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
+        double best = fabs(cs_readlane_d(m, 7 * c + c));
+        int p = c;
 #pragma unroll
-        for (int r = c + 1; r < 6; ++r) {
-            const bool sw = fabs(M[r][c]) > fabs(M[c][c]);
-#pragma unroll
-            for (int j = c; j < 7; ++j) {
-                const double x = M[c][j], y = M[r][j];
-                M[c][j] = sw ? y : x;
-                M[r][j] = sw ? x : y;
-            }
+        for (int rr = c + 1; rr < 6; ++rr) {
+            const double v = fabs(cs_readlane_d(m, 7 * rr + c));
+            if (v > best) best = v, p = rr;
         }
-        const double d = M[c][c];
-#pragma unroll
-        for (int j = c + 1; j < 7; ++j) M[c][j] /= d;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            if (r == c) continue;
-            const double f = M[r][c];
-#pragma unroll
-            for (int j = c + 1; j < 7; ++j) M[r][j] -= f * M[c][j];
-        }
+        const int srcRow = r == c ? p : (r == p ? c : r);
+        const double sw = cs_shfl_d(m, in ? 7 * srcRow + j : lane);
+        m = sw;
+        const double d = cs_readlane_d(m, 7 * c + c);
+        const double q = m / d;
+        if (r == c && j > c) m = q;
+        const double f = cs_shfl_d(m, in ? 7 * r + c : lane);
+        const double pr = cs_shfl_d(m, in ? 7 * c + j : lane);
+        const double e = m - f * pr;
+        if (in && r != c && j > c) m = e;
     }
 #pragma unroll
-    for (int r = 0; r < 6; ++r) param[r] = M[r][6];
+    for (int rr = 0; rr < 6; ++rr) param[rr] = cs_readlane_d(m, 7 * rr + 6);
 }
 
 __device__ __forceinline__ double tukey(double e, double tau) {  // :646-653
@@ -124,33 +149,46 @@ struct PoseCtx {
     int npts;
     double* red;          // LDS [PB/64][27]
     double dR[3][9];      // exp(eps e_k): independent of the iterate (SL_IntraCamPose.cpp:57-58)
+    int myEntry;          // which of the 28 sums this lane holds in the lane-parallel solve
 };
 
-// The 27 sums of the weighted normal equations and the weighted squared error, over the workgroup, in every lane: the waves'
-// transposed butterflies leave each total in ONE lane, which stores it; ONE barrier; every lane adds the waves' totals in wave
-// order.  The scratch is double-buffered (`par` flips per call), so no second barrier protects it from the next call's stores.
+// The 27 sums of the weighted normal equations and the weighted squared error over the workgroup: the waves' transposed butterflies
+// leave each total in ONE lane, which stores it; ONE barrier; then a lane fetches what IT needs -- the entry of [A | B] it holds in
+// the lane-parallel solve (`mine`) and the error -- adding the waves' totals in wave order.  The scratch is double-buffered (`par`
+// flips per call), so no second barrier protects it from the next call's stores.
 constexpr int NSUM = 28;
+// which of the 28 sums lane 7 r + j of the solve needs: A[r][j] = upper-triangle entry (min, max), B[r] = 21 + r
+__device__ __forceinline__ int solve_entry_of_lane(int lane) {
+    const int r = lane / 7, j = lane - 7 * r;
+    if (r >= 6) return 27;
+    if (j == 6) return 21 + r;
+    const int a = r < j ? r : j, b = r < j ? j : r;
+    return a * 6 - (a * (a - 1)) / 2 + (b - a);
+}
 template <int PB>
-__device__ __forceinline__ void block_sum28(double (&v)[NSUM], double* lds /* [2][PB/64][NSUM] */, int& par) {
+__device__ __forceinline__ void block_sum28(double (&v)[NSUM], double* lds /* [2][PB/64][NSUM] */, int& par, int myEntry, double& mine,
+                                            double& err) {
     constexpr int NW = PB / 64;
-    if (NW == 1) {
-        cs_wave_sum_many_d<NSUM>(v);
-        return;
-    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     cs_reduce_many<NSUM>(v, lane);
-    const int mine = cs_reduce_index<NSUM>(lane);
+    if (NW == 1) {
+        constexpr CsOwnerTable<NSUM> T{};
+        int owner = 0;   // the lane that holds the total of entry myEntry
+#pragma unroll
+        for (int q = 0; q < NSUM; ++q) owner = myEntry == q ? T.lane[q] : owner;
+        mine = cs_shfl_d(v[0], owner);
+        err = cs_readlane_d(v[0], T.lane[27]);
+        return;
+    }
+    const int have = cs_reduce_index<NSUM>(lane);
     double* buf = lds + par * (NW * NSUM);
     par ^= 1;
-    if (mine >= 0) buf[wv * NSUM + mine] = v[0];
+    if (have >= 0) buf[wv * NSUM + have] = v[0];
     __syncthreads();
+    double s = buf[myEntry], e = buf[27];
 #pragma unroll
-    for (int q = 0; q < NSUM; ++q) {
-        double s = buf[q];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) s += buf[w * NSUM + q];
-        v[q] = s;
-    }
+    for (int w = 1; w < NW; ++w) s += buf[w * NSUM + myEntry], e += buf[w * NSUM + 27];
+    mine = s, err = e;
 }
 
 // ONE pass over the points at the pose (R, t): acc[0..20] the upper triangle of sum J^T J, acc[21..26] sum J^T r
@@ -161,12 +199,13 @@ __device__ __forceinline__ void block_sum28(double (&v)[NSUM], double* lds /* [2
 // step is ONE pass and ONE reduction.  reweight: first the Tukey weights from the residuals at (R, t) (:687-701), which is where
 // the reference computes them: at the pose the next round starts from.
 template <int PB>
-__device__ void lm_pass(const PoseCtx& c, const double* R, const double* t, bool reweight, double tau, double (&acc)[NSUM], int& par) {
+__device__ void lm_pass(const PoseCtx& c, const double* R, const double* t, bool reweight, double tau, int& par, double& mine, double& err) {
     const double eps = 1e-8;
     // the perturbed rotations R * exp(eps e_k) do not depend on the point (:57-59)
     double R1[3][9];
 #pragma unroll
     for (int a = 0; a < 3; ++a) mat33AB(R, c.dR[a], R1[a]);
+    double acc[NSUM];
 #pragma unroll
     for (int q = 0; q < NSUM; ++q) acc[q] = 0;
     for (int i = threadIdx.x; i < c.npts; i += PB) {
@@ -207,27 +246,13 @@ __device__ void lm_pass(const PoseCtx& c, const double* R, const double* t, bool
 #pragma unroll
         for (int r = 0; r < 6; ++r) acc[21 + r] += J[r] * r0 + J[6 + r] * r1;
     }
-    block_sum28<PB>(acc, c.red, par);
+    block_sum28<PB>(acc, c.red, par, c.myEntry, mine, err);
 }
 
-// (sum J^T J + lambda I) p = sum J^T r
-__device__ __forceinline__ void lm_solve(const double (&acc)[NSUM], double lambda, double* param) {
-    double sA[36], sB[6];
-    int q = 0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int cc = r; cc < 6; ++cc) {
-            sA[6 * r + cc] = acc[q];
-            sA[6 * cc + r] = acc[q];
-            ++q;
-        }
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        sB[r] = acc[21 + r];
-        sA[7 * r] += lambda;
-    }
-    solve66(sA, sB, param);
+// (sum J^T J + lambda I) p = sum J^T r, the lane's entry of [A | B] in `mine`
+__device__ __forceinline__ void lm_solve(double mine, double lambda, double* param) {
+    const int lane = threadIdx.x & 63, r = lane / 7, j = lane - 7 * r;
+    solve66_lanes(r == j ? mine + lambda : mine, lane, param);
 }
 
 __device__ __forceinline__ void update_pose(const double* R, const double* t, const double* p, double* Rn, double* tn) {
@@ -243,11 +268,11 @@ template <int PB>
 __device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0, double* R_opt, double* t_opt,
                             cs_pose_option& opt, bool reweight, double tau, int& par) {  // :475-549
     double param[6];
-    double ne[NSUM], cand[NSUM];   // the normal equations at the accepted pose; error + normal equations at the tentative one
+    double ne, cand, err;   // this lane's entry of the normal equations at the accepted pose / at the tentative one
     opt.npts = c.npts;
     opt.lambda = opt.lambda0;
-    lm_pass<PB>(c, R0, t0, reweight, tau, ne, par);
-    opt.err0 = ne[27];
+    lm_pass<PB>(c, R0, t0, reweight, tau, par, ne, err);
+    opt.err0 = err;
     opt.err = opt.err0;
     double R[9], t[3], R_tmp[9], t_tmp[3];
 #pragma unroll
@@ -256,7 +281,6 @@ __device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0
     for (int i = 0; i < 3; ++i) t[i] = t_tmp[i] = t0[i];
     opt.retTypeLM = 1;
     int i = 0;
-    double err = opt.err0;
     for (; i < opt.maxIterLM; ++i) {
         lm_solve(ne, opt.lambda, param);
         update_pose(R, t, param, R_opt, t_opt);
@@ -266,8 +290,7 @@ __device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0
             opt.retTypeLM = 0;
             break;
         }
-        lm_pass<PB>(c, R_opt, t_opt, false, tau, cand, par);
-        err = cand[27];
+        lm_pass<PB>(c, R_opt, t_opt, false, tau, par, cand, err);
         if (fabs(err - opt.err) < opt.epsErrorChangeLM) {
             opt.retTypeLM = 0;
             break;
@@ -277,8 +300,7 @@ __device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0
             for (int q = 0; q < 9; ++q) R[q] = R_tmp[q] = R_opt[q];
 #pragma unroll
             for (int q = 0; q < 3; ++q) t[q] = t_tmp[q] = t_opt[q];
-#pragma unroll
-            for (int q = 0; q < NSUM; ++q) ne[q] = cand[q];
+            ne = cand;
             opt.err = err;
             opt.lambda /= 10;
         } else {
@@ -330,6 +352,7 @@ __global__ __launch_bounds__(PB) CS_IC_ATTR void k_intracam(int ptsStride, const
     c.ms = msAll + (size_t)2 * ptsStride * pb;
     c.npts = npts;
     c.red = red;
+    c.myEntry = solve_entry_of_lane(threadIdx.x & 63);
     c.Ws = wsScratch ? (wsScratch + (size_t)ptsStride * pb) : WsL;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {

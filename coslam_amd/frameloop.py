@@ -61,7 +61,8 @@ class LoopConfig:
 class FrameLoop:
     """Device state of ONE rank and the enqueue of one frame.  `video`: dict camera -> uint8 tensor [T, H, W] on the device for
     the rank's own cameras; `scene`: K, points (the map), pose(cam, frame) (first frame's poses, F matrices of the NCC leg);
-    `ic`: the inter-camera problem (coslam_amd.synth.make_intercam_problem); `klt_cfg`: KLT_SequenceTrackerConfig."""
+    `ic`: None = the inter-camera problem is built on the device from the frame's records (cs_ba_solve_intercam_async), else a
+    pre-baked problem (coslam_amd.synth.make_intercam_problem) re-solved from the current poses; `klt_cfg`: KLT_SequenceTrackerConfig."""
 
     def __init__(self, cfg, scene, video, ic, klt_cfg, map_cov, rank=0, world=1, device=0, dist_backend="nccl", associate=None):
         import torch
@@ -189,13 +190,23 @@ class FrameLoop:
             self.out = BAOutput(NA, cfg.n_key_frames, n_map, n_slots=8, device=device)
             self.out.attach(self.ba_ws)
             self.recv_rec = z((2, self.out.record_bytes), u8)     # records solved by other ranks arrive here
-        from coslam_amd.synth import csr_of_problem
+        self.icam = None
+        if ic is None:
+            from coslam_amd.ba import BAInterCam, intercam_cams
 
-        iptr, icam, ixy = csr_of_problem(ic)
-        self.ic_ws.upload(ic["Ks"], ic["Rs0"], ic["ts0"], ic["pts0"], iptr, icam, ixy)
-        self.d_iR = torch.from_numpy(ic["Rs0"].reshape(-1).copy()).to(dev)
-        self.d_iT = torch.from_numpy(ic["ts0"].reshape(-1).copy()).to(dev)
-        self.d_iM = torch.from_numpy(ic["pts0"].reshape(-1).copy()).to(dev)
+            # InterCamPoseEstimator::addMapPoints from the live records of ALL cameras (reference src/app/SL_InterCamPoseEstimator.cpp:18-91)
+            self.icam = BAInterCam(NA, N, cfg.pts_stride, n_map, max_dyn=60, device=device)
+            self.ic_cams = intercam_cams([dict(K=self.d_K1.data_ptr(), xy=self.d_xy[g].data_ptr(), state=self.d_state[g].data_ptr(),
+                                               slot2map=self.d_slot2map[g].data_ptr(), trackSpan=self.d_trackspan[g].data_ptr(),
+                                               isStatic=self.d_isstatic[g].data_ptr()) for g in range(NA)])
+        else:
+            from coslam_amd.synth import csr_of_problem
+
+            iptr, icam, ixy = csr_of_problem(ic)
+            self.ic_ws.upload(ic["Ks"], ic["Rs0"], ic["ts0"], ic["pts0"], iptr, icam, ixy)
+            self.d_iR = torch.from_numpy(ic["Rs0"].reshape(-1).copy()).to(dev)
+            self.d_iT = torch.from_numpy(ic["ts0"].reshape(-1).copy()).to(dev)
+            self.d_iM = torch.from_numpy(ic["pts0"].reshape(-1).copy()).to(dev)
         self.n_pushed = self.n_windows = self.n_key = self.n_my_solves = self.n_my_ic = 0
         self.apply_at, self.my_seq = {}, {}
         self.applied, self.last_apply = 0, None
@@ -421,13 +432,19 @@ class FrameLoop:
         k_ic = self.n_key
         self.n_key += 1
         if cfg.with_intercam and (k_ic + self.world // 2) % self.world == self.rank:
-            # InterCamPoseEstimator::addMapPoints (reference src/app/SL_InterCamPoseEstimator.cpp:24-37) starts the solve from every
-            # camera's CURRENT pose: all of them are here (own: just solved; others: this frame's all-gather)
-            with self.torch.cuda.stream(self.pose_s):
-                self.d_iR.copy_(self.d_R[dst].view(-1), non_blocking=True)
-                self.d_iT.copy_(self.d_t[dst].view(-1), non_blocking=True)
+            # InterCamPoseEstimator::addMapPoints + apply (reference src/app/SL_InterCamPoseEstimator.cpp:18-95): every camera's CURRENT
+            # pose (own: just solved; others: this frame's all-gather), the static features chosen per block with their map points
+            # held fixed, the dynamic points free; sigma 6, 3 x 40
             with self._sec("kf_intercam"):
-                self.ic_ws.solve_async(ps, self.d_iR.data_ptr(), self.d_iT.data_ptr(), self.d_iM.data_ptr(), 0, self.ic["n_static"], 6.0, 3, 40)
+                if self.icam is not None:
+                    self.icam.solve_async(self.ic_ws, ps, self.ic_cams, cfg.W, cfg.H, cfg.n_col_blk, cfg.n_row_blk, self.d_R[dst].data_ptr(),
+                                          self.d_t[dst].data_ptr(), self.d_map.data_ptr(), self.d_mapflags.data_ptr(), self.d_newpt.data_ptr(),
+                                          self.d_pf.data_ptr(), 6.0, 3, 40)
+                else:
+                    with self.torch.cuda.stream(self.pose_s):
+                        self.d_iR.copy_(self.d_R[dst].view(-1), non_blocking=True)
+                        self.d_iT.copy_(self.d_t[dst].view(-1), non_blocking=True)
+                    self.ic_ws.solve_async(ps, self.d_iR.data_ptr(), self.d_iT.data_ptr(), self.d_iM.data_ptr(), 0, self.ic["n_static"], 6.0, 3, 40)
             self.n_my_ic += 1
         if self.win is None:
             return

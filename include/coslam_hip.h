@@ -743,6 +743,32 @@ int cs_ba_output_apply_dev(cs_ba_output* o, const void* d_record, void* hip_stre
                            const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap, double* d_mapPts, double* d_mapCov,
                            unsigned char* d_mapFlags, double pixelErrVar, int firstKeyFrame, int keyEvery, double* d_Rcur, double* d_tcur,
                            int* d_counts);
+/* InterCamPoseEstimator::addMapPoints + apply's solve (src/app/SL_InterCamPoseEstimator.cpp:18-95) with the problem built ON THE DEVICE
+ * from the frame's own records: cameras = every camera's current pose, all free; static points = per camera chooseStaticFeatPts
+ * (src/app/SL_SingleSLAM.cpp:345-397) run on the records as they stand -- per 40 x 40 block the first track with a map point, else
+ * the first of the longest, among tracks whose newest feature is static (isStatic) or belongs to a certainly static map point --
+ * and of its winners those with a map point (the point as the map holds it now, ONE measurement, held fixed); dynamic points = chooseDynamicFeatPts per camera (src/app/SL_SingleSLAM.cpp:398-447), the union of
+ * their map points in map order, the first maxDyn + 1 of them, one measurement per camera with a feature of this frame
+ * (d_pointFeat: the hand-back's nMap x nCams table; numVisCam = its non-negative entries per point).  d_mapFlags: CS_MAP_* bytes;
+ * d_newPt: MapPoint::bNewPt.  The solve -- bundleAdjustRobust(0, ..., m_numStatic, ..., maxErr, maxIter, innerMaxIter) -- runs on
+ * workspace b's worker thread like cs_ba_solve_async; the result stays in the workspace (cs_ba_result_buffers, cs_ba_download with
+ * cs_ba_intercam_last_problem's sizes).  The reference never consumes it (CoSLAM::interCamPoseUpdate has no caller). */
+typedef struct cs_intercam_cam {
+    const double* K;     /* 9 */
+    const double* xy;    /* 2N: the hand-back's undistorted pixels */
+    const int* state;    /* N */
+    const int* slot2map; /* N */
+    const int* trackSpan;          /* 2N: first[N], last[N] frame of the slot's track (Track2D::length()) */
+    const unsigned char* isStatic; /* N: FeaturePoint::type == TYPE_FEATPOINT_STATIC */
+} cs_intercam_cam;
+typedef struct cs_ba_intercam cs_ba_intercam;
+cs_ba_intercam* cs_ba_intercam_create(int device, int nCams, int N, int ptsStride, int nMapPts, int maxDyn /* 60, :66 */);
+void cs_ba_intercam_destroy(cs_ba_intercam* ic);
+int cs_ba_solve_intercam_async(cs_ba* b, cs_ba_intercam* ic, void* after_stream, const cs_intercam_cam* cams /* host, nCams */, int W, int H,
+                               int nColBlk, int nRowBlk, const double* d_R, const double* d_t, const double* d_mapPts,
+                               const unsigned char* d_mapFlags, const unsigned char* d_newPt, const int* d_pointFeat, double maxErr,
+                               int maxIter, int innerMaxIter);
+int cs_ba_intercam_last_problem(cs_ba_intercam* ic, int* C, int* P, int* nObs, int* nStatic, const int** d_pointMap);
 /* size and bind workspace b for the largest problem w can produce (cs_ba_solve_window_async does it on first use); afterwards
  * cs_ba_result_buffers' addresses stay put across the window's solves -- a follow-up record can be built before the first */
 int cs_ba_reserve_for_window(cs_ba* b, cs_ba_window* w);

@@ -752,3 +752,86 @@ def parse_inputs_window(key_frames, map_pts, map_static=None):
         ptr.append(len(ocam))
     return dict(Ks=Ks, Rs=Rs, Ts=Ts, pts=np.asarray(pts, float).reshape(-1, 3), obs_ptr=np.asarray(ptr, np.int32),
                 obs_cam=np.asarray(ocam, np.int32), obs_xy=np.asarray(oxy, float).reshape(-1, 2), point_map=np.asarray(pmap, np.int32))
+
+
+def intercam_add_map_points(W, H, nColBlk, nRowBlk, ptsStride, xy, state, slot2map, trackSpan, isStatic, mapPts, mapFlags, newPt, pointFeat,
+                            maxDyn=60):
+    """InterCamPoseEstimator::addMapPoints (reference src/app/SL_InterCamPoseEstimator.cpp:18-91) restated over structure-of-arrays
+    records (TEST INFRASTRUCTURE; integer / index work, numpy): per camera xy (2N: x then y), state (N: 0 / 1 = the slot's track has
+    a feature in this frame), slot2map (N), trackSpan (2N: first, last frame), isStatic (N: FeaturePoint::type); mapFlags (CS_MAP_*
+    bytes), newPt (MapPoint::bNewPt), pointFeat (nMap x nCams: slot of the point's feature of THIS frame or -1).
+    Returns dict(pts [P,3], obs_ptr [P+1], obs_cam, obs_xy [nObs,2], point_map [P], n_static): vecPts3D / vecMeas2D flattened."""
+    nC = len(xy)
+    N = len(state[0])
+    blkW, blkH = W // nColBlk, H // nRowBlk     # src/app/SL_SingleSLAM.cpp:270-271
+    pf = np.asarray(pointFeat)
+    pts, ptr, cam, oxy, pmap = [], [0], [], [], []
+    for c in range(nC):
+        tracks = {}                              # chooseStaticFeatPts, src/app/SL_SingleSLAM.cpp:345-397
+        for s in range(N):
+            if state[c][s] not in (0, 1):        # tk->empty()
+                continue
+            m = int(slot2map[c][s])
+            certain_static = m >= 0 and (int(mapFlags[m]) & 7) == 0
+            if not (isStatic[c][s] or certain_static):
+                continue
+            bx, by = int(xy[c][s] / blkW), int(xy[c][N + s] / blkH)
+            if bx >= nColBlk or by >= nRowBlk or bx < 0 or by < 0:
+                continue
+            bi = by * nColBlk + bx
+            f1, f2 = int(trackSpan[c][s]), int(trackSpan[c][N + s])
+            ln = f2 - f1 + 1 if f1 >= 0 else 1
+            if bi not in tracks:
+                tracks[bi] = (s, m, ln)
+            else:
+                so, mo, lo = tracks[bi]
+                if mo < 0 and (m >= 0 or lo < ln):   # :372-381
+                    tracks[bi] = (s, m, ln)
+        k = 0
+        for bi in sorted(tracks):                # featPts in block order (:386-394); :39-52 static points: one measurement each
+            s, m, _ = tracks[bi]
+            if m < 0 or k >= ptsStride:          # `if (!fp->mpt) continue`
+                continue
+            pts.append(mapPts[m]), pmap.append(m)
+            cam.append(c), oxy.append((xy[c][s], xy[c][N + s]))
+            ptr.append(len(cam))
+            k += 1
+    n_static = len(pts)
+    dyn = set()
+    for c in range(nC):                          # chooseDynamicFeatPts, src/app/SL_SingleSLAM.cpp:398-447
+        best = {}
+        for s in range(N):
+            if state[c][s] not in (0, 1):
+                continue
+            m = int(slot2map[c][s])
+            if m < 0:
+                continue
+            nvis = int((pf[m] >= 0).sum())       # MapPoint::numVisCam as updateVisCamNum(curFrame) leaves it
+            if nvis < 2:
+                continue
+            fl = int(mapFlags[m])
+            unc = bool(fl & 4)
+            certain_dyn = (not unc) and (fl & 3) == 1
+            if not (certain_dyn or (unc and newPt[m])):
+                continue
+            bx, by = int(xy[c][s] / blkW), int(xy[c][N + s] / blkH)
+            if bx >= nColBlk or by >= nRowBlk or bx < 0 or by < 0:
+                continue
+            bi = by * nColBlk + bx
+            if bi not in best or best[bi][0] < nvis:   # `if (fpOld->mpt->numVisCam < fp->mpt->numVisCam)`: the first of the most visible
+                best[bi] = (nvis, s)
+        for nvis, s in best.values():
+            dyn.add(int(slot2map[c][s]))
+    k = 0
+    for m in sorted(dyn):                        # std::map<MapPoint*, int>: address order = map order
+        if k > maxDyn:                           # :72
+            continue
+        pts.append(mapPts[m]), pmap.append(m)
+        for c in range(nC):
+            s = int(pf[m, c])
+            if s >= 0:                           # `fp && fp->f == curFrame`
+                cam.append(c), oxy.append((xy[c][s], xy[c][N + s]))
+        ptr.append(len(cam))
+        k += 1
+    return dict(pts=np.array(pts, dtype=np.float64).reshape(-1, 3), obs_ptr=np.array(ptr, dtype=np.int32), obs_cam=np.array(cam, dtype=np.int32),
+                obs_xy=np.array(oxy, dtype=np.float64).reshape(-1, 2), point_map=np.array(pmap, dtype=np.int32), n_static=n_static)

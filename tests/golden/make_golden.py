@@ -232,6 +232,60 @@ def export_case():
     return out
 
 
+def intercam_case():
+    """the reference's own InterCamPoseEstimator::addMapPoints (oracle/_ref/ref_intercam_test golden, CPU): three scenes of cameras'
+    records and the flattened vecPts3D / vecMeas2D it built from them."""
+    import struct
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_intercam_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_intercam_test missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "ic.bin")
+        subprocess.run([exe, "golden", path], check=True, stdout=subprocess.DEVNULL)
+        raw = open(path, "rb").read()
+    o = [0]
+
+    def ints(n):
+        v = np.frombuffer(raw, dtype=np.int32, count=n, offset=o[0]).copy()
+        o[0] += 4 * n
+        return v
+
+    def dbls(n):
+        v = np.frombuffer(raw, dtype=np.float64, count=n, offset=o[0]).copy()
+        o[0] += 8 * n
+        return v
+
+    out = {}
+    (ns,) = ints(1)
+    out["n_scenes"] = np.int32(ns)
+    for sc in range(ns):
+        nc, N, nMap, frame, W, H, ncb, nrb, pts_stride = (int(v) for v in ints(9))
+        k = lambda n: f"s{sc}_{n}"   # noqa: E731
+        out[k("dims")] = np.array([nc, N, nMap, frame, W, H, ncb, nrb, pts_stride], np.int32)
+        out[k("mapPts")] = dbls(3 * nMap).reshape(nMap, 3)
+        out[k("mapFlags")] = ints(nMap).astype(np.uint8)
+        out[k("newPt")] = ints(nMap).astype(np.uint8)
+        out[k("pointFeat")] = ints(nMap * nc).reshape(nMap, nc)
+        xy, st, s2m, ft, sp = [], [], [], [], []
+        for _ in range(nc):
+            xy.append(dbls(2 * N)), st.append(ints(N)), s2m.append(ints(N)), ft.append(ints(N).astype(np.uint8)), sp.append(ints(2 * N))
+        out[k("xy")], out[k("state")], out[k("slot2map")] = np.stack(xy), np.stack(st), np.stack(s2m)
+        out[k("isStatic")], out[k("trackSpan")] = np.stack(ft), np.stack(sp)
+        n_static, n_dyn, P, n_obs = (int(v) for v in ints(4))
+        out[k("counts")] = np.array([n_static, n_dyn, P, n_obs], np.int32)
+        out[k("pts")] = dbls(3 * P).reshape(P, 3)
+        out[k("obs_ptr")], out[k("obs_cam")] = ints(P + 1), ints(n_obs)
+        out[k("obs_xy")] = dbls(2 * n_obs).reshape(n_obs, 2)
+        out[k("point_map")] = ints(P)
+        cams = dbls(24 * nc).reshape(nc, 24)
+        out[k("Rs")], out[k("Ts")], out[k("curR")], out[k("curT")] = cams[:, :9], cams[:, 9:12], cams[:, 12:21], cams[:, 21:24]
+    assert o[0] == len(raw)
+    return out
+
+
 def mergability_case():
     """the reference's own CoSLAM::staticCheckMergability (oracle/_ref/ref_mergability_test golden, CPU): 150 tracks of 1..24
     frames, newest first, and its verdicts."""
@@ -445,7 +499,7 @@ def classify_case():
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "update_points", "classify"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "update_points", "classify", "intercam"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -460,6 +514,8 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "posegraph_golden.npz"), **posegraph_case())
     if "export" in which:
         np.savez_compressed(os.path.join(HERE, "export_golden.npz"), **export_case())
+    if "intercam" in which:
+        np.savez_compressed(os.path.join(HERE, "intercam_golden.npz"), **intercam_case())
     if "mergability" in which:
         np.savez_compressed(os.path.join(HERE, "mergability_golden.npz"), **mergability_case())
     if "update_points" in which:

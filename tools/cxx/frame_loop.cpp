@@ -290,7 +290,19 @@ int main(int argc, char** argv) {
     } else {
         joint.upload(dev);
     }
-    ic.upload(dev);
+    // the inter-camera problem is built on the device from every key frame's records (InterCamPoseEstimator::addMapPoints); the
+    // file's pre-baked one is only read past
+    ic.ws = cs_ba_create(dev);
+    cs_ba_intercam* icam = cs_ba_intercam_create(dev, nCams, N, PTS, nMap, 60);
+    if (!ic.ws || !icam) {
+        fprintf(stderr, "cs_ba_intercam_create: %s\n", cs_last_error());
+        return 3;
+    }
+    std::vector<cs_intercam_cam> icCams(nCams);
+    for (int c = 0; c < nCams; ++c) {
+        icCams[c].K = dK, icCams[c].xy = dXY + (size_t)c * 2 * N, icCams[c].state = dState + (size_t)c * N;
+        icCams[c].slot2map = dS2M + (size_t)c * N, icCams[c].trackSpan = dSpan + (size_t)c * 2 * N, icCams[c].isStatic = dIsStatic + (size_t)c * N;
+    }
     // RobustBundleRTS::output(): every window solve's result packed by the worker, applied `baLag` key-frame intervals later
     cs_ba_output* bout = cs_ba_output_create(dev, nCams, WIN_KF, nMap, 8);
     if (!bout) {
@@ -382,10 +394,10 @@ int main(int argc, char** argv) {
         CSCHK(cs_register_mergability_dev(hist, (void*)poseS, pu.data(), P_REG, dMap, dCov, reg[1].slot, PIX, dMergeable));
         HIPCHK(hipEventRecord(destFree[b], poseS));
         if (key) {
-            // InterCamPoseEstimator::addMapPoints starts from every camera's current pose
-            HIPCHK(hipMemcpyAsync(ic.dR, dR[dsti], sizeof(double) * 9 * nCams, hipMemcpyDeviceToDevice, poseS));
-            HIPCHK(hipMemcpyAsync(ic.dT, dT[dsti], sizeof(double) * 3 * nCams, hipMemcpyDeviceToDevice, poseS));
-            ic.solve_async(poseS);
+            // InterCamPoseEstimator::addMapPoints + apply: every camera's current pose, the block-voted static features' map points
+            // fixed, the dynamic points free; sigma 6, 3 x 40
+            CSCHK(cs_ba_solve_intercam_async(ic.ws, icam, (void*)poseS, icCams.data(), W, H, nColBlk, nRowBlk, dR[dsti], dT[dsti], dMap, dMapFlags,
+                                             dNewPt, dPf, 6.0, 3, 40));
             // requestForBA(5, 2, 2, 30): the numCams * 2 oldest key cameras and 2 points held, maxIter 2, inner 10; static points only
             CSCHK(cs_ba_window_push_dev(win, (void*)poseS, hb[b].data(), dK, 1, dR[dsti], dT[dsti], i));
             if (++nPushed >= WIN_KF) {
@@ -510,13 +522,16 @@ int main(int argc, char** argv) {
     int jC = joint.C, jP = joint.P, jO = joint.nObs;
     if (win) CSCHK(cs_ba_window_last_problem(win, &jC, &jP, &jO, nullptr, nullptr));
     CSCHK(cs_ba_download(joint.ws, jC, jP, jO, nullptr, nullptr, nullptr, nullptr, &sj));
-    CSCHK(cs_ba_download(ic.ws, ic.C, ic.P, ic.nObs, nullptr, nullptr, nullptr, nullptr, &si));
+    int iC = 0, iP = 0, iO = 0, iS = 0;
+    CSCHK(cs_ba_intercam_last_problem(icam, &iC, &iP, &iO, &iS, nullptr));
+    CSCHK(cs_ba_download(ic.ws, iC, iP, iO, nullptr, nullptr, nullptr, nullptr, &si));
     printf("{\"frames_per_s\": %.3f, \"ms_per_step\": %.5f, \"steps\": %d, \"warmup\": %d, \"host_enqueue_ms_per_step\": %.5f, "
            "\"cams_per_tracker_launch\": %d, \"pose_ok\": %s, \"min_live_features\": %d, \"joint_lm_steps\": %d, \"joint_cost\": %.6f, "
            "\"intercam_lm_steps\": %d, \"intercam_cost\": %.6f, \"ncc_runs\": %d, \"joint_ba_from_window\": %s, \"joint_cameras\": %d, "
-           "\"joint_points\": %d, \"joint_measurements\": %d, \"ba_lag\": %d, \"windows_applied_in_timed_region\": %d, \"apply_wait_errors\": %d}\n",
+           "\"joint_points\": %d, \"joint_measurements\": %d, \"ba_lag\": %d, \"windows_applied_in_timed_region\": %d, \"apply_wait_errors\": %d, "
+           "\"intercam_static_points\": %d, \"intercam_dynamic_points\": %d}\n",
            steps / dt, dt / steps * 1e3, steps, warmup, dtHost / steps * 1e3, camsPerLaunch, okAll ? "true" : "false", minLive,
            sj.nIterTotal, sj.cost, si.nIterTotal, si.cost, nccRuns, win ? "true" : "false", jC, jP, jO, baLag, nApplied - applied0,
-           cs_ba_output_wait_errors(bout));
+           cs_ba_output_wait_errors(bout), iS, iP - iS);
     return 0;
 }
