@@ -407,6 +407,7 @@ def main():
     ap.add_argument("--no-classify", action="store_true", help="diagnostic: skip mapPointsClassify (not a valid bench line)")
     ap.add_argument("--no-pose-update", action="store_true", help="diagnostic: skip the gate / dynamic test / BA write-back (not a valid bench line)")
     ap.add_argument("--no-mergability", action="store_true", help="diagnostic: skip staticCheckMergability (not a valid bench line)")
+    ap.add_argument("--no-decide", action="store_true", help="diagnostic: skip the registration decision + refineMapPoint (not a valid bench line)")
     ap.add_argument("--no-ncc", action="store_true", help="diagnostic: skip the inter-camera NCC matching leg (not a valid bench line)")
     ap.add_argument("--no-register", action="store_true", help="diagnostic: skip the map-point registration search (not a valid bench line)")
     ap.add_argument("--no-cxx-loop", action="store_true", help="skip the C++ frame loop (tools/cxx/frame_loop.bin, config.cxx_frame_loop)")
@@ -483,7 +484,7 @@ def main():
                      key_every=max(ke, 1), ba_lag=args.ba_lag, p_reg=P_REG, klt_cams_per_launch=max(args.klt_cams_per_launch, 0),
                      prefetch=os.environ.get("BENCH_PREFETCH", "1") != "0", with_pose_update=not args.no_pose_update,
                      with_classify=not args.no_classify, with_register=not args.no_register, with_mergability=not args.no_mergability,
-                     with_ncc=not args.no_ncc, with_joint=args.only_solve != "intercam", with_intercam=args.only_solve != "joint",
+                     with_ncc=not args.no_ncc, with_decide=not args.no_decide, with_joint=args.only_solve != "intercam", with_intercam=args.only_solve != "joint",
                      native_comm=bool(args.native_comm),
                      klt_fused=os.environ.get("BENCH_FORCE_DEVICE") is None or world == 1)   # (ranks sharing ONE GPU: test hook)
     try:
@@ -909,6 +910,12 @@ def main():
                        {"active": int((reg_out[0]["slot"][:, lc] >= 0).sum().item()), "current_static": int((reg_out[1]["slot"][:, lc] >= 0).sum().item()),
                         "already_attached": int((reg_out[1]["slot"][:, lc] == -1).sum().item()),
                         "current_static_mergeable_over_the_whole_track": None if loop.pose_upd is None else int((loop.d_mergeable[:, lc] == 1).sum().item())},
+                       "register_decision": None if not hasattr(loop, "_dec") else dict(zip(
+                           ("features_attached_last_frame", "points_regged_last_frame", "sweeps_last_frame", "converged"), loop._dec["cnt"].cpu().tolist()),
+                           points_refined_last_frame=int(loop._dec["ref_cnt"].item()),
+                           what="curStaticPointsRegInGroup's decision (bMerge false) over the search + mergability tables of all cameras "
+                                "(cs_register_decide_static_dev: the sequential first-claimant rule resolved exactly), then refineMapPoint of "
+                                "the points that gained a feature (cs_refine_map_points_dev)"),
                        "pose_update": None if loop.pose_upd is None else {
                            "what": "poseUpdate3D's gate + seqTriangulate over all static mapped features and detectDynamicFeaturePoints over "
                                    "all unmapped / dynamic tracks, every frame, one launch for ALL cameras (cs_pose_update_frame_dev)",

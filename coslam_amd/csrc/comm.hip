@@ -284,6 +284,19 @@ int cs_comm_broadcast_dev(cs_comm* c, void* hip_stream, void* d_buf, size_t byte
     return CS_OK;
 }
 
+// every rank's `bytes` at d_send to every rank's d_recv (rank r's part at r * bytes), on hip_stream (ncclAllGather): the candidate
+// tables of the registration search (cs_register_candidates_pack_dev) before the decision every rank then takes on its replica
+int cs_comm_allgather_dev(cs_comm* c, void* hip_stream, const void* d_send, void* d_recv, size_t bytes) {
+    RcclApi* api = rccl_api();
+    if (!api || !c || !d_send || !d_recv) {
+        cs_set_error("cs_comm_allgather_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(c->device));
+    CS_NCCL(api->allGather(d_send, d_recv, bytes, ncclInt8, c->comm, (hipStream_t)hip_stream));
+    return CS_OK;
+}
+
 // ---- collective 2: bundleAdjustRobust over all ranks, points sliced by rank ------------------------------------------
 // Every rank passes the same replicated problem (cs_ba_upload) and ends with the same result (cs_ba_download).
 // Everything -- phases and collectives -- is enqueued on hip_stream; the host never synchronises.

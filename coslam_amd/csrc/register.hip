@@ -301,6 +301,239 @@ extern "C" int cs_register_search_dev(int device, void* hip_stream, int nCams, c
     return cs_register_search_passes_dev(device, hip_stream, nCams, cams, N, W, H, 1, &q);
 }
 
+namespace {
+
+// ---- the decision behind the current-static search: who attaches which feature -------------------------------------------------------
+// CoSLAM::curStaticPointsRegInGroup / curStaticPointRegInGroup with bMerge == false (src/app/SL_CoSLAM.cpp:854-898, 731-830) walk the
+// points one after the other: for every camera o, the certainly static points with a feature of this frame in o, in map order; each
+// walks the cameras in order and attaches the nearest feature where that is unmapped and mergeable, and STOPS at the first feature
+// that already carries a map point (:789-790) -- including one an earlier point has just taken.  The only coupling between the walks
+// is that: a feature belongs to the FIRST walk step that reaches it unmapped and can take it.  With step order
+// ((first camera in which the point has a feature) x P + point) x C + camera, owner[feature] = the smallest order among the steps
+// that (a) are reached -- no earlier camera of the same walk met a feature mapped on arrival: mapped before the pass, or owned by a
+// step of smaller order -- and (b) may attach.  That is a recursion along a total order, so it has ONE solution, the sequential
+// result; Jacobi sweeps (every walk re-evaluated against the previous sweep's owners) reach it in as many sweeps as the longest
+// chain of walks cutting each other short -- two or three here.  One workgroup, a thread per point (its <= 16 candidate features and
+// their flags in registers), sweeps separated by workgroup barriers; the owners live in a caller-supplied scratch (L2-resident).
+// A point's later visits (it appears once per camera in which it has a feature) find what its first visit left and change nothing.
+constexpr int RD_MAX_CAMS = 16, RD_PPT = 4;   // points per thread: P <= 4096
+struct RdArgs {
+    int nCams, N, P, mapBase, maxRounds;
+    const int* slot;                 // [P][nCams] the search's candidates
+    const int* flags;                // [P][nCams] bit 1: the candidate is dynamic
+    const unsigned char* mergeable;  // [P][nCams] 1: mergeable over the whole track
+    const unsigned char* mapFlags;   // [P] CS_MAP_* of the pass's points
+    int* pointFeat;                  // [P][nCams] in / out
+    int* slot2map[RD_MAX_CAMS];      // [N] per camera, in / out
+    unsigned char* attached;         // [P][nCams] out
+    unsigned char* regged;           // [P] out: refineMapPoint is due (:889-893)
+    int* owner;                      // scratch [2][nCams * N]
+    int* counts;                     // [4] out: features attached, points regged, sweeps, converged
+};
+__global__ __launch_bounds__(1024) void k_register_decide(RdArgs A) {
+    __shared__ int sChanged, sAtt, sReg;
+    const int tid = threadIdx.x, C = A.nCams, nFeat = C * A.N;
+    const int INF = 0x7fffffff;
+    int feat[RD_PPT][RD_MAX_CAMS];       // candidate feature of (point, camera) as camera * N + slot, or -1: the walk passes it by
+    unsigned initMapped[RD_PPT], canMerge[RD_PPT];
+    int base[RD_PPT];                    // order of the point's walk (x C), -1: the point is not visited
+    for (int q = 0; q < RD_PPT; ++q) {
+        const int p = tid + 1024 * q;
+        base[q] = -1, initMapped[q] = canMerge[q] = 0;
+#pragma unroll
+        for (int i = 0; i < RD_MAX_CAMS; ++i) feat[q][i] = -1;
+        if (p >= A.P) continue;
+        A.regged[p] = 0;
+        int ofirst = -1;
+#pragma unroll
+        for (int i = 0; i < RD_MAX_CAMS; ++i) {
+            if (i < C) {
+                const size_t k = (size_t)p * C + i;
+                A.attached[k] = 0;
+                const int pf = A.pointFeat[k];
+                if (pf >= 0) {   // :736-737
+                    if (ofirst < 0) ofirst = i;
+                } else {
+                    const int s = A.slot[k];
+                    if (s >= 0 && s < A.N && !(A.flags[k] & 2)) {   // (else: nothing found / a DYNAMIC feature, :757)
+                        feat[q][i] = i * A.N + s;
+                        if (A.slot2map[i][s] >= 0) initMapped[q] |= 1u << i;
+                        if (A.mergeable[k] == 1) canMerge[q] |= 1u << i;
+                    }
+                }
+            }
+        }
+        if (ofirst >= 0 && (A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) == 0) base[q] = (ofirst * A.P + p) * C;
+    }
+    int* prev = A.owner;
+    int* next = A.owner + nFeat;
+    for (int f = tid; f < nFeat; f += 1024) prev[f] = INF;
+    if (tid == 0) sChanged = 0, sAtt = 0, sReg = 0;
+    __syncthreads();
+    int rounds = 0, converged = 0;
+    for (; rounds < A.maxRounds; ++rounds) {
+        for (int f = tid; f < nFeat; f += 1024) next[f] = INF;
+        __syncthreads();
+        for (int q = 0; q < RD_PPT; ++q) {
+            if (base[q] < 0) continue;
+            int own[RD_MAX_CAMS];
+#pragma unroll
+            for (int i = 0; i < RD_MAX_CAMS; ++i) own[i] = (i < C && feat[q][i] >= 0) ? prev[feat[q][i]] : INF;   // (independent loads)
+            bool go = true;   // the walk is still under way
+#pragma unroll
+            for (int i = 0; i < RD_MAX_CAMS; ++i) {
+                if (go && feat[q][i] >= 0) {
+                    const int ord = base[q] + i;
+                    if (((initMapped[q] >> i) & 1u) || own[i] < ord)
+                        go = false;                                                       // mapped on arrival: the walk ends (:789-790)
+                    else if ((canMerge[q] >> i) & 1u)
+                        atomicMin(&next[feat[q][i]], ord);                                // it takes the feature unless an earlier step does
+                }
+            }
+        }
+        __syncthreads();
+        int ch = 0;
+        for (int f = tid; f < nFeat; f += 1024) ch |= next[f] != prev[f];
+        if (ch) sChanged = 1;
+        __syncthreads();
+        const int any = sChanged;
+        __syncthreads();
+        if (tid == 0) sChanged = 0;
+        int* t = prev;
+        prev = next, next = t;
+        if (!any) {
+            converged = 1;
+            ++rounds;
+            break;
+        }
+    }
+    __syncthreads();
+    // the owners are final: the walks once more, attaching
+    int nAtt = 0, nReg = 0;
+    int att[RD_PPT];
+    for (int q = 0; q < RD_PPT; ++q) {
+        att[q] = 0;
+        if (base[q] < 0) continue;
+        bool go = true;
+#pragma unroll
+        for (int i = 0; i < RD_MAX_CAMS; ++i) {
+            if (go && feat[q][i] >= 0) {
+                const int ord = base[q] + i, own = prev[feat[q][i]];
+                if (((initMapped[q] >> i) & 1u) || own < ord)
+                    go = false;
+                else if (((canMerge[q] >> i) & 1u) && own == ord)
+                    att[q] |= 1 << i;
+            }
+        }
+    }
+    __syncthreads();   // (every walk has read slot2map as it stood before the pass)
+    for (int q = 0; q < RD_PPT; ++q) {
+        if (!att[q]) continue;
+        const int p = tid + 1024 * q;
+#pragma unroll
+        for (int i = 0; i < RD_MAX_CAMS; ++i) {
+            if (!((att[q] >> i) & 1)) continue;
+            const int s = feat[q][i] - i * A.N;
+            A.slot2map[i][s] = A.mapBase + p;   // the feature and its predecessors on the track (:771-775): slot2map is per track
+            A.pointFeat[(size_t)p * C + i] = s;  // MapPoint::addFeature
+            A.attached[(size_t)p * C + i] = 1;
+            ++nAtt;
+        }
+        A.regged[p] = 1;
+        ++nReg;
+    }
+    if (nAtt) atomicAdd(&sAtt, nAtt);
+    if (nReg) atomicAdd(&sReg, nReg);
+    __syncthreads();
+    if (tid == 0 && A.counts) A.counts[0] = sAtt, A.counts[1] = sReg, A.counts[2] = rounds, A.counts[3] = converged;
+}
+
+}  // namespace
+
+extern "C" size_t cs_register_decide_scratch_bytes(int nCams, int N) { return sizeof(int) * 2 * (size_t)(nCams > 0 ? nCams : 0) * (size_t)(N > 0 ? N : 0); }
+
+extern "C" int cs_register_decide_static_dev(int device, void* hip_stream, int nCams, int N, int P, int mapBase, const int* d_slot, const int* d_flags,
+                                             const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
+                                             int* const* d_slot2map /* host array of nCams device pointers */, unsigned char* d_attached,
+                                             unsigned char* d_regged, void* d_scratch, int* d_counts) {
+    if (nCams < 1 || nCams > RD_MAX_CAMS || N < 1 || P < 0 || P > 1024 * RD_PPT || (long long)nCams * P * nCams > 0x7fffffffLL || mapBase < 0 ||
+        !d_slot || !d_flags || !d_mergeable || !d_mapFlags || !d_pointFeat || !d_slot2map || !d_attached || !d_regged || !d_scratch) {
+        cs_set_error("cs_register_decide_static_dev: bad arguments (1..%d cameras, P <= %d)", RD_MAX_CAMS, 1024 * RD_PPT);
+        return CS_ERR_INVALID;
+    }
+    RdArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = nCams, A.N = N, A.P = P, A.mapBase = mapBase, A.maxRounds = 64;
+    A.slot = d_slot, A.flags = d_flags, A.mergeable = d_mergeable, A.mapFlags = d_mapFlags, A.pointFeat = d_pointFeat;
+    for (int c = 0; c < nCams; ++c) {
+        if (!d_slot2map[c]) {
+            cs_set_error("cs_register_decide_static_dev: null slot2map of camera %d", c);
+            return CS_ERR_INVALID;
+        }
+        A.slot2map[c] = d_slot2map[c];
+    }
+    A.attached = d_attached, A.regged = d_regged, A.owner = (int*)d_scratch, A.counts = d_counts;
+    CS_HIP(hipSetDevice(device));
+    if (P == 0) return CS_OK;
+    hipLaunchKernelGGL(k_register_decide, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, A);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+namespace {
+
+// ---- the candidates of a rank's own cameras to every rank (cameras sharded over GPUs) ------------------------------------------------
+// pack: columns cam0 .. cam0 + nOwn - 1 of the P x nCams tables slot / flags / mergeable into one send record of 3 * nOwn * P ints
+// ([table][own camera][point]); unpack: the gathered records of all ranks (rank r owns cameras r * nOwn ..) back into the tables.
+__global__ __launch_bounds__(256) void k_candidates_pack(int P, int nCams, int cam0, int nOwn, const int* __restrict__ slot, const int* __restrict__ flags,
+                                                         const unsigned char* __restrict__ merg, int* __restrict__ send) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nOwn * P) return;
+    const int i = q / P, p = q - i * P;
+    const size_t k = (size_t)p * nCams + cam0 + i;
+    send[q] = slot[k], send[nOwn * P + q] = flags[k], send[2 * nOwn * P + q] = merg[k];
+}
+__global__ __launch_bounds__(256) void k_candidates_unpack(int P, int nCams, int nOwn, int skipRank, const int* __restrict__ recv, int* __restrict__ slot,
+                                                           int* __restrict__ flags, unsigned char* __restrict__ merg) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nCams * P) return;
+    const int g = q / P, p = q - g * P, r = g / nOwn, i = g - r * nOwn;
+    if (r == skipRank) return;
+    const int* rec = recv + (size_t)r * 3 * nOwn * P;
+    const size_t k = (size_t)p * nCams + g;
+    slot[k] = rec[i * P + p], flags[k] = rec[nOwn * P + i * P + p], merg[k] = (unsigned char)rec[2 * nOwn * P + i * P + p];
+}
+
+}  // namespace
+
+extern "C" int cs_register_candidates_pack_dev(int device, void* hip_stream, int P, int nCams, int cam0, int nOwn, const int* d_slot,
+                                               const int* d_flags, const unsigned char* d_mergeable, int* d_send) {
+    if (P < 1 || nCams < 1 || cam0 < 0 || nOwn < 1 || cam0 + nOwn > nCams || !d_slot || !d_flags || !d_mergeable || !d_send) {
+        cs_set_error("cs_register_candidates_pack_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_candidates_pack, dim3((nOwn * P + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, P, nCams, cam0, nOwn, d_slot, d_flags,
+                       d_mergeable, d_send);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+extern "C" int cs_register_candidates_unpack_dev(int device, void* hip_stream, int P, int nCams, int nOwn, int skipRank, const int* d_recv, int* d_slot,
+                                                 int* d_flags, unsigned char* d_mergeable) {
+    if (P < 1 || nCams < 1 || nOwn < 1 || nCams % nOwn || !d_recv || !d_slot || !d_flags || !d_mergeable) {
+        cs_set_error("cs_register_candidates_unpack_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_candidates_unpack, dim3((nCams * P + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, P, nCams, nOwn, skipRank, d_recv,
+                       d_slot, d_flags, d_mergeable);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+namespace {
+}  // namespace
+
 // Host-pointer form for the reference's loops: one upload, one launch, one read-back.  cams[c] holds HOST pointers.
 extern "C" int cs_register_search(int device, int nCams, const cs_register_cam* cams, int N, int W, int H, int P, const double* M,
                                   const double* cov, const int* pointFeat, double sigmaSearch, double maxDist, double sigmaMerge,

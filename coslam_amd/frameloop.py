@@ -46,6 +46,7 @@ class LoopConfig:
         self.prefetch = True
         self.with_pose_update = self.with_classify = self.with_register = self.with_mergability = self.with_ncc = True
         self.with_joint = self.with_intercam = True
+        self.with_decide = True    # the registration decision (who attaches which feature) + refineMapPoint of the points that gained one
         self.native_comm = True
         self.device_wait = True    # the BA result's apply waits for the solve on the device (cs_ba_output_wait_dev), not on the host
         for k, v in kw.items():
@@ -414,6 +415,8 @@ class FrameLoop:
                 self.pose_upd.register_mergability_dev(ps, self.pu_args, cfg.p_reg, self.d_map.data_ptr(), self.d_cov.data_ptr(),
                                                        self.reg_out[1]["slot"].data_ptr(), PIXEL_ERR_VAR, self.d_mergeable.data_ptr(),
                                                        cam0=c0, nCamsRun=nc)
+        if cfg.with_register and cfg.with_decide and self.pose_upd is not None and cfg.with_mergability:
+            self._decide(ps)
         self.dest_free[b].record(pose_s)
         if key_frame:
             if self._timing is not None:
@@ -426,6 +429,57 @@ class FrameLoop:
                 self._key_frame(i, dst)
         if self.ncc is not None and i % cfg.ncc_every == 0:
             self._ncc_leg(f)
+
+    def _decide(self, ps):
+        """curStaticPointsRegInGroup's decision (reference src/app/SL_CoSLAM.cpp:854-898, 731-830, bMerge == false) over the search
+        tables of ALL cameras, then refineMapPoint of the points that gained a feature (:889-893, :666-713).  N > 1: the own cameras'
+        columns of the tables travel first (one small all-gather), every rank then takes the same decisions on its replica."""
+        from coslam_amd.register import register_decide_scratch_bytes, register_decide_static_dev
+
+        cfg, NA = self.cfg, self.cfg.n_cams
+        if not hasattr(self, "_dec"):
+            torch = self.torch
+            z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.dev)   # noqa: E731
+            self._dec = dict(att=z((cfg.p_reg, NA), torch.uint8), reg=z(self.n_map, torch.uint8), cnt=z(4, torch.int32), ref_cnt=z(1, torch.int32),
+                             scr=z(register_decide_scratch_bytes(NA, cfg.n_feat), torch.uint8), s2m=None)
+        D = self._dec
+        if self.world > 1:
+            self._gather_candidates()
+        D["s2m"] = register_decide_static_dev(ps, NA, cfg.n_feat, cfg.p_reg, 0, self.reg_out[1]["slot"].data_ptr(), self.reg_out[1]["flags"].data_ptr(),
+                                              self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(),
+                                              D["s2m"] if D["s2m"] is not None else [self.d_slot2map[g].data_ptr() for g in range(NA)],
+                                              D["att"].data_ptr(), D["reg"].data_ptr(), D["scr"].data_ptr(), D["cnt"].data_ptr(), device=self.device)
+        # (d_regged covers the pass's P points = the first P map points; the rest of the select mask stays 0)
+        self.pose_upd.refine_map_points_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
+                                            PIXEL_ERR_VAR, d_select=D["reg"].data_ptr(), d_count=D["ref_cnt"].data_ptr())
+
+    def _gather_candidates(self):
+        """the own cameras' columns of the current-static pass's candidate tables to every rank (18 KB per camera: latency-bound, ONE
+        collective), so that every rank takes the same registration decisions on its replica"""
+        import ctypes as C_
+
+        import coslam_amd
+        from coslam_amd._lib import check
+
+        torch, cfg, nc, NA, P = self.torch, self.cfg, self.nc, self.cfg.n_cams, self.cfg.p_reg
+        L, vp, ps = coslam_amd.lib(), C_.c_void_p, self.pose_s.cuda_stream
+        if not hasattr(self, "_cand"):
+            self._cand = (torch.zeros(3 * nc * P, dtype=torch.int32, device=self.dev), torch.zeros(3 * nc * P * self.world, dtype=torch.int32, device=self.dev))
+        send, recv = self._cand
+        o = self.reg_out[1]
+        check(L.cs_register_candidates_pack_dev(self.device, vp(ps), P, NA, self.c0, nc, vp(o["slot"].data_ptr()), vp(o["flags"].data_ptr()),
+                                                vp(self.d_mergeable.data_ptr()), vp(send.data_ptr())), "cs_register_candidates_pack_dev")
+        if self.native is not None:
+            L.cs_comm_allgather_dev.argtypes = [vp, vp, vp, vp, C_.c_size_t]
+            check(L.cs_comm_allgather_dev(self.native.exchange_comm, vp(ps), vp(send.data_ptr()), vp(recv.data_ptr()), send.numel() * 4),
+                  "cs_comm_allgather_dev")
+        else:
+            import torch.distributed as dist
+
+            with torch.cuda.stream(self.pose_s):
+                dist.all_gather_into_tensor(recv, send)
+        check(L.cs_register_candidates_unpack_dev(self.device, vp(ps), P, NA, nc, self.rank, vp(recv.data_ptr()), vp(o["slot"].data_ptr()),
+                                                  vp(o["flags"].data_ptr()), vp(self.d_mergeable.data_ptr())), "cs_register_candidates_unpack_dev")
 
     def _key_frame(self, i, dst):
         cfg, ps, NA = self.cfg, self.pose_s.cuda_stream, self.cfg.n_cams

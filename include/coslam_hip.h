@@ -317,6 +317,35 @@ int cs_register_search(int device, int nCams, const cs_register_cam* cams, int N
                        const double* cov, const int* pointFeat, double sigmaSearch, double maxDist, double sigmaMerge, int* slot,
                        double* m, double* var, double* dist, int* flags);
 
+/* The DECISION behind the current-static search -- CoSLAM::curStaticPointsRegInGroup / curStaticPointRegInGroup with bMerge == false
+ * (src/app/SL_CoSLAM.cpp:854-898, 731-830) -- for all points and cameras in one launch: for every camera o in order, the certainly
+ * static points with a feature of this frame in o, in map order, each walking the cameras in order: a camera where the point already
+ * has a feature of this frame, where the search found nothing or found a DYNAMIC feature is passed by; the nearest feature is
+ * attached when it is unmapped and mergeable over its whole track (d_mergeable == 1: cs_register_mergability_dev; compareFeaturePt
+ * returns true whatever it computes, :546-558); a feature that already carries a map point -- before the pass, or taken by an earlier
+ * walk -- ends the point's walk (:789-790).  The sequential "first claimant wins" is resolved exactly (see csrc/register.hip).
+ * d_slot / d_flags: the search's P x nCams tables; d_mapFlags [P]: CS_MAP_* bytes of the pass's points (map points mapBase ..
+ * mapBase + P - 1); IN / OUT: d_pointFeat [P][nCams] (MapPoint::addFeature) and every camera's slot2map [N] (the attached feature's
+ * whole track takes the point, :771-775); OUT: d_attached [P][nCams], d_regged [P] (refineMapPoint is due: hand it to
+ * cs_refine_map_points_dev as d_select), d_counts [4] or NULL (features attached, points regged, sweeps, converged).
+ * d_scratch: cs_register_decide_scratch_bytes.  Not done here: the projections are those of the search as it ran (the reference
+ * refines a point before the next camera's round of walks, :889-893), and the bMerge == true branch (every 50th frame: checkUnify on
+ * a conflict, cs_check_unify_dev gives its verdicts when built). */
+size_t cs_register_decide_scratch_bytes(int nCams, int N);
+int cs_register_decide_static_dev(int device, void* hip_stream, int nCams, int N, int P, int mapBase, const int* d_slot, const int* d_flags,
+                                  const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
+                                  int* const* d_slot2map /* host array of nCams device pointers */, unsigned char* d_attached,
+                                  unsigned char* d_regged, void* d_scratch, int* d_counts);
+
+/* Cameras sharded over GPUs: a rank searches for its own cameras (cs_register_search_passes_range_dev, cs_register_mergability_range_dev);
+ * the decision needs every camera's candidates.  pack: columns cam0 .. cam0 + nOwn - 1 of the P x nCams tables into a send record of
+ * 3 * nOwn * P ints; unpack: the records of all ranks (cs_comm_allgather_dev: rank r owns cameras r * nOwn ..) into the tables
+ * (skipRank: that rank's columns are left alone, -1 = none). */
+int cs_register_candidates_pack_dev(int device, void* hip_stream, int P, int nCams, int cam0, int nOwn, const int* d_slot, const int* d_flags,
+                                    const unsigned char* d_mergeable, int* d_send);
+int cs_register_candidates_unpack_dev(int device, void* hip_stream, int P, int nCams, int nOwn, int skipRank, const int* d_recv, int* d_slot,
+                                      int* d_flags, unsigned char* d_mergeable);
+
 /* ------------------------------------------------------------------------------------------
  * What a frame does with the cameras' new poses: the gate + seqTriangulate loop of poseUpdate3D and the dynamic-point test
  * ------------------------------------------------------------------------------------------
@@ -842,6 +871,9 @@ int cs_exchange_unpack_poses_dev(cs_exchange* x, void* hip_stream, double* d_R, 
 /* collective 3: one buffer from rank `root` to every rank, in place (ncclBroadcast on hip_stream) -- a packed bundle-adjustment
  * result (cs_ba_output_*) from the rank that solved the window to every replica of the map.  World size 1: no-op. */
 int cs_comm_broadcast_dev(cs_comm* c, void* hip_stream, void* d_buf, size_t bytes, int root);
+
+/* every rank's `bytes` at d_send into every rank's d_recv (rank r at r * bytes): ncclAllGather on hip_stream */
+int cs_comm_allgather_dev(cs_comm* c, void* hip_stream, const void* d_send, void* d_recv, size_t bytes);
 
 /* collective 2: bundleAdjustRobust over all ranks of c.  Every rank uploads the same problem (cs_ba_upload) and calls
  * this with the same arguments; rank r linearises its contiguous slice of the points, S || rhs is all-reduced once per

@@ -835,3 +835,41 @@ def intercam_add_map_points(W, H, nColBlk, nRowBlk, ptsStride, xy, state, slot2m
         k += 1
     return dict(pts=np.array(pts, dtype=np.float64).reshape(-1, 3), obs_ptr=np.array(ptr, dtype=np.int32), obs_cam=np.array(cam, dtype=np.int32),
                 obs_xy=np.array(oxy, dtype=np.float64).reshape(-1, 2), point_map=np.array(pmap, dtype=np.int32), n_static=n_static)
+
+
+def register_decide_static(slot, flags, mergeable, mapFlags, pointFeat, slot2map, map_base=0):
+    """The decision half of CoSLAM::curStaticPointsRegInGroup / curStaticPointRegInGroup with bMerge == false (reference
+    src/app/SL_CoSLAM.cpp:854-898, 731-830) restated over the search tables (TEST INFRASTRUCTURE; index work, plain Python): for every
+    camera o in order, the certainly static points with a feature of this frame in o, in map order; each walks the cameras in order --
+    skipping those where it has a feature of this frame, where the search found nothing (slot < 0) or a DYNAMIC feature -- and
+    attaches the nearest feature when that is unmapped and mergeable over its whole track (staticCheckMergability; compareFeaturePt is
+    always true, :546-558); a feature that already carries a map point ENDS the point's walk (`if (!bMerge) return bReg`, :789-790).
+    slot / flags / mergeable: P x C tables of the search (flags bit 1: the candidate is dynamic); mapFlags [P] CS_MAP_* bytes;
+    pointFeat [P][C] and slot2map [C][N] are updated IN PLACE (a track's features all take the point: slot2map is per track).
+    Returns (attached [P][C] uint8, regged [P] uint8: the points refineMapPoint is called for, :889-893)."""
+    P, C = slot.shape
+    attached = np.zeros((P, C), dtype=np.uint8)
+    regged = np.zeros(P, dtype=np.uint8)
+    for o in range(C):
+        vec = [p for p in range(P) if (int(mapFlags[p]) & 7) == 0 and pointFeat[p, o] >= 0]   # :864-869
+        for p in vec:
+            breg = False
+            for i in range(C):
+                if pointFeat[p, i] >= 0:                 # :736-737
+                    continue
+                s = int(slot[p, i])
+                if s < 0:                                # behind the camera / outside the image / no feature
+                    continue
+                if int(flags[p, i]) & 2:                 # `pFeat->type != TYPE_FEATPOINT_DYNAMIC`
+                    continue
+                if slot2map[i][s] < 0:                   # `pFeat->mpt == 0`, as it is NOW
+                    if mergeable[p, i] == 1:
+                        slot2map[i][s] = map_base + p    # the feature and its predecessors (:771-775), MapPoint::addFeature
+                        pointFeat[p, i] = s
+                        attached[p, i] = 1
+                        breg = True
+                else:
+                    break                                # :789-790
+            if breg:
+                regged[p] = 1
+    return attached, regged

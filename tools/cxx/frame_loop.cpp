@@ -344,6 +344,12 @@ int main(int argc, char** argv) {
     auto img_ptrs = [&](int f, const void** out) {
         for (int c = 0; c < nCams; ++c) out[c] = dFrames[c] + imgBytes * f;
     };
+    std::vector<int*> s2mPtrs(nCams);
+    for (int c = 0; c < nCams; ++c) s2mPtrs[c] = dS2M + (size_t)c * N;
+    unsigned char* dAttached = dev_zeros<unsigned char>((size_t)P_REG * nCams);
+    unsigned char* dRegged = dev_zeros<unsigned char>(nMap);
+    void* dDecScratch = dev_zeros<unsigned char>(cs_register_decide_scratch_bytes(nCams, N));
+    int* dDecCnt = dev_zeros<int>(4);
     const double PIX = 10.0;  // Const::PIXEL_ERR_VAR, reference src/app/SL_GlobParam.cpp:37
     auto step = [&](int i, bool key) {
         const int f = order[i % orderLen], fn = order[(i + 1) % orderLen], b = i & 1;
@@ -392,6 +398,10 @@ int main(int argc, char** argv) {
         }
         // staticCheckMergability of the current-static pass's candidates over their whole tracks (SL_CoSLAM.cpp:714-729, :768)
         CSCHK(cs_register_mergability_dev(hist, (void*)poseS, pu.data(), P_REG, dMap, dCov, reg[1].slot, PIX, dMergeable));
+        // the decision (curStaticPointsRegInGroup, bMerge false: who attaches which feature), then refineMapPoint of the points that gained one
+        CSCHK(cs_register_decide_static_dev(dev, (void*)poseS, nCams, N, P_REG, 0, reg[1].slot, reg[1].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
+                                            dAttached, dRegged, dDecScratch, dDecCnt));
+        CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
         HIPCHK(hipEventRecord(destFree[b], poseS));
         if (key) {
             // InterCamPoseEstimator::addMapPoints + apply: every camera's current pose, the block-voted static features' map points
