@@ -325,7 +325,9 @@ __device__ bool weighted_lm(const PoseCtx& c, const double* R0, const double* t0
 
 // CS_IC_WAVES_PER_EU (A/B builds): compile for that many waves per SIMD (3: 168 VGPRs + 460 bytes of scratch per lane instead of 255
 // VGPRs: a workgroup then fits a compute unit that holds two tracker waves per SIMD)
-#ifdef CS_IC_WAVES_PER_EU
+#if defined(CS_IC_NUM_VGPR)
+#define CS_IC_ATTR __attribute__((amdgpu_num_vgpr(CS_IC_NUM_VGPR)))
+#elif defined(CS_IC_WAVES_PER_EU)
 #define CS_IC_ATTR __attribute__((amdgpu_waves_per_eu(CS_IC_WAVES_PER_EU, CS_IC_WAVES_PER_EU)))
 #else
 #define CS_IC_ATTR

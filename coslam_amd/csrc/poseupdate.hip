@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
 // between points (a feature belongs to one point), so the in-place updates need no ordering.  Helper definitions as above, plus
 // isAtCameraBack(R, t, M) = (R M + t).z < 0 and dist3 = Euclidean distance.
 struct ClsArgs {
-    int nCams, N, nMap, H, head, nHist, curFrame;
+    int nCams, N, nMap, H, head, nHist, curFrame, stageCen;
     int* pointFeat;        // [nMap][nCams] in / out (a detached feature becomes -1)
     const int* featFrame;  // [nMap][nCams] or null: the frame of MapPoint::pFeatures[iCam] (null: all of this frame)
     const int* featFirst;  // [nMap][nCams] or null: the first frame of that feature's track (null: the slot's trackSpan)
@@ -760,6 +760,14 @@ __device__ __noinline__ bool cls_is_dynamic(const ClsArgs& A, int m, double* M, 
 
 __global__ __launch_bounds__(256) void k_map_points_classify(ClsArgs A) {
     constexpr int FRAME_NUM_FOR_NEWPOINT = 30, FRAME_NUM_FOR_DONTMOVE = 50, NUM_FRAME_CHECK_STATIC = 60;
+    // the camera centres of the ring in LDS: an examined point's walks (up to 60 frames back per camera, isStaticPoint's widest-parallax
+    // search) are chains of loads a single lane waits for one after the other -- from HBM / L2 they were most of the kernel's time
+    extern __shared__ double cls_cen[];   // [nCams][nHist][3]
+    if (A.stageCen) {   // (uniform; a history too deep for LDS is walked where it lies)
+        for (int q = threadIdx.x; q < A.nCams * A.nHist * 3; q += 256) cls_cen[q] = A.cen[q];
+        __syncthreads();
+        A.cen = cls_cen;
+    }
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= A.nMap) return;
     // the current list after mapStateUpdate (:1183-1197): points with a feature in this frame; numVisCam counts those features
@@ -1255,7 +1263,9 @@ extern "C" int cs_map_points_classify_dev(const cs_track_history* h, void* hip_s
     if (nMap == 0) return CS_OK;
     hipLaunchKernelGGL(k_ring_centres, dim3((h->nCams * h->count + 255) / 256), dim3(256), 0, s, h->nCams, h->H, h->head, h->count, h->R, h->t,
                        h->cen);
-    hipLaunchKernelGGL(k_map_points_classify, dim3((nMap + 255) / 256), dim3(256), 0, s, A);
+    const size_t cenBytes = sizeof(double) * 3 * (size_t)h->nCams * h->count;
+    A.stageCen = cenBytes <= 48 * 1024 ? 1 : 0;
+    hipLaunchKernelGGL(k_map_points_classify, dim3((nMap + 255) / 256), dim3(256), A.stageCen ? cenBytes : 0, s, A);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

@@ -316,9 +316,9 @@ namespace {
 // chain of walks cutting each other short -- two or three here.  One workgroup, a thread per point (its <= 16 candidate features and
 // their flags in registers), sweeps separated by workgroup barriers; the owners live in a caller-supplied scratch (L2-resident).
 // A point's later visits (it appears once per camera in which it has a feature) find what its first visit left and change nothing.
-constexpr int RD_MAX_CAMS = 16, RD_PPT = 4;   // points per thread: P <= 4096
+constexpr int RD_MAX_CAMS = 16;
 struct RdArgs {
-    int nCams, N, P, mapBase, maxRounds;
+    int nCams, N, P, mapBase, nSweeps;
     const int* slot;                 // [P][nCams] the search's candidates
     const int* flags;                // [P][nCams] bit 1: the candidate is dynamic
     const unsigned char* mergeable;  // [P][nCams] 1: mergeable over the whole track
@@ -327,143 +327,112 @@ struct RdArgs {
     int* slot2map[RD_MAX_CAMS];      // [N] per camera, in / out
     unsigned char* attached;         // [P][nCams] out
     unsigned char* regged;           // [P] out: refineMapPoint is due (:889-893)
-    int* owner;                      // scratch [2][nCams * N]
+    int* code;                       // scratch [nCams][P]: the walk's view of (point, camera), see RD_* below
+    int* base;                       // scratch [P]: order of the point's walk (x nCams), -1: the point is not visited
+    int* owner[3];                   // scratch 3 x [nCams * N]: the sweeps rotate through them
     int* counts;                     // [4] out: features attached, points regged, sweeps, converged
 };
-__global__ __launch_bounds__(1024) void k_register_decide(RdArgs A) {
-    __shared__ int sChanged, sAtt, sReg;
-    const int tid = threadIdx.x, C = A.nCams, nFeat = C * A.N;
-    const int INF = 0x7fffffff;
-    int feat[RD_PPT][RD_MAX_CAMS];       // candidate feature of (point, camera) as camera * N + slot, or -1: the walk passes it by
-    unsigned initMapped[RD_PPT], canMerge[RD_PPT];
-    int base[RD_PPT];                    // order of the point's walk (x C), -1: the point is not visited
-    for (int q = 0; q < RD_PPT; ++q) {
-        const int p = tid + 1024 * q;
-        base[q] = -1, initMapped[q] = canMerge[q] = 0;
-#pragma unroll
-        for (int i = 0; i < RD_MAX_CAMS; ++i) feat[q][i] = -1;
-        if (p >= A.P) continue;
-        A.regged[p] = 0;
-        int ofirst = -1;
-#pragma unroll
-        for (int i = 0; i < RD_MAX_CAMS; ++i) {
-            if (i < C) {
-                const size_t k = (size_t)p * C + i;
-                A.attached[k] = 0;
-                const int pf = A.pointFeat[k];
-                if (pf >= 0) {   // :736-737
-                    if (ofirst < 0) ofirst = i;
-                } else {
-                    const int s = A.slot[k];
-                    if (s >= 0 && s < A.N && !(A.flags[k] & 2)) {   // (else: nothing found / a DYNAMIC feature, :757)
-                        feat[q][i] = i * A.N + s;
-                        if (A.slot2map[i][s] >= 0) initMapped[q] |= 1u << i;
-                        if (A.mergeable[k] == 1) canMerge[q] |= 1u << i;
-                    }
-                }
-            }
+// code of (point, camera): -1 the walk passes the camera by; else the candidate feature camera * N + slot in the low bits and
+constexpr int RD_INIT_MAPPED = 1 << 29, RD_CAN_MERGE = 1 << 28, RD_FEAT = (1 << 28) - 1;
+constexpr int RD_INF = 0x7fffffff;
+
+// entry-parallel (coalesced over the P x nCams tables): what every walk will see of (point, camera); the owners start at "nobody"
+__global__ __launch_bounds__(256) void k_decide_prepare(RdArgs A) {
+    const int k = blockIdx.x * 256 + threadIdx.x, C = A.nCams, nFeat = C * A.N;
+    for (int f = k; f < nFeat; f += gridDim.x * 256) A.owner[0][f] = RD_INF, A.owner[1][f] = RD_INF, A.owner[2][f] = RD_INF;
+    if (k < 4 && A.counts) A.counts[k] = k == 2 ? A.nSweeps : (k == 3 ? 1 : 0);   // (converged: cleared by the last launch when not)
+    if (k >= A.P * C) return;
+    const int p = k / C, i = k - p * C;
+    A.attached[k] = 0;
+    if (i == 0) A.regged[p] = 0;
+    int code = -1;
+    if (A.pointFeat[k] < 0) {   // (else :736-737: the point has a feature of this frame there)
+        const int s = A.slot[k];
+        if (s >= 0 && s < A.N && !(A.flags[k] & 2)) {   // (else: nothing found / a DYNAMIC feature, :757)
+            code = i * A.N + s;
+            if (A.slot2map[i][s] >= 0) code |= RD_INIT_MAPPED;
+            if (A.mergeable[k] == 1) code |= RD_CAN_MERGE;
         }
-        if (ofirst >= 0 && (A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) == 0) base[q] = (ofirst * A.P + p) * C;
     }
-    int* prev = A.owner;
-    int* next = A.owner + nFeat;
-    for (int f = tid; f < nFeat; f += 1024) prev[f] = INF;
-    if (tid == 0) sChanged = 0, sAtt = 0, sReg = 0;
-    __syncthreads();
-    int rounds = 0, converged = 0;
-    for (; rounds < A.maxRounds; ++rounds) {
-        for (int f = tid; f < nFeat; f += 1024) next[f] = INF;
-        __syncthreads();
-        for (int q = 0; q < RD_PPT; ++q) {
-            if (base[q] < 0) continue;
-            int own[RD_MAX_CAMS];
-#pragma unroll
-            for (int i = 0; i < RD_MAX_CAMS; ++i) own[i] = (i < C && feat[q][i] >= 0) ? prev[feat[q][i]] : INF;   // (independent loads)
-            bool go = true;   // the walk is still under way
-#pragma unroll
-            for (int i = 0; i < RD_MAX_CAMS; ++i) {
-                if (go && feat[q][i] >= 0) {
-                    const int ord = base[q] + i;
-                    if (((initMapped[q] >> i) & 1u) || own[i] < ord)
-                        go = false;                                                       // mapped on arrival: the walk ends (:789-790)
-                    else if ((canMerge[q] >> i) & 1u)
-                        atomicMin(&next[feat[q][i]], ord);                                // it takes the feature unless an earlier step does
-                }
-            }
-        }
-        __syncthreads();
+    A.code[(size_t)i * A.P + p] = code;
+}
+// thread per point: the order of its walk = ((first camera in which it has a feature of this frame) x P + point) x nCams
+__global__ __launch_bounds__(256) void k_decide_order(RdArgs A) {
+    const int p = blockIdx.x * 256 + threadIdx.x, C = A.nCams;
+    if (p >= A.P) return;
+    int ofirst = -1;
+    for (int i = C - 1; i >= 0; --i)
+        if (A.pointFeat[(size_t)p * C + i] >= 0) ofirst = i;
+    const bool certainStatic = (A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) == 0;
+    A.base[p] = (ofirst >= 0 && certainStatic) ? (ofirst * A.P + p) * C : -1;
+}
+// one Jacobi sweep, thread per point: its walk against the owners of the previous sweep (prev), claims into next; `clear` is the
+// buffer the FOLLOWING sweep will claim into.  mode 1: the owners in prev are final -- attach instead of claiming.
+__global__ __launch_bounds__(256) void k_decide_sweep(RdArgs A, const int* __restrict__ prev, int* __restrict__ next, int* __restrict__ clear,
+                                                      const int* __restrict__ prev2, int mode) {
+    const int p = blockIdx.x * 256 + threadIdx.x, C = A.nCams, nFeat = C * A.N;
+    if (clear)
+        for (int f = p; f < nFeat; f += gridDim.x * 256) clear[f] = RD_INF;
+    if (mode == 1 && prev2) {   // converged: the last two sweeps agree on every owner
         int ch = 0;
-        for (int f = tid; f < nFeat; f += 1024) ch |= next[f] != prev[f];
-        if (ch) sChanged = 1;
-        __syncthreads();
-        const int any = sChanged;
-        __syncthreads();
-        if (tid == 0) sChanged = 0;
-        int* t = prev;
-        prev = next, next = t;
-        if (!any) {
-            converged = 1;
-            ++rounds;
-            break;
-        }
+        for (int f = p; f < nFeat; f += gridDim.x * 256) ch |= prev[f] != prev2[f];
+        if (ch && A.counts) A.counts[3] = 0;
     }
-    __syncthreads();
-    // the owners are final: the walks once more, attaching
-    int nAtt = 0, nReg = 0;
-    int att[RD_PPT];
-    for (int q = 0; q < RD_PPT; ++q) {
-        att[q] = 0;
-        if (base[q] < 0) continue;
-        bool go = true;
+    if (p >= A.P) return;
+    const int base = A.base[p];
+    if (base < 0) return;
+    int code[RD_MAX_CAMS], own[RD_MAX_CAMS];
 #pragma unroll
-        for (int i = 0; i < RD_MAX_CAMS; ++i) {
-            if (go && feat[q][i] >= 0) {
-                const int ord = base[q] + i, own = prev[feat[q][i]];
-                if (((initMapped[q] >> i) & 1u) || own < ord)
-                    go = false;
-                else if (((canMerge[q] >> i) & 1u) && own == ord)
-                    att[q] |= 1 << i;
+    for (int i = 0; i < RD_MAX_CAMS; ++i) code[i] = i < C ? A.code[(size_t)i * A.P + p] : -1;
+#pragma unroll
+    for (int i = 0; i < RD_MAX_CAMS; ++i) own[i] = code[i] >= 0 ? prev[code[i] & RD_FEAT] : RD_INF;   // (independent loads)
+    bool go = true, reg = false;
+    int nAtt = 0;
+#pragma unroll
+    for (int i = 0; i < RD_MAX_CAMS; ++i) {
+        if (go && code[i] >= 0) {
+            const int ord = base + i, f = code[i] & RD_FEAT;
+            if ((code[i] & RD_INIT_MAPPED) || own[i] < ord) {
+                go = false;                                    // mapped on arrival: the walk ends (:789-790)
+            } else if (code[i] & RD_CAN_MERGE) {
+                if (mode == 0) {
+                    atomicMin(&next[f], ord);                  // it takes the feature unless an earlier step does
+                } else if (own[i] == ord) {
+                    const int s = f - i * A.N;
+                    A.slot2map[i][s] = A.mapBase + p;          // the feature and its predecessors on the track (:771-775): slot2map is per track
+                    A.pointFeat[(size_t)p * C + i] = s;         // MapPoint::addFeature
+                    A.attached[(size_t)p * C + i] = 1;
+                    reg = true, ++nAtt;
+                }
             }
         }
     }
-    __syncthreads();   // (every walk has read slot2map as it stood before the pass)
-    for (int q = 0; q < RD_PPT; ++q) {
-        if (!att[q]) continue;
-        const int p = tid + 1024 * q;
-#pragma unroll
-        for (int i = 0; i < RD_MAX_CAMS; ++i) {
-            if (!((att[q] >> i) & 1)) continue;
-            const int s = feat[q][i] - i * A.N;
-            A.slot2map[i][s] = A.mapBase + p;   // the feature and its predecessors on the track (:771-775): slot2map is per track
-            A.pointFeat[(size_t)p * C + i] = s;  // MapPoint::addFeature
-            A.attached[(size_t)p * C + i] = 1;
-            ++nAtt;
-        }
+    if (mode == 1 && reg) {
         A.regged[p] = 1;
-        ++nReg;
+        if (A.counts) atomicAdd(A.counts, nAtt), atomicAdd(A.counts + 1, 1);
     }
-    if (nAtt) atomicAdd(&sAtt, nAtt);
-    if (nReg) atomicAdd(&sReg, nReg);
-    __syncthreads();
-    if (tid == 0 && A.counts) A.counts[0] = sAtt, A.counts[1] = sReg, A.counts[2] = rounds, A.counts[3] = converged;
 }
 
 }  // namespace
 
-extern "C" size_t cs_register_decide_scratch_bytes(int nCams, int N) { return sizeof(int) * 2 * (size_t)(nCams > 0 ? nCams : 0) * (size_t)(N > 0 ? N : 0); }
+extern "C" size_t cs_register_decide_scratch_bytes(int nCams, int N, int P) {
+    if (nCams < 1 || N < 1 || P < 0) return 0;
+    return sizeof(int) * ((size_t)nCams * P + (size_t)P + 3 * (size_t)nCams * N);
+}
 
 extern "C" int cs_register_decide_static_dev(int device, void* hip_stream, int nCams, int N, int P, int mapBase, const int* d_slot, const int* d_flags,
                                              const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
                                              int* const* d_slot2map /* host array of nCams device pointers */, unsigned char* d_attached,
-                                             unsigned char* d_regged, void* d_scratch, int* d_counts) {
-    if (nCams < 1 || nCams > RD_MAX_CAMS || N < 1 || P < 0 || P > 1024 * RD_PPT || (long long)nCams * P * nCams > 0x7fffffffLL || mapBase < 0 ||
-        !d_slot || !d_flags || !d_mergeable || !d_mapFlags || !d_pointFeat || !d_slot2map || !d_attached || !d_regged || !d_scratch) {
-        cs_set_error("cs_register_decide_static_dev: bad arguments (1..%d cameras, P <= %d)", RD_MAX_CAMS, 1024 * RD_PPT);
+                                             unsigned char* d_regged, void* d_scratch, int nSweeps, int* d_counts) {
+    if (nCams < 1 || nCams > RD_MAX_CAMS || N < 1 || P < 0 || (long long)nCams * N > RD_FEAT || (long long)nCams * P * nCams > 0x7fffffffLL ||
+        mapBase < 0 || nSweeps < 1 || nSweeps > 256 || !d_slot || !d_flags || !d_mergeable || !d_mapFlags || !d_pointFeat || !d_slot2map ||
+        !d_attached || !d_regged || !d_scratch) {
+        cs_set_error("cs_register_decide_static_dev: bad arguments (1..%d cameras, 1..256 sweeps)", RD_MAX_CAMS);
         return CS_ERR_INVALID;
     }
     RdArgs A;
     memset(&A, 0, sizeof(A));
-    A.nCams = nCams, A.N = N, A.P = P, A.mapBase = mapBase, A.maxRounds = 64;
+    A.nCams = nCams, A.N = N, A.P = P, A.mapBase = mapBase, A.nSweeps = nSweeps;
     A.slot = d_slot, A.flags = d_flags, A.mergeable = d_mergeable, A.mapFlags = d_mapFlags, A.pointFeat = d_pointFeat;
     for (int c = 0; c < nCams; ++c) {
         if (!d_slot2map[c]) {
@@ -472,10 +441,23 @@ extern "C" int cs_register_decide_static_dev(int device, void* hip_stream, int n
         }
         A.slot2map[c] = d_slot2map[c];
     }
-    A.attached = d_attached, A.regged = d_regged, A.owner = (int*)d_scratch, A.counts = d_counts;
+    A.attached = d_attached, A.regged = d_regged, A.counts = d_counts;
+    int* scr = (int*)d_scratch;
+    A.code = scr, scr += (size_t)nCams * P;
+    A.base = scr, scr += P;
+    for (int k = 0; k < 3; ++k) A.owner[k] = scr, scr += (size_t)nCams * N;
     CS_HIP(hipSetDevice(device));
     if (P == 0) return CS_OK;
-    hipLaunchKernelGGL(k_register_decide, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, A);
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int gE = (P * nCams + 255) / 256, gP = (P + 255) / 256;
+    hipLaunchKernelGGL(k_decide_prepare, dim3(gE), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_decide_order, dim3(gP), dim3(256), 0, s, A);
+    // sweep k reads owner[k % 3], claims into owner[(k + 1) % 3] and clears owner[(k + 2) % 3] for the sweep after it
+    for (int k = 0; k < nSweeps; ++k)
+        hipLaunchKernelGGL(k_decide_sweep, dim3(gP), dim3(256), 0, s, A, (const int*)A.owner[k % 3], A.owner[(k + 1) % 3], A.owner[(k + 2) % 3],
+                           (const int*)nullptr, 0);
+    hipLaunchKernelGGL(k_decide_sweep, dim3(gP), dim3(256), 0, s, A, (const int*)A.owner[nSweeps % 3], (int*)nullptr, (int*)nullptr,
+                       (const int*)A.owner[(nSweeps + 2) % 3], 1);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

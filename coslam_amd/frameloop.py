@@ -441,7 +441,7 @@ class FrameLoop:
             torch = self.torch
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.dev)   # noqa: E731
             self._dec = dict(att=z((cfg.p_reg, NA), torch.uint8), reg=z(self.n_map, torch.uint8), cnt=z(4, torch.int32), ref_cnt=z(1, torch.int32),
-                             scr=z(register_decide_scratch_bytes(NA, cfg.n_feat), torch.uint8), s2m=None)
+                             scr=z(register_decide_scratch_bytes(NA, cfg.n_feat, cfg.p_reg), torch.uint8), s2m=None)
         D = self._dec
         if self.world > 1:
             self._gather_candidates()

@@ -107,18 +107,18 @@ def register_search(W, H, Ks, Rs, ts, xy, state, slot2map, isDynamic, Ms, covs, 
     return dict(slot=slot, m=m, var=var, dist=dist, flags=flags)
 
 
-def register_decide_scratch_bytes(nCams, N):
+def register_decide_scratch_bytes(nCams, N, P):
     L = lib()
     L.cs_register_decide_scratch_bytes.restype = C.c_size_t
-    return int(L.cs_register_decide_scratch_bytes(int(nCams), int(N)))
+    return int(L.cs_register_decide_scratch_bytes(int(nCams), int(N), int(P)))
 
 
 def register_decide_static_dev(stream_ptr, nCams, N, P, mapBase, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, d_slot2map, d_attached,
-                               d_regged, d_scratch, d_counts=0, device=0):
+                               d_regged, d_scratch, d_counts=0, device=0, n_sweeps=3):
     """cs_register_decide_static_dev: d_slot2map = list of nCams device pointers (or the prebuilt c_void_p array)"""
     vp = C.c_void_p
     arr = d_slot2map if isinstance(d_slot2map, C.Array) else (C.c_void_p * nCams)(*[int(x) for x in d_slot2map])
     check(lib().cs_register_decide_static_dev(int(device), vp(stream_ptr), int(nCams), int(N), int(P), int(mapBase), vp(d_slot), vp(d_flags),
                                               vp(d_mergeable), vp(d_mapFlags), vp(d_pointFeat), arr, vp(d_attached), vp(d_regged), vp(d_scratch),
-                                              vp(d_counts)), "cs_register_decide_static_dev")
+                                              int(n_sweeps), vp(d_counts)), "cs_register_decide_static_dev")
     return arr

@@ -323,7 +323,9 @@ int cs_register_search(int device, int nCams, const cs_register_cam* cams, int N
  * has a feature of this frame, where the search found nothing or found a DYNAMIC feature is passed by; the nearest feature is
  * attached when it is unmapped and mergeable over its whole track (d_mergeable == 1: cs_register_mergability_dev; compareFeaturePt
  * returns true whatever it computes, :546-558); a feature that already carries a map point -- before the pass, or taken by an earlier
- * walk -- ends the point's walk (:789-790).  The sequential "first claimant wins" is resolved exactly (see csrc/register.hip).
+ * walk -- ends the point's walk (:789-790).  The sequential "first claimant wins" is a recursion along the order of the walk steps;
+ * nSweeps Jacobi sweeps (one small launch each) solve it -- exactly once two consecutive sweeps agree (d_counts[3] = 1), which takes as
+ * many sweeps as the longest chain of walks cutting each other short: 1-2 on tracked frames, 3 is a safe default (csrc/register.hip).
  * d_slot / d_flags: the search's P x nCams tables; d_mapFlags [P]: CS_MAP_* bytes of the pass's points (map points mapBase ..
  * mapBase + P - 1); IN / OUT: d_pointFeat [P][nCams] (MapPoint::addFeature) and every camera's slot2map [N] (the attached feature's
  * whole track takes the point, :771-775); OUT: d_attached [P][nCams], d_regged [P] (refineMapPoint is due: hand it to
@@ -331,11 +333,11 @@ int cs_register_search(int device, int nCams, const cs_register_cam* cams, int N
  * d_scratch: cs_register_decide_scratch_bytes.  Not done here: the projections are those of the search as it ran (the reference
  * refines a point before the next camera's round of walks, :889-893), and the bMerge == true branch (every 50th frame: checkUnify on
  * a conflict, cs_check_unify_dev gives its verdicts when built). */
-size_t cs_register_decide_scratch_bytes(int nCams, int N);
+size_t cs_register_decide_scratch_bytes(int nCams, int N, int P);
 int cs_register_decide_static_dev(int device, void* hip_stream, int nCams, int N, int P, int mapBase, const int* d_slot, const int* d_flags,
                                   const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
                                   int* const* d_slot2map /* host array of nCams device pointers */, unsigned char* d_attached,
-                                  unsigned char* d_regged, void* d_scratch, int* d_counts);
+                                  unsigned char* d_regged, void* d_scratch, int nSweeps, int* d_counts);
 
 /* Cameras sharded over GPUs: a rank searches for its own cameras (cs_register_search_passes_range_dev, cs_register_mergability_range_dev);
  * the decision needs every camera's candidates.  pack: columns cam0 .. cam0 + nOwn - 1 of the P x nCams tables into a send record of

@@ -348,7 +348,7 @@ int main(int argc, char** argv) {
     for (int c = 0; c < nCams; ++c) s2mPtrs[c] = dS2M + (size_t)c * N;
     unsigned char* dAttached = dev_zeros<unsigned char>((size_t)P_REG * nCams);
     unsigned char* dRegged = dev_zeros<unsigned char>(nMap);
-    void* dDecScratch = dev_zeros<unsigned char>(cs_register_decide_scratch_bytes(nCams, N));
+    void* dDecScratch = dev_zeros<unsigned char>(cs_register_decide_scratch_bytes(nCams, N, P_REG));
     int* dDecCnt = dev_zeros<int>(4);
     const double PIX = 10.0;  // Const::PIXEL_ERR_VAR, reference src/app/SL_GlobParam.cpp:37
     auto step = [&](int i, bool key) {
@@ -400,7 +400,7 @@ int main(int argc, char** argv) {
         CSCHK(cs_register_mergability_dev(hist, (void*)poseS, pu.data(), P_REG, dMap, dCov, reg[1].slot, PIX, dMergeable));
         // the decision (curStaticPointsRegInGroup, bMerge false: who attaches which feature), then refineMapPoint of the points that gained one
         CSCHK(cs_register_decide_static_dev(dev, (void*)poseS, nCams, N, P_REG, 0, reg[1].slot, reg[1].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
-                                            dAttached, dRegged, dDecScratch, dDecCnt));
+                                            dAttached, dRegged, dDecScratch, 3, dDecCnt));
         CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
         HIPCHK(hipEventRecord(destFree[b], poseS));
         if (key) {
