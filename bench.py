@@ -909,7 +909,10 @@ def main():
                        "register_candidates_last_frame": None if args.no_register else
                        {"active": int((reg_out[0]["slot"][:, lc] >= 0).sum().item()), "current_static": int((reg_out[1]["slot"][:, lc] >= 0).sum().item()),
                         "already_attached": int((reg_out[1]["slot"][:, lc] == -1).sum().item()),
-                        "current_static_mergeable_over_the_whole_track": None if loop.pose_upd is None else int((loop.d_mergeable[:, lc] == 1).sum().item())},
+                        "current_static_mergeable_over_the_whole_track": None if loop.pose_upd is None else int((loop.d_mergeable[:, lc] == 1).sum().item()),
+                        "current_static_tracks_longer_than_the_history": None if loop.pose_upd is None else int((loop.d_mergeable[:, lc] == 2).sum().item()),
+                        "history_note": "a candidate whose track is longer than the 64-frame history and passes on every frame held is reported "
+                                        "as unjudged (2) and NOT attached: the reference walks the whole track"},
                        "register_decision": None if not hasattr(loop, "_dec") else dict(zip(
                            ("features_attached_last_frame", "points_regged_last_frame", "sweeps_last_frame", "converged"), loop._dec["cnt"].cpu().tolist()),
                            points_refined_last_frame=int(loop._dec["ref_cnt"].item()),

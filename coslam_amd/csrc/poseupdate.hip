@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void k_register_mergability(MgArgs A) {
     const int p = (blockIdx.x * 256 + tid) / MG_LPC;
     const bool live = p < A.P;
     const int s = live ? A.slot[(size_t)p * A.nCams + c] : -1;
-    bool fail = false;
+    bool fail = false, cut = false;
     if (s >= 0) {
         double M[3], cov[9];
 #pragma unroll
@@ -354,6 +354,7 @@ __global__ __launch_bounds__(256) void k_register_mergability(MgArgs A) {
         const int f1 = C.trackSpan[s], f2 = C.trackSpan[N + s];
         const int len = f1 >= 0 ? f2 - f1 + 1 : 0;
         const int depth = len < A.nHist ? len : A.nHist;
+        cut = len > A.nHist;   // the reference walks the whole preFrame chain: the frames the ring no longer holds stay unjudged
         for (int j = r; j < depth && !fail; j += MG_LPC) {
             const double* R = mg_pose + 12 * j;
             const double* t = R + 9;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void k_register_mergability(MgArgs A) {
     const unsigned long long b = __builtin_amdgcn_ballot_w64(fail);
     if (live && r == 0) {
         const bool anyFail = ((b >> (MG_LPC * g)) & ((1ull << MG_LPC) - 1ull)) != 0ull;
-        A.out[(size_t)p * A.nCams + c] = s < 0 ? 255 : (anyFail ? 0 : 1);
+        A.out[(size_t)p * A.nCams + c] = s < 0 ? 255 : (anyFail ? 0 : (cut ? 2 : 1));
     }
 }
 
@@ -584,6 +585,146 @@ __global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) A.mapPts[3 * (size_t)m + q] = M[q];
     if (A.counts) atomicAdd(A.counts + (locStatic ? 0 : 1), 1);
+}
+
+// ---- CoSLAM::checkUnify (src/app/SL_CoSLAM.cpp:561-665) for a batch of pairs ----------------------------------------------------------
+// What the registration loops ask when a point's nearest feature already carries ANOTHER static point (bMerge, every 50th frame,
+// :791-796): can the two be one?  The views of both points -- per camera, point 1 then point 2, each its feature of this frame and the
+// widest-parallax one further back on that track (around the point's OWN position) -- triangulated together, the covariance, and
+// every view within Mahalanobis distance 1 of the re-projection.  A wave per pair, as k_update_points: the walk for the second view
+// split over the lanes, the normal equations summed in the reference's view order by every lane, then lane v owns view v for the
+// Jacobian and the gate.  The gate's covariance term takes its rotation from `Rs + 3 * i` (:657: three doubles per view into an
+// array that holds nine) -- restated as written: the views' rotations go to LDS back to back and view i reads nine from offset 3 i.
+struct CuArgs {
+    int nCams, N, H, head, nHist, nPairs;
+    const int *pf1, *pf2;      // [nPairs][nCams] slot of the point's feature of this frame, < 0 none
+    const double *M1, *M2;     // [nPairs][3]
+    const double *histXY, *histR, *histT, *cen;
+    double sigma;
+    unsigned char* ok;         // [nPairs]
+    double *M, *cov;           // [nPairs][3], [nPairs][9]
+    cs_poseupdate_cam cam[PU_MAX_CAMS];
+};
+__global__ __launch_bounds__(256) void k_check_unify(CuArgs A) {
+    __shared__ double sR[4][64 * 9 + 16];
+    const int tid = threadIdx.x, g = tid / 64, r = tid % 64;
+    const int q = blockIdx.x * 4 + g;
+    if (q >= A.nPairs) return;
+    const int N = A.N, H = A.H;
+    UpNormalEq E;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) E.N[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) E.g[k] = 0;
+    int nv = 0, myC = -1, myJ = 0, myS = 0;   // lane v keeps view v: camera, ring depth, slot
+    for (int c = 0; c < A.nCams; ++c) {
+        const cs_poseupdate_cam& C = A.cam[c];
+        const double* hR = A.histR + (size_t)c * H * 9;
+        const double* hT = A.histT + (size_t)c * H * 3;
+        const double* hXY = A.histXY + (size_t)c * H * 2 * N;
+        const double* R0 = hR + (size_t)A.head * 9;
+        const double* t0 = hT + (size_t)A.head * 3;
+        for (int which = 0; which < 2; ++which) {
+            const int s = (which ? A.pf2 : A.pf1)[(size_t)q * A.nCams + c];
+            if (s < 0) continue;
+            const double* Mold = (which ? A.M2 : A.M1) + 3 * (size_t)q;
+            up_add_view(E, C.iK, R0, t0, hXY[(size_t)A.head * 2 * N + s], hXY[(size_t)A.head * 2 * N + N + s]);
+            if (r == nv) myC = c, myJ = 0, myS = s;
+            ++nv;
+            double C0[3];
+            up_cam_center(R0, t0, C0);
+            const double a0 = C0[0] - Mold[0], a1 = C0[1] - Mold[1], a2 = C0[2] - Mold[2];
+            const double na = (a0 * a0 + a1 * a1) + a2 * a2;
+            const int f1 = C.trackSpan[s], f2 = C.trackSpan[N + s];
+            const int len = f1 >= 0 ? f2 - f1 + 1 : 0;
+            const int depth = len < A.nHist ? len : A.nHist;
+            int best = -1;
+            double bestCos = 1.0;
+            for (int j = 1 + r; j < depth; j += 64) {
+                const double* Cj = A.cen + 3 * ((size_t)c * A.nHist + j);
+                const double b0 = Cj[0] - Mold[0], b1 = Cj[1] - Mold[1], b2 = Cj[2] - Mold[2];
+                const double d = (a0 * b0 + a1 * b1) + a2 * b2;
+                const double nb = (b0 * b0 + b1 * b1) + b2 * b2;
+                const double cv = d / sqrt(na * nb);
+                if (cv < bestCos) bestCos = cv, best = j;
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double oc = __shfl_xor(bestCos, off, 64);
+                const int oj = __shfl_xor(best, off, 64);
+                if (oj >= 0 && (oc < bestCos || (oc == bestCos && (best < 0 || oj < best)))) bestCos = oc, best = oj;
+            }
+            if (best >= 0) {
+                const int rs = (A.head - best + H) % H;
+                up_add_view(E, C.iK, hR + (size_t)rs * 9, hT + (size_t)rs * 3, hXY[(size_t)rs * 2 * N + s], hXY[(size_t)rs * 2 * N + N + s]);
+                if (r == nv) myC = c, myJ = best, myS = s;
+                ++nv;
+            }
+        }
+    }
+    double cf[6], M[3];
+    const double det = up_sym33_cof(E.N, cf);
+    M[0] = ((cf[0] * E.g[0] + cf[1] * E.g[1]) + cf[2] * E.g[2]) / det;  // triangulateMultiView
+    M[1] = ((cf[1] * E.g[0] + cf[3] * E.g[1]) + cf[4] * E.g[2]) / det;
+    M[2] = ((cf[2] * E.g[0] + cf[4] * E.g[1]) + cf[5] * E.g[2]) / det;
+    // lane v: view v's pose, its Jacobian at M (getTriangulateCovMat), its rotation into the flat array
+    const double *Rv = nullptr, *tv = nullptr;
+    double J[6] = {0, 0, 0, 0, 0, 0};
+    PuProj pv;
+    if (r < nv) {
+        const int rs = (A.head - myJ + H) % H;
+        Rv = A.histR + ((size_t)myC * H + rs) * 9, tv = A.histT + ((size_t)myC * H + rs) * 3;
+        pv = pu_project(A.cam[myC].K, Rv, tv, M);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) J[k] = pv.J[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sR[g][9 * r + k] = Rv[k];
+    }
+    double S[6] = {0, 0, 0, 0, 0, 0};
+    for (int v = 0; v < nv; ++v) {   // the J^T J blocks in view order
+        double Jv[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Jv[k] = __shfl(J[k], v, 64);
+        up_add_jtj(S, Jv);
+    }
+    const double dS = up_sym33_cof(S, cf), s2 = A.sigma * A.sigma;
+    double cov[9];
+    cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
+    cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
+    cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
+    __builtin_amdgcn_wave_barrier();   // (a wave's own LDS stores are visible to its own loads in program order)
+    bool fail = false;
+    if (r < nv) {   // :652-661
+        const double rm0 = pv.u / pv.w, rm1 = pv.v / pv.w;
+        double Rq[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rq[k] = sR[g][3 * r + k];   // `Rs + 3 * i`
+        const PuProj pq = pu_project(A.cam[myC].K, Rq, tv, M);
+        double JC[6], var[4], ivar[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) JC[3 * i + k] = (pq.J[3 * i] * cov[k] + pq.J[3 * i + 1] * cov[3 + k]) + pq.J[3 * i + 2] * cov[6 + k];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double sv = (JC[3 * i] * pq.J[3 * k] + JC[3 * i + 1] * pq.J[3 * k + 1]) + JC[3 * i + 2] * pq.J[3 * k + 2];
+                var[2 * i + k] = (i == k) ? sv + s2 : sv;
+            }
+        pu_mat22_inv(var, ivar);
+        const double* hXY = A.histXY + ((size_t)myC * H + (A.head - myJ + H) % H) * 2 * N;
+        const double dx = rm0 - hXY[myS], dy = rm1 - hXY[N + myS];
+        fail = dx * (ivar[0] * dx + ivar[1] * dy) + dy * (ivar[2] * dx + ivar[3] * dy) > 1.0;
+    }
+    const bool anyFail = __builtin_amdgcn_ballot_w64(fail) != 0;
+    if (r == 0) {
+        A.ok[q] = anyFail ? 0 : 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) A.M[3 * (size_t)q + k] = M[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) A.cov[9 * (size_t)q + k] = cov[k];
+    }
 }
 
 // ---- CoSLAM::mapPointsClassify (src/app/SL_CoSLAM.cpp:418-520) ------------------------------------------------------------------------
@@ -1225,6 +1366,41 @@ extern "C" int cs_refine_map_points_dev(const cs_track_history* h, void* hip_str
     A.sigma = pixelErrVar;
     A.refine = 1, A.select = d_select;
     return up_launch("cs_refine_map_points_dev", h, hip_stream, cams, A, d_count, 1);
+}
+
+extern "C" int cs_check_unify_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int nPairs, const int* d_pf1,
+                                  const int* d_pf2, const double* d_M1, const double* d_M2, double pixelErrVar, unsigned char* d_ok, double* d_M,
+                                  double* d_cov) {
+    if (!h || !cams || nPairs < 0 || (nPairs > 0 && (!d_pf1 || !d_pf2 || !d_M1 || !d_M2 || !d_ok || !d_M || !d_cov)) || h->nCams * 4 > 64) {
+        cs_set_error("cs_check_unify_dev: bad arguments (at most 16 cameras)");
+        return CS_ERR_INVALID;
+    }
+    if (h->count < 1) {
+        cs_set_error("cs_check_unify_dev: the history holds no frame");
+        return CS_ERR_INVALID;
+    }
+    if (nPairs == 0) return CS_OK;
+    CuArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = h->nCams, A.N = h->N, A.H = h->H, A.head = h->head, A.nHist = h->count, A.nPairs = nPairs;
+    A.pf1 = d_pf1, A.pf2 = d_pf2, A.M1 = d_M1, A.M2 = d_M2;
+    A.histXY = h->xy, A.histR = h->R, A.histT = h->t, A.cen = h->cen;
+    A.sigma = pixelErrVar;
+    A.ok = d_ok, A.M = d_M, A.cov = d_cov;
+    for (int c = 0; c < h->nCams; ++c) {
+        if (!cams[c].K || !cams[c].iK || !cams[c].trackSpan) {
+            cs_set_error("cs_check_unify_dev: null pointer in camera %d (K, iK, trackSpan are read)", c);
+            return CS_ERR_INVALID;
+        }
+        A.cam[c] = cams[c];
+    }
+    CS_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(k_ring_centres, dim3((h->nCams * h->count + 255) / 256), dim3(256), 0, s, h->nCams, h->H, h->head, h->count, h->R, h->t,
+                       h->cen);
+    hipLaunchKernelGGL(k_check_unify, dim3((nPairs + 3) / 4), dim3(256), 0, s, A);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
 }
 
 extern "C" int cs_map_points_classify_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int* d_pointFeat,

@@ -135,6 +135,12 @@ class TrackHistory:
                                                vp(d_mapPts), vp(d_mapCov), C.c_double(pixelErrVar), vp(d_count)),
               "cs_refine_map_points_dev")
 
+    def check_unify_dev(self, stream_ptr, cams, nPairs, d_pf1, d_pf2, d_M1, d_M2, pixelErrVar, d_ok, d_M, d_cov):
+        """CoSLAM::checkUnify (reference src/app/SL_CoSLAM.cpp:561-665) for nPairs pairs of map points, a wave per pair"""
+        vp = C.c_void_p
+        check(self._L.cs_check_unify_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), int(nPairs), vp(d_pf1), vp(d_pf2), vp(d_M1), vp(d_M2),
+                                         C.c_double(pixelErrVar), vp(d_ok), vp(d_M), vp(d_cov)), "cs_check_unify_dev")
+
     def map_points_classify_dev(self, stream_ptr, cams, d_pointFeat, nMap, curFrame, d_mapPts, d_mapCov, d_mapFlags, d_newPt,
                                 d_staticFrameNum, d_firstFrame, pixelVar=12.0, d_featFrame=None, d_featFirst=None, d_counts=None):
         """CoSLAM::mapPointsClassify (reference src/app/SL_CoSLAM.cpp:418-520; CoSLAM::poseUpdate calls it with 12.0 every frame):

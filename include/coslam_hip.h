@@ -407,7 +407,9 @@ int cs_pose_update_frame_dev(cs_track_history* h, void* hip_stream, const cs_pos
  * projection under the pose of its own frame (covariance J cov J^T + pixelErrVar^2 I).  d_slot: the P x nCams candidate table of
  * cs_register_search_dev (entries < 0: no candidate); the tracks' past pixels and the frames' poses come from the history h, whose
  * newest entry must be THIS frame (what cs_pose_update_frame_dev / cs_detect_dynamic_dev pushed); cams: K and trackSpan of every
- * camera.  d_mergeable [P x nCams]: 1 mergeable, 0 not, 255 no candidate.  (The search's own flag bit 2 is the first term of this
+ * camera.  d_mergeable [P x nCams]: 1 mergeable, 0 not, 255 no candidate, 2 = every frame the history holds passes but the track is
+ * LONGER than the history (the reference walks the whole chain: the older frames stay unjudged -- a caller that must not be more
+ * permissive than the reference treats 2 as 0, as cs_register_decide_static_dev does; or sizes the history for its tracks).  (The search's own flag bit 2 is the first term of this
  * walk -- this frame only.)  What the registration loops do with a mergeable candidate -- pointer updates, refineMapPoint,
  * checkUnify -- stays with the caller; compareFeaturePt, which they also call, returns true whatever its NCC score is (:546-558). */
 int cs_register_mergability_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int P, const double* d_M,
@@ -457,6 +459,17 @@ int cs_update_new_poses_points_dev(const cs_track_history* h, void* hip_stream, 
  * history and ordering rules as cs_update_new_poses_points_dev; cams: K, iK, trackSpan.  d_count [1] or NULL: points refined. */
 int cs_refine_map_points_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap,
                              const unsigned char* d_select, double* d_mapPts, double* d_mapCov, double pixelErrVar, int* d_count);
+
+/* CoSLAM::checkUnify (src/app/SL_CoSLAM.cpp:561-665) for nPairs pairs of map points in one launch: what the registration loops ask
+ * on a conflict -- the point's nearest feature already carries another static point (:791-796, bMerge: every 50th frame).  Per pair
+ * the slots of both points' features of this frame per camera (d_pf1 / d_pf2 [nPairs][nCams], < 0 none) and the points' positions
+ * (d_M1 / d_M2 [nPairs][3]: the widest-parallax second view of a feature's track is chosen around its own point); out: d_ok [nPairs]
+ * (1: the views of both points agree with ONE point), d_M [nPairs][3], d_cov [nPairs][9] -- what p->updatePosition(M, cov) takes when
+ * ok.  The gate's `Rs + 3 * i` of :657 is reproduced as written.  History, cams (K, iK, trackSpan) and ordering rules as
+ * cs_refine_map_points_dev.  What happens on ok -- the second point set false, its features moved over (:797-822) -- is the caller's. */
+int cs_check_unify_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int nPairs, const int* d_pf1,
+                       const int* d_pf2, const double* d_M1, const double* d_M2, double pixelErrVar, unsigned char* d_ok, double* d_M,
+                       double* d_cov);
 
 /* CoSLAM::mapPointsClassify (src/app/SL_CoSLAM.cpp:418-520) in one launch: what CoSLAM::poseUpdate runs every frame behind the pose
  * update (:381-385, pixelVar = 12.0) -- every map point with a feature in this frame that is uncertain (CS_MAP_UNCERTAIN: what the

@@ -388,7 +388,7 @@ def static_check_mergability(K, histR, histT, histXY, slot, length, M, cov, pixe
 
 def register_mergability_cam(K, histR, histT, histXY, trackSpan, Ms, covs, slot, pixelVar):
     """org_register_mergability_cam: staticCheckMergability for one camera's candidates (slot int32[P]); returns uint8[P]
-    (1 mergeable, 0 not, 255 no candidate)."""
+    (1 mergeable, 0 not, 255 no candidate, 2 every frame of the history passes but the track is longer than the history)."""
     L = lib()
     K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
     histR = np.ascontiguousarray(histR, dtype=np.float64)

@@ -672,7 +672,7 @@ int opu_map_points_classify(int nCams, int N, int nHist, const double* Ks, const
  * (:656) uses the right one.  Restated as written.  Features of this frame only (a pair's tables name the slot per camera, < 0 none);
  * the walk runs over the whole track (no window), bounded by the history.  Returns 1 / 0; M and cov are written in either case.
  * Pinned against the reference's own function (tests/cxx/ref_update_points_test.cpp: halves of one point's cameras, and different
- * points); no device counterpart yet. */
+ * points); the device counterpart is cs_check_unify_dev (coslam_amd/csrc/poseupdate.hip: k_check_unify). */
 int opu_check_unify(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
                     const double* histXY, const int* trackSpan, const int* pf1, const int* pf2, const double* M1, const double* M2,
                     double sigma, int cmpAcos, double* M, double* cov) {
