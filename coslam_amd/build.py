@@ -24,6 +24,7 @@ HIP_SOURCES = [
     "register.hip",
     "poseupdate.hip",
     "ncc.hip",
+    "newpts.hip",
     "posegraph.hip",
     "results.cpp",
     "ba.hip",

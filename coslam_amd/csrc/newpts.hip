@@ -1,0 +1,421 @@
+// newpts.hip -- from the inter-camera NCC matrices to NEW MAP POINTS, on the device.
+//
+// Replaces what NewMapPtsNCC::run / output do behind getEpiNccMat (reference src/app/SL_NewMapPointsInterCam.cpp):
+//   matchBetween's tail (:295-316)  the seeds of a camera pair (getSeedsBetween, :97-127: the map points both cameras see in this
+//                                   frame), the disparity guide and the greedy one-to-one matching of the pair's candidates
+//   featTracksFromMatches (:631-690) the matches of consecutive camera pairs chained into tracks, numbered in the order
+//                                   (pair, feature of the pair's first camera)
+//   reconstructTracks (:194-270)    per track of >= minLen views: triangulateMultiView, every view within maxRpErr pixels of the
+//                                   re-projection and in front of its camera, getTriangulateCovMat, reprojErr of every feature, the
+//                                   point's type (more than one DYNAMIC feature: dynamic, else uncertain)
+//   output (:163-192)               decidePointType (:22-93: an uncertain point becomes locally static unless one of its features lies
+//                                   within 20 pixels of a feature of a dynamic map point), the features take the point, the point
+//                                   joins the current list
+// The map is structure-of-arrays with spare capacity; new points are appended in track order behind *mapCount.
+// Un-vendored LibVisualSLAM, OUR definitions (the oracle's, operation for operation):
+//   greedyNCCMatch(ncc)                 the valid entries in order of falling score (ties: smaller row, then smaller column), an entry
+//                                       is a match when neither its row nor its column has one yet
+//   getDisparityMat(c1, c2, s1, s2, maxDisp)   entry (i, j) = | (c2_j - c1_i) - (s2_k - s1_k) | for the seed k nearest to c1_i in image
+//                                       1 (first of equals), invalid when larger than maxDisp
+//   greedyGuidedNCCMatch(ncc, disp)     greedyNCCMatch over the entries whose disparity entry is valid
+//   reprojErrorSingle(K, R, t, M, m)    Euclidean pixel distance of m from the projection; dist2 likewise
+// triangulateMultiView / getTriangulateCovMat / project / isAtCameraBack as in poseupdate.hip.
+#include "cs_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int NP_MAX_CAMS = 16, NP_MAX_CAND = 2048, NP_MAX_SEEDS = 512, NP_MAX_TRACKS = 4096, NP_MAX_N = 32768;
+
+struct NpArgs {
+    int nCams, N, mapCap, curFrame, pairCap, minLen;
+    double maxDisp, maxRpErr, sigma;
+    const cs_ncc_pair* pairs[NP_MAX_CAMS];   // candidates of camera pair (a, a + 1): cs_ncc_epi_pairs_group_dev's list
+    const int* pairCount[NP_MAX_CAMS];
+    cs_poseupdate_cam cam[NP_MAX_CAMS];      // K, iK, xy, state, slot2map (written), reprojErr (written), isStatic
+    const double *R, *t;                     // [nCams][9], [nCams][3]: the cameras' current poses
+    double *mapPts, *mapCov;                 // [mapCap][3], [mapCap][9]
+    unsigned char *mapFlags, *newPt;         // [mapCap]
+    int *firstFrame, *pointFeat;             // [mapCap], [mapCap][nCams]
+    int* mapCount;                           // [1] points in use: new ones are appended here
+    int* matchIdx;                           // scratch [nCams - 1][N]: feature of camera a -> its match in camera a + 1, or -1
+    int* inFlag;                             // scratch [nCams][N]: 1 = some feature of camera c - 1 is matched to this one
+    int* counts;                             // [4 + nCams] out: new points, tracks, tracks >= minLen, flags (bit 0: a candidate list
+                                             // overflowed, bit 1: the map is full), then the matches of every pair
+};
+
+__device__ __forceinline__ bool np_before(double sa, unsigned ia, double sb, unsigned ib) {   // falling score, then rising (row, column)
+    return sa > sb || (sa == sb && ia < ib);
+}
+
+// one workgroup per camera pair: seeds, disparity guide, the candidates sorted, the greedy walk
+__global__ __launch_bounds__(256) void k_np_match(NpArgs A) {
+    __shared__ double sKey[NP_MAX_CAND];
+    __shared__ unsigned sIdx[NP_MAX_CAND];
+    __shared__ double sSeed[NP_MAX_SEEDS][4];   // s1.x, s1.y, d.x, d.y (the first NP_MAX_SEEDS seeds in map order)
+    __shared__ unsigned sRow[NP_MAX_N / 32], sCol[NP_MAX_N / 32];
+    __shared__ int sNSeeds, sNCand, sNMatch;
+    const int a = blockIdx.x, b = a + 1, tid = threadIdx.x, N = A.N, C = A.nCams;
+    int* match = A.matchIdx + (size_t)a * N;
+    int* inB = A.inFlag + (size_t)b * N;
+    for (int i = tid; i < N; i += 256) match[i] = -1, inB[i] = 0;
+    for (int q = tid; q < (N + 31) / 32; q += 256) sRow[q] = 0, sCol[q] = 0;
+    if (tid == 0) sNSeeds = 0, sNCand = 0, sNMatch = 0;
+    __syncthreads();
+    // getSeedsBetween (:97-127): in map order -- kept in map order here by a chunked scan
+    {
+        const int cap = *A.mapCount < A.mapCap ? *A.mapCount : A.mapCap;
+        for (int m0 = 0; m0 < cap; m0 += 256) {
+            const int m = m0 + tid;
+            bool in = false;
+            int s1 = -1, s2 = -1;
+            if (m < cap && !(A.mapFlags[m] & (CS_MAP_FALSE | CS_MAP_UNCERTAIN))) {
+                s1 = A.pointFeat[(size_t)m * C + a], s2 = A.pointFeat[(size_t)m * C + b];
+                if (s1 >= 0 && s2 >= 0) {
+                    int nv = 0;
+                    for (int c = 0; c < C; ++c) nv += A.pointFeat[(size_t)m * C + c] >= 0;
+                    in = nv >= 2;
+                }
+            }
+            // ordered compaction of the chunk (ballot per wave, wave totals through LDS)
+            __shared__ int wTot[4];
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
+            const int lane = tid & 63, wv = tid >> 6;
+            if (lane == 0) wTot[wv] = __popcll(bal);
+            __syncthreads();
+            int off = sNSeeds;
+            for (int w = 0; w < wv; ++w) off += wTot[w];
+            const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
+            if (in && k < NP_MAX_SEEDS) {
+                const double x1 = A.cam[a].xy[s1], y1 = A.cam[a].xy[N + s1], x2 = A.cam[b].xy[s2], y2 = A.cam[b].xy[N + s2];
+                sSeed[k][0] = x1, sSeed[k][1] = y1, sSeed[k][2] = x2 - x1, sSeed[k][3] = y2 - y1;
+            }
+            __syncthreads();
+            if (tid == 0) sNSeeds = min(sNSeeds + wTot[0] + wTot[1] + wTot[2] + wTot[3], NP_MAX_SEEDS);
+            __syncthreads();
+        }
+    }
+    const int nSeeds = sNSeeds;
+    // the pair's candidates: the disparity guide (when there are seeds), then into the sort arrays
+    int nAll = *A.pairCount[a];
+    if (nAll > A.pairCap) nAll = A.pairCap;
+    for (int q0 = 0; q0 < nAll; q0 += 256) {
+        const int q = q0 + tid;
+        bool ok = false;
+        cs_ncc_pair p;
+        if (q < nAll) {
+            p = A.pairs[a][q];
+            ok = p.i >= 0 && p.i < N && p.j >= 0 && p.j < N;
+            if (ok && nSeeds > 0) {
+                const double x1 = A.cam[a].xy[p.i], y1 = A.cam[a].xy[N + p.i];
+                double best = 1.0e300;
+                int bk = 0;
+                for (int k = 0; k < nSeeds; ++k) {
+                    const double dx = sSeed[k][0] - x1, dy = sSeed[k][1] - y1, d2 = dx * dx + dy * dy;
+                    if (d2 < best) best = d2, bk = k;
+                }
+                const double ex = (A.cam[b].xy[p.j] - x1) - sSeed[bk][2];
+                const double ey = (A.cam[b].xy[N + p.j] - y1) - sSeed[bk][3];
+                ok = sqrt(ex * ex + ey * ey) <= A.maxDisp;
+            }
+        }
+        if (ok) {
+            const int k = atomicAdd(&sNCand, 1);
+            if (k < NP_MAX_CAND) sKey[k] = p.ncc, sIdx[k] = ((unsigned)p.i << 16) | (unsigned)p.j;
+        }
+    }
+    __syncthreads();
+    int L = sNCand;
+    if (L > NP_MAX_CAND) {
+        L = NP_MAX_CAND;
+        if (tid == 0 && A.counts) atomicOr(A.counts + 3, 1);
+    }
+    // bitonic sort over the next power of two (padding sorts last)
+    int L2 = 1;
+    while (L2 < L) L2 <<= 1;
+    for (int q = L + tid; q < L2; q += 256) sKey[q] = -1.0e300, sIdx[q] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int k = 2; k <= L2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int q = tid; q < L2; q += 256) {
+                const int x = q ^ j;
+                if (x > q) {
+                    const bool up = (q & k) == 0;
+                    const double ka = sKey[q], kb = sKey[x];
+                    const unsigned ia = sIdx[q], ib = sIdx[x];
+                    if (np_before(kb, ib, ka, ia) == up) sKey[q] = kb, sIdx[q] = ib, sKey[x] = ka, sIdx[x] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    // the greedy walk: one lane, the list is short (a few hundred entries)
+    if (tid == 0) {
+        int n = 0;
+        for (int q = 0; q < L; ++q) {
+            const unsigned id = sIdx[q], i = id >> 16, j = id & 0xFFFFu;
+            if ((sRow[i >> 5] >> (i & 31)) & 1u) continue;
+            if ((sCol[j >> 5] >> (j & 31)) & 1u) continue;
+            sRow[i >> 5] |= 1u << (i & 31), sCol[j >> 5] |= 1u << (j & 31);
+            match[i] = (int)j, inB[j] = 1;
+            ++n;
+        }
+        if (A.counts) A.counts[4 + a] = n;
+    }
+}
+
+struct NpView {
+    int c, s;
+};
+// one workgroup: featTracksFromMatches + reconstructTracks + output
+__global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
+    __shared__ int sScan[256];
+    __shared__ int sBase, sNTracks;
+    __shared__ unsigned short sTrkCam[NP_MAX_TRACKS];    // first camera of the track
+    __shared__ unsigned short sTrkSlot[NP_MAX_TRACKS];   // its slot there
+    __shared__ unsigned char sValid[NP_MAX_TRACKS];
+    const int tid = threadIdx.x, N = A.N, C = A.nCams, nP = C - 1;
+    if (tid == 0) sBase = 0, sNTracks = 0;
+    __syncthreads();
+    // ---- the tracks' starts in the order (pair, feature): (a, i) matched and not the continuation of a track of pair a - 1
+    const int total = nP * N, per = (total + 255) / 256, lo = min(tid * per, total), hi = min(lo + per, total);
+    auto is_start = [&](int e) {
+        const int a = e / N, i = e - a * N;
+        if (A.matchIdx[(size_t)a * N + i] < 0) return false;
+        if (a == 0) return true;
+        // flag[iCam][i] >= 0 <=> some feature of camera a - 1 matched to i: then the match EXTENDS that track (:668-676)
+        return A.inFlag[(size_t)a * N + i] == 0;
+    };
+    int cnt = 0;
+    for (int e = lo; e < hi; ++e) cnt += is_start(e) ? 1 : 0;
+    sScan[tid] = cnt;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = tid >= d ? sScan[tid - d] : 0;
+        __syncthreads();
+        sScan[tid] += v;
+        __syncthreads();
+    }
+    int rank = sScan[tid] - cnt;
+    for (int e = lo; e < hi; ++e)
+        if (is_start(e)) {
+            if (rank < NP_MAX_TRACKS) sTrkCam[rank] = (unsigned short)(e / N), sTrkSlot[rank] = (unsigned short)(e % N);
+            ++rank;
+        }
+    if (tid == 255) sNTracks = sScan[255] < NP_MAX_TRACKS ? sScan[255] : NP_MAX_TRACKS;
+    __syncthreads();
+    const int nTracks = sNTracks;
+    int nLong = 0;
+    // ---- reconstructTracks (:194-270), a lane per track
+    for (int t0 = 0; t0 < nTracks; t0 += 256) {
+        const int tk = t0 + tid;
+        NpView v[NP_MAX_CAMS];
+        int nv = 0;
+        bool valid = false;
+        double M[3] = {0, 0, 0}, cov[9];
+        unsigned char fl = 0;
+        if (tk < nTracks) {
+            int c = sTrkCam[tk], s = sTrkSlot[tk];
+            v[nv].c = c, v[nv].s = s, ++nv;
+            while (c < nP) {   // follow the chain: camera c's slot s matched into camera c + 1
+                const int m = A.matchIdx[(size_t)c * N + s];
+                if (m < 0) break;
+                ++c, s = m;
+                v[nv].c = c, v[nv].s = s, ++nv;
+            }
+            if (nv >= A.minLen) {
+                ++nLong;
+                // triangulateMultiView over the views' normalised points
+                double Nn[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+                for (int k = 0; k < nv; ++k) {
+                    const cs_poseupdate_cam& Cm = A.cam[v[k].c];
+                    const double* R = A.R + 9 * v[k].c;
+                    const double* t = A.t + 3 * v[k].c;
+                    const double mx = Cm.xy[v[k].s], my = Cm.xy[N + v[k].s];
+                    const double* iK = Cm.iK;
+                    const double w = (iK[6] * mx + iK[7] * my) + iK[8];
+                    const double x = ((iK[0] * mx + iK[1] * my) + iK[2]) / w, y = ((iK[3] * mx + iK[4] * my) + iK[5]) / w;   // normPoint
+                    const double a0[3] = {R[0] - x * R[6], R[1] - x * R[7], R[2] - x * R[8]}, a1[3] = {R[3] - y * R[6], R[4] - y * R[7], R[5] - y * R[8]};
+                    const double b0 = x * t[2] - t[0], b1 = y * t[2] - t[1];
+                    Nn[0] = Nn[0] + (a0[0] * a0[0] + a1[0] * a1[0]);
+                    Nn[1] = Nn[1] + (a0[0] * a0[1] + a1[0] * a1[1]);
+                    Nn[2] = Nn[2] + (a0[0] * a0[2] + a1[0] * a1[2]);
+                    Nn[3] = Nn[3] + (a0[1] * a0[1] + a1[1] * a1[1]);
+                    Nn[4] = Nn[4] + (a0[1] * a0[2] + a1[1] * a1[2]);
+                    Nn[5] = Nn[5] + (a0[2] * a0[2] + a1[2] * a1[2]);
+                    for (int q = 0; q < 3; ++q) g[q] = g[q] + (a0[q] * b0 + a1[q] * b1);
+                }
+                double cf[6];
+                cf[0] = Nn[3] * Nn[5] - Nn[4] * Nn[4], cf[1] = Nn[2] * Nn[4] - Nn[1] * Nn[5], cf[2] = Nn[1] * Nn[4] - Nn[2] * Nn[3];
+                cf[3] = Nn[0] * Nn[5] - Nn[2] * Nn[2], cf[4] = Nn[1] * Nn[2] - Nn[0] * Nn[4], cf[5] = Nn[0] * Nn[3] - Nn[1] * Nn[1];
+                const double det = (Nn[0] * cf[0] + Nn[1] * cf[1]) + Nn[2] * cf[2];
+                M[0] = ((cf[0] * g[0] + cf[1] * g[1]) + cf[2] * g[2]) / det;
+                M[1] = ((cf[1] * g[0] + cf[3] * g[1]) + cf[4] * g[2]) / det;
+                M[2] = ((cf[2] * g[0] + cf[4] * g[1]) + cf[5] * g[2]) / det;
+                // every view: within maxRpErr of the re-projection and in front of the camera (:226-236); J^T J for the covariance
+                bool outlier = false;
+                double S[6] = {0, 0, 0, 0, 0, 0};
+                double err[NP_MAX_CAMS];
+                for (int k = 0; k < nv; ++k) {
+                    const cs_poseupdate_cam& Cm = A.cam[v[k].c];
+                    const double* K = Cm.K;
+                    const double* R = A.R + 9 * v[k].c;
+                    const double* t = A.t + 3 * v[k].c;
+                    const double X = ((R[0] * M[0] + R[1] * M[1]) + R[2] * M[2]) + t[0];
+                    const double Y = ((R[3] * M[0] + R[4] * M[1]) + R[5] * M[2]) + t[1];
+                    const double Z = ((R[6] * M[0] + R[7] * M[1]) + R[8] * M[2]) + t[2];
+                    const double u = (K[0] * X + K[1] * Y) + K[2] * Z, vv = (K[3] * X + K[4] * Y) + K[5] * Z, w = (K[6] * X + K[7] * Y) + K[8] * Z;
+                    const double dx = Cm.xy[v[k].s] - u / w, dy = Cm.xy[N + v[k].s] - vv / w;
+                    err[k] = sqrt(dx * dx + dy * dy);
+                    if (err[k] > A.maxRpErr || Z < 0) outlier = true;
+                    double KR[9], J[6];
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = 0; j < 3; ++j) KR[3 * i + j] = (K[3 * i] * R[j] + K[3 * i + 1] * R[3 + j]) + K[3 * i + 2] * R[6 + j];
+                    const double ww = w * w;
+                    for (int j = 0; j < 3; ++j) J[j] = (KR[j] * w - u * KR[6 + j]) / ww, J[3 + j] = (KR[3 + j] * w - vv * KR[6 + j]) / ww;
+                    S[0] = S[0] + (J[0] * J[0] + J[3] * J[3]);
+                    S[1] = S[1] + (J[0] * J[1] + J[3] * J[4]);
+                    S[2] = S[2] + (J[0] * J[2] + J[3] * J[5]);
+                    S[3] = S[3] + (J[1] * J[1] + J[4] * J[4]);
+                    S[4] = S[4] + (J[1] * J[2] + J[4] * J[5]);
+                    S[5] = S[5] + (J[2] * J[2] + J[5] * J[5]);
+                }
+                if (!outlier) {
+                    valid = true;
+                    cf[0] = S[3] * S[5] - S[4] * S[4], cf[1] = S[2] * S[4] - S[1] * S[5], cf[2] = S[1] * S[4] - S[2] * S[3];
+                    cf[3] = S[0] * S[5] - S[2] * S[2], cf[4] = S[1] * S[2] - S[0] * S[4], cf[5] = S[0] * S[3] - S[1] * S[1];
+                    const double dS = (S[0] * cf[0] + S[1] * cf[1]) + S[2] * cf[2], s2 = A.sigma * A.sigma;
+                    cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
+                    cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
+                    cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
+                    int nDyn = 0;
+                    for (int k = 0; k < nv; ++k) {
+                        const cs_poseupdate_cam& Cm = A.cam[v[k].c];
+                        if (Cm.reprojErr) Cm.reprojErr[v[k].s] = err[k];                       // fp->reprojErr (:247-248)
+                        if (Cm.isStatic && !Cm.isStatic[v[k].s]) ++nDyn;                         // TYPE_FEATPOINT_DYNAMIC (:250-251)
+                    }
+                    if (nDyn > 1) {
+                        fl = CS_MAP_DYNAMIC;                                                     // :253-254
+                    } else {
+                        // :263-264 setUncertain().  decidePointType (:62-91) then calls setLocalStatic() on an uncertain point none of
+                        // whose features lies within 20 pixels of a dynamic map point's feature: that writes the type the constructor
+                        // already gave (iLocalType 0 = static) and leaves bUncertain alone -- nothing to do either way
+                        fl = CS_MAP_UNCERTAIN;
+                    }
+                }
+            }
+            sValid[tk] = valid ? 1 : 0;
+        }
+        // the valid tracks of this batch take consecutive map indices in track order
+        sScan[tid] = valid ? 1 : 0;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const int x = tid >= d ? sScan[tid - d] : 0;
+            __syncthreads();
+            sScan[tid] += x;
+            __syncthreads();
+        }
+        const int before = sBase + sScan[tid] - (valid ? 1 : 0);
+        const int m = *A.mapCount + before;
+        if (valid) {
+            if (m < A.mapCap) {
+                for (int q = 0; q < 3; ++q) A.mapPts[3 * (size_t)m + q] = M[q];
+                for (int q = 0; q < 9; ++q) A.mapCov[9 * (size_t)m + q] = cov[q];
+                A.mapFlags[m] = fl, A.newPt[m] = 1, A.firstFrame[m] = A.curFrame;
+                for (int c = 0; c < C; ++c) A.pointFeat[(size_t)m * C + c] = -1;
+                for (int k = 0; k < nv; ++k) {
+                    A.pointFeat[(size_t)m * C + v[k].c] = v[k].s;          // MapPoint::addFeature
+                    const_cast<int*>(A.cam[v[k].c].slot2map)[v[k].s] = m;  // the feature (and its track) takes the point (:168-172)
+                }
+            } else if (A.counts) {
+                atomicOr(A.counts + 3, 2);
+            }
+        }
+        __syncthreads();
+        if (tid == 255) sBase += sScan[255];
+        __syncthreads();
+    }
+    if (nLong && A.counts) atomicAdd(A.counts + 2, nLong);
+    __syncthreads();
+    if (tid == 0) {
+        int added = sBase;
+        if (*A.mapCount + added > A.mapCap) added = A.mapCap - *A.mapCount;
+        if (A.counts) A.counts[0] = added, A.counts[1] = nTracks;
+        *A.mapCount += added;
+    }
+}
+
+// valid[i] = slot i can become a new map point: a feature of this frame on a track of at least minTrack + 1 frames (getTrackedFeatPts
+// (.., 3), src/app/SL_SingleSLAM.cpp:173-184), unmapped or mapped to a FALSE point (NewMapPtsNCC::addSlam, SL_NewMapPointsInterCam.h:120-128)
+__global__ __launch_bounds__(256) void k_np_candidates(int n, int N, const int* __restrict__ state, const int* __restrict__ slot2map,
+                                                       const int* __restrict__ trackSpan, const unsigned char* __restrict__ mapFlags, int mapCap,
+                                                       int minTrack, int* __restrict__ valid) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const int c = q / N, s = q - c * N;
+    const int st = state[q], m = slot2map[q];
+    const int f1 = trackSpan[(size_t)c * 2 * N + s], f2 = trackSpan[(size_t)c * 2 * N + N + s];
+    const bool tracked = (st == 0 || st == 1) && f1 >= 0 && f2 - f1 >= minTrack;
+    const bool freeOrFalse = m < 0 || (m < mapCap && (mapFlags[m] & CS_MAP_FALSE));
+    valid[q] = tracked && freeOrFalse ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" size_t cs_newpts_scratch_bytes(int nCams, int N) {
+    if (nCams < 2 || N < 1) return 0;
+    return sizeof(int) * (size_t)(2 * nCams - 1) * N;
+}
+
+extern "C" int cs_ncc_candidate_mask_dev(int device, void* hip_stream, int nCams, int N, const int* d_state, const int* d_slot2map,
+                                         const int* d_trackSpan, const unsigned char* d_mapFlags, int mapCap, int minTrack, int* d_valid) {
+    if (nCams < 1 || N < 1 || !d_state || !d_slot2map || !d_trackSpan || !d_mapFlags || !d_valid) {
+        cs_set_error("cs_ncc_candidate_mask_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_np_candidates, dim3((nCams * N + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, nCams * N, N, d_state, d_slot2map,
+                       d_trackSpan, d_mapFlags, mapCap, minTrack, d_valid);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+extern "C" int cs_newpts_from_pairs_dev(int device, void* hip_stream, int nCams, int N, const cs_poseupdate_cam* cams,
+                                        const cs_ncc_pair* const* d_pairs, const int* const* d_pairCount, int pairCap, const double* d_R,
+                                        const double* d_t, double* d_mapPts, double* d_mapCov, unsigned char* d_mapFlags, unsigned char* d_newPt,
+                                        int* d_firstFrame, int* d_pointFeat, int mapCap, int* d_mapCount, int curFrame, double maxDisp,
+                                        double maxRpErr, double pixelErrVar, int minLen, void* d_scratch, int* d_counts) {
+    if (nCams < 2 || nCams > NP_MAX_CAMS || N < 1 || N > NP_MAX_N || !cams || !d_pairs || !d_pairCount || pairCap < 1 || !d_R || !d_t || !d_mapPts ||
+        !d_mapCov || !d_mapFlags || !d_newPt || !d_firstFrame || !d_pointFeat || mapCap < 1 || !d_mapCount || !d_scratch || minLen < 2) {
+        cs_set_error("cs_newpts_from_pairs_dev: bad arguments (2..%d cameras, N <= %d)", NP_MAX_CAMS, NP_MAX_N);
+        return CS_ERR_INVALID;
+    }
+    NpArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = nCams, A.N = N, A.mapCap = mapCap, A.curFrame = curFrame, A.pairCap = pairCap, A.minLen = minLen;
+    A.maxDisp = maxDisp, A.maxRpErr = maxRpErr, A.sigma = pixelErrVar;
+    for (int a = 0; a + 1 < nCams; ++a) {
+        if (!d_pairs[a] || !d_pairCount[a]) {
+            cs_set_error("cs_newpts_from_pairs_dev: null candidate list of camera pair %d", a);
+            return CS_ERR_INVALID;
+        }
+        A.pairs[a] = d_pairs[a], A.pairCount[a] = d_pairCount[a];
+    }
+    for (int c = 0; c < nCams; ++c) {
+        if (!cams[c].K || !cams[c].iK || !cams[c].xy || !cams[c].state || !cams[c].slot2map) {
+            cs_set_error("cs_newpts_from_pairs_dev: null pointer in camera %d (K, iK, xy, state, slot2map)", c);
+            return CS_ERR_INVALID;
+        }
+        A.cam[c] = cams[c];
+    }
+    A.R = d_R, A.t = d_t, A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.mapFlags = d_mapFlags, A.newPt = d_newPt, A.firstFrame = d_firstFrame;
+    A.pointFeat = d_pointFeat, A.mapCount = d_mapCount, A.matchIdx = (int*)d_scratch, A.inFlag = (int*)d_scratch + (size_t)(nCams - 1) * N;
+    A.counts = d_counts;
+    CS_HIP(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (d_counts) CS_HIP(hipMemsetAsync(d_counts, 0, sizeof(int) * (4 + (size_t)nCams), s));
+    hipLaunchKernelGGL(k_np_match, dim3(nCams - 1), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_np_reconstruct, dim3(1), dim3(256), 0, s, A);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}

@@ -873,3 +873,140 @@ def register_decide_static(slot, flags, mergeable, mapFlags, pointFeat, slot2map
             if breg:
                 regged[p] = 1
     return attached, regged
+
+
+def new_map_points_from_pairs(N, pairs, Ks, iKs, Rs, ts, xy, state, slot2map, isStatic, mapPts, mapCov, mapFlags, newPt, firstFrame, pointFeat,
+                              map_count, cur_frame, max_disp=80.0, max_rp_err=3.0, sigma=10.0, min_len=2, max_seeds=512, reproj=None):
+    """NewMapPtsNCC::run + output behind getEpiNccMat (reference src/app/SL_NewMapPointsInterCam.cpp:150-161, 163-192, 194-270, 295-316,
+    631-690) restated over structure-of-arrays records (TEST INFRASTRUCTURE, plain Python / numpy, operation for operation what
+    coslam_amd/csrc/newpts.hip does): per consecutive camera pair the candidate list (i, j, epi, ncc) of the NCC stage -> seeds,
+    disparity guide, greedy matches; the matches chained into tracks; every track of >= min_len views triangulated, gated and appended
+    to the map arrays IN PLACE behind map_count.  greedyNCCMatch / greedyGuidedNCCMatch / getDisparityMat are un-vendored: the
+    definitions are newpts.hip's header's.  Returns dict(matches [nC-1][N], tracks (list of [(cam, slot)]), new (indices of the new
+    points), map_count)."""
+    import math
+
+    nC = len(xy)
+    cap = len(mapPts)
+    pf = pointFeat
+    match = np.full((nC - 1, N), -1, dtype=np.int32)
+    has_in = np.zeros((nC, N), dtype=bool)
+    for a in range(nC - 1):
+        b = a + 1
+        seeds = []                                       # getSeedsBetween (:97-127), map order
+        for m in range(min(map_count, cap)):
+            if int(mapFlags[m]) & 6:                     # isFalse() / isUncertain()
+                continue
+            s1, s2 = int(pf[m, a]), int(pf[m, b])
+            if s1 >= 0 and s2 >= 0 and len(seeds) < max_seeds:
+                x1, y1 = xy[a][s1], xy[a][N + s1]
+                seeds.append((x1, y1, xy[b][s2] - x1, xy[b][N + s2] - y1))
+        cand = []
+        for (i, j, epi, ncc) in pairs[a]:
+            i, j = int(i), int(j)
+            if seeds:                                    # getDisparityMat + the guide
+                x1, y1 = xy[a][i], xy[a][N + i]
+                best, bk = 1.0e300, 0
+                for k, sd in enumerate(seeds):
+                    dx, dy = sd[0] - x1, sd[1] - y1
+                    d2 = dx * dx + dy * dy
+                    if d2 < best:
+                        best, bk = d2, k
+                ex = (xy[b][j] - x1) - seeds[bk][2]
+                ey = (xy[b][N + j] - y1) - seeds[bk][3]
+                if not math.sqrt(ex * ex + ey * ey) <= max_disp:
+                    continue
+            cand.append((-float(ncc), i, j))
+        cand.sort()                                      # falling score, then rising row, then rising column
+        rows, cols = set(), set()
+        for _, i, j in cand:
+            if i in rows or j in cols:
+                continue
+            rows.add(i), cols.add(j)
+            match[a, i] = j
+            has_in[b, j] = True
+    tracks = []                                          # featTracksFromMatches (:631-690): numbered by (pair, feature)
+    for a in range(nC - 1):
+        for i in range(N):
+            if match[a, i] < 0 or (a > 0 and has_in[a, i]):
+                continue
+            tk, c, s = [(a, i)], a, i
+            while c < nC - 1 and match[c, s] >= 0:
+                s = int(match[c, s])
+                c += 1
+                tk.append((c, s))
+            tracks.append(tk)
+    new = []
+    for tk in tracks:                                    # reconstructTracks (:194-270)
+        if len(tk) < min_len:
+            continue
+        Nn, g = [0.0] * 6, [0.0] * 3
+        for c, s in tk:
+            iK, R, t = iKs[c].reshape(9), Rs[c].reshape(9), ts[c]
+            mx, my = xy[c][s], xy[c][N + s]
+            w = (iK[6] * mx + iK[7] * my) + iK[8]
+            x, y = ((iK[0] * mx + iK[1] * my) + iK[2]) / w, ((iK[3] * mx + iK[4] * my) + iK[5]) / w
+            a0 = [R[0] - x * R[6], R[1] - x * R[7], R[2] - x * R[8]]
+            a1 = [R[3] - y * R[6], R[4] - y * R[7], R[5] - y * R[8]]
+            b0, b1 = x * t[2] - t[0], y * t[2] - t[1]
+            Nn[0] = Nn[0] + (a0[0] * a0[0] + a1[0] * a1[0])
+            Nn[1] = Nn[1] + (a0[0] * a0[1] + a1[0] * a1[1])
+            Nn[2] = Nn[2] + (a0[0] * a0[2] + a1[0] * a1[2])
+            Nn[3] = Nn[3] + (a0[1] * a0[1] + a1[1] * a1[1])
+            Nn[4] = Nn[4] + (a0[1] * a0[2] + a1[1] * a1[2])
+            Nn[5] = Nn[5] + (a0[2] * a0[2] + a1[2] * a1[2])
+            for q in range(3):
+                g[q] = g[q] + (a0[q] * b0 + a1[q] * b1)
+
+        def cof(S):
+            c_ = [S[3] * S[5] - S[4] * S[4], S[2] * S[4] - S[1] * S[5], S[1] * S[4] - S[2] * S[3], S[0] * S[5] - S[2] * S[2],
+                  S[1] * S[2] - S[0] * S[4], S[0] * S[3] - S[1] * S[1]]
+            return c_, (S[0] * c_[0] + S[1] * c_[1]) + S[2] * c_[2]
+
+        with np.errstate(all="ignore"):
+            cf, det = cof(Nn)
+            M = [np.float64((cf[0] * g[0] + cf[1] * g[1]) + cf[2] * g[2]) / det, np.float64((cf[1] * g[0] + cf[3] * g[1]) + cf[4] * g[2]) / det,
+                 np.float64((cf[2] * g[0] + cf[4] * g[1]) + cf[5] * g[2]) / det]
+            outlier, S, errs = False, [0.0] * 6, []
+            for c, s in tk:
+                K, R, t = Ks[c].reshape(9), Rs[c].reshape(9), ts[c]
+                X = ((R[0] * M[0] + R[1] * M[1]) + R[2] * M[2]) + t[0]
+                Y = ((R[3] * M[0] + R[4] * M[1]) + R[5] * M[2]) + t[1]
+                Z = ((R[6] * M[0] + R[7] * M[1]) + R[8] * M[2]) + t[2]
+                u, v, w = (K[0] * X + K[1] * Y) + K[2] * Z, (K[3] * X + K[4] * Y) + K[5] * Z, (K[6] * X + K[7] * Y) + K[8] * Z
+                dx, dy = xy[c][s] - u / w, xy[c][N + s] - v / w
+                e = np.sqrt(dx * dx + dy * dy)
+                errs.append(e)
+                if e > max_rp_err or Z < 0:
+                    outlier = True
+                KR = [(K[3 * i] * R[j] + K[3 * i + 1] * R[3 + j]) + K[3 * i + 2] * R[6 + j] for i in range(3) for j in range(3)]
+                ww = w * w
+                J = [(KR[j] * w - u * KR[6 + j]) / ww for j in range(3)] + [(KR[3 + j] * w - v * KR[6 + j]) / ww for j in range(3)]
+                S[0] = S[0] + (J[0] * J[0] + J[3] * J[3])
+                S[1] = S[1] + (J[0] * J[1] + J[3] * J[4])
+                S[2] = S[2] + (J[0] * J[2] + J[3] * J[5])
+                S[3] = S[3] + (J[1] * J[1] + J[4] * J[4])
+                S[4] = S[4] + (J[1] * J[2] + J[4] * J[5])
+                S[5] = S[5] + (J[2] * J[2] + J[5] * J[5])
+            if outlier:
+                continue
+            cf, dS = cof(S)
+            s2 = sigma * sigma
+            cov = [(cf[0] / dS) * s2, (cf[1] / dS) * s2, (cf[2] / dS) * s2, 0, (cf[3] / dS) * s2, (cf[4] / dS) * s2, 0, 0, (cf[5] / dS) * s2]
+            cov[3], cov[6], cov[7] = cov[1], cov[2], cov[5]
+        if map_count >= cap:
+            continue
+        m = map_count
+        map_count += 1
+        mapPts[m], mapCov[m] = M, cov
+        n_dyn = sum(1 for c, s in tk if isStatic is not None and not isStatic[c][s])
+        mapFlags[m] = 1 if n_dyn > 1 else 4            # setLocalDynamic / setUncertain (:253-264); decidePointType changes neither
+        newPt[m], firstFrame[m] = 1, cur_frame
+        pf[m, :] = -1
+        for k, (c, s) in enumerate(tk):
+            pf[m, c] = s
+            slot2map[c][s] = m
+            if reproj is not None:
+                reproj[c][s] = errs[k]
+        new.append(m)
+    return dict(matches=match, tracks=tracks, new=new, map_count=map_count)

@@ -1,0 +1,143 @@
+"""From the NCC stage's candidate pairs to new map points on the device (cs_newpts_from_pairs_dev) against the restatement of
+NewMapPtsNCC::run / output (oracle.new_map_points_from_pairs): seeds and the disparity guide, greedy matches with ties and conflicts,
+tracks over up to four cameras, the re-projection / behind-the-camera gate, the covariances, point types, the features' new owners."""
+import numpy as np
+import pytest
+
+from tests.poseupdate_scene import Scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(seed, nC=4, N=512, nMap=400, extra=300):
+    rng = np.random.default_rng(seed)
+    sc = Scene(nC=nC, N=N, nMap=nMap, T=3, seed=seed)
+    f = 2
+    recs = sc.frame(f)
+    xy = [r["xy"].copy() for r in recs]
+    state = [r["state"].copy() for r in recs]
+    s2m = [r["slot2map"].copy() for r in recs]
+    for c in range(nC):
+        state[c][state[c] == 1] = 0
+    R = np.stack([sc.Re[f][c].reshape(9) for c in range(nC)])
+    t = np.stack([sc.te[f][c] for c in range(nC)])
+    cap = nMap + extra
+    mapPts = np.zeros((cap, 3))
+    mapPts[:nMap] = sc.map0
+    mapCov = np.zeros((cap, 9))
+    mapCov[:nMap] = sc.cov0
+    flags = np.zeros(cap, dtype=np.uint8)
+    flags[:nMap] = sc.flags0
+    pf = np.full((cap, nC), -1, dtype=np.int32)
+    pf[:nMap] = Scene.point_feat([dict(state=state[c], slot2map=s2m[c]) for c in range(nC)], nMap)
+    is_static = [(rng.random(N) < 0.85).astype(np.uint8) for _ in range(nC)]
+    # candidate pairs: the same scene point unmapped in both cameras (true), plus wrong pairs; scores partly tied
+    pairs = []
+    for a in range(nC - 1):
+        by_pt = {int(sc.slotPt[a + 1, j]): j for j in range(N) if state[a + 1][j] == 0 and s2m[a + 1][j] < 0}
+        lst = []
+        for i in range(N):
+            if state[a][i] != 0 or s2m[a][i] >= 0:
+                continue
+            p = int(sc.slotPt[a, i])
+            if p in by_pt and rng.random() < 0.8:
+                lst.append((i, by_pt[p], rng.uniform(0, 5), round(float(rng.uniform(0.8, 1.0)), 2)))
+            for _ in range(int(rng.integers(0, 3))):       # distractors
+                j = int(rng.integers(0, N))
+                if state[a + 1][j] == 0 and s2m[a + 1][j] < 0:
+                    lst.append((i, j, rng.uniform(0, 50), round(float(rng.uniform(0.8, 1.0)), 2)))
+        seen, uniq = set(), []
+        for q in lst:
+            if (q[0], q[1]) not in seen:
+                seen.add((q[0], q[1])), uniq.append(q)
+        rng.shuffle(uniq)
+        pairs.append(uniq)
+    return dict(sc=sc, nC=nC, N=N, nMap=nMap, cap=cap, xy=xy, state=state, s2m=s2m, R=R, t=t, mapPts=mapPts, mapCov=mapCov, flags=flags, pf=pf,
+                is_static=is_static, pairs=pairs, frame=f)
+
+
+@pytest.mark.parametrize("seed,max_disp", [(11, 80.0), (12, 25.0), (13, 1e9)])
+def test_new_map_points_equal_the_restatement(hip, seed, max_disp):
+    import torch
+
+    import oracle
+    from coslam_amd.ncc import NCC_PAIR_DTYPE
+    from coslam_amd.newpts import NewPtsJob, newpts_from_pairs_dev, newpts_scratch_bytes
+
+    S = _scene(seed)
+    sc, nC, N, nMap, cap = S["sc"], S["nC"], S["N"], S["nMap"], S["cap"]
+    if seed == 13:
+        S["flags"][:nMap] |= 4      # no seeds at all (every map point uncertain): the unguided greedy
+    o = dict(mapPts=S["mapPts"].copy(), mapCov=S["mapCov"].copy(), flags=S["flags"].copy(), newPt=np.zeros(cap, np.uint8),
+             first=np.zeros(cap, np.int32), pf=S["pf"].copy(), s2m=[x.copy() for x in S["s2m"]], reproj=[np.zeros(N) for _ in range(nC)])
+    res = oracle.new_map_points_from_pairs(N, S["pairs"], [sc.K] * nC, [sc.iK] * nC, S["R"], S["t"], S["xy"], S["state"], o["s2m"], S["is_static"],
+                                           o["mapPts"], o["mapCov"], o["flags"], o["newPt"], o["first"], o["pf"], nMap, S["frame"],
+                                           max_disp=max_disp, reproj=o["reproj"])
+    assert len(res["new"]) > 20 and len(res["tracks"]) > len(res["new"]) and any(len(t) >= 3 for t in res["tracks"])
+    dev = torch.device("cuda:0")
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    dK, diK = d(sc.K.reshape(9)), d(sc.iK.reshape(9))
+    dxy, dst, ds2m, dstat = d(np.stack(S["xy"])), d(np.stack(S["state"])), d(np.stack(S["s2m"])), d(np.stack(S["is_static"]))
+    drep = torch.zeros((nC, N), dtype=torch.float64, device=dev)
+    CAPP = 4096
+    dpairs = torch.zeros((nC - 1, CAPP * NCC_PAIR_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    dcnt = torch.zeros(nC - 1, dtype=torch.int32, device=dev)
+    for a in range(nC - 1):
+        arr = np.zeros(len(S["pairs"][a]), dtype=NCC_PAIR_DTYPE)
+        for k, (i, j, e, n) in enumerate(S["pairs"][a]):
+            arr[k] = (i, j, e, n)
+        dpairs[a, :arr.nbytes] = torch.from_numpy(arr.view(np.uint8)).to(dev)
+        dcnt[a] = len(arr)
+    cams = [dict(K=dK.data_ptr(), iK=diK.data_ptr(), xy=dxy[c].data_ptr(), state=dst[c].data_ptr(), slot2map=ds2m[c].data_ptr(),
+                 isStatic=dstat[c].data_ptr(), reprojErr=drep[c].data_ptr()) for c in range(nC)]
+    job = NewPtsJob(cams, [dpairs[a].data_ptr() for a in range(nC - 1)], [dcnt[a:a + 1].data_ptr() for a in range(nC - 1)])
+    dM, dC, dF, dPf = d(S["mapPts"]), d(S["mapCov"]), d(S["flags"]), d(S["pf"])
+    dNew, dFirst = torch.zeros(cap, dtype=torch.uint8, device=dev), torch.zeros(cap, dtype=torch.int32, device=dev)
+    dCount = torch.tensor([nMap], dtype=torch.int32, device=dev)
+    dScr = torch.zeros(newpts_scratch_bytes(nC, N), dtype=torch.uint8, device=dev)
+    dOut = torch.zeros(4 + nC, dtype=torch.int32, device=dev)
+    dR, dT = d(S["R"]), d(S["t"])
+    newpts_from_pairs_dev(torch.cuda.current_stream().cuda_stream, job, N, CAPP, dR.data_ptr(), dT.data_ptr(), dM.data_ptr(), dC.data_ptr(),
+                          dF.data_ptr(), dNew.data_ptr(), dFirst.data_ptr(), dPf.data_ptr(), cap, dCount.data_ptr(), S["frame"], dScr.data_ptr(),
+                          dOut.data_ptr(), maxDisp=max_disp)
+    torch.cuda.synchronize()
+    out = dOut.cpu().tolist()
+    assert out[0] == len(res["new"]) and out[1] == len(res["tracks"]) and out[3] == 0
+    assert out[4:4 + nC - 1] == [int((res["matches"][a] >= 0).sum()) for a in range(nC - 1)]
+    assert int(dCount.item()) == res["map_count"] == nMap + len(res["new"])
+    match = dScr.view(torch.int32)[:(nC - 1) * N].view(nC - 1, N).cpu().numpy()
+    assert np.array_equal(match, res["matches"])
+    assert np.array_equal(dM.cpu().numpy(), o["mapPts"]) and np.array_equal(dC.cpu().numpy(), o["mapCov"])
+    assert np.array_equal(dF.cpu().numpy(), o["flags"]) and np.array_equal(dNew.cpu().numpy(), o["newPt"]) and np.array_equal(dFirst.cpu().numpy(), o["first"])
+    assert np.array_equal(dPf.cpu().numpy(), o["pf"])
+    for c in range(nC):
+        assert np.array_equal(ds2m[c].cpu().numpy(), o["s2m"][c]) and np.array_equal(drep[c].cpu().numpy(), o["reproj"][c])
+    assert (o["flags"][res["new"]] == 4).sum() > 10      # new uncertain points; dynamic ones need two DYNAMIC features
+
+
+def test_candidate_mask_is_addslams_filter(hip):
+    """cs_ncc_candidate_mask_dev: features of this frame on tracks of MORE than three frames, unmapped or mapped to a false point
+    (NewMapPtsNCC::addSlam + getTrackedFeatPts(.., 3), reference src/app/SL_NewMapPointsInterCam.h:103-131, SL_SingleSLAM.cpp:173-184)"""
+    import torch
+
+    from coslam_amd.newpts import ncc_candidate_mask_dev
+
+    rng = np.random.default_rng(5)
+    nC, N, cap = 3, 300, 50
+    state = rng.integers(-2, 2, (nC, N)).astype(np.int32)
+    s2m = np.where(rng.random((nC, N)) < 0.5, rng.integers(0, cap, (nC, N)), -1).astype(np.int32)
+    span = np.zeros((nC, 2 * N), dtype=np.int32)
+    span[:, :N] = rng.integers(0, 10, (nC, N))
+    span[:, N:] = span[:, :N] + rng.integers(0, 8, (nC, N))
+    span[:, :N][rng.random((nC, N)) < 0.1] = -1
+    flags = rng.choice([0, 1, 2, 4, 6], cap).astype(np.uint8)
+    dev = torch.device("cuda:0")
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    dv = torch.zeros((nC, N), dtype=torch.int32, device=dev)
+    keep = [d(state), d(s2m), d(span), d(flags)]
+    ncc_candidate_mask_dev(torch.cuda.current_stream().cuda_stream, nC, N, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(),
+                           cap, dv.data_ptr())
+    torch.cuda.synchronize()
+    f1, f2 = span[:, :N], span[:, N:]
+    want = ((state == 0) | (state == 1)) & (f1 >= 0) & (f2 - f1 >= 3) & ((s2m < 0) | ((flags[np.clip(s2m, 0, cap - 1)] & 2) != 0))
+    assert np.array_equal(dv.cpu().numpy(), want.astype(np.int32)) and 20 < want.sum() < nC * N - 20
