@@ -537,8 +537,13 @@ def main():
         barrier()
     run(args.warmup)
     barrier()
-    ba_ws.worker_stats(), ic_ws.worker_stats()   # (reset: the sums below cover the timed region only)
+    ba_ws.worker_stats(), [w.worker_stats() for w in loop.ic_wss]   # (reset: the sums below cover the timed region only)
     applied0 = loop.applied
+    prof = None
+    if os.environ.get("BENCH_PYPROFILE") and rank == 0:   # where the host thread's time goes (diagnostic: slows the loop)
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t_begin = time.perf_counter()
     t_step_max, i_step_max, t_prev = 0.0, -1, t_begin
     for i in range(args.steps):
@@ -552,7 +557,13 @@ def main():
     t_host = time.perf_counter() - t_begin
     barrier()
     dt = time.perf_counter() - t_begin
-    wj, wi = ba_ws.worker_stats(), ic_ws.worker_stats()
+    if prof is not None:
+        import pstats
+        prof.disable()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(45)
+    wj = ba_ws.worker_stats()
+    wis = [w.worker_stats() for w in loop.ic_wss]
+    wi = [sum(w[0] for w in wis), sum(w[1] for w in wis), 0, max(w[3] for w in wis)]
     applied_timed = loop.applied - applied0
     digest = loop.digest() if os.environ.get("BENCH_STATE_DIGEST") else None
     if loop._timing is not None:
@@ -561,7 +572,8 @@ def main():
     solve_duty = {"what": "time the key-frame solves THIS RANK ran held their workspaces' streams inside the timed region (GPU clock, from the "
                           "moment the frame they wait for was done), against the region's length",
                   "joint_ba": {"solves": wj[0], "ms_total": wj[1], "ms_max": wj[3], "ms_parse_total": wj[4], "share_of_timed_region": wj[1] / (dt * 1e3)},
-                  "inter_camera": {"solves": wi[0], "ms_total": wi[1], "ms_max": wi[3], "share_of_timed_region": wi[1] / (dt * 1e3)}}
+                  "inter_camera": {"solves": wi[0], "ms_total": wi[1], "ms_max": wi[3], "share_of_timed_region": wi[1] / (dt * 1e3),
+                                   "workspaces_the_key_frames_rotate_over": loop.n_ic_workers}}
     with_upload = None
     if not args.no_upload_leg:
         # the same loop once more, the images coming from pinned host memory every frame (same key-frame cadence, same drain):
@@ -616,7 +628,8 @@ def main():
     f_last = loop.vid(n_done)
     tl_ = d_t[last].cpu().numpy()
     pose_err = max(float(np.abs(tl_[c] - sc.pose(c, f_last)[1]).max()) for c in my_cams)
-    map_err = float((loop.d_map - torch.from_numpy(sc.points).to(dev)).abs().amax(dim=1).median().item())
+    n_pts0 = loop.n_pts0
+    map_err = float((loop.d_map[:n_pts0] - torch.from_numpy(sc.points).to(dev)).abs().amax(dim=1).median().item())
     win_info = st_j = None
     if loop.win is not None and loop.n_my_solves > 0:
         wC, wP, wO, _, wkf = loop.win.last_problem()
@@ -928,16 +941,23 @@ def main():
                                "examined_last_frame": int(loop.d_cls_counts[0].item()), "became_false_last_frame": int(loop.d_cls_counts[1].item()),
                                "map_points_false": int((d_mapflags & 2).ne(0).sum().item()),
                                "map_points_dynamic": int(((d_mapflags & 3) == 1).sum().item())},
-                           "map_points_refined": int((loop.d_map - torch.from_numpy(sc.points).to(dev)).abs().amax(dim=1).gt(0).sum().item()),
+                           "map_points_refined": int((loop.d_map[:n_pts0] - torch.from_numpy(sc.points).to(dev)).abs().amax(dim=1).gt(0).sum().item()),
                            "features_dynamic_last_frame": [int(v) for v in ((loop.d_isstatic == 0) & (loop.d_state >= 0)).sum(dim=1).cpu().tolist()],
                            "static_mapped_features_last_frame": [int(v) for v in ((loop.d_state >= 0) & (loop.d_slot2map >= 0)).sum(dim=1).cpu().tolist()]},
                        "key_frame_solves_duty": solve_duty,
                        "host_enqueue_ms_per_step": t_host / args.steps * 1e3, "host_enqueue_ms_max_step": t_step_max * 1e3, "host_enqueue_max_at_step": i_step_max,
                        "ncc_matching": None if loop.ncc is None else {
-                           "every_frames": cfg.ncc_every, "camera_pairs_per_run": nc - 1, "runs": loop.ncc["runs"],
-                           "output": "list of the passing pairs (cs_ncc_epi_pairs_dev)",
-                           "pairs_kept_last_run": [int(v) for v in loop.ncc["pair_count"].cpu().tolist()],
-                           "unmapped_features_last_run": [int(v) for v in loop.ncc["valid"].sum(dim=1).cpu().tolist()]},
+                           "every_frames": cfg.ncc_every, "camera_pairs_per_run": N_CAMS - 1, "runs": loop.ncc["runs"],
+                           "what": "NewMapPtsNCC every 4th frame: getNCCBlocks of the rank's cameras (N > 1: one all-gather of the blocks), "
+                                   "the epipolar / NCC test of all consecutive camera pairs as candidate lists, then on the device: seeds + "
+                                   "disparity guide + greedy matches, featTracksFromMatches, reconstructTracks, output -- new map points "
+                                   "appended to the live map (cs_newpts_from_pairs_dev)",
+                           "candidate_pairs_last_run": [int(v) for v in loop.ncc["pair_count"].cpu().tolist()],
+                           "candidate_features_last_run": [int(loop.ncc["valid"][g].view(torch.int32).sum().item()) for g in range(N_CAMS)],
+                           **dict(zip(("new_map_points_last_run", "tracks_last_run", "tracks_of_two_or_more_views_last_run", "flags_last_run"),
+                                      loop.ncc["np_cnt"].cpu().tolist()[:4])),
+                           "matches_per_pair_last_run": loop.ncc["np_cnt"].cpu().tolist()[4:4 + N_CAMS - 1],
+                           "map_points_in_use": int(loop.d_mapcount.item()), "map_points_at_start": n_pts0, "map_capacity": loop.n_map},
                        "with_upload": with_upload, "cxx_frame_loop": cxx,
                        "collectives": None if world == 1 else ("libcoslam_hip RCCL (C-ABI)" if loop.native else "torch.distributed " + dist_backend),
                        "streams": "tracker group | hand-back + pose + map update + registration (event-ordered behind the tracker of the same "

@@ -729,17 +729,25 @@ __global__ __launch_bounds__(256) void k_check_unify(CuArgs A) {
 
 // ---- CoSLAM::mapPointsClassify (src/app/SL_CoSLAM.cpp:418-520) ------------------------------------------------------------------------
 // Every frame behind the pose update (CoSLAM::poseUpdate, :381-385) the reference re-examines every map point of the current list that
-// is uncertain (what the gate above made of it) or locally dynamic: static again (isStaticPoint over the last 60 frames: the views of
-// updateStaticPointPosition inside that window, triangulation, covariance, every view within Mahalanobis distance 1), dynamic
-// (isDynamicPoint: this frame's features, in front of the first camera, a covariance small against the distance, every view within
-// the gate), static without its worst view (isStaticRemovable -> that feature is detached), or false; dynamic points that stand
-// still (isLittleMove) for more than 50 frames may return to static.  The examined points are few (what the gate rejected, the
-// moving objects' points) and each decision is a chain of small f64 solves: ONE LANE PER MAP POINT runs the reference's control
-// flow as written (src/slam/SL_CoSLAMHelper.cpp:67-330), the camera centres of the ring from k_ring_centres; nothing is shared
-// between points (a feature belongs to one point), so the in-place updates need no ordering.  Helper definitions as above, plus
-// isAtCameraBack(R, t, M) = (R M + t).z < 0 and dist3 = Euclidean distance.
+// is uncertain (what the gate above made of it, and every new point until it is 30 frames old) or locally dynamic: static again
+// (isStaticPoint over the last 60 frames: the views of updateStaticPointPosition inside that window, triangulation, covariance, every
+// view within Mahalanobis distance 1), dynamic (isDynamicPoint: this frame's features, in front of the first camera, a covariance
+// small against the distance, every view within the gate), static without its worst view (isStaticRemovable -> that feature is
+// detached), or false; dynamic points that stand still (isLittleMove) for more than 50 frames may return to static
+// (src/slam/SL_CoSLAMHelper.cpp:67-330).
+//
+// Two launches.  k_classify_select: a lane per map point puts the points to examine on a worklist (tens to a few hundred of the
+// map's thousands; new points sit next to each other at the map's end, so a wave that worked through its own 64 points would
+// serialise exactly the busy stretch).  k_map_points_classify: A WAVE PER EXAMINED POINT.  Lane c keeps camera c's feature of
+// the point; the widest-parallax walks (up to 60 frames back per camera) are split over the lanes and reduced (smallest cosine, the
+// nearest frame among equals -- what the reference's backwards walk with `<` keeps); then lane v owns view v: its row pair of the
+// triangulation's normal equations, its Jacobian for the covariance, its gate -- the f64 divisions, which are most of the
+// arithmetic, run once per view side by side, and the sums over views are taken in the reference's view order from the lanes'
+// registers (bit-identical to the sequential sum: -ffp-contract=off).  Every branch of the decision is uniform over the wave.
+// Nothing is shared between points (a feature belongs to one point), so the order of the worklist does not matter.
+// Helper definitions as above, plus isAtCameraBack(R, t, M) = (R M + t).z < 0 and dist3 = Euclidean distance.
 struct ClsArgs {
-    int nCams, N, nMap, H, head, nHist, curFrame, stageCen;
+    int nCams, N, nMap, H, head, nHist, curFrame;
     int* pointFeat;        // [nMap][nCams] in / out (a detached feature becomes -1)
     const int* featFrame;  // [nMap][nCams] or null: the frame of MapPoint::pFeatures[iCam] (null: all of this frame)
     const int* featFirst;  // [nMap][nCams] or null: the first frame of that feature's track (null: the slot's trackSpan)
@@ -755,20 +763,26 @@ struct ClsArgs {
     const int* firstFrame;
     double sigma;
     int* counts;  // [2] points examined / points that became false, or null
+    int* list;    // [1 + nMap] worklist: count, then the points
     cs_poseupdate_cam cam[PU_MAX_CAMS];
 };
-struct ClsView {
-    int c, j;  // camera, walk depth (0 = this frame)
+// camera c's feature of point m as the lane c of the point's wave keeps it: slot (< 0: none, or older than the history), walk
+// depth of its frame, that frame, the first frame of its track
+struct ClsFeat {
+    int s, j0, f, ff;
 };
-
-__device__ __forceinline__ bool cls_feature(const ClsArgs& A, int m, int c, int& s, int& j0, int& f, int& ff) {
-    s = A.pointFeat[(size_t)m * A.nCams + c];
-    if (s < 0) return false;
-    f = A.featFrame ? A.featFrame[(size_t)m * A.nCams + c] : A.curFrame;
-    j0 = A.curFrame - f;
-    if (j0 < 0 || j0 >= A.nHist) return false;  // older than the history: treated as absent
-    ff = A.featFirst ? A.featFirst[(size_t)m * A.nCams + c] : A.cam[c].trackSpan[s];
-    return true;
+__device__ __forceinline__ ClsFeat cls_feature(const ClsArgs& A, int m, int c) {
+    ClsFeat F;
+    F.s = -1, F.j0 = 0, F.f = 0, F.ff = 0;
+    if (c >= A.nCams) return F;
+    const int s = A.pointFeat[(size_t)m * A.nCams + c];
+    if (s < 0) return F;
+    F.f = A.featFrame ? A.featFrame[(size_t)m * A.nCams + c] : A.curFrame;
+    F.j0 = A.curFrame - F.f;
+    if (F.j0 < 0 || F.j0 >= A.nHist) return F;  // older than the history: treated as absent
+    F.ff = A.featFirst ? A.featFirst[(size_t)m * A.nCams + c] : A.cam[c].trackSpan[s];
+    F.s = s;
+    return F;
 }
 __device__ __forceinline__ const double* cls_R(const ClsArgs& A, int c, int j) {
     return A.histR + ((size_t)c * A.H + (A.head - j + A.H) % A.H) * 9;
@@ -780,11 +794,8 @@ __device__ __forceinline__ void cls_pixel(const ClsArgs& A, int c, int j, int s,
     const double* h = A.histXY + ((size_t)c * A.H + (A.head - j + A.H) % A.H) * 2 * A.N;
     mx = h[s], my = h[A.N + s];
 }
-// mahaDist2 of a feature from the projection of (M, cov) under its own frame's pose: project, getProjectionCovMat, mat22Inv
-__device__ __noinline__ double cls_err(const ClsArgs& A, int c, int j, int s, const double* M, const double* cov) {
-    double mx, my;
-    cls_pixel(A, c, j, s, mx, my);
-    const PuProj q = pu_project(A.cam[c].K, cls_R(A, c, j), cls_t(A, c, j), M);
+// mahaDist2 of a pixel from a projection of (M, cov): getProjectionCovMat, mat22Inv
+__device__ __forceinline__ double cls_maha(const PuProj& q, const double* cov, double s2, double mx, double my) {
     const double rm0 = q.u / q.w, rm1 = q.v / q.w;
     double JC[6], var[4], ivar[4];
 #pragma unroll
@@ -796,63 +807,93 @@ __device__ __noinline__ double cls_err(const ClsArgs& A, int c, int j, int s, co
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const double sv = (JC[3 * i] * q.J[3 * k] + JC[3 * i + 1] * q.J[3 * k + 1]) + JC[3 * i + 2] * q.J[3 * k + 2];
-            var[2 * i + k] = (i == k) ? sv + A.sigma * A.sigma : sv;
+            var[2 * i + k] = (i == k) ? sv + s2 : sv;
         }
     pu_mat22_inv(var, ivar);
     const double dx = rm0 - mx, dy = rm1 - my;
     return dx * (ivar[0] * dx + ivar[1] * dy) + dy * (ivar[2] * dx + ivar[3] * dy);
 }
-// triangulateMultiView over the view list; mode 2 stops there; else getTriangulateCovMat; mode 1 adds the gate of every view (> 1 fails)
-__device__ __noinline__ bool cls_triangulate(const ClsArgs& A, const int* slotOf, const ClsView* v, int nv, double* M, double* cov, int mode) {
+// the views of a wave's point: lane v < nv holds view v (camera, walk depth, slot)
+struct ClsViews {
+    int nv, c, j, s;
+};
+// triangulateMultiView + getTriangulateCovMat over the views (+ the gate of every view when asked: any view > 1 fails); M and cov
+// come back in every lane
+__device__ __forceinline__ bool cls_solve(const ClsArgs& A, const ClsViews& V, int r, double* M, double* cov, bool gate,
+                                          bool* atBackOfFirst = nullptr) {
+    UpNormalEq T;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) T.N[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) T.g[q] = 0;
+    double mx = 0, my = 0;
+    const double *Rv = A.histR, *tv = A.histT;
+    if (r < V.nv) {
+        cls_pixel(A, V.c, V.j, V.s, mx, my);
+        Rv = cls_R(A, V.c, V.j), tv = cls_t(A, V.c, V.j);
+        up_add_view(T, A.cam[V.c].iK, Rv, tv, mx, my);
+    }
     UpNormalEq E;
 #pragma unroll
     for (int q = 0; q < 6; ++q) E.N[q] = 0;
 #pragma unroll
     for (int q = 0; q < 3; ++q) E.g[q] = 0;
-    for (int i = 0; i < nv; ++i) {
-        double mx, my;
-        cls_pixel(A, v[i].c, v[i].j, slotOf[v[i].c], mx, my);
-        up_add_view(E, A.cam[v[i].c].iK, cls_R(A, v[i].c, v[i].j), cls_t(A, v[i].c, v[i].j), mx, my);
+    for (int v = 0; v < V.nv; ++v) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) E.N[q] = E.N[q] + __shfl(T.N[q], v, 64);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) E.g[q] = E.g[q] + __shfl(T.g[q], v, 64);
     }
     double cf[6];
     const double det = up_sym33_cof(E.N, cf);
     M[0] = ((cf[0] * E.g[0] + cf[1] * E.g[1]) + cf[2] * E.g[2]) / det;
     M[1] = ((cf[1] * E.g[0] + cf[3] * E.g[1]) + cf[4] * E.g[2]) / det;
     M[2] = ((cf[2] * E.g[0] + cf[4] * E.g[1]) + cf[5] * E.g[2]) / det;
-    if (mode == 2) return true;
+    if (atBackOfFirst) {  // isAtCameraBack under the first view's pose
+        const bool back = r == 0 && ((Rv[6] * M[0] + Rv[7] * M[1]) + Rv[8] * M[2]) + tv[2] < 0;
+        *atBackOfFirst = (__builtin_amdgcn_ballot_w64(back) & 1ull) != 0;
+    }
+    PuProj q;
+    q.u = q.v = 0, q.w = 1;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) q.J[k] = 0;
+    if (r < V.nv) q = pu_project(A.cam[V.c].K, Rv, tv, M);
     double S[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < nv; ++i) {
-        const PuProj q = pu_project(A.cam[v[i].c].K, cls_R(A, v[i].c, v[i].j), cls_t(A, v[i].c, v[i].j), M);
-        up_add_jtj(S, q.J);
+    for (int v = 0; v < V.nv; ++v) {
+        double Jv[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Jv[k] = __shfl(q.J[k], v, 64);
+        up_add_jtj(S, Jv);
     }
     const double dS = up_sym33_cof(S, cf), s2 = A.sigma * A.sigma;
     cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
     cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
     cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
-    if (mode == 0) return true;
-    for (int i = 0; i < nv; ++i)
-        if (cls_err(A, v[i].c, v[i].j, slotOf[v[i].c], M, cov) > 1.0) return false;
-    return true;
+    if (!gate) return true;
+    const bool fail = r < V.nv && cls_maha(q, cov, s2, mx, my) > 1.0;
+    return __builtin_amdgcn_ballot_w64(fail) == 0;
 }
 // isStaticPoint (exclude < 0) / isStaticPointExclude (src/slam/SL_CoSLAMHelper.cpp:117-250)
-__device__ __noinline__ bool cls_is_static(const ClsArgs& A, int m, const double* Mold, double* M, double* cov, int exclude, int numFrame) {
-    ClsView v[2 * PU_MAX_CAMS];
-    int slotOf[PU_MAX_CAMS], nv = 0;
+__device__ __noinline__ bool cls_is_static(const ClsArgs& A, const ClsFeat& F, int r, const double* Mold, double* M, double* cov, int exclude,
+                                           int numFrame) {
+    ClsViews V;
+    V.nv = 0, V.c = 0, V.j = 0, V.s = 0;
     const int firstFrame = A.curFrame - numFrame;
     for (int c = 0; c < A.nCams; ++c) {
-        int s, j0, f, ff;
-        if (c == exclude || !cls_feature(A, m, c, s, j0, f, ff) || f < firstFrame) continue;
-        slotOf[c] = s;
-        v[nv].c = c, v[nv].j = j0, ++nv;
+        const int s = __shfl(F.s, c, 64), f = __shfl(F.f, c, 64);
+        if (c == exclude || s < 0 || f < firstFrame) continue;
+        const int j0 = __shfl(F.j0, c, 64), ff = __shfl(F.ff, c, 64);
+        if (r == V.nv) V.c = c, V.j = j0, V.s = s;
+        ++V.nv;
         const double* C0 = A.cen + 3 * ((size_t)c * A.nHist + j0);
         const double a0 = C0[0] - Mold[0], a1 = C0[1] - Mold[1], a2 = C0[2] - Mold[2];
         const double na = (a0 * a0 + a1 * a1) + a2 * a2;
         int best = -1;
         double bestCos = 1.0;
+        // fp = fp->preFrame while fp->f >= firstFrame: frames f-1 .. lo, walk depths j0+1 .. curFrame-lo, as far as the ring goes
         const int lo = ff > firstFrame ? ff : firstFrame;
-        for (int fr = f - 1; fr >= lo; --fr) {  // fp = fp->preFrame while fp->f >= firstFrame
-            const int j = A.curFrame - fr;
-            if (j >= A.nHist) break;
+        const int jEnd = A.curFrame - lo < A.nHist - 1 ? A.curFrame - lo : A.nHist - 1;
+        for (int j = j0 + 1 + r; j <= jEnd; j += 64) {
             const double* Cj = A.cen + 3 * ((size_t)c * A.nHist + j);
             const double b0 = Cj[0] - Mold[0], b1 = Cj[1] - Mold[1], b2 = Cj[2] - Mold[2];
             const double d = (a0 * b0 + a1 * b1) + a2 * b2;
@@ -860,157 +901,170 @@ __device__ __noinline__ bool cls_is_static(const ClsArgs& A, int m, const double
             const double cv = d / sqrt(na * nb);
             if (cv < bestCos) bestCos = cv, best = j;
         }
-        if (best >= 0) v[nv].c = c, v[nv].j = best, ++nv;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double oc = __shfl_xor(bestCos, off, 64);
+            const int oj = __shfl_xor(best, off, 64);
+            if (oj >= 0 && (oc < bestCos || (oc == bestCos && (best < 0 || oj < best)))) bestCos = oc, best = oj;
+        }
+        if (best >= 0) {
+            if (r == V.nv) V.c = c, V.j = best, V.s = s;
+            ++V.nv;
+        }
     }
-    return cls_triangulate(A, slotOf, v, nv, M, cov, 1);
+    return cls_solve(A, V, r, M, cov, true);
 }
 // isDynamicPoint (:251-312)
-__device__ __noinline__ bool cls_is_dynamic(const ClsArgs& A, int m, double* M, double* cov) {
-    ClsView v[PU_MAX_CAMS];
-    int slotOf[PU_MAX_CAMS], nv = 0;
+__device__ __noinline__ bool cls_is_dynamic(const ClsArgs& A, const ClsFeat& F, int r, double* M, double* cov) {
+    ClsViews V;
+    V.nv = 0, V.c = 0, V.j = 0, V.s = 0;
     for (int c = 0; c < A.nCams; ++c) {
-        int s, j0, f, ff;
-        if (!cls_feature(A, m, c, s, j0, f, ff) || f != A.curFrame) continue;
-        slotOf[c] = s;
-        v[nv].c = c, v[nv].j = 0, ++nv;
+        const int s = __shfl(F.s, c, 64), f = __shfl(F.f, c, 64);
+        if (s < 0 || f != A.curFrame) continue;
+        if (r == V.nv) V.c = c, V.s = s;
+        ++V.nv;
     }
-    if (nv < 2) return false;
-    const double* org = A.cen + 3 * ((size_t)v[0].c * A.nHist);
-    cls_triangulate(A, slotOf, v, nv, M, cov, 2);
-    {
-        const double* R = cls_R(A, v[0].c, 0);
-        const double* t = cls_t(A, v[0].c, 0);
-        if (((R[6] * M[0] + R[7] * M[1]) + R[8] * M[2]) + t[2] < 0) return false;  // isAtCameraBack
-    }
-    double S[6] = {0, 0, 0, 0, 0, 0}, cf[6];
-    for (int i = 0; i < nv; ++i) {
-        const PuProj q = pu_project(A.cam[v[i].c].K, cls_R(A, v[i].c, 0), cls_t(A, v[i].c, 0), M);
-        up_add_jtj(S, q.J);
-    }
-    const double dS = up_sym33_cof(S, cf), s2 = A.sigma * A.sigma;
-    cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
-    cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
-    cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
+    if (V.nv < 2) return false;
+    const double* org = A.cen + 3 * ((size_t)__shfl(V.c, 0, 64) * A.nHist);
+    bool atBack;
+    cls_solve(A, V, r, M, cov, false, &atBack);
+    if (atBack) return false;
     const double sc = (fabs(cov[0]) + fabs(cov[4])) + fabs(cov[8]);
     const double dx = M[0] - org[0], dy = M[1] - org[1], dz = M[2] - org[2];
     if (sqrt((dx * dx + dy * dy) + dz * dz) * 0.2 < sqrt(sc)) return false;  // :290-293
-    for (int i = 0; i < nv; ++i)
-        if (cls_err(A, v[i].c, 0, slotOf[v[i].c], M, cov) > 1.0) return false;
-    return true;
+    bool fail = false;
+    if (r < V.nv) {
+        double mx, my;
+        cls_pixel(A, V.c, 0, V.s, mx, my);
+        fail = cls_maha(pu_project(A.cam[V.c].K, cls_R(A, V.c, 0), cls_t(A, V.c, 0), M), cov, A.sigma * A.sigma, mx, my) > 1.0;
+    }
+    return __builtin_amdgcn_ballot_w64(fail) == 0;
+}
+// lane c: the Mahalanobis distance of camera c's feature from the projection of (M, cov) under its own frame's pose (-1: no feature)
+__device__ __forceinline__ double cls_err_of_lane(const ClsArgs& A, const ClsFeat& F, int r, const double* M, const double* cov) {
+    if (F.s < 0) return -1.0;
+    double mx, my;
+    cls_pixel(A, r, F.j0, F.s, mx, my);
+    return cls_maha(pu_project(A.cam[r].K, cls_R(A, r, F.j0), cls_t(A, r, F.j0), M), cov, A.sigma * A.sigma, mx, my);
 }
 
-__global__ __launch_bounds__(256) void k_map_points_classify(ClsArgs A) {
-    constexpr int FRAME_NUM_FOR_NEWPOINT = 30, FRAME_NUM_FOR_DONTMOVE = 50, NUM_FRAME_CHECK_STATIC = 60;
-    // the camera centres of the ring in LDS: an examined point's walks (up to 60 frames back per camera, isStaticPoint's widest-parallax
-    // search) are chains of loads a single lane waits for one after the other -- from HBM / L2 they were most of the kernel's time
-    extern __shared__ double cls_cen[];   // [nCams][nHist][3]
-    if (A.stageCen) {   // (uniform; a history too deep for LDS is walked where it lies)
-        for (int q = threadIdx.x; q < A.nCams * A.nHist * 3; q += 256) cls_cen[q] = A.cen[q];
-        __syncthreads();
-        A.cen = cls_cen;
-    }
+__global__ __launch_bounds__(256) void k_classify_select(ClsArgs A) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= A.nMap) return;
-    // the current list after mapStateUpdate (:1183-1197): points with a feature in this frame; numVisCam counts those features
-    int numVisCam = 0;
-    for (int c = 0; c < A.nCams; ++c) {
-        int s, j0, f, ff;
-        if (cls_feature(A, m, c, s, j0, f, ff) && f == A.curFrame) ++numVisCam;
+    const unsigned char fl = A.mapFlags[m];
+    if (!((fl & CS_MAP_UNCERTAIN) || (fl & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) == CS_MAP_DYNAMIC)) return;  // :431
+    // the current list after mapStateUpdate (:1183-1197): points with a feature in this frame
+    bool vis = false;
+    for (int c = 0; c < A.nCams && !vis; ++c) {
+        const int s = A.pointFeat[(size_t)m * A.nCams + c];
+        vis = s >= 0 && (A.featFrame ? A.featFrame[(size_t)m * A.nCams + c] : A.curFrame) == A.curFrame;
     }
-    if (numVisCam == 0) return;
-    const unsigned char fl0 = A.mapFlags[m];
-    unsigned char fl = fl0;
-    const bool uncertain = (fl & CS_MAP_UNCERTAIN) != 0, locDyn = (fl & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) == CS_MAP_DYNAMIC;
-    if (!(uncertain || locDyn)) return;  // :431
-    if (A.counts) atomicAdd(A.counts, 1);
-    double* pM = A.mapPts + 3 * (size_t)m;
-    double* pCov = A.mapCov + 9 * (size_t)m;
-    double Mold[3];
+    if (!vis) return;
+    A.list[1 + atomicAdd(A.list, 1)] = m;
+}
+
+constexpr int CLS_WAVES = 1024;   // the worker grid: 256 workgroups of 4 waves, a wave per listed point (and round again past that)
+__global__ __launch_bounds__(256) void k_map_points_classify(ClsArgs A) {
+    constexpr int FRAME_NUM_FOR_NEWPOINT = 30, FRAME_NUM_FOR_DONTMOVE = 50, NUM_FRAME_CHECK_STATIC = 60;
+    const int r = threadIdx.x % 64;
+    const int n = A.list[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.counts) A.counts[0] = n;
+    for (int e = blockIdx.x * 4 + threadIdx.x / 64; e < n; e += CLS_WAVES) {
+        const int m = A.list[1 + e];
+        const ClsFeat F = cls_feature(A, m, r);
+        const int numVisCam = __popcll(__builtin_amdgcn_ballot_w64(F.s >= 0 && F.f == A.curFrame));
+        const unsigned char fl0 = A.mapFlags[m];
+        unsigned char fl = fl0;
+        const bool uncertain = (fl & CS_MAP_UNCERTAIN) != 0;
+        double* pM = A.mapPts + 3 * (size_t)m;
+        double* pCov = A.mapCov + 9 * (size_t)m;
+        double Mold[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) Mold[q] = pM[q];
-    double M[3], cov[9];
-    bool write = false;   // updatePosition(M, cov)
-    int sfn = A.staticFrameNum[m];
-    if (numVisCam == 1) {  // :433-437
-        fl = (unsigned char)((fl & ~CS_MAP_DYNAMIC) | CS_MAP_FALSE);
-    } else if (uncertain) {
-        if (A.newPt[m]) {
-            if (cls_is_static(A, m, Mold, M, cov, -1, NUM_FRAME_CHECK_STATIC)) {
-                if (A.curFrame - A.firstFrame[m] > FRAME_NUM_FOR_NEWPOINT) {
-                    fl = 0, sfn = 0;
-                    A.newPt[m] = 0;
+        for (int q = 0; q < 3; ++q) Mold[q] = pM[q];
+        double M[3], cov[9];
+        bool write = false;   // updatePosition(M, cov)
+        bool clearNew = false;
+        int sfn = A.staticFrameNum[m];
+        if (numVisCam == 1) {  // :433-437
+            fl = (unsigned char)((fl & ~CS_MAP_DYNAMIC) | CS_MAP_FALSE);
+        } else if (uncertain) {
+            if (A.newPt[m]) {
+                if (cls_is_static(A, F, r, Mold, M, cov, -1, NUM_FRAME_CHECK_STATIC)) {
+                    if (A.curFrame - A.firstFrame[m] > FRAME_NUM_FOR_NEWPOINT) {
+                        fl = 0, sfn = 0;
+                        clearNew = true;
+                        write = true;
+                    }
+                } else if (cls_is_dynamic(A, F, r, M, cov)) {
+                    fl = CS_MAP_DYNAMIC, sfn = 0;
                     write = true;
-                }
-            } else if (cls_is_dynamic(A, m, M, cov)) {
-                fl = CS_MAP_DYNAMIC, sfn = 0;
-                write = true;
-                A.newPt[m] = 0;
-            } else
-                fl = (unsigned char)((fl & ~CS_MAP_DYNAMIC) | CS_MAP_FALSE);
-        } else {
-            if (cls_is_dynamic(A, m, M, cov)) {
-                fl = CS_MAP_DYNAMIC, sfn = 0;
-                write = true;
-            } else {
-                // isStaticRemovable (:67-115): the view with the largest error (> 1) under the point as it stands; static without it?
-                double covOld[9];
-#pragma unroll
-                for (int q = 0; q < 9; ++q) covOld[q] = pCov[q];
-                int maxI = -1, nVis = 0;
-                double maxErr = 1.0;
-                for (int c = 0; c < A.nCams; ++c) {
-                    int s, j0, f, ff;
-                    if (!cls_feature(A, m, c, s, j0, f, ff)) continue;
-                    const double err = cls_err(A, c, j0, s, Mold, covOld);
-                    if (err > maxErr) maxErr = err, maxI = c;
-                    ++nVis;
-                }
-                if (maxI >= 0 && nVis > 2 && cls_is_static(A, m, Mold, M, cov, maxI, NUM_FRAME_CHECK_STATIC)) {  // :476-482
-                    const int s = A.pointFeat[(size_t)m * A.nCams + maxI];
-                    if (A.cam[maxI].slot2map) const_cast<int*>(A.cam[maxI].slot2map)[s] = -1;
-                    A.pointFeat[(size_t)m * A.nCams + maxI] = -1;
-                    fl = 0, sfn = 0;
-                    write = true;
+                    clearNew = true;
                 } else
                     fl = (unsigned char)((fl & ~CS_MAP_DYNAMIC) | CS_MAP_FALSE);
-            }
-        }
-    } else {  // locally dynamic (:489-516)
-        if (cls_is_dynamic(A, m, M, cov)) {
-            bool little = true;
-            for (int c = 0; c < A.nCams && little; ++c) {  // isLittleMove: >= 1 fails
-                int s, j0, f, ff;
-                if (!cls_feature(A, m, c, s, j0, f, ff)) continue;
-                if (cls_err(A, c, j0, s, M, cov) >= 1) little = false;
-            }
-            if (little) {
-                ++sfn;
-                if (sfn > FRAME_NUM_FOR_DONTMOVE) {
-                    double M0[3], cov0[9];
-                    if (cls_is_static(A, m, Mold, M0, cov0, -1, NUM_FRAME_CHECK_STATIC)) {
-                        fl = 0, sfn = 0;
-                        for (int c = 0; c < A.nCams; ++c) {
-                            int s, j0, f, ff;
-                            if (cls_feature(A, m, c, s, j0, f, ff) && f == A.curFrame) A.cam[c].isStatic[s] = 1;
+            } else {
+                if (cls_is_dynamic(A, F, r, M, cov)) {
+                    fl = CS_MAP_DYNAMIC, sfn = 0;
+                    write = true;
+                } else {
+                    // isStaticRemovable (:67-115): the view with the largest error (> 1) under the point as it stands; static without it?
+                    double covOld[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) covOld[q] = pCov[q];
+                    double err = cls_err_of_lane(A, F, r, Mold, covOld);
+                    if (!(err == err)) err = -1.0;   // (`err > maxErr` is false for a NaN: never the worst view)
+                    const int nVis = __popcll(__builtin_amdgcn_ballot_w64(F.s >= 0));
+                    int maxI = r;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {   // the first camera with the largest error
+                        const double oe = __shfl_xor(err, off, 64);
+                        const int oi = __shfl_xor(maxI, off, 64);
+                        if (oe > err || (oe == err && oi < maxI)) err = oe, maxI = oi;
+                    }
+                    if (!(err > 1.0)) maxI = -1;
+                    if (maxI >= 0 && nVis > 2 && cls_is_static(A, F, r, Mold, M, cov, maxI, NUM_FRAME_CHECK_STATIC)) {  // :476-482
+                        if (r == maxI) {
+                            if (A.cam[maxI].slot2map) const_cast<int*>(A.cam[maxI].slot2map)[F.s] = -1;
+                            A.pointFeat[(size_t)m * A.nCams + maxI] = -1;
                         }
+                        fl = 0, sfn = 0;
+                        write = true;
                     } else
-                        sfn = 0;
+                        fl = (unsigned char)((fl & ~CS_MAP_DYNAMIC) | CS_MAP_FALSE);
                 }
+            }
+        } else {  // locally dynamic (:489-516)
+            if (cls_is_dynamic(A, F, r, M, cov)) {
+                const double err = cls_err_of_lane(A, F, r, M, cov);
+                const bool little = __builtin_amdgcn_ballot_w64(err >= 1) == 0;  // isLittleMove: >= 1 fails
+                if (little) {
+                    ++sfn;
+                    if (sfn > FRAME_NUM_FOR_DONTMOVE) {
+                        double M0[3], cov0[9];
+                        if (cls_is_static(A, F, r, Mold, M0, cov0, -1, NUM_FRAME_CHECK_STATIC)) {
+                            fl = 0, sfn = 0;
+                            if (F.s >= 0 && F.f == A.curFrame) A.cam[r].isStatic[F.s] = 1;
+                        } else
+                            sfn = 0;
+                    }
+                } else
+                    sfn = 0;
+                write = true;  // :512: the dynamic triangulation is what stays, also for a point that went back to static
             } else
-                sfn = 0;
-            write = true;  // :512: the dynamic triangulation is what stays, also for a point that went back to static
-        } else
-            fl = (unsigned char)((fl & ~CS_MAP_DYNAMIC) | CS_MAP_FALSE);
-    }
-    if (write) {
+                fl = (unsigned char)((fl & ~CS_MAP_DYNAMIC) | CS_MAP_FALSE);
+        }
+        if (r == 0) {
+            if (write) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) pM[q] = M[q];
+                for (int q = 0; q < 3; ++q) pM[q] = M[q];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) pCov[q] = cov[q];
+                for (int q = 0; q < 9; ++q) pCov[q] = cov[q];
+            }
+            if (clearNew) A.newPt[m] = 0;
+            A.staticFrameNum[m] = sfn;
+            A.mapFlags[m] = fl;
+            if (A.counts && (fl & CS_MAP_FALSE) && !(fl0 & CS_MAP_FALSE)) atomicAdd(A.counts + 1, 1);
+        }
     }
-    A.staticFrameNum[m] = sfn;
-    A.mapFlags[m] = fl;
-    if (A.counts && (fl & CS_MAP_FALSE) && !(fl0 & CS_MAP_FALSE)) atomicAdd(A.counts + 1, 1);
 }
 
 // poses of (camera, frame) pairs into the ring: what RobustBundleRTS::output() writes through the CamPoseItem pointers the features
@@ -1052,7 +1106,11 @@ struct cs_track_history {
     int device, nCams, N, H;
     int head, count, lastFrame;
     double *xy, *R, *t;
-    double* cen;  // [nCams][H][3] scratch of cs_update_new_poses_points_dev: the camera centres by walk depth
+    // scratch of the map-point kernels (one stream at a time may run them on a handle): the camera centres by walk depth
+    // [nCams][H][3], and the worklist of cs_map_points_classify_dev [1 + clsCap] (grown when a larger map is passed)
+    double* cen;
+    mutable int* clsList;
+    mutable int clsCap;
 };
 
 extern "C" cs_track_history* cs_track_history_create(int device, int nCams, int N, int histLen) {
@@ -1067,6 +1125,7 @@ extern "C" cs_track_history* cs_track_history_create(int device, int nCams, int 
     cs_track_history* h = new cs_track_history();
     h->device = device, h->nCams = nCams, h->N = N, h->H = histLen;
     h->head = -1, h->count = 0, h->lastFrame = -0x7fffffff;
+    h->clsList = nullptr, h->clsCap = 0;
     const size_t nXY = (size_t)nCams * histLen * 2 * N, nR = (size_t)nCams * histLen * 9, nT = (size_t)nCams * histLen * 3;
     if (hipMalloc((void**)&h->xy, sizeof(double) * nXY) != hipSuccess || hipMalloc((void**)&h->R, sizeof(double) * nR) != hipSuccess ||
         hipMalloc((void**)&h->t, sizeof(double) * nT) != hipSuccess || hipMalloc((void**)&h->cen, sizeof(double) * nT) != hipSuccess) {
@@ -1085,6 +1144,7 @@ extern "C" void cs_track_history_destroy(cs_track_history* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipFree(h->xy), (void)hipFree(h->R), (void)hipFree(h->t), (void)hipFree(h->cen);
+    if (h->clsList) (void)hipFree(h->clsList);
     delete h;
 }
 
@@ -1437,11 +1497,18 @@ extern "C" int cs_map_points_classify_dev(const cs_track_history* h, void* hip_s
     hipStream_t s = (hipStream_t)hip_stream;
     if (d_counts) CS_HIP(hipMemsetAsync(d_counts, 0, 2 * sizeof(int), s));
     if (nMap == 0) return CS_OK;
+    if (nMap > h->clsCap) {   // (a larger map than any before: the only allocation, and it waits for the device)
+        if (h->clsList) CS_HIP(hipFree(h->clsList));
+        h->clsList = nullptr, h->clsCap = 0;
+        CS_HIP(hipMalloc((void**)&h->clsList, sizeof(int) * (1 + (size_t)nMap)));
+        h->clsCap = nMap;
+    }
+    A.list = h->clsList;
+    CS_HIP(hipMemsetAsync(A.list, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_ring_centres, dim3((h->nCams * h->count + 255) / 256), dim3(256), 0, s, h->nCams, h->H, h->head, h->count, h->R, h->t,
                        h->cen);
-    const size_t cenBytes = sizeof(double) * 3 * (size_t)h->nCams * h->count;
-    A.stageCen = cenBytes <= 48 * 1024 ? 1 : 0;
-    hipLaunchKernelGGL(k_map_points_classify, dim3((nMap + 255) / 256), dim3(256), A.stageCen ? cenBytes : 0, s, A);
+    hipLaunchKernelGGL(k_classify_select, dim3((nMap + 255) / 256), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_map_points_classify, dim3(CLS_WAVES / 4), dim3(256), 0, s, A);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

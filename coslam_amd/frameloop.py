@@ -36,10 +36,12 @@ class LoopConfig:
         self.n_cams, self.W, self.H, self.levels, self.fw, self.fh = 8, 640, 480, 4, 50, 40
         self.pts_stride, self.n_col_blk, self.n_row_blk = 192, 16, 12    # reference src/app/SL_SingleSLAM.h:36-37
         self.key_every, self.n_key_frames = 5, 5                         # requestForBA(5, 2, 2, 30), SL_CoSLAM.cpp:1345
+        self.ic_workers = 1        # workspaces (worker threads) the inter-camera solves of this rank rotate over (2 on one GPU: measured slower)
         self.ba_lag = 0            # key-frame intervals between a window's key frame and the frame its result is applied; 0 = min(N, 4)
         self.p_reg = 1536
         self.hist = 64
         self.ncc_every, self.ncc_pair_cap = 4, 1 << 16
+        self.map_spare = 8192      # room for new map points behind the initial map
         self.klt_cams_per_launch = 0
         self.klt_fused = True      # False: one launch per Gauss-Newton pass (bit-identical): for SEVERAL processes sharing one GPU, where the
                                    # persistent tracker's co-residency budget does not hold
@@ -90,7 +92,10 @@ class FrameLoop:
         self.T = int(next(iter(video.values())).shape[0])
         self.video = video
         self.associate = associate
-        n_map = self.n_map = len(scene.points)
+        # the map: structure-of-arrays with spare capacity (new map points are appended: cs_newpts_from_pairs_dev); unused entries carry
+        # no feature anywhere, which makes them inert for every kernel
+        n_pts = len(scene.points)
+        n_map = self.n_map = n_pts + cfg.map_spare
         f64, i32, u8 = torch.float64, torch.int32, torch.uint8
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
         K = np.ascontiguousarray(scene.K, dtype=np.float64)
@@ -99,8 +104,12 @@ class FrameLoop:
         self.d_iK1 = torch.from_numpy(np.linalg.inv(K).ravel().copy()).to(dev)
         self.d_kud = z(7, f64)
         # ---- the ONE map (a replica per rank) and every camera's records
-        self.d_map = torch.from_numpy(np.ascontiguousarray(scene.points, dtype=np.float64).copy()).to(dev)
-        self.d_cov = torch.from_numpy(np.ascontiguousarray(map_cov, dtype=np.float64).reshape(-1).copy()).to(dev)
+        self.d_map = z((n_map, 3), f64)
+        self.d_map[:n_pts] = torch.from_numpy(np.ascontiguousarray(scene.points, dtype=np.float64).copy()).to(dev)
+        self.d_cov = z(n_map * 9, f64)
+        self.d_cov[:n_pts * 9] = torch.from_numpy(np.ascontiguousarray(map_cov, dtype=np.float64).reshape(-1)[:n_pts * 9].copy()).to(dev)
+        self.d_mapcount = torch.tensor([n_pts], dtype=i32, device=dev)
+        self.n_pts0 = n_pts
         self.d_mapflags = z(n_map, u8)
         self.d_newpt, self.d_sfn, self.d_firstfrm = z(n_map, u8), z(n_map, i32), z(n_map, i32)
         self.d_slot2map = torch.full((NA, N), -1, dtype=i32, device=dev)
@@ -183,7 +192,14 @@ class FrameLoop:
                                            for k, (off, pf, sS) in enumerate(((cfg.p_reg, self.d_pf_none, 2.5 * PIXEL_ERR_VAR),
                                                                               (0, self.d_pf, PIXEL_ERR_VAR)))])
         # ---- key-frame solves
-        self.ba_ws, self.ic_ws = BAWorkspace(device), BAWorkspace(device)
+        # the inter-camera solves of consecutive key frames are independent of each other (each starts from its own frame's poses):
+        # key frame k of this rank goes to workspace k mod ic_workers, each with its own worker thread, stream and staging
+        self.n_ic_workers = max(cfg.ic_workers, 1)
+        if ic is not None:
+            self.n_ic_workers = 1
+        self.ba_ws = BAWorkspace(device)
+        self.ic_wss = [BAWorkspace(device) for _ in range(self.n_ic_workers)]
+        self.ic_ws = self.ic_wss[0]
         self.win = self.out = None
         if cfg.with_joint and self.pose_upd is not None:
             self.win = BAWindow(NA, cfg.n_key_frames, N, n_map, device=device)
@@ -196,7 +212,8 @@ class FrameLoop:
             from coslam_amd.ba import BAInterCam, intercam_cams
 
             # InterCamPoseEstimator::addMapPoints from the live records of ALL cameras (reference src/app/SL_InterCamPoseEstimator.cpp:18-91)
-            self.icam = BAInterCam(NA, N, cfg.pts_stride, n_map, max_dyn=60, device=device)
+            self.icams = [BAInterCam(NA, N, cfg.pts_stride, n_map, max_dyn=60, device=device) for _ in range(self.n_ic_workers)]
+            self.icam = self.icams[0]
             self.ic_cams = intercam_cams([dict(K=self.d_K1.data_ptr(), xy=self.d_xy[g].data_ptr(), state=self.d_state[g].data_ptr(),
                                                slot2map=self.d_slot2map[g].data_ptr(), trackSpan=self.d_trackspan[g].data_ptr(),
                                                isStatic=self.d_isstatic[g].data_ptr()) for g in range(NA)])
@@ -239,11 +256,17 @@ class FrameLoop:
         return i % self.T
 
     def _init_ncc(self):
+        """genNewMapPoints -> NewMapPtsNCC (reference src/app/SL_CoSLAM.cpp:1366-1371, src/app/SL_NewMapPointsInterCam.cpp): every
+        ncc_every-th frame.  A rank cuts the NCC blocks of its OWN cameras (it holds their images); N > 1: the blocks travel (one
+        all-gather of 330 KB per camera); every rank then scores all consecutive camera pairs and turns the matches into new map points
+        on its replica -- the same bytes in, the same points out."""
         torch, cfg = self.torch, self.cfg
         self.ncc = None
-        if not cfg.with_ncc or self.nc < 2:
+        NA, N = cfg.n_cams, cfg.n_feat
+        if not cfg.with_ncc or NA < 2 or self.pose_upd is None:
             return
         from coslam_amd.ncc import NCC_PAIR_DTYPE, ncc_scaled_dims
+        from coslam_amd.newpts import NewPtsJob, newpts_scratch_bytes
 
         ws_, hs_ = ncc_scaled_dims(cfg.W, cfg.H, 0.3)
         Kinv = np.linalg.inv(self.sc.K)
@@ -255,36 +278,79 @@ class FrameLoop:
             E = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
             return Kinv.T @ E @ Kinv
 
-        nc, N, dev = self.nc, cfg.n_feat, self.dev
+        dev = self.dev
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
-        self.ncc = dict(small=z((nc, ws_ * hs_), torch.uint8), blk=z((nc, N, 128), torch.uint8), abc=z((nc, N, 4), torch.float64),
-                        valid=z((nc, N), torch.int32), runs=0,
-                        F={(c, f): f_matrix(c, c + 1, f) for c in self.my_cams[:-1] for f in range(0, self.T)},
-                        pairs=z((nc - 1, cfg.ncc_pair_cap * NCC_PAIR_DTYPE.itemsize), torch.uint8), pair_count=z(nc - 1, torch.int32),
-                        group={})
+        rec = N * 128 + N * 32 + N * 4          # one camera's record: blocks | abc | valid
+        self.ncc = dict(small=z((self.nc, ws_ * hs_), torch.uint8), rec=z((NA, rec), torch.uint8), rec_bytes=rec, runs=0,
+                        send=z((self.nc, rec), torch.uint8) if self.world > 1 else None,
+                        F={(c, f): f_matrix(c, c + 1, f) for c in range(NA - 1) for f in range(self.T)},
+                        pairs=z((NA - 1, cfg.ncc_pair_cap * NCC_PAIR_DTYPE.itemsize), torch.uint8), pair_count=z(NA - 1, torch.int32),
+                        group={}, np_scr=z(newpts_scratch_bytes(NA, N), torch.uint8), np_cnt=z(4 + NA, torch.int32), new_total=0)
+        r = self.ncc["rec"]
+        self.ncc["blk"] = [r[g, :N * 128] for g in range(NA)]
+        self.ncc["abc"] = [r[g, N * 128: N * 160] for g in range(NA)]
+        self.ncc["valid"] = [r[g, N * 160:] for g in range(NA)]
+        cams = [dict(K=self.d_K1.data_ptr(), iK=self.d_iK1.data_ptr(), xy=self.d_xy[g].data_ptr(), state=self.d_state[g].data_ptr(),
+                     slot2map=self.d_slot2map[g].data_ptr(), isStatic=self.d_isstatic[g].data_ptr(), reprojErr=self.d_reproj[g].data_ptr())
+                for g in range(NA)]
+        self.ncc["job"] = NewPtsJob(cams, [self.ncc["pairs"][a].data_ptr() for a in range(NA - 1)],
+                                    [self.ncc["pair_count"][a:a + 1].data_ptr() for a in range(NA - 1)])
 
-    def _ncc_leg(self, f):
+    def _ncc_leg(self, i, f, dst):
         import coslam_amd
         from coslam_amd._lib import check
         from coslam_amd.ncc import ncc_cams, ncc_epi_pairs_group_dev, ncc_get_blocks_group_dev, ncc_pair_jobs
+        from coslam_amd.newpts import ncc_candidate_mask_dev, newpts_from_pairs_dev
 
-        cfg, nc, c0, N, ncc = self.cfg, self.nc, self.c0, self.cfg.n_feat, self.ncc
+        cfg, nc, c0, N, NA, ncc = self.cfg, self.nc, self.c0, self.cfg.n_feat, self.cfg.n_cams, self.ncc
         s_ = self.pose_s.cuda_stream
-        # unmapped features of this frame: state 0 / 1 and no map point (the own cameras' hand-back records, back to back)
-        check(coslam_amd.lib().cs_ncc_unmapped_mask_dev(self.device, C.c_void_p(s_), nc * N, C.c_void_p(self.d_state[c0].data_ptr()),
-                                                        C.c_void_p(self.d_slot2map[c0].data_ptr()), C.c_void_p(ncc["valid"].data_ptr())),
-              "cs_ncc_unmapped_mask_dev")
+        # NewMapPtsNCC::addSlam's features: this frame's, on tracks of more than three frames, unmapped or on a false point -- of the
+        # own cameras, straight into their records' `valid` part
+        for k in range(nc):
+            g = c0 + k
+            ncc_candidate_mask_dev(s_, 1, N, self.d_state[g].data_ptr(), self.d_slot2map[g].data_ptr(), self.d_trackspan[g].data_ptr(),
+                                   self.d_mapflags.data_ptr(), self.n_map, ncc["valid"][g].data_ptr(), device=self.device)
         if f not in ncc["group"]:
-            cams_ = ncc_cams([dict(img=self.img_ptrs[f][i], x=self.d_xy[c0 + i].data_ptr(), y=self.d_xy[c0 + i].data_ptr() + 8 * N,
-                                   scaled=ncc["small"][i].data_ptr(), blocks=ncc["blk"][i].data_ptr(), abc=ncc["abc"][i].data_ptr(),
-                                   valid=ncc["valid"][i].data_ptr()) for i in range(nc)])
-            jobs_ = ncc_pair_jobs([dict(F=ncc["F"][(c0 + i, f)], camA=i, camB=i + 1, pairs=ncc["pairs"][i].data_ptr(),
-                                        count=ncc["pair_count"][i:i + 1].data_ptr()) for i in range(nc - 1)])
-            ncc["group"][f] = (cams_, jobs_)
-        cams_, jobs_ = ncc["group"][f]
-        ncc_get_blocks_group_dev(s_, cams_, cfg.W, cfg.H, N, 0.3, device=self.device)
-        ncc_epi_pairs_group_dev(s_, cams_, N, jobs_, 50.0, 0.80, cfg.ncc_pair_cap, device=self.device)   # SL_NewMapPointsInterCam.h:71-72
+            own = ncc_cams([dict(img=self.img_ptrs[f][k], x=self.d_xy[c0 + k].data_ptr(), y=self.d_xy[c0 + k].data_ptr() + 8 * N,
+                                 scaled=ncc["small"][k].data_ptr(), blocks=ncc["blk"][c0 + k].data_ptr(), abc=ncc["abc"][c0 + k].data_ptr(),
+                                 valid=ncc["valid"][c0 + k].data_ptr()) for k in range(nc)])
+            allc = ncc_cams([dict(img=0, x=self.d_xy[g].data_ptr(), y=self.d_xy[g].data_ptr() + 8 * N, scaled=0, blocks=ncc["blk"][g].data_ptr(),
+                                  abc=ncc["abc"][g].data_ptr(), valid=ncc["valid"][g].data_ptr()) for g in range(NA)])
+            jobs_ = ncc_pair_jobs([dict(F=ncc["F"][(a, f)], camA=a, camB=a + 1, pairs=ncc["pairs"][a].data_ptr(),
+                                        count=ncc["pair_count"][a:a + 1].data_ptr()) for a in range(NA - 1)])
+            ncc["group"][f] = (own, allc, jobs_)
+        own, allc, jobs_ = ncc["group"][f]
+        ncc_get_blocks_group_dev(s_, own, cfg.W, cfg.H, N, 0.3, device=self.device)
+        if self.world > 1:
+            self._gather_ncc_records()
+        ncc_epi_pairs_group_dev(s_, allc, N, jobs_, 50.0, 0.80, cfg.ncc_pair_cap, device=self.device)   # SL_NewMapPointsInterCam.h:71-72
+        # matches -> tracks -> new map points (NewMapPtsNCC::run's tail + output), appended behind d_mapcount
+        newpts_from_pairs_dev(s_, ncc["job"], N, cfg.ncc_pair_cap, self.d_R[dst].data_ptr(), self.d_t[dst].data_ptr(), self.d_map.data_ptr(),
+                              self.d_cov.data_ptr(), self.d_mapflags.data_ptr(), self.d_newpt.data_ptr(), self.d_firstfrm.data_ptr(),
+                              self.d_pf.data_ptr(), self.n_map, self.d_mapcount.data_ptr(), i, ncc["np_scr"].data_ptr(), ncc["np_cnt"].data_ptr(),
+                              maxDisp=80.0, maxRpErr=3.0, pixelErrVar=PIXEL_ERR_VAR, minLen=2, device=self.device)
         ncc["runs"] += 1
+
+    def _gather_ncc_records(self):
+        """the own cameras' NCC records (blocks | abc | candidate mask) to every rank: ONE all-gather, 330 KB per camera, every 4th frame"""
+        import ctypes as C_
+
+        import coslam_amd
+        from coslam_amd._lib import check
+
+        torch, ncc, nc, c0 = self.torch, self.ncc, self.nc, self.c0
+        L, vp, ps = coslam_amd.lib(), C_.c_void_p, self.pose_s.cuda_stream
+        with torch.cuda.stream(self.pose_s):
+            ncc["send"].copy_(ncc["rec"][c0:c0 + nc], non_blocking=True)
+        if self.native is not None:
+            L.cs_comm_allgather_dev.argtypes = [vp, vp, vp, vp, C_.c_size_t]
+            check(L.cs_comm_allgather_dev(self.native.exchange_comm, vp(ps), vp(ncc["send"].data_ptr()), vp(ncc["rec"].data_ptr()),
+                                          ncc["send"].numel()), "cs_comm_allgather_dev")
+        else:
+            import torch.distributed as dist
+
+            with torch.cuda.stream(self.pose_s):
+                dist.all_gather_into_tensor(ncc["rec"].view(-1), ncc["send"].view(-1))
 
     # ---------------------------------------------------------------------------------------------------------------
     def first_frame(self):
@@ -428,7 +494,7 @@ class FrameLoop:
             else:
                 self._key_frame(i, dst)
         if self.ncc is not None and i % cfg.ncc_every == 0:
-            self._ncc_leg(f)
+            self._ncc_leg(i, f, dst)
 
     def _decide(self, ps):
         """curStaticPointsRegInGroup's decision (reference src/app/SL_CoSLAM.cpp:854-898, 731-830, bMerge == false) over the search
@@ -491,7 +557,8 @@ class FrameLoop:
             # held fixed, the dynamic points free; sigma 6, 3 x 40
             with self._sec("kf_intercam"):
                 if self.icam is not None:
-                    self.icam.solve_async(self.ic_ws, ps, self.ic_cams, cfg.W, cfg.H, cfg.n_col_blk, cfg.n_row_blk, self.d_R[dst].data_ptr(),
+                    w = self.n_my_ic % self.n_ic_workers
+                    self.icams[w].solve_async(self.ic_wss[w], ps, self.ic_cams, cfg.W, cfg.H, cfg.n_col_blk, cfg.n_row_blk, self.d_R[dst].data_ptr(),
                                           self.d_t[dst].data_ptr(), self.d_map.data_ptr(), self.d_mapflags.data_ptr(), self.d_newpt.data_ptr(),
                                           self.d_pf.data_ptr(), 6.0, 3, 40)
                 else:
@@ -521,7 +588,8 @@ class FrameLoop:
 
     def drain(self):
         """the worker threads' queues are part of the work: every requested solve completes"""
-        self.ic_ws.wait()
+        for w in self.ic_wss:
+            w.wait()
         self.ba_ws.wait()
         self.torch.cuda.synchronize()
 
