@@ -27,6 +27,7 @@
 namespace {
 
 constexpr int NP_MAX_CAMS = 16, NP_MAX_CAND = 2048, NP_MAX_SEEDS = 512, NP_MAX_TRACKS = 4096, NP_MAX_N = 32768;
+constexpr int NP_BAL_WORDS = 512;   // map points per round of the seed scan / 64
 
 struct NpArgs {
     int nCams, N, mapCap, curFrame, pairCap, minLen;
@@ -39,8 +40,9 @@ struct NpArgs {
     unsigned char *mapFlags, *newPt;         // [mapCap]
     int *firstFrame, *pointFeat;             // [mapCap], [mapCap][nCams]
     int* mapCount;                           // [1] points in use: new ones are appended here
-    int* matchIdx;                           // scratch [nCams - 1][N]: feature of camera a -> its match in camera a + 1, or -1
-    int* inFlag;                             // scratch [nCams][N]: 1 = some feature of camera c - 1 is matched to this one
+    int* matchIdx;                           // scratch [nCams - 1][N]: feature of camera a -> its match in camera a + 1 (matched rows only)
+    unsigned* rowMask;                       // scratch [nCams - 1][N / 32 words]: bit i = feature i of camera a has a match in a + 1
+    unsigned* colMask;                       // scratch [nCams - 1][N / 32 words]: bit j = feature j of camera a + 1 is such a match
     int* counts;                             // [4 + nCams] out: new points, tracks, tracks >= minLen, flags (bit 0: a candidate list
                                              // overflowed, bit 1: the map is full), then the matches of every pair
 };
@@ -55,72 +57,83 @@ __global__ __launch_bounds__(256) void k_np_match(NpArgs A) {
     __shared__ unsigned sIdx[NP_MAX_CAND];
     __shared__ double sSeed[NP_MAX_SEEDS][4];   // s1.x, s1.y, d.x, d.y (the first NP_MAX_SEEDS seeds in map order)
     __shared__ unsigned sRow[NP_MAX_N / 32], sCol[NP_MAX_N / 32];
-    __shared__ int sNSeeds, sNCand, sNMatch;
-    const int a = blockIdx.x, b = a + 1, tid = threadIdx.x, N = A.N, C = A.nCams;
-    int* match = A.matchIdx + (size_t)a * N;
-    int* inB = A.inFlag + (size_t)b * N;
-    for (int i = tid; i < N; i += 256) match[i] = -1, inB[i] = 0;
-    for (int q = tid; q < (N + 31) / 32; q += 256) sRow[q] = 0, sCol[q] = 0;
-    if (tid == 0) sNSeeds = 0, sNCand = 0, sNMatch = 0;
+    __shared__ unsigned long long sBal[NP_BAL_WORDS];   // a round's map points, 64 per word: is the point a seed of this pair
+    __shared__ int sWave[4];
+    __shared__ int sNSeeds, sNCand;
+    const int a = blockIdx.x, b = a + 1, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, N = A.N, C = A.nCams;
+    const int nWords = (N + 31) / 32;
+    for (int q = tid; q < nWords; q += 256) sRow[q] = 0, sCol[q] = 0;
+    if (tid == 0) sNSeeds = 0, sNCand = 0;
     __syncthreads();
-    // getSeedsBetween (:97-127): in map order -- kept in map order here by a chunked scan
+    // getSeedsBetween (:97-127): the certain, not false points with a feature in BOTH cameras (two features: numVisCam >= 2 holds),
+    // in map order.  Each wave takes a quarter of the round's map indices, 64 at a time (coalesced, nothing to wait for between
+    // the chunks); the ballots go to LDS, the waves' totals give each its place, a second walk over the set bits writes the seeds.
     {
         const int cap = *A.mapCount < A.mapCap ? *A.mapCount : A.mapCap;
-        for (int m0 = 0; m0 < cap; m0 += 256) {
-            const int m = m0 + tid;
-            bool in = false;
-            int s1 = -1, s2 = -1;
-            if (m < cap && !(A.mapFlags[m] & (CS_MAP_FALSE | CS_MAP_UNCERTAIN))) {
-                s1 = A.pointFeat[(size_t)m * C + a], s2 = A.pointFeat[(size_t)m * C + b];
-                if (s1 >= 0 && s2 >= 0) {
-                    int nv = 0;
-                    for (int c = 0; c < C; ++c) nv += A.pointFeat[(size_t)m * C + c] >= 0;
-                    in = nv >= 2;
+        for (int r0 = 0; r0 < cap && sNSeeds < NP_MAX_SEEDS; r0 += 64 * NP_BAL_WORDS) {
+            const int nw = min(NP_BAL_WORDS, (cap - r0 + 63) / 64), perWave = (nw + 3) / 4;
+            const int w0 = wv * perWave, w1 = min(w0 + perWave, nw);
+            int cnt = 0;
+            for (int w = w0; w < w1; ++w) {
+                const int m = r0 + 64 * w + lane;
+                bool in = false;
+                if (m < cap) {
+                    const unsigned char fl = A.mapFlags[m];
+                    const int s1 = A.pointFeat[(size_t)m * C + a], s2 = A.pointFeat[(size_t)m * C + b];
+                    in = !(fl & (CS_MAP_FALSE | CS_MAP_UNCERTAIN)) && s1 >= 0 && s2 >= 0;
                 }
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
+                if (lane == 0) sBal[w] = bal;
+                cnt += __popcll(bal);
             }
-            // ordered compaction of the chunk (ballot per wave, wave totals through LDS)
-            __shared__ int wTot[4];
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
-            const int lane = tid & 63, wv = tid >> 6;
-            if (lane == 0) wTot[wv] = __popcll(bal);
+            if (lane == 0) sWave[wv] = cnt;
             __syncthreads();
-            int off = sNSeeds;
-            for (int w = 0; w < wv; ++w) off += wTot[w];
-            const int k = off + __popcll(bal & ((1ull << lane) - 1ull));
-            if (in && k < NP_MAX_SEEDS) {
-                const double x1 = A.cam[a].xy[s1], y1 = A.cam[a].xy[N + s1], x2 = A.cam[b].xy[s2], y2 = A.cam[b].xy[N + s2];
-                sSeed[k][0] = x1, sSeed[k][1] = y1, sSeed[k][2] = x2 - x1, sSeed[k][3] = y2 - y1;
+            int k = sNSeeds;
+            for (int w = 0; w < wv; ++w) k += sWave[w];
+            for (int w = w0; w < w1 && k < NP_MAX_SEEDS; ++w) {
+                const unsigned long long bal = sBal[w];
+                const int kk = k + __popcll(bal & ((1ull << lane) - 1ull));
+                if (((bal >> lane) & 1ull) && kk < NP_MAX_SEEDS) {
+                    const int m = r0 + 64 * w + lane;
+                    const int s1 = A.pointFeat[(size_t)m * C + a], s2 = A.pointFeat[(size_t)m * C + b];
+                    const double x1 = A.cam[a].xy[s1], y1 = A.cam[a].xy[N + s1], x2 = A.cam[b].xy[s2], y2 = A.cam[b].xy[N + s2];
+                    sSeed[kk][0] = x1, sSeed[kk][1] = y1, sSeed[kk][2] = x2 - x1, sSeed[kk][3] = y2 - y1;
+                }
+                k += __popcll(bal);
             }
             __syncthreads();
-            if (tid == 0) sNSeeds = min(sNSeeds + wTot[0] + wTot[1] + wTot[2] + wTot[3], NP_MAX_SEEDS);
+            if (tid == 0) sNSeeds = min(sNSeeds + sWave[0] + sWave[1] + sWave[2] + sWave[3], NP_MAX_SEEDS);
             __syncthreads();
         }
     }
     const int nSeeds = sNSeeds;
-    // the pair's candidates: the disparity guide (when there are seeds), then into the sort arrays
+    // the pair's candidates: the disparity guide (when there are seeds: a WAVE per candidate, the seeds over the lanes, the nearest
+    // -- the first of equals -- by a reduction), then into the sort arrays
     int nAll = *A.pairCount[a];
     if (nAll > A.pairCap) nAll = A.pairCap;
-    for (int q0 = 0; q0 < nAll; q0 += 256) {
-        const int q = q0 + tid;
-        bool ok = false;
-        cs_ncc_pair p;
-        if (q < nAll) {
-            p = A.pairs[a][q];
-            ok = p.i >= 0 && p.i < N && p.j >= 0 && p.j < N;
-            if (ok && nSeeds > 0) {
-                const double x1 = A.cam[a].xy[p.i], y1 = A.cam[a].xy[N + p.i];
-                double best = 1.0e300;
-                int bk = 0;
-                for (int k = 0; k < nSeeds; ++k) {
-                    const double dx = sSeed[k][0] - x1, dy = sSeed[k][1] - y1, d2 = dx * dx + dy * dy;
-                    if (d2 < best) best = d2, bk = k;
-                }
-                const double ex = (A.cam[b].xy[p.j] - x1) - sSeed[bk][2];
-                const double ey = (A.cam[b].xy[N + p.j] - y1) - sSeed[bk][3];
-                ok = sqrt(ex * ex + ey * ey) <= A.maxDisp;
+    for (int q = wv; q < nAll; q += 4) {
+        const cs_ncc_pair p = A.pairs[a][q];
+        bool ok = p.i >= 0 && p.i < N && p.j >= 0 && p.j < N;   // (uniform over the wave)
+        if (ok && nSeeds > 0) {
+            const double x1 = A.cam[a].xy[p.i], y1 = A.cam[a].xy[N + p.i];
+            double best = 1.0e300;
+            int bk = 0x7fffffff;
+            for (int k = lane; k < nSeeds; k += 64) {
+                const double dx = sSeed[k][0] - x1, dy = sSeed[k][1] - y1, d2 = dx * dx + dy * dy;
+                if (d2 < best) best = d2, bk = k;
             }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double ob = __shfl_xor(best, off, 64);
+                const int ok_ = __shfl_xor(bk, off, 64);
+                if (ob < best || (ob == best && ok_ < bk)) best = ob, bk = ok_;
+            }
+            if (bk == 0x7fffffff) bk = 0;   // (every distance NaN or >= 1e300: the scalar walk's index stays 0)
+            const double ex = (A.cam[b].xy[p.j] - x1) - sSeed[bk][2];
+            const double ey = (A.cam[b].xy[N + p.j] - y1) - sSeed[bk][3];
+            ok = sqrt(ex * ex + ey * ey) <= A.maxDisp;
         }
-        if (ok) {
+        if (ok && lane == 0) {
             const int k = atomicAdd(&sNCand, 1);
             if (k < NP_MAX_CAND) sKey[k] = p.ncc, sIdx[k] = ((unsigned)p.i << 16) | (unsigned)p.j;
         }
@@ -149,19 +162,23 @@ __global__ __launch_bounds__(256) void k_np_match(NpArgs A) {
             }
             __syncthreads();
         }
-    // the greedy walk: one lane, the list is short (a few hundred entries)
+    // the greedy walk: one lane, the list is short (a few hundred entries); the matches leave as two bit masks (rows of camera a,
+    // columns of camera a + 1) and the matched rows' partners
     if (tid == 0) {
         int n = 0;
+        int* match = A.matchIdx + (size_t)a * N;
         for (int q = 0; q < L; ++q) {
             const unsigned id = sIdx[q], i = id >> 16, j = id & 0xFFFFu;
             if ((sRow[i >> 5] >> (i & 31)) & 1u) continue;
             if ((sCol[j >> 5] >> (j & 31)) & 1u) continue;
             sRow[i >> 5] |= 1u << (i & 31), sCol[j >> 5] |= 1u << (j & 31);
-            match[i] = (int)j, inB[j] = 1;
+            match[i] = (int)j;
             ++n;
         }
         if (A.counts) A.counts[4 + a] = n;
     }
+    __syncthreads();
+    for (int q = tid; q < nWords; q += 256) A.rowMask[(size_t)a * nWords + q] = sRow[q], A.colMask[(size_t)a * nWords + q] = sCol[q];
 }
 
 struct NpView {
@@ -177,33 +194,38 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
     const int tid = threadIdx.x, N = A.N, C = A.nCams, nP = C - 1;
     if (tid == 0) sBase = 0, sNTracks = 0;
     __syncthreads();
-    // ---- the tracks' starts in the order (pair, feature): (a, i) matched and not the continuation of a track of pair a - 1
-    const int total = nP * N, per = (total + 255) / 256, lo = min(tid * per, total), hi = min(lo + per, total);
-    auto is_start = [&](int e) {
-        const int a = e / N, i = e - a * N;
-        if (A.matchIdx[(size_t)a * N + i] < 0) return false;
-        if (a == 0) return true;
-        // flag[iCam][i] >= 0 <=> some feature of camera a - 1 matched to i: then the match EXTENDS that track (:668-676)
-        return A.inFlag[(size_t)a * N + i] == 0;
-    };
-    int cnt = 0;
-    for (int e = lo; e < hi; ++e) cnt += is_start(e) ? 1 : 0;
-    sScan[tid] = cnt;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-        const int v = tid >= d ? sScan[tid - d] : 0;
+    // ---- the tracks' starts in the order (pair, feature): (a, i) matched and not the continuation of a track of pair a - 1 (some
+    // feature of camera a - 1 matched to i: then the match EXTENDS that track, :668-676) -- from the pairs' bit masks, 32 features a word
+    const int nWords = (N + 31) / 32, totalW = nP * nWords;
+    for (int w0 = 0; w0 < totalW; w0 += 256) {
+        const int w = w0 + tid;
+        unsigned bits = 0;
+        int a = 0, q = 0;
+        if (w < totalW) {
+            a = w / nWords, q = w - a * nWords;
+            bits = A.rowMask[w];
+            if (a > 0) bits &= ~A.colMask[(size_t)(a - 1) * nWords + q];
+        }
+        const int cnt = __popc(bits);
+        sScan[tid] = cnt;
         __syncthreads();
-        sScan[tid] += v;
-        __syncthreads();
-    }
-    int rank = sScan[tid] - cnt;
-    for (int e = lo; e < hi; ++e)
-        if (is_start(e)) {
-            if (rank < NP_MAX_TRACKS) sTrkCam[rank] = (unsigned short)(e / N), sTrkSlot[rank] = (unsigned short)(e % N);
+        for (int d = 1; d < 256; d <<= 1) {
+            const int v = tid >= d ? sScan[tid - d] : 0;
+            __syncthreads();
+            sScan[tid] += v;
+            __syncthreads();
+        }
+        int rank = sNTracks + sScan[tid] - cnt;
+        while (bits) {
+            const int bit = __ffs(bits) - 1;
+            bits &= bits - 1;
+            if (rank < NP_MAX_TRACKS) sTrkCam[rank] = (unsigned short)a, sTrkSlot[rank] = (unsigned short)(32 * q + bit);
             ++rank;
         }
-    if (tid == 255) sNTracks = sScan[255] < NP_MAX_TRACKS ? sScan[255] : NP_MAX_TRACKS;
-    __syncthreads();
+        __syncthreads();
+        if (tid == 255) sNTracks = min(sNTracks + sScan[255], NP_MAX_TRACKS);
+        __syncthreads();
+    }
     const int nTracks = sNTracks;
     int nLong = 0;
     // ---- reconstructTracks (:194-270), a lane per track
@@ -218,8 +240,8 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
             int c = sTrkCam[tk], s = sTrkSlot[tk];
             v[nv].c = c, v[nv].s = s, ++nv;
             while (c < nP) {   // follow the chain: camera c's slot s matched into camera c + 1
+                if (!((A.rowMask[(size_t)c * nWords + (s >> 5)] >> (s & 31)) & 1u)) break;
                 const int m = A.matchIdx[(size_t)c * N + s];
-                if (m < 0) break;
                 ++c, s = m;
                 v[nv].c = c, v[nv].s = s, ++nv;
             }
@@ -349,7 +371,7 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
 // (.., 3), src/app/SL_SingleSLAM.cpp:173-184), unmapped or mapped to a FALSE point (NewMapPtsNCC::addSlam, SL_NewMapPointsInterCam.h:120-128)
 __global__ __launch_bounds__(256) void k_np_candidates(int n, int N, const int* __restrict__ state, const int* __restrict__ slot2map,
                                                        const int* __restrict__ trackSpan, const unsigned char* __restrict__ mapFlags, int mapCap,
-                                                       int minTrack, int* __restrict__ valid) {
+                                                       int minTrack, int* __restrict__ valid, size_t validStride) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= n) return;
     const int c = q / N, s = q - c * N;
@@ -357,25 +379,26 @@ __global__ __launch_bounds__(256) void k_np_candidates(int n, int N, const int* 
     const int f1 = trackSpan[(size_t)c * 2 * N + s], f2 = trackSpan[(size_t)c * 2 * N + N + s];
     const bool tracked = (st == 0 || st == 1) && f1 >= 0 && f2 - f1 >= minTrack;
     const bool freeOrFalse = m < 0 || (m < mapCap && (mapFlags[m] & CS_MAP_FALSE));
-    valid[q] = tracked && freeOrFalse ? 1 : 0;
+    valid[(size_t)c * validStride + s] = tracked && freeOrFalse ? 1 : 0;
 }
 
 }  // namespace
 
 extern "C" size_t cs_newpts_scratch_bytes(int nCams, int N) {
     if (nCams < 2 || N < 1) return 0;
-    return sizeof(int) * (size_t)(2 * nCams - 1) * N;
+    return sizeof(int) * (size_t)(nCams - 1) * ((size_t)N + 2 * (((size_t)N + 31) / 32));
 }
 
 extern "C" int cs_ncc_candidate_mask_dev(int device, void* hip_stream, int nCams, int N, const int* d_state, const int* d_slot2map,
-                                         const int* d_trackSpan, const unsigned char* d_mapFlags, int mapCap, int minTrack, int* d_valid) {
-    if (nCams < 1 || N < 1 || !d_state || !d_slot2map || !d_trackSpan || !d_mapFlags || !d_valid) {
+                                         const int* d_trackSpan, const unsigned char* d_mapFlags, int mapCap, int minTrack, int* d_valid,
+                                         size_t validStride) {
+    if (nCams < 1 || N < 1 || !d_state || !d_slot2map || !d_trackSpan || !d_mapFlags || !d_valid || (validStride && validStride < (size_t)N)) {
         cs_set_error("cs_ncc_candidate_mask_dev: bad arguments");
         return CS_ERR_INVALID;
     }
     CS_HIP(hipSetDevice(device));
     hipLaunchKernelGGL(k_np_candidates, dim3((nCams * N + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, nCams * N, N, d_state, d_slot2map,
-                       d_trackSpan, d_mapFlags, mapCap, minTrack, d_valid);
+                       d_trackSpan, d_mapFlags, mapCap, minTrack, d_valid, validStride ? validStride : (size_t)N);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }
@@ -409,7 +432,8 @@ extern "C" int cs_newpts_from_pairs_dev(int device, void* hip_stream, int nCams,
         A.cam[c] = cams[c];
     }
     A.R = d_R, A.t = d_t, A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.mapFlags = d_mapFlags, A.newPt = d_newPt, A.firstFrame = d_firstFrame;
-    A.pointFeat = d_pointFeat, A.mapCount = d_mapCount, A.matchIdx = (int*)d_scratch, A.inFlag = (int*)d_scratch + (size_t)(nCams - 1) * N;
+    A.pointFeat = d_pointFeat, A.mapCount = d_mapCount, A.matchIdx = (int*)d_scratch;
+    A.rowMask = (unsigned*)d_scratch + (size_t)(nCams - 1) * N, A.colMask = A.rowMask + (size_t)(nCams - 1) * ((N + 31) / 32);
     A.counts = d_counts;
     CS_HIP(hipSetDevice(device));
     hipStream_t s = (hipStream_t)hip_stream;

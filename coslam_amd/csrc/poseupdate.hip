@@ -763,7 +763,8 @@ struct ClsArgs {
     const int* firstFrame;
     double sigma;
     int* counts;  // [2] points examined / points that became false, or null
-    int* list;    // [1 + nMap] worklist: count, then the points
+    int* list;    // [2 + nMap] worklist: two counters (this call's, the next call's: zeroed here for it), then the points
+    int par;      // which counter is this call's
     cs_poseupdate_cam cam[PU_MAX_CAMS];
 };
 // camera c's feature of point m as the lane c of the point's wave keeps it: slot (< 0: none, or older than the history), walk
@@ -950,6 +951,7 @@ __device__ __forceinline__ double cls_err_of_lane(const ClsArgs& A, const ClsFea
 
 __global__ __launch_bounds__(256) void k_classify_select(ClsArgs A) {
     const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m == 0 && A.counts) A.counts[1] = 0;   // (the worker kernel adds to it)
     if (m >= A.nMap) return;
     const unsigned char fl = A.mapFlags[m];
     if (!((fl & CS_MAP_UNCERTAIN) || (fl & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) == CS_MAP_DYNAMIC)) return;  // :431
@@ -960,17 +962,20 @@ __global__ __launch_bounds__(256) void k_classify_select(ClsArgs A) {
         vis = s >= 0 && (A.featFrame ? A.featFrame[(size_t)m * A.nCams + c] : A.curFrame) == A.curFrame;
     }
     if (!vis) return;
-    A.list[1 + atomicAdd(A.list, 1)] = m;
+    A.list[2 + atomicAdd(A.list + A.par, 1)] = m;
 }
 
 constexpr int CLS_WAVES = 1024;   // the worker grid: 256 workgroups of 4 waves, a wave per listed point (and round again past that)
 __global__ __launch_bounds__(256) void k_map_points_classify(ClsArgs A) {
     constexpr int FRAME_NUM_FOR_NEWPOINT = 30, FRAME_NUM_FOR_DONTMOVE = 50, NUM_FRAME_CHECK_STATIC = 60;
     const int r = threadIdx.x % 64;
-    const int n = A.list[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && A.counts) A.counts[0] = n;
+    const int n = A.list[A.par];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (A.counts) A.counts[0] = n;
+        A.list[A.par ^ 1] = 0;   // the next call's counter (nobody reads it before that call's select kernel)
+    }
     for (int e = blockIdx.x * 4 + threadIdx.x / 64; e < n; e += CLS_WAVES) {
-        const int m = A.list[1 + e];
+        const int m = A.list[2 + e];
         const ClsFeat F = cls_feature(A, m, r);
         const int numVisCam = __popcll(__builtin_amdgcn_ballot_w64(F.s >= 0 && F.f == A.curFrame));
         const unsigned char fl0 = A.mapFlags[m];
@@ -1110,8 +1115,14 @@ struct cs_track_history {
     // [nCams][H][3], and the worklist of cs_map_points_classify_dev [1 + clsCap] (grown when a larger map is passed)
     double* cen;
     mutable int* clsList;
-    mutable int clsCap;
+    mutable int clsCap, clsPar;
+    // the centres are computed once per state of the ring's poses: every call that (re)writes poses moves ringVersion on, the
+    // kernels that walk the centres launch k_ring_centres only when cenVersion is behind (calls on a handle are enqueued in order)
+    mutable long long ringVersion, cenVersion;
 };
+
+// the camera centres by walk depth, if the ring's poses changed since they were last computed
+static void hist_centres(const cs_track_history* h, hipStream_t s);
 
 extern "C" cs_track_history* cs_track_history_create(int device, int nCams, int N, int histLen) {
     if (nCams < 1 || nCams > PU_MAX_CAMS || N < 1 || histLen < 1 || histLen > PU_MAX_HIST) {
@@ -1125,7 +1136,8 @@ extern "C" cs_track_history* cs_track_history_create(int device, int nCams, int 
     cs_track_history* h = new cs_track_history();
     h->device = device, h->nCams = nCams, h->N = N, h->H = histLen;
     h->head = -1, h->count = 0, h->lastFrame = -0x7fffffff;
-    h->clsList = nullptr, h->clsCap = 0;
+    h->clsList = nullptr, h->clsCap = 0, h->clsPar = 0;
+    h->ringVersion = 1, h->cenVersion = 0;
     const size_t nXY = (size_t)nCams * histLen * 2 * N, nR = (size_t)nCams * histLen * 9, nT = (size_t)nCams * histLen * 3;
     if (hipMalloc((void**)&h->xy, sizeof(double) * nXY) != hipSuccess || hipMalloc((void**)&h->R, sizeof(double) * nR) != hipSuccess ||
         hipMalloc((void**)&h->t, sizeof(double) * nT) != hipSuccess || hipMalloc((void**)&h->cen, sizeof(double) * nT) != hipSuccess) {
@@ -1149,6 +1161,13 @@ extern "C" void cs_track_history_destroy(cs_track_history* h) {
 }
 
 extern "C" int cs_track_history_frames(const cs_track_history* h) { return h ? h->count : 0; }
+
+static void hist_centres(const cs_track_history* h, hipStream_t s) {
+    if (h->cenVersion == h->ringVersion) return;
+    hipLaunchKernelGGL(k_ring_centres, dim3((h->nCams * h->count + 255) / 256), dim3(256), 0, s, h->nCams, h->H, h->head, h->count, h->R, h->t,
+                       h->cen);
+    h->cenVersion = h->ringVersion;
+}
 
 namespace {
 
@@ -1198,6 +1217,7 @@ void pu_fill_gate(PuArgs& A, const int* d_pointFeat, int nMap, double* d_mapPts,
 
 // advance the ring to `frame` (host bookkeeping only; the launch writes the entry)
 void pu_advance(cs_track_history* h, int frame) {
+    h->ringVersion += 1;
     if (frame == h->lastFrame) return;  // the same frame again (camera-by-camera calls): the entry is rewritten
     if (frame != h->lastFrame + 1) h->count = 0;  // Track2D's length() counts frames: a gap in the numbering loses the history
     h->head = (h->head + 1) % h->H;
@@ -1328,6 +1348,7 @@ extern "C" int cs_track_history_set_poses_dev(cs_track_history* h, void* hip_str
         return CS_ERR_INVALID;
     }
     if (n == 0 || h->count < 1) return CS_OK;
+    h->ringVersion += 1;
     CS_HIP(hipSetDevice(h->device));
     hipLaunchKernelGGL(k_history_set_poses, dim3((n * 12 + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, n, d_cam, d_frame, d_R, d_t,
                        h->R, h->t, h->nCams, h->H, h->head, h->count, h->lastFrame);
@@ -1347,6 +1368,7 @@ int hist_span(const char* who, cs_track_history* h, void* hip_stream, int set, i
                      h->count, h->lastFrame);
         return CS_ERR_INVALID;
     }
+    if (set) h->ringVersion += 1;
     CS_HIP(hipSetDevice(h->device));
     hipLaunchKernelGGL(k_history_span, dim3((h->nCams * nFrames * 12 + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, set, h->nCams,
                        firstFrame, nFrames, d_R, d_t, h->R, h->t, h->H, h->head, h->lastFrame);
@@ -1386,8 +1408,7 @@ int up_launch(const char* who, const cs_track_history* h, void* hip_stream, cons
     if (d_counts) CS_HIP(hipMemsetAsync(d_counts, 0, nCounts * sizeof(int), s));
     if (A.nMap == 0) return CS_OK;
     A.cen = h->cen;
-    hipLaunchKernelGGL(k_ring_centres, dim3((h->nCams * h->count + 255) / 256), dim3(256), 0, s, h->nCams, h->H, h->head, h->count, h->R, h->t,
-                       h->cen);
+    hist_centres(h, s);
     hipLaunchKernelGGL(k_update_points, dim3((A.nMap * UP_LPP + 255) / 256), dim3(256), 0, s, A);
     CS_HIP(hipGetLastError());
     return CS_OK;
@@ -1456,8 +1477,7 @@ extern "C" int cs_check_unify_dev(const cs_track_history* h, void* hip_stream, c
     }
     CS_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)hip_stream;
-    hipLaunchKernelGGL(k_ring_centres, dim3((h->nCams * h->count + 255) / 256), dim3(256), 0, s, h->nCams, h->H, h->head, h->count, h->R, h->t,
-                       h->cen);
+    hist_centres(h, s);
     hipLaunchKernelGGL(k_check_unify, dim3((nPairs + 3) / 4), dim3(256), 0, s, A);
     CS_HIP(hipGetLastError());
     return CS_OK;
@@ -1495,18 +1515,20 @@ extern "C" int cs_map_points_classify_dev(const cs_track_history* h, void* hip_s
     }
     CS_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)hip_stream;
-    if (d_counts) CS_HIP(hipMemsetAsync(d_counts, 0, 2 * sizeof(int), s));
-    if (nMap == 0) return CS_OK;
+    if (nMap == 0) {
+        if (d_counts) CS_HIP(hipMemsetAsync(d_counts, 0, 2 * sizeof(int), s));
+        return CS_OK;
+    }
     if (nMap > h->clsCap) {   // (a larger map than any before: the only allocation, and it waits for the device)
         if (h->clsList) CS_HIP(hipFree(h->clsList));
         h->clsList = nullptr, h->clsCap = 0;
-        CS_HIP(hipMalloc((void**)&h->clsList, sizeof(int) * (1 + (size_t)nMap)));
-        h->clsCap = nMap;
+        CS_HIP(hipMalloc((void**)&h->clsList, sizeof(int) * (2 + (size_t)nMap)));
+        CS_HIP(hipMemsetAsync(h->clsList, 0, 2 * sizeof(int), s));
+        h->clsCap = nMap, h->clsPar = 0;
     }
-    A.list = h->clsList;
-    CS_HIP(hipMemsetAsync(A.list, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_ring_centres, dim3((h->nCams * h->count + 255) / 256), dim3(256), 0, s, h->nCams, h->H, h->head, h->count, h->R, h->t,
-                       h->cen);
+    A.list = h->clsList, A.par = h->clsPar;
+    h->clsPar ^= 1;
+    hist_centres(h, s);
     hipLaunchKernelGGL(k_classify_select, dim3((nMap + 255) / 256), dim3(256), 0, s, A);
     hipLaunchKernelGGL(k_map_points_classify, dim3(CLS_WAVES / 4), dim3(256), 0, s, A);
     CS_HIP(hipGetLastError());

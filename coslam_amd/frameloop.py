@@ -306,10 +306,9 @@ class FrameLoop:
         s_ = self.pose_s.cuda_stream
         # NewMapPtsNCC::addSlam's features: this frame's, on tracks of more than three frames, unmapped or on a false point -- of the
         # own cameras, straight into their records' `valid` part
-        for k in range(nc):
-            g = c0 + k
-            ncc_candidate_mask_dev(s_, 1, N, self.d_state[g].data_ptr(), self.d_slot2map[g].data_ptr(), self.d_trackspan[g].data_ptr(),
-                                   self.d_mapflags.data_ptr(), self.n_map, ncc["valid"][g].data_ptr(), device=self.device)
+        ncc_candidate_mask_dev(s_, nc, N, self.d_state[c0].data_ptr(), self.d_slot2map[c0].data_ptr(), self.d_trackspan[c0].data_ptr(),
+                               self.d_mapflags.data_ptr(), self.n_map, ncc["valid"][c0].data_ptr(), device=self.device,
+                               validStride=ncc["rec"].stride(0) // 4)
         if f not in ncc["group"]:
             own = ncc_cams([dict(img=self.img_ptrs[f][k], x=self.d_xy[c0 + k].data_ptr(), y=self.d_xy[c0 + k].data_ptr() + 8 * N,
                                  scaled=ncc["small"][k].data_ptr(), blocks=ncc["blk"][c0 + k].data_ptr(), abc=ncc["abc"][c0 + k].data_ptr(),

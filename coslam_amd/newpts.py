@@ -13,10 +13,13 @@ def newpts_scratch_bytes(nCams, N):
     return int(L.cs_newpts_scratch_bytes(int(nCams), int(N)))
 
 
-def ncc_candidate_mask_dev(stream_ptr, nCams, N, d_state, d_slot2map, d_trackSpan, d_mapFlags, mapCap, d_valid, minTrack=3, device=0):
+def ncc_candidate_mask_dev(stream_ptr, nCams, N, d_state, d_slot2map, d_trackSpan, d_mapFlags, mapCap, d_valid, minTrack=3, device=0,
+                           validStride=0):
+    """validStride: ints from one camera's mask to the next (0: N, back to back)"""
     vp = C.c_void_p
     check(lib().cs_ncc_candidate_mask_dev(int(device), vp(stream_ptr), int(nCams), int(N), vp(d_state), vp(d_slot2map), vp(d_trackSpan),
-                                          vp(d_mapFlags), int(mapCap), int(minTrack), vp(d_valid)), "cs_ncc_candidate_mask_dev")
+                                          vp(d_mapFlags), int(mapCap), int(minTrack), vp(d_valid), C.c_size_t(int(validStride))),
+          "cs_ncc_candidate_mask_dev")
 
 
 class NewPtsJob:

@@ -676,7 +676,8 @@ int cs_ncc_match_between(int device, const unsigned char* img1, int W1, int H1, 
  * that are unmapped or mapped to a FALSE point (addSlam, SL_NewMapPointsInterCam.h:103-131): cs_ncc_candidate_mask_dev writes that
  * mask (d_state / d_slot2map [nCams][N], d_trackSpan [nCams][2N]) for cs_ncc_epi_pairs_group_dev's `valid`. */
 int cs_ncc_candidate_mask_dev(int device, void* hip_stream, int nCams, int N, const int* d_state, const int* d_slot2map,
-                              const int* d_trackSpan, const unsigned char* d_mapFlags, int mapCap, int minTrack /* 3 */, int* d_valid);
+                              const int* d_trackSpan, const unsigned char* d_mapFlags, int mapCap, int minTrack /* 3 */, int* d_valid,
+                              size_t validStride /* ints from one camera's mask to the next; 0: N, back to back */);
 size_t cs_newpts_scratch_bytes(int nCams, int N);
 int cs_newpts_from_pairs_dev(int device, void* hip_stream, int nCams, int N, const cs_poseupdate_cam* cams,
                              const cs_ncc_pair* const* d_pairs /* host array [nCams - 1] */, const int* const* d_pairCount /* host array */,

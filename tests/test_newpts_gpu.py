@@ -105,8 +105,19 @@ def test_new_map_points_equal_the_restatement(hip, seed, max_disp):
     assert out[0] == len(res["new"]) and out[1] == len(res["tracks"]) and out[3] == 0
     assert out[4:4 + nC - 1] == [int((res["matches"][a] >= 0).sum()) for a in range(nC - 1)]
     assert int(dCount.item()) == res["map_count"] == nMap + len(res["new"])
-    match = dScr.view(torch.int32)[:(nC - 1) * N].view(nC - 1, N).cpu().numpy()
-    assert np.array_equal(match, res["matches"])
+    # the scratch: every matched feature's partner, and the matched rows / columns of every pair as bit masks
+    scr = dScr.view(torch.int32).cpu().numpy()
+    nW = (N + 31) // 32
+    match = scr[:(nC - 1) * N].reshape(nC - 1, N)
+    rows = scr[(nC - 1) * N:(nC - 1) * (N + nW)].view(np.uint32).reshape(nC - 1, nW)
+    cols = scr[(nC - 1) * (N + nW):(nC - 1) * (N + 2 * nW)].view(np.uint32).reshape(nC - 1, nW)
+    bit = lambda msk, a: ((msk[a][np.arange(N) >> 5] >> (np.arange(N) & 31).astype(np.uint32)) & 1).astype(bool)   # noqa: E731
+    for a in range(nC - 1):
+        has = res["matches"][a] >= 0
+        assert np.array_equal(bit(rows, a), has) and np.array_equal(match[a][has], res["matches"][a][has])
+        is_col = np.zeros(N, dtype=bool)
+        is_col[res["matches"][a][has]] = True
+        assert np.array_equal(bit(cols, a), is_col)
     assert np.array_equal(dM.cpu().numpy(), o["mapPts"]) and np.array_equal(dC.cpu().numpy(), o["mapCov"])
     assert np.array_equal(dF.cpu().numpy(), o["flags"]) and np.array_equal(dNew.cpu().numpy(), o["newPt"]) and np.array_equal(dFirst.cpu().numpy(), o["first"])
     assert np.array_equal(dPf.cpu().numpy(), o["pf"])
