@@ -397,8 +397,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ba-lag", type=int, default=int(os.environ.get("BENCH_BA_LAG", "0")),
                     help="key-frame intervals between a window's key frame and the frame its bundle adjustment is written back into the "
-                         "map (RobustBundleRTS::output); 0 = min(N, 4): at N = 1 the result of window k is in the map before window "
-                         "k + 1 is built, at N > 1 window k is solved by rank k mod N, which has N intervals for it")
+                         "map (RobustBundleRTS::output); 0 = min(max(N, 2), 4): window k is solved by rank k mod N; with two intervals the "
+                         "solve's latency is off the frame loop's path also at N = 1 (1: the result of window k is in the map before "
+                         "window k + 1 is built, the pose stream waits for it -- measured in DESIGN.md 6)")
     ap.add_argument("--key-every", type=int, default=KEY_EVERY, help="diagnostic: 0 disables the key-frame solves (not a valid bench line)")
     ap.add_argument("--only-solve", choices=["both", "joint", "intercam"], default="both",
                     help="diagnostic: run only one of the two key-frame solves (not a valid bench line)")

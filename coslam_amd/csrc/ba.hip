@@ -2031,6 +2031,7 @@ __global__ __launch_bounds__(256) void k_control_step(BaDev D) {
 #include "ba_packed_dev.h"
 #include "ba_persist_dev.h"
 #include "ba_window_dev.h"
+#include "small_ops.h"
 #include "ba_output_dev.h"
 #include "ba_intercam_dev.h"
 
@@ -3485,16 +3486,14 @@ static int ba_worker_run_intercam(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
     ba_drop_graph(b);
     const IcStage& st = ic->st[J.icSlot];
     const size_t P1 = (size_t)ic->maxP, O1 = (size_t)ic->maxObs;
-    CS_HIP(hipMemcpyAsync(b->Ks, st.Ks, 72 * (size_t)C, hipMemcpyDeviceToDevice, s));
-    CS_HIP(hipMemcpyAsync(b->Rs, st.Rs, 72 * (size_t)C, hipMemcpyDeviceToDevice, s));
-    CS_HIP(hipMemcpyAsync(b->Ts, st.Ts, 24 * (size_t)C, hipMemcpyDeviceToDevice, s));
-    CS_HIP(hipMemcpyAsync(b->pts, st.pts, 24 * P1, hipMemcpyDeviceToDevice, s));
-    CS_HIP(hipMemcpyAsync(b->obs_xy, st.obs_xy, 16 * O1, hipMemcpyDeviceToDevice, s));
-    CS_HIP(hipMemcpyAsync(b->obs_ptr, st.obs_ptr, 4 * (P1 + 1), hipMemcpyDeviceToDevice, s));
-    CS_HIP(hipMemcpyAsync(b->obs_cam, st.obs_cam, 4 * O1, hipMemcpyDeviceToDevice, s));
-    CS_HIP(hipMemcpyAsync(b->obs_pt, st.obs_pt, 4 * O1, hipMemcpyDeviceToDevice, s));
-    CS_HIP(hipMemcpyAsync(b->obs_of, st.obs_of, 4 * P1 * C, hipMemcpyDeviceToDevice, s));
-    CS_HIP(hipMemcpyAsync(ic->lastPointMap, st.pointMap, 4 * P1, hipMemcpyDeviceToDevice, s));
+    {   // the staged problem into the workspace: one launch (small_ops.h)
+        cs_small::List ops;
+        ops.copy(b->Ks, st.Ks, 72 * (size_t)C), ops.copy(b->Rs, st.Rs, 72 * (size_t)C), ops.copy(b->Ts, st.Ts, 24 * (size_t)C);
+        ops.copy(b->pts, st.pts, 24 * P1), ops.copy(b->obs_xy, st.obs_xy, 16 * O1), ops.copy(b->obs_ptr, st.obs_ptr, 4 * (P1 + 1));
+        ops.copy(b->obs_cam, st.obs_cam, 4 * O1), ops.copy(b->obs_pt, st.obs_pt, 4 * O1), ops.copy(b->obs_of, st.obs_of, 4 * P1 * C);
+        ops.copy(ic->lastPointMap, st.pointMap, 4 * P1);
+        CS_HIP(ops.run(s));
+    }
     if (6 * C <= 36)   // (the small-order solver's Schur kernels walk camera-indexed lists)
         hipLaunchKernelGGL(k_cam_lists, dim3(1), dim3(1024), 0, s, C, st.totals, b->obs_cam, b->cam_ptr, b->cam_obs);
     const int nPairsAll = C * (C + 1) / 2;
@@ -4398,17 +4397,26 @@ int cs_ba_window_push_dev(cs_ba_window* w, void* hip_stream, const cs_handback_c
     }
     A.xyOut = w->xy + base * 2 * w->N;
     A.pfOut = w->pf + base * w->nMap;
-    CS_HIP(hipMemsetAsync(A.pfOut, 0xff, sizeof(int) * (size_t)w->nCams * w->nMap, s));
+    {   // the slot's feature table cleared, its intrinsics and poses: one launch (small_ops.h)
+        cs_small::List ops;
+        auto put = [&](void* dst, const void* src, size_t bytes, unsigned v) -> hipError_t {
+            if (ops.add(dst, src, bytes, v)) return hipSuccess;
+            const hipError_t e = ops.run(s);
+            ops.add(dst, src, bytes, v);
+            return e;
+        };
+        CS_HIP(put(A.pfOut, nullptr, sizeof(int) * (size_t)w->nCams * w->nMap, 0xff));
+        if (kShared) {
+            for (int c = 0; c < w->nCams; ++c) CS_HIP(put(w->K + (base + c) * 9, d_K, 72, 0));
+        } else {
+            CS_HIP(put(w->K + base * 9, d_K, 72 * (size_t)w->nCams, 0));
+        }
+        CS_HIP(put(w->R + base * 9, d_R, 72 * (size_t)w->nCams, 0));
+        CS_HIP(put(w->t + base * 3, d_t, 24 * (size_t)w->nCams, 0));
+        CS_HIP(ops.run(s));
+    }
     hipLaunchKernelGGL(k_win_snapshot, dim3((w->N + 255) / 256, w->nCams), dim3(256), 0, s, A);
     CS_CHECK_LAUNCH();
-    if (kShared) {
-        for (int c = 0; c < w->nCams; ++c)
-            CS_HIP(hipMemcpyAsync(w->K + (base + c) * 9, d_K, 72, hipMemcpyDeviceToDevice, s));
-    } else {
-        CS_HIP(hipMemcpyAsync(w->K + base * 9, d_K, 72 * (size_t)w->nCams, hipMemcpyDeviceToDevice, s));
-    }
-    CS_HIP(hipMemcpyAsync(w->R + base * 9, d_R, 72 * (size_t)w->nCams, hipMemcpyDeviceToDevice, s));
-    CS_HIP(hipMemcpyAsync(w->t + base * 3, d_t, 24 * (size_t)w->nCams, hipMemcpyDeviceToDevice, s));
     w->frameOf[slot] = frame;
     w->head = (slot + 1) % w->ring;
     if (w->count < w->nKf) w->count += 1;
@@ -4463,19 +4471,23 @@ static int ba_solve_window_async(cs_ba* b, cs_ba_window* w, void* after_stream, 
     // (cs_pose_update_frame_dev) while the worker parses
     const int sn = w->snapNext;
     w->snapNext = (sn + 1) % (WIN_SLACK + 1);
-    CS_HIP(hipMemcpyAsync(w->mapSnap[sn], d_mapPts, sizeof(double) * 3 * (size_t)w->nMap, hipMemcpyDeviceToDevice, (hipStream_t)after_stream));
+    // ... and the ring's key poses: cs_ba_output_apply_dev writes a finished solve's key poses back into the ring (the next
+    // window starts from them), possibly while this request is still waiting for its parse.  All four in one launch (small_ops.h).
+    const size_t KCs = (size_t)w->ring * w->nCams;
+    {
+        cs_small::List ops;
+        ops.copy(w->mapSnap[sn], d_mapPts, sizeof(double) * 3 * (size_t)w->nMap);
+        if (d_mapStatic) ops.copy(w->staticSnap[sn], d_mapStatic, (size_t)w->nMap);
+        ops.copy(w->poseSnapR[sn], w->R, sizeof(double) * 9 * KCs);
+        ops.copy(w->poseSnapT[sn], w->t, sizeof(double) * 3 * KCs);
+        CS_HIP(ops.run((hipStream_t)after_stream));
+    }
     if (d_mapStatic) {
-        CS_HIP(hipMemcpyAsync(w->staticSnap[sn], d_mapStatic, (size_t)w->nMap, hipMemcpyDeviceToDevice, (hipStream_t)after_stream));
         if (staticIsFlags) {
             hipLaunchKernelGGL(k_win_static_from_flags, dim3((w->nMap + 255) / 256), dim3(256), 0, (hipStream_t)after_stream, w->nMap, w->staticSnap[sn]);
             CS_CHECK_LAUNCH();
         }
     }
-    // ... and the ring's key poses: cs_ba_output_apply_dev writes a finished solve's key poses back into the ring (the next
-    // window starts from them), possibly while this request is still waiting for its parse
-    const size_t KCs = (size_t)w->ring * w->nCams;
-    CS_HIP(hipMemcpyAsync(w->poseSnapR[sn], w->R, sizeof(double) * 9 * KCs, hipMemcpyDeviceToDevice, (hipStream_t)after_stream));
-    CS_HIP(hipMemcpyAsync(w->poseSnapT[sn], w->t, sizeof(double) * 3 * KCs, hipMemcpyDeviceToDevice, (hipStream_t)after_stream));
     J.winR = w->poseSnapR[sn], J.winT = w->poseSnapT[sn];
     J.win = w, J.d_map = w->mapSnap[sn], J.d_mapStatic = d_mapStatic ? w->staticSnap[sn] : nullptr;
     J.winCount = w->count;
@@ -4794,15 +4806,17 @@ int cs_ba_output_apply_dev(cs_ba_output* o, const void* d_record, void* hip_stre
             }
     }
     hipLaunchKernelGGL(k_ba_output_poses, dim3((o->nKf * o->nCams * 12 + 255) / 256), dim3(256), 0, s, (const unsigned char*)d_record, o->L, A);
-    if (d_counts) CS_HIP(hipMemsetAsync(d_counts + 2, 0, sizeof(int), s));
+    {
+        cs_small::List ops;
+        if (d_counts) ops.fill(d_counts + 2, 0, sizeof(int));
+        if (nNodes <= 1) ops.copy(o->newR, o->nodeR, sizeof(double) * 9 * o->nCams), ops.copy(o->newT, o->nodeT, sizeof(double) * 3 * o->nCams);
+        CS_HIP(ops.run(s));
+    }
     hipLaunchKernelGGL(k_ba_output_points, dim3((o->L.maxP + 255) / 256), dim3(256), 0, s, (const unsigned char*)d_record, o->L, nMap, d_mapPts,
                        d_mapFlags, d_counts ? d_counts + 2 : nullptr);
     CS_CHECK_LAUNCH();
     if (nNodes > 1) {
         if ((rc = cs_posegraph_relax_dev(o->graph, hip_stream, o->nodeR, o->nodeT, o->edgeR, o->edgeT, o->newR, o->newT))) return rc;
-    } else {
-        CS_HIP(hipMemcpyAsync(o->newR, o->nodeR, sizeof(double) * 9 * o->nCams, hipMemcpyDeviceToDevice, s));
-        CS_HIP(hipMemcpyAsync(o->newT, o->nodeT, sizeof(double) * 3 * o->nCams, hipMemcpyDeviceToDevice, s));
     }
     if ((rc = cs_track_history_set_span_dev(h, hip_stream, firstKeyFrame, nNodes, o->newR, o->newT))) return rc;
     hipLaunchKernelGGL(k_ba_output_tail, dim3((o->nCams * 12 + 255) / 256), dim3(256), 0, s, o->nCams, nNodes, o->newR, o->newT, d_Rcur, d_tcur);
@@ -4926,7 +4940,11 @@ int cs_ba_solve_intercam_async(cs_ba* b, cs_ba_intercam* ic, void* after_stream,
     }
     A.st = ic->st[slot];
     hipStream_t as = (hipStream_t)after_stream;
-    CS_HIP(hipMemsetAsync(A.st.dynMark, 0, (size_t)ic->nMap, as));
+    {
+        cs_small::List ops;
+        ops.fill(A.st.dynMark, 0, (size_t)ic->nMap);
+        CS_HIP(ops.run(as));
+    }
     hipLaunchKernelGGL(k_ic_gather, dim3(ic->nCams), dim3(256), 0, as, A);
     hipLaunchKernelGGL(k_ic_assemble, dim3(1), dim3(1024), 0, as, A);
     CS_CHECK_LAUNCH();

@@ -45,6 +45,7 @@ __device__ __forceinline__ void undistort_point(const double* __restrict__ K, co
 __global__ __launch_bounds__(1024) void k_handback(HbArgs A) {
     __shared__ unsigned long long key[HB_MAX_BLOCKS];
     __shared__ int flag[HB_MAX_BLOCKS];
+    CS_POSE_STREAM_PRIO();
     const cs_handback_cam& C = A.cam[blockIdx.x];
     const int tid = threadIdx.x, N = A.N;
     const int nBlk = A.nColBlk * A.nRowBlk;

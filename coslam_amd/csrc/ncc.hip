@@ -21,6 +21,7 @@
 // point, 1)).  How matchBetween cuts its blocks (cv::getRectSubPix on a cv::resize'd image) is OpenCV; the in-tree
 // NCCBlock::compute (truncated position on the small image) is what cs_ncc_blocks* implements.
 #include "cs_common.h"
+#include "small_ops.h"
 
 #pragma clang fp contract(off)
 
@@ -544,6 +545,7 @@ extern "C" int cs_ncc_epi_pairs_group_dev(int device, void* hip_stream, int nCam
     hipStream_t s = (hipStream_t)hip_stream;
     NcJobs J;
     memset(&J, 0, sizeof(J));
+    cs_small::List zero;   // the jobs' pair counts: one launch (small_ops.h), not a memset each
     for (int k = 0; k < nJobs; ++k) {
         const cs_ncc_pair_job& q = jobs[k];
         if (q.camA < 0 || q.camA >= nCams || q.camB < 0 || q.camB >= nCams || !q.count || (pairCap > 0 && !q.pairs)) {
@@ -562,8 +564,9 @@ extern "C" int cs_ncc_epi_pairs_group_dev(int device, void* hip_stream, int nCam
         A.epiMax = epiMax, A.nccMin = nccMin, A.wNone = -1.0;
         A.epiMat = A.nccMat = nullptr;
         A.pairs = q.pairs, A.pairCap = pairCap, A.pairCount = q.count;
-        CS_HIP(hipMemsetAsync(q.count, 0, sizeof(int), s));
+        zero.fill(q.count, 0, sizeof(int));
     }
+    CS_HIP(zero.run(s));
     if (n == 0) return CS_OK;
     hipLaunchKernelGGL(k_ncc_epi_mat<true>, dim3((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64), (unsigned)nJobs), dim3(256), 0, s, J);
     CS_CHECK_LAUNCH();

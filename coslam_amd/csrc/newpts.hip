@@ -21,6 +21,7 @@
 //   reprojErrorSingle(K, R, t, M, m)    Euclidean pixel distance of m from the projection; dist2 likewise
 // triangulateMultiView / getTriangulateCovMat / project / isAtCameraBack as in poseupdate.hip.
 #include "cs_common.h"
+#include "small_ops.h"
 
 #pragma clang fp contract(off)
 
@@ -437,7 +438,11 @@ extern "C" int cs_newpts_from_pairs_dev(int device, void* hip_stream, int nCams,
     A.counts = d_counts;
     CS_HIP(hipSetDevice(device));
     hipStream_t s = (hipStream_t)hip_stream;
-    if (d_counts) CS_HIP(hipMemsetAsync(d_counts, 0, sizeof(int) * (4 + (size_t)nCams), s));
+    if (d_counts) {
+        cs_small::List ops;
+        ops.fill(d_counts, 0, sizeof(int) * (4 + (size_t)nCams));
+        CS_HIP(ops.run(s));
+    }
     hipLaunchKernelGGL(k_np_match, dim3(nCams - 1), dim3(256), 0, s, A);
     hipLaunchKernelGGL(k_np_reconstruct, dim3(1), dim3(256), 0, s, A);
     CS_CHECK_LAUNCH();

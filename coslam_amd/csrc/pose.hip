@@ -341,6 +341,7 @@ __global__ __launch_bounds__(PB) CS_IC_ATTR void k_intracam(int ptsStride, const
                                                  cs_pose_option* __restrict__ optAll, int* __restrict__ okAll,
                                                  double* __restrict__ wsScratch) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    CS_POSE_STREAM_PRIO();
     const int pb = blockIdx.x;
     constexpr int NW = PB / 64;
     double* red = smem;                  // [2][NW][NSUM]

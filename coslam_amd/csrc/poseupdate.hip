@@ -39,6 +39,7 @@
 #include <cstdlib>
 
 #include "cs_common.h"
+#include "small_ops.h"
 
 #pragma clang fp contract(off)
 
@@ -224,6 +225,7 @@ __device__ __forceinline__ void pu_fmat(const double* __restrict__ iK, const dou
 
 __global__ __launch_bounds__(256) void k_pose_update(PuArgs A) {
     extern __shared__ double Fs[];  // dynamic role: [nHist][9]
+    CS_POSE_STREAM_PRIO();
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < A.gateBlocks) {
         const int m = blockIdx.x * 256 + tid;
@@ -330,6 +332,7 @@ struct MgArgs {
 constexpr int MG_LPC = 8;
 __global__ __launch_bounds__(256) void k_register_mergability(MgArgs A) {
     extern __shared__ double mg_pose[];  // [nHist][12]
+    CS_POSE_STREAM_PRIO();
     const int c = A.cam0 + blockIdx.y, tid = threadIdx.x, N = A.N, H = A.H;
     const cs_poseupdate_cam& C = A.cam[c];
     const double* hR = A.histR + (size_t)c * H * 9;
@@ -968,6 +971,7 @@ __global__ __launch_bounds__(256) void k_classify_select(ClsArgs A) {
 constexpr int CLS_WAVES = 1024;   // the worker grid: 256 workgroups of 4 waves, a wave per listed point (and round again past that)
 __global__ __launch_bounds__(256) void k_map_points_classify(ClsArgs A) {
     constexpr int FRAME_NUM_FOR_NEWPOINT = 30, FRAME_NUM_FOR_DONTMOVE = 50, NUM_FRAME_CHECK_STATIC = 60;
+    CS_POSE_STREAM_PRIO();
     const int r = threadIdx.x % 64;
     const int n = A.list[A.par];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1405,7 +1409,11 @@ int up_launch(const char* who, const cs_track_history* h, void* hip_stream, cons
     }
     CS_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)hip_stream;
-    if (d_counts) CS_HIP(hipMemsetAsync(d_counts, 0, nCounts * sizeof(int), s));
+    if (d_counts) {
+        cs_small::List ops;
+        ops.fill(d_counts, 0, nCounts * sizeof(int));
+        CS_HIP(ops.run(s));
+    }
     if (A.nMap == 0) return CS_OK;
     A.cen = h->cen;
     hist_centres(h, s);

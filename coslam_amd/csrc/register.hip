@@ -88,6 +88,7 @@ constexpr int RG_CHUNK = 4096;    // features staged in LDS at a time (64 KB); l
 // order with a strict <, the waves' minima are merged lexicographically on (distance, slot): the serial loop's answer.
 __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
     extern __shared__ double lds[];
+    CS_POSE_STREAM_PRIO();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = A.cam0 + blockIdx.y;
     const int p = blockIdx.x * 64 + lane;

@@ -37,7 +37,7 @@ class LoopConfig:
         self.pts_stride, self.n_col_blk, self.n_row_blk = 192, 16, 12    # reference src/app/SL_SingleSLAM.h:36-37
         self.key_every, self.n_key_frames = 5, 5                         # requestForBA(5, 2, 2, 30), SL_CoSLAM.cpp:1345
         self.ic_workers = 1        # workspaces (worker threads) the inter-camera solves of this rank rotate over (2 on one GPU: measured slower)
-        self.ba_lag = 0            # key-frame intervals between a window's key frame and the frame its result is applied; 0 = min(N, 4)
+        self.ba_lag = 0            # key-frame intervals between a window's key frame and the frame its result is applied; 0 = min(max(N, 2), 4)
         self.p_reg = 1536
         self.hist = 64
         self.ncc_every, self.ncc_pair_cap = 4, 1 << 16
@@ -85,7 +85,7 @@ class FrameLoop:
         self.nc = nc = NA // world
         self.c0 = c0 = rank * nc
         self.my_cams = list(range(c0, c0 + nc))
-        self.lag = cfg.ba_lag if cfg.ba_lag > 0 else min(max(world, 1), 4)
+        self.lag = cfg.ba_lag if cfg.ba_lag > 0 else min(max(world, 2), 4)
         if (cfg.n_key_frames - 1 + self.lag) * cfg.key_every + 1 > cfg.hist:
             raise ValueError("the pose history is shorter than a window + its apply lag")
         dev = self.dev = torch.device("cuda", device)

@@ -101,12 +101,12 @@ struct BaProblem {
 
 int main(int argc, char** argv) {
     if (argc < 4) {
-        fprintf(stderr, "usage: %s <workload file> <steps> <warmup> [cams per tracker launch] [BA apply lag in key-frame intervals: 1]\n", argv[0]);
+        fprintf(stderr, "usage: %s <workload file> <steps> <warmup> [cams per tracker launch] [BA apply lag in key-frame intervals: 2]\n", argv[0]);
         return 1;
     }
     const int steps = atoi(argv[2]), warmup = atoi(argv[3]);
     const int camsPerLaunchArg = argc > 4 ? atoi(argv[4]) : -1;
-    const int baLag = argc > 5 && atoi(argv[5]) > 0 ? atoi(argv[5]) : 1;
+    const int baLag = argc > 5 && atoi(argv[5]) > 0 ? atoi(argv[5]) : 2;
     const bool useWindow = true;
     Reader rd{fopen(argv[1], "rb")};
     if (!rd.f) {
@@ -120,7 +120,7 @@ int main(int argc, char** argv) {
     }
     const std::vector<int> hd = rd.vec<int>(16);
     const int nCams = hd[0], W = hd[1], H = hd[2], L = hd[3], FW = hd[4], FH = hd[5], nFrames = hd[6], orderLen = hd[7],
-              nMap = hd[8], P_REG = hd[9], PTS = hd[10], nColBlk = hd[11], nRowBlk = hd[12], keyEvery = hd[13];
+              nPts = hd[8], P_REG = hd[9], PTS = hd[10], nColBlk = hd[11], nRowBlk = hd[12], keyEvery = hd[13];
     const int camsPerLaunch = camsPerLaunchArg >= 0 ? camsPerLaunchArg : hd[14];
     const int N = FW * FH, dev = 0;
     const std::vector<int> order = rd.vec<int>(orderLen);
@@ -139,7 +139,9 @@ int main(int argc, char** argv) {
     std::vector<uint8_t*> dFrames(nCams);
     const size_t imgBytes = (size_t)W * H;
     for (int c = 0; c < nCams; ++c) dFrames[c] = to_dev(rd.vec<uint8_t>(imgBytes * nFrames));
-    const std::vector<double> mapPts = rd.vec<double>(3 * (size_t)nMap);
+    // the map keeps spare capacity behind the scene's points: NewMapPtsNCC's new points are appended (cs_newpts_from_pairs_dev)
+    const int MAP_SPARE = 8192, nMap = nPts + MAP_SPARE;
+    const std::vector<double> mapPts = rd.vec<double>(3 * (size_t)nPts);
     // projections of the visible map points in the first frame (for the slot -> map point association that stands in for the
     // map initialisation, as in bench.py associate())
     std::vector<std::vector<int>> visIdx(nCams);
@@ -150,7 +152,7 @@ int main(int argc, char** argv) {
         visUV[c] = rd.vec<double>(2 * (size_t)nv);
     }
     const std::vector<double> R0 = rd.vec<double>(9 * (size_t)nCams), t0 = rd.vec<double>(3 * (size_t)nCams);
-    const std::vector<double> cov = rd.vec<double>(9 * (size_t)std::max(nMap, 2 * P_REG));  // MapPoint::cov of every map point
+    const std::vector<double> cov = rd.vec<double>(9 * (size_t)std::max(nPts, 2 * P_REG));  // MapPoint::cov of every map point
     BaProblem joint, ic;
     joint.read(rd);
     ic.read(rd);
@@ -189,8 +191,12 @@ int main(int argc, char** argv) {
     for (int c = 0; c < nCams; ++c) Kall.insert(Kall.end(), K.begin(), K.end());
     double* dKall = to_dev(Kall);
     double* dKud = dev_zeros<double>(7);
-    double* dMap = to_dev(mapPts);
-    double* dCov = to_dev(cov);
+    double* dMap = dev_zeros<double>(3 * (size_t)nMap);
+    double* dCov = dev_zeros<double>(9 * (size_t)std::max(nMap, 2 * P_REG));
+    HIPCHK(hipMemcpy(dMap, mapPts.data(), sizeof(double) * mapPts.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dCov, cov.data(), sizeof(double) * cov.size(), hipMemcpyHostToDevice));
+    int* dMapCount = dev_zeros<int>(1);
+    HIPCHK(hipMemcpy(dMapCount, &nPts, sizeof(int), hipMemcpyHostToDevice));
     int* dS2M = dev_zeros<int>((size_t)nCams * N);
     int* dSpan = dev_zeros<int>((size_t)nCams * 2 * N);
     HIPCHK(hipMemset(dS2M, 0xff, sizeof(int) * (size_t)nCams * N));
@@ -328,12 +334,11 @@ int main(int argc, char** argv) {
     unsigned char* dBlk = dev_zeros<unsigned char>((size_t)nCams * N * 128);
     double* dAbc = dev_zeros<double>((size_t)nCams * N * 4);
     int* dValid = dev_zeros<int>((size_t)nCams * N);
-    double* dEpi = dev_zeros<double>((size_t)N * N);
-    double* dScore = dev_zeros<double>((size_t)N * N);
     const int NCC_PAIR_CAP = 1 << 16;   // passing pairs kept per camera pair and run (cs_ncc_epi_pairs_dev)
     cs_ncc_pair* dPairs = (cs_ncc_pair*)dev_zeros<unsigned char>((size_t)(nCams > 1 ? nCams - 1 : 1) * NCC_PAIR_CAP * sizeof(cs_ncc_pair));
     int* dPairCount = dev_zeros<int>(nCams);
-    const bool nccDense = getenv("FRAME_LOOP_NCC_DENSE") != nullptr;
+    void* dNpScratch = dev_zeros<unsigned char>(cs_newpts_scratch_bytes(nCams, N));
+    int* dNpCounts = dev_zeros<int>(4 + nCams);
     int nccRuns = 0;
 
     hipEvent_t kltDone[2], destFree[2];
@@ -417,35 +422,29 @@ int main(int argc, char** argv) {
         }
         // (last on the pose stream: nothing of this frame waits for the matching leg)
         if (nCams >= 2 && i % NCC_EVERY == 0) {
-            CSCHK(cs_ncc_unmapped_mask_dev(dev, (void*)poseS, nCams * N, dState, dS2M, dValid));
-            if (!nccDense) {   // the whole run in three launches: resize + cutter of all cameras, the passing pairs of all camera pairs
-                std::vector<cs_ncc_cam> nc(nCams);
-                std::vector<cs_ncc_pair_job> jb(nCams - 1);
-                for (int c = 0; c < nCams; ++c) {
-                    nc[c].img = dFrames[c] + imgBytes * f, nc[c].x = dXY + (size_t)c * 2 * N, nc[c].y = dXY + (size_t)c * 2 * N + N;
-                    nc[c].scaled = dSmall + (size_t)c * wsS * hsS, nc[c].blocks = dBlk + (size_t)c * N * 128, nc[c].abc = dAbc + (size_t)c * N * 4;
-                    nc[c].valid = dValid + (size_t)c * N;
-                }
-                for (int c = 0; c + 1 < nCams; ++c) {
-                    memcpy(jb[c].F, Fs.data() + ((size_t)f * (nCams - 1) + c) * 9, 72);
-                    jb[c].camA = c, jb[c].camB = c + 1, jb[c].pairs = dPairs + (size_t)c * NCC_PAIR_CAP, jb[c].count = dPairCount + c;
-                }
-                CSCHK(cs_ncc_get_blocks_group_dev(dev, (void*)poseS, nCams, nc.data(), W, H, N, 0.3));
-                CSCHK(cs_ncc_epi_pairs_group_dev(dev, (void*)poseS, nCams, nc.data(), N, nCams - 1, jb.data(), 50.0, 0.80, NCC_PAIR_CAP));
-            } else {
-                for (int c = 0; c < nCams; ++c)
-                    CSCHK(cs_ncc_get_blocks_dev(dev, (void*)poseS, dFrames[c] + imgBytes * f, W, H, N, dXY + (size_t)c * 2 * N,
-                                                dXY + (size_t)c * 2 * N + N, 0.3, dSmall + (size_t)c * wsS * hsS, dBlk + (size_t)c * N * 128,
-                                                dAbc + (size_t)c * N * 4, nullptr));
-                for (int c = 0; c + 1 < nCams; ++c) {
-                    const double* xa = dXY + (size_t)c * 2 * N;
-                    const double* xb = dXY + (size_t)(c + 1) * 2 * N;
-                    CSCHK(cs_ncc_epi_mat_dev(dev, (void*)poseS, Fs.data() + ((size_t)f * (nCams - 1) + c) * 9, N, xa, xa + N,
-                                             dBlk + (size_t)c * N * 128, dAbc + (size_t)c * N * 4, dValid + (size_t)c * N, N, xb, xb + N,
-                                             dBlk + (size_t)(c + 1) * N * 128, dAbc + (size_t)(c + 1) * N * 4, dValid + (size_t)(c + 1) * N, 50.0,
-                                             0.80, -1.0, dEpi, dScore));
-                }
+            // NewMapPtsNCC::addSlam's features: this frame's, on tracks of more than three frames, unmapped or on a false point
+            CSCHK(cs_ncc_candidate_mask_dev(dev, (void*)poseS, nCams, N, dState, dS2M, dSpan, dMapFlags, nMap, 3, dValid, 0));
+            // the whole run in a handful of launches: resize + cutter of all cameras, the passing pairs of all camera pairs, then
+            // seeds + disparity guide + greedy matches, featTracksFromMatches, reconstructTracks, output: new points behind *dMapCount
+            std::vector<cs_ncc_cam> nc(nCams);
+            std::vector<cs_ncc_pair_job> jb(nCams - 1);
+            std::vector<const cs_ncc_pair*> pairPtr(nCams - 1);
+            std::vector<const int*> cntPtr(nCams - 1);
+            for (int c = 0; c < nCams; ++c) {
+                nc[c].img = dFrames[c] + imgBytes * f, nc[c].x = dXY + (size_t)c * 2 * N, nc[c].y = dXY + (size_t)c * 2 * N + N;
+                nc[c].scaled = dSmall + (size_t)c * wsS * hsS, nc[c].blocks = dBlk + (size_t)c * N * 128, nc[c].abc = dAbc + (size_t)c * N * 4;
+                nc[c].valid = dValid + (size_t)c * N;
             }
+            for (int c = 0; c + 1 < nCams; ++c) {
+                memcpy(jb[c].F, Fs.data() + ((size_t)f * (nCams - 1) + c) * 9, 72);
+                jb[c].camA = c, jb[c].camB = c + 1, jb[c].pairs = dPairs + (size_t)c * NCC_PAIR_CAP, jb[c].count = dPairCount + c;
+                pairPtr[c] = jb[c].pairs, cntPtr[c] = jb[c].count;
+            }
+            CSCHK(cs_ncc_get_blocks_group_dev(dev, (void*)poseS, nCams, nc.data(), W, H, N, 0.3));
+            CSCHK(cs_ncc_epi_pairs_group_dev(dev, (void*)poseS, nCams, nc.data(), N, nCams - 1, jb.data(), 50.0, 0.80, NCC_PAIR_CAP));
+            CSCHK(cs_newpts_from_pairs_dev(dev, (void*)poseS, nCams, N, pu.data(), pairPtr.data(), cntPtr.data(), NCC_PAIR_CAP, dR[dsti], dT[dsti],
+                                           dMap, dCov, dMapFlags, dNewPt, dFirstFrm, dPf, nMap, dMapCount, i, 80.0, 3.0, PIX, 2, dNpScratch,
+                                           dNpCounts));
             ++nccRuns;
         }
     };
@@ -535,13 +534,17 @@ int main(int argc, char** argv) {
     int iC = 0, iP = 0, iO = 0, iS = 0;
     CSCHK(cs_ba_intercam_last_problem(icam, &iC, &iP, &iO, &iS, nullptr));
     CSCHK(cs_ba_download(ic.ws, iC, iP, iO, nullptr, nullptr, nullptr, nullptr, &si));
+    int mapCountNow = 0, npCounts[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(&mapCountNow, dMapCount, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(npCounts, dNpCounts, sizeof(npCounts), hipMemcpyDeviceToHost));
     printf("{\"frames_per_s\": %.3f, \"ms_per_step\": %.5f, \"steps\": %d, \"warmup\": %d, \"host_enqueue_ms_per_step\": %.5f, "
            "\"cams_per_tracker_launch\": %d, \"pose_ok\": %s, \"min_live_features\": %d, \"joint_lm_steps\": %d, \"joint_cost\": %.6f, "
            "\"intercam_lm_steps\": %d, \"intercam_cost\": %.6f, \"ncc_runs\": %d, \"joint_ba_from_window\": %s, \"joint_cameras\": %d, "
            "\"joint_points\": %d, \"joint_measurements\": %d, \"ba_lag\": %d, \"windows_applied_in_timed_region\": %d, \"apply_wait_errors\": %d, "
-           "\"intercam_static_points\": %d, \"intercam_dynamic_points\": %d}\n",
+           "\"intercam_static_points\": %d, \"intercam_dynamic_points\": %d, \"map_points_at_start\": %d, \"map_points_in_use\": %d, "
+           "\"map_capacity\": %d, \"new_map_points_last_run\": %d}\n",
            steps / dt, dt / steps * 1e3, steps, warmup, dtHost / steps * 1e3, camsPerLaunch, okAll ? "true" : "false", minLive,
            sj.nIterTotal, sj.cost, si.nIterTotal, si.cost, nccRuns, win ? "true" : "false", jC, jP, jO, baLag, nApplied - applied0,
-           cs_ba_output_wait_errors(bout), iS, iP - iS);
+           cs_ba_output_wait_errors(bout), iS, iP - iS, nPts, mapCountNow, nMap, npCounts[0]);
     return 0;
 }
