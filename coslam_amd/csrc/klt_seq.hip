@@ -140,6 +140,7 @@ struct cs_klt {
     int* d_counts;
     float* d_present;
     int presentCap;
+    int* d_feed_ids;         // [presentCap + 1] cs_klt_feed's slots + count
     cs_klt_feature* h_dest;  // pinned
     int* h_counts;           // pinned
     float* h_feat;           // pinned
@@ -704,6 +705,7 @@ int cs_klt_deallocate(cs_klt* k) {
     hipFree(k->d_ctr);
     hipFree(k->d_dest);
     hipFree(k->d_present);
+    hipFree(k->d_feed_ids);
     hipFree(k->d_gran);
     if (k->d_probe) hipFree(k->d_probe);
     k->d_probe = nullptr;
@@ -800,6 +802,7 @@ int cs_klt_allocate(cs_klt* k, int W, int H, int nLevels, int fw, int fh, int pl
     k->d_counts = (int*)(k->d_dest + k->N);
     k->d_err = k->d_counts + 4;
     CS_HIP(hipMalloc((void**)&k->d_present, sizeof(float) * 3 * k->presentCap));
+    CS_HIP(hipMalloc((void**)&k->d_feed_ids, sizeof(int) * ((size_t)k->presentCap + 1)));
     {
         // one granule row per Gauss-Newton pass of the with-gain schedule (+ the initial row): levels visited x iterations
         int visited = 0;
@@ -813,7 +816,7 @@ int cs_klt_allocate(cs_klt* k, int W, int H, int nLevels, int fw, int fh, int pl
     CS_HIP(hipMemsetAsync(k->d_err, 0, 4 * sizeof(int), k->stream));  // error word, frame tag of the hand-off granules, spare
     CS_HIP(hipHostMalloc((void**)&k->h_dest, sizeof(cs_klt_feature) * k->N + 8 * sizeof(int), hipHostMallocDefault));
     CS_HIP(hipHostMalloc((void**)&k->h_counts, sizeof(int) * 8, hipHostMallocDefault));
-    CS_HIP(hipHostMalloc((void**)&k->h_feat, sizeof(float) * 3 * k->presentCap, hipHostMallocDefault));
+    CS_HIP(hipHostMalloc((void**)&k->h_feat, sizeof(float) * (4 * (size_t)k->presentCap + 4), hipHostMallocDefault));   // (+ cs_klt_feed's slots)
     CS_HIP(hipHostMalloc((void**)&k->h_img, (size_t)W * H, hipHostMallocDefault));
     // RTT buffers start undefined in the reference; we define every slot dead
     for (int i = 0; i < 3 * k->N; ++i) k->h_feat[i] = -1.0f;
@@ -1179,39 +1182,88 @@ int cs_klt_track(cs_klt* k, const uint8_t* image, int* nPresent, cs_klt_feature*
     return fetch_results(k, nPresent, dest);
 }
 
-int cs_klt_feed(cs_klt* k, int npts, const float* featPts, int* trackIds, int* nFed) {  // v3d_gpuklt.cpp:808-855
-    CS_REQUIRE(k && k->allocated && nFed && npts >= 0 && (npts == 0 || (featPts && trackIds)), "cs_klt_feed: bad arguments");
+// KLT_SequenceTracker::feedExternFeaturePoints (v3d_gpuklt.cpp:808-855) as one workgroup: every slot of the feature list against
+// the fed points (a slot within sqrt(1e-4) of one is freed -- the distance loop reads the stride-3 point list with stride 2, as
+// shipped, :826-827), then the free slots in slot order take the points in their order (an ordered rank over the list: ballots
+// per wave, the waves' totals through LDS) -- position from the stride-3 list, gain 1 -- and trackIds[k] = the slot point k took.
+// The list is read where readFeatures(AndGain) reads it and written where provideFeatures(AndGain) writes it.
+__global__ __launch_bounds__(1024) void k_feed_extern(int N, int npts, const float* __restrict__ pts, const float* in, float* outA, float* outB,
+                                                      int* __restrict__ trackIds, int* __restrict__ nFed) {
+    __shared__ int wTot[16];
+    __shared__ int sBase;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) sBase = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < N; i0 += 1024) {
+        const int i = i0 + tid;
+        float x = -1.0f, y = 0.0f, g = 0.0f;
+        bool isFree = false;
+        if (i < N) {
+            x = in[3 * i], y = in[3 * i + 1], g = in[3 * i + 2];
+            if (!(x < 0)) {
+                const double radius2 = 1e-4;
+                for (int q = 0; q < npts; ++q) {
+                    const double dx = (double)(pts[2 * q] - x), dy = (double)(pts[2 * q + 1] - y);
+                    if (dx * dx + dy * dy < radius2) {
+                        x = -1.0f;
+                        break;   // (a freed slot is skipped by every later point, :823-824)
+                    }
+                }
+            }
+            isFree = x < 0;
+        }
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(isFree);
+        if (lane == 0) wTot[wv] = __popcll(bal);
+        __syncthreads();
+        int r = sBase;
+        for (int w = 0; w < wv; ++w) r += wTot[w];
+        r += __popcll(bal & ((1ull << lane) - 1ull));
+        if (i < N) {
+            if (isFree && r < npts) {
+                x = pts[3 * r], y = pts[3 * r + 1], g = 1.0f;
+                trackIds[r] = i;
+            }
+            outA[3 * i] = x, outA[3 * i + 1] = y, outA[3 * i + 2] = g;
+            if (outB) outB[3 * i] = x, outB[3 * i + 1] = y, outB[3 * i + 2] = g;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = sBase;
+            for (int w = 0; w < 16; ++w) t += wTot[w];
+            sBase = t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *nFed = sBase < npts ? sBase : npts;
+}
+
+int cs_klt_feed_dev(cs_klt* k, int npts, const float* d_featPts, int* d_trackIds, int* d_nFed) {
+    CS_REQUIRE(k && k->allocated && d_nFed && npts >= 0 && (npts == 0 || (d_featPts && d_trackIds)), "cs_klt_feed_dev: bad arguments");
     int rc = bind_device(k);
     if (rc) return rc;
-    float* c = k->h_feat;
-    CS_HIP(hipMemcpyAsync(c, read_buffer(k), sizeof(float) * 3 * k->N, hipMemcpyDeviceToHost, k->stream));
+    hipLaunchKernelGGL(k_feed_extern, dim3(1), dim3(1024), 0, k->stream, k->N, npts, d_featPts, read_buffer(k), k->d_fb[k->b1],
+                       k->cfg.trackWithGain ? k->d_fb[k->b2] : nullptr, d_trackIds, d_nFed);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+int cs_klt_feed(cs_klt* k, int npts, const float* featPts, int* trackIds, int* nFed) {  // v3d_gpuklt.cpp:808-855
+    CS_REQUIRE(k && k->allocated && nFed && npts >= 0 && (npts == 0 || (featPts && trackIds)), "cs_klt_feed: bad arguments");
+    CS_REQUIRE(npts <= k->presentCap, "cs_klt_feed: more points than the tracker's staging holds");
+    int rc = bind_device(k);
+    if (rc) return rc;
+    // the points up, the kernel, the slots and the count back: the host form of cs_klt_feed_dev
+    if (npts > 0) {
+        memcpy(k->h_feat, featPts, sizeof(float) * 3 * npts);
+        CS_HIP(hipMemcpyAsync(k->d_present, k->h_feat, sizeof(float) * 3 * npts, hipMemcpyHostToDevice, k->stream));
+    }
+    if ((rc = cs_klt_feed_dev(k, npts, k->d_present, k->d_feed_ids, k->d_feed_ids + k->presentCap))) return rc;
+    int* h = (int*)(k->h_feat + 3 * (size_t)k->presentCap);   // (the staging's tail: count, then the slots)
+    CS_HIP(hipMemcpyAsync(h, k->d_feed_ids + k->presentCap, sizeof(int), hipMemcpyDeviceToHost, k->stream));
+    if (npts > 0) CS_HIP(hipMemcpyAsync(h + 1, k->d_feed_ids, sizeof(int) * npts, hipMemcpyDeviceToHost, k->stream));
     CS_HIP(hipStreamSynchronize(k->stream));
-    const double radius2 = 1e-4;
-    for (int q = 0; q < npts; ++q) {
-        for (int i = 0; i < k->N; ++i) {
-            if (c[3 * i] < 0) continue;
-            // stride-2 read of the stride-3 list: reproduces v3d_gpuklt.cpp:826-827 as shipped
-            double dx = (double)(featPts[2 * q] - c[3 * i]);
-            double dy = (double)(featPts[2 * q + 1] - c[3 * i + 1]);
-            if (dx * dx + dy * dy < radius2) c[3 * i] = -1.0f;
-        }
-    }
-    int q = 0;
-    for (int i = 0; i < k->N && q < npts; ++i) {
-        if (c[3 * i] < 0) {
-            c[3 * i] = featPts[3 * q];
-            c[3 * i + 1] = featPts[3 * q + 1];
-            c[3 * i + 2] = 1.0f;
-            trackIds[q] = i;
-            ++q;
-        }
-    }
-    *nFed = q;
-    CS_HIP(hipMemcpyAsync(k->d_fb[k->b1], c, sizeof(float) * 3 * k->N, hipMemcpyHostToDevice, k->stream));
-    if (k->cfg.trackWithGain) {
-        CS_HIP(hipMemcpyAsync(k->d_fb[k->b2], c, sizeof(float) * 3 * k->N, hipMemcpyHostToDevice, k->stream));
-    }
-    CS_HIP(hipStreamSynchronize(k->stream));
+    *nFed = h[0];
+    for (int q = 0; q < h[0]; ++q) trackIds[q] = h[1 + q];
     return CS_OK;
 }
 

@@ -156,6 +156,10 @@ class KLT_SequenceTracker:
                                   C.byref(n)), "cs_klt_feed")
         return n.value, ids[: n.value].copy()
 
+    def feed_dev(self, npts, d_featPts, d_trackIds, d_nFed):
+        """feedExternFeaturePoints with the list, the slots and the count in device memory (asynchronous on the tracker's stream)"""
+        check(self._L.cs_klt_feed_dev(self._h, int(npts), C.c_void_p(d_featPts), C.c_void_p(d_trackIds), C.c_void_p(d_nFed)), "cs_klt_feed_dev")
+
     def advanceFrame(self):
         check(self._L.cs_klt_advance(self._h), "cs_klt_advance")
 

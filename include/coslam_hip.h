@@ -96,6 +96,9 @@ int cs_klt_fetch(cs_klt* k, int* nNew, cs_klt_feature* dest);
 /* KLT_SequenceTracker::feedExternFeaturePoints(npts,featPts,trackIds,nFed), v3d_gpuklt.cpp:808-855.
  * featPts: npts*3 floats (stride 3 as GPUKLT.cpp:165-171 passes it); trackIds: npts ints. */
 int cs_klt_feed(cs_klt* k, int npts, const float* featPts, int* trackIds, int* nFed);
+/* ... with the point list, the slots and the count in device memory, asynchronous on the tracker's stream (one launch: the
+ * distance test per slot, then the free slots ranked in slot order).  cs_klt_feed is this plus the copies. */
+int cs_klt_feed_dev(cs_klt* k, int npts, const float* d_featPts, int* d_trackIds, int* d_nFed);
 /* KLT_SequenceTracker::advanceFrame(), v3d_gpuklt.h:252-259 */
 int cs_klt_advance(cs_klt* k);
 

@@ -353,6 +353,47 @@ def test_feed_extern_points_matches_oracle(hip):
     trk.close()
 
 
+@pytest.mark.parametrize("gain,npts", [(1, 40), (0, 700), (1, 0)])
+def test_feed_on_the_device_matches_oracle(hip, gain, npts):
+    """cs_klt_feed_dev: the list in HBM, one launch; more points than free slots, points on top of tracked features (the stride-2
+    read of the stride-3 list decides which), none at all."""
+    import torch
+
+    W, H = 320, 240
+    sc = Scene(1, W, H, 900, seed=9)
+    img = sc.render(0, 0)
+    cfg = cfg2(nLevels=2, minCornerness=800.0, trackWithGain=gain)
+    trk, ora = make_pair(cfg, W, H, 2, 24, 20)
+    trk.detect(img)
+    ora.detect(img)
+    trk.advanceFrame()
+    ora.advanceFrame()
+    feats = ora.read_features().reshape(-1, 3)
+    live = feats[feats[:, 0] >= 0]
+    rng = np.random.default_rng(5)
+    pts = np.zeros((npts, 3), np.float32)
+    if npts:
+        pts[:, :2] = rng.uniform(0.1, 0.9, (npts, 2))
+        # the distance loop reads floats 2k, 2k+1 of the flat list: put tracked features' positions THERE
+        flat = pts.reshape(-1)
+        for k in range(0, min(npts, 2 * (len(live) // 2)), 3):
+            flat[2 * k], flat[2 * k + 1] = live[k % len(live), 0], live[k % len(live), 1]
+    n_o, ids_o = ora.feedExternFeaturePoints(pts.copy())
+    dev = torch.device("cuda:0")
+    d_pts = torch.from_numpy(pts.reshape(-1).copy()).to(dev) if npts else torch.zeros(3, dtype=torch.float32, device=dev)
+    d_ids = torch.full((max(npts, 1),), -1, dtype=torch.int32, device=dev)
+    d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    trk.feed_dev(npts, d_pts.data_ptr(), d_ids.data_ptr(), d_n.data_ptr())
+    got = trk.read_features()
+    n_g = int(d_n.item())
+    assert n_g == n_o and np.array_equal(d_ids.cpu().numpy()[:n_g], ids_o)
+    if npts == 700:
+        assert n_g < npts          # the list has 480 slots
+    assert np.array_equal(got, ora.read_features())
+    trk.close()
+
+
 def test_device_resident_entry_points(hip):
     """*_dev variants: image and results stay in HBM; same answer as the host-pointer variants."""
     import torch
