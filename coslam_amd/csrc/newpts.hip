@@ -28,10 +28,11 @@
 namespace {
 
 constexpr int NP_MAX_CAMS = 16, NP_MAX_CAND = 2048, NP_MAX_SEEDS = 512, NP_MAX_TRACKS = 4096, NP_MAX_N = 32768;
-constexpr int NP_BAL_WORDS = 512;   // map points per round of the seed scan / 64
+constexpr int NP_BAL_WORDS = 512;
+constexpr int NP_MAX_DYN = 4096;     // features of certain dynamic points decidePointType's mask is drawn from (frame sizes up to 4032 x 4032)   // map points per round of the seed scan / 64
 
 struct NpArgs {
-    int nCams, N, mapCap, curFrame, pairCap, minLen;
+    int nCams, N, mapCap, curFrame, pairCap, minLen, W, H;
     double maxDisp, maxRpErr, sigma;
     const cs_ncc_pair* pairs[NP_MAX_CAMS];   // candidates of camera pair (a, a + 1): cs_ncc_epi_pairs_group_dev's list
     const int* pairCount[NP_MAX_CAMS];
@@ -45,7 +46,8 @@ struct NpArgs {
     unsigned* rowMask;                       // scratch [nCams - 1][N / 32 words]: bit i = feature i of camera a has a match in a + 1
     unsigned* colMask;                       // scratch [nCams - 1][N / 32 words]: bit j = feature j of camera a + 1 is such a match
     int* counts;                             // [4 + nCams] out: new points, tracks, tracks >= minLen, flags (bit 0: a candidate list
-                                             // overflowed, bit 1: the map is full), then the matches of every pair
+                                             // overflowed, bit 1: the map is full, bit 2: more than NP_MAX_DYN dynamic features), then the
+                                             // matches of every pair
 };
 
 __device__ __forceinline__ bool np_before(double sa, unsigned ia, double sb, unsigned ib) {   // falling score, then rising (row, column)
@@ -189,8 +191,7 @@ struct NpView {
 __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
     __shared__ int sScan[256];
     __shared__ int sBase, sNTracks;
-    __shared__ unsigned short sTrkCam[NP_MAX_TRACKS];    // first camera of the track
-    __shared__ unsigned short sTrkSlot[NP_MAX_TRACKS];   // its slot there
+    __shared__ unsigned sTrk[NP_MAX_TRACKS];             // first camera of the track << 16 | its slot there
     __shared__ unsigned char sValid[NP_MAX_TRACKS];
     const int tid = threadIdx.x, N = A.N, C = A.nCams, nP = C - 1;
     if (tid == 0) sBase = 0, sNTracks = 0;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
         while (bits) {
             const int bit = __ffs(bits) - 1;
             bits &= bits - 1;
-            if (rank < NP_MAX_TRACKS) sTrkCam[rank] = (unsigned short)a, sTrkSlot[rank] = (unsigned short)(32 * q + bit);
+            if (rank < NP_MAX_TRACKS) sTrk[rank] = ((unsigned)a << 16) | (unsigned)(32 * q + bit);
             ++rank;
         }
         __syncthreads();
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
         double M[3] = {0, 0, 0}, cov[9];
         unsigned char fl = 0;
         if (tk < nTracks) {
-            int c = sTrkCam[tk], s = sTrkSlot[tk];
+            int c = (int)(sTrk[tk] >> 16), s = (int)(sTrk[tk] & 0xFFFFu);
             v[nv].c = c, v[nv].s = s, ++nv;
             while (c < nP) {   // follow the chain: camera c's slot s matched into camera c + 1
                 if (!((A.rowMask[(size_t)c * nWords + (s >> 5)] >> (s & 31)) & 1u)) break;
@@ -320,9 +321,7 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
                     if (nDyn > 1) {
                         fl = CS_MAP_DYNAMIC;                                                     // :253-254
                     } else {
-                        // :263-264 setUncertain().  decidePointType (:62-91) then calls setLocalStatic() on an uncertain point none of
-                        // whose features lies within 20 pixels of a dynamic map point's feature: that writes the type the constructor
-                        // already gave (iLocalType 0 = static) and leaves bUncertain alone -- nothing to do either way
+                        // :263-264 setUncertain(); decidePointType below may make it certain static
                         fl = CS_MAP_UNCERTAIN;
                     }
                 }
@@ -360,11 +359,66 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
     }
     if (nLong && A.counts) atomicAdd(A.counts + 2, nLong);
     __syncthreads();
+    const int first = *A.mapCount;
+    int added = sBase;
+    if (first + added > A.mapCap) added = A.mapCap - first;
+    // ---- decidePointType (:25-91): a new UNCERTAIN point none of whose features lies within 20 pixels (in rounded coordinates, both
+    // axes) of a feature of this frame that belongs to a CERTAIN dynamic map point becomes certain static -- setLocalStatic()
+    // clears bUncertain (src/slam/SL_MapPoint.cpp:104-109).  The dynamic points of this very run count: reconstructTracks'
+    // addFeature already gave their features the point (src/slam/SL_MapPoint.cpp:58-69), so the scan below runs over the records
+    // as they stand now.  (The barrier above makes this workgroup's writes to the map and to slot2map visible to all its threads.)
+    bool anyUncertain = false;
+    for (int q = tid; q < added; q += 256) anyUncertain |= A.mapFlags[first + q] == CS_MAP_UNCERTAIN;
+    if (__syncthreads_or(anyUncertain ? 1 : 0)) {
+        __shared__ int sNDyn;
+        unsigned* sDyn = sTrk;   // the tracks' table is done with: [NP_MAX_DYN] camera << 24 | (y + 64) << 12 | (x + 64)
+        static_assert(NP_MAX_TRACKS >= NP_MAX_DYN && NP_MAX_CAMS <= 256 && NP_MAX_N <= 65536, "the dynamic features' list reuses the track table");
+        if (tid == 0) sNDyn = 0;
+        __syncthreads();
+        const int total = C * N;
+        for (int e = tid; e < total; e += 256) {
+            const int c = e / N, sl = e - c * N;
+            const int st = A.cam[c].state[sl], m = A.cam[c].slot2map[sl];
+            if ((st == 0 || st == 1) && m >= 0 && m < A.mapCap && A.mapFlags[m] == CS_MAP_DYNAMIC) {
+                const int x = (int)(A.cam[c].xy[sl] + 0.5), y = (int)(A.cam[c].xy[N + sl] + 0.5);
+                // (a feature whose 41 x 41 square misses the image marks nothing)
+                if (x + 20 >= 0 && x - 20 < A.W && y + 20 >= 0 && y - 20 < A.H) {
+                    const int k = atomicAdd(&sNDyn, 1);
+                    if (k < NP_MAX_DYN) sDyn[k] = ((unsigned)c << 24) | ((unsigned)(y + 64) << 12) | (unsigned)(x + 64);
+                }
+            }
+        }
+        __syncthreads();
+        int nDynF = sNDyn;
+        if (nDynF > NP_MAX_DYN) {
+            nDynF = NP_MAX_DYN;
+            if (tid == 0 && A.counts) atomicOr(A.counts + 3, 4);
+        }
+        for (int q = tid; q < added; q += 256) {
+            const int m = first + q;
+            if (A.mapFlags[m] != CS_MAP_UNCERTAIN) continue;
+            bool isStatic = true;
+            for (int c = 0; c < C && isStatic; ++c) {
+                const int sl = A.pointFeat[(size_t)m * C + c];
+                if (sl < 0) continue;
+                const int x = (int)(A.cam[c].xy[sl] + 0.5), y = (int)(A.cam[c].xy[N + sl] + 0.5);
+                if (x < 0 || x >= A.W || y < 0 || y >= A.H) continue;
+                for (int k = 0; k < nDynF; ++k) {
+                    const unsigned d = sDyn[k];
+                    if ((int)(d >> 24) != c) continue;
+                    const int dx = (int)(d & 0xFFFu) - 64 - x, dy = (int)((d >> 12) & 0xFFFu) - 64 - y;
+                    if (dx >= -20 && dx <= 20 && dy >= -20 && dy <= 20) {
+                        isStatic = false;
+                        break;
+                    }
+                }
+            }
+            if (isStatic) A.mapFlags[m] = 0;
+        }
+    }
     if (tid == 0) {
-        int added = sBase;
-        if (*A.mapCount + added > A.mapCap) added = A.mapCap - *A.mapCount;
         if (A.counts) A.counts[0] = added, A.counts[1] = nTracks;
-        *A.mapCount += added;
+        *A.mapCount = first + added;
     }
 }
 
@@ -408,7 +462,11 @@ extern "C" int cs_newpts_from_pairs_dev(int device, void* hip_stream, int nCams,
                                         const cs_ncc_pair* const* d_pairs, const int* const* d_pairCount, int pairCap, const double* d_R,
                                         const double* d_t, double* d_mapPts, double* d_mapCov, unsigned char* d_mapFlags, unsigned char* d_newPt,
                                         int* d_firstFrame, int* d_pointFeat, int mapCap, int* d_mapCount, int curFrame, double maxDisp,
-                                        double maxRpErr, double pixelErrVar, int minLen, void* d_scratch, int* d_counts) {
+                                        double maxRpErr, double pixelErrVar, int minLen, int W, int H, void* d_scratch, int* d_counts) {
+    if (W < 1 || H < 1 || W > 4032 || H > 4032) {
+        cs_set_error("cs_newpts_from_pairs_dev: frame size 1..4032");
+        return CS_ERR_INVALID;
+    }
     if (nCams < 2 || nCams > NP_MAX_CAMS || N < 1 || N > NP_MAX_N || !cams || !d_pairs || !d_pairCount || pairCap < 1 || !d_R || !d_t || !d_mapPts ||
         !d_mapCov || !d_mapFlags || !d_newPt || !d_firstFrame || !d_pointFeat || mapCap < 1 || !d_mapCount || !d_scratch || minLen < 2) {
         cs_set_error("cs_newpts_from_pairs_dev: bad arguments (2..%d cameras, N <= %d)", NP_MAX_CAMS, NP_MAX_N);
@@ -416,7 +474,7 @@ extern "C" int cs_newpts_from_pairs_dev(int device, void* hip_stream, int nCams,
     }
     NpArgs A;
     memset(&A, 0, sizeof(A));
-    A.nCams = nCams, A.N = N, A.mapCap = mapCap, A.curFrame = curFrame, A.pairCap = pairCap, A.minLen = minLen;
+    A.nCams = nCams, A.N = N, A.mapCap = mapCap, A.curFrame = curFrame, A.pairCap = pairCap, A.minLen = minLen, A.W = W, A.H = H;
     A.maxDisp = maxDisp, A.maxRpErr = maxRpErr, A.sigma = pixelErrVar;
     for (int a = 0; a + 1 < nCams; ++a) {
         if (!d_pairs[a] || !d_pairCount[a]) {

@@ -327,7 +327,7 @@ class FrameLoop:
         newpts_from_pairs_dev(s_, ncc["job"], N, cfg.ncc_pair_cap, self.d_R[dst].data_ptr(), self.d_t[dst].data_ptr(), self.d_map.data_ptr(),
                               self.d_cov.data_ptr(), self.d_mapflags.data_ptr(), self.d_newpt.data_ptr(), self.d_firstfrm.data_ptr(),
                               self.d_pf.data_ptr(), self.n_map, self.d_mapcount.data_ptr(), i, ncc["np_scr"].data_ptr(), ncc["np_cnt"].data_ptr(),
-                              maxDisp=80.0, maxRpErr=3.0, pixelErrVar=PIXEL_ERR_VAR, minLen=2, device=self.device)
+                              maxDisp=80.0, maxRpErr=3.0, pixelErrVar=PIXEL_ERR_VAR, minLen=2, device=self.device, W=cfg.W, H=cfg.H)
         ncc["runs"] += 1
 
     def _gather_ncc_records(self):

@@ -35,9 +35,9 @@ class NewPtsJob:
 
 
 def newpts_from_pairs_dev(stream_ptr, job, N, pairCap, d_R, d_t, d_mapPts, d_mapCov, d_mapFlags, d_newPt, d_firstFrame, d_pointFeat, mapCap,
-                          d_mapCount, curFrame, d_scratch, d_counts=0, maxDisp=80.0, maxRpErr=3.0, pixelErrVar=10.0, minLen=2, device=0):
+                          d_mapCount, curFrame, d_scratch, d_counts=0, maxDisp=80.0, maxRpErr=3.0, pixelErrVar=10.0, minLen=2, device=0, W=640, H=480):
     vp = C.c_void_p
     check(lib().cs_newpts_from_pairs_dev(int(device), vp(stream_ptr), job.n, int(N), job.cams, job.pairs, job.counts, int(pairCap), vp(d_R), vp(d_t),
                                          vp(d_mapPts), vp(d_mapCov), vp(d_mapFlags), vp(d_newPt), vp(d_firstFrame), vp(d_pointFeat), int(mapCap),
                                          vp(d_mapCount), int(curFrame), C.c_double(maxDisp), C.c_double(maxRpErr), C.c_double(pixelErrVar),
-                                         int(minLen), vp(d_scratch), vp(d_counts)), "cs_newpts_from_pairs_dev")
+                                         int(minLen), int(W), int(H), vp(d_scratch), vp(d_counts)), "cs_newpts_from_pairs_dev")

@@ -669,11 +669,13 @@ int cs_ncc_match_between(int device, const unsigned char* img1, int W1, int H1, 
  * reprojErr may be NULL): the frame's records; d_R / d_t: the cameras' current poses; the map as structure-of-arrays with capacity
  * mapCap of which *d_mapCount are in use.  Out: every track of >= minLen (2) views whose triangulation lies within maxRpErr (3.0)
  * pixels of each view and in front of each camera is APPENDED to the map in track order (position, covariance, flags: more than one
- * DYNAMIC feature CS_MAP_DYNAMIC, else CS_MAP_UNCERTAIN; newPt 1; firstFrame curFrame; its row of d_pointFeat), *d_mapCount grows, the
+ * DYNAMIC feature CS_MAP_DYNAMIC, else CS_MAP_UNCERTAIN -- and decidePointType (:25-91, frame size W x H): an uncertain new point none of
+ * whose features lies within 20 pixels of a feature of a CERTAIN dynamic point of this frame (this run's included) becomes certain
+ * static, flags 0; newPt 1; firstFrame curFrame; its row of d_pointFeat), *d_mapCount grows, the
  * features' slot2map entries take the point (written through cams[c].slot2map), their reprojErr the pixel error.  Seeds = the map
  * points (not false, not uncertain) with a feature of this frame in both cameras, at most 512 per pair (map order); maxDisp 80.
  * d_counts [4 + nCams] or NULL: new points, tracks, tracks of >= minLen views, flags (bit 0: a pair had more than 2048 guided
- * candidates -- the rest were dropped; bit 1: the map is full), then the matches of every pair.  d_scratch:
+ * candidates -- the rest were dropped; bit 1: the map is full; bit 2: more than 4096 dynamic features), then the matches of every pair.  d_scratch:
  * cs_newpts_scratch_bytes.  greedyNCCMatch, greedyGuidedNCCMatch, getDisparityMat are un-vendored LibVisualSLAM: OUR definitions
  * (csrc/newpts.hip).  NewMapPtsNCC's candidates are the features of this frame on tracks of more than three frames
  * that are unmapped or mapped to a FALSE point (addSlam, SL_NewMapPointsInterCam.h:103-131): cs_ncc_candidate_mask_dev writes that
@@ -686,7 +688,7 @@ int cs_newpts_from_pairs_dev(int device, void* hip_stream, int nCams, int N, con
                              const cs_ncc_pair* const* d_pairs /* host array [nCams - 1] */, const int* const* d_pairCount /* host array */,
                              int pairCap, const double* d_R, const double* d_t, double* d_mapPts, double* d_mapCov, unsigned char* d_mapFlags,
                              unsigned char* d_newPt, int* d_firstFrame, int* d_pointFeat, int mapCap, int* d_mapCount, int curFrame,
-                             double maxDisp, double maxRpErr, double pixelErrVar, int minLen, void* d_scratch, int* d_counts);
+                             double maxDisp, double maxRpErr, double pixelErrVar, int minLen, int W, int H, void* d_scratch, int* d_counts);
 
 /* ------------------------------------------------------------------------------------------
  * Robust multi-camera bundle adjustment

@@ -876,7 +876,7 @@ def register_decide_static(slot, flags, mergeable, mapFlags, pointFeat, slot2map
 
 
 def new_map_points_from_pairs(N, pairs, Ks, iKs, Rs, ts, xy, state, slot2map, isStatic, mapPts, mapCov, mapFlags, newPt, firstFrame, pointFeat,
-                              map_count, cur_frame, max_disp=80.0, max_rp_err=3.0, sigma=10.0, min_len=2, max_seeds=512, reproj=None):
+                              map_count, cur_frame, max_disp=80.0, max_rp_err=3.0, sigma=10.0, min_len=2, max_seeds=512, reproj=None, W=640, H=480):
     """NewMapPtsNCC::run + output behind getEpiNccMat (reference src/app/SL_NewMapPointsInterCam.cpp:150-161, 163-192, 194-270, 295-316,
     631-690) restated over structure-of-arrays records (TEST INFRASTRUCTURE, plain Python / numpy, operation for operation what
     coslam_amd/csrc/newpts.hip does): per consecutive camera pair the candidate list (i, j, epi, ncc) of the NCC stage -> seeds,
@@ -1000,7 +1000,7 @@ def new_map_points_from_pairs(N, pairs, Ks, iKs, Rs, ts, xy, state, slot2map, is
         map_count += 1
         mapPts[m], mapCov[m] = M, cov
         n_dyn = sum(1 for c, s in tk if isStatic is not None and not isStatic[c][s])
-        mapFlags[m] = 1 if n_dyn > 1 else 4            # setLocalDynamic / setUncertain (:253-264); decidePointType changes neither
+        mapFlags[m] = 1 if n_dyn > 1 else 4            # setLocalDynamic / setUncertain (:253-264); decidePointType below
         newPt[m], firstFrame[m] = 1, cur_frame
         pf[m, :] = -1
         for k, (c, s) in enumerate(tk):
@@ -1009,4 +1009,30 @@ def new_map_points_from_pairs(N, pairs, Ks, iKs, Rs, ts, xy, state, slot2map, is
             if reproj is not None:
                 reproj[c][s] = errs[k]
         new.append(m)
+    # decidePointType (:25-91): the features of this frame on CERTAIN dynamic map points -- this run's dynamic points included,
+    # addFeature gave their features the point already (src/slam/SL_MapPoint.cpp:58-69) -- mark 41 x 41 squares; a new uncertain point
+    # with no feature inside one becomes certain static (setLocalStatic() clears bUncertain, SL_MapPoint.cpp:104-109)
+    if any(int(mapFlags[m]) == 4 for m in new):
+        dyn = [[] for _ in range(nC)]
+        for c in range(nC):
+            for s_ in range(N):
+                m = int(slot2map[c][s_])
+                if int(state[c][s_]) in (0, 1) and 0 <= m < cap and int(mapFlags[m]) == 1:
+                    dyn[c].append((int(xy[c][s_] + 0.5), int(xy[c][N + s_] + 0.5)))
+        for m in new:
+            if int(mapFlags[m]) != 4:
+                continue
+            is_static = True
+            for c in range(nC):
+                s_ = int(pf[m, c])
+                if s_ < 0:
+                    continue
+                x, y = int(xy[c][s_] + 0.5), int(xy[c][N + s_] + 0.5)
+                if not (0 <= x < W and 0 <= y < H):
+                    continue
+                if any(abs(x - dx) <= 20 and abs(y - dy) <= 20 for dx, dy in dyn[c]):
+                    is_static = False
+                    break
+            if is_static:
+                mapFlags[m] = 0
     return dict(matches=match, tracks=tracks, new=new, map_count=map_count)

@@ -7,7 +7,6 @@
 #define REF_SHIM_NOT_ON_PATH_H
 template <class... A> void scaleDownAvg(const A&...);
 template <class... A> int searchNearestPoint(const A&...);
-template <class... A> double reprojErrorSingle(const A&...);
 template <class... A> bool intraCamEstimateEpi(const A&...);
 template <class... A> double getCameraDistance(const A&...);
 template <class... A> void getBinTriangulateCovMat(const A&...);
@@ -22,7 +21,10 @@ void getInvK(const double* K, double* iK);
 double getAbsRadiansBetween(const double* M, const double* C0, const double* C);
 bool isAtCameraBack(const double* R, const double* t, const double* M);   /* isDynamicPoint (:283) */
 double dist3(const double* a, const double* b);                           /* isDynamicPoint (:290) */
+/* NewMapPtsNCC::reconstructTracks (src/app/SL_NewMapPointsInterCam.cpp:247): the pixel distance of m from the projection of M */
+double reprojErrorSingle(const double* K, const double* R, const double* t, const double* M, const double* m);
 #else
+template <class... A> double reprojErrorSingle(const A&...);
 template <class... A> bool isAtCameraBack(const A&...);
 template <class... A> double dist3(const A&...);
 template <class... A> void normPoint(const A&...);

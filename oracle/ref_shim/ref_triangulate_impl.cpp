@@ -11,6 +11,7 @@
 //                         equations, symmetric 3x3 inverse by cofactors
 //   getTriangulateCovMat  sigma^2 (sum_i J_i^T J_i)^-1 with J_i = d project_i / dM at M
 //   isAtCameraBack, dist3 (isDynamicPoint, :251-312)
+//   reprojErrorSingle     Euclidean pixel distance of m from the projection of M (NewMapPtsNCC::reconstructTracks)
 #include <cmath>
 #include <cstring>
 
@@ -94,4 +95,12 @@ bool isAtCameraBack(const double* R, const double* t, const double* M) { return 
 double dist3(const double* a, const double* b) {
     const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
     return sqrt((dx * dx + dy * dy) + dz * dz);
+}
+
+void project(const double* K, const double* R, const double* t, const double* M, double* m);   // shim_impl.cpp
+double reprojErrorSingle(const double* K, const double* R, const double* t, const double* M, const double* m) {
+    double rm[2];
+    project(K, R, t, M, rm);
+    const double dx = m[0] - rm[0], dy = m[1] - rm[1];
+    return sqrt(dx * dx + dy * dy);
 }

@@ -286,6 +286,73 @@ def intercam_case():
     return out
 
 
+def newpts_case():
+    """the reference's own featTracksFromMatches + NewMapPtsNCC::reconstructTracks + decidePointType (oracle/_ref/ref_newpts_test golden,
+    CPU): three scenes of cameras, candidate features, given matches, dynamic points' features; the tracks in the reference's
+    numbering and the new map points it made of them."""
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_newpts_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_newpts_test missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "np.bin")
+        subprocess.run([exe, "golden", path], check=True, stdout=subprocess.DEVNULL)
+        raw = open(path, "rb").read()
+    o = [0]
+
+    def ints(n):
+        v = np.frombuffer(raw, dtype=np.int32, count=n, offset=o[0]).copy()
+        o[0] += 4 * n
+        return v
+
+    def dbls(n):
+        v = np.frombuffer(raw, dtype=np.float64, count=n, offset=o[0]).copy()
+        o[0] += 8 * n
+        return v
+
+    out = {}
+    (ns,) = ints(1)
+    out["n_scenes"] = np.int32(ns)
+    for sc in range(ns):
+        nc, N, frame, W, H = (int(v) for v in ints(5))
+        k = lambda n: f"s{sc}_{n}"   # noqa: E731
+        out[k("dims")] = np.array([nc, N, frame, W, H], np.int32)
+        out[k("K")] = dbls(9)
+        Rt = dbls(12 * nc).reshape(nc, 12)
+        out[k("R")], out[k("t")] = Rt[:, :9], Rt[:, 9:]
+        xy, st = [], []
+        for c in range(nc):
+            xy.append(dbls(2 * N)), st.append(ints(N).astype(np.uint8))
+            (nd,) = ints(1)
+            out[k(f"dyn{c}")] = dbls(2 * int(nd)).reshape(-1, 2)
+            (no,) = ints(1)
+            out[k(f"other{c}")] = dbls(2 * int(no)).reshape(-1, 2)
+        out[k("xy")], out[k("isStatic")] = np.stack(xy), np.stack(st)
+        for a in range(nc - 1):
+            (nm,) = ints(1)
+            out[k(f"match{a}")] = ints(2 * int(nm)).reshape(-1, 2)
+        (nt,) = ints(1)
+        lens, flat = [], []
+        for _ in range(int(nt)):
+            (ln,) = ints(1)
+            lens.append(int(ln)), flat.append(ints(2 * int(ln)).reshape(-1, 2))
+        out[k("track_len")] = np.asarray(lens, np.int32)
+        out[k("track_views")] = np.concatenate(flat) if flat else np.zeros((0, 2), np.int32)
+        (nn,) = ints(1)
+        M, cov, fl, ff, feat = [], [], [], [], []
+        for _ in range(int(nn)):
+            M.append(dbls(3)), cov.append(dbls(9))
+            a_, b_ = ints(2)
+            fl.append(int(a_)), ff.append(int(b_)), feat.append(ints(nc))
+        out[k("new_M")], out[k("new_cov")] = np.stack(M), np.stack(cov)
+        out[k("new_flags")], out[k("new_first")], out[k("new_feat")] = np.asarray(fl, np.uint8), np.asarray(ff, np.int32), np.stack(feat)
+        out[k("reproj")] = dbls(nc * N).reshape(nc, N)
+    assert o[0] == len(raw)
+    return out
+
+
 def mergability_case():
     """the reference's own CoSLAM::staticCheckMergability (oracle/_ref/ref_mergability_test golden, CPU): 150 tracks of 1..24
     frames, newest first, and its verdicts."""
@@ -499,7 +566,7 @@ def classify_case():
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "update_points", "classify", "intercam"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "update_points", "classify", "intercam", "newpts"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -522,4 +589,6 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "update_points_golden.npz"), **update_points_case())
     if "classify" in which:
         np.savez_compressed(os.path.join(HERE, "classify_golden.npz"), **classify_case())
+    if "newpts" in which:
+        np.savez_compressed(os.path.join(HERE, "newpts_golden.npz"), **newpts_case())
     print("golden fixtures written")

@@ -7,6 +7,7 @@ import pytest
 from tests.poseupdate_scene import Scene
 
 pytestmark = pytest.mark.gpu
+W_IMG, H_IMG = 640, 480
 
 
 def _scene(seed, nC=4, N=512, nMap=400, extra=300):
@@ -72,7 +73,7 @@ def test_new_map_points_equal_the_restatement(hip, seed, max_disp):
              first=np.zeros(cap, np.int32), pf=S["pf"].copy(), s2m=[x.copy() for x in S["s2m"]], reproj=[np.zeros(N) for _ in range(nC)])
     res = oracle.new_map_points_from_pairs(N, S["pairs"], [sc.K] * nC, [sc.iK] * nC, S["R"], S["t"], S["xy"], S["state"], o["s2m"], S["is_static"],
                                            o["mapPts"], o["mapCov"], o["flags"], o["newPt"], o["first"], o["pf"], nMap, S["frame"],
-                                           max_disp=max_disp, reproj=o["reproj"])
+                                           max_disp=max_disp, reproj=o["reproj"], W=W_IMG, H=H_IMG)
     assert len(res["new"]) > 20 and len(res["tracks"]) > len(res["new"]) and any(len(t) >= 3 for t in res["tracks"])
     dev = torch.device("cuda:0")
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
@@ -99,7 +100,7 @@ def test_new_map_points_equal_the_restatement(hip, seed, max_disp):
     dR, dT = d(S["R"]), d(S["t"])
     newpts_from_pairs_dev(torch.cuda.current_stream().cuda_stream, job, N, CAPP, dR.data_ptr(), dT.data_ptr(), dM.data_ptr(), dC.data_ptr(),
                           dF.data_ptr(), dNew.data_ptr(), dFirst.data_ptr(), dPf.data_ptr(), cap, dCount.data_ptr(), S["frame"], dScr.data_ptr(),
-                          dOut.data_ptr(), maxDisp=max_disp)
+                          dOut.data_ptr(), maxDisp=max_disp, W=W_IMG, H=H_IMG)
     torch.cuda.synchronize()
     out = dOut.cpu().tolist()
     assert out[0] == len(res["new"]) and out[1] == len(res["tracks"]) and out[3] == 0
@@ -123,7 +124,8 @@ def test_new_map_points_equal_the_restatement(hip, seed, max_disp):
     assert np.array_equal(dPf.cpu().numpy(), o["pf"])
     for c in range(nC):
         assert np.array_equal(ds2m[c].cpu().numpy(), o["s2m"][c]) and np.array_equal(drep[c].cpu().numpy(), o["reproj"][c])
-    assert (o["flags"][res["new"]] == 4).sum() > 10      # new uncertain points; dynamic ones need two DYNAMIC features
+    fl_new = o["flags"][res["new"]]
+    assert ((fl_new == 4) | (fl_new == 0)).sum() > 10    # uncertain, or certain static after decidePointType; dynamic ones need two DYNAMIC features
 
 
 def test_candidate_mask_is_addslams_filter(hip):
@@ -152,3 +154,59 @@ def test_candidate_mask_is_addslams_filter(hip):
     f1, f2 = span[:, :N], span[:, N:]
     want = ((state == 0) | (state == 1)) & (f1 >= 0) & (f2 - f1 >= 3) & ((s2m < 0) | ((flags[np.clip(s2m, 0, cap - 1)] & 2) != 0))
     assert np.array_equal(dv.cpu().numpy(), want.astype(np.int32)) and 20 < want.sum() < nC * N - 20
+
+
+def test_new_map_points_equal_the_reference_golden(hip):
+    """cs_newpts_from_pairs_dev on the reference's own scenes (tests/golden/newpts_golden.npz: featTracksFromMatches +
+    NewMapPtsNCC::reconstructTracks + decidePointType run by the reference's code): the same new points in the same order, position and
+    covariance bit for bit, the type decidePointType leaves (certain static / uncertain / dynamic), features, reprojErr."""
+    import torch
+
+    from coslam_amd.ncc import NCC_PAIR_DTYPE
+    from coslam_amd.newpts import NewPtsJob, newpts_from_pairs_dev, newpts_scratch_bytes
+    from tests.newpts_golden_util import GOLDEN, exact_inverse_of, scene
+
+    g = np.load(GOLDEN)
+    dev = torch.device("cuda:0")
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    for sc in range(int(g["n_scenes"])):
+        S = scene(g, sc)
+        nc, N, NS, cap, n_old = S["nc"], S["N"], S["NS"], S["cap"], S["n_old"]
+        dK, diK = d(S["K"].reshape(9)), d(exact_inverse_of(S["K"]).reshape(9))
+        dxy, dst, ds2m, dstat = d(np.stack(S["xy"])), d(np.stack(S["state"])), d(np.stack(S["s2m"])), d(np.stack(S["is_static"]))
+        drep = torch.zeros((nc, NS), dtype=torch.float64, device=dev)
+        CAPP = 1024
+        dpairs = torch.zeros((nc - 1, CAPP * NCC_PAIR_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        dcnt = torch.zeros(nc - 1, dtype=torch.int32, device=dev)
+        for a in range(nc - 1):
+            arr = np.zeros(len(S["pairs"][a]), dtype=NCC_PAIR_DTYPE)
+            for k, q in enumerate(S["pairs"][a]):
+                arr[k] = q
+            dpairs[a, :arr.nbytes] = torch.from_numpy(arr.view(np.uint8)).to(dev)
+            dcnt[a] = len(arr)
+        cams = [dict(K=dK.data_ptr(), iK=diK.data_ptr(), xy=dxy[c].data_ptr(), state=dst[c].data_ptr(), slot2map=ds2m[c].data_ptr(),
+                     isStatic=dstat[c].data_ptr(), reprojErr=drep[c].data_ptr()) for c in range(nc)]
+        job = NewPtsJob(cams, [dpairs[a].data_ptr() for a in range(nc - 1)], [dcnt[a:a + 1].data_ptr() for a in range(nc - 1)])
+        dM, dC = torch.zeros((cap, 3), dtype=torch.float64, device=dev), torch.zeros((cap, 9), dtype=torch.float64, device=dev)
+        dF, dPf = d(S["flags"]), d(S["pf"])
+        dNew, dFirst = torch.zeros(cap, dtype=torch.uint8, device=dev), torch.zeros(cap, dtype=torch.int32, device=dev)
+        dCount = torch.tensor([n_old], dtype=torch.int32, device=dev)
+        dScr = torch.zeros(newpts_scratch_bytes(nc, NS), dtype=torch.uint8, device=dev)
+        dOut = torch.zeros(4 + nc, dtype=torch.int32, device=dev)
+        dR, dT = d(S["R"]), d(S["t"])
+        newpts_from_pairs_dev(torch.cuda.current_stream().cuda_stream, job, NS, CAPP, dR.data_ptr(), dT.data_ptr(), dM.data_ptr(), dC.data_ptr(),
+                              dF.data_ptr(), dNew.data_ptr(), dFirst.data_ptr(), dPf.data_ptr(), cap, dCount.data_ptr(), S["frame"], dScr.data_ptr(),
+                              dOut.data_ptr(), maxDisp=80.0, W=S["W"], H=S["H"])
+        torch.cuda.synchronize()
+        w = S["want"]
+        out = dOut.cpu().tolist()
+        n_new = len(w["M"])
+        assert out[0] == n_new and out[1] == len(w["track_len"]) and out[2] == int((w["track_len"] >= 2).sum()) and out[3] == 0
+        assert int(dCount.item()) == n_old + n_new
+        new = slice(n_old, n_old + n_new)
+        assert np.array_equal(dM.cpu().numpy()[new], w["M"]) and np.array_equal(dC.cpu().numpy()[new], w["cov"])
+        assert np.array_equal(dF.cpu().numpy()[new], w["flags"]) and np.array_equal(dFirst.cpu().numpy()[new], w["first"])
+        assert np.array_equal(dPf.cpu().numpy()[new], w["feat"]) and np.all(dNew.cpu().numpy()[new] == 1)
+        assert np.array_equal(dF.cpu().numpy()[:n_old], S["flags"][:n_old])          # the old points keep their types
+        for c in range(nc):
+            assert np.array_equal(drep[c].cpu().numpy()[:N], w["reproj"][c])

@@ -443,7 +443,7 @@ int main(int argc, char** argv) {
             CSCHK(cs_ncc_get_blocks_group_dev(dev, (void*)poseS, nCams, nc.data(), W, H, N, 0.3));
             CSCHK(cs_ncc_epi_pairs_group_dev(dev, (void*)poseS, nCams, nc.data(), N, nCams - 1, jb.data(), 50.0, 0.80, NCC_PAIR_CAP));
             CSCHK(cs_newpts_from_pairs_dev(dev, (void*)poseS, nCams, N, pu.data(), pairPtr.data(), cntPtr.data(), NCC_PAIR_CAP, dR[dsti], dT[dsti],
-                                           dMap, dCov, dMapFlags, dNewPt, dFirstFrm, dPf, nMap, dMapCount, i, 80.0, 3.0, PIX, 2, dNpScratch,
+                                           dMap, dCov, dMapFlags, dNewPt, dFirstFrm, dPf, nMap, dMapCount, i, 80.0, 3.0, PIX, 2, W, H, dNpScratch,
                                            dNpCounts));
             ++nccRuns;
         }
