@@ -522,6 +522,8 @@ def main():
         for _ in range(n):
             step(n_done + 1, is_key(n_done), upload)
             n_done += 1
+            if os.environ.get("BENCH_DIGEST_EVERY_FRAME"):   # diagnostic: where two runs part ways (drains every frame)
+                print(f"[digest rank {rank} frame {n_done}]", json.dumps(loop.digest_parts()), file=sys.stderr, flush=True)
 
     run(5 * max(ke, 1) + 1)
     barrier()
@@ -655,7 +657,7 @@ def main():
                               "of every rank (cs_ba_output_apply_dev: key poses into the pose history / the window ring, points into the map, "
                               "outlier points false, relaxation of the non-key frames up to the newest, updateNewPosesPoints)",
                       "lag_key_frame_intervals": loop.lag, "windows_applied_in_timed_region": applied_timed, "windows_applied": loop.applied,
-                      "last": loop.last_apply, "static_points_retriangulated_last": cnt[0], "dynamic_points_retriangulated_last": cnt[1],
+                      "last": loop.last_apply, "apply_wait_errors": loop.out.wait_errors(), "static_points_retriangulated_last": cnt[0], "dynamic_points_retriangulated_last": cnt[1],
                       "points_set_false_last": cnt[2]}
 
     # ---- roofline of the dominant kernel: the persistent gain tracker of all cameras of this rank (one launch per frame).

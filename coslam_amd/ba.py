@@ -99,15 +99,6 @@ class BAWorkspace:
         to a CU range; 0 restores the workspace's own.  The caller keeps the stream alive."""
         check(self._L.cs_ba_set_stream(self._h, C.c_void_p(stream_ptr)), "cs_ba_set_stream")
 
-    def set_persistent(self, n_workgroups):
-        """cs_ba_set_persistent: the LM loop as one cooperative launch of at most n_workgroups workgroups (one compute unit
-        each, kept for the whole run); the caller budgets other persistent kernels for the rest of the chip.  0 = off."""
-        check(self._L.cs_ba_set_persistent(self._h, int(n_workgroups)), "cs_ba_set_persistent")
-
-    def stream(self):
-        self._L.cs_ba_stream.restype = C.c_void_p
-        return self._L.cs_ba_stream(self._h)
-
     def worker_stats(self):
         """(solves completed by the worker since the last call, GPU ms they held the stream in total, the last one, the longest, the
         window parses' part of the total)"""

@@ -21,8 +21,8 @@
 //                 registers of one wave; then the tentative step (cameras R exp(w), t + dt; points by
 //                 back-substitution, wave per point) and the tentative cost of the wave's own measurements;
 //                 N = 0: the system was solved by k_solve_blocked (one workgroup, LDS, orders 37..176), k_cholflow (one
-//                 dataflow launch, a workgroup per block column, orders 177..1040: ba_cholflow_dev.h) or, beyond that and
-//                 for A/B runs, k_chol_panel / k_chol_trail / k_chol_trsv (HBM, two launches per block);
+//                 dataflow launch, a workgroup per block column, orders 177..1040: ba_cholflow_dev.h) or, beyond that,
+//                 k_chol_panel / k_chol_trail / k_chol_trsv (HBM, two launches per block);
 //   k_control_step  one workgroup: fixed-order sum of the partials, accept/reject, lambda, commit, stop flags
 //                 (k_control: the same at the start of an outer round);
 //   k_cost / k_flag  start-of-round cost; outlier flags (residual > maxErr) and the "flags changed" bit.
@@ -60,7 +60,7 @@ namespace {
 struct BaState {
     double lambda, cost, cost_new, step2, cost0;
     int inner_it, inner_done, all_done, chol_ok, changed, nIterTotal, nOuter, nOutliers, first_cost;
-    int seq;            // packed path: LM steps started so far in this solve (diagnostic; the persistent kernel's barrier epochs)
+    int seq;            // packed path: LM steps started so far in this solve (diagnostic)
     int pending;        // packed path: a tentative step awaits its accept / reject (decided by the next k_lin_packed)
     int cur;            // packed path: which estimate is current: 0 = Rs / Ts / pts, 1 = Rn / Tn / Mn
     int nCholFail;      // LM steps whose reduced system could not be factorised (not positive definite, NaN, time-out)
@@ -759,68 +759,6 @@ __global__ __launch_bounds__(64) void k_schur_part(BaDev D) {
     }
 }
 
-// ---- one workgroup: Cholesky + solve of the reduced camera system --------------------------------
-template <int NT>
-__global__ __launch_bounds__(NT) void k_solve(BaDev D, int useLds) {
-    if (!BA_ACTIVE(D)) return;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ int okFlag;
-    const int n = D.n, tid = threadIdx.x;
-    if (n == 0) {
-        if (tid == 0) D.st->chol_ok = 1;
-        return;
-    }
-    double* A = useLds ? sm : D.S;
-    double* b = useLds ? (sm + (size_t)n * n) : D.rhs;
-    if (useLds) {
-        for (int q = tid; q < n * n; q += NT) A[q] = D.S[q];
-        for (int q = tid; q < n; q += NT) b[q] = D.rhs[q];
-    }
-    if (tid == 0) okFlag = 1;
-    __syncthreads();
-    // right-looking Cholesky on the lower triangle
-    for (int j = 0; j < n; ++j) {
-        if (tid == 0) {
-            double d = A[(size_t)j * n + j];
-            if (!(d > 0)) {
-                okFlag = 0;
-                d = 1.0;
-            }
-            A[(size_t)j * n + j] = sqrt(d);
-        }
-        __syncthreads();
-        const double djj = A[(size_t)j * n + j];
-        for (int i = j + 1 + tid; i < n; i += NT) A[(size_t)i * n + j] /= djj;
-        __syncthreads();
-        // trailing update: A[i][k] -= A[i][j] * A[k][j] for j < k <= i
-        const int m = n - j - 1;
-        for (int q = tid; q < m * m; q += NT) {
-            const int i = j + 1 + q / m, k = j + 1 + q % m;
-            if (k <= i) A[(size_t)i * n + k] -= A[(size_t)i * n + j] * A[(size_t)k * n + j];
-        }
-        __syncthreads();
-    }
-    // forward substitution L y = b (column oriented)
-    for (int j = 0; j < n; ++j) {
-        if (tid == 0) b[j] /= A[(size_t)j * n + j];
-        __syncthreads();
-        const double yj = b[j];
-        for (int i = j + 1 + tid; i < n; i += NT) b[i] -= A[(size_t)i * n + j] * yj;
-        __syncthreads();
-    }
-    // back substitution L^T x = y
-    for (int j = n - 1; j >= 0; --j) {
-        if (tid == 0) b[j] /= A[(size_t)j * n + j];
-        __syncthreads();
-        const double xj = b[j];
-        for (int i = tid; i < j; i += NT) b[i] -= A[(size_t)j * n + i] * xj;
-        __syncthreads();
-    }
-    if (useLds)
-        for (int q = tid; q < n; q += NT) D.rhs[q] = b[q];
-    if (tid == 0) D.st->chol_ok = okFlag;
-}
-
 // ---- large reduced systems (order > 138: the LDS single-workgroup Cholesky no longer fits) -----------------
 // Right-looking blocked Cholesky on S in HBM, block CB = 32, lower triangle, two launches per block column:
 //   k_chol_panel   every workgroup re-factors the 32x32 diagonal block in LDS (cheap, saves a launch and a grid-wide
@@ -1196,7 +1134,7 @@ __device__ __forceinline__ void sb_panel_mfma(double* A, int I, int kb, int lane
 
 // memory flavour of the solver's (and the packed LM-step functions') traffic: plain when a kernel boundary separates producer
 // and consumer, relaxed agent-scope atomics (sc1: never served from a stale L1 / non-coherent L2 line) when both run inside
-// ONE launch (ba_persist_dev.h)
+// ONE launch (the dataflow Cholesky, ba_cholflow_dev.h)
 template <bool COH>
 __device__ __forceinline__ double ldm(const double* p) {
     if (COH) return cf_ld(p);
@@ -1379,11 +1317,7 @@ __global__ __launch_bounds__(NW * 64) void k_solve_blocked(BaDev D) {
     if (stAllDone || stInnerDone) return;
     if (threadIdx.x == 0) D.st->chol_ok = okFlag;  // (behind the body's last workgroup barrier)
 }
-static int sb_solve_waves(int n) {  // COSLAM_BA_SOLVE_WAVES = 4 | 8 | 16 overrides (A/B runs)
-    static const int env = getenv("COSLAM_BA_SOLVE_WAVES") ? atoi(getenv("COSLAM_BA_SOLVE_WAVES")) : 0;
-    if (env == 4 || env == 8 || env == 16) return env;
-    return n <= 64 ? 4 : 8;
-}
+static int sb_solve_waves(int n) { return n <= 64 ? 4 : 8; }
 static void sb_launch_solve(hipStream_t stream, const BaDev& D) {
     const size_t lds = sb_lds_bytes(D.n);
     switch (sb_solve_waves(D.n)) {
@@ -1391,64 +1325,6 @@ static void sb_launch_solve(hipStream_t stream, const BaDev& D) {
         case 8: hipLaunchKernelGGL(k_solve_blocked<8>, dim3(1), dim3(512), lds, stream, D); break;
         default: hipLaunchKernelGGL(k_solve_blocked<16>, dim3(1), dim3(1024), lds, stream, D); break;
     }
-}
-
-// ---- one WAVE: reduced camera system of order n <= 64 -------------------------------------------------
-// Lane i owns row i of S (in LDS) and entry i of the right-hand side (in a register).  Column j of the Cholesky
-// factor is formed from one LDS read per lane plus v_readlane broadcasts of the pivot and of l_kj, the trailing
-// update touches only the lane's own row (no cross-lane hazard, so no barrier anywhere), the forward substitution
-// rides along with the factorisation, and the back substitution is a column sweep over the rows of L.
-__device__ __forceinline__ double rdlane_d(double v, int l) {
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
-__global__ __launch_bounds__(64) void k_solve_wave(BaDev D) {
-    if (!BA_ACTIVE(D)) return;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int n = D.n, i = threadIdx.x;
-    if (n == 0) {
-        if (i == 0) D.st->chol_ok = 1;
-        return;
-    }
-    const int ld = n | 1;  // odd leading dimension: a column read hits distinct banks
-    for (int q = i; q < n * n; q += 64) sm[(q / n) * ld + (q % n)] = D.S[q];
-    double b = (i < n) ? D.rhs[i] : 0.0;
-    double diag = 1.0;  // L[i][i]
-    bool ok = true;
-    __syncthreads();
-    double* row = sm + (size_t)(i < n ? i : 0) * ld;
-    for (int j = 0; j < n; ++j) {
-        const double cj = (i < n) ? row[j] : 0.0;
-        double d = rdlane_d(cj, j);
-        if (!(d > 0)) {
-            ok = false;
-            d = 1.0;
-        }
-        d = sqrt(d);
-        const double lij = (i > j && i < n) ? cj / d : 0.0;
-        if (i == j) diag = d;
-        if (i > j && i < n) row[j] = lij;
-        // forward substitution step
-        const double yj = rdlane_d(b, j) / d;
-        if (i == j) b = yj;
-        if (i > j) b -= lij * yj;
-        // trailing update of my own row: A[i][k] -= l_ij * l_kj, j < k <= i
-        for (int k = j + 1; k < n; ++k) {
-            const double lkj = rdlane_d(lij, k);
-            if (k <= i && i < n) row[k] -= lij * lkj;
-        }
-    }
-    __syncthreads();
-    // back substitution L^T x = y as a column sweep over the rows of L
-    for (int j = n - 1; j >= 0; --j) {
-        const double xj = rdlane_d(b, j) / rdlane_d(diag, j);
-        if (i == j) b = xj;
-        if (i < j) b -= sm[(size_t)j * ld + i] * xj;
-    }
-    if (i < n) D.rhs[i] = b;
-    if (i == 0) D.st->chol_ok = ok ? 1 : 0;
 }
 
 // ---- one WAVE, rows in REGISTERS: reduced camera systems of order n <= NMAX <= 36 -----------------------
@@ -1511,6 +1387,12 @@ __device__ __forceinline__ void solve_reg_combine(const BaDev& D, double* Ssm) {
         }
     }
     __syncthreads();
+}
+
+__device__ __forceinline__ double rdlane_d(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
 }
 
 template <int NMAX>
@@ -2029,7 +1911,6 @@ __global__ __launch_bounds__(256) void k_control_step(BaDev D) {
 }
 
 #include "ba_packed_dev.h"
-#include "ba_persist_dev.h"
 #include "ba_window_dev.h"
 #include "small_ops.h"
 #include "ba_output_dev.h"
@@ -2062,7 +1943,7 @@ struct BaInitCopy {  // initial estimate to copy into the workspace (cs_ba_solve
     double *R, *T, *M;
     int nR, nT, nM;
 };
-__global__ __launch_bounds__(256) void k_init_state(BaState* st, int* outlier, int nObs, BaInitCopy I, int* fuseBar) {
+__global__ __launch_bounds__(256) void k_init_state(BaState* st, int* outlier, int nObs, BaInitCopy I) {
     const int t0 = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
     for (int o = t0; o < nObs; o += stride) outlier[o] = 0;
     if (I.R0) {
@@ -2079,7 +1960,6 @@ __global__ __launch_bounds__(256) void k_init_state(BaState* st, int* outlier, i
     z.pending = z.cur = z.seq = z.fuseEpoch = 0;
     z.first_cost = 1;
     *st = z;
-    if (fuseBar) *fuseBar = 0;  // the grid barrier's counter of k_update_lin_packed (monotonic within a solve)
 }
 
 __global__ void k_outer_begin(BaDev D) {
@@ -2276,19 +2156,12 @@ __global__ void k_dist_zero_foreign(BaDev D) {
 struct BaPlan {
     bool seg8;  // eight lanes per point in the linearisation and the update (no point has more than 8 measurements)
     BaDev D;
-    int cb, gPts, gUpd, nPairs, useLds;
-    size_t ldsSolve;
+    int cb, gPts, gUpd, nPairs;
     bool sliced;
-    bool legacySolve;  // COSLAM_BA_LEGACY_SOLVE=1: k_solve_wave / k_solve<256> / HBM-blocked Cholesky (A/B runs)
     bool cholFlow;     // orders beyond the LDS solver: the one-launch dataflow Cholesky (ba_cholflow_dev.h)
     CholFlow F;
     bool packed;       // orders 37..176 with pair lists, no point with more than 64 measurements: ba_packed_dev.h
-    bool fuseUL;       // ... with update(k) + linearisation(k + 1) as one launch around a grid barrier (k_update_lin_packed)
     int gPack;
-    bool persist;      // ... and a run of LM steps as ONE cooperative launch of persistG workgroups (ba_persist_dev.h)
-    int persistG;
-    size_t persistLds;
-    int* persistBar;
     BaDev DB;          // packed path: the same launch arguments with the two LM state words swapped
     bool syrk;         // large orders without pair lists: the Schur sum as Z Z^T on the f64 matrix cores (ba_syrk_dev.h)
     SyrkDev Y;
@@ -2319,8 +2192,6 @@ struct cs_ba {
     int4* pairEnt;
     size_t pairPtrCap, pairEntCap;
     bool havePairs;
-    int persistWGs;  // cs_ba_set_persistent: compute units the LM loop may keep for itself (0: one launch per phase)
-    int* persistBar; // [16] barrier counter | chol_ok | time-out flag of the cooperative launch
     int* waveStart;  // packed lane plan of the uploaded problem (own allocation), nPackWaves waves; 0 = none
     size_t waveStartCap;
     int nPackWaves;
@@ -2380,7 +2251,6 @@ static int ba_free(cs_ba* b) {
     b->dist = nullptr;
     if (b->pairPtr) (void)hipFree(b->pairPtr);
     if (b->pairEnt) (void)hipFree(b->pairEnt);
-    b->persistBar = nullptr;  // (a piece of the slab)
     if (b->waveStart) (void)hipFree(b->waveStart);
     b->waveStart = nullptr;
     b->waveStartCap = 0;
@@ -2467,7 +2337,6 @@ static int ba_reserve(cs_ba* b, int C, int P, int nObs) {
     const Piece pieces[] = {
         {(void**)&b->st, sizeof(BaState)},
         {(void**)&b->st2, sizeof(BaState)},
-        {(void**)&b->persistBar, 32 * sizeof(int)},
         {(void**)&b->scal, 8 * sizeof(double)},
         {(void**)&b->costPart, (1024 + cP / 4 + cC / 256 + 2) * sizeof(double)},
         {(void**)&b->stepPart, (cP + cC + 1) * sizeof(double)},
@@ -2565,15 +2434,8 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
     b->nCostBlocks = cb;
     L.cb = cb;
     L.nPairs = D.nc * (D.nc + 1) / 2;
-    L.ldsSolve = sizeof(double) * ((size_t)D.n * D.n + D.n);
-    L.useLds = (L.ldsSolve <= 150 * 1024) ? 1 : 0;
-    if (L.useLds && L.ldsSolve > 64 * 1024) {
-        CS_HIP(hipFuncSetAttribute((const void*)k_solve<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.ldsSolve));
-    }
     {
-        static const bool legacy = getenv("COSLAM_BA_LEGACY_SOLVE") && getenv("COSLAM_BA_LEGACY_SOLVE")[0] == '1';
-        L.legacySolve = legacy;
-        if (!legacy && D.n > 36 && D.n <= SB_MAX_ORDER && sb_lds_bytes(D.n) > 64 * 1024) {
+        if (D.n > 36 && D.n <= SB_MAX_ORDER && sb_lds_bytes(D.n) > 64 * 1024) {
             CS_HIP(hipFuncSetAttribute((const void*)k_solve_blocked<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb_lds_bytes(D.n)));
             CS_HIP(hipFuncSetAttribute((const void*)k_solve_blocked<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb_lds_bytes(D.n)));
             CS_HIP(hipFuncSetAttribute((const void*)k_solve_blocked<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb_lds_bytes(D.n)));
@@ -2589,8 +2451,7 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
     // distributed solve needs the dense S || rhs for its all-reduce)
     L.sliced = (!distributed && D.n > 0 && D.n <= 36);
     {
-        static const bool noSeg = getenv("COSLAM_BA_SEG8") && getenv("COSLAM_BA_SEG8")[0] == '0';
-        L.seg8 = L.sliced && b->maxObs <= 8 && !noSeg;
+        L.seg8 = L.sliced && b->maxObs <= 8;
         if (L.seg8) {
             gUpd = (P + 31) / 32;
             if (gUpd * 256 < C) gUpd = (C + 255) / 256;
@@ -2608,13 +2469,12 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
         while (sl > 1 && (nFree + sl - 1) / sl < 32) sl /= 2;  // at least half a wave of points per slice
         D.nSlices = sl;
     }
-    // orders beyond the LDS solver: block columns owned by workgroups, one launch (COSLAM_BA_CHOLFLOW=0: the launch-per-block
-    // kernels)
+    // orders beyond the LDS solver: block columns owned by workgroups, one launch (beyond its 66 block columns: the
+    // launch-per-block kernels)
     L.cholFlow = false;
     {
-        const char* env = getenv("COSLAM_BA_CHOLFLOW");
         const int NB = (D.n + SB - 1) / SB;
-        if (!(env && env[0] == '0') && !L.legacySolve && D.n > SB_MAX_ORDER && NB + 1 <= CF_MAX_BLOCKS) {
+        if (D.n > SB_MAX_ORDER && NB + 1 <= CF_MAX_BLOCKS) {
             auto pad = [](size_t v) { return (v + 255) & ~(size_t)255; };
             const size_t bPub = pad(sizeof(double) * (size_t)NB * (NB + 1) * 256), bX = pad(sizeof(double) * 16 * (size_t)NB),
                          bF = pad(sizeof(int) * 2 * (size_t)NB);
@@ -2653,7 +2513,6 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
             Y.ldz = Y.nT * SY_TB;
             int sl = 512 / Y.nTiles;  // two workgroups per CU: 189 us at cfg5 (one per CU: 204, 1.3 per CU: 259)
             if (sl > 32) sl = 32;
-            if (const char* e = getenv("COSLAM_SYRK_SLICES")) sl = atoi(e);  // (A/B)
             if (sl < 1) sl = 1;
             const int K = 3 * P;
             int ks = (K + sl - 1) / sl;
@@ -2690,7 +2549,7 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
     // wave-per-point / workgroup-per-pair kernels, for A/B runs)
     {
         const bool noPacked = getenv("COSLAM_BA_PACKED") && getenv("COSLAM_BA_PACKED")[0] == '0';
-        L.packed = !noPacked && !distributed && !L.sliced && !L.legacySolve && !L.syrk && D.pairPtr && b->nPackWaves > 0 &&
+        L.packed = !noPacked && !distributed && !L.sliced && !L.syrk && D.pairPtr && b->nPackWaves > 0 &&
                    D.n > 36 && D.n <= SB_MAX_ORDER && P > 0 && nObs > 0;
         L.gPack = 0;
         if (L.packed) {
@@ -2701,40 +2560,6 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
             L.DB = D;
             L.DB.st = b->st2;
             L.DB.stn = b->st;
-        }
-        // COSLAM_BA_FUSE_UL=1: update(k) + linearisation(k + 1) as ONE launch around a grid barrier (k_update_lin_packed; its
-        // workgroups must all be resident together: a few dozen 256-thread workgroups are, anywhere).  Off by default: bit-identical
-        // results, one kernel boundary less per LM step, and NO gain in the frame loop (2.086 vs 2.088 ms per joint solve: the
-        // in-loop step is slowed by the co-running streams' kernels -- undisturbed solves run at the stand-alone 68 us per step
-        // with either schedule -- not by its launch boundaries).  (Read per plan so that a test can switch it.)
-        const char* fuseEnv = getenv("COSLAM_BA_FUSE_UL");
-        L.fuseUL = L.packed && fuseEnv && fuseEnv[0] == '1' && L.gPack <= 192;
-        L.persistBar = b->persistBar;
-        const bool noPersist = getenv("COSLAM_BA_PERSIST") && getenv("COSLAM_BA_PERSIST")[0] == '0';
-        L.persist = L.packed && !noPersist && b->persistWGs > 0;
-        L.persistG = 0;
-        L.persistLds = 0;
-        L.persistBar = b->persistBar;
-        if (L.persist) {
-            const int needL = (b->nPackWaves + LP_NW - 1) / LP_NW, needS = (L.nPairs * CS_SCHUR_WPP + LP_NW - 1) / LP_NW;
-            int g = needL > needS ? needL : needS;
-            if (g > b->persistWGs) g = b->persistWGs;
-            if (g < 1) g = 1;
-            L.persistG = g;
-            D.nUpdBlocks = g;
-            // LDS: the solver's blocks or the phases' scratch, whichever is larger -- and never less than what keeps a CU to
-            // this workgroup alone next to the persistent tracker (64 KB per tracker workgroup, 160 KB per CU):
-            // COSLAM_BA_PERSIST_LDS_KB (default 100)
-            size_t lds = sb_lds_bytes(D.n);
-            const size_t scratch = sizeof(double) * LP_NW * 10 * 64;
-            if (lds < scratch) lds = scratch;
-            const char* e = getenv("COSLAM_BA_PERSIST_LDS_KB");
-            const size_t floorB = (size_t)(e ? atoi(e) : 100) * 1024;
-            if (lds < floorB) lds = floorB;
-            if (lds > 160 * 1024 - 256) lds = 160 * 1024 - 256;
-            L.persistLds = lds;
-            CS_HIP(hipFuncSetAttribute((const void*)k_lm_persist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            CS_HIP(hipFuncSetAttribute((const void*)k_lm_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
     }
     return CS_OK;
@@ -2748,7 +2573,7 @@ static void ba_enqueue_init(cs_ba* b, hipStream_t stream, const BaPlan& L, bool 
     if (gi < 1) gi = 1;
     if (gi > 64) gi = 64;
     BaInitCopy I = {d_Rs0, d_Ts0, d_pts0, b->Rs, b->Ts, b->pts, 9 * D.C, 3 * D.C, 3 * D.P};
-    hipLaunchKernelGGL(k_init_state, dim3(gi), dim3(256), 0, stream, b->st, b->outlier, D.nObs, I, b->persistBar + 16);
+    hipLaunchKernelGGL(k_init_state, dim3(gi), dim3(256), 0, stream, b->st, b->outlier, D.nObs, I);
     // Z's entries of (point, camera) pairs without a measurement are never written: cleared once per solve (every present
     // entry is rewritten by every step)
     if (L.syrk) (void)hipMemsetAsync(L.Y.Zt, 0, L.syrkZtBytes, stream);
@@ -2771,8 +2596,7 @@ static void ba_enqueue_lin_schur(hipStream_t stream, const BaPlan& L) {
         return;
     }
     {
-        static const bool noSeg = getenv("COSLAM_BA_SEG8") && getenv("COSLAM_BA_SEG8")[0] == '0';
-        if (D.maxObsPerPoint <= 8 && !noSeg)
+        if (D.maxObsPerPoint <= 8)
             hipLaunchKernelGGL(k_linearize_seg8, dim3((D.P + 31) / 32 > 0 ? (D.P + 31) / 32 : 1), blk, 0, stream, D);
         else
             hipLaunchKernelGGL(k_linearize, dim3(L.gPts), blk, 0, stream, D);
@@ -2827,12 +2651,8 @@ static void ba_enqueue_solve_update(hipStream_t stream, const BaPlan& L) {
     } else if (L.sliced && D.n == 36) {
         hipLaunchKernelGGL(k_update<36>, dim3(gUpd), blk, 0, stream, D);
     } else {
-        if (D.n <= SB_MAX_ORDER && !L.legacySolve) {
+        if (D.n <= SB_MAX_ORDER) {
             sb_launch_solve(stream, D);
-        } else if (D.n <= 64) {
-            hipLaunchKernelGGL(k_solve_wave, dim3(1), dim3(64), sizeof(double) * (size_t)D.n * (D.n | 1), stream, D);
-        } else if (L.useLds) {
-            hipLaunchKernelGGL(k_solve<256>, dim3(1), blk, L.ldsSolve, stream, D, 1);
         } else if (L.cholFlow) {  // one launch: workgroup per block column, flags in HBM
             hipLaunchKernelGGL(k_cholflow_begin, dim3(1), dim3(128), 0, stream, D, L.F);
             hipLaunchKernelGGL(k_cholflow, dim3(L.F.NB), dim3(CF_NT), cf_lds_bytes(L.F.NB + 1), stream, D, L.F);
@@ -2866,38 +2686,6 @@ static void ba_enqueue_control_final(hipStream_t stream, const BaPlan& L) {
 
 // a run of up to `steps` LM steps (the state word says where it stops)
 static void ba_enqueue_lm_run(hipStream_t stream, const BaPlan& L, int steps) {
-    if (L.persist) {
-        (void)hipMemsetAsync(L.persistBar, 0, 16 * sizeof(int), stream);
-        LmPersist Q = {L.persistBar, steps};
-        if (L.persistG == 1)
-            hipLaunchKernelGGL(k_lm_persist<false>, dim3(1), dim3(LP_NT), L.persistLds, stream, L.D, Q);
-        else
-            hipLaunchKernelGGL(k_lm_persist<true>, dim3(L.persistG), dim3(LP_NT), L.persistLds, stream, L.D, Q);
-        return;
-    }
-    if (L.packed && L.fuseUL && steps > 1) {
-        // lin | (schur, solve, update + lin) x (steps - 1) | schur, solve, update | final: the LM state alternates between the two
-        // state words (X reads, Xo is written by the fused launch)
-        const dim3 blk(256);
-        const int gS = (L.nPairs * CS_SCHUR_WPP + 3) / 4;
-        hipLaunchKernelGGL(k_lin_packed, dim3(L.gPack), blk, 0, stream, L.D);  // reads A, writes B
-        const BaDev* X = &L.DB;
-        const BaDev* Xo = &L.D;
-        for (int it = 0; it < steps; ++it) {
-            if (L.D.nc > 0) hipLaunchKernelGGL(k_schur_wave, dim3(gS), blk, 0, stream, *X);
-            sb_launch_solve(stream, *X);
-            if (it + 1 < steps) {
-                hipLaunchKernelGGL(k_update_lin_packed, dim3(L.gPack), blk, 0, stream, *X, L.persistBar + 16);
-                const BaDev* t = X;
-                X = Xo;
-                Xo = t;
-            } else {
-                hipLaunchKernelGGL(k_update_packed, dim3(L.gPack), blk, 0, stream, *X);  // writes Xo's word, pending
-            }
-        }
-        hipLaunchKernelGGL(k_control_final, dim3(1), blk, 0, stream, *Xo);
-        return;
-    }
     for (int it = 0; it < steps; ++it) {
         ba_enqueue_lin_schur(stream, L);
         ba_enqueue_solve_update(stream, L);
@@ -3020,12 +2808,10 @@ static int ba_capture(hipStream_t s, hipGraphExec_t* out, F&& body) {
 }
 
 // Packed launch-per-phase schedule: the last launch of a chunk (k_control_final) and of a tail (k_outer_end) store the state word
-// straight into the worker's pinned host word -- no copy node on the chain.  Other schedules (large systems, the persistent
-// launch) keep the copy.  COSLAM_BA_STATE_COPY=1 (A/B): always the copy.
+// straight into the worker's pinned host word -- no copy node on the chain.  The schedules of large systems keep the copy.
 static bool ba_state_in_kernel(BaWorker* w, BaPlan& L) {
-    static const bool forceCopy = getenv("COSLAM_BA_STATE_COPY") && getenv("COSLAM_BA_STATE_COPY")[0] == '1';
     L.D.hostState = L.DB.hostState = nullptr;
-    if (forceCopy || !L.packed || L.persist || !w->h_state) return false;
+    if (!L.packed || !w->h_state) return false;
     int* dp = nullptr;
     if (hipHostGetDevicePointer((void**)&dp, w->h_state, 0) != hipSuccess || !dp) return false;
     L.D.hostState = L.DB.hostState = dp;
@@ -3050,15 +2836,12 @@ static int ba_run_segments(BaWorker* w, hipStream_t s, int maxIter, int innerMax
     // (a round's tail and the next round's start are ONE segment, 'U' = T + R: two launches each -- as separate segments the second
     // one waited for the host thread to wake up from the first one's event, ~15 us of idle stream per round; behind a converged
     // tail the round start runs as no-ops like any speculative segment)
-    static const bool splitTR = getenv("COSLAM_BA_SPLIT_TR") && getenv("COSLAM_BA_SPLIT_TR")[0] == '1';  // A/B
     seg.push_back({'H', 0});
     for (int outer = 0; outer < maxIter; ++outer) {
-        if (outer > 0 && splitTR) seg.push_back({'R', outer});
         for (int done = 0; done < innerMaxIter; done += w->chunk) seg.push_back({'C', outer});
-        seg.push_back({(outer + 1 < maxIter && !splitTR) ? 'U' : 'T', outer});
+        seg.push_back({outer + 1 < maxIter ? 'U' : 'T', outer});
     }
     seg.push_back({'F', maxIter});
-    static const bool noSpec = getenv("COSLAM_BA_SPECULATE") && getenv("COSLAM_BA_SPECULATE")[0] == '0';  // A/B
     if (!w->ev[0]) {
         CS_HIP(hipEventCreateWithFlags(&w->ev[0], hipEventDisableTiming));
         CS_HIP(hipEventCreateWithFlags(&w->ev[1], hipEventDisableTiming));
@@ -3081,82 +2864,25 @@ static int ba_run_segments(BaWorker* w, hipStream_t s, int maxIter, int innerMax
         }
         return n;
     };
-    // COSLAM_BA_SEGTIME=1 (diagnostic): GPU time between the ends of consecutive segments, summed per kind, printed per solve
-    static const bool segTime = getenv("COSLAM_BA_SEGTIME") != nullptr;
-    std::vector<std::pair<char, hipEvent_t>> stamps;
-    auto stamp = [&](char kind) {
-        if (!segTime) return;
-        hipEvent_t e = nullptr;
-        if (hipEventCreate(&e) == hipSuccess) {
-            (void)hipEventRecord(e, s);
-            stamps.push_back({kind, e});
-        }
-    };
-    double hostUs[128] = {0};   // (diagnostic) host time spent inside launch(kind), per kind
     auto launch_seg = [&](char kind) {
         if (kind != 'U') return launch(kind);
         const hipError_t e = launch('T');
         return e != hipSuccess ? e : launch('R');
     };
-    auto timed_launch = [&](char kind) {
-        if (!segTime) return launch_seg(kind);
-        const auto t0 = std::chrono::steady_clock::now();
-        const hipError_t e = launch_seg(kind);
-        hostUs[(int)kind] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        return e;
-    };
-    stamp('0');
     size_t i = 0;
-    CS_HIP(timed_launch(seg[0].kind));
+    CS_HIP(launch_seg(seg[0].kind));
     CS_HIP(hipEventRecord(w->ev[0], s));
-    stamp(seg[0].kind);
     int slot = 0;
-    struct StampDump {
-        std::vector<std::pair<char, hipEvent_t>>& st;
-        double* hostUs;
-        ~StampDump() {
-            if (st.size() < 2) return;
-            fprintf(stderr, "[ba segtime] host us inside launch(): H %.0f R %.0f C %.0f T %.0f F %.0f\n", hostUs['H'], hostUs['R'], hostUs['C'],
-                    hostUs['T'], hostUs['F']);
-            (void)hipEventSynchronize(st.back().second);
-            double sum[128] = {0};
-            int cnt[128] = {0};
-            std::string seq;
-            for (size_t k = 1; k < st.size(); ++k) {
-                float ms = 0;
-                (void)hipEventElapsedTime(&ms, st[k - 1].second, st[k].second);
-                sum[(int)st[k].first] += ms;
-                cnt[(int)st[k].first] += 1;
-                char buf[32];
-                snprintf(buf, sizeof(buf), " %c%.0f", st[k].first, ms * 1e3);
-                seq += buf;
-            }
-            fprintf(stderr, "[ba segtime] H %.0f us, R %.0f, C %d x %.0f, T %d x %.0f, F %.0f |%s\n", sum['H'] * 1e3, sum['R'] * 1e3, cnt['C'],
-                    cnt['C'] ? sum['C'] * 1e3 / cnt['C'] : 0.0, cnt['T'], cnt['T'] ? sum['T'] * 1e3 / cnt['T'] : 0.0, sum['F'] * 1e3, seq.c_str());
-            for (auto& q : st) (void)hipEventDestroy(q.second);
-        }
-    } stampDump{stamps, hostUs};
     while (i < seg.size()) {
         const size_t n = next_of(i);
-        if (n < seg.size() && !noSpec) {
-            CS_HIP(timed_launch(seg[n].kind));
+        if (n < seg.size()) {
+            CS_HIP(launch_seg(seg[n].kind));
             CS_HIP(hipEventRecord(w->ev[slot ^ 1], s));
-            stamp(seg[n].kind);
         }
         CS_HIP(hipEventSynchronize(w->ev[slot]));
         if (seg[i].kind == 'C' && (w->h_state[0] || w->h_state[1])) skipChunksOfOuter = seg[i].outer;  // inner_done / all_done
         if ((seg[i].kind == 'T' || seg[i].kind == 'U') && w->h_state[1]) allDone = true;
-        if (noSpec) {
-            const size_t m = next_of(i);
-            if (m < seg.size()) {
-                CS_HIP(launch_seg(seg[m].kind));
-                CS_HIP(hipEventRecord(w->ev[slot ^ 1], s));
-                stamp(seg[m].kind);
-            }
-            i = m;
-        } else {
-            i = n;
-        }
+        i = n;
         slot ^= 1;
     }
     return CS_OK;
@@ -3384,8 +3110,7 @@ static int ba_worker_run_window_inner(cs_ba* b, BaWorker* w, const BaAsyncJob& J
     rc = ba_make_plan(b, C, P, nObs, J.nCamsCon, J.nPtsCon, J.maxErr, J.innerMaxIter, false, &L);
     if (rc) return rc;
     {
-        static const int envChunk = getenv("COSLAM_BA_WINDOW_CHUNK") ? atoi(getenv("COSLAM_BA_WINDOW_CHUNK")) : 0;
-        w->chunk = envChunk > 0 ? envChunk : 2;   // (measured in the frame loop: 1 -> 1.85, 2 -> 1.81, 3 -> 1.89 ms per joint solve)
+        w->chunk = 2;   // LM steps per segment (measured in the frame loop: 1 -> 1.85, 2 -> 1.81, 3 -> 1.89 ms per joint solve)
         if (w->chunk > J.innerMaxIter && J.innerMaxIter > 0) w->chunk = J.innerMaxIter;
         if (w->chunk < 1) w->chunk = 1;
     }
@@ -3658,10 +3383,8 @@ static int ba_worker_run_inner(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
     const dim3 blk(256);
     if (!w->haveGraphs || memcmp(&key, &w->key, sizeof(key)) != 0) {
         ba_worker_destroy_graphs(w);
-        static const int envChunk = getenv("COSLAM_BA_CHUNK") ? atoi(getenv("COSLAM_BA_CHUNK")) : 0;
-        w->chunk = envChunk > 0 ? envChunk : 5;
+        w->chunk = 5;   // LM steps per captured segment
         if (w->chunk > J.innerMaxIter && J.innerMaxIter > 0) w->chunk = J.innerMaxIter;
-        if (L.persist && J.innerMaxIter > 0) w->chunk = J.innerMaxIter;  // the whole run is one launch: it stops itself
         // head: initial estimate into the workspace, cost and LM state of the first round
         rc = ba_capture(s, &w->gHead, [&] {
             ba_enqueue_init(b, s, L, false, J.R0, J.T0, J.M0);
@@ -3784,15 +3507,8 @@ cs_ba* cs_ba_create(int device) {
     cs_ba* b = new cs_ba();
     memset(b, 0, sizeof(*b));
     b->device = device;
-    // COSLAM_BA_STREAM_PRIO=1 (A/B): the workspace's stream (the async worker's) at the highest stream priority, so that its
-    // short kernels are dispatched ahead of the per-frame streams' workgroups
-    static const bool hiPrio = getenv("COSLAM_BA_STREAM_PRIO") && getenv("COSLAM_BA_STREAM_PRIO")[0] == '1';
-    int prLo = 0, prHi = 0;
     hipError_t se = hipSetDevice(device);
-    if (se == hipSuccess && hiPrio) (void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);
-    if (se == hipSuccess)
-        se = hiPrio ? hipStreamCreateWithPriority(&b->own_stream, hipStreamNonBlocking, prHi)
-                    : hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking);
+    if (se == hipSuccess) se = hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking);
     if (se != hipSuccess) {
         cs_set_error("cs_ba_create: cannot create a stream");
         delete b;
@@ -3815,25 +3531,6 @@ void cs_ba_destroy(cs_ba* b) {
 // The workspace's own stream: where the host-pointer entry points, cs_ba_solve_dev(NULL stream) and the asynchronous worker
 // enqueue.
 void* cs_ba_stream(cs_ba* b) { return b ? (void*)b->own_stream : nullptr; }
-
-// The LM loop of the solves this workspace runs from device memory (cs_ba_solve_dev / cs_ba_solve_async; reduced systems of order
-// 37..176 with pair lists) as ONE cooperative launch of at most n_workgroups workgroups that stay resident for the whole run
-// and keep a compute unit each (ba_persist_dev.h) -- instead of four short dependent kernels per LM step that queue behind
-// whatever else fills the chip.  The caller's side of the bargain: n_workgroups compute units must be obtainable, i.e. other
-// persistent kernels are budgeted for the rest of the chip (cs_klt_set_cu_count(total - n_workgroups) on the trackers).  0
-// switches back to one launch per phase.
-int cs_ba_set_persistent(cs_ba* b, int n_workgroups) {
-    if (!b || n_workgroups < 0) {
-        cs_set_error("cs_ba_set_persistent: bad arguments");
-        return CS_ERR_INVALID;
-    }
-    const int wrc = cs_ba_wait(b);
-    if (wrc) return wrc;
-    CS_HIP(hipSetDevice(b->device));
-    ba_drop_graph(b);
-    b->persistWGs = n_workgroups;
-    return CS_OK;
-}
 
 // Replace it by the caller's stream -- e.g. one confined to a CU range (cs_stream_create_cu_range), so that the solve's short
 // dependent kernels never queue behind the per-frame streams' workgroups.  The caller keeps ownership of `hip_stream` (it must
@@ -3977,10 +3674,9 @@ int cs_ba_robust_h(cs_ba* b, int C, int P, int nObs, const double* Ks, double* R
             const size_t k = (size_t)(obs_ptr[i + 1] - obs_ptr[i]);
             total += k * (k + 1) / 2;
         }
-        static const bool noPairs = getenv("COSLAM_BA_PAIR_LISTS") && getenv("COSLAM_BA_PAIR_LISTS")[0] == '0';  // A/B
         // Only on the upload path (cs_ba_upload: maxIter == 0), i.e. for callers that solve the same topology repeatedly
         // from device memory; a one-shot host call would pay ~1 ms of list building to save ~0.25 ms of LM steps.
-        if (!noPairs && maxIter == 0 && total > 0 && total <= ((size_t)4 << 20) && C <= 1024) {
+        if (maxIter == 0 && total > 0 && total <= ((size_t)4 << 20) && C <= 1024) {
             const size_t nPairsAll = (size_t)C * (C + 1) / 2;
             auto pid = [C](int ca, int cb) { return (size_t)ca * C - (size_t)ca * (ca - 1) / 2 + (size_t)(cb - ca); };
             std::vector<int> ptr(nPairsAll + 1, 0);
@@ -4381,8 +4077,7 @@ int cs_ba_window_push_dev(cs_ba_window* w, void* hip_stream, const cs_handback_c
     const int slot = w->head;
     {   // the slot about to be rewritten belongs to the window of the request WIN_SLACK + 1 pushes back: wait for its parse
         std::unique_lock<std::mutex> lk(w->mu);
-        static const bool noWait = getenv("COSLAM_WIN_NOWAIT") != nullptr;   // (diagnostic only: unsafe)
-        if (!noWait) w->cv.wait(lk, [&] { return w->parsesPending <= WIN_SLACK; });
+        w->cv.wait(lk, [&] { return w->parsesPending <= WIN_SLACK; });
     }
     const size_t base = (size_t)slot * w->nCams;
     WinSnapArgs A;

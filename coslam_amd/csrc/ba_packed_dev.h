@@ -528,112 +528,6 @@ __global__ __launch_bounds__(256) void k_update_packed(BaDev D) {
     }
 }
 
-// ---- update of step k AND linearisation of step k + 1 in ONE launch ------------------------------------------------------------
-// Between them sits the one thing of an LM step that needs every measurement's tentative residual: accept or reject.  The launch
-// is a few dozen small workgroups (the lane plan's waves, four per workgroup; 20 KB of LDS, 136 VGPRs: they fit next to the
-// tracker on any compute unit and are all resident together), so that dependence is a grid barrier -- one agent-scope counter,
-// the partial costs and the tentative camera poses as coherent (sc1) stores / loads, everything else plain: a wave linearises
-// exactly the points it just stepped, out of its own compute unit's caches -- instead of a kernel boundary (7-10 us next to the
-// tracker, profiles/r03_*).  Every workgroup then takes the decision itself from the same partials in the same order (lm_rule),
-// workgroup 0 records it.  The LM state alternates between the two state words from step to step: the launch reads D.st, which
-// nothing writes while it runs, and writes D.stn, which the Schur kernel, the solver and the next launch of this kind read.
-// Same arithmetic, same order of every sum as k_update_packed + k_lin_packed: bit-identical results.
-// The barrier cannot deadlock on residency (whatever holds the compute units a late workgroup waits for -- tracker launches --
-// ends without it); its poll is bounded all the same and a time-out ends the run (solverTimeout).
-__global__ __launch_bounds__(256) void k_update_lin_packed(BaDev D, int* bar) {
-    CS_BA_SETPRIO();
-    __shared__ double red[8];
-    __shared__ double segl[4][10 * 64];
-    __shared__ int aliveSh;
-    const BaState* st = D.st;
-    const int all_done = st->all_done, inner_done = st->inner_done, cur = st->cur, chol_ok = st->chol_ok, inner_it = st->inner_it,
-              epoch = st->fuseEpoch;
-    const double cost_old = st->cost, lambda = st->lambda;
-    const bool active = !all_done && !inner_done;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, w = blockIdx.x * 4 + wv, G = gridDim.x;
-    if (!active) {  // (a speculative launch behind a finished run: hand the state on unchanged)
-        if (blockIdx.x == 0 && tid == 0) *D.stn = *st;
-        return;
-    }
-    // ---- the tentative step and its cost (k_update_packed) ----
-    double cost = 0, step = 0;
-    if (w < D.nPackWaves) update_wave<false>(D, w, lane, cur, segl[wv], cost, step);
-    {
-        const int j = blockIdx.x * 256 + tid;
-        if (j < D.C) update_cam<false, false, true>(D, j, cur, step);
-    }
-    cost = wsum(cost);
-    step = wsum(step);
-    if (lane == 0) {
-        red[wv] = cost;
-        red[4 + wv] = step;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        cf_st(D.costPart + blockIdx.x, ((red[0] + red[1]) + red[2]) + red[3]);
-        cf_st(D.stepPart + blockIdx.x, ((red[4] + red[5]) + red[6]) + red[7]);
-    }
-    // ---- every workgroup's partials and tentative poses are out ----
-    cf_stores_done();
-    __syncthreads();
-    if (tid == 0) {
-        int ok = 1, spins = 0;
-        __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int target = (epoch + 1) * G;
-        while (lp_ld_i(bar) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 22)) {
-                ok = 0;
-                break;
-            }
-        }
-        aliveSh = ok;
-    }
-    __syncthreads();
-    const bool alive = aliveSh != 0;
-    // ---- accept / reject (lm_head's arithmetic, from the state this launch read) ----
-    double c = 0, s2 = 0;
-    for (int q = tid; q < G; q += 256) {
-        c += cf_ld(D.costPart + q);
-        s2 += cf_ld(D.stepPart + q);
-    }
-    c = wsum(c);
-    s2 = wsum(s2);
-    __syncthreads();  // (red is rewritten)
-    if (lane == 0) {
-        red[wv] = c;
-        red[4 + wv] = s2;
-    }
-    __syncthreads();
-    const double cost_sum = ((red[0] + red[1]) + red[2]) + red[3];
-    const double step2 = ((red[4] + red[5]) + red[6]) + red[7];
-    LmRule r = lm_rule(chol_ok, cost_old, lambda, inner_it, D.innerMaxIter, cost_sum, step2);
-    if (!alive) r.done = 1;
-    const int curNew = r.acc ? (cur ^ 1) : cur;
-    if (blockIdx.x == 0 && tid == 0) {
-        BaState s = *st;
-        s.nIterTotal += 1;
-        s.inner_it = inner_it + 1;
-        if (!chol_ok) s.nCholFail += 1;
-        if (r.acc) s.nAccepted += 1;
-        s.cost = r.cost;
-        s.lambda = r.lambda;
-        s.inner_done = r.done;
-        s.pending = 0;
-        s.cur = curNew;
-        s.fuseEpoch = epoch + 1;
-        if (!r.done) s.seq += 1;
-        if (!alive) {
-            s.solverTimeout = 1;
-            s.all_done = 1;
-        }
-        *D.stn = s;
-    }
-    if (r.done) return;
-    // ---- linearisation of the next step at the estimate just decided (k_lin_packed) ----
-    if (w < D.nPackWaves) lin_wave<false, true>(D, w, lane, curNew, r.lambda, segl[wv]);
-}
-
 // end of a run of LM steps: the decision on the last tentative step (if one is pending), the estimate back in Rs / Ts / pts,
 // and both state words equal (a speculative launch behind this one must see "done" in the word its solver and update read)
 __global__ __launch_bounds__(256) void k_control_final(BaDev D) {

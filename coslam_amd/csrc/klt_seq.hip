@@ -677,8 +677,7 @@ cs_klt* cs_klt_create(const cs_klt_config* cfg, int device, int tap_mode) {
     }
     k->graphs = new std::vector<cs_klt::GraphEntry>();
     k->ev_pairs = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
-    const char* env = getenv("COSLAM_KLT_FUSED");
-    k->use_fused = !(env && env[0] == '0');
+    k->use_fused = true;   // (cs_klt_set_fused selects the per-pass schedule)
     return k;
 }
 
@@ -1325,11 +1324,8 @@ struct cs_klt_group {
     std::vector<cs_klt*> ks;
     hipStream_t stream;
     // host images into the device off the frame's critical path (cs_klt_group_stage_h): a ring of CS_STAGE_SLOTS x n images,
-    // a copy stream, per slot "copied" (recorded on the copy stream) and "free again" (recorded on the group's stream) events
+    // filled by a pull kernel on the group's own stream, in order with the frames (see cs_klt_group_stage_h)
     uint8_t* d_stage = nullptr;
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t copied[CS_STAGE_SLOTS] = {nullptr, nullptr, nullptr};
-    hipEvent_t freed[CS_STAGE_SLOTS] = {nullptr, nullptr, nullptr};
     int next_slot = 0;
 };
 
@@ -1369,14 +1365,9 @@ cs_klt_group* cs_klt_group_create(cs_klt* const* handles, int n) {
 
 void cs_klt_group_destroy(cs_klt_group* g) {
     if (!g) return;
-    if (g->copy_stream) {
+    if (g->d_stage) {
         (void)hipSetDevice(g->ks[0]->device);
-        (void)hipStreamSynchronize(g->copy_stream);
-        (void)hipStreamDestroy(g->copy_stream);
-        for (int q = 0; q < CS_STAGE_SLOTS; ++q) {
-            (void)hipEventDestroy(g->copied[q]);
-            (void)hipEventDestroy(g->freed[q]);
-        }
+        (void)hipStreamSynchronize(g->stream);
         (void)hipFree(g->d_stage);
     }
     delete g;
@@ -1384,8 +1375,8 @@ void cs_klt_group_destroy(cs_klt_group* g) {
 
 // ---- host images into the device, asynchronously -----------------------------------------------------------------------
 // GPUKLT::next(const unsigned char*) (reference src/tracking/GPUKLT.cpp:144-161) uploads the frame and then tracks it: the
-// copy sits on the frame's critical path.  Here the n host images of a FUTURE frame go into the next slot of a small ring on
-// the group's copy stream while the current frame is tracked; the slot's device pointers are then handed to
+// copy sits on the frame's critical path.  Here the n host images of a FUTURE frame go into the next slot of a small ring,
+// enqueued on the group's stream ahead of the frames that use them; the slot's device pointers are then handed to
 // cs_klt_group_prefetch_dev / _redetect_dev like any device image.  Pinned host memory (cs_pinned_alloc) makes the copies
 // truly asynchronous; pageable memory works, the runtime then stages it (and blocks the caller for the duration).
 int cs_klt_group_stage_h(cs_klt_group* g, const unsigned char* const* h_images, int* slot) {
@@ -1394,27 +1385,14 @@ int cs_klt_group_stage_h(cs_klt_group* g, const unsigned char* const* h_images, 
     int rc = bind_device(k0);
     if (rc) return rc;
     const size_t bytes = (size_t)k0->W * k0->H, n = g->ks.size();
-    if (!g->copy_stream) {
-        CS_HIP(hipMalloc((void**)&g->d_stage, bytes * n * CS_STAGE_SLOTS));
-        CS_HIP(hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
-        for (int q = 0; q < CS_STAGE_SLOTS; ++q) {
-            CS_HIP(hipEventCreateWithFlags(&g->copied[q], hipEventDisableTiming));
-            CS_HIP(hipEventCreateWithFlags(&g->freed[q], hipEventDisableTiming));
-        }
-    }
+    if (!g->d_stage) CS_HIP(hipMalloc((void**)&g->d_stage, bytes * n * CS_STAGE_SLOTS));
     const int q = g->next_slot;
     g->next_slot = (q + 1) % CS_STAGE_SLOTS;
-    // By default the pull runs on the group's OWN stream, in order with the frames: 57 us in front of the next tracker launch,
-    // on a stream that has slack (the key-frame solves bound the loop) -- measured 0.88-0.91 of the resident-image frame rate,
-    // against 0.84 with the pull on a second stream beside the tracker (two more cross-stream events per frame cost more than
-    // the serialisation; COSLAM_STAGE_INLINE=0 selects that form).  profiles/r03_upload.txt
-    static const bool inlinePull = !(getenv("COSLAM_STAGE_INLINE") && getenv("COSLAM_STAGE_INLINE")[0] == '0');
-    hipStream_t cs = inlinePull ? g->stream : g->copy_stream;
-    if (!inlinePull) {
-        // whatever read this slot's previous images was enqueued on the group's stream before this call
-        CS_HIP(hipEventRecord(g->freed[q], g->stream));
-        CS_HIP(hipStreamWaitEvent(g->copy_stream, g->freed[q], 0));
-    }
+    // The pull runs on the group's OWN stream, in order with the frames: 57 us in front of the next tracker launch, on a stream
+    // that has slack -- measured 0.88-0.91 of the resident-image frame rate, against 0.84 with the pull on a second stream beside
+    // the tracker (two more cross-stream events per frame cost more than the serialisation; profiles/r03_upload.txt).  Whatever
+    // read this slot's previous images was enqueued on the same stream before this call.
+    hipStream_t cs = g->stream;
     bool contiguous = true;  // the capture side wrote the n images back to back (one pinned ring entry per frame): ONE copy
     for (size_t i = 0; i < n; ++i) {
         if (!h_images[i]) {
@@ -1430,7 +1408,7 @@ int cs_klt_group_stage_h(cs_klt_group* g, const unsigned char* const* h_images, 
     auto one = [&](uint8_t* dst, const unsigned char* src, size_t nbytes) -> int {
         void* dsrc = nullptr;
         if (hipHostGetDevicePointer(&dsrc, (void*)src, 0) == hipSuccess && dsrc) {
-            static const int blocks = getenv("COSLAM_STAGE_BLOCKS") ? atoi(getenv("COSLAM_STAGE_BLOCKS")) : 16;  // a few CUs
+            const int blocks = 16;  // a few CUs
             // are plenty for a PCIe-bound pull (~90 KB in flight saturate the link); the tracker and the solves keep the rest
             hipLaunchKernelGGL(k_stage_pull, dim3(blocks), dim3(256), 0, cs, dst, (const uint8_t*)dsrc, nbytes);
             CS_CHECK_LAUNCH();
@@ -1446,18 +1424,16 @@ int cs_klt_group_stage_h(cs_klt_group* g, const unsigned char* const* h_images, 
         for (size_t i = 0; i < n; ++i)
             if ((rc = one(g->d_stage + ((size_t)q * n + i) * bytes, h_images[i], bytes))) return rc;
     }
-    CS_HIP(hipEventRecord(g->copied[q], cs));
     *slot = q;
     return CS_OK;
 }
 
-// the device images of a staged slot; the group's stream waits for the slot's copy (on the device: the host does not block)
+// the device images of a staged slot (the pull is ahead of every later use on the group's stream: nothing to wait for)
 int cs_klt_group_staged(cs_klt_group* g, int slot, const void** d_images) {
-    CS_REQUIRE(g && d_images && slot >= 0 && slot < CS_STAGE_SLOTS && g->copy_stream, "cs_klt_group_staged: bad arguments (stage first)");
+    CS_REQUIRE(g && d_images && slot >= 0 && slot < CS_STAGE_SLOTS && g->d_stage, "cs_klt_group_staged: bad arguments (stage first)");
     cs_klt* k0 = g->ks[0];
     int rc = bind_device(k0);
     if (rc) return rc;
-    CS_HIP(hipStreamWaitEvent(g->stream, g->copied[slot], 0));
     const size_t bytes = (size_t)k0->W * k0->H, n = g->ks.size();
     for (size_t i = 0; i < n; ++i) d_images[i] = g->d_stage + ((size_t)slot * n + i) * bytes;
     return CS_OK;

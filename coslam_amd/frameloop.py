@@ -507,6 +507,7 @@ class FrameLoop:
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.dev)   # noqa: E731
             self._dec = dict(att=z((cfg.p_reg, NA), torch.uint8), reg=z(self.n_map, torch.uint8), cnt=z(4, torch.int32), ref_cnt=z(1, torch.int32),
                              scr=z(register_decide_scratch_bytes(NA, cfg.n_feat, cfg.p_reg), torch.uint8), s2m=None)
+            torch.cuda.synchronize()   # (the zero fills ran on torch's stream: done before the pose stream touches the buffers)
         D = self._dec
         if self.world > 1:
             self._gather_candidates()
@@ -530,6 +531,7 @@ class FrameLoop:
         L, vp, ps = coslam_amd.lib(), C_.c_void_p, self.pose_s.cuda_stream
         if not hasattr(self, "_cand"):
             self._cand = (torch.zeros(3 * nc * P, dtype=torch.int32, device=self.dev), torch.zeros(3 * nc * P * self.world, dtype=torch.int32, device=self.dev))
+            torch.cuda.synchronize()   # (zero-filled on torch's stream, used on the pose stream)
         send, recv = self._cand
         o = self.reg_out[1]
         check(L.cs_register_candidates_pack_dev(self.device, vp(ps), P, NA, self.c0, nc, vp(o["slot"].data_ptr()), vp(o["flags"].data_ptr()),
@@ -591,6 +593,16 @@ class FrameLoop:
             w.wait()
         self.ba_ws.wait()
         self.torch.cuda.synchronize()
+
+    def digest_parts(self):
+        """per-array short digests (diagnostic: finding where two runs part ways)"""
+        import hashlib
+
+        self.drain()
+        names = ("map", "cov", "mapflags", "slot2map", "trackspan", "xy", "state", "isstatic", "R0", "R1", "t0", "t1", "pf", "newpt", "sfn")
+        arrs = (self.d_map, self.d_cov, self.d_mapflags, self.d_slot2map, self.d_trackspan, self.d_xy, self.d_state, self.d_isstatic,
+                self.d_R[0], self.d_R[1], self.d_t[0], self.d_t[1], self.d_pf, self.d_newpt, self.d_sfn)
+        return {n: hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()[:10] for n, t in zip(names, arrs)}
 
     def digest(self):
         """sha256 over the state every rank must agree on (the map, its flags and covariances, every camera's records and poses)"""

@@ -169,10 +169,12 @@ int cs_klt_group_prefetch_dev(cs_klt_group* g, const void* const* d_images_next)
  * src/tracking/GPUKLT.cpp:144-161).  cs_klt_group_stage_h copies the n host images of a FUTURE frame (W*H bytes each; pinned
  * memory -- cs_pinned_alloc -- is PULLED by a copy kernel: a kernel launch for the caller; hipMemcpyAsync blocks the calling
  * thread for 160-280 us per 2.4 MB here; pageable memory falls back to it) into the next slot of a ring of 3 and returns
- * the slot; cs_klt_group_staged orders the group's stream behind that copy (a stream-side wait, the host does not block) and
- * returns the slot's device images, which then go to cs_klt_group_prefetch_dev / _redetect_dev like any device image.
+ * the slot; the pull is enqueued on the group's stream, ahead of every later use of the slot.  cs_klt_group_staged returns the
+ * slot's device images, which then go to cs_klt_group_prefetch_dev / _redetect_dev like any device image.
  * Stage frame f+2 while f is tracked and f+1 is prefetched.  Images written back to back (one ring entry per frame) go in
- * one copy. */
+ * one copy.  LIFETIME: the call only ENQUEUES the pull -- the host images must stay valid and unchanged until the group's
+ * stream has passed it (e.g. until the frame that uses the slot has been fetched, or cs_klt_group_synchronize); a slot is
+ * reused three stage calls later, by which time the frames that read it must have been enqueued (they are, in stream order). */
 int cs_klt_group_stage_h(cs_klt_group* g, const unsigned char* const* h_images, int* slot);
 int cs_klt_group_staged(cs_klt_group* g, int slot, const void** d_images);
 void* cs_pinned_alloc(size_t bytes);
@@ -727,12 +729,6 @@ void cs_ba_destroy(cs_ba* b);
  * workspace's own.  Waits for queued asynchronous solves. */
 void* cs_ba_stream(cs_ba* b);
 int cs_ba_set_stream(cs_ba* b, void* hip_stream);
-/* The LM loop of the device-resident solves of this workspace (orders 37..176, pair lists: the frame loop's joint local BA and
- * inter-camera solve) as ONE cooperative launch of at most n_workgroups workgroups that keep a compute unit each for the whole
- * run, instead of four short dependent kernels per LM step that queue behind whatever else fills the chip.  The caller
- * guarantees that n_workgroups compute units can be had: other persistent kernels are budgeted for the rest of the chip
- * (cs_klt_set_cu_count(total - n_workgroups)).  0 = one launch per phase (the default). */
-int cs_ba_set_persistent(cs_ba* b, int n_workgroups);
 int cs_ba_robust_h(cs_ba* b, int C, int P, int nObs, const double* Ks, double* Rs, double* Ts, double* pts,
                    const int* obs_ptr, const int* obs_cam, const double* obs_xy, int nCamsCon, int nPtsCon,
                    double maxErr, int maxIter, int innerMaxIter, int* out_outlier, cs_ba_stats* stats);
