@@ -625,3 +625,16 @@ def test_ba_window_requests_queue_up_behind_a_frame_loop_that_runs_ahead(hip):
     assert np.max(np.abs(R - R_o)) < 1e-6 and np.max(np.abs(T - T_o)) < 1e-6 and np.max(np.abs(M[sane] - M_o[sane])) < 1e-6
     win.close()
     ws.close()
+
+
+@pytest.mark.parametrize("n_cams,n_pts,ncon,npcon", [(5, 60, 2, 2), (9, 120, 2, 3)])
+def test_device_ba_ends_at_a_minimum_of_an_independently_written_cost(hip, n_cams, n_pts, ncon, npcon):
+    """The device solve's end point against a cost written from scratch in numpy (tests/ba_minimum_check.py): the reported cost is
+    that cost over the solve's inliers, its finite-difference gradient is zero there, scipy's least squares finds nothing better."""
+    from tests.ba_minimum_check import assert_is_a_minimum
+
+    pr, ptr, cam, xy = ba_inputs(n_cams=n_cams, n_pts=n_pts, noise=0.5, outlier_frac=0.05, seed=77 + n_cams)
+    R, T, M = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
+    out, st = coslam_amd.bundleAdjustRobust(ncon, pr["Ks"], R, T, npcon, M, (ptr, cam, xy), 6.0, 4, 60)
+    assert st.cost < st.cost0 and 0 < out.sum() < 0.2 * len(out)
+    assert_is_a_minimum(pr["Ks"], ptr, cam, xy, ncon, npcon, R, T, M, out, st.cost)
