@@ -248,7 +248,7 @@ __device__ __forceinline__ void cs_wave_sum_many_d(double (&v)[N]) {
 
 // The pose stream's kernels are a chain of short, latency-bound launches that share every SIMD with the persistent tracker's
 // two resident waves: their waves ask for the highest issue priority (s_setprio 3; the tracker has slack -- its frame is done long
-// before the pose stream wants the next one -- and runs at the default 0).  A/B in profiles/r04_setprio.txt.
+// before the pose stream wants the next one -- and runs at the default 0).  A/B in profiles/r04_ab_runs.txt.
 #define CS_POSE_STREAM_PRIO() __builtin_amdgcn_s_setprio(3)
 
 #endif  // __HIPCC__

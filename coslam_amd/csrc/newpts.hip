@@ -113,7 +113,10 @@ __global__ __launch_bounds__(256) void k_np_match(NpArgs A) {
     // the pair's candidates: the disparity guide (when there are seeds: a WAVE per candidate, the seeds over the lanes, the nearest
     // -- the first of equals -- by a reduction), then into the sort arrays
     int nAll = *A.pairCount[a];
-    if (nAll > A.pairCap) nAll = A.pairCap;
+    if (nAll > A.pairCap) {   // (the NCC stage kept only pairCap of its passing pairs, in no fixed order: say so)
+        nAll = A.pairCap;
+        if (tid == 0 && A.counts) atomicOr(A.counts + 3, 1);
+    }
     for (int q = wv; q < nAll; q += 4) {
         const cs_ncc_pair p = A.pairs[a][q];
         bool ok = p.i >= 0 && p.i < N && p.j >= 0 && p.j < N;   // (uniform over the wave)

@@ -78,7 +78,9 @@ __device__ __forceinline__ double maha_dist2(double mx, double my, double bx, do
     return dx * (ivar[0] * dx + ivar[1] * dy) + dy * (ivar[2] * dx + ivar[3] * dy);
 }
 
-constexpr int RG_WAVES = 16;      // waves per workgroup: each scans 1 / 16 of the staged features for the block's 64 points
+constexpr int RG_WAVES = 16;      // waves per workgroup: each scans 1 / 16 of the staged features for the block's 64 points (8 or 4 waves:
+                                  // the same frame rate in the loop, 2098 / 2053-2066 against 2070-2084 frames/s: profiles/r04_ab_runs.txt)
+constexpr int RG_ROWS = RG_WAVES > 6 ? RG_WAVES : 6;   // rows of the minima table (it first carries the 6 projection values)
 constexpr int RG_CHUNK = 4096;    // features staged in LDS at a time (64 KB); longer lists are scanned chunk by chunk
 
 // One workgroup = 64 map points x one camera.  Lane = point: its projection and scaled inverse covariance live in
@@ -98,8 +100,8 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
     const int CH = N < RG_CHUNK ? N : RG_CHUNK;
     double* sx = lds;
     double* sy = lds + CH;
-    double* cd = lds + 2 * CH;                        // [RG_WAVES][64]
-    int* ci = (int*)(cd + RG_WAVES * 64);             // [RG_WAVES][64]
+    double* cd = lds + 2 * CH;                        // [RG_ROWS][64]
+    int* ci = (int*)(cd + RG_ROWS * 64);              // [RG_WAVES][64]
     const size_t o = (size_t)p * A.nCams + c;
     int outSlot = -1, outFlags = 0;
     double m0 = 0, m1 = 0, var[4] = {0, 0, 0, 0}, outDist = 0;
@@ -270,7 +272,7 @@ extern "C" int cs_register_search_passes_range_dev(int device, void* hip_stream,
     }
     CS_HIP(hipSetDevice(device));
     const int CH = N < RG_CHUNK ? N : RG_CHUNK;
-    const size_t ldsBytes = (size_t)2 * CH * sizeof(double) + (size_t)RG_WAVES * 64 * (sizeof(double) + sizeof(int));
+    const size_t ldsBytes = (size_t)2 * CH * sizeof(double) + (size_t)RG_ROWS * 64 * sizeof(double) + (size_t)RG_WAVES * 64 * sizeof(int);
     if (ldsBytes > 64 * 1024) {
         static bool raised = false;
         if (!raised) {

@@ -2,7 +2,7 @@
 //
 // hipMemsetAsync / hipMemcpyAsync between kernels cost far more than the bytes they move: each is its own dispatch with a
 // barrier on either side, measured on the pose stream 4-5 us of execution plus 12-13 us of idle stream before the next operation
-// (profiles/r04_pose_stream_ops.txt), against back-to-back dispatch for ordinary kernels.  The key-frame path alone issued 14
+// (profiles/r04_ab_runs.txt), against back-to-back dispatch for ordinary kernels.  The key-frame path alone issued 14
 // of them.  cs_small_ops collects up to CS_SMALL_OPS operations (copy or fill, any byte count and alignment) and runs them as
 // one launch: blockIdx.y = operation, the x blocks stride over its 16-byte words, the unaligned head and tail byte by byte.
 #pragma once

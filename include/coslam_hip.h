@@ -387,6 +387,9 @@ typedef struct cs_poseupdate_cam {
     double* reprojErr;       /* N in/out: FeaturePoint::reprojErr (gate) */
     unsigned char* isStatic; /* N in/out: FeaturePoint::type == TYPE_FEATPOINT_STATIC (dynamic test) */
 } cs_poseupdate_cam;
+/* A history handle also owns scratch that the map-point calls below fill and read (the camera centres of the ring by walk depth,
+ * the worklist of cs_map_points_classify_dev): calls on ONE handle belong on ONE stream at a time, also those that take it
+ * as `const` (two streams running e.g. cs_refine_map_points_dev on the same handle at once would share that scratch). */
 typedef struct cs_track_history cs_track_history;
 cs_track_history* cs_track_history_create(int device, int nCams, int N, int histLen /* <= 512 */);
 void cs_track_history_destroy(cs_track_history* h);
@@ -461,7 +464,13 @@ int cs_update_new_poses_points_dev(const cs_track_history* h, void* hip_stream, 
  * updateStaticPointPosition (per camera holding a feature of the point in d_pointFeat: that feature and the widest-parallax one
  * further back on its track), then triangulateMultiView + getTriangulateCovMat IN PLACE -- whatever the point's type, no frame
  * test.  The reference does not look at the number of views; here a point with fewer than two is left alone.  The same kernel,
- * history and ordering rules as cs_update_new_poses_points_dev; cams: K, iK, trackSpan.  d_count [1] or NULL: points refined. */
+ * history and ordering rules as cs_update_new_poses_points_dev; cams: K, iK, trackSpan.  d_count [1] or NULL: points refined.
+ * KNOWN DIVERGENCE (re-linked tracks): when a point that still holds a STALE feature in a camera (an older frame's, its track lost)
+ * is registered to a new track there, the reference re-links pFeat->preFrame to that stale feature (:775-779), so its walks -- here,
+ * updateStaticPointPosition, isStaticPoint -- continue into the OLD track and no longer see the new track's earlier frames.  The
+ * kernels walk the slot's current track, [trackSpan first, this frame], within the history ring: for such a point the second view
+ * may be another frame than the reference's (same camera, same point; the triangulation stays a valid two-view-per-camera one).
+ * cs_map_points_classify_dev takes d_featFrame / d_featFirst for the stale feature itself; a full re-link table is not kept. */
 int cs_refine_map_points_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap,
                              const unsigned char* d_select, double* d_mapPts, double* d_mapCov, double pixelErrVar, int* d_count);
 
