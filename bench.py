@@ -600,6 +600,24 @@ def main():
                        "what": f"the same loop with every frame's {nc} x {W * H} B images copied from pinned host memory inside the "
                                "loop (cs_klt_group_stage_h: copy stream + ring of 3 device slots, two frames ahead of the tracker)"}
         loop.stage_slot.clear()
+    ref_policy = None
+    if world == 1 and not args.no_secondary and loop.out is not None:
+        # SECONDARY: the reference's own request policy -- CoSLAM::requestForBA refuses a request while the previous bundle adjustment
+        # is still running (src/app/SL_CoSLAM.cpp:1750-1755) -- instead of solving every key frame's window: same loop, same frames
+        loop.drain()
+        loop.skip_busy, w0, s0 = True, loop.n_windows, loop.n_skipped
+        run(args.warmup)
+        barrier()
+        w1, s1 = loop.n_windows, loop.n_skipped
+        tp = time.perf_counter()
+        run(args.steps)
+        barrier()
+        dtp = time.perf_counter() - tp
+        loop.skip_busy = False
+        ref_policy = {"frames_per_s": args.steps / dtp, "ms_per_step": dtp / args.steps * 1e3, "ratio_to_value": (args.steps / dtp) / (args.steps / dt),
+                      "windows_solved": loop.n_windows - w1, "requests_dropped_because_the_previous_solve_was_running": loop.n_skipped - s1,
+                      "what": "the same loop with the reference's request policy: a key frame's window BA is requested only when no bundle "
+                              "adjustment is running (CoSLAM::requestForBA, SL_CoSLAM.cpp:1750-1755); the headline solves EVERY window"}
     gc.enable()
     replicas = None
     if world > 1:
@@ -961,7 +979,7 @@ def main():
                                       loop.ncc["np_cnt"].cpu().tolist()[:4])),
                            "matches_per_pair_last_run": loop.ncc["np_cnt"].cpu().tolist()[4:4 + N_CAMS - 1],
                            "map_points_in_use": int(loop.d_mapcount.item()), "map_points_at_start": n_pts0, "map_capacity": loop.n_map},
-                       "with_upload": with_upload, "cxx_frame_loop": cxx,
+                       "with_upload": with_upload, "secondary_reference_ba_request_policy": ref_policy, "cxx_frame_loop": cxx,
                        "collectives": None if world == 1 else ("libcoslam_hip RCCL (C-ABI)" if loop.native else "torch.distributed " + dist_backend),
                        "streams": "tracker group | hand-back + pose + map update + registration (event-ordered behind the tracker of the same "
                                   "frame) | inter-camera solve and joint local BA each on its workspace's worker thread + stream "

@@ -273,29 +273,19 @@ constexpr int NC_MAX_JOBS = 8;
 struct NcJobs {
     NcArgs job[NC_MAX_JOBS];  // blockIdx.z = camera pair of a group launch (cs_ncc_epi_pairs_group_dev)
 };
+constexpr int NC_CT = 4;   // 64-column tiles a workgroup walks: the rows' operands and constants are loaded once for 256 columns
 template <bool SPARSE>
 __global__ __launch_bounds__(256) void k_ncc_epi_mat(NcJobs J) {
     const NcArgs& A = J.job[blockIdx.z];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int M = A.s1.n, N = A.s2.n;
     const int i0 = blockIdx.y * 64 + 16 * wv;  // this wave's 16 rows (features of camera 1)
-    const int j0 = blockIdx.x * 64;            // the tile's 64 columns (features of camera 2)
     if (i0 >= M) return;
     const int lr = lane & 15, lk = lane >> 4;  // MFMA operand layout: row / column lr, k-chunk lk (8 bytes)
-    nc_i32x4 acc[4];
+    // the rows' side, once: the four k-chunks of the A operand, and what the epilogue needs of rows 4 lk .. 4 lk + 3
+    long a[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (nc_i32x4){0, 0, 0, 0};
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const int off = 32 * ks + 8 * lk;
-        const long a = nc_row_chunk(A.s1.blocks, i0 + lr, M, off);
-        long b[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = nc_row_chunk(A.s2.blocks, j0 + 16 * t + lr, N, off);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b[t], acc[t], 0, 0, 0);
-    }
-    // ---- epilogue: lane holds rows 4 lk .. 4 lk + 3 of column lr of every 16 x 16 tile ----
+    for (int ks = 0; ks < 4; ++ks) a[ks] = nc_row_chunk(A.s1.blocks, i0 + lr, M, 32 * ks + 8 * lk);
     double x1[4], y1[4], A1[4], C1[4];
     int v1[4], s1[4];
 #pragma unroll
@@ -309,58 +299,75 @@ __global__ __launch_bounds__(256) void k_ncc_epi_mat(NcJobs J) {
         v1[r] = in ? A.s1.valid[i] : 0;
         s1[r] = (int)A1[r] - NC_LEN * 128;  // sum (I1 - 128)
     }
+    for (int ct = 0; ct < NC_CT; ++ct) {
+        const int j0 = (blockIdx.x * NC_CT + ct) * 64;  // the tile's 64 columns (features of camera 2)
+        if (j0 >= N) break;
+        nc_i32x4 acc[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int j = j0 + 16 * t + lr;
-        if (j >= N) continue;
-        const double bx = A.s2.x[j], by = A.s2.y[j];
-        const double A2 = A.s2.abc[4 * (size_t)j], C2 = A.s2.abc[4 * (size_t)j + 2];
-        const int v2 = A.s2.valid[j];
-        const int s2 = (int)A2 - NC_LEN * 128;
-        // epipolarError(F, p1, p2): the line of p2
-        const double l0 = (A.F[0] * bx + A.F[1] * by) + A.F[2];
-        const double l1 = (A.F[3] * bx + A.F[4] * by) + A.F[5];
-        const double l2 = (A.F[6] * bx + A.F[7] * by) + A.F[8];
-        const double nn = sqrt(l0 * l0 + l1 * l1);
-        const double den = nn > 0 ? nn : 1.0;
-        // |l . p1| / den <= epiMax is decided without the division wherever it is not close: a numerator beyond epiMax den (1 + 1e-12)
-        // fails for certain (the margin is 10^4 roundings wide), and a pair that fails writes wNone whatever its quotient is.  Only
-        // the few pairs near or inside the band pay the IEEE division (~20 instructions of the ~26 this test used to cost per pair).
-        const double numMax = (A.epiMax * den) * (1.0 + 1e-12);
+        for (int t = 0; t < 4; ++t) acc[t] = (nc_i32x4){0, 0, 0, 0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = i0 + 4 * lk + r;
-            if (i >= M) continue;
-            const double num = fabs((l0 * x1[r] + l1 * y1[r]) + l2);
-            double e = A.wNone, c = A.wNone;
-            bool pass = false;
-            double epiErr = 0;
-            bool near = v1[r] && v2 && !(num > numMax);   // (NaN stays in: the exact test below decides as it always did)
-            if (near) {
-                epiErr = num / den;                        // SL_FeatureMatching.cpp:24-25
-                near = epiErr <= A.epiMax;                 // :26
-            }
-            if (near) {
-                const int d = acc[t][r] + 128 * s1[r] + 128 * s2 + NC_LEN * 128 * 128;  // sum I1 I2, exact
-                const double ncc = (((double)NC_LEN * (double)d - A1[r] * A2) * C1[r]) * C2;  // SL_NCCBlock.cpp:263
-                if (ncc >= A.nccMin) {                                          // :29-31
-                    e = epiErr;
-                    c = ncc;
-                    pass = true;
+        for (int ks = 0; ks < 4; ++ks) {
+            const int off = 32 * ks + 8 * lk;
+            long b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[t] = nc_row_chunk(A.s2.blocks, j0 + 16 * t + lr, N, off);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a[ks], b[t], acc[t], 0, 0, 0);
+        }
+        // ---- epilogue: lane holds rows 4 lk .. 4 lk + 3 of column lr of every 16 x 16 tile ----
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = j0 + 16 * t + lr;
+            if (j >= N) continue;
+            const double bx = A.s2.x[j], by = A.s2.y[j];
+            const double A2 = A.s2.abc[4 * (size_t)j], C2 = A.s2.abc[4 * (size_t)j + 2];
+            const int v2 = A.s2.valid[j];
+            const int s2 = (int)A2 - NC_LEN * 128;
+            // epipolarError(F, p1, p2): the line of p2
+            const double l0 = (A.F[0] * bx + A.F[1] * by) + A.F[2];
+            const double l1 = (A.F[3] * bx + A.F[4] * by) + A.F[5];
+            const double l2 = (A.F[6] * bx + A.F[7] * by) + A.F[8];
+            const double nn = sqrt(l0 * l0 + l1 * l1);
+            const double den = nn > 0 ? nn : 1.0;
+            // |l . p1| / den <= epiMax is decided without the division wherever it is not close: a numerator beyond epiMax den (1 + 1e-12)
+            // fails for certain (the margin is 10^4 roundings wide), and a pair that fails writes wNone whatever its quotient is.  Only
+            // the few pairs near or inside the band pay the IEEE division (~20 instructions of the ~26 this test used to cost per pair).
+            const double numMax = (A.epiMax * den) * (1.0 + 1e-12);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + 4 * lk + r;
+                if (i >= M) continue;
+                const double num = fabs((l0 * x1[r] + l1 * y1[r]) + l2);
+                double e = A.wNone, c = A.wNone;
+                bool pass = false;
+                double epiErr = 0;
+                bool near = v1[r] && v2 && !(num > numMax);   // (NaN stays in: the exact test below decides as it always did)
+                if (near) {
+                    epiErr = num / den;                        // SL_FeatureMatching.cpp:24-25
+                    near = epiErr <= A.epiMax;                 // :26
                 }
-            }
-            if (SPARSE) {
-                if (pass) {
-                    const int at = atomicAdd(A.pairCount, 1);
-                    if (at < A.pairCap) {
-                        cs_ncc_pair q;
-                        q.i = i, q.j = j, q.epi = e, q.ncc = c;
-                        A.pairs[at] = q;
+                if (near) {
+                    const int d = acc[t][r] + 128 * s1[r] + 128 * s2 + NC_LEN * 128 * 128;  // sum I1 I2, exact
+                    const double ncc = (((double)NC_LEN * (double)d - A1[r] * A2) * C1[r]) * C2;  // SL_NCCBlock.cpp:263
+                    if (ncc >= A.nccMin) {                                          // :29-31
+                        e = epiErr;
+                        c = ncc;
+                        pass = true;
                     }
                 }
-            } else {
-                A.epiMat[(size_t)i * N + j] = e;
-                A.nccMat[(size_t)i * N + j] = c;
+                if (SPARSE) {
+                    if (pass) {
+                        const int at = atomicAdd(A.pairCount, 1);
+                        if (at < A.pairCap) {
+                            cs_ncc_pair q;
+                            q.i = i, q.j = j, q.epi = e, q.ncc = c;
+                            A.pairs[at] = q;
+                        }
+                    }
+                } else {
+                    A.epiMat[(size_t)i * N + j] = e;
+                    A.nccMat[(size_t)i * N + j] = c;
+                }
             }
         }
     }
@@ -494,7 +501,7 @@ extern "C" int cs_ncc_epi_mat_dev(int device, void* hip_stream, const double F[9
     A.pairs = nullptr, A.pairCap = 0, A.pairCount = nullptr;
     NcJobs J;
     J.job[0] = A;
-    hipLaunchKernelGGL(k_ncc_epi_mat<false>, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0,
+    hipLaunchKernelGGL(k_ncc_epi_mat<false>, dim3((unsigned)((N + 64 * NC_CT - 1) / (64 * NC_CT)), (unsigned)((M + 63) / 64)), dim3(256), 0,
                        (hipStream_t)hip_stream, J);
     CS_CHECK_LAUNCH();
     return CS_OK;
@@ -526,7 +533,7 @@ extern "C" int cs_ncc_epi_pairs_dev(int device, void* hip_stream, const double F
     A.pairs = d_pairs, A.pairCap = pairCap, A.pairCount = d_pairCount;
     NcJobs J;
     J.job[0] = A;
-    hipLaunchKernelGGL(k_ncc_epi_mat<true>, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0,
+    hipLaunchKernelGGL(k_ncc_epi_mat<true>, dim3((unsigned)((N + 64 * NC_CT - 1) / (64 * NC_CT)), (unsigned)((M + 63) / 64)), dim3(256), 0,
                        (hipStream_t)hip_stream, J);
     CS_CHECK_LAUNCH();
     return CS_OK;
@@ -568,7 +575,7 @@ extern "C" int cs_ncc_epi_pairs_group_dev(int device, void* hip_stream, int nCam
     }
     CS_HIP(zero.run(s));
     if (n == 0) return CS_OK;
-    hipLaunchKernelGGL(k_ncc_epi_mat<true>, dim3((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64), (unsigned)nJobs), dim3(256), 0, s, J);
+    hipLaunchKernelGGL(k_ncc_epi_mat<true>, dim3((unsigned)((n + 64 * NC_CT - 1) / (64 * NC_CT)), (unsigned)((n + 63) / 64), (unsigned)nJobs), dim3(256), 0, s, J);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

@@ -28,8 +28,9 @@
 namespace {
 
 constexpr int NP_MAX_CAMS = 16, NP_MAX_CAND = 2048, NP_MAX_SEEDS = 512, NP_MAX_TRACKS = 4096, NP_MAX_N = 32768;
-constexpr int NP_BAL_WORDS = 512;
-constexpr int NP_MAX_DYN = 4096;     // features of certain dynamic points decidePointType's mask is drawn from (frame sizes up to 4032 x 4032)   // map points per round of the seed scan / 64
+constexpr int NP_MAX_DYN = 4096;       // features of certain dynamic points decidePointType's mask is drawn from (frame sizes up to 4032 x 4032)
+constexpr int NP_SEGS = 8;             // a pair's seed scan is cut into this many map segments, a workgroup each (k_np_prep)
+constexpr int NP_DYN_PER_CAM = 1024;   // features of certain dynamic points per camera that decidePointType's mask takes (k_np_prep)
 
 struct NpArgs {
     int nCams, N, mapCap, curFrame, pairCap, minLen, W, H;
@@ -45,6 +46,10 @@ struct NpArgs {
     int* matchIdx;                           // scratch [nCams - 1][N]: feature of camera a -> its match in camera a + 1 (matched rows only)
     unsigned* rowMask;                       // scratch [nCams - 1][N / 32 words]: bit i = feature i of camera a has a match in a + 1
     unsigned* colMask;                       // scratch [nCams - 1][N / 32 words]: bit j = feature j of camera a + 1 is such a match
+    int* seedIdx;                            // scratch [nCams - 1][NP_SEGS][NP_MAX_SEEDS]: k_np_prep's seeds of a pair, map indices in map order
+    int* seedCnt;                            // scratch [nCams - 1][NP_SEGS]
+    unsigned* dynList;                       // scratch [nCams][NP_DYN_PER_CAM]: rounded positions of this frame's features on CERTAIN dynamic points
+    int* dynCnt;                             // scratch [nCams]
     int* counts;                             // [4 + nCams] out: new points, tracks, tracks >= minLen, flags (bit 0: a candidate list
                                              // overflowed, bit 1: the map is full, bit 2: more than NP_MAX_DYN dynamic features), then the
                                              // matches of every pair
@@ -54,61 +59,93 @@ __device__ __forceinline__ bool np_before(double sa, unsigned ia, double sb, uns
     return sa > sb || (sa == sb && ia < ib);
 }
 
+// ---- preparation, many workgroups side by side (both were serial scans inside the one-workgroup kernels below: 48 / 15 us) -----------
+// Workgroups [0, (nCams - 1) * NP_SEGS): getSeedsBetween (:97-127) of camera pair a for ONE segment of the map -- the certain, not
+// false points with a feature of this frame in BOTH cameras (two features: numVisCam >= 2 holds), in map order (ballots per wave,
+// the waves' totals through LDS), as map indices; k_np_match strings the segments together.
+// Workgroups behind them, one per camera: the features of this frame that belong to CERTAIN dynamic map points -- what
+// decidePointType's mask is drawn from (:38-59); this run's new dynamic points are added by k_np_reconstruct itself.
+__global__ __launch_bounds__(256) void k_np_prep(NpArgs A) {
+    __shared__ int wTot[4];
+    __shared__ int sBase;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, N = A.N, C = A.nCams, nP = C - 1;
+    if ((int)blockIdx.x < nP * NP_SEGS) {
+        const int a = blockIdx.x / NP_SEGS, seg = blockIdx.x % NP_SEGS, b = a + 1;
+        const int cap = *A.mapCount < A.mapCap ? *A.mapCount : A.mapCap;
+        const int per = ((cap + NP_SEGS - 1) / NP_SEGS + 255) / 256 * 256;
+        const int m0 = seg * per, m1 = min(m0 + per, cap);
+        int* out = A.seedIdx + ((size_t)a * NP_SEGS + seg) * NP_MAX_SEEDS;
+        if (tid == 0) sBase = 0;
+        __syncthreads();
+        for (int c0 = m0; c0 < m1 && sBase < NP_MAX_SEEDS; c0 += 256) {
+            const int m = c0 + tid;
+            bool in = false;
+            if (m < m1) {
+                const unsigned char fl = A.mapFlags[m];
+                in = !(fl & (CS_MAP_FALSE | CS_MAP_UNCERTAIN)) && A.pointFeat[(size_t)m * C + a] >= 0 && A.pointFeat[(size_t)m * C + b] >= 0;
+            }
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
+            if (lane == 0) wTot[wv] = __popcll(bal);
+            __syncthreads();
+            int k = sBase;
+            for (int w = 0; w < wv; ++w) k += wTot[w];
+            k += __popcll(bal & ((1ull << lane) - 1ull));
+            if (in && k < NP_MAX_SEEDS) out[k] = m;
+            __syncthreads();
+            if (tid == 0) sBase = min(sBase + wTot[0] + wTot[1] + wTot[2] + wTot[3], NP_MAX_SEEDS);
+            __syncthreads();
+        }
+        if (tid == 0) A.seedCnt[a * NP_SEGS + seg] = sBase;
+        return;
+    }
+    const int c = blockIdx.x - nP * NP_SEGS;
+    if (c >= C) return;
+    if (tid == 0) sBase = 0;
+    __syncthreads();
+    for (int sl = tid; sl < N; sl += 256) {
+        const int st = A.cam[c].state[sl], m = A.cam[c].slot2map[sl];
+        if ((st == 0 || st == 1) && m >= 0 && m < A.mapCap && A.mapFlags[m] == CS_MAP_DYNAMIC) {
+            const int x = (int)(A.cam[c].xy[sl] + 0.5), y = (int)(A.cam[c].xy[N + sl] + 0.5);
+            if (x + 20 >= 0 && x - 20 < A.W && y + 20 >= 0 && y - 20 < A.H) {   // (a square that misses the image marks nothing)
+                const int k = atomicAdd(&sBase, 1);
+                if (k < NP_DYN_PER_CAM) A.dynList[(size_t)c * NP_DYN_PER_CAM + k] = ((unsigned)(y + 64) << 12) | (unsigned)(x + 64);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) A.dynCnt[c] = sBase;   // (beyond NP_DYN_PER_CAM: k_np_reconstruct raises flag bit 2)
+}
+
 // one workgroup per camera pair: seeds, disparity guide, the candidates sorted, the greedy walk
 __global__ __launch_bounds__(256) void k_np_match(NpArgs A) {
     __shared__ double sKey[NP_MAX_CAND];
     __shared__ unsigned sIdx[NP_MAX_CAND];
     __shared__ double sSeed[NP_MAX_SEEDS][4];   // s1.x, s1.y, d.x, d.y (the first NP_MAX_SEEDS seeds in map order)
     __shared__ unsigned sRow[NP_MAX_N / 32], sCol[NP_MAX_N / 32];
-    __shared__ unsigned long long sBal[NP_BAL_WORDS];   // a round's map points, 64 per word: is the point a seed of this pair
-    __shared__ int sWave[4];
     __shared__ int sNSeeds, sNCand;
     const int a = blockIdx.x, b = a + 1, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, N = A.N, C = A.nCams;
     const int nWords = (N + 31) / 32;
     for (int q = tid; q < nWords; q += 256) sRow[q] = 0, sCol[q] = 0;
-    if (tid == 0) sNSeeds = 0, sNCand = 0;
-    __syncthreads();
-    // getSeedsBetween (:97-127): the certain, not false points with a feature in BOTH cameras (two features: numVisCam >= 2 holds),
-    // in map order.  Each wave takes a quarter of the round's map indices, 64 at a time (coalesced, nothing to wait for between
-    // the chunks); the ballots go to LDS, the waves' totals give each its place, a second walk over the set bits writes the seeds.
+    // the pair's seeds: k_np_prep's segments strung together (map order), the first NP_MAX_SEEDS of them
     {
-        const int cap = *A.mapCount < A.mapCap ? *A.mapCount : A.mapCap;
-        for (int r0 = 0; r0 < cap && sNSeeds < NP_MAX_SEEDS; r0 += 64 * NP_BAL_WORDS) {
-            const int nw = min(NP_BAL_WORDS, (cap - r0 + 63) / 64), perWave = (nw + 3) / 4;
-            const int w0 = wv * perWave, w1 = min(w0 + perWave, nw);
-            int cnt = 0;
-            for (int w = w0; w < w1; ++w) {
-                const int m = r0 + 64 * w + lane;
-                bool in = false;
-                if (m < cap) {
-                    const unsigned char fl = A.mapFlags[m];
-                    const int s1 = A.pointFeat[(size_t)m * C + a], s2 = A.pointFeat[(size_t)m * C + b];
-                    in = !(fl & (CS_MAP_FALSE | CS_MAP_UNCERTAIN)) && s1 >= 0 && s2 >= 0;
-                }
-                const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
-                if (lane == 0) sBal[w] = bal;
-                cnt += __popcll(bal);
-            }
-            if (lane == 0) sWave[wv] = cnt;
-            __syncthreads();
-            int k = sNSeeds;
-            for (int w = 0; w < wv; ++w) k += sWave[w];
-            for (int w = w0; w < w1 && k < NP_MAX_SEEDS; ++w) {
-                const unsigned long long bal = sBal[w];
-                const int kk = k + __popcll(bal & ((1ull << lane) - 1ull));
-                if (((bal >> lane) & 1ull) && kk < NP_MAX_SEEDS) {
-                    const int m = r0 + 64 * w + lane;
-                    const int s1 = A.pointFeat[(size_t)m * C + a], s2 = A.pointFeat[(size_t)m * C + b];
-                    const double x1 = A.cam[a].xy[s1], y1 = A.cam[a].xy[N + s1], x2 = A.cam[b].xy[s2], y2 = A.cam[b].xy[N + s2];
-                    sSeed[kk][0] = x1, sSeed[kk][1] = y1, sSeed[kk][2] = x2 - x1, sSeed[kk][3] = y2 - y1;
-                }
-                k += __popcll(bal);
-            }
-            __syncthreads();
-            if (tid == 0) sNSeeds = min(sNSeeds + sWave[0] + sWave[1] + sWave[2] + sWave[3], NP_MAX_SEEDS);
-            __syncthreads();
+        int off[NP_SEGS + 1];
+        off[0] = 0;
+#pragma unroll
+        for (int g = 0; g < NP_SEGS; ++g) off[g + 1] = off[g] + A.seedCnt[a * NP_SEGS + g];
+        const int total = off[NP_SEGS] < NP_MAX_SEEDS ? off[NP_SEGS] : NP_MAX_SEEDS;
+        if (tid == 0) sNSeeds = total, sNCand = 0;
+        for (int k = tid; k < total; k += 256) {
+            int g = 0, base = 0;
+#pragma unroll
+            for (int q = 1; q < NP_SEGS; ++q)
+                if (k >= off[q]) g = q, base = off[q];
+            const int m = A.seedIdx[((size_t)a * NP_SEGS + g) * NP_MAX_SEEDS + (k - base)];
+            const int s1 = A.pointFeat[(size_t)m * C + a], s2 = A.pointFeat[(size_t)m * C + b];
+            const double x1 = A.cam[a].xy[s1], y1 = A.cam[a].xy[N + s1], x2 = A.cam[b].xy[s2], y2 = A.cam[b].xy[N + s2];
+            sSeed[k][0] = x1, sSeed[k][1] = y1, sSeed[k][2] = x2 - x1, sSeed[k][3] = y2 - y1;
         }
     }
+    __syncthreads();
     const int nSeeds = sNSeeds;
     // the pair's candidates: the disparity guide (when there are seeds: a WAVE per candidate, the seeds over the lanes, the nearest
     // -- the first of equals -- by a reduction), then into the sort arrays
@@ -376,15 +413,26 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
         __shared__ int sNDyn;
         unsigned* sDyn = sTrk;   // the tracks' table is done with: [NP_MAX_DYN] camera << 24 | (y + 64) << 12 | (x + 64)
         static_assert(NP_MAX_TRACKS >= NP_MAX_DYN && NP_MAX_CAMS <= 256 && NP_MAX_N <= 65536, "the dynamic features' list reuses the track table");
-        if (tid == 0) sNDyn = 0;
+        // the existing certain dynamic points' features: k_np_prep's per-camera lists, camera after camera
+        int off = 0;
+        bool over = false;
+        for (int c = 0; c < C; ++c) {
+            int n = A.dynCnt[c];
+            if (n > NP_DYN_PER_CAM) n = NP_DYN_PER_CAM, over = true;
+            for (int k = tid; k < n; k += 256)
+                if (off + k < NP_MAX_DYN) sDyn[off + k] = ((unsigned)c << 24) | A.dynList[(size_t)c * NP_DYN_PER_CAM + k];
+            off += n;
+        }
+        if (tid == 0) sNDyn = off;
         __syncthreads();
-        const int total = C * N;
-        for (int e = tid; e < total; e += 256) {
-            const int c = e / N, sl = e - c * N;
-            const int st = A.cam[c].state[sl], m = A.cam[c].slot2map[sl];
-            if ((st == 0 || st == 1) && m >= 0 && m < A.mapCap && A.mapFlags[m] == CS_MAP_DYNAMIC) {
+        // ... and this run's new dynamic points: reconstructTracks' addFeature already gave their features the point
+        for (int q = tid; q < added; q += 256) {
+            const int m = first + q;
+            if (A.mapFlags[m] != CS_MAP_DYNAMIC) continue;
+            for (int c = 0; c < C; ++c) {
+                const int sl = A.pointFeat[(size_t)m * C + c];
+                if (sl < 0) continue;
                 const int x = (int)(A.cam[c].xy[sl] + 0.5), y = (int)(A.cam[c].xy[N + sl] + 0.5);
-                // (a feature whose 41 x 41 square misses the image marks nothing)
                 if (x + 20 >= 0 && x - 20 < A.W && y + 20 >= 0 && y - 20 < A.H) {
                     const int k = atomicAdd(&sNDyn, 1);
                     if (k < NP_MAX_DYN) sDyn[k] = ((unsigned)c << 24) | ((unsigned)(y + 64) << 12) | (unsigned)(x + 64);
@@ -393,10 +441,8 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
         }
         __syncthreads();
         int nDynF = sNDyn;
-        if (nDynF > NP_MAX_DYN) {
-            nDynF = NP_MAX_DYN;
-            if (tid == 0 && A.counts) atomicOr(A.counts + 3, 4);
-        }
+        if (nDynF > NP_MAX_DYN) nDynF = NP_MAX_DYN, over = true;
+        if (over && tid == 0 && A.counts) atomicOr(A.counts + 3, 4);
         for (int q = tid; q < added; q += 256) {
             const int m = first + q;
             if (A.mapFlags[m] != CS_MAP_UNCERTAIN) continue;
@@ -444,7 +490,8 @@ __global__ __launch_bounds__(256) void k_np_candidates(int n, int N, const int* 
 
 extern "C" size_t cs_newpts_scratch_bytes(int nCams, int N) {
     if (nCams < 2 || N < 1) return 0;
-    return sizeof(int) * (size_t)(nCams - 1) * ((size_t)N + 2 * (((size_t)N + 31) / 32));
+    const size_t nP = (size_t)nCams - 1, nW = ((size_t)N + 31) / 32;
+    return sizeof(int) * (nP * ((size_t)N + 2 * nW) + nP * NP_SEGS * (NP_MAX_SEEDS + 1) + (size_t)nCams * (NP_DYN_PER_CAM + 1));
 }
 
 extern "C" int cs_ncc_candidate_mask_dev(int device, void* hip_stream, int nCams, int N, const int* d_state, const int* d_slot2map,
@@ -496,6 +543,10 @@ extern "C" int cs_newpts_from_pairs_dev(int device, void* hip_stream, int nCams,
     A.R = d_R, A.t = d_t, A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.mapFlags = d_mapFlags, A.newPt = d_newPt, A.firstFrame = d_firstFrame;
     A.pointFeat = d_pointFeat, A.mapCount = d_mapCount, A.matchIdx = (int*)d_scratch;
     A.rowMask = (unsigned*)d_scratch + (size_t)(nCams - 1) * N, A.colMask = A.rowMask + (size_t)(nCams - 1) * ((N + 31) / 32);
+    A.seedIdx = (int*)(A.colMask + (size_t)(nCams - 1) * ((N + 31) / 32));
+    A.seedCnt = A.seedIdx + (size_t)(nCams - 1) * NP_SEGS * NP_MAX_SEEDS;
+    A.dynList = (unsigned*)(A.seedCnt + (size_t)(nCams - 1) * NP_SEGS);
+    A.dynCnt = (int*)(A.dynList + (size_t)nCams * NP_DYN_PER_CAM);
     A.counts = d_counts;
     CS_HIP(hipSetDevice(device));
     hipStream_t s = (hipStream_t)hip_stream;
@@ -504,6 +555,7 @@ extern "C" int cs_newpts_from_pairs_dev(int device, void* hip_stream, int nCams,
         ops.fill(d_counts, 0, sizeof(int) * (4 + (size_t)nCams));
         CS_HIP(ops.run(s));
     }
+    hipLaunchKernelGGL(k_np_prep, dim3((nCams - 1) * NP_SEGS + nCams), dim3(256), 0, s, A);
     hipLaunchKernelGGL(k_np_match, dim3(nCams - 1), dim3(256), 0, s, A);
     hipLaunchKernelGGL(k_np_reconstruct, dim3(1), dim3(256), 0, s, A);
     CS_CHECK_LAUNCH();

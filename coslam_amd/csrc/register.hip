@@ -358,16 +358,13 @@ __global__ __launch_bounds__(256) void k_decide_prepare(RdArgs A) {
         }
     }
     A.code[(size_t)i * A.P + p] = code;
-}
-// thread per point: the order of its walk = ((first camera in which it has a feature of this frame) x P + point) x nCams
-__global__ __launch_bounds__(256) void k_decide_order(RdArgs A) {
-    const int p = blockIdx.x * 256 + threadIdx.x, C = A.nCams;
-    if (p >= A.P) return;
-    int ofirst = -1;
-    for (int i = C - 1; i >= 0; --i)
-        if (A.pointFeat[(size_t)p * C + i] >= 0) ofirst = i;
-    const bool certainStatic = (A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) == 0;
-    A.base[p] = (ofirst >= 0 && certainStatic) ? (ofirst * A.P + p) * C : -1;
+    if (i == 0) {   // the order of the point's walk = ((first camera in which it has a feature of this frame) x P + point) x nCams
+        int ofirst = -1;
+        for (int q = C - 1; q >= 0; --q)
+            if (A.pointFeat[(size_t)p * C + q] >= 0) ofirst = q;
+        const bool certainStatic = (A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) == 0;
+        A.base[p] = (ofirst >= 0 && certainStatic) ? (ofirst * A.P + p) * C : -1;
+    }
 }
 // one Jacobi sweep, thread per point: its walk against the owners of the previous sweep (prev), claims into next; `clear` is the
 // buffer the FOLLOWING sweep will claim into.  mode 1: the owners in prev are final -- attach instead of claiming.
@@ -454,7 +451,6 @@ extern "C" int cs_register_decide_static_dev(int device, void* hip_stream, int n
     hipStream_t s = (hipStream_t)hip_stream;
     const int gE = (P * nCams + 255) / 256, gP = (P + 255) / 256;
     hipLaunchKernelGGL(k_decide_prepare, dim3(gE), dim3(256), 0, s, A);
-    hipLaunchKernelGGL(k_decide_order, dim3(gP), dim3(256), 0, s, A);
     // sweep k reads owner[k % 3], claims into owner[(k + 1) % 3] and clears owner[(k + 2) % 3] for the sweep after it
     for (int k = 0; k < nSweeps; ++k)
         hipLaunchKernelGGL(k_decide_sweep, dim3(gP), dim3(256), 0, s, A, (const int*)A.owner[k % 3], A.owner[(k + 1) % 3], A.owner[(k + 2) % 3],

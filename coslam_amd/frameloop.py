@@ -226,6 +226,7 @@ class FrameLoop:
             self.d_iT = torch.from_numpy(ic["ts0"].reshape(-1).copy()).to(dev)
             self.d_iM = torch.from_numpy(ic["pts0"].reshape(-1).copy()).to(dev)
         self.n_pushed = self.n_windows = self.n_key = self.n_my_solves = self.n_my_ic = 0
+        self.skip_busy, self.n_skipped = False, 0   # (set by the caller: drop a window request while the previous solve is running)
         self.apply_at, self.my_seq = {}, {}
         self.applied, self.last_apply = 0, None
         self.stage_slot, self.h_frames = {}, None
@@ -577,6 +578,14 @@ class FrameLoop:
         self.n_pushed += 1
         if self.n_pushed < cfg.n_key_frames:
             return
+        if self.skip_busy:
+            # the reference's own policy (CoSLAM::requestForBA, src/app/SL_CoSLAM.cpp:1750-1755): a request that finds the previous bundle
+            # adjustment still running is dropped.  "Running" is asked when the DEVICE has reached this key frame (the host enqueues
+            # frames ahead of it): one host wait per key frame.  Timing-dependent, so only on one rank (bench.py's secondary figure)
+            self.pose_s.synchronize()
+            if self.ba_ws.pending() > 0:
+                self.n_skipped += 1
+                return
         k = self.n_windows
         self.n_windows += 1
         owner = k % self.world
