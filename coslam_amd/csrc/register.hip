@@ -88,6 +88,10 @@ constexpr int RG_CHUNK = 4096;    // features staged in LDS at a time (64 KB); l
 // frame's list is staged as NaN, so its distance compares false and it can never win -- no state test in the loop), and
 // every wave walks its share of it with BROADCAST reads: one LDS read serves 64 points.  Per wave the walk is in slot
 // order with a strict <, the waves' minima are merged lexicographically on (distance, slot): the serial loop's answer.
+// (Round 4 built the alternative -- features binned into 32-pixel cells, a point looks at 3 x 3 cells and falls back to the full scan
+// when it cannot prove the answer global: 33 x fewer distance evaluations, bit-identical tables, 18.6 + 10.4 us alone -- and measured it
+// in the loop: 2114 / 2118 frames/s against this kernel's 2168 / 2159.  Scattered reads and a second launch cost more next to the tracker
+// than 50 M broadcast-fed evaluations.  Deleted; profiles/r04_ab_runs.txt.)
 __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
     extern __shared__ double lds[];
     CS_POSE_STREAM_PRIO();
