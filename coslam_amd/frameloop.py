@@ -463,6 +463,7 @@ class FrameLoop:
                 self.xchg.all_gather(pose_s)
                 self.xchg.unpack_poses(self.d_R[dst], self.d_t[dst], pose_s, skip_own=True)
             self._handback(b, i, "other")
+        self.dest_free[b].record(pose_s)             # (the hand-back and the exchange's pack were the last readers of this dest buffer)
         if self.pose_upd is not None:
             # parallelPoseUpdate(false): gate 2.0, sigma = PIXEL_ERR_VAR; detectDynamicFeaturePoints(20, 5, 3, MAX_EPI_ERR)
             self.pose_upd.pose_update_frame_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_R[dst].data_ptr(),
@@ -473,6 +474,11 @@ class FrameLoop:
                                                       self.d_cov.data_ptr(), self.d_mapflags.data_ptr(), self.d_newpt.data_ptr(),
                                                       self.d_sfn.data_ptr(), self.d_firstfrm.data_ptr(), 12.0,
                                                       d_counts=self.d_cls_counts.data_ptr())
+        # the reference's order of a frame (src/gui/CoSLAMThread.cpp:104-118): poseUpdate (with mapPointsClassify) -> activeMapPointsRegister ->
+        # genNewMapPoints -> currentMapPointsRegister: the new map points take their features BEFORE the current points' registration
+        # looks at them (a feature that carries a point ends a registration walk)
+        if self.ncc is not None and i % cfg.ncc_every == 0:
+            self._ncc_leg(i, f, dst)
         if cfg.with_register:
             register_search_passes_dev(ps, self.reg_args[dst], cfg.n_feat, cfg.W, cfg.H, self.reg_passes, device=self.device, cam0=c0,
                                        nCamsRun=nc)
@@ -483,7 +489,6 @@ class FrameLoop:
                                                        cam0=c0, nCamsRun=nc)
         if cfg.with_register and cfg.with_decide and self.pose_upd is not None and cfg.with_mergability:
             self._decide(ps)
-        self.dest_free[b].record(pose_s)
         if key_frame:
             if self._timing is not None:
                 import time as _t
@@ -493,8 +498,6 @@ class FrameLoop:
                 self._timing["key_frame"] = self._timing.get("key_frame", 0.0) + _t.perf_counter() - t0
             else:
                 self._key_frame(i, dst)
-        if self.ncc is not None and i % cfg.ncc_every == 0:
-            self._ncc_leg(i, f, dst)
 
     def _decide(self, ps):
         """curStaticPointsRegInGroup's decision (reference src/app/SL_CoSLAM.cpp:854-898, 731-830, bMerge == false) over the search

@@ -383,44 +383,15 @@ int main(int argc, char** argv) {
         CSCHK(cs_klt_handback_dev(dev, (void*)poseS, nCams, hb[b].data(), N, W, H, nColBlk, nRowBlk, PTS, i));
         CSCHK(cs_pose_intracam_batch_dev(dev, (void*)poseS, nCams, PTS, dKall, dR[src], dT[src], dNpts, nullptr, dMs, dms, 10.0,
                                          dR[dsti], dT[dsti], dOpt, dOk));
+        HIPCHK(hipEventRecord(destFree[b], poseS));   // (the hand-back was the last reader of this dest buffer)
         // parallelPoseUpdate(false): the gate + seqTriangulate loop of poseUpdate3D, detectDynamicFeaturePoints(20, 5, 3, MAX_EPI_ERR)
         CSCHK(cs_pose_update_frame_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dR[dsti], dT[dsti], dMap, dCov, dMapFlags, 0, PIX, i, 20, 5,
                                        3, 6.0, nullptr, nullptr, nullptr));
         // mapPointsClassify(12.0) (SL_CoSLAM.cpp:385): the uncertain / dynamic points of this frame decided again
         CSCHK(cs_map_points_classify_dev(hist, (void*)poseS, pu.data(), dPf, nMap, nullptr, nullptr, i, dMap, dCov, dMapFlags, dNewPt, dSfn,
                                          dFirstFrm, 12.0, nullptr));
-        // activeMapPointsRegister, then currentMapPointsRegister (static points), search step
-        {
-            cs_register_pass ps[2];
-            memset(ps, 0, sizeof(ps));
-            ps[0].P = P_REG, ps[0].sigmaSearch = 2.5 * PIX, ps[0].maxDist = 3 * PIX, ps[0].sigmaMerge = PIX;
-            ps[0].M = dMap + 3 * (size_t)P_REG, ps[0].cov = dCov + 9 * (size_t)P_REG, ps[0].pointFeat = dPfNone;
-            ps[0].slot = reg[0].slot, ps[0].m = reg[0].m, ps[0].var = reg[0].var, ps[0].dist = reg[0].dist, ps[0].flags = reg[0].flags;
-            ps[1].P = P_REG, ps[1].sigmaSearch = PIX, ps[1].maxDist = 3 * PIX, ps[1].sigmaMerge = PIX;
-            ps[1].M = dMap, ps[1].cov = dCov, ps[1].pointFeat = dPf;
-            ps[1].slot = reg[1].slot, ps[1].m = reg[1].m, ps[1].var = reg[1].var, ps[1].dist = reg[1].dist, ps[1].flags = reg[1].flags;
-            CSCHK(cs_register_search_passes_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, 2, ps));   // both passes, one launch
-        }
-        // staticCheckMergability of the current-static pass's candidates over their whole tracks (SL_CoSLAM.cpp:714-729, :768)
-        CSCHK(cs_register_mergability_dev(hist, (void*)poseS, pu.data(), P_REG, dMap, dCov, reg[1].slot, PIX, dMergeable));
-        // the decision (curStaticPointsRegInGroup, bMerge false: who attaches which feature), then refineMapPoint of the points that gained one
-        CSCHK(cs_register_decide_static_dev(dev, (void*)poseS, nCams, N, P_REG, 0, reg[1].slot, reg[1].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
-                                            dAttached, dRegged, dDecScratch, 3, dDecCnt));
-        CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
-        HIPCHK(hipEventRecord(destFree[b], poseS));
-        if (key) {
-            // InterCamPoseEstimator::addMapPoints + apply: every camera's current pose, the block-voted static features' map points
-            // fixed, the dynamic points free; sigma 6, 3 x 40
-            CSCHK(cs_ba_solve_intercam_async(ic.ws, icam, (void*)poseS, icCams.data(), W, H, nColBlk, nRowBlk, dR[dsti], dT[dsti], dMap, dMapFlags,
-                                             dNewPt, dPf, 6.0, 3, 40));
-            // requestForBA(5, 2, 2, 30): the numCams * 2 oldest key cameras and 2 points held, maxIter 2, inner 10; static points only
-            CSCHK(cs_ba_window_push_dev(win, (void*)poseS, hb[b].data(), dK, 1, dR[dsti], dT[dsti], i));
-            if (++nPushed >= WIN_KF) {
-                CSCHK(cs_ba_solve_window_flags_async(joint.ws, win, (void*)poseS, dMap, dMapFlags, 2 * nCams, 2, 6.0, 2, 10));
-                due.push_back({i + baLag * keyEvery, i - (WIN_KF - 1) * keyEvery, nRequested++});
-            }
-        }
-        // (last on the pose stream: nothing of this frame waits for the matching leg)
+        // genNewMapPoints every 4th frame -- BEFORE currentMapPointsRegister, as in the reference's frame (src/gui/CoSLAMThread.cpp:104-118):
+        // the new map points take their features before the current points' registration looks at them
         if (nCams >= 2 && i % NCC_EVERY == 0) {
             // NewMapPtsNCC::addSlam's features: this frame's, on tracks of more than three frames, unmapped or on a false point
             CSCHK(cs_ncc_candidate_mask_dev(dev, (void*)poseS, nCams, N, dState, dS2M, dSpan, dMapFlags, nMap, 3, dValid, 0));
@@ -446,6 +417,36 @@ int main(int argc, char** argv) {
                                            dMap, dCov, dMapFlags, dNewPt, dFirstFrm, dPf, nMap, dMapCount, i, 80.0, 3.0, PIX, 2, W, H, dNpScratch,
                                            dNpCounts));
             ++nccRuns;
+        }
+        // activeMapPointsRegister, then currentMapPointsRegister (static points), search step
+        {
+            cs_register_pass ps[2];
+            memset(ps, 0, sizeof(ps));
+            ps[0].P = P_REG, ps[0].sigmaSearch = 2.5 * PIX, ps[0].maxDist = 3 * PIX, ps[0].sigmaMerge = PIX;
+            ps[0].M = dMap + 3 * (size_t)P_REG, ps[0].cov = dCov + 9 * (size_t)P_REG, ps[0].pointFeat = dPfNone;
+            ps[0].slot = reg[0].slot, ps[0].m = reg[0].m, ps[0].var = reg[0].var, ps[0].dist = reg[0].dist, ps[0].flags = reg[0].flags;
+            ps[1].P = P_REG, ps[1].sigmaSearch = PIX, ps[1].maxDist = 3 * PIX, ps[1].sigmaMerge = PIX;
+            ps[1].M = dMap, ps[1].cov = dCov, ps[1].pointFeat = dPf;
+            ps[1].slot = reg[1].slot, ps[1].m = reg[1].m, ps[1].var = reg[1].var, ps[1].dist = reg[1].dist, ps[1].flags = reg[1].flags;
+            CSCHK(cs_register_search_passes_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, 2, ps));   // both passes, one launch
+        }
+        // staticCheckMergability of the current-static pass's candidates over their whole tracks (SL_CoSLAM.cpp:714-729, :768)
+        CSCHK(cs_register_mergability_dev(hist, (void*)poseS, pu.data(), P_REG, dMap, dCov, reg[1].slot, PIX, dMergeable));
+        // the decision (curStaticPointsRegInGroup, bMerge false: who attaches which feature), then refineMapPoint of the points that gained one
+        CSCHK(cs_register_decide_static_dev(dev, (void*)poseS, nCams, N, P_REG, 0, reg[1].slot, reg[1].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
+                                            dAttached, dRegged, dDecScratch, 3, dDecCnt));
+        CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
+        if (key) {
+            // InterCamPoseEstimator::addMapPoints + apply: every camera's current pose, the block-voted static features' map points
+            // fixed, the dynamic points free; sigma 6, 3 x 40
+            CSCHK(cs_ba_solve_intercam_async(ic.ws, icam, (void*)poseS, icCams.data(), W, H, nColBlk, nRowBlk, dR[dsti], dT[dsti], dMap, dMapFlags,
+                                             dNewPt, dPf, 6.0, 3, 40));
+            // requestForBA(5, 2, 2, 30): the numCams * 2 oldest key cameras and 2 points held, maxIter 2, inner 10; static points only
+            CSCHK(cs_ba_window_push_dev(win, (void*)poseS, hb[b].data(), dK, 1, dR[dsti], dT[dsti], i));
+            if (++nPushed >= WIN_KF) {
+                CSCHK(cs_ba_solve_window_flags_async(joint.ws, win, (void*)poseS, dMap, dMapFlags, 2 * nCams, 2, 6.0, 2, 10));
+                due.push_back({i + baLag * keyEvery, i - (WIN_KF - 1) * keyEvery, nRequested++});
+            }
         }
     };
     auto barrier = [&]() {
