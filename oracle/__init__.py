@@ -846,7 +846,9 @@ def register_decide_static(slot, flags, mergeable, mapFlags, pointFeat, slot2map
     always true, :546-558); a feature that already carries a map point ENDS the point's walk (`if (!bMerge) return bReg`, :789-790).
     slot / flags / mergeable: P x C tables of the search (flags bit 1: the candidate is dynamic); mapFlags [P] CS_MAP_* bytes;
     pointFeat [P][C] and slot2map [C][N] are updated IN PLACE (a track's features all take the point: slot2map is per track).
-    Returns (attached [P][C] uint8, regged [P] uint8: the points refineMapPoint is called for, :889-893)."""
+    Returns (attached [P][C] uint8, regged [P] uint8: the points refineMapPoint is called for, :889-893).
+    This is the SINGLE PASS the kernels run (every walk against the tables of one search); the reference's own run is pinned by
+    register_cur_static_sequential below, from which this differs only where a registered point is visited again."""
     P, C = slot.shape
     attached = np.zeros((P, C), dtype=np.uint8)
     regged = np.zeros(P, dtype=np.uint8)
@@ -873,6 +875,52 @@ def register_decide_static(slot, flags, mergeable, mapFlags, pointFeat, slot2map
             if breg:
                 regged[p] = 1
     return attached, regged
+
+
+def register_cur_static_sequential(W, H, Ks, iKs, histR, histT, histXY, trackSpan, state, isStatic, slot2map, mapPts, mapCov, mapFlags,
+                                   pointFeat, pixelVar):
+    """CoSLAM::curStaticPointsRegInGroup (bMerge == false) AS THE REFERENCE RUNS IT (src/app/SL_CoSLAM.cpp:854-898, 731-830), one point after
+    the other (TEST INFRASTRUCTURE, plain Python over the pinned restatements of the search, staticCheckMergability and refineMapPoint):
+    for every camera o in turn, the certainly static points that hold a feature of this frame in o -- INCLUDING features attached in an
+    earlier camera's loop -- in map order; each is projected with its position AS IT STANDS (refined at the end of every loop in which it
+    gained a feature, :889-893), walks the cameras, attaches the nearest unmapped, non-dynamic, mergeable feature, and stops at a feature
+    that carries a point.  This is what tests/golden/decide_golden.npz pins bit for bit; cs_register_decide_static_dev /
+    register_decide_static evaluate every walk against the positions at the START of the frame (one search, one decision, one refine)
+    and differ where a point that gained a feature is visited again in a later camera's loop.
+    histR / histT / histXY / trackSpan / pointFeat as refine_map_points takes them (entry 0 = this frame); slot2map (list per camera),
+    pointFeat, mapPts, mapCov are updated IN PLACE.  Returns (features attached, the reference's return value: registrations summed
+    over the camera loops)."""
+    nC, nP = len(state), len(mapPts)
+    xy0 = [np.ascontiguousarray(histXY[c][0]) for c in range(nC)]
+    is_dyn = [(1 - np.asarray(isStatic[c])).astype(np.uint8) for c in range(nC)]
+    n_att, n_reg_total = 0, 0
+    for o in range(nC):
+        vec = [p for p in range(nP) if (int(mapFlags[p]) & 7) == 0 and pointFeat[p, o] >= 0]      # :864-869
+        regged = []
+        for p in vec:
+            res = register_search(W, H, Ks, histR[:, 0], histT[:, 0], xy0, state, slot2map, is_dyn, mapPts[p:p + 1], mapCov[p:p + 1],
+                                  pointFeat[p:p + 1], pixelVar, 3 * pixelVar, pixelVar)
+            breg = False
+            for i in range(nC):
+                s = int(res["slot"][0, i])
+                if pointFeat[p, i] >= 0 or s < 0 or (int(res["flags"][0, i]) & 2):
+                    continue
+                if slot2map[i][s] >= 0:                                                               # :789-790
+                    break
+                sl = np.full(1, s, dtype=np.int32)
+                if register_mergability_cam(Ks[i], histR[i], histT[i], histXY[i], trackSpan[i], mapPts[p:p + 1], mapCov[p:p + 1], sl, pixelVar)[0] == 1:
+                    slot2map[i][s] = p
+                    pointFeat[p, i] = s
+                    n_att += 1
+                    breg = True
+            if breg:
+                regged.append(p)
+        for p in regged:                                                                              # :889-893
+            sel = np.zeros(nP, dtype=np.uint8)
+            sel[p] = 1
+            refine_map_points(Ks, iKs, histR, histT, histXY, trackSpan, pointFeat, mapPts, mapCov, pixelVar, select=sel)
+        n_reg_total += len(regged)
+    return n_att, n_reg_total
 
 
 def new_map_points_from_pairs(N, pairs, Ks, iKs, Rs, ts, xy, state, slot2map, isStatic, mapPts, mapCov, mapFlags, newPt, firstFrame, pointFeat,

@@ -353,6 +353,77 @@ def newpts_case():
     return out
 
 
+def decide_case():
+    """the reference's own CoSLAM::curStaticPointsRegInGroup (oracle/_ref/ref_decide_test golden, CPU): three scenes of cameras, pose
+    histories, feature tracks and map points; which feature carries which point afterwards, every point's position / covariance."""
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_decide_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_decide_test missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "d.bin")
+        subprocess.run([exe, "golden", path], check=True, stdout=subprocess.DEVNULL)
+        raw = open(path, "rb").read()
+    o = [0]
+
+    def ints(n):
+        v = np.frombuffer(raw, dtype=np.int32, count=n, offset=o[0]).copy()
+        o[0] += 4 * n
+        return v
+
+    def dbls(n):
+        v = np.frombuffer(raw, dtype=np.float64, count=n, offset=o[0]).copy()
+        o[0] += 8 * n
+        return v
+
+    out = {}
+    (ns,) = ints(1)
+    out["n_scenes"] = np.int32(ns)
+    for sc in range(ns):
+        nC, Hh, N, nP, cur, W, H = (int(v) for v in ints(7))
+        (pv,) = dbls(1)
+        k = lambda n: f"s{sc}_{n}"   # noqa: E731
+        out[k("dims")] = np.array([nC, Hh, N, nP, cur, W, H], np.int32)
+        out[k("pixelVar")] = np.float64(pv)
+        K, hR, hT = np.zeros((nC, 9)), np.zeros((nC, Hh, 9)), np.zeros((nC, Hh, 3))
+        for c in range(nC):
+            K[c] = dbls(9)
+            for j in range(Hh):
+                hR[c, j], hT[c, j] = dbls(9), dbls(3)
+        out[k("K")], out[k("histR")], out[k("histT")] = K, hR, hT
+        hXY = np.zeros((nC, Hh, 2 * N))
+        span = np.full((nC, 2 * N), -1, np.int32)
+        state = np.full((nC, N), -1, np.int32)
+        is_static = np.ones((nC, N), np.uint8)
+        s2m = np.full((nC, N), -1, np.int32)
+        for c in range(nC):
+            for s in range(N):
+                L, st, m = (int(v) for v in ints(3))
+                if L == 0:
+                    continue
+                xy = dbls(2 * L).reshape(L, 2)
+                hXY[c, :L, s], hXY[c, :L, N + s] = xy[:, 0], xy[:, 1]
+                span[c, s], span[c, N + s] = cur - L + 1, cur
+                state[c, s], is_static[c, s], s2m[c, s] = (1 if L == 1 else 0), st, m
+        out[k("histXY")], out[k("trackSpan")], out[k("state")], out[k("isStatic")], out[k("slot2map")] = hXY, span, state, is_static, s2m
+        M, cov, fl, pf = np.zeros((nP, 3)), np.zeros((nP, 9)), np.zeros(nP, np.uint8), np.zeros((nP, nC), np.int32)
+        for p_ in range(nP):
+            M[p_], cov[p_] = dbls(3), dbls(9)
+            (f_,) = ints(1)
+            fl[p_] = f_
+            pf[p_] = ints(nC)
+        out[k("M")], out[k("cov")], out[k("flags")], out[k("pointFeat")] = M, cov, fl, pf
+        (nreg,) = ints(1)
+        out[k("ref_regged")] = np.int32(nreg)
+        out[k("ref_slot2map")] = ints(nC * N).reshape(nC, N)
+        R = dbls(12 * nP).reshape(nP, 12)
+        out[k("ref_M")], out[k("ref_cov")] = R[:, :3], R[:, 3:]
+    assert o[0] == len(raw)
+    return out
+
+
 def mergability_case():
     """the reference's own CoSLAM::staticCheckMergability (oracle/_ref/ref_mergability_test golden, CPU): 150 tracks of 1..24
     frames, newest first, and its verdicts."""
@@ -566,7 +637,7 @@ def classify_case():
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "update_points", "classify", "intercam", "newpts"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "update_points", "classify", "intercam", "newpts", "decide"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -589,6 +660,8 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "update_points_golden.npz"), **update_points_case())
     if "classify" in which:
         np.savez_compressed(os.path.join(HERE, "classify_golden.npz"), **classify_case())
+    if "decide" in which:
+        np.savez_compressed(os.path.join(HERE, "decide_golden.npz"), **decide_case())
     if "newpts" in which:
         np.savez_compressed(os.path.join(HERE, "newpts_golden.npz"), **newpts_case())
     print("golden fixtures written")

@@ -1,6 +1,8 @@
 """The registration DECISION on the device (cs_register_decide_static_dev) against the sequential restatement of
 CoSLAM::curStaticPointsRegInGroup (oracle.register_decide_static): random search tables with many conflicts -- several points whose
 nearest feature is the same one, walks that end at a feature an earlier walk has just taken, points visited under several cameras."""
+import os
+
 import numpy as np
 import pytest
 
@@ -54,3 +56,80 @@ def test_decision_equals_the_sequential_walks(hip, seed, P, C, N, pc):
     assert cnt[0] == int(att_o.sum()) and cnt[1] == int(reg_o.sum())
     if seed in (1, 3):
         assert att_o.sum() > 100
+
+
+def test_device_registration_on_the_reference_golden_scenes(hip):
+    """The frame loop's registration of the current static points -- cs_register_search_passes_dev, cs_register_mergability_dev,
+    cs_register_decide_static_dev, cs_refine_map_points_dev, once each -- on the scenes of tests/golden/decide_golden.npz (the
+    reference's own curStaticPointsRegInGroup compiled in place): identical to the single-pass restatement (tables, owners,
+    positions bit for bit), and against the REFERENCE itself only the few attachments differ that it makes when it visits a point
+    again in a later camera's loop with its refined position (bounded at 3 %: DESIGN.md 8.2)."""
+    import torch
+
+    from coslam_amd.poseupdate import TrackHistory
+    from coslam_amd.register import register_cams, register_decide_scratch_bytes, register_decide_static_dev, register_passes, register_search_passes_dev
+    from tests.test_oracle_cpu import _decide_scene, single_pass_registration
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decide_golden.npz"))
+    dev = torch.device("cuda:0")
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    s_ = torch.cuda.current_stream().cuda_stream
+    att_total = diff_total = 0
+    for sc in range(int(g["n_scenes"])):
+        S = _decide_scene(g, sc)
+        want = single_pass_registration(S)
+        nC, N, nP, Hh = S["nC"], S["N"], S["nP"], S["hR"].shape[1]
+        cur = int(g[f"s{sc}_dims"][4])
+        th = TrackHistory(nC, N, Hh + 3)
+        dK, diK = d(S["K"]), d(S["iK"])
+        dxy, dstate, ds2m = d(S["hXY"][:, 0]), d(S["state"]), d(S["s2m"])
+        dspan, dstat, drep = d(S["span"]), d(S["st"]), torch.zeros((nC, N), dtype=torch.float64, device=dev)
+        ddyn = d((1 - S["st"]).astype(np.uint8))
+        dfl0 = d(S["fl"])
+        # the history ring: filled frame by frame (oldest first) with placeholder poses, then given the scene's poses
+        eye = d(np.tile(np.eye(3).reshape(9), (nC, 1)))
+        zero = torch.zeros((nC, 3), dtype=torch.float64, device=dev)
+        scratch = torch.ones((nC, N), dtype=torch.uint8, device=dev)
+        none = torch.full((nC, N), -1, dtype=torch.int32, device=dev)
+        keep = []
+        for j in range(Hh - 1, -1, -1):
+            xyj = d(S["hXY"][:, j])
+            stj = d(((S["span"][:, :N] >= 0) & (S["span"][:, :N] <= cur - j)).astype(np.int32) - 1)
+            keep += [xyj, stj]
+            cj = [dict(K=dK[c].data_ptr(), iK=diK[c].data_ptr(), xy=xyj[c].data_ptr(), state=stj[c].data_ptr(), slot2map=none[c].data_ptr(),
+                       trackSpan=dspan[c].data_ptr(), isStatic=scratch[c].data_ptr()) for c in range(nC)]
+            th.detect_dynamic_dev(s_, cj, eye.data_ptr(), zero.data_ptr(), nP, dfl0.data_ptr(), cur - j, minLen=1 << 30)
+        cam_i = np.repeat(np.arange(nC), Hh).astype(np.int32)
+        frm_i = np.tile(cur - np.arange(Hh), nC).astype(np.int32)
+        dp = [d(a) for a in (cam_i, frm_i, S["hR"].reshape(-1, 9), S["hT"].reshape(-1, 3))]
+        th.set_poses_dev(s_, len(cam_i), *[x.data_ptr() for x in dp])
+        cams = [dict(K=dK[c].data_ptr(), iK=diK[c].data_ptr(), xy=dxy[c].data_ptr(), state=dstate[c].data_ptr(), slot2map=ds2m[c].data_ptr(),
+                     trackSpan=dspan[c].data_ptr(), reprojErr=drep[c].data_ptr(), isStatic=dstat[c].data_ptr()) for c in range(nC)]
+        dM, dcov, dfl, dpf = d(S["M"]), d(S["cov"]), d(S["fl"]), d(S["pf"])
+        out = dict(slot=torch.zeros((nP, nC), dtype=torch.int32, device=dev), m=torch.zeros((nP, nC, 2), dtype=torch.float64, device=dev),
+                   var=torch.zeros((nP, nC, 4), dtype=torch.float64, device=dev), dist=torch.zeros((nP, nC), dtype=torch.float64, device=dev),
+                   flags=torch.zeros((nP, nC), dtype=torch.int32, device=dev))
+        dR0, dT0 = d(S["hR"][:, 0]), d(S["hT"][:, 0])
+        rc = register_cams([dict(K=dK[c].data_ptr(), R=dR0[c].data_ptr(), t=dT0[c].data_ptr(), xy=dxy[c].data_ptr(), state=dstate[c].data_ptr(),
+                                 slot2map=ds2m[c].data_ptr(), isDynamic=ddyn[c].data_ptr()) for c in range(nC)])
+        passes = register_passes([dict(P=nP, sigmaSearch=S["pv"], maxDist=3 * S["pv"], sigmaMerge=S["pv"], M=dM.data_ptr(), cov=dcov.data_ptr(),
+                                       pointFeat=dpf.data_ptr(), slot=out["slot"].data_ptr(), m=out["m"].data_ptr(), var=out["var"].data_ptr(),
+                                       dist=out["dist"].data_ptr(), flags=out["flags"].data_ptr())])
+        register_search_passes_dev(s_, rc, N, S["W"], S["H"], passes)
+        dmerge = torch.zeros((nP, nC), dtype=torch.uint8, device=dev)
+        th.register_mergability_dev(s_, cams, nP, dM.data_ptr(), dcov.data_ptr(), out["slot"].data_ptr(), S["pv"], dmerge.data_ptr())
+        datt, dreg = torch.zeros((nP, nC), dtype=torch.uint8, device=dev), torch.zeros(nP, dtype=torch.uint8, device=dev)
+        dscr = torch.zeros(register_decide_scratch_bytes(nC, N, nP), dtype=torch.uint8, device=dev)
+        dcnt = torch.zeros(4, dtype=torch.int32, device=dev)
+        register_decide_static_dev(s_, nC, N, nP, 0, out["slot"].data_ptr(), out["flags"].data_ptr(), dmerge.data_ptr(), dfl.data_ptr(), dpf.data_ptr(),
+                                   [ds2m[c].data_ptr() for c in range(nC)], datt.data_ptr(), dreg.data_ptr(), dscr.data_ptr(), dcnt.data_ptr(), n_sweeps=4)
+        th.refine_map_points_dev(s_, cams, dpf.data_ptr(), nP, dM.data_ptr(), dcov.data_ptr(), S["pv"], d_select=dreg.data_ptr())
+        torch.cuda.synchronize()
+        assert dcnt.cpu().tolist()[3] == 1                                   # the sweeps converged
+        assert np.array_equal(out["slot"].cpu().numpy(), want["res"]["slot"]) and np.array_equal(dmerge.cpu().numpy(), want["merge"])
+        assert np.array_equal(ds2m.cpu().numpy(), want["s2m"]) and np.array_equal(dpf.cpu().numpy(), want["pf"])
+        assert np.array_equal(dreg.cpu().numpy(), want["reg"]) and np.array_equal(dM.cpu().numpy(), want["M"]) and np.array_equal(dcov.cpu().numpy(), want["cov"])
+        att_total += int((S["ref_s2m"] != S["s2m"]).sum())
+        diff_total += int((ds2m.cpu().numpy() != S["ref_s2m"]).sum())
+        th.close()
+    assert 0 < diff_total <= 0.03 * att_total, (diff_total, att_total)
