@@ -492,10 +492,7 @@ def main():
         loop = FrameLoop(cfg, sc, video, None if os.environ.get("BENCH_IC_PREBAKED") is None else ic, klt_config(), reg_covariances(n_map), rank=rank, world=world, device=local_rank,
                          dist_backend=dist_backend, associate=associate)
     except coslam_amd.CoslamHipError as ex:
-        # no silent change of what is measured: the library's RCCL path is the product; torch.distributed collectives are
-        # available, but only when asked for
-        raise SystemExit(f"bench.py: the frame loop could not be set up ({ex}); N > 1 with --native-comm 0 measures with "
-                         "torch.distributed collectives instead of libcoslam_hip's RCCL communicator")
+        raise SystemExit(f"bench.py: the frame loop could not be set up ({ex})")
     trks, grp, klt_s, pose_s, ba_ws, ic_ws = loop.trks, loop.grp, loop.klt_s, loop.pose_s, loop.ba_ws, loop.ic_ws
     step = loop.step
 
@@ -980,7 +977,9 @@ def main():
                            "matches_per_pair_last_run": loop.ncc["np_cnt"].cpu().tolist()[4:4 + N_CAMS - 1],
                            "map_points_in_use": int(loop.d_mapcount.item()), "map_points_at_start": n_pts0, "map_capacity": loop.n_map},
                        "with_upload": with_upload, "secondary_reference_ba_request_policy": ref_policy, "cxx_frame_loop": cxx,
-                       "collectives": None if world == 1 else ("libcoslam_hip RCCL (C-ABI)" if loop.native else "torch.distributed " + dist_backend),
+                       "collectives": None if world == 1 else ("libcoslam_hip RCCL (C-ABI)" if loop.native else "torch.distributed " + dist_backend +
+                                                               (f" (FALLBACK: libcoslam_hip's communicator could not be created: {loop.native_fallback})"
+                                                                if getattr(loop, "native_fallback", None) else "")),
                        "streams": "tracker group | hand-back + pose + map update + registration (event-ordered behind the tracker of the same "
                                   "frame) | inter-camera solve and joint local BA each on its workspace's worker thread + stream "
                                   "(cs_ba_solve_async, like the reference's BA worker thread)"},

@@ -152,8 +152,26 @@ class FrameLoop:
         if world > 1:
             from coslam_amd import multicam
 
+            self.native_fallback = None
             if cfg.native_comm and dist_backend == "nccl":
-                self.native = multicam.NativeComm(world, rank, device)
+                # the library's own RCCL communicators; if ANY rank cannot bring them up, ALL ranks use torch.distributed's collectives
+                # instead (agreed through one all-reduce) -- said loudly: stderr here, `collectives` in bench.py's line
+                import torch.distributed as dist_
+
+                err = None
+                try:
+                    self.native = multicam.NativeComm(world, rank, device)
+                except coslam_amd.CoslamHipError as ex:
+                    err = str(ex)
+                ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+                dist_.all_reduce(ok, op=dist_.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    if self.native is not None:
+                        self.native.close()
+                        self.native = None
+                    self.native_fallback = err or "another rank could not create its communicator"
+                    print(f"[frameloop rank {rank}] libcoslam_hip's RCCL communicator is not available ({self.native_fallback}): "
+                          "torch.distributed collectives instead", file=__import__("sys").stderr, flush=True)
             self.xchg = multicam.CameraExchange(N * nc, dev, native=self.native, cams_per_rank=nc)
         # ---- per-camera argument tables (built once)
         def hb_cam(g, dest):

@@ -55,7 +55,28 @@ def test_single_rank_communicator_exchange_and_sliced_ba(hip):
     rec, nb = x.native_records(0)
     assert nb == N * 20 + 96
     assert _records_ok(rec.cpu().numpy(), nb, cams, feats, R, t, N)
+    # every gathered camera's pose back out of the records (what a rank does with the OTHER ranks' cameras each frame)
+    d_R2, d_t2 = torch.zeros((cams, 9), dtype=torch.float64, device=dev), torch.zeros((cams, 3), dtype=torch.float64, device=dev)
+    x.unpack_poses(d_R2, d_t2, s, skip_own=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_R2.cpu().numpy(), R) and np.array_equal(d_t2.cpu().numpy(), t)
     x.close()
+
+    # the frame loop's other collectives through the same communicator: a plain all-gather (registration candidates, NCC records) and
+    # a broadcast (a window's packed bundle-adjustment result) -- one rank: the data must come back unchanged
+    import ctypes as C
+
+    L = coslam_amd.lib()
+    L.cs_comm_allgather_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.cs_comm_broadcast_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    send = torch.arange(0, 100003, dtype=torch.int32, device=dev)
+    recv = torch.zeros_like(send)
+    assert L.cs_comm_allgather_dev(comm.exchange_comm, C.c_void_p(s.cuda_stream), C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), send.numel() * 4) == 0
+    buf = torch.arange(7, 445 * 1024 + 7, dtype=torch.int32, device=dev)
+    ref = buf.clone()
+    assert L.cs_comm_broadcast_dev(comm.exchange_comm, C.c_void_p(s.cuda_stream), C.c_void_p(buf.data_ptr()), buf.numel() * 4, 0) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(recv, send) and torch.equal(buf, ref)
 
     # the sliced joint BA through cs_ba_dist_solve == the oracle's bundleAdjustRobust
     sc = Scene(8, 640, 480, 7000, seed=0xC051A + 2, sigma=1.0)
