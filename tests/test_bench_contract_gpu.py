@@ -98,3 +98,16 @@ def test_two_ranks_compute_what_one_rank_computes(hip):
     assert c1["ba_output"]["windows_applied"] == c2["ba_output"]["windows_applied"] and c1["ba_output"]["last"]["window"] == c2["ba_output"]["last"]["window"]
     assert c2["replicas"]["identical_map_records_and_poses_on_every_rank"] is True
     assert c1["pose_update"]["map_points_refined"] == c2["pose_update"]["map_points_refined"]
+
+
+def test_four_ranks_compute_what_one_rank_computes(hip):
+    """... and with four ranks (two cameras each, apply lag min(max(N, 2), 4) = 4, window k on rank k mod 4, the inter-camera solve of key
+    frame k on rank (k + 2) mod 4): the same digest as one rank with the same lag, identical replicas."""
+    args = ["--steps", "40", "--warmup", "5", "--setup-rounds", "1"] + SHORT
+    one = _run_bench(["--gpus", "1", "--ba-lag", "4"] + args, env=dict(BENCH_STATE_DIGEST="1"))
+    four = _run_bench(["--gpus", "4"] + args, env=dict(TWO_RANKS_ON_ONE_GPU, BENCH_STATE_DIGEST="1"))
+    c1, c4 = one["config"], four["config"]
+    assert four["n_gpus"] == 4 and c4["cameras_per_gpu"] == 2 and c4["ba_output"]["lag_key_frame_intervals"] == 4
+    assert c4["replicas"]["ranks"] == 4 and c4["replicas"]["identical_map_records_and_poses_on_every_rank"] is True
+    assert c1["state_digest"] == c4["state_digest"] and c1["ba_output"]["windows_applied"] == c4["ba_output"]["windows_applied"] > 5
+    assert c1["ncc_matching"]["map_points_in_use"] == c4["ncc_matching"]["map_points_in_use"] > 7000
