@@ -481,7 +481,6 @@ class FrameLoop:
                 self.xchg.all_gather(pose_s)
                 self.xchg.unpack_poses(self.d_R[dst], self.d_t[dst], pose_s, skip_own=True)
             self._handback(b, i, "other")
-        self.dest_free[b].record(pose_s)             # (the hand-back and the exchange's pack were the last readers of this dest buffer)
         if self.pose_upd is not None:
             # parallelPoseUpdate(false): gate 2.0, sigma = PIXEL_ERR_VAR; detectDynamicFeaturePoints(20, 5, 3, MAX_EPI_ERR)
             self.pose_upd.pose_update_frame_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_R[dst].data_ptr(),
@@ -507,6 +506,11 @@ class FrameLoop:
                                                        cam0=c0, nCamsRun=nc)
         if cfg.with_register and cfg.with_decide and self.pose_upd is not None and cfg.with_mergability:
             self._decide(ps)
+        # the tracker of frame i + 2 (it writes this dest buffer) is released HERE, at the end of the frame's pose work, although the
+        # buffer's last reader was the hand-back: released earlier the tracker runs two frames ahead and under more of the pose stream's
+        # kernels -- measured 1978-1986 (behind the hand-back) / 1928-1934 (behind the gate) / 1894-1903 (behind the classification)
+        # against 2173-2193 frames/s here, 2119-2123 behind the key-frame requests (profiles/r04_ab_runs.txt)
+        self.dest_free[b].record(pose_s)
         if key_frame:
             if self._timing is not None:
                 import time as _t

@@ -383,7 +383,6 @@ int main(int argc, char** argv) {
         CSCHK(cs_klt_handback_dev(dev, (void*)poseS, nCams, hb[b].data(), N, W, H, nColBlk, nRowBlk, PTS, i));
         CSCHK(cs_pose_intracam_batch_dev(dev, (void*)poseS, nCams, PTS, dKall, dR[src], dT[src], dNpts, nullptr, dMs, dms, 10.0,
                                          dR[dsti], dT[dsti], dOpt, dOk));
-        HIPCHK(hipEventRecord(destFree[b], poseS));   // (the hand-back was the last reader of this dest buffer)
         // parallelPoseUpdate(false): the gate + seqTriangulate loop of poseUpdate3D, detectDynamicFeaturePoints(20, 5, 3, MAX_EPI_ERR)
         CSCHK(cs_pose_update_frame_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dR[dsti], dT[dsti], dMap, dCov, dMapFlags, 0, PIX, i, 20, 5,
                                        3, 6.0, nullptr, nullptr, nullptr));
@@ -436,6 +435,9 @@ int main(int argc, char** argv) {
         CSCHK(cs_register_decide_static_dev(dev, (void*)poseS, nCams, N, P_REG, 0, reg[1].slot, reg[1].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
                                             dAttached, dRegged, dDecScratch, 3, dDecCnt));
         CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
+        // the tracker of frame i + 2 is released at the END of the frame's pose work (released right behind the hand-back it runs two frames
+        // ahead and under more of the pose stream's kernels: -10 %, profiles/r04_ab_runs.txt)
+        HIPCHK(hipEventRecord(destFree[b], poseS));
         if (key) {
             // InterCamPoseEstimator::addMapPoints + apply: every camera's current pose, the block-voted static features' map points
             // fixed, the dynamic points free; sigma 6, 3 x 40
