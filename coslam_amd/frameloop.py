@@ -131,7 +131,8 @@ class FrameLoop:
         self.reg_out = [dict(slot=z((cfg.p_reg, NA), i32), m=z((cfg.p_reg, NA, 2), f64), var=z((cfg.p_reg, NA, 4), f64),
                              dist=z((cfg.p_reg, NA), f64), flags=z((cfg.p_reg, NA), i32)) for _ in range(2)]
         # ---- streams
-        self.klt_s, self.pose_s = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.klt_s, self.pose_s = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)   # (equal priorities: a high-priority pose or
+        # tracker stream halves the rate, 2188 -> 942 / 906 frames/s: profiles/r04_ab_runs.txt)
         self.klt_done = [torch.cuda.Event(), torch.cuda.Event()]
         self.dest_free = [torch.cuda.Event(), torch.cuda.Event()]
         # ---- trackers of the own cameras
