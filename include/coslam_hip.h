@@ -614,7 +614,10 @@ int cs_ncc_epi_mat_dev(int device, void* hip_stream, const double F[9] /* host *
  * one atomic counter (d_pairCount is zeroed by the call and counts every passing pair, also those beyond pairCap, which are
  * dropped; the order of the list is not defined).  The dense matrices above are this list scattered into wNone-filled arrays:
  * 64 MB of output per 2000 x 2000 camera pair, of which a matching run keeps a few dozen entries -- a device-resident caller
- * (or one that hands the greedy matcher a candidate list) wants this form. */
+ * (or one that hands the greedy matcher a candidate list) wants this form.  CONSUMERS: the list's order changes from run to run;
+ * anything that walks it in order (a greedy matcher) must first sort it by (score, i, j) -- cs_newpts_from_pairs_dev does -- or
+ * scatter it; *d_pairCount > pairCap means pairs were dropped in no fixed order (cs_newpts_from_pairs_dev reports that as bit 0
+ * of its flags; rerun with a larger pairCap or use the dense form). */
 typedef struct cs_ncc_pair {
     int i, j;        /* feature of camera 1, of camera 2 */
     double epi, ncc; /* epiMat(i, j), nccMat(i, j) */
