@@ -212,7 +212,7 @@ def export_workload(path, sc, frames, joint, ic, cams_per_launch):
         f.write(Fs.tobytes())
 
 
-def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True, with_posegraph=True):
+def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True, with_posegraph=True, with_ncc=True):
     """The oracle (C restatement of the reference's path: kind "port") on `n_threads` host cores: the cameras of a frame
     in parallel (the ctypes calls release the GIL), the key-frame solves on the calling thread."""
     import oracle
@@ -297,26 +297,59 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
             oracle.register_mergability_cam(Kc, np.stack(h["R"]), np.stack(h["t"]), np.stack(h["xy"]), tl[c], map_pts[:P_REG], cov[:P_REG],
                                             rs["slot"][:, 0], PIXEL_ERR_VAR)
 
+    # genNewMapPoints' NCC stage, every 4th frame like the GPU loop: getNCCBlocks of a camera's candidate features (with its thread),
+    # getEpiNccMat of the consecutive camera pairs behind the cameras (the C restatements; the match / reconstruct tail and the
+    # registration decision exist in plain Python only and are NOT timed here -- a Python loop would not be a fair CPU figure)
+    ncc_rec = [None] * N_CAMS
+    Kinv_ = np.linalg.inv(sc.K)
+
+    def ncc_cam(c, f):
+        f1, f2, m = tl[c][:N_FEAT], tl[c][N_FEAT:], s2m[c]
+        free_or_false = (m < 0) | ((map_flags[np.clip(m, 0, len(map_flags) - 1)] & 2) != 0)
+        idx = np.nonzero(((st[c] == 0) | (st[c] == 1)) & (f1 >= 0) & (f2 - f1 >= 3) & free_or_false)[0]
+        x, y = np.ascontiguousarray(xy[c][:N_FEAT][idx]), np.ascontiguousarray(xy[c][N_FEAT:][idx])
+        blk, abc = oracle.get_ncc_blocks(frames[c][f], x, y, 0.3)
+        ncc_rec[c] = (x, y, blk, abc, np.ones(len(idx), dtype=np.int32))
+
+    def ncc_pair(a, f):
+        (R1, t1), (R2, t2) = sc.pose(a, f), sc.pose(a + 1, f)
+        R = R1 @ R2.T
+        t = t1 - R @ t2
+        F = Kinv_.T @ (np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R) @ Kinv_
+        (x1, y1, b1, c1, v1), (x2, y2, b2, c2, v2) = ncc_rec[a], ncc_rec[a + 1]
+        if len(x1) and len(x2):
+            oracle.ncc_epi_mat(F, x1, y1, b1, c1, v1, x2, y2, b2, c2, v2, 50.0, 0.80)
+
     def run_cams(cams, f, frame_no):
         for c in cams:
             cam_step(c, f, frame_no)
             if with_register:
                 reg_step(c)
 
+    def run_ncc(what, items, f):
+        for q in items:
+            what(q, f)
+
+    def in_threads(fn, items, *a):
+        if n_threads <= 1:
+            fn(list(items), *a)
+            return
+        items = list(items)
+        th = [threading.Thread(target=fn, args=(items[q::n_threads],) + a) for q in range(n_threads) if items[q::n_threads]]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+
     t_start = time.perf_counter()
     n = 0
     while True:
         f = order[(n + 1) % len(order)]
-        if n_threads <= 1:
-            run_cams(range(N_CAMS), f, n + 1)
-        else:
-            parts = [list(range(N_CAMS))[q::n_threads] for q in range(n_threads)]
-            th = [threading.Thread(target=run_cams, args=(p, f, n + 1)) for p in parts if p]
-            for x in th:
-                x.start()
-            for x in th:
-                x.join()
+        in_threads(run_cams, range(N_CAMS), f, n + 1)
         pose_update_all(n + 1)
+        if with_ncc and (n + 1) % 4 == 0:
+            in_threads(lambda cs, f_: run_ncc(ncc_cam, cs, f_), range(N_CAMS), f)
+            in_threads(lambda ps, f_: run_ncc(ncc_pair, ps, f_), range(N_CAMS - 1), f)
         if n % KEY_EVERY == 0:
             jR, jT = oracle.ba_robust(joint["Ks"], joint["Rs0"], joint["ts0"], joint["pts0"], jptr, jcam, jxy,
                                       joint["n_cams_con"], joint["n_pts_con"], 6.0, 2, 10)[:2]
@@ -867,11 +900,15 @@ def main():
         cores = os.cpu_count() or 1
         nt = min(cores, N_CAMS)
         joint = build_joint_problem(sc)
-        v1, n1, dt1 = cpu_baseline(sc, frames, joint, ic, 1, 12.0, not args.no_register, True)
-        vN, nN, dtN = cpu_baseline(sc, frames, joint, ic, nt, 12.0, not args.no_register, True) if nt > 1 else (v1, n1, dt1)
+        v1, n1, dt1 = cpu_baseline(sc, frames, joint, ic, 1, 12.0, not args.no_register, True, not args.no_ncc)
+        vN, nN, dtN = cpu_baseline(sc, frames, joint, ic, nt, 12.0, not args.no_register, True, not args.no_ncc) if nt > 1 else (v1, n1, dt1)
         cpu = {"value": vN, "unit": "frames/s", "cores": nt, "kind": "port",
                "sample": f"{nN} frames of the same 8-camera workload on {nt} threads (cameras in parallel) in {dtN:.1f} s; "
-                         f"{n1} frames on 1 thread in {dt1:.1f} s (oracle/: C restatement, gcc -O2); host has {cores} cores",
+                         f"{n1} frames on 1 thread in {dt1:.1f} s (oracle/: C restatement, gcc -O2); host has {cores} cores.  Legs: KLT, "
+                         "hand-back, intra-camera pose, register search + mergability, pose update gate + dynamic test + classify, "
+                         "NCC blocks + epipolar/NCC matrix every 4th frame, joint BA + pose graph + the update behind it + inter-camera BA per key frame; "
+                         "NOT in the CPU figure (restated in plain Python only): the registration decision, the new-map-point match / "
+                         "reconstruct tail",
                "value_1_thread": v1, "host_cores": cores}
 
     # ---- the same loop driven from C++ through the C-ABI only (north_star: "Host stays C++"): tools/cxx/frame_loop.cpp, its
