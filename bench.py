@@ -984,6 +984,7 @@ def main():
                        "register_decision": None if not hasattr(loop, "_dec") else dict(zip(
                            ("features_attached_last_frame", "points_regged_last_frame", "sweeps_last_frame", "converged"), loop._dec["cnt"].cpu().tolist()),
                            points_refined_last_frame=int(loop._dec["ref_cnt"].item()),
+                           frames_whose_sweeps_did_not_settle=bool(loop._dec["scr"][-4:].view(torch.int32).item()),
                            what="curStaticPointsRegInGroup's decision (bMerge false) over the search + mergability tables of all cameras "
                                 "(cs_register_decide_static_dev: the sequential first-claimant rule resolved exactly), then refineMapPoint of "
                                 "the points that gained a feature (cs_refine_map_points_dev)"),

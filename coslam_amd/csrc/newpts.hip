@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
         NpView v[NP_MAX_CAMS];
         int nv = 0;
         bool valid = false;
-        double M[3] = {0, 0, 0}, cov[9];
+        double M[3] = {0, 0, 0}, cov[9], err[NP_MAX_CAMS];
         unsigned char fl = 0;
         if (tk < nTracks) {
             int c = (int)(sTrk[tk] >> 16), s = (int)(sTrk[tk] & 0xFFFFu);
@@ -319,7 +319,6 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
                 // every view: within maxRpErr of the re-projection and in front of the camera (:226-236); J^T J for the covariance
                 bool outlier = false;
                 double S[6] = {0, 0, 0, 0, 0, 0};
-                double err[NP_MAX_CAMS];
                 for (int k = 0; k < nv; ++k) {
                     const cs_poseupdate_cam& Cm = A.cam[v[k].c];
                     const double* K = Cm.K;
@@ -355,7 +354,6 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
                     int nDyn = 0;
                     for (int k = 0; k < nv; ++k) {
                         const cs_poseupdate_cam& Cm = A.cam[v[k].c];
-                        if (Cm.reprojErr) Cm.reprojErr[v[k].s] = err[k];                       // fp->reprojErr (:247-248)
                         if (Cm.isStatic && !Cm.isStatic[v[k].s]) ++nDyn;                         // TYPE_FEATPOINT_DYNAMIC (:250-251)
                     }
                     if (nDyn > 1) {
@@ -388,6 +386,7 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
                 for (int k = 0; k < nv; ++k) {
                     A.pointFeat[(size_t)m * C + v[k].c] = v[k].s;          // MapPoint::addFeature
                     const_cast<int*>(A.cam[v[k].c].slot2map)[v[k].s] = m;  // the feature (and its track) takes the point (:168-172)
+                    if (A.cam[v[k].c].reprojErr) A.cam[v[k].c].reprojErr[v[k].s] = err[k];   // fp->reprojErr (:247-248)
                 }
             } else if (A.counts) {
                 atomicOr(A.counts + 3, 2);

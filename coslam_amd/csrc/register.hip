@@ -338,6 +338,7 @@ struct RdArgs {
     int* base;                       // scratch [P]: order of the point's walk (x nCams), -1: the point is not visited
     int* owner[3];                   // scratch 3 x [nCams * N]: the sweeps rotate through them
     int* counts;                     // [4] out: features attached, points regged, sweeps, converged
+    int* unconverged;                // the scratch's last word: calls whose sweeps did not settle (never cleared here)
 };
 // code of (point, camera): -1 the walk passes the camera by; else the candidate feature camera * N + slot in the low bits and
 constexpr int RD_INIT_MAPPED = 1 << 29, RD_CAN_MERGE = 1 << 28, RD_FEAT = (1 << 28) - 1;
@@ -380,7 +381,10 @@ __global__ __launch_bounds__(256) void k_decide_sweep(RdArgs A, const int* __res
     if (mode == 1 && prev2) {   // converged: the last two sweeps agree on every owner
         int ch = 0;
         for (int f = p; f < nFeat; f += gridDim.x * 256) ch |= prev[f] != prev2[f];
-        if (ch && A.counts) A.counts[3] = 0;
+        if (ch) {
+            if (A.counts) A.counts[3] = 0;
+            atomicOr(A.unconverged, 1);
+        }
     }
     if (p >= A.P) return;
     const int base = A.base[p];
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(256) void k_decide_sweep(RdArgs A, const int* __res
 
 extern "C" size_t cs_register_decide_scratch_bytes(int nCams, int N, int P) {
     if (nCams < 1 || N < 1 || P < 0) return 0;
-    return sizeof(int) * ((size_t)nCams * P + (size_t)P + 3 * (size_t)nCams * N);
+    return sizeof(int) * ((size_t)nCams * P + (size_t)P + 3 * (size_t)nCams * N + 1);
 }
 
 extern "C" int cs_register_decide_static_dev(int device, void* hip_stream, int nCams, int N, int P, int mapBase, const int* d_slot, const int* d_flags,
@@ -450,6 +454,7 @@ extern "C" int cs_register_decide_static_dev(int device, void* hip_stream, int n
     A.code = scr, scr += (size_t)nCams * P;
     A.base = scr, scr += P;
     for (int k = 0; k < 3; ++k) A.owner[k] = scr, scr += (size_t)nCams * N;
+    A.unconverged = scr;
     CS_HIP(hipSetDevice(device));
     if (P == 0) return CS_OK;
     hipStream_t s = (hipStream_t)hip_stream;

@@ -335,7 +335,8 @@ int cs_register_search(int device, int nCams, const cs_register_cam* cams, int N
  * mapBase + P - 1); IN / OUT: d_pointFeat [P][nCams] (MapPoint::addFeature) and every camera's slot2map [N] (the attached feature's
  * whole track takes the point, :771-775); OUT: d_attached [P][nCams], d_regged [P] (refineMapPoint is due: hand it to
  * cs_refine_map_points_dev as d_select), d_counts [4] or NULL (features attached, points regged, sweeps, converged).
- * d_scratch: cs_register_decide_scratch_bytes.  Not done here: the projections are those of the search as it ran (the reference
+ * d_scratch: cs_register_decide_scratch_bytes; its LAST int is sticky: set to 1 by any call whose sweeps did not settle (the
+ * decision then is not the sequential one), never cleared here -- zero the scratch once, read the word at the end of a run.  Not done here: the projections are those of the search as it ran (the reference
  * refines a point before the next camera's round of walks, :889-893), and the bMerge == true branch (every 50th frame: checkUnify on
  * a conflict, cs_check_unify_dev gives its verdicts when built). */
 size_t cs_register_decide_scratch_bytes(int nCams, int N, int P);

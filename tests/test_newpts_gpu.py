@@ -128,6 +128,117 @@ def test_new_map_points_equal_the_restatement(hip, seed, max_disp):
     assert ((fl_new == 4) | (fl_new == 0)).sum() > 10    # uncertain, or certain static after decidePointType; dynamic ones need two DYNAMIC features
 
 
+def _run_both(S, max_disp, cap=None, pair_cap=4096):
+    """oracle.new_map_points_from_pairs and cs_newpts_from_pairs_dev on scene S (map arrays cut to `cap` entries, candidate lists cut
+    to `pair_cap` on the oracle's side -- the device is TOLD the full count); returns (oracle's result, oracle's arrays, device arrays)"""
+    import torch
+
+    import oracle
+    from coslam_amd.ncc import NCC_PAIR_DTYPE
+    from coslam_amd.newpts import NewPtsJob, newpts_from_pairs_dev, newpts_scratch_bytes
+
+    sc, nC, N, nMap = S["sc"], S["nC"], S["N"], S["nMap"]
+    cap = S["cap"] if cap is None else cap
+    o = dict(mapPts=S["mapPts"][:cap].copy(), mapCov=S["mapCov"][:cap].copy(), flags=S["flags"][:cap].copy(), newPt=np.zeros(cap, np.uint8),
+             first=np.zeros(cap, np.int32), pf=S["pf"][:cap].copy(), s2m=[x.copy() for x in S["s2m"]], reproj=[np.zeros(N) for _ in range(nC)])
+    res = oracle.new_map_points_from_pairs(N, [pl[:pair_cap] for pl in S["pairs"]], [sc.K] * nC, [sc.iK] * nC, S["R"], S["t"], S["xy"], S["state"],
+                                           o["s2m"], S["is_static"], o["mapPts"], o["mapCov"], o["flags"], o["newPt"], o["first"], o["pf"], nMap,
+                                           S["frame"], max_disp=max_disp, reproj=o["reproj"], W=W_IMG, H=H_IMG)
+    dev = torch.device("cuda:0")
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    dK, diK = d(sc.K.reshape(9)), d(sc.iK.reshape(9))
+    dxy, dst, ds2m, dstat = d(np.stack(S["xy"])), d(np.stack(S["state"])), d(np.stack(S["s2m"])), d(np.stack(S["is_static"]))
+    drep = torch.zeros((nC, N), dtype=torch.float64, device=dev)
+    alloc = max(max(len(pl) for pl in S["pairs"]), pair_cap, 1)
+    dpairs = torch.zeros((nC - 1, alloc * NCC_PAIR_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    dcnt = torch.zeros(nC - 1, dtype=torch.int32, device=dev)
+    for a in range(nC - 1):
+        arr = np.zeros(len(S["pairs"][a]), dtype=NCC_PAIR_DTYPE)
+        for k, (i, j, e, n) in enumerate(S["pairs"][a]):
+            arr[k] = (i, j, e, n)
+        if arr.nbytes:
+            dpairs[a, :arr.nbytes] = torch.from_numpy(arr.view(np.uint8)).to(dev)
+        dcnt[a] = len(arr)
+    cams = [dict(K=dK.data_ptr(), iK=diK.data_ptr(), xy=dxy[c].data_ptr(), state=dst[c].data_ptr(), slot2map=ds2m[c].data_ptr(),
+                 isStatic=dstat[c].data_ptr(), reprojErr=drep[c].data_ptr()) for c in range(nC)]
+    job = NewPtsJob(cams, [dpairs[a].data_ptr() for a in range(nC - 1)], [dcnt[a:a + 1].data_ptr() for a in range(nC - 1)])
+    dM, dC, dF, dPf = d(S["mapPts"][:cap]), d(S["mapCov"][:cap]), d(S["flags"][:cap]), d(S["pf"][:cap])
+    dNew, dFirst = torch.zeros(cap, dtype=torch.uint8, device=dev), torch.zeros(cap, dtype=torch.int32, device=dev)
+    dCount = torch.tensor([nMap], dtype=torch.int32, device=dev)
+    dScr = torch.zeros(newpts_scratch_bytes(nC, N), dtype=torch.uint8, device=dev)
+    dOut = torch.zeros(4 + nC, dtype=torch.int32, device=dev)
+    dR, dT = d(S["R"]), d(S["t"])
+    newpts_from_pairs_dev(torch.cuda.current_stream().cuda_stream, job, N, pair_cap, dR.data_ptr(), dT.data_ptr(), dM.data_ptr(), dC.data_ptr(),
+                          dF.data_ptr(), dNew.data_ptr(), dFirst.data_ptr(), dPf.data_ptr(), cap, dCount.data_ptr(), S["frame"], dScr.data_ptr(),
+                          dOut.data_ptr(), maxDisp=max_disp, W=W_IMG, H=H_IMG)
+    torch.cuda.synchronize()
+    g = dict(mapPts=dM.cpu().numpy(), mapCov=dC.cpu().numpy(), flags=dF.cpu().numpy(), newPt=dNew.cpu().numpy(), first=dFirst.cpu().numpy(),
+             pf=dPf.cpu().numpy(), s2m=[ds2m[c].cpu().numpy() for c in range(nC)], reproj=[drep[c].cpu().numpy() for c in range(nC)],
+             out=dOut.cpu().tolist(), count=int(dCount.item()))
+    return res, o, g
+
+
+def _same_map(o, g, nC):
+    for k in ("mapPts", "mapCov", "flags", "newPt", "first", "pf"):
+        assert np.array_equal(o[k], g[k]), k
+    for c in range(nC):
+        assert np.array_equal(o["s2m"][c], g["s2m"][c]) and np.array_equal(o["reproj"][c], g["reproj"][c]), c
+
+
+def test_no_candidate_pairs_leave_the_map_alone(hip):
+    """empty candidate lists (a frame whose NCC stage passes nothing): no track, no point, the map and every feature's owner untouched"""
+    S = _scene(21)
+    S["pairs"] = [[] for _ in S["pairs"]]
+    res, o, g = _run_both(S, 80.0)
+    assert res["new"] == [] and g["out"][:4] == [0, 0, 0, 0] and g["count"] == S["nMap"]
+    _same_map(o, g, S["nC"])
+    assert np.array_equal(g["mapPts"], S["mapPts"]) and all(np.array_equal(g["s2m"][c], S["s2m"][c]) for c in range(S["nC"]))
+
+
+def test_a_single_pair_makes_one_point(hip):
+    S = _scene(22)
+    keep = next(q for q in S["pairs"][1] if S["sc"].slotPt[1, q[0]] == S["sc"].slotPt[2, q[1]])     # a true correspondence
+    S["pairs"] = [[], [keep], []]
+    res, o, g = _run_both(S, 1e9)
+    assert len(res["tracks"]) == 1 and g["out"][1] == 1 and g["out"][0] == len(res["new"]) and g["count"] == res["map_count"]
+    _same_map(o, g, S["nC"])
+
+
+def test_map_without_room_takes_the_first_points_and_says_so(hip):
+    """mapCap reached: the points are appended in track order until the arrays are full, the rest dropped with flag bit 2 (the reference's
+    list grows without bound; a full map is this layout's own case)"""
+    S = _scene(23)
+    res_all, _, _ = _run_both(S, 80.0)
+    room = 7
+    assert len(res_all["new"]) > room + 5
+    res, o, g = _run_both(S, 80.0, cap=S["nMap"] + room)
+    assert len(res["new"]) == room and res["new"] == res_all["new"][:room]
+    assert g["out"][3] & 2 and g["count"] >= S["nMap"] + room       # (the count runs on: the caller sees by how much the map fell short)
+    _same_map(o, g, S["nC"])
+
+
+def test_candidate_list_longer_than_its_capacity_is_cut_and_flagged(hip):
+    """the NCC stage found more passing pairs than the list holds (count > pairCap): the first pairCap entries are used, flag bit 1"""
+    S = _scene(24)
+    pair_cap = 48
+    assert all(len(pl) > pair_cap + 10 for pl in S["pairs"])
+    res, o, g = _run_both(S, 80.0, pair_cap=pair_cap)
+    assert g["out"][3] & 1 and g["out"][0] == len(res["new"]) > 3 and g["out"][1] == len(res["tracks"])
+    _same_map(o, g, S["nC"])
+
+
+def test_bad_arguments_are_refused(hip):
+    import ctypes as C
+
+    import coslam_amd
+    L = coslam_amd.lib()
+    assert L.cs_newpts_from_pairs_dev(0, None, 1, 512, None, None, None, 16, None, None, None, None, None, None, None, None, 10, None, 0,
+                                      C.c_double(80.0), C.c_double(3.0), C.c_double(10.0), 2, 640, 480, None, None) != 0
+    assert b"cs_newpts_from_pairs_dev" in L.cs_last_error()
+    L.cs_newpts_scratch_bytes.restype = C.c_size_t
+    assert L.cs_newpts_scratch_bytes(1, 512) == 0 and L.cs_newpts_scratch_bytes(4, 0) == 0
+
+
 def test_candidate_mask_is_addslams_filter(hip):
     """cs_ncc_candidate_mask_dev: features of this frame on tracks of MORE than three frames, unmapped or mapped to a false point
     (NewMapPtsNCC::addSlam + getTrackedFeatPts(.., 3), reference src/app/SL_NewMapPointsInterCam.h:103-131, SL_SingleSLAM.cpp:173-184)"""

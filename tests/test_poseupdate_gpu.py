@@ -485,6 +485,15 @@ def test_map_points_classify_reproduces_the_reference_on_its_golden_scenes():
         with pytest.raises(Exception):   # the history's newest entry is not the frame that is asked for
             th.map_points_classify_dev(s, cams, d_pf.data_ptr(), nMap, cur + 1, d_M.data_ptr(), d_cov.data_ptr(), d_fl.data_ptr(),
                                        d_new.data_ptr(), d_sfn.data_ptr(), d_first.data_ptr())
+        # nothing to examine (every point certain and static, or false): an empty worklist, not one byte of the map changes
+        d_fl2 = torch.from_numpy(np.where(np.arange(nMap) % 5 == 0, 2, 0).astype(np.uint8)).to(dev)
+        before = [x.clone() for x in (d_M, d_cov, d_new, d_sfn, d_pf, d_s2m, d_fstat)]
+        th.map_points_classify_dev(s, cams, d_pf.data_ptr(), nMap, cur, d_M.data_ptr(), d_cov.data_ptr(), d_fl2.data_ptr(), d_new.data_ptr(),
+                                   d_sfn.data_ptr(), d_first.data_ptr(), float(G("pixelVar")), d_featFrame=d_ff.data_ptr(),
+                                   d_featFirst=d_f1.data_ptr(), d_counts=d_cnt.data_ptr())
+        torch.cuda.synchronize()
+        assert d_cnt.tolist() == [0, 0] and all(torch.equal(a, b) for a, b in zip(before, (d_M, d_cov, d_new, d_sfn, d_pf, d_s2m, d_fstat)))
+        assert np.array_equal(d_fl2.cpu().numpy(), np.where(np.arange(nMap) % 5 == 0, 2, 0))
         th.close()
     assert examined > 150
 

@@ -58,6 +58,56 @@ def test_decision_equals_the_sequential_walks(hip, seed, P, C, N, pc):
         assert att_o.sum() > 100
 
 
+def _device_decide(slot, flags, merg, mf, pf, s2m, n_sweeps, map_base=0, scratch=None):
+    import torch
+
+    from coslam_amd.register import register_decide_scratch_bytes, register_decide_static_dev
+
+    P, C = slot.shape
+    N = len(s2m[0])
+    dev = torch.device("cuda:0")
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    d_slot, d_flags, d_merg, d_mf, d_pf = d(slot), d(flags), d(merg), d(mf), d(pf)
+    d_s2m = [d(x) for x in s2m]
+    d_att, d_reg = torch.zeros((P, C), dtype=torch.uint8, device=dev), torch.zeros(P, dtype=torch.uint8, device=dev)
+    d_scr = torch.zeros(register_decide_scratch_bytes(C, N, P), dtype=torch.uint8, device=dev) if scratch is None else scratch
+    d_cnt = torch.zeros(4, dtype=torch.int32, device=dev)
+    register_decide_static_dev(torch.cuda.current_stream().cuda_stream, C, N, P, map_base, d_slot.data_ptr(), d_flags.data_ptr(), d_merg.data_ptr(),
+                               d_mf.data_ptr(), d_pf.data_ptr(), [x.data_ptr() for x in d_s2m], d_att.data_ptr(), d_reg.data_ptr(),
+                               d_scr.data_ptr(), d_cnt.data_ptr(), n_sweeps=n_sweeps)
+    torch.cuda.synchronize()
+    return dict(att=d_att.cpu().numpy(), reg=d_reg.cpu().numpy(), pf=d_pf.cpu().numpy(), s2m=[x.cpu().numpy() for x in d_s2m], cnt=d_cnt.cpu().tolist(),
+                unsettled=int(d_scr[-4:].view(torch.int32).item()), scratch=d_scr)
+
+
+def test_nothing_to_decide(hip):
+    """no candidate anywhere (every search came back empty) / no certainly static point: nothing attached, every table as it was"""
+    slot, flags, merg, mf, pf, s2m = _case(6, 500, 4, 300, 0.2)
+    empty = np.full_like(slot, -3)
+    g = _device_decide(empty, flags, merg, mf, pf, s2m, 3)
+    assert g["cnt"] == [0, 0, 3, 1] and not g["att"].any() and not g["reg"].any() and g["unsettled"] == 0
+    assert np.array_equal(g["pf"], pf) and all(np.array_equal(g["s2m"][c], s2m[c]) for c in range(4))
+    g = _device_decide(slot, flags, merg, np.full_like(mf, 4), pf, s2m, 3)        # every point uncertain
+    assert g["cnt"][:2] == [0, 0] and not g["att"].any() and np.array_equal(g["pf"], pf)
+    g = _device_decide(slot, flags, np.zeros_like(merg), mf, pf, s2m, 3)          # nothing mergeable over its track
+    assert g["cnt"][:2] == [0, 0] and not g["att"].any() and np.array_equal(g["pf"], pf)
+
+
+def test_too_few_sweeps_are_reported_and_the_word_sticks(hip):
+    """a conflict chain longer than the sweeps given: counts[3] = 0 for that call and the scratch's last int stays 1 over later, settled calls"""
+    import oracle
+
+    slot, flags, merg, mf, pf, s2m = _case(3, 4096, 8, 2000, 0.5)
+    g1 = _device_decide(slot, flags, merg, mf, pf, s2m, 1)
+    o_pf, o_s2m = pf.copy(), [x.copy() for x in s2m]
+    att_o, _ = oracle.register_decide_static(slot, flags, merg, mf, o_pf, o_s2m)
+    assert g1["cnt"][3] == 0 and g1["unsettled"] == 1
+    g2 = _device_decide(slot, flags, merg, mf, pf, s2m, 12, scratch=g1["scratch"])
+    assert g2["cnt"][3] == 1 and g2["unsettled"] == 1 and np.array_equal(g2["att"], att_o)
+    g3 = _device_decide(slot, flags, merg, mf, pf, s2m, 12)
+    assert g3["unsettled"] == 0
+
+
 def test_device_registration_on_the_reference_golden_scenes(hip):
     """The frame loop's registration of the current static points -- cs_register_search_passes_dev, cs_register_mergability_dev,
     cs_register_decide_static_dev, cs_refine_map_points_dev, once each -- on the scenes of tests/golden/decide_golden.npz (the
