@@ -78,10 +78,15 @@ __device__ __forceinline__ double maha_dist2(double mx, double my, double bx, do
     return dx * (ivar[0] * dx + ivar[1] * dy) + dy * (ivar[2] * dx + ivar[3] * dy);
 }
 
-constexpr int RG_WAVES = 16;      // waves per workgroup: each scans 1 / 16 of the staged features for the block's 64 points (8 or 4 waves:
-                                  // the same frame rate in the loop, 2098 / 2053-2066 against 2070-2084 frames/s: profiles/r04_ab_runs.txt)
+// The kernel has to FIT beside the persistent tracker, whose workgroups hold two waves of 160 VGPRs on every SIMD and 128 of a compute
+// unit's 160 KB of LDS for as long as its main kernel runs: 192 VGPRs per SIMD lane and 32 KB of LDS are what is left.  8 waves of 96
+// VGPRs (two per SIMD) and a 512-feature stage (8 KB + 6 KB of tables) fit; round 3's 16 waves (four per SIMD: 384 VGPRs) with the
+// whole list staged (44 KB) did not -- a search that became ready before the tracker's main kernel had retired waited for it.
+// Measured in the loop, alternating on one box (profiles/r04_ab_runs.txt): 16 waves / whole list 2141-2148 frames/s, 8 / 1024 2159-2167,
+// 8 / 512 2173-2179, 8 / 256 2159, 16 / 512 2134-2141, 4 / 512 2128-2140.
+constexpr int RG_WAVES = 8;       // waves per workgroup: each scans 1 / 8 of the staged features for the block's 64 points
 constexpr int RG_ROWS = RG_WAVES > 6 ? RG_WAVES : 6;   // rows of the minima table (it first carries the 6 projection values)
-constexpr int RG_CHUNK = 4096;    // features staged in LDS at a time (64 KB); longer lists are scanned chunk by chunk
+constexpr int RG_CHUNK = 512;     // features staged in LDS at a time; the list is scanned chunk by chunk
 
 // One workgroup = 64 map points x one camera.  Lane = point: its projection and scaled inverse covariance live in
 // registers.  The camera's feature list is staged in LDS once per workgroup (x, y as doubles; a slot that is not in this
@@ -277,13 +282,6 @@ extern "C" int cs_register_search_passes_range_dev(int device, void* hip_stream,
     CS_HIP(hipSetDevice(device));
     const int CH = N < RG_CHUNK ? N : RG_CHUNK;
     const size_t ldsBytes = (size_t)2 * CH * sizeof(double) + (size_t)RG_ROWS * 64 * sizeof(double) + (size_t)RG_WAVES * 64 * sizeof(int);
-    if (ldsBytes > 64 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            CS_HIP(hipFuncSetAttribute((const void*)k_register_search, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            raised = true;
-        }
-    }
     hipLaunchKernelGGL(k_register_search, dim3((unsigned)((maxP + 63) / 64), (unsigned)nCamsRun, (unsigned)nPass), dim3(64 * RG_WAVES), ldsBytes,
                        (hipStream_t)hip_stream, A);
     CS_CHECK_LAUNCH();
