@@ -148,6 +148,8 @@ struct PoseCtx {
     double* Ws;  // LDS or global scratch, npts
     int npts;
     double* red;          // LDS [PB/64][27]
+    double pM[3], pm[2];  // the lane's FIRST point (i = threadIdx.x), read once instead of in every LM pass (170 points per camera: one
+                          // point per lane; 2193-2200 against 2184-2186 frames/s in the loop, three alternating runs each)
     double dR[3][9];      // exp(eps e_k): independent of the iterate (SL_IntraCamPose.cpp:57-58)
     int myEntry;          // which of the 28 sums this lane holds in the lane-parallel solve
 };
@@ -209,10 +211,15 @@ __device__ void lm_pass(const PoseCtx& c, const double* R, const double* t, bool
 #pragma unroll
     for (int q = 0; q < NSUM; ++q) acc[q] = 0;
     for (int i = threadIdx.x; i < c.npts; i += PB) {
-        const double* pM = c.Ms + 3 * i;
+        double pM[3], pm[2];
+        if (i < PB) {   // (uniform: the first trip of every lane)
+            pM[0] = c.pM[0], pM[1] = c.pM[1], pM[2] = c.pM[2], pm[0] = c.pm[0], pm[1] = c.pm[1];
+        } else {
+            pM[0] = c.Ms[3 * i], pM[1] = c.Ms[3 * i + 1], pM[2] = c.Ms[3 * i + 2], pm[0] = c.ms[2 * i], pm[1] = c.ms[2 * i + 1];
+        }
         double rm0[2], rm[2], J[12];
         project(c.K, R, t, pM, rm0);
-        const double dx = rm0[0] - c.ms[2 * i], dy = rm0[1] - c.ms[2 * i + 1];
+        const double dx = rm0[0] - pm[0], dy = rm0[1] - pm[1];
         double w;
         if (reweight) {
             w = tukey(sqrt(dx * dx + dy * dy), tau);
@@ -237,7 +244,7 @@ __device__ void lm_pass(const PoseCtx& c, const double* R, const double* t, bool
         }
 #pragma unroll
         for (int q = 0; q < 12; ++q) J[q] = w * J[q];
-        const double r0 = (-rm0[0] + c.ms[2 * i]) * w, r1 = (-rm0[1] + c.ms[2 * i + 1]) * w;
+        const double r0 = (-rm0[0] + pm[0]) * w, r1 = (-rm0[1] + pm[1]) * w;
         int q = 0;
 #pragma unroll
         for (int r = 0; r < 6; ++r)
@@ -362,6 +369,12 @@ __global__ __launch_bounds__(PB) CS_IC_ATTR void k_intracam(int ptsStride, const
         double w[3] = {0, 0, 0};
         w[a] = 1e-8;
         so3_exp(w, c.dR[a]);
+    }
+    if ((int)threadIdx.x < npts) {
+        const int i = threadIdx.x;
+        c.pM[0] = c.Ms[3 * i], c.pM[1] = c.Ms[3 * i + 1], c.pM[2] = c.Ms[3 * i + 2], c.pm[0] = c.ms[2 * i], c.pm[1] = c.ms[2 * i + 1];
+    } else {
+        c.pM[0] = c.pM[1] = c.pM[2] = c.pm[0] = c.pm[1] = 0;
     }
     for (int i = threadIdx.x; i < npts; i += PB)
         c.Ws[i] = prevErrs ? tukey(fabs(prevErrs[(size_t)ptsStride * pb + i]), tau) : 1.0;  // :641-655
