@@ -598,6 +598,8 @@ def main():
     wis = [w.worker_stats() for w in loop.ic_wss]
     wi = [sum(w[0] for w in wis), sum(w[1] for w in wis), 0, max(w[3] for w in wis)]
     applied_timed = loop.applied - applied0
+    dec_counts = None if not hasattr(loop, "_dec") else (loop._dec["cnt"].cpu().tolist(), int(loop._dec["ref_cnt"].item()),
+                                                         bool(loop._dec["scr"][-4:].view(torch.int32).item()))
     digest = loop.digest() if os.environ.get("BENCH_STATE_DIGEST") else None
     if loop._timing is not None:
         print("[frameloop host seconds by section]", {k: round(v, 4) for k, v in loop._timing.items()}, file=sys.stderr)
@@ -648,6 +650,26 @@ def main():
                       "windows_solved": loop.n_windows - w1, "requests_dropped_because_the_previous_solve_was_running": loop.n_skipped - s1,
                       "what": "the same loop with the reference's request policy: a key frame's window BA is requested only when no bundle "
                               "adjustment is running (CoSLAM::requestForBA, SL_CoSLAM.cpp:1750-1755); the headline solves EVERY window"}
+    seq_reg = None
+    if world == 1 and not args.no_secondary and hasattr(loop, "_dec"):
+        # SECONDARY: the registration of the current static points step for step as the reference runs it (camera loop after camera
+        # loop, search + mergability + walks + refineMapPoint per loop: bit-identical to the reference's own run on its golden scenes,
+        # tests/test_register_decide_gpu.py) instead of the headline's single pass: same loop, same frames, fewer steps
+        loop.drain()
+        loop.sequential_registration = True
+        n_seq = max(args.steps // 3, 10)
+        run(min(args.warmup, 10))
+        barrier()
+        tq = time.perf_counter()
+        run(n_seq)
+        barrier()
+        dtq = time.perf_counter() - tq
+        loop.sequential_registration = False
+        seq_reg = {"frames_per_s": n_seq / dtq, "ms_per_step": dtq / n_seq * 1e3, "steps": n_seq, "ratio_to_value": (n_seq / dtq) / (args.steps / dt),
+                   "loops_whose_sweeps_did_not_settle": bool(loop._dec["scr"][-4:].view(torch.int32).item()),
+                   "what": "the same loop with CoSLAM::curStaticPointsRegInGroup reproduced step for step (cs_register_decide_static_cam_dev per "
+                           "camera loop, a search, a mergability pass and a refine per loop: 8 x the launches) instead of the headline's single "
+                           "pass -- the parity mode; the single pass differs from it in ~2 % of a frame's attachments (DESIGN.md 8.2)"}
     gc.enable()
     replicas = None
     if world > 1:
@@ -981,10 +1003,10 @@ def main():
                         "current_static_tracks_longer_than_the_history": None if loop.pose_upd is None else int((loop.d_mergeable[:, lc] == 2).sum().item()),
                         "history_note": "a candidate whose track is longer than the 64-frame history and passes on every frame held is reported "
                                         "as unjudged (2) and NOT attached: the reference walks the whole track"},
-                       "register_decision": None if not hasattr(loop, "_dec") else dict(zip(
-                           ("features_attached_last_frame", "points_regged_last_frame", "sweeps_last_frame", "converged"), loop._dec["cnt"].cpu().tolist()),
-                           points_refined_last_frame=int(loop._dec["ref_cnt"].item()),
-                           frames_whose_sweeps_did_not_settle=bool(loop._dec["scr"][-4:].view(torch.int32).item()),
+                       "register_decision": None if dec_counts is None else dict(zip(
+                           ("features_attached_last_frame", "points_regged_last_frame", "sweeps_last_frame", "converged"), dec_counts[0]),
+                           points_refined_last_frame=dec_counts[1],
+                           frames_whose_sweeps_did_not_settle=dec_counts[2],
                            what="curStaticPointsRegInGroup's decision (bMerge false) over the search + mergability tables of all cameras "
                                 "(cs_register_decide_static_dev: the sequential first-claimant rule resolved exactly), then refineMapPoint of "
                                 "the points that gained a feature (cs_refine_map_points_dev)"),
@@ -1014,7 +1036,8 @@ def main():
                                       loop.ncc["np_cnt"].cpu().tolist()[:4])),
                            "matches_per_pair_last_run": loop.ncc["np_cnt"].cpu().tolist()[4:4 + N_CAMS - 1],
                            "map_points_in_use": int(loop.d_mapcount.item()), "map_points_at_start": n_pts0, "map_capacity": loop.n_map},
-                       "with_upload": with_upload, "secondary_reference_ba_request_policy": ref_policy, "cxx_frame_loop": cxx,
+                       "with_upload": with_upload, "secondary_reference_ba_request_policy": ref_policy,
+                       "secondary_sequential_registration": seq_reg, "cxx_frame_loop": cxx,
                        "collectives": None if world == 1 else ("libcoslam_hip RCCL (C-ABI)" if loop.native else "torch.distributed " + dist_backend +
                                                                (f" (FALLBACK: libcoslam_hip's communicator could not be created: {loop.native_fallback})"
                                                                 if getattr(loop, "native_fallback", None) else "")),

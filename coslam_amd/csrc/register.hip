@@ -323,7 +323,7 @@ namespace {
 // A point's later visits (it appears once per camera in which it has a feature) find what its first visit left and change nothing.
 constexpr int RD_MAX_CAMS = 16;
 struct RdArgs {
-    int nCams, N, P, mapBase, nSweeps;
+    int nCams, N, P, mapBase, nSweeps, onlyCam;
     const int* slot;                 // [P][nCams] the search's candidates
     const int* flags;                // [P][nCams] bit 1: the candidate is dynamic
     const unsigned char* mergeable;  // [P][nCams] 1: mergeable over the whole track
@@ -365,6 +365,8 @@ __global__ __launch_bounds__(256) void k_decide_prepare(RdArgs A) {
         int ofirst = -1;
         for (int q = C - 1; q >= 0; --q)
             if (A.pointFeat[(size_t)p * C + q] >= 0) ofirst = q;
+        // onlyCam >= 0: ONE camera's loop of the reference (:864-869): the points with a feature of this frame in that camera, map order
+        if (A.onlyCam >= 0) ofirst = A.pointFeat[(size_t)p * C + A.onlyCam] >= 0 ? 0 : -1;
         const bool certainStatic = (A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) == 0;
         A.base[p] = (ofirst >= 0 && certainStatic) ? (ofirst * A.P + p) * C : -1;
     }
@@ -430,6 +432,18 @@ extern "C" int cs_register_decide_static_dev(int device, void* hip_stream, int n
                                              const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
                                              int* const* d_slot2map /* host array of nCams device pointers */, unsigned char* d_attached,
                                              unsigned char* d_regged, void* d_scratch, int nSweeps, int* d_counts) {
+    return cs_register_decide_static_cam_dev(device, hip_stream, nCams, N, P, mapBase, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, d_slot2map,
+                                             d_attached, d_regged, d_scratch, nSweeps, d_counts, -1);
+}
+
+extern "C" int cs_register_decide_static_cam_dev(int device, void* hip_stream, int nCams, int N, int P, int mapBase, const int* d_slot,
+                                                 const int* d_flags, const unsigned char* d_mergeable, const unsigned char* d_mapFlags,
+                                                 int* d_pointFeat, int* const* d_slot2map, unsigned char* d_attached, unsigned char* d_regged,
+                                                 void* d_scratch, int nSweeps, int* d_counts, int onlyCam) {
+    if (onlyCam >= nCams) {
+        cs_set_error("cs_register_decide_static_cam_dev: camera %d of %d", onlyCam, nCams);
+        return CS_ERR_INVALID;
+    }
     if (nCams < 1 || nCams > RD_MAX_CAMS || N < 1 || P < 0 || (long long)nCams * N > RD_FEAT || (long long)nCams * P * nCams > 0x7fffffffLL ||
         mapBase < 0 || nSweeps < 1 || nSweeps > 256 || !d_slot || !d_flags || !d_mergeable || !d_mapFlags || !d_pointFeat || !d_slot2map ||
         !d_attached || !d_regged || !d_scratch) {
@@ -438,7 +452,7 @@ extern "C" int cs_register_decide_static_dev(int device, void* hip_stream, int n
     }
     RdArgs A;
     memset(&A, 0, sizeof(A));
-    A.nCams = nCams, A.N = N, A.P = P, A.mapBase = mapBase, A.nSweeps = nSweeps;
+    A.nCams = nCams, A.N = N, A.P = P, A.mapBase = mapBase, A.nSweeps = nSweeps, A.onlyCam = onlyCam < 0 ? -1 : onlyCam;
     A.slot = d_slot, A.flags = d_flags, A.mergeable = d_mergeable, A.mapFlags = d_mapFlags, A.pointFeat = d_pointFeat;
     for (int c = 0; c < nCams; ++c) {
         if (!d_slot2map[c]) {

@@ -49,6 +49,8 @@ class LoopConfig:
         self.with_pose_update = self.with_classify = self.with_register = self.with_mergability = self.with_ncc = True
         self.with_joint = self.with_intercam = True
         self.with_decide = True    # the registration decision (who attaches which feature) + refineMapPoint of the points that gained one
+        self.sequential_registration = False   # the decision camera loop after camera loop with a search + refine per loop, as the
+        # reference runs it (register_cur_static_sequential_dev: bit-identical to the reference's run, nCams x the launches; one rank only)
         self.native_comm = True
         self.device_wait = True    # the BA result's apply waits for the solve on the device (cs_ba_output_wait_dev), not on the host
         for k, v in kw.items():
@@ -246,6 +248,7 @@ class FrameLoop:
             self.d_iM = torch.from_numpy(ic["pts0"].reshape(-1).copy()).to(dev)
         self.n_pushed = self.n_windows = self.n_key = self.n_my_solves = self.n_my_ic = 0
         self.skip_busy, self.n_skipped = False, 0   # (set by the caller: drop a window request while the previous solve is running)
+        self.sequential_registration = bool(cfg.sequential_registration)   # (may be switched between frames)
         self.apply_at, self.my_seq = {}, {}
         self.applied, self.last_apply = 0, None
         self.stage_slot, self.h_frames = {}, None
@@ -506,6 +509,7 @@ class FrameLoop:
                                                        self.reg_out[1]["slot"].data_ptr(), PIXEL_ERR_VAR, self.d_mergeable.data_ptr(),
                                                        cam0=c0, nCamsRun=nc)
         if cfg.with_register and cfg.with_decide and self.pose_upd is not None and cfg.with_mergability:
+            self._dst_now = dst
             self._decide(ps)
         # the tracker of frame i + 2 (it writes this dest buffer) is released HERE, at the end of the frame's pose work, although the
         # buffer's last reader was the hand-back: released earlier the tracker runs two frames ahead and under more of the pose stream's
@@ -536,6 +540,22 @@ class FrameLoop:
                              scr=z(register_decide_scratch_bytes(NA, cfg.n_feat, cfg.p_reg), torch.uint8), s2m=None)
             torch.cuda.synchronize()   # (the zero fills ran on torch's stream: done before the pose stream touches the buffers)
         D = self._dec
+        if self.sequential_registration:
+            from coslam_amd.register import register_cur_static_sequential_dev
+
+            if self.world > 1:
+                raise RuntimeError("sequential_registration: one rank only (the per-loop tables are not exchanged)")
+            if not hasattr(self, "_pass_current"):
+                T_ = type(self.reg_passes[0])
+                self._pass_current = (T_ * 1)(self.reg_passes[1])
+            o = self.reg_out[1]
+            D["s2m"] = register_cur_static_sequential_dev(ps, self.pose_upd, self.pu_args, self.reg_args[self._dst_now], cfg.n_feat, cfg.W, cfg.H,
+                                                          self._pass_current, cfg.p_reg, o["slot"].data_ptr(), o["flags"].data_ptr(),
+                                                          self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(),
+                                                          D["s2m"] if D["s2m"] is not None else [self.d_slot2map[g].data_ptr() for g in range(NA)],
+                                                          D["att"].data_ptr(), D["reg"].data_ptr(), D["scr"].data_ptr(), self.d_map.data_ptr(),
+                                                          self.d_cov.data_ptr(), PIXEL_ERR_VAR, d_counts=D["cnt"].data_ptr(), device=self.device)
+            return
         if self.world > 1:
             self._gather_candidates()
         D["s2m"] = register_decide_static_dev(ps, NA, cfg.n_feat, cfg.p_reg, 0, self.reg_out[1]["slot"].data_ptr(), self.reg_out[1]["flags"].data_ptr(),

@@ -114,11 +114,35 @@ def register_decide_scratch_bytes(nCams, N, P):
 
 
 def register_decide_static_dev(stream_ptr, nCams, N, P, mapBase, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, d_slot2map, d_attached,
-                               d_regged, d_scratch, d_counts=0, device=0, n_sweeps=3):
-    """cs_register_decide_static_dev: d_slot2map = list of nCams device pointers (or the prebuilt c_void_p array)"""
+                               d_regged, d_scratch, d_counts=0, device=0, n_sweeps=3, only_cam=-1):
+    """cs_register_decide_static_dev (only_cam >= 0: cs_register_decide_static_cam_dev, ONE camera's loop of the reference):
+    d_slot2map = list of nCams device pointers (or the prebuilt c_void_p array)"""
     vp = C.c_void_p
     arr = d_slot2map if isinstance(d_slot2map, C.Array) else (C.c_void_p * nCams)(*[int(x) for x in d_slot2map])
-    check(lib().cs_register_decide_static_dev(int(device), vp(stream_ptr), int(nCams), int(N), int(P), int(mapBase), vp(d_slot), vp(d_flags),
-                                              vp(d_mergeable), vp(d_mapFlags), vp(d_pointFeat), arr, vp(d_attached), vp(d_regged), vp(d_scratch),
-                                              int(n_sweeps), vp(d_counts)), "cs_register_decide_static_dev")
+    check(lib().cs_register_decide_static_cam_dev(int(device), vp(stream_ptr), int(nCams), int(N), int(P), int(mapBase), vp(d_slot), vp(d_flags),
+                                                  vp(d_mergeable), vp(d_mapFlags), vp(d_pointFeat), arr, vp(d_attached), vp(d_regged),
+                                                  vp(d_scratch), int(n_sweeps), vp(d_counts), int(only_cam)), "cs_register_decide_static_dev")
+    return arr
+
+
+def register_cur_static_sequential_dev(stream_ptr, history, pu_cams, reg_cams, N, W, H, search_pass, P, d_slot, d_flags, d_mergeable, d_mapFlags,
+                                       d_pointFeat, d_slot2map, d_attached, d_regged, d_scratch, d_mapPts, d_mapCov, pixelVar, d_counts=0,
+                                       after_loop=None, device=0, n_sweeps=6):
+    """CoSLAM::curStaticPointsRegInGroup (bMerge == false) AS THE REFERENCE RUNS IT (src/app/SL_CoSLAM.cpp:854-898), camera loop after
+    camera loop, on the device: for o = 0 .. nCams - 1 -- the search from the points as they stand (cs_register_search_passes_dev with
+    the ONE pass `search_pass`, whose tables are d_slot / d_flags), staticCheckMergability of its candidates (history: a TrackHistory),
+    the walks of the points that hold a feature in camera o (cs_register_decide_static_cam_dev), refineMapPoint of those that gained one
+    (:889-893).  nCams times the frame loop's launches: the parity mode.  after_loop(o): called behind every camera's
+    loop (e.g. to read d_counts -- features attached, points registered, sweeps, settled -- of that loop: the reference's return value is
+    the registrations summed over the loops)."""
+    nC = len(reg_cams)
+    arr = None
+    for o in range(nC):
+        register_search_passes_dev(stream_ptr, reg_cams, N, W, H, search_pass, device=device)
+        history.register_mergability_dev(stream_ptr, pu_cams, P, d_mapPts, d_mapCov, d_slot, pixelVar, d_mergeable)
+        arr = register_decide_static_dev(stream_ptr, nC, N, P, 0, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, arr or d_slot2map,
+                                         d_attached, d_regged, d_scratch, d_counts, device=device, n_sweeps=n_sweeps, only_cam=o)
+        history.refine_map_points_dev(stream_ptr, pu_cams, d_pointFeat, P, d_mapPts, d_mapCov, pixelVar, d_select=d_regged)
+        if after_loop is not None:
+            after_loop(o)
     return arr

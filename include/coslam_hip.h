@@ -344,6 +344,16 @@ int cs_register_decide_static_dev(int device, void* hip_stream, int nCams, int N
                                   const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
                                   int* const* d_slot2map /* host array of nCams device pointers */, unsigned char* d_attached,
                                   unsigned char* d_regged, void* d_scratch, int nSweeps, int* d_counts);
+/* ONE camera's loop of curStaticPointsRegInGroup (:864-893): only the points that hold a feature of this frame in camera onlyCam walk
+ * (map order); onlyCam < 0: the call above.  With it the reference's run is reproduced step for step: for onlyCam = 0 .. nCams - 1 --
+ * search (cs_register_search_dev on the points as they stand), cs_register_mergability_dev, this call, cs_refine_map_points_dev of
+ * d_regged -- so that a point refined in one camera's loop is projected from its new position in the next (the single call above takes
+ * every decision against ONE search).  nCams times the launches: a parity mode, tests/test_register_decide_gpu.py pins it
+ * to the reference's own run (tests/golden/decide_golden.npz) bit for bit. */
+int cs_register_decide_static_cam_dev(int device, void* hip_stream, int nCams, int N, int P, int mapBase, const int* d_slot, const int* d_flags,
+                                      const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
+                                      int* const* d_slot2map, unsigned char* d_attached, unsigned char* d_regged, void* d_scratch, int nSweeps,
+                                      int* d_counts, int onlyCam);
 
 /* Cameras sharded over GPUs: a rank searches for its own cameras (cs_register_search_passes_range_dev, cs_register_mergability_range_dev);
  * the decision needs every camera's candidates.  pack: columns cam0 .. cam0 + nOwn - 1 of the P x nCams tables into a send record of

@@ -117,7 +117,8 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
     import torch
 
     from coslam_amd.poseupdate import TrackHistory
-    from coslam_amd.register import register_cams, register_decide_scratch_bytes, register_decide_static_dev, register_passes, register_search_passes_dev
+    from coslam_amd.register import (register_cams, register_cur_static_sequential_dev, register_decide_scratch_bytes, register_decide_static_dev,
+                                     register_passes, register_search_passes_dev)
     from tests.test_oracle_cpu import _decide_scene, single_pass_registration
 
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decide_golden.npz"))
@@ -181,5 +182,22 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
         assert np.array_equal(dreg.cpu().numpy(), want["reg"]) and np.array_equal(dM.cpu().numpy(), want["M"]) and np.array_equal(dcov.cpu().numpy(), want["cov"])
         att_total += int((S["ref_s2m"] != S["s2m"]).sum())
         diff_total += int((ds2m.cpu().numpy() != S["ref_s2m"]).sum())
+        # ---- the reference's run step for step (camera loop after camera loop, refine in between): IDENTICAL to the reference
+        ds2m.copy_(d(S["s2m"])), dM.copy_(d(S["M"])), dcov.copy_(d(S["cov"])), dpf.copy_(d(S["pf"]))
+        rounds = []
+
+        def after_loop(o):
+            torch.cuda.synchronize()
+            rounds.append(dcnt.cpu().tolist())
+
+        register_cur_static_sequential_dev(s_, th, cams, rc, N, S["W"], S["H"], passes, nP, out["slot"].data_ptr(), out["flags"].data_ptr(),
+                                           dmerge.data_ptr(), dfl.data_ptr(), dpf.data_ptr(), [ds2m[c].data_ptr() for c in range(nC)], datt.data_ptr(),
+                                           dreg.data_ptr(), dscr.data_ptr(), dM.data_ptr(), dcov.data_ptr(), S["pv"], d_counts=dcnt.data_ptr(),
+                                           after_loop=after_loop)
+        torch.cuda.synchronize()
+        assert len(rounds) == nC and all(r[3] == 1 for r in rounds)          # every loop's sweeps settled
+        assert np.array_equal(ds2m.cpu().numpy(), S["ref_s2m"]), f"scene {sc}: {int((ds2m.cpu().numpy() != S['ref_s2m']).sum())} owners differ"
+        assert np.array_equal(dM.cpu().numpy(), S["ref_M"]) and np.array_equal(dcov.cpu().numpy(), S["ref_cov"])
+        assert sum(r[1] for r in rounds) == S["ref_regged"] and sum(r[0] for r in rounds) == int((S["ref_s2m"] != S["s2m"]).sum())
         th.close()
     assert 0 < diff_total <= 0.03 * att_total, (diff_total, att_total)
