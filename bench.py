@@ -667,9 +667,10 @@ def main():
         loop.sequential_registration = False
         seq_reg = {"frames_per_s": n_seq / dtq, "ms_per_step": dtq / n_seq * 1e3, "steps": n_seq, "ratio_to_value": (n_seq / dtq) / (args.steps / dt),
                    "loops_whose_sweeps_did_not_settle": bool(loop._dec["scr"][-4:].view(torch.int32).item()),
-                   "what": "the same loop with CoSLAM::curStaticPointsRegInGroup reproduced step for step (cs_register_decide_static_cam_dev per "
-                           "camera loop, a search, a mergability pass and a refine per loop: 8 x the launches) instead of the headline's single "
-                           "pass -- the parity mode; the single pass differs from it in ~2 % of a frame's attachments (DESIGN.md 8.2)"}
+                   "what": "the same loop with CoSLAM::currentMapPointsRegister reproduced step for step (8 camera loops of the static points, "
+                           "then 8 of the dynamic ones; per loop a search, a mergability pass, the walks of that camera's points and a refine: "
+                           "16 x the launches) instead of the headline's single pass -- the parity mode; the single pass differs from it in "
+                           "~2 % of a frame's attachments (DESIGN.md 8.2)"}
     gc.enable()
     replicas = None
     if world > 1:
@@ -1007,9 +1008,10 @@ def main():
                            ("features_attached_last_frame", "points_regged_last_frame", "sweeps_last_frame", "converged"), dec_counts[0]),
                            points_refined_last_frame=dec_counts[1],
                            frames_whose_sweeps_did_not_settle=dec_counts[2],
-                           what="curStaticPointsRegInGroup's decision (bMerge false) over the search + mergability tables of all cameras "
-                                "(cs_register_decide_static_dev: the sequential first-claimant rule resolved exactly), then refineMapPoint of "
-                                "the points that gained a feature (cs_refine_map_points_dev)"),
+                           what="currentMapPointsRegister's decisions (bMerge false) -- curStaticPointsRegInGroup and, behind it, "
+                                "curDynamicPointsRegInGroup on the certainly dynamic points -- over the search + mergability tables of all cameras "
+                                "(cs_register_decide_kinds_dev, kinds 3: the sequential first-claimant rule resolved exactly), then refineMapPoint "
+                                "of the points that gained a feature (cs_refine_map_points_dev)"),
                        "pose_update": None if loop.pose_upd is None else {
                            "what": "poseUpdate3D's gate + seqTriangulate over all static mapped features and detectDynamicFeaturePoints over "
                                    "all unmapped / dynamic tracks, every frame, one launch for ALL cameras (cs_pose_update_frame_dev)",

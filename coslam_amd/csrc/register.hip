@@ -139,7 +139,9 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
                     for (int j = 0; j < 3; ++j) q.KR[3 * i + j] = (K[3 * i] * R[j] + K[3 * i + 1] * R[3 + j]) + K[3 * i + 2] * R[6 + j];
                 projection_cov(q, Q.cov + 9 * (size_t)p, Q.sigmaSearch, var);  // :750-753
                 mat22_inv(var, ivar);                                          // SL_SingleSLAM.cpp:1148-1149
-                const double sc = 1 / Q.maxDist;
+                // (the certainly dynamic points of a pass that serves both registrations: their own scale, SL_CoSLAM.cpp:973)
+                const bool dynPt = Q.mapFlags && (Q.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) == CS_MAP_DYNAMIC;
+                const double sc = 1 / (dynPt ? Q.maxDistDynamic : Q.maxDist);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) ivar[k] = ivar[k] * sc;
                 search = true;
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
                 outSlot = iMin;
                 outDist = dMin;
                 if (C.slot2map[iMin] < 0) outFlags |= 1;               // :759 pFeat->mpt == 0
-                if (C.isDynamic && C.isDynamic[iMin]) outFlags |= 2;  // :758 pFeat->type
+                if (C.isDynamic ? C.isDynamic[iMin] != 0 : (C.isStatic && C.isStatic[iMin] == 0)) outFlags |= 2;  // :758 pFeat->type
                 double v2[4], iv[4];                                   // staticCheckMergability, the candidate itself (:716-725)
                 projection_cov(q, Q.cov + 9 * (size_t)p, Q.sigmaMerge, v2);
                 mat22_inv(v2, iv);
@@ -267,6 +269,10 @@ extern "C" int cs_register_search_passes_range_dev(int device, void* hip_stream,
             cs_set_error("cs_register_search_passes_dev: null pointer in pass %d", k);
             return CS_ERR_INVALID;
         }
+        if (q.mapFlags && !(q.maxDistDynamic > 0)) {
+            cs_set_error("cs_register_search_passes_dev: pass %d has mapFlags but maxDistDynamic <= 0", k);
+            return CS_ERR_INVALID;
+        }
         A.pass[k] = q;
         if (q.P > maxP) maxP = q.P;
     }
@@ -323,7 +329,7 @@ namespace {
 // A point's later visits (it appears once per camera in which it has a feature) find what its first visit left and change nothing.
 constexpr int RD_MAX_CAMS = 16;
 struct RdArgs {
-    int nCams, N, P, mapBase, nSweeps, onlyCam;
+    int nCams, N, P, mapBase, nSweeps, onlyCam, kinds;
     const int* slot;                 // [P][nCams] the search's candidates
     const int* flags;                // [P][nCams] bit 1: the candidate is dynamic
     const unsigned char* mergeable;  // [P][nCams] 1: mergeable over the whole track
@@ -352,9 +358,12 @@ __global__ __launch_bounds__(256) void k_decide_prepare(RdArgs A) {
     A.attached[k] = 0;
     if (i == 0) A.regged[p] = 0;
     int code = -1;
-    if (A.pointFeat[k] < 0) {   // (else :736-737: the point has a feature of this frame there)
+    // the point's kind: 0 certainly static, 1 certainly dynamic (its walk takes DYNAMIC features only, :981), -1 not visited
+    const unsigned char fl = A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN);
+    const int kind = (fl == 0 && (A.kinds & 1)) ? 0 : ((fl == CS_MAP_DYNAMIC && (A.kinds & 2)) ? 1 : -1);
+    if (A.pointFeat[k] < 0 && kind >= 0) {   // (else :736-737: the point has a feature of this frame there)
         const int s = A.slot[k];
-        if (s >= 0 && s < A.N && !(A.flags[k] & 2)) {   // (else: nothing found / a DYNAMIC feature, :757)
+        if (s >= 0 && s < A.N && ((A.flags[k] >> 1) & 1) == kind) {   // (else: nothing found / a feature of the other type, :757 / :981)
             code = i * A.N + s;
             if (A.slot2map[i][s] >= 0) code |= RD_INIT_MAPPED;
             if (A.mergeable[k] == 1) code |= RD_CAN_MERGE;
@@ -367,8 +376,7 @@ __global__ __launch_bounds__(256) void k_decide_prepare(RdArgs A) {
             if (A.pointFeat[(size_t)p * C + q] >= 0) ofirst = q;
         // onlyCam >= 0: ONE camera's loop of the reference (:864-869): the points with a feature of this frame in that camera, map order
         if (A.onlyCam >= 0) ofirst = A.pointFeat[(size_t)p * C + A.onlyCam] >= 0 ? 0 : -1;
-        const bool certainStatic = (A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) == 0;
-        A.base[p] = (ofirst >= 0 && certainStatic) ? (ofirst * A.P + p) * C : -1;
+        A.base[p] = (ofirst >= 0 && kind >= 0) ? (ofirst * A.P + p) * C : -1;
     }
 }
 // one Jacobi sweep, thread per point: its walk against the owners of the previous sweep (prev), claims into next; `clear` is the
@@ -440,8 +448,16 @@ extern "C" int cs_register_decide_static_cam_dev(int device, void* hip_stream, i
                                                  const int* d_flags, const unsigned char* d_mergeable, const unsigned char* d_mapFlags,
                                                  int* d_pointFeat, int* const* d_slot2map, unsigned char* d_attached, unsigned char* d_regged,
                                                  void* d_scratch, int nSweeps, int* d_counts, int onlyCam) {
-    if (onlyCam >= nCams) {
-        cs_set_error("cs_register_decide_static_cam_dev: camera %d of %d", onlyCam, nCams);
+    return cs_register_decide_kinds_dev(device, hip_stream, nCams, N, P, mapBase, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, d_slot2map,
+                                        d_attached, d_regged, d_scratch, nSweeps, d_counts, onlyCam, 1);
+}
+
+extern "C" int cs_register_decide_kinds_dev(int device, void* hip_stream, int nCams, int N, int P, int mapBase, const int* d_slot, const int* d_flags,
+                                            const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
+                                            int* const* d_slot2map, unsigned char* d_attached, unsigned char* d_regged, void* d_scratch,
+                                            int nSweeps, int* d_counts, int onlyCam, int kinds) {
+    if (onlyCam >= nCams || kinds < 1 || kinds > 3) {
+        cs_set_error("cs_register_decide_kinds_dev: camera %d of %d, kinds %d (1: static, 2: dynamic, 3: both)", onlyCam, nCams, kinds);
         return CS_ERR_INVALID;
     }
     if (nCams < 1 || nCams > RD_MAX_CAMS || N < 1 || P < 0 || (long long)nCams * N > RD_FEAT || (long long)nCams * P * nCams > 0x7fffffffLL ||
@@ -452,7 +468,7 @@ extern "C" int cs_register_decide_static_cam_dev(int device, void* hip_stream, i
     }
     RdArgs A;
     memset(&A, 0, sizeof(A));
-    A.nCams = nCams, A.N = N, A.P = P, A.mapBase = mapBase, A.nSweeps = nSweeps, A.onlyCam = onlyCam < 0 ? -1 : onlyCam;
+    A.nCams = nCams, A.N = N, A.P = P, A.mapBase = mapBase, A.nSweeps = nSweeps, A.onlyCam = onlyCam < 0 ? -1 : onlyCam, A.kinds = kinds;
     A.slot = d_slot, A.flags = d_flags, A.mergeable = d_mergeable, A.mapFlags = d_mapFlags, A.pointFeat = d_pointFeat;
     for (int c = 0; c < nCams; ++c) {
         if (!d_slot2map[c]) {
@@ -586,8 +602,12 @@ extern "C" int cs_register_search(int device, int nCams, const cs_register_cam* 
         memcpy(h + o2, q.slot2map, (size_t)N * 4);
         dc[c].slot2map = (const int*)(d + o2);
         o2 += (size_t)N * 4;
+        dc[c].isStatic = nullptr;
         if (q.isDynamic) {
             memcpy(h + o2, q.isDynamic, (size_t)N);
+            dc[c].isDynamic = (const unsigned char*)(d + o2);
+        } else if (q.isStatic) {   // (staged as its complement)
+            for (int i = 0; i < N; ++i) h[o2 + i] = q.isStatic[i] ? 0 : 1;
             dc[c].isDynamic = (const unsigned char*)(d + o2);
         } else {
             dc[c].isDynamic = nullptr;

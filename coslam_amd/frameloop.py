@@ -203,13 +203,17 @@ class FrameLoop:
                                                  isStatic=self.d_isstatic[g].data_ptr()) for g in range(NA)])
         self.reg_args = [register_cams([dict(K=self.d_K1.data_ptr(), R=self.d_R[b].data_ptr() + 72 * g, t=self.d_t[b].data_ptr() + 24 * g,
                                              xy=self.d_xy[g].data_ptr(), state=self.d_state[g].data_ptr(),
-                                             slot2map=self.d_slot2map[g].data_ptr()) for g in range(NA)]) for b in range(2)]
+                                             slot2map=self.d_slot2map[g].data_ptr(), isStatic=self.d_isstatic[g].data_ptr())
+                                        for g in range(NA)]) for b in range(2)]
         # CoSLAMThread.cpp:108 activeMapPointsRegister, then :117 currentMapPointsRegister (static points), search step
         self.reg_passes = register_passes([dict(P=cfg.p_reg, sigmaSearch=sS, maxDist=3 * PIXEL_ERR_VAR, sigmaMerge=PIXEL_ERR_VAR,
                                                 M=self.d_map.data_ptr() + 24 * off, cov=self.d_cov.data_ptr() + 72 * off, pointFeat=pf.data_ptr(),
                                                 slot=self.reg_out[k]["slot"].data_ptr(), m=self.reg_out[k]["m"].data_ptr(),
                                                 var=self.reg_out[k]["var"].data_ptr(), dist=self.reg_out[k]["dist"].data_ptr(),
-                                                flags=self.reg_out[k]["flags"].data_ptr())
+                                                flags=self.reg_out[k]["flags"].data_ptr(),
+                                                # the current points' pass serves the static AND the dynamic registration: the certainly
+                                                # dynamic points are searched with their own scale (SL_CoSLAM.cpp:973)
+                                                **(dict(mapFlags=self.d_mapflags.data_ptr(), maxDistDynamic=4 * PIXEL_ERR_VAR) if k == 1 else {}))
                                            for k, (off, pf, sS) in enumerate(((cfg.p_reg, self.d_pf_none, 2.5 * PIXEL_ERR_VAR),
                                                                               (0, self.d_pf, PIXEL_ERR_VAR)))])
         # ---- key-frame solves
@@ -527,7 +531,8 @@ class FrameLoop:
                 self._key_frame(i, dst)
 
     def _decide(self, ps):
-        """curStaticPointsRegInGroup's decision (reference src/app/SL_CoSLAM.cpp:854-898, 731-830, bMerge == false) over the search
+        """currentMapPointsRegister's decisions -- curStaticPointsRegInGroup (reference src/app/SL_CoSLAM.cpp:854-898, 731-830, bMerge ==
+        false) and behind it curDynamicPointsRegInGroup (:904-1020) on the certainly dynamic points, one call -- over the search
         tables of ALL cameras, then refineMapPoint of the points that gained a feature (:889-893, :666-713).  N > 1: the own cameras'
         columns of the tables travel first (one small all-gather), every rank then takes the same decisions on its replica."""
         from coslam_amd.register import register_decide_scratch_bytes, register_decide_static_dev
@@ -554,14 +559,16 @@ class FrameLoop:
                                                           self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(),
                                                           D["s2m"] if D["s2m"] is not None else [self.d_slot2map[g].data_ptr() for g in range(NA)],
                                                           D["att"].data_ptr(), D["reg"].data_ptr(), D["scr"].data_ptr(), self.d_map.data_ptr(),
-                                                          self.d_cov.data_ptr(), PIXEL_ERR_VAR, d_counts=D["cnt"].data_ptr(), device=self.device)
+                                                          self.d_cov.data_ptr(), PIXEL_ERR_VAR, d_counts=D["cnt"].data_ptr(), device=self.device,
+                                                          with_dynamic=True)
             return
         if self.world > 1:
             self._gather_candidates()
         D["s2m"] = register_decide_static_dev(ps, NA, cfg.n_feat, cfg.p_reg, 0, self.reg_out[1]["slot"].data_ptr(), self.reg_out[1]["flags"].data_ptr(),
                                               self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(),
                                               D["s2m"] if D["s2m"] is not None else [self.d_slot2map[g].data_ptr() for g in range(NA)],
-                                              D["att"].data_ptr(), D["reg"].data_ptr(), D["scr"].data_ptr(), D["cnt"].data_ptr(), device=self.device)
+                                              D["att"].data_ptr(), D["reg"].data_ptr(), D["scr"].data_ptr(), D["cnt"].data_ptr(), device=self.device,
+                                              kinds=3)   # curStaticPointsRegInGroup and curDynamicPointsRegInGroup (currentMapPointsRegister, :834-853)
         # (d_regged covers the pass's P points = the first P map points; the rest of the select mask stays 0)
         self.pose_upd.refine_map_points_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
                                             PIXEL_ERR_VAR, d_select=D["reg"].data_ptr(), d_count=D["ref_cnt"].data_ptr())

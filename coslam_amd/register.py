@@ -16,7 +16,7 @@ FLAG_UNMAPPED, FLAG_DYNAMIC, FLAG_MERGEABLE = 1, 2, 4
 class RegisterCam(C.Structure):
     """== cs_register_cam (include/coslam_hip.h)."""
 
-    _fields_ = [(n, C.c_void_p) for n in ("K", "R", "t", "xy", "state", "slot2map", "isDynamic")]
+    _fields_ = [(n, C.c_void_p) for n in ("K", "R", "t", "xy", "state", "slot2map", "isDynamic", "isStatic")]
 
 
 def register_cams(cams):
@@ -45,7 +45,7 @@ class RegisterPass(C.Structure):
     """== cs_register_pass (include/coslam_hip.h)."""
 
     _fields_ = [("P", C.c_int), ("sigmaSearch", C.c_double), ("maxDist", C.c_double), ("sigmaMerge", C.c_double)] + \
-               [(n, C.c_void_p) for n in ("M", "cov", "pointFeat", "slot", "m", "var", "dist", "flags")]
+               [(n, C.c_void_p) for n in ("M", "cov", "pointFeat", "slot", "m", "var", "dist", "flags", "mapFlags")] + [("maxDistDynamic", C.c_double)]
 
 
 def register_passes(passes):
@@ -57,6 +57,8 @@ def register_passes(passes):
         a.P, a.sigmaSearch, a.maxDist, a.sigmaMerge = int(q["P"]), float(q["sigmaSearch"]), float(q["maxDist"]), float(q["sigmaMerge"])
         for n in ("M", "cov", "pointFeat", "slot", "m", "var", "dist", "flags"):
             setattr(a, n, int(q[n]))
+        if q.get("mapFlags"):   # optional: the certainly dynamic points of the pass are searched with their own scale
+            a.mapFlags, a.maxDistDynamic = int(q["mapFlags"]), float(q["maxDistDynamic"])
     return arr
 
 
@@ -114,20 +116,20 @@ def register_decide_scratch_bytes(nCams, N, P):
 
 
 def register_decide_static_dev(stream_ptr, nCams, N, P, mapBase, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, d_slot2map, d_attached,
-                               d_regged, d_scratch, d_counts=0, device=0, n_sweeps=3, only_cam=-1):
-    """cs_register_decide_static_dev (only_cam >= 0: cs_register_decide_static_cam_dev, ONE camera's loop of the reference):
-    d_slot2map = list of nCams device pointers (or the prebuilt c_void_p array)"""
+                               d_regged, d_scratch, d_counts=0, device=0, n_sweeps=3, only_cam=-1, kinds=1):
+    """cs_register_decide_kinds_dev (only_cam >= 0: ONE camera's loop of the reference; kinds 1: the certainly static points, 2: the
+    certainly dynamic ones, 3: both): d_slot2map = list of nCams device pointers (or the prebuilt c_void_p array)"""
     vp = C.c_void_p
     arr = d_slot2map if isinstance(d_slot2map, C.Array) else (C.c_void_p * nCams)(*[int(x) for x in d_slot2map])
-    check(lib().cs_register_decide_static_cam_dev(int(device), vp(stream_ptr), int(nCams), int(N), int(P), int(mapBase), vp(d_slot), vp(d_flags),
-                                                  vp(d_mergeable), vp(d_mapFlags), vp(d_pointFeat), arr, vp(d_attached), vp(d_regged),
-                                                  vp(d_scratch), int(n_sweeps), vp(d_counts), int(only_cam)), "cs_register_decide_static_dev")
+    check(lib().cs_register_decide_kinds_dev(int(device), vp(stream_ptr), int(nCams), int(N), int(P), int(mapBase), vp(d_slot), vp(d_flags),
+                                             vp(d_mergeable), vp(d_mapFlags), vp(d_pointFeat), arr, vp(d_attached), vp(d_regged),
+                                             vp(d_scratch), int(n_sweeps), vp(d_counts), int(only_cam), int(kinds)), "cs_register_decide_kinds_dev")
     return arr
 
 
 def register_cur_static_sequential_dev(stream_ptr, history, pu_cams, reg_cams, N, W, H, search_pass, P, d_slot, d_flags, d_mergeable, d_mapFlags,
                                        d_pointFeat, d_slot2map, d_attached, d_regged, d_scratch, d_mapPts, d_mapCov, pixelVar, d_counts=0,
-                                       after_loop=None, device=0, n_sweeps=6):
+                                       after_loop=None, device=0, n_sweeps=6, with_dynamic=False):
     """CoSLAM::curStaticPointsRegInGroup (bMerge == false) AS THE REFERENCE RUNS IT (src/app/SL_CoSLAM.cpp:854-898), camera loop after
     camera loop, on the device: for o = 0 .. nCams - 1 -- the search from the points as they stand (cs_register_search_passes_dev with
     the ONE pass `search_pass`, whose tables are d_slot / d_flags), staticCheckMergability of its candidates (history: a TrackHistory),
@@ -137,12 +139,14 @@ def register_cur_static_sequential_dev(stream_ptr, history, pu_cams, reg_cams, N
     the registrations summed over the loops)."""
     nC = len(reg_cams)
     arr = None
-    for o in range(nC):
+    # with_dynamic: curDynamicPointsRegInGroup's loops behind the static ones (currentMapPointsRegister, :834-853); search_pass must then
+    # carry mapFlags / maxDistDynamic (the dynamic points' own scale).  after_loop(o) is called with o = nCams .. 2 nCams - 1 for them.
+    for kind, o in [(1, o_) for o_ in range(nC)] + ([(2, o_) for o_ in range(nC)] if with_dynamic else []):
         register_search_passes_dev(stream_ptr, reg_cams, N, W, H, search_pass, device=device)
         history.register_mergability_dev(stream_ptr, pu_cams, P, d_mapPts, d_mapCov, d_slot, pixelVar, d_mergeable)
         arr = register_decide_static_dev(stream_ptr, nC, N, P, 0, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, arr or d_slot2map,
-                                         d_attached, d_regged, d_scratch, d_counts, device=device, n_sweeps=n_sweeps, only_cam=o)
+                                         d_attached, d_regged, d_scratch, d_counts, device=device, n_sweeps=n_sweeps, only_cam=o, kinds=kind)
         history.refine_map_points_dev(stream_ptr, pu_cams, d_pointFeat, P, d_mapPts, d_mapCov, pixelVar, d_select=d_regged)
         if after_loop is not None:
-            after_loop(o)
+            after_loop(o + (nC if kind == 2 else 0))
     return arr

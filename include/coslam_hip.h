@@ -286,12 +286,15 @@ typedef struct cs_register_cam {
     const int* state;               /* N: 0 tracked, 1 new; anything else = not in this frame's list */
     const int* slot2map;            /* N: FeaturePoint::mpt as an index, < 0 = none */
     const unsigned char* isDynamic; /* N or NULL: FeaturePoint::type == TYPE_FEATPOINT_DYNAMIC */
+    const unsigned char* isStatic;  /* N or NULL, read when isDynamic is NULL: the complement, as the pose update keeps it
+                                       (cs_poseupdate_cam::isStatic: 0 = TYPE_FEATPOINT_DYNAMIC) */
 } cs_register_cam;
 /* Outputs are P x nCams tables (point-major).  slot: >= 0 the nearest feature's slot; -1 pointFeat says the point already
  * has a feature of this frame in the camera; -2 behind the camera; -3 projects outside [0,W) x [0,H); -4 the camera has
  * no feature this frame.  m (x2): the projection; var (x4): its covariance; dist: the winner's Mahalanobis distance
  * scaled by 1 / maxDist (the reference applies NO threshold to it); flags: bit 0 the candidate has no map point, bit 1
- * it is dynamic, bit 2 it passes the candidate's own mergability term (distance under var(sigmaMerge) <= 1).
+ * it is dynamic (a property of the FEATURE, cs_register_cam::isDynamic: the same for every point that finds it -- the registration
+ * decision relies on that), bit 2 it passes the candidate's own mergability term (distance under var(sigmaMerge) <= 1).
  * pointFeat (P x nCams): slot of p->pFeatures[iCam] when that feature belongs to the current frame, else -1.
  * cams: HOST array of nCams (<= 16) records; in the _dev form their members and every d_* argument are DEVICE pointers,
  * in the host form everything is host memory (one upload, one launch, one read-back). */
@@ -308,6 +311,11 @@ typedef struct cs_register_pass {
     double* var;
     double* dist;
     int* flags;
+    /* optional (NULL / 0: every point uses maxDist): the pass's points' CS_MAP_* bytes [P] and the scale of the certainly DYNAMIC ones --
+     * curDynamicPointRegInGroup searches with pixelErrVar * 4 where the static loop uses * 3 (src/app/SL_CoSLAM.cpp:973, :754), so ONE pass
+     * over the current points serves both registrations */
+    const unsigned char* mapFlags;
+    double maxDistDynamic;
 } cs_register_pass;
 int cs_register_search_passes_dev(int device, void* hip_stream, int nCams, const cs_register_cam* cams, int N, int W, int H,
                                   int nPass /* 1 or 2 */, const cs_register_pass* passes /* host array */);
@@ -354,6 +362,15 @@ int cs_register_decide_static_cam_dev(int device, void* hip_stream, int nCams, i
                                       const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
                                       int* const* d_slot2map, unsigned char* d_attached, unsigned char* d_regged, void* d_scratch, int nSweeps,
                                       int* d_counts, int onlyCam);
+/* The same with the point kinds spelled out -- kinds bit 0: the certainly static points (curStaticPointsRegInGroup: what the two calls above
+ * do), bit 1: the certainly DYNAMIC points (curDynamicPointsRegInGroup, :904-1020: the same walk over DYNAMIC features only -- a static
+ * candidate is passed by, a dynamic one that carries a point ends the walk -- which CoSLAM::currentMapPointsRegister runs behind the static
+ * loops, :834-853).  The two kinds never meet at a feature, so kinds = 3 registers both in ONE call with the result of one after the other
+ * (the search pass must then have searched the dynamic points with their own scale: cs_register_pass::mapFlags / maxDistDynamic). */
+int cs_register_decide_kinds_dev(int device, void* hip_stream, int nCams, int N, int P, int mapBase, const int* d_slot, const int* d_flags,
+                                 const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat, int* const* d_slot2map,
+                                 unsigned char* d_attached, unsigned char* d_regged, void* d_scratch, int nSweeps, int* d_counts, int onlyCam,
+                                 int kinds);
 
 /* Cameras sharded over GPUs: a rank searches for its own cameras (cs_register_search_passes_range_dev, cs_register_mergability_range_dev);
  * the decision needs every camera's candidates.  pack: columns cam0 .. cam0 + nOwn - 1 of the P x nCams tables into a send record of

@@ -837,7 +837,7 @@ def intercam_add_map_points(W, H, nColBlk, nRowBlk, ptsStride, xy, state, slot2m
                 obs_xy=np.array(oxy, dtype=np.float64).reshape(-1, 2), point_map=np.array(pmap, dtype=np.int32), n_static=n_static)
 
 
-def register_decide_static(slot, flags, mergeable, mapFlags, pointFeat, slot2map, map_base=0):
+def register_decide_static(slot, flags, mergeable, mapFlags, pointFeat, slot2map, map_base=0, kinds=1):
     """The decision half of CoSLAM::curStaticPointsRegInGroup / curStaticPointRegInGroup with bMerge == false (reference
     src/app/SL_CoSLAM.cpp:854-898, 731-830) restated over the search tables (TEST INFRASTRUCTURE; index work, plain Python): for every
     camera o in order, the certainly static points with a feature of this frame in o, in map order; each walks the cameras in order --
@@ -852,8 +852,11 @@ def register_decide_static(slot, flags, mergeable, mapFlags, pointFeat, slot2map
     P, C = slot.shape
     attached = np.zeros((P, C), dtype=np.uint8)
     regged = np.zeros(P, dtype=np.uint8)
-    for o in range(C):
-        vec = [p for p in range(P) if (int(mapFlags[p]) & 7) == 0 and pointFeat[p, o] >= 0]   # :864-869
+    # kinds bit 0: the certainly static points (curStaticPointsRegInGroup); bit 1: behind them the certainly DYNAMIC ones
+    # (curDynamicPointsRegInGroup, :904-1020: the same walk over DYNAMIC features only -- a static feature is passed by, a dynamic one that
+    # carries a point ends the walk; currentMapPointsRegister's order, :834-853).  The two kinds never meet at a feature.
+    for want_dyn, o in [(k, o_) for k in (0, 1) if kinds & (1 << k) for o_ in range(C)]:
+        vec = [p for p in range(P) if (int(mapFlags[p]) & 7) == want_dyn and pointFeat[p, o] >= 0]   # :864-869 / :917-922
         for p in vec:
             breg = False
             for i in range(C):
@@ -862,7 +865,7 @@ def register_decide_static(slot, flags, mergeable, mapFlags, pointFeat, slot2map
                 s = int(slot[p, i])
                 if s < 0:                                # behind the camera / outside the image / no feature
                     continue
-                if int(flags[p, i]) & 2:                 # `pFeat->type != TYPE_FEATPOINT_DYNAMIC`
+                if ((int(flags[p, i]) >> 1) & 1) != want_dyn:   # `pFeat->type != TYPE_FEATPOINT_DYNAMIC` (:757) / `== ...DYNAMIC` (:981)
                     continue
                 if slot2map[i][s] < 0:                   # `pFeat->mpt == 0`, as it is NOW
                     if mergeable[p, i] == 1:
@@ -878,7 +881,7 @@ def register_decide_static(slot, flags, mergeable, mapFlags, pointFeat, slot2map
 
 
 def register_cur_static_sequential(W, H, Ks, iKs, histR, histT, histXY, trackSpan, state, isStatic, slot2map, mapPts, mapCov, mapFlags,
-                                   pointFeat, pixelVar):
+                                   pointFeat, pixelVar, with_dynamic=False):
     """CoSLAM::curStaticPointsRegInGroup (bMerge == false) AS THE REFERENCE RUNS IT (src/app/SL_CoSLAM.cpp:854-898, 731-830), one point after
     the other (TEST INFRASTRUCTURE, plain Python over the pinned restatements of the search, staticCheckMergability and refineMapPoint):
     for every camera o in turn, the certainly static points that hold a feature of this frame in o -- INCLUDING features attached in an
@@ -894,16 +897,19 @@ def register_cur_static_sequential(W, H, Ks, iKs, histR, histT, histXY, trackSpa
     xy0 = [np.ascontiguousarray(histXY[c][0]) for c in range(nC)]
     is_dyn = [(1 - np.asarray(isStatic[c])).astype(np.uint8) for c in range(nC)]
     n_att, n_reg_total = 0, 0
-    for o in range(nC):
-        vec = [p for p in range(nP) if (int(mapFlags[p]) & 7) == 0 and pointFeat[p, o] >= 0]      # :864-869
+    # with_dynamic: curDynamicPointsRegInGroup behind the static points' loops (currentMapPointsRegister, :834-853): the certainly dynamic
+    # points, maxDist 4 sigma (:973), DYNAMIC candidates only; returns the registrations of both (static, dynamic) then
+    n_reg_kind = [0, 0]
+    for want_dyn, o in [(0, o_) for o_ in range(nC)] + ([(1, o_) for o_ in range(nC)] if with_dynamic else []):
+        vec = [p for p in range(nP) if (int(mapFlags[p]) & 7) == want_dyn and pointFeat[p, o] >= 0]      # :864-869 / :917-922
         regged = []
         for p in vec:
             res = register_search(W, H, Ks, histR[:, 0], histT[:, 0], xy0, state, slot2map, is_dyn, mapPts[p:p + 1], mapCov[p:p + 1],
-                                  pointFeat[p:p + 1], pixelVar, 3 * pixelVar, pixelVar)
+                                  pointFeat[p:p + 1], pixelVar, (4 if want_dyn else 3) * pixelVar, pixelVar)
             breg = False
             for i in range(nC):
                 s = int(res["slot"][0, i])
-                if pointFeat[p, i] >= 0 or s < 0 or (int(res["flags"][0, i]) & 2):
+                if pointFeat[p, i] >= 0 or s < 0 or ((int(res["flags"][0, i]) >> 1) & 1) != want_dyn:
                     continue
                 if slot2map[i][s] >= 0:                                                               # :789-790
                     break
@@ -920,7 +926,8 @@ def register_cur_static_sequential(W, H, Ks, iKs, histR, histT, histXY, trackSpa
             sel[p] = 1
             refine_map_points(Ks, iKs, histR, histT, histXY, trackSpan, pointFeat, mapPts, mapCov, pixelVar, select=sel)
         n_reg_total += len(regged)
-    return n_att, n_reg_total
+        n_reg_kind[want_dyn] += len(regged)
+    return (n_att, n_reg_total) if not with_dynamic else (n_att, n_reg_kind[0], n_reg_kind[1])
 
 
 def new_map_points_from_pairs(N, pairs, Ks, iKs, Rs, ts, xy, state, slot2map, isStatic, mapPts, mapCov, mapFlags, newPt, firstFrame, pointFeat,

@@ -13,9 +13,9 @@
 // further back (-> not mergeable); a DYNAMIC one (-> passed by); one that already carries ANOTHER point (-> the walk ends there);
 // nothing.  Twin points a few millimetres apart compete for the same features; distractor features fill the frames.
 //   ref_decide_test golden <out.bin>
-// out.bin (int32 / float64): nScenes; per scene: nCams Hh N nPts curFrame W H; pixelVar; per camera K[9], then per history entry
+// out.bin (int32 / float64): nScenes; per scene: nCams Hh N nPts curFrame W H withDynamic; pixelVar; per camera K[9], then per history entry
 // (newest first) R[9] t[3]; per camera and slot: L (0: empty) isStatic slot2map, L x m[2] (newest first); per point M[3] cov[9] flags
-// (1 dynamic, 2 false, 4 uncertain) pointFeat[nCams]; then the reference's result: nRegged; per camera slot2map[N]; per point
+// (1 dynamic, 2 false, 4 uncertain) pointFeat[nCams]; then the reference's result: nRegged nReggedDynamic; per camera slot2map[N]; per point
 // M[3] cov[9].   TEST INFRASTRUCTURE; built into oracle/_ref/ where the reference tree exists.
 #include <cmath>
 #include <cstdio>
@@ -75,11 +75,13 @@ int main(int argc, char** argv) {
     }
     FILE* f = fopen(argv[2], "wb");
     if (!f) return 1;
-    const int nScenes = 3;
+    const int nScenes = 5;   // 0-2: the static points' registration alone; 3, 4: more certainly dynamic points with DYNAMIC candidates, and
+                             // curDynamicPointsRegInGroup behind it (CoSLAM::currentMapPointsRegister's order, :834-853)
     puti(f, nScenes);
     int tot[6] = {0, 0, 0, 0, 0, 0};   // attached, not mergeable, dynamic passed by, walks ended by a mapped feature, twins, regged
     for (int sc = 0; sc < nScenes; ++sc) {
-        const int nCams = 3 + sc, Hh = 20, nBase = 110 + 20 * sc, curFrame = 200 + 11 * sc, W = 640, H = 480;
+        const bool dyn = sc >= 3;
+        const int nCams = dyn ? sc : 3 + sc, Hh = 20, nBase = 110 + 20 * sc, curFrame = 200 + 11 * sc, W = 640, H = 480;
         const double pixelVar = 10.0;   // Const::PIXEL_ERR_VAR as CoSLAMThread.cpp:117 passes it
         CoSLAM* co = new CoSLAM();
         co->numCams = nCams;
@@ -164,13 +166,15 @@ int main(int argc, char** argv) {
         };
         for (int b = 0; b < nBase; ++b) {
             const double X[3] = {-2.2 + 4.4 * urand(), -1.4 + 2.8 * urand(), 7 + 5 * urand()};
-            const int kind = b % 10;
+            int kind = b % 10;
+            if (dyn && (kind == 3 || kind == 5)) kind = 8;   // (three in ten certainly dynamic)
+            const bool dk = dyn && kind == 8;               // a dynamic point of a scene that registers them: its features are DYNAMIC ones
             const int p = new_point(X, kind);
-            const bool twin = kind < 7 && urand() < 0.12;
+            const bool twin = (kind < 7 || dk) && urand() < 0.12;
             int p2 = -1;
             if (twin) {
                 const double X2[3] = {X[0] + 0.004, X[1] - 0.003, X[2] + 0.005};
-                p2 = new_point(X2, 0);
+                p2 = new_point(X2, dk ? 8 : 0);
                 ++tot[4];
             }
             int nHas = 0;
@@ -181,23 +185,25 @@ int main(int argc, char** argv) {
                 if (c == nCams - 1 && nHas == 0) r = 0;   // every point is in the current list through at least one camera
                 const int L = 2 + (int)(urand() * (Hh - 2));
                 if (r < 0.42) {
-                    const int s = add_track(c, X, L, true, pts[p].mp, p, 0, 0);
+                    const int s = add_track(c, X, L, !dk, pts[p].mp, p, 0, 0);
                     pts[p].mp->pFeatures[c] = slots[c][s].tail;
                     ++nHas;
                     if (twin && urand() < 0.5) {   // the twin holds a feature of its own in this camera
-                        const int s2 = add_track(c, pts[p2].X, L, true, pts[p2].mp, p2, 0, 0);
+                        const int s2 = add_track(c, pts[p2].X, L, !dk, pts[p2].mp, p2, 0, 0);
                         pts[p2].mp->pFeatures[c] = slots[c][s2].tail;
                     }
                 } else if (r < 0.72) {
-                    add_track(c, X, urand() < 0.15 ? 1 : L, urand() < 0.9, nullptr, -1, 0, 0);   // a candidate (10 % DYNAMIC)
+                    const double ut = urand();   // (in this order: what the two draws in one argument list compiled to before)
+                    const int Lc = urand() < 0.15 ? 1 : L;
+                    add_track(c, X, Lc, dk ? ut < 0.2 : ut < 0.9, nullptr, -1, 0, 0);   // a candidate (10 % DYNAMIC; 80 % for a dynamic point)
                 } else if (r < 0.80) {
-                    add_track(c, X, L < 4 ? 4 : L, true, nullptr, -1, 22.0, 2);                    // inconsistent from two frames back on
+                    add_track(c, X, L < 4 ? 4 : L, !dk, nullptr, -1, 22.0, 2);                     // inconsistent from two frames back on
                 } else if (r < 0.89 && p > 4) {
                     // a feature at the projection that already carries ANOTHER point (one without a feature in this camera yet)
                     for (int tries = 0; tries < 12; ++tries) {
                         const int q = (int)(urand() * p);
                         if (q == p2 || pts[q].mp->pFeatures[c]) continue;
-                        const int s = add_track(c, X, L, true, pts[q].mp, q, 0, 0);
+                        const int s = add_track(c, X, L, !dk, pts[q].mp, q, 0, 0);
                         pts[q].mp->pFeatures[c] = slots[c][s].tail;
                         break;
                     }
@@ -210,7 +216,7 @@ int main(int argc, char** argv) {
                     const int c = 0;
                     double m[2];
                     if (project(c, 0, pts[p2].X, m)) {
-                        const int s2 = add_track(c, pts[p2].X, 6, true, pts[p2].mp, p2, 0, 0);
+                        const int s2 = add_track(c, pts[p2].X, 6, !dk, pts[p2].mp, p2, 0, 0);
                         pts[p2].mp->pFeatures[c] = slots[c][s2].tail;
                     }
                 }
@@ -230,7 +236,7 @@ int main(int argc, char** argv) {
             if (pts[p].mp->numVisCam > 0) co->curMapPts.add(pts[p].mp);
         }
         // ---- inputs
-        puti(f, nCams), puti(f, Hh), puti(f, N), puti(f, nPts), puti(f, curFrame), puti(f, W), puti(f, H);
+        puti(f, nCams), puti(f, Hh), puti(f, N), puti(f, nPts), puti(f, curFrame), puti(f, W), puti(f, H), puti(f, dyn ? 1 : 0);
         put(f, &pixelVar, 1);
         for (int c = 0; c < nCams; ++c) {
             put(f, K, 9);
@@ -261,8 +267,9 @@ int main(int argc, char** argv) {
         }
         // ---- the reference
         const int nRegged = co->curStaticPointsRegInGroup(group, pixelVar, false);
-        tot[5] += nRegged;
-        puti(f, nRegged);
+        const int nReggedDyn = dyn ? co->curDynamicPointsRegInGroup(group, pixelVar, false) : 0;
+        tot[5] += nRegged + nReggedDyn;
+        puti(f, nRegged), puti(f, nReggedDyn);
         for (int c = 0; c < nCams; ++c)
             for (int s = 0; s < N; ++s) {
                 int m = -1;
@@ -271,7 +278,8 @@ int main(int argc, char** argv) {
                 if (s < (int)slots[c].size() && slots[c][s].s2m < 0 && m >= 0) ++tot[0];
             }
         for (int p = 0; p < nPts; ++p) put(f, pts[p].mp->M, 3), put(f, pts[p].mp->cov, 9);
-        printf("scene %d: %d cameras, %d slots, %d points (%d on the current list): %d points registered\n", sc, nCams, N, nPts, co->curMapPts.getNum(), nRegged);
+        printf("scene %d: %d cameras, %d slots, %d points (%d on the current list): %d static + %d dynamic points registered\n", sc, nCams, N, nPts,
+               co->curMapPts.getNum(), nRegged, nReggedDyn);
         co->curMapPts.clearWithoutRelease();
     }
     fclose(f);

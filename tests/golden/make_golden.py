@@ -354,8 +354,9 @@ def newpts_case():
 
 
 def decide_case():
-    """the reference's own CoSLAM::curStaticPointsRegInGroup (oracle/_ref/ref_decide_test golden, CPU): three scenes of cameras, pose
-    histories, feature tracks and map points; which feature carries which point afterwards, every point's position / covariance."""
+    """the reference's own CoSLAM::curStaticPointsRegInGroup -- and, in the last two scenes, curDynamicPointsRegInGroup behind it, the
+    order of currentMapPointsRegister -- (oracle/_ref/ref_decide_test golden, CPU): five scenes of cameras, pose histories, feature
+    tracks and map points; which feature carries which point afterwards, every point's position / covariance."""
     import subprocess
     import tempfile
 
@@ -382,10 +383,11 @@ def decide_case():
     (ns,) = ints(1)
     out["n_scenes"] = np.int32(ns)
     for sc in range(ns):
-        nC, Hh, N, nP, cur, W, H = (int(v) for v in ints(7))
+        nC, Hh, N, nP, cur, W, H, with_dyn = (int(v) for v in ints(8))
         (pv,) = dbls(1)
         k = lambda n: f"s{sc}_{n}"   # noqa: E731
         out[k("dims")] = np.array([nC, Hh, N, nP, cur, W, H], np.int32)
+        out[k("with_dynamic")] = np.int32(with_dyn)   # curDynamicPointsRegInGroup ran behind the static points' registration
         out[k("pixelVar")] = np.float64(pv)
         K, hR, hT = np.zeros((nC, 9)), np.zeros((nC, Hh, 9)), np.zeros((nC, Hh, 3))
         for c in range(nC):
@@ -415,8 +417,8 @@ def decide_case():
             fl[p_] = f_
             pf[p_] = ints(nC)
         out[k("M")], out[k("cov")], out[k("flags")], out[k("pointFeat")] = M, cov, fl, pf
-        (nreg,) = ints(1)
-        out[k("ref_regged")] = np.int32(nreg)
+        nreg, nreg_dyn = (int(v) for v in ints(2))
+        out[k("ref_regged")], out[k("ref_regged_dynamic")] = np.int32(nreg), np.int32(nreg_dyn)
         out[k("ref_slot2map")] = ints(nC * N).reshape(nC, N)
         R = dbls(12 * nP).reshape(nP, 12)
         out[k("ref_M")], out[k("ref_cov")] = R[:, :3], R[:, 3:]

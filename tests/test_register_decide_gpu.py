@@ -9,14 +9,20 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _case(seed, P, C, N, p_conflict):
+def _case(seed, P, C, N, p_conflict, p_dyn=0.0):
     rng = np.random.default_rng(seed)
     slot = rng.integers(0, max(int(N * p_conflict), 4), (P, C)).astype(np.int32)     # few distinct features: many claimants each
     slot[rng.random((P, C)) < 0.25] = rng.choice([-2, -3, -4], size=int((rng.random((P, C)) < 0.25).sum()) or 1)[0]
     flags = rng.integers(0, 8, (P, C)).astype(np.int32)
     flags[rng.random((P, C)) < 0.8] &= ~2                                              # mostly not dynamic
     merg = np.where(rng.random((P, C)) < 0.75, 1, 0).astype(np.uint8)
-    mf = np.where(rng.random(P) < 0.1, rng.choice([1, 2, 4], P), 0).astype(np.uint8)
+    mf = np.where(rng.random(P) < 0.1, rng.choice([1, 2, 4, 5], P), 0).astype(np.uint8)
+    if p_dyn > 0:   # many certainly dynamic points, and dynamic candidates for them (DYNAMIC is a property of the FEATURE: the same for every
+        mf[rng.random(P) < p_dyn] = 1                      # point whose search found it -- which is why the two kinds never meet at one)
+        feat_dyn = rng.random((C, N)) < p_dyn
+        flags &= ~2
+        ii = np.broadcast_to(np.arange(C), (P, C))
+        flags[(slot >= 0) & feat_dyn[ii, np.clip(slot, 0, N - 1)]] |= 2
     pf = np.full((P, C), -1, np.int32)
     has = rng.random((P, C)) < 0.3
     pf[has] = rng.integers(0, N, int(has.sum()))
@@ -25,17 +31,17 @@ def _case(seed, P, C, N, p_conflict):
     return slot, flags, merg, mf, pf, s2m
 
 
-@pytest.mark.parametrize("seed,P,C,N,pc", [(1, 1536, 8, 2000, 0.2), (2, 700, 3, 500, 0.05), (3, 4096, 8, 2000, 0.5), (4, 64, 1, 100, 0.3),
-                                            (5, 2000, 16, 300, 0.02)])
-def test_decision_equals_the_sequential_walks(hip, seed, P, C, N, pc):
+@pytest.mark.parametrize("seed,P,C,N,pc,kinds", [(1, 1536, 8, 2000, 0.2, 1), (2, 700, 3, 500, 0.05, 1), (3, 4096, 8, 2000, 0.5, 1), (4, 64, 1, 100, 0.3, 1),
+                                                  (5, 2000, 16, 300, 0.02, 1), (6, 1536, 8, 2000, 0.2, 3), (7, 900, 4, 400, 0.1, 2), (8, 3000, 6, 1000, 0.4, 3)])
+def test_decision_equals_the_sequential_walks(hip, seed, P, C, N, pc, kinds):
     import torch
 
     import oracle
     from coslam_amd.register import register_decide_scratch_bytes, register_decide_static_dev
 
-    slot, flags, merg, mf, pf, s2m = _case(seed, P, C, N, pc)
+    slot, flags, merg, mf, pf, s2m = _case(seed, P, C, N, pc, p_dyn=0.4 if kinds > 1 else 0.0)
     o_pf, o_s2m = pf.copy(), [x.copy() for x in s2m]
-    att_o, reg_o = oracle.register_decide_static(slot, flags, merg, mf, o_pf, o_s2m, map_base=7)
+    att_o, reg_o = oracle.register_decide_static(slot, flags, merg, mf, o_pf, o_s2m, map_base=7, kinds=kinds)
     dev = torch.device("cuda:0")
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
     d_slot, d_flags, d_merg, d_mf, d_pf = d(slot), d(flags), d(merg), d(mf), d(pf)
@@ -45,7 +51,7 @@ def test_decision_equals_the_sequential_walks(hip, seed, P, C, N, pc):
     d_cnt = torch.zeros(4, dtype=torch.int32, device=dev)
     register_decide_static_dev(torch.cuda.current_stream().cuda_stream, C, N, P, 7, d_slot.data_ptr(), d_flags.data_ptr(), d_merg.data_ptr(),
                                d_mf.data_ptr(), d_pf.data_ptr(), [x.data_ptr() for x in d_s2m], d_att.data_ptr(), d_reg.data_ptr(),
-                               d_scr.data_ptr(), d_cnt.data_ptr(), n_sweeps=12)
+                               d_scr.data_ptr(), d_cnt.data_ptr(), n_sweeps=12, kinds=kinds)
     torch.cuda.synchronize()
     cnt = d_cnt.cpu().tolist()
     assert cnt[3] == 1 and cnt[2] == 12, cnt
@@ -54,8 +60,13 @@ def test_decision_equals_the_sequential_walks(hip, seed, P, C, N, pc):
     for c in range(C):
         assert np.array_equal(d_s2m[c].cpu().numpy(), o_s2m[c]), c
     assert cnt[0] == int(att_o.sum()) and cnt[1] == int(reg_o.sum())
-    if seed in (1, 3):
+    if seed in (1, 3, 6, 8):
         assert att_o.sum() > 100
+    if kinds > 1:   # dynamic points did register, and only to dynamic features
+        dynp = (mf & 7) == 1
+        assert att_o[dynp].sum() > 20
+        rows, cols = np.nonzero(att_o)
+        assert np.array_equal((flags[rows, cols] >> 1) & 1, dynp[rows].astype(flags.dtype))
 
 
 def _device_decide(slot, flags, merg, mf, pf, s2m, n_sweeps, map_base=0, scratch=None):
@@ -125,7 +136,7 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
     dev = torch.device("cuda:0")
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
     s_ = torch.cuda.current_stream().cuda_stream
-    att_total = diff_total = 0
+    att_total = diff_total = dyn_total = 0
     for sc in range(int(g["n_scenes"])):
         S = _decide_scene(g, sc)
         want = single_pass_registration(S)
@@ -165,7 +176,9 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
                                  slot2map=ds2m[c].data_ptr(), isDynamic=ddyn[c].data_ptr()) for c in range(nC)])
         passes = register_passes([dict(P=nP, sigmaSearch=S["pv"], maxDist=3 * S["pv"], sigmaMerge=S["pv"], M=dM.data_ptr(), cov=dcov.data_ptr(),
                                        pointFeat=dpf.data_ptr(), slot=out["slot"].data_ptr(), m=out["m"].data_ptr(), var=out["var"].data_ptr(),
-                                       dist=out["dist"].data_ptr(), flags=out["flags"].data_ptr())])
+                                       dist=out["dist"].data_ptr(), flags=out["flags"].data_ptr(),
+                                       **(dict(mapFlags=dfl.data_ptr(), maxDistDynamic=4 * S["pv"]) if S["with_dyn"] else {}))])
+        kinds = 3 if S["with_dyn"] else 1     # scenes 3, 4: the certainly dynamic points behind the static ones (curDynamicPointsRegInGroup)
         register_search_passes_dev(s_, rc, N, S["W"], S["H"], passes)
         dmerge = torch.zeros((nP, nC), dtype=torch.uint8, device=dev)
         th.register_mergability_dev(s_, cams, nP, dM.data_ptr(), dcov.data_ptr(), out["slot"].data_ptr(), S["pv"], dmerge.data_ptr())
@@ -173,7 +186,8 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
         dscr = torch.zeros(register_decide_scratch_bytes(nC, N, nP), dtype=torch.uint8, device=dev)
         dcnt = torch.zeros(4, dtype=torch.int32, device=dev)
         register_decide_static_dev(s_, nC, N, nP, 0, out["slot"].data_ptr(), out["flags"].data_ptr(), dmerge.data_ptr(), dfl.data_ptr(), dpf.data_ptr(),
-                                   [ds2m[c].data_ptr() for c in range(nC)], datt.data_ptr(), dreg.data_ptr(), dscr.data_ptr(), dcnt.data_ptr(), n_sweeps=4)
+                                   [ds2m[c].data_ptr() for c in range(nC)], datt.data_ptr(), dreg.data_ptr(), dscr.data_ptr(), dcnt.data_ptr(), n_sweeps=4,
+                                   kinds=kinds)
         th.refine_map_points_dev(s_, cams, dpf.data_ptr(), nP, dM.data_ptr(), dcov.data_ptr(), S["pv"], d_select=dreg.data_ptr())
         torch.cuda.synchronize()
         assert dcnt.cpu().tolist()[3] == 1                                   # the sweeps converged
@@ -193,11 +207,14 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
         register_cur_static_sequential_dev(s_, th, cams, rc, N, S["W"], S["H"], passes, nP, out["slot"].data_ptr(), out["flags"].data_ptr(),
                                            dmerge.data_ptr(), dfl.data_ptr(), dpf.data_ptr(), [ds2m[c].data_ptr() for c in range(nC)], datt.data_ptr(),
                                            dreg.data_ptr(), dscr.data_ptr(), dM.data_ptr(), dcov.data_ptr(), S["pv"], d_counts=dcnt.data_ptr(),
-                                           after_loop=after_loop)
+                                           after_loop=after_loop, with_dynamic=S["with_dyn"])
         torch.cuda.synchronize()
-        assert len(rounds) == nC and all(r[3] == 1 for r in rounds)          # every loop's sweeps settled
+        assert len(rounds) == nC * (2 if S["with_dyn"] else 1) and all(r[3] == 1 for r in rounds)          # every loop's sweeps settled
         assert np.array_equal(ds2m.cpu().numpy(), S["ref_s2m"]), f"scene {sc}: {int((ds2m.cpu().numpy() != S['ref_s2m']).sum())} owners differ"
         assert np.array_equal(dM.cpu().numpy(), S["ref_M"]) and np.array_equal(dcov.cpu().numpy(), S["ref_cov"])
-        assert sum(r[1] for r in rounds) == S["ref_regged"] and sum(r[0] for r in rounds) == int((S["ref_s2m"] != S["s2m"]).sum())
+        assert sum(r[1] for r in rounds[:nC]) == S["ref_regged"] and sum(r[1] for r in rounds[nC:]) == S["ref_regged_dyn"]
+        assert sum(r[0] for r in rounds) == int((S["ref_s2m"] != S["s2m"]).sum())
+        dyn_total += S["ref_regged_dyn"]
         th.close()
     assert 0 < diff_total <= 0.03 * att_total, (diff_total, att_total)
+    assert dyn_total > 30

@@ -268,6 +268,7 @@ int main(int argc, char** argv) {
             memset(&v[c], 0, sizeof(v[c]));
             v[c].K = dK, v[c].R = dR[dst] + 9 * c, v[c].t = dT[dst] + 3 * c, v[c].xy = dXY + (size_t)c * 2 * N;
             v[c].state = dState + (size_t)c * N, v[c].slot2map = dS2M + (size_t)c * N;
+            v[c].isStatic = dIsStatic + (size_t)c * N;   // (FeaturePoint::type as the pose update keeps it: a static point's walk passes DYNAMIC features by)
         }
         return v;
     };
@@ -426,14 +427,16 @@ int main(int argc, char** argv) {
             ps[0].slot = reg[0].slot, ps[0].m = reg[0].m, ps[0].var = reg[0].var, ps[0].dist = reg[0].dist, ps[0].flags = reg[0].flags;
             ps[1].P = P_REG, ps[1].sigmaSearch = PIX, ps[1].maxDist = 3 * PIX, ps[1].sigmaMerge = PIX;
             ps[1].M = dMap, ps[1].cov = dCov, ps[1].pointFeat = dPf;
+            ps[1].mapFlags = dMapFlags, ps[1].maxDistDynamic = 4 * PIX;   // (the certainly dynamic points' scale: SL_CoSLAM.cpp:973)
             ps[1].slot = reg[1].slot, ps[1].m = reg[1].m, ps[1].var = reg[1].var, ps[1].dist = reg[1].dist, ps[1].flags = reg[1].flags;
             CSCHK(cs_register_search_passes_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, 2, ps));   // both passes, one launch
         }
         // staticCheckMergability of the current-static pass's candidates over their whole tracks (SL_CoSLAM.cpp:714-729, :768)
         CSCHK(cs_register_mergability_dev(hist, (void*)poseS, pu.data(), P_REG, dMap, dCov, reg[1].slot, PIX, dMergeable));
         // the decision (curStaticPointsRegInGroup, bMerge false: who attaches which feature), then refineMapPoint of the points that gained one
-        CSCHK(cs_register_decide_static_dev(dev, (void*)poseS, nCams, N, P_REG, 0, reg[1].slot, reg[1].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
-                                            dAttached, dRegged, dDecScratch, 3, dDecCnt));
+        // currentMapPointsRegister's decisions: the certainly static points, behind them the certainly dynamic ones (kinds 3), one call
+        CSCHK(cs_register_decide_kinds_dev(dev, (void*)poseS, nCams, N, P_REG, 0, reg[1].slot, reg[1].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
+                                           dAttached, dRegged, dDecScratch, 3, dDecCnt, /*onlyCam*/ -1, /*kinds*/ 3));
         CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
         // the tracker of frame i + 2 is released at the END of the frame's pose work (released right behind the hand-back it runs two frames
         // ahead and under more of the pose stream's kernels: -10 %, profiles/r04_ab_runs.txt)
