@@ -53,6 +53,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys(hip):
     assert cfg["secondary_cfg2"]["camera_frames_per_s"] > 0 and cfg["secondary_cfg5_klt"]["frames_per_s"] > 0
     rd = cfg["secondary_reference_default_klt"]
     assert rd["frames_per_s"] > 0 and min(rd["live_features"]) > 1000 and "6 levels" in rd["workload"]
+    # the registration decisions: every frame's sweeps settled (single pass), and the step-for-step mode ran with every loop settled
+    assert cfg["register_decision"]["frames_whose_sweeps_did_not_settle"] is False and cx["register_decisions_unsettled"] is False
+    sq = cfg["secondary_sequential_registration"]
+    assert sq["frames_per_s"] > 0 and sq["loops_whose_sweeps_did_not_settle"] is False and sq["ratio_to_value"] < 1.0
     r = j["roofline"]
     assert r["valu"] is not None and 0.05 < r["valu"]["frac"] < 1.0 and r["launches_per_frame"] >= 1
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):

@@ -33,7 +33,7 @@ def _case(seed, P, C, N, p_conflict, p_dyn=0.0):
 
 @pytest.mark.parametrize("seed,P,C,N,pc,kinds", [(1, 1536, 8, 2000, 0.2, 1), (2, 700, 3, 500, 0.05, 1), (3, 4096, 8, 2000, 0.5, 1), (4, 64, 1, 100, 0.3, 1),
                                                   (5, 2000, 16, 300, 0.02, 1), (6, 1536, 8, 2000, 0.2, 3), (7, 900, 4, 400, 0.1, 2), (8, 3000, 6, 1000, 0.4, 3),
-                                                  (9, 9000, 8, 2000, 0.3, 1), (10, 8500, 8, 2000, 0.3, 3)])   # (9, 10: past the one-workgroup form's size)
+                                                  (9, 9000, 8, 2000, 0.3, 1), (10, 8500, 8, 2000, 0.3, 3)])   # (9, 10: tables of more than 65 k entries)
 def test_decision_equals_the_sequential_walks(hip, seed, P, C, N, pc, kinds):
     import torch
 
