@@ -136,6 +136,10 @@ __global__ __launch_bounds__(256) void k_exchange_unpack_poses(const int* __rest
 
 extern "C" {
 
+// 1: RCCL could be loaded and has every entry point used here (what a group of ranks should agree on BEFORE any of them enters
+// ncclCommInitRank: a rank that cannot load the library would leave the others waiting inside it)
+int cs_comm_available(void) { return rccl_api() ? 1 : 0; }
+
 int cs_comm_unique_id(unsigned char id[128]) {
     RcclApi* api = rccl_api();
     if (!api || !id) return CS_ERR_INVALID;

@@ -45,16 +45,27 @@ class NativeComm:
         L.cs_comm_create.restype = C.c_void_p
         L.cs_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         self.comms = []
+        # no rank may enter ncclCommInitRank unless ALL can: (1) every rank can load RCCL (one all-reduce), (2) rank 0's unique id arrives
+        # with a flag that says it was created -- a failure then raises on EVERY rank instead of leaving the others waiting
+        if world > 1:
+            backend = dist.get_backend(group)
+            dev = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
+            ok = torch.tensor([int(L.cs_comm_available())], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0:
+                raise CoslamHipError("cs_comm_available: RCCL cannot be loaded on at least one rank (" + L.cs_last_error().decode() + ")")
         for _ in range(2):
             ident = (C.c_ubyte * 128)()
-            if rank == 0:
-                check(L.cs_comm_unique_id(ident), "cs_comm_unique_id")
+            made = 1
+            if rank == 0 and L.cs_comm_unique_id(ident) != 0:
+                made = 0
             if world > 1:
-                backend = dist.get_backend(group)
-                dev = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
-                t = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
+                t = torch.tensor([made] + list(ident), dtype=torch.uint8, device=dev)
                 dist.broadcast(t, src=0, group=group)
-                ident = (C.c_ubyte * 128)(*t.cpu().tolist())
+                tl = t.cpu().tolist()
+                made, ident = tl[0], (C.c_ubyte * 128)(*tl[1:])
+            if not made:
+                raise CoslamHipError("cs_comm_unique_id failed on rank 0: " + L.cs_last_error().decode())
             h = L.cs_comm_create(ident, world, rank, device)
             if not h:
                 raise CoslamHipError("cs_comm_create: " + L.cs_last_error().decode())

@@ -934,6 +934,8 @@ int cs_ba_download(cs_ba* b, int C, int P, int nObs, double* Rs, double* Ts, dou
  * S || rhs per LM step.  RCCL is loaded at run time (dlopen); without it the cs_comm_* calls fail and nothing else is
  * affected. */
 typedef struct cs_comm cs_comm;
+int cs_comm_available(void); /* 1: RCCL loaded with every entry point used here -- agree on it across the ranks BEFORE cs_comm_create: a rank
+                                that cannot load the library would leave the others waiting inside ncclCommInitRank */
 int cs_comm_unique_id(unsigned char id[128]); /* rank 0 creates it; the caller ships it to the other ranks */
 cs_comm* cs_comm_create(const unsigned char id[128], int world, int rank, int device); /* ncclCommInitRank */
 void cs_comm_destroy(cs_comm* c);
