@@ -442,6 +442,8 @@ def main():
     ap.add_argument("--no-pose-update", action="store_true", help="diagnostic: skip the gate / dynamic test / BA write-back (not a valid bench line)")
     ap.add_argument("--no-mergability", action="store_true", help="diagnostic: skip staticCheckMergability (not a valid bench line)")
     ap.add_argument("--no-decide", action="store_true", help="diagnostic: skip the registration decision + refineMapPoint (not a valid bench line)")
+    ap.add_argument("--merge-every", type=int, default=50, help="bMerge frames: every n-th frame the static points' walks may unify two points "
+                    "(the reference: 50, CoSLAMThread.cpp:117-118); 0: never (diagnostic)")
     ap.add_argument("--no-ncc", action="store_true", help="diagnostic: skip the inter-camera NCC matching leg (not a valid bench line)")
     ap.add_argument("--no-register", action="store_true", help="diagnostic: skip the map-point registration search (not a valid bench line)")
     ap.add_argument("--no-cxx-loop", action="store_true", help="skip the C++ frame loop (tools/cxx/frame_loop.bin, config.cxx_frame_loop)")
@@ -518,7 +520,7 @@ def main():
                      key_every=max(ke, 1), ba_lag=args.ba_lag, p_reg=P_REG, klt_cams_per_launch=max(args.klt_cams_per_launch, 0),
                      prefetch=os.environ.get("BENCH_PREFETCH", "1") != "0", with_pose_update=not args.no_pose_update,
                      with_classify=not args.no_classify, with_register=not args.no_register, with_mergability=not args.no_mergability,
-                     with_ncc=not args.no_ncc, with_decide=not args.no_decide, with_joint=args.only_solve != "intercam", with_intercam=args.only_solve != "joint",
+                     with_ncc=not args.no_ncc, with_decide=not args.no_decide, merge_every=args.merge_every, with_joint=args.only_solve != "intercam", with_intercam=args.only_solve != "joint",
                      native_comm=bool(args.native_comm),
                      klt_fused=os.environ.get("BENCH_FORCE_DEVICE") is None or world == 1)   # (ranks sharing ONE GPU: test hook)
     try:
@@ -1008,6 +1010,10 @@ def main():
                            ("features_attached_last_frame", "points_regged_last_frame", "sweeps_last_frame", "converged"), dec_counts[0]),
                            points_refined_last_frame=dec_counts[1],
                            frames_whose_sweeps_did_not_settle=dec_counts[2],
+                           merge=None if not hasattr(loop, "_dec") else dict(
+                               every_frames=loop.cfg.merge_every, bmerge_frames=loop.n_merge_frames,
+                               **dict(zip(("features_attached", "points_registered", "points_unified_away", "check_unify_calls"),
+                                          (f"{v} (last bMerge frame)" for v in loop._dec["mcnt"].cpu().tolist())))),
                            what="currentMapPointsRegister's decisions (bMerge false) -- curStaticPointsRegInGroup and, behind it, "
                                 "curDynamicPointsRegInGroup on the certainly dynamic points -- over the search + mergability tables of all cameras "
                                 "(cs_register_decide_kinds_dev, kinds 3: the sequential first-claimant rule resolved exactly), then refineMapPoint "

@@ -608,11 +608,11 @@ struct CuArgs {
     double *M, *cov;           // [nPairs][3], [nPairs][9]
     cs_poseupdate_cam cam[PU_MAX_CAMS];
 };
-__global__ __launch_bounds__(256) void k_check_unify(CuArgs A) {
-    __shared__ double sR[4][64 * 9 + 16];
-    const int tid = threadIdx.x, g = tid / 64, r = tid % 64;
-    const int q = blockIdx.x * 4 + g;
-    if (q >= A.nPairs) return;
+// one pair, one wave: pf1 / pf2 the two points' rows of pointFeat, M1 / M2 their positions, sRw the wave's 64 * 9 + 16 doubles of LDS;
+// returns the verdict (uniform over the wave), M / cov the unified point (every lane)
+__device__ __forceinline__ bool check_unify_wave(const CuArgs& A, const int* pf1, const int* pf2, const double* M1, const double* M2,
+                                                 double* sRw, double (&M)[3], double (&cov)[9]) {
+    const int r = threadIdx.x % 64;
     const int N = A.N, H = A.H;
     UpNormalEq E;
 #pragma unroll
@@ -628,9 +628,9 @@ __global__ __launch_bounds__(256) void k_check_unify(CuArgs A) {
         const double* R0 = hR + (size_t)A.head * 9;
         const double* t0 = hT + (size_t)A.head * 3;
         for (int which = 0; which < 2; ++which) {
-            const int s = (which ? A.pf2 : A.pf1)[(size_t)q * A.nCams + c];
+            const int s = (which ? pf2 : pf1)[c];
             if (s < 0) continue;
-            const double* Mold = (which ? A.M2 : A.M1) + 3 * (size_t)q;
+            const double* Mold = which ? M2 : M1;
             up_add_view(E, C.iK, R0, t0, hXY[(size_t)A.head * 2 * N + s], hXY[(size_t)A.head * 2 * N + N + s]);
             if (r == nv) myC = c, myJ = 0, myS = s;
             ++nv;
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256) void k_check_unify(CuArgs A) {
             }
         }
     }
-    double cf[6], M[3];
+    double cf[6];
     const double det = up_sym33_cof(E.N, cf);
     M[0] = ((cf[0] * E.g[0] + cf[1] * E.g[1]) + cf[2] * E.g[2]) / det;  // triangulateMultiView
     M[1] = ((cf[1] * E.g[0] + cf[3] * E.g[1]) + cf[4] * E.g[2]) / det;
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256) void k_check_unify(CuArgs A) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) J[k] = pv.J[k];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) sR[g][9 * r + k] = Rv[k];
+        for (int k = 0; k < 9; ++k) sRw[9 * r + k] = Rv[k];
     }
     double S[6] = {0, 0, 0, 0, 0, 0};
     for (int v = 0; v < nv; ++v) {   // the J^T J blocks in view order
@@ -691,7 +691,6 @@ __global__ __launch_bounds__(256) void k_check_unify(CuArgs A) {
         up_add_jtj(S, Jv);
     }
     const double dS = up_sym33_cof(S, cf), s2 = A.sigma * A.sigma;
-    double cov[9];
     cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
     cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
     cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
@@ -701,7 +700,7 @@ __global__ __launch_bounds__(256) void k_check_unify(CuArgs A) {
         const double rm0 = pv.u / pv.w, rm1 = pv.v / pv.w;
         double Rq[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rq[k] = sR[g][3 * r + k];   // `Rs + 3 * i`
+        for (int k = 0; k < 9; ++k) Rq[k] = sRw[3 * r + k];   // `Rs + 3 * i`
         const PuProj pq = pu_project(A.cam[myC].K, Rq, tv, M);
         double JC[6], var[4], ivar[4];
 #pragma unroll
@@ -721,13 +720,135 @@ __global__ __launch_bounds__(256) void k_check_unify(CuArgs A) {
         fail = dx * (ivar[0] * dx + ivar[1] * dy) + dy * (ivar[2] * dx + ivar[3] * dy) > 1.0;
     }
     const bool anyFail = __builtin_amdgcn_ballot_w64(fail) != 0;
+    __builtin_amdgcn_wave_barrier();   // (the next call of this wave overwrites sRw)
+    return !anyFail;
+}
+__global__ __launch_bounds__(256) void k_check_unify(CuArgs A) {
+    __shared__ double sR[4][64 * 9 + 16];
+    const int tid = threadIdx.x, g = tid / 64, r = tid % 64;
+    const int q = blockIdx.x * 4 + g;
+    if (q >= A.nPairs) return;
+    double M[3], cov[9];
+    const bool ok = check_unify_wave(A, A.pf1 + (size_t)q * A.nCams, A.pf2 + (size_t)q * A.nCams, A.M1 + 3 * (size_t)q, A.M2 + 3 * (size_t)q, sR[g], M, cov);
     if (r == 0) {
-        A.ok[q] = anyFail ? 0 : 1;
+        A.ok[q] = ok ? 1 : 0;
 #pragma unroll
         for (int k = 0; k < 3; ++k) A.M[3 * (size_t)q + k] = M[k];
 #pragma unroll
         for (int k = 0; k < 9; ++k) A.cov[9 * (size_t)q + k] = cov[k];
     }
+}
+
+// ---- CoSLAM::curStaticPointsRegInGroup with bMerge == true (src/app/SL_CoSLAM.cpp:854-898, 731-830; every 50th frame) ---------------------
+// The walks in the reference's order, ONE wave, one point after the other: a walk that meets a feature of ANOTHER static point asks
+// checkUnify -- with both points' features and positions as they stand at that moment -- and on a yes takes that point's place
+// (:797-826: the position, the other point false, its features in the cameras up to the one of the conflict -- the loop reads
+// `pFeat->mpt->pFeatures[v]`, and pFeat->mpt is the walking point once pFeat itself has moved: the features behind it stay), which ends
+// the walk; on a no it goes on (with bMerge a mapped feature does not end a walk).  Sequential by nature (every verdict depends on what
+// the walks before it attached); lane c prefetches camera c's entries of the point, the wave evaluates checkUnify together.  The parity
+// mode's kernel: ~5 us per conflict, a frame of 8 cameras x 1500 points ~0.1 s -- for the frames that carry bMerge when the reference's
+// run is wanted step for step; the frame loop's single pass does not unify points.
+struct DmArgs {
+    CuArgs cu;                       // the history ring, cameras (slot2map is written), sigma
+    int P, mapBase, onlyCam;
+    const int* slot;                 // [P][nCams] the search's candidates
+    const int* flags;                // [P][nCams] bit 1: the candidate is dynamic
+    const unsigned char* mergeable;  // [P][nCams]
+    unsigned char* mapFlags;         // [P] in / out (a point unified away becomes false)
+    int* pointFeat;                  // [P][nCams] in / out
+    double* mapPts;                  // [P][3] in / out (the survivor takes the unified position)
+    double* mapCov;                  // [P][9]
+    unsigned char* attached;         // [P][nCams] out
+    unsigned char* regged;           // [P] out
+    unsigned char* inVec;            // scratch [P]: the camera loop's visiting list, fixed when the loop starts (:864-869)
+    int* counts;                     // [4] out: features attached, points registered, points unified away, checkUnify calls
+};
+__device__ __forceinline__ int mg_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
+    __shared__ double sR[64 * 9 + 16];
+    const int lane = threadIdx.x, C = A.cu.nCams, N = A.cu.N, P = A.P;
+    int nAtt = 0, nReg = 0, nMerged = 0, nAsked = 0;
+    for (int k = lane; k < P * C; k += 64) A.attached[k] = 0;
+    for (int p = lane; p < P; p += 64) A.regged[p] = 0;
+    const int o0 = A.onlyCam >= 0 ? A.onlyCam : 0, o1 = A.onlyCam >= 0 ? A.onlyCam + 1 : C;
+    for (int o = o0; o < o1; ++o) {
+        for (int p = lane; p < P; p += 64)
+            A.inVec[p] = ((A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) == 0 && A.pointFeat[(size_t)p * C + o] >= 0) ? 1 : 0;
+        __threadfence();
+        __syncthreads();
+        for (int p0 = 0; p0 < P; p0 += 64) {
+          // the next 64 points' places on the visiting list as a mask: the wave steps through the set bits only
+          unsigned long long todo = __builtin_amdgcn_ballot_w64(p0 + lane < P && A.inVec[p0 + lane] != 0);
+          while (todo) {
+            const int p = p0 + __builtin_ctzll(todo);
+            todo &= todo - 1;
+            if (*(volatile unsigned char*)(A.mapFlags + p) & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) continue;   // :734 isLocalStatic() (unified away meanwhile)
+            // lane c: camera c's entry of the point -- the candidate, and what it would meet there as things stand (the state changes only
+            // through this wave's own steps: an attach leaves the point's later cameras as they were, a unify ends the walk)
+            int mySlot = -1, myFlags = 0, myMerge = 0, myHas = 0, myOwner = -1;
+            if (lane < C) {
+                mySlot = A.slot[(size_t)p * C + lane], myFlags = A.flags[(size_t)p * C + lane], myMerge = A.mergeable[(size_t)p * C + lane];
+                myHas = mg_ld(A.pointFeat + (size_t)p * C + lane) >= 0;
+                if (mySlot >= N) mySlot = -1;
+                if (mySlot >= 0) myOwner = mg_ld(A.cu.cam[lane].slot2map + mySlot);
+            }
+            // cameras with something to do: no feature of the point, a non-dynamic candidate that is unmapped-and-mergeable or carries a point
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(lane < C && !myHas && mySlot >= 0 && !(myFlags & 2) && (myOwner >= 0 || myMerge == 1));
+            if (!act) continue;
+            bool reg = false;
+            for (int i = 0; i < C; ++i) {
+                if (!((act >> i) & 1)) continue;                                            // :736-737, :757: has a feature / nothing found / DYNAMIC
+                const int s = __shfl(mySlot, i, 64), mg = __shfl(myMerge, i, 64);
+                int* s2m = const_cast<int*>(A.cu.cam[i].slot2map);
+                const int m = __shfl(myOwner, i, 64);
+                if (m < 0) {
+                    if (mg == 1) {                                                          // :760-787
+                        if (lane == 0) {
+                            s2m[s] = A.mapBase + p;
+                            A.pointFeat[(size_t)p * C + i] = s;
+                            A.attached[(size_t)p * C + i] = 1;
+                        }
+                        __threadfence();
+                        reg = true, ++nAtt;
+                    }
+                    continue;
+                }
+                const int q = m - A.mapBase;                                               // :791-796
+                if (q < 0 || q >= P || q == p) continue;
+                if (*(volatile unsigned char*)(A.mapFlags + q) & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) continue;   // !isLocalStatic()
+                double M[3], cov[9];
+                ++nAsked;
+                const bool ok = check_unify_wave(A.cu, A.pointFeat + (size_t)p * C, A.pointFeat + (size_t)q * C, A.mapPts + 3 * (size_t)p,
+                                                 A.mapPts + 3 * (size_t)q, sR, M, cov);
+                if (!ok) continue;
+                if (lane == 0) {                                                            // :797-826
+                    for (int k = 0; k < 3; ++k) A.mapPts[3 * (size_t)p + k] = M[k];
+                    for (int k = 0; k < 9; ++k) A.mapCov[9 * (size_t)p + k] = cov[k];
+                    A.mapFlags[q] = (unsigned char)((A.mapFlags[q] & CS_MAP_UNCERTAIN) | CS_MAP_FALSE);
+                    for (int v = 0; v < C; ++v) {
+                        const int sq = A.pointFeat[(size_t)q * C + v];
+                        if (sq >= 0 && A.pointFeat[(size_t)p * C + v] < 0) {
+                            A.pointFeat[(size_t)q * C + v] = -1;
+                            const_cast<int*>(A.cu.cam[v].slot2map)[sq] = A.mapBase + p;
+                            A.pointFeat[(size_t)p * C + v] = sq;
+                            if (v == i && sq == s) break;   // pFeat->mpt is p from here on (:808)
+                        }
+                    }
+                }
+                __threadfence();
+                reg = true, ++nMerged;
+                break;                                                                      // :825 return
+            }
+            if (reg) {
+                if (lane == 0) A.regged[p] = 1;
+                ++nReg;
+            }
+          }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+    if (lane == 0 && A.counts) A.counts[0] = nAtt, A.counts[1] = nReg, A.counts[2] = nMerged, A.counts[3] = nAsked;
 }
 
 // ---- CoSLAM::mapPointsClassify (src/app/SL_CoSLAM.cpp:418-520) ------------------------------------------------------------------------
@@ -1487,6 +1608,46 @@ extern "C" int cs_check_unify_dev(const cs_track_history* h, void* hip_stream, c
     hipStream_t s = (hipStream_t)hip_stream;
     hist_centres(h, s);
     hipLaunchKernelGGL(k_check_unify, dim3((nPairs + 3) / 4), dim3(256), 0, s, A);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+extern "C" int cs_register_decide_merge_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int P, int mapBase,
+                                            const int* d_slot, const int* d_flags, const unsigned char* d_mergeable, unsigned char* d_mapFlags,
+                                            int* d_pointFeat, double* d_mapPts, double* d_mapCov, double pixelErrVar, unsigned char* d_attached,
+                                            unsigned char* d_regged, void* d_scratch, int* d_counts, int onlyCam) {
+    if (!h || !cams || P < 0 || mapBase < 0 || h->nCams * 4 > 64 || onlyCam >= h->nCams ||
+        (P > 0 && (!d_slot || !d_flags || !d_mergeable || !d_mapFlags || !d_pointFeat || !d_mapPts || !d_mapCov || !d_attached || !d_regged || !d_scratch))) {
+        cs_set_error("cs_register_decide_merge_dev: bad arguments (at most 16 cameras)");
+        return CS_ERR_INVALID;
+    }
+    if (h->count < 1) {
+        cs_set_error("cs_register_decide_merge_dev: the history holds no frame");
+        return CS_ERR_INVALID;
+    }
+    DmArgs A;
+    memset(&A, 0, sizeof(A));
+    A.cu.nCams = h->nCams, A.cu.N = h->N, A.cu.H = h->H, A.cu.head = h->head, A.cu.nHist = h->count;
+    A.cu.histXY = h->xy, A.cu.histR = h->R, A.cu.histT = h->t, A.cu.cen = h->cen;
+    A.cu.sigma = pixelErrVar;
+    for (int c = 0; c < h->nCams; ++c) {
+        if (!cams[c].K || !cams[c].iK || !cams[c].trackSpan || !cams[c].slot2map) {
+            cs_set_error("cs_register_decide_merge_dev: null pointer in camera %d (K, iK, trackSpan are read, slot2map is written)", c);
+            return CS_ERR_INVALID;
+        }
+        A.cu.cam[c] = cams[c];
+    }
+    A.P = P, A.mapBase = mapBase, A.onlyCam = onlyCam < 0 ? -1 : onlyCam;
+    A.slot = d_slot, A.flags = d_flags, A.mergeable = d_mergeable, A.mapFlags = d_mapFlags, A.pointFeat = d_pointFeat;
+    A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.attached = d_attached, A.regged = d_regged, A.inVec = (unsigned char*)d_scratch, A.counts = d_counts;
+    CS_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (P == 0) {
+        if (d_counts) CS_HIP(hipMemsetAsync(d_counts, 0, 4 * sizeof(int), s));
+        return CS_OK;
+    }
+    hist_centres(h, s);
+    hipLaunchKernelGGL(k_decide_merge, dim3(1), dim3(64), 0, s, A);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

@@ -49,6 +49,8 @@ class LoopConfig:
         self.with_pose_update = self.with_classify = self.with_register = self.with_mergability = self.with_ncc = True
         self.with_joint = self.with_intercam = True
         self.with_decide = True    # the registration decision (who attaches which feature) + refineMapPoint of the points that gained one
+        self.merge_every = 50      # bMerge: every 50th frame the static points' walks may UNIFY two points (CoSLAMThread.cpp:117-118:
+        # `i % 50 == 0`; cs_register_decide_merge_dev, sequential); 0: never
         self.sequential_registration = False   # the decision camera loop after camera loop with a search + refine per loop, as the
         # reference runs it (register_cur_static_sequential_dev: bit-identical to the reference's run, nCams x the launches; one rank only)
         self.native_comm = True
@@ -513,7 +515,7 @@ class FrameLoop:
                                                        self.reg_out[1]["slot"].data_ptr(), PIXEL_ERR_VAR, self.d_mergeable.data_ptr(),
                                                        cam0=c0, nCamsRun=nc)
         if cfg.with_register and cfg.with_decide and self.pose_upd is not None and cfg.with_mergability:
-            self._dst_now = dst
+            self._dst_now, self._frame_now = dst, i
             self._decide(ps)
         # the tracker of frame i + 2 (it writes this dest buffer) is released HERE, at the end of the frame's pose work, although the
         # buffer's last reader was the hand-back: released earlier the tracker runs two frames ahead and under more of the pose stream's
@@ -541,7 +543,9 @@ class FrameLoop:
         if not hasattr(self, "_dec"):
             torch = self.torch
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.dev)   # noqa: E731
+            self.n_merge_frames = 0
             self._dec = dict(att=z((cfg.p_reg, NA), torch.uint8), reg=z(self.n_map, torch.uint8), cnt=z(4, torch.int32), ref_cnt=z(1, torch.int32),
+                             mcnt=z(4, torch.int32),
                              scr=z(register_decide_scratch_bytes(NA, cfg.n_feat, cfg.p_reg), torch.uint8), s2m=None)
             torch.cuda.synchronize()   # (the zero fills ran on torch's stream: done before the pose stream touches the buffers)
         D = self._dec
@@ -560,15 +564,28 @@ class FrameLoop:
                                                           D["s2m"] if D["s2m"] is not None else [self.d_slot2map[g].data_ptr() for g in range(NA)],
                                                           D["att"].data_ptr(), D["reg"].data_ptr(), D["scr"].data_ptr(), self.d_map.data_ptr(),
                                                           self.d_cov.data_ptr(), PIXEL_ERR_VAR, d_counts=D["cnt"].data_ptr(), device=self.device,
-                                                          with_dynamic=True)
+                                                          with_dynamic=True, merge=(cfg.merge_every > 0 and self._frame_now % cfg.merge_every == 0),   # CoSLAMThread.cpp:117-118
+                                                          d_merge_scratch=D["scr"].data_ptr())
             return
         if self.world > 1:
             self._gather_candidates()
+        kinds = 3
+        if cfg.merge_every > 0 and self._frame_now % cfg.merge_every == 0:
+            # a bMerge frame: the static points' walks one after the other with checkUnify at a conflict, the dynamic points' behind them
+            o = self.reg_out[1]
+            self.pose_upd.register_decide_merge_dev(ps, self.pu_args, cfg.p_reg, 0, o["slot"].data_ptr(), o["flags"].data_ptr(),
+                                                    self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(),
+                                                    self.d_map.data_ptr(), self.d_cov.data_ptr(), PIXEL_ERR_VAR, D["att"].data_ptr(),
+                                                    D["reg"].data_ptr(), D["scr"].data_ptr(), D["mcnt"].data_ptr())
+            self.pose_upd.refine_map_points_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
+                                                PIXEL_ERR_VAR, d_select=D["reg"].data_ptr(), d_count=D["ref_cnt"].data_ptr())
+            self.n_merge_frames += 1
+            kinds = 2
         D["s2m"] = register_decide_static_dev(ps, NA, cfg.n_feat, cfg.p_reg, 0, self.reg_out[1]["slot"].data_ptr(), self.reg_out[1]["flags"].data_ptr(),
                                               self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(),
                                               D["s2m"] if D["s2m"] is not None else [self.d_slot2map[g].data_ptr() for g in range(NA)],
                                               D["att"].data_ptr(), D["reg"].data_ptr(), D["scr"].data_ptr(), D["cnt"].data_ptr(), device=self.device,
-                                              kinds=3)   # curStaticPointsRegInGroup and curDynamicPointsRegInGroup (currentMapPointsRegister, :834-853)
+                                              kinds=kinds)   # curStaticPointsRegInGroup and curDynamicPointsRegInGroup (currentMapPointsRegister, :834-853)
         # (d_regged covers the pass's P points = the first P map points; the rest of the select mask stays 0)
         self.pose_upd.refine_map_points_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
                                             PIXEL_ERR_VAR, d_select=D["reg"].data_ptr(), d_count=D["ref_cnt"].data_ptr())

@@ -141,6 +141,16 @@ class TrackHistory:
         check(self._L.cs_check_unify_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), int(nPairs), vp(d_pf1), vp(d_pf2), vp(d_M1), vp(d_M2),
                                          C.c_double(pixelErrVar), vp(d_ok), vp(d_M), vp(d_cov)), "cs_check_unify_dev")
 
+    def register_decide_merge_dev(self, stream_ptr, cams, P, mapBase, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, d_mapPts, d_mapCov,
+                                  pixelErrVar, d_attached, d_regged, d_scratch, d_counts=0, only_cam=-1):
+        """curStaticPointsRegInGroup with bMerge == true (reference src/app/SL_CoSLAM.cpp:854-898, 731-830), the walks in the reference's
+        order on one wave: attach, or ask checkUnify at a feature of another static point and unify on a yes (cs_register_decide_merge_dev)"""
+        vp = C.c_void_p
+        check(self._L.cs_register_decide_merge_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), int(P), int(mapBase), vp(d_slot), vp(d_flags),
+                                                   vp(d_mergeable), vp(d_mapFlags), vp(d_pointFeat), vp(d_mapPts), vp(d_mapCov),
+                                                   C.c_double(pixelErrVar), vp(d_attached), vp(d_regged), vp(d_scratch), vp(d_counts),
+                                                   int(only_cam)), "cs_register_decide_merge_dev")
+
     def map_points_classify_dev(self, stream_ptr, cams, d_pointFeat, nMap, curFrame, d_mapPts, d_mapCov, d_mapFlags, d_newPt,
                                 d_staticFrameNum, d_firstFrame, pixelVar=12.0, d_featFrame=None, d_featFirst=None, d_counts=None):
         """CoSLAM::mapPointsClassify (reference src/app/SL_CoSLAM.cpp:418-520; CoSLAM::poseUpdate calls it with 12.0 every frame):

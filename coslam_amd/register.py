@@ -129,7 +129,7 @@ def register_decide_static_dev(stream_ptr, nCams, N, P, mapBase, d_slot, d_flags
 
 def register_cur_static_sequential_dev(stream_ptr, history, pu_cams, reg_cams, N, W, H, search_pass, P, d_slot, d_flags, d_mergeable, d_mapFlags,
                                        d_pointFeat, d_slot2map, d_attached, d_regged, d_scratch, d_mapPts, d_mapCov, pixelVar, d_counts=0,
-                                       after_loop=None, device=0, n_sweeps=6, with_dynamic=False):
+                                       after_loop=None, device=0, n_sweeps=6, with_dynamic=False, merge=False, d_merge_scratch=0):
     """CoSLAM::curStaticPointsRegInGroup (bMerge == false) AS THE REFERENCE RUNS IT (src/app/SL_CoSLAM.cpp:854-898), camera loop after
     camera loop, on the device: for o = 0 .. nCams - 1 -- the search from the points as they stand (cs_register_search_passes_dev with
     the ONE pass `search_pass`, whose tables are d_slot / d_flags), staticCheckMergability of its candidates (history: a TrackHistory),
@@ -141,11 +141,18 @@ def register_cur_static_sequential_dev(stream_ptr, history, pu_cams, reg_cams, N
     arr = None
     # with_dynamic: curDynamicPointsRegInGroup's loops behind the static ones (currentMapPointsRegister, :834-853); search_pass must then
     # carry mapFlags / maxDistDynamic (the dynamic points' own scale).  after_loop(o) is called with o = nCams .. 2 nCams - 1 for them.
+    # merge: bMerge == true (every 50th frame) -- the static loops through cs_register_decide_merge_dev (pu_cams' slot2map = d_slot2map's
+    # arrays; d_merge_scratch: P bytes; d_mapFlags is then written)
     for kind, o in [(1, o_) for o_ in range(nC)] + ([(2, o_) for o_ in range(nC)] if with_dynamic else []):
         register_search_passes_dev(stream_ptr, reg_cams, N, W, H, search_pass, device=device)
         history.register_mergability_dev(stream_ptr, pu_cams, P, d_mapPts, d_mapCov, d_slot, pixelVar, d_mergeable)
-        arr = register_decide_static_dev(stream_ptr, nC, N, P, 0, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, arr or d_slot2map,
-                                         d_attached, d_regged, d_scratch, d_counts, device=device, n_sweeps=n_sweeps, only_cam=o, kinds=kind)
+        if merge and kind == 1:   # bMerge: the static points' walks one after the other, checkUnify at a conflict (the dynamic loops ignore bMerge);
+            # d_counts then reads: features attached, points registered, points unified away, checkUnify calls
+            history.register_decide_merge_dev(stream_ptr, pu_cams, P, 0, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, d_mapPts, d_mapCov,
+                                              pixelVar, d_attached, d_regged, d_merge_scratch, d_counts, only_cam=o)
+        else:
+            arr = register_decide_static_dev(stream_ptr, nC, N, P, 0, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, arr or d_slot2map,
+                                             d_attached, d_regged, d_scratch, d_counts, device=device, n_sweeps=n_sweeps, only_cam=o, kinds=kind)
         history.refine_map_points_dev(stream_ptr, pu_cams, d_pointFeat, P, d_mapPts, d_mapCov, pixelVar, d_select=d_regged)
         if after_loop is not None:
             after_loop(o + (nC if kind == 2 else 0))

@@ -512,6 +512,21 @@ int cs_refine_map_points_dev(const cs_track_history* h, void* hip_stream, const 
 int cs_check_unify_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int nPairs, const int* d_pf1,
                        const int* d_pf2, const double* d_M1, const double* d_M2, double pixelErrVar, unsigned char* d_ok, double* d_M,
                        double* d_cov);
+/* curStaticPointsRegInGroup with bMerge == true (src/app/SL_CoSLAM.cpp:854-898, 731-830: every 50th frame, CoSLAMThread.cpp:117-118) -- the
+ * walks in the reference's order on ONE wave: unmapped mergeable candidates are attached as above; a candidate that carries ANOTHER static
+ * point asks checkUnify with both points as they stand and, on a yes, the walking point takes the unified position, the other becomes false
+ * and hands over its features in the cameras up to the one of the conflict (:797-826 as written), which ends the walk; on a no the walk
+ * goes on.  Tables as cs_register_decide_static_dev's (one search + cs_register_mergability_dev before it); d_mapFlags / d_pointFeat /
+ * d_mapPts / d_mapCov [P] and the cameras' slot2map are updated IN PLACE; d_scratch: P bytes; d_counts [4] or NULL: features attached,
+ * points registered, points unified away, checkUnify calls; onlyCam >= 0: that camera's loop only (then refine d_regged and search again
+ * before the next: the reference's run step for step).  Sequential: ~5 us per conflict -- the parity mode's entry, pinned to the reference's
+ * own run with bMerge on tests/golden/decide_golden.npz scenes 5, 6; the dynamic points' loops ignore bMerge (cs_register_decide_kinds_dev,
+ * kinds 2, behind it). */
+int cs_register_decide_merge_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int P, int mapBase, const int* d_slot,
+                                 const int* d_flags, const unsigned char* d_mergeable, unsigned char* d_mapFlags, int* d_pointFeat, double* d_mapPts,
+                                 double* d_mapCov, double pixelErrVar, unsigned char* d_attached, unsigned char* d_regged, void* d_scratch,
+                                 int* d_counts, int onlyCam);
+
 
 /* CoSLAM::mapPointsClassify (src/app/SL_CoSLAM.cpp:418-520) in one launch: what CoSLAM::poseUpdate runs every frame behind the pose
  * update (:381-385, pixelVar = 12.0) -- every map point with a feature in this frame that is uncertain (CS_MAP_UNCERTAIN: what the

@@ -881,7 +881,7 @@ def register_decide_static(slot, flags, mergeable, mapFlags, pointFeat, slot2map
 
 
 def register_cur_static_sequential(W, H, Ks, iKs, histR, histT, histXY, trackSpan, state, isStatic, slot2map, mapPts, mapCov, mapFlags,
-                                   pointFeat, pixelVar, with_dynamic=False):
+                                   pointFeat, pixelVar, with_dynamic=False, merge=False):
     """CoSLAM::curStaticPointsRegInGroup (bMerge == false) AS THE REFERENCE RUNS IT (src/app/SL_CoSLAM.cpp:854-898, 731-830), one point after
     the other (TEST INFRASTRUCTURE, plain Python over the pinned restatements of the search, staticCheckMergability and refineMapPoint):
     for every camera o in turn, the certainly static points that hold a feature of this frame in o -- INCLUDING features attached in an
@@ -900,6 +900,7 @@ def register_cur_static_sequential(W, H, Ks, iKs, histR, histT, histXY, trackSpa
     # with_dynamic: curDynamicPointsRegInGroup behind the static points' loops (currentMapPointsRegister, :834-853): the certainly dynamic
     # points, maxDist 4 sigma (:973), DYNAMIC candidates only; returns the registrations of both (static, dynamic) then
     n_reg_kind = [0, 0]
+    n_merged = 0
     for want_dyn, o in [(0, o_) for o_ in range(nC)] + ([(1, o_) for o_ in range(nC)] if with_dynamic else []):
         vec = [p for p in range(nP) if (int(mapFlags[p]) & 7) == want_dyn and pointFeat[p, o] >= 0]      # :864-869 / :917-922
         regged = []
@@ -912,6 +913,29 @@ def register_cur_static_sequential(W, H, Ks, iKs, histR, histT, histXY, trackSpa
                 if pointFeat[p, i] >= 0 or s < 0 or ((int(res["flags"][0, i]) >> 1) & 1) != want_dyn:
                     continue
                 if slot2map[i][s] >= 0:                                                               # :789-790
+                    if not (merge and not want_dyn):
+                        break
+                    # bMerge (:791-826; curDynamicPointRegInGroup ignores the flag): can the two points be one?
+                    q = int(slot2map[i][s])
+                    if (int(mapFlags[q]) & 3) != 0 or q == p:                                         # !isLocalStatic() / itself
+                        continue
+                    ok, Mu, covu = check_unify(Ks, iKs, histR, histT, histXY, trackSpan, pointFeat[p], pointFeat[q], mapPts[p], mapPts[q], pixelVar)
+                    if not ok:
+                        continue
+                    mapPts[p], mapCov[p] = Mu, covu                                                    # updatePosition
+                    mapFlags[q] = (int(mapFlags[q]) & 4) | 2                                           # numVisCam = 0, setFalse()
+                    for v in range(nC):                                                               # its features where p has none ...
+                        sq = int(pointFeat[q, v])
+                        if sq >= 0 and pointFeat[p, v] < 0:
+                            pointFeat[q, v] = -1
+                            slot2map[v][sq] = p
+                            pointFeat[p, v] = sq
+                            if v == i and sq == s:
+                                # ... up to the camera of the conflict: the loop reads `pFeat->mpt->pFeatures[v]` (:808) and pFeat->mpt IS p
+                                # once pFeat itself has moved -- the other point's features in the cameras behind it stay where they are
+                                break
+                    n_merged += 1
+                    breg = True
                     break
                 sl = np.full(1, s, dtype=np.int32)
                 if register_mergability_cam(Ks[i], histR[i], histT[i], histXY[i], trackSpan[i], mapPts[p:p + 1], mapCov[p:p + 1], sl, pixelVar)[0] == 1:
@@ -927,6 +951,8 @@ def register_cur_static_sequential(W, H, Ks, iKs, histR, histT, histXY, trackSpa
             refine_map_points(Ks, iKs, histR, histT, histXY, trackSpan, pointFeat, mapPts, mapCov, pixelVar, select=sel)
         n_reg_total += len(regged)
         n_reg_kind[want_dyn] += len(regged)
+    if merge:
+        return n_att, n_reg_kind[0], n_reg_kind[1], n_merged
     return (n_att, n_reg_total) if not with_dynamic else (n_att, n_reg_kind[0], n_reg_kind[1])
 
 

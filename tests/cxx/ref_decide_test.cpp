@@ -13,10 +13,10 @@
 // further back (-> not mergeable); a DYNAMIC one (-> passed by); one that already carries ANOTHER point (-> the walk ends there);
 // nothing.  Twin points a few millimetres apart compete for the same features; distractor features fill the frames.
 //   ref_decide_test golden <out.bin>
-// out.bin (int32 / float64): nScenes; per scene: nCams Hh N nPts curFrame W H withDynamic; pixelVar; per camera K[9], then per history entry
+// out.bin (int32 / float64): nScenes; per scene: nCams Hh N nPts curFrame W H withDynamic withMerge; pixelVar; per camera K[9], then per history entry
 // (newest first) R[9] t[3]; per camera and slot: L (0: empty) isStatic slot2map, L x m[2] (newest first); per point M[3] cov[9] flags
 // (1 dynamic, 2 false, 4 uncertain) pointFeat[nCams]; then the reference's result: nRegged nReggedDynamic; per camera slot2map[N]; per point
-// M[3] cov[9].   TEST INFRASTRUCTURE; built into oracle/_ref/ where the reference tree exists.
+// M[3] cov[9]; per point flags pointFeat[nCams] afterwards.   TEST INFRASTRUCTURE; built into oracle/_ref/ where the reference tree exists.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -75,13 +75,15 @@ int main(int argc, char** argv) {
     }
     FILE* f = fopen(argv[2], "wb");
     if (!f) return 1;
-    const int nScenes = 5;   // 0-2: the static points' registration alone; 3, 4: more certainly dynamic points with DYNAMIC candidates, and
-                             // curDynamicPointsRegInGroup behind it (CoSLAM::currentMapPointsRegister's order, :834-853)
+    const int nScenes = 7;   // 0-2: the static points' registration alone; 3, 4: more certainly dynamic points with DYNAMIC candidates, and
+                             // curDynamicPointsRegInGroup behind it (CoSLAM::currentMapPointsRegister's order, :834-853); 5, 6: the same with
+                             // bMerge == true (every 50th frame, CoSLAMThread.cpp:117-118): a walk that meets a feature of another static
+                             // point asks checkUnify and, on a yes, takes that point's features (:791-826) -- more twins here
     puti(f, nScenes);
     int tot[6] = {0, 0, 0, 0, 0, 0};   // attached, not mergeable, dynamic passed by, walks ended by a mapped feature, twins, regged
     for (int sc = 0; sc < nScenes; ++sc) {
-        const bool dyn = sc >= 3;
-        const int nCams = dyn ? sc : 3 + sc, Hh = 20, nBase = 110 + 20 * sc, curFrame = 200 + 11 * sc, W = 640, H = 480;
+        const bool dyn = sc >= 3, merge = sc >= 5;
+        const int nCams = merge ? sc - 2 : (dyn ? sc : 3 + sc), Hh = 20, nBase = 110 + 20 * sc, curFrame = 200 + 11 * sc, W = 640, H = 480;
         const double pixelVar = 10.0;   // Const::PIXEL_ERR_VAR as CoSLAMThread.cpp:117 passes it
         CoSLAM* co = new CoSLAM();
         co->numCams = nCams;
@@ -170,7 +172,7 @@ int main(int argc, char** argv) {
             if (dyn && (kind == 3 || kind == 5)) kind = 8;   // (three in ten certainly dynamic)
             const bool dk = dyn && kind == 8;               // a dynamic point of a scene that registers them: its features are DYNAMIC ones
             const int p = new_point(X, kind);
-            const bool twin = (kind < 7 || dk) && urand() < 0.12;
+            const bool twin = (kind < 7 || dk) && urand() < (merge ? 0.45 : 0.12);
             int p2 = -1;
             if (twin) {
                 const double X2[3] = {X[0] + 0.004, X[1] - 0.003, X[2] + 0.005};
@@ -236,7 +238,7 @@ int main(int argc, char** argv) {
             if (pts[p].mp->numVisCam > 0) co->curMapPts.add(pts[p].mp);
         }
         // ---- inputs
-        puti(f, nCams), puti(f, Hh), puti(f, N), puti(f, nPts), puti(f, curFrame), puti(f, W), puti(f, H), puti(f, dyn ? 1 : 0);
+        puti(f, nCams), puti(f, Hh), puti(f, N), puti(f, nPts), puti(f, curFrame), puti(f, W), puti(f, H), puti(f, dyn ? 1 : 0), puti(f, merge ? 1 : 0);
         put(f, &pixelVar, 1);
         for (int c = 0; c < nCams; ++c) {
             put(f, K, 9);
@@ -266,8 +268,8 @@ int main(int argc, char** argv) {
             }
         }
         // ---- the reference
-        const int nRegged = co->curStaticPointsRegInGroup(group, pixelVar, false);
-        const int nReggedDyn = dyn ? co->curDynamicPointsRegInGroup(group, pixelVar, false) : 0;
+        const int nRegged = co->curStaticPointsRegInGroup(group, pixelVar, merge);
+        const int nReggedDyn = dyn ? co->curDynamicPointsRegInGroup(group, pixelVar, merge) : 0;
         tot[5] += nRegged + nReggedDyn;
         puti(f, nRegged), puti(f, nReggedDyn);
         for (int c = 0; c < nCams; ++c)
@@ -278,11 +280,26 @@ int main(int argc, char** argv) {
                 if (s < (int)slots[c].size() && slots[c][s].s2m < 0 && m >= 0) ++tot[0];
             }
         for (int p = 0; p < nPts; ++p) put(f, pts[p].mp->M, 3), put(f, pts[p].mp->cov, 9);
+        int nMerged = 0;
+        for (int p = 0; p < nPts; ++p) {   // the points' types afterwards (a point unified away is false) and their features of this frame
+            MapPoint* mp = pts[p].mp;
+            const int fl = (mp->isLocalDynamic() ? 1 : 0) | (mp->isFalse() ? 2 : 0) | (mp->isUncertain() ? 4 : 0);
+            puti(f, fl);
+            for (int c = 0; c < nCams; ++c) {
+                int sIdx = -1;
+                if (mp->pFeatures[c] && mp->pFeatures[c]->f == curFrame)
+                    for (int q = 0; q < (int)slots[c].size(); ++q)
+                        if (slots[c][q].tail == mp->pFeatures[c]) sIdx = q;
+                puti(f, sIdx);
+            }
+        }
+        for (int p = 0; p < nPts; ++p) nMerged += pts[p].mp->isFalse() && (p % 1 == 0) ? 1 : 0;
+        tot[3] += nMerged;
         printf("scene %d: %d cameras, %d slots, %d points (%d on the current list): %d static + %d dynamic points registered\n", sc, nCams, N, nPts,
                co->curMapPts.getNum(), nRegged, nReggedDyn);
         co->curMapPts.clearWithoutRelease();
     }
     fclose(f);
-    printf("ref_decide_test: %d features attached, %d twins, %d points registered\n", tot[0], tot[4], tot[5]);
+    printf("ref_decide_test: %d features attached, %d twins, %d points registered, %d points false afterwards\n", tot[0], tot[4], tot[5], tot[3]);
     return tot[0] > 100 ? 0 : 1;
 }

@@ -383,11 +383,12 @@ def decide_case():
     (ns,) = ints(1)
     out["n_scenes"] = np.int32(ns)
     for sc in range(ns):
-        nC, Hh, N, nP, cur, W, H, with_dyn = (int(v) for v in ints(8))
+        nC, Hh, N, nP, cur, W, H, with_dyn, with_merge = (int(v) for v in ints(9))
         (pv,) = dbls(1)
         k = lambda n: f"s{sc}_{n}"   # noqa: E731
         out[k("dims")] = np.array([nC, Hh, N, nP, cur, W, H], np.int32)
         out[k("with_dynamic")] = np.int32(with_dyn)   # curDynamicPointsRegInGroup ran behind the static points' registration
+        out[k("with_merge")] = np.int32(with_merge)   # bMerge == true: checkUnify at a conflict, the points unified on a yes
         out[k("pixelVar")] = np.float64(pv)
         K, hR, hT = np.zeros((nC, 9)), np.zeros((nC, Hh, 9)), np.zeros((nC, Hh, 3))
         for c in range(nC):
@@ -422,6 +423,8 @@ def decide_case():
         out[k("ref_slot2map")] = ints(nC * N).reshape(nC, N)
         R = dbls(12 * nP).reshape(nP, 12)
         out[k("ref_M")], out[k("ref_cov")] = R[:, :3], R[:, 3:]
+        after = ints(nP * (1 + nC)).reshape(nP, 1 + nC)
+        out[k("ref_flags")], out[k("ref_pointFeat")] = after[:, 0].astype(np.uint8), after[:, 1:].copy()
     assert o[0] == len(raw)
     return out
 

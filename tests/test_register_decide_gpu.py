@@ -137,10 +137,10 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
     dev = torch.device("cuda:0")
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
     s_ = torch.cuda.current_stream().cuda_stream
-    att_total = diff_total = dyn_total = 0
+    att_total = diff_total = dyn_total = merged_total = 0
     for sc in range(int(g["n_scenes"])):
         S = _decide_scene(g, sc)
-        want = single_pass_registration(S)
+        want = None if S["with_merge"] else single_pass_registration(S)     # (scenes 5, 6: bMerge == true, the step-for-step mode only)
         nC, N, nP, Hh = S["nC"], S["N"], S["nP"], S["hR"].shape[1]
         cur = int(g[f"s{sc}_dims"][4])
         th = TrackHistory(nC, N, Hh + 3)
@@ -180,23 +180,29 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
                                        dist=out["dist"].data_ptr(), flags=out["flags"].data_ptr(),
                                        **(dict(mapFlags=dfl.data_ptr(), maxDistDynamic=4 * S["pv"]) if S["with_dyn"] else {}))])
         kinds = 3 if S["with_dyn"] else 1     # scenes 3, 4: the certainly dynamic points behind the static ones (curDynamicPointsRegInGroup)
-        register_search_passes_dev(s_, rc, N, S["W"], S["H"], passes)
         dmerge = torch.zeros((nP, nC), dtype=torch.uint8, device=dev)
-        th.register_mergability_dev(s_, cams, nP, dM.data_ptr(), dcov.data_ptr(), out["slot"].data_ptr(), S["pv"], dmerge.data_ptr())
         datt, dreg = torch.zeros((nP, nC), dtype=torch.uint8, device=dev), torch.zeros(nP, dtype=torch.uint8, device=dev)
         dscr = torch.zeros(register_decide_scratch_bytes(nC, N, nP), dtype=torch.uint8, device=dev)
         dcnt = torch.zeros(4, dtype=torch.int32, device=dev)
-        register_decide_static_dev(s_, nC, N, nP, 0, out["slot"].data_ptr(), out["flags"].data_ptr(), dmerge.data_ptr(), dfl.data_ptr(), dpf.data_ptr(),
-                                   [ds2m[c].data_ptr() for c in range(nC)], datt.data_ptr(), dreg.data_ptr(), dscr.data_ptr(), dcnt.data_ptr(), n_sweeps=4,
-                                   kinds=kinds)
-        th.refine_map_points_dev(s_, cams, dpf.data_ptr(), nP, dM.data_ptr(), dcov.data_ptr(), S["pv"], d_select=dreg.data_ptr())
-        torch.cuda.synchronize()
-        assert dcnt.cpu().tolist()[3] == 1                                   # the sweeps converged
-        assert np.array_equal(out["slot"].cpu().numpy(), want["res"]["slot"]) and np.array_equal(dmerge.cpu().numpy(), want["merge"])
-        assert np.array_equal(ds2m.cpu().numpy(), want["s2m"]) and np.array_equal(dpf.cpu().numpy(), want["pf"])
-        assert np.array_equal(dreg.cpu().numpy(), want["reg"]) and np.array_equal(dM.cpu().numpy(), want["M"]) and np.array_equal(dcov.cpu().numpy(), want["cov"])
-        att_total += int((S["ref_s2m"] != S["s2m"]).sum())
-        diff_total += int((ds2m.cpu().numpy() != S["ref_s2m"]).sum())
+        dmscr = torch.zeros(nP, dtype=torch.uint8, device=dev)
+        if want is not None:
+            register_search_passes_dev(s_, rc, N, S["W"], S["H"], passes)
+            dmerge = torch.zeros((nP, nC), dtype=torch.uint8, device=dev)
+            th.register_mergability_dev(s_, cams, nP, dM.data_ptr(), dcov.data_ptr(), out["slot"].data_ptr(), S["pv"], dmerge.data_ptr())
+            datt, dreg = torch.zeros((nP, nC), dtype=torch.uint8, device=dev), torch.zeros(nP, dtype=torch.uint8, device=dev)
+            dscr = torch.zeros(register_decide_scratch_bytes(nC, N, nP), dtype=torch.uint8, device=dev)
+            dcnt = torch.zeros(4, dtype=torch.int32, device=dev)
+            register_decide_static_dev(s_, nC, N, nP, 0, out["slot"].data_ptr(), out["flags"].data_ptr(), dmerge.data_ptr(), dfl.data_ptr(), dpf.data_ptr(),
+                                       [ds2m[c].data_ptr() for c in range(nC)], datt.data_ptr(), dreg.data_ptr(), dscr.data_ptr(), dcnt.data_ptr(), n_sweeps=4,
+                                       kinds=kinds)
+            th.refine_map_points_dev(s_, cams, dpf.data_ptr(), nP, dM.data_ptr(), dcov.data_ptr(), S["pv"], d_select=dreg.data_ptr())
+            torch.cuda.synchronize()
+            assert dcnt.cpu().tolist()[3] == 1                                   # the sweeps converged
+            assert np.array_equal(out["slot"].cpu().numpy(), want["res"]["slot"]) and np.array_equal(dmerge.cpu().numpy(), want["merge"])
+            assert np.array_equal(ds2m.cpu().numpy(), want["s2m"]) and np.array_equal(dpf.cpu().numpy(), want["pf"])
+            assert np.array_equal(dreg.cpu().numpy(), want["reg"]) and np.array_equal(dM.cpu().numpy(), want["M"]) and np.array_equal(dcov.cpu().numpy(), want["cov"])
+            att_total += int((S["ref_s2m"] != S["s2m"]).sum())
+            diff_total += int((ds2m.cpu().numpy() != S["ref_s2m"]).sum())
         # ---- the reference's run step for step (camera loop after camera loop, refine in between): IDENTICAL to the reference
         ds2m.copy_(d(S["s2m"])), dM.copy_(d(S["M"])), dcov.copy_(d(S["cov"])), dpf.copy_(d(S["pf"]))
         rounds = []
@@ -208,14 +214,22 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
         register_cur_static_sequential_dev(s_, th, cams, rc, N, S["W"], S["H"], passes, nP, out["slot"].data_ptr(), out["flags"].data_ptr(),
                                            dmerge.data_ptr(), dfl.data_ptr(), dpf.data_ptr(), [ds2m[c].data_ptr() for c in range(nC)], datt.data_ptr(),
                                            dreg.data_ptr(), dscr.data_ptr(), dM.data_ptr(), dcov.data_ptr(), S["pv"], d_counts=dcnt.data_ptr(),
-                                           after_loop=after_loop, with_dynamic=S["with_dyn"])
+                                           after_loop=after_loop, with_dynamic=S["with_dyn"], merge=S["with_merge"],
+                                           d_merge_scratch=dmscr.data_ptr())
         torch.cuda.synchronize()
-        assert len(rounds) == nC * (2 if S["with_dyn"] else 1) and all(r[3] == 1 for r in rounds)          # every loop's sweeps settled
+        assert len(rounds) == nC * (2 if S["with_dyn"] else 1)
+        assert all(r[3] == 1 for r in (rounds[nC:] if S["with_merge"] else rounds))          # every loop's sweeps settled
         assert np.array_equal(ds2m.cpu().numpy(), S["ref_s2m"]), f"scene {sc}: {int((ds2m.cpu().numpy() != S['ref_s2m']).sum())} owners differ"
         assert np.array_equal(dM.cpu().numpy(), S["ref_M"]) and np.array_equal(dcov.cpu().numpy(), S["ref_cov"])
+        assert np.array_equal(dfl.cpu().numpy(), S["ref_fl"]) and np.array_equal(dpf.cpu().numpy(), S["ref_pf"])
         assert sum(r[1] for r in rounds[:nC]) == S["ref_regged"] and sum(r[1] for r in rounds[nC:]) == S["ref_regged_dyn"]
-        assert sum(r[0] for r in rounds) == int((S["ref_s2m"] != S["s2m"]).sum())
+        if S["with_merge"]:    # bMerge == true: points unified through checkUnify on the device, as the reference's own run unified them
+            merged = int((((S["ref_fl"] & 2) != 0) & ((S["fl"] & 2) == 0)).sum())
+            assert sum(r[2] for r in rounds[:nC]) == merged > 10 and sum(r[3] for r in rounds[:nC]) >= merged
+            merged_total += merged
+        else:
+            assert sum(r[0] for r in rounds) == int((S["ref_s2m"] != S["s2m"]).sum())
         dyn_total += S["ref_regged_dyn"]
         th.close()
     assert 0 < diff_total <= 0.03 * att_total, (diff_total, att_total)
-    assert dyn_total > 30
+    assert dyn_total > 30 and merged_total > 40

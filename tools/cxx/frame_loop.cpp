@@ -356,6 +356,8 @@ int main(int argc, char** argv) {
     unsigned char* dRegged = dev_zeros<unsigned char>(nMap);
     void* dDecScratch = dev_zeros<unsigned char>(cs_register_decide_scratch_bytes(nCams, N, P_REG));
     int* dDecCnt = dev_zeros<int>(4);
+    int* dMergeCnt = dev_zeros<int>(4);
+    int nMergeFrames = 0;
     const double PIX = 10.0;  // Const::PIXEL_ERR_VAR, reference src/app/SL_GlobParam.cpp:37
     auto step = [&](int i, bool key) {
         const int f = order[i % orderLen], fn = order[(i + 1) % orderLen], b = i & 1;
@@ -434,9 +436,18 @@ int main(int argc, char** argv) {
         // staticCheckMergability of the current-static pass's candidates over their whole tracks (SL_CoSLAM.cpp:714-729, :768)
         CSCHK(cs_register_mergability_dev(hist, (void*)poseS, pu.data(), P_REG, dMap, dCov, reg[1].slot, PIX, dMergeable));
         // the decision (curStaticPointsRegInGroup, bMerge false: who attaches which feature), then refineMapPoint of the points that gained one
-        // currentMapPointsRegister's decisions: the certainly static points, behind them the certainly dynamic ones (kinds 3), one call
+        // currentMapPointsRegister's decisions: the certainly static points, behind them the certainly dynamic ones (kinds 3), one call;
+        // every 50th frame with bMerge (CoSLAMThread.cpp:117-118): the static points' walks one after the other, checkUnify at a conflict
+        int kinds = 3;
+        if (i % 50 == 0) {
+            CSCHK(cs_register_decide_merge_dev(hist, (void*)poseS, pu.data(), P_REG, 0, reg[1].slot, reg[1].flags, dMergeable, dMapFlags, dPf, dMap, dCov,
+                                               PIX, dAttached, dRegged, dDecScratch, dMergeCnt, /*onlyCam*/ -1));
+            CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
+            ++nMergeFrames;
+            kinds = 2;
+        }
         CSCHK(cs_register_decide_kinds_dev(dev, (void*)poseS, nCams, N, P_REG, 0, reg[1].slot, reg[1].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
-                                           dAttached, dRegged, dDecScratch, 3, dDecCnt, /*onlyCam*/ -1, /*kinds*/ 3));
+                                           dAttached, dRegged, dDecScratch, 3, dDecCnt, /*onlyCam*/ -1, kinds));
         CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
         // the tracker of frame i + 2 is released at the END of the frame's pose work (released right behind the hand-back it runs two frames
         // ahead and under more of the pose stream's kernels: -10 %, profiles/r04_ab_runs.txt)
@@ -551,9 +562,9 @@ int main(int argc, char** argv) {
            "\"intercam_lm_steps\": %d, \"intercam_cost\": %.6f, \"ncc_runs\": %d, \"joint_ba_from_window\": %s, \"joint_cameras\": %d, "
            "\"joint_points\": %d, \"joint_measurements\": %d, \"ba_lag\": %d, \"windows_applied_in_timed_region\": %d, \"apply_wait_errors\": %d, "
            "\"intercam_static_points\": %d, \"intercam_dynamic_points\": %d, \"map_points_at_start\": %d, \"map_points_in_use\": %d, "
-           "\"map_capacity\": %d, \"new_map_points_last_run\": %d, \"register_decisions_unsettled\": %s}\n",
+           "\"map_capacity\": %d, \"new_map_points_last_run\": %d, \"register_decisions_unsettled\": %s, \"bmerge_frames\": %d}\n",
            steps / dt, dt / steps * 1e3, steps, warmup, dtHost / steps * 1e3, camsPerLaunch, okAll ? "true" : "false", minLive,
            sj.nIterTotal, sj.cost, si.nIterTotal, si.cost, nccRuns, win ? "true" : "false", jC, jP, jO, baLag, nApplied - applied0,
-           cs_ba_output_wait_errors(bout), iS, iP - iS, nPts, mapCountNow, nMap, npCounts[0], decUnsettled ? "true" : "false");
+           cs_ba_output_wait_errors(bout), iS, iP - iS, nPts, mapCountNow, nMap, npCounts[0], decUnsettled ? "true" : "false", nMergeFrames);
     return 0;
 }
