@@ -346,7 +346,7 @@ int cs_register_search(int device, int nCams, const cs_register_cam* cams, int N
  * d_scratch: cs_register_decide_scratch_bytes; its LAST int is sticky: set to 1 by any call whose sweeps did not settle (the
  * decision then is not the sequential one), never cleared here -- zero the scratch once, read the word at the end of a run.  Not done here: the projections are those of the search as it ran (the reference
  * refines a point before the next camera's round of walks, :889-893), and the bMerge == true branch (every 50th frame: checkUnify on
- * a conflict, cs_check_unify_dev gives its verdicts when built). */
+ * a conflict) -- that one is cs_register_decide_merge_dev further down. */
 size_t cs_register_decide_scratch_bytes(int nCams, int N, int P);
 int cs_register_decide_static_dev(int device, void* hip_stream, int nCams, int N, int P, int mapBase, const int* d_slot, const int* d_flags,
                                   const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
