@@ -1012,8 +1012,11 @@ def main():
                            frames_whose_sweeps_did_not_settle=dec_counts[2],
                            merge=None if not hasattr(loop, "_dec") else dict(
                                every_frames=loop.cfg.merge_every, bmerge_frames=loop.n_merge_frames,
-                               **dict(zip(("features_attached", "points_registered", "points_unified_away", "check_unify_calls"),
-                                          (f"{v} (last bMerge frame)" for v in loop._dec["mcnt"].cpu().tolist())))),
+                               what="every 50th frame the static points' walks run with bMerge (CoSLAMThread.cpp:117-118): one after the other, "
+                                    "checkUnify at a feature of another static point, the two unified on a yes (cs_register_decide_merge_dev)",
+                               **dict(zip(("features_attached_last_bmerge_frame", "points_registered_last_bmerge_frame",
+                                           "points_unified_away_last_bmerge_frame", "check_unify_calls_last_bmerge_frame"),
+                                          loop._dec["mcnt"].cpu().tolist()))),
                            what="currentMapPointsRegister's decisions (bMerge false) -- curStaticPointsRegInGroup and, behind it, "
                                 "curDynamicPointsRegInGroup on the certainly dynamic points -- over the search + mergability tables of all cameras "
                                 "(cs_register_decide_kinds_dev, kinds 3: the sequential first-claimant rule resolved exactly), then refineMapPoint "
