@@ -120,6 +120,80 @@ def test_too_few_sweeps_are_reported_and_the_word_sticks(hip):
     assert g3["unsettled"] == 0
 
 
+def test_merge_walk_edge_cases(hip):
+    """cs_register_decide_merge_dev where nothing may happen: no point on any visiting list, every candidate owned by a point outside the
+    pass or by a dynamic / false one (no checkUnify is asked), an empty pass; and what is refused"""
+    import torch
+
+    from coslam_amd.poseupdate import TrackHistory
+
+    dev = torch.device("cuda:0")
+    s_ = torch.cuda.current_stream().cuda_stream
+    nC, N, P, H = 3, 64, 40, 4
+    th = TrackHistory(nC, N, H)
+    K = torch.tensor([500.0, 0, 320, 0, 500, 240, 0, 0, 1], dtype=torch.float64, device=dev)
+    iK = torch.linalg.inv(K.view(3, 3)).contiguous().view(9)
+    xy, st = torch.zeros((nC, 2 * N), dtype=torch.float64, device=dev), torch.zeros((nC, N), dtype=torch.int32, device=dev)
+    s2m = torch.full((nC, N), -1, dtype=torch.int32, device=dev)
+    span = torch.zeros((nC, 2 * N), dtype=torch.int32, device=dev)
+    stat, fl0 = torch.ones((nC, N), dtype=torch.uint8, device=dev), torch.zeros(P, dtype=torch.uint8, device=dev)
+    eye, zero = torch.eye(3, dtype=torch.float64, device=dev).reshape(1, 9).repeat(nC, 1).contiguous(), torch.zeros((nC, 3), dtype=torch.float64, device=dev)
+    cams = [dict(K=K.data_ptr(), iK=iK.data_ptr(), xy=xy[c].data_ptr(), state=st[c].data_ptr(), slot2map=s2m[c].data_ptr(), trackSpan=span[c].data_ptr(),
+                 isStatic=stat[c].data_ptr()) for c in range(nC)]
+    th.detect_dynamic_dev(s_, cams, eye.data_ptr(), zero.data_ptr(), P, fl0.data_ptr(), 7, minLen=1 << 30)
+    slot = torch.from_numpy(((np.arange(P)[:, None] + 7 * np.arange(nC)[None, :]) % N).astype(np.int32)).to(dev)   # (no two points share a candidate)
+    flags = torch.zeros((P, nC), dtype=torch.int32, device=dev)
+    merg = torch.ones((P, nC), dtype=torch.uint8, device=dev)
+    M, cov = torch.zeros((P, 3), dtype=torch.float64, device=dev), torch.zeros((P, 9), dtype=torch.float64, device=dev)
+    att, reg = torch.ones((P, nC), dtype=torch.uint8, device=dev), torch.ones(P, dtype=torch.uint8, device=dev)
+    scr, cnt = torch.zeros(P, dtype=torch.uint8, device=dev), torch.full((4,), 9, dtype=torch.int32, device=dev)
+
+    def run(mf, pf, owners, only_cam=-1):
+        d_mf, d_pf = torch.from_numpy(mf.copy()).to(dev), torch.from_numpy(pf.copy()).to(dev)
+        s2m.copy_(torch.from_numpy(owners))
+        th.register_decide_merge_dev(s_, cams, P, 0, slot.data_ptr(), flags.data_ptr(), merg.data_ptr(), d_mf.data_ptr(), d_pf.data_ptr(), M.data_ptr(),
+                                     cov.data_ptr(), 10.0, att.data_ptr(), reg.data_ptr(), scr.data_ptr(), cnt.data_ptr(), only_cam=only_cam)
+        torch.cuda.synchronize()
+        return d_mf.cpu().numpy(), d_pf.cpu().numpy(), s2m.cpu().numpy().copy(), cnt.cpu().tolist()
+
+    none = np.full((nC, N), -1, np.int32)
+    # (a) no point holds a feature of this frame anywhere: no visiting list
+    mf, pf = np.zeros(P, np.uint8), np.full((P, nC), -1, np.int32)
+    a = run(mf, pf, none)
+    assert a[3] == [0, 0, 0, 0] and np.array_equal(a[1], pf) and np.array_equal(a[2], none) and not att.any() and not reg.any()
+    # (b) every point on the lists, every candidate owned by a point OUTSIDE the pass (>= P), by a dynamic or by a false one: nothing is asked
+    pf2 = pf.copy()
+    pf2[:, 0] = np.arange(P) % N
+    mf2 = np.zeros(P, np.uint8)
+    mf2[1::3], mf2[2::3] = 1, 2
+    owners = np.full((nC, N), P + 5, np.int32)
+    owners[1, ::2], owners[2, ::2] = 1, 2            # (points 1 and 2: dynamic, false)
+    b = run(mf2, pf2, owners)
+    assert b[3] == [0, 0, 0, 0] and np.array_equal(b[0], mf2) and np.array_equal(b[1], pf2) and np.array_equal(b[2], owners)
+    # (c) unmapped, mergeable candidates: attached by the first walk that reaches them, one camera's loop at a time
+    c0 = run(np.zeros(P, np.uint8), pf2, none, only_cam=1)
+    assert c0[3] == [0, 0, 0, 0]                    # (nobody holds a feature in camera 1: its loop visits no one)
+    c1 = run(np.zeros(P, np.uint8), pf2, none, only_cam=0)
+    want_s2m, want_pf = none.copy(), pf2.copy()
+    sl = slot.cpu().numpy()
+    for p in range(P):
+        for i in range(1, nC):
+            if want_s2m[i, sl[p, i]] < 0:
+                want_s2m[i, sl[p, i]], want_pf[p, i] = p, sl[p, i]
+    assert np.array_equal(c1[2], want_s2m) and np.array_equal(c1[1], want_pf) and c1[3][0] == int((want_pf != pf2).sum()) and c1[3][2] == 0
+    # (d) an empty pass, and what is refused
+    th.register_decide_merge_dev(s_, cams, 0, 0, 0, 0, 0, 0, 0, 0, 0, 10.0, 0, 0, 0, cnt.data_ptr())     # (P = 0: counts zeroed, nothing launched)
+    torch.cuda.synchronize()
+    assert cnt.cpu().tolist() == [0, 0, 0, 0]
+    with pytest.raises(Exception):
+        th.register_decide_merge_dev(s_, cams, P, 0, slot.data_ptr(), flags.data_ptr(), merg.data_ptr(), 0, 0, M.data_ptr(), cov.data_ptr(), 10.0,
+                                     att.data_ptr(), reg.data_ptr(), scr.data_ptr(), cnt.data_ptr())
+    with pytest.raises(Exception):
+        th.register_decide_merge_dev(s_, cams, P, 0, slot.data_ptr(), flags.data_ptr(), merg.data_ptr(), fl0.data_ptr(), slot.data_ptr(), M.data_ptr(),
+                                     cov.data_ptr(), 10.0, att.data_ptr(), reg.data_ptr(), scr.data_ptr(), cnt.data_ptr(), only_cam=nC)
+    th.close()
+
+
 def test_device_registration_on_the_reference_golden_scenes(hip):
     """The frame loop's registration of the current static points -- cs_register_search_passes_dev, cs_register_mergability_dev,
     cs_register_decide_static_dev, cs_refine_map_points_dev, once each -- on the scenes of tests/golden/decide_golden.npz (the
