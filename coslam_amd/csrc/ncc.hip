@@ -274,13 +274,57 @@ struct NcJobs {
     NcArgs job[NC_MAX_JOBS];  // blockIdx.z = camera pair of a group launch (cs_ncc_epi_pairs_group_dev)
 };
 constexpr int NC_CT = 4;   // 64-column tiles a workgroup walks: the rows' operands and constants are loaded once for 256 columns
+// The column side of a tile goes through LDS: the 64 columns' blocks are 8 KB back to back in memory -- 256 threads x two 16-byte loads,
+// shifted to signed bytes on the way in -- and their constants (x, y, A, C, valid) by the first 64 threads; the tile after it is fetched into
+// registers while this one is multiplied and tested, then stored into the other buffer.  Until r04 every wave read its MFMA operands
+// and the epilogue's constants straight from global memory: 36 short loads per lane and tile, 0.73 of the wave cycles waiting at one
+// workgroup per compute unit beside the tracker (profiles/r04_ab_runs.txt).
+constexpr int NC_TP = 136;                         // LDS pitch of a staged block row (128 + 8: consecutive rows on different banks)
+constexpr int NC_TILE_BYTES = 64 * NC_TP + 64 * 40;   // blocks | x[64] | y[64] | A[64] | C[64] (doubles) | valid[64] (ints)
+struct NcColRegs {   // one thread's share of a tile on its way from global memory to LDS
+    nc_i32x4 q0, q1;
+    double x, y, A, C;
+    int valid;
+};
+__device__ __forceinline__ void nc_tile_fetch(const NcSide& S2, int j0, int N, int tid, NcColRegs& r) {
+    // thread t: bytes 32 t .. 32 t + 31 of the tile's 8 KB = row t / 4, quarter t % 4; rows beyond N are zeros
+    const int row = j0 + (tid >> 2);
+    r.q0 = r.q1 = (nc_i32x4){0, 0, 0, 0};
+    if (row < N) {
+        const nc_i32x4* src = (const nc_i32x4*)(S2.blocks + (size_t)row * NC_PITCH + 32 * (tid & 3));
+        r.q0 = src[0], r.q1 = src[1];
+        const int sh = (int)0x80808080;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.q0[k] ^= sh, r.q1[k] ^= sh;   // x ^ 0x80 == x - 128 in two's complement
+    }
+    r.x = r.y = r.A = r.C = 0.0, r.valid = 0;
+    if (tid < 64 && j0 + tid < N) {
+        const int j = j0 + tid;
+        r.x = S2.x[j], r.y = S2.y[j], r.A = S2.abc[4 * (size_t)j], r.C = S2.abc[4 * (size_t)j + 2], r.valid = S2.valid[j];
+    }
+}
+__device__ __forceinline__ void nc_tile_store(unsigned char* buf, int tid, const NcColRegs& r) {
+    nc_i32x4* dst = (nc_i32x4*)(buf + (tid >> 2) * NC_TP + 32 * (tid & 3));   // (136 t / 4 + 32 (t % 4): 8-byte aligned -> two 8-byte halves each)
+    long* d8 = (long*)dst;
+    const long* s8 = (const long*)&r.q0;
+    d8[0] = s8[0], d8[1] = s8[1];
+    s8 = (const long*)&r.q1;
+    d8[2] = s8[0], d8[3] = s8[1];
+    if (tid < 64) {
+        double* c = (double*)(buf + 64 * NC_TP);
+        c[tid] = r.x, c[64 + tid] = r.y, c[128 + tid] = r.A, c[192 + tid] = r.C;
+        ((int*)(c + 256))[tid] = r.valid;
+    }
+}
 template <bool SPARSE>
 __global__ __launch_bounds__(256) void k_ncc_epi_mat(NcJobs J) {
+    __shared__ __attribute__((aligned(16))) unsigned char sTile[2][NC_TILE_BYTES];
     const NcArgs& A = J.job[blockIdx.z];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int M = A.s1.n, N = A.s2.n;
+    if ((int)blockIdx.y * 64 >= M || (int)blockIdx.x * NC_CT * 64 >= N) return;   // (uniform over the workgroup)
     const int i0 = blockIdx.y * 64 + 16 * wv;  // this wave's 16 rows (features of camera 1)
-    if (i0 >= M) return;
+    const bool rowsIn = i0 < M;                // (a wave past the last row still helps staging the columns)
     const int lr = lane & 15, lk = lane >> 4;  // MFMA operand layout: row / column lr, k-chunk lk (8 bytes)
     // the rows' side, once: the four k-chunks of the A operand, and what the epilogue needs of rows 4 lk .. 4 lk + 3
     long a[4];
@@ -299,77 +343,91 @@ __global__ __launch_bounds__(256) void k_ncc_epi_mat(NcJobs J) {
         v1[r] = in ? A.s1.valid[i] : 0;
         s1[r] = (int)A1[r] - NC_LEN * 128;  // sum (I1 - 128)
     }
+    const int jBase = blockIdx.x * NC_CT * 64;
+    NcColRegs cr;
+    nc_tile_fetch(A.s2, jBase, N, tid, cr);
+    nc_tile_store(sTile[0], tid, cr);
+    __syncthreads();
     for (int ct = 0; ct < NC_CT; ++ct) {
-        const int j0 = (blockIdx.x * NC_CT + ct) * 64;  // the tile's 64 columns (features of camera 2)
-        if (j0 >= N) break;
-        nc_i32x4 acc[4];
+        const int j0 = jBase + ct * 64;  // the tile's 64 columns (features of camera 2)
+        if (j0 >= N) break;              // (uniform)
+        const bool more = ct + 1 < NC_CT && j0 + 64 < N;
+        if (more) nc_tile_fetch(A.s2, j0 + 64, N, tid, cr);   // in flight while this tile is worked on
+        const unsigned char* tile = sTile[ct & 1];
+        const double* cc = (const double*)(tile + 64 * NC_TP);
+        const int* cv = (const int*)(cc + 256);
+        if (rowsIn) {
+            nc_i32x4 acc[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = (nc_i32x4){0, 0, 0, 0};
+            for (int t = 0; t < 4; ++t) acc[t] = (nc_i32x4){0, 0, 0, 0};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int off = 32 * ks + 8 * lk;
-            long b[4];
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = 32 * ks + 8 * lk;
+                long b[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) b[t] = nc_row_chunk(A.s2.blocks, j0 + 16 * t + lr, N, off);
+                for (int t = 0; t < 4; ++t) b[t] = *(const long*)(tile + (16 * t + lr) * NC_TP + off);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a[ks], b[t], acc[t], 0, 0, 0);
-        }
-        // ---- epilogue: lane holds rows 4 lk .. 4 lk + 3 of column lr of every 16 x 16 tile ----
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a[ks], b[t], acc[t], 0, 0, 0);
+            }
+            // ---- epilogue: lane holds rows 4 lk .. 4 lk + 3 of column lr of every 16 x 16 tile ----
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int j = j0 + 16 * t + lr;
-            if (j >= N) continue;
-            const double bx = A.s2.x[j], by = A.s2.y[j];
-            const double A2 = A.s2.abc[4 * (size_t)j], C2 = A.s2.abc[4 * (size_t)j + 2];
-            const int v2 = A.s2.valid[j];
-            const int s2 = (int)A2 - NC_LEN * 128;
-            // epipolarError(F, p1, p2): the line of p2
-            const double l0 = (A.F[0] * bx + A.F[1] * by) + A.F[2];
-            const double l1 = (A.F[3] * bx + A.F[4] * by) + A.F[5];
-            const double l2 = (A.F[6] * bx + A.F[7] * by) + A.F[8];
-            const double nn = sqrt(l0 * l0 + l1 * l1);
-            const double den = nn > 0 ? nn : 1.0;
-            // |l . p1| / den <= epiMax is decided without the division wherever it is not close: a numerator beyond epiMax den (1 + 1e-12)
-            // fails for certain (the margin is 10^4 roundings wide), and a pair that fails writes wNone whatever its quotient is.  Only
-            // the few pairs near or inside the band pay the IEEE division (~20 instructions of the ~26 this test used to cost per pair).
-            const double numMax = (A.epiMax * den) * (1.0 + 1e-12);
+            for (int t = 0; t < 4; ++t) {
+                const int jl = 16 * t + lr, j = j0 + jl;
+                if (j >= N) continue;
+                const double bx = cc[jl], by = cc[64 + jl];
+                const double A2 = cc[128 + jl], C2 = cc[192 + jl];
+                const int v2 = cv[jl];
+                const int s2 = (int)A2 - NC_LEN * 128;
+                // epipolarError(F, p1, p2): the line of p2
+                const double l0 = (A.F[0] * bx + A.F[1] * by) + A.F[2];
+                const double l1 = (A.F[3] * bx + A.F[4] * by) + A.F[5];
+                const double l2 = (A.F[6] * bx + A.F[7] * by) + A.F[8];
+                const double nn = sqrt(l0 * l0 + l1 * l1);
+                const double den = nn > 0 ? nn : 1.0;
+                // |l . p1| / den <= epiMax is decided without the division wherever it is not close: a numerator beyond epiMax den (1 + 1e-12)
+                // fails for certain (the margin is 10^4 roundings wide), and a pair that fails writes wNone whatever its quotient is.  Only
+                // the few pairs near or inside the band pay the IEEE division (~20 instructions of the ~26 this test used to cost per pair).
+                const double numMax = (A.epiMax * den) * (1.0 + 1e-12);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + 4 * lk + r;
-                if (i >= M) continue;
-                const double num = fabs((l0 * x1[r] + l1 * y1[r]) + l2);
-                double e = A.wNone, c = A.wNone;
-                bool pass = false;
-                double epiErr = 0;
-                bool near = v1[r] && v2 && !(num > numMax);   // (NaN stays in: the exact test below decides as it always did)
-                if (near) {
-                    epiErr = num / den;                        // SL_FeatureMatching.cpp:24-25
-                    near = epiErr <= A.epiMax;                 // :26
-                }
-                if (near) {
-                    const int d = acc[t][r] + 128 * s1[r] + 128 * s2 + NC_LEN * 128 * 128;  // sum I1 I2, exact
-                    const double ncc = (((double)NC_LEN * (double)d - A1[r] * A2) * C1[r]) * C2;  // SL_NCCBlock.cpp:263
-                    if (ncc >= A.nccMin) {                                          // :29-31
-                        e = epiErr;
-                        c = ncc;
-                        pass = true;
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + 4 * lk + r;
+                    if (i >= M) continue;
+                    const double num = fabs((l0 * x1[r] + l1 * y1[r]) + l2);
+                    double e = A.wNone, c = A.wNone;
+                    bool pass = false;
+                    double epiErr = 0;
+                    bool near = v1[r] && v2 && !(num > numMax);   // (NaN stays in: the exact test below decides as it always did)
+                    if (near) {
+                        epiErr = num / den;                        // SL_FeatureMatching.cpp:24-25
+                        near = epiErr <= A.epiMax;                 // :26
                     }
-                }
-                if (SPARSE) {
-                    if (pass) {
-                        const int at = atomicAdd(A.pairCount, 1);
-                        if (at < A.pairCap) {
-                            cs_ncc_pair q;
-                            q.i = i, q.j = j, q.epi = e, q.ncc = c;
-                            A.pairs[at] = q;
+                    if (near) {
+                        const int d = acc[t][r] + 128 * s1[r] + 128 * s2 + NC_LEN * 128 * 128;  // sum I1 I2, exact
+                        const double ncc = (((double)NC_LEN * (double)d - A1[r] * A2) * C1[r]) * C2;  // SL_NCCBlock.cpp:263
+                        if (ncc >= A.nccMin) {                                          // :29-31
+                            e = epiErr;
+                            c = ncc;
+                            pass = true;
                         }
                     }
-                } else {
-                    A.epiMat[(size_t)i * N + j] = e;
-                    A.nccMat[(size_t)i * N + j] = c;
+                    if (SPARSE) {
+                        if (pass) {
+                            const int at = atomicAdd(A.pairCount, 1);
+                            if (at < A.pairCap) {
+                                cs_ncc_pair q;
+                                q.i = i, q.j = j, q.epi = e, q.ncc = c;
+                                A.pairs[at] = q;
+                            }
+                        }
+                    } else {
+                        A.epiMat[(size_t)i * N + j] = e;
+                        A.nccMat[(size_t)i * N + j] = c;
+                    }
                 }
             }
         }
+        if (more) nc_tile_store(sTile[(ct + 1) & 1], tid, cr);
+        __syncthreads();
     }
 }
 
