@@ -127,6 +127,38 @@ int main() {
     printf("KLT_SequenceTracker::redetect + advanceFrame (640x480, 2000 slots, host image in / dest[] out): %.1f us/frame, %d live\n",
            (now_us() - t) / NF, n);
 
+    {   // the same through GPUKLT::next's two halves (cs_klt_redetect_async_h / cs_klt_fetch): 8 cameras, one handle each, every camera's
+        // frame in flight before the first result is waited for -- what a host loop over the cameras costs when it does not serialise them
+        const int NC8 = 8;
+        cs_klt_config c8;
+        cs_klt_config_default(&c8);
+        c8.nIterations = 10, c8.nLevels = L, c8.levelSkip = 1, c8.windowWidth = 7, c8.trackWithGain = 1;
+        c8.minCornerness = 3000.0f, c8.convergenceThreshold = 1.0f, c8.SSD_Threshold = 20000.0f, c8.minDistance = 4;
+        cs_klt* k8[NC8];
+        std::vector<std::vector<cs_klt_feature> > d8(NC8, std::vector<cs_klt_feature>(fw * fh));
+        int n8 = 0;
+        bool ok8 = true;
+        for (int c = 0; c < NC8; ++c) {
+            k8[c] = cs_klt_create(&c8, 0, 0);
+            ok8 = ok8 && k8[c] && cs_klt_allocate(k8[c], W, H, L, fw, fh, 0, 0) == 0 && cs_klt_detect(k8[c], frames[c % 32].data(), &n8, d8[c].data()) == 0 &&
+                  cs_klt_advance(k8[c]) == 0;
+        }
+        auto frame8 = [&](int i) {
+            for (int c = 0; c < NC8 && ok8; ++c) ok8 = cs_klt_redetect_async_h(k8[c], frames[(i + c) % 32].data()) == 0;
+            for (int c = 0; c < NC8 && ok8; ++c) ok8 = cs_klt_fetch(k8[c], &n8, d8[c].data()) == 0 && cs_klt_advance(k8[c]) == 0;
+        };
+        for (int i = 1; i < 20 && ok8; ++i) frame8(i);
+        double t8 = now_us();
+        for (int i = 0; i < NF && ok8; ++i) frame8(20 + i);
+        if (ok8)
+            printf("8 cameras through cs_klt_redetect_async_h + cs_klt_fetch (host images in / dest[] out, all cameras in flight): %.1f us per 8-camera frame "
+                   "= %.0f frames/s, %d live in the last camera\n", (now_us() - t8) / NF, 1e6 * NF / (now_us() - t8), n8);
+        else
+            printf("8-camera async host form: FAILED (%s)\n", cs_last_error());
+        for (int c = 0; c < NC8; ++c)
+            if (k8[c]) cs_klt_destroy(k8[c]);
+    }
+
     // intraCamEstimate
     double K[9] = {524.8, 0, 320, 0, 524.8, 240, 0, 0, 1}, R0[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t0[3] = {0.02, -0.01, 0.03};
     const int NP = 192;
