@@ -442,6 +442,8 @@ def main():
     ap.add_argument("--no-pose-update", action="store_true", help="diagnostic: skip the gate / dynamic test / BA write-back (not a valid bench line)")
     ap.add_argument("--no-mergability", action="store_true", help="diagnostic: skip staticCheckMergability (not a valid bench line)")
     ap.add_argument("--no-decide", action="store_true", help="diagnostic: skip the registration decision + refineMapPoint (not a valid bench line)")
+    ap.add_argument("--hist", type=int, default=64, help="frames of track / pose history the walks see (the reference walks whole tracks; "
+                    "a candidate whose track is longer is not judged and not attached: DESIGN.md 8.2 item 3)")
     ap.add_argument("--merge-every", type=int, default=50, help="bMerge frames: every n-th frame the static points' walks may unify two points "
                     "(the reference: 50, CoSLAMThread.cpp:117-118); 0: never (diagnostic)")
     ap.add_argument("--no-ncc", action="store_true", help="diagnostic: skip the inter-camera NCC matching leg (not a valid bench line)")
@@ -520,7 +522,7 @@ def main():
                      key_every=max(ke, 1), ba_lag=args.ba_lag, p_reg=P_REG, klt_cams_per_launch=max(args.klt_cams_per_launch, 0),
                      prefetch=os.environ.get("BENCH_PREFETCH", "1") != "0", with_pose_update=not args.no_pose_update,
                      with_classify=not args.no_classify, with_register=not args.no_register, with_mergability=not args.no_mergability,
-                     with_ncc=not args.no_ncc, with_decide=not args.no_decide, merge_every=args.merge_every, with_joint=args.only_solve != "intercam", with_intercam=args.only_solve != "joint",
+                     with_ncc=not args.no_ncc, with_decide=not args.no_decide, merge_every=args.merge_every, hist=args.hist, with_joint=args.only_solve != "intercam", with_intercam=args.only_solve != "joint",
                      native_comm=bool(args.native_comm),
                      klt_fused=os.environ.get("BENCH_FORCE_DEVICE") is None or world == 1)   # (ranks sharing ONE GPU: test hook)
     try:
