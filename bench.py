@@ -1006,8 +1006,8 @@ def main():
                         "already_attached": int((reg_out[1]["slot"][:, lc] == -1).sum().item()),
                         "current_static_mergeable_over_the_whole_track": None if loop.pose_upd is None else int((loop.d_mergeable[:, lc] == 1).sum().item()),
                         "current_static_tracks_longer_than_the_history": None if loop.pose_upd is None else int((loop.d_mergeable[:, lc] == 2).sum().item()),
-                        "history_note": "a candidate whose track is longer than the 64-frame history and passes on every frame held is reported "
-                                        "as unjudged (2) and NOT attached: the reference walks the whole track"},
+                        "history_note": "a candidate whose track is longer than the history (--hist, 64 frames) is reported as unjudged (2), not "
+                                        "walked and NOT attached: the reference walks the whole track"},
                        "register_decision": None if dec_counts is None else dict(zip(
                            ("features_attached_last_frame", "points_regged_last_frame", "sweeps_last_frame", "converged"), dec_counts[0]),
                            points_refined_last_frame=dec_counts[1],

@@ -357,8 +357,11 @@ __global__ __launch_bounds__(256) void k_register_mergability(MgArgs A) {
         const int f1 = C.trackSpan[s], f2 = C.trackSpan[N + s];
         const int len = f1 >= 0 ? f2 - f1 + 1 : 0;
         const int depth = len < A.nHist ? len : A.nHist;
-        cut = len > A.nHist;   // the reference walks the whole preFrame chain: the frames the ring no longer holds stay unjudged
-        for (int j = r; j < depth && !fail; j += MG_LPC) {
+        // the reference walks the whole preFrame chain: a track longer than the ring cannot be judged (verdict 2, never attached) -- and
+        // is not walked at all: whatever the frames the ring holds say, nothing reads it (in a long run that is most candidates: old,
+        // unmapped tracks; the walk over them was most of this kernel's time)
+        cut = len > A.nHist;
+        for (int j = r; j < depth && !fail && !cut; j += MG_LPC) {
             const double* R = mg_pose + 12 * j;
             const double* t = R + 9;
             const int rs = (A.head - j + H) % H;
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(256) void k_register_mergability(MgArgs A) {
     const unsigned long long b = __builtin_amdgcn_ballot_w64(fail);
     if (live && r == 0) {
         const bool anyFail = ((b >> (MG_LPC * g)) & ((1ull << MG_LPC) - 1ull)) != 0ull;
-        A.out[(size_t)p * A.nCams + c] = s < 0 ? 255 : (anyFail ? 0 : (cut ? 2 : 1));
+        A.out[(size_t)p * A.nCams + c] = s < 0 ? 255 : (cut ? 2 : (anyFail ? 0 : 1));
     }
 }
 

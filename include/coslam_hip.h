@@ -446,8 +446,8 @@ int cs_pose_update_frame_dev(cs_track_history* h, void* hip_stream, const cs_pos
  * projection under the pose of its own frame (covariance J cov J^T + pixelErrVar^2 I).  d_slot: the P x nCams candidate table of
  * cs_register_search_dev (entries < 0: no candidate); the tracks' past pixels and the frames' poses come from the history h, whose
  * newest entry must be THIS frame (what cs_pose_update_frame_dev / cs_detect_dynamic_dev pushed); cams: K and trackSpan of every
- * camera.  d_mergeable [P x nCams]: 1 mergeable, 0 not, 255 no candidate, 2 = every frame the history holds passes but the track is
- * LONGER than the history (the reference walks the whole chain: the older frames stay unjudged -- a caller that must not be more
+ * camera.  d_mergeable [P x nCams]: 1 mergeable, 0 not, 255 no candidate, 2 = the track is LONGER than the history (the reference
+ * walks the whole chain: the older frames cannot be judged, so the held ones are not looked at either -- a caller that must not be more
  * permissive than the reference treats 2 as 0, as cs_register_decide_static_dev does; or sizes the history for its tracks).  (The search's own flag bit 2 is the first term of this
  * walk -- this frame only.)  What the registration loops do with a mergeable candidate -- pointer updates, refineMapPoint,
  * checkUnify -- stays with the caller; compareFeaturePt, which they also call, returns true whatever its NCC score is (:546-558). */

@@ -204,10 +204,9 @@ void org_register_mergability_cam(const double K[9], int nHist, const double* hi
             continue;
         }
         const int len = trackSpan[s] >= 0 ? trackSpan[N + s] - trackSpan[s] + 1 : 0;
-        int v = org_static_check_mergability(K, nHist, histR, histT, histXY, N, s, len, Ms + 3 * (size_t)p, covs + 9 * (size_t)p, pixelVar);
-        /* a track longer than the history: the reference walks the whole preFrame chain, the frames beyond the history stay unjudged ->
-         * "2" instead of "1" (cs_register_mergability_dev's convention: not more permissive than the reference when read as 0) */
-        if (v == 1 && len > nHist) v = 2;
+        /* a track longer than the history: the reference walks the whole preFrame chain, the frames beyond the history cannot be judged ->
+         * "2" whatever the held frames say (cs_register_mergability_dev's convention: never attached, not walked) */
+        int v = len > nHist ? 2 : org_static_check_mergability(K, nHist, histR, histT, histXY, N, s, len, Ms + 3 * (size_t)p, covs + 9 * (size_t)p, pixelVar);
         out[(size_t)p * slotStride] = (unsigned char)v;
     }
 }

@@ -228,8 +228,8 @@ def test_register_mergability_walks_the_candidates_tracks_like_the_oracle():
                     continue
                 ln = span[N + sl] - span[sl] + 1 if span[sl] >= 0 else 0
                 ok = oracle.static_check_mergability(sc.K, hR, hT, hXY, sl, ln, sc.map0[m], sc.cov0[m], sigma)
-                # (a track longer than the ring: what the ring holds passes, the older frames stay unjudged -> 2, not 1)
-                want[m, c] = (2 if ln > H else 1) if ok else 0
+                # (a track longer than the ring cannot be judged: 2 whatever the held frames say, never attached)
+                want[m, c] = 2 if ln > H else (1 if ok else 0)
         assert np.array_equal(got, want), sigma
         n_true[sigma] = (int(((want == 1) | (want == 2)).sum()), int((want == 0).sum()))
         assert (want == 1).sum() > 10 and (want == 2).sum() > 10
