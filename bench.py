@@ -602,7 +602,7 @@ def main():
     wis = [w.worker_stats() for w in loop.ic_wss]
     wi = [sum(w[0] for w in wis), sum(w[1] for w in wis), 0, max(w[3] for w in wis)]
     applied_timed = loop.applied - applied0
-    dec_counts = None if not hasattr(loop, "_dec") else (loop._dec["cnt"].cpu().tolist(), int(loop._dec["ref_cnt"].item()),
+    dec_counts = None if not hasattr(loop, "_dec") else (loop._dec["cnt"].cpu().tolist(), int(loop._dec["cnt"][1].item()),   # (every registered point is refined: the count of one is the other's)
                                                          bool(loop._dec["scr"][-4:].view(torch.int32).item()))
     digest = loop.digest() if os.environ.get("BENCH_STATE_DIGEST") else None
     if loop._timing is not None:

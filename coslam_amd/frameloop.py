@@ -578,7 +578,7 @@ class FrameLoop:
                                                     self.d_map.data_ptr(), self.d_cov.data_ptr(), PIXEL_ERR_VAR, D["att"].data_ptr(),
                                                     D["reg"].data_ptr(), D["scr"].data_ptr(), D["mcnt"].data_ptr())
             self.pose_upd.refine_map_points_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
-                                                PIXEL_ERR_VAR, d_select=D["reg"].data_ptr(), d_count=D["ref_cnt"].data_ptr())
+                                                PIXEL_ERR_VAR, d_select=D["reg"].data_ptr())   # (no count asked for: that would be one more launch, and it is counts[1])
             self.n_merge_frames += 1
             kinds = 2
         D["s2m"] = register_decide_static_dev(ps, NA, cfg.n_feat, cfg.p_reg, 0, self.reg_out[1]["slot"].data_ptr(), self.reg_out[1]["flags"].data_ptr(),
@@ -588,7 +588,7 @@ class FrameLoop:
                                               kinds=kinds)   # curStaticPointsRegInGroup and curDynamicPointsRegInGroup (currentMapPointsRegister, :834-853)
         # (d_regged covers the pass's P points = the first P map points; the rest of the select mask stays 0)
         self.pose_upd.refine_map_points_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
-                                            PIXEL_ERR_VAR, d_select=D["reg"].data_ptr(), d_count=D["ref_cnt"].data_ptr())
+                                            PIXEL_ERR_VAR, d_select=D["reg"].data_ptr())   # (no count asked for: that would be one more launch, and it is counts[1])
 
     def _gather_candidates(self):
         """the own cameras' columns of the current-static pass's candidate tables to every rank (18 KB per camera: latency-bound, ONE
