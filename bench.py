@@ -284,6 +284,9 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
 
     Kc = sc.K
 
+    reg_slot, reg_flags = np.full((P_REG, N_CAMS), -1, np.int32), np.zeros((P_REG, N_CAMS), np.int32)
+    reg_merge, reg_pf = np.zeros((P_REG, N_CAMS), np.uint8), np.full((P_REG, N_CAMS), -1, np.int32)
+
     def reg_step(c):
         # activeMapPointsRegister + currentMapPointsRegister, search step, this camera's column of the tables
         one = lambda a: [a]  # noqa: E731
@@ -292,10 +295,28 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
         pf = oracle.point_features(st[c], s2m[c], P_REG).reshape(P_REG, 1)
         rs = oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), map_pts[:P_REG],
                                     cov[:P_REG], pf, PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)
+        reg_slot[:, c], reg_flags[:, c], reg_pf[:, c] = rs["slot"][:, 0], rs["flags"][:, 0], pf[:, 0]
         h = hist[c]
+        reg_merge[:, c] = 0
         if h["R"]:   # staticCheckMergability of the candidates over their whole tracks (the history as of the previous frame's pose update)
-            oracle.register_mergability_cam(Kc, np.stack(h["R"]), np.stack(h["t"]), np.stack(h["xy"]), tl[c], map_pts[:P_REG], cov[:P_REG],
-                                            rs["slot"][:, 0], PIXEL_ERR_VAR)
+            reg_merge[:, c] = oracle.register_mergability_cam(Kc, np.stack(h["R"]), np.stack(h["t"]), np.stack(h["xy"]), tl[c], map_pts[:P_REG],
+                                                              cov[:P_REG], rs["slot"][:, 0], PIXEL_ERR_VAR)
+
+    def decide_all():
+        # currentMapPointsRegister's decisions over the cameras' columns (org_register_decide: static points, then dynamic ones), then
+        # refineMapPoint of the points that gained a feature -- on the calling thread, behind the cameras' searches
+        s2m_all = np.ascontiguousarray(np.stack(s2m)).astype(np.int32)
+        pf_all = np.ascontiguousarray(reg_pf)
+        _, reg = oracle.register_decide_static_c(reg_slot, reg_flags, reg_merge, map_flags[:P_REG], pf_all, s2m_all, kinds=3)
+        if reg.any() and hist[0]["R"]:
+            for c in range(N_CAMS):
+                s2m[c][:] = s2m_all[c]
+            sel = np.zeros(len(map_pts), dtype=np.uint8)
+            sel[:P_REG] = reg
+            pf_map = np.ascontiguousarray(np.stack([oracle.point_features(st[c], s2m[c], len(sc.points)) for c in range(N_CAMS)], 1))
+            oracle.refine_map_points([Kc] * N_CAMS, [iK] * N_CAMS, np.stack([np.stack(h["R"]) for h in hist]), np.stack([np.stack(h["t"]) for h in hist]),
+                                     np.stack([np.stack(h["xy"]) for h in hist]), np.stack(tl), pf_map, map_pts, map_cov.reshape(-1, 9), PIXEL_ERR_VAR,
+                                     select=sel)
 
     # genNewMapPoints' NCC stage, every 4th frame like the GPU loop: getNCCBlocks of a camera's candidate features (with its thread),
     # getEpiNccMat of the consecutive camera pairs behind the cameras (the C restatements; the match / reconstruct tail and the
@@ -346,6 +367,8 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
     while True:
         f = order[(n + 1) % len(order)]
         in_threads(run_cams, range(N_CAMS), f, n + 1)
+        if with_register:
+            decide_all()
         pose_update_all(n + 1)
         if with_ncc and (n + 1) % 4 == 0:
             in_threads(lambda cs, f_: run_ncc(ncc_cam, cs, f_), range(N_CAMS), f)
@@ -934,8 +957,8 @@ def main():
                          f"{n1} frames on 1 thread in {dt1:.1f} s (oracle/: C restatement, gcc -O2); host has {cores} cores.  Legs: KLT, "
                          "hand-back, intra-camera pose, register search + mergability, pose update gate + dynamic test + classify, "
                          "NCC blocks + epipolar/NCC matrix every 4th frame, joint BA + pose graph + the update behind it + inter-camera BA per key frame; "
-                         "NOT in the CPU figure (restated in plain Python only): the registration decision, the new-map-point match / "
-                         "reconstruct tail",
+                         "the registration decision (C) + refineMapPoint; NOT in the CPU figure (restated in plain Python only): the new-map-point "
+                         "match / reconstruct tail",
                "value_1_thread": v1, "host_cores": cores}
 
     # ---- the same loop driven from C++ through the C-ABI only (north_star: "Host stays C++"): tools/cxx/frame_loop.cpp, its

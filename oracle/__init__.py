@@ -880,6 +880,21 @@ def register_decide_static(slot, flags, mergeable, mapFlags, pointFeat, slot2map
     return attached, regged
 
 
+def register_decide_static_c(slot, flags, mergeable, mapFlags, pointFeat, slot2map, map_base=0, kinds=1):
+    """org_register_decide: register_decide_static's walks in C (the CPU baseline's leg; checked against the Python restatement).
+    slot2map: ONE int32 array [nCams][N], updated in place like pointFeat.  Returns (attached, regged)."""
+    P, nC = slot.shape
+    N = slot2map.shape[1]
+    sl, fl = np.ascontiguousarray(slot, dtype=np.int32), np.ascontiguousarray(flags, dtype=np.int32)
+    mg, mf = np.ascontiguousarray(mergeable, dtype=np.uint8), np.ascontiguousarray(mapFlags, dtype=np.uint8)
+    assert pointFeat.dtype == np.int32 and pointFeat.flags.c_contiguous and slot2map.dtype == np.int32 and slot2map.flags.c_contiguous
+    att, reg = np.zeros((P, nC), dtype=np.uint8), np.zeros(P, dtype=np.uint8)
+    L = lib()
+    L.org_register_decide.restype = C.c_int
+    L.org_register_decide(P, nC, N, _p(sl), _p(fl), _p(mg), _p(mf), _p(pointFeat), _p(slot2map), int(map_base), int(kinds), _p(att), _p(reg))
+    return att, reg
+
+
 def register_cur_static_sequential(W, H, Ks, iKs, histR, histT, histXY, trackSpan, state, isStatic, slot2map, mapPts, mapCov, mapFlags,
                                    pointFeat, pixelVar, with_dynamic=False, merge=False):
     """CoSLAM::curStaticPointsRegInGroup (bMerge == false) AS THE REFERENCE RUNS IT (src/app/SL_CoSLAM.cpp:854-898, 731-830), one point after

@@ -210,3 +210,43 @@ void org_register_mergability_cam(const double K[9], int nHist, const double* hi
         out[(size_t)p * slotStride] = (unsigned char)v;
     }
 }
+
+/* The decision half of CoSLAM::curStaticPointsRegInGroup / curDynamicPointsRegInGroup with bMerge == false (reference
+ * src/app/SL_CoSLAM.cpp:854-898, 731-830, 904-1020) over the tables of ONE search: for every camera o in order the certainly static
+ * (kinds bit 0) -- then the certainly dynamic (bit 1) -- points with a feature of this frame in o, in map order; each walks the cameras,
+ * passes by those where it holds a feature, where nothing was found or the candidate's type is the other kind's, attaches the candidate
+ * when that is unmapped and mergeable over its whole track, and stops at one that carries a point.  The same walks as
+ * oracle/__init__.py's register_decide_static (which this is checked against), in C for the CPU baseline.
+ * slot / flags / mergeable: P x nCams; mapFlags [P]; pointFeat [P][nCams] and slot2map [nCams][N] in / out; attached [P][nCams], regged [P]
+ * out.  Returns the number of features attached. */
+int org_register_decide(int P, int nCams, int N, const int* slot, const int* flags, const unsigned char* mergeable, const unsigned char* mapFlags,
+                        int* pointFeat, int* slot2map, int mapBase, int kinds, unsigned char* attached, unsigned char* regged) {
+    int nAtt = 0;
+    for (size_t k = 0; k < (size_t)P * nCams; k++) attached[k] = 0;
+    for (int p = 0; p < P; p++) regged[p] = 0;
+    for (int kind = 0; kind < 2; kind++) {
+        if (!(kinds & (1 << kind))) continue;
+        for (int o = 0; o < nCams; o++)
+            for (int p = 0; p < P; p++) {
+                if ((mapFlags[p] & 7) != kind || pointFeat[(size_t)p * nCams + o] < 0) continue;
+                int breg = 0;
+                for (int i = 0; i < nCams; i++) {
+                    const size_t k = (size_t)p * nCams + i;
+                    if (pointFeat[k] >= 0) continue;
+                    const int s = slot[k];
+                    if (s < 0 || s >= N) continue;
+                    if (((flags[k] >> 1) & 1) != kind) continue;
+                    int* owner = slot2map + (size_t)i * N + s;
+                    if (*owner >= 0) break;
+                    if (mergeable[k] == 1) {
+                        *owner = mapBase + p;
+                        pointFeat[k] = s;
+                        attached[k] = 1;
+                        breg = 1, nAtt++;
+                    }
+                }
+                if (breg) regged[p] = 1;
+            }
+    }
+    return nAtt;
+}
