@@ -282,12 +282,20 @@ class BAOutput:
         return [x.value for x in a]
 
     def apply_dev(self, d_record, stream_ptr, history, window, pu_cams, d_pointFeat, n_map, d_mapPts, d_mapCov, d_mapFlags, pixelErrVar,
-                  first_key_frame, key_every, d_Rcur, d_tcur, d_counts=0):
+                  first_key_frame, key_every, d_Rcur, d_tcur, d_counts=0, seq=-1):
+        """seq >= 0: the record's sequence number on the rank that solved the window -- a slot holding another window's record (a
+        device-side wait that gave up) then applies nothing and is counted (wait_errors)"""
         vp = C.c_void_p
-        check(self._L.cs_ba_output_apply_dev(self._h, vp(d_record), vp(stream_ptr), vp(history._h), window._h if window is not None else None,
-                                             pu_cams, vp(d_pointFeat), int(n_map), vp(d_mapPts), vp(d_mapCov), vp(d_mapFlags),
-                                             C.c_double(pixelErrVar), int(first_key_frame), int(key_every), vp(d_Rcur), vp(d_tcur),
-                                             vp(d_counts)), "cs_ba_output_apply_dev")
+        check(self._L.cs_ba_output_apply_seq_dev(self._h, vp(d_record), C.c_longlong(int(seq)), vp(stream_ptr), vp(history._h),
+                                                 window._h if window is not None else None,
+                                                 pu_cams, vp(d_pointFeat), int(n_map), vp(d_mapPts), vp(d_mapCov), vp(d_mapFlags),
+                                                 C.c_double(pixelErrVar), int(first_key_frame), int(key_every), vp(d_Rcur), vp(d_tcur),
+                                                 vp(d_counts)), "cs_ba_output_apply_seq_dev")
+
+    def set_apply_mask(self, mask):
+        """diagnostic (tools/r05_drift.py): 1 key poses + relaxation, 2 points, 4 outlier points false, 8 updateNewPosesPoints; 15 = all"""
+        self._L.cs_ba_output_set_apply_mask.argtypes = [C.c_void_p, C.c_int]
+        check(self._L.cs_ba_output_set_apply_mask(self._h, int(mask)), "cs_ba_output_set_apply_mask")
 
     def close(self):
         if self._h:

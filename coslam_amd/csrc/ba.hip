@@ -2918,7 +2918,8 @@ struct cs_ba_output {
     int device, nCams, nKf, nMap, nSlots;
     BoLayout L;
     unsigned char* slab;  // nSlots records of L.bytes
-    int* d_err;           // cs_ba_output_wait_dev: waits that gave up
+    int* d_err;           // [2]: cs_ba_output_wait_dev's waits that gave up; records cs_ba_output_apply_seq_dev refused (not the one expected)
+    int applyMask;        // cs_ba_output_set_apply_mask (diagnostic): which parts of output() an apply performs
     std::mutex mu;
     std::condition_variable cv;
     long long issued;     // records the worker has started to pack (its slot = issued % nSlots)
@@ -3090,9 +3091,11 @@ static int ba_worker_run_window_inner(cs_ba* b, BaWorker* w, const BaAsyncJob& J
     const size_t nEnt = (size_t)win->h_totals[4];
     if (nEnt > 0 && nEnt <= ((size_t)8 << 20)) {
         if (nEnt > b->pairEntCap) {
+            // sized ONCE for the largest list this path accepts (128 MB of 288 GB): a later, larger window never frees -- hipFree
+            // synchronises the device, which would wait for a pose stream that is itself waiting for this solve (k_ba_output_wait)
             if (b->pairEnt) (void)hipFree(b->pairEnt);
             b->pairEnt = nullptr;
-            const size_t cap = nEnt + nEnt / 4 + 1024;
+            const size_t cap = (size_t)8 << 20;
             CS_HIP(hipMalloc((void**)&b->pairEnt, sizeof(int4) * cap));
             b->pairEntCap = cap;
         }
@@ -3282,9 +3285,12 @@ static int ba_worker_run_intercam(cs_ba* b, BaWorker* w, const BaAsyncJob& J) {
         return CS_ERR_INVALID;
     }
     if (nEnt > b->pairEntCap) {
+        // sized once for the largest problem addMapPoints can build (a static point: one entry; a dynamic one: every camera pair),
+        // so that no later solve frees (hipFree synchronises the device: see the window path)
         if (b->pairEnt) (void)hipFree(b->pairEnt);
         b->pairEnt = nullptr;
-        const size_t cap = nEnt + nEnt / 4 + 1024;
+        const size_t bound = (size_t)ic->nCams * ic->ptsStride + (size_t)(ic->maxDyn + 1) * ic->nCams * (ic->nCams + 1) / 2 + 1024;
+        const size_t cap = nEnt + nEnt / 4 + 1024 > bound ? nEnt + nEnt / 4 + 1024 : bound;
         CS_HIP(hipMalloc((void**)&b->pairEnt, sizeof(int4) * cap));
         b->pairEntCap = cap;
     }
@@ -4302,13 +4308,14 @@ cs_ba_output* cs_ba_output_create(int device, int nCams, int nKeyFrames, int nMa
     o->graph = nullptr, o->graphNodes = o->graphKeyEvery = o->maxNodes = 0;
     o->nodeR = o->nodeT = o->newR = o->newT = o->edgeR = o->edgeT = nullptr;
     o->scratch = nullptr, o->slab = nullptr, o->d_err = nullptr;
-    if (hipMalloc((void**)&o->slab, o->L.bytes * nSlots) != hipSuccess || hipMalloc((void**)&o->d_err, sizeof(int)) != hipSuccess) {
+    if (hipMalloc((void**)&o->slab, o->L.bytes * nSlots) != hipSuccess || hipMalloc((void**)&o->d_err, 2 * sizeof(int)) != hipSuccess) {
         cs_set_error("cs_ba_output_create: cannot allocate %zu KB", (o->L.bytes * nSlots) >> 10);
         delete o;
         return nullptr;
     }
     (void)hipMemset(o->slab, 0, o->L.bytes * nSlots);   // (hdr[6] = 0: an unwritten record applies nothing)
-    (void)hipMemset(o->d_err, 0, sizeof(int));
+    (void)hipMemset(o->d_err, 0, 2 * sizeof(int));
+    o->applyMask = CS_BA_APPLY_ALL;
     return o;
 }
 
@@ -4379,11 +4386,16 @@ int cs_ba_output_wait_dev(cs_ba_output* o, long long seq, void* hip_stream, int 
     *d_record = rec;
     return CS_OK;
 }
-int cs_ba_output_wait_errors(cs_ba_output* o) {   // synchronises the device
+int cs_ba_output_wait_errors(cs_ba_output* o) {   // synchronises the device; waits that gave up + records refused
     if (!o) return -1;
-    int v = 0;
-    if (hipSetDevice(o->device) != hipSuccess || hipMemcpy(&v, o->d_err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return v;
+    int v[2] = {0, 0};
+    if (hipSetDevice(o->device) != hipSuccess || hipMemcpy(v, o->d_err, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v[0] + v[1];
+}
+int cs_ba_output_set_apply_mask(cs_ba_output* o, int mask) {
+    if (!o) return CS_ERR_INVALID;
+    o->applyMask = mask & CS_BA_APPLY_ALL;
+    return CS_OK;
 }
 
 // slot `seq` would use, without waiting (the receive buffer of a broadcast on the ranks that did not solve this window)
@@ -4470,6 +4482,16 @@ int cs_ba_output_apply_dev(cs_ba_output* o, const void* d_record, void* hip_stre
                            const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap, double* d_mapPts, double* d_mapCov,
                            unsigned char* d_mapFlags, double pixelErrVar, int firstKeyFrame, int keyEvery, double* d_Rcur, double* d_tcur,
                            int* d_counts) {
+    return cs_ba_output_apply_seq_dev(o, d_record, -1, hip_stream, h, w, cams, d_pointFeat, nMap, d_mapPts, d_mapCov, d_mapFlags, pixelErrVar,
+                                      firstKeyFrame, keyEvery, d_Rcur, d_tcur, d_counts);
+}
+// ... and with the record's sequence number stated (seq >= 0: the number cs_ba_output_wait(_dev) was asked for, on the rank that
+// solved the window; the ranks that received the record by broadcast pass the solving rank's number): a slot that holds ANOTHER
+// window's record -- the wait gave up, the broadcast did not arrive -- moves nothing and is counted (cs_ba_output_wait_errors).
+int cs_ba_output_apply_seq_dev(cs_ba_output* o, const void* d_record, long long seq, void* hip_stream, cs_track_history* h, cs_ba_window* w,
+                               const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap, double* d_mapPts, double* d_mapCov,
+                               unsigned char* d_mapFlags, double pixelErrVar, int firstKeyFrame, int keyEvery, double* d_Rcur,
+                               double* d_tcur, int* d_counts) {
     if (!o || !d_record || !h || !cams || !d_pointFeat || nMap != o->nMap || !d_mapPts || !d_mapCov || !d_mapFlags || keyEvery < 1 ||
         !d_Rcur || !d_tcur || cs_track_history_cams(h) != o->nCams || (w && (w->nCams != o->nCams || w->device != o->device))) {
         cs_set_error("cs_ba_output_apply_dev: bad arguments");
@@ -4490,6 +4512,7 @@ int cs_ba_output_apply_dev(cs_ba_output* o, const void* d_record, void* hip_stre
     BoPosesArgs A;
     memset(&A, 0, sizeof(A));
     A.nKf = o->nKf, A.nCams = o->nCams, A.nNodes = nNodes, A.keyEvery = keyEvery;
+    A.seq = (int)seq, A.firstKeyFrame = firstKeyFrame;
     A.nodeR = o->nodeR, A.nodeT = o->nodeT;
     for (int j = 0; j < 16; ++j) A.slotOf[j] = -1;
     if (w) {
@@ -4500,15 +4523,20 @@ int cs_ba_output_apply_dev(cs_ba_output* o, const void* d_record, void* hip_stre
                 if (w->frameOf[slot] == firstKeyFrame + j * keyEvery) A.slotOf[j] = slot;
             }
     }
-    hipLaunchKernelGGL(k_ba_output_poses, dim3((o->nKf * o->nCams * 12 + 255) / 256), dim3(256), 0, s, (const unsigned char*)d_record, o->L, A);
+    const int mask = o->applyMask;
+    if (seq >= 0) hipLaunchKernelGGL(k_ba_output_check, dim3(1), dim3(1), 0, s, (const int*)d_record, (int)seq, firstKeyFrame, o->d_err);
+    if (mask & CS_BA_APPLY_POSES)
+        hipLaunchKernelGGL(k_ba_output_poses, dim3((o->nKf * o->nCams * 12 + 255) / 256), dim3(256), 0, s, (const unsigned char*)d_record, o->L, A);
     {
         cs_small::List ops;
         if (d_counts) ops.fill(d_counts + 2, 0, sizeof(int));
         if (nNodes <= 1) ops.copy(o->newR, o->nodeR, sizeof(double) * 9 * o->nCams), ops.copy(o->newT, o->nodeT, sizeof(double) * 3 * o->nCams);
         CS_HIP(ops.run(s));
     }
-    hipLaunchKernelGGL(k_ba_output_points, dim3((o->L.maxP + 255) / 256), dim3(256), 0, s, (const unsigned char*)d_record, o->L, nMap, d_mapPts,
-                       d_mapFlags, d_counts ? d_counts + 2 : nullptr);
+    if (mask & (CS_BA_APPLY_POINTS | CS_BA_APPLY_FALSE))
+        hipLaunchKernelGGL(k_ba_output_points, dim3((o->L.maxP + 255) / 256), dim3(256), 0, s, (const unsigned char*)d_record, o->L, nMap, d_mapPts,
+                           d_mapFlags, d_counts ? d_counts + 2 : nullptr, (int)seq, firstKeyFrame, (mask & CS_BA_APPLY_POINTS) ? 1 : 0,
+                           (mask & CS_BA_APPLY_FALSE) ? 1 : 0);
     CS_CHECK_LAUNCH();
     if (nNodes > 1) {
         if ((rc = cs_posegraph_relax_dev(o->graph, hip_stream, o->nodeR, o->nodeT, o->edgeR, o->edgeT, o->newR, o->newT))) return rc;
@@ -4516,6 +4544,7 @@ int cs_ba_output_apply_dev(cs_ba_output* o, const void* d_record, void* hip_stre
     if ((rc = cs_track_history_set_span_dev(h, hip_stream, firstKeyFrame, nNodes, o->newR, o->newT))) return rc;
     hipLaunchKernelGGL(k_ba_output_tail, dim3((o->nCams * 12 + 255) / 256), dim3(256), 0, s, o->nCams, nNodes, o->newR, o->newT, d_Rcur, d_tcur);
     CS_CHECK_LAUNCH();
+    if (!(mask & CS_BA_APPLY_UPDATE)) return CS_OK;
     return cs_update_new_poses_points_dev(h, hip_stream, cams, d_pointFeat, nMap, nullptr, nullptr, firstKeyFrame, d_mapPts, d_mapCov,
                                           d_mapFlags, pixelErrVar, d_counts);
 }

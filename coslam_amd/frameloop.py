@@ -54,6 +54,11 @@ class LoopConfig:
         self.sequential_registration = False   # the decision camera loop after camera loop with a search + refine per loop, as the
         # reference runs it (register_cur_static_sequential_dev: bit-identical to the reference's run, nCams x the launches; one rank only)
         self.native_comm = True
+        self.klt_cus = 0           # > 0: the tracker's stream is confined to CU-mask bits [0, klt_cus) (the same klt_cus / 8 CUs of every XCD)
+        self.pose_cus = 0          # > 0: the pose stream is confined to the LAST pose_cus mask bits (with klt_cus + pose_cus <= 256: disjoint)
+        self.klt_after_intracam = False   # the tracker of frame i + 1 starts behind frame i's intraCamEstimate: the pose solve -- one
+        # workgroup per camera, a latency chain of ~20 LM steps -- then runs on an otherwise empty chip instead of beside the
+        # persistent tracker's resident waves ("what the pose stream pays for co-residency")
         self.device_wait = True    # the BA result's apply waits for the solve on the device (cs_ba_output_wait_dev), not on the host
         for k, v in kw.items():
             if not hasattr(self, k):
@@ -137,6 +142,22 @@ class FrameLoop:
         # ---- streams
         self.klt_s, self.pose_s = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)   # (equal priorities: a high-priority pose or
         # tracker stream halves the rate, 2188 -> 942 / 906 frames/s: profiles/r04_ab_runs.txt)
+        if cfg.klt_cus > 0 or cfg.pose_cus > 0:
+            # CU-partitioned streams (cs_stream_create_cu_range = hipExtStreamCreateWithCUMask): VERDICT r04 item 3
+            L_ = coslam_amd.lib()
+            L_.cs_stream_create_cu_range.restype = C.c_void_p
+            L_.cs_stream_create_cu_range.argtypes = [C.c_int, C.c_int, C.c_int]
+            if cfg.klt_cus > 0:
+                h_ = L_.cs_stream_create_cu_range(device, 0, int(cfg.klt_cus))
+                if not h_:
+                    raise coslam_amd.CoslamHipError("cs_stream_create_cu_range: " + L_.cs_last_error().decode())
+                self.klt_s = torch.cuda.ExternalStream(h_, device=dev)
+            if cfg.pose_cus > 0:
+                h_ = L_.cs_stream_create_cu_range(device, 256 - int(cfg.pose_cus), int(cfg.pose_cus))
+                if not h_:
+                    raise coslam_amd.CoslamHipError("cs_stream_create_cu_range: " + L_.cs_last_error().decode())
+                self.pose_s = torch.cuda.ExternalStream(h_, device=dev)
+        self.intracam_done = [torch.cuda.Event(), torch.cuda.Event()]
         self.klt_done = [torch.cuda.Event(), torch.cuda.Event()]
         self.dest_free = [torch.cuda.Event(), torch.cuda.Event()]
         # ---- trackers of the own cameras
@@ -152,6 +173,9 @@ class FrameLoop:
         if cfg.klt_cams_per_launch > 0:
             for t in self.trks:   # co-residency budget of the persistent tracker = that many cameras per launch
                 t.set_cu_count(min(256, (250 * cfg.klt_cams_per_launch + 60) // 8 + 5))
+        elif cfg.klt_cus > 0:
+            for t in self.trks:   # the persistent tracker's co-residency budget = the CUs its stream may use
+                t.set_cu_count(int(cfg.klt_cus))
         # ---- multi-GPU exchange
         self.xchg = self.native = None
         if world > 1:
@@ -428,17 +452,18 @@ class FrameLoop:
         due = self.apply_at.pop(i, None)
         if due is None:
             return
-        k, owner, first_key = due
+        k, owner, first_key, seq = due
         if owner == self.rank:
             # the pose stream waits ON THE DEVICE for this rank's worker to publish the record: the host goes on enqueueing frames
-            rec = self.out.wait_dev(self.my_seq.pop(k), self.pose_s.cuda_stream) if self.cfg.device_wait else self.out.wait(self.my_seq.pop(k))
+            self.my_seq.pop(k)
+            rec = self.out.wait_dev(seq, self.pose_s.cuda_stream) if self.cfg.device_wait else self.out.wait(seq)
         else:
             rec = self.recv_rec[k & 1].data_ptr()
         if self.world > 1:
             self.xchg.broadcast(rec, self.out.record_bytes, owner, self.device, self.pose_s)
         self.out.apply_dev(rec, self.pose_s.cuda_stream, self.pose_upd, self.win, self.pu_args, self.d_pf.data_ptr(), self.n_map,
                            self.d_map.data_ptr(), self.d_cov.data_ptr(), self.d_mapflags.data_ptr(), PIXEL_ERR_VAR, first_key,
-                           self.cfg.key_every, self.d_R[src].data_ptr(), self.d_t[src].data_ptr(), self.d_apply_counts.data_ptr())
+                           self.cfg.key_every, self.d_R[src].data_ptr(), self.d_t[src].data_ptr(), self.d_apply_counts.data_ptr(), seq=seq)
         self.applied += 1
         self.last_apply = dict(window=k, solved_by_rank=owner, first_key_frame=first_key, applied_at_frame=i)
 
@@ -456,6 +481,8 @@ class FrameLoop:
         b = i & 1
         if i >= 2:
             klt_s.wait_event(self.dest_free[b])      # the consumer of this dest buffer two frames ago is done
+            if cfg.klt_after_intracam:
+                klt_s.wait_event(self.intracam_done[(i - 1) & 1])   # ... and the previous frame's pose solve has the chip to itself
         if upload:
             self.stage(i + 2)
             cur, nxt = self.grp.staged(self.stage_slot.pop(i)), self.grp.staged(self.stage_slot[i + 1])
@@ -484,6 +511,8 @@ class FrameLoop:
                                    self.d_Ms.data_ptr() + 24 * cfg.pts_stride * c0, self.d_ms.data_ptr() + 16 * cfg.pts_stride * c0, 10.0,
                                    self.d_R[dst].data_ptr() + 72 * c0, self.d_t[dst].data_ptr() + 24 * c0, self.d_opt.data_ptr() + 96 * c0,
                                    self.d_ok.data_ptr() + 4 * c0, device=self.device)
+        if cfg.klt_after_intracam:
+            self.intracam_done[b].record(pose_s)
         if self.world > 1:
             # the merge step: every camera's {dest[], R, t} to every rank, then the other ranks' cameras through the same hand-back
             with torch.cuda.stream(pose_s):
@@ -664,7 +693,10 @@ class FrameLoop:
                 self.win.solve_flags_async(self.ba_ws, ps, self.d_map.data_ptr(), self.d_mapflags.data_ptr(), 2 * NA, 2, 6.0, 2, 10)
             self.my_seq[k] = self.n_my_solves
             self.n_my_solves += 1
-        self.apply_at[i + self.lag * cfg.key_every] = (k, owner, i - (cfg.n_key_frames - 1) * cfg.key_every)
+        # the record's sequence number ON ITS OWNER: windows go round the ranks, so it is the owner's (k // world)-th solve (one rank:
+        # its own count, which the reference's request policy -- skip_busy -- may leave behind k)
+        seq = self.my_seq[k] if owner == self.rank else k // self.world
+        self.apply_at[i + self.lag * cfg.key_every] = (k, owner, i - (cfg.n_key_frames - 1) * cfg.key_every, seq)
 
     def drain(self):
         """the worker threads' queues are part of the work: every requested solve completes"""

@@ -875,6 +875,23 @@ int cs_ba_output_apply_dev(cs_ba_output* o, const void* d_record, void* hip_stre
                            const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap, double* d_mapPts, double* d_mapCov,
                            unsigned char* d_mapFlags, double pixelErrVar, int firstKeyFrame, int keyEvery, double* d_Rcur, double* d_tcur,
                            int* d_counts);
+/* The same with the record's sequence number stated (the number cs_ba_output_wait / _wait_dev was asked for on the rank that solved
+ * the window; -1: unchecked = cs_ba_output_apply_dev): the kernels compare it -- and firstKeyFrame -- with the record's header and
+ * move NOTHING when the slot holds another window's record (a device-side wait that gave up leaves the record of nSlots solves
+ * ago in place); such a refusal is counted in cs_ba_output_wait_errors. */
+int cs_ba_output_apply_seq_dev(cs_ba_output* o, const void* d_record, long long seq, void* hip_stream, cs_track_history* h, cs_ba_window* w,
+                               const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap, double* d_mapPts, double* d_mapCov,
+                               unsigned char* d_mapFlags, double pixelErrVar, int firstKeyFrame, int keyEvery, double* d_Rcur,
+                               double* d_tcur, int* d_counts);
+/* diagnostic: which parts of output() an apply performs (default CS_BA_APPLY_ALL).  POSES: key poses into history / window ring +
+ * relaxation of the non-key frames + the current poses; POINTS: adjusted points into the map; FALSE: points with an outlier
+ * measurement set false; UPDATE: updateNewPosesPoints.  tools/r05_drift.py separates their effects on the closed loop with it. */
+#define CS_BA_APPLY_POSES 1
+#define CS_BA_APPLY_POINTS 2
+#define CS_BA_APPLY_FALSE 4
+#define CS_BA_APPLY_UPDATE 8
+#define CS_BA_APPLY_ALL 15
+int cs_ba_output_set_apply_mask(cs_ba_output* o, int mask);
 /* InterCamPoseEstimator::addMapPoints + apply's solve (src/app/SL_InterCamPoseEstimator.cpp:18-95) with the problem built ON THE DEVICE
  * from the frame's own records: cameras = every camera's current pose, all free; static points = per camera chooseStaticFeatPts
  * (src/app/SL_SingleSLAM.cpp:345-397) run on the records as they stand -- per 40 x 40 block the first track with a map point, else

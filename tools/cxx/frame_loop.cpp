@@ -378,8 +378,8 @@ int main(int argc, char** argv) {
         if (!due.empty() && due.front().frame == i) {
             void* rec = nullptr;
             CSCHK(cs_ba_output_wait_dev(bout, due.front().seq, (void*)poseS, 0, &rec));
-            CSCHK(cs_ba_output_apply_dev(bout, rec, (void*)poseS, hist, win, pu.data(), dPf, nMap, dMap, dCov, dMapFlags, PIX, due.front().firstKey,
-                                         keyEvery, dR[src], dT[src], dApplyCnt));
+            CSCHK(cs_ba_output_apply_seq_dev(bout, rec, due.front().seq, (void*)poseS, hist, win, pu.data(), dPf, nMap, dMap, dCov, dMapFlags, PIX,
+                                             due.front().firstKey, keyEvery, dR[src], dT[src], dApplyCnt));
             due.erase(due.begin());
             ++nApplied;
         }

@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""r05_drift.py -- where does the closed loop's pose error come from?  ("next round" item 1)
+
+Runs the headline frame loop (coslam_amd.frameloop.FrameLoop: bench.py's loop, one rank) for --frames frames under ONE named
+variant and, every --every frames, drains the device and logs
+
+    pose error vs the synthetic truth     raw (bench.py's figure: max |t_est - t_true|; camera centres) AND after a similarity /
+                                          a rigid alignment of the 8 estimated camera centres onto the true ones -- a motion of the
+                                          whole map + rig (the gauge: nothing ties a SLAM map to the world frame it started in) is
+                                          thereby separated from a distortion of the rig
+    the alignment itself                  rotation angle, translation, scale of the gauge motion
+    map error                             over the map points this frame's static features USE (of the 7000 initial points: their
+                                          true positions are known): raw, after the cameras' alignment, after their own alignment
+    joint BA                              converged cost per measurement of the last window solved, LM steps, outliers
+    bookkeeping                           static mapped features per camera (on initial / on new points), pose correspondences, LM
+                                          steps of intraCamEstimate, map points false / in use, attachments of the registration
+
+as JSON lines (one per sample) to --out.  tools/r05_drift.sh runs the variants one process each; profiles/r05_drift_*.jsonl are
+its outputs, profiles/r05_drift_summary.md the table DESIGN.md quotes.  GPU only (the HIP path has no CPU fallback).
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+VARIANTS = {
+    # name: (LoopConfig overrides, BA apply mask or None, extra)
+    "full": ({}, None),
+    "no_decide": (dict(with_decide=False), None),
+    "no_ncc": (dict(with_ncc=False), None),
+    "no_decide_no_ncc": (dict(with_decide=False, with_ncc=False), None),
+    "no_writeback": ({}, 0),                       # the window BAs run, nothing is applied
+    "r03_like": (dict(with_decide=False, with_ncc=False), 0),
+    "lag1": (dict(ba_lag=1), None),
+    "lag4": (dict(ba_lag=4), None),
+    "points_only": ({}, 2 | 4),                    # adjusted points + false flags; key poses untouched, no re-triangulation
+    "poses_only": ({}, 1 | 8),                     # key poses + relaxation + updateNewPosesPoints; adjusted points dropped
+    "no_false": ({}, 1 | 2 | 8),                   # everything but "a point with an outlier measurement becomes false"
+    "no_update": ({}, 1 | 2 | 4),                  # everything but updateNewPosesPoints
+    "no_classify": (dict(with_classify=False), None),
+    "no_merge": (dict(merge_every=0), None),
+    "no_intercam": (dict(with_intercam=False), None),
+}
+
+
+def umeyama(X, Y, with_scale=True):
+    """similarity (s, R, t) minimising sum |s R X_i + t - Y_i|^2 (Umeyama 1991); X, Y: [n][3]"""
+    mx, my = X.mean(0), Y.mean(0)
+    Xc, Yc = X - mx, Y - my
+    S = Yc.T @ Xc / len(X)
+    U, D, Vt = np.linalg.svd(S)
+    E = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        E[2, 2] = -1
+    R = U @ E @ Vt
+    s = float((D * np.diag(E)).sum() / (Xc ** 2).sum() * len(X)) if with_scale else 1.0
+    t = my - s * R @ mx
+    return s, R, t
+
+
+def rot_angle_deg(R):
+    return float(np.degrees(np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variant", default="full", choices=sorted(VARIANTS))
+    ap.add_argument("--frames", type=int, default=1500)
+    ap.add_argument("--every", type=int, default=50)
+    ap.add_argument("--hist", type=int, default=64)
+    ap.add_argument("--min-distance", type=int, default=-1, help="KLT minDistance (-1: bench.py's)")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+
+    import bench
+
+    frames = bench.render_video(list(range(bench.N_CAMS)), bench.N_FRAMES)
+
+    import torch
+
+    import coslam_amd
+    from coslam_amd.frameloop import FrameLoop, LoopConfig
+    from coslam_amd.pose import IntraCamPoseOption
+
+    if not torch.cuda.is_available():
+        raise SystemExit("r05_drift.py needs an MI355X")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    sc = bench.build_scene()
+    NA, N = bench.N_CAMS, bench.N_FEAT
+    video = {c: torch.from_numpy(frames[c]).to(dev) for c in range(NA)}
+    over, mask = VARIANTS[args.variant]
+    kw = dict(n_cams=NA, W=bench.W, H=bench.H, levels=bench.LEVELS, fw=bench.FW, fh=bench.FH, pts_stride=bench.PTS_STRIDE,
+              n_col_blk=bench.N_COL_BLK, n_row_blk=bench.N_ROW_BLK, key_every=bench.KEY_EVERY, p_reg=bench.P_REG, hist=args.hist)
+    kw.update(over)
+    cfg = LoopConfig(**kw)
+    kc = bench.klt_config()
+    if args.min_distance > 0:
+        kc.minDistance = args.min_distance
+    n_map0 = len(sc.points)
+    loop = FrameLoop(cfg, sc, video, None, kc, bench.reg_covariances(n_map0), rank=0, world=1, device=0, associate=bench.associate)
+    if mask is not None and loop.out is not None:
+        loop.out.set_apply_mask(mask)
+    loop.first_frame()
+    truth_pts = np.ascontiguousarray(sc.points, dtype=np.float64)
+    out = open(args.out, "w") if args.out else sys.stdout
+    ke = cfg.key_every
+
+    def sample(i):
+        loop.drain()
+        dst = i & 1
+        R = loop.d_R[dst].cpu().numpy().reshape(NA, 3, 3)
+        t = loop.d_t[dst].cpu().numpy().reshape(NA, 3)
+        f = loop.vid(i)
+        Rt, tt = zip(*[sc.pose(c, f) for c in range(NA)])
+        Rt, tt = np.array(Rt), np.array(tt)
+        Ce = -np.einsum("cji,cj->ci", R, t)
+        Ct = -np.einsum("cji,cj->ci", Rt, tt)
+        rec = {"variant": args.variant, "frame": i, "t_err_max": float(np.abs(t - tt).max()),
+               "centre_err_raw_max": float(np.linalg.norm(Ce - Ct, axis=1).max())}
+        # rotation error raw: angle of R_est R_true^T
+        rec["rot_err_raw_deg_max"] = max(rot_angle_deg(R[c] @ Rt[c].T) for c in range(NA))
+        for name, ws in (("sim", True), ("rigid", False)):
+            s, Ra, ta = umeyama(Ce, Ct, ws)
+            Ca = s * Ce @ Ra.T + ta
+            rec[f"centre_err_{name}_max"] = float(np.linalg.norm(Ca - Ct, axis=1).max())
+            rec[f"centre_err_{name}_rms"] = float(np.sqrt((np.linalg.norm(Ca - Ct, axis=1) ** 2).mean()))
+            # a world transform x' = s Ra x + ta turns the world->camera rotation R into R Ra^T
+            rec[f"rot_err_{name}_deg_max"] = max(rot_angle_deg(R[c] @ Ra.T @ Rt[c].T) for c in range(NA))
+            rec[f"gauge_{name}"] = {"scale": s, "rot_deg": rot_angle_deg(Ra), "trans": float(np.linalg.norm(ta))}
+            if name == "sim":
+                cam_align = (s, Ra, ta)
+        # the map points this frame's static features use
+        state = loop.d_state.cpu().numpy()
+        s2m = loop.d_slot2map.cpu().numpy()
+        isst = loop.d_isstatic.cpu().numpy()
+        flags = loop.d_mapflags.cpu().numpy()
+        M = loop.d_map.cpu().numpy()
+        live = (state >= 0) & (s2m >= 0)
+        used = np.unique(s2m[live & (isst != 0)])
+        used = used[(flags[used] & 3) == 0]                 # local static, not false
+        u0 = used[used < n_map0]
+        rec["static_mapped_features_per_cam"] = [int(v) for v in live.sum(1)]
+        rec["features_on_initial_points"] = int((live & (s2m < n_map0)).sum())
+        rec["features_on_new_points"] = int((live & (s2m >= n_map0)).sum())
+        rec["used_points_initial"], rec["used_points_new"] = int(len(u0)), int(len(used) - len(u0))
+        if len(u0) >= 4:
+            e = np.linalg.norm(M[u0] - truth_pts[u0], axis=1)
+            rec["map_err_raw"] = {"median": float(np.median(e)), "p90": float(np.percentile(e, 90)), "max": float(e.max())}
+            s, Ra, ta = cam_align
+            e = np.linalg.norm(s * M[u0] @ Ra.T + ta - truth_pts[u0], axis=1)
+            rec["map_err_cam_aligned"] = {"median": float(np.median(e)), "p90": float(np.percentile(e, 90))}
+            s, Ra, ta = umeyama(M[u0], truth_pts[u0], True)
+            e = np.linalg.norm(s * M[u0] @ Ra.T + ta - truth_pts[u0], axis=1)
+            rec["map_err_self_aligned"] = {"median": float(np.median(e)), "p90": float(np.percentile(e, 90)),
+                                           "gauge": {"scale": s, "rot_deg": rot_angle_deg(Ra), "trans": float(np.linalg.norm(ta))}}
+            # the poses in the MAP's gauge: what intraCamEstimate can know
+            Ca = s * Ce @ Ra.T + ta
+            rec["centre_err_map_aligned_max"] = float(np.linalg.norm(Ca - Ct, axis=1).max())
+        rec["map_points_false"] = int(((flags & 2) != 0).sum())
+        rec["map_points_in_use"] = int(loop.d_mapcount.item())
+        rec["pose_correspondences"] = loop.d_npts.cpu().numpy().tolist()
+        opts = [IntraCamPoseOption.from_buffer_copy(loop.d_opt[c].cpu().numpy().tobytes()) for c in range(NA)]
+        rec["pose_rounds_lm"] = [[o.nIterRW, o.verboseRW] for o in opts]
+        if loop.win is not None and loop.n_my_solves > 0:
+            wC, wP, wO, _, wkf = loop.win.last_problem()
+            loop.ba_ws.set_sizes(wC, wP, wO)
+            st = loop.ba_ws.download()[4]
+            rec["joint_ba"] = {"points": wP, "meas": wO, "lm_steps": st.nIterTotal, "outliers": st.nOutliers, "cost0": st.cost0, "cost": st.cost,
+                               "cost_per_meas": st.cost / max(wO, 1), "cost0_per_meas": st.cost0 / max(wO, 1)}
+        if loop.n_my_ic > 0 and loop.icam is not None:
+            iC, iP, iO, iS, _ = loop.icam.last_problem()
+            loop.ic_ws.set_sizes(iC, iP, iO)
+            st = loop.ic_ws.download()[4]
+            rec["intercam"] = {"static": iS, "dynamic": iP - iS, "outliers": st.nOutliers, "cost_per_meas": st.cost / max(iO, 1)}
+        if hasattr(loop, "_dec"):
+            rec["decide_counts"] = loop._dec["cnt"].cpu().tolist()
+            rec["mergeable_verdicts"] = {str(v): int((loop.d_mergeable == v).sum().item()) for v in (0, 1, 2)}
+        if loop.out is not None:
+            rec["apply_counts"] = loop.d_apply_counts.cpu().tolist()
+            rec["apply_errors"] = loop.out.wait_errors()
+        out.write(json.dumps(rec) + "\n")
+        out.flush()
+
+    for i in range(1, args.frames + 1):
+        loop.step(i, ke > 0 and (i - 1) % ke == 0)
+        if i % args.every == 0 or i == 1:
+            sample(i)
+    loop.drain()
+    if args.out:
+        out.close()
+
+
+if __name__ == "__main__":
+    main()
