@@ -49,7 +49,8 @@ N_FRAMES = 120           # the video: a closed camera path of this many frames (
 PTS_STRIDE = 192          # 12 x 16 blocks (reference src/app/SL_SingleSLAM.h:36-37)
 N_COL_BLK, N_ROW_BLK = 16, 12
 KEY_EVERY = 5
-P_REG = 1536             # map points per registration pass (the size of the inter-camera solve's static set)
+P_REG = 4096             # cap on the frame's CURRENT map points (the registration's list; ~2300 of them in the steady state)
+CPU_P_REG = 1536         # map points per registration pass of the CPU baseline's restatement (rounds 2-4's pass size)
 PIXEL_ERR_VAR = 10.0      # Const::PIXEL_ERR_VAR, reference src/app/SL_GlobParam.cpp:37
 MAX_EPI_ERR = 6.0         # Const::MAX_EPI_ERR, :36
 HBM_PEAK_GBS = 8000.0
@@ -148,7 +149,7 @@ def build_pose_graphs(sc, joint, cams, n_kf=5, kf_step=5):
 def reg_covariances(n=None):
     """MapPoint::cov of the first n map points (default: the 2 x P_REG registered ones): synthetic SPD 3 x 3, a few cm"""
     rng = np.random.default_rng(SEED + 23)
-    A = rng.normal(size=(2 * P_REG if n is None else max(n, 2 * P_REG), 3, 3)) * 0.02
+    A = rng.normal(size=(2 * CPU_P_REG if n is None else max(n, 2 * CPU_P_REG), 3, 3)) * 0.02
     return A @ A.transpose(0, 2, 1) + 1e-6 * np.eye(3)
 
 
@@ -253,7 +254,7 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
                 Rc[c], tc[c] = R, t
 
     cov = reg_covariances(len(sc.points))
-    no_feat = np.full((P_REG, 1), -1, dtype=np.int32)
+    no_feat = np.full((CPU_P_REG, 1), -1, dtype=np.int32)
     # poseUpdate3D's gate + seqTriangulate and the dynamic-point test: camera after camera on the calling thread (they share the map)
     map_pts, map_cov = sc.points.copy(), np.ascontiguousarray(cov[:len(sc.points)].reshape(-1, 9))
     map_flags = np.zeros(len(sc.points), dtype=np.uint8)
@@ -284,35 +285,35 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
 
     Kc = sc.K
 
-    reg_slot, reg_flags = np.full((P_REG, N_CAMS), -1, np.int32), np.zeros((P_REG, N_CAMS), np.int32)
-    reg_merge, reg_pf = np.zeros((P_REG, N_CAMS), np.uint8), np.full((P_REG, N_CAMS), -1, np.int32)
+    reg_slot, reg_flags = np.full((CPU_P_REG, N_CAMS), -1, np.int32), np.zeros((CPU_P_REG, N_CAMS), np.int32)
+    reg_merge, reg_pf = np.zeros((CPU_P_REG, N_CAMS), np.uint8), np.full((CPU_P_REG, N_CAMS), -1, np.int32)
 
     def reg_step(c):
         # activeMapPointsRegister + currentMapPointsRegister, search step, this camera's column of the tables
         one = lambda a: [a]  # noqa: E731
-        oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), map_pts[P_REG:2 * P_REG],
-                               cov[P_REG:2 * P_REG], no_feat, 2.5 * PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)
-        pf = oracle.point_features(st[c], s2m[c], P_REG).reshape(P_REG, 1)
-        rs = oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), map_pts[:P_REG],
-                                    cov[:P_REG], pf, PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)
+        oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), map_pts[CPU_P_REG:2 * CPU_P_REG],
+                               cov[CPU_P_REG:2 * CPU_P_REG], no_feat, 2.5 * PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)
+        pf = oracle.point_features(st[c], s2m[c], CPU_P_REG).reshape(CPU_P_REG, 1)
+        rs = oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), map_pts[:CPU_P_REG],
+                                    cov[:CPU_P_REG], pf, PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)
         reg_slot[:, c], reg_flags[:, c], reg_pf[:, c] = rs["slot"][:, 0], rs["flags"][:, 0], pf[:, 0]
         h = hist[c]
         reg_merge[:, c] = 0
         if h["R"]:   # staticCheckMergability of the candidates over their whole tracks (the history as of the previous frame's pose update)
-            reg_merge[:, c] = oracle.register_mergability_cam(Kc, np.stack(h["R"]), np.stack(h["t"]), np.stack(h["xy"]), tl[c], map_pts[:P_REG],
-                                                              cov[:P_REG], rs["slot"][:, 0], PIXEL_ERR_VAR)
+            reg_merge[:, c] = oracle.register_mergability_cam(Kc, np.stack(h["R"]), np.stack(h["t"]), np.stack(h["xy"]), tl[c], map_pts[:CPU_P_REG],
+                                                              cov[:CPU_P_REG], rs["slot"][:, 0], PIXEL_ERR_VAR)
 
     def decide_all():
         # currentMapPointsRegister's decisions over the cameras' columns (org_register_decide: static points, then dynamic ones), then
         # refineMapPoint of the points that gained a feature -- on the calling thread, behind the cameras' searches
         s2m_all = np.ascontiguousarray(np.stack(s2m)).astype(np.int32)
         pf_all = np.ascontiguousarray(reg_pf)
-        _, reg = oracle.register_decide_static_c(reg_slot, reg_flags, reg_merge, map_flags[:P_REG], pf_all, s2m_all, kinds=3)
+        _, reg = oracle.register_decide_static_c(reg_slot, reg_flags, reg_merge, map_flags[:CPU_P_REG], pf_all, s2m_all, kinds=3)
         if reg.any() and hist[0]["R"]:
             for c in range(N_CAMS):
                 s2m[c][:] = s2m_all[c]
             sel = np.zeros(len(map_pts), dtype=np.uint8)
-            sel[:P_REG] = reg
+            sel[:CPU_P_REG] = reg
             pf_map = np.ascontiguousarray(np.stack([oracle.point_features(st[c], s2m[c], len(sc.points)) for c in range(N_CAMS)], 1))
             oracle.refine_map_points([Kc] * N_CAMS, [iK] * N_CAMS, np.stack([np.stack(h["R"]) for h in hist]), np.stack([np.stack(h["t"]) for h in hist]),
                                      np.stack([np.stack(h["xy"]) for h in hist]), np.stack(tl), pf_map, map_pts, map_cov.reshape(-1, 9), PIXEL_ERR_VAR,
@@ -465,8 +466,11 @@ def main():
     ap.add_argument("--no-pose-update", action="store_true", help="diagnostic: skip the gate / dynamic test / BA write-back (not a valid bench line)")
     ap.add_argument("--no-mergability", action="store_true", help="diagnostic: skip staticCheckMergability (not a valid bench line)")
     ap.add_argument("--no-decide", action="store_true", help="diagnostic: skip the registration decision + refineMapPoint (not a valid bench line)")
-    ap.add_argument("--hist", type=int, default=64, help="frames of track / pose history the walks see (the reference walks whole tracks; "
-                    "a candidate whose track is longer is not judged and not attached: DESIGN.md 8.2 item 3)")
+    ap.add_argument("--hist", type=int, default=64, help="depth of the bounded walks (dynamic test, classification, re-triangulation) and of the "
+                    "mergability walk's exact window; the whole-track verdict behind it is the running one (--hist-store)")
+    ap.add_argument("--hist-store", type=int, default=4096, help="frames of pixels + poses kept behind the walks (what a dropped mergability "
+                    "cache entry is rebuilt from)")
+    ap.add_argument("--active-search", type=int, default=0, help="diagnostic: 1 = also run the search half of activeMapPointsRegister (rounds 2-4)")
     ap.add_argument("--merge-every", type=int, default=50, help="bMerge frames: every n-th frame the static points' walks may unify two points "
                     "(the reference: 50, CoSLAMThread.cpp:117-118); 0: never (diagnostic)")
     ap.add_argument("--no-ncc", action="store_true", help="diagnostic: skip the inter-camera NCC matching leg (not a valid bench line)")
@@ -551,7 +555,7 @@ def main():
                      key_every=max(ke, 1), ba_lag=args.ba_lag, p_reg=P_REG, klt_cams_per_launch=max(args.klt_cams_per_launch, 0),
                      prefetch=os.environ.get("BENCH_PREFETCH", "1") != "0", with_pose_update=not args.no_pose_update,
                      with_classify=not args.no_classify, with_register=not args.no_register, with_mergability=not args.no_mergability,
-                     with_ncc=not args.no_ncc, with_decide=not args.no_decide, merge_every=args.merge_every, hist=args.hist, with_joint=args.only_solve != "intercam", with_intercam=args.only_solve != "joint",
+                     with_ncc=not args.no_ncc, with_decide=not args.no_decide, merge_every=args.merge_every, hist=args.hist, hist_store=args.hist_store, with_active_search=bool(args.active_search), with_joint=args.only_solve != "intercam", with_intercam=args.only_solve != "joint",
                      native_comm=bool(args.native_comm), klt_cus=args.klt_cus, pose_cus=args.pose_cus,
                      klt_after_intracam=bool(args.klt_after_intracam),
                      klt_fused=os.environ.get("BENCH_FORCE_DEVICE") is None or world == 1)   # (ranks sharing ONE GPU: test hook)
@@ -1032,12 +1036,19 @@ def main():
                        "frame_front_prefetch": bool(prefetch), "secondary_cfg2": cfg2, "secondary_cfg5_ba": cfg5, "secondary_cfg5_klt": cfg5_klt,
                        "secondary_reference_default_klt": ref_default,
                        "register_candidates_last_frame": None if args.no_register else
-                       {"active": int((reg_out[0]["slot"][:, lc] >= 0).sum().item()), "current_static": int((reg_out[1]["slot"][:, lc] >= 0).sum().item()),
-                        "already_attached": int((reg_out[1]["slot"][:, lc] == -1).sum().item()),
-                        "current_static_mergeable_over_the_whole_track": None if loop.pose_upd is None else int((loop.d_mergeable[:, lc] == 1).sum().item()),
-                        "current_static_tracks_longer_than_the_history": None if loop.pose_upd is None else int((loop.d_mergeable[:, lc] == 2).sum().item()),
-                        "history_note": "a candidate whose track is longer than the history (--hist, 64 frames) is reported as unjudged (2), not "
-                                        "walked and NOT attached: the reference walks the whole track"},
+                       {"current_points_listed": int(loop.d_curcount.item()), "list_cap": P_REG,
+                        "candidates": int((reg_out["slot"][:, lc] >= 0).sum().item()),
+                        "mergeable_over_the_whole_track": None if loop.pose_upd is None else int(((loop.d_mergeable[:, lc] == 1) & (reg_out["slot"][:, lc] >= 0)).sum().item()),
+                        "not_mergeable": None if loop.pose_upd is None else int(((loop.d_mergeable[:, lc] == 0) & (reg_out["slot"][:, lc] >= 0)).sum().item()),
+                        "unjudged_track_older_than_the_store": None if loop.pose_upd is None else int(((loop.d_mergeable[:, lc] == 2) & (reg_out["slot"][:, lc] >= 0)).sum().item()),
+                        "running_verdict": None if loop.pose_upd is None else dict(zip(
+                            ("cache_hits", "full_tail_walks", "verdicts_unjudged", "tail_terms_evaluated"), loop.d_merge_counts.cpu().tolist()),
+                            frames=n_timed_end, window_frames=cfg.hist, store_frames=cfg.hist_store, tol_pix=cfg.merge_tol_pix,
+                            what="staticCheckMergability over WHOLE tracks (reference SL_CoSLAM.cpp:714-729): the newest 64 frames of a candidate's "
+                                 "track walked every frame as they stand, the verdict over the older ones cached per (map point, camera) and extended "
+                                 "by one term per frame (cs_register_mergability_running_dev); counts summed over the whole run"),
+                        "active_search": "off: the reference's activeMapPointsRegister cannot attach (numVisCam == 0 on actMapPts, SL_CoSLAM.cpp:1114; "
+                                         "tests/cxx/ref_active_test.cpp)" if not cfg.with_active_search else "on (diagnostic)"},
                        "register_decision": None if dec_counts is None else dict(zip(
                            ("features_attached_last_frame", "points_regged_last_frame", "sweeps_last_frame", "converged"), dec_counts[0]),
                            points_refined_last_frame=dec_counts[1],

@@ -47,6 +47,7 @@ namespace {
 
 constexpr int PU_MAX_CAMS = 16;
 constexpr int PU_MAX_HIST = 512;
+constexpr int PU_MAX_STORE = 1 << 16;
 constexpr int PU_LPS = 8;  // lanes per slot in the dynamic-point test
 
 struct PuArgs {
@@ -330,6 +331,28 @@ struct MgArgs {
 // the frames: the order in which they are tested does not enter it), so a candidate's 64-frame walk is 8 steps deep and the
 // 12 k candidates of a pass are 1500 waves -- the whole chip -- instead of 190 waves walking 64 dependent steps each (68 us).
 constexpr int MG_LPC = 8;
+// one frame's term of the walk (:718-726): the feature (mx, my) against the point's projection under that frame's pose, Mahalanobis
+// distance^2 > 1 under J cov J^T + sigma^2 I
+__device__ __forceinline__ bool mg_term_fails(const double* __restrict__ K, const double* R, const double* t, const double* M, const double* cov,
+                                              double sigma, double mx, double my) {
+    const PuProj q = pu_project(K, R, t, M);
+    const double rm0 = q.u / q.w, rm1 = q.v / q.w;
+    double JC[6], var[4], ivar[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) JC[3 * i + k] = (q.J[3 * i] * cov[k] + q.J[3 * i + 1] * cov[3 + k]) + q.J[3 * i + 2] * cov[6 + k];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double sv = (JC[3 * i] * q.J[3 * k] + JC[3 * i + 1] * q.J[3 * k + 1]) + JC[3 * i + 2] * q.J[3 * k + 2];
+            var[2 * i + k] = (i == k) ? sv + sigma * sigma : sv;
+        }
+    pu_mat22_inv(var, ivar);
+    const double dx = rm0 - mx, dy = rm1 - my;
+    return dx * (ivar[0] * dx + ivar[1] * dy) + dy * (ivar[2] * dx + ivar[3] * dy) > 1.0;  // :723
+}
 __global__ __launch_bounds__(256) void k_register_mergability(MgArgs A) {
     extern __shared__ double mg_pose[];  // [nHist][12]
     CS_POSE_STREAM_PRIO();
@@ -366,29 +389,153 @@ __global__ __launch_bounds__(256) void k_register_mergability(MgArgs A) {
             const double* t = R + 9;
             const int rs = (A.head - j + H) % H;
             const double mx = hXY[(size_t)rs * 2 * N + s], my = hXY[(size_t)rs * 2 * N + N + s];
-            const PuProj q = pu_project(C.K, R, t, M);
-            const double rm0 = q.u / q.w, rm1 = q.v / q.w;
-            double JC[6], var[4], ivar[4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) JC[3 * i + k] = (q.J[3 * i] * cov[k] + q.J[3 * i + 1] * cov[3 + k]) + q.J[3 * i + 2] * cov[6 + k];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const double sv = (JC[3 * i] * q.J[3 * k] + JC[3 * i + 1] * q.J[3 * k + 1]) + JC[3 * i + 2] * q.J[3 * k + 2];
-                    var[2 * i + k] = (i == k) ? sv + A.sigma * A.sigma : sv;
-                }
-            pu_mat22_inv(var, ivar);
-            const double dx = rm0 - mx, dy = rm1 - my;
-            fail = dx * (ivar[0] * dx + ivar[1] * dy) + dy * (ivar[2] * dx + ivar[3] * dy) > 1.0;  // :723
+            fail = mg_term_fails(C.K, R, t, M, cov, A.sigma, mx, my);
         }
     }
     const unsigned long long b = __builtin_amdgcn_ballot_w64(fail);
     if (live && r == 0) {
         const bool anyFail = ((b >> (MG_LPC * g)) & ((1ull << MG_LPC) - 1ull)) != 0ull;
         A.out[(size_t)p * A.nCams + c] = s < 0 ? 255 : (cut ? 2 : (anyFail ? 0 : 1));
+    }
+}
+
+
+// ---- staticCheckMergability over WHOLE tracks as a running verdict --------------------------------------------------------------
+// The reference walks a candidate's track to its first frame (:715-729); tracks live for hundreds of frames, the candidates of a
+// frame are ~10 k, and re-walking all of it every frame would cost more than the rest of the frame.  Here the walk is split at
+// W = the history's walk depth (64 frames):
+//   the WINDOW -- the newest W frames of the track -- is walked every frame with the point, covariance and poses as they stand
+//                 (these are the frames a bundle adjustment still moves: a window BA's first key frame is < W frames old);
+//   the TAIL   -- every older frame, back to the track's first -- has its verdict CACHED per (map point, camera): which slot, which
+//                 track (its first frame), up to which frame the tail has been judged, the AND of those terms, and the point's
+//                 position they were judged with.  A frame that crosses from the window into the tail adds its one term (judged
+//                 with the point as it stands then; its pose is final by then).  The cache is dropped -- and the whole tail walked
+//                 again from the kept frames (the ring stores storeLen >> W frames: cs_track_history_create_ex) -- when the
+//                 candidate is another slot, the slot's track restarted, or the point has moved by more than tolPix pixels in
+//                 this camera's image since the tail was judged (|M - Mref| fx / z: every cached term is then at most that far
+//                 from what a fresh walk would test, against a gate of sigma = 10 px).
+// With the point and the poses held still (the golden tracks of the reference's own function, 200-420 frames) the verdict is the
+// reference's, term for term, whichever way the frames arrived.  A track whose first frame has left even the store: verdict 2.
+struct MgCache {   // 48 bytes, zero = empty
+    int slot1;     // candidate slot + 1
+    int f1;        // the track's first frame
+    int upto;      // the tail covers frames f1 .. upto
+    int ok;        // AND of the tail's terms
+    double M[3];   // the point the terms were judged with
+    double pad;
+};
+static_assert(sizeof(MgCache) == 48, "cs_register_mergability_cache_bytes");
+struct MgRunArgs {
+    MgArgs a;
+    int W, count, curFrame;  // window depth, frames the ring holds, frame number of the ring's head
+    double tolPix;
+    MgCache* cache;          // [P][nCams]
+    int* counts;             // [4] or null: cache hits, full tail walks, verdicts 2, tail terms evaluated
+    const int* list;         // null, or the rows to judge: list[0 .. nList), entries < 0 skipped
+    int nList;
+};
+__global__ __launch_bounds__(256) void k_register_mergability_running(MgRunArgs B) {
+    extern __shared__ double mg_pose[];  // [W][12]
+    CS_POSE_STREAM_PRIO();
+    const MgArgs& A = B.a;
+    const int c = A.cam0 + blockIdx.y, tid = threadIdx.x, N = A.N, H = A.H, W = B.W;
+    const cs_poseupdate_cam& C = A.cam[c];
+    const double* hR = A.histR + (size_t)c * H * 9;
+    const double* hT = A.histT + (size_t)c * H * 3;
+    const double* hXY = A.histXY + (size_t)c * H * 2 * N;
+    for (int q = tid; q < W * 12; q += 256) {
+        const int j = q / 12, e = q - 12 * j, rs = (A.head - j + H) % H;
+        mg_pose[q] = e < 9 ? hR[(size_t)rs * 9 + e] : hT[(size_t)rs * 3 + (e - 9)];
+    }
+    __syncthreads();
+    const int lane = tid & 63, r = lane % MG_LPC, g = lane / MG_LPC;
+    const unsigned long long gmask = ((1ull << MG_LPC) - 1ull) << (MG_LPC * g);
+    const int jj = (blockIdx.x * 256 + tid) / MG_LPC;
+    const int p = B.list ? (jj < B.nList ? B.list[jj] : -1) : (jj < A.P ? jj : -1);
+    const bool live = p >= 0 && p < A.P;
+    const int s = live ? A.slot[(size_t)p * A.nCams + c] : -1;
+    bool failW = false, cut = false, tailOK = true, hit = false, walked = false;
+    int nTerms = 0;
+    if (s >= 0) {
+        double M[3], cov[9];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) M[q] = A.M[3 * (size_t)p + q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) cov[q] = A.cov[9 * (size_t)p + q];
+        const int f1 = C.trackSpan[s], f2 = C.trackSpan[N + s];
+        const int len = f1 >= 0 ? f2 - f1 + 1 : 0;
+        const int depth = len < W ? len : W;
+        const int end = B.curFrame - W;  // the tail: frames f1 .. end (walk depths W .. len - 1)
+        MgCache* E = B.cache + (size_t)p * A.nCams + c;
+        MgCache e = *E;   // (the group's lanes read the same 48 bytes)
+        double Mref[3] = {M[0], M[1], M[2]};
+        int start = f1;
+        if (len > W) {
+            // how far has the point moved in this camera's image since the tail was judged?
+            const double* R0 = mg_pose;
+            const double z = ((R0[6] * M[0] + R0[7] * M[1]) + R0[8] * M[2]) + R0[11];
+            const double d0 = M[0] - e.M[0], d1 = M[1] - e.M[1], d2 = M[2] - e.M[2];
+            const double shift2 = (d0 * d0 + d1 * d1) + d2 * d2;
+            const double lim = B.tolPix * z / C.K[0];
+            hit = e.slot1 == s + 1 && e.f1 == f1 && e.upto >= f1 - 1 && e.upto <= end && z > 0 && shift2 <= lim * lim;
+            if (hit) {
+                start = e.upto + 1, tailOK = e.ok != 0;
+                Mref[0] = e.M[0], Mref[1] = e.M[1], Mref[2] = e.M[2];
+            }
+            if (tailOK && start <= end) {
+                if (B.curFrame - start >= B.count) {
+                    cut = true;   // the frames to judge have left even the store
+                } else {
+                    walked = !hit;
+                    for (int f = start; f <= end && tailOK; f += MG_LPC) {
+                        bool fail = false;
+                        const int ff = f + r;
+                        if (ff <= end) {
+                            const int j = B.curFrame - ff, rs = ((A.head - j) % H + H) % H;
+                            double Rt[12];
+#pragma unroll
+                            for (int q = 0; q < 9; ++q) Rt[q] = hR[(size_t)rs * 9 + q];
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) Rt[9 + q] = hT[(size_t)rs * 3 + q];
+                            const double mx = hXY[(size_t)rs * 2 * N + s], my = hXY[(size_t)rs * 2 * N + N + s];
+                            fail = mg_term_fails(C.K, Rt, Rt + 9, M, cov, A.sigma, mx, my);
+                            ++nTerms;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(fail) & gmask) tailOK = false;
+                    }
+                }
+            }
+        }
+        if (!cut && tailOK) {   // (a failed tail decides: the window is not walked)
+            for (int j = r; j < depth && !failW; j += MG_LPC) {
+                const double* R = mg_pose + 12 * j;
+                const double* t = R + 9;
+                const int rs = (A.head - j + H) % H;
+                const double mx = hXY[(size_t)rs * 2 * N + s], my = hXY[(size_t)rs * 2 * N + N + s];
+                failW = mg_term_fails(C.K, R, t, M, cov, A.sigma, mx, my);
+            }
+        }
+        if (!cut && r == 0 && len > 0) {
+            MgCache w;
+            w.slot1 = s + 1, w.f1 = f1, w.upto = len > W ? end : f1 - 1, w.ok = tailOK ? 1 : 0;
+            w.M[0] = Mref[0], w.M[1] = Mref[1], w.M[2] = Mref[2], w.pad = 0;
+            *E = w;
+        }
+    }
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(failW);
+    if (live && r == 0) A.out[(size_t)p * A.nCams + c] = s < 0 ? 255 : (cut ? 2 : ((b & gmask) != 0ull || !tailOK ? 0 : 1));
+    if (B.counts) {
+        const unsigned long long bh = __builtin_amdgcn_ballot_w64(hit && r == 0), bw = __builtin_amdgcn_ballot_w64(walked && r == 0),
+                                 bc = __builtin_amdgcn_ballot_w64(cut && r == 0);
+        int terms = nTerms;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) terms += __shfl_xor(terms, o, 64);
+        if (lane == 0) {
+            if (bh) atomicAdd(B.counts, __popcll(bh));
+            if (bw) atomicAdd(B.counts + 1, __popcll(bw));
+            if (bc) atomicAdd(B.counts + 2, __popcll(bc));
+            if (terms) atomicAdd(B.counts + 3, terms);
+        }
     }
 }
 
@@ -1236,7 +1383,9 @@ __global__ __launch_bounds__(256) void k_history_span(int set, int nCams, int fi
 }  // namespace
 
 struct cs_track_history {
-    int device, nCams, N, H;
+    int device, nCams, N, H;  // H: ring capacity in frames (cs_track_history_create_ex: storeLen >= histLen)
+    int walkLen;              // histLen: how deep the bounded walks go (dynamic test, classification, re-triangulation, checkUnify, the
+                              // mergability walk's exact window); the frames beyond it are only read by cs_register_mergability_running_dev
     int head, count, lastFrame;
     double *xy, *R, *t;
     // scratch of the map-point kernels (one stream at a time may run them on a handle): the camera centres by walk depth
@@ -1252,17 +1401,29 @@ struct cs_track_history {
 // the camera centres by walk depth, if the ring's poses changed since they were last computed
 static void hist_centres(const cs_track_history* h, hipStream_t s);
 
+static inline int hist_walk(const cs_track_history* h) { return h->count < h->walkLen ? h->count : h->walkLen; }
+
 extern "C" cs_track_history* cs_track_history_create(int device, int nCams, int N, int histLen) {
-    if (nCams < 1 || nCams > PU_MAX_CAMS || N < 1 || histLen < 1 || histLen > PU_MAX_HIST) {
-        cs_set_error("cs_track_history_create: nCams in 1..%d, N >= 1, histLen in 1..%d", PU_MAX_CAMS, PU_MAX_HIST);
+    return cs_track_history_create_ex(device, nCams, N, histLen, histLen);
+}
+
+// storeLen >= histLen frames are KEPT (pixels of every slot + poses: 16 N + 96 bytes per camera and frame -- 4096 frames of 8 cameras x
+// 2000 slots are 1 GB of the 288); the walks of every kernel but the running mergability verdict stay histLen deep
+extern "C" cs_track_history* cs_track_history_create_ex(int device, int nCams, int N, int histLen, int storeLen) {
+    if (nCams < 1 || nCams > PU_MAX_CAMS || N < 1 || histLen < 1 || histLen > PU_MAX_HIST || storeLen < histLen || storeLen > PU_MAX_STORE) {
+        cs_set_error("cs_track_history_create: nCams in 1..%d, N >= 1, histLen in 1..%d, histLen <= storeLen <= %d", PU_MAX_CAMS, PU_MAX_HIST,
+                     PU_MAX_STORE);
         return nullptr;
     }
+    const int walkLen_ = histLen;
+    histLen = storeLen;
     if (hipSetDevice(device) != hipSuccess) {
         cs_set_error("cs_track_history_create: no usable HIP device %d (there is no CPU fallback)", device);
         return nullptr;
     }
     cs_track_history* h = new cs_track_history();
     h->device = device, h->nCams = nCams, h->N = N, h->H = histLen;
+    h->walkLen = walkLen_;
     h->head = -1, h->count = 0, h->lastFrame = -0x7fffffff;
     h->clsList = nullptr, h->clsCap = 0, h->clsPar = 0;
     h->ringVersion = 1, h->cenVersion = 0;
@@ -1292,8 +1453,8 @@ extern "C" int cs_track_history_frames(const cs_track_history* h) { return h ? h
 
 static void hist_centres(const cs_track_history* h, hipStream_t s) {
     if (h->cenVersion == h->ringVersion) return;
-    hipLaunchKernelGGL(k_ring_centres, dim3((h->nCams * h->count + 255) / 256), dim3(256), 0, s, h->nCams, h->H, h->head, h->count, h->R, h->t,
-                       h->cen);
+    hipLaunchKernelGGL(k_ring_centres, dim3((h->nCams * hist_walk(h) + 255) / 256), dim3(256), 0, s, h->nCams, h->H, h->head, hist_walk(h), h->R,
+                       h->t, h->cen);
     h->cenVersion = h->ringVersion;
 }
 
@@ -1354,7 +1515,7 @@ void pu_advance(cs_track_history* h, int frame) {
 }
 
 void pu_fill_dyn(PuArgs& A, cs_track_history* h, int minLen, int minOutNum, double maxEpiErr, int* d_numDyn) {
-    A.H = h->H, A.head = h->head, A.nHist = h->count;
+    A.H = h->H, A.head = h->head, A.nHist = hist_walk(h);
     A.histXY = h->xy, A.histR = h->R, A.histT = h->t;
     A.minLen = minLen, A.minOutNum = minOutNum, A.maxEpiErr = maxEpiErr;
     A.numDyn = d_numDyn;
@@ -1451,7 +1612,7 @@ extern "C" int cs_register_mergability_range_dev(const cs_track_history* h, void
     MgArgs A;
     memset(&A, 0, sizeof(A));
     A.cam0 = cam0;
-    A.nCams = h->nCams, A.N = h->N, A.P = P, A.H = h->H, A.head = h->head, A.nHist = h->count;
+    A.nCams = h->nCams, A.N = h->N, A.P = P, A.H = h->H, A.head = h->head, A.nHist = hist_walk(h);
     A.sigma = pixelErrVar;
     A.M = d_M, A.cov = d_cov, A.slot = d_slot, A.out = d_mergeable;
     A.histXY = h->xy, A.histR = h->R, A.histT = h->t;
@@ -1463,8 +1624,70 @@ extern "C" int cs_register_mergability_range_dev(const cs_track_history* h, void
         A.cam[c] = cams[c];
     }
     CS_HIP(hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_register_mergability, dim3((P * MG_LPC + 255) / 256, nCamsRun), dim3(256), sizeof(double) * 12 * (size_t)h->count,
+    hipLaunchKernelGGL(k_register_mergability, dim3((P * MG_LPC + 255) / 256, nCamsRun), dim3(256), sizeof(double) * 12 * (size_t)hist_walk(h),
                        (hipStream_t)hip_stream, A);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+extern "C" size_t cs_register_mergability_cache_bytes(int P, int nCams) { return P > 0 && nCams > 0 ? sizeof(MgCache) * (size_t)P * nCams : 0; }
+
+// staticCheckMergability over whole tracks with the tail's verdict cached per (map point, camera) -- see k_register_mergability_running.
+// d_cache: cs_register_mergability_cache_bytes(P, nCams) bytes, ZERO-filled before the first call, kept between the frames (point p of
+// one call must be point p of the next); tolPix: how far a point may move in the camera's image before its cached tail is judged
+// again (0: any motion); d_counts [4] or NULL (added to): cache hits, full tail walks, verdicts 2, tail terms evaluated.
+extern "C" int cs_register_mergability_running_dev(const cs_track_history* h, void* hip_stream, int cam0, int nCamsRun,
+                                                   const cs_poseupdate_cam* cams, int P, const double* d_M, const double* d_cov,
+                                                   const int* d_slot, double pixelErrVar, double tolPix, void* d_cache,
+                                                   unsigned char* d_mergeable, int* d_counts) {
+    return cs_register_mergability_running_list_dev(h, hip_stream, cam0, nCamsRun, cams, P, nullptr, 0, d_M, d_cov, d_slot, pixelErrVar, tolPix, d_cache,
+                                                    d_mergeable, d_counts);
+}
+extern "C" int cs_register_mergability_running_list_dev(const cs_track_history* h, void* hip_stream, int cam0, int nCamsRun,
+                                                        const cs_poseupdate_cam* cams, int P, const int* d_list, int nList, const double* d_M,
+                                                        const double* d_cov, const int* d_slot, double pixelErrVar, double tolPix, void* d_cache,
+                                                        unsigned char* d_mergeable, int* d_counts) {
+    if (h && (cam0 < 0 || nCamsRun < 0 || cam0 + nCamsRun > h->nCams)) {
+        cs_set_error("cs_register_mergability_running_dev: camera range %d + %d of %d", cam0, nCamsRun, h->nCams);
+        return CS_ERR_INVALID;
+    }
+    if (!h || !cams || P < 0 || tolPix < 0 || (P > 0 && (!d_M || !d_cov || !d_slot || !d_mergeable || !d_cache))) {
+        cs_set_error("cs_register_mergability_running_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (h->count < 1) {
+        cs_set_error("cs_register_mergability_running_dev: the history holds no frame");
+        return CS_ERR_INVALID;
+    }
+    if (d_list && nList < 0) {
+        cs_set_error("cs_register_mergability_running_list_dev: nList < 0");
+        return CS_ERR_INVALID;
+    }
+    const int rows = d_list ? nList : P;
+    if (P == 0 || nCamsRun == 0 || rows == 0) return CS_OK;
+    MgRunArgs B;
+    memset(&B, 0, sizeof(B));
+    B.list = d_list, B.nList = nList;
+    MgArgs& A = B.a;
+    A.cam0 = cam0;
+    A.nCams = h->nCams, A.N = h->N, A.P = P, A.H = h->H, A.head = h->head, A.nHist = hist_walk(h);
+    A.sigma = pixelErrVar;
+    A.M = d_M, A.cov = d_cov, A.slot = d_slot, A.out = d_mergeable;
+    A.histXY = h->xy, A.histR = h->R, A.histT = h->t;
+    for (int c = 0; c < h->nCams; ++c) {
+        if (!cams[c].K || !cams[c].trackSpan) {
+            cs_set_error("cs_register_mergability_running_dev: null pointer in camera %d", c);
+            return CS_ERR_INVALID;
+        }
+        A.cam[c] = cams[c];
+    }
+    B.W = hist_walk(h), B.count = h->count, B.curFrame = h->lastFrame;
+    B.tolPix = tolPix;
+    B.cache = (MgCache*)d_cache;
+    B.counts = d_counts;
+    CS_HIP(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_register_mergability_running, dim3((rows * MG_LPC + 255) / 256, nCamsRun), dim3(256), sizeof(double) * 12 * (size_t)B.W,
+                       (hipStream_t)hip_stream, B);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
@@ -1521,7 +1744,7 @@ int up_launch(const char* who, const cs_track_history* h, void* hip_stream, cons
         cs_set_error("%s: the history holds no frame (cs_pose_update_frame_dev / cs_detect_dynamic_dev push one per frame)", who);
         return CS_ERR_INVALID;
     }
-    A.nCams = h->nCams, A.N = h->N, A.H = h->H, A.head = h->head, A.nHist = h->count;
+    A.nCams = h->nCams, A.N = h->N, A.H = h->H, A.head = h->head, A.nHist = hist_walk(h);
     A.histXY = h->xy, A.histR = h->R, A.histT = h->t;
     A.counts = d_counts;
     for (int c = 0; c < h->nCams; ++c) {
@@ -1595,7 +1818,7 @@ extern "C" int cs_check_unify_dev(const cs_track_history* h, void* hip_stream, c
     if (nPairs == 0) return CS_OK;
     CuArgs A;
     memset(&A, 0, sizeof(A));
-    A.nCams = h->nCams, A.N = h->N, A.H = h->H, A.head = h->head, A.nHist = h->count, A.nPairs = nPairs;
+    A.nCams = h->nCams, A.N = h->N, A.H = h->H, A.head = h->head, A.nHist = hist_walk(h), A.nPairs = nPairs;
     A.pf1 = d_pf1, A.pf2 = d_pf2, A.M1 = d_M1, A.M2 = d_M2;
     A.histXY = h->xy, A.histR = h->R, A.histT = h->t, A.cen = h->cen;
     A.sigma = pixelErrVar;
@@ -1630,7 +1853,7 @@ extern "C" int cs_register_decide_merge_dev(const cs_track_history* h, void* hip
     }
     DmArgs A;
     memset(&A, 0, sizeof(A));
-    A.cu.nCams = h->nCams, A.cu.N = h->N, A.cu.H = h->H, A.cu.head = h->head, A.cu.nHist = h->count;
+    A.cu.nCams = h->nCams, A.cu.N = h->N, A.cu.H = h->H, A.cu.head = h->head, A.cu.nHist = hist_walk(h);
     A.cu.histXY = h->xy, A.cu.histR = h->R, A.cu.histT = h->t, A.cu.cen = h->cen;
     A.cu.sigma = pixelErrVar;
     for (int c = 0; c < h->nCams; ++c) {
@@ -1671,7 +1894,7 @@ extern "C" int cs_map_points_classify_dev(const cs_track_history* h, void* hip_s
     }
     ClsArgs A;
     memset(&A, 0, sizeof(A));
-    A.nCams = h->nCams, A.N = h->N, A.nMap = nMap, A.H = h->H, A.head = h->head, A.nHist = h->count, A.curFrame = curFrame;
+    A.nCams = h->nCams, A.N = h->N, A.nMap = nMap, A.H = h->H, A.head = h->head, A.nHist = hist_walk(h), A.curFrame = curFrame;
     A.pointFeat = d_pointFeat, A.featFrame = d_featFrame, A.featFirst = d_featFirst;
     A.histXY = h->xy, A.histR = h->R, A.histT = h->t, A.cen = h->cen;
     A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.mapFlags = d_mapFlags, A.newPt = d_newPt, A.staticFrameNum = d_staticFrameNum;

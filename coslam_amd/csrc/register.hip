@@ -102,8 +102,11 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
     CS_POSE_STREAM_PRIO();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = A.cam0 + blockIdx.y;
-    const int p = blockIdx.x * 64 + lane;
     const cs_register_pass& Q = A.pass[blockIdx.z];
+    // Q.list: the pass's points are list[0 .. P) (map indices, < 0: no point) -- the tables stay indexed by the MAP index, so a compact
+    // list of the frame's current points (cs_register_list_current_dev) costs one workgroup per 64 LISTED points and camera
+    const int j = blockIdx.x * 64 + lane;
+    const int p = Q.list ? (j < Q.P ? Q.list[j] : -1) : (j < Q.P ? j : -1);
     const cs_register_cam& C = A.cam[c];
     const int N = A.N;
     const int CH = N < RG_CHUNK ? N : RG_CHUNK;
@@ -111,13 +114,13 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
     double* sy = lds + CH;
     double* cd = lds + 2 * CH;                        // [RG_ROWS][64]
     int* ci = (int*)(cd + RG_ROWS * 64);              // [RG_WAVES][64]
-    const size_t o = (size_t)p * A.nCams + c;
+    const size_t o = (size_t)(p < 0 ? 0 : p) * A.nCams + c;
     int outSlot = -1, outFlags = 0;
     double m0 = 0, m1 = 0, var[4] = {0, 0, 0, 0}, outDist = 0;
     double ivar[4] = {0, 0, 0, 0};
     bool search = false;
     Proj q;
-    if (wave == 0 && p < Q.P && Q.pointFeat[o] < 0) {  // SL_CoSLAM.cpp:737-738: no feature of this frame attached in this camera yet
+    if (wave == 0 && p >= 0 && Q.pointFeat[o] < 0) {  // SL_CoSLAM.cpp:737-738: no feature of this frame attached in this camera yet
         const double *K = C.K, *R = C.R, *t = C.t, *M = Q.M + 3 * (size_t)p;
         const double X = ((R[0] * M[0] + R[1] * M[1]) + R[2] * M[2]) + t[0];
         const double Y = ((R[3] * M[0] + R[4] * M[1]) + R[5] * M[2]) + t[1];
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
             }
         }
     }
-    if (wave == 0 && p < Q.P) {
+    if (wave == 0 && p >= 0) {
         Q.slot[o] = outSlot;
         Q.flags[o] = outFlags;
         Q.dist[o] = outDist;
@@ -226,6 +229,50 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) Q.var[4 * o + k] = var[k];
     }
+}
+
+// ---- the frame's CURRENT map points as a compact list ------------------------------------------------------------------------------
+// CoSLAM::currentMapPointsRegister walks curMapPts: the points with a feature of this frame in at least one camera (mapStateUpdate,
+// src/app/SL_CoSLAM.cpp:1176-1194, moves every other point off the list; :734 / :958 ask numVisCam > 0 again) -- wherever they sit
+// in the map, the points genNewMapPoints has just appended included.  One workgroup: a point is listed when it lies below the
+// live count, is not false (neither registration loop visits a false point) and holds a feature of this frame; the list keeps the
+// map's order (the order the reference's walks visit the points in).  list[count .. nMap) = -1; the rows of the points that
+// are NOT listed get slot = -1 in `slotTable` (nMap x nCams, optional), so that the tables never carry a stale candidate.
+__global__ __launch_bounds__(1024) void k_register_list(int nCams, int nMap, const int* __restrict__ mapCount, const int* __restrict__ pointFeat,
+                                                        const unsigned char* __restrict__ mapFlags, int* __restrict__ list,
+                                                        int* __restrict__ listCount, int* __restrict__ slotTable) {
+    __shared__ int waveSum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int live = mapCount ? (*mapCount < nMap ? *mapCount : nMap) : nMap;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int p0 = 0; p0 < nMap; p0 += 1024) {
+        const int p = p0 + tid;
+        bool in = false;
+        if (p < live && !(mapFlags && (mapFlags[p] & CS_MAP_FALSE))) {
+            for (int c = 0; c < nCams; ++c) in |= pointFeat[(size_t)p * nCams + c] >= 0;
+        }
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(in);
+        const int before = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) waveSum[wv] = __popcll(b);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wv; ++w) off += waveSum[w];
+        if (in) list[off + before] = p;
+        if (!in && p < nMap && slotTable)
+            for (int c = 0; c < nCams; ++c) slotTable[(size_t)p * nCams + c] = -1;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += waveSum[w];
+            base += t;
+        }
+        __syncthreads();
+    }
+    const int n = base;
+    for (int q = n + tid; q < nMap; q += 1024) list[q] = -1;
+    if (tid == 0 && listCount) *listCount = n;
 }
 
 int check_args(const char* who, int nCams, const cs_register_cam* cams, int N, int W, int H, int P, double sigmaSearch,
@@ -239,6 +286,20 @@ int check_args(const char* who, int nCams, const cs_register_cam* cams, int N, i
 }
 
 }  // namespace
+
+extern "C" int cs_register_list_current_dev(int device, void* hip_stream, int nCams, int nMap, const int* d_mapCount, const int* d_pointFeat,
+                                            const unsigned char* d_mapFlags, int* d_list, int* d_listCount, int* d_slotTable) {
+    if (nCams < 1 || nCams > RG_MAX_CAMS || nMap < 0 || (nMap > 0 && (!d_pointFeat || !d_list))) {
+        cs_set_error("cs_register_list_current_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (nMap == 0) return CS_OK;
+    CS_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_register_list, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, nCams, nMap, d_mapCount, d_pointFeat, d_mapFlags, d_list,
+                       d_listCount, d_slotTable);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
 
 extern "C" int cs_register_search_passes_dev(int device, void* hip_stream, int nCams, const cs_register_cam* cams, int N, int W, int H,
                                              int nPass, const cs_register_pass* passes) {
@@ -523,6 +584,59 @@ __global__ __launch_bounds__(256) void k_candidates_unpack(int P, int nCams, int
 }
 
 }  // namespace
+
+namespace {
+// the same over a LIST of rows (cs_register_list_current_dev: identical on every rank, since every rank holds the same pointFeat table): row j of
+// the record = map point list[j], j < cap; entries of rows beyond the list travel as -1 / 0 / 255.  The record stays cap rows long whatever
+// the map's capacity is.
+__global__ __launch_bounds__(256) void k_candidates_pack_list(int cap, int nCams, int cam0, int nOwn, const int* __restrict__ list,
+                                                              const int* __restrict__ slot, const int* __restrict__ flags,
+                                                              const unsigned char* __restrict__ merg, int* __restrict__ send) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nOwn * cap) return;
+    const int i = q / cap, j = q - i * cap, p = list[j];
+    const size_t k = (size_t)(p < 0 ? 0 : p) * nCams + cam0 + i;
+    send[q] = p < 0 ? -1 : slot[k], send[nOwn * cap + q] = p < 0 ? 0 : flags[k], send[2 * nOwn * cap + q] = p < 0 ? 255 : merg[k];
+}
+__global__ __launch_bounds__(256) void k_candidates_unpack_list(int cap, int nCams, int nOwn, int skipRank, const int* __restrict__ list,
+                                                                const int* __restrict__ recv, int* __restrict__ slot, int* __restrict__ flags,
+                                                                unsigned char* __restrict__ merg) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nCams * cap) return;
+    const int g = q / cap, j = q - g * cap, r = g / nOwn, i = g - r * nOwn, p = list[j];
+    if (r == skipRank || p < 0) return;
+    const int* rec = recv + (size_t)r * 3 * nOwn * cap;
+    const size_t k = (size_t)p * nCams + g;
+    slot[k] = rec[i * cap + j], flags[k] = rec[nOwn * cap + i * cap + j], merg[k] = (unsigned char)rec[2 * nOwn * cap + i * cap + j];
+}
+}  // namespace
+
+extern "C" int cs_register_candidates_pack_list_dev(int device, void* hip_stream, int cap, int nCams, int cam0, int nOwn, const int* d_list,
+                                                    const int* d_slot, const int* d_flags, const unsigned char* d_mergeable, int* d_send) {
+    if (cap < 0 || nCams < 1 || cam0 < 0 || nOwn < 1 || cam0 + nOwn > nCams || !d_list || !d_slot || !d_flags || !d_mergeable || !d_send) {
+        cs_set_error("cs_register_candidates_pack_list_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (cap == 0) return CS_OK;
+    CS_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_candidates_pack_list, dim3((nOwn * cap + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, cap, nCams, cam0, nOwn, d_list,
+                       d_slot, d_flags, d_mergeable, d_send);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+extern "C" int cs_register_candidates_unpack_list_dev(int device, void* hip_stream, int cap, int nCams, int nOwn, int skipRank, const int* d_list,
+                                                      const int* d_recv, int* d_slot, int* d_flags, unsigned char* d_mergeable) {
+    if (cap < 0 || nCams < 1 || nOwn < 1 || nCams % nOwn || !d_list || !d_recv || !d_slot || !d_flags || !d_mergeable) {
+        cs_set_error("cs_register_candidates_unpack_list_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (cap == 0) return CS_OK;
+    CS_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_candidates_unpack_list, dim3((nCams * cap + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, cap, nCams, nOwn, skipRank,
+                       d_list, d_recv, d_slot, d_flags, d_mergeable);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
 
 extern "C" int cs_register_candidates_pack_dev(int device, void* hip_stream, int P, int nCams, int cam0, int nOwn, const int* d_slot,
                                                const int* d_flags, const unsigned char* d_mergeable, int* d_send) {

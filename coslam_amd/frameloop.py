@@ -38,8 +38,14 @@ class LoopConfig:
         self.key_every, self.n_key_frames = 5, 5                         # requestForBA(5, 2, 2, 30), SL_CoSLAM.cpp:1345
         self.ic_workers = 1        # workspaces (worker threads) the inter-camera solves of this rank rotate over (2 on one GPU: measured slower)
         self.ba_lag = 0            # key-frame intervals between a window's key frame and the frame its result is applied; 0 = min(max(N, 2), 4)
-        self.p_reg = 1536
-        self.hist = 64
+        self.p_reg = 4096          # cap on the frame's CURRENT map points (the registration's list: cs_register_list_current_dev)
+        self.hist = 64             # depth of the bounded walks (dynamic test, classification, re-triangulation; the mergability walk's exact window)
+        self.hist_store = 4096     # frames of pixels + poses KEPT behind them (1 GB for 8 x 2000 slots): what the running whole-track
+                                   # mergability verdict rebuilds a cached tail from (cs_register_mergability_running_dev)
+        self.merge_tol_pix = 0.5   # a point that moved further than this in a camera's image has its cached tail judged again
+        self.with_active_search = False   # the search half of activeMapPointsRegister: OFF -- the reference's own attach loop cannot be
+        # reached (every point of actMapPts has numVisCam == 0, src/app/SL_CoSLAM.cpp:1114 asks for > 0: tests/cxx/ref_active_test.cpp runs
+        # the reference's code to say so), so the tables this pass used to fill fed nothing
         self.ncc_every, self.ncc_pair_cap = 4, 1 << 16
         self.map_spare = 8192      # room for new map points behind the initial map
         self.klt_cams_per_launch = 0
@@ -128,7 +134,6 @@ class FrameLoop:
         self.d_npts, self.d_opt, self.d_ok = z(NA, i32), z((NA, 96), u8), z(NA, i32)
         self.d_isstatic, self.d_reproj = torch.ones((NA, N), dtype=u8, device=dev), z((NA, N), f64)
         self.d_pf = torch.full((n_map, NA), -1, dtype=i32, device=dev)          # MapPoint::pFeatures of this frame (hand-back)
-        self.d_pf_none = torch.full((cfg.p_reg, NA), -1, dtype=i32, device=dev)
         R0 = np.stack([scene.pose(c, 0)[0].ravel() for c in range(NA)])
         t0 = np.stack([scene.pose(c, 0)[1] for c in range(NA)])
         self.d_R = [torch.from_numpy(R0.copy()).to(dev), torch.from_numpy(R0.copy()).to(dev)]   # pose ping-pong: frame i reads [(i+1)&1]
@@ -136,9 +141,12 @@ class FrameLoop:
         self.d_dests = [[z(N * 5, i32) for _ in range(nc)] for _ in range(2)]
         self.d_counts = [z(4, i32) for _ in range(nc)]
         self.d_cls_counts, self.d_apply_counts = z(2, i32), z(3, i32)
-        self.d_mergeable = z((cfg.p_reg, NA), u8)
-        self.reg_out = [dict(slot=z((cfg.p_reg, NA), i32), m=z((cfg.p_reg, NA, 2), f64), var=z((cfg.p_reg, NA, 4), f64),
-                             dist=z((cfg.p_reg, NA), f64), flags=z((cfg.p_reg, NA), i32)) for _ in range(2)]
+        # the registration's tables: indexed by the MAP index (whole-map tables); the frame's current points as a compact list
+        self.d_mergeable = z((n_map, NA), u8)
+        self.reg_out = dict(slot=torch.full((n_map, NA), -1, dtype=i32, device=dev), m=z((n_map, NA, 2), f64), var=z((n_map, NA, 4), f64),
+                            dist=z((n_map, NA), f64), flags=z((n_map, NA), i32))
+        self.d_curlist, self.d_curcount = torch.full((n_map,), -1, dtype=i32, device=dev), z(1, i32)
+        self.d_merge_counts = z(4, i32)   # running mergability: cache hits, full tail walks, verdicts 2, tail terms (summed over the run)
         # ---- streams
         self.klt_s, self.pose_s = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)   # (equal priorities: a high-priority pose or
         # tracker stream halves the rate, 2188 -> 942 / 906 frames/s: profiles/r04_ab_runs.txt)
@@ -222,7 +230,8 @@ class FrameLoop:
         self.img_ptrs = [[self.video[c][f].data_ptr() for c in self.my_cams] for f in range(self.T)]
         self.pose_upd = None
         if cfg.with_pose_update:
-            self.pose_upd = TrackHistory(NA, N, cfg.hist, device=device)
+            self.pose_upd = TrackHistory(NA, N, cfg.hist, device=device, storeLen=max(cfg.hist_store, cfg.hist))
+            self.d_merge_cache = z(self.pose_upd.mergability_cache_bytes(n_map), u8)
             self.pu_args = poseupdate_cams([dict(K=self.d_K1.data_ptr(), iK=self.d_iK1.data_ptr(), xy=self.d_xy[g].data_ptr(),
                                                  state=self.d_state[g].data_ptr(), slot2map=self.d_slot2map[g].data_ptr(),
                                                  trackSpan=self.d_trackspan[g].data_ptr(), reprojErr=self.d_reproj[g].data_ptr(),
@@ -231,17 +240,26 @@ class FrameLoop:
                                              xy=self.d_xy[g].data_ptr(), state=self.d_state[g].data_ptr(),
                                              slot2map=self.d_slot2map[g].data_ptr(), isStatic=self.d_isstatic[g].data_ptr())
                                         for g in range(NA)]) for b in range(2)]
-        # CoSLAMThread.cpp:108 activeMapPointsRegister, then :117 currentMapPointsRegister (static points), search step
-        self.reg_passes = register_passes([dict(P=cfg.p_reg, sigmaSearch=sS, maxDist=3 * PIXEL_ERR_VAR, sigmaMerge=PIXEL_ERR_VAR,
-                                                M=self.d_map.data_ptr() + 24 * off, cov=self.d_cov.data_ptr() + 72 * off, pointFeat=pf.data_ptr(),
-                                                slot=self.reg_out[k]["slot"].data_ptr(), m=self.reg_out[k]["m"].data_ptr(),
-                                                var=self.reg_out[k]["var"].data_ptr(), dist=self.reg_out[k]["dist"].data_ptr(),
-                                                flags=self.reg_out[k]["flags"].data_ptr(),
-                                                # the current points' pass serves the static AND the dynamic registration: the certainly
-                                                # dynamic points are searched with their own scale (SL_CoSLAM.cpp:973)
-                                                **(dict(mapFlags=self.d_mapflags.data_ptr(), maxDistDynamic=4 * PIXEL_ERR_VAR) if k == 1 else {}))
-                                           for k, (off, pf, sS) in enumerate(((cfg.p_reg, self.d_pf_none, 2.5 * PIXEL_ERR_VAR),
-                                                                              (0, self.d_pf, PIXEL_ERR_VAR)))])
+        # CoSLAMThread.cpp:117 currentMapPointsRegister, search step: ONE pass over the frame's current points (the list), wherever they sit
+        # in the map -- the points genNewMapPoints appended this frame included; it serves the static AND the dynamic registration (the
+        # certainly dynamic points are searched with their own scale, SL_CoSLAM.cpp:973)
+        o_ = self.reg_out
+        cur_pass = dict(P=cfg.p_reg, sigmaSearch=PIXEL_ERR_VAR, maxDist=3 * PIXEL_ERR_VAR, sigmaMerge=PIXEL_ERR_VAR, M=self.d_map.data_ptr(),
+                        cov=self.d_cov.data_ptr(), pointFeat=self.d_pf.data_ptr(), slot=o_["slot"].data_ptr(), m=o_["m"].data_ptr(),
+                        var=o_["var"].data_ptr(), dist=o_["dist"].data_ptr(), flags=o_["flags"].data_ptr(), mapFlags=self.d_mapflags.data_ptr(),
+                        maxDistDynamic=4 * PIXEL_ERR_VAR, list=self.d_curlist.data_ptr())
+        passes = [cur_pass]
+        if cfg.with_active_search:
+            # (diagnostic: the search half of activeMapPointsRegister as rounds 2-4 ran it -- points p_act0 .. + 1536 searched with the
+            # active loop's scale, their tables read by nothing)
+            self.act_out = dict(slot=z((1536, NA), i32), m=z((1536, NA, 2), f64), var=z((1536, NA, 4), f64), dist=z((1536, NA), f64),
+                                flags=z((1536, NA), i32), pf=torch.full((1536, NA), -1, dtype=i32, device=dev))
+            a_ = self.act_out
+            passes.append(dict(P=1536, sigmaSearch=2.5 * PIXEL_ERR_VAR, maxDist=3 * PIXEL_ERR_VAR, sigmaMerge=PIXEL_ERR_VAR,
+                               M=self.d_map.data_ptr() + 24 * 1536, cov=self.d_cov.data_ptr() + 72 * 1536, pointFeat=a_["pf"].data_ptr(),
+                               slot=a_["slot"].data_ptr(), m=a_["m"].data_ptr(), var=a_["var"].data_ptr(), dist=a_["dist"].data_ptr(),
+                               flags=a_["flags"].data_ptr()))
+        self.reg_passes = register_passes(passes)
         # ---- key-frame solves
         # the inter-camera solves of consecutive key frames are independent of each other (each starts from its own frame's poses):
         # key frame k of this rank goes to workspace k mod ic_workers, each with its own worker thread, stream and staging
@@ -476,7 +494,7 @@ class FrameLoop:
         from coslam_amd.register import register_search_passes_dev
 
         torch, cfg = self.torch, self.cfg
-        klt_s, pose_s, c0, nc = self.klt_s, self.pose_s, self.c0, self.nc
+        klt_s, pose_s, c0, nc, NA_ = self.klt_s, self.pose_s, self.c0, self.nc, self.cfg.n_cams
         f, fn = self.vid(i), self.vid(i + 1)
         b = i & 1
         if i >= 2:
@@ -536,13 +554,15 @@ class FrameLoop:
         if self.ncc is not None and i % cfg.ncc_every == 0:
             self._ncc_leg(i, f, dst)
         if cfg.with_register:
+            from coslam_amd.register import register_list_current_dev
+
+            # curMapPts of this frame as a list (mapStateUpdate, SL_CoSLAM.cpp:1176-1194); the rows of every other point lose their candidates
+            register_list_current_dev(ps, NA_, self.n_map, self.d_mapcount.data_ptr(), self.d_pf.data_ptr(), self.d_mapflags.data_ptr(),
+                                      self.d_curlist.data_ptr(), self.d_curcount.data_ptr(), self.reg_out["slot"].data_ptr(), device=self.device)
             register_search_passes_dev(ps, self.reg_args[dst], cfg.n_feat, cfg.W, cfg.H, self.reg_passes, device=self.device, cam0=c0,
                                        nCamsRun=nc)
             if self.pose_upd is not None and cfg.with_mergability:
-                # staticCheckMergability of every candidate of the current-static pass over its whole track (SL_CoSLAM.cpp:714-729, :768)
-                self.pose_upd.register_mergability_dev(ps, self.pu_args, cfg.p_reg, self.d_map.data_ptr(), self.d_cov.data_ptr(),
-                                                       self.reg_out[1]["slot"].data_ptr(), PIXEL_ERR_VAR, self.d_mergeable.data_ptr(),
-                                                       cam0=c0, nCamsRun=nc)
+                self._mergability(ps)
         if cfg.with_register and cfg.with_decide and self.pose_upd is not None and cfg.with_mergability:
             self._dst_now, self._frame_now = dst, i
             self._decide(ps)
@@ -561,6 +581,16 @@ class FrameLoop:
             else:
                 self._key_frame(i, dst)
 
+    def _mergability(self, ps):
+        """staticCheckMergability of every candidate of the current points' pass over its WHOLE track (SL_CoSLAM.cpp:714-729, :768), as a
+        running verdict: the newest `hist` frames walked as they stand, the older ones' verdict cached per (point, camera) and extended
+        by one term per frame (cs_register_mergability_running_dev) -- own cameras' columns"""
+        cfg = self.cfg
+        self.pose_upd.register_mergability_running_dev(ps, self.pu_args, self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
+                                                       self.reg_out["slot"].data_ptr(), PIXEL_ERR_VAR, self.d_merge_cache.data_ptr(),
+                                                       self.d_mergeable.data_ptr(), tolPix=cfg.merge_tol_pix, d_counts=self.d_merge_counts.data_ptr(),
+                                                       cam0=self.c0, nCamsRun=self.nc, d_list=self.d_curlist.data_ptr(), nList=cfg.p_reg)
+
     def _decide(self, ps):
         """currentMapPointsRegister's decisions -- curStaticPointsRegInGroup (reference src/app/SL_CoSLAM.cpp:854-898, 731-830, bMerge ==
         false) and behind it curDynamicPointsRegInGroup (:904-1020) on the certainly dynamic points, one call -- over the search
@@ -573,9 +603,9 @@ class FrameLoop:
             torch = self.torch
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.dev)   # noqa: E731
             self.n_merge_frames = 0
-            self._dec = dict(att=z((cfg.p_reg, NA), torch.uint8), reg=z(self.n_map, torch.uint8), cnt=z(4, torch.int32), ref_cnt=z(1, torch.int32),
+            self._dec = dict(att=z((self.n_map, NA), torch.uint8), reg=z(self.n_map, torch.uint8), cnt=z(4, torch.int32), ref_cnt=z(1, torch.int32),
                              mcnt=z(4, torch.int32),
-                             scr=z(register_decide_scratch_bytes(NA, cfg.n_feat, cfg.p_reg), torch.uint8), s2m=None)
+                             scr=z(register_decide_scratch_bytes(NA, cfg.n_feat, self.n_map), torch.uint8), s2m=None)
             torch.cuda.synchronize()   # (the zero fills ran on torch's stream: done before the pose stream touches the buffers)
         D = self._dec
         if self.sequential_registration:
@@ -585,24 +615,24 @@ class FrameLoop:
                 raise RuntimeError("sequential_registration: one rank only (the per-loop tables are not exchanged)")
             if not hasattr(self, "_pass_current"):
                 T_ = type(self.reg_passes[0])
-                self._pass_current = (T_ * 1)(self.reg_passes[1])
-            o = self.reg_out[1]
+                self._pass_current = (T_ * 1)(self.reg_passes[0])
+            o = self.reg_out
             D["s2m"] = register_cur_static_sequential_dev(ps, self.pose_upd, self.pu_args, self.reg_args[self._dst_now], cfg.n_feat, cfg.W, cfg.H,
-                                                          self._pass_current, cfg.p_reg, o["slot"].data_ptr(), o["flags"].data_ptr(),
+                                                          self._pass_current, self.n_map, o["slot"].data_ptr(), o["flags"].data_ptr(),
                                                           self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(),
                                                           D["s2m"] if D["s2m"] is not None else [self.d_slot2map[g].data_ptr() for g in range(NA)],
                                                           D["att"].data_ptr(), D["reg"].data_ptr(), D["scr"].data_ptr(), self.d_map.data_ptr(),
                                                           self.d_cov.data_ptr(), PIXEL_ERR_VAR, d_counts=D["cnt"].data_ptr(), device=self.device,
                                                           with_dynamic=True, merge=(cfg.merge_every > 0 and self._frame_now % cfg.merge_every == 0),   # CoSLAMThread.cpp:117-118
-                                                          d_merge_scratch=D["scr"].data_ptr())
+                                                          d_merge_scratch=D["scr"].data_ptr(), mergability=self._mergability)
             return
         if self.world > 1:
             self._gather_candidates()
         kinds = 3
         if cfg.merge_every > 0 and self._frame_now % cfg.merge_every == 0:
             # a bMerge frame: the static points' walks one after the other with checkUnify at a conflict, the dynamic points' behind them
-            o = self.reg_out[1]
-            self.pose_upd.register_decide_merge_dev(ps, self.pu_args, cfg.p_reg, 0, o["slot"].data_ptr(), o["flags"].data_ptr(),
+            o = self.reg_out
+            self.pose_upd.register_decide_merge_dev(ps, self.pu_args, self.n_map, 0, o["slot"].data_ptr(), o["flags"].data_ptr(),
                                                     self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(),
                                                     self.d_map.data_ptr(), self.d_cov.data_ptr(), PIXEL_ERR_VAR, D["att"].data_ptr(),
                                                     D["reg"].data_ptr(), D["scr"].data_ptr(), D["mcnt"].data_ptr())
@@ -610,12 +640,11 @@ class FrameLoop:
                                                 PIXEL_ERR_VAR, d_select=D["reg"].data_ptr())   # (no count asked for: that would be one more launch, and it is counts[1])
             self.n_merge_frames += 1
             kinds = 2
-        D["s2m"] = register_decide_static_dev(ps, NA, cfg.n_feat, cfg.p_reg, 0, self.reg_out[1]["slot"].data_ptr(), self.reg_out[1]["flags"].data_ptr(),
+        D["s2m"] = register_decide_static_dev(ps, NA, cfg.n_feat, self.n_map, 0, self.reg_out["slot"].data_ptr(), self.reg_out["flags"].data_ptr(),
                                               self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(),
                                               D["s2m"] if D["s2m"] is not None else [self.d_slot2map[g].data_ptr() for g in range(NA)],
                                               D["att"].data_ptr(), D["reg"].data_ptr(), D["scr"].data_ptr(), D["cnt"].data_ptr(), device=self.device,
                                               kinds=kinds)   # curStaticPointsRegInGroup and curDynamicPointsRegInGroup (currentMapPointsRegister, :834-853)
-        # (d_regged covers the pass's P points = the first P map points; the rest of the select mask stays 0)
         self.pose_upd.refine_map_points_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
                                             PIXEL_ERR_VAR, d_select=D["reg"].data_ptr())   # (no count asked for: that would be one more launch, and it is counts[1])
 
@@ -627,15 +656,16 @@ class FrameLoop:
         import coslam_amd
         from coslam_amd._lib import check
 
-        torch, cfg, nc, NA, P = self.torch, self.cfg, self.nc, self.cfg.n_cams, self.cfg.p_reg
+        torch, cfg, nc, NA, P = self.torch, self.cfg, self.nc, self.cfg.n_cams, self.cfg.p_reg   # P: rows of a record = the list's cap
         L, vp, ps = coslam_amd.lib(), C_.c_void_p, self.pose_s.cuda_stream
         if not hasattr(self, "_cand"):
             self._cand = (torch.zeros(3 * nc * P, dtype=torch.int32, device=self.dev), torch.zeros(3 * nc * P * self.world, dtype=torch.int32, device=self.dev))
             torch.cuda.synchronize()   # (zero-filled on torch's stream, used on the pose stream)
         send, recv = self._cand
-        o = self.reg_out[1]
-        check(L.cs_register_candidates_pack_dev(self.device, vp(ps), P, NA, self.c0, nc, vp(o["slot"].data_ptr()), vp(o["flags"].data_ptr()),
-                                                vp(self.d_mergeable.data_ptr()), vp(send.data_ptr())), "cs_register_candidates_pack_dev")
+        o = self.reg_out
+        check(L.cs_register_candidates_pack_list_dev(self.device, vp(ps), P, NA, self.c0, nc, vp(self.d_curlist.data_ptr()), vp(o["slot"].data_ptr()),
+                                                     vp(o["flags"].data_ptr()), vp(self.d_mergeable.data_ptr()), vp(send.data_ptr())),
+              "cs_register_candidates_pack_list_dev")
         if self.native is not None:
             L.cs_comm_allgather_dev.argtypes = [vp, vp, vp, vp, C_.c_size_t]
             check(L.cs_comm_allgather_dev(self.native.exchange_comm, vp(ps), vp(send.data_ptr()), vp(recv.data_ptr()), send.numel() * 4),
@@ -645,8 +675,9 @@ class FrameLoop:
 
             with torch.cuda.stream(self.pose_s):
                 dist.all_gather_into_tensor(recv, send)
-        check(L.cs_register_candidates_unpack_dev(self.device, vp(ps), P, NA, nc, self.rank, vp(recv.data_ptr()), vp(o["slot"].data_ptr()),
-                                                  vp(o["flags"].data_ptr()), vp(self.d_mergeable.data_ptr())), "cs_register_candidates_unpack_dev")
+        check(L.cs_register_candidates_unpack_list_dev(self.device, vp(ps), P, NA, nc, self.rank, vp(self.d_curlist.data_ptr()), vp(recv.data_ptr()),
+                                                       vp(o["slot"].data_ptr()), vp(o["flags"].data_ptr()), vp(self.d_mergeable.data_ptr())),
+              "cs_register_candidates_unpack_list_dev")
 
     def _key_frame(self, i, dst):
         cfg, ps, NA = self.cfg, self.pose_s.cuda_stream, self.cfg.n_cams

@@ -41,14 +41,17 @@ def pose_update3d_dev(stream_ptr, cams, N, d_pointFeat, nMap, d_R, d_t, d_mapPts
 class TrackHistory:
     """cs_track_history: the ring of the last histLen frames' hand-back pixels and poses the dynamic test walks."""
 
-    def __init__(self, nCams, N, histLen, device=0):
+    def __init__(self, nCams, N, histLen, device=0, storeLen=0):
+        """storeLen > histLen: that many frames are KEPT (cs_track_history_create_ex) while the walks stay histLen deep -- what the
+        running mergability verdict rebuilds a cached tail from"""
         L = lib()
-        L.cs_track_history_create.restype = C.c_void_p
+        L.cs_track_history_create_ex.restype = C.c_void_p
         self._L = L
         self.nCams, self.N, self.histLen = int(nCams), int(N), int(histLen)
-        self._h = L.cs_track_history_create(int(device), self.nCams, self.N, self.histLen)
+        self.storeLen = max(int(storeLen), self.histLen)
+        self._h = L.cs_track_history_create_ex(int(device), self.nCams, self.N, self.histLen, self.storeLen)
         if not self._h:
-            check(-1, "cs_track_history_create")
+            check(-1, "cs_track_history_create_ex")
 
     def close(self):
         if self._h:
@@ -83,6 +86,22 @@ class TrackHistory:
                                                         int(self.nCams - cam0 if nCamsRun is None else nCamsRun), poseupdate_cams(cams),
                                                         int(P), vp(d_M), vp(d_cov), vp(d_slot), C.c_double(pixelErrVar), vp(d_mergeable)),
               "cs_register_mergability_range_dev")
+
+    def mergability_cache_bytes(self, P):
+        self._L.cs_register_mergability_cache_bytes.restype = C.c_size_t
+        return int(self._L.cs_register_mergability_cache_bytes(int(P), self.nCams))
+
+    def register_mergability_running_dev(self, stream_ptr, cams, P, d_M, d_cov, d_slot, pixelErrVar, d_cache, d_mergeable, tolPix=0.5,
+                                         d_counts=None, cam0=0, nCamsRun=None, d_list=None, nList=0):
+        """staticCheckMergability over WHOLE tracks as a running verdict (cs_register_mergability_running_dev): the newest histLen
+        frames walked as they stand, the older ones' verdict cached per (point, camera) in d_cache (zero-filled, mergability_cache_bytes(P)).
+        d_list / nList: only the rows d_list[0 .. nList) of the P-row tables (cs_register_list_current_dev's list)"""
+        vp = C.c_void_p
+        check(self._L.cs_register_mergability_running_list_dev(vp(self._h), vp(stream_ptr), int(cam0),
+                                                               int(self.nCams - cam0 if nCamsRun is None else nCamsRun), poseupdate_cams(cams),
+                                                               int(P), vp(d_list), int(nList), vp(d_M), vp(d_cov), vp(d_slot),
+                                                               C.c_double(pixelErrVar), C.c_double(tolPix), vp(d_cache), vp(d_mergeable),
+                                                               vp(d_counts)), "cs_register_mergability_running_list_dev")
 
     def pose_update_frame_dev(self, stream_ptr, cams, d_pointFeat, nMap, d_R, d_t, d_mapPts, d_mapCov, d_mapFlags, largeErr,
                               pixelErrVar, frame, maxLen=20, minLen=5, minOutNum=3, maxEpiErr=6.0, d_numNodes=None, d_numOut=None,

@@ -45,7 +45,8 @@ class RegisterPass(C.Structure):
     """== cs_register_pass (include/coslam_hip.h)."""
 
     _fields_ = [("P", C.c_int), ("sigmaSearch", C.c_double), ("maxDist", C.c_double), ("sigmaMerge", C.c_double)] + \
-               [(n, C.c_void_p) for n in ("M", "cov", "pointFeat", "slot", "m", "var", "dist", "flags", "mapFlags")] + [("maxDistDynamic", C.c_double)]
+               [(n, C.c_void_p) for n in ("M", "cov", "pointFeat", "slot", "m", "var", "dist", "flags", "mapFlags")] + [("maxDistDynamic", C.c_double)] + \
+               [("list", C.c_void_p)]
 
 
 def register_passes(passes):
@@ -59,7 +60,17 @@ def register_passes(passes):
             setattr(a, n, int(q[n]))
         if q.get("mapFlags"):   # optional: the certainly dynamic points of the pass are searched with their own scale
             a.mapFlags, a.maxDistDynamic = int(q["mapFlags"]), float(q["maxDistDynamic"])
+        if q.get("list"):       # optional: the pass's points as a list of P map indices; the tables are then whole-map tables
+            a.list = int(q["list"])
     return arr
+
+
+def register_list_current_dev(stream_ptr, nCams, nMap, d_mapCount, d_pointFeat, d_mapFlags, d_list, d_listCount=0, d_slotTable=0, device=0):
+    """cs_register_list_current_dev: the frame's current map points (a feature of this frame in some camera, below the live count, not
+    false) as a compact list in map order -- what CoSLAM::currentMapPointsRegister walks (curMapPts)"""
+    vp = C.c_void_p
+    check(lib().cs_register_list_current_dev(int(device), vp(stream_ptr), int(nCams), int(nMap), vp(d_mapCount), vp(d_pointFeat), vp(d_mapFlags),
+                                             vp(d_list), vp(d_listCount), vp(d_slotTable)), "cs_register_list_current_dev")
 
 
 def register_search_passes_dev(stream_ptr, cams, N, W, H, passes, device=0, cam0=0, nCamsRun=None):
@@ -129,7 +140,7 @@ def register_decide_static_dev(stream_ptr, nCams, N, P, mapBase, d_slot, d_flags
 
 def register_cur_static_sequential_dev(stream_ptr, history, pu_cams, reg_cams, N, W, H, search_pass, P, d_slot, d_flags, d_mergeable, d_mapFlags,
                                        d_pointFeat, d_slot2map, d_attached, d_regged, d_scratch, d_mapPts, d_mapCov, pixelVar, d_counts=0,
-                                       after_loop=None, device=0, n_sweeps=6, with_dynamic=False, merge=False, d_merge_scratch=0):
+                                       after_loop=None, device=0, n_sweeps=6, with_dynamic=False, merge=False, d_merge_scratch=0, mergability=None):
     """CoSLAM::curStaticPointsRegInGroup (bMerge == false) AS THE REFERENCE RUNS IT (src/app/SL_CoSLAM.cpp:854-898), camera loop after
     camera loop, on the device: for o = 0 .. nCams - 1 -- the search from the points as they stand (cs_register_search_passes_dev with
     the ONE pass `search_pass`, whose tables are d_slot / d_flags), staticCheckMergability of its candidates (history: a TrackHistory),
@@ -145,7 +156,10 @@ def register_cur_static_sequential_dev(stream_ptr, history, pu_cams, reg_cams, N
     # arrays; d_merge_scratch: P bytes; d_mapFlags is then written)
     for kind, o in [(1, o_) for o_ in range(nC)] + ([(2, o_) for o_ in range(nC)] if with_dynamic else []):
         register_search_passes_dev(stream_ptr, reg_cams, N, W, H, search_pass, device=device)
-        history.register_mergability_dev(stream_ptr, pu_cams, P, d_mapPts, d_mapCov, d_slot, pixelVar, d_mergeable)
+        if mergability is not None:   # (the caller's own mergability launch: e.g. the running whole-track verdict over a list of rows)
+            mergability(stream_ptr)
+        else:
+            history.register_mergability_dev(stream_ptr, pu_cams, P, d_mapPts, d_mapCov, d_slot, pixelVar, d_mergeable)
         if merge and kind == 1:   # bMerge: the static points' walks one after the other, checkUnify at a conflict (the dynamic loops ignore bMerge);
             # d_counts then reads: features attached, points registered, points unified away, checkUnify calls
             history.register_decide_merge_dev(stream_ptr, pu_cams, P, 0, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, d_mapPts, d_mapCov,

@@ -319,7 +319,19 @@ typedef struct cs_register_pass {
      * over the current points serves both registrations */
     const unsigned char* mapFlags;
     double maxDistDynamic;
+    /* optional (NULL: the pass's points are map rows 0 .. P - 1): the pass's points as a LIST of P map indices (< 0: no point, idles its
+     * lane) -- every table above stays indexed by the map index (M, cov, pointFeat, slot, ... are then whole-map tables), only the
+     * rows of listed points are read and written.  cs_register_list_current_dev builds the list of a frame's current points. */
+    const int* list;
 } cs_register_pass;
+/* The frame's CURRENT map points -- what CoSLAM::currentMapPointsRegister walks: curMapPts = the points with a feature of this frame in
+ * at least one camera (mapStateUpdate, src/app/SL_CoSLAM.cpp:1176-1194; :734 / :958 ask numVisCam > 0 once more), wherever they sit in
+ * the map, the points genNewMapPoints has just appended included -- as a compact list in map order: d_list [nMap] (entries behind the
+ * list: -1), d_listCount [1] or NULL.  A point is listed when its index is below *d_mapCount (NULL: nMap), it is not CS_MAP_FALSE
+ * (d_mapFlags, may be NULL) and d_pointFeat [nMap][nCams] holds a feature of it.  d_slotTable (nMap x nCams ints, or NULL): the rows of
+ * the points NOT listed are set to -1 (a search driven by the list leaves them alone: no stale candidate survives a frame). */
+int cs_register_list_current_dev(int device, void* hip_stream, int nCams, int nMap, const int* d_mapCount, const int* d_pointFeat,
+                                 const unsigned char* d_mapFlags, int* d_list, int* d_listCount, int* d_slotTable);
 int cs_register_search_passes_dev(int device, void* hip_stream, int nCams, const cs_register_cam* cams, int N, int W, int H,
                                   int nPass /* 1 or 2 */, const cs_register_pass* passes /* host array */);
 /* the same for cameras cam0 .. cam0 + nCamsRun - 1 only: their columns of the nCams-wide tables (with the cameras sharded over
@@ -383,6 +395,12 @@ int cs_register_candidates_pack_dev(int device, void* hip_stream, int P, int nCa
                                     const unsigned char* d_mergeable, int* d_send);
 int cs_register_candidates_unpack_dev(int device, void* hip_stream, int P, int nCams, int nOwn, int skipRank, const int* d_recv, int* d_slot,
                                       int* d_flags, unsigned char* d_mergeable);
+/* the same for tables indexed by the MAP index and a list of the rows that matter (cs_register_list_current_dev; identical on every
+ * rank): row j of a record = map point d_list[j], j < cap -- records of 3 * nOwn * cap ints whatever the map's capacity is */
+int cs_register_candidates_pack_list_dev(int device, void* hip_stream, int cap, int nCams, int cam0, int nOwn, const int* d_list, const int* d_slot,
+                                         const int* d_flags, const unsigned char* d_mergeable, int* d_send);
+int cs_register_candidates_unpack_list_dev(int device, void* hip_stream, int cap, int nCams, int nOwn, int skipRank, const int* d_list,
+                                           const int* d_recv, int* d_slot, int* d_flags, unsigned char* d_mergeable);
 
 /* ------------------------------------------------------------------------------------------
  * What a frame does with the cameras' new poses: the gate + seqTriangulate loop of poseUpdate3D and the dynamic-point test
@@ -423,6 +441,10 @@ typedef struct cs_poseupdate_cam {
  * as `const` (two streams running e.g. cs_refine_map_points_dev on the same handle at once would share that scratch). */
 typedef struct cs_track_history cs_track_history;
 cs_track_history* cs_track_history_create(int device, int nCams, int N, int histLen /* <= 512 */);
+/* The same with a STORE behind the walks: storeLen (histLen <= storeLen <= 65536) frames of pixels and poses are kept -- 16 N + 96 bytes
+ * per camera and frame: 4096 frames of 8 cameras x 2000 slots are 1 GB of the 288 -- while every walk stays histLen deep; only
+ * cs_register_mergability_running_dev reads beyond (the tail of a whole-track walk whose cached verdict it has to rebuild). */
+cs_track_history* cs_track_history_create_ex(int device, int nCams, int N, int histLen, int storeLen);
 void cs_track_history_destroy(cs_track_history* h);
 int cs_track_history_frames(const cs_track_history* h); /* consecutive frames held (<= histLen) */
 /* cams: HOST array of nCams records; cameras cam0 .. cam0 + nCamsRun - 1 are processed (all: 0, nCams).  d_R nCams x 9, d_t
@@ -457,6 +479,25 @@ int cs_register_mergability_dev(const cs_track_history* h, void* hip_stream, con
 int cs_register_mergability_range_dev(const cs_track_history* h, void* hip_stream, int cam0, int nCamsRun, const cs_poseupdate_cam* cams,
                                       int P, const double* d_M, const double* d_cov, const int* d_slot, double pixelErrVar,
                                       unsigned char* d_mergeable); /* columns cam0 .. cam0 + nCamsRun - 1 only */
+/* The walk over WHOLE tracks (the reference's: fp, fp->preFrame, ... to the track's first frame) as a RUNNING verdict: the newest
+ * histLen frames of a candidate's track are walked every frame with the point, its covariance and the poses as they stand; the
+ * verdict over every OLDER frame is cached per (map point, camera) in d_cache and extended by one term when a frame crosses from
+ * the window into the tail.  The cache entry is dropped, and the tail walked again from the frames the store holds
+ * (cs_track_history_create_ex), when the candidate is another slot, the slot's track restarted, or the point moved by more than
+ * tolPix pixels in this camera's image since the tail was judged.  With point and poses held still the verdicts are the whole-track
+ * walk's, term for term (tests/golden/mergability_long_golden.npz: the reference's own function on tracks of 200-420 frames).
+ * d_cache: cs_register_mergability_cache_bytes(P, nCams) bytes, zero-filled before the first call, point p of one call = point p of
+ * the next; verdict 2 only for a track whose first frame has left the store; d_counts [4] or NULL, added to: cache hits, full tail
+ * walks, verdicts 2, tail terms evaluated. */
+size_t cs_register_mergability_cache_bytes(int P, int nCams);
+int cs_register_mergability_running_dev(const cs_track_history* h, void* hip_stream, int cam0, int nCamsRun, const cs_poseupdate_cam* cams,
+                                        int P, const double* d_M, const double* d_cov, const int* d_slot, double pixelErrVar, double tolPix,
+                                        void* d_cache, unsigned char* d_mergeable, int* d_counts);
+/* ... for the rows d_list[0 .. nList) of whole-map tables only (entries < 0 skipped; cs_register_pass::list's companion): d_M, d_cov,
+ * d_slot, d_cache, d_mergeable are indexed by the map index, P = the tables' rows */
+int cs_register_mergability_running_list_dev(const cs_track_history* h, void* hip_stream, int cam0, int nCamsRun, const cs_poseupdate_cam* cams,
+                                             int P, const int* d_list, int nList, const double* d_M, const double* d_cov, const int* d_slot,
+                                             double pixelErrVar, double tolPix, void* d_cache, unsigned char* d_mergeable, int* d_counts);
 
 /* RobustBundleRTS::updateNewPosesPoints (src/app/SL_CoSLAMRobustBA.cpp:248-271) in one launch: behind a bundle adjustment and the
  * relaxation of the non-key frames, every map point with lastFrame > firstKeyFrame is triangulated again from the moved poses --

@@ -460,6 +460,49 @@ def mergability_case():
                 verdict=np.array(verdict, np.int32))
 
 
+def mergability_long_case():
+    """the reference's own CoSLAM::staticCheckMergability on LONG tracks (oracle/_ref/ref_mergability_test golden_long, CPU): 3 cameras
+    x 420 frames of poses, 48 tracks per camera (most 200-420 frames long, a few inside the 64-frame window), each with its own map
+    point, laid out frame by frame the way the device's history is fed; pixels of frames before a track's first are NaN."""
+    import struct
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_mergability_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_mergability_test missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "m.bin")
+        subprocess.run([exe, "golden_long", path], check=True, stdout=subprocess.DEVNULL)
+        raw = open(path, "rb").read()
+    nC, T, nT = struct.unpack_from("iii", raw, 0)
+    (sigma,) = struct.unpack_from("d", raw, 12)
+    o = 20
+    K, R, t = np.zeros((nC, 9)), np.zeros((nC, T, 9)), np.zeros((nC, T, 3))
+    for c in range(nC):
+        v = np.frombuffer(raw, dtype=np.float64, count=9 + 12 * T, offset=o)
+        o += v.nbytes
+        K[c] = v[:9]
+        R[c], t[c] = v[9:].reshape(T, 12)[:, :9], v[9:].reshape(T, 12)[:, 9:]
+    M, cov = np.zeros((nC, nT, 3)), np.zeros((nC, nT, 9))
+    f1, bad, verdict = np.zeros((nC, nT), np.int32), np.zeros((nC, nT), np.int32), np.zeros((nC, nT), np.int32)
+    xy = np.full((nC, nT, T, 2), np.nan)
+    for c in range(nC):
+        for k in range(nT):
+            v = np.frombuffer(raw, dtype=np.float64, count=12, offset=o)
+            o += 96
+            M[c, k], cov[c, k] = v[:3], v[3:]
+            (f1[c, k],) = struct.unpack_from("i", raw, o)
+            o += 4
+            n = T - f1[c, k]
+            xy[c, k, f1[c, k]:] = np.frombuffer(raw, dtype=np.float64, count=2 * n, offset=o).reshape(n, 2)
+            o += 16 * n
+            bad[c, k], verdict[c, k] = struct.unpack_from("ii", raw, o)
+            o += 8
+    assert o == len(raw)
+    return dict(sigma=np.float64(sigma), K=K, R=R, t=t, M=M, cov=cov, f1=f1, bad_frame=bad, verdict=verdict, xy=xy.astype(np.float64))
+
+
 def update_points_case():
     """the reference's own RobustBundleRTS::updateNewPosesPoints over updateStaticPointPosition / updateDynamicPointPosition
     (oracle/_ref/ref_update_points_test golden, CPU): 6 scenes of 60 map points, re-laid out the way the device holds them (slot =
@@ -642,7 +685,7 @@ def classify_case():
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "update_points", "classify", "intercam", "newpts", "decide"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "mergability_long", "update_points", "classify", "intercam", "newpts", "decide"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -661,6 +704,8 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "intercam_golden.npz"), **intercam_case())
     if "mergability" in which:
         np.savez_compressed(os.path.join(HERE, "mergability_golden.npz"), **mergability_case())
+    if "mergability_long" in which:
+        np.savez_compressed(os.path.join(HERE, "mergability_long_golden.npz"), **mergability_long_case())
     if "update_points" in which:
         np.savez_compressed(os.path.join(HERE, "update_points_golden.npz"), **update_points_case())
     if "classify" in which:

@@ -237,6 +237,152 @@ def test_register_mergability_walks_the_candidates_tracks_like_the_oracle():
     th.close()
 
 
+def _feed_long_golden(g, th, f, dev, keep):
+    """frame f of tests/golden/mergability_long_golden.npz into the history (cs_detect_dynamic_dev pushes it): slot = track"""
+    import torch
+
+    nC, nT, T = g["xy"].shape[:3]
+    cams = []
+    f1 = g["f1"]
+    for c in range(nC):
+        xy = np.nan_to_num(g["xy"][c, :, f])                       # [nT][2]
+        alive = f >= f1[c]
+        rec = dict(xy=np.concatenate([xy[:, 0], xy[:, 1]]), state=np.where(alive, np.where(f == f1[c], 1, 0), -1).astype(np.int32),
+                   slot2map=np.full(nT, -1, np.int32),
+                   trackSpan=np.concatenate([np.where(alive, f1[c], -1), np.where(alive, f, -1)]).astype(np.int32))
+        t_ = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in rec.items()}
+        st = torch.ones(nT, dtype=torch.uint8, device=dev)
+        keep += [t_, st]
+        cams.append(dict(K=keep[0][c].data_ptr(), iK=keep[1][c].data_ptr(), xy=t_["xy"].data_ptr(), state=t_["state"].data_ptr(),
+                         slot2map=t_["slot2map"].data_ptr(), trackSpan=t_["trackSpan"].data_ptr(), isStatic=st.data_ptr()))
+    d_R = torch.from_numpy(np.ascontiguousarray(g["R"][:, f])).to(dev)
+    d_t = torch.from_numpy(np.ascontiguousarray(g["t"][:, f])).to(dev)
+    keep += [d_R, d_t]
+    s = torch.cuda.current_stream().cuda_stream
+    th.detect_dynamic_dev(s, cams, d_R.data_ptr(), d_t.data_ptr(), 1, keep[2].data_ptr(), f, minLen=1 << 30)
+    return cams
+
+
+def test_running_mergability_verdict_equals_the_references_whole_track_walk():
+    """cs_register_mergability_running_dev (VERDICT r04 item 2): CoSLAM::staticCheckMergability walks a candidate's WHOLE track
+    (reference src/app/SL_CoSLAM.cpp:714-729); the device walks the newest 64 frames every frame and keeps the verdict over the older
+    ones per (map point, camera), extended by one term per frame.  On tests/golden/mergability_long_golden.npz -- 144 tracks of up
+    to 420 frames judged by the reference's own function compiled in place -- fed frame by frame into a history whose WALK depth is
+    64:  (a) the running verdict at the last frame equals the reference's on every track, and at frames along the way the oracle's
+    whole-track verdict of that moment;  (b) with a store too short to ever re-walk a tail (128 frames) the same holds, because a
+    stable candidate never needs it;  (c) a cold cache at the last frame (512-frame store) walks every tail in full: same verdicts;
+    with the short store the long tracks come out 2 (unjudged);  (d) a point moved by less than tolPix keeps its cached tail (tail
+    terms of the old point AND window terms of the new one), one moved further has its tail judged again with the new point."""
+    import os
+
+    import torch
+
+    import oracle
+    from coslam_amd.poseupdate import TrackHistory
+
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "mergability_long_golden.npz")))
+    nC, nT, T = g["xy"].shape[:3]
+    sigma, W = float(g["sigma"]), 64
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    P = nC * nT                                               # point p = camera p // nT, track p % nT; a candidate in its own camera only
+    slot = np.full((P, nC), -1, np.int32)
+    for c in range(nC):
+        slot[c * nT:(c + 1) * nT, c] = np.arange(nT)
+    M0, cov0 = g["M"].reshape(P, 3).copy(), g["cov"].reshape(P, 9).copy()
+    d_M, d_cov = torch.from_numpy(M0).to(dev), torch.from_numpy(cov0).to(dev)
+
+    def whole_track(f, Mq=None, lo=0, hi=None):
+        """the oracle's verdict at frame f over walk depths lo .. hi - 1 of every track alive at f (255: not alive)"""
+        out = np.full((P, nC), 255, np.uint8)
+        for c in range(nC):
+            histR, histT = g["R"][c][:f + 1][::-1], g["t"][c][:f + 1][::-1]
+            for k in range(nT):
+                if f < g["f1"][c, k]:
+                    continue
+                L = f - int(g["f1"][c, k]) + 1
+                a, b = lo, L if hi is None else min(hi, L)
+                if b <= a:
+                    out[c * nT + k, c] = 1
+                    continue
+                hxy = np.ascontiguousarray(np.nan_to_num(g["xy"][c, k][:f + 1][::-1]))
+                p = c * nT + k
+                out[p, c] = 1 if oracle.static_check_mergability(g["K"][c], histR[a:b], histT[a:b], hxy[a:b], 0, b - a,
+                                                                 (M0 if Mq is None else Mq)[p], cov0[p], sigma) else 0
+        return out
+
+    finals = {}
+    for store in (512, 128):
+        th = TrackHistory(nC, nT, W, storeLen=store)
+        keep = [torch.from_numpy(g["K"].copy()).to(dev), torch.from_numpy(np.stack([np.linalg.inv(k.reshape(3, 3)).ravel() for k in g["K"]])).to(dev),
+                torch.zeros(4, dtype=torch.uint8, device=dev)]
+        cache = torch.zeros(th.mergability_cache_bytes(P), dtype=torch.uint8, device=dev)
+        cnt = torch.zeros(4, dtype=torch.int32, device=dev)
+        d_out = torch.full((P, nC), 77, dtype=torch.uint8, device=dev)
+        for f in range(T):
+            cams = _feed_long_golden(g, th, f, dev, keep)
+            live = (f >= g["f1"]).reshape(P)
+            sl = np.where(live[:, None], slot, -1).astype(np.int32)
+            d_slot = torch.from_numpy(sl).to(dev)
+            th.register_mergability_running_dev(s, cams, P, d_M.data_ptr(), d_cov.data_ptr(), d_slot.data_ptr(), sigma, cache.data_ptr(),
+                                                d_out.data_ptr(), tolPix=0.0, d_counts=cnt.data_ptr())
+            if f in (70, 150, 229, 300, 377, T - 1):
+                torch.cuda.synchronize()
+                want = whole_track(f)
+                assert np.array_equal(d_out.cpu().numpy(), want), (store, f)
+            del keep[3:-2 * nC - 2]                            # (the records of older frames are no longer read)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        for c in range(nC):                                   # (a): the reference's own verdicts
+            assert np.array_equal(got[c * nT:(c + 1) * nT, c], g["verdict"][c].astype(np.uint8)), (store, c)
+        hits, walks, cuts, terms = cnt.cpu().tolist()
+        tail_frames = int(np.clip(T - g["f1"] - W, 0, None).sum())   # frames in which a track was longer than the window
+        assert cuts == 0 and walks == 0 and hits == tail_frames > 20000   # every tail was built term by term: no full walk, nothing unjudged
+        assert 0 < terms <= tail_frames                                   # (a failed tail stops growing)
+        finals[store] = (th, cams, cache, keep)
+        # (c) a cold cache at the last frame
+        cold = torch.zeros_like(cache)
+        cnt.zero_()
+        d_cold = torch.full((P, nC), 77, dtype=torch.uint8, device=dev)
+        th.register_mergability_running_dev(s, cams, P, d_M.data_ptr(), d_cov.data_ptr(), d_slot.data_ptr(), sigma, cold.data_ptr(),
+                                            d_cold.data_ptr(), tolPix=0.0, d_counts=cnt.data_ptr())
+        torch.cuda.synchronize()
+        gc_, long_ = d_cold.cpu().numpy(), (T - g["f1"] > store).reshape(P)
+        if store == 512:
+            assert np.array_equal(gc_, got) and cnt[1].item() == int((T - g["f1"] > W).sum()) and cnt[2].item() == 0
+        else:
+            for c in range(nC):
+                col, lg = gc_[c * nT:(c + 1) * nT, c], long_[c * nT:(c + 1) * nT]
+                assert (col[lg] == 2).all() and np.array_equal(col[~lg], got[c * nT:(c + 1) * nT, c][~lg])
+            assert cnt[2].item() == int(long_.sum()) > 60
+    # (d) points that move: by a hair (the cached tail stays) and by a lot (the tail is judged again), on the 512-frame store
+    th, cams, cache, keep = finals[512]
+    rng = np.random.default_rng(5)
+    Mh = M0 + rng.normal(0, 2e-4, M0.shape)                   # ~0.01 px
+    Mf = M0 + rng.normal(0, 0.25, M0.shape)                   # ~15 px: many verdicts flip
+    live_slot = torch.from_numpy(slot).to(dev)
+    for Mq, moved_far in ((Mh, False), (Mf, True)):
+        c2 = cache.clone()
+        cnt = torch.zeros(4, dtype=torch.int32, device=dev)
+        d_o = torch.full((P, nC), 77, dtype=torch.uint8, device=dev)
+        d_Mq = torch.from_numpy(Mq).to(dev)
+        th.register_mergability_running_dev(s, cams, P, d_Mq.data_ptr(), d_cov.data_ptr(), live_slot.data_ptr(), sigma, c2.data_ptr(), d_o.data_ptr(),
+                                            tolPix=0.5, d_counts=cnt.data_ptr())
+        torch.cuda.synchronize()
+        got = d_o.cpu().numpy()
+        if moved_far:
+            want = whole_track(T - 1, Mq)
+            assert cnt[1].item() >= int((T - g["f1"] > W).sum()) - 8     # (a point that happened to move < 0.5 px keeps its tail)
+            assert (got != whole_track(T - 1)).sum() > 10
+        else:
+            tail, win = whole_track(T - 1, M0, W, None), whole_track(T - 1, Mq, 0, W)
+            want = np.where(tail == 255, 255, np.minimum(tail, win)).astype(np.uint8)
+            assert cnt[1].item() == 0
+        assert np.array_equal(got, want), moved_far
+    for v in finals.values():
+        v[0].close()
+
+
 def test_update_new_poses_points_reproduces_the_reference_on_its_golden_scenes():
     """cs_update_new_poses_points_dev against tests/golden/update_points_golden.npz -- what the reference's own
     RobustBundleRTS::updateNewPosesPoints + updateStaticPointPosition / updateDynamicPointPosition (src/app/SL_CoSLAMRobustBA.cpp:

@@ -218,3 +218,111 @@ def test_register_search_behind_the_tracker_and_the_hand_back(hip):
         for k in o1:
             assert np.array_equal(o1[k].cpu().numpy().view(np.uint8), o2[k].cpu().numpy().view(np.uint8)), k
     assert (fus[1]["slot"].cpu().numpy().reshape(P2, n_cams)[::7, 1] == -1).all()
+
+
+def test_current_points_list_drives_the_search_like_the_whole_table(hip):
+    """cs_register_list_current_dev + cs_register_pass::list (ADVICE r04: the registration must walk curMapPts -- the points with a
+    feature of this frame, wherever they sit in the map, the points genNewMapPoints appended included -- not the first P rows):
+    the list is the map-ordered set {p < mapCount, not false, some pointFeat[p][c] >= 0}; the rows of unlisted points lose their
+    candidates; a search over the list fills the listed rows of whole-map tables with exactly what a search over all rows writes
+    there and touches no other row; a pass capped below the list's length searches its first P entries only."""
+    import torch
+
+    from coslam_amd.register import register_list_current_dev, register_search_passes_dev
+
+    n_cams, N, P = 4, 700, 3000
+    Ks, Rs, ts, xy, state, s2m, dyn, Ms, covs, pf = _rig(n_cams, N, P, seed=77)
+    rng = np.random.default_rng(9)
+    pf[rng.uniform(size=P) < 0.6] = -1                     # most points hold no feature this frame
+    flags = np.where(rng.uniform(size=P) < 0.1, 2, np.where(rng.uniform(size=P) < 0.1, 1, 0)).astype(np.uint8)
+    live = 2600                                            # rows behind the live count are spare capacity
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    d_K, d_R, d_t = d(Ks.reshape(n_cams, 9)), d(Rs.reshape(n_cams, 9)), d(ts)
+    d_xy, d_st, d_s2m, d_dyn = [d(a) for a in xy], [d(a) for a in state], [d(a) for a in s2m], [d(a) for a in dyn]
+    cams = [dict(K=d_K[c].data_ptr(), R=d_R[c].data_ptr(), t=d_t[c].data_ptr(), xy=d_xy[c].data_ptr(), state=d_st[c].data_ptr(),
+                 slot2map=d_s2m[c].data_ptr(), isDynamic=d_dyn[c].data_ptr()) for c in range(n_cams)]
+    d_M, d_cov, d_pf, d_fl = d(Ms), d(covs.reshape(P, 9)), d(pf), d(flags)
+    d_cnt = torch.tensor([live], dtype=torch.int32, device=dev)
+    d_list = torch.full((P,), 12345, dtype=torch.int32, device=dev)
+    d_n = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def tables(fill):
+        return dict(slot=torch.full((P, n_cams), fill, dtype=torch.int32, device=dev), m=torch.full((P, n_cams, 2), 7.5, dtype=torch.float64, device=dev),
+                    var=torch.full((P, n_cams, 4), 7.5, dtype=torch.float64, device=dev), dist=torch.full((P, n_cams), 7.5, dtype=torch.float64, device=dev),
+                    flags=torch.full((P, n_cams), fill, dtype=torch.int32, device=dev))
+
+    T_list, T_all = tables(99), tables(99)
+    register_list_current_dev(s, n_cams, P, d_cnt.data_ptr(), d_pf.data_ptr(), d_fl.data_ptr(), d_list.data_ptr(), d_n.data_ptr(),
+                              T_list["slot"].data_ptr())
+    torch.cuda.synchronize()
+    want = np.nonzero((np.arange(P) < live) & ((flags & 2) == 0) & (pf >= 0).any(axis=1))[0]
+    lst = d_list.cpu().numpy()
+    assert d_n.item() == len(want) > 500 and np.array_equal(lst[:len(want)], want) and (lst[len(want):] == -1).all()
+    unlisted = np.setdiff1d(np.arange(P), want)
+    assert (T_list["slot"].cpu().numpy()[unlisted] == -1).all() and (T_list["slot"].cpu().numpy()[want] == 99).all()
+
+    def a_pass(T, P_, lst_=0):
+        return dict(P=P_, sigmaSearch=PIXEL_ERR_VAR, maxDist=3 * PIXEL_ERR_VAR, sigmaMerge=PIXEL_ERR_VAR, M=d_M.data_ptr(), cov=d_cov.data_ptr(),
+                    pointFeat=d_pf.data_ptr(), slot=T["slot"].data_ptr(), m=T["m"].data_ptr(), var=T["var"].data_ptr(), dist=T["dist"].data_ptr(),
+                    flags=T["flags"].data_ptr(), mapFlags=d_fl.data_ptr(), maxDistDynamic=4 * PIXEL_ERR_VAR, list=lst_)
+
+    register_search_passes_dev(s, cams, N, W, H, [a_pass(T_all, P)])
+    register_search_passes_dev(s, cams, N, W, H, [a_pass(T_list, P, d_list.data_ptr())])
+    torch.cuda.synchronize()
+    for k in T_all:
+        a, b = T_all[k].cpu().numpy(), T_list[k].cpu().numpy()
+        assert np.array_equal(a[want], b[want]), k
+    assert (T_list["flags"].cpu().numpy()[unlisted] == 99).all() and (T_list["m"].cpu().numpy()[unlisted] == 7.5).all()
+    assert (T_list["slot"].cpu().numpy()[want] >= 0).sum() > 300
+    # a cap below the list's length: the first 256 listed points only
+    T_cap = tables(55)
+    register_search_passes_dev(s, cams, N, W, H, [a_pass(T_cap, 256, d_list.data_ptr())])
+    torch.cuda.synchronize()
+    sl = T_cap["slot"].cpu().numpy()
+    assert np.array_equal(sl[want[:256]], T_all["slot"].cpu().numpy()[want[:256]]) and (sl[want[256:]] == 55).all()
+
+
+def test_candidate_records_of_listed_rows_round_trip(hip):
+    """cs_register_candidates_pack_list_dev / _unpack_list_dev: with the cameras sharded over ranks the own cameras' columns of the listed
+    rows travel as records of `cap` rows; unpacking every rank's record rebuilds the tables' listed rows, leaves the skipped rank's
+    columns and the unlisted rows alone."""
+    import ctypes as C
+
+    import torch
+
+    from coslam_amd._lib import check
+
+    L = coslam_amd.lib()
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(3)
+    nCams, nOwn, P, cap = 4, 2, 900, 256
+    world = nCams // nOwn
+    lst = np.full(P, -1, np.int32)
+    rows = np.sort(rng.choice(P, 200, replace=False)).astype(np.int32)
+    lst[:200] = rows
+    slot = rng.integers(-4, 500, (P, nCams)).astype(np.int32)
+    flags = rng.integers(0, 8, (P, nCams)).astype(np.int32)
+    merg = rng.integers(0, 3, (P, nCams)).astype(np.uint8)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    d_list, d_slot, d_flags, d_merg = d(lst), d(slot), d(flags), d(merg)
+    recv = torch.zeros(world * 3 * nOwn * cap, dtype=torch.int32, device=dev)
+    vp = C.c_void_p
+    for r in range(world):
+        send = recv[r * 3 * nOwn * cap:(r + 1) * 3 * nOwn * cap]
+        check(L.cs_register_candidates_pack_list_dev(0, vp(s), cap, nCams, r * nOwn, nOwn, vp(d_list.data_ptr()), vp(d_slot.data_ptr()),
+                                                     vp(d_flags.data_ptr()), vp(d_merg.data_ptr()), vp(send.data_ptr())), "pack")
+    o_slot, o_flags = torch.full((P, nCams), -77, dtype=torch.int32, device=dev), torch.full((P, nCams), -77, dtype=torch.int32, device=dev)
+    o_merg = torch.full((P, nCams), 77, dtype=torch.uint8, device=dev)
+    check(L.cs_register_candidates_unpack_list_dev(0, vp(s), cap, nCams, nOwn, 1, vp(d_list.data_ptr()), vp(recv.data_ptr()), vp(o_slot.data_ptr()),
+                                                   vp(o_flags.data_ptr()), vp(o_merg.data_ptr())), "unpack")
+    torch.cuda.synchronize()
+    gs, gf, gm = o_slot.cpu().numpy(), o_flags.cpu().numpy(), o_merg.cpu().numpy()
+    own1 = slice(nOwn, 2 * nOwn)                            # rank 1's columns: skipped
+    assert (gs[:, own1] == -77).all() and (gm[:, own1] == 77).all()
+    assert np.array_equal(gs[rows][:, :nOwn], slot[rows][:, :nOwn]) and np.array_equal(gf[rows][:, :nOwn], flags[rows][:, :nOwn])
+    assert np.array_equal(gm[rows][:, :nOwn], merg[rows][:, :nOwn])
+    other = np.setdiff1d(np.arange(P), rows)
+    assert (gs[other] == -77).all() and (gf[other] == -77).all()

@@ -210,7 +210,6 @@ int main(int argc, char** argv) {
     cs_pose_option* dOpt = (cs_pose_option*)dev_zeros<unsigned char>((size_t)nCams * sizeof(cs_pose_option));
     int* dOk = dev_zeros<int>(nCams);
     int* dPf = dev_zeros<int>((size_t)nMap * nCams);  // MapPoint::pFeatures of this frame, nMap x nCams (the hand-back writes it)
-    int* dPfNone = dev_zeros<int>((size_t)P_REG * nCams);
     HIPCHK(hipMemset(dPf, 0xff, sizeof(int) * (size_t)nMap * nCams));
     // poseUpdate3D's second half + detectDynamicFeaturePoints behind the pose solve (cs_pose_update_frame_dev)
     const std::vector<double> iKh = {1 / K[0], -K[1] / (K[0] * K[4]), (K[1] * K[5] - K[2] * K[4]) / (K[0] * K[4]), 0, 1 / K[4], -K[5] / K[4], 0, 0, 1};
@@ -219,17 +218,21 @@ int main(int argc, char** argv) {
     HIPCHK(hipMemset(dIsStatic, 1, (size_t)nCams * N));
     double* dReproj = dev_zeros<double>((size_t)nCams * N);
     unsigned char* dMapFlags = dev_zeros<unsigned char>(nMap);
-    unsigned char* dMergeable = dev_zeros<unsigned char>((size_t)P_REG * nCams);
+    unsigned char* dMergeable = dev_zeros<unsigned char>((size_t)nMap * nCams);   // the registration's tables are indexed by the MAP index
     // CoSLAM::mapPointsClassify behind the pose update: MapPoint::bNewPt / staticFrameNum / firstFrame of every map point
     unsigned char* dNewPt = dev_zeros<unsigned char>(nMap);
     int* dSfn = dev_zeros<int>(nMap);
     int* dFirstFrm = dev_zeros<int>(nMap);
-    cs_track_history* hist = cs_track_history_create(dev, nCams, N, 64);
+    // walks 64 frames deep; 4096 frames of pixels + poses kept behind them for the running whole-track mergability verdict
+    cs_track_history* hist = cs_track_history_create_ex(dev, nCams, N, 64, 4096);
     if (!hist) {
-        fprintf(stderr, "cs_track_history_create: %s\n", cs_last_error());
+        fprintf(stderr, "cs_track_history_create_ex: %s\n", cs_last_error());
         return 3;
     }
-    HIPCHK(hipMemset(dPfNone, 0xff, sizeof(int) * (size_t)P_REG * nCams));
+    void* dMergeCache = dev_zeros<unsigned char>(cs_register_mergability_cache_bytes(nMap, nCams));
+    int* dCurList = dev_zeros<int>(nMap);
+    int* dCurCount = dev_zeros<int>(1);
+    int* dMergeRun = dev_zeros<int>(4);
     double* dR[2] = {to_dev(R0), to_dev(R0)};
     double* dT[2] = {to_dev(t0), to_dev(t0)};
     cs_klt_feature* dDest[2][16];
@@ -242,11 +245,12 @@ int main(int argc, char** argv) {
     struct RegOut {
         int *slot, *flags;
         double *m, *var, *dist;
-    } reg[2];
+    } reg[1];
     for (RegOut& o : reg) {
-        o.slot = dev_zeros<int>((size_t)P_REG * nCams), o.flags = dev_zeros<int>((size_t)P_REG * nCams);
-        o.m = dev_zeros<double>((size_t)P_REG * nCams * 2), o.var = dev_zeros<double>((size_t)P_REG * nCams * 4);
-        o.dist = dev_zeros<double>((size_t)P_REG * nCams);
+        o.slot = dev_zeros<int>((size_t)nMap * nCams), o.flags = dev_zeros<int>((size_t)nMap * nCams);
+        o.m = dev_zeros<double>((size_t)nMap * nCams * 2), o.var = dev_zeros<double>((size_t)nMap * nCams * 4);
+        o.dist = dev_zeros<double>((size_t)nMap * nCams);
+        HIPCHK(hipMemset(o.slot, 0xff, sizeof(int) * (size_t)nMap * nCams));
     }
     auto hb_cams = [&](int b) {
         std::vector<cs_handback_cam> v(nCams);
@@ -352,9 +356,9 @@ int main(int argc, char** argv) {
     };
     std::vector<int*> s2mPtrs(nCams);
     for (int c = 0; c < nCams; ++c) s2mPtrs[c] = dS2M + (size_t)c * N;
-    unsigned char* dAttached = dev_zeros<unsigned char>((size_t)P_REG * nCams);
+    unsigned char* dAttached = dev_zeros<unsigned char>((size_t)nMap * nCams);
     unsigned char* dRegged = dev_zeros<unsigned char>(nMap);
-    void* dDecScratch = dev_zeros<unsigned char>(cs_register_decide_scratch_bytes(nCams, N, P_REG));
+    void* dDecScratch = dev_zeros<unsigned char>(cs_register_decide_scratch_bytes(nCams, N, nMap));
     int* dDecCnt = dev_zeros<int>(4);
     int* dMergeCnt = dev_zeros<int>(4);
     int nMergeFrames = 0;
@@ -420,33 +424,34 @@ int main(int argc, char** argv) {
                                            dNpCounts));
             ++nccRuns;
         }
-        // activeMapPointsRegister, then currentMapPointsRegister (static points), search step
+        // currentMapPointsRegister, search step: curMapPts of this frame as a list (the points with a feature of this frame, wherever they
+        // sit in the map -- the ones genNewMapPoints just appended included), ONE pass over it; the tables are indexed by the map index.
+        // (activeMapPointsRegister's search is not run: the reference's attach loop behind it cannot be reached, tests/cxx/ref_active_test.cpp)
+        CSCHK(cs_register_list_current_dev(dev, (void*)poseS, nCams, nMap, dMapCount, dPf, dMapFlags, dCurList, dCurCount, reg[0].slot));
         {
-            cs_register_pass ps[2];
+            cs_register_pass ps[1];
             memset(ps, 0, sizeof(ps));
-            ps[0].P = P_REG, ps[0].sigmaSearch = 2.5 * PIX, ps[0].maxDist = 3 * PIX, ps[0].sigmaMerge = PIX;
-            ps[0].M = dMap + 3 * (size_t)P_REG, ps[0].cov = dCov + 9 * (size_t)P_REG, ps[0].pointFeat = dPfNone;
+            ps[0].P = P_REG, ps[0].sigmaSearch = PIX, ps[0].maxDist = 3 * PIX, ps[0].sigmaMerge = PIX;
+            ps[0].M = dMap, ps[0].cov = dCov, ps[0].pointFeat = dPf, ps[0].list = dCurList;
+            ps[0].mapFlags = dMapFlags, ps[0].maxDistDynamic = 4 * PIX;   // (the certainly dynamic points' scale: SL_CoSLAM.cpp:973)
             ps[0].slot = reg[0].slot, ps[0].m = reg[0].m, ps[0].var = reg[0].var, ps[0].dist = reg[0].dist, ps[0].flags = reg[0].flags;
-            ps[1].P = P_REG, ps[1].sigmaSearch = PIX, ps[1].maxDist = 3 * PIX, ps[1].sigmaMerge = PIX;
-            ps[1].M = dMap, ps[1].cov = dCov, ps[1].pointFeat = dPf;
-            ps[1].mapFlags = dMapFlags, ps[1].maxDistDynamic = 4 * PIX;   // (the certainly dynamic points' scale: SL_CoSLAM.cpp:973)
-            ps[1].slot = reg[1].slot, ps[1].m = reg[1].m, ps[1].var = reg[1].var, ps[1].dist = reg[1].dist, ps[1].flags = reg[1].flags;
-            CSCHK(cs_register_search_passes_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, 2, ps));   // both passes, one launch
+            CSCHK(cs_register_search_passes_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, 1, ps));
         }
-        // staticCheckMergability of the current-static pass's candidates over their whole tracks (SL_CoSLAM.cpp:714-729, :768)
-        CSCHK(cs_register_mergability_dev(hist, (void*)poseS, pu.data(), P_REG, dMap, dCov, reg[1].slot, PIX, dMergeable));
+        // staticCheckMergability of the candidates over their WHOLE tracks (SL_CoSLAM.cpp:714-729, :768) as a running verdict
+        CSCHK(cs_register_mergability_running_list_dev(hist, (void*)poseS, 0, nCams, pu.data(), nMap, dCurList, P_REG, dMap, dCov, reg[0].slot, PIX, 0.5,
+                                                       dMergeCache, dMergeable, dMergeRun));
         // the decision (curStaticPointsRegInGroup, bMerge false: who attaches which feature), then refineMapPoint of the points that gained one
         // currentMapPointsRegister's decisions: the certainly static points, behind them the certainly dynamic ones (kinds 3), one call;
         // every 50th frame with bMerge (CoSLAMThread.cpp:117-118): the static points' walks one after the other, checkUnify at a conflict
         int kinds = 3;
         if (i % 50 == 0) {
-            CSCHK(cs_register_decide_merge_dev(hist, (void*)poseS, pu.data(), P_REG, 0, reg[1].slot, reg[1].flags, dMergeable, dMapFlags, dPf, dMap, dCov,
+            CSCHK(cs_register_decide_merge_dev(hist, (void*)poseS, pu.data(), nMap, 0, reg[0].slot, reg[0].flags, dMergeable, dMapFlags, dPf, dMap, dCov,
                                                PIX, dAttached, dRegged, dDecScratch, dMergeCnt, /*onlyCam*/ -1));
             CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
             ++nMergeFrames;
             kinds = 2;
         }
-        CSCHK(cs_register_decide_kinds_dev(dev, (void*)poseS, nCams, N, P_REG, 0, reg[1].slot, reg[1].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
+        CSCHK(cs_register_decide_kinds_dev(dev, (void*)poseS, nCams, N, nMap, 0, reg[0].slot, reg[0].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
                                            dAttached, dRegged, dDecScratch, 3, dDecCnt, /*onlyCam*/ -1, kinds));
         CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
         // the tracker of frame i + 2 is released at the END of the frame's pose work (released right behind the hand-back it runs two frames
@@ -555,7 +560,7 @@ int main(int argc, char** argv) {
     HIPCHK(hipMemcpy(&mapCountNow, dMapCount, sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(npCounts, dNpCounts, sizeof(npCounts), hipMemcpyDeviceToHost));
     int decUnsettled = 0;   // (the decision scratch's last int: sticky "some call's sweeps did not settle")
-    HIPCHK(hipMemcpy(&decUnsettled, (char*)dDecScratch + cs_register_decide_scratch_bytes(nCams, N, P_REG) - sizeof(int), sizeof(int),
+    HIPCHK(hipMemcpy(&decUnsettled, (char*)dDecScratch + cs_register_decide_scratch_bytes(nCams, N, nMap) - sizeof(int), sizeof(int),
                      hipMemcpyDeviceToHost));
     printf("{\"frames_per_s\": %.3f, \"ms_per_step\": %.5f, \"steps\": %d, \"warmup\": %d, \"host_enqueue_ms_per_step\": %.5f, "
            "\"cams_per_tracker_launch\": %d, \"pose_ok\": %s, \"min_live_features\": %d, \"joint_lm_steps\": %d, \"joint_cost\": %.6f, "

@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--hist", type=int, default=64)
     ap.add_argument("--min-distance", type=int, default=-1, help="KLT minDistance (-1: bench.py's)")
     ap.add_argument("--out", default="")
+    ap.add_argument("--time-intracam", action="store_true", help="at the end: k_intracam alone on the loop's last inputs (HIP events)")
+    ap.add_argument("--count-attach", action="store_true", help="sum the registration's attachments over the run (a device read-back per frame)")
     args = ap.parse_args()
 
     import bench
@@ -110,6 +112,7 @@ def main():
     truth_pts = np.ascontiguousarray(sc.points, dtype=np.float64)
     out = open(args.out, "w") if args.out else sys.stdout
     ke = cfg.key_every
+    attached_total = [0]
 
     def sample(i):
         loop.drain()
@@ -180,7 +183,12 @@ def main():
             rec["intercam"] = {"static": iS, "dynamic": iP - iS, "outliers": st.nOutliers, "cost_per_meas": st.cost / max(iO, 1)}
         if hasattr(loop, "_dec"):
             rec["decide_counts"] = loop._dec["cnt"].cpu().tolist()
-            rec["mergeable_verdicts"] = {str(v): int((loop.d_mergeable == v).sum().item()) for v in (0, 1, 2)}
+            cand = loop.reg_out["slot"] >= 0
+            rec["current_points_listed"] = int(loop.d_curcount.item())
+            rec["candidates"] = int(cand.sum().item())
+            rec["mergeable_verdicts"] = {str(v): int(((loop.d_mergeable == v) & cand).sum().item()) for v in (0, 1, 2)}
+            rec["running_verdict_counts"] = loop.d_merge_counts.cpu().tolist()   # hits, full tail walks, unjudged, tail terms (run totals)
+            rec["attached_total"] = attached_total[0]
         if loop.out is not None:
             rec["apply_counts"] = loop.d_apply_counts.cpu().tolist()
             rec["apply_errors"] = loop.out.wait_errors()
@@ -189,9 +197,46 @@ def main():
 
     for i in range(1, args.frames + 1):
         loop.step(i, ke > 0 and (i - 1) % ke == 0)
+        if args.count_attach and hasattr(loop, "_dec"):   # (a device read-back per frame: diagnostic runs only)
+            attached_total[0] += int(loop._dec["cnt"][0].item())
         if i % args.every == 0 or i == 1:
             sample(i)
     loop.drain()
+    if args.time_intracam:
+        # k_intracam ALONE on the loop's own last inputs (this frame's correspondences, the previous frame's poses): is its time in the loop
+        # (~105 us) the co-residency with the tracker / the solves, or the LM steps its data ask for?
+        src = (args.frames + 1) & 1
+        from coslam_amd.pose import intraCamEstimate_batch_dev
+
+        ps = loop.pose_s
+        opt0 = loop.d_opt.clone()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        Ro, to = torch.zeros_like(loop.d_R[0]), torch.zeros_like(loop.d_t[0])
+        tot, n = 0.0, 200
+
+        def one():
+            with torch.cuda.stream(ps):
+                loop.d_opt.copy_(opt0)
+            intraCamEstimate_batch_dev(ps.cuda_stream, NA, cfg.pts_stride, loop.d_K.data_ptr(), loop.d_R[src].data_ptr(), loop.d_t[src].data_ptr(),
+                                       loop.d_npts.data_ptr(), 0, loop.d_Ms.data_ptr(), loop.d_ms.data_ptr(), 10.0, Ro.data_ptr(), to.data_ptr(),
+                                       loop.d_opt.data_ptr(), loop.d_ok.data_ptr(), device=0)
+
+        for _ in range(20):
+            one()
+        torch.cuda.synchronize()
+        for _ in range(n):
+            with torch.cuda.stream(ps):
+                loop.d_opt.copy_(opt0)
+            e0.record(ps)
+            intraCamEstimate_batch_dev(ps.cuda_stream, NA, cfg.pts_stride, loop.d_K.data_ptr(), loop.d_R[src].data_ptr(), loop.d_t[src].data_ptr(),
+                                       loop.d_npts.data_ptr(), 0, loop.d_Ms.data_ptr(), loop.d_ms.data_ptr(), 10.0, Ro.data_ptr(), to.data_ptr(),
+                                       loop.d_opt.data_ptr(), loop.d_ok.data_ptr(), device=0)
+            e1.record(ps)
+            e1.synchronize()
+            tot += e0.elapsed_time(e1)
+        opts = [IntraCamPoseOption.from_buffer_copy(loop.d_opt[c].cpu().numpy().tobytes()) for c in range(NA)]
+        (out if args.out else sys.stdout).write(json.dumps({"variant": args.variant, "intracam_alone_us": tot / n * 1e3, "npts": loop.d_npts.cpu().tolist(),
+                                                            "rounds_lm": [[o.nIterRW, o.verboseRW] for o in opts]}) + "\n")
     if args.out:
         out.close()
 
