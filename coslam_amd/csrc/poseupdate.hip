@@ -433,9 +433,22 @@ struct MgRunArgs {
     int* counts;             // [4] or null: cache hits, full tail walks, verdicts 2, tail terms evaluated
     const int* list;         // null, or the rows to judge: list[0 .. nList), entries < 0 skipped
     int nList;
+    const int* flags;        // null, or the search's flags [P][nCams]: a candidate that already CARRIES a map point (bit 0 clear) is not
+                             // judged (verdict 0): the registration walks end at it (:789-790) or ask checkUnify, never this test
 };
+constexpr int MG_GAP_MAX = 2 * MG_LPC;   // a cached tail this many frames behind is caught up by the candidate's own 8 lanes; further: a wave
+struct MgMiss {   // a tail that a whole WAVE walks (phase B)
+    int p, s, start, end;
+};
+// Phase A, 8 lanes per candidate: the WINDOW (the newest W frames, exact) first -- a candidate that fails there is done: no tail is
+// looked at, none is built; then the tail: a cache hit is extended by the frames that crossed over since (usually one); anything
+// longer -- no entry, another slot, another track, a point that moved, a cache that fell behind -- goes on the block's list.
+// Phase B, a WAVE per listed tail: 64 lanes stride over its frames (a 900-frame tail is 15 steps deep instead of 113), any failure
+// ends it.  The verdict and the cache entry are written by whoever finished the candidate.
 __global__ __launch_bounds__(256) void k_register_mergability_running(MgRunArgs B) {
     extern __shared__ double mg_pose[];  // [W][12]
+    __shared__ MgMiss missList[256 / MG_LPC];
+    __shared__ int nMiss;
     CS_POSE_STREAM_PRIO();
     const MgArgs& A = B.a;
     const int c = A.cam0 + blockIdx.y, tid = threadIdx.x, N = A.N, H = A.H, W = B.W;
@@ -447,14 +460,17 @@ __global__ __launch_bounds__(256) void k_register_mergability_running(MgRunArgs 
         const int j = q / 12, e = q - 12 * j, rs = (A.head - j + H) % H;
         mg_pose[q] = e < 9 ? hR[(size_t)rs * 9 + e] : hT[(size_t)rs * 3 + (e - 9)];
     }
+    if (tid == 0) nMiss = 0;
     __syncthreads();
     const int lane = tid & 63, r = lane % MG_LPC, g = lane / MG_LPC;
     const unsigned long long gmask = ((1ull << MG_LPC) - 1ull) << (MG_LPC * g);
     const int jj = (blockIdx.x * 256 + tid) / MG_LPC;
     const int p = B.list ? (jj < B.nList ? B.list[jj] : -1) : (jj < A.P ? jj : -1);
     const bool live = p >= 0 && p < A.P;
-    const int s = live ? A.slot[(size_t)p * A.nCams + c] : -1;
-    bool failW = false, cut = false, tailOK = true, hit = false, walked = false;
+    int s = live ? A.slot[(size_t)p * A.nCams + c] : -1;
+    bool skipped = false;
+    if (s >= 0 && B.flags && !(B.flags[(size_t)p * A.nCams + c] & 1)) skipped = true, s = -2;   // the candidate carries a map point
+    bool failW = false, cut = false, tailOK = true, hit = false, listed = false;
     int nTerms = 0;
     if (s >= 0) {
         double M[3], cov[9];
@@ -465,28 +481,37 @@ __global__ __launch_bounds__(256) void k_register_mergability_running(MgRunArgs 
         const int f1 = C.trackSpan[s], f2 = C.trackSpan[N + s];
         const int len = f1 >= 0 ? f2 - f1 + 1 : 0;
         const int depth = len < W ? len : W;
-        const int end = B.curFrame - W;  // the tail: frames f1 .. end (walk depths W .. len - 1)
-        MgCache* E = B.cache + (size_t)p * A.nCams + c;
-        MgCache e = *E;   // (the group's lanes read the same 48 bytes)
-        double Mref[3] = {M[0], M[1], M[2]};
-        int start = f1;
-        if (len > W) {
-            // how far has the point moved in this camera's image since the tail was judged?
-            const double* R0 = mg_pose;
-            const double z = ((R0[6] * M[0] + R0[7] * M[1]) + R0[8] * M[2]) + R0[11];
-            const double d0 = M[0] - e.M[0], d1 = M[1] - e.M[1], d2 = M[2] - e.M[2];
-            const double shift2 = (d0 * d0 + d1 * d1) + d2 * d2;
-            const double lim = B.tolPix * z / C.K[0];
-            hit = e.slot1 == s + 1 && e.f1 == f1 && e.upto >= f1 - 1 && e.upto <= end && z > 0 && shift2 <= lim * lim;
-            if (hit) {
-                start = e.upto + 1, tailOK = e.ok != 0;
-                Mref[0] = e.M[0], Mref[1] = e.M[1], Mref[2] = e.M[2];
-            }
+        // ---- the window
+        for (int j = r; j < depth && !failW; j += MG_LPC) {
+            const double* R = mg_pose + 12 * j;
+            const double* t = R + 9;
+            const int rs = (A.head - j + H) % H;
+            const double mx = hXY[(size_t)rs * 2 * N + s], my = hXY[(size_t)rs * 2 * N + N + s];
+            failW = mg_term_fails(C.K, R, t, M, cov, A.sigma, mx, my);
+        }
+        failW = (__builtin_amdgcn_ballot_w64(failW) & gmask) != 0ull;
+        // ---- the tail: frames f1 .. end (walk depths W .. len - 1)
+        const int end = B.curFrame - W;
+        if (!failW && len > W) {
+            MgCache* E = B.cache + (size_t)p * A.nCams + c;
+            const MgCache e = *E;   // (the group's lanes read the same 48 bytes)
+            // how far has the point's projection in THIS camera moved since the tail was judged?
+            const PuProj q0 = pu_project(C.K, mg_pose, mg_pose + 9, M), q1 = pu_project(C.K, mg_pose, mg_pose + 9, e.M);
+            const double du = q0.u / q0.w - q1.u / q1.w, dv = q0.v / q0.w - q1.v / q1.w;
+            hit = e.slot1 == s + 1 && e.f1 == f1 && e.upto >= f1 - 1 && e.upto <= end && q0.w > 0 && q1.w > 0 &&
+                  du * du + dv * dv <= B.tolPix * B.tolPix;
+            const int start = hit ? e.upto + 1 : f1;
+            tailOK = hit ? e.ok != 0 : true;
             if (tailOK && start <= end) {
                 if (B.curFrame - start >= B.count) {
                     cut = true;   // the frames to judge have left even the store
+                } else if (end - start + 1 > MG_GAP_MAX) {
+                    listed = true;
+                    if (r == 0) {
+                        const int k = atomicAdd(&nMiss, 1);
+                        missList[k] = MgMiss{p, s, start, end};
+                    }
                 } else {
-                    walked = !hit;
                     for (int f = start; f <= end && tailOK; f += MG_LPC) {
                         bool fail = false;
                         const int ff = f + r;
@@ -505,27 +530,61 @@ __global__ __launch_bounds__(256) void k_register_mergability_running(MgRunArgs 
                     }
                 }
             }
-        }
-        if (!cut && tailOK) {   // (a failed tail decides: the window is not walked)
-            for (int j = r; j < depth && !failW; j += MG_LPC) {
-                const double* R = mg_pose + 12 * j;
-                const double* t = R + 9;
-                const int rs = (A.head - j + H) % H;
-                const double mx = hXY[(size_t)rs * 2 * N + s], my = hXY[(size_t)rs * 2 * N + N + s];
-                failW = mg_term_fails(C.K, R, t, M, cov, A.sigma, mx, my);
+            if (!cut && !listed && r == 0) {
+                MgCache w;
+                w.slot1 = s + 1, w.f1 = f1, w.upto = end, w.ok = tailOK ? 1 : 0;
+                w.M[0] = hit ? e.M[0] : M[0], w.M[1] = hit ? e.M[1] : M[1], w.M[2] = hit ? e.M[2] : M[2], w.pad = 0;
+                *E = w;
             }
-        }
-        if (!cut && r == 0 && len > 0) {
+        } else if (!failW && len > 0 && r == 0) {
+            // the track still fits the window: an empty tail, judged with the point as it stands
             MgCache w;
-            w.slot1 = s + 1, w.f1 = f1, w.upto = len > W ? end : f1 - 1, w.ok = tailOK ? 1 : 0;
-            w.M[0] = Mref[0], w.M[1] = Mref[1], w.M[2] = Mref[2], w.pad = 0;
-            *E = w;
+            w.slot1 = s + 1, w.f1 = f1, w.upto = f1 - 1, w.ok = 1;
+            w.M[0] = M[0], w.M[1] = M[1], w.M[2] = M[2], w.pad = 0;
+            B.cache[(size_t)p * A.nCams + c] = w;
         }
     }
-    const unsigned long long b = __builtin_amdgcn_ballot_w64(failW);
-    if (live && r == 0) A.out[(size_t)p * A.nCams + c] = s < 0 ? 255 : (cut ? 2 : ((b & gmask) != 0ull || !tailOK ? 0 : 1));
+    if (live && r == 0 && !listed) A.out[(size_t)p * A.nCams + c] = s == -1 ? 255 : (skipped ? 0 : (cut ? 2 : (failW || !tailOK ? 0 : 1)));
+    __syncthreads();
+    // ---- phase B: a wave per listed tail
+    const int wv = tid >> 6, nM = nMiss;
+    for (int k = wv; k < nM; k += 4) {
+        const MgMiss m = missList[k];
+        double M[3], cov[9];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) M[q] = A.M[3 * (size_t)m.p + q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) cov[q] = A.cov[9 * (size_t)m.p + q];
+        bool ok = true;
+        for (int f = m.start; f <= m.end && ok; f += 64) {
+            bool fail = false;
+            const int ff = f + lane;
+            if (ff <= m.end) {
+                const int j = B.curFrame - ff, rs = ((A.head - j) % H + H) % H;
+                double Rt[12];
+#pragma unroll
+                for (int q = 0; q < 9; ++q) Rt[q] = hR[(size_t)rs * 9 + q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) Rt[9 + q] = hT[(size_t)rs * 3 + q];
+                const double mx = hXY[(size_t)rs * 2 * N + m.s], my = hXY[(size_t)rs * 2 * N + N + m.s];
+                fail = mg_term_fails(C.K, Rt, Rt + 9, M, cov, A.sigma, mx, my);
+                ++nTerms;
+            }
+            if (__builtin_amdgcn_ballot_w64(fail)) ok = false;
+        }
+        if (lane == 0) {
+            MgCache* E = B.cache + (size_t)m.p * A.nCams + c;
+            // (a tail caught up from a cached prefix keeps the point the prefix was judged with; a fresh walk: the point as it stands)
+            const bool fresh = m.start == C.trackSpan[m.s];
+            MgCache w;
+            w.slot1 = m.s + 1, w.f1 = C.trackSpan[m.s], w.upto = m.end, w.ok = ok ? 1 : 0;
+            w.M[0] = fresh ? M[0] : E->M[0], w.M[1] = fresh ? M[1] : E->M[1], w.M[2] = fresh ? M[2] : E->M[2], w.pad = 0;
+            *E = w;
+            A.out[(size_t)m.p * A.nCams + c] = ok ? 1 : 0;   // (its window passed: that is why it was listed)
+        }
+    }
     if (B.counts) {
-        const unsigned long long bh = __builtin_amdgcn_ballot_w64(hit && r == 0), bw = __builtin_amdgcn_ballot_w64(walked && r == 0),
+        const unsigned long long bh = __builtin_amdgcn_ballot_w64(hit && r == 0), bw = __builtin_amdgcn_ballot_w64(listed && !hit && r == 0),
                                  bc = __builtin_amdgcn_ballot_w64(cut && r == 0);
         int terms = nTerms;
 #pragma unroll
@@ -912,25 +971,47 @@ struct DmArgs {
     unsigned char* regged;           // [P] out
     unsigned char* inVec;            // scratch [P]: the camera loop's visiting list, fixed when the loop starts (:864-869)
     int* counts;                     // [4] out: features attached, points registered, points unified away, checkUnify calls
+    const int* list;                 // null, or the points to walk as a compact list in map order (entries < 0 behind it): the frame's current
+    int nList;                       // points -- a point with a feature in a camera is one of them.  attached / regged are then cleared by the caller
 };
 __device__ __forceinline__ int mg_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned char mg_ldb(const unsigned char* p) { return *(volatile const unsigned char*)p; }
 __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
     __shared__ double sR[64 * 9 + 16];
     const int lane = threadIdx.x, C = A.cu.nCams, N = A.cu.N, P = A.P;
     int nAtt = 0, nReg = 0, nMerged = 0, nAsked = 0;
-    for (int k = lane; k < P * C; k += 64) A.attached[k] = 0;
-    for (int p = lane; p < P; p += 64) A.regged[p] = 0;
+    const bool byList = A.list != nullptr;
+    if (!byList) {
+        for (int k = lane; k < P * C; k += 64) A.attached[k] = 0;
+        for (int p = lane; p < P; p += 64) A.regged[p] = 0;
+    }
     const int o0 = A.onlyCam >= 0 ? A.onlyCam : 0, o1 = A.onlyCam >= 0 ? A.onlyCam + 1 : C;
+    const int nRows = byList ? A.nList : P;
     for (int o = o0; o < o1; ++o) {
-        for (int p = lane; p < P; p += 64)
-            A.inVec[p] = ((A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) == 0 && A.pointFeat[(size_t)p * C + o] >= 0) ? 1 : 0;
+        if (!byList) {
+            for (int p = lane; p < P; p += 64)
+                A.inVec[p] = ((A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) == 0 && A.pointFeat[(size_t)p * C + o] >= 0) ? 1 : 0;
+        }
         __threadfence();
         __syncthreads();
-        for (int p0 = 0; p0 < P; p0 += 64) {
-          // the next 64 points' places on the visiting list as a mask: the wave steps through the set bits only
-          unsigned long long todo = __builtin_amdgcn_ballot_w64(p0 + lane < P && A.inVec[p0 + lane] != 0);
+        for (int p0 = 0; p0 < nRows; p0 += 64) {
+          // the next 64 points' places on the visiting list as a mask: the wave steps through the set bits only.  By list: the visiting
+          // list of camera o (:864-869) is read off as the walk reaches a point -- the same set: only a point's OWN walk gives it features,
+          // and a point that lost them to a unification is false by then (tested below)
+          int myP = -1;
+          bool in = false;
+          if (byList) {
+              myP = p0 + lane < nRows ? A.list[p0 + lane] : -1;
+              in = myP >= 0 && myP < P && (mg_ldb(A.mapFlags + myP) & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) == 0 &&
+                   mg_ld(A.pointFeat + (size_t)myP * C + o) >= 0;
+              if (__builtin_amdgcn_ballot_w64(myP >= 0) == 0ull) break;   // behind the list's end
+          } else {
+              myP = p0 + lane;
+              in = myP < P && A.inVec[myP] != 0;
+          }
+          unsigned long long todo = __builtin_amdgcn_ballot_w64(in);
           while (todo) {
-            const int p = p0 + __builtin_ctzll(todo);
+            const int p = __shfl(myP, __builtin_ctzll(todo), 64);
             todo &= todo - 1;
             if (*(volatile unsigned char*)(A.mapFlags + p) & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) continue;   // :734 isLocalStatic() (unified away meanwhile)
             // lane c: camera c's entry of the point -- the candidate, and what it would meet there as things stand (the state changes only
@@ -1640,13 +1721,13 @@ extern "C" int cs_register_mergability_running_dev(const cs_track_history* h, vo
                                                    const cs_poseupdate_cam* cams, int P, const double* d_M, const double* d_cov,
                                                    const int* d_slot, double pixelErrVar, double tolPix, void* d_cache,
                                                    unsigned char* d_mergeable, int* d_counts) {
-    return cs_register_mergability_running_list_dev(h, hip_stream, cam0, nCamsRun, cams, P, nullptr, 0, d_M, d_cov, d_slot, pixelErrVar, tolPix, d_cache,
-                                                    d_mergeable, d_counts);
+    return cs_register_mergability_running_list_dev(h, hip_stream, cam0, nCamsRun, cams, P, nullptr, 0, d_M, d_cov, d_slot, nullptr, pixelErrVar, tolPix,
+                                                    d_cache, d_mergeable, d_counts);
 }
 extern "C" int cs_register_mergability_running_list_dev(const cs_track_history* h, void* hip_stream, int cam0, int nCamsRun,
                                                         const cs_poseupdate_cam* cams, int P, const int* d_list, int nList, const double* d_M,
-                                                        const double* d_cov, const int* d_slot, double pixelErrVar, double tolPix, void* d_cache,
-                                                        unsigned char* d_mergeable, int* d_counts) {
+                                                        const double* d_cov, const int* d_slot, const int* d_flags, double pixelErrVar,
+                                                        double tolPix, void* d_cache, unsigned char* d_mergeable, int* d_counts) {
     if (h && (cam0 < 0 || nCamsRun < 0 || cam0 + nCamsRun > h->nCams)) {
         cs_set_error("cs_register_mergability_running_dev: camera range %d + %d of %d", cam0, nCamsRun, h->nCams);
         return CS_ERR_INVALID;
@@ -1667,7 +1748,7 @@ extern "C" int cs_register_mergability_running_list_dev(const cs_track_history* 
     if (P == 0 || nCamsRun == 0 || rows == 0) return CS_OK;
     MgRunArgs B;
     memset(&B, 0, sizeof(B));
-    B.list = d_list, B.nList = nList;
+    B.list = d_list, B.nList = nList, B.flags = d_flags;
     MgArgs& A = B.a;
     A.cam0 = cam0;
     A.nCams = h->nCams, A.N = h->N, A.P = P, A.H = h->H, A.head = h->head, A.nHist = hist_walk(h);
@@ -1842,6 +1923,20 @@ extern "C" int cs_register_decide_merge_dev(const cs_track_history* h, void* hip
                                             const int* d_slot, const int* d_flags, const unsigned char* d_mergeable, unsigned char* d_mapFlags,
                                             int* d_pointFeat, double* d_mapPts, double* d_mapCov, double pixelErrVar, unsigned char* d_attached,
                                             unsigned char* d_regged, void* d_scratch, int* d_counts, int onlyCam) {
+    return cs_register_decide_merge_list_dev(h, hip_stream, cams, P, mapBase, nullptr, 0, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, d_mapPts,
+                                             d_mapCov, pixelErrVar, d_attached, d_regged, d_scratch, d_counts, onlyCam);
+}
+// ... walking a LIST of points (the frame's current points in map order, cs_register_list_current_dev; entries < 0 behind it) instead of
+// all P rows of the whole-map tables: the one wave's loops are as long as the list, not as the map's capacity
+extern "C" int cs_register_decide_merge_list_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int P, int mapBase,
+                                                 const int* d_list, int nList, const int* d_slot, const int* d_flags,
+                                                 const unsigned char* d_mergeable, unsigned char* d_mapFlags, int* d_pointFeat, double* d_mapPts,
+                                                 double* d_mapCov, double pixelErrVar, unsigned char* d_attached, unsigned char* d_regged,
+                                                 void* d_scratch, int* d_counts, int onlyCam) {
+    if (d_list && (nList < 0 || mapBase != 0)) {
+        cs_set_error("cs_register_decide_merge_list_dev: a list needs nList >= 0 and mapBase 0 (it holds map indices)");
+        return CS_ERR_INVALID;
+    }
     if (!h || !cams || P < 0 || mapBase < 0 || h->nCams * 4 > 64 || onlyCam >= h->nCams ||
         (P > 0 && (!d_slot || !d_flags || !d_mergeable || !d_mapFlags || !d_pointFeat || !d_mapPts || !d_mapCov || !d_attached || !d_regged || !d_scratch))) {
         cs_set_error("cs_register_decide_merge_dev: bad arguments (at most 16 cameras)");
@@ -1866,6 +1961,7 @@ extern "C" int cs_register_decide_merge_dev(const cs_track_history* h, void* hip
     A.P = P, A.mapBase = mapBase, A.onlyCam = onlyCam < 0 ? -1 : onlyCam;
     A.slot = d_slot, A.flags = d_flags, A.mergeable = d_mergeable, A.mapFlags = d_mapFlags, A.pointFeat = d_pointFeat;
     A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.attached = d_attached, A.regged = d_regged, A.inVec = (unsigned char*)d_scratch, A.counts = d_counts;
+    A.list = d_list, A.nList = nList;
     CS_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)hip_stream;
     if (P == 0) {
@@ -1873,6 +1969,11 @@ extern "C" int cs_register_decide_merge_dev(const cs_track_history* h, void* hip
         return CS_OK;
     }
     hist_centres(h, s);
+    if (d_list) {   // the whole tables' out-flags cleared by a wide launch (the one wave below only touches listed rows)
+        cs_small::List ops;
+        ops.fill(d_attached, 0, (size_t)P * h->nCams), ops.fill(d_regged, 0, (size_t)P);
+        CS_HIP(ops.run(s));
+    }
     hipLaunchKernelGGL(k_decide_merge, dim3(1), dim3(64), 0, s, A);
     CS_HIP(hipGetLastError());
     return CS_OK;

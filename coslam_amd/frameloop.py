@@ -453,6 +453,12 @@ class FrameLoop:
         torch.cuda.synchronize()
         self.d_slot2map.copy_(torch.from_numpy(s2m))   # the first hand-back starts every track as new (unmapped): put the map back
         torch.cuda.synchronize()
+        if self.pose_upd is not None:
+            # frame 0 into the history as well (its pixels and poses: the first term of every track born in it, which a whole-track
+            # mergability walk ends with); the dynamic test has nothing to say about one-frame tracks
+            self.pose_upd.detect_dynamic_dev(self.pose_s.cuda_stream, self.pu_args, self.d_R[0].data_ptr(), self.d_t[0].data_ptr(), self.n_map,
+                                             self.d_mapflags.data_ptr(), 0, 20, 5, 3, MAX_EPI_ERR)
+            torch.cuda.synchronize()
 
     def _handback(self, b, frame, which="all"):
         from coslam_amd.handback import handback_dev
@@ -589,7 +595,8 @@ class FrameLoop:
         self.pose_upd.register_mergability_running_dev(ps, self.pu_args, self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
                                                        self.reg_out["slot"].data_ptr(), PIXEL_ERR_VAR, self.d_merge_cache.data_ptr(),
                                                        self.d_mergeable.data_ptr(), tolPix=cfg.merge_tol_pix, d_counts=self.d_merge_counts.data_ptr(),
-                                                       cam0=self.c0, nCamsRun=self.nc, d_list=self.d_curlist.data_ptr(), nList=cfg.p_reg)
+                                                       cam0=self.c0, nCamsRun=self.nc, d_list=self.d_curlist.data_ptr(), nList=cfg.p_reg,
+                                                       d_flags=self.reg_out["flags"].data_ptr())
 
     def _decide(self, ps):
         """currentMapPointsRegister's decisions -- curStaticPointsRegInGroup (reference src/app/SL_CoSLAM.cpp:854-898, 731-830, bMerge ==
@@ -635,7 +642,8 @@ class FrameLoop:
             self.pose_upd.register_decide_merge_dev(ps, self.pu_args, self.n_map, 0, o["slot"].data_ptr(), o["flags"].data_ptr(),
                                                     self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(),
                                                     self.d_map.data_ptr(), self.d_cov.data_ptr(), PIXEL_ERR_VAR, D["att"].data_ptr(),
-                                                    D["reg"].data_ptr(), D["scr"].data_ptr(), D["mcnt"].data_ptr())
+                                                    D["reg"].data_ptr(), D["scr"].data_ptr(), D["mcnt"].data_ptr(),
+                                                    d_list=self.d_curlist.data_ptr(), nList=cfg.p_reg)
             self.pose_upd.refine_map_points_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
                                                 PIXEL_ERR_VAR, d_select=D["reg"].data_ptr())   # (no count asked for: that would be one more launch, and it is counts[1])
             self.n_merge_frames += 1
@@ -730,10 +738,19 @@ class FrameLoop:
         self.apply_at[i + self.lag * cfg.key_every] = (k, owner, i - (cfg.n_key_frames - 1) * cfg.key_every, seq)
 
     def drain(self):
-        """the worker threads' queues are part of the work: every requested solve completes"""
-        for w in self.ic_wss:
-            w.wait()
-        self.ba_ws.wait()
+        """the worker threads' queues are part of the work: every requested solve completes.  A window / a rig that holds no usable point
+        (every map point of its key frames false, say) is a solve with nothing to do, not a failure of the loop: it packed an empty
+        record (ok = 0, applies nothing) and is counted here."""
+        import coslam_amd
+
+        for w in self.ic_wss + [self.ba_ws]:
+            try:
+                w.wait()
+            except coslam_amd.CoslamHipError as ex:
+                if "no map point has two feature points" in str(ex) or "no static feature point carries a map point" in str(ex):
+                    self.n_empty_solves = getattr(self, "n_empty_solves", 0) + 1
+                else:
+                    raise
         self.torch.cuda.synchronize()
 
     def digest_parts(self):

@@ -92,14 +92,15 @@ class TrackHistory:
         return int(self._L.cs_register_mergability_cache_bytes(int(P), self.nCams))
 
     def register_mergability_running_dev(self, stream_ptr, cams, P, d_M, d_cov, d_slot, pixelErrVar, d_cache, d_mergeable, tolPix=0.5,
-                                         d_counts=None, cam0=0, nCamsRun=None, d_list=None, nList=0):
+                                         d_counts=None, cam0=0, nCamsRun=None, d_list=None, nList=0, d_flags=None):
         """staticCheckMergability over WHOLE tracks as a running verdict (cs_register_mergability_running_dev): the newest histLen
         frames walked as they stand, the older ones' verdict cached per (point, camera) in d_cache (zero-filled, mergability_cache_bytes(P)).
-        d_list / nList: only the rows d_list[0 .. nList) of the P-row tables (cs_register_list_current_dev's list)"""
+        d_list / nList: only the rows d_list[0 .. nList) of the P-row tables (cs_register_list_current_dev's list); d_flags: the search's
+        flags table -- candidates that already carry a map point are not judged"""
         vp = C.c_void_p
         check(self._L.cs_register_mergability_running_list_dev(vp(self._h), vp(stream_ptr), int(cam0),
                                                                int(self.nCams - cam0 if nCamsRun is None else nCamsRun), poseupdate_cams(cams),
-                                                               int(P), vp(d_list), int(nList), vp(d_M), vp(d_cov), vp(d_slot),
+                                                               int(P), vp(d_list), int(nList), vp(d_M), vp(d_cov), vp(d_slot), vp(d_flags),
                                                                C.c_double(pixelErrVar), C.c_double(tolPix), vp(d_cache), vp(d_mergeable),
                                                                vp(d_counts)), "cs_register_mergability_running_list_dev")
 
@@ -161,14 +162,14 @@ class TrackHistory:
                                          C.c_double(pixelErrVar), vp(d_ok), vp(d_M), vp(d_cov)), "cs_check_unify_dev")
 
     def register_decide_merge_dev(self, stream_ptr, cams, P, mapBase, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, d_mapPts, d_mapCov,
-                                  pixelErrVar, d_attached, d_regged, d_scratch, d_counts=0, only_cam=-1):
+                                  pixelErrVar, d_attached, d_regged, d_scratch, d_counts=0, only_cam=-1, d_list=None, nList=0):
         """curStaticPointsRegInGroup with bMerge == true (reference src/app/SL_CoSLAM.cpp:854-898, 731-830), the walks in the reference's
         order on one wave: attach, or ask checkUnify at a feature of another static point and unify on a yes (cs_register_decide_merge_dev)"""
         vp = C.c_void_p
-        check(self._L.cs_register_decide_merge_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), int(P), int(mapBase), vp(d_slot), vp(d_flags),
-                                                   vp(d_mergeable), vp(d_mapFlags), vp(d_pointFeat), vp(d_mapPts), vp(d_mapCov),
-                                                   C.c_double(pixelErrVar), vp(d_attached), vp(d_regged), vp(d_scratch), vp(d_counts),
-                                                   int(only_cam)), "cs_register_decide_merge_dev")
+        check(self._L.cs_register_decide_merge_list_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), int(P), int(mapBase), vp(d_list),
+                                                        int(nList), vp(d_slot), vp(d_flags), vp(d_mergeable), vp(d_mapFlags), vp(d_pointFeat),
+                                                        vp(d_mapPts), vp(d_mapCov), C.c_double(pixelErrVar), vp(d_attached), vp(d_regged),
+                                                        vp(d_scratch), vp(d_counts), int(only_cam)), "cs_register_decide_merge_list_dev")
 
     def map_points_classify_dev(self, stream_ptr, cams, d_pointFeat, nMap, curFrame, d_mapPts, d_mapCov, d_mapFlags, d_newPt,
                                 d_staticFrameNum, d_firstFrame, pixelVar=12.0, d_featFrame=None, d_featFirst=None, d_counts=None):

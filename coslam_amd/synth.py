@@ -133,6 +133,41 @@ def blob_image(W, H, centers, sigma=2.0, amp=120.0, base=100.0):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
+# ---- gauge-free comparison with the ground truth ----
+def umeyama(X, Y, with_scale=True):
+    """(s, R, t) minimising sum |s R X_i + t - Y_i|^2 (Umeyama 1991); X, Y: [n][3].  A SLAM map is defined up to such a transform of
+    the world frame (a similarity once the scale floats with the map): estimated camera centres / map points are compared with the
+    truth after it has been removed."""
+    X, Y = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+    mx, my = X.mean(0), Y.mean(0)
+    Xc, Yc = X - mx, Y - my
+    U, D, Vt = np.linalg.svd(Yc.T @ Xc / len(X))
+    E = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        E[2, 2] = -1
+    R = U @ E @ Vt
+    s = float((D * np.diag(E)).sum() / max((Xc ** 2).sum(), 1e-300) * len(X)) if with_scale else 1.0
+    return s, R, my - s * R @ mx
+
+
+def rig_error_vs_truth(scene, frame, R_est, t_est):
+    """How far the estimated rig of `frame` is from the synthetic truth: raw (max |t - t_true| as rounds 2-4 reported it; camera centres),
+    and after a similarity / a rigid alignment of the camera centres -- what is left is the rig's DISTORTION, what the alignment took
+    out is a motion of the whole map + rig (nothing ties the map to the frame it started in once its points are estimated)."""
+    nC = len(R_est)
+    R_est, t_est = np.asarray(R_est, dtype=np.float64).reshape(nC, 3, 3), np.asarray(t_est, dtype=np.float64).reshape(nC, 3)
+    Rt, tt = zip(*[scene.pose(c, frame) for c in range(nC)])
+    Rt, tt = np.array(Rt), np.array(tt)
+    Ce, Ct = -np.einsum("cji,cj->ci", R_est, t_est), -np.einsum("cji,cj->ci", Rt, tt)
+    out = {"raw_max_abs_t": float(np.abs(t_est - tt).max()), "centres_raw_max": float(np.linalg.norm(Ce - Ct, axis=1).max())}
+    for name, ws in (("sim3", True), ("rigid", False)):
+        s, Ra, ta = umeyama(Ce, Ct, ws)
+        out[f"centres_after_{name}_max"] = float(np.linalg.norm(s * Ce @ Ra.T + ta - Ct, axis=1).max())
+        ang = float(np.degrees(np.arccos(np.clip((np.trace(Ra) - 1) / 2, -1, 1))))
+        out[f"gauge_{name}"] = {"scale": s, "rot_deg": ang, "trans": float(np.linalg.norm(ta))}
+    return out
+
+
 # ---- bundle-adjustment problem generator (cfg1: 10 key frames x 500 points) ----
 def rodrigues(w):
     th = np.linalg.norm(w)

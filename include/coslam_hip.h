@@ -358,8 +358,8 @@ int cs_register_search(int device, int nCams, const cs_register_cam* cams, int N
  * mapBase + P - 1); IN / OUT: d_pointFeat [P][nCams] (MapPoint::addFeature) and every camera's slot2map [N] (the attached feature's
  * whole track takes the point, :771-775); OUT: d_attached [P][nCams], d_regged [P] (refineMapPoint is due: hand it to
  * cs_refine_map_points_dev as d_select), d_counts [4] or NULL (features attached, points regged, sweeps, converged).
- * d_scratch: cs_register_decide_scratch_bytes; its LAST int is sticky: set to 1 by any call whose sweeps did not settle (the
- * decision then is not the sequential one), never cleared here -- zero the scratch once, read the word at the end of a run.  Not done here: the projections are those of the search as it ran (the reference
+ * d_scratch: cs_register_decide_scratch_bytes; its LAST int COUNTS the calls whose sweeps did not settle (the decision then is not
+ * the sequential one), never cleared here -- zero the scratch once, read the word at the end of a run.  Not done here: the projections are those of the search as it ran (the reference
  * refines a point before the next camera's round of walks, :889-893), and the bMerge == true branch (every 50th frame: checkUnify on
  * a conflict) -- that one is cs_register_decide_merge_dev further down. */
 size_t cs_register_decide_scratch_bytes(int nCams, int N, int P);
@@ -493,11 +493,14 @@ size_t cs_register_mergability_cache_bytes(int P, int nCams);
 int cs_register_mergability_running_dev(const cs_track_history* h, void* hip_stream, int cam0, int nCamsRun, const cs_poseupdate_cam* cams,
                                         int P, const double* d_M, const double* d_cov, const int* d_slot, double pixelErrVar, double tolPix,
                                         void* d_cache, unsigned char* d_mergeable, int* d_counts);
-/* ... for the rows d_list[0 .. nList) of whole-map tables only (entries < 0 skipped; cs_register_pass::list's companion): d_M, d_cov,
- * d_slot, d_cache, d_mergeable are indexed by the map index, P = the tables' rows */
+/* ... for the rows d_list[0 .. nList) of whole-map tables only (entries < 0 skipped; cs_register_pass::list's companion; NULL: all P
+ * rows): d_M, d_cov, d_slot, d_cache, d_mergeable are indexed by the map index, P = the tables' rows.  d_flags (the search's flags
+ * table, or NULL): a candidate that already carries a map point (bit 0 clear) is not judged -- verdict 0; the registration walks end at
+ * such a feature or ask checkUnify about it, they never put it to this test. */
 int cs_register_mergability_running_list_dev(const cs_track_history* h, void* hip_stream, int cam0, int nCamsRun, const cs_poseupdate_cam* cams,
                                              int P, const int* d_list, int nList, const double* d_M, const double* d_cov, const int* d_slot,
-                                             double pixelErrVar, double tolPix, void* d_cache, unsigned char* d_mergeable, int* d_counts);
+                                             const int* d_flags, double pixelErrVar, double tolPix, void* d_cache, unsigned char* d_mergeable,
+                                             int* d_counts);
 
 /* RobustBundleRTS::updateNewPosesPoints (src/app/SL_CoSLAMRobustBA.cpp:248-271) in one launch: behind a bundle adjustment and the
  * relaxation of the non-key frames, every map point with lastFrame > firstKeyFrame is triangulated again from the moved poses --
@@ -570,6 +573,12 @@ int cs_register_decide_merge_dev(const cs_track_history* h, void* hip_stream, co
                                  const int* d_flags, const unsigned char* d_mergeable, unsigned char* d_mapFlags, int* d_pointFeat, double* d_mapPts,
                                  double* d_mapCov, double pixelErrVar, unsigned char* d_attached, unsigned char* d_regged, void* d_scratch,
                                  int* d_counts, int onlyCam);
+/* the same walking a LIST of the points (cs_register_list_current_dev: the frame's current points in map order, entries < 0 behind them;
+ * mapBase must be 0) over whole-map tables of P rows: the single wave's loops are as long as the list, not as the map's capacity */
+int cs_register_decide_merge_list_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int P, int mapBase,
+                                      const int* d_list, int nList, const int* d_slot, const int* d_flags, const unsigned char* d_mergeable,
+                                      unsigned char* d_mapFlags, int* d_pointFeat, double* d_mapPts, double* d_mapCov, double pixelErrVar,
+                                      unsigned char* d_attached, unsigned char* d_regged, void* d_scratch, int* d_counts, int onlyCam);
 
 
 /* CoSLAM::mapPointsClassify (src/app/SL_CoSLAM.cpp:418-520) in one launch: what CoSLAM::poseUpdate runs every frame behind the pose

@@ -38,8 +38,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys(hip):
     bo = cfg["ba_output"]
     assert bo["lag_key_frame_intervals"] == 2 and bo["windows_applied_in_timed_region"] == 2 and bo["static_points_retriangulated_last"] > 500
     assert bo["last"]["applied_at_frame"] - bo["last"]["first_key_frame"] == 30 and "pose-graph relaxation" in cfg["workload"]
-    assert cfg["intercam_last"]["lm_steps"] > 0 and cfg["register_candidates_last_frame"]["current_static"] > 1000
-    assert cfg["video"]["frames"] == 120 and cfg["pose_translation_error_vs_truth"] < 0.5
+    rc = cfg["register_candidates_last_frame"]
+    assert cfg["intercam_last"]["lm_steps"] > 0 and rc["current_points_listed"] > 300 and rc["candidates"] > 300
+    assert rc["unjudged_track_older_than_the_store"] == 0 and rc["running_verdict"]["verdicts_unjudged"] == 0
+    # the rig against the synthetic truth once the gauge is taken out (a similarity of the 8 camera centres): its distortion
+    assert cfg["video"]["frames"] == 120 and cfg["rig_error_vs_truth"]["centres_after_sim3_max"] < 0.06
     # the same loop from C++ through the C-ABI only (tools/cxx/frame_loop.cpp): same solves, a comparable rate
     cx = cfg["cxx_frame_loop"]
     assert "error" not in cx, cx

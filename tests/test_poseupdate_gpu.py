@@ -337,7 +337,9 @@ def test_running_mergability_verdict_equals_the_references_whole_track_walk():
             assert np.array_equal(got[c * nT:(c + 1) * nT, c], g["verdict"][c].astype(np.uint8)), (store, c)
         hits, walks, cuts, terms = cnt.cpu().tolist()
         tail_frames = int(np.clip(T - g["f1"] - W, 0, None).sum())   # frames in which a track was longer than the window
-        assert cuts == 0 and walks == 0 and hits == tail_frames > 20000   # every tail was built term by term: no full walk, nothing unjudged
+        # every tail was built term by term (a frame whose window fails builds none: the tail catches up when the window passes again):
+        # no tail walked from scratch, nothing unjudged
+        assert cuts == 0 and walks == 0 and 20000 < hits <= tail_frames
         assert 0 < terms <= tail_frames                                   # (a failed tail stops growing)
         finals[store] = (th, cams, cache, keep)
         # (c) a cold cache at the last frame
@@ -348,13 +350,16 @@ def test_running_mergability_verdict_equals_the_references_whole_track_walk():
                                             d_cold.data_ptr(), tolPix=0.0, d_counts=cnt.data_ptr())
         torch.cuda.synchronize()
         gc_, long_ = d_cold.cpu().numpy(), (T - g["f1"] > store).reshape(P)
+        win_ok = np.stack([whole_track(T - 1, None, 0, W)[c * nT:(c + 1) * nT, c] for c in range(nC)]).reshape(P) == 1   # (the window decides first)
+        has_tail = (T - g["f1"] - W > 16).reshape(P)   # (a tail of up to 16 frames is walked by the candidate's own lanes: not counted as a walk)
         if store == 512:
-            assert np.array_equal(gc_, got) and cnt[1].item() == int((T - g["f1"] > W).sum()) and cnt[2].item() == 0
+            assert np.array_equal(gc_, got) and cnt[1].item() == int((has_tail & win_ok).sum()) > 60 and cnt[2].item() == 0
         else:
             for c in range(nC):
-                col, lg = gc_[c * nT:(c + 1) * nT, c], long_[c * nT:(c + 1) * nT]
-                assert (col[lg] == 2).all() and np.array_equal(col[~lg], got[c * nT:(c + 1) * nT, c][~lg])
-            assert cnt[2].item() == int(long_.sum()) > 60
+                sl_ = slice(c * nT, (c + 1) * nT)
+                col, lg, wk = gc_[sl_, c], long_[sl_], win_ok[sl_]
+                assert (col[lg & wk] == 2).all() and (col[lg & ~wk] == 0).all() and np.array_equal(col[~lg], got[sl_, c][~lg])
+            assert cnt[2].item() == int((long_ & win_ok).sum()) > 40
     # (d) points that move: by a hair (the cached tail stays) and by a lot (the tail is judged again), on the 512-frame store
     th, cams, cache, keep = finals[512]
     rng = np.random.default_rng(5)
@@ -372,7 +377,8 @@ def test_running_mergability_verdict_equals_the_references_whole_track_walk():
         got = d_o.cpu().numpy()
         if moved_far:
             want = whole_track(T - 1, Mq)
-            assert cnt[1].item() >= int((T - g["f1"] > W).sum()) - 8     # (a point that happened to move < 0.5 px keeps its tail)
+            wq = np.stack([whole_track(T - 1, Mq, 0, W)[c * nT:(c + 1) * nT, c] for c in range(nC)]).reshape(P) == 1
+            assert cnt[1].item() >= int(((T - g["f1"] - W > 16).reshape(P) & wq).sum()) - 8 > 5    # (a point that happened to move < 0.5 px keeps its tail)
             assert (got != whole_track(T - 1)).sum() > 10
         else:
             tail, win = whole_track(T - 1, M0, W, None), whole_track(T - 1, Mq, 0, W)

@@ -438,14 +438,14 @@ int main(int argc, char** argv) {
             CSCHK(cs_register_search_passes_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, 1, ps));
         }
         // staticCheckMergability of the candidates over their WHOLE tracks (SL_CoSLAM.cpp:714-729, :768) as a running verdict
-        CSCHK(cs_register_mergability_running_list_dev(hist, (void*)poseS, 0, nCams, pu.data(), nMap, dCurList, P_REG, dMap, dCov, reg[0].slot, PIX, 0.5,
-                                                       dMergeCache, dMergeable, dMergeRun));
+        CSCHK(cs_register_mergability_running_list_dev(hist, (void*)poseS, 0, nCams, pu.data(), nMap, dCurList, P_REG, dMap, dCov, reg[0].slot, reg[0].flags, PIX,
+                                                       0.5, dMergeCache, dMergeable, dMergeRun));
         // the decision (curStaticPointsRegInGroup, bMerge false: who attaches which feature), then refineMapPoint of the points that gained one
         // currentMapPointsRegister's decisions: the certainly static points, behind them the certainly dynamic ones (kinds 3), one call;
         // every 50th frame with bMerge (CoSLAMThread.cpp:117-118): the static points' walks one after the other, checkUnify at a conflict
         int kinds = 3;
         if (i % 50 == 0) {
-            CSCHK(cs_register_decide_merge_dev(hist, (void*)poseS, pu.data(), nMap, 0, reg[0].slot, reg[0].flags, dMergeable, dMapFlags, dPf, dMap, dCov,
+            CSCHK(cs_register_decide_merge_list_dev(hist, (void*)poseS, pu.data(), nMap, 0, dCurList, P_REG, reg[0].slot, reg[0].flags, dMergeable, dMapFlags, dPf, dMap, dCov,
                                                PIX, dAttached, dRegged, dDecScratch, dMergeCnt, /*onlyCam*/ -1));
             CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
             ++nMergeFrames;
@@ -510,6 +510,10 @@ int main(int argc, char** argv) {
     CSCHK(cs_klt_handback_dev(dev, (void*)poseS, nCams, hb[0].data(), N, W, H, nColBlk, nRowBlk, PTS, 0));
     HIPCHK(hipDeviceSynchronize());
     associate();  // (the first hand-back starts every track as new, i.e. unmapped: put the map back)
+    HIPCHK(hipDeviceSynchronize());
+    // frame 0 into the history as well (its pixels and poses: the first term of every track born in it, which a whole-track mergability
+    // walk ends with); the dynamic test has nothing to say about one-frame tracks
+    CSCHK(cs_detect_dynamic_dev(hist, (void*)poseS, 0, nCams, pu.data(), dR[0], dT[0], nMap, dMapFlags, 0, 20, 5, 3, 6.0, nullptr));
     HIPCHK(hipDeviceSynchronize());
 
     // set-up (one key-frame interval: graph capture in the BA workers, lazy code-object loading), warm-up, timed loop

@@ -3,10 +3,10 @@
 # the registration now attaching, the headline loop (Python + C++) and its kernel trace.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r05b
+O=$R/gpurun_out/r05c
 mkdir -p $O/drift $O/ab $O/trace
 cd $R
-( time python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1
+( time python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1
 tail -15 $O/pytest_gpu.log
 for v in full no_ncc; do
   timeout 200 python tools/r05_drift.py --variant $v --frames 1500 --count-attach --time-intracam --out $O/drift/$v.jsonl > $O/drift/$v.log 2>&1 || echo "drift $v rc=$?"
@@ -26,7 +26,7 @@ except Exception as e:
 PY
 }
 ab base1
-ab active_on --no-cxx-loop --active-search 1
+
 ab base2 --no-cxx-loop
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d $O/trace/base -o t -- python $R/bench.py $SHORT --no-cxx-loop > $O/trace/base_line.json 2> $O/trace/base.err
