@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void k_register_mergability_running(MgRunArgs 
         failW = (__builtin_amdgcn_ballot_w64(failW) & gmask) != 0ull;
         // ---- the tail: frames f1 .. end (walk depths W .. len - 1)
         const int end = B.curFrame - W;
-        if (!failW && len > W) {
+        if (len > W) {
             MgCache* E = B.cache + (size_t)p * A.nCams + c;
             const MgCache e = *E;   // (the group's lanes read the same 48 bytes)
             // how far has the point's projection in THIS camera moved since the tail was judged?
@@ -502,41 +502,48 @@ __global__ __launch_bounds__(256) void k_register_mergability_running(MgRunArgs 
                   du * du + dv * dv <= B.tolPix * B.tolPix;
             const int start = hit ? e.upto + 1 : f1;
             tailOK = hit ? e.ok != 0 : true;
-            if (tailOK && start <= end) {
-                if (B.curFrame - start >= B.count) {
-                    cut = true;   // the frames to judge have left even the store
-                } else if (end - start + 1 > MG_GAP_MAX) {
-                    listed = true;
-                    if (r == 0) {
-                        const int k = atomicAdd(&nMiss, 1);
-                        missList[k] = MgMiss{p, s, start, end};
-                    }
-                } else {
-                    for (int f = start; f <= end && tailOK; f += MG_LPC) {
-                        bool fail = false;
-                        const int ff = f + r;
-                        if (ff <= end) {
-                            const int j = B.curFrame - ff, rs = ((A.head - j) % H + H) % H;
-                            double Rt[12];
+            const bool shortGap = end - start + 1 <= MG_GAP_MAX;
+            // a cached tail is kept up to date by its one new term per frame whatever the window says (a stable candidate then never needs
+            // the store); anything longer is only worth walking for a candidate whose window passed
+            bool wrote = false;
+            if (start > end) {
+                wrote = hit;
+            } else if (!tailOK) {
+                wrote = true;   // a failed tail stays failed: only its reach moves on
+            } else if (B.curFrame - start >= B.count) {
+                cut = !failW;   // the frames to judge have left even the store
+            } else if (shortGap && (hit || !failW)) {
+                for (int f = start; f <= end && tailOK; f += MG_LPC) {
+                    bool fail = false;
+                    const int ff = f + r;
+                    if (ff <= end) {
+                        const int j = B.curFrame - ff, rs = ((A.head - j) % H + H) % H;
+                        double Rt[12];
 #pragma unroll
-                            for (int q = 0; q < 9; ++q) Rt[q] = hR[(size_t)rs * 9 + q];
+                        for (int q = 0; q < 9; ++q) Rt[q] = hR[(size_t)rs * 9 + q];
 #pragma unroll
-                            for (int q = 0; q < 3; ++q) Rt[9 + q] = hT[(size_t)rs * 3 + q];
-                            const double mx = hXY[(size_t)rs * 2 * N + s], my = hXY[(size_t)rs * 2 * N + N + s];
-                            fail = mg_term_fails(C.K, Rt, Rt + 9, M, cov, A.sigma, mx, my);
-                            ++nTerms;
-                        }
-                        if (__builtin_amdgcn_ballot_w64(fail) & gmask) tailOK = false;
+                        for (int q = 0; q < 3; ++q) Rt[9 + q] = hT[(size_t)rs * 3 + q];
+                        const double mx = hXY[(size_t)rs * 2 * N + s], my = hXY[(size_t)rs * 2 * N + N + s];
+                        fail = mg_term_fails(C.K, Rt, Rt + 9, M, cov, A.sigma, mx, my);
+                        ++nTerms;
                     }
+                    if (__builtin_amdgcn_ballot_w64(fail) & gmask) tailOK = false;
+                }
+                wrote = true;
+            } else if (!failW) {
+                listed = true;
+                if (r == 0) {
+                    const int k = atomicAdd(&nMiss, 1);
+                    missList[k] = MgMiss{p, s, start, end};
                 }
             }
-            if (!cut && !listed && r == 0) {
+            if (wrote && r == 0) {
                 MgCache w;
                 w.slot1 = s + 1, w.f1 = f1, w.upto = end, w.ok = tailOK ? 1 : 0;
                 w.M[0] = hit ? e.M[0] : M[0], w.M[1] = hit ? e.M[1] : M[1], w.M[2] = hit ? e.M[2] : M[2], w.pad = 0;
                 *E = w;
             }
-        } else if (!failW && len > 0 && r == 0) {
+        } else if (len > 0 && r == 0) {
             // the track still fits the window: an empty tail, judged with the point as it stands
             MgCache w;
             w.slot1 = s + 1, w.f1 = f1, w.upto = f1 - 1, w.ok = 1;
@@ -973,7 +980,41 @@ struct DmArgs {
     int* counts;                     // [4] out: features attached, points registered, points unified away, checkUnify calls
     const int* list;                 // null, or the points to walk as a compact list in map order (entries < 0 behind it): the frame's current
     int nList;                       // points -- a point with a feature in a camera is one of them.  attached / regged are then cleared by the caller
+    // by list only: checkUnify of every (listed point, camera) whose candidate carries ANOTHER static point, evaluated side by side BEFORE the
+    // walk (k_merge_precheck) on the state the walk starts from; the walk takes a verdict from here as long as neither point has been
+    // touched by an earlier step (inVec[point] != 0: it gained a feature, moved, or was unified away) and evaluates it itself otherwise
+    unsigned char* preOk;            // [nList][nCams]: 0 not evaluated, 1 checkUnify said no, 2 yes
+    double* preM;                    // [nList][nCams][12]: the unified position and covariance of a yes
 };
+// the conflicts a bMerge walk can meet, judged side by side on the state the walk starts from: a wave per (listed point, camera)
+__global__ __launch_bounds__(256) void k_merge_precheck(DmArgs A) {
+    __shared__ double sR[4][64 * 9 + 16];
+    const int tid = threadIdx.x, g = tid / 64, r = tid % 64, C = A.cu.nCams, N = A.cu.N;
+    const int e = blockIdx.x * 4 + g;   // entry = list position x camera
+    if (e >= A.nList * C) return;
+    const int j = e / C, i = e - j * C;
+    if (r == 0) A.preOk[e] = 0;
+    const int p = A.list[j];
+    if (p < 0 || p >= A.P) return;
+    if ((A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) != 0) return;
+    if (A.pointFeat[(size_t)p * C + i] >= 0) return;
+    const int s = A.slot[(size_t)p * C + i];
+    if (s < 0 || s >= N || (A.flags[(size_t)p * C + i] & 2)) return;
+    const int q = A.cu.cam[i].slot2map[s] - A.mapBase;
+    if (q < 0 || q >= A.P || q == p) return;
+    if (A.mapFlags[q] & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) return;
+    double M[3], cov[9];
+    const bool ok = check_unify_wave(A.cu, A.pointFeat + (size_t)p * C, A.pointFeat + (size_t)q * C, A.mapPts + 3 * (size_t)p, A.mapPts + 3 * (size_t)q,
+                                     sR[g], M, cov);
+    if (r == 0) {
+        double* o = A.preM + 12 * (size_t)e;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[k] = M[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[3 + k] = cov[k];
+        A.preOk[e] = ok ? 2 : 1;
+    }
+}
 __device__ __forceinline__ int mg_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned char mg_ldb(const unsigned char* p) { return *(volatile const unsigned char*)p; }
 __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
@@ -1011,6 +1052,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
           }
           unsigned long long todo = __builtin_amdgcn_ballot_w64(in);
           while (todo) {
+            const int jP = p0 + __builtin_ctzll(todo);   // (by list: the point's place on the list)
             const int p = __shfl(myP, __builtin_ctzll(todo), 64);
             todo &= todo - 1;
             if (*(volatile unsigned char*)(A.mapFlags + p) & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) continue;   // :734 isLocalStatic() (unified away meanwhile)
@@ -1038,6 +1080,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
                             s2m[s] = A.mapBase + p;
                             A.pointFeat[(size_t)p * C + i] = s;
                             A.attached[(size_t)p * C + i] = 1;
+                            if (byList) A.inVec[p] = 1;   // the point has changed: a pre-checked verdict about it no longer stands
                         }
                         __threadfence();
                         reg = true, ++nAtt;
@@ -1049,13 +1092,25 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
                 if (*(volatile unsigned char*)(A.mapFlags + q) & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) continue;   // !isLocalStatic()
                 double M[3], cov[9];
                 ++nAsked;
-                const bool ok = check_unify_wave(A.cu, A.pointFeat + (size_t)p * C, A.pointFeat + (size_t)q * C, A.mapPts + 3 * (size_t)p,
-                                                 A.mapPts + 3 * (size_t)q, sR, M, cov);
+                bool ok;
+                const int pre = byList && A.preOk ? A.preOk[(size_t)jP * C + i] : 0;
+                if (pre != 0 && mg_ldb(A.inVec + p) == 0 && mg_ldb(A.inVec + q) == 0) {
+                    ok = pre == 2;   // judged before the walk on the very state it is asked about now
+                    const double* o = A.preM + 12 * ((size_t)jP * C + i);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) M[k] = o[k];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) cov[k] = o[3 + k];
+                } else {
+                    ok = check_unify_wave(A.cu, A.pointFeat + (size_t)p * C, A.pointFeat + (size_t)q * C, A.mapPts + 3 * (size_t)p,
+                                          A.mapPts + 3 * (size_t)q, sR, M, cov);
+                }
                 if (!ok) continue;
                 if (lane == 0) {                                                            // :797-826
                     for (int k = 0; k < 3; ++k) A.mapPts[3 * (size_t)p + k] = M[k];
                     for (int k = 0; k < 9; ++k) A.mapCov[9 * (size_t)p + k] = cov[k];
                     A.mapFlags[q] = (unsigned char)((A.mapFlags[q] & CS_MAP_UNCERTAIN) | CS_MAP_FALSE);
+                    if (byList) A.inVec[p] = 1, A.inVec[q] = 1;
                     for (int v = 0; v < C; ++v) {
                         const int sq = A.pointFeat[(size_t)q * C + v];
                         if (sq >= 0 && A.pointFeat[(size_t)p * C + v] < 0) {
@@ -1927,7 +1982,13 @@ extern "C" int cs_register_decide_merge_dev(const cs_track_history* h, void* hip
                                              d_mapCov, pixelErrVar, d_attached, d_regged, d_scratch, d_counts, onlyCam);
 }
 // ... walking a LIST of points (the frame's current points in map order, cs_register_list_current_dev; entries < 0 behind it) instead of
-// all P rows of the whole-map tables: the one wave's loops are as long as the list, not as the map's capacity
+// all P rows of the whole-map tables: the one wave's loops are as long as the list, not as the map's capacity, and the checkUnify
+// verdicts it may need are evaluated side by side before it starts.  d_scratch: cs_register_decide_merge_scratch_bytes(P, nList, nCams).
+extern "C" size_t cs_register_decide_merge_scratch_bytes(int P, int nList, int nCams) {
+    if (P < 0 || nList < 0 || nCams < 1) return 0;
+    const size_t offOk = ((size_t)P + 15) & ~(size_t)15, offM = (offOk + (size_t)nList * nCams + 15) & ~(size_t)15;
+    return offM + sizeof(double) * 12 * (size_t)nList * nCams;
+}
 extern "C" int cs_register_decide_merge_list_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int P, int mapBase,
                                                  const int* d_list, int nList, const int* d_slot, const int* d_flags,
                                                  const unsigned char* d_mergeable, unsigned char* d_mapFlags, int* d_pointFeat, double* d_mapPts,
@@ -1969,10 +2030,19 @@ extern "C" int cs_register_decide_merge_list_dev(const cs_track_history* h, void
         return CS_OK;
     }
     hist_centres(h, s);
-    if (d_list) {   // the whole tables' out-flags cleared by a wide launch (the one wave below only touches listed rows)
+    if (d_list) {
+        // the whole tables' out-flags and the walk's "touched" marks (scratch [0, P)) cleared by a wide launch (the one wave below only
+        // touches listed rows); behind the marks in the scratch: the pre-checked verdicts [nList][nCams] and their 12 doubles each
+        unsigned char* scr = (unsigned char*)d_scratch;
+        const size_t offOk = ((size_t)P + 15) & ~(size_t)15, offM = (offOk + (size_t)nList * h->nCams + 15) & ~(size_t)15;
+        A.preOk = scr + offOk, A.preM = (double*)(scr + offM);
         cs_small::List ops;
-        ops.fill(d_attached, 0, (size_t)P * h->nCams), ops.fill(d_regged, 0, (size_t)P);
+        ops.fill(d_attached, 0, (size_t)P * h->nCams), ops.fill(d_regged, 0, (size_t)P), ops.fill(scr, 0, (size_t)P);
         CS_HIP(ops.run(s));
+        if (nList > 0 && onlyCam < 0)
+            hipLaunchKernelGGL(k_merge_precheck, dim3((nList * h->nCams + 3) / 4), dim3(256), 0, s, A);
+        else
+            A.preOk = nullptr;
     }
     hipLaunchKernelGGL(k_decide_merge, dim3(1), dim3(64), 0, s, A);
     CS_HIP(hipGetLastError());

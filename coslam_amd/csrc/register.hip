@@ -241,23 +241,46 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
 __global__ __launch_bounds__(1024) void k_register_list(int nCams, int nMap, const int* __restrict__ mapCount, const int* __restrict__ pointFeat,
                                                         const unsigned char* __restrict__ mapFlags, int* __restrict__ list,
                                                         int* __restrict__ listCount, int* __restrict__ slotTable) {
-    // thread t owns the points t * per .. t * per + per - 1 (contiguous: the list keeps the map's order): count, ONE scan over the
-    // block's 1024 counts, then write.  (A first version scanned 1024 points at a time, 15 rounds of three barriers: 35 us.)
+    // pass 1, coalesced: thread t looks at the points t, t + 1024, ... (a wave = 64 consecutive rows of pointFeat), the verdicts go into
+    // a bitmap in LDS (and the unlisted points' rows of slotTable to -1); pass 2: thread t owns `per` consecutive points of the bitmap
+    // (the list keeps the map's order): count, ONE scan over the block, write.  (Earlier forms: 15 rounds of scan over 1024 points,
+    // 35 us; a thread reading its own 15 rows of pointFeat, 64 cache lines per wave load, 68 us.)
+    __shared__ unsigned long long bits[1024];   // 65536 points
     __shared__ int waveSum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int live = mapCount ? (*mapCount < nMap ? *mapCount : nMap) : nMap;
-    const int per = (nMap + 1023) / 1024;
-    const int p0 = tid * per, p1 = (p0 + per) < nMap ? (p0 + per) : nMap;
-    unsigned long long mask = 0ull;   // bit k: point p0 + k is listed (per <= 64: maps of up to 65536 points)
-    int cnt = 0;
-    for (int p = p0; p < p1; ++p) {
+    const bool vec4 = (nCams & 3) == 0 && (reinterpret_cast<uintptr_t>(pointFeat) & 15) == 0;
+    const bool vec4s = (nCams & 3) == 0 && (reinterpret_cast<uintptr_t>(slotTable) & 15) == 0;
+    for (int p0 = wv * 64; p0 < nMap; p0 += 1024) {
+        const int p = p0 + lane;
         bool in = false;
         if (p < live && !(mapFlags && (mapFlags[p] & CS_MAP_FALSE))) {
-            for (int c = 0; c < nCams; ++c) in |= pointFeat[(size_t)p * nCams + c] >= 0;
+            if (vec4) {   // (rows of 4 k ints on a 16-byte boundary: 16-byte loads)
+                const int4* row = reinterpret_cast<const int4*>(pointFeat + (size_t)p * nCams);
+                for (int c = 0; c < nCams / 4; ++c) {
+                    const int4 v = row[c];
+                    in |= v.x >= 0 || v.y >= 0 || v.z >= 0 || v.w >= 0;
+                }
+            } else {
+                for (int c = 0; c < nCams; ++c) in |= pointFeat[(size_t)p * nCams + c] >= 0;
+            }
         }
-        if (in) mask |= 1ull << (p - p0), ++cnt;
+        if (!in && p < nMap && slotTable) {
+            if (vec4s) {
+                int4* row = reinterpret_cast<int4*>(slotTable + (size_t)p * nCams);
+                for (int c = 0; c < nCams / 4; ++c) row[c] = make_int4(-1, -1, -1, -1);
+            } else {
+                for (int c = 0; c < nCams; ++c) slotTable[(size_t)p * nCams + c] = -1;
+            }
+        }
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(in);
+        if (lane == 0) bits[p0 >> 6] = b;
     }
-    // exclusive scan of cnt over the block: within the wave by shuffles, across the waves through LDS
+    __syncthreads();
+    const int per = (nMap + 1023) / 1024;
+    const int q0 = tid * per, q1 = (q0 + per) < nMap ? (q0 + per) : nMap;
+    int cnt = 0;
+    for (int p = q0; p < q1; ++p) cnt += (int)((bits[p >> 6] >> (p & 63)) & 1ull);
     int inc = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -271,13 +294,8 @@ __global__ __launch_bounds__(1024) void k_register_list(int nCams, int nMap, con
         if (w < wv) off += waveSum[w];
         total += waveSum[w];
     }
-    for (int p = p0; p < p1; ++p) {
-        if ((mask >> (p - p0)) & 1ull) {
-            list[off++] = p;
-        } else if (slotTable) {
-            for (int c = 0; c < nCams; ++c) slotTable[(size_t)p * nCams + c] = -1;
-        }
-    }
+    for (int p = q0; p < q1; ++p)
+        if ((bits[p >> 6] >> (p & 63)) & 1ull) list[off++] = p;
     for (int q = total + tid; q < nMap; q += 1024) list[q] = -1;
     if (tid == 0 && listCount) *listCount = total;
 }
@@ -412,7 +430,10 @@ struct RdArgs {
     int* counts;                     // [4] out: features attached, points regged, sweeps, converged
     int* unconverged;                // the scratch's last word: the NUMBER of calls whose sweeps did not settle (never cleared here)
     int* callFlag;                   // the word before it: this call has been counted
+    int* changed;                    // scratch [RD_MAX_SWEEPS]: sweep k changed an owner (the self-settling launch, k_decide_settle)
+    int* bar;                        // scratch [1]: its grid barrier's arrival counter
 };
+constexpr int RD_MAX_SWEEPS = 64;
 // code of (point, camera): -1 the walk passes the camera by; else the candidate feature camera * N + slot in the low bits and
 constexpr int RD_INIT_MAPPED = 1 << 29, RD_CAN_MERGE = 1 << 28, RD_FEAT = (1 << 28) - 1;
 constexpr int RD_INF = 0x7fffffff;
@@ -422,7 +443,8 @@ __global__ __launch_bounds__(256) void k_decide_prepare(RdArgs A) {
     const int k = blockIdx.x * 256 + threadIdx.x, C = A.nCams, nFeat = C * A.N;
     for (int f = k; f < nFeat; f += gridDim.x * 256) A.owner[0][f] = RD_INF, A.owner[1][f] = RD_INF, A.owner[2][f] = RD_INF;
     if (k < 4 && A.counts) A.counts[k] = k == 2 ? A.nSweeps : (k == 3 ? 1 : 0);   // (converged: cleared by the last launch when not)
-    if (k == 0) *A.callFlag = 0;
+    if (k == 0) *A.callFlag = 0, *A.bar = 0;
+    if (k < RD_MAX_SWEEPS) A.changed[k] = 0;
     if (k >= A.P * C) return;
     const int p = k / C, i = k - p * C;
     A.attached[k] = 0;
@@ -499,11 +521,118 @@ __global__ __launch_bounds__(256) void k_decide_sweep(RdArgs A, const int* __res
     }
 }
 
+// ---- the sweeps as ONE launch that stops when they have settled ------------------------------------------------------------------------
+// nSweeps launches with a fixed count either waste launches or, on a frame whose walks cut each other short in a longer chain than
+// the count allows, end on an answer that is not the sequential one (counted, not repaired -- ADVICE r04).  Here every workgroup of
+// ONE launch sweeps until a sweep changes no owner: sweep, grid barrier, compare the sweep's owners with the previous sweep's, grid
+// barrier, stop or go on -- as many sweeps as the frame needs (two on a quiet frame), never more than RD_MAX_SWEEPS, then the
+// attach.  The grid is P / 256 workgroups of 44 registers and no LDS: co-resident beside anything (the barrier spins on an arrival
+// counter in the scratch; a wait of more than 20 ms -- a grid that is NOT co-resident -- gives up and counts the call as unsettled).
+// Owners are read and cleared with agent-scope accesses (they are claimed by atomicMin in L2; a cached line of an earlier sweep must
+// not be read back).
+__device__ __forceinline__ bool rd_grid_barrier(int* ctr, int target) {
+    __syncthreads();
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(ctr, 1);
+        const long long t0 = wall_clock64();
+        int good = 1;
+        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > 2000000LL) {
+                good = 0;
+                break;
+            }
+        }
+        ok = good;
+    }
+    __syncthreads();
+    return ok != 0;
+}
+__device__ __forceinline__ int rd_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rd_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(256) void k_decide_settle(RdArgs A) {
+    const int p = blockIdx.x * 256 + threadIdx.x, C = A.nCams, nFeat = C * A.N, nB = gridDim.x, stride = nB * 256;
+    const int base = p < A.P ? A.base[p] : -1;
+    int code[RD_MAX_CAMS];
+#pragma unroll
+    for (int i = 0; i < RD_MAX_CAMS; ++i) code[i] = (base >= 0 && i < C) ? A.code[(size_t)i * A.P + p] : -1;
+    int arrivals = 0, k = 0;
+    bool settled = false, alive = true;
+    const int* fin = A.owner[0];
+    for (; k < RD_MAX_SWEEPS; ++k) {
+        const int* prev = A.owner[k % 3];
+        int* next = A.owner[(k + 1) % 3];
+        int* clear = A.owner[(k + 2) % 3];
+        for (int f = p; f < nFeat; f += stride) rd_st(clear + f, RD_INF);
+        if (base >= 0) {
+            bool go = true;
+#pragma unroll
+            for (int i = 0; i < RD_MAX_CAMS; ++i) {
+                if (go && code[i] >= 0) {
+                    const int ord = base + i, f = code[i] & RD_FEAT;
+                    if ((code[i] & RD_INIT_MAPPED) || rd_ld(prev + f) < ord) {
+                        go = false;
+                    } else if (code[i] & RD_CAN_MERGE) {
+                        atomicMin(&next[f], ord);
+                    }
+                }
+            }
+        }
+        arrivals += nB;
+        if (!rd_grid_barrier(A.bar, arrivals)) {
+            alive = false;
+            break;
+        }
+        int ch = 0;
+        for (int f = p; f < nFeat; f += stride) ch |= rd_ld(next + f) != rd_ld(prev + f);
+        if (__syncthreads_or(ch) && threadIdx.x == 0) atomicOr(A.changed + k, 1);
+        arrivals += nB;
+        if (!rd_grid_barrier(A.bar, arrivals)) {
+            alive = false;
+            break;
+        }
+        fin = next;
+        if (rd_ld(A.changed + k) == 0) {
+            settled = true;
+            ++k;
+            break;
+        }
+    }
+    if (p == 0 && A.counts) A.counts[2] = k, A.counts[3] = settled ? 1 : 0;
+    if (!settled && p == 0) atomicAdd(A.unconverged, 1);
+    if (!alive || base < 0) return;
+    // the owners in `fin` are final (or the best the sweeps reached): attach (k_decide_sweep's mode 1)
+    bool go = true, reg = false;
+    int nAtt = 0;
+#pragma unroll
+    for (int i = 0; i < RD_MAX_CAMS; ++i) {
+        if (go && code[i] >= 0) {
+            const int ord = base + i, f = code[i] & RD_FEAT, own = rd_ld(fin + f);
+            if ((code[i] & RD_INIT_MAPPED) || own < ord) {
+                go = false;
+            } else if ((code[i] & RD_CAN_MERGE) && own == ord) {
+                const int s2 = f - i * A.N;
+                A.slot2map[i][s2] = A.mapBase + p;
+                A.pointFeat[(size_t)p * C + i] = s2;
+                A.attached[(size_t)p * C + i] = 1;
+                reg = true, ++nAtt;
+            }
+        }
+    }
+    if (reg) {
+        A.regged[p] = 1;
+        if (A.counts) atomicAdd(A.counts, nAtt), atomicAdd(A.counts + 1, 1);
+    }
+}
+
 }  // namespace
 
 extern "C" size_t cs_register_decide_scratch_bytes(int nCams, int N, int P) {
     if (nCams < 1 || N < 1 || P < 0) return 0;
-    return sizeof(int) * ((size_t)nCams * P + (size_t)P + 3 * (size_t)nCams * N + 2);
+    return sizeof(int) * ((size_t)nCams * P + (size_t)P + 3 * (size_t)nCams * N + RD_MAX_SWEEPS + 3);
 }
 
 extern "C" int cs_register_decide_static_dev(int device, void* hip_stream, int nCams, int N, int P, int mapBase, const int* d_slot, const int* d_flags,
@@ -531,9 +660,9 @@ extern "C" int cs_register_decide_kinds_dev(int device, void* hip_stream, int nC
         return CS_ERR_INVALID;
     }
     if (nCams < 1 || nCams > RD_MAX_CAMS || N < 1 || P < 0 || (long long)nCams * N > RD_FEAT || (long long)nCams * P * nCams > 0x7fffffffLL ||
-        mapBase < 0 || nSweeps < 1 || nSweeps > 256 || !d_slot || !d_flags || !d_mergeable || !d_mapFlags || !d_pointFeat || !d_slot2map ||
+        mapBase < 0 || nSweeps < 0 || nSweeps > 256 || !d_slot || !d_flags || !d_mergeable || !d_mapFlags || !d_pointFeat || !d_slot2map ||
         !d_attached || !d_regged || !d_scratch) {
-        cs_set_error("cs_register_decide_static_dev: bad arguments (1..%d cameras, 1..256 sweeps)", RD_MAX_CAMS);
+        cs_set_error("cs_register_decide_static_dev: bad arguments (1..%d cameras, 0..256 sweeps)", RD_MAX_CAMS);
         return CS_ERR_INVALID;
     }
     RdArgs A;
@@ -552,12 +681,18 @@ extern "C" int cs_register_decide_kinds_dev(int device, void* hip_stream, int nC
     A.code = scr, scr += (size_t)nCams * P;
     A.base = scr, scr += P;
     for (int k = 0; k < 3; ++k) A.owner[k] = scr, scr += (size_t)nCams * N;
-    A.callFlag = scr, A.unconverged = scr + 1;
+    A.changed = scr, scr += RD_MAX_SWEEPS;
+    A.bar = scr, A.callFlag = scr + 1, A.unconverged = scr + 2;
     CS_HIP(hipSetDevice(device));
     if (P == 0) return CS_OK;
     hipStream_t s = (hipStream_t)hip_stream;
     const int gE = (P * nCams + 255) / 256, gP = (P + 255) / 256;
     hipLaunchKernelGGL(k_decide_prepare, dim3(gE), dim3(256), 0, s, A);
+    if (nSweeps == 0) {   // as many sweeps as the frame needs, ONE launch (k_decide_settle)
+        hipLaunchKernelGGL(k_decide_settle, dim3(gP), dim3(256), 0, s, A);
+        CS_CHECK_LAUNCH();
+        return CS_OK;
+    }
     // sweep k reads owner[k % 3], claims into owner[(k + 1) % 3] and clears owner[(k + 2) % 3] for the sweep after it
     for (int k = 0; k < nSweeps; ++k)
         hipLaunchKernelGGL(k_decide_sweep, dim3(gP), dim3(256), 0, s, A, (const int*)A.owner[k % 3], A.owner[(k + 1) % 3], A.owner[(k + 2) % 3],

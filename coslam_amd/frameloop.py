@@ -612,7 +612,8 @@ class FrameLoop:
             self.n_merge_frames = 0
             self._dec = dict(att=z((self.n_map, NA), torch.uint8), reg=z(self.n_map, torch.uint8), cnt=z(4, torch.int32), ref_cnt=z(1, torch.int32),
                              mcnt=z(4, torch.int32),
-                             scr=z(register_decide_scratch_bytes(NA, cfg.n_feat, self.n_map), torch.uint8), s2m=None)
+                             scr=z(register_decide_scratch_bytes(NA, cfg.n_feat, self.n_map), torch.uint8), s2m=None,
+                             mscr=z(self.pose_upd.decide_merge_scratch_bytes(self.n_map, cfg.p_reg), torch.uint8))
             torch.cuda.synchronize()   # (the zero fills ran on torch's stream: done before the pose stream touches the buffers)
         D = self._dec
         if self.sequential_registration:
@@ -631,7 +632,7 @@ class FrameLoop:
                                                           D["att"].data_ptr(), D["reg"].data_ptr(), D["scr"].data_ptr(), self.d_map.data_ptr(),
                                                           self.d_cov.data_ptr(), PIXEL_ERR_VAR, d_counts=D["cnt"].data_ptr(), device=self.device,
                                                           with_dynamic=True, merge=(cfg.merge_every > 0 and self._frame_now % cfg.merge_every == 0),   # CoSLAMThread.cpp:117-118
-                                                          d_merge_scratch=D["scr"].data_ptr(), mergability=self._mergability)
+                                                          d_merge_scratch=D["mscr"].data_ptr(), mergability=self._mergability, n_sweeps=0)
             return
         if self.world > 1:
             self._gather_candidates()
@@ -642,7 +643,7 @@ class FrameLoop:
             self.pose_upd.register_decide_merge_dev(ps, self.pu_args, self.n_map, 0, o["slot"].data_ptr(), o["flags"].data_ptr(),
                                                     self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(),
                                                     self.d_map.data_ptr(), self.d_cov.data_ptr(), PIXEL_ERR_VAR, D["att"].data_ptr(),
-                                                    D["reg"].data_ptr(), D["scr"].data_ptr(), D["mcnt"].data_ptr(),
+                                                    D["reg"].data_ptr(), D["mscr"].data_ptr(), D["mcnt"].data_ptr(),
                                                     d_list=self.d_curlist.data_ptr(), nList=cfg.p_reg)
             self.pose_upd.refine_map_points_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
                                                 PIXEL_ERR_VAR, d_select=D["reg"].data_ptr())   # (no count asked for: that would be one more launch, and it is counts[1])
@@ -652,7 +653,7 @@ class FrameLoop:
                                               self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(),
                                               D["s2m"] if D["s2m"] is not None else [self.d_slot2map[g].data_ptr() for g in range(NA)],
                                               D["att"].data_ptr(), D["reg"].data_ptr(), D["scr"].data_ptr(), D["cnt"].data_ptr(), device=self.device,
-                                              kinds=kinds)   # curStaticPointsRegInGroup and curDynamicPointsRegInGroup (currentMapPointsRegister, :834-853)
+                                              kinds=kinds, n_sweeps=0)   # (0: ONE launch that sweeps until the owners have settled)   # curStaticPointsRegInGroup and curDynamicPointsRegInGroup (currentMapPointsRegister, :834-853)
         self.pose_upd.refine_map_points_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
                                             PIXEL_ERR_VAR, d_select=D["reg"].data_ptr())   # (no count asked for: that would be one more launch, and it is counts[1])
 

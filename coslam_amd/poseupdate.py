@@ -161,6 +161,11 @@ class TrackHistory:
         check(self._L.cs_check_unify_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), int(nPairs), vp(d_pf1), vp(d_pf2), vp(d_M1), vp(d_M2),
                                          C.c_double(pixelErrVar), vp(d_ok), vp(d_M), vp(d_cov)), "cs_check_unify_dev")
 
+    def decide_merge_scratch_bytes(self, P, nList):
+        """d_scratch of register_decide_merge_dev with a list (without: P bytes)"""
+        self._L.cs_register_decide_merge_scratch_bytes.restype = C.c_size_t
+        return int(self._L.cs_register_decide_merge_scratch_bytes(int(P), int(nList), self.nCams))
+
     def register_decide_merge_dev(self, stream_ptr, cams, P, mapBase, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, d_mapPts, d_mapCov,
                                   pixelErrVar, d_attached, d_regged, d_scratch, d_counts=0, only_cam=-1, d_list=None, nList=0):
         """curStaticPointsRegInGroup with bMerge == true (reference src/app/SL_CoSLAM.cpp:854-898, 731-830), the walks in the reference's

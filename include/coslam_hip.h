@@ -353,7 +353,9 @@ int cs_register_search(int device, int nCams, const cs_register_cam* cams, int N
  * returns true whatever it computes, :546-558); a feature that already carries a map point -- before the pass, or taken by an earlier
  * walk -- ends the point's walk (:789-790).  The sequential "first claimant wins" is a recursion along the order of the walk steps;
  * nSweeps Jacobi sweeps (one small launch each) solve it -- exactly once two consecutive sweeps agree (d_counts[3] = 1), which takes as
- * many sweeps as the longest chain of walks cutting each other short: 1-2 on tracked frames, 3 is a safe default (csrc/register.hip).
+ * many sweeps as the longest chain of walks cutting each other short: 1-2 on tracked frames (csrc/register.hip).  nSweeps = 0: ONE
+ * launch whose workgroups sweep behind a grid barrier until a sweep changes nothing (at most 64 sweeps; d_counts[2] = the sweeps it took)
+ * -- what a frame loop should pass: the answer is then always the sequential one.
  * d_slot / d_flags: the search's P x nCams tables; d_mapFlags [P]: CS_MAP_* bytes of the pass's points (map points mapBase ..
  * mapBase + P - 1); IN / OUT: d_pointFeat [P][nCams] (MapPoint::addFeature) and every camera's slot2map [N] (the attached feature's
  * whole track takes the point, :771-775); OUT: d_attached [P][nCams], d_regged [P] (refineMapPoint is due: hand it to
@@ -575,6 +577,7 @@ int cs_register_decide_merge_dev(const cs_track_history* h, void* hip_stream, co
                                  int* d_counts, int onlyCam);
 /* the same walking a LIST of the points (cs_register_list_current_dev: the frame's current points in map order, entries < 0 behind them;
  * mapBase must be 0) over whole-map tables of P rows: the single wave's loops are as long as the list, not as the map's capacity */
+size_t cs_register_decide_merge_scratch_bytes(int P, int nList, int nCams); /* d_scratch of the list form (the plain form: P bytes) */
 int cs_register_decide_merge_list_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int P, int mapBase,
                                       const int* d_list, int nList, const int* d_slot, const int* d_flags, const unsigned char* d_mergeable,
                                       unsigned char* d_mapFlags, int* d_pointFeat, double* d_mapPts, double* d_mapCov, double pixelErrVar,

@@ -120,6 +120,24 @@ def test_too_few_sweeps_are_reported_and_the_word_sticks(hip):
     assert g3["unsettled"] == 0
 
 
+def test_self_settling_launch_always_ends_on_the_sequential_answer(hip):
+    """nSweeps = 0 (a fixed number of sweeps may end on an answer that is not the sequential one): ONE launch whose workgroups
+    sweep behind a grid barrier until a sweep changes no owner.  On scenes with long conflict chains (where 1 and 3 sweeps are reported
+    as not enough) and at the headline's table size (15 k rows, most of them without a walk) it reports `settled`, never counts the
+    call as unsettled, and the attachments are the sequential oracle's."""
+    import oracle
+
+    for seed, P, nC, N, dens in ((3, 4096, 8, 2000, 0.5), (11, 15192, 8, 2000, 0.12), (5, 300, 3, 64, 0.9)):
+        slot, flags, merg, mf, pf, s2m = _case(seed, P, nC, N, dens)
+        o_pf, o_s2m = pf.copy(), [x.copy() for x in s2m]
+        att_o, reg_o = oracle.register_decide_static(slot, flags, merg, mf, o_pf, o_s2m)
+        g = _device_decide(slot, flags, merg, mf, pf, s2m, 0)
+        assert g["cnt"][3] == 1 and g["unsettled"] == 0 and 2 <= g["cnt"][2] <= 64, (seed, g["cnt"])
+        assert np.array_equal(g["att"], att_o) and np.array_equal(g["reg"], reg_o) and np.array_equal(g["pf"], o_pf)
+        assert all(np.array_equal(g["s2m"][c], o_s2m[c]) for c in range(nC))
+        assert g["cnt"][0] == int(att_o.sum()) and g["cnt"][1] == int(reg_o.sum())
+
+
 def test_merge_walk_edge_cases(hip):
     """cs_register_decide_merge_dev where nothing may happen: no point on any visiting list, every candidate owned by a point outside the
     pass or by a dynamic / false one (no checkUnify is asked), an empty pass; and what is refused"""
@@ -304,6 +322,25 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
         else:
             assert sum(r[0] for r in rounds) == int((S["ref_s2m"] != S["s2m"]).sum())
         dyn_total += S["ref_regged_dyn"]
+        if S["with_merge"]:
+            # the frame loop's form of the bMerge walk -- all cameras' loops in ONE call over a LIST of points, the checkUnify verdicts it may
+            # need evaluated side by side before the walk (k_merge_precheck) and used while neither point has been touched -- against the
+            # same call without a list (every verdict evaluated by the walking wave as it goes): the same map, bit for bit
+            res = []
+            lst = torch.arange(nP, dtype=torch.int32, device=dev)
+            for use_list in (False, True):
+                ds2m.copy_(d(S["s2m"])), dM.copy_(d(S["M"])), dcov.copy_(d(S["cov"])), dpf.copy_(d(S["pf"])), dfl.copy_(d(S["fl"]))
+                register_search_passes_dev(s_, rc, N, S["W"], S["H"], passes)
+                th.register_mergability_dev(s_, cams, nP, dM.data_ptr(), dcov.data_ptr(), out["slot"].data_ptr(), S["pv"], dmerge.data_ptr())
+                scr = torch.zeros(th.decide_merge_scratch_bytes(nP, nP), dtype=torch.uint8, device=dev)
+                th.register_decide_merge_dev(s_, cams, nP, 0, out["slot"].data_ptr(), out["flags"].data_ptr(), dmerge.data_ptr(), dfl.data_ptr(),
+                                             dpf.data_ptr(), dM.data_ptr(), dcov.data_ptr(), S["pv"], datt.data_ptr(), dreg.data_ptr(), scr.data_ptr(),
+                                             dcnt.data_ptr(), d_list=lst.data_ptr() if use_list else None, nList=nP if use_list else 0)
+                torch.cuda.synchronize()
+                res.append([x.cpu().numpy().copy() for x in (ds2m, dM, dcov, dpf, dfl, datt, dreg, dcnt)])
+            for a, b in zip(*res):
+                assert np.array_equal(a, b)
+            assert res[1][7][2] > 5 and res[1][7][3] > res[1][7][2]      # points unified away; checkUnify asked more often than it said yes
         th.close()
     assert 0 < diff_total <= 0.03 * att_total, (diff_total, att_total)
     assert dyn_total > 30 and merged_total > 40

@@ -359,6 +359,7 @@ int main(int argc, char** argv) {
     unsigned char* dAttached = dev_zeros<unsigned char>((size_t)nMap * nCams);
     unsigned char* dRegged = dev_zeros<unsigned char>(nMap);
     void* dDecScratch = dev_zeros<unsigned char>(cs_register_decide_scratch_bytes(nCams, N, nMap));
+    void* dMergeScratch = dev_zeros<unsigned char>(cs_register_decide_merge_scratch_bytes(nMap, P_REG, nCams));
     int* dDecCnt = dev_zeros<int>(4);
     int* dMergeCnt = dev_zeros<int>(4);
     int nMergeFrames = 0;
@@ -446,13 +447,13 @@ int main(int argc, char** argv) {
         int kinds = 3;
         if (i % 50 == 0) {
             CSCHK(cs_register_decide_merge_list_dev(hist, (void*)poseS, pu.data(), nMap, 0, dCurList, P_REG, reg[0].slot, reg[0].flags, dMergeable, dMapFlags, dPf, dMap, dCov,
-                                               PIX, dAttached, dRegged, dDecScratch, dMergeCnt, /*onlyCam*/ -1));
+                                               PIX, dAttached, dRegged, dMergeScratch, dMergeCnt, /*onlyCam*/ -1));
             CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
             ++nMergeFrames;
             kinds = 2;
         }
         CSCHK(cs_register_decide_kinds_dev(dev, (void*)poseS, nCams, N, nMap, 0, reg[0].slot, reg[0].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
-                                           dAttached, dRegged, dDecScratch, 3, dDecCnt, /*onlyCam*/ -1, kinds));
+                                           dAttached, dRegged, dDecScratch, /*nSweeps: until settled*/ 0, dDecCnt, /*onlyCam*/ -1, kinds));
         CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
         // the tracker of frame i + 2 is released at the END of the frame's pose work (released right behind the hand-back it runs two frames
         // ahead and under more of the pose stream's kernels: -10 %, profiles/r04_ab_runs.txt)
