@@ -452,6 +452,8 @@ __global__ __launch_bounds__(256) void k_register_mergability_running(MgRunArgs 
     CS_POSE_STREAM_PRIO();
     const MgArgs& A = B.a;
     const int c = A.cam0 + blockIdx.y, tid = threadIdx.x, N = A.N, H = A.H, W = B.W;
+    // (a compact list is padded with -1: a workgroup whose first row lies behind the list's end has nothing to do -- before it stages a pose)
+    if (B.list && (int)(blockIdx.x * (256 / MG_LPC)) < B.nList && B.list[blockIdx.x * (256 / MG_LPC)] < 0) return;
     const cs_poseupdate_cam& C = A.cam[c];
     const double* hR = A.histR + (size_t)c * H * 9;
     const double* hT = A.histT + (size_t)c * H * 3;
@@ -1015,6 +1017,7 @@ __global__ __launch_bounds__(256) void k_merge_precheck(DmArgs A) {
         A.preOk[e] = ok ? 2 : 1;
     }
 }
+constexpr int DM_MAX_CAMS = 16;   // (cs_register_decide_merge_dev refuses more: lane c = camera c, four lanes' worth of columns)
 __device__ __forceinline__ int mg_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned char mg_ldb(const unsigned char* p) { return *(volatile const unsigned char*)p; }
 __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
@@ -1050,16 +1053,50 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
               myP = p0 + lane;
               in = myP < P && A.inVec[myP] != 0;
           }
+          // by list: the batch's 64 points read their rows side by side (lane = point: every camera's candidate, its flags, whether the point
+          // has a feature there, who owns the candidate) -- the walk below then takes a point's row out of its lane's registers instead of
+          // waiting for five dependent loads per visit (3900 visits of ~1.2 us were the kernel's 4.7 ms).  The rows stand until the wave
+          // itself changes something (an attach, a unification): from then on the rest of the batch reads memory again.
+          int bSlot[DM_MAX_CAMS], bOwner[DM_MAX_CAMS];
+          unsigned bHas = 0, bDyn = 0, bMerge = 0;
+          bool batchClean = byList;
+          if (byList) {
+#pragma unroll
+              for (int i = 0; i < DM_MAX_CAMS; ++i) {
+                  bSlot[i] = -1, bOwner[i] = -1;
+                  if (in && i < C) {
+                      int sl = A.slot[(size_t)myP * C + i];
+                      const int fl = A.flags[(size_t)myP * C + i];
+                      if (sl >= N) sl = -1;
+                      bSlot[i] = sl;
+                      if (fl & 2) bDyn |= 1u << i;
+                      if (A.mergeable[(size_t)myP * C + i] == 1) bMerge |= 1u << i;
+                      if (mg_ld(A.pointFeat + (size_t)myP * C + i) >= 0) bHas |= 1u << i;
+                      if (sl >= 0) bOwner[i] = mg_ld(A.cu.cam[i].slot2map + sl);
+                  }
+              }
+          }
           unsigned long long todo = __builtin_amdgcn_ballot_w64(in);
           while (todo) {
-            const int jP = p0 + __builtin_ctzll(todo);   // (by list: the point's place on the list)
-            const int p = __shfl(myP, __builtin_ctzll(todo), 64);
+            const int src = __builtin_ctzll(todo);
+            const int jP = p0 + src;   // (by list: the point's place on the list)
+            const int p = __shfl(myP, src, 64);
             todo &= todo - 1;
-            if (*(volatile unsigned char*)(A.mapFlags + p) & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) continue;   // :734 isLocalStatic() (unified away meanwhile)
+            // :734 isLocalStatic(): unified away meanwhile?  (only the wave's own steps unify: an untouched batch stands as it was read)
+            if (!batchClean && (*(volatile unsigned char*)(A.mapFlags + p) & (CS_MAP_DYNAMIC | CS_MAP_FALSE))) continue;
             // lane c: camera c's entry of the point -- the candidate, and what it would meet there as things stand (the state changes only
             // through this wave's own steps: an attach leaves the point's later cameras as they were, a unify ends the walk)
             int mySlot = -1, myFlags = 0, myMerge = 0, myHas = 0, myOwner = -1;
-            if (lane < C) {
+            if (batchClean) {
+                const unsigned hHas = (unsigned)__shfl((int)bHas, src, 64), hDyn = (unsigned)__shfl((int)bDyn, src, 64),
+                               hMerge = (unsigned)__shfl((int)bMerge, src, 64);
+#pragma unroll
+                for (int i = 0; i < DM_MAX_CAMS; ++i) {
+                    const int sl = __shfl(bSlot[i], src, 64), ow = __shfl(bOwner[i], src, 64);
+                    if (lane == i) mySlot = sl, myOwner = ow;
+                }
+                if (lane < C) myFlags = ((hDyn >> lane) & 1u) ? 2 : 0, myMerge = (hMerge >> lane) & 1u, myHas = (hHas >> lane) & 1u;
+            } else if (lane < C) {
                 mySlot = A.slot[(size_t)p * C + lane], myFlags = A.flags[(size_t)p * C + lane], myMerge = A.mergeable[(size_t)p * C + lane];
                 myHas = mg_ld(A.pointFeat + (size_t)p * C + lane) >= 0;
                 if (mySlot >= N) mySlot = -1;
@@ -1083,6 +1120,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
                             if (byList) A.inVec[p] = 1;   // the point has changed: a pre-checked verdict about it no longer stands
                         }
                         __threadfence();
+                        batchClean = false;
                         reg = true, ++nAtt;
                     }
                     continue;
@@ -1122,6 +1160,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
                     }
                 }
                 __threadfence();
+                batchClean = false;
                 reg = true, ++nMerged;
                 break;                                                                      // :825 return
             }

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
     // Q.list: the pass's points are list[0 .. P) (map indices, < 0: no point) -- the tables stay indexed by the MAP index, so a compact
     // list of the frame's current points (cs_register_list_current_dev) costs one workgroup per 64 LISTED points and camera
     const int j = blockIdx.x * 64 + lane;
+    if (Q.list && (int)(blockIdx.x * 64) < Q.P && Q.list[blockIdx.x * 64] < 0) return;   // (a compact list: this tile lies behind its end)
     const int p = Q.list ? (j < Q.P ? Q.list[j] : -1) : (j < Q.P ? j : -1);
     const cs_register_cam& C = A.cam[c];
     const int N = A.N;
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
 // in the map, the points genNewMapPoints has just appended included.  One workgroup: a point is listed when it lies below the
 // live count, is not false (neither registration loop visits a false point) and holds a feature of this frame; the list keeps the
 // map's order (the order the reference's walks visit the points in).  list[count .. nMap) = -1; the rows of the points that
-// are NOT listed get slot = -1 in `slotTable` (nMap x nCams, optional), so that the tables never carry a stale candidate.
+// left the list since the previous call get slot = -1 in `slotTable` (nMap x nCams, optional; it starts at -1 everywhere and only
+// listed rows are ever written), so that the tables never carry a stale candidate.
 __global__ __launch_bounds__(1024) void k_register_list(int nCams, int nMap, const int* __restrict__ mapCount, const int* __restrict__ pointFeat,
                                                         const unsigned char* __restrict__ mapFlags, int* __restrict__ list,
                                                         int* __restrict__ listCount, int* __restrict__ slotTable) {
@@ -251,7 +253,10 @@ __global__ __launch_bounds__(1024) void k_register_list(int nCams, int nMap, con
     const int live = mapCount ? (*mapCount < nMap ? *mapCount : nMap) : nMap;
     const bool vec4 = (nCams & 3) == 0 && (reinterpret_cast<uintptr_t>(pointFeat) & 15) == 0;
     const bool vec4s = (nCams & 3) == 0 && (reinterpret_cast<uintptr_t>(slotTable) & 15) == 0;
-    for (int p0 = wv * 64; p0 < nMap; p0 += 1024) {
+    const int oldCount = listCount ? (*listCount < nMap ? (*listCount < 0 ? 0 : *listCount) : nMap) : nMap;   // `list` still holds the previous call's
+    for (int w = tid; w < (nMap + 63) / 64; w += 1024) bits[w] = 0ull;
+    __syncthreads();
+    for (int p0 = wv * 64; p0 < live; p0 += 1024) {
         const int p = p0 + lane;
         bool in = false;
         if (p < live && !(mapFlags && (mapFlags[p] & CS_MAP_FALSE))) {
@@ -265,7 +270,16 @@ __global__ __launch_bounds__(1024) void k_register_list(int nCams, int nMap, con
                 for (int c = 0; c < nCams; ++c) in |= pointFeat[(size_t)p * nCams + c] >= 0;
             }
         }
-        if (!in && p < nMap && slotTable) {
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(in);
+        if (lane == 0) bits[p0 >> 6] = b;
+    }
+    __syncthreads();
+    // the rows of the points that were on the list a call ago and are not any more lose their candidates (every other unlisted row
+    // lost them when it left the list, or never had any: the table starts at -1) -- a few hundred rows instead of the whole map's
+    if (slotTable) {
+        for (int q = tid; q < oldCount; q += 1024) {
+            const int p = list[q];
+            if (p < 0 || p >= nMap || ((bits[p >> 6] >> (p & 63)) & 1ull)) continue;
             if (vec4s) {
                 int4* row = reinterpret_cast<int4*>(slotTable + (size_t)p * nCams);
                 for (int c = 0; c < nCams / 4; ++c) row[c] = make_int4(-1, -1, -1, -1);
@@ -273,10 +287,8 @@ __global__ __launch_bounds__(1024) void k_register_list(int nCams, int nMap, con
                 for (int c = 0; c < nCams; ++c) slotTable[(size_t)p * nCams + c] = -1;
             }
         }
-        const unsigned long long b = __builtin_amdgcn_ballot_w64(in);
-        if (lane == 0) bits[p0 >> 6] = b;
     }
-    __syncthreads();
+    __syncthreads();   // (the previous list has been read: it may be overwritten)
     const int per = (nMap + 1023) / 1024;
     const int q0 = tid * per, q1 = (q0 + per) < nMap ? (q0 + per) : nMap;
     int cnt = 0;

@@ -319,17 +319,19 @@ typedef struct cs_register_pass {
      * over the current points serves both registrations */
     const unsigned char* mapFlags;
     double maxDistDynamic;
-    /* optional (NULL: the pass's points are map rows 0 .. P - 1): the pass's points as a LIST of P map indices (< 0: no point, idles its
-     * lane) -- every table above stays indexed by the map index (M, cov, pointFeat, slot, ... are then whole-map tables), only the
-     * rows of listed points are read and written.  cs_register_list_current_dev builds the list of a frame's current points. */
+    /* optional (NULL: the pass's points are map rows 0 .. P - 1): the pass's points as a COMPACT list of up to P map indices (the first
+     * entry < 0 ends it) -- every table above stays indexed by the map index (M, cov, pointFeat, slot, ... are then whole-map tables),
+     * only the rows of listed points are read and written.  cs_register_list_current_dev builds the list of a frame's current points. */
     const int* list;
 } cs_register_pass;
 /* The frame's CURRENT map points -- what CoSLAM::currentMapPointsRegister walks: curMapPts = the points with a feature of this frame in
  * at least one camera (mapStateUpdate, src/app/SL_CoSLAM.cpp:1176-1194; :734 / :958 ask numVisCam > 0 once more), wherever they sit in
  * the map, the points genNewMapPoints has just appended included -- as a compact list in map order: d_list [nMap] (entries behind the
  * list: -1), d_listCount [1] or NULL.  A point is listed when its index is below *d_mapCount (NULL: nMap), it is not CS_MAP_FALSE
- * (d_mapFlags, may be NULL) and d_pointFeat [nMap][nCams] holds a feature of it.  d_slotTable (nMap x nCams ints, or NULL): the rows of
- * the points NOT listed are set to -1 (a search driven by the list leaves them alone: no stale candidate survives a frame). */
+ * (d_mapFlags, may be NULL) and d_pointFeat [nMap][nCams] holds a feature of it.  d_list / d_listCount are IN / OUT: they still hold
+ * the previous call's list (start: count 0), and the rows of d_slotTable (nMap x nCams ints, or NULL; start: -1 everywhere) of the
+ * points that have LEFT the list since are set to -1 -- a search driven by the list writes listed rows only, so no stale candidate
+ * survives a frame and no frame clears the whole table. */
 int cs_register_list_current_dev(int device, void* hip_stream, int nCams, int nMap, const int* d_mapCount, const int* d_pointFeat,
                                  const unsigned char* d_mapFlags, int* d_list, int* d_listCount, int* d_slotTable);
 int cs_register_search_passes_dev(int device, void* hip_stream, int nCams, const cs_register_cam* cams, int N, int W, int H,
@@ -495,8 +497,8 @@ size_t cs_register_mergability_cache_bytes(int P, int nCams);
 int cs_register_mergability_running_dev(const cs_track_history* h, void* hip_stream, int cam0, int nCamsRun, const cs_poseupdate_cam* cams,
                                         int P, const double* d_M, const double* d_cov, const int* d_slot, double pixelErrVar, double tolPix,
                                         void* d_cache, unsigned char* d_mergeable, int* d_counts);
-/* ... for the rows d_list[0 .. nList) of whole-map tables only (entries < 0 skipped; cs_register_pass::list's companion; NULL: all P
- * rows): d_M, d_cov, d_slot, d_cache, d_mergeable are indexed by the map index, P = the tables' rows.  d_flags (the search's flags
+/* ... for the rows d_list[0 .. nList) of whole-map tables only (a compact list: the first entry < 0 ends it; cs_register_pass::list's
+ * companion; NULL: all P rows): d_M, d_cov, d_slot, d_cache, d_mergeable are indexed by the map index, P = the tables' rows.  d_flags (the search's flags
  * table, or NULL): a candidate that already carries a map point (bit 0 clear) is not judged -- verdict 0; the registration walks end at
  * such a feature or ask checkUnify about it, they never put it to this test. */
 int cs_register_mergability_running_list_dev(const cs_track_history* h, void* hip_stream, int cam0, int nCamsRun, const cs_poseupdate_cam* cams,

@@ -254,6 +254,17 @@ def test_current_points_list_drives_the_search_like_the_whole_table(hip):
                     flags=torch.full((P, n_cams), fill, dtype=torch.int32, device=dev))
 
     T_list, T_all = tables(99), tables(99)
+    # a first call with MORE points holding a feature, its rows filled; the call that counts then drops the rows that left the list
+    pf_more = pf.copy()
+    extra = rng.choice(np.nonzero((pf < 0).all(axis=1) & (np.arange(P) < live) & ((flags & 2) == 0))[0], 300, replace=False)
+    pf_more[extra, 0] = 5
+    d_pf_more = d(pf_more)
+    register_list_current_dev(s, n_cams, P, d_cnt.data_ptr(), d_pf_more.data_ptr(), d_fl.data_ptr(), d_list.data_ptr(), d_n.data_ptr(),
+                              T_list["slot"].data_ptr())
+    torch.cuda.synchronize()
+    want_more = np.nonzero((np.arange(P) < live) & ((flags & 2) == 0) & (pf_more >= 0).any(axis=1))[0]
+    assert d_n.item() == len(want_more) and np.array_equal(d_list.cpu().numpy()[:len(want_more)], want_more)
+    assert (T_list["slot"].cpu().numpy() == 99).all()          # (nothing had been on a list before: no row to clear)
     register_list_current_dev(s, n_cams, P, d_cnt.data_ptr(), d_pf.data_ptr(), d_fl.data_ptr(), d_list.data_ptr(), d_n.data_ptr(),
                               T_list["slot"].data_ptr())
     torch.cuda.synchronize()
@@ -261,7 +272,9 @@ def test_current_points_list_drives_the_search_like_the_whole_table(hip):
     lst = d_list.cpu().numpy()
     assert d_n.item() == len(want) > 500 and np.array_equal(lst[:len(want)], want) and (lst[len(want):] == -1).all()
     unlisted = np.setdiff1d(np.arange(P), want)
-    assert (T_list["slot"].cpu().numpy()[unlisted] == -1).all() and (T_list["slot"].cpu().numpy()[want] == 99).all()
+    sl0 = T_list["slot"].cpu().numpy()
+    assert (sl0[extra] == -1).all() and (sl0[np.setdiff1d(np.arange(P), extra)] == 99).all()   # exactly the rows that left the list
+    T_list["slot"][torch.from_numpy(unlisted).to(dev)] = -1     # (a table in use starts at -1 and only listed rows are ever written)
 
     def a_pass(T, P_, lst_=0):
         return dict(P=P_, sigmaSearch=PIXEL_ERR_VAR, maxDist=3 * PIXEL_ERR_VAR, sigmaMerge=PIXEL_ERR_VAR, M=d_M.data_ptr(), cov=d_cov.data_ptr(),
