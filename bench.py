@@ -213,11 +213,14 @@ def export_workload(path, sc, frames, joint, ic, cams_per_launch):
         f.write(Fs.tobytes())
 
 
-def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True, with_posegraph=True, with_ncc=True):
+def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True, with_posegraph=True, with_ncc=True, reading="variance"):
     """The oracle (C restatement of the reference's path: kind "port") on `n_threads` host cores: the cameras of a frame
     in parallel (the ctypes calls release the GIL), the key-frame solves on the calling thread."""
     import oracle
 
+    # what the covariance helpers get where the reference passes Const::PIXEL_ERR_VAR (a variance: sqrt(10) px; "std": the constant as it is)
+    SIG = float(np.sqrt(PIXEL_ERR_VAR)) if reading == "variance" else PIXEL_ERR_VAR
+    SIG_CLS = float(np.sqrt(12.0)) if reading == "variance" else 12.0
     order = frame_order(N_FRAMES)
     cfg = klt_config()
     trk, s2m, tl, xy, Rc, tc, st = [], [], [], [], [], [], []
@@ -268,7 +271,7 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
     def pose_update_all(frame_no):
         for c in range(N_CAMS):
             oracle.pose_update_gate([Kc] * N_CAMS, np.stack([r.reshape(9) for r in Rc]), np.stack(tc), xy, st, s2m, map_pts, map_cov,
-                                    map_flags, 0, PIXEL_ERR_VAR, reproj, cams=[c])
+                                    map_flags, 0, SIG, reproj, cams=[c])
             h = hist[c]
             h["R"].insert(0, Rc[c].reshape(9).copy()), h["t"].insert(0, tc[c].copy()), h["xy"].insert(0, xy[c].copy())
             del h["R"][64:], h["t"][64:], h["xy"][64:]
@@ -279,45 +282,55 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
         fs_all = np.ascontiguousarray(np.stack(is_static))
         oracle.map_points_classify([Kc] * N_CAMS, [iK] * N_CAMS, np.stack([np.stack(h["R"]) for h in hist]),
                                    np.stack([np.stack(h["t"]) for h in hist]), np.stack([np.stack(h["xy"]) for h in hist]), np.stack(tl),
-                                   fs_all, pf_all, frame_no, map_pts, map_cov, map_flags, cls_new, cls_sfn, cls_first, 12.0)
+                                   fs_all, pf_all, frame_no, map_pts, map_cov, map_flags, cls_new, cls_sfn, cls_first, SIG_CLS)
         for c in range(N_CAMS):
             is_static[c][:] = fs_all[c]
 
     Kc = sc.K
 
-    reg_slot, reg_flags = np.full((CPU_P_REG, N_CAMS), -1, np.int32), np.zeros((CPU_P_REG, N_CAMS), np.int32)
-    reg_merge, reg_pf = np.zeros((CPU_P_REG, N_CAMS), np.uint8), np.full((CPU_P_REG, N_CAMS), -1, np.int32)
+    # currentMapPointsRegister as the GPU loop runs it: ONE search pass over the frame's CURRENT points (the map points with a feature of
+    # this frame in some camera, wherever they sit in the map), tables indexed by the map index; no active pass (the reference's attach
+    # loop behind it cannot be reached: tests/cxx/ref_active_test.cpp)
+    nMapAll = len(sc.points)
+    reg_slot, reg_flags = np.full((nMapAll, N_CAMS), -1, np.int32), np.zeros((nMapAll, N_CAMS), np.int32)
+    reg_merge, reg_pf = np.zeros((nMapAll, N_CAMS), np.uint8), np.full((nMapAll, N_CAMS), -1, np.int32)
+    cur_list = [np.zeros(0, np.int64)]
+
+    def list_current():
+        for c in range(N_CAMS):
+            reg_pf[:, c] = oracle.point_features(st[c], s2m[c], nMapAll)
+        cur_list[0] = np.nonzero((reg_pf >= 0).any(axis=1) & ((map_flags & 2) == 0))[0]
+        reg_slot[:] = -1
 
     def reg_step(c):
-        # activeMapPointsRegister + currentMapPointsRegister, search step, this camera's column of the tables
         one = lambda a: [a]  # noqa: E731
-        oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), map_pts[CPU_P_REG:2 * CPU_P_REG],
-                               cov[CPU_P_REG:2 * CPU_P_REG], no_feat, 2.5 * PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)
-        pf = oracle.point_features(st[c], s2m[c], CPU_P_REG).reshape(CPU_P_REG, 1)
-        rs = oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), map_pts[:CPU_P_REG],
-                                    cov[:CPU_P_REG], pf, PIXEL_ERR_VAR, 3 * PIXEL_ERR_VAR, PIXEL_ERR_VAR)
-        reg_slot[:, c], reg_flags[:, c], reg_pf[:, c] = rs["slot"][:, 0], rs["flags"][:, 0], pf[:, 0]
+        idx = cur_list[0]
+        if len(idx) == 0:
+            return
+        pf = np.ascontiguousarray(reg_pf[idx, c:c + 1])
+        rs = oracle.register_search(W, H, Kc, Rc[c], tc[c], one(xy[c]), one(st[c]), one(s2m[c]), one(None), map_pts[idx], cov[idx], pf, SIG,
+                                    3 * PIXEL_ERR_VAR, SIG)
+        reg_slot[idx, c], reg_flags[idx, c] = rs["slot"][:, 0], rs["flags"][:, 0]
         h = hist[c]
-        reg_merge[:, c] = 0
-        if h["R"]:   # staticCheckMergability of the candidates over their whole tracks (the history as of the previous frame's pose update)
-            reg_merge[:, c] = oracle.register_mergability_cam(Kc, np.stack(h["R"]), np.stack(h["t"]), np.stack(h["xy"]), tl[c], map_pts[:CPU_P_REG],
-                                                              cov[:CPU_P_REG], rs["slot"][:, 0], PIXEL_ERR_VAR)
+        reg_merge[idx, c] = 0
+        if h["R"]:   # staticCheckMergability of the candidates over the frames the history holds (64: the restatement keeps no store; a longer
+            # track comes out "unjudged" -- the GPU's running verdict judges it)
+            reg_merge[idx, c] = oracle.register_mergability_cam(Kc, np.stack(h["R"]), np.stack(h["t"]), np.stack(h["xy"]), tl[c], map_pts[idx],
+                                                                cov[idx], rs["slot"][:, 0], SIG)
 
     def decide_all():
         # currentMapPointsRegister's decisions over the cameras' columns (org_register_decide: static points, then dynamic ones), then
         # refineMapPoint of the points that gained a feature -- on the calling thread, behind the cameras' searches
         s2m_all = np.ascontiguousarray(np.stack(s2m)).astype(np.int32)
         pf_all = np.ascontiguousarray(reg_pf)
-        _, reg = oracle.register_decide_static_c(reg_slot, reg_flags, reg_merge, map_flags[:CPU_P_REG], pf_all, s2m_all, kinds=3)
+        _, reg = oracle.register_decide_static_c(reg_slot, reg_flags, reg_merge, map_flags, pf_all, s2m_all, kinds=3)
         if reg.any() and hist[0]["R"]:
             for c in range(N_CAMS):
                 s2m[c][:] = s2m_all[c]
-            sel = np.zeros(len(map_pts), dtype=np.uint8)
-            sel[:CPU_P_REG] = reg
-            pf_map = np.ascontiguousarray(np.stack([oracle.point_features(st[c], s2m[c], len(sc.points)) for c in range(N_CAMS)], 1))
+            pf_map = np.ascontiguousarray(np.stack([oracle.point_features(st[c], s2m[c], nMapAll) for c in range(N_CAMS)], 1))
             oracle.refine_map_points([Kc] * N_CAMS, [iK] * N_CAMS, np.stack([np.stack(h["R"]) for h in hist]), np.stack([np.stack(h["t"]) for h in hist]),
-                                     np.stack([np.stack(h["xy"]) for h in hist]), np.stack(tl), pf_map, map_pts, map_cov.reshape(-1, 9), PIXEL_ERR_VAR,
-                                     select=sel)
+                                     np.stack([np.stack(h["xy"]) for h in hist]), np.stack(tl), pf_map, map_pts, map_cov.reshape(-1, 9), SIG,
+                                     select=np.ascontiguousarray(reg, dtype=np.uint8))
 
     # genNewMapPoints' NCC stage, every 4th frame like the GPU loop: getNCCBlocks of a camera's candidate features (with its thread),
     # getEpiNccMat of the consecutive camera pairs behind the cameras (the C restatements; the match / reconstruct tail and the
@@ -345,8 +358,10 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
     def run_cams(cams, f, frame_no):
         for c in cams:
             cam_step(c, f, frame_no)
-            if with_register:
-                reg_step(c)
+
+    def run_reg(cams):
+        for c in cams:
+            reg_step(c)
 
     def run_ncc(what, items, f):
         for q in items:
@@ -368,7 +383,9 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
     while True:
         f = order[(n + 1) % len(order)]
         in_threads(run_cams, range(N_CAMS), f, n + 1)
-        if with_register:
+        if with_register:   # (behind ALL cameras' hand-backs: the list of current points needs every camera's features)
+            list_current()
+            in_threads(run_reg, range(N_CAMS))
             decide_all()
         pose_update_all(n + 1)
         if with_ncc and (n + 1) % 4 == 0:
@@ -389,7 +406,7 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
                 oracle.update_new_poses_points([Kc] * N_CAMS, [iK] * N_CAMS, np.stack([np.stack(h["R"]) for h in hist]),
                                                np.stack([np.stack(h["t"]) for h in hist]), np.stack([np.stack(h["xy"]) for h in hist]),
                                                np.stack(tl), np.stack(is_static), pf_all, map_pts.copy(), map_cov.copy(), map_flags,
-                                               PIXEL_ERR_VAR)
+                                               SIG)
             oracle.ba_robust(ic["Ks"], ic["Rs0"], ic["ts0"], ic["pts0"], iptr, icam, ixy, 0, ic["n_static"], 6.0, 3, 40)
         n += 1
         if time.perf_counter() - t_start > budget_s or n >= 200:
@@ -470,6 +487,9 @@ def main():
                     "mergability walk's exact window; the whole-track verdict behind it is the running one (--hist-store)")
     ap.add_argument("--hist-store", type=int, default=4096, help="frames of pixels + poses kept behind the walks (what a dropped mergability "
                     "cache entry is rebuilt from)")
+    ap.add_argument("--pixel-err-reading", choices=["variance", "std"], default=os.environ.get("BENCH_PIXEL_ERR_READING", "variance"),
+                    help="Const::PIXEL_ERR_VAR = 10 handed to the covariance helpers as a variance (sqrt(10) px: the default, the reference's own "
+                         "SL_Define.h:16) or as a standard deviation (10 px: rounds 1-4)")
     ap.add_argument("--active-search", type=int, default=0, help="diagnostic: 1 = also run the search half of activeMapPointsRegister (rounds 2-4)")
     ap.add_argument("--merge-every", type=int, default=50, help="bMerge frames: every n-th frame the static points' walks may unify two points "
                     "(the reference: 50, CoSLAMThread.cpp:117-118); 0: never (diagnostic)")
@@ -555,7 +575,7 @@ def main():
                      key_every=max(ke, 1), ba_lag=args.ba_lag, p_reg=P_REG, klt_cams_per_launch=max(args.klt_cams_per_launch, 0),
                      prefetch=os.environ.get("BENCH_PREFETCH", "1") != "0", with_pose_update=not args.no_pose_update,
                      with_classify=not args.no_classify, with_register=not args.no_register, with_mergability=not args.no_mergability,
-                     with_ncc=not args.no_ncc, with_decide=not args.no_decide, merge_every=args.merge_every, hist=args.hist, hist_store=args.hist_store, with_active_search=bool(args.active_search), with_joint=args.only_solve != "intercam", with_intercam=args.only_solve != "joint",
+                     with_ncc=not args.no_ncc, with_decide=not args.no_decide, merge_every=args.merge_every, hist=args.hist, hist_store=args.hist_store, with_active_search=bool(args.active_search), pixel_err_reading=args.pixel_err_reading, with_joint=args.only_solve != "intercam", with_intercam=args.only_solve != "joint",
                      native_comm=bool(args.native_comm), klt_cus=args.klt_cus, pose_cus=args.pose_cus,
                      klt_after_intracam=bool(args.klt_after_intracam),
                      klt_fused=os.environ.get("BENCH_FORCE_DEVICE") is None or world == 1)   # (ranks sharing ONE GPU: test hook)
@@ -979,8 +999,8 @@ def main():
         cores = os.cpu_count() or 1
         nt = min(cores, N_CAMS)
         joint = build_joint_problem(sc)
-        v1, n1, dt1 = cpu_baseline(sc, frames, joint, ic, 1, 12.0, not args.no_register, True, not args.no_ncc)
-        vN, nN, dtN = cpu_baseline(sc, frames, joint, ic, nt, 12.0, not args.no_register, True, not args.no_ncc) if nt > 1 else (v1, n1, dt1)
+        v1, n1, dt1 = cpu_baseline(sc, frames, joint, ic, 1, 12.0, not args.no_register, True, not args.no_ncc, args.pixel_err_reading)
+        vN, nN, dtN = cpu_baseline(sc, frames, joint, ic, nt, 12.0, not args.no_register, True, not args.no_ncc, args.pixel_err_reading) if nt > 1 else (v1, n1, dt1)
         cpu = {"value": vN, "unit": "frames/s", "cores": nt, "kind": "port",
                "sample": f"{nN} frames of the same 8-camera workload on {nt} threads (cameras in parallel) in {dtN:.1f} s; "
                          f"{n1} frames on 1 thread in {dt1:.1f} s (oracle/: C restatement, gcc -O2); host has {cores} cores.  Legs: KLT, "
@@ -1004,7 +1024,8 @@ def main():
                 wl = os.path.join(td, "workload.bin")
                 export_workload(wl, sc, frames, build_joint_problem(sc), ic, args.klt_cams_per_launch)
                 pr = subprocess.run([exe, wl, str(args.steps), str(args.warmup), str(args.klt_cams_per_launch), str(loop.lag)],
-                                    capture_output=True, text=True, timeout=600)
+                                    capture_output=True, text=True, timeout=600,
+                                    env=dict(os.environ, COSLAM_PIXEL_ERR_STD="1" if args.pixel_err_reading == "std" else "0"))
             if pr.returncode == 0 and pr.stdout.strip().startswith("{"):
                 cxx = json.loads(pr.stdout.strip().splitlines()[-1])
                 cxx["what"] = ("tools/cxx/frame_loop.cpp: the headline loop from C++ through include/coslam_hip.h only (no Python, no "

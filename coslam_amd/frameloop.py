@@ -43,6 +43,11 @@ class LoopConfig:
         self.hist_store = 4096     # frames of pixels + poses KEPT behind them (1 GB for 8 x 2000 slots): what the running whole-track
                                    # mergability verdict rebuilds a cached tail from (cs_register_mergability_running_dev)
         self.merge_tol_pix = 0.5   # a point that moved further than this in a camera's image has its cached tail judged again
+        self.pixel_err_reading = "variance"   # Const::PIXEL_ERR_VAR = 10 (src/app/SL_GlobParam.cpp:37) reaches getProjectionCovMat / seqTriangulate /
+        # getTriangulateCovMat (un-vendored LibVisualSLAM) as their last argument.  This library's definitions of them take a STANDARD
+        # DEVIATION (J cov J^T + s^2 I).  "variance": the constant is what its name says -- the reference's own retired define reads
+        # `SLAM_PIXEL_ERR_VAR 4 //2 pixels error` (src/slam/SL_Define.h:16) -- so the loop hands the helpers sqrt(10) = 3.16 px;
+        # "std": the constant handed over as it is (a 10 px gate: what rounds 1-4 ran).  DESIGN.md 5.1.
         self.with_active_search = False   # the search half of activeMapPointsRegister: OFF -- the reference's own attach loop cannot be
         # reached (every point of actMapPts has numVisCam == 0, src/app/SL_CoSLAM.cpp:1114 asks for > 0: tests/cxx/ref_active_test.cpp runs
         # the reference's code to say so), so the tables this pass used to fill fed nothing
@@ -93,6 +98,10 @@ class FrameLoop:
 
         self.torch = torch
         self.cfg, self.sc, self.ic = cfg, scene, ic
+        if cfg.pixel_err_reading not in ("variance", "std"):
+            raise ValueError("LoopConfig.pixel_err_reading: 'variance' or 'std'")
+        self.sig = (lambda v: float(np.sqrt(v))) if cfg.pixel_err_reading == "variance" else (lambda v: float(v))
+        self.sig_pix = self.sig(PIXEL_ERR_VAR)   # what the helpers get where the reference passes Const::PIXEL_ERR_VAR
         self.rank, self.world, self.device = rank, world, device
         NA, N = cfg.n_cams, cfg.n_feat
         if NA % world:
@@ -244,7 +253,8 @@ class FrameLoop:
         # in the map -- the points genNewMapPoints appended this frame included; it serves the static AND the dynamic registration (the
         # certainly dynamic points are searched with their own scale, SL_CoSLAM.cpp:973)
         o_ = self.reg_out
-        cur_pass = dict(P=cfg.p_reg, sigmaSearch=PIXEL_ERR_VAR, maxDist=3 * PIXEL_ERR_VAR, sigmaMerge=PIXEL_ERR_VAR, M=self.d_map.data_ptr(),
+        # (maxDist only scales every distance of a search alike -- searchMahaNearestFeatPt compares them with nothing: the reference's literal)
+        cur_pass = dict(P=cfg.p_reg, sigmaSearch=self.sig_pix, maxDist=3 * PIXEL_ERR_VAR, sigmaMerge=self.sig_pix, M=self.d_map.data_ptr(),
                         cov=self.d_cov.data_ptr(), pointFeat=self.d_pf.data_ptr(), slot=o_["slot"].data_ptr(), m=o_["m"].data_ptr(),
                         var=o_["var"].data_ptr(), dist=o_["dist"].data_ptr(), flags=o_["flags"].data_ptr(), mapFlags=self.d_mapflags.data_ptr(),
                         maxDistDynamic=4 * PIXEL_ERR_VAR, list=self.d_curlist.data_ptr())
@@ -255,7 +265,7 @@ class FrameLoop:
             self.act_out = dict(slot=z((1536, NA), i32), m=z((1536, NA, 2), f64), var=z((1536, NA, 4), f64), dist=z((1536, NA), f64),
                                 flags=z((1536, NA), i32), pf=torch.full((1536, NA), -1, dtype=i32, device=dev))
             a_ = self.act_out
-            passes.append(dict(P=1536, sigmaSearch=2.5 * PIXEL_ERR_VAR, maxDist=3 * PIXEL_ERR_VAR, sigmaMerge=PIXEL_ERR_VAR,
+            passes.append(dict(P=1536, sigmaSearch=self.sig(2.5 * PIXEL_ERR_VAR), maxDist=3 * PIXEL_ERR_VAR, sigmaMerge=self.sig_pix,
                                M=self.d_map.data_ptr() + 24 * 1536, cov=self.d_cov.data_ptr() + 72 * 1536, pointFeat=a_["pf"].data_ptr(),
                                slot=a_["slot"].data_ptr(), m=a_["m"].data_ptr(), var=a_["var"].data_ptr(), dist=a_["dist"].data_ptr(),
                                flags=a_["flags"].data_ptr()))
@@ -398,7 +408,7 @@ class FrameLoop:
         newpts_from_pairs_dev(s_, ncc["job"], N, cfg.ncc_pair_cap, self.d_R[dst].data_ptr(), self.d_t[dst].data_ptr(), self.d_map.data_ptr(),
                               self.d_cov.data_ptr(), self.d_mapflags.data_ptr(), self.d_newpt.data_ptr(), self.d_firstfrm.data_ptr(),
                               self.d_pf.data_ptr(), self.n_map, self.d_mapcount.data_ptr(), i, ncc["np_scr"].data_ptr(), ncc["np_cnt"].data_ptr(),
-                              maxDisp=80.0, maxRpErr=3.0, pixelErrVar=PIXEL_ERR_VAR, minLen=2, device=self.device, W=cfg.W, H=cfg.H)
+                              maxDisp=80.0, maxRpErr=3.0, pixelErrVar=self.sig_pix, minLen=2, device=self.device, W=cfg.W, H=cfg.H)
         ncc["runs"] += 1
 
     def _gather_ncc_records(self):
@@ -486,7 +496,7 @@ class FrameLoop:
         if self.world > 1:
             self.xchg.broadcast(rec, self.out.record_bytes, owner, self.device, self.pose_s)
         self.out.apply_dev(rec, self.pose_s.cuda_stream, self.pose_upd, self.win, self.pu_args, self.d_pf.data_ptr(), self.n_map,
-                           self.d_map.data_ptr(), self.d_cov.data_ptr(), self.d_mapflags.data_ptr(), PIXEL_ERR_VAR, first_key,
+                           self.d_map.data_ptr(), self.d_cov.data_ptr(), self.d_mapflags.data_ptr(), self.sig_pix, first_key,
                            self.cfg.key_every, self.d_R[src].data_ptr(), self.d_t[src].data_ptr(), self.d_apply_counts.data_ptr(), seq=seq)
         self.applied += 1
         self.last_apply = dict(window=k, solved_by_rank=owner, first_key_frame=first_key, applied_at_frame=i)
@@ -548,11 +558,11 @@ class FrameLoop:
             # parallelPoseUpdate(false): gate 2.0, sigma = PIXEL_ERR_VAR; detectDynamicFeaturePoints(20, 5, 3, MAX_EPI_ERR)
             self.pose_upd.pose_update_frame_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_R[dst].data_ptr(),
                                                 self.d_t[dst].data_ptr(), self.d_map.data_ptr(), self.d_cov.data_ptr(),
-                                                self.d_mapflags.data_ptr(), 0, PIXEL_ERR_VAR, i, 20, 5, 3, MAX_EPI_ERR)
+                                                self.d_mapflags.data_ptr(), 0, self.sig_pix, i, 20, 5, 3, MAX_EPI_ERR)
             if cfg.with_classify:
                 self.pose_upd.map_points_classify_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, i, self.d_map.data_ptr(),
                                                       self.d_cov.data_ptr(), self.d_mapflags.data_ptr(), self.d_newpt.data_ptr(),
-                                                      self.d_sfn.data_ptr(), self.d_firstfrm.data_ptr(), 12.0,
+                                                      self.d_sfn.data_ptr(), self.d_firstfrm.data_ptr(), self.sig(12.0),
                                                       d_counts=self.d_cls_counts.data_ptr())
         # the reference's order of a frame (src/gui/CoSLAMThread.cpp:104-118): poseUpdate (with mapPointsClassify) -> activeMapPointsRegister ->
         # genNewMapPoints -> currentMapPointsRegister: the new map points take their features BEFORE the current points' registration
@@ -593,7 +603,7 @@ class FrameLoop:
         by one term per frame (cs_register_mergability_running_dev) -- own cameras' columns"""
         cfg = self.cfg
         self.pose_upd.register_mergability_running_dev(ps, self.pu_args, self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
-                                                       self.reg_out["slot"].data_ptr(), PIXEL_ERR_VAR, self.d_merge_cache.data_ptr(),
+                                                       self.reg_out["slot"].data_ptr(), self.sig_pix, self.d_merge_cache.data_ptr(),
                                                        self.d_mergeable.data_ptr(), tolPix=cfg.merge_tol_pix, d_counts=self.d_merge_counts.data_ptr(),
                                                        cam0=self.c0, nCamsRun=self.nc, d_list=self.d_curlist.data_ptr(), nList=cfg.p_reg,
                                                        d_flags=self.reg_out["flags"].data_ptr())
@@ -630,7 +640,7 @@ class FrameLoop:
                                                           self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(),
                                                           D["s2m"] if D["s2m"] is not None else [self.d_slot2map[g].data_ptr() for g in range(NA)],
                                                           D["att"].data_ptr(), D["reg"].data_ptr(), D["scr"].data_ptr(), self.d_map.data_ptr(),
-                                                          self.d_cov.data_ptr(), PIXEL_ERR_VAR, d_counts=D["cnt"].data_ptr(), device=self.device,
+                                                          self.d_cov.data_ptr(), self.sig_pix, d_counts=D["cnt"].data_ptr(), device=self.device,
                                                           with_dynamic=True, merge=(cfg.merge_every > 0 and self._frame_now % cfg.merge_every == 0),   # CoSLAMThread.cpp:117-118
                                                           d_merge_scratch=D["mscr"].data_ptr(), mergability=self._mergability, n_sweeps=0)
             return
@@ -642,11 +652,11 @@ class FrameLoop:
             o = self.reg_out
             self.pose_upd.register_decide_merge_dev(ps, self.pu_args, self.n_map, 0, o["slot"].data_ptr(), o["flags"].data_ptr(),
                                                     self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(),
-                                                    self.d_map.data_ptr(), self.d_cov.data_ptr(), PIXEL_ERR_VAR, D["att"].data_ptr(),
+                                                    self.d_map.data_ptr(), self.d_cov.data_ptr(), self.sig_pix, D["att"].data_ptr(),
                                                     D["reg"].data_ptr(), D["mscr"].data_ptr(), D["mcnt"].data_ptr(),
                                                     d_list=self.d_curlist.data_ptr(), nList=cfg.p_reg)
             self.pose_upd.refine_map_points_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
-                                                PIXEL_ERR_VAR, d_select=D["reg"].data_ptr())   # (no count asked for: that would be one more launch, and it is counts[1])
+                                                self.sig_pix, d_select=D["reg"].data_ptr())   # (no count asked for: that would be one more launch, and it is counts[1])
             self.n_merge_frames += 1
             kinds = 2
         D["s2m"] = register_decide_static_dev(ps, NA, cfg.n_feat, self.n_map, 0, self.reg_out["slot"].data_ptr(), self.reg_out["flags"].data_ptr(),
@@ -655,7 +665,7 @@ class FrameLoop:
                                               D["att"].data_ptr(), D["reg"].data_ptr(), D["scr"].data_ptr(), D["cnt"].data_ptr(), device=self.device,
                                               kinds=kinds, n_sweeps=0)   # (0: ONE launch that sweeps until the owners have settled)   # curStaticPointsRegInGroup and curDynamicPointsRegInGroup (currentMapPointsRegister, :834-853)
         self.pose_upd.refine_map_points_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
-                                            PIXEL_ERR_VAR, d_select=D["reg"].data_ptr())   # (no count asked for: that would be one more launch, and it is counts[1])
+                                            self.sig_pix, d_select=D["reg"].data_ptr())   # (no count asked for: that would be one more launch, and it is counts[1])
 
     def _gather_candidates(self):
         """the own cameras' columns of the current-static pass's candidate tables to every rank (18 KB per camera: latency-bound, ONE

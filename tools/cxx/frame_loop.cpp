@@ -363,7 +363,12 @@ int main(int argc, char** argv) {
     int* dDecCnt = dev_zeros<int>(4);
     int* dMergeCnt = dev_zeros<int>(4);
     int nMergeFrames = 0;
-    const double PIX = 10.0;  // Const::PIXEL_ERR_VAR, reference src/app/SL_GlobParam.cpp:37
+    // Const::PIXEL_ERR_VAR = 10 (reference src/app/SL_GlobParam.cpp:37) is a VARIANCE (the retired define beside it: `SLAM_PIXEL_ERR_VAR 4
+    // //2 pixels error`, src/slam/SL_Define.h:16); this library's getProjectionCovMat / seqTriangulate / getTriangulateCovMat take a standard
+    // deviation: sqrt(10) px.  COSLAM_PIXEL_ERR_STD=1: the constant handed over as it is (a 10 px gate: rounds 1-4).  DESIGN.md 5.1
+    const double PIXVAR = 10.0;
+    const bool pixIsStd = getenv("COSLAM_PIXEL_ERR_STD") && getenv("COSLAM_PIXEL_ERR_STD")[0] == '1';
+    const double PIX = pixIsStd ? PIXVAR : sqrt(PIXVAR), PIX_CLASSIFY = pixIsStd ? 12.0 : sqrt(12.0);
     auto step = [&](int i, bool key) {
         const int f = order[i % orderLen], fn = order[(i + 1) % orderLen], b = i & 1;
         const void *cur[16], *nxt[16];
@@ -396,7 +401,7 @@ int main(int argc, char** argv) {
                                        3, 6.0, nullptr, nullptr, nullptr));
         // mapPointsClassify(12.0) (SL_CoSLAM.cpp:385): the uncertain / dynamic points of this frame decided again
         CSCHK(cs_map_points_classify_dev(hist, (void*)poseS, pu.data(), dPf, nMap, nullptr, nullptr, i, dMap, dCov, dMapFlags, dNewPt, dSfn,
-                                         dFirstFrm, 12.0, nullptr));
+                                         dFirstFrm, PIX_CLASSIFY, nullptr));
         // genNewMapPoints every 4th frame -- BEFORE currentMapPointsRegister, as in the reference's frame (src/gui/CoSLAMThread.cpp:104-118):
         // the new map points take their features before the current points' registration looks at them
         if (nCams >= 2 && i % NCC_EVERY == 0) {
@@ -432,9 +437,9 @@ int main(int argc, char** argv) {
         {
             cs_register_pass ps[1];
             memset(ps, 0, sizeof(ps));
-            ps[0].P = P_REG, ps[0].sigmaSearch = PIX, ps[0].maxDist = 3 * PIX, ps[0].sigmaMerge = PIX;
+            ps[0].P = P_REG, ps[0].sigmaSearch = PIX, ps[0].maxDist = 3 * PIXVAR, ps[0].sigmaMerge = PIX;   // (maxDist: a common scale of a search's distances)
             ps[0].M = dMap, ps[0].cov = dCov, ps[0].pointFeat = dPf, ps[0].list = dCurList;
-            ps[0].mapFlags = dMapFlags, ps[0].maxDistDynamic = 4 * PIX;   // (the certainly dynamic points' scale: SL_CoSLAM.cpp:973)
+            ps[0].mapFlags = dMapFlags, ps[0].maxDistDynamic = 4 * PIXVAR;   // (the certainly dynamic points' scale: SL_CoSLAM.cpp:973)
             ps[0].slot = reg[0].slot, ps[0].m = reg[0].m, ps[0].var = reg[0].var, ps[0].dist = reg[0].dist, ps[0].flags = reg[0].flags;
             CSCHK(cs_register_search_passes_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, 1, ps));
         }

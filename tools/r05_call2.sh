@@ -3,7 +3,7 @@
 # the registration now attaching, the headline loop (Python + C++) and its kernel trace.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r05d
+O=$R/gpurun_out/r05e
 mkdir -p $O/drift $O/ab $O/trace
 cd $R
 ( time python -m pytest tests -m gpu -q ) > $O/pytest_gpu.log 2>&1

@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--hist", type=int, default=64)
     ap.add_argument("--min-distance", type=int, default=-1, help="KLT minDistance (-1: bench.py's)")
     ap.add_argument("--out", default="")
+    ap.add_argument("--pixel-err-reading", choices=["variance", "std"], default="variance")
     ap.add_argument("--time-intracam", action="store_true", help="at the end: k_intracam alone on the loop's last inputs (HIP events)")
     ap.add_argument("--count-attach", action="store_true", help="sum the registration's attachments over the run (a device read-back per frame)")
     args = ap.parse_args()
@@ -98,7 +99,8 @@ def main():
     video = {c: torch.from_numpy(frames[c]).to(dev) for c in range(NA)}
     over, mask = VARIANTS[args.variant]
     kw = dict(n_cams=NA, W=bench.W, H=bench.H, levels=bench.LEVELS, fw=bench.FW, fh=bench.FH, pts_stride=bench.PTS_STRIDE,
-              n_col_blk=bench.N_COL_BLK, n_row_blk=bench.N_ROW_BLK, key_every=bench.KEY_EVERY, p_reg=bench.P_REG, hist=args.hist)
+              n_col_blk=bench.N_COL_BLK, n_row_blk=bench.N_ROW_BLK, key_every=bench.KEY_EVERY, p_reg=bench.P_REG, hist=args.hist,
+              pixel_err_reading=args.pixel_err_reading)
     kw.update(over)
     cfg = LoopConfig(**kw)
     kc = bench.klt_config()
