@@ -985,6 +985,7 @@ struct DmArgs {
     // by list only: checkUnify of every (listed point, camera) whose candidate carries ANOTHER static point, evaluated side by side BEFORE the
     // walk (k_merge_precheck) on the state the walk starts from; the walk takes a verdict from here as long as neither point has been
     // touched by an earlier step (inVec[point] != 0: it gained a feature, moved, or was unified away) and evaluates it itself otherwise
+    int debug;                       // COSLAM_MERGE_DEBUG=1: the walk prints where its time went (diagnostic)
     unsigned char* preOk;            // [nList][nCams]: 0 not evaluated, 1 checkUnify said no, 2 yes
     double* preM;                    // [nList][nCams][12]: the unified position and covariance of a yes
 };
@@ -1024,6 +1025,8 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
     __shared__ double sR[64 * 9 + 16];
     const int lane = threadIdx.x, C = A.cu.nCams, N = A.cu.N, P = A.P;
     int nAtt = 0, nReg = 0, nMerged = 0, nAsked = 0;
+    long long tPre = 0, tInline = 0, tUnify = 0, tAll = wall_clock64();
+    int nBatch = 0, nVisit = 0, nAct = 0, nInline = 0, nPreUsed = 0;
     const bool byList = A.list != nullptr;
     if (!byList) {
         for (int k = lane; k < P * C; k += 64) A.attached[k] = 0;
@@ -1060,10 +1063,17 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
           int bSlot[DM_MAX_CAMS], bOwner[DM_MAX_CAMS];
           unsigned bHas = 0, bDyn = 0, bMerge = 0;
           bool batchClean = byList;
+          const long long tb0 = wall_clock64();
+          ++nBatch;
           if (byList) {
+              // ONE acquire at agent scope (the wave's own earlier stores went out behind a release fence: the L1 is dropped, what follows
+              // comes from L2), then plain loads -- 5 x nCams of them in flight per lane.  (Read one by one as agent-scope atomic loads, each
+              // waited for, the batch's rows cost ~40 us: 112 batches of them were most of the kernel's 8 ms.)
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+              int hasV[DM_MAX_CAMS];
 #pragma unroll
               for (int i = 0; i < DM_MAX_CAMS; ++i) {
-                  bSlot[i] = -1, bOwner[i] = -1;
+                  bSlot[i] = -1, bOwner[i] = -1, hasV[i] = -1;
                   if (in && i < C) {
                       int sl = A.slot[(size_t)myP * C + i];
                       const int fl = A.flags[(size_t)myP * C + i];
@@ -1071,13 +1081,19 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
                       bSlot[i] = sl;
                       if (fl & 2) bDyn |= 1u << i;
                       if (A.mergeable[(size_t)myP * C + i] == 1) bMerge |= 1u << i;
-                      if (mg_ld(A.pointFeat + (size_t)myP * C + i) >= 0) bHas |= 1u << i;
-                      if (sl >= 0) bOwner[i] = mg_ld(A.cu.cam[i].slot2map + sl);
+                      hasV[i] = A.pointFeat[(size_t)myP * C + i];
                   }
               }
+#pragma unroll
+              for (int i = 0; i < DM_MAX_CAMS; ++i) {
+                  if (hasV[i] >= 0) bHas |= 1u << i;
+                  if (bSlot[i] >= 0) bOwner[i] = A.cu.cam[i].slot2map[bSlot[i]];
+              }
           }
+          tPre += wall_clock64() - tb0;
           unsigned long long todo = __builtin_amdgcn_ballot_w64(in);
           while (todo) {
+            ++nVisit;
             const int src = __builtin_ctzll(todo);
             const int jP = p0 + src;   // (by list: the point's place on the list)
             const int p = __shfl(myP, src, 64);
@@ -1105,6 +1121,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
             // cameras with something to do: no feature of the point, a non-dynamic candidate that is unmapped-and-mergeable or carries a point
             const unsigned long long act = __builtin_amdgcn_ballot_w64(lane < C && !myHas && mySlot >= 0 && !(myFlags & 2) && (myOwner >= 0 || myMerge == 1));
             if (!act) continue;
+            ++nAct;
             bool reg = false;
             for (int i = 0; i < C; ++i) {
                 if (!((act >> i) & 1)) continue;                                            // :736-737, :757: has a feature / nothing found / DYNAMIC
@@ -1133,6 +1150,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
                 bool ok;
                 const int pre = byList && A.preOk ? A.preOk[(size_t)jP * C + i] : 0;
                 if (pre != 0 && mg_ldb(A.inVec + p) == 0 && mg_ldb(A.inVec + q) == 0) {
+                    ++nPreUsed;
                     ok = pre == 2;   // judged before the walk on the very state it is asked about now
                     const double* o = A.preM + 12 * ((size_t)jP * C + i);
 #pragma unroll
@@ -1140,10 +1158,13 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
 #pragma unroll
                     for (int k = 0; k < 9; ++k) cov[k] = o[3 + k];
                 } else {
+                    const long long ti = wall_clock64();
                     ok = check_unify_wave(A.cu, A.pointFeat + (size_t)p * C, A.pointFeat + (size_t)q * C, A.mapPts + 3 * (size_t)p,
                                           A.mapPts + 3 * (size_t)q, sR, M, cov);
+                    tInline += wall_clock64() - ti, ++nInline;
                 }
                 if (!ok) continue;
+                const long long tu = wall_clock64();
                 if (lane == 0) {                                                            // :797-826
                     for (int k = 0; k < 3; ++k) A.mapPts[3 * (size_t)p + k] = M[k];
                     for (int k = 0; k < 9; ++k) A.mapCov[9 * (size_t)p + k] = cov[k];
@@ -1160,6 +1181,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
                     }
                 }
                 __threadfence();
+                tUnify += wall_clock64() - tu;
                 batchClean = false;
                 reg = true, ++nMerged;
                 break;                                                                      // :825 return
@@ -1174,6 +1196,10 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
         __syncthreads();
     }
     if (lane == 0 && A.counts) A.counts[0] = nAtt, A.counts[1] = nReg, A.counts[2] = nMerged, A.counts[3] = nAsked;
+    if (lane == 0 && A.debug)
+        printf("k_decide_merge: %lld us; %d batches read in %lld us; %d visits, %d with work; %d conflicts asked: %d from the pre-check, %d evaluated here in "
+               "%lld us; %d unified in %lld us; %d attached\n",
+               (wall_clock64() - tAll) / 100, nBatch, tPre / 100, nVisit, nAct, nAsked, nPreUsed, nInline, tInline / 100, nMerged, tUnify / 100, nAtt);
 }
 
 // ---- CoSLAM::mapPointsClassify (src/app/SL_CoSLAM.cpp:418-520) ------------------------------------------------------------------------
@@ -2062,6 +2088,10 @@ extern "C" int cs_register_decide_merge_list_dev(const cs_track_history* h, void
     A.slot = d_slot, A.flags = d_flags, A.mergeable = d_mergeable, A.mapFlags = d_mapFlags, A.pointFeat = d_pointFeat;
     A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.attached = d_attached, A.regged = d_regged, A.inVec = (unsigned char*)d_scratch, A.counts = d_counts;
     A.list = d_list, A.nList = nList;
+    {
+        const char* dbg = getenv("COSLAM_MERGE_DEBUG");
+        A.debug = dbg && dbg[0] == '1';
+    }
     CS_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)hip_stream;
     if (P == 0) {

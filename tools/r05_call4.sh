@@ -1,0 +1,18 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r05g
+mkdir -p $O
+cd $R
+COSLAM_MERGE_DEBUG=1 timeout 300 python tools/r05_drift.py --variant full --frames 420 --every 100 --out $O/dbg.jsonl > $O/dbg.log 2>&1
+grep k_decide_merge $O/dbg.log | tail -8
+SHORT="--no-cpu-baseline --no-secondary --no-upload-leg --no-cxx-loop"
+timeout 240 python bench.py $SHORT > $O/base.json 2> $O/base.err; python - <<PY
+import json
+d = json.loads(open("$O/base.json").read().strip().splitlines()[-1]); print("base", round(d["value"], 1))
+PY
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace -d $O/trace -o t -- python $R/bench.py $SHORT > $O/base_line.json 2> $O/trace.err
+python $R/tools/rocpd_summary.py kernels $O/trace/t_results.db --last-frames 300 > $O/base_kernel_stats.md
+rm -rf $O/trace
+head -30 $O/base_kernel_stats.md
