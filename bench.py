@@ -626,6 +626,11 @@ def main():
         run(4 * max(ke, 1))
         rounds += 1
         barrier()
+    # the bMerge frames (every 50th: a few milliseconds each) fall into the timed region at their true rate whatever K is: the region
+    # starts 25 frames behind one, so K steps hold round(K / 50) of them (K = 20: none, K = 50: one, K = 300: six) -- not "one if the
+    # set-up loop's clock happened to stop there"
+    if cfg.merge_every > 0 and ke > 0:
+        run((cfg.merge_every // 2 - args.warmup - n_done) % cfg.merge_every)
     run(args.warmup)
     barrier()
     ba_ws.worker_stats(), [w.worker_stats() for w in loop.ic_wss]   # (reset: the sums below cover the timed region only)

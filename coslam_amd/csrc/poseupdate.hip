@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
     auto set_dirty = [&](int x) { dirtyBits[(x >> 5) & (DM_DIRTY_WORDS - 1)] |= 1u << (x & 31); };   // (lane 0, between two barriers)
     const int lane = threadIdx.x, C = A.cu.nCams, N = A.cu.N, P = A.P;
     int nAtt = 0, nReg = 0, nMerged = 0, nAsked = 0;
-    long long tPre = 0, tInline = 0, tUnify = 0, tAll = wall_clock64();
+    long long tPre = 0, tInline = 0, tUnify = 0, tHead = 0, tWalk = 0, tAll = wall_clock64();
     int nBatch = 0, nVisit = 0, nAct = 0, nInline = 0, nPreUsed = 0;
     const bool byList = A.list != nullptr;
     if (!byList) {
@@ -1097,14 +1097,63 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
                   if (bSlot[i] >= 0) bOwner[i] = A.cu.cam[i].slot2map[bSlot[i]];
               }
           }
+          // ... and every lane works out, for ITS point on the rows as read, whether its walk could change anything: an unmapped candidate it
+          // may attach, a conflict the pre-check answered with yes, or a pair with a touched point (whose verdict has to be formed now).
+          // A walk that only meets conflicts answered with no changes nothing -- it is counted, not walked -- for as long as the batch
+          // stands as read (the wave's first attach / unification sends the rest of the batch through the walk proper).  Of ~4500 visits
+          // a pass ~100 remain: each was ~1.5 us of dependent latencies on the one wave, 7 of the kernel's 8 ms.
+          int lnAsk = 0;
+          bool lnVisit = false;
+          if (byList && in && A.preOk) {
+              const bool pDirty = is_dirty(myP);
+#pragma unroll
+              for (int i = 0; i < DM_MAX_CAMS; ++i) {
+                  if (i < C && !((bHas >> i) & 1u) && bSlot[i] >= 0 && !((bDyn >> i) & 1u)) {
+                      const int own = bOwner[i];
+                      if (own < 0) {
+                          lnVisit |= ((bMerge >> i) & 1u) != 0;
+                      } else {
+                          const int q = own - A.mapBase;
+                          if (q >= 0 && q < P && q != myP) {
+                              const unsigned pre = (bPre >> (2 * i)) & 3u;
+                              if (pDirty || is_dirty(q)) lnVisit = true;
+                              else if (pre == 2u) lnVisit = true;
+                              else if (pre == 1u) ++lnAsk;
+                          }
+                      }
+                  }
+              }
+          } else {
+              lnVisit = true;
+          }
+          const unsigned long long needMask = __builtin_amdgcn_ballot_w64(lnVisit);
           tPre += wall_clock64() - tb0;
           unsigned long long todo = __builtin_amdgcn_ballot_w64(in);
           while (todo) {
+            if (batchClean) {
+                // the walks in front of the next one that may change something: counted in one go
+                const unsigned long long need = todo & needMask;
+                const unsigned long long skip = need ? (todo & ~needMask & ((need & (~need + 1ull)) - 1ull)) : (todo & ~needMask);
+                if (skip) {
+                    int a = ((skip >> lane) & 1ull) ? lnAsk : 0;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+                    nAsked += a, nPreUsed += a, nVisit += __popcll(skip);
+                    todo &= ~skip;
+                    if (!todo) break;
+                }
+            }
             ++nVisit;
+            const long long tv0 = wall_clock64();
             const int src = __builtin_ctzll(todo);
             const int jP = p0 + src;   // (by list: the point's place on the list)
-            const int p = __shfl(myP, src, 64);
             todo &= todo - 1;
+            if (batchClean && !((needMask >> src) & 1ull)) {   // nothing this walk meets can change anything: its conflicts, all answered no, counted
+                const int a = __shfl(lnAsk, src, 64);
+                nAsked += a, nPreUsed += a;
+                continue;
+            }
+            const int p = __shfl(myP, src, 64);
             // :734 isLocalStatic(): unified away meanwhile?  (only the wave's own steps unify: an untouched batch stands as it was read)
             if (!batchClean && (*(volatile unsigned char*)(A.mapFlags + p) & (CS_MAP_DYNAMIC | CS_MAP_FALSE))) continue;
             // lane c: camera c's entry of the point -- the candidate, and what it would meet there as things stand (the state changes only
@@ -1128,8 +1177,10 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
             }
             // cameras with something to do: no feature of the point, a non-dynamic candidate that is unmapped-and-mergeable or carries a point
             const unsigned long long act = __builtin_amdgcn_ballot_w64(lane < C && !myHas && mySlot >= 0 && !(myFlags & 2) && (myOwner >= 0 || myMerge == 1));
+            tHead += wall_clock64() - tv0;
             if (!act) continue;
             ++nAct;
+            const long long tw0 = wall_clock64();
             bool reg = false;
             for (int i = 0; i < C; ++i) {
                 if (!((act >> i) & 1)) continue;                                            // :736-737, :757: has a feature / nothing found / DYNAMIC
@@ -1208,6 +1259,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
                 if (lane == 0) A.regged[p] = 1;
                 ++nReg;
             }
+            tWalk += wall_clock64() - tw0;
           }
         }
         __threadfence();
@@ -1216,8 +1268,9 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
     if (lane == 0 && A.counts) A.counts[0] = nAtt, A.counts[1] = nReg, A.counts[2] = nMerged, A.counts[3] = nAsked;
     if (lane == 0 && A.debug)
         printf("k_decide_merge: %lld us; %d batches read in %lld us; %d visits, %d with work; %d conflicts asked: %d from the pre-check, %d evaluated here in "
-               "%lld us; %d unified in %lld us; %d attached\n",
-               (wall_clock64() - tAll) / 100, nBatch, tPre / 100, nVisit, nAct, nAsked, nPreUsed, nInline, tInline / 100, nMerged, tUnify / 100, nAtt);
+               "%lld us; %d unified in %lld us; %d attached; visit heads %lld us, walks %lld us\n",
+               (wall_clock64() - tAll) / 100, nBatch, tPre / 100, nVisit, nAct, nAsked, nPreUsed, nInline, tInline / 100, nMerged, tUnify / 100, nAtt,
+               tHead / 100, tWalk / 100);
 }
 
 // ---- CoSLAM::mapPointsClassify (src/app/SL_CoSLAM.cpp:418-520) ------------------------------------------------------------------------

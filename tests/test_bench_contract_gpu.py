@@ -51,7 +51,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys(hip):
     assert cx["joint_lm_steps"] > 0 and cx["intercam_lm_steps"] > 0 and 0.5 < cx["frames_per_s"] / j["value"] < 2.0
     # ... and with every frame's images coming from pinned host memory inside the loop
     up = cfg["with_upload"]
-    assert up["frames_per_s"] > 0 and 0.5 < up["ratio_to_value"] < 1.2
+    assert up["frames_per_s"] > 0 and 0.3 < up["ratio_to_value"] < 1.3
     # secondary rows: cfg2, cfg5, and the reference-default KLT parameter set
     assert cfg["secondary_cfg2"]["camera_frames_per_s"] > 0 and cfg["secondary_cfg5_klt"]["frames_per_s"] > 0
     rd = cfg["secondary_reference_default_klt"]

@@ -1,10 +1,10 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r05h
+O=$R/gpurun_out/r05j
 mkdir -p $O
 cd $R
-python -m pytest tests/test_register_decide_gpu.py tests/test_register_gpu.py tests/test_poseupdate_gpu.py -m gpu -q -x 2>&1 | tail -4
+python -m pytest tests -m gpu -q 2>&1 | tail -6
 COSLAM_MERGE_DEBUG=1 timeout 300 python tools/r05_drift.py --variant full --frames 420 --every 100 --out $O/dbg.jsonl > $O/dbg.log 2>&1
 grep k_decide_merge $O/dbg.log | tail -4
 SHORT="--no-cpu-baseline --no-secondary --no-upload-leg"
