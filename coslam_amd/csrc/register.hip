@@ -26,7 +26,6 @@
 #include "cs_common.h"
 
 #include <cfloat>
-#include <mutex>
 
 #pragma clang fp contract(off)
 
@@ -34,15 +33,8 @@ namespace {
 
 constexpr int RG_MAX_CAMS = 16;
 
-struct RgPartial {   // what one workgroup of a split tile found in its part of the feature list
-    double d[64];
-    int i[64];
-};
 struct RgArgs {
     int nCams, N, W, H, nPass, cam0;   // cameras cam0 .. cam0 + gridDim.y - 1 of the nCams-wide tables
-    int nSplit;                        // workgroups per (tile, camera, pass): each scans 1 / nSplit of the feature list, the last to arrive merges
-    RgPartial* part;                   // [tiles x cameras run x passes][nSplit] (the device's scratch, cs_register_search_passes_range_dev)
-    int* arrive;                       // [tiles x cameras run x passes] arrival counters, zero between launches
     cs_register_pass pass[2];  // blockIdx.z: the passes of a frame share ONE launch (cs_register_search_passes_dev)
     cs_register_cam cam[RG_MAX_CAMS];
 };
@@ -110,8 +102,7 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
     CS_POSE_STREAM_PRIO();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = A.cam0 + blockIdx.y;
-    const int zPass = blockIdx.z / A.nSplit, zPart = blockIdx.z - zPass * A.nSplit;
-    const cs_register_pass& Q = A.pass[zPass];
+    const cs_register_pass& Q = A.pass[blockIdx.z];
     // Q.list: the pass's points are list[0 .. P) (map indices, < 0: no point) -- the tables stay indexed by the MAP index, so a compact
     // list of the frame's current points (cs_register_list_current_dev) costs one workgroup per 64 LISTED points and camera
     const int j = blockIdx.x * 64 + lane;
@@ -183,12 +174,9 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
         const int* __restrict__ st = C.state;
         double dMin = DBL_MAX;
         int iMin = 0x7fffffff;
-        // (a split tile: this workgroup's share of the list, a whole number of stages)
-        const int nStages = (N + CH - 1) / CH, stPer = (nStages + A.nSplit - 1) / A.nSplit;
-        const int base0 = zPart * stPer * CH, base1 = (base0 + stPer * CH) < N ? (base0 + stPer * CH) : N;
-        for (int base = base0; base < base1; base += CH) {
+        for (int base = 0; base < N; base += CH) {
             const int n = (N - base) < CH ? (N - base) : CH;
-            if (base != base0) __syncthreads();
+            if (base) __syncthreads();
             for (int i = threadIdx.x; i < n; i += 64 * RG_WAVES) {
                 const int s = st[base + i];
                 const bool in = (s == 0 || s == 1);
@@ -209,7 +197,7 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
         cd[wave * 64 + lane] = dMin;  // (every wave read its copy of sq before the staging barrier above)
         ci[wave * 64 + lane] = iMin;
         __syncthreads();
-        if (wave == 0) {
+        if (wave == 0 && search) {
 #pragma unroll 4
             for (int w = 1; w < RG_WAVES; ++w) {
                 const double d2 = cd[w * 64 + lane];
@@ -219,38 +207,6 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
                     iMin = i2;
                 }
             }
-        }
-        if (A.nSplit > 1) {
-            // this workgroup's minima into the tile's record; the LAST of the tile's workgroups to arrive merges them -- on (distance, slot)
-            // like the waves' -- and writes the tables; the others are done
-            __shared__ int amLast;
-            const size_t tile = ((size_t)zPass * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-            RgPartial* mine = A.part + tile * A.nSplit;
-            if (wave == 0) __hip_atomic_store(&mine[zPart].d[lane], dMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                           __hip_atomic_store(&mine[zPart].i[lane], iMin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence();
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const int old = atomicAdd(A.arrive + tile, 1);
-                amLast = old == A.nSplit - 1;
-                if (amLast) __hip_atomic_store(A.arrive + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (zero again for the next launch)
-            }
-            __syncthreads();
-            if (!amLast) return;
-            __threadfence();
-            if (wave == 0) {
-                for (int k = 0; k < A.nSplit; ++k) {
-                    if (k == zPart) continue;
-                    const double d2 = __hip_atomic_load(&mine[k].d[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int i2 = __hip_atomic_load(&mine[k].i[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (d2 < dMin || (d2 == dMin && i2 < iMin)) {
-                        dMin = d2;
-                        iMin = i2;
-                    }
-                }
-            }
-        }
-        if (wave == 0 && search) {
             if (iMin == 0x7fffffff) {
                 outSlot = -4;
             } else {
@@ -264,9 +220,6 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
                 if (!(maha_dist2(m0, m1, xs[iMin], ys[iMin], iv) > 1.0)) outFlags |= 4;
             }
         }
-    }
-    else if (zPart != 0) {
-        return;   // (no point of the tile searches: every part holds the same answers, part 0 writes them)
     }
     if (wave == 0 && p >= 0) {
         Q.slot[o] = outSlot;
@@ -433,39 +386,7 @@ extern "C" int cs_register_search_passes_range_dev(int device, void* hip_stream,
     CS_HIP(hipSetDevice(device));
     const int CH = N < RG_CHUNK ? N : RG_CHUNK;
     const size_t ldsBytes = (size_t)2 * CH * sizeof(double) + (size_t)RG_ROWS * 64 * sizeof(double) + (size_t)RG_WAVES * 64 * sizeof(int);
-    // A pass driven by a LIST is short (a frame's current points: a few hundred to a few thousand): its tiles alone leave most of the chip
-    // idle while each walks the whole feature list -- a latency chain of ~35 us.  Such a launch splits every tile over nSplit workgroups,
-    // each scanning 1 / nSplit of the list's stages.  The partial minima and the arrival counters live in a scratch this library keeps per
-    // device (searches of one device belong on one stream at a time).
-    const int tilesX = (maxP + 63) / 64, nStages = (N + CH - 1) / CH;
-    int nSplit = 1;
-    bool listed = true;
-    for (int k = 0; k < nPass; ++k) listed = listed && passes[k].list != nullptr;
-    if (listed && nStages > 1) nSplit = nStages < 4 ? nStages : 4;
-    A.nSplit = nSplit, A.part = nullptr, A.arrive = nullptr;
-    if (nSplit > 1) {
-        static std::mutex mu;
-        static RgPartial* sPart[64] = {nullptr};
-        static int* sArrive[64] = {nullptr};
-        static size_t sTiles[64] = {0};
-        std::lock_guard<std::mutex> lk(mu);
-        const size_t tiles = (size_t)tilesX * nCamsRun * nPass;
-        if (device < 0 || device >= 64) {
-            nSplit = A.nSplit = 1;
-        } else {
-            if (tiles > sTiles[device]) {
-                if (sPart[device]) (void)hipFree(sPart[device]), (void)hipFree(sArrive[device]);
-                sPart[device] = nullptr, sArrive[device] = nullptr, sTiles[device] = 0;
-                const size_t cap = tiles < 4096 ? 4096 : tiles;
-                CS_HIP(hipMalloc((void**)&sPart[device], sizeof(RgPartial) * cap * 4));
-                CS_HIP(hipMalloc((void**)&sArrive[device], sizeof(int) * cap));
-                CS_HIP(hipMemset(sArrive[device], 0, sizeof(int) * cap));
-                sTiles[device] = cap;
-            }
-            A.part = sPart[device], A.arrive = sArrive[device];
-        }
-    }
-    hipLaunchKernelGGL(k_register_search, dim3((unsigned)tilesX, (unsigned)nCamsRun, (unsigned)(nPass * nSplit)), dim3(64 * RG_WAVES), ldsBytes,
+    hipLaunchKernelGGL(k_register_search, dim3((unsigned)((maxP + 63) / 64), (unsigned)nCamsRun, (unsigned)nPass), dim3(64 * RG_WAVES), ldsBytes,
                        (hipStream_t)hip_stream, A);
     CS_CHECK_LAUNCH();
     return CS_OK;
