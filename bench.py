@@ -735,6 +735,13 @@ def main():
                            "16 x the launches) instead of the headline's single pass -- the parity mode; the single pass differs from it in "
                            "~2 % of a frame's attachments (DESIGN.md 8.2)"}
     gc.enable()
+    coll_us = None
+    if world > 1:
+        try:
+            loop.drain()
+            coll_us = loop.measure_collectives()
+        except Exception as ex:   # (a diagnostic: never the reason a bench line is lost)
+            coll_us = {"error": str(ex)[:300]}
     replicas = None
     if world > 1:
         # ONE map held N times: every rank hashes the state all ranks must agree on after the last frame
@@ -828,6 +835,17 @@ def main():
             grp.advanceFrame()
             n_done += 1
 
+    in_loop_us = None
+    if rank == 0 and world == 1:
+        # the same kernel INSIDE the frame loop (every stream busy): 100 more frames of the whole loop with the tracker launch bracketed
+        trks[0].set_profiling(True)
+        run(20)
+        trks[0].get_profile()
+        run(100)
+        barrier()
+        p_in = trks[0].get_profile()
+        trks[0].set_profiling(False)
+        in_loop_us = p_in["tracker_us_total"] / max(p_in["frames"], 1) / max(p_in["launches_per_frame"], 1)
     if rank == 0:
         trks[0].set_profiling(True)
         replay(100)   # (also for a short --steps run: the first frames after the switch to profiling are slower)
@@ -858,7 +876,9 @@ def main():
         roof = {"bound": "hbm", "kernel": "k_track_rows_fused" if fused_kernel else "k_track_rows_pass",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes / launches,
-                "avg_launch_us": avg_us, "launches_per_frame": launches, "frames_timed": prof["frames"],
+                "avg_launch_us": avg_us, "avg_launch_us_in_loop": in_loop_us,
+                "frac_in_loop": None if not in_loop_us else (alg_bytes / launches) / (in_loop_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "launches_per_frame": launches, "frames_timed": prof["frames"],
                 "cameras_per_launch": nc / launches, "valu": valu}
 
     # ---- secondary key: cfg2 (BASELINE.json configs[1]) = ONE camera on the GPU, KLT + hand-back + pose per frame, no
@@ -1028,7 +1048,8 @@ def main():
             with tempfile.TemporaryDirectory() as td:
                 wl = os.path.join(td, "workload.bin")
                 export_workload(wl, sc, frames, build_joint_problem(sc), ic, args.klt_cams_per_launch)
-                pr = subprocess.run([exe, wl, str(args.steps), str(args.warmup), str(args.klt_cams_per_launch), str(loop.lag)],
+                pr = subprocess.run([exe, wl, str(args.steps), str(args.warmup), str(args.klt_cams_per_launch), str(loop.lag),
+                                     str(n_timed_end - args.steps + 1)],   # (the same stretch of the sequence as the timed region above)
                                     capture_output=True, text=True, timeout=600,
                                     env=dict(os.environ, COSLAM_PIXEL_ERR_STD="1" if args.pixel_err_reading == "std" else "0"))
             if pr.returncode == 0 and pr.stdout.strip().startswith("{"):
@@ -1053,9 +1074,13 @@ def main():
                                    "gain, redetect every frame; on-device hand-back + intraCamEstimate of all 8 cameras "
                                    "every frame (fed by the tracker's output)"
                                    + ("" if loop.pose_upd is None else ", then poseUpdate3D's Mahalanobis gate + seqTriangulate refinement of the "
-                                      "map points, the dynamic-point test (64-frame history) and mapPointsClassify") + "; map-point registration "
-                                   f"search every frame (active + current static, {P_REG} points each x 8 cams x 2000 slots); every 4th frame the "
-                                   f"NCC matching of the consecutive camera pairs; every {KEY_EVERY}th frame: joint local BA C=40 (16 fixed), "
+                                      "map points, the dynamic-point test (64-frame history) and mapPointsClassify") + "; currentMapPointsRegister "
+                                   "every frame over the frame's CURRENT map points (a list built on the device: every point with a feature of this "
+                                   "frame, new ones included; search x 8 cams x 2000 slots, staticCheckMergability over WHOLE tracks as a running "
+                                   "verdict, the decision settled in one launch, refineMapPoint), every 50th frame with bMerge (checkUnify); "
+                                   "activeMapPointsRegister's search is not run (its attach loop is unreachable in the reference: "
+                                   "tests/cxx/ref_active_test.cpp); every 4th frame the NCC matching of the consecutive camera pairs (F from the "
+                                   f"poses just solved) -> new map points; every {KEY_EVERY}th frame: joint local BA C=40 (16 fixed), "
                                    "parsed on the device from the last 5 key frames' tracked features and poses"
                                    + (f" (last: {win_info['points']} pts x {win_info['measurements']} meas)" if win_info else "")
                                    + f", maxIter 2 / inner 10, its result written back into the LIVE map, pose history and window {loop.lag} "
@@ -1063,7 +1088,10 @@ def main():
                                    "frames, updateNewPosesPoints), and inter-camera solve C=8 free, built on the device from the "
                                    "frame's records (the block-voted static features' map points fixed, <= 61 dynamic points), sigma 6, 3 x 40; N>1: cameras sharded 8/N per "
                                    "GPU, one all-gather of features+pose per frame, every rank replays the other cameras' hand-back and the map "
-                                   "update (ONE map held N times, bit-identical), window k solved by rank k mod N and its packed result broadcast",
+                                   "update (ONE map held N times, bit-identical), window k solved by rank k mod N and its packed result broadcast; "
+                                   "KLT minDistance 4 (the reference's default is 8, SL_GlobParam.cpp:29: 4 keeps all 2000 slots alive on this "
+                                   "scene); Const::PIXEL_ERR_VAR = 10 handed to the covariance helpers as a " + args.pixel_err_reading +
+                                   " (DESIGN.md 5.1)",
                        "cameras": N_CAMS, "cameras_per_gpu": nc, "camera_frames_per_s": N_CAMS * args.steps / dt,
                        "video": {"frames": N_FRAMES, "what": "closed camera path (coslam_amd.synth.Scene loop_period): never reverses, never jumps",
                                  "host_render_s": t_render},
@@ -1136,9 +1164,11 @@ def main():
                            "map_points_in_use": int(loop.d_mapcount.item()), "map_points_at_start": n_pts0, "map_capacity": loop.n_map},
                        "with_upload": with_upload, "secondary_reference_ba_request_policy": ref_policy,
                        "secondary_sequential_registration": seq_reg, "cxx_frame_loop": cxx,
-                       "collectives": None if world == 1 else ("libcoslam_hip RCCL (C-ABI)" if loop.native else "torch.distributed " + dist_backend +
-                                                               (f" (FALLBACK: libcoslam_hip's communicator could not be created: {loop.native_fallback})"
-                                                                if getattr(loop, "native_fallback", None) else "")),
+                       "collectives": None if world == 1 else {
+                           "issued_by": ("libcoslam_hip RCCL (C-ABI)" if loop.native else "torch.distributed " + dist_backend +
+                                         (f" (FALLBACK: libcoslam_hip's communicator could not be created: {loop.native_fallback})"
+                                          if getattr(loop, "native_fallback", None) else "")),
+                           "us_per_call_measured_after_the_run": coll_us},
                        "streams": "tracker group | hand-back + pose + map update + registration (event-ordered behind the tracker of the same "
                                   "frame) | inter-camera solve and joint local BA each on its workspace's worker thread + stream "
                                   "(cs_ba_solve_async, like the reference's BA worker thread)"},

@@ -247,6 +247,7 @@ struct NcSide {
 };
 struct NcArgs {
     double F[9];
+    const double* dF;   // null, or the fundamental matrix in device memory (cs_ncc_fmats_dev: formed from the poses the frame has just solved)
     NcSide s1, s2;
     double epiMax, nccMin, wNone;
     double* epiMat;
@@ -325,6 +326,9 @@ __global__ __launch_bounds__(256) void k_ncc_epi_mat(NcJobs J) {
     if ((int)blockIdx.y * 64 >= M || (int)blockIdx.x * NC_CT * 64 >= N) return;   // (uniform over the workgroup)
     const int i0 = blockIdx.y * 64 + 16 * wv;  // this wave's 16 rows (features of camera 1)
     const bool rowsIn = i0 < M;                // (a wave past the last row still helps staging the columns)
+    double Fm[9];                              // the pair's fundamental matrix: by value, or from device memory (uniform loads)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Fm[k] = A.dF ? A.dF[k] : A.F[k];
     const int lr = lane & 15, lk = lane >> 4;  // MFMA operand layout: row / column lr, k-chunk lk (8 bytes)
     // the rows' side, once: the four k-chunks of the A operand, and what the epilogue needs of rows 4 lk .. 4 lk + 3
     long a[4];
@@ -379,9 +383,9 @@ __global__ __launch_bounds__(256) void k_ncc_epi_mat(NcJobs J) {
                 const int v2 = cv[jl];
                 const int s2 = (int)A2 - NC_LEN * 128;
                 // epipolarError(F, p1, p2): the line of p2
-                const double l0 = (A.F[0] * bx + A.F[1] * by) + A.F[2];
-                const double l1 = (A.F[3] * bx + A.F[4] * by) + A.F[5];
-                const double l2 = (A.F[6] * bx + A.F[7] * by) + A.F[8];
+                const double l0 = (Fm[0] * bx + Fm[1] * by) + Fm[2];
+                const double l1 = (Fm[3] * bx + Fm[4] * by) + Fm[5];
+                const double l2 = (Fm[6] * bx + Fm[7] * by) + Fm[8];
                 const double nn = sqrt(l0 * l0 + l1 * l1);
                 const double den = nn > 0 ? nn : 1.0;
                 // |l . p1| / den <= epiMax is decided without the division wherever it is not close: a numerator beyond epiMax den (1 + 1e-12)
@@ -597,6 +601,59 @@ extern "C" int cs_ncc_epi_pairs_dev(int device, void* hip_stream, const double F
     return CS_OK;
 }
 
+// NewMapPtsNCC::matchBetween forms E and F of a camera pair from the cameras' CURRENT poses (src/app/SL_NewMapPointsInterCam.cpp:284-292:
+// formEMat(R1, t1, R2, t2, E), getFMat(iK1, iK2, E, F)) -- the poses the frame has just solved, not anything known beforehand.  One lane
+// per pair: x_A = R x_B + t with R = R_A R_B^T, t = t_A - R t_B; E = [t]x R; F = iK_A^T E iK_B (epipolarError(F, a, b) measures a in
+// camera A against the line F (b, 1) of b in camera B).  formEMat / getFMat are un-vendored LibVisualSLAM: our definitions.
+struct NcFmArgs {
+    int n;
+    int camA[NC_MAX_JOBS], camB[NC_MAX_JOBS];
+    const double* iK[NC_MAX_JOBS][2];
+    const double *R, *t;
+    double* F;
+};
+__global__ void k_ncc_fmats(NcFmArgs A) {
+    const int k = threadIdx.x;
+    if (k >= A.n) return;
+    const double *Ra = A.R + 9 * A.camA[k], *Rb = A.R + 9 * A.camB[k], *ta = A.t + 3 * A.camA[k], *tb = A.t + 3 * A.camB[k];
+    double R[9], t[3], E[9], T[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = (Ra[3 * i] * Rb[3 * j] + Ra[3 * i + 1] * Rb[3 * j + 1]) + Ra[3 * i + 2] * Rb[3 * j + 2];
+    for (int i = 0; i < 3; ++i) t[i] = ta[i] - ((R[3 * i] * tb[0] + R[3 * i + 1] * tb[1]) + R[3 * i + 2] * tb[2]);
+    const double X[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) E[3 * i + j] = (X[3 * i] * R[j] + X[3 * i + 1] * R[3 + j]) + X[3 * i + 2] * R[6 + j];
+    const double *Ka = A.iK[k][0], *Kb = A.iK[k][1];
+    for (int i = 0; i < 3; ++i)   // T = iK_A^T E
+        for (int j = 0; j < 3; ++j) T[3 * i + j] = (Ka[i] * E[j] + Ka[3 + i] * E[3 + j]) + Ka[6 + i] * E[6 + j];
+    for (int i = 0; i < 3; ++i)   // F = T iK_B
+        for (int j = 0; j < 3; ++j) A.F[9 * k + 3 * i + j] = (T[3 * i] * Kb[j] + T[3 * i + 1] * Kb[3 + j]) + T[3 * i + 2] * Kb[6 + j];
+}
+// d_F [nPairs][9] <- the fundamental matrices of the pairs (camA[k], camB[k]) from the cameras' poses d_R [nCams][9], d_t [nCams][3] and
+// inverse intrinsics (d_iK: nCams pointers to 9 doubles each, host array); hand d_F + 9 k to job k of cs_ncc_epi_pairs_group_dev (dF)
+extern "C" int cs_ncc_fmats_dev(int device, void* hip_stream, int nCams, int nPairs, const int* camA, const int* camB, const double* const* d_iK,
+                                const double* d_R, const double* d_t, double* d_F) {
+    if (nCams < 1 || nPairs < 0 || nPairs > NC_MAX_JOBS || (nPairs && (!camA || !camB || !d_iK || !d_R || !d_t || !d_F))) {
+        cs_set_error("cs_ncc_fmats_dev: bad arguments (<= %d pairs)", NC_MAX_JOBS);
+        return CS_ERR_INVALID;
+    }
+    if (nPairs == 0) return CS_OK;
+    NcFmArgs A;
+    memset(&A, 0, sizeof(A));
+    A.n = nPairs, A.R = d_R, A.t = d_t, A.F = d_F;
+    for (int k = 0; k < nPairs; ++k) {
+        if (camA[k] < 0 || camA[k] >= nCams || camB[k] < 0 || camB[k] >= nCams || !d_iK[camA[k]] || !d_iK[camB[k]]) {
+            cs_set_error("cs_ncc_fmats_dev: bad pair %d", k);
+            return CS_ERR_INVALID;
+        }
+        A.camA[k] = camA[k], A.camB[k] = camB[k], A.iK[k][0] = d_iK[camA[k]], A.iK[k][1] = d_iK[camB[k]];
+    }
+    CS_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_ncc_fmats, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, A);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
 // the camera pairs of a matching run in ONE launch (blockIdx.z = pair): jobs[k] = {F, camA, camB, pairs, count}; the cameras'
 // blocks / abc / valid / positions as cs_ncc_get_blocks_group_dev left them (n features each)
 extern "C" int cs_ncc_epi_pairs_group_dev(int device, void* hip_stream, int nCams, const cs_ncc_cam* cams, int n, int nJobs,
@@ -624,6 +681,7 @@ extern "C" int cs_ncc_epi_pairs_group_dev(int device, void* hip_stream, int nCam
         }
         NcArgs& A = J.job[k];
         memcpy(A.F, q.F, sizeof(A.F));
+        A.dF = q.dF;
         A.s1 = {a.x, a.y, a.blocks, a.abc, a.valid, n};
         A.s2 = {b.x, b.y, b.blocks, b.abc, b.valid, n};
         A.epiMax = epiMax, A.nccMin = nccMin, A.wNone = -1.0;

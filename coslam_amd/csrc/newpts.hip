@@ -28,7 +28,7 @@
 namespace {
 
 constexpr int NP_MAX_CAMS = 16, NP_MAX_CAND = 2048, NP_MAX_SEEDS = 512, NP_MAX_TRACKS = 4096, NP_MAX_N = 32768;
-constexpr int NP_MAX_DYN = 4096;       // features of certain dynamic points decidePointType's mask is drawn from (frame sizes up to 4032 x 4032)
+constexpr int NP_MAX_DYN = 4096;       // features of certain dynamic points decidePointType's mask is drawn from (frame sizes up to 4011 x 4011)
 constexpr int NP_SEGS = 8;             // a pair's seed scan is cut into this many map segments, a workgroup each (k_np_prep)
 constexpr int NP_DYN_PER_CAM = 1024;   // features of certain dynamic points per camera that decidePointType's mask takes (k_np_prep)
 
@@ -512,8 +512,10 @@ extern "C" int cs_newpts_from_pairs_dev(int device, void* hip_stream, int nCams,
                                         const double* d_t, double* d_mapPts, double* d_mapCov, unsigned char* d_mapFlags, unsigned char* d_newPt,
                                         int* d_firstFrame, int* d_pointFeat, int mapCap, int* d_mapCount, int curFrame, double maxDisp,
                                         double maxRpErr, double pixelErrVar, int minLen, int W, int H, void* d_scratch, int* d_counts) {
-    if (W < 1 || H < 1 || W > 4032 || H > 4032) {
-        cs_set_error("cs_newpts_from_pairs_dev: frame size 1..4032");
+    // (the dynamic features' rounded positions travel as (y + 64) << 12 | (x + 64), 12 bits each, for positions within 20 px of the frame:
+    // x + 20 + 64 <= 4095)
+    if (W < 1 || H < 1 || W > 4011 || H > 4011) {
+        cs_set_error("cs_newpts_from_pairs_dev: frame size 1..4011");
         return CS_ERR_INVALID;
     }
     if (nCams < 2 || nCams > NP_MAX_CAMS || N < 1 || N > NP_MAX_N || !cams || !d_pairs || !d_pairCount || pairCap < 1 || !d_R || !d_t || !d_mapPts ||

@@ -352,19 +352,12 @@ class FrameLoop:
         ws_, hs_ = ncc_scaled_dims(cfg.W, cfg.H, 0.3)
         Kinv = np.linalg.inv(self.sc.K)
 
-        def f_matrix(c1, c2, f):
-            (R1, t1), (R2, t2) = self.sc.pose(c1, f), self.sc.pose(c2, f)
-            R = R1 @ R2.T
-            t = t1 - R @ t2
-            E = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
-            return Kinv.T @ E @ Kinv
-
         dev = self.dev
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
         rec = N * 128 + N * 32 + N * 4          # one camera's record: blocks | abc | valid
         self.ncc = dict(small=z((self.nc, ws_ * hs_), torch.uint8), rec=z((NA, rec), torch.uint8), rec_bytes=rec, runs=0,
                         send=z((self.nc, rec), torch.uint8) if self.world > 1 else None,
-                        F={(c, f): f_matrix(c, c + 1, f) for c in range(NA - 1) for f in range(self.T)},
+                        dF=z((NA - 1, 9), torch.float64),   # the pairs' fundamental matrices, formed per run from the poses just solved
                         pairs=z((NA - 1, cfg.ncc_pair_cap * NCC_PAIR_DTYPE.itemsize), torch.uint8), pair_count=z(NA - 1, torch.int32),
                         group={}, np_scr=z(newpts_scratch_bytes(NA, N), torch.uint8), np_cnt=z(4 + NA, torch.int32), new_total=0)
         r = self.ncc["rec"]
@@ -380,7 +373,7 @@ class FrameLoop:
     def _ncc_leg(self, i, f, dst):
         import coslam_amd
         from coslam_amd._lib import check
-        from coslam_amd.ncc import ncc_cams, ncc_epi_pairs_group_dev, ncc_get_blocks_group_dev, ncc_pair_jobs
+        from coslam_amd.ncc import ncc_cams, ncc_epi_pairs_group_dev, ncc_fmats_dev, ncc_get_blocks_group_dev, ncc_pair_jobs
         from coslam_amd.newpts import ncc_candidate_mask_dev, newpts_from_pairs_dev
 
         cfg, nc, c0, N, NA, ncc = self.cfg, self.nc, self.c0, self.cfg.n_feat, self.cfg.n_cams, self.ncc
@@ -396,13 +389,16 @@ class FrameLoop:
                                  valid=ncc["valid"][c0 + k].data_ptr()) for k in range(nc)])
             allc = ncc_cams([dict(img=0, x=self.d_xy[g].data_ptr(), y=self.d_xy[g].data_ptr() + 8 * N, scaled=0, blocks=ncc["blk"][g].data_ptr(),
                                   abc=ncc["abc"][g].data_ptr(), valid=ncc["valid"][g].data_ptr()) for g in range(NA)])
-            jobs_ = ncc_pair_jobs([dict(F=ncc["F"][(a, f)], camA=a, camB=a + 1, pairs=ncc["pairs"][a].data_ptr(),
+            jobs_ = ncc_pair_jobs([dict(dF=ncc["dF"][a].data_ptr(), camA=a, camB=a + 1, pairs=ncc["pairs"][a].data_ptr(),
                                         count=ncc["pair_count"][a:a + 1].data_ptr()) for a in range(NA - 1)])
             ncc["group"][f] = (own, allc, jobs_)
         own, allc, jobs_ = ncc["group"][f]
         ncc_get_blocks_group_dev(s_, own, cfg.W, cfg.H, N, 0.3, device=self.device)
         if self.world > 1:
             self._gather_ncc_records()
+        # E and F of the consecutive camera pairs from the poses this frame has solved (matchBetween, SL_NewMapPointsInterCam.cpp:284-292)
+        ncc_fmats_dev(s_, NA, list(range(NA - 1)), list(range(1, NA)), [self.d_iK1.data_ptr()] * NA, self.d_R[dst].data_ptr(),
+                      self.d_t[dst].data_ptr(), ncc["dF"].data_ptr(), device=self.device)
         ncc_epi_pairs_group_dev(s_, allc, N, jobs_, 50.0, 0.80, cfg.ncc_pair_cap, device=self.device)   # SL_NewMapPointsInterCam.h:71-72
         # matches -> tracks -> new map points (NewMapPtsNCC::run's tail + output), appended behind d_mapcount
         newpts_from_pairs_dev(s_, ncc["job"], N, cfg.ncc_pair_cap, self.d_R[dst].data_ptr(), self.d_t[dst].data_ptr(), self.d_map.data_ptr(),
@@ -747,6 +743,44 @@ class FrameLoop:
         # its own count, which the reference's request policy -- skip_busy -- may leave behind k)
         seq = self.my_seq[k] if owner == self.rank else k // self.world
         self.apply_at[i + self.lag * cfg.key_every] = (k, owner, i - (cfg.n_key_frames - 1) * cfg.key_every, seq)
+
+    def measure_collectives(self, n=40):
+        """GPU-clock latency of each of the frame loop's collectives as THIS loop issues them (the buffers of the last frame, the pose
+        stream; every rank calls it at the same point): microseconds per call, averaged over n back-to-back calls.  N = 1: {}."""
+        if self.world == 1:
+            return {}
+        torch, ps = self.torch, self.pose_s
+        out = {}
+
+        def timed(name, fn):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fn()
+            torch.cuda.synchronize()
+            e0.record(ps)
+            for _ in range(n):
+                fn()
+            e1.record(ps)
+            e1.synchronize()
+            out[name] = e0.elapsed_time(e1) * 1e3 / n
+
+        def gather_features():
+            with torch.cuda.stream(ps):
+                self.xchg.pack_group(self.d_dests[0], self.d_R[0][self.c0:self.c0 + self.nc], self.d_t[0][self.c0:self.c0 + self.nc], ps)
+                self.xchg.all_gather(ps)
+
+        timed("all_gather_features_and_poses_per_frame", gather_features)
+        if self.cfg.with_register and self.cfg.with_decide and self.pose_upd is not None and hasattr(self, "_cand"):
+            timed("all_gather_registration_candidates_per_frame", self._gather_candidates)
+        if self.ncc is not None:
+            timed("all_gather_ncc_records_every_4th_frame", self._gather_ncc_records)
+        if self.out is not None:
+            rec = self.recv_rec[0].data_ptr()
+            timed("broadcast_ba_result_per_key_frame", lambda: self.xchg.broadcast(rec, self.out.record_bytes, 0, self.device, ps))
+        out["bytes"] = {"features_and_poses_per_rank": int(self.nc * (self.cfg.n_feat * 20 + 96)),
+                        "registration_candidates_per_rank": int(3 * self.nc * self.cfg.p_reg * 4),
+                        "ncc_records_per_rank": int(self.nc * self.ncc["rec_bytes"]) if self.ncc is not None else 0,
+                        "ba_result": int(self.out.record_bytes) if self.out is not None else 0}
+        return out
 
     def drain(self):
         """the worker threads' queues are part of the work: every requested solve completes.  A window / a rig that holds no usable point

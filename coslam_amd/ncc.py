@@ -47,7 +47,7 @@ class NccCam(C.Structure):
 class NccPairJob(C.Structure):
     """== cs_ncc_pair_job."""
 
-    _fields_ = [("F", C.c_double * 9), ("camA", C.c_int), ("camB", C.c_int), ("pairs", C.c_void_p), ("count", C.c_void_p)]
+    _fields_ = [("F", C.c_double * 9), ("camA", C.c_int), ("camB", C.c_int), ("pairs", C.c_void_p), ("count", C.c_void_p), ("dF", C.c_void_p)]
 
 
 def ncc_cams(cams):
@@ -64,11 +64,24 @@ def ncc_pair_jobs(jobs):
     """list of dicts(F (9 floats), camA, camB, pairs, count) -> the ctypes array"""
     arr = (NccPairJob * len(jobs))()
     for a, q in zip(arr, jobs):
-        F = np.ascontiguousarray(q["F"], dtype=np.float64).reshape(9)
-        for k in range(9):
-            a.F[k] = float(F[k])
+        if q.get("F") is not None:
+            F = np.ascontiguousarray(q["F"], dtype=np.float64).reshape(9)
+            for k in range(9):
+                a.F[k] = float(F[k])
         a.camA, a.camB, a.pairs, a.count = int(q["camA"]), int(q["camB"]), int(q["pairs"]), int(q["count"])
+        if q.get("dF"):   # the matrix in device memory (ncc_fmats_dev), used instead of F
+            a.dF = int(q["dF"])
     return arr
+
+
+def ncc_fmats_dev(stream_ptr, nCams, camA, camB, d_iK, d_R, d_t, d_F, device=0):
+    """cs_ncc_fmats_dev: the fundamental matrices of the camera pairs (camA[k], camB[k]) from the cameras' CURRENT poses, on the device
+    (NewMapPtsNCC::matchBetween forms them from the poses the frame has just solved); d_iK: one device pointer per camera"""
+    n = len(camA)
+    ca, cb = (C.c_int * n)(*[int(v) for v in camA]), (C.c_int * n)(*[int(v) for v in camB])
+    ik = (C.c_void_p * nCams)(*[int(v) for v in d_iK])
+    check(lib().cs_ncc_fmats_dev(int(device), C.c_void_p(stream_ptr), int(nCams), n, ca, cb, ik, C.c_void_p(d_R), C.c_void_p(d_t), C.c_void_p(d_F)),
+          "cs_ncc_fmats_dev")
 
 
 def ncc_get_blocks_group_dev(stream_ptr, cams, W, H, n, scale, device=0):

@@ -745,7 +745,13 @@ typedef struct cs_ncc_pair_job {
     int camA, camB;
     cs_ncc_pair* pairs; /* pairCap records out */
     int* count;         /* 1 out: zeroed by the call */
+    const double* dF;   /* NULL, or the matrix in DEVICE memory (9 doubles), used instead of F: what cs_ncc_fmats_dev formed from the poses the
+                         * frame has just solved (NewMapPtsNCC::matchBetween, src/app/SL_NewMapPointsInterCam.cpp:284-292) */
 } cs_ncc_pair_job;
+/* d_F [nPairs][9] <- F of the pairs (camA[k], camB[k]) from the cameras' current poses: x_A = R x_B + t, E = [t]x R, F = iK_A^T E iK_B
+ * (formEMat / getFMat: our definitions).  camA / camB / d_iK (nCams pointers to 9 doubles): host arrays; <= 8 pairs. */
+int cs_ncc_fmats_dev(int device, void* hip_stream, int nCams, int nPairs, const int* camA, const int* camB, const double* const* d_iK,
+                     const double* d_R, const double* d_t, double* d_F);
 int cs_ncc_get_blocks_group_dev(int device, void* hip_stream, int nCams, const cs_ncc_cam* cams /* host */, int W, int H, int n,
                                 double scale);
 int cs_ncc_epi_pairs_group_dev(int device, void* hip_stream, int nCams, const cs_ncc_cam* cams /* host */, int n, int nJobs,

@@ -267,3 +267,60 @@ def test_group_launches_give_what_the_per_camera_calls_give(hip):
         a = np.sort(pr1[c].cpu().numpy().view(NCC_PAIR_DTYPE)[: c1[c]], order=("i", "j"))
         b = np.sort(pr2[c].cpu().numpy().view(NCC_PAIR_DTYPE)[: c2[c]], order=("i", "j"))
         assert np.array_equal(a, b)
+
+
+def test_fundamental_matrices_from_the_poses_on_the_device(hip):
+    """cs_ncc_fmats_dev (ADVICE r04: NewMapPtsNCC::matchBetween forms E and F from the cameras' CURRENT poses, reference
+    src/app/SL_NewMapPointsInterCam.cpp:284-292 -- the loop must not hand it matrices of the ground truth): F of the consecutive camera
+    pairs from poses in device memory, against x_A = R x_B + t, E = [t]x R, F = K^-T E K^-1 in numpy (<= 1e-12 of the matrix's size);
+    and a matching run whose jobs point at those matrices (dF) gives the pair lists of a run handed the same numbers by value."""
+    import torch
+
+    from coslam_amd.ncc import NCC_PAIR_DTYPE, ncc_epi_pairs_group_dev, ncc_fmats_dev, ncc_get_blocks_group_dev, ncc_scaled_dims
+
+    W, H, n, nC, scale, cap = 640, 480, 800, 4, 0.3, 1 << 16
+    sc = Scene(nC, W, H, 3000, seed=41)
+    rng = np.random.default_rng(8)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    R = np.stack([sc.pose(c, 7)[0].ravel() for c in range(nC)])
+    t = np.stack([sc.pose(c, 7)[1] for c in range(nC)]) + rng.normal(0, 0.01, (nC, 3))     # (estimated poses: not the truth's)
+    iK = np.linalg.inv(sc.K)
+    d_R, d_t, d_iK = torch.from_numpy(R.copy()).to(dev), torch.from_numpy(t.copy()).to(dev), torch.from_numpy(iK.ravel().copy()).to(dev)
+    d_F = torch.zeros((nC - 1, 9), dtype=torch.float64, device=dev)
+    ncc_fmats_dev(s, nC, list(range(nC - 1)), list(range(1, nC)), [d_iK.data_ptr()] * nC, d_R.data_ptr(), d_t.data_ptr(), d_F.data_ptr())
+    torch.cuda.synchronize()
+    F_dev = d_F.cpu().numpy()
+    for c in range(nC - 1):
+        Ra, Rb = R[c].reshape(3, 3), R[c + 1].reshape(3, 3)
+        Rr = Ra @ Rb.T
+        tr = t[c] - Rr @ t[c + 1]
+        E = np.array([[0, -tr[2], tr[1]], [tr[2], 0, -tr[0]], [-tr[1], tr[0], 0]]) @ Rr
+        Fw = iK.T @ E @ iK
+        assert np.abs(F_dev[c].reshape(3, 3) - Fw).max() <= 1e-12 * np.abs(Fw).max(), c
+    ws_, hs_ = ncc_scaled_dims(W, H, scale)
+    imgs = [torch.from_numpy(sc.render(c, 7)).to(dev) for c in range(nC)]
+    xs, ys, val = [], [], []
+    for c in range(nC):
+        uv, vis = sc.project(c, 7)
+        k = np.nonzero(vis)[0][:n]
+        xs.append(torch.from_numpy(np.ascontiguousarray(uv[k, 0])).to(dev)), ys.append(torch.from_numpy(np.ascontiguousarray(uv[k, 1])).to(dev))
+        val.append(torch.ones(n, dtype=torch.int32, device=dev))
+    sm = [torch.zeros(ws_ * hs_, dtype=torch.uint8, device=dev) for _ in range(nC)]
+    bl, ab = [torch.zeros((n, 128), dtype=torch.uint8, device=dev) for _ in range(nC)], [torch.zeros((n, 4), dtype=torch.float64, device=dev) for _ in range(nC)]
+    cams = [dict(img=imgs[c].data_ptr(), x=xs[c].data_ptr(), y=ys[c].data_ptr(), scaled=sm[c].data_ptr(), blocks=bl[c].data_ptr(), abc=ab[c].data_ptr(),
+                 valid=val[c].data_ptr()) for c in range(nC)]
+    ncc_get_blocks_group_dev(s, cams, W, H, n, scale)
+    out = []
+    for by_value in (True, False):
+        pr = [torch.zeros(cap * 24, dtype=torch.uint8, device=dev) for _ in range(nC - 1)]
+        cn = torch.zeros(nC - 1, dtype=torch.int32, device=dev)
+        jobs = [dict(camA=c, camB=c + 1, pairs=pr[c].data_ptr(), count=cn[c:c + 1].data_ptr(),
+                     **(dict(F=F_dev[c]) if by_value else dict(dF=d_F[c].data_ptr()))) for c in range(nC - 1)]
+        ncc_epi_pairs_group_dev(s, cams, n, jobs, 50.0, 0.5, cap)
+        torch.cuda.synchronize()
+        c_ = cn.cpu().numpy()
+        out.append([np.sort(pr[c].cpu().numpy().view(NCC_PAIR_DTYPE)[: c_[c]], order=("i", "j")) for c in range(nC - 1)])
+        assert c_.min() > 20
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
