@@ -551,6 +551,7 @@ extern "C" int cs_ncc_epi_mat_dev(int device, void* hip_stream, const double F[9
         return CS_ERR_INVALID;
     }
     NcArgs A;
+    memset(&A, 0, sizeof(A));   // (dF = null: the matrix by value)
     memcpy(A.F, F, sizeof(A.F));
     A.s1 = {d_x1, d_y1, d_blocks1, d_abc1, d_valid1, M};
     A.s2 = {d_x2, d_y2, d_blocks2, d_abc2, d_valid2, N};
@@ -585,6 +586,7 @@ extern "C" int cs_ncc_epi_pairs_dev(int device, void* hip_stream, const double F
         return CS_ERR_INVALID;
     }
     NcArgs A;
+    memset(&A, 0, sizeof(A));   // (dF = null: the matrix by value)
     memcpy(A.F, F, sizeof(A.F));
     A.s1 = {d_x1, d_y1, d_blocks1, d_abc1, d_valid1, M};
     A.s2 = {d_x2, d_y2, d_blocks2, d_abc2, d_valid2, N};
