@@ -664,6 +664,7 @@ def main():
     dec_counts = None if not hasattr(loop, "_dec") else (loop._dec["cnt"].cpu().tolist(), int(loop._dec["cnt"][1].item()),   # (every registered point is refined: the count of one is the other's)
                                                          int(loop._dec["scr"][-4:].view(torch.int32).item()))
     digest = loop.digest() if os.environ.get("BENCH_STATE_DIGEST") else None
+    map_in_use_timed_end = int(loop.d_mapcount.item())   # (as of the end of the timed region: the secondary legs run the loop on)
     if loop._timing is not None:
         print("[frameloop host seconds by section]", {k: round(v, 4) for k, v in loop._timing.items()}, file=sys.stderr)
     n_timed_end = n_done
@@ -859,7 +860,7 @@ def main():
         avg_us = prof["tracker_us_total"] / max(prof["frames"], 1) / launches
         ach = (alg_bytes / launches) / (avg_us * 1e-6) / 1e9
         traffic, traffic_src, valu = None, None, None
-        pmc_file = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_tracker_pmc.json", "r03_tracker_pmc.json"))
+        pmc_file = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_tracker_pmc.json", "r04_tracker_pmc.json", "r03_tracker_pmc.json"))
                          if os.path.exists(q)), None)
         pj = json.load(open(pmc_file)) if (nc == N_CAMS and pmc_file) else None
         if pj is not None:   # HBM bytes per frame's worth of launches from the committed --pmc passes (8 cameras per launch there)
@@ -1161,7 +1162,7 @@ def main():
                            **dict(zip(("new_map_points_last_run", "tracks_last_run", "tracks_of_two_or_more_views_last_run", "flags_last_run"),
                                       loop.ncc["np_cnt"].cpu().tolist()[:4])),
                            "matches_per_pair_last_run": loop.ncc["np_cnt"].cpu().tolist()[4:4 + N_CAMS - 1],
-                           "map_points_in_use": int(loop.d_mapcount.item()), "map_points_at_start": n_pts0, "map_capacity": loop.n_map},
+                           "map_points_in_use": map_in_use_timed_end, "map_points_at_start": n_pts0, "map_capacity": loop.n_map},
                        "with_upload": with_upload, "secondary_reference_ba_request_policy": ref_policy,
                        "secondary_sequential_registration": seq_reg, "cxx_frame_loop": cxx,
                        "collectives": None if world == 1 else {

@@ -81,7 +81,10 @@ def test_bare_gpus_2_spawns_two_ranks_that_hold_one_map(hip):
     of the poses are bit-identical."""
     j = _run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--setup-rounds", "1"] + SHORT, env=TWO_RANKS_ON_ONE_GPU)
     cfg = j["config"]
-    assert j["n_gpus"] == 2 and cfg["cameras_per_gpu"] == 4 and "gloo" in cfg["collectives"]
+    assert j["n_gpus"] == 2 and cfg["cameras_per_gpu"] == 4 and "gloo" in cfg["collectives"]["issued_by"]
+    lat = cfg["collectives"]["us_per_call_measured_after_the_run"]     # every collective of the loop timed on the GPU clock
+    assert "error" not in lat and lat["all_gather_features_and_poses_per_frame"] > 0 and lat["broadcast_ba_result_per_key_frame"] > 0
+    assert lat["all_gather_registration_candidates_per_frame"] > 0 and lat["bytes"]["registration_candidates_per_rank"] == 3 * 4 * 4096 * 4
     assert cfg["replicas"]["ranks"] == 2 and cfg["replicas"]["identical_map_records_and_poses_on_every_rank"] is True
     assert cfg["joint_ba_from_window"] is True and cfg["joint_ba_problem"]["cameras"] == 40 and cfg["joint_ba_problem"]["measurements"] > 5000
     bo = cfg["ba_output"]
