@@ -501,6 +501,8 @@ def main():
     ap.add_argument("--setup-rounds", type=int, default=int(os.environ.get("BENCH_SETUP_ROUNDS", "-1")),
                     help="untimed set-up rounds of 4 key-frame intervals in front of the warm-up; -1 = N = 1: run for BENCH_SETUP_SECONDS, "
                          "N > 1: 12 (every rank must take the same number of steps)")
+    ap.add_argument("--klt-xcd-placement", type=int, default=int(os.environ.get("BENCH_KLT_XCD", "1")),
+                    help="1: the persistent tracker numbers its workgroups so that a camera lands on its own XCD; 0: cameras as grid rows")
     ap.add_argument("--klt-cus", type=int, default=int(os.environ.get("BENCH_KLT_CUS", "0")),
                     help="> 0: the tracker stream confined to that many CU-mask bits (multiples of 32: the same CUs of every XCD); experiment")
     ap.add_argument("--pose-cus", type=int, default=int(os.environ.get("BENCH_POSE_CUS", "0")),
@@ -576,7 +578,7 @@ def main():
                      prefetch=os.environ.get("BENCH_PREFETCH", "1") != "0", with_pose_update=not args.no_pose_update,
                      with_classify=not args.no_classify, with_register=not args.no_register, with_mergability=not args.no_mergability,
                      with_ncc=not args.no_ncc, with_decide=not args.no_decide, merge_every=args.merge_every, hist=args.hist, hist_store=args.hist_store, with_active_search=bool(args.active_search), pixel_err_reading=args.pixel_err_reading, with_joint=args.only_solve != "intercam", with_intercam=args.only_solve != "joint",
-                     native_comm=bool(args.native_comm), klt_cus=args.klt_cus, pose_cus=args.pose_cus,
+                     native_comm=bool(args.native_comm), klt_cus=args.klt_cus, pose_cus=args.pose_cus, klt_xcd_placement=bool(args.klt_xcd_placement),
                      klt_after_intracam=bool(args.klt_after_intracam),
                      klt_fused=os.environ.get("BENCH_FORCE_DEVICE") is None or world == 1)   # (ranks sharing ONE GPU: test hook)
     try:

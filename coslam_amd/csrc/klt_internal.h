@@ -55,6 +55,7 @@ struct CsRowsArgs {
     int n1x[4], n1y[4];
     int level;  // per-pass kernel only: the level this launch works on
     int nCams;
+    int xcdsPerCam;  // persistent kernel: 0 = grid (workgroups of a camera, cameras); q > 0 = 1-D grid, camera c on XCDs c q .. c q + q - 1
     CsRowsCam cam[CS_MAX_CAMS];
 };
 

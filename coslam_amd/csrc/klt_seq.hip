@@ -157,6 +157,7 @@ struct cs_klt {
     unsigned long long* d_gran;  // [granRows][N] hand-off granules of the persistent tracker (one row per pass + 1)
     int granRows;
     int* d_err;
+    int xcd_placement;            // persistent tracker: 1 = a camera's workgroups on its own XCD(s) (cs_klt_set_xcd_placement)
     int cu_count;                 // compute units the handle's stream may use (cs_klt_set_cu_count; default: all)
     int concurrent;               // handles whose persistent kernels may overlap (cs_klt_set_concurrent_handles; 0: all live ones)
     unsigned long long* d_probe;  // diagnostic cycle counters of the persistent tracker (cs_klt_debug_probe)
@@ -230,11 +231,12 @@ static void gain_neighbour_offsets(int fw, int fh, int* n1x, int* n1y) {
 // independent launches that may overlap on the device.  A span with more cameras than fit is issued as several
 // persistent launches one after the other on its stream.  (Every spin in the kernel is bounded: a grid that is not
 // resident after all raises the handle's error word instead of hanging.)
-static int rows_cams_per_persistent_launch(const Span& S, int hw, int T) {
+static int rows_cams_per_persistent_launch(const Span& S, int hw, int T, int* perCuOut = nullptr) {
     cs_klt* k0 = S.k[0];
     if (!k0->use_fused || T < 1 || T + 1 > k0->granRows) return 0;
     int perCu = 0;  // resident waves per CU the runtime reports for this instantiation (VGPR- or LDS-bound here)
     if (cs_rows_max_resident_blocks(hw, k0->device, &perCu) <= 0) return 0;
+    if (perCuOut) *perCuOut = perCu;
     const long capacity = (long)perCu * k0->cu_count - k0->cu_count / 8;  // a little slack below the reported occupancy
     int live = 1;
     {
@@ -298,7 +300,8 @@ static int enqueue_tracker(const Span& S, cs_klt_feature* const* postDest, int d
         const float realConv = k0->convThr * k0->convThr, realSsd = k0->ssdThr;
         const float realVr[4] = {k0->margin / (float)k0->W, k0->margin / (float)k0->H, 1.0f - k0->margin / (float)k0->W,
                                  1.0f - k0->margin / (float)k0->H};
-        const int perLaunch = rows_cams_per_persistent_launch(S, hw, T);
+        int perCu = 0;   // resident waves per CU of the instantiation launched
+        const int perLaunch = rows_cams_per_persistent_launch(S, hw, T, &perCu);
         if (perLaunch >= 1) {
             A.sqrConvThr = realConv;
             A.ssdThr = realSsd;
@@ -307,6 +310,14 @@ static int enqueue_tracker(const Span& S, cs_klt_feature* const* postDest, int d
             for (int first = 0; first < S.n; first += perLaunch) {
                 const int m = (S.n - first < perLaunch) ? S.n - first : perLaunch;
                 A.nCams = m;
+                // camera per XCD when the launch's cameras divide the eight XCDs (1, 2, 4, 8 cameras) and a camera's workgroups fit
+                // the XCDs they are sent to with room to spare (the grid must stay co-resident wherever the dispatcher puts it)
+                A.xcdsPerCam = 0;
+                if (k0->xcd_placement && m <= 8 && 8 % m == 0) {
+                    const int q = 8 / m, wgPerCam = (cs_rows_waves(hw, k0->N) + 3) / 4;
+                    const long room = (long)(perCu / 4) * (k0->cu_count / 8);
+                    if ((long)((wgPerCam + q - 1) / q) * 5 <= room * 4) A.xcdsPerCam = q;   // <= 80 % of the XCDs' workgroup slots
+                }
                 for (int i = 0; i < m; ++i) {
                     cs_klt* k = S.k[first + i];
                     CsRowsCam& C = A.cam[i];
@@ -678,6 +689,7 @@ cs_klt* cs_klt_create(const cs_klt_config* cfg, int device, int tap_mode) {
     k->graphs = new std::vector<cs_klt::GraphEntry>();
     k->ev_pairs = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
     k->use_fused = true;   // (cs_klt_set_fused selects the per-pass schedule)
+    k->xcd_placement = 1;  // (cs_klt_set_xcd_placement)
     return k;
 }
 
@@ -877,6 +889,17 @@ int cs_klt_set_cu_count(cs_klt* k, int n_cus) {
     if (k->allocated) {
         int rc = bind_device(k);
         if (rc) return rc;
+        CS_HIP(hipStreamSynchronize(k->stream));
+        drop_graphs(k);
+    }
+    return CS_OK;
+}
+
+// Placement of the persistent tracker's workgroups (speed only; results are bit-identical either way).
+int cs_klt_set_xcd_placement(cs_klt* k, int on) {
+    CS_REQUIRE(k, "cs_klt_set_xcd_placement: null handle");
+    k->xcd_placement = on ? 1 : 0;
+    if (k->allocated) {
         CS_HIP(hipStreamSynchronize(k->stream));
         drop_graphs(k);
     }

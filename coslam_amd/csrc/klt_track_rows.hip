@@ -34,8 +34,8 @@ namespace {
 #define CS_ROWS_UNROLL 7
 #endif
 #ifndef CS_ROWS_WPB
-// Waves per workgroup.  4: a workgroup's waves go to the CU's four SIMDs and its 64 KB of LDS admit two workgroups per
-// CU, so eight cameras (2000 waves) land as exactly two waves on every SIMD.  With single-wave workgroups the
+// Waves per workgroup.  4: a workgroup's waves go to the CU's four SIMDs (53 KB of LDS per workgroup for a 7 x 7 window: up to three
+// per CU), so eight cameras (2000 waves) land as two waves on every SIMD.  With single-wave workgroups the
 // dispatcher piles up to ten of them on a CU while others idle: 218 vs 164 us for the eight-camera tracker stage.
 #define CS_ROWS_WPB 4
 #endif
@@ -49,7 +49,15 @@ namespace {
 #ifndef CS_ROWS_LDS_PAD
 #define CS_ROWS_LDS_PAD 0  // extra dynamic LDS per wave (bytes): caps the workgroups a CU admits
 #endif
-constexpr int RW_MARGIN = 2;  // texels of slack around the window footprint in the LDS patch
+#ifndef CS_ROWS_MARGIN
+// Texels of slack around the window footprint in the LDS patch.  1 (round 5; 2 before): a 7 x 7 window's wave then holds 13.25 KB
+// of LDS instead of 16, so a CU admits THREE workgroups instead of two -- 96 workgroup slots per XCD where a camera needs 63: the
+// room the camera-per-XCD placement (xcdsPerCam) needs beside the pose stream's kernels (with two per CU the placed grid met a
+// co-residency timeout in the frame loop; profiles/r05_ab_runs.txt).  Re-centring got no more frequent in the counters
+// (FETCH_SIZE 52.7 vs 54.7 MB per launch) and the launch 1.6 % shorter.
+#define CS_ROWS_MARGIN 1
+#endif
+constexpr int RW_MARGIN = CS_ROWS_MARGIN;
 typedef unsigned long long cs_granule;
 typedef __attribute__((address_space(1))) cs_granule gu64;
 
@@ -309,11 +317,21 @@ __global__ __launch_bounds__(64 * CS_ROWS_WPB, (LPF == 8 ? CS_ROWS_MINBLOCKS : 2
     if (PROBE) tStart = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_setprio(CS_ROWS_PRIO_BASE);
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int waveId = blockIdx.x * CS_ROWS_WPB + wib;
+    // Placement.  Workgroup b of a launch runs on XCD b % 8 (observed; used for speed only -- nothing below depends on it):
+    // with xcdsPerCam = q the 1-D grid hands XCDs c q .. c q + q - 1 to camera c, so a camera's two pyramids are fetched into
+    // ONE L2 instead of eight and its granule rows are swept inside that L2's XCD.
+    int camIdx = blockIdx.y, bx = blockIdx.x;
+    if (A.xcdsPerCam > 0) {
+        const int xcd = blockIdx.x & 7, round = blockIdx.x >> 3;
+        camIdx = xcd / A.xcdsPerCam;
+        bx = round * A.xcdsPerCam + (xcd - camIdx * A.xcdsPerCam);
+        if (bx * (CS_ROWS_WPB * FPW) >= A.N) return;  // (padding of the 1-D grid: no slot, nobody waits for it)
+    }
+    const int waveId = bx * CS_ROWS_WPB + wib;
     const int g = lane / LPF, r = lane - g * LPF;
     const int k = waveId * FPW + g;
     const bool valid = k < A.N;
-    const CsRowsCam& Cm = A.cam[blockIdx.y];
+    const CsRowsCam& Cm = A.cam[camIdx];
     const cs_texel* __restrict__ pyr0 = Cm.pyr0;
     const cs_texel* __restrict__ pyr1 = Cm.pyr1;
     cs_granule* gran = Cm.gran;
@@ -650,7 +668,9 @@ int launch_fused(const CsRowsArgs& a, hipStream_t stream) {
     constexpr int R = FW + 1 + 2 * RW_MARGIN, R0 = FW + 2, FPW = 64 / LPF;
     const size_t lds = (rows_lds_bytes(FPW, R, R0, FW) + CS_ROWS_LDS_PAD) * CS_ROWS_WPB;
     const int waves = (a.N + FPW - 1) / FPW;
-    dim3 grid((waves + CS_ROWS_WPB - 1) / CS_ROWS_WPB, a.nCams), block(64 * CS_ROWS_WPB);
+    const int wgPerCam = (waves + CS_ROWS_WPB - 1) / CS_ROWS_WPB;
+    dim3 grid(wgPerCam, a.nCams), block(64 * CS_ROWS_WPB);
+    if (a.xcdsPerCam > 0) grid = dim3(8 * ((wgPerCam + a.xcdsPerCam - 1) / a.xcdsPerCam), 1);
     bool probe = false;
     for (int c = 0; c < a.nCams; ++c) probe = probe || (a.cam[c].probe != nullptr);
     if (probe)

@@ -54,6 +54,7 @@ class LoopConfig:
         self.ncc_every, self.ncc_pair_cap = 4, 1 << 16
         self.map_spare = 8192      # room for new map points behind the initial map
         self.klt_cams_per_launch = 0
+        self.klt_xcd_placement = True
         self.klt_fused = True      # False: one launch per Gauss-Newton pass (bit-identical): for SEVERAL processes sharing one GPU, where the
                                    # persistent tracker's co-residency budget does not hold
         self.prefetch = True
@@ -187,6 +188,8 @@ class FrameLoop:
             self.trks.append(t)
         self.grp = coslam_amd.KLT_TrackerGroup(self.trks)
         self.grp.set_stream(self.klt_s.cuda_stream)
+        for t in self.trks:       # a camera's tracker workgroups on that camera's own XCD (one L2 per pyramid pair)
+            t.set_xcd_placement(cfg.klt_xcd_placement)
         if cfg.klt_cams_per_launch > 0:
             for t in self.trks:   # co-residency budget of the persistent tracker = that many cameras per launch
                 t.set_cu_count(min(256, (250 * cfg.klt_cams_per_launch + 60) // 8 + 5))

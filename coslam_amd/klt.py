@@ -219,6 +219,9 @@ class KLT_SequenceTracker:
     def set_cu_count(self, n_cus):
         check(self._L.cs_klt_set_cu_count(self._h, int(n_cus)), "cs_klt_set_cu_count")
 
+    def set_xcd_placement(self, on):
+        check(self._L.cs_klt_set_xcd_placement(self._h, int(bool(on))), "cs_klt_set_xcd_placement")
+
     def set_concurrent_handles(self, n):
         check(self._L.cs_klt_set_concurrent_handles(self._h, int(n)), "cs_klt_set_concurrent_handles")
 

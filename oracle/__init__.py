@@ -369,6 +369,73 @@ def check_unify(Ks, iKs, histR, histT, histXY, trackSpan, pf1, pf2, M1, M2, sigm
     return bool(ok), M, cov
 
 
+def _ref_args(histR, histT, histXY, Ks, iKs):
+    histR = np.ascontiguousarray(histR, dtype=np.float64)
+    histT = np.ascontiguousarray(histT, dtype=np.float64)
+    histXY = np.ascontiguousarray(histXY, dtype=np.float64)
+    nC, nH = histR.shape[0], histR.shape[1]
+    N = histXY.shape[2] // 2
+    Ks = np.ascontiguousarray(Ks, dtype=np.float64).reshape(nC, 9)
+    iKs = np.ascontiguousarray(iKs, dtype=np.float64).reshape(nC, 9)
+    return histR, histT, histXY, nC, nH, N, Ks, iKs
+
+
+def update_new_poses_points_ref(Ks, iKs, histR, histT, histXY, featStatic, featRef, segPool, curFrame, mapPts, mapCov, mapFlags, sigma,
+                                lastFrame=None, isCurrent=None, firstKeyFrame=-1, walkCap=64, cmpAcos=False):
+    """opu_update_new_poses_points_ref: update_new_poses_points with the features as REFERENCES -- featRef (nMap x nC x 4 int32:
+    slot, frame, first, seg) and segPool (nC x cap x 4: slot, last, first, next): MapPoint::pFeatures with the preFrame chains behind them,
+    stale features and re-linked tracks included (oracle/poseupdate_oracle.c, above update_points_core)."""
+    L = lib()
+    L.opu_update_new_poses_points_ref.restype = C.c_int
+    histR, histT, histXY, nC, nH, N, Ks, iKs = _ref_args(histR, histT, histXY, Ks, iKs)
+    fs = np.ascontiguousarray(featStatic, dtype=np.uint8).reshape(nC, N)
+    fr = np.ascontiguousarray(featRef, dtype=np.int32)
+    nMap = fr.shape[0]
+    sp = np.ascontiguousarray(segPool, dtype=np.int32)
+    assert fr.shape == (nMap, nC, 4) and sp.shape[0] == nC and sp.shape[2] == 4
+    assert mapPts.dtype == np.float64 and mapCov.dtype == np.float64 and mapPts.flags.c_contiguous and mapCov.flags.c_contiguous
+    fl = np.ascontiguousarray(mapFlags, dtype=np.uint8)
+    lf = None if lastFrame is None else np.ascontiguousarray(lastFrame, dtype=np.int32)
+    ic = None if isCurrent is None else np.ascontiguousarray(isCurrent, dtype=np.uint8)
+    chosen = np.full((nMap, nC), -1, dtype=np.int32)
+    ns, nd = C.c_int(0), C.c_int(0)
+    n = L.opu_update_new_poses_points_ref(nC, N, nH, _p(Ks), _p(iKs), _p(histR), _p(histT), _p(histXY), _p(fs), nMap, _p(fr), _p(sp),
+                                          sp.shape[1], int(curFrame), int(walkCap), _p(lf) if lf is not None else None,
+                                          _p(ic) if ic is not None else None, int(firstKeyFrame), _p(mapPts), _p(mapCov), _p(fl),
+                                          C.c_double(sigma), int(bool(cmpAcos)), _p(chosen), C.byref(ns), C.byref(nd))
+    return n, ns.value, nd.value, chosen
+
+
+def refine_map_points_ref(Ks, iKs, histR, histT, histXY, featRef, segPool, curFrame, mapPts, mapCov, sigma, select=None, walkCap=64,
+                          cmpAcos=False):
+    """opu_refine_map_points_ref (CoSLAM::refineMapPoint over feature references; layouts as update_new_poses_points_ref)."""
+    L = lib()
+    L.opu_refine_map_points_ref.restype = C.c_int
+    histR, histT, histXY, nC, nH, N, Ks, iKs = _ref_args(histR, histT, histXY, Ks, iKs)
+    fr = np.ascontiguousarray(featRef, dtype=np.int32)
+    nMap = fr.shape[0]
+    sp = np.ascontiguousarray(segPool, dtype=np.int32)
+    assert fr.shape == (nMap, nC, 4) and mapPts.dtype == np.float64 and mapCov.dtype == np.float64
+    sel = None if select is None else np.ascontiguousarray(select, dtype=np.uint8)
+    return L.opu_refine_map_points_ref(nC, N, nH, _p(Ks), _p(iKs), _p(histR), _p(histT), _p(histXY), nMap, _p(fr), _p(sp), sp.shape[1],
+                                       int(curFrame), int(walkCap), _p(sel) if sel is not None else None, _p(mapPts), _p(mapCov),
+                                       C.c_double(sigma), int(bool(cmpAcos)))
+
+
+def check_unify_ref(Ks, iKs, histR, histT, histXY, ref1, ref2, segPool, curFrame, M1, M2, sigma, walkCap=64, cmpAcos=False):
+    """opu_check_unify_ref (CoSLAM::checkUnify): ref1 / ref2 int32[nC][4] = the two points' feature references.  Returns (ok, M, cov)."""
+    L = lib()
+    L.opu_check_unify_ref.restype = C.c_int
+    histR, histT, histXY, nC, nH, N, Ks, iKs = _ref_args(histR, histT, histXY, Ks, iKs)
+    a, b = np.ascontiguousarray(ref1, dtype=np.int32).reshape(nC, 4), np.ascontiguousarray(ref2, dtype=np.int32).reshape(nC, 4)
+    sp = np.ascontiguousarray(segPool, dtype=np.int32)
+    m1, m2 = np.ascontiguousarray(M1, dtype=np.float64).reshape(3), np.ascontiguousarray(M2, dtype=np.float64).reshape(3)
+    M, cov = np.zeros(3), np.zeros(9)
+    ok = L.opu_check_unify_ref(nC, N, nH, _p(Ks), _p(iKs), _p(histR), _p(histT), _p(histXY), _p(a), _p(b), _p(sp), sp.shape[1],
+                               int(curFrame), int(walkCap), _p(m1), _p(m2), C.c_double(sigma), int(bool(cmpAcos)), _p(M), _p(cov))
+    return bool(ok), M, cov
+
+
 def static_check_mergability(K, histR, histT, histXY, slot, length, M, cov, pixelVar):
     """org_static_check_mergability (CoSLAM::staticCheckMergability): histR (nHist x 9), histT (nHist x 3), histXY (nHist x 2N),
     entry 0 = this frame; the track of `slot` covers the `length` newest entries.  Returns True / False."""

@@ -261,17 +261,77 @@ static void cov_add_view(double* S, const double* K, const double* R, const doub
     for (int q = 0; q < 6; q++) S[q] = S[q] + (Jm[I[q]] * Jm[J[q]] + Jm[3 + I[q]] * Jm[3 + J[q]]);
 }
 
+/* A point's feature in a camera AS THE REFERENCE HOLDS IT: MapPoint::pFeatures[c] -- of this frame, or an older one when the camera
+ * lost the point (nothing ever clears the pointer) -- with the FeaturePoint::preFrame chain behind it.  The chain is a run of
+ * consecutive frames on the feature's own slot, frame - 1 .. first, and then whatever the registration loops linked behind it:
+ * `pFeat->preFrame = p->pFeatures[iCam]` (/root/reference/src/app/SL_CoSLAM.cpp:775-779, :997-1000) hangs the point's OLD chain
+ * behind the feature of a new track (whose own earlier frames drop out of the chain: the assignment overwrites their link) --
+ * segments {slot, last, first, next} of a per-camera pool, `seg` the first of them or -1.
+ *   featRef [nMap][nCams][4] = {slot (< 0 none), frame, first, seg};  segPool [nCams][segCap][4] = {slot, last, first, next}.
+ * Pixels and poses of a node come from the history at entry curFrame - frame; a node older than the history (entry >= nHist) ends
+ * the walk, and so does the walkCap-th node of a chain (the bound every walk of this restatement has; the reference has none). */
+typedef struct {
+    int curFrame, nHist, walkCap, segCap, N, cmpAcos;
+    const int* segPool; /* or NULL */
+} opu_chain_ctx;
+
+/* the widest-parallax node behind the feature `ref` of camera c (first of equal angles in the walk, an angle of 0 never):
+ * /root/reference/src/slam/SL_CoSLAMHelper.cpp:362-373.  Returns 1 and (slot, history entry) of the node, 0 if there is none. */
+static int chain_widest(const opu_chain_ctx* X, int c, const int ref[4], const double* hR, const double* hT, const double* M,
+                        const double* C0, int* bestSlot, int* bestEntry) {
+    int found = 0, nodes = 1; /* (the feature itself is node 0) */
+    double bestCos = 1.0, bestAngle = 0.0;
+    int slot = ref[0], hi = ref[1] - 1, lo = ref[2], seg = ref[3];
+    for (;;) {
+        for (int f = hi; f >= lo; f--) {
+            const int j = X->curFrame - f;
+            if (j >= X->nHist || nodes >= X->walkCap) return found;
+            nodes++;
+            double Cj[3];
+            cam_center(hR + 9 * (size_t)j, hT + 3 * (size_t)j, Cj);
+            const double cv = cos_between(M, C0, Cj);
+            if (X->cmpAcos) {
+                const double ang = fabs(acos(cv));
+                if (ang > bestAngle) bestAngle = ang, *bestSlot = slot, *bestEntry = j, found = 1;
+            } else if (cv < bestCos)
+                bestCos = cv, *bestSlot = slot, *bestEntry = j, found = 1;
+        }
+        if (seg < 0 || !X->segPool || seg >= X->segCap) return found;
+        const int* g = X->segPool + ((size_t)c * X->segCap + seg) * 4;
+        slot = g[0], hi = g[1], lo = g[2], seg = g[3];
+    }
+}
+
+/* the reference of point m in camera c: from featRef when given, else the feature of this frame pointFeat names with its slot's track
+ * behind it (frames counted from curFrame = 0: only differences are used) */
+static void chain_ref(const int* featRef, const int* pointFeat, const int* trackSpan, int nCams, int N, int curFrame, int m, int c, int ref[4]) {
+    if (featRef) {
+        memcpy(ref, featRef + ((size_t)m * nCams + c) * 4, 16);
+        return;
+    }
+    const int s = pointFeat[(size_t)m * nCams + c];
+    ref[0] = s, ref[1] = curFrame, ref[2] = curFrame, ref[3] = -1;
+    if (s >= 0) {
+        const int f1 = trackSpan[(size_t)c * 2 * N + s], f2 = trackSpan[(size_t)c * 2 * N + N + s];
+        if (f1 >= 0) ref[2] = curFrame - (f2 - f1);
+    }
+}
+
 /* Layouts: Ks / iKs [nCams][9]; histR [nCams][nHist][9], histT [nCams][nHist][3], histXY [nCams][nHist][2N] with entry 0 = this
  * frame (the poses as they stand AFTER the adjustment); trackSpan [nCams][2N] (first | last frame of the slot's track),
  * featStatic [nCams][N] (1 = TYPE_FEATPOINT_STATIC); pointFeat [nMap][nCams] = the slot of the point's feature of this frame in
  * that camera, < 0 none; lastFrame [nMap] or NULL (= every point passes :250); isCurrent [nMap] or NULL (= all on curMapPts).
+ * featRef / segPool (or NULL): the features as references with their chains (above) -- then pointFeat and trackSpan are not read,
+ * stale features count as views with the pose of their own frame, and the walks follow the links.
  * chosen (or NULL): [nMap][nCams] the history entry taken as the second view (-1 none), for the tests.
  * Returns the number of points re-triangulated; *nStat / *nDyn count them by kind. */
 static int update_points_core(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR,
                               const double* histT, const double* histXY, const int* trackSpan, const unsigned char* featStatic,
                               int nMap, const int* pointFeat, const int* lastFrame, const unsigned char* isCurrent,
                               int firstKeyFrame, double* mapPts, double* mapCov, const unsigned char* mapFlags, double sigma,
-                              int cmpAcos, int* chosen, int* nStat, int* nDyn, int refine, const unsigned char* select) {
+                              int cmpAcos, int* chosen, int* nStat, int* nDyn, int refine, const unsigned char* select,
+                              const int* featRef, const int* segPool, int segCap, int curFrame, int walkCap) {
+    const opu_chain_ctx X = {featRef ? curFrame : 0, nHist, featRef ? walkCap : nHist, segCap, N, cmpAcos, segPool};
     int nUpd = 0, ns = 0, nd = 0;
     for (int m = 0; m < nMap; m++) {
         if (chosen)
@@ -284,40 +344,30 @@ static int update_points_core(int nCams, int N, int nHist, const double* Ks, con
         double* M = mapPts + 3 * (size_t)m;
         opu_normal_eq E;
         memset(&E, 0, sizeof(E));
-        int numView = 0, second[64];
+        int numView = 0, firstE[64], second[64];
         if (locStatic) { /* updateStaticPointPosition */
             for (int c = 0; c < nCams; c++) {
                 second[c] = -2;
-                const int s = pointFeat[(size_t)m * nCams + c];
-                if (s < 0) continue;
+                int ref[4];
+                chain_ref(featRef, pointFeat, trackSpan, nCams, N, X.curFrame, m, c, ref);
+                const int s = ref[0], j0 = X.curFrame - ref[1];
+                if (s < 0 || j0 >= nHist) continue; /* (a feature older than the history is no view) */
                 const double* hR = histR + (size_t)c * nHist * 9;
                 const double* hT = histT + (size_t)c * nHist * 3;
                 const double* hXY = histXY + (size_t)c * nHist * 2 * N;
                 const double* iK = iKs + 9 * c;
-                ne_add_view(&E, iK, hR, hT, hXY[s], hXY[N + s]); /* :347-356 */
+                firstE[c] = j0;
+                ne_add_view(&E, iK, hR + 9 * (size_t)j0, hT + 3 * (size_t)j0, hXY[(size_t)j0 * 2 * N + s], hXY[(size_t)j0 * 2 * N + N + s]); /* :347-356 */
                 numView++;
                 double C0[3];
-                cam_center(hR, hT, C0);
-                const int f1 = trackSpan[(size_t)c * 2 * N + s], f2 = trackSpan[(size_t)c * 2 * N + N + s];
-                const int len = f1 >= 0 ? f2 - f1 + 1 : 0;
-                const int depth = len < nHist ? len : nHist;
-                int best = -1;
-                double bestCos = 1.0, bestAngle = 0.0;
-                for (int j = 1; j < depth; j++) { /* :362-373 fp = fp->preFrame */
-                    double Cj[3];
-                    cam_center(hR + 9 * (size_t)j, hT + 3 * (size_t)j, Cj);
-                    const double cv = cos_between(M, C0, Cj);
-                    if (cmpAcos) {
-                        const double ang = fabs(acos(cv));
-                        if (ang > bestAngle) bestAngle = ang, best = j;
-                    } else if (cv < bestCos)
-                        bestCos = cv, best = j;
-                }
+                cam_center(hR + 9 * (size_t)j0, hT + 3 * (size_t)j0, C0);
+                int best = -1, bs = s;
+                if (!chain_widest(&X, c, ref, hR, hT, M, C0, &bs, &best)) best = -1; /* :362-373 fp = fp->preFrame */
                 second[c] = best;
                 if (chosen) chosen[(size_t)m * nCams + c] = best;
                 if (best >= 0) { /* :374-383 */
-                    ne_add_view(&E, iK, hR + 9 * (size_t)best, hT + 3 * (size_t)best, hXY[(size_t)best * 2 * N + s],
-                                hXY[(size_t)best * 2 * N + N + s]);
+                    ne_add_view(&E, iK, hR + 9 * (size_t)best, hT + 3 * (size_t)best, hXY[(size_t)best * 2 * N + bs],
+                                hXY[(size_t)best * 2 * N + N + bs]);
                     numView++;
                 }
             }
@@ -325,13 +375,17 @@ static int update_points_core(int nCams, int N, int nHist, const double* Ks, con
             int nDynamic = 0;
             for (int c = 0; c < nCams; c++) {
                 second[c] = -2;
-                const int s = pointFeat[(size_t)m * nCams + c];
-                if (s < 0) continue;
-                second[c] = -1;
-                ne_add_view(&E, iKs + 9 * c, histR + (size_t)c * nHist * 9, histT + (size_t)c * nHist * 3,
-                            histXY[(size_t)c * nHist * 2 * N + s], histXY[(size_t)c * nHist * 2 * N + N + s]);
+                int ref[4];
+                chain_ref(featRef, pointFeat, trackSpan, nCams, N, X.curFrame, m, c, ref);
+                const int s = ref[0], j0 = X.curFrame - ref[1];
+                if (s < 0 || j0 >= nHist) continue;
+                second[c] = -1, firstE[c] = j0;
+                ne_add_view(&E, iKs + 9 * c, histR + ((size_t)c * nHist + j0) * 9, histT + ((size_t)c * nHist + j0) * 3,
+                            histXY[((size_t)c * nHist + j0) * 2 * N + s], histXY[((size_t)c * nHist + j0) * 2 * N + N + s]);
                 numView++;
-                if (!featStatic[(size_t)c * N + s]) nDynamic++;
+                /* (fp->type of a stale feature: what it was in its own frame; the per-slot table knows this frame's only -- a stale
+                 * feature counts as static here) */
+                if (j0 == 0 && !featStatic[(size_t)c * N + s]) nDynamic++;
             }
             if (nDynamic < 1) continue; /* :475 */
         } else
@@ -347,7 +401,7 @@ static int update_points_core(int nCams, int N, int nHist, const double* Ks, con
             if (second[c] == -2) continue;
             const double* hR = histR + (size_t)c * nHist * 9;
             const double* hT = histT + (size_t)c * nHist * 3;
-            cov_add_view(S, Ks + 9 * c, hR, hT, M);
+            cov_add_view(S, Ks + 9 * c, hR + 9 * (size_t)firstE[c], hT + 3 * (size_t)firstE[c], M);
             if (second[c] >= 0) cov_add_view(S, Ks + 9 * c, hR + 9 * (size_t)second[c], hT + 3 * (size_t)second[c], M);
         }
         const double dS = sym33_cof(S, cf), s2 = sigma * sigma;
@@ -369,7 +423,17 @@ int opu_update_new_poses_points(int nCams, int N, int nHist, const double* Ks, c
                                 int firstKeyFrame, double* mapPts, double* mapCov, const unsigned char* mapFlags, double sigma,
                                 int cmpAcos, int* chosen, int* nStat, int* nDyn) {
     return update_points_core(nCams, N, nHist, Ks, iKs, histR, histT, histXY, trackSpan, featStatic, nMap, pointFeat, lastFrame, isCurrent,
-                              firstKeyFrame, mapPts, mapCov, mapFlags, sigma, cmpAcos, chosen, nStat, nDyn, 0, 0);
+                              firstKeyFrame, mapPts, mapCov, mapFlags, sigma, cmpAcos, chosen, nStat, nDyn, 0, 0, 0, 0, 0, 0, 0);
+}
+
+/* the same with the features as references (featRef / segPool: above update_points_core) */
+int opu_update_new_poses_points_ref(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR,
+                                    const double* histT, const double* histXY, const unsigned char* featStatic, int nMap,
+                                    const int* featRef, const int* segPool, int segCap, int curFrame, int walkCap, const int* lastFrame,
+                                    const unsigned char* isCurrent, int firstKeyFrame, double* mapPts, double* mapCov,
+                                    const unsigned char* mapFlags, double sigma, int cmpAcos, int* chosen, int* nStat, int* nDyn) {
+    return update_points_core(nCams, N, nHist, Ks, iKs, histR, histT, histXY, 0, featStatic, nMap, 0, lastFrame, isCurrent, firstKeyFrame,
+                              mapPts, mapCov, mapFlags, sigma, cmpAcos, chosen, nStat, nDyn, 0, 0, featRef, segPool, segCap, curFrame, walkCap);
 }
 
 /* CoSLAM::refineMapPoint (/root/reference/src/app/SL_CoSLAM.cpp:666-713) for the points `select` names (NULL: all): what the
@@ -383,7 +447,13 @@ int opu_refine_map_points(int nCams, int N, int nHist, const double* Ks, const d
                           const double* histXY, const int* trackSpan, int nMap, const int* pointFeat, const unsigned char* select,
                           double* mapPts, double* mapCov, double sigma, int cmpAcos) {
     return update_points_core(nCams, N, nHist, Ks, iKs, histR, histT, histXY, trackSpan, 0, nMap, pointFeat, 0, 0, 0, mapPts, mapCov, 0,
-                              sigma, cmpAcos, 0, 0, 0, 1, select);
+                              sigma, cmpAcos, 0, 0, 0, 1, select, 0, 0, 0, 0, 0);
+}
+int opu_refine_map_points_ref(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
+                              const double* histXY, int nMap, const int* featRef, const int* segPool, int segCap, int curFrame, int walkCap,
+                              const unsigned char* select, double* mapPts, double* mapCov, double sigma, int cmpAcos) {
+    return update_points_core(nCams, N, nHist, Ks, iKs, histR, histT, histXY, 0, 0, nMap, 0, 0, 0, 0, mapPts, mapCov, 0, sigma, cmpAcos, 0, 0, 0,
+                              1, select, featRef, segPool, segCap, curFrame, walkCap);
 }
 
 /* ---- CoSLAM::mapPointsClassify (/root/reference/src/app/SL_CoSLAM.cpp:418-520) --------------------------------------------------
@@ -673,37 +743,29 @@ int opu_map_points_classify(int nCams, int N, int nHist, const double* Ks, const
  * the walk runs over the whole track (no window), bounded by the history.  Returns 1 / 0; M and cov are written in either case.
  * Pinned against the reference's own function (tests/cxx/ref_update_points_test.cpp: halves of one point's cameras, and different
  * points); the device counterpart is cs_check_unify_dev (coslam_amd/csrc/poseupdate.hip: k_check_unify). */
-int opu_check_unify(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
-                    const double* histXY, const int* trackSpan, const int* pf1, const int* pf2, const double* M1, const double* M2,
-                    double sigma, int cmpAcos, double* M, double* cov) {
+static int check_unify_core(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
+                            const double* histXY, const int* trackSpan, const int* pf1, const int* pf2, const int* ref1, const int* ref2,
+                            const int* segPool, int segCap, int curFrame, int walkCap, const double* M1, const double* M2, double sigma,
+                            int cmpAcos, double* M, double* cov) {
+    const int byRef = ref1 != 0;
+    const opu_chain_ctx X = {byRef ? curFrame : 0, nHist, byRef ? walkCap : nHist, segCap, N, cmpAcos, segPool};
     opu_view v[128];
     int slotv[128], nv = 0;
     for (int c = 0; c < nCams; c++) {
         for (int which = 0; which < 2; which++) {
-            const int s = (which ? pf2 : pf1)[c];
-            if (s < 0) continue;
+            int ref[4];
+            /* (a point's row of references / of slots: chain_ref's m = 0 row of a one-point table) */
+            chain_ref(byRef ? (which ? ref2 : ref1) : 0, which ? pf2 : pf1, trackSpan, nCams, N, X.curFrame, 0, c, ref);
+            const int s = ref[0], j0 = X.curFrame - ref[1];
+            if (s < 0 || j0 >= nHist) continue;
             const double* Mold = which ? M2 : M1;
             const double* hR = histR + (size_t)c * nHist * 9;
             const double* hT = histT + (size_t)c * nHist * 3;
-            v[nv].c = c, v[nv].j = 0, slotv[nv] = s, nv++;
+            v[nv].c = c, v[nv].j = j0, slotv[nv] = s, nv++;
             double C0[3];
-            cam_center(hR, hT, C0);
-            const int f1 = trackSpan[(size_t)c * 2 * N + s], f2 = trackSpan[(size_t)c * 2 * N + N + s];
-            const int len = f1 >= 0 ? f2 - f1 + 1 : 0;
-            const int depth = len < nHist ? len : nHist;
-            int best = -1;
-            double bestCos = 1.0, bestAngle = 0.0;
-            for (int j = 1; j < depth; j++) {
-                double Cj[3];
-                cam_center(hR + 9 * (size_t)j, hT + 3 * (size_t)j, Cj);
-                const double cv = cos_between(Mold, C0, Cj);
-                if (cmpAcos) {
-                    const double ang = fabs(acos(cv));
-                    if (ang > bestAngle) bestAngle = ang, best = j;
-                } else if (cv < bestCos)
-                    bestCos = cv, best = j;
-            }
-            if (best >= 0) v[nv].c = c, v[nv].j = best, slotv[nv] = s, nv++;
+            cam_center(hR + 9 * (size_t)j0, hT + 3 * (size_t)j0, C0);
+            int best = -1, bs = s;
+            if (chain_widest(&X, c, ref, hR, hT, Mold, C0, &bs, &best)) v[nv].c = c, v[nv].j = best, slotv[nv] = bs, nv++;
         }
     }
     opu_normal_eq E;
@@ -739,4 +801,16 @@ int opu_check_unify(int nCams, int N, int nHist, const double* Ks, const double*
         if (maha_dist2(rm, h[slotv[i]], h[N + slotv[i]], ivar) > 1.0) return 0;
     }
     return 1;
+}
+int opu_check_unify(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
+                    const double* histXY, const int* trackSpan, const int* pf1, const int* pf2, const double* M1, const double* M2,
+                    double sigma, int cmpAcos, double* M, double* cov) {
+    return check_unify_core(nCams, N, nHist, Ks, iKs, histR, histT, histXY, trackSpan, pf1, pf2, 0, 0, 0, 0, 0, 0, M1, M2, sigma, cmpAcos, M, cov);
+}
+/* the same with the two points' features as references (ref1 / ref2 [nCams][4], segPool: above update_points_core) */
+int opu_check_unify_ref(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
+                        const double* histXY, const int* ref1, const int* ref2, const int* segPool, int segCap, int curFrame, int walkCap,
+                        const double* M1, const double* M2, double sigma, int cmpAcos, double* M, double* cov) {
+    return check_unify_core(nCams, N, nHist, Ks, iKs, histR, histT, histXY, 0, 0, 0, ref1, ref2, segPool, segCap, curFrame, walkCap, M1, M2, sigma,
+                            cmpAcos, M, cov);
 }

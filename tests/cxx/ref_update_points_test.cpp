@@ -10,6 +10,13 @@
 // current frame with a track of L <= H frames behind it (FeaturePoint::preFrame).  Scenes: moving rigs, a rig that stands still for
 // part of the history (equal angles: the first in the backward walk wins), cameras that only rotate (angle 0: no second view).
 //   ref_update_points_test golden <out.bin>
+//   ref_update_points_test golden_relink <out.bin>
+// golden_relink: chains as the registration loops leave them (src/app/SL_CoSLAM.cpp:775-779, :997-1000: `pFeat->preFrame =
+// p->pFeatures[iCam]` hangs the point's OLD chain behind the feature of a new track, whose own earlier frames drop out) and as a lost
+// track leaves them (nothing clears MapPoint::pFeatures[c]: the feature of an OLDER frame stays, and every loop here takes it as a
+// view with the pose of its own frame).  Per point and camera: 0-3 segments of consecutive frames, newest first, gaps in between, the
+// newest at the current frame or a few frames back (stale).  Same file layout except per point and camera: int32 nSeg, featDynamic,
+// per segment int32 j0 (history entry of its newest node), L, L x m[2].  Longer histories (40 / 70 frames), 4 scenes.
 // Layout of out.bin: int32 nScenes; per scene: int32 nCams, H, nPts, firstKeyFrame, curFrame; double sigma; per camera K[9], iK[9];
 // per camera and history entry (newest first) R[9], t[3]; per point: M[3], cov[9], int32 localType, uncertain, lastFrame, isCurrent,
 // per camera int32 L, int32 featDynamic, L x m[2] (newest first); then per point the reference's M[3], cov[9]; then per point int32
@@ -21,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "app/SL_CoSLAM.h"
@@ -52,17 +60,19 @@ template <class T> static void put(FILE* f, const T* p, size_t n) { fwrite(p, si
 static void puti(FILE* f, int v) { fwrite(&v, 4, 1, f); }
 
 int main(int argc, char** argv) {
-    if (argc < 3 || strcmp(argv[1], "golden")) {
-        fprintf(stderr, "usage: %s golden <out.bin>\n", argv[0]);
+    if (argc < 3 || (strcmp(argv[1], "golden") && strcmp(argv[1], "golden_relink"))) {
+        fprintf(stderr, "usage: %s golden|golden_relink <out.bin>\n", argv[0]);
         return 2;
     }
+    const bool relink = !strcmp(argv[1], "golden_relink");
+    int nStale = 0, nLinked = 0, nChains = 0;
     FILE* f = fopen(argv[2], "wb");
     if (!f) return 1;
-    const int nScenes = 6;
+    const int nScenes = relink ? 4 : 6;
     puti(f, nScenes);
     int nTouched = 0, nTotal = 0, nMoved2 = 0, nRefined = 0, nUnify = 0, nUnifyAll = 0;
     for (int sc = 0; sc < nScenes; ++sc) {
-        const int nCams = 2 + sc % 4, H = 6 + 5 * (sc % 3), nPts = 60, curFrame = 200 + sc, firstKey = curFrame - 12;
+        const int nCams = 2 + sc % 4, H = relink ? 40 + 30 * (sc % 2) : 6 + 5 * (sc % 3), nPts = 60, curFrame = 200 + sc, firstKey = curFrame - 12;
         // kind of motion: 0 moving rig, 1 stands still for the older half of the history, 2 rotation only
         const int motion = sc == 3 ? 1 : (sc == 4 ? 2 : 0);
         CoSLAM* co = new CoSLAM();
@@ -114,7 +124,46 @@ int main(int argc, char** argv) {
             const int isCur = urand() < 0.75;
             put(f, mp->M, 3), put(f, mp->cov, 9);
             puti(f, mp->iLocalType), puti(f, mp->bUncertain ? 1 : 0), puti(f, mp->lastFrame), puti(f, isCur);
-            for (int c = 0; c < nCams; ++c) {
+            for (int c = 0; c < nCams && relink; ++c) {
+                const double u2 = urand();
+                const int want = u2 < 0.2 ? 0 : (u2 < 0.4 ? 1 : (u2 < 0.8 ? 2 : 3));
+                const int dyn = urand() < 0.35;
+                int j = (want > 0 && urand() < 0.3) ? 1 + (int)(urand() * 6) : 0;   // a stale head: the camera lost the point j frames ago
+                std::vector<std::pair<int, int> > segs;   // (newest entry, nodes)
+                for (int q = 0; q < want && j < H; ++q) {
+                    int L = 1 + (int)(urand() * (q == 0 && want > 1 ? 10 : 25));   // (a freshly re-linked head is 1 node long)
+                    if (q == 0 && want > 1 && urand() < 0.3) L = 1;
+                    if (j + L > H) L = H - j;
+                    segs.push_back(std::make_pair(j, L));
+                    j += L + 1 + (int)(urand() * 12);   // the frames in which the camera did not see the point
+                }
+                puti(f, (int)segs.size()), puti(f, dyn);
+                if (!segs.empty()) ++nChains, nStale += segs[0].first > 0, nLinked += segs.size() > 1;
+                FeaturePoint* newer = nullptr;
+                for (size_t q = 0; q < segs.size(); ++q) {
+                    puti(f, segs[q].first), puti(f, segs[q].second);
+                    for (int jj = segs[q].first; jj < segs[q].first + segs[q].second; ++jj) {
+                        const double* R = cams[c][jj]->R;
+                        const double* t = cams[c][jj]->t;
+                        const double* K = Ks[c].data();
+                        double Xc[3], m[2];
+                        for (int r = 0; r < 3; ++r) Xc[r] = R[3 * r] * X[0] + R[3 * r + 1] * X[1] + R[3 * r + 2] * X[2] + t[r];
+                        m[0] = (K[0] * Xc[0] + K[1] * Xc[1] + K[2] * Xc[2]) / Xc[2] + 0.6 * nrand();
+                        m[1] = (K[4] * Xc[1] + K[5] * Xc[2]) / Xc[2] + 0.6 * nrand();
+                        put(f, m, 2);
+                        FeaturePoint* fp = new FeaturePoint(curFrame - jj, c, m[0], m[1]);
+                        fp->setIntrinsic(K);
+                        fp->setCameraPose(cams[c][jj]);
+                        fp->type = dyn ? TYPE_FEATPOINT_DYNAMIC : TYPE_FEATPOINT_STATIC;
+                        fp->preFrame = nullptr;
+                        if (newer) newer->preFrame = fp, fp->nextFrame = newer;   // (across a gap: what :777-778 assigns)
+                        else mp->pFeatures[c] = fp;
+                        newer = fp;
+                        allFp.push_back(fp);
+                    }
+                }
+            }
+            for (int c = 0; c < nCams && !relink; ++c) {
                 const int L = (urand() < 0.3) ? 0 : 1 + (int)(urand() * H);
                 const int dyn = urand() < 0.35;
                 puti(f, L), puti(f, dyn);
@@ -229,5 +278,9 @@ int main(int argc, char** argv) {
     fclose(f);
     printf("ref_update_points_test: %d scenes, %d of %d points re-triangulated, %d wild coordinates; refineMapPoint on %d points; checkUnify: %d of %d pairs unify\n",
            nScenes, nTouched, nTotal, nMoved2, nRefined, nUnify, nUnifyAll);
+    if (relink) {
+        printf("  chains: %d, with a stale head %d, with an older segment linked behind %d\n", nChains, nStale, nLinked);
+        return (nTouched > nTotal / 5 && nMoved2 == 0 && nRefined > nTotal / 5 && nStale > 40 && nLinked > 100 && nUnify > 10) ? 0 : 1;
+    }
     return (nTouched > nTotal / 4 && nTouched < nTotal && nMoved2 == 0 && nRefined > nTotal / 4 && nUnify > 20 && nUnifyAll - nUnify > 20) ? 0 : 1;
 }

@@ -596,6 +596,109 @@ def update_points_case():
     return out
 
 
+def update_points_relink_case():
+    """re-linked and stale feature chains (oracle/_ref/ref_update_points_test golden_relink, CPU): the reference's own
+    updateNewPosesPoints / refineMapPoint / checkUnify over chains as `pFeat->preFrame = p->pFeatures[iCam]` (SL_CoSLAM.cpp:775-779) and a
+    lost track leave them, re-laid out the way the device holds them: every segment of consecutive frames on a slot of its own (slot =
+    running number per camera), featRef [nP][nC][4] = {slot, frame, first, seg}, segPool [nC][cap][4] = {slot, last, first, next}."""
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_update_points_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_update_points_test missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "u.bin")
+        subprocess.run([exe, "golden_relink", path], check=True, stdout=subprocess.DEVNULL)
+        raw = open(path, "rb").read()
+    o = 0
+
+    def ints(n):
+        nonlocal o
+        v = np.frombuffer(raw, dtype=np.int32, count=n, offset=o).copy()
+        o += 4 * n
+        return v
+
+    def dbls(n):
+        nonlocal o
+        v = np.frombuffer(raw, dtype=np.float64, count=n, offset=o).copy()
+        o += 8 * n
+        return v
+
+    out = {}
+    (nS,) = ints(1)
+    out["n_scenes"] = np.int32(nS)
+    for sc in range(nS):
+        nC, H, nP, firstKey, cur = ints(5)
+        (sigma,) = dbls(1)
+        K, iK = np.zeros((nC, 9)), np.zeros((nC, 9))
+        for c in range(nC):
+            K[c], iK[c] = dbls(9), dbls(9)
+        hR, hT = np.zeros((nC, H, 9)), np.zeros((nC, H, 3))
+        for c in range(nC):
+            for j in range(H):
+                hR[c, j], hT[c, j] = dbls(9), dbls(3)
+        N = 3 * nP                                           # at most three segments per (point, camera), each on its own slot
+        hXY = np.full((nC, H, 2 * N), np.nan)                # (a pixel nobody should read)
+        fstat = np.ones((nC, N), np.uint8)
+        ref = np.full((nP, nC, 4), -1, np.int32)
+        pool = np.full((nC, 2 * nP, 4), -1, np.int32)
+        nslot, npool = [0] * nC, [0] * nC
+        M0, cov0 = np.zeros((nP, 3)), np.zeros((nP, 9))
+        flags, lastF, isCur = np.zeros(nP, np.uint8), np.zeros(nP, np.int32), np.zeros(nP, np.uint8)
+        for p in range(nP):
+            M0[p], cov0[p] = dbls(3), dbls(9)
+            ltype, unc, lastF[p], isCur[p] = ints(4)
+            flags[p] = (1 if ltype == 1 else 0) | (2 if ltype == -2 else 0) | (4 if unc else 0)
+            for c in range(nC):
+                nSeg, dyn = ints(2)
+                segs = []
+                for q in range(nSeg):
+                    j0, L = ints(2)
+                    m = dbls(2 * L).reshape(L, 2)
+                    s_ = nslot[c]
+                    nslot[c] += 1
+                    hXY[c, j0:j0 + L, s_], hXY[c, j0:j0 + L, N + s_] = m[:, 0], m[:, 1]
+                    segs.append((s_, cur - j0, cur - (j0 + L - 1)))
+                    if q == 0:
+                        fstat[c, s_] = 0 if dyn else 1
+                nxt = -1
+                for s_, last, first in reversed(segs[1:]):   # the oldest segment first: each names the one behind it
+                    pool[c, npool[c]] = (s_, last, first, nxt)
+                    nxt = npool[c]
+                    npool[c] += 1
+                if segs:
+                    ref[p, c] = (segs[0][0], segs[0][1], segs[0][2], nxt)
+        Mr, covr = np.zeros((nP, 3)), np.zeros((nP, 9))
+        for p in range(nP):
+            Mr[p], covr[p] = dbls(3), dbls(9)
+        rsel, Mf, covf = np.zeros(nP, np.uint8), np.zeros((nP, 3)), np.zeros((nP, 9))
+        for p in range(nP):
+            (rs_,) = ints(1)
+            rsel[p], Mf[p], covf[p] = rs_, dbls(3), dbls(9)
+        (nU,) = ints(1)
+        up = np.zeros((nU, 2), np.int32)
+        uh1, uh2 = np.zeros((nU, nC), np.uint8), np.zeros((nU, nC), np.uint8)
+        uM1, uM2, uM, ucov, uok = np.zeros((nU, 3)), np.zeros((nU, 3)), np.zeros((nU, 3)), np.zeros((nU, 9)), np.zeros(nU, np.uint8)
+        for q in range(nU):
+            up[q] = ints(2)
+            hh = ints(2 * nC).reshape(nC, 2)
+            uh1[q], uh2[q] = hh[:, 0], hh[:, 1]
+            uM1[q], uM2[q] = dbls(3), dbls(3)
+            (uok[q],) = ints(1)
+            uM[q], ucov[q] = dbls(3), dbls(9)
+        pre = f"s{sc}_"
+        for k, v in dict(unify_pts=up, unify_has1=uh1, unify_has2=uh2, unify_M1=uM1, unify_M2=uM2, unify_ok=uok, unify_M=uM,
+                         unify_cov=ucov).items():
+            out[pre + k] = v
+        for k, v in dict(K=K, iK=iK, histR=hR, histT=hT, histXY=hXY, featStatic=fstat, featRef=ref, segPool=pool, M0=M0, cov0=cov0,
+                         flags=flags, lastFrame=lastF, isCurrent=isCur, firstKey=np.int32(firstKey), curFrame=np.int32(cur),
+                         sigma=np.float64(sigma), M_ref=Mr, cov_ref=covr, refine_select=rsel, M_refine=Mf, cov_refine=covf).items():
+            out[pre + k] = v
+    assert o == len(raw)
+    return out
+
+
 def classify_case():
     """the reference's own CoSLAM::mapPointsClassify over isStaticPoint / isStaticPointExclude / isDynamicPoint / isLittleMove /
     isStaticRemovable (oracle/_ref/ref_classify_test golden, CPU): 3 scenes of 72 map points walking every branch, re-laid out the
@@ -685,7 +788,7 @@ def classify_case():
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "mergability_long", "update_points", "classify", "intercam", "newpts", "decide"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "mergability_long", "update_points", "update_points_relink", "classify", "intercam", "newpts", "decide"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -708,6 +811,8 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "mergability_long_golden.npz"), **mergability_long_case())
     if "update_points" in which:
         np.savez_compressed(os.path.join(HERE, "update_points_golden.npz"), **update_points_case())
+    if "update_points_relink" in which:
+        np.savez_compressed(os.path.join(HERE, "update_points_relink_golden.npz"), **update_points_relink_case())
     if "classify" in which:
         np.savez_compressed(os.path.join(HERE, "classify_golden.npz"), **classify_case())
     if "decide" in which:

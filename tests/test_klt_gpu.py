@@ -687,12 +687,14 @@ def test_cu_masked_stream_and_budget(hip):
     lib.cs_stream_destroy(C.c_void_p(h))
 
 
-@pytest.mark.parametrize("n_cams,prefetch", [(8, True), (3, False), (13, True)])
+@pytest.mark.parametrize("n_cams,prefetch", [(8, True), (3, False), (13, True), (4, False)])
 def test_camera_group_is_bit_identical_to_single_handles(hip, n_cams, prefetch):
     """cs_klt_group_*: the frame schedule of several cameras in ONE set of launches (camera = one more grid dimension, the
     gain tracker of all cameras in one persistent launch) must give exactly what driving each handle on its own gives:
     detect, redetect and track-only frames, with and without the frame-front prefetch, dest[] / counts / feature lists.
-    13 cameras (SLAM_MAX_NUM) x 2000 slots exceed the resident waves of one persistent launch -> two launches in a row."""
+    13 cameras (SLAM_MAX_NUM) x 2000 slots exceed the resident waves of one persistent launch -> two launches in a row.
+    cs_klt_set_xcd_placement (a camera's workgroups numbered onto its own XCDs: 8 cameras one XCD each, 4 cameras two each, 13 = 8
+    placed + 5 as grid rows, 3 not placed at all) changes where workgroups run and nothing else: the same bits."""
     import torch
 
     W, H, L, fw, fh = 640, 480, 4, 50, 40
@@ -703,11 +705,12 @@ def test_camera_group_is_bit_identical_to_single_handles(hip, n_cams, prefetch):
     frames = [[torch.from_numpy(sc.render(c % 8, f + (c // 8))).to(dev) for f in range(nf)] for c in range(n_cams)]
     plan = ["detect", "redetect", "redetect", "track", "redetect", "redetect", "redetect"]
 
-    def run(grouped):
+    def run(grouped, placed=False):
         ts = [coslam_amd.KLT_SequenceTracker(cfg, 0) for _ in range(n_cams)]
         for t in ts:
             t.allocate(W, H, L, fw, fh)
             t.set_stream(torch.cuda.current_stream().cuda_stream)
+            t.set_xcd_placement(placed)
         grp = coslam_amd.KLT_TrackerGroup(ts) if grouped else None
         if grp:
             grp.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -739,16 +742,17 @@ def test_camera_group_is_bit_identical_to_single_handles(hip, n_cams, prefetch):
             t.close()
         return out, feats
 
-    (single, f_single), (group, f_group) = run(False), run(True)
-    for s_ in range(len(plan)):
-        for c in range(n_cams):
-            (da, ca), (db, cb) = single[s_][c], group[s_][c]
-            assert np.array_equal(ca, cb), (s_, c, ca, cb)
-            assert np.array_equal(da["status"], db["status"]), (s_, c)
-            live = da["status"] >= 0
-            assert np.array_equal(da["pos"][live], db["pos"][live]), (s_, c)
-            assert np.array_equal(da["gain"][live], db["gain"][live]), (s_, c)
-            assert np.array_equal(f_single[s_][c], f_group[s_][c]), (s_, c)
+    (single, f_single), (group, f_group), (placed, f_placed) = run(False), run(True), run(True, placed=True)
+    for other, f_other in ((group, f_group), (placed, f_placed)):
+        for s_ in range(len(plan)):
+            for c in range(n_cams):
+                (da, ca), (db, cb) = single[s_][c], other[s_][c]
+                assert np.array_equal(ca, cb), (s_, c, ca, cb)
+                assert np.array_equal(da["status"], db["status"]), (s_, c)
+                live = da["status"] >= 0
+                assert np.array_equal(da["pos"][live], db["pos"][live]), (s_, c)
+                assert np.array_equal(da["gain"][live], db["gain"][live]), (s_, c)
+                assert np.array_equal(f_single[s_][c], f_other[s_][c]), (s_, c)
     assert (single[-1][0][0]["status"] == 0).sum() > 300
 
 

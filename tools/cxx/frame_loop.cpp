@@ -187,6 +187,10 @@ int main(int argc, char** argv) {
         return 3;
     }
     CSCHK(cs_klt_group_set_stream(grp, (void*)kltS));
+    {   // a camera's tracker workgroups on that camera's own XCD (COSLAM_KLT_XCD=0: cameras as grid rows, for the A/B)
+        const char* e = getenv("COSLAM_KLT_XCD");
+        for (cs_klt* k : trk) CSCHK(cs_klt_set_xcd_placement(k, !(e && e[0] == '0')));
+    }
     if (camsPerLaunch > 0)  // the co-residency budget of `camsPerLaunch` cameras (250 waves each, 8 resident waves per CU)
         for (cs_klt* k : trk) CSCHK(cs_klt_set_cu_count(k, std::min(256, (250 * camsPerLaunch + 60) / 8 + 5)));
 
