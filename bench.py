@@ -503,6 +503,9 @@ def main():
                          "N > 1: 12 (every rank must take the same number of steps)")
     ap.add_argument("--klt-xcd-placement", type=int, default=int(os.environ.get("BENCH_KLT_XCD", "1")),
                     help="1: the persistent tracker numbers its workgroups so that a camera lands on its own XCD; 0: cameras as grid rows")
+    ap.add_argument("--feature-chains", type=int, default=1,
+                    help="1: MapPoint::pFeatures kept as feature references (stale features are views, re-linked tracks: SL_CoSLAM.cpp:775-779); "
+                         "0: this frame's features on their own tracks (rounds 1-4)")
     ap.add_argument("--klt-cus", type=int, default=int(os.environ.get("BENCH_KLT_CUS", "0")),
                     help="> 0: the tracker stream confined to that many CU-mask bits (multiples of 32: the same CUs of every XCD); experiment")
     ap.add_argument("--pose-cus", type=int, default=int(os.environ.get("BENCH_POSE_CUS", "0")),
@@ -578,7 +581,7 @@ def main():
                      prefetch=os.environ.get("BENCH_PREFETCH", "1") != "0", with_pose_update=not args.no_pose_update,
                      with_classify=not args.no_classify, with_register=not args.no_register, with_mergability=not args.no_mergability,
                      with_ncc=not args.no_ncc, with_decide=not args.no_decide, merge_every=args.merge_every, hist=args.hist, hist_store=args.hist_store, with_active_search=bool(args.active_search), pixel_err_reading=args.pixel_err_reading, with_joint=args.only_solve != "intercam", with_intercam=args.only_solve != "joint",
-                     native_comm=bool(args.native_comm), klt_cus=args.klt_cus, pose_cus=args.pose_cus, klt_xcd_placement=bool(args.klt_xcd_placement),
+                     native_comm=bool(args.native_comm), klt_cus=args.klt_cus, pose_cus=args.pose_cus, klt_xcd_placement=bool(args.klt_xcd_placement), feature_chains=bool(args.feature_chains),
                      klt_after_intracam=bool(args.klt_after_intracam),
                      klt_fused=os.environ.get("BENCH_FORCE_DEVICE") is None or world == 1)   # (ranks sharing ONE GPU: test hook)
     try:
@@ -1124,6 +1127,14 @@ def main():
                                  "by one term per frame (cs_register_mergability_running_dev); counts summed over the whole run"),
                         "active_search": "off: the reference's activeMapPointsRegister cannot attach (numVisCam == 0 on actMapPts, SL_CoSLAM.cpp:1114; "
                                          "tests/cxx/ref_active_test.cpp)" if not cfg.with_active_search else "on (diagnostic)"},
+                       "feature_references": None if getattr(loop, "d_fref", None) is None else dict(zip(
+                           ("tracked_on", "first_features", "re_linked_behind_an_older_feature", "links_dropped_pool_full", "detached"),
+                           loop.d_fref_counts.cpu().tolist()),
+                           stale_now=int(((loop.d_fref[:, :, 0] >= 0) & (loop.d_fref[:, :, 1] < loop._frame_now)).sum().item()),
+                           linked_segments_per_camera=loop.pose_upd.segment_counts()[0].tolist(),
+                           what="MapPoint::pFeatures as the reference holds them (cs_feat_ref): a camera that lost a point keeps its last feature "
+                                "as a view of refineMapPoint / updateNewPosesPoints, a point registered to a new track where it held an older "
+                                "feature gets the old chain linked behind it (SL_CoSLAM.cpp:775-779); counts summed over the whole run"),
                        "register_decision": None if dec_counts is None else dict(zip(
                            ("features_attached_last_frame", "points_regged_last_frame", "sweeps_last_frame", "converged"), dec_counts[0]),
                            points_refined_last_frame=dec_counts[1],

@@ -292,6 +292,11 @@ class BAOutput:
                                                  C.c_double(pixelErrVar), int(first_key_frame), int(key_every), vp(d_Rcur), vp(d_tcur),
                                                  vp(d_counts)), "cs_ba_output_apply_seq_dev")
 
+    def set_feat_refs(self, d_featRef, d_refStatic=None):
+        """updateNewPosesPoints of every later apply over feature references (cs_feat_ref_advance_dev's table; None: this frame's features)"""
+        check(self._L.cs_ba_output_set_feat_refs(self._h, C.c_void_p(d_featRef),
+                                                 C.c_void_p(d_refStatic)), "cs_ba_output_set_feat_refs")
+
     def set_apply_mask(self, mask):
         """diagnostic (tools/r05_drift.py): 1 key poses + relaxation, 2 points, 4 outlier points false, 8 updateNewPosesPoints; 15 = all"""
         self._L.cs_ba_output_set_apply_mask.argtypes = [C.c_void_p, C.c_int]

@@ -2920,6 +2920,8 @@ struct cs_ba_output {
     unsigned char* slab;  // nSlots records of L.bytes
     int* d_err;           // [2]: cs_ba_output_wait_dev's waits that gave up; records cs_ba_output_apply_seq_dev refused (not the one expected)
     int applyMask;        // cs_ba_output_set_apply_mask (diagnostic): which parts of output() an apply performs
+    const void* featRef = nullptr;            // cs_ba_output_set_feat_refs: [nMap][nCams] cs_feat_ref or null
+    const unsigned char* refStatic = nullptr;
     std::mutex mu;
     std::condition_variable cv;
     long long issued;     // records the worker has started to pack (its slot = issued % nSlots)
@@ -4478,6 +4480,15 @@ static int bo_ensure_graph(cs_ba_output* o, int nNodes, int keyEvery) {
 // The key frames of the record must be firstKeyFrame + j * keyEvery, j < nKeyFrames (the caller knows its own schedule; the
 // record's header is not read back).  A record whose solve failed (ok = 0) moves nothing but still relaxes (a no-op up to rounding).
 // d_counts [3] or NULL: static / dynamic points re-triangulated, points that became false.
+// updateNewPosesPoints of every later apply over feature references (cs_feat_ref_advance_dev keeps the table; NULL: this frame's features)
+int cs_ba_output_set_feat_refs(cs_ba_output* o, const void* d_featRef, const unsigned char* d_refStatic) {
+    if (!o) {
+        cs_set_error("cs_ba_output_set_feat_refs: null handle");
+        return CS_ERR_INVALID;
+    }
+    o->featRef = d_featRef, o->refStatic = d_refStatic;
+    return CS_OK;
+}
 int cs_ba_output_apply_dev(cs_ba_output* o, const void* d_record, void* hip_stream, cs_track_history* h, cs_ba_window* w,
                            const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap, double* d_mapPts, double* d_mapCov,
                            unsigned char* d_mapFlags, double pixelErrVar, int firstKeyFrame, int keyEvery, double* d_Rcur, double* d_tcur,
@@ -4545,6 +4556,9 @@ int cs_ba_output_apply_seq_dev(cs_ba_output* o, const void* d_record, long long 
     hipLaunchKernelGGL(k_ba_output_tail, dim3((o->nCams * 12 + 255) / 256), dim3(256), 0, s, o->nCams, nNodes, o->newR, o->newT, d_Rcur, d_tcur);
     CS_CHECK_LAUNCH();
     if (!(mask & CS_BA_APPLY_UPDATE)) return CS_OK;
+    if (o->featRef)   // MapPoint::pFeatures as references: stale features are views, the walks follow re-linked chains, the frame test from them
+        return cs_update_new_poses_points_ref_dev(h, hip_stream, cams, (const cs_feat_ref*)o->featRef, o->refStatic, nMap, nullptr, nullptr,
+                                                  firstKeyFrame, d_mapPts, d_mapCov, d_mapFlags, pixelErrVar, d_counts);
     return cs_update_new_poses_points_dev(h, hip_stream, cams, d_pointFeat, nMap, nullptr, nullptr, firstKeyFrame, d_mapPts, d_mapCov,
                                           d_mapFlags, pixelErrVar, d_counts);
 }

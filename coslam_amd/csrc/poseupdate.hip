@@ -37,6 +37,7 @@
 // LibVisualSLAM (only their calls are in the reference): definitions in DESIGN.md, the same as register.hip / ncc.hip use;
 // seqTriangulate = one Kalman update of (M, cov) from the measurement with noise sigma^2 I.
 #include <cstdlib>
+#include <vector>
 
 #include "cs_common.h"
 #include "small_ops.h"
@@ -636,9 +637,15 @@ struct UpArgs {
     const double* cen;  // [nCams][nHist][3] camera centres by walk depth (0 = this frame): k_ring_centres, once per launch
     int refine;                   // CoSLAM::refineMapPoint: the points `select` names, whatever their type, no frame test
     const unsigned char* select;  // [nMap] or null (= all)
+    // the features as REFERENCES (cs_feat_ref: MapPoint::pFeatures[c] of whatever age, with its preFrame chain) instead of pointFeat
+    const int4* featRef;              // [nMap][nCams] {slot, frame, first, seg} or null
+    const unsigned char* refStatic;   // [nMap][nCams] the features' types in their own frames, or null (= isStatic of the slot)
+    const int4* segPool;              // [nCams][segCap] {slot, last, first, next}
+    int segCap, curFrame, stored;     // stored: frames the ring holds (a node further back ends a walk)
     cs_poseupdate_cam cam[PU_MAX_CAMS];
 };
 constexpr int UP_LPP = 64;  // a WAVE per map point
+
 static_assert(UP_LPP == 64 && PU_MAX_CAMS <= UP_LPP, "the covariance tail broadcasts from lane = camera of the point's own wave");
 
 struct UpNormalEq {
@@ -682,6 +689,74 @@ __device__ __forceinline__ void up_cam_center(const double* __restrict__ R, cons
     for (int i = 0; i < 3; ++i) C[i] = -((R[i] * t[0] + R[3 + i] * t[1]) + R[6 + i] * t[2]);
 }
 
+// ---- walks along FeaturePoint::preFrame ------------------------------------------------------------------------------------------------------
+// A point's feature in a camera as the reference holds it: MapPoint::pFeatures[c] -- of this frame, or an older one when the camera lost
+// the point (nothing clears the pointer) -- and the chain behind it: consecutive frames on the feature's own slot, frame - 1 .. first,
+// then the segments the registration loops linked behind it (`pFeat->preFrame = p->pFeatures[iCam]`, src/app/SL_CoSLAM.cpp:775-779,
+// :997-1000: the point's OLD chain hangs behind the feature of the new track, whose own earlier frames drop out).  Pixels and poses of a
+// node are the ring's entry of its frame.  The walks are bounded by `cap` NODES (the reference's are not) and end at a node older than the
+// ring.  The plain tables (pointFeat + trackSpan) are the special case {slot, this frame, the track's first frame, no segment}.
+struct ChainCtx {
+    int N, H, head, cap, curFrame, stored, segCap, nCen;
+    const double* cen;     // [nCams][nCen][3] camera centres of ring depths < nCen
+    const int4* segPool;   // or null
+};
+// the widest-parallax node behind `ref` around point M seen from centre C0 (a = C0 - M, na = |a|^2): the smallest cosine, the first of
+// equal ones in walk order, never an angle of 0 (cosine 1).  Wave-cooperative (lane r takes every 64th node of a segment); every lane
+// returns the node's ring depth (-1: none) and its slot.
+__device__ __forceinline__ int chain_widest(const ChainCtx& X, int c, int4 ref, const double* __restrict__ hR, const double* __restrict__ hT,
+                                            const double* a, double na, const double* M, int r, int& bestSlot) {
+    int best = -1, bestK = 0x7fffffff, bSlot = -1;
+    double bestCos = 1.0;
+    int slot = ref.x, hi = ref.y - 1, lo = ref.z, seg = ref.w, k0 = 1;   // (node 0 is the feature itself)
+    for (;;) {
+        const int oldest = X.curFrame - X.stored + 1;   // the oldest frame the ring holds
+        int cnt = hi - (lo > oldest ? lo : oldest) + 1;
+        const bool cut = lo < oldest;
+        if (cnt > X.cap - k0) cnt = X.cap - k0;
+        for (int i = r; i < cnt; i += 64) {
+            const int j = X.curFrame - (hi - i);
+            double Cj[3];
+            if (j < X.nCen) {
+                const double* q = X.cen + 3 * ((size_t)c * X.nCen + j);
+                Cj[0] = q[0], Cj[1] = q[1], Cj[2] = q[2];
+            } else {
+                const int rs = ((X.head - j) % X.H + X.H) % X.H;
+                up_cam_center(hR + (size_t)rs * 9, hT + (size_t)rs * 3, Cj);
+            }
+            const double b0 = Cj[0] - M[0], b1 = Cj[1] - M[1], b2 = Cj[2] - M[2];
+            const double d = (a[0] * b0 + a[1] * b1) + a[2] * b2;
+            const double nb = (b0 * b0 + b1 * b1) + b2 * b2;
+            const double cv = d / sqrt(na * nb);
+            if (cv < bestCos) bestCos = cv, best = j, bestK = k0 + i, bSlot = slot;   // (i ascending: the first of equal cosines stays)
+        }
+        if (cnt > 0) k0 += cnt;
+        if (cut || k0 >= X.cap || seg < 0 || !X.segPool || seg >= X.segCap) break;
+        const int4 g = X.segPool[(size_t)c * X.segCap + seg];
+        slot = g.x, hi = g.y, lo = g.z, seg = g.w;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double oc = __shfl_xor(bestCos, off, 64);
+        const int oj = __shfl_xor(best, off, 64), ok = __shfl_xor(bestK, off, 64), os = __shfl_xor(bSlot, off, 64);
+        if (oj >= 0 && (oc < bestCos || (oc == bestCos && ok < bestK))) bestCos = oc, best = oj, bestK = ok, bSlot = os;
+    }
+    bestSlot = bSlot;
+    return best;
+}
+// the reference of map point m in camera c: the table's, or the feature of this frame pointFeat names with its slot's track behind it
+// (frames then count from curFrame = 0: only differences are used)
+__device__ __forceinline__ int4 chain_ref(const int4* featRef, const int* pointFeat, const cs_poseupdate_cam& C, int N, int nCams, int m, int c) {
+    if (featRef) return featRef[(size_t)m * nCams + c];
+    const int s = pointFeat[(size_t)m * nCams + c];
+    int4 ref = make_int4(s, 0, 0, -1);
+    if (s >= 0) {
+        const int f1 = C.trackSpan[s], f2 = C.trackSpan[N + s];
+        if (f1 >= 0) ref.z = -(f2 - f1);
+    }
+    return ref;
+}
+
 // the camera centres of all (camera, ring entry) pairs by walk depth: every point's walk reads the same nCams x nHist of them
 __global__ __launch_bounds__(256) void k_ring_centres(int nCams, int H, int head, int nHist, const double* __restrict__ hR,
                                                       const double* __restrict__ hT, double* __restrict__ cen) {
@@ -698,8 +773,16 @@ __global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
     if (m >= A.nMap) return;
     if (A.refine) {
         if (A.select && !A.select[m]) return;
-    } else if (A.lastFrame && A.lastFrame[m] <= A.firstKeyFrame)
-        return;  // :250, :261
+    } else if (A.lastFrame) {
+        if (A.lastFrame[m] <= A.firstKeyFrame) return;  // :250, :261
+    } else if (A.featRef) {  // MapPoint::lastFrame = the newest frame a camera saw the point in (propagateFeatureStates, SL_SingleSLAM.cpp:51)
+        int lastF = -0x7fffffff;
+        for (int c = 0; c < A.nCams; ++c) {
+            const int4 q = A.featRef[(size_t)m * A.nCams + c];
+            if (q.x >= 0 && q.y > lastF) lastF = q.y;
+        }
+        if (lastF <= A.firstKeyFrame) return;
+    }
     const unsigned char fl = A.refine ? 0 : A.mapFlags[m];  // (refineMapPoint asks nothing about the point's type)
     const bool locStatic = (fl & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) == 0;               // isLocalStatic()
     const bool locDynamic = (fl & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) == CS_MAP_DYNAMIC;  // isLocalDynamic()
@@ -715,50 +798,39 @@ __global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) E.g[q] = 0;
     int numView = 0, nDynamic = 0;
-    int mySecond = -2;  // lane r keeps camera r's second view: ring depth, -1 none, -2 the camera holds no feature of the point
+    int mySecond = -2, myFirst = 0;  // lane r keeps camera r's views: ring depths; second -1 none, -2 the camera holds no feature of the point
+    ChainCtx X;
+    X.N = N, X.H = H, X.head = A.head, X.cap = A.nHist, X.curFrame = A.featRef ? A.curFrame : 0, X.stored = A.featRef ? A.stored : A.nHist;
+    X.segCap = A.segCap, X.nCen = A.nHist, X.cen = A.cen, X.segPool = A.segPool;
     for (int c = 0; c < A.nCams; ++c) {
-        const int s = A.pointFeat[(size_t)m * A.nCams + c];
-        if (s < 0) continue;
         const cs_poseupdate_cam& C = A.cam[c];
+        const int4 ref = chain_ref(A.featRef, A.pointFeat, C, N, A.nCams, m, c);
+        const int s = ref.x, j0 = X.curFrame - ref.y;
+        if (s < 0 || j0 >= X.stored) continue;   // (a feature older than the ring is no view)
         const double* hR = A.histR + (size_t)c * H * 9;
         const double* hT = A.histT + (size_t)c * H * 3;
         const double* hXY = A.histXY + (size_t)c * H * 2 * N;
-        const double* R0 = hR + (size_t)A.head * 9;
-        const double* t0 = hT + (size_t)A.head * 3;
-        up_add_view(E, C.iK, R0, t0, hXY[(size_t)A.head * 2 * N + s], hXY[(size_t)A.head * 2 * N + N + s]);  // :347-356 / :463-470
+        const int rs0 = (A.head - j0 + H) % H;
+        const double* R0 = hR + (size_t)rs0 * 9;
+        const double* t0 = hT + (size_t)rs0 * 3;
+        up_add_view(E, C.iK, R0, t0, hXY[(size_t)rs0 * 2 * N + s], hXY[(size_t)rs0 * 2 * N + N + s]);  // :347-356 / :463-470
         ++numView;
         int best = -1;
         if (locStatic) {
             double C0[3];
             up_cam_center(R0, t0, C0);
-            const double a0 = C0[0] - M[0], a1 = C0[1] - M[1], a2 = C0[2] - M[2];
-            const double na = (a0 * a0 + a1 * a1) + a2 * a2;
-            const int f1 = C.trackSpan[s], f2 = C.trackSpan[N + s];
-            const int len = f1 >= 0 ? f2 - f1 + 1 : 0;
-            const int depth = len < A.nHist ? len : A.nHist;
-            double bestCos = 1.0;
-            for (int j = 1 + r; j < depth; j += UP_LPP) {  // :362-373 fp = fp->preFrame
-                const double* Cj = A.cen + 3 * ((size_t)c * A.nHist + j);  // (consecutive lanes, consecutive entries)
-                const double b0 = Cj[0] - M[0], b1 = Cj[1] - M[1], b2 = Cj[2] - M[2];
-                const double d = (a0 * b0 + a1 * b1) + a2 * b2;
-                const double nb = (b0 * b0 + b1 * b1) + b2 * b2;
-                const double cv = d / sqrt(na * nb);
-                if (cv < bestCos) bestCos = cv, best = j;  // (j ascending: the first of equal cosines stays)
-            }
-#pragma unroll
-            for (int off = 1; off < UP_LPP; off <<= 1) {
-                const double oc = __shfl_xor(bestCos, off, 64);
-                const int oj = __shfl_xor(best, off, 64);
-                if (oj >= 0 && (oc < bestCos || (oc == bestCos && (best < 0 || oj < best)))) bestCos = oc, best = oj;
-            }
+            const double a[3] = {C0[0] - M[0], C0[1] - M[1], C0[2] - M[2]};
+            const double na = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+            int bs = s;
+            best = chain_widest(X, c, ref, hR, hT, a, na, M, r, bs);  // :362-373 fp = fp->preFrame
             if (best >= 0) {  // :374-383
                 const int rs = (A.head - best + H) % H;
-                up_add_view(E, C.iK, hR + (size_t)rs * 9, hT + (size_t)rs * 3, hXY[(size_t)rs * 2 * N + s], hXY[(size_t)rs * 2 * N + N + s]);
+                up_add_view(E, C.iK, hR + (size_t)rs * 9, hT + (size_t)rs * 3, hXY[(size_t)rs * 2 * N + bs], hXY[(size_t)rs * 2 * N + N + bs]);
                 ++numView;
             }
-        } else if (!C.isStatic[s])
+        } else if (A.refStatic ? !A.refStatic[(size_t)m * A.nCams + c] : !C.isStatic[s])
             ++nDynamic;  // :471-472
-        if (r == c) mySecond = best;
+        if (r == c) mySecond = best, myFirst = j0;
     }
     if (numView < 2 || (!locStatic && nDynamic < 1)) return;  // :388, :475
     double cf[6];
@@ -772,7 +844,8 @@ __global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
     if (r < A.nCams && mySecond != -2) {
         const double* hR = A.histR + (size_t)r * H * 9;
         const double* hT = A.histT + (size_t)r * H * 3;
-        const PuProj q1 = pu_project(A.cam[r].K, hR + (size_t)A.head * 9, hT + (size_t)A.head * 3, M);
+        const int rs1 = (A.head - myFirst + H) % H;
+        const PuProj q1 = pu_project(A.cam[r].K, hR + (size_t)rs1 * 9, hT + (size_t)rs1 * 3, M);
 #pragma unroll
         for (int k = 0; k < 6; ++k) J1[k] = q1.J[k];
         if (mySecond >= 0) {
@@ -824,12 +897,16 @@ struct CuArgs {
     double sigma;
     unsigned char* ok;         // [nPairs]
     double *M, *cov;           // [nPairs][3], [nPairs][9]
+    // the two points' features as references (rows of cs_feat_ref, see ChainCtx) instead of pf1 / pf2
+    const int4 *ref1, *ref2;   // [nPairs][nCams] or null
+    const int4* segPool;
+    int segCap, curFrame, stored;
     cs_poseupdate_cam cam[PU_MAX_CAMS];
 };
 // one pair, one wave: pf1 / pf2 the two points' rows of pointFeat, M1 / M2 their positions, sRw the wave's 64 * 9 + 16 doubles of LDS;
 // returns the verdict (uniform over the wave), M / cov the unified point (every lane)
-__device__ __forceinline__ bool check_unify_wave(const CuArgs& A, const int* pf1, const int* pf2, const double* M1, const double* M2,
-                                                 double* sRw, double (&M)[3], double (&cov)[9]) {
+__device__ __forceinline__ bool check_unify_wave(const CuArgs& A, const int* pf1, const int* pf2, const int4* rf1, const int4* rf2,
+                                                 const double* M1, const double* M2, double* sRw, double (&M)[3], double (&cov)[9]) {
     const int r = threadIdx.x % 64;
     const int N = A.N, H = A.H;
     UpNormalEq E;
@@ -838,47 +915,35 @@ __device__ __forceinline__ bool check_unify_wave(const CuArgs& A, const int* pf1
 #pragma unroll
     for (int k = 0; k < 3; ++k) E.g[k] = 0;
     int nv = 0, myC = -1, myJ = 0, myS = 0;   // lane v keeps view v: camera, ring depth, slot
+    ChainCtx X;
+    X.N = N, X.H = H, X.head = A.head, X.cap = A.nHist, X.curFrame = rf1 ? A.curFrame : 0, X.stored = rf1 ? A.stored : A.nHist;
+    X.segCap = A.segCap, X.nCen = A.nHist, X.cen = A.cen, X.segPool = A.segPool;
     for (int c = 0; c < A.nCams; ++c) {
         const cs_poseupdate_cam& C = A.cam[c];
         const double* hR = A.histR + (size_t)c * H * 9;
         const double* hT = A.histT + (size_t)c * H * 3;
         const double* hXY = A.histXY + (size_t)c * H * 2 * N;
-        const double* R0 = hR + (size_t)A.head * 9;
-        const double* t0 = hT + (size_t)A.head * 3;
         for (int which = 0; which < 2; ++which) {
-            const int s = (which ? pf2 : pf1)[c];
-            if (s < 0) continue;
+            const int4 ref = rf1 ? (which ? rf2 : rf1)[c] : chain_ref(nullptr, which ? pf2 : pf1, C, N, 0, 0, c);
+            const int s = ref.x, j0 = X.curFrame - ref.y;
+            if (s < 0 || j0 >= X.stored) continue;
             const double* Mold = which ? M2 : M1;
-            up_add_view(E, C.iK, R0, t0, hXY[(size_t)A.head * 2 * N + s], hXY[(size_t)A.head * 2 * N + N + s]);
-            if (r == nv) myC = c, myJ = 0, myS = s;
+            const int rs0 = (A.head - j0 + H) % H;
+            const double* R0 = hR + (size_t)rs0 * 9;
+            const double* t0 = hT + (size_t)rs0 * 3;
+            up_add_view(E, C.iK, R0, t0, hXY[(size_t)rs0 * 2 * N + s], hXY[(size_t)rs0 * 2 * N + N + s]);
+            if (r == nv) myC = c, myJ = j0, myS = s;
             ++nv;
             double C0[3];
             up_cam_center(R0, t0, C0);
-            const double a0 = C0[0] - Mold[0], a1 = C0[1] - Mold[1], a2 = C0[2] - Mold[2];
-            const double na = (a0 * a0 + a1 * a1) + a2 * a2;
-            const int f1 = C.trackSpan[s], f2 = C.trackSpan[N + s];
-            const int len = f1 >= 0 ? f2 - f1 + 1 : 0;
-            const int depth = len < A.nHist ? len : A.nHist;
-            int best = -1;
-            double bestCos = 1.0;
-            for (int j = 1 + r; j < depth; j += 64) {
-                const double* Cj = A.cen + 3 * ((size_t)c * A.nHist + j);
-                const double b0 = Cj[0] - Mold[0], b1 = Cj[1] - Mold[1], b2 = Cj[2] - Mold[2];
-                const double d = (a0 * b0 + a1 * b1) + a2 * b2;
-                const double nb = (b0 * b0 + b1 * b1) + b2 * b2;
-                const double cv = d / sqrt(na * nb);
-                if (cv < bestCos) bestCos = cv, best = j;
-            }
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const double oc = __shfl_xor(bestCos, off, 64);
-                const int oj = __shfl_xor(best, off, 64);
-                if (oj >= 0 && (oc < bestCos || (oc == bestCos && (best < 0 || oj < best)))) bestCos = oc, best = oj;
-            }
+            const double a[3] = {C0[0] - Mold[0], C0[1] - Mold[1], C0[2] - Mold[2]};
+            const double na = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+            int bs = s;
+            const int best = chain_widest(X, c, ref, hR, hT, a, na, Mold, r, bs);
             if (best >= 0) {
                 const int rs = (A.head - best + H) % H;
-                up_add_view(E, C.iK, hR + (size_t)rs * 9, hT + (size_t)rs * 3, hXY[(size_t)rs * 2 * N + s], hXY[(size_t)rs * 2 * N + N + s]);
-                if (r == nv) myC = c, myJ = best, myS = s;
+                up_add_view(E, C.iK, hR + (size_t)rs * 9, hT + (size_t)rs * 3, hXY[(size_t)rs * 2 * N + bs], hXY[(size_t)rs * 2 * N + N + bs]);
+                if (r == nv) myC = c, myJ = best, myS = bs;
                 ++nv;
             }
         }
@@ -947,7 +1012,9 @@ __global__ __launch_bounds__(256) void k_check_unify(CuArgs A) {
     const int q = blockIdx.x * 4 + g;
     if (q >= A.nPairs) return;
     double M[3], cov[9];
-    const bool ok = check_unify_wave(A, A.pf1 + (size_t)q * A.nCams, A.pf2 + (size_t)q * A.nCams, A.M1 + 3 * (size_t)q, A.M2 + 3 * (size_t)q, sR[g], M, cov);
+    const bool ok = check_unify_wave(A, A.ref1 ? nullptr : A.pf1 + (size_t)q * A.nCams, A.ref1 ? nullptr : A.pf2 + (size_t)q * A.nCams,
+                                     A.ref1 ? A.ref1 + (size_t)q * A.nCams : nullptr, A.ref1 ? A.ref2 + (size_t)q * A.nCams : nullptr, A.M1 + 3 * (size_t)q,
+                                     A.M2 + 3 * (size_t)q, sR[g], M, cov);
     if (r == 0) {
         A.ok[q] = ok ? 1 : 0;
 #pragma unroll
@@ -1007,7 +1074,7 @@ __global__ __launch_bounds__(256) void k_merge_precheck(DmArgs A) {
     if (q < 0 || q >= A.P || q == p) return;
     if (A.mapFlags[q] & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) return;
     double M[3], cov[9];
-    const bool ok = check_unify_wave(A.cu, A.pointFeat + (size_t)p * C, A.pointFeat + (size_t)q * C, A.mapPts + 3 * (size_t)p, A.mapPts + 3 * (size_t)q,
+    const bool ok = check_unify_wave(A.cu, A.pointFeat + (size_t)p * C, A.pointFeat + (size_t)q * C, nullptr, nullptr, A.mapPts + 3 * (size_t)p, A.mapPts + 3 * (size_t)q,
                                      sR[g], M, cov);
     if (r == 0) {
         double* o = A.preM + 12 * (size_t)e;
@@ -1227,7 +1294,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
                     }
                 } else {
                     const long long ti = wall_clock64();
-                    ok = check_unify_wave(A.cu, A.pointFeat + (size_t)p * C, A.pointFeat + (size_t)q * C, A.mapPts + 3 * (size_t)p,
+                    ok = check_unify_wave(A.cu, A.pointFeat + (size_t)p * C, A.pointFeat + (size_t)q * C, nullptr, nullptr, A.mapPts + 3 * (size_t)p,
                                           A.mapPts + 3 * (size_t)q, sR, M, cov);
                     tInline += wall_clock64() - ti, ++nInline;
                 }
@@ -1668,11 +1735,16 @@ struct cs_track_history {
     // the centres are computed once per state of the ring's poses: every call that (re)writes poses moves ringVersion on, the
     // kernels that walk the centres launch k_ring_centres only when cenVersion is behind (calls on a handle are enqueued in order)
     mutable long long ringVersion, cenVersion;
+    // the segments the registration loops linked behind features (ChainCtx): a pool per camera, filled by cs_feat_ref_advance_dev
+    int4* segPool;   // [nCams][segCap]
+    int* segCount;   // [nCams]
+    int segCap;
 };
 
 // the camera centres by walk depth, if the ring's poses changed since they were last computed
 static void hist_centres(const cs_track_history* h, hipStream_t s);
 
+constexpr int PU_SEG_CAP = 1 << 15;  // linked segments a camera's pool holds (16 bytes each; never recycled: a full pool drops further links)
 static inline int hist_walk(const cs_track_history* h) { return h->count < h->walkLen ? h->count : h->walkLen; }
 
 extern "C" cs_track_history* cs_track_history_create(int device, int nCams, int N, int histLen) {
@@ -1701,12 +1773,16 @@ extern "C" cs_track_history* cs_track_history_create_ex(int device, int nCams, i
     h->ringVersion = 1, h->cenVersion = 0;
     const size_t nXY = (size_t)nCams * histLen * 2 * N, nR = (size_t)nCams * histLen * 9, nT = (size_t)nCams * histLen * 3;
     if (hipMalloc((void**)&h->xy, sizeof(double) * nXY) != hipSuccess || hipMalloc((void**)&h->R, sizeof(double) * nR) != hipSuccess ||
-        hipMalloc((void**)&h->t, sizeof(double) * nT) != hipSuccess || hipMalloc((void**)&h->cen, sizeof(double) * nT) != hipSuccess) {
+        hipMalloc((void**)&h->t, sizeof(double) * nT) != hipSuccess || hipMalloc((void**)&h->cen, sizeof(double) * nT) != hipSuccess ||
+        hipMalloc((void**)&h->segPool, sizeof(int4) * (size_t)nCams * PU_SEG_CAP) != hipSuccess ||
+        hipMalloc((void**)&h->segCount, sizeof(int) * nCams) != hipSuccess) {
         cs_set_error("cs_track_history_create: hipMalloc failed");
-        (void)hipFree(h->xy), (void)hipFree(h->R), (void)hipFree(h->t), (void)hipFree(h->cen);
+        (void)hipFree(h->xy), (void)hipFree(h->R), (void)hipFree(h->t), (void)hipFree(h->cen), (void)hipFree(h->segPool), (void)hipFree(h->segCount);
         delete h;
         return nullptr;
     }
+    h->segCap = PU_SEG_CAP;
+    (void)hipMemset(h->segCount, 0, sizeof(int) * nCams);
     (void)hipMemset(h->xy, 0, sizeof(double) * nXY);
     (void)hipMemset(h->R, 0, sizeof(double) * nR);
     (void)hipMemset(h->t, 0, sizeof(double) * nT);
@@ -1716,7 +1792,7 @@ extern "C" cs_track_history* cs_track_history_create_ex(int device, int nCams, i
 extern "C" void cs_track_history_destroy(cs_track_history* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    (void)hipFree(h->xy), (void)hipFree(h->R), (void)hipFree(h->t), (void)hipFree(h->cen);
+    (void)hipFree(h->xy), (void)hipFree(h->R), (void)hipFree(h->t), (void)hipFree(h->cen), (void)hipFree(h->segPool), (void)hipFree(h->segCount);
     if (h->clsList) (void)hipFree(h->clsList);
     delete h;
 }
@@ -2020,7 +2096,7 @@ int up_launch(const char* who, const cs_track_history* h, void* hip_stream, cons
     A.histXY = h->xy, A.histR = h->R, A.histT = h->t;
     A.counts = d_counts;
     for (int c = 0; c < h->nCams; ++c) {
-        if (!cams[c].K || !cams[c].iK || !cams[c].trackSpan || (!A.refine && !cams[c].isStatic)) {
+        if (!cams[c].K || !cams[c].iK || (!A.featRef && !cams[c].trackSpan) || (!A.refine && !A.refStatic && !cams[c].isStatic)) {
             cs_set_error("%s: null pointer in camera %d (K, iK, trackSpan%s are read)", who, c, A.refine ? "" : ", isStatic");
             return CS_ERR_INVALID;
         }
@@ -2076,15 +2152,189 @@ extern "C" int cs_refine_map_points_dev(const cs_track_history* h, void* hip_str
     return up_launch("cs_refine_map_points_dev", h, hip_stream, cams, A, d_count, 1);
 }
 
-extern "C" int cs_check_unify_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int nPairs, const int* d_pf1,
-                                  const int* d_pf2, const double* d_M1, const double* d_M2, double pixelErrVar, unsigned char* d_ok, double* d_M,
-                                  double* d_cov) {
-    if (!h || !cams || nPairs < 0 || (nPairs > 0 && (!d_pf1 || !d_pf2 || !d_M1 || !d_M2 || !d_ok || !d_M || !d_cov)) || h->nCams * 4 > 64) {
-        cs_set_error("cs_check_unify_dev: bad arguments (at most 16 cameras)");
+// ---- MapPoint::pFeatures kept as references (cs_feat_ref) ---------------------------------------------------------------------------------
+// What the reference does to p->pFeatures[c] and the chain behind it, once per frame behind the registration's decisions:
+//   the camera tracks the point on (SingleSLAM::propagateFeatureStates, src/app/SL_SingleSLAM.cpp:34-60): the reference moves to this frame;
+//   the point gained a feature on a NEW track while it still held an older one there (curStaticPointRegInGroup, src/app/SL_CoSLAM.cpp:775-779;
+//     the dynamic loop :997-1000): the old reference becomes a segment of the camera's pool, the new one {slot, this frame, first = this
+//     frame, that segment} -- the new track's own earlier frames are cut off, exactly as `pFeat->preFrame = p->pFeatures[iCam]` cuts them;
+//   the point holds no feature there yet (MapPoint::addFeature on a null entry: new map points, a unification's hand-over): {slot, this
+//     frame, the track's first frame, no segment};
+//   the camera does not see the point: the reference stays as it is -- stale, and still a view of every walk.
+//   ... except when the reference was alive in the frame before and its slot's track lives ON without the point: the feature was detached
+//     (`p->pFeatures[outlierViewId] = 0` of mapPointsClassify, :470-472; `pFeat->mpt->pFeatures[v] = 0` of a unification, :810): cleared.
+// The call has to be made EVERY frame (a detachment is recognised against the frame before).
+struct FrArgs {
+    int nCams, N, nMap, curFrame, segCap;
+    const int* pointFeat;
+    int4* featRef;
+    unsigned char* refStatic;
+    int4* segPool;
+    int* segCount;
+    int* counts;   // [5] or null: tracked on, fresh, re-linked, links dropped (pool full), detached
+    cs_poseupdate_cam cam[PU_MAX_CAMS];
+};
+__global__ __launch_bounds__(256) void k_feat_ref_advance(FrArgs A) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    int kind = -1;   // 0 tracked on, 1 first, 2 re-linked, 3 re-linked with the link dropped, 4 detached; -1 nothing to count
+    if (e < A.nMap * A.nCams) {
+        const int c = e % A.nCams, s = A.pointFeat[e];
+        int4 ref = A.featRef[e];
+        const cs_poseupdate_cam& C = A.cam[c];
+        if (s < 0 || s >= A.N) {
+            if (ref.x >= 0 && ref.x < A.N && ref.y == A.curFrame - 1) {
+                const int g1 = C.trackSpan[ref.x], g2 = C.trackSpan[A.N + ref.x];
+                if (g1 >= 0 && g1 <= ref.y && g2 == A.curFrame) {   // the same track, alive in this frame, no longer the point's
+                    ref.x = -1, kind = 4;
+                    A.featRef[e] = ref;
+                }
+            }
+        } else {
+            const int f1 = C.trackSpan[s];
+            if (ref.x == s && f1 >= 0 && ref.y >= f1 && ref.y <= A.curFrame) {
+                kind = ref.y == A.curFrame ? -1 : 0;   // (a second call within the frame changes and counts nothing)
+                ref.y = A.curFrame;
+            } else if (ref.x >= 0 && ref.y < A.curFrame) {
+                const int idx = atomicAdd(A.segCount + c, 1);
+                kind = 2;
+                if (idx < A.segCap)
+                    A.segPool[(size_t)c * A.segCap + idx] = ref;   // {slot, last = its frame, first, next = its segment}
+                else
+                    kind = 3;
+                ref = make_int4(s, A.curFrame, A.curFrame, idx < A.segCap ? idx : -1);
+            } else {
+                ref = make_int4(s, A.curFrame, f1 >= 0 ? f1 : A.curFrame, -1), kind = 1;
+            }
+            A.featRef[e] = ref;
+            if (A.refStatic) A.refStatic[e] = C.isStatic ? C.isStatic[s] : 1;
+        }
+    }
+    if (A.counts) {   // one atomic per wave and counter (15 000 "tracked on" per frame on one address would cost more than the kernel)
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(k == 2 ? (kind == 2 || kind == 3) : (k == 3 ? kind == 3 : kind == k));
+            if (b && lane == 0) atomicAdd(A.counts + k, __popcll(b));
+        }
+    }
+}
+
+extern "C" int cs_feat_ref_advance_dev(cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int nMap, const int* d_pointFeat,
+                                       int curFrame, cs_feat_ref* d_featRef, unsigned char* d_refStatic, int* d_counts) {
+    if (!h || !cams || nMap < 0 || (nMap > 0 && (!d_pointFeat || !d_featRef))) {
+        cs_set_error("cs_feat_ref_advance_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    FrArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = h->nCams, A.N = h->N, A.nMap = nMap, A.curFrame = curFrame, A.segCap = h->segCap;
+    A.pointFeat = d_pointFeat, A.featRef = (int4*)d_featRef, A.refStatic = d_refStatic, A.segPool = h->segPool, A.segCount = h->segCount;
+    A.counts = d_counts;
+    for (int c = 0; c < h->nCams; ++c) {
+        if (!cams[c].trackSpan) {
+            cs_set_error("cs_feat_ref_advance_dev: null trackSpan in camera %d", c);
+            return CS_ERR_INVALID;
+        }
+        A.cam[c] = cams[c];
+    }
+    CS_HIP(hipSetDevice(h->device));
+    if (nMap == 0) return CS_OK;
+    hipLaunchKernelGGL(k_feat_ref_advance, dim3((nMap * h->nCams + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, A);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+extern "C" int cs_track_history_segments(const cs_track_history* h, cs_feat_seg** d_pool, int* cap, int** d_count) {
+    if (!h) {
+        cs_set_error("cs_track_history_segments: null handle");
+        return CS_ERR_INVALID;
+    }
+    if (d_pool) *d_pool = (cs_feat_seg*)h->segPool;
+    if (cap) *cap = h->segCap;
+    if (d_count) *d_count = h->segCount;
+    return CS_OK;
+}
+
+extern "C" int cs_track_history_segment_counts(const cs_track_history* h, int* counts) {
+    if (!h || !counts) {
+        cs_set_error("cs_track_history_segment_counts: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(h->device));
+    CS_HIP(hipMemcpy(counts, h->segCount, sizeof(int) * h->nCams, hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
+// host copy of `n` segments per camera ([nCams][n] cs_feat_seg) into the pools (tests, restoring a checkpoint); synchronous
+extern "C" int cs_track_history_load_segments(cs_track_history* h, const cs_feat_seg* segs, int n) {
+    if (!h || n < 0 || n > h->segCap || (n > 0 && !segs)) {
+        cs_set_error("cs_track_history_load_segments: bad arguments (at most %d segments per camera)", h ? h->segCap : 0);
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(h->device));
+    std::vector<int> cnt(h->nCams, n);
+    for (int c = 0; c < h->nCams && n > 0; ++c)
+        CS_HIP(hipMemcpy(h->segPool + (size_t)c * h->segCap, segs + (size_t)c * n, sizeof(int4) * n, hipMemcpyHostToDevice));
+    CS_HIP(hipMemcpy(h->segCount, cnt.data(), sizeof(int) * h->nCams, hipMemcpyHostToDevice));
+    return CS_OK;
+}
+
+namespace {
+// the reference tables of a *_ref_dev call into the launch arguments
+template <class Args>
+void up_set_refs(Args& A, const cs_track_history* h) {
+    A.segPool = h->segPool, A.segCap = h->segCap, A.curFrame = h->lastFrame, A.stored = h->count < h->H ? h->count : h->H;
+}
+}  // namespace
+
+extern "C" int cs_update_new_poses_points_ref_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams,
+                                                  const cs_feat_ref* d_featRef, const unsigned char* d_refStatic, int nMap, const int* d_lastFrame,
+                                                  const unsigned char* d_isCurrent, int firstKeyFrame, double* d_mapPts, double* d_mapCov,
+                                                  const unsigned char* d_mapFlags, double pixelErrVar, int* d_counts) {
+    if (!h || !cams || nMap < 0 || (nMap > 0 && (!d_featRef || !d_mapPts || !d_mapCov || !d_mapFlags))) {
+        cs_set_error("cs_update_new_poses_points_ref_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    UpArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nMap = nMap, A.firstKeyFrame = firstKeyFrame;
+    A.featRef = (const int4*)d_featRef, A.refStatic = d_refStatic, A.lastFrame = d_lastFrame, A.isCurrent = d_isCurrent;
+    A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.mapFlags = d_mapFlags;
+    A.sigma = pixelErrVar;
+    up_set_refs(A, h);
+    return up_launch("cs_update_new_poses_points_ref_dev", h, hip_stream, cams, A, d_counts, 2);
+}
+
+extern "C" int cs_refine_map_points_ref_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const cs_feat_ref* d_featRef,
+                                            int nMap, const unsigned char* d_select, double* d_mapPts, double* d_mapCov, double pixelErrVar,
+                                            int* d_count) {
+    if (!h || !cams || nMap < 0 || (nMap > 0 && (!d_featRef || !d_mapPts || !d_mapCov))) {
+        cs_set_error("cs_refine_map_points_ref_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    UpArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nMap = nMap;
+    A.featRef = (const int4*)d_featRef;
+    A.mapPts = d_mapPts, A.mapCov = d_mapCov;
+    A.sigma = pixelErrVar;
+    A.refine = 1, A.select = d_select;
+    up_set_refs(A, h);
+    return up_launch("cs_refine_map_points_ref_dev", h, hip_stream, cams, A, d_count, 1);
+}
+
+namespace {
+int cu_launch(const char* who, const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int nPairs, const int* d_pf1,
+              const int* d_pf2, const cs_feat_ref* d_ref1, const cs_feat_ref* d_ref2, const double* d_M1, const double* d_M2, double pixelErrVar,
+              unsigned char* d_ok, double* d_M, double* d_cov) {
+    const bool byRef = d_ref1 || d_ref2;
+    if (!h || !cams || nPairs < 0 || h->nCams * 4 > 64 ||
+        (nPairs > 0 && ((byRef ? (!d_ref1 || !d_ref2) : (!d_pf1 || !d_pf2)) || !d_M1 || !d_M2 || !d_ok || !d_M || !d_cov))) {
+        cs_set_error("%s: bad arguments (at most 16 cameras)", who);
         return CS_ERR_INVALID;
     }
     if (h->count < 1) {
-        cs_set_error("cs_check_unify_dev: the history holds no frame");
+        cs_set_error("%s: the history holds no frame", who);
         return CS_ERR_INVALID;
     }
     if (nPairs == 0) return CS_OK;
@@ -2092,12 +2342,14 @@ extern "C" int cs_check_unify_dev(const cs_track_history* h, void* hip_stream, c
     memset(&A, 0, sizeof(A));
     A.nCams = h->nCams, A.N = h->N, A.H = h->H, A.head = h->head, A.nHist = hist_walk(h), A.nPairs = nPairs;
     A.pf1 = d_pf1, A.pf2 = d_pf2, A.M1 = d_M1, A.M2 = d_M2;
+    A.ref1 = (const int4*)d_ref1, A.ref2 = (const int4*)d_ref2;
+    if (byRef) up_set_refs(A, h);
     A.histXY = h->xy, A.histR = h->R, A.histT = h->t, A.cen = h->cen;
     A.sigma = pixelErrVar;
     A.ok = d_ok, A.M = d_M, A.cov = d_cov;
     for (int c = 0; c < h->nCams; ++c) {
         if (!cams[c].K || !cams[c].iK || !cams[c].trackSpan) {
-            cs_set_error("cs_check_unify_dev: null pointer in camera %d (K, iK, trackSpan are read)", c);
+            cs_set_error("%s: null pointer in camera %d (K, iK, trackSpan are read)", who, c);
             return CS_ERR_INVALID;
         }
         A.cam[c] = cams[c];
@@ -2108,6 +2360,18 @@ extern "C" int cs_check_unify_dev(const cs_track_history* h, void* hip_stream, c
     hipLaunchKernelGGL(k_check_unify, dim3((nPairs + 3) / 4), dim3(256), 0, s, A);
     CS_HIP(hipGetLastError());
     return CS_OK;
+}
+}  // namespace
+
+extern "C" int cs_check_unify_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int nPairs, const int* d_pf1,
+                                  const int* d_pf2, const double* d_M1, const double* d_M2, double pixelErrVar, unsigned char* d_ok, double* d_M,
+                                  double* d_cov) {
+    return cu_launch("cs_check_unify_dev", h, hip_stream, cams, nPairs, d_pf1, d_pf2, nullptr, nullptr, d_M1, d_M2, pixelErrVar, d_ok, d_M, d_cov);
+}
+extern "C" int cs_check_unify_ref_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int nPairs,
+                                      const cs_feat_ref* d_ref1, const cs_feat_ref* d_ref2, const double* d_M1, const double* d_M2,
+                                      double pixelErrVar, unsigned char* d_ok, double* d_M, double* d_cov) {
+    return cu_launch("cs_check_unify_ref_dev", h, hip_stream, cams, nPairs, nullptr, nullptr, d_ref1, d_ref2, d_M1, d_M2, pixelErrVar, d_ok, d_M, d_cov);
 }
 
 extern "C" int cs_register_decide_merge_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int P, int mapBase,

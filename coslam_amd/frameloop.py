@@ -55,6 +55,9 @@ class LoopConfig:
         self.map_spare = 8192      # room for new map points behind the initial map
         self.klt_cams_per_launch = 0
         self.klt_xcd_placement = True
+        self.feature_chains = True   # MapPoint::pFeatures kept as feature references (cs_feat_ref): a camera that lost a point still contributes
+        # its last feature to refineMapPoint / updateNewPosesPoints, and a point registered to a new track where it held an older feature has
+        # the old chain linked behind it (reference src/app/SL_CoSLAM.cpp:775-779); False: the features of this frame on their own tracks
         self.klt_fused = True      # False: one launch per Gauss-Newton pass (bit-identical): for SEVERAL processes sharing one GPU, where the
                                    # persistent tracker's co-residency budget does not hold
         self.prefetch = True
@@ -240,10 +243,13 @@ class FrameLoop:
         self.dest_ptrs = [[d.data_ptr() for d in self.d_dests[b]] for b in range(2)]
         self.cnt_ptrs = [c.data_ptr() for c in self.d_counts]
         self.img_ptrs = [[self.video[c][f].data_ptr() for c in self.my_cams] for f in range(self.T)]
-        self.pose_upd = None
+        self.pose_upd = self.d_fref = None
         if cfg.with_pose_update:
             self.pose_upd = TrackHistory(NA, N, cfg.hist, device=device, storeLen=max(cfg.hist_store, cfg.hist))
             self.d_merge_cache = z(self.pose_upd.mergability_cache_bytes(n_map), u8)
+            self.d_fref = torch.full((n_map, NA, 4), -1, dtype=i32, device=dev) if cfg.feature_chains else None
+            self.d_rstat = z((n_map, NA), u8) if cfg.feature_chains else None
+            self.d_fref_counts = z(5, i32)   # tracked on, first features, re-linked, links dropped (pool full), detached -- summed over the run
             self.pu_args = poseupdate_cams([dict(K=self.d_K1.data_ptr(), iK=self.d_iK1.data_ptr(), xy=self.d_xy[g].data_ptr(),
                                                  state=self.d_state[g].data_ptr(), slot2map=self.d_slot2map[g].data_ptr(),
                                                  trackSpan=self.d_trackspan[g].data_ptr(), reprojErr=self.d_reproj[g].data_ptr(),
@@ -288,6 +294,8 @@ class FrameLoop:
             self.win.reserve(self.ba_ws)
             self.out = BAOutput(NA, cfg.n_key_frames, n_map, n_slots=8, device=device)
             self.out.attach(self.ba_ws)
+            if self.d_fref is not None:
+                self.out.set_feat_refs(self.d_fref.data_ptr(), self.d_rstat.data_ptr())
             self.recv_rec = z((2, self.out.record_bytes), u8)     # records solved by other ranks arrive here
         self.icam = None
         if ic is None:
@@ -578,9 +586,11 @@ class FrameLoop:
                                        nCamsRun=nc)
             if self.pose_upd is not None and cfg.with_mergability:
                 self._mergability(ps)
+        self._dst_now, self._frame_now = dst, i
         if cfg.with_register and cfg.with_decide and self.pose_upd is not None and cfg.with_mergability:
-            self._dst_now, self._frame_now = dst, i
             self._decide(ps)
+        elif self.pose_upd is not None:
+            self._advance_refs(ps)   # (no decisions in this configuration: the references still follow the tracks, every frame)
         # the tracker of frame i + 2 (it writes this dest buffer) is released HERE, at the end of the frame's pose work, although the
         # buffer's last reader was the hand-back: released earlier the tracker runs two frames ahead and under more of the pose stream's
         # kernels -- measured 1978-1986 (behind the hand-back) / 1928-1934 (behind the gate) / 1894-1903 (behind the classification)
@@ -642,6 +652,7 @@ class FrameLoop:
                                                           self.d_cov.data_ptr(), self.sig_pix, d_counts=D["cnt"].data_ptr(), device=self.device,
                                                           with_dynamic=True, merge=(cfg.merge_every > 0 and self._frame_now % cfg.merge_every == 0),   # CoSLAMThread.cpp:117-118
                                                           d_merge_scratch=D["mscr"].data_ptr(), mergability=self._mergability, n_sweeps=0)
+            self._advance_refs(ps)   # (the sequential mode refines inside its camera loops over this frame's features; the references follow)
             return
         if self.world > 1:
             self._gather_candidates()
@@ -654,8 +665,7 @@ class FrameLoop:
                                                     self.d_map.data_ptr(), self.d_cov.data_ptr(), self.sig_pix, D["att"].data_ptr(),
                                                     D["reg"].data_ptr(), D["mscr"].data_ptr(), D["mcnt"].data_ptr(),
                                                     d_list=self.d_curlist.data_ptr(), nList=cfg.p_reg)
-            self.pose_upd.refine_map_points_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
-                                                self.sig_pix, d_select=D["reg"].data_ptr())   # (no count asked for: that would be one more launch, and it is counts[1])
+            self._refine(ps, D["reg"].data_ptr())
             self.n_merge_frames += 1
             kinds = 2
         D["s2m"] = register_decide_static_dev(ps, NA, cfg.n_feat, self.n_map, 0, self.reg_out["slot"].data_ptr(), self.reg_out["flags"].data_ptr(),
@@ -663,8 +673,25 @@ class FrameLoop:
                                               D["s2m"] if D["s2m"] is not None else [self.d_slot2map[g].data_ptr() for g in range(NA)],
                                               D["att"].data_ptr(), D["reg"].data_ptr(), D["scr"].data_ptr(), D["cnt"].data_ptr(), device=self.device,
                                               kinds=kinds, n_sweeps=0)   # (0: ONE launch that sweeps until the owners have settled)   # curStaticPointsRegInGroup and curDynamicPointsRegInGroup (currentMapPointsRegister, :834-853)
-        self.pose_upd.refine_map_points_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
-                                            self.sig_pix, d_select=D["reg"].data_ptr())   # (no count asked for: that would be one more launch, and it is counts[1])
+        self._refine(ps, D["reg"].data_ptr())
+
+    def _advance_refs(self, ps):
+        """MapPoint::pFeatures of this frame: cs_feat_ref_advance_dev behind whatever changed pointFeat (hand-back, classification, the
+        registration's decisions) -- tracked on / first feature / re-linked behind an older one / stale / detached.  Idempotent within a frame."""
+        if self.d_fref is not None:
+            self.pose_upd.feat_ref_advance_dev(ps, self.pu_args, self.n_map, self.d_pf.data_ptr(), self._frame_now, self.d_fref.data_ptr(),
+                                               d_refStatic=self.d_rstat.data_ptr(), d_counts=self.d_fref_counts.data_ptr())
+
+    def _refine(self, ps, d_select):
+        """CoSLAM::refineMapPoint of the points that gained a feature (:889-893, :666-713) -- over the feature references when they are kept
+        (stale features of other cameras are views, a re-registered point's second view comes from its OLD chain), else over this frame's"""
+        if self.d_fref is not None:
+            self._advance_refs(ps)
+            self.pose_upd.refine_map_points_ref_dev(ps, self.pu_args, self.d_fref.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
+                                                    self.sig_pix, d_select=d_select)
+        else:
+            self.pose_upd.refine_map_points_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
+                                                self.sig_pix, d_select=d_select)   # (no count asked for: that would be one more launch, and it is counts[1])
 
     def _gather_candidates(self):
         """the own cameras' columns of the current-static pass's candidate tables to every rank (18 KB per camera: latency-bound, ONE

@@ -161,6 +161,54 @@ class TrackHistory:
         check(self._L.cs_check_unify_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), int(nPairs), vp(d_pf1), vp(d_pf2), vp(d_M1), vp(d_M2),
                                          C.c_double(pixelErrVar), vp(d_ok), vp(d_M), vp(d_cov)), "cs_check_unify_dev")
 
+    # ---- MapPoint::pFeatures as feature references (cs_feat_ref / cs_feat_seg, include/coslam_hip.h) --------------------------------
+    def feat_ref_advance_dev(self, stream_ptr, cams, nMap, d_pointFeat, curFrame, d_featRef, d_refStatic=None, d_counts=None):
+        """cs_feat_ref_advance_dev: every frame behind the registration's decisions -- tracked on / first feature / re-linked behind an
+        older one (reference src/app/SL_CoSLAM.cpp:775-779) / stale / detached"""
+        vp = C.c_void_p
+        check(self._L.cs_feat_ref_advance_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), int(nMap), vp(d_pointFeat), int(curFrame),
+                                              vp(d_featRef), vp(d_refStatic), vp(d_counts)), "cs_feat_ref_advance_dev")
+
+    def load_segments(self, segs):
+        """cs_track_history_load_segments: segs int32 [nCams][n][4] = {slot, last, first, next} from the host into the pools"""
+        import numpy as np
+
+        a = np.ascontiguousarray(segs, dtype=np.int32)
+        assert a.ndim == 3 and a.shape[0] == self.nCams and a.shape[2] == 4
+        check(self._L.cs_track_history_load_segments(C.c_void_p(self._h), a.ctypes.data_as(C.c_void_p), int(a.shape[1])),
+              "cs_track_history_load_segments")
+
+    def segment_counts(self):
+        """cs_track_history_segment_counts: how many linked segments every camera's pool holds (a synchronous read) and the capacity"""
+        import numpy as np
+
+        out, cap = np.zeros(self.nCams, dtype=np.int32), C.c_int()
+        check(self._L.cs_track_history_segments(C.c_void_p(self._h), None, C.byref(cap), None), "cs_track_history_segments")
+        check(self._L.cs_track_history_segment_counts(C.c_void_p(self._h), out.ctypes.data_as(C.c_void_p)), "cs_track_history_segment_counts")
+        return out, int(cap.value)
+
+    def update_new_poses_points_ref_dev(self, stream_ptr, cams, d_featRef, nMap, d_mapPts, d_mapCov, d_mapFlags, pixelErrVar,
+                                        d_refStatic=None, d_lastFrame=None, d_isCurrent=None, firstKeyFrame=-1, d_counts=None):
+        """cs_update_new_poses_points_ref_dev: updateNewPosesPoints with stale features as views and walks that follow the links"""
+        vp = C.c_void_p
+        check(self._L.cs_update_new_poses_points_ref_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), vp(d_featRef), vp(d_refStatic),
+                                                         int(nMap), vp(d_lastFrame), vp(d_isCurrent), int(firstKeyFrame), vp(d_mapPts),
+                                                         vp(d_mapCov), vp(d_mapFlags), C.c_double(pixelErrVar), vp(d_counts)),
+              "cs_update_new_poses_points_ref_dev")
+
+    def refine_map_points_ref_dev(self, stream_ptr, cams, d_featRef, nMap, d_mapPts, d_mapCov, pixelErrVar, d_select=None, d_count=None):
+        """cs_refine_map_points_ref_dev: CoSLAM::refineMapPoint over feature references"""
+        vp = C.c_void_p
+        check(self._L.cs_refine_map_points_ref_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), vp(d_featRef), int(nMap), vp(d_select),
+                                                   vp(d_mapPts), vp(d_mapCov), C.c_double(pixelErrVar), vp(d_count)),
+              "cs_refine_map_points_ref_dev")
+
+    def check_unify_ref_dev(self, stream_ptr, cams, nPairs, d_ref1, d_ref2, d_M1, d_M2, pixelErrVar, d_ok, d_M, d_cov):
+        """cs_check_unify_ref_dev: CoSLAM::checkUnify with the two points' features as references ([nPairs][nCams] cs_feat_ref each)"""
+        vp = C.c_void_p
+        check(self._L.cs_check_unify_ref_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), int(nPairs), vp(d_ref1), vp(d_ref2), vp(d_M1),
+                                             vp(d_M2), C.c_double(pixelErrVar), vp(d_ok), vp(d_M), vp(d_cov)), "cs_check_unify_ref_dev")
+
     def decide_merge_scratch_bytes(self, P, nList):
         """d_scratch of register_decide_merge_dev with a list (without: P bytes)"""
         self._L.cs_register_decide_merge_scratch_bytes.restype = C.c_size_t

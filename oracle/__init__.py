@@ -381,10 +381,11 @@ def _ref_args(histR, histT, histXY, Ks, iKs):
 
 
 def update_new_poses_points_ref(Ks, iKs, histR, histT, histXY, featStatic, featRef, segPool, curFrame, mapPts, mapCov, mapFlags, sigma,
-                                lastFrame=None, isCurrent=None, firstKeyFrame=-1, walkCap=64, cmpAcos=False):
+                                lastFrame=None, isCurrent=None, firstKeyFrame=-1, walkCap=64, cmpAcos=False, refStatic=None):
     """opu_update_new_poses_points_ref: update_new_poses_points with the features as REFERENCES -- featRef (nMap x nC x 4 int32:
     slot, frame, first, seg) and segPool (nC x cap x 4: slot, last, first, next): MapPoint::pFeatures with the preFrame chains behind them,
-    stale features and re-linked tracks included (oracle/poseupdate_oracle.c, above update_points_core)."""
+    stale features and re-linked tracks included (oracle/poseupdate_oracle.c, above update_points_core).  refStatic (nMap x nC uint8, optional):
+    the features' types as of their own frames (None: featStatic of the slot whatever the feature's age)."""
     L = lib()
     L.opu_update_new_poses_points_ref.restype = C.c_int
     histR, histT, histXY, nC, nH, N, Ks, iKs = _ref_args(histR, histT, histXY, Ks, iKs)
@@ -399,7 +400,9 @@ def update_new_poses_points_ref(Ks, iKs, histR, histT, histXY, featStatic, featR
     ic = None if isCurrent is None else np.ascontiguousarray(isCurrent, dtype=np.uint8)
     chosen = np.full((nMap, nC), -1, dtype=np.int32)
     ns, nd = C.c_int(0), C.c_int(0)
-    n = L.opu_update_new_poses_points_ref(nC, N, nH, _p(Ks), _p(iKs), _p(histR), _p(histT), _p(histXY), _p(fs), nMap, _p(fr), _p(sp),
+    rs = None if refStatic is None else np.ascontiguousarray(refStatic, dtype=np.uint8)
+    n = L.opu_update_new_poses_points_ref(nC, N, nH, _p(Ks), _p(iKs), _p(histR), _p(histT), _p(histXY), _p(fs), nMap, _p(fr),
+                                          _p(rs) if rs is not None else None, _p(sp),
                                           sp.shape[1], int(curFrame), int(walkCap), _p(lf) if lf is not None else None,
                                           _p(ic) if ic is not None else None, int(firstKeyFrame), _p(mapPts), _p(mapCov), _p(fl),
                                           C.c_double(sigma), int(bool(cmpAcos)), _p(chosen), C.byref(ns), C.byref(nd))

@@ -330,7 +330,7 @@ static int update_points_core(int nCams, int N, int nHist, const double* Ks, con
                               int nMap, const int* pointFeat, const int* lastFrame, const unsigned char* isCurrent,
                               int firstKeyFrame, double* mapPts, double* mapCov, const unsigned char* mapFlags, double sigma,
                               int cmpAcos, int* chosen, int* nStat, int* nDyn, int refine, const unsigned char* select,
-                              const int* featRef, const int* segPool, int segCap, int curFrame, int walkCap) {
+                              const int* featRef, const int* segPool, int segCap, int curFrame, int walkCap, const unsigned char* refStatic) {
     const opu_chain_ctx X = {featRef ? curFrame : 0, nHist, featRef ? walkCap : nHist, segCap, N, cmpAcos, segPool};
     int nUpd = 0, ns = 0, nd = 0;
     for (int m = 0; m < nMap; m++) {
@@ -383,9 +383,9 @@ static int update_points_core(int nCams, int N, int nHist, const double* Ks, con
                 ne_add_view(&E, iKs + 9 * c, histR + ((size_t)c * nHist + j0) * 9, histT + ((size_t)c * nHist + j0) * 3,
                             histXY[((size_t)c * nHist + j0) * 2 * N + s], histXY[((size_t)c * nHist + j0) * 2 * N + N + s]);
                 numView++;
-                /* (fp->type of a stale feature: what it was in its own frame; the per-slot table knows this frame's only -- a stale
-                 * feature counts as static here) */
-                if (j0 == 0 && !featStatic[(size_t)c * N + s]) nDynamic++;
+                /* fp->type: of a stale feature what it was in its own frame -- refStatic [nMap][nCams] when given (the caller's snapshot),
+                 * else the slot's entry of featStatic whatever the feature's age */
+                if (refStatic ? !refStatic[(size_t)m * nCams + c] : !featStatic[(size_t)c * N + s]) nDynamic++;
             }
             if (nDynamic < 1) continue; /* :475 */
         } else
@@ -423,17 +423,17 @@ int opu_update_new_poses_points(int nCams, int N, int nHist, const double* Ks, c
                                 int firstKeyFrame, double* mapPts, double* mapCov, const unsigned char* mapFlags, double sigma,
                                 int cmpAcos, int* chosen, int* nStat, int* nDyn) {
     return update_points_core(nCams, N, nHist, Ks, iKs, histR, histT, histXY, trackSpan, featStatic, nMap, pointFeat, lastFrame, isCurrent,
-                              firstKeyFrame, mapPts, mapCov, mapFlags, sigma, cmpAcos, chosen, nStat, nDyn, 0, 0, 0, 0, 0, 0, 0);
+                              firstKeyFrame, mapPts, mapCov, mapFlags, sigma, cmpAcos, chosen, nStat, nDyn, 0, 0, 0, 0, 0, 0, 0, 0);
 }
 
 /* the same with the features as references (featRef / segPool: above update_points_core) */
 int opu_update_new_poses_points_ref(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR,
                                     const double* histT, const double* histXY, const unsigned char* featStatic, int nMap,
-                                    const int* featRef, const int* segPool, int segCap, int curFrame, int walkCap, const int* lastFrame,
+                                    const int* featRef, const unsigned char* refStatic, const int* segPool, int segCap, int curFrame, int walkCap, const int* lastFrame,
                                     const unsigned char* isCurrent, int firstKeyFrame, double* mapPts, double* mapCov,
                                     const unsigned char* mapFlags, double sigma, int cmpAcos, int* chosen, int* nStat, int* nDyn) {
     return update_points_core(nCams, N, nHist, Ks, iKs, histR, histT, histXY, 0, featStatic, nMap, 0, lastFrame, isCurrent, firstKeyFrame,
-                              mapPts, mapCov, mapFlags, sigma, cmpAcos, chosen, nStat, nDyn, 0, 0, featRef, segPool, segCap, curFrame, walkCap);
+                              mapPts, mapCov, mapFlags, sigma, cmpAcos, chosen, nStat, nDyn, 0, 0, featRef, segPool, segCap, curFrame, walkCap, refStatic);
 }
 
 /* CoSLAM::refineMapPoint (/root/reference/src/app/SL_CoSLAM.cpp:666-713) for the points `select` names (NULL: all): what the
@@ -447,13 +447,13 @@ int opu_refine_map_points(int nCams, int N, int nHist, const double* Ks, const d
                           const double* histXY, const int* trackSpan, int nMap, const int* pointFeat, const unsigned char* select,
                           double* mapPts, double* mapCov, double sigma, int cmpAcos) {
     return update_points_core(nCams, N, nHist, Ks, iKs, histR, histT, histXY, trackSpan, 0, nMap, pointFeat, 0, 0, 0, mapPts, mapCov, 0,
-                              sigma, cmpAcos, 0, 0, 0, 1, select, 0, 0, 0, 0, 0);
+                              sigma, cmpAcos, 0, 0, 0, 1, select, 0, 0, 0, 0, 0, 0);
 }
 int opu_refine_map_points_ref(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
                               const double* histXY, int nMap, const int* featRef, const int* segPool, int segCap, int curFrame, int walkCap,
                               const unsigned char* select, double* mapPts, double* mapCov, double sigma, int cmpAcos) {
     return update_points_core(nCams, N, nHist, Ks, iKs, histR, histT, histXY, 0, 0, nMap, 0, 0, 0, 0, mapPts, mapCov, 0, sigma, cmpAcos, 0, 0, 0,
-                              1, select, featRef, segPool, segCap, curFrame, walkCap);
+                              1, select, featRef, segPool, segCap, curFrame, walkCap, 0);
 }
 
 /* ---- CoSLAM::mapPointsClassify (/root/reference/src/app/SL_CoSLAM.cpp:418-520) --------------------------------------------------

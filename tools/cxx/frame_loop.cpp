@@ -239,6 +239,17 @@ int main(int argc, char** argv) {
         return 3;
     }
     void* dMergeCache = dev_zeros<unsigned char>(cs_register_mergability_cache_bytes(nMap, nCams));
+    // MapPoint::pFeatures as feature references (stale features are views, re-linked chains: SL_CoSLAM.cpp:775-779); COSLAM_FEATURE_CHAINS=0:
+    // this frame's features on their own tracks
+    const bool chains = !(getenv("COSLAM_FEATURE_CHAINS") && getenv("COSLAM_FEATURE_CHAINS")[0] == '0');
+    cs_feat_ref* dFref = nullptr;
+    unsigned char* dRstat = nullptr;
+    int* dFrefCnt = dev_zeros<int>(5);
+    if (chains) {
+        HIPCHK(hipMalloc((void**)&dFref, sizeof(cs_feat_ref) * (size_t)nMap * nCams));
+        HIPCHK(hipMemset(dFref, 0xff, sizeof(cs_feat_ref) * (size_t)nMap * nCams));   // (-1 everywhere: no feature)
+        dRstat = dev_zeros<unsigned char>((size_t)nMap * nCams);
+    }
     int* dCurList = dev_zeros<int>(nMap);
     int* dCurCount = dev_zeros<int>(1);
     int* dMergeRun = dev_zeros<int>(4);
@@ -330,6 +341,7 @@ int main(int argc, char** argv) {
         return 3;
     }
     CSCHK(cs_ba_output_attach(bout, joint.ws));
+    if (chains) CSCHK(cs_ba_output_set_feat_refs(bout, dFref, dRstat));
     (void)pgFixed, (void)pgR, (void)pgT, (void)pgCam, (void)pgEdges;   // (the file's pre-baked camera graphs: the graphs are built live now)
     struct Due {
         int frame, firstKey;
@@ -465,17 +477,26 @@ int main(int argc, char** argv) {
         // the decision (curStaticPointsRegInGroup, bMerge false: who attaches which feature), then refineMapPoint of the points that gained one
         // currentMapPointsRegister's decisions: the certainly static points, behind them the certainly dynamic ones (kinds 3), one call;
         // every 50th frame with bMerge (CoSLAMThread.cpp:117-118): the static points' walks one after the other, checkUnify at a conflict
+        // refineMapPoint of the points that gained a feature: with the references brought up to this frame first (tracked on / first feature /
+        // re-linked behind an older one / stale / detached: cs_feat_ref_advance_dev, idempotent within a frame)
+        auto refine = [&]() {
+            if (chains) {
+                CSCHK(cs_feat_ref_advance_dev(hist, (void*)poseS, pu.data(), nMap, dPf, i, dFref, dRstat, dFrefCnt));
+                CSCHK(cs_refine_map_points_ref_dev(hist, (void*)poseS, pu.data(), dFref, nMap, dRegged, dMap, dCov, PIX, nullptr));
+            } else
+                CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
+        };
         int kinds = 3;
         if (i % 50 == 0) {
             CSCHK(cs_register_decide_merge_list_dev(hist, (void*)poseS, pu.data(), nMap, 0, dCurList, P_REG, reg[0].slot, reg[0].flags, dMergeable, dMapFlags, dPf, dMap, dCov,
                                                PIX, dAttached, dRegged, dMergeScratch, dMergeCnt, /*onlyCam*/ -1));
-            CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
+            refine();
             ++nMergeFrames;
             kinds = 2;
         }
         CSCHK(cs_register_decide_kinds_dev(dev, (void*)poseS, nCams, N, nMap, 0, reg[0].slot, reg[0].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
                                            dAttached, dRegged, dDecScratch, /*nSweeps: until settled*/ 0, dDecCnt, /*onlyCam*/ -1, kinds));
-        CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dRegged, dMap, dCov, PIX, nullptr));
+        refine();
         // the tracker of frame i + 2 is released at the END of the frame's pose work (released right behind the hand-back it runs two frames
         // ahead and under more of the pose stream's kernels: -10 %, profiles/r04_ab_runs.txt)
         HIPCHK(hipEventRecord(destFree[b], poseS));

@@ -45,6 +45,7 @@ VARIANTS = {
     "no_classify": (dict(with_classify=False), None),
     "no_merge": (dict(merge_every=0), None),
     "no_intercam": (dict(with_intercam=False), None),
+    "no_chains": (dict(feature_chains=False), None),   # this frame's features on their own tracks (the state before the feature references)
 }
 
 
