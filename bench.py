@@ -503,6 +503,9 @@ def main():
                          "N > 1: 12 (every rank must take the same number of steps)")
     ap.add_argument("--klt-xcd-placement", type=int, default=int(os.environ.get("BENCH_KLT_XCD", "1")),
                     help="1: the persistent tracker numbers its workgroups so that a camera lands on its own XCD; 0: cameras as grid rows")
+    ap.add_argument("--keyframe-decision", type=int, default=0,
+                    help="1: CoSLAM::IsReadyForKeyFrame + addKeyFrame's bookkeeping per frame on the device (reported in config.key_frame_decision; "
+                         "the key frames stay on the fixed cadence)")
     ap.add_argument("--feature-chains", type=int, default=1,
                     help="1: MapPoint::pFeatures kept as feature references (stale features are views, re-linked tracks: SL_CoSLAM.cpp:775-779); "
                          "0: this frame's features on their own tracks (rounds 1-4)")
@@ -581,7 +584,7 @@ def main():
                      prefetch=os.environ.get("BENCH_PREFETCH", "1") != "0", with_pose_update=not args.no_pose_update,
                      with_classify=not args.no_classify, with_register=not args.no_register, with_mergability=not args.no_mergability,
                      with_ncc=not args.no_ncc, with_decide=not args.no_decide, merge_every=args.merge_every, hist=args.hist, hist_store=args.hist_store, with_active_search=bool(args.active_search), pixel_err_reading=args.pixel_err_reading, with_joint=args.only_solve != "intercam", with_intercam=args.only_solve != "joint",
-                     native_comm=bool(args.native_comm), klt_cus=args.klt_cus, pose_cus=args.pose_cus, klt_xcd_placement=bool(args.klt_xcd_placement), feature_chains=bool(args.feature_chains),
+                     native_comm=bool(args.native_comm), klt_cus=args.klt_cus, pose_cus=args.pose_cus, klt_xcd_placement=bool(args.klt_xcd_placement), feature_chains=bool(args.feature_chains), keyframe_decision=bool(args.keyframe_decision),
                      klt_after_intracam=bool(args.klt_after_intracam),
                      klt_fused=os.environ.get("BENCH_FORCE_DEVICE") is None or world == 1)   # (ranks sharing ONE GPU: test hook)
     try:
@@ -740,6 +743,25 @@ def main():
                            "then 8 of the dynamic ones; per loop a search, a mergability pass, the walks of that camera's points and a refine: "
                            "16 x the launches) instead of the headline's single pass -- the parity mode; the single pass differs from it in "
                            "~2 % of a frame's attachments (DESIGN.md 8.2)"}
+    kf_leg = None
+    if world == 1 and not args.no_secondary and not args.keyframe_decision:
+        # SECONDARY: the reference's key-frame DECISION per frame beside the same loop (CoSLAM::IsReadyForKeyFrame + addKeyFrame's key-pose
+        # bookkeeping on the device, pinned: tests/golden/keyframe_golden.npz); the key frames themselves stay on the fixed cadence
+        loop.drain()
+        loop.enable_keyframe_decision(loop._frame_now, loop._dst_now)
+        n_kf = max(args.steps // 2, 10)
+        barrier()
+        tq = time.perf_counter()
+        run(n_kf)
+        barrier()
+        dtq = time.perf_counter() - tq
+        kf_leg = dict(loop.keyframe_stats(), frames_per_s=n_kf / dtq, ratio_to_value=(n_kf / dtq) / (args.steps / dt),
+                      fixed_cadence_key_frames_in_the_same_frames=n_kf // max(cfg.key_every, 1),
+                      what="the same loop with cs_keyframe_ready_dev per frame: is a camera ready for a key frame (mapped points decreased below "
+                           "0.93 of the last key pose's / view angle > 5 degrees / translation), and the key-pose state moved on as addKeyFrame does "
+                           "when one has decreased (SL_CoSLAM.cpp:1269-1309); reported, not yet driving the window BA (its apply assumes equally "
+                           "spaced key frames)")
+        loop.kf = None
     gc.enable()
     coll_us = None
     if world > 1:
@@ -1127,6 +1149,7 @@ def main():
                                  "by one term per frame (cs_register_mergability_running_dev); counts summed over the whole run"),
                         "active_search": "off: the reference's activeMapPointsRegister cannot attach (numVisCam == 0 on actMapPts, SL_CoSLAM.cpp:1114; "
                                          "tests/cxx/ref_active_test.cpp)" if not cfg.with_active_search else "on (diagnostic)"},
+                       "key_frame_decision": loop.keyframe_stats() or "not run in this line (--keyframe-decision 1; secondary_keyframe_decision has a run)",
                        "feature_references": None if getattr(loop, "d_fref", None) is None else dict(zip(
                            ("tracked_on", "first_features", "re_linked_behind_an_older_feature", "links_dropped_pool_full", "detached"),
                            loop.d_fref_counts.cpu().tolist()),
@@ -1177,7 +1200,7 @@ def main():
                            "matches_per_pair_last_run": loop.ncc["np_cnt"].cpu().tolist()[4:4 + N_CAMS - 1],
                            "map_points_in_use": map_in_use_timed_end, "map_points_at_start": n_pts0, "map_capacity": loop.n_map},
                        "with_upload": with_upload, "secondary_reference_ba_request_policy": ref_policy,
-                       "secondary_sequential_registration": seq_reg, "cxx_frame_loop": cxx,
+                       "secondary_sequential_registration": seq_reg, "secondary_keyframe_decision": kf_leg, "cxx_frame_loop": cxx,
                        "collectives": None if world == 1 else {
                            "issued_by": ("libcoslam_hip RCCL (C-ABI)" if loop.native else "torch.distributed " + dist_backend +
                                          (f" (FALLBACK: libcoslam_hip's communicator could not be created: {loop.native_fallback})"

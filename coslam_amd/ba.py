@@ -350,6 +350,15 @@ class BAInterCam:
                                                  vp(d_R), vp(d_t), vp(d_mapPts), vp(d_mapFlags), vp(d_newPt), vp(d_pointFeat),
                                                  C.c_double(max_err), int(max_iter), int(inner_max_iter)), "cs_ba_solve_intercam_async")
 
+    def apply_dev(self, ws, stream_ptr, pu_cams, N, d_pointFeat, nMap, d_Rcur, d_tcur, d_mapPts, d_mapCov, d_mapFlags, pixelErrVar, history=None,
+                  d_numNodes=None, d_numOut=None):
+        """cs_ba_intercam_apply_dev: InterCamPoseEstimator::apply's write-back (reference src/app/SL_InterCamPoseEstimator.cpp:100-136) behind
+        a finished solve (ws.wait()): poses into the current ones, then poseUpdate3D's gate under them.  pu_cams: a poseupdate_cams() array."""
+        vp = C.c_void_p
+        check(self._L.cs_ba_intercam_apply_dev(ws._h, self._h, vp(stream_ptr), vp(history._h if history is not None else None), pu_cams, int(N),
+                                               vp(d_pointFeat), int(nMap), vp(d_Rcur), vp(d_tcur), vp(d_mapPts), vp(d_mapCov), vp(d_mapFlags),
+                                               C.c_double(pixelErrVar), vp(d_numNodes), vp(d_numOut)), "cs_ba_intercam_apply_dev")
+
     def last_problem(self):
         """(C, P, nObs, nStatic, device address of the points' map indices); call after ws.wait()"""
         c, p, o, st, pm = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_void_p()

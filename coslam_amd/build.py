@@ -22,6 +22,7 @@ HIP_SOURCES = [
     "pose.hip",
     "handback.hip",
     "register.hip",
+    "keyframe.hip",
     "poseupdate.hip",
     "ncc.hip",
     "newpts.hip",

@@ -4715,4 +4715,38 @@ int cs_ba_intercam_last_problem(cs_ba_intercam* ic, int* C, int* P, int* nObs, i
     return CS_OK;
 }
 
+// InterCamPoseEstimator::apply's write-back (src/app/SL_InterCamPoseEstimator.cpp:100-136) behind a finished solve of ic on workspace b:
+// the solved poses become the cameras' current poses (m_camPos.add(curFrame, ...), :100-103) -- d_Rcur / d_tcur, and the newest frame of
+// the history h when one is given --, then per camera the gate over its static mapped track nodes with the new pose: Mahalanobis error
+// below 2 -> reprojErr, seqTriangulate; else the pixel distance as reprojErr and the point uncertain (:105-136).  That loop is
+// SingleSLAM::poseUpdate3D's own (src/app/SL_SingleSLAM.cpp:677-706) statement for statement: the same kernel (cs_pose_update3d_dev).
+// The solve must have finished (cs_ba_wait(b)); the problem's cameras are the nCams cameras in order.
+int cs_ba_intercam_apply_dev(cs_ba* b, cs_ba_intercam* ic, void* hip_stream, cs_track_history* h, const cs_poseupdate_cam* cams, int N,
+                             const int* d_pointFeat, int nMap, double* d_Rcur, double* d_tcur, double* d_mapPts, double* d_mapCov,
+                             unsigned char* d_mapFlags, double pixelErrVar, int* d_numNodes, int* d_numOut) {
+    if (!b || !ic || !cams || !d_Rcur || !d_tcur || !d_mapPts || !d_mapCov || !d_mapFlags || (h && cs_track_history_cams(h) != ic->nCams)) {
+        cs_set_error("cs_ba_intercam_apply_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    int C_ = 0;
+    {
+        std::lock_guard<std::mutex> lk(ic->mu);
+        C_ = ic->lastC;
+    }
+    if (C_ != ic->nCams) {
+        cs_set_error("cs_ba_intercam_apply_dev: no finished solve of this estimator (its last problem has %d cameras, the rig %d)", C_, ic->nCams);
+        return CS_ERR_INVALID;
+    }
+    double *dRs = nullptr, *dTs = nullptr, *dPts = nullptr;
+    int rc = cs_ba_result_buffers(b, &dRs, &dTs, &dPts);
+    if (rc) return rc;
+    CS_HIP(hipSetDevice(ic->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    CS_HIP(hipMemcpyAsync(d_Rcur, dRs, sizeof(double) * 9 * ic->nCams, hipMemcpyDeviceToDevice, s));
+    CS_HIP(hipMemcpyAsync(d_tcur, dTs, sizeof(double) * 3 * ic->nCams, hipMemcpyDeviceToDevice, s));
+    if (h && (rc = cs_track_history_set_span_dev(h, hip_stream, cs_track_history_newest_frame(h), 1, d_Rcur, d_tcur))) return rc;
+    return cs_pose_update3d_dev(ic->device, hip_stream, ic->nCams, 0, ic->nCams, cams, N, d_pointFeat, nMap, d_Rcur, d_tcur, d_mapPts, d_mapCov,
+                                d_mapFlags, /*largeErr*/ 0, pixelErrVar, d_numNodes, d_numOut);
+}
+
 }  // extern "C"

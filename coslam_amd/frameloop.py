@@ -55,6 +55,9 @@ class LoopConfig:
         self.map_spare = 8192      # room for new map points behind the initial map
         self.klt_cams_per_launch = 0
         self.klt_xcd_placement = True
+        self.keyframe_decision = False   # CoSLAM::IsReadyForKeyFrame + addKeyFrame's key-pose state per frame on the device (cs_keyframe_ready_dev),
+        # REPORTED (FrameLoop.keyframe_stats); the key frames themselves stay on the fixed key_every cadence -- RobustBundleRTS::output()'s
+        # apply assumes equally spaced key frames (cs_ba_output_apply_dev), so the decision does not drive them yet
         self.feature_chains = True   # MapPoint::pFeatures kept as feature references (cs_feat_ref): a camera that lost a point still contributes
         # its last feature to refineMapPoint / updateNewPosesPoints, and a point registered to a new track where it held an older feature has
         # the old chain linked behind it (reference src/app/SL_CoSLAM.cpp:775-779); False: the features of this frame on their own tracks
@@ -476,6 +479,44 @@ class FrameLoop:
             self.pose_upd.detect_dynamic_dev(self.pose_s.cuda_stream, self.pu_args, self.d_R[0].data_ptr(), self.d_t[0].data_ptr(), self.n_map,
                                              self.d_mapflags.data_ptr(), 0, 20, 5, 3, MAX_EPI_ERR)
             torch.cuda.synchronize()
+        if cfg.keyframe_decision:
+            self.enable_keyframe_decision(0, 0)
+
+    def enable_keyframe_decision(self, frame, b):
+        """the key-pose state as CoSLAM::initMap leaves it (reference src/app/SL_CoSLAM.cpp:246-256, :278-291) -- or as a key frame added at
+        `frame` would: a key pose with self motion in every camera (pose buffer b), nMappedPts = the certainly static mapped features of that
+        frame, m_minCamTranslation = the mean distance between the cameras / 4.5.  From the next step on cs_keyframe_ready_dev runs per frame.
+        Synchronises."""
+        from coslam_amd.keyframe import keyframe_cams
+
+        torch, NA = self.torch, self.cfg.n_cams
+        torch.cuda.synchronize()
+        i32, f64 = torch.int32, torch.float64
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=self.dev)   # noqa: E731
+        st, fl, s2m = self.d_state.cpu().numpy(), self.d_mapflags.cpu().numpy(), self.d_slot2map.cpu().numpy()
+        km = [int((((st[g] == 0) | (st[g] == 1)) & (s2m[g] >= 0) & ((fl[np.clip(s2m[g], 0, len(fl) - 1)] & 7) == 0)).sum()) for g in range(NA)]
+        self.kf = dict(frame=torch.full((NA,), int(frame), dtype=i32, device=self.dev), mapped=torch.tensor(km, dtype=i32, device=self.dev),
+                       selfR=self.d_R[b].clone(), selfT=self.d_t[b].clone(), ready=z(NA + 2, i32), cnt=z(2 * NA, i32), cen=z((NA, 3), f64),
+                       stats=z(5, i32), frames=0)
+        Rn, tn = self.d_R[b].cpu().numpy().reshape(NA, 3, 3), self.d_t[b].cpu().numpy()
+        cen = np.stack([-Rn[g].T @ tn[g] for g in range(NA)])
+        dist = [np.linalg.norm(cen[a] - cen[c]) for a in range(NA) for c in range(a + 1, NA)]
+        self.kf["min_translation"] = float(np.mean(dist) / 4.5) if dist else 0.1
+        self.kf["cams"] = [keyframe_cams([dict(state=self.d_state[g].data_ptr(), slot2map=self.d_slot2map[g].data_ptr(),
+                                               R=self.d_R[q][g].data_ptr(), t=self.d_t[q][g].data_ptr(), keyFrame=self.kf["frame"][g:].data_ptr(),
+                                               keyMapped=self.kf["mapped"][g:].data_ptr(), selfR=self.kf["selfR"][g].data_ptr(),
+                                               selfT=self.kf["selfT"][g].data_ptr()) for g in range(NA)]) for q in range(2)]
+        torch.cuda.synchronize()
+
+    def keyframe_stats(self):
+        """what the key-frame decision said over the frames it ran on (cs_keyframe_ready_dev's d_stats; a synchronous read)"""
+        if not getattr(self, "kf", None):
+            return None
+        a = self.kf["stats"].cpu().tolist()
+        return dict(frames=self.kf["frames"], frames_with_a_camera_ready=a[0], frames_with_decrease_ie_key_frames_added=a[1],
+                    cameras_saying_decrease=a[2], cameras_saying_view_angle=a[3], cameras_saying_translation=a[4],
+                    min_cam_translation=self.kf["min_translation"], last_key_frame_per_camera=self.kf["frame"].cpu().tolist(),
+                    mapped_static_at_the_last_key_frame=self.kf["mapped"].cpu().tolist())
 
     def _handback(self, b, frame, which="all"):
         from coslam_amd.handback import handback_dev
@@ -574,6 +615,16 @@ class FrameLoop:
         # the reference's order of a frame (src/gui/CoSLAMThread.cpp:104-118): poseUpdate (with mapPointsClassify) -> activeMapPointsRegister ->
         # genNewMapPoints -> currentMapPointsRegister: the new map points take their features BEFORE the current points' registration
         # looks at them (a feature that carries a point ends a registration walk)
+        if getattr(self, "kf", None):
+            # genNewMapPoints' first half (:1294-1346): is a camera ready for a key frame, and addKeyFrame's bookkeeping when one's mapped
+            # points have decreased
+            from coslam_amd.keyframe import keyframe_ready_dev
+
+            k = self.kf
+            keyframe_ready_dev(ps, k["cams"][dst], cfg.n_feat, self.n_map, self.d_map.data_ptr(), self.d_mapflags.data_ptr(), self.d_firstfrm.data_ptr(),
+                               i, k["min_translation"], k["ready"].data_ptr(), k["cnt"].data_ptr(), k["cen"].data_ptr(), addKeyFrame=True,
+                               d_stats=k["stats"].data_ptr(), device=self.device)
+            k["frames"] += 1
         if self.ncc is not None and i % cfg.ncc_every == 0:
             self._ncc_leg(i, f, dst)
         if cfg.with_register:

@@ -556,6 +556,34 @@ int cs_update_new_poses_points_dev(const cs_track_history* h, void* hip_stream, 
 int cs_refine_map_points_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap,
                              const unsigned char* d_select, double* d_mapPts, double* d_mapCov, double pixelErrVar, int* d_count);
 
+/* ---- The key-frame decision (CoSLAM::genNewMapPoints' first half; VERDICT r04 missing 7) ------------------------------------------------
+ * CoSLAM::IsReadyForKeyFrame (src/app/SL_CoSLAM.cpp:1269-1279) for every camera in one launch: READY_FOR_KEY_FRAME_DECREASE (1) when the
+ * frame's features whose map point is older than the camera's last key pose number fewer than `ratio` (m_mappedPtsReduceRatio, 0.93)
+ * times that key pose's nMappedPts, or fewer than 30 (:1249-1268); else _VIEWANGLE (2) when the angle at the mean of the frame's mapped,
+ * not false points (:1224-1247) between the last self-motion key pose's centre and the current one exceeds minViewAngleDeg
+ * (m_minViewAngleChange, 5.0; the reference's PI = 3.14 kept); else _TRANSLATION (3) when the two centres are further apart than
+ * minTranslation (m_minCamTranslation); else 0.  Both feature loops stop before the frame's LAST feature (`fp != pTail`, :1233, :1258);
+ * SingleSLAM::getNumMappedStaticPts (the count that becomes the next key pose's nMappedPts) does not.  Features = the hand-back's records
+ * (state 0 / 1, slot2map) in slot order.  d_ready [nCams + 2]: the codes, then genNewMapPoints' nReady and `decrease` (:1298-1309);
+ * d_mapped [2 nCams]: m_nMappedStaticPts, then the decrease test's count; d_center [nCams][3]; d_stats [5] or NULL, accumulated: frames
+ * with nReady > 0, frames with decrease, cameras that said 1 / 2 / 3.  addKeyFrame != 0: when `decrease` holds, every camera's key-pose
+ * state is moved on as CoSLAM::addKeyFrame -> SingleSLAM::addKeyPose does (:1280-1293, SL_SingleSLAM.cpp:835-862): keyFrame = curFrame,
+ * keyMapped = m_nMappedStaticPts, and the current pose becomes the self-motion key pose of the cameras whose code is > 0.
+ * Pinned against the reference's own functions compiled in place (tests/cxx/ref_keyframe_test.cpp -> tests/golden/keyframe_golden.npz). */
+typedef struct {
+    const int* state;      /* N: the hand-back's state (0 tracked, 1 new: a feature of this frame) */
+    const int* slot2map;   /* N: map point index of the slot's feature or -1 */
+    const double* R;       /* 9, 3: m_camPos.current() */
+    const double* t;
+    int* keyFrame;         /* [1] in / out: m_keyPose.tail->frame */
+    int* keyMapped;        /* [1] in / out: m_keyPose.tail->nMappedPts */
+    double* selfR;         /* 9, 3 in / out: m_selfKeyPose.back()->cam */
+    double* selfT;
+} cs_keyframe_cam;
+int cs_keyframe_ready_dev(int device, void* hip_stream, int nCams, int N, const cs_keyframe_cam* cams, int nMap, const double* d_mapPts,
+                          const unsigned char* d_mapFlags, const int* d_firstFrame, int curFrame, double ratio, double minViewAngleDeg,
+                          double minTranslation, int addKeyFrame, int* d_ready, int* d_mapped, double* d_center, int* d_stats);
+
 /* ---- MapPoint::pFeatures as the reference holds them: feature references (round 5; VERDICT r04 missing 3) ---------------------------------
  * p->pFeatures[c] is the feature of this frame while camera c tracks the point -- and STAYS what it last was when the camera loses it
  * (nothing clears the pointer): updateStaticPointPosition / updateDynamicPointPosition (src/slam/SL_CoSLAMHelper.cpp:338-394, 455-484),
@@ -1029,6 +1057,16 @@ int cs_ba_solve_intercam_async(cs_ba* b, cs_ba_intercam* ic, void* after_stream,
                                const unsigned char* d_mapFlags, const unsigned char* d_newPt, const int* d_pointFeat, double maxErr,
                                int maxIter, int innerMaxIter);
 int cs_ba_intercam_last_problem(cs_ba_intercam* ic, int* C, int* P, int* nObs, int* nStatic, const int** d_pointMap);
+/* InterCamPoseEstimator::apply's write-back (src/app/SL_InterCamPoseEstimator.cpp:100-136; VERDICT r04 missing 5) behind a FINISHED solve
+ * of ic on workspace b (cs_ba_wait): the solved poses become the cameras' current poses -- d_Rcur / d_tcur (nCams x 9 / 3), and the newest
+ * frame of h when h != NULL --, then per camera the gate over its static mapped track nodes under the new pose: error < 2 -> reprojErr and
+ * seqTriangulate, else reprojErr = the pixel distance and the point uncertain.  The loop is SingleSLAM::poseUpdate3D's own
+ * (src/app/SL_SingleSLAM.cpp:677-706): cs_pose_update3d_dev's kernel, its arguments (cams: K, xy, state, slot2map, reprojErr; d_numNodes /
+ * d_numOut [nCams] or NULL).  The reference's shipped loop never calls interCamPoseUpdate (src/gui/CoSLAMThread.cpp:95-130); neither do
+ * the frame loops here -- an entry point for a caller that does. */
+int cs_ba_intercam_apply_dev(cs_ba* b, cs_ba_intercam* ic, void* hip_stream, cs_track_history* h, const cs_poseupdate_cam* cams, int N,
+                             const int* d_pointFeat, int nMap, double* d_Rcur, double* d_tcur, double* d_mapPts, double* d_mapCov,
+                             unsigned char* d_mapFlags, double pixelErrVar, int* d_numNodes, int* d_numOut);
 /* size and bind workspace b for the largest problem w can produce (cs_ba_solve_window_async does it on first use); afterwards
  * cs_ba_result_buffers' addresses stay put across the window's solves -- a follow-up record can be built before the first */
 int cs_ba_reserve_for_window(cs_ba* b, cs_ba_window* w);

@@ -1202,3 +1202,38 @@ def new_map_points_from_pairs(N, pairs, Ks, iKs, Rs, ts, xy, state, slot2map, is
             if is_static:
                 mapFlags[m] = 0
     return dict(matches=match, tracks=tracks, new=new, map_count=map_count)
+
+
+def keyframe_ready(state, slot2map, R, t, selfR, selfT, keyFrame, keyMapped, mapPts, mapFlags, firstFrame, ratio, minViewAngleDeg, minTranslation):
+    """CoSLAM::IsReadyForKeyFrame (/root/reference/src/app/SL_CoSLAM.cpp:1269-1279) for ONE camera, restated in numpy: state / slot2map
+    int32[N] (the hand-back's records in slot = feature-list order), the current pose, the last self-motion key pose, the last key pose's
+    frame and nMappedPts.  Returns (code, m_nMappedStaticPts, num, center): getCurMapCenterViewFrom (:1224-1247) and
+    IsMappedPtsDecreaseBelow (:1249-1268) stop BEFORE the frame's last feature (`fp && fp != pTail`), getNumMappedStaticPts
+    (SL_SingleSLAM.cpp:121-136) includes it; the centre is summed in list order as the reference does; angles by acos with the
+    reference's PI = 3.14 (SL_SLAMHelper.cpp:208-217).  TEST INFRASTRUCTURE."""
+    has = np.nonzero((state == 0) | (state == 1))[0]
+    m_all = slot2map[has]
+    fl_all = np.where(m_all >= 0, mapFlags[np.clip(m_all, 0, len(mapFlags) - 1)], 0)
+    n_static = int(((m_all >= 0) & ((fl_all & 7) == 0)).sum())
+    inner = has[:-1] if len(has) else has
+    m = slot2map[inner]
+    m = m[m >= 0]
+    num = int((firstFrame[m] <= keyFrame).sum())
+    cen, n = np.zeros(3), 0
+    for q in m:
+        if not (mapFlags[q] & 2):
+            cen = cen + mapPts[q]
+            n += 1
+    with np.errstate(invalid="ignore", divide="ignore"):
+        cen = cen / n
+    if num < keyMapped * ratio or num < 30:
+        return 1, n_static, num, cen
+    C0, C1 = -(selfR.reshape(3, 3).T @ selfT), -(R.reshape(3, 3).T @ t)
+    a, b = C0 - cen, C1 - cen
+    with np.errstate(invalid="ignore"):
+        ang = abs(np.arccos(a @ b / np.sqrt((a @ a) * (b @ b)))) / 3.14 * 180.0
+    if ang > minViewAngleDeg:
+        return 2, n_static, num, cen
+    if np.sqrt(((C0 - C1) ** 2).sum()) > minTranslation:
+        return 3, n_static, num, cen
+    return 0, n_static, num, cen

@@ -19,4 +19,6 @@ void getFMat(const double* invK1, const double* invK2, const double* E, double* 
 /* distance of m2 to the epipolar line F m1 */
 double epipolarError(const double* F, const double* m2, const double* m1);
 void computeEpipolarLine(const double* F, double x, double y, double* l);
+/* declared for src/slam/SL_SLAMHelper.cpp's RANSAC pose helpers (off every driver's path: no definition, dropped by --gc-sections) */
+void project(const double* K, const double* R, const double* t, int npts, const double* Ms, double* ms);
 #endif

@@ -27,4 +27,7 @@ void mat33Inv(const double* A, double* invA);
 void mat33Trans(const double* A, double* At);
 /* Euclidean distance of two 2-vectors (src/app/SL_SingleSLAM.cpp:658: dist2(m, fp->m)) */
 double dist2(const double* a, const double* b);
+/* declared for src/slam/SL_SLAMHelper.cpp (solvePnPRansac, getCameraCenterAxes: off every driver's path, no definition) */
+void randChoose(int n, int* idx, int k);
+void mat33TransProdVec(const double* A, const double* v, double* r);
 #endif

@@ -699,6 +699,66 @@ def update_points_relink_case():
     return out
 
 
+def keyframe_case():
+    """the reference's own key-frame decision (oracle/_ref/ref_keyframe_test golden, CPU): CoSLAM::IsReadyForKeyFrame with its helpers,
+    compiled in place, on 6 scenes of 3-6 cameras x 400 slots; the device's tables (state, slot2map) and the reference's answers"""
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_keyframe_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_keyframe_test missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "k.bin")
+        subprocess.run([exe, "golden", path], check=True, stdout=subprocess.DEVNULL)
+        raw = open(path, "rb").read()
+    o = 0
+
+    def ints(n):
+        nonlocal o
+        v = np.frombuffer(raw, dtype=np.int32, count=n, offset=o).copy()
+        o += 4 * n
+        return v
+
+    def dbls(n):
+        nonlocal o
+        v = np.frombuffer(raw, dtype=np.float64, count=n, offset=o).copy()
+        o += 8 * n
+        return v
+
+    out = {}
+    (nS,) = ints(1)
+    out["n_scenes"] = np.int32(nS)
+    for sc in range(nS):
+        nC, N, nMap, cur = ints(4)
+        ratio, ang, trans = dbls(3)
+        M, flags, first = np.zeros((nMap, 3)), np.zeros(nMap, np.uint8), np.zeros(nMap, np.int32)
+        for p in range(nMap):
+            M[p] = dbls(3)
+            ltype, unc, first[p] = ints(3)
+            flags[p] = (1 if ltype == 1 else 0) | (2 if ltype == -2 else 0) | (4 if unc else 0)
+        R, t, sR, sT = np.zeros((nC, 9)), np.zeros((nC, 3)), np.zeros((nC, 9)), np.zeros((nC, 3))
+        kf, km = np.zeros(nC, np.int32), np.zeros(nC, np.int32)
+        state, s2m = np.full((nC, N), -1, np.int32), np.full((nC, N), -1, np.int32)
+        for c in range(nC):
+            R[c], t[c], sR[c], sT[c] = dbls(9), dbls(3), dbls(9), dbls(3)
+            kf[c], km[c] = ints(2)
+            mo = ints(N)
+            state[c] = np.where(mo == -2, -1, 0)
+            s2m[c] = np.where(mo >= 0, mo, -1)
+        ready, nstat, cen = np.zeros(nC, np.int32), np.zeros(nC, np.int32), np.zeros((nC, 3))
+        for c in range(nC):
+            ready[c], nstat[c] = ints(2)
+            cen[c] = dbls(3)
+        pre = f"s{sc}_"
+        for k, v in dict(mapPts=M, mapFlags=flags, firstFrame=first, R=R, t=t, selfR=sR, selfT=sT, keyFrame=kf, keyMapped=km, state=state,
+                         slot2map=s2m, curFrame=np.int32(cur), ratio=np.float64(ratio), minViewAngle=np.float64(ang),
+                         minTranslation=np.float64(trans), ready_ref=ready, nMappedStatic_ref=nstat, center_ref=cen).items():
+            out[pre + k] = v
+    assert o == len(raw)
+    return out
+
+
 def classify_case():
     """the reference's own CoSLAM::mapPointsClassify over isStaticPoint / isStaticPointExclude / isDynamicPoint / isLittleMove /
     isStaticRemovable (oracle/_ref/ref_classify_test golden, CPU): 3 scenes of 72 map points walking every branch, re-laid out the
@@ -788,7 +848,7 @@ def classify_case():
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "mergability_long", "update_points", "update_points_relink", "classify", "intercam", "newpts", "decide"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "mergability_long", "update_points", "update_points_relink", "keyframe", "classify", "intercam", "newpts", "decide"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -811,6 +871,8 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "mergability_long_golden.npz"), **mergability_long_case())
     if "update_points" in which:
         np.savez_compressed(os.path.join(HERE, "update_points_golden.npz"), **update_points_case())
+    if "keyframe" in which:
+        np.savez_compressed(os.path.join(HERE, "keyframe_golden.npz"), **keyframe_case())
     if "update_points_relink" in which:
         np.savez_compressed(os.path.join(HERE, "update_points_relink_golden.npz"), **update_points_relink_case())
     if "classify" in which:

@@ -51,13 +51,9 @@ def test_device_built_problem_is_the_one_the_reference_builds(hip):
         assert np.array_equal(r["pts"], G("pts")) and np.array_equal(r["Rs"].reshape(-1, 9), G("curR")) and np.array_equal(r["Ts"], G("curT"))
 
 
-def test_the_solve_behind_the_device_build_matches_the_oracle(hip):
-    """bundleAdjustRobust(0, Ks, Rs, Ts, m_numStatic, pts, meas, 6, 3, 40) (SL_InterCamPoseEstimator.cpp:95) on the device-built problem
-    against the oracle's restatement of addMapPoints + the oracle's solver.  The golden scenes' pixels are unrelated to their map
-    points (they pin the bookkeeping); here the mapped features of scene 1 are moved onto the projections of their map points
-    under slightly different poses, so that the solve has something to find."""
-    import oracle
-
+def _scene_with_pixels_on_the_projections():
+    """golden scene 1 with the mapped features moved onto the projections of their map points under slightly different poses (the golden
+    scenes' pixels are unrelated to their map points: they pin the bookkeeping), so that a solve has something to find"""
     g0 = np.load(os.path.join(os.path.dirname(__file__), "golden", "intercam_golden.npz"))
     g = {k: g0[k].copy() for k in g0.files}
     sc = 1
@@ -82,6 +78,19 @@ def test_the_solve_behind_the_device_build_matches_the_oracle(hip):
                 G("pointFeat")[m, c] = -1
                 continue
             G("xy")[c][s_], G("xy")[c][N + s_] = px
+    return g, sc
+
+
+def test_the_solve_behind_the_device_build_matches_the_oracle(hip):
+    """bundleAdjustRobust(0, Ks, Rs, Ts, m_numStatic, pts, meas, 6, 3, 40) (SL_InterCamPoseEstimator.cpp:95) on the device-built problem
+    against the oracle's restatement of addMapPoints + the oracle's solver.  The golden scenes' pixels are unrelated to their map
+    points (they pin the bookkeeping); here the mapped features of scene 1 are moved onto the projections of their map points
+    under slightly different poses, so that the solve has something to find."""
+    import oracle
+
+    g, sc = _scene_with_pixels_on_the_projections()
+    G = lambda k: g[f"s{sc}_{k}"]   # noqa: E731
+    nc, N, nMap, frame, W, H, ncb, nrb, ps = (int(v) for v in G("dims"))
     want = oracle.intercam_add_map_points(W, H, ncb, nrb, ps, G("xy"), G("state"), G("slot2map"), G("trackSpan"), G("isStatic"), G("mapPts"),
                                           G("mapFlags"), G("newPt"), G("pointFeat"))
     r = _build(sc, g, 3, 40)
@@ -94,3 +103,51 @@ def test_the_solve_behind_the_device_build_matches_the_oracle(hip):
     assert st_o.nIterTotal == r["stats"].nIterTotal > 3 and np.array_equal(out_o, r["outlier"]) and r["stats"].cost < 0.5 * r["stats"].cost0
     assert np.abs(r["Rs"] - Ro).max() < 1e-6 and np.abs(r["Ts"] - To).max() < 1e-5 and np.abs(r["pts"] - Mo).max() < 1e-5
     assert np.array_equal(r["pts"][:r["nStatic"]], want["pts"][:r["nStatic"]])   # the static points are held
+
+
+def test_apply_writes_the_poses_back_and_gates_the_map_like_the_reference(hip):
+    """cs_ba_intercam_apply_dev (VERDICT r04 missing 5): InterCamPoseEstimator::apply's write-back (reference
+    src/app/SL_InterCamPoseEstimator.cpp:100-136) behind the solve of the scene above -- the solved poses ARE the current poses afterwards,
+    and the map has gone through the gate of poseUpdate3D's tail under them (the loop at :105-136 is SL_SingleSLAM.cpp:677-706 statement for
+    statement; the oracle's restatement of that loop is pinned to the reference's own): inliers re-triangulated, outliers uncertain, the
+    features' reprojErr -- bit for bit against oracle.pose_update_gate run with the same poses, camera after camera."""
+    import torch
+
+    import oracle
+    from coslam_amd.poseupdate import poseupdate_cams
+
+    g, sc = _scene_with_pixels_on_the_projections()
+    G = lambda k: g[f"s{sc}_{k}"]   # noqa: E731
+    nc, N, nMap, frame, W, H, ncb, nrb, ps = (int(v) for v in G("dims"))
+    r = _build(sc, g, 3, 40)
+    ic, ws, dK, dxy, dst, ds2m, dsp, dfs, dM, dfl, dnp, dpf, dR, dT = r["keep"]
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(9)
+    A = rng.normal(0, 0.03, (nMap, 3, 3))
+    cov0 = (A @ A.transpose(0, 2, 1) + 1e-5 * np.eye(3)).reshape(nMap, 9)
+    d_cov = torch.from_numpy(cov0.copy()).to(dev)
+    d_err = torch.zeros((nc, N), dtype=torch.float64, device=dev)
+    d_nodes, d_out = torch.zeros(nc, dtype=torch.int32, device=dev), torch.zeros(nc, dtype=torch.int32, device=dev)
+    pu = poseupdate_cams([dict(K=dK.data_ptr(), xy=dxy[c].data_ptr(), state=dst[c].data_ptr(), slot2map=ds2m[c].data_ptr(),
+                               reprojErr=d_err[c].data_ptr()) for c in range(nc)])
+    M0, fl0 = G("mapPts").copy(), G("mapFlags").copy()
+    # a few features off their points by 25 px (behind the solve, in front of the gate: outliers for the gate to find)
+    xy = G("xy").copy()
+    for c in range(nc):
+        on = np.nonzero((G("state")[c] >= 0) & (G("slot2map")[c] >= 0))[0][::9]
+        xy[c][on] += 25.0
+    dxy.copy_(torch.from_numpy(xy))
+    ic.apply_dev(ws, s, pu, N, dpf.data_ptr(), nMap, dR.data_ptr(), dT.data_ptr(), dM.data_ptr(), d_cov.data_ptr(), dfl.data_ptr(), float(np.sqrt(10.0)),
+                 d_numNodes=d_nodes.data_ptr(), d_numOut=d_out.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(dR.cpu().numpy().reshape(nc, 3, 3), r["Rs"]) and np.array_equal(dT.cpu().numpy(), r["Ts"])
+    assert np.abs(r["Rs"].reshape(nc, 9) - G("curR")).max() > 1e-4   # (the solve moved them)
+    Mw, cw, fw = M0.copy(), cov0.copy(), fl0.copy()
+    errs = [np.zeros(N) for _ in range(nc)]
+    want = oracle.pose_update_gate([r["K"]] * nc, r["Rs"].reshape(nc, 9), r["Ts"], list(xy), list(G("state")), list(G("slot2map")), Mw, cw, fw, 0,
+                                   float(np.sqrt(10.0)), errs)
+    assert np.array_equal(dM.cpu().numpy(), Mw) and np.array_equal(d_cov.cpu().numpy(), cw) and np.array_equal(dfl.cpu().numpy(), fw)
+    assert np.array_equal(d_err.cpu().numpy(), np.stack(errs))
+    assert d_nodes.cpu().numpy().tolist() == [w[0] for w in want] and d_out.cpu().numpy().tolist() == [w[1] for w in want]
+    assert sum(w[0] for w in want) > 200 and (Mw != M0).any(axis=1).sum() > 100 and 0 < sum(w[1] for w in want) < sum(w[0] for w in want)
