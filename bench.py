@@ -544,6 +544,11 @@ def main():
     else:
         frames = render_video(my_cams, N_FRAMES)
     t_render = time.perf_counter() - t_r
+    # N > 1: rank 0 also holds the other cameras' frames on the host, for the workload file of the C++ loop's ranks (config.cxx_frame_loop)
+    cxx_frames = None
+    if n_gpus > 1 and rank == 0 and not args.no_cxx_loop and os.environ.get("BENCH_VIDEO") != "pingpong":
+        cxx_frames = dict(frames)
+        cxx_frames.update(render_video([c for c in range(N_CAMS) if c not in my_cams], N_FRAMES))
 
     import torch
     import torch.distributed as dist
@@ -1066,20 +1071,20 @@ def main():
     # ---- the same loop driven from C++ through the C-ABI only (north_star: "Host stays C++"): tools/cxx/frame_loop.cpp, its
     # own process, the workload handed over as a file; same steps / warm-up / key-frame cadence / drain
     cxx = None
+    cxx_args = [str(args.steps), str(args.warmup), str(args.klt_cams_per_launch), str(loop.lag), str(n_timed_end - args.steps + 1)]   # (the same
+    # stretch of the sequence as the timed region above)
+    cxx_env = dict(os.environ, COSLAM_PIXEL_ERR_STD="1" if args.pixel_err_reading == "std" else "0", HSA_KERNARG_POOL_SIZE=str(64 << 20))
+    cxx_exe = os.path.join(ROOT, "tools", "cxx", "frame_loop.bin")
     if rank == 0 and n_gpus == 1 and not args.no_cxx_loop and ke == KEY_EVERY:
         import subprocess
         import tempfile
 
-        exe = os.path.join(ROOT, "tools", "cxx", "frame_loop.bin")
-        if os.path.exists(exe):
+        if os.path.exists(cxx_exe):
             torch.cuda.synchronize()
             with tempfile.TemporaryDirectory() as td:
                 wl = os.path.join(td, "workload.bin")
                 export_workload(wl, sc, frames, build_joint_problem(sc), ic, args.klt_cams_per_launch)
-                pr = subprocess.run([exe, wl, str(args.steps), str(args.warmup), str(args.klt_cams_per_launch), str(loop.lag),
-                                     str(n_timed_end - args.steps + 1)],   # (the same stretch of the sequence as the timed region above)
-                                    capture_output=True, text=True, timeout=600,
-                                    env=dict(os.environ, COSLAM_PIXEL_ERR_STD="1" if args.pixel_err_reading == "std" else "0"))
+                pr = subprocess.run([cxx_exe, wl] + cxx_args, capture_output=True, text=True, timeout=600, env=cxx_env)
             if pr.returncode == 0 and pr.stdout.strip().startswith("{"):
                 cxx = json.loads(pr.stdout.strip().splitlines()[-1])
                 cxx["what"] = ("tools/cxx/frame_loop.cpp: the headline loop from C++ through include/coslam_hip.h only (no Python, no "
@@ -1088,6 +1093,63 @@ def main():
                 cxx = {"error": (pr.stderr or pr.stdout)[-400:]}
         else:
             cxx = {"error": "tools/cxx/frame_loop.bin not built (python -c 'import __graft_entry__ as g; g.build()')"}
+    elif n_gpus > 1 and not args.no_cxx_loop and ke == KEY_EVERY:
+        # N > 1, host stays C++: every rank starts ITS rank of tools/cxx/frame_loop.bin (one process per GPU; the ranks find each other
+        # through cs_comm_unique_id left in a file by rank 0, ncclCommInitRank inside the library) on the workload file rank 0 wrote.  A
+        # diagnostic leg: bounded by a timeout, never the reason a bench line is lost.
+        import shutil
+        import subprocess
+
+        td = os.path.join("/tmp", f"coslam_cxx_{os.environ.get('MASTER_PORT', '0')}_{n_gpus}")
+        cdev = dev if dist_backend == "nccl" else torch.device("cpu")   # (where the backend takes its tensors)
+        ok_here = torch.tensor([1 if os.path.exists(cxx_exe) else 0], dtype=torch.int32, device=cdev)
+        try:
+            if rank == 0:
+                shutil.rmtree(td, ignore_errors=True)
+                os.makedirs(td)
+                if cxx_frames is not None:
+                    export_workload(os.path.join(td, "workload.bin"), sc, cxx_frames, build_joint_problem(sc), ic, args.klt_cams_per_launch)
+                else:
+                    ok_here[0] = 0
+        except Exception:   # noqa: BLE001
+            ok_here[0] = 0
+        dist.all_reduce(ok_here, op=dist.ReduceOp.MIN)   # (also the barrier behind the export)
+        if int(ok_here.item()) == 1:
+            torch.cuda.synchronize()
+            env = dict(cxx_env, COSLAM_COMM_ID_FILE=os.path.join(td, "id"))
+            env.pop("COSLAM_FORCE_DEVICE", None)
+            if os.environ.get("BENCH_FORCE_DEVICE") is not None:
+                # test hook (ranks sharing ONE GPU, tests/test_bench_contract_gpu.py): RCCL refuses two ranks on a device -- the library's
+                # test transport and the launch-per-pass tracker instead
+                env.update(COSLAM_FORCE_DEVICE=os.environ["BENCH_FORCE_DEVICE"], COSLAM_COMM=f"host:/coslam_bench_{os.environ.get('MASTER_PORT', '0')}",
+                           COSLAM_KLT_FUSED="0")
+            try:
+                pr = subprocess.run([cxx_exe, os.path.join(td, "workload.bin")] + cxx_args, capture_output=True, text=True, timeout=240, env=env)
+                mine = json.loads(pr.stdout.strip().splitlines()[-1]) if pr.returncode == 0 and pr.stdout.strip().startswith("{") else \
+                    {"error": (pr.stderr or pr.stdout)[-400:]}
+            except Exception as ex:   # noqa: BLE001  (timeout: a rank that never arrived)
+                mine = {"error": str(ex)[:300]}
+            # the ranks' digests must agree; the rate is the slowest rank's
+            try:
+                dgv, msv = (int(mine["digest"], 16) >> 1, int(1e6 * float(mine["ms_per_step"]))) if "digest" in mine else (-1, -1)
+            except Exception:   # noqa: BLE001
+                dgv, msv = -1, -1
+            dg = torch.tensor([dgv, msv], dtype=torch.int64, device=cdev)
+            alld = [torch.zeros_like(dg) for _ in range(world)]
+            dist.all_gather(alld, dg)
+            if rank == 0:
+                cxx = dict(mine)
+                if "error" not in mine and all(int(v[0]) >= 0 for v in alld):
+                    ms = max(int(v[1]) for v in alld) / 1e6
+                    cxx.update(ms_per_step=ms, frames_per_s=1e3 / ms, ranks=world,
+                               identical_digest_on_every_rank=bool(all(int(v[0]) == int(alld[0][0]) for v in alld)),
+                               what="tools/cxx/frame_loop.cpp at N > 1: one C++ process per GPU, cameras sharded like the Python loop's, the "
+                                    "collectives through the library's own cs_comm_* / cs_exchange_* (RCCL); the slowest rank's rate")
+                else:
+                    cxx["ranks_that_failed"] = [q for q, v in enumerate(alld) if int(v[0]) < 0]
+                shutil.rmtree(td, ignore_errors=True)
+        elif rank == 0:
+            cxx = {"error": "the C++ loop's ranks were not started (binary or workload file missing on a rank)"}
 
     if rank == 0:
         reg_out, d_mapflags = loop.reg_out, loop.d_mapflags

@@ -13,9 +13,16 @@
 // carries PyTorch's copy shares it.  Payloads are small (40 KB per camera; 166 KB of S at order 144): latency-bound on
 // xGMI, so each is ONE collective, never chunked.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
+#include <atomic>
+#include <chrono>
 #include <new>
+#include <thread>
 
 #include "cs_common.h"
 
@@ -73,10 +80,63 @@ RcclApi* rccl_api() {
 
 }  // namespace
 
+// ---- the test transport: ranks that SHARE one GPU (RCCL refuses two ranks on a device) -----------------------------------------------
+// cs_comm_create_host: the same collectives staged through a POSIX shared-memory segment -- stream synchronised, device -> segment,
+// barrier, segment -> device, barrier.  It blocks the host and moves every byte twice: it exists so that the N > 1 code paths of a
+// frame loop can be RUN where only one GPU is visible (tests/test_cxx_dropin_gpu.py: two ranks of tools/cxx/frame_loop.bin on one
+// MI355X end in the one-rank run's map), the role gloo plays for the Python loop's tests.  Never the transport of a measured number.
+struct HostShm {
+    std::atomic<int> arrived;
+    std::atomic<int> generation;
+    std::atomic<int> attached;
+    int world;
+    size_t capacity;   // bytes of payload behind the header
+};
+constexpr size_t CS_HOST_SHM_BYTES = (size_t)96 << 20;
+
 struct cs_comm {
     ncclComm_t comm;
     int world, rank, device;
+    HostShm* host = nullptr;   // non-null: the test transport
+    unsigned char* hostData = nullptr;
+    char hostName[96] = {0};
 };
+
+namespace {
+int host_barrier(cs_comm* c) {
+    HostShm* h = c->host;
+    const int gen = h->generation.load(std::memory_order_acquire);
+    if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == c->world) {
+        h->arrived.store(0, std::memory_order_relaxed);
+        h->generation.store(gen + 1, std::memory_order_release);
+        return CS_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (h->generation.load(std::memory_order_acquire) == gen) {
+        std::this_thread::yield();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+            cs_set_error("host transport: a rank did not reach the barrier within 60 s");
+            return CS_ERR_HIP;
+        }
+    }
+    return CS_OK;
+}
+// every rank's `bytes` at d_send to every rank's d_recv; root >= 0: only root's part travels, into d_recv of every rank
+int host_collect(cs_comm* c, hipStream_t s, const void* d_send, void* d_recv, size_t bytes, int root) {
+    const size_t total = root >= 0 ? bytes : bytes * (size_t)c->world;
+    if (total > c->host->capacity) {
+        cs_set_error("host transport: %zu bytes exceed the segment's %zu", total, c->host->capacity);
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipStreamSynchronize(s));
+    if (root < 0 || root == c->rank)
+        CS_HIP(hipMemcpy(c->hostData + (root >= 0 ? 0 : bytes * (size_t)c->rank), d_send, bytes, hipMemcpyDeviceToHost));
+    int rc = host_barrier(c);
+    if (rc) return rc;
+    if (root < 0 || root != c->rank) CS_HIP(hipMemcpy(d_recv, c->hostData, total, hipMemcpyHostToDevice));
+    return host_barrier(c);   // (nobody overwrites the segment before everybody has read it)
+}
+}  // namespace
 
 constexpr int CS_EX_MAX_CAMS = 16;
 struct cs_exchange {
@@ -177,8 +237,78 @@ cs_comm* cs_comm_create(const unsigned char id[128], int world, int rank, int de
     return c;
 }
 
+// the test transport (above): every rank names the same segment; rank 0 creates it, the others attach
+cs_comm* cs_comm_create_host(const char* name, int world, int rank, int device) {
+    if (!name || !name[0] || strlen(name) > 90 || world < 1 || rank < 0 || rank >= world) {
+        cs_set_error("cs_comm_create_host: bad arguments");
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        cs_set_error("cs_comm_create_host: cannot select device %d", device);
+        return nullptr;
+    }
+    const size_t bytes = sizeof(HostShm) + CS_HOST_SHM_BYTES;
+    int fd = -1;
+    if (rank == 0) {
+        (void)shm_unlink(name);
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd >= 0 && ftruncate(fd, (off_t)bytes) != 0) {
+            close(fd);
+            fd = -1;
+        }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (fd < 0 && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(60)) {
+            fd = shm_open(name, O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes)) {   // (created, not yet sized)
+                close(fd);
+                fd = -1;
+            }
+            if (fd < 0) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        }
+    }
+    if (fd < 0) {
+        cs_set_error("cs_comm_create_host: cannot open the shared-memory segment %s", name);
+        return nullptr;
+    }
+    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) {
+        cs_set_error("cs_comm_create_host: mmap failed");
+        return nullptr;
+    }
+    cs_comm* c = new (std::nothrow) cs_comm();
+    if (!c) return nullptr;
+    c->comm = nullptr, c->world = world, c->rank = rank, c->device = device;
+    c->host = (HostShm*)m, c->hostData = (unsigned char*)m + sizeof(HostShm);
+    snprintf(c->hostName, sizeof(c->hostName), "%s", name);
+    if (rank == 0) {   // (a fresh segment is zero-filled: counters at 0; the others wait for `world` before their first barrier)
+        c->host->capacity = CS_HOST_SHM_BYTES;
+        c->host->world = world;
+    }
+    c->host->attached.fetch_add(1);
+    const auto t0 = std::chrono::steady_clock::now();
+    while (c->host->attached.load() < world || c->host->world != world) {
+        std::this_thread::yield();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+            cs_set_error("cs_comm_create_host: %d of %d ranks attached within 60 s", c->host->attached.load(), world);
+            munmap(m, bytes);
+            delete c;
+            return nullptr;
+        }
+    }
+    return c;
+}
+
 void cs_comm_destroy(cs_comm* c) {
     if (!c) return;
+    if (c->host) {
+        munmap((void*)c->host, sizeof(HostShm) + CS_HOST_SHM_BYTES);
+        if (c->rank == 0) (void)shm_unlink(c->hostName);
+        delete c;
+        return;
+    }
     RcclApi* api = rccl_api();
     if (api && c->comm) (void)api->commDestroy(c->comm);
     delete c;
@@ -220,8 +350,8 @@ void cs_exchange_destroy(cs_exchange* x) {
 
 int cs_exchange_allgather_dev(cs_exchange* x, void* hip_stream, const void* const* d_dests, const double* d_R,
                               const double* d_t) {
-    RcclApi* api = rccl_api();
-    if (!api || !x || !d_dests || !d_R || !d_t) {
+    RcclApi* api = (x && x->c->host) ? nullptr : rccl_api();
+    if ((!api && !(x && x->c->host)) || !x || !d_dests || !d_R || !d_t) {
         cs_set_error("cs_exchange_allgather_dev: bad arguments");
         return CS_ERR_INVALID;
     }
@@ -246,6 +376,7 @@ int cs_exchange_allgather_dev(cs_exchange* x, void* hip_stream, const void* cons
     hipLaunchKernelGGL(k_exchange_pack, dim3(gx, x->nCams), dim3(256), 0, s, A);
     CS_CHECK_LAUNCH();
     const size_t sendBytes = sizeof(int) * x->recWords * x->nCams;
+    if (x->c->host) return host_collect(x->c, s, x->send, x->recv, sendBytes, -1);
     CS_NCCL(api->allGather(x->send, x->recv, sendBytes, ncclInt8, x->c->comm, s));
     return CS_OK;
 }
@@ -277,13 +408,14 @@ int cs_exchange_unpack_poses_dev(cs_exchange* x, void* hip_stream, double* d_R, 
 // one buffer from rank `root` to every rank, in place, on hip_stream (ncclBroadcast): the packed result of a bundle adjustment
 // (cs_ba_output_*) from the rank that solved the window to every replica of the map
 int cs_comm_broadcast_dev(cs_comm* c, void* hip_stream, void* d_buf, size_t bytes, int root) {
-    RcclApi* api = rccl_api();
-    if (!api || !c || !d_buf || root < 0 || root >= c->world) {
+    RcclApi* api = (c && c->host) ? nullptr : rccl_api();
+    if ((!api && !(c && c->host)) || !c || !d_buf || root < 0 || root >= c->world) {
         cs_set_error("cs_comm_broadcast_dev: bad arguments");
         return CS_ERR_INVALID;
     }
     if (c->world == 1 || bytes == 0) return CS_OK;
     CS_HIP(hipSetDevice(c->device));
+    if (c->host) return host_collect(c, (hipStream_t)hip_stream, d_buf, d_buf, bytes, root);
     CS_NCCL(api->broadcast(d_buf, d_buf, bytes, ncclInt8, root, c->comm, (hipStream_t)hip_stream));
     return CS_OK;
 }
@@ -291,12 +423,13 @@ int cs_comm_broadcast_dev(cs_comm* c, void* hip_stream, void* d_buf, size_t byte
 // every rank's `bytes` at d_send to every rank's d_recv (rank r's part at r * bytes), on hip_stream (ncclAllGather): the candidate
 // tables of the registration search (cs_register_candidates_pack_dev) before the decision every rank then takes on its replica
 int cs_comm_allgather_dev(cs_comm* c, void* hip_stream, const void* d_send, void* d_recv, size_t bytes) {
-    RcclApi* api = rccl_api();
-    if (!api || !c || !d_send || !d_recv) {
+    RcclApi* api = (c && c->host) ? nullptr : rccl_api();
+    if ((!api && !(c && c->host)) || !c || !d_send || !d_recv) {
         cs_set_error("cs_comm_allgather_dev: bad arguments");
         return CS_ERR_INVALID;
     }
     CS_HIP(hipSetDevice(c->device));
+    if (c->host) return host_collect(c, (hipStream_t)hip_stream, d_send, d_recv, bytes, -1);
     CS_NCCL(api->allGather(d_send, d_recv, bytes, ncclInt8, c->comm, (hipStream_t)hip_stream));
     return CS_OK;
 }
@@ -307,8 +440,8 @@ int cs_comm_allgather_dev(cs_comm* c, void* hip_stream, const void* d_send, void
 int cs_ba_dist_solve(cs_ba* b, cs_comm* c, void* hip_stream, int C, int P, int nObs, const double* d_Rs0, const double* d_Ts0,
                      const double* d_pts0, int nCamsCon, int nPtsCon, double maxErr, int maxIter, int innerMaxIter) {
     RcclApi* api = rccl_api();
-    if (!api || !b || !c) {
-        cs_set_error("cs_ba_dist_solve: bad arguments");
+    if (!api || !b || !c || c->host) {
+        cs_set_error("cs_ba_dist_solve: bad arguments (RCCL communicators only: the host test transport has no all-reduce)");
         return CS_ERR_INVALID;
     }
     // ONE stream for the phases and the collectives: a NULL argument means the workspace's own stream for both (the phases

@@ -1122,6 +1122,11 @@ int cs_comm_available(void); /* 1: RCCL loaded with every entry point used here 
                                 that cannot load the library would leave the others waiting inside ncclCommInitRank */
 int cs_comm_unique_id(unsigned char id[128]); /* rank 0 creates it; the caller ships it to the other ranks */
 cs_comm* cs_comm_create(const unsigned char id[128], int world, int rank, int device); /* ncclCommInitRank */
+/* TEST TRANSPORT for ranks that share ONE GPU (RCCL refuses two ranks on a device): the same all-gather / broadcast entry points staged
+ * through a POSIX shared-memory segment `name` (rank 0 creates it) -- stream synchronised, device -> segment, barrier, segment -> device.
+ * It blocks the host; it exists so that a frame loop's N > 1 paths can run where one GPU is visible (what gloo is for the Python loop's
+ * tests).  Never the transport of a measured number; cs_ba_dist_solve refuses it. */
+cs_comm* cs_comm_create_host(const char* name, int world, int rank, int device);
 void cs_comm_destroy(cs_comm* c);
 int cs_comm_world(const cs_comm* c);
 int cs_comm_rank(const cs_comm* c);

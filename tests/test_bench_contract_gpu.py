@@ -96,6 +96,20 @@ def test_bare_gpus_2_spawns_two_ranks_that_hold_one_map(hip):
     assert len(cfg["pose_update"]["static_mapped_features_last_frame"]) == 8 and min(cfg["pose_update"]["static_mapped_features_last_frame"]) > 100
 
 
+def test_bench_starts_the_cxx_loops_ranks_at_n_greater_than_one(hip):
+    """`bench.py --gpus 2` with the C++ leg on: every rank starts ITS rank of tools/cxx/frame_loop.bin (north_star: host stays C++) on the
+    workload file rank 0 wrote; the ranks shard the cameras like the Python loop and talk through cs_comm_* / cs_exchange_* -- here, two
+    ranks on the one GPU, through the library's test transport (a real run: RCCL).  The line carries the slowest rank's rate and the
+    ranks' digests agree."""
+    j = _run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--setup-rounds", "1", "--no-cpu-baseline", "--no-secondary", "--no-upload-leg"],
+                   env=TWO_RANKS_ON_ONE_GPU)
+    cx = j["config"]["cxx_frame_loop"]
+    assert "error" not in cx, cx
+    assert cx["ranks"] == 2 and cx["world"] == 2 and cx["cameras_per_rank"] == 4 and cx["identical_digest_on_every_rank"] is True
+    assert cx["transport"] == "host segment (test)" and cx["pose_ok"] is True and cx["frames_per_s"] > 50
+    assert cx["apply_wait_errors"] == 0 and cx["windows_applied_in_timed_region"] == 4
+
+
 def test_two_ranks_compute_what_one_rank_computes(hip):
     """The same frames, the same apply lag, one rank with 8 cameras against two ranks with 4 each: the map, every camera's records and
     the poses after the timed region are bit-identical (sha256), and so is the joint BA problem the last window parsed."""

