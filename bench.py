@@ -378,6 +378,7 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
         for x in th:
             x.join()
 
+    kf_ring, joint_sizes = [], [0, 0, 0]
     t_start = time.perf_counter()
     n = 0
     while True:
@@ -392,8 +393,19 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
             in_threads(lambda cs, f_: run_ncc(ncc_cam, cs, f_), range(N_CAMS), f)
             in_threads(lambda ps, f_: run_ncc(ncc_pair, ps, f_), range(N_CAMS - 1), f)
         if n % KEY_EVERY == 0:
-            jR, jT = oracle.ba_robust(joint["Ks"], joint["Rs0"], joint["ts0"], joint["pts0"], jptr, jcam, jxy,
-                                      joint["n_cams_con"], joint["n_pts_con"], 6.0, 2, 10)[:2]
+            # RobustBundleRTS::addKeyFrames / addPoints / parseInputs over the last 5 key frames' records (the window the GPU loop parses on
+            # the device), then requestForBA(5, 2, 2, 30): 2 * numCams oldest key cameras and 2 points held, maxIter 2, inner 10; static points
+            kf_ring.append([dict(xy=xy[c].copy(), state=st[c].copy(), slot2map=s2m[c].copy(), K=sc.K.ravel(), R=Rc[c].ravel().copy(), t=tc[c].copy())
+                            for c in range(N_CAMS)])
+            del kf_ring[:-5]
+            if len(kf_ring) == 5:
+                pw = oracle.parse_inputs_window_fast(kf_ring, map_pts, (map_flags & 7) == 0)
+                jR, jT = oracle.ba_robust(pw["Ks"].reshape(-1, 3, 3), pw["Rs"].reshape(-1, 3, 3), pw["Ts"], pw["pts"], pw["obs_ptr"], pw["obs_cam"],
+                                          pw["obs_xy"], 2 * N_CAMS, 2, 6.0, 2, 10)[:2]
+                joint_sizes[:] = [len(pw["Ks"]), len(pw["pts"]), len(pw["obs_cam"])]
+            else:   # (the first four key frames: the pre-baked problem of the same size stands in, as in rounds 3-4)
+                jR, jT = oracle.ba_robust(joint["Ks"], joint["Rs0"], joint["ts0"], joint["pts0"], jptr, jcam, jxy,
+                                          joint["n_cams_con"], joint["n_pts_con"], 6.0, 2, 10)[:2]
             if with_posegraph:   # RobustBundleRTS::output(): the non-key frames follow the adjusted key frames
                 nR, nT = pg_R.copy(), pg_T.copy()
                 nR[pg_cam[pg_cam >= 0]], nT[pg_cam[pg_cam >= 0]] = jR.reshape(-1, 9)[pg_cam >= 0], jT[pg_cam >= 0]
@@ -412,7 +424,7 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
         if time.perf_counter() - t_start > budget_s or n >= 200:
             break
     dt = time.perf_counter() - t_start
-    return n / dt, n, dt
+    return n / dt, n, dt, joint_sizes
 
 
 def spawn_command(n_gpus, argv, port):
@@ -1057,15 +1069,17 @@ def main():
         cores = os.cpu_count() or 1
         nt = min(cores, N_CAMS)
         joint = build_joint_problem(sc)
-        v1, n1, dt1 = cpu_baseline(sc, frames, joint, ic, 1, 12.0, not args.no_register, True, not args.no_ncc, args.pixel_err_reading)
-        vN, nN, dtN = cpu_baseline(sc, frames, joint, ic, nt, 12.0, not args.no_register, True, not args.no_ncc, args.pixel_err_reading) if nt > 1 else (v1, n1, dt1)
+        v1, n1, dt1, js1 = cpu_baseline(sc, frames, joint, ic, 1, 12.0, not args.no_register, True, not args.no_ncc, args.pixel_err_reading)
+        vN, nN, dtN, jsN = cpu_baseline(sc, frames, joint, ic, nt, 12.0, not args.no_register, True, not args.no_ncc, args.pixel_err_reading) if nt > 1 else (v1, n1, dt1, js1)
         cpu = {"value": vN, "unit": "frames/s", "cores": nt, "kind": "port",
                "sample": f"{nN} frames of the same 8-camera workload on {nt} threads (cameras in parallel) in {dtN:.1f} s; "
                          f"{n1} frames on 1 thread in {dt1:.1f} s (oracle/: C restatement, gcc -O2); host has {cores} cores.  Legs: KLT, "
                          "hand-back, intra-camera pose, register search + mergability, pose update gate + dynamic test + classify, "
-                         "NCC blocks + epipolar/NCC matrix every 4th frame, joint BA + pose graph + the update behind it + inter-camera BA per key frame; "
-                         "the registration decision (C) + refineMapPoint; NOT in the CPU figure (restated in plain Python only): the new-map-point "
-                         "match / reconstruct tail",
+                         "NCC blocks + epipolar/NCC matrix every 4th frame, per key frame the joint BA of the window PARSED from the last 5 key "
+                         "frames' records like the GPU's (numpy parse; the pre-baked problem only until 5 key frames exist) + pose graph + the "
+                         "update behind it + inter-camera BA; the registration decision (C) + refineMapPoint; NOT in the CPU figure (restated in "
+                         "plain Python only): the new-map-point match / reconstruct tail",
+               "joint_problem_last_parsed": dict(zip(("cameras", "points", "measurements"), jsN)),
                "value_1_thread": v1, "host_cores": cores}
 
     # ---- the same loop driven from C++ through the C-ABI only (north_star: "Host stays C++"): tools/cxx/frame_loop.cpp, its

@@ -1739,6 +1739,8 @@ struct cs_track_history {
     int4* segPool;   // [nCams][segCap]
     int* segCount;   // [nCams]
     int segCap;
+    unsigned char* alive;   // cs_feat_ref_advance_dev's scratch [aliveCap]
+    int aliveCap;
 };
 
 // the camera centres by walk depth, if the ring's poses changed since they were last computed
@@ -1794,6 +1796,7 @@ extern "C" void cs_track_history_destroy(cs_track_history* h) {
     (void)hipSetDevice(h->device);
     (void)hipFree(h->xy), (void)hipFree(h->R), (void)hipFree(h->t), (void)hipFree(h->cen), (void)hipFree(h->segPool), (void)hipFree(h->segCount);
     if (h->clsList) (void)hipFree(h->clsList);
+    if (h->alive) (void)hipFree(h->alive);
     delete h;
 }
 
@@ -2172,49 +2175,67 @@ struct FrArgs {
     int4* segPool;
     int* segCount;
     int* counts;   // [5] or null: tracked on, fresh, re-linked, links dropped (pool full), detached
+    unsigned char* alive;   // [nMap]: one of the point's references was of the frame of the last call (the history's scratch)
     cs_poseupdate_cam cam[PU_MAX_CAMS];
 };
+// a thread per MAP POINT (its nCams entries): most of a map's points are seen by no camera in a frame and were not the frame before --
+// their row of pointFeat (and one byte saying whether any of their references was alive last frame) is all that is read
 __global__ __launch_bounds__(256) void k_feat_ref_advance(FrArgs A) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    int kind = -1;   // 0 tracked on, 1 first, 2 re-linked, 3 re-linked with the link dropped, 4 detached; -1 nothing to count
-    if (e < A.nMap * A.nCams) {
-        const int c = e % A.nCams, s = A.pointFeat[e];
-        int4 ref = A.featRef[e];
-        const cs_poseupdate_cam& C = A.cam[c];
-        if (s < 0 || s >= A.N) {
-            if (ref.x >= 0 && ref.x < A.N && ref.y == A.curFrame - 1) {
-                const int g1 = C.trackSpan[ref.x], g2 = C.trackSpan[A.N + ref.x];
-                if (g1 >= 0 && g1 <= ref.y && g2 == A.curFrame) {   // the same track, alive in this frame, no longer the point's
-                    ref.x = -1, kind = 4;
-                    A.featRef[e] = ref;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    int cnt[5] = {0, 0, 0, 0, 0};   // tracked on, first, re-linked, links dropped, detached
+    if (m < A.nMap) {
+        const int* pf = A.pointFeat + (size_t)m * A.nCams;
+        bool any = false;
+        for (int c = 0; c < A.nCams; ++c) any = any || pf[c] >= 0;
+        const bool was = A.alive[m] != 0;
+        bool aliveNow = false;
+        if (any || was) {
+            for (int c = 0; c < A.nCams; ++c) {
+                const size_t e = (size_t)m * A.nCams + c;
+                const int s = pf[c];
+                int4 ref = A.featRef[e];
+                const cs_poseupdate_cam& C = A.cam[c];
+                if (s < 0 || s >= A.N) {
+                    if (ref.x >= 0 && ref.x < A.N && ref.y == A.curFrame - 1) {
+                        const int g1 = C.trackSpan[ref.x], g2 = C.trackSpan[A.N + ref.x];
+                        if (g1 >= 0 && g1 <= ref.y && g2 == A.curFrame) {   // the same track, alive in this frame, no longer the point's
+                            ref.x = -1, ++cnt[4];
+                            A.featRef[e] = ref;
+                        }
+                    }
+                    aliveNow = aliveNow || (ref.x >= 0 && ref.y == A.curFrame);
+                    continue;
                 }
+                const int f1 = C.trackSpan[s];
+                if (ref.x == s && f1 >= 0 && ref.y >= f1 && ref.y <= A.curFrame) {
+                    if (ref.y != A.curFrame) ++cnt[0];   // (a second call within the frame changes and counts nothing)
+                    ref.y = A.curFrame;
+                } else if (ref.x >= 0 && ref.y < A.curFrame) {
+                    const int idx = atomicAdd(A.segCount + c, 1);
+                    ++cnt[2];
+                    if (idx < A.segCap)
+                        A.segPool[(size_t)c * A.segCap + idx] = ref;   // {slot, last = its frame, first, next = its segment}
+                    else
+                        ++cnt[3];
+                    ref = make_int4(s, A.curFrame, A.curFrame, idx < A.segCap ? idx : -1);
+                } else {
+                    ref = make_int4(s, A.curFrame, f1 >= 0 ? f1 : A.curFrame, -1), ++cnt[1];
+                }
+                A.featRef[e] = ref;
+                if (A.refStatic) A.refStatic[e] = C.isStatic ? C.isStatic[s] : 1;
+                aliveNow = true;
             }
-        } else {
-            const int f1 = C.trackSpan[s];
-            if (ref.x == s && f1 >= 0 && ref.y >= f1 && ref.y <= A.curFrame) {
-                kind = ref.y == A.curFrame ? -1 : 0;   // (a second call within the frame changes and counts nothing)
-                ref.y = A.curFrame;
-            } else if (ref.x >= 0 && ref.y < A.curFrame) {
-                const int idx = atomicAdd(A.segCount + c, 1);
-                kind = 2;
-                if (idx < A.segCap)
-                    A.segPool[(size_t)c * A.segCap + idx] = ref;   // {slot, last = its frame, first, next = its segment}
-                else
-                    kind = 3;
-                ref = make_int4(s, A.curFrame, A.curFrame, idx < A.segCap ? idx : -1);
-            } else {
-                ref = make_int4(s, A.curFrame, f1 >= 0 ? f1 : A.curFrame, -1), kind = 1;
-            }
-            A.featRef[e] = ref;
-            if (A.refStatic) A.refStatic[e] = C.isStatic ? C.isStatic[s] : 1;
+            A.alive[m] = aliveNow ? 1 : 0;
         }
     }
     if (A.counts) {   // one atomic per wave and counter (15 000 "tracked on" per frame on one address would cost more than the kernel)
         const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            const unsigned long long b = __builtin_amdgcn_ballot_w64(k == 2 ? (kind == 2 || kind == 3) : (k == 3 ? kind == 3 : kind == k));
-            if (b && lane == 0) atomicAdd(A.counts + k, __popcll(b));
+            int v = cnt[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (v && lane == 0) atomicAdd(A.counts + k, v);
         }
     }
 }
@@ -2230,6 +2251,14 @@ extern "C" int cs_feat_ref_advance_dev(cs_track_history* h, void* hip_stream, co
     A.nCams = h->nCams, A.N = h->N, A.nMap = nMap, A.curFrame = curFrame, A.segCap = h->segCap;
     A.pointFeat = d_pointFeat, A.featRef = (int4*)d_featRef, A.refStatic = d_refStatic, A.segPool = h->segPool, A.segCount = h->segCount;
     A.counts = d_counts;
+    if (nMap > h->aliveCap) {   // (grown on first use / for a larger map: a point nobody has seen yet has no live reference)
+        if (h->alive) CS_HIP(hipFree(h->alive));
+        h->alive = nullptr, h->aliveCap = 0;
+        CS_HIP(hipMalloc((void**)&h->alive, (size_t)nMap));
+        CS_HIP(hipMemsetAsync(h->alive, 1, (size_t)nMap, (hipStream_t)hip_stream));   // (1: look at every row once)
+        h->aliveCap = nMap;
+    }
+    A.alive = h->alive;
     for (int c = 0; c < h->nCams; ++c) {
         if (!cams[c].trackSpan) {
             cs_set_error("cs_feat_ref_advance_dev: null trackSpan in camera %d", c);
@@ -2239,7 +2268,7 @@ extern "C" int cs_feat_ref_advance_dev(cs_track_history* h, void* hip_stream, co
     }
     CS_HIP(hipSetDevice(h->device));
     if (nMap == 0) return CS_OK;
-    hipLaunchKernelGGL(k_feat_ref_advance, dim3((nMap * h->nCams + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, A);
+    hipLaunchKernelGGL(k_feat_ref_advance, dim3((nMap + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, A);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

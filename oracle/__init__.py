@@ -824,6 +824,41 @@ def parse_inputs_window(key_frames, map_pts, map_static=None):
                 obs_cam=np.asarray(ocam, np.int32), obs_xy=np.asarray(oxy, float).reshape(-1, 2), point_map=np.asarray(pmap, np.int32))
 
 
+def parse_inputs_window_fast(key_frames, map_pts, map_static=None):
+    """parse_inputs_window with the per-slot loops as numpy array operations (what bench.py's CPU baseline times: a Python loop over
+    80 000 slots per key frame would not be a fair CPU figure).  Same arguments, same result, array for array
+    (tests/test_oracle_cpu.py holds the two against each other)."""
+    n_cams = len(key_frames[0])
+    n_map = len(map_pts)
+    cams = [(j, c) for j in range(len(key_frames)) for c in range(n_cams)]
+    feat = np.full((len(cams), n_map), -1, dtype=np.int64)
+    for ci, (j, c) in enumerate(cams):
+        rec = key_frames[j][c]
+        st, m = np.asarray(rec["state"]), np.asarray(rec["slot2map"])
+        ok = ((st == 0) | (st == 1)) & (m >= 0) & (m < n_map)
+        if map_static is not None:
+            ok &= np.asarray(map_static)[np.clip(m, 0, n_map - 1)].astype(bool)
+        idx = np.nonzero(ok)[0]
+        feat[ci, m[idx]] = idx                                  # (slot order: for a repeated map point the last slot stays)
+    Ks = np.stack([np.asarray(key_frames[j][c]["K"], float).reshape(9) for j, c in cams])
+    Rs = np.stack([np.asarray(key_frames[j][c]["R"], float).reshape(9) for j, c in cams])
+    Ts = np.stack([np.asarray(key_frames[j][c]["t"], float).reshape(3) for j, c in cams])
+    seen = feat >= 0
+    keep = np.nonzero(seen.sum(0) > 1)[0]                      # nfpts > 1 (:120-121), map index order
+    sub = seen[:, keep]                                         # [camera][kept point]
+    pi, ci = np.nonzero(sub.T)                                  # per kept point its cameras in camera order (:146-151)
+    slots = feat[ci, keep[pi]]
+    N = np.array([len(key_frames[j][c]["state"]) for j, c in cams])
+    xy_all = [np.asarray(key_frames[j][c]["xy"], float) for j, c in cams]
+    oxy = np.empty((len(ci), 2))
+    for q in range(len(cams)):                                  # (one gather per camera, not per measurement)
+        sel = np.nonzero(ci == q)[0]
+        oxy[sel, 0], oxy[sel, 1] = xy_all[q][slots[sel]], xy_all[q][N[q] + slots[sel]]
+    ptr = np.concatenate([[0], np.cumsum(sub.sum(0))]).astype(np.int32)
+    return dict(Ks=Ks, Rs=Rs, Ts=Ts, pts=np.asarray(map_pts, float)[keep].reshape(-1, 3), obs_ptr=ptr, obs_cam=ci.astype(np.int32),
+                obs_xy=oxy, point_map=keep.astype(np.int32))
+
+
 def intercam_add_map_points(W, H, nColBlk, nRowBlk, ptsStride, xy, state, slot2map, trackSpan, isStatic, mapPts, mapFlags, newPt, pointFeat,
                             maxDyn=60):
     """InterCamPoseEstimator::addMapPoints (reference src/app/SL_InterCamPoseEstimator.cpp:18-91) restated over structure-of-arrays
