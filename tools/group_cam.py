@@ -42,7 +42,7 @@ def run(n_cams, n_frames=80, prefetch=True, fused=1, probe=False, profile=True):
         t = coslam_amd.KLT_SequenceTracker(cfg(), 0)
         t.allocate(W, H, L, FW, FH)
         t.set_fused(fused)
-        t.set_xcd_placement(os.environ.get("KLT_XCD", "0") != "0")   # (A/B hook: a camera per XCD)
+        t.set_xcd_placement(os.environ.get("KLT_XCD", "1") != "0")   # (the default placement: a camera per XCD; KLT_XCD=0: cameras as grid rows)
         ts.append(t)
     grp = coslam_amd.KLT_TrackerGroup(ts)
     grp.set_stream(stream.cuda_stream)
