@@ -1181,7 +1181,7 @@ def main():
                                       "map points, the dynamic-point test (64-frame history) and mapPointsClassify") + "; currentMapPointsRegister "
                                    "every frame over the frame's CURRENT map points (a list built on the device: every point with a feature of this "
                                    "frame, new ones included; search x 8 cams x 2000 slots, staticCheckMergability over WHOLE tracks as a running "
-                                   "verdict, the decision settled in one launch, refineMapPoint), every 50th frame with bMerge (checkUnify); "
+                                   "verdict, the decision settled in one launch, refineMapPoint" + (" over feature references -- MapPoint::pFeatures as the reference holds them: stale features are views, a re-registered point's old chain is linked behind the new feature" if cfg.feature_chains else "") + "), every 50th frame with bMerge (checkUnify); "
                                    "activeMapPointsRegister's search is not run (its attach loop is unreachable in the reference: "
                                    "tests/cxx/ref_active_test.cpp); every 4th frame the NCC matching of the consecutive camera pairs (F from the "
                                    f"poses just solved) -> new map points; every {KEY_EVERY}th frame: joint local BA C=40 (16 fixed), "
