@@ -311,12 +311,13 @@ static int enqueue_tracker(const Span& S, cs_klt_feature* const* postDest, int d
                 const int m = (S.n - first < perLaunch) ? S.n - first : perLaunch;
                 A.nCams = m;
                 // camera per XCD when the launch's cameras divide the eight XCDs (1, 2, 4, 8 cameras) and a camera's workgroups fit
-                // the XCDs they are sent to with room to spare (the grid must stay co-resident wherever the dispatcher puts it)
+                // the XCDs they are sent to
                 A.xcdsPerCam = 0;
                 if (k0->xcd_placement && m <= 8 && 8 % m == 0) {
                     const int q = 8 / m, wgPerCam = (cs_rows_waves(hw, k0->N) + 3) / 4;
                     const long room = (long)(perCu / 4) * (k0->cu_count / 8);
-                    if ((long)((wgPerCam + q - 1) / q) * 5 <= room * 4) A.xcdsPerCam = q;   // <= 80 % of the XCDs' workgroup slots
+                    if ((long)((wgPerCam + q - 1) / q) <= room) A.xcdsPerCam = q;   // (every camera's last workgroup sits at the end of the
+                    // placed dispatch order: ALL of an XCD's share has to be resident at once -- 65 on a 64-slot XCD never finish)
                 }
                 for (int i = 0; i < m; ++i) {
                     cs_klt* k = S.k[first + i];

@@ -34,8 +34,8 @@ namespace {
 #define CS_ROWS_UNROLL 7
 #endif
 #ifndef CS_ROWS_WPB
-// Waves per workgroup.  4: a workgroup's waves go to the CU's four SIMDs (53 KB of LDS per workgroup for a 7 x 7 window: up to three
-// per CU), so eight cameras (2000 waves) land as two waves on every SIMD.  With single-wave workgroups the
+// Waves per workgroup.  4: a workgroup's waves go to the CU's four SIMDs (53 KB of LDS per workgroup for a 7 x 7 window: two per
+// CU), so eight cameras (2000 waves) land as two waves on every SIMD.  With single-wave workgroups the
 // dispatcher piles up to ten of them on a CU while others idle: 218 vs 164 us for the eight-camera tracker stage.
 #define CS_ROWS_WPB 4
 #endif
@@ -51,10 +51,11 @@ namespace {
 #endif
 #ifndef CS_ROWS_MARGIN
 // Texels of slack around the window footprint in the LDS patch.  1 (round 5; 2 before): a 7 x 7 window's wave then holds 13.25 KB
-// of LDS instead of 16, so a CU admits THREE workgroups instead of two -- 96 workgroup slots per XCD where a camera needs 63: the
-// room the camera-per-XCD placement (xcdsPerCam) needs beside the pose stream's kernels (with two per CU the placed grid met a
-// co-residency timeout in the frame loop; profiles/r05_ab_runs.txt).  Re-centring got no more frequent in the counters
-// (FETCH_SIZE 52.7 vs 54.7 MB per launch) and the launch 1.6 % shorter.
+// of LDS instead of 16.  A CU still holds TWO of these workgroups (64 per XCD: measured, tools/r05_diag.py -- the occupancy query's
+// "three" does not materialise), but beside them 52 KB of its LDS stay free instead of 32: the pose stream's kernels find room on
+// a CU that carries two tracker workgroups, which is what the camera-per-XCD placement (xcdsPerCam: 63 of an XCD's 64 slots) needs
+// beside them (with 16 KB per wave the placed grid met a co-residency timeout in the frame loop; profiles/r05_ab_runs.txt).
+// Re-centring got no more frequent in the counters (FETCH_SIZE 52.7 vs 54.7 MB per launch) and the launch 1.6 % shorter.
 #define CS_ROWS_MARGIN 1
 #endif
 constexpr int RW_MARGIN = CS_ROWS_MARGIN;
@@ -744,6 +745,14 @@ int cs_rows_max_resident_blocks(int hw, int device, int* blocksPerCu) {
 #undef CS_ROWS_OCC
     if (rc != CS_OK) return 0;
     if (per > 32) per = 32;  // 32 waves per CU
+    {
+        // What the chip really holds is less than the query says when the workgroups' LDS adds up to almost all of a CU's 160 KB: the
+        // 7 x 7 instantiation (53 KB per workgroup) is reported as three per CU, and an XCD takes 64 of them, not 65 -- two per CU
+        // (tools/r05_diag.py, profiles/r05_ab_runs.txt).  Budget with 4 KB of a CU's LDS set aside.
+        const size_t lds = cs_rows_lds_bytes(hw);
+        const int byLds = lds ? (int)((160 * 1024 - 4096) / lds) * CS_ROWS_WPB : per;
+        if (per > byLds) per = byLds;
+    }
     if (blocksPerCu) *blocksPerCu = per;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;

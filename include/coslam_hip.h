@@ -136,7 +136,7 @@ int cs_klt_set_cu_count(cs_klt* k, int n_cus);
 /* Persistent tracker placement: 1 (default) = the workgroups of a camera are numbered so that they land on that camera's own XCD(s)
  * (workgroup b runs on XCD b % 8 on MI355X): its pyramids are fetched into one L2 instead of eight -- FETCH_SIZE 25.8 MB per
  * 8-camera launch instead of 52.7 (profiles/r05_tracker_pmc.json).  Applies when the launch carries 1, 2, 4 or 8 cameras and a
- * camera's workgroups fill at most 80 % of its XCDs' slots; results are bit-identical either way.  The first camera of a group decides. */
+ * camera's share of workgroups fits its XCDs (two 7 x 7 workgroups per CU: 64 per XCD); results are bit-identical either way.  The first camera of a group decides. */
 int cs_klt_set_xcd_placement(cs_klt* k, int on);
 /* how many handles of this device may have their persistent tracker in flight at the same time (0 = every live handle) */
 int cs_klt_set_concurrent_handles(cs_klt* k, int n);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B on one box, alternating: the persistent tracker's placement (cs_klt_set_xcd_placement) x the LDS patch margin
-# (CS_ROWS_MARGIN=1: 13.25 KB of LDS per wave, three workgroups per CU instead of two)
+# (CS_ROWS_MARGIN=1: 13.25 KB of LDS per wave: 52 KB of a CU's LDS free beside its two tracker workgroups instead of 32)
 mkdir -p gpurun_out/r05x
 o=gpurun_out/r05x
 M1=$PWD/coslam_amd/lib/libcoslam_hip_margin1.so
