@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--frames", type=int, default=1500)
     ap.add_argument("--every", type=int, default=50)
     ap.add_argument("--hist", type=int, default=64)
+    ap.add_argument("--hist-store", type=int, default=0, help="frames the track history keeps (0: LoopConfig's 4096)")
+    ap.add_argument("--map-spare", type=int, default=0, help="room for new map points behind the initial map (0: LoopConfig's 8192)")
     ap.add_argument("--min-distance", type=int, default=-1, help="KLT minDistance (-1: bench.py's)")
     ap.add_argument("--out", default="")
     ap.add_argument("--pixel-err-reading", choices=["variance", "std"], default="variance")
@@ -103,6 +105,10 @@ def main():
               n_col_blk=bench.N_COL_BLK, n_row_blk=bench.N_ROW_BLK, key_every=bench.KEY_EVERY, p_reg=bench.P_REG, hist=args.hist,
               pixel_err_reading=args.pixel_err_reading)
     kw.update(over)
+    if args.hist_store > 0:
+        kw["hist_store"] = args.hist_store
+    if args.map_spare > 0:
+        kw["map_spare"] = args.map_spare
     cfg = LoopConfig(**kw)
     kc = bench.klt_config()
     if args.min_distance > 0:
