@@ -2155,6 +2155,209 @@ extern "C" int cs_refine_map_points_dev(const cs_track_history* h, void* hip_str
     return up_launch("cs_refine_map_points_dev", h, hip_stream, cams, A, d_count, 1);
 }
 
+// ---- SingleSLAM::newMapPoints (src/app/SL_SingleSLAM.cpp:922-1004): the intra-camera source of new map points -----------------------------
+// What CoSLAM::genNewMapPoints calls for a camera that IsReadyForKeyFrame (SL_CoSLAM.cpp:1310-1330; cs_keyframe_ready_dev's codes): every
+// unmapped feature on a track of at least minTrackLen frames (getUnMappedAndTrackedFeatPts, :152-172) is triangulated from its OWN track --
+// the track's oldest feature the history still holds against the current one --, thrown out when the point lies behind the camera, nearer
+// than the square root of its covariance's trace (:960-962) or re-projects further off than maxEpiErr in either view; refineTriangulation
+// (:1005-1049) then pairs the current view with the widest-parallax one behind it (chain_widest: at most maxWalk nodes back) and the tests
+// run once more.  The reference walks every candidate on the host; here a wave per (camera, slot) tries its slot and leaves the result in a
+// scratch record, and ONE workgroup then appends the successes to the map in (camera, slot) order -- the order the reference's loop over
+// the cameras and its loop over the tracks would create them in -- so that map indices do not depend on scheduling.
+struct InArgs {
+    int nCams, N, H, head, nHist, stored, curFrame, minTrackLen, maxWalk, readyMin, mapCap;
+    const double *histXY, *histR, *histT, *cen;
+    const int* ready;          // [nCams] or null (= every camera)
+    double maxEpiErr, sigma;
+    double* rec;               // scratch [nCams * N][12]: M, cov (symmetric: 9 stored)
+    int* first;                // scratch [nCams * N]
+    unsigned char* ok;         // scratch [nCams * N]
+    double *mapPts, *mapCov;
+    unsigned char *mapFlags, *newPt;
+    int *firstFrame, *pointFeat, *mapCount, *counts;
+    cs_poseupdate_cam cam[PU_MAX_CAMS];
+};
+__device__ __forceinline__ void in_tri2(const double* iK, const double* R1, const double* t1, double x1, double y1, const double* R2, const double* t2,
+                                        double x2, double y2, double* M) {
+    UpNormalEq E;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) E.N[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) E.g[q] = 0;
+    up_add_view(E, iK, R1, t1, x1, y1);
+    up_add_view(E, iK, R2, t2, x2, y2);
+    double cf[6];
+    const double det = up_sym33_cof(E.N, cf);
+    M[0] = ((cf[0] * E.g[0] + cf[1] * E.g[1]) + cf[2] * E.g[2]) / det;
+    M[1] = ((cf[1] * E.g[0] + cf[3] * E.g[1]) + cf[4] * E.g[2]) / det;
+    M[2] = ((cf[2] * E.g[0] + cf[4] * E.g[1]) + cf[5] * E.g[2]) / det;
+}
+__device__ __forceinline__ void in_cov2(const double* K, const double* R1, const double* t1, const double* R2, const double* t2, const double* M,
+                                        double sigma, double* cov) {
+    double S[6] = {0, 0, 0, 0, 0, 0}, cf[6];
+    const PuProj q1 = pu_project(K, R1, t1, M), q2 = pu_project(K, R2, t2, M);
+    up_add_jtj(S, q1.J);
+    up_add_jtj(S, q2.J);
+    const double dS = up_sym33_cof(S, cf), s2 = sigma * sigma;
+    cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
+    cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
+    cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
+}
+__device__ __forceinline__ double in_reproj_err(const double* K, const double* R, const double* t, const double* M, double mx, double my) {
+    const PuProj q = pu_project(K, R, t, M);
+    const double dx = mx - q.u / q.w, dy = my - q.v / q.w;
+    return sqrt(dx * dx + dy * dy);
+}
+__device__ __forceinline__ bool in_behind(const double* R, const double* t, const double* M) {
+    return ((R[6] * M[0] + R[7] * M[1]) + R[8] * M[2]) + t[2] < 0;
+}
+__global__ __launch_bounds__(256) void k_intracam_newpts_try(InArgs A) {
+    const int tid = threadIdx.x, g = tid / 64, r = tid % 64;
+    const int e = blockIdx.x * 4 + g;   // (camera, slot)
+    if (e >= A.nCams * A.N) return;
+    const int c = e / A.N, k = e - c * A.N, N = A.N, H = A.H;
+    if (r == 0) A.ok[e] = 0;
+    if (A.ready && A.ready[c] < A.readyMin) return;
+    const cs_poseupdate_cam& C = A.cam[c];
+    const int st = C.state[k];
+    if (st != 0 && st != 1) return;
+    const int f1 = C.trackSpan[k], f2 = C.trackSpan[N + k];
+    if (f1 < 0 || f2 - f1 < A.minTrackLen || C.slot2map[k] >= 0 || !C.isStatic[k]) return;   // :159, :938-944
+    int jp = f2 - f1;
+    if (jp > A.stored - 1) jp = A.stored - 1;   // the oldest feature that still has a pose (:937)
+    if (jp < 1) return;
+    if (r == 0 && A.counts) atomicAdd(A.counts, 1);
+    const double* hR = A.histR + (size_t)c * H * 9;
+    const double* hT = A.histT + (size_t)c * H * 3;
+    const double* hXY = A.histXY + (size_t)c * H * 2 * N;
+    const int rsP = ((A.head - jp) % H + H) % H;
+    const double *R0 = hR + (size_t)A.head * 9, *t0 = hT + (size_t)A.head * 3, *Rp = hR + (size_t)rsP * 9, *tp = hT + (size_t)rsP * 3;
+    const double cx = hXY[(size_t)A.head * 2 * N + k], cy = hXY[(size_t)A.head * 2 * N + N + k];
+    const double px = hXY[(size_t)rsP * 2 * N + k], py = hXY[(size_t)rsP * 2 * N + N + k];
+    double M[3], cov[9];
+    in_tri2(C.iK, Rp, tp, px, py, R0, t0, cx, cy, M);                                   // :950
+    if (in_behind(R0, t0, M)) return;                                                    // :953
+    in_cov2(C.K, Rp, tp, R0, t0, M, A.sigma, cov);                                       // :957
+    double org[3];
+    up_cam_center(R0, t0, org);
+    {
+        const double sTr = fabs((cov[0] + cov[4]) + cov[8]);
+        const double dx = org[0] - M[0], dy = org[1] - M[1], dz = org[2] - M[2];
+        if (sqrt((dx * dx + dy * dy) + dz * dz) < sqrt(sTr)) return;                     // :960-962
+    }
+    if (!(in_reproj_err(C.K, Rp, tp, M, px, py) < A.maxEpiErr && in_reproj_err(C.K, R0, t0, M, cx, cy) < A.maxEpiErr)) return;   // :965-970
+    // refineTriangulation(cur_fp, M, cov): the current view and the widest-parallax one of the track behind it
+    ChainCtx X;
+    X.N = N, X.H = H, X.head = A.head, X.cap = (jp + 1 < A.maxWalk ? jp + 1 : A.maxWalk), X.curFrame = A.curFrame, X.stored = A.stored;
+    X.segCap = 0, X.nCen = A.nHist, X.cen = A.cen, X.segPool = nullptr;
+    const double a[3] = {org[0] - M[0], org[1] - M[1], org[2] - M[2]};
+    const double na = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+    int bs = k;
+    const int best = chain_widest(X, c, make_int4(k, A.curFrame, A.curFrame - jp, -1), hR, hT, a, na, M, r, bs);
+    if (best >= 0) {
+        const int rs = ((A.head - best) % H + H) % H;
+        const double *Rb = hR + (size_t)rs * 9, *tb = hT + (size_t)rs * 3;
+        in_tri2(C.iK, R0, t0, cx, cy, Rb, tb, hXY[(size_t)rs * 2 * N + k], hXY[(size_t)rs * 2 * N + N + k], M);
+        in_cov2(C.K, R0, t0, Rb, tb, M, A.sigma, cov);
+    }
+    const double e1 = in_reproj_err(C.K, Rp, tp, M, px, py), e2 = in_reproj_err(C.K, R0, t0, M, cx, cy);
+    if (in_behind(R0, t0, M) || in_behind(Rp, tp, M)) return;                            // :977-979
+    if (!(e1 < A.maxEpiErr && e2 < A.maxEpiErr)) return;                                 // :980
+    if (r != 0) return;
+    double* o = A.rec + 12 * (size_t)e;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) o[q] = M[q];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) o[3 + q] = cov[q];
+    A.first[e] = f2 - jp;
+    A.ok[e] = 1;
+}
+// the successes into the map in (camera, slot) order: MapPoint(M, pre_fp->f), cov, addFeature(camId, cur_fp), setLocalStatic() (:981-990)
+__global__ __launch_bounds__(1024) void k_intracam_newpts_commit(InArgs A) {
+    __shared__ int sWave[16], sBase;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, total = A.nCams * A.N;
+    if (tid == 0) sBase = *A.mapCount;
+    __syncthreads();
+    int added = 0;
+    for (int e0 = 0; e0 < total; e0 += 1024) {
+        const int e = e0 + tid;
+        const bool ok = e < total && A.ok[e] != 0;
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(ok);
+        if (lane == 0) sWave[wv] = __popcll(b);
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) before += w < wv ? sWave[w] : 0, all += sWave[w];
+        const int idx = sBase + added + before + __popcll(b & ((1ull << lane) - 1ull));
+        if (ok && idx < A.mapCap) {
+            const int c = e / A.N, k = e - c * A.N;
+            const double* o = A.rec + 12 * (size_t)e;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) A.mapPts[3 * (size_t)idx + q] = o[q];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) A.mapCov[9 * (size_t)idx + q] = o[3 + q];
+            A.mapFlags[idx] = 0;   // setLocalStatic(), bUncertain = false
+            A.newPt[idx] = 1;      // bNewPt = true (the constructor's)
+            A.firstFrame[idx] = A.first[e];
+            for (int v = 0; v < A.nCams; ++v) A.pointFeat[(size_t)idx * A.nCams + v] = v == c ? k : -1;
+            const_cast<int*>(A.cam[c].slot2map)[k] = idx;
+        }
+        added += all;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int kept = added;
+        if (sBase + kept > A.mapCap) kept = A.mapCap - sBase > 0 ? A.mapCap - sBase : 0;
+        *A.mapCount = sBase + kept;
+        if (A.counts) A.counts[1] = kept, A.counts[2] = added - kept;
+    }
+}
+
+extern "C" size_t cs_newpts_intracam_scratch_bytes(int nCams, int N) {
+    if (nCams < 1 || N < 1) return 0;
+    const size_t n = (size_t)nCams * N;
+    return n * 12 * sizeof(double) + n * sizeof(int) + ((n + 15) & ~(size_t)15);
+}
+extern "C" int cs_newpts_intracam_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const int* d_ready, int readyMin,
+                                      int minTrackLen, int maxWalk, double maxEpiErr, double pixelErrVar, double* d_mapPts, double* d_mapCov,
+                                      unsigned char* d_mapFlags, unsigned char* d_newPt, int* d_firstFrame, int* d_pointFeat, int mapCap,
+                                      int* d_mapCount, void* d_scratch, int* d_counts) {
+    if (!h || !cams || minTrackLen < 1 || maxWalk < 2 || !d_mapPts || !d_mapCov || !d_mapFlags || !d_newPt || !d_firstFrame || !d_pointFeat ||
+        mapCap < 1 || !d_mapCount || !d_scratch) {
+        cs_set_error("cs_newpts_intracam_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (h->count < 1) {
+        cs_set_error("cs_newpts_intracam_dev: the history holds no frame");
+        return CS_ERR_INVALID;
+    }
+    InArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = h->nCams, A.N = h->N, A.H = h->H, A.head = h->head, A.nHist = hist_walk(h), A.stored = h->count < h->H ? h->count : h->H;
+    A.curFrame = h->lastFrame, A.minTrackLen = minTrackLen, A.maxWalk = maxWalk, A.readyMin = readyMin, A.mapCap = mapCap;
+    A.histXY = h->xy, A.histR = h->R, A.histT = h->t, A.cen = h->cen;
+    A.ready = d_ready, A.maxEpiErr = maxEpiErr, A.sigma = pixelErrVar;
+    const size_t n = (size_t)h->nCams * h->N;
+    A.rec = (double*)d_scratch, A.first = (int*)((char*)d_scratch + n * 12 * sizeof(double)), A.ok = (unsigned char*)(A.first + n);
+    A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.mapFlags = d_mapFlags, A.newPt = d_newPt, A.firstFrame = d_firstFrame, A.pointFeat = d_pointFeat;
+    A.mapCount = d_mapCount, A.counts = d_counts;
+    for (int c = 0; c < h->nCams; ++c) {
+        if (!cams[c].K || !cams[c].iK || !cams[c].state || !cams[c].slot2map || !cams[c].trackSpan || !cams[c].isStatic) {
+            cs_set_error("cs_newpts_intracam_dev: null pointer in camera %d (K, iK, state, slot2map, trackSpan, isStatic)", c);
+            return CS_ERR_INVALID;
+        }
+        A.cam[c] = cams[c];
+    }
+    CS_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (d_counts) CS_HIP(hipMemsetAsync(d_counts, 0, 3 * sizeof(int), s));
+    hist_centres(h, s);
+    hipLaunchKernelGGL(k_intracam_newpts_try, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_intracam_newpts_commit, dim3(1), dim3(1024), 0, s, A);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
 // ---- MapPoint::pFeatures kept as references (cs_feat_ref) ---------------------------------------------------------------------------------
 // What the reference does to p->pFeatures[c] and the chain behind it, once per frame behind the registration's decisions:
 //   the camera tracks the point on (SingleSLAM::propagateFeatureStates, src/app/SL_SingleSLAM.cpp:34-60): the reference moves to this frame;

@@ -161,6 +161,19 @@ class TrackHistory:
         check(self._L.cs_check_unify_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), int(nPairs), vp(d_pf1), vp(d_pf2), vp(d_M1), vp(d_M2),
                                          C.c_double(pixelErrVar), vp(d_ok), vp(d_M), vp(d_cov)), "cs_check_unify_dev")
 
+    def newpts_intracam_scratch_bytes(self):
+        self._L.cs_newpts_intracam_scratch_bytes.restype = C.c_size_t
+        return int(self._L.cs_newpts_intracam_scratch_bytes(self.nCams, self.N))
+
+    def newpts_intracam_dev(self, stream_ptr, cams, d_mapPts, d_mapCov, d_mapFlags, d_newPt, d_firstFrame, d_pointFeat, mapCap, d_mapCount, d_scratch,
+                            pixelErrVar, d_ready=None, readyMin=2, minTrackLen=20, maxWalk=1024, maxEpiErr=2.0, d_counts=None):
+        """cs_newpts_intracam_dev: SingleSLAM::newMapPoints (reference src/app/SL_SingleSLAM.cpp:922-1004) for the cameras d_ready selects"""
+        vp = C.c_void_p
+        check(self._L.cs_newpts_intracam_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), vp(d_ready), int(readyMin), int(minTrackLen),
+                                             int(maxWalk), C.c_double(maxEpiErr), C.c_double(pixelErrVar), vp(d_mapPts), vp(d_mapCov),
+                                             vp(d_mapFlags), vp(d_newPt), vp(d_firstFrame), vp(d_pointFeat), int(mapCap), vp(d_mapCount),
+                                             vp(d_scratch), vp(d_counts)), "cs_newpts_intracam_dev")
+
     # ---- MapPoint::pFeatures as feature references (cs_feat_ref / cs_feat_seg, include/coslam_hip.h) --------------------------------
     def feat_ref_advance_dev(self, stream_ptr, cams, nMap, d_pointFeat, curFrame, d_featRef, d_refStatic=None, d_counts=None):
         """cs_feat_ref_advance_dev: every frame behind the registration's decisions -- tracked on / first feature / re-linked behind an

@@ -556,6 +556,27 @@ int cs_update_new_poses_points_dev(const cs_track_history* h, void* hip_stream, 
 int cs_refine_map_points_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap,
                              const unsigned char* d_select, double* d_mapPts, double* d_mapCov, double pixelErrVar, int* d_count);
 
+/* ---- SingleSLAM::newMapPoints: the intra-camera source of new map points (src/app/SL_SingleSLAM.cpp:922-1004) ------------------------------
+ * What CoSLAM::genNewMapPoints calls for a camera that IsReadyForKeyFrame (SL_CoSLAM.cpp:1310-1330): every unmapped feature of this frame
+ * on a track of at least minTrackLen frames (Param::nMinFeatTrkLen = 20; getUnMappedAndTrackedFeatPts, :152-172) is triangulated from its
+ * own track -- the oldest feature of the track the history still holds against the current one --, thrown out when the point is behind the
+ * camera, nearer than sqrt(trace cov) (:960-962) or re-projects further off than maxEpiErr (2.0) in either view; refineTriangulation
+ * (:1005-1049) pairs the current view with the widest-parallax one behind it (at most maxWalk nodes back; the reference walks the whole
+ * track) and the tests run once more.  Cameras: all (d_ready NULL) or those with d_ready[c] >= readyMin (cs_keyframe_ready_dev's codes: the
+ * reference asks > 1 with several cameras, > 0 with one).  A dynamic feature stops the reference's walk (:938-944): the slot's isStatic
+ * stands for its whole track here.  New points are appended behind *d_mapCount in (camera, slot) order -- the order the reference's loops
+ * create them in -- with MapPoint(M, firstFrame = the oldest view's frame), the covariance, TYPE_MAP_STATIC, bNewPt, the feature attached
+ * (d_pointFeat row, cams[c].slot2map -- written through the const pointer); points beyond mapCap are dropped and counted.
+ * d_scratch: cs_newpts_intracam_scratch_bytes(nCams, N).  d_counts [3] or NULL: candidates tried, points added, points dropped.
+ * The current frame is the history's newest.  Pinned against the reference's own function compiled in place
+ * (tests/cxx/ref_intracam_newpts_test.cpp -> tests/golden/intracam_newpts_golden.npz); binTriangulate / getBinTriangulateCovMat are the
+ * multi-view definitions of DESIGN.md 5.1 over two views. */
+size_t cs_newpts_intracam_scratch_bytes(int nCams, int N);
+int cs_newpts_intracam_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const int* d_ready, int readyMin,
+                           int minTrackLen, int maxWalk, double maxEpiErr, double pixelErrVar, double* d_mapPts, double* d_mapCov,
+                           unsigned char* d_mapFlags, unsigned char* d_newPt, int* d_firstFrame, int* d_pointFeat, int mapCap, int* d_mapCount,
+                           void* d_scratch, int* d_counts);
+
 /* ---- The key-frame decision (CoSLAM::genNewMapPoints' first half; VERDICT r04 missing 7) ------------------------------------------------
  * CoSLAM::IsReadyForKeyFrame (src/app/SL_CoSLAM.cpp:1269-1279) for every camera in one launch: READY_FOR_KEY_FRAME_DECREASE (1) when the
  * frame's features whose map point is older than the camera's last key pose number fewer than `ratio` (m_mappedPtsReduceRatio, 0.93)

@@ -1272,3 +1272,25 @@ def keyframe_ready(state, slot2map, R, t, selfR, selfT, keyFrame, keyMapped, map
     if np.sqrt(((C0 - C1) ** 2).sum()) > minTranslation:
         return 3, n_static, num, cen
     return 0, n_static, num, cen
+
+
+def intracam_new_points(K, iK, histR, histT, histXY, state, slot2map, trackSpan, isStatic, minTrackLen, maxEpiErr, sigma, cmpAcos=False):
+    """opu_intracam_new_points (SingleSLAM::newMapPoints for one camera): histR (nHist x 9), histT (nHist x 3), histXY (nHist x 2N), entry 0 =
+    this frame; state / slot2map int32[N], trackSpan int32[2N], isStatic uint8[N].  Returns (slots, firstFrames, M [n x 3], cov [n x 9])
+    in slot order."""
+    L = lib()
+    L.opu_intracam_new_points.restype = C.c_int
+    histR = np.ascontiguousarray(histR, dtype=np.float64)
+    histT = np.ascontiguousarray(histT, dtype=np.float64)
+    histXY = np.ascontiguousarray(histXY, dtype=np.float64)
+    nH, N = histR.shape[0], histXY.shape[1] // 2
+    K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+    iK = np.ascontiguousarray(iK, dtype=np.float64).reshape(9)
+    st, s2m = np.ascontiguousarray(state, dtype=np.int32), np.ascontiguousarray(slot2map, dtype=np.int32)
+    sp, fs = np.ascontiguousarray(trackSpan, dtype=np.int32), np.ascontiguousarray(isStatic, dtype=np.uint8)
+    assert histT.shape == (nH, 3) and histXY.shape == (nH, 2 * N) and len(st) == len(s2m) == len(fs) == N and len(sp) == 2 * N
+    slot, first = np.zeros(N, np.int32), np.zeros(N, np.int32)
+    M, cov = np.zeros((N, 3)), np.zeros((N, 9))
+    n = L.opu_intracam_new_points(_p(K), _p(iK), N, nH, _p(histR), _p(histT), _p(histXY), _p(st), _p(s2m), _p(sp), _p(fs), int(minTrackLen),
+                                  C.c_double(maxEpiErr), C.c_double(sigma), int(bool(cmpAcos)), _p(slot), _p(first), _p(M), _p(cov))
+    return slot[:n].copy(), first[:n].copy(), M[:n].copy(), cov[:n].copy()

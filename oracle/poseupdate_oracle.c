@@ -456,6 +456,100 @@ int opu_refine_map_points_ref(int nCams, int N, int nHist, const double* Ks, con
                               1, select, featRef, segPool, segCap, curFrame, walkCap, 0);
 }
 
+/* ---- SingleSLAM::newMapPoints (/root/reference/src/app/SL_SingleSLAM.cpp:922-1004) for ONE camera ---------------------------------------
+ * What CoSLAM::genNewMapPoints calls for a camera that IsReadyForKeyFrame (SL_CoSLAM.cpp:1310-1330): every unmapped feature on a track of
+ * at least minTrackLen frames (getUnMappedAndTrackedFeatPts, :152-172: tk.f2 - tk.f1 >= trackLen) is triangulated from its OWN track --
+ * the track's oldest feature within the history (the walk stops at a feature without a pose, :937) against the current one
+ * (binTriangulate), thrown out when the point lies behind the camera, when it is nearer to the camera than the square root of its
+ * covariance's trace (:960-962), when one of the two views re-projects further off than maxEpiErr; refineTriangulation (:1005-1049) then
+ * triangulates the current view with the widest-parallax one of the track, and the tests run once more.  A dynamic feature stops the
+ * walk (:938-944): the slot's type (isStatic) stands for the whole track here.
+ * hist* [nHist] with entry 0 = this frame; histXY [nHist][2N]; trackSpan [2N]; state / slot2map / isStatic [N].
+ * Out, in slot order: newSlot, newFirst (MapPoint::firstFrame = the oldest view's frame), newM [..][3], newCov [..][9].  Returns the count.
+ * PARITY: the loop is pinned against the reference's own function compiled in place (tests/cxx/ref_intracam_newpts_test.cpp ->
+ * tests/golden/intracam_newpts_golden.npz); binTriangulate / getBinTriangulateCovMat = triangulateMultiView / getTriangulateCovMat over
+ * the two views in the order given (un-vendored LibVisualSLAM: our definitions on both sides). */
+static void tri2(const double* iK, const double* R1, const double* t1, double x1, double y1, const double* R2, const double* t2, double x2, double y2,
+                 double* M) {
+    opu_normal_eq E;
+    memset(&E, 0, sizeof(E));
+    ne_add_view(&E, iK, R1, t1, x1, y1);
+    ne_add_view(&E, iK, R2, t2, x2, y2);
+    double cf[6];
+    const double det = sym33_cof(E.N, cf);
+    M[0] = ((cf[0] * E.g[0] + cf[1] * E.g[1]) + cf[2] * E.g[2]) / det;
+    M[1] = ((cf[1] * E.g[0] + cf[3] * E.g[1]) + cf[4] * E.g[2]) / det;
+    M[2] = ((cf[2] * E.g[0] + cf[4] * E.g[1]) + cf[5] * E.g[2]) / det;
+}
+static void cov2(const double* K, const double* R1, const double* t1, const double* R2, const double* t2, const double* M, double sigma, double* cov) {
+    double S[6] = {0, 0, 0, 0, 0, 0}, cf[6];
+    cov_add_view(S, K, R1, t1, M);
+    cov_add_view(S, K, R2, t2, M);
+    const double dS = sym33_cof(S, cf), s2 = sigma * sigma;
+    cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
+    cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
+    cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
+}
+static double reproj_err(const double* K, const double* R, const double* t, const double* M, double mx, double my) {
+    double rm[2];
+    org_project(K, R, t, M, rm);
+    const double dx = mx - rm[0], dy = my - rm[1];
+    return sqrt(dx * dx + dy * dy);
+}
+static int behind(const double* R, const double* t, const double* M) { return ((R[6] * M[0] + R[7] * M[1]) + R[8] * M[2]) + t[2] < 0; }
+
+int opu_intracam_new_points(const double* K, const double* iK, int N, int nHist, const double* histR, const double* histT, const double* histXY,
+                            const int* state, const int* slot2map, const int* trackSpan, const unsigned char* isStatic, int minTrackLen,
+                            double maxEpiErr, double sigma, int cmpAcos, int* newSlot, int* newFirst, double* newM, double* newCov) {
+    int n = 0;
+    for (int k = 0; k < N; k++) {
+        if (state[k] != 0 && state[k] != 1) continue;                  /* tk.empty() */
+        const int f1 = trackSpan[k], f2 = trackSpan[N + k];
+        if (f1 < 0 || f2 - f1 < minTrackLen || slot2map[k] >= 0) continue; /* :159 */
+        if (!isStatic[k]) continue;                                     /* :938-944 */
+        int jp = f2 - f1;                                               /* the track's first feature ... */
+        if (jp > nHist - 1) jp = nHist - 1;                             /* ... or the oldest one that still has a pose (:937) */
+        if (jp < 1) continue;
+        const double *R0 = histR, *t0 = histT, *Rp = histR + 9 * (size_t)jp, *tp = histT + 3 * (size_t)jp;
+        const double cx = histXY[k], cy = histXY[N + k], px = histXY[(size_t)jp * 2 * N + k], py = histXY[(size_t)jp * 2 * N + N + k];
+        double M[3], cov[9];
+        tri2(iK, Rp, tp, px, py, R0, t0, cx, cy, M);                    /* :950 */
+        if (behind(R0, t0, M)) continue;                                /* :953 */
+        cov2(K, Rp, tp, R0, t0, M, sigma, cov);                         /* :957 */
+        double org[3];
+        cam_center(R0, t0, org);
+        const double sTr = fabs((cov[0] + cov[4]) + cov[8]);
+        const double dx = org[0] - M[0], dy = org[1] - M[1], dz = org[2] - M[2];
+        if (sqrt((dx * dx + dy * dy) + dz * dz) < sqrt(sTr)) continue;  /* :960-962 */
+        if (!(reproj_err(K, Rp, tp, M, px, py) < maxEpiErr && reproj_err(K, R0, t0, M, cx, cy) < maxEpiErr)) continue; /* :965-970 */
+        /* refineTriangulation(cur_fp, M, cov): the current view and the widest-parallax one behind it */
+        int best = -1;
+        double bestCos = 1.0, bestAngle = 0.0;
+        for (int j = 1; j <= jp; j++) {
+            double Cj[3];
+            cam_center(histR + 9 * (size_t)j, histT + 3 * (size_t)j, Cj);
+            const double cv = cos_between(M, org, Cj);
+            if (cmpAcos) {
+                const double ang = fabs(acos(cv));
+                if (ang > bestAngle) bestAngle = ang, best = j;
+            } else if (cv < bestCos)
+                bestCos = cv, best = j;
+        }
+        if (best >= 0) {
+            const double *Rb = histR + 9 * (size_t)best, *tb = histT + 3 * (size_t)best;
+            tri2(iK, R0, t0, cx, cy, Rb, tb, histXY[(size_t)best * 2 * N + k], histXY[(size_t)best * 2 * N + N + k], M);
+            cov2(K, R0, t0, Rb, tb, M, sigma, cov);
+        }
+        const double e1 = reproj_err(K, Rp, tp, M, px, py), e2 = reproj_err(K, R0, t0, M, cx, cy);
+        if (behind(R0, t0, M) || behind(Rp, tp, M)) continue;           /* :977-979 */
+        if (!(e1 < maxEpiErr && e2 < maxEpiErr)) continue;              /* :980 */
+        newSlot[n] = k, newFirst[n] = f2 - jp;
+        memcpy(newM + 3 * (size_t)n, M, 24), memcpy(newCov + 9 * (size_t)n, cov, 72);
+        n++;
+    }
+    return n;
+}
+
 /* ---- CoSLAM::mapPointsClassify (/root/reference/src/app/SL_CoSLAM.cpp:418-520) --------------------------------------------------
  * Every frame, behind the pose update (CoSLAM::poseUpdate, :381-385: mapStateUpdate(), then mapPointsClassify(12.0)), every map point
  * of the current list that is uncertain (what the gate of poseUpdate3D made of it) or locally dynamic is re-examined:

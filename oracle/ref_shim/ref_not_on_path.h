@@ -9,7 +9,6 @@ template <class... A> void scaleDownAvg(const A&...);
 template <class... A> int searchNearestPoint(const A&...);
 template <class... A> bool intraCamEstimateEpi(const A&...);
 template <class... A> double getCameraDistance(const A&...);
-template <class... A> void getBinTriangulateCovMat(const A&...);
 #ifdef REF_SHIM_TRIANGULATE_ON_PATH
 /* src/slam/SL_CoSLAMHelper.cpp compiled in place for updateStaticPointPosition / updateDynamicPointPosition (:338-394, :455-484):
  * there these helpers ARE on the path -- real prototypes, OUR definitions in ref_triangulate_impl.cpp (un-vendored LibVisualSLAM) */
@@ -23,7 +22,14 @@ bool isAtCameraBack(const double* R, const double* t, const double* M);   /* isD
 double dist3(const double* a, const double* b);                           /* isDynamicPoint (:290) */
 /* NewMapPtsNCC::reconstructTracks (src/app/SL_NewMapPointsInterCam.cpp:247): the pixel distance of m from the projection of M */
 double reprojErrorSingle(const double* K, const double* R, const double* t, const double* M, const double* m);
+/* SingleSLAM::newMapPoints (src/app/SL_SingleSLAM.cpp:950, :957): the two-view forms -- OUR definitions: triangulateMultiView /
+ * getTriangulateCovMat over the two views in the order given (ref_triangulate_impl.cpp) */
+void binTriangulate(const double* R1, const double* t1, const double* R2, const double* t2, const double* m1, const double* m2, double* M);
+void getBinTriangulateCovMat(const double* K1, const double* R1, const double* t1, const double* K2, const double* R2, const double* t2,
+                             const double* M, double* cov, double sigma);
 #else
+template <class... A> void getBinTriangulateCovMat(const A&...);
+template <class... A> void binTriangulate(const A&...);
 template <class... A> double reprojErrorSingle(const A&...);
 template <class... A> bool isAtCameraBack(const A&...);
 template <class... A> double dist3(const A&...);
@@ -34,7 +40,6 @@ template <class... A> void getTriangulateCovMat(const A&...);
 template <class... A> void getInvK(const A&...);
 template <class... A> double getAbsRadiansBetween(const A&...);
 #endif
-template <class... A> void binTriangulate(const A&...);
 #define CV_8UC1 0
 namespace cv {
 struct Size {

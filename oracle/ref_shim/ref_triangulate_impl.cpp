@@ -104,3 +104,18 @@ double reprojErrorSingle(const double* K, const double* R, const double* t, cons
     const double dx = m[0] - rm[0], dy = m[1] - rm[1];
     return sqrt(dx * dx + dy * dy);
 }
+
+// the two-view forms SingleSLAM::newMapPoints names (src/app/SL_SingleSLAM.cpp:950, :957): the multi-view definitions above over the two
+// views in the order given (first the track's oldest static feature, then the current one)
+void binTriangulate(const double* R1, const double* t1, const double* R2, const double* t2, const double* m1, const double* m2, double* M) {
+    double Rs[18], ts[6], nms[4];
+    memcpy(Rs, R1, 72), memcpy(Rs + 9, R2, 72), memcpy(ts, t1, 24), memcpy(ts + 3, t2, 24);
+    nms[0] = m1[0], nms[1] = m1[1], nms[2] = m2[0], nms[3] = m2[1];
+    triangulateMultiView(2, Rs, ts, nms, M);
+}
+void getBinTriangulateCovMat(const double* K1, const double* R1, const double* t1, const double* K2, const double* R2, const double* t2,
+                             const double* M, double* cov, double sigma) {
+    double Ks[18], Rs[18], ts[6];
+    memcpy(Ks, K1, 72), memcpy(Ks + 9, K2, 72), memcpy(Rs, R1, 72), memcpy(Rs + 9, R2, 72), memcpy(ts, t1, 24), memcpy(ts + 3, t2, 24);
+    getTriangulateCovMat(2, Ks, Rs, ts, M, cov, sigma);
+}

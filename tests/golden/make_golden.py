@@ -759,6 +759,70 @@ def keyframe_case():
     return out
 
 
+def intracam_newpts_case():
+    """the reference's own SingleSLAM::newMapPoints (oracle/_ref/ref_intracam_newpts_test golden, CPU): three one-camera scenes of 160 slots;
+    the device's tables (history, state, slot2map, trackSpan, isStatic) and the reference's new points in slot order"""
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_intracam_newpts_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_intracam_newpts_test missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "n.bin")
+        subprocess.run([exe, "golden", path], check=True, stdout=subprocess.DEVNULL)
+        raw = open(path, "rb").read()
+    o = 0
+
+    def ints(n):
+        nonlocal o
+        v = np.frombuffer(raw, dtype=np.int32, count=n, offset=o).copy()
+        o += 4 * n
+        return v
+
+    def dbls(n):
+        nonlocal o
+        v = np.frombuffer(raw, dtype=np.float64, count=n, offset=o).copy()
+        o += 8 * n
+        return v
+
+    out = {}
+    (nS,) = ints(1)
+    out["n_scenes"] = np.int32(nS)
+    for sc in range(nS):
+        H, N, cur = ints(3)
+        K, iK = dbls(9), dbls(9)
+        sigma, max_epi = dbls(2)
+        (min_len,) = ints(1)
+        hR, hT = np.zeros((H, 9)), np.zeros((H, 3))
+        for j in range(H):
+            hR[j], hT[j] = dbls(9), dbls(3)
+        hXY = np.zeros((H, 2 * N))
+        state, s2m = np.full(N, -1, np.int32), np.full(N, -1, np.int32)
+        span, fstat = np.full(2 * N, -1, np.int32), np.ones(N, np.uint8)
+        for k in range(N):
+            L, mapped, dyn = ints(3)
+            m = dbls(2 * L).reshape(L, 2)
+            if L:
+                state[k] = 0
+                s2m[k] = 7 if mapped else -1
+                fstat[k] = 0 if dyn else 1
+                span[k], span[N + k] = cur - L + 1, cur
+                hXY[:L, k], hXY[:L, N + k] = m[:, 0], m[:, 1]
+        (n_new,) = ints(1)
+        slot, first, M, cov = np.zeros(n_new, np.int32), np.zeros(n_new, np.int32), np.zeros((n_new, 3)), np.zeros((n_new, 9))
+        for q in range(n_new):
+            slot[q], first[q] = ints(2)
+            M[q], cov[q] = dbls(3), dbls(9)
+        pre = f"s{sc}_"
+        for k, v in dict(K=K, iK=iK, sigma=np.float64(sigma), maxEpiErr=np.float64(max_epi), minTrackLen=np.int32(min_len), curFrame=np.int32(cur),
+                         histR=hR, histT=hT, histXY=hXY, state=state, slot2map=s2m, trackSpan=span, isStatic=fstat, new_slot=slot,
+                         new_first=first, new_M=M, new_cov=cov).items():
+            out[pre + k] = v
+    assert o == len(raw)
+    return out
+
+
 def classify_case():
     """the reference's own CoSLAM::mapPointsClassify over isStaticPoint / isStaticPointExclude / isDynamicPoint / isLittleMove /
     isStaticRemovable (oracle/_ref/ref_classify_test golden, CPU): 3 scenes of 72 map points walking every branch, re-laid out the
@@ -848,7 +912,7 @@ def classify_case():
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "mergability_long", "update_points", "update_points_relink", "keyframe", "classify", "intercam", "newpts", "decide"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "mergability_long", "update_points", "update_points_relink", "keyframe", "intracam_newpts", "classify", "intercam", "newpts", "decide"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -871,6 +935,8 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "mergability_long_golden.npz"), **mergability_long_case())
     if "update_points" in which:
         np.savez_compressed(os.path.join(HERE, "update_points_golden.npz"), **update_points_case())
+    if "intracam_newpts" in which:
+        np.savez_compressed(os.path.join(HERE, "intracam_newpts_golden.npz"), **intracam_newpts_case())
     if "keyframe" in which:
         np.savez_compressed(os.path.join(HERE, "keyframe_golden.npz"), **keyframe_case())
     if "update_points_relink" in which:

@@ -890,3 +890,78 @@ def test_check_unify_reproduces_the_reference_on_its_golden_pairs():
         n_all += nP
         n_yes += int(ok.sum())
     assert n_all > 500 and 200 < n_yes < n_all - 200
+
+
+def test_intracam_new_map_points_reproduce_the_reference():
+    """cs_newpts_intracam_dev against tests/golden/intracam_newpts_golden.npz: the reference's own SingleSLAM::newMapPoints (reference
+    src/app/SL_SingleSLAM.cpp:922-1004, compiled in place) on three one-camera scenes.  The ring is fed frame by frame (walks 64 frames
+    deep, 43-73 frames kept), the kernel appends behind a map that already holds 11 points: the same points in the same order -- position
+    and covariance bit for bit, first frame, TYPE_MAP_STATIC, bNewPt, the feature attached in pointFeat and slot2map --, the old map
+    untouched; a map with room for only 5 more drops the rest and says so; a camera that is not ready (d_ready below readyMin) adds nothing."""
+    import os
+
+    import torch
+
+    from coslam_amd.poseupdate import TrackHistory
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "intracam_newpts_golden.npz"))
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)   # noqa: E731
+    total = 0
+    for sc in range(int(g["n_scenes"])):
+        G = lambda k: g[f"s{sc}_{k}"]   # noqa: E731
+        hR, hT, hXY, span = G("histR"), G("histT"), G("histXY"), G("trackSpan")
+        H, N, cur = hR.shape[0], len(G("state")), int(G("curFrame"))
+        th = TrackHistory(1, N, 64, storeLen=H + 3)
+        dK, diK, d_span, d_fs = d(G("K")), d(G("iK")), d(span[None]), d(G("isStatic")[None])
+        d_fl0 = torch.zeros(64, dtype=torch.uint8, device=dev)
+        d_scr = torch.ones((1, N), dtype=torch.uint8, device=dev)
+        d_s2m_feed = torch.full((1, N), -1, dtype=torch.int32, device=dev)
+        eye, zero = d(np.eye(3).reshape(1, 9)), torch.zeros((1, 3), dtype=torch.float64, device=dev)
+        keep = []
+        for j in range(H - 1, -1, -1):
+            f = cur - j
+            xy = d(hXY[j][None])
+            st = d((((span[:N] >= 0) & (span[:N] <= f)).astype(np.int32) - 1)[None])
+            keep += [xy, st]
+            th.detect_dynamic_dev(s, [dict(K=dK.data_ptr(), iK=diK.data_ptr(), xy=xy.data_ptr(), state=st.data_ptr(), slot2map=d_s2m_feed.data_ptr(),
+                                           trackSpan=d_span.data_ptr(), isStatic=d_scr.data_ptr())], eye.data_ptr(), zero.data_ptr(), 64,
+                                  d_fl0.data_ptr(), f, minLen=1 << 30)
+        pose = [d(np.zeros(H, np.int32)), d((cur - np.arange(H)).astype(np.int32)), d(hR), d(hT)]
+        th.set_poses_dev(s, H, *[x.data_ptr() for x in pose])
+        n_ref = len(G("new_slot"))
+        for cap_extra, ready in ((4096, None), (5, None), (4096, 1)):
+            base = 11
+            cap = base + cap_extra
+            d_M, d_cov = torch.full((cap, 3), 7.0, dtype=torch.float64, device=dev), torch.full((cap, 9), 7.0, dtype=torch.float64, device=dev)
+            d_fl, d_np = torch.full((cap,), 9, dtype=torch.uint8, device=dev), torch.full((cap,), 9, dtype=torch.uint8, device=dev)
+            d_ff, d_pf = torch.full((cap,), -5, dtype=torch.int32, device=dev), torch.full((cap, 1), -9, dtype=torch.int32, device=dev)
+            d_cnt, d_mc = torch.zeros(3, dtype=torch.int32, device=dev), torch.tensor([base], dtype=torch.int32, device=dev)
+            d_st, d_s2m = d(G("state")[None]), d(G("slot2map")[None])
+            d_scratch = torch.zeros(th.newpts_intracam_scratch_bytes(), dtype=torch.uint8, device=dev)
+            d_ready = None if ready is None else torch.tensor([ready], dtype=torch.int32, device=dev)
+            cams = [dict(K=dK.data_ptr(), iK=diK.data_ptr(), state=d_st.data_ptr(), slot2map=d_s2m.data_ptr(), trackSpan=d_span.data_ptr(),
+                         isStatic=d_fs.data_ptr())]
+            th.newpts_intracam_dev(s, cams, d_M.data_ptr(), d_cov.data_ptr(), d_fl.data_ptr(), d_np.data_ptr(), d_ff.data_ptr(), d_pf.data_ptr(), cap,
+                                   d_mc.data_ptr(), d_scratch.data_ptr(), float(G("sigma")), d_ready=None if d_ready is None else d_ready.data_ptr(),
+                                   readyMin=2, minTrackLen=int(G("minTrackLen")), maxWalk=1024, maxEpiErr=float(G("maxEpiErr")), d_counts=d_cnt.data_ptr())
+            torch.cuda.synchronize()
+            want = 0 if ready is not None else min(n_ref, cap_extra)
+            assert int(d_mc.item()) == base + want, (sc, cap_extra, ready, int(d_mc.item()))
+            cnt = d_cnt.cpu().numpy().tolist()
+            assert cnt[1] == want and cnt[2] == (0 if ready is not None else n_ref - want)
+            M, cov = d_M.cpu().numpy(), d_cov.cpu().numpy()
+            assert (M[:base] == 7.0).all() and (d_fl.cpu().numpy()[:base] == 9).all() and (M[base + want:] == 7.0).all()
+            assert np.array_equal(M[base:base + want], G("new_M")[:want]) and np.array_equal(cov[base:base + want], G("new_cov")[:want]), (sc, cap_extra)
+            assert np.array_equal(d_ff.cpu().numpy()[base:base + want], G("new_first")[:want])
+            assert (d_fl.cpu().numpy()[base:base + want] == 0).all() and (d_np.cpu().numpy()[base:base + want] == 1).all()
+            assert np.array_equal(d_pf.cpu().numpy()[base:base + want, 0], G("new_slot")[:want])
+            s2m = d_s2m.cpu().numpy()[0]
+            exp = G("slot2map").copy()
+            exp[G("new_slot")[:want]] = base + np.arange(want)
+            assert np.array_equal(s2m, exp)
+            if ready is None and cap_extra > 100:
+                total += want
+        th.close()
+    assert total > 150
