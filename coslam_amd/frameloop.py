@@ -55,6 +55,10 @@ class LoopConfig:
         self.map_spare = 8192      # room for new map points behind the initial map
         self.klt_cams_per_launch = 0
         self.klt_xcd_placement = True
+        self.intracam_mapping = False    # SingleSLAM::newMapPoints for the cameras the key-frame decision calls ready (genNewMapPoints' first half,
+        # reference src/app/SL_CoSLAM.cpp:1294-1346): every unmapped feature on a track of 20+ frames becomes a map point from its own track
+        # (cs_newpts_intracam_dev).  Implies keyframe_decision.  Off in the headline: ~50 new points per frame need a map that recycles its
+        # points; with map_spare raised the loop runs on it for as long as the capacity lasts
         self.keyframe_decision = False   # CoSLAM::IsReadyForKeyFrame + addKeyFrame's key-pose state per frame on the device (cs_keyframe_ready_dev),
         # REPORTED (FrameLoop.keyframe_stats); the key frames themselves stay on the fixed key_every cadence -- RobustBundleRTS::output()'s
         # apply assumes equally spaced key frames (cs_ba_output_apply_dev), so the decision does not drive them yet
@@ -479,7 +483,7 @@ class FrameLoop:
             self.pose_upd.detect_dynamic_dev(self.pose_s.cuda_stream, self.pu_args, self.d_R[0].data_ptr(), self.d_t[0].data_ptr(), self.n_map,
                                              self.d_mapflags.data_ptr(), 0, 20, 5, 3, MAX_EPI_ERR)
             torch.cuda.synchronize()
-        if cfg.keyframe_decision:
+        if cfg.keyframe_decision or cfg.intracam_mapping:
             self.enable_keyframe_decision(0, 0)
 
     def enable_keyframe_decision(self, frame, b):
@@ -513,7 +517,8 @@ class FrameLoop:
         if not getattr(self, "kf", None):
             return None
         a = self.kf["stats"].cpu().tolist()
-        return dict(frames=self.kf["frames"], frames_with_a_camera_ready=a[0], frames_with_decrease_ie_key_frames_added=a[1],
+        im = None if "im_total" not in self.kf else dict(zip(("candidates_tried", "points_added", "points_dropped_map_full"), self.kf["im_total"].cpu().tolist()))
+        return dict(frames=self.kf["frames"], intracam_new_map_points=im, frames_with_a_camera_ready=a[0], frames_with_decrease_ie_key_frames_added=a[1],
                     cameras_saying_decrease=a[2], cameras_saying_view_angle=a[3], cameras_saying_translation=a[4],
                     min_cam_translation=self.kf["min_translation"], last_key_frame_per_camera=self.kf["frame"].cpu().tolist(),
                     mapped_static_at_the_last_key_frame=self.kf["mapped"].cpu().tolist())
@@ -625,6 +630,21 @@ class FrameLoop:
                                i, k["min_translation"], k["ready"].data_ptr(), k["cnt"].data_ptr(), k["cen"].data_ptr(), addKeyFrame=True,
                                d_stats=k["stats"].data_ptr(), device=self.device)
             k["frames"] += 1
+            if cfg.intracam_mapping and self.pose_upd is not None:
+                # ... and for the cameras that are ready (view angle / translation; with `decrease` the cameras that said so too: :1310-1346)
+                # SingleSLAM::newMapPoints: the unmapped features on tracks of nMinFeatTrkLen = 20 frames, each from its own track
+                if "im_scr" not in k:
+                    torch = self.torch
+                    k["im_scr"] = torch.zeros(self.pose_upd.newpts_intracam_scratch_bytes(), dtype=torch.uint8, device=self.dev)
+                    k["im_cnt"] = torch.zeros(3, dtype=torch.int32, device=self.dev)
+                    k["im_total"] = torch.zeros(3, dtype=torch.int64, device=self.dev)
+                    torch.cuda.synchronize()
+                self.pose_upd.newpts_intracam_dev(ps, self.pu_args, self.d_map.data_ptr(), self.d_cov.data_ptr(), self.d_mapflags.data_ptr(),
+                                                  self.d_newpt.data_ptr(), self.d_firstfrm.data_ptr(), self.d_pf.data_ptr(), self.n_map,
+                                                  self.d_mapcount.data_ptr(), k["im_scr"].data_ptr(), self.sig_pix, d_ready=k["ready"].data_ptr(),
+                                                  readyMin=1, minTrackLen=20, maxWalk=1024, maxEpiErr=2.0, d_counts=k["im_cnt"].data_ptr())
+                with self.torch.cuda.stream(self.pose_s):
+                    k["im_total"] += k["im_cnt"]
         if self.ncc is not None and i % cfg.ncc_every == 0:
             self._ncc_leg(i, f, dst)
         if cfg.with_register:

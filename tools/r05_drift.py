@@ -45,7 +45,8 @@ VARIANTS = {
     "no_classify": (dict(with_classify=False), None),
     "no_merge": (dict(merge_every=0), None),
     "no_intercam": (dict(with_intercam=False), None),
-    "no_chains": (dict(feature_chains=False), None),   # this frame's features on their own tracks (the state before the feature references)
+    "no_chains": (dict(feature_chains=False), None),
+    "intracam": (dict(intracam_mapping=True, map_spare=50000), None),   # + SingleSLAM::newMapPoints for the cameras that are ready for a key frame   # this frame's features on their own tracks (the state before the feature references)
 }
 
 
@@ -211,6 +212,8 @@ def main():
         if i % args.every == 0 or i == 1:
             sample(i)
     loop.drain()
+    if getattr(loop, "kf", None):
+        print(json.dumps({"keyframe_stats": loop.keyframe_stats()}), file=out, flush=True)
     if args.time_intracam:
         # k_intracam ALONE on the loop's own last inputs (this frame's correspondences, the previous frame's poses): is its time in the loop
         # (~105 us) the co-residency with the tracker / the solves, or the LM steps its data ask for?
