@@ -427,6 +427,50 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
     return n / dt, n, dt, joint_sizes
 
 
+def live_tracker_pmc():
+    """FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU of k_track_rows_fused per launch (KB, KB, wave instructions), collected now: one rocprofv3 --pmc
+    pass each over tools/pmc_klt.py (the 8-camera KLT stage), summarised by tools/rocpd_summary.py.  {"error": ...} when anything fails."""
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return {"error": "rocprofv3 not on PATH"}
+    out = {}
+    td = tempfile.mkdtemp(prefix="coslam_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+            d = os.path.join(td, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", "pmc_klt.py")]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                 start_new_session=True)
+            try:
+                p.wait(timeout=45)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)   # (the process group this call started: rocprofv3 and its child)
+                return {"error": f"{ctr} pass timed out"}
+            dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+            if p.returncode != 0 or not dbs:
+                return {"error": f"{ctr} pass failed (rc {p.returncode})"}
+            txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocpd_summary.py"), "counters", dbs[0]], capture_output=True, text=True,
+                                 timeout=60).stdout
+            val = None
+            for ln in txt.splitlines():
+                c = [x.strip() for x in ln.split("|")]
+                if len(c) > 5 and c[1].startswith("k_track_rows_fused") and c[2] == ctr:
+                    val = float(c[4])
+            if val is None:
+                return {"error": f"{ctr}: no k_track_rows_fused row in the summary"}
+            out[ctr] = val
+        return out
+    except Exception as ex:   # noqa: BLE001
+        return {"error": str(ex)[:200]}
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+
+
 def spawn_command(n_gpus, argv, port):
     """the launcher line the driver itself uses for N > 1 (one rank per GPU, rendezvous on 127.0.0.1)"""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
@@ -515,6 +559,10 @@ def main():
                          "N > 1: 12 (every rank must take the same number of steps)")
     ap.add_argument("--klt-xcd-placement", type=int, default=int(os.environ.get("BENCH_KLT_XCD", "1")),
                     help="1: the persistent tracker numbers its workgroups so that a camera lands on its own XCD; 0: cameras as grid rows")
+    ap.add_argument("--live-pmc", type=int, default=int(os.environ.get("BENCH_LIVE_PMC", "1")),
+                    help="1 (default): roofline.traffic / valu are collected by THIS run -- three rocprofv3 --pmc passes of the 8-camera KLT stage in "
+                         "child processes behind the timed loops, a few seconds each, bounded by timeouts; a pass that fails falls back to the "
+                         "committed profiles/r05_tracker_pmc.json and says so.  0: read the committed file")
     ap.add_argument("--keyframe-decision", type=int, default=0,
                     help="1: CoSLAM::IsReadyForKeyFrame + addKeyFrame's bookkeeping per frame on the device (reported in config.key_frame_decision; "
                          "the key frames stay on the fixed cadence)")
@@ -917,6 +965,20 @@ def main():
                 floor_us = insts * 4.0 / (1024 * pj.get("sclk_ghz", 2.4) * 1e3)
                 valu = {"insts": insts, "floor_us": floor_us, "frac": floor_us / avg_us, "unit": "wave64 VALU instructions per launch",
                         "source": os.path.relpath(pmc_file, ROOT) + " (SQ_INSTS_VALU, separate --pmc pass)"}
+        if args.live_pmc and pj is not None:
+            # the same counters collected NOW (opt-in: three rocprofv3 --pmc passes of the 8-camera KLT stage in child processes, ~10 s each, the
+            # way MI355X_MICROARCH.md prescribes: separate passes, --kernel-trace only beside them); a pass that fails leaves the committed figure
+            live = live_tracker_pmc()
+            if "error" not in live:
+                traffic = (2.0 * live["FETCH_SIZE"] * 1024 + live["WRITE_SIZE"] * 1024) / launches
+                traffic_src = "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of tools/pmc_klt.py (x 2 on the fetch counter: gfx950 tallies 128-byte requests at 64 B)"
+                if valu is not None and "SQ_INSTS_VALU" in live:
+                    insts = live["SQ_INSTS_VALU"] / launches
+                    floor_us = insts * 4.0 / (1024 * pj.get("sclk_ghz", 2.4) * 1e3)
+                    valu = {"insts": insts, "floor_us": floor_us, "frac": floor_us / avg_us, "unit": "wave64 VALU instructions per launch",
+                            "source": "measured in this run (SQ_INSTS_VALU, its own --pmc pass)"}
+            else:
+                traffic_src += "; --live-pmc failed: " + live["error"]
         fused_kernel = prof["launches_per_frame"] <= N_CAMS
         roof = {"bound": "hbm", "kernel": "k_track_rows_fused" if fused_kernel else "k_track_rows_pass",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
