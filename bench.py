@@ -333,9 +333,9 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
                                      select=np.ascontiguousarray(reg, dtype=np.uint8))
 
     # genNewMapPoints' NCC stage, every 4th frame like the GPU loop: getNCCBlocks of a camera's candidate features (with its thread),
-    # getEpiNccMat of the consecutive camera pairs behind the cameras (the C restatements; the match / reconstruct tail and the
-    # registration decision exist in plain Python only and are NOT timed here -- a Python loop would not be a fair CPU figure)
+    # getEpiNccMat of the consecutive camera pairs behind the cameras, then the match / reconstruct / decidePointType tail (all C restatements)
     ncc_rec = [None] * N_CAMS
+    ncc_pairs = [np.zeros((0, 4))] * (N_CAMS - 1)
     Kinv_ = np.linalg.inv(sc.K)
 
     def ncc_cam(c, f):
@@ -344,16 +344,37 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
         idx = np.nonzero(((st[c] == 0) | (st[c] == 1)) & (f1 >= 0) & (f2 - f1 >= 3) & free_or_false)[0]
         x, y = np.ascontiguousarray(xy[c][:N_FEAT][idx]), np.ascontiguousarray(xy[c][N_FEAT:][idx])
         blk, abc = oracle.get_ncc_blocks(frames[c][f], x, y, 0.3)
-        ncc_rec[c] = (x, y, blk, abc, np.ones(len(idx), dtype=np.int32))
+        ncc_rec[c] = (x, y, blk, abc, np.ones(len(idx), dtype=np.int32), idx)
 
     def ncc_pair(a, f):
         (R1, t1), (R2, t2) = sc.pose(a, f), sc.pose(a + 1, f)
         R = R1 @ R2.T
         t = t1 - R @ t2
         F = Kinv_.T @ (np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R) @ Kinv_
-        (x1, y1, b1, c1, v1), (x2, y2, b2, c2, v2) = ncc_rec[a], ncc_rec[a + 1]
+        (x1, y1, b1, c1, v1, i1), (x2, y2, b2, c2, v2, i2) = ncc_rec[a], ncc_rec[a + 1]
+        ncc_pairs[a] = np.zeros((0, 4))
         if len(x1) and len(x2):
-            oracle.ncc_epi_mat(F, x1, y1, b1, c1, v1, x2, y2, b2, c2, v2, 50.0, 0.80)
+            epi, ncc = oracle.ncc_epi_mat(F, x1, y1, b1, c1, v1, x2, y2, b2, c2, v2, 50.0, 0.80)
+            ii, jj = np.nonzero(ncc >= 0)          # the pairs that passed both gates: what NewMapPtsNCC::matchBetween's matcher gets
+            ncc_pairs[a] = np.stack([i1[ii].astype(np.float64), i2[jj].astype(np.float64), epi[ii, jj], ncc[ii, jj]], 1)
+
+    tail_s = [0.0]
+
+    def ncc_tail(frame_no):
+        # NewMapPtsNCC::run's tail + output in C (onc_new_points_from_pairs): seeds, disparity guide, greedy matches, tracks, triangulation,
+        # decidePointType -- on a scratch copy of the map with room behind it (the CPU loop's map does not grow: the result is dropped)
+        t0 = time.perf_counter()
+        n0 = len(map_pts)
+        sp = 2048
+        M_ = np.concatenate([map_pts, np.zeros((sp, 3))])
+        C_ = np.concatenate([map_cov.reshape(-1, 9), np.zeros((sp, 9))])
+        fl_ = np.concatenate([map_flags, np.zeros(sp, np.uint8)])
+        pf_ = np.ascontiguousarray(np.concatenate([np.stack([oracle.point_features(st[c], s2m[c], n0) for c in range(N_CAMS)], 1).astype(np.int32),
+                                                   np.full((sp, N_CAMS), -1, np.int32)]))
+        oracle.new_map_points_from_pairs_c(N_FEAT, [ncc_pairs[a] for a in range(N_CAMS - 1)], [sc.K] * N_CAMS, [Kinv_] * N_CAMS, Rc, tc, xy, st,
+                                           [q.copy() for q in s2m], is_static, M_, C_, fl_, np.zeros(n0 + sp, np.uint8), np.zeros(n0 + sp, np.int32),
+                                           pf_, n0, frame_no, max_disp=80.0, max_rp_err=3.0, sigma=SIG, min_len=2, W=W, H=H)
+        tail_s[0] += time.perf_counter() - t0
 
     def run_cams(cams, f, frame_no):
         for c in cams:
@@ -392,6 +413,7 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
         if with_ncc and (n + 1) % 4 == 0:
             in_threads(lambda cs, f_: run_ncc(ncc_cam, cs, f_), range(N_CAMS), f)
             in_threads(lambda ps, f_: run_ncc(ncc_pair, ps, f_), range(N_CAMS - 1), f)
+            ncc_tail(n + 1)
         if n % KEY_EVERY == 0:
             # RobustBundleRTS::addKeyFrames / addPoints / parseInputs over the last 5 key frames' records (the window the GPU loop parses on
             # the device), then requestForBA(5, 2, 2, 30): 2 * numCams oldest key cameras and 2 points held, maxIter 2, inner 10; static points
@@ -424,6 +446,7 @@ def cpu_baseline(sc, frames, joint, ic, n_threads, budget_s, with_register=True,
         if time.perf_counter() - t_start > budget_s or n >= 200:
             break
     dt = time.perf_counter() - t_start
+    joint_sizes.append(tail_s[0] / dt)   # (the share of the new-map-point tail in the figure)
     return n / dt, n, dt, joint_sizes
 
 
@@ -1139,9 +1162,10 @@ def main():
                          "hand-back, intra-camera pose, register search + mergability, pose update gate + dynamic test + classify, "
                          "NCC blocks + epipolar/NCC matrix every 4th frame, per key frame the joint BA of the window PARSED from the last 5 key "
                          "frames' records like the GPU's (numpy parse; the pre-baked problem only until 5 key frames exist) + pose graph + the "
-                         "update behind it + inter-camera BA; the registration decision (C) + refineMapPoint; NOT in the CPU figure (restated in "
-                         "plain Python only): the new-map-point match / reconstruct tail",
-               "joint_problem_last_parsed": dict(zip(("cameras", "points", "measurements"), jsN)),
+                         "update behind it + inter-camera BA; the registration decision (C) + refineMapPoint; the new-map-point match / reconstruct / "
+                         "decidePointType tail in C on a scratch copy of the map (the CPU loop's map does not grow)",
+               "joint_problem_last_parsed": dict(zip(("cameras", "points", "measurements"), jsN[:3])),
+               "new_map_point_tail_share_of_the_figure": jsN[3],
                "value_1_thread": v1, "host_cores": cores}
 
     # ---- the same loop driven from C++ through the C-ABI only (north_star: "Host stays C++"): tools/cxx/frame_loop.cpp, its

@@ -1294,3 +1294,36 @@ def intracam_new_points(K, iK, histR, histT, histXY, state, slot2map, trackSpan,
     n = L.opu_intracam_new_points(_p(K), _p(iK), N, nH, _p(histR), _p(histT), _p(histXY), _p(st), _p(s2m), _p(sp), _p(fs), int(minTrackLen),
                                   C.c_double(maxEpiErr), C.c_double(sigma), int(bool(cmpAcos)), _p(slot), _p(first), _p(M), _p(cov))
     return slot[:n].copy(), first[:n].copy(), M[:n].copy(), cov[:n].copy()
+
+
+def new_map_points_from_pairs_c(N, pairs, Ks, iKs, Rs, ts, xy, state, slot2map, isStatic, mapPts, mapCov, mapFlags, newPt, firstFrame, pointFeat,
+                                map_count, cur_frame, max_disp=80.0, max_rp_err=3.0, sigma=10.0, min_len=2, max_seeds=512, W=640, H=480):
+    """onc_new_points_from_pairs: new_map_points_from_pairs in C (what bench.py's CPU baseline times).  Same arguments (reproj is not
+    kept); the map arrays and slot2map (a list of int32 arrays, one per camera) are updated IN PLACE.  Returns dict(matches, new, map_count)."""
+    L = lib()
+    L.onc_new_points_from_pairs.restype = C.c_int
+    nC = len(xy)
+    cap = len(mapPts)
+    pl = [np.ascontiguousarray(np.asarray(p, dtype=np.float64).reshape(-1, 4)) for p in pairs]
+    pp = (C.c_void_p * max(nC - 1, 1))(*[p.ctypes.data for p in pl])
+    npairs = np.asarray([len(p) for p in pl] + [0] * (max(nC - 1, 1) - len(pl)), dtype=np.int32)
+    K_ = np.ascontiguousarray(np.stack([np.asarray(k, float).reshape(9) for k in Ks]))
+    iK_ = np.ascontiguousarray(np.stack([np.asarray(k, float).reshape(9) for k in iKs]))
+    R_ = np.ascontiguousarray(np.stack([np.asarray(r, float).reshape(9) for r in Rs]))
+    t_ = np.ascontiguousarray(np.stack([np.asarray(t, float).reshape(3) for t in ts]))
+    xy_ = np.ascontiguousarray(np.stack([np.asarray(x, float)[:2 * N] if len(x) == 2 * N else np.concatenate([np.asarray(x, float)[:N], np.asarray(x, float)[len(x) // 2:len(x) // 2 + N]]) for x in xy]))
+    st_ = np.ascontiguousarray(np.stack([np.asarray(q, np.int32)[:N] for q in state]))
+    s2m_ = np.ascontiguousarray(np.stack([np.asarray(q, np.int32)[:N] for q in slot2map]))
+    is_ = None if isStatic is None else np.ascontiguousarray(np.stack([np.asarray(q, np.uint8)[:N] for q in isStatic]))
+    for a, dt in ((mapPts, np.float64), (mapCov, np.float64), (mapFlags, np.uint8), (newPt, np.uint8), (firstFrame, np.int32), (pointFeat, np.int32)):
+        assert a.dtype == dt and a.flags.c_contiguous
+    assert pointFeat.shape == (cap, nC)
+    mc = C.c_int(int(map_count))
+    match = np.full((max(nC - 1, 1), N), -1, dtype=np.int32)
+    n = L.onc_new_points_from_pairs(nC, N, pp, _p(npairs), _p(K_), _p(iK_), _p(R_), _p(t_), _p(xy_), _p(st_), _p(s2m_),
+                                    _p(is_) if is_ is not None else None, _p(mapPts), _p(mapCov), _p(mapFlags), _p(newPt), _p(firstFrame),
+                                    _p(pointFeat), cap, C.byref(mc), int(cur_frame), C.c_double(max_disp), C.c_double(max_rp_err),
+                                    C.c_double(sigma), int(min_len), int(max_seeds), int(W), int(H), _p(match))
+    for c in range(nC):
+        slot2map[c][:N] = s2m_[c]
+    return dict(matches=match[:nC - 1], new=list(range(int(map_count), int(map_count) + n)), map_count=mc.value)

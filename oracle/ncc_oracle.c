@@ -278,3 +278,180 @@ void onc_get_ncc_blocks(const unsigned char* img, int W, int H, int n, const dou
         abc[4 * i + 3] = avg / ONC_LEN;
     }
 }
+
+/* ---- NewMapPtsNCC::run + output behind getEpiNccMat, in C (bench.py's CPU baseline: a Python loop would not be a fair CPU figure) ---------
+ * oracle.new_map_points_from_pairs (oracle/__init__.py: the line-cited restatement of /root/reference/src/app/SL_NewMapPointsInterCam.cpp:
+ * 97-127, 150-161, 163-192, 194-270, 25-91, 295-316, 631-690, itself pinned to the reference's own featTracksFromMatches / reconstructTracks
+ * / decidePointType compiled in place) operation for operation; tests/test_oracle_cpu.py holds the two against each other.
+ * nC cameras with N slots each; consecutive pairs (a, a + 1); pairs[a] = nPairs[a] candidates {i, j, epi, ncc} of the NCC stage (pairStride
+ * doubles apart: 4 doubles each).  Ks / iKs / Rs [nC][9], ts [nC][3]; xy [nC][2N]; state / slot2map / isStatic [nC][N] (slot2map is written);
+ * the map arrays (mapPts [cap][3], mapCov [cap][9], mapFlags, newPt, firstFrame [cap], pointFeat [cap][nC]) are appended behind *mapCount.
+ * match [nC - 1][N] out.  Returns the number of new points.  TEST INFRASTRUCTURE. */
+typedef struct {
+    double negNcc;
+    int i, j;
+} onc_cand;
+static int onc_cand_cmp(const void* a, const void* b) {
+    const onc_cand *x = (const onc_cand*)a, *y = (const onc_cand*)b;
+    if (x->negNcc != y->negNcc) return x->negNcc < y->negNcc ? -1 : 1;
+    if (x->i != y->i) return x->i < y->i ? -1 : 1;
+    return x->j < y->j ? -1 : (x->j > y->j ? 1 : 0);
+}
+static double onc_sym33_cof(const double* S, double* c) {
+    c[0] = S[3] * S[5] - S[4] * S[4], c[1] = S[2] * S[4] - S[1] * S[5], c[2] = S[1] * S[4] - S[2] * S[3];
+    c[3] = S[0] * S[5] - S[2] * S[2], c[4] = S[1] * S[2] - S[0] * S[4], c[5] = S[0] * S[3] - S[1] * S[1];
+    return (S[0] * c[0] + S[1] * c[1]) + S[2] * c[2];
+}
+int onc_new_points_from_pairs(int nC, int N, const double* const* pairs, const int* nPairs, const double* Ks, const double* iKs, const double* Rs,
+                              const double* ts, const double* xy, const int* state, int* slot2map, const unsigned char* isStatic, double* mapPts,
+                              double* mapCov, unsigned char* mapFlags, unsigned char* newPt, int* firstFrame, int* pointFeat, int cap,
+                              int* mapCount, int curFrame, double maxDisp, double maxRpErr, double sigma, int minLen, int maxSeeds, int W, int H,
+                              int* match) {
+    unsigned char* hasIn = (unsigned char*)calloc((size_t)nC * N, 1);
+    unsigned char *rowUsed = (unsigned char*)malloc(N), *colUsed = (unsigned char*)malloc(N);
+    double* seeds = (double*)malloc(sizeof(double) * 4 * (maxSeeds > 0 ? maxSeeds : 1));
+    int count = *mapCount, nNew = 0;
+    int* newIdx = (int*)malloc(sizeof(int) * (size_t)(nC > 1 ? (nC - 1) : 1) * N);
+    for (int q = 0; q < (nC - 1) * N; q++) match[q] = -1;
+    for (int a = 0; a + 1 < nC; a++) {
+        const int b = a + 1;
+        const double *xa = xy + (size_t)a * 2 * N, *xb = xy + (size_t)b * 2 * N;
+        int nSeeds = 0; /* getSeedsBetween (:97-127), map order */
+        for (int m = 0; m < (count < cap ? count : cap) && nSeeds < maxSeeds; m++) {
+            if (mapFlags[m] & 6) continue;
+            const int s1 = pointFeat[(size_t)m * nC + a], s2 = pointFeat[(size_t)m * nC + b];
+            if (s1 >= 0 && s2 >= 0) {
+                double* sd = seeds + 4 * nSeeds++;
+                sd[0] = xa[s1], sd[1] = xa[N + s1], sd[2] = xb[s2] - sd[0], sd[3] = xb[N + s2] - sd[1];
+            }
+        }
+        onc_cand* cand = (onc_cand*)malloc(sizeof(onc_cand) * (size_t)(nPairs[a] > 0 ? nPairs[a] : 1));
+        int nCand = 0;
+        for (int q = 0; q < nPairs[a]; q++) {
+            const double* p = pairs[a] + 4 * (size_t)q;
+            const int i = (int)p[0], j = (int)p[1];
+            if (nSeeds) { /* getDisparityMat + the guide */
+                const double x1 = xa[i], y1 = xa[N + i];
+                double best = 1.0e300;
+                int bk = 0;
+                for (int k = 0; k < nSeeds; k++) {
+                    const double dx = seeds[4 * k] - x1, dy = seeds[4 * k + 1] - y1, d2 = dx * dx + dy * dy;
+                    if (d2 < best) best = d2, bk = k;
+                }
+                const double ex = (xb[j] - x1) - seeds[4 * bk + 2], ey = (xb[N + j] - y1) - seeds[4 * bk + 3];
+                if (!(sqrt(ex * ex + ey * ey) <= maxDisp)) continue;
+            }
+            cand[nCand].negNcc = -p[3], cand[nCand].i = i, cand[nCand].j = j, nCand++;
+        }
+        qsort(cand, nCand, sizeof(onc_cand), onc_cand_cmp); /* falling score, then rising row, then rising column */
+        memset(rowUsed, 0, N), memset(colUsed, 0, N);
+        for (int q = 0; q < nCand; q++) {
+            if (rowUsed[cand[q].i] || colUsed[cand[q].j]) continue;
+            rowUsed[cand[q].i] = colUsed[cand[q].j] = 1;
+            match[(size_t)a * N + cand[q].i] = cand[q].j;
+            hasIn[(size_t)b * N + cand[q].j] = 1;
+        }
+        free(cand);
+    }
+    int tkC[64], tkS[64];
+    for (int a = 0; a + 1 < nC; a++) /* featTracksFromMatches (:631-690): numbered by (pair, feature) */
+        for (int i0 = 0; i0 < N; i0++) {
+            if (match[(size_t)a * N + i0] < 0 || (a > 0 && hasIn[(size_t)a * N + i0])) continue;
+            int len = 0, c = a, s = i0;
+            tkC[len] = c, tkS[len] = s, len++;
+            while (c < nC - 1 && match[(size_t)c * N + s] >= 0) {
+                s = match[(size_t)c * N + s];
+                c++;
+                tkC[len] = c, tkS[len] = s, len++;
+            }
+            if (len < minLen) continue; /* reconstructTracks (:194-270) */
+            double Nn[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+            for (int v = 0; v < len; v++) {
+                const double *iK = iKs + 9 * tkC[v], *R = Rs + 9 * tkC[v], *t = ts + 3 * tkC[v];
+                const double mx = xy[(size_t)tkC[v] * 2 * N + tkS[v]], my = xy[(size_t)tkC[v] * 2 * N + N + tkS[v]];
+                const double w = (iK[6] * mx + iK[7] * my) + iK[8];
+                const double x = ((iK[0] * mx + iK[1] * my) + iK[2]) / w, y = ((iK[3] * mx + iK[4] * my) + iK[5]) / w;
+                const double a0[3] = {R[0] - x * R[6], R[1] - x * R[7], R[2] - x * R[8]}, a1[3] = {R[3] - y * R[6], R[4] - y * R[7], R[5] - y * R[8]};
+                const double b0 = x * t[2] - t[0], b1 = y * t[2] - t[1];
+                Nn[0] = Nn[0] + (a0[0] * a0[0] + a1[0] * a1[0]), Nn[1] = Nn[1] + (a0[0] * a0[1] + a1[0] * a1[1]);
+                Nn[2] = Nn[2] + (a0[0] * a0[2] + a1[0] * a1[2]), Nn[3] = Nn[3] + (a0[1] * a0[1] + a1[1] * a1[1]);
+                Nn[4] = Nn[4] + (a0[1] * a0[2] + a1[1] * a1[2]), Nn[5] = Nn[5] + (a0[2] * a0[2] + a1[2] * a1[2]);
+                for (int q = 0; q < 3; q++) g[q] = g[q] + (a0[q] * b0 + a1[q] * b1);
+            }
+            double cf[6];
+            const double det = onc_sym33_cof(Nn, cf);
+            const double M[3] = {((cf[0] * g[0] + cf[1] * g[1]) + cf[2] * g[2]) / det, ((cf[1] * g[0] + cf[3] * g[1]) + cf[4] * g[2]) / det,
+                                 ((cf[2] * g[0] + cf[4] * g[1]) + cf[5] * g[2]) / det};
+            int outlier = 0;
+            double S[6] = {0, 0, 0, 0, 0, 0};
+            for (int v = 0; v < len; v++) {
+                const double *K = Ks + 9 * tkC[v], *R = Rs + 9 * tkC[v], *t = ts + 3 * tkC[v];
+                const double X = ((R[0] * M[0] + R[1] * M[1]) + R[2] * M[2]) + t[0], Y = ((R[3] * M[0] + R[4] * M[1]) + R[5] * M[2]) + t[1];
+                const double Z = ((R[6] * M[0] + R[7] * M[1]) + R[8] * M[2]) + t[2];
+                const double u = (K[0] * X + K[1] * Y) + K[2] * Z, vv = (K[3] * X + K[4] * Y) + K[5] * Z, w = (K[6] * X + K[7] * Y) + K[8] * Z;
+                const double dx = xy[(size_t)tkC[v] * 2 * N + tkS[v]] - u / w, dy = xy[(size_t)tkC[v] * 2 * N + N + tkS[v]] - vv / w;
+                const double e = sqrt(dx * dx + dy * dy);
+                if (e > maxRpErr || Z < 0) outlier = 1;
+                double KR[9], J[6];
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) KR[3 * i + j] = (K[3 * i] * R[j] + K[3 * i + 1] * R[3 + j]) + K[3 * i + 2] * R[6 + j];
+                const double ww = w * w;
+                for (int j = 0; j < 3; j++) J[j] = (KR[j] * w - u * KR[6 + j]) / ww, J[3 + j] = (KR[3 + j] * w - vv * KR[6 + j]) / ww;
+                S[0] = S[0] + (J[0] * J[0] + J[3] * J[3]), S[1] = S[1] + (J[0] * J[1] + J[3] * J[4]), S[2] = S[2] + (J[0] * J[2] + J[3] * J[5]);
+                S[3] = S[3] + (J[1] * J[1] + J[4] * J[4]), S[4] = S[4] + (J[1] * J[2] + J[4] * J[5]), S[5] = S[5] + (J[2] * J[2] + J[5] * J[5]);
+            }
+            if (outlier || count >= cap) continue;
+            const double dS = onc_sym33_cof(S, cf), s2 = sigma * sigma;
+            const int m = count++;
+            double* cov = mapCov + 9 * (size_t)m;
+            cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
+            cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
+            cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
+            memcpy(mapPts + 3 * (size_t)m, M, 24);
+            int nDyn = 0;
+            for (int v = 0; v < len; v++) nDyn += isStatic && !isStatic[(size_t)tkC[v] * N + tkS[v]];
+            mapFlags[m] = nDyn > 1 ? 1 : 4; /* setLocalDynamic / setUncertain (:253-264) */
+            newPt[m] = 1, firstFrame[m] = curFrame;
+            for (int c2 = 0; c2 < nC; c2++) pointFeat[(size_t)m * nC + c2] = -1;
+            for (int v = 0; v < len; v++) pointFeat[(size_t)m * nC + tkC[v]] = tkS[v], slot2map[(size_t)tkC[v] * N + tkS[v]] = m;
+            newIdx[nNew++] = m;
+        }
+    /* decidePointType (:25-91) */
+    int anyUncertain = 0;
+    for (int q = 0; q < nNew; q++) anyUncertain |= mapFlags[newIdx[q]] == 4;
+    if (anyUncertain) {
+        int* dynXY = (int*)malloc(sizeof(int) * 2 * (size_t)nC * N);
+        int* nDynC = (int*)calloc(nC, sizeof(int));
+        for (int c = 0; c < nC; c++)
+            for (int s = 0; s < N; s++) {
+                const int m = slot2map[(size_t)c * N + s], st = state[(size_t)c * N + s];
+                if ((st == 0 || st == 1) && m >= 0 && m < cap && mapFlags[m] == 1) {
+                    int* o = dynXY + 2 * ((size_t)c * N + nDynC[c]++);
+                    o[0] = (int)(xy[(size_t)c * 2 * N + s] + 0.5), o[1] = (int)(xy[(size_t)c * 2 * N + N + s] + 0.5);
+                }
+            }
+        for (int q = 0; q < nNew; q++) {
+            const int m = newIdx[q];
+            if (mapFlags[m] != 4) continue;
+            int isStat = 1;
+            for (int c = 0; c < nC && isStat; c++) {
+                const int s = pointFeat[(size_t)m * nC + c];
+                if (s < 0) continue;
+                const int x = (int)(xy[(size_t)c * 2 * N + s] + 0.5), y = (int)(xy[(size_t)c * 2 * N + N + s] + 0.5);
+                if (!(x >= 0 && x < W && y >= 0 && y < H)) continue;
+                for (int k = 0; k < nDynC[c]; k++) {
+                    const int* o = dynXY + 2 * ((size_t)c * N + k);
+                    if (abs(x - o[0]) <= 20 && abs(y - o[1]) <= 20) {
+                        isStat = 0;
+                        break;
+                    }
+                }
+            }
+            if (isStat) mapFlags[m] = 0;
+        }
+        free(dynXY), free(nDynC);
+    }
+    *mapCount = count;
+    free(hasIn), free(rowUsed), free(colUsed), free(seeds), free(newIdx);
+    return nNew;
+}
