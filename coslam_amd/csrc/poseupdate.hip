@@ -2388,57 +2388,85 @@ __global__ __launch_bounds__(256) void k_feat_ref_advance(FrArgs A) {
     int cnt[5] = {0, 0, 0, 0, 0};   // tracked on, first, re-linked, links dropped, detached
     if (m < A.nMap) {
         const int* pf = A.pointFeat + (size_t)m * A.nCams;
-        bool any = false;
-        for (int c = 0; c < A.nCams; ++c) any = any || pf[c] >= 0;
+        int top = -1;   // (no short circuit: the row's loads go out together, not one after the other)
+#pragma unroll 8
+        for (int c = 0; c < A.nCams; ++c) top = max(top, pf[c]);
+        const bool any = top >= 0;
         const bool was = A.alive[m] != 0;
         bool aliveNow = false;
         if (any || was) {
-            for (int c = 0; c < A.nCams; ++c) {
-                const size_t e = (size_t)m * A.nCams + c;
-                const int s = pf[c];
-                int4 ref = A.featRef[e];
-                const cs_poseupdate_cam& C = A.cam[c];
-                if (s < 0 || s >= A.N) {
-                    if (ref.x >= 0 && ref.x < A.N && ref.y == A.curFrame - 1) {
-                        const int g1 = C.trackSpan[ref.x], g2 = C.trackSpan[A.N + ref.x];
-                        if (g1 >= 0 && g1 <= ref.y && g2 == A.curFrame) {   // the same track, alive in this frame, no longer the point's
-                            ref.x = -1, ++cnt[4];
+            // four cameras at a time: their references, then the track spans those name, are requested together (a point's eight cameras one
+            // after the other were sixteen dependent memory round trips under the tracker's load: most of this kernel's 15 us)
+            for (int c0 = 0; c0 < A.nCams; c0 += 4) {
+                int4 refs[4];
+                int sl[4], g1[4], g2[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = c0 + q < A.nCams ? c0 + q : A.nCams - 1;
+                    refs[q] = A.featRef[(size_t)m * A.nCams + c];
+                    sl[q] = pf[c];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = c0 + q < A.nCams ? c0 + q : A.nCams - 1;
+                    const int* span = A.cam[c].trackSpan;
+                    const bool on = sl[q] >= 0 && sl[q] < A.N;
+                    const int look = on ? sl[q] : ((refs[q].x >= 0 && refs[q].x < A.N) ? refs[q].x : 0);
+                    g1[q] = span[look], g2[q] = span[A.N + look];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = c0 + q;
+                    if (c >= A.nCams) break;
+                    const size_t e = (size_t)m * A.nCams + c;
+                    const int s = sl[q];
+                    int4 ref = refs[q];
+                    const cs_poseupdate_cam& C = A.cam[c];
+                    if (s < 0 || s >= A.N) {
+                        if (ref.x >= 0 && ref.x < A.N && ref.y == A.curFrame - 1 && g1[q] >= 0 && g1[q] <= ref.y && g2[q] == A.curFrame) {
+                            ref.x = -1, ++cnt[4];   // the same track, alive in this frame, no longer the point's: detached
                             A.featRef[e] = ref;
                         }
+                        aliveNow = aliveNow || (ref.x >= 0 && ref.y == A.curFrame);
+                        continue;
                     }
-                    aliveNow = aliveNow || (ref.x >= 0 && ref.y == A.curFrame);
-                    continue;
+                    const int f1 = g1[q];
+                    if (ref.x == s && f1 >= 0 && ref.y >= f1 && ref.y <= A.curFrame) {
+                        if (ref.y != A.curFrame) ++cnt[0];   // (a second call within the frame changes and counts nothing)
+                        ref.y = A.curFrame;
+                    } else if (ref.x >= 0 && ref.y < A.curFrame) {
+                        const int idx = atomicAdd(A.segCount + c, 1);
+                        ++cnt[2];
+                        if (idx < A.segCap)
+                            A.segPool[(size_t)c * A.segCap + idx] = ref;   // {slot, last = its frame, first, next = its segment}
+                        else
+                            ++cnt[3];
+                        ref = make_int4(s, A.curFrame, A.curFrame, idx < A.segCap ? idx : -1);
+                    } else {
+                        ref = make_int4(s, A.curFrame, f1 >= 0 ? f1 : A.curFrame, -1), ++cnt[1];
+                    }
+                    A.featRef[e] = ref;
+                    if (A.refStatic) A.refStatic[e] = C.isStatic ? C.isStatic[s] : 1;
+                    aliveNow = true;
                 }
-                const int f1 = C.trackSpan[s];
-                if (ref.x == s && f1 >= 0 && ref.y >= f1 && ref.y <= A.curFrame) {
-                    if (ref.y != A.curFrame) ++cnt[0];   // (a second call within the frame changes and counts nothing)
-                    ref.y = A.curFrame;
-                } else if (ref.x >= 0 && ref.y < A.curFrame) {
-                    const int idx = atomicAdd(A.segCount + c, 1);
-                    ++cnt[2];
-                    if (idx < A.segCap)
-                        A.segPool[(size_t)c * A.segCap + idx] = ref;   // {slot, last = its frame, first, next = its segment}
-                    else
-                        ++cnt[3];
-                    ref = make_int4(s, A.curFrame, A.curFrame, idx < A.segCap ? idx : -1);
-                } else {
-                    ref = make_int4(s, A.curFrame, f1 >= 0 ? f1 : A.curFrame, -1), ++cnt[1];
-                }
-                A.featRef[e] = ref;
-                if (A.refStatic) A.refStatic[e] = C.isStatic ? C.isStatic[s] : 1;
-                aliveNow = true;
             }
             A.alive[m] = aliveNow ? 1 : 0;
         }
     }
-    if (A.counts) {   // one atomic per wave and counter (15 000 "tracked on" per frame on one address would cost more than the kernel)
-        const int lane = threadIdx.x & 63;
+    if (A.counts) {   // one atomic per WORKGROUP and counter: atomics on one address serialise (360 waves' worth were most of this kernel's time)
+        __shared__ int sCnt[4][5];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             int v = cnt[k];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (v && lane == 0) atomicAdd(A.counts + k, v);
+            if (lane == 0) sCnt[wv][k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 5) {
+            const int v = (sCnt[0][threadIdx.x] + sCnt[1][threadIdx.x]) + (sCnt[2][threadIdx.x] + sCnt[3][threadIdx.x]);
+            if (v) atomicAdd(A.counts + threadIdx.x, v);
         }
     }
 }
