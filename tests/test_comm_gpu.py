@@ -185,3 +185,59 @@ def test_two_rank_rccl_exchange_and_sliced_ba(hip, tmp_path):
     mp.spawn(_rccl_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert bool(np.load(tmp_path / f"ok{r}.npy")[0]), f"rank {r}"
+
+
+def _host_transport_worker(rank, world, name, out_dir):
+    """One rank of the TEST transport (cs_comm_create_host): the same entry points as the RCCL ones, both ranks on device 0."""
+    import ctypes as C
+
+    import torch
+
+    L = coslam_amd.lib()
+    L.cs_comm_create_host.restype = C.c_void_p
+    L.cs_comm_create_host.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+    L.cs_comm_destroy.argtypes = [C.c_void_p]
+    L.cs_comm_world.argtypes = [C.c_void_p]
+    L.cs_comm_rank.argtypes = [C.c_void_p]
+    L.cs_comm_allgather_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.cs_comm_broadcast_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    dev = torch.device("cuda:0")
+    c = L.cs_comm_create_host(name.encode(), world, rank, 0)
+    ok = bool(c) and L.cs_comm_world(c) == world and L.cs_comm_rank(c) == rank
+    s = torch.cuda.Stream(dev)
+    n = 100003  # not a multiple of anything the staging might assume
+    for rnd in range(3):  # the segment is reused: a round must not see the previous one's bytes
+        mine = (torch.arange(n, dtype=torch.int32, device=dev) * (rank + 1) + rnd * 7919)
+        recv = torch.zeros(world * n, dtype=torch.int32, device=dev)
+        ok = ok and L.cs_comm_allgather_dev(c, C.c_void_p(s.cuda_stream), C.c_void_p(mine.data_ptr()), C.c_void_p(recv.data_ptr()), n * 4) == 0
+        torch.cuda.synchronize()
+        want = torch.cat([torch.arange(n, dtype=torch.int32, device=dev) * (r + 1) + rnd * 7919 for r in range(world)])
+        ok = ok and torch.equal(recv, want)
+        # in place, the way the loop gathers the NCC blocks: the rank's own part already sits at rank * bytes of the receive buffer
+        inpl = torch.full((world * n,), -1, dtype=torch.int32, device=dev)
+        inpl[rank * n: (rank + 1) * n] = mine
+        own = inpl[rank * n:]
+        ok = ok and L.cs_comm_allgather_dev(c, C.c_void_p(s.cuda_stream), C.c_void_p(own.data_ptr()), C.c_void_p(inpl.data_ptr()), n * 4) == 0
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(inpl, want)
+        for root in range(world):
+            buf = torch.arange(445 * 1024, dtype=torch.int32, device=dev) + (1000 * (rank + 1) + rnd)
+            ok = ok and L.cs_comm_broadcast_dev(c, C.c_void_p(s.cuda_stream), C.c_void_p(buf.data_ptr()), buf.numel() * 4, root) == 0
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(buf, torch.arange(445 * 1024, dtype=torch.int32, device=dev) + (1000 * (root + 1) + rnd))
+    if c:
+        L.cs_comm_destroy(c)
+    np.save(os.path.join(out_dir, f"host_ok{rank}.npy"), np.array([bool(ok)]))
+
+
+@pytest.mark.timeout(300)
+def test_host_test_transport_two_ranks_on_one_device(hip, tmp_path):
+    """cs_comm_create_host, the transport the one-GPU tests of the N > 1 frame loop ride on (tests/test_cxx_dropin_gpu.py, bench.py's
+    BENCH_FORCE_DEVICE hook): all-gather (separate and in-place receive), broadcast from either root, over three rounds of the same
+    segment -- every rank must end with exactly the bytes RCCL's calls would leave."""
+    import torch.multiprocessing as mp
+
+    name = f"/coslam_test_{os.getpid()}"
+    mp.spawn(_host_transport_worker, args=(2, name, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert bool(np.load(tmp_path / f"host_ok{r}.npy")[0]), f"rank {r}"
