@@ -292,6 +292,19 @@ class BAOutput:
                                                  C.c_double(pixelErrVar), int(first_key_frame), int(key_every), vp(d_Rcur), vp(d_tcur),
                                                  vp(d_counts)), "cs_ba_output_apply_seq_dev")
 
+    def apply_frames_dev(self, d_record, stream_ptr, history, window, pu_cams, d_pointFeat, n_map, d_mapPts, d_mapCov, d_mapFlags,
+                         pixelErrVar, key_frames, d_Rcur, d_tcur, d_counts=0, seq=-1):
+        """apply_dev for key frames that are not equally spaced (the reference's fall where genNewMapPoints' decision puts them,
+        SL_CoSLAM.cpp:1294-1346): key_frames = the window's frame numbers, ascending; with seq >= 0 every one of them is compared
+        with the record's header."""
+        vp = C.c_void_p
+        kf = (C.c_int * len(key_frames))(*[int(f) for f in key_frames])
+        check(self._L.cs_ba_output_apply_frames_dev(self._h, vp(d_record), C.c_longlong(int(seq)), vp(stream_ptr), vp(history._h),
+                                                    window._h if window is not None else None,
+                                                    pu_cams, vp(d_pointFeat), int(n_map), vp(d_mapPts), vp(d_mapCov), vp(d_mapFlags),
+                                                    C.c_double(pixelErrVar), kf, len(key_frames), vp(d_Rcur), vp(d_tcur),
+                                                    vp(d_counts)), "cs_ba_output_apply_frames_dev")
+
     def set_feat_refs(self, d_featRef, d_refStatic=None):
         """updateNewPosesPoints of every later apply over feature references (cs_feat_ref_advance_dev's table; None: this frame's features)"""
         check(self._L.cs_ba_output_set_feat_refs(self._h, C.c_void_p(d_featRef),

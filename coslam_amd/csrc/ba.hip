@@ -2928,7 +2928,7 @@ struct cs_ba_output {
     long long packed;     // records complete on the device (the worker has synchronised with the pack)
     // the applying side's scratch (cs_ba_output_apply_dev: one caller thread): camera graphs of nCams chains of graphNodes nodes
     cs_posegraph* graph;
-    int graphNodes, graphKeyEvery, maxNodes;
+    int graphNodes, graphKeyNode[16], maxNodes;   // graphKeyNode[j]: key frame j's node in a chain (its frame number - the first key frame's)
     double *nodeR, *nodeT, *newR, *newT, *edgeR, *edgeT;
     unsigned char* scratch;
 };
@@ -4307,7 +4307,8 @@ cs_ba_output* cs_ba_output_create(int device, int nCams, int nKeyFrames, int nMa
     o->device = device, o->nCams = nCams, o->nKf = nKeyFrames, o->nMap = nMapPts, o->nSlots = nSlots;
     o->L = bo_layout(nCams * nKeyFrames, nMapPts);
     o->issued = o->packed = 0;
-    o->graph = nullptr, o->graphNodes = o->graphKeyEvery = o->maxNodes = 0;
+    o->graph = nullptr, o->graphNodes = o->maxNodes = 0;
+    for (int j = 0; j < 16; ++j) o->graphKeyNode[j] = -1;
     o->nodeR = o->nodeT = o->newR = o->newT = o->edgeR = o->edgeT = nullptr;
     o->scratch = nullptr, o->slab = nullptr, o->d_err = nullptr;
     if (hipMalloc((void**)&o->slab, o->L.bytes * nSlots) != hipSuccess || hipMalloc((void**)&o->d_err, 2 * sizeof(int)) != hipSuccess) {
@@ -4432,8 +4433,10 @@ int cs_ba_output_arrays(cs_ba_output* o, const void* d_record, const double** d_
     return CS_OK;
 }
 
-static int bo_ensure_graph(cs_ba_output* o, int nNodes, int keyEvery) {
-    if (o->graph && o->graphNodes == nNodes && o->graphKeyEvery == keyEvery) return CS_OK;
+static int bo_ensure_graph(cs_ba_output* o, int nNodes, const int* keyNode) {
+    bool same = o->graph && o->graphNodes == nNodes;
+    for (int j = 0; same && j < o->nKf; ++j) same = o->graphKeyNode[j] == keyNode[j];
+    if (same) return CS_OK;
     if (o->graph) cs_posegraph_destroy(o->graph);
     o->graph = nullptr;
     if (nNodes > o->maxNodes) {
@@ -4458,14 +4461,15 @@ static int bo_ensure_graph(cs_ba_output* o, int nNodes, int keyEvery) {
     for (int c = 0; c <= o->nCams; ++c) nodePtr[c] = c * nNodes, edgePtr[c] = c * (nNodes - 1);
     for (int c = 0; c < o->nCams; ++c) {
         for (int j = 0; j < o->nKf; ++j)
-            if (j * keyEvery < nNodes) fixed[(size_t)c * nNodes + j * keyEvery] = 1;
+            if (keyNode[j] < nNodes) fixed[(size_t)c * nNodes + keyNode[j]] = 1;
         for (int i = 0; i + 1 < nNodes; ++i) id1.push_back(i), id2.push_back(i + 1);
     }
     static const int none = 0;
     const int rc = cs_posegraph_create(o->device, o->nCams, nodePtr.data(), edgePtr.data(), fixed.data(), id1.empty() ? &none : id1.data(),
                                        id2.empty() ? &none : id2.data(), &o->graph);
     if (rc != CS_OK) return rc;
-    o->graphNodes = nNodes, o->graphKeyEvery = keyEvery;
+    o->graphNodes = nNodes;
+    for (int j = 0; j < o->nKf; ++j) o->graphKeyNode[j] = keyNode[j];
     return CS_OK;
 }
 
@@ -4478,7 +4482,8 @@ static int bo_ensure_graph(cs_ba_output* o, int nNodes, int keyEvery) {
 //   poses the next frame's pose solve starts from),
 //   updateNewPosesPoints over the live map (cs_update_new_poses_points_dev).
 // The key frames of the record must be firstKeyFrame + j * keyEvery, j < nKeyFrames (the caller knows its own schedule; the
-// record's header is not read back).  A record whose solve failed (ok = 0) moves nothing but still relaxes (a no-op up to rounding).
+// record's header is not read back) -- or, cs_ba_output_apply_frames_dev, ANY ascending list of frames: the reference's key frames
+// fall where CoSLAM::genNewMapPoints' decision puts them (cs_keyframe_ready_dev), not on a fixed cadence.  A record whose solve failed (ok = 0) moves nothing but still relaxes (a no-op up to rounding).
 // d_counts [3] or NULL: static / dynamic points re-triangulated, points that became false.
 // updateNewPosesPoints of every later apply over feature references (cs_feat_ref_advance_dev keeps the table; NULL: this frame's features)
 int cs_ba_output_set_feat_refs(cs_ba_output* o, const void* d_featRef, const unsigned char* d_refStatic) {
@@ -4503,27 +4508,54 @@ int cs_ba_output_apply_seq_dev(cs_ba_output* o, const void* d_record, long long 
                                const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap, double* d_mapPts, double* d_mapCov,
                                unsigned char* d_mapFlags, double pixelErrVar, int firstKeyFrame, int keyEvery, double* d_Rcur,
                                double* d_tcur, int* d_counts) {
-    if (!o || !d_record || !h || !cams || !d_pointFeat || nMap != o->nMap || !d_mapPts || !d_mapCov || !d_mapFlags || keyEvery < 1 ||
-        !d_Rcur || !d_tcur || cs_track_history_cams(h) != o->nCams || (w && (w->nCams != o->nCams || w->device != o->device))) {
+    if (!o || keyEvery < 1) {
         cs_set_error("cs_ba_output_apply_dev: bad arguments");
         return CS_ERR_INVALID;
     }
+    int frames[16];
+    for (int j = 0; j < 16; ++j) frames[j] = firstKeyFrame + j * keyEvery;
+    return cs_ba_output_apply_frames_dev(o, d_record, seq, hip_stream, h, w, cams, d_pointFeat, nMap, d_mapPts, d_mapCov, d_mapFlags, pixelErrVar,
+                                         frames, o->nKf, d_Rcur, d_tcur, d_counts);
+}
+// ... and with the window's key frames as a list (keyFrames: HOST array of nKeyFrames = the output's key-frame count, strictly ascending):
+// node keyFrames[j] - keyFrames[0] of every camera's chain is fixed at the record's pose j, the frames between and behind them relax.
+// The camera graphs are rebuilt (host side: cs_posegraph_create) whenever the spacing or the span differs from the previous apply's.
+int cs_ba_output_apply_frames_dev(cs_ba_output* o, const void* d_record, long long seq, void* hip_stream, cs_track_history* h, cs_ba_window* w,
+                                  const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap, double* d_mapPts, double* d_mapCov,
+                                  unsigned char* d_mapFlags, double pixelErrVar, const int* keyFrames, int nKeyFrames, double* d_Rcur,
+                                  double* d_tcur, int* d_counts) {
+    if (!o || !d_record || !h || !cams || !d_pointFeat || nMap != o->nMap || !d_mapPts || !d_mapCov || !d_mapFlags || !keyFrames ||
+        nKeyFrames != o->nKf || !d_Rcur || !d_tcur || cs_track_history_cams(h) != o->nCams ||
+        (w && (w->nCams != o->nCams || w->device != o->device))) {
+        cs_set_error("cs_ba_output_apply_dev: bad arguments (the key frames: a host list of the output's %d)", o ? o->nKf : 0);
+        return CS_ERR_INVALID;
+    }
+    int keyNode[16];
+    for (int j = 0; j < o->nKf; ++j) {
+        keyNode[j] = keyFrames[j] - keyFrames[0];
+        if (j && keyFrames[j] <= keyFrames[j - 1]) {
+            cs_set_error("cs_ba_output_apply_dev: key frames must ascend (%d after %d)", keyFrames[j], keyFrames[j - 1]);
+            return CS_ERR_INVALID;
+        }
+    }
+    const int firstKeyFrame = keyFrames[0];
     const int newest = cs_track_history_newest_frame(h), nNodes = newest - firstKeyFrame + 1;
-    if (nNodes < (o->nKf - 1) * keyEvery + 1) {
+    if (nNodes < keyNode[o->nKf - 1] + 1) {
         cs_set_error("cs_ba_output_apply_dev: the history's newest frame %d lies before the window's last key frame %d", newest,
-                     firstKeyFrame + (o->nKf - 1) * keyEvery);
+                     keyFrames[o->nKf - 1]);
         return CS_ERR_INVALID;
     }
     CS_HIP(hipSetDevice(o->device));
-    int rc = bo_ensure_graph(o, nNodes, keyEvery);
+    int rc = bo_ensure_graph(o, nNodes, keyNode);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)hip_stream;
     if ((rc = cs_track_history_get_span_dev(h, hip_stream, firstKeyFrame, nNodes, o->nodeR, o->nodeT))) return rc;
     if (nNodes > 1 && (rc = cs_posegraph_edges_dev(o->graph, hip_stream, o->nodeR, o->nodeT, o->edgeR, o->edgeT))) return rc;
     BoPosesArgs A;
     memset(&A, 0, sizeof(A));
-    A.nKf = o->nKf, A.nCams = o->nCams, A.nNodes = nNodes, A.keyEvery = keyEvery;
-    A.seq = (int)seq, A.firstKeyFrame = firstKeyFrame;
+    A.nKf = o->nKf, A.nCams = o->nCams, A.nNodes = nNodes;
+    A.win.seq = (int)seq, A.win.nKf = o->nKf;
+    for (int j = 0; j < 16; ++j) A.win.kf[j] = j < o->nKf ? keyFrames[j] : -1, A.nodeOf[j] = j < o->nKf ? keyNode[j] : 0;
     A.nodeR = o->nodeR, A.nodeT = o->nodeT;
     for (int j = 0; j < 16; ++j) A.slotOf[j] = -1;
     if (w) {
@@ -4531,11 +4563,11 @@ int cs_ba_output_apply_seq_dev(cs_ba_output* o, const void* d_record, long long 
         for (int j = 0; j < o->nKf; ++j)
             for (int k = 0; k < w->count; ++k) {
                 const int slot = (w->head - 1 - k + 2 * w->ring) % w->ring;
-                if (w->frameOf[slot] == firstKeyFrame + j * keyEvery) A.slotOf[j] = slot;
+                if (w->frameOf[slot] == keyFrames[j]) A.slotOf[j] = slot;
             }
     }
     const int mask = o->applyMask;
-    if (seq >= 0) hipLaunchKernelGGL(k_ba_output_check, dim3(1), dim3(1), 0, s, (const int*)d_record, (int)seq, firstKeyFrame, o->d_err);
+    if (seq >= 0) hipLaunchKernelGGL(k_ba_output_check, dim3(1), dim3(1), 0, s, (const int*)d_record, A.win, o->d_err);
     if (mask & CS_BA_APPLY_POSES)
         hipLaunchKernelGGL(k_ba_output_poses, dim3((o->nKf * o->nCams * 12 + 255) / 256), dim3(256), 0, s, (const unsigned char*)d_record, o->L, A);
     {
@@ -4546,7 +4578,7 @@ int cs_ba_output_apply_seq_dev(cs_ba_output* o, const void* d_record, long long 
     }
     if (mask & (CS_BA_APPLY_POINTS | CS_BA_APPLY_FALSE))
         hipLaunchKernelGGL(k_ba_output_points, dim3((o->L.maxP + 255) / 256), dim3(256), 0, s, (const unsigned char*)d_record, o->L, nMap, d_mapPts,
-                           d_mapFlags, d_counts ? d_counts + 2 : nullptr, (int)seq, firstKeyFrame, (mask & CS_BA_APPLY_POINTS) ? 1 : 0,
+                           d_mapFlags, d_counts ? d_counts + 2 : nullptr, A.win, (mask & CS_BA_APPLY_POINTS) ? 1 : 0,
                            (mask & CS_BA_APPLY_FALSE) ? 1 : 0);
     CS_CHECK_LAUNCH();
     if (nNodes > 1) {

@@ -100,24 +100,33 @@ __global__ void k_ba_output_wait(const int* hdr, int seq, long long maxTicks, in
 // the points of a record into the map (SL_CoSLAMRobustBA.cpp:297-309): M <- pt3Ds[i]; any outlier measurement: setFalse
 // (MapPoint::setFalse keeps bUncertain and leaves TYPE_MAP_FALSE: CS_MAP_DYNAMIC cleared, as cs_map_points_classify_dev does)
 // Is the record the one the caller means to apply?  seq >= 0: its sequence number (hdr[5]) and its release word (hdr[7], stored
-// behind the pack) must say so, and its first key frame (hdr[8]) must be the window's.  A wait that gave up (k_ba_output_wait's
+// behind the pack) must say so, and its key frames (hdr[8 + j]) must be the window's.  A wait that gave up (k_ba_output_wait's
 // timeout) leaves a slot holding the record of nSlots solves ago -- complete, ok = 1, but of ANOTHER window: it applies nothing.
-__device__ __forceinline__ bool bo_record_is(const int* hdr, int seq, int firstKeyFrame) {
+// (the window being applied: its request number and ALL of its key frames' numbers, hdr[8 + j] -- they need not be equally spaced)
+struct BoWin {
+    int seq, nKf;
+    int kf[16];
+};
+__device__ __forceinline__ bool bo_record_is(const int* hdr, const BoWin& W) {
     if (!hdr[6]) return false;
-    if (seq < 0) return true;
-    return hdr[5] == seq && hdr[7] == seq + 1 && hdr[8] == firstKeyFrame;
+    if (W.seq < 0) return true;
+    if (hdr[5] != W.seq || hdr[7] != W.seq + 1) return false;
+    bool same = true;
+    for (int j = 0; j < 16; ++j)   // (a window requested before its ring had filled holds hdr[3] < nKf key frames: those it has must agree)
+        if (j < W.nKf && j < hdr[3] && hdr[8 + j] != W.kf[j]) same = false;
+    return same;
 }
 // one thread: counts a record that was refused although it claims to hold a result (err[1]; err[0] counts the waits that gave up)
-__global__ void k_ba_output_check(const int* hdr, int seq, int firstKeyFrame, int* err) {
-    if (hdr[6] && !bo_record_is(hdr, seq, firstKeyFrame)) atomicAdd(err + 1, 1);
+__global__ void k_ba_output_check(const int* hdr, BoWin W, int* err) {
+    if (hdr[6] && !bo_record_is(hdr, W)) atomicAdd(err + 1, 1);
 }
 
 __global__ __launch_bounds__(256) void k_ba_output_points(const unsigned char* __restrict__ rec, BoLayout L, int nMap, double* __restrict__ mapPts,
-                                                          unsigned char* __restrict__ mapFlags, int* __restrict__ counts, int seq,
-                                                          int firstKeyFrame, int writePts, int writeFalse) {
+                                                          unsigned char* __restrict__ mapFlags, int* __restrict__ counts, BoWin W,
+                                                          int writePts, int writeFalse) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int* hdr = (const int*)rec;
-    if (!bo_record_is(hdr, seq, firstKeyFrame) || i >= hdr[1]) return;
+    if (!bo_record_is(hdr, W) || i >= hdr[1]) return;
     const int m = ((const int*)(rec + L.offMap))[i];
     if (m < 0 || m >= nMap) return;
     const double* p = (const double*)(rec + L.offPts) + 3 * (size_t)i;
@@ -130,21 +139,21 @@ __global__ __launch_bounds__(256) void k_ba_output_points(const unsigned char* _
 }
 
 // the record's key poses into (a) the fixed nodes of the camera graphs' node arrays ([nCams][nNodes]: node of key frame j of
-// camera c = c * nNodes + j * keyEvery) and (b) the window ring's copies of those key frames (slotOf[j] < 0: the ring no longer
+// camera c = c * nNodes + nodeOf[j], nodeOf[j] = the key frame's number - the first key frame's) and (b) the window ring's copies of those key frames (slotOf[j] < 0: the ring no longer
 // holds it), so that the next window's parse starts from the adjusted key poses the way the reference's shared CamPoseItems do
 struct BoPosesArgs {
-    int nKf, nCams, nNodes, keyEvery;
-    int seq, firstKeyFrame;   // bo_record_is
-    int slotOf[16];
+    int nKf, nCams, nNodes;
+    BoWin win;   // bo_record_is
+    int nodeOf[16], slotOf[16];
     double *nodeR, *nodeT, *winR, *winT;
 };
 __global__ __launch_bounds__(256) void k_ba_output_poses(const unsigned char* __restrict__ rec, BoLayout L, BoPosesArgs A) {
     const int q = blockIdx.x * 256 + threadIdx.x, i = q / 12, e = q - 12 * i;
     const int* hdr = (const int*)rec;
-    if (!bo_record_is(hdr, A.seq, A.firstKeyFrame) || i >= A.nKf * A.nCams || i >= hdr[0]) return;
+    if (!bo_record_is(hdr, A.win) || i >= A.nKf * A.nCams || i >= hdr[0]) return;
     const int j = i / A.nCams, c = i - j * A.nCams;
     const double v = e < 9 ? ((const double*)(rec + L.offRs))[9 * (size_t)i + e] : ((const double*)(rec + L.offTs))[3 * (size_t)i + (e - 9)];
-    const size_t node = (size_t)c * A.nNodes + (size_t)j * A.keyEvery;
+    const size_t node = (size_t)c * A.nNodes + (size_t)A.nodeOf[j];
     if (e < 9)
         A.nodeR[9 * node + e] = v;
     else

@@ -1032,13 +1032,24 @@ int cs_ba_output_apply_dev(cs_ba_output* o, const void* d_record, void* hip_stre
                            unsigned char* d_mapFlags, double pixelErrVar, int firstKeyFrame, int keyEvery, double* d_Rcur, double* d_tcur,
                            int* d_counts);
 /* The same with the record's sequence number stated (the number cs_ba_output_wait / _wait_dev was asked for on the rank that solved
- * the window; -1: unchecked = cs_ba_output_apply_dev): the kernels compare it -- and firstKeyFrame -- with the record's header and
+ * the window; -1: unchecked = cs_ba_output_apply_dev): the kernels compare it -- and the key frames' numbers -- with the record's header and
  * move NOTHING when the slot holds another window's record (a device-side wait that gave up leaves the record of nSlots solves
  * ago in place); such a refusal is counted in cs_ba_output_wait_errors. */
 int cs_ba_output_apply_seq_dev(cs_ba_output* o, const void* d_record, long long seq, void* hip_stream, cs_track_history* h, cs_ba_window* w,
                                const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap, double* d_mapPts, double* d_mapCov,
                                unsigned char* d_mapFlags, double pixelErrVar, int firstKeyFrame, int keyEvery, double* d_Rcur,
                                double* d_tcur, int* d_counts);
+/* The same for key frames that are NOT equally spaced -- the reference's fall where CoSLAM::genNewMapPoints' decision puts them
+ * (src/app/SL_CoSLAM.cpp:1294-1346; cs_keyframe_ready_dev), and constructCameraGraphs fixes whichever frames the window's key poses
+ * belong to (src/app/SL_CoSLAMRobustBA.cpp:182-229).  keyFrames: HOST array of nKeyFrames (= the output's key-frame count) frame
+ * numbers, strictly ascending; node keyFrames[j] - keyFrames[0] of every camera's chain takes the record's pose j.  With seq >= 0 the
+ * kernels compare EVERY key frame's number with the record's header (hdr[8 + j]).  The camera graphs are rebuilt on the host whenever
+ * the spacing or the span differs from the previous apply's (cs_ba_output_apply_dev / _seq_dev are this call on
+ * firstKeyFrame + j * keyEvery). */
+int cs_ba_output_apply_frames_dev(cs_ba_output* o, const void* d_record, long long seq, void* hip_stream, cs_track_history* h, cs_ba_window* w,
+                                  const cs_poseupdate_cam* cams, const int* d_pointFeat, int nMap, double* d_mapPts, double* d_mapCov,
+                                  unsigned char* d_mapFlags, double pixelErrVar, const int* keyFrames, int nKeyFrames, double* d_Rcur,
+                                  double* d_tcur, int* d_counts);
 /* RobustBundleRTS::updateNewPosesPoints of every later apply over feature references (d_featRef [nMap][nCams] cs_feat_ref kept by
  * cs_feat_ref_advance_dev, d_refStatic [nMap][nCams] or NULL): stale features are views, the walks follow re-linked chains and
  * `mpt->lastFrame <= firstKeyFrame->f` (src/app/SL_CoSLAMRobustBA.cpp:250) is judged from the references' frames.  NULL: back to d_pointFeat. */

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 SIGMA, MAX_EPI = 10.0, 6.0
 
 
-def _drive(T=27, first_key=2, key_every=5, n_kf=5, hist=40, seed=31, lag_frames=None):
+def _drive(T=27, first_key=2, key_every=5, n_kf=5, hist=40, seed=31, lag_frames=None, key_frames_at=None):
     import torch
 
     import coslam_amd
@@ -54,7 +54,8 @@ def _drive(T=27, first_key=2, key_every=5, n_kf=5, hist=40, seed=31, lag_frames=
         d_R, d_t = torch.from_numpy(Rs).to(dev), torch.from_numpy(ts).to(dev)
         keep += [d_R, d_t]
         th.detect_dynamic_dev(s, cams, d_R.data_ptr(), d_t.data_ptr(), nMap, d_fl.data_ptr(), f, maxEpiErr=MAX_EPI)
-        if f >= first_key and (f - first_key) % key_every == 0 and len(key_frames) < n_kf:
+        is_key = f in key_frames_at if key_frames_at is not None else (f >= first_key and (f - first_key) % key_every == 0)
+        if is_key and len(key_frames) < n_kf:
             win.push_dev(s, handback_cams(hb), d_K.data_ptr(), 1, d_R.data_ptr(), d_t.data_ptr(), f)
             key_frames.append(f)
             kf_recs.append(recs)
@@ -96,18 +97,22 @@ def test_the_worker_packs_every_window_solve_into_a_record(hip):
     assert np.array_equal(g(pOut, Pw, "|u1"), want) and want.sum() > 0
 
 
-def test_apply_writes_poses_points_and_flags_back_and_relaxes_the_non_key_frames(hip):
+@pytest.mark.parametrize("kf_at", [None, [2, 5, 11, 14, 22], [3, 4, 5, 19, 26]])
+def test_apply_writes_poses_points_and_flags_back_and_relaxes_the_non_key_frames(hip, kf_at):
+    """kf_at: key frames where a decision put them (cs_ba_output_apply_frames_dev; the last case: neighbouring key frames, and the
+    newest frame itself a key frame -- no free tail) instead of the fixed cadence."""
     import torch
 
     import oracle
     from coslam_amd.multicam import _DevArray
     from coslam_amd.poseupdate import poseupdate_cams
 
-    D = _drive()
+    D = _drive(key_frames_at=kf_at)
     sc, th, ws, out, win, s, dev = D["sc"], D["th"], D["ws"], D["out"], D["win"], D["s"], D["dev"]
     nC, N, nMap, T = sc.nC, sc.N, sc.nMap, sc.T
     rec = out.wait(0)
     Cw, Pw, Ow, d_pm, kfs = win.last_problem()
+    assert kf_at is None or kfs == kf_at
     ws.set_sizes(Cw, Pw, Ow)
     Rs, Ts, pts, outl, _ = ws.download()
     g = lambda p, n, ty: torch.as_tensor(_DevArray(p, n, ty), device=dev).cpu().numpy()   # noqa: E731
@@ -122,8 +127,13 @@ def test_apply_writes_poses_points_and_flags_back_and_relaxes_the_non_key_frames
     d_tc = torch.from_numpy(D["ts_last"].copy()).to(dev)
     d_cnt = torch.zeros(3, dtype=torch.int32, device=dev)
     M0, cov0, fl0 = D["d_map"].cpu().numpy().copy(), D["d_cov"].cpu().numpy().copy(), D["d_fl"].cpu().numpy().copy()
-    out.apply_dev(rec, s, th, win, poseupdate_cams(D["cams"]), d_pf.data_ptr(), nMap, D["d_map"].data_ptr(), D["d_cov"].data_ptr(),
-                  D["d_fl"].data_ptr(), SIGMA, first_key, key_every, d_Rc.data_ptr(), d_tc.data_ptr(), d_cnt.data_ptr())
+    if kf_at is None:
+        out.apply_dev(rec, s, th, win, poseupdate_cams(D["cams"]), d_pf.data_ptr(), nMap, D["d_map"].data_ptr(), D["d_cov"].data_ptr(),
+                      D["d_fl"].data_ptr(), SIGMA, first_key, key_every, d_Rc.data_ptr(), d_tc.data_ptr(), d_cnt.data_ptr())
+    else:   # with the sequence number stated: every key frame's number is held against the record's header
+        out.apply_frames_dev(rec, s, th, win, poseupdate_cams(D["cams"]), d_pf.data_ptr(), nMap, D["d_map"].data_ptr(), D["d_cov"].data_ptr(),
+                             D["d_fl"].data_ptr(), SIGMA, kfs, d_Rc.data_ptr(), d_tc.data_ptr(), d_cnt.data_ptr(), seq=0)
+    node_of = [f - first_key for f in kfs]
     d_nR = torch.zeros((nC, nN, 9), dtype=torch.float64, device=dev)
     d_nT = torch.zeros((nC, nN, 3), dtype=torch.float64, device=dev)
     th.get_span_dev(s, first_key, nN, d_nR.data_ptr(), d_nT.data_ptr())
@@ -132,23 +142,24 @@ def test_apply_writes_poses_points_and_flags_back_and_relaxes_the_non_key_frames
     # --- the camera chains: edges from the poses as tracked, the key frames fixed at the adjusted poses, the rest relaxed
     id1, id2 = np.arange(nN - 1), np.arange(1, nN)
     fixed = np.zeros(nN, dtype=np.uint8)
-    fixed[[j * key_every for j in range(n_kf)]] = 1
+    fixed[node_of] = 1
     moved = 0.0
     for c in range(nC):
         R0 = np.stack([D["hR"][c][newest - f] for f in range(first_key, newest + 1)])
         t0 = np.stack([D["hT"][c][newest - f] for f in range(first_key, newest + 1)])
         eR, eT = oracle.posegraph_edges(R0, t0, id1, id2)
         for j in range(n_kf):
-            R0[j * key_every], t0[j * key_every] = Rs[j * nC + c].reshape(9), Ts[j * nC + c]
+            R0[node_of[j]], t0[node_of[j]] = Rs[j * nC + c].reshape(9), Ts[j * nC + c]
         rc, wR, wT = oracle.posegraph_relax(fixed, R0, t0, id1, id2, eR, eT)
         assert rc == 0
         assert np.abs(nR[c] - wR).max() < 1e-9 and np.abs(nT[c] - wT).max() < 1e-9, (c, np.abs(nR[c] - wR).max(), np.abs(nT[c] - wT).max())
         for j in range(n_kf):   # the adjusted key poses themselves: copied, bit for bit
-            assert np.array_equal(nR[c, j * key_every], Rs[j * nC + c].reshape(9)) and np.array_equal(nT[c, j * key_every], Ts[j * nC + c])
+            assert np.array_equal(nR[c, node_of[j]], Rs[j * nC + c].reshape(9)) and np.array_equal(nT[c, node_of[j]], Ts[j * nC + c])
         moved = max(moved, np.abs(nT[c, -1] - D["hT"][c][0]).max())
         # the newest relaxed pose is the camera's current pose
         assert np.array_equal(d_Rc.cpu().numpy()[c], nR[c, -1]) and np.array_equal(d_tc.cpu().numpy()[c], nT[c, -1])
-    assert moved > 1e-6, "the free tail of the chains followed the last key frame"
+    assert moved > 1e-6, "the free tail of the chains followed the last key frame (or IS the last key frame)"
+    assert out.wait_errors() == 0
     # --- the window's ring holds the adjusted key poses now: a second request parses them as its start
     # --- the map: adjusted points, outlier points false, then updateNewPosesPoints with the relaxed history
     M, cov, fl = M0.copy(), cov0.copy(), fl0.copy()
