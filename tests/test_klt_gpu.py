@@ -687,14 +687,14 @@ def test_cu_masked_stream_and_budget(hip):
     lib.cs_stream_destroy(C.c_void_p(h))
 
 
-@pytest.mark.parametrize("n_cams,prefetch", [(8, True), (3, False), (13, True), (4, False)])
+@pytest.mark.parametrize("n_cams,prefetch", [(8, True), (3, False), (13, True), (4, False), (2, True), (1, False)])
 def test_camera_group_is_bit_identical_to_single_handles(hip, n_cams, prefetch):
     """cs_klt_group_*: the frame schedule of several cameras in ONE set of launches (camera = one more grid dimension, the
     gain tracker of all cameras in one persistent launch) must give exactly what driving each handle on its own gives:
     detect, redetect and track-only frames, with and without the frame-front prefetch, dest[] / counts / feature lists.
     13 cameras (SLAM_MAX_NUM) x 2000 slots exceed the resident waves of one persistent launch -> two launches in a row.
     cs_klt_set_xcd_placement (a camera's workgroups numbered onto its own XCDs: 8 cameras one XCD each, 4 cameras two each, 13 = 8
-    placed + 5 as grid rows, 3 not placed at all) changes where workgroups run and nothing else: the same bits."""
+    placed + 5 as grid rows, 3 not placed at all; 2 and 1 -- a rank's share of 8 cameras on 4 and 8 GPUs -- four and all eight XCDs each) changes where workgroups run and nothing else: the same bits."""
     import torch
 
     W, H, L, fw, fh = 640, 480, 4, 50, 40
