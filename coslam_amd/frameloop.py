@@ -60,8 +60,14 @@ class LoopConfig:
         # (cs_newpts_intracam_dev).  Implies keyframe_decision.  Off in the headline: ~50 new points per frame need a map that recycles its
         # points; with map_spare raised the loop runs on it for as long as the capacity lasts
         self.keyframe_decision = False   # CoSLAM::IsReadyForKeyFrame + addKeyFrame's key-pose state per frame on the device (cs_keyframe_ready_dev),
-        # REPORTED (FrameLoop.keyframe_stats); the key frames themselves stay on the fixed key_every cadence -- RobustBundleRTS::output()'s
-        # apply assumes equally spaced key frames (cs_ba_output_apply_dev), so the decision does not drive them yet
+        # REPORTED (FrameLoop.keyframe_stats); the key frames themselves stay on the fixed key_every cadence unless keyframe_drives
+        self.keyframe_drives = False     # the decision PLACES the key frames (genNewMapPoints :1331-1346: `decrease` -> addKeyFrame, requestForBA):
+        # step()'s key_frame argument is ignored, the host reads `decrease` back every frame (a wait per frame, as the reference's one
+        # thread has it), the windows' key frames fall where they fall and their results are applied through cs_ba_output_apply_frames_dev.
+        # A window whose first key frame has left the pose history (hist frames) by the time its result is due is not applied (counted:
+        # FrameLoop.keyframe_stats()["windows_not_applied_history_too_short"]).  One rank only.  Implies keyframe_decision.  Off in the headline:
+        # in the bench's world the decision never says `decrease` -- there would be no window bundle adjustment to measure
+        self.keyframe_ratio = 0.93       # m_mappedPtsReduceRatio (reference src/app/SL_CoSLAM.cpp:42)
         self.feature_chains = True   # MapPoint::pFeatures kept as feature references (cs_feat_ref): a camera that lost a point still contributes
         # its last feature to refineMapPoint / updateNewPosesPoints, and a point registered to a new track where it held an older feature has
         # the old chain linked behind it (reference src/app/SL_CoSLAM.cpp:775-779); False: the features of this frame on their own tracks
@@ -117,6 +123,8 @@ class FrameLoop:
         NA, N = cfg.n_cams, cfg.n_feat
         if NA % world:
             raise ValueError(f"{NA} cameras do not shard over {world} ranks")
+        if cfg.keyframe_drives and world > 1:
+            raise ValueError("LoopConfig.keyframe_drives: one rank only (the host reads the decision back every frame)")
         self.nc = nc = NA // world
         self.c0 = c0 = rank * nc
         self.my_cams = list(range(c0, c0 + nc))
@@ -299,7 +307,8 @@ class FrameLoop:
         if cfg.with_joint and self.pose_upd is not None:
             self.win = BAWindow(NA, cfg.n_key_frames, N, n_map, device=device)
             self.win.reserve(self.ba_ws)
-            self.out = BAOutput(NA, cfg.n_key_frames, n_map, n_slots=8, device=device)
+            # (records in flight: lag windows on the cadence; with the decision placing the key frames, up to one request per frame of the lag)
+            self.out = BAOutput(NA, cfg.n_key_frames, n_map, n_slots=8 if not cfg.keyframe_drives else self.lag * cfg.key_every + 6, device=device)
             self.out.attach(self.ba_ws)
             if self.d_fref is not None:
                 self.out.set_feat_refs(self.d_fref.data_ptr(), self.d_rstat.data_ptr())
@@ -326,7 +335,7 @@ class FrameLoop:
         self.skip_busy, self.n_skipped = False, 0   # (set by the caller: drop a window request while the previous solve is running)
         self.sequential_registration = bool(cfg.sequential_registration)   # (may be switched between frames)
         self.apply_at, self.my_seq = {}, {}
-        self.applied, self.last_apply = 0, None
+        self.applied, self.last_apply, self.pushed_frames = 0, None, []
         self.stage_slot, self.h_frames = {}, None
         import os as _os
 
@@ -483,7 +492,7 @@ class FrameLoop:
             self.pose_upd.detect_dynamic_dev(self.pose_s.cuda_stream, self.pu_args, self.d_R[0].data_ptr(), self.d_t[0].data_ptr(), self.n_map,
                                              self.d_mapflags.data_ptr(), 0, 20, 5, 3, MAX_EPI_ERR)
             torch.cuda.synchronize()
-        if cfg.keyframe_decision or cfg.intracam_mapping:
+        if cfg.keyframe_decision or cfg.intracam_mapping or cfg.keyframe_drives:
             self.enable_keyframe_decision(0, 0)
 
     def enable_keyframe_decision(self, frame, b):
@@ -501,7 +510,7 @@ class FrameLoop:
         km = [int((((st[g] == 0) | (st[g] == 1)) & (s2m[g] >= 0) & ((fl[np.clip(s2m[g], 0, len(fl) - 1)] & 7) == 0)).sum()) for g in range(NA)]
         self.kf = dict(frame=torch.full((NA,), int(frame), dtype=i32, device=self.dev), mapped=torch.tensor(km, dtype=i32, device=self.dev),
                        selfR=self.d_R[b].clone(), selfT=self.d_t[b].clone(), ready=z(NA + 2, i32), cnt=z(2 * NA, i32), cen=z((NA, 3), f64),
-                       stats=z(5, i32), frames=0)
+                       stats=z(5, i32), frames=0, placed=[], not_applied=0)
         Rn, tn = self.d_R[b].cpu().numpy().reshape(NA, 3, 3), self.d_t[b].cpu().numpy()
         cen = np.stack([-Rn[g].T @ tn[g] for g in range(NA)])
         dist = [np.linalg.norm(cen[a] - cen[c]) for a in range(NA) for c in range(a + 1, NA)]
@@ -520,7 +529,8 @@ class FrameLoop:
         im = None if "im_total" not in self.kf else dict(zip(("candidates_tried", "points_added", "points_dropped_map_full"), self.kf["im_total"].cpu().tolist()))
         return dict(frames=self.kf["frames"], intracam_new_map_points=im, frames_with_a_camera_ready=a[0], frames_with_decrease_ie_key_frames_added=a[1],
                     cameras_saying_decrease=a[2], cameras_saying_view_angle=a[3], cameras_saying_translation=a[4],
-                    min_cam_translation=self.kf["min_translation"], last_key_frame_per_camera=self.kf["frame"].cpu().tolist(),
+                    min_cam_translation=self.kf["min_translation"], key_frames_placed_by_the_decision=list(self.kf["placed"]),
+                    windows_not_applied_history_too_short=self.kf["not_applied"], last_key_frame_per_camera=self.kf["frame"].cpu().tolist(),
                     mapped_static_at_the_last_key_frame=self.kf["mapped"].cpu().tolist())
 
     def _handback(self, b, frame, which="all"):
@@ -540,6 +550,14 @@ class FrameLoop:
         if due is None:
             return
         k, owner, first_key, seq = due
+        frames = None
+        if isinstance(first_key, (list, tuple)):   # (key frames the decision placed: a list instead of first + j * key_every)
+            frames, first_key = list(first_key), first_key[0]
+            if (i - 1) - first_key + 1 > self.cfg.hist:
+                # the camera graphs would start behind the pose history's oldest frame: the record is consumed, nothing is written back
+                self.my_seq.pop(k, None)
+                self.kf["not_applied"] += 1
+                return
         if owner == self.rank:
             # the pose stream waits ON THE DEVICE for this rank's worker to publish the record: the host goes on enqueueing frames
             self.my_seq.pop(k)
@@ -548,9 +566,14 @@ class FrameLoop:
             rec = self.recv_rec[k & 1].data_ptr()
         if self.world > 1:
             self.xchg.broadcast(rec, self.out.record_bytes, owner, self.device, self.pose_s)
-        self.out.apply_dev(rec, self.pose_s.cuda_stream, self.pose_upd, self.win, self.pu_args, self.d_pf.data_ptr(), self.n_map,
-                           self.d_map.data_ptr(), self.d_cov.data_ptr(), self.d_mapflags.data_ptr(), self.sig_pix, first_key,
-                           self.cfg.key_every, self.d_R[src].data_ptr(), self.d_t[src].data_ptr(), self.d_apply_counts.data_ptr(), seq=seq)
+        if frames is not None:
+            self.out.apply_frames_dev(rec, self.pose_s.cuda_stream, self.pose_upd, self.win, self.pu_args, self.d_pf.data_ptr(), self.n_map,
+                                      self.d_map.data_ptr(), self.d_cov.data_ptr(), self.d_mapflags.data_ptr(), self.sig_pix, frames,
+                                      self.d_R[src].data_ptr(), self.d_t[src].data_ptr(), self.d_apply_counts.data_ptr(), seq=seq)
+        else:
+            self.out.apply_dev(rec, self.pose_s.cuda_stream, self.pose_upd, self.win, self.pu_args, self.d_pf.data_ptr(), self.n_map,
+                               self.d_map.data_ptr(), self.d_cov.data_ptr(), self.d_mapflags.data_ptr(), self.sig_pix, first_key,
+                               self.cfg.key_every, self.d_R[src].data_ptr(), self.d_t[src].data_ptr(), self.d_apply_counts.data_ptr(), seq=seq)
         self.applied += 1
         self.last_apply = dict(window=k, solved_by_rank=owner, first_key_frame=first_key, applied_at_frame=i)
 
@@ -627,9 +650,16 @@ class FrameLoop:
 
             k = self.kf
             keyframe_ready_dev(ps, k["cams"][dst], cfg.n_feat, self.n_map, self.d_map.data_ptr(), self.d_mapflags.data_ptr(), self.d_firstfrm.data_ptr(),
-                               i, k["min_translation"], k["ready"].data_ptr(), k["cnt"].data_ptr(), k["cen"].data_ptr(), addKeyFrame=True,
-                               d_stats=k["stats"].data_ptr(), device=self.device)
+                               i, k["min_translation"], k["ready"].data_ptr(), k["cnt"].data_ptr(), k["cen"].data_ptr(), ratio=cfg.keyframe_ratio,
+                               addKeyFrame=True, d_stats=k["stats"].data_ptr(), device=self.device)
             k["frames"] += 1
+            if cfg.keyframe_drives:
+                # `decrease` (ready[nCams + 1]) back to the host: the frame is a key frame for ALL cameras when one camera's mapped points
+                # have decreased (:1331-1346) -- the push and the request below follow the device's answer, not the caller's cadence
+                pose_s.synchronize()
+                key_frame = bool(int(k["ready"][NA_ + 1].item()))
+                if key_frame:
+                    k["placed"].append(i)
             if cfg.intracam_mapping and self.pose_upd is not None:
                 # ... and for the cameras that are ready (view angle / translation; with `decrease` the cameras that said so too: :1310-1346)
                 # SingleSLAM::newMapPoints: the unmapped features on tracks of nMinFeatTrkLen = 20 frames, each from its own track
@@ -822,6 +852,7 @@ class FrameLoop:
         with self._sec("kf_push"):
             self.win.push_dev(ps, self.hb_all, self.d_K1.data_ptr(), 1, self.d_R[dst].data_ptr(), self.d_t[dst].data_ptr(), i)
         self.n_pushed += 1
+        self.pushed_frames = (self.pushed_frames + [i])[-cfg.n_key_frames:]   # the ring's key frames, oldest first
         if self.n_pushed < cfg.n_key_frames:
             return
         if self.skip_busy:
@@ -843,7 +874,10 @@ class FrameLoop:
         # the record's sequence number ON ITS OWNER: windows go round the ranks, so it is the owner's (k // world)-th solve (one rank:
         # its own count, which the reference's request policy -- skip_busy -- may leave behind k)
         seq = self.my_seq[k] if owner == self.rank else k // self.world
-        self.apply_at[i + self.lag * cfg.key_every] = (k, owner, i - (cfg.n_key_frames - 1) * cfg.key_every, seq)
+        first = i - (cfg.n_key_frames - 1) * cfg.key_every
+        if cfg.keyframe_drives:
+            first = list(self.pushed_frames)   # the window's key frames where the decision put them
+        self.apply_at[i + self.lag * cfg.key_every] = (k, owner, first, seq)
 
     def measure_collectives(self, n=40):
         """GPU-clock latency of each of the frame loop's collectives as THIS loop issues them (the buffers of the last frame, the pose

@@ -1,0 +1,58 @@
+"""The frame loop with its key frames where CoSLAM::genNewMapPoints' decision puts them (reference src/app/SL_CoSLAM.cpp:1294-1346: one
+camera's mapped points decreased -> addKeyFrame for all cameras -> requestForBA) instead of bench.py's fixed cadence: LoopConfig.keyframe_drives.
+The decision runs on the device (cs_keyframe_ready_dev, pinned against the reference's own functions: tests/test_register_decide_gpu.py), the
+host reads `decrease` back, pushes the frame into the window's ring and requests the bundle adjustment; RobustBundleRTS::output() is applied
+through cs_ba_output_apply_frames_dev with the window's key frames as a list, every one of them held against the record's header."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(300)
+def test_the_decision_places_the_key_frames_and_their_windows_are_applied(hip):
+    import torch
+
+    import bench
+    from coslam_amd.frameloop import FrameLoop, LoopConfig
+
+    dev = torch.device("cuda", 0)
+    NA = bench.N_CAMS
+    frames = bench.render_video(list(range(NA)), bench.N_FRAMES)
+    video = {c: torch.from_numpy(frames[c]).to(dev) for c in range(NA)}
+    sc = bench.build_scene()
+    # m_mappedPtsReduceRatio raised from 0.93: in this synthetic world the mapped points of a camera never fall below 0.93 of a key frame's
+    # (DESIGN.md 3.15); at 1.2, with the key-pose state re-based at frame 60, the decision fires in a burst and then at long intervals
+    cfg = LoopConfig(n_cams=NA, W=bench.W, H=bench.H, levels=bench.LEVELS, fw=bench.FW, fh=bench.FH, pts_stride=bench.PTS_STRIDE,
+                     n_col_blk=bench.N_COL_BLK, n_row_blk=bench.N_ROW_BLK, key_every=bench.KEY_EVERY, p_reg=bench.P_REG, keyframe_drives=True,
+                     keyframe_ratio=1.2)
+    loop = FrameLoop(cfg, sc, video, None, bench.klt_config(), bench.reg_covariances(len(sc.points)), rank=0, world=1, device=0,
+                     associate=bench.associate)
+    loop.first_frame()
+    BASE, T = 60, 300
+    for i in range(1, BASE + 1):
+        loop.step(i, True)           # (the caller's cadence is ignored: 60 calls saying "key frame" ...)
+    loop.drain()
+    early = loop.keyframe_stats()["key_frames_placed_by_the_decision"]
+    assert loop.n_pushed == len(early) <= 2, early   # (... and the decision's one or two: the first tracked frame maps fewer features than initMap did)
+    loop.enable_keyframe_decision(BASE, BASE & 1)   # the key-pose state as a key frame added at frame 60 would leave it
+    for i in range(BASE + 1, T + 1):
+        loop.step(i, False)
+    loop.drain()
+    st = loop.keyframe_stats()
+    placed = st["key_frames_placed_by_the_decision"]
+    n_kf = cfg.n_key_frames
+    assert len(placed) > n_kf and len(set(np.diff(placed).tolist())) > 1, placed          # key frames, and not on a cadence
+    assert st["frames_with_decrease_ie_key_frames_added"] == len(placed) == loop.n_pushed - len(early)  # the device's bookkeeping and the host's agree
+    assert st["last_key_frame_per_camera"] == [placed[-1]] * NA                            # addKeyFrame: a key pose for ALL cameras
+    every = early + placed
+    assert loop.n_windows == len(every) - n_kf + 1
+    lag_frames = loop.lag * cfg.key_every
+    due = sum(1 for f in every[n_kf - 1:] if f + lag_frames <= T)
+    assert loop.applied + st["windows_not_applied_history_too_short"] == due and loop.applied >= 2
+    assert loop.out.wait_errors() == 0        # no wait gave up, and every applied record carried exactly the window's key frames
+    assert loop.last_apply["first_key_frame"] in every
+    R = loop.d_R[T & 1].cpu().numpy().reshape(NA, 3, 3)
+    t = loop.d_t[T & 1].cpu().numpy()
+    tt = np.stack([sc.pose(c, loop.vid(T))[1] for c in range(NA)])
+    assert np.isfinite(R).all() and float(np.abs(t - tt).max()) < 0.1

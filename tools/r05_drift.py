@@ -46,6 +46,10 @@ VARIANTS = {
     "no_merge": (dict(merge_every=0), None),
     "no_intercam": (dict(with_intercam=False), None),
     "no_chains": (dict(feature_chains=False), None),
+    "kf_drives": (dict(keyframe_drives=True), None),                     # the key frames where the decision puts them (m_mappedPtsReduceRatio = 0.93)
+    "kf_drives_r098": (dict(keyframe_drives=True, keyframe_ratio=0.98), None),
+    "kf_drives_r100": (dict(keyframe_drives=True, keyframe_ratio=1.0), None),
+    "kf_drives_r102": (dict(keyframe_drives=True, keyframe_ratio=1.02), None),
     "intracam": (dict(intracam_mapping=True, map_spare=50000), None),   # + SingleSLAM::newMapPoints for the cameras that are ready for a key frame   # this frame's features on their own tracks (the state before the feature references)
 }
 
