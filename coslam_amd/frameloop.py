@@ -64,7 +64,7 @@ class LoopConfig:
         self.keyframe_drives = False     # the decision PLACES the key frames (genNewMapPoints :1331-1346: `decrease` -> addKeyFrame, requestForBA):
         # step()'s key_frame argument is ignored, the host reads `decrease` back every frame (a wait per frame, as the reference's one
         # thread has it), the windows' key frames fall where they fall and their results are applied through cs_ba_output_apply_frames_dev.
-        # A window whose first key frame has left the pose history (hist frames) by the time its result is due is not applied (counted:
+        # A window whose first key frame has left the pose history (hist_store frames) by the time its result is due is not applied (counted:
         # FrameLoop.keyframe_stats()["windows_not_applied_history_too_short"]).  One rank only.  Implies keyframe_decision.  Off in the headline:
         # in the bench's world the decision never says `decrease` -- there would be no window bundle adjustment to measure
         self.keyframe_ratio = 0.93       # m_mappedPtsReduceRatio (reference src/app/SL_CoSLAM.cpp:42)
@@ -553,7 +553,7 @@ class FrameLoop:
         frames = None
         if isinstance(first_key, (list, tuple)):   # (key frames the decision placed: a list instead of first + j * key_every)
             frames, first_key = list(first_key), first_key[0]
-            if (i - 1) - first_key + 1 > self.cfg.hist:
+            if (i - 1) - first_key + 1 > self.pose_upd.storeLen:   # (the frames the history KEEPS: hist_store, not the walks' depth)
                 # the camera graphs would start behind the pose history's oldest frame: the record is consumed, nothing is written back
                 self.my_seq.pop(k, None)
                 self.kf["not_applied"] += 1

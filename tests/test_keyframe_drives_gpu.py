@@ -49,7 +49,7 @@ def test_the_decision_places_the_key_frames_and_their_windows_are_applied(hip):
     assert loop.n_windows == len(every) - n_kf + 1
     lag_frames = loop.lag * cfg.key_every
     due = sum(1 for f in every[n_kf - 1:] if f + lag_frames <= T)
-    assert loop.applied + st["windows_not_applied_history_too_short"] == due and loop.applied >= 2
+    assert loop.applied == due >= 4 and st["windows_not_applied_history_too_short"] == 0   # (the camera graphs reach back through the kept history)
     assert loop.out.wait_errors() == 0        # no wait gave up, and every applied record carried exactly the window's key frames
     assert loop.last_apply["first_key_frame"] in every
     R = loop.d_R[T & 1].cpu().numpy().reshape(NA, 3, 3)
