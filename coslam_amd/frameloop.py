@@ -308,7 +308,7 @@ class FrameLoop:
             self.win = BAWindow(NA, cfg.n_key_frames, N, n_map, device=device)
             self.win.reserve(self.ba_ws)
             # (records in flight: lag windows on the cadence; with the decision placing the key frames, up to one request per frame of the lag)
-            self.out = BAOutput(NA, cfg.n_key_frames, n_map, n_slots=8 if not cfg.keyframe_drives else self.lag * cfg.key_every + 6, device=device)
+            self.out = BAOutput(NA, cfg.n_key_frames, n_map, n_slots=8 if not cfg.keyframe_drives else min(self.lag * cfg.key_every + 6, 64), device=device)
             self.out.attach(self.ba_ws)
             if self.d_fref is not None:
                 self.out.set_feat_refs(self.d_fref.data_ptr(), self.d_rstat.data_ptr())
