@@ -1,6 +1,7 @@
 /*
  * oracle/klt_oracle.c -- CPU restatement of CoSLAM's GPU-KLT hot path (see klt_oracle.h).
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (no reference tests/fixtures exist).
+ * TEST INFRASTRUCTURE ONLY.  Arithmetic pinned, pass by pass and bit for bit, to the reference's own .cg shaders compiled in
+ * place (oracle/build_cgref.sh, tests/test_cgklt_cpu.py); the GL texture model and the host's pass schedule are restatements.
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fPIC -shared (oracle/Makefile).
  * All citations are relative to the reference root (danping/CoSLAM).

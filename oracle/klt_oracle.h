@@ -5,14 +5,16 @@
  * call this.  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg use it, and only as the checker / the reported baseline.
  *
- * PARITY UNPINNED for the KLT part: the reference (danping/CoSLAM) runs this
- * path as Nvidia Cg fragment shaders through OpenGL FBOs and ships no tests,
- * golden vectors or fixtures.  It cannot run in this
- * image (no Cg, no GL context).  This file restates, line by line, what the
- * shaders and their host scheduling compute; each function cites the
- * reference file:line it follows (paths relative to the reference root).
- * The known-answer tests in tests/ (analytic shifts, ramps, isolated corner)
- * are ours, not the reference's.
+ * KLT PARITY: arithmetic pinned to the reference's shaders, sampling model and pass schedule ours.  The reference
+ * (danping/CoSLAM) runs this path as Nvidia Cg fragment shaders through OpenGL FBOs and ships no tests, golden vectors
+ * or fixtures; Cg / GL cannot run in this image.  The shader BODIES can: oracle/build_cgref.sh
+ * compiles each .cg file where it lies under /root/reference (piped through four syntactic sed rewrites, over
+ * ref_shim/cg/cg_shim.h) into oracle/_ref/libcgklt_ref.so, ref_shim/cg/cgklt_driver.cpp rasterises the passes in the
+ * host's order, and this file -- in its serial summation mode -- reproduces every pass BIT FOR BIT
+ * (tests/test_cgklt_cpu.py; tests/golden/cgklt_golden.npz holds the shaders' outputs).  This file restates, line by
+ * line, what the shaders and their host scheduling compute; each function cites the reference file:line it follows
+ * (paths relative to the reference root).  The frame logic (KLT_SequenceTracker, GL-bound host C++) and the GL texture
+ * model below remain restatements.
  *
  * Numeric model (the places where OpenGL leaves bits to the hardware and we
  * had to pick; all are stated in DESIGN.md):

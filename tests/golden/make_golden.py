@@ -6,8 +6,15 @@ pose_golden.npz  -- inputs and outputs of the REFERENCE's own intraCamEstimate (
                     container only.  These vectors pin oracle/pose_oracle.c and the HIP pose kernel to the reference.
 klt_golden.npz   -- small KLT cases (pyramid texels, detection list, two tracked frames) produced by oracle/klt_oracle.c
                     (the with-gain case in the oracle's "tree" summation mode, which the HIP tracker matches bit for bit).
-                    The reference's KLT cannot run here (Cg/OpenGL), so these pin our restatement against regressions;
-                    they are NOT reference outputs (parity unpinned, see oracle/klt_oracle.h).
+                    A regression fixture in the KERNELS' summation order; the shaders' own outputs are in cgklt_golden.npz.
+cgklt_golden.npz -- the KLT passes run by the REFERENCE's own fragment programs (src/tracking/CGKLT/Shaders/*.cg compiled in place
+                    into oracle/_ref/libcgklt_ref.so by oracle/build_cgref.sh; rasteriser + GL texture model in
+                    oracle/ref_shim/cg/): pyramids of three frames (two scenes), cornerness after klt_detector_pass1/2, after the
+                    suppression + non-max passes, the HistoPyramid point list, and detect / redetect / redetect sequences with and
+                    without gain in which EVERY pass was produced by the shaders (the frame logic around them is
+                    oracle.SequenceTracker's restatement of v3d_gpuklt.cpp:650-889, asserted here to reproduce the shader
+                    outputs bit for bit at every step).  Pins oracle/klt_oracle.c (serial mode) and, on the GPU box, the HIP
+                    pyramid / detector (bit for bit) and trackers (<= 0.02 px, status flips only at recorded threshold margins).
 ba_golden.npz    -- cfg1-shaped BA problem solved by oracle/ba_oracle.c (our definition; parity unpinned).
 register_golden.npz -- a feature list, 400 (m, var, maxDist) queries and the answers of the REFERENCE's own
                     searchMahaNearestFeatPt (src/app/SL_SingleSLAM.cpp:1141-1164 compiled in place into
@@ -909,10 +916,112 @@ def classify_case():
     return out
 
 
+def cgklt_cases():
+    """see the module docstring.  Every array named *_cg comes out of libcgklt_ref.so."""
+    from oracle import cgref
+    if not cgref.have():
+        raise SystemExit("oracle/_ref/libcgklt_ref.so missing: run oracle/build_cgref.sh where /root/reference exists")
+    out = {}
+    scenes = [  # W, H, L, fw, fh, window, iterations, levelSkip, minDistance, minCornerness, scene seed
+        (160, 120, 3, 10, 8, 7, 6, 1, 5, 800.0, 9),
+        (256, 192, 4, 16, 8, 5, 8, 1, 7, 1500.0, 13),   # 2:1 slot grid: the gain shader's neighbour taps land on texel edges
+    ]
+    out["scenes"] = np.array([s[:9] for s in scenes], dtype=np.int64)
+    out["minCornerness"] = np.array([s[9] for s in scenes], dtype=np.float32)
+    for si, (W, H, L, fw, fh, win, iters, skip, mind, minc, seed) in enumerate(scenes):
+        sc = Scene(1, W, H, int(W * H / 75), seed=seed, sigma=1.4)
+        imgs = np.stack([sc.render(0, f) for f in range(3)])
+        out[f"s{si}_images"] = imgs
+        pyr = [cgref.pyramid_build(imgs[f], W, H, L, 0) for f in range(3)]
+        import hashlib
+        sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+        for f in range(3):
+            # the texels in full for scene 0 and the first frame of scene 1, SHA-256 of the same bytes for the rest (fixture size)
+            out[f"s{si}_pyr{f}_cg" if (si == 0 or f == 0) else f"s{si}_pyr{f}_sha_cg"] = pyr[f] if (si == 0 or f == 0) else sha(pyr[f])
+            assert np.array_equal(pyr[f], oracle.pyramid_build(imgs[f], W, H, L, 0)), "oracle pyramid != shader pyramid"
+        # the other reading of the decimation taps (NEAREST exactly on a texel edge resolves downwards); even sizes only
+        cen = cgref.pyramid_build(imgs[0], W, H, L, 1)
+        out[f"s{si}_pyr0_centered_cg" if si == 0 else f"s{si}_pyr0_centered_sha_cg"] = cen if si == 0 else sha(cen)
+        assert np.array_equal(cen, oracle.pyramid_build(imgs[0], W, H, L, 1))
+        hw = win // 2
+        for gain in (0, 1):
+            pre = f"s{si}_g{gain}_"
+            cfg = KLT_SequenceTrackerConfig(nIterations=iters, nLevels=L, levelSkip=skip, windowWidth=win, trackWithGain=gain,
+                                            minCornerness=minc, convergenceThreshold=1.0, SSD_Threshold=20000.0, minDistance=mind)
+            o = oracle.SequenceTracker(cfg, sum_mode=0)   # the shader's serial summation order
+            o.allocate(W, H, L, fw, fh)
+            plw, cap = 2 * fw, 4 * fw * fh
+            margin_t, margin_d = cfg.trackBorderMargin, 10.0   # v3d_gpuklt.h:114, KLT_SequenceTracker::allocate
+            for f in range(3):
+                if f:
+                    o.advanceFrame()
+                    mbuf = np.full(fw * fh, 1e30, np.float32)
+                    oracle.set_threshold_margin_buffer(mbuf)
+                    try:
+                        n, d = o.redetect(imgs[f])
+                    finally:
+                        oracle.set_threshold_margin_buffer(None)
+                    # --- the tracker, by the shaders
+                    if gain:
+                        trk = cgref.track_gain(pyr[f - 1], pyr[f], W, H, L, skip, hw, iters, fw, fh, margin_t, 1.0, 20000.0, prov, prov)
+                    else:
+                        trk = cgref.track_nogain(pyr[f - 1], pyr[f], W, H, L, skip, hw, fw, fh, margin_t, 1.0, 20000.0, prov)
+                    alive = trk[:, 0] >= 0
+                    assert np.array_equal(alive, d["status"] == 0), "tracked set: oracle != shaders"
+                    assert np.array_equal(trk[alive, :2], d["pos"][alive]) and np.array_equal(trk[alive, 2], d["gain"][alive])
+                    out[pre + f"tracked{f}_cg"] = trk
+                    out[pre + f"margin{f}"] = mbuf
+                    present = np.where(alive[:, None], np.concatenate([trk[:, :2], np.zeros((fw * fh, 1), np.float32)], 1),
+                                       np.array([-1, -1, 0], np.float32)).astype(np.float32)
+                else:
+                    n, d = o.detect(imgs[0])
+                    present = None
+                # --- the detector, by the shaders
+                lvl0 = oracle.level_view(pyr[f], W, H, L, 0)
+                c = cgref.cornerness(lvl0, W, H, minc, margin_d)
+                if f == 0 and gain == 0:
+                    out[f"s{si}_cornerness0_cg"] = c
+                    assert np.array_equal(c.view(np.uint32), oracle.cornerness(lvl0, W, H, minc, margin_d).view(np.uint32))
+                if present is not None:
+                    c = cgref.suppress_present(c, present)
+                c = cgref.nonmax(c, mind)
+                assert np.array_equal(c.view(np.uint32), o.read_cornerness().view(np.uint32)), "non-max map: oracle != shaders"
+                cnt, lst = cgref.extract(c, plw, cap)
+                cnt_o, lst_o = oracle.extract(c, cap)
+                assert cnt == cnt_o and np.array_equal(lst.view(np.uint32), lst_o.view(np.uint32)), "point list: oracle != shaders"
+                new = d["status"] == 1
+                assert set(map(tuple, d["pos"][new].tolist())) <= set(map(tuple, lst[:, :2].tolist()))
+                out[pre + f"nonmax{f}_cg"], out[pre + f"list{f}_cg"] = c, lst
+                out[pre + f"n{f}"] = np.array([n])
+                out[pre + f"status{f}"], out[pre + f"pos{f}"], out[pre + f"gain{f}"] = d["status"], d["pos"], d["gain"]
+                prov = o.read_features()
+                out[pre + f"provided{f}"] = prov
+            o.close()
+    # pass-level vectors: one launch of klt_tracker_with_gain.cg per level on a list with dead slots and real thresholds
+    si, (W, H, L, fw, fh, win) = 0, scenes[0][:6]
+    rng = np.random.default_rng(31)
+    N = fw * fh
+    feat0 = out["s0_g1_provided0"].copy()
+    cur = feat0.copy()
+    cur[:, :2] += (rng.uniform(-0.4, 0.4, (N, 2)) / np.array([W, H])).astype(np.float32)
+    cur[:, 2] = rng.uniform(0.9, 1.1, N).astype(np.float32)
+    cur[feat0[:, 0] < 0] = -1.0
+    cur[rng.random(N) < 0.05] = -1.0
+    vr = np.array([4.0 / W, 4.0 / H, 1 - 4.0 / W, 1 - 4.0 / H], np.float32)
+    out["pass_feat0"], out["pass_cur"], out["pass_vr"] = feat0, cur, vr
+    p0, p1 = out["s0_pyr0_cg"], out["s0_pyr1_cg"]
+    for level in range(L):
+        r = cgref.track_gain_pass(p0, p1, W, H, L, level, fw, fh, win // 2, feat0, cur, 4.0, 20000.0, vr, 1.0, 200.0)
+        assert np.array_equal(r.view(np.uint32),
+                              cgref.okl_track_gain_pass(p0, p1, W, H, L, level, fw, fh, win // 2, feat0, cur, 4.0, 20000.0, vr).view(np.uint32))
+        out[f"pass_level{level}_cg"] = r
+    return out
+
+
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "mergability_long", "update_points", "update_points_relink", "keyframe", "intracam_newpts", "classify", "intercam", "newpts", "decide"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "mergability_long", "update_points", "update_points_relink", "keyframe", "intracam_newpts", "classify", "intercam", "newpts", "decide", "cgklt"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -947,4 +1056,6 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "decide_golden.npz"), **decide_case())
     if "newpts" in which:
         np.savez_compressed(os.path.join(HERE, "newpts_golden.npz"), **newpts_case())
+    if "cgklt" in which:
+        np.savez_compressed(os.path.join(HERE, "cgklt_golden.npz"), **cgklt_cases())
     print("golden fixtures written")
