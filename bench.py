@@ -1298,7 +1298,7 @@ def main():
                        "frame_front_prefetch": bool(prefetch), "secondary_cfg2": cfg2, "secondary_cfg5_ba": cfg5, "secondary_cfg5_klt": cfg5_klt,
                        "secondary_reference_default_klt": ref_default,
                        "register_candidates_last_frame": None if args.no_register else
-                       {"current_points_listed": int(loop.d_curcount.item()), "list_cap": P_REG,
+                       {"current_points_listed": int(loop.d_curcount.item()), "list_cap": P_REG, "current_points_beyond_the_cap_all_frames": int(loop.d_curoverflow.item()),
                         "candidates": int((reg_out["slot"][:, lc] >= 0).sum().item()),
                         "mergeable_over_the_whole_track": None if loop.pose_upd is None else int(((loop.d_mergeable[:, lc] == 1) & (reg_out["slot"][:, lc] >= 0)).sum().item()),
                         "not_mergeable": None if loop.pose_upd is None else int(((loop.d_mergeable[:, lc] == 0) & (reg_out["slot"][:, lc] >= 0)).sum().item()),

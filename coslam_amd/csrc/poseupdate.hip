@@ -2482,6 +2482,7 @@ extern "C" int cs_feat_ref_advance_dev(cs_track_history* h, void* hip_stream, co
     A.nCams = h->nCams, A.N = h->N, A.nMap = nMap, A.curFrame = curFrame, A.segCap = h->segCap;
     A.pointFeat = d_pointFeat, A.featRef = (int4*)d_featRef, A.refStatic = d_refStatic, A.segPool = h->segPool, A.segCount = h->segCount;
     A.counts = d_counts;
+    CS_HIP(hipSetDevice(h->device));   // (before the allocation below: the calling thread's current device may be another)
     if (nMap > h->aliveCap) {   // (grown on first use / for a larger map: a point nobody has seen yet has no live reference)
         if (h->alive) CS_HIP(hipFree(h->alive));
         h->alive = nullptr, h->aliveCap = 0;
@@ -2497,7 +2498,6 @@ extern "C" int cs_feat_ref_advance_dev(cs_track_history* h, void* hip_stream, co
         }
         A.cam[c] = cams[c];
     }
-    CS_HIP(hipSetDevice(h->device));
     if (nMap == 0) return CS_OK;
     hipLaunchKernelGGL(k_feat_ref_advance, dim3((nMap + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, A);
     CS_HIP(hipGetLastError());

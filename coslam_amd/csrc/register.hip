@@ -242,7 +242,8 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_register_search(RgArgs A) {
 // listed rows are ever written), so that the tables never carry a stale candidate.
 __global__ __launch_bounds__(1024) void k_register_list(int nCams, int nMap, const int* __restrict__ mapCount, const int* __restrict__ pointFeat,
                                                         const unsigned char* __restrict__ mapFlags, int* __restrict__ list,
-                                                        int* __restrict__ listCount, int* __restrict__ slotTable) {
+                                                        int* __restrict__ listCount, int* __restrict__ slotTable, int listCap,
+                                                        int* __restrict__ overflow) {
     // pass 1, coalesced: thread t looks at the points t, t + 1024, ... (a wave = 64 consecutive rows of pointFeat), the verdicts go into
     // a bitmap in LDS (and the unlisted points' rows of slotTable to -1); pass 2: thread t owns `per` consecutive points of the bitmap
     // (the list keeps the map's order): count, ONE scan over the block, write.  (Earlier forms: 15 rounds of scan over 1024 points,
@@ -306,10 +307,20 @@ __global__ __launch_bounds__(1024) void k_register_list(int nCams, int nMap, con
         if (w < wv) off += waveSum[w];
         total += waveSum[w];
     }
+    // listCap: the passes behind this list (search, running mergability, merge walk, candidate records) cover its first listCap
+    // entries.  A current point beyond the cap is NOT listed this frame: its row of slotTable is cleared, so that the decision -- which
+    // visits every point with a feature -- finds no candidate for it instead of an older frame's; *overflow counts such points.
+    const int kept = total < listCap ? total : listCap;
     for (int p = q0; p < q1; ++p)
-        if ((bits[p >> 6] >> (p & 63)) & 1ull) list[off++] = p;
-    for (int q = total + tid; q < nMap; q += 1024) list[q] = -1;
-    if (tid == 0 && listCount) *listCount = total;
+        if ((bits[p >> 6] >> (p & 63)) & 1ull) {
+            if (off < listCap) list[off] = p;
+            else if (slotTable)
+                for (int c = 0; c < nCams; ++c) slotTable[(size_t)p * nCams + c] = -1;
+            ++off;
+        }
+    for (int q = kept + tid; q < nMap; q += 1024) list[q] = -1;
+    if (tid == 0 && listCount) *listCount = kept;
+    if (tid == 0 && overflow && total > listCap) atomicAdd(overflow, total - listCap);
 }
 
 int check_args(const char* who, int nCams, const cs_register_cam* cams, int N, int W, int H, int P, double sigmaSearch,
@@ -326,14 +337,21 @@ int check_args(const char* who, int nCams, const cs_register_cam* cams, int N, i
 
 extern "C" int cs_register_list_current_dev(int device, void* hip_stream, int nCams, int nMap, const int* d_mapCount, const int* d_pointFeat,
                                             const unsigned char* d_mapFlags, int* d_list, int* d_listCount, int* d_slotTable) {
-    if (nCams < 1 || nCams > RG_MAX_CAMS || nMap < 0 || nMap > 65536 || (nMap > 0 && (!d_pointFeat || !d_list))) {
+    return cs_register_list_current_cap_dev(device, hip_stream, nCams, nMap, d_mapCount, d_pointFeat, d_mapFlags, d_list, d_listCount, d_slotTable,
+                                            nMap, nullptr);
+}
+
+extern "C" int cs_register_list_current_cap_dev(int device, void* hip_stream, int nCams, int nMap, const int* d_mapCount, const int* d_pointFeat,
+                                                const unsigned char* d_mapFlags, int* d_list, int* d_listCount, int* d_slotTable, int listCap,
+                                                int* d_overflow) {
+    if (nCams < 1 || nCams > RG_MAX_CAMS || nMap < 0 || nMap > 65536 || listCap < 0 || (nMap > 0 && (!d_pointFeat || !d_list))) {
         cs_set_error("cs_register_list_current_dev: bad arguments (at most 65536 map points)");
         return CS_ERR_INVALID;
     }
     if (nMap == 0) return CS_OK;
     CS_HIP(hipSetDevice(device));
     hipLaunchKernelGGL(k_register_list, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, nCams, nMap, d_mapCount, d_pointFeat, d_mapFlags, d_list,
-                       d_listCount, d_slotTable);
+                       d_listCount, d_slotTable, listCap < nMap ? listCap : nMap, d_overflow);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

@@ -174,6 +174,7 @@ class FrameLoop:
         self.reg_out = dict(slot=torch.full((n_map, NA), -1, dtype=i32, device=dev), m=z((n_map, NA, 2), f64), var=z((n_map, NA, 4), f64),
                             dist=z((n_map, NA), f64), flags=z((n_map, NA), i32))
         self.d_curlist, self.d_curcount = torch.full((n_map,), -1, dtype=i32, device=dev), z(1, i32)
+        self.d_curoverflow = z(1, i32)   # current points beyond the list's cap (left out of that frame's registration; 0 in every bench configuration)
         self.d_merge_counts = z(4, i32)   # running mergability: cache hits, full tail walks, verdicts 2, tail terms (summed over the run)
         # ---- streams
         self.klt_s, self.pose_s = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)   # (equal priorities: a high-priority pose or
@@ -682,7 +683,8 @@ class FrameLoop:
 
             # curMapPts of this frame as a list (mapStateUpdate, SL_CoSLAM.cpp:1176-1194); the rows of every other point lose their candidates
             register_list_current_dev(ps, NA_, self.n_map, self.d_mapcount.data_ptr(), self.d_pf.data_ptr(), self.d_mapflags.data_ptr(),
-                                      self.d_curlist.data_ptr(), self.d_curcount.data_ptr(), self.reg_out["slot"].data_ptr(), device=self.device)
+                                      self.d_curlist.data_ptr(), self.d_curcount.data_ptr(), self.reg_out["slot"].data_ptr(), device=self.device,
+                                      listCap=cfg.p_reg, d_overflow=self.d_curoverflow.data_ptr())
             register_search_passes_dev(ps, self.reg_args[dst], cfg.n_feat, cfg.W, cfg.H, self.reg_passes, device=self.device, cam0=c0,
                                        nCamsRun=nc)
             if self.pose_upd is not None and cfg.with_mergability:

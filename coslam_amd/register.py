@@ -65,12 +65,15 @@ def register_passes(passes):
     return arr
 
 
-def register_list_current_dev(stream_ptr, nCams, nMap, d_mapCount, d_pointFeat, d_mapFlags, d_list, d_listCount=0, d_slotTable=0, device=0):
-    """cs_register_list_current_dev: the frame's current map points (a feature of this frame in some camera, below the live count, not
-    false) as a compact list in map order -- what CoSLAM::currentMapPointsRegister walks (curMapPts)"""
+def register_list_current_dev(stream_ptr, nCams, nMap, d_mapCount, d_pointFeat, d_mapFlags, d_list, d_listCount=0, d_slotTable=0, device=0,
+                              listCap=None, d_overflow=0):
+    """cs_register_list_current_cap_dev: the frame's current map points (a feature of this frame in some camera, below the live count, not
+    false) as a compact list in map order -- what CoSLAM::currentMapPointsRegister walks (curMapPts).  listCap: at most that many are
+    listed; the rest lose their candidate rows for this frame and are counted into d_overflow."""
     vp = C.c_void_p
-    check(lib().cs_register_list_current_dev(int(device), vp(stream_ptr), int(nCams), int(nMap), vp(d_mapCount), vp(d_pointFeat), vp(d_mapFlags),
-                                             vp(d_list), vp(d_listCount), vp(d_slotTable)), "cs_register_list_current_dev")
+    check(lib().cs_register_list_current_cap_dev(int(device), vp(stream_ptr), int(nCams), int(nMap), vp(d_mapCount), vp(d_pointFeat), vp(d_mapFlags),
+                                                 vp(d_list), vp(d_listCount), vp(d_slotTable), int(nMap if listCap is None else listCap), vp(d_overflow)),
+          "cs_register_list_current_cap_dev")
 
 
 def register_search_passes_dev(stream_ptr, cams, N, W, H, passes, device=0, cam0=0, nCamsRun=None):

@@ -339,6 +339,13 @@ typedef struct cs_register_pass {
  * survives a frame and no frame clears the whole table. */
 int cs_register_list_current_dev(int device, void* hip_stream, int nCams, int nMap, const int* d_mapCount, const int* d_pointFeat,
                                  const unsigned char* d_mapFlags, int* d_list, int* d_listCount, int* d_slotTable);
+/* the same with a CAP on the list: the passes a frame loop runs behind the list (search, running mergability, the merge walk, the
+ * candidate records between ranks) are sized for listCap rows.  The first listCap current points in map order are listed; every
+ * current point beyond them is left out for this frame -- its row of d_slotTable is cleared, so the decision (which visits every point
+ * that has a feature) finds no candidate for it rather than an older frame's -- and counted into *d_overflow (accumulating; or NULL). */
+int cs_register_list_current_cap_dev(int device, void* hip_stream, int nCams, int nMap, const int* d_mapCount, const int* d_pointFeat,
+                                     const unsigned char* d_mapFlags, int* d_list, int* d_listCount, int* d_slotTable, int listCap,
+                                     int* d_overflow);
 int cs_register_search_passes_dev(int device, void* hip_stream, int nCams, const cs_register_cam* cams, int N, int W, int H,
                                   int nPass /* 1 or 2 */, const cs_register_pass* passes /* host array */);
 /* the same for cameras cam0 .. cam0 + nCamsRun - 1 only: their columns of the nCams-wide tables (with the cameras sharded over

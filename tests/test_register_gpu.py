@@ -339,3 +339,38 @@ def test_candidate_records_of_listed_rows_round_trip(hip):
     assert np.array_equal(gm[rows][:, :nOwn], merg[rows][:, :nOwn])
     other = np.setdiff1d(np.arange(P), rows)
     assert (gs[other] == -77).all() and (gf[other] == -77).all()
+
+
+def test_current_points_list_with_a_cap_drops_the_overflow_cleanly(hip):
+    """cs_register_list_current_cap_dev: the passes behind the list cover listCap rows.  A current point beyond
+    the cap must not keep an older frame's candidates: it is left off the list, its candidate row is cleared, the overflow is counted."""
+    import torch
+
+    from coslam_amd.register import register_list_current_dev
+
+    n_cams, P, cap = 4, 3000, 400
+    rng = np.random.default_rng(4)
+    pf = np.where(rng.uniform(size=(P, n_cams)) < 0.15, 5, -1).astype(np.int32)
+    flags = np.where(rng.uniform(size=P) < 0.1, 2, 0).astype(np.uint8)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    d_pf, d_fl = torch.from_numpy(pf).to(dev), torch.from_numpy(flags).to(dev)
+    d_list = torch.full((P,), -1, dtype=torch.int32, device=dev)
+    d_n, d_over = torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    slot = torch.full((P, n_cams), 7, dtype=torch.int32, device=dev)    # every row carries a (stale) candidate
+    want = np.nonzero(((flags & 2) == 0) & (pf >= 0).any(axis=1))[0]
+    assert len(want) > 2 * cap
+    for rep in (1, 2):
+        register_list_current_dev(s, n_cams, P, 0, d_pf.data_ptr(), d_fl.data_ptr(), d_list.data_ptr(), d_n.data_ptr(), slot.data_ptr(),
+                                  listCap=cap, d_overflow=d_over.data_ptr())
+        torch.cuda.synchronize()
+        lst = d_list.cpu().numpy()
+        assert d_n.item() == cap and np.array_equal(lst[:cap], want[:cap]) and (lst[cap:] == -1).all()
+        assert d_over.item() == rep * (len(want) - cap)                 # accumulates over the frames
+        sl = slot.cpu().numpy()
+        assert (sl[want[cap:]] == -1).all() and (sl[want[:cap]] == 7).all()
+    # no cap given: the whole list, nothing counted
+    d_over.zero_()
+    register_list_current_dev(s, n_cams, P, 0, d_pf.data_ptr(), d_fl.data_ptr(), d_list.data_ptr(), d_n.data_ptr(), 0, d_overflow=d_over.data_ptr())
+    torch.cuda.synchronize()
+    assert d_n.item() == len(want) and d_over.item() == 0 and np.array_equal(d_list.cpu().numpy()[:len(want)], want)

@@ -319,6 +319,7 @@ int main(int argc, char** argv) {
     }
     int* dCurList = dev_zeros<int>(nMap);
     int* dCurCount = dev_zeros<int>(1);
+    int* dCurOverflow = dev_zeros<int>(1);   // current points beyond the list's cap P_REG (left out of that frame's registration)
     int* dMergeRun = dev_zeros<int>(4);
     double* dR[2] = {to_dev(R0), to_dev(R0)};
     double* dT[2] = {to_dev(t0), to_dev(t0)};
@@ -558,7 +559,7 @@ int main(int argc, char** argv) {
         // currentMapPointsRegister, search step: curMapPts of this frame as a list (the points with a feature of this frame, wherever they
         // sit in the map -- the ones genNewMapPoints just appended included), ONE pass over it; the tables are indexed by the map index.
         // (activeMapPointsRegister's search is not run: the reference's attach loop behind it cannot be reached, tests/cxx/ref_active_test.cpp)
-        CSCHK(cs_register_list_current_dev(dev, (void*)poseS, nCams, nMap, dMapCount, dPf, dMapFlags, dCurList, dCurCount, reg[0].slot));
+        CSCHK(cs_register_list_current_cap_dev(dev, (void*)poseS, nCams, nMap, dMapCount, dPf, dMapFlags, dCurList, dCurCount, reg[0].slot, P_REG, dCurOverflow));
         {
             cs_register_pass ps[1];
             memset(ps, 0, sizeof(ps));
@@ -751,6 +752,8 @@ int main(int argc, char** argv) {
     int mapCountNow = 0, npCounts[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpy(&mapCountNow, dMapCount, sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(npCounts, dNpCounts, sizeof(npCounts), hipMemcpyDeviceToHost));
+    int curOverflow = 0;
+    HIPCHK(hipMemcpy(&curOverflow, dCurOverflow, sizeof(int), hipMemcpyDeviceToHost));
     int decUnsettled = 0;   // (the decision scratch's last int: sticky "some call's sweeps did not settle")
     HIPCHK(hipMemcpy(&decUnsettled, (char*)dDecScratch + cs_register_decide_scratch_bytes(nCams, N, nMap) - sizeof(int), sizeof(int),
                      hipMemcpyDeviceToHost));
@@ -759,11 +762,11 @@ int main(int argc, char** argv) {
            "\"intercam_lm_steps\": %d, \"intercam_cost\": %.6f, \"ncc_runs\": %d, \"joint_ba_from_window\": %s, \"joint_cameras\": %d, "
            "\"joint_points\": %d, \"joint_measurements\": %d, \"ba_lag\": %d, \"windows_applied_in_timed_region\": %d, \"apply_wait_errors\": %d, "
            "\"intercam_static_points\": %d, \"intercam_dynamic_points\": %d, \"map_points_at_start\": %d, \"map_points_in_use\": %d, "
-           "\"map_capacity\": %d, \"new_map_points_last_run\": %d, \"register_decisions_unsettled\": %s, \"bmerge_frames\": %d, "
+           "\"map_capacity\": %d, \"new_map_points_last_run\": %d, \"register_decisions_unsettled\": %s, \"bmerge_frames\": %d, \"current_points_beyond_the_cap\": %d, "
            "\"rank\": %d, \"world\": %d, \"cameras_per_rank\": %d, \"transport\": \"%s\", \"digest\": \"%016llx\"}\n",
            steps / dt, dt / steps * 1e3, steps, warmup, dtHost / steps * 1e3, camsPerLaunch, okAll ? "true" : "false", minLive,
            sj.nIterTotal, sj.cost, si.nIterTotal, si.cost, nccRuns, win ? "true" : "false", jC, jP, jO, baLag, nApplied - applied0,
-           cs_ba_output_wait_errors(bout), iS, iP - iS, nPts, mapCountNow, nMap, npCounts[0], decUnsettled ? "true" : "false", nMergeFrames,
+           cs_ba_output_wait_errors(bout), iS, iP - iS, nPts, mapCountNow, nMap, npCounts[0], decUnsettled ? "true" : "false", nMergeFrames, curOverflow,
            rank, world, nc, world == 1 ? "none" : (getenv("COSLAM_COMM") && !strncmp(getenv("COSLAM_COMM"), "host:", 5) ? "host segment (test)" : "rccl"),
            digest);
     fflush(stdout);
