@@ -21,6 +21,7 @@ HIP_SOURCES = [
     "klt_seq.hip",
     "pose.hip",
     "handback.hip",
+    "hostview.hip",
     "register.hip",
     "keyframe.hip",
     "poseupdate.hip",

@@ -272,6 +272,33 @@ typedef struct cs_handback_cam {
 int cs_klt_handback_dev(int device, void* hip_stream, int nCams, const cs_handback_cam* cams, int N, int W, int H,
                         int nColBlk, int nRowBlk, int ptsStride, int frame /* GPUKLT::m_frame of this call, >= 0 */);
 
+/* ---- SURVEY 8f-1, second half: the group's frames as HOST records, for a lazy FeaturePoints / Track2D adaptor ----
+ * GPUKLT::next (src/tracking/GPUKLT.cpp:144-161) = redetect + addToFeaturePoints + advanceFrame per camera; addToFeaturePoints
+ * (:36-60) heap-allocates one FeaturePoint and one Track2DNode per feature per frame (src/slam/SL_FeaturePoints.cpp:81-87,
+ * src/tracking/SL_Track2D.h:79-82).  A host view runs the frame for ALL cameras on the device -- cs_klt_group_* + cs_klt_handback_dev
+ * -- and streams what addToFeaturePoints would have appended, per slot {state (0 tracked, 1 new, -1 dead, -2 dropped by the
+ * out >= W | H rule), undistorted x, y}, into a ring of `depth` frames in pinned host memory (stores from a kernel; nothing on the
+ * host waits).  include/shim/tracking/GPUKLTGroup.h replays the frames a consumer has not seen into the reference's lists when it
+ * asks.  handles: the cameras' trackers (KLT_SequenceTracker::handle()), allocated, same size / grid / configuration; K [nCams][9],
+ * kud [nCams][7] (GPUKLT::m_K, m_kud) are HOST arrays.  The view owns its stream. */
+typedef struct cs_klt_hostview cs_klt_hostview;
+cs_klt_hostview* cs_klt_hostview_create(int device, cs_klt* const* handles, int nCams, int W, int H, int N, const double* K,
+                                        const double* kud, int depth /* frames the ring holds, >= 2 */);
+void cs_klt_hostview_destroy(cs_klt_hostview* v); /* the handles are NOT destroyed */
+/* W*H bytes of pinned memory for the NEXT frame's image of camera `cam` (decode straight into it: no host copy).  Blocks only
+ * while the device still has to pull the frame that used this buffer 4 frames ago. */
+unsigned char* cs_klt_hostview_image(cs_klt_hostview* v, int cam);
+/* One frame for all cameras, enqueued: images (h_images NULL: already in cs_klt_hostview_image(); else nCams host pointers that are
+ * COPIED there, so the caller may reuse its buffers at once), detect (first != 0: GPUKLT::first, :113-121) or redetect (GPUKLT::next),
+ * advanceFrame, hand-back with GPUKLT::m_frame = frame, the records into ring slot frame % depth.  Frames must increase. */
+int cs_klt_hostview_frame(cs_klt_hostview* v, const unsigned char* const* h_images, int frame, int first);
+/* Blocks until `frame`'s records are on the host: state [nCams][N], xy [nCams][2N] (x[N] then y[N]) inside the ring -- valid until
+ * `depth` more frames have been enqueued.  CS_ERR_INVALID when the frame has been overwritten. */
+int cs_klt_hostview_fetch(cs_klt_hostview* v, int frame, const int** state, const double** xy);
+int cs_klt_hostview_oldest(const cs_klt_hostview* v); /* oldest frame still in the ring, -1: none */
+int cs_klt_hostview_newest(const cs_klt_hostview* v);
+int cs_klt_hostview_synchronize(cs_klt_hostview* v);
+
 /* ------------------------------------------------------------------------------------------
  * Map-point registration: the search step for all map points x all cameras in one launch
  * ------------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 * oracle/_ref/ref_gpuklt_dropin_test   the REFERENCE'S OWN src/tracking/GPUKLT.cpp (+ SL_Track2D.cpp and the data model)
                                        compiled in place over the shims, driven as SingleSLAM drives it, and checked slot
                                        by slot against the on-device hand-back (cs_klt_handback_dev);
+* oracle/_ref/ref_lazy_adaptor_test    the same sources + SL_SingleSLAM.cpp under the lazy list adaptor (include/shim/tracking/GPUKLTGroup.h).
 * oracle/_ref/ref_ba_dropin_test       the REFERENCE'S OWN src/app/SL_CoSLAMRobustBA.cpp (parseInputs / run),
                                        SL_InterCamPoseEstimator.cpp (addMapPoints / apply) and SL_SingleSLAM.cpp
                                        (chooseStaticFeatPts ...) compiled in place over the shims.
@@ -39,6 +40,14 @@ def _run(exe, ok_text):
 
 def test_reference_gpuklt_source_runs_over_the_shim_and_matches_the_device_handback(hip):
     out = _run(os.path.join(ROOT, "oracle", "_ref", "ref_gpuklt_dropin_test"), "ref GPUKLT drop-in ok")
+    print(out)
+
+
+def test_lazy_feature_list_adaptor_leaves_the_lists_as_the_reference_would(hip):
+    """SURVEY 8f-1, second half (include/shim/tracking/GPUKLTGroup.h): three cameras' frames run as a device-resident group, the reference's
+    FeaturePoints / Track2D lists rebuilt only at frames 4, 9 and 13 -- tracks, frame lists and the reference's own
+    SingleSLAM::chooseStaticFeatPts / getNumMappedStaticPts equal the synchronous drop-in's"""
+    out = _run(os.path.join(ROOT, "oracle", "_ref", "ref_lazy_adaptor_test"), "lazy adaptor ok")
     print(out)
 
 
