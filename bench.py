@@ -761,6 +761,8 @@ def main():
                                                          int(loop._dec["scr"][-4:].view(torch.int32).item()))
     digest = loop.digest() if os.environ.get("BENCH_STATE_DIGEST") else None
     map_in_use_timed_end = int(loop.d_mapcount.item())   # (as of the end of the timed region: the secondary legs run the loop on)
+    if loop._marks is not None:
+        print("[pose stream, GPU us per section]", json.dumps(loop.gpu_sections(first_frame=args.warmup), indent=1), file=sys.stderr)
     if loop._timing is not None:
         print("[frameloop host seconds by section]", {k: round(v, 4) for k, v in loop._timing.items()}, file=sys.stderr)
     n_timed_end = n_done

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void k_np_prep(NpArgs A) {
     __shared__ int wTot[4];
     __shared__ int sBase;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, N = A.N, C = A.nCams, nP = C - 1;
+    if (blockIdx.x == 0 && A.counts && tid < 4 + C) A.counts[tid] = 0;   // (the kernels behind this one add to them; was a launch of its own)
     if ((int)blockIdx.x < nP * NP_SEGS) {
         const int a = blockIdx.x / NP_SEGS, seg = blockIdx.x % NP_SEGS, b = a + 1;
         const int cap = *A.mapCount < A.mapCap ? *A.mapCount : A.mapCap;
@@ -224,16 +225,29 @@ __global__ __launch_bounds__(256) void k_np_match(NpArgs A) {
     for (int q = tid; q < nWords; q += 256) A.rowMask[(size_t)a * nWords + q] = sRow[q], A.colMask[(size_t)a * nWords + q] = sCol[q];
 }
 
-struct NpView {
-    int c, s;
+// ---- featTracksFromMatches + reconstructTracks + output: one workgroup, EIGHT LANES PER TRACK ------------------------------------------
+// (Round 5's form gave a track to a lane: its views in a private array -- scratch memory --, every view's projections, divisions and
+// square roots one after the other, and decidePointType's scan of the dynamic features' list by that one lane: 134 us on average for
+// at most three tracks, profiles/r05_headline_bench_kernel_stats.md.)  A track's views are the cameras a0, a0 + 1, ..: lane r of the
+// track's group holds views r and r + 8 in registers, computes their terms side by side, and the sums the reference takes view after
+// view (:205-246) are taken in THAT order by fetching the terms lane by lane -- same additions, same order, same bits.  32 tracks per
+// round of the 256 threads.
+constexpr int NP_LPT = 8;                       // lanes per track
+constexpr int NP_TPB = 256 / NP_LPT;            // tracks per round
+static_assert(NP_MAX_CAMS <= 2 * NP_LPT, "a lane holds two views of a track");
+
+struct NpTerm {   // what ONE view adds to the sums
+    double n[6], g[3];
 };
-// one workgroup: featTracksFromMatches + reconstructTracks + output
+__device__ __forceinline__ double np_pick(double a, double b, bool second) { return second ? b : a; }
+__device__ __forceinline__ int np_pick_i(int a, int b, bool second) { return second ? b : a; }
+
 __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
-    __shared__ int sScan[256];
-    __shared__ int sBase, sNTracks;
+    __shared__ int sBase, sNTracks, sWave[4];
     __shared__ unsigned sTrk[NP_MAX_TRACKS];             // first camera of the track << 16 | its slot there
-    __shared__ unsigned char sValid[NP_MAX_TRACKS];
+    __shared__ int sDynOff[NP_MAX_CAMS + 2];
     const int tid = threadIdx.x, N = A.N, C = A.nCams, nP = C - 1;
+    const int lane = tid & 63, wv = tid >> 6, r = tid & (NP_LPT - 1), gbase = lane & ~(NP_LPT - 1);
     if (tid == 0) sBase = 0, sNTracks = 0;
     __syncthreads();
     // ---- the tracks' starts in the order (pair, feature): (a, i) matched and not the continuation of a track of pair a - 1 (some
@@ -249,15 +263,21 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
             if (a > 0) bits &= ~A.colMask[(size_t)(a - 1) * nWords + q];
         }
         const int cnt = __popc(bits);
-        sScan[tid] = cnt;
-        __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {
-            const int v = tid >= d ? sScan[tid - d] : 0;
-            __syncthreads();
-            sScan[tid] += v;
-            __syncthreads();
+        // inclusive scan of cnt over the block: inside the wave by shuffles, the waves' totals through LDS
+        int inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += v;
         }
-        int rank = sNTracks + sScan[tid] - cnt;
+        if (lane == 63) sWave[wv] = inc;
+        __syncthreads();
+        int before = inc - cnt, total = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (k < wv) before += sWave[k];
+            total += sWave[k];
+        }
+        int rank = sNTracks + before;
         while (bits) {
             const int bit = __ffs(bits) - 1;
             bits &= bits - 1;
@@ -265,137 +285,205 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
             ++rank;
         }
         __syncthreads();
-        if (tid == 255) sNTracks = min(sNTracks + sScan[255], NP_MAX_TRACKS);
+        if (tid == 0) sNTracks = min(sNTracks + total, NP_MAX_TRACKS);
         __syncthreads();
     }
     const int nTracks = sNTracks;
     int nLong = 0;
-    // ---- reconstructTracks (:194-270), a lane per track
-    for (int t0 = 0; t0 < nTracks; t0 += 256) {
-        const int tk = t0 + tid;
-        NpView v[NP_MAX_CAMS];
-        int nv = 0;
-        bool valid = false;
-        double M[3] = {0, 0, 0}, cov[9], err[NP_MAX_CAMS];
-        unsigned char fl = 0;
+    // ---- reconstructTracks (:194-270), eight lanes per track
+    for (int t0 = 0; t0 < nTracks; t0 += NP_TPB) {
+        const int tk = t0 + tid / NP_LPT;
+        // the chain: camera c's slot s matched into camera c + 1 (every lane of the group walks it; view k lives in lane k & 7)
+        int nv = 0, c0 = 0, vs0 = -1, vs1 = -1;
         if (tk < nTracks) {
-            int c = (int)(sTrk[tk] >> 16), s = (int)(sTrk[tk] & 0xFFFFu);
-            v[nv].c = c, v[nv].s = s, ++nv;
-            while (c < nP) {   // follow the chain: camera c's slot s matched into camera c + 1
-                if (!((A.rowMask[(size_t)c * nWords + (s >> 5)] >> (s & 31)) & 1u)) break;
-                const int m = A.matchIdx[(size_t)c * N + s];
-                ++c, s = m;
-                v[nv].c = c, v[nv].s = s, ++nv;
+            int c = (int)(sTrk[tk] >> 16), sl = (int)(sTrk[tk] & 0xFFFFu);
+            c0 = c;
+            for (;;) {
+                if ((nv & (NP_LPT - 1)) == r) (nv < NP_LPT ? vs0 : vs1) = sl;
+                ++nv;
+                if (c >= nP || !((A.rowMask[(size_t)c * nWords + (sl >> 5)] >> (sl & 31)) & 1u)) break;
+                sl = A.matchIdx[(size_t)c * N + sl];
+                ++c;
             }
-            if (nv >= A.minLen) {
-                ++nLong;
-                // triangulateMultiView over the views' normalised points
-                double Nn[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-                for (int k = 0; k < nv; ++k) {
-                    const cs_poseupdate_cam& Cm = A.cam[v[k].c];
-                    const double* R = A.R + 9 * v[k].c;
-                    const double* t = A.t + 3 * v[k].c;
-                    const double mx = Cm.xy[v[k].s], my = Cm.xy[N + v[k].s];
-                    const double* iK = Cm.iK;
-                    const double w = (iK[6] * mx + iK[7] * my) + iK[8];
-                    const double x = ((iK[0] * mx + iK[1] * my) + iK[2]) / w, y = ((iK[3] * mx + iK[4] * my) + iK[5]) / w;   // normPoint
-                    const double a0[3] = {R[0] - x * R[6], R[1] - x * R[7], R[2] - x * R[8]}, a1[3] = {R[3] - y * R[6], R[4] - y * R[7], R[5] - y * R[8]};
-                    const double b0 = x * t[2] - t[0], b1 = y * t[2] - t[1];
-                    Nn[0] = Nn[0] + (a0[0] * a0[0] + a1[0] * a1[0]);
-                    Nn[1] = Nn[1] + (a0[0] * a0[1] + a1[0] * a1[1]);
-                    Nn[2] = Nn[2] + (a0[0] * a0[2] + a1[0] * a1[2]);
-                    Nn[3] = Nn[3] + (a0[1] * a0[1] + a1[1] * a1[1]);
-                    Nn[4] = Nn[4] + (a0[1] * a0[2] + a1[1] * a1[2]);
-                    Nn[5] = Nn[5] + (a0[2] * a0[2] + a1[2] * a1[2]);
-                    for (int q = 0; q < 3; ++q) g[q] = g[q] + (a0[q] * b0 + a1[q] * b1);
+        }
+        const bool lng = tk < nTracks && nv >= A.minLen;
+        if (lng && r == 0) ++nLong;
+        bool valid = false;
+        double M[3] = {0, 0, 0}, cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, err0 = 0, err1 = 0;
+        unsigned char fl = 0;
+        // (the whole wave goes through the phases together -- the shuffles need every lane -- with `lng` guarding the work)
+        {
+            // phase A: a view's terms of triangulateMultiView's normal equations (normPoint, the two rows, :205-216)
+            NpTerm T0, T1;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                NpTerm& T = kk ? T1 : T0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) T.n[q] = 0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) T.g[q] = 0;
+                const int k = r + NP_LPT * kk, sl = kk ? vs1 : vs0;
+                if (!lng || k >= nv) continue;
+                const int cam = c0 + k;
+                const cs_poseupdate_cam& Cm = A.cam[cam];
+                const double* R = A.R + 9 * cam;
+                const double* t = A.t + 3 * cam;
+                const double mx = Cm.xy[sl], my = Cm.xy[N + sl];
+                const double* iK = Cm.iK;
+                const double w = (iK[6] * mx + iK[7] * my) + iK[8];
+                const double x = ((iK[0] * mx + iK[1] * my) + iK[2]) / w, y = ((iK[3] * mx + iK[4] * my) + iK[5]) / w;   // normPoint
+                const double a0[3] = {R[0] - x * R[6], R[1] - x * R[7], R[2] - x * R[8]}, a1[3] = {R[3] - y * R[6], R[4] - y * R[7], R[5] - y * R[8]};
+                const double b0 = x * t[2] - t[0], b1 = y * t[2] - t[1];
+                T.n[0] = a0[0] * a0[0] + a1[0] * a1[0];
+                T.n[1] = a0[0] * a0[1] + a1[0] * a1[1];
+                T.n[2] = a0[0] * a0[2] + a1[0] * a1[2];
+                T.n[3] = a0[1] * a0[1] + a1[1] * a1[1];
+                T.n[4] = a0[1] * a0[2] + a1[1] * a1[2];
+                T.n[5] = a0[2] * a0[2] + a1[2] * a1[2];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) T.g[q] = a0[q] * b0 + a1[q] * b1;
+            }
+            // the sums view after view, as the reference takes them
+            double Nn[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+            for (int k = 0; k < NP_MAX_CAMS; ++k) {
+                if (!__builtin_amdgcn_ballot_w64(lng && k < nv)) break;
+                const int src = gbase + (k & (NP_LPT - 1));
+                const bool second = k >= NP_LPT;
+                double tn[6], tg[3];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) tn[q] = __shfl(np_pick(T0.n[q], T1.n[q], second), src, 64);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) tg[q] = __shfl(np_pick(T0.g[q], T1.g[q], second), src, 64);
+                if (lng && k < nv) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) Nn[q] = Nn[q] + tn[q];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) g[q] = g[q] + tg[q];
                 }
-                double cf[6];
+            }
+            double cf[6];
+            if (lng) {
                 cf[0] = Nn[3] * Nn[5] - Nn[4] * Nn[4], cf[1] = Nn[2] * Nn[4] - Nn[1] * Nn[5], cf[2] = Nn[1] * Nn[4] - Nn[2] * Nn[3];
                 cf[3] = Nn[0] * Nn[5] - Nn[2] * Nn[2], cf[4] = Nn[1] * Nn[2] - Nn[0] * Nn[4], cf[5] = Nn[0] * Nn[3] - Nn[1] * Nn[1];
                 const double det = (Nn[0] * cf[0] + Nn[1] * cf[1]) + Nn[2] * cf[2];
                 M[0] = ((cf[0] * g[0] + cf[1] * g[1]) + cf[2] * g[2]) / det;
                 M[1] = ((cf[1] * g[0] + cf[3] * g[1]) + cf[4] * g[2]) / det;
                 M[2] = ((cf[2] * g[0] + cf[4] * g[1]) + cf[5] * g[2]) / det;
-                // every view: within maxRpErr of the re-projection and in front of the camera (:226-236); J^T J for the covariance
-                bool outlier = false;
-                double S[6] = {0, 0, 0, 0, 0, 0};
-                for (int k = 0; k < nv; ++k) {
-                    const cs_poseupdate_cam& Cm = A.cam[v[k].c];
-                    const double* K = Cm.K;
-                    const double* R = A.R + 9 * v[k].c;
-                    const double* t = A.t + 3 * v[k].c;
-                    const double X = ((R[0] * M[0] + R[1] * M[1]) + R[2] * M[2]) + t[0];
-                    const double Y = ((R[3] * M[0] + R[4] * M[1]) + R[5] * M[2]) + t[1];
-                    const double Z = ((R[6] * M[0] + R[7] * M[1]) + R[8] * M[2]) + t[2];
-                    const double u = (K[0] * X + K[1] * Y) + K[2] * Z, vv = (K[3] * X + K[4] * Y) + K[5] * Z, w = (K[6] * X + K[7] * Y) + K[8] * Z;
-                    const double dx = Cm.xy[v[k].s] - u / w, dy = Cm.xy[N + v[k].s] - vv / w;
-                    err[k] = sqrt(dx * dx + dy * dy);
-                    if (err[k] > A.maxRpErr || Z < 0) outlier = true;
-                    double KR[9], J[6];
-                    for (int i = 0; i < 3; ++i)
-                        for (int j = 0; j < 3; ++j) KR[3 * i + j] = (K[3 * i] * R[j] + K[3 * i + 1] * R[3 + j]) + K[3 * i + 2] * R[6 + j];
-                    const double ww = w * w;
-                    for (int j = 0; j < 3; ++j) J[j] = (KR[j] * w - u * KR[6 + j]) / ww, J[3 + j] = (KR[3 + j] * w - vv * KR[6 + j]) / ww;
-                    S[0] = S[0] + (J[0] * J[0] + J[3] * J[3]);
-                    S[1] = S[1] + (J[0] * J[1] + J[3] * J[4]);
-                    S[2] = S[2] + (J[0] * J[2] + J[3] * J[5]);
-                    S[3] = S[3] + (J[1] * J[1] + J[4] * J[4]);
-                    S[4] = S[4] + (J[1] * J[2] + J[4] * J[5]);
-                    S[5] = S[5] + (J[2] * J[2] + J[5] * J[5]);
-                }
-                if (!outlier) {
-                    valid = true;
-                    cf[0] = S[3] * S[5] - S[4] * S[4], cf[1] = S[2] * S[4] - S[1] * S[5], cf[2] = S[1] * S[4] - S[2] * S[3];
-                    cf[3] = S[0] * S[5] - S[2] * S[2], cf[4] = S[1] * S[2] - S[0] * S[4], cf[5] = S[0] * S[3] - S[1] * S[1];
-                    const double dS = (S[0] * cf[0] + S[1] * cf[1]) + S[2] * cf[2], s2 = A.sigma * A.sigma;
-                    cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
-                    cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
-                    cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
-                    int nDyn = 0;
-                    for (int k = 0; k < nv; ++k) {
-                        const cs_poseupdate_cam& Cm = A.cam[v[k].c];
-                        if (Cm.isStatic && !Cm.isStatic[v[k].s]) ++nDyn;                         // TYPE_FEATPOINT_DYNAMIC (:250-251)
-                    }
-                    if (nDyn > 1) {
-                        fl = CS_MAP_DYNAMIC;                                                     // :253-254
-                    } else {
-                        // :263-264 setUncertain(); decidePointType below may make it certain static
-                        fl = CS_MAP_UNCERTAIN;
-                    }
+            }
+            // phase B: every view within maxRpErr of the re-projection and in front of the camera (:226-236); its J^T J for the covariance
+            double S0[6], S1[6];
+            bool out = false, dyn0 = false, dyn1 = false;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                double* Sx = kk ? S1 : S0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) Sx[q] = 0;
+                const int k = r + NP_LPT * kk, sl = kk ? vs1 : vs0;
+                if (!lng || k >= nv) continue;
+                const int cam = c0 + k;
+                const cs_poseupdate_cam& Cm = A.cam[cam];
+                const double* K = Cm.K;
+                const double* R = A.R + 9 * cam;
+                const double* t = A.t + 3 * cam;
+                const double X = ((R[0] * M[0] + R[1] * M[1]) + R[2] * M[2]) + t[0];
+                const double Y = ((R[3] * M[0] + R[4] * M[1]) + R[5] * M[2]) + t[1];
+                const double Z = ((R[6] * M[0] + R[7] * M[1]) + R[8] * M[2]) + t[2];
+                const double u = (K[0] * X + K[1] * Y) + K[2] * Z, vv = (K[3] * X + K[4] * Y) + K[5] * Z, w = (K[6] * X + K[7] * Y) + K[8] * Z;
+                const double dx = Cm.xy[sl] - u / w, dy = Cm.xy[N + sl] - vv / w;
+                const double e = sqrt(dx * dx + dy * dy);
+                (kk ? err1 : err0) = e;
+                if (e > A.maxRpErr || Z < 0) out = true;
+                if (Cm.isStatic && !Cm.isStatic[sl]) (kk ? dyn1 : dyn0) = true;       // TYPE_FEATPOINT_DYNAMIC (:250-251)
+                double KR[9], J[6];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) KR[3 * i + j] = (K[3 * i] * R[j] + K[3 * i + 1] * R[3 + j]) + K[3 * i + 2] * R[6 + j];
+                const double ww = w * w;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) J[j] = (KR[j] * w - u * KR[6 + j]) / ww, J[3 + j] = (KR[3 + j] * w - vv * KR[6 + j]) / ww;
+                Sx[0] = J[0] * J[0] + J[3] * J[3];
+                Sx[1] = J[0] * J[1] + J[3] * J[4];
+                Sx[2] = J[0] * J[2] + J[3] * J[5];
+                Sx[3] = J[1] * J[1] + J[4] * J[4];
+                Sx[4] = J[1] * J[2] + J[4] * J[5];
+                Sx[5] = J[2] * J[2] + J[5] * J[5];
+            }
+            double S[6] = {0, 0, 0, 0, 0, 0};
+            int nDyn = (dyn0 ? 1 : 0) + (dyn1 ? 1 : 0);
+            for (int k = 0; k < NP_MAX_CAMS; ++k) {
+                if (!__builtin_amdgcn_ballot_w64(lng && k < nv)) break;
+                const int src = gbase + (k & (NP_LPT - 1));
+                const bool second = k >= NP_LPT;
+                double ts[6];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) ts[q] = __shfl(np_pick(S0[q], S1[q], second), src, 64);
+                if (lng && k < nv) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) S[q] = S[q] + ts[q];
                 }
             }
-            sValid[tk] = valid ? 1 : 0;
+            // any view an outlier / the number of DYNAMIC features: over the group's lanes
+#pragma unroll
+            for (int o = 1; o < NP_LPT; o <<= 1) {
+                out |= __shfl_xor((int)out, o, 64) != 0;
+                nDyn += __shfl_xor(nDyn, o, 64);
+            }
+            if (lng && !out) {
+                valid = true;
+                cf[0] = S[3] * S[5] - S[4] * S[4], cf[1] = S[2] * S[4] - S[1] * S[5], cf[2] = S[1] * S[4] - S[2] * S[3];
+                cf[3] = S[0] * S[5] - S[2] * S[2], cf[4] = S[1] * S[2] - S[0] * S[4], cf[5] = S[0] * S[3] - S[1] * S[1];
+                const double dS = (S[0] * cf[0] + S[1] * cf[1]) + S[2] * cf[2], s2 = A.sigma * A.sigma;
+                cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
+                cov[3] = cov[1], cov[4] = (cf[3] / dS) * s2, cov[5] = (cf[4] / dS) * s2;
+                cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
+                // more than one DYNAMIC feature: dynamic (:253-254); else uncertain (:263-264; decidePointType below may make it certain static)
+                fl = nDyn > 1 ? CS_MAP_DYNAMIC : CS_MAP_UNCERTAIN;
+            }
         }
-        // the valid tracks of this batch take consecutive map indices in track order
-        sScan[tid] = valid ? 1 : 0;
+        // the valid tracks of this round take consecutive map indices in track order
+        const unsigned long long lead = __builtin_amdgcn_ballot_w64(valid && r == 0);
+        if (lane == 0) sWave[wv] = __popcll(lead);
         __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {
-            const int x = tid >= d ? sScan[tid - d] : 0;
-            __syncthreads();
-            sScan[tid] += x;
-            __syncthreads();
+        int before = sBase + __popcll(lead & ((1ull << gbase) - 1ull)), total = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (k < wv) before += sWave[k];
+            total += sWave[k];
         }
-        const int before = sBase + sScan[tid] - (valid ? 1 : 0);
         const int m = *A.mapCount + before;
         if (valid) {
             if (m < A.mapCap) {
-                for (int q = 0; q < 3; ++q) A.mapPts[3 * (size_t)m + q] = M[q];
-                for (int q = 0; q < 9; ++q) A.mapCov[9 * (size_t)m + q] = cov[q];
-                A.mapFlags[m] = fl, A.newPt[m] = 1, A.firstFrame[m] = A.curFrame;
-                for (int c = 0; c < C; ++c) A.pointFeat[(size_t)m * C + c] = -1;
-                for (int k = 0; k < nv; ++k) {
-                    A.pointFeat[(size_t)m * C + v[k].c] = v[k].s;          // MapPoint::addFeature
-                    const_cast<int*>(A.cam[v[k].c].slot2map)[v[k].s] = m;  // the feature (and its track) takes the point (:168-172)
-                    if (A.cam[v[k].c].reprojErr) A.cam[v[k].c].reprojErr[v[k].s] = err[k];   // fp->reprojErr (:247-248)
+                if (r < 3) A.mapPts[3 * (size_t)m + r] = M[r];
+                // (cov[] is indexed by a lane-dependent subscript below: select instead, the array stays in registers)
+                double cr = cov[0];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) cr = r == q ? cov[q] : cr;
+                A.mapCov[9 * (size_t)m + r] = cr;
+                if (r == 0) A.mapCov[9 * (size_t)m + 8] = cov[8], A.mapFlags[m] = fl, A.newPt[m] = 1, A.firstFrame[m] = A.curFrame;
+                // MapPoint::addFeature: camera c0 + k's column takes view k's slot, every other column -1 (ONE store per column)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int c = r + NP_LPT * kk, k = c - c0;   // column c; the view there, if any
+                    const int kSafe = (k >= 0 && k < nv) ? k : 0;
+                    const int sv = __shfl(np_pick_i(vs0, vs1, kSafe >= NP_LPT), gbase + (kSafe & (NP_LPT - 1)), 64);
+                    if (c < C) A.pointFeat[(size_t)m * C + c] = (k >= 0 && k < nv) ? sv : -1;
                 }
-            } else if (A.counts) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int k = r + NP_LPT * kk, sl = kk ? vs1 : vs0;
+                    if (k >= nv) continue;
+                    const_cast<int*>(A.cam[c0 + k].slot2map)[sl] = m;   // the feature (and its track) takes the point (:168-172)
+                    if (A.cam[c0 + k].reprojErr) A.cam[c0 + k].reprojErr[sl] = kk ? err1 : err0;   // fp->reprojErr (:247-248)
+                }
+            } else if (A.counts && r == 0) {
                 atomicOr(A.counts + 3, 2);
             }
         }
         __syncthreads();
-        if (tid == 255) sBase += sScan[255];
+        if (tid == 0) sBase += total;
         __syncthreads();
     }
+    // (nLong: counted by the groups' first lanes)
     if (nLong && A.counts) atomicAdd(A.counts + 2, nLong);
     __syncthreads();
     const int first = *A.mapCount;
@@ -410,21 +498,22 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
     for (int q = tid; q < added; q += 256) anyUncertain |= A.mapFlags[first + q] == CS_MAP_UNCERTAIN;
     if (__syncthreads_or(anyUncertain ? 1 : 0)) {
         __shared__ int sNDyn;
-        unsigned* sDyn = sTrk;   // the tracks' table is done with: [NP_MAX_DYN] camera << 24 | (y + 64) << 12 | (x + 64)
+        unsigned* sDyn = sTrk;   // the tracks' table is done with: [NP_MAX_DYN] (y + 64) << 12 | (x + 64), camera after camera
         static_assert(NP_MAX_TRACKS >= NP_MAX_DYN && NP_MAX_CAMS <= 256 && NP_MAX_N <= 65536, "the dynamic features' list reuses the track table");
-        // the existing certain dynamic points' features: k_np_prep's per-camera lists, camera after camera
+        // the existing certain dynamic points' features: k_np_prep's per-camera lists, camera c at [sDynOff[c], sDynOff[c + 1])
         int off = 0;
         bool over = false;
         for (int c = 0; c < C; ++c) {
             int n = A.dynCnt[c];
             if (n > NP_DYN_PER_CAM) n = NP_DYN_PER_CAM, over = true;
-            for (int k = tid; k < n; k += 256)
-                if (off + k < NP_MAX_DYN) sDyn[off + k] = ((unsigned)c << 24) | A.dynList[(size_t)c * NP_DYN_PER_CAM + k];
+            if (off + n > NP_MAX_DYN) n = NP_MAX_DYN - off, over = true;
+            if (tid == 0) sDynOff[c] = off;
+            for (int k = tid; k < n; k += 256) sDyn[off + k] = A.dynList[(size_t)c * NP_DYN_PER_CAM + k];
             off += n;
         }
-        if (tid == 0) sNDyn = off;
+        if (tid == 0) sDynOff[C] = off, sNDyn = off;
         __syncthreads();
-        // ... and this run's new dynamic points: reconstructTracks' addFeature already gave their features the point
+        // ... and this run's new dynamic points (rare), behind them with their camera in the top byte
         for (int q = tid; q < added; q += 256) {
             const int m = first + q;
             if (A.mapFlags[m] != CS_MAP_DYNAMIC) continue;
@@ -442,26 +531,34 @@ __global__ __launch_bounds__(256) void k_np_reconstruct(NpArgs A) {
         int nDynF = sNDyn;
         if (nDynF > NP_MAX_DYN) nDynF = NP_MAX_DYN, over = true;
         if (over && tid == 0 && A.counts) atomicOr(A.counts + 3, 4);
-        for (int q = tid; q < added; q += 256) {
-            const int m = first + q;
-            if (A.mapFlags[m] != CS_MAP_UNCERTAIN) continue;
-            bool isStatic = true;
-            for (int c = 0; c < C && isStatic; ++c) {
-                const int sl = A.pointFeat[(size_t)m * C + c];
-                if (sl < 0) continue;
-                const int x = (int)(A.cam[c].xy[sl] + 0.5), y = (int)(A.cam[c].xy[N + sl] + 0.5);
-                if (x < 0 || x >= A.W || y < 0 || y >= A.H) continue;
-                for (int k = 0; k < nDynF; ++k) {
-                    const unsigned d = sDyn[k];
-                    if ((int)(d >> 24) != c) continue;
-                    const int dx = (int)(d & 0xFFFu) - 64 - x, dy = (int)((d >> 12) & 0xFFFu) - 64 - y;
-                    if (dx >= -20 && dx <= 20 && dy >= -20 && dy <= 20) {
-                        isStatic = false;
-                        break;
+        const int offNew = sDynOff[C];
+        // eight lanes per new point: a camera's list and this run's tail in strides of eight
+        for (int q0 = 0; q0 < added; q0 += NP_TPB) {
+            const int q = q0 + tid / NP_LPT, m = first + q;
+            const bool unc = q < added && A.mapFlags[m] == CS_MAP_UNCERTAIN;
+            bool hit = false;
+            if (unc) {
+                for (int c = 0; c < C; ++c) {
+                    const int sl = A.pointFeat[(size_t)m * C + c];
+                    if (sl < 0) continue;
+                    const int x = (int)(A.cam[c].xy[sl] + 0.5), y = (int)(A.cam[c].xy[N + sl] + 0.5);
+                    if (x < 0 || x >= A.W || y < 0 || y >= A.H) continue;
+                    for (int k = sDynOff[c] + r; k < sDynOff[c + 1]; k += NP_LPT) {
+                        const unsigned d = sDyn[k];
+                        const int dx = (int)(d & 0xFFFu) - 64 - x, dy = (int)((d >> 12) & 0xFFFu) - 64 - y;
+                        hit |= dx >= -20 && dx <= 20 && dy >= -20 && dy <= 20;
+                    }
+                    for (int k = offNew + r; k < nDynF; k += NP_LPT) {
+                        const unsigned d = sDyn[k];
+                        if ((int)(d >> 24) != c) continue;
+                        const int dx = (int)(d & 0xFFFu) - 64 - x, dy = (int)((d >> 12) & 0xFFFu) - 64 - y;
+                        hit |= dx >= -20 && dx <= 20 && dy >= -20 && dy <= 20;
                     }
                 }
             }
-            if (isStatic) A.mapFlags[m] = 0;
+#pragma unroll
+            for (int o = 1; o < NP_LPT; o <<= 1) hit |= __shfl_xor((int)hit, o, 64) != 0;
+            if (unc && !hit && r == 0) A.mapFlags[m] = 0;
         }
     }
     if (tid == 0) {
@@ -551,11 +648,6 @@ extern "C" int cs_newpts_from_pairs_dev(int device, void* hip_stream, int nCams,
     A.counts = d_counts;
     CS_HIP(hipSetDevice(device));
     hipStream_t s = (hipStream_t)hip_stream;
-    if (d_counts) {
-        cs_small::List ops;
-        ops.fill(d_counts, 0, sizeof(int) * (4 + (size_t)nCams));
-        CS_HIP(ops.run(s));
-    }
     hipLaunchKernelGGL(k_np_prep, dim3((nCams - 1) * NP_SEGS + nCams), dim3(256), 0, s, A);
     hipLaunchKernelGGL(k_np_match, dim3(nCams - 1), dim3(256), 0, s, A);
     hipLaunchKernelGGL(k_np_reconstruct, dim3(1), dim3(256), 0, s, A);

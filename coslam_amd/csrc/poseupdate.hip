@@ -72,6 +72,14 @@ struct PuArgs {
     int minLen, minOutNum;
     double maxEpiErr;
     int* numDyn;  // [nCams] or null
+    // fused behind the gate (cs_pose_update_classify_frame_dev): mapPointsClassify's worklist -- what k_classify_select builds -- by the
+    // gate's own lane of a map point, and the camera centres by walk depth in blocks of their own (k_ring_centres); null / 0: not fused
+    int* clsList;              // [2 + nMap]: counters of the two parities, then the list
+    int clsPar, clsCurFrame;
+    int* clsCounts;            // mapPointsClassify's counts [2] or null: [1] is reset here (the worker adds to it)
+    const int* clsFeatFrame;   // [nMap][nCams] or null
+    double* cenOut;            // [nCams][nHist][3] or null
+    int cenBlocks;
     cs_poseupdate_cam cam[PU_MAX_CAMS];
 };
 
@@ -225,6 +233,8 @@ __device__ __forceinline__ void pu_fmat(const double* __restrict__ iK, const dou
     pu_mat33_ab(T, iK, F);
 }
 
+__device__ __forceinline__ void up_cam_center(const double* __restrict__ R, const double* __restrict__ t, double* C);
+
 __global__ __launch_bounds__(256) void k_pose_update(PuArgs A) {
     extern __shared__ double Fs[];  // dynamic role: [nHist][9]
     CS_POSE_STREAM_PRIO();
@@ -232,6 +242,29 @@ __global__ __launch_bounds__(256) void k_pose_update(PuArgs A) {
     if ((int)blockIdx.x < A.gateBlocks) {
         const int m = blockIdx.x * 256 + tid;
         if (m < A.nMap) pu_gate_point(A, m);
+        if (A.clsList) {   // k_classify_select's test, by the lane that has just finished the point's gate (every camera's, in camera order)
+            if (m == 0 && A.clsCounts) A.clsCounts[1] = 0;
+            if (m < A.nMap) {
+                const unsigned char fl = A.mapFlags[m];
+                if ((fl & CS_MAP_UNCERTAIN) || (fl & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) == CS_MAP_DYNAMIC) {  // SL_CoSLAM.cpp:431
+                    bool vis = false;
+                    for (int c = 0; c < A.nCams && !vis; ++c) {
+                        const int sl = A.pointFeat[(size_t)m * A.nCams + c];
+                        vis = sl >= 0 && (A.clsFeatFrame ? A.clsFeatFrame[(size_t)m * A.nCams + c] : A.clsCurFrame) == A.clsCurFrame;
+                    }
+                    if (vis) A.clsList[2 + atomicAdd(A.clsList + A.clsPar, 1)] = m;
+                }
+            }
+        }
+        return;
+    }
+    if ((int)blockIdx.x >= (int)gridDim.x - A.cenBlocks) {   // the camera centres by walk depth; depth 0 = this frame's pose, given
+        const int q = (blockIdx.x - (gridDim.x - A.cenBlocks)) * 256 + tid;
+        if (q < A.nCams * A.nHist) {
+            const int c = q / A.nHist, j = q - c * A.nHist, rs = (A.head - j + A.H) % A.H;
+            if (j == 0) up_cam_center(A.R + 9 * c, A.t + 3 * c, A.cenOut + 3 * (size_t)q);
+            else up_cam_center(A.histR + ((size_t)c * A.H + rs) * 9, A.histT + ((size_t)c * A.H + rs) * 3, A.cenOut + 3 * (size_t)q);
+        }
         return;
     }
     const int b = blockIdx.x - A.gateBlocks;
@@ -1831,7 +1864,8 @@ int pu_launch(const char* who, int device, void* hip_stream, PuArgs& A, const cs
     if (gate && A.numOut) CS_HIP(hipMemsetAsync(A.numOut + A.cam0, 0, sizeof(int) * A.nCamsRun, s));
     if (dyn && A.numDyn) CS_HIP(hipMemsetAsync(A.numDyn + A.cam0, 0, sizeof(int) * A.nCamsRun, s));
     const size_t lds = dyn ? sizeof(double) * 9 * (size_t)(A.nHist > 0 ? A.nHist : 1) : 0;
-    hipLaunchKernelGGL(k_pose_update, dim3(A.gateBlocks + dynBlocks), dim3(256), lds, s, A);
+    A.cenBlocks = A.cenOut ? (A.nCams * A.nHist + 255) / 256 : 0;
+    hipLaunchKernelGGL(k_pose_update, dim3(A.gateBlocks + dynBlocks + A.cenBlocks), dim3(256), lds, s, A);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }
@@ -2713,10 +2747,13 @@ extern "C" int cs_register_decide_merge_list_dev(const cs_track_history* h, void
     return CS_OK;
 }
 
-extern "C" int cs_map_points_classify_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int* d_pointFeat,
+static int cls_reserve_list(const cs_track_history* h, int nMap, hipStream_t s);
+
+// selectFused: k_pose_update has already built the worklist of this parity and the centres (cs_pose_update_classify_frame_dev): the worker only
+static int cls_run(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int* d_pointFeat,
                                           int nMap, const int* d_featFrame, const int* d_featFirst, int curFrame, double* d_mapPts,
                                           double* d_mapCov, unsigned char* d_mapFlags, unsigned char* d_newPt, int* d_staticFrameNum,
-                                          const int* d_firstFrame, double pixelVar, int* d_counts) {
+                                          const int* d_firstFrame, double pixelVar, int* d_counts, bool selectFused, int fusedPar) {
     if (!h || !cams || nMap < 0 ||
         (nMap > 0 && (!d_pointFeat || !d_mapPts || !d_mapCov || !d_mapFlags || !d_newPt || !d_staticFrameNum || !d_firstFrame))) {
         cs_set_error("cs_map_points_classify_dev: bad arguments");
@@ -2749,18 +2786,81 @@ extern "C" int cs_map_points_classify_dev(const cs_track_history* h, void* hip_s
         if (d_counts) CS_HIP(hipMemsetAsync(d_counts, 0, 2 * sizeof(int), s));
         return CS_OK;
     }
-    if (nMap > h->clsCap) {   // (a larger map than any before: the only allocation, and it waits for the device)
+    {
+        const int rc_ = cls_reserve_list(h, nMap, s);
+        if (rc_ != CS_OK) return rc_;
+    }
+    A.list = h->clsList;
+    if (selectFused) {
+        A.par = fusedPar;   // (the parity the fused kernel listed into; cls_reserve_list moved h->clsPar on)
+    } else {
+        A.par = h->clsPar;
+        h->clsPar ^= 1;
+        hist_centres(h, s);
+        hipLaunchKernelGGL(k_classify_select, dim3((nMap + 255) / 256), dim3(256), 0, s, A);
+    }
+    hipLaunchKernelGGL(k_map_points_classify, dim3(CLS_WAVES / 4), dim3(256), 0, s, A);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+extern "C" int cs_map_points_classify_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int* d_pointFeat,
+                                          int nMap, const int* d_featFrame, const int* d_featFirst, int curFrame, double* d_mapPts,
+                                          double* d_mapCov, unsigned char* d_mapFlags, unsigned char* d_newPt, int* d_staticFrameNum,
+                                          const int* d_firstFrame, double pixelVar, int* d_counts) {
+    return cls_run(h, hip_stream, cams, d_pointFeat, nMap, d_featFrame, d_featFirst, curFrame, d_mapPts, d_mapCov, d_mapFlags, d_newPt,
+                   d_staticFrameNum, d_firstFrame, pixelVar, d_counts, false, 0);
+}
+
+// the worklist's storage for a map of nMap points (grown on first use / for a larger map: the only allocation, and it waits for the device)
+static int cls_reserve_list(const cs_track_history* h, int nMap, hipStream_t s) {
+    if (nMap > h->clsCap) {
         if (h->clsList) CS_HIP(hipFree(h->clsList));
         h->clsList = nullptr, h->clsCap = 0;
         CS_HIP(hipMalloc((void**)&h->clsList, sizeof(int) * (2 + (size_t)nMap)));
         CS_HIP(hipMemsetAsync(h->clsList, 0, 2 * sizeof(int), s));
         h->clsCap = nMap, h->clsPar = 0;
     }
-    A.list = h->clsList, A.par = h->clsPar;
-    h->clsPar ^= 1;
-    hist_centres(h, s);
-    hipLaunchKernelGGL(k_classify_select, dim3((nMap + 255) / 256), dim3(256), 0, s, A);
-    hipLaunchKernelGGL(k_map_points_classify, dim3(CLS_WAVES / 4), dim3(256), 0, s, A);
-    CS_HIP(hipGetLastError());
     return CS_OK;
+}
+
+// cs_pose_update_frame_dev + cs_map_points_classify_dev of the same frame as TWO launches instead of four: the gate's lane of a map point
+// also decides whether mapPointsClassify examines it (k_classify_select's test, on the flags the gate has just left), the camera centres
+// by walk depth (k_ring_centres) are blocks of the same launch; then the classification's worker.  Same results as the two calls.
+extern "C" int cs_pose_update_classify_frame_dev(cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int* d_pointFeat, int nMap,
+                                                 const double* d_R, const double* d_t, double* d_mapPts, double* d_mapCov, unsigned char* d_mapFlags,
+                                                 int largeErr, double pixelErrVar, int frame, int maxLen, int minLen, int minOutNum, double maxEpiErr,
+                                                 int* d_numNodes, int* d_numOut, int* d_numDyn, const int* d_featFrame, const int* d_featFirst,
+                                                 unsigned char* d_newPt, int* d_staticFrameNum, const int* d_firstFrame, double pixelVarClassify,
+                                                 int* d_clsCounts) {
+    if (!h) {
+        cs_set_error("cs_pose_update_classify_frame_dev: null history");
+        return CS_ERR_INVALID;
+    }
+    (void)maxLen;
+    int rc = pu_check_common("cs_pose_update_classify_frame_dev", h->nCams, 0, h->nCams, cams, h->N, d_R, d_t);
+    if (rc != CS_OK) return rc;
+    if (nMap < 1 || !d_pointFeat || !d_mapPts || !d_mapCov || !d_mapFlags || !d_newPt || !d_staticFrameNum || !d_firstFrame) {
+        cs_set_error("cs_pose_update_classify_frame_dev: null map pointer (or an empty map: use the two calls)");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    rc = cls_reserve_list(h, nMap, s);
+    if (rc != CS_OK) return rc;
+    PuArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = h->nCams, A.N = h->N, A.cam0 = 0, A.nCamsRun = h->nCams, A.R = d_R, A.t = d_t;
+    pu_fill_gate(A, d_pointFeat, nMap, d_mapPts, d_mapCov, d_mapFlags, largeErr, pixelErrVar, d_numNodes, d_numOut);
+    pu_advance(h, frame);
+    pu_fill_dyn(A, h, minLen, minOutNum, maxEpiErr, d_numDyn);
+    const int par = h->clsPar;
+    h->clsPar ^= 1;
+    A.clsList = h->clsList, A.clsPar = par, A.clsCurFrame = frame, A.clsCounts = d_clsCounts, A.clsFeatFrame = d_featFrame;
+    A.cenOut = h->cen;
+    rc = pu_launch("cs_pose_update_classify_frame_dev", h->device, hip_stream, A, cams, true, true);
+    if (rc != CS_OK) return rc;
+    h->cenVersion = h->ringVersion;   // (the centres of this state of the ring are what the launch has just written)
+    return cls_run(h, hip_stream, cams, d_pointFeat, nMap, d_featFrame, d_featFirst, frame, d_mapPts, d_mapCov, d_mapFlags, d_newPt, d_staticFrameNum,
+                   d_firstFrame, pixelVarClassify, d_clsCounts, true, par);
 }

@@ -341,6 +341,9 @@ class FrameLoop:
         import os as _os
 
         self._timing = {} if _os.environ.get("FRAMELOOP_TIMING") else None   # (diagnostic: host seconds per section)
+        # (diagnostic, FRAMELOOP_GPU_SECTIONS=1: events on the pose stream at the sections' boundaries -> gpu_sections(): untraced GPU time
+        # of every section of a frame, by kind of frame.  Not a valid bench line: two events per section cost a few microseconds each.)
+        self._marks = [] if _os.environ.get("FRAMELOOP_GPU_SECTIONS") else None
         self._init_ncc()
 
     # ---------------------------------------------------------------------------------------------------------------
@@ -360,6 +363,30 @@ class FrameLoop:
             finally:
                 self._timing[name] = self._timing.get(name, 0.0) + _t.perf_counter() - t0
         return cm()
+
+    def _mark(self, i, name):
+        if self._marks is not None:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record(self.pose_s)
+            self._marks.append((i, name, e))
+
+    def gpu_sections(self, first_frame=0):
+        """mean GPU microseconds between consecutive marks of a frame on the pose stream, by kind of frame (after drain())"""
+        cfg, out, by = self.cfg, {}, {}
+        for i, name, e in self._marks or []:
+            by.setdefault(i, []).append((name, e))
+        for i, ms in by.items():
+            if i < first_frame:
+                continue
+            kind = ("ncc+" if self.ncc is not None and i % cfg.ncc_every == 0 else "") + ("key" if i % 5 == 0 else "plain")
+            for (n0, e0), (n1, e1) in zip(ms[:-1], ms[1:]):
+                acc = out.setdefault(kind, {}).setdefault(n0 + " -> " + n1, [0.0, 0])
+                acc[0] += e0.elapsed_time(e1) * 1e3
+                acc[1] += 1
+            acc = out.setdefault(kind, {}).setdefault("WHOLE FRAME on the pose stream", [0.0, 0])
+            acc[0] += ms[0][1].elapsed_time(ms[-1][1]) * 1e3
+            acc[1] += 1
+        return {k: {n: round(a / c, 1) for n, (a, c) in v.items()} | {"frames": max(c for _, c in v.values())} for k, v in out.items()}
 
     def vid(self, i):
         return i % self.T
@@ -607,6 +634,7 @@ class FrameLoop:
         pose_s.wait_event(self.klt_done[b])          # pose(f) consumes what the tracker produced for frame f
         src, dst = (i + 1) & 1, i & 1
         ps = pose_s.cuda_stream
+        self._mark(i, "tracker done")
         if self.out is not None:
             if self._timing is not None:
                 import time as _t
@@ -616,7 +644,9 @@ class FrameLoop:
                 self._timing["apply"] = self._timing.get("apply", 0.0) + _t.perf_counter() - t0
             else:
                 self._apply_due(i, src)
+        self._mark(i, "BA applied")
         self._handback(b, i, "own")
+        self._mark(i, "hand-back")
         intraCamEstimate_batch_dev(ps, nc, cfg.pts_stride, self.d_K.data_ptr(), self.d_R[src].data_ptr() + 72 * c0,
                                    self.d_t[src].data_ptr() + 24 * c0, self.d_npts.data_ptr() + 4 * c0, 0,
                                    self.d_Ms.data_ptr() + 24 * cfg.pts_stride * c0, self.d_ms.data_ptr() + 16 * cfg.pts_stride * c0, 10.0,
@@ -624,6 +654,7 @@ class FrameLoop:
                                    self.d_ok.data_ptr() + 4 * c0, device=self.device)
         if cfg.klt_after_intracam:
             self.intracam_done[b].record(pose_s)
+        self._mark(i, "intracam")
         if self.world > 1:
             # the merge step: every camera's {dest[], R, t} to every rank, then the other ranks' cameras through the same hand-back
             with torch.cuda.stream(pose_s):
@@ -633,14 +664,17 @@ class FrameLoop:
             self._handback(b, i, "other")
         if self.pose_upd is not None:
             # parallelPoseUpdate(false): gate 2.0, sigma = PIXEL_ERR_VAR; detectDynamicFeaturePoints(20, 5, 3, MAX_EPI_ERR)
-            self.pose_upd.pose_update_frame_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_R[dst].data_ptr(),
-                                                self.d_t[dst].data_ptr(), self.d_map.data_ptr(), self.d_cov.data_ptr(),
-                                                self.d_mapflags.data_ptr(), 0, self.sig_pix, i, 20, 5, 3, MAX_EPI_ERR)
-            if cfg.with_classify:
-                self.pose_upd.map_points_classify_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, i, self.d_map.data_ptr(),
-                                                      self.d_cov.data_ptr(), self.d_mapflags.data_ptr(), self.d_newpt.data_ptr(),
-                                                      self.d_sfn.data_ptr(), self.d_firstfrm.data_ptr(), self.sig(12.0),
-                                                      d_counts=self.d_cls_counts.data_ptr())
+            if cfg.with_classify:   # CoSLAM::poseUpdate as a whole: two launches (the gate also builds the classification's worklist)
+                self.pose_upd.pose_update_classify_frame_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_R[dst].data_ptr(),
+                                                             self.d_t[dst].data_ptr(), self.d_map.data_ptr(), self.d_cov.data_ptr(),
+                                                             self.d_mapflags.data_ptr(), 0, self.sig_pix, i, self.d_newpt.data_ptr(),
+                                                             self.d_sfn.data_ptr(), self.d_firstfrm.data_ptr(), self.sig(12.0), 20, 5, 3,
+                                                             MAX_EPI_ERR, d_counts=self.d_cls_counts.data_ptr())
+            else:
+                self.pose_upd.pose_update_frame_dev(ps, self.pu_args, self.d_pf.data_ptr(), self.n_map, self.d_R[dst].data_ptr(),
+                                                    self.d_t[dst].data_ptr(), self.d_map.data_ptr(), self.d_cov.data_ptr(),
+                                                    self.d_mapflags.data_ptr(), 0, self.sig_pix, i, 20, 5, 3, MAX_EPI_ERR)
+        self._mark(i, "pose update + classify")
         # the reference's order of a frame (src/gui/CoSLAMThread.cpp:104-118): poseUpdate (with mapPointsClassify) -> activeMapPointsRegister ->
         # genNewMapPoints -> currentMapPointsRegister: the new map points take their features BEFORE the current points' registration
         # looks at them (a feature that carries a point ends a registration walk)
@@ -678,6 +712,7 @@ class FrameLoop:
                     k["im_total"] += k["im_cnt"]
         if self.ncc is not None and i % cfg.ncc_every == 0:
             self._ncc_leg(i, f, dst)
+            self._mark(i, "ncc leg")
         if cfg.with_register:
             from coslam_amd.register import register_list_current_dev
 
@@ -687,8 +722,10 @@ class FrameLoop:
                                       listCap=cfg.p_reg, d_overflow=self.d_curoverflow.data_ptr())
             register_search_passes_dev(ps, self.reg_args[dst], cfg.n_feat, cfg.W, cfg.H, self.reg_passes, device=self.device, cam0=c0,
                                        nCamsRun=nc)
+            self._mark(i, "list + search")
             if self.pose_upd is not None and cfg.with_mergability:
                 self._mergability(ps)
+                self._mark(i, "mergability")
         self._dst_now, self._frame_now = dst, i
         if cfg.with_register and cfg.with_decide and self.pose_upd is not None and cfg.with_mergability:
             self._decide(ps)
@@ -698,6 +735,7 @@ class FrameLoop:
         # buffer's last reader was the hand-back: released earlier the tracker runs two frames ahead and under more of the pose stream's
         # kernels -- measured 1978-1986 (behind the hand-back) / 1928-1934 (behind the gate) / 1894-1903 (behind the classification)
         # against 2173-2193 frames/s here, 2119-2123 behind the key-frame requests (profiles/r04_ab_runs.txt)
+        self._mark(i, "decide + refine")
         self.dest_free[b].record(pose_s)
         if key_frame:
             if self._timing is not None:
@@ -708,6 +746,7 @@ class FrameLoop:
                 self._timing["key_frame"] = self._timing.get("key_frame", 0.0) + _t.perf_counter() - t0
             else:
                 self._key_frame(i, dst)
+            self._mark(i, "key-frame push + requests")
 
     def _mergability(self, ps):
         """staticCheckMergability of every candidate of the current points' pass over its WHOLE track (SL_CoSLAM.cpp:714-729, :768), as a

@@ -115,6 +115,19 @@ class TrackHistory:
                                                int(frame), int(maxLen), int(minLen), int(minOutNum), C.c_double(maxEpiErr),
                                                vp(d_numNodes), vp(d_numOut), vp(d_numDyn)), "cs_pose_update_frame_dev")
 
+    def pose_update_classify_frame_dev(self, stream_ptr, cams, d_pointFeat, nMap, d_R, d_t, d_mapPts, d_mapCov, d_mapFlags, largeErr, pixelErrVar,
+                                       frame, d_newPt, d_staticFrameNum, d_firstFrame, pixelVarClassify=12.0, maxLen=20, minLen=5, minOutNum=3,
+                                       maxEpiErr=6.0, d_numNodes=None, d_numOut=None, d_numDyn=None, d_featFrame=None, d_featFirst=None,
+                                       d_counts=None):
+        """pose_update_frame_dev + map_points_classify_dev of the same frame in two launches (cs_pose_update_classify_frame_dev)."""
+        vp = C.c_void_p
+        check(self._L.cs_pose_update_classify_frame_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), vp(d_pointFeat), int(nMap), vp(d_R),
+                                                        vp(d_t), vp(d_mapPts), vp(d_mapCov), vp(d_mapFlags), int(largeErr), C.c_double(pixelErrVar),
+                                                        int(frame), int(maxLen), int(minLen), int(minOutNum), C.c_double(maxEpiErr),
+                                                        vp(d_numNodes), vp(d_numOut), vp(d_numDyn), vp(d_featFrame), vp(d_featFirst), vp(d_newPt),
+                                                        vp(d_staticFrameNum), vp(d_firstFrame), C.c_double(pixelVarClassify), vp(d_counts)),
+              "cs_pose_update_classify_frame_dev")
+
     def set_poses_dev(self, stream_ptr, n, d_cam, d_frame, d_R, d_t):
         """Poses of n (camera, frame) pairs into the ring (RobustBundleRTS::output(): adjusted key poses and relaxed non-key poses,
         reference src/app/SL_CoSLAMRobustBA.cpp:283-285, 239-244); pairs the ring does not hold are skipped."""

@@ -733,6 +733,17 @@ int cs_map_points_classify_dev(const cs_track_history* h, void* hip_stream, cons
                                const int* d_featFrame, const int* d_featFirst, int curFrame, double* d_mapPts, double* d_mapCov,
                                unsigned char* d_mapFlags, unsigned char* d_newPt, int* d_staticFrameNum, const int* d_firstFrame,
                                double pixelVar, int* d_counts);
+/* cs_pose_update_frame_dev and cs_map_points_classify_dev of the same frame -- CoSLAM::poseUpdate as a whole (src/app/SL_CoSLAM.cpp:398-417:
+ * every camera's poseUpdate3D + detectDynamicFeaturePoints, then mapPointsClassify(12.0)) -- as TWO launches instead of four: the gate's
+ * lane of a map point also decides whether the classification examines it, the camera centres of the walks are blocks of the same
+ * launch, then the classification's worker.  Same arguments as the two calls (d_clsCounts = the classification's d_counts), same
+ * results; nMap >= 1. */
+int cs_pose_update_classify_frame_dev(cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int* d_pointFeat, int nMap,
+                                      const double* d_R, const double* d_t, double* d_mapPts, double* d_mapCov, unsigned char* d_mapFlags,
+                                      int largeErr, double pixelErrVar, int frame, int maxLen, int minLen, int minOutNum, double maxEpiErr,
+                                      int* d_numNodes, int* d_numOut, int* d_numDyn, const int* d_featFrame, const int* d_featFirst,
+                                      unsigned char* d_newPt, int* d_staticFrameNum, const int* d_firstFrame, double pixelVarClassify,
+                                      int* d_clsCounts);
 
 /* ------------------------------------------------------------------------------------------
  * Pose-graph relaxation of the non-key frames after a bundle adjustment, all camera graphs in one launch

@@ -965,3 +965,74 @@ def test_intracam_new_map_points_reproduce_the_reference():
                 total += want
         th.close()
     assert total > 150
+
+
+def test_pose_update_and_classification_as_two_launches_equal_the_two_calls():
+    """cs_pose_update_classify_frame_dev (round 6: the gate's lane of a map point also lists it for mapPointsClassify, the walks' camera
+    centres are blocks of the same launch) against cs_pose_update_frame_dev + cs_map_points_classify_dev on a copy of the same state,
+    frame after frame: every array the calls write is byte-identical, the classification examined points in every frame."""
+    import torch
+
+    from coslam_amd.poseupdate import TrackHistory
+
+    sc = Scene(T=14)
+    nC, N, nMap = sc.nC, sc.N, sc.nMap
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(3)
+    fl0 = sc.flags0.copy()
+    fl0[rng.random(nMap) < 0.15] |= 4                      # more uncertain points for the classification to look at
+    newpt0 = (rng.random(nMap) < 0.3).astype(np.uint8)
+    first0 = rng.integers(-40, 1, nMap).astype(np.int32)
+
+    def state():
+        d = dict(map=torch.from_numpy(sc.map0.copy()).to(dev), cov=torch.from_numpy(sc.cov0.copy()).to(dev), fl=torch.from_numpy(fl0.copy()).to(dev),
+                 newpt=torch.from_numpy(newpt0.copy()).to(dev), sfn=torch.zeros(nMap, dtype=torch.int32, device=dev),
+                 first=torch.from_numpy(first0.copy()).to(dev), err=[torch.zeros(N, dtype=torch.float64, device=dev) for _ in range(nC)],
+                 stat=[torch.ones(N, dtype=torch.uint8, device=dev) for _ in range(nC)], cnt=torch.zeros(3, nC, dtype=torch.int32, device=dev),
+                 ccnt=torch.zeros(2, dtype=torch.int32, device=dev), th=TrackHistory(nC, N, 32))
+        return d
+
+    A, B = state(), state()
+    d_K = torch.from_numpy(sc.K.reshape(9).copy()).to(dev)
+    d_iK = torch.from_numpy(sc.iK.reshape(9).copy()).to(dev)
+    examined = 0
+    for f in range(sc.T):
+        recs = sc.frame(f)
+        pf = Scene.point_feat(recs, nMap)
+        Rs = np.stack([sc.Re[f][c].reshape(9) for c in range(nC)])
+        ts = np.stack([sc.te[f][c] for c in range(nC)])
+        d_R, d_t = torch.from_numpy(Rs).to(dev), torch.from_numpy(ts).to(dev)
+        outs = []
+        for S, fused in ((A, False), (B, True)):
+            keep, cams = [], []
+            for c, r in enumerate(recs):
+                t_ = {k: torch.from_numpy(v.copy()).to(dev) for k, v in r.items()}
+                keep.append(t_)
+                cams.append(dict(K=d_K.data_ptr(), iK=d_iK.data_ptr(), xy=t_["xy"].data_ptr(), state=t_["state"].data_ptr(),
+                                 slot2map=t_["slot2map"].data_ptr(), trackSpan=t_["trackSpan"].data_ptr(), reprojErr=S["err"][c].data_ptr(),
+                                 isStatic=S["stat"][c].data_ptr()))
+            d_pf = torch.from_numpy(pf.copy()).to(dev)
+            kw = dict(d_numNodes=S["cnt"][0].data_ptr(), d_numOut=S["cnt"][1].data_ptr(), d_numDyn=S["cnt"][2].data_ptr())
+            if fused:
+                S["th"].pose_update_classify_frame_dev(s, cams, d_pf.data_ptr(), nMap, d_R.data_ptr(), d_t.data_ptr(), S["map"].data_ptr(),
+                                                       S["cov"].data_ptr(), S["fl"].data_ptr(), 0, SIGMA, f, S["newpt"].data_ptr(), S["sfn"].data_ptr(),
+                                                       S["first"].data_ptr(), 12.0, maxEpiErr=MAX_EPI, d_counts=S["ccnt"].data_ptr(), **kw)
+            else:
+                S["th"].pose_update_frame_dev(s, cams, d_pf.data_ptr(), nMap, d_R.data_ptr(), d_t.data_ptr(), S["map"].data_ptr(), S["cov"].data_ptr(),
+                                              S["fl"].data_ptr(), 0, SIGMA, f, maxEpiErr=MAX_EPI, **kw)
+                S["th"].map_points_classify_dev(s, cams, d_pf.data_ptr(), nMap, f, S["map"].data_ptr(), S["cov"].data_ptr(), S["fl"].data_ptr(),
+                                                S["newpt"].data_ptr(), S["sfn"].data_ptr(), S["first"].data_ptr(), 12.0, d_counts=S["ccnt"].data_ptr())
+            torch.cuda.synchronize()
+            outs.append(dict(pf=d_pf.cpu().numpy(), s2m=[k_["slot2map"].cpu().numpy() for k_ in keep], map=S["map"].cpu().numpy(),
+                             cov=S["cov"].cpu().numpy(), fl=S["fl"].cpu().numpy(), newpt=S["newpt"].cpu().numpy(), sfn=S["sfn"].cpu().numpy(),
+                             err=[e.cpu().numpy() for e in S["err"]], stat=[e.cpu().numpy() for e in S["stat"]], cnt=S["cnt"].cpu().numpy(),
+                             ccnt=S["ccnt"].cpu().numpy()))
+        a, b = outs
+        for k in a:
+            xs, ys = (a[k], b[k]) if isinstance(a[k], list) else ([a[k]], [b[k]])
+            for x, y in zip(xs, ys):
+                assert x.tobytes() == y.tobytes(), (f, k)
+        examined += int(a["ccnt"][0])
+    assert examined > 50
+    A["th"].close(), B["th"].close()

@@ -510,11 +510,10 @@ int main(int argc, char** argv) {
             CSCHK(cs_klt_handback_dev(dev, (void*)poseS, nCams - nc, hbOther.data(), N, W, H, nColBlk, nRowBlk, PTS, i));
         }
         // parallelPoseUpdate(false): the gate + seqTriangulate loop of poseUpdate3D, detectDynamicFeaturePoints(20, 5, 3, MAX_EPI_ERR)
-        CSCHK(cs_pose_update_frame_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dR[dsti], dT[dsti], dMap, dCov, dMapFlags, 0, PIX, i, 20, 5,
-                                       3, 6.0, nullptr, nullptr, nullptr));
-        // mapPointsClassify(12.0) (SL_CoSLAM.cpp:385): the uncertain / dynamic points of this frame decided again
-        CSCHK(cs_map_points_classify_dev(hist, (void*)poseS, pu.data(), dPf, nMap, nullptr, nullptr, i, dMap, dCov, dMapFlags, dNewPt, dSfn,
-                                         dFirstFrm, PIX_CLASSIFY, nullptr));
+        // and mapPointsClassify(12.0) (SL_CoSLAM.cpp:385): the uncertain / dynamic points of this frame decided again -- CoSLAM::poseUpdate as two
+        // launches (the gate's lane of a point also lists it for the classification)
+        CSCHK(cs_pose_update_classify_frame_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dR[dsti], dT[dsti], dMap, dCov, dMapFlags, 0, PIX, i, 20, 5,
+                                                3, 6.0, nullptr, nullptr, nullptr, nullptr, nullptr, dNewPt, dSfn, dFirstFrm, PIX_CLASSIFY, nullptr));
         // genNewMapPoints every 4th frame -- BEFORE currentMapPointsRegister, as in the reference's frame (src/gui/CoSLAMThread.cpp:104-118):
         // the new map points take their features before the current points' registration looks at them
         if (nCams >= 2 && i % NCC_EVERY == 0) {
