@@ -4710,12 +4710,8 @@ int cs_ba_solve_intercam_async(cs_ba* b, cs_ba_intercam* ic, void* after_stream,
     }
     A.st = ic->st[slot];
     hipStream_t as = (hipStream_t)after_stream;
-    {
-        cs_small::List ops;
-        ops.fill(A.st.dynMark, 0, (size_t)ic->nMap);
-        CS_HIP(ops.run(as));
-    }
-    hipLaunchKernelGGL(k_ic_gather, dim3(ic->nCams), dim3(256), 0, as, A);
+    // (dynMark: zero from the start, and every build clears the marks it read -- k_ic_assemble)
+    hipLaunchKernelGGL(k_ic_gather, dim3(ic->nCams), dim3(1024), 0, as, A);
     hipLaunchKernelGGL(k_ic_assemble, dim3(1), dim3(1024), 0, as, A);
     CS_CHECK_LAUNCH();
     BaAsyncJob J;

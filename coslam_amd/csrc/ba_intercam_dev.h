@@ -42,7 +42,8 @@ struct IcArgs {
 constexpr int IC_MAX_BLOCKS = 1024;
 // one workgroup per camera: (1) chooseStaticFeatPts' block vote and, in block order, the winners that carry a map point; (2) the
 // block vote of chooseDynamicFeatPts, its winners' map points marked
-__global__ __launch_bounds__(256) void k_ic_gather(IcArgs A) {
+// (1024 threads: the slots' dependent loads -- slot -> map point -> flags / the point's row -- two trips deep instead of eight)
+__global__ __launch_bounds__(1024) void k_ic_gather(IcArgs A) {
     __shared__ unsigned long long skey[IC_MAX_BLOCKS];
     __shared__ unsigned key[IC_MAX_BLOCKS];
     __shared__ unsigned char sflag[IC_MAX_BLOCKS];
@@ -52,10 +53,10 @@ __global__ __launch_bounds__(256) void k_ic_gather(IcArgs A) {
     const int* state = A.cam.state[c];
     const int* s2m = A.cam.slot2map[c];
     const int nBlk = A.nColBlk * A.nRowBlk;
-    for (int q = tid; q < nBlk; q += 256) skey[q] = 0, key[q] = 0;
+    for (int q = tid; q < nBlk; q += 1024) skey[q] = 0, key[q] = 0;
     __syncthreads();
     // ---- static (:351-384): `tracks[bi]` replaced only while it holds an unmapped feature -- by the first mapped one, else by a longer one
-    for (int s = tid; s < N; s += 256) {
+    for (int s = tid; s < N; s += 1024) {
         const int st = state[s];
         if (st != 0 && st != 1) continue;
         int m = s2m[s];
@@ -71,9 +72,9 @@ __global__ __launch_bounds__(256) void k_ic_gather(IcArgs A) {
         atomicMax(&skey[by * A.nColBlk + bx], m >= 0 ? ((1ull << 62) | order) : ((len << 24) | order));
     }
     __syncthreads();
-    for (int b = tid; b < nBlk; b += 256) sflag[b] = (skey[b] >> 62) ? 1 : 0;   // `if (!fp->mpt) continue` (:44-45)
+    for (int b = tid; b < nBlk; b += 1024) sflag[b] = (skey[b] >> 62) ? 1 : 0;   // `if (!fp->mpt) continue` (:44-45)
     __syncthreads();
-    for (int b = tid; b < nBlk; b += 256) {
+    for (int b = tid; b < nBlk; b += 1024) {
         if (!sflag[b]) continue;
         int k = 0;
         for (int q = 0; q < b; ++q) k += sflag[q];
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void k_ic_gather(IcArgs A) {
         A.st.stCount[c] = n < A.ptsStride ? n : A.ptsStride;
     }
     // ---- dynamic: per block the feature whose map point the most cameras see; ties: the lowest slot (the first in slot order)
-    for (int s = tid; s < N; s += 256) {
+    for (int s = tid; s < N; s += 1024) {
         const int st = state[s];
         if (st != 0 && st != 1) continue;          // the track is empty (its tail is not a feature of this frame)
         const int m = s2m[s];
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void k_ic_gather(IcArgs A) {
         atomicMax(&key[by * A.nColBlk + bx], ((unsigned)nVis << 24) | (unsigned)(0xFFFFFF - s));
     }
     __syncthreads();
-    for (int q = tid; q < nBlk; q += 256) {
+    for (int q = tid; q < nBlk; q += 1024) {
         const unsigned k = key[q];
         if (k) A.st.dynMark[s2m[0xFFFFFF - (int)(k & 0xFFFFFF)]] = 1;
     }
@@ -144,16 +145,22 @@ __global__ __launch_bounds__(1024) void k_ic_assemble(IcArgs A) {
         if (A.st.dynMark[m]) {
             if (rank < keep) sDynMap[rank] = m;
             ++rank;
+            A.st.dynMark[m] = 0;   // (left clean for the next request that builds into this staging record: no fill launch in front of it)
         }
     if (tid == 1023) sNDyn = sScan[1023] < keep ? sScan[1023] : keep;
     __syncthreads();
     const int nStatic = sBase[C], nDyn = sNDyn, P = nStatic + nDyn;
-    if (tid == 0) {   // measurements of the dynamic points: the cameras holding a feature of this frame
+    // measurements of the dynamic points: the cameras holding a feature of this frame -- counted side by side, then strung together
+    __shared__ int sDynCnt[64];
+    if (tid < nDyn) {
+        int n = 0;
+        for (int c = 0; c < C; ++c) n += A.pointFeat[(size_t)sDynMap[tid] * C + c] >= 0;
+        sDynCnt[tid] = n;
+    }
+    __syncthreads();
+    if (tid == 0) {
         int o = nStatic;
-        for (int k = 0; k < nDyn; ++k) {
-            sDynObs[k] = o;
-            for (int c = 0; c < C; ++c) o += A.pointFeat[(size_t)sDynMap[k] * C + c] >= 0;
-        }
+        for (int k = 0; k < nDyn; ++k) sDynObs[k] = o, o += sDynCnt[k];
         sDynObs[nDyn] = o;
         int mx = nStatic > 0 ? 1 : 0;
         for (int k = 0; k < nDyn; ++k) mx = max(mx, sDynObs[k + 1] - sDynObs[k]);

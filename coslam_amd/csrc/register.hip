@@ -257,22 +257,44 @@ __global__ __launch_bounds__(1024) void k_register_list(int nCams, int nMap, con
     const int oldCount = listCount ? (*listCount < nMap ? (*listCount < 0 ? 0 : *listCount) : nMap) : nMap;   // `list` still holds the previous call's
     for (int w = tid; w < (nMap + 63) / 64; w += 1024) bits[w] = 0ull;
     __syncthreads();
-    for (int p0 = wv * 64; p0 < live; p0 += 1024) {
-        const int p = p0 + lane;
-        bool in = false;
-        if (p < live && !(mapFlags && (mapFlags[p] & CS_MAP_FALSE))) {
-            if (vec4) {   // (rows of 4 k ints on a 16-byte boundary: 16-byte loads)
-                const int4* row = reinterpret_cast<const int4*>(pointFeat + (size_t)p * nCams);
-                for (int c = 0; c < nCams / 4; ++c) {
-                    const int4 v = row[c];
-                    in |= v.x >= 0 || v.y >= 0 || v.z >= 0 || v.w >= 0;
+    // (eight trips' loads in flight together: the rows are independent, a trip by itself is one dependent round of memory latency)
+    for (int pb = wv * 64; pb < live; pb += 8 * 1024) {
+        int4 v0[8], v1[8];
+        unsigned char fl[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = pb + 1024 * k + lane;
+            v0[k] = v1[k] = make_int4(-1, -1, -1, -1), fl[k] = CS_MAP_FALSE;
+            if (p < live) {
+                fl[k] = mapFlags ? mapFlags[p] : 0;
+                if (vec4 && nCams <= 8) {   // (rows of 4 or 8 ints on a 16-byte boundary: one or two 16-byte loads)
+                    const int4* row = reinterpret_cast<const int4*>(pointFeat + (size_t)p * nCams);
+                    v0[k] = row[0];
+                    if (nCams == 8) v1[k] = row[1];
                 }
-            } else {
-                for (int c = 0; c < nCams; ++c) in |= pointFeat[(size_t)p * nCams + c] >= 0;
             }
         }
-        const unsigned long long b = __builtin_amdgcn_ballot_w64(in);
-        if (lane == 0) bits[p0 >> 6] = b;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p0 = pb + 1024 * k, p = p0 + lane;
+            if (p0 >= live) break;   // (uniform over the wave)
+            bool in = false;
+            if (p < live && !(fl[k] & CS_MAP_FALSE)) {
+                if (vec4 && nCams <= 8) {
+                    in = v0[k].x >= 0 || v0[k].y >= 0 || v0[k].z >= 0 || v0[k].w >= 0 || v1[k].x >= 0 || v1[k].y >= 0 || v1[k].z >= 0 || v1[k].w >= 0;
+                } else if (vec4) {
+                    const int4* row = reinterpret_cast<const int4*>(pointFeat + (size_t)p * nCams);
+                    for (int c = 0; c < nCams / 4; ++c) {
+                        const int4 v = row[c];
+                        in |= v.x >= 0 || v.y >= 0 || v.z >= 0 || v.w >= 0;
+                    }
+                } else {
+                    for (int c = 0; c < nCams; ++c) in |= pointFeat[(size_t)p * nCams + c] >= 0;
+                }
+            }
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(in);
+            if (lane == 0) bits[p0 >> 6] = b;
+        }
     }
     __syncthreads();
     // the rows of the points that were on the list a call ago and are not any more lose their candidates (every other unlisted row
