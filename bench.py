@@ -1143,7 +1143,7 @@ def main():
         cfg5_klt = dict(klt_stage(1920, 1080, 4, 100, 50, 4, conf5, fr5),
                         workload="cfg5 KLT: 4 cameras 1920x1080 x 5000 slots (100x50) as one camera group on one GPU, 4 levels, 7x7, 10 it/level "
                                  "with gain, redetect + prefetch per frame",
-                        pmc="profiles/r05_cfg5_klt_pmc.json (traffic 2.85 x the algorithmic bytes, VALU issue 0.47 of the launch; 3 + 1 cameras per launch: the camera-per-XCD placement does not apply)")
+                        pmc="profiles/r06_cfg5_klt_pmc.json (2 + 2 cameras per launch, a camera on four XCDs: traffic 2.56 x the algorithmic bytes -- 128-byte fetches of sparse 72-byte patch rows --, VALU issue 0.52 of the launch; round 5, 3 + 1 unplaced: 2.85 x, 0.47)")
         del fr5
         confd = coslam_amd.KLT_SequenceTrackerConfig(trackWithGain=1, minCornerness=3000.0, SSD_Threshold=20000.0, minDistance=4)
         ref_default = dict(klt_stage(W, H, 6, FW, FH, N_CAMS, confd, [video[c] for c in range(N_CAMS)]),

@@ -301,8 +301,14 @@ static int enqueue_tracker(const Span& S, cs_klt_feature* const* postDest, int d
         const float realVr[4] = {k0->margin / (float)k0->W, k0->margin / (float)k0->H, 1.0f - k0->margin / (float)k0->W,
                                  1.0f - k0->margin / (float)k0->H};
         int perCu = 0;   // resident waves per CU of the instantiation launched
-        const int perLaunch = rows_cams_per_persistent_launch(S, hw, T, &perCu);
+        int perLaunch = rows_cams_per_persistent_launch(S, hw, T, &perCu);
         if (perLaunch >= 1) {
+            // a span that needs several launches is cut EVENLY (4 cameras, 3 fit: 2 + 2, not 3 + 1): the launches follow each other on
+            // one stream and each lasts about as long as its slowest camera, so nothing is lost -- and 1, 2, 4 or 8 cameras per launch
+            // divide the eight XCDs, so the camera-per-XCD placement below applies (cfg5: four XCDs = four L2s per camera instead of
+            // eight for a launch of three)
+            const int nLaunches = (S.n + perLaunch - 1) / perLaunch;
+            perLaunch = (S.n + nLaunches - 1) / nLaunches;
             A.sqrConvThr = realConv;
             A.ssdThr = realSsd;
             for (int q = 0; q < 4; ++q) A.vr[q] = realVr[q];
