@@ -1256,10 +1256,19 @@ def main():
     if rank == 0:
         reg_out, d_mapflags = loop.reg_out, loop.d_mapflags
         lc = slice(my_cams[0], my_cams[-1] + 1)
+        # north_star: "host stays C++".  `value` is the C++ frame loop's rate (tools/cxx/frame_loop.cpp: the same W warm-up + K timed steps over the
+        # same stretch of the sequence, barrier + device synchronisation on both sides, at N > 1 the slowest rank) whenever that process ran to
+        # its end (and, N > 1, every rank ended in the same state); the Python loop timed above -- the same library calls from ctypes -- is
+        # config.python_frame_loop, and the fallback when the binary is missing or failed.
+        py_loop = {"frames_per_s": args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                   "what": "coslam_amd/frameloop.py: the same loop driven from Python (ctypes), timed in this process per the bench contract"}
+        cxx_ok = (isinstance(cxx, dict) and "error" not in cxx and cxx.get("frames_per_s") and cxx.get("steps") == args.steps and
+                  cxx.get("pose_ok", True) and (n_gpus == 1 or cxx.get("identical_digest_on_every_rank")))
+        value, ms_step = (float(cxx["frames_per_s"]), float(cxx["ms_per_step"])) if cxx_ok else (py_loop["frames_per_s"], py_loop["ms_per_step"])
         out = {
             "metric": "frames/sec for track+local-BA loop, 8 cams 640x480 x 2000 feats (one frame = all 8 cameras)",
-            "value": args.steps / dt, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32 (KLT, f16 pyramid storage) + f64 (pose, BA)",
             "data": "synthetic",
             "config": {"workload": "8 cams 640x480 x 2000 KLT slots (50x40), 4-level pyramid, 7x7 window, 10 it/level with "
@@ -1284,7 +1293,7 @@ def main():
                                    "KLT minDistance 4 (the reference's default is 8, SL_GlobParam.cpp:29: 4 keeps all 2000 slots alive on this "
                                    "scene); Const::PIXEL_ERR_VAR = 10 handed to the covariance helpers as a " + args.pixel_err_reading +
                                    " (DESIGN.md 5.1)",
-                       "cameras": N_CAMS, "cameras_per_gpu": nc, "camera_frames_per_s": N_CAMS * args.steps / dt,
+                       "cameras": N_CAMS, "cameras_per_gpu": nc, "camera_frames_per_s": N_CAMS * value,
                        "video": {"frames": N_FRAMES, "what": "closed camera path (coslam_amd.synth.Scene loop_period): never reverses, never jumps",
                                  "host_render_s": t_render},
                        "frames_enqueued_until_end_of_timed_region": n_timed_end,
@@ -1365,6 +1374,9 @@ def main():
                            "map_points_in_use": map_in_use_timed_end, "map_points_at_start": n_pts0, "map_capacity": loop.n_map},
                        "with_upload": with_upload, "secondary_reference_ba_request_policy": ref_policy,
                        "secondary_sequential_registration": seq_reg, "secondary_keyframe_decision": kf_leg, "cxx_frame_loop": cxx,
+                       "value_source": "cxx_frame_loop" if cxx_ok else "python_frame_loop (the C++ loop did not run: see cxx_frame_loop)",
+                       "python_frame_loop": py_loop,
+                       "secondary_legs_note": "the secondary_* legs and with_upload are run by the Python loop: their ratio_to_value compares with python_frame_loop",
                        "collectives": None if world == 1 else {
                            "issued_by": ("libcoslam_hip RCCL (C-ABI)" if loop.native else "torch.distributed " + dist_backend +
                                          (f" (FALLBACK: libcoslam_hip's communicator could not be created: {loop.native_fallback})"

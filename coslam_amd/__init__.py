@@ -14,6 +14,16 @@ from .klt import (  # noqa: F401
 )
 
 __version__ = "0.1.0"
+
+
+def debug_set(key, value):
+    """cs_debug_set: a test / diagnostic switch of the whole process ("ba_syrk", "ba_packed", "ba_graphs", "merge_print"; -1 = default).
+    The library reads nothing from the environment."""
+    from ._lib import check
+
+    check(lib().cs_debug_set(key.encode(), int(value)), "cs_debug_set")
+
+
 from .pose import IntraCamPoseOption, intraCamEstimate  # noqa: F401,E402
 from .ba import BAInterCam, BAOutput, BAStats, BAWindow, BAWorkspace, bundleAdjustRobust  # noqa: F401,E402
 from .handback import HandbackCam, handback_cams, handback_dev  # noqa: F401,E402

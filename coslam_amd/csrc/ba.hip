@@ -2502,9 +2502,9 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
     // orders beyond the LDS solver whose pair lists were too large to build: Z Z^T on the matrix cores
     L.syrk = false;
     {
-        // COSLAM_BA_SYRK=0: never (k_schur); =2: always, also where the pair lists or the LDS solver would apply (tests)
-        const char* env = getenv("COSLAM_BA_SYRK");
-        const bool noSyrk = env && env[0] == '0', force = env && env[0] == '2';
+        // cs_debug_set("ba_syrk", 0): never (k_schur); 2: always, also where the pair lists or the LDS solver would apply (tests)
+        const int sw = cs_debug_get(CS_DBG_BA_SYRK);
+        const bool noSyrk = sw == 0, force = sw == 2;
         if (force && D.n > 0) D.pairPtr = nullptr, D.pairEnt = nullptr;
         if (!distributed && !noSyrk && !D.pairPtr && (D.n > SB_MAX_ORDER || (force && D.n > 0)) && P > 0 && nObs > 0) {
             SyrkDev& Y = L.Y;
@@ -2545,10 +2545,10 @@ static int ba_make_plan(cs_ba* b, int C, int P, int nObs, int nCamsCon, int nPts
             L.syrk = true;
         }
     }
-    // orders 37..176 with pair lists and a lane plan: the kernels that fit a few compute units (COSLAM_BA_PACKED=0: the
+    // orders 37..176 with pair lists and a lane plan: the kernels that fit a few compute units (cs_debug_set("ba_packed", 0): the
     // wave-per-point / workgroup-per-pair kernels, for A/B runs)
     {
-        const bool noPacked = getenv("COSLAM_BA_PACKED") && getenv("COSLAM_BA_PACKED")[0] == '0';
+        const bool noPacked = cs_debug_get(CS_DBG_BA_PACKED) == 0;
         L.packed = !noPacked && !distributed && !L.sliced && !L.syrk && D.pairPtr && b->nPackWaves > 0 &&
                    D.n > 36 && D.n <= SB_MAX_ORDER && P > 0 && nObs > 0;
         L.gPack = 0;
@@ -3781,8 +3781,7 @@ int cs_ba_solve_dev(cs_ba* b, void* hip_stream, int C, int P, int nObs, const do
     }
     CS_HIP(hipSetDevice(b->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : b->own_stream;
-    const char* env = getenv("COSLAM_BA_GRAPHS");
-    const bool useGraph = !(env && env[0] == '0');
+    const bool useGraph = cs_debug_get(CS_DBG_BA_GRAPHS) != 0;   // (cs_debug_set("ba_graphs", 0): eager launches keep their names under a profiler)
     cs_ba::GraphKey key = {C, P, nObs, nCamsCon, nPtsCon, maxIter, innerMaxIter, maxErr, d_Rs0, d_Ts0, d_pts0};
     if (useGraph && b->gexec && memcmp(&key, &b->gkey, sizeof(key)) == 0) {
         CS_HIP(hipGraphLaunch(b->gexec, s));

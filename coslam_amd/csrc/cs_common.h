@@ -16,6 +16,9 @@
 
 // ---- error plumbing -------------------------------------------------------------------------
 void cs_set_error(const char* fmt, ...);
+// test / diagnostic switches (cs_debug_set in the C-ABI; nothing reads the environment): -1 = not set
+enum { CS_DBG_BA_SYRK = 0, CS_DBG_BA_PACKED = 1, CS_DBG_BA_GRAPHS = 2, CS_DBG_MERGE_PRINT = 3, CS_DBG_COUNT = 4 };
+int cs_debug_get(int which);
 
 #define CS_HIP(call)                                                                              \
     do {                                                                                          \

@@ -20,10 +20,26 @@ void cs_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---- test / diagnostic switches: set through the C-ABI by whoever drives a test or a profile, never read from the environment ----
+#include <atomic>
+static std::atomic<int> g_dbg[CS_DBG_COUNT] = {{-1}, {-1}, {-1}, {-1}};
+int cs_debug_get(int which) { return which >= 0 && which < CS_DBG_COUNT ? g_dbg[which].load(std::memory_order_relaxed) : -1; }
+
 extern "C" {
 
 int cs_version(void) { return 100; }
 const char* cs_last_error(void) { return g_err; }
+int cs_debug_set(const char* key, int value) {
+    static const char* names[CS_DBG_COUNT] = {"ba_syrk", "ba_packed", "ba_graphs", "merge_print"};
+    for (int k = 0; k < CS_DBG_COUNT; ++k)
+        if (key && !strcmp(key, names[k])) {
+            g_dbg[k].store(value, std::memory_order_relaxed);
+            return CS_OK;
+        }
+    cs_set_error("cs_debug_set: unknown switch (ba_syrk, ba_packed, ba_graphs, merge_print)");
+    return CS_ERR_INVALID;
+}
+
 
 int cs_device_count(void) {
     int n = 0;

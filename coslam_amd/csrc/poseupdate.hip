@@ -2717,10 +2717,7 @@ extern "C" int cs_register_decide_merge_list_dev(const cs_track_history* h, void
     A.slot = d_slot, A.flags = d_flags, A.mergeable = d_mergeable, A.mapFlags = d_mapFlags, A.pointFeat = d_pointFeat;
     A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.attached = d_attached, A.regged = d_regged, A.inVec = (unsigned char*)d_scratch, A.counts = d_counts;
     A.list = d_list, A.nList = nList;
-    {
-        const char* dbg = getenv("COSLAM_MERGE_DEBUG");
-        A.debug = dbg && dbg[0] == '1';
-    }
+    A.debug = cs_debug_get(CS_DBG_MERGE_PRINT) == 1;   // (cs_debug_set("merge_print", 1): the kernel prints its own account)
     CS_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)hip_stream;
     if (P == 0) {

@@ -33,6 +33,13 @@ extern "C" {
 
 int cs_version(void);
 const char* cs_last_error(void);
+/* Test / diagnostic switches of the whole process (nothing in the library reads the environment): key one of
+ *   "ba_syrk"     0: never the matrix-core Schur product, 2: always (parity tests force a size-dependent path onto small problems)
+ *   "ba_packed"   0: the wave-per-point / workgroup-per-pair LM kernels instead of the packed ones (A/B runs, parity tests)
+ *   "ba_graphs"   0: eager launches instead of the captured graph (kernel names under a profiler)
+ *   "merge_print" 1: cs_register_decide_merge_dev's kernel prints its own time account
+ * value -1 restores the default.  Returns CS_ERR_INVALID for an unknown key. */
+int cs_debug_set(const char* key, int value);
 int cs_device_count(void);
 
 /* ------------------------------------------------------------------------------------------

@@ -154,12 +154,12 @@ def test_ba_random_large_shapes(hip, case):
     maxIter, inner = int(rng.integers(1, 3)), int(rng.integers(2, 8))
     pr, ptr, cam, xy = ba_inputs(**kw)
     if case % 2:
-        os.environ["COSLAM_BA_SYRK"] = "2"
+        coslam_amd.debug_set("ba_syrk", 2)
     try:
         Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
         out, st = coslam_amd.bundleAdjustRobust(ncon, pr["Ks"], Rs, Ts, npcon, pts, (ptr, cam, xy), 6.0, maxIter, inner)
     finally:
-        os.environ.pop("COSLAM_BA_SYRK", None)
+        coslam_amd.debug_set("ba_syrk", -1)
     R_o, T_o, M_o, out_o, st_o = oracle.ba_robust(pr["Ks"], pr["Rs0"], pr["ts0"], pr["pts0"], ptr, cam, xy, ncon, npcon, 6.0,
                                                   maxIter, inner)
     assert np.array_equal(out, out_o), (kw, (out != out_o).sum())
@@ -325,7 +325,7 @@ def test_ba_orders_of_the_dataflow_cholesky(hip, n_cams, ncon, vis):
 ])
 def test_schur_complement_on_the_matrix_cores_matches_oracle(hip, kw, ncon, npcon):
     """The reduced camera system as Z Z^T on v_mfma_f64_16x16x4f64 (ba_syrk_dev.h; the path large problems without pair lists
-    take, BASELINE cfg5) forced onto problems small enough for the oracle (COSLAM_BA_SYRK=2): same flags, same iteration
+    take, BASELINE cfg5) forced onto problems small enough for the oracle (cs_debug_set ba_syrk = 2): same flags, same iteration
     counts, same minimum as the oracle -- the summation order differs (K slices of 16-row panels instead of camera pairs),
     the tolerance is the BA's 1e-6."""
     kw = dict(kw)
@@ -334,12 +334,12 @@ def test_schur_complement_on_the_matrix_cores_matches_oracle(hip, kw, ncon, npco
     pr, ptr, cam, xy = ba_inputs(**kw)
     res = {}
     for mode in ("2", "0"):
-        os.environ["COSLAM_BA_SYRK"] = mode
+        coslam_amd.debug_set("ba_syrk", int(mode))
         try:
             Rs, Ts, pts = pr["Rs0"].copy(), pr["ts0"].copy(), pr["pts0"].copy()
             out, st = coslam_amd.bundleAdjustRobust(ncon, pr["Ks"], Rs, Ts, npcon, pts, (ptr, cam, xy), 6.0, 2, 8)
         finally:
-            del os.environ["COSLAM_BA_SYRK"]
+            coslam_amd.debug_set("ba_syrk", -1)
         res[mode] = (Rs, Ts, pts, out, st)
     Rs, Ts, pts, out, st = res["2"]
     _check_vs_oracle(pr, ptr, cam, xy, ncon, npcon, 6.0, 2, 8, Rs, Ts, pts, out, st)
@@ -351,11 +351,11 @@ def test_schur_complement_on_the_matrix_cores_matches_oracle(hip, kw, ncon, npco
 
 def _solve_in_workspace(pr, ptr, cam, xy, ncon, npcon, maxIter, inner, packed=True, use_async=False):
     """upload + cs_ba_solve_dev: the device-resident form the frame loop uses (pair lists, lane plan -> the packed LM-step
-    kernels of ba_packed_dev.h unless COSLAM_BA_PACKED=0)"""
+    kernels of ba_packed_dev.h unless cs_debug_set ba_packed = 0)"""
     import torch
 
     if not packed:
-        os.environ["COSLAM_BA_PACKED"] = "0"
+        coslam_amd.debug_set("ba_packed", 0)
     try:
         ws = coslam_amd.BAWorkspace(0)
         ws.upload(pr["Ks"], pr["Rs0"], pr["ts0"], pr["pts0"], ptr, cam, xy)
@@ -366,7 +366,7 @@ def _solve_in_workspace(pr, ptr, cam, xy, ncon, npcon, maxIter, inner, packed=Tr
         R, T, M, out, st = ws.download()
         ws.close()
     finally:
-        os.environ.pop("COSLAM_BA_PACKED", None)
+        coslam_amd.debug_set("ba_packed", -1)
     return R, T, M, out, st
 
 
@@ -375,7 +375,7 @@ def test_packed_lm_step_kernels_match_oracle(hip, case):
     """The LM step that fits a few compute units (ba_packed_dev.h: whole points back to back in a wave, one wave per camera
     pair, the LM control folded into the next linearisation, current / tentative estimates as two buffers and an index) -- what
     the frame loop's two key-frame solves run -- against the oracle (flags, iteration counts, 1e-6) and against the
-    wave-per-point / workgroup-per-pair kernels on the same device (COSLAM_BA_PACKED=0)."""
+    wave-per-point / workgroup-per-pair kernels on the same device (cs_debug_set ba_packed = 0)."""
     if isinstance(case, str):
         joint, ic = _headline_problems("bench" if case.startswith("bench") else "test")
         if case.endswith("joint"):

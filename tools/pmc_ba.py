@@ -11,7 +11,7 @@ from coslam_amd.synth import make_ba_problem
 
 dev = torch.device("cuda:0")
 s = torch.cuda.current_stream().cuda_stream
-os.environ.setdefault("COSLAM_BA_GRAPHS", "0")   # eager launches: per-kernel records keep their names under the profiler
+coslam_amd.debug_set("ba_graphs", 0)   # eager launches: per-kernel records keep their names under the profiler
 
 
 def solve(pr, ncon, npcon, maxIter, inner, reps):
