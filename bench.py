@@ -1264,7 +1264,7 @@ def main():
                    "what": "coslam_amd/frameloop.py: the same loop driven from Python (ctypes), timed in this process per the bench contract"}
         cxx_ok = (isinstance(cxx, dict) and "error" not in cxx and cxx.get("frames_per_s") and cxx.get("steps") == args.steps and
                   cxx.get("pose_ok", True) and (n_gpus == 1 or cxx.get("identical_digest_on_every_rank")))
-        value, ms_step = (float(cxx["frames_per_s"]), float(cxx["ms_per_step"])) if cxx_ok else (py_loop["frames_per_s"], py_loop["ms_per_step"])
+        value, ms_step = (float(cxx["frames_per_s"]), 1e3 / float(cxx["frames_per_s"])) if cxx_ok else (py_loop["frames_per_s"], py_loop["ms_per_step"])
         out = {
             "metric": "frames/sec for track+local-BA loop, 8 cams 640x480 x 2000 feats (one frame = all 8 cameras)",
             "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps,
