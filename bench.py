@@ -731,6 +731,7 @@ def main():
     barrier()
     ba_ws.worker_stats(), [w.worker_stats() for w in loop.ic_wss]   # (reset: the sums below cover the timed region only)
     applied0 = loop.applied
+    rv0 = loop.d_rv_counts.cpu().tolist()   # (the second visits' counters at the start of the timed region: the first frame's bootstrap is behind us)
     prof = None
     if os.environ.get("BENCH_PYPROFILE") and rank == 0:   # where the host thread's time goes (diagnostic: slows the loop)
         import cProfile
@@ -1278,7 +1279,7 @@ def main():
                                       "map points, the dynamic-point test (64-frame history) and mapPointsClassify") + "; currentMapPointsRegister "
                                    "every frame over the frame's CURRENT map points (a list built on the device: every point with a feature of this "
                                    "frame, new ones included; search x 8 cams x 2000 slots, staticCheckMergability over WHOLE tracks as a running "
-                                   "verdict, the decision settled in one launch, refineMapPoint" + (" over feature references -- MapPoint::pFeatures as the reference holds them: stale features are views, a re-registered point's old chain is linked behind the new feature" if cfg.feature_chains else "") + "), every 50th frame with bMerge (checkUnify); "
+                                   "verdict, the decision settled in one launch, refineMapPoint, then the reference's SECOND VISITS of the points that registered -- two rounds of list / search / mergability / walks / refine over just those points" + (" over feature references -- MapPoint::pFeatures as the reference holds them: stale features are views, a re-registered point's old chain is linked behind the new feature" if cfg.feature_chains else "") + "), every 50th frame with bMerge (checkUnify); "
                                    "activeMapPointsRegister's search is not run (its attach loop is unreachable in the reference: "
                                    "tests/cxx/ref_active_test.cpp); every 4th frame the NCC matching of the consecutive camera pairs (F from the "
                                    f"poses just solved) -> new map points; every {KEY_EVERY}th frame: joint local BA C=40 (16 fixed), "
@@ -1335,6 +1336,16 @@ def main():
                            ("features_attached_last_frame", "points_regged_last_frame", "sweeps_last_frame", "converged"), dec_counts[0]),
                            points_refined_last_frame=dec_counts[1],
                            frames_whose_sweeps_did_not_settle=dec_counts[2],
+                           second_visits=dict(zip(("features_attached", "registrations", "conflicts_counted", "rounds_unsettled"), loop.d_rv_counts.cpu().tolist()),
+                                              since_the_timed_region_began=dict(zip(("features_attached", "registrations", "conflicts_counted", "rounds_unsettled"),
+                                                                                    [a - b for a, b in zip(loop.d_rv_counts.cpu().tolist(), rv0)])),
+                                              rounds_per_frame=loop.cfg.revisit_rounds, points_beyond_the_list=int(loop.d_rv_listcounts[1].item()),
+                                              what="the reference visits a point that registered AGAIN, refined, in its next camera's loop "
+                                                   "(SL_CoSLAM.cpp:864-869, :889-893): played behind the single pass in rounds over just those points "
+                                                   "(cs_register_revisit_*); counts over the whole run of this process.  tools/r06_exact_vs_single.py / "
+                                                   "profiles/r06_exact_vs_single.txt: with two rounds 450 of 450 compared frames end in the map of the "
+                                                   "reference's step-for-step order, byte for byte; conflicts_counted = visits whose outcome the reference's "
+                                                   "order would have changed and the rounds could not take back (0 outside the first frame's bootstrap)"),
                            merge=None if not hasattr(loop, "_dec") else dict(
                                every_frames=loop.cfg.merge_every, bmerge_frames=loop.n_merge_frames,
                                what="every 50th frame the static points' walks run with bMerge (CoSLAMThread.cpp:117-118): one after the other, "

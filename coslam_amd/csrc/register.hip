@@ -680,8 +680,268 @@ __global__ __launch_bounds__(256) void k_decide_settle(RdArgs A) {
     }
 }
 
+// ---- the SECOND VISITS of the reference's order (round 6) -----------------------------------------------------------------------------
+// CoSLAM::curStaticPointsRegInGroup builds every camera's visiting list afresh (src/app/SL_CoSLAM.cpp:864-869) and refines the points that
+// gained a feature at the end of every camera's loop (:889-893): a point that registers in camera a's loop is visited AGAIN in the loop of
+// every later camera b in which it holds a feature of this frame -- the one it has just gained included -- projected with its refined
+// position.  A later visit of a point that did NOT register changes nothing (same position, same candidates, and a candidate can only have
+// gone from unmapped to mapped since, which ends a walk earlier): the single pass above is the reference's run up to the second visits of
+// the points it registered.  Those are played here, in rounds: round r visits the points that registered in round r - 1 (round 0 = the
+// single pass) in their next loop -- behind a search and a mergability pass over JUST those points at their refined positions -- and a
+// refine of the ones that registered again follows.  One workgroup, a thread per listed point; the visits of a round are ordered among
+// themselves like all walks ((loop x P + point) x C + camera, Jacobi sweeps over the features they compete for).
+// What a round cannot do is take back what a LATER-ordered visit of the single pass did with a feature this visit would have reached
+// first: such a frame is counted (conflicts) and left as the single pass decided.  tools/r06_exact_vs_single.py measures what remains.
+struct RvListArgs {
+    int nCams, P, cap, firstRound;
+    const int* pointFeat;              // [P][nCams]
+    const unsigned char* attached;     // [P][nCams]: attached in THIS frame (the single pass's and the rounds' so far)
+    unsigned char* regIn;              // [P]: registered in the previous round (read; cleared unless keepIn)
+    int keepIn;
+    unsigned char* regOutClear;        // [P] or null: the array this round's walks will mark -- cleared here (it may hold an earlier frame's marks)
+    int* visitLoop;                    // [P]: the loop of the point's latest registering visit
+    int* nextLoop;                     // [P]: the loop of the visit listed here
+    int* list;                         // [cap] out, padded with -1
+    int* counts;                       // [4]: listed, overflow (points beyond cap), -, -
+};
+__global__ __launch_bounds__(1024) void k_revisit_list(RvListArgs A) {
+    __shared__ int sCount;
+    const int tid = threadIdx.x, C = A.nCams;
+    if (tid == 0) sCount = 0;
+    __syncthreads();
+    for (int p = tid; p < A.P; p += 1024) {
+        if (A.regOutClear) A.regOutClear[p] = 0;
+        if (!A.regIn[p]) continue;
+        if (!A.keepIn) A.regIn[p] = 0;
+        int last;
+        if (A.firstRound) {   // the loop of its first visit: the first camera that held a feature of this frame BEFORE the pass attached any
+            last = -1;
+            for (int c = C - 1; c >= 0; --c)
+                if (A.pointFeat[(size_t)p * C + c] >= 0 && !A.attached[(size_t)p * C + c]) last = c;
+            A.visitLoop[p] = last;
+        } else {
+            last = A.visitLoop[p];
+        }
+        if (last < 0) continue;
+        int b = -1;
+        for (int c = C - 1; c > last; --c)
+            if (A.pointFeat[(size_t)p * C + c] >= 0) b = c;
+        if (b < 0) continue;   // no later loop holds the point: it is not visited again
+        const int k = atomicAdd(&sCount, 1);
+        if (k < A.cap) A.list[k] = p, A.nextLoop[p] = b;
+    }
+    __syncthreads();
+    const int n = sCount < A.cap ? sCount : A.cap;
+    for (int k = n + tid; k < A.cap; k += 1024) A.list[k] = -1;
+    if (tid == 0 && A.counts) {
+        A.counts[0] = n;
+        if (sCount > A.cap) atomicAdd(A.counts + 1, sCount - A.cap);
+    }
+}
+
+struct RvArgs {
+    int nCams, N, P, cap, mapBase, kinds;
+    const int* list;                 // [cap]: the points visited again (k_revisit_list)
+    const int* nextLoop;             // [P]
+    int* visitLoop;                  // [P]
+    const int* slot;                 // the search's tables over the listed rows, [P][nCams]
+    const int* flags;
+    const unsigned char* mergeable;
+    const unsigned char* mapFlags;
+    int* pointFeat;
+    int* slot2map[RD_MAX_CAMS];
+    unsigned char* attached;         // [P][nCams]: set where this round attaches
+    unsigned char* regOut;           // [P]: set for the points that registered in this round
+    int* owner[3];                   // the decision's owner arrays (scratch): only the entries of this round's candidates are touched
+    const int* curList;              // the frame's current points (cs_register_list_current_dev) and their count: who else wanted a feature
+    const int* curCount;
+    int curCap;
+    int* counts;                     // [4] (accumulating): features attached, points registered, conflicts, sweeps that did not settle
+};
+constexpr int RV_MAX_ROWS = 1024;
+__global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
+    __shared__ int sChanged, sAttF[256], sAttKey[256], sNAtt;
+    const int j = threadIdx.x, C = A.nCams;
+    const int p = j < A.cap ? A.list[j] : -1;
+    int code[RD_MAX_CAMS], base = -1, kind = -1, nConf = 0;
+#pragma unroll
+    for (int i = 0; i < RD_MAX_CAMS; ++i) code[i] = -1;
+    if (j == 0) sNAtt = 0;
+    if (p >= 0 && p < A.P) {
+        const unsigned char fl = A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN);
+        kind = (fl == 0 && (A.kinds & 1)) ? 0 : ((fl == CS_MAP_DYNAMIC && (A.kinds & 2)) ? 1 : -1);
+        if (kind >= 0) base = (A.nextLoop[p] * A.P + p) * C;
+    }
+    if (base >= 0) {
+#pragma unroll
+        for (int i = 0; i < RD_MAX_CAMS; ++i) {
+            if (i >= C) continue;
+            const size_t k = (size_t)p * C + i;
+            if (A.pointFeat[k] >= 0) continue;                               // :736-737
+            const int sl = A.slot[k];
+            if (sl < 0 || sl >= A.N || ((A.flags[k] >> 1) & 1) != kind) continue;   // nothing found / a feature of the other type
+            int c = i * A.N + sl;
+            const int own = A.slot2map[i][sl] - A.mapBase;
+            if (own >= 0) {
+                c |= RD_INIT_MAPPED;
+                // mapped NOW.  Was it mapped when this visit takes place?  Not if a later-ordered visit of this frame attached it.
+                if (own < A.P && A.attached[(size_t)own * C + i] && A.pointFeat[(size_t)own * C + i] == sl &&
+                    (A.visitLoop[own] * A.P + own) * C + i > base + i)
+                    ++nConf;
+            } else if (A.mergeable[k] == 1) {
+                c |= RD_CAN_MERGE;
+            }
+            code[i] = c;
+        }
+#pragma unroll
+        for (int i = 0; i < RD_MAX_CAMS; ++i)
+            if (code[i] >= 0) rd_st(A.owner[0] + (code[i] & RD_FEAT), RD_INF), rd_st(A.owner[1] + (code[i] & RD_FEAT), RD_INF), rd_st(A.owner[2] + (code[i] & RD_FEAT), RD_INF);
+    }
+    __threadfence();
+    __syncthreads();
+    // Jacobi sweeps among the round's visits (k_decide_settle's recursion, one workgroup)
+    int k = 0;
+    const int* fin = A.owner[0];
+    bool settled = false;
+    for (; k < 32; ++k) {
+        const int* prev = A.owner[k % 3];
+        int* next = A.owner[(k + 1) % 3];
+        int* clear = A.owner[(k + 2) % 3];
+        if (j == 0) sChanged = 0;
+        if (base >= 0) {
+#pragma unroll
+            for (int i = 0; i < RD_MAX_CAMS; ++i)
+                if (code[i] >= 0) rd_st(clear + (code[i] & RD_FEAT), RD_INF);
+        }
+        __syncthreads();
+        if (base >= 0) {
+            bool go = true;
+#pragma unroll
+            for (int i = 0; i < RD_MAX_CAMS; ++i) {
+                if (go && code[i] >= 0) {
+                    const int ord = base + i, f = code[i] & RD_FEAT;
+                    if ((code[i] & RD_INIT_MAPPED) || rd_ld(prev + f) < ord) go = false;
+                    else if (code[i] & RD_CAN_MERGE) atomicMin(&next[f], ord);
+                }
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        if (base >= 0) {
+            int ch = 0;
+#pragma unroll
+            for (int i = 0; i < RD_MAX_CAMS; ++i)
+                if (code[i] >= 0) ch |= rd_ld(next + (code[i] & RD_FEAT)) != rd_ld(prev + (code[i] & RD_FEAT));
+            if (ch) sChanged = 1;
+        }
+        __syncthreads();
+        fin = next;
+        const int chg = sChanged;
+        __syncthreads();
+        if (!chg) {
+            settled = true;
+            break;
+        }
+    }
+    // attach (the owners in `fin` are final)
+    bool reg = false;
+    int nAtt = 0;
+    if (base >= 0) {
+        bool go = true;
+#pragma unroll
+        for (int i = 0; i < RD_MAX_CAMS; ++i) {
+            if (go && code[i] >= 0) {
+                const int ord = base + i, f = code[i] & RD_FEAT, own = rd_ld(fin + f);
+                if ((code[i] & RD_INIT_MAPPED) || own < ord) {
+                    go = false;
+                } else if ((code[i] & RD_CAN_MERGE) && own == ord) {
+                    const int s2 = f - i * A.N;
+                    A.slot2map[i][s2] = A.mapBase + p;
+                    A.pointFeat[(size_t)p * C + i] = s2;
+                    A.attached[(size_t)p * C + i] = 1;
+                    reg = true, ++nAtt;
+                    const int q = atomicAdd(&sNAtt, 1);
+                    if (q < 256) sAttF[q] = f, sAttKey[q] = ord;
+                }
+            }
+        }
+        if (reg) A.regOut[p] = 1, A.visitLoop[p] = A.nextLoop[p];
+    }
+    __syncthreads();
+    // a feature attached here was unmapped until now: a LATER-ordered visit of this frame that had it as its candidate walked past it (it
+    // could not take it) and went on to other cameras -- in the reference's order that walk ends at it.  Counted where that walk attached
+    // something behind it (what it did there would not have happened).
+    const int nA = sNAtt < 256 ? sNAtt : 256;
+    if (nA > 0) {
+        const int nCur = *A.curCount < A.curCap ? *A.curCount : A.curCap;
+        for (int e = j; e < nCur; e += (int)blockDim.x) {
+            const int q = A.curList[e];
+            if (q < 0 || q >= A.P) continue;
+            for (int a = 0; a < nA; ++a) {
+                const int f = sAttF[a], i = f / A.N, sl = f - i * A.N;
+                const size_t kq = (size_t)q * C + i;
+                if (A.slot[kq] != sl || A.pointFeat[kq] >= 0) continue;
+                int lq = -1;   // the loop of q's (first) visit in this frame
+                for (int c = C - 1; c >= 0; --c)
+                    if (A.pointFeat[(size_t)q * C + c] >= 0 && !A.attached[(size_t)q * C + c]) lq = c;
+                if (lq < 0 || (lq * A.P + q) * C + i <= sAttKey[a]) continue;
+                bool later = false;
+                for (int c = i + 1; c < C; ++c) later |= A.attached[(size_t)q * C + c] != 0;
+                if (later) ++nConf;
+            }
+        }
+    }
+    if (A.counts) {
+        if (nAtt) atomicAdd(A.counts, nAtt);
+        if (reg) atomicAdd(A.counts + 1, 1);
+        if (nConf) atomicAdd(A.counts + 2, nConf);
+        if (j == 0 && !settled) atomicAdd(A.counts + 3, 1);
+    }
+}
+
 }  // namespace
 
+extern "C" int cs_register_revisit_list_dev(int device, void* hip_stream, int nCams, int P, int cap, int firstRound, const int* d_pointFeat,
+                                            const unsigned char* d_attached, unsigned char* d_regIn, int keepIn, unsigned char* d_regOutClear,
+                                            int* d_visitLoop, int* d_nextLoop, int* d_list, int* d_counts) {
+    if (nCams < 1 || nCams > RD_MAX_CAMS || P < 1 || cap < 1 || cap > RV_MAX_ROWS || !d_pointFeat || !d_attached || !d_regIn || d_regOutClear == d_regIn || !d_visitLoop || !d_nextLoop ||
+        !d_list) {
+        cs_set_error("cs_register_revisit_list_dev: bad arguments (1..%d cameras, 1..%d rows)", RD_MAX_CAMS, RV_MAX_ROWS);
+        return CS_ERR_INVALID;
+    }
+    RvListArgs A;
+    A.nCams = nCams, A.P = P, A.cap = cap, A.firstRound = firstRound ? 1 : 0, A.pointFeat = d_pointFeat, A.attached = d_attached;
+    A.regIn = d_regIn, A.keepIn = keepIn ? 1 : 0, A.regOutClear = d_regOutClear, A.visitLoop = d_visitLoop, A.nextLoop = d_nextLoop, A.list = d_list, A.counts = d_counts;
+    CS_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_revisit_list, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, A);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
+
+extern "C" int cs_register_revisit_decide_dev(int device, void* hip_stream, int nCams, int N, int P, int cap, int mapBase, int kinds, const int* d_list,
+                                              const int* d_nextLoop, int* d_visitLoop, const int* d_slot, const int* d_flags,
+                                              const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
+                                              int* const* d_slot2map, unsigned char* d_attached, unsigned char* d_regOut, void* d_decideScratch,
+                                              const int* d_curList, const int* d_curCount, int curCap, int* d_counts) {
+    if (nCams < 1 || nCams > RD_MAX_CAMS || N < 1 || P < 1 || cap < 1 || cap > RV_MAX_ROWS || kinds < 1 || kinds > 3 || !d_list || !d_nextLoop || !d_visitLoop ||
+        !d_slot || !d_flags || !d_mergeable || !d_mapFlags || !d_pointFeat || !d_slot2map || !d_attached || !d_regOut || !d_decideScratch ||
+        !d_curList || !d_curCount || (long long)nCams * N > RD_FEAT || (long long)nCams * P * nCams > 0x7fffffffLL) {
+        cs_set_error("cs_register_revisit_decide_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    RvArgs A;
+    memset(&A, 0, sizeof(A));
+    A.nCams = nCams, A.N = N, A.P = P, A.cap = cap, A.mapBase = mapBase, A.kinds = kinds, A.list = d_list, A.nextLoop = d_nextLoop, A.visitLoop = d_visitLoop;
+    A.slot = d_slot, A.flags = d_flags, A.mergeable = d_mergeable, A.mapFlags = d_mapFlags, A.pointFeat = d_pointFeat;
+    for (int c = 0; c < nCams; ++c) A.slot2map[c] = d_slot2map[c];
+    A.attached = d_attached, A.regOut = d_regOut, A.curList = d_curList, A.curCount = d_curCount, A.curCap = curCap, A.counts = d_counts;
+    int* scr = (int*)d_decideScratch + (size_t)nCams * P + P;   // (cs_register_decide_kinds_dev's carve-up: code | base | owner x 3 | ...)
+    for (int k = 0; k < 3; ++k) A.owner[k] = scr, scr += (size_t)nCams * N;
+    CS_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_revisit_decide, dim3(1), dim3(cap <= 256 ? 256 : (cap + 63) / 64 * 64), 0, (hipStream_t)hip_stream, A);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
 extern "C" size_t cs_register_decide_scratch_bytes(int nCams, int N, int P) {
     if (nCams < 1 || N < 1 || P < 0) return 0;
     return sizeof(int) * ((size_t)nCams * P + (size_t)P + 3 * (size_t)nCams * N + RD_MAX_SWEEPS + 3);

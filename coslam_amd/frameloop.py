@@ -79,6 +79,9 @@ class LoopConfig:
         self.with_decide = True    # the registration decision (who attaches which feature) + refineMapPoint of the points that gained one
         self.merge_every = 50      # bMerge: every 50th frame the static points' walks may UNIFY two points (CoSLAMThread.cpp:117-118:
         # `i % 50 == 0`; cs_register_decide_merge_dev, sequential); 0: never
+        self.revisit_rounds = 2   # the reference's SECOND VISITS behind the single-pass registration: a point that registered is refined and
+        #                           visited again in its next camera's loop (SL_CoSLAM.cpp:864-869, :889-893) -- rounds of list + search +
+        #                           mergability + walks + refine over just those points (cs_register_revisit_*).  0: the single pass alone
         self.sequential_registration = False   # the decision camera loop after camera loop with a search + refine per loop, as the
         # reference runs it (register_cur_static_sequential_dev: bit-identical to the reference's run, nCams x the launches; one rank only)
         self.native_comm = True
@@ -295,6 +298,13 @@ class FrameLoop:
                                slot=a_["slot"].data_ptr(), m=a_["m"].data_ptr(), var=a_["var"].data_ptr(), dist=a_["dist"].data_ptr(),
                                flags=a_["flags"].data_ptr()))
         self.reg_passes = register_passes(passes)
+        # the second visits' rounds (cfg.revisit_rounds): their own short list, the same tables (rows of listed points only are rewritten)
+        self.RV_CAP = 1024
+        self.d_rvlist = torch.full((self.RV_CAP,), -1, dtype=i32, device=dev)
+        self.d_rv_visit, self.d_rv_next = z(n_map, i32), z(n_map, i32)
+        self.d_rv_reg = [z(n_map, torch.uint8), z(n_map, torch.uint8)]
+        self.d_rv_counts, self.d_rv_listcounts = z(4, i32), z(4, i32)
+        self.rv_pass = register_passes([dict(cur_pass, P=self.RV_CAP, list=self.d_rvlist.data_ptr())])
         # ---- key-frame solves
         # the inter-camera solves of consecutive key frames are independent of each other (each starts from its own frame's poses):
         # key frame k of this rank goes to workspace k mod ic_workers, each with its own worker thread, stream and staging
@@ -816,6 +826,35 @@ class FrameLoop:
                                               D["att"].data_ptr(), D["reg"].data_ptr(), D["scr"].data_ptr(), D["cnt"].data_ptr(), device=self.device,
                                               kinds=kinds, n_sweeps=0)   # (0: ONE launch that sweeps until the owners have settled)   # curStaticPointsRegInGroup and curDynamicPointsRegInGroup (currentMapPointsRegister, :834-853)
         self._refine(ps, D["reg"].data_ptr())
+        if cfg.revisit_rounds > 0 and kinds == 3:
+            self._revisit_rounds(ps, D)
+
+    def _revisit_rounds(self, ps, D):
+        """The reference's SECOND VISITS (src/app/SL_CoSLAM.cpp:864-869, :889-893) behind the single pass and its refine: the points that
+        registered are visited again in their next camera's loop, from their refined positions -- list, search, whole-track mergability
+        (no cached tail: tolPix 0), the walks, refine; the points that registered again go round once more.  Every rank plays the rounds
+        for ALL cameras on its replica (the lists are short): no collective."""
+        from coslam_amd.register import register_revisit_decide_dev, register_revisit_list_dev, register_search_passes_dev
+
+        cfg, NA = self.cfg, self.cfg.n_cams
+        reg_in, keep = D["reg"], True
+        for r in range(cfg.revisit_rounds):
+            reg_out = self.d_rv_reg[r & 1]
+            register_revisit_list_dev(ps, NA, self.n_map, self.RV_CAP, r == 0, self.d_pf.data_ptr(), D["att"].data_ptr(), reg_in.data_ptr(), keep,
+                                      self.d_rv_visit.data_ptr(), self.d_rv_next.data_ptr(), self.d_rvlist.data_ptr(), self.d_rv_listcounts.data_ptr(),
+                                      device=self.device, d_regOutClear=reg_out.data_ptr())
+            register_search_passes_dev(ps, self.reg_args[self._dst_now], cfg.n_feat, cfg.W, cfg.H, self.rv_pass, device=self.device)
+            self.pose_upd.register_mergability_running_dev(ps, self.pu_args, self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
+                                                           self.reg_out["slot"].data_ptr(), self.sig_pix, self.d_merge_cache.data_ptr(),
+                                                           self.d_mergeable.data_ptr(), tolPix=0.0, d_counts=0, cam0=0, nCamsRun=NA,
+                                                           d_list=self.d_rvlist.data_ptr(), nList=self.RV_CAP, d_flags=self.reg_out["flags"].data_ptr())
+            D["s2m"] = register_revisit_decide_dev(ps, NA, cfg.n_feat, self.n_map, self.RV_CAP, 0, 3, self.d_rvlist.data_ptr(), self.d_rv_next.data_ptr(),
+                                                   self.d_rv_visit.data_ptr(), self.reg_out["slot"].data_ptr(), self.reg_out["flags"].data_ptr(),
+                                                   self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(), D["s2m"],
+                                                   D["att"].data_ptr(), reg_out.data_ptr(), D["scr"].data_ptr(), self.d_curlist.data_ptr(),
+                                                   self.d_curcount.data_ptr(), cfg.p_reg, self.d_rv_counts.data_ptr(), device=self.device)
+            self._refine(ps, reg_out.data_ptr())
+            reg_in, keep = reg_out, False
 
     def _advance_refs(self, ps):
         """MapPoint::pFeatures of this frame: cs_feat_ref_advance_dev behind whatever changed pointFeat (hand-back, classification, the

@@ -141,6 +141,27 @@ def register_decide_static_dev(stream_ptr, nCams, N, P, mapBase, d_slot, d_flags
     return arr
 
 
+def register_revisit_list_dev(stream_ptr, nCams, P, cap, first_round, d_pointFeat, d_attached, d_regIn, keep_in, d_visitLoop, d_nextLoop, d_list,
+                              d_counts=0, device=0, d_regOutClear=0):
+    """cs_register_revisit_list_dev: the points that registered in the previous round and are visited again in a later camera's loop"""
+    vp = C.c_void_p
+    check(lib().cs_register_revisit_list_dev(int(device), vp(stream_ptr), int(nCams), int(P), int(cap), int(bool(first_round)), vp(d_pointFeat),
+                                             vp(d_attached), vp(d_regIn), int(bool(keep_in)), vp(d_regOutClear), vp(d_visitLoop), vp(d_nextLoop), vp(d_list), vp(d_counts)),
+          "cs_register_revisit_list_dev")
+
+
+def register_revisit_decide_dev(stream_ptr, nCams, N, P, cap, mapBase, kinds, d_list, d_nextLoop, d_visitLoop, d_slot, d_flags, d_mergeable, d_mapFlags,
+                                d_pointFeat, d_slot2map, d_attached, d_regOut, d_decideScratch, d_curList, d_curCount, curCap, d_counts=0, device=0):
+    """cs_register_revisit_decide_dev: the listed points' walks in their next loop (see include/coslam_hip.h)"""
+    vp = C.c_void_p
+    arr = d_slot2map if isinstance(d_slot2map, C.Array) else (C.c_void_p * nCams)(*[int(x) for x in d_slot2map])
+    check(lib().cs_register_revisit_decide_dev(int(device), vp(stream_ptr), int(nCams), int(N), int(P), int(cap), int(mapBase), int(kinds), vp(d_list),
+                                               vp(d_nextLoop), vp(d_visitLoop), vp(d_slot), vp(d_flags), vp(d_mergeable), vp(d_mapFlags),
+                                               vp(d_pointFeat), arr, vp(d_attached), vp(d_regOut), vp(d_decideScratch), vp(d_curList), vp(d_curCount),
+                                               int(curCap), vp(d_counts)), "cs_register_revisit_decide_dev")
+    return arr
+
+
 def register_cur_static_sequential_dev(stream_ptr, history, pu_cams, reg_cams, N, W, H, search_pass, P, d_slot, d_flags, d_mergeable, d_mapFlags,
                                        d_pointFeat, d_slot2map, d_attached, d_regged, d_scratch, d_mapPts, d_mapCov, pixelVar, d_counts=0,
                                        after_loop=None, device=0, n_sweeps=6, with_dynamic=False, merge=False, d_merge_scratch=0, mergability=None):

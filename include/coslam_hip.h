@@ -437,6 +437,32 @@ int cs_register_decide_kinds_dev(int device, void* hip_stream, int nCams, int N,
                                  unsigned char* d_attached, unsigned char* d_regged, void* d_scratch, int nSweeps, int* d_counts, int onlyCam,
                                  int kinds);
 
+/* The SECOND VISITS of the reference's order (src/app/SL_CoSLAM.cpp:864-869, :889-893): a point that registers a feature in camera a's
+ * loop is refined at the end of that loop and visited AGAIN in the loop of the next camera in which it now holds a feature of this frame.
+ * (A later visit of a point that did not register changes nothing, so cs_register_decide_kinds_dev's single pass IS the reference's run
+ * up to these visits.)  Played in rounds behind the single pass + its refine:
+ *   cs_register_revisit_list_dev    the points that registered in the previous round (d_regIn [P]: the single pass's d_regged with
+ *                                   firstRound = 1 / keepIn = 1, later the previous round's d_regOut) and have a later loop: d_list [cap],
+ *                                   padded with -1; d_visitLoop / d_nextLoop [P] ints keep the loops; d_counts [4]: listed, beyond cap
+ *   -- then the caller's search (cs_register_pass.list = d_list, P = cap) and mergability pass over those rows at their refined positions --
+ *   cs_register_revisit_decide_dev  the listed points' walks in their next loop, ordered among themselves like all walks; attaches, sets
+ *                                   d_regOut; d_decideScratch = the single pass's scratch (its owner arrays are reused); d_curList /
+ *                                   d_curCount: the frame's current points.  d_counts [4], accumulating: features attached, points
+ *                                   registered, CONFLICTS (this visit met a feature that a later-ordered visit of the frame had already
+ *                                   taken, or took one that such a visit had walked past before attaching elsewhere: the reference's order
+ *                                   would have ended differently -- counted, not repaired), rounds whose sweeps did not settle
+ *   -- then the caller's refine of d_regOut's points, and the next round.
+ * cap <= 1024 rows; one workgroup each. */
+int cs_register_revisit_list_dev(int device, void* hip_stream, int nCams, int P, int cap, int firstRound, const int* d_pointFeat,
+                                 const unsigned char* d_attached, unsigned char* d_regIn, int keepIn, unsigned char* d_regOutClear /* [P] or NULL: the
+                                 array this round's cs_register_revisit_decide_dev will mark, zeroed here; not d_regIn */,
+                                 int* d_visitLoop, int* d_nextLoop, int* d_list, int* d_counts);
+int cs_register_revisit_decide_dev(int device, void* hip_stream, int nCams, int N, int P, int cap, int mapBase, int kinds, const int* d_list,
+                                   const int* d_nextLoop, int* d_visitLoop, const int* d_slot, const int* d_flags, const unsigned char* d_mergeable,
+                                   const unsigned char* d_mapFlags, int* d_pointFeat, int* const* d_slot2map, unsigned char* d_attached,
+                                   unsigned char* d_regOut, void* d_decideScratch, const int* d_curList, const int* d_curCount, int curCap,
+                                   int* d_counts);
+
 /* Cameras sharded over GPUs: a rank searches for its own cameras (cs_register_search_passes_range_dev, cs_register_mergability_range_dev);
  * the decision needs every camera's candidates.  pack: columns cam0 .. cam0 + nOwn - 1 of the P x nCams tables into a send record of
  * 3 * nOwn * P ints; unpack: the records of all ranks (cs_comm_allgather_dev: rank r owns cameras r * nOwn ..) into the tables

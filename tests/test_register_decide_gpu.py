@@ -229,7 +229,7 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
     dev = torch.device("cuda:0")
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
     s_ = torch.cuda.current_stream().cuda_stream
-    att_total = diff_total = dyn_total = merged_total = 0
+    att_total = diff_total = dyn_total = merged_total = rv_left_total = rv_conf_total = 0
     for sc in range(int(g["n_scenes"])):
         S = _decide_scene(g, sc)
         want = None if S["with_merge"] else single_pass_registration(S)     # (scenes 5, 6: bMerge == true, the step-for-step mode only)
@@ -295,6 +295,46 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
             assert np.array_equal(dreg.cpu().numpy(), want["reg"]) and np.array_equal(dM.cpu().numpy(), want["M"]) and np.array_equal(dcov.cpu().numpy(), want["cov"])
             att_total += int((S["ref_s2m"] != S["s2m"]).sum())
             diff_total += int((ds2m.cpu().numpy() != S["ref_s2m"]).sum())
+            # ---- ... and the reference's SECOND VISITS behind it (round 6, cs_register_revisit_*): the points that registered, from their
+            # refined positions, in their next camera's loop -- rounds until nobody registers again.  Where no conflict is counted the map
+            # is then the reference's own, bit for bit.
+            from coslam_amd.register import register_revisit_decide_dev, register_revisit_list_dev
+
+            CAP = 256
+            rvlist = torch.full((CAP,), -1, dtype=torch.int32, device=dev)
+            visit, nxt = torch.zeros(nP, dtype=torch.int32, device=dev), torch.zeros(nP, dtype=torch.int32, device=dev)
+            rv_reg = [torch.zeros(nP, dtype=torch.uint8, device=dev) for _ in range(2)]
+            rv_cnt, rv_lcnt = torch.zeros(4, dtype=torch.int32, device=dev), torch.zeros(4, dtype=torch.int32, device=dev)
+            curlist = torch.arange(nP, dtype=torch.int32, device=dev)
+            curcount = torch.tensor([nP], dtype=torch.int32, device=dev)
+            rv_pass = register_passes([dict(P=CAP, sigmaSearch=S["pv"], maxDist=3 * S["pv"], sigmaMerge=S["pv"], M=dM.data_ptr(), cov=dcov.data_ptr(),
+                                            pointFeat=dpf.data_ptr(), slot=out["slot"].data_ptr(), m=out["m"].data_ptr(), var=out["var"].data_ptr(),
+                                            dist=out["dist"].data_ptr(), flags=out["flags"].data_ptr(), list=rvlist.data_ptr(),
+                                            **(dict(mapFlags=dfl.data_ptr(), maxDistDynamic=4 * S["pv"]) if S["with_dyn"] else {}))])
+            reg_in, keep_in, listed = dreg, True, []
+            for r in range(nC):
+                register_revisit_list_dev(s_, nC, nP, CAP, r == 0, dpf.data_ptr(), datt.data_ptr(), reg_in.data_ptr(), keep_in, visit.data_ptr(), nxt.data_ptr(),
+                                          rvlist.data_ptr(), rv_lcnt.data_ptr(), d_regOutClear=rv_reg[r & 1].data_ptr())
+                register_search_passes_dev(s_, rc, N, S["W"], S["H"], rv_pass)
+                th.register_mergability_dev(s_, cams, nP, dM.data_ptr(), dcov.data_ptr(), out["slot"].data_ptr(), S["pv"], dmerge.data_ptr())
+                register_revisit_decide_dev(s_, nC, N, nP, CAP, 0, kinds, rvlist.data_ptr(), nxt.data_ptr(), visit.data_ptr(), out["slot"].data_ptr(),
+                                            out["flags"].data_ptr(), dmerge.data_ptr(), dfl.data_ptr(), dpf.data_ptr(), [ds2m[c].data_ptr() for c in range(nC)],
+                                            datt.data_ptr(), rv_reg[r & 1].data_ptr(), dscr.data_ptr(), curlist.data_ptr(), curcount.data_ptr(), nP,
+                                            rv_cnt.data_ptr())
+                th.refine_map_points_dev(s_, cams, dpf.data_ptr(), nP, dM.data_ptr(), dcov.data_ptr(), S["pv"], d_select=rv_reg[r & 1].data_ptr())
+                torch.cuda.synchronize()
+                listed.append(rv_lcnt.cpu().tolist()[:2])
+                reg_in, keep_in = rv_reg[r & 1], False
+            att2, regd2, conflicts, unsettled = rv_cnt.cpu().tolist()
+            left = int((ds2m.cpu().numpy() != S["ref_s2m"]).sum())
+            print(f"scene {sc}: second visits listed per round {listed}: {att2} features attached by {regd2} registrations, {conflicts} conflicts; "
+                  f"owners differing from the reference: {int((want['s2m'] != S['ref_s2m']).sum())} after the single pass, {left} after the rounds")
+            assert unsettled == 0 and all(n_over == 0 for _, n_over in listed) and listed[-1][0] == 0   # the rounds ran dry
+            rv_left_total += left
+            rv_conf_total += conflicts
+            if conflicts == 0:
+                assert left == 0 and np.array_equal(dpf.cpu().numpy(), S["ref_pf"]), f"scene {sc}"
+                assert np.array_equal(dM.cpu().numpy(), S["ref_M"]) and np.array_equal(dcov.cpu().numpy(), S["ref_cov"]), f"scene {sc}: positions"
         # ---- the reference's run step for step (camera loop after camera loop, refine in between): IDENTICAL to the reference
         ds2m.copy_(d(S["s2m"])), dM.copy_(d(S["M"])), dcov.copy_(d(S["cov"])), dpf.copy_(d(S["pf"]))
         rounds = []
@@ -343,6 +383,7 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
             assert res[1][7][2] > 5 and res[1][7][3] > res[1][7][2]      # points unified away; checkUnify asked more often than it said yes
         th.close()
     assert 0 < diff_total <= 0.03 * att_total, (diff_total, att_total)
+    assert rv_conf_total >= 1 and rv_left_total <= 3 * rv_conf_total, (rv_left_total, rv_conf_total)   # what the rounds leave lies in the scene whose conflict they counted
     assert dyn_total > 30 and merged_total > 40
 
 

@@ -319,7 +319,12 @@ int main(int argc, char** argv) {
     }
     int* dCurList = dev_zeros<int>(nMap);
     int* dCurCount = dev_zeros<int>(1);
-    int* dCurOverflow = dev_zeros<int>(1);   // current points beyond the list's cap P_REG (left out of that frame's registration)
+    int* dCurOverflow = dev_zeros<int>(1);
+    // the second visits' rounds (cs_register_revisit_*)
+    const int RV_CAP = 1024, RV_ROUNDS = getenv("COSLAM_REVISIT_ROUNDS") ? atoi(getenv("COSLAM_REVISIT_ROUNDS")) : 2;
+    int* dRvList = dev_zeros<int>(RV_CAP);
+    int *dRvVisit = dev_zeros<int>(nMap), *dRvNext = dev_zeros<int>(nMap), *dRvCnt = dev_zeros<int>(4), *dRvListCnt = dev_zeros<int>(4);
+    unsigned char* dRvReg[2] = {dev_zeros<unsigned char>(nMap), dev_zeros<unsigned char>(nMap)};   // current points beyond the list's cap P_REG (left out of that frame's registration)
     int* dMergeRun = dev_zeros<int>(4);
     double* dR[2] = {to_dev(R0), to_dev(R0)};
     double* dT[2] = {to_dev(t0), to_dev(t0)};
@@ -601,6 +606,34 @@ int main(int argc, char** argv) {
         CSCHK(cs_register_decide_kinds_dev(dev, (void*)poseS, nCams, N, nMap, 0, reg[0].slot, reg[0].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
                                            dAttached, dRegged, dDecScratch, /*nSweeps: until settled*/ 0, dDecCnt, /*onlyCam*/ -1, kinds));
         refine();
+        // the reference's SECOND VISITS (SL_CoSLAM.cpp:864-869, :889-893): the points that registered are refined and visited again in their next
+        // camera's loop -- rounds of list + search + whole-track mergability + walks + refine over just those points, every rank for ALL cameras
+        // on its replica (cs_register_revisit_*; tools/r06_exact_vs_single.py: with two rounds the map is the reference order's, frame after frame)
+        if (kinds == 3) {
+            unsigned char* regIn = dRegged;
+            for (int r = 0; r < RV_ROUNDS; ++r) {
+                unsigned char* regOut = dRvReg[r & 1];
+                CSCHK(cs_register_revisit_list_dev(dev, (void*)poseS, nCams, nMap, RV_CAP, r == 0, dPf, dAttached, regIn, r == 0, regOut, dRvVisit, dRvNext, dRvList,
+                                                   dRvListCnt));
+                cs_register_pass ps[1];
+                memset(ps, 0, sizeof(ps));
+                ps[0].P = RV_CAP, ps[0].sigmaSearch = PIX, ps[0].maxDist = 3 * PIXVAR, ps[0].sigmaMerge = PIX;
+                ps[0].M = dMap, ps[0].cov = dCov, ps[0].pointFeat = dPf, ps[0].list = dRvList;
+                ps[0].mapFlags = dMapFlags, ps[0].maxDistDynamic = 4 * PIXVAR;
+                ps[0].slot = reg[0].slot, ps[0].m = reg[0].m, ps[0].var = reg[0].var, ps[0].dist = reg[0].dist, ps[0].flags = reg[0].flags;
+                CSCHK(cs_register_search_passes_range_dev(dev, (void*)poseS, nCams, 0, nCams, rc[dsti].data(), N, W, H, 1, ps));
+                CSCHK(cs_register_mergability_running_list_dev(hist, (void*)poseS, 0, nCams, pu.data(), nMap, dRvList, RV_CAP, dMap, dCov, reg[0].slot, reg[0].flags,
+                                                               PIX, 0.0, dMergeCache, dMergeable, nullptr));
+                CSCHK(cs_register_revisit_decide_dev(dev, (void*)poseS, nCams, N, nMap, RV_CAP, 0, 3, dRvList, dRvNext, dRvVisit, reg[0].slot, reg[0].flags, dMergeable,
+                                                     dMapFlags, dPf, s2mPtrs.data(), dAttached, regOut, dDecScratch, dCurList, dCurCount, P_REG, dRvCnt));
+                if (chains) {
+                    CSCHK(cs_feat_ref_advance_dev(hist, (void*)poseS, pu.data(), nMap, dPf, i, dFref, dRstat, dFrefCnt));
+                    CSCHK(cs_refine_map_points_ref_dev(hist, (void*)poseS, pu.data(), dFref, nMap, regOut, dMap, dCov, PIX, nullptr));
+                } else
+                    CSCHK(cs_refine_map_points_dev(hist, (void*)poseS, pu.data(), dPf, nMap, regOut, dMap, dCov, PIX, nullptr));
+                regIn = regOut;
+            }
+        }
         // the tracker of frame i + 2 is released at the END of the frame's pose work (released right behind the hand-back it runs two frames
         // ahead and under more of the pose stream's kernels: -10 %, profiles/r04_ab_runs.txt)
         HIPCHK(hipEventRecord(destFree[b], poseS));
@@ -703,6 +736,8 @@ int main(int argc, char** argv) {
     run(warmup);
     barrier();
     const int applied0 = nApplied;
+    int rvCnt0[4] = {0, 0, 0, 0};   // (the second visits' counters at the start of the timed region)
+    HIPCHK(hipMemcpy(rvCnt0, dRvCnt, sizeof(rvCnt0), hipMemcpyDeviceToHost));
     const auto t0c = std::chrono::steady_clock::now();
     run(steps);
     const auto t1c = std::chrono::steady_clock::now();
@@ -753,6 +788,9 @@ int main(int argc, char** argv) {
     HIPCHK(hipMemcpy(npCounts, dNpCounts, sizeof(npCounts), hipMemcpyDeviceToHost));
     int curOverflow = 0;
     HIPCHK(hipMemcpy(&curOverflow, dCurOverflow, sizeof(int), hipMemcpyDeviceToHost));
+    int rvCnt[4] = {0, 0, 0, 0}, rvListCnt[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(rvCnt, dRvCnt, sizeof(rvCnt), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rvListCnt, dRvListCnt, sizeof(rvListCnt), hipMemcpyDeviceToHost));
     int decUnsettled = 0;   // (the decision scratch's last int: sticky "some call's sweeps did not settle")
     HIPCHK(hipMemcpy(&decUnsettled, (char*)dDecScratch + cs_register_decide_scratch_bytes(nCams, N, nMap) - sizeof(int), sizeof(int),
                      hipMemcpyDeviceToHost));
@@ -761,11 +799,12 @@ int main(int argc, char** argv) {
            "\"intercam_lm_steps\": %d, \"intercam_cost\": %.6f, \"ncc_runs\": %d, \"joint_ba_from_window\": %s, \"joint_cameras\": %d, "
            "\"joint_points\": %d, \"joint_measurements\": %d, \"ba_lag\": %d, \"windows_applied_in_timed_region\": %d, \"apply_wait_errors\": %d, "
            "\"intercam_static_points\": %d, \"intercam_dynamic_points\": %d, \"map_points_at_start\": %d, \"map_points_in_use\": %d, "
-           "\"map_capacity\": %d, \"new_map_points_last_run\": %d, \"register_decisions_unsettled\": %s, \"bmerge_frames\": %d, \"current_points_beyond_the_cap\": %d, "
+           "\"map_capacity\": %d, \"new_map_points_last_run\": %d, \"register_decisions_unsettled\": %s, \"bmerge_frames\": %d, \"current_points_beyond_the_cap\": %d, \"second_visit_rounds\": %d, \"second_visit_features_attached\": %d, "
+           "\"second_visit_conflicts\": %d, \"second_visit_conflicts_in_timed_region\": %d, \"second_visit_points_beyond_the_list\": %d, "
            "\"rank\": %d, \"world\": %d, \"cameras_per_rank\": %d, \"transport\": \"%s\", \"digest\": \"%016llx\"}\n",
            steps / dt, dt / steps * 1e3, steps, warmup, dtHost / steps * 1e3, camsPerLaunch, okAll ? "true" : "false", minLive,
            sj.nIterTotal, sj.cost, si.nIterTotal, si.cost, nccRuns, win ? "true" : "false", jC, jP, jO, baLag, nApplied - applied0,
-           cs_ba_output_wait_errors(bout), iS, iP - iS, nPts, mapCountNow, nMap, npCounts[0], decUnsettled ? "true" : "false", nMergeFrames, curOverflow,
+           cs_ba_output_wait_errors(bout), iS, iP - iS, nPts, mapCountNow, nMap, npCounts[0], decUnsettled ? "true" : "false", nMergeFrames, curOverflow, RV_ROUNDS, rvCnt[0], rvCnt[2], rvCnt[2] - rvCnt0[2], rvListCnt[1],
            rank, world, nc, world == 1 ? "none" : (getenv("COSLAM_COMM") && !strncmp(getenv("COSLAM_COMM"), "host:", 5) ? "host segment (test)" : "rccl"),
            digest);
     fflush(stdout);
