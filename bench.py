@@ -813,7 +813,7 @@ def main():
                       "windows_solved": loop.n_windows - w1, "requests_dropped_because_the_previous_solve_was_running": loop.n_skipped - s1,
                       "what": "the same loop with the reference's request policy: a key frame's window BA is requested only when no bundle "
                               "adjustment is running (CoSLAM::requestForBA, SL_CoSLAM.cpp:1750-1755); the headline solves EVERY window"}
-    seq_reg = None
+    seq_reg = single_pass = None
     if world == 1 and not args.no_secondary and hasattr(loop, "_dec"):
         # SECONDARY: the registration of the current static points step for step as the reference runs it (camera loop after camera
         # loop, search + mergability + walks + refineMapPoint per loop: bit-identical to the reference's own run on its golden scenes,
@@ -832,8 +832,23 @@ def main():
                    "loops_whose_sweeps_did_not_settle": int(loop._dec["scr"][-4:].view(torch.int32).item()),
                    "what": "the same loop with CoSLAM::currentMapPointsRegister reproduced step for step (8 camera loops of the static points, "
                            "then 8 of the dynamic ones; per loop a search, a mergability pass, the walks of that camera's points and a refine: "
-                           "16 x the launches) instead of the headline's single pass -- the parity mode; the single pass differs from it in "
-                           "~2 % of a frame's attachments (DESIGN.md 8.2)"}
+                           "16 x the launches) -- the parity mode the headline's form is measured against: tools/r06_exact_vs_single.py runs both from "
+                           "the same state, frame by frame; with the second visits' two rounds 450 of 450 compared frames are byte-identical "
+                           "(profiles/r06_exact_vs_single.txt)"}
+        # SECONDARY: the single pass ALONE (rounds 3-5's headline form): what the second visits cost
+        rr = loop.cfg.revisit_rounds
+        loop.cfg.revisit_rounds = 0
+        n_sp = max(args.steps // 2, 20)
+        run((-n_done) % max(ke, 1))
+        barrier()
+        tq = time.perf_counter()
+        run(n_sp)
+        barrier()
+        dtq = time.perf_counter() - tq
+        loop.cfg.revisit_rounds = rr
+        single_pass = {"frames_per_s": n_sp / dtq, "ms_per_step": dtq / n_sp * 1e3, "steps": n_sp, "ratio_to_value": (n_sp / dtq) / (args.steps / dt),
+                       "what": "the same loop without the second visits' rounds (LoopConfig.revisit_rounds = 0): the registration of rounds 3-5, which "
+                               "parts from the reference's order within a few registering frames (1 / 8 / 18 frames from three start frames)"}
     kf_leg = None
     if world == 1 and not args.no_secondary and not args.keyframe_decision:
         # SECONDARY: the reference's key-frame DECISION per frame beside the same loop (CoSLAM::IsReadyForKeyFrame + addKeyFrame's key-pose
@@ -1384,7 +1399,7 @@ def main():
                            "matches_per_pair_last_run": loop.ncc["np_cnt"].cpu().tolist()[4:4 + N_CAMS - 1],
                            "map_points_in_use": map_in_use_timed_end, "map_points_at_start": n_pts0, "map_capacity": loop.n_map},
                        "with_upload": with_upload, "secondary_reference_ba_request_policy": ref_policy,
-                       "secondary_sequential_registration": seq_reg, "secondary_keyframe_decision": kf_leg, "cxx_frame_loop": cxx,
+                       "secondary_sequential_registration": seq_reg, "secondary_single_pass_registration": single_pass, "secondary_keyframe_decision": kf_leg, "cxx_frame_loop": cxx,
                        "value_source": "cxx_frame_loop" if cxx_ok else "python_frame_loop (the C++ loop did not run: see cxx_frame_loop)",
                        "python_frame_loop": py_loop,
                        "secondary_legs_note": "the secondary_* legs and with_upload are run by the Python loop: their ratio_to_value compares with python_frame_loop",

@@ -2413,14 +2413,17 @@ struct FrArgs {
     int* segCount;
     int* counts;   // [5] or null: tracked on, fresh, re-linked, links dropped (pool full), detached
     unsigned char* alive;   // [nMap]: one of the point's references was of the frame of the last call (the history's scratch)
+    const int* list;        // null, or the rows to look at: list[0 .. nList), entries < 0 skipped (a SECOND call within a frame, behind a
+    int nList;              // registration round that changed just these points' features: every other row stands as the first call left it)
     cs_poseupdate_cam cam[PU_MAX_CAMS];
 };
 // a thread per MAP POINT (its nCams entries): most of a map's points are seen by no camera in a frame and were not the frame before --
 // their row of pointFeat (and one byte saying whether any of their references was alive last frame) is all that is read
 __global__ __launch_bounds__(256) void k_feat_ref_advance(FrArgs A) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int idx0 = blockIdx.x * 256 + threadIdx.x;
+    const int m = A.list ? (idx0 < A.nList ? A.list[idx0] : -1) : idx0;
     int cnt[5] = {0, 0, 0, 0, 0};   // tracked on, first, re-linked, links dropped, detached
-    if (m < A.nMap) {
+    if (m >= 0 && m < A.nMap) {
         const int* pf = A.pointFeat + (size_t)m * A.nCams;
         int top = -1;   // (no short circuit: the row's loads go out together, not one after the other)
 #pragma unroll 8
@@ -2507,7 +2510,13 @@ __global__ __launch_bounds__(256) void k_feat_ref_advance(FrArgs A) {
 
 extern "C" int cs_feat_ref_advance_dev(cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int nMap, const int* d_pointFeat,
                                        int curFrame, cs_feat_ref* d_featRef, unsigned char* d_refStatic, int* d_counts) {
-    if (!h || !cams || nMap < 0 || (nMap > 0 && (!d_pointFeat || !d_featRef))) {
+    return cs_feat_ref_advance_list_dev(h, hip_stream, cams, nMap, d_pointFeat, curFrame, d_featRef, d_refStatic, d_counts, nullptr, 0);
+}
+
+extern "C" int cs_feat_ref_advance_list_dev(cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int nMap, const int* d_pointFeat,
+                                            int curFrame, cs_feat_ref* d_featRef, unsigned char* d_refStatic, int* d_counts, const int* d_list,
+                                            int nList) {
+    if (!h || !cams || nMap < 0 || nList < 0 || (nMap > 0 && (!d_pointFeat || !d_featRef))) {
         cs_set_error("cs_feat_ref_advance_dev: bad arguments");
         return CS_ERR_INVALID;
     }
@@ -2532,8 +2541,9 @@ extern "C" int cs_feat_ref_advance_dev(cs_track_history* h, void* hip_stream, co
         }
         A.cam[c] = cams[c];
     }
-    if (nMap == 0) return CS_OK;
-    hipLaunchKernelGGL(k_feat_ref_advance, dim3((nMap + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, A);
+    if (nMap == 0 || (d_list && nList == 0)) return CS_OK;
+    A.list = d_list, A.nList = nList;
+    hipLaunchKernelGGL(k_feat_ref_advance, dim3(((d_list ? nList : nMap) + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, A);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

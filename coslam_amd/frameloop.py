@@ -853,21 +853,22 @@ class FrameLoop:
                                                    self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(), D["s2m"],
                                                    D["att"].data_ptr(), reg_out.data_ptr(), D["scr"].data_ptr(), self.d_curlist.data_ptr(),
                                                    self.d_curcount.data_ptr(), cfg.p_reg, self.d_rv_counts.data_ptr(), device=self.device)
-            self._refine(ps, reg_out.data_ptr())
+            self._refine(ps, reg_out.data_ptr(), self.d_rvlist.data_ptr(), self.RV_CAP)   # (the round changed the listed points only)
             reg_in, keep = reg_out, False
 
-    def _advance_refs(self, ps):
+    def _advance_refs(self, ps, d_list=None, n_list=0):
         """MapPoint::pFeatures of this frame: cs_feat_ref_advance_dev behind whatever changed pointFeat (hand-back, classification, the
-        registration's decisions) -- tracked on / first feature / re-linked behind an older one / stale / detached.  Idempotent within a frame."""
+        registration's decisions) -- tracked on / first feature / re-linked behind an older one / stale / detached.  Idempotent within a frame;
+        d_list: a further call of the frame over just the rows a registration round has changed."""
         if self.d_fref is not None:
             self.pose_upd.feat_ref_advance_dev(ps, self.pu_args, self.n_map, self.d_pf.data_ptr(), self._frame_now, self.d_fref.data_ptr(),
-                                               d_refStatic=self.d_rstat.data_ptr(), d_counts=self.d_fref_counts.data_ptr())
+                                               d_refStatic=self.d_rstat.data_ptr(), d_counts=self.d_fref_counts.data_ptr(), d_list=d_list, nList=n_list)
 
-    def _refine(self, ps, d_select):
+    def _refine(self, ps, d_select, d_list=None, n_list=0):
         """CoSLAM::refineMapPoint of the points that gained a feature (:889-893, :666-713) -- over the feature references when they are kept
         (stale features of other cameras are views, a re-registered point's second view comes from its OLD chain), else over this frame's"""
         if self.d_fref is not None:
-            self._advance_refs(ps)
+            self._advance_refs(ps, d_list, n_list)
             self.pose_upd.refine_map_points_ref_dev(ps, self.pu_args, self.d_fref.data_ptr(), self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
                                                     self.sig_pix, d_select=d_select)
         else:

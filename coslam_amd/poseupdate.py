@@ -188,12 +188,12 @@ class TrackHistory:
                                              vp(d_scratch), vp(d_counts)), "cs_newpts_intracam_dev")
 
     # ---- MapPoint::pFeatures as feature references (cs_feat_ref / cs_feat_seg, include/coslam_hip.h) --------------------------------
-    def feat_ref_advance_dev(self, stream_ptr, cams, nMap, d_pointFeat, curFrame, d_featRef, d_refStatic=None, d_counts=None):
-        """cs_feat_ref_advance_dev: every frame behind the registration's decisions -- tracked on / first feature / re-linked behind an
-        older one (reference src/app/SL_CoSLAM.cpp:775-779) / stale / detached"""
+    def feat_ref_advance_dev(self, stream_ptr, cams, nMap, d_pointFeat, curFrame, d_featRef, d_refStatic=None, d_counts=None, d_list=None, nList=0):
+        """cs_feat_ref_advance_(list_)dev: every frame behind the registration's decisions -- tracked on / first feature / re-linked behind an
+        older one (reference src/app/SL_CoSLAM.cpp:775-779) / stale / detached.  d_list / nList: a further call within the frame over those rows only"""
         vp = C.c_void_p
-        check(self._L.cs_feat_ref_advance_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), int(nMap), vp(d_pointFeat), int(curFrame),
-                                              vp(d_featRef), vp(d_refStatic), vp(d_counts)), "cs_feat_ref_advance_dev")
+        check(self._L.cs_feat_ref_advance_list_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), int(nMap), vp(d_pointFeat), int(curFrame),
+                                                   vp(d_featRef), vp(d_refStatic), vp(d_counts), vp(d_list), int(nList)), "cs_feat_ref_advance_list_dev")
 
     def load_segments(self, segs):
         """cs_track_history_load_segments: segs int32 [nCams][n][4] = {slot, last, first, next} from the host into the pools"""

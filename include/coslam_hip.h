@@ -695,6 +695,10 @@ typedef struct { int slot, frame, first, seg; } cs_feat_ref;
 typedef struct { int slot, last, first, next; } cs_feat_seg;
 int cs_feat_ref_advance_dev(cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int nMap, const int* d_pointFeat,
                             int curFrame, cs_feat_ref* d_featRef, unsigned char* d_refStatic, int* d_counts);
+/* a FURTHER call within the same frame over the rows d_list[0 .. nList) only (entries < 0 skipped): behind a registration round that changed
+ * just those points' features (cs_register_revisit_decide_dev) -- every other row stands as the frame's first call left it */
+int cs_feat_ref_advance_list_dev(cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int nMap, const int* d_pointFeat,
+                                 int curFrame, cs_feat_ref* d_featRef, unsigned char* d_refStatic, int* d_counts, const int* d_list, int nList);
 /* the pools: device pointer ([nCams][cap]), capacity per camera, device counters [nCams] */
 int cs_track_history_segments(const cs_track_history* h, cs_feat_seg** d_pool, int* cap, int** d_count);
 /* the counters copied to the host (counts [nCams]); synchronous */
