@@ -1333,6 +1333,7 @@ def main():
                         "running_verdict": None if loop.pose_upd is None else dict(zip(
                             ("cache_hits", "full_tail_walks", "verdicts_unjudged", "tail_terms_evaluated"), loop.d_merge_counts.cpu().tolist()),
                             frames=n_timed_end, window_frames=cfg.hist, store_frames=cfg.hist_store, tol_pix=cfg.merge_tol_pix,
+                            cache_check=loop.verdict_check(),
                             what="staticCheckMergability over WHOLE tracks (reference SL_CoSLAM.cpp:714-729): the newest 64 frames of a candidate's "
                                  "track walked every frame as they stand, the verdict over the older ones cached per (map point, camera) and extended "
                                  "by one term per frame (cs_register_mergability_running_dev); counts summed over the whole run"),

@@ -42,6 +42,7 @@ class LoopConfig:
         self.hist = 64             # depth of the bounded walks (dynamic test, classification, re-triangulation; the mergability walk's exact window)
         self.hist_store = 4096     # frames of pixels + poses KEPT behind them (1 GB for 8 x 2000 slots): what the running whole-track
                                    # mergability verdict rebuilds a cached tail from (cs_register_mergability_running_dev)
+        self.verdict_check_every = 100   # diagnostic: every n-th frame the running verdict's candidates are judged again without cached tails (0: never)
         self.merge_tol_pix = 0.5   # a point that moved further than this in a camera's image has its cached tail judged again
         self.pixel_err_reading = "variance"   # Const::PIXEL_ERR_VAR = 10 (src/app/SL_GlobParam.cpp:37) reaches getProjectionCovMat / seqTriangulate /
         # getTriangulateCovMat (un-vendored LibVisualSLAM) as their last argument.  This library's definitions of them take a STANDARD
@@ -625,6 +626,7 @@ class FrameLoop:
 
         torch, cfg = self.torch, self.cfg
         klt_s, pose_s, c0, nc, NA_ = self.klt_s, self.pose_s, self.c0, self.nc, self.cfg.n_cams
+        self._frame_in_step = i
         f, fn = self.vid(i), self.vid(i + 1)
         b = i & 1
         if i >= 2:
@@ -768,6 +770,37 @@ class FrameLoop:
                                                        self.d_mergeable.data_ptr(), tolPix=cfg.merge_tol_pix, d_counts=self.d_merge_counts.data_ptr(),
                                                        cam0=self.c0, nCamsRun=self.nc, d_list=self.d_curlist.data_ptr(), nList=cfg.p_reg,
                                                        d_flags=self.reg_out["flags"].data_ptr())
+        if cfg.merge_tol_pix > 0 and cfg.verdict_check_every > 0 and self._frame_now_for_check() % cfg.verdict_check_every == 0:
+            # diagnostic: how often does a CACHED tail change a verdict?  Every n-th frame the same candidates are judged once more
+            # with tolPix = 0 -- every tail whose point has moved at all walked again with today's point -- on a copy of the cache, into a
+            # scratch table; the two tables are compared where a candidate was judged.  Two launches + a 6 MB copy on those frames.
+            torch = self.torch
+            with torch.cuda.stream(self.pose_s):
+                if not hasattr(self, "_vc"):
+                    self._vc = dict(cache=torch.empty_like(self.d_merge_cache), out=torch.empty_like(self.d_mergeable),
+                                    n=torch.zeros(3, dtype=torch.int64, device=self.dev))
+                V = self._vc
+                V["cache"].copy_(self.d_merge_cache, non_blocking=True)
+                V["out"].copy_(self.d_mergeable, non_blocking=True)
+            self.pose_upd.register_mergability_running_dev(ps, self.pu_args, self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(),
+                                                           self.reg_out["slot"].data_ptr(), self.sig_pix, V["cache"].data_ptr(), V["out"].data_ptr(),
+                                                           tolPix=0.0, d_counts=None, cam0=self.c0, nCamsRun=self.nc, d_list=self.d_curlist.data_ptr(),
+                                                           nList=cfg.p_reg, d_flags=self.reg_out["flags"].data_ptr())
+            with torch.cuda.stream(self.pose_s):
+                lc = slice(self.c0, self.c0 + self.nc)
+                judged = (self.reg_out["slot"][:, lc] >= 0) & ((self.d_mergeable[:, lc] == 0) | (self.d_mergeable[:, lc] == 1))
+                V["n"] += torch.stack([judged.sum(), (judged & (self.d_mergeable[:, lc] != V["out"][:, lc])).sum(),
+                                       torch.ones((), dtype=torch.int64, device=self.dev)])
+
+    def _frame_now_for_check(self):
+        return getattr(self, "_frame_in_step", 0)
+
+    def verdict_check(self):
+        """{candidates judged, verdicts the cached tails changed, frames checked} of the running mergability verdict's diagnostic"""
+        if not hasattr(self, "_vc"):
+            return None
+        a = self._vc["n"].cpu().tolist()
+        return {"candidates_judged": a[0], "verdicts_changed_by_the_cache": a[1], "frames_checked": a[2]}
 
     def _decide(self, ps):
         """currentMapPointsRegister's decisions -- curStaticPointsRegInGroup (reference src/app/SL_CoSLAM.cpp:854-898, 731-830, bMerge ==
