@@ -1352,6 +1352,7 @@ def main():
                            ("features_attached_last_frame", "points_regged_last_frame", "sweeps_last_frame", "converged"), dec_counts[0]),
                            points_refined_last_frame=dec_counts[1],
                            frames_whose_sweeps_did_not_settle=dec_counts[2],
+                           of_which_barrier_timeouts=int(loop._dec["scr"][-8:-4].view(torch.int32).item()),
                            second_visits=dict(zip(("features_attached", "registrations", "conflicts_counted", "rounds_unsettled"), loop.d_rv_counts.cpu().tolist()),
                                               since_the_timed_region_began=dict(zip(("features_attached", "registrations", "conflicts_counted", "rounds_unsettled"),
                                                                                     [a - b for a, b in zip(loop.d_rv_counts.cpu().tolist(), rv0)])),

@@ -481,6 +481,8 @@ struct RdArgs {
     int* owner[3];                   // scratch 3 x [nCams * N]: the sweeps rotate through them
     int* counts;                     // [4] out: features attached, points regged, sweeps, converged
     int* unconverged;                // the scratch's last word: the NUMBER of calls whose sweeps did not settle (never cleared here)
+    int* timeouts;                   // the word before it: the number of those calls that ended on a grid-barrier TIME-OUT (the launch's workgroups
+                                     // were not co-resident within 20 ms: nothing was attached) -- apart from `sweeps ran out`
     int* callFlag;                   // the word before it: this call has been counted
     int* changed;                    // scratch [RD_MAX_SWEEPS]: sweep k changed an owner (the self-settling launch, k_decide_settle)
     int* bar;                        // scratch [1]: its grid barrier's arrival counter
@@ -655,6 +657,7 @@ __global__ __launch_bounds__(256) void k_decide_settle(RdArgs A) {
     }
     if (p == 0 && A.counts) A.counts[2] = k, A.counts[3] = settled ? 1 : 0;
     if (!settled && p == 0) atomicAdd(A.unconverged, 1);
+    if (!alive && p == 0) atomicAdd(A.timeouts, 1);
     if (!alive || base < 0) return;
     // the owners in `fin` are final (or the best the sweeps reached): attach (k_decide_sweep's mode 1)
     bool go = true, reg = false;
@@ -757,10 +760,12 @@ struct RvArgs {
     const int* curCount;
     int curCap;
     int* counts;                     // [4] (accumulating): features attached, points registered, conflicts, sweeps that did not settle
+    const int* listCount;            // null, or k_revisit_list's count: 0 = nobody is visited again (the usual round): leave at once
 };
 constexpr int RV_MAX_ROWS = 1024;
 __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
     __shared__ int sChanged, sAttF[256], sAttKey[256], sNAtt;
+    if (A.listCount && *A.listCount == 0) return;   // (uniform: before any barrier)
     const int j = threadIdx.x, C = A.nCams;
     const int p = j < A.cap ? A.list[j] : -1;
     int code[RD_MAX_CAMS], base = -1, kind = -1, nConf = 0;
@@ -922,7 +927,7 @@ extern "C" int cs_register_revisit_decide_dev(int device, void* hip_stream, int 
                                               const int* d_nextLoop, int* d_visitLoop, const int* d_slot, const int* d_flags,
                                               const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
                                               int* const* d_slot2map, unsigned char* d_attached, unsigned char* d_regOut, void* d_decideScratch,
-                                              const int* d_curList, const int* d_curCount, int curCap, int* d_counts) {
+                                              const int* d_curList, const int* d_curCount, int curCap, int* d_counts, const int* d_listCount) {
     if (nCams < 1 || nCams > RD_MAX_CAMS || N < 1 || P < 1 || cap < 1 || cap > RV_MAX_ROWS || kinds < 1 || kinds > 3 || !d_list || !d_nextLoop || !d_visitLoop ||
         !d_slot || !d_flags || !d_mergeable || !d_mapFlags || !d_pointFeat || !d_slot2map || !d_attached || !d_regOut || !d_decideScratch ||
         !d_curList || !d_curCount || (long long)nCams * N > RD_FEAT || (long long)nCams * P * nCams > 0x7fffffffLL) {
@@ -934,7 +939,7 @@ extern "C" int cs_register_revisit_decide_dev(int device, void* hip_stream, int 
     A.nCams = nCams, A.N = N, A.P = P, A.cap = cap, A.mapBase = mapBase, A.kinds = kinds, A.list = d_list, A.nextLoop = d_nextLoop, A.visitLoop = d_visitLoop;
     A.slot = d_slot, A.flags = d_flags, A.mergeable = d_mergeable, A.mapFlags = d_mapFlags, A.pointFeat = d_pointFeat;
     for (int c = 0; c < nCams; ++c) A.slot2map[c] = d_slot2map[c];
-    A.attached = d_attached, A.regOut = d_regOut, A.curList = d_curList, A.curCount = d_curCount, A.curCap = curCap, A.counts = d_counts;
+    A.attached = d_attached, A.regOut = d_regOut, A.curList = d_curList, A.curCount = d_curCount, A.curCap = curCap, A.counts = d_counts, A.listCount = d_listCount;
     int* scr = (int*)d_decideScratch + (size_t)nCams * P + P;   // (cs_register_decide_kinds_dev's carve-up: code | base | owner x 3 | ...)
     for (int k = 0; k < 3; ++k) A.owner[k] = scr, scr += (size_t)nCams * N;
     CS_HIP(hipSetDevice(device));
@@ -944,7 +949,7 @@ extern "C" int cs_register_revisit_decide_dev(int device, void* hip_stream, int 
 }
 extern "C" size_t cs_register_decide_scratch_bytes(int nCams, int N, int P) {
     if (nCams < 1 || N < 1 || P < 0) return 0;
-    return sizeof(int) * ((size_t)nCams * P + (size_t)P + 3 * (size_t)nCams * N + RD_MAX_SWEEPS + 3);
+    return sizeof(int) * ((size_t)nCams * P + (size_t)P + 3 * (size_t)nCams * N + RD_MAX_SWEEPS + 4);
 }
 
 extern "C" int cs_register_decide_static_dev(int device, void* hip_stream, int nCams, int N, int P, int mapBase, const int* d_slot, const int* d_flags,
@@ -994,7 +999,7 @@ extern "C" int cs_register_decide_kinds_dev(int device, void* hip_stream, int nC
     A.base = scr, scr += P;
     for (int k = 0; k < 3; ++k) A.owner[k] = scr, scr += (size_t)nCams * N;
     A.changed = scr, scr += RD_MAX_SWEEPS;
-    A.bar = scr, A.callFlag = scr + 1, A.unconverged = scr + 2;
+    A.bar = scr, A.callFlag = scr + 1, A.timeouts = scr + 2, A.unconverged = scr + 3;
     CS_HIP(hipSetDevice(device));
     if (P == 0) return CS_OK;
     hipStream_t s = (hipStream_t)hip_stream;

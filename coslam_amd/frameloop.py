@@ -885,7 +885,8 @@ class FrameLoop:
                                                    self.d_rv_visit.data_ptr(), self.reg_out["slot"].data_ptr(), self.reg_out["flags"].data_ptr(),
                                                    self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(), D["s2m"],
                                                    D["att"].data_ptr(), reg_out.data_ptr(), D["scr"].data_ptr(), self.d_curlist.data_ptr(),
-                                                   self.d_curcount.data_ptr(), cfg.p_reg, self.d_rv_counts.data_ptr(), device=self.device)
+                                                   self.d_curcount.data_ptr(), cfg.p_reg, self.d_rv_counts.data_ptr(), device=self.device,
+                                                   d_listCount=self.d_rv_listcounts.data_ptr())
             self._refine(ps, reg_out.data_ptr(), self.d_rvlist.data_ptr(), self.RV_CAP)   # (the round changed the listed points only)
             reg_in, keep = reg_out, False
 

@@ -151,14 +151,14 @@ def register_revisit_list_dev(stream_ptr, nCams, P, cap, first_round, d_pointFea
 
 
 def register_revisit_decide_dev(stream_ptr, nCams, N, P, cap, mapBase, kinds, d_list, d_nextLoop, d_visitLoop, d_slot, d_flags, d_mergeable, d_mapFlags,
-                                d_pointFeat, d_slot2map, d_attached, d_regOut, d_decideScratch, d_curList, d_curCount, curCap, d_counts=0, device=0):
+                                d_pointFeat, d_slot2map, d_attached, d_regOut, d_decideScratch, d_curList, d_curCount, curCap, d_counts=0, device=0, d_listCount=0):
     """cs_register_revisit_decide_dev: the listed points' walks in their next loop (see include/coslam_hip.h)"""
     vp = C.c_void_p
     arr = d_slot2map if isinstance(d_slot2map, C.Array) else (C.c_void_p * nCams)(*[int(x) for x in d_slot2map])
     check(lib().cs_register_revisit_decide_dev(int(device), vp(stream_ptr), int(nCams), int(N), int(P), int(cap), int(mapBase), int(kinds), vp(d_list),
                                                vp(d_nextLoop), vp(d_visitLoop), vp(d_slot), vp(d_flags), vp(d_mergeable), vp(d_mapFlags),
                                                vp(d_pointFeat), arr, vp(d_attached), vp(d_regOut), vp(d_decideScratch), vp(d_curList), vp(d_curCount),
-                                               int(curCap), vp(d_counts)), "cs_register_revisit_decide_dev")
+                                               int(curCap), vp(d_counts), vp(d_listCount)), "cs_register_revisit_decide_dev")
     return arr
 
 

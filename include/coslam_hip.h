@@ -409,7 +409,8 @@ int cs_register_search(int device, int nCams, const cs_register_cam* cams, int N
  * whole track takes the point, :771-775); OUT: d_attached [P][nCams], d_regged [P] (refineMapPoint is due: hand it to
  * cs_refine_map_points_dev as d_select), d_counts [4] or NULL (features attached, points regged, sweeps, converged).
  * d_scratch: cs_register_decide_scratch_bytes; its LAST int COUNTS the calls whose sweeps did not settle (the decision then is not
- * the sequential one), never cleared here -- zero the scratch once, read the word at the end of a run.  Not done here: the projections are those of the search as it ran (the reference
+ * the sequential one), the int before it how many of those ended on a grid-barrier time-out of the self-settling launch (its workgroups were
+ * not co-resident within 20 ms: nothing was attached that frame); never cleared here -- zero the scratch once, read the words at the end of a run.  Not done here: the projections are those of the search as it ran (the reference
  * refines a point before the next camera's round of walks, :889-893), and the bMerge == true branch (every 50th frame: checkUnify on
  * a conflict) -- that one is cs_register_decide_merge_dev further down. */
 size_t cs_register_decide_scratch_bytes(int nCams, int N, int P);
@@ -461,7 +462,8 @@ int cs_register_revisit_decide_dev(int device, void* hip_stream, int nCams, int 
                                    const int* d_nextLoop, int* d_visitLoop, const int* d_slot, const int* d_flags, const unsigned char* d_mergeable,
                                    const unsigned char* d_mapFlags, int* d_pointFeat, int* const* d_slot2map, unsigned char* d_attached,
                                    unsigned char* d_regOut, void* d_decideScratch, const int* d_curList, const int* d_curCount, int curCap,
-                                   int* d_counts);
+                                   int* d_counts, const int* d_listCount /* cs_register_revisit_list_dev's d_counts (its [0]: rows listed) or
+                                   NULL: an empty list ends the launch at once */);
 
 /* Cameras sharded over GPUs: a rank searches for its own cameras (cs_register_search_passes_range_dev, cs_register_mergability_range_dev);
  * the decision needs every camera's candidates.  pack: columns cam0 .. cam0 + nOwn - 1 of the P x nCams tables into a send record of

@@ -320,7 +320,7 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
                 register_revisit_decide_dev(s_, nC, N, nP, CAP, 0, kinds, rvlist.data_ptr(), nxt.data_ptr(), visit.data_ptr(), out["slot"].data_ptr(),
                                             out["flags"].data_ptr(), dmerge.data_ptr(), dfl.data_ptr(), dpf.data_ptr(), [ds2m[c].data_ptr() for c in range(nC)],
                                             datt.data_ptr(), rv_reg[r & 1].data_ptr(), dscr.data_ptr(), curlist.data_ptr(), curcount.data_ptr(), nP,
-                                            rv_cnt.data_ptr())
+                                            rv_cnt.data_ptr(), d_listCount=rv_lcnt.data_ptr())
                 th.refine_map_points_dev(s_, cams, dpf.data_ptr(), nP, dM.data_ptr(), dcov.data_ptr(), S["pv"], d_select=rv_reg[r & 1].data_ptr())
                 torch.cuda.synchronize()
                 listed.append(rv_lcnt.cpu().tolist()[:2])

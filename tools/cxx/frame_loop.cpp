@@ -625,7 +625,7 @@ int main(int argc, char** argv) {
                 CSCHK(cs_register_mergability_running_list_dev(hist, (void*)poseS, 0, nCams, pu.data(), nMap, dRvList, RV_CAP, dMap, dCov, reg[0].slot, reg[0].flags,
                                                                PIX, 0.0, dMergeCache, dMergeable, nullptr));
                 CSCHK(cs_register_revisit_decide_dev(dev, (void*)poseS, nCams, N, nMap, RV_CAP, 0, 3, dRvList, dRvNext, dRvVisit, reg[0].slot, reg[0].flags, dMergeable,
-                                                     dMapFlags, dPf, s2mPtrs.data(), dAttached, regOut, dDecScratch, dCurList, dCurCount, P_REG, dRvCnt));
+                                                     dMapFlags, dPf, s2mPtrs.data(), dAttached, regOut, dDecScratch, dCurList, dCurCount, P_REG, dRvCnt, dRvListCnt));
                 if (chains) {
                     CSCHK(cs_feat_ref_advance_list_dev(hist, (void*)poseS, pu.data(), nMap, dPf, i, dFref, dRstat, dFrefCnt, dRvList, RV_CAP));
                     CSCHK(cs_refine_map_points_ref_dev(hist, (void*)poseS, pu.data(), dFref, nMap, regOut, dMap, dCov, PIX, nullptr));
