@@ -1098,6 +1098,17 @@ def main():
                 "outliers": st5.nOutliers}
         ws5.close()
 
+    # ---- secondary key: NewMapPtsNCC's tail on a LOADED run: the reference's own scenes (tests/golden/newpts_golden.npz, made by the
+    # reference's featTracksFromMatches + reconstructTracks + decidePointType), the one with the most tracks, through
+    # cs_newpts_from_pairs_dev.  (The frame loop's runs above find few pairs on the synthetic scene; this one has every track to
+    # reconstruct.)
+    newpts_loaded = None
+    if rank == 0 and n_gpus == 1 and not args.no_secondary:
+        try:
+            newpts_loaded = _newpts_loaded_leg(dev)
+        except Exception as e:   # (the fixture is data under tests/golden; a missing file must not cost the line)
+            newpts_loaded = {"error": repr(e)}
+
     # ---- secondary keys: KLT stages of other configurations as one camera group on one GPU: cfg5 (BASELINE.json configs[4]: 4 cameras
     # 1920 x 1080 x 5000 slots) and the headline's 8 cameras with the REFERENCE-DEFAULT parameter set (nLevels 6,
     # levelSkip 2, 12 iterations, 5 x 5 window -- v3d_gpuklt.h:181-191 -- with gain as CoSLAM runs it)
@@ -1323,7 +1334,7 @@ def main():
                                                                   "cost": st_i.cost},
                        "intercam_problem": ic_info, "ba_output": apply_info, "state_digest": digest, "replicas": replicas,
                        "frame_front_prefetch": bool(prefetch), "secondary_cfg2": cfg2, "secondary_cfg5_ba": cfg5, "secondary_cfg5_klt": cfg5_klt,
-                       "secondary_reference_default_klt": ref_default,
+                       "secondary_reference_default_klt": ref_default, "secondary_newpts_loaded": newpts_loaded,
                        "register_candidates_last_frame": None if args.no_register else
                        {"current_points_listed": int(loop.d_curcount.item()), "list_cap": P_REG, "current_points_beyond_the_cap_all_frames": int(loop.d_curoverflow.item()),
                         "candidates": int((reg_out["slot"][:, lc] >= 0).sum().item()),
@@ -1419,6 +1430,70 @@ def main():
     if world > 1:
         dist.destroy_process_group()
 
+
+
+def _newpts_loaded_leg(dev, reps=20):
+    """cs_newpts_from_pairs_dev on the golden scene with the most tracks: per-launch time by HIP events on the launch's stream, the
+    new points checked against the reference's (count, positions bit for bit) after every launch."""
+    import numpy as np
+    import torch
+
+    from coslam_amd.ncc import NCC_PAIR_DTYPE
+    from coslam_amd.newpts import NewPtsJob, newpts_from_pairs_dev, newpts_scratch_bytes
+    from tests.newpts_golden_util import GOLDEN, exact_inverse_of, scene
+
+    g = np.load(GOLDEN)
+    sc = max(range(int(g["n_scenes"])), key=lambda i: len(g[f"s{i}_track_len"]))
+    S = scene(g, sc)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    nc, N, NS, cap, n_old = S["nc"], S["N"], S["NS"], S["cap"], S["n_old"]
+    dK, diK = d(S["K"].reshape(9)), d(exact_inverse_of(S["K"]).reshape(9))
+    dxy, dst, ds2m, dstat = d(np.stack(S["xy"])), d(np.stack(S["state"])), d(np.stack(S["s2m"])), d(np.stack(S["is_static"]))
+    drep = torch.zeros((nc, NS), dtype=torch.float64, device=dev)
+    CAPP = 1024
+    dpairs = torch.zeros((nc - 1, CAPP * NCC_PAIR_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    dcnt = torch.zeros(nc - 1, dtype=torch.int32, device=dev)
+    for a in range(nc - 1):
+        arr = np.zeros(len(S["pairs"][a]), dtype=NCC_PAIR_DTYPE)
+        for k, q in enumerate(S["pairs"][a]):
+            arr[k] = q
+        dpairs[a, :arr.nbytes] = torch.from_numpy(arr.view(np.uint8)).to(dev)
+        dcnt[a] = len(arr)
+    cams = [dict(K=dK.data_ptr(), iK=diK.data_ptr(), xy=dxy[c].data_ptr(), state=dst[c].data_ptr(), slot2map=ds2m[c].data_ptr(),
+                 isStatic=dstat[c].data_ptr(), reprojErr=drep[c].data_ptr()) for c in range(nc)]
+    job = NewPtsJob(cams, [dpairs[a].data_ptr() for a in range(nc - 1)], [dcnt[a:a + 1].data_ptr() for a in range(nc - 1)])
+    dM, dC = torch.zeros((cap, 3), dtype=torch.float64, device=dev), torch.zeros((cap, 9), dtype=torch.float64, device=dev)
+    dF0, dPf0, ds2m0 = d(S["flags"]), d(S["pf"]), ds2m.clone()
+    dF, dPf = dF0.clone(), dPf0.clone()
+    dNew, dFirst = torch.zeros(cap, dtype=torch.uint8, device=dev), torch.zeros(cap, dtype=torch.int32, device=dev)
+    dCount = torch.tensor([n_old], dtype=torch.int32, device=dev)
+    dScr = torch.zeros(newpts_scratch_bytes(nc, NS), dtype=torch.uint8, device=dev)
+    dOut = torch.zeros(4 + nc, dtype=torch.int32, device=dev)
+    dR, dT = d(S["R"]), d(S["t"])
+    st = torch.cuda.current_stream()
+    w = S["want"]
+    n_new = len(w["M"])
+    us, ok = [], True
+    for rep in range(reps + 3):
+        dF.copy_(dF0), dPf.copy_(dPf0), ds2m.copy_(ds2m0), dCount.fill_(n_old), dNew.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        newpts_from_pairs_dev(st.cuda_stream, job, NS, CAPP, dR.data_ptr(), dT.data_ptr(), dM.data_ptr(), dC.data_ptr(), dF.data_ptr(),
+                              dNew.data_ptr(), dFirst.data_ptr(), dPf.data_ptr(), cap, dCount.data_ptr(), S["frame"], dScr.data_ptr(),
+                              dOut.data_ptr(), maxDisp=80.0, W=S["W"], H=S["H"])
+        e1.record(st)
+        torch.cuda.synchronize()
+        if rep >= 3:
+            us.append(e0.elapsed_time(e1) * 1e3)
+        ok = ok and int(dOut[0].item()) == n_new and bool(np.array_equal(dM.cpu().numpy()[n_old:n_old + n_new], w["M"]))
+    us.sort()
+    return {"workload": "tests/golden/newpts_golden.npz scene %d: %d cameras, %d candidate features per camera, %d matches over the "
+                        "consecutive pairs, %d tracks (%d of two or more views), %d new map points" %
+                        (sc, nc, N, sum(len(q) for q in S["pairs"]), len(w["track_len"]), int((w["track_len"] >= 2).sum()), n_new),
+            "what": "cs_newpts_from_pairs_dev (greedy matches, featTracksFromMatches, reconstructTracks, decidePointType, output), "
+                    "timed per call with HIP events on its stream; the new points compared with the reference's after every call",
+            "us_per_call_median": us[len(us) // 2], "us_per_call_min": us[0], "us_per_call_max": us[-1], "calls": len(us),
+            "new_points_equal_the_reference": ok}
 
 if __name__ == "__main__":
     main()

@@ -731,6 +731,7 @@ __device__ __forceinline__ void up_cam_center(const double* __restrict__ R, cons
 // ring.  The plain tables (pointFeat + trackSpan) are the special case {slot, this frame, the track's first frame, no segment}.
 struct ChainCtx {
     int N, H, head, cap, curFrame, stored, segCap, nCen;
+    int minFrame;          // the walk ends at the first node before this frame (isStaticPoint's window; INT_MIN: no window)
     const double* cen;     // [nCams][nCen][3] camera centres of ring depths < nCen
     const int4* segPool;   // or null
 };
@@ -743,7 +744,8 @@ __device__ __forceinline__ int chain_widest(const ChainCtx& X, int c, int4 ref, 
     double bestCos = 1.0;
     int slot = ref.x, hi = ref.y - 1, lo = ref.z, seg = ref.w, k0 = 1;   // (node 0 is the feature itself)
     for (;;) {
-        const int oldest = X.curFrame - X.stored + 1;   // the oldest frame the ring holds
+        const int ringOldest = X.curFrame - X.stored + 1;   // the oldest frame the ring holds
+        const int oldest = ringOldest > X.minFrame ? ringOldest : X.minFrame;
         int cnt = hi - (lo > oldest ? lo : oldest) + 1;
         const bool cut = lo < oldest;
         if (cnt > X.cap - k0) cnt = X.cap - k0;
@@ -835,6 +837,7 @@ __global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
     ChainCtx X;
     X.N = N, X.H = H, X.head = A.head, X.cap = A.nHist, X.curFrame = A.featRef ? A.curFrame : 0, X.stored = A.featRef ? A.stored : A.nHist;
     X.segCap = A.segCap, X.nCen = A.nHist, X.cen = A.cen, X.segPool = A.segPool;
+    X.minFrame = -2147483647 - 1;
     for (int c = 0; c < A.nCams; ++c) {
         const cs_poseupdate_cam& C = A.cam[c];
         const int4 ref = chain_ref(A.featRef, A.pointFeat, C, N, A.nCams, m, c);
@@ -951,6 +954,7 @@ __device__ __forceinline__ bool check_unify_wave(const CuArgs& A, const int* pf1
     ChainCtx X;
     X.N = N, X.H = H, X.head = A.head, X.cap = A.nHist, X.curFrame = rf1 ? A.curFrame : 0, X.stored = rf1 ? A.stored : A.nHist;
     X.segCap = A.segCap, X.nCen = A.nHist, X.cen = A.cen, X.segPool = A.segPool;
+    X.minFrame = -2147483647 - 1;
     for (int c = 0; c < A.nCams; ++c) {
         const cs_poseupdate_cam& C = A.cam[c];
         const double* hR = A.histR + (size_t)c * H * 9;
@@ -1397,6 +1401,11 @@ struct ClsArgs {
     int* pointFeat;        // [nMap][nCams] in / out (a detached feature becomes -1)
     const int* featFrame;  // [nMap][nCams] or null: the frame of MapPoint::pFeatures[iCam] (null: all of this frame)
     const int* featFirst;  // [nMap][nCams] or null: the first frame of that feature's track (null: the slot's trackSpan)
+    int4* featRef;         // [nMap][nCams] or null: the features as references (cs_feat_ref as the END of the previous frame left the table,
+                           // or already at this frame); then featFrame / featFirst are not read.  In / out: a detached view's is cleared
+    unsigned char* refStatic;  // [nMap][nCams] or null: the stale features' types (a point that returns to static sets them)
+    const int4* segPool;   // [nCams][segCap]
+    int segCap, stored;    // stored: frames the ring holds
     const double* histXY;
     const double* histR;
     const double* histT;
@@ -1416,13 +1425,36 @@ struct ClsArgs {
 // camera c's feature of point m as the lane c of the point's wave keeps it: slot (< 0: none, or older than the history), walk
 // depth of its frame, that frame, the first frame of its track
 struct ClsFeat {
-    int s, j0, f, ff;
+    int s, j0, f, ff, seg;   // seg: the first linked segment behind the feature's own run (-1 none)
 };
+// With references (A.featRef): pointFeat names this frame's features -- the hand-back has moved a live pointer along its track
+// (SL_SingleSLAM.cpp:34-60) -- and the table is MapPoint::pFeatures as the END of the previous frame left it: a feature of this frame is
+// the reference moved on by one frame (a table already at this frame is taken as it is); no feature of this frame and an older reference:
+// the camera lost the point, the stale feature stands (a view of isStaticPoint inside its window, of isLittleMove and isStaticRemovable).
 __device__ __forceinline__ ClsFeat cls_feature(const ClsArgs& A, int m, int c) {
     ClsFeat F;
-    F.s = -1, F.j0 = 0, F.f = 0, F.ff = 0;
+    F.s = -1, F.j0 = 0, F.f = 0, F.ff = 0, F.seg = -1;
     if (c >= A.nCams) return F;
     const int s = A.pointFeat[(size_t)m * A.nCams + c];
+    if (A.featRef) {
+        const int4 ref = A.featRef[(size_t)m * A.nCams + c];
+        int sl = s;
+        if (s >= 0) {
+            F.f = A.curFrame;
+            if (ref.x == s && (ref.y == A.curFrame || ref.y == A.curFrame - 1)) F.ff = ref.z, F.seg = ref.w;
+            else F.ff = A.cam[c].trackSpan[s];
+        } else if (ref.x >= 0 && ref.y < A.curFrame)
+            sl = ref.x, F.f = ref.y, F.ff = ref.z, F.seg = ref.w;
+        else
+            return F;
+        F.j0 = A.curFrame - F.f;
+        if (F.j0 < 0 || F.j0 >= A.stored) {   // older than the ring: treated as absent
+            F.seg = -1;
+            return F;
+        }
+        F.s = sl;
+        return F;
+    }
     if (s < 0) return F;
     F.f = A.featFrame ? A.featFrame[(size_t)m * A.nCams + c] : A.curFrame;
     F.j0 = A.curFrame - F.f;
@@ -1526,36 +1558,27 @@ __device__ __noinline__ bool cls_is_static(const ClsArgs& A, const ClsFeat& F, i
     ClsViews V;
     V.nv = 0, V.c = 0, V.j = 0, V.s = 0;
     const int firstFrame = A.curFrame - numFrame;
+    ChainCtx X;
+    X.N = A.N, X.H = A.H, X.head = A.head, X.cap = A.nHist, X.curFrame = A.curFrame, X.segCap = A.segCap, X.nCen = A.nHist, X.cen = A.cen;
+    X.stored = A.stored < A.nHist ? A.stored : A.nHist;   // (the walks stay inside the centre table: nHist frames)
+    X.segPool = A.featRef ? A.segPool : nullptr, X.minFrame = firstFrame;
     for (int c = 0; c < A.nCams; ++c) {
         const int s = __shfl(F.s, c, 64), f = __shfl(F.f, c, 64);
-        if (c == exclude || s < 0 || f < firstFrame) continue;
         const int j0 = __shfl(F.j0, c, 64), ff = __shfl(F.ff, c, 64);
+        if (c == exclude || s < 0 || f < firstFrame || j0 >= A.nHist) continue;
         if (r == V.nv) V.c = c, V.j = j0, V.s = s;
         ++V.nv;
         const double* C0 = A.cen + 3 * ((size_t)c * A.nHist + j0);
-        const double a0 = C0[0] - Mold[0], a1 = C0[1] - Mold[1], a2 = C0[2] - Mold[2];
-        const double na = (a0 * a0 + a1 * a1) + a2 * a2;
-        int best = -1;
-        double bestCos = 1.0;
-        // fp = fp->preFrame while fp->f >= firstFrame: frames f-1 .. lo, walk depths j0+1 .. curFrame-lo, as far as the ring goes
-        const int lo = ff > firstFrame ? ff : firstFrame;
-        const int jEnd = A.curFrame - lo < A.nHist - 1 ? A.curFrame - lo : A.nHist - 1;
-        for (int j = j0 + 1 + r; j <= jEnd; j += 64) {
-            const double* Cj = A.cen + 3 * ((size_t)c * A.nHist + j);
-            const double b0 = Cj[0] - Mold[0], b1 = Cj[1] - Mold[1], b2 = Cj[2] - Mold[2];
-            const double d = (a0 * b0 + a1 * b1) + a2 * b2;
-            const double nb = (b0 * b0 + b1 * b1) + b2 * b2;
-            const double cv = d / sqrt(na * nb);
-            if (cv < bestCos) bestCos = cv, best = j;
-        }
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const double oc = __shfl_xor(bestCos, off, 64);
-            const int oj = __shfl_xor(best, off, 64);
-            if (oj >= 0 && (oc < bestCos || (oc == bestCos && (best < 0 || oj < best)))) bestCos = oc, best = oj;
-        }
+        const double a[3] = {C0[0] - Mold[0], C0[1] - Mold[1], C0[2] - Mold[2]};
+        const double na = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+        // fp = fp->preFrame while fp && fp->f >= firstFrame (:141-152): the feature's own run of frames f-1 .. ff, then the linked segments,
+        // ending at the first node before the window (or the ring); the smallest cosine, the nearest node among equals
+        const int seg = __shfl(F.seg, c, 64);
+        int bestSlot = -1;
+        const int best = chain_widest(X, c, make_int4(s, f, ff, seg), A.histR + (size_t)c * A.H * 9, A.histT + (size_t)c * A.H * 3, a, na, Mold, r,
+                                      bestSlot);
         if (best >= 0) {
-            if (r == V.nv) V.c = c, V.j = best, V.s = s;
+            if (r == V.nv) V.c = c, V.j = best, V.s = bestSlot;
             ++V.nv;
         }
     }
@@ -1674,9 +1697,12 @@ __global__ __launch_bounds__(256) void k_map_points_classify(ClsArgs A) {
                     }
                     if (!(err > 1.0)) maxI = -1;
                     if (maxI >= 0 && nVis > 2 && cls_is_static(A, F, r, Mold, M, cov, maxI, NUM_FRAME_CHECK_STATIC)) {  // :476-482
-                        if (r == maxI) {
-                            if (A.cam[maxI].slot2map) const_cast<int*>(A.cam[maxI].slot2map)[F.s] = -1;
-                            A.pointFeat[(size_t)m * A.nCams + maxI] = -1;
+                        if (r == maxI) {   // (with references the view that goes may be a stale one: then only the reference is cleared)
+                            if (F.f == A.curFrame) {
+                                if (A.cam[maxI].slot2map) const_cast<int*>(A.cam[maxI].slot2map)[F.s] = -1;
+                                A.pointFeat[(size_t)m * A.nCams + maxI] = -1;
+                            }
+                            if (A.featRef) A.featRef[(size_t)m * A.nCams + maxI] = make_int4(-1, 0, 0, -1);   // p->pFeatures[outlierViewId] = 0
                         }
                         fl = 0, sfn = 0;
                         write = true;
@@ -1695,6 +1721,7 @@ __global__ __launch_bounds__(256) void k_map_points_classify(ClsArgs A) {
                         if (cls_is_static(A, F, r, Mold, M0, cov0, -1, NUM_FRAME_CHECK_STATIC)) {
                             fl = 0, sfn = 0;
                             if (F.s >= 0 && F.f == A.curFrame) A.cam[r].isStatic[F.s] = 1;
+                            else if (F.s >= 0 && A.refStatic) A.refStatic[(size_t)m * A.nCams + r] = 1;   // (:494-498: every feature held)
                         } else
                             sfn = 0;
                     }
@@ -1774,6 +1801,9 @@ struct cs_track_history {
     int segCap;
     unsigned char* alive;   // cs_feat_ref_advance_dev's scratch [aliveCap]
     int aliveCap;
+    // cs_track_history_set_classify_refs: the classification reads (and clears) the points' features as references
+    int4* clsFeatRef;
+    unsigned char* clsRefStatic;
 };
 
 // the camera centres by walk depth, if the ring's poses changed since they were last computed
@@ -2284,6 +2314,7 @@ __global__ __launch_bounds__(256) void k_intracam_newpts_try(InArgs A) {
     ChainCtx X;
     X.N = N, X.H = H, X.head = A.head, X.cap = (jp + 1 < A.maxWalk ? jp + 1 : A.maxWalk), X.curFrame = A.curFrame, X.stored = A.stored;
     X.segCap = 0, X.nCen = A.nHist, X.cen = A.cen, X.segPool = nullptr;
+    X.minFrame = -2147483647 - 1;
     const double a[3] = {org[0] - M[0], org[1] - M[1], org[2] - M[2]};
     const double na = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
     int bs = k;
@@ -2775,6 +2806,9 @@ static int cls_run(const cs_track_history* h, void* hip_stream, const cs_poseupd
     memset(&A, 0, sizeof(A));
     A.nCams = h->nCams, A.N = h->N, A.nMap = nMap, A.H = h->H, A.head = h->head, A.nHist = hist_walk(h), A.curFrame = curFrame;
     A.pointFeat = d_pointFeat, A.featFrame = d_featFrame, A.featFirst = d_featFirst;
+    A.featRef = h->clsFeatRef, A.refStatic = h->clsRefStatic, A.segPool = h->segPool, A.segCap = h->segCap;
+    A.stored = h->count < h->H ? h->count : h->H;
+    if (A.featRef) A.featFrame = nullptr, A.featFirst = nullptr;
     A.histXY = h->xy, A.histR = h->R, A.histT = h->t, A.cen = h->cen;
     A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.mapFlags = d_mapFlags, A.newPt = d_newPt, A.staticFrameNum = d_staticFrameNum;
     A.firstFrame = d_firstFrame;
@@ -2817,6 +2851,17 @@ extern "C" int cs_map_points_classify_dev(const cs_track_history* h, void* hip_s
                                           const int* d_firstFrame, double pixelVar, int* d_counts) {
     return cls_run(h, hip_stream, cams, d_pointFeat, nMap, d_featFrame, d_featFirst, curFrame, d_mapPts, d_mapCov, d_mapFlags, d_newPt,
                    d_staticFrameNum, d_firstFrame, pixelVar, d_counts, false, 0);
+}
+
+// From the next call on cs_map_points_classify_dev / cs_pose_update_classify_frame_dev take the points' features as references (d_featRef
+// [nMap][nCams] cs_feat_ref, the table cs_feat_ref_advance_dev keeps; d_refStatic [nMap][nCams] or NULL); NULL: back to d_pointFeat alone.
+extern "C" int cs_track_history_set_classify_refs(cs_track_history* h, cs_feat_ref* d_featRef, unsigned char* d_refStatic) {
+    if (!h) {
+        cs_set_error("cs_track_history_set_classify_refs: null history");
+        return CS_ERR_INVALID;
+    }
+    h->clsFeatRef = (int4*)d_featRef, h->clsRefStatic = d_featRef ? d_refStatic : nullptr;
+    return CS_OK;
 }
 
 // the worklist's storage for a map of nMap points (grown on first use / for a larger map: the only allocation, and it waits for the device)

@@ -69,6 +69,7 @@ class LoopConfig:
         # FrameLoop.keyframe_stats()["windows_not_applied_history_too_short"]).  One rank only.  Implies keyframe_decision.  Off in the headline:
         # in the bench's world the decision never says `decrease` -- there would be no window bundle adjustment to measure
         self.keyframe_ratio = 0.93       # m_mappedPtsReduceRatio (reference src/app/SL_CoSLAM.cpp:42)
+        self.classify_refs = True    # mapPointsClassify reads the references too (stale features, linked segments: cs_track_history_set_classify_refs)
         self.feature_chains = True   # MapPoint::pFeatures kept as feature references (cs_feat_ref): a camera that lost a point still contributes
         # its last feature to refineMapPoint / updateNewPosesPoints, and a point registered to a new track where it held an older feature has
         # the old chain linked behind it (reference src/app/SL_CoSLAM.cpp:775-779); False: the features of this frame on their own tracks
@@ -270,6 +271,8 @@ class FrameLoop:
             self.d_fref = torch.full((n_map, NA, 4), -1, dtype=i32, device=dev) if cfg.feature_chains else None
             self.d_rstat = z((n_map, NA), u8) if cfg.feature_chains else None
             self.d_fref_counts = z(5, i32)   # tracked on, first features, re-linked, links dropped (pool full), detached -- summed over the run
+            if self.d_fref is not None and cfg.classify_refs:
+                self.pose_upd.set_classify_refs(self.d_fref.data_ptr(), self.d_rstat.data_ptr())
             self.pu_args = poseupdate_cams([dict(K=self.d_K1.data_ptr(), iK=self.d_iK1.data_ptr(), xy=self.d_xy[g].data_ptr(),
                                                  state=self.d_state[g].data_ptr(), slot2map=self.d_slot2map[g].data_ptr(),
                                                  trackSpan=self.d_trackspan[g].data_ptr(), reprojErr=self.d_reproj[g].data_ptr(),

@@ -188,6 +188,12 @@ class TrackHistory:
                                              vp(d_scratch), vp(d_counts)), "cs_newpts_intracam_dev")
 
     # ---- MapPoint::pFeatures as feature references (cs_feat_ref / cs_feat_seg, include/coslam_hip.h) --------------------------------
+    def set_classify_refs(self, d_featRef, d_refStatic=None):
+        """cs_track_history_set_classify_refs: the classification (map_points_classify_dev, pose_update_classify_frame_dev) reads the points'
+        features as references from now on (stale features are views, the walks follow the links); d_featRef None: pointFeat alone again"""
+        vp = C.c_void_p
+        check(self._L.cs_track_history_set_classify_refs(vp(self._h), vp(d_featRef), vp(d_refStatic)), "cs_track_history_set_classify_refs")
+
     def feat_ref_advance_dev(self, stream_ptr, cams, nMap, d_pointFeat, curFrame, d_featRef, d_refStatic=None, d_counts=None, d_list=None, nList=0):
         """cs_feat_ref_advance_(list_)dev: every frame behind the registration's decisions -- tracked on / first feature / re-linked behind an
         older one (reference src/app/SL_CoSLAM.cpp:775-779) / stale / detached.  d_list / nList: a further call within the frame over those rows only"""

@@ -717,6 +717,17 @@ int cs_update_new_poses_points_ref_dev(const cs_track_history* h, void* hip_stre
 int cs_refine_map_points_ref_dev(const cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, const cs_feat_ref* d_featRef,
                                  int nMap, const unsigned char* d_select, double* d_mapPts, double* d_mapCov, double pixelErrVar, int* d_count);
 
+/* CoSLAM::mapPointsClassify (src/app/SL_CoSLAM.cpp:418-520) over the references: from the next call on cs_map_points_classify_dev and
+ * cs_pose_update_classify_frame_dev read d_featRef ([nMap][nCams], the table cs_feat_ref_advance_dev keeps: as the END of the previous
+ * frame left it, or already at this frame) next to d_pointFeat (this frame's features): a camera that lost the point still gives
+ * isStaticPoint (inside its 60 frames), isLittleMove and isStaticRemovable its stale feature with the pose of that frame
+ * (src/slam/SL_CoSLAMHelper.cpp:67-115, :117-250, :314-330), isStaticPoint's backward walks follow the linked segments, the view
+ * isStaticRemovable drops may be a stale one (its reference is cleared: `p->pFeatures[outlierViewId] = 0`, :470-472), a point that
+ * returns to static sets d_refStatic ([nMap][nCams] or NULL) of its stale features (:494-498).  d_featFrame / d_featFirst are then not
+ * read.  d_featRef NULL: back to d_pointFeat alone.  Pinned against the reference's own functions over chains built with its classes
+ * (tests/cxx/ref_classify_test.cpp golden_relink -> tests/golden/classify_relink_golden.npz). */
+int cs_track_history_set_classify_refs(cs_track_history* h, cs_feat_ref* d_featRef, unsigned char* d_refStatic);
+
 /* CoSLAM::checkUnify (src/app/SL_CoSLAM.cpp:561-665) for nPairs pairs of map points in one launch: what the registration loops ask
  * on a conflict -- the point's nearest feature already carries another static point (:791-796, bMerge: every 50th frame).  Per pair
  * the slots of both points' features of this frame per camera (d_pf1 / d_pf2 [nPairs][nCams], < 0 none) and the points' positions

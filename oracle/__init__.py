@@ -348,6 +348,41 @@ def map_points_classify(Ks, iKs, histR, histT, histXY, trackSpan, featStatic, po
     return n, nf.value
 
 
+def map_points_classify_ref(Ks, iKs, histR, histT, histXY, trackSpan, featStatic, pointFeat, featRef, segPool, refStatic, curFrame, mapPts,
+                            mapCov, mapFlags, newPt, staticFrameNum, firstFrame, pixelVar, slot2map=None):
+    """opu_map_points_classify_ref: the classification with the points' features as references -- featRef (nMap x nC x 4 int32, in / out:
+    a detached view's reference is cleared), segPool (nC x cap x 4 int32), refStatic (nMap x nC uint8, in / out) or None.  Everything
+    else as map_points_classify.  Returns (points examined, points that became false)."""
+    L = lib()
+    L.opu_map_points_classify_ref.restype = C.c_int
+    histR = np.ascontiguousarray(histR, dtype=np.float64)
+    histT = np.ascontiguousarray(histT, dtype=np.float64)
+    histXY = np.ascontiguousarray(histXY, dtype=np.float64)
+    nC, nH = histR.shape[0], histR.shape[1]
+    N = histXY.shape[2] // 2
+    Ks = np.ascontiguousarray(Ks, dtype=np.float64).reshape(nC, 9)
+    iKs = np.ascontiguousarray(iKs, dtype=np.float64).reshape(nC, 9)
+    sp = np.ascontiguousarray(trackSpan, dtype=np.int32).reshape(nC, 2 * N)
+    nMap = pointFeat.shape[0]
+    for a, dt in ((featStatic, np.uint8), (pointFeat, np.int32), (featRef, np.int32), (mapPts, np.float64), (mapCov, np.float64),
+                  (mapFlags, np.uint8), (newPt, np.uint8), (staticFrameNum, np.int32)):
+        assert a.dtype == dt and a.flags.c_contiguous
+    assert pointFeat.shape == (nMap, nC) and featStatic.shape == (nC, N) and featRef.shape == (nMap, nC, 4)
+    pool = np.ascontiguousarray(segPool, dtype=np.int32)
+    assert pool.ndim == 3 and pool.shape[0] == nC and pool.shape[2] == 4
+    if refStatic is not None:
+        assert refStatic.dtype == np.uint8 and refStatic.flags.c_contiguous and refStatic.shape == (nMap, nC)
+    fr = np.ascontiguousarray(firstFrame, dtype=np.int32)
+    if slot2map is not None:
+        assert slot2map.dtype == np.int32 and slot2map.flags.c_contiguous and slot2map.shape == (nC, N)
+    nf = C.c_int(0)
+    n = L.opu_map_points_classify_ref(nC, N, nH, _p(Ks), _p(iKs), _p(histR), _p(histT), _p(histXY), _p(sp), _p(featStatic),
+                                      _p(slot2map) if slot2map is not None else None, nMap, _p(pointFeat), _p(featRef), _p(pool),
+                                      int(pool.shape[1]), _p(refStatic) if refStatic is not None else None, int(curFrame), _p(mapPts),
+                                      _p(mapCov), _p(mapFlags), _p(newPt), _p(staticFrameNum), _p(fr), C.c_double(pixelVar), C.byref(nf))
+    return n, nf.value
+
+
 def check_unify(Ks, iKs, histR, histT, histXY, trackSpan, pf1, pf2, M1, M2, sigma, cmpAcos=False):
     """opu_check_unify (CoSLAM::checkUnify): pf1 / pf2 int32[nC] = the two points' slots per camera (< 0 none), M1 / M2 their
     positions.  Returns (ok, M, cov)."""

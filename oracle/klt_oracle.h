@@ -181,6 +181,11 @@ int opu_map_points_classify(int nCams, int N, int nHist, const double* Ks, const
                             const int* featFrame, const int* featFirst, int curFrame, double* mapPts, double* mapCov,
                             unsigned char* mapFlags, unsigned char* newPt, int* staticFrameNum, const int* firstFrame, double pixelVar,
                             int* numFalse);
+int opu_map_points_classify_ref(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
+                                const double* histXY, const int* trackSpan, unsigned char* featStatic, int* slot2map, int nMap, int* pointFeat,
+                                int* featRef, const int* segPool, int segCap, unsigned char* refStatic, int curFrame, double* mapPts,
+                                double* mapCov, unsigned char* mapFlags, unsigned char* newPt, int* staticFrameNum, const int* firstFrame,
+                                double pixelVar, int* numFalse);
 int opu_check_unify(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
                     const double* histXY, const int* trackSpan, const int* pf1, const int* pf2, const double* M1, const double* M2,
                     double sigma, int cmpAcos, double* M, double* cov);

@@ -575,22 +575,47 @@ typedef struct {
     const double *Ks, *iKs, *histR, *histT, *histXY;
     const int* trackSpan;
     const int *featFrame, *featFirst; /* [nMap][nCams] or NULL */
+    const int* featRef;               /* [nMap][nCams][4] or NULL: the features as references (then featFrame / featFirst are not read) */
+    const int* segPool;               /* [nCams][segCap][4] or NULL */
+    int segCap;
 } opu_cls_ctx;
 
 typedef struct {
-    int c, j; /* camera, history entry */
+    int c, j, s; /* camera, history entry, slot */
 } opu_view;
 
-/* the feature of point m in camera c: slot, history entry of its frame, first frame of its track; 0 if none (or older than the history) */
-static int cls_feature(const opu_cls_ctx* X, const int* pf, int m, int c, int* slot, int* j0, int* frame, int* first) {
+/* the feature of point m in camera c: slot, history entry of its frame, that frame, the first frame of the run of consecutive frames behind
+ * it, the first linked segment (-1 none); 0 if there is none (or it is older than the history).
+ * With references: the table is MapPoint::pFeatures as the END of the previous frame left it (cs_feat_ref_advance_dev) and pointFeat names
+ * this frame's features (the hand-back has moved a live pointer along its track, SL_SingleSLAM.cpp:34-60): a feature of this frame is the
+ * reference moved on by one frame (a table that is already at this frame is taken as it is); no feature of this frame and an older
+ * reference: the camera lost the point, the stale feature stands. */
+static int cls_feature_seg(const opu_cls_ctx* X, const int* pf, int m, int c, int* slot, int* j0, int* frame, int* first, int* seg) {
     const int s = pf[(size_t)m * X->nCams + c];
-    if (s < 0) return 0;
-    const int f = X->featFrame ? X->featFrame[(size_t)m * X->nCams + c] : X->curFrame;
+    int f, ff, sg = -1, sl = s;
+    if (X->featRef) {
+        const int* r = X->featRef + ((size_t)m * X->nCams + c) * 4;
+        if (s >= 0) {
+            f = X->curFrame;
+            if (r[0] == s && (r[1] == f || r[1] == f - 1)) ff = r[2], sg = r[3];
+            else ff = X->trackSpan[(size_t)c * 2 * X->N + s];
+        } else if (r[0] >= 0 && r[1] < X->curFrame)
+            sl = r[0], f = r[1], ff = r[2], sg = r[3];
+        else
+            return 0;
+    } else {
+        if (s < 0) return 0;
+        f = X->featFrame ? X->featFrame[(size_t)m * X->nCams + c] : X->curFrame;
+        ff = X->featFirst ? X->featFirst[(size_t)m * X->nCams + c] : X->trackSpan[(size_t)c * 2 * X->N + s];
+    }
     const int j = X->curFrame - f;
     if (j < 0 || j >= X->nHist) return 0;
-    *slot = s, *j0 = j, *frame = f;
-    *first = X->featFirst ? X->featFirst[(size_t)m * X->nCams + c] : X->trackSpan[(size_t)c * 2 * X->N + s];
+    *slot = sl, *j0 = j, *frame = f, *first = ff, *seg = sg;
     return 1;
+}
+static int cls_feature(const opu_cls_ctx* X, const int* pf, int m, int c, int* slot, int* j0, int* frame, int* first) {
+    int seg;
+    return cls_feature_seg(X, pf, m, c, slot, j0, frame, first, &seg);
 }
 static const double* cls_R(const opu_cls_ctx* X, int c, int j) { return X->histR + ((size_t)c * X->nHist + j) * 9; }
 static const double* cls_t(const opu_cls_ctx* X, int c, int j) { return X->histT + ((size_t)c * X->nHist + j) * 3; }
@@ -599,13 +624,12 @@ static void cls_pixel(const opu_cls_ctx* X, int c, int j, int s, double* mx, dou
     *mx = h[s], *my = h[X->N + s];
 }
 /* triangulateMultiView + getTriangulateCovMat over a view list, then the reprojection gate of every view (> 1.0 fails) */
-static int cls_triangulate_and_gate(const opu_cls_ctx* X, const int* slotOf, const opu_view* v, int nv, double sigma, double* M, double* cov,
-                                    int gate) {
+static int cls_triangulate_and_gate(const opu_cls_ctx* X, const opu_view* v, int nv, double sigma, double* M, double* cov, int gate) {
     opu_normal_eq E;
     memset(&E, 0, sizeof(E));
     for (int i = 0; i < nv; i++) {
         double mx, my;
-        cls_pixel(X, v[i].c, v[i].j, slotOf[v[i].c], &mx, &my);
+        cls_pixel(X, v[i].c, v[i].j, v[i].s, &mx, &my);
         ne_add_view(&E, X->iKs + 9 * v[i].c, cls_R(X, v[i].c, v[i].j), cls_t(X, v[i].c, v[i].j), mx, my);
     }
     double cf[6];
@@ -623,7 +647,7 @@ static int cls_triangulate_and_gate(const opu_cls_ctx* X, const int* slotOf, con
     if (!gate) return 1;
     for (int i = 0; i < nv; i++) {
         double rm[2], var[4], ivar[4], mx, my;
-        cls_pixel(X, v[i].c, v[i].j, slotOf[v[i].c], &mx, &my);
+        cls_pixel(X, v[i].c, v[i].j, v[i].s, &mx, &my);
         org_project(X->Ks + 9 * v[i].c, cls_R(X, v[i].c, v[i].j), cls_t(X, v[i].c, v[i].j), M, rm);
         org_projection_cov(X->Ks + 9 * v[i].c, cls_R(X, v[i].c, v[i].j), cls_t(X, v[i].c, v[i].j), M, cov, var, sigma);
         mat22_inv(var, ivar);
@@ -631,49 +655,56 @@ static int cls_triangulate_and_gate(const opu_cls_ctx* X, const int* slotOf, con
     }
     return 1;
 }
-/* isStaticPoint (exclude < 0) / isStaticPointExclude: the views of updateStaticPointPosition inside the window of numFrame frames */
+/* isStaticPoint (exclude < 0) / isStaticPointExclude: the views of updateStaticPointPosition inside the window of numFrame frames.  The
+ * backward walk `fp = fp->preFrame while fp && fp->f >= firstFrame` (:141-152) runs along the feature's own run of frames and then
+ * through the linked segments (each older than the one before it), and ends at the first node before the window. */
 static int cls_is_static(const opu_cls_ctx* X, const int* pf, int m, const double* Mold, double sigma, double* M, double* cov, int exclude,
                          int numFrame) {
     opu_view v[64];
-    int slotOf[32], nv = 0;
+    int nv = 0;
     const int firstFrame = X->curFrame - numFrame; /* p->lastFrame - numFrame; lastFrame == curFrame on the current list */
     for (int c = 0; c < X->nCams; c++) {
-        int s, j0, f, ff;
-        if (c == exclude || !cls_feature(X, pf, m, c, &s, &j0, &f, &ff) || f < firstFrame) continue;
-        slotOf[c] = s;
-        v[nv].c = c, v[nv].j = j0, nv++;
+        int s, j0, f, ff, seg;
+        if (c == exclude || !cls_feature_seg(X, pf, m, c, &s, &j0, &f, &ff, &seg) || f < firstFrame) continue;
+        v[nv].c = c, v[nv].j = j0, v[nv].s = s, nv++;
         double C0[3];
         cam_center(cls_R(X, c, j0), cls_t(X, c, j0), C0);
-        int best = -1;
+        int best = -1, bestSlot = -1, slot = s, hi = f - 1, lo = ff, ended = 0;
         double bestCos = 1.0;
-        const int lo = ff > firstFrame ? ff : firstFrame;
-        for (int fr = f - 1; fr >= lo; fr--) { /* fp = fp->preFrame while fp->f >= firstFrame */
-            const int j = X->curFrame - fr;
-            if (j >= X->nHist) break;
-            double Cj[3];
-            cam_center(cls_R(X, c, j), cls_t(X, c, j), Cj);
-            const double cv = cos_between(Mold, C0, Cj);
-            if (cv < bestCos) bestCos = cv, best = j;
+        for (;;) {
+            for (int fr = hi; fr >= lo; fr--) {
+                const int j = X->curFrame - fr;
+                if (fr < firstFrame || j >= X->nHist) {
+                    ended = 1;
+                    break;
+                }
+                double Cj[3];
+                cam_center(cls_R(X, c, j), cls_t(X, c, j), Cj);
+                const double cv = cos_between(Mold, C0, Cj);
+                if (cv < bestCos) bestCos = cv, best = j, bestSlot = slot;
+            }
+            if (ended || seg < 0 || !X->segPool || seg >= X->segCap) break;
+            const int* g = X->segPool + ((size_t)c * X->segCap + seg) * 4;
+            slot = g[0], hi = g[1], lo = g[2], seg = g[3];
         }
-        if (best >= 0) v[nv].c = c, v[nv].j = best, nv++;
+        if (best >= 0) v[nv].c = c, v[nv].j = best, v[nv].s = bestSlot, nv++;
     }
-    return cls_triangulate_and_gate(X, slotOf, v, nv, sigma, M, cov, 1);
+    return cls_triangulate_and_gate(X, v, nv, sigma, M, cov, 1);
 }
 /* isDynamicPoint: this frame's features only */
 static int cls_is_dynamic(const opu_cls_ctx* X, const int* pf, const unsigned char* featStatic, int m, double sigma, double* M, double* cov) {
     opu_view v[32];
-    int slotOf[32], nv = 0;
+    int nv = 0;
     for (int c = 0; c < X->nCams; c++) {
         int s, j0, f, ff;
         if (!cls_feature(X, pf, m, c, &s, &j0, &f, &ff) || f != X->curFrame) continue;
-        slotOf[c] = s;
-        v[nv].c = c, v[nv].j = 0, nv++;
+        v[nv].c = c, v[nv].j = 0, v[nv].s = s, nv++;
     }
     (void)featStatic; /* (:269-270 count the dynamic features and never use the count) */
     if (nv < 2) return 0;
     double org[3];
     cam_center(cls_R(X, v[0].c, 0), cls_t(X, v[0].c, 0), org);
-    cls_triangulate_and_gate(X, slotOf, v, nv, sigma, M, cov, 2);
+    cls_triangulate_and_gate(X, v, nv, sigma, M, cov, 2);
     {
         const double* R = cls_R(X, v[0].c, 0);
         const double* t = cls_t(X, v[0].c, 0);
@@ -691,7 +722,7 @@ static int cls_is_dynamic(const opu_cls_ctx* X, const int* pf, const unsigned ch
     if (sqrt((dx * dx + dy * dy) + dz * dz) * 0.2 < sqrt(sc)) return 0; /* :290-293 */
     for (int i = 0; i < nv; i++) {
         double rm[2], var[4], ivar[4], mx, my;
-        cls_pixel(X, v[i].c, 0, slotOf[v[i].c], &mx, &my);
+        cls_pixel(X, v[i].c, 0, v[i].s, &mx, &my);
         org_project(X->Ks + 9 * v[i].c, cls_R(X, v[i].c, 0), cls_t(X, v[i].c, 0), M, rm);
         org_projection_cov(X->Ks + 9 * v[i].c, cls_R(X, v[i].c, 0), cls_t(X, v[i].c, 0), M, cov, var, sigma);
         mat22_inv(var, ivar);
@@ -714,13 +745,13 @@ static double cls_feature_err(const opu_cls_ctx* X, int c, int j, int s, const d
  * In / out tables: pointFeat (a detached feature becomes -1), slot2map [nCams][N] (or NULL; the detached feature's slot becomes
  * -1), featStatic [nCams][N] (feature types; a point that returns to static sets its features' types to static).  Returns the number
  * of points examined; *numFalse = those that became false. */
-int opu_map_points_classify(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
-                            const double* histXY, const int* trackSpan, unsigned char* featStatic, int* slot2map, int nMap, int* pointFeat,
-                            const int* featFrame, const int* featFirst, int curFrame, double* mapPts, double* mapCov,
-                            unsigned char* mapFlags, unsigned char* newPt, int* staticFrameNum, const int* firstFrame, double pixelVar,
-                            int* numFalse) {
+static int classify_core(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
+                         const double* histXY, const int* trackSpan, unsigned char* featStatic, int* slot2map, int nMap, int* pointFeat,
+                         const int* featFrame, const int* featFirst, int* featRef, const int* segPool, int segCap, unsigned char* refStatic,
+                         int curFrame, double* mapPts, double* mapCov, unsigned char* mapFlags, unsigned char* newPt, int* staticFrameNum,
+                         const int* firstFrame, double pixelVar, int* numFalse) {
     const int FRAME_NUM_FOR_NEWPOINT = 30, FRAME_NUM_FOR_DONTMOVE = 50, NUM_FRAME_CHECK_STATIC = 60;
-    opu_cls_ctx X = {nCams, N, nHist, curFrame, Ks, iKs, histR, histT, histXY, trackSpan, featFrame, featFirst};
+    opu_cls_ctx X = {nCams, N, nHist, curFrame, Ks, iKs, histR, histT, histXY, trackSpan, featFrame, featFirst, featRef, segPool, segCap};
     int nExamined = 0, nFalse = 0;
     for (int m = 0; m < nMap; m++) {
         /* the current list after mapStateUpdate (:1183-1197): points with a feature in this frame; numVisCam counts those features */
@@ -779,9 +810,13 @@ int opu_map_points_classify(int nCams, int N, int nHist, const double* Ks, const
                     int out = -1;
                     if (maxI >= 0 && nVis > 2 && cls_is_static(&X, pointFeat, m, pM, pixelVar, M, cov, maxI, NUM_FRAME_CHECK_STATIC)) out = maxI;
                     if (out >= 0) { /* :476-482 */
-                        const int s = pointFeat[(size_t)m * nCams + out];
-                        if (slot2map) slot2map[(size_t)out * N + s] = -1;
+                        const int s = pointFeat[(size_t)m * nCams + out]; /* (< 0 with references: the view that goes is a stale one) */
+                        if (slot2map && s >= 0) slot2map[(size_t)out * N + s] = -1;
                         pointFeat[(size_t)m * nCams + out] = -1;
+                        if (featRef) { /* p->pFeatures[outlierViewId] = 0: the chain behind it goes with it */
+                            int* r = featRef + ((size_t)m * nCams + out) * 4;
+                            r[0] = -1, r[1] = 0, r[2] = 0, r[3] = -1;
+                        }
                         SET_STATIC();
                         UPDATE_POS(M, cov);
                     } else
@@ -804,7 +839,9 @@ int opu_map_points_classify(int nCams, int N, int nHist, const double* Ks, const
                             SET_STATIC();
                             for (int c = 0; c < nCams; c++) {
                                 int s, j0, f, ff;
-                                if (cls_feature(&X, pointFeat, m, c, &s, &j0, &f, &ff) && f == curFrame) featStatic[(size_t)c * N + s] = 1;
+                                if (!cls_feature(&X, pointFeat, m, c, &s, &j0, &f, &ff)) continue;
+                                if (f == curFrame) featStatic[(size_t)c * N + s] = 1;
+                                else if (refStatic) refStatic[(size_t)m * nCams + c] = 1; /* (:494-498 set the type of every feature held) */
                             }
                         } else
                             staticFrameNum[m] = 0;
@@ -824,6 +861,29 @@ int opu_map_points_classify(int nCams, int N, int nHist, const double* Ks, const
     }
     if (numFalse) *numFalse = nFalse;
     return nExamined;
+}
+
+int opu_map_points_classify(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
+                            const double* histXY, const int* trackSpan, unsigned char* featStatic, int* slot2map, int nMap, int* pointFeat,
+                            const int* featFrame, const int* featFirst, int curFrame, double* mapPts, double* mapCov,
+                            unsigned char* mapFlags, unsigned char* newPt, int* staticFrameNum, const int* firstFrame, double pixelVar,
+                            int* numFalse) {
+    return classify_core(nCams, N, nHist, Ks, iKs, histR, histT, histXY, trackSpan, featStatic, slot2map, nMap, pointFeat, featFrame, featFirst,
+                         NULL, NULL, 0, NULL, curFrame, mapPts, mapCov, mapFlags, newPt, staticFrameNum, firstFrame, pixelVar, numFalse);
+}
+/* ... with the points' features as references (featRef [nMap][nCams][4] in / out, segPool [nCams][segCap][4], refStatic [nMap][nCams] in /
+ * out or NULL: cls_feature_seg above): stale features are views of isStaticPoint (inside its window), isLittleMove and isStaticRemovable,
+ * isStaticPoint's backward walks follow the linked segments, the view isStaticRemovable drops may be a stale one (its reference is
+ * cleared), a point that returns to static sets the type of its stale features too.
+ * PARITY: tests/cxx/ref_classify_test.cpp golden_relink -> tests/golden/classify_relink_golden.npz (the reference's own functions over
+ * chains built with its classes). */
+int opu_map_points_classify_ref(int nCams, int N, int nHist, const double* Ks, const double* iKs, const double* histR, const double* histT,
+                                const double* histXY, const int* trackSpan, unsigned char* featStatic, int* slot2map, int nMap, int* pointFeat,
+                                int* featRef, const int* segPool, int segCap, unsigned char* refStatic, int curFrame, double* mapPts,
+                                double* mapCov, unsigned char* mapFlags, unsigned char* newPt, int* staticFrameNum, const int* firstFrame,
+                                double pixelVar, int* numFalse) {
+    return classify_core(nCams, N, nHist, Ks, iKs, histR, histT, histXY, trackSpan, featStatic, slot2map, nMap, pointFeat, NULL, NULL, featRef,
+                         segPool, segCap, refStatic, curFrame, mapPts, mapCov, mapFlags, newPt, staticFrameNum, firstFrame, pixelVar, numFalse);
 }
 
 /* ---- CoSLAM::checkUnify (/root/reference/src/app/SL_CoSLAM.cpp:561-665) ---------------------------------------------------------

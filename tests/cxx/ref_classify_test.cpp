@@ -12,6 +12,12 @@
 // dynamic (moving; standing still with the counter below / at the threshold of 50 frames -> back to static), seen by one camera,
 // and certain static ones that are not looked at.
 //   ref_classify_test golden <out.bin>
+//   ref_classify_test golden_relink <out.bin>
+// golden_relink: the features as the registration loops and lost tracks leave MapPoint::pFeatures over time (src/app/SL_CoSLAM.cpp:775-779,
+// :997-1000: `pFeat->preFrame = p->pFeatures[iCam]`): per point and camera 1-3 segments of consecutive frames, newest first, gaps in
+// between, the newest at the current frame or a few frames back (a stale head; also in the camera whose view is off, so that the view
+// mapPointsClassify detaches can be a stale one), 70 frames of history so that chains reach behind isStaticPoint's window of 60 frames.
+// Same layout except per point and camera: int32 nSeg, featDynamic, per segment int32 j0 (history entry of its newest node), L, L x m[2].
 // Layout of out.bin: int32 nScenes; per scene: int32 nCams, H, nPts, curFrame; double pixelVar; per camera K[9], iK[9]; per camera
 // and history entry (newest first) R[9], t[3]; per point: M[3], cov[9], int32 localType, uncertain, newPt, staticFrameNum,
 // firstFrame, per camera int32 L (0 = no feature), int32 back (the feature's frame = curFrame - back), int32 featDynamic,
@@ -21,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "app/SL_CoSLAM.h"
@@ -51,17 +58,20 @@ template <class T> static void put(FILE* f, const T* p, size_t n) { fwrite(p, si
 static void puti(FILE* f, int v) { fwrite(&v, 4, 1, f); }
 
 int main(int argc, char** argv) {
-    if (argc < 3 || strcmp(argv[1], "golden")) {
-        fprintf(stderr, "usage: %s golden <out.bin>\n", argv[0]);
+    if (argc < 3 || (strcmp(argv[1], "golden") && strcmp(argv[1], "golden_relink"))) {
+        fprintf(stderr, "usage: %s golden|golden_relink <out.bin>\n", argv[0]);
         return 2;
     }
+    const bool relink = !strcmp(argv[1], "golden_relink");
+    if (relink) g_rng = 0xD1B54A32D192ED03ull;
+    int nChains = 0, nStale = 0, nLinked = 0, nStaleOff = 0;
     FILE* f = fopen(argv[2], "wb");
     if (!f) return 1;
     const int nScenes = 3;
     puti(f, nScenes);
     int outcome[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 0 untouched certain, 1 -> static, 2 -> dynamic, 3 -> false, 4 stays uncertain, 5 detached, 6 counter++, 7 back to static
     for (int sc = 0; sc < nScenes; ++sc) {
-        const int nCams = 3 + sc % 3, H = 64, nPts = 72, curFrame = 300 + 7 * sc;
+        const int nCams = 3 + sc % 3, H = relink ? 70 : 64, nPts = 72, curFrame = 300 + 7 * sc;
         const double pixelVar = 12.0;  // CoSLAM::poseUpdate: mapPointsClassify(12.0) (src/app/SL_CoSLAM.cpp:385)
         CoSLAM* co = new CoSLAM();
         co->numCams = nCams;
@@ -118,33 +128,57 @@ int main(int argc, char** argv) {
             for (int c = 0; c < nCams; ++c) {
                 // which cameras see the point: kind 11 one camera; kind 6 all (the removable test needs more than two); else most
                 bool has = kind == 11 ? (c == p % nCams) : (kind == 6 ? true : (urand() < 0.85 || c < 2));
-                const int back = (has && kind != 11 && c >= 2 && urand() < 0.2) ? 1 + (int)(urand() * 8) : 0;   // a camera that lost the point
-                const int L = has ? 2 + (int)(urand() * (H - 2 - back)) : 0;
+                int back = (has && kind != 11 && c >= 2 && urand() < 0.2) ? 1 + (int)(urand() * 8) : 0;   // a camera that lost the point
+                if (relink && has && kind == 6 && c == offCam && c >= 2 && urand() < 0.5) back = 1 + (int)(urand() * 8);
+                int L = has ? 2 + (int)(urand() * (H - 2 - back)) : 0;
                 const int dyn = (kind >= 8 && kind <= 10) ? (urand() < 0.7) : (urand() < 0.1);
-                puti(f, L), puti(f, back), puti(f, dyn);
+                std::vector<std::pair<int, int> > segs;   // (history entry of the newest node, nodes)
+                if (!relink) {
+                    puti(f, L), puti(f, back), puti(f, dyn);
+                    if (L > 0) segs.push_back(std::make_pair(back, L));
+                } else if (has) {
+                    const double u2 = urand();
+                    const int want = u2 < 0.3 ? 1 : (u2 < 0.7 ? 2 : 3);
+                    int j = back;
+                    for (int q = 0; q < want && j < H; ++q) {
+                        int Lq = 1 + (int)(urand() * (q == 0 && want > 1 ? 12 : 30));   // (a freshly re-linked head is short)
+                        if (q == 0 && want > 1 && urand() < 0.25) Lq = 1;
+                        if (j + Lq > H) Lq = H - j;
+                        segs.push_back(std::make_pair(j, Lq));
+                        j += Lq + 1 + (int)(urand() * 10);   // the frames in which the camera did not see the point
+                    }
+                    L = 1;
+                    puti(f, (int)segs.size()), puti(f, dyn);
+                    ++nChains, nStale += back > 0, nLinked += segs.size() > 1, nStaleOff += (c == offCam && back > 0);
+                } else {
+                    L = 0;
+                    puti(f, 0), puti(f, dyn);
+                }
                 FeaturePoint* newer = nullptr;
-                for (int q = 0; q < L; ++q) {
-                    const int j = back + q;   // history entry of this feature's frame
-                    const double* R = cams[c][j]->R;
-                    const double* t = cams[c][j]->t;
-                    const double* K = Ks[c].data();
-                    const double X[3] = {X0[0] - vel[0] * j, X0[1] - vel[1] * j, X0[2] - vel[2] * j};
-                    double Xc[3], m[2];
-                    for (int r = 0; r < 3; ++r) Xc[r] = R[3 * r] * X[0] + R[3 * r + 1] * X[1] + R[3 * r + 2] * X[2] + t[r];
-                    m[0] = (K[0] * Xc[0] + K[1] * Xc[1] + K[2] * Xc[2]) / Xc[2] + 0.4 * nrand();
-                    m[1] = (K[4] * Xc[1] + K[5] * Xc[2]) / Xc[2] + 0.4 * nrand();
-                    if (garbage) m[0] += 60 * nrand(), m[1] += 60 * nrand();
-                    if (c == offCam) m[0] += 45, m[1] -= 38;
-                    put(f, m, 2);
-                    FeaturePoint* fp = new FeaturePoint(curFrame - j, c, m[0], m[1]);
-                    fp->setIntrinsic(K);
-                    fp->setCameraPose(cams[c][j]);
-                    fp->type = dyn ? TYPE_FEATPOINT_DYNAMIC : TYPE_FEATPOINT_STATIC;
-                    fp->preFrame = nullptr;
-                    fp->mpt = mp;
-                    if (newer) newer->preFrame = fp, fp->nextFrame = newer;
-                    else mp->pFeatures[c] = fp;
-                    newer = fp;
+                for (size_t sg = 0; sg < segs.size(); ++sg) {
+                    if (relink) puti(f, segs[sg].first), puti(f, segs[sg].second);
+                    for (int j = segs[sg].first; j < segs[sg].first + segs[sg].second; ++j) {   // j: history entry of this feature's frame
+                        const double* R = cams[c][j]->R;
+                        const double* t = cams[c][j]->t;
+                        const double* K = Ks[c].data();
+                        const double X[3] = {X0[0] - vel[0] * j, X0[1] - vel[1] * j, X0[2] - vel[2] * j};
+                        double Xc[3], m[2];
+                        for (int r = 0; r < 3; ++r) Xc[r] = R[3 * r] * X[0] + R[3 * r + 1] * X[1] + R[3 * r + 2] * X[2] + t[r];
+                        m[0] = (K[0] * Xc[0] + K[1] * Xc[1] + K[2] * Xc[2]) / Xc[2] + 0.4 * nrand();
+                        m[1] = (K[4] * Xc[1] + K[5] * Xc[2]) / Xc[2] + 0.4 * nrand();
+                        if (garbage) m[0] += 60 * nrand(), m[1] += 60 * nrand();
+                        if (c == offCam) m[0] += 45, m[1] -= 38;
+                        put(f, m, 2);
+                        FeaturePoint* fp = new FeaturePoint(curFrame - j, c, m[0], m[1]);
+                        fp->setIntrinsic(K);
+                        fp->setCameraPose(cams[c][j]);
+                        fp->type = dyn ? TYPE_FEATPOINT_DYNAMIC : TYPE_FEATPOINT_STATIC;
+                        fp->preFrame = nullptr;
+                        fp->mpt = mp;
+                        if (newer) newer->preFrame = fp, fp->nextFrame = newer;   // (across a gap: what :777-778 assigns)
+                        else mp->pFeatures[c] = fp;
+                        newer = fp;
+                    }
                 }
                 if (L > 0 && back == 0) ++nCur;
             }
@@ -173,6 +207,7 @@ int main(int argc, char** argv) {
         co->curMapPts.clearWithoutRelease();
     }
     fclose(f);
+    if (relink) printf("ref_classify_test golden_relink: %d chains, %d with a stale head (%d of them the view that is off), %d with linked segments\n", nChains, nStale, nStaleOff, nLinked);
     printf("ref_classify_test: certain %d, -> static %d, -> dynamic %d, -> false %d, still uncertain %d, view detached %d, dynamic kept %d, back to static %d\n",
            outcome[0], outcome[1], outcome[2], outcome[3], outcome[4], outcome[5], outcome[6], outcome[7]);
     for (int q = 0; q < 8; ++q)

@@ -916,6 +916,110 @@ def classify_case():
     return out
 
 
+def classify_relink_case():
+    """the reference's own mapPointsClassify over re-linked and stale feature chains (oracle/_ref/ref_classify_test golden_relink, CPU),
+    re-laid out the way the device holds them: every segment of consecutive frames on a slot of its own (running number per camera),
+    featRef [nP][nC][4] = {slot, frame, first, seg}, segPool [nC][cap][4] = {slot, last, first, next}; pointFeat names the heads that are
+    of this frame.  featDyn_ref [nP][nC]: the type the reference left on the feature each pointer names (live or stale)."""
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_classify_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_classify_test missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "c.bin")
+        subprocess.run([exe, "golden_relink", path], check=True, stdout=subprocess.DEVNULL)
+        raw = open(path, "rb").read()
+    o = 0
+
+    def ints(n):
+        nonlocal o
+        v = np.frombuffer(raw, dtype=np.int32, count=n, offset=o).copy()
+        o += 4 * n
+        return v
+
+    def dbls(n):
+        nonlocal o
+        v = np.frombuffer(raw, dtype=np.float64, count=n, offset=o).copy()
+        o += 8 * n
+        return v
+
+    def flags_of(ltype, unc):
+        return (1 if ltype == 1 else 0) | (2 if ltype == -2 else 0) | (4 if unc else 0)
+
+    out = {}
+    (nS,) = ints(1)
+    out["n_scenes"] = np.int32(nS)
+    for sc in range(nS):
+        nC, H, nP, cur = ints(4)
+        (pixelVar,) = dbls(1)
+        K, iK = np.zeros((nC, 9)), np.zeros((nC, 9))
+        for c in range(nC):
+            K[c], iK[c] = dbls(9), dbls(9)
+        hR, hT = np.zeros((nC, H, 9)), np.zeros((nC, H, 3))
+        for c in range(nC):
+            for j in range(H):
+                hR[c, j], hT[c, j] = dbls(9), dbls(3)
+        N = 3 * nP                                           # at most three segments per (point, camera), each on its own slot
+        hXY = np.full((nC, H, 2 * N), np.nan)                # (a pixel nobody should read)
+        span = np.full((nC, 2 * N), -1, np.int32)
+        fstat = np.ones((nC, N), np.uint8)
+        rstat = np.ones((nP, nC), np.uint8)
+        pf = np.full((nP, nC), -1, np.int32)
+        s2m = np.full((nC, N), -1, np.int32)
+        ref = np.full((nP, nC, 4), -1, np.int32)
+        ref[:, :, 1:3] = 0
+        pool = np.full((nC, 2 * nP, 4), -1, np.int32)
+        nslot, npool = [0] * nC, [0] * nC
+        M0, cov0 = np.zeros((nP, 3)), np.zeros((nP, 9))
+        flags, newpt, sfn, first = np.zeros(nP, np.uint8), np.zeros(nP, np.uint8), np.zeros(nP, np.int32), np.zeros(nP, np.int32)
+        for p in range(nP):
+            M0[p], cov0[p] = dbls(3), dbls(9)
+            ltype, unc, newpt[p], sfn[p], first[p] = ints(5)
+            flags[p] = flags_of(ltype, unc)
+            for c in range(nC):
+                nSeg, dyn = ints(2)
+                segs = []
+                for q in range(nSeg):
+                    j0, L = ints(2)
+                    m = dbls(2 * L).reshape(L, 2)
+                    s_ = nslot[c]
+                    nslot[c] += 1
+                    hXY[c, j0:j0 + L, s_], hXY[c, j0:j0 + L, N + s_] = m[:, 0], m[:, 1]
+                    segs.append((s_, cur - j0, cur - (j0 + L - 1)))
+                    span[c, s_], span[c, N + s_] = cur - (j0 + L - 1), cur - j0
+                nxt = -1
+                for s_, last, first_ in reversed(segs[1:]):   # the oldest segment first: each names the one behind it
+                    pool[c, npool[c]] = (s_, last, first_, nxt)
+                    nxt = npool[c]
+                    npool[c] += 1
+                if segs:
+                    ref[p, c] = (segs[0][0], segs[0][1], segs[0][2], nxt)
+                    rstat[p, c] = 0 if dyn else 1
+                    if segs[0][1] == cur:
+                        pf[p, c] = segs[0][0]
+                        s2m[c, segs[0][0]] = p
+                        fstat[c, segs[0][0]] = 0 if dyn else 1
+        Mr, covr = np.zeros((nP, 3)), np.zeros((nP, 9))
+        flr, newr, sfr = np.zeros(nP, np.uint8), np.zeros(nP, np.uint8), np.zeros(nP, np.int32)
+        has_r, dyn_r = np.zeros((nP, nC), np.uint8), np.zeros((nP, nC), np.uint8)
+        for p in range(nP):
+            Mr[p], covr[p] = dbls(3), dbls(9)
+            ltype, unc, newr[p], sfr[p] = ints(4)
+            flr[p] = flags_of(ltype, unc)
+            for c in range(nC):
+                has_r[p, c], dyn_r[p, c] = ints(2)
+        pre = f"s{sc}_"
+        for k, v in dict(K=K, iK=iK, histR=hR, histT=hT, histXY=hXY, trackSpan=span, featStatic=fstat, refStatic=rstat, pointFeat=pf,
+                         slot2map=s2m, featRef=ref, segPool=pool, M0=M0, cov0=cov0, flags=flags, newPt=newpt, staticFrameNum=sfn,
+                         firstFrame=first, curFrame=np.int32(cur), pixelVar=np.float64(pixelVar), M_ref=Mr, cov_ref=covr, flags_ref=flr,
+                         newPt_ref=newr, staticFrameNum_ref=sfr, hasFeature_ref=has_r, featDyn_ref=dyn_r).items():
+            out[pre + k] = v
+    assert o == len(raw)
+    return out
+
+
 def cgklt_cases():
     """see the module docstring.  Every array named *_cg comes out of libcgklt_ref.so."""
     from oracle import cgref
@@ -1021,7 +1125,7 @@ def cgklt_cases():
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "mergability_long", "update_points", "update_points_relink", "keyframe", "intracam_newpts", "classify", "intercam", "newpts", "decide", "cgklt"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "mergability_long", "update_points", "update_points_relink", "keyframe", "intracam_newpts", "classify", "classify_relink", "intercam", "newpts", "decide", "cgklt"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -1048,6 +1152,8 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "intracam_newpts_golden.npz"), **intracam_newpts_case())
     if "keyframe" in which:
         np.savez_compressed(os.path.join(HERE, "keyframe_golden.npz"), **keyframe_case())
+    if "classify_relink" in which:
+        np.savez_compressed(os.path.join(HERE, "classify_relink_golden.npz"), **classify_relink_case())
     if "update_points_relink" in which:
         np.savez_compressed(os.path.join(HERE, "update_points_relink_golden.npz"), **update_points_relink_case())
     if "classify" in which:

@@ -696,6 +696,72 @@ def _relink_ring(g, sc, dev, s):
     return th, cams, keep
 
 
+def test_map_points_classify_over_feature_references_reproduces_the_reference():
+    """cs_map_points_classify_dev behind cs_track_history_set_classify_refs against tests/golden/classify_relink_golden.npz -- the
+    reference's own CoSLAM::mapPointsClassify over chains as the registration loops and lost tracks leave them (748 chains, 64 stale
+    heads, 516 with linked segments; 70 frames of history, isStaticPoint's window of 60 ends inside chains): positions and covariances
+    bit for bit, types, flags, counters, which features / references stay, the features' types -- with the table at this frame and
+    with the live references one frame behind (as the frame loop holds them when the classification runs)."""
+    import os
+
+    import torch
+
+    from tests.test_oracle_cpu import classify_relink_expect, shifted_refs
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "classify_relink_golden.npz"))
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    examined = stale_detached = 0
+    for sc in range(int(g["n_scenes"])):
+        G = lambda k: g[f"s{sc}_{k}"]   # noqa: E731
+        cur, nMap = int(G("curFrame")), G("M0").shape[0]
+        for behind in (False, True):
+            th, cams, keep = _relink_ring(g, sc, dev, s)
+            nC = len(cams)
+            ref0 = shifted_refs(G)[0] if behind else G("featRef").copy()
+            d_ref, d_rstat = torch.from_numpy(ref0.copy()).to(dev), torch.from_numpy(G("refStatic").copy()).to(dev)
+            d_s2m = torch.from_numpy(G("slot2map").copy()).to(dev)
+            for c in range(nC):
+                cams[c]["slot2map"] = d_s2m[c].data_ptr()
+            d_M, d_cov = torch.from_numpy(G("M0").copy()).to(dev), torch.from_numpy(G("cov0").copy()).to(dev)
+            d_fl, d_new = torch.from_numpy(G("flags").copy()).to(dev), torch.from_numpy(G("newPt").copy()).to(dev)
+            d_sfn, d_first = torch.from_numpy(G("staticFrameNum").copy()).to(dev), torch.from_numpy(G("firstFrame").copy()).to(dev)
+            d_pf = torch.from_numpy(G("pointFeat").copy()).to(dev)
+            d_cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+            th.set_classify_refs(d_ref.data_ptr(), d_rstat.data_ptr())
+            th.map_points_classify_dev(s, cams, d_pf.data_ptr(), nMap, cur, d_M.data_ptr(), d_cov.data_ptr(), d_fl.data_ptr(), d_new.data_ptr(),
+                                       d_sfn.data_ptr(), d_first.data_ptr(), float(G("pixelVar")), d_counts=d_cnt.data_ptr())
+            torch.cuda.synchronize()
+            M, cov, fl = d_M.cpu().numpy(), d_cov.cpu().numpy(), d_fl.cpu().numpy()
+            assert np.array_equal(fl, G("flags_ref")), f"scene {sc} behind {behind}: types differ at {np.nonzero(fl != G('flags_ref'))[0][:8]}"
+            assert np.array_equal(d_new.cpu().numpy(), G("newPt_ref")) and np.array_equal(d_sfn.cpu().numpy(), G("staticFrameNum_ref"))
+            dM, dC = np.abs(M - G("M_ref")).max(), np.abs(cov - G("cov_ref")).max()
+            assert np.array_equal(M, G("M_ref")) and np.array_equal(cov, G("cov_ref")), f"scene {sc}: max |dM| {dM:.3e}, max |dcov| {dC:.3e}"
+            pf, ref = d_pf.cpu().numpy(), d_ref.cpu().numpy()
+            has, dyn = classify_relink_expect(G, pf, ref, keep["fstat"].cpu().numpy(), d_rstat.cpu().numpy())
+            assert np.array_equal(has, G("hasFeature_ref")) and np.array_equal(dyn, G("featDyn_ref") * has)
+            gone = (ref0[:, :, 0] >= 0) & (ref[:, :, 0] < 0)
+            assert np.array_equal(gone, (G("hasFeature_ref") == 0) & (ref0[:, :, 0] >= 0))
+            assert np.array_equal(ref[~gone], ref0[~gone])                                   # every other reference stands as it was
+            assert int((d_s2m.cpu().numpy() >= 0).sum()) == int((pf >= 0).sum())
+            cnt = d_cnt.tolist()
+            assert cnt[1] == int((((fl & 2) != 0) & ((G("flags") & 2) == 0)).sum()) and cnt[0] > 50
+            if not behind:
+                examined += cnt[0]
+                stale_detached += int((gone & (G("pointFeat") < 0)).sum())
+            # without the references the same call sees this frame's features only: some points come out differently
+            if behind:
+                th.set_classify_refs(None)
+                d_M2, d_cov2, d_fl2 = torch.from_numpy(G("M0").copy()).to(dev), torch.from_numpy(G("cov0").copy()).to(dev), torch.from_numpy(G("flags").copy()).to(dev)
+                d_new2, d_sfn2, d_pf2 = torch.from_numpy(G("newPt").copy()).to(dev), torch.from_numpy(G("staticFrameNum").copy()).to(dev), torch.from_numpy(G("pointFeat").copy()).to(dev)
+                th.map_points_classify_dev(s, cams, d_pf2.data_ptr(), nMap, cur, d_M2.data_ptr(), d_cov2.data_ptr(), d_fl2.data_ptr(), d_new2.data_ptr(),
+                                           d_sfn2.data_ptr(), d_first.data_ptr(), float(G("pixelVar")))
+                torch.cuda.synchronize()
+                assert not np.array_equal(d_fl2.cpu().numpy(), G("flags_ref")) or not np.array_equal(d_M2.cpu().numpy(), G("M_ref"))
+            th.close()
+    assert examined > 150 and stale_detached >= 1
+
+
 def test_relinked_and_stale_feature_chains_reproduce_the_reference():
     """cs_update_new_poses_points_ref_dev / cs_refine_map_points_ref_dev / cs_check_unify_ref_dev against
     tests/golden/update_points_relink_golden.npz (VERDICT r04 missing 3): chains as `pFeat->preFrame = p->pFeatures[iCam]`
