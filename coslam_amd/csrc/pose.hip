@@ -203,6 +203,10 @@ __device__ __forceinline__ void block_sum28(double (&v)[NSUM], double* lds /* [2
 template <int PB>
 __device__ void lm_pass(const PoseCtx& c, const double* R, const double* t, bool reweight, double tau, int& par, double& mine, double& err) {
     const double eps = 1e-8;
+    // The forward differences are SCALED by 1e8 where the reference divides by 1e-8 (:271-287): 12 of a point's 26 f64 divisions per pass
+    // (each ~30 instructions with a quarter-rate reciprocal) become multiplications -- at most 1 ulp per Jacobian entry, the size of what
+    // the tree sums below already differ from the reference's serial ones by; the tolerances of tests/test_pose_ba_gpu.py are unchanged.
+    const double ieps = 1e8;
     // the perturbed rotations R * exp(eps e_k) do not depend on the point (:57-59)
     double R1[3][9];
 #pragma unroll
@@ -231,16 +235,16 @@ __device__ void lm_pass(const PoseCtx& c, const double* R, const double* t, bool
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             project(c.K, R1[a], t, pM, rm);
-            J[a] = (rm[0] - rm0[0]) / eps;
-            J[6 + a] = (rm[1] - rm0[1]) / eps;
+            J[a] = (rm[0] - rm0[0]) * ieps;
+            J[6 + a] = (rm[1] - rm0[1]) * ieps;
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             double t1[3] = {t[0], t[1], t[2]};
             t1[a] = t[a] + eps;
             project(c.K, R, t1, pM, rm);
-            J[3 + a] = (rm[0] - rm0[0]) / eps;
-            J[9 + a] = (rm[1] - rm0[1]) / eps;
+            J[3 + a] = (rm[0] - rm0[0]) * ieps;
+            J[9 + a] = (rm[1] - rm0[1]) * ieps;
         }
 #pragma unroll
         for (int q = 0; q < 12; ++q) J[q] = w * J[q];

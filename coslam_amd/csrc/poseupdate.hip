@@ -801,10 +801,8 @@ __global__ __launch_bounds__(256) void k_ring_centres(int nCams, int H, int head
     up_cam_center(hR + ((size_t)c * H + rs) * 9, hT + ((size_t)c * H + rs) * 3, cen + 3 * (size_t)q);
 }
 
-__global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
-    const int tid = threadIdx.x, g = tid / UP_LPP, r = tid % UP_LPP;
-    const int m = blockIdx.x * (256 / UP_LPP) + g;
-    // (every test below is uniform over a point's lanes: whole groups leave together, the shuffles stay inside a group)
+// one map point, one wave (lane r): every test below is uniform over the point's lanes, the shuffles stay inside the wave
+__device__ __forceinline__ void up_point(const UpArgs& A, int m, int r) {
     if (m >= A.nMap) return;
     if (A.refine) {
         if (A.select && !A.select[m]) return;
@@ -915,6 +913,10 @@ __global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) A.mapPts[3 * (size_t)m + q] = M[q];
     if (A.counts) atomicAdd(A.counts + (locStatic ? 0 : 1), 1);
+}
+__global__ __launch_bounds__(256) void k_update_points(UpArgs A) {
+    const int tid = threadIdx.x, g = tid / UP_LPP, r = tid % UP_LPP;
+    up_point(A, blockIdx.x * (256 / UP_LPP) + g, r);
 }
 
 // ---- CoSLAM::checkUnify (src/app/SL_CoSLAM.cpp:561-665) for a batch of pairs ----------------------------------------------------------
@@ -2435,7 +2437,7 @@ extern "C" int cs_newpts_intracam_dev(const cs_track_history* h, void* hip_strea
 //   ... except when the reference was alive in the frame before and its slot's track lives ON without the point: the feature was detached
 //     (`p->pFeatures[outlierViewId] = 0` of mapPointsClassify, :470-472; `pFeat->mpt->pFeatures[v] = 0` of a unification, :810): cleared.
 // The call has to be made EVERY frame (a detachment is recognised against the frame before).
-struct FrArgs {
+struct FrCore {
     int nCams, N, nMap, curFrame, segCap;
     const int* pointFeat;
     int4* featRef;
@@ -2446,14 +2448,12 @@ struct FrArgs {
     unsigned char* alive;   // [nMap]: one of the point's references was of the frame of the last call (the history's scratch)
     const int* list;        // null, or the rows to look at: list[0 .. nList), entries < 0 skipped (a SECOND call within a frame, behind a
     int nList;              // registration round that changed just these points' features: every other row stands as the first call left it)
+};
+struct FrArgs : FrCore {
     cs_poseupdate_cam cam[PU_MAX_CAMS];
 };
-// a thread per MAP POINT (its nCams entries): most of a map's points are seen by no camera in a frame and were not the frame before --
-// their row of pointFeat (and one byte saying whether any of their references was alive last frame) is all that is read
-__global__ __launch_bounds__(256) void k_feat_ref_advance(FrArgs A) {
-    const int idx0 = blockIdx.x * 256 + threadIdx.x;
-    const int m = A.list ? (idx0 < A.nList ? A.list[idx0] : -1) : idx0;
-    int cnt[5] = {0, 0, 0, 0, 0};   // tracked on, first, re-linked, links dropped, detached
+// one row (a map point's nCams references) of cs_feat_ref_advance_dev; cnt: tracked on, first, re-linked, links dropped, detached
+__device__ __forceinline__ void fr_advance_row(const FrCore& A, const cs_poseupdate_cam* cam, int m, int (&cnt)[5]) {
     if (m >= 0 && m < A.nMap) {
         const int* pf = A.pointFeat + (size_t)m * A.nCams;
         int top = -1;   // (no short circuit: the row's loads go out together, not one after the other)
@@ -2477,7 +2477,7 @@ __global__ __launch_bounds__(256) void k_feat_ref_advance(FrArgs A) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c = c0 + q < A.nCams ? c0 + q : A.nCams - 1;
-                    const int* span = A.cam[c].trackSpan;
+                    const int* span = cam[c].trackSpan;
                     const bool on = sl[q] >= 0 && sl[q] < A.N;
                     const int look = on ? sl[q] : ((refs[q].x >= 0 && refs[q].x < A.N) ? refs[q].x : 0);
                     g1[q] = span[look], g2[q] = span[A.N + look];
@@ -2489,7 +2489,7 @@ __global__ __launch_bounds__(256) void k_feat_ref_advance(FrArgs A) {
                     const size_t e = (size_t)m * A.nCams + c;
                     const int s = sl[q];
                     int4 ref = refs[q];
-                    const cs_poseupdate_cam& C = A.cam[c];
+                    const cs_poseupdate_cam& C = cam[c];
                     if (s < 0 || s >= A.N) {
                         if (ref.x >= 0 && ref.x < A.N && ref.y == A.curFrame - 1 && g1[q] >= 0 && g1[q] <= ref.y && g2[q] == A.curFrame) {
                             ref.x = -1, ++cnt[4];   // the same track, alive in this frame, no longer the point's: detached
@@ -2521,6 +2521,14 @@ __global__ __launch_bounds__(256) void k_feat_ref_advance(FrArgs A) {
             A.alive[m] = aliveNow ? 1 : 0;
         }
     }
+}
+// a thread per MAP POINT (its nCams entries): most of a map's points are seen by no camera in a frame and were not the frame before --
+// their row of pointFeat (and one byte saying whether any of their references was alive last frame) is all that is read
+__global__ __launch_bounds__(256) void k_feat_ref_advance(FrArgs A) {
+    const int idx0 = blockIdx.x * 256 + threadIdx.x;
+    const int m = A.list ? (idx0 < A.nList ? A.list[idx0] : -1) : idx0;
+    int cnt[5] = {0, 0, 0, 0, 0};   // tracked on, first, re-linked, links dropped, detached
+    fr_advance_row(A, A.cam, m, cnt);
     if (A.counts) {   // one atomic per WORKGROUP and counter: atomics on one address serialise (360 waves' worth were most of this kernel's time)
         __shared__ int sCnt[4][5];
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -2575,6 +2583,101 @@ extern "C" int cs_feat_ref_advance_list_dev(cs_track_history* h, void* hip_strea
     if (nMap == 0 || (d_list && nList == 0)) return CS_OK;
     A.list = d_list, A.nList = nList;
     hipLaunchKernelGGL(k_feat_ref_advance, dim3(((d_list ? nList : nMap) + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, A);
+    CS_HIP(hipGetLastError());
+    return CS_OK;
+}
+
+// cs_feat_ref_advance_(list_)dev + cs_refine_map_points_ref_dev as ONE launch: the rows that are not refined are advanced by the first
+// blocks (a thread per row, as k_feat_ref_advance); a row that IS refined (select[m] != 0; it has to be on `list`) is advanced by lane 0 of
+// its own wave, which then re-triangulates the point from the references it has just written (k_update_points' refine mode).  Rows are
+// independent (a pool segment is taken with an atomic), so the table and the map come out as the two calls leave them.
+struct ArArgs : UpArgs {
+    FrCore F;
+    const int* list;     // the rows refined are among list[0 .. nList) (entries < 0 skipped)
+    int nList, advAll;   // advAll: the first blocks advance every row of the map (the frame's first call), else the listed rows
+    int blocksA, clearSelect;
+    unsigned char* selectW;   // = select (written when clearSelect: the mark is consumed)
+};
+__global__ __launch_bounds__(256) void k_advance_refine(ArArgs A) {
+    int cnt[5] = {0, 0, 0, 0, 0};
+    if ((int)blockIdx.x < A.blocksA) {
+        const int idx0 = blockIdx.x * 256 + threadIdx.x;
+        const int m = A.advAll ? idx0 : (idx0 < A.nList ? A.list[idx0] : -1);
+        if (m >= 0 && m < A.nMap && !A.select[m]) fr_advance_row(A.F, A.cam, m, cnt);
+    } else {
+        const int j = ((int)blockIdx.x - A.blocksA) * 4 + (int)threadIdx.x / 64, r = threadIdx.x % 64;
+        const int m = j < A.nList ? A.list[j] : -1;
+        if (m >= 0 && m < A.nMap && A.select[m]) {   // (uniform over the wave)
+            if (r == 0) fr_advance_row(A.F, A.cam, m, cnt);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            up_point(A, m, r);
+            if (A.clearSelect && r == 0) A.selectW[m] = 0;
+        }
+    }
+    if (A.F.counts) {
+        __shared__ int sCnt[4][5];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            int v = cnt[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) sCnt[wv][k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 5) {
+            const int v = (sCnt[0][threadIdx.x] + sCnt[1][threadIdx.x]) + (sCnt[2][threadIdx.x] + sCnt[3][threadIdx.x]);
+            if (v) atomicAdd(A.F.counts + threadIdx.x, v);
+        }
+    }
+}
+
+extern "C" int cs_feat_ref_advance_refine_dev(cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int nMap, const int* d_pointFeat,
+                                              int curFrame, cs_feat_ref* d_featRef, unsigned char* d_refStatic, int* d_counts, const int* d_list,
+                                              int nList, int advanceAll, unsigned char* d_select, int clearSelect, double* d_mapPts,
+                                              double* d_mapCov, double pixelErrVar) {
+    if (!h || !cams || nMap < 1 || nList < 1 || !d_pointFeat || !d_featRef || !d_list || !d_select || !d_mapPts || !d_mapCov) {
+        cs_set_error("cs_feat_ref_advance_refine_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    if (h->count < 1 || curFrame != h->lastFrame) {
+        cs_set_error("cs_feat_ref_advance_refine_dev: the history's newest entry must be frame %d (it holds %d frame(s), the newest %d)", curFrame,
+                     h->count, h->lastFrame);
+        return CS_ERR_INVALID;
+    }
+    ArArgs A;
+    memset((void*)&A, 0, sizeof(A));
+    A.nMap = nMap, A.featRef = (const int4*)d_featRef, A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.sigma = pixelErrVar;
+    A.refine = 1, A.select = d_select, A.selectW = d_select, A.clearSelect = clearSelect ? 1 : 0;
+    A.segPool = h->segPool, A.segCap = h->segCap, A.curFrame = h->lastFrame, A.stored = h->count < h->H ? h->count : h->H;
+    A.nCams = h->nCams, A.N = h->N, A.H = h->H, A.head = h->head, A.nHist = hist_walk(h);
+    A.histXY = h->xy, A.histR = h->R, A.histT = h->t, A.cen = h->cen;
+    A.F.nCams = h->nCams, A.F.N = h->N, A.F.nMap = nMap, A.F.curFrame = curFrame, A.F.segCap = h->segCap;
+    A.F.pointFeat = d_pointFeat, A.F.featRef = (int4*)d_featRef, A.F.refStatic = d_refStatic, A.F.segPool = h->segPool, A.F.segCount = h->segCount;
+    A.F.counts = d_counts;
+    A.list = d_list, A.nList = nList, A.advAll = advanceAll ? 1 : 0;
+    CS_HIP(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (nMap > h->aliveCap) {
+        if (h->alive) CS_HIP(hipFree(h->alive));
+        h->alive = nullptr, h->aliveCap = 0;
+        CS_HIP(hipMalloc((void**)&h->alive, (size_t)nMap));
+        CS_HIP(hipMemsetAsync(h->alive, 1, (size_t)nMap, s));
+        h->aliveCap = nMap;
+    }
+    A.F.alive = h->alive;
+    for (int c = 0; c < h->nCams; ++c) {
+        if (!cams[c].K || !cams[c].iK || !cams[c].trackSpan) {
+            cs_set_error("cs_feat_ref_advance_refine_dev: null pointer in camera %d (K, iK, trackSpan are read)", c);
+            return CS_ERR_INVALID;
+        }
+        A.cam[c] = cams[c];
+    }
+    hist_centres(h, s);
+    A.blocksA = ((advanceAll ? nMap : nList) + 255) / 256;
+    hipLaunchKernelGGL(k_advance_refine, dim3(A.blocksA + (nList + 3) / 4), dim3(256), 0, s, A);
     CS_HIP(hipGetLastError());
     return CS_OK;
 }

@@ -486,6 +486,13 @@ struct RdArgs {
     int* callFlag;                   // the word before it: this call has been counted
     int* changed;                    // scratch [RD_MAX_SWEEPS]: sweep k changed an owner (the self-settling launch, k_decide_settle)
     int* bar;                        // scratch [1]: its grid barrier's arrival counter
+    // the second visits' first list built by the walks themselves (cs_register_decide_kinds_rounds_dev; null: not asked for): a point that
+    // registered and holds a feature in a later camera's loop appends itself -- what k_revisit_list(firstRound) would find
+    int* rvLists;                    // [nRounds][rvCap]: cleared to -1 by the prepare launch, list 0 filled by the settle launch
+    int* rvCounts;                   // [nRounds]: cleared; [0] = points appended (may exceed rvCap: the rest is not visited again)
+    int rvCap, nRounds;
+    int* visitLoop;                  // [P]: the loop of a registered point's visit
+    int* nextLoop;                   // [P]: the loop of its next visit
 };
 constexpr int RD_MAX_SWEEPS = 64;
 // code of (point, camera): -1 the walk passes the camera by; else the candidate feature camera * N + slot in the low bits and
@@ -499,6 +506,10 @@ __global__ __launch_bounds__(256) void k_decide_prepare(RdArgs A) {
     if (k < 4 && A.counts) A.counts[k] = k == 2 ? A.nSweeps : (k == 3 ? 1 : 0);   // (converged: cleared by the last launch when not)
     if (k == 0) *A.callFlag = 0, *A.bar = 0;
     if (k < RD_MAX_SWEEPS) A.changed[k] = 0;
+    if (A.rvLists) {
+        for (int f = k; f < A.nRounds * A.rvCap; f += gridDim.x * 256) A.rvLists[f] = -1;
+        if (k < A.nRounds) A.rvCounts[k] = 0;
+    }
     if (k >= A.P * C) return;
     const int p = k / C, i = k - p * C;
     A.attached[k] = 0;
@@ -680,6 +691,18 @@ __global__ __launch_bounds__(256) void k_decide_settle(RdArgs A) {
     if (reg) {
         A.regged[p] = 1;
         if (A.counts) atomicAdd(A.counts, nAtt), atomicAdd(A.counts + 1, 1);
+        if (A.rvLists && A.onlyCam < 0) {   // k_revisit_list's first round, by the walk itself
+            const int last = (base / C) / A.P;   // the loop of this visit: the first camera that held a feature before the pass (k_decide_prepare)
+            A.visitLoop[p] = last;
+            int b = -1;
+            for (int c = C - 1; c > last; --c)
+                if (A.pointFeat[(size_t)p * C + c] >= 0) b = c;
+            if (b >= 0) {
+                const int q = atomicAdd(A.rvCounts, 1);
+                if (q < A.rvCap) A.rvLists[q] = p, A.nextLoop[p] = b;
+                else atomicAdd(A.rvCounts + A.nRounds, 1);   // (never cleared here: the points beyond the lists over the run)
+            }
+        }
     }
 }
 
@@ -761,6 +784,10 @@ struct RvArgs {
     int curCap;
     int* counts;                     // [4] (accumulating): features attached, points registered, conflicts, sweeps that did not settle
     const int* listCount;            // null, or k_revisit_list's count: 0 = nobody is visited again (the usual round): leave at once
+    int* nextList;                   // null, or the NEXT round's list [cap] (cleared to -1 before): a point that registered here and holds a
+    int* nextCount;                  // feature in a later loop appends itself (what k_revisit_list would find), *nextCount counts them
+    int* nextLoopW;                  // = nextLoop, written for the appended points
+    int* overflow;                   // null, or where the points beyond the next list are counted
 };
 constexpr int RV_MAX_ROWS = 1024;
 __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
@@ -870,7 +897,20 @@ __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
                 }
             }
         }
-        if (reg) A.regOut[p] = 1, A.visitLoop[p] = A.nextLoop[p];
+        if (reg) {
+            const int last = A.nextLoop[p];
+            A.regOut[p] = 1, A.visitLoop[p] = last;
+            if (A.nextList) {
+                int b = -1;
+                for (int c = C - 1; c > last; --c)
+                    if (A.pointFeat[(size_t)p * C + c] >= 0) b = c;
+                if (b >= 0) {
+                    const int q = atomicAdd(A.nextCount, 1);
+                    if (q < A.cap) A.nextList[q] = p, A.nextLoopW[p] = b;
+                    else if (A.overflow) atomicAdd(A.overflow, 1);
+                }
+            }
+        }
     }
     __syncthreads();
     // a feature attached here was unmapped until now: a LATER-ordered visit of this frame that had it as its candidate walked past it (it
@@ -928,6 +968,21 @@ extern "C" int cs_register_revisit_decide_dev(int device, void* hip_stream, int 
                                               const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
                                               int* const* d_slot2map, unsigned char* d_attached, unsigned char* d_regOut, void* d_decideScratch,
                                               const int* d_curList, const int* d_curCount, int curCap, int* d_counts, const int* d_listCount) {
+    return cs_register_revisit_decide_next_dev(device, hip_stream, nCams, N, P, cap, mapBase, kinds, d_list, (int*)d_nextLoop, d_visitLoop, d_slot, d_flags,
+                                               d_mergeable, d_mapFlags, d_pointFeat, d_slot2map, d_attached, d_regOut, d_decideScratch, d_curList, d_curCount,
+                                               curCap, d_counts, d_listCount, nullptr, nullptr, nullptr);
+}
+
+extern "C" int cs_register_revisit_decide_next_dev(int device, void* hip_stream, int nCams, int N, int P, int cap, int mapBase, int kinds, const int* d_list,
+                                                   int* d_nextLoop, int* d_visitLoop, const int* d_slot, const int* d_flags,
+                                                   const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
+                                                   int* const* d_slot2map, unsigned char* d_attached, unsigned char* d_regOut, void* d_decideScratch,
+                                                   const int* d_curList, const int* d_curCount, int curCap, int* d_counts, const int* d_listCount,
+                                                   int* d_nextList, int* d_nextCount, int* d_overflow) {
+    if ((d_nextList != nullptr) != (d_nextCount != nullptr)) {
+        cs_set_error("cs_register_revisit_decide_next_dev: the next round's list and its count go together");
+        return CS_ERR_INVALID;
+    }
     if (nCams < 1 || nCams > RD_MAX_CAMS || N < 1 || P < 1 || cap < 1 || cap > RV_MAX_ROWS || kinds < 1 || kinds > 3 || !d_list || !d_nextLoop || !d_visitLoop ||
         !d_slot || !d_flags || !d_mergeable || !d_mapFlags || !d_pointFeat || !d_slot2map || !d_attached || !d_regOut || !d_decideScratch ||
         !d_curList || !d_curCount || (long long)nCams * N > RD_FEAT || (long long)nCams * P * nCams > 0x7fffffffLL) {
@@ -940,6 +995,7 @@ extern "C" int cs_register_revisit_decide_dev(int device, void* hip_stream, int 
     A.slot = d_slot, A.flags = d_flags, A.mergeable = d_mergeable, A.mapFlags = d_mapFlags, A.pointFeat = d_pointFeat;
     for (int c = 0; c < nCams; ++c) A.slot2map[c] = d_slot2map[c];
     A.attached = d_attached, A.regOut = d_regOut, A.curList = d_curList, A.curCount = d_curCount, A.curCap = curCap, A.counts = d_counts, A.listCount = d_listCount;
+    A.nextList = d_nextList, A.nextCount = d_nextCount, A.nextLoopW = d_nextLoop, A.overflow = d_overflow;
     int* scr = (int*)d_decideScratch + (size_t)nCams * P + P;   // (cs_register_decide_kinds_dev's carve-up: code | base | owner x 3 | ...)
     for (int k = 0; k < 3; ++k) A.owner[k] = scr, scr += (size_t)nCams * N;
     CS_HIP(hipSetDevice(device));
@@ -972,6 +1028,20 @@ extern "C" int cs_register_decide_kinds_dev(int device, void* hip_stream, int nC
                                             const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
                                             int* const* d_slot2map, unsigned char* d_attached, unsigned char* d_regged, void* d_scratch,
                                             int nSweeps, int* d_counts, int onlyCam, int kinds) {
+    return cs_register_decide_kinds_rounds_dev(device, hip_stream, nCams, N, P, mapBase, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, d_slot2map,
+                                               d_attached, d_regged, d_scratch, nSweeps, d_counts, onlyCam, kinds, nullptr, 0, 0, nullptr, nullptr, nullptr);
+}
+
+extern "C" int cs_register_decide_kinds_rounds_dev(int device, void* hip_stream, int nCams, int N, int P, int mapBase, const int* d_slot, const int* d_flags,
+                                                   const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat,
+                                                   int* const* d_slot2map, unsigned char* d_attached, unsigned char* d_regged, void* d_scratch,
+                                                   int nSweeps, int* d_counts, int onlyCam, int kinds, int* d_rvLists, int rvCap, int nRounds,
+                                                   int* d_rvCounts, int* d_visitLoop, int* d_nextLoop) {
+    if (d_rvLists && (rvCap < 1 || rvCap > RV_MAX_ROWS || nRounds < 1 || nRounds > 8 || !d_rvCounts || !d_visitLoop || !d_nextLoop || nSweeps != 0 || onlyCam >= 0)) {
+        cs_set_error("cs_register_decide_kinds_rounds_dev: the second visits' lists need 1..%d rows, 1..8 rounds, their counters, visitLoop / nextLoop, "
+                     "the self-settling launch (nSweeps 0) and all cameras' loops", RV_MAX_ROWS);
+        return CS_ERR_INVALID;
+    }
     if (onlyCam >= nCams || kinds < 1 || kinds > 3) {
         cs_set_error("cs_register_decide_kinds_dev: camera %d of %d, kinds %d (1: static, 2: dynamic, 3: both)", onlyCam, nCams, kinds);
         return CS_ERR_INVALID;
@@ -994,6 +1064,7 @@ extern "C" int cs_register_decide_kinds_dev(int device, void* hip_stream, int nC
         A.slot2map[c] = d_slot2map[c];
     }
     A.attached = d_attached, A.regged = d_regged, A.counts = d_counts;
+    A.rvLists = d_rvLists, A.rvCap = rvCap, A.nRounds = nRounds, A.rvCounts = d_rvCounts, A.visitLoop = d_visitLoop, A.nextLoop = d_nextLoop;
     int* scr = (int*)d_scratch;
     A.code = scr, scr += (size_t)nCams * P;
     A.base = scr, scr += P;

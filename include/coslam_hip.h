@@ -465,6 +465,27 @@ int cs_register_revisit_decide_dev(int device, void* hip_stream, int nCams, int 
                                    int* d_counts, const int* d_listCount /* cs_register_revisit_list_dev's d_counts (its [0]: rows listed) or
                                    NULL: an empty list ends the launch at once */);
 
+/* The same rounds with TWO launches fewer each: the lists are built by the walks themselves.
+ *   cs_register_decide_kinds_rounds_dev   cs_register_decide_kinds_dev (nSweeps 0, all cameras' loops) whose prepare launch clears
+ *       d_rvLists [nRounds][rvCap] to -1 and d_rvCounts [nRounds] to 0 and whose walks append the points that registered and hold a
+ *       feature in a later loop to list 0 (d_visitLoop / d_nextLoop [P] written as cs_register_revisit_list_dev(firstRound) writes them;
+ *       d_rvCounts[0] = points appended, beyond rvCap they are not visited again and counted in d_rvCounts[nRounds], which is NOT cleared:
+ *       the array has nRounds + 1 entries);
+ *   cs_register_revisit_decide_next_dev   cs_register_revisit_decide_dev whose walks append the points that registered again to the NEXT
+ *       round's list (d_nextList = d_rvLists + (r + 1) * rvCap, d_nextCount = d_rvCounts + r + 1; NULL in the last round;
+ *       d_overflow = d_rvCounts + nRounds or NULL).
+ * The marks of a round (d_regOut) are consumed by cs_feat_ref_advance_refine_dev(clearSelect), so nothing has to clear them.
+ * A list's order is the order of the appends (the decisions do not depend on it: every visit carries its own order key). */
+int cs_register_decide_kinds_rounds_dev(int device, void* hip_stream, int nCams, int N, int P, int mapBase, const int* d_slot, const int* d_flags,
+                                        const unsigned char* d_mergeable, const unsigned char* d_mapFlags, int* d_pointFeat, int* const* d_slot2map,
+                                        unsigned char* d_attached, unsigned char* d_regged, void* d_scratch, int nSweeps, int* d_counts, int onlyCam,
+                                        int kinds, int* d_rvLists, int rvCap, int nRounds, int* d_rvCounts, int* d_visitLoop, int* d_nextLoop);
+int cs_register_revisit_decide_next_dev(int device, void* hip_stream, int nCams, int N, int P, int cap, int mapBase, int kinds, const int* d_list,
+                                        int* d_nextLoop, int* d_visitLoop, const int* d_slot, const int* d_flags, const unsigned char* d_mergeable,
+                                        const unsigned char* d_mapFlags, int* d_pointFeat, int* const* d_slot2map, unsigned char* d_attached,
+                                        unsigned char* d_regOut, void* d_decideScratch, const int* d_curList, const int* d_curCount, int curCap,
+                                        int* d_counts, const int* d_listCount, int* d_nextList, int* d_nextCount, int* d_overflow);
+
 /* Cameras sharded over GPUs: a rank searches for its own cameras (cs_register_search_passes_range_dev, cs_register_mergability_range_dev);
  * the decision needs every camera's candidates.  pack: columns cam0 .. cam0 + nOwn - 1 of the P x nCams tables into a send record of
  * 3 * nOwn * P ints; unpack: the records of all ranks (cs_comm_allgather_dev: rank r owns cameras r * nOwn ..) into the tables
@@ -701,6 +722,15 @@ int cs_feat_ref_advance_dev(cs_track_history* h, void* hip_stream, const cs_pose
  * just those points' features (cs_register_revisit_decide_dev) -- every other row stands as the frame's first call left it */
 int cs_feat_ref_advance_list_dev(cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int nMap, const int* d_pointFeat,
                                  int curFrame, cs_feat_ref* d_featRef, unsigned char* d_refStatic, int* d_counts, const int* d_list, int nList);
+/* cs_feat_ref_advance_(list_)dev and cs_refine_map_points_ref_dev of the same rows as ONE launch (the pose stream's launches are its
+ * time: DESIGN.md 3.13.1): the rows of d_list[0 .. nList) with d_select[m] != 0 are advanced AND refined (CoSLAM::refineMapPoint,
+ * src/app/SL_CoSLAM.cpp:666-713, over the references just written), every other row -- of the whole map when advanceAll, else of the
+ * list -- is advanced only.  A row that is to be refined has to be on the list.  clearSelect: the marks are consumed (set to 0).  Same
+ * tables and map as the two calls. */
+int cs_feat_ref_advance_refine_dev(cs_track_history* h, void* hip_stream, const cs_poseupdate_cam* cams, int nMap, const int* d_pointFeat,
+                                   int curFrame, cs_feat_ref* d_featRef, unsigned char* d_refStatic, int* d_counts, const int* d_list, int nList,
+                                   int advanceAll, unsigned char* d_select, int clearSelect, double* d_mapPts, double* d_mapCov,
+                                   double pixelErrVar);
 /* the pools: device pointer ([nCams][cap]), capacity per camera, device counters [nCams] */
 int cs_track_history_segments(const cs_track_history* h, cs_feat_seg** d_pool, int* cap, int** d_count);
 /* the counters copied to the host (counts [nCams]); synchronous */

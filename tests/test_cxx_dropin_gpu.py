@@ -132,6 +132,15 @@ def test_cxx_frame_loop_on_two_ranks_ends_in_the_one_rank_runs_map(hip, tmp_path
     assert one.returncode == 0, one.stderr[-2000:]
     j1 = line(one.stdout)
     assert j1["world"] == 1 and j1["pose_ok"] and j1["windows_applied_in_timed_region"] >= 10
+    # the registration's launches fused (the second visits' lists built by the walks, advance + refine as one launch: the default) against
+    # the launch-per-step sequence: the same map, tables and poses, the same second visits
+    plain = subprocess.run([exe, wl, steps, warm, "0", "2"], env=dict(base, COSLAM_FUSED_ROUNDS="0"), capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    jp = line(plain.stdout)
+    assert jp["digest"] == j1["digest"], "the fused registration launches do not end where the launch-per-step sequence does"
+    for k in ("second_visit_features_attached", "second_visit_conflicts", "map_points_in_use", "second_visit_points_beyond_the_list"):
+        assert jp[k] == j1[k], (k, jp[k], j1[k])
+    assert j1["second_visit_features_attached"] > 0
     seg = f"/coslam_cxx_{os.getpid()}"
     procs = [subprocess.Popen([exe, wl, steps, warm, "0", "2"], env=dict(base, RANK=str(r), WORLD_SIZE="2", COSLAM_FORCE_DEVICE="0",
                                                                         COSLAM_COMM="host:" + seg),

@@ -324,6 +324,8 @@ int main(int argc, char** argv) {
     const int RV_CAP = 1024, RV_ROUNDS = getenv("COSLAM_REVISIT_ROUNDS") ? atoi(getenv("COSLAM_REVISIT_ROUNDS")) : 2;
     int* dRvList = dev_zeros<int>(RV_CAP);
     int *dRvVisit = dev_zeros<int>(nMap), *dRvNext = dev_zeros<int>(nMap), *dRvCnt = dev_zeros<int>(4), *dRvListCnt = dev_zeros<int>(4);
+    const bool fusedRounds = chains && !(getenv("COSLAM_FUSED_ROUNDS") && getenv("COSLAM_FUSED_ROUNDS")[0] == '0');   // the lists by the walks, advance + refine as one launch
+    int *dRvLists = dev_zeros<int>((size_t)(RV_ROUNDS > 0 ? RV_ROUNDS : 1) * RV_CAP), *dRvCounts = dev_zeros<int>(RV_ROUNDS + 1);
     unsigned char* dRvReg[2] = {dev_zeros<unsigned char>(nMap), dev_zeros<unsigned char>(nMap)};   // current points beyond the list's cap P_REG (left out of that frame's registration)
     int* dMergeRun = dev_zeros<int>(4);
     double* dR[2] = {to_dev(R0), to_dev(R0)};
@@ -604,12 +606,39 @@ int main(int argc, char** argv) {
             ++nMergeFrames;
             kinds = 2;
         }
-        CSCHK(cs_register_decide_kinds_dev(dev, (void*)poseS, nCams, N, nMap, 0, reg[0].slot, reg[0].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
-                                           dAttached, dRegged, dDecScratch, /*nSweeps: until settled*/ 0, dDecCnt, /*onlyCam*/ -1, kinds));
-        refine();
-        // the reference's SECOND VISITS (SL_CoSLAM.cpp:864-869, :889-893): the points that registered are refined and visited again in their next
-        // camera's loop -- rounds of list + search + whole-track mergability + walks + refine over just those points, every rank for ALL cameras
-        // on its replica (cs_register_revisit_*; tools/r06_exact_vs_single.py: with two rounds the map is the reference order's, frame after frame)
+        if (fusedRounds && kinds == 3) {
+            // the same with the lists built by the walks themselves and advance + refine as one launch: 4 launches per round instead of 6, 2 instead
+            // of 3 behind the single pass (cs_register_decide_kinds_rounds_dev, cs_feat_ref_advance_refine_dev)
+            CSCHK(cs_register_decide_kinds_rounds_dev(dev, (void*)poseS, nCams, N, nMap, 0, reg[0].slot, reg[0].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
+                                                      dAttached, dRegged, dDecScratch, 0, dDecCnt, -1, 3, RV_ROUNDS > 0 ? dRvLists : nullptr, RV_CAP, RV_ROUNDS,
+                                                      dRvCounts, dRvVisit, dRvNext));
+            CSCHK(cs_feat_ref_advance_refine_dev(hist, (void*)poseS, pu.data(), nMap, dPf, i, dFref, dRstat, dFrefCnt, dCurList, P_REG, 1, dRegged, 0, dMap, dCov, PIX));
+            for (int r = 0; r < RV_ROUNDS; ++r) {
+                int* list = dRvLists + (size_t)r * RV_CAP;
+                cs_register_pass ps[1];
+                memset(ps, 0, sizeof(ps));
+                ps[0].P = RV_CAP, ps[0].sigmaSearch = PIX, ps[0].maxDist = 3 * PIXVAR, ps[0].sigmaMerge = PIX;
+                ps[0].M = dMap, ps[0].cov = dCov, ps[0].pointFeat = dPf, ps[0].list = list;
+                ps[0].mapFlags = dMapFlags, ps[0].maxDistDynamic = 4 * PIXVAR;
+                ps[0].slot = reg[0].slot, ps[0].m = reg[0].m, ps[0].var = reg[0].var, ps[0].dist = reg[0].dist, ps[0].flags = reg[0].flags;
+                CSCHK(cs_register_search_passes_range_dev(dev, (void*)poseS, nCams, 0, nCams, rc[dsti].data(), N, W, H, 1, ps));
+                CSCHK(cs_register_mergability_running_list_dev(hist, (void*)poseS, 0, nCams, pu.data(), nMap, list, RV_CAP, dMap, dCov, reg[0].slot, reg[0].flags,
+                                                               PIX, 0.0, dMergeCache, dMergeable, nullptr));
+                const bool more = r + 1 < RV_ROUNDS;
+                CSCHK(cs_register_revisit_decide_next_dev(dev, (void*)poseS, nCams, N, nMap, RV_CAP, 0, 3, list, dRvNext, dRvVisit, reg[0].slot, reg[0].flags, dMergeable,
+                                                          dMapFlags, dPf, s2mPtrs.data(), dAttached, dRvReg[0], dDecScratch, dCurList, dCurCount, P_REG, dRvCnt,
+                                                          dRvCounts + r, more ? list + RV_CAP : nullptr, more ? dRvCounts + r + 1 : nullptr, dRvCounts + RV_ROUNDS));
+                CSCHK(cs_feat_ref_advance_refine_dev(hist, (void*)poseS, pu.data(), nMap, dPf, i, dFref, dRstat, dFrefCnt, list, RV_CAP, 0, dRvReg[0], 1, dMap, dCov, PIX));
+            }
+            kinds = 0;   // (done)
+        } else {
+            CSCHK(cs_register_decide_kinds_dev(dev, (void*)poseS, nCams, N, nMap, 0, reg[0].slot, reg[0].flags, dMergeable, dMapFlags, dPf, s2mPtrs.data(),
+                                               dAttached, dRegged, dDecScratch, /*nSweeps: until settled*/ 0, dDecCnt, /*onlyCam*/ -1, kinds));
+            refine();
+            // the reference's SECOND VISITS (SL_CoSLAM.cpp:864-869, :889-893): the points that registered are refined and visited again in their next
+            // camera's loop -- rounds of list + search + whole-track mergability + walks + refine over just those points, every rank for ALL cameras
+            // on its replica (cs_register_revisit_*; tools/r06_exact_vs_single.py: with two rounds the map is the reference order's, frame after frame)
+        }
         if (kinds == 3) {
             unsigned char* regIn = dRegged;
             for (int r = 0; r < RV_ROUNDS; ++r) {
@@ -792,6 +821,7 @@ int main(int argc, char** argv) {
     int rvCnt[4] = {0, 0, 0, 0}, rvListCnt[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpy(rvCnt, dRvCnt, sizeof(rvCnt), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(rvListCnt, dRvListCnt, sizeof(rvListCnt), hipMemcpyDeviceToHost));
+    if (fusedRounds) HIPCHK(hipMemcpy(&rvListCnt[1], dRvCounts + RV_ROUNDS, sizeof(int), hipMemcpyDeviceToHost));
     int decUnsettled = 0;   // (the decision scratch's last int: sticky "some call's sweeps did not settle")
     HIPCHK(hipMemcpy(&decUnsettled, (char*)dDecScratch + cs_register_decide_scratch_bytes(nCams, N, nMap) - sizeof(int), sizeof(int),
                      hipMemcpyDeviceToHost));
