@@ -738,8 +738,9 @@ struct ChainCtx {
 // the widest-parallax node behind `ref` around point M seen from centre C0 (a = C0 - M, na = |a|^2): the smallest cosine, the first of
 // equal ones in walk order, never an angle of 0 (cosine 1).  Wave-cooperative (lane r takes every 64th node of a segment); every lane
 // returns the node's ring depth (-1: none) and its slot.
-__device__ __forceinline__ int chain_widest(const ChainCtx& X, int c, int4 ref, const double* __restrict__ hR, const double* __restrict__ hT,
-                                            const double* a, double na, const double* M, int r, int& bestSlot) {
+// W lanes work together (a group of W consecutive lanes, W a power of two; r = the lane's index in its group): W = 64 is the wave.
+__device__ __forceinline__ int chain_widest_w(const ChainCtx& X, int c, int4 ref, const double* __restrict__ hR, const double* __restrict__ hT,
+                                              const double* a, double na, const double* M, int r, int& bestSlot, int W) {
     int best = -1, bestK = 0x7fffffff, bSlot = -1;
     double bestCos = 1.0;
     int slot = ref.x, hi = ref.y - 1, lo = ref.z, seg = ref.w, k0 = 1;   // (node 0 is the feature itself)
@@ -749,7 +750,7 @@ __device__ __forceinline__ int chain_widest(const ChainCtx& X, int c, int4 ref, 
         int cnt = hi - (lo > oldest ? lo : oldest) + 1;
         const bool cut = lo < oldest;
         if (cnt > X.cap - k0) cnt = X.cap - k0;
-        for (int i = r; i < cnt; i += 64) {
+        for (int i = r; i < cnt; i += W) {
             const int j = X.curFrame - (hi - i);
             double Cj[3];
             if (j < X.nCen) {
@@ -770,14 +771,17 @@ __device__ __forceinline__ int chain_widest(const ChainCtx& X, int c, int4 ref, 
         const int4 g = X.segPool[(size_t)c * X.segCap + seg];
         slot = g.x, hi = g.y, lo = g.z, seg = g.w;
     }
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
+    for (int off = 1; off < W; off <<= 1) {
         const double oc = __shfl_xor(bestCos, off, 64);
         const int oj = __shfl_xor(best, off, 64), ok = __shfl_xor(bestK, off, 64), os = __shfl_xor(bSlot, off, 64);
         if (oj >= 0 && (oc < bestCos || (oc == bestCos && ok < bestK))) bestCos = oc, best = oj, bestK = ok, bSlot = os;
     }
     bestSlot = bSlot;
     return best;
+}
+__device__ __forceinline__ int chain_widest(const ChainCtx& X, int c, int4 ref, const double* __restrict__ hR, const double* __restrict__ hT,
+                                            const double* a, double na, const double* M, int r, int& bestSlot) {
+    return chain_widest_w(X, c, ref, hR, hT, a, na, M, r, bestSlot, 64);
 }
 // the reference of map point m in camera c: the table's, or the feature of this frame pointFeat names with its slot's track behind it
 // (frames then count from curFrame = 0: only differences are used)
@@ -943,48 +947,91 @@ struct CuArgs {
 };
 // one pair, one wave: pf1 / pf2 the two points' rows of pointFeat, M1 / M2 their positions, sRw the wave's 64 * 9 + 16 doubles of LDS;
 // returns the verdict (uniform over the wave), M / cov the unified point (every lane)
+// The (camera, point) pairs of a call -- 2 nCams of them, in the order the reference walks them: camera by camera, point 1 then point 2 --
+// are worked on SIDE BY SIDE: a group of LPP = 64 / (2 nCams) lanes (a power of two, at most 8) per pair reads the pair's feature and
+// walks its chain for the widest-parallax second view (chain_widest_w over the group), the group's first two lanes then hold the pair's
+// (up to) two views: each works out its view's terms of the normal equations, and the sums are taken in the reference's view order from
+// those lanes' registers -- the same additions in the same order as one pair after the other (which is what a single wave did until
+// round 6: sixteen dependent rounds of loads, ~27 us a call, most of a bMerge walk's 5 ms).  View v then belongs to
+// the lane that holds it (myV) for the Jacobian, the flat rotation array and the gate.
+__device__ __forceinline__ void up_view_terms(const double* __restrict__ iK, const double* __restrict__ R, const double* __restrict__ t,
+                                              double mx, double my, double (&q)[9]) {
+    const double w = (iK[6] * mx + iK[7] * my) + iK[8];
+    const double x = ((iK[0] * mx + iK[1] * my) + iK[2]) / w, y = ((iK[3] * mx + iK[4] * my) + iK[5]) / w;  // normPoint
+    const double a0[3] = {R[0] - x * R[6], R[1] - x * R[7], R[2] - x * R[8]}, a1[3] = {R[3] - y * R[6], R[4] - y * R[7], R[5] - y * R[8]};
+    const double b0 = x * t[2] - t[0], b1 = y * t[2] - t[1];
+    q[0] = (a0[0] * a0[0] + a1[0] * a1[0]);
+    q[1] = (a0[0] * a0[1] + a1[0] * a1[1]);
+    q[2] = (a0[0] * a0[2] + a1[0] * a1[2]);
+    q[3] = (a0[1] * a0[1] + a1[1] * a1[1]);
+    q[4] = (a0[1] * a0[2] + a1[1] * a1[2]);
+    q[5] = (a0[2] * a0[2] + a1[2] * a1[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) q[6 + k] = (a0[k] * b0 + a1[k] * b1);
+}
 __device__ __forceinline__ bool check_unify_wave(const CuArgs& A, const int* pf1, const int* pf2, const int4* rf1, const int4* rf2,
                                                  const double* M1, const double* M2, double* sRw, double (&M)[3], double (&cov)[9]) {
     const int r = threadIdx.x % 64;
-    const int N = A.N, H = A.H;
+    const int N = A.N, H = A.H, nPairs = 2 * A.nCams;
+    int LPP = 8;
+    while (LPP * nPairs > 64) LPP >>= 1;   // (nCams <= 16: LPP >= 2)
+    const int pair = r / LPP, sub = r - pair * LPP;
+    const bool mine = pair < nPairs;
+    const int c = mine ? pair >> 1 : 0, which = pair & 1;
+    ChainCtx X;
+    X.N = N, X.H = H, X.head = A.head, X.cap = A.nHist, X.curFrame = rf1 ? A.curFrame : 0, X.stored = rf1 ? A.stored : A.nHist;
+    X.segCap = A.segCap, X.nCen = A.nHist, X.cen = A.cen, X.segPool = A.segPool;
+    X.minFrame = -2147483647 - 1;
+    const cs_poseupdate_cam& C = A.cam[c];
+    const double* hR = A.histR + (size_t)c * H * 9;
+    const double* hT = A.histT + (size_t)c * H * 3;
+    const double* hXY = A.histXY + (size_t)c * H * 2 * N;
+    int4 ref = make_int4(-1, 0, 0, -1);
+    if (mine) ref = rf1 ? (which ? rf2 : rf1)[c] : chain_ref(nullptr, which ? pf2 : pf1, C, N, 0, 0, c);
+    const int s = ref.x, j0 = X.curFrame - ref.y;
+    const bool valid = mine && s >= 0 && j0 < X.stored;
+    const double* Mold = which ? M2 : M1;
+    const int rs0 = valid ? (A.head - j0 + H) % H : 0;
+    const double* R0 = hR + (size_t)rs0 * 9;
+    const double* t0 = hT + (size_t)rs0 * 3;
+    int best = -1, bs = s;
+    {
+        double C0[3] = {0, 0, 0};
+        if (valid) up_cam_center(R0, t0, C0);
+        const double a[3] = {C0[0] - Mold[0], C0[1] - Mold[1], C0[2] - Mold[2]};
+        const double na = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
+        // (an invalid pair walks an empty chain: the group's shuffles are executed by every lane)
+        best = chain_widest_w(X, c, valid ? ref : make_int4(-1, 0, 1, -1), hR, hT, a, na, Mold, sub, bs, LPP);
+        if (!valid) best = -1;
+    }
+    // the group's lane 0 holds the pair's first view, lane 1 the second (if there is one)
+    const bool has = valid && (sub == 0 || (sub == 1 && best >= 0));
+    const int myC = c, myJ = sub == 0 ? j0 : best, myS = sub == 0 ? s : bs;
+    double q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const double *Rv = nullptr, *tv = nullptr;
+    if (has) {
+        const int rs = (A.head - myJ + H) % H;
+        Rv = hR + (size_t)rs * 9, tv = hT + (size_t)rs * 3;
+        up_view_terms(C.iK, Rv, tv, hXY[(size_t)rs * 2 * N + myS], hXY[(size_t)rs * 2 * N + N + myS], q);
+    }
     UpNormalEq E;
 #pragma unroll
     for (int k = 0; k < 6; ++k) E.N[k] = 0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) E.g[k] = 0;
-    int nv = 0, myC = -1, myJ = 0, myS = 0;   // lane v keeps view v: camera, ring depth, slot
-    ChainCtx X;
-    X.N = N, X.H = H, X.head = A.head, X.cap = A.nHist, X.curFrame = rf1 ? A.curFrame : 0, X.stored = rf1 ? A.stored : A.nHist;
-    X.segCap = A.segCap, X.nCen = A.nHist, X.cen = A.cen, X.segPool = A.segPool;
-    X.minFrame = -2147483647 - 1;
-    for (int c = 0; c < A.nCams; ++c) {
-        const cs_poseupdate_cam& C = A.cam[c];
-        const double* hR = A.histR + (size_t)c * H * 9;
-        const double* hT = A.histT + (size_t)c * H * 3;
-        const double* hXY = A.histXY + (size_t)c * H * 2 * N;
-        for (int which = 0; which < 2; ++which) {
-            const int4 ref = rf1 ? (which ? rf2 : rf1)[c] : chain_ref(nullptr, which ? pf2 : pf1, C, N, 0, 0, c);
-            const int s = ref.x, j0 = X.curFrame - ref.y;
-            if (s < 0 || j0 >= X.stored) continue;
-            const double* Mold = which ? M2 : M1;
-            const int rs0 = (A.head - j0 + H) % H;
-            const double* R0 = hR + (size_t)rs0 * 9;
-            const double* t0 = hT + (size_t)rs0 * 3;
-            up_add_view(E, C.iK, R0, t0, hXY[(size_t)rs0 * 2 * N + s], hXY[(size_t)rs0 * 2 * N + N + s]);
-            if (r == nv) myC = c, myJ = j0, myS = s;
+    const unsigned long long hasMask = __builtin_amdgcn_ballot_w64(has);
+    int nv = 0, myV = -1;
+    for (int pr = 0; pr < nPairs; ++pr) {
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int src = pr * LPP + w;
+            if (!((hasMask >> src) & 1ull)) continue;   // (uniform)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) E.N[k] = E.N[k] + __shfl(q[k], src, 64);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) E.g[k] = E.g[k] + __shfl(q[6 + k], src, 64);
+            if (r == src) myV = nv;
             ++nv;
-            double C0[3];
-            up_cam_center(R0, t0, C0);
-            const double a[3] = {C0[0] - Mold[0], C0[1] - Mold[1], C0[2] - Mold[2]};
-            const double na = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
-            int bs = s;
-            const int best = chain_widest(X, c, ref, hR, hT, a, na, Mold, r, bs);
-            if (best >= 0) {
-                const int rs = (A.head - best + H) % H;
-                up_add_view(E, C.iK, hR + (size_t)rs * 9, hT + (size_t)rs * 3, hXY[(size_t)rs * 2 * N + bs], hXY[(size_t)rs * 2 * N + N + bs]);
-                if (r == nv) myC = c, myJ = best, myS = bs;
-                ++nv;
-            }
         }
     }
     double cf[6];
@@ -992,25 +1039,27 @@ __device__ __forceinline__ bool check_unify_wave(const CuArgs& A, const int* pf1
     M[0] = ((cf[0] * E.g[0] + cf[1] * E.g[1]) + cf[2] * E.g[2]) / det;  // triangulateMultiView
     M[1] = ((cf[1] * E.g[0] + cf[3] * E.g[1]) + cf[4] * E.g[2]) / det;
     M[2] = ((cf[2] * E.g[0] + cf[4] * E.g[1]) + cf[5] * E.g[2]) / det;
-    // lane v: view v's pose, its Jacobian at M (getTriangulateCovMat), its rotation into the flat array
-    const double *Rv = nullptr, *tv = nullptr;
+    // the lane of view v: the view's pose, its Jacobian at M (getTriangulateCovMat), its rotation into the flat array
     double J[6] = {0, 0, 0, 0, 0, 0};
     PuProj pv;
-    if (r < nv) {
-        const int rs = (A.head - myJ + H) % H;
-        Rv = A.histR + ((size_t)myC * H + rs) * 9, tv = A.histT + ((size_t)myC * H + rs) * 3;
+    if (has) {
         pv = pu_project(A.cam[myC].K, Rv, tv, M);
 #pragma unroll
         for (int k = 0; k < 6; ++k) J[k] = pv.J[k];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) sRw[9 * r + k] = Rv[k];
+        for (int k = 0; k < 9; ++k) sRw[9 * myV + k] = Rv[k];
     }
     double S[6] = {0, 0, 0, 0, 0, 0};
-    for (int v = 0; v < nv; ++v) {   // the J^T J blocks in view order
-        double Jv[6];
+    for (int pr = 0; pr < nPairs; ++pr) {   // the J^T J blocks in view order
 #pragma unroll
-        for (int k = 0; k < 6; ++k) Jv[k] = __shfl(J[k], v, 64);
-        up_add_jtj(S, Jv);
+        for (int w = 0; w < 2; ++w) {
+            const int src = pr * LPP + w;
+            if (!((hasMask >> src) & 1ull)) continue;
+            double Jv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Jv[k] = __shfl(J[k], src, 64);
+            up_add_jtj(S, Jv);
+        }
     }
     const double dS = up_sym33_cof(S, cf), s2 = A.sigma * A.sigma;
     cov[0] = (cf[0] / dS) * s2, cov[1] = (cf[1] / dS) * s2, cov[2] = (cf[2] / dS) * s2;
@@ -1018,11 +1067,11 @@ __device__ __forceinline__ bool check_unify_wave(const CuArgs& A, const int* pf1
     cov[6] = cov[2], cov[7] = cov[5], cov[8] = (cf[5] / dS) * s2;
     __builtin_amdgcn_wave_barrier();   // (a wave's own LDS stores are visible to its own loads in program order)
     bool fail = false;
-    if (r < nv) {   // :652-661
+    if (has) {   // :652-661
         const double rm0 = pv.u / pv.w, rm1 = pv.v / pv.w;
         double Rq[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rq[k] = sRw[3 * r + k];   // `Rs + 3 * i`
+        for (int k = 0; k < 9; ++k) Rq[k] = sRw[3 * myV + k];   // `Rs + 3 * i`
         const PuProj pq = pu_project(A.cam[myC].K, Rq, tv, M);
         double JC[6], var[4], ivar[4];
 #pragma unroll
@@ -1037,8 +1086,8 @@ __device__ __forceinline__ bool check_unify_wave(const CuArgs& A, const int* pf1
                 var[2 * i + k] = (i == k) ? sv + s2 : sv;
             }
         pu_mat22_inv(var, ivar);
-        const double* hXY = A.histXY + ((size_t)myC * H + (A.head - myJ + H) % H) * 2 * N;
-        const double dx = rm0 - hXY[myS], dy = rm1 - hXY[N + myS];
+        const double* px = hXY + (size_t)((A.head - myJ + H) % H) * 2 * N;
+        const double dx = rm0 - px[myS], dy = rm1 - px[N + myS];
         fail = dx * (ivar[0] * dx + ivar[1] * dy) + dy * (ivar[2] * dx + ivar[3] * dy) > 1.0;
     }
     const bool anyFail = __builtin_amdgcn_ballot_w64(fail) != 0;

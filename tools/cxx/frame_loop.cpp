@@ -308,6 +308,7 @@ int main(int argc, char** argv) {
     void* dMergeCache = dev_zeros<unsigned char>(cs_register_mergability_cache_bytes(nMap, nCams));
     // MapPoint::pFeatures as feature references (stale features are views, re-linked chains: SL_CoSLAM.cpp:775-779); COSLAM_FEATURE_CHAINS=0:
     // this frame's features on their own tracks
+    if (getenv("COSLAM_MERGE_PRINT")) cs_debug_set("merge_print", 1);   // (k_decide_merge prints its own account per call)
     const bool chains = !(getenv("COSLAM_FEATURE_CHAINS") && getenv("COSLAM_FEATURE_CHAINS")[0] == '0');
     cs_feat_ref* dFref = nullptr;
     unsigned char* dRstat = nullptr;
