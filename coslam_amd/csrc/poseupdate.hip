@@ -1613,23 +1613,34 @@ __device__ __noinline__ bool cls_is_static(const ClsArgs& A, const ClsFeat& F, i
     X.N = A.N, X.H = A.H, X.head = A.head, X.cap = A.nHist, X.curFrame = A.curFrame, X.segCap = A.segCap, X.nCen = A.nHist, X.cen = A.cen;
     X.stored = A.stored < A.nHist ? A.stored : A.nHist;   // (the walks stay inside the centre table: nHist frames)
     X.segPool = A.featRef ? A.segPool : nullptr, X.minFrame = firstFrame;
-    for (int c = 0; c < A.nCams; ++c) {
-        const int s = __shfl(F.s, c, 64), f = __shfl(F.f, c, 64);
-        const int j0 = __shfl(F.j0, c, 64), ff = __shfl(F.ff, c, 64);
-        if (c == exclude || s < 0 || f < firstFrame || j0 >= A.nHist) continue;
-        if (r == V.nv) V.c = c, V.j = j0, V.s = s;
-        ++V.nv;
-        const double* C0 = A.cen + 3 * ((size_t)c * A.nHist + j0);
+    // the cameras' walks SIDE BY SIDE: a group of LPC = 64 / nCams lanes (a power of two, at most 8) per camera walks that camera's chain
+    // (one camera after the other on the whole wave was eight dependent rounds in front of the solve); the views are then handed to the
+    // lanes in the reference's order -- camera by camera, the feature and then its widest-parallax predecessor
+    int LPC = 8;
+    while (LPC * A.nCams > 64) LPC >>= 1;
+    const int grp = r / LPC, sub = r - grp * LPC;
+    const int c = grp < A.nCams ? grp : 0;
+    const int s = __shfl(F.s, c, 64), f = __shfl(F.f, c, 64), j0 = __shfl(F.j0, c, 64), ff = __shfl(F.ff, c, 64), seg = __shfl(F.seg, c, 64);
+    const bool valid = grp < A.nCams && !(c == exclude || s < 0 || f < firstFrame || j0 >= A.nHist);
+    int best = -1, bestSlot = -1;
+    {
+        const double* C0 = A.cen + 3 * ((size_t)c * A.nHist + (valid ? j0 : 0));
         const double a[3] = {C0[0] - Mold[0], C0[1] - Mold[1], C0[2] - Mold[2]};
         const double na = (a[0] * a[0] + a[1] * a[1]) + a[2] * a[2];
         // fp = fp->preFrame while fp && fp->f >= firstFrame (:141-152): the feature's own run of frames f-1 .. ff, then the linked segments,
         // ending at the first node before the window (or the ring); the smallest cosine, the nearest node among equals
-        const int seg = __shfl(F.seg, c, 64);
-        int bestSlot = -1;
-        const int best = chain_widest(X, c, make_int4(s, f, ff, seg), A.histR + (size_t)c * A.H * 9, A.histT + (size_t)c * A.H * 3, a, na, Mold, r,
-                                      bestSlot);
-        if (best >= 0) {
-            if (r == V.nv) V.c = c, V.j = best, V.s = bestSlot;
+        best = chain_widest_w(X, c, valid ? make_int4(s, f, ff, seg) : make_int4(-1, 0, 1, -1), A.histR + (size_t)c * A.H * 9,
+                              A.histT + (size_t)c * A.H * 3, a, na, Mold, sub, bestSlot, LPC);
+        if (!valid) best = -1;
+    }
+    for (int cc = 0; cc < A.nCams; ++cc) {
+        const int lead = cc * LPC;
+        if (!__shfl((int)valid, lead, 64)) continue;   // (uniform)
+        const int j0c = __shfl(j0, lead, 64), sc = __shfl(s, lead, 64), b = __shfl(best, lead, 64), bsl = __shfl(bestSlot, lead, 64);
+        if (r == V.nv) V.c = cc, V.j = j0c, V.s = sc;
+        ++V.nv;
+        if (b >= 0) {
+            if (r == V.nv) V.c = cc, V.j = b, V.s = bsl;
             ++V.nv;
         }
     }
@@ -2636,6 +2647,43 @@ extern "C" int cs_feat_ref_advance_list_dev(cs_track_history* h, void* hip_strea
     return CS_OK;
 }
 
+// one ENTRY (map point m, camera c) of the same: the row's cameras side by side on the lanes of the point's own wave (k_advance_refine's
+// refined rows: a lane walking the row's cameras one after the other was 10 us of dependent loads in front of every refine).  Returns
+// whether the reference is alive in this frame; the row's `alive` byte is the caller's (any lane's yes).
+__device__ __forceinline__ bool fr_advance_entry(const FrCore& A, const cs_poseupdate_cam* cam, int m, int c, int (&cnt)[5]) {
+    const size_t e = (size_t)m * A.nCams + c;
+    const int s = A.pointFeat[e];
+    int4 ref = A.featRef[e];
+    const int* span = cam[c].trackSpan;
+    const bool on = s >= 0 && s < A.N;
+    const int look = on ? s : ((ref.x >= 0 && ref.x < A.N) ? ref.x : 0);
+    const int g1 = span[look], g2 = span[A.N + look];
+    if (!on) {
+        if (ref.x >= 0 && ref.x < A.N && ref.y == A.curFrame - 1 && g1 >= 0 && g1 <= ref.y && g2 == A.curFrame) {
+            ref.x = -1, ++cnt[4];   // the same track, alive in this frame, no longer the point's: detached
+            A.featRef[e] = ref;
+        }
+        return ref.x >= 0 && ref.y == A.curFrame;
+    }
+    const int f1 = g1;
+    if (ref.x == s && f1 >= 0 && ref.y >= f1 && ref.y <= A.curFrame) {
+        if (ref.y != A.curFrame) ++cnt[0];
+        ref.y = A.curFrame;
+    } else if (ref.x >= 0 && ref.y < A.curFrame) {
+        const int idx = atomicAdd(A.segCount + c, 1);
+        ++cnt[2];
+        if (idx < A.segCap)
+            A.segPool[(size_t)c * A.segCap + idx] = ref;
+        else
+            ++cnt[3];
+        ref = make_int4(s, A.curFrame, A.curFrame, idx < A.segCap ? idx : -1);
+    } else {
+        ref = make_int4(s, A.curFrame, f1 >= 0 ? f1 : A.curFrame, -1), ++cnt[1];
+    }
+    A.featRef[e] = ref;
+    if (A.refStatic) A.refStatic[e] = cam[c].isStatic ? cam[c].isStatic[s] : 1;
+    return true;
+}
 // cs_feat_ref_advance_(list_)dev + cs_refine_map_points_ref_dev as ONE launch: the rows that are not refined are advanced by the first
 // blocks (a thread per row, as k_feat_ref_advance); a row that IS refined (select[m] != 0; it has to be on `list`) is advanced by lane 0 of
 // its own wave, which then re-triangulates the point from the references it has just written (k_update_points' refine mode).  Rows are
@@ -2657,7 +2705,9 @@ __global__ __launch_bounds__(256) void k_advance_refine(ArArgs A) {
         const int j = ((int)blockIdx.x - A.blocksA) * 4 + (int)threadIdx.x / 64, r = threadIdx.x % 64;
         const int m = j < A.nList ? A.list[j] : -1;
         if (m >= 0 && m < A.nMap && A.select[m]) {   // (uniform over the wave)
-            if (r == 0) fr_advance_row(A.F, A.cam, m, cnt);
+            const bool al = r < A.nCams && fr_advance_entry(A.F, A.cam, m, r, cnt);
+            const bool anyAlive = __builtin_amdgcn_ballot_w64(al) != 0ull;
+            if (r == 0) A.F.alive[m] = anyAlive ? 1 : 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -805,22 +805,38 @@ __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
         if (kind >= 0) base = (A.nextLoop[p] * A.P + p) * C;
     }
     if (base >= 0) {
+        // the row's loads in three rounds (the cameras' entries together; then who owns the candidates; then those owners' state) instead of
+        // up to four dependent loads per camera one camera after the other: the launch is a handful of rows' latency
+        int pfv[RD_MAX_CAMS], slv[RD_MAX_CAMS], flv[RD_MAX_CAMS], own[RD_MAX_CAMS];
+        unsigned char mgv[RD_MAX_CAMS];
 #pragma unroll
         for (int i = 0; i < RD_MAX_CAMS; ++i) {
-            if (i >= C) continue;
-            const size_t k = (size_t)p * C + i;
-            if (A.pointFeat[k] >= 0) continue;                               // :736-737
-            const int sl = A.slot[k];
-            if (sl < 0 || sl >= A.N || ((A.flags[k] >> 1) & 1) != kind) continue;   // nothing found / a feature of the other type
+            const size_t k = (size_t)p * C + (i < C ? i : 0);
+            pfv[i] = A.pointFeat[k], slv[i] = A.slot[k], flv[i] = A.flags[k], mgv[i] = A.mergeable[k];
+        }
+#pragma unroll
+        for (int i = 0; i < RD_MAX_CAMS; ++i) {
+            const bool cand = i < C && pfv[i] < 0 && slv[i] >= 0 && slv[i] < A.N && ((flv[i] >> 1) & 1) == kind;   // :736-737; nothing found / the other type
+            if (!cand) slv[i] = -1;
+            own[i] = cand ? A.slot2map[i][slv[i]] - A.mapBase : -1;
+        }
+        int oAtt[RD_MAX_CAMS], oPf[RD_MAX_CAMS], oLoop[RD_MAX_CAMS];
+#pragma unroll
+        for (int i = 0; i < RD_MAX_CAMS; ++i) {
+            const bool look = slv[i] >= 0 && own[i] >= 0 && own[i] < A.P;
+            const size_t ko = (size_t)(look ? own[i] : 0) * C + (i < C ? i : 0);
+            oAtt[i] = look ? A.attached[ko] : 0, oPf[i] = look ? A.pointFeat[ko] : -1, oLoop[i] = look ? A.visitLoop[look ? own[i] : 0] : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < RD_MAX_CAMS; ++i) {
+            if (slv[i] < 0) continue;
+            const int sl = slv[i];
             int c = i * A.N + sl;
-            const int own = A.slot2map[i][sl] - A.mapBase;
-            if (own >= 0) {
+            if (own[i] >= 0) {
                 c |= RD_INIT_MAPPED;
                 // mapped NOW.  Was it mapped when this visit takes place?  Not if a later-ordered visit of this frame attached it.
-                if (own < A.P && A.attached[(size_t)own * C + i] && A.pointFeat[(size_t)own * C + i] == sl &&
-                    (A.visitLoop[own] * A.P + own) * C + i > base + i)
-                    ++nConf;
-            } else if (A.mergeable[k] == 1) {
+                if (own[i] < A.P && oAtt[i] && oPf[i] == sl && (oLoop[i] * A.P + own[i]) * C + i > base + i) ++nConf;
+            } else if (mgv[i] == 1) {
                 c |= RD_CAN_MERGE;
             }
             code[i] = c;
@@ -922,17 +938,29 @@ __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
         for (int e = j; e < nCur; e += (int)blockDim.x) {
             const int q = A.curList[e];
             if (q < 0 || q >= A.P) continue;
+            // q's row once (the cameras' entries together), then the round's attachments against it out of registers / LDS
+            int qs[RD_MAX_CAMS], qp[RD_MAX_CAMS];
+            unsigned qatt = 0;
+#pragma unroll
+            for (int i = 0; i < RD_MAX_CAMS; ++i) {
+                const size_t kq = (size_t)q * C + (i < C ? i : 0);
+                qs[i] = A.slot[kq], qp[i] = A.pointFeat[kq];
+                if (i < C && A.attached[kq]) qatt |= 1u << i;
+            }
+            int lq = -1;   // the loop of q's (first) visit in this frame
+#pragma unroll
+            for (int i = RD_MAX_CAMS - 1; i >= 0; --i)
+                if (i < C && qp[i] >= 0 && !((qatt >> i) & 1u)) lq = i;
+            if (lq < 0) continue;
             for (int a = 0; a < nA; ++a) {
                 const int f = sAttF[a], i = f / A.N, sl = f - i * A.N;
-                const size_t kq = (size_t)q * C + i;
-                if (A.slot[kq] != sl || A.pointFeat[kq] >= 0) continue;
-                int lq = -1;   // the loop of q's (first) visit in this frame
-                for (int c = C - 1; c >= 0; --c)
-                    if (A.pointFeat[(size_t)q * C + c] >= 0 && !A.attached[(size_t)q * C + c]) lq = c;
-                if (lq < 0 || (lq * A.P + q) * C + i <= sAttKey[a]) continue;
-                bool later = false;
-                for (int c = i + 1; c < C; ++c) later |= A.attached[(size_t)q * C + c] != 0;
-                if (later) ++nConf;
+                int qsi = -1, qpi = 0;
+#pragma unroll
+                for (int t = 0; t < RD_MAX_CAMS; ++t)
+                    if (t == i) qsi = qs[t], qpi = qp[t];
+                if (qsi != sl || qpi >= 0) continue;
+                if ((lq * A.P + q) * C + i <= sAttKey[a]) continue;
+                if ((qatt >> (i + 1)) != 0u) ++nConf;   // it attached something in a camera behind the one it walked past
             }
         }
     }
