@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
             for (int p = lane; p < P; p += 64)
                 A.inVec[p] = ((A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN)) == 0 && A.pointFeat[(size_t)p * C + o] >= 0) ? 1 : 0;
         }
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         for (int p0 = 0; p0 < nRows; p0 += 64) {
           // the next 64 points' places on the visiting list as a mask: the wave steps through the set bits only.  By list: the visiting
@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
               // ONE acquire at agent scope (the wave's own earlier stores went out behind a release fence: the L1 is dropped, what follows
               // comes from L2), then plain loads -- 5 x nCams of them in flight per lane.  (Read one by one as agent-scope atomic loads, each
               // waited for, the batch's rows cost ~40 us: 112 batches of them were most of the kernel's 8 ms.)
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (one wave: workgroup scope orders its own accesses; agent scope wrote the XCD's L2 back every time)
               int hasV[DM_MAX_CAMS];
 #pragma unroll
               for (int i = 0; i < DM_MAX_CAMS; ++i) {
@@ -1350,7 +1350,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
                             A.attached[(size_t)p * C + i] = 1;
                             if (byList) set_dirty(p);   // the point has changed: a pre-checked verdict about it no longer stands
                         }
-                        __threadfence();
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         __syncthreads();
                         batchClean = false;
                         reg = true, ++nAtt;
@@ -1403,7 +1403,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
                         }
                     }
                 }
-                __threadfence();
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __syncthreads();
                 tUnify += wall_clock64() - tu;
                 batchClean = false;
@@ -1417,7 +1417,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
             tWalk += wall_clock64() - tw0;
           }
         }
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
     }
     if (lane == 0 && A.counts) A.counts[0] = nAtt, A.counts[1] = nReg, A.counts[2] = nMerged, A.counts[3] = nAsked;

@@ -788,16 +788,21 @@ struct RvArgs {
     int* nextCount;                  // feature in a later loop appends itself (what k_revisit_list would find), *nextCount counts them
     int* nextLoopW;                  // = nextLoop, written for the appended points
     int* overflow;                   // null, or where the points beyond the next list are counted
+    int debug;                       // cs_debug_set("merge_print", 1): the launch prints where its time went
 };
 constexpr int RV_MAX_ROWS = 1024;
+// MC: the cameras the row arrays are sized for (8 or MC: 16 cameras' worth of registers per thread spill at 1024 threads)
+template <int MC>
 __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
     __shared__ int sChanged, sAttF[256], sAttKey[256], sNAtt;
     if (A.listCount && *A.listCount == 0) return;   // (uniform: before any barrier)
     const int j = threadIdx.x, C = A.nCams;
+    const long long tD0 = A.debug ? wall_clock64() : 0;
+    long long tD1 = 0, tD2 = 0, tD3 = 0;
     const int p = j < A.cap ? A.list[j] : -1;
-    int code[RD_MAX_CAMS], base = -1, kind = -1, nConf = 0;
+    int code[MC], base = -1, kind = -1, nConf = 0;
 #pragma unroll
-    for (int i = 0; i < RD_MAX_CAMS; ++i) code[i] = -1;
+    for (int i = 0; i < MC; ++i) code[i] = -1;
     if (j == 0) sNAtt = 0;
     if (p >= 0 && p < A.P) {
         const unsigned char fl = A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN);
@@ -807,28 +812,28 @@ __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
     if (base >= 0) {
         // the row's loads in three rounds (the cameras' entries together; then who owns the candidates; then those owners' state) instead of
         // up to four dependent loads per camera one camera after the other: the launch is a handful of rows' latency
-        int pfv[RD_MAX_CAMS], slv[RD_MAX_CAMS], flv[RD_MAX_CAMS], own[RD_MAX_CAMS];
-        unsigned char mgv[RD_MAX_CAMS];
+        int pfv[MC], slv[MC], flv[MC], own[MC];
+        unsigned char mgv[MC];
 #pragma unroll
-        for (int i = 0; i < RD_MAX_CAMS; ++i) {
+        for (int i = 0; i < MC; ++i) {
             const size_t k = (size_t)p * C + (i < C ? i : 0);
             pfv[i] = A.pointFeat[k], slv[i] = A.slot[k], flv[i] = A.flags[k], mgv[i] = A.mergeable[k];
         }
 #pragma unroll
-        for (int i = 0; i < RD_MAX_CAMS; ++i) {
+        for (int i = 0; i < MC; ++i) {
             const bool cand = i < C && pfv[i] < 0 && slv[i] >= 0 && slv[i] < A.N && ((flv[i] >> 1) & 1) == kind;   // :736-737; nothing found / the other type
             if (!cand) slv[i] = -1;
             own[i] = cand ? A.slot2map[i][slv[i]] - A.mapBase : -1;
         }
-        int oAtt[RD_MAX_CAMS], oPf[RD_MAX_CAMS], oLoop[RD_MAX_CAMS];
+        int oAtt[MC], oPf[MC], oLoop[MC];
 #pragma unroll
-        for (int i = 0; i < RD_MAX_CAMS; ++i) {
+        for (int i = 0; i < MC; ++i) {
             const bool look = slv[i] >= 0 && own[i] >= 0 && own[i] < A.P;
             const size_t ko = (size_t)(look ? own[i] : 0) * C + (i < C ? i : 0);
             oAtt[i] = look ? A.attached[ko] : 0, oPf[i] = look ? A.pointFeat[ko] : -1, oLoop[i] = look ? A.visitLoop[look ? own[i] : 0] : 0;
         }
 #pragma unroll
-        for (int i = 0; i < RD_MAX_CAMS; ++i) {
+        for (int i = 0; i < MC; ++i) {
             if (slv[i] < 0) continue;
             const int sl = slv[i];
             int c = i * A.N + sl;
@@ -842,11 +847,11 @@ __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
             code[i] = c;
         }
 #pragma unroll
-        for (int i = 0; i < RD_MAX_CAMS; ++i)
+        for (int i = 0; i < MC; ++i)
             if (code[i] >= 0) rd_st(A.owner[0] + (code[i] & RD_FEAT), RD_INF), rd_st(A.owner[1] + (code[i] & RD_FEAT), RD_INF), rd_st(A.owner[2] + (code[i] & RD_FEAT), RD_INF);
     }
-    __threadfence();
-    __syncthreads();
+    __syncthreads();   // (ONE workgroup: its barrier orders the agent-scope accesses above -- an agent-scope fence here writes the XCD's L2 back, tracker's lines and all: 30-70 us a launch)
+    if (A.debug) tD1 = wall_clock64();
     // Jacobi sweeps among the round's visits (k_decide_settle's recursion, one workgroup)
     int k = 0;
     const int* fin = A.owner[0];
@@ -858,14 +863,14 @@ __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
         if (j == 0) sChanged = 0;
         if (base >= 0) {
 #pragma unroll
-            for (int i = 0; i < RD_MAX_CAMS; ++i)
+            for (int i = 0; i < MC; ++i)
                 if (code[i] >= 0) rd_st(clear + (code[i] & RD_FEAT), RD_INF);
         }
         __syncthreads();
         if (base >= 0) {
             bool go = true;
 #pragma unroll
-            for (int i = 0; i < RD_MAX_CAMS; ++i) {
+            for (int i = 0; i < MC; ++i) {
                 if (go && code[i] >= 0) {
                     const int ord = base + i, f = code[i] & RD_FEAT;
                     if ((code[i] & RD_INIT_MAPPED) || rd_ld(prev + f) < ord) go = false;
@@ -873,12 +878,11 @@ __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
                 }
             }
         }
-        __threadfence();
         __syncthreads();
         if (base >= 0) {
             int ch = 0;
 #pragma unroll
-            for (int i = 0; i < RD_MAX_CAMS; ++i)
+            for (int i = 0; i < MC; ++i)
                 if (code[i] >= 0) ch |= rd_ld(next + (code[i] & RD_FEAT)) != rd_ld(prev + (code[i] & RD_FEAT));
             if (ch) sChanged = 1;
         }
@@ -891,13 +895,14 @@ __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
             break;
         }
     }
+    if (A.debug) tD2 = wall_clock64();
     // attach (the owners in `fin` are final)
     bool reg = false;
     int nAtt = 0;
     if (base >= 0) {
         bool go = true;
 #pragma unroll
-        for (int i = 0; i < RD_MAX_CAMS; ++i) {
+        for (int i = 0; i < MC; ++i) {
             if (go && code[i] >= 0) {
                 const int ord = base + i, f = code[i] & RD_FEAT, own = rd_ld(fin + f);
                 if ((code[i] & RD_INIT_MAPPED) || own < ord) {
@@ -932,6 +937,7 @@ __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
     // a feature attached here was unmapped until now: a LATER-ordered visit of this frame that had it as its candidate walked past it (it
     // could not take it) and went on to other cameras -- in the reference's order that walk ends at it.  Counted where that walk attached
     // something behind it (what it did there would not have happened).
+    if (A.debug) tD3 = wall_clock64();
     const int nA = sNAtt < 256 ? sNAtt : 256;
     if (nA > 0) {
         const int nCur = *A.curCount < A.curCap ? *A.curCount : A.curCap;
@@ -939,24 +945,24 @@ __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
             const int q = A.curList[e];
             if (q < 0 || q >= A.P) continue;
             // q's row once (the cameras' entries together), then the round's attachments against it out of registers / LDS
-            int qs[RD_MAX_CAMS], qp[RD_MAX_CAMS];
+            int qs[MC], qp[MC];
             unsigned qatt = 0;
 #pragma unroll
-            for (int i = 0; i < RD_MAX_CAMS; ++i) {
+            for (int i = 0; i < MC; ++i) {
                 const size_t kq = (size_t)q * C + (i < C ? i : 0);
                 qs[i] = A.slot[kq], qp[i] = A.pointFeat[kq];
                 if (i < C && A.attached[kq]) qatt |= 1u << i;
             }
             int lq = -1;   // the loop of q's (first) visit in this frame
 #pragma unroll
-            for (int i = RD_MAX_CAMS - 1; i >= 0; --i)
+            for (int i = MC - 1; i >= 0; --i)
                 if (i < C && qp[i] >= 0 && !((qatt >> i) & 1u)) lq = i;
             if (lq < 0) continue;
             for (int a = 0; a < nA; ++a) {
                 const int f = sAttF[a], i = f / A.N, sl = f - i * A.N;
                 int qsi = -1, qpi = 0;
 #pragma unroll
-                for (int t = 0; t < RD_MAX_CAMS; ++t)
+                for (int t = 0; t < MC; ++t)
                     if (t == i) qsi = qs[t], qpi = qp[t];
                 if (qsi != sl || qpi >= 0) continue;
                 if ((lq * A.P + q) * C + i <= sAttKey[a]) continue;
@@ -964,6 +970,9 @@ __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
             }
         }
     }
+    if (A.debug && j == 0)
+        printf("k_revisit_decide: rows %d; build %lld us, %d sweeps %lld us, attach %lld us (%d attached), scan %lld us\n", A.listCount ? *A.listCount : -1,
+               (tD1 - tD0) / 100, k + 1, (tD2 - tD1) / 100, (tD3 - tD2) / 100, nA, (wall_clock64() - tD3) / 100);
     if (A.counts) {
         if (nAtt) atomicAdd(A.counts, nAtt);
         if (reg) atomicAdd(A.counts + 1, 1);
@@ -1024,10 +1033,14 @@ extern "C" int cs_register_revisit_decide_next_dev(int device, void* hip_stream,
     for (int c = 0; c < nCams; ++c) A.slot2map[c] = d_slot2map[c];
     A.attached = d_attached, A.regOut = d_regOut, A.curList = d_curList, A.curCount = d_curCount, A.curCap = curCap, A.counts = d_counts, A.listCount = d_listCount;
     A.nextList = d_nextList, A.nextCount = d_nextCount, A.nextLoopW = d_nextLoop, A.overflow = d_overflow;
+    A.debug = cs_debug_get(CS_DBG_MERGE_PRINT) == 1;
     int* scr = (int*)d_decideScratch + (size_t)nCams * P + P;   // (cs_register_decide_kinds_dev's carve-up: code | base | owner x 3 | ...)
     for (int k = 0; k < 3; ++k) A.owner[k] = scr, scr += (size_t)nCams * N;
     CS_HIP(hipSetDevice(device));
-    hipLaunchKernelGGL(k_revisit_decide, dim3(1), dim3(cap <= 256 ? 256 : (cap + 63) / 64 * 64), 0, (hipStream_t)hip_stream, A);
+    if (nCams <= 8)
+        hipLaunchKernelGGL(k_revisit_decide<8>, dim3(1), dim3(cap <= 256 ? 256 : (cap + 63) / 64 * 64), 0, (hipStream_t)hip_stream, A);
+    else
+        hipLaunchKernelGGL(k_revisit_decide<RD_MAX_CAMS>, dim3(1), dim3(cap <= 256 ? 256 : (cap + 63) / 64 * 64), 0, (hipStream_t)hip_stream, A);
     CS_CHECK_LAUNCH();
     return CS_OK;
 }

@@ -13,5 +13,5 @@ bench.export_workload("/tmp/workload.bin", sc, frames, bench.build_joint_problem
 PY
 export HSA_KERNARG_POOL_SIZE=$((64 << 20))
 COSLAM_MERGE_PRINT=1 $R/tools/cxx/frame_loop.bin /tmp/workload.bin 300 30 0 2 > $O/out.txt 2> $O/err.txt
-grep k_decide_merge $O/out.txt $O/err.txt | head -20
+grep "k_decide_merge\|k_revisit_decide" $O/out.txt | sed -n "1,400p" | awk "NR%9==0" | head -60
 tail -c 400 $O/out.txt
