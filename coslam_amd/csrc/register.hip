@@ -794,7 +794,7 @@ constexpr int RV_MAX_ROWS = 1024;
 // MC: the cameras the row arrays are sized for (8 or MC: 16 cameras' worth of registers per thread spill at 1024 threads)
 template <int MC>
 __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
-    __shared__ int sChanged, sAttF[256], sAttKey[256], sNAtt;
+    __shared__ int sChanged, sAttCam[256], sAttSl[256], sAttKey[256], sNAtt;
     if (A.listCount && *A.listCount == 0) return;   // (uniform: before any barrier)
     const int j = threadIdx.x, C = A.nCams;
     const long long tD0 = A.debug ? wall_clock64() : 0;
@@ -804,21 +804,39 @@ __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
 #pragma unroll
     for (int i = 0; i < MC; ++i) code[i] = -1;
     if (j == 0) sNAtt = 0;
-    if (p >= 0 && p < A.P) {
-        const unsigned char fl = A.mapFlags[p] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN);
-        kind = (fl == 0 && (A.kinds & 1)) ? 0 : ((fl == CS_MAP_DYNAMIC && (A.kinds & 2)) ? 1 : -1);
-        if (kind >= 0) base = (A.nextLoop[p] * A.P + p) * C;
+    // the conflict count's scan (at the end) compares every current point's candidates with what this round attached: the candidate rows do
+    // not change in this launch, so a thread asks for its (up to two) current points' rows NOW -- the loads travel while the walks are built
+    // and swept -- and the scan is register compares (it was 13 us of three dependent rounds of loads behind the attach, as much as the walks)
+    const int nCurPre = *A.curCount < A.curCap ? *A.curCount : A.curCap;
+    int preQ[2], preS[2][MC];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int e = j + u * (int)blockDim.x;
+        preQ[u] = e < nCurPre ? A.curList[e] : -1;
+        if (preQ[u] >= A.P) preQ[u] = -1;
+#pragma unroll
+        for (int i = 0; i < MC; ++i) preS[u][i] = preQ[u] >= 0 ? A.slot[(size_t)preQ[u] * C + (i < C ? i : 0)] : -1;
     }
-    if (base >= 0) {
-        // the row's loads in three rounds (the cameras' entries together; then who owns the candidates; then those owners' state) instead of
-        // up to four dependent loads per camera one camera after the other: the launch is a handful of rows' latency
-        int pfv[MC], slv[MC], flv[MC], own[MC];
-        unsigned char mgv[MC];
+    // the row's loads in three rounds (the point's flags, its loop and every camera's entry together; then who owns the candidates; then those
+    // owners' state) instead of up to four dependent loads per camera one camera after the other: the launch is a handful of rows' latency
+    int pfv[MC], slv[MC], flv[MC], own[MC];
+    unsigned char mgv[MC];
+    {
+        const bool pv = p >= 0 && p < A.P;
+        const size_t pr = pv ? (size_t)p : 0;
+        const unsigned char fl = A.mapFlags[pr] & (CS_MAP_DYNAMIC | CS_MAP_FALSE | CS_MAP_UNCERTAIN);
+        const int nl = A.nextLoop[pr];
 #pragma unroll
         for (int i = 0; i < MC; ++i) {
-            const size_t k = (size_t)p * C + (i < C ? i : 0);
+            const size_t k = pr * C + (i < C ? i : 0);
             pfv[i] = A.pointFeat[k], slv[i] = A.slot[k], flv[i] = A.flags[k], mgv[i] = A.mergeable[k];
         }
+        if (pv) {
+            kind = (fl == 0 && (A.kinds & 1)) ? 0 : ((fl == CS_MAP_DYNAMIC && (A.kinds & 2)) ? 1 : -1);
+            if (kind >= 0) base = (nl * A.P + p) * C;
+        }
+    }
+    if (base >= 0) {
 #pragma unroll
         for (int i = 0; i < MC; ++i) {
             const bool cand = i < C && pfv[i] < 0 && slv[i] >= 0 && slv[i] < A.N && ((flv[i] >> 1) & 1) == kind;   // :736-737; nothing found / the other type
@@ -914,7 +932,7 @@ __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
                     A.attached[(size_t)p * C + i] = 1;
                     reg = true, ++nAtt;
                     const int q = atomicAdd(&sNAtt, 1);
-                    if (q < 256) sAttF[q] = f, sAttKey[q] = ord;
+                    if (q < 256) sAttCam[q] = i, sAttSl[q] = s2, sAttKey[q] = ord;
                 }
             }
         }
@@ -940,17 +958,27 @@ __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
     if (A.debug) tD3 = wall_clock64();
     const int nA = sNAtt < 256 ? sNAtt : 256;
     if (nA > 0) {
-        const int nCur = *A.curCount < A.curCap ? *A.curCount : A.curCap;
-        for (int e = j; e < nCur; e += (int)blockDim.x) {
-            const int q = A.curList[e];
+        const int nCur = nCurPre;
+        for (int e = j, u = 0; e < nCur; e += (int)blockDim.x, ++u) {
+            const int q = u < 2 ? preQ[u < 2 ? u : 0] : A.curList[e];
             if (q < 0 || q >= A.P) continue;
-            // q's row once (the cameras' entries together), then the round's attachments against it out of registers / LDS
-            int qs[MC], qp[MC];
+            int qs[MC];
+#pragma unroll
+            for (int i = 0; i < MC; ++i) qs[i] = u == 0 ? preS[0][i] : (u == 1 ? preS[1][i] : A.slot[(size_t)q * C + (i < C ? i : 0)]);
+            // does ANY of the round's attachments name one of q's candidates?  (almost never: only then is q's row of features looked at)
+            bool any = false;
+            for (int a = 0; a < nA && !any; ++a) {
+                const int i = sAttCam[a], sl = sAttSl[a];
+#pragma unroll
+                for (int t = 0; t < MC; ++t) any |= t == i && qs[t] == sl;
+            }
+            if (!any) continue;
+            int qp[MC];
             unsigned qatt = 0;
 #pragma unroll
             for (int i = 0; i < MC; ++i) {
                 const size_t kq = (size_t)q * C + (i < C ? i : 0);
-                qs[i] = A.slot[kq], qp[i] = A.pointFeat[kq];
+                qp[i] = A.pointFeat[kq];
                 if (i < C && A.attached[kq]) qatt |= 1u << i;
             }
             int lq = -1;   // the loop of q's (first) visit in this frame
@@ -959,7 +987,7 @@ __global__ __launch_bounds__(1024) void k_revisit_decide(RvArgs A) {
                 if (i < C && qp[i] >= 0 && !((qatt >> i) & 1u)) lq = i;
             if (lq < 0) continue;
             for (int a = 0; a < nA; ++a) {
-                const int f = sAttF[a], i = f / A.N, sl = f - i * A.N;
+                const int i = sAttCam[a], sl = sAttSl[a];
                 int qsi = -1, qpi = 0;
 #pragma unroll
                 for (int t = 0; t < MC; ++t)
