@@ -1367,7 +1367,7 @@ def main():
                            second_visits=dict(zip(("features_attached", "registrations", "conflicts_counted", "rounds_unsettled"), loop.d_rv_counts.cpu().tolist()),
                                               since_the_timed_region_began=dict(zip(("features_attached", "registrations", "conflicts_counted", "rounds_unsettled"),
                                                                                     [a - b for a, b in zip(loop.d_rv_counts.cpu().tolist(), rv0)])),
-                                              rounds_per_frame=loop.cfg.revisit_rounds, points_beyond_the_list=int(loop.d_rv_listcounts[1].item()),
+                                              rounds_per_frame=loop.cfg.revisit_rounds, points_beyond_the_list=int(loop.d_rv_listcounts[1].item()) + int(loop.d_rvcounts[loop.cfg.revisit_rounds].item()),
                                               what="the reference visits a point that registered AGAIN, refined, in its next camera's loop "
                                                    "(SL_CoSLAM.cpp:864-869, :889-893): played behind the single pass in rounds over just those points "
                                                    "(cs_register_revisit_*); counts over the whole run of this process.  tools/r06_exact_vs_single.py / "

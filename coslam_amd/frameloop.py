@@ -69,6 +69,9 @@ class LoopConfig:
         # FrameLoop.keyframe_stats()["windows_not_applied_history_too_short"]).  One rank only.  Implies keyframe_decision.  Off in the headline:
         # in the bench's world the decision never says `decrease` -- there would be no window bundle adjustment to measure
         self.keyframe_ratio = 0.93       # m_mappedPtsReduceRatio (reference src/app/SL_CoSLAM.cpp:42)
+        self.fused_registration = True   # the registration's launches fused as tools/cxx/frame_loop.cpp runs them: the second visits' lists built by the
+        # walks (cs_register_decide_kinds_rounds_dev, cs_register_revisit_decide_next_dev), advance + refine as one launch
+        # (cs_feat_ref_advance_refine_dev); needs feature_chains.  False: a launch per step (the form DESIGN.md 3.13.1 describes first)
         self.classify_refs = True    # mapPointsClassify reads the references too (stale features, linked segments: cs_track_history_set_classify_refs)
         self.feature_chains = True   # MapPoint::pFeatures kept as feature references (cs_feat_ref): a camera that lost a point still contributes
         # its last feature to refineMapPoint / updateNewPosesPoints, and a point registered to a new track where it held an older feature has
@@ -309,6 +312,11 @@ class FrameLoop:
         self.d_rv_reg = [z(n_map, torch.uint8), z(n_map, torch.uint8)]
         self.d_rv_counts, self.d_rv_listcounts = z(4, i32), z(4, i32)
         self.rv_pass = register_passes([dict(cur_pass, P=self.RV_CAP, list=self.d_rvlist.data_ptr())])
+        # the fused form (LoopConfig.fused_registration): a list per round, built by the walks themselves
+        nr = max(cfg.revisit_rounds, 1)
+        self.d_rvlists = torch.full((nr, self.RV_CAP), -1, dtype=i32, device=dev)
+        self.d_rvcounts = z(nr + 1, i32)
+        self.rv_passes = [register_passes([dict(cur_pass, P=self.RV_CAP, list=self.d_rvlists[r].data_ptr())]) for r in range(nr)]
         # ---- key-frame solves
         # the inter-camera solves of consecutive key frames are independent of each other (each starts from its own frame's poses):
         # key frame k of this rank goes to workspace k mod ic_workers, each with its own worker thread, stream and staging
@@ -856,6 +864,9 @@ class FrameLoop:
             self._refine(ps, D["reg"].data_ptr())
             self.n_merge_frames += 1
             kinds = 2
+        if cfg.fused_registration and kinds == 3 and self.d_fref is not None:
+            self._decide_fused(ps, D)
+            return
         D["s2m"] = register_decide_static_dev(ps, NA, cfg.n_feat, self.n_map, 0, self.reg_out["slot"].data_ptr(), self.reg_out["flags"].data_ptr(),
                                               self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(), self.d_pf.data_ptr(),
                                               D["s2m"] if D["s2m"] is not None else [self.d_slot2map[g].data_ptr() for g in range(NA)],
@@ -864,6 +875,37 @@ class FrameLoop:
         self._refine(ps, D["reg"].data_ptr())
         if cfg.revisit_rounds > 0 and kinds == 3:
             self._revisit_rounds(ps, D)
+
+    def _decide_fused(self, ps, D):
+        """the single pass, its refine and the second visits' rounds with the launches fused (tools/cxx/frame_loop.cpp's sequence): 2 + 4 per
+        round instead of 3 + 6; the same map, tables and poses"""
+        from coslam_amd.register import register_decide_kinds_rounds_dev, register_revisit_decide_next_dev, register_search_passes_dev
+
+        cfg, NA, R = self.cfg, self.cfg.n_cams, self.cfg.revisit_rounds
+        o = self.reg_out
+        s2m = D["s2m"] if D["s2m"] is not None else [self.d_slot2map[g].data_ptr() for g in range(NA)]
+        D["s2m"] = register_decide_kinds_rounds_dev(ps, NA, cfg.n_feat, self.n_map, 0, o["slot"].data_ptr(), o["flags"].data_ptr(), self.d_mergeable.data_ptr(),
+                                                    self.d_mapflags.data_ptr(), self.d_pf.data_ptr(), s2m, D["att"].data_ptr(), D["reg"].data_ptr(),
+                                                    D["scr"].data_ptr(), self.d_rvlists.data_ptr() if R > 0 else 0, self.RV_CAP, R, self.d_rvcounts.data_ptr(),
+                                                    self.d_rv_visit.data_ptr(), self.d_rv_next.data_ptr(), d_counts=D["cnt"].data_ptr(), device=self.device)
+        adv = lambda lst, n, all_, sel, clr: self.pose_upd.feat_ref_advance_refine_dev(   # noqa: E731
+            ps, self.pu_args, self.n_map, self.d_pf.data_ptr(), self._frame_now, self.d_fref.data_ptr(), self.d_rstat.data_ptr(), lst, n, all_, sel, clr,
+            self.d_map.data_ptr(), self.d_cov.data_ptr(), self.sig_pix, d_counts=self.d_fref_counts.data_ptr())
+        adv(self.d_curlist.data_ptr(), cfg.p_reg, True, D["reg"].data_ptr(), False)
+        for r in range(R):
+            lst = self.d_rvlists[r].data_ptr()
+            register_search_passes_dev(ps, self.reg_args[self._dst_now], cfg.n_feat, cfg.W, cfg.H, self.rv_passes[r], device=self.device)
+            self.pose_upd.register_mergability_running_dev(ps, self.pu_args, self.n_map, self.d_map.data_ptr(), self.d_cov.data_ptr(), o["slot"].data_ptr(),
+                                                           self.sig_pix, self.d_merge_cache.data_ptr(), self.d_mergeable.data_ptr(), tolPix=0.0, d_counts=0,
+                                                           cam0=0, nCamsRun=NA, d_list=lst, nList=self.RV_CAP, d_flags=o["flags"].data_ptr())
+            more = r + 1 < R
+            register_revisit_decide_next_dev(ps, NA, cfg.n_feat, self.n_map, self.RV_CAP, 0, 3, lst, self.d_rv_next.data_ptr(), self.d_rv_visit.data_ptr(),
+                                             o["slot"].data_ptr(), o["flags"].data_ptr(), self.d_mergeable.data_ptr(), self.d_mapflags.data_ptr(),
+                                             self.d_pf.data_ptr(), D["s2m"], D["att"].data_ptr(), self.d_rv_reg[0].data_ptr(), D["scr"].data_ptr(),
+                                             self.d_curlist.data_ptr(), self.d_curcount.data_ptr(), cfg.p_reg, self.d_rv_counts.data_ptr(), device=self.device,
+                                             d_listCount=self.d_rvcounts[r:].data_ptr(), d_nextList=self.d_rvlists[r + 1].data_ptr() if more else 0,
+                                             d_nextCount=self.d_rvcounts[r + 1:].data_ptr() if more else 0, d_overflow=self.d_rvcounts[R:].data_ptr())
+            adv(lst, self.RV_CAP, False, self.d_rv_reg[0].data_ptr(), True)
 
     def _revisit_rounds(self, ps, D):
         """The reference's SECOND VISITS (src/app/SL_CoSLAM.cpp:864-869, :889-893) behind the single pass and its refine: the points that

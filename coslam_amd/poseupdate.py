@@ -219,6 +219,18 @@ class TrackHistory:
         check(self._L.cs_track_history_segment_counts(C.c_void_p(self._h), out.ctypes.data_as(C.c_void_p)), "cs_track_history_segment_counts")
         return out, int(cap.value)
 
+    def feat_ref_advance_refine_dev(self, stream_ptr, cams, nMap, d_pointFeat, curFrame, d_featRef, d_refStatic, d_list, nList, advanceAll, d_select,
+                                    clearSelect, d_mapPts, d_mapCov, pixelErrVar, d_counts=None):
+        """cs_feat_ref_advance_refine_dev: the references' advance and refineMapPoint as ONE launch -- the listed rows with d_select set are
+        advanced and refined, every other row (of the whole map when advanceAll, else of the list) is advanced only; clearSelect: the marks
+        are consumed"""
+        vp = C.c_void_p
+        self._L.cs_feat_ref_advance_refine_dev.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, C.c_double]
+        check(self._L.cs_feat_ref_advance_refine_dev(vp(self._h), vp(stream_ptr), poseupdate_cams(cams), int(nMap), vp(d_pointFeat), int(curFrame),
+                                                     vp(d_featRef), vp(d_refStatic), vp(d_counts), vp(d_list), int(nList), int(bool(advanceAll)),
+                                                     vp(d_select), int(bool(clearSelect)), vp(d_mapPts), vp(d_mapCov), float(pixelErrVar)),
+              "cs_feat_ref_advance_refine_dev")
+
     def update_new_poses_points_ref_dev(self, stream_ptr, cams, d_featRef, nMap, d_mapPts, d_mapCov, d_mapFlags, pixelErrVar,
                                         d_refStatic=None, d_lastFrame=None, d_isCurrent=None, firstKeyFrame=-1, d_counts=None):
         """cs_update_new_poses_points_ref_dev: updateNewPosesPoints with stale features as views and walks that follow the links"""

@@ -162,6 +162,35 @@ def register_revisit_decide_dev(stream_ptr, nCams, N, P, cap, mapBase, kinds, d_
     return arr
 
 
+def register_decide_kinds_rounds_dev(stream_ptr, nCams, N, P, mapBase, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, d_slot2map, d_attached,
+                                     d_regged, d_scratch, d_rvLists, rvCap, nRounds, d_rvCounts, d_visitLoop, d_nextLoop, d_counts=0, device=0, kinds=3):
+    """cs_register_decide_kinds_rounds_dev: the single pass (self-settling launch, all cameras' loops) whose walks build the second visits'
+    first list themselves -- d_rvLists [nRounds][rvCap] (cleared here), d_rvCounts [nRounds + 1] (the last entry, points beyond the lists, is
+    not cleared), d_visitLoop / d_nextLoop [P]"""
+    vp = C.c_void_p
+    arr = d_slot2map if isinstance(d_slot2map, C.Array) else (C.c_void_p * nCams)(*[int(x) for x in d_slot2map])
+    check(lib().cs_register_decide_kinds_rounds_dev(int(device), vp(stream_ptr), int(nCams), int(N), int(P), int(mapBase), vp(d_slot), vp(d_flags),
+                                                    vp(d_mergeable), vp(d_mapFlags), vp(d_pointFeat), arr, vp(d_attached), vp(d_regged), vp(d_scratch), 0,
+                                                    vp(d_counts), -1, int(kinds), vp(d_rvLists), int(rvCap), int(nRounds), vp(d_rvCounts), vp(d_visitLoop),
+                                                    vp(d_nextLoop)), "cs_register_decide_kinds_rounds_dev")
+    return arr
+
+
+def register_revisit_decide_next_dev(stream_ptr, nCams, N, P, cap, mapBase, kinds, d_list, d_nextLoop, d_visitLoop, d_slot, d_flags, d_mergeable, d_mapFlags,
+                                     d_pointFeat, d_slot2map, d_attached, d_regOut, d_decideScratch, d_curList, d_curCount, curCap, d_counts=0, device=0,
+                                     d_listCount=0, d_nextList=0, d_nextCount=0, d_overflow=0):
+    """cs_register_revisit_decide_next_dev: cs_register_revisit_decide_dev whose walks append the points that registered again to the next
+    round's list (d_nextList / d_nextCount: both or neither)"""
+    vp = C.c_void_p
+    arr = d_slot2map if isinstance(d_slot2map, C.Array) else (C.c_void_p * nCams)(*[int(x) for x in d_slot2map])
+    check(lib().cs_register_revisit_decide_next_dev(int(device), vp(stream_ptr), int(nCams), int(N), int(P), int(cap), int(mapBase), int(kinds), vp(d_list),
+                                                    vp(d_nextLoop), vp(d_visitLoop), vp(d_slot), vp(d_flags), vp(d_mergeable), vp(d_mapFlags),
+                                                    vp(d_pointFeat), arr, vp(d_attached), vp(d_regOut), vp(d_decideScratch), vp(d_curList), vp(d_curCount),
+                                                    int(curCap), vp(d_counts), vp(d_listCount), vp(d_nextList), vp(d_nextCount), vp(d_overflow)),
+          "cs_register_revisit_decide_next_dev")
+    return arr
+
+
 def register_cur_static_sequential_dev(stream_ptr, history, pu_cams, reg_cams, N, W, H, search_pass, P, d_slot, d_flags, d_mergeable, d_mapFlags,
                                        d_pointFeat, d_slot2map, d_attached, d_regged, d_scratch, d_mapPts, d_mapCov, pixelVar, d_counts=0,
                                        after_loop=None, device=0, n_sweeps=6, with_dynamic=False, merge=False, d_merge_scratch=0, mergability=None):

@@ -56,3 +56,49 @@ def test_the_decision_places_the_key_frames_and_their_windows_are_applied(hip):
     t = loop.d_t[T & 1].cpu().numpy()
     tt = np.stack([sc.pose(c, loop.vid(T))[1] for c in range(NA)])
     assert np.isfinite(R).all() and float(np.abs(t - tt).max()) < 0.1
+
+
+@pytest.mark.timeout(300)
+def test_the_fused_registration_launches_end_where_the_launch_per_step_sequence_does(hip):
+    """LoopConfig.fused_registration (the second visits' lists built by the walks: cs_register_decide_kinds_rounds_dev /
+    cs_register_revisit_decide_next_dev; advance + refine as one launch: cs_feat_ref_advance_refine_dev) against the launch-per-step
+    sequence (cs_register_revisit_list_dev, cs_feat_ref_advance_list_dev, cs_refine_map_points_ref_dev): two Python loops on the same
+    video, 110 frames with a bMerge frame among them and no key-frame solves (their write-back is thread-timed) -- the feature table, the
+    slot tables, the map, the covariances, the flags, the feature references, their types and the second visits' counters are
+    byte-identical after every tenth frame."""
+    import torch
+
+    import bench
+    from coslam_amd.frameloop import FrameLoop, LoopConfig
+
+    dev = torch.device("cuda", 0)
+    NA = bench.N_CAMS
+    frames = bench.render_video(list(range(NA)), bench.N_FRAMES)
+    video = {c: torch.from_numpy(frames[c]).to(dev) for c in range(NA)}
+
+    def make(fused):
+        sc = bench.build_scene()
+        cfg = LoopConfig(n_cams=NA, W=bench.W, H=bench.H, levels=bench.LEVELS, fw=bench.FW, fh=bench.FH, pts_stride=bench.PTS_STRIDE,
+                         n_col_blk=bench.N_COL_BLK, n_row_blk=bench.N_ROW_BLK, key_every=bench.KEY_EVERY, p_reg=bench.P_REG, fused_registration=fused)
+        lp = FrameLoop(cfg, sc, video, None, bench.klt_config(), bench.reg_covariances(len(sc.points)), rank=0, world=1, device=0, associate=bench.associate)
+        lp.first_frame()
+        return lp
+
+    def state(lp):
+        # (a reference's `seg` is an index into the camera's pool, handed out by an atomic: which of two re-links of a frame gets which index
+        # depends on the launch's shape -- the references are compared by slot / frame / first frame and by WHETHER something is linked behind,
+        # the pools by their fill; what the chains hold is compared through the refined points and covariances)
+        fref = lp.d_fref.cpu().numpy()
+        return [t.cpu().numpy() for t in (lp.d_pf, lp.d_map, lp.d_cov, lp.d_mapflags, lp.d_rstat, lp.d_rv_counts, lp.d_fref_counts)] + \
+               [np.stack([x.cpu().numpy() for x in lp.d_slot2map]), fref[:, :, :3], fref[:, :, 3] >= 0, lp.pose_upd.segment_counts()[0]]
+
+    A, B = make(True), make(False)
+    for i in range(1, 111):
+        A.step(i, False), B.step(i, False)
+        if i % 10 == 0:
+            torch.cuda.synchronize()
+            for k, (x, y) in enumerate(zip(state(A), state(B))):
+                assert np.array_equal(x, y), f"frame {i}: array {k} differs in {int((x != y).sum())} entries"
+    rv = A.d_rv_counts.cpu().tolist()
+    assert rv[0] > 0 and rv[1] > 0 and A.n_merge_frames == B.n_merge_frames >= 2      # second visits attached features; frames 50 and 100 carried bMerge
+    assert int(A.d_rvcounts[A.cfg.revisit_rounds].item()) == 0                         # no point beyond the lists
