@@ -3,7 +3,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r06/pyfused
 mkdir -p $O
 cd $R
-python -m pytest tests/test_keyframe_drives_gpu.py tests/test_bench_contract_gpu.py tests/test_register_decide_gpu.py -x -q -m gpu > $O/pytest.txt 2>&1
+python -m pytest tests/test_keyframe_drives_gpu.py tests/test_cxx_dropin_gpu.py tests/test_register_decide_gpu.py tests/test_register_gpu.py -x -q -m gpu > $O/pytest.txt 2>&1
 tail -15 $O/pytest.txt
 SHORT="--no-cpu-baseline --no-secondary --no-upload-leg --live-pmc 0"
 python bench.py $SHORT --steps 300 --warmup 30 2>/dev/null | python -c "
