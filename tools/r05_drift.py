@@ -46,6 +46,8 @@ VARIANTS = {
     "no_merge": (dict(merge_every=0), None),
     "no_intercam": (dict(with_intercam=False), None),
     "no_chains": (dict(feature_chains=False), None),
+    "classify_plain": (dict(classify_refs=False), None),                 # round 6: mapPointsClassify back on this frame's features
+    "no_rounds": (dict(revisit_rounds=0), None),                         # round 6: the single pass alone (no second visits)
     "kf_drives": (dict(keyframe_drives=True), None),                     # the key frames where the decision puts them (m_mappedPtsReduceRatio = 0.93)
     "kf_drives_r098": (dict(keyframe_drives=True, keyframe_ratio=0.98), None),
     "kf_drives_r100": (dict(keyframe_drives=True, keyframe_ratio=1.0), None),
