@@ -801,6 +801,23 @@ def test_relinked_and_stale_feature_chains_reproduce_the_reference():
         torch.cuda.synchronize()
         assert int(d_n.item()) == int(G("refine_select").sum())
         assert np.array_equal(d_M2.cpu().numpy(), G("M_refine")) and np.array_equal(d_cov2.cpu().numpy(), G("cov_refine")), sc
+        # ... and as ONE launch with the references' advance in front (cs_feat_ref_advance_refine_dev): on tables that are already at this
+        # frame the advance changes nothing -- live heads are "tracked on", stale ones stay -- so the refined points are the reference's again;
+        # the marks are consumed when asked
+        cur = int(G("curFrame"))
+        pf = np.where(ref[:, :, 1] == cur, ref[:, :, 0], -1).astype(np.int32)
+        for clear in (False, True):
+            d_M3, d_cov3, d_sel3, d_ref3, d_pf3 = d(G("M0")), d(G("cov0")), d(G("refine_select")), d(ref), d(pf)
+            d_list = torch.arange(nMap, dtype=torch.int32, device=dev)
+            d_fc = torch.zeros(5, dtype=torch.int32, device=dev)
+            for c in range(nC):
+                cams[c]["trackSpan"] = keep["span"][c].data_ptr()
+            th.feat_ref_advance_refine_dev(s, cams, nMap, d_pf3.data_ptr(), cur, d_ref3.data_ptr(), 0, d_list.data_ptr(), nMap, True, d_sel3.data_ptr(), clear,
+                                           d_M3.data_ptr(), d_cov3.data_ptr(), float(G("sigma")), d_counts=d_fc.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(d_M3.cpu().numpy(), G("M_refine")) and np.array_equal(d_cov3.cpu().numpy(), G("cov_refine")), (sc, clear)
+            assert np.array_equal(d_ref3.cpu().numpy(), ref) and d_fc.tolist() == [0, 0, 0, 0, 0]
+            assert int(d_sel3.sum().item()) == (0 if clear else int(G("refine_select").sum()))
         nP = len(G("unify_ok"))
         a = np.stack([np.where(G("unify_has1")[q][:, None] > 0, ref[G("unify_pts")[q][0]], -1) for q in range(nP)]).astype(np.int32)
         b = np.stack([np.where(G("unify_has2")[q][:, None] > 0, ref[G("unify_pts")[q][1]], -1) for q in range(nP)]).astype(np.int32)

@@ -335,6 +335,44 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
             if conflicts == 0:
                 assert left == 0 and np.array_equal(dpf.cpu().numpy(), S["ref_pf"]), f"scene {sc}"
                 assert np.array_equal(dM.cpu().numpy(), S["ref_M"]) and np.array_equal(dcov.cpu().numpy(), S["ref_cov"]), f"scene {sc}: positions"
+            # ---- the same rounds with the lists built BY THE WALKS (cs_register_decide_kinds_rounds_dev, cs_register_revisit_decide_next_dev: what
+            # the frame loops run): from the scene's start again -- the same owners, features, positions, covariances and counters
+            from coslam_amd.register import register_decide_kinds_rounds_dev, register_revisit_decide_next_dev
+
+            first_run = [x.cpu().numpy().copy() for x in (ds2m, dpf, dM, dcov, rv_cnt, datt)]
+            ds2m.copy_(d(S["s2m"])), dM.copy_(d(S["M"])), dcov.copy_(d(S["cov"])), dpf.copy_(d(S["pf"]))
+            register_search_passes_dev(s_, rc, N, S["W"], S["H"], passes)
+            th.register_mergability_dev(s_, cams, nP, dM.data_ptr(), dcov.data_ptr(), out["slot"].data_ptr(), S["pv"], dmerge.data_ptr())
+            lists = torch.zeros((nC, CAP), dtype=torch.int32, device=dev)          # (not -1: the prepare launch has to clear them)
+            lcnt = torch.full((nC + 1,), 7, dtype=torch.int32, device=dev)
+            lcnt[nC] = 0
+            rv_cnt2 = torch.zeros(4, dtype=torch.int32, device=dev)
+            register_decide_kinds_rounds_dev(s_, nC, N, nP, 0, out["slot"].data_ptr(), out["flags"].data_ptr(), dmerge.data_ptr(), dfl.data_ptr(), dpf.data_ptr(),
+                                             [ds2m[c].data_ptr() for c in range(nC)], datt.data_ptr(), dreg.data_ptr(), dscr.data_ptr(), lists.data_ptr(), CAP, nC,
+                                             lcnt.data_ptr(), visit.data_ptr(), nxt.data_ptr(), d_counts=dcnt.data_ptr(), kinds=kinds)
+            th.refine_map_points_dev(s_, cams, dpf.data_ptr(), nP, dM.data_ptr(), dcov.data_ptr(), S["pv"], d_select=dreg.data_ptr())
+            regm = torch.zeros(nP, dtype=torch.uint8, device=dev)
+            for r in range(nC):
+                pr = register_passes([dict(P=CAP, sigmaSearch=S["pv"], maxDist=3 * S["pv"], sigmaMerge=S["pv"], M=dM.data_ptr(), cov=dcov.data_ptr(),
+                                           pointFeat=dpf.data_ptr(), slot=out["slot"].data_ptr(), m=out["m"].data_ptr(), var=out["var"].data_ptr(),
+                                           dist=out["dist"].data_ptr(), flags=out["flags"].data_ptr(), list=lists[r].data_ptr(),
+                                           **(dict(mapFlags=dfl.data_ptr(), maxDistDynamic=4 * S["pv"]) if S["with_dyn"] else {}))])
+                register_search_passes_dev(s_, rc, N, S["W"], S["H"], pr)
+                th.register_mergability_dev(s_, cams, nP, dM.data_ptr(), dcov.data_ptr(), out["slot"].data_ptr(), S["pv"], dmerge.data_ptr())
+                more = r + 1 < nC
+                regm.zero_()
+                torch.cuda.synchronize()
+                register_revisit_decide_next_dev(s_, nC, N, nP, CAP, 0, kinds, lists[r].data_ptr(), nxt.data_ptr(), visit.data_ptr(), out["slot"].data_ptr(),
+                                                 out["flags"].data_ptr(), dmerge.data_ptr(), dfl.data_ptr(), dpf.data_ptr(), [ds2m[c].data_ptr() for c in range(nC)],
+                                                 datt.data_ptr(), regm.data_ptr(), dscr.data_ptr(), curlist.data_ptr(), curcount.data_ptr(), nP, rv_cnt2.data_ptr(),
+                                                 d_listCount=lcnt[r:].data_ptr(), d_nextList=lists[r + 1].data_ptr() if more else 0,
+                                                 d_nextCount=lcnt[r + 1:].data_ptr() if more else 0, d_overflow=lcnt[nC:].data_ptr())
+                th.refine_map_points_dev(s_, cams, dpf.data_ptr(), nP, dM.data_ptr(), dcov.data_ptr(), S["pv"], d_select=regm.data_ptr())
+                torch.cuda.synchronize()
+            lc = lcnt.cpu().tolist()
+            assert [n for n, _ in listed] == lc[:nC] and lc[nC] == 0, (listed, lc)                # the walks listed whom the list launches listed
+            for a_, b_ in zip(first_run, (ds2m, dpf, dM, dcov, rv_cnt2, datt)):
+                assert np.array_equal(a_, b_.cpu().numpy()), f"scene {sc}: the lists built by the walks end elsewhere"
         # ---- the reference's run step for step (camera loop after camera loop, refine in between): IDENTICAL to the reference
         ds2m.copy_(d(S["s2m"])), dM.copy_(d(S["M"])), dcov.copy_(d(S["cov"])), dpf.copy_(d(S["pf"]))
         rounds = []
