@@ -68,6 +68,10 @@ class LoopConfig:
         # A window whose first key frame has left the pose history (hist_store frames) by the time its result is due is not applied (counted:
         # FrameLoop.keyframe_stats()["windows_not_applied_history_too_short"]).  One rank only.  Implies keyframe_decision.  Off in the headline:
         # in the bench's world the decision never says `decrease` -- there would be no window bundle adjustment to measure
+        self.keyframe_lag = 0            # keyframe_drives WITHOUT a host wait per frame: D > 0 = the host acts on the decision of frame i - D, which it reads
+        # from pinned memory behind that frame's event (complete long before: the host is never more than D frames ahead of what it reads, the
+        # device never waits for the host) -- the key frame's records and poses are kept in a ring of D + 1 snapshots, its window is requested D
+        # frames late (the request reads the map as it stands then) and applied at the same frame as before.  0: the read-back of rounds 5-6
         self.keyframe_ratio = 0.93       # m_mappedPtsReduceRatio (reference src/app/SL_CoSLAM.cpp:42)
         self.fused_registration = True   # the registration's launches fused as tools/cxx/frame_loop.cpp runs them: the second visits' lists built by the
         # walks (cs_register_decide_kinds_rounds_dev, cs_register_revisit_decide_next_dev), advance + refine as one launch
@@ -131,8 +135,9 @@ class FrameLoop:
         NA, N = cfg.n_cams, cfg.n_feat
         if NA % world:
             raise ValueError(f"{NA} cameras do not shard over {world} ranks")
-        if cfg.keyframe_drives and world > 1:
-            raise ValueError("LoopConfig.keyframe_drives: one rank only (the host reads the decision back every frame)")
+        if cfg.keyframe_drives and world > 1 and cfg.keyframe_lag <= 0:
+            raise ValueError("LoopConfig.keyframe_drives: one rank only (the host reads the decision back every frame); keyframe_lag > 0 has every "
+                             "rank read its replica's decision")
         self.nc = nc = NA // world
         self.c0 = c0 = rank * nc
         self.my_cams = list(range(c0, c0 + nc))
@@ -571,6 +576,58 @@ class FrameLoop:
                                                selfT=self.kf["selfT"][g].data_ptr()) for g in range(NA)]) for q in range(2)]
         torch.cuda.synchronize()
 
+    def _kf_lag_ring(self):
+        """the ring of D + 1 snapshots a lagged key-frame decision acts on: per slot the hand-back's xy / state / slot2map of all cameras, the
+        poses, the decision word in pinned host memory and an event behind it"""
+        k, torch, cfg, NA, N = self.kf, self.torch, self.cfg, self.cfg.n_cams, self.cfg.n_feat
+        if "lag_ring" in k:
+            return k["lag_ring"]
+        from coslam_amd.handback import handback_cams
+
+        ring = []
+        for _ in range(cfg.keyframe_lag + 1):
+            xy = torch.zeros((NA, 2 * N), dtype=torch.float64, device=self.dev)
+            st = torch.zeros((NA, N), dtype=torch.int32, device=self.dev)
+            s2m = torch.zeros((NA, N), dtype=torch.int32, device=self.dev)
+            R, t = torch.zeros((NA, 9), dtype=torch.float64, device=self.dev), torch.zeros((NA, 3), dtype=torch.float64, device=self.dev)
+            hb = handback_cams([dict(dest=self.d_dests[0][0].data_ptr(), K=self.d_K1.data_ptr(), kud=self.d_kud.data_ptr(), mapPts=self.d_map.data_ptr(),
+                                     slot2map=s2m[g].data_ptr(), trackSpan=self.d_trackspan[g].data_ptr(), xy=xy[g].data_ptr(), state=st[g].data_ptr(),
+                                     Ms=self.d_Ms[g].data_ptr(), ms=self.d_ms[g].data_ptr(), sel=self.d_sel[g].data_ptr(),
+                                     npts=self.d_npts[g:g + 1].data_ptr(), opt=self.d_opt[g].data_ptr(), pointFeat=0, pointFeatStride=NA, nPointFeat=0,
+                                     isStatic=0) for g in range(NA)])
+            ring.append(dict(xy=xy, st=st, s2m=s2m, R=R, t=t, hb=hb, word=torch.zeros(1, dtype=torch.int32).pin_memory(),
+                             ev=torch.cuda.Event(), frame=-1))
+        torch.cuda.synchronize()   # (zero-filled on torch's stream, used on the pose stream)
+        k["lag_ring"], k["lag_blocked"] = ring, 0
+        return ring
+
+    def _kf_lag_record(self, i, dst):
+        """frame i's decision word, records and poses into its ring slot, on the pose stream; no host wait"""
+        k, torch, NA = self.kf, self.torch, self.cfg.n_cams
+        sl = self._kf_lag_ring()[i % (self.cfg.keyframe_lag + 1)]
+        with torch.cuda.stream(self.pose_s):
+            sl["xy"].copy_(self.d_xy, non_blocking=True), sl["st"].copy_(self.d_state, non_blocking=True), sl["s2m"].copy_(self.d_slot2map, non_blocking=True)
+            sl["R"].copy_(self.d_R[dst].view(NA, 9), non_blocking=True), sl["t"].copy_(self.d_t[dst].view(NA, 3), non_blocking=True)
+            sl["word"].copy_(k["ready"][NA + 1:NA + 2], non_blocking=True)
+            sl["ev"].record(self.pose_s)
+        sl["frame"] = i
+
+    def _kf_lag_act(self, i, dst):
+        """the decision of frame i - D, read from pinned memory behind that frame's event: a key frame -> the push of THAT frame's records and
+        poses and the window's request (genNewMapPoints :1331-1346), D frames late"""
+        k, D = self.kf, self.cfg.keyframe_lag
+        f = i - D
+        sl = self._kf_lag_ring()[f % (D + 1)]
+        if f < 1 or sl["frame"] != f:
+            return
+        if not sl["ev"].query():
+            k["lag_blocked"] += 1     # (the host caught up with the device: it waits for a frame D behind, the device has D frames queued)
+            sl["ev"].synchronize()
+        if int(sl["word"][0]) == 0:
+            return
+        k["placed"].append(f)
+        self._key_frame(f, dst, snap=sl)
+
     def keyframe_stats(self):
         """what the key-frame decision said over the frames it ran on (cs_keyframe_ready_dev's d_stats; a synchronous read)"""
         if not getattr(self, "kf", None):
@@ -581,6 +638,7 @@ class FrameLoop:
                     cameras_saying_decrease=a[2], cameras_saying_view_angle=a[3], cameras_saying_translation=a[4],
                     min_cam_translation=self.kf["min_translation"], key_frames_placed_by_the_decision=list(self.kf["placed"]),
                     windows_not_applied_history_too_short=self.kf["not_applied"], last_key_frame_per_camera=self.kf["frame"].cpu().tolist(),
+                    decision_lag_frames=self.cfg.keyframe_lag, host_waits_that_blocked=self.kf.get("lag_blocked"),
                     mapped_static_at_the_last_key_frame=self.kf["mapped"].cpu().tolist())
 
     def _handback(self, b, frame, which="all"):
@@ -711,7 +769,11 @@ class FrameLoop:
                                i, k["min_translation"], k["ready"].data_ptr(), k["cnt"].data_ptr(), k["cen"].data_ptr(), ratio=cfg.keyframe_ratio,
                                addKeyFrame=True, d_stats=k["stats"].data_ptr(), device=self.device)
             k["frames"] += 1
-            if cfg.keyframe_drives:
+            if cfg.keyframe_drives and cfg.keyframe_lag > 0:
+                # no wait: this frame's `decrease`, records and poses go into slot i % (D + 1) of a ring (the word into pinned host memory, an
+                # event behind it); what the host acts on below is the decision of frame i - D
+                key_frame = False   # (recorded at the end of the frame, where the push of a key frame sits: behind the registration's attachments)
+            elif cfg.keyframe_drives:
                 # `decrease` (ready[nCams + 1]) back to the host: the frame is a key frame for ALL cameras when one camera's mapped points
                 # have decreased (:1331-1346) -- the push and the request below follow the device's answer, not the caller's cadence
                 pose_s.synchronize()
@@ -760,6 +822,9 @@ class FrameLoop:
         # against 2173-2193 frames/s here, 2119-2123 behind the key-frame requests (profiles/r04_ab_runs.txt)
         self._mark(i, "decide + refine")
         self.dest_free[b].record(pose_s)
+        if cfg.keyframe_drives and cfg.keyframe_lag > 0 and getattr(self, "kf", None):
+            self._kf_lag_record(i, dst)
+            self._kf_lag_act(i, dst)
         if key_frame:
             if self._timing is not None:
                 import time as _t
@@ -985,7 +1050,7 @@ class FrameLoop:
                                                        vp(o["slot"].data_ptr()), vp(o["flags"].data_ptr()), vp(self.d_mergeable.data_ptr())),
               "cs_register_candidates_unpack_list_dev")
 
-    def _key_frame(self, i, dst):
+    def _key_frame(self, i, dst, snap=None):
         cfg, ps, NA = self.cfg, self.pose_s.cuda_stream, self.cfg.n_cams
         k_ic = self.n_key
         self.n_key += 1
@@ -1010,7 +1075,10 @@ class FrameLoop:
         # this key frame into the ring (every camera's records and poses: identical on every rank), then requestForBA(5, 2, 2, 30):
         # the numCams * 2 oldest key cameras held, 2 points held, maxIter 2, inner 10 -- solved by ONE rank
         with self._sec("kf_push"):
-            self.win.push_dev(ps, self.hb_all, self.d_K1.data_ptr(), 1, self.d_R[dst].data_ptr(), self.d_t[dst].data_ptr(), i)
+            if snap is not None:   # (a lagged decision: the key frame's own records and poses, kept in the ring)
+                self.win.push_dev(ps, snap["hb"], self.d_K1.data_ptr(), 1, snap["R"].data_ptr(), snap["t"].data_ptr(), i)
+            else:
+                self.win.push_dev(ps, self.hb_all, self.d_K1.data_ptr(), 1, self.d_R[dst].data_ptr(), self.d_t[dst].data_ptr(), i)
         self.n_pushed += 1
         self.pushed_frames = (self.pushed_frames + [i])[-cfg.n_key_frames:]   # the ring's key frames, oldest first
         if self.n_pushed < cfg.n_key_frames:

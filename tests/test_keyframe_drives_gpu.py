@@ -102,3 +102,57 @@ def test_the_fused_registration_launches_end_where_the_launch_per_step_sequence_
     rv = A.d_rv_counts.cpu().tolist()
     assert rv[0] > 0 and rv[1] > 0 and A.n_merge_frames == B.n_merge_frames >= 2      # second visits attached features; frames 50 and 100 carried bMerge
     assert int(A.d_rvcounts[A.cfg.revisit_rounds].item()) == 0                         # no point beyond the lists
+
+
+@pytest.mark.timeout(300)
+def test_the_decision_places_the_key_frames_without_a_host_wait_per_frame(hip):
+    """LoopConfig.keyframe_lag = 2 (the Python loop): the host never drains the device to learn `decrease` -- the word of
+    frame i goes into pinned memory behind an event, and what the host acts on at frame i is the decision of frame i - 2, whose event has
+    long fired; the key frame's own records and poses come out of a ring of three snapshots, its window is requested two frames late and
+    applied at the frame it would have been.  Same world as the test above: the device's bookkeeping and the host's agree on every key
+    frame but the ones still in the ring when the run ends, every window that is due is applied, no wait gives up, the rig stays put."""
+    import torch
+
+    import bench
+    from coslam_amd.frameloop import FrameLoop, LoopConfig
+
+    dev = torch.device("cuda", 0)
+    NA = bench.N_CAMS
+    frames = bench.render_video(list(range(NA)), bench.N_FRAMES)
+    video = {c: torch.from_numpy(frames[c]).to(dev) for c in range(NA)}
+    sc = bench.build_scene()
+    D = 2
+    cfg = LoopConfig(n_cams=NA, W=bench.W, H=bench.H, levels=bench.LEVELS, fw=bench.FW, fh=bench.FH, pts_stride=bench.PTS_STRIDE,
+                     n_col_blk=bench.N_COL_BLK, n_row_blk=bench.N_ROW_BLK, key_every=bench.KEY_EVERY, p_reg=bench.P_REG, keyframe_drives=True,
+                     keyframe_ratio=1.2, keyframe_lag=D)
+    loop = FrameLoop(cfg, sc, video, None, bench.klt_config(), bench.reg_covariances(len(sc.points)), rank=0, world=1, device=0,
+                     associate=bench.associate)
+    loop.first_frame()
+    BASE, T = 60, 300
+    for i in range(1, BASE + 1):
+        loop.step(i, True)
+    loop.drain()
+    early = list(loop.keyframe_stats()["key_frames_placed_by_the_decision"])
+    loop.enable_keyframe_decision(BASE, BASE & 1)
+    for i in range(BASE + 1, T + 1):
+        loop.step(i, False)
+    loop.drain()
+    st = loop.keyframe_stats()
+    placed = [f for f in st["key_frames_placed_by_the_decision"] if f not in early]
+    n_kf = cfg.n_key_frames
+    assert st["decision_lag_frames"] == D and len(placed) > n_kf and len(set(np.diff(placed).tolist())) > 1, placed
+    said = st["frames_with_decrease_ie_key_frames_added"]        # the device's count (since the re-base) covers the last D frames too
+    assert 0 <= said - len(placed) <= D and loop.n_pushed == len(early) + len(placed), (said, len(placed), loop.n_pushed)
+    assert st["last_key_frame_per_camera"][0] >= placed[-1]
+    every = early + placed
+    assert loop.n_windows == len(every) - n_kf + 1
+    lag_frames = loop.lag * cfg.key_every
+    due = sum(1 for f in every[n_kf - 1:] if f + lag_frames <= T)
+    assert loop.applied == due >= 4 and st["windows_not_applied_history_too_short"] == 0
+    assert loop.out.wait_errors() == 0
+    assert st["host_waits_that_blocked"] is not None and st["host_waits_that_blocked"] <= (T - BASE) // 4   # (the host rarely catches up with a frame two behind)
+    R = loop.d_R[T & 1].cpu().numpy().reshape(NA, 3, 3)
+    t = loop.d_t[T & 1].cpu().numpy()
+    tt = np.stack([sc.pose(c, loop.vid(T))[1] for c in range(NA)])
+    assert np.isfinite(R).all() and float(np.abs(t - tt).max()) < 0.1
+    print("key frames placed", placed[:12], "... host waits that blocked:", st["host_waits_that_blocked"], "of", T - BASE)
