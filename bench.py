@@ -589,6 +589,11 @@ def main():
     ap.add_argument("--keyframe-decision", type=int, default=0,
                     help="1: CoSLAM::IsReadyForKeyFrame + addKeyFrame's bookkeeping per frame on the device (reported in config.key_frame_decision; "
                          "the key frames stay on the fixed cadence)")
+    ap.add_argument("--keyframe-drives", type=int, default=0,
+                    help="1: the decision PLACES the key frames (LoopConfig.keyframe_drives; Python loop only: the C++ loop's leg is skipped); with "
+                         "--keyframe-lag D > 0 the host acts on the decision of frame i - D read from pinned memory (no wait per frame; any N)")
+    ap.add_argument("--keyframe-lag", type=int, default=0)
+    ap.add_argument("--keyframe-ratio", type=float, default=0.93, help="m_mappedPtsReduceRatio (0.93 in the reference; never fires in this synthetic world)")
     ap.add_argument("--feature-chains", type=int, default=1,
                     help="1: MapPoint::pFeatures kept as feature references (stale features are views, re-linked tracks: SL_CoSLAM.cpp:775-779); "
                          "0: this frame's features on their own tracks (rounds 1-4)")
@@ -673,6 +678,7 @@ def main():
                      with_classify=not args.no_classify, with_register=not args.no_register, with_mergability=not args.no_mergability,
                      with_ncc=not args.no_ncc, with_decide=not args.no_decide, merge_every=args.merge_every, hist=args.hist, hist_store=args.hist_store, with_active_search=bool(args.active_search), pixel_err_reading=args.pixel_err_reading, with_joint=args.only_solve != "intercam", with_intercam=args.only_solve != "joint",
                      native_comm=bool(args.native_comm), klt_cus=args.klt_cus, pose_cus=args.pose_cus, klt_xcd_placement=bool(args.klt_xcd_placement), feature_chains=bool(args.feature_chains), keyframe_decision=bool(args.keyframe_decision),
+                     keyframe_drives=bool(args.keyframe_drives), keyframe_lag=args.keyframe_lag, keyframe_ratio=args.keyframe_ratio,
                      klt_after_intracam=bool(args.klt_after_intracam),
                      klt_fused=os.environ.get("BENCH_FORCE_DEVICE") is None or world == 1)   # (ranks sharing ONE GPU: test hook)
     try:
@@ -1204,7 +1210,7 @@ def main():
     # stretch of the sequence as the timed region above)
     cxx_env = dict(os.environ, COSLAM_PIXEL_ERR_STD="1" if args.pixel_err_reading == "std" else "0", HSA_KERNARG_POOL_SIZE=str(64 << 20))
     cxx_exe = os.path.join(ROOT, "tools", "cxx", "frame_loop.bin")
-    if rank == 0 and n_gpus == 1 and not args.no_cxx_loop and ke == KEY_EVERY:
+    if rank == 0 and n_gpus == 1 and not args.no_cxx_loop and ke == KEY_EVERY and not args.keyframe_drives:
         import subprocess
         import tempfile
 
@@ -1222,7 +1228,7 @@ def main():
                 cxx = {"error": (pr.stderr or pr.stdout)[-400:]}
         else:
             cxx = {"error": "tools/cxx/frame_loop.bin not built (python -c 'import __graft_entry__ as g; g.build()')"}
-    elif n_gpus > 1 and not args.no_cxx_loop and ke == KEY_EVERY:
+    elif n_gpus > 1 and not args.no_cxx_loop and ke == KEY_EVERY and not args.keyframe_drives:
         # N > 1, host stays C++: every rank starts ITS rank of tools/cxx/frame_loop.bin (one process per GPU; the ranks find each other
         # through cs_comm_unique_id left in a file by rank 0, ncclCommInitRank inside the library) on the workload file rank 0 wrote.  A
         # diagnostic leg: bounded by a timeout, never the reason a bench line is lost.

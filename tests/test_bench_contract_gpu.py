@@ -141,6 +141,26 @@ def test_two_ranks_compute_what_one_rank_computes(hip):
     assert c1["pose_update"]["map_points_refined"] == c2["pose_update"]["map_points_refined"]
 
 
+def test_two_ranks_place_the_key_frames_where_one_rank_places_them(hip):
+    """The key-frame DECISION drives the window BA (LoopConfig.keyframe_drives) and no rank waits for its device to learn it
+    (--keyframe-lag 1: the decision of frame i - 1 read from pinned memory): every rank computes the decision from its replica, so two
+    ranks place the same key frames, request and apply the same windows and end in the one-rank run's state, bit for bit."""
+    args = ["--steps", "40", "--warmup", "5", "--setup-rounds", "1", "--ba-lag", "2", "--keyframe-drives", "1", "--keyframe-lag", "1",
+            "--keyframe-ratio", "1.5"] + SHORT   # (1.5: in the bench's world the decision fires on every frame of this stretch -- a window per frame)
+    one = _run_bench(["--gpus", "1"] + args, env=dict(BENCH_STATE_DIGEST="1"))
+    two = _run_bench(["--gpus", "2"] + args, env=dict(TWO_RANKS_ON_ONE_GPU, BENCH_STATE_DIGEST="1"))
+    c1, c2 = one["config"], two["config"]
+    k1, k2 = c1["key_frame_decision"], c2["key_frame_decision"]
+    n_end = c1["frames_enqueued_until_end_of_timed_region"]
+    assert n_end == c2["frames_enqueued_until_end_of_timed_region"]
+    p1 = [f for f in k1["key_frames_placed_by_the_decision"] if f <= n_end - 1]   # (one rank runs further legs behind the timed region: the lists are
+    p2 = [f for f in k2["key_frames_placed_by_the_decision"] if f <= n_end - 1]   # compared up to its end, less the frame still in the ring)
+    assert k1["decision_lag_frames"] == 1 and len(p1) >= 5 and p1 == p2, (p1[-5:], p2[-5:])
+    assert c1["ba_output"]["windows_applied"] == c2["ba_output"]["windows_applied"] >= 1
+    assert c1["state_digest"] is not None and c1["state_digest"] == c2["state_digest"]
+    assert c2["replicas"]["identical_map_records_and_poses_on_every_rank"] is True
+
+
 def test_four_ranks_compute_what_one_rank_computes(hip):
     """... and with four ranks (two cameras each, apply lag min(max(N, 2), 4) = 4, window k on rank k mod 4, the inter-camera solve of key
     frame k on rank (k + 2) mod 4): the same digest as one rank with the same lag, identical replicas."""
