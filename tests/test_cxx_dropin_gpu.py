@@ -160,3 +160,50 @@ def test_cxx_frame_loop_on_two_ranks_ends_in_the_one_rank_runs_map(hip, tmp_path
     assert outs[0]["digest"] == outs[1]["digest"], "the two ranks' replicas differ"
     assert outs[0]["digest"] == j1["digest"], "two ranks do not end where one rank does"
     assert outs[0]["map_points_in_use"] == j1["map_points_in_use"] > j1["map_points_at_start"]
+    # ---- the key frames where the DECISION puts them, no host wait per frame (COSLAM_KEYFRAME_DRIVES=1, lag 1: VERDICT r05 item 6's C++
+    # counterpart): the C++ loop places the key frames the Python loop places on the same frames, requests and applies their windows, and two
+    # C++ ranks -- each reading its own replica's decision -- end in the one-rank run's state
+    kf_env = dict(base, COSLAM_KEYFRAME_DRIVES="1", COSLAM_KEYFRAME_LAG="1", COSLAM_KEYFRAME_RATIO="1.5")
+    kd = subprocess.run([exe, wl, steps, warm, "0", "2"], env=kf_env, capture_output=True, text=True, timeout=600)
+    assert kd.returncode == 0, kd.stderr[-2000:]
+    jk = line(kd.stdout)
+    placed = jk["key_frames_placed_by_the_decision"]
+    assert jk["keyframe_lag"] == 1 and jk["pose_ok"] and len(placed) >= 10 and jk["windows_applied"] >= 3 and jk["apply_wait_errors"] == 0
+    assert jk["windows_not_applied_history_too_short"] == 0 and jk["digest"] != j1["digest"]      # (another schedule of windows: another map)
+    seg2 = f"/coslam_cxxkf_{os.getpid()}"
+    procs = [subprocess.Popen([exe, wl, steps, warm, "0", "2"], env=dict(kf_env, RANK=str(r), WORLD_SIZE="2", COSLAM_FORCE_DEVICE="0", COSLAM_COMM="host:" + seg2),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs2 = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, e[-2000:]
+        outs2.append(line(o))
+    assert all(o["key_frames_placed_by_the_decision"] == placed and o["windows_applied"] == jk["windows_applied"] for o in outs2)
+    assert outs2[0]["digest"] == outs2[1]["digest"] == jk["digest"], "two ranks placing their key frames do not end where one rank does"
+    # the Python loop over the same frames: the same decisions
+    import torch
+
+    from coslam_amd.frameloop import FrameLoop, LoopConfig
+
+    dev = torch.device("cuda", 0)
+    NA = bench.N_CAMS
+    frames = bench.render_video(list(range(NA)), bench.N_FRAMES)
+    video = {c: torch.from_numpy(frames[c]).to(dev) for c in range(NA)}
+    cfg = LoopConfig(n_cams=NA, W=bench.W, H=bench.H, levels=bench.LEVELS, fw=bench.FW, fh=bench.FH, pts_stride=bench.PTS_STRIDE, n_col_blk=bench.N_COL_BLK,
+                     n_row_blk=bench.N_ROW_BLK, key_every=bench.KEY_EVERY, p_reg=bench.P_REG, keyframe_drives=True, keyframe_ratio=1.5, keyframe_lag=1)
+    lp = FrameLoop(cfg, bench.build_scene(), video, None, bench.klt_config(), bench.reg_covariances(len(sc.points)), rank=0, world=1, device=0,
+                   associate=bench.associate)
+    lp.first_frame()
+    n_frames = jk["frames_run"]   # (set-up intervals + warm-up + steps)
+    assert n_frames >= int(steps) + int(warm)
+    for i in range(1, n_frames + 1):
+        lp.step(i, False)
+    lp.drain()
+    py_placed = lp.keyframe_stats()["key_frames_placed_by_the_decision"]
+    assert py_placed == placed, (py_placed[:10], placed[:10], len(py_placed), len(placed))
+    assert lp.applied == jk["windows_applied"]

@@ -21,6 +21,8 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <algorithm>
+#include <string>
 #include <vector>
 
 #include "coslam_hip.h"
@@ -419,7 +421,14 @@ int main(int argc, char** argv) {
         icCams[c].slot2map = dS2M + (size_t)c * N, icCams[c].trackSpan = dSpan + (size_t)c * 2 * N, icCams[c].isStatic = dIsStatic + (size_t)c * N;
     }
     // RobustBundleRTS::output(): every window solve's result packed by the worker, applied `baLag` key-frame intervals later
-    cs_ba_output* bout = cs_ba_output_create(dev, nCams, WIN_KF, nMap, 8);
+    // COSLAM_KEYFRAME_DRIVES=1: the key frames where CoSLAM::genNewMapPoints' decision puts them (src/app/SL_CoSLAM.cpp:1294-1346: one camera's
+    // mapped points decreased -> addKeyFrame for all cameras -> requestForBA) instead of the fixed cadence -- and no host wait per frame: the
+    // decision word of frame i goes into pinned memory behind an event, the host acts on the decision of frame i - COSLAM_KEYFRAME_LAG (>= 1),
+    // the key frame's own records and poses come out of a ring of LAG + 1 snapshots (coslam_amd/frameloop.py: LoopConfig.keyframe_lag)
+    const bool kfDrives = getenv("COSLAM_KEYFRAME_DRIVES") && getenv("COSLAM_KEYFRAME_DRIVES")[0] == '1';
+    const int kfLag = std::max(1, envi("COSLAM_KEYFRAME_LAG", 1));
+    const double kfRatio = getenv("COSLAM_KEYFRAME_RATIO") ? atof(getenv("COSLAM_KEYFRAME_RATIO")) : 0.93;   // m_mappedPtsReduceRatio
+    cs_ba_output* bout = cs_ba_output_create(dev, nCams, WIN_KF, nMap, kfDrives ? std::min(baLag * keyEvery + 6, 64) : 8);
     if (!bout) {
         fprintf(stderr, "cs_ba_output_create: %s\n", cs_last_error());
         return 3;
@@ -432,9 +441,64 @@ int main(int argc, char** argv) {
         int frame, firstKey;
         long long seq;   // the record's sequence number ON ITS OWNER (windows go round the ranks: the owner's (k / world)-th solve)
         int k, owner;    // window number, the rank that solves it (k % world)
+        std::vector<int> frames;   // the window's key frames where the decision put them (empty: firstKey + j * keyEvery)
     };
     std::vector<Due> due;   // applies still to come, in frame order
     int nPushed = 0, nApplied = 0, nKey = 0;
+    // ---- the key-frame decision's state (cs_keyframe_ready_dev) as CoSLAM::initMap leaves it: a key pose with self motion in every camera at
+    // frame 0, nMappedPts 0, m_minCamTranslation = the mean distance between the cameras / 4.5 (src/app/SL_CoSLAM.cpp:246-256, :278-291)
+    int *dKfFrame = dev_zeros<int>(nCams), *dKfMapped = dev_zeros<int>(nCams), *dKfReady = dev_zeros<int>(nCams + 2), *dKfCnt = dev_zeros<int>(2 * nCams);
+    int* dKfStats = dev_zeros<int>(5);
+    double *dKfSelfR = dev_zeros<double>(9 * (size_t)nCams), *dKfSelfT = dev_zeros<double>(3 * (size_t)nCams), *dKfCen = dev_zeros<double>(3 * (size_t)nCams);
+    double kfMinTranslation = 0.1;
+    std::vector<cs_keyframe_cam> kfCams[2];
+    struct KfSnap {
+        double *xy, *R, *t;
+        int *st, *s2m, *word;   // word: pinned host memory
+        hipEvent_t ev;
+        int frame;
+        std::vector<cs_handback_cam> hb;
+    };
+    std::vector<KfSnap> kfRing;
+    std::vector<int> kfPlaced, kfPushedFrames;
+    int kfNotApplied = 0;
+    if (kfDrives) {
+        HIPCHK(hipMemcpy(dKfSelfR, dR[0], sizeof(double) * 9 * nCams, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(dKfSelfT, dT[0], sizeof(double) * 3 * nCams, hipMemcpyDeviceToDevice));
+        std::vector<double> hR(9 * (size_t)nCams), hT(3 * (size_t)nCams), cen(3 * (size_t)nCams);
+        HIPCHK(hipMemcpy(hR.data(), dR[0], sizeof(double) * hR.size(), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hT.data(), dT[0], sizeof(double) * hT.size(), hipMemcpyDeviceToHost));
+        for (int c = 0; c < nCams; ++c)
+            for (int k = 0; k < 3; ++k) cen[3 * c + k] = -(hR[9 * c + k] * hT[3 * c] + hR[9 * c + 3 + k] * hT[3 * c + 1] + hR[9 * c + 6 + k] * hT[3 * c + 2]);
+        double sum = 0;
+        int n = 0;
+        for (int a = 0; a < nCams; ++a)
+            for (int c = a + 1; c < nCams; ++c, ++n) {
+                const double d0 = cen[3 * a] - cen[3 * c], d1 = cen[3 * a + 1] - cen[3 * c + 1], d2 = cen[3 * a + 2] - cen[3 * c + 2];
+                sum += sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+            }
+        if (n > 0) kfMinTranslation = sum / n / 4.5;
+        for (int q = 0; q < 2; ++q) {
+            kfCams[q].resize(nCams);
+            for (int c = 0; c < nCams; ++c) {
+                cs_keyframe_cam& k = kfCams[q][c];
+                k.state = dState + (size_t)c * N, k.slot2map = dS2M + (size_t)c * N, k.R = dR[q] + 9 * c, k.t = dT[q] + 3 * c;
+                k.keyFrame = dKfFrame + c, k.keyMapped = dKfMapped + c, k.selfR = dKfSelfR + 9 * c, k.selfT = dKfSelfT + 3 * c;
+            }
+        }
+        kfRing.resize(kfLag + 1);
+        for (auto& sn : kfRing) {
+            sn.xy = dev_zeros<double>((size_t)nCams * 2 * N), sn.R = dev_zeros<double>(9 * (size_t)nCams), sn.t = dev_zeros<double>(3 * (size_t)nCams);
+            sn.st = dev_zeros<int>((size_t)nCams * N), sn.s2m = dev_zeros<int>((size_t)nCams * N);
+            HIPCHK(hipHostMalloc((void**)&sn.word, sizeof(int), hipHostMallocDefault));
+            *sn.word = 0;
+            HIPCHK(hipEventCreateWithFlags(&sn.ev, hipEventDisableTiming));
+            sn.frame = -1;
+            sn.hb = hb[0];
+            for (int c = 0; c < nCams; ++c)
+                sn.hb[c].xy = sn.xy + (size_t)c * 2 * N, sn.hb[c].state = sn.st + (size_t)c * N, sn.hb[c].slot2map = sn.s2m + (size_t)c * N;
+        }
+    }
     long long nRequested = 0, nMySolves = 0;
     const size_t recordBytes = cs_ba_output_record_bytes(bout);
     if (world > 1)
@@ -495,6 +559,10 @@ int main(int argc, char** argv) {
         const int src = (i + 1) & 1, dsti = i & 1;
         // output() of the window whose lag ends at this frame, before anything of frame i touches the map: the pose stream waits ON
         // THE DEVICE for the worker to publish the record; the host goes on enqueueing
+        if (!due.empty() && due.front().frame == i && !due.front().frames.empty() && (i - 1) - due.front().frames.front() + 1 > 4096) {
+            due.erase(due.begin());   // (the camera graphs would start behind the pose history's oldest frame: the record is consumed, nothing written back)
+            ++kfNotApplied;
+        }
         if (!due.empty() && due.front().frame == i) {
             void* rec = nullptr;
             if (due.front().owner == rank)
@@ -502,8 +570,12 @@ int main(int argc, char** argv) {
             else
                 rec = dRecvRec[due.front().k & 1];
             if (world > 1) CSCHK(cs_comm_broadcast_dev(comm, (void*)poseS, rec, recordBytes, due.front().owner));   // the owner's record to every replica
-            CSCHK(cs_ba_output_apply_seq_dev(bout, rec, due.front().seq, (void*)poseS, hist, win, pu.data(), dPf, nMap, dMap, dCov, dMapFlags, PIX,
-                                             due.front().firstKey, keyEvery, dR[src], dT[src], dApplyCnt));
+            if (!due.front().frames.empty())
+                CSCHK(cs_ba_output_apply_frames_dev(bout, rec, due.front().seq, (void*)poseS, hist, win, pu.data(), dPf, nMap, dMap, dCov, dMapFlags, PIX,
+                                                    due.front().frames.data(), (int)due.front().frames.size(), dR[src], dT[src], dApplyCnt));
+            else
+                CSCHK(cs_ba_output_apply_seq_dev(bout, rec, due.front().seq, (void*)poseS, hist, win, pu.data(), dPf, nMap, dMap, dCov, dMapFlags, PIX,
+                                                 due.front().firstKey, keyEvery, dR[src], dT[src], dApplyCnt));
             due.erase(due.begin());
             ++nApplied;
         }
@@ -523,6 +595,9 @@ int main(int argc, char** argv) {
         // launches (the gate's lane of a point also lists it for the classification)
         CSCHK(cs_pose_update_classify_frame_dev(hist, (void*)poseS, pu.data(), dPf, nMap, dR[dsti], dT[dsti], dMap, dCov, dMapFlags, 0, PIX, i, 20, 5,
                                                 3, 6.0, nullptr, nullptr, nullptr, nullptr, nullptr, dNewPt, dSfn, dFirstFrm, PIX_CLASSIFY, nullptr));
+        if (kfDrives)   // genNewMapPoints' first half (:1294-1346): is a camera ready for a key frame; addKeyFrame's bookkeeping when `decrease` holds
+            CSCHK(cs_keyframe_ready_dev(dev, (void*)poseS, nCams, N, kfCams[dsti].data(), nMap, dMap, dMapFlags, dFirstFrm, i, kfRatio, 5.0, kfMinTranslation, 1,
+                                        dKfReady, dKfCnt, dKfCen, dKfStats));
         // genNewMapPoints every 4th frame -- BEFORE currentMapPointsRegister, as in the reference's frame (src/gui/CoSLAMThread.cpp:104-118):
         // the new map points take their features before the current points' registration looks at them
         if (nCams >= 2 && i % NCC_EVERY == 0) {
@@ -668,7 +743,8 @@ int main(int argc, char** argv) {
         // the tracker of frame i + 2 is released at the END of the frame's pose work (released right behind the hand-back it runs two frames
         // ahead and under more of the pose stream's kernels: -10 %, profiles/r04_ab_runs.txt)
         HIPCHK(hipEventRecord(destFree[b], poseS));
-        if (key) {
+        // a key frame's actions: the inter-camera solve, the frame's records and poses into the window's ring, the window's request
+        auto key_frame_actions = [&](int f, const cs_handback_cam* cams, const double* Rk, const double* tk, bool placed) {
             // InterCamPoseEstimator::addMapPoints + apply: every camera's current pose, the block-voted static features' map points
             // fixed, the dynamic points free; sigma 6, 3 x 40
             // (key frame k's inter-camera solve on rank (k + world / 2) % world, its window on rank k % world: the two chains on different GPUs)
@@ -677,7 +753,9 @@ int main(int argc, char** argv) {
                                                  dNewPt, dPf, 6.0, 3, 40));
             ++nKey;
             // requestForBA(5, 2, 2, 30): the numCams * 2 oldest key cameras and 2 points held, maxIter 2, inner 10; static points only
-            CSCHK(cs_ba_window_push_dev(win, (void*)poseS, hb[b].data(), dK, 1, dR[dsti], dT[dsti], i));
+            CSCHK(cs_ba_window_push_dev(win, (void*)poseS, cams, dK, 1, Rk, tk, f));
+            kfPushedFrames.push_back(f);
+            if ((int)kfPushedFrames.size() > WIN_KF) kfPushedFrames.erase(kfPushedFrames.begin());
             if (++nPushed >= WIN_KF) {
                 // window k is solved by rank k % world (the ring is identical on every rank); its packed result is broadcast and applied by
                 // every rank baLag key-frame intervals behind its key frame
@@ -687,8 +765,33 @@ int main(int argc, char** argv) {
                     CSCHK(cs_ba_solve_window_flags_async(joint.ws, win, (void*)poseS, dMap, dMapFlags, 2 * nCams, 2, 6.0, 2, 10));
                     seq = nMySolves++;
                 }
-                due.push_back({i + baLag * keyEvery, i - (WIN_KF - 1) * keyEvery, seq, k, owner});
+                Due d{f + baLag * keyEvery, f - (WIN_KF - 1) * keyEvery, seq, k, owner, {}};
+                if (placed) d.frames = kfPushedFrames, d.firstKey = kfPushedFrames.front();
+                due.push_back(d);
             }
+        };
+        if (kfDrives) {
+            // this frame's decision word, records and poses into slot i % (LAG + 1) of the ring (no host wait), then the decision of frame i - LAG
+            KfSnap& sn = kfRing[i % (kfLag + 1)];
+            HIPCHK(hipMemcpyAsync(sn.xy, dXY, sizeof(double) * (size_t)nCams * 2 * N, hipMemcpyDeviceToDevice, poseS));
+            HIPCHK(hipMemcpyAsync(sn.st, dState, sizeof(int) * (size_t)nCams * N, hipMemcpyDeviceToDevice, poseS));
+            HIPCHK(hipMemcpyAsync(sn.s2m, dS2M, sizeof(int) * (size_t)nCams * N, hipMemcpyDeviceToDevice, poseS));
+            HIPCHK(hipMemcpyAsync(sn.R, dR[dsti], sizeof(double) * 9 * nCams, hipMemcpyDeviceToDevice, poseS));
+            HIPCHK(hipMemcpyAsync(sn.t, dT[dsti], sizeof(double) * 3 * nCams, hipMemcpyDeviceToDevice, poseS));
+            HIPCHK(hipMemcpyAsync(sn.word, dKfReady + nCams + 1, sizeof(int), hipMemcpyDeviceToHost, poseS));
+            HIPCHK(hipEventRecord(sn.ev, poseS));
+            sn.frame = i;
+            const int f = i - kfLag;
+            KfSnap& old = kfRing[((f % (kfLag + 1)) + (kfLag + 1)) % (kfLag + 1)];
+            if (f >= 1 && old.frame == f) {
+                HIPCHK(hipEventSynchronize(old.ev));   // (a frame LAG behind: fired long ago unless the host has caught up with the device)
+                if (*old.word) {
+                    kfPlaced.push_back(f);
+                    key_frame_actions(f, old.hb.data(), old.R, old.t, true);
+                }
+            }
+        } else if (key) {
+            key_frame_actions(i, hb[b].data(), dR[dsti], dT[dsti], false);
         }
     };
     int* dBar = dev_zeros<int>(64);
@@ -748,6 +851,21 @@ int main(int argc, char** argv) {
     CSCHK(cs_detect_dynamic_dev(hist, (void*)poseS, 0, nCams, pu.data(), dR[0], dT[0], nMap, dMapFlags, 0, 20, 5, 3, 6.0, nullptr));
     HIPCHK(hipDeviceSynchronize());
 
+    if (kfDrives) {   // nMappedPts of frame 0's key pose: the certainly static mapped features of the frame (enable_keyframe_decision, coslam_amd/frameloop.py)
+        std::vector<int> st((size_t)nCams * N), sm((size_t)nCams * N), km(nCams, 0);
+        std::vector<unsigned char> fl(nMap);
+        HIPCHK(hipMemcpy(st.data(), dState, sizeof(int) * st.size(), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(sm.data(), dS2M, sizeof(int) * sm.size(), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(fl.data(), dMapFlags, fl.size(), hipMemcpyDeviceToHost));
+        for (int c = 0; c < nCams; ++c)
+            for (int q = 0; q < N; ++q) {
+                const int sv = st[(size_t)c * N + q], m = sm[(size_t)c * N + q];
+                if ((sv == 0 || sv == 1) && m >= 0 && m < nMap && (fl[m] & 7) == 0) ++km[c];
+            }
+        HIPCHK(hipMemcpy(dKfMapped, km.data(), sizeof(int) * nCams, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dKfSelfR, dR[0], sizeof(double) * 9 * nCams, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(dKfSelfT, dT[0], sizeof(double) * 3 * nCams, hipMemcpyDeviceToDevice));
+    }
     // set-up (one key-frame interval: graph capture in the BA workers, lazy code-object loading), warm-up, timed loop
     // (with the window: 5 key-frame intervals, so that every timed solve has its 5 key frames = 5 x nCams cameras); the frame
     // sequence runs on through set-up, warm-up and the timed region
@@ -823,6 +941,9 @@ int main(int argc, char** argv) {
     HIPCHK(hipMemcpy(rvCnt, dRvCnt, sizeof(rvCnt), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(rvListCnt, dRvListCnt, sizeof(rvListCnt), hipMemcpyDeviceToHost));
     if (fusedRounds) HIPCHK(hipMemcpy(&rvListCnt[1], dRvCounts + RV_ROUNDS, sizeof(int), hipMemcpyDeviceToHost));
+    std::string placedJson = "[";
+    for (size_t q = 0; q < kfPlaced.size(); ++q) placedJson += (q ? ", " : "") + std::to_string(kfPlaced[q]);
+    placedJson += "]";
     int decUnsettled = 0;   // (the decision scratch's last int: sticky "some call's sweeps did not settle")
     HIPCHK(hipMemcpy(&decUnsettled, (char*)dDecScratch + cs_register_decide_scratch_bytes(nCams, N, nMap) - sizeof(int), sizeof(int),
                      hipMemcpyDeviceToHost));
@@ -833,10 +954,12 @@ int main(int argc, char** argv) {
            "\"intercam_static_points\": %d, \"intercam_dynamic_points\": %d, \"map_points_at_start\": %d, \"map_points_in_use\": %d, "
            "\"map_capacity\": %d, \"new_map_points_last_run\": %d, \"register_decisions_unsettled\": %s, \"bmerge_frames\": %d, \"current_points_beyond_the_cap\": %d, \"second_visit_rounds\": %d, \"second_visit_features_attached\": %d, "
            "\"second_visit_conflicts\": %d, \"second_visit_conflicts_in_timed_region\": %d, \"second_visit_points_beyond_the_list\": %d, "
+           "\"key_frames_placed_by_the_decision\": %s, \"keyframe_lag\": %d, \"frames_run\": %d, \"windows_requested\": %lld, \"windows_applied\": %d, \"windows_not_applied_history_too_short\": %d, "
            "\"rank\": %d, \"world\": %d, \"cameras_per_rank\": %d, \"transport\": \"%s\", \"digest\": \"%016llx\"}\n",
            steps / dt, dt / steps * 1e3, steps, warmup, dtHost / steps * 1e3, camsPerLaunch, okAll ? "true" : "false", minLive,
            sj.nIterTotal, sj.cost, si.nIterTotal, si.cost, nccRuns, win ? "true" : "false", jC, jP, jO, baLag, nApplied - applied0,
            cs_ba_output_wait_errors(bout), iS, iP - iS, nPts, mapCountNow, nMap, npCounts[0], decUnsettled ? "true" : "false", nMergeFrames, curOverflow, RV_ROUNDS, rvCnt[0], rvCnt[2], rvCnt[2] - rvCnt0[2], rvListCnt[1],
+           kfDrives ? placedJson.c_str() : "null", kfDrives ? kfLag : 0, nDone, (long long)nRequested, nApplied, kfNotApplied,
            rank, world, nc, world == 1 ? "none" : (getenv("COSLAM_COMM") && !strncmp(getenv("COSLAM_COMM"), "host:", 5) ? "host segment (test)" : "rccl"),
            digest);
     fflush(stdout);
