@@ -91,7 +91,17 @@ struct HostShm {
     std::atomic<int> attached;
     int world;
     size_t capacity;   // bytes of payload behind the header
+    // who made the segment and when (a rank could attach to a same-named segment a crashed run left behind -- rank 0 unlinks and
+    // re-creates it, but an attaching rank may open the OLD name first; the stale sizes and counters passed every check and the ranks waited out
+    // 60 s on different segments): rank 0 stamps its segment, an attaching rank takes only one that is stamped, younger than two minutes and
+    // not yet full, and opens the name again otherwise
+    std::atomic<unsigned long long> magic;
+    long long createdNs;
 };
+constexpr unsigned long long CS_HOST_MAGIC = 0x43534C414D484F53ull;   // "CSLAMHOS"
+static long long host_now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
 constexpr size_t CS_HOST_SHM_BYTES = (size_t)96 << 20;
 
 struct cs_comm {
@@ -248,34 +258,57 @@ cs_comm* cs_comm_create_host(const char* name, int world, int rank, int device) 
         return nullptr;
     }
     const size_t bytes = sizeof(HostShm) + CS_HOST_SHM_BYTES;
-    int fd = -1;
+    void* m = MAP_FAILED;
     if (rank == 0) {
         (void)shm_unlink(name);
-        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd >= 0 && ftruncate(fd, (off_t)bytes) != 0) {
             close(fd);
             fd = -1;
         }
+        if (fd < 0) {
+            cs_set_error("cs_comm_create_host: cannot create the shared-memory segment %s", name);
+            return nullptr;
+        }
+        m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m != MAP_FAILED) {   // (a fresh segment is zero-filled: counters at 0)
+            HostShm* h = (HostShm*)m;
+            h->capacity = CS_HOST_SHM_BYTES, h->world = world, h->createdNs = host_now_ns();
+            h->magic.store(CS_HOST_MAGIC, std::memory_order_release);
+        }
     } else {
         const auto t0 = std::chrono::steady_clock::now();
-        while (fd < 0 && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(60)) {
-            fd = shm_open(name, O_RDWR, 0600);
+        while (m == MAP_FAILED && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(60)) {
+            int fd = shm_open(name, O_RDWR, 0600);
             struct stat st;
             if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes)) {   // (created, not yet sized)
                 close(fd);
                 fd = -1;
             }
-            if (fd < 0) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+            if (fd >= 0) {
+                void* q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                close(fd);
+                if (q != MAP_FAILED) {
+                    HostShm* h = (HostShm*)q;
+                    // this run's segment: stamped by rank 0 (it may be a moment away from that), made within the last two minutes, not full
+                    bool mine = false;
+                    for (int tries = 0; tries < 40 && !mine; ++tries) {
+                        mine = h->magic.load(std::memory_order_acquire) == CS_HOST_MAGIC && h->world == world && h->attached.load() < world &&
+                               llabs(host_now_ns() - h->createdNs) < 120LL * 1000000000LL;
+                        if (!mine) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+                    }
+                    if (mine)
+                        m = q;
+                    else
+                        munmap(q, bytes);   // (a segment a crashed run left behind, or one rank 0 is about to replace: open the name again)
+                }
+            }
+            if (m == MAP_FAILED) std::this_thread::sleep_for(std::chrono::milliseconds(5));
         }
     }
-    if (fd < 0) {
-        cs_set_error("cs_comm_create_host: cannot open the shared-memory segment %s", name);
-        return nullptr;
-    }
-    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
     if (m == MAP_FAILED) {
-        cs_set_error("cs_comm_create_host: mmap failed");
+        cs_set_error("cs_comm_create_host: cannot open / map this run's shared-memory segment %s", name);
         return nullptr;
     }
     cs_comm* c = new (std::nothrow) cs_comm();
@@ -283,11 +316,7 @@ cs_comm* cs_comm_create_host(const char* name, int world, int rank, int device) 
     c->comm = nullptr, c->world = world, c->rank = rank, c->device = device;
     c->host = (HostShm*)m, c->hostData = (unsigned char*)m + sizeof(HostShm);
     snprintf(c->hostName, sizeof(c->hostName), "%s", name);
-    if (rank == 0) {   // (a fresh segment is zero-filled: counters at 0; the others wait for `world` before their first barrier)
-        c->host->capacity = CS_HOST_SHM_BYTES;
-        c->host->world = world;
-    }
-    c->host->attached.fetch_add(1);
+    c->host->attached.fetch_add(1);   // (the others wait for `world` before their first barrier)
     const auto t0 = std::chrono::steady_clock::now();
     while (c->host->attached.load() < world || c->host->world != world) {
         std::this_thread::yield();
