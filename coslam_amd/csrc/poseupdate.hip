@@ -1121,6 +1121,12 @@ __global__ __launch_bounds__(256) void k_check_unify(CuArgs A) {
 // the walks before it attached); lane c prefetches camera c's entries of the point, the wave evaluates checkUnify together.  The parity
 // mode's kernel: ~5 us per conflict, a frame of 8 cameras x 1500 points ~0.1 s -- for the frames that carry bMerge when the reference's
 // run is wanted step for step; the frame loop's single pass does not unify points.
+constexpr int DM_MAX_CAMS = 16;   // (cs_register_decide_merge_dev refuses more: lane c = camera c, four lanes' worth of columns)
+__device__ __forceinline__ void wave_fence_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 struct DmArgs {
     CuArgs cu;                       // the history ring, cameras (slot2map is written), sigma
     int P, mapBase, onlyCam;
@@ -1143,7 +1149,43 @@ struct DmArgs {
     int debug;                       // COSLAM_MERGE_DEBUG=1: the walk prints where its time went (diagnostic)
     unsigned char* preOk;            // [nList][nCams]: 0 not evaluated, 1 checkUnify said no, 2 yes
     double* preM;                    // [nList][nCams][12]: the unified position and covariance of a yes
+    // MapPoint::pFeatures as references (cs_track_history_set_merge_refs; null: this frame's features alone): checkUnify reads both points'
+    // rows composed from pointFeat + the table (dm_compose), an attach brings its entry up at once (a stale feature there becomes a linked
+    // segment, :775-779), the hand-over of a unification follows the reference's loop over pFeatures (:806-816)
+    int4* featRef;                   // [P][nCams]
+    unsigned char* refStatic;        // [P][nCams] or null
+    int4* segPoolW;                  // [nCams][segCap]
+    int* segCount;                   // [nCams]
 };
+// the feature of map point x in camera c as the reference holds it NOW: this frame's (pointFeat) with what the table knows of its chain -- the
+// table's entry moved on by a frame, or already brought up -- or, without a feature of this frame, the table's stale one
+__device__ __forceinline__ int4 dm_compose(const DmArgs& A, int x, int c, int pf) {
+    const int4 ref = A.featRef[(size_t)x * A.cu.nCams + c];
+    const int cur = A.cu.curFrame;
+    if (pf >= 0) {
+        if (ref.x == pf && (ref.y == cur || ref.y == cur - 1)) return make_int4(pf, cur, ref.z, ref.w);
+        const int f1 = A.cu.cam[c].trackSpan[pf];
+        return make_int4(pf, cur, f1 >= 0 ? f1 : cur, -1);
+    }
+    if (ref.x >= 0 && ref.y < cur) return ref;
+    return make_int4(-1, 0, 0, -1);
+}
+// what cs_feat_ref_advance_dev does to the entry of (point x, camera c) when the walk gives it feature s of this frame
+__device__ __forceinline__ void dm_attach_ref(const DmArgs& A, int x, int c, int s) {
+    const size_t e = (size_t)x * A.cu.nCams + c;
+    int4 ref = A.featRef[e];
+    const int cur = A.cu.curFrame;
+    if (ref.x >= 0 && ref.y < cur) {   // a stale feature held there: it hangs behind the new one (pFeat->preFrame = p->pFeatures[iCam])
+        const int idx = atomicAdd(A.segCount + c, 1);
+        if (idx < A.cu.segCap) A.segPoolW[(size_t)c * A.cu.segCap + idx] = ref;
+        ref = make_int4(s, cur, cur, idx < A.cu.segCap ? idx : -1);
+    } else {
+        const int f1 = A.cu.cam[c].trackSpan[s];
+        ref = make_int4(s, cur, f1 >= 0 ? f1 : cur, -1);
+    }
+    A.featRef[e] = ref;
+    if (A.refStatic) A.refStatic[e] = A.cu.cam[c].isStatic ? A.cu.cam[c].isStatic[s] : 1;
+}
 // the conflicts a bMerge walk can meet, judged side by side on the state the walk starts from: a wave per (listed point, camera)
 __global__ __launch_bounds__(256) void k_merge_precheck(DmArgs A) {
     __shared__ double sR[4][64 * 9 + 16];
@@ -1162,8 +1204,14 @@ __global__ __launch_bounds__(256) void k_merge_precheck(DmArgs A) {
     if (q < 0 || q >= A.P || q == p) return;
     if (A.mapFlags[q] & (CS_MAP_DYNAMIC | CS_MAP_FALSE)) return;
     double M[3], cov[9];
-    const bool ok = check_unify_wave(A.cu, A.pointFeat + (size_t)p * C, A.pointFeat + (size_t)q * C, nullptr, nullptr, A.mapPts + 3 * (size_t)p, A.mapPts + 3 * (size_t)q,
-                                     sR[g], M, cov);
+    __shared__ int4 sRef[4][2][DM_MAX_CAMS];
+    if (A.featRef) {
+        if (r < C) sRef[g][0][r] = dm_compose(A, p, r, A.pointFeat[(size_t)p * C + r]);
+        else if (r >= 16 && r < 16 + C) sRef[g][1][r - 16] = dm_compose(A, q, r - 16, A.pointFeat[(size_t)q * C + r - 16]);
+        wave_fence_lds();
+    }
+    const bool ok = check_unify_wave(A.cu, A.pointFeat + (size_t)p * C, A.pointFeat + (size_t)q * C, A.featRef ? sRef[g][0] : nullptr,
+                                     A.featRef ? sRef[g][1] : nullptr, A.mapPts + 3 * (size_t)p, A.mapPts + 3 * (size_t)q, sR[g], M, cov);
     if (r == 0) {
         double* o = A.preM + 12 * (size_t)e;
 #pragma unroll
@@ -1173,12 +1221,12 @@ __global__ __launch_bounds__(256) void k_merge_precheck(DmArgs A) {
         A.preOk[e] = ok ? 2 : 1;
     }
 }
-constexpr int DM_MAX_CAMS = 16;   // (cs_register_decide_merge_dev refuses more: lane c = camera c, four lanes' worth of columns)
 __device__ __forceinline__ int mg_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned char mg_ldb(const unsigned char* p) { return *(volatile const unsigned char*)p; }
 constexpr int DM_DIRTY_WORDS = 2048;   // by list: the "touched" marks of up to 65536 points as a bitmap in LDS
 __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
     __shared__ double sR[64 * 9 + 16];
+    __shared__ int4 sRefW[2][DM_MAX_CAMS];
     __shared__ unsigned dirtyBits[DM_DIRTY_WORDS];
     for (int w = threadIdx.x; w < DM_DIRTY_WORDS; w += 64) dirtyBits[w] = 0u;
     __syncthreads();
@@ -1348,6 +1396,7 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
                             s2m[s] = A.mapBase + p;
                             A.pointFeat[(size_t)p * C + i] = s;
                             A.attached[(size_t)p * C + i] = 1;
+                            if (A.featRef) dm_attach_ref(A, p, i, s);
                             if (byList) set_dirty(p);   // the point has changed: a pre-checked verdict about it no longer stands
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1382,8 +1431,13 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
                     }
                 } else {
                     const long long ti = wall_clock64();
-                    ok = check_unify_wave(A.cu, A.pointFeat + (size_t)p * C, A.pointFeat + (size_t)q * C, nullptr, nullptr, A.mapPts + 3 * (size_t)p,
-                                          A.mapPts + 3 * (size_t)q, sR, M, cov);
+                    if (A.featRef) {
+                        if (lane < C) sRefW[0][lane] = dm_compose(A, p, lane, mg_ld(A.pointFeat + (size_t)p * C + lane));
+                        else if (lane >= 16 && lane < 16 + C) sRefW[1][lane - 16] = dm_compose(A, q, lane - 16, mg_ld(A.pointFeat + (size_t)q * C + lane - 16));
+                        wave_fence_lds();
+                    }
+                    ok = check_unify_wave(A.cu, A.pointFeat + (size_t)p * C, A.pointFeat + (size_t)q * C, A.featRef ? sRefW[0] : nullptr,
+                                          A.featRef ? sRefW[1] : nullptr, A.mapPts + 3 * (size_t)p, A.mapPts + 3 * (size_t)q, sR, M, cov);
                     tInline += wall_clock64() - ti, ++nInline;
                 }
                 if (!ok) continue;
@@ -1395,6 +1449,22 @@ __global__ __launch_bounds__(64) void k_decide_merge(DmArgs A) {
                     if (byList) set_dirty(p), set_dirty(q);
                     for (int v = 0; v < C; ++v) {
                         const int sq = A.pointFeat[(size_t)q * C + v];
+                        if (A.featRef) {
+                            // :806-816 over pFeatures as they are: `pFt && !p->pFeatures[v]` -- a stale feature of p blocks the hand-over in its
+                            // camera, a stale feature of q moves like a live one (its chain with it)
+                            const size_t ep = (size_t)p * C + v, eq = (size_t)q * C + v;
+                            const int4 rq = dm_compose(A, q, v, sq), rp = dm_compose(A, p, v, A.pointFeat[ep]);
+                            if (rq.x < 0 || rp.x >= 0) continue;
+                            A.featRef[ep] = rq, A.featRef[eq] = make_int4(-1, 0, 0, -1);
+                            if (A.refStatic) A.refStatic[ep] = A.refStatic[eq];
+                            if (sq >= 0) {
+                                A.pointFeat[eq] = -1;
+                                const_cast<int*>(A.cu.cam[v].slot2map)[sq] = A.mapBase + p;
+                                A.pointFeat[ep] = sq;
+                                if (v == i && sq == s) break;   // pFeat->mpt is p from here on (:808)
+                            }
+                            continue;
+                        }
                         if (sq >= 0 && A.pointFeat[(size_t)p * C + v] < 0) {
                             A.pointFeat[(size_t)q * C + v] = -1;
                             const_cast<int*>(A.cu.cam[v].slot2map)[sq] = A.mapBase + p;
@@ -1866,6 +1936,9 @@ struct cs_track_history {
     // cs_track_history_set_classify_refs: the classification reads (and clears) the points' features as references
     int4* clsFeatRef;
     unsigned char* clsRefStatic;
+    // cs_track_history_set_merge_refs: the bMerge walks read and write them
+    int4* mergeFeatRef;
+    unsigned char* mergeRefStatic;
 };
 
 // the camera centres by walk depth, if the ring's poses changed since they were last computed
@@ -2816,6 +2889,18 @@ extern "C" int cs_track_history_load_segments(cs_track_history* h, const cs_feat
     return CS_OK;
 }
 
+// the first n segments of every camera's pool to the host ([nCams][n] cs_feat_seg; tests, saving a state); synchronous
+extern "C" int cs_track_history_download_segments(const cs_track_history* h, cs_feat_seg* segs, int n) {
+    if (!h || !segs || n < 0 || n > h->segCap) {
+        cs_set_error("cs_track_history_download_segments: bad arguments (at most %d segments per camera)", h ? h->segCap : 0);
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(h->device));
+    for (int c = 0; c < h->nCams && n > 0; ++c)
+        CS_HIP(hipMemcpy(segs + (size_t)c * n, h->segPool + (size_t)c * h->segCap, sizeof(int4) * n, hipMemcpyDeviceToHost));
+    return CS_OK;
+}
+
 namespace {
 // the reference tables of a *_ref_dev call into the launch arguments
 template <class Args>
@@ -2960,6 +3045,8 @@ extern "C" int cs_register_decide_merge_list_dev(const cs_track_history* h, void
     A.slot = d_slot, A.flags = d_flags, A.mergeable = d_mergeable, A.mapFlags = d_mapFlags, A.pointFeat = d_pointFeat;
     A.mapPts = d_mapPts, A.mapCov = d_mapCov, A.attached = d_attached, A.regged = d_regged, A.inVec = (unsigned char*)d_scratch, A.counts = d_counts;
     A.list = d_list, A.nList = nList;
+    A.featRef = h->mergeFeatRef, A.refStatic = h->mergeRefStatic, A.segPoolW = h->segPool, A.segCount = h->segCount;
+    if (A.featRef) A.cu.segPool = h->segPool, A.cu.segCap = h->segCap, A.cu.curFrame = h->lastFrame, A.cu.stored = h->count < h->H ? h->count : h->H;
     A.debug = cs_debug_get(CS_DBG_MERGE_PRINT) == 1;   // (cs_debug_set("merge_print", 1): the kernel prints its own account)
     CS_HIP(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)hip_stream;
@@ -3063,6 +3150,17 @@ extern "C" int cs_track_history_set_classify_refs(cs_track_history* h, cs_feat_r
         return CS_ERR_INVALID;
     }
     h->clsFeatRef = (int4*)d_featRef, h->clsRefStatic = d_featRef ? d_refStatic : nullptr;
+    return CS_OK;
+}
+
+// From the next call on cs_register_decide_merge(_list)_dev takes the points' features as references (d_featRef [P][nCams] cs_feat_ref, read AND
+// written; d_refStatic [P][nCams] or NULL); NULL: this frame's features alone.
+extern "C" int cs_track_history_set_merge_refs(cs_track_history* h, cs_feat_ref* d_featRef, unsigned char* d_refStatic) {
+    if (!h) {
+        cs_set_error("cs_track_history_set_merge_refs: null history");
+        return CS_ERR_INVALID;
+    }
+    h->mergeFeatRef = (int4*)d_featRef, h->mergeRefStatic = d_featRef ? d_refStatic : nullptr;
     return CS_OK;
 }
 

@@ -76,6 +76,8 @@ class LoopConfig:
         self.fused_registration = True   # the registration's launches fused as tools/cxx/frame_loop.cpp runs them: the second visits' lists built by the
         # walks (cs_register_decide_kinds_rounds_dev, cs_register_revisit_decide_next_dev), advance + refine as one launch
         # (cs_feat_ref_advance_refine_dev); needs feature_chains.  False: a launch per step (the form DESIGN.md 3.13.1 describes first)
+        self.merge_refs = True       # the bMerge walks read and write the references too (checkUnify over stale features and chains, the hand-over as the
+        # reference's loop over pFeatures does it: cs_track_history_set_merge_refs)
         self.classify_refs = True    # mapPointsClassify reads the references too (stale features, linked segments: cs_track_history_set_classify_refs)
         self.feature_chains = True   # MapPoint::pFeatures kept as feature references (cs_feat_ref): a camera that lost a point still contributes
         # its last feature to refineMapPoint / updateNewPosesPoints, and a point registered to a new track where it held an older feature has
@@ -281,6 +283,8 @@ class FrameLoop:
             self.d_fref_counts = z(5, i32)   # tracked on, first features, re-linked, links dropped (pool full), detached -- summed over the run
             if self.d_fref is not None and cfg.classify_refs:
                 self.pose_upd.set_classify_refs(self.d_fref.data_ptr(), self.d_rstat.data_ptr())
+            if self.d_fref is not None and cfg.merge_refs:
+                self.pose_upd.set_merge_refs(self.d_fref.data_ptr(), self.d_rstat.data_ptr())
             self.pu_args = poseupdate_cams([dict(K=self.d_K1.data_ptr(), iK=self.d_iK1.data_ptr(), xy=self.d_xy[g].data_ptr(),
                                                  state=self.d_state[g].data_ptr(), slot2map=self.d_slot2map[g].data_ptr(),
                                                  trackSpan=self.d_trackspan[g].data_ptr(), reprojErr=self.d_reproj[g].data_ptr(),

@@ -210,6 +210,23 @@ class TrackHistory:
         check(self._L.cs_track_history_load_segments(C.c_void_p(self._h), a.ctypes.data_as(C.c_void_p), int(a.shape[1])),
               "cs_track_history_load_segments")
 
+    def segments(self):
+        """the cameras' pools of linked segments as they stand: (nCams, n, 4) int32 {slot, last, first, next}, n = the fullest pool's count"""
+        import numpy as np
+
+        cnt, _ = self.segment_counts()
+        n = max(int(cnt.max()), 1)
+        out = np.full((self.nCams, n, 4), -1, dtype=np.int32)
+        check(self._L.cs_track_history_download_segments(C.c_void_p(self._h), out.ctypes.data_as(C.c_void_p), n), "cs_track_history_download_segments")
+        return out
+
+    def set_merge_refs(self, d_featRef, d_refStatic=None):
+        """cs_track_history_set_merge_refs: the bMerge walks (register_decide_merge_dev) take the points' features as references from now on --
+        checkUnify over stale features and linked chains, a new feature behind a stale one linked at once, the hand-over of a unification as the
+        reference's loop does it (a stale feature blocks it in its camera, the other point's stale features move too); None: pointFeat alone"""
+        vp = C.c_void_p
+        check(self._L.cs_track_history_set_merge_refs(vp(self._h), vp(d_featRef), vp(d_refStatic)), "cs_track_history_set_merge_refs")
+
     def segment_counts(self):
         """cs_track_history_segment_counts: how many linked segments every camera's pool holds (a synchronous read) and the capacity"""
         import numpy as np

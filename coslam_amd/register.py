@@ -193,7 +193,8 @@ def register_revisit_decide_next_dev(stream_ptr, nCams, N, P, cap, mapBase, kind
 
 def register_cur_static_sequential_dev(stream_ptr, history, pu_cams, reg_cams, N, W, H, search_pass, P, d_slot, d_flags, d_mergeable, d_mapFlags,
                                        d_pointFeat, d_slot2map, d_attached, d_regged, d_scratch, d_mapPts, d_mapCov, pixelVar, d_counts=0,
-                                       after_loop=None, device=0, n_sweeps=6, with_dynamic=False, merge=False, d_merge_scratch=0, mergability=None):
+                                       after_loop=None, device=0, n_sweeps=6, with_dynamic=False, merge=False, d_merge_scratch=0, mergability=None,
+                                       d_featRef=0, d_refStatic=0, curFrame=None):
     """CoSLAM::curStaticPointsRegInGroup (bMerge == false) AS THE REFERENCE RUNS IT (src/app/SL_CoSLAM.cpp:854-898), camera loop after
     camera loop, on the device: for o = 0 .. nCams - 1 -- the search from the points as they stand (cs_register_search_passes_dev with
     the ONE pass `search_pass`, whose tables are d_slot / d_flags), staticCheckMergability of its candidates (history: a TrackHistory),
@@ -220,7 +221,11 @@ def register_cur_static_sequential_dev(stream_ptr, history, pu_cams, reg_cams, N
         else:
             arr = register_decide_static_dev(stream_ptr, nC, N, P, 0, d_slot, d_flags, d_mergeable, d_mapFlags, d_pointFeat, arr or d_slot2map,
                                              d_attached, d_regged, d_scratch, d_counts, device=device, n_sweeps=n_sweeps, only_cam=o, kinds=kind)
-        history.refine_map_points_dev(stream_ptr, pu_cams, d_pointFeat, P, d_mapPts, d_mapCov, pixelVar, d_select=d_regged)
+        if d_featRef:   # MapPoint::pFeatures as references: brought up to the loop's attachments (re-links, hand-overs), then refineMapPoint over them
+            history.feat_ref_advance_dev(stream_ptr, pu_cams, P, d_pointFeat, curFrame, d_featRef, d_refStatic=d_refStatic or None)
+            history.refine_map_points_ref_dev(stream_ptr, pu_cams, d_featRef, P, d_mapPts, d_mapCov, pixelVar, d_select=d_regged)
+        else:
+            history.refine_map_points_dev(stream_ptr, pu_cams, d_pointFeat, P, d_mapPts, d_mapCov, pixelVar, d_select=d_regged)
         if after_loop is not None:
             after_loop(o + (nC if kind == 2 else 0))
     return arr

@@ -737,6 +737,8 @@ int cs_track_history_segments(const cs_track_history* h, cs_feat_seg** d_pool, i
 int cs_track_history_segment_counts(const cs_track_history* h, int* counts);
 /* n segments per camera from the host ([nCams][n]) into the pools, counters = n (tests, restoring a saved state); synchronous */
 int cs_track_history_load_segments(cs_track_history* h, const cs_feat_seg* segs, int n);
+/* the first n segments of every camera's pool back ([nCams][n]); synchronous */
+int cs_track_history_download_segments(const cs_track_history* h, cs_feat_seg* segs, int n);
 /* cs_update_new_poses_points_dev / cs_refine_map_points_dev / cs_check_unify_dev with the points' features as references: stale features
  * are views, the widest-parallax walk follows the links.  The current frame is the history's newest.  Pinned against the reference's own
  * functions on chains built with its classes (tests/cxx/ref_update_points_test.cpp golden_relink -> tests/golden/update_points_relink_golden.npz). */
@@ -757,6 +759,15 @@ int cs_refine_map_points_ref_dev(const cs_track_history* h, void* hip_stream, co
  * read.  d_featRef NULL: back to d_pointFeat alone.  Pinned against the reference's own functions over chains built with its classes
  * (tests/cxx/ref_classify_test.cpp golden_relink -> tests/golden/classify_relink_golden.npz). */
 int cs_track_history_set_classify_refs(cs_track_history* h, cs_feat_ref* d_featRef, unsigned char* d_refStatic);
+
+/* The bMerge walks (cs_register_decide_merge_dev / _list_dev below) over the references: from the next call on checkUnify reads both points'
+ * rows as the reference holds MapPoint::pFeatures at that moment (this frame's features with their chains, stale features of cameras that
+ * lost the point), a feature attached where the point held a stale one gets the old chain linked behind it at once (SL_CoSLAM.cpp:775-779;
+ * the table and the camera's pool are written), and the hand-over of a unification follows `pFt && !p->pFeatures[v]` (:806-816): a stale
+ * feature of the walking point blocks it in its camera, the other point's stale features move with their chains.  NULL: this frame's
+ * features alone.  Pinned against the reference's own curStaticPointsRegInGroup over stale and re-linked chains
+ * (tests/cxx/ref_decide_test.cpp golden_relink -> tests/golden/decide_relink_golden.npz). */
+int cs_track_history_set_merge_refs(cs_track_history* h, cs_feat_ref* d_featRef, unsigned char* d_refStatic);
 
 /* CoSLAM::checkUnify (src/app/SL_CoSLAM.cpp:561-665) for nPairs pairs of map points in one launch: what the registration loops ask
  * on a conflict -- the point's nearest feature already carries another static point (:791-796, bMerge: every 50th frame).  Per pair

@@ -69,19 +69,32 @@ struct Slot {
 };
 
 int main(int argc, char** argv) {
-    if (argc < 3 || strcmp(argv[1], "golden")) {
-        fprintf(stderr, "usage: %s golden <out.bin>\n", argv[0]);
+    if (argc < 3 || (strcmp(argv[1], "golden") && strcmp(argv[1], "golden_relink"))) {
+        fprintf(stderr, "usage: %s golden|golden_relink <out.bin>\n", argv[0]);
         return 2;
     }
+    // golden_relink: MapPoint::pFeatures as the registration loops and lost tracks leave them over time -- a camera that lost a point keeps its
+    // last feature (a STALE head: every walk of checkUnify / refineMapPoint takes it as a view, curStaticPointRegInGroup looks for a new
+    // feature there and links the old chain behind it, :775-779; at a unification it blocks the hand-over in its camera, :806-816, and the
+    // other point's stale features move too), and a feature's preFrame chain may jump into an older track.  Scenes 5, 6 (bMerge) and 0, 3.
+    // Added to the file per point and camera (behind the point's record): int32 staleHead (1: the point's feature there is a stale one),
+    // isStatic of that feature, nExtra segments of consecutive frames on dead tracks -- the stale head's run first, then what is linked behind
+    // -- each int32 j0 (history entry of its newest node), L, L x m[2]; behind the reference's result per point and camera: int32
+    // staleOwner (the point that owned the stale feature now held there, -1 none), preOwner (the owner of the dead-track chain linked
+    // directly behind the live feature now held there, -1 none).
+    const bool relink = !strcmp(argv[1], "golden_relink");
+    if (relink) g_rng = 0xA0761D6478BD642Full;
     FILE* f = fopen(argv[2], "wb");
     if (!f) return 1;
-    const int nScenes = 7;   // 0-2: the static points' registration alone; 3, 4: more certainly dynamic points with DYNAMIC candidates, and
+    const int nScenes = relink ? 4 : 7;   // 0-2: the static points' registration alone; 3, 4: more certainly dynamic points with DYNAMIC candidates, and
                              // curDynamicPointsRegInGroup behind it (CoSLAM::currentMapPointsRegister's order, :834-853); 5, 6: the same with
                              // bMerge == true (every 50th frame, CoSLAMThread.cpp:117-118): a walk that meets a feature of another static
                              // point asks checkUnify and, on a yes, takes that point's features (:791-826) -- more twins here
     puti(f, nScenes);
     int tot[6] = {0, 0, 0, 0, 0, 0};   // attached, not mergeable, dynamic passed by, walks ended by a mapped feature, twins, regged
-    for (int sc = 0; sc < nScenes; ++sc) {
+    for (int scq = 0; scq < nScenes; ++scq) {
+        static const int relinkScenes[4] = {5, 6, 0, 3};
+        const int sc = relink ? relinkScenes[scq] : scq;
         const bool dyn = sc >= 3, merge = sc >= 5;
         const int nCams = merge ? sc - 2 : (dyn ? sc : 3 + sc), Hh = 20, nBase = 110 + 20 * sc, curFrame = 200 + 11 * sc, W = 640, H = 480;
         const double pixelVar = 10.0;   // Const::PIXEL_ERR_VAR as CoSLAMThread.cpp:117 passes it
@@ -150,6 +163,55 @@ int main(int argc, char** argv) {
             double X[3];
         };
         std::vector<Pt> pts;
+        // chains on dead tracks (relink): per (point, camera) the segments and whether the first of them is the point's (stale) feature there
+        struct DeadSeg {
+            int j0, L;
+            std::vector<double> m;
+            FeaturePoint *newest, *oldest;
+        };
+        std::map<std::pair<int, int>, std::vector<DeadSeg> > dead;
+        std::map<std::pair<int, int>, int> staleHead, staleStatic;
+        std::map<const FeaturePoint*, int> deadOwner;   // every node of a dead-track chain -> the point that owned it when the scene was built
+        auto add_dead = [&](int c, const double* X, int j0, int L, bool isStatic, MapPoint* owner, int ownerIdx) {
+            DeadSeg sg;
+            sg.j0 = j0, sg.L = L, sg.newest = sg.oldest = nullptr;
+            FeaturePoint* newer = nullptr;
+            for (int q = 0; q < L; ++q) {
+                double m[2];
+                project(c, j0 + q, X, m);
+                m[0] += 0.35 * nrand(), m[1] += 0.35 * nrand();
+                sg.m.push_back(m[0]), sg.m.push_back(m[1]);
+                FeaturePoint* fp = new FeaturePoint(curFrame - (j0 + q), c, m[0], m[1]);
+                fp->setIntrinsic(co->slam[c].K.data);
+                fp->setCameraPose(cams[c][j0 + q]);
+                fp->type = isStatic ? TYPE_FEATPOINT_STATIC : TYPE_FEATPOINT_DYNAMIC;
+                fp->mpt = owner;
+                deadOwner[fp] = ownerIdx;
+                if (newer) newer->preFrame = fp, fp->nextFrame = newer;
+                else sg.newest = fp;
+                newer = fp;
+            }
+            sg.oldest = newer;
+            return sg;
+        };
+        // the point's pFeatures in camera c gets (more of) a chain on dead tracks: a stale head when it holds no feature there, else segments
+        // linked behind the live feature's own track (whose oldest node is `liveOldest`, `liveL` frames long)
+        auto give_chain = [&](int p, int c, FeaturePoint* liveOldest, int liveL, bool isStatic) {
+            const std::pair<int, int> key(p, c);
+            int j = liveOldest ? liveL + (int)(urand() * 3) : 1 + (int)(urand() * 5);
+            const int want = 1 + (urand() < 0.35 ? 1 : 0);
+            FeaturePoint* link = liveOldest;
+            for (int q = 0; q < want && j + 1 < Hh; ++q) {
+                int L = 1 + (int)(urand() * 5);
+                if (j + L > Hh) L = Hh - j;
+                DeadSeg sg = add_dead(c, pts[p].X, j, L, isStatic, pts[p].mp, p);
+                if (link) link->preFrame = sg.newest, sg.newest->nextFrame = link;
+                else pts[p].mp->pFeatures[c] = sg.newest, staleHead[key] = 1, staleStatic[key] = isStatic ? 1 : 0;
+                link = sg.oldest;
+                dead[key].push_back(sg);
+                j += L + 1 + (int)(urand() * 3);
+            }
+        };
         auto new_point = [&](const double* X, int kind) {
             Pt P;
             memcpy(P.X, X, 24);
@@ -187,9 +249,15 @@ int main(int argc, char** argv) {
                 if (c == nCams - 1 && nHas == 0) r = 0;   // every point is in the current list through at least one camera
                 const int L = 2 + (int)(urand() * (Hh - 2));
                 if (r < 0.42) {
-                    const int s = add_track(c, X, L, !dk, pts[p].mp, p, 0, 0);
+                    const int Lh = relink && urand() < 0.3 ? 1 + (int)(urand() * 4) : L;   // (relink: a short live track with the OLD chain linked behind it)
+                    const int s = add_track(c, X, relink ? Lh : L, !dk, pts[p].mp, p, 0, 0);
                     pts[p].mp->pFeatures[c] = slots[c][s].tail;
                     ++nHas;
+                    if (relink && Lh != L) {
+                        FeaturePoint* o = slots[c][s].tail;
+                        while (o->preFrame) o = o->preFrame;
+                        give_chain(p, c, o, Lh, !dk);
+                    }
                     if (twin && urand() < 0.5) {   // the twin holds a feature of its own in this camera
                         const int s2 = add_track(c, pts[p2].X, L, !dk, pts[p2].mp, p2, 0, 0);
                         pts[p2].mp->pFeatures[c] = slots[c][s2].tail;
@@ -211,6 +279,12 @@ int main(int argc, char** argv) {
                     }
                 }
             }
+            if (relink)   // cameras in which the point holds no feature of this frame: some keep a stale one
+                for (int c = 0; c < nCams; ++c) {
+                    double m[2];
+                    if (!pts[p].mp->pFeatures[c] && project(c, 0, X, m) && urand() < 0.4) give_chain(p, c, nullptr, 0, !dk);
+                    if (twin && !pts[p2].mp->pFeatures[c] && project(c, 0, pts[p2].X, m) && urand() < 0.3) give_chain(p2, c, nullptr, 0, !dk);
+                }
             if (twin) {   // make sure the twin is in the current list too
                 bool any = false;
                 for (int c = 0; c < nCams; ++c) any |= pts[p2].mp->pFeatures[c] != nullptr;
@@ -266,6 +340,14 @@ int main(int argc, char** argv) {
                     if (slots[c][q].tail == mp->pFeatures[c]) s = q;
                 puti(f, mp->pFeatures[c] ? s : -1);
             }
+            if (relink)
+                for (int c = 0; c < nCams; ++c) {
+                    const std::pair<int, int> key(p, c);
+                    puti(f, staleHead.count(key) ? 1 : 0), puti(f, staleStatic.count(key) ? staleStatic[key] : 1);
+                    const std::vector<DeadSeg>& v = dead[key];
+                    puti(f, (int)v.size());
+                    for (size_t q = 0; q < v.size(); ++q) puti(f, v[q].j0), puti(f, v[q].L), put(f, v[q].m.data(), v[q].m.size());
+                }
         }
         // ---- the reference
         const int nRegged = co->curStaticPointsRegInGroup(group, pixelVar, merge);
@@ -292,11 +374,23 @@ int main(int argc, char** argv) {
                         if (slots[c][q].tail == mp->pFeatures[c]) sIdx = q;
                 puti(f, sIdx);
             }
+            if (relink)
+                for (int c = 0; c < nCams; ++c) {
+                    const FeaturePoint* fp = mp->pFeatures[c];
+                    int staleOwner = -1, preOwner = -1;
+                    if (fp && fp->f != curFrame) staleOwner = deadOwner.count(fp) ? deadOwner[fp] : -2;
+                    if (fp && fp->f == curFrame) {   // the first dead-track node behind the live feature's own run of consecutive frames
+                        const FeaturePoint* o = fp;
+                        while (o->preFrame && !deadOwner.count(o->preFrame)) o = o->preFrame;
+                        if (o->preFrame) preOwner = deadOwner[o->preFrame];
+                    }
+                    puti(f, staleOwner), puti(f, preOwner);
+                }
         }
         for (int p = 0; p < nPts; ++p) nMerged += pts[p].mp->isFalse() && (p % 1 == 0) ? 1 : 0;
         tot[3] += nMerged;
-        printf("scene %d: %d cameras, %d slots, %d points (%d on the current list): %d static + %d dynamic points registered\n", sc, nCams, N, nPts,
-               co->curMapPts.getNum(), nRegged, nReggedDyn);
+        printf("scene %d: %d cameras, %d slots, %d points (%d on the current list): %d static + %d dynamic points registered; %d stale heads, %d dead-track segments\n",
+               sc, nCams, N, nPts, co->curMapPts.getNum(), nRegged, nReggedDyn, (int)staleHead.size(), (int)deadOwner.size());
         co->curMapPts.clearWithoutRelease();
     }
     fclose(f);

@@ -436,6 +436,143 @@ def decide_case():
     return out
 
 
+def decide_relink_case():
+    """the same with MapPoint::pFeatures as time leaves them (oracle/_ref/ref_decide_test golden_relink, CPU): stale heads and chains that
+    jump into older tracks, in two bMerge scenes and two plain ones.  Re-laid out the way the device holds them: every dead-track segment
+    on a slot of its own behind the frame's N slots (state -1 in this frame, its pixels in the history), featRef [nP][nC][4] = {slot, frame,
+    first, seg}, segPool [nC][cap][4] = {slot, last, first, next}, refStatic; deadOwner [nC][Ntot] = the point that owned a dead slot's chain.
+    Afterwards per (point, camera): ref_staleOwner (whose stale feature the point holds there, -1 none), ref_preOwner (whose dead-track chain
+    hangs directly behind the live feature it holds there, -1 none)."""
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_decide_test")
+    if not os.path.exists(exe):
+        raise SystemExit("oracle/_ref/ref_decide_test missing: run `make -C oracle` where /root/reference exists")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "d.bin")
+        subprocess.run([exe, "golden_relink", path], check=True, stdout=subprocess.DEVNULL)
+        raw = open(path, "rb").read()
+    o = [0]
+
+    def ints(n):
+        v = np.frombuffer(raw, dtype=np.int32, count=n, offset=o[0]).copy()
+        o[0] += 4 * n
+        return v
+
+    def dbls(n):
+        v = np.frombuffer(raw, dtype=np.float64, count=n, offset=o[0]).copy()
+        o[0] += 8 * n
+        return v
+
+    out = {}
+    (ns,) = ints(1)
+    out["n_scenes"] = np.int32(ns)
+    for sc in range(ns):
+        nC, Hh, N, nP, cur, W, H, with_dyn, with_merge = (int(v) for v in ints(9))
+        (pv,) = dbls(1)
+        k = lambda n: f"s{sc}_{n}"   # noqa: E731
+        out[k("dims")] = np.array([nC, Hh, N, nP, cur, W, H], np.int32)
+        out[k("with_dynamic")] = np.int32(with_dyn)   # curDynamicPointsRegInGroup ran behind the static points' registration
+        out[k("with_merge")] = np.int32(with_merge)   # bMerge == true: checkUnify at a conflict, the points unified on a yes
+        out[k("pixelVar")] = np.float64(pv)
+        K, hR, hT = np.zeros((nC, 9)), np.zeros((nC, Hh, 9)), np.zeros((nC, Hh, 3))
+        for c in range(nC):
+            K[c] = dbls(9)
+            for j in range(Hh):
+                hR[c, j], hT[c, j] = dbls(9), dbls(3)
+        out[k("K")], out[k("histR")], out[k("histT")] = K, hR, hT
+        hXY = np.zeros((nC, Hh, 2 * N))
+        span = np.full((nC, 2 * N), -1, np.int32)
+        state = np.full((nC, N), -1, np.int32)
+        is_static = np.ones((nC, N), np.uint8)
+        s2m = np.full((nC, N), -1, np.int32)
+        for c in range(nC):
+            for s in range(N):
+                L, st, m = (int(v) for v in ints(3))
+                if L == 0:
+                    continue
+                xy = dbls(2 * L).reshape(L, 2)
+                hXY[c, :L, s], hXY[c, :L, N + s] = xy[:, 0], xy[:, 1]
+                span[c, s], span[c, N + s] = cur - L + 1, cur
+                state[c, s], is_static[c, s], s2m[c, s] = (1 if L == 1 else 0), st, m
+        M, cov, fl, pf = np.zeros((nP, 3)), np.zeros((nP, 9)), np.zeros(nP, np.uint8), np.zeros((nP, nC), np.int32)
+        chains = {}
+        for p_ in range(nP):
+            M[p_], cov[p_] = dbls(3), dbls(9)
+            (f_,) = ints(1)
+            fl[p_] = f_
+            pf[p_] = ints(nC)
+            for c in range(nC):
+                stale, stat, nx = (int(v) for v in ints(3))
+                segs = []
+                for _ in range(nx):
+                    j0, L = (int(v) for v in ints(2))
+                    segs.append((j0, L, dbls(2 * L).reshape(L, 2)))
+                chains[(p_, c)] = (stale, stat, segs)
+        n_dead = [sum(len(chains[(p_, c)][2]) for p_ in range(nP)) for c in range(nC)]
+        Nt = N + max(n_dead)
+        hXY2 = np.full((nC, Hh, 2 * Nt), np.nan)
+        hXY2[:, :, :N], hXY2[:, :, Nt:Nt + N] = hXY[:, :, :N], hXY[:, :, N:]
+        span2 = np.full((nC, 2 * Nt), -1, np.int32)
+        span2[:, :N], span2[:, Nt:Nt + N] = span[:, :N], span[:, N:]
+        state2, stat2, s2m2 = np.full((nC, Nt), -1, np.int32), np.ones((nC, Nt), np.uint8), np.full((nC, Nt), -1, np.int32)
+        state2[:, :N], stat2[:, :N], s2m2[:, :N] = state, is_static, s2m
+        ref = np.full((nP, nC, 4), -1, np.int32)
+        ref[:, :, 1:3] = 0
+        pool = np.full((nC, max(max(n_dead), 1), 4), -1, np.int32)
+        rstat = np.ones((nP, nC), np.uint8)
+        dead_owner = np.full((nC, Nt), -1, np.int32)
+        nxt_slot, npool = [N] * nC, [0] * nC
+        for p_ in range(nP):
+            for c in range(nC):
+                stale, stat, segs = chains[(p_, c)]
+                placed = []
+                for j0, L, xy in segs:
+                    s_ = nxt_slot[c]
+                    nxt_slot[c] += 1
+                    hXY2[c, j0:j0 + L, s_], hXY2[c, j0:j0 + L, Nt + s_] = xy[:, 0], xy[:, 1]
+                    span2[c, s_], span2[c, Nt + s_] = cur - (j0 + L - 1), cur - j0
+                    stat2[c, s_] = stat
+                    dead_owner[c, s_] = p_
+                    placed.append((s_, cur - j0, cur - (j0 + L - 1)))
+                behind = placed[1:] if stale else placed       # (a stale head's own run is its first segment)
+                nxt = -1
+                for s_, last, first in reversed(behind):       # the oldest first: each names the one behind it
+                    pool[c, npool[c]] = (s_, last, first, nxt)
+                    nxt = npool[c]
+                    npool[c] += 1
+                if stale:
+                    ref[p_, c] = (placed[0][0], placed[0][1], placed[0][2], nxt)
+                    rstat[p_, c] = stat
+                elif pf[p_, c] >= 0:
+                    s_ = int(pf[p_, c])
+                    ref[p_, c] = (s_, cur, span[c, s_], nxt)
+                    rstat[p_, c] = is_static[c, s_]
+        out[k("dims")] = np.array([nC, Hh, Nt, nP, cur, W, H], np.int32)
+        out[k("n_live_slots")] = np.int32(N)
+        out[k("histXY")], out[k("trackSpan")], out[k("state")], out[k("isStatic")], out[k("slot2map")] = hXY2, span2, state2, stat2, s2m2
+        out[k("featRef")], out[k("segPool")], out[k("refStatic")], out[k("deadOwner")] = ref, pool, rstat, dead_owner
+        out[k("M")], out[k("cov")], out[k("flags")], out[k("pointFeat")] = M, cov, fl, pf
+        nreg, nreg_dyn = (int(v) for v in ints(2))
+        out[k("ref_regged")], out[k("ref_regged_dynamic")] = np.int32(nreg), np.int32(nreg_dyn)
+        rs2m = np.full((nC, Nt), -1, np.int32)
+        rs2m[:, :N] = ints(nC * N).reshape(nC, N)
+        out[k("ref_slot2map")] = rs2m
+        R = dbls(12 * nP).reshape(nP, 12)
+        out[k("ref_M")], out[k("ref_cov")] = R[:, :3], R[:, 3:]
+        rfl, rpf = np.zeros(nP, np.uint8), np.zeros((nP, nC), np.int32)
+        r_stale, r_pre = np.full((nP, nC), -1, np.int32), np.full((nP, nC), -1, np.int32)
+        for p_ in range(nP):
+            after = ints(1 + nC)
+            rfl[p_], rpf[p_] = after[0], after[1:]
+            so = ints(2 * nC).reshape(nC, 2)
+            r_stale[p_], r_pre[p_] = so[:, 0], so[:, 1]
+        out[k("ref_flags")], out[k("ref_pointFeat")], out[k("ref_staleOwner")], out[k("ref_preOwner")] = rfl, rpf, r_stale, r_pre
+    assert o[0] == len(raw)
+    return out
+
+
 def mergability_case():
     """the reference's own CoSLAM::staticCheckMergability (oracle/_ref/ref_mergability_test golden, CPU): 150 tracks of 1..24
     frames, newest first, and its verdicts."""
@@ -1125,7 +1262,7 @@ def cgklt_cases():
 if __name__ == "__main__":
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libintracam_ref.so missing: run `make -C oracle` where /root/reference exists")
-    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "mergability_long", "update_points", "update_points_relink", "keyframe", "intracam_newpts", "classify", "classify_relink", "intercam", "newpts", "decide", "cgklt"]
+    which = sys.argv[1:] or ["pose", "klt", "ba", "register", "ncc", "posegraph", "export", "mergability", "mergability_long", "update_points", "update_points_relink", "keyframe", "intracam_newpts", "classify", "classify_relink", "intercam", "decide_relink", "newpts", "decide", "cgklt"]
     if "pose" in which:
         np.savez_compressed(os.path.join(HERE, "pose_golden.npz"), **pose_cases())
     if "klt" in which:
@@ -1154,6 +1291,8 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "keyframe_golden.npz"), **keyframe_case())
     if "classify_relink" in which:
         np.savez_compressed(os.path.join(HERE, "classify_relink_golden.npz"), **classify_relink_case())
+    if "decide_relink" in which:
+        np.savez_compressed(os.path.join(HERE, "decide_relink_golden.npz"), **decide_relink_case())
     if "update_points_relink" in which:
         np.savez_compressed(os.path.join(HERE, "update_points_relink_golden.npz"), **update_points_relink_case())
     if "classify" in which:

@@ -425,6 +425,109 @@ def test_device_registration_on_the_reference_golden_scenes(hip):
     assert dyn_total > 30 and merged_total > 40
 
 
+def test_registration_step_for_step_over_feature_references_reproduces_the_reference(hip):
+    """tests/golden/decide_relink_golden.npz: the reference's own curStaticPointsRegInGroup / curDynamicPointsRegInGroup (bMerge in two of the
+    four scenes) over MapPoint::pFeatures as time leaves them -- 640 stale heads, 540 chains that jump into older tracks.  A camera in which
+    a point holds a stale feature is searched again and a new feature there gets the OLD chain linked behind it (SL_CoSLAM.cpp:775-779);
+    refineMapPoint and checkUnify take stale features as views; at a unification a stale feature blocks the hand-over in its camera and the
+    other point's stale features move too (:806-816).  The step-for-step mode over the feature references (cs_feat_ref_advance_dev +
+    cs_refine_map_points_ref_dev between the cameras' loops; cs_track_history_set_merge_refs for the bMerge walks) ends where the reference
+    does: owners, features, positions and covariances bit for bit, the flags, whose stale feature every point holds where, whose old chain
+    hangs behind every live feature."""
+    import torch
+
+    from coslam_amd.poseupdate import TrackHistory
+    from coslam_amd.register import register_cams, register_cur_static_sequential_dev, register_decide_scratch_bytes, register_passes
+    from tests.test_oracle_cpu import _decide_scene
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decide_relink_golden.npz"))
+    dev = torch.device("cuda:0")
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)   # noqa: E731
+    s_ = torch.cuda.current_stream().cuda_stream
+    relinked = moved = merged_total = 0
+    for sc in range(int(g["n_scenes"])):
+        S = _decide_scene(g, sc)
+        G = lambda k: g[f"s{sc}_{k}"]   # noqa: E731
+        nC, N, nP, Hh = S["nC"], S["N"], S["nP"], S["hR"].shape[1]
+        cur = int(g[f"s{sc}_dims"][4])
+        hXY = np.nan_to_num(S["hXY"], nan=-1e9)
+        th = TrackHistory(nC, N, Hh + 3)
+        dK, diK = d(S["K"]), d(S["iK"])
+        dxy, dstate, ds2m = d(hXY[:, 0]), d(S["state"]), d(S["s2m"])
+        dspan, dstat, drep = d(S["span"]), d(S["st"]), torch.zeros((nC, N), dtype=torch.float64, device=dev)
+        ddyn = d((1 - S["st"]).astype(np.uint8))
+        dfl0 = d(S["fl"])
+        eye = d(np.tile(np.eye(3).reshape(9), (nC, 1)))
+        zero = torch.zeros((nC, 3), dtype=torch.float64, device=dev)
+        scratch = torch.ones((nC, N), dtype=torch.uint8, device=dev)
+        none = torch.full((nC, N), -1, dtype=torch.int32, device=dev)
+        keep = []
+        for j in range(Hh - 1, -1, -1):   # the ring, oldest first; a slot is alive from its segment's first to its last frame
+            f = cur - j
+            xyj = d(hXY[:, j])
+            stj = d(((S["span"][:, :N] >= 0) & (S["span"][:, :N] <= f) & (f <= S["span"][:, N:])).astype(np.int32) - 1)
+            keep += [xyj, stj]
+            cj = [dict(K=dK[c].data_ptr(), iK=diK[c].data_ptr(), xy=xyj[c].data_ptr(), state=stj[c].data_ptr(), slot2map=none[c].data_ptr(),
+                       trackSpan=dspan[c].data_ptr(), isStatic=scratch[c].data_ptr()) for c in range(nC)]
+            th.detect_dynamic_dev(s_, cj, eye.data_ptr(), zero.data_ptr(), nP, dfl0.data_ptr(), f, minLen=1 << 30)
+        cam_i = np.repeat(np.arange(nC), Hh).astype(np.int32)
+        frm_i = np.tile(cur - np.arange(Hh), nC).astype(np.int32)
+        dp = [d(a) for a in (cam_i, frm_i, S["hR"].reshape(-1, 9), S["hT"].reshape(-1, 3))]
+        th.set_poses_dev(s_, len(cam_i), *[x.data_ptr() for x in dp])
+        torch.cuda.synchronize()
+        th.load_segments(G("segPool"))
+        cams = [dict(K=dK[c].data_ptr(), iK=diK[c].data_ptr(), xy=dxy[c].data_ptr(), state=dstate[c].data_ptr(), slot2map=ds2m[c].data_ptr(),
+                     trackSpan=dspan[c].data_ptr(), reprojErr=drep[c].data_ptr(), isStatic=dstat[c].data_ptr()) for c in range(nC)]
+        dM, dcov, dfl, dpf = d(S["M"]), d(S["cov"]), d(S["fl"]), d(S["pf"])
+        dref, drstat = d(G("featRef")), d(G("refStatic"))
+        out = dict(slot=torch.zeros((nP, nC), dtype=torch.int32, device=dev), m=torch.zeros((nP, nC, 2), dtype=torch.float64, device=dev),
+                   var=torch.zeros((nP, nC, 4), dtype=torch.float64, device=dev), dist=torch.zeros((nP, nC), dtype=torch.float64, device=dev),
+                   flags=torch.zeros((nP, nC), dtype=torch.int32, device=dev))
+        dR0, dT0 = d(S["hR"][:, 0]), d(S["hT"][:, 0])
+        rc = register_cams([dict(K=dK[c].data_ptr(), R=dR0[c].data_ptr(), t=dT0[c].data_ptr(), xy=dxy[c].data_ptr(), state=dstate[c].data_ptr(),
+                                 slot2map=ds2m[c].data_ptr(), isDynamic=ddyn[c].data_ptr()) for c in range(nC)])
+        passes = register_passes([dict(P=nP, sigmaSearch=S["pv"], maxDist=3 * S["pv"], sigmaMerge=S["pv"], M=dM.data_ptr(), cov=dcov.data_ptr(),
+                                       pointFeat=dpf.data_ptr(), slot=out["slot"].data_ptr(), m=out["m"].data_ptr(), var=out["var"].data_ptr(),
+                                       dist=out["dist"].data_ptr(), flags=out["flags"].data_ptr(),
+                                       **(dict(mapFlags=dfl.data_ptr(), maxDistDynamic=4 * S["pv"]) if S["with_dyn"] else {}))])
+        dmerge = torch.zeros((nP, nC), dtype=torch.uint8, device=dev)
+        datt, dreg = torch.zeros((nP, nC), dtype=torch.uint8, device=dev), torch.zeros(nP, dtype=torch.uint8, device=dev)
+        dscr = torch.zeros(register_decide_scratch_bytes(nC, N, nP), dtype=torch.uint8, device=dev)
+        dcnt = torch.zeros(4, dtype=torch.int32, device=dev)
+        dmscr = torch.zeros(nP, dtype=torch.uint8, device=dev)
+        if S["with_merge"]:
+            th.set_merge_refs(dref.data_ptr(), drstat.data_ptr())
+        register_cur_static_sequential_dev(s_, th, cams, rc, N, S["W"], S["H"], passes, nP, out["slot"].data_ptr(), out["flags"].data_ptr(),
+                                           dmerge.data_ptr(), dfl.data_ptr(), dpf.data_ptr(), [ds2m[c].data_ptr() for c in range(nC)], datt.data_ptr(),
+                                           dreg.data_ptr(), dscr.data_ptr(), dM.data_ptr(), dcov.data_ptr(), S["pv"], d_counts=dcnt.data_ptr(),
+                                           with_dynamic=S["with_dyn"], merge=S["with_merge"], d_merge_scratch=dmscr.data_ptr(),
+                                           d_featRef=dref.data_ptr(), d_refStatic=drstat.data_ptr(), curFrame=cur)
+        torch.cuda.synchronize()
+        s2m, pf, ref = ds2m.cpu().numpy(), dpf.cpu().numpy(), dref.cpu().numpy()
+        pool = th.segments()
+        assert np.array_equal(s2m, S["ref_s2m"]), f"scene {sc}: {int((s2m != S['ref_s2m']).sum())} owners differ"
+        assert np.array_equal(dfl.cpu().numpy(), S["ref_fl"]) and np.array_equal(pf, S["ref_pf"]), f"scene {sc}: flags / features"
+        dMn, dCn = dM.cpu().numpy(), dcov.cpu().numpy()
+        bad = np.nonzero((dMn != S["ref_M"]).any(axis=1))[0]
+        assert np.array_equal(dMn, S["ref_M"]) and np.array_equal(dCn, S["ref_cov"]), f"scene {sc}: positions differ at {bad[:8]} ({len(bad)})"
+        owner = G("deadOwner")
+        stale_o, pre_o = np.full((nP, nC), -1, np.int32), np.full((nP, nC), -1, np.int32)
+        for p_ in range(nP):
+            for c in range(nC):
+                sl, fr, _, sg = ref[p_, c]
+                if pf[p_, c] < 0 and sl >= 0 and fr < cur:
+                    stale_o[p_, c] = owner[c, sl]
+                if pf[p_, c] >= 0 and sg >= 0:
+                    pre_o[p_, c] = owner[c, pool[c, sg, 0]]
+        assert np.array_equal(stale_o, G("ref_staleOwner")), f"scene {sc}: stale features held differ at {np.argwhere(stale_o != G('ref_staleOwner'))[:6].tolist()}"
+        assert np.array_equal(pre_o, G("ref_preOwner")), f"scene {sc}: chains behind live features differ at {np.argwhere(pre_o != G('ref_preOwner'))[:6].tolist()}"
+        relinked += int(((G("pointFeat") < 0) & (G("featRef")[:, :, 0] >= 0) & (pf >= 0) & (pre_o >= 0)).sum())
+        moved += int(((stale_o >= 0) & (stale_o != np.arange(nP)[:, None])).sum())
+        merged_total += int((((S["ref_fl"] & 2) != 0) & ((S["fl"] & 2) == 0)).sum())
+        th.close()
+    assert relinked > 30 and moved >= 5 and merged_total > 40, (relinked, moved, merged_total)
+
+
 def test_keyframe_decision_reproduces_the_reference(hip):
     """cs_keyframe_ready_dev against tests/golden/keyframe_golden.npz (VERDICT r04 missing 7): the reference's own
     CoSLAM::IsReadyForKeyFrame and helpers (src/app/SL_CoSLAM.cpp:1224-1279, SL_SingleSLAM.cpp:121-136, :825-834, SL_SLAMHelper.cpp:201-217,

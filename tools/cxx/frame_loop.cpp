@@ -436,6 +436,7 @@ int main(int argc, char** argv) {
     CSCHK(cs_ba_output_attach(bout, joint.ws));
     if (chains) CSCHK(cs_ba_output_set_feat_refs(bout, dFref, dRstat));
     if (chains && !getenv("COSLAM_CLASSIFY_PLAIN")) CSCHK(cs_track_history_set_classify_refs(hist, (cs_feat_ref*)dFref, dRstat));   // mapPointsClassify over the references
+    if (chains && !getenv("COSLAM_MERGE_PLAIN")) CSCHK(cs_track_history_set_merge_refs(hist, (cs_feat_ref*)dFref, dRstat));         // ... and the bMerge walks
     (void)pgFixed, (void)pgR, (void)pgT, (void)pgCam, (void)pgEdges;   // (the file's pre-baked camera graphs: the graphs are built live now)
     struct Due {
         int frame, firstKey;
