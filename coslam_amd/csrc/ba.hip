@@ -2738,6 +2738,7 @@ struct BaAsyncJob {
     struct cs_ba_intercam* ic = nullptr;             // cs_ba_solve_intercam_async: the problem sits in staging record icSlot
     int icSlot = 0;
     int winCount = 0, winSlotOf[16], winFrames[16];  // the window as it stood when the solve was requested (oldest first)
+    long long winNewest = -1;                        // the push count of its newest key frame (cs_ba_window::pendingNewest)
 };
 
 struct BaWorker {
@@ -2900,6 +2901,12 @@ struct cs_ba_window {
     std::mutex mu;       // parsesPending / lastFrames: the requesting thread and the worker
     std::condition_variable cv;
     int parsesPending;   // solves requested whose parse has not read the ring yet
+    // ... and WHICH: the push count of each pending request's newest key frame.  Push n rewrites the slot of push n - ring, which a request whose
+    // newest key frame is push m still reads when m - nKf + 1 <= n - ring, i.e. m < n - WIN_SLACK.  (Counting the pending requests alone is the
+    // same thing only when every push is followed by a request: with the windows dealt round the ranks a rank requests every N-th one, and a
+    // loop that places a key frame per frame then rewrote slots under a parse -- found by the two-rank run of the key-frame decision, round 6.)
+    long long pushCount;
+    std::deque<long long> pendingNewest;
     int lastFrames[16], lastCount;
     unsigned char* slab;
     double *xy, *K, *R, *t;
@@ -2993,6 +3000,7 @@ static int ba_worker_run_window_inner(cs_ba* b, BaWorker* w, const BaAsyncJob& J
     }
     struct ParseDone {   // whatever way this function is left: the ring is free for the pushes that wait for this parse
         cs_ba_window* w;
+        long long newest;
         bool done = false;
         void release() {
             if (done) return;
@@ -3000,11 +3008,16 @@ static int ba_worker_run_window_inner(cs_ba* b, BaWorker* w, const BaAsyncJob& J
             {
                 std::lock_guard<std::mutex> lk(w->mu);
                 w->parsesPending -= 1;
+                for (auto it = w->pendingNewest.begin(); it != w->pendingNewest.end(); ++it)
+                    if (*it == newest) {
+                        w->pendingNewest.erase(it);
+                        break;
+                    }
             }
             w->cv.notify_all();
         }
         ~ParseDone() { release(); }
-    } parseDone{win};
+    } parseDone{win, J.winNewest};
     if (J.winCount < 1) {
         cs_set_error("cs_ba_solve_window_async: the window holds no key frame");
         return CS_ERR_INVALID;
@@ -4022,6 +4035,7 @@ cs_ba_window* cs_ba_window_create(int device, int nCams, int nKeyFrames, int N, 
     w->device = device, w->nCams = nCams, w->nKf = nKeyFrames, w->N = N, w->nMap = nMapPts;
     w->ring = nKeyFrames + WIN_SLACK;
     w->head = w->count = w->parsesPending = w->lastCount = w->snapNext = 0;
+    w->pushCount = 0;
     w->lastC = w->lastP = w->lastObs = 0;
     w->slab = nullptr, w->h_totals = w->h_plan = nullptr;
     const size_t KC = (size_t)w->ring * nCams, KW = (size_t)nKeyFrames * nCams, nPairs = KW * (KW + 1) / 2;
@@ -4084,7 +4098,9 @@ int cs_ba_window_push_dev(cs_ba_window* w, void* hip_stream, const cs_handback_c
     const int slot = w->head;
     {   // the slot about to be rewritten belongs to the window of the request WIN_SLACK + 1 pushes back: wait for its parse
         std::unique_lock<std::mutex> lk(w->mu);
-        w->cv.wait(lk, [&] { return w->parsesPending <= WIN_SLACK; });
+        const long long n = w->pushCount;
+        w->cv.wait(lk, [&] { return w->parsesPending <= WIN_SLACK && (w->pendingNewest.empty() || w->pendingNewest.front() >= n - WIN_SLACK); });
+        w->pushCount = n + 1;
     }
     const size_t base = (size_t)slot * w->nCams;
     WinSnapArgs A;
@@ -4202,6 +4218,8 @@ static int ba_solve_window_async(cs_ba* b, cs_ba_window* w, void* after_stream, 
     {   // (behind everything that can fail: a request that is counted is a request the worker will release)
         std::lock_guard<std::mutex> lk(w->mu);
         w->parsesPending += 1;
+        w->pendingNewest.push_back(w->pushCount - 1);
+        J.winNewest = w->pushCount - 1;
     }
     {
         std::lock_guard<std::mutex> lk(b->worker->mu);

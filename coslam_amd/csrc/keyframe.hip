@@ -130,7 +130,36 @@ __global__ __launch_bounds__(64) void k_keyframe_sum(KfArgs A) {
     }
 }
 
+// what a key frame's push would read of this frame, and the decision word, into one slot of a caller's ring: ONE launch (cs_keyframe_snapshot_dev)
+__global__ __launch_bounds__(256) void k_keyframe_snapshot(int nXY, int nSt, int nR, int nT, const double* __restrict__ xy, const int* __restrict__ st,
+                                                           const int* __restrict__ s2m, const double* __restrict__ R, const double* __restrict__ t,
+                                                           const int* __restrict__ word, double* __restrict__ oxy, int* __restrict__ ost,
+                                                           int* __restrict__ os2m, double* __restrict__ oR, double* __restrict__ ot, int* hostWord) {
+    const int q = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    for (int i = q; i < nXY; i += stride) oxy[i] = xy[i];
+    for (int i = q; i < nSt; i += stride) ost[i] = st[i], os2m[i] = s2m[i];
+    for (int i = q; i < nR; i += stride) oR[i] = R[i];
+    for (int i = q; i < nT; i += stride) ot[i] = t[i];
+    if (q == 0) __hip_atomic_store(hostWord, *word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (pinned host memory: seen behind the stream's next event)
+}
+
 }  // namespace
+
+extern "C" int cs_keyframe_snapshot_dev(int device, void* hip_stream, int nCams, int N, const double* d_xy, const int* d_state, const int* d_slot2map,
+                                        const double* d_R, const double* d_t, const int* d_word, double* d_xyOut, int* d_stateOut, int* d_slot2mapOut,
+                                        double* d_ROut, double* d_tOut, int* h_word) {
+    if (nCams < 1 || N < 1 || !d_xy || !d_state || !d_slot2map || !d_R || !d_t || !d_word || !d_xyOut || !d_stateOut || !d_slot2mapOut || !d_ROut ||
+        !d_tOut || !h_word) {
+        cs_set_error("cs_keyframe_snapshot_dev: bad arguments");
+        return CS_ERR_INVALID;
+    }
+    CS_HIP(hipSetDevice(device));
+    const int nXY = nCams * 2 * N;
+    hipLaunchKernelGGL(k_keyframe_snapshot, dim3((nXY + 255) / 256 < 64 ? (nXY + 255) / 256 : 64), dim3(256), 0, (hipStream_t)hip_stream, nXY, nCams * N,
+                       9 * nCams, 3 * nCams, d_xy, d_state, d_slot2map, d_R, d_t, d_word, d_xyOut, d_stateOut, d_slot2mapOut, d_ROut, d_tOut, h_word);
+    CS_CHECK_LAUNCH();
+    return CS_OK;
+}
 
 extern "C" int cs_keyframe_ready_dev(int device, void* hip_stream, int nCams, int N, const cs_keyframe_cam* cams, int nMap, const double* d_mapPts,
                                      const unsigned char* d_mapFlags, const int* d_firstFrame, int curFrame, double ratio,

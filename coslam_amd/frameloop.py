@@ -609,11 +609,12 @@ class FrameLoop:
         """frame i's decision word, records and poses into its ring slot, on the pose stream; no host wait"""
         k, torch, NA = self.kf, self.torch, self.cfg.n_cams
         sl = self._kf_lag_ring()[i % (self.cfg.keyframe_lag + 1)]
-        with torch.cuda.stream(self.pose_s):
-            sl["xy"].copy_(self.d_xy, non_blocking=True), sl["st"].copy_(self.d_state, non_blocking=True), sl["s2m"].copy_(self.d_slot2map, non_blocking=True)
-            sl["R"].copy_(self.d_R[dst].view(NA, 9), non_blocking=True), sl["t"].copy_(self.d_t[dst].view(NA, 3), non_blocking=True)
-            sl["word"].copy_(k["ready"][NA + 1:NA + 2], non_blocking=True)
-            sl["ev"].record(self.pose_s)
+        from coslam_amd.keyframe import keyframe_snapshot_dev
+
+        keyframe_snapshot_dev(self.pose_s.cuda_stream, NA, self.cfg.n_feat, self.d_xy.data_ptr(), self.d_state.data_ptr(), self.d_slot2map.data_ptr(),
+                              self.d_R[dst].data_ptr(), self.d_t[dst].data_ptr(), k["ready"][NA + 1:].data_ptr(), sl["xy"].data_ptr(), sl["st"].data_ptr(),
+                              sl["s2m"].data_ptr(), sl["R"].data_ptr(), sl["t"].data_ptr(), sl["word"].data_ptr(), device=self.device)
+        sl["ev"].record(self.pose_s)
         sl["frame"] = i
 
     def _kf_lag_act(self, i, dst):

@@ -695,6 +695,14 @@ int cs_keyframe_ready_dev(int device, void* hip_stream, int nCams, int N, const 
                           const unsigned char* d_mapFlags, const int* d_firstFrame, int curFrame, double ratio, double minViewAngleDeg,
                           double minTranslation, int addKeyFrame, int* d_ready, int* d_mapped, double* d_center, int* d_stats);
 
+/* A frame loop whose key frames the decision places WITHOUT a host wait per frame: behind a frame's registration, what a key
+ * frame's push would read of it -- every camera's xy [nCams][2N], state and slot2map [nCams][N], the poses [nCams][9] / [3] -- into one slot of
+ * the caller's ring of snapshots, and the decision word (d_word = cs_keyframe_ready_dev's d_ready + nCams + 1) into PINNED host memory
+ * (h_word: hipHostMalloc'ed, read by the host behind an event it records next on the stream).  One launch. */
+int cs_keyframe_snapshot_dev(int device, void* hip_stream, int nCams, int N, const double* d_xy, const int* d_state, const int* d_slot2map,
+                             const double* d_R, const double* d_t, const int* d_word, double* d_xyOut, int* d_stateOut, int* d_slot2mapOut,
+                             double* d_ROut, double* d_tOut, int* h_word);
+
 /* ---- MapPoint::pFeatures as the reference holds them: feature references (round 5; VERDICT r04 missing 3) ---------------------------------
  * p->pFeatures[c] is the feature of this frame while camera c tracks the point -- and STAYS what it last was when the camera loses it
  * (nothing clears the pointer): updateStaticPointPosition / updateDynamicPointPosition (src/slam/SL_CoSLAMHelper.cpp:338-394, 455-484),

@@ -774,12 +774,8 @@ int main(int argc, char** argv) {
         if (kfDrives) {
             // this frame's decision word, records and poses into slot i % (LAG + 1) of the ring (no host wait), then the decision of frame i - LAG
             KfSnap& sn = kfRing[i % (kfLag + 1)];
-            HIPCHK(hipMemcpyAsync(sn.xy, dXY, sizeof(double) * (size_t)nCams * 2 * N, hipMemcpyDeviceToDevice, poseS));
-            HIPCHK(hipMemcpyAsync(sn.st, dState, sizeof(int) * (size_t)nCams * N, hipMemcpyDeviceToDevice, poseS));
-            HIPCHK(hipMemcpyAsync(sn.s2m, dS2M, sizeof(int) * (size_t)nCams * N, hipMemcpyDeviceToDevice, poseS));
-            HIPCHK(hipMemcpyAsync(sn.R, dR[dsti], sizeof(double) * 9 * nCams, hipMemcpyDeviceToDevice, poseS));
-            HIPCHK(hipMemcpyAsync(sn.t, dT[dsti], sizeof(double) * 3 * nCams, hipMemcpyDeviceToDevice, poseS));
-            HIPCHK(hipMemcpyAsync(sn.word, dKfReady + nCams + 1, sizeof(int), hipMemcpyDeviceToHost, poseS));
+            CSCHK(cs_keyframe_snapshot_dev(dev, (void*)poseS, nCams, N, dXY, dState, dS2M, dR[dsti], dT[dsti], dKfReady + nCams + 1, sn.xy, sn.st, sn.s2m, sn.R,
+                                           sn.t, sn.word));
             HIPCHK(hipEventRecord(sn.ev, poseS));
             sn.frame = i;
             const int f = i - kfLag;
