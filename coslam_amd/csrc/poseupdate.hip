@@ -456,7 +456,8 @@ struct MgCache {   // 48 bytes, zero = empty
     int upto;      // the tail covers frames f1 .. upto
     int ok;        // AND of the tail's terms
     double M[3];   // the point the terms were judged with
-    double pad;
+    int epoch;     // the history's tail-rewrite epoch the terms were judged in (see MgRunArgs::epoch)
+    int pad;
 };
 static_assert(sizeof(MgCache) == 48, "cs_register_mergability_cache_bytes");
 struct MgRunArgs {
@@ -464,6 +465,11 @@ struct MgRunArgs {
     int W, count, curFrame;  // window depth, frames the ring holds, frame number of the ring's head
     double tolPix;
     MgCache* cache;          // [P][nCams]
+    // poses of TAIL frames rewritten behind a cached verdict (an apply whose window reaches further back than the walk depth: the key frames the
+    // decision places can lie hundreds of frames apart): the history counts such rewrites (epoch) and keeps the oldest frame any of them touched
+    // (fromMin).  A cached tail stands if it was judged in this epoch or ends before fromMin; else it is walked again.  (The fixed cadence never
+    // rewrites a tail frame: epoch stays 0.  ADVICE r05.)
+    int epoch, fromMin;
     int* counts;             // [4] or null: cache hits, full tail walks, verdicts 2, tail terms evaluated
     const int* list;         // null, or the rows to judge: list[0 .. nList), entries < 0 skipped
     int nList;
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(256) void k_register_mergability_running(MgRunArgs 
             const PuProj q0 = pu_project(C.K, mg_pose, mg_pose + 9, M), q1 = pu_project(C.K, mg_pose, mg_pose + 9, e.M);
             const double du = q0.u / q0.w - q1.u / q1.w, dv = q0.v / q0.w - q1.v / q1.w;
             hit = e.slot1 == s + 1 && e.f1 == f1 && e.upto >= f1 - 1 && e.upto <= end && q0.w > 0 && q1.w > 0 &&
-                  du * du + dv * dv <= B.tolPix * B.tolPix;
+                  du * du + dv * dv <= B.tolPix * B.tolPix && (e.epoch == B.epoch || e.upto < B.fromMin);
             const int start = hit ? e.upto + 1 : f1;
             tailOK = hit ? e.ok != 0 : true;
             const bool shortGap = end - start + 1 <= MG_GAP_MAX;
@@ -576,14 +582,14 @@ __global__ __launch_bounds__(256) void k_register_mergability_running(MgRunArgs 
             if (wrote && r == 0) {
                 MgCache w;
                 w.slot1 = s + 1, w.f1 = f1, w.upto = end, w.ok = tailOK ? 1 : 0;
-                w.M[0] = hit ? e.M[0] : M[0], w.M[1] = hit ? e.M[1] : M[1], w.M[2] = hit ? e.M[2] : M[2], w.pad = 0;
+                w.M[0] = hit ? e.M[0] : M[0], w.M[1] = hit ? e.M[1] : M[1], w.M[2] = hit ? e.M[2] : M[2], w.epoch = B.epoch, w.pad = 0;
                 *E = w;
             }
         } else if (len > 0 && r == 0) {
             // the track still fits the window: an empty tail, judged with the point as it stands
             MgCache w;
             w.slot1 = s + 1, w.f1 = f1, w.upto = f1 - 1, w.ok = 1;
-            w.M[0] = M[0], w.M[1] = M[1], w.M[2] = M[2], w.pad = 0;
+            w.M[0] = M[0], w.M[1] = M[1], w.M[2] = M[2], w.epoch = B.epoch, w.pad = 0;
             B.cache[(size_t)p * A.nCams + c] = w;
         }
     }
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(256) void k_register_mergability_running(MgRunArgs 
             const bool fresh = m.start == C.trackSpan[m.s];
             MgCache w;
             w.slot1 = m.s + 1, w.f1 = C.trackSpan[m.s], w.upto = m.end, w.ok = ok ? 1 : 0;
-            w.M[0] = fresh ? M[0] : E->M[0], w.M[1] = fresh ? M[1] : E->M[1], w.M[2] = fresh ? M[2] : E->M[2], w.pad = 0;
+            w.M[0] = fresh ? M[0] : E->M[0], w.M[1] = fresh ? M[1] : E->M[1], w.M[2] = fresh ? M[2] : E->M[2], w.epoch = B.epoch, w.pad = 0;
             *E = w;
             A.out[(size_t)m.p * A.nCams + c] = ok ? 1 : 0;   // (its window passed: that is why it was listed)
         }
@@ -1939,6 +1945,8 @@ struct cs_track_history {
     // cs_track_history_set_merge_refs: the bMerge walks read and write them
     int4* mergeFeatRef;
     unsigned char* mergeRefStatic;
+    // poses rewritten in frames older than the walk depth (the running mergability verdict's cached tails: MgRunArgs::epoch)
+    mutable int tailEpoch = 0, tailFromMin = 0x7fffffff;
 };
 
 // the camera centres by walk depth, if the ring's poses changed since they were last computed
@@ -2232,6 +2240,7 @@ extern "C" int cs_register_mergability_running_list_dev(const cs_track_history* 
         A.cam[c] = cams[c];
     }
     B.W = hist_walk(h), B.count = h->count, B.curFrame = h->lastFrame;
+    B.epoch = h->tailEpoch, B.fromMin = h->tailFromMin;
     B.tolPix = tolPix;
     B.cache = (MgCache*)d_cache;
     B.counts = d_counts;
@@ -2250,6 +2259,7 @@ extern "C" int cs_track_history_set_poses_dev(cs_track_history* h, void* hip_str
     }
     if (n == 0 || h->count < 1) return CS_OK;
     h->ringVersion += 1;
+    h->tailEpoch += 1, h->tailFromMin = -0x7fffffff;   // (which frames: only the device knows -- every cached tail is walked again)
     CS_HIP(hipSetDevice(h->device));
     hipLaunchKernelGGL(k_history_set_poses, dim3((n * 12 + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, n, d_cam, d_frame, d_R, d_t,
                        h->R, h->t, h->nCams, h->H, h->head, h->count, h->lastFrame);
@@ -2269,7 +2279,13 @@ int hist_span(const char* who, cs_track_history* h, void* hip_stream, int set, i
                      h->count, h->lastFrame);
         return CS_ERR_INVALID;
     }
-    if (set) h->ringVersion += 1;
+    if (set) {
+        h->ringVersion += 1;
+        if (firstFrame <= h->lastFrame - h->walkLen) {   // tail frames rewritten: the cached verdicts that cover them are stale
+            h->tailEpoch += 1;
+            if (firstFrame < h->tailFromMin) h->tailFromMin = firstFrame;
+        }
+    }
     CS_HIP(hipSetDevice(h->device));
     hipLaunchKernelGGL(k_history_span, dim3((h->nCams * nFrames * 12 + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, set, h->nCams,
                        firstFrame, nFrames, d_R, d_t, h->R, h->t, h->H, h->head, h->lastFrame);

@@ -384,6 +384,31 @@ def test_running_mergability_verdict_equals_the_references_whole_track_walk():
             want = np.where(tail == 255, 255, np.minimum(tail, win)).astype(np.uint8)
             assert cnt[1].item() == 0
         assert np.array_equal(got, want), moved_far
+    # (e) poses rewritten behind cached tails (an apply whose window reaches back beyond the walk depth: cs_track_history_set_span_dev): a span
+    # inside the newest 64 frames leaves the cache alone; a span of TAIL frames makes every cached verdict that covers it stale -- the tails are
+    # walked again with the poses as they stand, and the verdict is the whole-track walk's over the rewritten poses
+    for f0, n, tail_span in ((T - 40, 30, False), (120, 60, True)):
+        R_span, t_span = np.ascontiguousarray(g["R"][:, f0:f0 + n]), np.ascontiguousarray(g["t"][:, f0:f0 + n]).copy()
+        t_span[0] += np.array([0.35, -0.2, 0.1])              # camera 0's poses of the span moved: many of its terms fail now
+        d_Rs, d_ts = torch.from_numpy(R_span).to(dev), torch.from_numpy(t_span).to(dev)
+        th.set_span_dev(s, f0, n, d_Rs.data_ptr(), d_ts.data_ptr())
+        t_keep = g["t"].copy()
+        g["t"][:, f0:f0 + n] = t_span
+        c2 = cache.clone()
+        cnt = torch.zeros(4, dtype=torch.int32, device=dev)
+        d_o = torch.full((P, nC), 77, dtype=torch.uint8, device=dev)
+        th.register_mergability_running_dev(s, cams, P, d_M.data_ptr(), d_cov.data_ptr(), live_slot.data_ptr(), sigma, c2.data_ptr(), d_o.data_ptr(),
+                                            tolPix=0.0, d_counts=cnt.data_ptr())
+        torch.cuda.synchronize()
+        got, want = d_o.cpu().numpy(), whole_track(T - 1)
+        if tail_span:
+            assert np.array_equal(got, want) and cnt[1].item() > 20 and (want != whole_track_before).sum() > 5, (cnt.tolist(), int((got != want).sum()))
+        else:
+            assert cnt[1].item() == 0 and np.array_equal(got, want)   # (window frames are judged afresh every call anyway)
+            whole_track_before = want
+        # the span back as it was (the next round of the loop, and the handles' owners, see the golden poses)
+        th.set_span_dev(s, f0, n, d_Rs.data_ptr(), torch.from_numpy(np.ascontiguousarray(t_keep[:, f0:f0 + n])).to(dev).data_ptr())
+        g["t"][:] = t_keep
     for v in finals.values():
         v[0].close()
 
