@@ -792,9 +792,26 @@ int main(int argc, char** argv) {
         }
     };
     int* dBar = dev_zeros<int>(64);
+    // a window / a rig that holds no usable point (every map point of its key frames false, say: the closed orbit starves after some thousands
+    // of frames) is a solve with nothing to do -- it packed an empty record (ok = 0, applies nothing) -- not a failure of the
+    // loop: counted (coslam_amd/frameloop.py: drain())
+    int nEmptySolves = 0;
+    auto wait_ws = [&](cs_ba* ws) {
+        for (;;) {
+            const int rc = cs_ba_wait(ws);
+            if (rc == CS_OK) return;
+            const char* e = cs_last_error();
+            if (e && (strstr(e, "no map point has two feature points") || strstr(e, "no static feature point carries a map point"))) {
+                ++nEmptySolves;
+                continue;   // (the worker goes on with the next request: wait again)
+            }
+            fprintf(stderr, "cs_ba_wait failed (%d): %s\n", rc, e ? e : "?");
+            exit(3);
+        }
+    };
     auto barrier = [&]() {
-        CSCHK(cs_ba_wait(ic.ws));
-        CSCHK(cs_ba_wait(joint.ws));
+        wait_ws(ic.ws);
+        wait_ws(joint.ws);
         HIPCHK(hipDeviceSynchronize());
         if (world > 1) {   // every rank has drained: a small all-gather as the barrier between the ranks
             CSCHK(cs_comm_allgather_dev(comm, (void*)poseS, dBar + rank, dBar, sizeof(int)));
